@@ -1,0 +1,393 @@
+"""TEST INFRASTRUCTURE — eager-PyTorch CPU restatement of AlignQ's hot path.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
+the product (alignq_amd/) never does.  Parity pinned: every function here is checked bit-for-bit
+against tensors captured from the reference's own Python (tests/golden/*.npz, produced by
+tests/golden/gen_goldens.py) in tests/test_oracle_torch.py.
+
+The op *sequence* of each function follows the cited reference lines so that torch-CPU produces
+the same bits; the structure (one flat functional module, explicit Config instead of a
+process-global argparse namespace) is this repo's own.  Reference paths are relative to
+/root/reference; "ADMM tree" = cdf_alignment_admm/resnet-56-cifar-10, "CDF tree" =
+cdf_alignment/resnet-20-cifar-10, "Office tree" = cdf_alignment_admm/dann_office.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+SQRT2 = math.sqrt(2)
+LOG_SQRT_2PI = math.log(math.sqrt(2 * math.pi))
+
+
+@dataclass
+class Config:
+    """The handful of `args.*` fields the reference ops read (utils/options.py:32-95)."""
+    tree: str = "admm"          # "admm" | "cdf" | "office"   (which directory's formulas)
+    act_range: float = 2.0      # options.py: ACT_RANGE
+    method: str = "ours"        # options.py: METHOD
+    bitW: int = 8
+    abitW: int = 8
+    lam: float = 1.0
+    lam2: float = 4.0
+    train_batch_size: int = 128
+
+    @property
+    def corr_eps(self) -> float:
+        return 1e-5 if self.tree == "office" else 0.0
+
+
+# ------------------------------------------------------------------------------------------------
+# R1  uniform_quantize — model/quantization.py:19-38 (identical in all trees)
+class _RoundSTE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v, k):
+        if k == 32:
+            return v
+        if k == 1:
+            return torch.sign(v)
+        n = 2 ** k - 1
+        return torch.round(v * n) / n
+
+    @staticmethod
+    def backward(ctx, gout):
+        return gout.clone(), None
+
+
+def quantize_ste(v: torch.Tensor, k: int) -> torch.Tensor:
+    return _RoundSTE.apply(v, k)
+
+
+# ------------------------------------------------------------------------------------------------
+# R2  cdf — ADMM tree model/quantization.py:41-59; CDF tree cdf_alignment/.../quantization.py:37-50.
+# torch.distributions.Normal.cdf / log_prob written out (same ATen op sequence as the installed
+# torch/distributions/normal.py: cdf = 0.5*(1+erf((v-loc)*scale.reciprocal()/sqrt(2)));
+# log_prob = -((v-loc)**2)/(2*var) - log(scale) - log(sqrt(2*pi))).
+def gaussian_cdf(v, loc, scale):
+    return 0.5 * (1 + torch.erf((v - loc) * scale.reciprocal() / SQRT2))
+
+
+def gaussian_pdf2(v, loc, scale):
+    var = scale ** 2
+    logp = -((v - loc) ** 2) / (2 * var) - scale.log() - LOG_SQRT_2PI
+    return torch.exp(logp) * 2
+
+
+def cdf_transform(v, loc, scale, src: str, cfg: Config):
+    """Returns (transformed, pdf*2).  ADMM/Office trees: 2*cdf-1 (x act_range for activations);
+    CDF tree: the raw cdf."""
+    c = gaussian_cdf(v, loc, scale)
+    if cfg.tree != "cdf":
+        c = c * 2 - 1
+        if src == "a":
+            c = c * cfg.act_range
+    return c, gaussian_pdf2(v, loc, scale)
+
+
+# ------------------------------------------------------------------------------------------------
+# R3  weight_quantize_fn.forward — ADMM tree :71-85, CDF tree :62-78
+def weight_quant(W: torch.Tensor, k: int, cfg: Config):
+    """Returns (W_q, weight_cdf, weight_pdf)."""
+    if k == 32:
+        return W, W, None
+    t, pdf = cdf_transform(W, torch.mean(W), torch.std(W), "w", cfg)
+    if cfg.tree == "cdf":
+        Wq = quantize_ste(t, k) * 2 - 1
+    else:
+        Wq = quantize_ste(t, k)
+    return Wq, t, pdf
+
+
+# R5  corr — ADMM tree :134-137 ; Office tree :158-161 (std + 1e-5)
+def corr(x: torch.Tensor, y: torch.Tensor, eps: float = 0.0) -> torch.Tensor:
+    if eps:
+        xs = (x - torch.mean(x, dim=0)) / (torch.std(x, dim=0) + eps)
+        ys = (y - torch.mean(y, dim=0)) / (torch.std(y, dim=0) + eps)
+    else:
+        xs = (x - torch.mean(x, dim=0)) / torch.std(x, dim=0)
+        ys = (y - torch.mean(y, dim=0)) / torch.std(y, dim=0)
+    return torch.matmul(xs, torch.transpose(ys, 0, 1)) / xs.shape[1]
+
+
+# R6  ADMM.forward — utils/admm.py:24-33
+def admm_loss(D, alterD, gamma, mu: float, rho: float):
+    A = alterD[: D.shape[0], : D.shape[1]]
+    Gm = gamma[: D.shape[0], : D.shape[1]]
+    reg = mu * torch.mean(torch.abs(A))
+    constraint = rho / 2 * torch.mean((D - A) ** 2) ** 0.5
+    relax = torch.mean(Gm * torch.abs(D - A))
+    return reg + constraint + relax
+
+
+class ADMM(nn.Module):
+    """utils/admm.py:12-33 — parameter names alterD / gamma are part of the interface."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.mu = 0.2
+        self.rho = 0.3
+        self.alterD = nn.Parameter(torch.rand(dim, dim))
+        self.gamma = nn.Parameter(torch.rand(dim, dim))
+
+    def forward(self, D):
+        self.D = D
+        return admm_loss(D, self.alterD, self.gamma, self.mu, self.rho)
+
+
+# R4  activation_quantize_fn — ADMM tree :102-132, CDF tree :91-103, Office :97-110 / :126-156
+def act_quant(x: torch.Tensor, k: int, stage: str, cfg: Config, admm: Optional[ADMM] = None):
+    """Returns (x_q, trans_loss).  trans_loss is the python int 0 when the site carries no ADMM."""
+    if k == 32 and stage != "align":
+        return x, 0
+    zero, one = torch.zeros(1), torch.ones(1)
+    t, _ = cdf_transform(x, zero, one, "a", cfg)
+    if cfg.tree == "cdf":
+        xq = (quantize_ste(t, k) * 2 - 1) * cfg.act_range
+        return (t if k == 32 else xq), 0
+    xq = quantize_ste(t, k)
+    loss = 0
+    if admm is not None and cfg.method == "ours" and k < 32:
+        xf = x.view(x.shape[0], -1)
+        tf = t.view(x.shape[0], -1)
+        c0 = corr(xf, xf, cfg.corr_eps)
+        c1 = corr(tf, tf, cfg.corr_eps)
+        loss = admm(c1 - c0)
+    return (t if k == 32 else xq), loss
+
+
+# ------------------------------------------------------------------------------------------------
+# R7  ADMM_OPT.step — utils/optimizer.py:60-135
+def admm_update(D, alterD, gamma, mu: float, rho: float):
+    """One site's closed-form primal/dual update; returns (alterD_new, gamma_new) (detached)."""
+    D = D.detach()
+    Dp = torch.zeros_like(gamma)
+    Dp[: D.shape[0], : D.shape[1]] = D
+    V = Dp + 1 / rho * gamma.detach()
+    nv = torch.norm(V, 2)
+    if nv > (mu / rho):
+        A = (1 - mu / rho / nv) * V
+    else:
+        A = torch.zeros_like(alterD)
+    G = gamma.detach() + rho * (Dp - A)
+    return A, G
+
+
+class ADMM_OPT(torch.optim.Optimizer):
+    def __init__(self, params):
+        super().__init__(params, dict())
+
+    @torch.no_grad()
+    def step(self, alterD_idx, gamma_idx, Ds, alterDs, gammas, mus, rhos, closure=None, bitW=8):
+        loss = closure() if closure is not None else None
+        for group in self.param_groups:
+            last = None
+            for i, p in enumerate(group["params"]):
+                if p.grad is None:
+                    continue
+                if bitW >= 32:
+                    p.data.add_(p.grad.data, alpha=-group.get("lr", 0.0))
+                    continue
+                if i in alterD_idx:
+                    j = alterD_idx.index(i)
+                    A, G = admm_update(Ds[j], p, gammas[j], mus[j], rhos[j])
+                    p.data = A
+                    last = G
+                elif i in gamma_idx:
+                    # the reference reuses D_ and alterD left over from the preceding alterD
+                    # iteration (optimizer.py:116-124); `last` carries exactly that result.
+                    p.data = last
+        return loss
+
+
+# R8  SGD.step — utils/optimizer.py:196-262 (+ helpers :6-13)
+def _sigmoid(v):
+    return 1 / (1 + torch.exp(-v))
+
+
+def grad_approx_factor(w_cdf, bitW: int, lam: float, lam2: float):
+    tr = (((w_cdf + 0.5) * (2 ** bitW - 1)) % 1) * lam2 * 2
+    return _sigmoid(tr) * (1 - _sigmoid(tr)) * lam
+
+
+class SGD(torch.optim.Optimizer):
+    def __init__(self, params, lr, momentum=0, dampening=0, weight_decay=0, nesterov=False, bitW=8):
+        super().__init__(params, dict(lr=lr, momentum=momentum, dampening=dampening,
+                                      weight_decay=weight_decay, nesterov=nesterov))
+        self.bitW = bitW
+
+    @torch.no_grad()
+    def step(self, idx, w_cdf, w_pdf, lam, lam2, closure=None):
+        loss = closure() if closure is not None else None
+        for group in self.param_groups:
+            wd, mom, damp, nest = group["weight_decay"], group["momentum"], group["dampening"], group["nesterov"]
+            for i, p in enumerate(group["params"]):
+                if p.grad is None:
+                    continue
+                d_p = p.grad.data
+                if wd != 0:
+                    d_p.add_(p.data, alpha=wd)
+                if mom != 0:
+                    st = self.state[p]
+                    if "momentum_buffer" not in st:
+                        buf = st["momentum_buffer"] = torch.zeros_like(p.data)
+                        buf.mul_(mom).add_(d_p)
+                    else:
+                        buf = st["momentum_buffer"]
+                        buf.mul_(mom).add_(d_p, alpha=1 - damp)
+                    d_p = d_p.add(buf, alpha=mom) if nest else buf
+                if self.bitW < 32 and i in idx:
+                    j = idx.index(i)
+                    p.grad.data = d_p * grad_approx_factor(w_cdf[j].data, self.bitW, lam, lam2) * w_pdf[j].data
+                    p.data.add_(d_p, alpha=-group["lr"])
+                else:
+                    p.data.add_(d_p, alpha=-group["lr"])
+                    p.grad.data = d_p
+        return loss
+
+
+# ------------------------------------------------------------------------------------------------
+# Harness model (caller of the hot path): pre-activation ResNet-20/56 for CIFAR shapes.
+# Wiring follows ADMM tree model/resnet.py:36-167 and CDF tree model/resnet.py:33-137.
+class QConv2d(nn.Conv2d):
+    def __init__(self, cfg: Config, k: int, cin, cout, ksize, stride=1, padding=0):
+        super().__init__(cin, cout, ksize, stride, padding, bias=False)
+        self.cfg, self.k = cfg, k
+        self.weight_cdf = self.weight_pdf = None
+
+    def forward(self, x):
+        Wq, self.weight_cdf, self.weight_pdf = weight_quant(self.weight, self.k, self.cfg)
+        return F.conv2d(x, Wq, None, self.stride, self.padding, self.dilation, self.groups)
+
+
+class _Site(nn.Module):
+    """One activation-quant site (+ its ADMM state in the ADMM tree)."""
+
+    def __init__(self, cfg: Config, k: int, stage: str):
+        super().__init__()
+        self.cfg, self.k, self.stage = cfg, k, stage
+        self.admm = ADMM(cfg.train_batch_size) if cfg.tree != "cdf" else None
+
+    def forward(self, x):
+        return act_quant(x, self.k, self.stage, self.cfg, self.admm)
+
+
+class PreActBlock(nn.Module):
+    def __init__(self, cfg, stage, wbit, abit, cin, cout, stride):
+        super().__init__()
+        self.site0, self.site1 = _Site(cfg, abit, stage), _Site(cfg, abit, stage)
+        self.bn0 = nn.BatchNorm2d(cout)
+        self.conv0 = QConv2d(cfg, wbit, cin, cout, 3, stride, 1)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.conv1 = QConv2d(cfg, wbit, cout, cout, 3, 1, 1)
+        self.skip_conv = None
+        if stride != 1:
+            self.site_skip = _Site(cfg, abit, stage)
+            self.skip_conv = QConv2d(cfg, wbit, cin, cout, 1, stride, 0)
+            self.skip_bn = nn.BatchNorm2d(cout)
+
+    def forward(self, x):
+        tl = 0.0
+        if self.skip_conv is not None:
+            sc, l = self.site_skip(self.skip_bn(self.skip_conv(x)))
+            tl += l
+        else:
+            sc = x
+        out, l = self.site0(self.bn0(self.conv0(x)))
+        tl += l
+        out = F.relu(out)
+        out, l = self.site1(self.bn1(self.conv1(out)))
+        tl += l
+        out += sc
+        return F.relu(out), tl
+
+
+class PreActResNet(nn.Module):
+    def __init__(self, cfg: Config, units: Sequence[int], wbit, abit, stage="second", num_classes=10):
+        super().__init__()
+        self.cfg = cfg
+        self.conv0 = QConv2d(cfg, wbit, 3, 16, 3, 1, 1)
+        self.site0 = _Site(cfg, abit, stage)
+        strides = [1] * units[0] + [2] + [1] * (units[1] - 1) + [2] + [1] * (units[2] - 1)
+        chans = [16] * units[0] + [32] * units[1] + [64] * units[2]
+        self.layers = nn.ModuleList()
+        cin = 16
+        for s, c in zip(strides, chans):
+            self.layers.append(PreActBlock(cfg, stage, wbit, abit, cin, c, s))
+            cin = c
+        self.bn = nn.BatchNorm2d(16)
+        self.logit = nn.Linear(64, num_classes)
+
+    def forward(self, x):
+        out, tl = self.site0(self.bn(self.conv0(x)))
+        tl = 0.0 + tl
+        out = F.relu(out)
+        for layer in self.layers:
+            out, l = layer(out)
+            tl += l
+        out = F.adaptive_avg_pool2d(out, 1).view(out.size(0), -1)
+        return self.logit(out), tl
+
+    # helpers reproducing the gathers of main.py:313-369
+    def quant_convs(self) -> List[QConv2d]:
+        res = []
+        for layer in self.layers:
+            for c in (layer.conv0, layer.conv1, layer.skip_conv):
+                if c is not None:
+                    res.append(c)
+        return res
+
+    def admm_modules(self) -> List[ADMM]:
+        mods = [self.site0.admm]
+        for layer in self.layers:
+            mods += [layer.site0.admm, layer.site1.admm]
+            if layer.skip_conv is not None:
+                mods.append(layer.site_skip.admm)
+        return mods
+
+
+def resnet20(cfg: Config, stage="second"):
+    return PreActResNet(cfg, [3, 3, 3], cfg.bitW, cfg.abitW, stage)
+
+
+def resnet56(cfg: Config, stage="second"):
+    return PreActResNet(cfg, [9, 9, 9], cfg.bitW, cfg.abitW, stage)
+
+
+class TrainStep:
+    """One training iteration in the reference's order
+    (cdf_alignment_admm/resnet-20-cifar-10/main.py:288-374)."""
+
+    def __init__(self, net: PreActResNet, cfg: Config, lr=0.04, momentum=0.9, weight_decay=1e-4):
+        self.net, self.cfg = net, cfg
+        named = list(net.named_parameters())
+        self.param_t = [(n, p) for n, p in named if "alterD" not in n and "gamma" not in n]
+        self.param_admm = [(n, p) for n, p in named if "alterD" in n or "gamma" in n]
+        self.opt_t = SGD([p for _, p in self.param_t], lr=lr, momentum=momentum,
+                         weight_decay=weight_decay, bitW=cfg.bitW)
+        self.opt_admm = ADMM_OPT([p for _, p in self.param_admm]) if self.param_admm else None
+        self.idx = [j for j, (n, _) in enumerate(self.param_t) if "conv" in n and "weight" in n][1:]
+        self.a_idx = [j for j, (n, _) in enumerate(self.param_admm) if "alterD" in n]
+        self.g_idx = [j for j, (n, _) in enumerate(self.param_admm) if "gamma" in n]
+
+    def __call__(self, x, y):
+        net = self.net
+        self.opt_t.zero_grad()
+        if self.opt_admm is not None:
+            self.opt_admm.zero_grad()
+        logits, tl = net(x)
+        ce = F.cross_entropy(logits, y)
+        (ce + tl).backward()
+        convs = net.quant_convs()
+        self.opt_t.step(self.idx, [c.weight_cdf for c in convs], [c.weight_pdf for c in convs],
+                        self.cfg.lam, self.cfg.lam2)
+        if self.opt_admm is not None:
+            mods = net.admm_modules()
+            self.opt_admm.step(self.a_idx, self.g_idx, [m.D for m in mods], [m.alterD for m in mods],
+                               [m.gamma for m in mods], [m.mu for m in mods], [m.rho for m in mods],
+                               bitW=self.cfg.bitW)
+        return logits, ce, tl

@@ -1,0 +1,372 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: imports the *reference's own Python* on CPU and records
+input/output tensors of the hot-path ops as small .npz fixtures.
+
+Runs only in the build container (needs /root/reference); the fixtures it writes
+are committed next to it.  Nothing but tensors leaves the reference: no source text.
+
+Import recipe: argparse runs at import in the reference
+(utils/options.py:95), so sys.argv is set first; the module-global `device`
+(model/quantization.py:16, model/resnet.py:25) is overwritten with cpu.  One process
+per variant directory because the module names collide.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_goldens.py            # all variants
+    python tests/golden/gen_goldens.py --variant admm_cifar                 # one variant (child)
+
+torch build used for capture is recorded in every file (`torch_version`).
+"""
+import argparse
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("ALIGNQ_REFERENCE", "/root/reference")
+
+VARIANTS = {
+    # name -> (directory under the reference, options module)
+    "admm_cifar": ("cdf_alignment_admm/resnet-56-cifar-10", "utils.options"),
+    "cdf_only": ("cdf_alignment/resnet-20-cifar-10", "utils.options"),
+    "office": ("cdf_alignment_admm/dann_office", "utils.options_office"),
+}
+
+
+def _np(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def _save(name, **arrays):
+    import torch
+    arrays["torch_version"] = np.array(torch.__version__)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote", path, {k: getattr(v, "shape", None) for k, v in arrays.items()})
+
+
+def _enter(variant, extra_argv):
+    """Perform the import recipe; returns (quantization module, args)."""
+    import torch
+    sys.dont_write_bytecode = True
+    vdir, optmod = VARIANTS[variant]
+    vdir = os.path.join(REF, vdir)
+    sys.argv = ["main.py"] + extra_argv
+    os.chdir(vdir)
+    sys.path.insert(0, vdir)
+    import importlib
+    q = importlib.import_module("model.quantization")
+    q.device = torch.device("cpu")
+    args = importlib.import_module(optmod).args
+    return q, args
+
+
+# ----------------------------------------------------------------------------------------------
+def gen_admm_cifar():
+    import torch
+    q, args = _enter("admm_cifar", ["--bitW", "8", "--abitW", "8", "--train_batch_size", "8"])
+    from utils.admm import ADMM
+    from utils.optimizer import SGD, ADMM_OPT
+    import model.resnet as r
+    r.device = torch.device("cpu")
+    g = torch.Generator().manual_seed(1234)
+
+    # G1 uniform_quantize (model/quantization.py:19-38)
+    x = torch.randn(4096, generator=g)
+    ties = torch.tensor([0.5, 1.5, 2.5, -0.5, -1.5, 0.0, 1.0 / 6.0, 0.5 / 3.0, 0.5 / 15, 1.5 / 15, 2.5 / 255, -3.5 / 255])
+    x = torch.cat([x, ties])
+    out = {"x": _np(x)}
+    for k in (1, 2, 4, 8, 32):
+        xi = x.clone().requires_grad_(True)
+        y = q.uniform_quantize(k)(xi)
+        gy = torch.randn(y.shape, generator=g)
+        y.backward(gy)
+        out[f"y_k{k}"] = _np(y)
+        out[f"gy_k{k}"] = _np(gy)
+        out[f"gx_k{k}"] = _np(xi.grad)
+    _save("g1_uniform_quantize", **out)
+
+    # G2 weight quant, ADMM tree (model/quantization.py:61-85)
+    out = {}
+    for si, shape in enumerate([(16, 3, 3, 3), (64, 64, 3, 3), (32, 16, 1, 1)]):
+        W = torch.randn(shape, generator=g) * 0.05 + 0.01
+        gq = torch.randn(shape, generator=g)
+        out[f"W_s{si}"] = _np(W)
+        out[f"g_s{si}"] = _np(gq)
+        for k in (2, 4, 8):
+            Wi = W.clone().requires_grad_(True)
+            fn = q.weight_quantize_fn(k, "second")
+            Wq = fn(Wi)
+            Wq.backward(gq)
+            out[f"m_s{si}"] = _np(torch.mean(W))
+            out[f"s_s{si}"] = _np(torch.std(W))
+            out[f"cdf_s{si}"] = _np(fn.weight_cdf)
+            out[f"pdf_s{si}"] = _np(fn.weight_pdf)
+            out[f"Wq_s{si}_k{k}"] = _np(Wq)
+            out[f"dW_s{si}_k{k}"] = _np(Wi.grad)
+    _save("g2_weight_quant_admm", **out)
+
+    # G3 activation quant, ADMM-tree formula without the corr/ADMM branch
+    # (model/quantization.py:102-132 with args.method != 'ours').
+    out = {}
+    args.method = "plain"
+    x = torch.randn(8, 16, 8, 8, generator=g) * 1.3
+    x.view(-1)[:7] = torch.tensor([-2.0, -1.0, -0.3, 0.0, 0.3, 1.0, 2.0])
+    gq = torch.randn(x.shape, generator=g)
+    out["x"] = _np(x)
+    out["g"] = _np(gq)
+    out["act_range"] = np.array(float(args.act_range), dtype=np.float32)
+    for k in (2, 4, 8):
+        xi = x.clone().requires_grad_(True)
+        fn = q.activation_quantize_fn(k, "second", None)
+        # pre-round transform (what uniform_q sees), for tie-zone masks
+        t, _ = q.cdf(torch.zeros(1), torch.ones(1), "a")(x)
+        xq, tl = fn(xi)
+        assert tl == 0
+        xq.backward(gq)
+        out["t"] = _np(t)
+        out[f"xq_k{k}"] = _np(xq)
+        out[f"dx_k{k}"] = _np(xi.grad)
+    args.method = "ours"
+    _save("g3_act_quant_admm", **out)
+
+    # G4 corr, no eps (model/quantization.py:134-137)
+    out = {}
+    for ci, (B, Fdim) in enumerate([(16, 256), (128, 1024), (8, 96)]):
+        x = torch.randn(B, Fdim, generator=g) * 0.8 + 0.1
+        dG = torch.randn(B, B, generator=g)
+        xi = x.clone().requires_grad_(True)
+        G = q.corr(xi, xi)
+        G.backward(dG)
+        out[f"x_c{ci}"] = _np(x)
+        out[f"dG_c{ci}"] = _np(dG)
+        out[f"G_c{ci}"] = _np(G)
+        out[f"dx_c{ci}"] = _np(xi.grad)
+    _save("g4_corr_noeps", **out)
+
+    # G5 ADMM site end to end + G6 ADMM_OPT.step (utils/admm.py:24-33, utils/optimizer.py:60-135)
+    out = {}
+    cases = [  # (name, dim, batch, C, H, W, k)
+        ("a", 16, 16, 4, 8, 8, 4),
+        ("b", 128, 128, 16, 8, 8, 8),
+        ("short", 16, 10, 4, 8, 8, 2),   # last, short batch: D is [10,10] inside dim 16
+    ]
+    for name, dim, B, C, H, W, k in cases:
+        torch.manual_seed(77)
+        admm = ADMM(dim)
+        fn = q.activation_quantize_fn(k, "second", admm)
+        x = torch.randn(B, C, H, W, generator=g)
+        gq = torch.randn(x.shape, generator=g) * 0.01
+        xi = x.clone().requires_grad_(True)
+        alterD0, gamma0 = _np(admm.alterD), _np(admm.gamma)
+        xq, tl = fn(xi)
+        (tl + (xq * gq).sum()).backward()
+        out[f"x_{name}"] = _np(x)
+        out[f"g_{name}"] = _np(gq)
+        out[f"k_{name}"] = np.array(k)
+        out[f"alterD0_{name}"] = alterD0
+        out[f"gamma0_{name}"] = gamma0
+        out[f"xq_{name}"] = _np(xq)
+        out[f"loss_{name}"] = _np(tl)
+        out[f"D_{name}"] = _np(admm.D)
+        out[f"dx_{name}"] = _np(xi.grad)
+        out[f"dalterD_{name}"] = _np(admm.alterD.grad)
+        out[f"dgamma_{name}"] = _np(admm.gamma.grad)
+        opt = ADMM_OPT([admm.alterD, admm.gamma])
+        opt.step([0], [1], [admm.D], [admm.alterD], [admm.gamma], [admm.mu], [admm.rho])
+        out[f"alterD1_{name}"] = _np(admm.alterD)
+        out[f"gamma1_{name}"] = _np(admm.gamma)
+    # the ||V||_F <= mu/rho branch (optimizer.py:109-112)
+    admm = ADMM(4)
+    with torch.no_grad():
+        admm.alterD.mul_(0.1)
+        admm.gamma.mul_(0.01)
+    D = (torch.randn(4, 4, generator=g) * 0.05)
+    Di = D.clone().requires_grad_(True)
+    out["alterD0_small"], out["gamma0_small"], out["D_small"] = _np(admm.alterD), _np(admm.gamma), _np(D)
+    loss = admm(Di)
+    loss.backward()
+    out["loss_small"] = _np(loss)
+    out["dD_small"] = _np(Di.grad)
+    out["dalterD_small"] = _np(admm.alterD.grad)
+    out["dgamma_small"] = _np(admm.gamma.grad)
+    opt = ADMM_OPT([admm.alterD, admm.gamma])
+    opt.step([0], [1], [admm.D], [admm.alterD], [admm.gamma], [admm.mu], [admm.rho])
+    out["alterD1_small"], out["gamma1_small"] = _np(admm.alterD), _np(admm.gamma)
+    out["mu"], out["rho"] = np.array(admm.mu, dtype=np.float32), np.array(admm.rho, dtype=np.float32)
+    _save("g5_g6_admm_site", **out)
+
+    # G7 SGD.step (utils/optimizer.py:196-262): 2 steps, 3 tensors, tensor 1 in idx
+    out = {}
+    args.bitW = 4
+    ps = [torch.nn.Parameter(torch.randn(s, generator=g) * 0.1) for s in [(8, 4, 3, 3), (16, 8, 3, 3), (10,)]]
+    opt = SGD(ps, lr=0.04, momentum=0.9, weight_decay=1e-4)
+    w_cdf = [torch.rand(16, 8, 3, 3, generator=g) * 2 - 1]
+    w_pdf = [torch.rand(16, 8, 3, 3, generator=g) * 8]
+    out["w_cdf"], out["w_pdf"] = _np(w_cdf[0]), _np(w_pdf[0])
+    out["bitW"] = np.array(4)
+    for i, p in enumerate(ps):
+        out[f"p{i}_0"] = _np(p)
+    for step in (1, 2):
+        for i, p in enumerate(ps):
+            p.grad = torch.randn(p.shape, generator=g)
+            out[f"grad{i}_{step}"] = _np(p.grad)
+        opt.step([1], w_cdf, w_pdf, float(args.lam), float(args.lam2))
+        for i, p in enumerate(ps):
+            out[f"p{i}_{step}"] = _np(p)
+            out[f"buf{i}_{step}"] = _np(opt.state[p]["momentum_buffer"])
+            out[f"gradout{i}_{step}"] = _np(p.grad)
+    out["lam"], out["lam2"] = np.array(float(args.lam)), np.array(float(args.lam2))
+    args.bitW = 8
+    _save("g7_sgd_step", **out)
+
+    # G8 tiny PreActResNet([1,1,1]) — two full training iterations in the reference's order
+    # (cdf_alignment_admm/resnet-20-cifar-10/main.py:288-374: zero_grad x2 -> fwd -> CE+trans -> bwd ->
+    #  SGD.step -> ADMM_OPT.step), k=4, B=8.
+    out = {}
+    args.bitW = 4
+    args.abitW = 4
+    args.train_batch_size = 8
+    torch.manual_seed(5)
+    net = r.PreActResNet(r.PreActBlock_conv_Q, [1, 1, 1], 4, 4, "second", 10)
+    net.train()
+    for n_, p_ in net.state_dict().items():
+        out["init/" + n_] = _np(p_)
+    named = list(net.named_parameters())
+    param_t = [(n, p) for n, p in named if "alterD" not in n and "gamma" not in n]
+    param_admm = [(n, p) for n, p in named if "alterD" in n or "gamma" in n]
+    opt_t = SGD([p for _, p in param_t], lr=0.04, momentum=0.9, weight_decay=1e-4)
+    opt_a = ADMM_OPT([p for _, p in param_admm])
+    ce = torch.nn.CrossEntropyLoss()
+    xs = torch.randn(2, 8, 3, 32, 32, generator=g)
+    ys = torch.randint(0, 10, (2, 8), generator=g)
+    out["xs"], out["ys"] = _np(xs), _np(ys)
+    for it in range(2):
+        opt_t.zero_grad()
+        opt_a.zero_grad()
+        logits, tl = net(xs[it])
+        loss_ce = ce(logits, ys[it])
+        (loss_ce + tl).backward()
+        idx = [j for j, (n, _) in enumerate(param_t) if "conv" in n and "weight" in n][1:]
+        w_cdf, w_pdf = [], []
+        for layer in net.layers:
+            for conv in (layer.conv0, layer.conv1, layer.skip_conv):
+                if conv is not None:
+                    w_cdf.append(conv.quantize_fn.weight_cdf)
+                    w_pdf.append(conv.quantize_fn.weight_pdf)
+        a_idx = [j for j, (n, _) in enumerate(param_admm) if "alterD" in n]
+        g_idx = [j for j, (n, _) in enumerate(param_admm) if "gamma" in n]
+        mods = [net.admm0]
+        for layer in net.layers:
+            mods += [layer.admm0, layer.admm1]
+            if layer.skip_conv is not None:
+                mods.append(layer.admm_skip)
+        out[f"logits_{it}"] = _np(logits)
+        out[f"ce_{it}"] = _np(loss_ce)
+        out[f"trans_{it}"] = _np(tl)
+        for si, m in enumerate(mods):
+            out[f"D_{it}_{si}"] = _np(m.D)
+        opt_t.step(idx, w_cdf, w_pdf, float(args.lam), float(args.lam2))
+        opt_a.step(a_idx, g_idx, [m.D for m in mods], [m.alterD for m in mods], [m.gamma for m in mods],
+                   [m.mu for m in mods], [m.rho for m in mods])
+        for n_, p_ in net.state_dict().items():
+            out[f"after{it}/" + n_] = _np(p_)
+    _save("g8_tiny_resnet_admm", **out)
+
+
+# ----------------------------------------------------------------------------------------------
+def gen_cdf_only():
+    import torch
+    q, args = _enter("cdf_only", ["--bitW", "8", "--abitW", "8"])
+    g = torch.Generator().manual_seed(4321)
+    out = {}
+    for si, shape in enumerate([(16, 3, 3, 3), (64, 64, 3, 3)]):
+        W = torch.randn(shape, generator=g) * 0.05 - 0.02
+        gq = torch.randn(shape, generator=g)
+        out[f"W_s{si}"], out[f"g_s{si}"] = _np(W), _np(gq)
+        for k in (2, 4, 8):
+            Wi = W.clone().requires_grad_(True)
+            Wq = q.weight_quantize_fn(k, "second")(Wi)
+            Wq.backward(gq)
+            c, pdf = q.cdf(torch.mean(W), torch.std(W), "w")(W)
+            out[f"cdf_s{si}"], out[f"pdf_s{si}"] = _np(c), _np(pdf)
+            out[f"m_s{si}"], out[f"s_s{si}"] = _np(torch.mean(W)), _np(torch.std(W))
+            out[f"Wq_s{si}_k{k}"] = _np(Wq)
+            out[f"dW_s{si}_k{k}"] = _np(Wi.grad)
+    _save("g2_weight_quant_cdfonly", **out)
+
+    out = {}
+    x = torch.randn(8, 16, 8, 8, generator=g) * 1.3
+    x.view(-1)[:7] = torch.tensor([-2.0, -1.0, -0.3, 0.0, 0.3, 1.0, 2.0])
+    gq = torch.randn(x.shape, generator=g)
+    out["x"], out["g"] = _np(x), _np(gq)
+    out["act_range"] = np.array(float(args.act_range), dtype=np.float32)
+    c, _ = q.cdf(torch.zeros(1), torch.ones(1), "a")(x)
+    out["c"] = _np(c)
+    for k in (2, 4, 8):
+        xi = x.clone().requires_grad_(True)
+        xq = q.activation_quantize_fn(k, "second")(xi)
+        xq.backward(gq)
+        out[f"xq_k{k}"] = _np(xq)
+        out[f"dx_k{k}"] = _np(xi.grad)
+    _save("g3_act_quant_cdfonly", **out)
+
+
+# ----------------------------------------------------------------------------------------------
+def gen_office():
+    import torch
+    q, args = _enter("office", ["--bitW", "8", "--abitW", "8"])
+    from utils.admm import ADMM
+    g = torch.Generator().manual_seed(999)
+    out = {}
+    for ci, (B, Fdim) in enumerate([(28, 1024), (16, 256)]):
+        x = torch.randn(B, Fdim, generator=g) * 0.8 + 0.1
+        if ci == 1:
+            x[:, 5] = 0.25          # a constant feature: finite only thanks to the +1e-5
+        dG = torch.randn(B, B, generator=g)
+        xi = x.clone().requires_grad_(True)
+        G = q.corr(xi, xi)
+        G.backward(dG)
+        out[f"x_c{ci}"], out[f"dG_c{ci}"], out[f"G_c{ci}"], out[f"dx_c{ci}"] = _np(x), _np(dG), _np(G), _np(xi.grad)
+    _save("g4_corr_eps", **out)
+
+    out = {}
+    torch.manual_seed(3)
+    admm = ADMM(28)
+    k = 8
+    x = torch.randn(28, 8, 4, 4, generator=g)
+    gq = torch.randn(x.shape, generator=g) * 0.01
+    # plain (no ADMM) Office activation quant: returns a tensor (dann_office/model/quantization.py:87-110)
+    xi = x.clone().requires_grad_(True)
+    xq = q.activation_quantize_fn(k, "aligned")(xi)
+    xq.backward(gq)
+    out["x"], out["g"], out["k"] = _np(x), _np(gq), np.array(k)
+    out["act_range"] = np.array(float(args.act_range), dtype=np.float32)
+    out["xq_plain"], out["dx_plain"] = _np(xq), _np(xi.grad)
+    # ADMM site (activation_quantize_fn2, :112-156) with the eps corr
+    xi = x.clone().requires_grad_(True)
+    out["alterD0"], out["gamma0"] = _np(admm.alterD), _np(admm.gamma)
+    xq, tl = q.activation_quantize_fn2(k, "aligned", admm)(xi)
+    (tl + (xq * gq).sum()).backward()
+    out["xq"], out["loss"], out["D"], out["dx"] = _np(xq), _np(tl), _np(admm.D), _np(xi.grad)
+    out["dalterD"], out["dgamma"] = _np(admm.alterD.grad), _np(admm.gamma.grad)
+    _save("g5_office_site", **out)
+
+
+GEN = {"admm_cifar": gen_admm_cifar, "cdf_only": gen_cdf_only, "office": gen_office}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--variant", choices=sorted(GEN), default=None)
+    a = ap.parse_args()
+    if a.variant is None:
+        env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+        for v in GEN:
+            subprocess.run([sys.executable, os.path.abspath(__file__), "--variant", v], check=True, env=env)
+        return
+    GEN[a.variant]()
+
+
+if __name__ == "__main__":
+    main()
