@@ -1,0 +1,92 @@
+"""ctypes binding of libalignq_hip.so (include/alignq.h).  The product path has NO fallback: if the HIP
+library is missing or a tensor is not a CUDA fp32 tensor, the call raises."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "lib", "libalignq_hip.so")
+
+FORMULA_ADMM, FORMULA_CDF = 0, 1
+MAX_BATCH = 128
+ABI_VERSION = 1
+
+_c = ctypes
+_vp, _i, _i64, _f, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_size_t
+
+# name -> (restype, argtypes)   — mirrors include/alignq.h one to one
+SIGNATURES = {
+    "alignq_abi_version": (_i, []),
+    "alignq_strerror": (_c.c_char_p, [_i]),
+    "alignq_uniform_quantize": (_i, [_vp, _vp, _i64, _i, _vp]),
+    "alignq_act_quant_fwd": (_i, [_vp, _vp, _vp, _i64, _i, _f, _i, _vp]),
+    "alignq_act_quant_bwd": (_i, [_vp, _vp, _vp, _i64, _f, _vp]),
+    "alignq_weight_ws_bytes": (_sz, [_i64]),
+    "alignq_weight_stats": (_i, [_vp, _i64, _vp, _vp, _vp]),
+    "alignq_weight_quant_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp]),
+    "alignq_weight_quant_bwd": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "alignq_site_ws_bytes": (_sz, [_i, _i64]),
+    "alignq_site_fwd": (_i, [_vp, _i, _i64, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "alignq_site_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _f, _f, _vp, _vp]),
+    "alignq_corr_fwd": (_i, [_vp, _i, _i64, _f, _vp, _vp, _vp, _vp]),
+    "alignq_corr_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _f, _vp, _vp]),
+    "alignq_admm_ws_bytes": (_sz, [_i]),
+    "alignq_admm_loss": (_i, [_vp, _i, _vp, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "alignq_admm_update": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _vp]),
+    "alignq_sgd_step": (_i, [_vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _i, _vp]),
+    "alignq_sgd_grad_approx": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _f, _f, _vp]),
+}
+
+_lib = None
+
+
+class AlignQLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Raises AlignQLibraryError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise AlignQLibraryError(
+            f"{SO_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C alignq_amd/csrc` (hipcc --offload-arch=gfx950). alignq_amd has no CPU fallback.")
+    lib = ctypes.CDLL(SO_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError if the .so does not export what alignq.h declares
+        fn.restype, fn.argtypes = res, args
+    if lib.alignq_abi_version() != ABI_VERSION:
+        raise AlignQLibraryError("libalignq_hip.so ABI version mismatch; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().alignq_strerror(rc).decode()
+        raise RuntimeError(f"{what}: {msg} (code {rc})")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def dev_f32(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:
+    """Validate (CUDA, fp32) and return a contiguous view/copy.  No silent CPU path."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"alignq_amd: {name} is on {t.device}; the HIP kernels need a CUDA/ROCm tensor "
+                           "(there is no CPU fallback in the product path)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"alignq_amd: {name} must be float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()

@@ -1,0 +1,206 @@
+// admm_sgd_kernels.hip — ADMM loss (+grads), batched ADMM primal/dual update, SGD step kernels (gfx950).
+//
+// All of these touch a few KiB..MiB per step and are launch-latency bound; the design goal is ONE launch
+// per logical operation (the reference issues ~10 eager kernels per site for the loss and a Python loop
+// with list.index() searches for the update) and determinism (double tree sums).
+#include <hip/hip_runtime.h>
+
+#include "../../include/alignq.h"
+#include "alignq_math.h"
+
+using namespace alignq;
+
+namespace {
+
+constexpr int kBig = 1024;  // one workgroup of 16 waves per site
+
+__device__ __forceinline__ void block_sum3(double& a, double& b, double& c, double* sm /* [48] */) {
+  a = wave_sum_d(a);
+  b = wave_sum_d(b);
+  c = wave_sum_d(c);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) { sm[w] = a; sm[16 + w] = b; sm[32 + w] = c; }
+  __syncthreads();
+  const int nw = blockDim.x >> 6;
+  a = b = c = 0;
+  for (int i = 0; i < nw; i++) { a += sm[i]; b += sm[16 + i]; c += sm[32 + i]; }
+}
+
+// utils/admm.py:24-33 and its autograd:  loss = mu*mean|A| + rho/2*sqrt(mean (D-A)^2) + mean(gamma*|D-A|)
+__global__ __launch_bounds__(kBig) void admm_loss_kernel(const float* __restrict__ D, int b,
+                                                         const float* __restrict__ A,
+                                                         const float* __restrict__ gamma, int dim, float mu,
+                                                         float rho, float* __restrict__ loss,
+                                                         float* __restrict__ dD, float* __restrict__ dA,
+                                                         float* __restrict__ dgamma) {
+  __shared__ double sm[48];
+  const int nn = b * b;
+  double sabs = 0, ssq = 0, srel = 0;
+  for (int e = threadIdx.x; e < nn; e += kBig) {
+    int i = e / b, j = e - i * b;
+    float a = A[i * dim + j];
+    float d = D[e] - a;
+    sabs += fabsf(a);
+    ssq += (double)d * (double)d;
+    srel += (double)gamma[i * dim + j] * fabsf(d);
+  }
+  block_sum3(sabs, ssq, srel, sm);
+  const double n = (double)nn;
+  const double rms = sqrt(ssq / n);
+  if (threadIdx.x == 0) *loss = (float)(mu * sabs / n + 0.5 * rho * rms + srel / n);
+  const float c_con = (float)(0.5 * rho / (n * rms));
+  const float inv_n = (float)(1.0 / n);
+  // gradients; entries of dA / dgamma outside the [:b,:b] slice are zero
+  const int full = dim * dim;
+  for (int e = threadIdx.x; e < full; e += kBig) {
+    int i = e / dim, j = e - i * dim;
+    float ga = 0.0f, gg = 0.0f;
+    if (i < b && j < b) {
+      float a = A[e], gm = gamma[e];
+      float d = D[i * b + j] - a;
+      float sg = (float)((d > 0.0f) - (d < 0.0f));
+      float sa = (float)((a > 0.0f) - (a < 0.0f));
+      float gD = c_con * d + gm * sg * inv_n;
+      if (dD) dD[i * b + j] = gD;
+      ga = mu * sa * inv_n - gD;
+      gg = fabsf(d) * inv_n;
+    }
+    if (dA) dA[e] = ga;
+    if (dgamma) dgamma[e] = gg;
+  }
+}
+
+// utils/optimizer.py:97-124, one workgroup per site.
+__global__ __launch_bounds__(kBig) void admm_update_kernel(const float* const* __restrict__ D_tab,
+                                                           float* const* __restrict__ A_tab,
+                                                           float* const* __restrict__ G_tab, int b, int dim,
+                                                           float mu, float rho) {
+  __shared__ double sm[48];
+  const float* D = D_tab[blockIdx.x];
+  float* A = A_tab[blockIdx.x];
+  float* G = G_tab[blockIdx.x];
+  const int full = dim * dim;
+  const float inv_rho = 1.0f / rho;
+  double ss = 0, z0 = 0, z1 = 0;
+  for (int e = threadIdx.x; e < full; e += kBig) {
+    int i = e / dim, j = e - i * dim;
+    float d = (i < b && j < b) ? D[i * b + j] : 0.0f;
+    float v = d + inv_rho * G[e];
+    ss += (double)v * (double)v;
+  }
+  block_sum3(ss, z0, z1, sm);
+  const float nv = (float)sqrt(ss);
+  const float thr = mu / rho;
+  const float shrink = (nv > thr) ? (1.0f - thr / nv) : 0.0f;
+  for (int e = threadIdx.x; e < full; e += kBig) {
+    int i = e / dim, j = e - i * dim;
+    float d = (i < b && j < b) ? D[i * b + j] : 0.0f;
+    float gm = G[e];
+    float a = shrink * (d + inv_rho * gm);
+    A[e] = a;
+    G[e] = gm + rho * (d - a);
+  }
+}
+
+constexpr int kThreads = 256;
+
+__global__ __launch_bounds__(kThreads) void sgd_step_kernel(float* __restrict__ p, float* __restrict__ g,
+                                                            float* __restrict__ buf, int64_t n, float lr,
+                                                            float mom, float damp, float wd, int nesterov,
+                                                            int first) {
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+    float pv = p[i];
+    float d = g[i];
+    if (wd != 0.0f) d = __fmaf_rn(wd, pv, d);
+    float dir = d;
+    if (mom != 0.0f) {
+      float bv = first ? d : __fmaf_rn(1.0f - damp, d, buf[i] * mom);
+      buf[i] = bv;
+      dir = nesterov ? __fmaf_rn(mom, bv, d) : bv;
+    }
+    p[i] = __fmaf_rn(-lr, dir, pv);
+    g[i] = dir;
+  }
+}
+
+// utils/optimizer.py:6-13: transform(w) = (((w+0.5)*(2^bitW-1)) % 1)*lam2*2 ; sigmoid_d = s(1-s)*lam
+__global__ __launch_bounds__(kThreads) void sgd_grad_approx_kernel(const float* __restrict__ dir,
+                                                                   const float* __restrict__ w_cdf,
+                                                                   const float* __restrict__ w_pdf,
+                                                                   float* __restrict__ gout, int64_t n, float nlev,
+                                                                   float lam, float lam2) {
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+    float a = (w_cdf[i] + 0.5f) * nlev;
+    float fr = a - floorf(a);
+    float tr = fr * lam2 * 2.0f;
+    float sg = 1.0f / (1.0f + __expf(-tr));
+    gout[i] = dir[i] * (sg * (1.0f - sg) * lam) * w_pdf[i];
+  }
+}
+
+inline int grid_for(int64_t n) {
+  int64_t b = (n + kThreads - 1) / kThreads;
+  if (b < 1) b = 1;
+  return (int)(b > 2048 ? 2048 : b);
+}
+
+}  // namespace
+
+#define LAUNCH_CHECK()                          \
+  do {                                          \
+    hipError_t e__ = hipGetLastError();         \
+    if (e__ != hipSuccess) return (int)e__;     \
+  } while (0)
+
+extern "C" {
+
+size_t alignq_admm_ws_bytes(int dim) {
+  (void)dim;
+  return 16;
+}
+
+int alignq_admm_loss(const float* D, int b, const float* alterD, const float* gamma, int dim, float mu, float rho,
+                     float* loss, float* dD, float* dalterD, float* dgamma, void* ws, void* stream) {
+  (void)ws;
+  if (!D || !alterD || !gamma || !loss || b <= 0 || dim < b) return ALIGNQ_EINVAL;
+  if (dim > 4096) return ALIGNQ_EUNSUPPORTED;
+  hipLaunchKernelGGL(admm_loss_kernel, 1, kBig, 0, (hipStream_t)stream, D, b, alterD, gamma, dim, mu, rho, loss, dD,
+                     dalterD, dgamma);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int alignq_admm_update(const float* const* D_tab, float* const* alterD_tab, float* const* gamma_tab, int S, int b,
+                       int dim, float mu, float rho, void* stream) {
+  if (!D_tab || !alterD_tab || !gamma_tab || S <= 0 || b <= 0 || dim < b) return ALIGNQ_EINVAL;
+  if (dim > 4096) return ALIGNQ_EUNSUPPORTED;
+  hipLaunchKernelGGL(admm_update_kernel, S, kBig, 0, (hipStream_t)stream, D_tab, alterD_tab, gamma_tab, b, dim, mu,
+                     rho);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int alignq_sgd_step(float* p, float* g, float* buf, int64_t n, float lr, float mom, float damp, float wd,
+                    int nesterov, int first, void* stream) {
+  if (!p || !g || n <= 0) return ALIGNQ_EINVAL;
+  if (mom != 0.0f && !buf) return ALIGNQ_EINVAL;
+  hipLaunchKernelGGL(sgd_step_kernel, grid_for(n), kThreads, 0, (hipStream_t)stream, p, g, buf, n, lr, mom, damp, wd,
+                     nesterov, first);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int alignq_sgd_grad_approx(const float* dir, const float* w_cdf, const float* w_pdf, float* grad_out, int64_t n,
+                           int bitW, float lam, float lam2, void* stream) {
+  if (!dir || !w_cdf || !w_pdf || !grad_out || n <= 0 || bitW < 1 || bitW > 30) return ALIGNQ_EINVAL;
+  float nlev = (float)((1 << bitW) - 1);
+  hipLaunchKernelGGL(sgd_grad_approx_kernel, grid_for(n), kThreads, 0, (hipStream_t)stream, dir, w_cdf, w_pdf,
+                     grad_out, n, nlev, lam, lam2);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

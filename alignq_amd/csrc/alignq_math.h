@@ -1,0 +1,135 @@
+// Device-side ALIGNQ-EXP32 / ALIGNQ-ERF32 (spec: gen_erf32_coeffs.py docstring).
+// Every step is one IEEE-754 single operation (fma / mul / add / rint / exact 2^k scaling), so the
+// result is bit-identical to the scalar C statement of the same spec used by the test oracle.
+// Translation units including this header are compiled with -ffp-contract=off.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/alignq_erf32_coeffs.h"
+
+namespace alignq {
+
+__device__ __forceinline__ float pow2i(int e) { return __int_as_float((e + 127) << 23); }
+
+__device__ __forceinline__ float exp32(float x) {
+  float nf = rintf(x * ALIGNQ_LOG2E);
+  float r = __fmaf_rn(nf, -ALIGNQ_LN2_HI, x);
+  r = __fmaf_rn(nf, -ALIGNQ_LN2_LO, r);
+  float p = ALIGNQ_PE5;
+  p = __fmaf_rn(p, r, ALIGNQ_PE4);
+  p = __fmaf_rn(p, r, ALIGNQ_PE3);
+  p = __fmaf_rn(p, r, ALIGNQ_PE2);
+  p = __fmaf_rn(p, r, ALIGNQ_PE1);
+  p = __fmaf_rn(p, r, ALIGNQ_PE0);
+  float r2 = r * r;
+  float e = 1.0f + __fmaf_rn(r2, p, r);
+  int n = (int)nf;
+  int h = n >> 1;
+  float res = e * pow2i(h) * pow2i(n - h);
+  if (!(x >= -104.0f)) res = (x != x) ? x : 0.0f;
+  if (x > 88.7f) res = __int_as_float(0x7f800000);
+  return res;
+}
+
+// exp32 for arguments known to lie in [-40, 0] (the erf tail): no range guards, single 2^n scale.
+__device__ __forceinline__ float exp32_neg_small(float x) {
+  float nf = rintf(x * ALIGNQ_LOG2E);
+  float r = __fmaf_rn(nf, -ALIGNQ_LN2_HI, x);
+  r = __fmaf_rn(nf, -ALIGNQ_LN2_LO, r);
+  float p = ALIGNQ_PE5;
+  p = __fmaf_rn(p, r, ALIGNQ_PE4);
+  p = __fmaf_rn(p, r, ALIGNQ_PE3);
+  p = __fmaf_rn(p, r, ALIGNQ_PE2);
+  p = __fmaf_rn(p, r, ALIGNQ_PE1);
+  p = __fmaf_rn(p, r, ALIGNQ_PE0);
+  float r2 = r * r;
+  float e = 1.0f + __fmaf_rn(r2, p, r);
+  int n = (int)nf;
+  int h = n >> 1;
+  // two exact power-of-two scalings == the spec's e*2^h*2^(n-h) (no subnormals for n >= -58)
+  return e * pow2i(h) * pow2i(n - h);
+}
+
+__device__ __forceinline__ float erf32(float x) {
+  float a = fabsf(x);
+  float res;
+  if (a < ALIGNQ_ERF_T) {
+    float s = a * a;
+    float p = ALIGNQ_PA6;
+    p = __fmaf_rn(p, s, ALIGNQ_PA5);
+    p = __fmaf_rn(p, s, ALIGNQ_PA4);
+    p = __fmaf_rn(p, s, ALIGNQ_PA3);
+    p = __fmaf_rn(p, s, ALIGNQ_PA2);
+    p = __fmaf_rn(p, s, ALIGNQ_PA1);
+    p = __fmaf_rn(p, s, ALIGNQ_PA0);
+    res = __fmaf_rn(a, p, a);
+  } else if (a < ALIGNQ_ERF_HI) {
+    float p = ALIGNQ_PB7;
+    p = __fmaf_rn(p, a, ALIGNQ_PB6);
+    p = __fmaf_rn(p, a, ALIGNQ_PB5);
+    p = __fmaf_rn(p, a, ALIGNQ_PB4);
+    p = __fmaf_rn(p, a, ALIGNQ_PB3);
+    p = __fmaf_rn(p, a, ALIGNQ_PB2);
+    p = __fmaf_rn(p, a, ALIGNQ_PB1);
+    p = __fmaf_rn(p, a, ALIGNQ_PB0);
+    res = 1.0f - exp32_neg_small(-p);
+  } else {
+    res = (a != a) ? a : 1.0f;
+  }
+  return copysignf(res, x);
+}
+
+#define ALIGNQ_SQRT2F 1.41421356237309504880f
+#define ALIGNQ_LOG_SQRT_2PI_F 0.91893853320467274178f
+#define ALIGNQ_TWO_OVER_SQRT_2PI 0.79788456080286535588f  // 2*phi(0)
+
+// Normal(m,s).cdf in torch's op order (torch/distributions/normal.py; reference
+// model/quantization.py:50-51): 0.5*(1+erf((v-m)*(1/s)/sqrt(2))).  rs = 1/s.
+__device__ __forceinline__ float gauss_cdf32(float v, float m, float rs) {
+  float z = __fdiv_rn(__fmul_rn(__fsub_rn(v, m), rs), ALIGNQ_SQRT2F);
+  return __fmul_rn(0.5f, __fadd_rn(1.0f, erf32(z)));
+}
+
+// uniform_quantize(k).forward (model/quantization.py:23-31) on a transformed value; n = 2^k-1 as float.
+// k==32 -> identity, k==1 -> sign.  *bin receives the integer level.
+__device__ __forceinline__ float round_bins(float t, int k, float n, float* bin) {
+  if (k == 32) { *bin = t; return t; }
+  if (k == 1) { float s = (float)((t > 0.0f) - (t < 0.0f)); *bin = s; return s; }
+  float b = rintf(__fmul_rn(t, n));
+  *bin = b;
+  return __fdiv_rn(b, n);
+}
+
+// activation transform + quantise for one element; returns x_q, *t_pre = pre-round transform
+template <int FORMULA>
+__device__ __forceinline__ float act_quant1(float x, int k, float n, float r, float* t_pre, float* bin) {
+  float c = gauss_cdf32(x, 0.0f, 1.0f);
+  if (FORMULA == 0) {
+    float t = __fmul_rn(__fsub_rn(__fmul_rn(c, 2.0f), 1.0f), r);
+    *t_pre = t;
+    return round_bins(t, k, n, bin);
+  } else {
+    *t_pre = c;
+    float q = round_bins(c, k, n, bin);
+    return __fmul_rn(__fsub_rn(__fmul_rn(q, 2.0f), 1.0f), r);
+  }
+}
+
+// d t / d x = r * 2*phi(x)   (tolerance-checked, not bit-checked: fast exp is fine)
+__device__ __forceinline__ float act_jac(float x, float r) {
+  return r * ALIGNQ_TWO_OVER_SQRT_2PI * __expf(-0.5f * x * x);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+}  // namespace alignq

@@ -1,0 +1,321 @@
+// quant_kernels.hip — elementwise CDF-quantise kernels (activations and weights) for gfx950.
+//
+// HBM-bound streaming kernels: 16 B/lane coalesced loads/stores (one 1 KiB wave-instruction per
+// float4), grid capped at a few waves per SIMD with a grid-stride loop, no LDS.  The only
+// reductions (weight mean/std, weight-backward sums) are done in double with a deterministic
+// two-level tree (wave shuffle -> LDS -> per-block partial in the workspace -> every block of the
+// consumer kernel re-reduces the <= ALIGNQ_WS_BLOCKS partials), so results do not depend on
+// scheduling and need no atomics.
+#include <hip/hip_runtime.h>
+
+#include "../../include/alignq.h"
+#include "alignq_math.h"
+
+using namespace alignq;
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxBlocks = 2048;      // 256 CUs x 8 blocks (guide: cap the grid, stride the rest)
+constexpr int kWsBlocks = 256;        // partials per reduction (one block per CU)
+
+inline int grid_for(int64_t n_vec) {
+  int64_t b = (n_vec + kThreads - 1) / kThreads;
+  if (b < 1) b = 1;
+  return (int)(b > kMaxBlocks ? kMaxBlocks : b);
+}
+
+// ------------------------------------------------------------------ activations ---------------
+template <int FORMULA, bool BINS>
+__global__ __launch_bounds__(kThreads) void act_quant_fwd_kernel(const float* __restrict__ x,
+                                                                 float* __restrict__ xq,
+                                                                 int32_t* __restrict__ bins, int64_t n,
+                                                                 int k, float r) {
+  const float nlev = (float)((1 << (k & 31)) - 1);
+  const int64_t nvec = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  float4* q4 = reinterpret_cast<float4*>(xq);
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += stride) {
+    float4 v = x4[i];
+    float4 o;
+    float t, b0, b1, b2, b3;
+    o.x = act_quant1<FORMULA>(v.x, k, nlev, r, &t, &b0);
+    o.y = act_quant1<FORMULA>(v.y, k, nlev, r, &t, &b1);
+    o.z = act_quant1<FORMULA>(v.z, k, nlev, r, &t, &b2);
+    o.w = act_quant1<FORMULA>(v.w, k, nlev, r, &t, &b3);
+    q4[i] = o;
+    if (BINS) {
+      int4 bi = make_int4((int)b0, (int)b1, (int)b2, (int)b3);
+      reinterpret_cast<int4*>(bins)[i] = bi;
+    }
+  }
+  // tail (n % 4) by the first threads of block 0
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    int64_t i = (nvec << 2) + threadIdx.x;
+    float t, b;
+    xq[i] = act_quant1<FORMULA>(x[i], k, nlev, r, &t, &b);
+    if (BINS) bins[i] = (int)b;
+  }
+}
+
+// uniform_quantize(k).forward alone (model/quantization.py:23-31): y = round(x*n)/n | sign(x) | x
+__global__ __launch_bounds__(kThreads) void uniform_quantize_kernel(const float* __restrict__ x,
+                                                                    float* __restrict__ y, int64_t n, int k) {
+  const float nlev = (float)((1 << (k & 31)) - 1);
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+    float b;
+    y[i] = round_bins(x[i], k, nlev, &b);
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void act_quant_bwd_kernel(const float* __restrict__ g,
+                                                                 const float* __restrict__ x,
+                                                                 float* __restrict__ dx, int64_t n, float r) {
+  const int64_t nvec = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  float4* d4 = reinterpret_cast<float4*>(dx);
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += stride) {
+    float4 gv = g4[i], xv = x4[i], o;
+    o.x = gv.x * act_jac(xv.x, r);
+    o.y = gv.y * act_jac(xv.y, r);
+    o.z = gv.z * act_jac(xv.z, r);
+    o.w = gv.w * act_jac(xv.w, r);
+    d4[i] = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    int64_t i = (nvec << 2) + threadIdx.x;
+    dx[i] = g[i] * act_jac(x[i], r);
+  }
+}
+
+// ------------------------------------------------------------------ block reduction helper ----
+// Sums two doubles over the block; result valid in every thread.  LDS: 2*4 doubles.
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* sm /* [16] */) {
+  a = wave_sum_d(a);
+  b = wave_sum_d(b);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) { sm[w] = a; sm[8 + w] = b; }
+  __syncthreads();
+  const int nw = blockDim.x >> 6;
+  a = 0; b = 0;
+  for (int i = 0; i < nw; i++) { a += sm[i]; b += sm[8 + i]; }
+}
+
+// ------------------------------------------------------------------ weights: stats ------------
+// pass 1: per-block partial (sum w, sum w^2) in double -> ws[2*blk]
+__global__ __launch_bounds__(kThreads) void weight_partial_sums_kernel(const float* __restrict__ w, int64_t n,
+                                                                       double* __restrict__ ws) {
+  __shared__ double sm[16];
+  double s = 0, s2 = 0;
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+    double v = w[i];
+    s += v;
+    s2 += v * v;
+  }
+  block_sum2(s, s2, sm);
+  if (threadIdx.x == 0) { ws[2 * blockIdx.x] = s; ws[2 * blockIdx.x + 1] = s2; }
+}
+
+// pass 2 (1 block): combine partials -> ms = {mean, unbiased std}
+__global__ __launch_bounds__(kThreads) void weight_finalize_stats_kernel(const double* __restrict__ ws, int nblk,
+                                                                         int64_t n, float* __restrict__ ms) {
+  __shared__ double sm[16];
+  double s = 0, s2 = 0;
+  for (int i = threadIdx.x; i < nblk; i += kThreads) { s += ws[2 * i]; s2 += ws[2 * i + 1]; }
+  block_sum2(s, s2, sm);
+  if (threadIdx.x == 0) {
+    double dn = (double)n;
+    double mean = s / dn;
+    double var = (s2 - s * s / dn) / (dn - 1.0);
+    if (var < 0) var = 0;
+    ms[0] = (float)mean;
+    ms[1] = (float)sqrt(var);
+  }
+}
+
+// ------------------------------------------------------------------ weights: forward ----------
+template <int FORMULA>
+__global__ __launch_bounds__(kThreads) void weight_quant_fwd_kernel(const float* __restrict__ w,
+                                                                    const float* __restrict__ ms,
+                                                                    float* __restrict__ q, float* __restrict__ cdf_out,
+                                                                    float* __restrict__ pdf_out,
+                                                                    int32_t* __restrict__ bins, int64_t n, int k) {
+  const float m = ms[0], s = ms[1];
+  const float rs = __fdiv_rn(1.0f, s);
+  const float var2 = __fmul_rn(2.0f, __fmul_rn(s, s));
+  const float logs = (float)log((double)s);
+  const float nlev = (float)((1 << (k & 31)) - 1);
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+    float v = w[i];
+    float c = gauss_cdf32(v, m, rs);
+    float t, b, qq;
+    if (FORMULA == 0) {
+      t = __fsub_rn(__fmul_rn(c, 2.0f), 1.0f);
+      qq = round_bins(t, k, nlev, &b);
+    } else {
+      t = c;
+      qq = __fsub_rn(__fmul_rn(round_bins(c, k, nlev, &b), 2.0f), 1.0f);
+    }
+    q[i] = qq;
+    if (cdf_out) cdf_out[i] = t;
+    if (bins) bins[i] = (int)b;
+    if (pdf_out) {
+      float d = __fsub_rn(v, m);
+      float lp = __fsub_rn(__fsub_rn(__fdiv_rn(-__fmul_rn(d, d), var2), logs), ALIGNQ_LOG_SQRT_2PI_F);
+      pdf_out[i] = __fmul_rn(exp32(lp), 2.0f);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ weights: backward ---------
+// P = 2*pdf_N(m,s)(w) = 2/(s*sqrt(2pi)) * exp(-z^2/2), z = (w-m)/s
+__device__ __forceinline__ void weight_PZ(float w, float m, float rs, float cs, float* P, float* z) {
+  float zz = (w - m) * rs;
+  *z = zz;
+  *P = cs * __expf(-0.5f * zz * zz);
+}
+
+__global__ __launch_bounds__(kThreads) void weight_bwd_partial_kernel(const float* __restrict__ g,
+                                                                      const float* __restrict__ w,
+                                                                      const float* __restrict__ ms, int64_t n,
+                                                                      double* __restrict__ ws) {
+  __shared__ double sm[16];
+  const float m = ms[0], s = ms[1], rs = 1.0f / s, cs = ALIGNQ_TWO_OVER_SQRT_2PI * rs;
+  double s1 = 0, s2 = 0;
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+    float P, z;
+    weight_PZ(w[i], m, rs, cs, &P, &z);
+    double gp = (double)g[i] * (double)P;
+    s1 += gp;
+    s2 += gp * (double)z;
+  }
+  block_sum2(s1, s2, sm);
+  if (threadIdx.x == 0) { ws[2 * blockIdx.x] = s1; ws[2 * blockIdx.x + 1] = s2; }
+}
+
+__global__ __launch_bounds__(kThreads) void weight_bwd_apply_kernel(const float* __restrict__ g,
+                                                                    const float* __restrict__ w,
+                                                                    const float* __restrict__ ms,
+                                                                    const double* __restrict__ ws, int nblk,
+                                                                    float* __restrict__ dw, int64_t n) {
+  __shared__ double sm[16];
+  double s1 = 0, s2 = 0;
+  for (int i = threadIdx.x; i < nblk; i += kThreads) { s1 += ws[2 * i]; s2 += ws[2 * i + 1]; }
+  block_sum2(s1, s2, sm);
+  const float m = ms[0], s = ms[1], rs = 1.0f / s, cs = ALIGNQ_TWO_OVER_SQRT_2PI * rs;
+  const float mean_gp = (float)(s1 / (double)n);
+  const float dotn = (float)(s2 / (double)(n - 1));
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+    float P, z;
+    weight_PZ(w[i], m, rs, cs, &P, &z);
+    dw[i] = g[i] * P - mean_gp - z * dotn;
+  }
+}
+
+inline int ws_blocks(int64_t n) {
+  int64_t b = (n + (int64_t)kThreads * 8 - 1) / ((int64_t)kThreads * 8);
+  if (b < 1) b = 1;
+  return (int)(b > kWsBlocks ? kWsBlocks : b);
+}
+
+}  // namespace
+
+#define LAUNCH_CHECK()                          \
+  do {                                          \
+    hipError_t e__ = hipGetLastError();         \
+    if (e__ != hipSuccess) return (int)e__;     \
+  } while (0)
+
+extern "C" {
+
+int alignq_act_quant_fwd(const float* x, float* xq, int32_t* bins, int64_t n, int k, float act_range,
+                         int formula, void* stream) {
+  if (!x || !xq || n <= 0) return ALIGNQ_EINVAL;
+  if (!((k >= 1 && k <= 16) || k == 32)) return ALIGNQ_EINVAL;
+  if (formula != ALIGNQ_FORMULA_ADMM && formula != ALIGNQ_FORMULA_CDF) return ALIGNQ_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(xq) | reinterpret_cast<uintptr_t>(bins)) & 15)
+    return ALIGNQ_EINVAL;  // 16-byte alignment for the float4 path (torch allocations are 256-B aligned)
+  hipStream_t st = (hipStream_t)stream;
+  int grid = grid_for(n >> 2);
+  if (formula == ALIGNQ_FORMULA_ADMM) {
+    if (bins) hipLaunchKernelGGL((act_quant_fwd_kernel<0, true>), grid, kThreads, 0, st, x, xq, bins, n, k, act_range);
+    else hipLaunchKernelGGL((act_quant_fwd_kernel<0, false>), grid, kThreads, 0, st, x, xq, bins, n, k, act_range);
+  } else {
+    if (bins) hipLaunchKernelGGL((act_quant_fwd_kernel<1, true>), grid, kThreads, 0, st, x, xq, bins, n, k, act_range);
+    else hipLaunchKernelGGL((act_quant_fwd_kernel<1, false>), grid, kThreads, 0, st, x, xq, bins, n, k, act_range);
+  }
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int alignq_uniform_quantize(const float* x, float* y, int64_t n, int k, void* stream) {
+  if (!x || !y || n <= 0) return ALIGNQ_EINVAL;
+  if (!((k >= 1 && k <= 16) || k == 32)) return ALIGNQ_EINVAL;
+  hipLaunchKernelGGL(uniform_quantize_kernel, grid_for(n), kThreads, 0, (hipStream_t)stream, x, y, n, k);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int alignq_act_quant_bwd(const float* g, const float* x, float* dx, int64_t n, float act_range, void* stream) {
+  if (!g || !x || !dx || n <= 0) return ALIGNQ_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(dx)) & 15)
+    return ALIGNQ_EINVAL;
+  hipLaunchKernelGGL(act_quant_bwd_kernel, grid_for(n >> 2), kThreads, 0, (hipStream_t)stream, g, x, dx, n, act_range);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+size_t alignq_weight_ws_bytes(int64_t n) {
+  (void)n;
+  return (size_t)kWsBlocks * 2 * sizeof(double);
+}
+
+int alignq_weight_stats(const float* w, int64_t n, float* ms, void* ws, void* stream) {
+  if (!w || !ms || !ws || n < 2) return ALIGNQ_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  int nb = ws_blocks(n);
+  hipLaunchKernelGGL(weight_partial_sums_kernel, nb, kThreads, 0, st, w, n, (double*)ws);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(weight_finalize_stats_kernel, 1, kThreads, 0, st, (const double*)ws, nb, n, ms);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int alignq_weight_quant_fwd(const float* w, const float* ms, float* q, float* cdf_out, float* pdf_out,
+                            int32_t* bins, int64_t n, int k, int formula, void* stream) {
+  if (!w || !ms || !q || n <= 0) return ALIGNQ_EINVAL;
+  if (!((k >= 1 && k <= 16) || k == 32)) return ALIGNQ_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  int grid = grid_for(n);
+  if (formula == ALIGNQ_FORMULA_ADMM)
+    hipLaunchKernelGGL((weight_quant_fwd_kernel<0>), grid, kThreads, 0, st, w, ms, q, cdf_out, pdf_out, bins, n, k);
+  else if (formula == ALIGNQ_FORMULA_CDF)
+    hipLaunchKernelGGL((weight_quant_fwd_kernel<1>), grid, kThreads, 0, st, w, ms, q, cdf_out, pdf_out, bins, n, k);
+  else
+    return ALIGNQ_EINVAL;
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int alignq_weight_quant_bwd(const float* g, const float* w, const float* ms, float* dw, int64_t n, void* ws,
+                            void* stream) {
+  if (!g || !w || !ms || !dw || !ws || n < 2) return ALIGNQ_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  int nb = ws_blocks(n);
+  hipLaunchKernelGGL(weight_bwd_partial_kernel, nb, kThreads, 0, st, g, w, ms, n, (double*)ws);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(weight_bwd_apply_kernel, grid_for(n), kThreads, 0, st, g, w, ms, (const double*)ws, nb, dw, n);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

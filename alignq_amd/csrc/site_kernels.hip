@@ -1,0 +1,565 @@
+// site_kernels.hip — fused ADMM-site kernels for gfx950: activation quantise + the pair of sample-
+// correlation (Gram) matrices, forward and backward, on exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+// Reference semantics: activation_quantize_fn.forward (ADMM tree model/quantization.py:102-132), corr
+// (:134-137; Office tree :158-161), with x viewed as [B, F], B <= 128.
+//
+// Data layout / tiling:
+//   * x is row-major [B,F]; a workgroup (256 threads = 4 waves) owns column tiles of TF=64 features:
+//     each row contributes 256 contiguous bytes -> 16 lanes x float4, fully coalesced; x is read ONCE.
+//   * per-feature batch statistics (mean, unbiased std) of x and of t = r(2Phi(x)-1) are reduced over the
+//     rows through LDS; standardised tiles Xh, Th are staged in LDS [BP][65] (odd stride => the strided
+//     MFMA A/B fragment reads `row = lane&31` are bank-conflict free).
+//   * D = Th Th^T - Xh Xh^T is accumulated in ONE set of MFMA accumulators per 32x32 output tile
+//     (the x contribution enters with a negated A operand), K = the tile's 64 features.
+//   * cross-workgroup reduction is deterministic: each workgroup writes its partial [BP,BP] slab, a second
+//     kernel sums the slabs (16 slab groups x 64 elements per 1024-thread block) and scales by 1/F.
+//   * backward is tile-local (no cross-workgroup traffic): dXh = S Xh with S = (dD+dD^T)*scale/F held as
+//     MFMA A fragments in registers, Xh/Th from LDS as B fragments; the per-feature projections of the
+//     standardisation backward are wave-shuffle + LDS reductions over the batch dimension.
+#include <hip/hip_runtime.h>
+
+#include "../../include/alignq.h"
+#include "alignq_math.h"
+
+using namespace alignq;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int TF = 64;        // features per tile
+constexpr int LD = TF + 1;    // LDS row stride in floats
+constexpr int kThreads = 256;
+constexpr int kMaxGridFwd = 256;   // slabs (K-splits) per site for NB=4 (one workgroup per CU)
+constexpr int kMaxGridSmall = 512; // for NB<4
+
+__device__ __forceinline__ float4 load4(const float* __restrict__ x, int64_t off, int col, int64_t F, bool row_ok,
+                                        bool aligned) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!row_ok) return v;
+  if (aligned) {
+    if (col < F) v = *reinterpret_cast<const float4*>(x + off);
+  } else {
+    if (col + 0 < F) v.x = x[off + 0];
+    if (col + 1 < F) v.y = x[off + 1];
+    if (col + 2 < F) v.z = x[off + 2];
+    if (col + 3 < F) v.w = x[off + 3];
+  }
+  return v;
+}
+
+__device__ __forceinline__ void store4(float* __restrict__ y, int64_t off, int col, int64_t F, bool row_ok, bool aligned,
+                                       float4 v) {
+  if (!row_ok) return;
+  if (aligned) {
+    if (col < F) *reinterpret_cast<float4*>(y + off) = v;
+  } else {
+    if (col + 0 < F) y[off + 0] = v.x;
+    if (col + 1 < F) y[off + 1] = v.y;
+    if (col + 2 < F) y[off + 2] = v.z;
+    if (col + 3 < F) y[off + 3] = v.w;
+  }
+}
+
+// ================================================================================================
+// forward: per column tile -> quantise, statistics, standardise, MFMA Gram difference
+//   NB   : number of 32-row blocks (BP = 32*NB >= B)
+//   PAIR : true  -> D = corr(t,t) - corr(x,x) and x_q;  false -> G = corr(x,x) only
+template <int NB, bool PAIR>
+__global__ __launch_bounds__(kThreads) void site_fwd_kernel(const float* __restrict__ x, int B, int64_t F, int k,
+                                                            float r, float eps, float* __restrict__ xq,
+                                                            float* __restrict__ slabs, float* __restrict__ stats,
+                                                            int n_tiles, int aligned) {
+  constexpr int BP = 32 * NB;
+  constexpr int RJ = BP / 16;                 // rows per thread in the load mapping
+  constexpr int NOP = PAIR ? 2 : 1;           // operands staged in LDS (x, t)
+  constexpr int RI = (NB == 4) ? 2 : 1;       // 32x32 output tiles per wave per dimension
+  constexpr int KS = (NB == 1) ? 4 : 1;       // K-split across waves when there is a single output tile
+  constexpr int LDS_FLOATS = (2 * BP * LD > 4096 ? 2 * BP * LD : 4096) + 4 * TF;
+  __shared__ float lds[LDS_FLOATS];
+  float* Xs = lds;                            // [BP][LD]
+  float* Ts = lds + BP * LD;                  // [BP][LD]
+  float* red = Ts;                            // [2][16][TF]   (aliased: used before Ts is written)
+  float* colv = lds + (2 * BP * LD > 4096 ? 2 * BP * LD : 4096);  // mean_x, rho_x, mean_t, rho_t : [4][TF]
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c = tid & 15, rg = tid >> 4;
+  const int h = lane >> 5, l31 = lane & 31;
+  const float nlev = (float)((1 << (k & 31)) - 1);
+  const float invB = 1.0f / (float)B, invBm1 = 1.0f / (float)(B - 1);
+
+  // wave -> output tiles
+  const int wr = (NB == 1) ? 0 : (w >> 1), wc = (NB == 1) ? 0 : (w & 1);
+  f32x16 acc[RI][RI];
+#pragma unroll
+  for (int i = 0; i < RI; i++)
+#pragma unroll
+    for (int j = 0; j < RI; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int col0 = tile * TF;
+    const int col = col0 + 4 * c;
+    float4 xv[RJ], tv[RJ];
+    // ---- load + transform + quantise --------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < RJ; j++) {
+      const int row = rg + 16 * j;
+      const bool ok = row < B;
+      const int64_t off = (int64_t)row * F + col;
+      xv[j] = load4(x, off, col, F, ok, aligned);
+      if (PAIR) {
+        float4 q;
+        float b;
+        q.x = act_quant1<0>(xv[j].x, k, nlev, r, &tv[j].x, &b);
+        q.y = act_quant1<0>(xv[j].y, k, nlev, r, &tv[j].y, &b);
+        q.z = act_quant1<0>(xv[j].z, k, nlev, r, &tv[j].z, &b);
+        q.w = act_quant1<0>(xv[j].w, k, nlev, r, &tv[j].w, &b);
+        if (xq) store4(xq, off, col, F, ok, aligned, q);
+      }
+    }
+    // ---- column means -----------------------------------------------------------------------
+    {
+      float4 sx = make_float4(0, 0, 0, 0), st = make_float4(0, 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < RJ; j++) {
+        if (rg + 16 * j < B) {
+          sx.x += xv[j].x; sx.y += xv[j].y; sx.z += xv[j].z; sx.w += xv[j].w;
+          if (PAIR) { st.x += tv[j].x; st.y += tv[j].y; st.z += tv[j].z; st.w += tv[j].w; }
+        }
+      }
+      float* p0 = red + rg * TF + 4 * c;
+      p0[0] = sx.x; p0[1] = sx.y; p0[2] = sx.z; p0[3] = sx.w;
+      if (PAIR) {
+        float* p1 = red + 16 * TF + rg * TF + 4 * c;
+        p1[0] = st.x; p1[1] = st.y; p1[2] = st.z; p1[3] = st.w;
+      }
+    }
+    __syncthreads();
+    if (tid < NOP * TF) {
+      const int op = tid >> 6, cc = tid & 63;
+      float s = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; g++) s += red[op * 16 * TF + g * TF + cc];
+      colv[(2 * op) * TF + cc] = s * invB;
+    }
+    __syncthreads();
+    // ---- column variances (two-pass) ----------------------------------------------------------
+    {
+      const float4 mx = make_float4(colv[4 * c], colv[4 * c + 1], colv[4 * c + 2], colv[4 * c + 3]);
+      float4 mt = make_float4(0, 0, 0, 0);
+      if (PAIR) mt = make_float4(colv[2 * TF + 4 * c], colv[2 * TF + 4 * c + 1], colv[2 * TF + 4 * c + 2],
+                                 colv[2 * TF + 4 * c + 3]);
+      float4 sx = make_float4(0, 0, 0, 0), st = make_float4(0, 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < RJ; j++) {
+        if (rg + 16 * j < B) {
+          float d;
+          d = xv[j].x - mx.x; sx.x += d * d;
+          d = xv[j].y - mx.y; sx.y += d * d;
+          d = xv[j].z - mx.z; sx.z += d * d;
+          d = xv[j].w - mx.w; sx.w += d * d;
+          if (PAIR) {
+            d = tv[j].x - mt.x; st.x += d * d;
+            d = tv[j].y - mt.y; st.y += d * d;
+            d = tv[j].z - mt.z; st.z += d * d;
+            d = tv[j].w - mt.w; st.w += d * d;
+          }
+        }
+      }
+      float* p0 = red + rg * TF + 4 * c;
+      p0[0] = sx.x; p0[1] = sx.y; p0[2] = sx.z; p0[3] = sx.w;
+      if (PAIR) {
+        float* p1 = red + 16 * TF + rg * TF + 4 * c;
+        p1[0] = st.x; p1[1] = st.y; p1[2] = st.z; p1[3] = st.w;
+      }
+    }
+    __syncthreads();
+    if (tid < NOP * TF) {
+      const int op = tid >> 6, cc = tid & 63;
+      float s = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; g++) s += red[op * 16 * TF + g * TF + cc];
+      const float sd = sqrtf(s * invBm1);
+      const float rho = 1.0f / (sd + eps);
+      colv[(2 * op + 1) * TF + cc] = rho;
+      if (stats && col0 + cc < F) {
+        stats[(int64_t)(2 * op) * F + col0 + cc] = colv[(2 * op) * TF + cc];
+        stats[(int64_t)(2 * op + 1) * F + col0 + cc] = rho;
+      }
+    }
+    __syncthreads();
+    // ---- standardise into LDS -------------------------------------------------------------------
+    {
+      float mx[4], rx[4], mt[4], rt[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        mx[e] = colv[4 * c + e];
+        rx[e] = colv[TF + 4 * c + e];
+        if (PAIR) { mt[e] = colv[2 * TF + 4 * c + e]; rt[e] = colv[3 * TF + 4 * c + e]; }
+      }
+#pragma unroll
+      for (int j = 0; j < RJ; j++) {
+        const int row = rg + 16 * j;
+        const bool ok = row < B;
+        const float xe[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
+        const float te[4] = {tv[j].x, tv[j].y, tv[j].z, tv[j].w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const bool okc = ok && (col + e < F);
+          Xs[row * LD + 4 * c + e] = okc ? (xe[e] - mx[e]) * rx[e] : 0.0f;
+          if (PAIR) Ts[row * LD + 4 * c + e] = okc ? (te[e] - mt[e]) * rt[e] : 0.0f;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- MFMA: acc += Th Th^T - Xh Xh^T over this tile's 64 features ------------------------------
+    {
+      const int kbeg = (KS == 1) ? 0 : w * (TF / KS);
+      const int kend = (KS == 1) ? TF : kbeg + TF / KS;
+      const int rowA = (NB == 4 ? wr * 64 : wr * 32) + l31;
+      const int rowB = (NB == 4 ? wc * 64 : wc * 32) + l31;
+#pragma unroll 4
+      for (int k0 = kbeg; k0 < kend; k0 += 2) {
+        float ax[RI], bx[RI], at[RI], bt[RI];
+#pragma unroll
+        for (int i = 0; i < RI; i++) {
+          ax[i] = Xs[(rowA + 32 * i) * LD + k0 + h];
+          bx[i] = Xs[(rowB + 32 * i) * LD + k0 + h];
+          if (PAIR) {
+            at[i] = Ts[(rowA + 32 * i) * LD + k0 + h];
+            bt[i] = Ts[(rowB + 32 * i) * LD + k0 + h];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < RI; i++)
+#pragma unroll
+          for (int j = 0; j < RI; j++) {
+            if (PAIR) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(at[i], bt[j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(-ax[i], bx[j], acc[i][j], 0, 0, 0);
+            } else {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[i], bx[j], acc[i][j], 0, 0, 0);
+            }
+          }
+      }
+    }
+    __syncthreads();   // LDS tiles are overwritten by the next iteration
+  }
+
+  // ---- write this workgroup's partial slab [BP][BP] ----------------------------------------------
+  float* slab = slabs + (int64_t)blockIdx.x * BP * BP;
+  if (KS == 1) {
+#pragma unroll
+    for (int i = 0; i < RI; i++)
+#pragma unroll
+      for (int j = 0; j < RI; j++) {
+        const int I = (NB == 4 ? wr * 2 : wr) + i, J = (NB == 4 ? wc * 2 : wc) + j;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          const int row = I * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          slab[row * BP + J * 32 + l31] = acc[i][j][e];
+        }
+      }
+  } else {
+    // single 32x32 tile, four K-slices (one per wave): combine through LDS
+    float* buf = lds;  // [4][32][32]
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+      buf[w * 1024 + row * 32 + l31] = acc[0][0][e];
+    }
+    __syncthreads();
+    for (int e = tid; e < 1024; e += kThreads) slab[e] = buf[e] + buf[1024 + e] + buf[2048 + e] + buf[3072 + e];
+  }
+}
+
+// ================================================================================================
+// slab reduction: out[i][j] = scale * sum_s slab[s][i][j],  i,j < B.  1024 threads = 16 slab groups x 64 elems
+__global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restrict__ slabs, int n_slabs, int BP,
+                                                           int B, float scale, float* __restrict__ out) {
+  __shared__ float part[16][64];
+  const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + lane;
+  const bool ok = e < B * B;
+  const int i = ok ? e / B : 0, j = ok ? e - i * B : 0;
+  const float* p = slabs + (int64_t)i * BP + j;
+  const int64_t sstride = (int64_t)BP * BP;
+  float s = 0.f;
+  if (ok) {
+#pragma unroll 4
+    for (int sl = sg; sl < n_slabs; sl += 16) s += p[(int64_t)sl * sstride];
+  }
+  part[sg][lane] = s;
+  __syncthreads();
+  if (sg == 0 && ok) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; g++) t += part[g][lane];
+    out[e] = t * scale;
+  }
+}
+
+// ================================================================================================
+// backward.  dx = g*jac + jac * d(corr(t,t))/dt [with +dD] + d(corr(x,x))/dx [with -dD]      (PAIR)
+//            dx = d(corr(x,x))/dx [with +dG]                                                   (!PAIR)
+// Wave w owns output row block I (32 batch rows) and PX column blocks of 32 features; for every owned
+// column block it holds the accumulator tile of BOTH operands, so the final assembly is wave-local.
+//   NB=4: I = w,    column blocks {0,1}
+//   NB=2: I = w>>1, column block  w&1
+//   NB=1: I = 0,    column block  w (waves 0,1; waves 2,3 only help with loads and LDS staging)
+template <int NB, bool PAIR>
+__global__ __launch_bounds__(kThreads) void site_bwd_kernel(const float* __restrict__ g, const float* __restrict__ dD,
+                                                            const float* __restrict__ dD_scale,
+                                                            const float* __restrict__ x,
+                                                            const float* __restrict__ stats, int B, int64_t F, float r,
+                                                            float eps, float* __restrict__ dx, int n_tiles,
+                                                            int aligned) {
+  constexpr int BP = 32 * NB;
+  constexpr int RJ = BP / 16;
+  constexpr int NOP = PAIR ? 2 : 1;
+  constexpr int PX = (NB == 4) ? 2 : 1;
+  constexpr int KSTEPS = BP / 2;
+  __shared__ float lds[2 * BP * LD + 4 * TF + NB * NOP * 2 * TF];
+  float* Xs = lds;
+  float* Ts = lds + BP * LD;
+  float* colv = lds + 2 * BP * LD;             // mean_x, rho_x, mean_t, rho_t  [4][TF]
+  float* red = colv + 4 * TF;                  // [NB row blocks][NOP][2][TF]
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c = tid & 15, rg = tid >> 4;
+  const int h = lane >> 5, l31 = lane & 31;
+
+  const int I = (NB == 4) ? w : (NB == 2 ? (w >> 1) : 0);
+  const bool wave_active = (NB != 1) || (w < 2);
+
+  // S fragments (MFMA A operand): A[i][k] = (dD[i][k] + dD[k][i]) * scale / F,  i = I*32 + l31, k = 2*s + h
+  float sfrag[KSTEPS];
+  {
+    const float sc = (dD_scale ? dD_scale[0] : 1.0f) / (float)F;
+    const int i = I * 32 + l31;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; s++) {
+      const int kk = 2 * s + h;
+      float v = 0.f;
+      if (i < B && kk < B) v = (dD[i * B + kk] + dD[kk * B + i]) * sc;
+      sfrag[s] = v;
+    }
+  }
+  const float invB = 1.0f / (float)B, invBm1 = 1.0f / (float)(B - 1);
+
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int col0 = tile * TF;
+    const int col = col0 + 4 * c;
+    // ---- column constants -------------------------------------------------------------------------
+    if (tid < 2 * NOP * TF) {
+      const int a = tid >> 6, cc = tid & 63;
+      colv[a * TF + cc] = (col0 + cc < F) ? stats[(int64_t)a * F + col0 + cc] : 0.0f;
+    }
+    __syncthreads();
+    // ---- load x, recompute t, standardise into LDS ---------------------------------------------
+    {
+      float mx[4], rx[4], mt[4], rt[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        mx[e] = colv[4 * c + e];
+        rx[e] = colv[TF + 4 * c + e];
+        if (PAIR) { mt[e] = colv[2 * TF + 4 * c + e]; rt[e] = colv[3 * TF + 4 * c + e]; }
+      }
+#pragma unroll
+      for (int j = 0; j < RJ; j++) {
+        const int row = rg + 16 * j;
+        const bool ok = row < B;
+        const int64_t off = (int64_t)row * F + col;
+        const float4 xv = load4(x, off, col, F, ok, aligned);
+        const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const bool okc = ok && (col + e < F);
+          Xs[row * LD + 4 * c + e] = okc ? (xe[e] - mx[e]) * rx[e] : 0.0f;
+          if (PAIR) {
+            const float cdfv = gauss_cdf32(xe[e], 0.0f, 1.0f);
+            const float t = (cdfv * 2.0f - 1.0f) * r;
+            Ts[row * LD + 4 * c + e] = okc ? (t - mt[e]) * rt[e] : 0.0f;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- MFMA: accX[p] = S[I,:] Xh[:, cb(p)],  accT[p] = S[I,:] Th[:, cb(p)] ------------------------
+    f32x16 accX[PX], accT[PX];
+    int cb[PX];
+#pragma unroll
+    for (int p = 0; p < PX; p++) {
+      cb[p] = ((NB == 4) ? p : (w & 1)) * 32 + l31;      // this lane's feature column inside the tile
+#pragma unroll
+      for (int e = 0; e < 16; e++) { accX[p][e] = 0.0f; accT[p][e] = 0.0f; }
+    }
+    if (wave_active) {
+#pragma unroll
+      for (int s = 0; s < KSTEPS; s++) {
+        const int kk = 2 * s + h;
+#pragma unroll
+        for (int p = 0; p < PX; p++) {
+          accX[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(sfrag[s], Xs[kk * LD + cb[p]], accX[p], 0, 0, 0);
+          if (PAIR) accT[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(sfrag[s], Ts[kk * LD + cb[p]], accT[p], 0, 0, 0);
+        }
+      }
+      // ---- per-feature projections over this wave's 32 batch rows: sum dVh, sum dVh*Vh ------------
+#pragma unroll
+      for (int p = 0; p < PX; p++) {
+        float x0 = 0.f, x1 = 0.f, t0 = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          const int row = I * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          x0 += accX[p][e];
+          x1 += accX[p][e] * Xs[row * LD + cb[p]];
+          if (PAIR) { t0 += accT[p][e]; t1 += accT[p][e] * Ts[row * LD + cb[p]]; }
+        }
+        x0 += __shfl_xor(x0, 32, 64);
+        x1 += __shfl_xor(x1, 32, 64);
+        if (PAIR) { t0 += __shfl_xor(t0, 32, 64); t1 += __shfl_xor(t1, 32, 64); }
+        if (h == 0) {
+          float* rp = red + (I * NOP * 2) * TF + cb[p];
+          rp[0] = x0;
+          rp[TF] = x1;
+          if (PAIR) { rp[2 * TF] = t0; rp[3 * TF] = t1; }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- assemble and write dx (accumulator layout: 32 consecutive features per half-wave) ----------
+    if (wave_active) {
+#pragma unroll
+      for (int p = 0; p < PX; p++) {
+        float sx0 = 0.f, sx1 = 0.f, st0 = 0.f, st1 = 0.f;
+#pragma unroll
+        for (int rb = 0; rb < NB; rb++) {
+          const float* rp = red + (rb * NOP * 2) * TF + cb[p];
+          sx0 += rp[0];
+          sx1 += rp[TF];
+          if (PAIR) { st0 += rp[2 * TF]; st1 += rp[3 * TF]; }
+        }
+        const float rho_x = colv[TF + cb[p]];
+        const float rho_t = PAIR ? colv[3 * TF + cb[p]] : 0.0f;
+        // through-std factor (sd+eps)/sd = 1/(1-eps*rho); torch's std backward is 0 where sd == 0
+        float kap_x = 1.0f, kap_t = 1.0f;
+        if (eps != 0.0f) {
+          const float dxn = 1.0f - eps * rho_x, dtn = 1.0f - eps * rho_t;
+          kap_x = (dxn > 1e-12f) ? 1.0f / dxn : 0.0f;
+          kap_t = (dtn > 1e-12f) ? 1.0f / dtn : 0.0f;
+        }
+        const float mean_x = sx0 * invB, proj_x = sx1 * invBm1 * kap_x;
+        const float mean_t = st0 * invB, proj_t = st1 * invBm1 * kap_t;
+        const bool colok = (col0 + cb[p]) < F;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          const int row = I * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (row < B && colok) {
+            const int64_t off = (int64_t)row * F + col0 + cb[p];
+            const float cx = rho_x * (accX[p][e] - mean_x - Xs[row * LD + cb[p]] * proj_x);
+            float out;
+            if (PAIR) {
+              const float ct = rho_t * (accT[p][e] - mean_t - Ts[row * LD + cb[p]] * proj_t);
+              const float jac = act_jac(x[off], r);
+              const float gv = g ? g[off] : 0.0f;
+              out = (gv + ct) * jac - cx;       // corr(x,x) enters D with a minus sign
+            } else {
+              out = cx;
+            }
+            dx[off] = out;
+          }
+        }
+      }
+    }
+    __syncthreads();   // LDS is overwritten by the next tile
+  }
+}
+
+inline int nb_for(int B) { return B <= 32 ? 1 : (B <= 64 ? 2 : 4); }
+
+inline int fwd_grid(int B, int n_tiles) {
+  int cap = (nb_for(B) == 4) ? kMaxGridFwd : kMaxGridSmall;
+  return n_tiles < cap ? n_tiles : cap;
+}
+
+template <bool PAIR>
+int launch_fwd(const float* x, int B, int64_t F, int k, float r, float eps, float* xq, float* out, float* stats,
+               void* ws, hipStream_t st) {
+  const int n_tiles = (int)((F + TF - 1) / TF);
+  const int grid = fwd_grid(B, n_tiles);
+  const int nb = nb_for(B);
+  const int aligned = ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
+                      (!xq || (reinterpret_cast<uintptr_t>(xq) & 15) == 0);
+  float* slabs = (float*)ws;
+  switch (nb) {
+    case 1: hipLaunchKernelGGL((site_fwd_kernel<1, PAIR>), grid, kThreads, 0, st, x, B, F, k, r, eps, xq, slabs, stats, n_tiles, aligned); break;
+    case 2: hipLaunchKernelGGL((site_fwd_kernel<2, PAIR>), grid, kThreads, 0, st, x, B, F, k, r, eps, xq, slabs, stats, n_tiles, aligned); break;
+    default: hipLaunchKernelGGL((site_fwd_kernel<4, PAIR>), grid, kThreads, 0, st, x, B, F, k, r, eps, xq, slabs, stats, n_tiles, aligned); break;
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  const int BP = 32 * nb;
+  hipLaunchKernelGGL(slab_reduce_kernel, (B * B + 63) / 64, 1024, 0, st, slabs, grid, BP, B, 1.0f / (float)F, out);
+  e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+template <bool PAIR>
+int launch_bwd(const float* g, const float* dD, const float* dD_scale, const float* x, const float* stats, int B,
+               int64_t F, float r, float eps, float* dx, hipStream_t st) {
+  const int n_tiles = (int)((F + TF - 1) / TF);
+  const int grid = n_tiles < 2048 ? n_tiles : 2048;
+  const int nb = nb_for(B);
+  const int aligned = ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  switch (nb) {
+    case 1: hipLaunchKernelGGL((site_bwd_kernel<1, PAIR>), grid, kThreads, 0, st, g, dD, dD_scale, x, stats, B, F, r, eps, dx, n_tiles, aligned); break;
+    case 2: hipLaunchKernelGGL((site_bwd_kernel<2, PAIR>), grid, kThreads, 0, st, g, dD, dD_scale, x, stats, B, F, r, eps, dx, n_tiles, aligned); break;
+    default: hipLaunchKernelGGL((site_bwd_kernel<4, PAIR>), grid, kThreads, 0, st, g, dD, dD_scale, x, stats, B, F, r, eps, dx, n_tiles, aligned); break;
+  }
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t alignq_site_ws_bytes(int B, int64_t F) {
+  if (B < 2 || B > ALIGNQ_MAX_BATCH || F <= 0) return 0;
+  const int nb = nb_for(B);
+  const int n_tiles = (int)((F + TF - 1) / TF);
+  return (size_t)fwd_grid(B, n_tiles) * (32 * nb) * (32 * nb) * sizeof(float);
+}
+
+int alignq_site_fwd(const float* x, int B, int64_t F, int k, float act_range, float eps, float* xq, float* D,
+                    float* stats, void* ws, void* stream) {
+  if (!x || !D || !ws || F <= 0) return ALIGNQ_EINVAL;
+  if (B < 2 || B > ALIGNQ_MAX_BATCH) return ALIGNQ_EUNSUPPORTED;
+  if (!((k >= 1 && k <= 16) || k == 32)) return ALIGNQ_EINVAL;
+  return launch_fwd<true>(x, B, F, k, act_range, eps, xq, D, stats, ws, (hipStream_t)stream);
+}
+
+int alignq_site_bwd(const float* g, const float* dD, const float* dD_scale, const float* x, const float* stats,
+                    int B, int64_t F, float act_range, float eps, float* dx, void* stream) {
+  if (!dD || !x || !stats || !dx || F <= 0) return ALIGNQ_EINVAL;
+  if (B < 2 || B > ALIGNQ_MAX_BATCH) return ALIGNQ_EUNSUPPORTED;
+  return launch_bwd<true>(g, dD, dD_scale, x, stats, B, F, act_range, eps, dx, (hipStream_t)stream);
+}
+
+int alignq_corr_fwd(const float* x, int B, int64_t F, float eps, float* G, float* stats, void* ws, void* stream) {
+  if (!x || !G || !ws || F <= 0) return ALIGNQ_EINVAL;
+  if (B < 2 || B > ALIGNQ_MAX_BATCH) return ALIGNQ_EUNSUPPORTED;
+  return launch_fwd<false>(x, B, F, 32, 1.0f, eps, nullptr, G, stats, ws, (hipStream_t)stream);
+}
+
+int alignq_corr_bwd(const float* dG, const float* x, const float* stats, int B, int64_t F, float eps, float* dx,
+                    void* stream) {
+  if (!dG || !x || !stats || !dx || F <= 0) return ALIGNQ_EINVAL;
+  if (B < 2 || B > ALIGNQ_MAX_BATCH) return ALIGNQ_EUNSUPPORTED;
+  return launch_bwd<false>(nullptr, dG, nullptr, x, stats, B, F, 1.0f, eps, dx, (hipStream_t)stream);
+}
+
+}  // extern "C"

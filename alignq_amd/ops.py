@@ -1,0 +1,223 @@
+"""torch.autograd.Function wrappers over the C ABI (include/alignq.h).
+
+Each Function allocates its outputs/workspaces with torch (device memory + stream plumbing only) and
+enqueues the HIP kernels on torch's current stream, so a whole training step can be captured into a
+HIP graph (torch.cuda.CUDAGraph).  No host synchronisation happens here.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------------------------------------ R1
+class UniformQuantizeFn(torch.autograd.Function):
+    """uniform_quantize(k) — model/quantization.py:19-38: forward round, backward straight-through."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        if k == 32:
+            return x
+        x = L.dev_f32(x, "input")
+        y = torch.empty_like(x)
+        L.check(L.load().alignq_uniform_quantize(L.ptr(x), L.ptr(y), x.numel(), int(k), L.stream_ptr()),
+                "alignq_uniform_quantize")
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.clone(), None
+
+
+# ------------------------------------------------------------------------------------------------ R4 (plain)
+class ActQuantFn(torch.autograd.Function):
+    """Activation CDF transform + quantise without the correlation branch."""
+
+    @staticmethod
+    def forward(ctx, x, k, act_range, formula):
+        x = L.dev_f32(x, "activation")
+        xq = torch.empty_like(x)
+        L.check(L.load().alignq_act_quant_fwd(L.ptr(x), L.ptr(xq), None, x.numel(), int(k), float(act_range),
+                                              int(formula), L.stream_ptr()), "alignq_act_quant_fwd")
+        ctx.save_for_backward(x)
+        ctx.act_range = float(act_range)
+        return xq
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        g = L.dev_f32(g, "grad")
+        dx = torch.empty_like(x)
+        L.check(L.load().alignq_act_quant_bwd(L.ptr(g), L.ptr(x), L.ptr(dx), x.numel(), ctx.act_range,
+                                              L.stream_ptr()), "alignq_act_quant_bwd")
+        return dx, None, None, None
+
+
+def act_quant_bins(x, k, act_range, formula):
+    """Parity instrumentation: (x_q, int32 bins) of the activation quantiser."""
+    x = L.dev_f32(x, "activation")
+    xq = torch.empty_like(x)
+    bins = torch.empty(x.shape, dtype=torch.int32, device=x.device)
+    L.check(L.load().alignq_act_quant_fwd(L.ptr(x), L.ptr(xq), L.ptr(bins), x.numel(), int(k), float(act_range),
+                                          int(formula), L.stream_ptr()), "alignq_act_quant_fwd")
+    return xq, bins
+
+
+# ------------------------------------------------------------------------------------------------ R3
+def weight_stats(w):
+    w = L.dev_f32(w, "weight")
+    lib = L.load()
+    ms = torch.empty(2, dtype=torch.float32, device=w.device)
+    ws = _ws(lib.alignq_weight_ws_bytes(w.numel()), w.device)
+    L.check(lib.alignq_weight_stats(L.ptr(w), w.numel(), L.ptr(ms), L.ptr(ws), L.stream_ptr()), "alignq_weight_stats")
+    return ms
+
+
+def weight_quant_given_stats(w, ms, k, formula, want_aux=True, want_bins=False):
+    w = L.dev_f32(w, "weight")
+    q = torch.empty_like(w)
+    c = torch.empty_like(w) if want_aux else None
+    pdf = torch.empty_like(w) if want_aux else None
+    bins = torch.empty(w.shape, dtype=torch.int32, device=w.device) if want_bins else None
+    L.check(L.load().alignq_weight_quant_fwd(L.ptr(w), L.ptr(ms), L.ptr(q), L.ptr(c), L.ptr(pdf), L.ptr(bins),
+                                             w.numel(), int(k), int(formula), L.stream_ptr()),
+            "alignq_weight_quant_fwd")
+    return q, c, pdf, bins
+
+
+class WeightQuantFn(torch.autograd.Function):
+    """weight_quantize_fn.forward (ADMM tree :71-85; CDF tree :62-78) with the backward through
+    mean(W) and std(W).  Returns (W_q, weight_cdf, weight_pdf); only W_q is differentiable."""
+
+    @staticmethod
+    def forward(ctx, w, k, formula):
+        w = L.dev_f32(w, "weight")
+        ms = weight_stats(w)
+        q, c, pdf, _ = weight_quant_given_stats(w, ms, k, formula, True)
+        ctx.save_for_backward(w, ms)
+        ctx.mark_non_differentiable(c, pdf)
+        return q, c, pdf
+
+    @staticmethod
+    def backward(ctx, g, _gc, _gp):
+        w, ms = ctx.saved_tensors
+        g = L.dev_f32(g, "grad")
+        lib = L.load()
+        dw = torch.empty_like(w)
+        ws = _ws(lib.alignq_weight_ws_bytes(w.numel()), w.device)
+        L.check(lib.alignq_weight_quant_bwd(L.ptr(g), L.ptr(w), L.ptr(ms), L.ptr(dw), w.numel(), L.ptr(ws),
+                                            L.stream_ptr()), "alignq_weight_quant_bwd")
+        return dw, None, None
+
+
+# ------------------------------------------------------------------------------------------------ R5
+def _as_bf(x):
+    B = x.shape[0]
+    return B, x.numel() // B
+
+
+class CorrFn(torch.autograd.Function):
+    """corr(x, x) — ADMM tree model/quantization.py:134-137; Office tree :158-161 (eps=1e-5)."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        x = L.dev_f32(x, "corr input")
+        B, F = _as_bf(x)
+        lib = L.load()
+        G = torch.empty(B, B, dtype=torch.float32, device=x.device)
+        stats = torch.empty(2, F, dtype=torch.float32, device=x.device)
+        ws = _ws(lib.alignq_site_ws_bytes(B, F), x.device)
+        L.check(lib.alignq_corr_fwd(L.ptr(x), B, F, float(eps), L.ptr(G), L.ptr(stats), L.ptr(ws), L.stream_ptr()),
+                "alignq_corr_fwd")
+        ctx.save_for_backward(x, stats)
+        ctx.eps = float(eps)
+        return G
+
+    @staticmethod
+    def backward(ctx, dG):
+        x, stats = ctx.saved_tensors
+        B, F = _as_bf(x)
+        dG = L.dev_f32(dG, "grad")
+        dx = torch.empty_like(x)
+        L.check(L.load().alignq_corr_bwd(L.ptr(dG), L.ptr(x), L.ptr(stats), B, F, ctx.eps, L.ptr(dx),
+                                         L.stream_ptr()), "alignq_corr_bwd")
+        return dx, None
+
+
+# ------------------------------------------------------------------------------------------------ R6
+class AdmmLossFn(torch.autograd.Function):
+    """ADMM.forward — utils/admm.py:24-33; gradients for D, alterD, gamma come from the same launch."""
+
+    @staticmethod
+    def forward(ctx, D, alterD, gamma, mu, rho):
+        D = L.dev_f32(D, "D")
+        A = L.dev_f32(alterD, "alterD")
+        Gm = L.dev_f32(gamma, "gamma")
+        b, dim = D.shape[0], A.shape[0]
+        loss = torch.empty((), dtype=torch.float32, device=D.device)
+        dD, dA, dG = torch.empty_like(D), torch.empty_like(A), torch.empty_like(Gm)
+        L.check(L.load().alignq_admm_loss(L.ptr(D), b, L.ptr(A), L.ptr(Gm), dim, float(mu), float(rho), L.ptr(loss),
+                                          L.ptr(dD), L.ptr(dA), L.ptr(dG), None, L.stream_ptr()), "alignq_admm_loss")
+        ctx.save_for_backward(dD, dA, dG)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        dD, dA, dG = ctx.saved_tensors
+        return dD * g, dA * g, dG * g, None, None
+
+
+# ------------------------------------------------------------------------------------------------ R4+R5+R6 fused
+class SiteFn(torch.autograd.Function):
+    """One ADMM activation site: x -> (x_q, trans_loss, D).
+
+    activation_quantize_fn.forward, ADMM tree model/quantization.py:102-132 (Office :126-156):
+    x_q = quantise(t), D = corr(t,t) - corr(x,x), trans_loss = ADMM(D).  Three launches forward
+    (fused quantise+Gram partials, slab reduction, ADMM loss+grads), one launch backward.
+    D is returned for ADMM_OPT.step (values only)."""
+
+    @staticmethod
+    def forward(ctx, x, alterD, gamma, k, act_range, eps, mu, rho):
+        x = L.dev_f32(x, "activation")
+        A = L.dev_f32(alterD, "alterD")
+        Gm = L.dev_f32(gamma, "gamma")
+        B, F = _as_bf(x)
+        dim = A.shape[0]
+        if B > dim:
+            raise RuntimeError(f"batch {B} larger than ADMM dim {dim}")
+        lib = L.load()
+        dev = x.device
+        xq = torch.empty_like(x)
+        D = torch.empty(B, B, dtype=torch.float32, device=dev)
+        stats = torch.empty(4, F, dtype=torch.float32, device=dev)
+        ws = _ws(lib.alignq_site_ws_bytes(B, F), dev)
+        st = L.stream_ptr()
+        L.check(lib.alignq_site_fwd(L.ptr(x), B, F, int(k), float(act_range), float(eps), L.ptr(xq), L.ptr(D),
+                                    L.ptr(stats), L.ptr(ws), st), "alignq_site_fwd")
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        dD, dA, dG = torch.empty_like(D), torch.empty_like(A), torch.empty_like(Gm)
+        L.check(lib.alignq_admm_loss(L.ptr(D), B, L.ptr(A), L.ptr(Gm), dim, float(mu), float(rho), L.ptr(loss),
+                                     L.ptr(dD), L.ptr(dA), L.ptr(dG), None, st), "alignq_admm_loss")
+        ctx.save_for_backward(x, stats, dD, dA, dG)
+        ctx.cfg = (float(act_range), float(eps))
+        ctx.mark_non_differentiable(D)
+        return xq, loss, D
+
+    @staticmethod
+    def backward(ctx, g_xq, g_loss, _gD):
+        x, stats, dD, dA, dG = ctx.saved_tensors
+        act_range, eps = ctx.cfg
+        B, F = _as_bf(x)
+        g_xq = None if g_xq is None else L.dev_f32(g_xq, "grad")
+        if g_loss is None:
+            g_loss = torch.zeros((), dtype=torch.float32, device=x.device)
+        g_loss = L.dev_f32(g_loss, "loss grad")
+        dx = torch.empty_like(x)
+        L.check(L.load().alignq_site_bwd(L.ptr(g_xq), L.ptr(dD), L.ptr(g_loss), L.ptr(x), L.ptr(stats), B, F,
+                                         act_range, eps, L.ptr(dx), L.stream_ptr()), "alignq_site_bwd")
+        return dx, dA * g_loss, dG * g_loss, None, None, None, None, None

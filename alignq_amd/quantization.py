@@ -1,0 +1,171 @@
+"""Host-side mirror of the reference's model/quantization.py for the three source trees.
+
+`make_namespace(tree)` builds the module-level names the reference exports
+(`uniform_quantize`, `cdf`, `weight_quantize_fn`, `activation_quantize_fn[2]`, `corr`, `conv2d_Q_fn`)
+with the signatures and return arities of that tree:
+
+  tree="admm"   cdf_alignment_admm/resnet-{20,56}-cifar-10/model/quantization.py:19-156
+  tree="cdf"    cdf_alignment/*/model/quantization.py:15-122
+  tree="office" cdf_alignment_admm/{dann,dsan}_office/model/quantization.py:20-181
+
+Importable drop-ins: alignq_amd.cdf_alignment_admm, alignq_amd.cdf_alignment, alignq_amd.office.
+All arithmetic runs in hand-written HIP kernels (alignq_amd/csrc) through ops.py; there is no eager
+fallback.  Options the reference reads from its global `args` come from alignq_amd.config.args.
+"""
+from __future__ import annotations
+
+import types
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib as L
+from . import config, ops
+
+_FORMULA = {"admm": L.FORMULA_ADMM, "office": L.FORMULA_ADMM, "cdf": L.FORMULA_CDF}
+_EPS = {"admm": 0.0, "office": 1e-5, "cdf": 0.0}
+
+
+def uniform_quantize(k):
+    """model/quantization.py:19-38 — returns a callable Tensor -> Tensor (round forward, STE backward)."""
+    def apply(x):
+        return ops.UniformQuantizeFn.apply(x, k)
+    return apply
+
+
+def make_namespace(tree: str) -> types.SimpleNamespace:
+    formula, eps = _FORMULA[tree], _EPS[tree]
+
+    class cdf(nn.Module):
+        """cdf(m, s, quant_src).forward(tensor) -> (cdf, pdf)  (ADMM tree :41-59; CDF tree :37-50).
+        Standalone use: values come from the HIP weight kernel with the given (m, s); the gradient is
+        propagated to `tensor` only through the first output (m, s are treated as constants)."""
+
+        def __init__(self, m, s, quant_src):
+            super().__init__()
+            self.m, self.s, self.quant_src = m, s, quant_src
+
+        def forward(self, tensor):
+            x = L.dev_f32(tensor, "tensor")
+            ms = torch.stack([torch.as_tensor(self.m, dtype=torch.float32, device=x.device).reshape(()),
+                              torch.as_tensor(self.s, dtype=torch.float32, device=x.device).reshape(())])
+            _, c, pdf, _ = ops.weight_quant_given_stats(x.detach(), ms, 32, formula, True)
+            if tree != "cdf" and self.quant_src == "a":
+                c = c * config.args.act_range
+            if tensor.requires_grad:
+                scale = (config.args.act_range if self.quant_src == "a" else 1.0) if tree != "cdf" else 0.5
+                c = _AttachGrad.apply(tensor, c, pdf * scale)
+            return c, pdf
+
+    class weight_quantize_fn(nn.Module):
+        def __init__(self, w_bit, stage):
+            super().__init__()
+            self.w_bit = w_bit
+            self.stage = stage
+            self.uniform_q = uniform_quantize(k=w_bit)
+
+        def forward(self, x):
+            if self.w_bit == 32:
+                if tree != "cdf":
+                    self.weight_cdf = x
+                    self.weight_q = x
+                return x
+            q, c, pdf = ops.WeightQuantFn.apply(x, self.w_bit, formula)
+            if tree != "cdf":   # the CDF tree keeps these as locals (quantization.py:70-72)
+                self.weight_cdf, self.weight_pdf, self.weight_q = c, pdf, q
+            else:
+                self._weight_cdf, self._weight_pdf = c, pdf
+            return q
+
+    def _plain_act(x, a_bit, stage):
+        if a_bit == 32 and stage != "align":
+            return x
+        if a_bit == 32 and tree == "cdf":
+            # returns the raw cdf (quantization.py:100-101)
+            xx = L.dev_f32(x, "activation")
+            ms = torch.tensor([0.0, 1.0], dtype=torch.float32, device=xx.device)
+            _, c, pdf, _ = ops.weight_quant_given_stats(xx.detach(), ms, 32, L.FORMULA_CDF, True)
+            return _AttachGrad.apply(x, c, pdf * 0.5) if x.requires_grad else c
+        return ops.ActQuantFn.apply(x, a_bit, config.args.act_range, formula)
+
+    def _site_act(mod, x):
+        a_bit = mod.a_bit
+        if a_bit == 32 and mod.stage != "align":
+            return x, 0
+        if config.args.method == "ours" and a_bit < 32:
+            admm = mod.opt
+            xq, loss, D = ops.SiteFn.apply(x, admm.alterD, admm.gamma, a_bit, config.args.act_range, eps,
+                                           admm.mu, admm.rho)
+            admm.D = D
+            return xq, loss
+        return _plain_act(x, a_bit, mod.stage), 0
+
+    class _act_plain(nn.Module):
+        def __init__(self, a_bit, stage):
+            super().__init__()
+            self.a_bit, self.stage = a_bit, stage
+            self.uniform_q = uniform_quantize(k=a_bit)
+
+        def forward(self, x):
+            return _plain_act(x, self.a_bit, self.stage)
+
+    class _act_admm(nn.Module):
+        def __init__(self, a_bit, stage, admm):
+            super().__init__()
+            self.a_bit, self.stage = a_bit, stage
+            self.uniform_q = uniform_quantize(k=a_bit)
+            self.opt = admm
+
+        def forward(self, x):
+            return _site_act(self, x)
+
+    def corr(x, y):
+        """corr(x, y) -> [B,B]; the reference only ever calls it with y is x (SYRK)."""
+        if y is not x and not (y.data_ptr() == x.data_ptr() and y.shape == x.shape):
+            raise NotImplementedError("alignq_amd.corr implements the reference's only use: corr(x, x)")
+        return ops.CorrFn.apply(x, eps)
+
+    def conv2d_Q_fn(w_bit, stage):
+        class Conv2d_Q(nn.Conv2d):
+            def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                         bias=True):
+                super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias)
+                self.quantize_fn = weight_quantize_fn(w_bit=w_bit, stage=stage)
+
+            def forward(self, input, order=None):
+                weight_q = self.quantize_fn(self.weight)
+                return F.conv2d(input, weight_q, self.bias, self.stride, self.padding, self.dilation, self.groups)
+
+        return Conv2d_Q
+
+    ns = types.SimpleNamespace(uniform_quantize=uniform_quantize, cdf=cdf, weight_quantize_fn=weight_quantize_fn,
+                               conv2d_Q_fn=conv2d_Q_fn)
+    if tree == "cdf":
+        _act_plain.__name__ = _act_plain.__qualname__ = "activation_quantize_fn"
+        ns.activation_quantize_fn = _act_plain
+    elif tree == "admm":
+        _act_admm.__name__ = _act_admm.__qualname__ = "activation_quantize_fn"
+        ns.activation_quantize_fn = _act_admm
+        ns.corr = corr
+    else:
+        _act_plain.__name__ = _act_plain.__qualname__ = "activation_quantize_fn"
+        _act_admm.__name__ = _act_admm.__qualname__ = "activation_quantize_fn2"
+        ns.activation_quantize_fn = _act_plain
+        ns.activation_quantize_fn2 = _act_admm
+        ns.corr = corr
+    return ns
+
+
+class _AttachGrad(torch.autograd.Function):
+    """y = value (precomputed by a kernel) with dy/dx = jac elementwise."""
+
+    @staticmethod
+    def forward(ctx, x, value, jac):
+        ctx.save_for_backward(jac)
+        return value.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (jac,) = ctx.saved_tensors
+        return g * jac, None, None

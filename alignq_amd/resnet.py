@@ -1,0 +1,128 @@
+"""Harness models: the callers of the hot path for the CIFAR configs (BASELINE.json configs 1-4).
+
+Pre-activation ResNet-20/56 wired like the reference's model/resnet.py (ADMM tree :36-167, CDF tree
+:33-137) with the SAME attribute / parameter names (`conv0`, `admm0`, `act_q0`, `layers[i].{admm0,admm1,
+admm_skip,act_q0,act_q1,act_skip_q,bn0,conv0,bn1,conv1,skip_conv,skip_bn}`, `bn`, `logit`), so the
+reference drivers' gathers (main.py:313-369) and checkpoints (state_dict keys) work unchanged.  Conv/BN/
+linear go to MIOpen/rocBLAS through PyTorch-ROCm (not part of the hot path); every weight and activation
+quantiser, correlation and ADMM op goes through alignq_amd's HIP kernels.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import cdf_alignment as _cdf
+from . import cdf_alignment_admm as _admm
+from . import config
+from .admm import ADMM
+
+
+class PreActBlock_conv_Q(nn.Module):
+    """Pre-activation basic block; `tree` selects the ADMM (tuple-returning) or CDF-only activation fn."""
+
+    def __init__(self, stage, wbit, abit, in_planes, out_planes, stride=1, tree="admm"):
+        super().__init__()
+        self.tree = tree
+        ns = _admm if tree == "admm" else _cdf
+        Conv2d = ns.conv2d_Q_fn(w_bit=wbit, stage=stage)
+        if tree == "admm":
+            dim = config.args.train_batch_size if self.training else config.args.eval_batch_size
+            self.admm0 = ADMM(dim)
+            self.admm1 = ADMM(dim)
+            self.act_q0 = ns.activation_quantize_fn(a_bit=abit, stage=stage, admm=self.admm0)
+            self.act_q1 = ns.activation_quantize_fn(a_bit=abit, stage=stage, admm=self.admm1)
+        else:
+            self.act_q0 = ns.activation_quantize_fn(a_bit=abit, stage=stage)
+            self.act_q1 = ns.activation_quantize_fn(a_bit=abit, stage=stage)
+        self.bn0 = nn.BatchNorm2d(out_planes)
+        self.conv0 = Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(out_planes)
+        self.conv1 = Conv2d(out_planes, out_planes, kernel_size=3, stride=1, padding=1, bias=False)
+        self.skip_conv = None
+        if stride != 1:
+            if tree == "admm":
+                self.admm_skip = ADMM(dim)
+                self.act_skip_q = ns.activation_quantize_fn(a_bit=abit, stage=stage, admm=self.admm_skip)
+            else:
+                self.act_skip_q = ns.activation_quantize_fn(a_bit=abit, stage=stage)
+            self.skip_conv = Conv2d(in_planes, out_planes, kernel_size=1, stride=stride, padding=0, bias=False)
+            self.skip_bn = nn.BatchNorm2d(out_planes)
+
+    def _q(self, fn, x):
+        if self.tree == "admm":
+            return fn(x)
+        return fn(x), 0
+
+    def forward(self, x):
+        trans_loss = 0.
+        if self.skip_conv is not None:
+            shortcut, loss = self._q(self.act_skip_q, self.skip_bn(self.skip_conv(x)))
+            trans_loss += loss
+        else:
+            shortcut = x
+        out, loss = self._q(self.act_q0, self.bn0(self.conv0(x)))
+        trans_loss += loss
+        out = F.relu(out)
+        out, loss = self._q(self.act_q1, self.bn1(self.conv1(out)))
+        trans_loss += loss
+        out += shortcut
+        out = F.relu(out)
+        if self.tree == "admm":
+            return out, trans_loss
+        return out
+
+
+class PreActResNet(nn.Module):
+    def __init__(self, block, num_units, wbit, abit, stage, num_classes, tree="admm"):
+        super().__init__()
+        self.tree = tree
+        ns = _admm if tree == "admm" else _cdf
+        Conv2d = ns.conv2d_Q_fn(w_bit=wbit, stage=stage)
+        self.conv0 = Conv2d(3, 16, kernel_size=3, stride=1, padding=1, bias=False)
+        if tree == "admm":
+            dim = config.args.train_batch_size if self.training else config.args.eval_batch_size
+            self.admm0 = ADMM(dim)
+            self.act_q0 = ns.activation_quantize_fn(a_bit=abit, stage=stage, admm=self.admm0)
+        else:
+            self.act_q0 = ns.activation_quantize_fn(a_bit=abit, stage=stage)
+        self.layers = nn.ModuleList()
+        in_planes = 16
+        strides = [1] * num_units[0] + [2] + [1] * (num_units[1] - 1) + [2] + [1] * (num_units[2] - 1)
+        channels = [16] * num_units[0] + [32] * num_units[1] + [64] * num_units[2]
+        for stride, channel in zip(strides, channels):
+            self.layers.append(block(stage, wbit, abit, in_planes, channel, stride, tree=tree))
+            in_planes = channel
+        self.bn = nn.BatchNorm2d(16)
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.logit = nn.Linear(64, num_classes)
+
+    def forward(self, x):
+        out = self.bn(self.conv0(x))
+        if self.tree == "admm":
+            out, loss = self.act_q0(out)
+            trans_loss = 0. + loss
+        else:
+            out = self.act_q0(out)
+        out = F.relu(out)
+        for layer in self.layers:
+            if self.tree == "admm":
+                out, loss = layer(out)
+                trans_loss += loss
+            else:
+                out = layer(out)
+        out = self.avgpool(out)
+        out = out.view(out.size(0), -1)
+        out = self.logit(out)
+        if self.tree == "admm":
+            return out, trans_loss
+        return out
+
+
+def resnet20_quant(bitW, abitW, stage="second", num_classes=10, tree="admm"):
+    return PreActResNet(PreActBlock_conv_Q, [3, 3, 3], bitW, abitW, stage, num_classes, tree=tree)
+
+
+def resnet56_quant(bitW, abitW, stage="second", num_classes=10, tree="admm"):
+    return PreActResNet(PreActBlock_conv_Q, [9, 9, 9], bitW, abitW, stage, num_classes, tree=tree)

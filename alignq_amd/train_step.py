@@ -1,0 +1,97 @@
+"""One training iteration in the reference's order (cdf_alignment_admm/resnet-20-cifar-10/main.py:288-374):
+zero_grad x2 -> forward -> CE + trans_loss -> backward -> SGD.step(idx, w_cdf, w_pdf, lam, lam2) ->
+ADMM_OPT.step(alterD_idx, gamma_idx, Ds, alterDs, gammas, mus, rhos).
+
+The list gathering of main.py:313-369 is done once (indices) / per step (tensors) without host syncs;
+`capture()` records the whole iteration into one HIP graph (static input buffers), which removes the
+per-launch host overhead that dominates the small CIFAR shapes."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import config
+from .optimizer import ADMM_OPT, SGD
+
+
+class TrainStep:
+    def __init__(self, model, lr=0.04, momentum=0.9, weight_decay=1e-4, grad_hook=None):
+        self.model = model
+        named = list(model.named_parameters())
+        self.param_t = [(n, p) for n, p in named if "alterD" not in n and "gamma" not in n]
+        self.param_admm = [(n, p) for n, p in named if "alterD" in n or "gamma" in n]
+        self.optimizer_t = SGD([p for _, p in self.param_t], lr=lr, momentum=momentum, weight_decay=weight_decay)
+        self.optimizer_admm = ADMM_OPT([p for _, p in self.param_admm]) if self.param_admm else None
+        # main.py:313-317: conv weights except the stem
+        self.idx = [j for j, (n, _) in enumerate(self.param_t) if "conv" in n and "weight" in n][1:]
+        self.alterD_idx = [j for j, (n, _) in enumerate(self.param_admm) if "alterD" in n]
+        self.gamma_idx = [j for j, (n, _) in enumerate(self.param_admm) if "gamma" in n]
+        self.convs = [c for layer in model.layers for c in (layer.conv0, layer.conv1, layer.skip_conv) if c is not None]
+        self.admms = []
+        if self.param_admm:
+            self.admms = [model.admm0]
+            for layer in model.layers:
+                self.admms += [layer.admm0, layer.admm1]
+                if layer.skip_conv is not None:
+                    self.admms.append(layer.admm_skip)
+        self.grad_hook = grad_hook          # e.g. the data-parallel all-reduce (alignq_amd.dp)
+        self._graph: Optional[torch.cuda.CUDAGraph] = None
+        self._static = None
+
+    # -------------------------------------------------------------------------------------------
+    def _iteration(self, x, y, set_to_none=True):
+        model = self.model
+        self.optimizer_t.zero_grad(set_to_none=set_to_none)
+        if self.optimizer_admm is not None:
+            self.optimizer_admm.zero_grad(set_to_none=set_to_none)
+        out = model(x)
+        if isinstance(out, tuple):
+            logits, trans_loss = out
+        else:
+            logits, trans_loss = out, None
+        ce = F.cross_entropy(logits, y)
+        total = ce if trans_loss is None else ce + trans_loss
+        total.backward()
+        if self.grad_hook is not None:
+            self.grad_hook(self)
+        if config.args.bitW < 32 and self.admms:
+            w_cdf = [c.quantize_fn.weight_cdf for c in self.convs]
+            w_pdf = [c.quantize_fn.weight_pdf for c in self.convs]
+            self.optimizer_t.step(self.idx, w_cdf, w_pdf, config.args.lam, config.args.lam2)
+            a = self.admms
+            self.optimizer_admm.step(self.alterD_idx, self.gamma_idx, [m.D for m in a], [m.alterD for m in a],
+                                     [m.gamma for m in a], [m.mu for m in a], [m.rho for m in a])
+        else:
+            # CDF-only tree (main.py:308 crashes as shipped): plain momentum SGD, no grad rewrite
+            self.optimizer_t.step([], [], [], config.args.lam, config.args.lam2)
+        return logits, ce, trans_loss
+
+    def __call__(self, x, y):
+        if self._graph is None:
+            return self._iteration(x, y)
+        sx, sy = self._static[0], self._static[1]
+        sx.copy_(x, non_blocking=True)
+        sy.copy_(y, non_blocking=True)
+        self._graph.replay()
+        return self._static[2]
+
+    # -------------------------------------------------------------------------------------------
+    def capture(self, x, y, warmup=3):
+        """Capture the full iteration into a HIP graph.  Runs `warmup` eager iterations first (they DO
+        update the model, as real steps) so allocator pools, momentum buffers and MIOpen plans exist."""
+        sx, sy = x.clone(), y.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._iteration(sx, sy, set_to_none=False)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            outs = self._iteration(sx, sy, set_to_none=False)
+        self._graph = graph
+        self._static = (sx, sy, outs)
+        return self

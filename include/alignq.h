@@ -1,0 +1,126 @@
+/* alignq.h — C ABI of libalignq_hip.so: AlignQ's quantize / correlation / ADMM hot path on MI355X (gfx950).
+ *
+ * The reference has no FFI for this path: it is pure Python on PyTorch and its
+ * boundary is a Python module API (model/quantization.py, utils/admm.py, utils/optimizer.py).  The
+ * package alignq_amd/ mirrors that API; underneath, its autograd Functions call THIS library through
+ * ctypes (INTEGRATION.md shows the binding).  Each entry point cites the reference lines it replaces;
+ * paths are relative to the reference root, "ADMM tree" = cdf_alignment_admm/resnet-56-cifar-10,
+ * "CDF tree" = cdf_alignment/resnet-20-cifar-10, "Office tree" = cdf_alignment_admm/dann_office.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no C++/torch types, no exceptions across the boundary;
+ *   - every function returns int: 0 = ok, >0 = hipError_t of the launch, <0 = ALIGNQ_E* argument error;
+ *   - the CALLER owns every buffer (inputs, outputs, workspaces); all pointers are DEVICE pointers to
+ *     contiguous fp32 unless stated; `*_ws_bytes` functions size the scratch buffers;
+ *   - functions only ENQUEUE work on `stream` (a hipStream_t, may be NULL = default stream): no
+ *     allocation, no synchronisation, no global mutable state => re-entrant, callable from the autograd
+ *     thread, capturable into a hipGraph;
+ *   - `formula`: ALIGNQ_FORMULA_ADMM (ADMM/Office trees: transform to [-1,1]*(r) first, then round with
+ *     n=2^k-1) or ALIGNQ_FORMULA_CDF (CDF tree: round the cdf in [0,1], then map) — SURVEY.md §0-F5;
+ *   - erf/exp are the repo's ALIGNQ-ERF32/EXP32: bit-identical to oracle/alignq_oracle.c.
+ */
+#ifndef ALIGNQ_H
+#define ALIGNQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALIGNQ_ABI_VERSION 1
+
+#define ALIGNQ_FORMULA_ADMM 0
+#define ALIGNQ_FORMULA_CDF 1
+
+#define ALIGNQ_EINVAL (-1)       /* bad argument (null pointer, k out of range, n <= 0 ...) */
+#define ALIGNQ_EUNSUPPORTED (-2) /* shape outside what the kernels handle (e.g. batch > ALIGNQ_MAX_BATCH) */
+
+#define ALIGNQ_MAX_BATCH 128 /* rows of a correlation site the fused kernels hold on chip */
+
+int alignq_abi_version(void);
+/* message for a return code of this library (static string) */
+const char* alignq_strerror(int code);
+
+/* ---- R1: uniform_quantize(k).forward alone (model/quantization.py:19-31, identical in all trees):
+ * y = round_half_even(x*n)/n with n = 2^k-1; k==1 -> sign(x); k==32 -> x.  Backward is the identity
+ * (straight-through, :34-36) and needs no kernel.                                                    */
+int alignq_uniform_quantize(const float* x, float* y, int64_t n, int k, void* stream);
+
+/* ---- R1/R2/R4: activation CDF transform + uniform quantize/dequantize --------------------------
+ * forward: ADMM tree model/quantization.py:109-110 (+cdf :49-56, qfn :23-31); CDF tree :97-98;
+ *          Office tree :103-104.  x,xq: [n].  k in {1..16, 32}; k==32 writes the transform itself.
+ * bins (optional, may be NULL): int32 bin index round(t*n) per element (parity instrumentation).   */
+int alignq_act_quant_fwd(const float* x, float* xq, int32_t* bins, int64_t n, int k, float act_range,
+                         int formula, void* stream);
+/* backward (STE of :34-36 chained through the transform): dx = g * act_range * 2*phi(x).            */
+int alignq_act_quant_bwd(const float* g, const float* x, float* dx, int64_t n, float act_range,
+                         void* stream);
+
+/* ---- R3: weight quantisation -------------------------------------------------------------------
+ * stats: torch.mean / torch.std (unbiased) over all n elements (model/quantization.py:78).
+ *        ms: device float[2] = {mean, std}.  ws: alignq_weight_ws_bytes(n) bytes of scratch.        */
+size_t alignq_weight_ws_bytes(int64_t n);
+int alignq_weight_stats(const float* w, int64_t n, float* ms, void* ws, void* stream);
+/* forward given ms: q = quantised weight; cdf_out / pdf_out (optional) = the module's weight_cdf /
+ * weight_pdf attributes (ADMM tree :78-80; CDF tree :70-72); bins optional as above.               */
+int alignq_weight_quant_fwd(const float* w, const float* ms, float* q, float* cdf_out, float* pdf_out,
+                            int32_t* bins, int64_t n, int k, int formula, void* stream);
+/* backward THROUGH mean and std (they are in the autograd graph):
+ * dw_i = g_i P_i - mean(g P) - z_i/(n-1) * sum(g P z).  ws as above.                               */
+int alignq_weight_quant_bwd(const float* g, const float* w, const float* ms, float* dw, int64_t n,
+                            void* ws, void* stream);
+
+/* ---- R4+R5: fused ADMM site: quantise + both sample-correlation matrices -----------------------
+ * x: [B,F] (the [B,C,H,W] activation viewed as [B,-1]); B <= ALIGNQ_MAX_BATCH.
+ * Computes xq (as alignq_act_quant_fwd, ADMM formula) and
+ *   D = corr(t,t) - corr(x,x),  t = act_range*(2*Phi(x)-1)  (pre-round),
+ *   corr(v,v) = Vh Vh^T / F, Vh = (v - mean_b v)/(std_b v + eps)     (model/quantization.py:115-122,
+ *   corr :134-137; Office tree corr :158-161 uses eps = 1e-5).
+ * stats: [4][F] out (mean_x, 1/(std_x+eps), mean_t, 1/(std_t+eps)) consumed by alignq_site_bwd.
+ * xq may be NULL (correlation only).  ws: alignq_site_ws_bytes(B,F) bytes.                         */
+size_t alignq_site_ws_bytes(int B, int64_t F);
+int alignq_site_fwd(const float* x, int B, int64_t F, int k, float act_range, float eps, float* xq,
+                    float* D, float* stats, void* ws, void* stream);
+/* dx = g*dt/dx + d(corr pair)/dx for upstream dD [B,B] (gradient w.r.t. D).  g may be NULL.
+ * dD_scale: optional DEVICE scalar multiplying dD (the upstream gradient of the scalar loss).       */
+int alignq_site_bwd(const float* g, const float* dD, const float* dD_scale, const float* x,
+                    const float* stats, int B, int64_t F, float act_range, float eps, float* dx,
+                    void* stream);
+/* corr(x,x) alone (module-level `corr`, model/quantization.py:134-137): G [B,B]; stats [2][F].      */
+int alignq_corr_fwd(const float* x, int B, int64_t F, float eps, float* G, float* stats, void* ws,
+                    void* stream);
+int alignq_corr_bwd(const float* dG, const float* x, const float* stats, int B, int64_t F, float eps,
+                    float* dx, void* stream);
+
+/* ---- R6: ADMM loss (utils/admm.py:24-33) --------------------------------------------------------
+ * D: [b,b]; alterD, gamma: [dim,dim] with b <= dim (sliced [:b,:b]).  Writes loss (device scalar) and
+ * the gradients dD [b,b], dalterD, dgamma [dim,dim] (zero outside the slice); any grad may be NULL.
+ * ws: alignq_admm_ws_bytes(dim).                                                                    */
+size_t alignq_admm_ws_bytes(int dim);
+int alignq_admm_loss(const float* D, int b, const float* alterD, const float* gamma, int dim, float mu,
+                     float rho, float* loss, float* dD, float* dalterD, float* dgamma, void* ws,
+                     void* stream);
+
+/* ---- R7: ADMM primal/dual update (utils/optimizer.py:97-124), batched over S sites ---------------
+ * D_tab, alterD_tab, gamma_tab: DEVICE arrays of S device pointers; D_s is [b,b] (zero-padded to dim
+ * as :104-105 does), alterD_s/gamma_s [dim,dim] updated in place:
+ *   V = pad(D)+gamma/rho; A = (1-(mu/rho)/|V|_F) V if |V|_F > mu/rho else 0; gamma += rho (pad(D)-A). */
+int alignq_admm_update(const float* const* D_tab, float* const* alterD_tab, float* const* gamma_tab,
+                       int S, int b, int dim, float mu, float rho, void* stream);
+
+/* ---- R8: SGD step (utils/optimizer.py:212-229,251,255) and the grad rewrite (:6-13,233-249) ------
+ * d = g + wd*p; buf = first ? d : mom*buf + (1-damp)*d; dir = nesterov ? d + mom*buf : buf;
+ * p -= lr*dir; g <- dir (what the reference leaves in p.grad for tensors outside idx).
+ * buf may be NULL when mom == 0.                                                                    */
+int alignq_sgd_step(float* p, float* g, float* buf, int64_t n, float lr, float mom, float damp, float wd,
+                    int nesterov, int first, void* stream);
+/* grad_out = dir * sigmoid_d(transform(w_cdf)) * w_pdf for tensors in idx.                          */
+int alignq_sgd_grad_approx(const float* dir, const float* w_cdf, const float* w_pdf, float* grad_out,
+                           int64_t n, int bitW, float lam, float lam2, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALIGNQ_H */

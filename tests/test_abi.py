@@ -1,0 +1,88 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads and exports every symbol that
+include/alignq.h declares (no compute calls: there is no GPU here), the ctypes table mirrors the header,
+and the Python mirror exposes the reference's names and signatures."""
+import inspect
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "alignq.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(alignq_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from alignq_amd import _lib
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(_lib.SIGNATURES) == names
+    assert lib.alignq_abi_version() == 1
+    assert b"invalid" in lib.alignq_strerror(-1)
+    # pure host-side queries are safe without a GPU
+    assert lib.alignq_site_ws_bytes(128, 16384) == 256 * 128 * 128 * 4
+    assert lib.alignq_site_ws_bytes(28, 802816) == 512 * 32 * 32 * 4
+    assert lib.alignq_site_ws_bytes(129, 64) == 0
+
+
+def test_argument_validation_without_gpu():
+    from alignq_amd import _lib
+    lib = _lib.load()
+    assert lib.alignq_act_quant_fwd(None, None, None, 16, 8, 2.0, 0, None) == -1
+    assert lib.alignq_site_fwd(None, 128, 64, 8, 2.0, 0.0, None, None, None, None, None) == -1
+    assert lib.alignq_admm_update(None, None, None, 1, 8, 8, 0.2, 0.3, None) == -1
+
+
+def test_python_mirror_names_and_signatures():
+    import alignq_amd.cdf_alignment as C
+    import alignq_amd.cdf_alignment_admm as A
+    import alignq_amd.office as Off
+    for ns in (C, A, Off):
+        for name in ("uniform_quantize", "cdf", "weight_quantize_fn", "activation_quantize_fn", "conv2d_Q_fn", "ADMM",
+                     "ADMM_OPT", "SGD"):
+            assert hasattr(ns, name), (ns.__name__, name)
+    assert hasattr(A, "corr") and hasattr(Off, "corr") and hasattr(Off, "activation_quantize_fn2")
+    assert list(inspect.signature(A.activation_quantize_fn.__init__).parameters)[1:] == ["a_bit", "stage", "admm"]
+    assert list(inspect.signature(C.activation_quantize_fn.__init__).parameters)[1:] == ["a_bit", "stage"]
+    assert list(inspect.signature(Off.activation_quantize_fn2.__init__).parameters)[1:] == ["a_bit", "stage", "admm"]
+    assert list(inspect.signature(A.SGD.step).parameters)[1:] == ["idx", "w_cdf", "w_pdf", "lam", "lam2", "closure"]
+    assert list(inspect.signature(A.ADMM_OPT.step).parameters)[1:] == [
+        "alterD_idx", "gamma_idx", "Ds", "alterDs", "gammas", "mus", "rhos", "closure"]
+    conv = A.conv2d_Q_fn(8, "second")(3, 16, 3, 1, 1, bias=False)
+    assert isinstance(conv, torch.nn.Conv2d) and conv.quantize_fn.w_bit == 8
+    m = A.ADMM(16)
+    assert sorted(n for n, _ in m.named_parameters()) == ["alterD", "gamma"] and (m.mu, m.rho) == (0.2, 0.3)
+
+
+def test_harness_model_keeps_reference_parameter_names():
+    from alignq_amd import config
+    from alignq_amd.resnet import resnet20_quant
+    from tests.conftest import load_golden
+    config.args.train_batch_size = 8
+    try:
+        from alignq_amd.resnet import PreActBlock_conv_Q, PreActResNet
+        net = PreActResNet(PreActBlock_conv_Q, [1, 1, 1], 4, 4, "second", 10)
+        g = load_golden("g8_tiny_resnet_admm")
+        ref_keys = sorted(k[5:] for k in g if k.startswith("init/"))
+        assert sorted(net.state_dict().keys()) == ref_keys
+        n20 = resnet20_quant(8, 8)
+        assert sum(1 for n, _ in n20.named_parameters() if "alterD" in n) == 21
+    finally:
+        config.args.train_batch_size = 128
+
+
+def test_no_cpu_fallback():
+    from alignq_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.ActQuantFn.apply(torch.randn(8), 4, 2.0, 0)
+    import alignq_amd.cdf_alignment_admm as A
+    with pytest.raises(RuntimeError):
+        A.weight_quantize_fn(8, "second")(torch.randn(4, 4))

@@ -1,0 +1,376 @@
+"""GPU parity tests (run on the MI355X box with -m gpu): the HIP kernels, called through the C ABI
+(alignq_amd._lib / ops), against
+  (1) the plain-C oracle on the same seeded inputs        -> bit-exact for bins and dequantised values
+      (same ALIGNQ-ERF32 spec), 1e-5 for reductions / Gram / gradients;
+  (2) the golden vectors captured from the reference       -> bins exact outside the erf tie zone
+      (|frac(t*n) - 1/2| < 1e-4), dequantised values and residuals within 1e-5;
+  (3) size-independent properties at BASELINE.json's full sizes.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests import oracle_c as O
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+TIE = 1e-4
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X box"
+    from alignq_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def cu(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def bits_equal(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+def check_bins_vs_ref(q_ours, q_ref, y_ref, n, scale=1.0):
+    frac = y_ref - np.floor(y_ref)
+    tie = np.abs(frac - 0.5) < TIE
+    diff = np.abs(q_ours - q_ref) * n / scale
+    assert np.all(diff[~tie] == 0)
+    assert np.all(diff[tie] <= 1.0 + 1e-3)
+
+
+# ------------------------------------------------------------------------------------------- R1/R4 plain
+@pytest.mark.parametrize("formula", [0, 1])
+@pytest.mark.parametrize("k", [1, 2, 4, 8, 32])
+def test_act_quant_bit_exact_vs_oracle(dev, formula, k):
+    from alignq_amd import ops
+    rng = np.random.default_rng(10 + k)
+    x = np.concatenate([rng.standard_normal(1 << 18) * 1.7, rng.uniform(-6, 6, 4099),
+                        np.array([0.0, -0.0, 0.875 * 1.4142135, 4.0 * 1.4142135, 30.0, -30.0, 1e-30])]).astype(np.float32)
+    xq, bins = ops.act_quant_bins(cu(x, dev), k, 2.0, formula)
+    oq, ot, ob = O.act_quant_fwd(x, k, 2.0, formula)
+    assert bits_equal(npy(xq), oq)
+    if k not in (32,):
+        assert np.array_equal(npy(bins), ob)
+
+
+def test_act_quant_ragged_and_tiny(dev):
+    from alignq_amd import ops
+    for n in (1, 2, 3, 5, 1023, 1025):
+        x = np.random.default_rng(n).standard_normal(n).astype(np.float32)
+        xq, bins = ops.act_quant_bins(cu(x, dev), 4, 2.0, 0)
+        oq, _, ob = O.act_quant_fwd(x, 4, 2.0, 0)
+        assert bits_equal(npy(xq), oq) and np.array_equal(npy(bins), ob)
+
+
+@pytest.mark.parametrize("tree,fname,formula", [("admm", "g3_act_quant_admm", 0), ("cdf", "g3_act_quant_cdfonly", 1)])
+def test_act_quant_vs_reference_golden(dev, tree, fname, formula):
+    from alignq_amd import ops
+    g = load_golden(fname)
+    r = float(g["act_range"])
+    pre = g["t"] if tree == "admm" else g["c"]
+    for k in (2, 4, 8):
+        n = 2 ** k - 1
+        x = cu(g["x"], dev).requires_grad_(True)
+        xq = ops.ActQuantFn.apply(x, k, r, formula)
+        xq.backward(cu(g["g"], dev))
+        check_bins_vs_ref(npy(xq), g[f"xq_k{k}"], pre * n, n, 1.0 if tree == "admm" else 2.0 * r)
+        np.testing.assert_allclose(npy(xq), g[f"xq_k{k}"], atol=(1.0 if tree == "admm" else 2.0 * r) / n + TOL)
+        np.testing.assert_allclose(npy(x.grad), g[f"dx_k{k}"], atol=TOL, rtol=1e-4)
+
+
+@pytest.mark.parametrize("k", [1, 2, 4, 8, 32])
+def test_uniform_quantize_golden(dev, k):
+    from alignq_amd.quantization import uniform_quantize
+    g = load_golden("g1_uniform_quantize")
+    x = cu(g["x"], dev).requires_grad_(True)
+    y = uniform_quantize(k)(x)
+    y.backward(cu(g[f"gy_k{k}"], dev))
+    assert bits_equal(npy(y), g[f"y_k{k}"])
+    assert bits_equal(npy(x.grad), g[f"gx_k{k}"])
+
+
+# ------------------------------------------------------------------------------------------- R3 weights
+@pytest.mark.parametrize("tree,fname,formula", [("admm", "g2_weight_quant_admm", 0), ("cdf", "g2_weight_quant_cdfonly", 1)])
+def test_weight_quant(dev, tree, fname, formula):
+    from alignq_amd import ops
+    g = load_golden(fname)
+    si = 0
+    while f"W_s{si}" in g:
+        W = g[f"W_s{si}"]
+        ms = npy(ops.weight_stats(cu(W, dev)))
+        np.testing.assert_allclose(ms[0], g[f"m_s{si}"], rtol=2e-6, atol=1e-9)
+        np.testing.assert_allclose(ms[1], g[f"s_s{si}"], rtol=2e-6)
+        ms_ref = np.array([g[f"m_s{si}"], g[f"s_s{si}"]], np.float32)
+        for k in (2, 4, 8):
+            n = 2 ** k - 1
+            # (a) given the reference's (m, s): bit-exact vs the C oracle, tie-zone rule vs the reference
+            q, c, pdf, bins = ops.weight_quant_given_stats(cu(W, dev), cu(ms_ref, dev), k, formula, True, True)
+            oq, oc, opdf, ob = O.weight_quant_fwd(W, ms_ref, k, formula)
+            assert bits_equal(npy(q), oq) and bits_equal(npy(c), oc) and np.array_equal(npy(bins), ob)
+            np.testing.assert_allclose(npy(pdf), opdf, rtol=1e-6, atol=1e-7)
+            check_bins_vs_ref(npy(q), g[f"Wq_s{si}_k{k}"], g[f"cdf_s{si}"] * n, n, 1.0 if tree == "admm" else 2.0)
+            np.testing.assert_allclose(npy(c), g[f"cdf_s{si}"], atol=3e-7)
+            np.testing.assert_allclose(npy(pdf), g[f"pdf_s{si}"], rtol=3e-6, atol=1e-6)
+            # (b) end to end through the autograd Function (own stats), incl. backward through mean/std
+            Wt = cu(W, dev).requires_grad_(True)
+            q2, c2, p2 = ops.WeightQuantFn.apply(Wt, k, formula)
+            q2.backward(cu(g[f"g_s{si}"], dev))
+            np.testing.assert_allclose(npy(c2), g[f"cdf_s{si}"], atol=1e-6)
+            np.testing.assert_allclose(npy(q2), g[f"Wq_s{si}_k{k}"], atol=(1.0 if tree == "admm" else 2.0) / n + TOL)
+            np.testing.assert_allclose(npy(Wt.grad), g[f"dW_s{si}_k{k}"], atol=2e-5, rtol=1e-4)
+        si += 1
+
+
+# ------------------------------------------------------------------------------------------- R5 corr
+@pytest.mark.parametrize("fname,eps", [("g4_corr_noeps", 0.0), ("g4_corr_eps", 1e-5)])
+def test_corr_vs_reference(dev, fname, eps):
+    from alignq_amd import ops
+    g = load_golden(fname)
+    ci = 0
+    while f"x_c{ci}" in g:
+        x = cu(g[f"x_c{ci}"], dev).requires_grad_(True)
+        G = ops.CorrFn.apply(x, eps)
+        G.backward(cu(g[f"dG_c{ci}"], dev))
+        np.testing.assert_allclose(npy(G), g[f"G_c{ci}"], atol=TOL, rtol=0)
+        ref = g[f"dx_c{ci}"]
+        np.testing.assert_allclose(npy(x.grad), ref, atol=TOL * max(1.0, np.abs(ref).max()), rtol=1e-4)
+        ci += 1
+
+
+@pytest.mark.parametrize("B,F", [(128, 4096), (128, 16384), (28, 1568), (64, 640), (10, 100), (33, 70), (2, 64)])
+def test_corr_vs_oracle_shapes(dev, B, F):
+    """ragged shapes: F not a multiple of the 64-feature tile or of 4, B not a multiple of 32."""
+    from alignq_amd import ops
+    rng = np.random.default_rng(B * 1000 + F)
+    x = (rng.standard_normal((B, F)) * 0.7 + 0.2).astype(np.float32)
+    dG = rng.standard_normal((B, B)).astype(np.float32)
+    xt = cu(x, dev).requires_grad_(True)
+    G = ops.CorrFn.apply(xt, 0.0)
+    G.backward(cu(dG, dev))
+    np.testing.assert_allclose(npy(G), O.corr_fwd(x, 0.0), atol=TOL, rtol=0)
+    ref = O.corr_bwd(dG, x, 0.0)
+    np.testing.assert_allclose(npy(xt.grad), ref, atol=TOL * max(1.0, np.abs(ref).max()), rtol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------- R4+R5+R6 site
+def _site(dev, x, g, A0, G0, k, r, eps, mu=0.2, rho=0.3):
+    from alignq_amd import ops
+    xt = cu(x, dev).requires_grad_(True)
+    A = cu(A0, dev).requires_grad_(True)
+    Gm = cu(G0, dev).requires_grad_(True)
+    xq, loss, D = ops.SiteFn.apply(xt, A, Gm, k, r, eps, mu, rho)
+    (loss + (xq * cu(g, dev)).sum()).backward()
+    return npy(xq), float(loss), npy(D), npy(xt.grad), npy(A.grad), npy(Gm.grad)
+
+
+@pytest.mark.parametrize("name", ["a", "b", "short"])
+def test_site_vs_reference(dev, name):
+    g = load_golden("g5_g6_admm_site")
+    k, x = int(g[f"k_{name}"]), g[f"x_{name}"]
+    n = 2 ** k - 1
+    xq, loss, D, dx, dA, dG = _site(dev, x, g[f"g_{name}"], g[f"alterD0_{name}"], g[f"gamma0_{name}"], k, 2.0, 0.0)
+    oq, ot, _ = O.act_quant_fwd(x, k, 2.0, 0)
+    assert bits_equal(xq, oq)                                   # same spec => same bits as the C oracle
+    check_bins_vs_ref(xq, g[f"xq_{name}"], ot.astype(np.float64) * n, n)
+    np.testing.assert_allclose(D, g[f"D_{name}"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(loss, g[f"loss_{name}"], atol=TOL)
+    np.testing.assert_allclose(dx, g[f"dx_{name}"], atol=TOL, rtol=1e-4)
+    np.testing.assert_allclose(dA, g[f"dalterD_{name}"], atol=1e-7, rtol=1e-4)
+    np.testing.assert_allclose(dG, g[f"dgamma_{name}"], atol=1e-7, rtol=1e-4)
+
+
+def test_site_office_vs_reference(dev):
+    g = load_golden("g5_office_site")
+    k, x, r = int(g["k"]), g["x"], float(g["act_range"])
+    xq, loss, D, dx, dA, dG = _site(dev, x, g["g"], g["alterD0"], g["gamma0"], k, r, 1e-5)
+    np.testing.assert_allclose(D, g["D"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(loss, g["loss"], atol=TOL)
+    np.testing.assert_allclose(dx, g["dx"], atol=TOL, rtol=1e-4)
+    np.testing.assert_allclose(dA, g["dalterD"], atol=1e-7, rtol=1e-4)
+
+
+@pytest.mark.parametrize("B,C,H,W,k", [(128, 16, 32, 32, 8), (128, 64, 8, 8, 2), (28, 8, 14, 14, 8), (64, 3, 5, 7, 4),
+                                      (100, 16, 16, 16, 4)])
+def test_site_vs_oracle_shapes(dev, B, C, H, W, k):
+    """CIFAR site shapes (incl. the largest, 128x16384), an Office-like B=28 site, ragged F, eval batch 100."""
+    rng = np.random.default_rng(B + C + H)
+    x = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    gq = (rng.standard_normal(x.shape) * 0.01).astype(np.float32)
+    A0, G0 = rng.random((128, 128)).astype(np.float32), rng.random((128, 128)).astype(np.float32)
+    xq, loss, D, dx, dA, dG = _site(dev, x, gq, A0, G0, k, 2.0, 0.0)
+    oq, oD = O.site_fwd(x, k, 2.0, 0.0)
+    assert bits_equal(xq, oq)
+    np.testing.assert_allclose(D, oD, atol=TOL, rtol=0)
+    ol, odD, odA, odG = O.admm_loss(oD, A0, G0, 0.2, 0.3)
+    np.testing.assert_allclose(loss, ol, atol=TOL)
+    odx = O.site_bwd(gq, odD, x, 2.0, 0.0)
+    np.testing.assert_allclose(dx, odx, atol=TOL, rtol=1e-4)
+    np.testing.assert_allclose(dA, odA, atol=1e-7, rtol=1e-4)
+    np.testing.assert_allclose(dG, odG, atol=1e-7, rtol=1e-4)
+
+
+def test_site_properties_full_size(dev):
+    """Size-independent properties at config-5's largest site (28 x 802816): D symmetric, zero diagonal-sum
+    identity trace(corr)= (B-1) for both matrices => trace(D) = 0, x_q on the k-bit lattice, D invariant under
+    a per-feature affine map of x in the corr(x,x) term (checked through corr alone)."""
+    from alignq_amd import ops
+    torch.manual_seed(0)
+    B, F, k = 28, 802816, 8
+    x = torch.randn(B, F, device=dev)
+    A = torch.rand(B, B, device=dev)
+    Gm = torch.rand(B, B, device=dev)
+    xq, loss, D = ops.SiteFn.apply(x, A, Gm, k, 2.0, 1e-5, 0.2, 0.3)
+    D = npy(D)
+    assert np.allclose(D, D.T, atol=1e-6)
+    assert abs(np.trace(D)) < 1e-3
+    lat = npy(xq[:, :4096]) * 255.0
+    assert np.all(np.abs(lat - np.rint(lat)) < 1e-3) and np.abs(lat).max() <= 510
+    G1 = npy(ops.CorrFn.apply(x[:, :100352].contiguous(), 0.0))
+    G2 = npy(ops.CorrFn.apply((x[:, :100352] * 3.0 + 1.5).contiguous(), 0.0))
+    np.testing.assert_allclose(G1, G2, atol=2e-5)
+    assert abs(np.trace(G1) - (B - 1)) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------- R6/R7
+def test_admm_loss_and_update(dev):
+    from alignq_amd.admm import ADMM
+    from alignq_amd.optimizer import ADMM_OPT
+    from alignq_amd import config
+    g = load_golden("g5_g6_admm_site")
+    config.args.bitW = 8
+    for name in ("a", "b", "short", "small"):
+        dim = g[f"alterD0_{name}"].shape[0]
+        admm = ADMM(dim).to(dev)
+        with torch.no_grad():
+            admm.alterD.copy_(cu(g[f"alterD0_{name}"], dev))
+            admm.gamma.copy_(cu(g[f"gamma0_{name}"], dev))
+        D = cu(g[f"D_{name}"], dev).requires_grad_(True)
+        loss = admm(D)
+        loss.backward()
+        np.testing.assert_allclose(float(loss), g[f"loss_{name}"], atol=TOL)
+        np.testing.assert_allclose(npy(admm.alterD.grad), g[f"dalterD_{name}"], atol=1e-6, rtol=1e-4)
+        np.testing.assert_allclose(npy(admm.gamma.grad), g[f"dgamma_{name}"], atol=1e-6, rtol=1e-4)
+        if name == "small":
+            np.testing.assert_allclose(npy(D.grad), g["dD_small"], atol=1e-6)
+        opt = ADMM_OPT([admm.alterD, admm.gamma])
+        a_ptr, g_ptr = admm.alterD.data_ptr(), admm.gamma.data_ptr()
+        opt.step([0], [1], [admm.D], [admm.alterD], [admm.gamma], [admm.mu], [admm.rho])
+        np.testing.assert_allclose(npy(admm.alterD), g[f"alterD1_{name}"], atol=TOL)
+        np.testing.assert_allclose(npy(admm.gamma), g[f"gamma1_{name}"], atol=TOL)
+        assert (admm.alterD.data_ptr(), admm.gamma.data_ptr()) == (a_ptr, g_ptr)    # in place: graph-safe
+    assert np.all(g["alterD1_small"] == 0)
+
+
+def test_admm_opt_skips_params_without_grad(dev):
+    from alignq_amd.admm import ADMM
+    from alignq_amd.optimizer import ADMM_OPT
+    admm = ADMM(8).to(dev)
+    before = npy(admm.alterD).copy()
+    opt = ADMM_OPT([admm.alterD, admm.gamma])
+    opt.step([0], [1], [torch.zeros(8, 8, device=dev)], [admm.alterD], [admm.gamma], [0.2], [0.3])
+    assert np.array_equal(npy(admm.alterD), before)
+
+
+# ------------------------------------------------------------------------------------------- R8
+def test_sgd_step_vs_reference(dev):
+    from alignq_amd.optimizer import SGD
+    from alignq_amd import config
+    g = load_golden("g7_sgd_step")
+    config.args.bitW = int(g["bitW"])
+    ps = [torch.nn.Parameter(cu(g[f"p{i}_0"], dev)) for i in range(3)]
+    opt = SGD(ps, lr=0.04, momentum=0.9, weight_decay=1e-4)
+    for step in (1, 2):
+        for i, p in enumerate(ps):
+            p.grad = cu(g[f"grad{i}_{step}"], dev)
+        opt.step([1], [cu(g["w_cdf"], dev)], [cu(g["w_pdf"], dev)], float(g["lam"]), float(g["lam2"]))
+        for i, p in enumerate(ps):
+            np.testing.assert_allclose(npy(p), g[f"p{i}_{step}"], atol=1e-6)
+            np.testing.assert_allclose(npy(opt.state[p]["momentum_buffer"]), g[f"buf{i}_{step}"], atol=1e-6, rtol=1e-6)
+            np.testing.assert_allclose(npy(p.grad), g[f"gradout{i}_{step}"], atol=1e-5, rtol=1e-5)
+    config.args.bitW = 8
+    assert "momentum_buffer" in opt.state_dict()["state"][0]
+
+
+# ------------------------------------------------------------------------------------------- whole model
+def _load_ref_state(net, g, prefix):
+    sd = net.state_dict()
+    for key, v in g.items():
+        if key.startswith(prefix):
+            sd[key[len(prefix):]] = torch.from_numpy(v)
+    net.load_state_dict(sd, strict=True)
+
+
+def test_tiny_resnet_two_steps_vs_reference(dev):
+    """G8: PreActResNet([1,1,1]) B=8 k=4, two full iterations in the reference's order; the harness model keeps the
+    reference's parameter names, so the captured state_dict loads as is."""
+    from alignq_amd import config
+    from alignq_amd.resnet import PreActBlock_conv_Q, PreActResNet
+    from alignq_amd.train_step import TrainStep
+    g = load_golden("g8_tiny_resnet_admm")
+    config.args.bitW = config.args.abitW = 4
+    config.args.train_batch_size = 8
+    try:
+        net = PreActResNet(PreActBlock_conv_Q, [1, 1, 1], 4, 4, "second", 10)
+        _load_ref_state(net, g, "init/")
+        net = net.to(dev).train()
+        step = TrainStep(net)
+        for it in range(2):
+            logits, ce, tl = step(cu(g["xs"][it], dev), cu(g["ys"][it], dev))
+            np.testing.assert_allclose(npy(logits), g[f"logits_{it}"], atol=5e-4, rtol=1e-3)
+            np.testing.assert_allclose(float(ce), g[f"ce_{it}"], atol=1e-4)
+            np.testing.assert_allclose(float(tl), g[f"trans_{it}"], atol=1e-4)
+            for si, m in enumerate(step.admms):
+                np.testing.assert_allclose(npy(m.D), g[f"D_{it}_{si}"], atol=5e-5)
+            got = net.state_dict()
+            for key, v in g.items():
+                if key.startswith(f"after{it}/") and "num_batches" not in key:
+                    np.testing.assert_allclose(npy(got[key[len(f"after{it}/"):]]), v, atol=3e-4, rtol=2e-3, err_msg=key)
+    finally:
+        config.args.bitW = config.args.abitW = 8
+        config.args.train_batch_size = 128
+
+
+def test_graph_capture_matches_eager(dev):
+    """The captured HIP graph of the full iteration reproduces eager iterations."""
+    from alignq_amd import config
+    from alignq_amd.resnet import PreActBlock_conv_Q, PreActResNet
+    from alignq_amd.train_step import TrainStep
+    config.args.bitW = config.args.abitW = 4
+    config.args.train_batch_size = 16
+    try:
+        torch.manual_seed(1)
+        nets = []
+        for _ in range(2):
+            torch.manual_seed(1)
+            nets.append(PreActResNet(PreActBlock_conv_Q, [1, 1, 1], 4, 4, "second", 10).to(dev).train())
+        x = torch.randn(16, 3, 32, 32, device=dev)
+        y = torch.randint(0, 10, (16,), device=dev)
+        eager, graphed = TrainStep(nets[0]), TrainStep(nets[1])
+        for _ in range(3):
+            eager(x, y)
+        graphed.capture(x, y, warmup=3)          # 3 real warm-up iterations
+        for _ in range(2):
+            eager(x, y)
+            graphed(x, y)
+        torch.cuda.synchronize()
+        # eager did 5 iterations; graphed did 3 warm-up + 1 capture pass (not executed) + 2 replays = 5
+        for (n1, p1), (_, p2) in zip(nets[0].named_parameters(), nets[1].named_parameters()):
+            np.testing.assert_allclose(npy(p1), npy(p2), atol=2e-4, rtol=1e-3, err_msg=n1)
+    finally:
+        config.args.bitW = config.args.abitW = 8
+        config.args.train_batch_size = 128
+
+
+def test_product_path_refuses_cpu_tensors():
+    from alignq_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.ActQuantFn.apply(torch.randn(8), 4, 2.0, 0)
