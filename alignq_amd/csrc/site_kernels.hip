@@ -486,8 +486,8 @@ inline int fwd_grid(int B, int n_tiles) {
 }
 
 template <bool PAIR>
-int launch_fwd(const float* x, int B, int64_t F, int k, float r, float eps, float* xq, float* out, float* stats,
-               void* ws, hipStream_t st) {
+int launch_partials(const float* x, int B, int64_t F, int k, float r, float eps, float* xq, float* stats, void* ws,
+                    hipStream_t st) {
   const int n_tiles = (int)((F + TF - 1) / TF);
   const int grid = fwd_grid(B, n_tiles);
   const int nb = nb_for(B);
@@ -500,11 +500,25 @@ int launch_fwd(const float* x, int B, int64_t F, int k, float r, float eps, floa
     default: hipLaunchKernelGGL((site_fwd_kernel<4, PAIR>), grid, kThreads, 0, st, x, B, F, k, r, eps, xq, slabs, stats, n_tiles, aligned); break;
   }
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return (int)e;
-  const int BP = 32 * nb;
-  hipLaunchKernelGGL(slab_reduce_kernel, (B * B + 63) / 64, 1024, 0, st, slabs, grid, BP, B, 1.0f / (float)F, out);
-  e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
+}
+
+int launch_reduce(const void* ws, int B, int64_t F, float* out, hipStream_t st) {
+  const int n_tiles = (int)((F + TF - 1) / TF);
+  const int grid = fwd_grid(B, n_tiles);
+  const int BP = 32 * nb_for(B);
+  hipLaunchKernelGGL(slab_reduce_kernel, (B * B + 63) / 64, 1024, 0, st, (const float*)ws, grid, BP, B,
+                     1.0f / (float)F, out);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+template <bool PAIR>
+int launch_fwd(const float* x, int B, int64_t F, int k, float r, float eps, float* xq, float* out, float* stats,
+               void* ws, hipStream_t st) {
+  int rc = launch_partials<PAIR>(x, B, F, k, r, eps, xq, stats, ws, st);
+  if (rc) return rc;
+  return launch_reduce(ws, B, F, out, st);
 }
 
 template <bool PAIR>
@@ -540,6 +554,20 @@ int alignq_site_fwd(const float* x, int B, int64_t F, int k, float act_range, fl
   if (B < 2 || B > ALIGNQ_MAX_BATCH) return ALIGNQ_EUNSUPPORTED;
   if (!((k >= 1 && k <= 16) || k == 32)) return ALIGNQ_EINVAL;
   return launch_fwd<true>(x, B, F, k, act_range, eps, xq, D, stats, ws, (hipStream_t)stream);
+}
+
+int alignq_site_partials(const float* x, int B, int64_t F, int k, float act_range, float eps, float* xq, float* stats,
+                         void* ws, void* stream) {
+  if (!x || !ws || F <= 0) return ALIGNQ_EINVAL;
+  if (B < 2 || B > ALIGNQ_MAX_BATCH) return ALIGNQ_EUNSUPPORTED;
+  if (!((k >= 1 && k <= 16) || k == 32)) return ALIGNQ_EINVAL;
+  return launch_partials<true>(x, B, F, k, act_range, eps, xq, stats, ws, (hipStream_t)stream);
+}
+
+int alignq_site_reduce(const void* ws, int B, int64_t F, float* D, void* stream) {
+  if (!ws || !D || F <= 0) return ALIGNQ_EINVAL;
+  if (B < 2 || B > ALIGNQ_MAX_BATCH) return ALIGNQ_EUNSUPPORTED;
+  return launch_reduce(ws, B, F, D, (hipStream_t)stream);
 }
 
 int alignq_site_bwd(const float* g, const float* dD, const float* dD_scale, const float* x, const float* stats,

@@ -38,10 +38,11 @@ class TrainStep:
                     self.admms.append(layer.admm_skip)
         self.grad_hook = grad_hook          # e.g. the data-parallel all-reduce (alignq_amd.dp)
         self._graph: Optional[torch.cuda.CUDAGraph] = None
+        self._graph2: Optional[torch.cuda.CUDAGraph] = None
         self._static = None
 
     # -------------------------------------------------------------------------------------------
-    def _iteration(self, x, y, set_to_none=True):
+    def _forward_backward(self, x, y, set_to_none=True):
         model = self.model
         self.optimizer_t.zero_grad(set_to_none=set_to_none)
         if self.optimizer_admm is not None:
@@ -54,8 +55,9 @@ class TrainStep:
         ce = F.cross_entropy(logits, y)
         total = ce if trans_loss is None else ce + trans_loss
         total.backward()
-        if self.grad_hook is not None:
-            self.grad_hook(self)
+        return logits, ce, trans_loss
+
+    def _optimizer_steps(self):
         if config.args.bitW < 32 and self.admms:
             w_cdf = [c.quantize_fn.weight_cdf for c in self.convs]
             w_pdf = [c.quantize_fn.weight_pdf for c in self.convs]
@@ -66,7 +68,13 @@ class TrainStep:
         else:
             # CDF-only tree (main.py:308 crashes as shipped): plain momentum SGD, no grad rewrite
             self.optimizer_t.step([], [], [], config.args.lam, config.args.lam2)
-        return logits, ce, trans_loss
+
+    def _iteration(self, x, y, set_to_none=True):
+        outs = self._forward_backward(x, y, set_to_none)
+        if self.grad_hook is not None:
+            self.grad_hook(self)
+        self._optimizer_steps()
+        return outs
 
     def __call__(self, x, y):
         if self._graph is None:
@@ -75,12 +83,18 @@ class TrainStep:
         sx.copy_(x, non_blocking=True)
         sy.copy_(y, non_blocking=True)
         self._graph.replay()
+        if self._graph2 is not None:
+            # data-parallel: the collective runs eagerly between the two captured halves
+            self.grad_hook(self)
+            self._graph2.replay()
         return self._static[2]
 
     # -------------------------------------------------------------------------------------------
     def capture(self, x, y, warmup=3):
-        """Capture the full iteration into a HIP graph.  Runs `warmup` eager iterations first (they DO
-        update the model, as real steps) so allocator pools, momentum buffers and MIOpen plans exist."""
+        """Capture the iteration into HIP graphs.  Runs `warmup` eager iterations first (they DO update
+        the model, as real steps) so allocator pools, momentum buffers, pointer tables and MIOpen plans
+        exist.  Without a grad_hook the whole iteration is ONE graph; with one (data parallel) it is two
+        graphs (forward+backward | optimizer steps) with the all-reduce launched eagerly in between."""
         sx, sy = x.clone(), y.clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -90,8 +104,17 @@ class TrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            outs = self._iteration(sx, sy, set_to_none=False)
+        self._graph2 = None
+        if self.grad_hook is None:
+            with torch.cuda.graph(graph):
+                outs = self._iteration(sx, sy, set_to_none=False)
+        else:
+            with torch.cuda.graph(graph):
+                outs = self._forward_backward(sx, sy, set_to_none=False)
+            graph2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph2, pool=graph.pool()):
+                self._optimizer_steps()
+            self._graph2 = graph2
         self._graph = graph
         self._static = (sx, sy, outs)
         return self

@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of BASELINE.json: images/sec of one full training step
+(zero_grad -> fwd -> CE + trans_loss -> bwd -> SGD.step -> ADMM_OPT.step) of ResNet-20 CIFAR-shape,
+8W/8A, CDF alignment + ADMM, batch 128 per GPU (BASELINE.json configs[1]), synthetic 3x32x32 inputs
+resident in HBM, random-init weights.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  Besides the contract fields it carries
+  roofline      : the dominant hand-written kernel of the step (by summed time over its launches in one step),
+                  timed live with HIP events on the launch stream, vs the gfx950 peak that bounds it;
+  kernels       : the same measurement for every hot-path kernel family (incl. the plain CDF-quantise
+                  kernel on a 2^26-element tensor, the "quant-kernel HBM GB/s" of BASELINE.json);
+  cpu_baseline  : the eager-torch CPU restatement of the reference (oracle/torch_ref.py, kind "port") timed on
+                  this box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (the reference's train_batch_size)")
+    ap.add_argument("--bits", type=int, default=8)
+    ap.add_argument("--model", default="resnet20", choices=["resnet20", "resnet56"])
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernels", action="store_true", help="skip the per-kernel roofline measurements")
+    ap.add_argument("--cpu-steps", type=int, default=6)
+    return ap.parse_args()
+
+
+def time_call(fn, reps, warm=3):
+    """Average duration (s) of fn() over `reps` back-to-back enqueues, HIP events on the current stream."""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
+def measure_kernels(dev, B, k, site_F_counts):
+    """Per-kernel live timings through the C ABI.  site_F_counts: {F: number of ADMM sites with F features}."""
+    from alignq_amd import _lib as L
+    lib = L.load()
+    st = L.stream_ptr()
+    out = {}
+    per_step = {"site_partials": [0.0, 0.0], "site_bwd": [0.0, 0.0], "site_reduce": [0.0, 0.0], "admm_loss": [0.0, 0.0]}
+    A = torch.rand(B, B, device=dev)
+    Gm = torch.rand(B, B, device=dev)
+    for F, count in sorted(site_F_counts.items()):
+        x = torch.randn(B, F, device=dev)
+        g = torch.randn(B, F, device=dev) * 0.01
+        xq, dx = torch.empty_like(x), torch.empty_like(x)
+        D = torch.empty(B, B, device=dev)
+        stats = torch.empty(4, F, device=dev)
+        ws = torch.empty(lib.alignq_site_ws_bytes(B, F), dtype=torch.uint8, device=dev)
+        loss = torch.empty((), device=dev)
+        dD, dA, dG = torch.empty_like(D), torch.empty_like(A), torch.empty_like(Gm)
+        one = torch.ones((), device=dev)
+        p = L.ptr
+        t_part = time_call(lambda: lib.alignq_site_partials(p(x), B, F, k, 2.0, 0.0, p(xq), p(stats), p(ws), st), 50)
+        t_red = time_call(lambda: lib.alignq_site_reduce(p(ws), B, F, p(D), st), 50)
+        t_loss = time_call(lambda: lib.alignq_admm_loss(p(D), B, p(A), p(Gm), B, 0.2, 0.3, p(loss), p(dD), p(dA), p(dG), None, st), 50)
+        t_bwd = time_call(lambda: lib.alignq_site_bwd(p(g), p(dD), p(one), p(x), p(stats), B, F, 2.0, 0.0, p(dx), st), 50)
+        gram_flops = 2 * 2.0 * B * B * F            # two Grams, full-matrix count
+        out[f"site_F{F}"] = {
+            "partials_us": t_part * 1e6, "reduce_us": t_red * 1e6, "admm_loss_us": t_loss * 1e6, "bwd_us": t_bwd * 1e6,
+            "partials_tflops": gram_flops / t_part / 1e12, "bwd_tflops": gram_flops / t_bwd / 1e12,
+            "partials_hbm_gbs": 8.0 * B * F / t_part / 1e9, "bwd_hbm_gbs": 12.0 * B * F / t_bwd / 1e9, "sites": count}
+        for name, t, fl in (("site_partials", t_part, gram_flops), ("site_bwd", t_bwd, gram_flops),
+                            ("site_reduce", t_red, 0.0), ("admm_loss", t_loss, 0.0)):
+            per_step[name][0] += t * count
+            per_step[name][1] += fl * count
+    # plain CDF-quantise kernels on a roofline-sized tensor (2^26 elements = 268 MB, beyond the 256 MiB L3)
+    n = 1 << 26
+    x = torch.randn(n, device=dev)
+    y = torch.empty_like(x)
+    g = torch.randn(n, device=dev)
+    p = L.ptr
+    t_f = time_call(lambda: lib.alignq_act_quant_fwd(p(x), p(y), None, n, k, 2.0, 0, st), 20)
+    t_b = time_call(lambda: lib.alignq_act_quant_bwd(p(g), p(x), p(y), n, 2.0, st), 20)
+    out["act_quant_fwd_2p26"] = {"us": t_f * 1e6, "hbm_gbs": 8.0 * n / t_f / 1e9, "frac_of_8TBs": 8.0 * n / t_f / 1e9 / HBM_PEAK_GBS}
+    out["act_quant_bwd_2p26"] = {"us": t_b * 1e6, "hbm_gbs": 12.0 * n / t_b / 1e9, "frac_of_8TBs": 12.0 * n / t_b / 1e9 / HBM_PEAK_GBS}
+    del x, y, g
+    n_sites = sum(site_F_counts.values())
+    dom = max(("site_partials", "site_bwd"), key=lambda kname: per_step[kname][0])
+    t_sum, fl_sum = per_step[dom]
+    kernel_sym = {"site_partials": "site_fwd_kernel<4,true>", "site_bwd": "site_bwd_kernel<4,true>"}[dom]
+    roofline = {"kernel": kernel_sym, "bound": "mfma", "achieved": fl_sum / t_sum / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": fl_sum / t_sum / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                "launches_per_step": n_sites, "avg_launch_us": t_sum / n_sites * 1e6,
+                "flops_per_launch_avg": fl_sum / n_sites,
+                "note": "achieved = (2 Grams x 2*B^2*F flop, summed over the step's sites) / summed launch time"}
+    out["per_step_us"] = {kname: v[0] * 1e6 for kname, v in per_step.items()}
+    return roofline, out
+
+
+def cpu_baseline(batch, bits, model, steps):
+    """The eager-torch restatement of the reference on the host cores: same workload, bounded sample."""
+    from oracle import torch_ref as R
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))
+    torch.set_num_threads(cores)
+    cfg = R.Config(tree="admm", bitW=bits, abitW=bits, train_batch_size=batch)
+    torch.manual_seed(0)
+    net = (R.resnet20 if model == "resnet20" else R.resnet56)(cfg).train()
+    step = R.TrainStep(net, cfg)
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn(batch, 3, 32, 32, generator=gen)
+    y = torch.randint(0, 10, (batch,), generator=gen)
+    for _ in range(2):
+        step(x, y)
+    ts = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        step(x, y)
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    return {"value": batch / med, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} full training steps (median) of the same workload after 2 warm-ups, batch {batch}, "
+                      f"oracle/torch_ref.py on torch-CPU {torch.__version__}",
+            "s_per_step": med}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback in the product path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    from alignq_amd import _lib, config, dp
+    from alignq_amd.resnet import resnet20_quant, resnet56_quant
+    from alignq_amd.train_step import TrainStep
+    if not os.path.exists(_lib.SO_PATH) and rank == 0:
+        import __graft_entry__
+        __graft_entry__.build()
+    if world > 1:
+        dist.barrier()
+    _lib.load()
+
+    config.args.bitW = config.args.abitW = a.bits
+    config.args.train_batch_size = a.batch
+    torch.manual_seed(0)
+    model = (resnet20_quant if a.model == "resnet20" else resnet56_quant)(a.bits, a.bits).to(dev).train()
+    step = TrainStep(model)
+    if world > 1:
+        dp.attach(step)
+    gen = torch.Generator().manual_seed(rank)
+    x = torch.randn(a.batch, 3, 32, 32, generator=gen).to(dev)
+    y = torch.randint(0, 10, (a.batch,), generator=gen).to(dev)
+    if a.no_graph:
+        for _ in range(3):
+            step(x, y)
+    else:
+        step.capture(x, y, warmup=3)
+    for _ in range(a.warmup):
+        step(x, y)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step(x, y)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    logits, ce, tl = out
+    assert torch.isfinite(ce).item(), "training step produced a non-finite loss"
+
+    if rank == 0:
+        images = a.steps * a.batch * world
+        res = {
+            "metric": "images/sec (train step, CDF+ADMM) ResNet-20 8-bit",
+            "value": images / elapsed, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{a.model} CIFAR-shape 3x32x32, {a.bits}W/{a.bits}A CDF+ADMM full train step "
+                                   f"(cdf_alignment_admm/resnet-20-cifar-10), batch {a.batch}/GPU, "
+                                   f"{'HIP-graph replay' if not a.no_graph else 'eager launches'}",
+                       "global_batch": a.batch * world, "parallelism": f"dp{world}",
+                       "final_ce": float(ce), "final_trans_loss": float(tl) if tl is not None else None},
+        }
+        if not a.no_kernels:
+            counts = {}
+            units = [3, 3, 3] if a.model == "resnet20" else [9, 9, 9]
+            # site F per stage: 16x32x32, 32x16x16, 64x8x8 ; stem + 2/block + 1 skip in the first block of stages 2,3
+            counts[16384] = 1 + 2 * units[0]
+            counts[8192] = 2 * units[1] + 1
+            counts[4096] = 2 * units[2] + 1
+            roof, kernels = measure_kernels(dev, a.batch, a.bits, counts)
+            res["roofline"] = roof
+            res["kernels"] = kernels
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(a.batch, a.bits, a.model, a.cpu_steps)
+            res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

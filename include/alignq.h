@@ -83,6 +83,11 @@ int alignq_weight_quant_bwd(const float* g, const float* w, const float* ms, flo
 size_t alignq_site_ws_bytes(int B, int64_t F);
 int alignq_site_fwd(const float* x, int B, int64_t F, int k, float act_range, float eps, float* xq,
                     float* D, float* stats, void* ws, void* stream);
+/* The two launches of alignq_site_fwd, separately (same arguments): per-tile quantise + Gram partial slabs into
+ * ws, then the deterministic slab reduction ws -> D (scaled by 1/F).                                  */
+int alignq_site_partials(const float* x, int B, int64_t F, int k, float act_range, float eps, float* xq,
+                         float* stats, void* ws, void* stream);
+int alignq_site_reduce(const void* ws, int B, int64_t F, float* D, void* stream);
 /* dx = g*dt/dx + d(corr pair)/dx for upstream dD [B,B] (gradient w.r.t. D).  g may be NULL.
  * dD_scale: optional DEVICE scalar multiplying dD (the upstream gradient of the scalar loss).       */
 int alignq_site_bwd(const float* g, const float* dD, const float* dD_scale, const float* x,

@@ -144,7 +144,7 @@ def act_quant(x: torch.Tensor, k: int, stage: str, cfg: Config, admm: Optional[A
     """Returns (x_q, trans_loss).  trans_loss is the python int 0 when the site carries no ADMM."""
     if k == 32 and stage != "align":
         return x, 0
-    zero, one = torch.zeros(1), torch.ones(1)
+    zero, one = torch.zeros(1, device=x.device), torch.ones(1, device=x.device)
     t, _ = cdf_transform(x, zero, one, "a", cfg)
     if cfg.tree == "cdf":
         xq = (quantize_ste(t, k) * 2 - 1) * cfg.act_range
