@@ -40,6 +40,10 @@ SIGNATURES = {
     "alignq_admm_update": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _vp]),
     "alignq_sgd_step": (_i, [_vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _i, _vp]),
     "alignq_sgd_grad_approx": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _f, _f, _vp]),
+    "alignq_weight_multi_ws_bytes": (_sz, [_i]),
+    "alignq_weight_quant_fwd_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "alignq_weight_quant_bwd_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "alignq_sgd_step_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i, _i, _f, _f, _vp]),
 }
 
 _lib = None
@@ -80,6 +84,19 @@ def stream_ptr() -> int:
 
 def ptr(t):
     return None if t is None else t.data_ptr()
+
+
+def ptr_array(tensors):
+    """HOST array of device pointers (NULL for None) for the multi-tensor entry points."""
+    return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+def i64_array(values):
+    return (ctypes.c_int64 * len(values))(*[int(v) for v in values])
+
+
+def i32_array(values):
+    return (ctypes.c_int32 * len(values))(*[int(v) for v in values])
 
 
 def dev_f32(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:

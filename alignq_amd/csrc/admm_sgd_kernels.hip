@@ -71,15 +71,19 @@ __global__ __launch_bounds__(kBig) void admm_loss_kernel(const float* __restrict
   }
 }
 
-// utils/optimizer.py:97-124, one workgroup per site.
-__global__ __launch_bounds__(kBig) void admm_update_kernel(const float* const* __restrict__ D_tab,
-                                                           float* const* __restrict__ A_tab,
-                                                           float* const* __restrict__ G_tab, int b, int dim,
-                                                           float mu, float rho) {
+// utils/optimizer.py:97-124, one workgroup per site; the per-site pointers travel by value in the arguments.
+constexpr int kSiteChunk = 64;
+struct AChunk {
+  const float* D[kSiteChunk];
+  float* A[kSiteChunk];
+  float* G[kSiteChunk];
+};
+
+__global__ __launch_bounds__(kBig) void admm_update_kernel(AChunk c, int b, int dim, float mu, float rho) {
   __shared__ double sm[48];
-  const float* D = D_tab[blockIdx.x];
-  float* A = A_tab[blockIdx.x];
-  float* G = G_tab[blockIdx.x];
+  const float* __restrict__ D = c.D[blockIdx.x];
+  float* __restrict__ A = c.A[blockIdx.x];
+  float* __restrict__ G = c.G[blockIdx.x];
   const int full = dim * dim;
   const float inv_rho = 1.0f / rho;
   double ss = 0, z0 = 0, z1 = 0;
@@ -177,9 +181,16 @@ int alignq_admm_update(const float* const* D_tab, float* const* alterD_tab, floa
                        int dim, float mu, float rho, void* stream) {
   if (!D_tab || !alterD_tab || !gamma_tab || S <= 0 || b <= 0 || dim < b) return ALIGNQ_EINVAL;
   if (dim > 4096) return ALIGNQ_EUNSUPPORTED;
-  hipLaunchKernelGGL(admm_update_kernel, S, kBig, 0, (hipStream_t)stream, D_tab, alterD_tab, gamma_tab, b, dim, mu,
-                     rho);
-  LAUNCH_CHECK();
+  for (int s0 = 0; s0 < S; s0 += kSiteChunk) {
+    const int cnt = (S - s0 < kSiteChunk) ? S - s0 : kSiteChunk;
+    AChunk c;
+    for (int i = 0; i < cnt; i++) {
+      if (!D_tab[s0 + i] || !alterD_tab[s0 + i] || !gamma_tab[s0 + i]) return ALIGNQ_EINVAL;
+      c.D[i] = D_tab[s0 + i]; c.A[i] = alterD_tab[s0 + i]; c.G[i] = gamma_tab[s0 + i];
+    }
+    hipLaunchKernelGGL(admm_update_kernel, cnt, kBig, 0, (hipStream_t)stream, c, b, dim, mu, rho);
+    LAUNCH_CHECK();
+  }
   return 0;
 }
 

@@ -133,3 +133,61 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 
 }  // namespace alignq
+
+// ---- weight quantiser element functions shared by the single- and multi-tensor kernels -----------------
+namespace alignq {
+
+struct WeightConsts {
+  float m, rs, var2, logs, nlev;
+};
+
+__device__ __forceinline__ WeightConsts weight_consts(float m, float s, int k) {
+  WeightConsts c;
+  c.m = m;
+  c.rs = __fdiv_rn(1.0f, s);
+  c.var2 = __fmul_rn(2.0f, __fmul_rn(s, s));
+  c.logs = (float)log((double)s);
+  c.nlev = (float)((1 << (k & 31)) - 1);
+  return c;
+}
+
+// weight_quantize_fn.forward for one element given (m, s): returns W_q, *t = the tree's weight_cdf
+template <int FORMULA>
+__device__ __forceinline__ float weight_quant1(float v, const WeightConsts& wc, int k, float* t, float* bin) {
+  float c = gauss_cdf32(v, wc.m, wc.rs);
+  if (FORMULA == 0) {
+    *t = __fsub_rn(__fmul_rn(c, 2.0f), 1.0f);
+    return round_bins(*t, k, wc.nlev, bin);
+  }
+  *t = c;
+  return __fsub_rn(__fmul_rn(round_bins(c, k, wc.nlev, bin), 2.0f), 1.0f);
+}
+
+// weight_pdf = exp(Normal(m,s).log_prob(v)) * 2   (model/quantization.py:58)
+__device__ __forceinline__ float weight_pdf2(float v, const WeightConsts& wc) {
+  float d = __fsub_rn(v, wc.m);
+  float lp = __fsub_rn(__fsub_rn(__fdiv_rn(-__fmul_rn(d, d), wc.var2), wc.logs), ALIGNQ_LOG_SQRT_2PI_F);
+  return __fmul_rn(exp32(lp), 2.0f);
+}
+
+// backward helpers: P = 2*pdf_N(m,s)(w), z = (w-m)/s ; cs = 2/(s*sqrt(2*pi))
+__device__ __forceinline__ void weight_PZ(float w, float m, float rs, float cs, float* P, float* z) {
+  float zz = (w - m) * rs;
+  *z = zz;
+  *P = cs * __expf(-0.5f * zz * zz);
+}
+
+// block-wide sum of two doubles (result in every thread); sm: >= 2*16 doubles of LDS
+__device__ __forceinline__ void block_sum2d(double& a, double& b, double* sm) {
+  a = wave_sum_d(a);
+  b = wave_sum_d(b);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) { sm[w] = a; sm[16 + w] = b; }
+  __syncthreads();
+  const int nw = blockDim.x >> 6;
+  a = 0; b = 0;
+  for (int i = 0; i < nw; i++) { a += sm[i]; b += sm[16 + i]; }
+}
+
+}  // namespace alignq

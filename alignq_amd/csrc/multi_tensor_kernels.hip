@@ -1,0 +1,277 @@
+// multi_tensor_kernels.hip — one launch for ALL weight tensors / parameters of a model (gfx950).
+//
+// A CIFAR ResNet has 21..57 conv weights of 432..36864 elements and 65..185 parameters: per-tensor launches
+// (what the reference does in eager PyTorch, ~20 kernels per tensor) are pure launch latency.  Here the
+// per-tensor pointer tables travel BY VALUE in the kernel arguments (<= kChunk tensors per launch, 4 KB
+// argument limit), so there are no device-side tables to keep in sync and every launch is hipGraph-capturable;
+// blockIdx.y selects the tensor, blockIdx.x strides over its elements.
+#include <hip/hip_runtime.h>
+
+#include "../../include/alignq.h"
+#include "alignq_math.h"
+
+using namespace alignq;
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kChunk = 48;      // tensors per launch: 48 * (5 pointers + 1 size) * 8 B = 2304 B of arguments
+constexpr int kMaxBlk = 64;     // blocks per tensor (partials per tensor in the workspace)
+
+struct WChunk {
+  const float* w[kChunk];
+  const float* g[kChunk];   // backward only
+  float* q[kChunk];         // fwd: W_q         | bwd: dW
+  float* cdf[kChunk];
+  float* pdf[kChunk];
+  long n[kChunk];
+};
+
+__global__ __launch_bounds__(kThreads) void mt_weight_partial_kernel(WChunk c, double* __restrict__ ws, int t0) {
+  __shared__ double sm[32];
+  const int t = blockIdx.y;
+  const float* __restrict__ w = c.w[t];
+  const long n = c.n[t];
+  double s = 0, s2 = 0;
+  for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
+    double v = w[i];
+    s += v;
+    s2 += v * v;
+  }
+  block_sum2d(s, s2, sm);
+  if (threadIdx.x == 0) {
+    double* p = ws + ((long)(t0 + t) * kMaxBlk + blockIdx.x) * 2;
+    p[0] = s;
+    p[1] = s2;
+  }
+}
+
+template <int FORMULA>
+__global__ __launch_bounds__(kThreads) void mt_weight_apply_kernel(WChunk c, const double* __restrict__ ws,
+                                                                   float* __restrict__ ms_out, int t0, int k) {
+  __shared__ double sm[32];
+  const int t = blockIdx.y;
+  const long n = c.n[t];
+  double s = 0, s2 = 0;
+  if (threadIdx.x < gridDim.x) {
+    const double* p = ws + ((long)(t0 + t) * kMaxBlk + threadIdx.x) * 2;
+    s = p[0];
+    s2 = p[1];
+  }
+  block_sum2d(s, s2, sm);
+  const double dn = (double)n;
+  const double mean = s / dn;
+  double var = (s2 - s * s / dn) / (dn - 1.0);
+  if (var < 0) var = 0;
+  const float m = (float)mean, sd = (float)sqrt(var);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { ms_out[2 * (t0 + t)] = m; ms_out[2 * (t0 + t) + 1] = sd; }
+  const WeightConsts wc = weight_consts(m, sd, k);
+  const float* __restrict__ w = c.w[t];
+  float* __restrict__ q = c.q[t];
+  float* __restrict__ cdf = c.cdf[t];
+  float* __restrict__ pdf = c.pdf[t];
+  for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
+    float v = w[i], tt, b;
+    q[i] = weight_quant1<FORMULA>(v, wc, k, &tt, &b);
+    if (cdf) cdf[i] = tt;
+    if (pdf) pdf[i] = weight_pdf2(v, wc);
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void mt_weight_bwd_partial_kernel(WChunk c, const float* __restrict__ ms,
+                                                                         double* __restrict__ ws, int t0) {
+  __shared__ double sm[32];
+  const int t = blockIdx.y;
+  const float* __restrict__ w = c.w[t];
+  const float* __restrict__ g = c.g[t];
+  const long n = c.n[t];
+  const float m = ms[2 * (t0 + t)], s = ms[2 * (t0 + t) + 1], rs = 1.0f / s, cs = ALIGNQ_TWO_OVER_SQRT_2PI * rs;
+  double s1 = 0, s2 = 0;
+  for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
+    float P, z;
+    weight_PZ(w[i], m, rs, cs, &P, &z);
+    double gp = (double)g[i] * (double)P;
+    s1 += gp;
+    s2 += gp * (double)z;
+  }
+  block_sum2d(s1, s2, sm);
+  if (threadIdx.x == 0) {
+    double* p = ws + ((long)(t0 + t) * kMaxBlk + blockIdx.x) * 2;
+    p[0] = s1;
+    p[1] = s2;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void mt_weight_bwd_apply_kernel(WChunk c, const float* __restrict__ ms,
+                                                                       const double* __restrict__ ws, int t0) {
+  __shared__ double sm[32];
+  const int t = blockIdx.y;
+  const long n = c.n[t];
+  double s1 = 0, s2 = 0;
+  if (threadIdx.x < gridDim.x) {
+    const double* p = ws + ((long)(t0 + t) * kMaxBlk + threadIdx.x) * 2;
+    s1 = p[0];
+    s2 = p[1];
+  }
+  block_sum2d(s1, s2, sm);
+  const float m = ms[2 * (t0 + t)], s = ms[2 * (t0 + t) + 1], rs = 1.0f / s, cs = ALIGNQ_TWO_OVER_SQRT_2PI * rs;
+  const float mean_gp = (float)(s1 / (double)n);
+  const float dotn = (float)(s2 / (double)(n - 1));
+  const float* __restrict__ w = c.w[t];
+  const float* __restrict__ g = c.g[t];
+  float* __restrict__ dw = c.q[t];
+  for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
+    float P, z;
+    weight_PZ(w[i], m, rs, cs, &P, &z);
+    dw[i] = g[i] * P - mean_gp - z * dotn;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ SGD
+struct SChunk {
+  float* p[kChunk];
+  float* g[kChunk];
+  float* buf[kChunk];
+  const float* cdf[kChunk];   // non-NULL => tensor is in `idx`: p.grad <- dir * sigmoid_d(transform(cdf)) * pdf
+  const float* pdf[kChunk];
+  long n[kChunk];
+  unsigned long long first_mask;   // bit t set => momentum buffer is being created this step
+};
+
+__global__ __launch_bounds__(kThreads) void mt_sgd_kernel(SChunk c, float lr, float mom, float damp, float wd,
+                                                          int nesterov, float nlev, float lam, float lam2) {
+  const int t = blockIdx.y;
+  float* __restrict__ p = c.p[t];
+  float* __restrict__ g = c.g[t];
+  float* __restrict__ buf = c.buf[t];
+  const float* __restrict__ cdf = c.cdf[t];
+  const float* __restrict__ pdf = c.pdf[t];
+  const long n = c.n[t];
+  const bool first = (c.first_mask >> t) & 1ull;
+  for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
+    float pv = p[i];
+    float d = g[i];
+    if (wd != 0.0f) d = __fmaf_rn(wd, pv, d);
+    float dir = d;
+    if (mom != 0.0f) {
+      float bv = first ? d : __fmaf_rn(1.0f - damp, d, buf[i] * mom);
+      buf[i] = bv;
+      dir = nesterov ? __fmaf_rn(mom, bv, d) : bv;
+    }
+    p[i] = __fmaf_rn(-lr, dir, pv);
+    float gout = dir;
+    if (cdf) {
+      float a = (cdf[i] + 0.5f) * nlev;
+      float fr = a - floorf(a);
+      float tr = fr * lam2 * 2.0f;
+      float sg = 1.0f / (1.0f + __expf(-tr));
+      gout = dir * (sg * (1.0f - sg) * lam) * pdf[i];
+    }
+    g[i] = gout;
+  }
+}
+
+inline int blocks_for(long max_n) {
+  long b = (max_n + 2047) / 2048;
+  if (b < 1) b = 1;
+  return (int)(b > kMaxBlk ? kMaxBlk : b);
+}
+
+}  // namespace
+
+#define LAUNCH_CHECK()                          \
+  do {                                          \
+    hipError_t e__ = hipGetLastError();         \
+    if (e__ != hipSuccess) return (int)e__;     \
+  } while (0)
+
+extern "C" {
+
+size_t alignq_weight_multi_ws_bytes(int T) { return (size_t)(T > 0 ? T : 1) * kMaxBlk * 2 * sizeof(double); }
+
+int alignq_weight_quant_fwd_multi(int T, const float* const* w, float* const* q, float* const* cdf_out,
+                                  float* const* pdf_out, const int64_t* n, float* ms, int k, int formula, void* ws,
+                                  void* stream) {
+  if (T <= 0 || !w || !q || !n || !ms || !ws) return ALIGNQ_EINVAL;
+  if (!((k >= 1 && k <= 16) || k == 32)) return ALIGNQ_EINVAL;
+  if (formula != ALIGNQ_FORMULA_ADMM && formula != ALIGNQ_FORMULA_CDF) return ALIGNQ_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  for (int t0 = 0; t0 < T; t0 += kChunk) {
+    const int cnt = (T - t0 < kChunk) ? T - t0 : kChunk;
+    WChunk c;
+    long max_n = 0;
+    for (int i = 0; i < cnt; i++) {
+      if (!w[t0 + i] || !q[t0 + i] || n[t0 + i] < 2) return ALIGNQ_EINVAL;
+      c.w[i] = w[t0 + i]; c.g[i] = nullptr; c.q[i] = q[t0 + i];
+      c.cdf[i] = cdf_out ? cdf_out[t0 + i] : nullptr;
+      c.pdf[i] = pdf_out ? pdf_out[t0 + i] : nullptr;
+      c.n[i] = (long)n[t0 + i];
+      if (c.n[i] > max_n) max_n = c.n[i];
+    }
+    dim3 grid(blocks_for(max_n), cnt);
+    hipLaunchKernelGGL(mt_weight_partial_kernel, grid, kThreads, 0, st, c, (double*)ws, t0);
+    LAUNCH_CHECK();
+    if (formula == ALIGNQ_FORMULA_ADMM)
+      hipLaunchKernelGGL((mt_weight_apply_kernel<0>), grid, kThreads, 0, st, c, (const double*)ws, ms, t0, k);
+    else
+      hipLaunchKernelGGL((mt_weight_apply_kernel<1>), grid, kThreads, 0, st, c, (const double*)ws, ms, t0, k);
+    LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+int alignq_weight_quant_bwd_multi(int T, const float* const* g, const float* const* w, const float* ms,
+                                  float* const* dw, const int64_t* n, void* ws, void* stream) {
+  if (T <= 0 || !g || !w || !ms || !dw || !n || !ws) return ALIGNQ_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  for (int t0 = 0; t0 < T; t0 += kChunk) {
+    const int cnt = (T - t0 < kChunk) ? T - t0 : kChunk;
+    WChunk c;
+    long max_n = 0;
+    for (int i = 0; i < cnt; i++) {
+      if (!w[t0 + i] || !g[t0 + i] || !dw[t0 + i] || n[t0 + i] < 2) return ALIGNQ_EINVAL;
+      c.w[i] = w[t0 + i]; c.g[i] = g[t0 + i]; c.q[i] = dw[t0 + i]; c.cdf[i] = nullptr; c.pdf[i] = nullptr;
+      c.n[i] = (long)n[t0 + i];
+      if (c.n[i] > max_n) max_n = c.n[i];
+    }
+    dim3 grid(blocks_for(max_n), cnt);
+    hipLaunchKernelGGL(mt_weight_bwd_partial_kernel, grid, kThreads, 0, st, c, ms, (double*)ws, t0);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(mt_weight_bwd_apply_kernel, grid, kThreads, 0, st, c, ms, (const double*)ws, t0);
+    LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+int alignq_sgd_step_multi(int T, float* const* p, float* const* g, float* const* buf, const int64_t* n,
+                          const float* const* w_cdf, const float* const* w_pdf, const int32_t* first, float lr,
+                          float mom, float damp, float wd, int nesterov, int bitW, float lam, float lam2,
+                          void* stream) {
+  if (T <= 0 || !p || !g || !n) return ALIGNQ_EINVAL;
+  if (mom != 0.0f && !buf) return ALIGNQ_EINVAL;
+  if (bitW < 1 || bitW > 30) bitW = 1;
+  const float nlev = (float)((1 << bitW) - 1);
+  hipStream_t st = (hipStream_t)stream;
+  for (int t0 = 0; t0 < T; t0 += kChunk) {
+    const int cnt = (T - t0 < kChunk) ? T - t0 : kChunk;
+    SChunk c;
+    c.first_mask = 0;
+    long max_n = 0;
+    for (int i = 0; i < cnt; i++) {
+      if (!p[t0 + i] || !g[t0 + i] || n[t0 + i] <= 0) return ALIGNQ_EINVAL;
+      if (mom != 0.0f && !buf[t0 + i]) return ALIGNQ_EINVAL;
+      c.p[i] = p[t0 + i]; c.g[i] = g[t0 + i]; c.buf[i] = buf ? buf[t0 + i] : nullptr;
+      c.cdf[i] = (w_cdf && w_pdf && w_cdf[t0 + i] && w_pdf[t0 + i]) ? w_cdf[t0 + i] : nullptr;
+      c.pdf[i] = c.cdf[i] ? w_pdf[t0 + i] : nullptr;
+      c.n[i] = (long)n[t0 + i];
+      if (first && first[t0 + i]) c.first_mask |= (1ull << i);
+      if (c.n[i] > max_n) max_n = c.n[i];
+    }
+    dim3 grid(blocks_for(max_n), cnt);
+    hipLaunchKernelGGL(mt_sgd_kernel, grid, kThreads, 0, st, c, lr, mom, damp, wd, nesterov, nlev, lam, lam2);
+    LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+}  // extern "C"

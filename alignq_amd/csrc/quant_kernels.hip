@@ -146,42 +146,19 @@ __global__ __launch_bounds__(kThreads) void weight_quant_fwd_kernel(const float*
                                                                     float* __restrict__ q, float* __restrict__ cdf_out,
                                                                     float* __restrict__ pdf_out,
                                                                     int32_t* __restrict__ bins, int64_t n, int k) {
-  const float m = ms[0], s = ms[1];
-  const float rs = __fdiv_rn(1.0f, s);
-  const float var2 = __fmul_rn(2.0f, __fmul_rn(s, s));
-  const float logs = (float)log((double)s);
-  const float nlev = (float)((1 << (k & 31)) - 1);
+  const WeightConsts wc = weight_consts(ms[0], ms[1], k);
   const int64_t stride = (int64_t)gridDim.x * kThreads;
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
     float v = w[i];
-    float c = gauss_cdf32(v, m, rs);
-    float t, b, qq;
-    if (FORMULA == 0) {
-      t = __fsub_rn(__fmul_rn(c, 2.0f), 1.0f);
-      qq = round_bins(t, k, nlev, &b);
-    } else {
-      t = c;
-      qq = __fsub_rn(__fmul_rn(round_bins(c, k, nlev, &b), 2.0f), 1.0f);
-    }
-    q[i] = qq;
+    float t, b;
+    q[i] = weight_quant1<FORMULA>(v, wc, k, &t, &b);
     if (cdf_out) cdf_out[i] = t;
     if (bins) bins[i] = (int)b;
-    if (pdf_out) {
-      float d = __fsub_rn(v, m);
-      float lp = __fsub_rn(__fsub_rn(__fdiv_rn(-__fmul_rn(d, d), var2), logs), ALIGNQ_LOG_SQRT_2PI_F);
-      pdf_out[i] = __fmul_rn(exp32(lp), 2.0f);
-    }
+    if (pdf_out) pdf_out[i] = weight_pdf2(v, wc);
   }
 }
 
 // ------------------------------------------------------------------ weights: backward ---------
-// P = 2*pdf_N(m,s)(w) = 2/(s*sqrt(2pi)) * exp(-z^2/2), z = (w-m)/s
-__device__ __forceinline__ void weight_PZ(float w, float m, float rs, float cs, float* P, float* z) {
-  float zz = (w - m) * rs;
-  *z = zz;
-  *P = cs * __expf(-0.5f * zz * zz);
-}
-
 __global__ __launch_bounds__(kThreads) void weight_bwd_partial_kernel(const float* __restrict__ g,
                                                                       const float* __restrict__ w,
                                                                       const float* __restrict__ ms, int64_t n,

@@ -12,8 +12,6 @@ Reference quirks kept:
 """
 from __future__ import annotations
 
-from typing import List
-
 import torch
 from torch.optim.optimizer import Optimizer
 
@@ -51,53 +49,43 @@ class SGD(Optimizer):
         for group in self.param_groups:
             wd, mom, damp, nest, lr = (group["weight_decay"], group["momentum"], group["dampening"],
                                        group["nesterov"], group["lr"])
+            ps, gs, bufs, firsts, cdfs, pdfs = [], [], [], [], [], []
             for i, p in enumerate(group["params"]):
                 if p.grad is None:
                     continue
                 L.dev_f32(p, "parameter")
+                if not p.is_contiguous():
+                    raise RuntimeError("alignq_amd.SGD needs contiguous parameters")
                 g = p.grad
                 if not g.is_contiguous():
                     g = p.grad = g.contiguous()
-                first = 0
-                buf = None
+                first, buf = 0, None
                 if mom != 0:
                     state = self.state[p]
                     if "momentum_buffer" not in state:
                         state["momentum_buffer"] = torch.empty_like(p, memory_format=torch.contiguous_format)
                         first = 1
                     buf = state["momentum_buffer"]
-                L.check(lib.alignq_sgd_step(p.data_ptr(), g.data_ptr(), L.ptr(buf), p.numel(), float(lr), float(mom),
-                                            float(damp), float(wd), int(bool(nest)), first, st), "alignq_sgd_step")
+                c = pdf = None
                 if bitW < 32 and i in idx:
                     j = idx.index(i)
                     c, pdf = L.dev_f32(w_cdf[j].detach(), "w_cdf"), L.dev_f32(w_pdf[j].detach(), "w_pdf")
-                    L.check(lib.alignq_sgd_grad_approx(g.data_ptr(), c.data_ptr(), pdf.data_ptr(), g.data_ptr(),
-                                                       p.numel(), bitW, float(lam), float(lam2), st),
-                            "alignq_sgd_grad_approx")
+                ps.append(p); gs.append(g); bufs.append(buf); firsts.append(first); cdfs.append(c); pdfs.append(pdf)
+            if not ps:
+                continue
+            # one multi-tensor launch (per <=48 tensors) for the whole group: step + p.grad rewrite for idx members
+            L.check(lib.alignq_sgd_step_multi(len(ps), L.ptr_array(ps), L.ptr_array(gs),
+                                              L.ptr_array(bufs) if mom != 0 else None,
+                                              L.i64_array([p.numel() for p in ps]), L.ptr_array(cdfs),
+                                              L.ptr_array(pdfs), L.i32_array(firsts), float(lr), float(mom),
+                                              float(damp), float(wd), int(bool(nest)), min(bitW, 30), float(lam),
+                                              float(lam2), st), "alignq_sgd_step_multi")
         return loss
 
 
 class ADMM_OPT(Optimizer):
     def __init__(self, params):
         super().__init__(params, dict())
-        self._tab_host = None      # pinned [3, S] int64
-        self._tab_dev = None
-        self._tab_key = None
-
-    def _tables(self, Dp: List[int], Ap: List[int], Gp: List[int], device):
-        key = (tuple(Dp), tuple(Ap), tuple(Gp))
-        S = len(Dp)
-        if self._tab_dev is None or self._tab_dev.shape[1] != S or self._tab_dev.device != device:
-            self._tab_host = torch.empty(3, S, dtype=torch.int64).pin_memory()
-            self._tab_dev = torch.empty(3, S, dtype=torch.int64, device=device)
-            self._tab_key = None
-        if key != self._tab_key:
-            self._tab_host.copy_(torch.tensor([Dp, Ap, Gp], dtype=torch.int64))
-            # pinned source: capturable as a memcpy node; outside capture make it blocking so the pinned
-            # buffer is never rewritten under an in-flight copy
-            self._tab_dev.copy_(self._tab_host, non_blocking=torch.cuda.is_current_stream_capturing())
-            self._tab_key = key
-        return self._tab_dev
 
     @torch.no_grad()
     def step(self, alterD_idx, gamma_idx, Ds, alterDs, gammas, mus, rhos, closure=None):
@@ -139,10 +127,7 @@ class ADMM_OPT(Optimizer):
                 raise NotImplementedError("alterD parameter without a following gamma parameter")
         st = L.stream_ptr()
         for (mu, rho, b, dim), sites in groups.items():
-            keep = [s[0] for s in sites]   # keep D tensors alive until the launch is enqueued
-            tab = self._tables([s[0].data_ptr() for s in sites], [s[1].data_ptr() for s in sites],
-                               [s[2].data_ptr() for s in sites], sites[0][1].device)
-            L.check(lib.alignq_admm_update(tab[0].data_ptr(), tab[1].data_ptr(), tab[2].data_ptr(), len(sites), b, dim,
-                                           mu, rho, st), "alignq_admm_update")
-            del keep
+            L.check(lib.alignq_admm_update(L.ptr_array([s_[0] for s_ in sites]), L.ptr_array([s_[1] for s_ in sites]),
+                                           L.ptr_array([s_[2] for s_ in sites]), len(sites), b, dim, mu, rho, st),
+                    "alignq_admm_update")
         return loss

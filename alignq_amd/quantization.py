@@ -64,6 +64,8 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
             self.w_bit = w_bit
             self.stage = stage
             self.uniform_q = uniform_quantize(k=w_bit)
+            self._formula = formula
+            self._pre = None      # (weight, q, cdf, pdf) parked by fused.prequantize_weights for the next call
 
         def forward(self, x):
             if self.w_bit == 32:
@@ -71,7 +73,11 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
                     self.weight_cdf = x
                     self.weight_q = x
                 return x
-            q, c, pdf = ops.WeightQuantFn.apply(x, self.w_bit, formula)
+            pre, self._pre = self._pre, None
+            if pre is not None and pre[0] is x:
+                q, c, pdf = pre[1], pre[2], pre[3]
+            else:
+                q, c, pdf = ops.WeightQuantFn.apply(x, self.w_bit, formula)
             if tree != "cdf":   # the CDF tree keeps these as locals (quantization.py:70-72)
                 self.weight_cdf, self.weight_pdf, self.weight_q = c, pdf, q
             else:

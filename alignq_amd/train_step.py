@@ -13,6 +13,7 @@ import torch
 import torch.nn.functional as F
 
 from . import config
+from .fused import prequantize_weights
 from .optimizer import ADMM_OPT, SGD
 
 
@@ -29,6 +30,7 @@ class TrainStep:
         self.alterD_idx = [j for j, (n, _) in enumerate(self.param_admm) if "alterD" in n]
         self.gamma_idx = [j for j, (n, _) in enumerate(self.param_admm) if "gamma" in n]
         self.convs = [c for layer in model.layers for c in (layer.conv0, layer.conv1, layer.skip_conv) if c is not None]
+        self.all_convs = [m for m in model.modules() if hasattr(m, "quantize_fn")]
         self.admms = []
         if self.param_admm:
             self.admms = [model.admm0]
@@ -47,6 +49,7 @@ class TrainStep:
         self.optimizer_t.zero_grad(set_to_none=set_to_none)
         if self.optimizer_admm is not None:
             self.optimizer_admm.zero_grad(set_to_none=set_to_none)
+        prequantize_weights(self.all_convs)     # all conv weights in two launches
         out = model(x)
         if isinstance(out, tuple):
             logits, trans_loss = out
@@ -105,12 +108,18 @@ class TrainStep:
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         self._graph2 = None
+        # inside the capture grads are re-created (set_to_none=True): no zero-fill and no accumulate-add per
+        # parameter; the fresh grad tensors live in the graph's private pool at fixed addresses and stay
+        # referenced by p.grad, so the captured optimizer kernels (and the eager all-reduce) see them on replay.
+        self.optimizer_t.zero_grad(set_to_none=True)
+        if self.optimizer_admm is not None:
+            self.optimizer_admm.zero_grad(set_to_none=True)
         if self.grad_hook is None:
             with torch.cuda.graph(graph):
-                outs = self._iteration(sx, sy, set_to_none=False)
+                outs = self._iteration(sx, sy, set_to_none=True)
         else:
             with torch.cuda.graph(graph):
-                outs = self._forward_backward(sx, sy, set_to_none=False)
+                outs = self._forward_backward(sx, sy, set_to_none=True)
             graph2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph2, pool=graph.pool()):
                 self._optimizer_steps()

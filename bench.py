@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true", help="skip the per-kernel roofline measurements")
     ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--miopen-benchmark", action="store_true", help="torch.backends.cudnn.benchmark (MIOpen find)")
     return ap.parse_args()
 
 
@@ -156,6 +157,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback in the product path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    torch.backends.cudnn.benchmark = bool(a.miopen_benchmark)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -109,8 +109,9 @@ int alignq_admm_loss(const float* D, int b, const float* alterD, const float* ga
                      void* stream);
 
 /* ---- R7: ADMM primal/dual update (utils/optimizer.py:97-124), batched over S sites ---------------
- * D_tab, alterD_tab, gamma_tab: DEVICE arrays of S device pointers; D_s is [b,b] (zero-padded to dim
- * as :104-105 does), alterD_s/gamma_s [dim,dim] updated in place:
+ * D_tab, alterD_tab, gamma_tab: HOST arrays of S DEVICE pointers (they are passed to the kernel by value,
+ * so the call is graph-capturable and needs no device-side table); D_s is [b,b] (zero-padded to dim as
+ * :104-105 does), alterD_s/gamma_s [dim,dim] are updated in place:
  *   V = pad(D)+gamma/rho; A = (1-(mu/rho)/|V|_F) V if |V|_F > mu/rho else 0; gamma += rho (pad(D)-A). */
 int alignq_admm_update(const float* const* D_tab, float* const* alterD_tab, float* const* gamma_tab,
                        int S, int b, int dim, float mu, float rho, void* stream);
@@ -124,6 +125,26 @@ int alignq_sgd_step(float* p, float* g, float* buf, int64_t n, float lr, float m
 /* grad_out = dir * sigmoid_d(transform(w_cdf)) * w_pdf for tensors in idx.                          */
 int alignq_sgd_grad_approx(const float* dir, const float* w_cdf, const float* w_pdf, float* grad_out,
                            int64_t n, int bitW, float lam, float lam2, void* stream);
+
+/* ---- multi-tensor forms: ALL conv weights / ALL parameters of a model in one or two launches -------
+ * Every `*_tab`/array argument is a HOST array of T entries (device pointers / sizes); entries travel to the
+ * kernels by value in chunks, so these calls are hipGraph-capturable.  Semantics per tensor are exactly those
+ * of the single-tensor entry points above.
+ * weight fwd: ms is a DEVICE float[T][2] output (mean, std per tensor); cdf_out/pdf_out may be NULL.
+ * ws: alignq_weight_multi_ws_bytes(T).                                                                 */
+size_t alignq_weight_multi_ws_bytes(int T);
+int alignq_weight_quant_fwd_multi(int T, const float* const* w, float* const* q, float* const* cdf_out,
+                                  float* const* pdf_out, const int64_t* n, float* ms, int k, int formula,
+                                  void* ws, void* stream);
+int alignq_weight_quant_bwd_multi(int T, const float* const* g, const float* const* w, const float* ms,
+                                  float* const* dw, const int64_t* n, void* ws, void* stream);
+/* SGD over T parameters (utils/optimizer.py:212-255): w_cdf[t]/w_pdf[t] non-NULL marks tensor t as a member
+ * of `idx` (its p.grad receives the sigmoid_d(transform(w_cdf))*w_pdf rewrite); first[t] != 0 marks a
+ * momentum buffer created in this step.                                                               */
+int alignq_sgd_step_multi(int T, float* const* p, float* const* g, float* const* buf, const int64_t* n,
+                          const float* const* w_cdf, const float* const* w_pdf, const int32_t* first, float lr,
+                          float mom, float damp, float wd, int nesterov, int bitW, float lam, float lam2,
+                          void* stream);
 
 #ifdef __cplusplus
 }
