@@ -32,9 +32,13 @@ SIGNATURES = {
     "alignq_site_fwd": (_i, [_vp, _i, _i64, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "alignq_site_partials": (_i, [_vp, _i, _i64, _i, _f, _f, _vp, _vp, _vp, _vp]),
     "alignq_site_reduce": (_i, [_vp, _i, _i64, _vp, _vp]),
-    "alignq_site_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _f, _f, _vp, _vp]),
+    "alignq_site_reduce_loss": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _i, _f, _f, _vp, _vp]),
+    "alignq_site_bwd_ws_bytes": (_sz, [_i]),
+    "alignq_site_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _f, _f, _vp, _vp, _vp]),
+    "alignq_site_bwd_fused": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _f, _vp, _vp, _vp, _i, _i64, _f, _f, _vp, _vp, _vp,
+                                   _vp, _vp]),
     "alignq_corr_fwd": (_i, [_vp, _i, _i64, _f, _vp, _vp, _vp, _vp]),
-    "alignq_corr_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _f, _vp, _vp]),
+    "alignq_corr_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _f, _vp, _vp, _vp]),
     "alignq_admm_ws_bytes": (_sz, [_i]),
     "alignq_admm_loss": (_i, [_vp, _i, _vp, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "alignq_admm_update": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _vp]),

@@ -191,3 +191,37 @@ __device__ __forceinline__ void block_sum2d(double& a, double& b, double* sm) {
 }
 
 }  // namespace alignq
+
+// ---- fast (non-bit-specified) helpers for BACKWARD kernels: results are tolerance-checked (1e-5) -------
+namespace alignq {
+
+// Abramowitz-Stegun 7.1.26, |abs err| <= 1.5e-7 (+ fast exp / rcp rounding); ~14 VALU ops.
+__device__ __forceinline__ float erf_fast(float x) {
+  const float a = fabsf(x);
+  const float t = __frcp_rn(__fmaf_rn(0.3275911f, a, 1.0f));
+  float p = 1.061405429f;
+  p = __fmaf_rn(p, t, -1.453152027f);
+  p = __fmaf_rn(p, t, 1.421413741f);
+  p = __fmaf_rn(p, t, -0.284496736f);
+  p = __fmaf_rn(p, t, 0.254829592f);
+  const float e = __expf(-a * a);
+  const float r = __fmaf_rn(-p * t, e, 1.0f);
+  return copysignf(r, x);
+}
+
+// t = r*(2*Phi(x)-1) = r*erf(x/sqrt(2)) and its derivative r*2*phi(x), sharing one exponential
+__device__ __forceinline__ void act_transform_fast(float x, float r, float* t, float* jac) {
+  const float z = x * 0.70710678118654752440f;
+  const float a = fabsf(z);
+  const float tt = __frcp_rn(__fmaf_rn(0.3275911f, a, 1.0f));
+  float p = 1.061405429f;
+  p = __fmaf_rn(p, tt, -1.453152027f);
+  p = __fmaf_rn(p, tt, 1.421413741f);
+  p = __fmaf_rn(p, tt, -0.284496736f);
+  p = __fmaf_rn(p, tt, 0.254829592f);
+  const float e = __expf(-a * a);               // = exp(-x^2/2)
+  *t = r * copysignf(__fmaf_rn(-p * tt, e, 1.0f), x);
+  *jac = r * ALIGNQ_TWO_OVER_SQRT_2PI * e;
+}
+
+}  // namespace alignq

@@ -1,0 +1,651 @@
+// site4_kernels.hip — the ADMM-site kernels for batches of 65..128 rows (the reference's train batch 128 and
+// eval batch 100) on gfx950, plus the slab reduction with its ADMM-loss epilogue and the backward "prep" kernel.
+//
+// Why a second set of kernels: at B=128 the Gram pair of one 64-feature tile is 1024 v_mfma_f32_32x32x2_f32
+// (6.8 us of one CU's matrix pipes) and the CDF transform is ~90 VALU ops per element; a 256-thread workgroup
+// (one wave per SIMD) runs load -> erf -> statistics -> LDS -> MFMA -> store as one serial chain (measured
+// 25 us forward / 52 us backward per launch).  Here a workgroup is 16 waves (4 per SIMD):
+//   forward : D is symmetric, so only the 10 upper-triangular 32x32 tiles are computed; the 20 work items
+//             (tile, K-half) are dealt to the 16 waves so that every SIMD gets exactly 5 items whatever the
+//             wave->SIMD rotation is (waves 0-3 take two items); the two K-halves of a tile are combined in
+//             LDS in a fixed order (deterministic) and the slab shrinks from 64 KB to 40 KB;
+//             small sites use 32- or 16-feature tiles so that all 256 CUs still get a tile.
+//   backward: 16 units (row block, operand, column block) -> one 32x32 accumulator per wave, S = sym(dD)*c as
+//             register-resident MFMA A fragments (prepared once per site by site_prep_kernel), the activation
+//             transform re-evaluated with a cheap 1.5e-7 erf (tolerance-checked, not bit-checked), output
+//             assembled in LDS and written back as full 256-byte rows.
+#include <hip/hip_runtime.h>
+
+#include "../../include/alignq.h"
+#include "alignq_math.h"
+#include "site_internal.h"
+
+using namespace alignq;
+
+namespace alignq_site {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int NT = 1024;
+
+__device__ __forceinline__ float4 ld4(const float* __restrict__ x, int64_t off, int col, int64_t F, bool row_ok,
+                                      bool aligned) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!row_ok) return v;
+  if (aligned) {
+    if (col < F) v = *reinterpret_cast<const float4*>(x + off);
+  } else {
+    if (col + 0 < F) v.x = x[off + 0];
+    if (col + 1 < F) v.y = x[off + 1];
+    if (col + 2 < F) v.z = x[off + 2];
+    if (col + 3 < F) v.w = x[off + 3];
+  }
+  return v;
+}
+
+__device__ __forceinline__ void st4(float* __restrict__ y, int64_t off, int col, int64_t F, bool row_ok, bool aligned,
+                                    float4 v) {
+  if (!row_ok) return;
+  if (aligned) {
+    if (col < F) *reinterpret_cast<float4*>(y + off) = v;
+  } else {
+    if (col + 0 < F) y[off + 0] = v.x;
+    if (col + 1 < F) y[off + 1] = v.y;
+    if (col + 2 < F) y[off + 2] = v.z;
+    if (col + 3 < F) y[off + 3] = v.w;
+  }
+}
+
+// upper-triangular tile index -> (I, J), I <= J, order (0,0)(0,1)(0,2)(0,3)(1,1)(1,2)(1,3)(2,2)(2,3)(3,3)
+__device__ __forceinline__ void tile_ij(int tile, int& I, int& J) {
+  int t = tile;
+  I = 0;
+  while (t >= 4 - I) { t -= 4 - I; I++; }
+  J = I + t;
+}
+
+// ================================================================================================ forward
+template <int TFv, bool PAIR>
+__global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__ x, int B, int64_t F, int k, float r,
+                                                       float eps, float* __restrict__ xq, float* __restrict__ slabs,
+                                                       float* __restrict__ stats, int n_tiles, int aligned,
+                                                       unsigned* __restrict__ counter) {
+  constexpr int LDv = TFv + 1;
+  constexpr int LPR = TFv / 4;                    // lanes per row (float4 each)
+  constexpr int RG = NT / LPR;                    // row groups: 64 / 128 / 256
+  constexpr int RJ = (128 + RG - 1) / RG;         // rows per thread: 2 / 1 / 1
+  constexpr int NOP = PAIR ? 2 : 1;
+  constexpr int TILE = 128 * LDv;
+  constexpr int STAGE = (2 * TILE > 10240) ? 2 * TILE : 10240;
+  __shared__ __attribute__((aligned(16))) float lds[STAGE + 4 * TFv + 2 * 16 * TFv];
+  float* Xs = lds;
+  float* Ts = lds + TILE;
+  float* colv = lds + STAGE;                      // mean_x, rho_x, mean_t, rho_t : [4][TFv]
+  float* red = colv + 4 * TFv;                    // [2 operands][16 waves][TFv]
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c = tid % LPR, rg = tid / LPR;
+  const int h = lane >> 5, l31 = lane & 31;
+  const float nlev = (float)((1 << (k & 31)) - 1);
+  const float invB = 1.0f / (float)B, invBm1 = 1.0f / (float)(B - 1);
+
+  if (blockIdx.x == 0 && tid == 0 && counter) *counter = 0u;   // arrival counter of the reduce kernel's epilogue
+
+  // work items of this wave: q = w (all waves) and q = 16 + w (waves 0..3); item q = (tile q%10, K-half q/10)
+  const int tile0 = w % 10, kh0 = w / 10;
+  const int tile1 = 6 + w;                        // only meaningful for w < 4 (K-half 1)
+  int I0, J0, I1 = 0, J1 = 0;
+  tile_ij(tile0, I0, J0);
+  if (w < 4) tile_ij(tile1, I1, J1);
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int e = 0; e < 16; e++) { acc0[e] = 0.0f; acc1[e] = 0.0f; }
+
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int col0 = tile * TFv;
+    const int col = col0 + 4 * c;
+    float4 xv[RJ], tv[RJ];
+    // ---- load + transform + quantise ----------------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < RJ; j++) {
+      const int row = rg + RG * j;
+      const bool ok = row < B;
+      const int64_t off = (int64_t)row * F + col;
+      xv[j] = ld4(x, off, col, F, ok, aligned);
+      tv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (PAIR) {
+        float4 q;
+        float b;
+        q.x = act_quant1<0>(xv[j].x, k, nlev, r, &tv[j].x, &b);
+        q.y = act_quant1<0>(xv[j].y, k, nlev, r, &tv[j].y, &b);
+        q.z = act_quant1<0>(xv[j].z, k, nlev, r, &tv[j].z, &b);
+        q.w = act_quant1<0>(xv[j].w, k, nlev, r, &tv[j].w, &b);
+        if (xq) st4(xq, off, col, F, ok, aligned, q);
+      }
+    }
+    // ---- column means: registers -> wave shuffles over the row groups of the wave -> LDS over waves ----
+    {
+      float sx[4] = {0, 0, 0, 0}, st[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < RJ; j++) {
+        if (rg + RG * j < B) {
+          sx[0] += xv[j].x; sx[1] += xv[j].y; sx[2] += xv[j].z; sx[3] += xv[j].w;
+          if (PAIR) { st[0] += tv[j].x; st[1] += tv[j].y; st[2] += tv[j].z; st[3] += tv[j].w; }
+        }
+      }
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          sx[e] += __shfl_xor(sx[e], o, 64);
+          if (PAIR) st[e] += __shfl_xor(st[e], o, 64);
+        }
+      }
+      if (lane < LPR) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          red[w * TFv + 4 * c + e] = sx[e];
+          if (PAIR) red[16 * TFv + w * TFv + 4 * c + e] = st[e];
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < NOP * TFv) {
+      const int op = tid / TFv, cc = tid % TFv;
+      float s = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; g++) s += red[op * 16 * TFv + g * TFv + cc];
+      colv[(2 * op) * TFv + cc] = s * invB;
+    }
+    __syncthreads();
+    // ---- column variances (two-pass) --------------------------------------------------------------
+    {
+      float mx[4], mt[4], sx[4] = {0, 0, 0, 0}, st[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int e = 0; e < 4; e++) { mx[e] = colv[4 * c + e]; mt[e] = PAIR ? colv[2 * TFv + 4 * c + e] : 0.f; }
+#pragma unroll
+      for (int j = 0; j < RJ; j++) {
+        if (rg + RG * j < B) {
+          const float xe[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
+          const float te[4] = {tv[j].x, tv[j].y, tv[j].z, tv[j].w};
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            float d = xe[e] - mx[e];
+            sx[e] += d * d;
+            if (PAIR) { d = te[e] - mt[e]; st[e] += d * d; }
+          }
+        }
+      }
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          sx[e] += __shfl_xor(sx[e], o, 64);
+          if (PAIR) st[e] += __shfl_xor(st[e], o, 64);
+        }
+      }
+      if (lane < LPR) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          red[w * TFv + 4 * c + e] = sx[e];
+          if (PAIR) red[16 * TFv + w * TFv + 4 * c + e] = st[e];
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < NOP * TFv) {
+      const int op = tid / TFv, cc = tid % TFv;
+      float s = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; g++) s += red[op * 16 * TFv + g * TFv + cc];
+      const float sd = sqrtf(s * invBm1);
+      const float rho = 1.0f / (sd + eps);
+      colv[(2 * op + 1) * TFv + cc] = rho;
+      if (stats && col0 + cc < F) {
+        stats[(int64_t)(2 * op) * F + col0 + cc] = colv[(2 * op) * TFv + cc];
+        stats[(int64_t)(2 * op + 1) * F + col0 + cc] = rho;
+      }
+    }
+    __syncthreads();
+    // ---- standardise into LDS ---------------------------------------------------------------------
+    {
+      float mx[4], rx[4], mt[4], rt[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        mx[e] = colv[4 * c + e];
+        rx[e] = colv[TFv + 4 * c + e];
+        mt[e] = PAIR ? colv[2 * TFv + 4 * c + e] : 0.f;
+        rt[e] = PAIR ? colv[3 * TFv + 4 * c + e] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < RJ; j++) {
+        const int row = rg + RG * j;
+        if (row < 128) {
+          const bool ok = row < B;
+          const float xe[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
+          const float te[4] = {tv[j].x, tv[j].y, tv[j].z, tv[j].w};
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const bool okc = ok && (col + e < F);
+            Xs[row * LDv + 4 * c + e] = okc ? (xe[e] - mx[e]) * rx[e] : 0.0f;
+            if (PAIR) Ts[row * LDv + 4 * c + e] = okc ? (te[e] - mt[e]) * rt[e] : 0.0f;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- MFMA: upper-triangular tiles of  Th Th^T - Xh Xh^T  over this tile's features ----------------
+    {
+      const int ra = (I0 * 32 + l31) * LDv + h, rb = (J0 * 32 + l31) * LDv + h;
+#pragma unroll 4
+      for (int k0 = kh0 * (TFv / 2); k0 < (kh0 + 1) * (TFv / 2); k0 += 2) {
+        const float ax = Xs[ra + k0], bx = Xs[rb + k0];
+        if (PAIR) {
+          const float at = Ts[ra + k0], bt = Ts[rb + k0];
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(at, bt, acc0, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(-ax, bx, acc0, 0, 0, 0);
+        } else {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ax, bx, acc0, 0, 0, 0);
+        }
+      }
+      if (w < 4) {
+        const int ra1 = (I1 * 32 + l31) * LDv + h, rb1 = (J1 * 32 + l31) * LDv + h;
+#pragma unroll 4
+        for (int k0 = TFv / 2; k0 < TFv; k0 += 2) {
+          const float ax = Xs[ra1 + k0], bx = Xs[rb1 + k0];
+          if (PAIR) {
+            const float at = Ts[ra1 + k0], bt = Ts[rb1 + k0];
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(at, bt, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(-ax, bx, acc1, 0, 0, 0);
+          } else {
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ax, bx, acc1, 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();   // LDS tiles are overwritten by the next iteration / by the combine below
+  }
+
+  // ---- combine the two K-halves of every tile in LDS (fixed order => deterministic), write the slab -----
+  float* C = lds;   // [10][32][32]
+  if (kh0 == 0) {
+#pragma unroll
+    for (int e = 0; e < 16; e++) C[tile0 * 1024 + ((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + l31] = acc0[e];
+  }
+  __syncthreads();
+  if (kh0 == 1) {
+#pragma unroll
+    for (int e = 0; e < 16; e++) C[tile0 * 1024 + ((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + l31] += acc0[e];
+  }
+  if (w < 4) {
+#pragma unroll
+    for (int e = 0; e < 16; e++) C[tile1 * 1024 + ((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + l31] += acc1[e];
+  }
+  __syncthreads();
+  float4* slab4 = reinterpret_cast<float4*>(slabs + (int64_t)blockIdx.x * 10240);
+  const float4* C4 = reinterpret_cast<const float4*>(C);
+  for (int e = tid; e < 2560; e += NT) slab4[e] = C4[e];
+}
+
+// ================================================================================================ reduce
+// out[i][j] = scale * sum_s slab[s](i,j), i,j < B.  1024 threads = 16 slab groups x 64 elements.
+// SYM : slabs hold the 10 upper-triangular tiles (site4 geometry) instead of a full BPxBP matrix.
+// LOSS: additionally the ADMM loss scalar (utils/admm.py:24-33) through a last-block epilogue:
+//       scal = {loss, c_con = rho/2/(n*rms), 1/n, rms}.
+template <bool SYM, bool LOSS>
+__global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restrict__ slabs, int n_slabs,
+                                                           int slab_floats, int BP, int B, float scale,
+                                                           float* __restrict__ out, const float* __restrict__ A,
+                                                           const float* __restrict__ gamma, int dim, float mu,
+                                                           float rho, float* __restrict__ parts,
+                                                           unsigned* __restrict__ counter, float* __restrict__ scal) {
+  __shared__ float part[16][64];
+  __shared__ double fin[48];
+  __shared__ int is_last;
+  const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + lane;
+  const bool ok = e < B * B;
+  const int i = ok ? e / B : 0, j = ok ? e - i * B : 0;
+  int off;
+  if (SYM) {
+    int ii = i, jj = j;
+    if ((ii >> 5) > (jj >> 5)) { ii = j; jj = i; }
+    const int I = ii >> 5, J = jj >> 5;
+    off = (I * 4 - (I * (I - 1)) / 2 + (J - I)) * 1024 + (ii & 31) * 32 + (jj & 31);
+  } else {
+    off = i * BP + j;
+  }
+  const float* p = slabs + off;
+  float s = 0.f;
+  if (ok) {
+#pragma unroll 4
+    for (int sl = sg; sl < n_slabs; sl += 16) s += p[(int64_t)sl * slab_floats];
+  }
+  part[sg][lane] = s;
+  __syncthreads();
+  if (sg == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; g++) t += part[g][lane];
+    const float d = t * scale;
+    if (ok) out[e] = d;
+    if (LOSS) {
+      float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+      if (ok) {
+        const float a = A[i * dim + j], gm = gamma[i * dim + j];
+        const float dd = d - a;
+        v0 = fabsf(a);
+        v1 = dd * dd;
+        v2 = gm * fabsf(dd);
+      }
+      v0 = wave_sum(v0);
+      v1 = wave_sum(v1);
+      v2 = wave_sum(v2);
+      if (lane == 0) {
+        parts[blockIdx.x * 4 + 0] = v0;
+        parts[blockIdx.x * 4 + 1] = v1;
+        parts[blockIdx.x * 4 + 2] = v2;
+        // publish the partial (own store) then take a ticket; the last arriver acquires and finishes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned tk = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (tk == gridDim.x - 1);
+        if (last) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        is_last = last;
+      }
+    }
+  }
+  if (!LOSS) return;
+  __syncthreads();
+  if (!is_last) return;
+  double s0 = 0, s1 = 0, s2 = 0;
+  if ((int)threadIdx.x < (int)gridDim.x) {
+    s0 = parts[threadIdx.x * 4 + 0];
+    s1 = parts[threadIdx.x * 4 + 1];
+    s2 = parts[threadIdx.x * 4 + 2];
+  }
+  s0 = wave_sum_d(s0);
+  s1 = wave_sum_d(s1);
+  s2 = wave_sum_d(s2);
+  if (lane == 0) { fin[sg] = s0; fin[16 + sg] = s1; fin[32 + sg] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a0 = 0, a1 = 0, a2 = 0;
+    for (int g = 0; g < 16; g++) { a0 += fin[g]; a1 += fin[16 + g]; a2 += fin[32 + g]; }
+    const double n = (double)B * (double)B;
+    const double rms = sqrt(a1 / n);
+    scal[0] = (float)(mu * a0 / n + 0.5 * rho * rms + a2 / n);
+    scal[1] = (float)(0.5 * rho / (n * rms));
+    scal[2] = (float)(1.0 / n);
+    scal[3] = (float)rms;
+  }
+}
+
+// ================================================================================================ backward prep
+// S = (gD + gD^T) * gscale / F  [B,B]   (MFMA A operand of the backward), and (FUSED) the scaled parameter
+// gradients dA_out = gscale*(mu*sign(A)/n - gD), dG_out = gscale*|D-A|/n  (zero outside [:B,:B]).
+//   FUSED : gD = c_con*(D-A) + gamma*sign(D-A)/n from the forward's scal = {loss, c_con, 1/n, rms}
+//   !FUSED: gD = dD (explicit upstream gradient)
+template <bool FUSED>
+__global__ __launch_bounds__(256) void site_prep_kernel(const float* __restrict__ dD, const float* __restrict__ D,
+                                                        const float* __restrict__ A, const float* __restrict__ gamma,
+                                                        int dim, const float* __restrict__ scal, float mu,
+                                                        const float* __restrict__ gscale, int B, float invF,
+                                                        float* __restrict__ S, float* __restrict__ dA_out,
+                                                        float* __restrict__ dG_out) {
+  const float gs = gscale ? gscale[0] : 1.0f;
+  const int total = FUSED ? dim * dim : B * B;
+  const int side = FUSED ? dim : B;
+  const float c_con = FUSED ? scal[1] : 0.f, inv_n = FUSED ? scal[2] : 0.f;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int i = e / side, j = e - i * side;
+    if (i < B && j < B) {
+      float gij, gji;
+      if (FUSED) {
+        const float a = A[i * dim + j], gm = gamma[i * dim + j];
+        const float d = D[i * B + j] - a;
+        gij = c_con * d + gm * (float)((d > 0.f) - (d < 0.f)) * inv_n;
+        const float a2 = A[j * dim + i], gm2 = gamma[j * dim + i];
+        const float d2 = D[j * B + i] - a2;
+        gji = c_con * d2 + gm2 * (float)((d2 > 0.f) - (d2 < 0.f)) * inv_n;
+        if (dA_out) dA_out[e] = gs * (mu * (float)((a > 0.f) - (a < 0.f)) * inv_n - gij);
+        if (dG_out) dG_out[e] = gs * fabsf(d) * inv_n;
+      } else {
+        gij = dD[i * B + j];
+        gji = dD[j * B + i];
+      }
+      S[i * B + j] = (gij + gji) * gs * invF;
+    } else if (FUSED) {
+      if (dA_out) dA_out[e] = 0.f;
+      if (dG_out) dG_out[e] = 0.f;
+    }
+  }
+}
+
+// ================================================================================================ backward
+// wave w: row block I = w>>2, operand op = (w>>1)&1 (0: x, 1: t), column block cj = w&1 of the 64-feature tile
+template <bool PAIR>
+__global__ __launch_bounds__(NT) void site_bwd4_kernel(const float* __restrict__ gup, const float* __restrict__ S,
+                                                       const float* __restrict__ x, const float* __restrict__ stats,
+                                                       int B, int64_t F, float r, float eps, float* __restrict__ dx,
+                                                       int n_tiles, int aligned) {
+  constexpr int TFv = 64, LDv = 65, TILE = 128 * LDv;
+  constexpr int NARR = PAIR ? 4 : 2;
+  __shared__ __attribute__((aligned(16))) float lds[NARR * TILE + 4 * TFv + 4 * 2 * 2 * TFv];
+  float* Xs = lds;                         // standardised x
+  float* Os = lds + TILE;                  // output staging (PAIR: starts as g*jac)
+  float* Ts = lds + 2 * TILE;              // standardised t            (PAIR)
+  float* Js = lds + 3 * TILE;              // dt/dx                     (PAIR)
+  float* colv = lds + NARR * TILE;         // mean_x, rho_x, mean_t, rho_t [4][64]
+  float* red = colv + 4 * TFv;             // [4 row blocks][2 operands][2][64]
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c = tid & 15, rg = tid >> 4;   // load mapping: 16 lanes per row, 64 row groups, rows rg and rg+64
+  const int h = lane >> 5, l31 = lane & 31;
+  const int I = w >> 2, op = (w >> 1) & 1, cj = w & 1;
+  const bool mfma_wave = PAIR || op == 0;
+  const int cc = cj * 32 + l31;            // this lane's feature column inside the tile (accumulator layout)
+
+  // S fragments (symmetric, already scaled): A[i][k] = S[k][i], i = I*32 + l31, k = 2s + h  -> coalesced in i
+  float sfrag[64];
+  {
+    const int i = I * 32 + l31;
+#pragma unroll
+    for (int s = 0; s < 64; s++) {
+      const int kk = 2 * s + h;
+      sfrag[s] = (mfma_wave && i < B && kk < B) ? S[kk * B + i] : 0.0f;
+    }
+  }
+  const float invB = 1.0f / (float)B, invBm1 = 1.0f / (float)(B - 1);
+
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int col0 = tile * TFv;
+    const int col = col0 + 4 * c;
+    if (tid < (PAIR ? 4 : 2) * TFv) {
+      const int a = tid >> 6, q = tid & 63;
+      colv[a * TFv + q] = (col0 + q < F) ? stats[(int64_t)a * F + col0 + q] : 0.0f;
+    }
+    __syncthreads();
+    // ---- load x (and g), recompute t / jac, standardise into LDS ------------------------------------
+    {
+      float mx[4], rx[4], mt[4], rt[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        mx[e] = colv[4 * c + e];
+        rx[e] = colv[TFv + 4 * c + e];
+        mt[e] = PAIR ? colv[2 * TFv + 4 * c + e] : 0.f;
+        rt[e] = PAIR ? colv[3 * TFv + 4 * c + e] : 0.f;
+      }
+#pragma unroll 1
+      for (int j = 0; j < 2; j++) {
+        const int row = rg + 64 * j;
+        const bool ok = row < B;
+        const int64_t off = (int64_t)row * F + col;
+        const float4 xv = ld4(x, off, col, F, ok, aligned);
+        float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (PAIR && gup) gv = ld4(gup, off, col, F, ok, aligned);
+        const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
+        const float ge[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const bool okc = ok && (col + e < F);
+          const int a = row * LDv + 4 * c + e;
+          Xs[a] = okc ? (xe[e] - mx[e]) * rx[e] : 0.0f;
+          if (PAIR) {
+            float t, jac;
+            act_transform_fast(xe[e], r, &t, &jac);
+            Ts[a] = okc ? (t - mt[e]) * rt[e] : 0.0f;
+            Js[a] = jac;
+            Os[a] = ge[e] * jac;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- MFMA: acc = S[I-block, :] * {Xh|Th}[:, column block] ---------------------------------------
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[e] = 0.0f;
+    const float* src = (PAIR && op) ? Ts : Xs;
+    if (mfma_wave) {
+#pragma unroll
+      for (int s = 0; s < 64; s++)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sfrag[s], src[(2 * s + h) * LDv + cc], acc, 0, 0, 0);
+      // projections over this wave's 32 batch rows
+      float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int row = I * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        p0 += acc[e];
+        p1 += acc[e] * src[row * LDv + cc];
+      }
+      p0 += __shfl_xor(p0, 32, 64);
+      p1 += __shfl_xor(p1, 32, 64);
+      if (h == 0) {
+        red[((I * 2 + op) * 2 + 0) * TFv + cc] = p0;
+        red[((I * 2 + op) * 2 + 1) * TFv + cc] = p1;
+      }
+    }
+    __syncthreads();
+    // ---- own-input contribution: rho * (acc - mean_b - vh * proj) -----------------------------------
+    if (mfma_wave) {
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int rb = 0; rb < 4; rb++) {
+        s0 += red[((rb * 2 + op) * 2 + 0) * TFv + cc];
+        s1 += red[((rb * 2 + op) * 2 + 1) * TFv + cc];
+      }
+      const float rho = colv[(2 * op + 1) * TFv + cc];
+      float kap = 1.0f;   // (sd+eps)/sd = 1/(1-eps*rho); torch's std backward is 0 where sd == 0
+      if (eps != 0.0f) { const float den = 1.0f - eps * rho; kap = (den > 1e-12f) ? 1.0f / den : 0.0f; }
+      const float mean_d = s0 * invB, proj = s1 * invBm1 * kap;
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int row = I * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        acc[e] = rho * (acc[e] - mean_d - src[row * LDv + cc] * proj);
+      }
+    }
+    // phase A: x-operand waves.  PAIR: corr(x,x) enters D with a minus sign.  !PAIR: it is the result.
+    if (op == 0) {
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int a = (I * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LDv + cc;
+        if (PAIR) Os[a] -= acc[e];
+        else Os[a] = acc[e];
+      }
+    }
+    if (PAIR) {
+      __syncthreads();
+      // phase B: t-operand waves add their contribution chained through dt/dx
+      if (op == 1) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          const int a = (I * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LDv + cc;
+          Os[a] += acc[e] * Js[a];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- copy out: full 256-byte rows ---------------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int row = rg + 64 * j;
+      const int a = row * LDv + 4 * c;
+      const float4 o = make_float4(Os[a], Os[a + 1], Os[a + 2], Os[a + 3]);
+      st4(dx, (int64_t)row * F + col, col, F, row < B, aligned, o);
+    }
+    __syncthreads();   // LDS is overwritten by the next tile
+  }
+}
+
+#define RET_ON_ERR()                                  \
+  do {                                                \
+    hipError_t e__ = hipGetLastError();               \
+    if (e__ != hipSuccess) return (int)e__;           \
+  } while (0)
+
+}  // namespace
+
+int launch_partials4(bool pair, const Geom& g, const float* x, int B, int64_t F, int k, float r, float eps, float* xq,
+                     float* stats, float* ws, hipStream_t st) {
+  const int aligned = ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
+                      (!xq || (reinterpret_cast<uintptr_t>(xq) & 15) == 0);
+  unsigned* counter = reinterpret_cast<unsigned*>(ws + (size_t)g.grid * g.slab_floats + kPartFloats);
+#define L4(TFV, P) hipLaunchKernelGGL((site_fwd4_kernel<TFV, P>), g.grid, NT, 0, st, x, B, F, k, r, eps, xq, ws, stats, g.n_tiles, aligned, counter)
+  if (pair) {
+    if (g.tf == 64) L4(64, true); else if (g.tf == 32) L4(32, true); else L4(16, true);
+  } else {
+    if (g.tf == 64) L4(64, false); else if (g.tf == 32) L4(32, false); else L4(16, false);
+  }
+#undef L4
+  RET_ON_ERR();
+  return 0;
+}
+
+int launch_reduce_any(const Geom& g, const float* ws_c, float* ws_mut, int B, int64_t F, float* out, bool with_loss,
+                      const float* alterD, const float* gamma, int dim, float mu, float rho, float* scal,
+                      hipStream_t st) {
+  const int BP = 32 * g.nb;
+  const int blocks = (B * B + 63) / 64;
+  float* parts = ws_mut ? ws_mut + (size_t)g.grid * g.slab_floats : nullptr;
+  unsigned* counter = ws_mut ? reinterpret_cast<unsigned*>(ws_mut + (size_t)g.grid * g.slab_floats + kPartFloats) : nullptr;
+  const float scale = 1.0f / (float)F;
+#define LR(SYM, LOSS) hipLaunchKernelGGL((slab_reduce_kernel<SYM, LOSS>), blocks, 1024, 0, st, ws_c, g.grid, g.slab_floats, BP, B, scale, out, alterD, gamma, dim, mu, rho, parts, counter, scal)
+  if (g.nb == 4) { if (with_loss) LR(true, true); else LR(true, false); }
+  else { if (with_loss) LR(false, true); else LR(false, false); }
+#undef LR
+  RET_ON_ERR();
+  return 0;
+}
+
+int launch_prep(bool fused, const float* dD, const float* D, const float* alterD, const float* gamma, int dim,
+                const float* scal, float mu, const float* gscale, int B, int64_t F, float* S, float* dA_out,
+                float* dG_out, hipStream_t st) {
+  const int total = fused ? dim * dim : B * B;
+  const int blocks = (total + 255) / 256;
+  const float invF = 1.0f / (float)F;
+  if (fused)
+    hipLaunchKernelGGL((site_prep_kernel<true>), blocks, 256, 0, st, dD, D, alterD, gamma, dim, scal, mu, gscale, B, invF, S, dA_out, dG_out);
+  else
+    hipLaunchKernelGGL((site_prep_kernel<false>), blocks, 256, 0, st, dD, D, alterD, gamma, dim, scal, mu, gscale, B, invF, S, dA_out, dG_out);
+  RET_ON_ERR();
+  return 0;
+}
+
+int launch_bwd4(bool pair, const Geom& g, const float* gup, const float* S, const float* x, const float* stats, int B,
+                int64_t F, float r, float eps, float* dx, hipStream_t st) {
+  (void)g;
+  const int n_tiles = (int)((F + 63) / 64);
+  const int grid = n_tiles < 2048 ? n_tiles : 2048;
+  const int aligned = ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(dx) & 15) == 0) && (!gup || (reinterpret_cast<uintptr_t>(gup) & 15) == 0);
+  if (pair) hipLaunchKernelGGL((site_bwd4_kernel<true>), grid, NT, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_tiles, aligned);
+  else hipLaunchKernelGGL((site_bwd4_kernel<false>), grid, NT, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_tiles, aligned);
+  RET_ON_ERR();
+  return 0;
+}
+
+}  // namespace alignq_site

@@ -1,0 +1,55 @@
+// site_internal.h — geometry and launcher declarations shared by site_kernels.hip (generic B<=64 kernels,
+// C ABI) and site4_kernels.hip (the B in (64,128] kernels: 1024-thread workgroups, symmetric tiles).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace alignq_site {
+
+// Workspace layout (floats): [grid * slab_floats partial slabs][kPartFloats loss partials][counter, pad]
+constexpr int kPartFloats = 1024;   // up to 256 blocks x 4 floats of ADMM-loss partial sums
+constexpr int kTailFloats = kPartFloats + 16;
+
+struct Geom {
+  int nb;           // 32-row blocks: 1, 2 (generic kernels) or 4 (site4 kernels)
+  int tf;           // features per tile
+  int n_tiles;
+  int grid;         // workgroups of the partials kernel == number of slabs
+  int slab_floats;  // nb<4: BP*BP (full matrix);  nb==4: 10 upper-triangular 32x32 tiles
+};
+
+inline Geom geom(int B, int64_t F) {
+  Geom g;
+  g.nb = B <= 32 ? 1 : (B <= 64 ? 2 : 4);
+  if (g.nb == 4) {
+    // keep >= 256 tiles (one per CU) when the site is small: 64 -> 32 -> 16 features per tile
+    g.tf = (F >= 64 * 256) ? 64 : ((F >= 32 * 256) ? 32 : 16);
+    g.n_tiles = (int)((F + g.tf - 1) / g.tf);
+    g.grid = g.n_tiles < 256 ? g.n_tiles : 256;
+    g.slab_floats = 10 * 1024;
+  } else {
+    g.tf = 64;
+    g.n_tiles = (int)((F + 63) / 64);
+    g.grid = g.n_tiles < 512 ? g.n_tiles : 512;
+    g.slab_floats = (32 * g.nb) * (32 * g.nb);
+  }
+  return g;
+}
+
+inline size_t ws_floats(const Geom& g) { return (size_t)g.grid * g.slab_floats + kTailFloats; }
+
+// ---- launchers defined in site4_kernels.hip ----------------------------------------------------------------
+int launch_partials4(bool pair, const Geom& g, const float* x, int B, int64_t F, int k, float r, float eps, float* xq,
+                     float* stats, float* ws, hipStream_t st);
+int launch_bwd4(bool pair, const Geom& g, const float* gup, const float* S, const float* x, const float* stats, int B,
+                int64_t F, float r, float eps, float* dx, hipStream_t st);
+// S = sym(gD) * gscale / F (and, fused, the scaled ADMM parameter gradients) — first launch of every backward
+int launch_prep(bool fused, const float* dD, const float* D, const float* alterD, const float* gamma, int dim,
+                const float* scal, float mu, const float* gscale, int B, int64_t F, float* S, float* dA_out,
+                float* dG_out, hipStream_t st);
+// slab reduction for both geometries (+ optional ADMM-loss scalar through a last-block epilogue)
+int launch_reduce_any(const Geom& g, const float* ws_c, float* ws_mut, int B, int64_t F, float* out, bool with_loss,
+                      const float* alterD, const float* gamma, int dim, float mu, float rho, float* scal,
+                      hipStream_t st);
+
+}  // namespace alignq_site

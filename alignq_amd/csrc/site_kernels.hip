@@ -21,8 +21,10 @@
 
 #include "../../include/alignq.h"
 #include "alignq_math.h"
+#include "site_internal.h"
 
 using namespace alignq;
+using namespace alignq_site;
 
 namespace {
 
@@ -31,8 +33,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int TF = 64;        // features per tile
 constexpr int LD = TF + 1;    // LDS row stride in floats
 constexpr int kThreads = 256;
-constexpr int kMaxGridFwd = 256;   // slabs (K-splits) per site for NB=4 (one workgroup per CU)
-constexpr int kMaxGridSmall = 512; // for NB<4
 
 __device__ __forceinline__ float4 load4(const float* __restrict__ x, int64_t off, int col, int64_t F, bool row_ok,
                                         bool aligned) {
@@ -70,7 +70,7 @@ template <int NB, bool PAIR>
 __global__ __launch_bounds__(kThreads) void site_fwd_kernel(const float* __restrict__ x, int B, int64_t F, int k,
                                                             float r, float eps, float* __restrict__ xq,
                                                             float* __restrict__ slabs, float* __restrict__ stats,
-                                                            int n_tiles, int aligned) {
+                                                            int n_tiles, int aligned, unsigned* __restrict__ counter) {
   constexpr int BP = 32 * NB;
   constexpr int RJ = BP / 16;                 // rows per thread in the load mapping
   constexpr int NOP = PAIR ? 2 : 1;           // operands staged in LDS (x, t)
@@ -88,6 +88,7 @@ __global__ __launch_bounds__(kThreads) void site_fwd_kernel(const float* __restr
   const int h = lane >> 5, l31 = lane & 31;
   const float nlev = (float)((1 << (k & 31)) - 1);
   const float invB = 1.0f / (float)B, invBm1 = 1.0f / (float)(B - 1);
+  if (blockIdx.x == 0 && tid == 0 && counter) *counter = 0u;   // arrival counter of the reduce epilogue
 
   // wave -> output tiles
   const int wr = (NB == 1) ? 0 : (w >> 1), wc = (NB == 1) ? 0 : (w & 1);
@@ -277,32 +278,6 @@ __global__ __launch_bounds__(kThreads) void site_fwd_kernel(const float* __restr
 }
 
 // ================================================================================================
-// slab reduction: out[i][j] = scale * sum_s slab[s][i][j],  i,j < B.  1024 threads = 16 slab groups x 64 elems
-__global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restrict__ slabs, int n_slabs, int BP,
-                                                           int B, float scale, float* __restrict__ out) {
-  __shared__ float part[16][64];
-  const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + lane;
-  const bool ok = e < B * B;
-  const int i = ok ? e / B : 0, j = ok ? e - i * B : 0;
-  const float* p = slabs + (int64_t)i * BP + j;
-  const int64_t sstride = (int64_t)BP * BP;
-  float s = 0.f;
-  if (ok) {
-#pragma unroll 4
-    for (int sl = sg; sl < n_slabs; sl += 16) s += p[(int64_t)sl * sstride];
-  }
-  part[sg][lane] = s;
-  __syncthreads();
-  if (sg == 0 && ok) {
-    float t = 0.f;
-#pragma unroll
-    for (int g = 0; g < 16; g++) t += part[g][lane];
-    out[e] = t * scale;
-  }
-}
-
-// ================================================================================================
 // backward.  dx = g*jac + jac * d(corr(t,t))/dt [with +dD] + d(corr(x,x))/dx [with -dD]      (PAIR)
 //            dx = d(corr(x,x))/dx [with +dG]                                                   (!PAIR)
 // Wave w owns output row block I (32 batch rows) and PX column blocks of 32 features; for every owned
@@ -311,8 +286,7 @@ __global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restri
 //   NB=2: I = w>>1, column block  w&1
 //   NB=1: I = 0,    column block  w (waves 0,1; waves 2,3 only help with loads and LDS staging)
 template <int NB, bool PAIR>
-__global__ __launch_bounds__(kThreads) void site_bwd_kernel(const float* __restrict__ g, const float* __restrict__ dD,
-                                                            const float* __restrict__ dD_scale,
+__global__ __launch_bounds__(kThreads) void site_bwd_kernel(const float* __restrict__ g, const float* __restrict__ S,
                                                             const float* __restrict__ x,
                                                             const float* __restrict__ stats, int B, int64_t F, float r,
                                                             float eps, float* __restrict__ dx, int n_tiles,
@@ -335,17 +309,15 @@ __global__ __launch_bounds__(kThreads) void site_bwd_kernel(const float* __restr
   const int I = (NB == 4) ? w : (NB == 2 ? (w >> 1) : 0);
   const bool wave_active = (NB != 1) || (w < 2);
 
-  // S fragments (MFMA A operand): A[i][k] = (dD[i][k] + dD[k][i]) * scale / F,  i = I*32 + l31, k = 2*s + h
+  // S fragments (MFMA A operand): S = sym(dD)*scale/F prepared by site_prep_kernel (symmetric => read as S[k][i],
+  // coalesced in i):  A[i][k], i = I*32 + l31, k = 2*s + h
   float sfrag[KSTEPS];
   {
-    const float sc = (dD_scale ? dD_scale[0] : 1.0f) / (float)F;
     const int i = I * 32 + l31;
 #pragma unroll
     for (int s = 0; s < KSTEPS; s++) {
       const int kk = 2 * s + h;
-      float v = 0.f;
-      if (i < B && kk < B) v = (dD[i * B + kk] + dD[kk * B + i]) * sc;
-      sfrag[s] = v;
+      sfrag[s] = (i < B && kk < B) ? S[kk * B + i] : 0.0f;
     }
   }
   const float invB = 1.0f / (float)B, invBm1 = 1.0f / (float)(B - 1);
@@ -478,116 +450,127 @@ __global__ __launch_bounds__(kThreads) void site_bwd_kernel(const float* __restr
   }
 }
 
-inline int nb_for(int B) { return B <= 32 ? 1 : (B <= 64 ? 2 : 4); }
-
-inline int fwd_grid(int B, int n_tiles) {
-  int cap = (nb_for(B) == 4) ? kMaxGridFwd : kMaxGridSmall;
-  return n_tiles < cap ? n_tiles : cap;
-}
-
 template <bool PAIR>
-int launch_partials(const float* x, int B, int64_t F, int k, float r, float eps, float* xq, float* stats, void* ws,
-                    hipStream_t st) {
-  const int n_tiles = (int)((F + TF - 1) / TF);
-  const int grid = fwd_grid(B, n_tiles);
-  const int nb = nb_for(B);
+int launch_partials(const Geom& g, const float* x, int B, int64_t F, int k, float r, float eps, float* xq, float* stats,
+                    float* ws, hipStream_t st) {
+  if (g.nb == 4) return launch_partials4(PAIR, g, x, B, F, k, r, eps, xq, stats, ws, st);
   const int aligned = ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
                       (!xq || (reinterpret_cast<uintptr_t>(xq) & 15) == 0);
-  float* slabs = (float*)ws;
-  switch (nb) {
-    case 1: hipLaunchKernelGGL((site_fwd_kernel<1, PAIR>), grid, kThreads, 0, st, x, B, F, k, r, eps, xq, slabs, stats, n_tiles, aligned); break;
-    case 2: hipLaunchKernelGGL((site_fwd_kernel<2, PAIR>), grid, kThreads, 0, st, x, B, F, k, r, eps, xq, slabs, stats, n_tiles, aligned); break;
-    default: hipLaunchKernelGGL((site_fwd_kernel<4, PAIR>), grid, kThreads, 0, st, x, B, F, k, r, eps, xq, slabs, stats, n_tiles, aligned); break;
-  }
-  hipError_t e = hipGetLastError();
-  return e == hipSuccess ? 0 : (int)e;
-}
-
-int launch_reduce(const void* ws, int B, int64_t F, float* out, hipStream_t st) {
-  const int n_tiles = (int)((F + TF - 1) / TF);
-  const int grid = fwd_grid(B, n_tiles);
-  const int BP = 32 * nb_for(B);
-  hipLaunchKernelGGL(slab_reduce_kernel, (B * B + 63) / 64, 1024, 0, st, (const float*)ws, grid, BP, B,
-                     1.0f / (float)F, out);
+  unsigned* counter = reinterpret_cast<unsigned*>(ws + (size_t)g.grid * g.slab_floats + kPartFloats);
+  if (g.nb == 1)
+    hipLaunchKernelGGL((site_fwd_kernel<1, PAIR>), g.grid, kThreads, 0, st, x, B, F, k, r, eps, xq, ws, stats, g.n_tiles, aligned, counter);
+  else
+    hipLaunchKernelGGL((site_fwd_kernel<2, PAIR>), g.grid, kThreads, 0, st, x, B, F, k, r, eps, xq, ws, stats, g.n_tiles, aligned, counter);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
 
 template <bool PAIR>
-int launch_fwd(const float* x, int B, int64_t F, int k, float r, float eps, float* xq, float* out, float* stats,
-               void* ws, hipStream_t st) {
-  int rc = launch_partials<PAIR>(x, B, F, k, r, eps, xq, stats, ws, st);
-  if (rc) return rc;
-  return launch_reduce(ws, B, F, out, st);
-}
-
-template <bool PAIR>
-int launch_bwd(const float* g, const float* dD, const float* dD_scale, const float* x, const float* stats, int B,
-               int64_t F, float r, float eps, float* dx, hipStream_t st) {
+int launch_bwd(const Geom& g, const float* gup, const float* S, const float* x, const float* stats, int B, int64_t F,
+               float r, float eps, float* dx, hipStream_t st) {
+  if (g.nb == 4) return launch_bwd4(PAIR, g, gup, S, x, stats, B, F, r, eps, dx, st);
   const int n_tiles = (int)((F + TF - 1) / TF);
   const int grid = n_tiles < 2048 ? n_tiles : 2048;
-  const int nb = nb_for(B);
   const int aligned = ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-  switch (nb) {
-    case 1: hipLaunchKernelGGL((site_bwd_kernel<1, PAIR>), grid, kThreads, 0, st, g, dD, dD_scale, x, stats, B, F, r, eps, dx, n_tiles, aligned); break;
-    case 2: hipLaunchKernelGGL((site_bwd_kernel<2, PAIR>), grid, kThreads, 0, st, g, dD, dD_scale, x, stats, B, F, r, eps, dx, n_tiles, aligned); break;
-    default: hipLaunchKernelGGL((site_bwd_kernel<4, PAIR>), grid, kThreads, 0, st, g, dD, dD_scale, x, stats, B, F, r, eps, dx, n_tiles, aligned); break;
-  }
+  if (g.nb == 1)
+    hipLaunchKernelGGL((site_bwd_kernel<1, PAIR>), grid, kThreads, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_tiles, aligned);
+  else
+    hipLaunchKernelGGL((site_bwd_kernel<2, PAIR>), grid, kThreads, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_tiles, aligned);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
+
+inline bool bad_shape(int B, int64_t F) { return B < 2 || B > ALIGNQ_MAX_BATCH || F <= 0; }
+inline bool bad_k(int k) { return !((k >= 1 && k <= 16) || k == 32); }
 
 }  // namespace
 
 extern "C" {
 
 size_t alignq_site_ws_bytes(int B, int64_t F) {
-  if (B < 2 || B > ALIGNQ_MAX_BATCH || F <= 0) return 0;
-  const int nb = nb_for(B);
-  const int n_tiles = (int)((F + TF - 1) / TF);
-  return (size_t)fwd_grid(B, n_tiles) * (32 * nb) * (32 * nb) * sizeof(float);
+  if (bad_shape(B, F)) return 0;
+  return ws_floats(geom(B, F)) * sizeof(float);
+}
+
+size_t alignq_site_bwd_ws_bytes(int B) { return (size_t)(B > 0 ? B : 1) * (size_t)(B > 0 ? B : 1) * sizeof(float); }
+
+int alignq_site_partials(const float* x, int B, int64_t F, int k, float act_range, float eps, float* xq, float* stats,
+                         void* ws, void* stream) {
+  if (!x || !ws) return ALIGNQ_EINVAL;
+  if (bad_shape(B, F)) return F <= 0 ? ALIGNQ_EINVAL : ALIGNQ_EUNSUPPORTED;
+  if (bad_k(k)) return ALIGNQ_EINVAL;
+  return launch_partials<true>(geom(B, F), x, B, F, k, act_range, eps, xq, stats, (float*)ws, (hipStream_t)stream);
+}
+
+int alignq_site_reduce(const void* ws, int B, int64_t F, float* D, void* stream) {
+  if (!ws || !D) return ALIGNQ_EINVAL;
+  if (bad_shape(B, F)) return F <= 0 ? ALIGNQ_EINVAL : ALIGNQ_EUNSUPPORTED;
+  return launch_reduce_any(geom(B, F), (const float*)ws, nullptr, B, F, D, false, nullptr, nullptr, 0, 0.f, 0.f, nullptr,
+                           (hipStream_t)stream);
+}
+
+int alignq_site_reduce_loss(void* ws, int B, int64_t F, float* D, const float* alterD, const float* gamma, int dim,
+                            float mu, float rho, float* scal, void* stream) {
+  if (!ws || !D || !alterD || !gamma || !scal || dim < B) return ALIGNQ_EINVAL;
+  if (bad_shape(B, F)) return F <= 0 ? ALIGNQ_EINVAL : ALIGNQ_EUNSUPPORTED;
+  return launch_reduce_any(geom(B, F), (const float*)ws, (float*)ws, B, F, D, true, alterD, gamma, dim, mu, rho, scal,
+                           (hipStream_t)stream);
 }
 
 int alignq_site_fwd(const float* x, int B, int64_t F, int k, float act_range, float eps, float* xq, float* D,
                     float* stats, void* ws, void* stream) {
-  if (!x || !D || !ws || F <= 0) return ALIGNQ_EINVAL;
-  if (B < 2 || B > ALIGNQ_MAX_BATCH) return ALIGNQ_EUNSUPPORTED;
-  if (!((k >= 1 && k <= 16) || k == 32)) return ALIGNQ_EINVAL;
-  return launch_fwd<true>(x, B, F, k, act_range, eps, xq, D, stats, ws, (hipStream_t)stream);
-}
-
-int alignq_site_partials(const float* x, int B, int64_t F, int k, float act_range, float eps, float* xq, float* stats,
-                         void* ws, void* stream) {
-  if (!x || !ws || F <= 0) return ALIGNQ_EINVAL;
-  if (B < 2 || B > ALIGNQ_MAX_BATCH) return ALIGNQ_EUNSUPPORTED;
-  if (!((k >= 1 && k <= 16) || k == 32)) return ALIGNQ_EINVAL;
-  return launch_partials<true>(x, B, F, k, act_range, eps, xq, stats, ws, (hipStream_t)stream);
-}
-
-int alignq_site_reduce(const void* ws, int B, int64_t F, float* D, void* stream) {
-  if (!ws || !D || F <= 0) return ALIGNQ_EINVAL;
-  if (B < 2 || B > ALIGNQ_MAX_BATCH) return ALIGNQ_EUNSUPPORTED;
-  return launch_reduce(ws, B, F, D, (hipStream_t)stream);
+  if (!x || !D || !ws) return ALIGNQ_EINVAL;
+  if (bad_shape(B, F)) return F <= 0 ? ALIGNQ_EINVAL : ALIGNQ_EUNSUPPORTED;
+  if (bad_k(k)) return ALIGNQ_EINVAL;
+  const Geom g = geom(B, F);
+  int rc = launch_partials<true>(g, x, B, F, k, act_range, eps, xq, stats, (float*)ws, (hipStream_t)stream);
+  if (rc) return rc;
+  return launch_reduce_any(g, (const float*)ws, nullptr, B, F, D, false, nullptr, nullptr, 0, 0.f, 0.f, nullptr,
+                           (hipStream_t)stream);
 }
 
 int alignq_site_bwd(const float* g, const float* dD, const float* dD_scale, const float* x, const float* stats,
-                    int B, int64_t F, float act_range, float eps, float* dx, void* stream) {
-  if (!dD || !x || !stats || !dx || F <= 0) return ALIGNQ_EINVAL;
-  if (B < 2 || B > ALIGNQ_MAX_BATCH) return ALIGNQ_EUNSUPPORTED;
-  return launch_bwd<true>(g, dD, dD_scale, x, stats, B, F, act_range, eps, dx, (hipStream_t)stream);
+                    int B, int64_t F, float act_range, float eps, float* dx, void* ws, void* stream) {
+  if (!dD || !x || !stats || !dx || !ws) return ALIGNQ_EINVAL;
+  if (bad_shape(B, F)) return F <= 0 ? ALIGNQ_EINVAL : ALIGNQ_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = launch_prep(false, dD, nullptr, nullptr, nullptr, 0, nullptr, 0.f, dD_scale, B, F, (float*)ws, nullptr,
+                       nullptr, st);
+  if (rc) return rc;
+  return launch_bwd<true>(geom(B, F), g, (const float*)ws, x, stats, B, F, act_range, eps, dx, st);
+}
+
+int alignq_site_bwd_fused(const float* g, const float* D, const float* alterD, const float* gamma, int dim,
+                          const float* scal, float mu, const float* dD_scale, const float* x, const float* stats,
+                          int B, int64_t F, float act_range, float eps, float* dx, float* dalterD, float* dgamma,
+                          void* ws, void* stream) {
+  if (!D || !alterD || !gamma || !scal || !x || !stats || !dx || !ws || dim < B) return ALIGNQ_EINVAL;
+  if (bad_shape(B, F)) return F <= 0 ? ALIGNQ_EINVAL : ALIGNQ_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = launch_prep(true, nullptr, D, alterD, gamma, dim, scal, mu, dD_scale, B, F, (float*)ws, dalterD, dgamma, st);
+  if (rc) return rc;
+  return launch_bwd<true>(geom(B, F), g, (const float*)ws, x, stats, B, F, act_range, eps, dx, st);
 }
 
 int alignq_corr_fwd(const float* x, int B, int64_t F, float eps, float* G, float* stats, void* ws, void* stream) {
-  if (!x || !G || !ws || F <= 0) return ALIGNQ_EINVAL;
-  if (B < 2 || B > ALIGNQ_MAX_BATCH) return ALIGNQ_EUNSUPPORTED;
-  return launch_fwd<false>(x, B, F, 32, 1.0f, eps, nullptr, G, stats, ws, (hipStream_t)stream);
+  if (!x || !G || !ws) return ALIGNQ_EINVAL;
+  if (bad_shape(B, F)) return F <= 0 ? ALIGNQ_EINVAL : ALIGNQ_EUNSUPPORTED;
+  const Geom g = geom(B, F);
+  int rc = launch_partials<false>(g, x, B, F, 32, 1.0f, eps, nullptr, stats, (float*)ws, (hipStream_t)stream);
+  if (rc) return rc;
+  return launch_reduce_any(g, (const float*)ws, nullptr, B, F, G, false, nullptr, nullptr, 0, 0.f, 0.f, nullptr,
+                           (hipStream_t)stream);
 }
 
 int alignq_corr_bwd(const float* dG, const float* x, const float* stats, int B, int64_t F, float eps, float* dx,
-                    void* stream) {
-  if (!dG || !x || !stats || !dx || F <= 0) return ALIGNQ_EINVAL;
-  if (B < 2 || B > ALIGNQ_MAX_BATCH) return ALIGNQ_EUNSUPPORTED;
-  return launch_bwd<false>(nullptr, dG, nullptr, x, stats, B, F, 1.0f, eps, dx, (hipStream_t)stream);
+                    void* ws, void* stream) {
+  if (!dG || !x || !stats || !dx || !ws) return ALIGNQ_EINVAL;
+  if (bad_shape(B, F)) return F <= 0 ? ALIGNQ_EINVAL : ALIGNQ_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = launch_prep(false, dG, nullptr, nullptr, nullptr, 0, nullptr, 0.f, nullptr, B, F, (float*)ws, nullptr, nullptr,
+                       st);
+  if (rc) return rc;
+  return launch_bwd<false>(geom(B, F), nullptr, (const float*)ws, x, stats, B, F, 1.0f, eps, dx, st);
 }
 
 }  // extern "C"

@@ -144,8 +144,10 @@ class CorrFn(torch.autograd.Function):
         B, F = _as_bf(x)
         dG = L.dev_f32(dG, "grad")
         dx = torch.empty_like(x)
-        L.check(L.load().alignq_corr_bwd(L.ptr(dG), L.ptr(x), L.ptr(stats), B, F, ctx.eps, L.ptr(dx),
-                                         L.stream_ptr()), "alignq_corr_bwd")
+        lib = L.load()
+        ws = _ws(lib.alignq_site_bwd_ws_bytes(B), x.device)
+        L.check(lib.alignq_corr_bwd(L.ptr(dG), L.ptr(x), L.ptr(stats), B, F, ctx.eps, L.ptr(dx), L.ptr(ws),
+                                    L.stream_ptr()), "alignq_corr_bwd")
         return dx, None
 
 
@@ -177,9 +179,9 @@ class SiteFn(torch.autograd.Function):
     """One ADMM activation site: x -> (x_q, trans_loss, D).
 
     activation_quantize_fn.forward, ADMM tree model/quantization.py:102-132 (Office :126-156):
-    x_q = quantise(t), D = corr(t,t) - corr(x,x), trans_loss = ADMM(D).  Three launches forward
-    (fused quantise+Gram partials, slab reduction, ADMM loss+grads), one launch backward.
-    D is returned for ADMM_OPT.step (values only)."""
+    x_q = quantise(t), D = corr(t,t) - corr(x,x), trans_loss = ADMM(D).  Two launches forward (fused
+    quantise + Gram partial slabs; slab reduction with the ADMM-loss epilogue), two launches backward (S/parameter
+    gradient prep; fused standardisation-backward + MFMA kernel).  D is returned for ADMM_OPT.step (values only)."""
 
     @staticmethod
     def forward(ctx, x, alterD, gamma, k, act_range, eps, mu, rho):
@@ -195,29 +197,34 @@ class SiteFn(torch.autograd.Function):
         xq = torch.empty_like(x)
         D = torch.empty(B, B, dtype=torch.float32, device=dev)
         stats = torch.empty(4, F, dtype=torch.float32, device=dev)
+        scal = torch.empty(4, dtype=torch.float32, device=dev)
         ws = _ws(lib.alignq_site_ws_bytes(B, F), dev)
         st = L.stream_ptr()
-        L.check(lib.alignq_site_fwd(L.ptr(x), B, F, int(k), float(act_range), float(eps), L.ptr(xq), L.ptr(D),
-                                    L.ptr(stats), L.ptr(ws), st), "alignq_site_fwd")
-        loss = torch.empty((), dtype=torch.float32, device=dev)
-        dD, dA, dG = torch.empty_like(D), torch.empty_like(A), torch.empty_like(Gm)
-        L.check(lib.alignq_admm_loss(L.ptr(D), B, L.ptr(A), L.ptr(Gm), dim, float(mu), float(rho), L.ptr(loss),
-                                     L.ptr(dD), L.ptr(dA), L.ptr(dG), None, st), "alignq_admm_loss")
-        ctx.save_for_backward(x, stats, dD, dA, dG)
-        ctx.cfg = (float(act_range), float(eps))
+        L.check(lib.alignq_site_partials(L.ptr(x), B, F, int(k), float(act_range), float(eps), L.ptr(xq),
+                                         L.ptr(stats), L.ptr(ws), st), "alignq_site_partials")
+        L.check(lib.alignq_site_reduce_loss(L.ptr(ws), B, F, L.ptr(D), L.ptr(A), L.ptr(Gm), dim, float(mu),
+                                            float(rho), L.ptr(scal), st), "alignq_site_reduce_loss")
+        loss = scal[0]
+        ctx.save_for_backward(x, stats, D, A, Gm, scal)
+        ctx.cfg = (float(act_range), float(eps), float(mu))
         ctx.mark_non_differentiable(D)
         return xq, loss, D
 
     @staticmethod
     def backward(ctx, g_xq, g_loss, _gD):
-        x, stats, dD, dA, dG = ctx.saved_tensors
-        act_range, eps = ctx.cfg
+        x, stats, D, A, Gm, scal = ctx.saved_tensors
+        act_range, eps, mu = ctx.cfg
         B, F = _as_bf(x)
+        dim = A.shape[0]
         g_xq = None if g_xq is None else L.dev_f32(g_xq, "grad")
         if g_loss is None:
             g_loss = torch.zeros((), dtype=torch.float32, device=x.device)
         g_loss = L.dev_f32(g_loss, "loss grad")
+        lib = L.load()
         dx = torch.empty_like(x)
-        L.check(L.load().alignq_site_bwd(L.ptr(g_xq), L.ptr(dD), L.ptr(g_loss), L.ptr(x), L.ptr(stats), B, F,
-                                         act_range, eps, L.ptr(dx), L.stream_ptr()), "alignq_site_bwd")
-        return dx, dA * g_loss, dG * g_loss, None, None, None, None, None
+        dA, dG = torch.empty_like(A), torch.empty_like(Gm)
+        ws = _ws(lib.alignq_site_bwd_ws_bytes(B), x.device)
+        L.check(lib.alignq_site_bwd_fused(L.ptr(g_xq), L.ptr(D), L.ptr(A), L.ptr(Gm), dim, L.ptr(scal), mu,
+                                          L.ptr(g_loss), L.ptr(x), L.ptr(stats), B, F, act_range, eps, L.ptr(dx),
+                                          L.ptr(dA), L.ptr(dG), L.ptr(ws), L.stream_ptr()), "alignq_site_bwd_fused")
+        return dx, dA, dG, None, None, None, None, None

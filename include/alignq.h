@@ -72,32 +72,46 @@ int alignq_weight_quant_fwd(const float* w, const float* ms, float* q, float* cd
 int alignq_weight_quant_bwd(const float* g, const float* w, const float* ms, float* dw, int64_t n,
                             void* ws, void* stream);
 
-/* ---- R4+R5: fused ADMM site: quantise + both sample-correlation matrices -----------------------
- * x: [B,F] (the [B,C,H,W] activation viewed as [B,-1]); B <= ALIGNQ_MAX_BATCH.
+/* ---- R4+R5(+R6): fused ADMM site: quantise + both sample-correlation matrices (+ ADMM loss) ---------
+ * x: [B,F] (the [B,C,H,W] activation viewed as [B,-1]); 2 <= B <= ALIGNQ_MAX_BATCH.
  * Computes xq (as alignq_act_quant_fwd, ADMM formula) and
  *   D = corr(t,t) - corr(x,x),  t = act_range*(2*Phi(x)-1)  (pre-round),
  *   corr(v,v) = Vh Vh^T / F, Vh = (v - mean_b v)/(std_b v + eps)     (model/quantization.py:115-122,
  *   corr :134-137; Office tree corr :158-161 uses eps = 1e-5).
- * stats: [4][F] out (mean_x, 1/(std_x+eps), mean_t, 1/(std_t+eps)) consumed by alignq_site_bwd.
- * xq may be NULL (correlation only).  ws: alignq_site_ws_bytes(B,F) bytes.                         */
+ * stats: [4][F] out (mean_x, 1/(std_x+eps), mean_t, 1/(std_t+eps)) consumed by the backward.
+ * xq may be NULL (correlation only).  ws: alignq_site_ws_bytes(B,F) bytes (partial slabs + reduction tail).
+ * alignq_site_fwd = alignq_site_partials (per-tile quantise + Gram partial slabs -> ws) followed by
+ * alignq_site_reduce (deterministic slab reduction ws -> D, scaled by 1/F).
+ * alignq_site_reduce_loss = the same reduction plus the ADMM loss of utils/admm.py:24-33 in the same launch
+ * (alterD, gamma: [dim,dim] sliced [:B,:B]): scal = device float[4] {loss, rho/2/(n*rms), 1/n, rms}, n = B*B.   */
 size_t alignq_site_ws_bytes(int B, int64_t F);
 int alignq_site_fwd(const float* x, int B, int64_t F, int k, float act_range, float eps, float* xq,
                     float* D, float* stats, void* ws, void* stream);
-/* The two launches of alignq_site_fwd, separately (same arguments): per-tile quantise + Gram partial slabs into
- * ws, then the deterministic slab reduction ws -> D (scaled by 1/F).                                  */
 int alignq_site_partials(const float* x, int B, int64_t F, int k, float act_range, float eps, float* xq,
                          float* stats, void* ws, void* stream);
 int alignq_site_reduce(const void* ws, int B, int64_t F, float* D, void* stream);
-/* dx = g*dt/dx + d(corr pair)/dx for upstream dD [B,B] (gradient w.r.t. D).  g may be NULL.
- * dD_scale: optional DEVICE scalar multiplying dD (the upstream gradient of the scalar loss).       */
+int alignq_site_reduce_loss(void* ws, int B, int64_t F, float* D, const float* alterD, const float* gamma,
+                            int dim, float mu, float rho, float* scal, void* stream);
+/* backward: dx = g*dt/dx + d(corr pair)/dx.  g may be NULL.  ws: alignq_site_bwd_ws_bytes(B) (holds sym(dD)).
+ * dD_scale: optional DEVICE scalar (the upstream gradient of the scalar loss).
+ *   alignq_site_bwd       : explicit upstream gradient dD [B,B] w.r.t. D;
+ *   alignq_site_bwd_fused : dD is the ADMM-loss gradient, rebuilt from (D, alterD, gamma, scal of
+ *                           alignq_site_reduce_loss); also writes the parameter gradients of the loss,
+ *                           dalterD / dgamma [dim,dim] (already multiplied by dD_scale; may be NULL).          */
+size_t alignq_site_bwd_ws_bytes(int B);
 int alignq_site_bwd(const float* g, const float* dD, const float* dD_scale, const float* x,
-                    const float* stats, int B, int64_t F, float act_range, float eps, float* dx,
+                    const float* stats, int B, int64_t F, float act_range, float eps, float* dx, void* ws,
                     void* stream);
-/* corr(x,x) alone (module-level `corr`, model/quantization.py:134-137): G [B,B]; stats [2][F].      */
+int alignq_site_bwd_fused(const float* g, const float* D, const float* alterD, const float* gamma, int dim,
+                          const float* scal, float mu, const float* dD_scale, const float* x,
+                          const float* stats, int B, int64_t F, float act_range, float eps, float* dx,
+                          float* dalterD, float* dgamma, void* ws, void* stream);
+/* corr(x,x) alone (module-level `corr`, model/quantization.py:134-137): G [B,B]; stats [2][F];
+ * ws: alignq_site_ws_bytes(B,F) forward, alignq_site_bwd_ws_bytes(B) backward.                               */
 int alignq_corr_fwd(const float* x, int B, int64_t F, float eps, float* G, float* stats, void* ws,
                     void* stream);
 int alignq_corr_bwd(const float* dG, const float* x, const float* stats, int B, int64_t F, float eps,
-                    float* dx, void* stream);
+                    float* dx, void* ws, void* stream);
 
 /* ---- R6: ADMM loss (utils/admm.py:24-33) --------------------------------------------------------
  * D: [b,b]; alterD, gamma: [dim,dim] with b <= dim (sliced [:b,:b]).  Writes loss (device scalar) and

@@ -21,16 +21,19 @@ def test_library_exports_every_declared_symbol():
     from alignq_amd import _lib
     lib = _lib.load()
     names = _declared()
-    assert len(names) >= 18
+    assert len(names) >= 24
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_lib.SIGNATURES) == names
     assert lib.alignq_abi_version() == 1
     assert b"invalid" in lib.alignq_strerror(-1)
     # pure host-side queries are safe without a GPU
-    assert lib.alignq_site_ws_bytes(128, 16384) == 256 * 128 * 128 * 4
-    assert lib.alignq_site_ws_bytes(28, 802816) == 512 * 32 * 32 * 4
+    tail = 1024 + 16                                     # loss partials + arrival counter
+    assert lib.alignq_site_ws_bytes(128, 16384) == (256 * 10 * 1024 + tail) * 4   # 10 upper-triangular 32x32 tiles
+    assert lib.alignq_site_ws_bytes(128, 4096) == (256 * 10 * 1024 + tail) * 4    # 16-feature tiles keep 256 CUs busy
+    assert lib.alignq_site_ws_bytes(28, 802816) == (512 * 32 * 32 + tail) * 4
     assert lib.alignq_site_ws_bytes(129, 64) == 0
+    assert lib.alignq_site_bwd_ws_bytes(128) == 128 * 128 * 4
 
 
 def test_argument_validation_without_gpu():
