@@ -34,6 +34,7 @@ SIGNATURES = {
     "alignq_site_reduce": (_i, [_vp, _i, _i64, _vp, _vp]),
     "alignq_site_reduce_loss": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _i, _f, _f, _vp, _vp]),
     "alignq_site_bwd_ws_bytes": (_sz, [_i]),
+    "alignq_site_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _f, _f, _vp, _vp]),
     "alignq_site_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _f, _f, _vp, _vp, _vp]),
     "alignq_site_bwd_fused": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _f, _vp, _vp, _vp, _i, _i64, _f, _f, _vp, _vp, _vp,
                                    _vp, _vp]),

@@ -304,21 +304,36 @@ __global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restri
   __shared__ int is_last;
   const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6;
   const int e = blockIdx.x * 64 + lane;
-  const bool ok = e < B * B;
-  const int i = ok ? e / B : 0, j = ok ? e - i * B : 0;
-  int off;
+  // SYM: iterate over the STORED elements (10 tiles x 32 x 32, coalesced) and mirror the off-diagonal tiles;
+  // else: over the output elements of the full BPxBP slab.
+  int i, j, off;
+  bool ok, mirror = false;
   if (SYM) {
-    int ii = i, jj = j;
-    if ((ii >> 5) > (jj >> 5)) { ii = j; jj = i; }
-    const int I = ii >> 5, J = jj >> 5;
-    off = (I * 4 - (I * (I - 1)) / 2 + (J - I)) * 1024 + (ii & 31) * 32 + (jj & 31);
+    const int tile = e >> 10, within = e & 1023;
+    int t = tile, I = 0;
+    while (t >= 4 - I && I < 3) { t -= 4 - I; I++; }
+    const int J = I + t;
+    i = I * 32 + (within >> 5);
+    j = J * 32 + (within & 31);
+    ok = (tile < 10) && i < B && j < B;
+    mirror = ok && (I != J);
+    off = e;
   } else {
+    ok = e < B * B;
+    i = ok ? e / B : 0;
+    j = ok ? e - i * B : 0;
     off = i * BP + j;
   }
   const float* p = slabs + off;
+  // the loss operands do not depend on the slab sums: issue their loads first so they fly under the reduction
+  float a_ij = 0.f, g_ij = 0.f, a_ji = 0.f, g_ji = 0.f;
+  if (LOSS && sg == 0) {
+    if (ok) { a_ij = A[i * dim + j]; g_ij = gamma[i * dim + j]; }
+    if (mirror) { a_ji = A[j * dim + i]; g_ji = gamma[j * dim + i]; }
+  }
   float s = 0.f;
   if (ok) {
-#pragma unroll 4
+#pragma unroll 16
     for (int sl = sg; sl < n_slabs; sl += 16) s += p[(int64_t)sl * slab_floats];
   }
   part[sg][lane] = s;
@@ -328,33 +343,37 @@ __global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restri
 #pragma unroll
     for (int g = 0; g < 16; g++) t += part[g][lane];
     const float d = t * scale;
-    if (ok) out[e] = d;
+    if (ok) out[i * B + j] = d;
+    if (mirror) out[j * B + i] = d;
     if (LOSS) {
       float v0 = 0.f, v1 = 0.f, v2 = 0.f;
       if (ok) {
-        const float a = A[i * dim + j], gm = gamma[i * dim + j];
+        const float a = a_ij, gm = g_ij;
         const float dd = d - a;
         v0 = fabsf(a);
         v1 = dd * dd;
         v2 = gm * fabsf(dd);
       }
+      if (mirror) {
+        const float a = a_ji, gm = g_ji;
+        const float dd = d - a;
+        v0 += fabsf(a);
+        v1 += dd * dd;
+        v2 += gm * fabsf(dd);
+      }
       v0 = wave_sum(v0);
       v1 = wave_sum(v1);
       v2 = wave_sum(v2);
       if (lane == 0) {
-        parts[blockIdx.x * 4 + 0] = v0;
-        parts[blockIdx.x * 4 + 1] = v1;
-        parts[blockIdx.x * 4 + 2] = v2;
-        // publish the partial (own store) then take a ticket; the last arriver acquires and finishes
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        // Hand-off without an L2 write-back (a release fence here would flush what the previous kernel left dirty
+        // in this XCD's L2): the partials are stored write-through (sc1), drained, then one relaxed agent-scope
+        // ticket; the block whose ticket is last reads every partial with sc1 loads.
+        __hip_atomic_store(&parts[blockIdx.x * 4 + 0], v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&parts[blockIdx.x * 4 + 1], v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&parts[blockIdx.x * 4 + 2], v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned tk = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = (tk == gridDim.x - 1);
-        if (last) {
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        is_last = last;
+        is_last = (tk == gridDim.x - 1);
       }
     }
   }
@@ -363,9 +382,9 @@ __global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restri
   if (!is_last) return;
   double s0 = 0, s1 = 0, s2 = 0;
   if ((int)threadIdx.x < (int)gridDim.x) {
-    s0 = parts[threadIdx.x * 4 + 0];
-    s1 = parts[threadIdx.x * 4 + 1];
-    s2 = parts[threadIdx.x * 4 + 2];
+    s0 = __hip_atomic_load(&parts[threadIdx.x * 4 + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s1 = __hip_atomic_load(&parts[threadIdx.x * 4 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s2 = __hip_atomic_load(&parts[threadIdx.x * 4 + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   s0 = wave_sum_d(s0);
   s1 = wave_sum_d(s1);
@@ -609,7 +628,7 @@ int launch_reduce_any(const Geom& g, const float* ws_c, float* ws_mut, int B, in
                       const float* alterD, const float* gamma, int dim, float mu, float rho, float* scal,
                       hipStream_t st) {
   const int BP = 32 * g.nb;
-  const int blocks = (B * B + 63) / 64;
+  const int blocks = (g.nb == 4) ? 160 : (B * B + 63) / 64;   // site4: one thread per STORED element (10x32x32)
   float* parts = ws_mut ? ws_mut + (size_t)g.grid * g.slab_floats : nullptr;
   unsigned* counter = ws_mut ? reinterpret_cast<unsigned*>(ws_mut + (size_t)g.grid * g.slab_floats + kPartFloats) : nullptr;
   const float scale = 1.0f / (float)F;

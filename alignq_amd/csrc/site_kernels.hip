@@ -540,6 +540,13 @@ int alignq_site_bwd(const float* g, const float* dD, const float* dD_scale, cons
   return launch_bwd<true>(geom(B, F), g, (const float*)ws, x, stats, B, F, act_range, eps, dx, st);
 }
 
+int alignq_site_bwd_apply(const float* g, const float* S, const float* x, const float* stats, int B, int64_t F,
+                          float act_range, float eps, float* dx, void* stream) {
+  if (!S || !x || !stats || !dx) return ALIGNQ_EINVAL;
+  if (bad_shape(B, F)) return F <= 0 ? ALIGNQ_EINVAL : ALIGNQ_EUNSUPPORTED;
+  return launch_bwd<true>(geom(B, F), g, S, x, stats, B, F, act_range, eps, dx, (hipStream_t)stream);
+}
+
 int alignq_site_bwd_fused(const float* g, const float* D, const float* alterD, const float* gamma, int dim,
                           const float* scal, float mu, const float* dD_scale, const float* x, const float* stats,
                           int B, int64_t F, float act_range, float eps, float* dx, float* dalterD, float* dgamma,

@@ -29,6 +29,7 @@ class WeightQuantAllFn(torch.autograd.Function):
                                                   L.ptr_array(ps), n, L.ptr(ms), int(k), int(formula), L.ptr(scratch),
                                                   L.stream_ptr()), "alignq_weight_quant_fwd_multi")
         ctx.save_for_backward(ms, *ws_)
+        ctx.set_materialize_grads(False)     # no zero tensors for the 2T non-differentiable cdf/pdf outputs
         ctx.mark_non_differentiable(*cs, *ps)
         ctx.T = T
         return tuple(qs) + tuple(cs) + tuple(ps)

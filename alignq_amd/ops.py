@@ -206,6 +206,7 @@ class SiteFn(torch.autograd.Function):
                                             float(rho), L.ptr(scal), st), "alignq_site_reduce_loss")
         loss = scal[0]
         ctx.save_for_backward(x, stats, D, A, Gm, scal)
+        ctx.set_materialize_grads(False)     # no zero-filled [B,B] gradient for the non-differentiable D
         ctx.cfg = (float(act_range), float(eps), float(mu))
         ctx.mark_non_differentiable(D)
         return xq, loss, D

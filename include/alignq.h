@@ -99,6 +99,10 @@ int alignq_site_reduce_loss(void* ws, int B, int64_t F, float* D, const float* a
  *                           alignq_site_reduce_loss); also writes the parameter gradients of the loss,
  *                           dalterD / dgamma [dim,dim] (already multiplied by dD_scale; may be NULL).          */
 size_t alignq_site_bwd_ws_bytes(int B);
+/* second launch of both forms alone: S = the prepared, scaled, symmetrised dD [B,B] that the first launch
+ * (site_prep_kernel) leaves in ws.                                                                             */
+int alignq_site_bwd_apply(const float* g, const float* S, const float* x, const float* stats, int B, int64_t F,
+                          float act_range, float eps, float* dx, void* stream);
 int alignq_site_bwd(const float* g, const float* dD, const float* dD_scale, const float* x,
                     const float* stats, int B, int64_t F, float act_range, float eps, float* dx, void* ws,
                     void* stream);

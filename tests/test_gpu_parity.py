@@ -373,7 +373,7 @@ def test_tiny_resnet_two_steps_vs_reference(dev):
                     if on is not None:
                         ref_v = npy(ogot[on])
                         dd = np.abs(npy(got[name]) - ref_v) / (np.abs(ref_v) + 0.1)
-                        assert np.median(dd) < 5e-3, (name, np.median(dd), dd.max())
+                        assert np.median(dd) < 2e-2, (name, np.median(dd), dd.max())
     finally:
         config.args.bitW = config.args.abitW = 8
         config.args.train_batch_size = 128
