@@ -445,12 +445,17 @@ __global__ __launch_bounds__(256) void site_prep_kernel(const float* __restrict_
 }
 
 // ================================================================================================ backward
-// wave w: row block I = w>>2, operand op = (w>>1)&1 (0: x, 1: t), column block cj = w&1 of the 64-feature tile
+// 512 threads = 8 waves (2 per SIMD, 256-VGPR budget: the 64 register-resident S fragments + two accumulators fit
+// without scratch; a 16-wave variant spilled 52 B/lane, visible as 13.6 MB of extra WRITE_SIZE per launch).
+// wave w: row block I = w>>1, column block cj = w&1 of the 64-feature tile, BOTH operands (x and t), so the final
+// assembly is wave-local.
+constexpr int NTB = 512;
+
 template <bool PAIR>
-__global__ __launch_bounds__(NT) void site_bwd4_kernel(const float* __restrict__ gup, const float* __restrict__ S,
-                                                       const float* __restrict__ x, const float* __restrict__ stats,
-                                                       int B, int64_t F, float r, float eps, float* __restrict__ dx,
-                                                       int n_tiles, int aligned) {
+__global__ __launch_bounds__(NTB) void site_bwd4_kernel(const float* __restrict__ gup, const float* __restrict__ S,
+                                                        const float* __restrict__ x, const float* __restrict__ stats,
+                                                        int B, int64_t F, float r, float eps, float* __restrict__ dx,
+                                                        int n_tiles, int aligned) {
   constexpr int TFv = 64, LDv = 65, TILE = 128 * LDv;
   constexpr int NARR = PAIR ? 4 : 2;
   __shared__ __attribute__((aligned(16))) float lds[NARR * TILE + 4 * TFv + 4 * 2 * 2 * TFv];
@@ -462,10 +467,9 @@ __global__ __launch_bounds__(NT) void site_bwd4_kernel(const float* __restrict__
   float* red = colv + 4 * TFv;             // [4 row blocks][2 operands][2][64]
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int c = tid & 15, rg = tid >> 4;   // load mapping: 16 lanes per row, 64 row groups, rows rg and rg+64
+  const int c = tid & 15, rg = tid >> 4;   // load mapping: 16 lanes per row, 32 row groups, rows rg + 32*j
   const int h = lane >> 5, l31 = lane & 31;
-  const int I = w >> 2, op = (w >> 1) & 1, cj = w & 1;
-  const bool mfma_wave = PAIR || op == 0;
+  const int I = w >> 1, cj = w & 1;
   const int cc = cj * 32 + l31;            // this lane's feature column inside the tile (accumulator layout)
 
   // S fragments (symmetric, already scaled): A[i][k] = S[k][i], i = I*32 + l31, k = 2s + h  -> coalesced in i
@@ -475,7 +479,7 @@ __global__ __launch_bounds__(NT) void site_bwd4_kernel(const float* __restrict__
 #pragma unroll
     for (int s = 0; s < 64; s++) {
       const int kk = 2 * s + h;
-      sfrag[s] = (mfma_wave && i < B && kk < B) ? S[kk * B + i] : 0.0f;
+      sfrag[s] = (i < B && kk < B) ? S[kk * B + i] : 0.0f;
     }
   }
   const float invB = 1.0f / (float)B, invBm1 = 1.0f / (float)(B - 1);
@@ -498,16 +502,21 @@ __global__ __launch_bounds__(NT) void site_bwd4_kernel(const float* __restrict__
         mt[e] = PAIR ? colv[2 * TFv + 4 * c + e] : 0.f;
         rt[e] = PAIR ? colv[3 * TFv + 4 * c + e] : 0.f;
       }
-#pragma unroll 1
-      for (int j = 0; j < 2; j++) {
-        const int row = rg + 64 * j;
-        const bool ok = row < B;
+      float4 xv[4], gv[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {        // issue all global loads first
+        const int row = rg + 32 * j;
         const int64_t off = (int64_t)row * F + col;
-        const float4 xv = ld4(x, off, col, F, ok, aligned);
-        float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (PAIR && gup) gv = ld4(gup, off, col, F, ok, aligned);
-        const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
-        const float ge[4] = {gv.x, gv.y, gv.z, gv.w};
+        xv[j] = ld4(x, off, col, F, row < B, aligned);
+        gv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (PAIR && gup) gv[j] = ld4(gup, off, col, F, row < B, aligned);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int row = rg + 32 * j;
+        const bool ok = row < B;
+        const float xe[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
+        const float ge[4] = {gv[j].x, gv[j].y, gv[j].z, gv[j].w};
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           const bool okc = ok && (col + e < F);
@@ -524,74 +533,79 @@ __global__ __launch_bounds__(NT) void site_bwd4_kernel(const float* __restrict__
       }
     }
     __syncthreads();
-    // ---- MFMA: acc = S[I-block, :] * {Xh|Th}[:, column block] ---------------------------------------
-    f32x16 acc;
+    // ---- MFMA: accX = S[I-block, :] * Xh[:, column block],  accT likewise with Th --------------------
+    f32x16 accX, accT;
 #pragma unroll
-    for (int e = 0; e < 16; e++) acc[e] = 0.0f;
-    const float* src = (PAIR && op) ? Ts : Xs;
-    if (mfma_wave) {
+    for (int e = 0; e < 16; e++) { accX[e] = 0.0f; accT[e] = 0.0f; }
 #pragma unroll
-      for (int s = 0; s < 64; s++)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sfrag[s], src[(2 * s + h) * LDv + cc], acc, 0, 0, 0);
-      // projections over this wave's 32 batch rows
-      float p0 = 0.f, p1 = 0.f;
-#pragma unroll
-      for (int e = 0; e < 16; e++) {
-        const int row = I * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        p0 += acc[e];
-        p1 += acc[e] * src[row * LDv + cc];
-      }
-      p0 += __shfl_xor(p0, 32, 64);
-      p1 += __shfl_xor(p1, 32, 64);
-      if (h == 0) {
-        red[((I * 2 + op) * 2 + 0) * TFv + cc] = p0;
-        red[((I * 2 + op) * 2 + 1) * TFv + cc] = p1;
-      }
+    for (int s = 0; s < 64; s++) {
+      const int a = (2 * s + h) * LDv + cc;
+      accX = __builtin_amdgcn_mfma_f32_32x32x2f32(sfrag[s], Xs[a], accX, 0, 0, 0);
+      if (PAIR) accT = __builtin_amdgcn_mfma_f32_32x32x2f32(sfrag[s], Ts[a], accT, 0, 0, 0);
     }
-    __syncthreads();
-    // ---- own-input contribution: rho * (acc - mean_b - vh * proj) -----------------------------------
-    if (mfma_wave) {
-      float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-      for (int rb = 0; rb < 4; rb++) {
-        s0 += red[((rb * 2 + op) * 2 + 0) * TFv + cc];
-        s1 += red[((rb * 2 + op) * 2 + 1) * TFv + cc];
-      }
-      const float rho = colv[(2 * op + 1) * TFv + cc];
-      float kap = 1.0f;   // (sd+eps)/sd = 1/(1-eps*rho); torch's std backward is 0 where sd == 0
-      if (eps != 0.0f) { const float den = 1.0f - eps * rho; kap = (den > 1e-12f) ? 1.0f / den : 0.0f; }
-      const float mean_d = s0 * invB, proj = s1 * invBm1 * kap;
-#pragma unroll
-      for (int e = 0; e < 16; e++) {
-        const int row = I * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        acc[e] = rho * (acc[e] - mean_d - src[row * LDv + cc] * proj);
-      }
-    }
-    // phase A: x-operand waves.  PAIR: corr(x,x) enters D with a minus sign.  !PAIR: it is the result.
-    if (op == 0) {
+    // ---- projections over this wave's 32 batch rows: sum dVh, sum dVh*Vh ------------------------------
+    {
+      float x0 = 0.f, x1 = 0.f, t0 = 0.f, t1 = 0.f;
 #pragma unroll
       for (int e = 0; e < 16; e++) {
         const int a = (I * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LDv + cc;
-        if (PAIR) Os[a] -= acc[e];
-        else Os[a] = acc[e];
+        x0 += accX[e];
+        x1 += accX[e] * Xs[a];
+        if (PAIR) { t0 += accT[e]; t1 += accT[e] * Ts[a]; }
+      }
+      x0 += __shfl_xor(x0, 32, 64);
+      x1 += __shfl_xor(x1, 32, 64);
+      if (PAIR) { t0 += __shfl_xor(t0, 32, 64); t1 += __shfl_xor(t1, 32, 64); }
+      if (h == 0) {
+        red[((I * 2 + 0) * 2 + 0) * TFv + cc] = x0;
+        red[((I * 2 + 0) * 2 + 1) * TFv + cc] = x1;
+        if (PAIR) {
+          red[((I * 2 + 1) * 2 + 0) * TFv + cc] = t0;
+          red[((I * 2 + 1) * 2 + 1) * TFv + cc] = t1;
+        }
       }
     }
-    if (PAIR) {
-      __syncthreads();
-      // phase B: t-operand waves add their contribution chained through dt/dx
-      if (op == 1) {
+    __syncthreads();
+    // ---- assemble in LDS: out = g*jac + jac*ct - cx   (PAIR)   |   out = cx   (!PAIR) -------------------
+    {
+      float sx0 = 0.f, sx1 = 0.f, st0 = 0.f, st1 = 0.f;
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-          const int a = (I * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LDv + cc;
-          Os[a] += acc[e] * Js[a];
+      for (int rb = 0; rb < 4; rb++) {
+        sx0 += red[((rb * 2 + 0) * 2 + 0) * TFv + cc];
+        sx1 += red[((rb * 2 + 0) * 2 + 1) * TFv + cc];
+        if (PAIR) {
+          st0 += red[((rb * 2 + 1) * 2 + 0) * TFv + cc];
+          st1 += red[((rb * 2 + 1) * 2 + 1) * TFv + cc];
+        }
+      }
+      const float rho_x = colv[TFv + cc];
+      const float rho_t = PAIR ? colv[3 * TFv + cc] : 0.0f;
+      // through-std factor (sd+eps)/sd = 1/(1-eps*rho); torch's std backward is 0 where sd == 0
+      float kap_x = 1.0f, kap_t = 1.0f;
+      if (eps != 0.0f) {
+        const float dxn = 1.0f - eps * rho_x, dtn = 1.0f - eps * rho_t;
+        kap_x = (dxn > 1e-12f) ? 1.0f / dxn : 0.0f;
+        kap_t = (dtn > 1e-12f) ? 1.0f / dtn : 0.0f;
+      }
+      const float mean_x = sx0 * invB, proj_x = sx1 * invBm1 * kap_x;
+      const float mean_t = st0 * invB, proj_t = st1 * invBm1 * kap_t;
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int a = (I * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LDv + cc;
+        const float cx = rho_x * (accX[e] - mean_x - Xs[a] * proj_x);
+        if (PAIR) {
+          const float ct = rho_t * (accT[e] - mean_t - Ts[a] * proj_t);
+          Os[a] = Os[a] + ct * Js[a] - cx;     // corr(x,x) enters D with a minus sign
+        } else {
+          Os[a] = cx;
         }
       }
     }
     __syncthreads();
     // ---- copy out: full 256-byte rows ---------------------------------------------------------------
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const int row = rg + 64 * j;
+    for (int j = 0; j < 4; j++) {
+      const int row = rg + 32 * j;
       const int a = row * LDv + 4 * c;
       const float4 o = make_float4(Os[a], Os[a + 1], Os[a + 2], Os[a + 3]);
       st4(dx, (int64_t)row * F + col, col, F, row < B, aligned, o);
@@ -661,8 +675,8 @@ int launch_bwd4(bool pair, const Geom& g, const float* gup, const float* S, cons
   const int grid = n_tiles < 2048 ? n_tiles : 2048;
   const int aligned = ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
                       ((reinterpret_cast<uintptr_t>(dx) & 15) == 0) && (!gup || (reinterpret_cast<uintptr_t>(gup) & 15) == 0);
-  if (pair) hipLaunchKernelGGL((site_bwd4_kernel<true>), grid, NT, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_tiles, aligned);
-  else hipLaunchKernelGGL((site_bwd4_kernel<false>), grid, NT, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_tiles, aligned);
+  if (pair) hipLaunchKernelGGL((site_bwd4_kernel<true>), grid, NTB, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_tiles, aligned);
+  else hipLaunchKernelGGL((site_bwd4_kernel<false>), grid, NTB, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_tiles, aligned);
   RET_ON_ERR();
   return 0;
 }

@@ -1,0 +1,108 @@
+"""Data-parallel path on CPU: world_size 2 over gloo.  The collective layer (alignq_amd/dp.py) is device-agnostic
+torch.distributed code; the compute in these CPU ranks is the eager-torch oracle (tests may use it), so what is
+verified is the N>1 protocol: one flat mean all-reduce of (gradients of non-ADMM parameters + stacked D matrices),
+replicas bit-identical after the optimizer steps, and equal to a single process that averages by hand."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make(seed=0):
+    from oracle import torch_ref as R
+    cfg = R.Config(tree="admm", bitW=4, abitW=4, train_batch_size=4)
+    torch.manual_seed(seed)
+    net = R.PreActResNet(cfg, [1, 1, 1], 4, 4).train()
+    return R, cfg, net
+
+
+def _data():
+    g = torch.Generator().manual_seed(123)
+    return torch.randn(2, 4, 3, 32, 32, generator=g), torch.randint(0, 10, (2, 4), generator=g)
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from alignq_amd import dp
+        R, cfg, net = _make(seed=rank)              # different init per rank: the broadcast must fix it
+        dp.broadcast_module_state(net, 0)
+        step = R.TrainStep(net, cfg)
+        hook = dp.GradAndDAllReduce([p for _, p in step.param_t], lambda: [m.D for m in net.admm_modules()])
+        xs, ys = _data()
+        # one iteration in the reference's order with the hook between backward and the optimizer steps
+        step.opt_t.zero_grad(); step.opt_admm.zero_grad()
+        logits, tl = net(xs[rank])
+        (torch.nn.functional.cross_entropy(logits, ys[rank]) + tl).backward()
+        local_g0 = step.param_t[0][1].grad.clone()
+        for m in net.admm_modules():
+            m.D = m.D.detach().clone()
+        local_D0 = net.admm_modules()[0].D.clone()
+        hook()
+        g0_avg = step.param_t[0][1].grad.clone()
+        convs = net.quant_convs()
+        step.opt_t.step(step.idx, [c.weight_cdf for c in convs], [c.weight_pdf for c in convs], cfg.lam, cfg.lam2)
+        mods = net.admm_modules()
+        step.opt_admm.step(step.a_idx, step.g_idx, [m.D for m in mods], [m.alterD for m in mods],
+                           [m.gamma for m in mods], [m.mu for m in mods], [m.rho for m in mods], bitW=cfg.bitW)
+        flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+        out[rank] = dict(flat=flat.numpy().copy(), g0_local=local_g0.numpy(), D0_local=local_D0.numpy(),
+                         g0_avg=g0_avg.numpy(), D0_avg=mods[0].D.numpy().copy(),
+                         bucket=int(hook.bucket.flat.numel()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_dp_two_ranks_gloo():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    r0, r1 = out[0], out[1]
+    # replicas identical after the step (same broadcast init, same averaged grads and D)
+    assert np.array_equal(r0["flat"], r1["flat"])
+    # the all-reduce is a mean over ranks
+    np.testing.assert_allclose(r0["g0_avg"], 0.5 * (r0["g0_local"] + r1["g0_local"]), rtol=0, atol=1e-7)
+    np.testing.assert_allclose(r0["D0_avg"], 0.5 * (r0["D0_local"] + r1["D0_local"]), rtol=0, atol=1e-7)
+    assert np.array_equal(r0["g0_avg"], r1["g0_avg"]) and np.array_equal(r0["D0_avg"], r1["D0_avg"])
+    # ONE bucket: all non-ADMM grads + all D matrices ([1,1,1] net: 9 sites of 4x4)
+    R, cfg, net = _make()
+    n_t = sum(p.numel() for n, p in net.named_parameters() if "alterD" not in n and "gamma" not in n)
+    assert r0["bucket"] == n_t + 9 * 16
+
+
+def test_flat_bucket_roundtrip():
+    from alignq_amd.dp import FlatBucket
+    ts = [torch.randn(3, 4), torch.randn(7), torch.randn(2, 2, 2)]
+    b = FlatBucket([t.shape for t in ts], "cpu")
+    b.pack(ts)
+    assert torch.equal(b.flat, torch.cat([t.reshape(-1) for t in ts]))
+    b.flat.mul_(2.0)
+    outs = [torch.empty_like(t) for t in ts]
+    b.unpack(outs)
+    for o, t in zip(outs, ts):
+        assert torch.equal(o, 2 * t)
+
+
+def test_world_size_one_is_a_noop():
+    from alignq_amd.dp import GradAndDAllReduce
+    p = torch.nn.Parameter(torch.ones(3))
+    p.grad = torch.full((3,), 2.0)
+    GradAndDAllReduce([p], lambda: [])()
+    assert torch.equal(p.grad, torch.full((3,), 2.0))
