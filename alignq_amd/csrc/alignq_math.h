@@ -84,26 +84,56 @@ __device__ __forceinline__ float erf32(float x) {
 #define ALIGNQ_LOG_SQRT_2PI_F 0.91893853320467274178f
 #define ALIGNQ_TWO_OVER_SQRT_2PI 0.79788456080286535588f  // 2*phi(0)
 
+// IEEE-754 division x/d by a fixed divisor through its correctly rounded reciprocal y = RN(1/d):
+//   q0 = x*y; r = fma(-q0, d, x) (exact remainder); q = fma(r, y, q0)      (3 VALU ops instead of ~10)
+// The arithmetic SPEC remains "IEEE division" (the C oracle divides).  tests/native/verify_div.c proves equality
+// exhaustively for d = float(sqrt(2)) over every finite float with |x| >= 1e-30 (below that the remainder underflows;
+// such z are absorbed by 0.5*(1+erf(z)) == 0.5 exactly, so no output changes), both zeros included, and for d = 2^k-1,
+// k<=16, over every integer-valued |x| <= 8*d+2 and -0 (the bin indices).  +-inf is passed through like a division would.
+__device__ __forceinline__ float div_const(float x, float d, float y) {
+  const float q0 = __fmul_rn(x, y);
+  const float r = __fmaf_rn(-q0, d, x);
+  const float q = __fmaf_rn(r, y, q0);
+  // q0 already is the answer for the two cases the correction step mangles: a signed zero (the fma chain turns -0
+  // into +0) and +-inf (inf - inf = NaN)
+  return (q0 == 0.0f || fabsf(q0) == __int_as_float(0x7f800000)) ? q0 : q;
+}
+#define ALIGNQ_RCP_SQRT2F 0.707106769084930419921875f   // RN(1/float(sqrt(2)))
+
 // Normal(m,s).cdf in torch's op order (torch/distributions/normal.py; reference
 // model/quantization.py:50-51): 0.5*(1+erf((v-m)*(1/s)/sqrt(2))).  rs = 1/s.
 __device__ __forceinline__ float gauss_cdf32(float v, float m, float rs) {
-  float z = __fdiv_rn(__fmul_rn(__fsub_rn(v, m), rs), ALIGNQ_SQRT2F);
+  float z = div_const(__fmul_rn(__fsub_rn(v, m), rs), ALIGNQ_SQRT2F, ALIGNQ_RCP_SQRT2F);
   return __fmul_rn(0.5f, __fadd_rn(1.0f, erf32(z)));
 }
 
-// uniform_quantize(k).forward (model/quantization.py:23-31) on a transformed value; n = 2^k-1 as float.
+// Level-division context: n = 2^k-1 and, when every |bin| of the call is known to stay within the exhaustively
+// verified range (|t| <= 8: activations with act_range <= 8, weights), yn = RN(1/n) for div_const; yn == 0 selects
+// the hardware divider (arbitrary inputs, e.g. the stand-alone uniform_quantize).  yn is wave-uniform => scalar branch.
+struct Levels {
+  float n, yn;
+};
+__host__ __device__ __forceinline__ Levels make_levels(int k, bool bounded) {
+  Levels L;
+  L.n = (float)((1 << (k & 31)) - 1);
+  L.yn = (bounded && k != 32 && k != 1) ? 1.0f / L.n : 0.0f;
+  return L;
+}
+
+// uniform_quantize(k).forward (model/quantization.py:23-31) on a transformed value.
 // k==32 -> identity, k==1 -> sign.  *bin receives the integer level.
-__device__ __forceinline__ float round_bins(float t, int k, float n, float* bin) {
+__device__ __forceinline__ float round_bins(float t, int k, const Levels& L, float* bin) {
   if (k == 32) { *bin = t; return t; }
   if (k == 1) { float s = (float)((t > 0.0f) - (t < 0.0f)); *bin = s; return s; }
-  float b = rintf(__fmul_rn(t, n));
+  float b = rintf(__fmul_rn(t, L.n));
   *bin = b;
-  return __fdiv_rn(b, n);
+  if (L.yn != 0.0f) return div_const(b, L.n, L.yn);
+  return __fdiv_rn(b, L.n);
 }
 
 // activation transform + quantise for one element; returns x_q, *t_pre = pre-round transform
 template <int FORMULA>
-__device__ __forceinline__ float act_quant1(float x, int k, float n, float r, float* t_pre, float* bin) {
+__device__ __forceinline__ float act_quant1(float x, int k, const Levels& n, float r, float* t_pre, float* bin) {
   float c = gauss_cdf32(x, 0.0f, 1.0f);
   if (FORMULA == 0) {
     float t = __fmul_rn(__fsub_rn(__fmul_rn(c, 2.0f), 1.0f), r);
@@ -138,7 +168,8 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 namespace alignq {
 
 struct WeightConsts {
-  float m, rs, var2, logs, nlev;
+  float m, rs, var2, logs;
+  Levels nlev;
 };
 
 __device__ __forceinline__ WeightConsts weight_consts(float m, float s, int k) {
@@ -147,7 +178,7 @@ __device__ __forceinline__ WeightConsts weight_consts(float m, float s, int k) {
   c.rs = __fdiv_rn(1.0f, s);
   c.var2 = __fmul_rn(2.0f, __fmul_rn(s, s));
   c.logs = (float)log((double)s);
-  c.nlev = (float)((1 << (k & 31)) - 1);
+  c.nlev = make_levels(k, true);   // |weight transform| <= 1
   return c;
 }
 

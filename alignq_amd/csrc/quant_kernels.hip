@@ -31,7 +31,7 @@ __global__ __launch_bounds__(kThreads) void act_quant_fwd_kernel(const float* __
                                                                  float* __restrict__ xq,
                                                                  int32_t* __restrict__ bins, int64_t n,
                                                                  int k, float r) {
-  const float nlev = (float)((1 << (k & 31)) - 1);
+  const Levels nlev = make_levels(k, fabsf(r) <= 8.0f);
   const int64_t nvec = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * kThreads;
   const float4* x4 = reinterpret_cast<const float4*>(x);
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(kThreads) void act_quant_fwd_kernel(const float* __
 // uniform_quantize(k).forward alone (model/quantization.py:23-31): y = round(x*n)/n | sign(x) | x
 __global__ __launch_bounds__(kThreads) void uniform_quantize_kernel(const float* __restrict__ x,
                                                                     float* __restrict__ y, int64_t n, int k) {
-  const float nlev = (float)((1 << (k & 31)) - 1);
+  const Levels nlev = make_levels(k, false);   // arbitrary inputs: hardware divider
   const int64_t stride = (int64_t)gridDim.x * kThreads;
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
     float b;

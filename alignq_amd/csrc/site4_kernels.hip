@@ -86,7 +86,7 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c = tid % LPR, rg = tid / LPR;
   const int h = lane >> 5, l31 = lane & 31;
-  const float nlev = (float)((1 << (k & 31)) - 1);
+  const Levels nlev = make_levels(k, fabsf(r) <= 8.0f);
   const float invB = 1.0f / (float)B, invBm1 = 1.0f / (float)(B - 1);
 
   if (blockIdx.x == 0 && tid == 0 && counter) *counter = 0u;   // arrival counter of the reduce kernel's epilogue

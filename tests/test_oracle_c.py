@@ -184,3 +184,16 @@ def test_sgd_step_vs_reference():
             if i == 1:
                 d = O.sgd_grad_approx(d, g["w_cdf"], g["w_pdf"], bitW, lam, lam2)
             np.testing.assert_allclose(d, g[f"gradout{i}_{step}"], atol=1e-5, rtol=1e-5)
+
+
+def test_fma_division_is_ieee_division_exhaustive(tmp_path):
+    """Proof obligation of alignq_math.h::div_const (the HIP kernels divide by sqrt(2) and by the level count with an
+    fma sequence): exhaustive equality with IEEE division, tests/native/verify_div.c (all 2^32 floats, ~25 s)."""
+    import os
+    import subprocess
+    src = os.path.join(os.path.dirname(__file__), "native", "verify_div.c")
+    exe = str(tmp_path / "verify_div")
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-mfma", "-fopenmp", src, "-o", exe, "-lm"], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout
+    assert "mismatches 0 (|x|>=1e-30)" in out.stdout and "levels: mismatches 0" in out.stdout
