@@ -114,3 +114,30 @@ def dev_f32(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:
     if t.dtype != torch.float32:
         raise TypeError(f"alignq_amd: {name} must be float32, got {t.dtype}")
     return t if t.is_contiguous() else t.contiguous()
+
+
+def dense_f32(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:
+    """Like dev_f32 but also accepts channels-last (NHWC-strided) 4-D tensors without copying: the elementwise and
+    per-site kernels only need ONE dense [B, F] row-major image of the storage (any fixed permutation of the feature
+    axis leaves statistics, Gram matrices and elementwise results unchanged), so the storage is used as it lies."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"alignq_amd: {name} is on {t.device}; the HIP kernels need a CUDA/ROCm tensor "
+                           "(there is no CPU fallback in the product path)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"alignq_amd: {name} must be float32, got {t.dtype}")
+    if t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)):
+        return t
+    return t.contiguous()
+
+
+def like_layout(g: torch.Tensor, ref: torch.Tensor, name: str = "grad") -> torch.Tensor:
+    """Return g (CUDA fp32) laid out in memory exactly like ref (same strides), copying only if it is not."""
+    if not g.is_cuda or g.dtype != torch.float32:
+        raise TypeError(f"alignq_amd: {name} must be a CUDA float32 tensor")
+    if g.stride() == ref.stride():
+        return g
+    out = torch.empty_like(ref)
+    out.copy_(g)
+    return out

@@ -43,15 +43,17 @@ def broadcast_module_state(module: torch.nn.Module, src: int = 0, group=None):
 class GradAndDAllReduce:
     """grad_hook for alignq_amd.train_step.TrainStep (called between backward and the optimizer steps)."""
 
-    def __init__(self, params: List[torch.nn.Parameter], get_Ds: Callable[[], List[torch.Tensor]], group=None):
+    def __init__(self, params: List[torch.nn.Parameter], get_Ds: Callable[[], List[torch.Tensor]], group=None,
+                 force: bool = False):
         self.params = params
         self.get_Ds = get_Ds
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.force = force and dist.is_initialized()      # run the collective even at world size 1 (self-test)
         self.bucket = None
 
     def __call__(self, _step=None):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         grads = [p.grad for p in self.params if p.grad is not None]
         Ds = [d for d in self.get_Ds() if d is not None]
@@ -64,9 +66,10 @@ class GradAndDAllReduce:
         self.bucket.unpack(tensors)
 
 
-def attach(train_step, group=None):
+def attach(train_step, group=None, force=False):
     """Wire data parallelism into a TrainStep: broadcast the initial state, install the all-reduce hook."""
     broadcast_module_state(train_step.model, 0, group)
-    hook = GradAndDAllReduce([p for _, p in train_step.param_t], lambda: [m.D for m in train_step.admms], group)
+    hook = GradAndDAllReduce([p for _, p in train_step.param_t], lambda: [m.D for m in train_step.admms], group,
+                             force=force)
     train_step.grad_hook = hook
     return hook

@@ -16,7 +16,7 @@ class WeightQuantAllFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, k, formula, *weights):
         lib = L.load()
-        ws_ = [L.dev_f32(w, "weight") for w in weights]
+        ws_ = [L.dense_f32(w, "weight") for w in weights]
         T = len(ws_)
         dev = ws_[0].device
         qs = [torch.empty_like(w) for w in ws_]
@@ -39,7 +39,7 @@ class WeightQuantAllFn(torch.autograd.Function):
         T = ctx.T
         ms, ws_ = ctx.saved_tensors[0], ctx.saved_tensors[1:]
         lib = L.load()
-        gs = [torch.zeros_like(w) if g is None else L.dev_f32(g, "grad") for g, w in zip(grads[:T], ws_)]
+        gs = [torch.zeros_like(w) if g is None else L.like_layout(g, w) for g, w in zip(grads[:T], ws_)]
         dws = [torch.empty_like(w) for w in ws_]
         scratch = torch.empty(lib.alignq_weight_multi_ws_bytes(T), dtype=torch.uint8, device=ws_[0].device)
         L.check(lib.alignq_weight_quant_bwd_multi(T, L.ptr_array(gs), L.ptr_array(list(ws_)), L.ptr(ms),

@@ -40,7 +40,7 @@ class ActQuantFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, k, act_range, formula):
-        x = L.dev_f32(x, "activation")
+        x = L.dense_f32(x, "activation")
         xq = torch.empty_like(x)
         L.check(L.load().alignq_act_quant_fwd(L.ptr(x), L.ptr(xq), None, x.numel(), int(k), float(act_range),
                                               int(formula), L.stream_ptr()), "alignq_act_quant_fwd")
@@ -51,7 +51,7 @@ class ActQuantFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (x,) = ctx.saved_tensors
-        g = L.dev_f32(g, "grad")
+        g = L.like_layout(g, x)
         dx = torch.empty_like(x)
         L.check(L.load().alignq_act_quant_bwd(L.ptr(g), L.ptr(x), L.ptr(dx), x.numel(), ctx.act_range,
                                               L.stream_ptr()), "alignq_act_quant_bwd")
@@ -70,7 +70,7 @@ def act_quant_bins(x, k, act_range, formula):
 
 # ------------------------------------------------------------------------------------------------ R3
 def weight_stats(w):
-    w = L.dev_f32(w, "weight")
+    w = L.dense_f32(w, "weight")
     lib = L.load()
     ms = torch.empty(2, dtype=torch.float32, device=w.device)
     ws = _ws(lib.alignq_weight_ws_bytes(w.numel()), w.device)
@@ -79,7 +79,7 @@ def weight_stats(w):
 
 
 def weight_quant_given_stats(w, ms, k, formula, want_aux=True, want_bins=False):
-    w = L.dev_f32(w, "weight")
+    w = L.dense_f32(w, "weight")
     q = torch.empty_like(w)
     c = torch.empty_like(w) if want_aux else None
     pdf = torch.empty_like(w) if want_aux else None
@@ -96,7 +96,7 @@ class WeightQuantFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, w, k, formula):
-        w = L.dev_f32(w, "weight")
+        w = L.dense_f32(w, "weight")
         ms = weight_stats(w)
         q, c, pdf, _ = weight_quant_given_stats(w, ms, k, formula, True)
         ctx.save_for_backward(w, ms)
@@ -106,7 +106,7 @@ class WeightQuantFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _gc, _gp):
         w, ms = ctx.saved_tensors
-        g = L.dev_f32(g, "grad")
+        g = L.like_layout(g, w)
         lib = L.load()
         dw = torch.empty_like(w)
         ws = _ws(lib.alignq_weight_ws_bytes(w.numel()), w.device)
@@ -185,7 +185,7 @@ class SiteFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, alterD, gamma, k, act_range, eps, mu, rho):
-        x = L.dev_f32(x, "activation")
+        x = L.dense_f32(x, "activation")
         A = L.dev_f32(alterD, "alterD")
         Gm = L.dev_f32(gamma, "gamma")
         B, F = _as_bf(x)
@@ -217,7 +217,7 @@ class SiteFn(torch.autograd.Function):
         act_range, eps, mu = ctx.cfg
         B, F = _as_bf(x)
         dim = A.shape[0]
-        g_xq = None if g_xq is None else L.dev_f32(g_xq, "grad")
+        g_xq = None if g_xq is None else L.like_layout(g_xq, x)
         if g_loss is None:
             g_loss = torch.zeros((), dtype=torch.float32, device=x.device)
         g_loss = L.dev_f32(g_loss, "loss grad")

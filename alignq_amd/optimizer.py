@@ -53,23 +53,22 @@ class SGD(Optimizer):
             for i, p in enumerate(group["params"]):
                 if p.grad is None:
                     continue
-                L.dev_f32(p, "parameter")
-                if not p.is_contiguous():
-                    raise RuntimeError("alignq_amd.SGD needs contiguous parameters")
+                if L.dense_f32(p, "parameter") is not p:
+                    raise RuntimeError("alignq_amd.SGD needs dense (contiguous or channels-last) parameters")
                 g = p.grad
-                if not g.is_contiguous():
-                    g = p.grad = g.contiguous()
+                if g.stride() != p.stride():
+                    g = p.grad = L.like_layout(g, p)
                 first, buf = 0, None
                 if mom != 0:
                     state = self.state[p]
                     if "momentum_buffer" not in state:
-                        state["momentum_buffer"] = torch.empty_like(p, memory_format=torch.contiguous_format)
+                        state["momentum_buffer"] = torch.empty_like(p)
                         first = 1
                     buf = state["momentum_buffer"]
                 c = pdf = None
                 if bitW < 32 and i in idx:
                     j = idx.index(i)
-                    c, pdf = L.dev_f32(w_cdf[j].detach(), "w_cdf"), L.dev_f32(w_pdf[j].detach(), "w_pdf")
+                    c, pdf = L.like_layout(w_cdf[j].detach(), p, "w_cdf"), L.like_layout(w_pdf[j].detach(), p, "w_pdf")
                 ps.append(p); gs.append(g); bufs.append(buf); firsts.append(first); cdfs.append(c); pdfs.append(pdf)
             if not ps:
                 continue

@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true", help="skip the per-kernel roofline measurements")
     ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--dp-selftest", action="store_true", help="run the DP path (RCCL all-reduce, two graphs) even at N=1")
+    ap.add_argument("--channels-last", action="store_true", help="NHWC activations/weights end to end")
     ap.add_argument("--miopen-benchmark", action="store_true", help="torch.backends.cudnn.benchmark (MIOpen find)")
     return ap.parse_args()
 
@@ -167,8 +169,11 @@ def main():
     dev = torch.device("cuda", local)
     torch.backends.cudnn.benchmark = bool(a.miopen_benchmark)
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or a.dp_selftest:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
     from alignq_amd import _lib, config, dp
     from alignq_amd.resnet import resnet20_quant, resnet56_quant
@@ -184,12 +189,16 @@ def main():
     config.args.train_batch_size = a.batch
     torch.manual_seed(0)
     model = (resnet20_quant if a.model == "resnet20" else resnet56_quant)(a.bits, a.bits).to(dev).train()
+    if a.channels_last:
+        model = model.to(memory_format=torch.channels_last)
     step = TrainStep(model)
-    if world > 1:
-        dp.attach(step)
+    if world > 1 or a.dp_selftest:
+        dp.attach(step, force=a.dp_selftest)
     gen = torch.Generator().manual_seed(rank)
     x = torch.randn(a.batch, 3, 32, 32, generator=gen).to(dev)
     y = torch.randint(0, 10, (a.batch,), generator=gen).to(dev)
+    if a.channels_last:
+        x = x.contiguous(memory_format=torch.channels_last)
     if a.no_graph:
         for _ in range(3):
             step(x, y)
@@ -228,7 +237,7 @@ def main():
                                    f"(cdf_alignment_admm/resnet-20-cifar-10), batch {a.batch}/GPU, "
                                    f"{'HIP-graph replay' if not a.no_graph else 'eager launches'}",
                        "global_batch": a.batch * world, "parallelism": f"dp{world}",
-                       "final_ce": float(ce), "final_trans_loss": float(tl) if tl is not None else None},
+                       "final_ce": float(ce.detach()), "final_trans_loss": float(tl.detach()) if tl is not None else None},
         }
         if not a.no_kernels:
             counts = {}
@@ -244,7 +253,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(a.batch, a.bits, a.model, a.cpu_steps)
             res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
         print(json.dumps(res))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
