@@ -28,6 +28,18 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int NT = 1024;
 
+// Diagnostic build only (-DALIGNQ_STAMPS, never shipped): wall-clock stamps (100 MHz) of workgroup 0 at phase
+// boundaries, written to a buffer no kernel reads.
+#ifdef ALIGNQ_STAMPS
+__device__ unsigned long long g_stamps[64];
+#define STAMP(i)                                                             \
+  do {                                                                       \
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps[i] = wall_clock64();   \
+  } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ float4 ld4(const float* __restrict__ x, int64_t off, int col, int64_t F, bool row_ok,
                                       bool aligned) {
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -101,6 +113,7 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
 #pragma unroll
   for (int e = 0; e < 16; e++) { acc0[e] = 0.0f; acc1[e] = 0.0f; }
 
+  STAMP(0);
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int col0 = tile * TFv;
     const int col = col0 + 4 * c;
@@ -123,6 +136,7 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
         if (xq) st4(xq, off, col, F, ok, aligned, q);
       }
     }
+    STAMP(1);
     // ---- column means: registers -> wave shuffles over the row groups of the wave -> LDS over waves ----
     {
       float sx[4] = {0, 0, 0, 0}, st[4] = {0, 0, 0, 0};
@@ -207,6 +221,7 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
       }
     }
     __syncthreads();
+    STAMP(2);
     // ---- standardise into LDS ---------------------------------------------------------------------
     {
       float mx[4], rx[4], mt[4], rt[4];
@@ -234,6 +249,7 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
       }
     }
     __syncthreads();
+    STAMP(3);
     // ---- MFMA: upper-triangular tiles of  Th Th^T - Xh Xh^T  over this tile's features ----------------
     {
       const int ra = (I0 * 32 + l31) * LDv + h, rb = (J0 * 32 + l31) * LDv + h;
@@ -266,6 +282,7 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
     __syncthreads();   // LDS tiles are overwritten by the next iteration / by the combine below
   }
 
+  STAMP(4);
   // ---- combine the two K-halves of every tile in LDS (fixed order => deterministic), write the slab -----
   float* C = lds;   // [10][32][32]
   if (kh0 == 0) {
@@ -285,6 +302,7 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
   float4* slab4 = reinterpret_cast<float4*>(slabs + (int64_t)blockIdx.x * 10240);
   const float4* C4 = reinterpret_cast<const float4*>(C);
   for (int e = tid; e < 2560; e += NT) slab4[e] = C4[e];
+  STAMP(5);
 }
 
 // ================================================================================================ reduce
@@ -483,6 +501,7 @@ __global__ __launch_bounds__(NTB) void site_bwd4_kernel(const float* __restrict_
     }
   }
   const float invB = 1.0f / (float)B, invBm1 = 1.0f / (float)(B - 1);
+  STAMP(10);
 
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int col0 = tile * TFv;
@@ -533,6 +552,7 @@ __global__ __launch_bounds__(NTB) void site_bwd4_kernel(const float* __restrict_
       }
     }
     __syncthreads();
+    STAMP(11);
     // ---- MFMA: accX = S[I-block, :] * Xh[:, column block],  accT likewise with Th --------------------
     f32x16 accX, accT;
 #pragma unroll
@@ -543,6 +563,7 @@ __global__ __launch_bounds__(NTB) void site_bwd4_kernel(const float* __restrict_
       accX = __builtin_amdgcn_mfma_f32_32x32x2f32(sfrag[s], Xs[a], accX, 0, 0, 0);
       if (PAIR) accT = __builtin_amdgcn_mfma_f32_32x32x2f32(sfrag[s], Ts[a], accT, 0, 0, 0);
     }
+    STAMP(12);
     // ---- projections over this wave's 32 batch rows: sum dVh, sum dVh*Vh ------------------------------
     {
       float x0 = 0.f, x1 = 0.f, t0 = 0.f, t1 = 0.f;
@@ -566,6 +587,7 @@ __global__ __launch_bounds__(NTB) void site_bwd4_kernel(const float* __restrict_
       }
     }
     __syncthreads();
+    STAMP(13);
     // ---- assemble in LDS: out = g*jac + jac*ct - cx   (PAIR)   |   out = cx   (!PAIR) -------------------
     {
       float sx0 = 0.f, sx1 = 0.f, st0 = 0.f, st1 = 0.f;
@@ -602,6 +624,7 @@ __global__ __launch_bounds__(NTB) void site_bwd4_kernel(const float* __restrict_
       }
     }
     __syncthreads();
+    STAMP(14);
     // ---- copy out: full 256-byte rows ---------------------------------------------------------------
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -611,6 +634,7 @@ __global__ __launch_bounds__(NTB) void site_bwd4_kernel(const float* __restrict_
       st4(dx, (int64_t)row * F + col, col, F, row < B, aligned, o);
     }
     __syncthreads();   // LDS is overwritten by the next tile
+    STAMP(15);
   }
 }
 
@@ -680,5 +704,11 @@ int launch_bwd4(bool pair, const Geom& g, const float* gup, const float* S, cons
   RET_ON_ERR();
   return 0;
 }
+
+#ifdef ALIGNQ_STAMPS
+extern "C" int alignq_debug_read_stamps(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64);
+}
+#endif
 
 }  // namespace alignq_site
