@@ -77,23 +77,49 @@ __device__ __forceinline__ void tile_ij(int tile, int& I, int& J) {
 }
 
 // ================================================================================================ forward
+// Split-bf16 Gram: every standardised value v is stored as hi = bf16(v), lo = bf16(v - hi) and a product u*v is
+// evaluated as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  bf16 products are exact
+// in fp32, the dropped lo*lo term is < 2^-16 relative and the representation error of hi+lo is 2^-17: the Gram
+// difference D comes out within 6e-7 of an fp64 evaluation (plain fp32 sgemm: 2e-7; tolerance 1e-5) while the
+// matrix pipe does 16x the K per instruction at half the cycles of v_mfma_f32_32x32x2_f32 (3 instead of 8 MFMAs
+// per 16 features, 32 instead of 64 cycles each).  Measured MFMA phase at F=16384: 6.0 us -> see DESIGN.md §4.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// flip the sign of 8 packed bf16 (4 VGPRs, 4 v_xor): lets T-Gram minus X-Gram share ONE accumulator
+__device__ __forceinline__ bf16x8 neg8(bf16x8 v) {
+  u32x4 u = __builtin_bit_cast(u32x4, v);
+  u ^= (u32x4){0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u};
+  return __builtin_bit_cast(bf16x8, u);
+}
+
+__device__ __forceinline__ void split_bf16(float v, __bf16& hi, __bf16& lo) {
+  hi = (__bf16)v;
+  lo = (__bf16)(v - (float)hi);
+}
+
 template <int TFv, bool PAIR>
 __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__ x, int B, int64_t F, int k, float r,
                                                        float eps, float* __restrict__ xq, float* __restrict__ slabs,
                                                        float* __restrict__ stats, int n_tiles, int aligned,
                                                        unsigned* __restrict__ counter) {
-  constexpr int LDv = TFv + 1;
+  constexpr int LDB = TFv + 8;                    // bf16 elements per LDS row (row bytes multiple of 16, see bank note)
   constexpr int LPR = TFv / 4;                    // lanes per row (float4 each)
   constexpr int RG = NT / LPR;                    // row groups: 64 / 128 / 256
   constexpr int RJ = (128 + RG - 1) / RG;         // rows per thread: 2 / 1 / 1
   constexpr int NOP = PAIR ? 2 : 1;
-  constexpr int TILE = 128 * LDv;
-  constexpr int STAGE = (2 * TILE > 10240) ? 2 * TILE : 10240;
-  __shared__ __attribute__((aligned(16))) float lds[STAGE + 4 * TFv + 2 * 16 * TFv];
-  float* Xs = lds;
-  float* Ts = lds + TILE;
-  float* colv = lds + STAGE;                      // mean_x, rho_x, mean_t, rho_t : [4][TFv]
-  float* red = colv + 4 * TFv;                    // [2 operands][16 waves][TFv]
+  constexpr int ARR = 128 * LDB;                  // bf16 elements per array
+  constexpr int STAGE_BYTES = (4 * ARR * 2 > 40960) ? 4 * ARR * 2 : 40960;
+  constexpr int KSPLIT = (TFv >= 32) ? 2 : 1;     // K-halves per tile (a half must hold >= 16 features)
+  constexpr int KSTEPS = TFv / 16 / KSPLIT;       // 16-feature MFMA steps per item
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STAGE_BYTES + (4 * TFv + 2 * 16 * TFv) * 4];
+  __bf16* Xhi = reinterpret_cast<__bf16*>(lds_raw);
+  __bf16* Xlo = Xhi + ARR;
+  __bf16* Thi = Xhi + 2 * ARR;
+  __bf16* Tlo = Xhi + 3 * ARR;
+  float* colv = reinterpret_cast<float*>(lds_raw + STAGE_BYTES);   // mean_x, rho_x, mean_t, rho_t : [4][TFv]
+  float* red = colv + 4 * TFv;                                     // [2 operands][16 waves][TFv]
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c = tid % LPR, rg = tid / LPR;
@@ -103,13 +129,16 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
 
   if (blockIdx.x == 0 && tid == 0 && counter) *counter = 0u;   // arrival counter of the reduce kernel's epilogue
 
-  // work items of this wave: q = w (all waves) and q = 16 + w (waves 0..3); item q = (tile q%10, K-half q/10)
-  const int tile0 = w % 10, kh0 = w / 10;
-  const int tile1 = 6 + w;                        // only meaningful for w < 4 (K-half 1)
+  // work items: KSPLIT==2: q = w (all waves) and q = 16 + w (waves 0..3), item q = (tile q%10, K-half q/10);
+  //             KSPLIT==1: waves 0..9 own tile w with the whole K.
+  const int tile0 = w % 10, kh0 = (KSPLIT == 2) ? w / 10 : 0;
+  const bool item0 = (KSPLIT == 2) || (w < 10);
+  const bool item1 = (KSPLIT == 2) && (w < 4);
+  const int tile1 = 6 + w;                        // K-half 1
   int I0, J0, I1 = 0, J1 = 0;
   tile_ij(tile0, I0, J0);
-  if (w < 4) tile_ij(tile1, I1, J1);
-  f32x16 acc0, acc1;
+  if (item1) tile_ij(tile1, I1, J1);
+  f32x16 acc0, acc1;    // PAIR: T-Gram minus X-Gram (the x A-operand enters negated); else the X-Gram
 #pragma unroll
   for (int e = 0; e < 16; e++) { acc0[e] = 0.0f; acc1[e] = 0.0f; }
 
@@ -222,7 +251,7 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
     }
     __syncthreads();
     STAMP(2);
-    // ---- standardise into LDS ---------------------------------------------------------------------
+    // ---- standardise, split into bf16 hi/lo, stage in LDS (one 8-byte store per array and row) -------------
     {
       float mx[4], rx[4], mt[4], rt[4];
 #pragma unroll
@@ -239,43 +268,77 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
           const bool ok = row < B;
           const float xe[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
           const float te[4] = {tv[j].x, tv[j].y, tv[j].z, tv[j].w};
+          bf16x4 xh, xl, th, tl;
 #pragma unroll
           for (int e = 0; e < 4; e++) {
             const bool okc = ok && (col + e < F);
-            Xs[row * LDv + 4 * c + e] = okc ? (xe[e] - mx[e]) * rx[e] : 0.0f;
-            if (PAIR) Ts[row * LDv + 4 * c + e] = okc ? (te[e] - mt[e]) * rt[e] : 0.0f;
+            __bf16 a, b2;
+            split_bf16(okc ? (xe[e] - mx[e]) * rx[e] : 0.0f, a, b2);
+            xh[e] = a; xl[e] = b2;
+            if (PAIR) {
+              split_bf16(okc ? (te[e] - mt[e]) * rt[e] : 0.0f, a, b2);
+              th[e] = a; tl[e] = b2;
+            }
+          }
+          const int o = row * LDB + 4 * c;
+          *reinterpret_cast<bf16x4*>(Xhi + o) = xh;
+          *reinterpret_cast<bf16x4*>(Xlo + o) = xl;
+          if (PAIR) {
+            *reinterpret_cast<bf16x4*>(Thi + o) = th;
+            *reinterpret_cast<bf16x4*>(Tlo + o) = tl;
           }
         }
       }
     }
     __syncthreads();
     STAMP(3);
-    // ---- MFMA: upper-triangular tiles of  Th Th^T - Xh Xh^T  over this tile's features ----------------
-    {
-      const int ra = (I0 * 32 + l31) * LDv + h, rb = (J0 * 32 + l31) * LDv + h;
-#pragma unroll 4
-      for (int k0 = kh0 * (TFv / 2); k0 < (kh0 + 1) * (TFv / 2); k0 += 2) {
-        const float ax = Xs[ra + k0], bx = Xs[rb + k0];
+    // ---- MFMA: upper-triangular tiles of Th Th^T and Xh Xh^T (3 bf16 MFMAs each per 16 features) ------------
+    // A operand: lane -> row I*32 + l31, 8 consecutive features k0 + 8h..; B operand: row J*32 + l31, same features
+    if (item0) {
+      const int ra = (I0 * 32 + l31) * LDB + 8 * h, rb = (J0 * 32 + l31) * LDB + 8 * h;
+#pragma unroll
+      for (int s = 0; s < KSTEPS; s++) {
+        const int k0 = (kh0 * KSTEPS + s) * 16;
+        bf16x8 axh = *reinterpret_cast<const bf16x8*>(Xhi + ra + k0);
+        bf16x8 axl = *reinterpret_cast<const bf16x8*>(Xlo + ra + k0);
+        const bf16x8 bxh = *reinterpret_cast<const bf16x8*>(Xhi + rb + k0);
+        const bf16x8 bxl = *reinterpret_cast<const bf16x8*>(Xlo + rb + k0);
+        if (PAIR) { axh = neg8(axh); axl = neg8(axl); }
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(axh, bxh, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(axh, bxl, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(axl, bxh, acc0, 0, 0, 0);
         if (PAIR) {
-          const float at = Ts[ra + k0], bt = Ts[rb + k0];
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(at, bt, acc0, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(-ax, bx, acc0, 0, 0, 0);
-        } else {
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ax, bx, acc0, 0, 0, 0);
+          const bf16x8 ath = *reinterpret_cast<const bf16x8*>(Thi + ra + k0);
+          const bf16x8 atl = *reinterpret_cast<const bf16x8*>(Tlo + ra + k0);
+          const bf16x8 bth = *reinterpret_cast<const bf16x8*>(Thi + rb + k0);
+          const bf16x8 btl = *reinterpret_cast<const bf16x8*>(Tlo + rb + k0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ath, bth, acc0, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ath, btl, acc0, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(atl, bth, acc0, 0, 0, 0);
         }
       }
-      if (w < 4) {
-        const int ra1 = (I1 * 32 + l31) * LDv + h, rb1 = (J1 * 32 + l31) * LDv + h;
-#pragma unroll 4
-        for (int k0 = TFv / 2; k0 < TFv; k0 += 2) {
-          const float ax = Xs[ra1 + k0], bx = Xs[rb1 + k0];
-          if (PAIR) {
-            const float at = Ts[ra1 + k0], bt = Ts[rb1 + k0];
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(at, bt, acc1, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(-ax, bx, acc1, 0, 0, 0);
-          } else {
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ax, bx, acc1, 0, 0, 0);
-          }
+    }
+    if (item1) {
+      const int ra = (I1 * 32 + l31) * LDB + 8 * h, rb = (J1 * 32 + l31) * LDB + 8 * h;
+#pragma unroll
+      for (int s = 0; s < KSTEPS; s++) {
+        const int k0 = (KSTEPS + s) * 16;
+        bf16x8 axh = *reinterpret_cast<const bf16x8*>(Xhi + ra + k0);
+        bf16x8 axl = *reinterpret_cast<const bf16x8*>(Xlo + ra + k0);
+        const bf16x8 bxh = *reinterpret_cast<const bf16x8*>(Xhi + rb + k0);
+        const bf16x8 bxl = *reinterpret_cast<const bf16x8*>(Xlo + rb + k0);
+        if (PAIR) { axh = neg8(axh); axl = neg8(axl); }
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(axh, bxh, acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(axh, bxl, acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(axl, bxh, acc1, 0, 0, 0);
+        if (PAIR) {
+          const bf16x8 ath = *reinterpret_cast<const bf16x8*>(Thi + ra + k0);
+          const bf16x8 atl = *reinterpret_cast<const bf16x8*>(Tlo + ra + k0);
+          const bf16x8 bth = *reinterpret_cast<const bf16x8*>(Thi + rb + k0);
+          const bf16x8 btl = *reinterpret_cast<const bf16x8*>(Tlo + rb + k0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ath, bth, acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ath, btl, acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(atl, bth, acc1, 0, 0, 0);
         }
       }
     }
@@ -283,20 +346,23 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
   }
 
   STAMP(4);
-  // ---- combine the two K-halves of every tile in LDS (fixed order => deterministic), write the slab -----
-  float* C = lds;   // [10][32][32]
-  if (kh0 == 0) {
+  // ---- combine the K-halves of every tile in LDS in a fixed order (deterministic); write the slab ---------------
+  float* C = reinterpret_cast<float*>(lds_raw);   // [10][32][32]
+  if (item0 && kh0 == 0) {
 #pragma unroll
-    for (int e = 0; e < 16; e++) C[tile0 * 1024 + ((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + l31] = acc0[e];
+    for (int e = 0; e < 16; e++)
+      C[tile0 * 1024 + ((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + l31] = acc0[e];
   }
   __syncthreads();
-  if (kh0 == 1) {
+  if (item0 && kh0 == 1) {
 #pragma unroll
-    for (int e = 0; e < 16; e++) C[tile0 * 1024 + ((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + l31] += acc0[e];
+    for (int e = 0; e < 16; e++)
+      C[tile0 * 1024 + ((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + l31] += acc0[e];
   }
-  if (w < 4) {
+  if (item1) {
 #pragma unroll
-    for (int e = 0; e < 16; e++) C[tile1 * 1024 + ((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + l31] += acc1[e];
+    for (int e = 0; e < 16; e++)
+      C[tile1 * 1024 + ((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + l31] += acc1[e];
   }
   __syncthreads();
   float4* slab4 = reinterpret_cast<float4*>(slabs + (int64_t)blockIdx.x * 10240);
