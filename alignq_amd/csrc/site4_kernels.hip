@@ -529,10 +529,13 @@ __global__ __launch_bounds__(256) void site_prep_kernel(const float* __restrict_
 }
 
 // ================================================================================================ backward
-// 512 threads = 8 waves (2 per SIMD, 256-VGPR budget: the 64 register-resident S fragments + two accumulators fit
-// without scratch; a 16-wave variant spilled 52 B/lane, visible as 13.6 MB of extra WRITE_SIZE per launch).
-// wave w: row block I = w>>1, column block cj = w&1 of the 64-feature tile, BOTH operands (x and t), so the final
-// assembly is wave-local.
+// 512 threads = 8 waves; wave w: row block I = w>>1 (32 batch rows of dVh), column block cj = w&1 of the 64-feature
+// tile, BOTH operands, so the final assembly is wave-local.
+// dVh = S * Vh on split-bf16 MFMA (same 3-term scheme as the forward; relative error 5e-6, tolerance 1e-4):
+//   A = S[i][j] (K = batch index j): 8 k-steps x (hi, lo) fragments live in registers for the whole kernel;
+//   B = Vh[j][c] needs 8 CONSECUTIVE j per lane, so the standardised tiles are staged TRANSPOSED in LDS
+//       ([feature][batch], bf16 hi/lo): the load mapping gives each thread one feature column and 16 consecutive
+//       batch rows (256-byte coalesced row segments per wave instruction), two 16-byte LDS stores per array.
 constexpr int NTB = 512;
 
 template <bool PAIR>
@@ -540,30 +543,54 @@ __global__ __launch_bounds__(NTB) void site_bwd4_kernel(const float* __restrict_
                                                         const float* __restrict__ x, const float* __restrict__ stats,
                                                         int B, int64_t F, float r, float eps, float* __restrict__ dx,
                                                         int n_tiles, int aligned) {
+  (void)aligned;
   constexpr int TFv = 64, LDv = 65, TILE = 128 * LDv;
-  constexpr int NARR = PAIR ? 4 : 2;
-  __shared__ __attribute__((aligned(16))) float lds[NARR * TILE + 4 * TFv + 4 * 2 * 2 * TFv];
-  float* Xs = lds;                         // standardised x
-  float* Os = lds + TILE;                  // output staging (PAIR: starts as g*jac)
-  float* Ts = lds + 2 * TILE;              // standardised t            (PAIR)
-  float* Js = lds + 3 * TILE;              // dt/dx                     (PAIR)
-  float* colv = lds + NARR * TILE;         // mean_x, rho_x, mean_t, rho_t [4][64]
-  float* red = colv + 4 * TFv;             // [4 row blocks][2 operands][2][64]
+  constexpr int LDT = 128 + 8;                       // bf16 elements per transposed row (272 B: 16-B aligned, 4-bank skew)
+  constexpr int TARR = TFv * LDT;                    // bf16 elements per transposed array
+  constexpr int NT_ARR = PAIR ? 4 : 2;
+  constexpr int NF_ARR = PAIR ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[NT_ARR * TARR * 2 + NF_ARR * TILE * 4 + 4 * 2 * 2 * TFv * 4];
+  __bf16* XThi = reinterpret_cast<__bf16*>(lds_raw);
+  __bf16* XTlo = XThi + TARR;
+  __bf16* TThi = XThi + 2 * TARR;                    // (PAIR)
+  __bf16* TTlo = XThi + 3 * TARR;                    // (PAIR)
+  float* Os = reinterpret_cast<float*>(lds_raw + NT_ARR * TARR * 2);   // [128][65] output staging (PAIR: starts as g*jac)
+  float* Js = Os + TILE;                                               // [128][65] dt/dx (PAIR)
+  float* red = Os + NF_ARR * TILE;                                     // [4 row blocks][2 operands][2][64]
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int c = tid & 15, rg = tid >> 4;   // load mapping: 16 lanes per row, 32 row groups, rows rg + 32*j
   const int h = lane >> 5, l31 = lane & 31;
   const int I = w >> 1, cj = w & 1;
   const int cc = cj * 32 + l31;            // this lane's feature column inside the tile (accumulator layout)
+  const int lcol = lane, lrow0 = w * 16;   // load mapping: one feature column, 16 consecutive batch rows
 
-  // S fragments (symmetric, already scaled): A[i][k] = S[k][i], i = I*32 + l31, k = 2s + h  -> coalesced in i
-  float sfrag[64];
+  // S fragments (already scaled, symmetric): A[i][k], i = I*32 + l31, k = 16*ks + 8h + jj, split into bf16 hi/lo
+  bf16x8 sh[8], sl[8];
   {
     const int i = I * 32 + l31;
+    const bool vec = ((B & 7) == 0) && ((reinterpret_cast<uintptr_t>(S) & 15) == 0);
 #pragma unroll
-    for (int s = 0; s < 64; s++) {
-      const int kk = 2 * s + h;
-      sfrag[s] = (i < B && kk < B) ? S[kk * B + i] : 0.0f;
+    for (int ks = 0; ks < 8; ks++) {
+      const int kk0 = 16 * ks + 8 * h;
+      float v[8];
+      if (vec) {                              // 8 consecutive j of row i: two 16-byte loads
+        float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = a4;
+        if (i < B && kk0 < B) {
+          a4 = *reinterpret_cast<const float4*>(S + i * B + kk0);
+          b4 = *reinterpret_cast<const float4*>(S + i * B + kk0 + 4);
+        }
+        v[0] = a4.x; v[1] = a4.y; v[2] = a4.z; v[3] = a4.w; v[4] = b4.x; v[5] = b4.y; v[6] = b4.z; v[7] = b4.w;
+      } else {
+#pragma unroll
+        for (int jj = 0; jj < 8; jj++) v[jj] = (i < B && kk0 + jj < B) ? S[i * B + kk0 + jj] : 0.0f;
+      }
+#pragma unroll
+      for (int jj = 0; jj < 8; jj++) {
+        __bf16 a, b2;
+        split_bf16(v[jj], a, b2);
+        sh[ks][jj] = a;
+        sl[ks][jj] = b2;
+      }
     }
   }
   const float invB = 1.0f / (float)B, invBm1 = 1.0f / (float)(B - 1);
@@ -571,74 +598,97 @@ __global__ __launch_bounds__(NTB) void site_bwd4_kernel(const float* __restrict_
 
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int col0 = tile * TFv;
-    const int col = col0 + 4 * c;
-    if (tid < (PAIR ? 4 : 2) * TFv) {
-      const int a = tid >> 6, q = tid & 63;
-      colv[a * TFv + q] = (col0 + q < F) ? stats[(int64_t)a * F + col0 + q] : 0.0f;
-    }
-    __syncthreads();
-    // ---- load x (and g), recompute t / jac, standardise into LDS ------------------------------------
+    const bool lcol_ok = (col0 + lcol) < F;
+    // ---- load x (and g) for (feature lcol, rows lrow0..+15), recompute t / jac, standardise ---------------
     {
-      float mx[4], rx[4], mt[4], rt[4];
+      const float mx = lcol_ok ? stats[col0 + lcol] : 0.f;
+      const float rx = lcol_ok ? stats[F + col0 + lcol] : 0.f;
+      const float mt = (PAIR && lcol_ok) ? stats[2 * F + col0 + lcol] : 0.f;
+      const float rt = (PAIR && lcol_ok) ? stats[3 * F + col0 + lcol] : 0.f;
+      float xr[16], gr[16];
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
-        mx[e] = colv[4 * c + e];
-        rx[e] = colv[TFv + 4 * c + e];
-        mt[e] = PAIR ? colv[2 * TFv + 4 * c + e] : 0.f;
-        rt[e] = PAIR ? colv[3 * TFv + 4 * c + e] : 0.f;
-      }
-      float4 xv[4], gv[4];
-#pragma unroll
-      for (int j = 0; j < 4; j++) {        // issue all global loads first
-        const int row = rg + 32 * j;
-        const int64_t off = (int64_t)row * F + col;
-        xv[j] = ld4(x, off, col, F, row < B, aligned);
-        gv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (PAIR && gup) gv[j] = ld4(gup, off, col, F, row < B, aligned);
+      for (int q = 0; q < 16; q++) {          // all 32 loads in flight before the first use
+        const int row = lrow0 + q;
+        const bool ok = lcol_ok && row < B;
+        const int64_t off = (int64_t)row * F + col0 + lcol;
+        xr[q] = ok ? x[off] : 0.0f;
+        gr[q] = (PAIR && gup && ok) ? gup[off] : 0.0f;
       }
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int row = rg + 32 * j;
-        const bool ok = row < B;
-        const float xe[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
-        const float ge[4] = {gv[j].x, gv[j].y, gv[j].z, gv[j].w};
+      for (int half = 0; half < 2; half++) {
+        bf16x8 xh, xl, th, tl;
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const bool okc = ok && (col + e < F);
-          const int a = row * LDv + 4 * c + e;
-          Xs[a] = okc ? (xe[e] - mx[e]) * rx[e] : 0.0f;
+        for (int q = 0; q < 8; q++) {
+          const int row = lrow0 + 8 * half + q;
+          const bool ok = lcol_ok && row < B;
+          const float xe = xr[8 * half + q];
+          __bf16 a, b2;
+          split_bf16(ok ? (xe - mx) * rx : 0.0f, a, b2);
+          xh[q] = a; xl[q] = b2;
           if (PAIR) {
             float t, jac;
-            act_transform_fast(xe[e], r, &t, &jac);
-            Ts[a] = okc ? (t - mt[e]) * rt[e] : 0.0f;
-            Js[a] = jac;
-            Os[a] = ge[e] * jac;
+            act_transform_fast(xe, r, &t, &jac);
+            split_bf16(ok ? (t - mt) * rt : 0.0f, a, b2);
+            th[q] = a; tl[q] = b2;
+            Js[row * LDv + lcol] = jac;
+            Os[row * LDv + lcol] = gr[8 * half + q] * jac;
           }
+        }
+        const int o = lcol * LDT + lrow0 + 8 * half;
+        *reinterpret_cast<bf16x8*>(XThi + o) = xh;
+        *reinterpret_cast<bf16x8*>(XTlo + o) = xl;
+        if (PAIR) {
+          *reinterpret_cast<bf16x8*>(TThi + o) = th;
+          *reinterpret_cast<bf16x8*>(TTlo + o) = tl;
         }
       }
     }
     __syncthreads();
     STAMP(11);
-    // ---- MFMA: accX = S[I-block, :] * Xh[:, column block],  accT likewise with Th --------------------
+    // ---- MFMA: accX = S[I-block, :] * Xh[:, column block], accT likewise (3 bf16 MFMAs per 16 batch rows) ---------
     f32x16 accX, accT;
 #pragma unroll
     for (int e = 0; e < 16; e++) { accX[e] = 0.0f; accT[e] = 0.0f; }
 #pragma unroll
-    for (int s = 0; s < 64; s++) {
-      const int a = (2 * s + h) * LDv + cc;
-      accX = __builtin_amdgcn_mfma_f32_32x32x2f32(sfrag[s], Xs[a], accX, 0, 0, 0);
-      if (PAIR) accT = __builtin_amdgcn_mfma_f32_32x32x2f32(sfrag[s], Ts[a], accT, 0, 0, 0);
+    for (int ks = 0; ks < 8; ks++) {
+      const int o = cc * LDT + 16 * ks + 8 * h;
+      const bf16x8 bxh = *reinterpret_cast<const bf16x8*>(XThi + o);
+      const bf16x8 bxl = *reinterpret_cast<const bf16x8*>(XTlo + o);
+      accX = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sh[ks], bxh, accX, 0, 0, 0);
+      accX = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sh[ks], bxl, accX, 0, 0, 0);
+      accX = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sl[ks], bxh, accX, 0, 0, 0);
+      if (PAIR) {
+        const bf16x8 bth = *reinterpret_cast<const bf16x8*>(TThi + o);
+        const bf16x8 btl = *reinterpret_cast<const bf16x8*>(TTlo + o);
+        accT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sh[ks], bth, accT, 0, 0, 0);
+        accT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sh[ks], btl, accT, 0, 0, 0);
+        accT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sl[ks], bth, accT, 0, 0, 0);
+      }
     }
     STAMP(12);
-    // ---- projections over this wave's 32 batch rows: sum dVh, sum dVh*Vh ------------------------------
+    // ---- projections over this wave's 32 batch rows: sum dVh, sum dVh*Vh.  Vh of this lane's accumulator cells
+    //      (rows (e&3)+8(e>>2)+4h of block I, column cc) are 4 consecutive entries of the transposed row: 8-byte reads
     {
       float x0 = 0.f, x1 = 0.f, t0 = 0.f, t1 = 0.f;
 #pragma unroll
-      for (int e = 0; e < 16; e++) {
-        const int a = (I * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LDv + cc;
-        x0 += accX[e];
-        x1 += accX[e] * Xs[a];
-        if (PAIR) { t0 += accT[e]; t1 += accT[e] * Ts[a]; }
+      for (int g4 = 0; g4 < 4; g4++) {
+        const int o = cc * LDT + I * 32 + 8 * g4 + 4 * h;
+        const bf16x4 a = *reinterpret_cast<const bf16x4*>(XThi + o);
+        const bf16x4 b2 = *reinterpret_cast<const bf16x4*>(XTlo + o);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          x0 += accX[4 * g4 + q];
+          x1 += accX[4 * g4 + q] * ((float)a[q] + (float)b2[q]);
+        }
+        if (PAIR) {
+          const bf16x4 c2 = *reinterpret_cast<const bf16x4*>(TThi + o);
+          const bf16x4 d2 = *reinterpret_cast<const bf16x4*>(TTlo + o);
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            t0 += accT[4 * g4 + q];
+            t1 += accT[4 * g4 + q] * ((float)c2[q] + (float)d2[q]);
+          }
+        }
       }
       x0 += __shfl_xor(x0, 32, 64);
       x1 += __shfl_xor(x1, 32, 64);
@@ -666,8 +716,9 @@ __global__ __launch_bounds__(NTB) void site_bwd4_kernel(const float* __restrict_
           st1 += red[((rb * 2 + 1) * 2 + 1) * TFv + cc];
         }
       }
-      const float rho_x = colv[TFv + cc];
-      const float rho_t = PAIR ? colv[3 * TFv + cc] : 0.0f;
+      const bool cok = (col0 + cc) < F;
+      const float rho_x = cok ? stats[F + col0 + cc] : 0.f;
+      const float rho_t = (PAIR && cok) ? stats[3 * F + col0 + cc] : 0.0f;
       // through-std factor (sd+eps)/sd = 1/(1-eps*rho); torch's std backward is 0 where sd == 0
       float kap_x = 1.0f, kap_t = 1.0f;
       if (eps != 0.0f) {
@@ -678,26 +729,38 @@ __global__ __launch_bounds__(NTB) void site_bwd4_kernel(const float* __restrict_
       const float mean_x = sx0 * invB, proj_x = sx1 * invBm1 * kap_x;
       const float mean_t = st0 * invB, proj_t = st1 * invBm1 * kap_t;
 #pragma unroll
-      for (int e = 0; e < 16; e++) {
-        const int a = (I * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LDv + cc;
-        const float cx = rho_x * (accX[e] - mean_x - Xs[a] * proj_x);
+      for (int g4 = 0; g4 < 4; g4++) {
+        const int o = cc * LDT + I * 32 + 8 * g4 + 4 * h;
+        const bf16x4 xa = *reinterpret_cast<const bf16x4*>(XThi + o);
+        const bf16x4 xb = *reinterpret_cast<const bf16x4*>(XTlo + o);
+        bf16x4 ta, tb;
         if (PAIR) {
-          const float ct = rho_t * (accT[e] - mean_t - Ts[a] * proj_t);
-          Os[a] = Os[a] + ct * Js[a] - cx;     // corr(x,x) enters D with a minus sign
-        } else {
-          Os[a] = cx;
+          ta = *reinterpret_cast<const bf16x4*>(TThi + o);
+          tb = *reinterpret_cast<const bf16x4*>(TTlo + o);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int e = 4 * g4 + q;
+          const int a = (I * 32 + 8 * g4 + 4 * h + q) * LDv + cc;
+          const float cx = rho_x * (accX[e] - mean_x - ((float)xa[q] + (float)xb[q]) * proj_x);
+          if (PAIR) {
+            const float ct = rho_t * (accT[e] - mean_t - ((float)ta[q] + (float)tb[q]) * proj_t);
+            Os[a] = Os[a] + ct * Js[a] - cx;     // corr(x,x) enters D with a minus sign
+          } else {
+            Os[a] = cx;
+          }
         }
       }
     }
     __syncthreads();
     STAMP(14);
-    // ---- copy out: full 256-byte rows ---------------------------------------------------------------
+    // ---- copy out: 256-byte row segments, one feature column per lane -----------------------------------
+    if (lcol_ok) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int row = rg + 32 * j;
-      const int a = row * LDv + 4 * c;
-      const float4 o = make_float4(Os[a], Os[a + 1], Os[a + 2], Os[a + 3]);
-      st4(dx, (int64_t)row * F + col, col, F, row < B, aligned, o);
+      for (int q = 0; q < 16; q++) {
+        const int row = lrow0 + q;
+        if (row < B) dx[(int64_t)row * F + col0 + lcol] = Os[row * LDv + lcol];
+      }
     }
     __syncthreads();   // LDS is overwritten by the next tile
     STAMP(15);
