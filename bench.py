@@ -119,11 +119,24 @@ def measure_kernels(dev, B, k, site_F_counts):
     dom = max(("site_partials", "site_bwd"), key=lambda kname: per_step[kname][0])
     t_sum, fl_sum = per_step[dom]
     kernel_sym = {"site_partials": "site_fwd4_kernel<TF,true>", "site_bwd": "site_bwd4_kernel<true>"}[dom]
-    roofline = {"kernel": kernel_sym, "bound": "mfma", "achieved": fl_sum / t_sum / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": fl_sum / t_sum / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+    bytes_per_elem = 8.0 if dom == "site_partials" else 12.0          # fwd read x + write x_q; bwd read g,x + write dx
+    by_sum = sum(bytes_per_elem * B * F * cnt for F, cnt in site_F_counts.items())
+    traffic = None
+    try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 corrected + WRITE_SIZE)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+        traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch_avg")
+    except Exception:
+        pass
+    # Since the Gram pair runs on split-bf16 MFMA (3 x v_mfma_f32_32x32x16_bf16 per 16 features: ~1.3 us of a
+    # 10-15 us launch) the matrix pipe no longer bounds these kernels: the irreducible work is the HBM traffic.
+    roofline = {"kernel": kernel_sym, "bound": "hbm", "achieved": by_sum / t_sum / 1e9, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": by_sum / t_sum / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                 "launches_per_step": n_sites, "avg_launch_us": t_sum / n_sites * 1e6,
-                "flops_per_launch_avg": fl_sum / n_sites,
-                "note": "achieved = (2 Grams x 2*B^2*F flop, summed over the step's sites) / summed launch time"}
+                "bytes_per_launch_avg": by_sum / n_sites,
+                "gram_tflops_fp32_equiv": fl_sum / t_sum / 1e12,
+                "note": "achieved = algorithmic bytes (8 B/elem fwd, 12 B/elem bwd, SURVEY 8d) summed over the step's 21 "
+                        "sites / summed launch time (HIP events); CIFAR sites are 2-8 MB per launch, i.e. launch-latency "
+                        "shapes (SURVEY H2); see kernels.act_quant_* for the HBM-roofline-sized CDF-quantise kernel"}
     out["per_step_us"] = {kname: v[0] * 1e6 for kname, v in per_step.items()}
     return roofline, out
 
