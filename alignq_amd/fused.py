@@ -61,3 +61,46 @@ def prequantize_weights(convs):
         T = len(cs)
         for i, c in enumerate(cs):
             c.quantize_fn._pre = (c.weight, outs[i], outs[T + i], outs[2 * T + i])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+class DeferredLosses:
+    """Fast path for a whole-model step: the per-site slab reduction + ADMM loss is launched on a side stream (it is
+    not needed by the next layer, only x_q is) and the 21..57 site losses are summed once at the end instead of one
+    tiny add kernel per site.  While active, activation modules return the python float 0.0 as their trans_loss and
+    park the real loss tensor here; `total()` joins the side stream and returns the sum (differentiable)."""
+
+    def __init__(self, use_side_stream=False):
+        # Measured on MI355X / ROCm 7.2 (ResNet-20 step, one HIP graph): forking the 21 reductions onto a side stream
+        # costs more in cross-queue graph dependencies than the overlap returns (4.09 vs 3.44 ms per step), so the
+        # default keeps everything on one stream and only defers the loss sum.
+        self.side = torch.cuda.Stream() if use_side_stream else None
+        self.losses = []
+
+    def __enter__(self):
+        global _active
+        self.losses = []
+        _active = self
+        return self
+
+    def __exit__(self, *exc):
+        global _active
+        _active = None
+        return False
+
+    def add(self, loss):
+        self.losses.append(loss)
+
+    def total(self):
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
+        if not self.losses:
+            return None
+        return torch.stack(self.losses).sum()
+
+
+_active = None
+
+
+def active_deferred():
+    return _active

@@ -184,7 +184,11 @@ class SiteFn(torch.autograd.Function):
     gradient prep; fused standardisation-backward + MFMA kernel).  D is returned for ADMM_OPT.step (values only)."""
 
     @staticmethod
-    def forward(ctx, x, alterD, gamma, k, act_range, eps, mu, rho):
+    def forward(ctx, x, alterD, gamma, k, act_range, eps, mu, rho, side=None, bufs=None):
+        """side: optional torch.cuda.Stream for the slab reduction + loss (it is off the critical path of the
+        network's forward: only x_q feeds the next layer); the CALLER must make the consuming stream wait for it.
+        bufs: optional dict of persistent per-site buffers (ws, D, scal) — required with `side` so that no
+        allocator block is recycled under in-flight side-stream work."""
         x = L.dense_f32(x, "activation")
         A = L.dev_f32(alterD, "alterD")
         Gm = L.dev_f32(gamma, "gamma")
@@ -195,13 +199,22 @@ class SiteFn(torch.autograd.Function):
         lib = L.load()
         dev = x.device
         xq = torch.empty_like(x)
-        D = torch.empty(B, B, dtype=torch.float32, device=dev)
         stats = torch.empty(4, F, dtype=torch.float32, device=dev)
-        scal = torch.empty(4, dtype=torch.float32, device=dev)
-        ws = _ws(lib.alignq_site_ws_bytes(B, F), dev)
+        key = (B, F)
+        if bufs is not None and bufs.get("key") == key:
+            ws, D, scal = bufs["ws"], bufs["D"], bufs["scal"]
+        else:
+            D = torch.empty(B, B, dtype=torch.float32, device=dev)
+            scal = torch.empty(4, dtype=torch.float32, device=dev)
+            ws = _ws(lib.alignq_site_ws_bytes(B, F), dev)
+            if bufs is not None:
+                bufs.update(key=key, ws=ws, D=D, scal=scal)
         st = L.stream_ptr()
         L.check(lib.alignq_site_partials(L.ptr(x), B, F, int(k), float(act_range), float(eps), L.ptr(xq),
                                          L.ptr(stats), L.ptr(ws), st), "alignq_site_partials")
+        if side is not None and bufs is not None:
+            side.wait_stream(torch.cuda.current_stream())
+            st = side.cuda_stream
         L.check(lib.alignq_site_reduce_loss(L.ptr(ws), B, F, L.ptr(D), L.ptr(A), L.ptr(Gm), dim, float(mu),
                                             float(rho), L.ptr(scal), st), "alignq_site_reduce_loss")
         loss = scal[0]
@@ -228,4 +241,4 @@ class SiteFn(torch.autograd.Function):
         L.check(lib.alignq_site_bwd_fused(L.ptr(g_xq), L.ptr(D), L.ptr(A), L.ptr(Gm), dim, L.ptr(scal), mu,
                                           L.ptr(g_loss), L.ptr(x), L.ptr(stats), B, F, act_range, eps, L.ptr(dx),
                                           L.ptr(dA), L.ptr(dG), L.ptr(ws), L.stream_ptr()), "alignq_site_bwd_fused")
-        return dx, dA, dG, None, None, None, None, None
+        return dx, dA, dG, None, None, None, None, None, None, None

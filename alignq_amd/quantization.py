@@ -101,6 +101,16 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
             return x, 0
         if config.args.method == "ours" and a_bit < 32:
             admm = mod.opt
+            from . import fused
+            deferred = fused.active_deferred()
+            if deferred is not None:
+                if not hasattr(mod, "_site_bufs"):
+                    mod._site_bufs = {}
+                xq, loss, D = ops.SiteFn.apply(x, admm.alterD, admm.gamma, a_bit, config.args.act_range, eps,
+                                               admm.mu, admm.rho, deferred.side, mod._site_bufs)
+                admm.D = D
+                deferred.add(loss)
+                return xq, 0.0          # the real loss is summed once by DeferredLosses.total()
             xq, loss, D = ops.SiteFn.apply(x, admm.alterD, admm.gamma, a_bit, config.args.act_range, eps,
                                            admm.mu, admm.rho)
             admm.D = D

@@ -13,13 +13,15 @@ import torch
 import torch.nn.functional as F
 
 from . import config
-from .fused import prequantize_weights
+from .fused import DeferredLosses, prequantize_weights
 from .optimizer import ADMM_OPT, SGD
 
 
 class TrainStep:
-    def __init__(self, model, lr=0.04, momentum=0.9, weight_decay=1e-4, grad_hook=None):
+    def __init__(self, model, lr=0.04, momentum=0.9, weight_decay=1e-4, grad_hook=None, defer_losses=True):
         self.model = model
+        self.defer_losses = defer_losses
+        self._deferred = DeferredLosses() if (defer_losses and torch.cuda.is_available()) else None
         named = list(model.named_parameters())
         self.param_t = [(n, p) for n, p in named if "alterD" not in n and "gamma" not in n]
         self.param_admm = [(n, p) for n, p in named if "alterD" in n or "gamma" in n]
@@ -50,11 +52,17 @@ class TrainStep:
         if self.optimizer_admm is not None:
             self.optimizer_admm.zero_grad(set_to_none=set_to_none)
         prequantize_weights(self.all_convs)     # all conv weights in two launches
-        out = model(x)
-        if isinstance(out, tuple):
-            logits, trans_loss = out
+        if self._deferred is not None and self.admms:
+            with self._deferred as d:
+                out = model(x)
+                logits = out[0] if isinstance(out, tuple) else out
+                trans_loss = d.total()          # joins the side stream, one stacked sum
         else:
-            logits, trans_loss = out, None
+            out = model(x)
+            if isinstance(out, tuple):
+                logits, trans_loss = out
+            else:
+                logits, trans_loss = out, None
         ce = F.cross_entropy(logits, y)
         total = ce if trans_loss is None else ce + trans_loss
         total.backward()
