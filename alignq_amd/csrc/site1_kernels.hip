@@ -1,0 +1,369 @@
+// site1_kernels.hip — ADMM-site kernels for SMALL batches (2 <= B <= 32: Office-31's train batch 28, short last
+// batches) on gfx950.  These sites are HBM-bound (B flop/byte is below the machine balance) and can be
+// huge (config 5: 28 x 802816 = 90 MB), so the design goal is streaming without workgroup barriers:
+//
+//   * each WAVE owns 32-feature sub-tiles, two lanes per feature column (16 batch rows each): a lane loads its rows
+//     (every wave instruction reads two 128-byte row segments), so the per-feature batch statistics are register
+//     reductions plus ONE cross-half shuffle — no LDS, no __syncthreads anywhere in the main loop; 16 rows per lane
+//     keep the kernels at <=~100 VGPRs (a one-lane-per-column variant needed 128/203 and ran at 3/2 waves per SIMD);
+//   * the standardised column is packed as (bf16 hi << 16 | bf16 lo) words and written to a wave-private LDS buffer
+//     [feature][row] with 16-byte stores; the same wave reads it back in MFMA fragment order (lane = row, 8 consecutive
+//     features: conflict-free 4-byte reads, hi and lo in one word) and runs the 3-term split-bf16 Gram
+//     (v_mfma_f32_32x32x16_bf16) into ONE 32x32 accumulator per wave, D = T-Gram - X-Gram (x A-operand sign-flipped);
+//   * backward: the same staging feeds S*Xh / S*Th (S = 32x32, two K-steps, register-resident hi/lo A fragments);
+//     the 32x32 results go back through the wave's LDS buffer into lane = column layout, where the standardisation
+//     backward (batch projections) is again pure register arithmetic and dx leaves as 256-byte row segments.
+//   * the four waves of a workgroup only meet at the very end of the forward to add their accumulators into the slab.
+#include <hip/hip_runtime.h>
+
+#include "../../include/alignq.h"
+#include "alignq_math.h"
+#include "site_internal.h"
+
+using namespace alignq;
+
+namespace alignq_site {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWaves = 4;
+constexpr int kThreads1 = 64 * kWaves;
+constexpr int SUBF = 32;                // features per wave iteration: lane = (feature l&31, row half l>>5)
+constexpr int RPL = 16;                 // rows per lane (two lanes share a feature column: halves of 16 rows)
+constexpr int LDW = 36;                 // words per feature row of the wave buffer (32 rows + pad; 144 B: 16-B aligned)
+constexpr int WBUF = SUBF * LDW;        // words per wave buffer
+
+__device__ __forceinline__ unsigned pack_hi_lo(float v) {
+  const __bf16 hi = (__bf16)v;
+  const __bf16 lo = (__bf16)(v - (float)hi);
+  return ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16) | (unsigned)__builtin_bit_cast(unsigned short, lo);
+}
+
+// 8 packed words -> bf16x8 of the high halves / of the low halves (element j from word j)
+__device__ __forceinline__ void unpack8(const unsigned (&wd)[8], bf16x8& hi, bf16x8& lo) {
+  u32x4 h, l;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    h[q] = (wd[2 * q] >> 16) | (wd[2 * q + 1] & 0xffff0000u);
+    l[q] = (wd[2 * q] & 0xffffu) | (wd[2 * q + 1] << 16);
+  }
+  hi = __builtin_bit_cast(bf16x8, h);
+  lo = __builtin_bit_cast(bf16x8, l);
+}
+
+__device__ __forceinline__ bf16x8 neg8(bf16x8 v) {
+  u32x4 u = __builtin_bit_cast(u32x4, v);
+  u ^= (u32x4){0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u};
+  return __builtin_bit_cast(bf16x8, u);
+}
+
+// wave-private LDS hand-off between lanes of ONE wave: LDS operations of a wave complete in order; the fence keeps
+// the compiler from moving accesses across the phase boundary.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// stage this lane's 16 standardised rows of feature l31 (zeros beyond B) into the wave buffer: W[feature][row]
+__device__ __forceinline__ void stage_rows(unsigned* __restrict__ W, int l31, int hh, const unsigned (&wd)[RPL]) {
+  u32x4* dst = reinterpret_cast<u32x4*>(W + l31 * LDW + RPL * hh);
+#pragma unroll
+  for (int q = 0; q < RPL / 4; q++) dst[q] = (u32x4){wd[4 * q], wd[4 * q + 1], wd[4 * q + 2], wd[4 * q + 3]};
+}
+
+// Gram of the staged 32 features: acc (+/-)= V V^T, lane = (row l&31, feature group h): 2 K-steps of 16 features
+template <bool NEG>
+__device__ __forceinline__ void gram32(const unsigned* __restrict__ W, int l31, int h, f32x16& acc) {
+#pragma unroll
+  for (int ks = 0; ks < SUBF / 16; ks++) {
+    unsigned wd[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) wd[j] = W[(16 * ks + 8 * h + j) * LDW + l31];
+    bf16x8 hi, lo;
+    unpack8(wd, hi, lo);
+    const bf16x8 ahi = NEG ? neg8(hi) : hi, alo = NEG ? neg8(lo) : lo;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, lo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, hi, acc, 0, 0, 0);
+  }
+}
+
+// ================================================================================================ forward
+template <bool PAIR>
+__global__ __launch_bounds__(kThreads1) void site1_fwd_kernel(const float* __restrict__ x, int B, int64_t F, int k,
+                                                              float r, float eps, float* __restrict__ xq,
+                                                              float* __restrict__ slabs, float* __restrict__ stats,
+                                                              int n_sub, unsigned* __restrict__ counter) {
+  __shared__ __attribute__((aligned(16))) unsigned lds[(kWaves * WBUF > 4096) ? kWaves * WBUF : 4096];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;      // h doubles as the row half of the load mapping
+  unsigned* W = lds + w * WBUF;
+  const Levels nlev = make_levels(k, fabsf(r) <= 8.0f);
+  const float invB = 1.0f / (float)B, invBm1 = 1.0f / (float)(B - 1);
+  if (blockIdx.x == 0 && tid == 0 && counter) *counter = 0u;
+
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; e++) acc[e] = 0.0f;
+
+  for (int sub = blockIdx.x * kWaves + w; sub < n_sub; sub += gridDim.x * kWaves) {
+    const int64_t col = (int64_t)sub * SUBF + l31;
+    const bool cok = col < F;
+    const float* __restrict__ xp = x + (int64_t)(RPL * h) * F + col;
+    float* __restrict__ qp = xq ? xq + (int64_t)(RPL * h) * F + col : nullptr;
+    float xr[RPL], tr[RPL];
+#pragma unroll
+    for (int q = 0; q < RPL; q++) xr[q] = (cok && RPL * h + q < B) ? xp[(int64_t)q * F] : 0.0f;
+    // ---- transform + quantise; batch statistics: registers + one cross-half shuffle ---------------------------
+    float sx = 0.f, st = 0.f;
+#pragma unroll
+    for (int q = 0; q < RPL; q++) {
+      tr[q] = 0.f;
+      if (RPL * h + q < B) {
+        if (PAIR) {
+          float b;
+          const float qq = act_quant1<0>(xr[q], k, nlev, r, &tr[q], &b);
+          if (qp && cok) qp[(int64_t)q * F] = qq;
+          st += tr[q];
+        }
+        sx += xr[q];
+      }
+    }
+    sx += __shfl_xor(sx, 32, 64);
+    if (PAIR) st += __shfl_xor(st, 32, 64);
+    const float mx = sx * invB, mt = st * invB;
+    float vx = 0.f, vt = 0.f;
+#pragma unroll
+    for (int q = 0; q < RPL; q++) {
+      if (RPL * h + q < B) {
+        const float d = xr[q] - mx;
+        vx += d * d;
+        if (PAIR) { const float d2 = tr[q] - mt; vt += d2 * d2; }
+      }
+    }
+    vx += __shfl_xor(vx, 32, 64);
+    if (PAIR) vt += __shfl_xor(vt, 32, 64);
+    const float rx = 1.0f / (sqrtf(vx * invBm1) + eps);
+    const float rt = PAIR ? 1.0f / (sqrtf(vt * invBm1) + eps) : 0.f;
+    if (stats && cok && h == 0) {
+      stats[col] = mx;
+      stats[F + col] = rx;
+      if (PAIR) { stats[2 * F + col] = mt; stats[3 * F + col] = rt; }
+    }
+    // ---- x operand: stage, Gram (negated when it is subtracted from the t Gram) --------------------------------
+    {
+      unsigned wd[RPL];
+#pragma unroll
+      for (int q = 0; q < RPL; q++) wd[q] = (cok && RPL * h + q < B) ? pack_hi_lo((xr[q] - mx) * rx) : 0u;
+      stage_rows(W, l31, h, wd);
+    }
+    wave_lds_sync();
+    gram32<PAIR>(W, l31, h, acc);
+    wave_lds_sync();
+    if (PAIR) {
+      unsigned wd[RPL];
+#pragma unroll
+      for (int q = 0; q < RPL; q++) wd[q] = (cok && RPL * h + q < B) ? pack_hi_lo((tr[q] - mt) * rt) : 0u;
+      stage_rows(W, l31, h, wd);
+      wave_lds_sync();
+      gram32<false>(W, l31, h, acc);
+      wave_lds_sync();
+    }
+  }
+  // ---- the only workgroup-wide step: add the four wave accumulators, write the [32][32] slab -------------------
+  __syncthreads();
+  float* Cw = reinterpret_cast<float*>(lds) + w * 1024;
+#pragma unroll
+  for (int e = 0; e < 16; e++) Cw[((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + l31] = acc[e];
+  __syncthreads();
+  const float* C = reinterpret_cast<const float*>(lds);
+  float* slab = slabs + (int64_t)blockIdx.x * 1024;
+  for (int e = tid; e < 1024; e += kThreads1) slab[e] = C[e] + C[1024 + e] + C[2048 + e] + C[3072 + e];
+}
+
+// ================================================================================================ backward
+// dVh = S Vh for the staged 32 features: [32 batch rows][32 features] in accumulator layout
+// (lane -> feature l31, rows (e&3)+8(e>>2)+4h)
+__device__ __forceinline__ void s_times_staged(const unsigned* __restrict__ W, const bf16x8 (&sh)[2],
+                                               const bf16x8 (&sl)[2], int l31, int h, f32x16& acc) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ks++) {
+    // B operand: feature l31, 8 consecutive batch rows 16ks + 8h .. : contiguous words of W
+    const u32x4* src = reinterpret_cast<const u32x4*>(W + l31 * LDW + 16 * ks + 8 * h);
+    const u32x4 a = src[0], b = src[1];
+    const unsigned wd[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    bf16x8 hi, lo;
+    unpack8(wd, hi, lo);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sh[ks], hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sh[ks], lo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sl[ks], hi, acc, 0, 0, 0);
+  }
+}
+
+// accumulator layout -> (feature l31, row half hh) layout through the wave buffer (as fp32): R[feature][row]
+__device__ __forceinline__ void acc_to_rows(float* __restrict__ R, int l31, int h, const f32x16& acc,
+                                            float (&out)[RPL]) {
+#pragma unroll
+  for (int e = 0; e < 16; e++) R[l31 * LDW + (e & 3) + 8 * (e >> 2) + 4 * h] = acc[e];
+  wave_lds_sync();
+  const float4* src = reinterpret_cast<const float4*>(R + l31 * LDW + RPL * h);
+#pragma unroll
+  for (int q = 0; q < RPL / 4; q++) {
+    const float4 v = src[q];
+    out[4 * q] = v.x; out[4 * q + 1] = v.y; out[4 * q + 2] = v.z; out[4 * q + 3] = v.w;
+  }
+  wave_lds_sync();
+}
+
+template <bool PAIR>
+__global__ __launch_bounds__(kThreads1) void site1_bwd_kernel(const float* __restrict__ gup, const float* __restrict__ S,
+                                                              const float* __restrict__ x,
+                                                              const float* __restrict__ stats, int B, int64_t F, float r,
+                                                              float eps, float* __restrict__ dx, int n_sub) {
+  __shared__ __attribute__((aligned(16))) unsigned lds[kWaves * WBUF];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  unsigned* W = lds + w * WBUF;
+  float* R = reinterpret_cast<float*>(W);
+  const float invB = 1.0f / (float)B, invBm1 = 1.0f / (float)(B - 1);
+
+  // S fragments (already scaled, symmetric): A[i][k], i = l31, k = 16ks + 8h + jj
+  bf16x8 sh[2], sl[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ks++) {
+    unsigned wd[8];
+#pragma unroll
+    for (int jj = 0; jj < 8; jj++) {
+      const int kk = 16 * ks + 8 * h + jj;
+      wd[jj] = (l31 < B && kk < B) ? pack_hi_lo(S[l31 * B + kk]) : 0u;
+    }
+    unpack8(wd, sh[ks], sl[ks]);
+  }
+
+  for (int sub = blockIdx.x * kWaves + w; sub < n_sub; sub += gridDim.x * kWaves) {
+    const int64_t col = (int64_t)sub * SUBF + l31;
+    const bool cok = col < F;
+    const int64_t base = (int64_t)(RPL * h) * F + col;
+    float xr[RPL], gr[RPL], out[RPL];
+#pragma unroll
+    for (int q = 0; q < RPL; q++) {
+      const bool ok = cok && RPL * h + q < B;
+      xr[q] = ok ? x[base + (int64_t)q * F] : 0.0f;
+      gr[q] = (PAIR && gup && ok) ? gup[base + (int64_t)q * F] : 0.0f;
+    }
+    const float mx = cok ? stats[col] : 0.f, rx = cok ? stats[F + col] : 0.f;
+    const float mt = (PAIR && cok) ? stats[2 * F + col] : 0.f, rt = (PAIR && cok) ? stats[3 * F + col] : 0.f;
+    float kap_x = 1.0f, kap_t = 1.0f;       // (sd+eps)/sd = 1/(1-eps*rho); torch's std backward is 0 where sd == 0
+    if (eps != 0.0f) {
+      const float dxn = 1.0f - eps * rx, dtn = 1.0f - eps * rt;
+      kap_x = (dxn > 1e-12f) ? 1.0f / dxn : 0.0f;
+      kap_t = (dtn > 1e-12f) ? 1.0f / dtn : 0.0f;
+    }
+    // ---- x operand -------------------------------------------------------------------------------------------
+    {
+      unsigned wd[RPL];
+#pragma unroll
+      for (int q = 0; q < RPL; q++) wd[q] = (cok && RPL * h + q < B) ? pack_hi_lo((xr[q] - mx) * rx) : 0u;
+      stage_rows(W, l31, h, wd);
+    }
+    wave_lds_sync();
+    {
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[e] = 0.f;
+      s_times_staged(W, sh, sl, l31, h, acc);
+      wave_lds_sync();
+      float d[RPL];
+      acc_to_rows(R, l31, h, acc, d);
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int q = 0; q < RPL; q++) {
+        if (RPL * h + q < B) { s0 += d[q]; s1 += d[q] * ((xr[q] - mx) * rx); }
+      }
+      s0 += __shfl_xor(s0, 32, 64);
+      s1 += __shfl_xor(s1, 32, 64);
+      const float mean_d = s0 * invB, proj = s1 * invBm1 * kap_x;
+#pragma unroll
+      for (int q = 0; q < RPL; q++) {
+        const float cx = rx * (d[q] - mean_d - ((xr[q] - mx) * rx) * proj);
+        out[q] = PAIR ? -cx : cx;          // corr(x,x) enters D with a minus sign
+      }
+    }
+    // ---- t operand (PAIR) -------------------------------------------------------------------------------------
+    if (PAIR) {
+      float th[RPL];
+      {
+        unsigned wd[RPL];
+#pragma unroll
+        for (int q = 0; q < RPL; q++) {
+          float t, jac;
+          act_transform_fast(xr[q], r, &t, &jac);
+          th[q] = (t - mt) * rt;
+          wd[q] = (cok && RPL * h + q < B) ? pack_hi_lo(th[q]) : 0u;
+        }
+        stage_rows(W, l31, h, wd);
+      }
+      wave_lds_sync();
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[e] = 0.f;
+      s_times_staged(W, sh, sl, l31, h, acc);
+      wave_lds_sync();
+      float d[RPL];
+      acc_to_rows(R, l31, h, acc, d);
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int q = 0; q < RPL; q++) {
+        if (RPL * h + q < B) { s0 += d[q]; s1 += d[q] * th[q]; }
+      }
+      s0 += __shfl_xor(s0, 32, 64);
+      s1 += __shfl_xor(s1, 32, 64);
+      const float mean_d = s0 * invB, proj = s1 * invBm1 * kap_t;
+#pragma unroll
+      for (int q = 0; q < RPL; q++) {
+        const float ct = rt * (d[q] - mean_d - th[q] * proj);
+        out[q] += (gr[q] + ct) * act_jac(xr[q], r);
+      }
+    }
+    if (cok) {
+#pragma unroll
+      for (int q = 0; q < RPL; q++)
+        if (RPL * h + q < B) dx[base + (int64_t)q * F] = out[q];
+    }
+  }
+}
+
+#define RET_ON_ERR1()                                 \
+  do {                                                \
+    hipError_t e__ = hipGetLastError();               \
+    if (e__ != hipSuccess) return (int)e__;           \
+  } while (0)
+
+}  // namespace
+
+int launch_partials1(bool pair, const Geom& g, const float* x, int B, int64_t F, int k, float r, float eps, float* xq,
+                     float* stats, float* ws, hipStream_t st) {
+  unsigned* counter = reinterpret_cast<unsigned*>(ws + (size_t)g.grid * g.slab_floats + kPartFloats);
+  const int n_sub = (int)((F + SUBF - 1) / SUBF);
+  if (pair) hipLaunchKernelGGL((site1_fwd_kernel<true>), g.grid, kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter);
+  else hipLaunchKernelGGL((site1_fwd_kernel<false>), g.grid, kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter);
+  RET_ON_ERR1();
+  return 0;
+}
+
+int launch_bwd1(bool pair, const float* gup, const float* S, const float* x, const float* stats, int B, int64_t F,
+                float r, float eps, float* dx, hipStream_t st) {
+  const int n_sub = (int)((F + SUBF - 1) / SUBF);
+  int grid = (n_sub + kWaves - 1) / kWaves;
+  if (grid > 2048) grid = 2048;
+  if (pair) hipLaunchKernelGGL((site1_bwd_kernel<true>), grid, kThreads1, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_sub);
+  else hipLaunchKernelGGL((site1_bwd_kernel<false>), grid, kThreads1, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_sub);
+  RET_ON_ERR1();
+  return 0;
+}
+
+}  // namespace alignq_site

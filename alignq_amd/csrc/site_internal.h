@@ -30,13 +30,25 @@ inline Geom geom(int B, int64_t F) {
   } else {
     g.tf = 64;
     g.n_tiles = (int)((F + 63) / 64);
-    g.grid = g.n_tiles < 512 ? g.n_tiles : 512;
+    // 8 workgroups (of 4 waves) per CU keep enough loads in flight for the HBM-bound small-batch sites; the slabs
+    // are only (32*nb)^2 floats each
+    g.grid = g.n_tiles < 2048 ? g.n_tiles : 2048;
+    if (g.nb == 1) {                 // site1 kernels: four wave-autonomous 32-feature sub-tiles per workgroup
+      g.grid = (int)((F + 127) / 128);
+      if (g.grid > 2048) g.grid = 2048;
+    }
     g.slab_floats = (32 * g.nb) * (32 * g.nb);
   }
   return g;
 }
 
 inline size_t ws_floats(const Geom& g) { return (size_t)g.grid * g.slab_floats + kTailFloats; }
+
+// ---- launchers defined in site1_kernels.hip (2 <= B <= 32) ---------------------------------------------------
+int launch_partials1(bool pair, const Geom& g, const float* x, int B, int64_t F, int k, float r, float eps, float* xq,
+                     float* stats, float* ws, hipStream_t st);
+int launch_bwd1(bool pair, const float* gup, const float* S, const float* x, const float* stats, int B, int64_t F,
+                float r, float eps, float* dx, hipStream_t st);
 
 // ---- launchers defined in site4_kernels.hip ----------------------------------------------------------------
 int launch_partials4(bool pair, const Geom& g, const float* x, int B, int64_t F, int k, float r, float eps, float* xq,

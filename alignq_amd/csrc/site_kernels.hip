@@ -454,6 +454,7 @@ template <bool PAIR>
 int launch_partials(const Geom& g, const float* x, int B, int64_t F, int k, float r, float eps, float* xq, float* stats,
                     float* ws, hipStream_t st) {
   if (g.nb == 4) return launch_partials4(PAIR, g, x, B, F, k, r, eps, xq, stats, ws, st);
+  if (g.nb == 1) return launch_partials1(PAIR, g, x, B, F, k, r, eps, xq, stats, ws, st);
   const int aligned = ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
                       (!xq || (reinterpret_cast<uintptr_t>(xq) & 15) == 0);
   unsigned* counter = reinterpret_cast<unsigned*>(ws + (size_t)g.grid * g.slab_floats + kPartFloats);
@@ -469,6 +470,7 @@ template <bool PAIR>
 int launch_bwd(const Geom& g, const float* gup, const float* S, const float* x, const float* stats, int B, int64_t F,
                float r, float eps, float* dx, hipStream_t st) {
   if (g.nb == 4) return launch_bwd4(PAIR, g, gup, S, x, stats, B, F, r, eps, dx, st);
+  if (g.nb == 1) return launch_bwd1(PAIR, gup, S, x, stats, B, F, r, eps, dx, st);
   const int n_tiles = (int)((F + TF - 1) / TF);
   const int grid = n_tiles < 2048 ? n_tiles : 2048;
   const int aligned = ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);

@@ -31,7 +31,8 @@ def test_library_exports_every_declared_symbol():
     tail = 1024 + 16                                     # loss partials + arrival counter
     assert lib.alignq_site_ws_bytes(128, 16384) == (256 * 10 * 1024 + tail) * 4   # 10 upper-triangular 32x32 tiles
     assert lib.alignq_site_ws_bytes(128, 4096) == (256 * 10 * 1024 + tail) * 4    # 16-feature tiles keep 256 CUs busy
-    assert lib.alignq_site_ws_bytes(28, 802816) == (512 * 32 * 32 + tail) * 4
+    assert lib.alignq_site_ws_bytes(28, 802816) == (2048 * 32 * 32 + tail) * 4
+    assert lib.alignq_site_ws_bytes(28, 1024) == (8 * 32 * 32 + tail) * 4            # 32 sub-tiles of 32 features / 4 waves
     assert lib.alignq_site_ws_bytes(129, 64) == 0
     assert lib.alignq_site_bwd_ws_bytes(128) == 128 * 128 * 4
 
