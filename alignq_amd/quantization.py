@@ -104,10 +104,13 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
             from . import fused
             deferred = fused.active_deferred()
             if deferred is not None:
-                if not hasattr(mod, "_site_bufs"):
-                    mod._site_bufs = {}
+                bufs = None
+                if deferred.side is not None:        # persistent buffers only matter for side-stream launches
+                    if not hasattr(mod, "_site_bufs"):
+                        mod._site_bufs = {}
+                    bufs = mod._site_bufs
                 xq, loss, D = ops.SiteFn.apply(x, admm.alterD, admm.gamma, a_bit, config.args.act_range, eps,
-                                               admm.mu, admm.rho, deferred.side, mod._site_bufs)
+                                               admm.mu, admm.rho, deferred.side, bufs)
                 admm.D = D
                 deferred.add(loss)
                 return xq, 0.0          # the real loss is summed once by DeferredLosses.total()

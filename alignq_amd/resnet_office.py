@@ -1,0 +1,138 @@
+"""Harness model for BASELINE.json config 5: ResNet-50 + DANN head for Office-31 (224x224 inputs), the caller of the
+hot path in the Office tree.  Wiring follows cdf_alignment_admm/dann_office/model/resnet.py: Bottleneck :89-156 (act_q1,
+act_q2 = plain CDF quantisers, act_q3 = activation_quantize_fn2 with the block's ADMM), ResNet :159-271 (stem conv7x7 ->
+bn -> act_q0 -> relu -> maxpool; the fc layer exists but only `feature` is used), ReverseLayerF :302-313, DANN :316-334.
+Attribute and parameter names are the reference's (feature.layerN.M.{conv1,bn1,conv2,bn2,conv3,bn3,admm0,downsample.0,
+downsample.1}, class_classifier.c_fc3, domain_classifier.d_fc2) so its checkpoints load.  No ImageNet download: random init
+(the reference's `pretrained=True` default needs the network)."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import config
+from . import office as Q
+from .admm import ADMM
+
+
+def conv3x3(wbit, stage, cin, cout, stride=1):
+    return Q.conv2d_Q_fn(w_bit=wbit, stage=stage)(cin, cout, kernel_size=3, stride=stride, padding=1, bias=False)
+
+
+def conv1x1(wbit, stage, cin, cout, stride=1):
+    return Q.conv2d_Q_fn(w_bit=wbit, stage=stage)(cin, cout, kernel_size=1, stride=stride, bias=False)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, wbit, abit, stage, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        width = planes
+        self.conv1 = conv1x1(wbit, stage, inplanes, width)
+        self.bn1 = nn.BatchNorm2d(width)
+        self.conv2 = conv3x3(wbit, stage, width, width, stride)
+        self.bn2 = nn.BatchNorm2d(width)
+        self.conv3 = conv1x1(wbit, stage, width, planes * self.expansion)
+        self.bn3 = nn.BatchNorm2d(planes * self.expansion)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+        dim = config.args.train_batch_size if self.training else config.args.eval_batch_size
+        self.admm0 = ADMM(dim)
+        self.act_q1 = Q.activation_quantize_fn(a_bit=abit, stage=stage)
+        self.act_q2 = Q.activation_quantize_fn(a_bit=abit, stage=stage)
+        self.act_q3 = Q.activation_quantize_fn2(a_bit=abit, stage=stage, admm=self.admm0)
+
+    def forward(self, x):
+        trans_loss = 0.
+        identity = x
+        out = self.relu(self.act_q1(self.bn1(self.conv1(x))))
+        out = self.relu(self.act_q2(self.bn2(self.conv2(out))))
+        out, loss = self.act_q3(self.bn3(self.conv3(out)))
+        trans_loss += loss
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        out += identity
+        out = self.relu(out)
+        return out, trans_loss
+
+
+class ResNet(nn.Module):
+    def __init__(self, wbit, abit, stage, block, layers, num_classes=1000):
+        super().__init__()
+        self.wbit, self.abit, self.stage = wbit, abit, stage
+        self.act_q0 = Q.activation_quantize_fn(a_bit=abit, stage=stage)
+        self.inplanes = 64
+        self.conv1 = Q.conv2d_Q_fn(w_bit=wbit, stage=stage)(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(512 * block.expansion, num_classes)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(conv1x1(self.wbit, self.stage, self.inplanes, planes * block.expansion, stride),
+                                       nn.BatchNorm2d(planes * block.expansion))
+        layers = [block(self.wbit, self.abit, self.stage, self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(self.wbit, self.abit, self.stage, self.inplanes, planes))
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        trans_loss = 0.
+        x = self.maxpool(self.relu(self.act_q0(self.bn1(self.conv1(x)))))
+        for layers in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for layer in layers:
+                x, loss = layer(x)
+                trans_loss += loss
+        feature = torch.flatten(self.avgpool(x), 1)
+        return feature, trans_loss
+
+
+def resnet50_quant(wbit, abit, stage):
+    return ResNet(wbit, abit, stage, Bottleneck, [3, 4, 6, 3])
+
+
+class ReverseLayerF(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, alpha):
+        ctx.alpha = alpha
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return grad_output.neg() * ctx.alpha, None
+
+
+class DANN(nn.Module):
+    def __init__(self, arch, wbit, abit, stage, num_classes=31):
+        super().__init__()
+        self.feature = arch(wbit, abit, stage)
+        self.class_classifier = nn.Sequential()
+        self.class_classifier.add_module("c_fc3", nn.Linear(2048, num_classes))
+        self.domain_classifier = nn.Sequential()
+        self.domain_classifier.add_module("d_fc2", nn.Linear(2048, 2))
+
+    def forward(self, input_data, alpha):
+        feature, trans_loss = self.feature(input_data)
+        feature = feature.view(-1, 2048)
+        reverse_feature = ReverseLayerF.apply(feature, alpha)
+        return self.class_classifier(feature), self.domain_classifier(reverse_feature), trans_loss
+
+
+def resnet50_dann(wbit, abit, stage="aligned", **kwargs):
+    return DANN(resnet50_quant, wbit, abit, stage)

@@ -135,3 +135,83 @@ class TrainStep:
         self._graph = graph
         self._static = (sx, sy, outs)
         return self
+
+
+class OfficeTrainStep:
+    """One DANN iteration of the Office tree (cdf_alignment_admm/dann_office/main.py:343-456): zero_grad x2 -> source pass
+    -> target pass -> src class CE + src/tgt domain CE + both trans losses -> backward -> SGD.step(idx, w_cdf, w_pdf, lam,
+    lam2) over the three parameter groups (feature incl. alterD/gamma, class head, domain head: main.py:324-328) ->
+    ADMM_OPT.step.  Each ADMM.D holds the TARGET pass's D when ADMM_OPT runs (admm.py:25 overwrites) and alterD/gamma are
+    SGD-stepped first and then overwritten by the closed form, exactly like the reference."""
+
+    def __init__(self, model, lr=0.04, momentum=0.9, weight_decay=5e-4, alpha=0.5):
+        self.model, self.alpha = model, alpha
+        named = list(model.named_parameters())
+        self.param_admm = [(n, p) for n, p in named if "alterD" in n or "gamma" in n]
+        self.optimizer_t = SGD([{"params": list(model.feature.parameters())},
+                                {"params": list(model.class_classifier.parameters()), "lr": lr},
+                                {"params": list(model.domain_classifier.parameters()), "lr": lr}],
+                               lr=lr / 10, momentum=momentum, weight_decay=weight_decay)
+        self.optimizer_admm = ADMM_OPT([p for _, p in self.param_admm])
+        # main.py:405-410 (param_t there lists ALL named parameters, so j indexes feature.parameters())
+        self.idx = [j for j, (n, _) in enumerate(named) if ("conv" in n or "downsample.0" in n) and "weight" in n][1:]
+        self.alterD_idx = [j for j, (n, _) in enumerate(self.param_admm) if "alterD" in n]
+        self.gamma_idx = [j for j, (n, _) in enumerate(self.param_admm) if "gamma" in n]
+        f = model.feature
+        self.blocks = [b for layer in (f.layer1, f.layer2, f.layer3, f.layer4) for b in layer]
+        self.convs = []
+        for b in self.blocks:
+            for k, conv in enumerate((b.conv1, b.conv2, b.conv3, b.downsample)):
+                if conv is not None:
+                    self.convs.append(conv[0] if k == 3 else conv)
+        self.all_convs = [m for m in model.modules() if hasattr(m, "quantize_fn")]
+        self._graph: Optional[torch.cuda.CUDAGraph] = None
+        self._static = None
+
+    def _iteration(self, xs, ys, xt, set_to_none=True):
+        m = self.model
+        self.optimizer_t.zero_grad(set_to_none=set_to_none)
+        self.optimizer_admm.zero_grad(set_to_none=set_to_none)
+        dev = xs.device
+        label_src = torch.zeros(xs.shape[0], dtype=torch.long, device=dev)
+        label_tgt = torch.ones(xt.shape[0], dtype=torch.long, device=dev)
+        prequantize_weights(self.all_convs)
+        cls_s, dom_s, tl_s = m(xs, alpha=self.alpha)
+        prequantize_weights(self.all_convs)          # the reference quantises every weight once per pass
+        _, dom_t, tl_t = m(xt, alpha=self.alpha)
+        loss = (F.cross_entropy(cls_s, ys) + F.cross_entropy(dom_s, label_src) + F.cross_entropy(dom_t, label_tgt)
+                + tl_s + tl_t)
+        loss.backward()
+        w_cdf = [c.quantize_fn.weight_cdf for c in self.convs]
+        w_pdf = [c.quantize_fn.weight_pdf for c in self.convs]
+        self.optimizer_t.step(self.idx, w_cdf, w_pdf, config.args.lam, config.args.lam2)
+        a = [b.admm0 for b in self.blocks]
+        self.optimizer_admm.step(self.alterD_idx, self.gamma_idx, [q.D for q in a], [q.alterD for q in a],
+                                 [q.gamma for q in a], [q.mu for q in a], [q.rho for q in a])
+        return cls_s, loss, tl_s + tl_t
+
+    def __call__(self, xs, ys, xt):
+        if self._graph is None:
+            return self._iteration(xs, ys, xt)
+        for dst, src in zip(self._static[:3], (xs, ys, xt)):
+            dst.copy_(src, non_blocking=True)
+        self._graph.replay()
+        return self._static[3]
+
+    def capture(self, xs, ys, xt, warmup=2):
+        sxs, sys_, sxt = xs.clone(), ys.clone(), xt.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._iteration(sxs, sys_, sxt, set_to_none=False)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.optimizer_t.zero_grad(set_to_none=True)
+        self.optimizer_admm.zero_grad(set_to_none=True)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            outs = self._iteration(sxs, sys_, sxt, set_to_none=True)
+        self._graph = graph
+        self._static = (sxs, sys_, sxt, outs)
+        return self

@@ -38,7 +38,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (the reference's train_batch_size)")
     ap.add_argument("--bits", type=int, default=8)
-    ap.add_argument("--model", default="resnet20", choices=["resnet20", "resnet56"])
+    ap.add_argument("--model", default="resnet20", choices=["resnet20", "resnet56", "resnet50_dann"],
+                    help="resnet50_dann = BASELINE config 5 (Office-31 shapes 3x224x224, use --batch 28)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true", help="skip the per-kernel roofline measurements")
@@ -200,23 +201,45 @@ def main():
 
     config.args.bitW = config.args.abitW = a.bits
     config.args.train_batch_size = a.batch
+    config.args.eval_batch_size = a.batch
     torch.manual_seed(0)
-    model = (resnet20_quant if a.model == "resnet20" else resnet56_quant)(a.bits, a.bits).to(dev).train()
-    if a.channels_last:
-        model = model.to(memory_format=torch.channels_last)
-    step = TrainStep(model)
-    if world > 1 or a.dp_selftest:
-        dp.attach(step, force=a.dp_selftest)
     gen = torch.Generator().manual_seed(rank)
-    x = torch.randn(a.batch, 3, 32, 32, generator=gen).to(dev)
-    y = torch.randint(0, 10, (a.batch,), generator=gen).to(dev)
-    if a.channels_last:
-        x = x.contiguous(memory_format=torch.channels_last)
-    if a.no_graph:
-        for _ in range(3):
-            step(x, y)
+    office = a.model == "resnet50_dann"
+    if office:
+        from alignq_amd.resnet_office import resnet50_dann
+        from alignq_amd.train_step import OfficeTrainStep
+        model = resnet50_dann(a.bits, a.bits).to(dev).train()
+        ostep = OfficeTrainStep(model)
+        xs = torch.randn(a.batch, 3, 224, 224, generator=gen).to(dev)
+        xt = torch.randn(a.batch, 3, 224, 224, generator=gen).to(dev)
+        ys = torch.randint(0, 31, (a.batch,), generator=gen).to(dev)
+        if a.no_graph:
+            for _ in range(2):
+                ostep(xs, ys, xt)
+        else:
+            ostep.capture(xs, ys, xt, warmup=2)
+
+        def step(_x, _y):
+            return ostep(xs, ys, xt)
+        x = y = None
+        images_per_step = 2 * a.batch            # source + target images both pass through the network
     else:
-        step.capture(x, y, warmup=3)
+        model = (resnet20_quant if a.model == "resnet20" else resnet56_quant)(a.bits, a.bits).to(dev).train()
+        if a.channels_last:
+            model = model.to(memory_format=torch.channels_last)
+        step = TrainStep(model)
+        if world > 1 or a.dp_selftest:
+            dp.attach(step, force=a.dp_selftest)
+        x = torch.randn(a.batch, 3, 32, 32, generator=gen).to(dev)
+        y = torch.randint(0, 10, (a.batch,), generator=gen).to(dev)
+        if a.channels_last:
+            x = x.contiguous(memory_format=torch.channels_last)
+        if a.no_graph:
+            for _ in range(3):
+                step(x, y)
+        else:
+            step.capture(x, y, warmup=3)
+        images_per_step = a.batch
     for _ in range(a.warmup):
         step(x, y)
 
@@ -240,19 +263,23 @@ def main():
     assert torch.isfinite(ce).item(), "training step produced a non-finite loss"
 
     if rank == 0:
-        images = a.steps * a.batch * world
+        images = a.steps * images_per_step * world
         res = {
-            "metric": "images/sec (train step, CDF+ADMM) ResNet-20 8-bit",
+            "metric": "images/sec (train step, CDF+ADMM) ResNet-20 8-bit" if a.model == "resnet20" else
+                      f"images/sec (train step, CDF+ADMM) {a.model} {a.bits}-bit",
             "value": images / elapsed, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{a.model} CIFAR-shape 3x32x32, {a.bits}W/{a.bits}A CDF+ADMM full train step "
-                                   f"(cdf_alignment_admm/resnet-20-cifar-10), batch {a.batch}/GPU, "
-                                   f"{'HIP-graph replay' if not a.no_graph else 'eager launches'}",
+            "config": {"workload": (f"{a.model} Office-31 shape 3x224x224 DANN, {a.bits}W/{a.bits}A CDF+ADMM full train step "
+                                    f"(cdf_alignment_admm/dann_office: source+target pass), batch {a.batch}+{a.batch}/GPU, "
+                                    if office else
+                                    f"{a.model} CIFAR-shape 3x32x32, {a.bits}W/{a.bits}A CDF+ADMM full train step "
+                                    f"(cdf_alignment_admm/resnet-20-cifar-10), batch {a.batch}/GPU, ")
+                                   + f"{'HIP-graph replay' if not a.no_graph else 'eager launches'}",
                        "global_batch": a.batch * world, "parallelism": f"dp{world}",
                        "final_ce": float(ce.detach()), "final_trans_loss": float(tl.detach()) if tl is not None else None},
         }
-        if not a.no_kernels:
+        if not a.no_kernels and not office:
             counts = {}
             units = [3, 3, 3] if a.model == "resnet20" else [9, 9, 9]
             # site F per stage: 16x32x32, 32x16x16, 64x8x8 ; stem + 2/block + 1 skip in the first block of stages 2,3
@@ -262,7 +289,7 @@ def main():
             roof, kernels = measure_kernels(dev, a.batch, a.bits, counts)
             res["roofline"] = roof
             res["kernels"] = kernels
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and not office:
             res["cpu_baseline"] = cpu_baseline(a.batch, a.bits, a.model, a.cpu_steps)
             res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
         print(json.dumps(res))

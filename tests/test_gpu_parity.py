@@ -438,3 +438,39 @@ def test_prequantize_all_weights_matches_per_tensor(dev):
         assert bits_equal(npy(q), npy(q2)) and bits_equal(npy(c.quantize_fn.weight_cdf), npy(c2))
         np.testing.assert_allclose(npy(c.quantize_fn.weight_pdf), npy(p2), rtol=1e-6)
         np.testing.assert_allclose(npy(c.weight.grad), npy(w2.grad), atol=1e-6, rtol=1e-5)
+
+
+def test_office_dann_harness_runs_and_matches_eager_under_graph(dev):
+    """Config-5 harness (ResNet-Bottleneck + DANN head, Office tree ops: eps-corr, activation_quantize_fn2, two passes per
+    step, three SGD groups incl. alterD/gamma): a small instance runs, every ADMM site takes the TARGET pass's D, and
+    the HIP-graph replay reproduces eager iterations."""
+    from alignq_amd import config
+    from alignq_amd.resnet_office import DANN, Bottleneck, ResNet
+    from alignq_amd.train_step import OfficeTrainStep
+    config.args.bitW = config.args.abitW = 8
+    config.args.train_batch_size = config.args.eval_batch_size = 6
+    try:
+        def make():
+            torch.manual_seed(7)
+            m = DANN(lambda w, a, s: ResNet(w, a, s, Bottleneck, [1, 1, 1, 1]), 8, 8, "aligned").to(dev).train()
+            return m
+        m1, m2 = make(), make()
+        g = torch.Generator().manual_seed(0)
+        xs = torch.randn(6, 3, 64, 64, generator=g).to(dev)
+        xt = torch.randn(6, 3, 64, 64, generator=g).to(dev)
+        ys = torch.randint(0, 31, (6,), generator=g).to(dev)
+        s1, s2 = OfficeTrainStep(m1), OfficeTrainStep(m2)
+        a0 = npy(m1.feature.layer1[0].admm0.alterD).copy()
+        for _ in range(2):
+            cls, loss, tl = s1(xs, ys, xt)
+        assert torch.isfinite(loss) and torch.isfinite(tl) and torch.isfinite(cls).all()
+        assert not np.array_equal(npy(m1.feature.layer1[0].admm0.alterD), a0)
+        assert m1.feature.layer1[0].admm0.D.shape == (6, 6)
+        s2.capture(xs, ys, xt, warmup=2)       # 2 real warm-up iterations
+        s1(xs, ys, xt)
+        s2(xs, ys, xt)
+        torch.cuda.synchronize()
+        for (n1, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+            np.testing.assert_allclose(npy(p1), npy(p2), atol=5e-4, rtol=5e-3, err_msg=n1)
+    finally:
+        config.args.train_batch_size, config.args.eval_batch_size = 128, 100
