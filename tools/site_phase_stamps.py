@@ -1,7 +1,7 @@
 import ctypes, sys, numpy as np, torch
 sys.path.insert(0, '.')
 from alignq_amd import _lib as L
-L.SO_PATH = 'scratch/lib/libalignq_stamps.so'
+L.SO_PATH = 'tools/lib/libalignq_stamps.so'
 lib = L.load()
 lib.alignq_debug_read_stamps.argtypes = [ctypes.c_void_p]
 dev = torch.device('cuda:0')
