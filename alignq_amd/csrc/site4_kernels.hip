@@ -103,7 +103,7 @@ template <int TFv, bool PAIR>
 __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__ x, int B, int64_t F, int k, float r,
                                                        float eps, float* __restrict__ xq, float* __restrict__ slabs,
                                                        float* __restrict__ stats, int n_tiles, int aligned,
-                                                       unsigned* __restrict__ counter) {
+                                                       unsigned* __restrict__ counter, BnFold bn) {
   constexpr int LDB = TFv + 8;                    // bf16 elements per LDS row (row bytes multiple of 16, see bank note)
   constexpr int LPR = TFv / 4;                    // lanes per row (float4 each)
   constexpr int RG = NT / LPR;                    // row groups: 64 / 128 / 256
@@ -154,6 +154,12 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
       const bool ok = row < B;
       const int64_t off = (int64_t)row * F + col;
       xv[j] = ld4(x, off, col, F, ok, aligned);
+      if (bn.ab && ok && col < F) {          // folded batch-norm: x = a[c]*z + b[c]; the 4 features share a channel (HW % 4 == 0)
+        const int ch = col / bn.HW;
+        const float a = bn.ab[ch], b0 = bn.ab[bn.C + ch];
+        xv[j].x = __fmaf_rn(a, xv[j].x, b0); xv[j].y = __fmaf_rn(a, xv[j].y, b0);
+        xv[j].z = __fmaf_rn(a, xv[j].z, b0); xv[j].w = __fmaf_rn(a, xv[j].w, b0);
+      }
       tv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (PAIR) {
         float4 q;
@@ -538,11 +544,11 @@ __global__ __launch_bounds__(256) void site_prep_kernel(const float* __restrict_
 //       batch rows (256-byte coalesced row segments per wave instruction), two 16-byte LDS stores per array.
 constexpr int NTB = 512;
 
-template <bool PAIR>
+template <bool PAIR, bool BN>
 __global__ __launch_bounds__(NTB) void site_bwd4_kernel(const float* __restrict__ gup, const float* __restrict__ S,
                                                         const float* __restrict__ x, const float* __restrict__ stats,
                                                         int B, int64_t F, float r, float eps, float* __restrict__ dx,
-                                                        int n_tiles, int aligned) {
+                                                        int n_tiles, int aligned, BnFold bn) {
   (void)aligned;
   constexpr int TFv = 64, LDv = 65, TILE = 128 * LDv;
   constexpr int LDT = 128 + 8;                       // bf16 elements per transposed row (272 B: 16-B aligned, 4-bank skew)
@@ -605,6 +611,8 @@ __global__ __launch_bounds__(NTB) void site_bwd4_kernel(const float* __restrict_
       const float rx = lcol_ok ? stats[F + col0 + lcol] : 0.f;
       const float mt = (PAIR && lcol_ok) ? stats[2 * F + col0 + lcol] : 0.f;
       const float rt = (PAIR && lcol_ok) ? stats[3 * F + col0 + lcol] : 0.f;
+      float bn_a = 1.f, bn_b = 0.f;
+      if (BN && lcol_ok) { const int ch = (col0 + lcol) / bn.HW; bn_a = bn.ab[ch]; bn_b = bn.ab[bn.C + ch]; }
       float xr[16], gr[16];
 #pragma unroll
       for (int q = 0; q < 16; q++) {          // all 32 loads in flight before the first use
@@ -612,6 +620,7 @@ __global__ __launch_bounds__(NTB) void site_bwd4_kernel(const float* __restrict_
         const bool ok = lcol_ok && row < B;
         const int64_t off = (int64_t)row * F + col0 + lcol;
         xr[q] = ok ? x[off] : 0.0f;
+        if (BN && ok) xr[q] = __fmaf_rn(bn_a, xr[q], bn_b);
         gr[q] = (PAIR && gup && ok) ? gup[off] : 0.0f;
       }
 #pragma unroll
@@ -755,14 +764,38 @@ __global__ __launch_bounds__(NTB) void site_bwd4_kernel(const float* __restrict_
     __syncthreads();
     STAMP(14);
     // ---- copy out: 256-byte row segments, one feature column per lane -----------------------------------
+    float bp0 = 0.f, bp1 = 0.f;     // folded batch-norm backward: this tile's sum dx and sum dx*zhat (one channel per tile)
     if (lcol_ok) {
-#pragma unroll
+      float bmu = 0.f, bis = 0.f;
+      if (BN) { const int ch = (col0 + lcol) / bn.HW; bmu = bn.save[ch]; bis = bn.save[bn.C + ch]; }
+#pragma unroll 4
       for (int q = 0; q < 16; q++) {
         const int row = lrow0 + q;
-        if (row < B) dx[(int64_t)row * F + col0 + lcol] = Os[row * LDv + lcol];
+        if (row < B) {
+          const int64_t off = (int64_t)row * F + col0 + lcol;
+          const float o = Os[row * LDv + lcol];
+          dx[off] = o;
+          if (BN) {
+            const float zh = (x[off] - bmu) * bis;     // x is the conv output z here (L2-resident: this tile just read it)
+            bp0 += o;
+            bp1 += o * zh;
+          }
+        }
       }
     }
+    if (BN) {
+      bp0 = wave_sum(bp0);
+      bp1 = wave_sum(bp1);
+      if (lane == 0) { red[2 * w] = bp0; red[2 * w + 1] = bp1; }   // red is free again (all reads finished before the barrier above)
+    }
     __syncthreads();   // LDS is overwritten by the next tile
+    if (BN && tid == 0) {
+      float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; q++) { t0 += red[2 * q]; t1 += red[2 * q + 1]; }
+      bn.dx_part[2 * tile] = t0;
+      bn.dx_part[2 * tile + 1] = t1;
+    }
     STAMP(15);
   }
 }
@@ -776,11 +809,11 @@ __global__ __launch_bounds__(NTB) void site_bwd4_kernel(const float* __restrict_
 }  // namespace
 
 int launch_partials4(bool pair, const Geom& g, const float* x, int B, int64_t F, int k, float r, float eps, float* xq,
-                     float* stats, float* ws, hipStream_t st) {
+                     float* stats, float* ws, hipStream_t st, BnFold bn) {
   const int aligned = ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
                       (!xq || (reinterpret_cast<uintptr_t>(xq) & 15) == 0);
   unsigned* counter = reinterpret_cast<unsigned*>(ws + (size_t)g.grid * g.slab_floats + kPartFloats);
-#define L4(TFV, P) hipLaunchKernelGGL((site_fwd4_kernel<TFV, P>), g.grid, NT, 0, st, x, B, F, k, r, eps, xq, ws, stats, g.n_tiles, aligned, counter)
+#define L4(TFV, P) hipLaunchKernelGGL((site_fwd4_kernel<TFV, P>), g.grid, NT, 0, st, x, B, F, k, r, eps, xq, ws, stats, g.n_tiles, aligned, counter, bn)
   if (pair) {
     if (g.tf == 64) L4(64, true); else if (g.tf == 32) L4(32, true); else L4(16, true);
   } else {
@@ -822,14 +855,15 @@ int launch_prep(bool fused, const float* dD, const float* D, const float* alterD
 }
 
 int launch_bwd4(bool pair, const Geom& g, const float* gup, const float* S, const float* x, const float* stats, int B,
-                int64_t F, float r, float eps, float* dx, hipStream_t st) {
+                int64_t F, float r, float eps, float* dx, hipStream_t st, BnFold bn) {
   (void)g;
   const int n_tiles = (int)((F + 63) / 64);
   const int grid = n_tiles < 2048 ? n_tiles : 2048;
   const int aligned = ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
                       ((reinterpret_cast<uintptr_t>(dx) & 15) == 0) && (!gup || (reinterpret_cast<uintptr_t>(gup) & 15) == 0);
-  if (pair) hipLaunchKernelGGL((site_bwd4_kernel<true>), grid, NTB, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_tiles, aligned);
-  else hipLaunchKernelGGL((site_bwd4_kernel<false>), grid, NTB, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_tiles, aligned);
+  if (pair && bn.ab) hipLaunchKernelGGL((site_bwd4_kernel<true, true>), grid, NTB, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_tiles, aligned, bn);
+  else if (pair) hipLaunchKernelGGL((site_bwd4_kernel<true, false>), grid, NTB, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_tiles, aligned, bn);
+  else hipLaunchKernelGGL((site_bwd4_kernel<false, false>), grid, NTB, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_tiles, aligned, bn);
   RET_ON_ERR();
   return 0;
 }

@@ -10,6 +10,17 @@ namespace alignq_site {
 constexpr int kPartFloats = 1024;   // up to 256 blocks x 4 floats of ADMM-loss partial sums
 constexpr int kTailFloats = kPartFloats + 16;
 
+// Optional batch-norm fold: the site kernels read the CONV output z and apply x = a[c]*z + b[c] on load
+// (c = feature / HW), a = gamma*invstd, b = beta - mean*a; ab == nullptr means the input already is x.
+struct BnFold {
+  const float* ab;      // [2][C]: a then b
+  const float* save;    // [2][C]: batch mean then invstd (backward only)
+  int HW, C;
+  float* dx_part;       // backward only: per-tile partial sums (sum dx, sum dx*zhat) [n_tiles][2]
+  const float* z;       // backward only: same pointer as the kernel's x argument (kept for clarity)
+};
+inline BnFold no_bn() { return BnFold{nullptr, nullptr, 1, 1, nullptr, nullptr}; }
+
 struct Geom {
   int nb;           // 32-row blocks: 1, 2 (generic kernels) or 4 (site4 kernels)
   int tf;           // features per tile
@@ -52,9 +63,9 @@ int launch_bwd1(bool pair, const float* gup, const float* S, const float* x, con
 
 // ---- launchers defined in site4_kernels.hip ----------------------------------------------------------------
 int launch_partials4(bool pair, const Geom& g, const float* x, int B, int64_t F, int k, float r, float eps, float* xq,
-                     float* stats, float* ws, hipStream_t st);
+                     float* stats, float* ws, hipStream_t st, BnFold bn = no_bn());
 int launch_bwd4(bool pair, const Geom& g, const float* gup, const float* S, const float* x, const float* stats, int B,
-                int64_t F, float r, float eps, float* dx, hipStream_t st);
+                int64_t F, float r, float eps, float* dx, hipStream_t st, BnFold bn = no_bn());
 // S = sym(gD) * gscale / F (and, fused, the scaled ADMM parameter gradients) — first launch of every backward
 int launch_prep(bool fused, const float* dD, const float* D, const float* alterD, const float* gamma, int dim,
                 const float* scal, float mu, const float* gscale, int B, int64_t F, float* S, float* dA_out,

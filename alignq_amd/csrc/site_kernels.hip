@@ -542,6 +542,40 @@ int alignq_site_bwd(const float* g, const float* dD, const float* dD_scale, cons
   return launch_bwd<true>(geom(B, F), g, (const float*)ws, x, stats, B, F, act_range, eps, dx, st);
 }
 
+// ---- batch-norm folded forms (B in (64,128] only) ------------------------------------------------
+static inline bool bn_shape_ok(int B, int64_t F, int C, int HW) {
+  return B > 64 && B <= ALIGNQ_MAX_BATCH && C >= 1 && HW >= 64 && (HW % 64) == 0 && (int64_t)C * HW == F;
+}
+
+int alignq_site_partials_bn(const float* z, const float* ab, int C, int HW, int B, int64_t F, int k, float act_range,
+                            float eps, float* xq, float* stats, void* ws, void* stream) {
+  if (!z || !ab || !ws) return ALIGNQ_EINVAL;
+  if (bad_k(k)) return ALIGNQ_EINVAL;
+  if (!bn_shape_ok(B, F, C, HW)) return ALIGNQ_EUNSUPPORTED;
+  BnFold bn{ab, nullptr, HW, C, nullptr, z};
+  return launch_partials4(true, geom(B, F), z, B, F, k, act_range, eps, xq, stats, (float*)ws, (hipStream_t)stream, bn);
+}
+
+size_t alignq_site_bn_part_bytes(int64_t F) { return (size_t)((F + 63) / 64) * 2 * sizeof(float); }
+
+int alignq_site_bwd_apply_bn(const float* g, const float* S, const float* z, const float* ab, const float* save, int C,
+                             int HW, const float* stats, int B, int64_t F, float act_range, float eps, float* dx,
+                             float* dx_part, void* stream) {
+  if (!S || !z || !ab || !save || !stats || !dx || !dx_part) return ALIGNQ_EINVAL;
+  if (!bn_shape_ok(B, F, C, HW)) return ALIGNQ_EUNSUPPORTED;
+  BnFold bn{ab, save, HW, C, dx_part, z};
+  return launch_bwd4(true, geom(B, F), g, S, z, stats, B, F, act_range, eps, dx, (hipStream_t)stream, bn);
+}
+
+int alignq_site_prep_fused(const float* D, const float* alterD, const float* gamma, int dim, const float* scal, float mu,
+                           const float* dD_scale, int B, int64_t F, float* S, float* dalterD, float* dgamma,
+                           void* stream) {
+  if (!D || !alterD || !gamma || !scal || !S || dim < B) return ALIGNQ_EINVAL;
+  if (bad_shape(B, F)) return F <= 0 ? ALIGNQ_EINVAL : ALIGNQ_EUNSUPPORTED;
+  return launch_prep(true, nullptr, D, alterD, gamma, dim, scal, mu, dD_scale, B, F, S, dalterD, dgamma,
+                     (hipStream_t)stream);
+}
+
 int alignq_site_bwd_apply(const float* g, const float* S, const float* x, const float* stats, int B, int64_t F,
                           float act_range, float eps, float* dx, void* stream) {
   if (!S || !x || !stats || !dx) return ALIGNQ_EINVAL;

@@ -104,3 +104,104 @@ _active = None
 
 def active_deferred():
     return _active
+
+
+# ------------------------------------------------------------------------------------------------------------------
+class BNSiteFn(torch.autograd.Function):
+    """act_q(bn(z)) with the batch-norm folded into the ADMM-site kernels (training mode).
+
+    Forward: bn statistics (2 launches) -> site partials reading z with x = a*z + b on load -> slab reduce + loss.
+    Backward: prep (S, dalterD, dgamma) -> site backward writing dx and per-tile BN sums -> bn backward apply (dz, dgamma_bn,
+    dbeta).  The normalised activation is never written to HBM.  Values: x differs from torch's ((z-mean)*invstd)*gamma+beta
+    only by the rounding of one fma (1e-7 relative)."""
+
+    @staticmethod
+    def forward(ctx, z, bn_weight, bn_bias, running_mean, running_var, nbt, momentum, bn_eps, alterD, gamma, k, act_range,
+                eps, mu, rho):
+        z = L.dev_f32(z, "conv output")
+        A = L.dev_f32(alterD, "alterD")
+        Gm = L.dev_f32(gamma, "gamma")
+        B, C, H, W = z.shape
+        HW, F = H * W, C * H * W
+        dim = A.shape[0]
+        lib = L.load()
+        dev = z.device
+        st = L.stream_ptr()
+        ab = torch.empty(2, C, dtype=torch.float32, device=dev)
+        save = torch.empty(2, C, dtype=torch.float32, device=dev)
+        ws_bn = torch.empty(lib.alignq_bn_ws_bytes(C), dtype=torch.uint8, device=dev)
+        L.check(lib.alignq_bn_stats(L.ptr(z), B, C, HW, L.ptr(bn_weight), L.ptr(bn_bias), L.ptr(running_mean),
+                                    L.ptr(running_var), L.ptr(nbt), float(momentum), float(bn_eps), L.ptr(ab), L.ptr(save),
+                                    L.ptr(ws_bn), st), "alignq_bn_stats")
+        xq = torch.empty_like(z)
+        D = torch.empty(B, B, dtype=torch.float32, device=dev)
+        stats = torch.empty(4, F, dtype=torch.float32, device=dev)
+        scal = torch.empty(4, dtype=torch.float32, device=dev)
+        ws = torch.empty(lib.alignq_site_ws_bytes(B, F), dtype=torch.uint8, device=dev)
+        L.check(lib.alignq_site_partials_bn(L.ptr(z), L.ptr(ab), C, HW, B, F, int(k), float(act_range), float(eps),
+                                            L.ptr(xq), L.ptr(stats), L.ptr(ws), st), "alignq_site_partials_bn")
+        L.check(lib.alignq_site_reduce_loss(L.ptr(ws), B, F, L.ptr(D), L.ptr(A), L.ptr(Gm), dim, float(mu), float(rho),
+                                            L.ptr(scal), st), "alignq_site_reduce_loss")
+        ctx.save_for_backward(z, ab, save, stats, D, A, Gm, scal)
+        ctx.set_materialize_grads(False)
+        ctx.cfg = (float(act_range), float(eps), float(mu), bn_weight is not None, bn_bias is not None)
+        ctx.mark_non_differentiable(D)
+        return xq, scal[0], D
+
+    @staticmethod
+    def backward(ctx, g_xq, g_loss, _gD):
+        z, ab, save, stats, D, A, Gm, scal = ctx.saved_tensors
+        act_range, eps, mu, has_w, has_b = ctx.cfg
+        B, C, H, W = z.shape
+        HW, F = H * W, C * H * W
+        dim = A.shape[0]
+        lib = L.load()
+        dev = z.device
+        st = L.stream_ptr()
+        g_xq = None if g_xq is None else L.like_layout(g_xq, z)
+        if g_loss is None:
+            g_loss = torch.zeros((), dtype=torch.float32, device=dev)
+        g_loss = L.dev_f32(g_loss, "loss grad")
+        S = torch.empty(B, B, dtype=torch.float32, device=dev)
+        dA, dG = torch.empty_like(A), torch.empty_like(Gm)
+        L.check(lib.alignq_site_prep_fused(L.ptr(D), L.ptr(A), L.ptr(Gm), dim, L.ptr(scal), mu, L.ptr(g_loss), B, F,
+                                           L.ptr(S), L.ptr(dA), L.ptr(dG), st), "alignq_site_prep_fused")
+        dx = torch.empty_like(z)
+        part = torch.empty(lib.alignq_site_bn_part_bytes(F), dtype=torch.uint8, device=dev)
+        L.check(lib.alignq_site_bwd_apply_bn(L.ptr(g_xq), L.ptr(S), L.ptr(z), L.ptr(ab), L.ptr(save), C, HW, L.ptr(stats),
+                                             B, F, act_range, eps, L.ptr(dx), L.ptr(part), st), "alignq_site_bwd_apply_bn")
+        dz = torch.empty_like(z)
+        dgam = torch.empty(C, dtype=torch.float32, device=dev) if has_w else None
+        dbet = torch.empty(C, dtype=torch.float32, device=dev) if has_b else None
+        L.check(lib.alignq_bn_bwd_apply(L.ptr(dx), L.ptr(z), L.ptr(ab), L.ptr(save), L.ptr(part), B, C, HW, L.ptr(dz),
+                                        L.ptr(dgam), L.ptr(dbet), st), "alignq_bn_bwd_apply")
+        return (dz, dgam, dbet, None, None, None, None, None, dA, dG, None, None, None, None, None)
+
+
+def bn_site_fusable(bn, act, z) -> bool:
+    from . import config
+    if not (isinstance(bn, torch.nn.BatchNorm2d) and bn.training and bn.track_running_stats and bn.momentum is not None):
+        return False
+    if not (z.is_cuda and z.dim() == 4 and z.dtype == torch.float32 and z.is_contiguous()):
+        return False
+    B, C, H, W = z.shape
+    a_bit = getattr(act, "a_bit", 32)
+    return (64 < B <= L.MAX_BATCH and (H * W) % 64 == 0 and hasattr(act, "opt") and a_bit < 32
+            and config.args.method == "ours" and act.opt.alterD.shape[0] >= B)
+
+
+def bn_site(bn, act, z, eps=0.0):
+    """out, loss = act(bn(z)) — folded when `bn_site_fusable`, otherwise exactly that composition."""
+    from . import config
+    if not bn_site_fusable(bn, act, z):
+        return act(bn(z))
+    admm = act.opt
+    xq, loss, D = BNSiteFn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                 bn.momentum, bn.eps, admm.alterD, admm.gamma, act.a_bit, config.args.act_range, eps,
+                                 admm.mu, admm.rho)
+    admm.D = D
+    deferred = active_deferred()
+    if deferred is not None:
+        deferred.add(loss)
+        return xq, 0.0
+    return xq, loss

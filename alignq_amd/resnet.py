@@ -17,6 +17,7 @@ from . import cdf_alignment as _cdf
 from . import cdf_alignment_admm as _admm
 from . import config
 from .admm import ADMM
+from .fused import bn_site
 
 
 class PreActBlock_conv_Q(nn.Module):
@@ -25,6 +26,7 @@ class PreActBlock_conv_Q(nn.Module):
     def __init__(self, stage, wbit, abit, in_planes, out_planes, stride=1, tree="admm"):
         super().__init__()
         self.tree = tree
+        self.fuse_bn = False           # set by alignq_amd.resnet.enable_bn_fusion
         ns = _admm if tree == "admm" else _cdf
         Conv2d = ns.conv2d_Q_fn(w_bit=wbit, stage=stage)
         if tree == "admm":
@@ -55,17 +57,23 @@ class PreActBlock_conv_Q(nn.Module):
             return fn(x)
         return fn(x), 0
 
+    def _bnq(self, bn, fn, z):
+        """act(bn(z)); with fuse_bn the batch-norm is folded into the site kernels (alignq_amd.fused.bn_site)."""
+        if self.tree == "admm" and self.fuse_bn:
+            return bn_site(bn, fn, z)
+        return self._q(fn, bn(z))
+
     def forward(self, x):
         trans_loss = 0.
         if self.skip_conv is not None:
-            shortcut, loss = self._q(self.act_skip_q, self.skip_bn(self.skip_conv(x)))
+            shortcut, loss = self._bnq(self.skip_bn, self.act_skip_q, self.skip_conv(x))
             trans_loss += loss
         else:
             shortcut = x
-        out, loss = self._q(self.act_q0, self.bn0(self.conv0(x)))
+        out, loss = self._bnq(self.bn0, self.act_q0, self.conv0(x))
         trans_loss += loss
         out = F.relu(out)
-        out, loss = self._q(self.act_q1, self.bn1(self.conv1(out)))
+        out, loss = self._bnq(self.bn1, self.act_q1, self.conv1(out))
         trans_loss += loss
         out += shortcut
         out = F.relu(out)
@@ -78,6 +86,7 @@ class PreActResNet(nn.Module):
     def __init__(self, block, num_units, wbit, abit, stage, num_classes, tree="admm"):
         super().__init__()
         self.tree = tree
+        self.fuse_bn = False
         ns = _admm if tree == "admm" else _cdf
         Conv2d = ns.conv2d_Q_fn(w_bit=wbit, stage=stage)
         self.conv0 = Conv2d(3, 16, kernel_size=3, stride=1, padding=1, bias=False)
@@ -99,12 +108,14 @@ class PreActResNet(nn.Module):
         self.logit = nn.Linear(64, num_classes)
 
     def forward(self, x):
-        out = self.bn(self.conv0(x))
-        if self.tree == "admm":
-            out, loss = self.act_q0(out)
+        if self.tree == "admm" and self.fuse_bn:
+            out, loss = bn_site(self.bn, self.act_q0, self.conv0(x))
+            trans_loss = 0. + loss
+        elif self.tree == "admm":
+            out, loss = self.act_q0(self.bn(self.conv0(x)))
             trans_loss = 0. + loss
         else:
-            out = self.act_q0(out)
+            out = self.act_q0(self.bn(self.conv0(x)))
         out = F.relu(out)
         for layer in self.layers:
             if self.tree == "admm":
@@ -126,3 +137,12 @@ def resnet20_quant(bitW, abitW, stage="second", num_classes=10, tree="admm"):
 
 def resnet56_quant(bitW, abitW, stage="second", num_classes=10, tree="admm"):
     return PreActResNet(PreActBlock_conv_Q, [9, 9, 9], bitW, abitW, stage, num_classes, tree=tree)
+
+
+def enable_bn_fusion(model, on=True):
+    """Fold every batch-norm that feeds an ADMM activation site into the site kernels (training mode, 64 < batch <= 128).
+    Results match the unfused composition to fp32 rounding; module/parameter names and state_dict are unchanged."""
+    for m in model.modules():
+        if hasattr(m, "fuse_bn"):
+            m.fuse_bn = bool(on)
+    return model

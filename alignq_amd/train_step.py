@@ -18,8 +18,12 @@ from .optimizer import ADMM_OPT, SGD
 
 
 class TrainStep:
-    def __init__(self, model, lr=0.04, momentum=0.9, weight_decay=1e-4, grad_hook=None, defer_losses=True):
+    def __init__(self, model, lr=0.04, momentum=0.9, weight_decay=1e-4, grad_hook=None, defer_losses=True, fuse_bn=True):
         self.model = model
+        if fuse_bn:      # fold BN into the site kernels where shapes allow (training, 64 < batch <= 128); no-op otherwise
+            for m in model.modules():
+                if hasattr(m, "fuse_bn"):
+                    m.fuse_bn = True
         self.defer_losses = defer_losses
         self._deferred = DeferredLosses() if (defer_losses and torch.cuda.is_available()) else None
         named = list(model.named_parameters())

@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true", help="skip the per-kernel roofline measurements")
     ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--no-fuse-bn", action="store_true", help="keep torch/MIOpen batch-norm instead of folding it into the ADMM-site kernels")
     ap.add_argument("--dp-selftest", action="store_true", help="run the DP path (RCCL all-reduce, two graphs) even at N=1")
     ap.add_argument("--channels-last", action="store_true", help="NHWC activations/weights end to end")
     ap.add_argument("--miopen-benchmark", action="store_true", help="torch.backends.cudnn.benchmark (MIOpen find)")
@@ -227,7 +228,7 @@ def main():
         model = (resnet20_quant if a.model == "resnet20" else resnet56_quant)(a.bits, a.bits).to(dev).train()
         if a.channels_last:
             model = model.to(memory_format=torch.channels_last)
-        step = TrainStep(model)
+        step = TrainStep(model, fuse_bn=not a.no_fuse_bn)
         if world > 1 or a.dp_selftest:
             dp.attach(step, force=a.dp_selftest)
         x = torch.randn(a.batch, 3, 32, 32, generator=gen).to(dev)
@@ -275,7 +276,8 @@ def main():
                                     if office else
                                     f"{a.model} CIFAR-shape 3x32x32, {a.bits}W/{a.bits}A CDF+ADMM full train step "
                                     f"(cdf_alignment_admm/resnet-20-cifar-10), batch {a.batch}/GPU, ")
-                                   + f"{'HIP-graph replay' if not a.no_graph else 'eager launches'}",
+                                   + f"{'HIP-graph replay' if not a.no_graph else 'eager launches'}"
+                                   + ("" if (office or a.no_fuse_bn) else ", batch-norm folded into the site kernels"),
                        "global_batch": a.batch * world, "parallelism": f"dp{world}",
                        "final_ce": float(ce.detach()), "final_trans_loss": float(tl.detach()) if tl is not None else None},
         }

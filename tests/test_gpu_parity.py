@@ -478,3 +478,51 @@ def test_office_dann_harness_runs_and_matches_eager_under_graph(dev):
             assert np.median(d) < 5e-4 and d.max() < 2e-2, (n1, float(np.median(d)), float(d.max()))
     finally:
         config.args.train_batch_size, config.args.eval_batch_size = 128, 100
+
+
+@pytest.mark.parametrize("B,C,H,W,k", [(128, 16, 32, 32, 8), (128, 64, 8, 8, 4), (100, 32, 16, 16, 8)])
+def test_bn_folded_site_matches_unfused(dev, B, C, H, W, k):
+    """fused.bn_site (batch-norm folded into the site kernels, training mode) against act(bn(z)) with torch's BatchNorm2d
+    + the unfused site: x_q equal up to tie-zone bin flips (x differs by one fma rounding), D / loss / dz / dgamma / dbeta /
+    running statistics within fp32 tolerance."""
+    import alignq_amd.cdf_alignment_admm as A
+    from alignq_amd import config
+    from alignq_amd.fused import bn_site, bn_site_fusable
+    config.args.bitW = config.args.abitW = k
+    torch.manual_seed(B + C)
+    z = (torch.randn(B, C, H, W, device=dev) * 1.7 + 0.3)
+    gq = torch.randn(B, C, H, W, device=dev) * 0.01
+    outs = []
+    for fused in (False, True):
+        torch.manual_seed(1)
+        bn = torch.nn.BatchNorm2d(C).to(dev).train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(C, device=dev) + 0.5)
+            bn.bias.copy_(torch.randn(C, device=dev) * 0.2)
+        admm = A.ADMM(128).to(dev)
+        act = A.activation_quantize_fn(k, "second", admm)
+        zz = z.clone().requires_grad_(True)
+        if fused:
+            assert bn_site_fusable(bn, act, zz)
+            xq, loss = bn_site(bn, act, zz)
+        else:
+            xq, loss = act(bn(zz))
+        (loss + (xq * gq).sum()).backward()
+        outs.append(dict(xq=npy(xq), loss=float(loss.detach()), D=npy(admm.D), dz=npy(zz.grad), dw=npy(bn.weight.grad),
+                         db=npy(bn.bias.grad), rm=npy(bn.running_mean), rv=npy(bn.running_var),
+                         nbt=int(bn.num_batches_tracked), dA=npy(admm.alterD.grad)))
+    u, f = outs
+    n = 2 ** k - 1
+    flips = np.abs(u["xq"] - f["xq"]) * n
+    assert flips.max() <= 1.0 + 1e-3 and (flips > 0.5).mean() < 1e-3          # tie-zone flips only
+    np.testing.assert_allclose(f["D"], u["D"], atol=TOL)
+    np.testing.assert_allclose(f["loss"], u["loss"], atol=TOL)
+    np.testing.assert_allclose(f["rm"], u["rm"], atol=1e-6, rtol=1e-5)
+    np.testing.assert_allclose(f["rv"], u["rv"], atol=1e-6, rtol=1e-5)
+    assert f["nbt"] == u["nbt"] == 1
+    np.testing.assert_allclose(f["dA"], u["dA"], atol=1e-7, rtol=1e-4)
+    # gradients see the flipped bins only through g (STE), so they agree to tolerance
+    np.testing.assert_allclose(f["dz"], u["dz"], atol=2e-5, rtol=1e-3)
+    np.testing.assert_allclose(f["dw"], u["dw"], atol=2e-4, rtol=1e-3)
+    np.testing.assert_allclose(f["db"], u["db"], atol=2e-4, rtol=1e-3)
+    config.args.bitW = config.args.abitW = 8
