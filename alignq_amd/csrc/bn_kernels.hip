@@ -13,13 +13,14 @@
 
 #include "../../include/alignq.h"
 #include "alignq_math.h"
+#include "site_internal.h"
 
 using namespace alignq;
 
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kSplit = 16;          // batch splits per channel (partials per channel)
+constexpr int kSplit = alignq_site::kBnSplit;   // batch splits per channel (partials per channel)
 
 __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const float* __restrict__ z, int B, int C, int HW,
                                                             double* __restrict__ part) {
@@ -125,6 +126,14 @@ int alignq_bn_stats(const float* z, int B, int C, int HW, const float* gamma, co
   LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_finalize_kernel, (C + 63) / 64, 64, 0, st, (const double*)ws, B, C, HW, gamma, beta, running_mean,
                      running_var, (long long*)num_batches_tracked, momentum, eps, ab, save);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int alignq_bn_partial_stats(const float* z, int B, int C, int HW, void* ws, void* stream) {
+  if (!z || !ws || B < 1 || C < 1 || HW < 4) return ALIGNQ_EINVAL;
+  if ((HW & 3) || (reinterpret_cast<uintptr_t>(z) & 15)) return ALIGNQ_EUNSUPPORTED;
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(kSplit, C), kThreads, 0, (hipStream_t)stream, z, B, C, HW, (double*)ws);
   LAUNCH_CHECK();
   return 0;
 }

@@ -154,12 +154,60 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
       const bool ok = row < B;
       const int64_t off = (int64_t)row * F + col;
       xv[j] = ld4(x, off, col, F, ok, aligned);
-      if (bn.ab && ok && col < F) {          // folded batch-norm: x = a[c]*z + b[c]; the 4 features share a channel (HW % 4 == 0)
-        const int ch = col / bn.HW;
-        const float a = bn.ab[ch], b0 = bn.ab[bn.C + ch];
-        xv[j].x = __fmaf_rn(a, xv[j].x, b0); xv[j].y = __fmaf_rn(a, xv[j].y, b0);
-        xv[j].z = __fmaf_rn(a, xv[j].z, b0); xv[j].w = __fmaf_rn(a, xv[j].w, b0);
+    }
+    // ---- folded batch-norm: x = a*z + b with (a, b) of this tile's channel (HW % 64 == 0: one channel per tile) -------
+    if (bn.ab) {
+      const int ch = col0 / bn.HW;
+      float bn_a, bn_b;
+      if (bn.part) {
+        // finalise the batch statistics here (saves a launch): 16 lanes reduce the 16 split partials of the channel
+        if (w == 0) {
+          double sa = 0, sq = 0;
+          if (lane < kBnSplit) { sa = bn.part[(ch * kBnSplit + lane) * 2]; sq = bn.part[(ch * kBnSplit + lane) * 2 + 1]; }
+          sa = wave_sum_d(sa);
+          sq = wave_sum_d(sq);
+          if (lane == 0) {
+            const double n = (double)B * (double)bn.HW;
+            const double mean = sa / n;
+            double var = sq / n - mean * mean;
+            if (var < 0) var = 0;
+            const float invstd = (float)(1.0 / sqrt(var + (double)bn.bn_eps));
+            const float av = (bn.gamma ? bn.gamma[ch] : 1.0f) * invstd;
+            const float bv = (bn.beta ? bn.beta[ch] : 0.0f) - (float)mean * av;
+            colv[0] = av;
+            colv[1] = bv;
+            if (col0 % bn.HW == 0) {          // first tile of the channel publishes the per-channel results
+              float* abo = const_cast<float*>(bn.ab);
+              float* svo = const_cast<float*>(bn.save);
+              abo[ch] = av; abo[bn.C + ch] = bv;
+              svo[ch] = (float)mean; svo[bn.C + ch] = invstd;
+              if (bn.running_mean) bn.running_mean[ch] = (1.0f - bn.momentum) * bn.running_mean[ch] + bn.momentum * (float)mean;
+              if (bn.running_var) bn.running_var[ch] = (1.0f - bn.momentum) * bn.running_var[ch] + bn.momentum * (float)(var * n / (n - 1.0));
+              if (col0 == 0 && bn.nbt) *bn.nbt += 1;
+            }
+          }
+        }
+        __syncthreads();
+        bn_a = colv[0];
+        bn_b = colv[1];
+        __syncthreads();                     // colv is reused by the column statistics below
+      } else {
+        bn_a = bn.ab[ch];
+        bn_b = bn.ab[bn.C + ch];
       }
+#pragma unroll
+      for (int j = 0; j < RJ; j++) {
+        if (rg + RG * j < B && col < F) {
+          xv[j].x = __fmaf_rn(bn_a, xv[j].x, bn_b); xv[j].y = __fmaf_rn(bn_a, xv[j].y, bn_b);
+          xv[j].z = __fmaf_rn(bn_a, xv[j].z, bn_b); xv[j].w = __fmaf_rn(bn_a, xv[j].w, bn_b);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < RJ; j++) {
+      const int row = rg + RG * j;
+      const bool ok = row < B;
+      const int64_t off = (int64_t)row * F + col;
       tv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (PAIR) {
         float4 q;
@@ -168,6 +216,7 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
         q.y = act_quant1<0>(xv[j].y, k, nlev, r, &tv[j].y, &b);
         q.z = act_quant1<0>(xv[j].z, k, nlev, r, &tv[j].z, &b);
         q.w = act_quant1<0>(xv[j].w, k, nlev, r, &tv[j].w, &b);
+        if (bn.relu) { q.x = fmaxf(q.x, 0.f); q.y = fmaxf(q.y, 0.f); q.z = fmaxf(q.z, 0.f); q.w = fmaxf(q.w, 0.f); }
         if (xq) st4(xq, off, col, F, ok, aligned, q);
       }
     }
@@ -622,6 +671,7 @@ __global__ __launch_bounds__(NTB) void site_bwd4_kernel(const float* __restrict_
         xr[q] = ok ? x[off] : 0.0f;
         if (BN && ok) xr[q] = __fmaf_rn(bn_a, xr[q], bn_b);
         gr[q] = (PAIR && gup && ok) ? gup[off] : 0.0f;
+        if (BN && bn.y && ok) gr[q] = (bn.y[off] > 0.0f) ? gr[q] : 0.0f;     // fused ReLU backward
       }
 #pragma unroll
       for (int half = 0; half < 2; half++) {

@@ -12,14 +12,27 @@ constexpr int kTailFloats = kPartFloats + 16;
 
 // Optional batch-norm fold: the site kernels read the CONV output z and apply x = a[c]*z + b[c] on load
 // (c = feature / HW), a = gamma*invstd, b = beta - mean*a; ab == nullptr means the input already is x.
+constexpr int kBnSplit = 16;   // batch splits per channel in bn_stats (partials per channel)
+
 struct BnFold {
-  const float* ab;      // [2][C]: a then b
-  const float* save;    // [2][C]: batch mean then invstd (backward only)
+  const float* ab;      // [2][C]: a then b.  Forward with `part`: OUTPUT (written by the first tile of each channel)
+  const float* save;    // [2][C]: batch mean then invstd.  Forward with `part`: OUTPUT
   int HW, C;
   float* dx_part;       // backward only: per-tile partial sums (sum dx, sum dx*zhat) [n_tiles][2]
-  const float* z;       // backward only: same pointer as the kernel's x argument (kept for clarity)
+  const float* y;       // backward only: the forward's relu(x_q) output when the ReLU is fused (mask y > 0), else nullptr
+  // forward, in-kernel finalisation of the batch statistics (bn_stats partials -> mean/invstd/a/b + running statistics)
+  const double* part;   // [C][kBnSplit][2] {sum z, sum z^2}; nullptr => `ab` is an input
+  const float* gamma;
+  const float* beta;
+  float* running_mean;
+  float* running_var;
+  long long* nbt;
+  float momentum, bn_eps;
+  int relu;             // forward: store relu(x_q)
 };
-inline BnFold no_bn() { return BnFold{nullptr, nullptr, 1, 1, nullptr, nullptr}; }
+inline BnFold no_bn() {
+  return BnFold{nullptr, nullptr, 1, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0};
+}
 
 struct Geom {
   int nb;           // 32-row blocks: 1, 2 (generic kernels) or 4 (site4 kernels)

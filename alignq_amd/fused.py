@@ -117,7 +117,7 @@ class BNSiteFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, bn_weight, bn_bias, running_mean, running_var, nbt, momentum, bn_eps, alterD, gamma, k, act_range,
-                eps, mu, rho):
+                eps, mu, rho, relu):
         z = L.dev_f32(z, "conv output")
         A = L.dev_f32(alterD, "alterD")
         Gm = L.dev_f32(gamma, "gamma")
@@ -130,27 +130,27 @@ class BNSiteFn(torch.autograd.Function):
         ab = torch.empty(2, C, dtype=torch.float32, device=dev)
         save = torch.empty(2, C, dtype=torch.float32, device=dev)
         ws_bn = torch.empty(lib.alignq_bn_ws_bytes(C), dtype=torch.uint8, device=dev)
-        L.check(lib.alignq_bn_stats(L.ptr(z), B, C, HW, L.ptr(bn_weight), L.ptr(bn_bias), L.ptr(running_mean),
-                                    L.ptr(running_var), L.ptr(nbt), float(momentum), float(bn_eps), L.ptr(ab), L.ptr(save),
-                                    L.ptr(ws_bn), st), "alignq_bn_stats")
-        xq = torch.empty_like(z)
+        L.check(lib.alignq_bn_partial_stats(L.ptr(z), B, C, HW, L.ptr(ws_bn), st), "alignq_bn_partial_stats")
+        y = torch.empty_like(z)
         D = torch.empty(B, B, dtype=torch.float32, device=dev)
         stats = torch.empty(4, F, dtype=torch.float32, device=dev)
         scal = torch.empty(4, dtype=torch.float32, device=dev)
         ws = torch.empty(lib.alignq_site_ws_bytes(B, F), dtype=torch.uint8, device=dev)
-        L.check(lib.alignq_site_partials_bn(L.ptr(z), L.ptr(ab), C, HW, B, F, int(k), float(act_range), float(eps),
-                                            L.ptr(xq), L.ptr(stats), L.ptr(ws), st), "alignq_site_partials_bn")
+        L.check(lib.alignq_site_partials_bn(L.ptr(z), L.ptr(ws_bn), L.ptr(bn_weight), L.ptr(bn_bias), L.ptr(running_mean),
+                                            L.ptr(running_var), L.ptr(nbt), float(momentum), float(bn_eps), L.ptr(ab),
+                                            L.ptr(save), C, HW, B, F, int(k), float(act_range), float(eps), int(bool(relu)),
+                                            L.ptr(y), L.ptr(stats), L.ptr(ws), st), "alignq_site_partials_bn")
         L.check(lib.alignq_site_reduce_loss(L.ptr(ws), B, F, L.ptr(D), L.ptr(A), L.ptr(Gm), dim, float(mu), float(rho),
                                             L.ptr(scal), st), "alignq_site_reduce_loss")
-        ctx.save_for_backward(z, ab, save, stats, D, A, Gm, scal)
+        ctx.save_for_backward(z, ab, save, stats, D, A, Gm, scal, y if relu else None)
         ctx.set_materialize_grads(False)
         ctx.cfg = (float(act_range), float(eps), float(mu), bn_weight is not None, bn_bias is not None)
         ctx.mark_non_differentiable(D)
-        return xq, scal[0], D
+        return y, scal[0], D
 
     @staticmethod
-    def backward(ctx, g_xq, g_loss, _gD):
-        z, ab, save, stats, D, A, Gm, scal = ctx.saved_tensors
+    def backward(ctx, g_y, g_loss, _gD):
+        z, ab, save, stats, D, A, Gm, scal, y = ctx.saved_tensors
         act_range, eps, mu, has_w, has_b = ctx.cfg
         B, C, H, W = z.shape
         HW, F = H * W, C * H * W
@@ -158,7 +158,7 @@ class BNSiteFn(torch.autograd.Function):
         lib = L.load()
         dev = z.device
         st = L.stream_ptr()
-        g_xq = None if g_xq is None else L.like_layout(g_xq, z)
+        g_y = None if g_y is None else L.like_layout(g_y, z)
         if g_loss is None:
             g_loss = torch.zeros((), dtype=torch.float32, device=dev)
         g_loss = L.dev_f32(g_loss, "loss grad")
@@ -168,14 +168,15 @@ class BNSiteFn(torch.autograd.Function):
                                            L.ptr(S), L.ptr(dA), L.ptr(dG), st), "alignq_site_prep_fused")
         dx = torch.empty_like(z)
         part = torch.empty(lib.alignq_site_bn_part_bytes(F), dtype=torch.uint8, device=dev)
-        L.check(lib.alignq_site_bwd_apply_bn(L.ptr(g_xq), L.ptr(S), L.ptr(z), L.ptr(ab), L.ptr(save), C, HW, L.ptr(stats),
-                                             B, F, act_range, eps, L.ptr(dx), L.ptr(part), st), "alignq_site_bwd_apply_bn")
+        L.check(lib.alignq_site_bwd_apply_bn(L.ptr(g_y), L.ptr(S), L.ptr(z), L.ptr(ab), L.ptr(save), C, HW, L.ptr(y),
+                                             L.ptr(stats), B, F, act_range, eps, L.ptr(dx), L.ptr(part), st),
+                "alignq_site_bwd_apply_bn")
         dz = torch.empty_like(z)
         dgam = torch.empty(C, dtype=torch.float32, device=dev) if has_w else None
         dbet = torch.empty(C, dtype=torch.float32, device=dev) if has_b else None
         L.check(lib.alignq_bn_bwd_apply(L.ptr(dx), L.ptr(z), L.ptr(ab), L.ptr(save), L.ptr(part), B, C, HW, L.ptr(dz),
                                         L.ptr(dgam), L.ptr(dbet), st), "alignq_bn_bwd_apply")
-        return (dz, dgam, dbet, None, None, None, None, None, dA, dG, None, None, None, None, None)
+        return (dz, dgam, dbet, None, None, None, None, None, dA, dG, None, None, None, None, None, None)
 
 
 def bn_site_fusable(bn, act, z) -> bool:
@@ -190,18 +191,20 @@ def bn_site_fusable(bn, act, z) -> bool:
             and config.args.method == "ours" and act.opt.alterD.shape[0] >= B)
 
 
-def bn_site(bn, act, z, eps=0.0):
-    """out, loss = act(bn(z)) — folded when `bn_site_fusable`, otherwise exactly that composition."""
+def bn_site(bn, act, z, eps=0.0, relu=False):
+    """out, loss = act(bn(z)) [; out = relu(out) when relu=True] — folded when `bn_site_fusable`, otherwise exactly that
+    composition."""
     from . import config
     if not bn_site_fusable(bn, act, z):
-        return act(bn(z))
+        out, loss = act(bn(z))
+        return (torch.nn.functional.relu(out) if relu else out), loss
     admm = act.opt
-    xq, loss, D = BNSiteFn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                                 bn.momentum, bn.eps, admm.alterD, admm.gamma, act.a_bit, config.args.act_range, eps,
-                                 admm.mu, admm.rho)
+    y, loss, D = BNSiteFn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                bn.momentum, bn.eps, admm.alterD, admm.gamma, act.a_bit, config.args.act_range, eps,
+                                admm.mu, admm.rho, relu)
     admm.D = D
     deferred = active_deferred()
     if deferred is not None:
         deferred.add(loss)
-        return xq, 0.0
-    return xq, loss
+        return y, 0.0
+    return y, loss

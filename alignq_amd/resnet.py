@@ -57,11 +57,13 @@ class PreActBlock_conv_Q(nn.Module):
             return fn(x)
         return fn(x), 0
 
-    def _bnq(self, bn, fn, z):
-        """act(bn(z)); with fuse_bn the batch-norm is folded into the site kernels (alignq_amd.fused.bn_site)."""
+    def _bnq(self, bn, fn, z, relu=False):
+        """act(bn(z)) [+ relu]; with fuse_bn both the batch-norm and the ReLU are folded into the site kernels
+        (alignq_amd.fused.bn_site)."""
         if self.tree == "admm" and self.fuse_bn:
-            return bn_site(bn, fn, z)
-        return self._q(fn, bn(z))
+            return bn_site(bn, fn, z, relu=relu)
+        out, loss = self._q(fn, bn(z))
+        return (F.relu(out) if relu else out), loss
 
     def forward(self, x):
         trans_loss = 0.
@@ -70,9 +72,8 @@ class PreActBlock_conv_Q(nn.Module):
             trans_loss += loss
         else:
             shortcut = x
-        out, loss = self._bnq(self.bn0, self.act_q0, self.conv0(x))
+        out, loss = self._bnq(self.bn0, self.act_q0, self.conv0(x), relu=True)
         trans_loss += loss
-        out = F.relu(out)
         out, loss = self._bnq(self.bn1, self.act_q1, self.conv1(out))
         trans_loss += loss
         out += shortcut
@@ -109,14 +110,14 @@ class PreActResNet(nn.Module):
 
     def forward(self, x):
         if self.tree == "admm" and self.fuse_bn:
-            out, loss = bn_site(self.bn, self.act_q0, self.conv0(x))
+            out, loss = bn_site(self.bn, self.act_q0, self.conv0(x), relu=True)
             trans_loss = 0. + loss
         elif self.tree == "admm":
             out, loss = self.act_q0(self.bn(self.conv0(x)))
             trans_loss = 0. + loss
+            out = F.relu(out)
         else:
-            out = self.act_q0(self.bn(self.conv0(x)))
-        out = F.relu(out)
+            out = F.relu(self.act_q0(self.bn(self.conv0(x))))
         for layer in self.layers:
             if self.tree == "admm":
                 out, loss = layer(out)

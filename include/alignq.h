@@ -164,29 +164,36 @@ int alignq_sgd_step_multi(int T, float* const* p, float* const* g, float* const*
                           float mom, float damp, float wd, int nesterov, int bitW, float lam, float lam2,
                           void* stream);
 
-/* ---- batch-norm folded into the ADMM site (caller: out, loss = act_q(bn(conv(x))),
- * cdf_alignment_admm/resnet-56-cifar-10/model/resnet.py:87-94) -----------------------------------------------
+/* ---- batch-norm (and the ReLU that follows) folded into the ADMM site (caller:
+ * out, loss = act_q(bn(conv(x))); out = relu(out), cdf_alignment_admm/resnet-56-cifar-10/model/resnet.py:87-94) ----
  * Training-mode nn.BatchNorm2d semantics.  z = conv output [B,C,HW] (HW % 64 == 0, 64 < B <= 128 for the folded site
- * kernels).  alignq_bn_stats: per-channel batch statistics (two launches) -> ab = {a[C], b[C]} with
- * a = gamma*invstd, b = beta - mean*a; save = {mean[C], invstd[C]}; updates running_mean / running_var (momentum,
- * unbiased variance) and *num_batches_tracked (any of the three may be NULL).  ws: alignq_bn_ws_bytes(C).
- * alignq_site_partials_bn: as alignq_site_partials but reads z and applies x = a[c]*z + b[c] on load (x is never
- * materialised).  Backward: alignq_site_prep_fused (first launch of alignq_site_bwd_fused alone) then
- * alignq_site_bwd_apply_bn, which writes dx (gradient w.r.t. the BN output) and per-tile sums
- * dx_part [F/64][2] = {sum dx, sum dx*zhat}, then alignq_bn_bwd_apply: dz, dgamma, dbeta.                        */
+ * kernels).
+ * alignq_bn_partial_stats: per-(channel, batch split) sums of z and z^2 into ws (alignq_bn_ws_bytes(C)); one launch.
+ * alignq_site_partials_bn: as alignq_site_partials, but reads z, finalises the batch statistics of its tile's channel
+ *   from bn_part in-kernel (mean, invstd, a = gamma*invstd, b = beta - mean*a) and applies x = a*z + b on load: the
+ *   normalised activation is never materialised.  OUTPUTS besides xq/stats/ws: ab = {a[C], b[C]}, save = {mean[C],
+ *   invstd[C]} (for the backward), running_mean / running_var (momentum, unbiased variance) and *num_batches_tracked
+ *   (+1) — any of the last three may be NULL.  relu != 0 stores relu(x_q).
+ * alignq_bn_stats: the stand-alone form (statistics + finalisation, two launches) producing the same ab / save.
+ * Backward: alignq_site_prep_fused (first launch of alignq_site_bwd_fused alone), then alignq_site_bwd_apply_bn which
+ *   writes dx (gradient w.r.t. the BN output; y_relu = the forward's output when relu was fused, else NULL) and per-tile
+ *   sums dx_part [F/64][2] = {sum dx, sum dx*zhat}, then alignq_bn_bwd_apply: dz, dgamma, dbeta.                    */
 size_t alignq_bn_ws_bytes(int C);
+int alignq_bn_partial_stats(const float* z, int B, int C, int HW, void* ws, void* stream);
 int alignq_bn_stats(const float* z, int B, int C, int HW, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, int64_t* num_batches_tracked, float momentum, float eps, float* ab, float* save,
                     void* ws, void* stream);
-int alignq_site_partials_bn(const float* z, const float* ab, int C, int HW, int B, int64_t F, int k, float act_range,
-                            float eps, float* xq, float* stats, void* ws, void* stream);
+int alignq_site_partials_bn(const float* z, const void* bn_part, const float* bn_gamma, const float* bn_beta,
+                            float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                            float bn_eps, float* ab, float* save, int C, int HW, int B, int64_t F, int k, float act_range,
+                            float eps, int relu, float* xq, float* stats, void* ws, void* stream);
 size_t alignq_site_bn_part_bytes(int64_t F);
 int alignq_site_prep_fused(const float* D, const float* alterD, const float* gamma, int dim, const float* scal, float mu,
                            const float* dD_scale, int B, int64_t F, float* S, float* dalterD, float* dgamma,
                            void* stream);
 int alignq_site_bwd_apply_bn(const float* g, const float* S, const float* z, const float* ab, const float* save, int C,
-                             int HW, const float* stats, int B, int64_t F, float act_range, float eps, float* dx,
-                             float* dx_part, void* stream);
+                             int HW, const float* y_relu, const float* stats, int B, int64_t F, float act_range,
+                             float eps, float* dx, float* dx_part, void* stream);
 int alignq_bn_bwd_apply(const float* dx, const float* z, const float* ab, const float* save, const float* dx_part, int B,
                         int C, int HW, float* dz, float* dgamma, float* dbeta, void* stream);
 

@@ -480,8 +480,9 @@ def test_office_dann_harness_runs_and_matches_eager_under_graph(dev):
         config.args.train_batch_size, config.args.eval_batch_size = 128, 100
 
 
+@pytest.mark.parametrize("relu", [False, True])
 @pytest.mark.parametrize("B,C,H,W,k", [(128, 16, 32, 32, 8), (128, 64, 8, 8, 4), (100, 32, 16, 16, 8)])
-def test_bn_folded_site_matches_unfused(dev, B, C, H, W, k):
+def test_bn_folded_site_matches_unfused(dev, B, C, H, W, k, relu):
     """fused.bn_site (batch-norm folded into the site kernels, training mode) against act(bn(z)) with torch's BatchNorm2d
     + the unfused site: x_q equal up to tie-zone bin flips (x differs by one fma rounding), D / loss / dz / dgamma / dbeta /
     running statistics within fp32 tolerance."""
@@ -504,9 +505,11 @@ def test_bn_folded_site_matches_unfused(dev, B, C, H, W, k):
         zz = z.clone().requires_grad_(True)
         if fused:
             assert bn_site_fusable(bn, act, zz)
-            xq, loss = bn_site(bn, act, zz)
+            xq, loss = bn_site(bn, act, zz, relu=relu)
         else:
             xq, loss = act(bn(zz))
+            if relu:
+                xq = torch.nn.functional.relu(xq)
         (loss + (xq * gq).sum()).backward()
         outs.append(dict(xq=npy(xq), loss=float(loss.detach()), D=npy(admm.D), dz=npy(zz.grad), dw=npy(bn.weight.grad),
                          db=npy(bn.bias.grad), rm=npy(bn.running_mean), rv=npy(bn.running_var),
