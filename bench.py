@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true", help="skip the per-kernel roofline measurements")
-    ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--no-fuse-bn", action="store_true", help="keep torch/MIOpen batch-norm instead of folding it into the ADMM-site kernels")
     ap.add_argument("--dp-selftest", action="store_true", help="run the DP path (RCCL all-reduce, two graphs) even at N=1")
     ap.add_argument("--channels-last", action="store_true", help="NHWC activations/weights end to end")
@@ -65,20 +65,24 @@ def time_call(fn, reps, warm=3):
     return e0.elapsed_time(e1) * 1e-3 / reps
 
 
-def measure_kernels(dev, B, k, site_F_counts):
-    """Per-kernel live timings through the C ABI.  site_F_counts: {F: number of ADMM sites with F features}."""
+def measure_kernels(dev, B, k, site_F_counts, hw_of_F, folded=True):
+    """Per-kernel live timings through the C ABI, HIP events on the launch stream.
+    site_F_counts: {F: number of ADMM sites with F features}; hw_of_F: {F: H*W} (the channel size for the BN fold).
+    folded=True times the entry points the training step actually uses (batch-norm + ReLU folded into the site kernels)."""
     from alignq_amd import _lib as L
     lib = L.load()
     st = L.stream_ptr()
     out = {}
-    per_step = {"site_partials": [0.0, 0.0], "site_bwd": [0.0, 0.0], "site_reduce_loss": [0.0, 0.0],
-                "site_bwd_prep": [0.0, 0.0]}
+    names = ("bn_partial_stats", "site_partials", "site_reduce_loss", "site_bwd_prep", "site_bwd", "bn_bwd_apply")
+    per_step = {n: [0.0, 0.0] for n in names}
     A = torch.rand(B, B, device=dev)
     Gm = torch.rand(B, B, device=dev)
     for F, count in sorted(site_F_counts.items()):
+        HW = hw_of_F[F]
+        C = F // HW
         x = torch.randn(B, F, device=dev)
         g = torch.randn(B, F, device=dev) * 0.01
-        xq, dx = torch.empty_like(x), torch.empty_like(x)
+        xq, dx, dz = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
         D = torch.empty(B, B, device=dev)
         stats = torch.empty(4, F, device=dev)
         ws = torch.empty(lib.alignq_site_ws_bytes(B, F), dtype=torch.uint8, device=dev)
@@ -86,24 +90,48 @@ def measure_kernels(dev, B, k, site_F_counts):
         scal = torch.empty(4, device=dev)
         dA, dG = torch.empty_like(A), torch.empty_like(Gm)
         one = torch.ones((), device=dev)
+        gam, bet = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev) * 0.1
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        nbt = torch.zeros((), dtype=torch.int64, device=dev)
+        ab, save = torch.empty(2, C, device=dev), torch.empty(2, C, device=dev)
+        ws_bn = torch.empty(lib.alignq_bn_ws_bytes(C), dtype=torch.uint8, device=dev)
+        part = torch.empty(lib.alignq_site_bn_part_bytes(F), dtype=torch.uint8, device=dev)
+        dgam, dbet = torch.empty(C, device=dev), torch.empty(C, device=dev)
         p = L.ptr
+        if folded:
+            f_stats = lambda: lib.alignq_bn_partial_stats(p(x), B, C, HW, p(ws_bn), st)
+            f_part = lambda: lib.alignq_site_partials_bn(p(x), p(ws_bn), p(gam), p(bet), p(rm), p(rv), p(nbt), 0.1, 1e-5, p(ab),
+                                                         p(save), C, HW, B, F, k, 2.0, 0.0, 1, p(xq), p(stats), p(ws), st)
+            f_bwd = lambda: lib.alignq_site_bwd_apply_bn(p(g), p(S), p(x), p(ab), p(save), C, HW, p(xq), p(stats), B, F, 2.0,
+                                                         0.0, p(dx), p(part), st)
+            f_bnb = lambda: lib.alignq_bn_bwd_apply(p(dx), p(x), p(ab), p(save), p(part), B, C, HW, p(dz), p(dgam), p(dbet), st)
+        else:
+            f_stats = None
+            f_part = lambda: lib.alignq_site_partials(p(x), B, F, k, 2.0, 0.0, p(xq), p(stats), p(ws), st)
+            f_bwd = lambda: lib.alignq_site_bwd_apply(p(g), p(S), p(x), p(stats), B, F, 2.0, 0.0, p(dx), st)
+            f_bnb = None
+        f_red = lambda: lib.alignq_site_reduce_loss(p(ws), B, F, p(D), p(A), p(Gm), B, 0.2, 0.3, p(scal), st)
+        f_prep = lambda: lib.alignq_site_prep_fused(p(D), p(A), p(Gm), B, p(scal), 0.2, p(one), B, F, p(S), p(dA), p(dG), st)
 
         def fwd_pair():   # the reduction's arrival counter is re-armed by the partials kernel: time them as a pair
-            lib.alignq_site_partials(p(x), B, F, k, 2.0, 0.0, p(xq), p(stats), p(ws), st)
-            lib.alignq_site_reduce_loss(p(ws), B, F, p(D), p(A), p(Gm), B, 0.2, 0.3, p(scal), st)
+            f_part()
+            f_red()
 
-        t_part = time_call(lambda: lib.alignq_site_partials(p(x), B, F, k, 2.0, 0.0, p(xq), p(stats), p(ws), st), 50)
+        t_stats = time_call(f_stats, 50) if f_stats else 0.0
+        t_part = time_call(f_part, 50)
         t_red = max(time_call(fwd_pair, 50) - t_part, 0.0)
-        t_both = time_call(lambda: lib.alignq_site_bwd_fused(p(g), p(D), p(A), p(Gm), B, p(scal), 0.2, p(one), p(x), p(stats), B, F, 2.0, 0.0, p(dx), p(dA), p(dG), p(S), st), 50)
-        t_bwd = time_call(lambda: lib.alignq_site_bwd_apply(p(g), p(S), p(x), p(stats), B, F, 2.0, 0.0, p(dx), st), 50)
-        t_prep = max(t_both - t_bwd, 0.0)
+        t_prep = time_call(f_prep, 50)
+        t_bwd = time_call(f_bwd, 50)
+        t_bnb = time_call(f_bnb, 50) if f_bnb else 0.0
         gram_flops = 2 * 2.0 * B * B * F            # two Grams, full-matrix count
         out[f"site_F{F}"] = {
-            "partials_us": t_part * 1e6, "reduce_loss_us": t_red * 1e6, "bwd_prep_us": t_prep * 1e6, "bwd_us": t_bwd * 1e6,
-            "partials_tflops": gram_flops / t_part / 1e12, "bwd_tflops": gram_flops / t_bwd / 1e12,
-            "partials_hbm_gbs": 8.0 * B * F / t_part / 1e9, "bwd_hbm_gbs": 12.0 * B * F / t_bwd / 1e9, "sites": count}
-        for name, t, fl in (("site_partials", t_part, gram_flops), ("site_bwd", t_bwd, gram_flops),
-                            ("site_reduce_loss", t_red, 0.0), ("site_bwd_prep", t_prep, 0.0)):
+            "bn_partial_stats_us": t_stats * 1e6, "partials_us": t_part * 1e6, "reduce_loss_us": t_red * 1e6,
+            "bwd_prep_us": t_prep * 1e6, "bwd_us": t_bwd * 1e6, "bn_bwd_apply_us": t_bnb * 1e6,
+            "partials_hbm_gbs": 8.0 * B * F / t_part / 1e9, "bwd_hbm_gbs": 12.0 * B * F / t_bwd / 1e9,
+            "partials_tflops_fp32_equiv": gram_flops / t_part / 1e12, "sites": count, "C": C, "HW": HW}
+        for name, t, fl in (("bn_partial_stats", t_stats, 0.0), ("site_partials", t_part, gram_flops),
+                            ("site_reduce_loss", t_red, 0.0), ("site_bwd_prep", t_prep, 0.0), ("site_bwd", t_bwd, gram_flops),
+                            ("bn_bwd_apply", t_bnb, 0.0)):
             per_step[name][0] += t * count
             per_step[name][1] += fl * count
     # plain CDF-quantise kernels on a roofline-sized tensor (2^26 elements = 268 MB, beyond the 256 MiB L3)
@@ -120,7 +148,8 @@ def measure_kernels(dev, B, k, site_F_counts):
     n_sites = sum(site_F_counts.values())
     dom = max(("site_partials", "site_bwd"), key=lambda kname: per_step[kname][0])
     t_sum, fl_sum = per_step[dom]
-    kernel_sym = {"site_partials": "site_fwd4_kernel<TF,true>", "site_bwd": "site_bwd4_kernel<true>"}[dom]
+    kernel_sym = {"site_partials": "site_fwd4_kernel<TF,true> (BN+ReLU folded)" if folded else "site_fwd4_kernel<TF,true>",
+                  "site_bwd": "site_bwd4_kernel<true,true> (BN+ReLU folded)" if folded else "site_bwd4_kernel<true,false>"}[dom]
     bytes_per_elem = 8.0 if dom == "site_partials" else 12.0          # fwd read x + write x_q; bwd read g,x + write dx
     by_sum = sum(bytes_per_elem * B * F * cnt for F, cnt in site_F_counts.items())
     traffic = None
@@ -144,33 +173,41 @@ def measure_kernels(dev, B, k, site_F_counts):
 
 
 def cpu_baseline(batch, bits, model, steps):
-    """The eager-torch restatement of the reference on the host cores: same workload, bounded sample."""
+    """The eager-torch restatement of the reference on the host cores: same workload, bounded sample.  Oversubscribing
+    torch's intra-op pool hurts this elementwise-heavy workload (64 threads ran slower than 16 on the GPU box), so two
+    thread counts are tried and the FASTER one is reported."""
     from oracle import torch_ref as R
     try:
-        cores = len(os.sched_getaffinity(0))
+        avail = len(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 64))
-    torch.set_num_threads(cores)
+        avail = os.cpu_count() or 1
     cfg = R.Config(tree="admm", bitW=bits, abitW=bits, train_batch_size=batch)
-    torch.manual_seed(0)
-    net = (R.resnet20 if model == "resnet20" else R.resnet56)(cfg).train()
-    step = R.TrainStep(net, cfg)
     gen = torch.Generator().manual_seed(0)
     x = torch.randn(batch, 3, 32, 32, generator=gen)
     y = torch.randint(0, 10, (batch,), generator=gen)
-    for _ in range(2):
-        step(x, y)
-    ts = []
-    for _ in range(steps):
-        t0 = time.perf_counter()
-        step(x, y)
-        ts.append(time.perf_counter() - t0)
-    ts.sort()
-    med = ts[len(ts) // 2]
-    return {"value": batch / med, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+    best = None
+    tried = {}
+    for cores in sorted({max(1, min(avail, 16)), max(1, min(avail, 64))}):
+        torch.set_num_threads(cores)
+        torch.manual_seed(0)
+        net = (R.resnet20 if model == "resnet20" else R.resnet56)(cfg).train()
+        step = R.TrainStep(net, cfg)
+        for _ in range(2):
+            step(x, y)
+        ts = []
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            step(x, y)
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        med = ts[len(ts) // 2]
+        tried[str(cores)] = batch / med
+        if best is None or med < best[1]:
+            best = (cores, med)
+    cores, med = best
+    return {"value": batch / med, "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": f"{steps} full training steps (median) of the same workload after 2 warm-ups, batch {batch}, "
-                      f"oracle/torch_ref.py on torch-CPU {torch.__version__}",
+                      f"oracle/torch_ref.py on torch-CPU {torch.__version__}; thread counts tried -> images/sec: {tried}",
             "s_per_step": med}
 
 
@@ -288,7 +325,8 @@ def main():
             counts[16384] = 1 + 2 * units[0]
             counts[8192] = 2 * units[1] + 1
             counts[4096] = 2 * units[2] + 1
-            roof, kernels = measure_kernels(dev, a.batch, a.bits, counts)
+            roof, kernels = measure_kernels(dev, a.batch, a.bits, counts, {16384: 1024, 8192: 256, 4096: 64},
+                                            folded=not a.no_fuse_bn)
             res["roofline"] = roof
             res["kernels"] = kernels
         if world == 1 and not a.no_cpu_baseline and not office:
