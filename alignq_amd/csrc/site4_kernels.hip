@@ -432,7 +432,7 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
 // LOSS: additionally the ADMM loss scalar (utils/admm.py:24-33) through a last-block epilogue:
 //       scal = {loss, c_con = rho/2/(n*rms), 1/n, rms}.
 template <bool SYM, bool LOSS>
-__global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restrict__ slabs, int n_slabs,
+__device__ __forceinline__ void slab_reduce_body(const float* __restrict__ slabs, int n_slabs,
                                                            int slab_floats, int BP, int B, float scale,
                                                            float* __restrict__ out, const float* __restrict__ A,
                                                            const float* __restrict__ gamma, int dim, float mu,
@@ -542,13 +542,44 @@ __global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restri
   }
 }
 
+template <bool SYM, bool LOSS>
+__global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restrict__ slabs, int n_slabs,
+                                                           int slab_floats, int BP, int B, float scale,
+                                                           float* __restrict__ out, const float* __restrict__ A,
+                                                           const float* __restrict__ gamma, int dim, float mu,
+                                                           float rho, float* __restrict__ parts,
+                                                           unsigned* __restrict__ counter, float* __restrict__ scal) {
+  slab_reduce_body<SYM, LOSS>(slabs, n_slabs, slab_floats, BP, B, scale, out, A, gamma, dim, mu, rho, parts, counter, scal);
+}
+
+// All sites of a model in ONE launch (blockIdx.y = site): the per-site reductions are off the critical path of the
+// network's forward (only x_q feeds the next layer), so a whole-model step defers them to the end of the forward.
+constexpr int kMultiSites = 32;
+struct RChunk {
+  const float* slabs[kMultiSites];
+  float* out[kMultiSites];
+  const float* A[kMultiSites];
+  const float* gamma[kMultiSites];
+  float* scal[kMultiSites];
+  float scale[kMultiSites];
+  int n_slabs[kMultiSites];
+};
+__global__ __launch_bounds__(1024) void slab_reduce_multi_kernel(RChunk c, int B, int dim, float mu, float rho) {
+  const int s = blockIdx.y;
+  float* ws = const_cast<float*>(c.slabs[s]);
+  float* parts = ws + (size_t)c.n_slabs[s] * 10240;
+  unsigned* counter = reinterpret_cast<unsigned*>(parts + kPartFloats);
+  slab_reduce_body<true, true>(c.slabs[s], c.n_slabs[s], 10240, 128, B, c.scale[s], c.out[s], c.A[s], c.gamma[s], dim, mu,
+                               rho, parts, counter, c.scal[s]);
+}
+
 // ================================================================================================ backward prep
 // S = (gD + gD^T) * gscale / F  [B,B]   (MFMA A operand of the backward), and (FUSED) the scaled parameter
 // gradients dA_out = gscale*(mu*sign(A)/n - gD), dG_out = gscale*|D-A|/n  (zero outside [:B,:B]).
 //   FUSED : gD = c_con*(D-A) + gamma*sign(D-A)/n from the forward's scal = {loss, c_con, 1/n, rms}
 //   !FUSED: gD = dD (explicit upstream gradient)
 template <bool FUSED>
-__global__ __launch_bounds__(256) void site_prep_kernel(const float* __restrict__ dD, const float* __restrict__ D,
+__device__ __forceinline__ void site_prep_body(const float* __restrict__ dD, const float* __restrict__ D,
                                                         const float* __restrict__ A, const float* __restrict__ gamma,
                                                         int dim, const float* __restrict__ scal, float mu,
                                                         const float* __restrict__ gscale, int B, float invF,
@@ -581,6 +612,33 @@ __global__ __launch_bounds__(256) void site_prep_kernel(const float* __restrict_
       if (dG_out) dG_out[e] = 0.f;
     }
   }
+}
+
+template <bool FUSED>
+__global__ __launch_bounds__(256) void site_prep_kernel(const float* __restrict__ dD, const float* __restrict__ D,
+                                                        const float* __restrict__ A, const float* __restrict__ gamma,
+                                                        int dim, const float* __restrict__ scal, float mu,
+                                                        const float* __restrict__ gscale, int B, float invF,
+                                                        float* __restrict__ S, float* __restrict__ dA_out,
+                                                        float* __restrict__ dG_out) {
+  site_prep_body<FUSED>(dD, D, A, gamma, dim, scal, mu, gscale, B, invF, S, dA_out, dG_out);
+}
+
+struct PChunk {
+  const float* D[kMultiSites];
+  const float* A[kMultiSites];
+  const float* gamma[kMultiSites];
+  const float* scal[kMultiSites];
+  float* S[kMultiSites];
+  float* dA[kMultiSites];
+  float* dG[kMultiSites];
+  float invF[kMultiSites];
+};
+__global__ __launch_bounds__(256) void site_prep_multi_kernel(PChunk c, int dim, float mu, const float* __restrict__ gscale,
+                                                              int B) {
+  const int s = blockIdx.y;
+  site_prep_body<true>(nullptr, c.D[s], c.A[s], c.gamma[s], dim, c.scal[s], mu, gscale, B, c.invF[s], c.S[s], c.dA[s],
+                       c.dG[s]);
 }
 
 // ================================================================================================ backward
@@ -901,6 +959,39 @@ int launch_prep(bool fused, const float* dD, const float* D, const float* alterD
   else
     hipLaunchKernelGGL((site_prep_kernel<false>), blocks, 256, 0, st, dD, D, alterD, gamma, dim, scal, mu, gscale, B, invF, S, dA_out, dG_out);
   RET_ON_ERR();
+  return 0;
+}
+
+int launch_reduce_loss_multi(int S, void* const* ws, float* const* D, const float* const* alterD,
+                             const float* const* gamma, float* const* scal, const int64_t* F, int B, int dim, float mu,
+                             float rho, hipStream_t st) {
+  for (int s0 = 0; s0 < S; s0 += kMultiSites) {
+    const int cnt = (S - s0 < kMultiSites) ? S - s0 : kMultiSites;
+    RChunk c;
+    for (int i = 0; i < cnt; i++) {
+      const Geom g = geom(B, F[s0 + i]);
+      c.slabs[i] = (const float*)ws[s0 + i]; c.out[i] = D[s0 + i]; c.A[i] = alterD[s0 + i]; c.gamma[i] = gamma[s0 + i];
+      c.scal[i] = scal[s0 + i]; c.scale[i] = 1.0f / (float)F[s0 + i]; c.n_slabs[i] = g.grid;
+    }
+    hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3(160, cnt), 1024, 0, st, c, B, dim, mu, rho);
+    RET_ON_ERR();
+  }
+  return 0;
+}
+
+int launch_prep_multi(int S, const float* const* D, const float* const* alterD, const float* const* gamma,
+                      const float* const* scal, const float* gscale, const int64_t* F, int B, int dim, float mu,
+                      float* const* Sout, float* const* dA, float* const* dG, hipStream_t st) {
+  for (int s0 = 0; s0 < S; s0 += kMultiSites) {
+    const int cnt = (S - s0 < kMultiSites) ? S - s0 : kMultiSites;
+    PChunk c;
+    for (int i = 0; i < cnt; i++) {
+      c.D[i] = D[s0 + i]; c.A[i] = alterD[s0 + i]; c.gamma[i] = gamma[s0 + i]; c.scal[i] = scal[s0 + i];
+      c.S[i] = Sout[s0 + i]; c.dA[i] = dA[s0 + i]; c.dG[i] = dG[s0 + i]; c.invF[i] = 1.0f / (float)F[s0 + i];
+    }
+    hipLaunchKernelGGL(site_prep_multi_kernel, dim3((dim * dim + 255) / 256, cnt), 256, 0, st, c, dim, mu, gscale, B);
+    RET_ON_ERR();
+  }
   return 0;
 }
 

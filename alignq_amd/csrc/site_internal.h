@@ -83,6 +83,13 @@ int launch_bwd4(bool pair, const Geom& g, const float* gup, const float* S, cons
 int launch_prep(bool fused, const float* dD, const float* D, const float* alterD, const float* gamma, int dim,
                 const float* scal, float mu, const float* gscale, int B, int64_t F, float* S, float* dA_out,
                 float* dG_out, hipStream_t st);
+// all sites of a model in one launch each (64 < B <= 128 only)
+int launch_reduce_loss_multi(int S, void* const* ws, float* const* D, const float* const* alterD,
+                             const float* const* gamma, float* const* scal, const int64_t* F, int B, int dim, float mu,
+                             float rho, hipStream_t st);
+int launch_prep_multi(int S, const float* const* D, const float* const* alterD, const float* const* gamma,
+                      const float* const* scal, const float* gscale, const int64_t* F, int B, int dim, float mu,
+                      float* const* Sout, float* const* dA, float* const* dG, hipStream_t st);
 // slab reduction for both geometries (+ optional ADMM-loss scalar through a last-block epilogue)
 int launch_reduce_any(const Geom& g, const float* ws_c, float* ws_mut, int B, int64_t F, float* out, bool with_loss,
                       const float* alterD, const float* gamma, int dim, float mu, float rho, float* scal,

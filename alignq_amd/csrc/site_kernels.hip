@@ -583,6 +583,27 @@ int alignq_site_prep_fused(const float* D, const float* alterD, const float* gam
                      (hipStream_t)stream);
 }
 
+int alignq_site_reduce_loss_multi(int S, void* const* ws, float* const* D, const float* const* alterD,
+                                  const float* const* gamma, float* const* scal, const int64_t* F, int B, int dim,
+                                  float mu, float rho, void* stream) {
+  if (S <= 0 || !ws || !D || !alterD || !gamma || !scal || !F || dim < B) return ALIGNQ_EINVAL;
+  if (B <= 64 || B > ALIGNQ_MAX_BATCH) return ALIGNQ_EUNSUPPORTED;
+  for (int i = 0; i < S; i++)
+    if (!ws[i] || !D[i] || !alterD[i] || !gamma[i] || !scal[i] || F[i] <= 0) return ALIGNQ_EINVAL;
+  return launch_reduce_loss_multi(S, ws, D, alterD, gamma, scal, F, B, dim, mu, rho, (hipStream_t)stream);
+}
+
+int alignq_site_prep_fused_multi(int S, const float* const* D, const float* const* alterD, const float* const* gamma,
+                                 const float* const* scal, const float* dD_scale, const int64_t* F, int B, int dim,
+                                 float mu, float* const* S_out, float* const* dalterD, float* const* dgamma,
+                                 void* stream) {
+  if (S <= 0 || !D || !alterD || !gamma || !scal || !F || !S_out || !dalterD || !dgamma || dim < B) return ALIGNQ_EINVAL;
+  for (int i = 0; i < S; i++)
+    if (!D[i] || !alterD[i] || !gamma[i] || !scal[i] || !S_out[i] || !dalterD[i] || !dgamma[i] || F[i] <= 0)
+      return ALIGNQ_EINVAL;
+  return launch_prep_multi(S, D, alterD, gamma, scal, dD_scale, F, B, dim, mu, S_out, dalterD, dgamma, (hipStream_t)stream);
+}
+
 int alignq_site_bwd_apply(const float* g, const float* S, const float* x, const float* stats, int B, int64_t F,
                           float act_range, float eps, float* dx, void* stream) {
   if (!S || !x || !stats || !dx) return ALIGNQ_EINVAL;

@@ -64,22 +64,83 @@ def prequantize_weights(convs):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-class DeferredLosses:
-    """Fast path for a whole-model step: the per-site slab reduction + ADMM loss is launched on a side stream (it is
-    not needed by the next layer, only x_q is) and the 21..57 site losses are summed once at the end instead of one
-    tiny add kernel per site.  While active, activation modules return the python float 0.0 as their trans_loss and
-    park the real loss tensor here; `total()` joins the side stream and returns the sum (differentiable)."""
+class SiteRecord:
+    """Per-site bookkeeping of a batched (deferred) step: the site's forward only launches the partial-slab kernel and
+    parks its buffers here; `DeferredLosses.total()` reduces all sites' slabs (+ ADMM loss) in one launch and its backward
+    prepares all sites' S / dalterD / dgamma in one launch."""
+    __slots__ = ("ws", "D", "A", "Gm", "scal", "B", "F", "dim", "mu", "rho", "S", "dA", "dG", "prepared")
 
-    def __init__(self, use_side_stream=False):
+    def __init__(self):
+        self.prepared = False
+
+
+class LossSumFn(torch.autograd.Function):
+    """total = sum_s trans_loss_s over the batched sites.  Forward: alignq_site_reduce_loss_multi (D_s and the loss scalars
+    of every site), then one sum.  Backward: alignq_site_prep_fused_multi with the upstream scalar.  The per-site losses
+    are inputs, so autograd runs this node's backward before any site's backward."""
+
+    @staticmethod
+    def forward(ctx, collector, scal_all, *losses):
+        lib = L.load()
+        st = L.stream_ptr()
+        for (B, dim, mu, rho), recs in collector.groups().items():
+            L.check(lib.alignq_site_reduce_loss_multi(
+                len(recs), L.ptr_array([r.ws for r in recs]), L.ptr_array([r.D for r in recs]),
+                L.ptr_array([r.A for r in recs]), L.ptr_array([r.Gm for r in recs]),
+                L.ptr_array([r.scal for r in recs]), L.i64_array([r.F for r in recs]), B, dim, mu, rho, st),
+                "alignq_site_reduce_loss_multi")
+        ctx.collector = collector
+        ctx.recs = list(collector.records)
+        return scal_all[:len(losses), 0].sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = L.load()
+        st = L.stream_ptr()
+        g = L.dev_f32(g, "loss grad")
+        groups = {}
+        for r in ctx.recs:
+            groups.setdefault((r.B, r.dim, r.mu, r.rho), []).append(r)
+        for (B, dim, mu, rho), recs in groups.items():
+            dev = recs[0].D.device
+            for r in recs:
+                r.S = torch.empty(B, B, dtype=torch.float32, device=dev)
+                r.dA, r.dG = torch.empty_like(r.A), torch.empty_like(r.Gm)
+            L.check(lib.alignq_site_prep_fused_multi(
+                len(recs), L.ptr_array([r.D for r in recs]), L.ptr_array([r.A for r in recs]),
+                L.ptr_array([r.Gm for r in recs]), L.ptr_array([r.scal for r in recs]), L.ptr(g),
+                L.i64_array([r.F for r in recs]), B, dim, mu, L.ptr_array([r.S for r in recs]),
+                L.ptr_array([r.dA for r in recs]), L.ptr_array([r.dG for r in recs]), st),
+                "alignq_site_prep_fused_multi")
+            for r in recs:
+                r.prepared = True
+        return (None, None) + (g,) * len(ctx.recs)
+
+
+class DeferredLosses:
+    """Fast path for a whole-model step.  While active, activation modules return the python float 0.0 as their
+    trans_loss and park the real loss here; `total()` returns the (differentiable) sum.
+
+    batch=True (default): sites with 64 < B <= 128 additionally defer their slab reduction + ADMM loss to `total()`, where
+    ONE launch covers all of them (it is off the forward's critical path: only x_q feeds the next layer), and their
+    backward shares ONE prep launch.  Other sites keep their own launches and only the loss sum is deferred."""
+
+    _CHUNK = 64
+
+    def __init__(self, use_side_stream=False, batch=True):
         # Measured on MI355X / ROCm 7.2 (ResNet-20 step, one HIP graph): forking the 21 reductions onto a side stream
         # costs more in cross-queue graph dependencies than the overlap returns (4.09 vs 3.44 ms per step), so the
-        # default keeps everything on one stream and only defers the loss sum.
+        # default keeps everything on one stream.
         self.side = torch.cuda.Stream() if use_side_stream else None
+        self.batch = batch and not use_side_stream
         self.losses = []
+        self.records = []
+        self._rec_losses = []
+        self._scal_all = None
 
     def __enter__(self):
         global _active
-        self.losses = []
+        self.losses, self.records, self._rec_losses, self._scal_all = [], [], [], None
         _active = self
         return self
 
@@ -91,12 +152,38 @@ class DeferredLosses:
     def add(self, loss):
         self.losses.append(loss)
 
+    def new_record(self, B, device):
+        """A SiteRecord (with its loss-scalar row) when this site can join the batched launches, else None."""
+        if not self.batch or not (64 < B <= L.MAX_BATCH) or len(self.records) >= self._CHUNK:
+            return None
+        if self._scal_all is None:
+            self._scal_all = torch.empty(self._CHUNK, 4, dtype=torch.float32, device=device)
+        rec = SiteRecord()
+        rec.scal = self._scal_all[len(self.records)]
+        self.records.append(rec)
+        return rec
+
+    def add_record_loss(self, loss):
+        self._rec_losses.append(loss)
+
+    def groups(self):
+        g = {}
+        for r in self.records:
+            g.setdefault((r.B, r.dim, r.mu, r.rho), []).append(r)
+        return g
+
     def total(self):
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
-        if not self.losses:
+        parts = []
+        if self.records:
+            assert len(self._rec_losses) == len(self.records)
+            parts.append(LossSumFn.apply(self, self._scal_all, *self._rec_losses))
+        if self.losses:
+            parts.append(torch.stack(self.losses).sum())
+        if not parts:
             return None
-        return torch.stack(self.losses).sum()
+        return parts[0] if len(parts) == 1 else parts[0] + parts[1]
 
 
 _active = None
@@ -117,7 +204,7 @@ class BNSiteFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, bn_weight, bn_bias, running_mean, running_var, nbt, momentum, bn_eps, alterD, gamma, k, act_range,
-                eps, mu, rho, relu):
+                eps, mu, rho, relu, rec=None):
         z = L.dev_f32(z, "conv output")
         A = L.dev_f32(alterD, "alterD")
         Gm = L.dev_f32(gamma, "gamma")
@@ -134,14 +221,19 @@ class BNSiteFn(torch.autograd.Function):
         y = torch.empty_like(z)
         D = torch.empty(B, B, dtype=torch.float32, device=dev)
         stats = torch.empty(4, F, dtype=torch.float32, device=dev)
-        scal = torch.empty(4, dtype=torch.float32, device=dev)
+        scal = rec.scal if rec is not None else torch.empty(4, dtype=torch.float32, device=dev)
         ws = torch.empty(lib.alignq_site_ws_bytes(B, F), dtype=torch.uint8, device=dev)
         L.check(lib.alignq_site_partials_bn(L.ptr(z), L.ptr(ws_bn), L.ptr(bn_weight), L.ptr(bn_bias), L.ptr(running_mean),
                                             L.ptr(running_var), L.ptr(nbt), float(momentum), float(bn_eps), L.ptr(ab),
                                             L.ptr(save), C, HW, B, F, int(k), float(act_range), float(eps), int(bool(relu)),
                                             L.ptr(y), L.ptr(stats), L.ptr(ws), st), "alignq_site_partials_bn")
-        L.check(lib.alignq_site_reduce_loss(L.ptr(ws), B, F, L.ptr(D), L.ptr(A), L.ptr(Gm), dim, float(mu), float(rho),
-                                            L.ptr(scal), st), "alignq_site_reduce_loss")
+        if rec is not None:      # reduced with all other sites in DeferredLosses.total()
+            rec.ws, rec.D, rec.A, rec.Gm, rec.B, rec.F, rec.dim = ws, D, A, Gm, B, F, dim
+            rec.mu, rec.rho = float(mu), float(rho)
+        else:
+            L.check(lib.alignq_site_reduce_loss(L.ptr(ws), B, F, L.ptr(D), L.ptr(A), L.ptr(Gm), dim, float(mu),
+                                                float(rho), L.ptr(scal), st), "alignq_site_reduce_loss")
+        ctx.rec = rec
         ctx.save_for_backward(z, ab, save, stats, D, A, Gm, scal, y if relu else None)
         ctx.set_materialize_grads(False)
         ctx.cfg = (float(act_range), float(eps), float(mu), bn_weight is not None, bn_bias is not None)
@@ -162,10 +254,15 @@ class BNSiteFn(torch.autograd.Function):
         if g_loss is None:
             g_loss = torch.zeros((), dtype=torch.float32, device=dev)
         g_loss = L.dev_f32(g_loss, "loss grad")
-        S = torch.empty(B, B, dtype=torch.float32, device=dev)
-        dA, dG = torch.empty_like(A), torch.empty_like(Gm)
-        L.check(lib.alignq_site_prep_fused(L.ptr(D), L.ptr(A), L.ptr(Gm), dim, L.ptr(scal), mu, L.ptr(g_loss), B, F,
-                                           L.ptr(S), L.ptr(dA), L.ptr(dG), st), "alignq_site_prep_fused")
+        rec = ctx.rec
+        if rec is not None and rec.prepared:
+            S, dA, dG = rec.S, rec.dA, rec.dG
+            rec.S = rec.dA = rec.dG = None       # sole owner: AccumulateGrad takes dA/dG without a copy
+        else:
+            S = torch.empty(B, B, dtype=torch.float32, device=dev)
+            dA, dG = torch.empty_like(A), torch.empty_like(Gm)
+            L.check(lib.alignq_site_prep_fused(L.ptr(D), L.ptr(A), L.ptr(Gm), dim, L.ptr(scal), mu, L.ptr(g_loss), B, F,
+                                               L.ptr(S), L.ptr(dA), L.ptr(dG), st), "alignq_site_prep_fused")
         dx = torch.empty_like(z)
         part = torch.empty(lib.alignq_site_bn_part_bytes(F), dtype=torch.uint8, device=dev)
         L.check(lib.alignq_site_bwd_apply_bn(L.ptr(g_y), L.ptr(S), L.ptr(z), L.ptr(ab), L.ptr(save), C, HW, L.ptr(y),
@@ -176,7 +273,7 @@ class BNSiteFn(torch.autograd.Function):
         dbet = torch.empty(C, dtype=torch.float32, device=dev) if has_b else None
         L.check(lib.alignq_bn_bwd_apply(L.ptr(dx), L.ptr(z), L.ptr(ab), L.ptr(save), L.ptr(part), B, C, HW, L.ptr(dz),
                                         L.ptr(dgam), L.ptr(dbet), st), "alignq_bn_bwd_apply")
-        return (dz, dgam, dbet, None, None, None, None, None, dA, dG, None, None, None, None, None, None)
+        return (dz, dgam, dbet, None, None, None, None, None, dA, dG, None, None, None, None, None, None, None)
 
 
 def bn_site_fusable(bn, act, z) -> bool:
@@ -199,12 +296,16 @@ def bn_site(bn, act, z, eps=0.0, relu=False):
         out, loss = act(bn(z))
         return (torch.nn.functional.relu(out) if relu else out), loss
     admm = act.opt
+    deferred = active_deferred()
+    rec = deferred.new_record(z.shape[0], z.device) if deferred is not None else None
     y, loss, D = BNSiteFn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
                                 bn.momentum, bn.eps, admm.alterD, admm.gamma, act.a_bit, config.args.act_range, eps,
-                                admm.mu, admm.rho, relu)
+                                admm.mu, admm.rho, relu, rec)
     admm.D = D
-    deferred = active_deferred()
     if deferred is not None:
-        deferred.add(loss)
+        if rec is not None:
+            deferred.add_record_loss(loss)
+        else:
+            deferred.add(loss)
         return y, 0.0
     return y, loss

@@ -184,11 +184,13 @@ class SiteFn(torch.autograd.Function):
     gradient prep; fused standardisation-backward + MFMA kernel).  D is returned for ADMM_OPT.step (values only)."""
 
     @staticmethod
-    def forward(ctx, x, alterD, gamma, k, act_range, eps, mu, rho, side=None, bufs=None):
+    def forward(ctx, x, alterD, gamma, k, act_range, eps, mu, rho, side=None, bufs=None, rec=None):
         """side: optional torch.cuda.Stream for the slab reduction + loss (it is off the critical path of the
         network's forward: only x_q feeds the next layer); the CALLER must make the consuming stream wait for it.
         bufs: optional dict of persistent per-site buffers (ws, D, scal) — required with `side` so that no
-        allocator block is recycled under in-flight side-stream work."""
+        allocator block is recycled under in-flight side-stream work.
+        rec: optional fused.SiteRecord — the slab reduction + loss (and the backward's prep) are then launched for all
+        sites at once by fused.DeferredLosses.total(); until then D and the loss hold no value."""
         x = L.dense_f32(x, "activation")
         A = L.dev_f32(alterD, "alterD")
         Gm = L.dev_f32(gamma, "gamma")
@@ -205,7 +207,7 @@ class SiteFn(torch.autograd.Function):
             ws, D, scal = bufs["ws"], bufs["D"], bufs["scal"]
         else:
             D = torch.empty(B, B, dtype=torch.float32, device=dev)
-            scal = torch.empty(4, dtype=torch.float32, device=dev)
+            scal = rec.scal if rec is not None else torch.empty(4, dtype=torch.float32, device=dev)
             ws = _ws(lib.alignq_site_ws_bytes(B, F), dev)
             if bufs is not None:
                 bufs.update(key=key, ws=ws, D=D, scal=scal)
@@ -215,9 +217,14 @@ class SiteFn(torch.autograd.Function):
         if side is not None and bufs is not None:
             side.wait_stream(torch.cuda.current_stream())
             st = side.cuda_stream
-        L.check(lib.alignq_site_reduce_loss(L.ptr(ws), B, F, L.ptr(D), L.ptr(A), L.ptr(Gm), dim, float(mu),
-                                            float(rho), L.ptr(scal), st), "alignq_site_reduce_loss")
+        if rec is not None:
+            rec.ws, rec.D, rec.A, rec.Gm, rec.B, rec.F, rec.dim = ws, D, A, Gm, B, F, dim
+            rec.mu, rec.rho = float(mu), float(rho)
+        else:
+            L.check(lib.alignq_site_reduce_loss(L.ptr(ws), B, F, L.ptr(D), L.ptr(A), L.ptr(Gm), dim, float(mu),
+                                                float(rho), L.ptr(scal), st), "alignq_site_reduce_loss")
         loss = scal[0]
+        ctx.rec = rec
         ctx.save_for_backward(x, stats, D, A, Gm, scal)
         ctx.set_materialize_grads(False)     # no zero-filled [B,B] gradient for the non-differentiable D
         ctx.cfg = (float(act_range), float(eps), float(mu))
@@ -236,9 +243,15 @@ class SiteFn(torch.autograd.Function):
         g_loss = L.dev_f32(g_loss, "loss grad")
         lib = L.load()
         dx = torch.empty_like(x)
+        rec = ctx.rec
+        if rec is not None and rec.prepared:
+            L.check(lib.alignq_site_bwd_apply(L.ptr(g_xq), L.ptr(rec.S), L.ptr(x), L.ptr(stats), B, F, act_range, eps,
+                                              L.ptr(dx), L.stream_ptr()), "alignq_site_bwd_apply")
+            dA, dG, rec.dA, rec.dG = rec.dA, rec.dG, None, None     # sole owner: AccumulateGrad takes them without a copy
+            return dx, dA, dG, None, None, None, None, None, None, None, None
         dA, dG = torch.empty_like(A), torch.empty_like(Gm)
         ws = _ws(lib.alignq_site_bwd_ws_bytes(B), x.device)
         L.check(lib.alignq_site_bwd_fused(L.ptr(g_xq), L.ptr(D), L.ptr(A), L.ptr(Gm), dim, L.ptr(scal), mu,
                                           L.ptr(g_loss), L.ptr(x), L.ptr(stats), B, F, act_range, eps, L.ptr(dx),
                                           L.ptr(dA), L.ptr(dG), L.ptr(ws), L.stream_ptr()), "alignq_site_bwd_fused")
-        return dx, dA, dG, None, None, None, None, None, None, None
+        return dx, dA, dG, None, None, None, None, None, None, None, None

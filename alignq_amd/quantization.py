@@ -109,10 +109,11 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
                     if not hasattr(mod, "_site_bufs"):
                         mod._site_bufs = {}
                     bufs = mod._site_bufs
+                rec = deferred.new_record(x.shape[0], x.device)
                 xq, loss, D = ops.SiteFn.apply(x, admm.alterD, admm.gamma, a_bit, config.args.act_range, eps,
-                                               admm.mu, admm.rho, deferred.side, bufs)
+                                               admm.mu, admm.rho, deferred.side, bufs, rec)
                 admm.D = D
-                deferred.add(loss)
+                (deferred.add_record_loss if rec is not None else deferred.add)(loss)
                 return xq, 0.0          # the real loss is summed once by DeferredLosses.total()
             xq, loss, D = ops.SiteFn.apply(x, admm.alterD, admm.gamma, a_bit, config.args.act_range, eps,
                                            admm.mu, admm.rho)

@@ -164,6 +164,18 @@ int alignq_sgd_step_multi(int T, float* const* p, float* const* g, float* const*
                           float mom, float damp, float wd, int nesterov, int bitW, float lam, float lam2,
                           void* stream);
 
+/* ---- all ADMM sites of a model in one launch each (64 < B <= 128): the slab reduction + loss of every site is off the
+ * network's critical path (only x_q feeds the next layer), so a whole-model step can defer them to the end of the forward;
+ * likewise ONE prep launch at the start of the backward.  Arrays are HOST arrays of S entries (passed by value to the
+ * kernels in chunks of 32); per-site semantics are those of alignq_site_reduce_loss / alignq_site_prep_fused.          */
+int alignq_site_reduce_loss_multi(int S, void* const* ws, float* const* D, const float* const* alterD,
+                                  const float* const* gamma, float* const* scal, const int64_t* F, int B, int dim,
+                                  float mu, float rho, void* stream);
+int alignq_site_prep_fused_multi(int S, const float* const* D, const float* const* alterD, const float* const* gamma,
+                                 const float* const* scal, const float* dD_scale, const int64_t* F, int B, int dim,
+                                 float mu, float* const* S_out, float* const* dalterD, float* const* dgamma,
+                                 void* stream);
+
 /* ---- batch-norm (and the ReLU that follows) folded into the ADMM site (caller:
  * out, loss = act_q(bn(conv(x))); out = relu(out), cdf_alignment_admm/resnet-56-cifar-10/model/resnet.py:87-94) ----
  * Training-mode nn.BatchNorm2d semantics.  z = conv output [B,C,HW] (HW % 64 == 0, 64 < B <= 128 for the folded site

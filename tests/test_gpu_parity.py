@@ -529,3 +529,53 @@ def test_bn_folded_site_matches_unfused(dev, B, C, H, W, k, relu):
     np.testing.assert_allclose(f["dw"], u["dw"], atol=2e-4, rtol=1e-3)
     np.testing.assert_allclose(f["db"], u["db"], atol=2e-4, rtol=1e-3)
     config.args.bitW = config.args.abitW = 8
+
+
+@pytest.mark.parametrize("B", [128, 100])
+def test_batched_deferred_sites_match_per_site_launches(dev, B):
+    """fused.DeferredLosses(batch=True): one alignq_site_reduce_loss_multi / alignq_site_prep_fused_multi launch for all
+    sites of a step must give bit-identical D, x_q and gradients to the per-site launches (same kernel bodies), and the
+    same loss sum up to the order of one fp32 sum.  Mixed plain (SiteFn) and BN-folded (BNSiteFn) sites, different F,
+    upstream loss scale != 1."""
+    import alignq_amd.cdf_alignment_admm as A
+    from alignq_amd import config
+    from alignq_amd.fused import DeferredLosses, bn_site
+    config.args.bitW = config.args.abitW = 8
+    shapes = [(16, 32, 32), (32, 16, 16), (64, 8, 8), (3, 8, 8)]
+    torch.manual_seed(5)
+    zs = [torch.randn(B, *s, device=dev) * 1.3 + 0.1 for s in shapes]
+    gqs = [torch.randn(B, *s, device=dev) * 0.01 for s in shapes]
+    res = []
+    for batch in (False, True):
+        torch.manual_seed(2)
+        admms = [A.ADMM(128).to(dev) for _ in shapes]
+        for a in admms:
+            with torch.no_grad():
+                a.alterD.copy_(torch.randn(128, 128, device=dev) * 0.05)
+                a.gamma.copy_(torch.randn(128, 128, device=dev) * 0.05)
+        acts = [A.activation_quantize_fn(8, "second", a) for a in admms]
+        bns = [torch.nn.BatchNorm2d(s[0]).to(dev).train() for s in shapes]
+        xs = [z.clone().requires_grad_(True) for z in zs]
+        d = DeferredLosses(batch=batch)
+        with d:
+            outs = []
+            for i, (x, act, bn) in enumerate(zip(xs, acts, bns)):
+                if i % 2 == 0:
+                    xq, l = act(x)
+                else:
+                    xq, l = bn_site(bn, act, x, relu=(i == 1))
+                assert l == 0.0
+                outs.append(xq)
+            total = d.total()
+        assert len(d.records) == (len(shapes) if batch else 0)
+        obj = 0.7 * total + sum((o * g).sum() for o, g in zip(outs, gqs))
+        obj.backward()
+        res.append(dict(total=float(total.detach()), xq=[npy(o) for o in outs], D=[npy(a.D) for a in admms],
+                        dx=[npy(x.grad) for x in xs], dA=[npy(a.alterD.grad) for a in admms],
+                        dG=[npy(a.gamma.grad) for a in admms],
+                        dw=[npy(bn.weight.grad) for i, bn in enumerate(bns) if i % 2 == 1]))
+    u, b = res
+    np.testing.assert_allclose(b["total"], u["total"], rtol=1e-6)
+    for key in ("xq", "D", "dx", "dA", "dG", "dw"):
+        for x, y in zip(u[key], b[key]):
+            assert np.array_equal(x, y), key
