@@ -203,6 +203,17 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
         }
       }
     }
+    // fused residual add: loads issued here and consumed after the erf work below; the 64-feature tile has no registers
+    // to spare (128-VGPR budget at 1024 threads) and loads row by row inside the loop instead
+    constexpr bool kEarlyRes = TFv < 64;
+    float4 rv[RJ];
+    if (PAIR && kEarlyRes && bn.res) {
+#pragma unroll
+      for (int j = 0; j < RJ; j++) {
+        const int row = rg + RG * j;
+        rv[j] = ld4(bn.res, (int64_t)row * F + col, col, F, row < B, aligned);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < RJ; j++) {
       const int row = rg + RG * j;
@@ -210,12 +221,17 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
       const int64_t off = (int64_t)row * F + col;
       tv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (PAIR) {
-        float4 q;
+        float4 q, rl = make_float4(0.f, 0.f, 0.f, 0.f);
         float b;
+        if (!kEarlyRes && bn.res) rl = ld4(bn.res, off, col, F, ok, aligned);
         q.x = act_quant1<0>(xv[j].x, k, nlev, r, &tv[j].x, &b);
         q.y = act_quant1<0>(xv[j].y, k, nlev, r, &tv[j].y, &b);
         q.z = act_quant1<0>(xv[j].z, k, nlev, r, &tv[j].z, &b);
         q.w = act_quant1<0>(xv[j].w, k, nlev, r, &tv[j].w, &b);
+        if (bn.res) {
+          const float4 rr = kEarlyRes ? rv[j] : rl;
+          q.x += rr.x; q.y += rr.y; q.z += rr.z; q.w += rr.w;
+        }
         if (bn.relu) { q.x = fmaxf(q.x, 0.f); q.y = fmaxf(q.y, 0.f); q.z = fmaxf(q.z, 0.f); q.w = fmaxf(q.w, 0.f); }
         if (xq) st4(xq, off, col, F, ok, aligned, q);
       }
@@ -677,35 +693,6 @@ __global__ __launch_bounds__(NTB) void site_bwd4_kernel(const float* __restrict_
   const int cc = cj * 32 + l31;            // this lane's feature column inside the tile (accumulator layout)
   const int lcol = lane, lrow0 = w * 16;   // load mapping: one feature column, 16 consecutive batch rows
 
-  // S fragments (already scaled, symmetric): A[i][k], i = I*32 + l31, k = 16*ks + 8h + jj, split into bf16 hi/lo
-  bf16x8 sh[8], sl[8];
-  {
-    const int i = I * 32 + l31;
-    const bool vec = ((B & 7) == 0) && ((reinterpret_cast<uintptr_t>(S) & 15) == 0);
-#pragma unroll
-    for (int ks = 0; ks < 8; ks++) {
-      const int kk0 = 16 * ks + 8 * h;
-      float v[8];
-      if (vec) {                              // 8 consecutive j of row i: two 16-byte loads
-        float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = a4;
-        if (i < B && kk0 < B) {
-          a4 = *reinterpret_cast<const float4*>(S + i * B + kk0);
-          b4 = *reinterpret_cast<const float4*>(S + i * B + kk0 + 4);
-        }
-        v[0] = a4.x; v[1] = a4.y; v[2] = a4.z; v[3] = a4.w; v[4] = b4.x; v[5] = b4.y; v[6] = b4.z; v[7] = b4.w;
-      } else {
-#pragma unroll
-        for (int jj = 0; jj < 8; jj++) v[jj] = (i < B && kk0 + jj < B) ? S[i * B + kk0 + jj] : 0.0f;
-      }
-#pragma unroll
-      for (int jj = 0; jj < 8; jj++) {
-        __bf16 a, b2;
-        split_bf16(v[jj], a, b2);
-        sh[ks][jj] = a;
-        sl[ks][jj] = b2;
-      }
-    }
-  }
   const float invB = 1.0f / (float)B, invBm1 = 1.0f / (float)(B - 1);
   STAMP(10);
 
@@ -730,6 +717,13 @@ __global__ __launch_bounds__(NTB) void site_bwd4_kernel(const float* __restrict_
         if (BN && ok) xr[q] = __fmaf_rn(bn_a, xr[q], bn_b);
         gr[q] = (PAIR && gup && ok) ? gup[off] : 0.0f;
         if (BN && bn.y && ok) gr[q] = (bn.y[off] > 0.0f) ? gr[q] : 0.0f;     // fused ReLU backward
+      }
+      if (BN && bn.dres && lcol_ok) {         // the masked gradient is also the residual branch's gradient
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+          const int row = lrow0 + q;
+          if (row < B) bn.dres[(int64_t)row * F + col0 + lcol] = gr[q];
+        }
       }
 #pragma unroll
       for (int half = 0; half < 2; half++) {
@@ -757,6 +751,36 @@ __global__ __launch_bounds__(NTB) void site_bwd4_kernel(const float* __restrict_
         if (PAIR) {
           *reinterpret_cast<bf16x8*>(TThi + o) = th;
           *reinterpret_cast<bf16x8*>(TTlo + o) = tl;
+        }
+      }
+    }
+    // S fragments (already scaled, symmetric): A[i][k], i = I*32 + l31, k = 16*ks + 8h + jj, split into bf16 hi/lo.
+    // Loaded here, after the load phase's registers are dead (a workgroup normally owns ONE tile: grid == n_tiles)
+    bf16x8 sh[8], sl[8];
+    {
+      const int i = I * 32 + l31;
+      const bool vec = ((B & 7) == 0) && ((reinterpret_cast<uintptr_t>(S) & 15) == 0);
+  #pragma unroll
+      for (int ks = 0; ks < 8; ks++) {
+        const int kk0 = 16 * ks + 8 * h;
+        float v[8];
+        if (vec) {                              // 8 consecutive j of row i: two 16-byte loads
+          float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = a4;
+          if (i < B && kk0 < B) {
+            a4 = *reinterpret_cast<const float4*>(S + i * B + kk0);
+            b4 = *reinterpret_cast<const float4*>(S + i * B + kk0 + 4);
+          }
+          v[0] = a4.x; v[1] = a4.y; v[2] = a4.z; v[3] = a4.w; v[4] = b4.x; v[5] = b4.y; v[6] = b4.z; v[7] = b4.w;
+        } else {
+  #pragma unroll
+          for (int jj = 0; jj < 8; jj++) v[jj] = (i < B && kk0 + jj < B) ? S[i * B + kk0 + jj] : 0.0f;
+        }
+  #pragma unroll
+        for (int jj = 0; jj < 8; jj++) {
+          __bf16 a, b2;
+          split_bf16(v[jj], a, b2);
+          sh[ks][jj] = a;
+          sl[ks][jj] = b2;
         }
       }
     }

@@ -28,10 +28,13 @@ struct BnFold {
   float* running_var;
   long long* nbt;
   float momentum, bn_eps;
-  int relu;             // forward: store relu(x_q)
+  int relu;             // forward: store relu(x_q [+ res])
+  const float* res;     // forward: optional residual (shortcut) added to x_q before the ReLU, same [B,F] layout
+  float* dres;          // backward: optional output, the upstream gradient after the ReLU mask (= gradient of `res`)
 };
 inline BnFold no_bn() {
-  return BnFold{nullptr, nullptr, 1, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0};
+  return BnFold{nullptr, nullptr, 1, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0,
+                nullptr, nullptr};
 }
 
 struct Geom {

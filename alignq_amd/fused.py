@@ -204,8 +204,12 @@ class BNSiteFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, bn_weight, bn_bias, running_mean, running_var, nbt, momentum, bn_eps, alterD, gamma, k, act_range,
-                eps, mu, rho, relu, rec=None):
+                eps, mu, rho, relu, rec=None, res=None):
         z = L.dev_f32(z, "conv output")
+        if res is not None:
+            res = L.dev_f32(res, "residual")
+            if res.shape != z.shape or not res.is_contiguous():
+                raise RuntimeError("residual must be a contiguous tensor of the conv output's shape")
         A = L.dev_f32(alterD, "alterD")
         Gm = L.dev_f32(gamma, "gamma")
         B, C, H, W = z.shape
@@ -226,7 +230,7 @@ class BNSiteFn(torch.autograd.Function):
         L.check(lib.alignq_site_partials_bn(L.ptr(z), L.ptr(ws_bn), L.ptr(bn_weight), L.ptr(bn_bias), L.ptr(running_mean),
                                             L.ptr(running_var), L.ptr(nbt), float(momentum), float(bn_eps), L.ptr(ab),
                                             L.ptr(save), C, HW, B, F, int(k), float(act_range), float(eps), int(bool(relu)),
-                                            L.ptr(y), L.ptr(stats), L.ptr(ws), st), "alignq_site_partials_bn")
+                                            L.ptr(res), L.ptr(y), L.ptr(stats), L.ptr(ws), st), "alignq_site_partials_bn")
         if rec is not None:      # reduced with all other sites in DeferredLosses.total()
             rec.ws, rec.D, rec.A, rec.Gm, rec.B, rec.F, rec.dim = ws, D, A, Gm, B, F, dim
             rec.mu, rec.rho = float(mu), float(rho)
@@ -236,14 +240,14 @@ class BNSiteFn(torch.autograd.Function):
         ctx.rec = rec
         ctx.save_for_backward(z, ab, save, stats, D, A, Gm, scal, y if relu else None)
         ctx.set_materialize_grads(False)
-        ctx.cfg = (float(act_range), float(eps), float(mu), bn_weight is not None, bn_bias is not None)
+        ctx.cfg = (float(act_range), float(eps), float(mu), bn_weight is not None, bn_bias is not None, res is not None)
         ctx.mark_non_differentiable(D)
         return y, scal[0], D
 
     @staticmethod
     def backward(ctx, g_y, g_loss, _gD):
         z, ab, save, stats, D, A, Gm, scal, y = ctx.saved_tensors
-        act_range, eps, mu, has_w, has_b = ctx.cfg
+        act_range, eps, mu, has_w, has_b, has_res = ctx.cfg
         B, C, H, W = z.shape
         HW, F = H * W, C * H * W
         dim = A.shape[0]
@@ -265,15 +269,20 @@ class BNSiteFn(torch.autograd.Function):
                                                L.ptr(S), L.ptr(dA), L.ptr(dG), st), "alignq_site_prep_fused")
         dx = torch.empty_like(z)
         part = torch.empty(lib.alignq_site_bn_part_bytes(F), dtype=torch.uint8, device=dev)
+        # gradient of the residual: the upstream gradient, ReLU-masked by the kernel when the ReLU was fused
+        dres = None
+        if has_res and g_y is not None:
+            dres = torch.empty_like(z) if y is not None else g_y
         L.check(lib.alignq_site_bwd_apply_bn(L.ptr(g_y), L.ptr(S), L.ptr(z), L.ptr(ab), L.ptr(save), C, HW, L.ptr(y),
-                                             L.ptr(stats), B, F, act_range, eps, L.ptr(dx), L.ptr(part), st),
+                                             L.ptr(dres) if y is not None else None, L.ptr(stats), B, F, act_range, eps,
+                                             L.ptr(dx), L.ptr(part), st),
                 "alignq_site_bwd_apply_bn")
         dz = torch.empty_like(z)
         dgam = torch.empty(C, dtype=torch.float32, device=dev) if has_w else None
         dbet = torch.empty(C, dtype=torch.float32, device=dev) if has_b else None
         L.check(lib.alignq_bn_bwd_apply(L.ptr(dx), L.ptr(z), L.ptr(ab), L.ptr(save), L.ptr(part), B, C, HW, L.ptr(dz),
                                         L.ptr(dgam), L.ptr(dbet), st), "alignq_bn_bwd_apply")
-        return (dz, dgam, dbet, None, None, None, None, None, dA, dG, None, None, None, None, None, None, None)
+        return (dz, dgam, dbet, None, None, None, None, None, dA, dG, None, None, None, None, None, None, None, dres)
 
 
 def bn_site_fusable(bn, act, z) -> bool:
@@ -288,19 +297,22 @@ def bn_site_fusable(bn, act, z) -> bool:
             and config.args.method == "ours" and act.opt.alterD.shape[0] >= B)
 
 
-def bn_site(bn, act, z, eps=0.0, relu=False):
-    """out, loss = act(bn(z)) [; out = relu(out) when relu=True] — folded when `bn_site_fusable`, otherwise exactly that
-    composition."""
+def bn_site(bn, act, z, eps=0.0, relu=False, residual=None):
+    """out, loss = act(bn(z)) [; out = out + residual] [; out = relu(out) when relu=True] — folded into the site kernels
+    when `bn_site_fusable`, otherwise exactly that composition."""
     from . import config
-    if not bn_site_fusable(bn, act, z):
+    if not bn_site_fusable(bn, act, z) or (residual is not None and not (
+            residual.shape == z.shape and residual.is_contiguous() and residual.dtype == torch.float32)):
         out, loss = act(bn(z))
+        if residual is not None:
+            out = out + residual
         return (torch.nn.functional.relu(out) if relu else out), loss
     admm = act.opt
     deferred = active_deferred()
     rec = deferred.new_record(z.shape[0], z.device) if deferred is not None else None
     y, loss, D = BNSiteFn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
                                 bn.momentum, bn.eps, admm.alterD, admm.gamma, act.a_bit, config.args.act_range, eps,
-                                admm.mu, admm.rho, relu, rec)
+                                admm.mu, admm.rho, relu, rec, residual)
     admm.D = D
     if deferred is not None:
         if rec is not None:

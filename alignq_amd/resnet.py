@@ -57,12 +57,14 @@ class PreActBlock_conv_Q(nn.Module):
             return fn(x)
         return fn(x), 0
 
-    def _bnq(self, bn, fn, z, relu=False):
-        """act(bn(z)) [+ relu]; with fuse_bn both the batch-norm and the ReLU are folded into the site kernels
-        (alignq_amd.fused.bn_site)."""
+    def _bnq(self, bn, fn, z, relu=False, residual=None):
+        """act(bn(z)) [+ residual] [-> relu]; with fuse_bn the batch-norm, the shortcut add and the ReLU are folded into
+        the site kernels (alignq_amd.fused.bn_site)."""
         if self.tree == "admm" and self.fuse_bn:
-            return bn_site(bn, fn, z, relu=relu)
+            return bn_site(bn, fn, z, relu=relu, residual=residual)
         out, loss = self._q(fn, bn(z))
+        if residual is not None:
+            out += residual
         return (F.relu(out) if relu else out), loss
 
     def forward(self, x):
@@ -74,10 +76,8 @@ class PreActBlock_conv_Q(nn.Module):
             shortcut = x
         out, loss = self._bnq(self.bn0, self.act_q0, self.conv0(x), relu=True)
         trans_loss += loss
-        out, loss = self._bnq(self.bn1, self.act_q1, self.conv1(out))
+        out, loss = self._bnq(self.bn1, self.act_q1, self.conv1(out), relu=True, residual=shortcut)   # out += shortcut; relu
         trans_loss += loss
-        out += shortcut
-        out = F.relu(out)
         if self.tree == "admm":
             return out, trans_loss
         return out

@@ -47,7 +47,9 @@ def parse():
     ap.add_argument("--no-fuse-bn", action="store_true", help="keep torch/MIOpen batch-norm instead of folding it into the ADMM-site kernels")
     ap.add_argument("--dp-selftest", action="store_true", help="run the DP path (RCCL all-reduce, two graphs) even at N=1")
     ap.add_argument("--channels-last", action="store_true", help="NHWC activations/weights end to end")
-    ap.add_argument("--miopen-benchmark", action="store_true", help="torch.backends.cudnn.benchmark (MIOpen find)")
+    ap.add_argument("--no-miopen-find", action="store_true",
+                    help="torch.backends.cudnn.benchmark=False: MIOpen's immediate-mode solver choice instead of its find "
+                         "step for the (not ours) convolutions; find is on by default, it is worth ~2%% of a step")
     return ap.parse_args()
 
 
@@ -101,8 +103,8 @@ def measure_kernels(dev, B, k, site_F_counts, hw_of_F, folded=True):
         if folded:
             f_stats = lambda: lib.alignq_bn_partial_stats(p(x), B, C, HW, p(ws_bn), st)
             f_part = lambda: lib.alignq_site_partials_bn(p(x), p(ws_bn), p(gam), p(bet), p(rm), p(rv), p(nbt), 0.1, 1e-5, p(ab),
-                                                         p(save), C, HW, B, F, k, 2.0, 0.0, 1, p(xq), p(stats), p(ws), st)
-            f_bwd = lambda: lib.alignq_site_bwd_apply_bn(p(g), p(S), p(x), p(ab), p(save), C, HW, p(xq), p(stats), B, F, 2.0,
+                                                         p(save), C, HW, B, F, k, 2.0, 0.0, 1, None, p(xq), p(stats), p(ws), st)
+            f_bwd = lambda: lib.alignq_site_bwd_apply_bn(p(g), p(S), p(x), p(ab), p(save), C, HW, p(xq), None, p(stats), B, F, 2.0,
                                                          0.0, p(dx), p(part), st)
             f_bnb = lambda: lib.alignq_bn_bwd_apply(p(dx), p(x), p(ab), p(save), p(part), B, C, HW, p(dz), p(dgam), p(dbet), st)
         else:
@@ -219,7 +221,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback in the product path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    torch.backends.cudnn.benchmark = bool(a.miopen_benchmark)
+    torch.backends.cudnn.benchmark = not a.no_miopen_find
     import torch.distributed as dist
     if world > 1 or a.dp_selftest:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -314,7 +316,8 @@ def main():
                                     f"{a.model} CIFAR-shape 3x32x32, {a.bits}W/{a.bits}A CDF+ADMM full train step "
                                     f"(cdf_alignment_admm/resnet-20-cifar-10), batch {a.batch}/GPU, ")
                                    + f"{'HIP-graph replay' if not a.no_graph else 'eager launches'}"
-                                   + ("" if (office or a.no_fuse_bn) else ", batch-norm folded into the site kernels"),
+                                   + ("" if (office or a.no_fuse_bn) else ", batch-norm folded into the site kernels")
+                                   + ("" if a.no_miopen_find else ", MIOpen find mode for the convolutions"),
                        "global_batch": a.batch * world, "parallelism": f"dp{world}",
                        "final_ce": float(ce.detach()), "final_trans_loss": float(tl.detach()) if tl is not None else None},
         }

@@ -185,10 +185,12 @@ int alignq_site_prep_fused_multi(int S, const float* const* D, const float* cons
  *   from bn_part in-kernel (mean, invstd, a = gamma*invstd, b = beta - mean*a) and applies x = a*z + b on load: the
  *   normalised activation is never materialised.  OUTPUTS besides xq/stats/ws: ab = {a[C], b[C]}, save = {mean[C],
  *   invstd[C]} (for the backward), running_mean / running_var (momentum, unbiased variance) and *num_batches_tracked
- *   (+1) — any of the last three may be NULL.  relu != 0 stores relu(x_q).
+ *   (+1) — any of the last three may be NULL.  residual != NULL adds a [B,F] tensor to x_q (the block's shortcut,
+ *   `out += shortcut`, resnet.py:95-96), relu != 0 then stores relu(.) — the stored tensor is what the next layer reads.
  * alignq_bn_stats: the stand-alone form (statistics + finalisation, two launches) producing the same ab / save.
  * Backward: alignq_site_prep_fused (first launch of alignq_site_bwd_fused alone), then alignq_site_bwd_apply_bn which
- *   writes dx (gradient w.r.t. the BN output; y_relu = the forward's output when relu was fused, else NULL) and per-tile
+ *   writes dx (gradient w.r.t. the BN output; y_relu = the forward's output when relu was fused, else NULL; dresidual
+ *   != NULL additionally receives the ReLU-masked upstream gradient, i.e. the gradient of `residual`) and per-tile
  *   sums dx_part [F/64][2] = {sum dx, sum dx*zhat}, then alignq_bn_bwd_apply: dz, dgamma, dbeta.                    */
 size_t alignq_bn_ws_bytes(int C);
 int alignq_bn_partial_stats(const float* z, int B, int C, int HW, void* ws, void* stream);
@@ -198,14 +200,15 @@ int alignq_bn_stats(const float* z, int B, int C, int HW, const float* gamma, co
 int alignq_site_partials_bn(const float* z, const void* bn_part, const float* bn_gamma, const float* bn_beta,
                             float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
                             float bn_eps, float* ab, float* save, int C, int HW, int B, int64_t F, int k, float act_range,
-                            float eps, int relu, float* xq, float* stats, void* ws, void* stream);
+                            float eps, int relu, const float* residual, float* xq, float* stats, void* ws,
+                            void* stream);
 size_t alignq_site_bn_part_bytes(int64_t F);
 int alignq_site_prep_fused(const float* D, const float* alterD, const float* gamma, int dim, const float* scal, float mu,
                            const float* dD_scale, int B, int64_t F, float* S, float* dalterD, float* dgamma,
                            void* stream);
 int alignq_site_bwd_apply_bn(const float* g, const float* S, const float* z, const float* ab, const float* save, int C,
-                             int HW, const float* y_relu, const float* stats, int B, int64_t F, float act_range,
-                             float eps, float* dx, float* dx_part, void* stream);
+                             int HW, const float* y_relu, float* dresidual, const float* stats, int B, int64_t F,
+                             float act_range, float eps, float* dx, float* dx_part, void* stream);
 int alignq_bn_bwd_apply(const float* dx, const float* z, const float* ab, const float* save, const float* dx_part, int B,
                         int C, int HW, float* dz, float* dgamma, float* dbeta, void* stream);
 

@@ -480,9 +480,9 @@ def test_office_dann_harness_runs_and_matches_eager_under_graph(dev):
         config.args.train_batch_size, config.args.eval_batch_size = 128, 100
 
 
-@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("relu,residual", [(False, False), (True, False), (True, True), (False, True)])
 @pytest.mark.parametrize("B,C,H,W,k", [(128, 16, 32, 32, 8), (128, 64, 8, 8, 4), (100, 32, 16, 16, 8)])
-def test_bn_folded_site_matches_unfused(dev, B, C, H, W, k, relu):
+def test_bn_folded_site_matches_unfused(dev, B, C, H, W, k, relu, residual):
     """fused.bn_site (batch-norm folded into the site kernels, training mode) against act(bn(z)) with torch's BatchNorm2d
     + the unfused site: x_q equal up to tie-zone bin flips (x differs by one fma rounding), D / loss / dz / dgamma / dbeta /
     running statistics within fp32 tolerance."""
@@ -493,9 +493,11 @@ def test_bn_folded_site_matches_unfused(dev, B, C, H, W, k, relu):
     torch.manual_seed(B + C)
     z = (torch.randn(B, C, H, W, device=dev) * 1.7 + 0.3)
     gq = torch.randn(B, C, H, W, device=dev) * 0.01
+    res0 = torch.randn(B, C, H, W, device=dev) * 0.7
     outs = []
     for fused in (False, True):
         torch.manual_seed(1)
+        res = res0.clone().requires_grad_(True) if residual else None
         bn = torch.nn.BatchNorm2d(C).to(dev).train()
         with torch.no_grad():
             bn.weight.copy_(torch.rand(C, device=dev) + 0.5)
@@ -505,15 +507,18 @@ def test_bn_folded_site_matches_unfused(dev, B, C, H, W, k, relu):
         zz = z.clone().requires_grad_(True)
         if fused:
             assert bn_site_fusable(bn, act, zz)
-            xq, loss = bn_site(bn, act, zz, relu=relu)
+            xq, loss = bn_site(bn, act, zz, relu=relu, residual=res)
         else:
             xq, loss = act(bn(zz))
+            if residual:
+                xq = xq + res
             if relu:
                 xq = torch.nn.functional.relu(xq)
         (loss + (xq * gq).sum()).backward()
         outs.append(dict(xq=npy(xq), loss=float(loss.detach()), D=npy(admm.D), dz=npy(zz.grad), dw=npy(bn.weight.grad),
                          db=npy(bn.bias.grad), rm=npy(bn.running_mean), rv=npy(bn.running_var),
-                         nbt=int(bn.num_batches_tracked), dA=npy(admm.alterD.grad)))
+                         nbt=int(bn.num_batches_tracked), dA=npy(admm.alterD.grad),
+                         dres=npy(res.grad) if residual else None))
     u, f = outs
     n = 2 ** k - 1
     flips = np.abs(u["xq"] - f["xq"]) * n
@@ -528,6 +533,8 @@ def test_bn_folded_site_matches_unfused(dev, B, C, H, W, k, relu):
     np.testing.assert_allclose(f["dz"], u["dz"], atol=2e-5, rtol=1e-3)
     np.testing.assert_allclose(f["dw"], u["dw"], atol=2e-4, rtol=1e-3)
     np.testing.assert_allclose(f["db"], u["db"], atol=2e-4, rtol=1e-3)
+    if residual:        # gq masked by relu(x_q + res) > 0: differs only where a flipped bin moves the sum across 0
+        assert (f["dres"] != u["dres"]).mean() < 1e-3
     config.args.bitW = config.args.abitW = 8
 
 
