@@ -36,8 +36,15 @@ __device__ unsigned long long g_stamps[64];
   do {                                                                       \
     if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps[i] = wall_clock64();   \
   } while (0)
+// every workgroup's entry / exit time: [kernel (0 fwd, 1 bwd)][entry, exit][block]
+__device__ unsigned long long g_blk[2][2][2048];
+#define BSTAMP(kern, which)                                                                        \
+  do {                                                                                             \
+    if (threadIdx.x == 0 && blockIdx.x < 2048) g_blk[kern][which][blockIdx.x] = wall_clock64();    \
+  } while (0)
 #else
 #define STAMP(i) do { } while (0)
+#define BSTAMP(kern, which) do { } while (0)
 #endif
 
 __device__ __forceinline__ float4 ld4(const float* __restrict__ x, int64_t off, int col, int64_t F, bool row_ok,
@@ -104,6 +111,7 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
                                                        float eps, float* __restrict__ xq, float* __restrict__ slabs,
                                                        float* __restrict__ stats, int n_tiles, int aligned,
                                                        unsigned* __restrict__ counter, BnFold bn) {
+  BSTAMP(0, 0);
   constexpr int LDB = TFv + 8;                    // bf16 elements per LDS row (row bytes multiple of 16, see bank note)
   constexpr int LPR = TFv / 4;                    // lanes per row (float4 each)
   constexpr int RG = NT / LPR;                    // row groups: 64 / 128 / 256
@@ -440,6 +448,7 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
   const float4* C4 = reinterpret_cast<const float4*>(C);
   for (int e = tid; e < 2560; e += NT) slab4[e] = C4[e];
   STAMP(5);
+  BSTAMP(0, 1);
 }
 
 // ================================================================================================ reduce
@@ -672,6 +681,7 @@ __global__ __launch_bounds__(NTB) void site_bwd4_kernel(const float* __restrict_
                                                         const float* __restrict__ x, const float* __restrict__ stats,
                                                         int B, int64_t F, float r, float eps, float* __restrict__ dx,
                                                         int n_tiles, int aligned, BnFold bn) {
+  BSTAMP(1, 0);
   (void)aligned;
   constexpr int TFv = 64, LDv = 65, TILE = 128 * LDv;
   constexpr int LDT = 128 + 8;                       // bf16 elements per transposed row (272 B: 16-B aligned, 4-bank skew)
@@ -696,9 +706,20 @@ __global__ __launch_bounds__(NTB) void site_bwd4_kernel(const float* __restrict_
   const float invB = 1.0f / (float)B, invBm1 = 1.0f / (float)(B - 1);
   STAMP(10);
 
-  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  const int tile = blockIdx.x;            // one tile per workgroup (grid == n_tiles): no tile loop, nothing to hoist
+  if (tile < n_tiles) {
     const int col0 = tile * TFv;
     const bool lcol_ok = (col0 + lcol) < F;
+    // Addressing: kernel-argument base (SGPR pair) + one 32-bit byte offset per element, shared by x / g / y / dx /
+    // dres (global_load saddr+voffset form; the launcher guarantees B*F*4 < 2^32).  Loads use offsets CLAMPED into the
+    // tensor and are unconditional (a conditional load costs a branch each); out-of-range lanes are zeroed afterwards.
+    const unsigned rowB = (unsigned)F * 4u;
+    const unsigned colc = (unsigned)(lcol_ok ? col0 + lcol : (int)F - 1) * 4u;
+    unsigned boff[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) boff[q] = (unsigned)min(lrow0 + q, B - 1) * rowB + colc;
+#define AT(ptr, q) (*reinterpret_cast<const float*>(reinterpret_cast<const char*>(ptr) + boff[q]))
+#define ATW(ptr, q) (*reinterpret_cast<float*>(reinterpret_cast<char*>(ptr) + boff[q]))
     // ---- load x (and g) for (feature lcol, rows lrow0..+15), recompute t / jac, standardise ---------------
     {
       const float mx = lcol_ok ? stats[col0 + lcol] : 0.f;
@@ -709,20 +730,39 @@ __global__ __launch_bounds__(NTB) void site_bwd4_kernel(const float* __restrict_
       if (BN && lcol_ok) { const int ch = (col0 + lcol) / bn.HW; bn_a = bn.ab[ch]; bn_b = bn.ab[bn.C + ch]; }
       float xr[16], gr[16];
 #pragma unroll
-      for (int q = 0; q < 16; q++) {          // all 32 loads in flight before the first use
-        const int row = lrow0 + q;
-        const bool ok = lcol_ok && row < B;
-        const int64_t off = (int64_t)row * F + col0 + lcol;
-        xr[q] = ok ? x[off] : 0.0f;
-        if (BN && ok) xr[q] = __fmaf_rn(bn_a, xr[q], bn_b);
-        gr[q] = (PAIR && gup && ok) ? gup[off] : 0.0f;
-        if (BN && bn.y && ok) gr[q] = (bn.y[off] > 0.0f) ? gr[q] : 0.0f;     // fused ReLU backward
+      for (int q = 0; q < 16; q++) xr[q] = AT(x, q);          // all loads in flight before the first use
+      const bool has_g = PAIR && gup != nullptr;
+      if (has_g) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) gr[q] = AT(gup, q);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 16; q++) gr[q] = 0.0f;
+      }
+      if (BN) {      // separate loops: a use inside a load loop would serialise the loads on their latency
+        float yr[16];
+        const bool masked = bn.y != nullptr;
+        if (masked) {
+#pragma unroll
+          for (int q = 0; q < 16; q++) yr[q] = AT(bn.y, q);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+          xr[q] = __fmaf_rn(bn_a, xr[q], bn_b);
+          if (masked) gr[q] = (yr[q] > 0.0f) ? gr[q] : 0.0f;     // fused ReLU backward
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        const bool ok = lcol_ok && (lrow0 + q) < B;
+        xr[q] = ok ? xr[q] : 0.0f;
+        gr[q] = ok ? gr[q] : 0.0f;
       }
       if (BN && bn.dres && lcol_ok) {         // the masked gradient is also the residual branch's gradient
 #pragma unroll
         for (int q = 0; q < 16; q++) {
           const int row = lrow0 + q;
-          if (row < B) bn.dres[(int64_t)row * F + col0 + lcol] = gr[q];
+          if (row < B) ATW(bn.dres, q) = gr[q];
         }
       }
 #pragma unroll
@@ -754,6 +794,7 @@ __global__ __launch_bounds__(NTB) void site_bwd4_kernel(const float* __restrict_
         }
       }
     }
+    __builtin_amdgcn_sched_barrier(0);   // keep the 16 fragment loads below out of the register-hungry load phase
     // S fragments (already scaled, symmetric): A[i][k], i = I*32 + l31, k = 16*ks + 8h + jj, split into bf16 hi/lo.
     // Loaded here, after the load phase's registers are dead (a workgroup normally owns ONE tile: grid == n_tiles)
     bf16x8 sh[8], sl[8];
@@ -807,6 +848,18 @@ __global__ __launch_bounds__(NTB) void site_bwd4_kernel(const float* __restrict_
       }
     }
     STAMP(12);
+    // folded batch-norm backward needs zhat of the elements this thread copies out below (the ones it loaded above):
+    // re-issue those 16 loads now (L2 hits), while no other large register array is live, so that their latency
+    // overlaps the projection / assemble phases
+    float zr[16];
+    if (BN) {
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        const int row = lrow0 + q;
+        (void)row;
+        zr[q] = AT(x, q);                      // clamped offset; out-of-range elements are not used below
+      }
+    }
     // ---- projections over this wave's 32 batch rows: sum dVh, sum dVh*Vh.  Vh of this lane's accumulator cells
     //      (rows (e&3)+8(e>>2)+4h of block I, column cc) are 4 consecutive entries of the transposed row: 8-byte reads
     {
@@ -900,15 +953,14 @@ __global__ __launch_bounds__(NTB) void site_bwd4_kernel(const float* __restrict_
     if (lcol_ok) {
       float bmu = 0.f, bis = 0.f;
       if (BN) { const int ch = (col0 + lcol) / bn.HW; bmu = bn.save[ch]; bis = bn.save[bn.C + ch]; }
-#pragma unroll 4
+#pragma unroll
       for (int q = 0; q < 16; q++) {
         const int row = lrow0 + q;
         if (row < B) {
-          const int64_t off = (int64_t)row * F + col0 + lcol;
           const float o = Os[row * LDv + lcol];
-          dx[off] = o;
+          ATW(dx, q) = o;
           if (BN) {
-            const float zh = (x[off] - bmu) * bis;     // x is the conv output z here (L2-resident: this tile just read it)
+            const float zh = (zr[q] - bmu) * bis;      // x is the conv output z here
             bp0 += o;
             bp1 += o * zh;
           }
@@ -929,7 +981,10 @@ __global__ __launch_bounds__(NTB) void site_bwd4_kernel(const float* __restrict_
       bn.dx_part[2 * tile + 1] = t1;
     }
     STAMP(15);
+#undef AT
+#undef ATW
   }
+  BSTAMP(1, 1);
 }
 
 #define RET_ON_ERR()                                  \
@@ -1022,10 +1077,10 @@ int launch_prep_multi(int S, const float* const* D, const float* const* alterD, 
 int launch_bwd4(bool pair, const Geom& g, const float* gup, const float* S, const float* x, const float* stats, int B,
                 int64_t F, float r, float eps, float* dx, hipStream_t st, BnFold bn) {
   (void)g;
+  if ((int64_t)B * F * 4 >= ((int64_t)1 << 32)) return ALIGNQ_EUNSUPPORTED;   // 32-bit byte offsets inside a tile column
   const int n_tiles = (int)((F + 63) / 64);
-  const int grid = n_tiles < 2048 ? n_tiles : 2048;
-  const int aligned = ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
-                      ((reinterpret_cast<uintptr_t>(dx) & 15) == 0) && (!gup || (reinterpret_cast<uintptr_t>(gup) & 15) == 0);
+  const int grid = n_tiles;               // one 64-feature tile per workgroup
+  const int aligned = 0;
   if (pair && bn.ab) hipLaunchKernelGGL((site_bwd4_kernel<true, true>), grid, NTB, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_tiles, aligned, bn);
   else if (pair) hipLaunchKernelGGL((site_bwd4_kernel<true, false>), grid, NTB, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_tiles, aligned, bn);
   else hipLaunchKernelGGL((site_bwd4_kernel<false, false>), grid, NTB, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_tiles, aligned, bn);
@@ -1036,6 +1091,9 @@ int launch_bwd4(bool pair, const Geom& g, const float* gup, const float* S, cons
 #ifdef ALIGNQ_STAMPS
 extern "C" int alignq_debug_read_stamps(unsigned long long* host_out) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64);
+}
+extern "C" int alignq_debug_read_block_stamps(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_blk), sizeof(unsigned long long) * 2 * 2 * 2048);
 }
 #endif
 
