@@ -66,15 +66,15 @@ __global__ void bn_finalize_kernel(const double* __restrict__ part, int B, int C
   if (running_var) running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)(var * n / (n - 1.0));
 }
 
-// grid (kSplit, C).  dx_part: per 64-feature tile (tile = c*(HW/64) + t) {sum dx, sum dx*zhat}
+// grid (kSplit, C).  dx_part: per tile of `tile_f` features (tile = c*(HW/tile_f) + t) {sum dx, sum dx*zhat}
 __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const float* __restrict__ dx, const float* __restrict__ z,
                                                                 const float* __restrict__ ab,
                                                                 const float* __restrict__ save,
                                                                 const float* __restrict__ dx_part, int B, int C, int HW,
                                                                 float* __restrict__ dz, float* __restrict__ dgamma,
-                                                                float* __restrict__ dbeta) {
+                                                                float* __restrict__ dbeta, int tile_f) {
   const int c = blockIdx.y, s = blockIdx.x;
-  const int tpc = HW / 64;
+  const int tpc = HW / tile_f;
   double s0 = 0, s1 = 0;
   for (int t = 0; t < tpc; t++) { s0 += dx_part[2 * (c * tpc + t)]; s1 += dx_part[2 * (c * tpc + t) + 1]; }
   if (s == 0 && threadIdx.x == 0) {
@@ -143,7 +143,7 @@ int alignq_bn_bwd_apply(const float* dx, const float* z, const float* ab, const 
   if (!dx || !z || !ab || !save || !dx_part || !dz || B < 1 || C < 1) return ALIGNQ_EINVAL;
   if (HW % 64) return ALIGNQ_EUNSUPPORTED;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(kSplit, C), kThreads, 0, (hipStream_t)stream, dx, z, ab, save, dx_part, B, C,
-                     HW, dz, dgamma, dbeta);
+                     HW, dz, dgamma, dbeta, alignq_site::bwd_tile_features(B, (int64_t)C * HW));
   LAUNCH_CHECK();
   return 0;
 }

@@ -674,16 +674,18 @@ __global__ __launch_bounds__(256) void site_prep_multi_kernel(PChunk c, int dim,
 //   B = Vh[j][c] needs 8 CONSECUTIVE j per lane, so the standardised tiles are staged TRANSPOSED in LDS
 //       ([feature][batch], bf16 hi/lo): the load mapping gives each thread one feature column and 16 consecutive
 //       batch rows (256-byte coalesced row segments per wave instruction), two 16-byte LDS stores per array.
-constexpr int NTB = 512;
-
-template <bool PAIR, bool BN>
-__global__ __launch_bounds__(NTB) void site_bwd4_kernel(const float* __restrict__ gup, const float* __restrict__ S,
+// TFv = 64: 512 threads, one workgroup per CU (138 KB LDS);  TFv = 32: 256 threads, 69 KB LDS, two workgroups per CU whose
+// phases interleave, and twice as many tiles for the small-F sites.
+template <int TFv, bool PAIR, bool BN>
+__global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restrict__ gup, const float* __restrict__ S,
                                                         const float* __restrict__ x, const float* __restrict__ stats,
                                                         int B, int64_t F, float r, float eps, float* __restrict__ dx,
                                                         int n_tiles, int aligned, BnFold bn) {
   BSTAMP(1, 0);
   (void)aligned;
-  constexpr int TFv = 64, LDv = 65, TILE = 128 * LDv;
+  constexpr int LDv = TFv + 1, TILE = 128 * LDv;
+  constexpr int NWv = TFv / 8;                       // waves per workgroup
+  constexpr int CB = TFv / 32;                       // 32-column blocks per tile
   constexpr int LDT = 128 + 8;                       // bf16 elements per transposed row (272 B: 16-B aligned, 4-bank skew)
   constexpr int TARR = TFv * LDT;                    // bf16 elements per transposed array
   constexpr int NT_ARR = PAIR ? 4 : 2;
@@ -699,9 +701,9 @@ __global__ __launch_bounds__(NTB) void site_bwd4_kernel(const float* __restrict_
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
-  const int I = w >> 1, cj = w & 1;
+  const int I = w / CB, cj = w % CB;
   const int cc = cj * 32 + l31;            // this lane's feature column inside the tile (accumulator layout)
-  const int lcol = lane, lrow0 = w * 16;   // load mapping: one feature column, 16 consecutive batch rows
+  const int lcol = tid % TFv, lrow0 = (tid / TFv) * 16;   // load mapping: one feature column, 16 consecutive batch rows
 
   const float invB = 1.0f / (float)B, invBm1 = 1.0f / (float)(B - 1);
   STAMP(10);
@@ -976,7 +978,7 @@ __global__ __launch_bounds__(NTB) void site_bwd4_kernel(const float* __restrict_
     if (BN && tid == 0) {
       float t0 = 0.f, t1 = 0.f;
 #pragma unroll
-      for (int q = 0; q < 8; q++) { t0 += red[2 * q]; t1 += red[2 * q + 1]; }
+      for (int q = 0; q < NWv; q++) { t0 += red[2 * q]; t1 += red[2 * q + 1]; }
       bn.dx_part[2 * tile] = t0;
       bn.dx_part[2 * tile + 1] = t1;
     }
@@ -1078,12 +1080,17 @@ int launch_bwd4(bool pair, const Geom& g, const float* gup, const float* S, cons
                 int64_t F, float r, float eps, float* dx, hipStream_t st, BnFold bn) {
   (void)g;
   if ((int64_t)B * F * 4 >= ((int64_t)1 << 32)) return ALIGNQ_EUNSUPPORTED;   // 32-bit byte offsets inside a tile column
-  const int n_tiles = (int)((F + 63) / 64);
-  const int grid = n_tiles;               // one 64-feature tile per workgroup
+  const int tf = bwd_tile_features(B, F);
+  const int n_tiles = (int)((F + tf - 1) / tf);
+  const int grid = n_tiles;               // one tile per workgroup
   const int aligned = 0;
-  if (pair && bn.ab) hipLaunchKernelGGL((site_bwd4_kernel<true, true>), grid, NTB, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_tiles, aligned, bn);
-  else if (pair) hipLaunchKernelGGL((site_bwd4_kernel<true, false>), grid, NTB, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_tiles, aligned, bn);
-  else hipLaunchKernelGGL((site_bwd4_kernel<false, false>), grid, NTB, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_tiles, aligned, bn);
+#define LB(TFV, P, N) hipLaunchKernelGGL((site_bwd4_kernel<TFV, P, N>), grid, TFV * 8, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_tiles, aligned, bn)
+  if (tf == 64) {
+    if (pair && bn.ab) LB(64, true, true); else if (pair) LB(64, true, false); else LB(64, false, false);
+  } else {
+    if (pair && bn.ab) LB(32, true, true); else if (pair) LB(32, true, false); else LB(32, false, false);
+  }
+#undef LB
   RET_ON_ERR();
   return 0;
 }

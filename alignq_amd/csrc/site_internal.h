@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace alignq_site {
 
@@ -18,7 +19,7 @@ struct BnFold {
   const float* ab;      // [2][C]: a then b.  Forward with `part`: OUTPUT (written by the first tile of each channel)
   const float* save;    // [2][C]: batch mean then invstd.  Forward with `part`: OUTPUT
   int HW, C;
-  float* dx_part;       // backward only: per-tile partial sums (sum dx, sum dx*zhat) [n_tiles][2]
+  float* dx_part;       // backward only: per-tile partial sums (sum dx, sum dx*zhat) [F / bwd_tile_features][2]
   const float* y;       // backward only: the forward's relu(x_q) output when the ReLU is fused (mask y > 0), else nullptr
   // forward, in-kernel finalisation of the batch statistics (bn_stats partials -> mean/invstd/a/b + running statistics)
   const double* part;   // [C][kBnSplit][2] {sum z, sum z^2}; nullptr => `ab` is an input
@@ -35,6 +36,14 @@ struct BnFold {
 inline BnFold no_bn() {
   return BnFold{nullptr, nullptr, 1, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0,
                 nullptr, nullptr};
+}
+
+// Features per tile of the B in (64,128] backward kernel (also the granularity of BnFold::dx_part).
+inline int bwd_tile_features(int B, int64_t F) {
+  (void)B;
+  static const int forced = [] { const char* e = getenv("ALIGNQ_BWD_TF"); return e ? atoi(e) : 0; }();   // tuning aid
+  if (forced == 32 || forced == 64) return forced;
+  return F >= 16384 ? 64 : 32;
 }
 
 struct Geom {

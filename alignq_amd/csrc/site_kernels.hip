@@ -563,7 +563,7 @@ int alignq_site_partials_bn(const float* z, const void* bn_part, const float* bn
   return launch_partials4(true, geom(B, F), z, B, F, k, act_range, eps, xq, stats, (float*)ws, (hipStream_t)stream, bn);
 }
 
-size_t alignq_site_bn_part_bytes(int64_t F) { return (size_t)((F + 63) / 64) * 2 * sizeof(float); }
+size_t alignq_site_bn_part_bytes(int64_t F) { return (size_t)((F + 31) / 32) * 2 * sizeof(float); }   // smallest backward tile
 
 int alignq_site_bwd_apply_bn(const float* g, const float* S, const float* z, const float* ab, const float* save, int C,
                              int HW, const float* y_relu, float* dresidual, const float* stats, int B, int64_t F,
