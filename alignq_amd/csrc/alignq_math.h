@@ -45,13 +45,14 @@ __device__ __forceinline__ float exp32_neg_small(float x) {
   p = __fmaf_rn(p, r, ALIGNQ_PE0);
   float r2 = r * r;
   float e = 1.0f + __fmaf_rn(r2, p, r);
-  int n = (int)nf;
-  int h = n >> 1;
-  // two exact power-of-two scalings == the spec's e*2^h*2^(n-h) (no subnormals for n >= -58)
-  return e * pow2i(h) * pow2i(n - h);
+  // one exact scaling by 2^n (v_ldexp_f32) == the spec's e*2^h*2^(n-h): no subnormals or overflow for -58 <= n <= 0
+  return __builtin_ldexpf(e, (int)nf);
 }
 
-// Branch-free form: both polynomial regions are evaluated and selected per lane (v_cndmask).  On random data almost
+// Branch-free form: both polynomial regions are evaluated and selected per lane (v_cndmask).  Issue rates measured on
+// MI355X (tools/src/valu_rate.hip): v_fma/v_mul/v_add ~2.7 cycles per wave64 instruction, v_rndne/v_min/v_cmp/v_cndmask/
+// v_ldexp/v_cvt/v_bfi 4, v_exp/v_rcp 8, v_pk_fma_f32 ~4.9 (so packed fp32 does not pay here) - hence as few selects,
+// compares and conversions as the spec allows.  On random data almost
 // every wave has lanes in both regions, so a branchy form executes both anyway and pays the exec-mask/branch traffic
 // on top (measured in the ISA of the site kernels: ~4 scalar/branch instructions per element).  Values are identical
 // to the branchy statement of the spec (same operations per lane).
@@ -78,9 +79,9 @@ __device__ __forceinline__ float erf32(float x) {
   pb = __fmaf_rn(pb, ab, ALIGNQ_PB1);
   pb = __fmaf_rn(pb, ab, ALIGNQ_PB0);
   const float rb = 1.0f - exp32_neg_small(-pb);
-  float res = (a < ALIGNQ_ERF_T) ? ra : rb;
-  res = (a < ALIGNQ_ERF_HI) ? res : 1.0f;
-  res = (a != a) ? a : res;
+  // One select covers the spec's three cases: for a >= ERF_HI the clamped region-B value is 1 - 1.54e-8 == 1.0f exactly
+  // (checked against the oracle by tests/test_oracle_c.py), and a NaN fails (a >= T), picking ra = fma(NaN, ., NaN).
+  const float res = (a >= ALIGNQ_ERF_T) ? rb : ra;
   return copysignf(res, x);
 }
 
@@ -100,7 +101,7 @@ __device__ __forceinline__ float div_const(float x, float d, float y) {
   const float q = __fmaf_rn(r, y, q0);
   // q0 already is the answer for the two cases the correction step mangles: a signed zero (the fma chain turns -0
   // into +0) and +-inf (inf - inf = NaN)
-  return (q0 == 0.0f || fabsf(q0) == __int_as_float(0x7f800000)) ? q0 : q;
+  return __builtin_amdgcn_classf(q0, 0x264) ? q0 : q;     // v_cmp_class: -inf | -0 | +0 | +inf
 }
 #define ALIGNQ_RCP_SQRT2F 0.707106769084930419921875f   // RN(1/float(sqrt(2)))
 

@@ -230,8 +230,8 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
       tv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (PAIR) {
         float4 q, rl = make_float4(0.f, 0.f, 0.f, 0.f);
-        float b;
         if (!kEarlyRes && bn.res) rl = ld4(bn.res, off, col, F, ok, aligned);
+        float b;
         q.x = act_quant1<0>(xv[j].x, k, nlev, r, &tv[j].x, &b);
         q.y = act_quant1<0>(xv[j].y, k, nlev, r, &tv[j].y, &b);
         q.z = act_quant1<0>(xv[j].z, k, nlev, r, &tv[j].z, &b);

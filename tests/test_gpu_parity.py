@@ -54,10 +54,18 @@ def test_act_quant_bit_exact_vs_oracle(dev, formula, k):
     from alignq_amd import ops
     rng = np.random.default_rng(10 + k)
     x = np.concatenate([rng.standard_normal(1 << 18) * 1.7, rng.uniform(-6, 6, 4099),
-                        np.array([0.0, -0.0, 0.875 * 1.4142135, 4.0 * 1.4142135, 30.0, -30.0, 1e-30])]).astype(np.float32)
+                        np.array([0.0, -0.0, 0.875 * 1.4142135, 4.0 * 1.4142135, 30.0, -30.0, 1e-30]),
+                        # region boundaries of ERF32 (|z| = 0.875, 4) approached from both sides, +-inf, huge
+                        np.nextafter(np.float32(0.875 * 2 ** 0.5), np.float32([0, 9] * 4)) * np.float32([1, 1, -1, -1] * 2),
+                        np.linspace(5.6568, 5.6570, 201), -np.linspace(5.6568, 5.6570, 201),
+                        np.linspace(1.23743, 1.23745, 201), -np.linspace(1.23743, 1.23745, 201),
+                        np.array([np.inf, -np.inf, 1e30, -1e30, 3e38, -3e38])]).astype(np.float32)
     xq, bins = ops.act_quant_bins(cu(x, dev), k, 2.0, formula)
     oq, ot, ob = O.act_quant_fwd(x, k, 2.0, formula)
     assert bits_equal(npy(xq), oq)
+    nanq, _ = ops.act_quant_bins(cu(np.array([np.nan, 1.0], np.float32), dev), k, 2.0, formula)
+    # NaN propagates (k == 1 is sign(): torch.sign(nan) == 0, formula 1 then maps 0 -> -r)
+    assert (np.isnan(npy(nanq)[0]) if k != 1 else not np.isnan(npy(nanq)[0])) and not np.isnan(npy(nanq)[1])
     if k not in (32,):
         assert np.array_equal(npy(bins), ob)
 
