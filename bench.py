@@ -144,8 +144,16 @@ def measure_kernels(dev, B, k, site_F_counts, hw_of_F, folded=True):
     p = L.ptr
     t_f = time_call(lambda: lib.alignq_act_quant_fwd(p(x), p(y), None, n, k, 2.0, 0, st), 20)
     t_b = time_call(lambda: lib.alignq_act_quant_bwd(p(g), p(x), p(y), n, 2.0, st), 20)
-    out["act_quant_fwd_2p26"] = {"us": t_f * 1e6, "hbm_gbs": 8.0 * n / t_f / 1e9, "frac_of_8TBs": 8.0 * n / t_f / 1e9 / HBM_PEAK_GBS}
-    out["act_quant_bwd_2p26"] = {"us": t_b * 1e6, "hbm_gbs": 12.0 * n / t_b / 1e9, "frac_of_8TBs": 12.0 * n / t_b / 1e9 / HBM_PEAK_GBS}
+    # on-box streaming ceilings with the same traffic shapes: a device copy (1 read + 1 write per element)
+    # and an elementwise add (2 reads + 1 write), both plain PyTorch-ROCm kernels
+    t_copy = time_call(lambda: y.copy_(x), 20)
+    t_add = time_call(lambda: torch.add(g, x, out=y), 20)
+    copy_gbs, add_gbs = 8.0 * n / t_copy / 1e9, 12.0 * n / t_add / 1e9
+    out["stream_ceiling_2p26"] = {"copy_us": t_copy * 1e6, "copy_gbs": copy_gbs, "add_us": t_add * 1e6, "add_gbs": add_gbs}
+    out["act_quant_fwd_2p26"] = {"us": t_f * 1e6, "hbm_gbs": 8.0 * n / t_f / 1e9, "frac_of_8TBs": 8.0 * n / t_f / 1e9 / HBM_PEAK_GBS,
+                                 "frac_of_copy_ceiling": t_copy / t_f}
+    out["act_quant_bwd_2p26"] = {"us": t_b * 1e6, "hbm_gbs": 12.0 * n / t_b / 1e9, "frac_of_8TBs": 12.0 * n / t_b / 1e9 / HBM_PEAK_GBS,
+                                 "frac_of_add_ceiling": t_add / t_b}
     del x, y, g
     n_sites = sum(site_F_counts.values())
     dom = max(("site_partials", "site_bwd"), key=lambda kname: per_step[kname][0])
