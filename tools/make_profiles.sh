@@ -4,7 +4,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/prof && mkdir -p gpurun_out/prof
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/stats -o run -- python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline > gpurun_out/prof/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/stats -o run -- python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-miopen-find > gpurun_out/prof/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/prof/fetch -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/prof/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/prof/write -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/prof/write.log 2>&1
 find gpurun_out/prof -name "*.csv" | head -20
@@ -12,7 +12,7 @@ find gpurun_out/prof -name "*.csv" | head -20
 find gpurun_out/prof/fetch gpurun_out/prof/write -name "*kernel_trace.csv" -delete
 du -sh gpurun_out/prof
 python3 tools/summarise_profiles.py gpurun_out/prof gpurun_out/profiles
-tail -1 gpurun_out/prof/stats.log > gpurun_out/profiles/bench_under_rocprof.json
+grep "^{\"metric" gpurun_out/prof/stats.log > gpurun_out/profiles/bench_under_rocprof.json || true
 rm -rf gpurun_out/prof
 python3 bench.py --steps 200 --warmup 20 > gpurun_out/profiles/bench_n1.json 2> gpurun_out/profiles/bench_n1.err
 tail -c 600 gpurun_out/profiles/bench_n1.json
