@@ -12,7 +12,7 @@ SO_PATH = os.path.join(_HERE, "lib", "libalignq_hip.so")
 
 FORMULA_ADMM, FORMULA_CDF = 0, 1
 MAX_BATCH = 128
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _c = ctypes
 _vp, _i, _i64, _f, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_size_t
@@ -51,11 +51,13 @@ SIGNATURES = {
     "alignq_bn_stats": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp]),
     "alignq_bn_partial_stats": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "alignq_site_partials_bn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _i, _i, _i, _i64, _i, _f, _f, _i,
-                                     _vp, _vp, _vp, _vp, _vp]),
-    "alignq_site_bn_part_bytes": (_sz, [_i64]),
+                                     _vp, _i, _vp, _vp, _vp, _vp]),
+    "alignq_site_bn_part_bytes": (_sz, [_i64, _i]),
+    "alignq_bn_nhwc_ws_bytes": (_sz, [_i]),
+    "alignq_bn_stats_nhwc": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "alignq_site_prep_fused": (_i, [_vp, _vp, _vp, _i, _vp, _f, _vp, _i, _i64, _vp, _vp, _vp, _vp]),
-    "alignq_site_bwd_apply_bn": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i64, _f, _f, _vp, _vp, _vp]),
-    "alignq_bn_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "alignq_site_bwd_apply_bn": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i64, _f, _f, _vp, _vp, _vp]),
+    "alignq_bn_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "alignq_weight_multi_ws_bytes": (_sz, [_i]),
     "alignq_weight_quant_fwd_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "alignq_weight_quant_bwd_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

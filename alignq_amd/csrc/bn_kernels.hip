@@ -66,6 +66,84 @@ __global__ void bn_finalize_kernel(const double* __restrict__ part, int B, int C
   if (running_var) running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)(var * n / (n - 1.0));
 }
 
+// ---- channels-last (NHWC) statistics + finalisation in ONE launch ---------------------------------------------------
+// z is [B, H, W, C] in memory (torch.channels_last), C % 4 == 0.  Block g owns a contiguous range of pixels (all C
+// channels of a pixel are contiguous): thread -> (pixel slot, channel quad), double accumulation, fixed-order LDS
+// reduction over the pixel slots, per-block per-channel partials stored write-through; the block that draws the last
+// ticket sums the partials in block order (deterministic) and writes a, b, mean, invstd and the running statistics.
+// `ticket` is a PERSISTENT device counter that must be zero before the first launch; it is only ever incremented by
+// gridDim.x per launch (a multiple of 32 is required of the grid so that 2^32 wraps cleanly), never reset.
+constexpr int kNhwcThreads = 256;
+__global__ __launch_bounds__(kNhwcThreads) void bn_stats_nhwc_kernel(
+    const float* __restrict__ z, int B, int C, int HW, double* __restrict__ part, unsigned* __restrict__ ticket,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ running_mean,
+    float* __restrict__ running_var, long long* __restrict__ nbt, float momentum, float eps, float* __restrict__ ab,
+    float* __restrict__ save) {
+  __shared__ double sm[kNhwcThreads][8];
+  __shared__ bool is_last;
+  const int tid = threadIdx.x;
+  const int C4 = C >> 2;                       // channel quads per pixel
+  const int slots = kNhwcThreads / C4;         // pixels in flight per block iteration (C = 4 * 2^k <= 256)
+  const int cq = tid % C4, slot = tid / C4;
+  const int64_t npix = (int64_t)B * HW;
+  const int64_t per = (npix + gridDim.x - 1) / gridDim.x;
+  const int64_t p0 = (int64_t)blockIdx.x * per, p1 = (p0 + per < npix) ? p0 + per : npix;
+  double a[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  {
+    for (int64_t px = p0 + slot; px < p1; px += slots) {
+      const float4 v = *reinterpret_cast<const float4*>(z + px * C + 4 * cq);
+      a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
+      q[0] += (double)v.x * v.x; q[1] += (double)v.y * v.y; q[2] += (double)v.z * v.z; q[3] += (double)v.w * v.w;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; e++) { sm[tid][e] = a[e]; sm[tid][4 + e] = q[e]; }
+  __syncthreads();
+  if (tid < C) {                                // channel tid: quad tid/4, component tid%4, summed over the pixel slots
+    const int qd = tid >> 2, e = tid & 3;
+    double sa = 0, sq = 0;
+    for (int sl = 0; sl < slots; sl++) { sa += sm[sl * C4 + qd][e]; sq += sm[sl * C4 + qd][4 + e]; }
+    __hip_atomic_store(&part[((int64_t)blockIdx.x * C + tid) * 2], sa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&part[((int64_t)blockIdx.x * C + tid) * 2 + 1], sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (tk % gridDim.x) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  // ---- last block: channel c = tid % C, partial group tid / C (C <= 256 divides 256), fixed order ----
+  const int groups = kNhwcThreads / C;
+  const int c = tid % C, grp = tid / C;
+  double sa = 0, sq = 0;
+  for (int g = grp; g < (int)gridDim.x; g += groups) {
+    sa += __hip_atomic_load(&part[((int64_t)g * C + c) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sq += __hip_atomic_load(&part[((int64_t)g * C + c) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  sm[tid][0] = sa;
+  sm[tid][1] = sq;
+  __syncthreads();
+  if (grp == 0) {
+    double ta = 0, tq = 0;
+    for (int g = 0; g < groups; g++) { ta += sm[g * C + c][0]; tq += sm[g * C + c][1]; }
+    const double n = (double)B * (double)HW;
+    const double mean = ta / n;
+    double var = tq / n - mean * mean;
+    if (var < 0) var = 0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float av = (gamma ? gamma[c] : 1.0f) * invstd;
+    ab[c] = av;
+    ab[C + c] = (beta ? beta[c] : 0.0f) - (float)mean * av;
+    save[c] = (float)mean;
+    save[C + c] = invstd;
+    if (running_mean) running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_var) running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)(var * n / (n - 1.0));
+    if (c == 0 && nbt) *nbt += 1;
+  }
+}
+
 // grid (kSplit, C).  dx_part: per tile of `tile_f` features (tile = c*(HW/tile_f) + t) {sum dx, sum dx*zhat}
 __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const float* __restrict__ dx, const float* __restrict__ z,
                                                                 const float* __restrict__ ab,
@@ -104,6 +182,62 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const float* __r
   }
 }
 
+// channels-last backward apply: grid = B blocks (one batch row each).  col_part: per feature column {sum_b dx, sum_b dx*zhat}
+// written by the site backward; every block re-derives the per-channel totals (F*2 floats from L2, fixed order), then
+// dz = a[c] * (dx - k0[c] - zhat * k1[c]) with c = f mod C.
+__global__ __launch_bounds__(kNhwcThreads) void bn_bwd_apply_nhwc_kernel(
+    const float* __restrict__ dx, const float* __restrict__ z, const float* __restrict__ ab, const float* __restrict__ save,
+    const float* __restrict__ col_part, int B, int C, int HW, float* __restrict__ dz, float* __restrict__ dgamma,
+    float* __restrict__ dbeta) {
+  __shared__ double sm[kNhwcThreads][2];
+  __shared__ float kk[2][256];
+  const int tid = threadIdx.x;
+  const int groups = kNhwcThreads / C;
+  const int c = tid % C, grp = tid / C;
+  double s0 = 0, s1 = 0;
+  for (int p = grp; p < HW; p += groups) {
+    const float2 v = *reinterpret_cast<const float2*>(col_part + 2 * ((int64_t)p * C + c));
+    s0 += v.x;
+    s1 += v.y;
+  }
+  sm[tid][0] = s0;
+  sm[tid][1] = s1;
+  __syncthreads();
+  if (grp == 0) {
+    double t0 = 0, t1 = 0;
+    for (int g = 0; g < groups; g++) { t0 += sm[g * C + c][0]; t1 += sm[g * C + c][1]; }
+    if (blockIdx.x == 0) {
+      if (dbeta) dbeta[c] = (float)t0;
+      if (dgamma) dgamma[c] = (float)t1;
+    }
+    const double n = (double)B * (double)HW;
+    kk[0][c] = (float)(t0 / n);
+    kk[1][c] = (float)(t1 / n);
+  }
+  __syncthreads();
+  const int64_t F = (int64_t)C * HW;
+  const int64_t base = (int64_t)blockIdx.x * F;
+  const float4* pd = reinterpret_cast<const float4*>(dx + base);
+  const float4* pz = reinterpret_cast<const float4*>(z + base);
+  float4* po = reinterpret_cast<float4*>(dz + base);
+  const int nv = (int)(F >> 2);
+  const int cstep = (kNhwcThreads * 4) & (C - 1);          // channel advance per loop iteration (C a power of two)
+  int ch = (4 * tid) & (C - 1);
+  for (int i = tid; i < nv; i += kNhwcThreads) {
+    const float4 d = pd[i], zz = pz[i];
+    const float4 a4 = *reinterpret_cast<const float4*>(ab + ch);
+    const float4 m4 = *reinterpret_cast<const float4*>(save + ch);
+    const float4 i4 = *reinterpret_cast<const float4*>(save + C + ch);
+    float4 o;
+    o.x = a4.x * (d.x - kk[0][ch + 0] - (zz.x - m4.x) * i4.x * kk[1][ch + 0]);
+    o.y = a4.y * (d.y - kk[0][ch + 1] - (zz.y - m4.y) * i4.y * kk[1][ch + 1]);
+    o.z = a4.z * (d.z - kk[0][ch + 2] - (zz.z - m4.z) * i4.z * kk[1][ch + 2]);
+    o.w = a4.w * (d.w - kk[0][ch + 3] - (zz.w - m4.w) * i4.w * kk[1][ch + 3]);
+    po[i] = o;
+    ch = (ch + cstep) & (C - 1);
+  }
+}
+
 }  // namespace
 
 #define LAUNCH_CHECK()                          \
@@ -138,9 +272,35 @@ int alignq_bn_partial_stats(const float* z, int B, int C, int HW, void* ws, void
   return 0;
 }
 
+static inline bool nhwc_channels_ok(int C) { return C >= 4 && C <= 256 && (C & (C - 1)) == 0; }
+
+size_t alignq_bn_nhwc_ws_bytes(int C) { return (size_t)256 * (size_t)(C > 0 ? C : 1) * 2 * sizeof(double); }
+
+int alignq_bn_stats_nhwc(const float* z, int B, int C, int HW, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, int64_t* num_batches_tracked, float momentum, float eps, float* ab,
+                         float* save, void* ws, unsigned* ticket, void* stream) {
+  if (!z || !ab || !save || !ws || !ticket || B < 1 || C < 1 || HW < 1) return ALIGNQ_EINVAL;
+  if (!nhwc_channels_ok(C) || (reinterpret_cast<uintptr_t>(z) & 15)) return ALIGNQ_EUNSUPPORTED;
+  const int64_t npix = (int64_t)B * HW;
+  int grid = (int)((npix + 127) / 128);          // >= 128 pixels per block; a multiple of 32 so the ticket wraps cleanly
+  grid = (grid + 31) / 32 * 32;
+  if (grid > 256) grid = 256;
+  hipLaunchKernelGGL(bn_stats_nhwc_kernel, grid, kNhwcThreads, 0, (hipStream_t)stream, z, B, C, HW, (double*)ws, ticket,
+                     gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, momentum, eps, ab, save);
+  LAUNCH_CHECK();
+  return 0;
+}
+
 int alignq_bn_bwd_apply(const float* dx, const float* z, const float* ab, const float* save, const float* dx_part, int B,
-                        int C, int HW, float* dz, float* dgamma, float* dbeta, void* stream) {
+                        int C, int HW, int nhwc, float* dz, float* dgamma, float* dbeta, void* stream) {
   if (!dx || !z || !ab || !save || !dx_part || !dz || B < 1 || C < 1) return ALIGNQ_EINVAL;
+  if (nhwc) {
+    if (!nhwc_channels_ok(C)) return ALIGNQ_EUNSUPPORTED;
+    hipLaunchKernelGGL(bn_bwd_apply_nhwc_kernel, B, kNhwcThreads, 0, (hipStream_t)stream, dx, z, ab, save, dx_part, B, C, HW,
+                       dz, dgamma, dbeta);
+    LAUNCH_CHECK();
+    return 0;
+  }
   if (HW % 64) return ALIGNQ_EUNSUPPORTED;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(kSplit, C), kThreads, 0, (hipStream_t)stream, dx, z, ab, save, dx_part, B, C,
                      HW, dz, dgamma, dbeta, alignq_site::bwd_tile_features(B, (int64_t)C * HW));

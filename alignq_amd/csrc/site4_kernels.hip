@@ -164,7 +164,19 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
       xv[j] = ld4(x, off, col, F, ok, aligned);
     }
     // ---- folded batch-norm: x = a*z + b with (a, b) of this tile's channel (HW % 64 == 0: one channel per tile) -------
-    if (bn.ab) {
+    if (bn.ab && bn.nhwc) {
+      // channels-last: the float4 at column `col` covers channels (col mod C) .. +3 (C % 4 == 0); a, b are inputs
+      const int ch = col & (bn.C - 1);
+      const float4 a4 = *reinterpret_cast<const float4*>(bn.ab + ch);
+      const float4 b4 = *reinterpret_cast<const float4*>(bn.ab + bn.C + ch);
+#pragma unroll
+      for (int j = 0; j < RJ; j++) {
+        if (rg + RG * j < B && col < F) {
+          xv[j].x = __fmaf_rn(a4.x, xv[j].x, b4.x); xv[j].y = __fmaf_rn(a4.y, xv[j].y, b4.y);
+          xv[j].z = __fmaf_rn(a4.z, xv[j].z, b4.z); xv[j].w = __fmaf_rn(a4.w, xv[j].w, b4.w);
+        }
+      }
+    } else if (bn.ab) {
       const int ch = col0 / bn.HW;
       float bn_a, bn_b;
       if (bn.part) {
@@ -729,7 +741,11 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
       const float mt = (PAIR && lcol_ok) ? stats[2 * F + col0 + lcol] : 0.f;
       const float rt = (PAIR && lcol_ok) ? stats[3 * F + col0 + lcol] : 0.f;
       float bn_a = 1.f, bn_b = 0.f;
-      if (BN && lcol_ok) { const int ch = (col0 + lcol) / bn.HW; bn_a = bn.ab[ch]; bn_b = bn.ab[bn.C + ch]; }
+      if (BN && lcol_ok) {
+        const int ch = bn.nhwc ? ((col0 + lcol) & (bn.C - 1)) : (col0 + lcol) / bn.HW;
+        bn_a = bn.ab[ch];
+        bn_b = bn.ab[bn.C + ch];
+      }
       float xr[16], gr[16];
 #pragma unroll
       for (int q = 0; q < 16; q++) xr[q] = AT(x, q);          // all loads in flight before the first use
@@ -954,7 +970,11 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
     float bp0 = 0.f, bp1 = 0.f;     // folded batch-norm backward: this tile's sum dx and sum dx*zhat (one channel per tile)
     if (lcol_ok) {
       float bmu = 0.f, bis = 0.f;
-      if (BN) { const int ch = (col0 + lcol) / bn.HW; bmu = bn.save[ch]; bis = bn.save[bn.C + ch]; }
+      if (BN) {
+        const int ch = bn.nhwc ? ((col0 + lcol) & (bn.C - 1)) : (col0 + lcol) / bn.HW;
+        bmu = bn.save[ch];
+        bis = bn.save[bn.C + ch];
+      }
 #pragma unroll
       for (int q = 0; q < 16; q++) {
         const int row = lrow0 + q;
@@ -969,13 +989,25 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
         }
       }
     }
-    if (BN) {
+    // red is free again (all its reads finished before the barrier above)
+    if (BN && bn.nhwc) {             // one channel per COLUMN: per-column sums over the 8 row groups of the tile
+      red[(2 * (tid / TFv)) * TFv + lcol] = bp0;
+      red[(2 * (tid / TFv) + 1) * TFv + lcol] = bp1;
+    } else if (BN) {                 // one channel per tile
       bp0 = wave_sum(bp0);
       bp1 = wave_sum(bp1);
-      if (lane == 0) { red[2 * w] = bp0; red[2 * w + 1] = bp1; }   // red is free again (all reads finished before the barrier above)
+      if (lane == 0) { red[2 * w] = bp0; red[2 * w + 1] = bp1; }
     }
-    __syncthreads();   // LDS is overwritten by the next tile
-    if (BN && tid == 0) {
+    __syncthreads();
+    if (BN && bn.nhwc) {
+      if (tid < TFv && lcol_ok) {
+        float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; q++) { t0 += red[(2 * q) * TFv + tid]; t1 += red[(2 * q + 1) * TFv + tid]; }
+        bn.dx_part[2 * (int64_t)(col0 + tid)] = t0;
+        bn.dx_part[2 * (int64_t)(col0 + tid) + 1] = t1;
+      }
+    } else if (BN && tid == 0) {
       float t0 = 0.f, t1 = 0.f;
 #pragma unroll
       for (int q = 0; q < NWv; q++) { t0 += red[2 * q]; t1 += red[2 * q + 1]; }

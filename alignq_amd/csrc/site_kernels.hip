@@ -543,35 +543,40 @@ int alignq_site_bwd(const float* g, const float* dD, const float* dD_scale, cons
 }
 
 // ---- batch-norm folded forms (B in (64,128] only) ------------------------------------------------
-static inline bool bn_shape_ok(int B, int64_t F, int C, int HW) {
-  return B > 64 && B <= ALIGNQ_MAX_BATCH && C >= 1 && HW >= 64 && (HW % 64) == 0 && (int64_t)C * HW == F;
+static inline bool bn_shape_ok(int B, int64_t F, int C, int HW, int nhwc) {
+  if (!(B > 64 && B <= ALIGNQ_MAX_BATCH && C >= 1 && (int64_t)C * HW == F)) return false;
+  if (nhwc) return C >= 4 && C <= 256 && (C & (C - 1)) == 0 && (F % 64) == 0;   // channel = f mod C
+  return HW >= 64 && (HW % 64) == 0;                                             // one channel per 64-feature tile
 }
 
 int alignq_site_partials_bn(const float* z, const void* bn_part, const float* bn_gamma, const float* bn_beta,
                             float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
                             float bn_eps, float* ab, float* save, int C, int HW, int B, int64_t F, int k, float act_range,
-                            float eps, int relu, const float* residual, float* xq, float* stats, void* ws,
+                            float eps, int relu, const float* residual, int nhwc, float* xq, float* stats, void* ws,
                             void* stream) {
   if (!z || !ab || !save || !ws) return ALIGNQ_EINVAL;
   if (bad_k(k)) return ALIGNQ_EINVAL;
-  if (!bn_shape_ok(B, F, C, HW)) return ALIGNQ_EUNSUPPORTED;
+  if (!bn_shape_ok(B, F, C, HW, nhwc)) return ALIGNQ_EUNSUPPORTED;
+  if (nhwc && bn_part) return ALIGNQ_EINVAL;      // channels-last: alignq_bn_stats_nhwc has finalised ab / save already
   BnFold bn = no_bn();
-  bn.ab = ab; bn.save = save; bn.HW = HW; bn.C = C;
+  bn.ab = ab; bn.save = save; bn.HW = HW; bn.C = C; bn.nhwc = nhwc;
   bn.part = (const double*)bn_part; bn.gamma = bn_gamma; bn.beta = bn_beta;
   bn.running_mean = running_mean; bn.running_var = running_var; bn.nbt = (long long*)num_batches_tracked;
   bn.momentum = momentum; bn.bn_eps = bn_eps; bn.relu = relu; bn.res = residual;
   return launch_partials4(true, geom(B, F), z, B, F, k, act_range, eps, xq, stats, (float*)ws, (hipStream_t)stream, bn);
 }
 
-size_t alignq_site_bn_part_bytes(int64_t F) { return (size_t)((F + 31) / 32) * 2 * sizeof(float); }   // smallest backward tile
+size_t alignq_site_bn_part_bytes(int64_t F, int nhwc) {
+  return (nhwc ? (size_t)F : (size_t)((F + 31) / 32)) * 2 * sizeof(float);   // per column | per smallest backward tile
+}
 
 int alignq_site_bwd_apply_bn(const float* g, const float* S, const float* z, const float* ab, const float* save, int C,
-                             int HW, const float* y_relu, float* dresidual, const float* stats, int B, int64_t F,
+                             int HW, int nhwc, const float* y_relu, float* dresidual, const float* stats, int B, int64_t F,
                              float act_range, float eps, float* dx, float* dx_part, void* stream) {
   if (!S || !z || !ab || !save || !stats || !dx || !dx_part) return ALIGNQ_EINVAL;
-  if (!bn_shape_ok(B, F, C, HW)) return ALIGNQ_EUNSUPPORTED;
+  if (!bn_shape_ok(B, F, C, HW, nhwc)) return ALIGNQ_EUNSUPPORTED;
   BnFold bn = no_bn();
-  bn.ab = ab; bn.save = save; bn.HW = HW; bn.C = C; bn.dx_part = dx_part; bn.y = y_relu; bn.dres = dresidual;
+  bn.ab = ab; bn.save = save; bn.HW = HW; bn.C = C; bn.nhwc = nhwc; bn.dx_part = dx_part; bn.y = y_relu; bn.dres = dresidual;
   return launch_bwd4(true, geom(B, F), g, S, z, stats, B, F, act_range, eps, dx, (hipStream_t)stream, bn);
 }
 

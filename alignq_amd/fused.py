@@ -204,12 +204,13 @@ class BNSiteFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, bn_weight, bn_bias, running_mean, running_var, nbt, momentum, bn_eps, alterD, gamma, k, act_range,
-                eps, mu, rho, relu, rec=None, res=None):
-        z = L.dev_f32(z, "conv output")
+                eps, mu, rho, relu, rec=None, res=None, ticket=None):
+        z = L.dense_f32(z, "conv output")
+        nhwc = not z.is_contiguous()             # dense_f32 only lets contiguous or channels-last 4-D tensors through
         if res is not None:
-            res = L.dev_f32(res, "residual")
-            if res.shape != z.shape or not res.is_contiguous():
-                raise RuntimeError("residual must be a contiguous tensor of the conv output's shape")
+            res = L.dense_f32(res, "residual")
+            if res.shape != z.shape or res.stride() != z.stride():
+                raise RuntimeError("residual must have the conv output's shape and memory layout")
         A = L.dev_f32(alterD, "alterD")
         Gm = L.dev_f32(gamma, "gamma")
         B, C, H, W = z.shape
@@ -220,17 +221,33 @@ class BNSiteFn(torch.autograd.Function):
         st = L.stream_ptr()
         ab = torch.empty(2, C, dtype=torch.float32, device=dev)
         save = torch.empty(2, C, dtype=torch.float32, device=dev)
-        ws_bn = torch.empty(lib.alignq_bn_ws_bytes(C), dtype=torch.uint8, device=dev)
-        L.check(lib.alignq_bn_partial_stats(L.ptr(z), B, C, HW, L.ptr(ws_bn), st), "alignq_bn_partial_stats")
+        if nhwc:
+            # channels-last: statistics AND finalisation in one launch; the site kernel takes a/b as inputs
+            if ticket is None:
+                raise RuntimeError("channels-last BN fold needs the module's persistent ticket counter (use fused.bn_site)")
+            ws_bn = torch.empty(lib.alignq_bn_nhwc_ws_bytes(C), dtype=torch.uint8, device=dev)
+            L.check(lib.alignq_bn_stats_nhwc(L.ptr(z), B, C, HW, L.ptr(bn_weight), L.ptr(bn_bias), L.ptr(running_mean),
+                                             L.ptr(running_var), L.ptr(nbt), float(momentum), float(bn_eps), L.ptr(ab),
+                                             L.ptr(save), L.ptr(ws_bn), L.ptr(ticket), st), "alignq_bn_stats_nhwc")
+        else:
+            ws_bn = torch.empty(lib.alignq_bn_ws_bytes(C), dtype=torch.uint8, device=dev)
+            L.check(lib.alignq_bn_partial_stats(L.ptr(z), B, C, HW, L.ptr(ws_bn), st), "alignq_bn_partial_stats")
         y = torch.empty_like(z)
         D = torch.empty(B, B, dtype=torch.float32, device=dev)
         stats = torch.empty(4, F, dtype=torch.float32, device=dev)
         scal = rec.scal if rec is not None else torch.empty(4, dtype=torch.float32, device=dev)
         ws = torch.empty(lib.alignq_site_ws_bytes(B, F), dtype=torch.uint8, device=dev)
-        L.check(lib.alignq_site_partials_bn(L.ptr(z), L.ptr(ws_bn), L.ptr(bn_weight), L.ptr(bn_bias), L.ptr(running_mean),
-                                            L.ptr(running_var), L.ptr(nbt), float(momentum), float(bn_eps), L.ptr(ab),
-                                            L.ptr(save), C, HW, B, F, int(k), float(act_range), float(eps), int(bool(relu)),
-                                            L.ptr(res), L.ptr(y), L.ptr(stats), L.ptr(ws), st), "alignq_site_partials_bn")
+        if nhwc:
+            L.check(lib.alignq_site_partials_bn(L.ptr(z), None, None, None, None, None, None, 0.0, 0.0, L.ptr(ab),
+                                                L.ptr(save), C, HW, B, F, int(k), float(act_range), float(eps),
+                                                int(bool(relu)), L.ptr(res), 1, L.ptr(y), L.ptr(stats), L.ptr(ws), st),
+                    "alignq_site_partials_bn")
+        else:
+            L.check(lib.alignq_site_partials_bn(L.ptr(z), L.ptr(ws_bn), L.ptr(bn_weight), L.ptr(bn_bias),
+                                                L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt), float(momentum),
+                                                float(bn_eps), L.ptr(ab), L.ptr(save), C, HW, B, F, int(k),
+                                                float(act_range), float(eps), int(bool(relu)), L.ptr(res), 0, L.ptr(y),
+                                                L.ptr(stats), L.ptr(ws), st), "alignq_site_partials_bn")
         if rec is not None:      # reduced with all other sites in DeferredLosses.total()
             rec.ws, rec.D, rec.A, rec.Gm, rec.B, rec.F, rec.dim = ws, D, A, Gm, B, F, dim
             rec.mu, rec.rho = float(mu), float(rho)
@@ -240,14 +257,15 @@ class BNSiteFn(torch.autograd.Function):
         ctx.rec = rec
         ctx.save_for_backward(z, ab, save, stats, D, A, Gm, scal, y if relu else None)
         ctx.set_materialize_grads(False)
-        ctx.cfg = (float(act_range), float(eps), float(mu), bn_weight is not None, bn_bias is not None, res is not None)
+        ctx.cfg = (float(act_range), float(eps), float(mu), bn_weight is not None, bn_bias is not None, res is not None,
+                   int(nhwc))
         ctx.mark_non_differentiable(D)
         return y, scal[0], D
 
     @staticmethod
     def backward(ctx, g_y, g_loss, _gD):
         z, ab, save, stats, D, A, Gm, scal, y = ctx.saved_tensors
-        act_range, eps, mu, has_w, has_b, has_res = ctx.cfg
+        act_range, eps, mu, has_w, has_b, has_res, nhwc = ctx.cfg
         B, C, H, W = z.shape
         HW, F = H * W, C * H * W
         dim = A.shape[0]
@@ -268,51 +286,67 @@ class BNSiteFn(torch.autograd.Function):
             L.check(lib.alignq_site_prep_fused(L.ptr(D), L.ptr(A), L.ptr(Gm), dim, L.ptr(scal), mu, L.ptr(g_loss), B, F,
                                                L.ptr(S), L.ptr(dA), L.ptr(dG), st), "alignq_site_prep_fused")
         dx = torch.empty_like(z)
-        part = torch.empty(lib.alignq_site_bn_part_bytes(F), dtype=torch.uint8, device=dev)
+        part = torch.empty(lib.alignq_site_bn_part_bytes(F, nhwc), dtype=torch.uint8, device=dev)
         # gradient of the residual: the upstream gradient, ReLU-masked by the kernel when the ReLU was fused
         dres = None
         if has_res and g_y is not None:
             dres = torch.empty_like(z) if y is not None else g_y
-        L.check(lib.alignq_site_bwd_apply_bn(L.ptr(g_y), L.ptr(S), L.ptr(z), L.ptr(ab), L.ptr(save), C, HW, L.ptr(y),
+        L.check(lib.alignq_site_bwd_apply_bn(L.ptr(g_y), L.ptr(S), L.ptr(z), L.ptr(ab), L.ptr(save), C, HW, nhwc, L.ptr(y),
                                              L.ptr(dres) if y is not None else None, L.ptr(stats), B, F, act_range, eps,
                                              L.ptr(dx), L.ptr(part), st),
                 "alignq_site_bwd_apply_bn")
         dz = torch.empty_like(z)
         dgam = torch.empty(C, dtype=torch.float32, device=dev) if has_w else None
         dbet = torch.empty(C, dtype=torch.float32, device=dev) if has_b else None
-        L.check(lib.alignq_bn_bwd_apply(L.ptr(dx), L.ptr(z), L.ptr(ab), L.ptr(save), L.ptr(part), B, C, HW, L.ptr(dz),
+        L.check(lib.alignq_bn_bwd_apply(L.ptr(dx), L.ptr(z), L.ptr(ab), L.ptr(save), L.ptr(part), B, C, HW, nhwc, L.ptr(dz),
                                         L.ptr(dgam), L.ptr(dbet), st), "alignq_bn_bwd_apply")
-        return (dz, dgam, dbet, None, None, None, None, None, dA, dG, None, None, None, None, None, None, None, dres)
+        return (dz, dgam, dbet, None, None, None, None, None, dA, dG, None, None, None, None, None, None, None, dres, None)
+
+
+def _is_nhwc(z) -> bool:
+    return z.dim() == 4 and not z.is_contiguous() and z.is_contiguous(memory_format=torch.channels_last)
 
 
 def bn_site_fusable(bn, act, z) -> bool:
     from . import config
     if not (isinstance(bn, torch.nn.BatchNorm2d) and bn.training and bn.track_running_stats and bn.momentum is not None):
         return False
-    if not (z.is_cuda and z.dim() == 4 and z.dtype == torch.float32 and z.is_contiguous()):
+    if not (z.is_cuda and z.dim() == 4 and z.dtype == torch.float32):
         return False
     B, C, H, W = z.shape
+    if z.is_contiguous():
+        layout_ok = (H * W) % 64 == 0                       # one channel per 64-feature tile
+    elif _is_nhwc(z):
+        layout_ok = 4 <= C <= 256 and (C & (C - 1)) == 0 and (C * H * W) % 64 == 0     # channel = f mod C
+    else:
+        return False
     a_bit = getattr(act, "a_bit", 32)
-    return (64 < B <= L.MAX_BATCH and (H * W) % 64 == 0 and hasattr(act, "opt") and a_bit < 32
+    return (layout_ok and 64 < B <= L.MAX_BATCH and hasattr(act, "opt") and a_bit < 32
             and config.args.method == "ours" and act.opt.alterD.shape[0] >= B)
 
 
 def bn_site(bn, act, z, eps=0.0, relu=False, residual=None):
     """out, loss = act(bn(z)) [; out = out + residual] [; out = relu(out) when relu=True] — folded into the site kernels
-    when `bn_site_fusable`, otherwise exactly that composition."""
+    when `bn_site_fusable`, otherwise exactly that composition.  z may be contiguous (NCHW) or channels-last."""
     from . import config
     if not bn_site_fusable(bn, act, z) or (residual is not None and not (
-            residual.shape == z.shape and residual.is_contiguous() and residual.dtype == torch.float32)):
+            residual.shape == z.shape and residual.stride() == z.stride() and residual.dtype == torch.float32)):
         out, loss = act(bn(z))
         if residual is not None:
             out = out + residual
         return (torch.nn.functional.relu(out) if relu else out), loss
+    ticket = None
+    if _is_nhwc(z):
+        ticket = getattr(bn, "_alignq_ticket", None)
+        if ticket is None or ticket.device != z.device:
+            ticket = torch.zeros(1, dtype=torch.int32, device=z.device)     # persistent, only ever incremented
+            bn._alignq_ticket = ticket
     admm = act.opt
     deferred = active_deferred()
     rec = deferred.new_record(z.shape[0], z.device) if deferred is not None else None
     y, loss, D = BNSiteFn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
                                 bn.momentum, bn.eps, admm.alterD, admm.gamma, act.a_bit, config.args.act_range, eps,
-                                admm.mu, admm.rho, relu, rec, residual)
+                                admm.mu, admm.rho, relu, rec, residual, ticket)
     admm.D = D
     if deferred is not None:
         if rec is not None:

@@ -97,16 +97,16 @@ def measure_kernels(dev, B, k, site_F_counts, hw_of_F, folded=True):
         nbt = torch.zeros((), dtype=torch.int64, device=dev)
         ab, save = torch.empty(2, C, device=dev), torch.empty(2, C, device=dev)
         ws_bn = torch.empty(lib.alignq_bn_ws_bytes(C), dtype=torch.uint8, device=dev)
-        part = torch.empty(lib.alignq_site_bn_part_bytes(F), dtype=torch.uint8, device=dev)
+        part = torch.empty(lib.alignq_site_bn_part_bytes(F, 0), dtype=torch.uint8, device=dev)
         dgam, dbet = torch.empty(C, device=dev), torch.empty(C, device=dev)
         p = L.ptr
         if folded:
             f_stats = lambda: lib.alignq_bn_partial_stats(p(x), B, C, HW, p(ws_bn), st)
             f_part = lambda: lib.alignq_site_partials_bn(p(x), p(ws_bn), p(gam), p(bet), p(rm), p(rv), p(nbt), 0.1, 1e-5, p(ab),
-                                                         p(save), C, HW, B, F, k, 2.0, 0.0, 1, None, p(xq), p(stats), p(ws), st)
-            f_bwd = lambda: lib.alignq_site_bwd_apply_bn(p(g), p(S), p(x), p(ab), p(save), C, HW, p(xq), None, p(stats), B, F, 2.0,
+                                                         p(save), C, HW, B, F, k, 2.0, 0.0, 1, None, 0, p(xq), p(stats), p(ws), st)
+            f_bwd = lambda: lib.alignq_site_bwd_apply_bn(p(g), p(S), p(x), p(ab), p(save), C, HW, 0, p(xq), None, p(stats), B, F, 2.0,
                                                          0.0, p(dx), p(part), st)
-            f_bnb = lambda: lib.alignq_bn_bwd_apply(p(dx), p(x), p(ab), p(save), p(part), B, C, HW, p(dz), p(dgam), p(dbet), st)
+            f_bnb = lambda: lib.alignq_bn_bwd_apply(p(dx), p(x), p(ab), p(save), p(part), B, C, HW, 0, p(dz), p(dgam), p(dbet), st)
         else:
             f_stats = None
             f_part = lambda: lib.alignq_site_partials(p(x), B, F, k, 2.0, 0.0, p(xq), p(stats), p(ws), st)

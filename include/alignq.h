@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALIGNQ_ABI_VERSION 1
+#define ALIGNQ_ABI_VERSION 2
 
 #define ALIGNQ_FORMULA_ADMM 0
 #define ALIGNQ_FORMULA_CDF 1
@@ -200,17 +200,26 @@ int alignq_bn_stats(const float* z, int B, int C, int HW, const float* gamma, co
 int alignq_site_partials_bn(const float* z, const void* bn_part, const float* bn_gamma, const float* bn_beta,
                             float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
                             float bn_eps, float* ab, float* save, int C, int HW, int B, int64_t F, int k, float act_range,
-                            float eps, int relu, const float* residual, float* xq, float* stats, void* ws,
+                            float eps, int relu, const float* residual, int nhwc, float* xq, float* stats, void* ws,
                             void* stream);
-size_t alignq_site_bn_part_bytes(int64_t F);
+size_t alignq_site_bn_part_bytes(int64_t F, int nhwc);
 int alignq_site_prep_fused(const float* D, const float* alterD, const float* gamma, int dim, const float* scal, float mu,
                            const float* dD_scale, int B, int64_t F, float* S, float* dalterD, float* dgamma,
                            void* stream);
 int alignq_site_bwd_apply_bn(const float* g, const float* S, const float* z, const float* ab, const float* save, int C,
-                             int HW, const float* y_relu, float* dresidual, const float* stats, int B, int64_t F,
+                             int HW, int nhwc, const float* y_relu, float* dresidual, const float* stats, int B, int64_t F,
                              float act_range, float eps, float* dx, float* dx_part, void* stream);
 int alignq_bn_bwd_apply(const float* dx, const float* z, const float* ab, const float* save, const float* dx_part, int B,
-                        int C, int HW, float* dz, float* dgamma, float* dbeta, void* stream);
+                        int C, int HW, int nhwc, float* dz, float* dgamma, float* dbeta, void* stream);
+/* Channels-last (torch.channels_last, memory [B,H,W,C]) form of the fold, nhwc = 1 above: channel = f mod C with C a power
+ * of two in [4,256].  alignq_bn_stats_nhwc computes AND finalises the batch statistics in one launch (ab, save, running
+ * statistics; ws = alignq_bn_nhwc_ws_bytes(C)); `ticket` is a persistent device uint32 that the caller zeroes ONCE (it is
+ * only incremented).  alignq_site_partials_bn is then called with bn_part = NULL (ab / save are inputs), the site backward
+ * writes dx_part per feature column ([F][2], alignq_site_bn_part_bytes(F, 1)).                                          */
+size_t alignq_bn_nhwc_ws_bytes(int C);
+int alignq_bn_stats_nhwc(const float* z, int B, int C, int HW, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, int64_t* num_batches_tracked, float momentum, float eps, float* ab,
+                         float* save, void* ws, unsigned* ticket, void* stream);
 
 #ifdef __cplusplus
 }

@@ -594,3 +594,64 @@ def test_batched_deferred_sites_match_per_site_launches(dev, B):
     for key in ("xq", "D", "dx", "dA", "dG", "dw"):
         for x, y in zip(u[key], b[key]):
             assert np.array_equal(x, y), key
+
+
+@pytest.mark.parametrize("relu,residual", [(False, False), (True, True)])
+@pytest.mark.parametrize("B,C,H,W,k", [(128, 16, 32, 32, 8), (128, 64, 8, 8, 4), (100, 32, 16, 16, 8), (128, 8, 4, 4, 8)])
+def test_bn_folded_site_channels_last_matches_nchw(dev, B, C, H, W, k, relu, residual):
+    """The channels-last (torch.channels_last) form of the BN fold against the unfused composition on contiguous tensors:
+    the same logical tensors in the other memory layout must give the same results (tie-zone bin flips only; D is
+    invariant under the feature permutation up to summation order)."""
+    import alignq_amd.cdf_alignment_admm as A
+    from alignq_amd import config
+    from alignq_amd.fused import bn_site, bn_site_fusable
+    config.args.bitW = config.args.abitW = k
+    torch.manual_seed(B + C + 1)
+    z = (torch.randn(B, C, H, W, device=dev) * 1.7 + 0.3)
+    gq = torch.randn(B, C, H, W, device=dev) * 0.01
+    res0 = torch.randn(B, C, H, W, device=dev) * 0.7
+    outs = []
+    for nhwc in (False, True):
+        fmt = torch.channels_last if nhwc else torch.contiguous_format
+        torch.manual_seed(1)
+        res = res0.clone(memory_format=fmt).requires_grad_(True) if residual else None
+        bn = torch.nn.BatchNorm2d(C).to(dev).train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(C, device=dev) + 0.5)
+            bn.bias.copy_(torch.randn(C, device=dev) * 0.2)
+        admm = A.ADMM(128).to(dev)
+        act = A.activation_quantize_fn(k, "second", admm)
+        zz = z.clone(memory_format=fmt).requires_grad_(True)
+        if nhwc:
+            assert bn_site_fusable(bn, act, zz) and not zz.is_contiguous()
+            for _ in range(2):          # twice: the persistent ticket counter must survive re-use
+                bn.running_mean.zero_(); bn.running_var.fill_(1.0); bn.num_batches_tracked.zero_()
+                xq, loss = bn_site(bn, act, zz, relu=relu, residual=res)
+            assert xq.is_contiguous(memory_format=torch.channels_last)
+        else:
+            xq, loss = act(bn(zz))
+            if residual:
+                xq = xq + res
+            if relu:
+                xq = torch.nn.functional.relu(xq)
+        (loss + (xq * gq).sum()).backward()
+        outs.append(dict(xq=npy(xq), loss=float(loss.detach()), D=npy(admm.D), dz=npy(zz.grad), dw=npy(bn.weight.grad),
+                         db=npy(bn.bias.grad), rm=npy(bn.running_mean), rv=npy(bn.running_var),
+                         nbt=int(bn.num_batches_tracked), dA=npy(admm.alterD.grad),
+                         dres=npy(res.grad) if residual else None))
+    u, f = outs
+    n = 2 ** k - 1
+    flips = np.abs(u["xq"] - f["xq"]) * n
+    assert flips.max() <= 1.0 + 1e-3 and (flips > 0.5).mean() < 1e-3
+    np.testing.assert_allclose(f["D"], u["D"], atol=TOL)
+    np.testing.assert_allclose(f["loss"], u["loss"], atol=TOL)
+    np.testing.assert_allclose(f["rm"], u["rm"], atol=1e-6, rtol=1e-5)
+    np.testing.assert_allclose(f["rv"], u["rv"], atol=1e-6, rtol=1e-5)
+    assert f["nbt"] == u["nbt"] == 1
+    np.testing.assert_allclose(f["dA"], u["dA"], atol=1e-7, rtol=1e-4)
+    np.testing.assert_allclose(f["dz"], u["dz"], atol=2e-5, rtol=1e-3)
+    np.testing.assert_allclose(f["dw"], u["dw"], atol=2e-4, rtol=1e-3)
+    np.testing.assert_allclose(f["db"], u["db"], atol=2e-4, rtol=1e-3)
+    if residual:
+        assert (f["dres"] != u["dres"]).mean() < 1e-3
+    config.args.bitW = config.args.abitW = 8

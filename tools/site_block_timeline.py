@@ -30,15 +30,15 @@ for (C, HW) in ((16, 1024), (32, 256), (64, 64)):
     ws_bn = torch.empty(lib.alignq_bn_ws_bytes(C), dtype=torch.uint8, device=dev)
     ab, save = torch.empty(2, C, device=dev), torch.empty(2, C, device=dev)
     gam, bet = torch.ones(C, device=dev), torch.zeros(C, device=dev)
-    part = torch.empty(lib.alignq_site_bn_part_bytes(F), dtype=torch.uint8, device=dev)
+    part = torch.empty(lib.alignq_site_bn_part_bytes(F, 0), dtype=torch.uint8, device=dev)
     S = torch.rand(B, B, device=dev) * 1e-6
     st = L.stream_ptr()
     for it in range(4):
         lib.alignq_bn_partial_stats(p(z), B, C, HW, p(ws_bn), st)
         lib.alignq_site_partials_bn(p(z), p(ws_bn), p(gam), p(bet), None, None, None, 0.1, 1e-5, p(ab), p(save), C, HW, B, F,
-                                    k, 2.0, 0.0, 1, None, p(xq), p(stats), p(ws), st)
+                                    k, 2.0, 0.0, 1, None, 0, p(xq), p(stats), p(ws), st)
         torch.cuda.synchronize()
-        lib.alignq_site_bwd_apply_bn(p(g), p(S), p(z), p(ab), p(save), C, HW, p(xq), None, p(stats), B, F, 2.0, 0.0, p(dx),
+        lib.alignq_site_bwd_apply_bn(p(g), p(S), p(z), p(ab), p(save), C, HW, 0, p(xq), None, p(stats), B, F, 2.0, 0.0, p(dx),
                                      p(part), st)
         torch.cuda.synchronize()
     buf = (ctypes.c_ulonglong * 64)()
