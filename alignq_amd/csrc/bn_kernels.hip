@@ -89,20 +89,40 @@ __global__ __launch_bounds__(kNhwcThreads) void bn_stats_nhwc_kernel(
   const int64_t per = (npix + gridDim.x - 1) / gridDim.x;
   const int64_t p0 = (int64_t)blockIdx.x * per, p1 = (p0 + per < npix) ? p0 + per : npix;
   double a[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
-  {
-    for (int64_t px = p0 + slot; px < p1; px += slots) {
-      const float4 v = *reinterpret_cast<const float4*>(z + px * C + 4 * cq);
-      a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
-      q[0] += (double)v.x * v.x; q[1] += (double)v.y * v.y; q[2] += (double)v.z * v.z; q[3] += (double)v.w * v.w;
+  constexpr int U = 8;                         // loads in flight per thread
+  for (int64_t base = p0 + slot; base < p1; base += (int64_t)slots * U) {
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {              // clamped address, masked below: no branch around the load
+      const int64_t px = base + (int64_t)u * slots;
+      v[u] = *reinterpret_cast<const float4*>(z + (px < p1 ? px : p1 - 1) * C + 4 * cq);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (base + (int64_t)u * slots < p1) {
+        a[0] += v[u].x; a[1] += v[u].y; a[2] += v[u].z; a[3] += v[u].w;
+        q[0] += (double)v[u].x * v[u].x; q[1] += (double)v[u].y * v[u].y;
+        q[2] += (double)v[u].z * v[u].z; q[3] += (double)v[u].w * v[u].w;
+      }
     }
   }
+  // lanes of a wave that share a channel quad (lane = cq mod C4): butterfly over the slot bits, then waves via LDS
+  const int lane = tid & 63, w = tid >> 6;
+  for (int o = C4; o < 64; o <<= 1) {          // C4 < 64 always (C <= 256 would give C4 = 64: then no lane shares)
 #pragma unroll
-  for (int e = 0; e < 4; e++) { sm[tid][e] = a[e]; sm[tid][4 + e] = q[e]; }
+    for (int e = 0; e < 4; e++) { a[e] += __shfl_xor(a[e], o, 64); q[e] += __shfl_xor(q[e], o, 64); }
+  }
+  if (lane < C4 || C4 >= 64) {
+    const int row = (C4 >= 64) ? tid : w * C4 + lane;      // [wave][quad]
+#pragma unroll
+    for (int e = 0; e < 4; e++) { sm[row][e] = a[e]; sm[row][4 + e] = q[e]; }
+  }
   __syncthreads();
-  if (tid < C) {                                // channel tid: quad tid/4, component tid%4, summed over the pixel slots
+  if (tid < C) {                                // channel tid: quad tid/4, component tid%4, summed over the waves
     const int qd = tid >> 2, e = tid & 3;
     double sa = 0, sq = 0;
-    for (int sl = 0; sl < slots; sl++) { sa += sm[sl * C4 + qd][e]; sq += sm[sl * C4 + qd][4 + e]; }
+    const int nw = (C4 >= 64) ? kNhwcThreads / C4 : kNhwcThreads / 64;
+    for (int ww = 0; ww < nw; ww++) { sa += sm[ww * C4 + qd][e]; sq += sm[ww * C4 + qd][4 + e]; }
     __hip_atomic_store(&part[((int64_t)blockIdx.x * C + tid) * 2], sa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&part[((int64_t)blockIdx.x * C + tid) * 2 + 1], sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -118,6 +138,7 @@ __global__ __launch_bounds__(kNhwcThreads) void bn_stats_nhwc_kernel(
   const int groups = kNhwcThreads / C;
   const int c = tid % C, grp = tid / C;
   double sa = 0, sq = 0;
+#pragma unroll 8
   for (int g = grp; g < (int)gridDim.x; g += groups) {
     sa += __hip_atomic_load(&part[((int64_t)g * C + c) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     sq += __hip_atomic_load(&part[((int64_t)g * C + c) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -182,59 +203,41 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const float* __r
   }
 }
 
-// channels-last backward apply: grid = B blocks (one batch row each).  col_part: per feature column {sum_b dx, sum_b dx*zhat}
-// written by the site backward; every block re-derives the per-channel totals (F*2 floats from L2, fixed order), then
-// dz = a[c] * (dx - k0[c] - zhat * k1[c]) with c = f mod C.
+// channels-last backward apply, purely elementwise: dz = a[c] * (dx - k0[c] - zhat * k1[c]) with c = f mod C.  ktot = {k0[C],
+// k1[C]} comes from the site backward's last workgroup.  Each thread handles 4 float4 (12 loads in flight).
 __global__ __launch_bounds__(kNhwcThreads) void bn_bwd_apply_nhwc_kernel(
     const float* __restrict__ dx, const float* __restrict__ z, const float* __restrict__ ab, const float* __restrict__ save,
-    const float* __restrict__ col_part, int B, int C, int HW, float* __restrict__ dz, float* __restrict__ dgamma,
-    float* __restrict__ dbeta) {
-  __shared__ double sm[kNhwcThreads][2];
-  __shared__ float kk[2][256];
-  const int tid = threadIdx.x;
-  const int groups = kNhwcThreads / C;
-  const int c = tid % C, grp = tid / C;
-  double s0 = 0, s1 = 0;
-  for (int p = grp; p < HW; p += groups) {
-    const float2 v = *reinterpret_cast<const float2*>(col_part + 2 * ((int64_t)p * C + c));
-    s0 += v.x;
-    s1 += v.y;
+    const float* __restrict__ ktot, int64_t nvec, int C, float* __restrict__ dz) {
+  const float4* pd = reinterpret_cast<const float4*>(dx);
+  const float4* pz = reinterpret_cast<const float4*>(z);
+  float4* po = reinterpret_cast<float4*>(dz);
+  constexpr int U = 4;
+  const int64_t i0 = ((int64_t)blockIdx.x * U) * kNhwcThreads + threadIdx.x;
+  float4 d[U], zz[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const int64_t i = i0 + (int64_t)u * kNhwcThreads;
+    const int64_t ic = i < nvec ? i : nvec - 1;
+    d[u] = pd[ic];
+    zz[u] = pz[ic];
   }
-  sm[tid][0] = s0;
-  sm[tid][1] = s1;
-  __syncthreads();
-  if (grp == 0) {
-    double t0 = 0, t1 = 0;
-    for (int g = 0; g < groups; g++) { t0 += sm[g * C + c][0]; t1 += sm[g * C + c][1]; }
-    if (blockIdx.x == 0) {
-      if (dbeta) dbeta[c] = (float)t0;
-      if (dgamma) dgamma[c] = (float)t1;
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const int64_t i = i0 + (int64_t)u * kNhwcThreads;
+    if (i < nvec) {
+      const int ch = (int)((i * 4) & (C - 1));
+      const float4 a4 = *reinterpret_cast<const float4*>(ab + ch);
+      const float4 m4 = *reinterpret_cast<const float4*>(save + ch);
+      const float4 i4 = *reinterpret_cast<const float4*>(save + C + ch);
+      const float4 k0 = *reinterpret_cast<const float4*>(ktot + ch);
+      const float4 k1 = *reinterpret_cast<const float4*>(ktot + C + ch);
+      float4 o;
+      o.x = a4.x * (d[u].x - k0.x - (zz[u].x - m4.x) * i4.x * k1.x);
+      o.y = a4.y * (d[u].y - k0.y - (zz[u].y - m4.y) * i4.y * k1.y);
+      o.z = a4.z * (d[u].z - k0.z - (zz[u].z - m4.z) * i4.z * k1.z);
+      o.w = a4.w * (d[u].w - k0.w - (zz[u].w - m4.w) * i4.w * k1.w);
+      po[i] = o;
     }
-    const double n = (double)B * (double)HW;
-    kk[0][c] = (float)(t0 / n);
-    kk[1][c] = (float)(t1 / n);
-  }
-  __syncthreads();
-  const int64_t F = (int64_t)C * HW;
-  const int64_t base = (int64_t)blockIdx.x * F;
-  const float4* pd = reinterpret_cast<const float4*>(dx + base);
-  const float4* pz = reinterpret_cast<const float4*>(z + base);
-  float4* po = reinterpret_cast<float4*>(dz + base);
-  const int nv = (int)(F >> 2);
-  const int cstep = (kNhwcThreads * 4) & (C - 1);          // channel advance per loop iteration (C a power of two)
-  int ch = (4 * tid) & (C - 1);
-  for (int i = tid; i < nv; i += kNhwcThreads) {
-    const float4 d = pd[i], zz = pz[i];
-    const float4 a4 = *reinterpret_cast<const float4*>(ab + ch);
-    const float4 m4 = *reinterpret_cast<const float4*>(save + ch);
-    const float4 i4 = *reinterpret_cast<const float4*>(save + C + ch);
-    float4 o;
-    o.x = a4.x * (d.x - kk[0][ch + 0] - (zz.x - m4.x) * i4.x * kk[1][ch + 0]);
-    o.y = a4.y * (d.y - kk[0][ch + 1] - (zz.y - m4.y) * i4.y * kk[1][ch + 1]);
-    o.z = a4.z * (d.z - kk[0][ch + 2] - (zz.z - m4.z) * i4.z * kk[1][ch + 2]);
-    o.w = a4.w * (d.w - kk[0][ch + 3] - (zz.w - m4.w) * i4.w * kk[1][ch + 3]);
-    po[i] = o;
-    ch = (ch + cstep) & (C - 1);
   }
 }
 
@@ -294,10 +297,12 @@ int alignq_bn_stats_nhwc(const float* z, int B, int C, int HW, const float* gamm
 int alignq_bn_bwd_apply(const float* dx, const float* z, const float* ab, const float* save, const float* dx_part, int B,
                         int C, int HW, int nhwc, float* dz, float* dgamma, float* dbeta, void* stream) {
   if (!dx || !z || !ab || !save || !dx_part || !dz || B < 1 || C < 1) return ALIGNQ_EINVAL;
-  if (nhwc) {
+  if (nhwc) {     // dx_part is ktot [2][C] here; dgamma / dbeta were written by the site backward already
     if (!nhwc_channels_ok(C)) return ALIGNQ_EUNSUPPORTED;
-    hipLaunchKernelGGL(bn_bwd_apply_nhwc_kernel, B, kNhwcThreads, 0, (hipStream_t)stream, dx, z, ab, save, dx_part, B, C, HW,
-                       dz, dgamma, dbeta);
+    const int64_t nvec = (int64_t)B * C * HW / 4;
+    const int64_t blocks = (nvec + kNhwcThreads * 4 - 1) / (kNhwcThreads * 4);
+    hipLaunchKernelGGL(bn_bwd_apply_nhwc_kernel, (unsigned)blocks, kNhwcThreads, 0, (hipStream_t)stream, dx, z, ab, save,
+                       dx_part, nvec, C, dz);
     LAUNCH_CHECK();
     return 0;
   }

@@ -990,7 +990,7 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
       }
     }
     // red is free again (all its reads finished before the barrier above)
-    if (BN && bn.nhwc) {             // one channel per COLUMN: per-column sums over the 8 row groups of the tile
+    if (BN && bn.nhwc) {             // channels-last: column j of the tile belongs to channel (col0 + j) mod C
       red[(2 * (tid / TFv)) * TFv + lcol] = bp0;
       red[(2 * (tid / TFv) + 1) * TFv + lcol] = bp1;
     } else if (BN) {                 // one channel per tile
@@ -1000,12 +1000,57 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
     }
     __syncthreads();
     if (BN && bn.nhwc) {
-      if (tid < TFv && lcol_ok) {
+      // per-tile, per-channel partial sums -> scratch (write-through), then the last workgroup (ticket) reduces all
+      // tiles in fixed order into per-channel totals: no extra launch, deterministic
+      const int C = bn.C;
+      const int cp = C < TFv ? C : TFv;                      // distinct channels in a tile
+      if (tid < cp) {
         float t0 = 0.f, t1 = 0.f;
+        for (int j = tid; j < TFv; j += cp) {
 #pragma unroll
-        for (int q = 0; q < 8; q++) { t0 += red[(2 * q) * TFv + tid]; t1 += red[(2 * q + 1) * TFv + tid]; }
-        bn.dx_part[2 * (int64_t)(col0 + tid)] = t0;
-        bn.dx_part[2 * (int64_t)(col0 + tid) + 1] = t1;
+          for (int q = 0; q < 8; q++) { t0 += red[(2 * q) * TFv + j]; t1 += red[(2 * q + 1) * TFv + j]; }
+        }
+        float* dst = bn.dx_part + ((int64_t)tile * cp + tid) * 2;
+        __hip_atomic_store(dst, t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + 1, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
+      unsigned* flag = reinterpret_cast<unsigned*>(red);     // red's readers are past the barrier above
+      if (tid == 0) {
+        const unsigned tk = __hip_atomic_fetch_add(bn.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = ((tk % gridDim.x) == gridDim.x - 1) ? 1u : 0u;
+      }
+      __syncthreads();
+      if (*flag) {
+        constexpr int NTBv = TFv * 8;
+        double* dsm = reinterpret_cast<double*>(Os);         // [NTBv][2] doubles (<= 8 KB of the 33 KB staging tile)
+        const int groups = NTBv / C > 0 ? NTBv / C : 1;
+        const int c = tid % C, grp = tid / C;
+        const int cyc = C > TFv ? C / TFv : 1;               // a channel recurs every `cyc` tiles (C > TF) or in every tile
+        const int cnt = n_tiles / cyc;
+        const int e = C > TFv ? c % TFv : c, t_first = C > TFv ? c / TFv : 0;
+        double s0 = 0, s1 = 0;
+        if (grp < groups) {
+#pragma unroll 8
+          for (int i = grp; i < cnt; i += groups) {
+            const float* src = bn.dx_part + ((int64_t)(i * cyc + t_first) * cp + e) * 2;
+            s0 += __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s1 += __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        dsm[2 * tid] = s0;
+        dsm[2 * tid + 1] = s1;
+        __syncthreads();
+        if (grp == 0) {
+          double t0 = 0, t1 = 0;
+          for (int g = 0; g < groups; g++) { t0 += dsm[2 * (g * C + c)]; t1 += dsm[2 * (g * C + c) + 1]; }
+          const double n = (double)B * (double)bn.HW;
+          bn.ktot[c] = (float)(t0 / n);
+          bn.ktot[C + c] = (float)(t1 / n);
+          if (bn.dbeta) bn.dbeta[c] = (float)t0;
+          if (bn.dgamma) bn.dgamma[c] = (float)t1;
+        }
       }
     } else if (BN && tid == 0) {
       float t0 = 0.f, t1 = 0.f;

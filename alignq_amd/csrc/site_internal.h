@@ -33,11 +33,16 @@ struct BnFold {
   const float* res;     // forward: optional residual (shortcut) added to x_q before the ReLU, same [B,F] layout
   float* dres;          // backward: optional output, the upstream gradient after the ReLU mask (= gradient of `res`)
   int nhwc;             // 0: z is [B,C,HW] (channel = f / HW);  1: channels-last [B,HW,C] (channel = f mod C, C a power of
-                        // two): `ab` is always an input then (alignq_bn_stats_nhwc finalises), dx_part is per COLUMN [F][2]
+                        // two <= 256): `ab` is always an input then (alignq_bn_stats_nhwc finalises); backward: dx_part is
+                        // scratch [n_tiles][min(C,TF)][2] and the workgroup drawing the last ticket reduces it to
+  float* ktot;          //   ktot [2][C] = {sum dx, sum dx*zhat} / (B*HW),
+  float* dgamma;        //   dgamma [C] (may be nullptr),
+  float* dbeta;         //   dbeta [C] (may be nullptr);
+  unsigned* ticket;     //   persistent counter, zero before its first use, only ever incremented
 };
 inline BnFold no_bn() {
   return BnFold{nullptr, nullptr, 1, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0,
-                nullptr, nullptr, 0};
+                nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
 }
 
 // Features per tile of the B in (64,128] backward kernel (also the granularity of BnFold::dx_part).

@@ -255,6 +255,7 @@ class BNSiteFn(torch.autograd.Function):
             L.check(lib.alignq_site_reduce_loss(L.ptr(ws), B, F, L.ptr(D), L.ptr(A), L.ptr(Gm), dim, float(mu),
                                                 float(rho), L.ptr(scal), st), "alignq_site_reduce_loss")
         ctx.rec = rec
+        ctx.ticket = ticket
         ctx.save_for_backward(z, ab, save, stats, D, A, Gm, scal, y if relu else None)
         ctx.set_materialize_grads(False)
         ctx.cfg = (float(act_range), float(eps), float(mu), bn_weight is not None, bn_bias is not None, res is not None,
@@ -291,15 +292,17 @@ class BNSiteFn(torch.autograd.Function):
         dres = None
         if has_res and g_y is not None:
             dres = torch.empty_like(z) if y is not None else g_y
-        L.check(lib.alignq_site_bwd_apply_bn(L.ptr(g_y), L.ptr(S), L.ptr(z), L.ptr(ab), L.ptr(save), C, HW, nhwc, L.ptr(y),
-                                             L.ptr(dres) if y is not None else None, L.ptr(stats), B, F, act_range, eps,
-                                             L.ptr(dx), L.ptr(part), st),
-                "alignq_site_bwd_apply_bn")
-        dz = torch.empty_like(z)
         dgam = torch.empty(C, dtype=torch.float32, device=dev) if has_w else None
         dbet = torch.empty(C, dtype=torch.float32, device=dev) if has_b else None
-        L.check(lib.alignq_bn_bwd_apply(L.ptr(dx), L.ptr(z), L.ptr(ab), L.ptr(save), L.ptr(part), B, C, HW, nhwc, L.ptr(dz),
-                                        L.ptr(dgam), L.ptr(dbet), st), "alignq_bn_bwd_apply")
+        ktot = torch.empty(2, C, dtype=torch.float32, device=dev) if nhwc else None
+        ticket = ctx.ticket[1:] if nhwc else None          # second persistent counter of the module
+        L.check(lib.alignq_site_bwd_apply_bn(L.ptr(g_y), L.ptr(S), L.ptr(z), L.ptr(ab), L.ptr(save), C, HW, nhwc, L.ptr(y),
+                                             L.ptr(dres) if y is not None else None, L.ptr(stats), B, F, act_range, eps,
+                                             L.ptr(dx), L.ptr(part), L.ptr(ktot), L.ptr(dgam), L.ptr(dbet), L.ptr(ticket),
+                                             st), "alignq_site_bwd_apply_bn")
+        dz = torch.empty_like(z)
+        L.check(lib.alignq_bn_bwd_apply(L.ptr(dx), L.ptr(z), L.ptr(ab), L.ptr(save), L.ptr(ktot if nhwc else part), B, C, HW,
+                                        nhwc, L.ptr(dz), L.ptr(dgam), L.ptr(dbet), st), "alignq_bn_bwd_apply")
         return (dz, dgam, dbet, None, None, None, None, None, dA, dG, None, None, None, None, None, None, None, dres, None)
 
 
@@ -339,7 +342,7 @@ def bn_site(bn, act, z, eps=0.0, relu=False, residual=None):
     if _is_nhwc(z):
         ticket = getattr(bn, "_alignq_ticket", None)
         if ticket is None or ticket.device != z.device:
-            ticket = torch.zeros(1, dtype=torch.int32, device=z.device)     # persistent, only ever incremented
+            ticket = torch.zeros(2, dtype=torch.int32, device=z.device)     # persistent {stats, backward} counters, only incremented
             bn._alignq_ticket = ticket
     admm = act.opt
     deferred = active_deferred()

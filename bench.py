@@ -105,7 +105,7 @@ def measure_kernels(dev, B, k, site_F_counts, hw_of_F, folded=True):
             f_part = lambda: lib.alignq_site_partials_bn(p(x), p(ws_bn), p(gam), p(bet), p(rm), p(rv), p(nbt), 0.1, 1e-5, p(ab),
                                                          p(save), C, HW, B, F, k, 2.0, 0.0, 1, None, 0, p(xq), p(stats), p(ws), st)
             f_bwd = lambda: lib.alignq_site_bwd_apply_bn(p(g), p(S), p(x), p(ab), p(save), C, HW, 0, p(xq), None, p(stats), B, F, 2.0,
-                                                         0.0, p(dx), p(part), st)
+                                                         0.0, p(dx), p(part), None, None, None, None, st)
             f_bnb = lambda: lib.alignq_bn_bwd_apply(p(dx), p(x), p(ab), p(save), p(part), B, C, HW, 0, p(dz), p(dgam), p(dbet), st)
         else:
             f_stats = None
