@@ -54,10 +54,9 @@ SIGNATURES = {
                                      _vp, _i, _vp, _vp, _vp, _vp]),
     "alignq_site_bn_part_bytes": (_sz, [_i64, _i]),
     "alignq_bn_nhwc_ws_bytes": (_sz, [_i]),
-    "alignq_bn_stats_nhwc": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "alignq_bn_partial_stats_nhwc": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "alignq_site_prep_fused": (_i, [_vp, _vp, _vp, _i, _vp, _f, _vp, _i, _i64, _vp, _vp, _vp, _vp]),
-    "alignq_site_bwd_apply_bn": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i64, _f, _f, _vp, _vp, _vp, _vp,
-                                      _vp, _vp, _vp]),
+    "alignq_site_bwd_apply_bn": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i64, _f, _f, _vp, _vp, _vp]),
     "alignq_bn_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "alignq_weight_multi_ws_bytes": (_sz, [_i]),
     "alignq_weight_quant_fwd_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),

@@ -66,21 +66,16 @@ __global__ void bn_finalize_kernel(const double* __restrict__ part, int B, int C
   if (running_var) running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)(var * n / (n - 1.0));
 }
 
-// ---- channels-last (NHWC) statistics + finalisation in ONE launch ---------------------------------------------------
-// z is [B, H, W, C] in memory (torch.channels_last), C % 4 == 0.  Block g owns a contiguous range of pixels (all C
-// channels of a pixel are contiguous): thread -> (pixel slot, channel quad), double accumulation, fixed-order LDS
-// reduction over the pixel slots, per-block per-channel partials stored write-through; the block that draws the last
-// ticket sums the partials in block order (deterministic) and writes a, b, mean, invstd and the running statistics.
-// `ticket` is a PERSISTENT device counter that must be zero before the first launch; it is only ever incremented by
-// gridDim.x per launch (a multiple of 32 is required of the grid so that 2^32 wraps cleanly), never reset.
+// ---- channels-last (NHWC) statistics ---------------------------------------------------------------------------------
+// z is [B, H, W, C] in memory (torch.channels_last), C = 4 * 2^k <= 256.  kNhwcParts workgroups; block g owns a contiguous
+// range of pixels (all C channels of a pixel are contiguous): thread -> (pixel slot, channel quad), 8 loads in flight,
+// double accumulation, butterfly over the lanes sharing a quad, waves through LDS, one {sum, sum of squares} partial per
+// (channel, block): part [C][kNhwcParts][2].  The site forward finalises its tile's channels from these (a wave per channel).
 constexpr int kNhwcThreads = 256;
-__global__ __launch_bounds__(kNhwcThreads) void bn_stats_nhwc_kernel(
-    const float* __restrict__ z, int B, int C, int HW, double* __restrict__ part, unsigned* __restrict__ ticket,
-    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ running_mean,
-    float* __restrict__ running_var, long long* __restrict__ nbt, float momentum, float eps, float* __restrict__ ab,
-    float* __restrict__ save) {
+constexpr int kNhwcParts = alignq_site::kNhwcParts;
+__global__ __launch_bounds__(kNhwcThreads) void bn_stats_nhwc_kernel(const float* __restrict__ z, int B, int C, int HW,
+                                                                 double* __restrict__ part) {
   __shared__ double sm[kNhwcThreads][8];
-  __shared__ bool is_last;
   const int tid = threadIdx.x;
   const int C4 = C >> 2;                       // channel quads per pixel
   const int slots = kNhwcThreads / C4;         // pixels in flight per block iteration (C = 4 * 2^k <= 256)
@@ -123,45 +118,8 @@ __global__ __launch_bounds__(kNhwcThreads) void bn_stats_nhwc_kernel(
     double sa = 0, sq = 0;
     const int nw = (C4 >= 64) ? kNhwcThreads / C4 : kNhwcThreads / 64;
     for (int ww = 0; ww < nw; ww++) { sa += sm[ww * C4 + qd][e]; sq += sm[ww * C4 + qd][4 + e]; }
-    __hip_atomic_store(&part[((int64_t)blockIdx.x * C + tid) * 2], sa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&part[((int64_t)blockIdx.x * C + tid) * 2 + 1], sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __syncthreads();
-  if (tid == 0) {
-    const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    is_last = (tk % gridDim.x) == gridDim.x - 1;
-  }
-  __syncthreads();
-  if (!is_last) return;
-  // ---- last block: channel c = tid % C, partial group tid / C (C <= 256 divides 256), fixed order ----
-  const int groups = kNhwcThreads / C;
-  const int c = tid % C, grp = tid / C;
-  double sa = 0, sq = 0;
-#pragma unroll 8
-  for (int g = grp; g < (int)gridDim.x; g += groups) {
-    sa += __hip_atomic_load(&part[((int64_t)g * C + c) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    sq += __hip_atomic_load(&part[((int64_t)g * C + c) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  sm[tid][0] = sa;
-  sm[tid][1] = sq;
-  __syncthreads();
-  if (grp == 0) {
-    double ta = 0, tq = 0;
-    for (int g = 0; g < groups; g++) { ta += sm[g * C + c][0]; tq += sm[g * C + c][1]; }
-    const double n = (double)B * (double)HW;
-    const double mean = ta / n;
-    double var = tq / n - mean * mean;
-    if (var < 0) var = 0;
-    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float av = (gamma ? gamma[c] : 1.0f) * invstd;
-    ab[c] = av;
-    ab[C + c] = (beta ? beta[c] : 0.0f) - (float)mean * av;
-    save[c] = (float)mean;
-    save[C + c] = invstd;
-    if (running_mean) running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
-    if (running_var) running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)(var * n / (n - 1.0));
-    if (c == 0 && nbt) *nbt += 1;
+    part[((int64_t)tid * kNhwcParts + blockIdx.x) * 2] = sa;
+    part[((int64_t)tid * kNhwcParts + blockIdx.x) * 2 + 1] = sq;
   }
 }
 
@@ -203,40 +161,88 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const float* __r
   }
 }
 
-// channels-last backward apply, purely elementwise: dz = a[c] * (dx - k0[c] - zhat * k1[c]) with c = f mod C.  ktot = {k0[C],
-// k1[C]} comes from the site backward's last workgroup.  Each thread handles 4 float4 (12 loads in flight).
+// channels-last backward apply.  Stage 1 (every block, fixed order): per-channel totals of the site backward's per-tile
+// partials part [n_tiles][cp][2] (cp = min(C, tile_f); channel c sits at entry c mod tile_f of the tiles t with
+// t mod (C/cp) == c / tile_f) -> k0 = sum dx / n, k1 = sum dx*zhat / n; block 0 writes dbeta / dgamma.  Stage 2: this block's
+// slice of dz = a[c] * (dx - k0[c] - zhat * k1[c]), c = f mod C, 4 float4 per thread and iteration (8 loads in flight).
 __global__ __launch_bounds__(kNhwcThreads) void bn_bwd_apply_nhwc_kernel(
     const float* __restrict__ dx, const float* __restrict__ z, const float* __restrict__ ab, const float* __restrict__ save,
-    const float* __restrict__ ktot, int64_t nvec, int C, float* __restrict__ dz) {
+    const float* __restrict__ part, int n_tiles, int tile_f, int B, int C, int HW, float* __restrict__ dz,
+    float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ double sm[kNhwcThreads][2];
+  __shared__ __attribute__((aligned(16))) float kk[2][256];
+  const int tid = threadIdx.x;
+  {
+    const int cp = C < tile_f ? C : tile_f;
+    const int cyc = C / cp;
+    const int cnt = n_tiles / cyc;
+    const int groups = kNhwcThreads / C;
+    const int c = tid % C, grp = tid / C;
+    const int e = c % cp, t_first = c / cp;
+    double s0 = 0, s1 = 0;
+    constexpr int U = 8;
+    for (int i0 = grp; i0 < cnt; i0 += groups * U) {
+      float2 v[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int i = i0 + u * groups;
+        const int ic = i < cnt ? i : cnt - 1;
+        v[u] = *reinterpret_cast<const float2*>(part + ((int64_t)(ic * cyc + t_first) * cp + e) * 2);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (i0 + u * groups < cnt) { s0 += v[u].x; s1 += v[u].y; }
+      }
+    }
+    sm[tid][0] = s0;
+    sm[tid][1] = s1;
+    __syncthreads();
+    if (grp == 0) {
+      double t0 = 0, t1 = 0;
+      for (int g = 0; g < groups; g++) { t0 += sm[g * C + c][0]; t1 += sm[g * C + c][1]; }
+      if (blockIdx.x == 0) {
+        if (dbeta) dbeta[c] = (float)t0;
+        if (dgamma) dgamma[c] = (float)t1;
+      }
+      const double n = (double)B * (double)HW;
+      kk[0][c] = (float)(t0 / n);
+      kk[1][c] = (float)(t1 / n);
+    }
+    __syncthreads();
+  }
+  const int64_t nvec = (int64_t)B * C * HW / 4;
+  const int64_t per = (nvec + gridDim.x - 1) / gridDim.x;
+  const int64_t v0 = (int64_t)blockIdx.x * per, v1 = (v0 + per < nvec) ? v0 + per : nvec;
   const float4* pd = reinterpret_cast<const float4*>(dx);
   const float4* pz = reinterpret_cast<const float4*>(z);
   float4* po = reinterpret_cast<float4*>(dz);
   constexpr int U = 4;
-  const int64_t i0 = ((int64_t)blockIdx.x * U) * kNhwcThreads + threadIdx.x;
-  float4 d[U], zz[U];
+  for (int64_t i0 = v0 + tid; i0 < v1; i0 += (int64_t)kNhwcThreads * U) {
+    float4 d[U], zz[U];
 #pragma unroll
-  for (int u = 0; u < U; u++) {
-    const int64_t i = i0 + (int64_t)u * kNhwcThreads;
-    const int64_t ic = i < nvec ? i : nvec - 1;
-    d[u] = pd[ic];
-    zz[u] = pz[ic];
-  }
+    for (int u = 0; u < U; u++) {
+      const int64_t i = i0 + (int64_t)u * kNhwcThreads;
+      const int64_t ic = i < v1 ? i : v1 - 1;
+      d[u] = pd[ic];
+      zz[u] = pz[ic];
+    }
 #pragma unroll
-  for (int u = 0; u < U; u++) {
-    const int64_t i = i0 + (int64_t)u * kNhwcThreads;
-    if (i < nvec) {
-      const int ch = (int)((i * 4) & (C - 1));
-      const float4 a4 = *reinterpret_cast<const float4*>(ab + ch);
-      const float4 m4 = *reinterpret_cast<const float4*>(save + ch);
-      const float4 i4 = *reinterpret_cast<const float4*>(save + C + ch);
-      const float4 k0 = *reinterpret_cast<const float4*>(ktot + ch);
-      const float4 k1 = *reinterpret_cast<const float4*>(ktot + C + ch);
-      float4 o;
-      o.x = a4.x * (d[u].x - k0.x - (zz[u].x - m4.x) * i4.x * k1.x);
-      o.y = a4.y * (d[u].y - k0.y - (zz[u].y - m4.y) * i4.y * k1.y);
-      o.z = a4.z * (d[u].z - k0.z - (zz[u].z - m4.z) * i4.z * k1.z);
-      o.w = a4.w * (d[u].w - k0.w - (zz[u].w - m4.w) * i4.w * k1.w);
-      po[i] = o;
+    for (int u = 0; u < U; u++) {
+      const int64_t i = i0 + (int64_t)u * kNhwcThreads;
+      if (i < v1) {
+        const int ch = (int)((i * 4) & (C - 1));
+        const float4 a4 = *reinterpret_cast<const float4*>(ab + ch);
+        const float4 m4 = *reinterpret_cast<const float4*>(save + ch);
+        const float4 i4 = *reinterpret_cast<const float4*>(save + C + ch);
+        const float4 k0 = *reinterpret_cast<const float4*>(&kk[0][ch]);
+        const float4 k1 = *reinterpret_cast<const float4*>(&kk[1][ch]);
+        float4 o;
+        o.x = a4.x * (d[u].x - k0.x - (zz[u].x - m4.x) * i4.x * k1.x);
+        o.y = a4.y * (d[u].y - k0.y - (zz[u].y - m4.y) * i4.y * k1.y);
+        o.z = a4.z * (d[u].z - k0.z - (zz[u].z - m4.z) * i4.z * k1.z);
+        o.w = a4.w * (d[u].w - k0.w - (zz[u].w - m4.w) * i4.w * k1.w);
+        po[i] = o;
+      }
     }
   }
 }
@@ -277,19 +283,12 @@ int alignq_bn_partial_stats(const float* z, int B, int C, int HW, void* ws, void
 
 static inline bool nhwc_channels_ok(int C) { return C >= 4 && C <= 256 && (C & (C - 1)) == 0; }
 
-size_t alignq_bn_nhwc_ws_bytes(int C) { return (size_t)256 * (size_t)(C > 0 ? C : 1) * 2 * sizeof(double); }
+size_t alignq_bn_nhwc_ws_bytes(int C) { return (size_t)kNhwcParts * (size_t)(C > 0 ? C : 1) * 2 * sizeof(double); }
 
-int alignq_bn_stats_nhwc(const float* z, int B, int C, int HW, const float* gamma, const float* beta, float* running_mean,
-                         float* running_var, int64_t* num_batches_tracked, float momentum, float eps, float* ab,
-                         float* save, void* ws, unsigned* ticket, void* stream) {
-  if (!z || !ab || !save || !ws || !ticket || B < 1 || C < 1 || HW < 1) return ALIGNQ_EINVAL;
+int alignq_bn_partial_stats_nhwc(const float* z, int B, int C, int HW, void* ws, void* stream) {
+  if (!z || !ws || B < 1 || C < 1 || HW < 1) return ALIGNQ_EINVAL;
   if (!nhwc_channels_ok(C) || (reinterpret_cast<uintptr_t>(z) & 15)) return ALIGNQ_EUNSUPPORTED;
-  const int64_t npix = (int64_t)B * HW;
-  int grid = (int)((npix + 127) / 128);          // >= 128 pixels per block; a multiple of 32 so the ticket wraps cleanly
-  grid = (grid + 31) / 32 * 32;
-  if (grid > 256) grid = 256;
-  hipLaunchKernelGGL(bn_stats_nhwc_kernel, grid, kNhwcThreads, 0, (hipStream_t)stream, z, B, C, HW, (double*)ws, ticket,
-                     gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, momentum, eps, ab, save);
+  hipLaunchKernelGGL(bn_stats_nhwc_kernel, kNhwcParts, kNhwcThreads, 0, (hipStream_t)stream, z, B, C, HW, (double*)ws);
   LAUNCH_CHECK();
   return 0;
 }
@@ -297,12 +296,14 @@ int alignq_bn_stats_nhwc(const float* z, int B, int C, int HW, const float* gamm
 int alignq_bn_bwd_apply(const float* dx, const float* z, const float* ab, const float* save, const float* dx_part, int B,
                         int C, int HW, int nhwc, float* dz, float* dgamma, float* dbeta, void* stream) {
   if (!dx || !z || !ab || !save || !dx_part || !dz || B < 1 || C < 1) return ALIGNQ_EINVAL;
-  if (nhwc) {     // dx_part is ktot [2][C] here; dgamma / dbeta were written by the site backward already
+  if (nhwc) {
     if (!nhwc_channels_ok(C)) return ALIGNQ_EUNSUPPORTED;
-    const int64_t nvec = (int64_t)B * C * HW / 4;
-    const int64_t blocks = (nvec + kNhwcThreads * 4 - 1) / (kNhwcThreads * 4);
-    hipLaunchKernelGGL(bn_bwd_apply_nhwc_kernel, (unsigned)blocks, kNhwcThreads, 0, (hipStream_t)stream, dx, z, ab, save,
-                       dx_part, nvec, C, dz);
+    const int64_t F = (int64_t)C * HW;
+    const int tf = alignq_site::bwd_tile_features(B, F);
+    if (F % tf) return ALIGNQ_EUNSUPPORTED;
+    const int n_tiles = (int)(F / tf);
+    hipLaunchKernelGGL(bn_bwd_apply_nhwc_kernel, 128, kNhwcThreads, 0, (hipStream_t)stream, dx, z, ab, save, dx_part, n_tiles,
+                       tf, B, C, HW, dz, dgamma, dbeta);
     LAUNCH_CHECK();
     return 0;
   }

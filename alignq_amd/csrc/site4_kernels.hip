@@ -167,8 +167,49 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
     if (bn.ab && bn.nhwc) {
       // channels-last: the float4 at column `col` covers channels (col mod C) .. +3 (C % 4 == 0); a, b are inputs
       const int ch = col & (bn.C - 1);
-      const float4 a4 = *reinterpret_cast<const float4*>(bn.ab + ch);
-      const float4 b4 = *reinterpret_cast<const float4*>(bn.ab + bn.C + ch);
+      float4 a4, b4;
+      if (bn.part) {
+        // finalise the batch statistics of this tile's channels here (saves a launch and a grid-wide hand-off): wave w
+        // reduces the kNhwcParts partials of channel chbase + w (+16, ...) with a fixed butterfly
+        const int C = bn.C;
+        const int nch = C < TFv ? C : TFv;
+        const int chbase = col0 & (C - 1);
+        for (int cl = w; cl < nch; cl += 16) {
+          const int cc = chbase + cl;
+          double sa = bn.part[((int64_t)cc * kNhwcParts + lane) * 2];
+          double sq = bn.part[((int64_t)cc * kNhwcParts + lane) * 2 + 1];
+          sa = wave_sum_d(sa);
+          sq = wave_sum_d(sq);
+          if (lane == 0) {
+            const double n = (double)B * (double)bn.HW;
+            const double mean = sa / n;
+            double var = sq / n - mean * mean;
+            if (var < 0) var = 0;
+            const float invstd = (float)(1.0 / sqrt(var + (double)bn.bn_eps));
+            const float av = (bn.gamma ? bn.gamma[cc] : 1.0f) * invstd;
+            const float bv = (bn.beta ? bn.beta[cc] : 0.0f) - (float)mean * av;
+            colv[cl] = av;
+            colv[TFv + cl] = bv;
+            if (col0 < C) {                  // the tiles of the first pixel cover every channel exactly once: they publish
+              float* abo = const_cast<float*>(bn.ab);
+              float* svo = const_cast<float*>(bn.save);
+              abo[cc] = av; abo[C + cc] = bv;
+              svo[cc] = (float)mean; svo[C + cc] = invstd;
+              if (bn.running_mean) bn.running_mean[cc] = (1.0f - bn.momentum) * bn.running_mean[cc] + bn.momentum * (float)mean;
+              if (bn.running_var) bn.running_var[cc] = (1.0f - bn.momentum) * bn.running_var[cc] + bn.momentum * (float)(var * n / (n - 1.0));
+              if (cc == 0 && bn.nbt) *bn.nbt += 1;
+            }
+          }
+        }
+        __syncthreads();
+        const int jl = (4 * c) & (nch - 1);                // this thread's columns -> local channel index
+        a4 = *reinterpret_cast<const float4*>(colv + jl);
+        b4 = *reinterpret_cast<const float4*>(colv + TFv + jl);
+        __syncthreads();                     // colv is reused by the column statistics below
+      } else {
+        a4 = *reinterpret_cast<const float4*>(bn.ab + ch);
+        b4 = *reinterpret_cast<const float4*>(bn.ab + bn.C + ch);
+      }
 #pragma unroll
       for (int j = 0; j < RJ; j++) {
         if (rg + RG * j < B && col < F) {
@@ -1000,8 +1041,7 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
     }
     __syncthreads();
     if (BN && bn.nhwc) {
-      // per-tile, per-channel partial sums -> scratch (write-through), then the last workgroup (ticket) reduces all
-      // tiles in fixed order into per-channel totals: no extra launch, deterministic
+      // per-tile, per-channel partial sums [n_tiles][min(C,TF)][2]; alignq_bn_bwd_apply (nhwc) reduces them per channel
       const int C = bn.C;
       const int cp = C < TFv ? C : TFv;                      // distinct channels in a tile
       if (tid < cp) {
@@ -1010,47 +1050,8 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
 #pragma unroll
           for (int q = 0; q < 8; q++) { t0 += red[(2 * q) * TFv + j]; t1 += red[(2 * q + 1) * TFv + j]; }
         }
-        float* dst = bn.dx_part + ((int64_t)tile * cp + tid) * 2;
-        __hip_atomic_store(dst, t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(dst + 1, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      __syncthreads();
-      unsigned* flag = reinterpret_cast<unsigned*>(red);     // red's readers are past the barrier above
-      if (tid == 0) {
-        const unsigned tk = __hip_atomic_fetch_add(bn.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *flag = ((tk % gridDim.x) == gridDim.x - 1) ? 1u : 0u;
-      }
-      __syncthreads();
-      if (*flag) {
-        constexpr int NTBv = TFv * 8;
-        double* dsm = reinterpret_cast<double*>(Os);         // [NTBv][2] doubles (<= 8 KB of the 33 KB staging tile)
-        const int groups = NTBv / C > 0 ? NTBv / C : 1;
-        const int c = tid % C, grp = tid / C;
-        const int cyc = C > TFv ? C / TFv : 1;               // a channel recurs every `cyc` tiles (C > TF) or in every tile
-        const int cnt = n_tiles / cyc;
-        const int e = C > TFv ? c % TFv : c, t_first = C > TFv ? c / TFv : 0;
-        double s0 = 0, s1 = 0;
-        if (grp < groups) {
-#pragma unroll 8
-          for (int i = grp; i < cnt; i += groups) {
-            const float* src = bn.dx_part + ((int64_t)(i * cyc + t_first) * cp + e) * 2;
-            s0 += __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s1 += __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
-        dsm[2 * tid] = s0;
-        dsm[2 * tid + 1] = s1;
-        __syncthreads();
-        if (grp == 0) {
-          double t0 = 0, t1 = 0;
-          for (int g = 0; g < groups; g++) { t0 += dsm[2 * (g * C + c)]; t1 += dsm[2 * (g * C + c) + 1]; }
-          const double n = (double)B * (double)bn.HW;
-          bn.ktot[c] = (float)(t0 / n);
-          bn.ktot[C + c] = (float)(t1 / n);
-          if (bn.dbeta) bn.dbeta[c] = (float)t0;
-          if (bn.dgamma) bn.dgamma[c] = (float)t1;
-        }
+        bn.dx_part[((int64_t)tile * cp + tid) * 2] = t0;
+        bn.dx_part[((int64_t)tile * cp + tid) * 2 + 1] = t1;
       }
     } else if (BN && tid == 0) {
       float t0 = 0.f, t1 = 0.f;

@@ -14,6 +14,7 @@ constexpr int kTailFloats = kPartFloats + 16;
 // Optional batch-norm fold: the site kernels read the CONV output z and apply x = a[c]*z + b[c] on load
 // (c = feature / HW), a = gamma*invstd, b = beta - mean*a; ab == nullptr means the input already is x.
 constexpr int kBnSplit = 16;   // batch splits per channel in bn_stats (partials per channel)
+constexpr int kNhwcParts = 64; // channels-last statistics: partials per channel (one per workgroup of the statistics kernel)
 
 struct BnFold {
   const float* ab;      // [2][C]: a then b.  Forward with `part`: OUTPUT (written by the first tile of each channel)
@@ -33,16 +34,11 @@ struct BnFold {
   const float* res;     // forward: optional residual (shortcut) added to x_q before the ReLU, same [B,F] layout
   float* dres;          // backward: optional output, the upstream gradient after the ReLU mask (= gradient of `res`)
   int nhwc;             // 0: z is [B,C,HW] (channel = f / HW);  1: channels-last [B,HW,C] (channel = f mod C, C a power of
-                        // two <= 256): `ab` is always an input then (alignq_bn_stats_nhwc finalises); backward: dx_part is
-                        // scratch [n_tiles][min(C,TF)][2] and the workgroup drawing the last ticket reduces it to
-  float* ktot;          //   ktot [2][C] = {sum dx, sum dx*zhat} / (B*HW),
-  float* dgamma;        //   dgamma [C] (may be nullptr),
-  float* dbeta;         //   dbeta [C] (may be nullptr);
-  unsigned* ticket;     //   persistent counter, zero before its first use, only ever incremented
+                        // two in [4,256]): forward `part` is [C][kNhwcParts][2]; backward dx_part is [n_tiles][min(C,TF)][2]
 };
 inline BnFold no_bn() {
   return BnFold{nullptr, nullptr, 1, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0,
-                nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
+                nullptr, nullptr, 0};
 }
 
 // Features per tile of the B in (64,128] backward kernel (also the granularity of BnFold::dx_part).

@@ -557,7 +557,6 @@ int alignq_site_partials_bn(const float* z, const void* bn_part, const float* bn
   if (!z || !ab || !save || !ws) return ALIGNQ_EINVAL;
   if (bad_k(k)) return ALIGNQ_EINVAL;
   if (!bn_shape_ok(B, F, C, HW, nhwc)) return ALIGNQ_EUNSUPPORTED;
-  if (nhwc && bn_part) return ALIGNQ_EINVAL;      // channels-last: alignq_bn_stats_nhwc has finalised ab / save already
   BnFold bn = no_bn();
   bn.ab = ab; bn.save = save; bn.HW = HW; bn.C = C; bn.nhwc = nhwc;
   bn.part = (const double*)bn_part; bn.gamma = bn_gamma; bn.beta = bn_beta;
@@ -572,14 +571,12 @@ size_t alignq_site_bn_part_bytes(int64_t F, int nhwc) {
 
 int alignq_site_bwd_apply_bn(const float* g, const float* S, const float* z, const float* ab, const float* save, int C,
                              int HW, int nhwc, const float* y_relu, float* dresidual, const float* stats, int B, int64_t F,
-                             float act_range, float eps, float* dx, float* dx_part, float* ktot, float* bn_dgamma,
-                             float* bn_dbeta, unsigned* ticket, void* stream) {
+                             float act_range, float eps, float* dx, float* dx_part, void* stream) {
   if (!S || !z || !ab || !save || !stats || !dx || !dx_part) return ALIGNQ_EINVAL;
-  if (nhwc && (!ktot || !ticket)) return ALIGNQ_EINVAL;
   if (!bn_shape_ok(B, F, C, HW, nhwc)) return ALIGNQ_EUNSUPPORTED;
   BnFold bn = no_bn();
   bn.ab = ab; bn.save = save; bn.HW = HW; bn.C = C; bn.nhwc = nhwc;
-  bn.ktot = ktot; bn.dgamma = bn_dgamma; bn.dbeta = bn_dbeta; bn.ticket = ticket; bn.dx_part = dx_part; bn.y = y_relu; bn.dres = dresidual;
+  bn.dx_part = dx_part; bn.y = y_relu; bn.dres = dresidual;
   return launch_bwd4(true, geom(B, F), g, S, z, stats, B, F, act_range, eps, dx, (hipStream_t)stream, bn);
 }
 

@@ -204,7 +204,7 @@ class BNSiteFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, bn_weight, bn_bias, running_mean, running_var, nbt, momentum, bn_eps, alterD, gamma, k, act_range,
-                eps, mu, rho, relu, rec=None, res=None, ticket=None):
+                eps, mu, rho, relu, rec=None, res=None):
         z = L.dense_f32(z, "conv output")
         nhwc = not z.is_contiguous()             # dense_f32 only lets contiguous or channels-last 4-D tensors through
         if res is not None:
@@ -222,13 +222,8 @@ class BNSiteFn(torch.autograd.Function):
         ab = torch.empty(2, C, dtype=torch.float32, device=dev)
         save = torch.empty(2, C, dtype=torch.float32, device=dev)
         if nhwc:
-            # channels-last: statistics AND finalisation in one launch; the site kernel takes a/b as inputs
-            if ticket is None:
-                raise RuntimeError("channels-last BN fold needs the module's persistent ticket counter (use fused.bn_site)")
             ws_bn = torch.empty(lib.alignq_bn_nhwc_ws_bytes(C), dtype=torch.uint8, device=dev)
-            L.check(lib.alignq_bn_stats_nhwc(L.ptr(z), B, C, HW, L.ptr(bn_weight), L.ptr(bn_bias), L.ptr(running_mean),
-                                             L.ptr(running_var), L.ptr(nbt), float(momentum), float(bn_eps), L.ptr(ab),
-                                             L.ptr(save), L.ptr(ws_bn), L.ptr(ticket), st), "alignq_bn_stats_nhwc")
+            L.check(lib.alignq_bn_partial_stats_nhwc(L.ptr(z), B, C, HW, L.ptr(ws_bn), st), "alignq_bn_partial_stats_nhwc")
         else:
             ws_bn = torch.empty(lib.alignq_bn_ws_bytes(C), dtype=torch.uint8, device=dev)
             L.check(lib.alignq_bn_partial_stats(L.ptr(z), B, C, HW, L.ptr(ws_bn), st), "alignq_bn_partial_stats")
@@ -237,17 +232,11 @@ class BNSiteFn(torch.autograd.Function):
         stats = torch.empty(4, F, dtype=torch.float32, device=dev)
         scal = rec.scal if rec is not None else torch.empty(4, dtype=torch.float32, device=dev)
         ws = torch.empty(lib.alignq_site_ws_bytes(B, F), dtype=torch.uint8, device=dev)
-        if nhwc:
-            L.check(lib.alignq_site_partials_bn(L.ptr(z), None, None, None, None, None, None, 0.0, 0.0, L.ptr(ab),
-                                                L.ptr(save), C, HW, B, F, int(k), float(act_range), float(eps),
-                                                int(bool(relu)), L.ptr(res), 1, L.ptr(y), L.ptr(stats), L.ptr(ws), st),
-                    "alignq_site_partials_bn")
-        else:
-            L.check(lib.alignq_site_partials_bn(L.ptr(z), L.ptr(ws_bn), L.ptr(bn_weight), L.ptr(bn_bias),
-                                                L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt), float(momentum),
-                                                float(bn_eps), L.ptr(ab), L.ptr(save), C, HW, B, F, int(k),
-                                                float(act_range), float(eps), int(bool(relu)), L.ptr(res), 0, L.ptr(y),
-                                                L.ptr(stats), L.ptr(ws), st), "alignq_site_partials_bn")
+        L.check(lib.alignq_site_partials_bn(L.ptr(z), L.ptr(ws_bn), L.ptr(bn_weight), L.ptr(bn_bias), L.ptr(running_mean),
+                                            L.ptr(running_var), L.ptr(nbt), float(momentum), float(bn_eps), L.ptr(ab),
+                                            L.ptr(save), C, HW, B, F, int(k), float(act_range), float(eps),
+                                            int(bool(relu)), L.ptr(res), int(nhwc), L.ptr(y), L.ptr(stats), L.ptr(ws), st),
+                "alignq_site_partials_bn")
         if rec is not None:      # reduced with all other sites in DeferredLosses.total()
             rec.ws, rec.D, rec.A, rec.Gm, rec.B, rec.F, rec.dim = ws, D, A, Gm, B, F, dim
             rec.mu, rec.rho = float(mu), float(rho)
@@ -255,7 +244,6 @@ class BNSiteFn(torch.autograd.Function):
             L.check(lib.alignq_site_reduce_loss(L.ptr(ws), B, F, L.ptr(D), L.ptr(A), L.ptr(Gm), dim, float(mu),
                                                 float(rho), L.ptr(scal), st), "alignq_site_reduce_loss")
         ctx.rec = rec
-        ctx.ticket = ticket
         ctx.save_for_backward(z, ab, save, stats, D, A, Gm, scal, y if relu else None)
         ctx.set_materialize_grads(False)
         ctx.cfg = (float(act_range), float(eps), float(mu), bn_weight is not None, bn_bias is not None, res is not None,
@@ -292,18 +280,15 @@ class BNSiteFn(torch.autograd.Function):
         dres = None
         if has_res and g_y is not None:
             dres = torch.empty_like(z) if y is not None else g_y
-        dgam = torch.empty(C, dtype=torch.float32, device=dev) if has_w else None
-        dbet = torch.empty(C, dtype=torch.float32, device=dev) if has_b else None
-        ktot = torch.empty(2, C, dtype=torch.float32, device=dev) if nhwc else None
-        ticket = ctx.ticket[1:] if nhwc else None          # second persistent counter of the module
         L.check(lib.alignq_site_bwd_apply_bn(L.ptr(g_y), L.ptr(S), L.ptr(z), L.ptr(ab), L.ptr(save), C, HW, nhwc, L.ptr(y),
                                              L.ptr(dres) if y is not None else None, L.ptr(stats), B, F, act_range, eps,
-                                             L.ptr(dx), L.ptr(part), L.ptr(ktot), L.ptr(dgam), L.ptr(dbet), L.ptr(ticket),
-                                             st), "alignq_site_bwd_apply_bn")
+                                             L.ptr(dx), L.ptr(part), st), "alignq_site_bwd_apply_bn")
         dz = torch.empty_like(z)
-        L.check(lib.alignq_bn_bwd_apply(L.ptr(dx), L.ptr(z), L.ptr(ab), L.ptr(save), L.ptr(ktot if nhwc else part), B, C, HW,
-                                        nhwc, L.ptr(dz), L.ptr(dgam), L.ptr(dbet), st), "alignq_bn_bwd_apply")
-        return (dz, dgam, dbet, None, None, None, None, None, dA, dG, None, None, None, None, None, None, None, dres, None)
+        dgam = torch.empty(C, dtype=torch.float32, device=dev) if has_w else None
+        dbet = torch.empty(C, dtype=torch.float32, device=dev) if has_b else None
+        L.check(lib.alignq_bn_bwd_apply(L.ptr(dx), L.ptr(z), L.ptr(ab), L.ptr(save), L.ptr(part), B, C, HW, nhwc, L.ptr(dz),
+                                        L.ptr(dgam), L.ptr(dbet), st), "alignq_bn_bwd_apply")
+        return (dz, dgam, dbet, None, None, None, None, None, dA, dG, None, None, None, None, None, None, None, dres)
 
 
 def _is_nhwc(z) -> bool:
@@ -338,18 +323,12 @@ def bn_site(bn, act, z, eps=0.0, relu=False, residual=None):
         if residual is not None:
             out = out + residual
         return (torch.nn.functional.relu(out) if relu else out), loss
-    ticket = None
-    if _is_nhwc(z):
-        ticket = getattr(bn, "_alignq_ticket", None)
-        if ticket is None or ticket.device != z.device:
-            ticket = torch.zeros(2, dtype=torch.int32, device=z.device)     # persistent {stats, backward} counters, only incremented
-            bn._alignq_ticket = ticket
     admm = act.opt
     deferred = active_deferred()
     rec = deferred.new_record(z.shape[0], z.device) if deferred is not None else None
     y, loss, D = BNSiteFn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
                                 bn.momentum, bn.eps, admm.alterD, admm.gamma, act.a_bit, config.args.act_range, eps,
-                                admm.mu, admm.rho, relu, rec, residual, ticket)
+                                admm.mu, admm.rho, relu, rec, residual)
     admm.D = D
     if deferred is not None:
         if rec is not None:

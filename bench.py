@@ -46,7 +46,9 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--no-fuse-bn", action="store_true", help="keep torch/MIOpen batch-norm instead of folding it into the ADMM-site kernels")
     ap.add_argument("--dp-selftest", action="store_true", help="run the DP path (RCCL all-reduce, two graphs) even at N=1")
-    ap.add_argument("--channels-last", action="store_true", help="NHWC activations/weights end to end")
+    ap.add_argument("--nchw", action="store_true",
+                    help="contiguous NCHW activations/weights instead of torch.channels_last (the default: MIOpen's NHWC "
+                         "kernels need no transposes; 2.22 vs 2.50 ms per step)")
     ap.add_argument("--no-miopen-find", action="store_true",
                     help="torch.backends.cudnn.benchmark=False: MIOpen's immediate-mode solver choice instead of its find "
                          "step for the (not ours) convolutions; find is on by default, it is worth ~2%% of a step")
@@ -67,10 +69,11 @@ def time_call(fn, reps, warm=3):
     return e0.elapsed_time(e1) * 1e-3 / reps
 
 
-def measure_kernels(dev, B, k, site_F_counts, hw_of_F, folded=True):
+def measure_kernels(dev, B, k, site_F_counts, hw_of_F, folded=True, nhwc=False):
     """Per-kernel live timings through the C ABI, HIP events on the launch stream.
     site_F_counts: {F: number of ADMM sites with F features}; hw_of_F: {F: H*W} (the channel size for the BN fold).
-    folded=True times the entry points the training step actually uses (batch-norm + ReLU folded into the site kernels)."""
+    folded=True times the entry points the training step actually uses (batch-norm + ReLU folded into the site kernels);
+    nhwc=True their channels-last forms (the [B,F] buffers are then read as [B,HW,C])."""
     from alignq_amd import _lib as L
     lib = L.load()
     st = L.stream_ptr()
@@ -96,17 +99,19 @@ def measure_kernels(dev, B, k, site_F_counts, hw_of_F, folded=True):
         rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
         nbt = torch.zeros((), dtype=torch.int64, device=dev)
         ab, save = torch.empty(2, C, device=dev), torch.empty(2, C, device=dev)
-        ws_bn = torch.empty(lib.alignq_bn_ws_bytes(C), dtype=torch.uint8, device=dev)
-        part = torch.empty(lib.alignq_site_bn_part_bytes(F, 0), dtype=torch.uint8, device=dev)
+        nh = int(bool(nhwc))
+        ws_bn = torch.empty(lib.alignq_bn_nhwc_ws_bytes(C) if nh else lib.alignq_bn_ws_bytes(C), dtype=torch.uint8, device=dev)
+        part = torch.empty(lib.alignq_site_bn_part_bytes(F, nh), dtype=torch.uint8, device=dev)
         dgam, dbet = torch.empty(C, device=dev), torch.empty(C, device=dev)
         p = L.ptr
         if folded:
-            f_stats = lambda: lib.alignq_bn_partial_stats(p(x), B, C, HW, p(ws_bn), st)
+            f_stats = ((lambda: lib.alignq_bn_partial_stats_nhwc(p(x), B, C, HW, p(ws_bn), st)) if nh else
+                       (lambda: lib.alignq_bn_partial_stats(p(x), B, C, HW, p(ws_bn), st)))
             f_part = lambda: lib.alignq_site_partials_bn(p(x), p(ws_bn), p(gam), p(bet), p(rm), p(rv), p(nbt), 0.1, 1e-5, p(ab),
-                                                         p(save), C, HW, B, F, k, 2.0, 0.0, 1, None, 0, p(xq), p(stats), p(ws), st)
-            f_bwd = lambda: lib.alignq_site_bwd_apply_bn(p(g), p(S), p(x), p(ab), p(save), C, HW, 0, p(xq), None, p(stats), B, F, 2.0,
-                                                         0.0, p(dx), p(part), None, None, None, None, st)
-            f_bnb = lambda: lib.alignq_bn_bwd_apply(p(dx), p(x), p(ab), p(save), p(part), B, C, HW, 0, p(dz), p(dgam), p(dbet), st)
+                                                         p(save), C, HW, B, F, k, 2.0, 0.0, 1, None, nh, p(xq), p(stats), p(ws), st)
+            f_bwd = lambda: lib.alignq_site_bwd_apply_bn(p(g), p(S), p(x), p(ab), p(save), C, HW, nh, p(xq), None, p(stats), B, F, 2.0,
+                                                         0.0, p(dx), p(part), st)
+            f_bnb = lambda: lib.alignq_bn_bwd_apply(p(dx), p(x), p(ab), p(save), p(part), B, C, HW, nh, p(dz), p(dgam), p(dbet), st)
         else:
             f_stats = None
             f_part = lambda: lib.alignq_site_partials(p(x), B, F, k, 2.0, 0.0, p(xq), p(stats), p(ws), st)
@@ -159,7 +164,7 @@ def measure_kernels(dev, B, k, site_F_counts, hw_of_F, folded=True):
     dom = max(("site_partials", "site_bwd"), key=lambda kname: per_step[kname][0])
     t_sum, fl_sum = per_step[dom]
     kernel_sym = {"site_partials": "site_fwd4_kernel<TF,true> (BN+ReLU folded)" if folded else "site_fwd4_kernel<TF,true>",
-                  "site_bwd": "site_bwd4_kernel<true,true> (BN+ReLU folded)" if folded else "site_bwd4_kernel<true,false>"}[dom]
+                  "site_bwd": "site_bwd4_kernel<TF,true,true> (BN+ReLU folded)" if folded else "site_bwd4_kernel<true,false>"}[dom]
     bytes_per_elem = 8.0 if dom == "site_partials" else 12.0          # fwd read x + write x_q; bwd read g,x + write dx
     by_sum = sum(bytes_per_elem * B * F * cnt for F, cnt in site_F_counts.items())
     traffic = None
@@ -273,15 +278,11 @@ def main():
         images_per_step = 2 * a.batch            # source + target images both pass through the network
     else:
         model = (resnet20_quant if a.model == "resnet20" else resnet56_quant)(a.bits, a.bits).to(dev).train()
-        if a.channels_last:
-            model = model.to(memory_format=torch.channels_last)
-        step = TrainStep(model, fuse_bn=not a.no_fuse_bn)
+        step = TrainStep(model, fuse_bn=not a.no_fuse_bn, channels_last=not a.nchw)
         if world > 1 or a.dp_selftest:
             dp.attach(step, force=a.dp_selftest)
         x = torch.randn(a.batch, 3, 32, 32, generator=gen).to(dev)
         y = torch.randint(0, 10, (a.batch,), generator=gen).to(dev)
-        if a.channels_last:
-            x = x.contiguous(memory_format=torch.channels_last)
         if a.no_graph:
             for _ in range(3):
                 step(x, y)
@@ -325,7 +326,8 @@ def main():
                                     f"(cdf_alignment_admm/resnet-20-cifar-10), batch {a.batch}/GPU, ")
                                    + f"{'HIP-graph replay' if not a.no_graph else 'eager launches'}"
                                    + ("" if (office or a.no_fuse_bn) else ", batch-norm folded into the site kernels")
-                                   + ("" if a.no_miopen_find else ", MIOpen find mode for the convolutions"),
+                                   + ("" if a.no_miopen_find else ", MIOpen find mode for the convolutions")
+                                   + ("" if (office or a.nchw) else ", channels-last tensors"),
                        "global_batch": a.batch * world, "parallelism": f"dp{world}",
                        "final_ce": float(ce.detach()), "final_trans_loss": float(tl.detach()) if tl is not None else None},
         }
@@ -337,7 +339,7 @@ def main():
             counts[8192] = 2 * units[1] + 1
             counts[4096] = 2 * units[2] + 1
             roof, kernels = measure_kernels(dev, a.batch, a.bits, counts, {16384: 1024, 8192: 256, 4096: 64},
-                                            folded=not a.no_fuse_bn)
+                                            folded=not a.no_fuse_bn, nhwc=not a.nchw)
             res["roofline"] = roof
             res["kernels"] = kernels
         if world == 1 and not a.no_cpu_baseline and not office:

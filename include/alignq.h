@@ -208,22 +208,16 @@ int alignq_site_prep_fused(const float* D, const float* alterD, const float* gam
                            void* stream);
 int alignq_site_bwd_apply_bn(const float* g, const float* S, const float* z, const float* ab, const float* save, int C,
                              int HW, int nhwc, const float* y_relu, float* dresidual, const float* stats, int B, int64_t F,
-                             float act_range, float eps, float* dx, float* dx_part, float* ktot, float* bn_dgamma,
-                             float* bn_dbeta, unsigned* ticket, void* stream);
+                             float act_range, float eps, float* dx, float* dx_part, void* stream);
 int alignq_bn_bwd_apply(const float* dx, const float* z, const float* ab, const float* save, const float* dx_part, int B,
                         int C, int HW, int nhwc, float* dz, float* dgamma, float* dbeta, void* stream);
 /* Channels-last (torch.channels_last, memory [B,H,W,C]) form of the fold, nhwc = 1 above: channel = f mod C with C a power
- * of two in [4,256].  alignq_bn_stats_nhwc computes AND finalises the batch statistics in one launch (ab, save, running
- * statistics; ws = alignq_bn_nhwc_ws_bytes(C)); `ticket` is a persistent device uint32 that the caller zeroes ONCE (it is
- * only incremented; one counter per launch site and grid size).  alignq_site_partials_bn is then called with bn_part = NULL
- * (ab / save are inputs).  alignq_site_bwd_apply_bn with nhwc = 1 uses dx_part (alignq_site_bn_part_bytes(F, 1)) as scratch
- * and its last workgroup (second persistent `ticket`) reduces it to ktot [2][C] = {sum dx, sum dx*zhat} / (B*HW) and writes
- * bn_dgamma / bn_dbeta (may be NULL); alignq_bn_bwd_apply with nhwc = 1 then takes ktot in place of dx_part and only
- * computes dz.  With nhwc = 0 ktot / bn_dgamma / bn_dbeta / ticket are ignored (pass NULL).                              */
+ * of two in [4,256], F % 64 == 0.  alignq_bn_partial_stats_nhwc writes 64 {sum, sum of squares} partials per channel into
+ * ws (alignq_bn_nhwc_ws_bytes(C)); alignq_site_partials_bn(bn_part = ws, nhwc = 1) finalises its tile's channels from
+ * them exactly as in the NCHW form.  The site backward leaves per-tile per-channel sums in dx_part
+ * (alignq_site_bn_part_bytes(F, 1)) and alignq_bn_bwd_apply(nhwc = 1) reduces them itself.                               */
 size_t alignq_bn_nhwc_ws_bytes(int C);
-int alignq_bn_stats_nhwc(const float* z, int B, int C, int HW, const float* gamma, const float* beta, float* running_mean,
-                         float* running_var, int64_t* num_batches_tracked, float momentum, float eps, float* ab,
-                         float* save, void* ws, unsigned* ticket, void* stream);
+int alignq_bn_partial_stats_nhwc(const float* z, int B, int C, int HW, void* ws, void* stream);
 
 #ifdef __cplusplus
 }

@@ -624,7 +624,7 @@ def test_bn_folded_site_channels_last_matches_nchw(dev, B, C, H, W, k, relu, res
         zz = z.clone(memory_format=fmt).requires_grad_(True)
         if nhwc:
             assert bn_site_fusable(bn, act, zz) and not zz.is_contiguous()
-            for _ in range(2):          # twice: the persistent ticket counter must survive re-use
+            for _ in range(2):          # twice: no state may leak between calls
                 bn.running_mean.zero_(); bn.running_var.fill_(1.0); bn.num_batches_tracked.zero_()
                 xq, loss = bn_site(bn, act, zz, relu=relu, residual=res)
             assert xq.is_contiguous(memory_format=torch.channels_last)

@@ -39,7 +39,7 @@ for (C, HW) in ((16, 1024), (32, 256), (64, 64)):
                                     k, 2.0, 0.0, 1, None, 0, p(xq), p(stats), p(ws), st)
         torch.cuda.synchronize()
         lib.alignq_site_bwd_apply_bn(p(g), p(S), p(z), p(ab), p(save), C, HW, 0, p(xq), None, p(stats), B, F, 2.0, 0.0, p(dx),
-                                     p(part), None, None, None, None, st)
+                                     p(part), st)
         torch.cuda.synchronize()
     buf = (ctypes.c_ulonglong * 64)()
     lib.alignq_debug_read_stamps(buf)
