@@ -169,18 +169,34 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
       const int ch = col & (bn.C - 1);
       float4 a4, b4;
       if (bn.part) {
+        {
         // finalise the batch statistics of this tile's channels here (saves a launch and a grid-wide hand-off): wave w
         // reduces the kNhwcParts partials of channel chbase + w (+16, ...) with a fixed butterfly
         const int C = bn.C;
         const int nch = C < TFv ? C : TFv;
         const int chbase = col0 & (C - 1);
-        for (int cl = w; cl < nch; cl += 16) {
-          const int cc = chbase + cl;
-          double sa = bn.part[((int64_t)cc * kNhwcParts + lane) * 2];
-          double sq = bn.part[((int64_t)cc * kNhwcParts + lane) * 2 + 1];
-          sa = wave_sum_d(sa);
-          sq = wave_sum_d(sq);
-          if (lane == 0) {
+        // two channels per wave and pass (w, w+16): independent load + butterfly chains interleave
+        // (the 64-feature tile runs at its 128-VGPR budget: one channel per pass there)
+        constexpr bool kPairCh = TFv < 64;
+        for (int cl0 = w; cl0 < nch; cl0 += kPairCh ? 32 : 16) {
+          const int cl1 = cl0 + 16;
+          const bool two = kPairCh && cl1 < nch;
+          const int c0 = chbase + cl0, c1 = chbase + (two ? cl1 : cl0);
+          double sa0 = bn.part[((int64_t)c0 * kNhwcParts + lane) * 2];
+          double sq0 = bn.part[((int64_t)c0 * kNhwcParts + lane) * 2 + 1];
+          double sa1 = 0, sq1 = 0;
+          if (kPairCh) {
+            sa1 = bn.part[((int64_t)c1 * kNhwcParts + lane) * 2];
+            sq1 = bn.part[((int64_t)c1 * kNhwcParts + lane) * 2 + 1];
+          }
+    #pragma unroll
+          for (int o = 32; o > 0; o >>= 1) {
+            sa0 += __shfl_xor(sa0, o, 64); sq0 += __shfl_xor(sq0, o, 64);
+            if (kPairCh) { sa1 += __shfl_xor(sa1, o, 64); sq1 += __shfl_xor(sq1, o, 64); }
+          }
+          if (lane < 2 && (lane == 0 || two)) {            // lane 0: channel c0, lane 1: channel c1
+            const int cl = lane ? cl1 : cl0, cc = lane ? c1 : c0;
+            const double sa = lane ? sa1 : sa0, sq = lane ? sq1 : sq0;
             const double n = (double)B * (double)bn.HW;
             const double mean = sa / n;
             double var = sq / n - mean * mean;
@@ -201,6 +217,8 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
             }
           }
         }
+        }
+        const int nch = bn.C < TFv ? bn.C : TFv;
         __syncthreads();
         const int jl = (4 * c) & (nch - 1);                // this thread's columns -> local channel index
         a4 = *reinterpret_cast<const float4*>(colv + jl);
