@@ -177,6 +177,66 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
     return ns
 
 
+def make_uniform_admm_namespace() -> types.SimpleNamespace:
+    """The paper's `use_cdf=False` ablation: cdf_alignment_admm/resnet-20-cifar-10/model/
+    quantization_uniform_admm.py — plain uniform quantisers with the ADMM loss still attached.
+
+    weight_quantize_fn.forward (:61-85): W_q = uniform_quantize(k)(W) (no CDF; only `.weight_q` is stored, plus
+    `.weight_cdf = x` for w_bit == 32).  activation_quantize_fn.forward (:88-139): x_q = uniform_quantize(k)(x) and, with
+    args.method containing 'ours' and a_bit < 32, D = corr(x,x) - corr(x,x) (zero wherever the correlation is finite, NaN
+    where a feature has zero batch variance, exactly like the reference) and trans_loss = admm(D).  The two corr terms are
+    the same tensor, so the reference's gradient of D w.r.t. x cancels term by term; D is detached here."""
+    base = make_namespace("admm")
+
+    class weight_quantize_fn(nn.Module):
+        def __init__(self, w_bit, stage):
+            super().__init__()
+            self.w_bit, self.stage = w_bit, stage
+            self.uniform_q = uniform_quantize(k=w_bit)
+
+        def forward(self, x):
+            if self.w_bit == 32:
+                self.weight_cdf = x
+                self.weight_q = x
+                return x
+            self.weight_q = self.uniform_q(x)
+            return self.weight_q
+
+    class activation_quantize_fn(nn.Module):
+        def __init__(self, a_bit, stage, admm):
+            super().__init__()
+            self.a_bit, self.stage = a_bit, stage
+            self.uniform_q = uniform_quantize(k=a_bit)
+            self.opt = admm
+
+        def forward(self, x):
+            if self.a_bit == 32 and self.stage != "align":
+                return x, 0
+            activation_q = self.uniform_q(x)
+            if "ours" in config.args.method and self.a_bit < 32:
+                G = ops.CorrFn.apply(x.detach(), 0.0)
+                trans_loss = self.opt(G - G)
+            else:
+                trans_loss = 0
+            return (x if self.a_bit == 32 else activation_q), trans_loss
+
+    def conv2d_Q_fn(w_bit, stage):
+        class Conv2d_Q(nn.Conv2d):
+            def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                         bias=True):
+                super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias)
+                self.quantize_fn = weight_quantize_fn(w_bit=w_bit, stage=stage)
+
+            def forward(self, input, order=None):
+                weight_q = self.quantize_fn(self.weight)
+                return F.conv2d(input, weight_q, self.bias, self.stride, self.padding, self.dilation, self.groups)
+
+        return Conv2d_Q
+
+    return types.SimpleNamespace(uniform_quantize=uniform_quantize, cdf=base.cdf, weight_quantize_fn=weight_quantize_fn,
+                                 activation_quantize_fn=activation_quantize_fn, corr=base.corr, conv2d_Q_fn=conv2d_Q_fn)
+
+
 class _AttachGrad(torch.autograd.Function):
     """y = value (precomputed by a kernel) with dy/dx = jac elementwise."""
 

@@ -115,6 +115,18 @@ class TrainStep:
         return self._static[2]
 
     # -------------------------------------------------------------------------------------------
+    def set_lr(self, lr):
+        """The reference steps a StepLR scheduler once per epoch (main.py:112,150).  Scalar hyper-parameters are baked into
+        a captured graph as kernel arguments, so a captured step is re-captured (no warm-up iterations: the model is not
+        touched) whenever the learning rate changes."""
+        changed = False
+        for g in self.optimizer_t.param_groups:
+            changed |= g["lr"] != lr
+            g["lr"] = lr
+        if changed and self._graph is not None:
+            self.capture(self._static[0], self._static[1], warmup=0)
+        return self
+
     def capture(self, x, y, warmup=3):
         """Capture the iteration into HIP graphs.  Runs `warmup` eager iterations first (they DO update
         the model, as real steps) so allocator pools, momentum buffers, pointer tables and MIOpen plans
@@ -205,9 +217,28 @@ class OfficeTrainStep:
                                  [q.gamma for q in a], [q.mu for q in a], [q.rho for q in a])
         return cls_s, loss, tl_s + tl_t
 
+    def new_epoch(self, epoch, num_epochs, lr, momentum=0.9, weight_decay=5e-4):
+        """dann_office/main.py:321-328: every epoch the reference builds a NEW SGD (so momentum buffers start from scratch)
+        with LEARNING_RATE = lr / (1 + 10 (epoch-1) / num_epochs)^0.75 for the two heads and a tenth of it for the feature
+        extractor.  A captured step is re-captured (graph kernel arguments hold the learning rates)."""
+        rate = lr / (1.0 + 10.0 * (epoch - 1) / num_epochs) ** 0.75
+        m = self.model
+        self.optimizer_t = SGD([{"params": list(m.feature.parameters())},
+                                {"params": list(m.class_classifier.parameters()), "lr": rate},
+                                {"params": list(m.domain_classifier.parameters()), "lr": rate}],
+                               lr=rate / 10, momentum=momentum, weight_decay=weight_decay)
+        if self._graph is not None:
+            # the first step of the epoch creates the fresh momentum buffers (buf = grad) and must not be the captured one
+            self._graph, self._recapture = None, True
+        return rate
+
     def __call__(self, xs, ys, xt):
         if self._graph is None:
-            return self._iteration(xs, ys, xt)
+            out = self._iteration(xs, ys, xt)
+            if getattr(self, "_recapture", False):
+                self._recapture = False
+                self.capture(xs, ys, xt, warmup=0)
+            return out
         for dst, src in zip(self._static[:3], (xs, ys, xt)):
             dst.copy_(src, non_blocking=True)
         self._graph.replay()

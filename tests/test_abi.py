@@ -49,7 +49,10 @@ def test_python_mirror_names_and_signatures():
     import alignq_amd.cdf_alignment as C
     import alignq_amd.cdf_alignment_admm as A
     import alignq_amd.office as Off
-    for ns in (C, A, Off):
+    import alignq_amd.uniform_admm as U          # the use_cdf=False ablation (quantization_uniform_admm.py)
+    assert hasattr(U, "corr")
+    assert list(inspect.signature(U.activation_quantize_fn.__init__).parameters)[1:] == ["a_bit", "stage", "admm"]
+    for ns in (C, A, Off, U):
         for name in ("uniform_quantize", "cdf", "weight_quantize_fn", "activation_quantize_fn", "conv2d_Q_fn", "ADMM",
                      "ADMM_OPT", "SGD"):
             assert hasattr(ns, name), (ns.__name__, name)

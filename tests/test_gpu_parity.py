@@ -655,3 +655,68 @@ def test_bn_folded_site_channels_last_matches_nchw(dev, B, C, H, W, k, relu, res
     if residual:
         assert (f["dres"] != u["dres"]).mean() < 1e-3
     config.args.bitW = config.args.abitW = 8
+
+
+@pytest.mark.parametrize("k", [2, 4, 8])
+def test_uniform_admm_ablation(dev, k):
+    """alignq_amd.uniform_admm (model/quantization_uniform_admm.py, the use_cdf=False ablation): plain uniform quantisers,
+    D = corr(x,x) - corr(x,x) == 0, trans_loss = admm(0); STE gradient; alterD / gamma receive the loss gradient."""
+    import alignq_amd.uniform_admm as U
+    from alignq_amd import config
+    import oracle.torch_ref as R
+    torch.manual_seed(k)
+    B = 64
+    x = torch.randn(B, 8, 6, 6, device=dev).requires_grad_(True)
+    admm = U.ADMM(B).to(dev)
+    act = U.activation_quantize_fn(k, "second", admm)
+    xq, loss = act(x)
+    g = torch.randn_like(xq)
+    (loss + (xq * g).sum()).backward()
+    n = 2 ** k - 1
+    ref_q = torch.round(x.detach().cpu() * n) / n              # IEEE division on the CPU (torch-GPU multiplies by a reciprocal)
+    assert bits_equal(npy(xq), npy(ref_q))
+    assert np.array_equal(npy(admm.D), np.zeros((B, B), np.float32))
+    A0, G0 = admm.alterD.detach().cpu().requires_grad_(True), admm.gamma.detach().cpu().requires_grad_(True)
+    ref_loss = R.admm_loss(torch.zeros(B, B), A0, G0, admm.mu, admm.rho)
+    ref_loss.backward()
+    np.testing.assert_allclose(float(loss.detach()), float(ref_loss.detach()), rtol=1e-6)
+    np.testing.assert_allclose(npy(admm.alterD.grad), A0.grad.numpy(), atol=1e-9, rtol=1e-5)
+    np.testing.assert_allclose(npy(admm.gamma.grad), G0.grad.numpy(), atol=1e-9, rtol=1e-5)
+    assert np.array_equal(npy(x.grad), npy(g))                     # pure straight-through
+    w = torch.randn(16, 8, 3, 3, device=dev) * 0.3
+    conv = U.conv2d_Q_fn(k, "second")(8, 16, 3, 1, 1, bias=False).to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(w)
+    conv(x.detach())
+    assert bits_equal(npy(conv.quantize_fn.weight_q), npy(torch.round(w.cpu() * n) / n))
+
+
+def test_set_lr_recaptures_graph(dev):
+    """TrainStep.set_lr on a captured step (the reference's per-epoch StepLR): the re-captured graph must use the new rate.
+    With lr = 0 no trainable tensor may move; alterD/gamma still follow their closed-form update."""
+    from alignq_amd import config
+    from alignq_amd.resnet import PreActBlock_conv_Q, PreActResNet
+    from alignq_amd.train_step import TrainStep
+    config.args.bitW = config.args.abitW = 4
+    config.args.train_batch_size = 16
+    try:
+        torch.manual_seed(2)
+        net = PreActResNet(PreActBlock_conv_Q, [1, 1, 1], 4, 4, "second", 10).to(dev).train()
+        x = torch.randn(16, 3, 32, 32, device=dev)
+        y = torch.randint(0, 10, (16,), device=dev)
+        step = TrainStep(net, lr=0.04, momentum=0.0, weight_decay=0.0).capture(x, y, warmup=2)
+        w0 = net.layers[0].conv0.weight.detach().clone()
+        step(x, y)
+        torch.cuda.synchronize()
+        assert not torch.equal(w0, net.layers[0].conv0.weight)
+        step.set_lr(0.0)
+        w1 = net.layers[0].conv0.weight.detach().clone()
+        a1 = net.layers[0].admm0.alterD.detach().clone()
+        step(x, y)
+        step(x, y)
+        torch.cuda.synchronize()
+        assert torch.equal(w1, net.layers[0].conv0.weight)
+        assert not torch.equal(a1, net.layers[0].admm0.alterD)
+    finally:
+        config.args.bitW = config.args.abitW = 8
+        config.args.train_batch_size = 128
