@@ -353,7 +353,31 @@ def gen_office():
     _save("g5_office_site", **out)
 
 
-GEN = {"admm_cifar": gen_admm_cifar, "cdf_only": gen_cdf_only, "office": gen_office}
+def gen_office_keys():
+    """state_dict key names / shapes and the SGD state_dict layout of the reference's ResNet-50-DANN (config 5): what a
+    checkpoint written by dann_office/main.py:165-183 contains (checkpoint-name compatibility)."""
+    import importlib
+    import torch
+    q, args = _enter("office", ["--bitW", "8", "--abitW", "8", "--train_batch_size", "28"])
+    r = importlib.import_module("model.resnet")
+    r.device = torch.device("cpu")
+    r.load_state_dict_from_url = lambda *a, **k: {}          # DANN defaults to pretrained=True (no network here)
+    torch.manual_seed(0)
+    net = r.resnet50_dann(wbit=8, abit=8, stage=args.stage)
+    sd = net.state_dict()
+    keys = list(sd.keys())
+    from utils.optimizer import SGD
+    opt = SGD([{"params": net.feature.parameters()},
+               {"params": net.class_classifier.parameters(), "lr": 0.01},
+               {"params": net.domain_classifier.parameters(), "lr": 0.01}], lr=0.001, momentum=0.9, weight_decay=5e-4)
+    osd = opt.state_dict()
+    _save("g9_office_state_keys", keys=np.array(keys), shapes=np.array([",".join(map(str, sd[k].shape)) for k in keys]),
+          named_parameters=np.array([n for n, _ in net.named_parameters()]),
+          sgd_group_sizes=np.array([len(g["params"]) for g in osd["param_groups"]]),
+          sgd_group_keys=np.array(sorted(osd["param_groups"][0].keys())), stage=np.array(str(args.stage)))
+
+
+GEN = {"admm_cifar": gen_admm_cifar, "cdf_only": gen_cdf_only, "office": gen_office, "office_keys": gen_office_keys}
 
 
 def main():

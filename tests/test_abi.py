@@ -93,3 +93,29 @@ def test_no_cpu_fallback():
     import alignq_amd.cdf_alignment_admm as A
     with pytest.raises(RuntimeError):
         A.weight_quantize_fn(8, "second")(torch.randn(4, 4))
+
+
+def test_office_model_and_optimizer_keep_reference_checkpoint_layout():
+    """Checkpoint compatibility for config 5: the state_dict keys / shapes of alignq_amd's ResNet-50-DANN
+    and the param-group layout of its SGD equal the reference's (fixture g9, captured from dann_office/model/resnet.py and
+    utils/optimizer.py), so `state_dict_t` / `optimizer_t` of a reference checkpoint (main.py:165-183) load unchanged."""
+    from alignq_amd import config
+    from alignq_amd.optimizer import SGD
+    from alignq_amd.resnet_office import resnet50_dann
+    from tests.conftest import load_golden
+    g = load_golden("g9_office_state_keys")
+    config.args.train_batch_size = 28
+    try:
+        net = resnet50_dann(8, 8, stage=str(g["stage"]))
+        sd = net.state_dict()
+        assert list(sd.keys()) == [str(k) for k in g["keys"]]
+        assert [",".join(map(str, v.shape)) for v in sd.values()] == [str(s) for s in g["shapes"]]
+        assert [n for n, _ in net.named_parameters()] == [str(n) for n in g["named_parameters"]]
+        opt = SGD([{"params": net.feature.parameters()},
+                   {"params": net.class_classifier.parameters(), "lr": 0.01},
+                   {"params": net.domain_classifier.parameters(), "lr": 0.01}], lr=0.001, momentum=0.9, weight_decay=5e-4)
+        osd = opt.state_dict()
+        assert [len(gr["params"]) for gr in osd["param_groups"]] == list(g["sgd_group_sizes"])
+        assert set(str(k) for k in g["sgd_group_keys"]) <= set(osd["param_groups"][0].keys())
+    finally:
+        config.args.train_batch_size = 128
