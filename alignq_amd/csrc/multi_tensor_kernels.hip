@@ -177,6 +177,25 @@ inline int blocks_for(long max_n) {
   return (int)(b > kMaxBlk ? kMaxBlk : b);
 }
 
+// ------------------------------------------------------------------------------------------ flat-bucket pack / unpack
+// Data-parallel bucket (alignq_amd/dp.py): gather T dense tensors into one flat buffer (dir 0) or scatter them back
+// (dir 1) in one launch per 48 tensors.  Storage order is copied as it lies (any dense layout: the all-reduce is
+// elementwise, every rank uses the same layouts).
+struct CChunk {
+  float* t[kChunk];
+  long off[kChunk];
+  long n[kChunk];
+};
+__global__ __launch_bounds__(kThreads) void mt_copy_kernel(CChunk c, float* __restrict__ flat, int dir) {
+  const int t = blockIdx.y;
+  float* __restrict__ x = c.t[t];
+  float* __restrict__ f = flat + c.off[t];
+  const long n = c.n[t];
+  for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
+    if (dir == 0) f[i] = x[i]; else x[i] = f[i];
+  }
+}
+
 }  // namespace
 
 #define LAUNCH_CHECK()                          \
@@ -269,6 +288,27 @@ int alignq_sgd_step_multi(int T, float* const* p, float* const* g, float* const*
     }
     dim3 grid(blocks_for(max_n), cnt);
     hipLaunchKernelGGL(mt_sgd_kernel, grid, kThreads, 0, st, c, lr, mom, damp, wd, nesterov, nlev, lam, lam2);
+    LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+int alignq_bucket_copy_multi(int T, float* const* tensors, const int64_t* n, float* flat, int unpack, void* stream) {
+  if (T <= 0 || !tensors || !n || !flat) return ALIGNQ_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  long off = 0;
+  for (int t0 = 0; t0 < T; t0 += kChunk) {
+    const int cnt = (T - t0 < kChunk) ? T - t0 : kChunk;
+    CChunk c;
+    long max_n = 0;
+    for (int i = 0; i < cnt; i++) {
+      if (!tensors[t0 + i] || n[t0 + i] <= 0) return ALIGNQ_EINVAL;
+      c.t[i] = tensors[t0 + i]; c.off[i] = off; c.n[i] = (long)n[t0 + i];
+      off += c.n[i];
+      if (c.n[i] > max_n) max_n = c.n[i];
+    }
+    dim3 grid(blocks_for(max_n), cnt);
+    hipLaunchKernelGGL(mt_copy_kernel, grid, kThreads, 0, st, c, flat, unpack ? 1 : 0);
     LAUNCH_CHECK();
   }
   return 0;

@@ -27,10 +27,24 @@ class FlatBucket:
             self.views.append(self.flat[off:off + n].view(s))
             off += n
 
+    @staticmethod
+    def _dense(t):
+        return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+
+    def _native(self, tensors, unpack):
+        """One HIP launch per 48 tensors (alignq_bucket_copy_multi): dense CUDA fp32 tensors are copied in storage order."""
+        from . import _lib as L
+        L.check(L.load().alignq_bucket_copy_multi(len(tensors), L.ptr_array(tensors), L.i64_array(self.numels),
+                                                  L.ptr(self.flat), int(unpack), L.stream_ptr()), "alignq_bucket_copy_multi")
+
     def pack(self, tensors: Sequence[torch.Tensor]):
+        if self.flat.is_cuda and all(t.is_cuda and t.dtype == torch.float32 and self._dense(t) for t in tensors):
+            return self._native(tensors, False)
         torch._foreach_copy_(self.views, [t.detach() for t in tensors])
 
     def unpack(self, tensors: Sequence[torch.Tensor]):
+        if self.flat.is_cuda and all(t.is_cuda and t.dtype == torch.float32 and self._dense(t) for t in tensors):
+            return self._native(tensors, True)
         torch._foreach_copy_([t.detach() for t in tensors], self.views)
 
 
@@ -52,18 +66,43 @@ class GradAndDAllReduce:
         self.force = force and dist.is_initialized()      # run the collective even at world size 1 (self-test)
         self.bucket = None
 
-    def __call__(self, _step=None):
-        if self.world == 1 and not self.force:
-            return
+    # The hook is three phases so that a captured TrainStep can keep pack / unpack INSIDE its two HIP graphs and leave only
+    # the collective itself eager (one RCCL launch between two graph launches per step).
+    def active(self) -> bool:
+        return self.world > 1 or self.force
+
+    def _tensors(self):
         grads = [p.grad for p in self.params if p.grad is not None]
         Ds = [d for d in self.get_Ds() if d is not None]
-        tensors = grads + Ds
+        return grads + Ds
+
+    def pack(self):
+        if not self.active():
+            return
+        tensors = self._tensors()
         if self.bucket is None:
             self.bucket = FlatBucket([t.shape for t in tensors], tensors[0].device)
         self.bucket.pack(tensors)
-        dist.all_reduce(self.bucket.flat, op=dist.ReduceOp.SUM, group=self.group)
-        self.bucket.flat.mul_(1.0 / self.world)
-        self.bucket.unpack(tensors)
+
+    def reduce(self):
+        if not self.active():
+            return
+        backend = dist.get_backend(self.group)
+        if backend == "nccl":        # RCCL averages in the collective itself: no separate scaling kernel
+            dist.all_reduce(self.bucket.flat, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(self.bucket.flat, op=dist.ReduceOp.SUM, group=self.group)
+            self.bucket.flat.mul_(1.0 / self.world)
+
+    def unpack(self):
+        if not self.active():
+            return
+        self.bucket.unpack(self._tensors())
+
+    def __call__(self, _step=None):
+        self.pack()
+        self.reduce()
+        self.unpack()
 
 
 def attach(train_step, group=None, force=False):

@@ -109,8 +109,9 @@ class TrainStep:
         sy.copy_(y, non_blocking=True)
         self._graph.replay()
         if self._graph2 is not None:
-            # data-parallel: the collective runs eagerly between the two captured halves
-            self.grad_hook(self)
+            # data-parallel: only the collective runs eagerly between the two captured halves (pack / unpack of the flat
+            # bucket are captured at the end of the first and the start of the second graph)
+            self.grad_hook.reduce() if hasattr(self.grad_hook, "reduce") else self.grad_hook(self)
             self._graph2.replay()
         return self._static[2]
 
@@ -153,10 +154,15 @@ class TrainStep:
             with torch.cuda.graph(graph):
                 outs = self._iteration(sx, sy, set_to_none=True)
         else:
+            phased = hasattr(self.grad_hook, "reduce")
             with torch.cuda.graph(graph):
                 outs = self._forward_backward(sx, sy, set_to_none=True)
+                if phased:
+                    self.grad_hook.pack()
             graph2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph2, pool=graph.pool()):
+                if phased:
+                    self.grad_hook.unpack()
                 self._optimizer_steps()
             self._graph2 = graph2
         self._graph = graph

@@ -176,6 +176,11 @@ int alignq_site_prep_fused_multi(int S, const float* const* D, const float* cons
                                  float mu, float* const* S_out, float* const* dalterD, float* const* dgamma,
                                  void* stream);
 
+/* ---- data-parallel flat bucket (ONE mean all-reduce per step over gradients + stacked D matrices):
+ * gather T dense device tensors (HOST array of pointers, element counts n[T]) into `flat` back to back (unpack = 0) or
+ * scatter them back (unpack = 1); one launch per 48 tensors instead of one copy kernel per tensor.                      */
+int alignq_bucket_copy_multi(int T, float* const* tensors, const int64_t* n, float* flat, int unpack, void* stream);
+
 /* ---- batch-norm (and the ReLU that follows) folded into the ADMM site (caller:
  * out, loss = act_q(bn(conv(x))); out = relu(out), cdf_alignment_admm/resnet-56-cifar-10/model/resnet.py:87-94) ----
  * Training-mode nn.BatchNorm2d semantics.  z = conv output [B,C,HW] (HW % 64 == 0, 64 < B <= 128 for the folded site

@@ -720,3 +720,26 @@ def test_set_lr_recaptures_graph(dev):
     finally:
         config.args.bitW = config.args.abitW = 8
         config.args.train_batch_size = 128
+
+
+def test_flat_bucket_native_pack_unpack(dev):
+    """dp.FlatBucket on the GPU: one multi-tensor launch each way; dense tensors of any layout round-trip bit-exactly and
+    the packed image is the storage order of each tensor (what the elementwise all-reduce needs)."""
+    from alignq_amd.dp import FlatBucket
+    torch.manual_seed(0)
+    ts = [torch.randn(16, 8, 3, 3, device=dev).contiguous(memory_format=torch.channels_last), torch.randn(7, device=dev),
+          torch.randn(128, 128, device=dev), torch.randn(64, 16, 1, 1, device=dev)] + [torch.randn(5, 3, device=dev)
+                                                                                    for _ in range(60)]
+    b = FlatBucket([t.shape for t in ts], dev)
+    b.pack(ts)
+    off = 0
+    for t in ts[:3]:
+        n = t.numel()
+        raw = torch.as_strided(t, (n,), (1,))          # storage order
+        assert torch.equal(b.flat[off:off + n], raw)
+        off += n
+    b.flat.mul_(2.0)
+    want = [t.clone() * 2.0 for t in ts]
+    b.unpack(ts)
+    for t, w in zip(ts, want):
+        assert torch.equal(t, w)
