@@ -255,3 +255,53 @@ class SiteFn(torch.autograd.Function):
                                           L.ptr(g_loss), L.ptr(x), L.ptr(stats), B, F, act_range, eps, L.ptr(dx),
                                           L.ptr(dA), L.ptr(dG), L.ptr(ws), L.stream_ptr()), "alignq_site_bwd_fused")
         return dx, dA, dG, None, None, None, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------ R9 (Conv2d_Q's conv)
+def qconv3x3_supported(x, w, stride, padding, dilation, groups, bias, w_bit) -> bool:
+    """Shapes alignq_conv3x3_nhwc implements: channels-last fp32, 3x3 / stride 1 / padding 1, C_in == C_out in {16,32,64}
+    at width 32 / 16 / 8 (the ResNet-20/56 body), a <= 8-bit quantised filter.  Everything else stays on MIOpen."""
+    if bias is not None or groups != 1 or not (1 <= w_bit <= 8):
+        return False
+    if tuple(stride) != (1, 1) or tuple(padding) != (1, 1) or tuple(dilation) != (1, 1):
+        return False
+    if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and w.dtype == torch.float32):
+        return False
+    B, C, H, W = x.shape
+    if tuple(w.shape) != (C, C, 3, 3) or (C, W) not in ((16, 32), (32, 16), (64, 8)):
+        return False
+    if H % (128 // W if C < 64 else 4):
+        return False
+    cl = torch.channels_last
+    return (x.is_contiguous(memory_format=cl) and not x.is_contiguous()) and w.is_contiguous(memory_format=cl)
+
+
+class QConv3x3Fn(torch.autograd.Function):
+    """F.conv2d(input, weight_q, None, 1, 1) of Conv2d_Q.forward (model/quantization.py:149-154) on the bf16 matrix cores
+    with exact products (integer filter bins x three-way split activations, see csrc/conv_kernels.hip).  The data gradient
+    is the same kernel on the flipped / transposed filter; the filter gradient stays on MIOpen."""
+
+    @staticmethod
+    def forward(ctx, x, w, w_bit):
+        B, C, H, W = x.shape
+        y = torch.empty_like(x)
+        L.check(L.load().alignq_conv3x3_nhwc(L.ptr(x), L.ptr(w), L.ptr(y), B, H, W, C, int(w_bit), 0, L.stream_ptr()),
+                "alignq_conv3x3_nhwc")
+        ctx.save_for_backward(x, w)
+        ctx.w_bit = int(w_bit)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        B, C, H, W = x.shape
+        gy = L.like_layout(gy, x)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            L.check(L.load().alignq_conv3x3_nhwc(L.ptr(gy), L.ptr(w), L.ptr(dx), B, H, W, C, ctx.w_bit, 1, L.stream_ptr()),
+                    "alignq_conv3x3_nhwc")
+        if ctx.needs_input_grad[1]:
+            dw = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                     [False, True, False])[1]
+        return dx, dw, None

@@ -155,6 +155,11 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
 
             def forward(self, input, order=None):
                 weight_q = self.quantize_fn(self.weight)
+                # opt-in (TrainStep(channels_last=True) sets use_qconv): the 3x3 body convolutions on the matrix cores
+                if getattr(self, "use_qconv", False) and ops.qconv3x3_supported(
+                        input, weight_q, self.stride, self.padding, self.dilation, self.groups, self.bias,
+                        self.quantize_fn.w_bit):
+                    return ops.QConv3x3Fn.apply(input, weight_q, self.quantize_fn.w_bit)
                 return F.conv2d(input, weight_q, self.bias, self.stride, self.padding, self.dilation, self.groups)
 
         return Conv2d_Q

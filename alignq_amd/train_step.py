@@ -19,13 +19,17 @@ from .optimizer import ADMM_OPT, SGD
 
 class TrainStep:
     def __init__(self, model, lr=0.04, momentum=0.9, weight_decay=1e-4, grad_hook=None, defer_losses=True, fuse_bn=True,
-                 channels_last=False):
+                 channels_last=False, qconv=True):
         """channels_last: keep activations and conv weights in torch.channels_last memory (values, parameter names and
         state_dict are unchanged).  MIOpen's NHWC convolution kernels need no layout transposes around the weight-gradient
         igemm (2.22 vs 2.50 ms per ResNet-20 step on MI355X); the quantise / Gram / ADMM kernels are layout-agnostic and the
         BN fold has a channels-last form."""
         if channels_last:
             model = model.to(memory_format=torch.channels_last)
+            if qconv:    # Conv2d_Q's 3x3 body convolutions (forward + data gradient) on the matrix cores, exact products
+                for m in model.modules():
+                    if hasattr(m, "quantize_fn"):
+                        m.use_qconv = True
         self.channels_last = channels_last
         self.model = model
         if fuse_bn:      # fold BN into the site kernels where shapes allow (training, 64 < batch <= 128); no-op otherwise

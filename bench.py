@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--no-fuse-bn", action="store_true", help="keep torch/MIOpen batch-norm instead of folding it into the ADMM-site kernels")
     ap.add_argument("--dp-selftest", action="store_true", help="run the DP path (RCCL all-reduce, two graphs) even at N=1")
+    ap.add_argument("--no-qconv", action="store_true", help="keep MIOpen for every convolution (default: Conv2d_Q's 3x3 "
+                    "stride-1 body convolutions, forward and data gradient, run on alignq_conv3x3_nhwc)")
     ap.add_argument("--nchw", action="store_true",
                     help="contiguous NCHW activations/weights instead of torch.channels_last (the default: MIOpen's NHWC "
                          "kernels need no transposes; 2.22 vs 2.50 ms per step)")
@@ -278,7 +280,7 @@ def main():
         images_per_step = 2 * a.batch            # source + target images both pass through the network
     else:
         model = (resnet20_quant if a.model == "resnet20" else resnet56_quant)(a.bits, a.bits).to(dev).train()
-        step = TrainStep(model, fuse_bn=not a.no_fuse_bn, channels_last=not a.nchw)
+        step = TrainStep(model, fuse_bn=not a.no_fuse_bn, channels_last=not a.nchw, qconv=not a.no_qconv)
         if world > 1 or a.dp_selftest:
             dp.attach(step, force=a.dp_selftest)
         x = torch.randn(a.batch, 3, 32, 32, generator=gen).to(dev)

@@ -176,6 +176,18 @@ int alignq_site_prep_fused_multi(int S, const float* const* D, const float* cons
                                  float mu, float* const* S_out, float* const* dalterD, float* const* dgamma,
                                  void* stream);
 
+/* ---- Conv2d_Q's convolution on the matrix cores (model/quantization.py:149-154: F.conv2d(input, weight_q, bias, stride,
+ * padding, dilation, groups)) for the ResNet-20/56 body: 3x3, stride 1, padding 1, groups 1, no bias, C_in == C_out == C,
+ * channels-last fp32 tensors x [B,H,W,C], wt [C,3,3,C] (torch.channels_last storage of a [C,C,3,3] weight), y [B,H,W,C].
+ * wt MUST be weight_quantize_fn's output for w_bit <= 8, i.e. values b / (2^w_bit - 1) with integer |b| <= 2^w_bit - 1
+ * (both trees' formulas give that): the kernel multiplies the exact integers b on the bf16 matrix pipe with an exact
+ * three-way bf16 split of the fp32 activations and divides by 2^w_bit - 1 at the end, so products are exact and only fp32
+ * accumulation error remains.  Supported (C, W): (16, 32), (32, 16), (64, 8), H a multiple or divisor of the tile rows;
+ * anything else returns ALIGNQ_EUNSUPPORTED and the caller keeps MIOpen.
+ * dgrad = 0: y = conv(x, wt);  dgrad = 1: x is dy and y receives dx (the same kernel on the flipped, transposed filter). */
+int alignq_conv3x3_nhwc(const float* x, const float* wt, float* y, int B, int H, int W, int C, int w_bit, int dgrad,
+                        void* stream);
+
 /* ---- data-parallel flat bucket (ONE mean all-reduce per step over gradients + stacked D matrices):
  * gather T dense device tensors (HOST array of pointers, element counts n[T]) into `flat` back to back (unpack = 0) or
  * scatter them back (unpack = 1); one launch per 48 tensors instead of one copy kernel per tensor.                      */

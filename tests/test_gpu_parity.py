@@ -743,3 +743,32 @@ def test_flat_bucket_native_pack_unpack(dev):
     b.unpack(ts)
     for t, w in zip(ts, want):
         assert torch.equal(t, w)
+
+
+@pytest.mark.parametrize("B,C,H,k", [(128, 16, 32, 8), (128, 32, 16, 4), (128, 64, 8, 8), (3, 16, 32, 2), (5, 64, 8, 1),
+                                     (2, 32, 16, 8)])
+def test_qconv3x3_matches_fp64_convolution(dev, B, C, H, k):
+    """alignq_conv3x3_nhwc (Conv2d_Q's F.conv2d for the ResNet body) forward and data gradient against an fp64 convolution of
+    the same fp32 inputs: exact products, so the error is fp32 accumulation error only — required here to stay below the
+    error of MIOpen's own fp32 convolution on the same data (+ a small floor)."""
+    from alignq_amd import ops
+    torch.manual_seed(C + B + k)
+    n = 2 ** k - 1
+    cl = torch.channels_last
+    x = (torch.randn(B, C, H, H, device=dev) * 1.3).contiguous(memory_format=cl).requires_grad_(True)
+    wq = (torch.round(torch.tanh(torch.randn(C, C, 3, 3)) * n) / n).to(dev).contiguous(memory_format=cl).requires_grad_(True)
+    assert ops.qconv3x3_supported(x, wq, (1, 1), (1, 1), (1, 1), 1, None, k)
+    y = ops.QConv3x3Fn.apply(x, wq, k)
+    assert y.is_contiguous(memory_format=cl)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    xd, wd = x.detach().double().requires_grad_(True), wq.detach().double().requires_grad_(True)
+    yd = torch.nn.functional.conv2d(xd, wd, padding=1)
+    yd.backward(gy.double())
+    y32 = torch.nn.functional.conv2d(x.detach(), wq.detach(), padding=1)
+    floor = 2e-6 * float(yd.abs().max())
+    assert float((y.detach() - yd).abs().max()) <= max(float((y32 - yd).abs().max()), floor)
+    dx32 = torch.nn.grad.conv2d_input(x.shape, wq.detach(), gy, padding=1)
+    floor = 2e-6 * float(xd.grad.abs().max())
+    assert float((x.grad - xd.grad).abs().max()) <= max(float((dx32 - xd.grad).abs().max()), floor)
+    np.testing.assert_allclose(npy(wq.grad), wd.grad.float().cpu().numpy(), rtol=2e-4, atol=1e-3 * float(wd.grad.abs().max()))
