@@ -155,6 +155,252 @@ int launch(const float* x, const float* w, float* y, int B, int H, int dgrad, fl
   return e == hipSuccess ? 0 : (int)e;
 }
 
+// =====================================================================================================================
+// Filter gradient of the same convolution:  dW[co][tap][ci] = sum_pixels dy[p][co] * x[p + shift(tap)][ci].
+// The reduction runs over PIXELS, so MFMA's k index is the pixel.  With the f32 MFMAs (v_mfma_f32_16x16x4_f32 /
+// v_mfma_f32_32x32x2_f32) every lane feeds ONE element per operand, A[m = co][k = pixel] and B[k = pixel][n = ci], which
+// is exactly how the channels-last tiles lie in LDS (a pixel's channels are contiguous: conflict-free 4-byte reads, any
+// tap shift is just an address) - no transposed staging, no operand splitting, products and accumulation are plain fp32
+// (bit-for-bit an fmaf chain).  The f32 matrix rate (157 TF) bounds the kernel at 3.8 us per layer.
+// Workgroup = (pixel range, 32x32 block of (co, ci)) [16x16 for C = 16]; its four waves split the tile's pixels and keep
+// 9 accumulators (one per tap) across the workgroup's whole tile loop; one tree reduction through LDS at the end, then a
+// partial-sum slab [C][9][C] per pixel range; wgrad_reduce_kernel sums the slabs in fixed order (deterministic).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int C, int WD, int PT>
+__global__ __launch_bounds__(256) void wgrad3x3_nhwc_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            float* __restrict__ slabs, int H, int n_tiles) {
+  constexpr int TR = PT / WD;
+  constexpr int CB = C >= 32 ? 32 : 16;          // channel block (both co and ci)
+  constexpr int NBLK = C / CB;                   // blocks per side
+  constexpr int LW = WD + 2;
+  constexpr int XT = (TR + 2) * LW * CB;         // floats: x tile with halo, this block's input channels
+  constexpr int DT = TR * WD * CB;               // floats: dy tile, this block's output channels
+  constexpr int KPS = CB == 32 ? 2 : 4;          // pixels per MFMA step
+  constexpr int ACC = CB == 32 ? 16 : 4;         // accumulator registers per tap
+  constexpr int RED = 2 * 9 * CB * CB;           // floats: reduction buffer for two waves
+  constexpr int LDSF = (XT + DT) > RED ? (XT + DT) : RED;
+  __shared__ __attribute__((aligned(16))) float lds[LDSF];
+  float* Xs = lds;
+  float* Ds = lds + XT;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int bi = blockIdx.y / NBLK, bj = blockIdx.y % NBLK;      // (co block, ci block)
+  const int mrow = CB == 32 ? (lane & 31) : (lane & 15);
+  const int kq = CB == 32 ? (lane >> 5) : (lane >> 4);
+
+  float acc[9][ACC];
+#pragma unroll
+  for (int t = 0; t < 9; t++)
+#pragma unroll
+    for (int e = 0; e < ACC; e++) acc[t][e] = 0.f;
+
+  // Software pipeline over the workgroup's tiles: the NEXT tile's global loads (clamped addresses, all in flight) are
+  // issued into registers before the MFMA phase of the current tile and parked in LDS after it.
+  constexpr int C4 = CB / 4;
+  constexpr int N4 = (TR + 2) * LW * C4;           // float4 slots of the x tile with halo
+  constexpr int M4 = TR * WD * C4;                 // float4 slots of the dy tile
+  constexpr int NIX = (N4 + 255) / 256, NID = (M4 + 255) / 256;
+  f32x4 rx[NIX], rd[NID];     // plain vector registers (HIP's float4 struct here ends up in scratch)
+  // (fetch / park are spelled out twice below rather than hidden in a lambda or macro: the register arrays must be indexed
+  // by unrolled constants or they end up in scratch)
+  int nxt = blockIdx.x;
+  if (nxt < n_tiles) {
+    const int row0_ = nxt * TR;
+    const int img_lo_ = (row0_ / H) * H, img_hi_ = img_lo_ + H;
+#pragma unroll
+    for (int it = 0; it < NIX; it++) {
+      const int i = tid + 256 * it;
+      const int c4 = i % C4, col = (i / C4) % LW, lr = i / (C4 * LW);
+      const int grow = row0_ + lr - 1;
+      const bool ok = i < N4 && col >= 1 && col <= WD && grow >= img_lo_ && grow < img_hi_;
+      const int64_t off = ok ? ((int64_t)grow * WD + (col - 1)) * C + bj * CB + 4 * c4 : 0;
+      rx[it] = *reinterpret_cast<const f32x4*>(x + off);
+      if (!ok) rx[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int it = 0; it < NID; it++) {
+      const int i = tid + 256 * it;
+      const int64_t off = i < M4 ? ((int64_t)row0_ * WD + i / C4) * C + bi * CB + 4 * (i % C4) : 0;
+      rd[it] = *reinterpret_cast<const f32x4*>(dy + off);
+    }
+  }
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    __syncthreads();                               // previous tile's readers are done
+#pragma unroll
+    for (int it = 0; it < NIX; it++) {             // park the fetched tile in LDS
+      const int i = tid + 256 * it;
+      if (i < N4) {
+        const int c4 = i % C4, col = (i / C4) % LW, lr = i / (C4 * LW);
+        *reinterpret_cast<f32x4*>(Xs + (lr * LW + col) * CB + 4 * c4) = rx[it];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NID; it++) {
+      const int i = tid + 256 * it;
+      if (i < M4) *reinterpret_cast<f32x4*>(Ds + (i / C4) * CB + 4 * (i % C4)) = rd[it];
+    }
+    __syncthreads();
+    nxt = tile + gridDim.x;
+    if (nxt < n_tiles) {                           // next tile's loads fly under this tile's MFMA phase
+      const int row0_ = nxt * TR;
+      const int img_lo_ = (row0_ / H) * H, img_hi_ = img_lo_ + H;
+#pragma unroll
+      for (int it = 0; it < NIX; it++) {
+        const int i = tid + 256 * it;
+        const int c4 = i % C4, col = (i / C4) % LW, lr = i / (C4 * LW);
+        const int grow = row0_ + lr - 1;
+        const bool ok = i < N4 && col >= 1 && col <= WD && grow >= img_lo_ && grow < img_hi_;
+        const int64_t off = ok ? ((int64_t)grow * WD + (col - 1)) * C + bj * CB + 4 * c4 : 0;
+        rx[it] = *reinterpret_cast<const f32x4*>(x + off);
+        if (!ok) rx[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int it = 0; it < NID; it++) {
+        const int i = tid + 256 * it;
+        const int64_t off = i < M4 ? ((int64_t)row0_ * WD + i / C4) * C + bi * CB + 4 * (i % C4) : 0;
+        rd[it] = *reinterpret_cast<const f32x4*>(dy + off);
+      }
+    }
+    // this wave's pixels: PT / 4 consecutive pixels, KPS per step (a step never crosses a row: WD % 4 == 0)
+    constexpr int PW = PT / 4;
+#pragma unroll 2
+    for (int s = 0; s < PW / KPS; s++) {
+      const int pix = wv * PW + s * KPS + kq;
+      const int r = pix / WD, c = pix % WD;
+      const float a = Ds[pix * CB + mrow];
+      float b[9];
+#pragma unroll
+      for (int t = 0; t < 9; t++) b[t] = Xs[((r + t / 3) * LW + (c + t % 3)) * CB + mrow];
+#pragma unroll
+      for (int t = 0; t < 9; t++) {
+        if (CB == 32) {
+          f32x16 v;
+#pragma unroll
+          for (int e = 0; e < 16; e++) v[e] = acc[t][e];
+          v = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[t], v, 0, 0, 0);
+#pragma unroll
+          for (int e = 0; e < 16; e++) acc[t][e] = v[e];
+        } else {
+          f32x4 v = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
+          v = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[t], v, 0, 0, 0);
+          acc[t][0] = v[0]; acc[t][1] = v[1]; acc[t][2] = v[2]; acc[t][3] = v[3];
+        }
+      }
+    }
+  }
+  // ---- tree reduction over the four waves (fixed order): (2,3) -> LDS -> (0,1) += ; 1 -> LDS -> 0 += ; 0 writes the slab
+  // element e of tap t, lane l lives at red[w'][t][e][l] (lane fastest: conflict-free)
+  float* red = lds;
+  __syncthreads();
+  if (wv >= 2) {
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+      for (int e = 0; e < ACC; e++) red[(((wv - 2) * 9 + t) * ACC + e) * 64 + lane] = acc[t][e];
+  }
+  __syncthreads();
+  if (wv < 2) {
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+      for (int e = 0; e < ACC; e++) acc[t][e] += red[((wv * 9 + t) * ACC + e) * 64 + lane];
+  }
+  __syncthreads();
+  if (wv == 1) {
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+      for (int e = 0; e < ACC; e++) red[(t * ACC + e) * 64 + lane] = acc[t][e];
+  }
+  __syncthreads();
+  if (wv == 0) {
+    float* slab = slabs + (int64_t)blockIdx.x * (9 * C * C);
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+#pragma unroll
+      for (int e = 0; e < ACC; e++) {
+        const float v = acc[t][e] + red[(t * ACC + e) * 64 + lane];
+        // C/D layouts: 16x16: col = lane & 15 (ci), row = 4 (lane >> 4) + e (co);
+        //              32x32: col = lane & 31 (ci), row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5) (co)
+        const int ci = CB == 32 ? (lane & 31) : (lane & 15);
+        const int co = CB == 32 ? ((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) : (4 * (lane >> 4) + e);
+        slab[((int64_t)(bi * CB + co) * 9 + t) * C + bj * CB + ci] = v;
+      }
+    }
+  }
+}
+
+// dW[e] = sum over slabs, fixed order: 1024 threads = 64 elements x 16 slab groups
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ slabs, int n_slabs, int n_elem,
+                                                            float* __restrict__ dw) {
+  __shared__ float part[16][64];
+  const int l = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + l;
+  float s = 0.f;
+  if (e < n_elem) {
+#pragma unroll 8
+    for (int sl = sg; sl < n_slabs; sl += 16) s += slabs[(int64_t)sl * n_elem + e];
+  }
+  part[sg][l] = s;
+  __syncthreads();
+  if (sg == 0 && e < n_elem) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; g++) t += part[g][l];
+    dw[e] = t;
+  }
+}
+
+// the same reduction for up to 32 convolutions in ONE launch (blockIdx.y = tensor): a whole-model step defers all filter-
+// gradient reductions to the end of the backward (nothing reads a filter gradient before the optimizer step)
+constexpr int kWgMulti = 32;
+struct WgChunk {
+  const float* slabs[kWgMulti];
+  float* dw[kWgMulti];
+  int n_slabs[kWgMulti];
+  int n_elem[kWgMulti];
+};
+__global__ __launch_bounds__(1024) void wgrad_reduce_multi_kernel(WgChunk c) {
+  __shared__ float part[16][64];
+  const int t = blockIdx.y;
+  const int n_elem = c.n_elem[t], n_slabs = c.n_slabs[t];
+  if ((int)blockIdx.x * 64 >= n_elem) return;            // block-uniform
+  const float* __restrict__ slabs = c.slabs[t];
+  const int l = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + l;
+  float s = 0.f;
+  if (e < n_elem) {
+#pragma unroll 8
+    for (int sl = sg; sl < n_slabs; sl += 16) s += slabs[(int64_t)sl * n_elem + e];
+  }
+  part[sg][l] = s;
+  __syncthreads();
+  if (sg == 0 && e < n_elem) {
+    float tt = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; g++) tt += part[g][l];
+    c.dw[t][e] = tt;
+  }
+}
+
+template <int C, int WD, int PT>
+int launch_wgrad(const float* x, const float* dy, float* dw, float* ws, int B, int H, int* n_slabs_out, hipStream_t st) {
+  constexpr int TR = PT / WD;
+  if (H % TR) return ALIGNQ_EUNSUPPORTED;
+  const int n_tiles = B * H / TR;
+  constexpr int NB = (C >= 32 ? C / 32 : 1);
+  int splits = 256 / (NB * NB);                    // pixel ranges (= slabs): ~256 workgroups in total
+  if (splits > n_tiles) splits = n_tiles;
+  hipLaunchKernelGGL((wgrad3x3_nhwc_kernel<C, WD, PT>), dim3(splits, NB * NB), 256, 0, st, x, dy, ws, H, n_tiles);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  if (n_slabs_out) { *n_slabs_out = splits; return 0; }      // deferred: the caller reduces (alignq_conv3x3_wgrad_reduce_multi)
+  const int n_elem = 9 * C * C;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, (n_elem + 63) / 64, 1024, 0, st, ws, splits, n_elem, dw);
+  e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
 }  // namespace
 
 extern "C" {
@@ -173,6 +419,44 @@ int alignq_conv3x3_nhwc(const float* x, const float* wt, float* y, int B, int H,
   if (C == 32 && W == 16) return launch<32, 16, 128>(x, wt, y, B, H, dgrad, nlev, st);
   if (C == 64 && W == 8) return launch<64, 8, 32>(x, wt, y, B, H, dgrad, nlev, st);
   return ALIGNQ_EUNSUPPORTED;
+}
+
+size_t alignq_conv3x3_wgrad_ws_bytes(int C) { return (size_t)256 * 9 * (size_t)C * C * sizeof(float); }
+
+// dW[co,ky,kx,ci] = sum_{b,h,w} dy[b,h,w,co] * x[b,h+ky-1,w+kx-1,ci]; plain fp32 (v_mfma_f32_*_f32), deterministic.
+// n_slabs_out == NULL: partial sums + reduction (two launches), dw is complete on return.
+// n_slabs_out != NULL: partial sums only; *n_slabs_out receives the number of slabs left in ws for
+// alignq_conv3x3_wgrad_reduce_multi.
+int alignq_conv3x3_nhwc_wgrad(const float* x, const float* dy, float* dw, void* ws, int B, int H, int W, int C,
+                              int* n_slabs_out, void* stream) {
+  if (!x || !dy || !ws || B < 1 || H < 1 || (!dw && !n_slabs_out)) return ALIGNQ_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dw)) & 15) return ALIGNQ_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (C == 16 && W == 32) return launch_wgrad<16, 32, 128>(x, dy, dw, (float*)ws, B, H, n_slabs_out, st);
+  if (C == 32 && W == 16) return launch_wgrad<32, 16, 128>(x, dy, dw, (float*)ws, B, H, n_slabs_out, st);
+  if (C == 64 && W == 8) return launch_wgrad<64, 8, 64>(x, dy, dw, (float*)ws, B, H, n_slabs_out, st);
+  return ALIGNQ_EUNSUPPORTED;
+}
+
+int alignq_conv3x3_wgrad_reduce_multi(int T, const void* const* ws, float* const* dw, const int* n_slabs, const int* C,
+                                      void* stream) {
+  if (T <= 0 || !ws || !dw || !n_slabs || !C) return ALIGNQ_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  for (int t0 = 0; t0 < T; t0 += kWgMulti) {
+    const int cnt = (T - t0 < kWgMulti) ? T - t0 : kWgMulti;
+    WgChunk c;
+    int max_elem = 0;
+    for (int i = 0; i < cnt; i++) {
+      if (!ws[t0 + i] || !dw[t0 + i] || n_slabs[t0 + i] < 1 || C[t0 + i] < 1) return ALIGNQ_EINVAL;
+      c.slabs[i] = (const float*)ws[t0 + i]; c.dw[i] = dw[t0 + i]; c.n_slabs[i] = n_slabs[t0 + i];
+      c.n_elem[i] = 9 * C[t0 + i] * C[t0 + i];
+      if (c.n_elem[i] > max_elem) max_elem = c.n_elem[i];
+    }
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((max_elem + 63) / 64, cnt), 1024, 0, st, c);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+  }
+  return 0;
 }
 
 }  // extern "C"

@@ -186,6 +186,48 @@ class DeferredLosses:
         return parts[0] if len(parts) == 1 else parts[0] + parts[1]
 
 
+class DeferredWgrads:
+    """Collects the partial-sum slabs of ops.QConv3x3Fn's filter gradients during a backward and finishes all of them with
+    ONE alignq_conv3x3_wgrad_reduce_multi launch (`flush`).  Only valid when nothing reads a filter gradient before the
+    flush: the parameters' .grad must be None when backward runs (zero_grad(set_to_none=True)), so that autograd just
+    stores the not-yet-reduced tensor."""
+
+    def __init__(self):
+        self.items = []
+
+    def __enter__(self):
+        global _active_wgrads
+        self.items = []
+        _active_wgrads = self
+        return self
+
+    def __exit__(self, *exc):
+        global _active_wgrads
+        _active_wgrads = None
+        return False
+
+    def add(self, ws, dw, n_slabs, C):
+        self.items.append((ws, dw, int(n_slabs), int(C)))
+
+    def flush(self):
+        if not self.items:
+            return
+        import ctypes
+        T = len(self.items)
+        L.check(L.load().alignq_conv3x3_wgrad_reduce_multi(
+            T, L.ptr_array([i[0] for i in self.items]), L.ptr_array([i[1] for i in self.items]),
+            (ctypes.c_int * T)(*[i[2] for i in self.items]), (ctypes.c_int * T)(*[i[3] for i in self.items]),
+            L.stream_ptr()), "alignq_conv3x3_wgrad_reduce_multi")
+        self.items = []
+
+
+_active_wgrads = None
+
+
+def active_wgrads():
+    return _active_wgrads
+
+
 _active = None
 
 

@@ -279,7 +279,8 @@ def qconv3x3_supported(x, w, stride, padding, dilation, groups, bias, w_bit) -> 
 class QConv3x3Fn(torch.autograd.Function):
     """F.conv2d(input, weight_q, None, 1, 1) of Conv2d_Q.forward (model/quantization.py:149-154) on the bf16 matrix cores
     with exact products (integer filter bins x three-way split activations, see csrc/conv_kernels.hip).  The data gradient
-    is the same kernel on the flipped / transposed filter; the filter gradient stays on MIOpen."""
+    is the same kernel on the flipped / transposed filter; the filter gradient runs on the f32 MFMAs (plain fp32,
+    deterministic partial-sum slabs)."""
 
     @staticmethod
     def forward(ctx, x, w, w_bit):
@@ -302,6 +303,18 @@ class QConv3x3Fn(torch.autograd.Function):
             L.check(L.load().alignq_conv3x3_nhwc(L.ptr(gy), L.ptr(w), L.ptr(dx), B, H, W, C, ctx.w_bit, 1, L.stream_ptr()),
                     "alignq_conv3x3_nhwc")
         if ctx.needs_input_grad[1]:
-            dw = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                                                     [False, True, False])[1]
+            lib = L.load()
+            import ctypes
+            from . import fused
+            dw = torch.empty_like(w)          # channels-last [C,3,3,C] storage like w
+            ws = _ws(lib.alignq_conv3x3_wgrad_ws_bytes(C), x.device)
+            pending = fused.active_wgrads()
+            if pending is not None:           # whole-model step: all filter-gradient reductions in one launch at the end
+                ns = ctypes.c_int(0)
+                L.check(lib.alignq_conv3x3_nhwc_wgrad(L.ptr(x), L.ptr(gy), None, L.ptr(ws), B, H, W, C, ctypes.byref(ns),
+                                                      L.stream_ptr()), "alignq_conv3x3_nhwc_wgrad")
+                pending.add(ws, dw, ns.value, C)
+            else:
+                L.check(lib.alignq_conv3x3_nhwc_wgrad(L.ptr(x), L.ptr(gy), L.ptr(dw), L.ptr(ws), B, H, W, C, None,
+                                                      L.stream_ptr()), "alignq_conv3x3_nhwc_wgrad")
         return dx, dw, None

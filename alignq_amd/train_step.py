@@ -13,7 +13,7 @@ import torch
 import torch.nn.functional as F
 
 from . import config
-from .fused import DeferredLosses, prequantize_weights
+from .fused import DeferredLosses, DeferredWgrads, prequantize_weights
 from .optimizer import ADMM_OPT, SGD
 
 
@@ -31,6 +31,7 @@ class TrainStep:
                     if hasattr(m, "quantize_fn"):
                         m.use_qconv = True
         self.channels_last = channels_last
+        self._wgrads = DeferredWgrads() if (channels_last and qconv and torch.cuda.is_available()) else None
         self.model = model
         if fuse_bn:      # fold BN into the site kernels where shapes allow (training, 64 < batch <= 128); no-op otherwise
             for m in model.modules():
@@ -83,7 +84,12 @@ class TrainStep:
                 logits, trans_loss = out, None
         ce = F.cross_entropy(logits, y)
         total = ce if trans_loss is None else ce + trans_loss
-        total.backward()
+        if self._wgrads is not None and set_to_none:
+            with self._wgrads as wg:          # all filter-gradient slab reductions in one launch after the backward
+                total.backward()
+                wg.flush()
+        else:
+            total.backward()
         return logits, ce, trans_loss
 
     def _optimizer_steps(self):

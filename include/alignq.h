@@ -188,6 +188,17 @@ int alignq_site_prep_fused_multi(int S, const float* const* D, const float* cons
 int alignq_conv3x3_nhwc(const float* x, const float* wt, float* y, int B, int H, int W, int C, int w_bit, int dgrad,
                         void* stream);
 
+/* Filter gradient of the same convolution, dW [C,3,3,C] (channels-last weight storage) from x and dy: plain fp32 on the f32
+ * MFMAs (products and accumulation bit-for-bit an fmaf chain), per-pixel-range partial sums in ws
+ * (alignq_conv3x3_wgrad_ws_bytes(C)) reduced in fixed order by a second launch: deterministic, no zero-fill, no atomics.  */
+size_t alignq_conv3x3_wgrad_ws_bytes(int C);
+int alignq_conv3x3_nhwc_wgrad(const float* x, const float* dy, float* dw, void* ws, int B, int H, int W, int C,
+                              int* n_slabs_out, void* stream);
+/* n_slabs_out (HOST pointer) != NULL defers the reduction: only the partial sums are launched, *n_slabs_out receives the
+ * slab count, and ONE alignq_conv3x3_wgrad_reduce_multi launch later finishes T filters (HOST arrays ws / dw / n_slabs / C). */
+int alignq_conv3x3_wgrad_reduce_multi(int T, const void* const* ws, float* const* dw, const int* n_slabs, const int* C,
+                                      void* stream);
+
 /* ---- data-parallel flat bucket (ONE mean all-reduce per step over gradients + stacked D matrices):
  * gather T dense device tensors (HOST array of pointers, element counts n[T]) into `flat` back to back (unpack = 0) or
  * scatter them back (unpack = 1); one launch per 48 tensors instead of one copy kernel per tensor.                      */
