@@ -316,7 +316,7 @@ def main():
     if rank == 0:
         images = a.steps * images_per_step * world
         res = {
-            "metric": "images/sec (train step, CDF+ADMM) ResNet-20 8-bit" if a.model == "resnet20" else
+            "metric": "images/sec (train step, CDF+ADMM) ResNet-20 8-bit" if (a.model == "resnet20" and a.bits == 8) else
                       f"images/sec (train step, CDF+ADMM) {a.model} {a.bits}-bit",
             "value": images / elapsed, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -329,7 +329,9 @@ def main():
                                    + f"{'HIP-graph replay' if not a.no_graph else 'eager launches'}"
                                    + ("" if (office or a.no_fuse_bn) else ", batch-norm folded into the site kernels")
                                    + ("" if a.no_miopen_find else ", MIOpen find mode for the convolutions")
-                                   + ("" if (office or a.nchw) else ", channels-last tensors"),
+                                   + ("" if (office or a.nchw) else ", channels-last tensors")
+                                   + ("" if (office or a.nchw or a.no_qconv) else
+                                      ", Conv2d_Q 3x3 body convolutions on alignq_conv3x3_nhwc"),
                        "global_batch": a.batch * world, "parallelism": f"dp{world}",
                        "final_ce": float(ce.detach()), "final_trans_loss": float(tl.detach()) if tl is not None else None},
         }

@@ -22,7 +22,7 @@ def one(pattern):
 # ---- kernel stats -------------------------------------------------------------------------------------------------
 stats = one("stats/**/*kernel_stats.csv")
 with open(stats) as fi, open(os.path.join(out, "kernel_stats_train_step.csv"), "w") as fo:
-    fo.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-miopen-find   (MI355X; find mode off so that MIOpen trial kernels do not flood the table)\n")
+    fo.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline   (MI355X; rows of MIOpen kernels include its find-mode trials for the five convolutions that stay on MIOpen)\n")
     fo.write("# 3 eager warm-ups + HIP-graph capture + 33 replays of the ResNet-20 8W/8A CDF+ADMM step (batch 128), then bench.py's per-kernel\n")
     fo.write("# measurement loops (site kernels x ~55 launches per shape, act_quant / copy / add x 23 launches on 2^26 elements)\n")
     fo.write(fi.read())
