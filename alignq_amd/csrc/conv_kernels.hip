@@ -27,9 +27,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // C channels, WD image width, PT pixels per workgroup (TR = PT / WD whole image rows, TR divides H so a tile never straddles
 // two images).  LDS pixel stride is C + 8 bf16: the 16 lanes of a ds_read_b128 phase then hit 16 distinct 16-byte slots.
+template <int C, int WD, int PT>
+struct ConvLds {
+  static constexpr int kBf16 = 3 * ((PT / WD) + 2) * (WD + 2) * (C + 8);      // three bf16 images of the tile with halo
+};
+
 template <int C, int WD, int PT, bool DGRAD>
-__global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                           float* __restrict__ y, int H, int total_rows, float nlev) {
+__device__ __forceinline__ void conv3x3_body(const float* __restrict__ x, const float* __restrict__ w,
+                                             float* __restrict__ y, int H, int total_rows, float nlev, __bf16* lds,
+                                             int block) {
   constexpr int TR = PT / WD;                 // image rows per workgroup
   constexpr int NS = (9 * C + 31) / 32;       // k steps of 32
   constexpr int NCG = C / 16;                 // 16-channel output groups
@@ -39,13 +45,13 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const float* __restri
   constexpr int CP = C + 8;                   // padded pixel stride (bf16 elements)
   constexpr int LROWS = TR + 2;               // + halo row above / below
   constexpr int ARR = LROWS * LW * CP;        // bf16 elements per array
-  __shared__ __attribute__((aligned(16))) __bf16 lds[3 * ARR];
+  static_assert(3 * ARR == ConvLds<C, WD, PT>::kBf16, "LDS size");
   __bf16* Xhi = lds;
   __bf16* Xmi = lds + ARR;
   __bf16* Xlo = lds + 2 * ARR;
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int row0 = blockIdx.x * TR;           // first (image*H + h) row of this tile
+  const int row0 = block * TR;                // first (image*H + h) row of this tile
   const int img_lo = (row0 / H) * H, img_hi = img_lo + H;       // rows of the tile's image
   // ---- stage the input tile (+ halo) as three bf16 terms; padding and out-of-image rows are zeros --------------------
   {
@@ -143,6 +149,13 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const float* __restri
   }
 }
 
+template <int C, int WD, int PT, bool DGRAD>
+__global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           float* __restrict__ y, int H, int total_rows, float nlev) {
+  __shared__ __attribute__((aligned(16))) __bf16 lds[ConvLds<C, WD, PT>::kBf16];
+  conv3x3_body<C, WD, PT, DGRAD>(x, w, y, H, total_rows, nlev, lds, blockIdx.x);
+}
+
 template <int C, int WD, int PT>
 int launch(const float* x, const float* w, float* y, int B, int H, int dgrad, float nlev, hipStream_t st) {
   constexpr int TR = PT / WD;
@@ -168,8 +181,17 @@ int launch(const float* x, const float* w, float* y, int B, int H, int dgrad, fl
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int C, int WD, int PT>
-__global__ __launch_bounds__(256) void wgrad3x3_nhwc_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                            float* __restrict__ slabs, int H, int n_tiles) {
+struct WgradLds {
+  static constexpr int CB = C >= 32 ? 32 : 16;
+  static constexpr int XT = ((PT / WD) + 2) * (WD + 2) * CB, DT = PT * CB, RED = 2 * 9 * CB * CB;
+  static constexpr int kFloats = (XT + DT) > RED ? (XT + DT) : RED;
+};
+
+// bx / gx: index and count of the pixel-range workgroups, by: (co block, ci block) index
+template <int C, int WD, int PT>
+__device__ __forceinline__ void wgrad3x3_body(const float* __restrict__ x, const float* __restrict__ dy,
+                                              float* __restrict__ slabs, int H, int n_tiles, float* lds, int bx, int gx,
+                                              int by) {
   constexpr int TR = PT / WD;
   constexpr int CB = C >= 32 ? 32 : 16;          // channel block (both co and ci)
   constexpr int NBLK = C / CB;                   // blocks per side
@@ -180,11 +202,11 @@ __global__ __launch_bounds__(256) void wgrad3x3_nhwc_kernel(const float* __restr
   constexpr int ACC = CB == 32 ? 16 : 4;         // accumulator registers per tap
   constexpr int RED = 2 * 9 * CB * CB;           // floats: reduction buffer for two waves
   constexpr int LDSF = (XT + DT) > RED ? (XT + DT) : RED;
-  __shared__ __attribute__((aligned(16))) float lds[LDSF];
+  static_assert(LDSF == WgradLds<C, WD, PT>::kFloats, "LDS size");
   float* Xs = lds;
   float* Ds = lds + XT;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int bi = blockIdx.y / NBLK, bj = blockIdx.y % NBLK;      // (co block, ci block)
+  const int bi = by / NBLK, bj = by % NBLK;      // (co block, ci block)
   const int mrow = CB == 32 ? (lane & 31) : (lane & 15);
   const int kq = CB == 32 ? (lane >> 5) : (lane >> 4);
 
@@ -203,7 +225,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_nhwc_kernel(const float* __restr
   f32x4 rx[NIX], rd[NID];     // plain vector registers (HIP's float4 struct here ends up in scratch)
   // (fetch / park are spelled out twice below rather than hidden in a lambda or macro: the register arrays must be indexed
   // by unrolled constants or they end up in scratch)
-  int nxt = blockIdx.x;
+  int nxt = bx;
   if (nxt < n_tiles) {
     const int row0_ = nxt * TR;
     const int img_lo_ = (row0_ / H) * H, img_hi_ = img_lo_ + H;
@@ -224,7 +246,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_nhwc_kernel(const float* __restr
       rd[it] = *reinterpret_cast<const f32x4*>(dy + off);
     }
   }
-  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  for (int tile = bx; tile < n_tiles; tile += gx) {
     __syncthreads();                               // previous tile's readers are done
 #pragma unroll
     for (int it = 0; it < NIX; it++) {             // park the fetched tile in LDS
@@ -240,7 +262,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_nhwc_kernel(const float* __restr
       if (i < M4) *reinterpret_cast<f32x4*>(Ds + (i / C4) * CB + 4 * (i % C4)) = rd[it];
     }
     __syncthreads();
-    nxt = tile + gridDim.x;
+    nxt = tile + gx;
     if (nxt < n_tiles) {                           // next tile's loads fly under this tile's MFMA phase
       const int row0_ = nxt * TR;
       const int img_lo_ = (row0_ / H) * H, img_hi_ = img_lo_ + H;
@@ -314,7 +336,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_nhwc_kernel(const float* __restr
   }
   __syncthreads();
   if (wv == 0) {
-    float* slab = slabs + (int64_t)blockIdx.x * (9 * C * C);
+    float* slab = slabs + (int64_t)bx * (9 * C * C);
 #pragma unroll
     for (int t = 0; t < 9; t++) {
 #pragma unroll
@@ -327,6 +349,31 @@ __global__ __launch_bounds__(256) void wgrad3x3_nhwc_kernel(const float* __restr
         slab[((int64_t)(bi * CB + co) * 9 + t) * C + bj * CB + ci] = v;
       }
     }
+  }
+}
+
+template <int C, int WD, int PT>
+__global__ __launch_bounds__(256) void wgrad3x3_nhwc_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            float* __restrict__ slabs, int H, int n_tiles) {
+  __shared__ __attribute__((aligned(16))) float lds[WgradLds<C, WD, PT>::kFloats];
+  wgrad3x3_body<C, WD, PT>(x, dy, slabs, H, n_tiles, lds, blockIdx.x, gridDim.x, blockIdx.y);
+}
+
+// Backward of one convolution in ONE launch: the first n_wg workgroups take the filter-gradient role (the longer one, so
+// it starts first), the rest the data-gradient role; the two are independent and fill the chip together.
+template <int C, int WD, int PTD, int PTW>
+__global__ __launch_bounds__(256) void conv3x3_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          const float* __restrict__ w, float* __restrict__ dx,
+                                                          float* __restrict__ slabs, int H, int total_rows, float nlev,
+                                                          int n_tiles_w, int splits, int nblk2) {
+  constexpr int kBytesD = ConvLds<C, WD, PTD>::kBf16 * 2, kBytesW = WgradLds<C, WD, PTW>::kFloats * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kBytesD > kBytesW ? kBytesD : kBytesW];
+  const int n_wg = splits * nblk2;
+  if ((int)blockIdx.x < n_wg) {
+    wgrad3x3_body<C, WD, PTW>(x, dy, slabs, H, n_tiles_w, reinterpret_cast<float*>(lds), blockIdx.x % splits, splits,
+                              blockIdx.x / splits);
+  } else {
+    conv3x3_body<C, WD, PTD, true>(dy, w, dx, H, total_rows, nlev, reinterpret_cast<__bf16*>(lds), blockIdx.x - n_wg);
   }
 }
 
@@ -401,6 +448,25 @@ int launch_wgrad(const float* x, const float* dy, float* dw, float* ws, int B, i
   return e == hipSuccess ? 0 : (int)e;
 }
 
+template <int C, int WD, int PTD, int PTW>
+int launch_bwd(const float* x, const float* dy, const float* w, float* dx, float* ws, int B, int H, float nlev,
+               int* n_slabs_out, hipStream_t st) {
+  constexpr int TRD = PTD / WD, TRW = PTW / WD;
+  if (H % TRD || H % TRW) return ALIGNQ_EUNSUPPORTED;
+  const int total_rows = B * H;
+  const int n_tiles_w = total_rows / TRW;
+  constexpr int NB = (C >= 32 ? C / 32 : 1);
+  int splits = 256 / (NB * NB);
+  if (splits > n_tiles_w) splits = n_tiles_w;
+  const int grid = splits * NB * NB + total_rows / TRD;
+  hipLaunchKernelGGL((conv3x3_bwd_kernel<C, WD, PTD, PTW>), grid, 256, 0, st, x, dy, w, dx, ws, H, total_rows, nlev, n_tiles_w,
+                     splits, NB * NB);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  *n_slabs_out = splits;
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -457,6 +523,22 @@ int alignq_conv3x3_wgrad_reduce_multi(int T, const void* const* ws, float* const
     if (e != hipSuccess) return (int)e;
   }
   return 0;
+}
+
+// Both gradients of one convolution in a single launch (data gradient as alignq_conv3x3_nhwc(dgrad = 1), filter-gradient
+// partial sums as alignq_conv3x3_nhwc_wgrad with a deferred reduction: *n_slabs_out slabs are left in ws).
+int alignq_conv3x3_nhwc_bwd(const float* x, const float* dy, const float* wt, float* dx, void* ws, int B, int H, int W,
+                            int C, int w_bit, int* n_slabs_out, void* stream) {
+  if (!x || !dy || !wt || !dx || !ws || !n_slabs_out || B < 1 || H < 1) return ALIGNQ_EINVAL;
+  if (w_bit < 1 || w_bit > 8) return ALIGNQ_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(wt) |
+       reinterpret_cast<uintptr_t>(dx)) & 15) return ALIGNQ_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const float nlev = (float)((1 << w_bit) - 1);
+  if (C == 16 && W == 32) return launch_bwd<16, 32, 128, 128>(x, dy, wt, dx, (float*)ws, B, H, nlev, n_slabs_out, st);
+  if (C == 32 && W == 16) return launch_bwd<32, 16, 128, 128>(x, dy, wt, dx, (float*)ws, B, H, nlev, n_slabs_out, st);
+  if (C == 64 && W == 8) return launch_bwd<64, 8, 32, 64>(x, dy, wt, dx, (float*)ws, B, H, nlev, n_slabs_out, st);
+  return ALIGNQ_EUNSUPPORTED;
 }
 
 }  // extern "C"

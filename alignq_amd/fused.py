@@ -39,6 +39,11 @@ class WeightQuantAllFn(torch.autograd.Function):
         T = ctx.T
         ms, ws_ = ctx.saved_tensors[0], ctx.saved_tensors[1:]
         lib = L.load()
+        # the incoming W_q gradients of ops.QConv3x3Fn may still be partial-sum slabs: this node runs after every
+        # convolution's backward, so finish all of them here with one launch
+        pending = active_wgrads()
+        if pending is not None:
+            pending.flush()
         gs = [torch.zeros_like(w) if g is None else L.like_layout(g, w) for g, w in zip(grads[:T], ws_)]
         dws = [torch.empty_like(w) for w in ws_]
         scratch = torch.empty(lib.alignq_weight_multi_ws_bytes(T), dtype=torch.uint8, device=ws_[0].device)
@@ -188,9 +193,10 @@ class DeferredLosses:
 
 class DeferredWgrads:
     """Collects the partial-sum slabs of ops.QConv3x3Fn's filter gradients during a backward and finishes all of them with
-    ONE alignq_conv3x3_wgrad_reduce_multi launch (`flush`).  Only valid when nothing reads a filter gradient before the
-    flush: the parameters' .grad must be None when backward runs (zero_grad(set_to_none=True)), so that autograd just
-    stores the not-yet-reduced tensor."""
+    ONE alignq_conv3x3_wgrad_reduce_multi launch (`flush`).  The consumer of those gradients is the weight quantiser's
+    backward: WeightQuantAllFn.backward (all weights, runs after every convolution's backward) flushes before it reads them,
+    and so does the per-tensor ops.WeightQuantFn.backward.  Use only around a backward whose W_q gradients have no other
+    consumer (TrainStep)."""
 
     def __init__(self):
         self.items = []

@@ -106,6 +106,10 @@ class WeightQuantFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _gc, _gp):
         w, ms = ctx.saved_tensors
+        from . import fused
+        pending = fused.active_wgrads()
+        if pending is not None:      # g may still be partial-sum slabs of a deferred filter gradient
+            pending.flush()
         g = L.like_layout(g, w)
         lib = L.load()
         dw = torch.empty_like(w)
@@ -298,17 +302,28 @@ class QConv3x3Fn(torch.autograd.Function):
         B, C, H, W = x.shape
         gy = L.like_layout(gy, x)
         dx = dw = None
+        import ctypes
+        from . import fused
+        pending = fused.active_wgrads()
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and pending is not None:
+            # whole-model step: data gradient + filter-gradient partial sums in ONE launch; the slab reduction of all
+            # convolutions follows in one launch at the end of the backward (fused.DeferredWgrads.flush)
+            lib = L.load()
+            dx, dw = torch.empty_like(x), torch.empty_like(w)
+            ws = _ws(lib.alignq_conv3x3_wgrad_ws_bytes(C), x.device)
+            ns = ctypes.c_int(0)
+            L.check(lib.alignq_conv3x3_nhwc_bwd(L.ptr(x), L.ptr(gy), L.ptr(w), L.ptr(dx), L.ptr(ws), B, H, W, C, ctx.w_bit,
+                                                ctypes.byref(ns), L.stream_ptr()), "alignq_conv3x3_nhwc_bwd")
+            pending.add(ws, dw, ns.value, C)
+            return dx, dw, None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             L.check(L.load().alignq_conv3x3_nhwc(L.ptr(gy), L.ptr(w), L.ptr(dx), B, H, W, C, ctx.w_bit, 1, L.stream_ptr()),
                     "alignq_conv3x3_nhwc")
         if ctx.needs_input_grad[1]:
             lib = L.load()
-            import ctypes
-            from . import fused
             dw = torch.empty_like(w)          # channels-last [C,3,3,C] storage like w
             ws = _ws(lib.alignq_conv3x3_wgrad_ws_bytes(C), x.device)
-            pending = fused.active_wgrads()
             if pending is not None:           # whole-model step: all filter-gradient reductions in one launch at the end
                 ns = ctypes.c_int(0)
                 L.check(lib.alignq_conv3x3_nhwc_wgrad(L.ptr(x), L.ptr(gy), None, L.ptr(ws), B, H, W, C, ctypes.byref(ns),

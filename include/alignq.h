@@ -199,6 +199,11 @@ int alignq_conv3x3_nhwc_wgrad(const float* x, const float* dy, float* dw, void* 
 int alignq_conv3x3_wgrad_reduce_multi(int T, const void* const* ws, float* const* dw, const int* n_slabs, const int* C,
                                       void* stream);
 
+/* Data gradient AND filter-gradient partial sums of one convolution in a single launch (workgroup roles by block index; the
+ * two are independent and fill the chip together).  The slabs left in ws are finished by alignq_conv3x3_wgrad_reduce_multi. */
+int alignq_conv3x3_nhwc_bwd(const float* x, const float* dy, const float* wt, float* dx, void* ws, int B, int H, int W,
+                            int C, int w_bit, int* n_slabs_out, void* stream);
+
 /* ---- data-parallel flat bucket (ONE mean all-reduce per step over gradients + stacked D matrices):
  * gather T dense device tensors (HOST array of pointers, element counts n[T]) into `flat` back to back (unpack = 0) or
  * scatter them back (unpack = 1); one launch per 48 tensors instead of one copy kernel per tensor.                      */

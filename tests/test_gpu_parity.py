@@ -772,3 +772,66 @@ def test_qconv3x3_matches_fp64_convolution(dev, B, C, H, k):
     floor = 2e-6 * float(xd.grad.abs().max())
     assert float((x.grad - xd.grad).abs().max()) <= max(float((dx32 - xd.grad).abs().max()), floor)
     np.testing.assert_allclose(npy(wq.grad), wd.grad.float().cpu().numpy(), rtol=2e-4, atol=1e-3 * float(wd.grad.abs().max()))
+
+
+@pytest.mark.parametrize("B,C,H,k", [(128, 16, 32, 8), (128, 32, 16, 4), (128, 64, 8, 8), (4, 64, 8, 2)])
+def test_qconv3x3_fused_backward_matches_separate_launches(dev, B, C, H, k):
+    """alignq_conv3x3_nhwc_bwd (data gradient + filter-gradient slabs in one launch, reduction deferred to
+    fused.DeferredWgrads.flush) must reproduce the separate launches bit for bit (same device code per role)."""
+    from alignq_amd import ops
+    from alignq_amd.fused import DeferredWgrads
+    torch.manual_seed(C + B + k)
+    n = 2 ** k - 1
+    cl = torch.channels_last
+    x0 = (torch.randn(B, C, H, H, device=dev) * 1.3).contiguous(memory_format=cl)
+    w0 = (torch.round(torch.tanh(torch.randn(C, C, 3, 3)) * n) / n).to(dev).contiguous(memory_format=cl)
+    gy = torch.randn_like(x0)
+    res = []
+    for fused_mode in (False, True):
+        x, w = x0.clone(memory_format=cl).requires_grad_(True), w0.clone(memory_format=cl).requires_grad_(True)
+        if fused_mode:
+            # the consumer of a deferred filter gradient must flush before reading it (in a model that is the weight
+            # quantiser's backward); here a pass-through node plays that role
+            class Consumer(torch.autograd.Function):
+                @staticmethod
+                def forward(ctx, t):
+                    return t.view_as(t)
+
+                @staticmethod
+                def backward(ctx, g):
+                    from alignq_amd.fused import active_wgrads
+                    assert len(active_wgrads().items) == 1
+                    active_wgrads().flush()
+                    return g
+            with DeferredWgrads():
+                ops.QConv3x3Fn.apply(x, Consumer.apply(w), k).backward(gy)
+        else:
+            ops.QConv3x3Fn.apply(x, w, k).backward(gy)
+        res.append((npy(x.grad), npy(w.grad)))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
+def test_trainstep_gradients_with_own_convolutions_match_miopen(dev):
+    """Whole-step guard for the deferred filter-gradient reduction and the fused convolution backward: after one
+    forward+backward of the same model on the same batch, every parameter gradient of TrainStep(channels_last, qconv) must
+    point the same way as with MIOpen convolutions (cosine > 0.999; rounding-level differences and rare bin flips only)."""
+    from alignq_amd import config
+    from alignq_amd.resnet import PreActBlock_conv_Q, PreActResNet
+    from alignq_amd.train_step import TrainStep
+    config.args.bitW = config.args.abitW = 8
+    config.args.train_batch_size = 128
+    grads = []
+    x = torch.randn(128, 3, 32, 32, device=dev)
+    y = torch.randint(0, 10, (128,), device=dev)
+    for qconv in (False, True):
+        torch.manual_seed(3)
+        net = PreActResNet(PreActBlock_conv_Q, [1, 1, 1], 8, 8, "second", 10).to(dev).train()
+        step = TrainStep(net, channels_last=True, qconv=qconv)
+        step._forward_backward(x, y, set_to_none=True)
+        torch.cuda.synchronize()
+        grads.append({n: p.grad.detach().float().flatten().clone() for n, p in net.named_parameters() if p.grad is not None})
+    for n in grads[0]:
+        a, b = grads[0][n], grads[1][n]
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
+        assert cos > 0.999, (n, cos)
+        assert abs(float(a.norm() / (b.norm() + 1e-30)) - 1.0) < 0.02, n
