@@ -35,7 +35,7 @@ struct ConvLds {
 template <int C, int WD, int PT, bool DGRAD>
 __device__ __forceinline__ void conv3x3_body(const float* __restrict__ x, const float* __restrict__ w,
                                              float* __restrict__ y, int H, int total_rows, float nlev, __bf16* lds,
-                                             int block) {
+                                             int block, const float* __restrict__ add) {
   constexpr int TR = PT / WD;                 // image rows per workgroup
   constexpr int NS = (9 * C + 31) / 32;       // k steps of 32
   constexpr int NCG = C / 16;                 // 16-channel output groups
@@ -143,27 +143,34 @@ __device__ __forceinline__ void conv3x3_body(const float* __restrict__ x, const 
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[s], bh, acc, 0, 0, 0);
     }
     const int grow = row0 + r;
-    if (grow < total_rows)
-      *reinterpret_cast<float4*>(y + ((int64_t)grow * WD + c) * C + cog * 16 + 4 * q) =
-          make_float4(acc[0] / nlev, acc[1] / nlev, acc[2] / nlev, acc[3] / nlev);
+    if (grow < total_rows) {
+      const int64_t o = ((int64_t)grow * WD + c) * C + cog * 16 + 4 * q;
+      float4 v = make_float4(acc[0] / nlev, acc[1] / nlev, acc[2] / nlev, acc[3] / nlev);
+      if (add) {       // e.g. the identity shortcut's gradient joining the data gradient (saves an accumulation kernel)
+        const float4 r = *reinterpret_cast<const float4*>(add + o);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      }
+      *reinterpret_cast<float4*>(y + o) = v;
+    }
   }
 }
 
 template <int C, int WD, int PT, bool DGRAD>
 __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                           float* __restrict__ y, int H, int total_rows, float nlev) {
+                                                           float* __restrict__ y, int H, int total_rows, float nlev,
+                                                           const float* __restrict__ add) {
   __shared__ __attribute__((aligned(16))) __bf16 lds[ConvLds<C, WD, PT>::kBf16];
-  conv3x3_body<C, WD, PT, DGRAD>(x, w, y, H, total_rows, nlev, lds, blockIdx.x);
+  conv3x3_body<C, WD, PT, DGRAD>(x, w, y, H, total_rows, nlev, lds, blockIdx.x, add);
 }
 
 template <int C, int WD, int PT>
-int launch(const float* x, const float* w, float* y, int B, int H, int dgrad, float nlev, hipStream_t st) {
+int launch(const float* x, const float* w, float* y, int B, int H, int dgrad, float nlev, const float* add, hipStream_t st) {
   constexpr int TR = PT / WD;
   const int total_rows = B * H;
   if (H % TR) return ALIGNQ_EUNSUPPORTED;
   const int grid = total_rows / TR;
-  if (dgrad) hipLaunchKernelGGL((conv3x3_nhwc_kernel<C, WD, PT, true>), grid, 256, 0, st, x, w, y, H, total_rows, nlev);
-  else hipLaunchKernelGGL((conv3x3_nhwc_kernel<C, WD, PT, false>), grid, 256, 0, st, x, w, y, H, total_rows, nlev);
+  if (dgrad) hipLaunchKernelGGL((conv3x3_nhwc_kernel<C, WD, PT, true>), grid, 256, 0, st, x, w, y, H, total_rows, nlev, add);
+  else hipLaunchKernelGGL((conv3x3_nhwc_kernel<C, WD, PT, false>), grid, 256, 0, st, x, w, y, H, total_rows, nlev, add);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
@@ -365,7 +372,8 @@ template <int C, int WD, int PTD, int PTW>
 __global__ __launch_bounds__(256) void conv3x3_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                           const float* __restrict__ w, float* __restrict__ dx,
                                                           float* __restrict__ slabs, int H, int total_rows, float nlev,
-                                                          int n_tiles_w, int splits, int nblk2) {
+                                                          int n_tiles_w, int splits, int nblk2,
+                                                          const float* __restrict__ add) {
   constexpr int kBytesD = ConvLds<C, WD, PTD>::kBf16 * 2, kBytesW = WgradLds<C, WD, PTW>::kFloats * 4;
   __shared__ __attribute__((aligned(16))) unsigned char lds[kBytesD > kBytesW ? kBytesD : kBytesW];
   const int n_wg = splits * nblk2;
@@ -373,7 +381,7 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_kernel(const float* __restric
     wgrad3x3_body<C, WD, PTW>(x, dy, slabs, H, n_tiles_w, reinterpret_cast<float*>(lds), blockIdx.x % splits, splits,
                               blockIdx.x / splits);
   } else {
-    conv3x3_body<C, WD, PTD, true>(dy, w, dx, H, total_rows, nlev, reinterpret_cast<__bf16*>(lds), blockIdx.x - n_wg);
+    conv3x3_body<C, WD, PTD, true>(dy, w, dx, H, total_rows, nlev, reinterpret_cast<__bf16*>(lds), blockIdx.x - n_wg, add);
   }
 }
 
@@ -450,7 +458,7 @@ int launch_wgrad(const float* x, const float* dy, float* dw, float* ws, int B, i
 
 template <int C, int WD, int PTD, int PTW>
 int launch_bwd(const float* x, const float* dy, const float* w, float* dx, float* ws, int B, int H, float nlev,
-               int* n_slabs_out, hipStream_t st) {
+               int* n_slabs_out, const float* add, hipStream_t st) {
   constexpr int TRD = PTD / WD, TRW = PTW / WD;
   if (H % TRD || H % TRW) return ALIGNQ_EUNSUPPORTED;
   const int total_rows = B * H;
@@ -460,7 +468,7 @@ int launch_bwd(const float* x, const float* dy, const float* w, float* dx, float
   if (splits > n_tiles_w) splits = n_tiles_w;
   const int grid = splits * NB * NB + total_rows / TRD;
   hipLaunchKernelGGL((conv3x3_bwd_kernel<C, WD, PTD, PTW>), grid, 256, 0, st, x, dy, w, dx, ws, H, total_rows, nlev, n_tiles_w,
-                     splits, NB * NB);
+                     splits, NB * NB, add);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   *n_slabs_out = splits;
@@ -475,15 +483,15 @@ extern "C" {
 // dx[b,h,w,ci] = sum dy[b,h-ky+1,w-kx+1,co] * wt[co,ky,kx,ci] (dgrad = 1: x := dy)
 // wt must hold k-bit quantised values b / (2^k - 1), 1 <= k <= 8 (weight_quantize_fn's output).
 int alignq_conv3x3_nhwc(const float* x, const float* wt, float* y, int B, int H, int W, int C, int w_bit, int dgrad,
-                        void* stream) {
+                        const float* add, void* stream) {
   if (!x || !wt || !y || B < 1 || H < 1) return ALIGNQ_EINVAL;
   if (w_bit < 1 || w_bit > 8) return ALIGNQ_EUNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(wt) | reinterpret_cast<uintptr_t>(y)) & 15) return ALIGNQ_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const float nlev = (float)((1 << w_bit) - 1);
-  if (C == 16 && W == 32) return launch<16, 32, 128>(x, wt, y, B, H, dgrad, nlev, st);
-  if (C == 32 && W == 16) return launch<32, 16, 128>(x, wt, y, B, H, dgrad, nlev, st);
-  if (C == 64 && W == 8) return launch<64, 8, 32>(x, wt, y, B, H, dgrad, nlev, st);
+  if (C == 16 && W == 32) return launch<16, 32, 128>(x, wt, y, B, H, dgrad, nlev, add, st);
+  if (C == 32 && W == 16) return launch<32, 16, 128>(x, wt, y, B, H, dgrad, nlev, add, st);
+  if (C == 64 && W == 8) return launch<64, 8, 32>(x, wt, y, B, H, dgrad, nlev, add, st);
   return ALIGNQ_EUNSUPPORTED;
 }
 
@@ -528,16 +536,16 @@ int alignq_conv3x3_wgrad_reduce_multi(int T, const void* const* ws, float* const
 // Both gradients of one convolution in a single launch (data gradient as alignq_conv3x3_nhwc(dgrad = 1), filter-gradient
 // partial sums as alignq_conv3x3_nhwc_wgrad with a deferred reduction: *n_slabs_out slabs are left in ws).
 int alignq_conv3x3_nhwc_bwd(const float* x, const float* dy, const float* wt, float* dx, void* ws, int B, int H, int W,
-                            int C, int w_bit, int* n_slabs_out, void* stream) {
+                            int C, int w_bit, int* n_slabs_out, const float* add, void* stream) {
   if (!x || !dy || !wt || !dx || !ws || !n_slabs_out || B < 1 || H < 1) return ALIGNQ_EINVAL;
   if (w_bit < 1 || w_bit > 8) return ALIGNQ_EUNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(wt) |
        reinterpret_cast<uintptr_t>(dx)) & 15) return ALIGNQ_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const float nlev = (float)((1 << w_bit) - 1);
-  if (C == 16 && W == 32) return launch_bwd<16, 32, 128, 128>(x, dy, wt, dx, (float*)ws, B, H, nlev, n_slabs_out, st);
-  if (C == 32 && W == 16) return launch_bwd<32, 16, 128, 128>(x, dy, wt, dx, (float*)ws, B, H, nlev, n_slabs_out, st);
-  if (C == 64 && W == 8) return launch_bwd<64, 8, 32, 64>(x, dy, wt, dx, (float*)ws, B, H, nlev, n_slabs_out, st);
+  if (C == 16 && W == 32) return launch_bwd<16, 32, 128, 128>(x, dy, wt, dx, (float*)ws, B, H, nlev, n_slabs_out, add, st);
+  if (C == 32 && W == 16) return launch_bwd<32, 16, 128, 128>(x, dy, wt, dx, (float*)ws, B, H, nlev, n_slabs_out, add, st);
+  if (C == 64 && W == 8) return launch_bwd<64, 8, 32, 64>(x, dy, wt, dx, (float*)ws, B, H, nlev, n_slabs_out, add, st);
   return ALIGNQ_EUNSUPPORTED;
 }
 

@@ -284,44 +284,54 @@ class QConv3x3Fn(torch.autograd.Function):
     """F.conv2d(input, weight_q, None, 1, 1) of Conv2d_Q.forward (model/quantization.py:149-154) on the bf16 matrix cores
     with exact products (integer filter bins x three-way split activations, see csrc/conv_kernels.hip).  The data gradient
     is the same kernel on the flipped / transposed filter; the filter gradient runs on the f32 MFMAs (plain fp32,
-    deterministic partial-sum slabs)."""
+    deterministic partial-sum slabs).
+
+    tap=True additionally returns the input itself as a second output (an alias for the block's identity shortcut,
+    `shortcut = x`, resnet.py:84-86): its gradient then arrives HERE and is added in the data-gradient kernel's epilogue
+    instead of by a separate accumulation kernel."""
 
     @staticmethod
-    def forward(ctx, x, w, w_bit):
+    def forward(ctx, x, w, w_bit, tap=False):
         B, C, H, W = x.shape
         y = torch.empty_like(x)
-        L.check(L.load().alignq_conv3x3_nhwc(L.ptr(x), L.ptr(w), L.ptr(y), B, H, W, C, int(w_bit), 0, L.stream_ptr()),
-                "alignq_conv3x3_nhwc")
+        L.check(L.load().alignq_conv3x3_nhwc(L.ptr(x), L.ptr(w), L.ptr(y), B, H, W, C, int(w_bit), 0, None,
+                                             L.stream_ptr()), "alignq_conv3x3_nhwc")
         ctx.save_for_backward(x, w)
         ctx.w_bit = int(w_bit)
+        ctx.tap = bool(tap)
+        if tap:
+            ctx.set_materialize_grads(False)
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gtap=None):
         x, w = ctx.saved_tensors
         B, C, H, W = x.shape
+        if gy is None:                     # only the shortcut alias was used downstream
+            return gtap, None, None, None
         gy = L.like_layout(gy, x)
+        add = None if gtap is None else L.like_layout(gtap, x)
         dx = dw = None
         import ctypes
         from . import fused
+        lib = L.load()
         pending = fused.active_wgrads()
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and pending is not None:
             # whole-model step: data gradient + filter-gradient partial sums in ONE launch; the slab reduction of all
             # convolutions follows in one launch at the end of the backward (fused.DeferredWgrads.flush)
-            lib = L.load()
             dx, dw = torch.empty_like(x), torch.empty_like(w)
             ws = _ws(lib.alignq_conv3x3_wgrad_ws_bytes(C), x.device)
             ns = ctypes.c_int(0)
             L.check(lib.alignq_conv3x3_nhwc_bwd(L.ptr(x), L.ptr(gy), L.ptr(w), L.ptr(dx), L.ptr(ws), B, H, W, C, ctx.w_bit,
-                                                ctypes.byref(ns), L.stream_ptr()), "alignq_conv3x3_nhwc_bwd")
+                                                ctypes.byref(ns), L.ptr(add), L.stream_ptr()), "alignq_conv3x3_nhwc_bwd")
             pending.add(ws, dw, ns.value, C)
-            return dx, dw, None
+            return dx, dw, None, None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            L.check(L.load().alignq_conv3x3_nhwc(L.ptr(gy), L.ptr(w), L.ptr(dx), B, H, W, C, ctx.w_bit, 1, L.stream_ptr()),
-                    "alignq_conv3x3_nhwc")
+            L.check(lib.alignq_conv3x3_nhwc(L.ptr(gy), L.ptr(w), L.ptr(dx), B, H, W, C, ctx.w_bit, 1, L.ptr(add),
+                                            L.stream_ptr()), "alignq_conv3x3_nhwc")
         if ctx.needs_input_grad[1]:
-            lib = L.load()
             dw = torch.empty_like(w)          # channels-last [C,3,3,C] storage like w
             ws = _ws(lib.alignq_conv3x3_wgrad_ws_bytes(C), x.device)
             if pending is not None:           # whole-model step: all filter-gradient reductions in one launch at the end
@@ -332,4 +342,4 @@ class QConv3x3Fn(torch.autograd.Function):
             else:
                 L.check(lib.alignq_conv3x3_nhwc_wgrad(L.ptr(x), L.ptr(gy), L.ptr(dw), L.ptr(ws), B, H, W, C, None,
                                                       L.stream_ptr()), "alignq_conv3x3_nhwc_wgrad")
-        return dx, dw, None
+        return dx, dw, None, None

@@ -162,6 +162,18 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
                     return ops.QConv3x3Fn.apply(input, weight_q, self.quantize_fn.w_bit)
                 return F.conv2d(input, weight_q, self.bias, self.stride, self.padding, self.dilation, self.groups)
 
+            def forward_with_shortcut(self, input):
+                """(conv(input), shortcut) for a block whose shortcut is the identity (`shortcut = x`): when the convolution
+                runs on alignq_conv3x3_nhwc the shortcut is returned as an output of the same autograd node, so its gradient
+                is added inside the data-gradient kernel; otherwise plainly (forward(input), input)."""
+                weight_q = self.quantize_fn(self.weight)
+                if getattr(self, "use_qconv", False) and input.requires_grad and ops.qconv3x3_supported(
+                        input, weight_q, self.stride, self.padding, self.dilation, self.groups, self.bias,
+                        self.quantize_fn.w_bit):
+                    return ops.QConv3x3Fn.apply(input, weight_q, self.quantize_fn.w_bit, True)
+                return (F.conv2d(input, weight_q, self.bias, self.stride, self.padding, self.dilation, self.groups),
+                        input)
+
         return Conv2d_Q
 
     ns = types.SimpleNamespace(uniform_quantize=uniform_quantize, cdf=cdf, weight_quantize_fn=weight_quantize_fn,

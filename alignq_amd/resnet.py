@@ -72,9 +72,10 @@ class PreActBlock_conv_Q(nn.Module):
         if self.skip_conv is not None:
             shortcut, loss = self._bnq(self.skip_bn, self.act_skip_q, self.skip_conv(x))
             trans_loss += loss
+            z0 = self.conv0(x)
         else:
-            shortcut = x
-        out, loss = self._bnq(self.bn0, self.act_q0, self.conv0(x), relu=True)
+            z0, shortcut = self.conv0.forward_with_shortcut(x)      # shortcut = x (its gradient joins conv0's data gradient)
+        out, loss = self._bnq(self.bn0, self.act_q0, z0, relu=True)
         trans_loss += loss
         out, loss = self._bnq(self.bn1, self.act_q1, self.conv1(out), relu=True, residual=shortcut)   # out += shortcut; relu
         trans_loss += loss

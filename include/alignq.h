@@ -184,9 +184,10 @@ int alignq_site_prep_fused_multi(int S, const float* const* D, const float* cons
  * three-way bf16 split of the fp32 activations and divides by 2^w_bit - 1 at the end, so products are exact and only fp32
  * accumulation error remains.  Supported (C, W): (16, 32), (32, 16), (64, 8), H a multiple or divisor of the tile rows;
  * anything else returns ALIGNQ_EUNSUPPORTED and the caller keeps MIOpen.
- * dgrad = 0: y = conv(x, wt);  dgrad = 1: x is dy and y receives dx (the same kernel on the flipped, transposed filter). */
+ * dgrad = 0: y = conv(x, wt);  dgrad = 1: x is dy and y receives dx (the same kernel on the flipped, transposed filter).
+ * add != NULL: a [B,H,W,C] tensor added to the result in the epilogue (the identity shortcut's gradient joining dx).      */
 int alignq_conv3x3_nhwc(const float* x, const float* wt, float* y, int B, int H, int W, int C, int w_bit, int dgrad,
-                        void* stream);
+                        const float* add, void* stream);
 
 /* Filter gradient of the same convolution, dW [C,3,3,C] (channels-last weight storage) from x and dy: plain fp32 on the f32
  * MFMAs (products and accumulation bit-for-bit an fmaf chain), per-pixel-range partial sums in ws
@@ -202,7 +203,7 @@ int alignq_conv3x3_wgrad_reduce_multi(int T, const void* const* ws, float* const
 /* Data gradient AND filter-gradient partial sums of one convolution in a single launch (workgroup roles by block index; the
  * two are independent and fill the chip together).  The slabs left in ws are finished by alignq_conv3x3_wgrad_reduce_multi. */
 int alignq_conv3x3_nhwc_bwd(const float* x, const float* dy, const float* wt, float* dx, void* ws, int B, int H, int W,
-                            int C, int w_bit, int* n_slabs_out, void* stream);
+                            int C, int w_bit, int* n_slabs_out, const float* add, void* stream);
 
 /* ---- data-parallel flat bucket (ONE mean all-reduce per step over gradients + stacked D matrices):
  * gather T dense device tensors (HOST array of pointers, element counts n[T]) into `flat` back to back (unpack = 0) or
