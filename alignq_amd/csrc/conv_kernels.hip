@@ -177,54 +177,64 @@ int launch(const float* x, const float* w, float* y, int B, int H, int dgrad, fl
 
 // =====================================================================================================================
 // Filter gradient of the same convolution:  dW[co][tap][ci] = sum_pixels dy[p][co] * x[p + shift(tap)][ci].
-// The reduction runs over PIXELS, so MFMA's k index is the pixel.  With the f32 MFMAs (v_mfma_f32_16x16x4_f32 /
-// v_mfma_f32_32x32x2_f32) every lane feeds ONE element per operand, A[m = co][k = pixel] and B[k = pixel][n = ci], which
-// is exactly how the channels-last tiles lie in LDS (a pixel's channels are contiguous: conflict-free 4-byte reads, any
-// tap shift is just an address) - no transposed staging, no operand splitting, products and accumulation are plain fp32
-// (bit-for-bit an fmaf chain).  The f32 matrix rate (157 TF) bounds the kernel at 3.8 us per layer.
-// Workgroup = (pixel range, 32x32 block of (co, ci)) [16x16 for C = 16]; its four waves split the tile's pixels and keep
-// 9 accumulators (one per tap) across the workgroup's whole tile loop; one tree reduction through LDS at the end, then a
-// partial-sum slab [C][9][C] per pixel range; wgrad_reduce_kernel sums the slabs in fixed order (deterministic).
+// The contraction runs over PIXELS, so MFMA's k index is the pixel while the tiles lie channels-last in LDS.  gfx950's
+// ds_read_b64_tr_b16 reads a 4-pixel x 16-channel block and hands every lane ONE channel of the 4 pixels: two such reads
+// give a lane its 8 consecutive k of v_mfma_f32_16x16x32_bf16 straight from the [pixel][channel] image - for dy (A operand,
+// rows = co) and for x at any tap shift (B operand, columns = ci).  Both operands are arbitrary fp32, so each is split
+// exactly into three bf16 terms and a product keeps the six leading term pairs (hh, hm, mh, hl, lh, mm: everything above
+// 2^-24 relative), accumulated in fp32: fp32-grade accuracy at 6/16 of the f32-MFMA time (1.4 us instead of 3.8 us per
+// layer).  Workgroup = (pixel range, 32x32 block of (co, ci)) [16x16 for C = 16]:
+//   C >= 32: wave = one 16x16 (co, ci) tile of the block over ALL pixels of the tile loop - no cross-wave reduction;
+//   C == 16: the four waves take alternate 32-pixel steps and are summed through LDS once at the end.
+// 9 per-tap accumulators live across a software-pipelined tile loop (the next tile's global loads fly under the MFMAs).  One
+// partial-sum slab [C][9][C] per pixel range; wgrad_reduce[_multi]_kernel sums the slabs in fixed order (deterministic).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 template <int C, int WD, int PT>
 struct WgradLds {
   static constexpr int CB = C >= 32 ? 32 : 16;
-  static constexpr int XT = ((PT / WD) + 2) * (WD + 2) * CB, DT = PT * CB, RED = 2 * 9 * CB * CB;
-  static constexpr int kFloats = (XT + DT) > RED ? (XT + DT) : RED;
+  static constexpr int XA = ((PT / WD) + 2) * (WD + 2) * CB;     // bf16 elements per x image (with halo)
+  static constexpr int DA = PT * CB;                             // bf16 elements per dy image
+  static constexpr int kBytes = (3 * (XA + DA) * 2) > (3 * 9 * 4 * 64 * 4) ? (3 * (XA + DA) * 2) : (3 * 9 * 4 * 64 * 4);
+  static constexpr int kFloats = kBytes / 4;
 };
+
+// 4 pixels x 16 channels block at `p` (this lane's row q = (lane & 15) >> 2, columns 4 * (lane & 3)), transposed: the lane
+// receives channel (lane & 15) of the 4 pixels.  EXEC must be all ones (it is: no divergence around the calls).
+__device__ __forceinline__ s16x4 tr_read(const __bf16* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+__device__ __forceinline__ bf16x8 join8(s16x4 a, s16x4 b) {
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
 
 // bx / gx: index and count of the pixel-range workgroups, by: (co block, ci block) index
 template <int C, int WD, int PT>
 __device__ __forceinline__ void wgrad3x3_body(const float* __restrict__ x, const float* __restrict__ dy,
-                                              float* __restrict__ slabs, int H, int n_tiles, float* lds, int bx, int gx,
+                                              float* __restrict__ slabs, int H, int n_tiles, float* lds_f, int bx, int gx,
                                               int by) {
   constexpr int TR = PT / WD;
-  constexpr int CB = C >= 32 ? 32 : 16;          // channel block (both co and ci)
-  constexpr int NBLK = C / CB;                   // blocks per side
+  constexpr int CB = C >= 32 ? 32 : 16;          // channel block (both co and ci) of the workgroup
+  constexpr int NBLK = C / CB;
   constexpr int LW = WD + 2;
-  constexpr int XT = (TR + 2) * LW * CB;         // floats: x tile with halo, this block's input channels
-  constexpr int DT = TR * WD * CB;               // floats: dy tile, this block's output channels
-  constexpr int KPS = CB == 32 ? 2 : 4;          // pixels per MFMA step
-  constexpr int ACC = CB == 32 ? 16 : 4;         // accumulator registers per tap
-  constexpr int RED = 2 * 9 * CB * CB;           // floats: reduction buffer for two waves
-  constexpr int LDSF = (XT + DT) > RED ? (XT + DT) : RED;
-  static_assert(LDSF == WgradLds<C, WD, PT>::kFloats, "LDS size");
-  float* Xs = lds;
-  float* Ds = lds + XT;
+  constexpr int XA = WgradLds<C, WD, PT>::XA, DA = WgradLds<C, WD, PT>::DA;
+  constexpr int NSTEP = PT / 32;                 // 32-pixel k steps per tile
+  __bf16* lds = reinterpret_cast<__bf16*>(lds_f);
+  __bf16* Xi[3] = {lds, lds + XA, lds + 2 * XA};
+  __bf16* Di[3] = {lds + 3 * XA, lds + 3 * XA + DA, lds + 3 * XA + 2 * DA};
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int bi = by / NBLK, bj = by % NBLK;      // (co block, ci block)
-  const int mrow = CB == 32 ? (lane & 31) : (lane & 15);
-  const int kq = CB == 32 ? (lane >> 5) : (lane >> 4);
+  // this wave's 16x16 tile inside the block, and whether the waves split the k steps (C == 16)
+  const int cob = CB == 32 ? (wv >> 1) : 0, cib = CB == 32 ? (wv & 1) : 0;
+  const int g = lane >> 4, q = (lane & 15) >> 2, pcol = 4 * (lane & 3);
 
-  float acc[9][ACC];
+  f32x4 acc[9];
 #pragma unroll
-  for (int t = 0; t < 9; t++)
-#pragma unroll
-    for (int e = 0; e < ACC; e++) acc[t][e] = 0.f;
+  for (int t = 0; t < 9; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // Software pipeline over the workgroup's tiles: the NEXT tile's global loads (clamped addresses, all in flight) are
-  // issued into registers before the MFMA phase of the current tile and parked in LDS after it.
   constexpr int C4 = CB / 4;
   constexpr int N4 = (TR + 2) * LW * C4;           // float4 slots of the x tile with halo
   constexpr int M4 = TR * WD * C4;                 // float4 slots of the dy tile
@@ -256,17 +266,43 @@ __device__ __forceinline__ void wgrad3x3_body(const float* __restrict__ x, const
   for (int tile = bx; tile < n_tiles; tile += gx) {
     __syncthreads();                               // previous tile's readers are done
 #pragma unroll
-    for (int it = 0; it < NIX; it++) {             // park the fetched tile in LDS
+    for (int it = 0; it < NIX; it++) {             // park the fetched tile in LDS as three bf16 terms
       const int i = tid + 256 * it;
       if (i < N4) {
         const int c4 = i % C4, col = (i / C4) % LW, lr = i / (C4 * LW);
-        *reinterpret_cast<f32x4*>(Xs + (lr * LW + col) * CB + 4 * c4) = rx[it];
+        bf16x4 h4, m4, l4;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const float v = rx[it][e];
+          const __bf16 hi = (__bf16)v;
+          const float r1 = v - (float)hi;
+          const __bf16 mi = (__bf16)r1;
+          h4[e] = hi; m4[e] = mi; l4[e] = (__bf16)(r1 - (float)mi);
+        }
+        const int o = (lr * LW + col) * CB + 4 * c4;
+        *reinterpret_cast<bf16x4*>(Xi[0] + o) = h4;
+        *reinterpret_cast<bf16x4*>(Xi[1] + o) = m4;
+        *reinterpret_cast<bf16x4*>(Xi[2] + o) = l4;
       }
     }
 #pragma unroll
     for (int it = 0; it < NID; it++) {
       const int i = tid + 256 * it;
-      if (i < M4) *reinterpret_cast<f32x4*>(Ds + (i / C4) * CB + 4 * (i % C4)) = rd[it];
+      if (i < M4) {
+        bf16x4 h4, m4, l4;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const float v = rd[it][e];
+          const __bf16 hi = (__bf16)v;
+          const float r1 = v - (float)hi;
+          const __bf16 mi = (__bf16)r1;
+          h4[e] = hi; m4[e] = mi; l4[e] = (__bf16)(r1 - (float)mi);
+        }
+        const int o = (i / C4) * CB + 4 * (i % C4);
+        *reinterpret_cast<bf16x4*>(Di[0] + o) = h4;
+        *reinterpret_cast<bf16x4*>(Di[1] + o) = m4;
+        *reinterpret_cast<bf16x4*>(Di[2] + o) = l4;
+      }
     }
     __syncthreads();
     nxt = tile + gx;
@@ -290,72 +326,68 @@ __device__ __forceinline__ void wgrad3x3_body(const float* __restrict__ x, const
         rd[it] = *reinterpret_cast<const f32x4*>(dy + off);
       }
     }
-    // this wave's pixels: PT / 4 consecutive pixels, KPS per step (a step never crosses a row: WD % 4 == 0)
-    constexpr int PW = PT / 4;
-#pragma unroll 2
-    for (int s = 0; s < PW / KPS; s++) {
-      const int pix = wv * PW + s * KPS + kq;
-      const int r = pix / WD, c = pix % WD;
-      const float a = Ds[pix * CB + mrow];
-      float b[9];
+    // ---- MFMA phase: 32 pixels per step; lane group g owns pixels p0 + 8g .. + 7 (8 consecutive columns of one row) ---
+    for (int s = (CB == 16 ? wv : 0); s < NSTEP; s += (CB == 16 ? 4 : 1)) {
+      const int p0 = 32 * s + 8 * g;
+      const int r = p0 / WD, c0 = p0 % WD;
+      // A = dy: lane address = pixel p0 + 4*half + q, channels cob*16 + pcol
+      bf16x8 a[3];
 #pragma unroll
-      for (int t = 0; t < 9; t++) b[t] = Xs[((r + t / 3) * LW + (c + t % 3)) * CB + mrow];
+      for (int t = 0; t < 3; t++) {
+        const __bf16* pa = Di[t] + (p0 + q) * CB + cob * 16 + pcol;
+        a[t] = join8(tr_read(pa), tr_read(pa + 4 * CB));
+      }
+#pragma unroll
+      for (int tap = 0; tap < 9; tap++) {
+        const int ky = tap / 3, kx = tap % 3;
+        bf16x8 b[3];
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+          const __bf16* pb = Xi[t] + ((r + ky) * LW + (c0 + kx + q)) * CB + cib * 16 + pcol;
+          b[t] = join8(tr_read(pb), tr_read(pb + 4 * CB));
+        }
+        // six leading term pairs, smallest first
+        f32x4 v = acc[tap];
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], v, 0, 0, 0);
+        acc[tap] = v;
+      }
+    }
+  }
+  // ---- results: C/D layout of the 16x16 MFMA: column (ci) = lane & 15, rows (co) = 4 (lane >> 4) + e ---------------------
+  float* slab = slabs + (int64_t)bx * (9 * C * C);
+  if (CB == 16) {      // the four waves hold partial sums over alternate steps: fixed-order sum through LDS, wave 0 writes
+    float* red = lds_f;
+    __syncthreads();
+    if (wv > 0) {
+#pragma unroll
+      for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) red[(((wv - 1) * 9 + t) * 4 + e) * 64 + lane] = acc[t][e];
+    }
+    __syncthreads();
+    if (wv == 0) {
 #pragma unroll
       for (int t = 0; t < 9; t++) {
-        if (CB == 32) {
-          f32x16 v;
 #pragma unroll
-          for (int e = 0; e < 16; e++) v[e] = acc[t][e];
-          v = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[t], v, 0, 0, 0);
+        for (int e = 0; e < 4; e++) {
+          float v = acc[t][e];
 #pragma unroll
-          for (int e = 0; e < 16; e++) acc[t][e] = v[e];
-        } else {
-          f32x4 v = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
-          v = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[t], v, 0, 0, 0);
-          acc[t][0] = v[0]; acc[t][1] = v[1]; acc[t][2] = v[2]; acc[t][3] = v[3];
+          for (int w2 = 0; w2 < 3; w2++) v += red[((w2 * 9 + t) * 4 + e) * 64 + lane];
+          slab[((int64_t)(4 * (lane >> 4) + e) * 9 + t) * C + (lane & 15)] = v;
         }
       }
     }
-  }
-  // ---- tree reduction over the four waves (fixed order): (2,3) -> LDS -> (0,1) += ; 1 -> LDS -> 0 += ; 0 writes the slab
-  // element e of tap t, lane l lives at red[w'][t][e][l] (lane fastest: conflict-free)
-  float* red = lds;
-  __syncthreads();
-  if (wv >= 2) {
+  } else {
 #pragma unroll
     for (int t = 0; t < 9; t++)
 #pragma unroll
-      for (int e = 0; e < ACC; e++) red[(((wv - 2) * 9 + t) * ACC + e) * 64 + lane] = acc[t][e];
-  }
-  __syncthreads();
-  if (wv < 2) {
-#pragma unroll
-    for (int t = 0; t < 9; t++)
-#pragma unroll
-      for (int e = 0; e < ACC; e++) acc[t][e] += red[((wv * 9 + t) * ACC + e) * 64 + lane];
-  }
-  __syncthreads();
-  if (wv == 1) {
-#pragma unroll
-    for (int t = 0; t < 9; t++)
-#pragma unroll
-      for (int e = 0; e < ACC; e++) red[(t * ACC + e) * 64 + lane] = acc[t][e];
-  }
-  __syncthreads();
-  if (wv == 0) {
-    float* slab = slabs + (int64_t)bx * (9 * C * C);
-#pragma unroll
-    for (int t = 0; t < 9; t++) {
-#pragma unroll
-      for (int e = 0; e < ACC; e++) {
-        const float v = acc[t][e] + red[(t * ACC + e) * 64 + lane];
-        // C/D layouts: 16x16: col = lane & 15 (ci), row = 4 (lane >> 4) + e (co);
-        //              32x32: col = lane & 31 (ci), row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5) (co)
-        const int ci = CB == 32 ? (lane & 31) : (lane & 15);
-        const int co = CB == 32 ? ((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) : (4 * (lane >> 4) + e);
-        slab[((int64_t)(bi * CB + co) * 9 + t) * C + bj * CB + ci] = v;
-      }
-    }
+      for (int e = 0; e < 4; e++)
+        slab[((int64_t)(bi * CB + cob * 16 + 4 * (lane >> 4) + e) * 9 + t) * C + bj * CB + cib * 16 + (lane & 15)] = acc[t][e];
   }
 }
 
