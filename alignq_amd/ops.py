@@ -274,7 +274,7 @@ def qconv3x3_supported(x, w, stride, padding, dilation, groups, bias, w_bit) -> 
     B, C, H, W = x.shape
     if tuple(w.shape) != (C, C, 3, 3) or (C, W) not in ((16, 32), (32, 16), (64, 8)):
         return False
-    if H % (128 // W if C < 64 else 4):
+    if H % 8:            # tiles are 8 / 8 / 4-8 whole image rows
         return False
     cl = torch.channels_last
     return (x.is_contiguous(memory_format=cl) and not x.is_contiguous()) and w.is_contiguous(memory_format=cl)
