@@ -20,12 +20,30 @@ def one(pattern):
 
 
 # ---- kernel stats -------------------------------------------------------------------------------------------------
+OURS = ("alignq_site", "site_fwd", "site_bwd", "slab_reduce", "site_prep", "bn_stats", "bn_bwd_apply", "bn_finalize", "conv3x3",
+        "wgrad", "mt_", "admm_update", "act_quant", "weight_quant", "weight_stats", "uniform_quantize", "sgd_", "admm_loss")
+
+
+def is_ours(name):
+    return "ck::" not in name and "_ZN2ck" not in name and any(k in name for k in OURS)
+
+
 stats = one("stats/**/*kernel_stats.csv")
-with open(stats) as fi, open(os.path.join(out, "kernel_stats_train_step.csv"), "w") as fo:
-    fo.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline   (MI355X; rows of MIOpen kernels include its find-mode trials for the five convolutions that stay on MIOpen)\n")
+rows = list(csv.reader(open(stats)))
+head, data = rows[0], rows[1:]
+ours = [r for r in data if is_ours(r[0])]
+others = [r for r in data if not is_ours(r[0])]
+with open(os.path.join(out, "kernel_stats_train_step.csv"), "w") as fo:
+    fo.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline   (MI355X)\n")
     fo.write("# 3 eager warm-ups + HIP-graph capture + 33 replays of the ResNet-20 8W/8A CDF+ADMM step (batch 128), then bench.py's per-kernel\n")
     fo.write("# measurement loops (site kernels x ~55 launches per shape, act_quant / copy / add x 23 launches on 2^26 elements)\n")
-    fo.write(fi.read())
+    fo.write("# --- this repository's kernels (all of them), by total time ---\n")
+    w = csv.writer(fo, quoting=csv.QUOTE_ALL)
+    w.writerow(head)
+    w.writerows(ours)
+    fo.write(f"# --- other kernels (top 40 of {len(others)} by total time): MIOpen incl. its find-mode trials for the five convolutions\n")
+    fo.write("# --- that stay on MIOpen, rocBLAS, torch elementwise ---\n")
+    w.writerows(others[:40])
 
 
 def counters(which, name):
