@@ -835,3 +835,44 @@ def test_trainstep_gradients_with_own_convolutions_match_miopen(dev):
         cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
         assert cos > 0.999, (n, cos)
         assert abs(float(a.norm() / (b.norm() + 1e-30)) - 1.0) < 0.02, n
+
+
+def test_fast_path_trajectory_tracks_plain_path(dev):
+    """End-to-end guard for everything TrainStep fuses (BN/ReLU/shortcut fold, channels-last, own convolutions forward and
+    backward, deferred reductions, HIP graph): ten training iterations on a fixed batch against the plain per-module path
+    (NCHW, MIOpen convolutions and batch-norm, eager launches — the path the per-op and two-step reference tests pin).  The
+    two runs differ by rounding and rare tie-zone bin flips only, so the loss curves and the trained weights must stay close."""
+    import copy
+    from alignq_amd import config
+    from alignq_amd.resnet import PreActBlock_conv_Q, PreActResNet
+    from alignq_amd.train_step import TrainStep
+    config.args.bitW = config.args.abitW = 8
+    config.args.train_batch_size = 128
+    torch.manual_seed(11)
+    base = PreActResNet(PreActBlock_conv_Q, [1, 1, 1], 8, 8, "second", 10).to(dev).train()
+    x = torch.randn(128, 3, 32, 32, device=dev)
+    y = torch.randint(0, 10, (128,), device=dev)
+    runs = []
+    for fast in (False, True):
+        net = copy.deepcopy(base)
+        if fast:      # two eager warm-up iterations (real steps: MIOpen plans its five convolutions), then graph replays
+            step = TrainStep(net, lr=0.02, channels_last=True, qconv=True, fuse_bn=True).capture(x, y, warmup=2)
+        else:
+            step = TrainStep(net, lr=0.02, channels_last=False, fuse_bn=False, defer_losses=False)
+            for _ in range(2):
+                step(x, y)
+        ces, tls = [], []
+        for _ in range(8):
+            _, ce, tl = step(x, y)
+            ces.append(float(ce.detach())); tls.append(float(tl.detach()))
+        torch.cuda.synchronize()
+        runs.append((ces, tls, {n: p.detach().float().flatten().clone() for n, p in net.named_parameters()}))
+    (ce_a, tl_a, w_a), (ce_b, tl_b, w_b) = runs
+    assert ce_a[-1] < ce_a[0] and ce_b[-1] < ce_b[0]                       # both actually train
+    np.testing.assert_allclose(ce_b, ce_a, rtol=0.05, atol=0.02)
+    np.testing.assert_allclose(tl_b, tl_a, rtol=0.02)
+    for n in w_a:
+        if "alterD" in n or "gamma" in n or w_a[n].numel() < 64:
+            continue
+        cos = float(torch.dot(w_a[n], w_b[n]) / (w_a[n].norm() * w_b[n].norm() + 1e-30))
+        assert cos > 0.995, (n, cos)
