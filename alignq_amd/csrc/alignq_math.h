@@ -166,6 +166,26 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// Sum over the 64 lanes on the DPP path (row_shr 1/2/4/8 inside the rows of 16, then row_bcast15 / row_bcast31 across rows:
+// an inclusive scan whose last lane holds the total), ~10x cheaper than six ds_bpermute round trips per dword.  Returns the
+// total in EVERY lane (v_readlane of lane 63).  Fixed summation order.
+__device__ __forceinline__ double wave_sum_d_dpp(double v) {
+#define ALIGNQ_DPP_STEP(CTRL, ROWMASK)                                                                      \
+  {                                                                                                         \
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, false);            \
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, false);            \
+    v += __hiloint2double(hi, lo);                                                                          \
+  }
+  ALIGNQ_DPP_STEP(0x111, 0xf)   // row_shr:1
+  ALIGNQ_DPP_STEP(0x112, 0xf)   // row_shr:2
+  ALIGNQ_DPP_STEP(0x114, 0xf)   // row_shr:4
+  ALIGNQ_DPP_STEP(0x118, 0xf)   // row_shr:8
+  ALIGNQ_DPP_STEP(0x142, 0xa)   // row_bcast:15 into rows 1 and 3
+  ALIGNQ_DPP_STEP(0x143, 0xc)   // row_bcast:31 into rows 2 and 3
+#undef ALIGNQ_DPP_STEP
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
 
 }  // namespace alignq
 

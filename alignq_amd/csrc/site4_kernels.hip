@@ -189,11 +189,9 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
             sa1 = bn.part[((int64_t)c1 * kNhwcParts + lane) * 2];
             sq1 = bn.part[((int64_t)c1 * kNhwcParts + lane) * 2 + 1];
           }
-    #pragma unroll
-          for (int o = 32; o > 0; o >>= 1) {
-            sa0 += __shfl_xor(sa0, o, 64); sq0 += __shfl_xor(sq0, o, 64);
-            if (kPairCh) { sa1 += __shfl_xor(sa1, o, 64); sq1 += __shfl_xor(sq1, o, 64); }
-          }
+              sa0 = wave_sum_d_dpp(sa0);
+          sq0 = wave_sum_d_dpp(sq0);
+          if (kPairCh) { sa1 = wave_sum_d_dpp(sa1); sq1 = wave_sum_d_dpp(sq1); }
           if (lane < 2 && (lane == 0 || two)) {            // lane 0: channel c0, lane 1: channel c1
             const int cl = lane ? cl1 : cl0, cc = lane ? c1 : c0;
             const double sa = lane ? sa1 : sa0, sq = lane ? sq1 : sq0;
@@ -201,7 +199,7 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
             const double mean = sa / n;
             double var = sq / n - mean * mean;
             if (var < 0) var = 0;
-            const float invstd = (float)(1.0 / sqrt(var + (double)bn.bn_eps));
+            const float invstd = 1.0f / sqrtf((float)(var + (double)bn.bn_eps));     // fp32 like torch's batch-norm
             const float av = (bn.gamma ? bn.gamma[cc] : 1.0f) * invstd;
             const float bv = (bn.beta ? bn.beta[cc] : 0.0f) - (float)mean * av;
             colv[cl] = av;

@@ -9,6 +9,7 @@ lib.alignq_debug_read_stamps.argtypes = [ctypes.c_void_p]
 lib.alignq_debug_read_block_stamps.argtypes = [ctypes.c_void_p]
 dev = torch.device('cuda:0')
 B, k = 128, 8
+NHWC = int(os.environ.get('NHWC', '0'))
 p = L.ptr
 
 
@@ -27,18 +28,18 @@ for (C, HW) in ((16, 1024), (32, 256), (64, 64)):
     xq, dx = torch.empty(B, F, device=dev), torch.empty(B, F, device=dev)
     stats = torch.empty(4, F, device=dev)
     ws = torch.empty(lib.alignq_site_ws_bytes(B, F), dtype=torch.uint8, device=dev)
-    ws_bn = torch.empty(lib.alignq_bn_ws_bytes(C), dtype=torch.uint8, device=dev)
+    ws_bn = torch.empty(lib.alignq_bn_nhwc_ws_bytes(C) if NHWC else lib.alignq_bn_ws_bytes(C), dtype=torch.uint8, device=dev)
     ab, save = torch.empty(2, C, device=dev), torch.empty(2, C, device=dev)
     gam, bet = torch.ones(C, device=dev), torch.zeros(C, device=dev)
-    part = torch.empty(lib.alignq_site_bn_part_bytes(F, 0), dtype=torch.uint8, device=dev)
+    part = torch.empty(lib.alignq_site_bn_part_bytes(F, NHWC), dtype=torch.uint8, device=dev)
     S = torch.rand(B, B, device=dev) * 1e-6
     st = L.stream_ptr()
     for it in range(4):
-        lib.alignq_bn_partial_stats(p(z), B, C, HW, p(ws_bn), st)
+        (lib.alignq_bn_partial_stats_nhwc if NHWC else lib.alignq_bn_partial_stats)(p(z), B, C, HW, p(ws_bn), st)
         lib.alignq_site_partials_bn(p(z), p(ws_bn), p(gam), p(bet), None, None, None, 0.1, 1e-5, p(ab), p(save), C, HW, B, F,
-                                    k, 2.0, 0.0, 1, None, 0, p(xq), p(stats), p(ws), st)
+                                    k, 2.0, 0.0, 1, None, NHWC, p(xq), p(stats), p(ws), st)
         torch.cuda.synchronize()
-        lib.alignq_site_bwd_apply_bn(p(g), p(S), p(z), p(ab), p(save), C, HW, 0, p(xq), None, p(stats), B, F, 2.0, 0.0, p(dx),
+        lib.alignq_site_bwd_apply_bn(p(g), p(S), p(z), p(ab), p(save), C, HW, NHWC, p(xq), None, p(stats), B, F, 2.0, 0.0, p(dx),
                                      p(part), st)
         torch.cuda.synchronize()
     buf = (ctypes.c_ulonglong * 64)()
