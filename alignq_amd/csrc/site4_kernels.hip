@@ -221,7 +221,8 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
         const int jl = (4 * c) & (nch - 1);                // this thread's columns -> local channel index
         a4 = *reinterpret_cast<const float4*>(colv + jl);
         b4 = *reinterpret_cast<const float4*>(colv + TFv + jl);
-        __syncthreads();                     // colv is reused by the column statistics below
+        // (no barrier needed before colv is reused: its next writer, the column statistics, writes only after a barrier
+        // that every thread reaches after these reads)
       } else {
         a4 = *reinterpret_cast<const float4*>(bn.ab + ch);
         b4 = *reinterpret_cast<const float4*>(bn.ab + bn.C + ch);
@@ -266,8 +267,7 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
         }
         __syncthreads();
         bn_a = colv[0];
-        bn_b = colv[1];
-        __syncthreads();                     // colv is reused by the column statistics below
+        bn_b = colv[1];       // (colv's next writer runs behind a later barrier: no second barrier here)
       } else {
         bn_a = bn.ab[ch];
         bn_b = bn.ab[bn.C + ch];
