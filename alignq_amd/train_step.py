@@ -187,7 +187,12 @@ class OfficeTrainStep:
     ADMM_OPT.step.  Each ADMM.D holds the TARGET pass's D when ADMM_OPT runs (admm.py:25 overwrites) and alterD/gamma are
     SGD-stepped first and then overwritten by the closed form, exactly like the reference."""
 
-    def __init__(self, model, lr=0.04, momentum=0.9, weight_decay=5e-4, alpha=0.5):
+    def __init__(self, model, lr=0.04, momentum=0.9, weight_decay=5e-4, alpha=0.5, channels_last=False):
+        """channels_last: activations and conv weights in torch.channels_last memory (values / names unchanged): MIOpen's NHWC
+        kernels run the ResNet-50 step in 30.9 instead of 34.7 ms on MI355X; the quantise / Gram kernels are layout-agnostic."""
+        if channels_last:
+            model = model.to(memory_format=torch.channels_last)
+        self.channels_last = channels_last
         self.model, self.alpha = model, alpha
         named = list(model.named_parameters())
         self.param_admm = [(n, p) for n, p in named if "alterD" in n or "gamma" in n]
@@ -216,6 +221,9 @@ class OfficeTrainStep:
         self.optimizer_t.zero_grad(set_to_none=set_to_none)
         self.optimizer_admm.zero_grad(set_to_none=set_to_none)
         dev = xs.device
+        if self.channels_last:
+            xs = xs.contiguous(memory_format=torch.channels_last)
+            xt = xt.contiguous(memory_format=torch.channels_last)
         label_src = torch.zeros(xs.shape[0], dtype=torch.long, device=dev)
         label_tgt = torch.ones(xt.shape[0], dtype=torch.long, device=dev)
         prequantize_weights(self.all_convs)
@@ -261,7 +269,8 @@ class OfficeTrainStep:
         return self._static[3]
 
     def capture(self, xs, ys, xt, warmup=2):
-        sxs, sys_, sxt = xs.clone(), ys.clone(), xt.clone()
+        fmt = torch.channels_last if self.channels_last else torch.contiguous_format
+        sxs, sys_, sxt = xs.clone(memory_format=fmt), ys.clone(), xt.clone(memory_format=fmt)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

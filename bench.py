@@ -264,7 +264,7 @@ def main():
         from alignq_amd.resnet_office import resnet50_dann
         from alignq_amd.train_step import OfficeTrainStep
         model = resnet50_dann(a.bits, a.bits).to(dev).train()
-        ostep = OfficeTrainStep(model)
+        ostep = OfficeTrainStep(model, channels_last=not a.nchw)
         xs = torch.randn(a.batch, 3, 224, 224, generator=gen).to(dev)
         xt = torch.randn(a.batch, 3, 224, 224, generator=gen).to(dev)
         ys = torch.randint(0, 31, (a.batch,), generator=gen).to(dev)
@@ -329,7 +329,7 @@ def main():
                                    + f"{'HIP-graph replay' if not a.no_graph else 'eager launches'}"
                                    + ("" if (office or a.no_fuse_bn) else ", batch-norm folded into the site kernels")
                                    + ("" if a.no_miopen_find else ", MIOpen find mode for the convolutions")
-                                   + ("" if (office or a.nchw) else ", channels-last tensors")
+                                   + ("" if a.nchw else ", channels-last tensors")
                                    + ("" if (office or a.nchw or a.no_qconv) else
                                       ", Conv2d_Q 3x3 body convolutions on alignq_conv3x3_nhwc"),
                        "global_batch": a.batch * world, "parallelism": f"dp{world}",

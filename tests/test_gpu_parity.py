@@ -448,7 +448,8 @@ def test_prequantize_all_weights_matches_per_tensor(dev):
         np.testing.assert_allclose(npy(c.weight.grad), npy(w2.grad), atol=1e-6, rtol=1e-5)
 
 
-def test_office_dann_harness_runs_and_matches_eager_under_graph(dev):
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_office_dann_harness_runs_and_matches_eager_under_graph(dev, channels_last):
     """Config-5 harness (ResNet-Bottleneck + DANN head, Office tree ops: eps-corr, activation_quantize_fn2, two passes per
     step, three SGD groups incl. alterD/gamma): a small instance runs, every ADMM site takes the TARGET pass's D, and
     the HIP-graph replay reproduces eager iterations."""
@@ -466,9 +467,10 @@ def test_office_dann_harness_runs_and_matches_eager_under_graph(dev):
         xs = torch.randn(6, 3, 64, 64, generator=g).to(dev)
         xt = torch.randn(6, 3, 64, 64, generator=g).to(dev)
         ys = torch.randint(0, 31, (6,), generator=g).to(dev)
-        OfficeTrainStep(make(), lr=0.004)(xs, ys, xt)      # throw-away: lets MIOpen settle its solver choice per shape
+        cl = dict(channels_last=channels_last)
+        OfficeTrainStep(make(), lr=0.004, **cl)(xs, ys, xt)      # throw-away: lets MIOpen settle its solver choice per shape
         m1, m2 = make(), make()
-        s1, s2 = OfficeTrainStep(m1, lr=0.004), OfficeTrainStep(m2, lr=0.004)
+        s1, s2 = OfficeTrainStep(m1, lr=0.004, **cl), OfficeTrainStep(m2, lr=0.004, **cl)
         a0 = npy(m1.feature.layer1[0].admm0.alterD).copy()
         for _ in range(2):
             cls, loss, tl = s1(xs, ys, xt)
