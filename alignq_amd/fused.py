@@ -1,10 +1,15 @@
-"""Whole-model fast paths that keep the reference's per-module API intact.
+"""Whole-model fast paths that keep the reference's per-module API intact (all opt-in; TrainStep switches them on).
 
-`prequantize_weights(convs)` quantises ALL conv weights of a model with two multi-tensor launches
-(alignq_weight_quant_fwd_multi) instead of four launches per tensor, and parks the results in each
-`conv.quantize_fn`; the next `weight_quantize_fn.forward(conv.weight)` consumes them.  Autograd goes through one
-Function with T inputs, whose backward is again two multi-tensor launches.  Used by TrainStep; calling the
-modules without it still works (per-tensor kernels)."""
+* `prequantize_weights(convs)` / `WeightQuantAllFn`: ALL conv weights of a model quantised with two multi-tensor launches
+  (alignq_weight_quant_fwd_multi) instead of four launches per tensor; results are parked in each `conv.quantize_fn` and
+  consumed by the next `weight_quantize_fn.forward(conv.weight)`.  The backward is again two multi-tensor launches (and
+  first finishes any deferred filter-gradient reductions).
+* `DeferredLosses` / `LossSumFn` / `SiteRecord`: every ADMM site's slab reduction + loss in ONE launch after the last layer,
+  every site's backward prep in ONE launch.
+* `BNSiteFn` / `bn_site`: `act_q(bn(z)) [+ residual] [-> relu]` with the batch-norm folded into the site kernels (NCHW or
+  channels-last).
+* `DeferredWgrads`: the slab reductions of ops.QConv3x3Fn's filter gradients in ONE launch per backward.
+"""
 from __future__ import annotations
 
 import torch

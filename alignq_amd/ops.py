@@ -6,9 +6,12 @@ HIP graph (torch.cuda.CUDAGraph).  No host synchronisation happens here.
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
 from . import _lib as L
+from . import fused
 
 
 def _ws(nbytes: int, device) -> torch.Tensor:
@@ -106,7 +109,6 @@ class WeightQuantFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _gc, _gp):
         w, ms = ctx.saved_tensors
-        from . import fused
         pending = fused.active_wgrads()
         if pending is not None:      # g may still be partial-sum slabs of a deferred filter gradient
             pending.flush()
@@ -313,8 +315,6 @@ class QConv3x3Fn(torch.autograd.Function):
         gy = L.like_layout(gy, x)
         add = None if gtap is None else L.like_layout(gtap, x)
         dx = dw = None
-        import ctypes
-        from . import fused
         lib = L.load()
         pending = fused.active_wgrads()
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and pending is not None:
