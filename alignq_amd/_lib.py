@@ -47,7 +47,8 @@ SIGNATURES = {
     "alignq_sgd_grad_approx": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _f, _f, _vp]),
     "alignq_site_reduce_loss_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp]),
     "alignq_site_prep_fused_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
-    "alignq_conv3x3_nhwc": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "alignq_conv3x3_bn_parts": (_i, [_i, _i, _i, _i]),
+    "alignq_conv3x3_nhwc": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "alignq_conv3x3_wgrad_ws_bytes": (_sz, [_i]),
     "alignq_conv3x3_nhwc_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "alignq_conv3x3_nhwc_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -57,7 +58,7 @@ SIGNATURES = {
     "alignq_bn_stats": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp]),
     "alignq_bn_partial_stats": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "alignq_site_partials_bn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _i, _i, _i, _i64, _i, _f, _f, _i,
-                                     _vp, _i, _vp, _vp, _vp, _vp]),
+                                     _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "alignq_site_bn_part_bytes": (_sz, [_i64, _i]),
     "alignq_bn_nhwc_ws_bytes": (_sz, [_i]),
     "alignq_bn_partial_stats_nhwc": (_i, [_vp, _i, _i, _i, _vp, _vp]),

@@ -36,7 +36,8 @@ struct ConvLds {
 template <int C, int WD, int PT, bool DGRAD>
 __device__ __forceinline__ void conv3x3_body(const float* __restrict__ x, const float* __restrict__ w,
                                              float* __restrict__ y, int H, int total_rows, float nlev, __bf16* lds,
-                                             int block, const float* __restrict__ add) {
+                                             int block, const float* __restrict__ add,
+                                             float* __restrict__ bn_part = nullptr, int n_wg = 0) {
   constexpr int TR = PT / WD;                 // image rows per workgroup
   constexpr int NS = (9 * C + 31) / 32;       // k steps of 32
   constexpr int NCG = C / 16;                 // 16-channel output groups
@@ -119,6 +120,7 @@ __device__ __forceinline__ void conv3x3_body(const float* __restrict__ x, const 
   }
   __syncthreads();
   // ---- MFMA over this wave's pixel groups ----------------------------------------------------------------------------
+  float bs[4] = {0.f, 0.f, 0.f, 0.f}, bq[4] = {0.f, 0.f, 0.f, 0.f};   // batch-norm statistics of this lane's outputs
   for (int g = pp; g < NG; g += NPP) {
     const int p = g * 16 + (lane & 15);          // pixel of the tile owned by this lane (B column)
     const int r = p / WD, c = p % WD;            // tile row / column
@@ -152,6 +154,41 @@ __device__ __forceinline__ void conv3x3_body(const float* __restrict__ x, const 
         v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
       }
       *reinterpret_cast<float4*>(y + o) = v;
+      bs[0] += v.x; bs[1] += v.y; bs[2] += v.z; bs[3] += v.w;
+      bq[0] += v.x * v.x; bq[1] += v.y * v.y; bq[2] += v.z * v.z; bq[3] += v.w * v.w;
+    }
+  }
+  // ---- optional epilogue: per-workgroup, per-channel {sum z, sum z^2} of the tile just produced, so that the batch-norm
+  //      that follows needs no pass of its own over z.  Row (16-lane) sums on the DPP path, waves through LDS, fixed order.
+  if (!DGRAD && bn_part) {
+    float* red = reinterpret_cast<float*>(lds);
+#define ROW_SHR_ADD(V, CTRL) V += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V), CTRL, 0xf, 0xf, false))
+#pragma unroll
+    for (int e = 0; e < 4; e++) {                // row_shr 1, 2, 4, 8: lane 15 of each 16-lane row ends with the row total
+      ROW_SHR_ADD(bs[e], 0x111); ROW_SHR_ADD(bs[e], 0x112); ROW_SHR_ADD(bs[e], 0x114); ROW_SHR_ADD(bs[e], 0x118);
+      ROW_SHR_ADD(bq[e], 0x111); ROW_SHR_ADD(bq[e], 0x112); ROW_SHR_ADD(bq[e], 0x114); ROW_SHR_ADD(bq[e], 0x118);
+    }
+#undef ROW_SHR_ADD
+    __syncthreads();                             // every wave is done with the LDS image
+    if ((lane & 15) == 15) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        red[(wv * 16 + 4 * q + e) * 2] = bs[e];
+        red[(wv * 16 + 4 * q + e) * 2 + 1] = bq[e];
+      }
+    }
+    __syncthreads();
+    if (tid < C) {                               // channel tid: group tid / 16, summed over that group's NPP waves
+      const int cg = tid / 16, cl = tid % 16;
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int ppi = 0; ppi < NPP; ppi++) {
+        const int w2 = ppi * NCG + cg;
+        s0 += red[(w2 * 16 + cl) * 2];
+        s1 += red[(w2 * 16 + cl) * 2 + 1];
+      }
+      bn_part[((int64_t)tid * n_wg + block) * 2] = s0;
+      bn_part[((int64_t)tid * n_wg + block) * 2 + 1] = s1;
     }
   }
 }
@@ -159,19 +196,20 @@ __device__ __forceinline__ void conv3x3_body(const float* __restrict__ x, const 
 template <int C, int WD, int PT, bool DGRAD>
 __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            float* __restrict__ y, int H, int total_rows, float nlev,
-                                                           const float* __restrict__ add) {
+                                                           const float* __restrict__ add, float* __restrict__ bn_part) {
   __shared__ __attribute__((aligned(16))) __bf16 lds[ConvLds<C, WD, PT>::kBf16];
-  conv3x3_body<C, WD, PT, DGRAD>(x, w, y, H, total_rows, nlev, lds, blockIdx.x, add);
+  conv3x3_body<C, WD, PT, DGRAD>(x, w, y, H, total_rows, nlev, lds, blockIdx.x, add, bn_part, gridDim.x);
 }
 
 template <int C, int WD, int PT>
-int launch(const float* x, const float* w, float* y, int B, int H, int dgrad, float nlev, const float* add, hipStream_t st) {
+int launch(const float* x, const float* w, float* y, int B, int H, int dgrad, float nlev, const float* add, float* bn_part,
+           hipStream_t st) {
   constexpr int TR = PT / WD;
   const int total_rows = B * H;
   if (H % TR) return ALIGNQ_EUNSUPPORTED;
   const int grid = total_rows / TR;
-  if (dgrad) hipLaunchKernelGGL((conv3x3_nhwc_kernel<C, WD, PT, true>), grid, 256, 0, st, x, w, y, H, total_rows, nlev, add);
-  else hipLaunchKernelGGL((conv3x3_nhwc_kernel<C, WD, PT, false>), grid, 256, 0, st, x, w, y, H, total_rows, nlev, add);
+  if (dgrad) hipLaunchKernelGGL((conv3x3_nhwc_kernel<C, WD, PT, true>), grid, 256, 0, st, x, w, y, H, total_rows, nlev, add, nullptr);
+  else hipLaunchKernelGGL((conv3x3_nhwc_kernel<C, WD, PT, false>), grid, 256, 0, st, x, w, y, H, total_rows, nlev, add, bn_part);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
@@ -515,8 +553,15 @@ extern "C" {
 // y[b,h,w,co] = sum x[b,h+ky-1,w+kx-1,ci] * wt[co,ky,kx,ci]   (dgrad = 0)
 // dx[b,h,w,ci] = sum dy[b,h-ky+1,w-kx+1,co] * wt[co,ky,kx,ci] (dgrad = 1: x := dy)
 // wt must hold k-bit quantised values b / (2^k - 1), 1 <= k <= 8 (weight_quantize_fn's output).
+// workgroups (= batch-norm partials per channel) of the forward launch for this shape; 0 if unsupported
+int alignq_conv3x3_bn_parts(int B, int H, int W, int C) {
+  const int pt = (C == 16 && W == 32) ? 256 : (C == 32 && W == 16) ? 128 : (C == 64 && W == 8) ? 32 : 0;
+  if (!pt || B < 1 || H < 1 || H % (pt / W)) return 0;
+  return B * H / (pt / W);
+}
+
 int alignq_conv3x3_nhwc(const float* x, const float* wt, float* y, int B, int H, int W, int C, int w_bit, int dgrad,
-                        const float* add, void* stream) {
+                        const float* add, float* bn_part, void* stream) {
   if (!x || !wt || !y || B < 1 || H < 1) return ALIGNQ_EINVAL;
   if (w_bit < 1 || w_bit > 8) return ALIGNQ_EUNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(wt) | reinterpret_cast<uintptr_t>(y)) & 15) return ALIGNQ_EUNSUPPORTED;
@@ -524,9 +569,9 @@ int alignq_conv3x3_nhwc(const float* x, const float* wt, float* y, int B, int H,
   const float nlev = (float)((1 << w_bit) - 1);
   // tile sizes measured on MI355X (forward us per layer at batch 128): C=16: 256 pixels 7.8 (128: 8.7); C=32: 128 pixels 8.0
   // (256: 11.0); C=64: 32 pixels 9.3 (64: 12.3)
-  if (C == 16 && W == 32) return launch<16, 32, 256>(x, wt, y, B, H, dgrad, nlev, add, st);
-  if (C == 32 && W == 16) return launch<32, 16, 128>(x, wt, y, B, H, dgrad, nlev, add, st);
-  if (C == 64 && W == 8) return launch<64, 8, 32>(x, wt, y, B, H, dgrad, nlev, add, st);
+  if (C == 16 && W == 32) return launch<16, 32, 256>(x, wt, y, B, H, dgrad, nlev, add, bn_part, st);
+  if (C == 32 && W == 16) return launch<32, 16, 128>(x, wt, y, B, H, dgrad, nlev, add, bn_part, st);
+  if (C == 64 && W == 8) return launch<64, 8, 32>(x, wt, y, B, H, dgrad, nlev, add, bn_part, st);
   return ALIGNQ_EUNSUPPORTED;
 }
 

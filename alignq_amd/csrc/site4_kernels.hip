@@ -182,12 +182,24 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
           const int cl1 = cl0 + 16;
           const bool two = kPairCh && cl1 < nch;
           const int c0 = chbase + cl0, c1 = chbase + (two ? cl1 : cl0);
-          double sa0 = bn.part[((int64_t)c0 * kNhwcParts + lane) * 2];
-          double sq0 = bn.part[((int64_t)c0 * kNhwcParts + lane) * 2 + 1];
-          double sa1 = 0, sq1 = 0;
-          if (kPairCh) {
-            sa1 = bn.part[((int64_t)c1 * kNhwcParts + lane) * 2];
-            sq1 = bn.part[((int64_t)c1 * kNhwcParts + lane) * 2 + 1];
+          double sa0 = 0, sq0 = 0, sa1 = 0, sq1 = 0;
+          if (bn.part_f32) {       // per-workgroup float partials of the convolution that produced z: [C][n_parts][2]
+            const float2* pf = reinterpret_cast<const float2*>(bn.part);
+            for (int pi = lane; pi < bn.n_parts; pi += 64) {
+              const float2 v0 = pf[(int64_t)c0 * bn.n_parts + pi];
+              sa0 += v0.x; sq0 += v0.y;
+              if (kPairCh) {
+                const float2 v1 = pf[(int64_t)c1 * bn.n_parts + pi];
+                sa1 += v1.x; sq1 += v1.y;
+              }
+            }
+          } else {
+            sa0 = bn.part[((int64_t)c0 * kNhwcParts + lane) * 2];
+            sq0 = bn.part[((int64_t)c0 * kNhwcParts + lane) * 2 + 1];
+            if (kPairCh) {
+              sa1 = bn.part[((int64_t)c1 * kNhwcParts + lane) * 2];
+              sq1 = bn.part[((int64_t)c1 * kNhwcParts + lane) * 2 + 1];
+            }
           }
               sa0 = wave_sum_d_dpp(sa0);
           sq0 = wave_sum_d_dpp(sq0);

@@ -34,11 +34,13 @@ struct BnFold {
   const float* res;     // forward: optional residual (shortcut) added to x_q before the ReLU, same [B,F] layout
   float* dres;          // backward: optional output, the upstream gradient after the ReLU mask (= gradient of `res`)
   int nhwc;             // 0: z is [B,C,HW] (channel = f / HW);  1: channels-last [B,HW,C] (channel = f mod C, C a power of
-                        // two in [4,256]): forward `part` is [C][kNhwcParts][2]; backward dx_part is [n_tiles][min(C,TF)][2]
+                        // two in [4,256]): forward `part` is [C][n_parts][2]; backward dx_part is [n_tiles][min(C,TF)][2]
+  int n_parts;          // channels-last forward: partials per channel (kNhwcParts doubles from alignq_bn_partial_stats_nhwc,
+  int part_f32;         //   or, part_f32 = 1, the convolution epilogue's per-workgroup FLOAT partials)
 };
 inline BnFold no_bn() {
   return BnFold{nullptr, nullptr, 1, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0,
-                nullptr, nullptr, 0};
+                nullptr, nullptr, 0, 0, 0};
 }
 
 // Features per tile of the B in (64,128] backward kernel (also the granularity of BnFold::dx_part).

@@ -552,8 +552,8 @@ static inline bool bn_shape_ok(int B, int64_t F, int C, int HW, int nhwc) {
 int alignq_site_partials_bn(const float* z, const void* bn_part, const float* bn_gamma, const float* bn_beta,
                             float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
                             float bn_eps, float* ab, float* save, int C, int HW, int B, int64_t F, int k, float act_range,
-                            float eps, int relu, const float* residual, int nhwc, float* xq, float* stats, void* ws,
-                            void* stream) {
+                            float eps, int relu, const float* residual, int nhwc, int conv_parts, float* xq, float* stats,
+                            void* ws, void* stream) {
   if (!z || !ab || !save || !ws) return ALIGNQ_EINVAL;
   if (bad_k(k)) return ALIGNQ_EINVAL;
   if (!bn_shape_ok(B, F, C, HW, nhwc)) return ALIGNQ_EUNSUPPORTED;
@@ -562,6 +562,10 @@ int alignq_site_partials_bn(const float* z, const void* bn_part, const float* bn
   bn.part = (const double*)bn_part; bn.gamma = bn_gamma; bn.beta = bn_beta;
   bn.running_mean = running_mean; bn.running_var = running_var; bn.nbt = (long long*)num_batches_tracked;
   bn.momentum = momentum; bn.bn_eps = bn_eps; bn.relu = relu; bn.res = residual;
+  if (conv_parts > 0) {          // bn_part holds the producing convolution's per-workgroup float partials
+    if (!nhwc || !bn_part) return ALIGNQ_EINVAL;
+    bn.n_parts = conv_parts; bn.part_f32 = 1;
+  }
   return launch_partials4(true, geom(B, F), z, B, F, k, act_range, eps, xq, stats, (float*)ws, (hipStream_t)stream, bn);
 }
 

@@ -257,7 +257,7 @@ class BNSiteFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, bn_weight, bn_bias, running_mean, running_var, nbt, momentum, bn_eps, alterD, gamma, k, act_range,
-                eps, mu, rho, relu, rec=None, res=None):
+                eps, mu, rho, relu, rec=None, res=None, conv_part=None):
         z = L.dense_f32(z, "conv output")
         nhwc = not z.is_contiguous()             # dense_f32 only lets contiguous or channels-last 4-D tensors through
         if res is not None:
@@ -274,7 +274,11 @@ class BNSiteFn(torch.autograd.Function):
         st = L.stream_ptr()
         ab = torch.empty(2, C, dtype=torch.float32, device=dev)
         save = torch.empty(2, C, dtype=torch.float32, device=dev)
-        if nhwc:
+        conv_parts = 0
+        if nhwc and conv_part is not None:
+            # the convolution that produced z left per-workgroup partial statistics: no pass over z here
+            ws_bn, conv_parts = conv_part
+        elif nhwc:
             ws_bn = torch.empty(lib.alignq_bn_nhwc_ws_bytes(C), dtype=torch.uint8, device=dev)
             L.check(lib.alignq_bn_partial_stats_nhwc(L.ptr(z), B, C, HW, L.ptr(ws_bn), st), "alignq_bn_partial_stats_nhwc")
         else:
@@ -288,7 +292,7 @@ class BNSiteFn(torch.autograd.Function):
         L.check(lib.alignq_site_partials_bn(L.ptr(z), L.ptr(ws_bn), L.ptr(bn_weight), L.ptr(bn_bias), L.ptr(running_mean),
                                             L.ptr(running_var), L.ptr(nbt), float(momentum), float(bn_eps), L.ptr(ab),
                                             L.ptr(save), C, HW, B, F, int(k), float(act_range), float(eps),
-                                            int(bool(relu)), L.ptr(res), int(nhwc), L.ptr(y), L.ptr(stats), L.ptr(ws), st),
+                                            int(bool(relu)), L.ptr(res), int(nhwc), int(conv_parts), L.ptr(y), L.ptr(stats), L.ptr(ws), st),
                 "alignq_site_partials_bn")
         if rec is not None:      # reduced with all other sites in DeferredLosses.total()
             rec.ws, rec.D, rec.A, rec.Gm, rec.B, rec.F, rec.dim = ws, D, A, Gm, B, F, dim
@@ -341,7 +345,7 @@ class BNSiteFn(torch.autograd.Function):
         dbet = torch.empty(C, dtype=torch.float32, device=dev) if has_b else None
         L.check(lib.alignq_bn_bwd_apply(L.ptr(dx), L.ptr(z), L.ptr(ab), L.ptr(save), L.ptr(part), B, C, HW, nhwc, L.ptr(dz),
                                         L.ptr(dgam), L.ptr(dbet), st), "alignq_bn_bwd_apply")
-        return (dz, dgam, dbet, None, None, None, None, None, dA, dG, None, None, None, None, None, None, None, dres)
+        return (dz, dgam, dbet, None, None, None, None, None, dA, dG, None, None, None, None, None, None, None, dres, None)
 
 
 def _is_nhwc(z) -> bool:
@@ -381,7 +385,8 @@ def bn_site(bn, act, z, eps=0.0, relu=False, residual=None):
     rec = deferred.new_record(z.shape[0], z.device) if deferred is not None else None
     y, loss, D = BNSiteFn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
                                 bn.momentum, bn.eps, admm.alterD, admm.gamma, act.a_bit, config.args.act_range, eps,
-                                admm.mu, admm.rho, relu, rec, residual)
+                                admm.mu, admm.rho, relu, rec, residual,
+                                getattr(z, "_alignq_bn_part", None) if _is_nhwc(z) else None)
     admm.D = D
     if deferred is not None:
         if rec is not None:

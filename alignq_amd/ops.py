@@ -293,25 +293,49 @@ class QConv3x3Fn(torch.autograd.Function):
     instead of by a separate accumulation kernel."""
 
     @staticmethod
-    def forward(ctx, x, w, w_bit, tap=False):
+    def forward(ctx, x, w, w_bit, tap=False, bn_stats=False):
+        """bn_stats=True: the kernel's epilogue also leaves per-workgroup per-channel {sum y, sum y^2}; they are attached to
+        the output as `y._alignq_bn_part = (float tensor [C, parts, 2], parts)` for fused.bn_site, which then skips its own
+        statistics pass over y."""
         B, C, H, W = x.shape
+        lib = L.load()
         y = torch.empty_like(x)
-        L.check(L.load().alignq_conv3x3_nhwc(L.ptr(x), L.ptr(w), L.ptr(y), B, H, W, C, int(w_bit), 0, None,
-                                             L.stream_ptr()), "alignq_conv3x3_nhwc")
+        part, n_parts = None, 0
+        if bn_stats:
+            n_parts = lib.alignq_conv3x3_bn_parts(B, H, W, C)
+            part = torch.empty(C, n_parts, 2, dtype=torch.float32, device=x.device) if n_parts > 0 else None
+        L.check(lib.alignq_conv3x3_nhwc(L.ptr(x), L.ptr(w), L.ptr(y), B, H, W, C, int(w_bit), 0, None, L.ptr(part),
+                                        L.stream_ptr()), "alignq_conv3x3_nhwc")
         ctx.save_for_backward(x, w)
         ctx.w_bit = int(w_bit)
         ctx.tap = bool(tap)
+        if part is not None:
+            QConv3x3Fn._mailbox = (part, n_parts)
         if tap:
             ctx.set_materialize_grads(False)
             return y, x.view_as(x)
         return y
 
     @staticmethod
+    def apply_with_stats(x, w, w_bit, tap=False):
+        """apply(...) with bn_stats=True; attaches the partial statistics to the returned y (a plain python attribute)."""
+        # the partials are created inside forward; fetch them through a one-slot mailbox (autograd hides ctx from callers)
+        QConv3x3Fn._mailbox = None
+        out = QConv3x3Fn.apply(x, w, w_bit, tap, True)
+        y = out[0] if tap else out
+        if QConv3x3Fn._mailbox is not None:
+            y._alignq_bn_part = QConv3x3Fn._mailbox
+            QConv3x3Fn._mailbox = None
+        return out
+
+    _mailbox = None
+
+    @staticmethod
     def backward(ctx, gy, gtap=None):
         x, w = ctx.saved_tensors
         B, C, H, W = x.shape
         if gy is None:                     # only the shortcut alias was used downstream
-            return gtap, None, None, None
+            return gtap, None, None, None, None
         gy = L.like_layout(gy, x)
         add = None if gtap is None else L.like_layout(gtap, x)
         dx = dw = None
@@ -326,10 +350,10 @@ class QConv3x3Fn(torch.autograd.Function):
             L.check(lib.alignq_conv3x3_nhwc_bwd(L.ptr(x), L.ptr(gy), L.ptr(w), L.ptr(dx), L.ptr(ws), B, H, W, C, ctx.w_bit,
                                                 ctypes.byref(ns), L.ptr(add), L.stream_ptr()), "alignq_conv3x3_nhwc_bwd")
             pending.add(ws, dw, ns.value, C)
-            return dx, dw, None, None
+            return dx, dw, None, None, None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            L.check(lib.alignq_conv3x3_nhwc(L.ptr(gy), L.ptr(w), L.ptr(dx), B, H, W, C, ctx.w_bit, 1, L.ptr(add),
+            L.check(lib.alignq_conv3x3_nhwc(L.ptr(gy), L.ptr(w), L.ptr(dx), B, H, W, C, ctx.w_bit, 1, L.ptr(add), None,
                                             L.stream_ptr()), "alignq_conv3x3_nhwc")
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)          # channels-last [C,3,3,C] storage like w
@@ -342,4 +366,4 @@ class QConv3x3Fn(torch.autograd.Function):
             else:
                 L.check(lib.alignq_conv3x3_nhwc_wgrad(L.ptr(x), L.ptr(gy), L.ptr(dw), L.ptr(ws), B, H, W, C, None,
                                                       L.stream_ptr()), "alignq_conv3x3_nhwc_wgrad")
-        return dx, dw, None, None
+        return dx, dw, None, None, None

@@ -159,7 +159,8 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
                 if getattr(self, "use_qconv", False) and ops.qconv3x3_supported(
                         input, weight_q, self.stride, self.padding, self.dilation, self.groups, self.bias,
                         self.quantize_fn.w_bit):
-                    return ops.QConv3x3Fn.apply(input, weight_q, self.quantize_fn.w_bit)
+                    # (with the batch-norm statistics of its output as a by-product for fused.bn_site)
+                    return ops.QConv3x3Fn.apply_with_stats(input, weight_q, self.quantize_fn.w_bit)
                 return F.conv2d(input, weight_q, self.bias, self.stride, self.padding, self.dilation, self.groups)
 
             def forward_with_shortcut(self, input):
@@ -170,7 +171,7 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
                 if getattr(self, "use_qconv", False) and input.requires_grad and ops.qconv3x3_supported(
                         input, weight_q, self.stride, self.padding, self.dilation, self.groups, self.bias,
                         self.quantize_fn.w_bit):
-                    return ops.QConv3x3Fn.apply(input, weight_q, self.quantize_fn.w_bit, True)
+                    return ops.QConv3x3Fn.apply_with_stats(input, weight_q, self.quantize_fn.w_bit, True)
                 return (F.conv2d(input, weight_q, self.bias, self.stride, self.padding, self.dilation, self.groups),
                         input)
 

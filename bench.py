@@ -110,7 +110,7 @@ def measure_kernels(dev, B, k, site_F_counts, hw_of_F, folded=True, nhwc=False):
             f_stats = ((lambda: lib.alignq_bn_partial_stats_nhwc(p(x), B, C, HW, p(ws_bn), st)) if nh else
                        (lambda: lib.alignq_bn_partial_stats(p(x), B, C, HW, p(ws_bn), st)))
             f_part = lambda: lib.alignq_site_partials_bn(p(x), p(ws_bn), p(gam), p(bet), p(rm), p(rv), p(nbt), 0.1, 1e-5, p(ab),
-                                                         p(save), C, HW, B, F, k, 2.0, 0.0, 1, None, nh, p(xq), p(stats), p(ws), st)
+                                                         p(save), C, HW, B, F, k, 2.0, 0.0, 1, None, nh, 0, p(xq), p(stats), p(ws), st)
             f_bwd = lambda: lib.alignq_site_bwd_apply_bn(p(g), p(S), p(x), p(ab), p(save), C, HW, nh, p(xq), None, p(stats), B, F, 2.0,
                                                          0.0, p(dx), p(part), st)
             f_bnb = lambda: lib.alignq_bn_bwd_apply(p(dx), p(x), p(ab), p(save), p(part), B, C, HW, nh, p(dz), p(dgam), p(dbet), st)

@@ -185,9 +185,12 @@ int alignq_site_prep_fused_multi(int S, const float* const* D, const float* cons
  * accumulation error remains.  Supported (C, W): (16, 32), (32, 16), (64, 8), H a multiple or divisor of the tile rows;
  * anything else returns ALIGNQ_EUNSUPPORTED and the caller keeps MIOpen.
  * dgrad = 0: y = conv(x, wt);  dgrad = 1: x is dy and y receives dx (the same kernel on the flipped, transposed filter).
- * add != NULL: a [B,H,W,C] tensor added to the result in the epilogue (the identity shortcut's gradient joining dx).      */
+ * add != NULL: a [B,H,W,C] tensor added to the result in the epilogue (the identity shortcut's gradient joining dx).
+ * bn_part != NULL (forward only): per-workgroup per-channel {sum y, sum y^2} as floats [C][alignq_conv3x3_bn_parts][2] for the
+ * batch-norm that follows (alignq_site_partials_bn, conv_parts).                                                          */
+int alignq_conv3x3_bn_parts(int B, int H, int W, int C);   /* workgroups of the forward launch (0: unsupported shape) */
 int alignq_conv3x3_nhwc(const float* x, const float* wt, float* y, int B, int H, int W, int C, int w_bit, int dgrad,
-                        const float* add, void* stream);
+                        const float* add, float* bn_part, void* stream);
 
 /* Filter gradient of the same convolution, dW [C,3,3,C] (channels-last weight storage) from x and dy: plain fp32 on the f32
  * MFMAs (products and accumulation bit-for-bit an fmaf chain), per-pixel-range partial sums in ws
@@ -234,8 +237,8 @@ int alignq_bn_stats(const float* z, int B, int C, int HW, const float* gamma, co
 int alignq_site_partials_bn(const float* z, const void* bn_part, const float* bn_gamma, const float* bn_beta,
                             float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
                             float bn_eps, float* ab, float* save, int C, int HW, int B, int64_t F, int k, float act_range,
-                            float eps, int relu, const float* residual, int nhwc, float* xq, float* stats, void* ws,
-                            void* stream);
+                            float eps, int relu, const float* residual, int nhwc, int conv_parts, float* xq, float* stats,
+                            void* ws, void* stream);
 size_t alignq_site_bn_part_bytes(int64_t F, int nhwc);
 int alignq_site_prep_fused(const float* D, const float* alterD, const float* gamma, int dim, const float* scal, float mu,
                            const float* dD_scale, int B, int64_t F, float* S, float* dalterD, float* dgamma,
@@ -250,6 +253,9 @@ int alignq_bn_bwd_apply(const float* dx, const float* z, const float* ab, const 
  * ws (alignq_bn_nhwc_ws_bytes(C)); alignq_site_partials_bn(bn_part = ws, nhwc = 1) finalises its tile's channels from
  * them exactly as in the NCHW form.  The site backward leaves per-tile per-channel sums in dx_part
  * (alignq_site_bn_part_bytes(F, 1)) and alignq_bn_bwd_apply(nhwc = 1) reduces them itself.                               */
+/* conv_parts > 0 (channels-last only): bn_part is not alignq_bn_partial_stats_nhwc's buffer but the FLOAT partials
+ * [C][conv_parts][2] that alignq_conv3x3_nhwc(bn_part = ...) left while it produced z (conv_parts =
+ * alignq_conv3x3_bn_parts(B,H,W,C)): the batch-norm then needs no statistics pass of its own over z.                      */
 size_t alignq_bn_nhwc_ws_bytes(int C);
 int alignq_bn_partial_stats_nhwc(const float* z, int B, int C, int HW, void* ws, void* stream);
 

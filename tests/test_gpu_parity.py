@@ -878,3 +878,48 @@ def test_fast_path_trajectory_tracks_plain_path(dev):
             continue
         cos = float(torch.dot(w_a[n], w_b[n]) / (w_a[n].norm() * w_b[n].norm() + 1e-30))
         assert cos > 0.995, (n, cos)
+
+
+@pytest.mark.parametrize("B,C,H,k", [(128, 16, 32, 8), (128, 32, 16, 8), (128, 64, 8, 4), (72, 16, 32, 8)])
+def test_conv_epilogue_bn_statistics_feed_the_fold(dev, B, C, H, k):
+    """The convolution's epilogue leaves per-workgroup per-channel {sum y, sum y^2}; (1) they add up to the statistics of y,
+    (2) fused.bn_site consuming them (no statistics pass over y) gives the same site results as with its own statistics
+    kernel: identical up to the float-vs-double rounding of the partial sums (tie-zone bin flips only)."""
+    import alignq_amd.cdf_alignment_admm as A
+    from alignq_amd import config, ops
+    from alignq_amd.fused import bn_site
+    config.args.bitW = config.args.abitW = k
+    torch.manual_seed(B + C)
+    n = 2 ** k - 1
+    cl = torch.channels_last
+    x = (torch.randn(B, C, H, H, device=dev) * 1.1).contiguous(memory_format=cl)
+    wq = (torch.round(torch.tanh(torch.randn(C, C, 3, 3)) * n) / n).to(dev).contiguous(memory_format=cl)
+    y = ops.QConv3x3Fn.apply_with_stats(x, wq, k)
+    part, n_parts = y._alignq_bn_part
+    assert part.shape == (C, n_parts, 2)
+    yd = y.double()
+    np.testing.assert_allclose(npy(part[:, :, 0].double().sum(1)), npy(yd.sum((0, 2, 3))), rtol=1e-5, atol=1e-2)
+    np.testing.assert_allclose(npy(part[:, :, 1].double().sum(1)), npy((yd * yd).sum((0, 2, 3))), rtol=1e-5)
+    gq = torch.randn_like(y) * 0.01
+    outs = []
+    for with_part in (False, True):
+        torch.manual_seed(1)
+        bn = torch.nn.BatchNorm2d(C).to(dev).train()
+        admm = A.ADMM(128).to(dev)
+        act = A.activation_quantize_fn(k, "second", admm)
+        z = y.detach().clone(memory_format=cl).requires_grad_(True)
+        if with_part:
+            z._alignq_bn_part = (part, n_parts)
+        xq, loss = bn_site(bn, act, z, relu=True)
+        (loss + (xq * gq).sum()).backward()
+        outs.append(dict(xq=npy(xq), D=npy(admm.D), loss=float(loss.detach()), dz=npy(z.grad), rm=npy(bn.running_mean),
+                         rv=npy(bn.running_var)))
+    a, b = outs
+    flips = np.abs(a["xq"] - b["xq"]) * n
+    assert flips.max() <= 1.0 + 1e-3 and (flips > 0.5).mean() < 1e-3
+    np.testing.assert_allclose(b["D"], a["D"], atol=TOL)
+    np.testing.assert_allclose(b["loss"], a["loss"], atol=TOL)
+    np.testing.assert_allclose(b["rm"], a["rm"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(b["rv"], a["rv"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(b["dz"], a["dz"], atol=2e-5, rtol=1e-3)
+    config.args.bitW = config.args.abitW = 8
