@@ -247,6 +247,50 @@ __global__ __launch_bounds__(kNhwcThreads) void bn_bwd_apply_nhwc_kernel(
   }
 }
 
+// Stage 1 of bn_bwd_apply_nhwc_kernel alone: per-channel totals of the site backward's per-tile partial sums ->
+// ktot = {sum g / n, sum g*zhat / n} and dgamma / dbeta.  One workgroup; used when the consumer of the batch-norm input
+// gradient (alignq_conv3x3_nhwc_bwd) forms that gradient on load.
+__global__ __launch_bounds__(kNhwcThreads) void bn_bwd_totals_nhwc_kernel(const float* __restrict__ part, int n_tiles,
+                                                                      int tile_f, int B, int C, int HW,
+                                                                      float* __restrict__ ktot, float* __restrict__ dgamma,
+                                                                      float* __restrict__ dbeta) {
+  __shared__ double sm[kNhwcThreads][2];
+  const int tid = threadIdx.x;
+  const int cp = C < tile_f ? C : tile_f;
+  const int cyc = C / cp;
+  const int cnt = n_tiles / cyc;
+  const int groups = kNhwcThreads / C;
+  const int c = tid % C, grp = tid / C;
+  const int e = c % cp, t_first = c / cp;
+  double s0 = 0, s1 = 0;
+  constexpr int U = 8;
+  for (int i0 = grp; i0 < cnt; i0 += groups * U) {
+    float2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = i0 + u * groups;
+      const int ic = i < cnt ? i : cnt - 1;
+      v[u] = *reinterpret_cast<const float2*>(part + ((int64_t)(ic * cyc + t_first) * cp + e) * 2);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (i0 + u * groups < cnt) { s0 += v[u].x; s1 += v[u].y; }
+    }
+  }
+  sm[tid][0] = s0;
+  sm[tid][1] = s1;
+  __syncthreads();
+  if (grp == 0) {
+    double t0 = 0, t1 = 0;
+    for (int g = 0; g < groups; g++) { t0 += sm[g * C + c][0]; t1 += sm[g * C + c][1]; }
+    if (dbeta) dbeta[c] = (float)t0;
+    if (dgamma) dgamma[c] = (float)t1;
+    const double n = (double)B * (double)HW;
+    ktot[c] = (float)(t0 / n);
+    ktot[C + c] = (float)(t1 / n);
+  }
+}
+
 }  // namespace
 
 #define LAUNCH_CHECK()                          \
@@ -289,6 +333,18 @@ int alignq_bn_partial_stats_nhwc(const float* z, int B, int C, int HW, void* ws,
   if (!z || !ws || B < 1 || C < 1 || HW < 1) return ALIGNQ_EINVAL;
   if (!nhwc_channels_ok(C) || (reinterpret_cast<uintptr_t>(z) & 15)) return ALIGNQ_EUNSUPPORTED;
   hipLaunchKernelGGL(bn_stats_nhwc_kernel, kNhwcParts, kNhwcThreads, 0, (hipStream_t)stream, z, B, C, HW, (double*)ws);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int alignq_bn_bwd_totals(const float* dx_part, int B, int C, int HW, float* ktot, float* dgamma, float* dbeta, void* stream) {
+  if (!dx_part || !ktot || B < 1 || C < 1 || HW < 1) return ALIGNQ_EINVAL;
+  if (!nhwc_channels_ok(C)) return ALIGNQ_EUNSUPPORTED;
+  const int64_t F = (int64_t)C * HW;
+  const int tf = alignq_site::bwd_tile_features(B, F);
+  if (F % tf) return ALIGNQ_EUNSUPPORTED;
+  hipLaunchKernelGGL(bn_bwd_totals_nhwc_kernel, 1, kNhwcThreads, 0, (hipStream_t)stream, dx_part, (int)(F / tf), tf, B, C, HW,
+                     ktot, dgamma, dbeta);
   LAUNCH_CHECK();
   return 0;
 }

@@ -28,6 +28,24 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // C channels, WD image width, PT pixels per workgroup (TR = PT / WD whole image rows, TR divides H so a tile never straddles
 // two images).  LDS pixel stride is C + 8 bf16: the 16 lanes of a ds_read_b128 phase then hit 16 distinct 16-byte slots.
+// The gradient w.r.t. a folded batch-norm's input, formed ON LOAD from the site backward's output g (gradient w.r.t. the BN
+// output) instead of by a separate elementwise kernel:  dy = a[c] * (g - k0[c] - (z - mean[c]) * invstd[c] * k1[c]).
+struct BnLazy {
+  const float* z;      // the convolution's forward output (= BN input), same layout as g; nullptr => g already is dy
+  const float* ab;     // [2][C]: a = gamma * invstd, (b)
+  const float* save;   // [2][C]: batch mean, invstd
+  const float* ktot;   // [2][C]: k0 = sum g / n, k1 = sum g * zhat / n
+};
+__device__ __forceinline__ float4 bn_lazy4(const float4& g, const float4& z, const float4& a, const float4& m, const float4& is,
+                                           const float4& k0, const float4& k1) {
+  float4 o;
+  o.x = a.x * (g.x - k0.x - (z.x - m.x) * is.x * k1.x);
+  o.y = a.y * (g.y - k0.y - (z.y - m.y) * is.y * k1.y);
+  o.z = a.z * (g.z - k0.z - (z.z - m.z) * is.z * k1.z);
+  o.w = a.w * (g.w - k0.w - (z.w - m.w) * is.w * k1.w);
+  return o;
+}
+
 template <int C, int WD, int PT>
 struct ConvLds {
   static constexpr int kBf16 = 3 * ((PT / WD) + 2) * (WD + 2) * (C + 8);      // three bf16 images of the tile with halo
@@ -37,7 +55,8 @@ template <int C, int WD, int PT, bool DGRAD>
 __device__ __forceinline__ void conv3x3_body(const float* __restrict__ x, const float* __restrict__ w,
                                              float* __restrict__ y, int H, int total_rows, float nlev, __bf16* lds,
                                              int block, const float* __restrict__ add,
-                                             float* __restrict__ bn_part = nullptr, int n_wg = 0) {
+                                             float* __restrict__ bn_part = nullptr, int n_wg = 0,
+                                             BnLazy lazy = BnLazy{nullptr, nullptr, nullptr, nullptr}) {
   constexpr int TR = PT / WD;                 // image rows per workgroup
   constexpr int NS = (9 * C + 31) / 32;       // k steps of 32
   constexpr int NCG = C / 16;                 // 16-channel output groups
@@ -70,6 +89,31 @@ __device__ __forceinline__ void conv3x3_body(const float* __restrict__ x, const 
       const int64_t off = ok ? ((int64_t)grow * WD + (col - 1)) * C + 4 * c4 : 0;
       v[it] = *reinterpret_cast<const float4*>(x + off);
       if (!ok) v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (DGRAD && lazy.z) {       // x is g: turn it into the batch-norm input gradient here (zeros stay zeros: padding)
+      float4 zz[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+        const int i = tid + 256 * it;
+        const int c4 = i % C4, col = (i / C4) % LW, lr = i / (C4 * LW);
+        const int grow = row0 + lr - 1;
+        const bool ok = i < N4 && col >= 1 && col <= WD && grow >= img_lo && grow < img_hi && grow < total_rows;
+        zz[it] = *reinterpret_cast<const float4*>(lazy.z + (ok ? ((int64_t)grow * WD + (col - 1)) * C + 4 * c4 : 0));
+      }
+      const int c4t = tid % C4;             // 256 % C4 == 0: a thread always handles the same channel quad
+      const float4 a4 = *reinterpret_cast<const float4*>(lazy.ab + 4 * c4t);
+      const float4 m4 = *reinterpret_cast<const float4*>(lazy.save + 4 * c4t);
+      const float4 i4 = *reinterpret_cast<const float4*>(lazy.save + C + 4 * c4t);
+      const float4 k0 = *reinterpret_cast<const float4*>(lazy.ktot + 4 * c4t);
+      const float4 k1 = *reinterpret_cast<const float4*>(lazy.ktot + C + 4 * c4t);
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+        const int i = tid + 256 * it;
+        const int col = (i / C4) % LW, lr = i / (C4 * LW);
+        const int grow = row0 + lr - 1;
+        const bool ok = i < N4 && col >= 1 && col <= WD && grow >= img_lo && grow < img_hi && grow < total_rows;
+        if (ok) v[it] = bn_lazy4(v[it], zz[it], a4, m4, i4, k0, k1);
+      }
     }
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
@@ -254,7 +298,7 @@ __device__ __forceinline__ bf16x8 join8(s16x4 a, s16x4 b) {
 template <int C, int WD, int PT>
 __device__ __forceinline__ void wgrad3x3_body(const float* __restrict__ x, const float* __restrict__ dy,
                                               float* __restrict__ slabs, int H, int n_tiles, float* lds_f, int bx, int gx,
-                                              int by) {
+                                              int by, BnLazy lazy = BnLazy{nullptr, nullptr, nullptr, nullptr}) {
   constexpr int TR = PT / WD;
   constexpr int CB = C >= 32 ? 32 : 16;          // channel block (both co and ci) of the workgroup
   constexpr int NBLK = C / CB;
@@ -278,7 +322,7 @@ __device__ __forceinline__ void wgrad3x3_body(const float* __restrict__ x, const
   constexpr int N4 = (TR + 2) * LW * C4;           // float4 slots of the x tile with halo
   constexpr int M4 = TR * WD * C4;                 // float4 slots of the dy tile
   constexpr int NIX = (N4 + 255) / 256, NID = (M4 + 255) / 256;
-  f32x4 rx[NIX], rd[NID];     // plain vector registers (HIP's float4 struct here ends up in scratch)
+  f32x4 rx[NIX], rd[NID], rz[NID];     // plain vector registers (HIP's float4 struct here ends up in scratch)
   // (fetch / park are spelled out twice below rather than hidden in a lambda or macro: the register arrays must be indexed
   // by unrolled constants or they end up in scratch)
   int nxt = bx;
@@ -300,7 +344,18 @@ __device__ __forceinline__ void wgrad3x3_body(const float* __restrict__ x, const
       const int i = tid + 256 * it;
       const int64_t off = i < M4 ? ((int64_t)row0_ * WD + i / C4) * C + bi * CB + 4 * (i % C4) : 0;
       rd[it] = *reinterpret_cast<const f32x4*>(dy + off);
+      if (lazy.z) rz[it] = *reinterpret_cast<const f32x4*>(lazy.z + off);
     }
+  }
+  // per-thread channel quad of the dy tile (256 % C4 == 0) and its batch-norm constants for the lazy form
+  f32x4 la = {0, 0, 0, 0}, lm = la, li = la, lk0 = la, lk1 = la;
+  if (lazy.z) {
+    const int cq = bi * CB + 4 * (tid % C4);
+    la = *reinterpret_cast<const f32x4*>(lazy.ab + cq);
+    lm = *reinterpret_cast<const f32x4*>(lazy.save + cq);
+    li = *reinterpret_cast<const f32x4*>(lazy.save + C + cq);
+    lk0 = *reinterpret_cast<const f32x4*>(lazy.ktot + cq);
+    lk1 = *reinterpret_cast<const f32x4*>(lazy.ktot + C + cq);
   }
   for (int tile = bx; tile < n_tiles; tile += gx) {
     __syncthreads();                               // previous tile's readers are done
@@ -329,9 +384,11 @@ __device__ __forceinline__ void wgrad3x3_body(const float* __restrict__ x, const
       const int i = tid + 256 * it;
       if (i < M4) {
         bf16x4 h4, m4, l4;
+        f32x4 dv = rd[it];
+        if (lazy.z) dv = la * (dv - lk0 - (rz[it] - lm) * li * lk1);     // batch-norm input gradient formed on load
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-          const float v = rd[it][e];
+          const float v = dv[e];
           const __bf16 hi = (__bf16)v;
           const float r1 = v - (float)hi;
           const __bf16 mi = (__bf16)r1;
@@ -363,6 +420,7 @@ __device__ __forceinline__ void wgrad3x3_body(const float* __restrict__ x, const
         const int i = tid + 256 * it;
         const int64_t off = i < M4 ? ((int64_t)row0_ * WD + i / C4) * C + bi * CB + 4 * (i % C4) : 0;
         rd[it] = *reinterpret_cast<const f32x4*>(dy + off);
+        if (lazy.z) rz[it] = *reinterpret_cast<const f32x4*>(lazy.z + off);
       }
     }
     // ---- MFMA phase: 32 pixels per step; lane group g owns pixels p0 + 8g .. + 7 (8 consecutive columns of one row) ---
@@ -444,15 +502,16 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_kernel(const float* __restric
                                                           const float* __restrict__ w, float* __restrict__ dx,
                                                           float* __restrict__ slabs, int H, int total_rows, float nlev,
                                                           int n_tiles_w, int splits, int nblk2,
-                                                          const float* __restrict__ add) {
+                                                          const float* __restrict__ add, BnLazy lazy) {
   constexpr int kBytesD = ConvLds<C, WD, PTD>::kBf16 * 2, kBytesW = WgradLds<C, WD, PTW>::kFloats * 4;
   __shared__ __attribute__((aligned(16))) unsigned char lds[kBytesD > kBytesW ? kBytesD : kBytesW];
   const int n_wg = splits * nblk2;
   if ((int)blockIdx.x < n_wg) {
     wgrad3x3_body<C, WD, PTW>(x, dy, slabs, H, n_tiles_w, reinterpret_cast<float*>(lds), blockIdx.x % splits, splits,
-                              blockIdx.x / splits);
+                              blockIdx.x / splits, lazy);
   } else {
-    conv3x3_body<C, WD, PTD, true>(dy, w, dx, H, total_rows, nlev, reinterpret_cast<__bf16*>(lds), blockIdx.x - n_wg, add);
+    conv3x3_body<C, WD, PTD, true>(dy, w, dx, H, total_rows, nlev, reinterpret_cast<__bf16*>(lds), blockIdx.x - n_wg, add,
+                                   nullptr, 0, lazy);
   }
 }
 
@@ -529,7 +588,7 @@ int launch_wgrad(const float* x, const float* dy, float* dw, float* ws, int B, i
 
 template <int C, int WD, int PTD, int PTW>
 int launch_bwd(const float* x, const float* dy, const float* w, float* dx, float* ws, int B, int H, float nlev,
-               int* n_slabs_out, const float* add, hipStream_t st) {
+               int* n_slabs_out, const float* add, BnLazy lazy, hipStream_t st) {
   constexpr int TRD = PTD / WD, TRW = PTW / WD;
   if (H % TRD || H % TRW) return ALIGNQ_EUNSUPPORTED;
   const int total_rows = B * H;
@@ -539,7 +598,7 @@ int launch_bwd(const float* x, const float* dy, const float* w, float* dx, float
   if (splits > n_tiles_w) splits = n_tiles_w;
   const int grid = splits * NB * NB + total_rows / TRD;
   hipLaunchKernelGGL((conv3x3_bwd_kernel<C, WD, PTD, PTW>), grid, 256, 0, st, x, dy, w, dx, ws, H, total_rows, nlev, n_tiles_w,
-                     splits, NB * NB, add);
+                     splits, NB * NB, add, lazy);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   *n_slabs_out = splits;
@@ -616,16 +675,19 @@ int alignq_conv3x3_wgrad_reduce_multi(int T, const void* const* ws, float* const
 // Both gradients of one convolution in a single launch (data gradient as alignq_conv3x3_nhwc(dgrad = 1), filter-gradient
 // partial sums as alignq_conv3x3_nhwc_wgrad with a deferred reduction: *n_slabs_out slabs are left in ws).
 int alignq_conv3x3_nhwc_bwd(const float* x, const float* dy, const float* wt, float* dx, void* ws, int B, int H, int W,
-                            int C, int w_bit, int* n_slabs_out, const float* add, void* stream) {
+                            int C, int w_bit, int* n_slabs_out, const float* add, const float* bn_z, const float* bn_ab,
+                            const float* bn_save, const float* bn_ktot, void* stream) {
+  if (bn_z && (!bn_ab || !bn_save || !bn_ktot)) return ALIGNQ_EINVAL;
+  const BnLazy lazy{bn_z, bn_ab, bn_save, bn_ktot};
   if (!x || !dy || !wt || !dx || !ws || !n_slabs_out || B < 1 || H < 1) return ALIGNQ_EINVAL;
   if (w_bit < 1 || w_bit > 8) return ALIGNQ_EUNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(wt) |
        reinterpret_cast<uintptr_t>(dx)) & 15) return ALIGNQ_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const float nlev = (float)((1 << w_bit) - 1);
-  if (C == 16 && W == 32) return launch_bwd<16, 32, 256, 128>(x, dy, wt, dx, (float*)ws, B, H, nlev, n_slabs_out, add, st);
-  if (C == 32 && W == 16) return launch_bwd<32, 16, 128, 128>(x, dy, wt, dx, (float*)ws, B, H, nlev, n_slabs_out, add, st);
-  if (C == 64 && W == 8) return launch_bwd<64, 8, 32, 64>(x, dy, wt, dx, (float*)ws, B, H, nlev, n_slabs_out, add, st);
+  if (C == 16 && W == 32) return launch_bwd<16, 32, 256, 128>(x, dy, wt, dx, (float*)ws, B, H, nlev, n_slabs_out, add, lazy, st);
+  if (C == 32 && W == 16) return launch_bwd<32, 16, 128, 128>(x, dy, wt, dx, (float*)ws, B, H, nlev, n_slabs_out, add, lazy, st);
+  if (C == 64 && W == 8) return launch_bwd<64, 8, 32, 64>(x, dy, wt, dx, (float*)ws, B, H, nlev, n_slabs_out, add, lazy, st);
   return ALIGNQ_EUNSUPPORTED;
 }
 

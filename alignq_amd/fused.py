@@ -209,6 +209,7 @@ class DeferredWgrads:
     def __enter__(self):
         global _active_wgrads
         self.items = []
+        _lazy_dz.clear()
         _active_wgrads = self
         return self
 
@@ -237,6 +238,20 @@ _active_wgrads = None
 
 def active_wgrads():
     return _active_wgrads
+
+
+# Lazy batch-norm input gradients: BNSiteFn.backward may hand the gradient g w.r.t. the BN OUTPUT to the convolution that
+# produced z instead of the finished dz; ops.QConv3x3Fn.backward forms dz on load (alignq_conv3x3_nhwc_bwd, bn_z ...).
+# Keyed by the gradient tensor's data pointer; only used inside a DeferredWgrads context (TrainStep).
+_lazy_dz = {}
+
+
+def post_lazy_dz(g, z, ab, save, ktot):
+    _lazy_dz[g.data_ptr()] = (g, z, ab, save, ktot)
+
+
+def take_lazy_dz(g):
+    return _lazy_dz.pop(g.data_ptr(), None) if _lazy_dz else None
 
 
 _active = None
@@ -301,6 +316,7 @@ class BNSiteFn(torch.autograd.Function):
             L.check(lib.alignq_site_reduce_loss(L.ptr(ws), B, F, L.ptr(D), L.ptr(A), L.ptr(Gm), dim, float(mu),
                                                 float(rho), L.ptr(scal), st), "alignq_site_reduce_loss")
         ctx.rec = rec
+        ctx.from_qconv = bool(nhwc and conv_part is not None)
         ctx.save_for_backward(z, ab, save, stats, D, A, Gm, scal, y if relu else None)
         ctx.set_materialize_grads(False)
         ctx.cfg = (float(act_range), float(eps), float(mu), bn_weight is not None, bn_bias is not None, res is not None,
@@ -340,9 +356,17 @@ class BNSiteFn(torch.autograd.Function):
         L.check(lib.alignq_site_bwd_apply_bn(L.ptr(g_y), L.ptr(S), L.ptr(z), L.ptr(ab), L.ptr(save), C, HW, nhwc, L.ptr(y),
                                              L.ptr(dres) if y is not None else None, L.ptr(stats), B, F, act_range, eps,
                                              L.ptr(dx), L.ptr(part), st), "alignq_site_bwd_apply_bn")
-        dz = torch.empty_like(z)
         dgam = torch.empty(C, dtype=torch.float32, device=dev) if has_w else None
         dbet = torch.empty(C, dtype=torch.float32, device=dev) if has_b else None
+        if ctx.from_qconv and active_wgrads() is not None:
+            # z is the output of ops.QConv3x3Fn and a whole-model backward is running: only the per-channel totals are
+            # computed here; the convolution's backward forms dz = a*(g - k0 - zhat*k1) on load (no elementwise pass)
+            ktot = torch.empty(2, C, dtype=torch.float32, device=dev)
+            L.check(lib.alignq_bn_bwd_totals(L.ptr(part), B, C, HW, L.ptr(ktot), L.ptr(dgam), L.ptr(dbet), st),
+                    "alignq_bn_bwd_totals")
+            post_lazy_dz(dx, z, ab, save, ktot)
+            return (dx, dgam, dbet, None, None, None, None, None, dA, dG, None, None, None, None, None, None, None, dres, None)
+        dz = torch.empty_like(z)
         L.check(lib.alignq_bn_bwd_apply(L.ptr(dx), L.ptr(z), L.ptr(ab), L.ptr(save), L.ptr(part), B, C, HW, nhwc, L.ptr(dz),
                                         L.ptr(dgam), L.ptr(dbet), st), "alignq_bn_bwd_apply")
         return (dz, dgam, dbet, None, None, None, None, None, dA, dG, None, None, None, None, None, None, None, dres, None)

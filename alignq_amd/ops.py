@@ -336,6 +336,7 @@ class QConv3x3Fn(torch.autograd.Function):
         B, C, H, W = x.shape
         if gy is None:                     # only the shortcut alias was used downstream
             return gtap, None, None, None, None
+        lazy = fused.take_lazy_dz(gy)      # (g, z, ab, save, ktot): gy is the gradient w.r.t. the folded BN's OUTPUT
         gy = L.like_layout(gy, x)
         add = None if gtap is None else L.like_layout(gtap, x)
         dx = dw = None
@@ -347,10 +348,17 @@ class QConv3x3Fn(torch.autograd.Function):
             dx, dw = torch.empty_like(x), torch.empty_like(w)
             ws = _ws(lib.alignq_conv3x3_wgrad_ws_bytes(C), x.device)
             ns = ctypes.c_int(0)
+            bz, bab, bsave, bk = (lazy[1], lazy[2], lazy[3], lazy[4]) if lazy is not None else (None, None, None, None)
             L.check(lib.alignq_conv3x3_nhwc_bwd(L.ptr(x), L.ptr(gy), L.ptr(w), L.ptr(dx), L.ptr(ws), B, H, W, C, ctx.w_bit,
-                                                ctypes.byref(ns), L.ptr(add), L.stream_ptr()), "alignq_conv3x3_nhwc_bwd")
+                                                ctypes.byref(ns), L.ptr(add), L.ptr(bz), L.ptr(bab), L.ptr(bsave), L.ptr(bk),
+                                                L.stream_ptr()), "alignq_conv3x3_nhwc_bwd")
             pending.add(ws, dw, ns.value, C)
             return dx, dw, None, None, None
+        if lazy is not None:               # not the fused path after all: finish the batch-norm input gradient here
+            _, bz, bab, bsave, bk = lazy
+            shp = (1, C, 1, 1)
+            gy = bab[0].view(shp) * (gy - bk[0].view(shp) - (bz - bsave[0].view(shp)) * bsave[1].view(shp) * bk[1].view(shp))
+            gy = L.like_layout(gy, x)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             L.check(lib.alignq_conv3x3_nhwc(L.ptr(gy), L.ptr(w), L.ptr(dx), B, H, W, C, ctx.w_bit, 1, L.ptr(add), None,

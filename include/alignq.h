@@ -206,7 +206,13 @@ int alignq_conv3x3_wgrad_reduce_multi(int T, const void* const* ws, float* const
 /* Data gradient AND filter-gradient partial sums of one convolution in a single launch (workgroup roles by block index; the
  * two are independent and fill the chip together).  The slabs left in ws are finished by alignq_conv3x3_wgrad_reduce_multi. */
 int alignq_conv3x3_nhwc_bwd(const float* x, const float* dy, const float* wt, float* dx, void* ws, int B, int H, int W,
-                            int C, int w_bit, int* n_slabs_out, const float* add, void* stream);
+                            int C, int w_bit, int* n_slabs_out, const float* add, const float* bn_z, const float* bn_ab,
+                            const float* bn_save, const float* bn_ktot, void* stream);
+/* bn_z != NULL: `dy` is not the convolution output's gradient but g, the gradient w.r.t. the OUTPUT of the training-mode
+ * batch-norm that follows the convolution (what alignq_site_bwd_apply_bn writes); both roles form
+ * dy = a[c] * (g - k0[c] - (z - mean[c]) * invstd[c] * k1[c]) on load from bn_z (the convolution's forward output), bn_ab,
+ * bn_save and bn_ktot = {k0[C], k1[C]} (alignq_bn_bwd_totals), which replaces the elementwise pass of alignq_bn_bwd_apply. */
+int alignq_bn_bwd_totals(const float* dx_part, int B, int C, int HW, float* ktot, float* dgamma, float* dbeta, void* stream);
 
 /* ---- data-parallel flat bucket (ONE mean all-reduce per step over gradients + stacked D matrices):
  * gather T dense device tensors (HOST array of pointers, element counts n[T]) into `flat` back to back (unpack = 0) or
