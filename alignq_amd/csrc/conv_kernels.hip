@@ -245,6 +245,168 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const float* __restri
   conv3x3_body<C, WD, PT, DGRAD>(x, w, y, H, total_rows, nlev, lds, blockIdx.x, add, bn_part, gridDim.x);
 }
 
+// ---- forward of the remaining Conv2d_Q shapes of the ResNet body: stride 2 (3x3, padding 1) and the 1x1 stride-2 shortcut
+// convolutions, C_in != C_out.  Same scheme as conv3x3_body (integer filter bins x three exact bf16 terms of the activation,
+// 16x16x32 bf16 MFMA, optional batch-norm partial statistics in the epilogue); the LDS image holds the input rows / columns the
+// tile's taps touch ((KS = 3) all of them with halo; (KS = 1) only the strided pixels) and a lane's B address is
+// (S*r + ky, S*c + kx).  H is the OUTPUT height, the input is [B, S*H, WDI, CIN], the output [B, H, WDI / S, COUT].
+template <int CIN, int COUT, int WDI, int KS, int S, int PT>
+struct ConvGen {
+  static constexpr int WDO = WDI / S, TR = PT / WDO;
+  static constexpr int LROWS = KS == 3 ? TR * S + (S == 1 ? 2 : 1) : TR;
+  static constexpr int LW = KS == 3 ? WDI + 2 : WDO;
+  static constexpr int CP = CIN + 8;
+  static constexpr int ARR = LROWS * LW * CP;
+};
+
+template <int CIN, int COUT, int WDI, int KS, int S, int PT>
+__global__ __launch_bounds__(256) void convgen_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          float* __restrict__ y, int H, int total_rows, float nlev,
+                                                          float* __restrict__ bn_part) {
+  using G = ConvGen<CIN, COUT, WDI, KS, S, PT>;
+  constexpr int WDO = G::WDO, TR = G::TR, LROWS = G::LROWS, LW = G::LW, CP = G::CP, ARR = G::ARR;
+  constexpr int NS = (KS * KS * CIN + 31) / 32;
+  constexpr int NCG = COUT / 16, NPP = 4 / NCG, NG = PT / 16;
+  static_assert(NCG == 1 || NCG == 2 || NCG == 4, "output channels");
+  __shared__ __attribute__((aligned(16))) __bf16 lds[3 * ARR];
+  __bf16* Xhi = lds;
+  __bf16* Xmi = lds + ARR;
+  __bf16* Xlo = lds + 2 * ARR;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int row0 = blockIdx.x * TR;                              // first OUTPUT row (image*H + h) of the tile
+  const int Hin = H * S;
+  const int img_lo = (row0 / H) * Hin, img_hi = img_lo + Hin;    // INPUT rows of the tile's image
+  {
+    constexpr int C4 = CIN / 4;
+    constexpr int N4 = LROWS * LW * C4;
+    constexpr int NIT = (N4 + 255) / 256;
+    float4 v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int i = tid + 256 * it;
+      const int c4 = i % C4, col = (i / C4) % LW, lr = i / (C4 * LW);
+      int grow, gcol;
+      if (KS == 3) { grow = row0 * S - 1 + lr; gcol = col - 1; }
+      else { grow = (row0 + lr) * S; gcol = col * S; }
+      const bool ok = i < N4 && gcol >= 0 && gcol < WDI && grow >= img_lo && grow < img_hi;
+      v[it] = *reinterpret_cast<const float4*>(x + (ok ? ((int64_t)grow * WDI + gcol) * CIN + 4 * c4 : 0));
+      if (!ok) v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int i = tid + 256 * it;
+      if (i < N4) {
+        const int c4 = i % C4, col = (i / C4) % LW, lr = i / (C4 * LW);
+        bf16x4 h4, m4, l4;
+        const float vv[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const __bf16 hi = (__bf16)vv[e];
+          const float r1 = vv[e] - (float)hi;
+          const __bf16 mi = (__bf16)r1;
+          h4[e] = hi; m4[e] = mi; l4[e] = (__bf16)(r1 - (float)mi);
+        }
+        const int o = (lr * LW + col) * CP + 4 * c4;
+        *reinterpret_cast<bf16x4*>(Xhi + o) = h4;
+        *reinterpret_cast<bf16x4*>(Xmi + o) = m4;
+        *reinterpret_cast<bf16x4*>(Xlo + o) = l4;
+      }
+    }
+  }
+  const int cog = wv % NCG, pp = wv / NCG;
+  const int m = lane & 15, q = lane >> 4;
+  bf16x8 ab[NS];
+#pragma unroll
+  for (int s = 0; s < NS; s++) {
+    const int k0 = 32 * s + 8 * q;
+    const int tap = k0 / CIN, c0 = k0 % CIN;
+    if (tap < KS * KS) {
+      const float* p = w + ((int64_t)(cog * 16 + m) * (KS * KS) + tap) * CIN + c0;
+      const float4 a4 = *reinterpret_cast<const float4*>(p), b4 = *reinterpret_cast<const float4*>(p + 4);
+      const float v[8] = {a4.x, a4.y, a4.z, a4.w, b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+      for (int j = 0; j < 8; j++) ab[s][j] = (__bf16)rintf(v[j] * nlev);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; j++) ab[s][j] = (__bf16)0.f;
+    }
+  }
+  __syncthreads();
+  float bs[4] = {0.f, 0.f, 0.f, 0.f}, bq[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int g = pp; g < NG; g += NPP) {
+    const int p = g * 16 + (lane & 15);
+    const int r = p / WDO, c = p % WDO;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+      const int k0 = 32 * s + 8 * q;
+      const int tap = k0 / CIN, c0 = k0 % CIN;
+      bf16x8 bh, bm, bl;
+      if (tap < KS * KS) {
+        const int ky = tap / KS, kx = tap % KS;
+        const int o = (KS == 3 ? ((r * S + ky) * LW + (c * S + kx)) : (r * LW + c)) * CP + c0;
+        bh = *reinterpret_cast<const bf16x8*>(Xhi + o);
+        bm = *reinterpret_cast<const bf16x8*>(Xmi + o);
+        bl = *reinterpret_cast<const bf16x8*>(Xlo + o);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) { bh[j] = (__bf16)0.f; bm[j] = (__bf16)0.f; bl[j] = (__bf16)0.f; }
+      }
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[s], bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[s], bm, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[s], bh, acc, 0, 0, 0);
+    }
+    const int grow = row0 + r;
+    if (grow < total_rows) {
+      const float4 v = make_float4(acc[0] / nlev, acc[1] / nlev, acc[2] / nlev, acc[3] / nlev);
+      *reinterpret_cast<float4*>(y + ((int64_t)grow * WDO + c) * COUT + cog * 16 + 4 * q) = v;
+      bs[0] += v.x; bs[1] += v.y; bs[2] += v.z; bs[3] += v.w;
+      bq[0] += v.x * v.x; bq[1] += v.y * v.y; bq[2] += v.z * v.z; bq[3] += v.w * v.w;
+    }
+  }
+  if (bn_part) {       // per-workgroup per-channel {sum y, sum y^2} for the batch-norm that follows (see conv3x3_body)
+    float* red = reinterpret_cast<float*>(lds);
+#define ROW_SHR_ADD(V, CTRL) V += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V), CTRL, 0xf, 0xf, false))
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      ROW_SHR_ADD(bs[e], 0x111); ROW_SHR_ADD(bs[e], 0x112); ROW_SHR_ADD(bs[e], 0x114); ROW_SHR_ADD(bs[e], 0x118);
+      ROW_SHR_ADD(bq[e], 0x111); ROW_SHR_ADD(bq[e], 0x112); ROW_SHR_ADD(bq[e], 0x114); ROW_SHR_ADD(bq[e], 0x118);
+    }
+#undef ROW_SHR_ADD
+    __syncthreads();
+    if ((lane & 15) == 15) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        red[(wv * 16 + 4 * q + e) * 2] = bs[e];
+        red[(wv * 16 + 4 * q + e) * 2 + 1] = bq[e];
+      }
+    }
+    __syncthreads();
+    if (tid < COUT) {
+      const int cg = tid / 16, cl = tid % 16;
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int ppi = 0; ppi < NPP; ppi++) {
+        s0 += red[((ppi * NCG + cg) * 16 + cl) * 2];
+        s1 += red[((ppi * NCG + cg) * 16 + cl) * 2 + 1];
+      }
+      bn_part[((int64_t)tid * gridDim.x + blockIdx.x) * 2] = s0;
+      bn_part[((int64_t)tid * gridDim.x + blockIdx.x) * 2 + 1] = s1;
+    }
+  }
+}
+
+template <int CIN, int COUT, int WDI, int KS, int S, int PT>
+int launch_gen(const float* x, const float* w, float* y, int B, int H, float nlev, float* bn_part, hipStream_t st) {
+  constexpr int TR = ConvGen<CIN, COUT, WDI, KS, S, PT>::TR;
+  if (H % TR) return ALIGNQ_EUNSUPPORTED;
+  const int total_rows = B * H;
+  hipLaunchKernelGGL((convgen_fwd_kernel<CIN, COUT, WDI, KS, S, PT>), total_rows / TR, 256, 0, st, x, w, y, H, total_rows,
+                     nlev, bn_part);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
 template <int C, int WD, int PT>
 int launch(const float* x, const float* w, float* y, int B, int H, int dgrad, float nlev, const float* add, float* bn_part,
            hipStream_t st) {
@@ -688,6 +850,35 @@ int alignq_conv3x3_nhwc_bwd(const float* x, const float* dy, const float* wt, fl
   if (C == 16 && W == 32) return launch_bwd<16, 32, 256, 128>(x, dy, wt, dx, (float*)ws, B, H, nlev, n_slabs_out, add, lazy, st);
   if (C == 32 && W == 16) return launch_bwd<32, 16, 128, 128>(x, dy, wt, dx, (float*)ws, B, H, nlev, n_slabs_out, add, lazy, st);
   if (C == 64 && W == 8) return launch_bwd<64, 8, 32, 64>(x, dy, wt, dx, (float*)ws, B, H, nlev, n_slabs_out, add, lazy, st);
+  return ALIGNQ_EUNSUPPORTED;
+}
+
+// Forward of the ResNet body's transition convolutions (see convgen_fwd_kernel): (KS, stride) = (3, 2) padding 1 or (1, 2)
+// padding 0, (CIN, COUT, W_in) in {(16, 32, 32), (32, 64, 16)}.  x [B, H_in, W_in, CIN], wt [COUT, KS, KS, CIN] (channels-last
+// storage), y [B, H_in/2, W_in/2, COUT].  bn_part as in alignq_conv3x3_nhwc ([COUT][alignq_conv_gen_bn_parts][2] floats).
+static int gen_tile_rows(int H_in, int W_in, int CIN, int COUT, int KS, int stride) {
+  if (stride != 2 || (KS != 1 && KS != 3)) return 0;
+  if (CIN == 16 && COUT == 32 && W_in == 32) return KS == 3 ? 4 : 8;       // output rows per workgroup
+  if (CIN == 32 && COUT == 64 && W_in == 16) return KS == 3 ? 4 : 8;
+  return 0;
+}
+int alignq_conv_gen_bn_parts(int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride) {
+  const int tr = gen_tile_rows(H_in, W_in, CIN, COUT, KS, stride);
+  if (!tr || B < 1 || H_in < 2 || (H_in % 2) || ((H_in / 2) % tr)) return 0;
+  return B * (H_in / 2) / tr;
+}
+int alignq_conv_gen_nhwc_fwd(const float* x, const float* wt, float* y, int B, int H_in, int W_in, int CIN, int COUT, int KS,
+                             int stride, int w_bit, float* bn_part, void* stream) {
+  if (!x || !wt || !y || B < 1) return ALIGNQ_EINVAL;
+  if (w_bit < 1 || w_bit > 8 || !alignq_conv_gen_bn_parts(B, H_in, W_in, CIN, COUT, KS, stride)) return ALIGNQ_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(wt) | reinterpret_cast<uintptr_t>(y)) & 15) return ALIGNQ_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const float nlev = (float)((1 << w_bit) - 1);
+  const int H = H_in / 2;
+  if (CIN == 16 && KS == 3) return launch_gen<16, 32, 32, 3, 2, 64>(x, wt, y, B, H, nlev, bn_part, st);
+  if (CIN == 16 && KS == 1) return launch_gen<16, 32, 32, 1, 2, 128>(x, wt, y, B, H, nlev, bn_part, st);
+  if (CIN == 32 && KS == 3) return launch_gen<32, 64, 16, 3, 2, 32>(x, wt, y, B, H, nlev, bn_part, st);
+  if (CIN == 32 && KS == 1) return launch_gen<32, 64, 16, 1, 2, 64>(x, wt, y, B, H, nlev, bn_part, st);
   return ALIGNQ_EUNSUPPORTED;
 }
 

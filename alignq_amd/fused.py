@@ -292,7 +292,7 @@ class BNSiteFn(torch.autograd.Function):
         conv_parts = 0
         if nhwc and conv_part is not None:
             # the convolution that produced z left per-workgroup partial statistics: no pass over z here
-            ws_bn, conv_parts = conv_part
+            ws_bn, conv_parts = conv_part[0], conv_part[1]
         elif nhwc:
             ws_bn = torch.empty(lib.alignq_bn_nhwc_ws_bytes(C), dtype=torch.uint8, device=dev)
             L.check(lib.alignq_bn_partial_stats_nhwc(L.ptr(z), B, C, HW, L.ptr(ws_bn), st), "alignq_bn_partial_stats_nhwc")
@@ -316,7 +316,7 @@ class BNSiteFn(torch.autograd.Function):
             L.check(lib.alignq_site_reduce_loss(L.ptr(ws), B, F, L.ptr(D), L.ptr(A), L.ptr(Gm), dim, float(mu),
                                                 float(rho), L.ptr(scal), st), "alignq_site_reduce_loss")
         ctx.rec = rec
-        ctx.from_qconv = bool(nhwc and conv_part is not None)
+        ctx.from_qconv = bool(nhwc and conv_part is not None and len(conv_part) > 2 and conv_part[2])
         ctx.save_for_backward(z, ab, save, stats, D, A, Gm, scal, y if relu else None)
         ctx.set_materialize_grads(False)
         ctx.cfg = (float(act_range), float(eps), float(mu), bn_weight is not None, bn_bias is not None, res is not None,

@@ -310,7 +310,7 @@ class QConv3x3Fn(torch.autograd.Function):
         ctx.w_bit = int(w_bit)
         ctx.tap = bool(tap)
         if part is not None:
-            QConv3x3Fn._mailbox = (part, n_parts)
+            QConv3x3Fn._mailbox = (part, n_parts, True)      # True: this producer's backward accepts a lazy BN gradient
         if tap:
             ctx.set_materialize_grads(False)
             return y, x.view_as(x)
@@ -375,3 +375,60 @@ class QConv3x3Fn(torch.autograd.Function):
                 L.check(lib.alignq_conv3x3_nhwc_wgrad(L.ptr(x), L.ptr(gy), L.ptr(dw), L.ptr(ws), B, H, W, C, None,
                                                       L.stream_ptr()), "alignq_conv3x3_nhwc_wgrad")
         return dx, dw, None, None, None
+
+
+def qconv_gen_supported(x, w, stride, padding, dilation, groups, bias, w_bit) -> bool:
+    """The transition convolutions alignq_conv_gen_nhwc_fwd implements: stride 2, 3x3 (padding 1) or 1x1 (padding 0),
+    (C_in, C_out, W_in) in {(16, 32, 32), (32, 64, 16)}, channels-last fp32, <= 8-bit quantised filter."""
+    if bias is not None or groups != 1 or not (1 <= w_bit <= 8) or tuple(stride) != (2, 2) or tuple(dilation) != (1, 1):
+        return False
+    if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and w.dtype == torch.float32):
+        return False
+    B, CIN, H, W = x.shape
+    COUT, ks = w.shape[0], w.shape[2]
+    if tuple(w.shape) != (COUT, CIN, ks, ks) or (ks, tuple(padding)) not in ((3, (1, 1)), (1, (0, 0))):
+        return False
+    cl = torch.channels_last
+    if not (x.is_contiguous(memory_format=cl) and not x.is_contiguous()):
+        return False
+    if not (w.is_contiguous(memory_format=cl) or (ks == 1 and w.is_contiguous())):
+        return False
+    return L.load().alignq_conv_gen_bn_parts(B, H, W, CIN, COUT, ks, 2) > 0
+
+
+class QConvGenFn(torch.autograd.Function):
+    """Forward of Conv2d_Q's stride-2 transition convolutions (3x3 and the 1x1 shortcut) on alignq_conv_gen_nhwc_fwd, with the
+    batch-norm partial statistics of the output as a by-product; both gradients stay on MIOpen."""
+
+    @staticmethod
+    def forward(ctx, x, w, w_bit, padding):
+        B, CIN, H, W = x.shape
+        COUT, ks = w.shape[0], w.shape[2]
+        lib = L.load()
+        y = torch.empty((B, COUT, H // 2, W // 2), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        n_parts = lib.alignq_conv_gen_bn_parts(B, H, W, CIN, COUT, ks, 2)
+        part = torch.empty(COUT, n_parts, 2, dtype=torch.float32, device=x.device)
+        L.check(lib.alignq_conv_gen_nhwc_fwd(L.ptr(x), L.ptr(w), L.ptr(y), B, H, W, CIN, COUT, ks, 2, int(w_bit), L.ptr(part),
+                                             L.stream_ptr()), "alignq_conv_gen_nhwc_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.padding = int(padding)
+        QConv3x3Fn._mailbox = (part, n_parts, False)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        pd = ctx.padding
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        dx, dw, _ = torch.ops.aten.convolution_backward(gy, x, w, None, [2, 2], [pd, pd], [1, 1], False, [0, 0], 1,
+                                                        [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
+        return dx, dw, None, None
+
+    @staticmethod
+    def apply_with_stats(x, w, w_bit, padding):
+        QConv3x3Fn._mailbox = None
+        y = QConvGenFn.apply(x, w, w_bit, padding)
+        if QConv3x3Fn._mailbox is not None:
+            y._alignq_bn_part = QConv3x3Fn._mailbox
+            QConv3x3Fn._mailbox = None
+        return y

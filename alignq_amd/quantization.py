@@ -161,6 +161,10 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
                         self.quantize_fn.w_bit):
                     # (with the batch-norm statistics of its output as a by-product for fused.bn_site)
                     return ops.QConv3x3Fn.apply_with_stats(input, weight_q, self.quantize_fn.w_bit)
+                if getattr(self, "use_qconv", False) and ops.qconv_gen_supported(
+                        input, weight_q, self.stride, self.padding, self.dilation, self.groups, self.bias,
+                        self.quantize_fn.w_bit):
+                    return ops.QConvGenFn.apply_with_stats(input, weight_q, self.quantize_fn.w_bit, self.padding[0])
                 return F.conv2d(input, weight_q, self.bias, self.stride, self.padding, self.dilation, self.groups)
 
             def forward_with_shortcut(self, input):

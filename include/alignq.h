@@ -192,6 +192,14 @@ int alignq_conv3x3_bn_parts(int B, int H, int W, int C);   /* workgroups of the 
 int alignq_conv3x3_nhwc(const float* x, const float* wt, float* y, int B, int H, int W, int C, int w_bit, int dgrad,
                         const float* add, float* bn_part, void* stream);
 
+/* Forward of the body's transition convolutions (stride 2: 3x3 padding 1, and the 1x1 shortcut), C_in != C_out:
+ * (CIN, COUT, W_in) in {(16, 32, 32), (32, 64, 16)}; x [B,H_in,W_in,CIN], wt [COUT,KS,KS,CIN], y [B,H_in/2,W_in/2,COUT], all
+ * channels-last; same exact-product scheme and optional bn_part ([COUT][alignq_conv_gen_bn_parts][2]) as alignq_conv3x3_nhwc.
+ * Their gradients stay on MIOpen.                                                                                        */
+int alignq_conv_gen_bn_parts(int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride);
+int alignq_conv_gen_nhwc_fwd(const float* x, const float* wt, float* y, int B, int H_in, int W_in, int CIN, int COUT, int KS,
+                             int stride, int w_bit, float* bn_part, void* stream);
+
 /* Filter gradient of the same convolution, dW [C,3,3,C] (channels-last weight storage) from x and dy: plain fp32 on the f32
  * MFMAs (products and accumulation bit-for-bit an fmaf chain), per-pixel-range partial sums in ws
  * (alignq_conv3x3_wgrad_ws_bytes(C)) reduced in fixed order by a second launch: deterministic, no zero-fill, no atomics.  */

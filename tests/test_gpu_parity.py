@@ -895,7 +895,7 @@ def test_conv_epilogue_bn_statistics_feed_the_fold(dev, B, C, H, k):
     x = (torch.randn(B, C, H, H, device=dev) * 1.1).contiguous(memory_format=cl)
     wq = (torch.round(torch.tanh(torch.randn(C, C, 3, 3)) * n) / n).to(dev).contiguous(memory_format=cl)
     y = ops.QConv3x3Fn.apply_with_stats(x, wq, k)
-    part, n_parts = y._alignq_bn_part
+    part, n_parts = y._alignq_bn_part[:2]
     assert part.shape == (C, n_parts, 2)
     yd = y.double()
     np.testing.assert_allclose(npy(part[:, :, 0].double().sum(1)), npy(yd.sum((0, 2, 3))), rtol=1e-5, atol=1e-2)
@@ -923,3 +923,34 @@ def test_conv_epilogue_bn_statistics_feed_the_fold(dev, B, C, H, k):
     np.testing.assert_allclose(b["rv"], a["rv"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(b["dz"], a["dz"], atol=2e-5, rtol=1e-3)
     config.args.bitW = config.args.abitW = 8
+
+
+@pytest.mark.parametrize("B,CIN,COUT,H,ks,k", [(128, 16, 32, 32, 3, 8), (128, 16, 32, 32, 1, 8), (128, 32, 64, 16, 3, 4),
+                                               (128, 32, 64, 16, 1, 8), (8, 16, 32, 32, 3, 2), (8, 32, 64, 16, 1, 8)])
+def test_qconv_transition_forward_matches_fp64(dev, B, CIN, COUT, H, ks, k):
+    """alignq_conv_gen_nhwc_fwd (stride-2 3x3 and 1x1 shortcut convolutions) against fp64, its batch-norm partials against the
+    statistics of its output, and its (MIOpen) gradients through the autograd Function."""
+    from alignq_amd import ops
+    torch.manual_seed(CIN + ks + k)
+    n = 2 ** k - 1
+    cl = torch.channels_last
+    pad = 1 if ks == 3 else 0
+    x = (torch.randn(B, CIN, H, H, device=dev) * 1.2).contiguous(memory_format=cl).requires_grad_(True)
+    wq = (torch.round(torch.tanh(torch.randn(COUT, CIN, ks, ks)) * n) / n).to(dev).contiguous(memory_format=cl).requires_grad_(True)
+    assert ops.qconv_gen_supported(x, wq, (2, 2), (pad, pad), (1, 1), 1, None, k)
+    y = ops.QConvGenFn.apply_with_stats(x, wq, k, pad)
+    assert y.shape == (B, COUT, H // 2, H // 2) and y.is_contiguous(memory_format=cl)
+    yd = torch.nn.functional.conv2d(x.detach().double(), wq.detach().double(), stride=2, padding=pad)
+    y32 = torch.nn.functional.conv2d(x.detach(), wq.detach(), stride=2, padding=pad)
+    floor = 2e-6 * float(yd.abs().max())
+    assert float((y.detach() - yd).abs().max()) <= max(float((y32 - yd).abs().max()), floor)
+    part, n_parts, lazy_ok = y._alignq_bn_part
+    assert not lazy_ok and part.shape == (COUT, n_parts, 2)
+    np.testing.assert_allclose(npy(part[:, :, 0].double().sum(1)), npy(yd.sum((0, 2, 3))), rtol=1e-5, atol=1e-2)
+    np.testing.assert_allclose(npy(part[:, :, 1].double().sum(1)), npy((yd * yd).sum((0, 2, 3))), rtol=1e-5)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    xr, wr = x.detach().clone().requires_grad_(True), wq.detach().clone().requires_grad_(True)
+    torch.nn.functional.conv2d(xr, wr, stride=2, padding=pad).backward(gy)
+    np.testing.assert_allclose(npy(x.grad), npy(xr.grad), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(npy(wq.grad), npy(wr.grad), rtol=1e-3, atol=1e-3 * float(wr.grad.abs().max()))
