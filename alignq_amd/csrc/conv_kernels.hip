@@ -436,14 +436,22 @@ int launch(const float* x, const float* w, float* y, int B, int H, int dgrad, fl
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-template <int C, int WD, int PT>
-struct WgradLds {
-  static constexpr int CB = C >= 32 ? 32 : 16;
-  static constexpr int XA = ((PT / WD) + 2) * (WD + 2) * CB;     // bf16 elements per x image (with halo)
-  static constexpr int DA = PT * CB;                             // bf16 elements per dy image
-  static constexpr int kBytes = (3 * (XA + DA) * 2) > (3 * 9 * 4 * 64 * 4) ? (3 * (XA + DA) * 2) : (3 * 9 * 4 * 64 * 4);
+// Geometry of the filter-gradient kernel for a convolution CIN -> COUT, KS x KS, stride S, input width WDI, PT OUTPUT pixels per
+// tile (whole output rows).  The 3x3 stride-1 body convolutions are <C, C, WD, 3, 1, PT>.
+template <int CIN, int COUT, int WDI, int KS, int S, int PT>
+struct WgradGeo {
+  static constexpr int WDO = WDI / S, TR = PT / WDO, NT = KS * KS;
+  static constexpr int CB = (CIN < COUT ? CIN : COUT) >= 32 ? 32 : 16;           // channel block (co and ci) of a workgroup
+  static constexpr int XROWS = KS == 3 ? TR * S + (S == 1 ? 2 : 1) : TR;
+  static constexpr int LW = KS == 3 ? WDI + 2 : WDO;
+  static constexpr int XA = XROWS * LW * CB;                                     // bf16 elements per x image
+  static constexpr int DA = PT * CB;                                             // bf16 elements per dy image
+  static constexpr int kRed = 3 * NT * 4 * 64 * 4;                               // bytes: cross-wave reduction (CB == 16)
+  static constexpr int kBytes = (3 * (XA + DA) * 2) > kRed ? (3 * (XA + DA) * 2) : kRed;
   static constexpr int kFloats = kBytes / 4;
 };
+template <int C, int WD, int PT>
+struct WgradLds : WgradGeo<C, C, WD, 3, 1, PT> {};
 
 // 4 pixels x 16 channels block at `p` (this lane's row q = (lane & 15) >> 2, columns 4 * (lane & 3)), transposed: the lane
 // receives channel (lane & 15) of the 4 pixels.  EXEC must be all ones (it is: no divergence around the calls).
@@ -457,16 +465,16 @@ __device__ __forceinline__ bf16x8 join8(s16x4 a, s16x4 b) {
 }
 
 // bx / gx: index and count of the pixel-range workgroups, by: (co block, ci block) index
-template <int C, int WD, int PT>
-__device__ __forceinline__ void wgrad3x3_body(const float* __restrict__ x, const float* __restrict__ dy,
-                                              float* __restrict__ slabs, int H, int n_tiles, float* lds_f, int bx, int gx,
-                                              int by, BnLazy lazy = BnLazy{nullptr, nullptr, nullptr, nullptr}) {
-  constexpr int TR = PT / WD;
-  constexpr int CB = C >= 32 ? 32 : 16;          // channel block (both co and ci) of the workgroup
-  constexpr int NBLK = C / CB;
-  constexpr int LW = WD + 2;
-  constexpr int XA = WgradLds<C, WD, PT>::XA, DA = WgradLds<C, WD, PT>::DA;
+// H is the OUTPUT height (the input has S*H rows); x [.., S*H, WDI, CIN], dy [.., H, WDI/S, COUT].
+template <int CIN, int COUT, int WDI, int KS, int S, int PT>
+__device__ __forceinline__ void wgrad_body(const float* __restrict__ x, const float* __restrict__ dy,
+                                           float* __restrict__ slabs, int H, int n_tiles, float* lds_f, int bx, int gx,
+                                           int by, BnLazy lazy = BnLazy{nullptr, nullptr, nullptr, nullptr}) {
+  using G = WgradGeo<CIN, COUT, WDI, KS, S, PT>;
+  constexpr int WDO = G::WDO, TR = G::TR, NT = G::NT, CB = G::CB, LW = G::LW, XA = G::XA, DA = G::DA, XROWS = G::XROWS;
+  constexpr int NBLK = CIN / CB;                 // ci blocks (by = co block * NBLK + ci block)
   constexpr int NSTEP = PT / 32;                 // 32-pixel k steps per tile
+  static_assert(WDO % 8 == 0 && PT % 32 == 0, "a lane group's 8 pixels lie in one output row");
   __bf16* lds = reinterpret_cast<__bf16*>(lds_f);
   __bf16* Xi[3] = {lds, lds + XA, lds + 2 * XA};
   __bf16* Di[3] = {lds + 3 * XA, lds + 3 * XA + DA, lds + 3 * XA + 2 * DA};
@@ -476,13 +484,13 @@ __device__ __forceinline__ void wgrad3x3_body(const float* __restrict__ x, const
   const int cob = CB == 32 ? (wv >> 1) : 0, cib = CB == 32 ? (wv & 1) : 0;
   const int g = lane >> 4, q = (lane & 15) >> 2, pcol = 4 * (lane & 3);
 
-  f32x4 acc[9];
+  f32x4 acc[NT];
 #pragma unroll
-  for (int t = 0; t < 9; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < NT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   constexpr int C4 = CB / 4;
-  constexpr int N4 = (TR + 2) * LW * C4;           // float4 slots of the x tile with halo
-  constexpr int M4 = TR * WD * C4;                 // float4 slots of the dy tile
+  constexpr int N4 = XROWS * LW * C4;              // float4 slots of the x tile (with halo for KS == 3)
+  constexpr int M4 = PT * C4;                      // float4 slots of the dy tile
   constexpr int NIX = (N4 + 255) / 256, NID = (M4 + 255) / 256;
   f32x4 rx[NIX], rd[NID], rz[NID];     // plain vector registers (HIP's float4 struct here ends up in scratch)
   // (fetch / park are spelled out twice below rather than hidden in a lambda or macro: the register arrays must be indexed
@@ -490,21 +498,22 @@ __device__ __forceinline__ void wgrad3x3_body(const float* __restrict__ x, const
   int nxt = bx;
   if (nxt < n_tiles) {
     const int row0_ = nxt * TR;
-    const int img_lo_ = (row0_ / H) * H, img_hi_ = img_lo_ + H;
+    const int img_lo_ = (row0_ / H) * (H * S), img_hi_ = img_lo_ + H * S;      // INPUT rows of the tile's image
 #pragma unroll
     for (int it = 0; it < NIX; it++) {
       const int i = tid + 256 * it;
       const int c4 = i % C4, col = (i / C4) % LW, lr = i / (C4 * LW);
-      const int grow = row0_ + lr - 1;
-      const bool ok = i < N4 && col >= 1 && col <= WD && grow >= img_lo_ && grow < img_hi_;
-      const int64_t off = ok ? ((int64_t)grow * WD + (col - 1)) * C + bj * CB + 4 * c4 : 0;
+      const int grow = KS == 3 ? row0_ * S - 1 + lr : (row0_ + lr) * S;
+      const int gcol = KS == 3 ? col - 1 : col * S;
+      const bool ok = i < N4 && gcol >= 0 && gcol < WDI && grow >= img_lo_ && grow < img_hi_;
+      const int64_t off = ok ? ((int64_t)grow * WDI + gcol) * CIN + bj * CB + 4 * c4 : 0;
       rx[it] = *reinterpret_cast<const f32x4*>(x + off);
       if (!ok) rx[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int it = 0; it < NID; it++) {
       const int i = tid + 256 * it;
-      const int64_t off = i < M4 ? ((int64_t)row0_ * WD + i / C4) * C + bi * CB + 4 * (i % C4) : 0;
+      const int64_t off = i < M4 ? ((int64_t)row0_ * WDO + i / C4) * COUT + bi * CB + 4 * (i % C4) : 0;
       rd[it] = *reinterpret_cast<const f32x4*>(dy + off);
       if (lazy.z) rz[it] = *reinterpret_cast<const f32x4*>(lazy.z + off);
     }
@@ -515,9 +524,9 @@ __device__ __forceinline__ void wgrad3x3_body(const float* __restrict__ x, const
     const int cq = bi * CB + 4 * (tid % C4);
     la = *reinterpret_cast<const f32x4*>(lazy.ab + cq);
     lm = *reinterpret_cast<const f32x4*>(lazy.save + cq);
-    li = *reinterpret_cast<const f32x4*>(lazy.save + C + cq);
+    li = *reinterpret_cast<const f32x4*>(lazy.save + COUT + cq);
     lk0 = *reinterpret_cast<const f32x4*>(lazy.ktot + cq);
-    lk1 = *reinterpret_cast<const f32x4*>(lazy.ktot + C + cq);
+    lk1 = *reinterpret_cast<const f32x4*>(lazy.ktot + COUT + cq);
   }
   for (int tile = bx; tile < n_tiles; tile += gx) {
     __syncthreads();                               // previous tile's readers are done
@@ -566,21 +575,22 @@ __device__ __forceinline__ void wgrad3x3_body(const float* __restrict__ x, const
     nxt = tile + gx;
     if (nxt < n_tiles) {                           // next tile's loads fly under this tile's MFMA phase
       const int row0_ = nxt * TR;
-      const int img_lo_ = (row0_ / H) * H, img_hi_ = img_lo_ + H;
+      const int img_lo_ = (row0_ / H) * (H * S), img_hi_ = img_lo_ + H * S;      // INPUT rows of the tile's image
 #pragma unroll
       for (int it = 0; it < NIX; it++) {
         const int i = tid + 256 * it;
         const int c4 = i % C4, col = (i / C4) % LW, lr = i / (C4 * LW);
-        const int grow = row0_ + lr - 1;
-        const bool ok = i < N4 && col >= 1 && col <= WD && grow >= img_lo_ && grow < img_hi_;
-        const int64_t off = ok ? ((int64_t)grow * WD + (col - 1)) * C + bj * CB + 4 * c4 : 0;
+        const int grow = KS == 3 ? row0_ * S - 1 + lr : (row0_ + lr) * S;
+        const int gcol = KS == 3 ? col - 1 : col * S;
+        const bool ok = i < N4 && gcol >= 0 && gcol < WDI && grow >= img_lo_ && grow < img_hi_;
+        const int64_t off = ok ? ((int64_t)grow * WDI + gcol) * CIN + bj * CB + 4 * c4 : 0;
         rx[it] = *reinterpret_cast<const f32x4*>(x + off);
         if (!ok) rx[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int it = 0; it < NID; it++) {
         const int i = tid + 256 * it;
-        const int64_t off = i < M4 ? ((int64_t)row0_ * WD + i / C4) * C + bi * CB + 4 * (i % C4) : 0;
+        const int64_t off = i < M4 ? ((int64_t)row0_ * WDO + i / C4) * COUT + bi * CB + 4 * (i % C4) : 0;
         rd[it] = *reinterpret_cast<const f32x4*>(dy + off);
         if (lazy.z) rz[it] = *reinterpret_cast<const f32x4*>(lazy.z + off);
       }
@@ -588,7 +598,7 @@ __device__ __forceinline__ void wgrad3x3_body(const float* __restrict__ x, const
     // ---- MFMA phase: 32 pixels per step; lane group g owns pixels p0 + 8g .. + 7 (8 consecutive columns of one row) ---
     for (int s = (CB == 16 ? wv : 0); s < NSTEP; s += (CB == 16 ? 4 : 1)) {
       const int p0 = 32 * s + 8 * g;
-      const int r = p0 / WD, c0 = p0 % WD;
+      const int r = p0 / WDO, c0 = p0 % WDO;
       // A = dy: lane address = pixel p0 + 4*half + q, channels cob*16 + pcol
       bf16x8 a[3];
 #pragma unroll
@@ -597,13 +607,14 @@ __device__ __forceinline__ void wgrad3x3_body(const float* __restrict__ x, const
         a[t] = join8(tr_read(pa), tr_read(pa + 4 * CB));
       }
 #pragma unroll
-      for (int tap = 0; tap < 9; tap++) {
-        const int ky = tap / 3, kx = tap % 3;
+      for (int tap = 0; tap < NT; tap++) {
+        const int ky = tap / KS, kx = tap % KS;
         bf16x8 b[3];
 #pragma unroll
-        for (int t = 0; t < 3; t++) {
-          const __bf16* pb = Xi[t] + ((r + ky) * LW + (c0 + kx + q)) * CB + cib * 16 + pcol;
-          b[t] = join8(tr_read(pb), tr_read(pb + 4 * CB));
+        for (int t = 0; t < 3; t++) {      // the lane's block row q is output pixel c0 + q (+4): input column S * that + kx
+          const __bf16* pb = Xi[t] + (KS == 3 ? ((r * S + ky) * LW + ((c0 + q) * S + kx)) : (r * LW + c0 + q)) * CB +
+                             cib * 16 + pcol;
+          b[t] = join8(tr_read(pb), tr_read(pb + 4 * (KS == 3 ? S : 1) * CB));
         }
         // six leading term pairs, smallest first
         f32x4 v = acc[tap];
@@ -618,36 +629,51 @@ __device__ __forceinline__ void wgrad3x3_body(const float* __restrict__ x, const
     }
   }
   // ---- results: C/D layout of the 16x16 MFMA: column (ci) = lane & 15, rows (co) = 4 (lane >> 4) + e ---------------------
-  float* slab = slabs + (int64_t)bx * (9 * C * C);
+  float* slab = slabs + (int64_t)bx * (NT * CIN * COUT);
   if (CB == 16) {      // the four waves hold partial sums over alternate steps: fixed-order sum through LDS, wave 0 writes
     float* red = lds_f;
     __syncthreads();
     if (wv > 0) {
 #pragma unroll
-      for (int t = 0; t < 9; t++)
+      for (int t = 0; t < NT; t++)
 #pragma unroll
-        for (int e = 0; e < 4; e++) red[(((wv - 1) * 9 + t) * 4 + e) * 64 + lane] = acc[t][e];
+        for (int e = 0; e < 4; e++) red[(((wv - 1) * NT + t) * 4 + e) * 64 + lane] = acc[t][e];
     }
     __syncthreads();
     if (wv == 0) {
 #pragma unroll
-      for (int t = 0; t < 9; t++) {
+      for (int t = 0; t < NT; t++) {
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           float v = acc[t][e];
 #pragma unroll
-          for (int w2 = 0; w2 < 3; w2++) v += red[((w2 * 9 + t) * 4 + e) * 64 + lane];
-          slab[((int64_t)(4 * (lane >> 4) + e) * 9 + t) * C + (lane & 15)] = v;
+          for (int w2 = 0; w2 < 3; w2++) v += red[((w2 * NT + t) * 4 + e) * 64 + lane];
+          slab[((int64_t)(bi * CB + 4 * (lane >> 4) + e) * NT + t) * CIN + bj * CB + (lane & 15)] = v;
         }
       }
     }
   } else {
 #pragma unroll
-    for (int t = 0; t < 9; t++)
+    for (int t = 0; t < NT; t++)
 #pragma unroll
       for (int e = 0; e < 4; e++)
-        slab[((int64_t)(bi * CB + cob * 16 + 4 * (lane >> 4) + e) * 9 + t) * C + bj * CB + cib * 16 + (lane & 15)] = acc[t][e];
+        slab[((int64_t)(bi * CB + cob * 16 + 4 * (lane >> 4) + e) * NT + t) * CIN + bj * CB + cib * 16 + (lane & 15)] = acc[t][e];
   }
+}
+
+template <int C, int WD, int PT>
+__device__ __forceinline__ void wgrad3x3_body(const float* __restrict__ x, const float* __restrict__ dy,
+                                              float* __restrict__ slabs, int H, int n_tiles, float* lds_f, int bx, int gx,
+                                              int by, BnLazy lazy = BnLazy{nullptr, nullptr, nullptr, nullptr}) {
+  wgrad_body<C, C, WD, 3, 1, PT>(x, dy, slabs, H, n_tiles, lds_f, bx, gx, by, lazy);
+}
+
+// stand-alone filter gradient of the transition convolutions (stride 2: 3x3 and 1x1)
+template <int CIN, int COUT, int WDI, int KS, int S, int PT>
+__global__ __launch_bounds__(256) void wgradgen_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       float* __restrict__ slabs, int H, int n_tiles) {
+  __shared__ __attribute__((aligned(16))) float lds[WgradGeo<CIN, COUT, WDI, KS, S, PT>::kFloats];
+  wgrad_body<CIN, COUT, WDI, KS, S, PT>(x, dy, slabs, H, n_tiles, lds, blockIdx.x, gridDim.x, blockIdx.y);
 }
 
 template <int C, int WD, int PT>
@@ -767,6 +793,24 @@ int launch_bwd(const float* x, const float* dy, const float* w, float* dx, float
   return 0;
 }
 
+template <int CIN, int COUT, int WDI, int KS, int S, int PT>
+int launch_wgradgen(const float* x, const float* dy, float* dw, float* ws, int B, int H, int* n_slabs_out, hipStream_t st) {
+  using G = WgradGeo<CIN, COUT, WDI, KS, S, PT>;
+  if (H % G::TR) return ALIGNQ_EUNSUPPORTED;
+  const int n_tiles = B * H / G::TR;
+  constexpr int NBY = (COUT / G::CB) * (CIN / G::CB);
+  int splits = 256 / NBY;
+  if (splits > n_tiles) splits = n_tiles;
+  hipLaunchKernelGGL((wgradgen_kernel<CIN, COUT, WDI, KS, S, PT>), dim3(splits, NBY), 256, 0, st, x, dy, ws, H, n_tiles);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  if (n_slabs_out) { *n_slabs_out = splits; return 0; }
+  const int n_elem = G::NT * CIN * COUT;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, (n_elem + 63) / 64, 1024, 0, st, ws, splits, n_elem, dw);
+  e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
 }  // namespace
 
 extern "C" {
@@ -813,18 +857,18 @@ int alignq_conv3x3_nhwc_wgrad(const float* x, const float* dy, float* dw, void* 
   return ALIGNQ_EUNSUPPORTED;
 }
 
-int alignq_conv3x3_wgrad_reduce_multi(int T, const void* const* ws, float* const* dw, const int* n_slabs, const int* C,
+int alignq_conv3x3_wgrad_reduce_multi(int T, const void* const* ws, float* const* dw, const int* n_slabs, const int* n_elem,
                                       void* stream) {
-  if (T <= 0 || !ws || !dw || !n_slabs || !C) return ALIGNQ_EINVAL;
+  if (T <= 0 || !ws || !dw || !n_slabs || !n_elem) return ALIGNQ_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   for (int t0 = 0; t0 < T; t0 += kWgMulti) {
     const int cnt = (T - t0 < kWgMulti) ? T - t0 : kWgMulti;
     WgChunk c;
     int max_elem = 0;
     for (int i = 0; i < cnt; i++) {
-      if (!ws[t0 + i] || !dw[t0 + i] || n_slabs[t0 + i] < 1 || C[t0 + i] < 1) return ALIGNQ_EINVAL;
+      if (!ws[t0 + i] || !dw[t0 + i] || n_slabs[t0 + i] < 1 || n_elem[t0 + i] < 1) return ALIGNQ_EINVAL;
       c.slabs[i] = (const float*)ws[t0 + i]; c.dw[i] = dw[t0 + i]; c.n_slabs[i] = n_slabs[t0 + i];
-      c.n_elem[i] = 9 * C[t0 + i] * C[t0 + i];
+      c.n_elem[i] = n_elem[t0 + i];
       if (c.n_elem[i] > max_elem) max_elem = c.n_elem[i];
     }
     hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((max_elem + 63) / 64, cnt), 1024, 0, st, c);
@@ -879,6 +923,23 @@ int alignq_conv_gen_nhwc_fwd(const float* x, const float* wt, float* y, int B, i
   if (CIN == 16 && KS == 1) return launch_gen<16, 32, 32, 1, 2, 128>(x, wt, y, B, H, nlev, bn_part, st);
   if (CIN == 32 && KS == 3) return launch_gen<32, 64, 16, 3, 2, 32>(x, wt, y, B, H, nlev, bn_part, st);
   if (CIN == 32 && KS == 1) return launch_gen<32, 64, 16, 1, 2, 64>(x, wt, y, B, H, nlev, bn_part, st);
+  return ALIGNQ_EUNSUPPORTED;
+}
+
+// Filter gradient of the transition convolutions (shapes of alignq_conv_gen_nhwc_fwd): dW [COUT,KS,KS,CIN] from x [B,H_in,W_in,CIN]
+// and dy [B,H_in/2,W_in/2,COUT]; ws = alignq_conv_gen_wgrad_ws_bytes; n_slabs_out as in alignq_conv3x3_nhwc_wgrad.
+size_t alignq_conv_gen_wgrad_ws_bytes(int CIN, int COUT, int KS) { return (size_t)256 * KS * KS * (size_t)CIN * COUT * sizeof(float); }
+int alignq_conv_gen_nhwc_wgrad(const float* x, const float* dy, float* dw, void* ws, int B, int H_in, int W_in, int CIN,
+                               int COUT, int KS, int stride, int* n_slabs_out, void* stream) {
+  if (!x || !dy || !ws || B < 1 || (!dw && !n_slabs_out)) return ALIGNQ_EINVAL;
+  if (!alignq_conv_gen_bn_parts(B, H_in, W_in, CIN, COUT, KS, stride)) return ALIGNQ_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dw)) & 15) return ALIGNQ_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int H = H_in / 2;
+  if (CIN == 16 && KS == 3) return launch_wgradgen<16, 32, 32, 3, 2, 64>(x, dy, dw, (float*)ws, B, H, n_slabs_out, st);
+  if (CIN == 16 && KS == 1) return launch_wgradgen<16, 32, 32, 1, 2, 128>(x, dy, dw, (float*)ws, B, H, n_slabs_out, st);
+  if (CIN == 32 && KS == 3) return launch_wgradgen<32, 64, 16, 3, 2, 64>(x, dy, dw, (float*)ws, B, H, n_slabs_out, st);
+  if (CIN == 32 && KS == 1) return launch_wgradgen<32, 64, 16, 1, 2, 64>(x, dy, dw, (float*)ws, B, H, n_slabs_out, st);
   return ALIGNQ_EUNSUPPORTED;
 }
 

@@ -218,8 +218,8 @@ class DeferredWgrads:
         _active_wgrads = None
         return False
 
-    def add(self, ws, dw, n_slabs, C):
-        self.items.append((ws, dw, int(n_slabs), int(C)))
+    def add(self, ws, dw, n_slabs, n_elem):
+        self.items.append((ws, dw, int(n_slabs), int(n_elem)))
 
     def flush(self):
         if not self.items:

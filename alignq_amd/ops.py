@@ -352,7 +352,7 @@ class QConv3x3Fn(torch.autograd.Function):
             L.check(lib.alignq_conv3x3_nhwc_bwd(L.ptr(x), L.ptr(gy), L.ptr(w), L.ptr(dx), L.ptr(ws), B, H, W, C, ctx.w_bit,
                                                 ctypes.byref(ns), L.ptr(add), L.ptr(bz), L.ptr(bab), L.ptr(bsave), L.ptr(bk),
                                                 L.stream_ptr()), "alignq_conv3x3_nhwc_bwd")
-            pending.add(ws, dw, ns.value, C)
+            pending.add(ws, dw, ns.value, 9 * C * C)
             return dx, dw, None, None, None
         if lazy is not None:               # not the fused path after all: finish the batch-norm input gradient here
             _, bz, bab, bsave, bk = lazy
@@ -370,7 +370,7 @@ class QConv3x3Fn(torch.autograd.Function):
                 ns = ctypes.c_int(0)
                 L.check(lib.alignq_conv3x3_nhwc_wgrad(L.ptr(x), L.ptr(gy), None, L.ptr(ws), B, H, W, C, ctypes.byref(ns),
                                                       L.stream_ptr()), "alignq_conv3x3_nhwc_wgrad")
-                pending.add(ws, dw, ns.value, C)
+                pending.add(ws, dw, ns.value, 9 * C * C)
             else:
                 L.check(lib.alignq_conv3x3_nhwc_wgrad(L.ptr(x), L.ptr(gy), L.ptr(dw), L.ptr(ws), B, H, W, C, None,
                                                       L.stream_ptr()), "alignq_conv3x3_nhwc_wgrad")
@@ -398,7 +398,8 @@ def qconv_gen_supported(x, w, stride, padding, dilation, groups, bias, w_bit) ->
 
 class QConvGenFn(torch.autograd.Function):
     """Forward of Conv2d_Q's stride-2 transition convolutions (3x3 and the 1x1 shortcut) on alignq_conv_gen_nhwc_fwd, with the
-    batch-norm partial statistics of the output as a by-product; both gradients stay on MIOpen."""
+    batch-norm partial statistics of the output as a by-product; the filter gradient is ours too, the data gradient stays on
+    MIOpen."""
 
     @staticmethod
     def forward(ctx, x, w, w_bit, padding):
@@ -420,8 +421,25 @@ class QConvGenFn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         pd = ctx.padding
         gy = gy.contiguous(memory_format=torch.channels_last)
-        dx, dw, _ = torch.ops.aten.convolution_backward(gy, x, w, None, [2, 2], [pd, pd], [1, 1], False, [0, 0], 1,
-                                                        [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
+        dx = dw = None
+        if ctx.needs_input_grad[0]:        # data gradient: MIOpen
+            dx = torch.ops.aten.convolution_backward(gy, x, w, None, [2, 2], [pd, pd], [1, 1], False, [0, 0], 1,
+                                                     [True, False, False])[0]
+        if ctx.needs_input_grad[1]:        # filter gradient: ours (split-bf16 MFMA, deterministic slabs)
+            B, CIN, H, W = x.shape
+            COUT, ks = w.shape[0], w.shape[2]
+            lib = L.load()
+            dw = torch.empty_like(w)
+            ws = _ws(lib.alignq_conv_gen_wgrad_ws_bytes(CIN, COUT, ks), x.device)
+            pending = fused.active_wgrads()
+            if pending is not None:
+                ns = ctypes.c_int(0)
+                L.check(lib.alignq_conv_gen_nhwc_wgrad(L.ptr(x), L.ptr(gy), None, L.ptr(ws), B, H, W, CIN, COUT, ks, 2,
+                                                       ctypes.byref(ns), L.stream_ptr()), "alignq_conv_gen_nhwc_wgrad")
+                pending.add(ws, dw, ns.value, ks * ks * CIN * COUT)
+            else:
+                L.check(lib.alignq_conv_gen_nhwc_wgrad(L.ptr(x), L.ptr(gy), L.ptr(dw), L.ptr(ws), B, H, W, CIN, COUT, ks, 2,
+                                                       None, L.stream_ptr()), "alignq_conv_gen_nhwc_wgrad")
         return dx, dw, None, None
 
     @staticmethod

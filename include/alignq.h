@@ -195,7 +195,7 @@ int alignq_conv3x3_nhwc(const float* x, const float* wt, float* y, int B, int H,
 /* Forward of the body's transition convolutions (stride 2: 3x3 padding 1, and the 1x1 shortcut), C_in != C_out:
  * (CIN, COUT, W_in) in {(16, 32, 32), (32, 64, 16)}; x [B,H_in,W_in,CIN], wt [COUT,KS,KS,CIN], y [B,H_in/2,W_in/2,COUT], all
  * channels-last; same exact-product scheme and optional bn_part ([COUT][alignq_conv_gen_bn_parts][2]) as alignq_conv3x3_nhwc.
- * Their gradients stay on MIOpen.                                                                                        */
+ * Filter gradient: alignq_conv_gen_nhwc_wgrad; the data gradient stays on MIOpen.                                         */
 int alignq_conv_gen_bn_parts(int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride);
 int alignq_conv_gen_nhwc_fwd(const float* x, const float* wt, float* y, int B, int H_in, int W_in, int CIN, int COUT, int KS,
                              int stride, int w_bit, float* bn_part, void* stream);
@@ -208,8 +208,12 @@ int alignq_conv3x3_nhwc_wgrad(const float* x, const float* dy, float* dw, void* 
                               int* n_slabs_out, void* stream);
 /* n_slabs_out (HOST pointer) != NULL defers the reduction: only the partial sums are launched, *n_slabs_out receives the
  * slab count, and ONE alignq_conv3x3_wgrad_reduce_multi launch later finishes T filters (HOST arrays ws / dw / n_slabs / C). */
-int alignq_conv3x3_wgrad_reduce_multi(int T, const void* const* ws, float* const* dw, const int* n_slabs, const int* C,
-                                      void* stream);
+int alignq_conv3x3_wgrad_reduce_multi(int T, const void* const* ws, float* const* dw, const int* n_slabs, const int* n_elem,
+                                      void* stream);       /* n_elem[t] = elements of filter t (9*C*C, or KS*KS*CIN*COUT) */
+/* filter gradient of the transition convolutions (shapes of alignq_conv_gen_nhwc_fwd), same deferred-reduction contract */
+size_t alignq_conv_gen_wgrad_ws_bytes(int CIN, int COUT, int KS);
+int alignq_conv_gen_nhwc_wgrad(const float* x, const float* dy, float* dw, void* ws, int B, int H_in, int W_in, int CIN,
+                               int COUT, int KS, int stride, int* n_slabs_out, void* stream);
 
 /* Data gradient AND filter-gradient partial sums of one convolution in a single launch (workgroup roles by block index; the
  * two are independent and fill the chip together).  The slabs left in ws are finished by alignq_conv3x3_wgrad_reduce_multi. */
