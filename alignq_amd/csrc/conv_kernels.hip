@@ -396,6 +396,143 @@ __global__ __launch_bounds__(256) void convgen_fwd_kernel(const float* __restric
   }
 }
 
+// ---- data gradient of the stride-2 transition convolutions -----------------------------------------------------------
+// dx[ih, iw, ci] = sum_{ky, kx, co} dy[(ih + P - ky) / 2, (iw + P - kx) / 2, co] * W[co][ky][kx][ci]  over the taps whose
+// parities match (P = padding: 1 for 3x3, 0 for 1x1).  Implicit GEMM with k = (tap, co): A[m = ci][k] = W[co][tap][ci] (integer
+// bins, registers), B[k][n = input pixel] = the dy pixel that tap reaches, or a zero pixel of the LDS image when the parity
+// does not match / the position lies outside (address select, no branch).  dy may arrive in the lazy batch-norm form.
+// H is the INPUT height (rows of dx), WDI its width; dy is [.., H/2, WDI/2, COUT].  PT input pixels (an even number of rows).
+template <int CIN, int COUT, int WDI, int KS, int PT>
+__global__ __launch_bounds__(256) void dgrad_s2_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                       float* __restrict__ dx, int H, int total_rows, float nlev,
+                                                       BnLazy lazy) {
+  constexpr int P = KS == 3 ? 1 : 0;
+  constexpr int WDO = WDI / 2, TR = PT / WDI;
+  constexpr int DROWS = TR / 2 + P, DCOLS = WDO + P;       // dy rows / columns the tile's taps can reach
+  constexpr int CP = COUT + 8;
+  constexpr int NPIX = DROWS * DCOLS + 1;                  // + one all-zero pixel
+  constexpr int ARR = NPIX * CP;
+  constexpr int NT = KS * KS;
+  constexpr int NS = (NT * COUT + 31) / 32;
+  constexpr int NCG = CIN / 16, NPP = 4 / NCG, NG = PT / 16;
+  __shared__ __attribute__((aligned(16))) __bf16 lds[3 * ARR];
+  __bf16* Xhi = lds;
+  __bf16* Xmi = lds + ARR;
+  __bf16* Xlo = lds + 2 * ARR;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int row0 = blockIdx.x * TR;                         // first INPUT row (image*H + ih), even
+  const int Ho = H / 2;
+  const int orow0 = (row0 / H) * Ho + (row0 % H) / 2;       // first dy row the tile reaches (ky = P)
+  const int oimg_hi = (row0 / H + 1) * Ho;                  // end of the image's dy rows
+  {
+    constexpr int C4 = COUT / 4;
+    constexpr int N4 = NPIX * C4;
+    constexpr int NIT = (N4 + 255) / 256;
+    float4 v[NIT], zz[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int i = tid + 256 * it;
+      const int c4 = i % C4, pix = i / C4;
+      const int lr = pix / DCOLS, col = pix % DCOLS;
+      const int grow = orow0 + lr;
+      const bool ok = i < N4 && pix < DROWS * DCOLS && col < WDO && grow < oimg_hi;
+      const int64_t off = ok ? ((int64_t)grow * WDO + col) * COUT + 4 * c4 : 0;
+      v[it] = *reinterpret_cast<const float4*>(dy + off);
+      if (lazy.z) zz[it] = *reinterpret_cast<const float4*>(lazy.z + off);
+      if (!ok) v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (lazy.z) {
+      const int c4t = tid % C4;
+      const float4 a4 = *reinterpret_cast<const float4*>(lazy.ab + 4 * c4t);
+      const float4 m4 = *reinterpret_cast<const float4*>(lazy.save + 4 * c4t);
+      const float4 i4 = *reinterpret_cast<const float4*>(lazy.save + COUT + 4 * c4t);
+      const float4 k0 = *reinterpret_cast<const float4*>(lazy.ktot + 4 * c4t);
+      const float4 k1 = *reinterpret_cast<const float4*>(lazy.ktot + COUT + 4 * c4t);
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+        const int i = tid + 256 * it;
+        const int pix = i / C4;
+        const int lr = pix / DCOLS, col = pix % DCOLS;
+        const bool ok = i < N4 && pix < DROWS * DCOLS && col < WDO && orow0 + lr < oimg_hi;
+        if (ok) v[it] = bn_lazy4(v[it], zz[it], a4, m4, i4, k0, k1);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int i = tid + 256 * it;
+      if (i < N4) {
+        const int c4 = i % C4, pix = i / C4;
+        bf16x4 h4, m4, l4;
+        const float vv[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const __bf16 hi = (__bf16)vv[e];
+          const float r1 = vv[e] - (float)hi;
+          const __bf16 mi = (__bf16)r1;
+          h4[e] = hi; m4[e] = mi; l4[e] = (__bf16)(r1 - (float)mi);
+        }
+        const int o = pix * CP + 4 * c4;
+        *reinterpret_cast<bf16x4*>(Xhi + o) = h4;
+        *reinterpret_cast<bf16x4*>(Xmi + o) = m4;
+        *reinterpret_cast<bf16x4*>(Xlo + o) = l4;
+      }
+    }
+  }
+  const int cig = wv % NCG, pp = wv / NCG;
+  const int m = lane & 15, q = lane >> 4;
+  bf16x8 ab[NS];
+#pragma unroll
+  for (int s = 0; s < NS; s++) {
+    const int k0 = 32 * s + 8 * q;
+    const int tap = k0 / COUT, c0 = k0 % COUT;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const float v = tap < NT ? w[((int64_t)(c0 + j) * NT + tap) * CIN + cig * 16 + m] : 0.f;
+      ab[s][j] = (__bf16)rintf(v * nlev);
+    }
+  }
+  __syncthreads();
+  for (int g = pp; g < NG; g += NPP) {
+    const int p = g * 16 + (lane & 15);
+    const int r = p / WDI, c = p % WDI;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+      const int k0 = 32 * s + 8 * q;
+      const int tap = k0 / COUT, c0 = k0 % COUT;
+      int pix = DROWS * DCOLS;                              // the zero pixel
+      if (tap < NT) {
+        const int ky = tap / KS, kx = tap % KS;
+        const int a = r + P - ky, b = c + P - kx;           // 2 * (dy row - orow0 ... ) when even and >= 0
+        if (a >= 0 && b >= 0 && !(a & 1) && !(b & 1)) pix = (a >> 1) * DCOLS + (b >> 1);
+      }
+      const int o = pix * CP + c0;
+      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Xhi + o);
+      const bf16x8 bm = *reinterpret_cast<const bf16x8*>(Xmi + o);
+      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(Xlo + o);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[s], bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[s], bm, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[s], bh, acc, 0, 0, 0);
+    }
+    const int grow = row0 + r;
+    if (grow < total_rows)
+      *reinterpret_cast<float4*>(dx + ((int64_t)grow * WDI + c) * CIN + cig * 16 + 4 * q) =
+          make_float4(acc[0] / nlev, acc[1] / nlev, acc[2] / nlev, acc[3] / nlev);
+  }
+}
+
+template <int CIN, int COUT, int WDI, int KS, int PT>
+int launch_dgrad_s2(const float* dy, const float* w, float* dx, int B, int H, float nlev, BnLazy lazy, hipStream_t st) {
+  constexpr int TR = PT / WDI;
+  static_assert(TR % 2 == 0, "even number of input rows per tile");
+  if (H % TR) return ALIGNQ_EUNSUPPORTED;
+  const int total_rows = B * H;
+  hipLaunchKernelGGL((dgrad_s2_kernel<CIN, COUT, WDI, KS, PT>), total_rows / TR, 256, 0, st, dy, w, dx, H, total_rows, nlev,
+                     lazy);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
 template <int CIN, int COUT, int WDI, int KS, int S, int PT>
 int launch_gen(const float* x, const float* w, float* y, int B, int H, float nlev, float* bn_part, hipStream_t st) {
   constexpr int TR = ConvGen<CIN, COUT, WDI, KS, S, PT>::TR;
@@ -671,9 +808,9 @@ __device__ __forceinline__ void wgrad3x3_body(const float* __restrict__ x, const
 // stand-alone filter gradient of the transition convolutions (stride 2: 3x3 and 1x1)
 template <int CIN, int COUT, int WDI, int KS, int S, int PT>
 __global__ __launch_bounds__(256) void wgradgen_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                       float* __restrict__ slabs, int H, int n_tiles) {
+                                                       float* __restrict__ slabs, int H, int n_tiles, BnLazy lazy) {
   __shared__ __attribute__((aligned(16))) float lds[WgradGeo<CIN, COUT, WDI, KS, S, PT>::kFloats];
-  wgrad_body<CIN, COUT, WDI, KS, S, PT>(x, dy, slabs, H, n_tiles, lds, blockIdx.x, gridDim.x, blockIdx.y);
+  wgrad_body<CIN, COUT, WDI, KS, S, PT>(x, dy, slabs, H, n_tiles, lds, blockIdx.x, gridDim.x, blockIdx.y, lazy);
 }
 
 template <int C, int WD, int PT>
@@ -794,14 +931,15 @@ int launch_bwd(const float* x, const float* dy, const float* w, float* dx, float
 }
 
 template <int CIN, int COUT, int WDI, int KS, int S, int PT>
-int launch_wgradgen(const float* x, const float* dy, float* dw, float* ws, int B, int H, int* n_slabs_out, hipStream_t st) {
+int launch_wgradgen(const float* x, const float* dy, float* dw, float* ws, int B, int H, int* n_slabs_out, BnLazy lazy,
+                    hipStream_t st) {
   using G = WgradGeo<CIN, COUT, WDI, KS, S, PT>;
   if (H % G::TR) return ALIGNQ_EUNSUPPORTED;
   const int n_tiles = B * H / G::TR;
   constexpr int NBY = (COUT / G::CB) * (CIN / G::CB);
   int splits = 256 / NBY;
   if (splits > n_tiles) splits = n_tiles;
-  hipLaunchKernelGGL((wgradgen_kernel<CIN, COUT, WDI, KS, S, PT>), dim3(splits, NBY), 256, 0, st, x, dy, ws, H, n_tiles);
+  hipLaunchKernelGGL((wgradgen_kernel<CIN, COUT, WDI, KS, S, PT>), dim3(splits, NBY), 256, 0, st, x, dy, ws, H, n_tiles, lazy);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   if (n_slabs_out) { *n_slabs_out = splits; return 0; }
@@ -930,16 +1068,38 @@ int alignq_conv_gen_nhwc_fwd(const float* x, const float* wt, float* y, int B, i
 // and dy [B,H_in/2,W_in/2,COUT]; ws = alignq_conv_gen_wgrad_ws_bytes; n_slabs_out as in alignq_conv3x3_nhwc_wgrad.
 size_t alignq_conv_gen_wgrad_ws_bytes(int CIN, int COUT, int KS) { return (size_t)256 * KS * KS * (size_t)CIN * COUT * sizeof(float); }
 int alignq_conv_gen_nhwc_wgrad(const float* x, const float* dy, float* dw, void* ws, int B, int H_in, int W_in, int CIN,
-                               int COUT, int KS, int stride, int* n_slabs_out, void* stream) {
+                               int COUT, int KS, int stride, int* n_slabs_out, const float* bn_z, const float* bn_ab,
+                               const float* bn_save, const float* bn_ktot, void* stream) {
   if (!x || !dy || !ws || B < 1 || (!dw && !n_slabs_out)) return ALIGNQ_EINVAL;
+  if (bn_z && (!bn_ab || !bn_save || !bn_ktot)) return ALIGNQ_EINVAL;
+  const BnLazy lazy{bn_z, bn_ab, bn_save, bn_ktot};
   if (!alignq_conv_gen_bn_parts(B, H_in, W_in, CIN, COUT, KS, stride)) return ALIGNQ_EUNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dw)) & 15) return ALIGNQ_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const int H = H_in / 2;
-  if (CIN == 16 && KS == 3) return launch_wgradgen<16, 32, 32, 3, 2, 64>(x, dy, dw, (float*)ws, B, H, n_slabs_out, st);
-  if (CIN == 16 && KS == 1) return launch_wgradgen<16, 32, 32, 1, 2, 128>(x, dy, dw, (float*)ws, B, H, n_slabs_out, st);
-  if (CIN == 32 && KS == 3) return launch_wgradgen<32, 64, 16, 3, 2, 64>(x, dy, dw, (float*)ws, B, H, n_slabs_out, st);
-  if (CIN == 32 && KS == 1) return launch_wgradgen<32, 64, 16, 1, 2, 64>(x, dy, dw, (float*)ws, B, H, n_slabs_out, st);
+  if (CIN == 16 && KS == 3) return launch_wgradgen<16, 32, 32, 3, 2, 64>(x, dy, dw, (float*)ws, B, H, n_slabs_out, lazy, st);
+  if (CIN == 16 && KS == 1) return launch_wgradgen<16, 32, 32, 1, 2, 128>(x, dy, dw, (float*)ws, B, H, n_slabs_out, lazy, st);
+  if (CIN == 32 && KS == 3) return launch_wgradgen<32, 64, 16, 3, 2, 64>(x, dy, dw, (float*)ws, B, H, n_slabs_out, lazy, st);
+  if (CIN == 32 && KS == 1) return launch_wgradgen<32, 64, 16, 1, 2, 64>(x, dy, dw, (float*)ws, B, H, n_slabs_out, lazy, st);
+  return ALIGNQ_EUNSUPPORTED;
+}
+
+// Data gradient of the transition convolutions: dx [B,H_in,W_in,CIN] from dy [B,H_in/2,W_in/2,COUT]; bn_* as in
+// alignq_conv3x3_nhwc_bwd (dy given in the lazy batch-norm form when bn_z != NULL).
+int alignq_conv_gen_nhwc_dgrad(const float* dy, const float* wt, float* dx, int B, int H_in, int W_in, int CIN, int COUT, int KS,
+                               int stride, int w_bit, const float* bn_z, const float* bn_ab, const float* bn_save,
+                               const float* bn_ktot, void* stream) {
+  if (!dy || !wt || !dx || B < 1) return ALIGNQ_EINVAL;
+  if (bn_z && (!bn_ab || !bn_save || !bn_ktot)) return ALIGNQ_EINVAL;
+  if (w_bit < 1 || w_bit > 8 || !alignq_conv_gen_bn_parts(B, H_in, W_in, CIN, COUT, KS, stride)) return ALIGNQ_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(wt) | reinterpret_cast<uintptr_t>(dx)) & 15) return ALIGNQ_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const float nlev = (float)((1 << w_bit) - 1);
+  const BnLazy lazy{bn_z, bn_ab, bn_save, bn_ktot};
+  if (CIN == 16 && KS == 3) return launch_dgrad_s2<16, 32, 32, 3, 128>(dy, wt, dx, B, H_in, nlev, lazy, st);
+  if (CIN == 16 && KS == 1) return launch_dgrad_s2<16, 32, 32, 1, 128>(dy, wt, dx, B, H_in, nlev, lazy, st);
+  if (CIN == 32 && KS == 3) return launch_dgrad_s2<32, 64, 16, 3, 128>(dy, wt, dx, B, H_in, nlev, lazy, st);
+  if (CIN == 32 && KS == 1) return launch_dgrad_s2<32, 64, 16, 1, 128>(dy, wt, dx, B, H_in, nlev, lazy, st);
   return ALIGNQ_EUNSUPPORTED;
 }
 

@@ -398,8 +398,8 @@ def qconv_gen_supported(x, w, stride, padding, dilation, groups, bias, w_bit) ->
 
 class QConvGenFn(torch.autograd.Function):
     """Forward of Conv2d_Q's stride-2 transition convolutions (3x3 and the 1x1 shortcut) on alignq_conv_gen_nhwc_fwd, with the
-    batch-norm partial statistics of the output as a by-product; the filter gradient is ours too, the data gradient stays on
-    MIOpen."""
+    batch-norm partial statistics of the output as a by-product; data gradient (alignq_conv_gen_nhwc_dgrad) and filter gradient
+    (alignq_conv_gen_nhwc_wgrad) accept the lazy batch-norm form of the incoming gradient."""
 
     @staticmethod
     def forward(ctx, x, w, w_bit, padding):
@@ -412,34 +412,39 @@ class QConvGenFn(torch.autograd.Function):
         L.check(lib.alignq_conv_gen_nhwc_fwd(L.ptr(x), L.ptr(w), L.ptr(y), B, H, W, CIN, COUT, ks, 2, int(w_bit), L.ptr(part),
                                              L.stream_ptr()), "alignq_conv_gen_nhwc_fwd")
         ctx.save_for_backward(x, w)
-        ctx.padding = int(padding)
-        QConv3x3Fn._mailbox = (part, n_parts, False)
+        ctx.w_bit = int(w_bit)
+        QConv3x3Fn._mailbox = (part, n_parts, True)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
-        pd = ctx.padding
+        lazy = fused.take_lazy_dz(gy)      # (g, z, ab, save, ktot): gy is the gradient w.r.t. the folded BN's OUTPUT
         gy = gy.contiguous(memory_format=torch.channels_last)
+        bz, bab, bsave, bk = (lazy[1], lazy[2], lazy[3], lazy[4]) if lazy is not None else (None, None, None, None)
+        B, CIN, H, W = x.shape
+        COUT, ks = w.shape[0], w.shape[2]
+        lib = L.load()
         dx = dw = None
-        if ctx.needs_input_grad[0]:        # data gradient: MIOpen
-            dx = torch.ops.aten.convolution_backward(gy, x, w, None, [2, 2], [pd, pd], [1, 1], False, [0, 0], 1,
-                                                     [True, False, False])[0]
-        if ctx.needs_input_grad[1]:        # filter gradient: ours (split-bf16 MFMA, deterministic slabs)
-            B, CIN, H, W = x.shape
-            COUT, ks = w.shape[0], w.shape[2]
-            lib = L.load()
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            L.check(lib.alignq_conv_gen_nhwc_dgrad(L.ptr(gy), L.ptr(w), L.ptr(dx), B, H, W, CIN, COUT, ks, 2, ctx.w_bit,
+                                                   L.ptr(bz), L.ptr(bab), L.ptr(bsave), L.ptr(bk), L.stream_ptr()),
+                    "alignq_conv_gen_nhwc_dgrad")
+        if ctx.needs_input_grad[1]:        # split-bf16 MFMA, deterministic slabs
             dw = torch.empty_like(w)
             ws = _ws(lib.alignq_conv_gen_wgrad_ws_bytes(CIN, COUT, ks), x.device)
             pending = fused.active_wgrads()
             if pending is not None:
                 ns = ctypes.c_int(0)
                 L.check(lib.alignq_conv_gen_nhwc_wgrad(L.ptr(x), L.ptr(gy), None, L.ptr(ws), B, H, W, CIN, COUT, ks, 2,
-                                                       ctypes.byref(ns), L.stream_ptr()), "alignq_conv_gen_nhwc_wgrad")
+                                                       ctypes.byref(ns), L.ptr(bz), L.ptr(bab), L.ptr(bsave), L.ptr(bk),
+                                                       L.stream_ptr()), "alignq_conv_gen_nhwc_wgrad")
                 pending.add(ws, dw, ns.value, ks * ks * CIN * COUT)
             else:
                 L.check(lib.alignq_conv_gen_nhwc_wgrad(L.ptr(x), L.ptr(gy), L.ptr(dw), L.ptr(ws), B, H, W, CIN, COUT, ks, 2,
-                                                       None, L.stream_ptr()), "alignq_conv_gen_nhwc_wgrad")
+                                                       None, L.ptr(bz), L.ptr(bab), L.ptr(bsave), L.ptr(bk), L.stream_ptr()),
+                        "alignq_conv_gen_nhwc_wgrad")
         return dx, dw, None, None
 
     @staticmethod

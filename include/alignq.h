@@ -195,10 +195,15 @@ int alignq_conv3x3_nhwc(const float* x, const float* wt, float* y, int B, int H,
 /* Forward of the body's transition convolutions (stride 2: 3x3 padding 1, and the 1x1 shortcut), C_in != C_out:
  * (CIN, COUT, W_in) in {(16, 32, 32), (32, 64, 16)}; x [B,H_in,W_in,CIN], wt [COUT,KS,KS,CIN], y [B,H_in/2,W_in/2,COUT], all
  * channels-last; same exact-product scheme and optional bn_part ([COUT][alignq_conv_gen_bn_parts][2]) as alignq_conv3x3_nhwc.
- * Filter gradient: alignq_conv_gen_nhwc_wgrad; the data gradient stays on MIOpen.                                         */
+ * Gradients: alignq_conv_gen_nhwc_wgrad, alignq_conv_gen_nhwc_dgrad.                                                     */
 int alignq_conv_gen_bn_parts(int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride);
 int alignq_conv_gen_nhwc_fwd(const float* x, const float* wt, float* y, int B, int H_in, int W_in, int CIN, int COUT, int KS,
                              int stride, int w_bit, float* bn_part, void* stream);
+
+/* data gradient of the transition convolutions; bn_* as in alignq_conv3x3_nhwc_bwd (lazy batch-norm form of dy) */
+int alignq_conv_gen_nhwc_dgrad(const float* dy, const float* wt, float* dx, int B, int H_in, int W_in, int CIN, int COUT, int KS,
+                               int stride, int w_bit, const float* bn_z, const float* bn_ab, const float* bn_save,
+                               const float* bn_ktot, void* stream);
 
 /* Filter gradient of the same convolution, dW [C,3,3,C] (channels-last weight storage) from x and dy: plain fp32 on the f32
  * MFMAs (products and accumulation bit-for-bit an fmaf chain), per-pixel-range partial sums in ws
@@ -213,7 +218,8 @@ int alignq_conv3x3_wgrad_reduce_multi(int T, const void* const* ws, float* const
 /* filter gradient of the transition convolutions (shapes of alignq_conv_gen_nhwc_fwd), same deferred-reduction contract */
 size_t alignq_conv_gen_wgrad_ws_bytes(int CIN, int COUT, int KS);
 int alignq_conv_gen_nhwc_wgrad(const float* x, const float* dy, float* dw, void* ws, int B, int H_in, int W_in, int CIN,
-                               int COUT, int KS, int stride, int* n_slabs_out, void* stream);
+                               int COUT, int KS, int stride, int* n_slabs_out, const float* bn_z, const float* bn_ab,
+                               const float* bn_save, const float* bn_ktot, void* stream);
 
 /* Data gradient AND filter-gradient partial sums of one convolution in a single launch (workgroup roles by block index; the
  * two are independent and fill the chip together).  The slabs left in ws are finished by alignq_conv3x3_wgrad_reduce_multi. */

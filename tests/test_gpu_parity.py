@@ -929,7 +929,7 @@ def test_conv_epilogue_bn_statistics_feed_the_fold(dev, B, C, H, k):
                                                (128, 32, 64, 16, 1, 8), (8, 16, 32, 32, 3, 2), (8, 32, 64, 16, 1, 8)])
 def test_qconv_transition_forward_matches_fp64(dev, B, CIN, COUT, H, ks, k):
     """alignq_conv_gen_nhwc_fwd (stride-2 3x3 and 1x1 shortcut convolutions) against fp64, its batch-norm partials against the
-    statistics of its output, and its (MIOpen) gradients through the autograd Function."""
+    statistics of its output, and its data / filter gradients (alignq_conv_gen_nhwc_dgrad / _wgrad) against MIOpen's."""
     from alignq_amd import ops
     torch.manual_seed(CIN + ks + k)
     n = 2 ** k - 1
@@ -945,7 +945,7 @@ def test_qconv_transition_forward_matches_fp64(dev, B, CIN, COUT, H, ks, k):
     floor = 2e-6 * float(yd.abs().max())
     assert float((y.detach() - yd).abs().max()) <= max(float((y32 - yd).abs().max()), floor)
     part, n_parts, lazy_ok = y._alignq_bn_part
-    assert not lazy_ok and part.shape == (COUT, n_parts, 2)
+    assert lazy_ok and part.shape == (COUT, n_parts, 2)
     np.testing.assert_allclose(npy(part[:, :, 0].double().sum(1)), npy(yd.sum((0, 2, 3))), rtol=1e-5, atol=1e-2)
     np.testing.assert_allclose(npy(part[:, :, 1].double().sum(1)), npy((yd * yd).sum((0, 2, 3))), rtol=1e-5)
     gy = torch.randn_like(y)
