@@ -25,6 +25,19 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// 4 pixels x 16 channels block at `p` (this lane's row q = (lane & 15) >> 2, columns 4 * (lane & 3)), transposed: the lane
+// receives channel (lane & 15) of the 4 pixels.  EXEC must be all ones (it is: no divergence around the calls).
+__device__ __forceinline__ s16x4 tr_read(const __bf16* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+__device__ __forceinline__ bf16x8 join8(s16x4 a, s16x4 b) {
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
 
 // C channels, WD image width, PT pixels per workgroup (TR = PT / WD whole image rows, TR divides H so a tile never straddles
 // two images).  LDS pixel stride is C + 8 bf16: the 16 lanes of a ds_read_b128 phase then hit 16 distinct 16-byte slots.
@@ -533,6 +546,203 @@ int launch_dgrad_s2(const float* dy, const float* w, float* dx, int B, int H, fl
   return e == hipSuccess ? 0 : (int)e;
 }
 
+// ---- the stem: 3x3, stride 1, padding 1, 3 input channels -> 16 ---------------------------------------------------------
+// K = 27 fits ONE 32-wide k step, so the tile is staged as an im2col image [pixel][32] (k = tap * 3 + ci, k >= 27 zero) of
+// three bf16 terms; forward: B fragments are plain ds_read_b128 of it (A = integer filter bins [16][32]); filter gradient:
+// dW[co][k] = sum_pixels dy[p][co] * col[p][k] with the pixel as MFMA k index, both operands through ds_read_b64_tr_b16 as in
+// wgrad_body (two 16-column blocks of col).  x [B,H,32,3] (channels-last storage of [B,3,H,32]), wt [16][3][3][3], y [B,H,32,16].
+constexpr int kStemPT = 128;                       // pixels per tile: 4 rows of 32
+__device__ __forceinline__ void stem_stage(const float* __restrict__ x, int H, int row0, __bf16* Chi, __bf16* Cmi, __bf16* Clo) {
+  // thread -> (pixel, tap-triple): 128 pixels x 2 halves of the 32-wide k vector (k 0..15, 16..31)
+  const int tid = threadIdx.x;
+  const int pix = tid >> 1, half = tid & 1;
+  const int r = pix / 32, c = pix % 32;
+  const int grow = row0 + r;
+  const int ih = grow % H;
+  float v[16];
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    const int k = 16 * half + j;
+    const int tap = k / 3, ci = k % 3;
+    const int ky = tap / 3, kx = tap % 3;
+    const int yy = ih + ky - 1, xx = c + kx - 1;
+    const bool ok = k < 27 && yy >= 0 && yy < H && xx >= 0 && xx < 32;
+    v[j] = x[ok ? ((int64_t)(grow + ky - 1) * 32 + xx) * 3 + ci : 0];
+    if (!ok) v[j] = 0.f;
+  }
+  bf16x8 h[2], m[2], l[2];
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    const __bf16 hi = (__bf16)v[j];
+    const float r1 = v[j] - (float)hi;
+    const __bf16 mi = (__bf16)r1;
+    h[j >> 3][j & 7] = hi; m[j >> 3][j & 7] = mi; l[j >> 3][j & 7] = (__bf16)(r1 - (float)mi);
+  }
+  const int o = pix * 32 + 16 * half;
+  *reinterpret_cast<bf16x8*>(Chi + o) = h[0]; *reinterpret_cast<bf16x8*>(Chi + o + 8) = h[1];
+  *reinterpret_cast<bf16x8*>(Cmi + o) = m[0]; *reinterpret_cast<bf16x8*>(Cmi + o + 8) = m[1];
+  *reinterpret_cast<bf16x8*>(Clo + o) = l[0]; *reinterpret_cast<bf16x8*>(Clo + o + 8) = l[1];
+}
+
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       float* __restrict__ y, int H, int total_rows, float nlev,
+                                                       float* __restrict__ bn_part) {
+  __shared__ __attribute__((aligned(16))) __bf16 lds[3 * kStemPT * 32];
+  __bf16* Chi = lds;
+  __bf16* Cmi = lds + kStemPT * 32;
+  __bf16* Clo = lds + 2 * kStemPT * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int row0 = blockIdx.x * 4;
+  stem_stage(x, H, row0, Chi, Cmi, Clo);
+  const int m = lane & 15, q = lane >> 4;
+  bf16x8 ab;                                     // A[m = co][k = 8q + j] = W[co][k] (k < 27)
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int k = 8 * q + j;
+    ab[j] = (__bf16)rintf((k < 27 ? w[m * 27 + k] : 0.f) * nlev);
+  }
+  __syncthreads();
+  float bs[4] = {0.f, 0.f, 0.f, 0.f}, bq[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int g = wv; g < kStemPT / 16; g += 4) {
+    const int p = g * 16 + (lane & 15);
+    const int o = p * 32 + 8 * q;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, *reinterpret_cast<const bf16x8*>(Clo + o), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, *reinterpret_cast<const bf16x8*>(Cmi + o), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, *reinterpret_cast<const bf16x8*>(Chi + o), acc, 0, 0, 0);
+    const int grow = row0 + p / 32;
+    if (grow < total_rows) {
+      const float4 v = make_float4(acc[0] / nlev, acc[1] / nlev, acc[2] / nlev, acc[3] / nlev);
+      *reinterpret_cast<float4*>(y + ((int64_t)grow * 32 + p % 32) * 16 + 4 * q) = v;
+      bs[0] += v.x; bs[1] += v.y; bs[2] += v.z; bs[3] += v.w;
+      bq[0] += v.x * v.x; bq[1] += v.y * v.y; bq[2] += v.z * v.z; bq[3] += v.w * v.w;
+    }
+  }
+  if (bn_part) {
+    float* red = reinterpret_cast<float*>(lds);
+#define ROW_SHR_ADD(V, CTRL) V += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V), CTRL, 0xf, 0xf, false))
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      ROW_SHR_ADD(bs[e], 0x111); ROW_SHR_ADD(bs[e], 0x112); ROW_SHR_ADD(bs[e], 0x114); ROW_SHR_ADD(bs[e], 0x118);
+      ROW_SHR_ADD(bq[e], 0x111); ROW_SHR_ADD(bq[e], 0x112); ROW_SHR_ADD(bq[e], 0x114); ROW_SHR_ADD(bq[e], 0x118);
+    }
+#undef ROW_SHR_ADD
+    __syncthreads();
+    if ((lane & 15) == 15) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        red[(wv * 16 + 4 * q + e) * 2] = bs[e];
+        red[(wv * 16 + 4 * q + e) * 2 + 1] = bq[e];
+      }
+    }
+    __syncthreads();
+    if (tid < 16) {
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < 4; w2++) { s0 += red[(w2 * 16 + tid) * 2]; s1 += red[(w2 * 16 + tid) * 2 + 1]; }
+      bn_part[((int64_t)tid * gridDim.x + blockIdx.x) * 2] = s0;
+      bn_part[((int64_t)tid * gridDim.x + blockIdx.x) * 2 + 1] = s1;
+    }
+  }
+}
+
+// filter gradient of the stem: slab [16][27] per workgroup (pixel range), reduced by wgrad_reduce[_multi]_kernel
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         float* __restrict__ slabs, int H, int n_tiles, BnLazy lazy) {
+  __shared__ __attribute__((aligned(16))) __bf16 lds[3 * kStemPT * 32 + 3 * kStemPT * 16];
+  __bf16* Ci[3] = {lds, lds + kStemPT * 32, lds + 2 * kStemPT * 32};
+  __bf16* Di[3] = {lds + 3 * kStemPT * 32, lds + 3 * kStemPT * 32 + kStemPT * 16, lds + 3 * kStemPT * 32 + 2 * kStemPT * 16};
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int g = lane >> 4, q = (lane & 15) >> 2, pcol = 4 * (lane & 3);
+  f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};      // the two 16-column blocks of k
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int row0 = tile * 4;
+    __syncthreads();
+    stem_stage(x, H, row0, Ci[0], Ci[1], Ci[2]);
+    {   // dy tile [128 pixels][16 co] as three bf16 terms (optionally the lazy batch-norm form)
+      const int c4 = tid % 4;
+      f32x4 la = {0, 0, 0, 0}, lm = la, li = la, lk0 = la, lk1 = la;
+      if (lazy.z) {
+        la = *reinterpret_cast<const f32x4*>(lazy.ab + 4 * c4);
+        lm = *reinterpret_cast<const f32x4*>(lazy.save + 4 * c4);
+        li = *reinterpret_cast<const f32x4*>(lazy.save + 16 + 4 * c4);
+        lk0 = *reinterpret_cast<const f32x4*>(lazy.ktot + 4 * c4);
+        lk1 = *reinterpret_cast<const f32x4*>(lazy.ktot + 16 + 4 * c4);
+      }
+#pragma unroll
+      for (int it = 0; it < 2; it++) {
+        const int i = tid + 256 * it;                  // 512 float4 slots
+        const int64_t off = ((int64_t)row0 * 32 + i / 4) * 16 + 4 * c4;
+        f32x4 dv = *reinterpret_cast<const f32x4*>(dy + off);
+        if (lazy.z) dv = la * (dv - lk0 - (*reinterpret_cast<const f32x4*>(lazy.z + off) - lm) * li * lk1);
+        bf16x4 h4, m4, l4;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const __bf16 hi = (__bf16)dv[e];
+          const float r1 = dv[e] - (float)hi;
+          const __bf16 mi = (__bf16)r1;
+          h4[e] = hi; m4[e] = mi; l4[e] = (__bf16)(r1 - (float)mi);
+        }
+        const int o = (i / 4) * 16 + 4 * c4;
+        *reinterpret_cast<bf16x4*>(Di[0] + o) = h4;
+        *reinterpret_cast<bf16x4*>(Di[1] + o) = m4;
+        *reinterpret_cast<bf16x4*>(Di[2] + o) = l4;
+      }
+    }
+    __syncthreads();
+    {   // one 32-pixel step per wave: pixels 32 wv + 8 g .. + 7
+      const int p0 = 32 * wv + 8 * g;
+      bf16x8 a[3];
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        const __bf16* pa = Di[t] + (p0 + q) * 16 + pcol;
+        a[t] = join8(tr_read(pa), tr_read(pa + 4 * 16));
+      }
+#pragma unroll
+      for (int blk = 0; blk < 2; blk++) {
+        bf16x8 b[3];
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+          const __bf16* pb = Ci[t] + (p0 + q) * 32 + 16 * blk + pcol;
+          b[t] = join8(tr_read(pb), tr_read(pb + 4 * 32));
+        }
+        f32x4 v = acc[blk];
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], v, 0, 0, 0);
+        acc[blk] = v;
+      }
+    }
+  }
+  // four waves -> LDS -> wave 0; C/D: column (k within block) = lane & 15, rows (co) = 4 (lane >> 4) + e
+  float* red = reinterpret_cast<float*>(lds);
+  __syncthreads();
+  if (wv > 0) {
+#pragma unroll
+    for (int blk = 0; blk < 2; blk++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) red[(((wv - 1) * 2 + blk) * 4 + e) * 64 + lane] = acc[blk][e];
+  }
+  __syncthreads();
+  if (wv == 0) {
+    float* slab = slabs + (int64_t)blockIdx.x * (16 * 27);
+#pragma unroll
+    for (int blk = 0; blk < 2; blk++) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        float v = acc[blk][e];
+#pragma unroll
+        for (int w2 = 0; w2 < 3; w2++) v += red[((w2 * 2 + blk) * 4 + e) * 64 + lane];
+        const int k = 16 * blk + (lane & 15), co = 4 * (lane >> 4) + e;
+        if (k < 27) slab[co * 27 + k] = v;
+      }
+    }
+  }
+}
+
 template <int CIN, int COUT, int WDI, int KS, int S, int PT>
 int launch_gen(const float* x, const float* w, float* y, int B, int H, float nlev, float* bn_part, hipStream_t st) {
   constexpr int TR = ConvGen<CIN, COUT, WDI, KS, S, PT>::TR;
@@ -571,7 +781,6 @@ int launch(const float* x, const float* w, float* y, int B, int H, int dgrad, fl
 // 9 per-tap accumulators live across a software-pipelined tile loop (the next tile's global loads fly under the MFMAs).  One
 // partial-sum slab [C][9][C] per pixel range; wgrad_reduce[_multi]_kernel sums the slabs in fixed order (deterministic).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 // Geometry of the filter-gradient kernel for a convolution CIN -> COUT, KS x KS, stride S, input width WDI, PT OUTPUT pixels per
 // tile (whole output rows).  The 3x3 stride-1 body convolutions are <C, C, WD, 3, 1, PT>.
@@ -589,17 +798,6 @@ struct WgradGeo {
 };
 template <int C, int WD, int PT>
 struct WgradLds : WgradGeo<C, C, WD, 3, 1, PT> {};
-
-// 4 pixels x 16 channels block at `p` (this lane's row q = (lane & 15) >> 2, columns 4 * (lane & 3)), transposed: the lane
-// receives channel (lane & 15) of the 4 pixels.  EXEC must be all ones (it is: no divergence around the calls).
-__device__ __forceinline__ s16x4 tr_read(const __bf16* p) {
-  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
-}
-__device__ __forceinline__ bf16x8 join8(s16x4 a, s16x4 b) {
-  typedef short s16x8 __attribute__((ext_vector_type(8)));
-  s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-  return __builtin_bit_cast(bf16x8, v);
-}
 
 // bx / gx: index and count of the pixel-range workgroups, by: (co block, ci block) index
 // H is the OUTPUT height (the input has S*H rows); x [.., S*H, WDI, CIN], dy [.., H, WDI/S, COUT].
@@ -1101,6 +1299,38 @@ int alignq_conv_gen_nhwc_dgrad(const float* dy, const float* wt, float* dx, int 
   if (CIN == 32 && KS == 3) return launch_dgrad_s2<32, 64, 16, 3, 128>(dy, wt, dx, B, H_in, nlev, lazy, st);
   if (CIN == 32 && KS == 1) return launch_dgrad_s2<32, 64, 16, 1, 128>(dy, wt, dx, B, H_in, nlev, lazy, st);
   return ALIGNQ_EUNSUPPORTED;
+}
+
+// The stem convolution (3 -> 16 channels, 3x3, stride 1, padding 1, width 32): x [B,H,32,3], wt [16,3,3,3] (channels-last
+// storage), y [B,H,32,16]; H % 4 == 0.  bn_part: [16][alignq_conv_stem_bn_parts][2] floats or NULL.
+int alignq_conv_stem_bn_parts(int B, int H, int W) { return (W == 32 && B >= 1 && H >= 4 && H % 4 == 0) ? B * H / 4 : 0; }
+int alignq_conv_stem_nhwc_fwd(const float* x, const float* wt, float* y, int B, int H, int W, int w_bit, float* bn_part,
+                              void* stream) {
+  if (!x || !wt || !y) return ALIGNQ_EINVAL;
+  if (w_bit < 1 || w_bit > 8 || !alignq_conv_stem_bn_parts(B, H, W)) return ALIGNQ_EUNSUPPORTED;
+  if (reinterpret_cast<uintptr_t>(y) & 15) return ALIGNQ_EUNSUPPORTED;
+  hipLaunchKernelGGL(stem_fwd_kernel, B * H / 4, 256, 0, (hipStream_t)stream, x, wt, y, H, B * H, (float)((1 << w_bit) - 1),
+                     bn_part);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+// filter gradient of the stem: dW [16,3,3,3]; ws = 256 * 16 * 27 floats; n_slabs_out / bn_* as in alignq_conv_gen_nhwc_wgrad
+int alignq_conv_stem_nhwc_wgrad(const float* x, const float* dy, float* dw, void* ws, int B, int H, int W, int* n_slabs_out,
+                                const float* bn_z, const float* bn_ab, const float* bn_save, const float* bn_ktot,
+                                void* stream) {
+  if (!x || !dy || !ws || (!dw && !n_slabs_out)) return ALIGNQ_EINVAL;
+  if (bn_z && (!bn_ab || !bn_save || !bn_ktot)) return ALIGNQ_EINVAL;
+  if (!alignq_conv_stem_bn_parts(B, H, W) || (reinterpret_cast<uintptr_t>(dy) & 15)) return ALIGNQ_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int n_tiles = B * H / 4;
+  const int splits = n_tiles < 256 ? n_tiles : 256;
+  hipLaunchKernelGGL(stem_wgrad_kernel, splits, 256, 0, st, x, dy, (float*)ws, H, n_tiles, BnLazy{bn_z, bn_ab, bn_save, bn_ktot});
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  if (n_slabs_out) { *n_slabs_out = splits; return 0; }
+  hipLaunchKernelGGL(wgrad_reduce_kernel, (16 * 27 + 63) / 64, 1024, 0, st, (const float*)ws, splits, 16 * 27, dw);
+  e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
 }
 
 }  // extern "C"

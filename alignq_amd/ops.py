@@ -455,3 +455,69 @@ class QConvGenFn(torch.autograd.Function):
             y._alignq_bn_part = QConv3x3Fn._mailbox
             QConv3x3Fn._mailbox = None
         return y
+
+
+def qconv_stem_supported(x, w, stride, padding, dilation, groups, bias, w_bit) -> bool:
+    """The stem convolution alignq_conv_stem_nhwc_fwd implements: 3 -> 16 channels, 3x3 / stride 1 / padding 1, width 32,
+    channels-last fp32 input that needs no gradient, <= 8-bit quantised filter."""
+    if bias is not None or groups != 1 or not (1 <= w_bit <= 8) or x.requires_grad:
+        return False
+    if tuple(stride) != (1, 1) or tuple(padding) != (1, 1) or tuple(dilation) != (1, 1):
+        return False
+    if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and w.dtype == torch.float32):
+        return False
+    B, C, H, W = x.shape
+    cl = torch.channels_last
+    return (C == 3 and tuple(w.shape) == (16, 3, 3, 3) and W == 32 and H % 4 == 0 and x.is_contiguous(memory_format=cl)
+            and not x.is_contiguous() and w.is_contiguous(memory_format=cl))
+
+
+class QConvStemFn(torch.autograd.Function):
+    """The stem convolution (model/resnet.py: conv0 = Conv2d_Q(3, 16, 3, 1, 1)) on alignq_conv_stem_nhwc_fwd / _wgrad."""
+
+    @staticmethod
+    def forward(ctx, x, w, w_bit):
+        B, _, H, W = x.shape
+        lib = L.load()
+        y = torch.empty((B, 16, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        n_parts = lib.alignq_conv_stem_bn_parts(B, H, W)
+        part = torch.empty(16, n_parts, 2, dtype=torch.float32, device=x.device)
+        L.check(lib.alignq_conv_stem_nhwc_fwd(L.ptr(x), L.ptr(w), L.ptr(y), B, H, W, int(w_bit), L.ptr(part), L.stream_ptr()),
+                "alignq_conv_stem_nhwc_fwd")
+        ctx.save_for_backward(x, w)
+        QConv3x3Fn._mailbox = (part, n_parts, True)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        lazy = fused.take_lazy_dz(gy)
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        bz, bab, bsave, bk = (lazy[1], lazy[2], lazy[3], lazy[4]) if lazy is not None else (None, None, None, None)
+        B, _, H, W = x.shape
+        lib = L.load()
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            ws = _ws(256 * 16 * 27 * 4, x.device)
+            pending = fused.active_wgrads()
+            if pending is not None:
+                ns = ctypes.c_int(0)
+                L.check(lib.alignq_conv_stem_nhwc_wgrad(L.ptr(x), L.ptr(gy), None, L.ptr(ws), B, H, W, ctypes.byref(ns),
+                                                        L.ptr(bz), L.ptr(bab), L.ptr(bsave), L.ptr(bk), L.stream_ptr()),
+                        "alignq_conv_stem_nhwc_wgrad")
+                pending.add(ws, dw, ns.value, 16 * 27)
+            else:
+                L.check(lib.alignq_conv_stem_nhwc_wgrad(L.ptr(x), L.ptr(gy), L.ptr(dw), L.ptr(ws), B, H, W, None, L.ptr(bz),
+                                                        L.ptr(bab), L.ptr(bsave), L.ptr(bk), L.stream_ptr()),
+                        "alignq_conv_stem_nhwc_wgrad")
+        return None, dw, None
+
+    @staticmethod
+    def apply_with_stats(x, w, w_bit):
+        QConv3x3Fn._mailbox = None
+        y = QConvStemFn.apply(x, w, w_bit)
+        if QConv3x3Fn._mailbox is not None:
+            y._alignq_bn_part = QConv3x3Fn._mailbox
+            QConv3x3Fn._mailbox = None
+        return y

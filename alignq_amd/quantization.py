@@ -165,6 +165,10 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
                         input, weight_q, self.stride, self.padding, self.dilation, self.groups, self.bias,
                         self.quantize_fn.w_bit):
                     return ops.QConvGenFn.apply_with_stats(input, weight_q, self.quantize_fn.w_bit, self.padding[0])
+                if getattr(self, "use_qconv", False) and ops.qconv_stem_supported(
+                        input, weight_q, self.stride, self.padding, self.dilation, self.groups, self.bias,
+                        self.quantize_fn.w_bit):
+                    return ops.QConvStemFn.apply_with_stats(input, weight_q, self.quantize_fn.w_bit)
                 return F.conv2d(input, weight_q, self.bias, self.stride, self.padding, self.dilation, self.groups)
 
             def forward_with_shortcut(self, input):

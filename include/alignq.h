@@ -205,6 +205,16 @@ int alignq_conv_gen_nhwc_dgrad(const float* dy, const float* wt, float* dx, int 
                                int stride, int w_bit, const float* bn_z, const float* bn_ab, const float* bn_save,
                                const float* bn_ktot, void* stream);
 
+/* The stem (3 -> 16 channels, 3x3, stride 1, padding 1, width 32; x [B,H,32,3], wt [16,3,3,3], y [B,H,32,16], channels-last):
+ * forward with the optional batch-norm partials, and its filter gradient (ws: 256 * 432 floats); K = 27 is one MFMA k step
+ * over an im2col image of the tile.                                                                                      */
+int alignq_conv_stem_bn_parts(int B, int H, int W);
+int alignq_conv_stem_nhwc_fwd(const float* x, const float* wt, float* y, int B, int H, int W, int w_bit, float* bn_part,
+                              void* stream);
+int alignq_conv_stem_nhwc_wgrad(const float* x, const float* dy, float* dw, void* ws, int B, int H, int W, int* n_slabs_out,
+                                const float* bn_z, const float* bn_ab, const float* bn_save, const float* bn_ktot,
+                                void* stream);
+
 /* Filter gradient of the same convolution, dW [C,3,3,C] (channels-last weight storage) from x and dy: plain fp32 on the f32
  * MFMAs (products and accumulation bit-for-bit an fmaf chain), per-pixel-range partial sums in ws
  * (alignq_conv3x3_wgrad_ws_bytes(C)) reduced in fixed order by a second launch: deterministic, no zero-fill, no atomics.  */

@@ -954,3 +954,28 @@ def test_qconv_transition_forward_matches_fp64(dev, B, CIN, COUT, H, ks, k):
     torch.nn.functional.conv2d(xr, wr, stride=2, padding=pad).backward(gy)
     np.testing.assert_allclose(npy(x.grad), npy(xr.grad), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(npy(wq.grad), npy(wr.grad), rtol=1e-3, atol=1e-3 * float(wr.grad.abs().max()))
+
+
+@pytest.mark.parametrize("B,H,k", [(128, 32, 8), (6, 32, 4), (3, 8, 8)])
+def test_qconv_stem_matches_fp64(dev, B, H, k):
+    """alignq_conv_stem_nhwc_fwd / _wgrad (3 -> 16 channels) against fp64 / MIOpen, incl. the batch-norm partials."""
+    from alignq_amd import ops
+    torch.manual_seed(B + k)
+    n = 2 ** k - 1
+    cl = torch.channels_last
+    x = torch.randn(B, 3, H, 32, device=dev).contiguous(memory_format=cl)
+    wq = (torch.round(torch.tanh(torch.randn(16, 3, 3, 3)) * n) / n).to(dev).contiguous(memory_format=cl).requires_grad_(True)
+    assert ops.qconv_stem_supported(x, wq, (1, 1), (1, 1), (1, 1), 1, None, k)
+    y = ops.QConvStemFn.apply_with_stats(x, wq, k)
+    yd = torch.nn.functional.conv2d(x.double(), wq.detach().double(), padding=1)
+    y32 = torch.nn.functional.conv2d(x, wq.detach(), padding=1)
+    floor = 2e-6 * float(yd.abs().max())
+    assert float((y.detach() - yd).abs().max()) <= max(float((y32 - yd).abs().max()), floor)
+    part, n_parts, _ = y._alignq_bn_part
+    np.testing.assert_allclose(npy(part[:, :, 0].double().sum(1)), npy(yd.sum((0, 2, 3))), rtol=1e-5, atol=1e-2)
+    np.testing.assert_allclose(npy(part[:, :, 1].double().sum(1)), npy((yd * yd).sum((0, 2, 3))), rtol=1e-5)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    wd = wq.detach().double().requires_grad_(True)
+    torch.nn.functional.conv2d(x.double(), wd, padding=1).backward(gy.double())
+    np.testing.assert_allclose(npy(wq.grad), wd.grad.float().cpu().numpy(), rtol=2e-4, atol=1e-4 * float(wd.grad.abs().max()))
