@@ -419,3 +419,54 @@ def bn_site(bn, act, z, eps=0.0, relu=False, residual=None):
             deferred.add(loss)
         return y, 0.0
     return y, loss
+
+
+# ------------------------------------------------------------------------------------------------------------------
+class HeadCEFn(torch.autograd.Function):
+    """logits = logit(avgpool(feat).flatten(1)); ce = cross_entropy(logits, target) (mean) as one forward and one backward
+    launch (alignq_head_ce_fwd / _bwd) for channels-last features.  Returns (logits, ce); only ce is differentiable."""
+
+    @staticmethod
+    def forward(ctx, feat, weight, bias, target):
+        feat = L.dense_f32(feat, "features")
+        if feat.dim() != 4 or feat.is_contiguous():
+            raise RuntimeError("HeadCEFn needs channels-last 4-D features")
+        B, C, H, W = feat.shape
+        K = weight.shape[0]
+        lib = L.load()
+        dev = feat.device
+        pooled = torch.empty(B, C, dtype=torch.float32, device=dev)
+        logits = torch.empty(B, K, dtype=torch.float32, device=dev)
+        probs = torch.empty(B, K, dtype=torch.float32, device=dev)
+        loss = torch.empty(B, dtype=torch.float32, device=dev)
+        w = L.dev_f32(weight, "head weight")
+        L.check(lib.alignq_head_ce_fwd(L.ptr(feat), L.ptr(w), L.ptr(bias), L.ptr(target), B, H * W, C, K, L.ptr(pooled),
+                                       L.ptr(logits), L.ptr(probs), L.ptr(loss), L.stream_ptr()), "alignq_head_ce_fwd")
+        ctx.save_for_backward(feat, w, target, pooled, probs)
+        ctx.has_bias = bias is not None
+        ctx.mark_non_differentiable(logits)
+        ctx.set_materialize_grads(False)
+        return logits, loss.mean()
+
+    @staticmethod
+    def backward(ctx, _g_logits, g_ce):
+        feat, w, target, pooled, probs = ctx.saved_tensors
+        B, C, H, W = feat.shape
+        K = w.shape[0]
+        dev = feat.device
+        if g_ce is None:
+            g_ce = torch.zeros((), dtype=torch.float32, device=dev)
+        g_ce = L.dev_f32(g_ce, "loss grad")
+        dfeat = torch.empty_like(feat)
+        dW = torch.empty_like(w)
+        db = torch.empty(K, dtype=torch.float32, device=dev) if ctx.has_bias else None
+        L.check(L.load().alignq_head_ce_bwd(L.ptr(g_ce), L.ptr(probs), L.ptr(target), L.ptr(pooled), L.ptr(w), B, H * W, C, K,
+                                            L.ptr(dfeat), L.ptr(dW), L.ptr(db), L.stream_ptr()), "alignq_head_ce_bwd")
+        return dfeat, dW, db, None
+
+
+def head_ce_supported(feat, weight, target) -> bool:
+    return (feat.is_cuda and feat.dim() == 4 and feat.dtype == torch.float32 and not feat.is_contiguous()
+            and feat.is_contiguous(memory_format=torch.channels_last) and feat.shape[1] <= 256 and weight.shape[0] <= 64
+            and weight.shape[1] == feat.shape[1] and target.dtype == torch.int64 and target.dim() == 1)
+

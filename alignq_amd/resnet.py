@@ -125,6 +125,8 @@ class PreActResNet(nn.Module):
                 trans_loss += loss
             else:
                 out = layer(out)
+        if getattr(self, "_features_only", False):     # TrainStep's fused head takes over from here (pool, logit, loss)
+            return out, (trans_loss if self.tree == "admm" else None)
         out = self.avgpool(out)
         out = out.view(out.size(0), -1)
         out = self.logit(out)

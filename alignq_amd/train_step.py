@@ -13,7 +13,7 @@ import torch
 import torch.nn.functional as F
 
 from . import config
-from .fused import DeferredLosses, DeferredWgrads, prequantize_weights
+from .fused import DeferredLosses, DeferredWgrads, HeadCEFn, head_ce_supported, prequantize_weights
 from .optimizer import ADMM_OPT, SGD
 
 
@@ -71,18 +71,30 @@ class TrainStep:
         if self.channels_last and x.dim() == 4:
             x = x.contiguous(memory_format=torch.channels_last)      # no-op for the captured static input
         prequantize_weights(self.all_convs)     # all conv weights in two launches
-        if self._deferred is not None and self.admms:
-            with self._deferred as d:
-                out = model(x)
-                logits = out[0] if isinstance(out, tuple) else out
-                trans_loss = d.total()          # joins the side stream, one stacked sum
-        else:
-            out = model(x)
-            if isinstance(out, tuple):
-                logits, trans_loss = out
+        fused_head = self.channels_last and hasattr(model, "logit") and hasattr(model, "avgpool")
+        model._features_only = fused_head
+        try:
+            if self._deferred is not None and self.admms:
+                with self._deferred as d:
+                    out = model(x)
+                    logits = out[0] if isinstance(out, tuple) else out
+                    trans_loss = d.total()          # joins the side stream, one stacked sum
             else:
-                logits, trans_loss = out, None
-        ce = F.cross_entropy(logits, y)
+                out = model(x)
+                if isinstance(out, tuple):
+                    logits, trans_loss = out
+                else:
+                    logits, trans_loss = out, None
+        finally:
+            model._features_only = False
+        if fused_head and head_ce_supported(logits, model.logit.weight, y):
+            # `logits` still holds the pre-pool features: pool + linear + cross-entropy in one launch each way
+            logits, ce = HeadCEFn.apply(logits, model.logit.weight, model.logit.bias, y)
+        else:
+            if fused_head:       # unsupported shape: finish the head the plain way
+                feats = logits
+                logits = model.logit(model.avgpool(feats).view(feats.size(0), -1))
+            ce = F.cross_entropy(logits, y)
         total = ce if trans_loss is None else ce + trans_loss
         if self._wgrads is not None and set_to_none:
             with self._wgrads as wg:          # all filter-gradient slab reductions in one launch after the backward

@@ -242,6 +242,15 @@ int alignq_conv3x3_nhwc_bwd(const float* x, const float* dy, const float* wt, fl
  * bn_save and bn_ktot = {k0[C], k1[C]} (alignq_bn_bwd_totals), which replaces the elementwise pass of alignq_bn_bwd_apply. */
 int alignq_bn_bwd_totals(const float* dx_part, int B, int C, int HW, float* ktot, float* dgamma, float* dbeta, void* stream);
 
+/* ---- classifier head of the training harness fused with its loss (channels-last features feat [B,HW,C]):
+ * pooled = mean over HW; logits = pooled W^T + bias (W [K,C]); loss[b] = cross-entropy(logits[b], target[b]) per sample (the
+ * caller averages); probs = softmax(logits) kept for the backward.  Backward for the MEAN of loss with upstream scalar *g:
+ * dfeat, dW, dbias (dbias may be NULL).  C <= 256, K <= 64.  Reference: model/resnet.py:127-129 + main.py's criterion.   */
+int alignq_head_ce_fwd(const float* feat, const float* W, const float* bias, const int64_t* target, int B, int HW, int C, int K,
+                       float* pooled, float* logits, float* probs, float* loss, void* stream);
+int alignq_head_ce_bwd(const float* g, const float* probs, const int64_t* target, const float* pooled, const float* W, int B,
+                       int HW, int C, int K, float* dfeat, float* dW, float* dbias, void* stream);
+
 /* ---- data-parallel flat bucket (ONE mean all-reduce per step over gradients + stacked D matrices):
  * gather T dense device tensors (HOST array of pointers, element counts n[T]) into `flat` back to back (unpack = 0) or
  * scatter them back (unpack = 1); one launch per 48 tensors instead of one copy kernel per tensor.                      */

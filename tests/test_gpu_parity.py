@@ -979,3 +979,28 @@ def test_qconv_stem_matches_fp64(dev, B, H, k):
     wd = wq.detach().double().requires_grad_(True)
     torch.nn.functional.conv2d(x.double(), wd, padding=1).backward(gy.double())
     np.testing.assert_allclose(npy(wq.grad), wd.grad.float().cpu().numpy(), rtol=2e-4, atol=1e-4 * float(wd.grad.abs().max()))
+
+
+def test_fused_head_matches_torch(dev):
+    """fused.HeadCEFn (avgpool + linear + mean cross-entropy, one launch each way) against the PyTorch composition."""
+    from alignq_amd.fused import HeadCEFn, head_ce_supported
+    torch.manual_seed(0)
+    B, C, H, K = 128, 64, 8, 10
+    feat0 = torch.randn(B, C, H, H, device=dev).contiguous(memory_format=torch.channels_last)
+    lin = torch.nn.Linear(C, K).to(dev)
+    y = torch.randint(0, K, (B,), device=dev)
+    f1 = feat0.clone(memory_format=torch.channels_last).requires_grad_(True)
+    assert head_ce_supported(f1, lin.weight, y)
+    logits, ce = HeadCEFn.apply(f1, lin.weight, lin.bias, y)
+    (ce * 1.7).backward()
+    got = (npy(logits), float(ce.detach()), npy(f1.grad), npy(lin.weight.grad), npy(lin.bias.grad))
+    lin.zero_grad()
+    f2 = feat0.clone(memory_format=torch.channels_last).requires_grad_(True)
+    lg = lin(torch.nn.functional.adaptive_avg_pool2d(f2, 1).view(B, -1))
+    ce2 = torch.nn.functional.cross_entropy(lg, y)
+    (ce2 * 1.7).backward()
+    np.testing.assert_allclose(got[0], npy(lg), atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(got[1], float(ce2.detach()), rtol=1e-6)
+    np.testing.assert_allclose(got[2], npy(f2.grad), atol=1e-9, rtol=1e-4)
+    np.testing.assert_allclose(got[3], npy(lin.weight.grad), atol=1e-7, rtol=1e-4)
+    np.testing.assert_allclose(got[4], npy(lin.bias.grad), atol=1e-7, rtol=1e-4)
