@@ -1004,3 +1004,82 @@ def test_fused_head_matches_torch(dev):
     np.testing.assert_allclose(got[2], npy(f2.grad), atol=1e-9, rtol=1e-4)
     np.testing.assert_allclose(got[3], npy(lin.weight.grad), atol=1e-7, rtol=1e-4)
     np.testing.assert_allclose(got[4], npy(lin.bias.grad), atol=1e-7, rtol=1e-4)
+
+
+def test_eval_forward_fast_layout_matches_plain(dev):
+    """The reference's test() pass (main.py: model.eval(), forward under no_grad, eval batch != train batch): batch-norm
+    uses its running statistics, so nothing is folded, and the ADMM sites slice alterD/gamma to the evaluation batch.  The
+    channels-last network on this repository's convolutions must give the logits of the plain NCHW / MIOpen network."""
+    from alignq_amd import config
+    from alignq_amd.resnet import PreActBlock_conv_Q, PreActResNet
+    from alignq_amd.train_step import TrainStep
+    config.args.bitW = config.args.abitW = 8
+    config.args.train_batch_size = 128
+    torch.manual_seed(5)
+    net = PreActResNet(PreActBlock_conv_Q, [1, 1, 1], 8, 8, "second", 10).to(dev).train()
+    x = torch.randn(128, 3, 32, 32, device=dev)
+    y = torch.randint(0, 10, (128,), device=dev)
+    step = TrainStep(net, channels_last=True, qconv=True)       # marks the convolutions for the own kernels
+    for _ in range(3):
+        step(x, y)                                              # running statistics away from their initial values
+    net.eval()
+    xe = torch.randn(100, 3, 32, 32, device=dev)                # evaluation batch of the reference's CIFAR runs
+    with torch.no_grad():
+        fast, tl_fast = net(xe.contiguous(memory_format=torch.channels_last))
+        convs = [m for m in net.modules() if hasattr(m, "use_qconv")]
+        assert convs and all(m.use_qconv for m in convs)
+        for m in convs:
+            m.use_qconv = False
+        fuse = net.fuse_bn
+        try:
+            plain, tl_plain = net(xe)
+        finally:
+            for m in convs:
+                m.use_qconv = True
+            net.fuse_bn = fuse
+    assert fast.shape == plain.shape == (100, 10)
+    a, b = npy(fast).ravel(), npy(plain).ravel()
+    assert np.isfinite(a).all() and np.isfinite(b).all()
+    cos = float(np.dot(a, b) / (np.linalg.norm(a) * np.linalg.norm(b)))
+    assert cos > 0.9995, cos                                    # rounding + rare tie-zone bin flips only
+    assert np.median(np.abs(a - b)) < 2e-3 * max(1.0, float(np.abs(b).max()))
+    np.testing.assert_allclose(float(tl_fast), float(tl_plain), rtol=2e-3)
+    net.train()
+
+
+def test_short_last_batch_runs_through_the_fast_path(dev):
+    """CIFAR's 50000 images leave a last batch of 80 at batch 128: ADMM(dim=128) slices its state to [80,80]
+    (utils/admm.py:21-27) and ADMM_OPT zero-pads D back to dim (utils/optimizer.py:95-103).  One eager iteration of the fast
+    path (fold, channels-last, own convolutions) at B=80 against the plain path on the same weights."""
+    import copy
+    from alignq_amd import config
+    from alignq_amd.resnet import PreActBlock_conv_Q, PreActResNet
+    from alignq_amd.train_step import TrainStep
+    config.args.bitW = config.args.abitW = 8
+    config.args.train_batch_size = 128
+    torch.manual_seed(9)
+    base = PreActResNet(PreActBlock_conv_Q, [1, 1, 1], 8, 8, "second", 10).to(dev).train()
+    x = torch.randn(80, 3, 32, 32, device=dev)
+    y = torch.randint(0, 10, (80,), device=dev)
+    outs = []
+    for fast in (False, True):
+        net = copy.deepcopy(base)
+        step = (TrainStep(net, channels_last=True, qconv=True) if fast else
+                TrainStep(net, channels_last=False, fuse_bn=False, defer_losses=False))
+        logits, ce, tl = step(x, y)
+        torch.cuda.synchronize()
+        assert logits.shape == (80, 10)
+        outs.append((float(ce.detach()), float(tl.detach()), {n: p.detach().clone() for n, p in net.named_parameters()}))
+    (ce_a, tl_a, w_a), (ce_b, tl_b, w_b) = outs
+    np.testing.assert_allclose(ce_b, ce_a, rtol=2e-3)
+    np.testing.assert_allclose(tl_b, tl_a, rtol=2e-3)
+    for n in w_a:
+        a, b = w_a[n].float().flatten(), w_b[n].float().flatten()
+        assert torch.isfinite(b).all(), n
+        if "alterD" in n or "gamma" in n:
+            # rows/columns beyond the batch see a zero-padded D: identical update on both paths
+            np.testing.assert_allclose(npy(b), npy(a), atol=2e-4, err_msg=n)
+        elif a.numel() >= 64:
+            # batch-norm biases start at 0, so after one step they ARE -lr * gradient: same bound as the gradient guard above
+            cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
+            assert cos > 0.999, (n, cos)
