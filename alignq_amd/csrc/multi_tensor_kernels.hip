@@ -4,7 +4,9 @@
 // (what the reference does in eager PyTorch, ~20 kernels per tensor) are pure launch latency.  Here the
 // per-tensor pointer tables travel BY VALUE in the kernel arguments (<= kChunk tensors per launch, 4 KB
 // argument limit), so there are no device-side tables to keep in sync and every launch is hipGraph-capturable;
-// blockIdx.y selects the tensor, blockIdx.x strides over its elements.
+// blockIdx.y selects the tensor, blockIdx.x strides over its elements.  Every element loop issues kU independent (clamped,
+// unconditional) loads per thread before the first use: with one load per iteration a 36864-element filter cost eight
+// dependent memory round trips per thread (mt_sgd_kernel: 12.5 us), a 2.4 M-element ResNet-50 filter 144 of them.
 #include <hip/hip_runtime.h>
 
 #include "../../include/alignq.h"
@@ -15,8 +17,18 @@ using namespace alignq;
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kChunk = 48;      // tensors per launch: 48 * (5 pointers + 1 size) * 8 B = 2304 B of arguments
-constexpr int kMaxBlk = 64;     // blocks per tensor (partials per tensor in the workspace)
+constexpr int kChunk = 64;      // weight tensors per launch: 64 * (5 pointers + 1 size) * 8 B = 3072 B of arguments
+constexpr int kSgdChunk = 72;   // parameters per SGD launch: 72 * (48 + 1) B = 3528 B (ResNet-20's 65 in one launch)
+constexpr int kCopyChunk = 128; // tensors per bucket pack / unpack launch: 128 * 24 B = 3072 B
+constexpr int kMaxBlk = 256;    // blocks per tensor (partials per tensor in the workspace; <= kThreads)
+constexpr int kU = 8;           // loads in flight per thread and pass (= elements per thread at 2048 elements per block)
+
+// element index of pass slot u, clamped for the (unconditional) load; `ok` tells whether the slot is real
+#define MT_FOR_ELEMENTS(n)                                                                   \
+  const long stride__ = (long)gridDim.x * kThreads;                                          \
+  for (long i0 = (long)blockIdx.x * kThreads + threadIdx.x; i0 < (n); i0 += stride__ * kU)
+#define MT_IDX(u) (i0 + (long)(u) * stride__)
+#define MT_CLAMP(i, n) ((i) < (n) ? (i) : (n) - 1)
 
 struct WChunk {
   const float* w[kChunk];
@@ -33,10 +45,18 @@ __global__ __launch_bounds__(kThreads) void mt_weight_partial_kernel(WChunk c, d
   const float* __restrict__ w = c.w[t];
   const long n = c.n[t];
   double s = 0, s2 = 0;
-  for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
-    double v = w[i];
-    s += v;
-    s2 += v * v;
+  MT_FOR_ELEMENTS(n) {
+    float v[kU];
+#pragma unroll
+    for (int u = 0; u < kU; u++) v[u] = w[MT_CLAMP(MT_IDX(u), n)];
+#pragma unroll
+    for (int u = 0; u < kU; u++) {
+      if (MT_IDX(u) < n) {
+        const double d = v[u];
+        s += d;
+        s2 += d * d;
+      }
+    }
   }
   block_sum2d(s, s2, sm);
   if (threadIdx.x == 0) {
@@ -70,11 +90,20 @@ __global__ __launch_bounds__(kThreads) void mt_weight_apply_kernel(WChunk c, con
   float* __restrict__ q = c.q[t];
   float* __restrict__ cdf = c.cdf[t];
   float* __restrict__ pdf = c.pdf[t];
-  for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
-    float v = w[i], tt, b;
-    q[i] = weight_quant1<FORMULA>(v, wc, k, &tt, &b);
-    if (cdf) cdf[i] = tt;
-    if (pdf) pdf[i] = weight_pdf2(v, wc);
+  MT_FOR_ELEMENTS(n) {
+    float v[kU];
+#pragma unroll
+    for (int u = 0; u < kU; u++) v[u] = w[MT_CLAMP(MT_IDX(u), n)];
+#pragma unroll
+    for (int u = 0; u < kU; u++) {
+      const long i = MT_IDX(u);
+      if (i < n) {
+        float tt, b;
+        q[i] = weight_quant1<FORMULA>(v[u], wc, k, &tt, &b);
+        if (cdf) cdf[i] = tt;
+        if (pdf) pdf[i] = weight_pdf2(v[u], wc);
+      }
+    }
   }
 }
 
@@ -87,12 +116,24 @@ __global__ __launch_bounds__(kThreads) void mt_weight_bwd_partial_kernel(WChunk 
   const long n = c.n[t];
   const float m = ms[2 * (t0 + t)], s = ms[2 * (t0 + t) + 1], rs = 1.0f / s, cs = ALIGNQ_TWO_OVER_SQRT_2PI * rs;
   double s1 = 0, s2 = 0;
-  for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
-    float P, z;
-    weight_PZ(w[i], m, rs, cs, &P, &z);
-    double gp = (double)g[i] * (double)P;
-    s1 += gp;
-    s2 += gp * (double)z;
+  MT_FOR_ELEMENTS(n) {
+    float wv[kU], gv[kU];
+#pragma unroll
+    for (int u = 0; u < kU; u++) {
+      const long i = MT_CLAMP(MT_IDX(u), n);
+      wv[u] = w[i];
+      gv[u] = g[i];
+    }
+#pragma unroll
+    for (int u = 0; u < kU; u++) {
+      if (MT_IDX(u) < n) {
+        float P, z;
+        weight_PZ(wv[u], m, rs, cs, &P, &z);
+        const double gp = (double)gv[u] * (double)P;
+        s1 += gp;
+        s2 += gp * (double)z;
+      }
+    }
   }
   block_sum2d(s1, s2, sm);
   if (threadIdx.x == 0) {
@@ -120,22 +161,35 @@ __global__ __launch_bounds__(kThreads) void mt_weight_bwd_apply_kernel(WChunk c,
   const float* __restrict__ w = c.w[t];
   const float* __restrict__ g = c.g[t];
   float* __restrict__ dw = c.q[t];
-  for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
-    float P, z;
-    weight_PZ(w[i], m, rs, cs, &P, &z);
-    dw[i] = g[i] * P - mean_gp - z * dotn;
+  MT_FOR_ELEMENTS(n) {
+    float wv[kU], gv[kU];
+#pragma unroll
+    for (int u = 0; u < kU; u++) {
+      const long i = MT_CLAMP(MT_IDX(u), n);
+      wv[u] = w[i];
+      gv[u] = g[i];
+    }
+#pragma unroll
+    for (int u = 0; u < kU; u++) {
+      const long i = MT_IDX(u);
+      if (i < n) {
+        float P, z;
+        weight_PZ(wv[u], m, rs, cs, &P, &z);
+        dw[i] = gv[u] * P - mean_gp - z * dotn;
+      }
+    }
   }
 }
 
 // ------------------------------------------------------------------------------------------ SGD
 struct SChunk {
-  float* p[kChunk];
-  float* g[kChunk];
-  float* buf[kChunk];
-  const float* cdf[kChunk];   // non-NULL => tensor is in `idx`: p.grad <- dir * sigmoid_d(transform(cdf)) * pdf
-  const float* pdf[kChunk];
-  long n[kChunk];
-  unsigned long long first_mask;   // bit t set => momentum buffer is being created this step
+  float* p[kSgdChunk];
+  float* g[kSgdChunk];
+  float* buf[kSgdChunk];
+  const float* cdf[kSgdChunk];   // non-NULL => tensor is in `idx`: p.grad <- dir * sigmoid_d(transform(cdf)) * pdf
+  const float* pdf[kSgdChunk];
+  long n[kSgdChunk];
+  unsigned char first[kSgdChunk];   // 1 => momentum buffer is being created this step
 };
 
 __global__ __launch_bounds__(kThreads) void mt_sgd_kernel(SChunk c, float lr, float mom, float damp, float wd,
@@ -147,27 +201,43 @@ __global__ __launch_bounds__(kThreads) void mt_sgd_kernel(SChunk c, float lr, fl
   const float* __restrict__ cdf = c.cdf[t];
   const float* __restrict__ pdf = c.pdf[t];
   const long n = c.n[t];
-  const bool first = (c.first_mask >> t) & 1ull;
-  for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
-    float pv = p[i];
-    float d = g[i];
-    if (wd != 0.0f) d = __fmaf_rn(wd, pv, d);
-    float dir = d;
-    if (mom != 0.0f) {
-      float bv = first ? d : __fmaf_rn(1.0f - damp, d, buf[i] * mom);
-      buf[i] = bv;
-      dir = nesterov ? __fmaf_rn(mom, bv, d) : bv;
+  const bool first = c.first[t] != 0;
+  const bool use_buf = mom != 0.0f && !first;
+  MT_FOR_ELEMENTS(n) {
+    float pv[kU], gv[kU], bv[kU], cv[kU], fv[kU];
+#pragma unroll
+    for (int u = 0; u < kU; u++) {
+      const long i = MT_CLAMP(MT_IDX(u), n);
+      pv[u] = p[i];
+      gv[u] = g[i];
+      bv[u] = use_buf ? buf[i] : 0.0f;          // block-uniform conditions: no per-load branches
+      cv[u] = cdf ? cdf[i] : 0.0f;
+      fv[u] = cdf ? pdf[i] : 0.0f;
     }
-    p[i] = __fmaf_rn(-lr, dir, pv);
-    float gout = dir;
-    if (cdf) {
-      float a = (cdf[i] + 0.5f) * nlev;
-      float fr = a - floorf(a);
-      float tr = fr * lam2 * 2.0f;
-      float sg = 1.0f / (1.0f + __expf(-tr));
-      gout = dir * (sg * (1.0f - sg) * lam) * pdf[i];
+#pragma unroll
+    for (int u = 0; u < kU; u++) {
+      const long i = MT_IDX(u);
+      if (i < n) {
+        float d = gv[u];
+        if (wd != 0.0f) d = __fmaf_rn(wd, pv[u], d);
+        float dir = d;
+        if (mom != 0.0f) {
+          const float b = first ? d : __fmaf_rn(1.0f - damp, d, bv[u] * mom);
+          buf[i] = b;
+          dir = nesterov ? __fmaf_rn(mom, b, d) : b;
+        }
+        p[i] = __fmaf_rn(-lr, dir, pv[u]);
+        float gout = dir;
+        if (cdf) {
+          const float a = (cv[u] + 0.5f) * nlev;
+          const float fr = a - floorf(a);
+          const float tr = fr * lam2 * 2.0f;
+          const float sg = 1.0f / (1.0f + __expf(-tr));
+          gout = dir * (sg * (1.0f - sg) * lam) * fv[u];
+        }
+        g[i] = gout;
+      }
     }
-    g[i] = gout;
   }
 }
 
@@ -179,20 +249,28 @@ inline int blocks_for(long max_n) {
 
 // ------------------------------------------------------------------------------------------ flat-bucket pack / unpack
 // Data-parallel bucket (alignq_amd/dp.py): gather T dense tensors into one flat buffer (dir 0) or scatter them back
-// (dir 1) in one launch per 48 tensors.  Storage order is copied as it lies (any dense layout: the all-reduce is
+// (dir 1) in one launch per 128 tensors.  Storage order is copied as it lies (any dense layout: the all-reduce is
 // elementwise, every rank uses the same layouts).
 struct CChunk {
-  float* t[kChunk];
-  long off[kChunk];
-  long n[kChunk];
+  float* t[kCopyChunk];
+  long off[kCopyChunk];
+  long n[kCopyChunk];
 };
 __global__ __launch_bounds__(kThreads) void mt_copy_kernel(CChunk c, float* __restrict__ flat, int dir) {
   const int t = blockIdx.y;
   float* __restrict__ x = c.t[t];
   float* __restrict__ f = flat + c.off[t];
   const long n = c.n[t];
-  for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
-    if (dir == 0) f[i] = x[i]; else x[i] = f[i];
+  const float* __restrict__ src = dir == 0 ? x : f;
+  float* __restrict__ dst = dir == 0 ? f : x;
+  MT_FOR_ELEMENTS(n) {
+    float v[kU];
+#pragma unroll
+    for (int u = 0; u < kU; u++) v[u] = src[MT_CLAMP(MT_IDX(u), n)];
+#pragma unroll
+    for (int u = 0; u < kU; u++) {
+      if (MT_IDX(u) < n) dst[MT_IDX(u)] = v[u];
+    }
   }
 }
 
@@ -271,10 +349,9 @@ int alignq_sgd_step_multi(int T, float* const* p, float* const* g, float* const*
   if (bitW < 1 || bitW > 30) bitW = 1;
   const float nlev = (float)((1 << bitW) - 1);
   hipStream_t st = (hipStream_t)stream;
-  for (int t0 = 0; t0 < T; t0 += kChunk) {
-    const int cnt = (T - t0 < kChunk) ? T - t0 : kChunk;
+  for (int t0 = 0; t0 < T; t0 += kSgdChunk) {
+    const int cnt = (T - t0 < kSgdChunk) ? T - t0 : kSgdChunk;
     SChunk c;
-    c.first_mask = 0;
     long max_n = 0;
     for (int i = 0; i < cnt; i++) {
       if (!p[t0 + i] || !g[t0 + i] || n[t0 + i] <= 0) return ALIGNQ_EINVAL;
@@ -283,7 +360,7 @@ int alignq_sgd_step_multi(int T, float* const* p, float* const* g, float* const*
       c.cdf[i] = (w_cdf && w_pdf && w_cdf[t0 + i] && w_pdf[t0 + i]) ? w_cdf[t0 + i] : nullptr;
       c.pdf[i] = c.cdf[i] ? w_pdf[t0 + i] : nullptr;
       c.n[i] = (long)n[t0 + i];
-      if (first && first[t0 + i]) c.first_mask |= (1ull << i);
+      c.first[i] = (first && first[t0 + i]) ? 1 : 0;
       if (c.n[i] > max_n) max_n = c.n[i];
     }
     dim3 grid(blocks_for(max_n), cnt);
@@ -297,8 +374,8 @@ int alignq_bucket_copy_multi(int T, float* const* tensors, const int64_t* n, flo
   if (T <= 0 || !tensors || !n || !flat) return ALIGNQ_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   long off = 0;
-  for (int t0 = 0; t0 < T; t0 += kChunk) {
-    const int cnt = (T - t0 < kChunk) ? T - t0 : kChunk;
+  for (int t0 = 0; t0 < T; t0 += kCopyChunk) {
+    const int cnt = (T - t0 < kCopyChunk) ? T - t0 : kCopyChunk;
     CChunk c;
     long max_n = 0;
     for (int i = 0; i < cnt; i++) {

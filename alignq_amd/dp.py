@@ -32,7 +32,7 @@ class FlatBucket:
         return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
 
     def _native(self, tensors, unpack):
-        """One HIP launch per 48 tensors (alignq_bucket_copy_multi): dense CUDA fp32 tensors are copied in storage order."""
+        """One HIP launch per 128 tensors (alignq_bucket_copy_multi): dense CUDA fp32 tensors are copied in storage order."""
         from . import _lib as L
         L.check(L.load().alignq_bucket_copy_multi(len(tensors), L.ptr_array(tensors), L.i64_array(self.numels),
                                                   L.ptr(self.flat), int(unpack), L.stream_ptr()), "alignq_bucket_copy_multi")

@@ -72,7 +72,7 @@ class SGD(Optimizer):
                 ps.append(p); gs.append(g); bufs.append(buf); firsts.append(first); cdfs.append(c); pdfs.append(pdf)
             if not ps:
                 continue
-            # one multi-tensor launch (per <=48 tensors) for the whole group: step + p.grad rewrite for idx members
+            # one multi-tensor launch (per <=72 tensors) for the whole group: step + p.grad rewrite for idx members
             L.check(lib.alignq_sgd_step_multi(len(ps), L.ptr_array(ps), L.ptr_array(gs),
                                               L.ptr_array(bufs) if mom != 0 else None,
                                               L.i64_array([p.numel() for p in ps]), L.ptr_array(cdfs),

@@ -253,7 +253,7 @@ int alignq_head_ce_bwd(const float* g, const float* probs, const int64_t* target
 
 /* ---- data-parallel flat bucket (ONE mean all-reduce per step over gradients + stacked D matrices):
  * gather T dense device tensors (HOST array of pointers, element counts n[T]) into `flat` back to back (unpack = 0) or
- * scatter them back (unpack = 1); one launch per 48 tensors instead of one copy kernel per tensor.                      */
+ * scatter them back (unpack = 1); one launch per 128 tensors instead of one copy kernel per tensor.                      */
 int alignq_bucket_copy_multi(int T, float* const* tensors, const int64_t* n, float* flat, int unpack, void* stream);
 
 /* ---- batch-norm (and the ReLU that follows) folded into the ADMM site (caller:
