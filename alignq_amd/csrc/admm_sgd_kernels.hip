@@ -86,7 +86,42 @@ __global__ __launch_bounds__(kBig) void admm_update_kernel(AChunk c, int b, int 
   float* __restrict__ G = c.G[blockIdx.x];
   const int full = dim * dim;
   const float inv_rho = 1.0f / rho;
+  const float thr = mu / rho;
   double ss = 0, z0 = 0, z1 = 0;
+  constexpr int R = 16;                       // dim <= 128: the whole site lives in registers, ONE memory round trip
+  if (full <= R * kBig) {
+    float dv[R], gv[R];
+#pragma unroll
+    for (int u = 0; u < R; u++) {             // clamped, unconditional loads: all in flight together
+      const int e = threadIdx.x + u * kBig;
+      const int ec = e < full ? e : full - 1;
+      const int i = ec / dim, j = ec - i * dim;
+      const bool in = i < b && j < b;
+      const float d = D[in ? i * b + j : 0];
+      dv[u] = in ? d : 0.0f;
+      gv[u] = G[ec];
+    }
+#pragma unroll
+    for (int u = 0; u < R; u++) {
+      if (threadIdx.x + u * kBig < full) {
+        const float v = dv[u] + inv_rho * gv[u];
+        ss += (double)v * (double)v;
+      }
+    }
+    block_sum3(ss, z0, z1, sm);
+    const float nv = (float)sqrt(ss);
+    const float shrink = (nv > thr) ? (1.0f - thr / nv) : 0.0f;
+#pragma unroll
+    for (int u = 0; u < R; u++) {
+      const int e = threadIdx.x + u * kBig;
+      if (e < full) {
+        const float a = shrink * (dv[u] + inv_rho * gv[u]);
+        A[e] = a;
+        G[e] = gv[u] + rho * (dv[u] - a);
+      }
+    }
+    return;
+  }
   for (int e = threadIdx.x; e < full; e += kBig) {
     int i = e / dim, j = e - i * dim;
     float d = (i < b && j < b) ? D[i * b + j] : 0.0f;
@@ -95,7 +130,6 @@ __global__ __launch_bounds__(kBig) void admm_update_kernel(AChunk c, int b, int 
   }
   block_sum3(ss, z0, z1, sm);
   const float nv = (float)sqrt(ss);
-  const float thr = mu / rho;
   const float shrink = (nv > thr) ? (1.0f - thr / nv) : 0.0f;
   for (int e = threadIdx.x; e < full; e += kBig) {
     int i = e / dim, j = e - i * dim;

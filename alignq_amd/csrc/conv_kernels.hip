@@ -1059,27 +1059,40 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
   }
 }
 
-// the same reduction for up to 32 convolutions in ONE launch (blockIdx.y = tensor): a whole-model step defers all filter-
-// gradient reductions to the end of the backward (nothing reads a filter gradient before the optimizer step)
+// the same reduction for up to 32 convolutions in ONE launch: a whole-model step defers all filter-gradient reductions to the
+// end of the backward (nothing reads a filter gradient before the optimizer step).  One-dimensional grid over the 64-element
+// column blocks of all tensors (blk0 = prefix sums: no empty workgroups), and every thread has its (up to 16) slab rows in
+// flight together; the summation order per element is that of wgrad_reduce_kernel.
 constexpr int kWgMulti = 32;
 struct WgChunk {
   const float* slabs[kWgMulti];
   float* dw[kWgMulti];
   int n_slabs[kWgMulti];
   int n_elem[kWgMulti];
+  int blk0[kWgMulti + 1];
 };
-__global__ __launch_bounds__(1024) void wgrad_reduce_multi_kernel(WgChunk c) {
+__global__ __launch_bounds__(1024) void wgrad_reduce_multi_kernel(WgChunk c, int cnt) {
   __shared__ float part[16][64];
-  const int t = blockIdx.y;
+  int t = 0;
+  while (t + 1 < cnt && (int)blockIdx.x >= c.blk0[t + 1]) t++;          // block-uniform (scalar) search
   const int n_elem = c.n_elem[t], n_slabs = c.n_slabs[t];
-  if ((int)blockIdx.x * 64 >= n_elem) return;            // block-uniform
   const float* __restrict__ slabs = c.slabs[t];
   const int l = threadIdx.x & 63, sg = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + l;
+  const int e = ((int)blockIdx.x - c.blk0[t]) * 64 + l;
+  const int ec = e < n_elem ? e : n_elem - 1;
   float s = 0.f;
-  if (e < n_elem) {
-#pragma unroll 8
-    for (int sl = sg; sl < n_slabs; sl += 16) s += slabs[(int64_t)sl * n_elem + e];
+  constexpr int U = 16;
+  for (int sl0 = sg; sl0 < n_slabs; sl0 += 16 * U) {
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int sl = sl0 + 16 * u;
+      v[u] = slabs[(int64_t)(sl < n_slabs ? sl : n_slabs - 1) * n_elem + ec];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (sl0 + 16 * u < n_slabs) s += v[u];
+    }
   }
   part[sg][l] = s;
   __syncthreads();
@@ -1200,14 +1213,16 @@ int alignq_conv3x3_wgrad_reduce_multi(int T, const void* const* ws, float* const
   for (int t0 = 0; t0 < T; t0 += kWgMulti) {
     const int cnt = (T - t0 < kWgMulti) ? T - t0 : kWgMulti;
     WgChunk c;
-    int max_elem = 0;
+    int blocks = 0;
     for (int i = 0; i < cnt; i++) {
       if (!ws[t0 + i] || !dw[t0 + i] || n_slabs[t0 + i] < 1 || n_elem[t0 + i] < 1) return ALIGNQ_EINVAL;
       c.slabs[i] = (const float*)ws[t0 + i]; c.dw[i] = dw[t0 + i]; c.n_slabs[i] = n_slabs[t0 + i];
       c.n_elem[i] = n_elem[t0 + i];
-      if (c.n_elem[i] > max_elem) max_elem = c.n_elem[i];
+      c.blk0[i] = blocks;
+      blocks += (c.n_elem[i] + 63) / 64;
     }
-    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((max_elem + 63) / 64, cnt), 1024, 0, st, c);
+    for (int i = cnt; i <= kWgMulti; i++) c.blk0[i] = blocks;
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, blocks, 1024, 0, st, c, cnt);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
   }
