@@ -61,6 +61,7 @@ class TrainStep:
         self._graph: Optional[torch.cuda.CUDAGraph] = None
         self._graph2: Optional[torch.cuda.CUDAGraph] = None
         self._static = None
+        self._one = None
 
     # -------------------------------------------------------------------------------------------
     def _forward_backward(self, x, y, set_to_none=True):
@@ -95,13 +96,18 @@ class TrainStep:
                 feats = logits
                 logits = model.logit(model.avgpool(feats).view(feats.size(0), -1))
             ce = F.cross_entropy(logits, y)
-        total = ce if trans_loss is None else ce + trans_loss
+        # d(ce + trans_loss) = 1 * d(ce) + 1 * d(trans_loss): two roots with a persistent unit gradient instead of forming the
+        # sum (one add and one ones_like fill fewer on the in-order chain; main.py:300-304 only needs the gradients of the sum)
+        roots = [ce] if (trans_loss is None or not torch.is_tensor(trans_loss) or not trans_loss.requires_grad) \
+            else [ce, trans_loss]
+        if self._one is None or self._one.device != ce.device:
+            self._one = torch.ones((), dtype=torch.float32, device=ce.device)
         if self._wgrads is not None and set_to_none:
             with self._wgrads as wg:          # all filter-gradient slab reductions in one launch after the backward
-                total.backward()
+                torch.autograd.backward(roots, [self._one] * len(roots))
                 wg.flush()
         else:
-            total.backward()
+            torch.autograd.backward(roots, [self._one] * len(roots))
         return logits, ce, trans_loss
 
     def _optimizer_steps(self):
