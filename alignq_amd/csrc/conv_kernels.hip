@@ -1038,31 +1038,61 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_kernel(const float* __restric
   }
 }
 
-// dW[e] = sum over slabs, fixed order: 1024 threads = 64 elements x 16 slab groups
-__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ slabs, int n_slabs, int n_elem,
-                                                            float* __restrict__ dw) {
-  __shared__ float part[16][64];
-  const int l = threadIdx.x & 63, sg = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + l;
+// dW[e] = sum over slabs in a fixed order.  1024 threads = G slab groups x (1024 / G) elements with G = n_slabs / 16 clipped to
+// [1, 16] (a power of two): every thread owns (up to) 16 slab rows sl = g, g + G, ... and has all of them in flight at once;
+// the G partial sums of an element meet in LDS and are added in group order.  Few slabs (C = 64: 16) therefore mean wide
+// workgroups (1024 elements, 64 KB) instead of sixteen times as many workgroups of one load per thread.
+__host__ __device__ __forceinline__ int wgrad_reduce_groups(int n_slabs) {
+  int g = 1;
+  while (g < 16 && g * 16 < n_slabs) g <<= 1;
+  return g;
+}
+__host__ __device__ __forceinline__ int wgrad_reduce_blocks(int n_slabs, int n_elem) {
+  const int per = 1024 / wgrad_reduce_groups(n_slabs);
+  return (n_elem + per - 1) / per;
+}
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ slabs, int n_slabs, int n_elem,
+                                                  float* __restrict__ dw, int blk, float* __restrict__ part /* [1024] */) {
+  const int G = wgrad_reduce_groups(n_slabs), per = 1024 / G;
+  const int g = threadIdx.x / per, l = threadIdx.x - g * per;
+  const int e = blk * per + l;
+  const int ec = e < n_elem ? e : n_elem - 1;
   float s = 0.f;
-  if (e < n_elem) {
-#pragma unroll 8
-    for (int sl = sg; sl < n_slabs; sl += 16) s += slabs[(int64_t)sl * n_elem + e];
-  }
-  part[sg][l] = s;
-  __syncthreads();
-  if (sg == 0 && e < n_elem) {
-    float t = 0.f;
+  constexpr int U = 16;
+  for (int sl0 = g; sl0 < n_slabs; sl0 += G * U) {
+    float v[U];
 #pragma unroll
-    for (int g = 0; g < 16; g++) t += part[g][l];
+    for (int u = 0; u < U; u++) {
+      const int sl = sl0 + G * u;
+      v[u] = slabs[(int64_t)(sl < n_slabs ? sl : n_slabs - 1) * n_elem + ec];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (sl0 + G * u < n_slabs) s += v[u];
+    }
+  }
+  if (G == 1) {                                    // block-uniform
+    if (e < n_elem) dw[e] = s;
+    return;
+  }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (g == 0 && e < n_elem) {
+    float t = 0.f;
+    for (int q = 0; q < G; q++) t += part[q * per + l];
     dw[e] = t;
   }
 }
 
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ slabs, int n_slabs, int n_elem,
+                                                            float* __restrict__ dw) {
+  __shared__ float part[1024];
+  wgrad_reduce_body(slabs, n_slabs, n_elem, dw, blockIdx.x, part);
+}
+
 // the same reduction for up to 32 convolutions in ONE launch: a whole-model step defers all filter-gradient reductions to the
-// end of the backward (nothing reads a filter gradient before the optimizer step).  One-dimensional grid over the 64-element
-// column blocks of all tensors (blk0 = prefix sums: no empty workgroups), and every thread has its (up to 16) slab rows in
-// flight together; the summation order per element is that of wgrad_reduce_kernel.
+// end of the backward (nothing reads a filter gradient before the optimizer step).  One-dimensional grid over the workgroups
+// of all tensors (blk0 = prefix sums: no empty workgroups).
 constexpr int kWgMulti = 32;
 struct WgChunk {
   const float* slabs[kWgMulti];
@@ -1072,36 +1102,10 @@ struct WgChunk {
   int blk0[kWgMulti + 1];
 };
 __global__ __launch_bounds__(1024) void wgrad_reduce_multi_kernel(WgChunk c, int cnt) {
-  __shared__ float part[16][64];
+  __shared__ float part[1024];
   int t = 0;
   while (t + 1 < cnt && (int)blockIdx.x >= c.blk0[t + 1]) t++;          // block-uniform (scalar) search
-  const int n_elem = c.n_elem[t], n_slabs = c.n_slabs[t];
-  const float* __restrict__ slabs = c.slabs[t];
-  const int l = threadIdx.x & 63, sg = threadIdx.x >> 6;
-  const int e = ((int)blockIdx.x - c.blk0[t]) * 64 + l;
-  const int ec = e < n_elem ? e : n_elem - 1;
-  float s = 0.f;
-  constexpr int U = 16;
-  for (int sl0 = sg; sl0 < n_slabs; sl0 += 16 * U) {
-    float v[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int sl = sl0 + 16 * u;
-      v[u] = slabs[(int64_t)(sl < n_slabs ? sl : n_slabs - 1) * n_elem + ec];
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      if (sl0 + 16 * u < n_slabs) s += v[u];
-    }
-  }
-  part[sg][l] = s;
-  __syncthreads();
-  if (sg == 0 && e < n_elem) {
-    float tt = 0.f;
-#pragma unroll
-    for (int g = 0; g < 16; g++) tt += part[g][l];
-    c.dw[t][e] = tt;
-  }
+  wgrad_reduce_body(c.slabs[t], c.n_slabs[t], c.n_elem[t], c.dw[t], (int)blockIdx.x - c.blk0[t], part);
 }
 
 template <int C, int WD, int PT>
@@ -1117,7 +1121,7 @@ int launch_wgrad(const float* x, const float* dy, float* dw, float* ws, int B, i
   if (e != hipSuccess) return (int)e;
   if (n_slabs_out) { *n_slabs_out = splits; return 0; }      // deferred: the caller reduces (alignq_conv3x3_wgrad_reduce_multi)
   const int n_elem = 9 * C * C;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, (n_elem + 63) / 64, 1024, 0, st, ws, splits, n_elem, dw);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, wgrad_reduce_blocks(splits, n_elem), 1024, 0, st, ws, splits, n_elem, dw);
   e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
@@ -1155,7 +1159,7 @@ int launch_wgradgen(const float* x, const float* dy, float* dw, float* ws, int B
   if (e != hipSuccess) return (int)e;
   if (n_slabs_out) { *n_slabs_out = splits; return 0; }
   const int n_elem = G::NT * CIN * COUT;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, (n_elem + 63) / 64, 1024, 0, st, ws, splits, n_elem, dw);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, wgrad_reduce_blocks(splits, n_elem), 1024, 0, st, ws, splits, n_elem, dw);
   e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
@@ -1219,7 +1223,7 @@ int alignq_conv3x3_wgrad_reduce_multi(int T, const void* const* ws, float* const
       c.slabs[i] = (const float*)ws[t0 + i]; c.dw[i] = dw[t0 + i]; c.n_slabs[i] = n_slabs[t0 + i];
       c.n_elem[i] = n_elem[t0 + i];
       c.blk0[i] = blocks;
-      blocks += (c.n_elem[i] + 63) / 64;
+      blocks += wgrad_reduce_blocks(c.n_slabs[i], c.n_elem[i]);
     }
     for (int i = cnt; i <= kWgMulti; i++) c.blk0[i] = blocks;
     hipLaunchKernelGGL(wgrad_reduce_multi_kernel, blocks, 1024, 0, st, c, cnt);
@@ -1343,7 +1347,7 @@ int alignq_conv_stem_nhwc_wgrad(const float* x, const float* dy, float* dw, void
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   if (n_slabs_out) { *n_slabs_out = splits; return 0; }
-  hipLaunchKernelGGL(wgrad_reduce_kernel, (16 * 27 + 63) / 64, 1024, 0, st, (const float*)ws, splits, 16 * 27, dw);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, wgrad_reduce_blocks(splits, 16 * 27), 1024, 0, st, (const float*)ws, splits, 16 * 27, dw);
   e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
