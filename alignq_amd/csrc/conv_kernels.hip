@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void convgen_fwd_kernel(const float* __restric
 template <int CIN, int COUT, int WDI, int KS, int PT>
 __global__ __launch_bounds__(256) void dgrad_s2_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                        float* __restrict__ dx, int H, int total_rows, float nlev,
-                                                       BnLazy lazy) {
+                                                       const float* __restrict__ add, BnLazy lazy) {
   constexpr int P = KS == 3 ? 1 : 0;
   constexpr int WDO = WDI / 2, TR = PT / WDI;
   constexpr int DROWS = TR / 2 + P, DCOLS = WDO + P;       // dy rows / columns the tile's taps can reach
@@ -528,20 +528,27 @@ __global__ __launch_bounds__(256) void dgrad_s2_kernel(const float* __restrict__
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[s], bh, acc, 0, 0, 0);
     }
     const int grow = row0 + r;
-    if (grow < total_rows)
-      *reinterpret_cast<float4*>(dx + ((int64_t)grow * WDI + c) * CIN + cig * 16 + 4 * q) =
-          make_float4(acc[0] / nlev, acc[1] / nlev, acc[2] / nlev, acc[3] / nlev);
+    if (grow < total_rows) {
+      const int64_t o = ((int64_t)grow * WDI + c) * CIN + cig * 16 + 4 * q;
+      float4 out = make_float4(acc[0] / nlev, acc[1] / nlev, acc[2] / nlev, acc[3] / nlev);
+      if (add) {            // a second gradient w.r.t. the same input (the block's other branch): summed here
+        const float4 a4 = *reinterpret_cast<const float4*>(add + o);
+        out.x += a4.x; out.y += a4.y; out.z += a4.z; out.w += a4.w;
+      }
+      *reinterpret_cast<float4*>(dx + o) = out;
+    }
   }
 }
 
 template <int CIN, int COUT, int WDI, int KS, int PT>
-int launch_dgrad_s2(const float* dy, const float* w, float* dx, int B, int H, float nlev, BnLazy lazy, hipStream_t st) {
+int launch_dgrad_s2(const float* dy, const float* w, float* dx, int B, int H, float nlev, const float* add, BnLazy lazy,
+                    hipStream_t st) {
   constexpr int TR = PT / WDI;
   static_assert(TR % 2 == 0, "even number of input rows per tile");
   if (H % TR) return ALIGNQ_EUNSUPPORTED;
   const int total_rows = B * H;
   hipLaunchKernelGGL((dgrad_s2_kernel<CIN, COUT, WDI, KS, PT>), total_rows / TR, 256, 0, st, dy, w, dx, H, total_rows, nlev,
-                     lazy);
+                     add, lazy);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
@@ -1304,19 +1311,20 @@ int alignq_conv_gen_nhwc_wgrad(const float* x, const float* dy, float* dw, void*
 // Data gradient of the transition convolutions: dx [B,H_in,W_in,CIN] from dy [B,H_in/2,W_in/2,COUT]; bn_* as in
 // alignq_conv3x3_nhwc_bwd (dy given in the lazy batch-norm form when bn_z != NULL).
 int alignq_conv_gen_nhwc_dgrad(const float* dy, const float* wt, float* dx, int B, int H_in, int W_in, int CIN, int COUT, int KS,
-                               int stride, int w_bit, const float* bn_z, const float* bn_ab, const float* bn_save,
-                               const float* bn_ktot, void* stream) {
+                               int stride, int w_bit, const float* add, const float* bn_z, const float* bn_ab,
+                               const float* bn_save, const float* bn_ktot, void* stream) {
   if (!dy || !wt || !dx || B < 1) return ALIGNQ_EINVAL;
+  if (add && (reinterpret_cast<uintptr_t>(add) & 15)) return ALIGNQ_EUNSUPPORTED;
   if (bn_z && (!bn_ab || !bn_save || !bn_ktot)) return ALIGNQ_EINVAL;
   if (w_bit < 1 || w_bit > 8 || !alignq_conv_gen_bn_parts(B, H_in, W_in, CIN, COUT, KS, stride)) return ALIGNQ_EUNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(wt) | reinterpret_cast<uintptr_t>(dx)) & 15) return ALIGNQ_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const float nlev = (float)((1 << w_bit) - 1);
   const BnLazy lazy{bn_z, bn_ab, bn_save, bn_ktot};
-  if (CIN == 16 && KS == 3) return launch_dgrad_s2<16, 32, 32, 3, 128>(dy, wt, dx, B, H_in, nlev, lazy, st);
-  if (CIN == 16 && KS == 1) return launch_dgrad_s2<16, 32, 32, 1, 128>(dy, wt, dx, B, H_in, nlev, lazy, st);
-  if (CIN == 32 && KS == 3) return launch_dgrad_s2<32, 64, 16, 3, 128>(dy, wt, dx, B, H_in, nlev, lazy, st);
-  if (CIN == 32 && KS == 1) return launch_dgrad_s2<32, 64, 16, 1, 128>(dy, wt, dx, B, H_in, nlev, lazy, st);
+  if (CIN == 16 && KS == 3) return launch_dgrad_s2<16, 32, 32, 3, 128>(dy, wt, dx, B, H_in, nlev, add, lazy, st);
+  if (CIN == 16 && KS == 1) return launch_dgrad_s2<16, 32, 32, 1, 128>(dy, wt, dx, B, H_in, nlev, add, lazy, st);
+  if (CIN == 32 && KS == 3) return launch_dgrad_s2<32, 64, 16, 3, 128>(dy, wt, dx, B, H_in, nlev, add, lazy, st);
+  if (CIN == 32 && KS == 1) return launch_dgrad_s2<32, 64, 16, 1, 128>(dy, wt, dx, B, H_in, nlev, add, lazy, st);
   return ALIGNQ_EUNSUPPORTED;
 }
 

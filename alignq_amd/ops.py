@@ -399,10 +399,14 @@ def qconv_gen_supported(x, w, stride, padding, dilation, groups, bias, w_bit) ->
 class QConvGenFn(torch.autograd.Function):
     """Forward of Conv2d_Q's stride-2 transition convolutions (3x3 and the 1x1 shortcut) on alignq_conv_gen_nhwc_fwd, with the
     batch-norm partial statistics of the output as a by-product; data gradient (alignq_conv_gen_nhwc_dgrad) and filter gradient
-    (alignq_conv_gen_nhwc_wgrad) accept the lazy batch-norm form of the incoming gradient."""
+    (alignq_conv_gen_nhwc_wgrad) accept the lazy batch-norm form of the incoming gradient.
+
+    tap=True additionally returns the input as a second output (an alias): the transition block feeds it to its OTHER
+    convolution (resnet.py:78-86: `skip_conv(x)` and `conv0(x)` read the same x), whose input gradient then arrives here and
+    is added in this data-gradient kernel's epilogue instead of by a separate accumulation kernel."""
 
     @staticmethod
-    def forward(ctx, x, w, w_bit, padding):
+    def forward(ctx, x, w, w_bit, padding, tap=False):
         B, CIN, H, W = x.shape
         COUT, ks = w.shape[0], w.shape[2]
         lib = L.load()
@@ -414,11 +418,17 @@ class QConvGenFn(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.w_bit = int(w_bit)
         QConv3x3Fn._mailbox = (part, n_parts, True)
+        if tap:
+            ctx.set_materialize_grads(False)
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gtap=None):
         x, w = ctx.saved_tensors
+        if gy is None:                     # only the alias was used downstream
+            return gtap, None, None, None, None
+        add = None if gtap is None else L.like_layout(gtap, x)
         lazy = fused.take_lazy_dz(gy)      # (g, z, ab, save, ktot): gy is the gradient w.r.t. the folded BN's OUTPUT
         gy = gy.contiguous(memory_format=torch.channels_last)
         bz, bab, bsave, bk = (lazy[1], lazy[2], lazy[3], lazy[4]) if lazy is not None else (None, None, None, None)
@@ -429,8 +439,10 @@ class QConvGenFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             L.check(lib.alignq_conv_gen_nhwc_dgrad(L.ptr(gy), L.ptr(w), L.ptr(dx), B, H, W, CIN, COUT, ks, 2, ctx.w_bit,
-                                                   L.ptr(bz), L.ptr(bab), L.ptr(bsave), L.ptr(bk), L.stream_ptr()),
-                    "alignq_conv_gen_nhwc_dgrad")
+                                                   L.ptr(add), L.ptr(bz), L.ptr(bab), L.ptr(bsave), L.ptr(bk),
+                                                   L.stream_ptr()), "alignq_conv_gen_nhwc_dgrad")
+        elif add is not None:
+            dx = add
         if ctx.needs_input_grad[1]:        # split-bf16 MFMA, deterministic slabs
             dw = torch.empty_like(w)
             ws = _ws(lib.alignq_conv_gen_wgrad_ws_bytes(CIN, COUT, ks), x.device)
@@ -445,16 +457,17 @@ class QConvGenFn(torch.autograd.Function):
                 L.check(lib.alignq_conv_gen_nhwc_wgrad(L.ptr(x), L.ptr(gy), L.ptr(dw), L.ptr(ws), B, H, W, CIN, COUT, ks, 2,
                                                        None, L.ptr(bz), L.ptr(bab), L.ptr(bsave), L.ptr(bk), L.stream_ptr()),
                         "alignq_conv_gen_nhwc_wgrad")
-        return dx, dw, None, None
+        return dx, dw, None, None, None
 
     @staticmethod
-    def apply_with_stats(x, w, w_bit, padding):
+    def apply_with_stats(x, w, w_bit, padding, tap=False):
         QConv3x3Fn._mailbox = None
-        y = QConvGenFn.apply(x, w, w_bit, padding)
+        out = QConvGenFn.apply(x, w, w_bit, padding, tap)
+        y = out[0] if tap else out
         if QConv3x3Fn._mailbox is not None:
             y._alignq_bn_part = QConv3x3Fn._mailbox
             QConv3x3Fn._mailbox = None
-        return y
+        return out
 
 
 def qconv_stem_supported(x, w, stride, padding, dilation, groups, bias, w_bit) -> bool:

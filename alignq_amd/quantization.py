@@ -154,34 +154,36 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
                 self.quantize_fn = weight_quantize_fn(w_bit=w_bit, stage=stage)
 
             def forward(self, input, order=None):
-                weight_q = self.quantize_fn(self.weight)
-                # opt-in (TrainStep(channels_last=True) sets use_qconv): the 3x3 body convolutions on the matrix cores
-                if getattr(self, "use_qconv", False) and ops.qconv3x3_supported(
-                        input, weight_q, self.stride, self.padding, self.dilation, self.groups, self.bias,
-                        self.quantize_fn.w_bit):
-                    # (with the batch-norm statistics of its output as a by-product for fused.bn_site)
-                    return ops.QConv3x3Fn.apply_with_stats(input, weight_q, self.quantize_fn.w_bit)
-                if getattr(self, "use_qconv", False) and ops.qconv_gen_supported(
-                        input, weight_q, self.stride, self.padding, self.dilation, self.groups, self.bias,
-                        self.quantize_fn.w_bit):
-                    return ops.QConvGenFn.apply_with_stats(input, weight_q, self.quantize_fn.w_bit, self.padding[0])
-                if getattr(self, "use_qconv", False) and ops.qconv_stem_supported(
-                        input, weight_q, self.stride, self.padding, self.dilation, self.groups, self.bias,
-                        self.quantize_fn.w_bit):
-                    return ops.QConvStemFn.apply_with_stats(input, weight_q, self.quantize_fn.w_bit)
+                return self._conv(input, self.quantize_fn(self.weight))
+
+            def _conv(self, input, weight_q):
+                # opt-in (TrainStep(channels_last=True) sets use_qconv): the convolutions on the matrix cores
+                # (with the batch-norm statistics of the output as a by-product for fused.bn_site)
+                if getattr(self, "use_qconv", False):
+                    args = (input, weight_q, self.stride, self.padding, self.dilation, self.groups, self.bias,
+                            self.quantize_fn.w_bit)
+                    if ops.qconv3x3_supported(*args):
+                        return ops.QConv3x3Fn.apply_with_stats(input, weight_q, self.quantize_fn.w_bit)
+                    if ops.qconv_gen_supported(*args):
+                        return ops.QConvGenFn.apply_with_stats(input, weight_q, self.quantize_fn.w_bit, self.padding[0])
+                    if ops.qconv_stem_supported(*args):
+                        return ops.QConvStemFn.apply_with_stats(input, weight_q, self.quantize_fn.w_bit)
                 return F.conv2d(input, weight_q, self.bias, self.stride, self.padding, self.dilation, self.groups)
 
             def forward_with_shortcut(self, input):
-                """(conv(input), shortcut) for a block whose shortcut is the identity (`shortcut = x`): when the convolution
-                runs on alignq_conv3x3_nhwc the shortcut is returned as an output of the same autograd node, so its gradient
+                """(conv(input), alias of input) for a block that uses its input twice — as the identity shortcut
+                (`shortcut = x`) or as the input of the shortcut convolution: when the convolution runs on this repository's
+                kernels (and a gradient is needed) the alias is an output of the same autograd node, so the second gradient
                 is added inside the data-gradient kernel; otherwise plainly (forward(input), input)."""
                 weight_q = self.quantize_fn(self.weight)
-                if getattr(self, "use_qconv", False) and input.requires_grad and ops.qconv3x3_supported(
-                        input, weight_q, self.stride, self.padding, self.dilation, self.groups, self.bias,
-                        self.quantize_fn.w_bit):
-                    return ops.QConv3x3Fn.apply_with_stats(input, weight_q, self.quantize_fn.w_bit, True)
-                return (F.conv2d(input, weight_q, self.bias, self.stride, self.padding, self.dilation, self.groups),
-                        input)
+                if getattr(self, "use_qconv", False) and input.requires_grad:
+                    args = (input, weight_q, self.stride, self.padding, self.dilation, self.groups, self.bias,
+                            self.quantize_fn.w_bit)
+                    if ops.qconv3x3_supported(*args):
+                        return ops.QConv3x3Fn.apply_with_stats(input, weight_q, self.quantize_fn.w_bit, True)
+                    if ops.qconv_gen_supported(*args):      # transition block: the alias feeds the shortcut convolution
+                        return ops.QConvGenFn.apply_with_stats(input, weight_q, self.quantize_fn.w_bit, self.padding[0], True)
+                return self._conv(input, weight_q), input
 
         return Conv2d_Q
 

@@ -70,9 +70,9 @@ class PreActBlock_conv_Q(nn.Module):
     def forward(self, x):
         trans_loss = 0.
         if self.skip_conv is not None:
-            shortcut, loss = self._bnq(self.skip_bn, self.act_skip_q, self.skip_conv(x))
+            z0, xa = self.conv0.forward_with_shortcut(x)            # xa = x (skip_conv's input gradient joins conv0's)
+            shortcut, loss = self._bnq(self.skip_bn, self.act_skip_q, self.skip_conv(xa))
             trans_loss += loss
-            z0 = self.conv0(x)
         else:
             z0, shortcut = self.conv0.forward_with_shortcut(x)      # shortcut = x (its gradient joins conv0's data gradient)
         out, loss = self._bnq(self.bn0, self.act_q0, z0, relu=True)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALIGNQ_ABI_VERSION 2
+#define ALIGNQ_ABI_VERSION 3
 
 #define ALIGNQ_FORMULA_ADMM 0
 #define ALIGNQ_FORMULA_CDF 1
@@ -200,10 +200,11 @@ int alignq_conv_gen_bn_parts(int B, int H_in, int W_in, int CIN, int COUT, int K
 int alignq_conv_gen_nhwc_fwd(const float* x, const float* wt, float* y, int B, int H_in, int W_in, int CIN, int COUT, int KS,
                              int stride, int w_bit, float* bn_part, void* stream);
 
-/* data gradient of the transition convolutions; bn_* as in alignq_conv3x3_nhwc_bwd (lazy batch-norm form of dy) */
+/* data gradient of the transition convolutions; bn_* as in alignq_conv3x3_nhwc_bwd (lazy batch-norm form of dy); add (or NULL):
+ * a tensor of dx's shape added in the epilogue (the gradient the block's other branch sends to the same input) */
 int alignq_conv_gen_nhwc_dgrad(const float* dy, const float* wt, float* dx, int B, int H_in, int W_in, int CIN, int COUT, int KS,
-                               int stride, int w_bit, const float* bn_z, const float* bn_ab, const float* bn_save,
-                               const float* bn_ktot, void* stream);
+                               int stride, int w_bit, const float* add, const float* bn_z, const float* bn_ab,
+                               const float* bn_save, const float* bn_ktot, void* stream);
 
 /* The stem (3 -> 16 channels, 3x3, stride 1, padding 1, width 32; x [B,H,32,3], wt [16,3,3,3], y [B,H,32,16], channels-last):
  * forward with the optional batch-norm partials, and its filter gradient (ws: 256 * 432 floats); K = 27 is one MFMA k step

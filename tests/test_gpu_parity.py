@@ -954,6 +954,13 @@ def test_qconv_transition_forward_matches_fp64(dev, B, CIN, COUT, H, ks, k):
     torch.nn.functional.conv2d(xr, wr, stride=2, padding=pad).backward(gy)
     np.testing.assert_allclose(npy(x.grad), npy(xr.grad), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(npy(wq.grad), npy(wr.grad), rtol=1e-3, atol=1e-3 * float(wr.grad.abs().max()))
+    # tap: the input alias as a second output; its gradient is added in the data-gradient kernel's epilogue
+    xt = x.detach().clone().requires_grad_(True)
+    yt, xa = ops.QConvGenFn.apply_with_stats(xt, wq.detach(), k, pad, True)
+    assert xa.data_ptr() == xt.data_ptr() and bits_equal(npy(yt), npy(y))
+    gt = torch.randn_like(xt)
+    torch.autograd.backward([yt, xa], [gy, gt])
+    np.testing.assert_allclose(npy(xt.grad), npy(x.grad + gt), rtol=1e-6, atol=1e-6)
 
 
 @pytest.mark.parametrize("B,H,k", [(128, 32, 8), (6, 32, 4), (3, 8, 8)])
