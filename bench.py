@@ -331,7 +331,7 @@ def main():
                                    + ("" if a.no_miopen_find else ", MIOpen find mode for the convolutions")
                                    + ("" if a.nchw else ", channels-last tensors")
                                    + ("" if (office or a.nchw or a.no_qconv) else
-                                      ", Conv2d_Q 3x3 body convolutions on alignq_conv3x3_nhwc"),
+                                      ", all Conv2d_Q convolutions on alignq_conv*_nhwc (exact-product bf16 MFMA)"),
                        "global_batch": a.batch * world, "parallelism": f"dp{world}",
                        "final_ce": float(ce.detach()), "final_trans_loss": float(tl.detach()) if tl is not None else None},
         }
