@@ -328,7 +328,8 @@ def main():
                                     f"(cdf_alignment_admm/resnet-20-cifar-10), batch {a.batch}/GPU, ")
                                    + f"{'HIP-graph replay' if not a.no_graph else 'eager launches'}"
                                    + ("" if (office or a.no_fuse_bn) else ", batch-norm folded into the site kernels")
-                                   + ("" if a.no_miopen_find else ", MIOpen find mode for the convolutions")
+                                   + ("" if (a.no_miopen_find or not (office or a.nchw or a.no_qconv)) else
+                                      ", MIOpen find mode for the convolutions")
                                    + ("" if a.nchw else ", channels-last tensors")
                                    + ("" if (office or a.nchw or a.no_qconv) else
                                       ", all Conv2d_Q convolutions on alignq_conv*_nhwc (exact-product bf16 MFMA)"),
