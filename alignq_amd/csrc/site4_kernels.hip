@@ -184,13 +184,24 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
           const int c0 = chbase + cl0, c1 = chbase + (two ? cl1 : cl0);
           double sa0 = 0, sq0 = 0, sa1 = 0, sq1 = 0;
           if (bn.part_f32) {       // per-workgroup float partials of the convolution that produced z: [C][n_parts][2]
-            const float2* pf = reinterpret_cast<const float2*>(bn.part);
-            for (int pi = lane; pi < bn.n_parts; pi += 64) {
-              const float2 v0 = pf[(int64_t)c0 * bn.n_parts + pi];
-              sa0 += v0.x; sq0 += v0.y;
-              if (kPairCh) {
-                const float2 v1 = pf[(int64_t)c1 * bn.n_parts + pi];
-                sa1 += v1.x; sq1 += v1.y;
+            // (up to 8 x 64 = 512 partials per channel in flight at once: one memory round trip, not n_parts / 64 of them)
+            const float2* pf0 = reinterpret_cast<const float2*>(bn.part) + (int64_t)c0 * bn.n_parts;
+            const float2* pf1 = reinterpret_cast<const float2*>(bn.part) + (int64_t)c1 * bn.n_parts;
+            constexpr int PU = kPairCh ? 4 : 8;     // 16 registers of loads either way
+            for (int p0 = lane; p0 < bn.n_parts; p0 += 64 * PU) {
+              float2 v0[PU], v1[PU];
+#pragma unroll
+              for (int u = 0; u < PU; u++) {
+                const int pi = p0 + 64 * u, pc = pi < bn.n_parts ? pi : bn.n_parts - 1;
+                v0[u] = pf0[pc];
+                if (kPairCh) v1[u] = pf1[pc];
+              }
+#pragma unroll
+              for (int u = 0; u < PU; u++) {
+                if (p0 + 64 * u < bn.n_parts) {
+                  sa0 += v0[u].x; sq0 += v0[u].y;
+                  if (kPairCh) { sa1 += v1[u].x; sq1 += v1[u].y; }
+                }
               }
             }
           } else {

@@ -72,7 +72,7 @@ def time_call(fn, reps, warm=3):
 
 
 def measure_kernels(dev, B, k, site_F_counts, hw_of_F, folded=True, nhwc=False):
-    """Per-kernel live timings through the C ABI, HIP events on the launch stream.
+    """Per-kernel live timings through the C ABI, HIP events on the launch stream, over R rotating buffer sets.
     site_F_counts: {F: number of ADMM sites with F features}; hw_of_F: {F: H*W} (the channel size for the BN fold).
     folded=True times the entry points the training step actually uses (batch-norm + ReLU folded into the site kernels);
     nhwc=True their channels-last forms (the [B,F] buffers are then read as [B,HW,C])."""
@@ -84,15 +84,23 @@ def measure_kernels(dev, B, k, site_F_counts, hw_of_F, folded=True, nhwc=False):
     per_step = {n: [0.0, 0.0] for n in names}
     A = torch.rand(B, B, device=dev)
     Gm = torch.rand(B, B, device=dev)
+    R = 4   # buffer sets in rotation: a launch finds its operands where the training step finds them (written a few launches
+    #         ago: out of the 8 x 4 MB L2s, still in the 256 MB Infinity Cache), not L2-hot from the previous identical launch
     for F, count in sorted(site_F_counts.items()):
         HW = hw_of_F[F]
         C = F // HW
-        x = torch.randn(B, F, device=dev)
-        g = torch.randn(B, F, device=dev) * 0.01
-        xq, dx, dz = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        nh = int(bool(nhwc))
+        xs = [torch.randn(B, F, device=dev) for _ in range(R)]
+        gs = [torch.randn(B, F, device=dev) * 0.01 for _ in range(R)]
+        xqs, dxs, dzs = ([torch.empty(B, F, device=dev) for _ in range(R)] for _ in range(3))
+        statss = [torch.empty(4, F, device=dev) for _ in range(R)]
+        wss = [torch.empty(lib.alignq_site_ws_bytes(B, F), dtype=torch.uint8, device=dev) for _ in range(R)]
+        ws_bns = [torch.empty(lib.alignq_bn_nhwc_ws_bytes(C) if nh else lib.alignq_bn_ws_bytes(C), dtype=torch.uint8, device=dev)
+                  for _ in range(R)]
+        parts = [torch.empty(lib.alignq_site_bn_part_bytes(F, nh), dtype=torch.uint8, device=dev) for _ in range(R)]
+        ress = [torch.randn(B, F, device=dev) for _ in range(R)]       # the block's shortcut (added before the ReLU)
+        dress = [torch.empty(B, F, device=dev) for _ in range(R)]
         D = torch.empty(B, B, device=dev)
-        stats = torch.empty(4, F, device=dev)
-        ws = torch.empty(lib.alignq_site_ws_bytes(B, F), dtype=torch.uint8, device=dev)
         S = torch.empty(B, B, device=dev)
         scal = torch.empty(4, device=dev)
         dA, dG = torch.empty_like(A), torch.empty_like(Gm)
@@ -101,41 +109,90 @@ def measure_kernels(dev, B, k, site_F_counts, hw_of_F, folded=True, nhwc=False):
         rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
         nbt = torch.zeros((), dtype=torch.int64, device=dev)
         ab, save = torch.empty(2, C, device=dev), torch.empty(2, C, device=dev)
-        nh = int(bool(nhwc))
-        ws_bn = torch.empty(lib.alignq_bn_nhwc_ws_bytes(C) if nh else lib.alignq_bn_ws_bytes(C), dtype=torch.uint8, device=dev)
-        part = torch.empty(lib.alignq_site_bn_part_bytes(F, nh), dtype=torch.uint8, device=dev)
         dgam, dbet = torch.empty(C, device=dev), torch.empty(C, device=dev)
         p = L.ptr
+        turn = {"stats": 0, "part": 0, "pair": 0, "bwd": 0, "bnb": 0}
+
+        def nxt(name):
+            i = turn[name] % R
+            turn[name] += 1
+            return i
+
         if folded:
-            f_stats = ((lambda: lib.alignq_bn_partial_stats_nhwc(p(x), B, C, HW, p(ws_bn), st)) if nh else
-                       (lambda: lib.alignq_bn_partial_stats(p(x), B, C, HW, p(ws_bn), st)))
-            f_part = lambda: lib.alignq_site_partials_bn(p(x), p(ws_bn), p(gam), p(bet), p(rm), p(rv), p(nbt), 0.1, 1e-5, p(ab),
-                                                         p(save), C, HW, B, F, k, 2.0, 0.0, 1, None, nh, 0, p(xq), p(stats), p(ws), st)
-            f_bwd = lambda: lib.alignq_site_bwd_apply_bn(p(g), p(S), p(x), p(ab), p(save), C, HW, nh, p(xq), None, p(stats), B, F, 2.0,
-                                                         0.0, p(dx), p(part), st)
-            f_bnb = lambda: lib.alignq_bn_bwd_apply(p(dx), p(x), p(ab), p(save), p(part), B, C, HW, nh, p(dz), p(dgam), p(dbet), st)
+            stats_fn = lib.alignq_bn_partial_stats_nhwc if nh else lib.alignq_bn_partial_stats
+
+            def stats_i(i):
+                return stats_fn(p(xs[i]), B, C, HW, p(ws_bns[i]), st)
+
+            def part_i(i, res=False):
+                return lib.alignq_site_partials_bn(p(xs[i]), p(ws_bns[i]), p(gam), p(bet), p(rm), p(rv), p(nbt), 0.1, 1e-5, p(ab),
+                                                   p(save), C, HW, B, F, k, 2.0, 0.0, 1, p(ress[i]) if res else None, nh, 0,
+                                                   p(xqs[i]), p(statss[i]), p(wss[i]), st)
+
+            def bwd_i(i, res=False):
+                return lib.alignq_site_bwd_apply_bn(p(gs[i]), p(S), p(xs[i]), p(ab), p(save), C, HW, nh, p(xqs[i]),
+                                                    p(dress[i]) if res else None, p(statss[i]), B, F, 2.0, 0.0, p(dxs[i]),
+                                                    p(parts[i]), st)
+
+            def bnb_i(i):
+                return lib.alignq_bn_bwd_apply(p(dxs[i]), p(xs[i]), p(ab), p(save), p(parts[i]), B, C, HW, nh, p(dzs[i]), p(dgam),
+                                               p(dbet), st)
+
+            f_stats = lambda: stats_i(nxt("stats"))
+            f_bnb = lambda: bnb_i(nxt("bnb"))
         else:
-            f_stats = None
-            f_part = lambda: lib.alignq_site_partials(p(x), B, F, k, 2.0, 0.0, p(xq), p(stats), p(ws), st)
-            f_bwd = lambda: lib.alignq_site_bwd_apply(p(g), p(S), p(x), p(stats), B, F, 2.0, 0.0, p(dx), st)
-            f_bnb = None
-        f_red = lambda: lib.alignq_site_reduce_loss(p(ws), B, F, p(D), p(A), p(Gm), B, 0.2, 0.3, p(scal), st)
+            stats_i = None
+
+            def part_i(i, res=False):
+                return lib.alignq_site_partials(p(xs[i]), B, F, k, 2.0, 0.0, p(xqs[i]), p(statss[i]), p(wss[i]), st)
+
+            def bwd_i(i, res=False):
+                return lib.alignq_site_bwd_apply(p(gs[i]), p(S), p(xs[i]), p(statss[i]), B, F, 2.0, 0.0, p(dxs[i]), st)
+
+            f_stats = f_bnb = None
+        f_part = lambda: part_i(nxt("part"))
+        f_bwd = lambda: bwd_i(nxt("bwd"))
+        f_part_res = lambda: part_i(nxt("part"), True)
+        f_bwd_res = lambda: bwd_i(nxt("bwd"), True)
+
+        def red_i(i):
+            return lib.alignq_site_reduce_loss(p(wss[i]), B, F, p(D), p(A), p(Gm), B, 0.2, 0.3, p(scal), st)
+
         f_prep = lambda: lib.alignq_site_prep_fused(p(D), p(A), p(Gm), B, p(scal), 0.2, p(one), B, F, p(S), p(dA), p(dG), st)
 
         def fwd_pair():   # the reduction's arrival counter is re-armed by the partials kernel: time them as a pair
-            f_part()
-            f_red()
+            i = nxt("pair")
+            part_i(i)
+            red_i(i)
 
+        for i in range(R):          # every set holds a finished forward (statistics, x_q, slabs) before anything is timed
+            if stats_i:
+                stats_i(i)
+            part_i(i)
+            red_i(i)
+        f_prep()
+        for i in range(R):
+            bwd_i(i)
+
+        # the step's mix: the second site of every residual block adds the shortcut before the ReLU (3 of the 7 sites of a
+        # ResNet-20 stage, 9 of 19 for ResNet-56); the other sites have no residual operand
+        n_res = (count - 1) // 2 if folded else 0
         t_stats = time_call(f_stats, 50) if f_stats else 0.0
-        t_part = time_call(f_part, 50)
-        t_red = max(time_call(fwd_pair, 50) - t_part, 0.0)
+        t_part_plain = time_call(f_part, 50)
+        t_red = max(time_call(fwd_pair, 50) - t_part_plain, 0.0)
         t_prep = time_call(f_prep, 50)
-        t_bwd = time_call(f_bwd, 50)
+        t_bwd_plain = time_call(f_bwd, 50)
+        t_part_res = time_call(f_part_res, 50) if n_res else t_part_plain
+        t_bwd_res = time_call(f_bwd_res, 50) if n_res else t_bwd_plain
+        t_part = (t_part_plain * (count - n_res) + t_part_res * n_res) / count
+        t_bwd = (t_bwd_plain * (count - n_res) + t_bwd_res * n_res) / count
         t_bnb = time_call(f_bnb, 50) if f_bnb else 0.0
         gram_flops = 2 * 2.0 * B * B * F            # two Grams, full-matrix count
         out[f"site_F{F}"] = {
             "bn_partial_stats_us": t_stats * 1e6, "partials_us": t_part * 1e6, "reduce_loss_us": t_red * 1e6,
             "bwd_prep_us": t_prep * 1e6, "bwd_us": t_bwd * 1e6, "bn_bwd_apply_us": t_bnb * 1e6,
+            "partials_us_plain_residual": [t_part_plain * 1e6, t_part_res * 1e6],
+            "bwd_us_plain_residual": [t_bwd_plain * 1e6, t_bwd_res * 1e6], "sites_with_residual": n_res,
             "partials_hbm_gbs": 8.0 * B * F / t_part / 1e9, "bwd_hbm_gbs": 12.0 * B * F / t_bwd / 1e9,
             "partials_tflops_fp32_equiv": gram_flops / t_part / 1e12, "sites": count, "C": C, "HW": HW}
         for name, t, fl in (("bn_partial_stats", t_stats, 0.0), ("site_partials", t_part, gram_flops),
@@ -182,9 +239,11 @@ def measure_kernels(dev, B, k, site_F_counts, hw_of_F, folded=True, nhwc=False):
                 "launches_per_step": n_sites, "avg_launch_us": t_sum / n_sites * 1e6,
                 "bytes_per_launch_avg": by_sum / n_sites,
                 "gram_tflops_fp32_equiv": fl_sum / t_sum / 1e12,
-                "note": "achieved = algorithmic bytes (8 B/elem fwd, 12 B/elem bwd, SURVEY 8d) summed over the step's 21 "
-                        "sites / summed launch time (HIP events); CIFAR sites are 2-8 MB per launch, i.e. launch-latency "
-                        "shapes (SURVEY H2); see kernels.act_quant_* for the HBM-roofline-sized CDF-quantise kernel"}
+                "note": f"achieved = algorithmic bytes (8 B/elem fwd, 12 B/elem bwd, SURVEY 8d; the fused shortcut operand is "
+                        f"not counted) summed over the step's {n_sites} sites / summed launch time (HIP events, back-to-back "
+                        "launches over 4 rotating buffer sets, the step's mix of sites with and without a residual operand); "
+                        "CIFAR sites are 2-8 MB per launch, i.e. launch-latency shapes (SURVEY H2); see kernels.act_quant_* "
+                        "for the HBM-roofline-sized CDF-quantise kernel"}
     out["per_step_us"] = {kname: v[0] * 1e6 for kname, v in per_step.items()}
     return roofline, out
 
