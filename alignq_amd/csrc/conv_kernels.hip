@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 #include "../../include/alignq.h"
+#include "site_internal.h"
 
 namespace {
 
@@ -47,8 +48,62 @@ struct BnLazy {
   const float* z;      // the convolution's forward output (= BN input), same layout as g; nullptr => g already is dy
   const float* ab;     // [2][C]: a = gamma * invstd, (b)
   const float* save;   // [2][C]: batch mean, invstd
-  const float* ktot;   // [2][C]: k0 = sum g / n, k1 = sum g * zhat / n
+  const float* ktot;   // [2][C]: k0 = sum g / n, k1 = sum g * zhat / n   (or nullptr: formed from `part` by every workgroup)
+  // the site backward's per-tile sums [n_tiles][min(C, tile_f)][2] = {sum g, sum g * zhat}; tile t covers the features
+  // t * tile_f .. of the channels-last [pixel][C] row (channel = feature mod C)
+  const float* part = nullptr;
+  int n_tiles = 0, tile_f = 0;
+  double n = 1.0;              // B * H * W
+  float* dgamma = nullptr;     // published by one workgroup (batch-norm parameter gradients = the totals)
+  float* dbeta = nullptr;
 };
+
+// Per-channel totals of the site backward's per-tile sums, formed by EVERY workgroup (256 threads) for itself into LDS
+// kt[2 * C] = {sum g / n, sum g * zhat / n}: the one-workgroup launch that otherwise sits between the site backward and the
+// convolution backward (4.7 us per layer) is gone.  Thread -> (channel, group); up to 16 partials per thread in flight at
+// once; double accumulation in a fixed order.  Call with all 256 threads; ends with a barrier.
+template <int C>
+__device__ __forceinline__ void bn_totals_lds(const BnLazy& t, float* __restrict__ kt, bool publish) {
+  static_assert(256 % C == 0, "thread -> (channel, group)");
+  __shared__ double red[256][2];
+  constexpr int G = 256 / C;
+  const int tid = threadIdx.x;
+  const int cp = C < t.tile_f ? C : t.tile_f;            // channels per tile
+  const int cyc = C / cp, cnt = t.n_tiles / cyc;         // tiles per channel cycle, partials per channel
+  const int c = tid % C, grp = tid / C;
+  const int e = c % cp, t_first = c / cp;
+  double s0 = 0, s1 = 0;
+  constexpr int U = 16;
+  for (int i0 = grp; i0 < cnt; i0 += G * U) {
+    float2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = i0 + u * G;
+      const int ic = i < cnt ? i : cnt - 1;
+      v[u] = *reinterpret_cast<const float2*>(t.part + ((int64_t)(ic * cyc + t_first) * cp + e) * 2);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (i0 + u * G < cnt) { s0 += v[u].x; s1 += v[u].y; }
+    }
+  }
+  red[tid][0] = s0;
+  red[tid][1] = s1;
+  __syncthreads();
+  if (tid < C) {
+    double t0 = 0, t1 = 0;
+#pragma unroll
+    for (int g = 0; g < G; g++) { t0 += red[g * C + tid][0]; t1 += red[g * C + tid][1]; }
+    kt[tid] = (float)(t0 / t.n);
+    kt[C + tid] = (float)(t1 / t.n);
+    if (publish) {
+      if (t.dbeta) t.dbeta[tid] = (float)t0;
+      if (t.dgamma) t.dgamma[tid] = (float)t1;
+    }
+  }
+  __syncthreads();
+}
+
 __device__ __forceinline__ float4 bn_lazy4(const float4& g, const float4& z, const float4& a, const float4& m, const float4& is,
                                            const float4& k0, const float4& k1) {
   float4 o;
@@ -117,8 +172,16 @@ __device__ __forceinline__ void conv3x3_body(const float* __restrict__ x, const 
       const float4 a4 = *reinterpret_cast<const float4*>(lazy.ab + 4 * c4t);
       const float4 m4 = *reinterpret_cast<const float4*>(lazy.save + 4 * c4t);
       const float4 i4 = *reinterpret_cast<const float4*>(lazy.save + C + 4 * c4t);
-      const float4 k0 = *reinterpret_cast<const float4*>(lazy.ktot + 4 * c4t);
-      const float4 k1 = *reinterpret_cast<const float4*>(lazy.ktot + C + 4 * c4t);
+      float4 k0, k1;
+      if (lazy.part) {           // (workgroup-uniform) totals from the site backward's per-tile sums, every workgroup for itself
+        __shared__ __attribute__((aligned(16))) float kt[2 * C];
+        bn_totals_lds<C>(lazy, kt, block == 0);
+        k0 = *reinterpret_cast<const float4*>(kt + 4 * c4t);
+        k1 = *reinterpret_cast<const float4*>(kt + C + 4 * c4t);
+      } else {
+        k0 = *reinterpret_cast<const float4*>(lazy.ktot + 4 * c4t);
+        k1 = *reinterpret_cast<const float4*>(lazy.ktot + C + 4 * c4t);
+      }
 #pragma unroll
       for (int it = 0; it < NIT; it++) {
         const int i = tid + 256 * it;
@@ -867,8 +930,15 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ x, const fl
     la = *reinterpret_cast<const f32x4*>(lazy.ab + cq);
     lm = *reinterpret_cast<const f32x4*>(lazy.save + cq);
     li = *reinterpret_cast<const f32x4*>(lazy.save + COUT + cq);
-    lk0 = *reinterpret_cast<const f32x4*>(lazy.ktot + cq);
-    lk1 = *reinterpret_cast<const f32x4*>(lazy.ktot + COUT + cq);
+    if (lazy.part) {             // (workgroup-uniform) see bn_totals_lds; the first tile's loads above are already in flight
+      __shared__ __attribute__((aligned(16))) float kt[2 * COUT];
+      bn_totals_lds<COUT>(lazy, kt, false);
+      lk0 = *reinterpret_cast<const f32x4*>(kt + cq);
+      lk1 = *reinterpret_cast<const f32x4*>(kt + COUT + cq);
+    } else {
+      lk0 = *reinterpret_cast<const f32x4*>(lazy.ktot + cq);
+      lk1 = *reinterpret_cast<const f32x4*>(lazy.ktot + COUT + cq);
+    }
   }
   for (int tile = bx; tile < n_tiles; tile += gx) {
     __syncthreads();                               // previous tile's readers are done
@@ -1244,9 +1314,17 @@ int alignq_conv3x3_wgrad_reduce_multi(int T, const void* const* ws, float* const
 // partial sums as alignq_conv3x3_nhwc_wgrad with a deferred reduction: *n_slabs_out slabs are left in ws).
 int alignq_conv3x3_nhwc_bwd(const float* x, const float* dy, const float* wt, float* dx, void* ws, int B, int H, int W,
                             int C, int w_bit, int* n_slabs_out, const float* add, const float* bn_z, const float* bn_ab,
-                            const float* bn_save, const float* bn_ktot, void* stream) {
-  if (bn_z && (!bn_ab || !bn_save || !bn_ktot)) return ALIGNQ_EINVAL;
-  const BnLazy lazy{bn_z, bn_ab, bn_save, bn_ktot};
+                            const float* bn_save, const float* bn_ktot, const float* bn_dx_part, float* bn_dgamma,
+                            float* bn_dbeta, void* stream) {
+  if (bn_z && (!bn_ab || !bn_save || (!bn_ktot && !bn_dx_part))) return ALIGNQ_EINVAL;
+  BnLazy lazy{bn_z, bn_ab, bn_save, bn_ktot};
+  if (bn_z && bn_dx_part && !bn_ktot) {          // totals formed inside the kernel from the site backward's per-tile sums
+    const int64_t F = (int64_t)C * H * W;
+    const int tf = alignq_site::bwd_tile_features(B, F);
+    if (F % tf || (C > tf && C % tf) || (C < tf && tf % C)) return ALIGNQ_EUNSUPPORTED;
+    lazy.part = bn_dx_part; lazy.n_tiles = (int)(F / tf); lazy.tile_f = tf; lazy.n = (double)B * H * W;
+    lazy.dgamma = bn_dgamma; lazy.dbeta = bn_dbeta;
+  }
   if (!x || !dy || !wt || !dx || !ws || !n_slabs_out || B < 1 || H < 1) return ALIGNQ_EINVAL;
   if (w_bit < 1 || w_bit > 8) return ALIGNQ_EUNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(wt) |

@@ -203,8 +203,13 @@ class DeferredWgrads:
     and so does the per-tensor ops.WeightQuantFn.backward.  Use only around a backward whose W_q gradients have no other
     consumer (TrainStep)."""
 
-    def __init__(self):
+    def __init__(self, fresh_grads=False):
+        """fresh_grads=True promises that every parameter's .grad is None when the backward starts (zero_grad(set_to_none=True)):
+        autograd then adopts an incoming gradient tensor as .grad instead of adding it to an existing one, which lets a LATER
+        kernel of the same backward fill gradients autograd already holds (the batch-norm parameter gradients written by
+        alignq_conv3x3_nhwc_bwd, see BNSiteFn.backward)."""
         self.items = []
+        self.fresh_grads = bool(fresh_grads)
 
     def __enter__(self):
         global _active_wgrads
@@ -246,8 +251,10 @@ def active_wgrads():
 _lazy_dz = {}
 
 
-def post_lazy_dz(g, z, ab, save, ktot):
-    _lazy_dz[g.data_ptr()] = (g, z, ab, save, ktot)
+def post_lazy_dz(g, z, ab, save, ktot, part=None, dgamma=None, dbeta=None):
+    """ktot None: the consumer reduces the site backward's per-tile sums `part` itself (alignq_conv3x3_nhwc_bwd) and fills the
+    batch-norm parameter gradients dgamma / dbeta, which autograd already holds."""
+    _lazy_dz[g.data_ptr()] = (g, z, ab, save, ktot, part, dgamma, dbeta)
 
 
 def take_lazy_dz(g):
@@ -316,7 +323,7 @@ class BNSiteFn(torch.autograd.Function):
             L.check(lib.alignq_site_reduce_loss(L.ptr(ws), B, F, L.ptr(D), L.ptr(A), L.ptr(Gm), dim, float(mu),
                                                 float(rho), L.ptr(scal), st), "alignq_site_reduce_loss")
         ctx.rec = rec
-        ctx.from_qconv = bool(nhwc and conv_part is not None and len(conv_part) > 2 and conv_part[2])
+        ctx.from_qconv = int(conv_part[2]) if (nhwc and conv_part is not None and len(conv_part) > 2) else 0
         ctx.save_for_backward(z, ab, save, stats, D, A, Gm, scal, y if relu else None)
         ctx.set_materialize_grads(False)
         ctx.cfg = (float(act_range), float(eps), float(mu), bn_weight is not None, bn_bias is not None, res is not None,
@@ -358,9 +365,17 @@ class BNSiteFn(torch.autograd.Function):
                                              L.ptr(dx), L.ptr(part), st), "alignq_site_bwd_apply_bn")
         dgam = torch.empty(C, dtype=torch.float32, device=dev) if has_w else None
         dbet = torch.empty(C, dtype=torch.float32, device=dev) if has_b else None
+        if ctx.from_qconv == 2 and active_wgrads() is not None and active_wgrads().fresh_grads:
+            # z is the output of a 3x3 body convolution whose fused backward reduces the per-tile sums itself: nothing is
+            # launched here; dgam / dbet are filled by that kernel (later in this backward, before anything reads them).
+            # Autograd receives VIEWS: it adopts a gradient as .grad only while nobody else holds the tensor object (it would
+            # copy the still unwritten buffer otherwise); the buffers themselves travel with the lazy record.
+            post_lazy_dz(dx, z, ab, save, None, part, dgam, dbet)
+            return (dx, None if dgam is None else dgam.view_as(dgam), None if dbet is None else dbet.view_as(dbet), None, None,
+                    None, None, None, dA, dG, None, None, None, None, None, None, None, dres, None)
         if ctx.from_qconv and active_wgrads() is not None:
-            # z is the output of ops.QConv3x3Fn and a whole-model backward is running: only the per-channel totals are
-            # computed here; the convolution's backward forms dz = a*(g - k0 - zhat*k1) on load (no elementwise pass)
+            # z is the output of one of ops' convolutions and a whole-model backward is running: only the per-channel totals
+            # are computed here; the convolution's backward forms dz = a*(g - k0 - zhat*k1) on load (no elementwise pass)
             ktot = torch.empty(2, C, dtype=torch.float32, device=dev)
             L.check(lib.alignq_bn_bwd_totals(L.ptr(part), B, C, HW, L.ptr(ktot), L.ptr(dgam), L.ptr(dbet), st),
                     "alignq_bn_bwd_totals")

@@ -310,7 +310,9 @@ class QConv3x3Fn(torch.autograd.Function):
         ctx.w_bit = int(w_bit)
         ctx.tap = bool(tap)
         if part is not None:
-            QConv3x3Fn._mailbox = (part, n_parts, True)      # True: this producer's backward accepts a lazy BN gradient
+            # third field: this producer's backward accepts a lazy BN gradient (1), and reduces the site backward's per-tile
+            # sums itself when both of its gradients are needed (2: the fused alignq_conv3x3_nhwc_bwd)
+            QConv3x3Fn._mailbox = (part, n_parts, 2 if (x.requires_grad and w.requires_grad) else 1)
         if tap:
             ctx.set_materialize_grads(False)
             return y, x.view_as(x)
@@ -348,14 +350,19 @@ class QConv3x3Fn(torch.autograd.Function):
             dx, dw = torch.empty_like(x), torch.empty_like(w)
             ws = _ws(lib.alignq_conv3x3_wgrad_ws_bytes(C), x.device)
             ns = ctypes.c_int(0)
-            bz, bab, bsave, bk = (lazy[1], lazy[2], lazy[3], lazy[4]) if lazy is not None else (None, None, None, None)
+            bz, bab, bsave, bk, bpart, bdg, bdb = lazy[1:8] if lazy is not None else (None,) * 7
             L.check(lib.alignq_conv3x3_nhwc_bwd(L.ptr(x), L.ptr(gy), L.ptr(w), L.ptr(dx), L.ptr(ws), B, H, W, C, ctx.w_bit,
                                                 ctypes.byref(ns), L.ptr(add), L.ptr(bz), L.ptr(bab), L.ptr(bsave), L.ptr(bk),
+                                                L.ptr(bpart) if bk is None else None, L.ptr(bdg), L.ptr(bdb),
                                                 L.stream_ptr()), "alignq_conv3x3_nhwc_bwd")
             pending.add(ws, dw, ns.value, 9 * C * C)
             return dx, dw, None, None, None
         if lazy is not None:               # not the fused path after all: finish the batch-norm input gradient here
-            _, bz, bab, bsave, bk = lazy
+            _, bz, bab, bsave, bk, bpart, bdg, bdb = lazy
+            if bk is None:                 # the totals were left to the fused kernel: form them now
+                bk = torch.empty(2, C, dtype=torch.float32, device=x.device)
+                L.check(lib.alignq_bn_bwd_totals(L.ptr(bpart), B, C, H * W, L.ptr(bk), L.ptr(bdg), L.ptr(bdb), L.stream_ptr()),
+                        "alignq_bn_bwd_totals")
             shp = (1, C, 1, 1)
             gy = bab[0].view(shp) * (gy - bk[0].view(shp) - (bz - bsave[0].view(shp)) * bsave[1].view(shp) * bk[1].view(shp))
             gy = L.like_layout(gy, x)

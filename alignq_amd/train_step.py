@@ -31,7 +31,7 @@ class TrainStep:
                     if hasattr(m, "quantize_fn"):
                         m.use_qconv = True
         self.channels_last = channels_last
-        self._wgrads = DeferredWgrads() if (channels_last and qconv and torch.cuda.is_available()) else None
+        self._wgrads = DeferredWgrads(fresh_grads=True) if (channels_last and qconv and torch.cuda.is_available()) else None
         self.model = model
         if fuse_bn:      # fold BN into the site kernels where shapes allow (training, 64 < batch <= 128); no-op otherwise
             for m in model.modules():

@@ -233,10 +233,15 @@ int alignq_conv_gen_nhwc_wgrad(const float* x, const float* dy, float* dw, void*
                                const float* bn_save, const float* bn_ktot, void* stream);
 
 /* Data gradient AND filter-gradient partial sums of one convolution in a single launch (workgroup roles by block index; the
- * two are independent and fill the chip together).  The slabs left in ws are finished by alignq_conv3x3_wgrad_reduce_multi. */
+ * two are independent and fill the chip together).  The slabs left in ws are finished by alignq_conv3x3_wgrad_reduce_multi.
+ * Lazy batch-norm form of dy (bn_z != NULL): dy is the gradient g w.r.t. the folded batch-norm's OUTPUT and the kernel forms
+ * dz = a*(g - k0 - zhat*k1) on load; the totals k0, k1 come from bn_ktot (alignq_bn_bwd_totals) or, with bn_ktot == NULL, are
+ * reduced by every workgroup from bn_dx_part = alignq_site_bwd_apply_bn's per-tile sums (no launch in between); one
+ * workgroup then also writes the batch-norm parameter gradients bn_dgamma / bn_dbeta ([C] each, may be NULL). */
 int alignq_conv3x3_nhwc_bwd(const float* x, const float* dy, const float* wt, float* dx, void* ws, int B, int H, int W,
                             int C, int w_bit, int* n_slabs_out, const float* add, const float* bn_z, const float* bn_ab,
-                            const float* bn_save, const float* bn_ktot, void* stream);
+                            const float* bn_save, const float* bn_ktot, const float* bn_dx_part, float* bn_dgamma,
+                            float* bn_dbeta, void* stream);
 /* bn_z != NULL: `dy` is not the convolution output's gradient but g, the gradient w.r.t. the OUTPUT of the training-mode
  * batch-norm that follows the convolution (what alignq_site_bwd_apply_bn writes); both roles form
  * dy = a[c] * (g - k0[c] - (z - mean[c]) * invstd[c] * k1[c]) on load from bn_z (the convolution's forward output), bn_ab,

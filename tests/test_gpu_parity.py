@@ -925,6 +925,64 @@ def test_conv_epilogue_bn_statistics_feed_the_fold(dev, B, C, H, k):
     config.args.bitW = config.args.abitW = 8
 
 
+@pytest.mark.parametrize("B,C,H,k", [(128, 16, 32, 8), (128, 32, 16, 8), (128, 64, 8, 4), (80, 32, 16, 8)])
+def test_lazy_bn_backward_inside_the_fused_convolution_backward(dev, B, C, H, k):
+    """conv (alignq_conv3x3_nhwc) -> folded BN + site.  Inside a fused.DeferredWgrads context the site backward hands its
+    per-tile sums to alignq_conv3x3_nhwc_bwd, which reduces them itself, forms dz on load and writes the batch-norm parameter
+    gradients; outside it the batch-norm input gradient is materialised (alignq_bn_bwd_apply) and the convolution gradients
+    run as separate launches.  Same numbers up to summation order."""
+    import alignq_amd.cdf_alignment_admm as A
+    from alignq_amd import config, ops
+    from alignq_amd.fused import DeferredWgrads, bn_site
+    config.args.bitW = config.args.abitW = k
+    torch.manual_seed(B + C + k)
+    n = 2 ** k - 1
+    cl = torch.channels_last
+    x0 = (torch.randn(B, C, H, H, device=dev) * 1.1).contiguous(memory_format=cl)
+    w0 = (torch.round(torch.tanh(torch.randn(C, C, 3, 3)) * n) / n).to(dev).contiguous(memory_format=cl)
+    gq = torch.randn(B, C, H, H, device=dev).contiguous(memory_format=cl) * 0.01
+    outs = []
+    for fused_bwd in (False, True):
+        torch.manual_seed(1)
+        bn = torch.nn.BatchNorm2d(C).to(dev).train()
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.1)
+        admm = A.ADMM(128).to(dev)
+        act = A.activation_quantize_fn(k, "second", admm)
+        x = x0.clone(memory_format=cl).requires_grad_(True)
+        w = w0.clone(memory_format=cl).requires_grad_(True)
+
+        class Consumer(torch.autograd.Function):      # stands in for the weight quantiser's backward: flushes before it reads dW
+            @staticmethod
+            def forward(ctx, t):
+                return t.view_as(t)
+
+            @staticmethod
+            def backward(ctx, g):
+                from alignq_amd.fused import active_wgrads
+                if active_wgrads() is not None:
+                    active_wgrads().flush()
+                return g
+        z = ops.QConv3x3Fn.apply_with_stats(x, Consumer.apply(w), k)
+        assert z._alignq_bn_part[2] == 2
+        xq, loss = bn_site(bn, act, z, relu=True)
+        total = loss + (xq * gq).sum()
+        if fused_bwd:
+            with DeferredWgrads(fresh_grads=True) as wg:       # all .grad are None here
+                total.backward()
+                wg.flush()
+        else:
+            total.backward()
+        torch.cuda.synchronize()
+        outs.append(dict(dx=npy(x.grad), dw=npy(w.grad), dg=npy(bn.weight.grad), db=npy(bn.bias.grad)))
+    a, b = outs
+    for key in ("dg", "db"):
+        np.testing.assert_allclose(b[key], a[key], rtol=2e-5, atol=1e-6 * float(np.abs(a[key]).max() + 1e-12), err_msg=key)
+    np.testing.assert_allclose(b["dx"], a["dx"], rtol=1e-4, atol=1e-5 * float(np.abs(a["dx"]).max()))
+    np.testing.assert_allclose(b["dw"], a["dw"], rtol=1e-4, atol=1e-5 * float(np.abs(a["dw"]).max()))
+    config.args.bitW = config.args.abitW = 8
+
+
 @pytest.mark.parametrize("B,CIN,COUT,H,ks,k", [(128, 16, 32, 32, 3, 8), (128, 16, 32, 32, 1, 8), (128, 32, 64, 16, 3, 4),
                                                (128, 32, 64, 16, 1, 8), (8, 16, 32, 32, 3, 2), (8, 32, 64, 16, 1, 8)])
 def test_qconv_transition_forward_matches_fp64(dev, B, CIN, COUT, H, ks, k):
