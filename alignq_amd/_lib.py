@@ -51,12 +51,12 @@ SIGNATURES = {
     "alignq_conv3x3_nhwc": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "alignq_conv_gen_bn_parts": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "alignq_conv_gen_nhwc_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
-    "alignq_conv_gen_nhwc_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "alignq_conv_gen_nhwc_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "alignq_conv_stem_bn_parts": (_i, [_i, _i, _i]),
     "alignq_conv_stem_nhwc_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "alignq_conv_stem_nhwc_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "alignq_conv_stem_nhwc_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "alignq_conv_gen_wgrad_ws_bytes": (_sz, [_i, _i, _i]),
-    "alignq_conv_gen_nhwc_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "alignq_conv_gen_nhwc_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "alignq_conv3x3_wgrad_ws_bytes": (_sz, [_i]),
     "alignq_conv3x3_nhwc_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "alignq_conv3x3_nhwc_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

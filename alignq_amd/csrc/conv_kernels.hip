@@ -522,8 +522,16 @@ __global__ __launch_bounds__(256) void dgrad_s2_kernel(const float* __restrict__
       const float4 a4 = *reinterpret_cast<const float4*>(lazy.ab + 4 * c4t);
       const float4 m4 = *reinterpret_cast<const float4*>(lazy.save + 4 * c4t);
       const float4 i4 = *reinterpret_cast<const float4*>(lazy.save + COUT + 4 * c4t);
-      const float4 k0 = *reinterpret_cast<const float4*>(lazy.ktot + 4 * c4t);
-      const float4 k1 = *reinterpret_cast<const float4*>(lazy.ktot + COUT + 4 * c4t);
+      float4 k0, k1;
+      if (lazy.part) {           // (workgroup-uniform) see bn_totals_lds
+        __shared__ __attribute__((aligned(16))) float kt[2 * COUT];
+        bn_totals_lds<COUT>(lazy, kt, blockIdx.x == 0);
+        k0 = *reinterpret_cast<const float4*>(kt + 4 * c4t);
+        k1 = *reinterpret_cast<const float4*>(kt + COUT + 4 * c4t);
+      } else {
+        k0 = *reinterpret_cast<const float4*>(lazy.ktot + 4 * c4t);
+        k1 = *reinterpret_cast<const float4*>(lazy.ktot + COUT + 4 * c4t);
+      }
 #pragma unroll
       for (int it = 0; it < NIT; it++) {
         const int i = tid + 256 * it;
@@ -725,6 +733,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int g = lane >> 4, q = (lane & 15) >> 2, pcol = 4 * (lane & 3);
   f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};      // the two 16-column blocks of k
+  __shared__ __attribute__((aligned(16))) float kt[32];
+  if (lazy.z && lazy.part) bn_totals_lds<16>(lazy, kt, blockIdx.x == 0);      // (workgroup-uniform) totals by this workgroup
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int row0 = tile * 4;
     __syncthreads();
@@ -736,8 +746,9 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
         la = *reinterpret_cast<const f32x4*>(lazy.ab + 4 * c4);
         lm = *reinterpret_cast<const f32x4*>(lazy.save + 4 * c4);
         li = *reinterpret_cast<const f32x4*>(lazy.save + 16 + 4 * c4);
-        lk0 = *reinterpret_cast<const f32x4*>(lazy.ktot + 4 * c4);
-        lk1 = *reinterpret_cast<const f32x4*>(lazy.ktot + 16 + 4 * c4);
+        const float* kp = lazy.part ? kt : lazy.ktot;
+        lk0 = *reinterpret_cast<const f32x4*>(kp + 4 * c4);
+        lk1 = *reinterpret_cast<const f32x4*>(kp + 16 + 4 * c4);
       }
 #pragma unroll
       for (int it = 0; it < 2; it++) {
@@ -1243,6 +1254,17 @@ int launch_wgradgen(const float* x, const float* dy, float* dw, float* ws, int B
 
 }  // namespace
 
+// lazy.ktot == nullptr: fill the in-kernel totals form from the site backward's per-tile sums of a [B, HW, C] tensor
+static int lazy_parts(BnLazy& lazy, const float* dx_part, float* dgamma, float* dbeta, int B, int C, int HW) {
+  if (!lazy.z || lazy.ktot || !dx_part) return 0;
+  const int64_t F = (int64_t)C * HW;
+  const int tf = alignq_site::bwd_tile_features(B, F);
+  if (F % tf || (C > tf && C % tf) || (C < tf && tf % C)) return ALIGNQ_EUNSUPPORTED;
+  lazy.part = dx_part; lazy.n_tiles = (int)(F / tf); lazy.tile_f = tf; lazy.n = (double)B * HW;
+  lazy.dgamma = dgamma; lazy.dbeta = dbeta;
+  return 0;
+}
+
 extern "C" {
 
 // y[b,h,w,co] = sum x[b,h+ky-1,w+kx-1,ci] * wt[co,ky,kx,ci]   (dgrad = 0)
@@ -1318,13 +1340,7 @@ int alignq_conv3x3_nhwc_bwd(const float* x, const float* dy, const float* wt, fl
                             float* bn_dbeta, void* stream) {
   if (bn_z && (!bn_ab || !bn_save || (!bn_ktot && !bn_dx_part))) return ALIGNQ_EINVAL;
   BnLazy lazy{bn_z, bn_ab, bn_save, bn_ktot};
-  if (bn_z && bn_dx_part && !bn_ktot) {          // totals formed inside the kernel from the site backward's per-tile sums
-    const int64_t F = (int64_t)C * H * W;
-    const int tf = alignq_site::bwd_tile_features(B, F);
-    if (F % tf || (C > tf && C % tf) || (C < tf && tf % C)) return ALIGNQ_EUNSUPPORTED;
-    lazy.part = bn_dx_part; lazy.n_tiles = (int)(F / tf); lazy.tile_f = tf; lazy.n = (double)B * H * W;
-    lazy.dgamma = bn_dgamma; lazy.dbeta = bn_dbeta;
-  }
+  if (int rc = lazy_parts(lazy, bn_dx_part, bn_dgamma, bn_dbeta, B, C, H * W)) return rc;   // totals formed inside the kernel
   if (!x || !dy || !wt || !dx || !ws || !n_slabs_out || B < 1 || H < 1) return ALIGNQ_EINVAL;
   if (w_bit < 1 || w_bit > 8) return ALIGNQ_EUNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(wt) |
@@ -1371,11 +1387,12 @@ int alignq_conv_gen_nhwc_fwd(const float* x, const float* wt, float* y, int B, i
 size_t alignq_conv_gen_wgrad_ws_bytes(int CIN, int COUT, int KS) { return (size_t)256 * KS * KS * (size_t)CIN * COUT * sizeof(float); }
 int alignq_conv_gen_nhwc_wgrad(const float* x, const float* dy, float* dw, void* ws, int B, int H_in, int W_in, int CIN,
                                int COUT, int KS, int stride, int* n_slabs_out, const float* bn_z, const float* bn_ab,
-                               const float* bn_save, const float* bn_ktot, void* stream) {
+                               const float* bn_save, const float* bn_ktot, const float* bn_dx_part, void* stream) {
   if (!x || !dy || !ws || B < 1 || (!dw && !n_slabs_out)) return ALIGNQ_EINVAL;
-  if (bn_z && (!bn_ab || !bn_save || !bn_ktot)) return ALIGNQ_EINVAL;
-  const BnLazy lazy{bn_z, bn_ab, bn_save, bn_ktot};
+  if (bn_z && (!bn_ab || !bn_save || (!bn_ktot && !bn_dx_part))) return ALIGNQ_EINVAL;
+  BnLazy lazy{bn_z, bn_ab, bn_save, bn_ktot};
   if (!alignq_conv_gen_bn_parts(B, H_in, W_in, CIN, COUT, KS, stride)) return ALIGNQ_EUNSUPPORTED;
+  if (int rc = lazy_parts(lazy, bn_dx_part, nullptr, nullptr, B, COUT, (H_in / 2) * (W_in / 2))) return rc;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dw)) & 15) return ALIGNQ_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const int H = H_in / 2;
@@ -1390,15 +1407,17 @@ int alignq_conv_gen_nhwc_wgrad(const float* x, const float* dy, float* dw, void*
 // alignq_conv3x3_nhwc_bwd (dy given in the lazy batch-norm form when bn_z != NULL).
 int alignq_conv_gen_nhwc_dgrad(const float* dy, const float* wt, float* dx, int B, int H_in, int W_in, int CIN, int COUT, int KS,
                                int stride, int w_bit, const float* add, const float* bn_z, const float* bn_ab,
-                               const float* bn_save, const float* bn_ktot, void* stream) {
+                               const float* bn_save, const float* bn_ktot, const float* bn_dx_part, float* bn_dgamma,
+                               float* bn_dbeta, void* stream) {
   if (!dy || !wt || !dx || B < 1) return ALIGNQ_EINVAL;
   if (add && (reinterpret_cast<uintptr_t>(add) & 15)) return ALIGNQ_EUNSUPPORTED;
-  if (bn_z && (!bn_ab || !bn_save || !bn_ktot)) return ALIGNQ_EINVAL;
+  if (bn_z && (!bn_ab || !bn_save || (!bn_ktot && !bn_dx_part))) return ALIGNQ_EINVAL;
   if (w_bit < 1 || w_bit > 8 || !alignq_conv_gen_bn_parts(B, H_in, W_in, CIN, COUT, KS, stride)) return ALIGNQ_EUNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(wt) | reinterpret_cast<uintptr_t>(dx)) & 15) return ALIGNQ_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const float nlev = (float)((1 << w_bit) - 1);
-  const BnLazy lazy{bn_z, bn_ab, bn_save, bn_ktot};
+  BnLazy lazy{bn_z, bn_ab, bn_save, bn_ktot};
+  if (int rc = lazy_parts(lazy, bn_dx_part, bn_dgamma, bn_dbeta, B, COUT, (H_in / 2) * (W_in / 2))) return rc;
   if (CIN == 16 && KS == 3) return launch_dgrad_s2<16, 32, 32, 3, 128>(dy, wt, dx, B, H_in, nlev, add, lazy, st);
   if (CIN == 16 && KS == 1) return launch_dgrad_s2<16, 32, 32, 1, 128>(dy, wt, dx, B, H_in, nlev, add, lazy, st);
   if (CIN == 32 && KS == 3) return launch_dgrad_s2<32, 64, 16, 3, 128>(dy, wt, dx, B, H_in, nlev, add, lazy, st);
@@ -1422,14 +1441,16 @@ int alignq_conv_stem_nhwc_fwd(const float* x, const float* wt, float* y, int B, 
 // filter gradient of the stem: dW [16,3,3,3]; ws = 256 * 16 * 27 floats; n_slabs_out / bn_* as in alignq_conv_gen_nhwc_wgrad
 int alignq_conv_stem_nhwc_wgrad(const float* x, const float* dy, float* dw, void* ws, int B, int H, int W, int* n_slabs_out,
                                 const float* bn_z, const float* bn_ab, const float* bn_save, const float* bn_ktot,
-                                void* stream) {
+                                const float* bn_dx_part, float* bn_dgamma, float* bn_dbeta, void* stream) {
   if (!x || !dy || !ws || (!dw && !n_slabs_out)) return ALIGNQ_EINVAL;
-  if (bn_z && (!bn_ab || !bn_save || !bn_ktot)) return ALIGNQ_EINVAL;
+  if (bn_z && (!bn_ab || !bn_save || (!bn_ktot && !bn_dx_part))) return ALIGNQ_EINVAL;
   if (!alignq_conv_stem_bn_parts(B, H, W) || (reinterpret_cast<uintptr_t>(dy) & 15)) return ALIGNQ_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const int n_tiles = B * H / 4;
   const int splits = n_tiles < 256 ? n_tiles : 256;
-  hipLaunchKernelGGL(stem_wgrad_kernel, splits, 256, 0, st, x, dy, (float*)ws, H, n_tiles, BnLazy{bn_z, bn_ab, bn_save, bn_ktot});
+  BnLazy lazy{bn_z, bn_ab, bn_save, bn_ktot};
+  if (int rc = lazy_parts(lazy, bn_dx_part, bn_dgamma, bn_dbeta, B, 16, H * W)) return rc;
+  hipLaunchKernelGGL(stem_wgrad_kernel, splits, 256, 0, st, x, dy, (float*)ws, H, n_tiles, lazy);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   if (n_slabs_out) { *n_slabs_out = splits; return 0; }

@@ -358,11 +358,7 @@ class QConv3x3Fn(torch.autograd.Function):
             pending.add(ws, dw, ns.value, 9 * C * C)
             return dx, dw, None, None, None
         if lazy is not None:               # not the fused path after all: finish the batch-norm input gradient here
-            _, bz, bab, bsave, bk, bpart, bdg, bdb = lazy
-            if bk is None:                 # the totals were left to the fused kernel: form them now
-                bk = torch.empty(2, C, dtype=torch.float32, device=x.device)
-                L.check(lib.alignq_bn_bwd_totals(L.ptr(bpart), B, C, H * W, L.ptr(bk), L.ptr(bdg), L.ptr(bdb), L.stream_ptr()),
-                        "alignq_bn_bwd_totals")
+            bz, bab, bsave, bk = _lazy_fields(lazy, True, B, C, H * W, x.device)[:4]
             shp = (1, C, 1, 1)
             gy = bab[0].view(shp) * (gy - bk[0].view(shp) - (bz - bsave[0].view(shp)) * bsave[1].view(shp) * bk[1].view(shp))
             gy = L.like_layout(gy, x)
@@ -382,6 +378,20 @@ class QConv3x3Fn(torch.autograd.Function):
                 L.check(lib.alignq_conv3x3_nhwc_wgrad(L.ptr(x), L.ptr(gy), L.ptr(dw), L.ptr(ws), B, H, W, C, None,
                                                       L.stream_ptr()), "alignq_conv3x3_nhwc_wgrad")
         return dx, dw, None, None, None
+
+
+def _lazy_fields(lazy, need_totals_now, B, C, HW, device):
+    """(z, ab, save, ktot, part, dgamma, dbeta) of a lazy batch-norm record (fused.post_lazy_dz); when the record carries the
+    site backward's per-tile sums instead of finished totals and the caller's kernels cannot publish the parameter gradients
+    (need_totals_now), the totals are formed here (alignq_bn_bwd_totals)."""
+    if lazy is None:
+        return (None,) * 7
+    bz, bab, bsave, bk, bpart, bdg, bdb = lazy[1:8]
+    if bk is None and need_totals_now:
+        bk = torch.empty(2, C, dtype=torch.float32, device=device)
+        L.check(L.load().alignq_bn_bwd_totals(L.ptr(bpart), B, C, HW, L.ptr(bk), L.ptr(bdg), L.ptr(bdb), L.stream_ptr()),
+                "alignq_bn_bwd_totals")
+    return bz, bab, bsave, bk, (bpart if bk is None else None), bdg, bdb
 
 
 def qconv_gen_supported(x, w, stride, padding, dilation, groups, bias, w_bit) -> bool:
@@ -424,7 +434,8 @@ class QConvGenFn(torch.autograd.Function):
                                              L.stream_ptr()), "alignq_conv_gen_nhwc_fwd")
         ctx.save_for_backward(x, w)
         ctx.w_bit = int(w_bit)
-        QConv3x3Fn._mailbox = (part, n_parts, True)
+        # 2: the data-gradient kernel reduces the site backward's per-tile sums and publishes the BN parameter gradients
+        QConv3x3Fn._mailbox = (part, n_parts, 2 if x.requires_grad else 1)
         if tap:
             ctx.set_materialize_grads(False)
             return y, x.view_as(x)
@@ -438,16 +449,17 @@ class QConvGenFn(torch.autograd.Function):
         add = None if gtap is None else L.like_layout(gtap, x)
         lazy = fused.take_lazy_dz(gy)      # (g, z, ab, save, ktot): gy is the gradient w.r.t. the folded BN's OUTPUT
         gy = gy.contiguous(memory_format=torch.channels_last)
-        bz, bab, bsave, bk = (lazy[1], lazy[2], lazy[3], lazy[4]) if lazy is not None else (None, None, None, None)
         B, CIN, H, W = x.shape
         COUT, ks = w.shape[0], w.shape[2]
+        bz, bab, bsave, bk, bpart, bdg, bdb = _lazy_fields(lazy, not ctx.needs_input_grad[0], B, COUT, (H // 2) * (W // 2),
+                                                           x.device)
         lib = L.load()
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             L.check(lib.alignq_conv_gen_nhwc_dgrad(L.ptr(gy), L.ptr(w), L.ptr(dx), B, H, W, CIN, COUT, ks, 2, ctx.w_bit,
-                                                   L.ptr(add), L.ptr(bz), L.ptr(bab), L.ptr(bsave), L.ptr(bk),
-                                                   L.stream_ptr()), "alignq_conv_gen_nhwc_dgrad")
+                                                   L.ptr(add), L.ptr(bz), L.ptr(bab), L.ptr(bsave), L.ptr(bk), L.ptr(bpart),
+                                                   L.ptr(bdg), L.ptr(bdb), L.stream_ptr()), "alignq_conv_gen_nhwc_dgrad")
         elif add is not None:
             dx = add
         if ctx.needs_input_grad[1]:        # split-bf16 MFMA, deterministic slabs
@@ -458,12 +470,12 @@ class QConvGenFn(torch.autograd.Function):
                 ns = ctypes.c_int(0)
                 L.check(lib.alignq_conv_gen_nhwc_wgrad(L.ptr(x), L.ptr(gy), None, L.ptr(ws), B, H, W, CIN, COUT, ks, 2,
                                                        ctypes.byref(ns), L.ptr(bz), L.ptr(bab), L.ptr(bsave), L.ptr(bk),
-                                                       L.stream_ptr()), "alignq_conv_gen_nhwc_wgrad")
+                                                       L.ptr(bpart), L.stream_ptr()), "alignq_conv_gen_nhwc_wgrad")
                 pending.add(ws, dw, ns.value, ks * ks * CIN * COUT)
             else:
                 L.check(lib.alignq_conv_gen_nhwc_wgrad(L.ptr(x), L.ptr(gy), L.ptr(dw), L.ptr(ws), B, H, W, CIN, COUT, ks, 2,
-                                                       None, L.ptr(bz), L.ptr(bab), L.ptr(bsave), L.ptr(bk), L.stream_ptr()),
-                        "alignq_conv_gen_nhwc_wgrad")
+                                                       None, L.ptr(bz), L.ptr(bab), L.ptr(bsave), L.ptr(bk), L.ptr(bpart),
+                                                       L.stream_ptr()), "alignq_conv_gen_nhwc_wgrad")
         return dx, dw, None, None, None
 
     @staticmethod
@@ -505,7 +517,8 @@ class QConvStemFn(torch.autograd.Function):
         L.check(lib.alignq_conv_stem_nhwc_fwd(L.ptr(x), L.ptr(w), L.ptr(y), B, H, W, int(w_bit), L.ptr(part), L.stream_ptr()),
                 "alignq_conv_stem_nhwc_fwd")
         ctx.save_for_backward(x, w)
-        QConv3x3Fn._mailbox = (part, n_parts, True)
+        # 2: the filter-gradient kernel (the stem's only gradient) reduces the site backward's per-tile sums itself
+        QConv3x3Fn._mailbox = (part, n_parts, 2 if w.requires_grad else 1)
         return y
 
     @staticmethod
@@ -513,8 +526,8 @@ class QConvStemFn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         lazy = fused.take_lazy_dz(gy)
         gy = gy.contiguous(memory_format=torch.channels_last)
-        bz, bab, bsave, bk = (lazy[1], lazy[2], lazy[3], lazy[4]) if lazy is not None else (None, None, None, None)
         B, _, H, W = x.shape
+        bz, bab, bsave, bk, bpart, bdg, bdb = _lazy_fields(lazy, not ctx.needs_input_grad[1], B, 16, H * W, x.device)
         lib = L.load()
         dw = None
         if ctx.needs_input_grad[1]:
@@ -524,13 +537,13 @@ class QConvStemFn(torch.autograd.Function):
             if pending is not None:
                 ns = ctypes.c_int(0)
                 L.check(lib.alignq_conv_stem_nhwc_wgrad(L.ptr(x), L.ptr(gy), None, L.ptr(ws), B, H, W, ctypes.byref(ns),
-                                                        L.ptr(bz), L.ptr(bab), L.ptr(bsave), L.ptr(bk), L.stream_ptr()),
-                        "alignq_conv_stem_nhwc_wgrad")
+                                                        L.ptr(bz), L.ptr(bab), L.ptr(bsave), L.ptr(bk), L.ptr(bpart),
+                                                        L.ptr(bdg), L.ptr(bdb), L.stream_ptr()), "alignq_conv_stem_nhwc_wgrad")
                 pending.add(ws, dw, ns.value, 16 * 27)
             else:
                 L.check(lib.alignq_conv_stem_nhwc_wgrad(L.ptr(x), L.ptr(gy), L.ptr(dw), L.ptr(ws), B, H, W, None, L.ptr(bz),
-                                                        L.ptr(bab), L.ptr(bsave), L.ptr(bk), L.stream_ptr()),
-                        "alignq_conv_stem_nhwc_wgrad")
+                                                        L.ptr(bab), L.ptr(bsave), L.ptr(bk), L.ptr(bpart), L.ptr(bdg),
+                                                        L.ptr(bdb), L.stream_ptr()), "alignq_conv_stem_nhwc_wgrad")
         return None, dw, None
 
     @staticmethod

@@ -200,11 +200,14 @@ int alignq_conv_gen_bn_parts(int B, int H_in, int W_in, int CIN, int COUT, int K
 int alignq_conv_gen_nhwc_fwd(const float* x, const float* wt, float* y, int B, int H_in, int W_in, int CIN, int COUT, int KS,
                              int stride, int w_bit, float* bn_part, void* stream);
 
-/* data gradient of the transition convolutions; bn_* as in alignq_conv3x3_nhwc_bwd (lazy batch-norm form of dy); add (or NULL):
+/* data gradient of the transition convolutions; bn_* as in alignq_conv3x3_nhwc_bwd (lazy batch-norm form of dy, incl. the
+ * in-kernel totals form bn_ktot == NULL + bn_dx_part; the filter-gradient entry points take bn_dx_part too but leave the
+ * parameter gradients to the data-gradient kernel — the stem has none, so its filter gradient writes them); add (or NULL):
  * a tensor of dx's shape added in the epilogue (the gradient the block's other branch sends to the same input) */
 int alignq_conv_gen_nhwc_dgrad(const float* dy, const float* wt, float* dx, int B, int H_in, int W_in, int CIN, int COUT, int KS,
                                int stride, int w_bit, const float* add, const float* bn_z, const float* bn_ab,
-                               const float* bn_save, const float* bn_ktot, void* stream);
+                               const float* bn_save, const float* bn_ktot, const float* bn_dx_part, float* bn_dgamma,
+                               float* bn_dbeta, void* stream);
 
 /* The stem (3 -> 16 channels, 3x3, stride 1, padding 1, width 32; x [B,H,32,3], wt [16,3,3,3], y [B,H,32,16], channels-last):
  * forward with the optional batch-norm partials, and its filter gradient (ws: 256 * 432 floats); K = 27 is one MFMA k step
@@ -214,7 +217,7 @@ int alignq_conv_stem_nhwc_fwd(const float* x, const float* wt, float* y, int B, 
                               void* stream);
 int alignq_conv_stem_nhwc_wgrad(const float* x, const float* dy, float* dw, void* ws, int B, int H, int W, int* n_slabs_out,
                                 const float* bn_z, const float* bn_ab, const float* bn_save, const float* bn_ktot,
-                                void* stream);
+                                const float* bn_dx_part, float* bn_dgamma, float* bn_dbeta, void* stream);
 
 /* Filter gradient of the same convolution, dW [C,3,3,C] (channels-last weight storage) from x and dy: plain fp32 on the f32
  * MFMAs (products and accumulation bit-for-bit an fmaf chain), per-pixel-range partial sums in ws
@@ -230,7 +233,7 @@ int alignq_conv3x3_wgrad_reduce_multi(int T, const void* const* ws, float* const
 size_t alignq_conv_gen_wgrad_ws_bytes(int CIN, int COUT, int KS);
 int alignq_conv_gen_nhwc_wgrad(const float* x, const float* dy, float* dw, void* ws, int B, int H_in, int W_in, int CIN,
                                int COUT, int KS, int stride, int* n_slabs_out, const float* bn_z, const float* bn_ab,
-                               const float* bn_save, const float* bn_ktot, void* stream);
+                               const float* bn_save, const float* bn_ktot, const float* bn_dx_part, void* stream);
 
 /* Data gradient AND filter-gradient partial sums of one convolution in a single launch (workgroup roles by block index; the
  * two are independent and fill the chip together).  The slabs left in ws are finished by alignq_conv3x3_wgrad_reduce_multi.
