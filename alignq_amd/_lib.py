@@ -12,7 +12,7 @@ SO_PATH = os.path.join(_HERE, "lib", "libalignq_hip.so")
 
 FORMULA_ADMM, FORMULA_CDF = 0, 1
 MAX_BATCH = 128
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _c = ctypes
 _vp, _i, _i64, _f, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_size_t
