@@ -26,7 +26,8 @@ inline int grid_for(int64_t n_vec) {
 }
 
 // ------------------------------------------------------------------ activations ---------------
-template <int FORMULA, bool BINS>
+// RELU: stores relu(x_q) — `self.relu(self.act_q(...))` of the Office bottleneck (dann_office/model/resnet.py:137-138, 142-143) in one pass
+template <int FORMULA, bool BINS, bool RELU = false>
 __global__ __launch_bounds__(kThreads) void act_quant_fwd_kernel(const float* __restrict__ x,
                                                                  float* __restrict__ xq,
                                                                  int32_t* __restrict__ bins, int64_t n,
@@ -44,6 +45,7 @@ __global__ __launch_bounds__(kThreads) void act_quant_fwd_kernel(const float* __
     o.y = act_quant1<FORMULA>(v.y, k, nlev, r, &t, &b1);
     o.z = act_quant1<FORMULA>(v.z, k, nlev, r, &t, &b2);
     o.w = act_quant1<FORMULA>(v.w, k, nlev, r, &t, &b3);
+    if (RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
     q4[i] = o;
     if (BINS) {
       int4 bi = make_int4((int)b0, (int)b1, (int)b2, (int)b3);
@@ -54,7 +56,8 @@ __global__ __launch_bounds__(kThreads) void act_quant_fwd_kernel(const float* __
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     int64_t i = (nvec << 2) + threadIdx.x;
     float t, b;
-    xq[i] = act_quant1<FORMULA>(x[i], k, nlev, r, &t, &b);
+    const float q = act_quant1<FORMULA>(x[i], k, nlev, r, &t, &b);
+    xq[i] = RELU ? fmaxf(q, 0.f) : q;
     if (BINS) bins[i] = (int)b;
   }
 }
@@ -70,8 +73,11 @@ __global__ __launch_bounds__(kThreads) void uniform_quantize_kernel(const float*
   }
 }
 
+// MASK: y = the forward's relu(x_q); the ReLU's backward (g where y > 0, else 0) is applied on load
+template <bool MASK>
 __global__ __launch_bounds__(kThreads) void act_quant_bwd_kernel(const float* __restrict__ g,
                                                                  const float* __restrict__ x,
+                                                                 const float* __restrict__ y,
                                                                  float* __restrict__ dx, int64_t n, float r) {
   const int64_t nvec = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * kThreads;
@@ -80,6 +86,11 @@ __global__ __launch_bounds__(kThreads) void act_quant_bwd_kernel(const float* __
   float4* d4 = reinterpret_cast<float4*>(dx);
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += stride) {
     float4 gv = g4[i], xv = x4[i], o;
+    if (MASK) {
+      const float4 yv = reinterpret_cast<const float4*>(y)[i];
+      gv.x = yv.x > 0.f ? gv.x : 0.f; gv.y = yv.y > 0.f ? gv.y : 0.f;
+      gv.z = yv.z > 0.f ? gv.z : 0.f; gv.w = yv.w > 0.f ? gv.w : 0.f;
+    }
     o.x = gv.x * act_jac(xv.x, r);
     o.y = gv.y * act_jac(xv.y, r);
     o.z = gv.z * act_jac(xv.z, r);
@@ -88,7 +99,7 @@ __global__ __launch_bounds__(kThreads) void act_quant_bwd_kernel(const float* __
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     int64_t i = (nvec << 2) + threadIdx.x;
-    dx[i] = g[i] * act_jac(x[i], r);
+    dx[i] = ((MASK && !(y[i] > 0.f)) ? 0.f : g[i]) * act_jac(x[i], r);
   }
 }
 
@@ -246,7 +257,33 @@ int alignq_act_quant_bwd(const float* g, const float* x, float* dx, int64_t n, f
   if (!g || !x || !dx || n <= 0) return ALIGNQ_EINVAL;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(dx)) & 15)
     return ALIGNQ_EINVAL;
-  hipLaunchKernelGGL(act_quant_bwd_kernel, grid_for(n >> 2), kThreads, 0, (hipStream_t)stream, g, x, dx, n, act_range);
+  hipLaunchKernelGGL(act_quant_bwd_kernel<false>, grid_for(n >> 2), kThreads, 0, (hipStream_t)stream, g, x, nullptr, dx, n, act_range);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int alignq_act_quant_relu_fwd(const float* x, float* y, int64_t n, int k, float act_range, int formula, void* stream) {
+  if (!x || !y || n <= 0) return ALIGNQ_EINVAL;
+  if (!((k >= 1 && k <= 16) || k == 32)) return ALIGNQ_EINVAL;
+  if (formula != ALIGNQ_FORMULA_ADMM && formula != ALIGNQ_FORMULA_CDF) return ALIGNQ_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) return ALIGNQ_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = grid_for(n >> 2);
+  if (formula == ALIGNQ_FORMULA_ADMM)
+    hipLaunchKernelGGL((act_quant_fwd_kernel<0, false, true>), grid, kThreads, 0, st, x, y, nullptr, n, k, act_range);
+  else
+    hipLaunchKernelGGL((act_quant_fwd_kernel<1, false, true>), grid, kThreads, 0, st, x, y, nullptr, n, k, act_range);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int alignq_act_quant_relu_bwd(const float* g, const float* x, const float* y, float* dx, int64_t n, float act_range,
+                              void* stream) {
+  if (!g || !x || !y || !dx || n <= 0) return ALIGNQ_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(dx) |
+       reinterpret_cast<uintptr_t>(y)) & 15)
+    return ALIGNQ_EINVAL;
+  hipLaunchKernelGGL(act_quant_bwd_kernel<true>, grid_for(n >> 2), kThreads, 0, (hipStream_t)stream, g, x, y, dx, n, act_range);
   LAUNCH_CHECK();
   return 0;
 }

@@ -61,6 +61,30 @@ class ActQuantFn(torch.autograd.Function):
         return dx, None, None, None
 
 
+class ActQuantReluFn(torch.autograd.Function):
+    """relu(activation_quantize_fn(x)) — `self.relu(self.act_q1(...))` of the Office bottleneck (dann_office/model/
+    resnet.py:137-138, 142-143) — as one launch each way (alignq_act_quant_relu_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, k, act_range, formula):
+        x = L.dense_f32(x, "activation")
+        y = torch.empty_like(x)
+        L.check(L.load().alignq_act_quant_relu_fwd(L.ptr(x), L.ptr(y), x.numel(), int(k), float(act_range), int(formula),
+                                                   L.stream_ptr()), "alignq_act_quant_relu_fwd")
+        ctx.save_for_backward(x, y)
+        ctx.act_range = float(act_range)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        g = L.like_layout(g, x)
+        dx = torch.empty_like(x)
+        L.check(L.load().alignq_act_quant_relu_bwd(L.ptr(g), L.ptr(x), L.ptr(y), L.ptr(dx), x.numel(), ctx.act_range,
+                                                   L.stream_ptr()), "alignq_act_quant_relu_bwd")
+        return dx, None, None, None
+
+
 def act_quant_bins(x, k, act_range, formula):
     """Parity instrumentation: (x_q, int32 bins) of the activation quantiser."""
     x = L.dev_f32(x, "activation")

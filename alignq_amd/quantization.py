@@ -95,6 +95,12 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
             return _AttachGrad.apply(x, c, pdf * 0.5) if x.requires_grad else c
         return ops.ActQuantFn.apply(x, a_bit, config.args.act_range, formula)
 
+    def _plain_act_relu(x, a_bit, stage):
+        """relu(_plain_act(x)); one launch each way when the quantiser is active."""
+        if (a_bit == 32) or not (x.is_cuda and x.dtype == torch.float32 and x.numel() % 4 == 0):
+            return torch.relu(_plain_act(x, a_bit, stage))
+        return ops.ActQuantReluFn.apply(x, a_bit, config.args.act_range, formula)
+
     def _site_act(mod, x):
         a_bit = mod.a_bit
         if a_bit == 32 and mod.stage != "align":
@@ -129,6 +135,10 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
 
         def forward(self, x):
             return _plain_act(x, self.a_bit, self.stage)
+
+        def forward_relu(self, x):
+            """relu(self(x)) in one launch each way (not part of the reference's interface: an opt-in for the caller)."""
+            return _plain_act_relu(x, self.a_bit, self.stage)
 
     class _act_admm(nn.Module):
         def __init__(self, a_bit, stage, admm):

@@ -47,8 +47,12 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         trans_loss = 0.
         identity = x
-        out = self.relu(self.act_q1(self.bn1(self.conv1(x))))
-        out = self.relu(self.act_q2(self.bn2(self.conv2(out))))
+        if getattr(self, "fuse_relu", False):       # opt-in (OfficeTrainStep): quantiser + ReLU in one launch each way
+            out = self.act_q1.forward_relu(self.bn1(self.conv1(x)))
+            out = self.act_q2.forward_relu(self.bn2(self.conv2(out)))
+        else:
+            out = self.relu(self.act_q1(self.bn1(self.conv1(x))))
+            out = self.relu(self.act_q2(self.bn2(self.conv2(out))))
         out, loss = self.act_q3(self.bn3(self.conv3(out)))
         trans_loss += loss
         if self.downsample is not None:
@@ -94,7 +98,10 @@ class ResNet(nn.Module):
 
     def forward(self, x):
         trans_loss = 0.
-        x = self.maxpool(self.relu(self.act_q0(self.bn1(self.conv1(x)))))
+        if getattr(self, "fuse_relu", False):
+            x = self.maxpool(self.act_q0.forward_relu(self.bn1(self.conv1(x))))
+        else:
+            x = self.maxpool(self.relu(self.act_q0(self.bn1(self.conv1(x)))))
         for layers in (self.layer1, self.layer2, self.layer3, self.layer4):
             for layer in layers:
                 x, loss = layer(x)

@@ -58,6 +58,13 @@ int alignq_act_quant_fwd(const float* x, float* xq, int32_t* bins, int64_t n, in
 int alignq_act_quant_bwd(const float* g, const float* x, float* dx, int64_t n, float act_range,
                          void* stream);
 
+/* The same pair with a ReLU after the quantiser — `self.relu(self.act_q1(self.bn1(...)))` of the Office bottleneck
+ * (cdf_alignment_admm/dann_office/model/resnet.py:137-138, :142-143) — in one pass each way: y = relu(x_q); backward
+ * dx = (y > 0 ? g : 0) * d t / d x. */
+int alignq_act_quant_relu_fwd(const float* x, float* y, int64_t N, int k, float act_range, int formula, void* stream);
+int alignq_act_quant_relu_bwd(const float* g, const float* x, const float* y, float* dx, int64_t N, float act_range,
+                              void* stream);
+
 /* ---- R3: weight quantisation -------------------------------------------------------------------
  * stats: torch.mean / torch.std (unbiased) over all n elements (model/quantization.py:78).
  *        ms: device float[2] = {mean, std}.  ws: alignq_weight_ws_bytes(n) bytes of scratch.        */
