@@ -170,6 +170,11 @@ class TrainStep:
                 self._iteration(sx, sy, set_to_none=False)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if self.grad_hook is not None and torch.distributed.is_available() and torch.distributed.is_initialized():
+            # the warm-up iterations issued collectives: give the process group's watchdog thread (it polls completion
+            # events every 100 ms) time to retire them, so that it does not touch the HIP runtime while streams are capturing
+            import time
+            time.sleep(0.5)
         graph = torch.cuda.CUDAGraph()
         self._graph2 = None
         # inside the capture grads are re-created (set_to_none=True): no zero-fill and no accumulate-add per
