@@ -405,6 +405,48 @@ def test_tiny_resnet_two_steps_vs_reference(dev):
         config.args.train_batch_size = 128
 
 
+def test_cdf_only_tree_two_steps_vs_oracle(dev):
+    """BASELINE config 1's tree (cdf_alignment/resnet-20-cifar-10: CDF quantisers, no ADMM sites, plain momentum SGD because
+    main.py:308 crashes as shipped — SURVEY F6a): a small PreActResNet, two full iterations of TrainStep against the
+    eager-torch oracle on the same GPU from the same initial state.  The two differ by last-ulp quantiser arithmetic, so
+    whole-network values are compared at bin-flip scale (see test_tiny_resnet_two_steps_vs_reference)."""
+    from alignq_amd import config
+    from alignq_amd.resnet import PreActBlock_conv_Q, PreActResNet
+    from alignq_amd.train_step import TrainStep
+    from oracle import torch_ref as R
+    config.args.bitW = config.args.abitW = 4
+    config.args.train_batch_size = 8
+    try:
+        torch.manual_seed(21)
+        net = PreActResNet(PreActBlock_conv_Q, [1, 1, 1], 4, 4, "second", 10, tree="cdf").to(dev).train()
+        cfg = R.Config(tree="cdf", bitW=4, abitW=4, train_batch_size=8)
+        onet = R.PreActResNet(cfg, [1, 1, 1], 4, 4)
+        onet.load_state_dict({k: v.detach().cpu().clone() for k, v in net.state_dict().items()}, strict=True)
+        onet = onet.to(dev).train()
+        step, ostep = TrainStep(net), R.TrainStep(onet, cfg)
+        assert not step.admms
+        g = torch.Generator().manual_seed(5)
+        for it in range(2):
+            x = torch.randn(8, 3, 32, 32, generator=g).to(dev)
+            y = torch.randint(0, 10, (8,), generator=g).to(dev)
+            logits, ce, tl = step(x, y)
+            ologits, oce, _ = ostep(x, y)
+            assert tl is None or float(tl) == 0.0
+            d = np.abs(npy(logits) - npy(ologits))
+            assert np.median(d) < (5e-3 if it == 0 else 3e-2) and d.max() < (3e-2 if it == 0 else 0.15), (np.median(d), d.max())
+            np.testing.assert_allclose(float(ce.detach()), float(oce.detach()), atol=3e-3 if it == 0 else 3e-2)
+        got, ogot = net.state_dict(), onet.state_dict()
+        for name, v in ogot.items():
+            if "num_batches" in name:
+                continue
+            ref_v = npy(v)
+            dd = np.abs(npy(got[name]) - ref_v) / (np.abs(ref_v) + 0.1)
+            assert np.median(dd) < 2e-2, (name, float(np.median(dd)), float(dd.max()))
+    finally:
+        config.args.bitW = config.args.abitW = 8
+        config.args.train_batch_size = 128
+
+
 def test_graph_capture_matches_eager(dev):
     """The captured HIP graph of the full iteration reproduces eager iterations."""
     from alignq_amd import config
