@@ -33,6 +33,7 @@ SIGNATURES = {
     "alignq_site_ws_bytes": (_sz, [_i, _i64]),
     "alignq_site_fwd": (_i, [_vp, _i, _i64, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "alignq_site_partials": (_i, [_vp, _i, _i64, _i, _f, _f, _vp, _vp, _vp, _vp]),
+    "alignq_site_partials_res": (_i, [_vp, _i, _i64, _i, _f, _f, _vp, _i, _vp, _vp, _vp, _vp]),
     "alignq_site_reduce": (_i, [_vp, _i, _i64, _vp, _vp]),
     "alignq_site_reduce_loss": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _i, _f, _f, _vp, _vp]),
     "alignq_site_bwd_ws_bytes": (_sz, [_i]),

@@ -93,11 +93,14 @@ __device__ __forceinline__ void gram32(const unsigned* __restrict__ W, int l31, 
 }
 
 // ================================================================================================ forward
-template <bool PAIR>
+// res (or nullptr): a [B,F] tensor added to x_q before it is stored (the bottleneck's `out += identity`); relu: store relu(.)
+// (`out = self.relu(out)`): dann_office/model/resnet.py:153-154 — the stored tensor is what the next layer reads.
+template <bool PAIR, bool RES>
 __global__ __launch_bounds__(kThreads1) void site1_fwd_kernel(const float* __restrict__ x, int B, int64_t F, int k,
                                                               float r, float eps, float* __restrict__ xq,
                                                               float* __restrict__ slabs, float* __restrict__ stats,
-                                                              int n_sub, unsigned* __restrict__ counter) {
+                                                              int n_sub, unsigned* __restrict__ counter,
+                                                              const float* __restrict__ res, int relu) {
   __shared__ __attribute__((aligned(16))) unsigned lds[(kWaves * WBUF > 4096) ? kWaves * WBUF : 4096];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;      // h doubles as the row half of the load mapping
@@ -115,9 +118,14 @@ __global__ __launch_bounds__(kThreads1) void site1_fwd_kernel(const float* __res
     const bool cok = col < F;
     const float* __restrict__ xp = x + (int64_t)(RPL * h) * F + col;
     float* __restrict__ qp = xq ? xq + (int64_t)(RPL * h) * F + col : nullptr;
-    float xr[RPL], tr[RPL];
+    float xr[RPL], tr[RPL], rr[RES ? RPL : 1];
 #pragma unroll
     for (int q = 0; q < RPL; q++) xr[q] = (cok && RPL * h + q < B) ? xp[(int64_t)q * F] : 0.0f;
+    if (PAIR && RES) {        // the shortcut rows: in flight under the transform below
+      const float* __restrict__ rp = res + (int64_t)(RPL * h) * F + col;
+#pragma unroll
+      for (int q = 0; q < RPL; q++) rr[q] = (cok && RPL * h + q < B) ? rp[(int64_t)q * F] : 0.0f;
+    }
     // ---- transform + quantise; batch statistics: registers + one cross-half shuffle ---------------------------
     float sx = 0.f, st = 0.f;
 #pragma unroll
@@ -126,7 +134,9 @@ __global__ __launch_bounds__(kThreads1) void site1_fwd_kernel(const float* __res
       if (RPL * h + q < B) {
         if (PAIR) {
           float b;
-          const float qq = act_quant1<0>(xr[q], k, nlev, r, &tr[q], &b);
+          float qq = act_quant1<0>(xr[q], k, nlev, r, &tr[q], &b);
+          if (RES) qq += rr[q];
+          if (relu) qq = fmaxf(qq, 0.0f);
           if (qp && cok) qp[(int64_t)q * F] = qq;
           st += tr[q];
         }
@@ -346,11 +356,12 @@ __global__ __launch_bounds__(kThreads1) void site1_bwd_kernel(const float* __res
 }  // namespace
 
 int launch_partials1(bool pair, const Geom& g, const float* x, int B, int64_t F, int k, float r, float eps, float* xq,
-                     float* stats, float* ws, hipStream_t st) {
+                     float* stats, float* ws, hipStream_t st, const float* res, int relu) {
   unsigned* counter = reinterpret_cast<unsigned*>(ws + (size_t)g.grid * g.slab_floats + kPartFloats);
   const int n_sub = (int)((F + SUBF - 1) / SUBF);
-  if (pair) hipLaunchKernelGGL((site1_fwd_kernel<true>), g.grid, kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter);
-  else hipLaunchKernelGGL((site1_fwd_kernel<false>), g.grid, kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter);
+  if (pair && res) hipLaunchKernelGGL((site1_fwd_kernel<true, true>), g.grid, kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter, res, relu);
+  else if (pair) hipLaunchKernelGGL((site1_fwd_kernel<true, false>), g.grid, kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter, nullptr, relu);
+  else hipLaunchKernelGGL((site1_fwd_kernel<false, false>), g.grid, kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter, nullptr, 0);
   RET_ON_ERR1();
   return 0;
 }

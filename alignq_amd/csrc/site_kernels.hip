@@ -504,6 +504,18 @@ int alignq_site_partials(const float* x, int B, int64_t F, int k, float act_rang
   return launch_partials<true>(geom(B, F), x, B, F, k, act_range, eps, xq, stats, (float*)ws, (hipStream_t)stream);
 }
 
+// Small batches (B <= 32, the Office tree's 28): the same launch with the bottleneck's `out += identity; out = relu(out)`
+// (dann_office/model/resnet.py:153-154) folded into the store of x_q.
+int alignq_site_partials_res(const float* x, int B, int64_t F, int k, float act_range, float eps, const float* residual,
+                             int relu, float* y, float* stats, void* ws, void* stream) {
+  if (!x || !ws || !y) return ALIGNQ_EINVAL;
+  if (bad_shape(B, F)) return F <= 0 ? ALIGNQ_EINVAL : ALIGNQ_EUNSUPPORTED;
+  if (bad_k(k)) return ALIGNQ_EINVAL;
+  const Geom g = geom(B, F);
+  if (g.nb != 1) return ALIGNQ_EUNSUPPORTED;
+  return launch_partials1(true, g, x, B, F, k, act_range, eps, y, stats, (float*)ws, (hipStream_t)stream, residual, relu);
+}
+
 int alignq_site_reduce(const void* ws, int B, int64_t F, float* D, void* stream) {
   if (!ws || !D) return ALIGNQ_EINVAL;
   if (bad_shape(B, F)) return F <= 0 ? ALIGNQ_EINVAL : ALIGNQ_EUNSUPPORTED;

@@ -214,8 +214,11 @@ class SiteFn(torch.autograd.Function):
     gradient prep; fused standardisation-backward + MFMA kernel).  D is returned for ADMM_OPT.step (values only)."""
 
     @staticmethod
-    def forward(ctx, x, alterD, gamma, k, act_range, eps, mu, rho, side=None, bufs=None, rec=None):
-        """side: optional torch.cuda.Stream for the slab reduction + loss (it is off the critical path of the
+    def forward(ctx, x, alterD, gamma, k, act_range, eps, mu, rho, side=None, bufs=None, rec=None, residual=None,
+                relu=False):
+        """residual / relu (batches <= 32 only, see site_res_supported): the first output is relu(x_q + residual) — the Office
+        bottleneck's `out += identity; out = self.relu(out)` folded into the site forward kernel.
+        side: optional torch.cuda.Stream for the slab reduction + loss (it is off the critical path of the
         network's forward: only x_q feeds the next layer); the CALLER must make the consuming stream wait for it.
         bufs: optional dict of persistent per-site buffers (ws, D, scal) — required with `side` so that no
         allocator block is recycled under in-flight side-stream work.
@@ -242,8 +245,16 @@ class SiteFn(torch.autograd.Function):
             if bufs is not None:
                 bufs.update(key=key, ws=ws, D=D, scal=scal)
         st = L.stream_ptr()
-        L.check(lib.alignq_site_partials(L.ptr(x), B, F, int(k), float(act_range), float(eps), L.ptr(xq),
-                                         L.ptr(stats), L.ptr(ws), st), "alignq_site_partials")
+        fold = residual is not None or relu
+        if fold:
+            if residual is not None:
+                residual = L.like_layout(L.dense_f32(residual, "residual"), x)
+            L.check(lib.alignq_site_partials_res(L.ptr(x), B, F, int(k), float(act_range), float(eps), L.ptr(residual),
+                                                 int(bool(relu)), L.ptr(xq), L.ptr(stats), L.ptr(ws), st),
+                    "alignq_site_partials_res")
+        else:
+            L.check(lib.alignq_site_partials(L.ptr(x), B, F, int(k), float(act_range), float(eps), L.ptr(xq),
+                                             L.ptr(stats), L.ptr(ws), st), "alignq_site_partials")
         if side is not None and bufs is not None:
             side.wait_stream(torch.cuda.current_stream())
             st = side.cuda_stream
@@ -255,15 +266,16 @@ class SiteFn(torch.autograd.Function):
                                                 float(rho), L.ptr(scal), st), "alignq_site_reduce_loss")
         loss = scal[0]
         ctx.rec = rec
-        ctx.save_for_backward(x, stats, D, A, Gm, scal)
+        ctx.save_for_backward(x, stats, D, A, Gm, scal, xq if (fold and relu) else None)
         ctx.set_materialize_grads(False)     # no zero-filled [B,B] gradient for the non-differentiable D
         ctx.cfg = (float(act_range), float(eps), float(mu))
+        ctx.fold = (bool(fold), residual is not None)
         ctx.mark_non_differentiable(D)
         return xq, loss, D
 
     @staticmethod
     def backward(ctx, g_xq, g_loss, _gD):
-        x, stats, D, A, Gm, scal = ctx.saved_tensors
+        x, stats, D, A, Gm, scal, y = ctx.saved_tensors
         act_range, eps, mu = ctx.cfg
         B, F = _as_bf(x)
         dim = A.shape[0]
@@ -274,17 +286,34 @@ class SiteFn(torch.autograd.Function):
         lib = L.load()
         dx = torch.empty_like(x)
         rec = ctx.rec
+        fold, has_res = ctx.fold
+        dres = None
+        if fold and g_xq is not None:
+            # the ReLU's backward stays a pass of its own (its result is also the residual's gradient: folding it into the
+            # site backward saves no bytes and ran slower); the site backward then sees the masked gradient
+            if y is not None:
+                g_xq = torch.ops.aten.threshold_backward(g_xq, y, 0.0)
+            if has_res and ctx.needs_input_grad[11]:
+                dres = g_xq
         if rec is not None and rec.prepared:
             L.check(lib.alignq_site_bwd_apply(L.ptr(g_xq), L.ptr(rec.S), L.ptr(x), L.ptr(stats), B, F, act_range, eps,
                                               L.ptr(dx), L.stream_ptr()), "alignq_site_bwd_apply")
             dA, dG, rec.dA, rec.dG = rec.dA, rec.dG, None, None     # sole owner: AccumulateGrad takes them without a copy
-            return dx, dA, dG, None, None, None, None, None, None, None, None
+            return dx, dA, dG, None, None, None, None, None, None, None, None, dres, None
         dA, dG = torch.empty_like(A), torch.empty_like(Gm)
         ws = _ws(lib.alignq_site_bwd_ws_bytes(B), x.device)
         L.check(lib.alignq_site_bwd_fused(L.ptr(g_xq), L.ptr(D), L.ptr(A), L.ptr(Gm), dim, L.ptr(scal), mu,
                                           L.ptr(g_loss), L.ptr(x), L.ptr(stats), B, F, act_range, eps, L.ptr(dx),
                                           L.ptr(dA), L.ptr(dG), L.ptr(ws), L.stream_ptr()), "alignq_site_bwd_fused")
-        return dx, dA, dG, None, None, None, None, None, None, None, None
+        return dx, dA, dG, None, None, None, None, None, None, None, None, dres, None
+
+
+def site_res_supported(x, residual) -> bool:
+    """SiteFn(residual=, relu=): the small-batch site kernels (2 <= B <= 32) with a residual of x's shape and layout."""
+    if not (x.is_cuda and x.dtype == torch.float32 and 2 <= x.shape[0] <= 32):
+        return False
+    return residual is None or (residual.shape == x.shape and residual.dtype == torch.float32 and residual.is_cuda
+                                and residual.stride() == x.stride())
 
 
 # ------------------------------------------------------------------------------------------------ R9 (Conv2d_Q's conv)

@@ -127,6 +127,21 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
             return xq, loss
         return _plain_act(x, a_bit, mod.stage), 0
 
+    def _site_act_res_relu(mod, x, residual):
+        """(relu(act(x)[0] + residual), loss): the Office bottleneck's tail.  One launch each way on the small-batch site
+        kernels when they apply (and no deferred-loss context is active), else exactly the composition."""
+        from . import fused
+        if (config.args.method == "ours" and mod.a_bit < 32 and fused.active_deferred() is None
+                and ops.site_res_supported(x, residual)):
+            admm = mod.opt
+            y, loss, D = ops.SiteFn.apply(x, admm.alterD, admm.gamma, mod.a_bit, config.args.act_range, eps, admm.mu,
+                                          admm.rho, None, None, None, residual, True)
+            admm.D = D
+            return y, loss
+        out, loss = _site_act(mod, x)
+        out = out + residual
+        return torch.relu(out), loss
+
     class _act_plain(nn.Module):
         def __init__(self, a_bit, stage):
             super().__init__()
@@ -149,6 +164,10 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
 
         def forward(self, x):
             return _site_act(self, x)
+
+        def forward_res_relu(self, x, residual):
+            """(relu(self(x)[0] + residual), loss) (not part of the reference's interface: an opt-in for the caller)."""
+            return _site_act_res_relu(self, x, residual)
 
     def corr(x, y):
         """corr(x, y) -> [B,B]; the reference only ever calls it with y is x (SYRK)."""

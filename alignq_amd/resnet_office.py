@@ -53,6 +53,12 @@ class Bottleneck(nn.Module):
         else:
             out = self.relu(self.act_q1(self.bn1(self.conv1(x))))
             out = self.relu(self.act_q2(self.bn2(self.conv2(out))))
+        if getattr(self, "fuse_relu", False):       # `out += identity; relu` inside the site kernels
+            z = self.bn3(self.conv3(out))
+            if self.downsample is not None:
+                identity = self.downsample(x)
+            out, loss = self.act_q3.forward_res_relu(z, identity)
+            return out, trans_loss + loss
         out, loss = self.act_q3(self.bn3(self.conv3(out)))
         trans_loss += loss
         if self.downsample is not None:

@@ -96,6 +96,12 @@ int alignq_site_fwd(const float* x, int B, int64_t F, int k, float act_range, fl
                     float* D, float* stats, void* ws, void* stream);
 int alignq_site_partials(const float* x, int B, int64_t F, int k, float act_range, float eps, float* xq,
                          float* stats, void* ws, void* stream);
+/* Small batches (B <= 32; ALIGNQ_EUNSUPPORTED otherwise): alignq_site_partials with the Office bottleneck's
+ * `out += identity; out = self.relu(out)` (cdf_alignment_admm/dann_office/model/resnet.py:153-154) folded into the store:
+ * y = [relu](x_q + residual) (residual may be NULL).  (The backward keeps the ReLU mask as its own pass: the masked gradient
+ * is an output in its own right — the residual's gradient — so folding it saves no bytes; measured slower.) */
+int alignq_site_partials_res(const float* x, int B, int64_t F, int k, float act_range, float eps, const float* residual,
+                             int relu, float* y, float* stats, void* ws, void* stream);
 int alignq_site_reduce(const void* ws, int B, int64_t F, float* D, void* stream);
 int alignq_site_reduce_loss(void* ws, int B, int64_t F, float* D, const float* alterD, const float* gamma,
                             int dim, float mu, float rho, float* scal, void* stream);

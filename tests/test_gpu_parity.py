@@ -65,6 +65,38 @@ def test_act_quant_with_fused_relu_equals_the_composition(dev):
         assert float(yb.min()) >= 0.0 and float((yb == 0).float().mean()) > 0.2
 
 
+@pytest.mark.parametrize("B,shape", [(28, (64, 14, 14)), (16, (8, 6, 6)), (28, (256, 7, 9))])
+def test_small_batch_site_with_folded_residual_and_relu(dev, B, shape):
+    """ops.SiteFn(residual=, relu=True) (alignq_site_partials_res: the Office bottleneck's `out += identity; out =
+    self.relu(out)` inside the site forward kernel) against relu(SiteFn(x)[0] + residual): forward bit for bit; gradients of
+    x, of the residual and of the ADMM state equal (the backward runs the same kernels on the ReLU-masked gradient)."""
+    from alignq_amd import ops
+    torch.manual_seed(B)
+    x0 = torch.randn(B, *shape, device=dev) * 1.2
+    r0 = torch.randn(B, *shape, device=dev)
+    g = torch.randn(B, *shape, device=dev) * 0.01
+    A0, G0 = torch.rand(32, 32, device=dev), torch.rand(32, 32, device=dev)
+    outs = []
+    for fold in (False, True):
+        x, r = x0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+        A, Gm = A0.clone().requires_grad_(True), G0.clone().requires_grad_(True)
+        if fold:
+            assert ops.site_res_supported(x, r)
+            y, loss, D = ops.SiteFn.apply(x, A, Gm, 8, 2.0, 1e-5, 0.2, 0.3, None, None, None, r, True)
+        else:
+            xq, loss, D = ops.SiteFn.apply(x, A, Gm, 8, 2.0, 1e-5, 0.2, 0.3)
+            y = torch.relu(xq + r)
+        (loss + (y * g).sum()).backward()
+        outs.append(dict(y=npy(y), D=npy(D), loss=float(loss.detach()), dx=npy(x.grad), dr=npy(r.grad), dA=npy(A.grad),
+                         dG=npy(Gm.grad)))
+    a, b = outs
+    assert bits_equal(a["y"], b["y"]) and bits_equal(a["D"], b["D"]) and a["loss"] == b["loss"]
+    assert bits_equal(a["dr"], b["dr"])
+    np.testing.assert_allclose(b["dx"], a["dx"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(b["dA"], a["dA"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(b["dG"], a["dG"], rtol=1e-6, atol=1e-9)
+
+
 # ------------------------------------------------------------------------------------------- R1/R4 plain
 @pytest.mark.parametrize("formula", [0, 1])
 @pytest.mark.parametrize("k", [1, 2, 4, 8, 32])
