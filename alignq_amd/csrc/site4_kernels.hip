@@ -624,6 +624,10 @@ __device__ __forceinline__ void slab_reduce_body(const float* __restrict__ slabs
         // Hand-off without an L2 write-back (a release fence here would flush what the previous kernel left dirty
         // in this XCD's L2): the partials are stored write-through (sc1), drained, then one relaxed agent-scope
         // ticket; the block whose ticket is last reads every partial with sc1 loads.
+        // ISA ASSUMPTION (gfx950, not the C++ memory model): agent-scope atomic stores/loads are emitted with sc1 and
+        // bypass the non-coherent per-XCD L2 for these addresses; s_waitcnt vmcnt(0) orders this wave's three stores
+        // before its ticket.  Formally this is a relaxed hand-off; tests/test_gpu_bench_path.py::
+        // test_reduce_loss_is_idempotent_and_matches_the_oracle runs it 20x against the oracle's loss.
         __hip_atomic_store(&parts[blockIdx.x * 4 + 0], v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&parts[blockIdx.x * 4 + 1], v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&parts[blockIdx.x * 4 + 2], v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -656,6 +660,9 @@ __device__ __forceinline__ void slab_reduce_body(const float* __restrict__ slabs
     scal[1] = (float)(0.5 * rho / (n * rms));
     scal[2] = (float)(1.0 / n);
     scal[3] = (float)rms;
+    // re-arm the ticket: the entry point is idempotent (a second reduction of the same workspace finds counter == 0 again;
+    // the partials kernel also zeroes it, which covers the very first use of an uninitialised workspace)
+    __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

@@ -31,6 +31,19 @@ class FlatBucket:
     def _dense(t):
         return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
 
+    def matches(self, tensors) -> bool:
+        """True when `tensors` are exactly the tensors this bucket was laid out for (count and element counts)."""
+        return len(tensors) == len(self.numels) and all(int(t.numel()) == n for t, n in zip(tensors, self.numels))
+
+    def _check(self, tensors):
+        # the native copy kernel takes the element counts cached at construction and cannot see the tensors' real sizes:
+        # a short last batch (D is [b',b'] instead of [b,b]) or a changed set of non-None gradients must never reach it
+        if not self.matches(tensors):
+            raise RuntimeError(
+                "FlatBucket: tensor list changed since the bucket was laid out "
+                f"({len(tensors)} tensors / {sum(int(t.numel()) for t in tensors)} elements now, "
+                f"{len(self.numels)} / {sum(self.numels)} at construction); rebuild the bucket")
+
     def _native(self, tensors, unpack):
         """One HIP launch per 128 tensors (alignq_bucket_copy_multi): dense CUDA fp32 tensors are copied in storage order."""
         from . import _lib as L
@@ -38,11 +51,13 @@ class FlatBucket:
                                                   L.ptr(self.flat), int(unpack), L.stream_ptr()), "alignq_bucket_copy_multi")
 
     def pack(self, tensors: Sequence[torch.Tensor]):
+        self._check(tensors)
         if self.flat.is_cuda and all(t.is_cuda and t.dtype == torch.float32 and self._dense(t) for t in tensors):
             return self._native(tensors, False)
         torch._foreach_copy_(self.views, [t.detach() for t in tensors])
 
     def unpack(self, tensors: Sequence[torch.Tensor]):
+        self._check(tensors)
         if self.flat.is_cuda and all(t.is_cuda and t.dtype == torch.float32 and self._dense(t) for t in tensors):
             return self._native(tensors, True)
         torch._foreach_copy_([t.detach() for t in tensors], self.views)
@@ -65,6 +80,7 @@ class GradAndDAllReduce:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.force = force and dist.is_initialized()      # run the collective even at world size 1 (self-test)
         self.bucket = None
+        self._buckets = {}          # layout (tuple of shapes) -> FlatBucket: the short last batch gets its own bucket
 
     # The hook is three phases so that a captured TrainStep can keep pack / unpack INSIDE its two HIP graphs and leave only
     # the collective itself eager (one RCCL launch between two graph launches per step).
@@ -80,8 +96,14 @@ class GradAndDAllReduce:
         if not self.active():
             return
         tensors = self._tensors()
-        if self.bucket is None:
-            self.bucket = FlatBucket([t.shape for t in tensors], tensors[0].device)
+        if self.bucket is None or not self.bucket.matches(tensors):
+            # The reference's loaders have no drop_last: the last batch of an epoch is short (D is [b',b']), and which
+            # gradients are None may change.  Every rank sees the same shapes (same sampler length), so each layout gets
+            # its own persistent bucket; a captured step never comes here with a new layout (static shapes).
+            key = tuple(tuple(t.shape) for t in tensors)
+            if key not in self._buckets:
+                self._buckets[key] = FlatBucket([t.shape for t in tensors], tensors[0].device)
+            self.bucket = self._buckets[key]
         self.bucket.pack(tensors)
 
     def reduce(self):

@@ -214,13 +214,22 @@ class DeferredWgrads:
     def __enter__(self):
         global _active_wgrads
         self.items = []
-        _lazy_dz.clear()
+        del _posted_links[:]
         _active_wgrads = self
         return self
 
-    def __exit__(self, *exc):
+    def __exit__(self, exc_type, *exc):
         global _active_wgrads
         _active_wgrads = None
+        stale = [l for l in _posted_links if l.record is not None]
+        del _posted_links[:]
+        for l in stale:
+            l.record = None
+        if stale and exc_type is None:
+            # a lazy batch-norm gradient nobody consumed means the producing convolution's backward never ran with it
+            # (e.g. its input and weight need no gradient): the BN parameter gradients autograd holds were never written
+            raise RuntimeError(f"alignq_amd: {len(stale)} lazy batch-norm gradient record(s) were never consumed by the "
+                               "producing convolution's backward; gradients of this backward are incomplete")
         return False
 
     def add(self, ws, dw, n_slabs, n_elem):
@@ -247,18 +256,41 @@ def active_wgrads():
 
 # Lazy batch-norm input gradients: BNSiteFn.backward may hand the gradient g w.r.t. the BN OUTPUT to the convolution that
 # produced z instead of the finished dz; ops.QConv3x3Fn.backward forms dz on load (alignq_conv3x3_nhwc_bwd, bn_z ...).
-# Keyed by the gradient tensor's data pointer; only used inside a DeferredWgrads context (TrainStep).
-_lazy_dz = {}
+# Producer and consumer are tied together by a LazyLink object created in the convolution's forward (kept on its ctx and
+# handed to the BN site with the partial statistics), NOT by the gradient tensor's address: if anything stands between the
+# two backward nodes (a tensor hook or retain_grad on z, a second consumer of z whose gradient autograd adds), the tensor
+# arriving at the convolution is no longer the posted one and the consumer raises instead of treating it as dz.
+# Only used inside a DeferredWgrads context (TrainStep).
+class LazyLink:
+    __slots__ = ("record",)
+
+    def __init__(self):
+        self.record = None
 
 
-def post_lazy_dz(g, z, ab, save, ktot, part=None, dgamma=None, dbeta=None):
+_posted_links = []
+
+
+def post_lazy_dz(link, g, z, ab, save, ktot, part=None, dgamma=None, dbeta=None):
     """ktot None: the consumer reduces the site backward's per-tile sums `part` itself (alignq_conv3x3_nhwc_bwd) and fills the
     batch-norm parameter gradients dgamma / dbeta, which autograd already holds."""
-    _lazy_dz[g.data_ptr()] = (g, z, ab, save, ktot, part, dgamma, dbeta)
+    link.record = (g, z, ab, save, ktot, part, dgamma, dbeta)
+    _posted_links.append(link)
 
 
-def take_lazy_dz(g):
-    return _lazy_dz.pop(g.data_ptr(), None) if _lazy_dz else None
+def take_lazy_dz(link, g):
+    """The record posted for this convolution's output gradient, or None.  Raises if a record exists but the incoming
+    gradient is not the posted tensor (it was altered or summed with another gradient on the way)."""
+    if link is None or link.record is None:
+        return None
+    rec, link.record = link.record, None
+    posted = rec[0]
+    if g is None or g.data_ptr() != posted.data_ptr() or g.shape != posted.shape or g.stride() != posted.stride():
+        raise RuntimeError(
+            "alignq_amd: the gradient reaching the convolution is not the lazy batch-norm gradient its BN site posted "
+            "(a tensor hook / retain_grad on the convolution output, or a second consumer of it, stands in between). "
+            "Remove the hook or build the TrainStep with qconv=False / fuse_bn=False.")
+    return rec
 
 
 _active = None
@@ -323,7 +355,9 @@ class BNSiteFn(torch.autograd.Function):
             L.check(lib.alignq_site_reduce_loss(L.ptr(ws), B, F, L.ptr(D), L.ptr(A), L.ptr(Gm), dim, float(mu),
                                                 float(rho), L.ptr(scal), st), "alignq_site_reduce_loss")
         ctx.rec = rec
-        ctx.from_qconv = int(conv_part[2]) if (nhwc and conv_part is not None and len(conv_part) > 2) else 0
+        ctx.from_qconv = int(conv_part[2]) if (nhwc and conv_part is not None and len(conv_part) > 3) else 0
+        ctx.link = conv_part[3] if ctx.from_qconv else None
+        ctx.bn_params = (bn_weight, bn_bias)
         ctx.save_for_backward(z, ab, save, stats, D, A, Gm, scal, y if relu else None)
         ctx.set_materialize_grads(False)
         ctx.cfg = (float(act_range), float(eps), float(mu), bn_weight is not None, bn_bias is not None, res is not None,
@@ -365,12 +399,15 @@ class BNSiteFn(torch.autograd.Function):
                                              L.ptr(dx), L.ptr(part), st), "alignq_site_bwd_apply_bn")
         dgam = torch.empty(C, dtype=torch.float32, device=dev) if has_w else None
         dbet = torch.empty(C, dtype=torch.float32, device=dev) if has_b else None
-        if ctx.from_qconv == 2 and active_wgrads() is not None and active_wgrads().fresh_grads:
+        # the in-kernel form fills dgam / dbet AFTER autograd has adopted them as .grad: only valid while both .grad are
+        # really None (the DeferredWgrads(fresh_grads=True) promise, checked here rather than trusted)
+        fresh = all(p is None or p.grad is None for p in ctx.bn_params)
+        if ctx.from_qconv == 2 and active_wgrads() is not None and active_wgrads().fresh_grads and fresh:
             # z is the output of a 3x3 body convolution whose fused backward reduces the per-tile sums itself: nothing is
             # launched here; dgam / dbet are filled by that kernel (later in this backward, before anything reads them).
             # Autograd receives VIEWS: it adopts a gradient as .grad only while nobody else holds the tensor object (it would
             # copy the still unwritten buffer otherwise); the buffers themselves travel with the lazy record.
-            post_lazy_dz(dx, z, ab, save, None, part, dgam, dbet)
+            post_lazy_dz(ctx.link, dx, z, ab, save, None, part, dgam, dbet)
             return (dx, None if dgam is None else dgam.view_as(dgam), None if dbet is None else dbet.view_as(dbet), None, None,
                     None, None, None, dA, dG, None, None, None, None, None, None, None, dres, None)
         if ctx.from_qconv and active_wgrads() is not None:
@@ -379,7 +416,7 @@ class BNSiteFn(torch.autograd.Function):
             ktot = torch.empty(2, C, dtype=torch.float32, device=dev)
             L.check(lib.alignq_bn_bwd_totals(L.ptr(part), B, C, HW, L.ptr(ktot), L.ptr(dgam), L.ptr(dbet), st),
                     "alignq_bn_bwd_totals")
-            post_lazy_dz(dx, z, ab, save, ktot)
+            post_lazy_dz(ctx.link, dx, z, ab, save, ktot)
             return (dx, dgam, dbet, None, None, None, None, None, dA, dG, None, None, None, None, None, None, None, dres, None)
         dz = torch.empty_like(z)
         L.check(lib.alignq_bn_bwd_apply(L.ptr(dx), L.ptr(z), L.ptr(ab), L.ptr(save), L.ptr(part), B, C, HW, nhwc, L.ptr(dz),

@@ -362,10 +362,16 @@ class QConv3x3Fn(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.w_bit = int(w_bit)
         ctx.tap = bool(tap)
+        ctx.link = None
         if part is not None:
             # third field: this producer's backward accepts a lazy BN gradient (1), and reduces the site backward's per-tile
-            # sums itself when both of its gradients are needed (2: the fused alignq_conv3x3_nhwc_bwd)
-            QConv3x3Fn._mailbox = (part, n_parts, 2 if (x.requires_grad and w.requires_grad) else 1)
+            # sums itself when both of its gradients are needed (2: the fused alignq_conv3x3_nhwc_bwd); fourth: the link
+            # through which the BN site's backward hands that gradient's record to THIS node's backward
+            if x.requires_grad or w.requires_grad:
+                ctx.link = fused.LazyLink()
+                QConv3x3Fn._mailbox = (part, n_parts, 2 if (x.requires_grad and w.requires_grad) else 1, ctx.link)
+            else:       # this node's backward never runs: the BN site must finish its own input gradient
+                QConv3x3Fn._mailbox = (part, n_parts)
         if tap:
             ctx.set_materialize_grads(False)
             return y, x.view_as(x)
@@ -391,7 +397,7 @@ class QConv3x3Fn(torch.autograd.Function):
         B, C, H, W = x.shape
         if gy is None:                     # only the shortcut alias was used downstream
             return gtap, None, None, None, None
-        lazy = fused.take_lazy_dz(gy)      # (g, z, ab, save, ktot): gy is the gradient w.r.t. the folded BN's OUTPUT
+        lazy = fused.take_lazy_dz(ctx.link, gy)      # (g, z, ab, save, ktot): gy is the gradient w.r.t. the folded BN's OUTPUT
         gy = L.like_layout(gy, x)
         add = None if gtap is None else L.like_layout(gtap, x)
         dx = dw = None
@@ -488,7 +494,12 @@ class QConvGenFn(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.w_bit = int(w_bit)
         # 2: the data-gradient kernel reduces the site backward's per-tile sums and publishes the BN parameter gradients
-        QConv3x3Fn._mailbox = (part, n_parts, 2 if x.requires_grad else 1)
+        ctx.link = None
+        if x.requires_grad or w.requires_grad:
+            ctx.link = fused.LazyLink()
+            QConv3x3Fn._mailbox = (part, n_parts, 2 if x.requires_grad else 1, ctx.link)
+        else:
+            QConv3x3Fn._mailbox = (part, n_parts)
         if tap:
             ctx.set_materialize_grads(False)
             return y, x.view_as(x)
@@ -500,7 +511,7 @@ class QConvGenFn(torch.autograd.Function):
         if gy is None:                     # only the alias was used downstream
             return gtap, None, None, None, None
         add = None if gtap is None else L.like_layout(gtap, x)
-        lazy = fused.take_lazy_dz(gy)      # (g, z, ab, save, ktot): gy is the gradient w.r.t. the folded BN's OUTPUT
+        lazy = fused.take_lazy_dz(ctx.link, gy)      # (g, z, ab, save, ktot): gy is the gradient w.r.t. the folded BN's OUTPUT
         gy = gy.contiguous(memory_format=torch.channels_last)
         B, CIN, H, W = x.shape
         COUT, ks = w.shape[0], w.shape[2]
@@ -571,13 +582,18 @@ class QConvStemFn(torch.autograd.Function):
                 "alignq_conv_stem_nhwc_fwd")
         ctx.save_for_backward(x, w)
         # 2: the filter-gradient kernel (the stem's only gradient) reduces the site backward's per-tile sums itself
-        QConv3x3Fn._mailbox = (part, n_parts, 2 if w.requires_grad else 1)
+        ctx.link = None
+        if w.requires_grad:
+            ctx.link = fused.LazyLink()
+            QConv3x3Fn._mailbox = (part, n_parts, 2, ctx.link)
+        else:
+            QConv3x3Fn._mailbox = (part, n_parts)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
-        lazy = fused.take_lazy_dz(gy)
+        lazy = fused.take_lazy_dz(ctx.link, gy)
         gy = gy.contiguous(memory_format=torch.channels_last)
         B, _, H, W = x.shape
         bz, bab, bsave, bk, bpart, bdg, bdb = _lazy_fields(lazy, not ctx.needs_input_grad[1], B, 16, H * W, x.device)

@@ -133,6 +133,11 @@ class TrainStep:
         if self._graph is None:
             return self._iteration(x, y)
         sx, sy = self._static[0], self._static[1]
+        if x.shape != sx.shape or y.shape != sy.shape:
+            # off-shape batch (the reference's loaders have no drop_last: CIFAR's last batch is 80 of 128): a captured
+            # graph only fits its static shapes, so this one iteration runs eagerly; the graph's own gradient / D tensors
+            # (which p.grad and ADMM.D name between replays) are put back afterwards
+            return self._eager_fallback(x, y)
         sx.copy_(x, non_blocking=True)
         sy.copy_(y, non_blocking=True)
         self._graph.replay()
@@ -142,6 +147,29 @@ class TrainStep:
             self.grad_hook.reduce() if hasattr(self.grad_hook, "reduce") else self.grad_hook(self)
             self._graph2.replay()
         return self._static[2]
+
+    def _eager_fallback(self, x, y):
+        params = [p for _, p in self.param_t + self.param_admm]
+        keep_g, keep_D = [p.grad for p in params], [m.D for m in self.admms]
+        try:
+            return self._iteration(x, y)
+        finally:
+            for p, g in zip(params, keep_g):
+                p.grad = g
+            for m, D in zip(self.admms, keep_D):
+                m.D = D
+
+    def _assert_momentum_buffers(self):
+        """A momentum buffer created INSIDE a capture is baked into the graph with first=1 (buf = grad on every replay:
+        silently momentum-free training) and lives in the graph's private pool.  Capture therefore needs every parameter the
+        step updates to own its buffer already, i.e. at least one eager step since the optimizer was created."""
+        for group in self.optimizer_t.param_groups:
+            if group["momentum"] == 0:
+                continue
+            for p in group["params"]:
+                if p.requires_grad and "momentum_buffer" not in self.optimizer_t.state[p]:
+                    raise RuntimeError("TrainStep.capture: a parameter has no momentum buffer yet; run at least one eager "
+                                       "iteration (capture(..., warmup>=1)) before capturing the step")
 
     # -------------------------------------------------------------------------------------------
     def set_lr(self, lr):
@@ -170,11 +198,18 @@ class TrainStep:
                 self._iteration(sx, sy, set_to_none=False)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        if self.grad_hook is not None and torch.distributed.is_available() and torch.distributed.is_initialized():
-            # the warm-up iterations issued collectives: give the process group's watchdog thread (it polls completion
-            # events every 100 ms) time to retire them, so that it does not touch the HIP runtime while streams are capturing
-            import time
-            time.sleep(0.5)
+        self._assert_momentum_buffers()
+        dist_on = (self.grad_hook is not None and torch.distributed.is_available() and torch.distributed.is_initialized())
+        if dist_on:
+            # The warm-up iterations issued collectives.  Quiesce explicitly instead of sleeping: a barrier orders every rank
+            # behind its peers' warm-up collectives and the device synchronise retires them, so no collective is in flight
+            # when the capture starts; the capture itself uses capture_error_mode="thread_local", under which HIP calls made
+            # by OTHER threads (the process group's watchdog polling its completion events) neither fail nor invalidate it.
+            # (Round 1 slept 0.5 s here against a "operation not permitted when stream is capturing" abort seen once with
+            # the default global mode; no log of it was kept.)
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+        cap_mode = dict(capture_error_mode="thread_local") if dist_on else {}
         graph = torch.cuda.CUDAGraph()
         self._graph2 = None
         # inside the capture grads are re-created (set_to_none=True): no zero-fill and no accumulate-add per
@@ -188,12 +223,12 @@ class TrainStep:
                 outs = self._iteration(sx, sy, set_to_none=True)
         else:
             phased = hasattr(self.grad_hook, "reduce")
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, **cap_mode):
                 outs = self._forward_backward(sx, sy, set_to_none=True)
                 if phased:
                     self.grad_hook.pack()
             graph2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph2, pool=graph.pool()):
+            with torch.cuda.graph(graph2, pool=graph.pool(), **cap_mode):
                 if phased:
                     self.grad_hook.unpack()
                 self._optimizer_steps()
@@ -290,10 +325,24 @@ class OfficeTrainStep:
                 self._recapture = False
                 self.capture(xs, ys, xt, warmup=0)
             return out
+        if any(src.shape != dst.shape for dst, src in zip(self._static[:3], (xs, ys, xt))):
+            return self._eager_fallback(xs, ys, xt)       # off-shape (short last) batch: one eager iteration
         for dst, src in zip(self._static[:3], (xs, ys, xt)):
             dst.copy_(src, non_blocking=True)
         self._graph.replay()
         return self._static[3]
+
+    def _eager_fallback(self, xs, ys, xt):
+        params = [p for g in self.optimizer_t.param_groups for p in g["params"]]
+        admms = [b.admm0 for b in self.blocks]
+        keep_g, keep_D = [p.grad for p in params], [q.D for q in admms]
+        try:
+            return self._iteration(xs, ys, xt)
+        finally:
+            for p, g in zip(params, keep_g):
+                p.grad = g
+            for q, D in zip(admms, keep_D):
+                q.D = D
 
     def capture(self, xs, ys, xt, warmup=2):
         fmt = torch.channels_last if self.channels_last else torch.contiguous_format

@@ -398,3 +398,117 @@ void oq_sgd_grad_approx(const float* dir, const float* w_cdf, const float* w_pdf
     gout[i] = (float)((double)dir[i] * (sg * (1.0 - sg) * lam) * (double)w_pdf[i]);
   }
 }
+
+/* ------------------------------------------------------------------ N1: batch-norm folded into the ADMM site ---- */
+/* Caller being restated: `out, loss = self.act_q0(self.bn0(conv(x))); out += shortcut; out = relu(out)` of the ADMM
+ * tree's block, cdf_alignment_admm/resnet-56-cifar-10/model/resnet.py:78-98, i.e. training-mode nn.BatchNorm2d followed
+ * by activation_quantize_fn.forward (model/quantization.py:102-132).  torch-CPU's batch-norm evaluates the affine as
+ * alpha = invstd*weight, beta' = bias - mean*alpha, out = z*alpha + beta' with the batch statistics accumulated in
+ * double (aten/native/cpu/batch_norm_kernel.cpp); the HIP fold specifies the last step as ONE fma per element.
+ * z is [B,C,HW] (nhwc == 0: feature f = c*HW + p) or channels-last [B,HW,C] (nhwc == 1: f = p*C + c); the site math
+ * only sees the [B,F] matrix, F = C*HW, in the given memory order (D is invariant under feature permutations). */
+static inline int bn_channel(long f, int C, long HW, int nhwc) { return nhwc ? (int)(f % C) : (int)(f / HW); }
+
+/* ab = {a[C], b[C]}, save = {mean[C], invstd[C]}, var_unbiased (optional, [C]) for the running-variance update. */
+void oq_bn_fold_ab(const float* z, int B, int C, long HW, int nhwc, const float* gamma, const float* beta, float bn_eps,
+                   float* ab, float* save, float* var_unbiased) {
+  long F = (long)C * HW;
+  double* s = calloc(C, sizeof(double)), *q = calloc(C, sizeof(double));
+  for (int b = 0; b < B; b++)
+    for (long f = 0; f < F; f++) s[bn_channel(f, C, HW, nhwc)] += z[(long)b * F + f];
+  double n = (double)B * (double)HW;
+  for (int c = 0; c < C; c++) s[c] /= n;
+  for (int b = 0; b < B; b++)
+    for (long f = 0; f < F; f++) {
+      int c = bn_channel(f, C, HW, nhwc);
+      double d = z[(long)b * F + f] - s[c];
+      q[c] += d * d;
+    }
+  for (int c = 0; c < C; c++) {
+    double var = q[c] / n;
+    float invstd = (float)(1.0 / sqrt(var + (double)bn_eps));
+    float a = (gamma ? gamma[c] : 1.0f) * invstd;
+    float bb = (beta ? beta[c] : 0.0f) - (float)s[c] * a;
+    ab[c] = a; ab[C + c] = bb;
+    save[c] = (float)s[c]; save[C + c] = invstd;
+    if (var_unbiased) var_unbiased[c] = (float)(q[c] / (n - 1.0));
+  }
+  free(s); free(q);
+}
+
+/* forward given (a,b): x = fma(a,z,b); (x_q, D) as oq_site_fwd; y = [relu](x_q [+ residual]).  x_out optional. */
+void oq_bn_site_fwd(const float* z, int B, int C, long HW, int nhwc, const float* ab, int k, float r, float eps,
+                    const float* residual, int relu, float* y, float* D, float* x_out) {
+  long F = (long)C * HW, N = (long)B * F;
+  float* x = x_out ? x_out : malloc(sizeof(float) * N);
+  for (int b = 0; b < B; b++)
+    for (long f = 0; f < F; f++) {
+      int c = bn_channel(f, C, HW, nhwc);
+      x[(long)b * F + f] = fmaf(ab[c], z[(long)b * F + f], ab[C + c]);
+    }
+  oq_site_fwd(x, B, F, k, r, eps, y, D);
+  for (long i = 0; i < N; i++) {
+    float v = y[i];
+    if (residual) v = v + residual[i];
+    if (relu) v = v > 0.0f ? v : 0.0f;      /* fmaxf(v, 0) of the kernel; NaN does not occur here */
+    y[i] = v;
+  }
+  if (!x_out) free(x);
+}
+
+/* backward: g_y = gradient w.r.t. y; y_relu != NULL masks it by y > 0 (the masked gradient is also the residual's
+ * gradient, dres); dx = site backward at x = fma(a,z,b) for upstream dD; then the training-mode batch-norm backward
+ *   dgamma = sum dx*zhat, dbeta = sum dx, dz = a*(dx - mean(dx) - zhat*mean(dx*zhat)), zhat = (z-mean)*invstd.
+ * dx_out (optional) = the gradient w.r.t. the batch-norm OUTPUT (what alignq_site_bwd_apply_bn writes). */
+void oq_bn_site_bwd(const float* g_y, const float* dD, const float* z, int B, int C, long HW, int nhwc, const float* ab,
+                    const float* save, const float* y_relu, float r, float eps, float* dz, float* dgamma, float* dbeta,
+                    float* dres, float* dx_out) {
+  long F = (long)C * HW, N = (long)B * F;
+  float* x = malloc(sizeof(float) * N), *g = malloc(sizeof(float) * N);
+  float* dx = dx_out ? dx_out : malloc(sizeof(float) * N);
+  for (int b = 0; b < B; b++)
+    for (long f = 0; f < F; f++) {
+      long i = (long)b * F + f;
+      int c = bn_channel(f, C, HW, nhwc);
+      x[i] = fmaf(ab[c], z[i], ab[C + c]);
+      float gv = g_y ? g_y[i] : 0.0f;
+      if (y_relu && !(y_relu[i] > 0.0f)) gv = 0.0f;
+      g[i] = gv;
+      if (dres) dres[i] = gv;
+    }
+  oq_site_bwd(g, dD, x, B, F, r, eps, dx);
+  double* s0 = calloc(C, sizeof(double)), *s1 = calloc(C, sizeof(double));
+  for (int b = 0; b < B; b++)
+    for (long f = 0; f < F; f++) {
+      long i = (long)b * F + f;
+      int c = bn_channel(f, C, HW, nhwc);
+      double zh = ((double)z[i] - (double)save[c]) * (double)save[C + c];
+      s0[c] += dx[i];
+      s1[c] += (double)dx[i] * zh;
+    }
+  double n = (double)B * (double)HW;
+  for (int c = 0; c < C; c++) {
+    if (dgamma) dgamma[c] = (float)s1[c];
+    if (dbeta) dbeta[c] = (float)s0[c];
+  }
+  if (dz)
+    for (int b = 0; b < B; b++)
+      for (long f = 0; f < F; f++) {
+        long i = (long)b * F + f;
+        int c = bn_channel(f, C, HW, nhwc);
+        double zh = ((double)z[i] - (double)save[c]) * (double)save[C + c];
+        dz[i] = (float)((double)ab[c] * ((double)dx[i] - s0[c] / n - zh * s1[c] / n));
+      }
+  free(s0); free(s1); free(x); free(g);
+  if (!dx_out) free(dx);
+}
+
+/* the fold's affine alone: x = fma(a[c], z, b[c]) (cheap elementwise checker for x_q at a given (a,b)) */
+void oq_bn_apply(const float* z, int B, int C, long HW, int nhwc, const float* ab, float* x) {
+  long F = (long)C * HW;
+  for (int b = 0; b < B; b++)
+    for (long f = 0; f < F; f++) {
+      int c = bn_channel(f, C, HW, nhwc);
+      x[(long)b * F + f] = fmaf(ab[c], z[(long)b * F + f], ab[C + c]);
+    }
+}

@@ -123,3 +123,38 @@ def sgd_step(p, g, buf, lr, mom, damp, wd, nesterov, first):
 def sgd_grad_approx(d, w_cdf, w_pdf, bitW, lam, lam2):
     d, w_cdf, w_pdf = _f32(d), _f32(w_cdf), _f32(w_pdf); out = np.empty_like(d)
     lib().oq_sgd_grad_approx(_p(d), _p(w_cdf), _p(w_pdf), _p(out), c_long(d.size), c_int(bitW), c_float(lam), c_float(lam2)); return out
+
+
+def bn_fold_ab(z, C, nhwc, gamma, beta, bn_eps=1e-5):
+    """z: [B,F] in memory order (F = C*HW); returns ab [2,C], save [2,C], unbiased variance [C]."""
+    z = _f32(z); B = z.shape[0]; HW = z.size // B // C
+    ab, save, vu = np.empty((2, C), np.float32), np.empty((2, C), np.float32), np.empty(C, np.float32)
+    lib().oq_bn_fold_ab(_p(z), c_int(B), c_int(C), c_long(HW), c_int(nhwc), _p(None if gamma is None else _f32(gamma)),
+                        _p(None if beta is None else _f32(beta)), c_float(bn_eps), _p(ab), _p(save), _p(vu))
+    return ab, save, vu
+
+
+def bn_site_fwd(z, C, nhwc, ab, k, r, eps=0.0, residual=None, relu=False):
+    z, ab = _f32(z), _f32(ab); B = z.shape[0]; HW = z.size // B // C
+    res = None if residual is None else _f32(residual)
+    y, D, x = np.empty_like(z), np.empty((B, B), np.float32), np.empty_like(z)
+    lib().oq_bn_site_fwd(_p(z), c_int(B), c_int(C), c_long(HW), c_int(nhwc), _p(ab), c_int(k), c_float(r), c_float(eps),
+                         _p(res), c_int(int(relu)), _p(y), _p(D), _p(x))
+    return y, D, x
+
+
+def bn_site_bwd(g_y, dD, z, C, nhwc, ab, save, y_relu, r, eps=0.0):
+    z, ab, save, dD = _f32(z), _f32(ab), _f32(save), _f32(dD); B = z.shape[0]; HW = z.size // B // C
+    g_y = None if g_y is None else _f32(g_y)
+    y_relu = None if y_relu is None else _f32(y_relu)
+    dz, dres, dx = np.empty_like(z), np.empty_like(z), np.empty_like(z)
+    dg, db = np.empty(C, np.float32), np.empty(C, np.float32)
+    lib().oq_bn_site_bwd(_p(g_y), _p(dD), _p(z), c_int(B), c_int(C), c_long(HW), c_int(nhwc), _p(ab), _p(save), _p(y_relu),
+                         c_float(r), c_float(eps), _p(dz), _p(dg), _p(db), _p(dres), _p(dx))
+    return dz, dg, db, dres, dx
+
+
+def bn_apply(z, C, nhwc, ab):
+    z, ab = _f32(z), _f32(ab); B = z.shape[0]; HW = z.size // B // C
+    x = np.empty_like(z)
+    lib().oq_bn_apply(_p(z), c_int(B), c_int(C), c_long(HW), c_int(nhwc), _p(ab), _p(x)); return x

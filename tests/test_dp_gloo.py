@@ -60,9 +60,25 @@ def _worker(rank, world, port, out):
         step.opt_admm.step(step.a_idx, step.g_idx, [m.D for m in mods], [m.alterD for m in mods],
                            [m.gamma for m in mods], [m.mu for m in mods], [m.rho for m in mods], bitW=cfg.bitW)
         flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
-        out[rank] = dict(flat=flat.numpy().copy(), g0_local=local_g0.numpy(), D0_local=local_D0.numpy(),
-                         g0_avg=g0_avg.numpy(), D0_avg=mods[0].D.numpy().copy(),
-                         bucket=int(hook.bucket.flat.numel()))
+        D0_avg, full_bucket = mods[0].D.clone(), int(hook.bucket.flat.numel())
+        # second iteration with a SHORT batch (the reference's loaders have no drop_last: CIFAR's last batch is 80 of 128):
+        # D is [3,3] inside ADMM(dim=4), so the flat bucket's layout changes and the hook must switch buckets, not reuse
+        # the cached element counts (the native copy kernel would run past D)
+        step.opt_t.zero_grad(); step.opt_admm.zero_grad()
+        logits, tl = net(xs[rank][:3])
+        (torch.nn.functional.cross_entropy(logits, ys[rank][:3]) + tl).backward()
+        for m in net.admm_modules():
+            m.D = m.D.detach().clone()
+        assert tuple(net.admm_modules()[0].D.shape) == (3, 3)
+        hook()
+        short_bucket = int(hook.bucket.flat.numel())
+        step.opt_t.step(step.idx, [c.weight_cdf for c in convs], [c.weight_pdf for c in convs], cfg.lam, cfg.lam2)
+        step.opt_admm.step(step.a_idx, step.g_idx, [m.D for m in mods], [m.alterD for m in mods],
+                           [m.gamma for m in mods], [m.mu for m in mods], [m.rho for m in mods], bitW=cfg.bitW)
+        flat2 = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+        out[rank] = dict(flat2=flat2.numpy().copy(), short_bucket=short_bucket, n_buckets=len(hook._buckets),
+                         flat=flat.numpy().copy(), g0_local=local_g0.numpy(), D0_local=local_D0.numpy(),
+                         g0_avg=g0_avg.numpy(), D0_avg=D0_avg.numpy(), bucket=full_bucket)
     finally:
         dist.destroy_process_group()
 
@@ -85,6 +101,9 @@ def test_dp_two_ranks_gloo():
     R, cfg, net = _make()
     n_t = sum(p.numel() for n, p in net.named_parameters() if "alterD" not in n and "gamma" not in n)
     assert r0["bucket"] == n_t + 9 * 16
+    # the short batch got its own bucket (9 sites of 3x3) and the replicas are still bit-identical after it
+    assert r0["short_bucket"] == n_t + 9 * 9 and r0["n_buckets"] == 2
+    assert np.array_equal(r0["flat2"], r1["flat2"]) and np.isfinite(r0["flat2"]).all()
 
 
 def test_flat_bucket_roundtrip():
@@ -106,3 +125,32 @@ def test_world_size_one_is_a_noop():
     p.grad = torch.full((3,), 2.0)
     GradAndDAllReduce([p], lambda: [])()
     assert torch.equal(p.grad, torch.full((3,), 2.0))
+
+
+def test_flat_bucket_rejects_a_changed_layout_and_the_hook_switches_buckets():
+    """the native pack / unpack kernel copies the element counts cached at construction; a short last
+    batch (D [b',b']) or a changed set of non-None gradients must raise in FlatBucket and make the hook lay out a new
+    bucket instead of running past the tensors."""
+    from alignq_amd.dp import FlatBucket, GradAndDAllReduce
+    b = FlatBucket([(4, 4), (3,)], "cpu")
+    with pytest.raises(RuntimeError, match="tensor list changed"):
+        b.pack([torch.zeros(3, 3), torch.zeros(3)])
+    with pytest.raises(RuntimeError, match="tensor list changed"):
+        b.unpack([torch.zeros(4, 4)])
+    p = torch.nn.Parameter(torch.ones(5))
+    p.grad = torch.full((5,), 2.0)
+    Ds = [torch.ones(4, 4)]
+    hook = GradAndDAllReduce([p], lambda: Ds)
+    hook.active = lambda: True
+    hook.reduce = lambda: None
+    hook()
+    first = hook.bucket
+    assert first.flat.numel() == 5 + 16
+    Ds[0] = torch.full((3, 3), 7.0)            # short batch
+    guard = torch.zeros(64)                    # would be overwritten by an unpack past D
+    hook()
+    assert hook.bucket is not first and hook.bucket.flat.numel() == 5 + 9
+    assert torch.equal(Ds[0], torch.full((3, 3), 7.0)) and not guard.any()
+    Ds[0] = torch.ones(4, 4)
+    hook()
+    assert hook.bucket is first                # layouts are cached, not re-allocated every time

@@ -1106,7 +1106,7 @@ def test_qconv_transition_forward_matches_fp64(dev, B, CIN, COUT, H, ks, k):
     y32 = torch.nn.functional.conv2d(x.detach(), wq.detach(), stride=2, padding=pad)
     floor = 2e-6 * float(yd.abs().max())
     assert float((y.detach() - yd).abs().max()) <= max(float((y32 - yd).abs().max()), floor)
-    part, n_parts, lazy_ok = y._alignq_bn_part
+    part, n_parts, lazy_ok = y._alignq_bn_part[:3]
     assert lazy_ok and part.shape == (COUT, n_parts, 2)
     np.testing.assert_allclose(npy(part[:, :, 0].double().sum(1)), npy(yd.sum((0, 2, 3))), rtol=1e-5, atol=1e-2)
     np.testing.assert_allclose(npy(part[:, :, 1].double().sum(1)), npy((yd * yd).sum((0, 2, 3))), rtol=1e-5)
@@ -1140,7 +1140,7 @@ def test_qconv_stem_matches_fp64(dev, B, H, k):
     y32 = torch.nn.functional.conv2d(x, wq.detach(), padding=1)
     floor = 2e-6 * float(yd.abs().max())
     assert float((y.detach() - yd).abs().max()) <= max(float((y32 - yd).abs().max()), floor)
-    part, n_parts, _ = y._alignq_bn_part
+    part, n_parts, _ = y._alignq_bn_part[:3]
     np.testing.assert_allclose(npy(part[:, :, 0].double().sum(1)), npy(yd.sum((0, 2, 3))), rtol=1e-5, atol=1e-2)
     np.testing.assert_allclose(npy(part[:, :, 1].double().sum(1)), npy((yd * yd).sum((0, 2, 3))), rtol=1e-5)
     gy = torch.randn_like(y)

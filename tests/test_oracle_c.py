@@ -197,3 +197,55 @@ def test_fma_division_is_ieee_division_exhaustive(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout
     assert "mismatches 0 (|x|>=1e-30)" in out.stdout and "levels: mismatches 0" in out.stdout
+
+
+@pytest.mark.parametrize("nhwc", [0, 1])
+@pytest.mark.parametrize("relu,residual", [(False, False), (True, True)])
+def test_bn_folded_site_oracle_vs_torch_batchnorm(nhwc, relu, residual):
+    """oq_bn_fold_ab / oq_bn_site_fwd / oq_bn_site_bwd (the BN-folded ADMM site the GPU bench path runs) against the
+    composition the reference's block executes (cdf_alignment_admm/resnet-56-cifar-10/model/resnet.py:87-96): torch's own
+    training-mode nn.BatchNorm2d followed by the golden-pinned eager restatement of activation_quantize_fn (+ shortcut add
+    + relu), forward and autograd backward."""
+    import torch
+    from oracle import torch_ref as R
+    torch.manual_seed(7 + nhwc)
+    B, C, H, W, k, r = 12, 8, 6, 4, 4, 2.0
+    cfg = R.Config(tree="admm", abitW=k, train_batch_size=B)
+    z = (torch.randn(B, C, H, W) * 1.6 + 0.2)
+    res = torch.randn(B, C, H, W) * 0.7 if residual else None
+    gq = torch.randn(B, C, H, W) * 0.01
+    bn = torch.nn.BatchNorm2d(C).train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.2)
+    admm = R.ADMM(B)
+    zz = z.clone().requires_grad_(True)
+    rr = res.clone().requires_grad_(True) if residual else None
+    xq, loss = R.act_quant(bn(zz), k, "second", cfg, admm)
+    y = xq + rr if residual else xq
+    y = torch.relu(y) if relu else y
+    (loss + (y * gq).sum()).backward()
+
+    def mem(t):     # the [B,F] matrix in the memory order under test
+        t = t.detach()
+        return (t.permute(0, 2, 3, 1) if nhwc else t).reshape(B, -1).numpy()
+
+    def unmem(a):
+        return (a.reshape(B, H, W, C).transpose(0, 3, 1, 2) if nhwc else a.reshape(B, C, H, W))
+
+    zm = mem(z)
+    ab, save, vu = O.bn_fold_ab(zm, C, nhwc, bn.weight.detach().numpy(), bn.bias.detach().numpy(), bn.eps)
+    np.testing.assert_allclose(save[0], z.mean((0, 2, 3)).numpy(), atol=1e-6)
+    np.testing.assert_allclose(vu, z.transpose(0, 1).reshape(C, -1).var(1, unbiased=True).numpy(), rtol=1e-5)
+    np.testing.assert_allclose(0.1 * vu + 0.9, bn.running_var.numpy(), rtol=1e-5)
+    yo, Do, xo = O.bn_site_fwd(zm, C, nhwc, ab, k, r, 0.0, None if res is None else mem(res), relu)
+    np.testing.assert_allclose(unmem(xo), bn(z).detach().numpy(), atol=2e-6)          # fma vs torch's mul+add
+    flips = np.abs(unmem(yo) - y.detach().numpy()) * (2 ** k - 1)
+    assert flips.max() <= 1.0 + 1e-3 and (flips > 0.5).mean() < 2e-3                   # tie-zone flips only
+    np.testing.assert_allclose(Do, admm.D.detach().numpy(), atol=TOL)
+    _, dD, _, _ = O.admm_loss(Do, admm.alterD.detach().numpy(), admm.gamma.detach().numpy(), 0.2, 0.3)
+    dz, dg, db, dres, _ = O.bn_site_bwd(mem(gq), dD, zm, C, nhwc, ab, save, yo if relu else None, r, 0.0)
+    np.testing.assert_allclose(unmem(dz), zz.grad.numpy(), atol=TOL, rtol=1e-3)
+    np.testing.assert_allclose(dg, bn.weight.grad.numpy(), atol=1e-4, rtol=1e-3)
+    np.testing.assert_allclose(db, bn.bias.grad.numpy(), atol=1e-4, rtol=1e-3)
+    if residual:
+        assert (unmem(dres) != rr.grad.numpy()).mean() < 2e-3
