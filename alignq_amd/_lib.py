@@ -12,7 +12,7 @@ SO_PATH = os.path.join(_HERE, "lib", "libalignq_hip.so")
 
 FORMULA_ADMM, FORMULA_CDF = 0, 1
 MAX_BATCH = 128
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _c = ctypes
 _vp, _i, _i64, _f, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_size_t
@@ -43,6 +43,9 @@ SIGNATURES = {
                                    _vp, _vp]),
     "alignq_corr_fwd": (_i, [_vp, _i, _i64, _f, _vp, _vp, _vp, _vp]),
     "alignq_corr_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _f, _vp, _vp, _vp]),
+    "alignq_corr_xy_ws_bytes": (_sz, [_i, _i64]),
+    "alignq_corr_xy_fwd": (_i, [_vp, _vp, _i, _i64, _f, _vp, _vp, _vp, _vp]),
+    "alignq_corr_xy_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _f, _vp, _vp, _vp]),
     "alignq_admm_ws_bytes": (_sz, [_i]),
     "alignq_admm_loss": (_i, [_vp, _i, _vp, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "alignq_admm_update": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _vp]),

@@ -181,6 +181,38 @@ class CorrFn(torch.autograd.Function):
         return dx, None
 
 
+class CorrXYFn(torch.autograd.Function):
+    """corr(x, y) with y a different matrix — the general form of model/quantization.py:134-137 (Office :158-161);
+    alignq_corr_xy_fwd / _bwd (exact fp32, deterministic)."""
+
+    @staticmethod
+    def forward(ctx, x, y, eps):
+        x, y = L.dev_f32(x, "corr x"), L.dev_f32(y, "corr y")
+        B, F = _as_bf(x)
+        if _as_bf(y) != (B, F):
+            raise RuntimeError(f"corr(x, y): shapes {tuple(x.shape)} and {tuple(y.shape)} do not give the same [B, F]")
+        lib = L.load()
+        G = torch.empty(B, B, dtype=torch.float32, device=x.device)
+        stats = torch.empty(4, F, dtype=torch.float32, device=x.device)
+        ws = _ws(lib.alignq_corr_xy_ws_bytes(B, F), x.device)
+        L.check(lib.alignq_corr_xy_fwd(L.ptr(x), L.ptr(y), B, F, float(eps), L.ptr(G), L.ptr(stats), L.ptr(ws),
+                                       L.stream_ptr()), "alignq_corr_xy_fwd")
+        ctx.save_for_backward(x, y, stats)
+        ctx.eps = float(eps)
+        return G
+
+    @staticmethod
+    def backward(ctx, dG):
+        x, y, stats = ctx.saved_tensors
+        B, F = _as_bf(x)
+        dG = L.dev_f32(dG, "grad")
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dy = torch.empty_like(y) if ctx.needs_input_grad[1] else None
+        L.check(L.load().alignq_corr_xy_bwd(L.ptr(dG), L.ptr(x), L.ptr(y), L.ptr(stats), B, F, ctx.eps, L.ptr(dx), L.ptr(dy),
+                                            L.stream_ptr()), "alignq_corr_xy_bwd")
+        return dx, dy, None
+
+
 # ------------------------------------------------------------------------------------------------ R6
 class AdmmLossFn(torch.autograd.Function):
     """ADMM.forward — utils/admm.py:24-33; gradients for D, alterD, gamma come from the same launch."""

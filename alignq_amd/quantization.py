@@ -170,10 +170,11 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
             return _site_act_res_relu(self, x, residual)
 
     def corr(x, y):
-        """corr(x, y) -> [B,B]; the reference only ever calls it with y is x (SYRK)."""
-        if y is not x and not (y.data_ptr() == x.data_ptr() and y.shape == x.shape):
-            raise NotImplementedError("alignq_amd.corr implements the reference's only use: corr(x, x)")
-        return ops.CorrFn.apply(x, eps)
+        """corr(x, y) -> [B,B] (ADMM tree :134-137; Office :158-161).  The reference only ever calls it with y is x: that
+        is the SYRK served by the fused MFMA kernels; any other y takes the general exact-fp32 kernels."""
+        if y is x or (y.data_ptr() == x.data_ptr() and y.shape == x.shape and y.stride() == x.stride()):
+            return ops.CorrFn.apply(x, eps)
+        return ops.CorrXYFn.apply(x, y, eps)
 
     def conv2d_Q_fn(w_bit, stage):
         class Conv2d_Q(nn.Conv2d):

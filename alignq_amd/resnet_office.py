@@ -26,9 +26,9 @@ def conv1x1(wbit, stage, cin, cout, stride=1):
 class Bottleneck(nn.Module):
     expansion = 4
 
-    def __init__(self, wbit, abit, stage, inplanes, planes, stride=1, downsample=None):
+    def __init__(self, wbit, abit, stage, inplanes, planes, stride=1, downsample=None, base_width=64):
         super().__init__()
-        width = planes
+        width = int(planes * (base_width / 64.))          # dann_office/model/resnet.py:103 (groups == 1)
         self.conv1 = conv1x1(wbit, stage, inplanes, width)
         self.bn1 = nn.BatchNorm2d(width)
         self.conv2 = conv3x3(wbit, stage, width, width, stride)
@@ -69,9 +69,10 @@ class Bottleneck(nn.Module):
 
 
 class ResNet(nn.Module):
-    def __init__(self, wbit, abit, stage, block, layers, num_classes=1000):
+    def __init__(self, wbit, abit, stage, block, layers, num_classes=1000, width_per_group=64):
         super().__init__()
         self.wbit, self.abit, self.stage = wbit, abit, stage
+        self.base_width = width_per_group
         self.act_q0 = Q.activation_quantize_fn(a_bit=abit, stage=stage)
         self.inplanes = 64
         self.conv1 = Q.conv2d_Q_fn(w_bit=wbit, stage=stage)(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
@@ -96,10 +97,10 @@ class ResNet(nn.Module):
         if stride != 1 or self.inplanes != planes * block.expansion:
             downsample = nn.Sequential(conv1x1(self.wbit, self.stage, self.inplanes, planes * block.expansion, stride),
                                        nn.BatchNorm2d(planes * block.expansion))
-        layers = [block(self.wbit, self.abit, self.stage, self.inplanes, planes, stride, downsample)]
+        layers = [block(self.wbit, self.abit, self.stage, self.inplanes, planes, stride, downsample, self.base_width)]
         self.inplanes = planes * block.expansion
         for _ in range(1, blocks):
-            layers.append(block(self.wbit, self.abit, self.stage, self.inplanes, planes))
+            layers.append(block(self.wbit, self.abit, self.stage, self.inplanes, planes, base_width=self.base_width))
         return nn.Sequential(*layers)
 
     def forward(self, x):

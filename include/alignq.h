@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALIGNQ_ABI_VERSION 4
+#define ALIGNQ_ABI_VERSION 5
 
 #define ALIGNQ_FORMULA_ADMM 0
 #define ALIGNQ_FORMULA_CDF 1
@@ -129,6 +129,16 @@ int alignq_corr_fwd(const float* x, int B, int64_t F, float eps, float* G, float
                     void* stream);
 int alignq_corr_bwd(const float* dG, const float* x, const float* stats, int B, int64_t F, float eps,
                     float* dx, void* ws, void* stream);
+
+/* The GENERAL corr(x, y), y a different [B,F] matrix (same reference lines: `x.matmul(y.T) / x.shape[1]` after both
+ * operands were standardised per feature over the batch): G = Xh Yh^T / F (not symmetric).  No BASELINE configuration
+ * calls it with y != x; plain exact-fp32 kernels (corr_xy_kernels.hip).  stats [4][F] out: mean_x, 1/(std_x+eps), mean_y,
+ * 1/(std_y+eps).  Backward: dx = d/dx sum(dG o G), dy likewise (either may be NULL).  ws: alignq_corr_xy_ws_bytes(B,F).  */
+size_t alignq_corr_xy_ws_bytes(int B, int64_t F);
+int alignq_corr_xy_fwd(const float* x, const float* y, int B, int64_t F, float eps, float* G, float* stats, void* ws,
+                       void* stream);
+int alignq_corr_xy_bwd(const float* dG, const float* x, const float* y, const float* stats, int B, int64_t F, float eps,
+                       float* dx, float* dy, void* stream);
 
 /* ---- R6: ADMM loss (utils/admm.py:24-33) --------------------------------------------------------
  * D: [b,b]; alterD, gamma: [dim,dim] with b <= dim (sliced [:b,:b]).  Writes loss (device scalar) and

@@ -512,3 +512,61 @@ void oq_bn_apply(const float* z, int B, int C, long HW, int nhwc, const float* a
       x[(long)b * F + f] = fmaf(ab[c], z[(long)b * F + f], ab[C + c]);
     }
 }
+
+/* ------------------------------------------------------------------ general corr(x, y) ------ */
+/* model/quantization.py:134-137 with y a different matrix (Office :158-161 adds eps): G = Xh Yh^T / F. */
+void oq_corr_xy_fwd(const float* x, const float* y, int B, long F, float eps, float* G) {
+  double* mx = malloc(sizeof(double) * F), *sx = malloc(sizeof(double) * F);
+  double* my = malloc(sizeof(double) * F), *sy = malloc(sizeof(double) * F);
+  double* xh = malloc(sizeof(double) * B * F), *yh = malloc(sizeof(double) * B * F);
+  col_stats(x, B, F, mx, sx);
+  col_stats(y, B, F, my, sy);
+  for (int b = 0; b < B; b++)
+    for (long f = 0; f < F; f++) {
+      xh[(long)b * F + f] = (x[(long)b * F + f] - mx[f]) / (sx[f] + eps);
+      yh[(long)b * F + f] = (y[(long)b * F + f] - my[f]) / (sy[f] + eps);
+    }
+  for (int i = 0; i < B; i++)
+    for (int j = 0; j < B; j++) {
+      double a = 0;
+      for (long f = 0; f < F; f++) a += xh[(long)i * F + f] * yh[(long)j * F + f];
+      G[i * B + j] = (float)(a / (double)F);
+    }
+  free(mx); free(sx); free(my); free(sy); free(xh); free(yh);
+}
+
+/* dv for v in {x (which=0), y (which=1)}: dVh = S Wh / F with S = dG (x) or dG^T (y), then the standardisation backward */
+static void corr_xy_bwd_one(const float* dG, int transpose, const float* v, const float* w, int B, long F, double eps,
+                            float* dv) {
+  double* mv = malloc(sizeof(double) * F), *sv = malloc(sizeof(double) * F);
+  double* mw = malloc(sizeof(double) * F), *sw = malloc(sizeof(double) * F);
+  double* vh = malloc(sizeof(double) * B), *wh = malloc(sizeof(double) * B), *d = malloc(sizeof(double) * B);
+  col_stats(v, B, F, mv, sv);
+  col_stats(w, B, F, mw, sw);
+  for (long f = 0; f < F; f++) {
+    double den = sv[f] + eps;
+    for (int b = 0; b < B; b++) {
+      vh[b] = (v[(long)b * F + f] - mv[f]) / den;
+      wh[b] = (w[(long)b * F + f] - mw[f]) / (sw[f] + eps);
+    }
+    double mean_d = 0, dot = 0;
+    for (int i = 0; i < B; i++) {
+      double a = 0;
+      for (int j = 0; j < B; j++) a += (double)(transpose ? dG[j * B + i] : dG[i * B + j]) * wh[j];
+      d[i] = a / (double)F;
+      mean_d += d[i];
+      dot += d[i] * vh[i];
+    }
+    mean_d /= B;
+    for (int b = 0; b < B; b++) {
+      double through_std = sv[f] > 0 ? (v[(long)b * F + f] - mv[f]) / ((B - 1) * sv[f]) * dot / den : 0.0;
+      dv[(long)b * F + f] = (float)((d[b] - mean_d) / den - through_std);
+    }
+  }
+  free(mv); free(sv); free(mw); free(sw); free(vh); free(wh); free(d);
+}
+
+void oq_corr_xy_bwd(const float* dG, const float* x, const float* y, int B, long F, float eps, float* dx, float* dy) {
+  if (dx) corr_xy_bwd_one(dG, 0, x, y, B, F, eps, dx);
+  if (dy) corr_xy_bwd_one(dG, 1, y, x, B, F, eps, dy);
+}

@@ -391,3 +391,153 @@ class TrainStep:
                                [m.gamma for m in mods], [m.mu for m in mods], [m.rho for m in mods],
                                bitW=self.cfg.bitW)
         return logits, ce, tl
+
+
+# ------------------------------------------------------------------------------------------------
+# Office / DANN harness (BASELINE config 5's caller of the hot path), restated from
+# cdf_alignment_admm/dann_office/model/resnet.py: Bottleneck :89-156, ResNet :159-271, ReverseLayerF :302-313,
+# DANN :316-334, and one iteration of dann_office/main.py:343-456 with the per-epoch SGD of :321-328.
+# Module / parameter names and registration ORDER are the reference's (named_parameters() order is part of the
+# interface: main.py:405-410 indexes it).  Pinned by tests/golden/g10_office_tiny_dann.npz.
+class _RevGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, alpha):
+        ctx.alpha = alpha
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.neg() * ctx.alpha, None
+
+
+class OfficeBottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, cfg: Config, wbit, abit, stage, inplanes, planes, stride=1, downsample=None, base_width=64):
+        super().__init__()
+        width = int(planes * (base_width / 64.))
+        self.cfg, self.abit, self.stage = cfg, abit, stage
+        self.conv1 = QConv2d(cfg, wbit, inplanes, width, 1)
+        self.bn1 = nn.BatchNorm2d(width)
+        self.conv2 = QConv2d(cfg, wbit, width, width, 3, stride, 1)
+        self.bn2 = nn.BatchNorm2d(width)
+        self.conv3 = QConv2d(cfg, wbit, width, planes * 4, 1)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.downsample = downsample
+        self.admm0 = ADMM(cfg.train_batch_size)
+
+    def forward(self, x):
+        cfg, k, st = self.cfg, self.abit, self.stage
+        identity = x
+        out = F.relu(act_quant(self.bn1(self.conv1(x)), k, st, cfg, None)[0])           # act_q1: plain quantiser
+        out = F.relu(act_quant(self.bn2(self.conv2(out)), k, st, cfg, None)[0])         # act_q2
+        out, loss = act_quant(self.bn3(self.conv3(out)), k, st, cfg, self.admm0)        # act_q3: corr pair + ADMM
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        out = out + identity
+        return F.relu(out), 0. + loss
+
+
+class OfficeResNet(nn.Module):
+    def __init__(self, cfg: Config, wbit, abit, stage, layers, width_per_group=64):
+        super().__init__()
+        self.cfg, self.wbit, self.abit, self.stage, self.base_width = cfg, wbit, abit, stage, width_per_group
+        self.inplanes = 64
+        self.conv1 = QConv2d(cfg, wbit, 3, 64, 7, 2, 3)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.layer1 = self._make_layer(64, layers[0])
+        self.layer2 = self._make_layer(128, layers[1], 2)
+        self.layer3 = self._make_layer(256, layers[2], 2)
+        self.layer4 = self._make_layer(512, layers[3], 2)
+        self.fc = nn.Linear(2048, 1000)                   # present in the reference, never used by DANN.forward
+
+    def _make_layer(self, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * 4:
+            downsample = nn.Sequential(QConv2d(self.cfg, self.wbit, self.inplanes, planes * 4, 1, stride),
+                                       nn.BatchNorm2d(planes * 4))
+        mods = [OfficeBottleneck(self.cfg, self.wbit, self.abit, self.stage, self.inplanes, planes, stride, downsample,
+                                 self.base_width)]
+        self.inplanes = planes * 4
+        for _ in range(1, blocks):
+            mods.append(OfficeBottleneck(self.cfg, self.wbit, self.abit, self.stage, self.inplanes, planes,
+                                         base_width=self.base_width))
+        return nn.Sequential(*mods)
+
+    def blocks(self):
+        return [b for layer in (self.layer1, self.layer2, self.layer3, self.layer4) for b in layer]
+
+    def forward(self, x):
+        x = F.relu(act_quant(self.bn1(self.conv1(x)), self.abit, self.stage, self.cfg, None)[0])
+        x = F.max_pool2d(x, 3, 2, 1)
+        tl = 0.
+        for b in self.blocks():
+            x, loss = b(x)
+            tl = tl + loss
+        return torch.flatten(F.adaptive_avg_pool2d(x, 1), 1), tl
+
+
+class OfficeDANN(nn.Module):
+    def __init__(self, cfg: Config, wbit, abit, stage="aligned", layers=(3, 4, 6, 3), width_per_group=64, num_classes=31):
+        super().__init__()
+        self.feature = OfficeResNet(cfg, wbit, abit, stage, layers, width_per_group)
+        self.class_classifier = nn.Sequential()
+        self.class_classifier.add_module("c_fc3", nn.Linear(2048, num_classes))
+        self.domain_classifier = nn.Sequential()
+        self.domain_classifier.add_module("d_fc2", nn.Linear(2048, 2))
+
+    def forward(self, x, alpha):
+        feature, tl = self.feature(x)
+        feature = feature.view(-1, 2048)
+        return self.class_classifier(feature), self.domain_classifier(_RevGrad.apply(feature, alpha)), tl
+
+
+class OfficeTrainStep:
+    """dann_office/main.py:343-456; `new_epoch` = the SGD re-creation of :321-328."""
+
+    def __init__(self, net: OfficeDANN, cfg: Config, lr=0.04, momentum=0.9, weight_decay=5e-4, alpha=0.5):
+        self.net, self.cfg, self.alpha = net, cfg, alpha
+        self.momentum, self.weight_decay = momentum, weight_decay
+        named = list(net.named_parameters())
+        self.named = named
+        self.param_admm = [(n, p) for n, p in named if "alterD" in n or "gamma" in n]
+        self.opt_admm = ADMM_OPT([p for _, p in self.param_admm])
+        self.idx = [j for j, (n, _) in enumerate(named) if ("conv" in n or "downsample.0" in n) and "weight" in n][1:]
+        self.a_idx = [j for j, (n, _) in enumerate(self.param_admm) if "alterD" in n]
+        self.g_idx = [j for j, (n, _) in enumerate(self.param_admm) if "gamma" in n]
+        self._make_sgd(lr)
+
+    def _make_sgd(self, rate):
+        m = self.net
+        self.opt_t = SGD([{"params": list(m.feature.parameters())},
+                          {"params": list(m.class_classifier.parameters()), "lr": rate},
+                          {"params": list(m.domain_classifier.parameters()), "lr": rate}],
+                         lr=rate / 10, momentum=self.momentum, weight_decay=self.weight_decay, bitW=self.cfg.bitW)
+
+    def new_epoch(self, epoch, num_epochs, lr):
+        rate = lr / math.pow(1 + 10 * (epoch - 1) / num_epochs, 0.75)
+        self._make_sgd(rate)
+        return rate
+
+    def __call__(self, xs, ys, xt):
+        net = self.net
+        self.opt_t.zero_grad()
+        self.opt_admm.zero_grad()
+        cls_s, dom_s, tl_s = net(xs, self.alpha)
+        self.D_src = [b.admm0.D.detach().clone() for b in net.feature.blocks()]
+        l_cls = F.cross_entropy(cls_s, ys)
+        l_ds = F.cross_entropy(dom_s, torch.zeros(xs.shape[0], dtype=torch.long))
+        _, dom_t, tl_t = net(xt, self.alpha)
+        l_dt = F.cross_entropy(dom_t, torch.ones(xt.shape[0], dtype=torch.long))
+        loss = l_cls + l_ds + l_dt + tl_s + tl_t
+        loss.backward()
+        convs = []
+        for b in net.feature.blocks():
+            for k, conv in enumerate((b.conv1, b.conv2, b.conv3, b.downsample)):
+                if conv is not None:
+                    convs.append(conv[0] if k == 3 else conv)
+        self.opt_t.step(self.idx, [c.weight_cdf for c in convs], [c.weight_pdf for c in convs], self.cfg.lam, self.cfg.lam2)
+        a = [b.admm0 for b in net.feature.blocks()]
+        self.opt_admm.step(self.a_idx, self.g_idx, [q.D for q in a], [q.alterD for q in a], [q.gamma for q in a],
+                           [q.mu for q in a], [q.rho for q in a], bitW=self.cfg.bitW)
+        return dict(cls_s=cls_s, dom_s=dom_s, dom_t=dom_t, tl_s=tl_s, tl_t=tl_t, loss=loss)

@@ -377,7 +377,138 @@ def gen_office_keys():
           sgd_group_keys=np.array(sorted(osd["param_groups"][0].keys())), stage=np.array(str(args.stage)))
 
 
-GEN = {"admm_cifar": gen_admm_cifar, "cdf_only": gen_cdf_only, "office": gen_office, "office_keys": gen_office_keys}
+# ----------------------------------------------------------------------------------------------
+# Round-2 additions.  Each lives in its OWN variant (own process, own generators) so that the fixtures above stay
+# byte-identical when the script is re-run.
+def gen_corr_xy_admm():
+    """G4b: the GENERAL corr(x, y), y is not x (model/quantization.py:134-137), and G11: the `cdf` nn.Module used
+    stand-alone (model/quantization.py:41-59) for both quant_src values, with its autograd gradient."""
+    import torch
+    q, args = _enter("admm_cifar", ["--bitW", "8", "--abitW", "8", "--train_batch_size", "8"])
+    g = torch.Generator().manual_seed(2024)
+    out = {}
+    for ci, (B, Fdim) in enumerate([(16, 256), (128, 1024), (5, 70)]):
+        x = torch.randn(B, Fdim, generator=g) * 0.8 + 0.1
+        y = torch.randn(B, Fdim, generator=g) * 1.3 - 0.2 + 0.3 * x
+        dG = torch.randn(B, B, generator=g)
+        xi, yi = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+        G = q.corr(xi, yi)
+        G.backward(dG)
+        out[f"x_c{ci}"], out[f"y_c{ci}"], out[f"dG_c{ci}"] = _np(x), _np(y), _np(dG)
+        out[f"G_c{ci}"], out[f"dx_c{ci}"], out[f"dy_c{ci}"] = _np(G), _np(xi.grad), _np(yi.grad)
+    _save("g4b_corr_xy_noeps", **out)
+
+    out = {"act_range": np.array(float(args.act_range), dtype=np.float32)}
+    v = torch.randn(4, 6, 5, 5, generator=g) * 1.1
+    gc = torch.randn(v.shape, generator=g)
+    out["v"], out["gc"] = _np(v), _np(gc)
+    for src, m, s in (("a", 0.0, 1.0), ("w", 0.07, 0.6)):
+        vi = v.clone().requires_grad_(True)
+        c, pdf = q.cdf(torch.tensor(m), torch.tensor(s), src)(vi)
+        c.backward(gc)
+        out[f"m_{src}"], out[f"s_{src}"] = np.array(m, np.float32), np.array(s, np.float32)
+        out[f"cdf_{src}"], out[f"pdf_{src}"], out[f"dv_{src}"] = _np(c), _np(pdf), _np(vi.grad)
+    _save("g11_cdf_module_admm", **out)
+
+
+def gen_corr_xy_office():
+    """G4b, Office tree: corr(x, y) with the +1e-5 (dann_office/model/quantization.py:158-161)."""
+    import torch
+    q, args = _enter("office", ["--bitW", "8", "--abitW", "8"])
+    g = torch.Generator().manual_seed(2025)
+    out = {}
+    for ci, (B, Fdim) in enumerate([(28, 512), (7, 96)]):
+        x = torch.randn(B, Fdim, generator=g) * 0.8 + 0.1
+        y = torch.randn(B, Fdim, generator=g) * 1.3 - 0.2 + 0.3 * x
+        if ci == 1:
+            y[:, 3] = -0.5          # a constant feature of y: finite only thanks to the +1e-5
+        dG = torch.randn(B, B, generator=g)
+        xi, yi = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+        G = q.corr(xi, yi)
+        G.backward(dG)
+        out[f"x_c{ci}"], out[f"y_c{ci}"], out[f"dG_c{ci}"] = _np(x), _np(y), _np(dG)
+        out[f"G_c{ci}"], out[f"dx_c{ci}"], out[f"dy_c{ci}"] = _np(G), _np(xi.grad), _np(yi.grad)
+    _save("g4b_corr_xy_eps", **out)
+
+
+def gen_office_tiny_dann():
+    """G10 (SURVEY.md §8f-N3 at value level): a tiny DANN — ResNet(Bottleneck, [1,1,1,1], width_per_group=8) + both heads,
+    4W/4A, batch 6, 64x64 inputs — through TWO iterations of dann_office/main.py:343-456 (source pass, target pass, summed
+    loss, SGD over the three groups incl. alterD/gamma, ADMM_OPT.step on the TARGET pass's D), with the per-epoch SGD
+    re-creation of main.py:321-328 between them (epoch 1 -> epoch 2: new learning rates, momentum buffers start over).
+    Initial parameters come from tests/golden/det_init.py (same function on the test side), so no state_dict is stored."""
+    import importlib
+    import math
+    import torch
+    sys.path.insert(0, HERE)
+    from det_init import det_init_, sample
+    q, args = _enter("office", ["--bitW", "4", "--abitW", "4", "--train_batch_size", "6"])
+    r = importlib.import_module("model.resnet")
+    r.device = torch.device("cpu")
+    from utils.optimizer import SGD, ADMM_OPT
+    torch.manual_seed(0)
+    net = r.DANN(lambda w, a, s: r.ResNet(w, a, s, r.Bottleneck, [1, 1, 1, 1], width_per_group=8), 4, 4, args.stage)
+    net.train()
+    det_init_(net)
+    g = torch.Generator().manual_seed(31)
+    xs = torch.randn(2, 6, 3, 64, 64, generator=g)
+    xt = torch.randn(2, 6, 3, 64, 64, generator=g) * 1.2 + 0.1
+    ys = torch.randint(0, 31, (2, 6), generator=g)
+    out = dict(xs=_np(xs), xt=_np(xt), ys=_np(ys), stage=np.array(str(args.stage)), lr=np.array(0.004),
+               num_epochs=np.array(10), alpha=np.array(0.5), names=np.array([n for n, _ in net.named_parameters()]))
+    named = list(net.named_parameters())
+    param_admm = [(n, p) for n, p in named if "alterD" in n or "gamma" in n]
+    opt_a = ADMM_OPT([p for _, p in param_admm])
+    ce = torch.nn.CrossEntropyLoss()
+    blocks = [b for layer in (net.feature.layer1, net.feature.layer2, net.feature.layer3, net.feature.layer4) for b in layer]
+    for it, epoch in enumerate((1, 2)):
+        rate = 0.004 / math.pow(1 + 10 * (epoch - 1) / 10, 0.75)                    # main.py:321
+        opt_t = SGD([{"params": net.feature.parameters()},                          # main.py:324-328 (new every epoch)
+                     {"params": net.class_classifier.parameters(), "lr": rate},
+                     {"params": net.domain_classifier.parameters(), "lr": rate}],
+                    lr=rate / 10, momentum=0.9, weight_decay=5e-4)
+        opt_t.zero_grad()
+        opt_a.zero_grad()
+        cls_s, dom_s, tl_s = net(xs[it], alpha=0.5)
+        D_src = [_np(b.admm0.D) for b in blocks]
+        l_cls = ce(cls_s, ys[it])
+        l_ds = ce(dom_s, torch.zeros(6, dtype=torch.long))
+        _, dom_t, tl_t = net(xt[it], alpha=0.5)
+        l_dt = ce(dom_t, torch.ones(6, dtype=torch.long))
+        loss = l_cls + l_ds + l_dt + tl_s + tl_t
+        loss.backward()
+        idx = [j for j, (n, _) in enumerate(named) if ("conv" in n or "downsample.0" in n) and "weight" in n][1:]
+        w_cdf, w_pdf = [], []
+        for b in blocks:
+            for k, conv in enumerate([b.conv1, b.conv2, b.conv3, b.downsample]):
+                if conv is not None:
+                    conv = conv[0] if k == 3 else conv
+                    w_cdf.append(conv.quantize_fn.weight_cdf)
+                    w_pdf.append(conv.quantize_fn.weight_pdf)
+        a_idx = [j for j, (n, _) in enumerate(param_admm) if "alterD" in n]
+        g_idx = [j for j, (n, _) in enumerate(param_admm) if "gamma" in n]
+        out[f"cls_s_{it}"], out[f"dom_s_{it}"], out[f"dom_t_{it}"] = _np(cls_s), _np(dom_s), _np(dom_t)
+        out[f"tl_s_{it}"], out[f"tl_t_{it}"], out[f"loss_{it}"] = _np(tl_s), _np(tl_t), _np(loss)
+        for bi, b in enumerate(blocks):
+            out[f"Dsrc_{it}_{bi}"] = D_src[bi]
+            out[f"D_{it}_{bi}"] = _np(b.admm0.D)                                    # the TARGET pass's D
+        for j, (n, p) in enumerate(named):
+            if p.grad is not None:                      # feature.fc is never used by DANN.forward
+                out[f"grad_{it}/{j}"] = _np(sample(p.grad))
+        opt_t.step(idx, w_cdf, w_pdf, float(args.lam), float(args.lam2))
+        opt_a.step(a_idx, g_idx, [b.admm0.D for b in blocks], [b.admm0.alterD for b in blocks],
+                   [b.admm0.gamma for b in blocks], [b.admm0.mu for b in blocks], [b.admm0.rho for b in blocks])
+        for j, (n, p) in enumerate(named):
+            out[f"after_{it}/{j}"] = _np(sample(p))
+            st = opt_t.state.get(p, {})
+            if "momentum_buffer" in st:
+                out[f"buf_{it}/{j}"] = _np(sample(st["momentum_buffer"]))
+        out[f"rate_{it}"] = np.array(rate)
+    _save("g10_office_tiny_dann", **out)
+
+
+GEN = {"admm_cifar": gen_admm_cifar, "cdf_only": gen_cdf_only, "office": gen_office, "office_keys": gen_office_keys,
+       "corr_xy_admm": gen_corr_xy_admm, "corr_xy_office": gen_corr_xy_office, "office_tiny_dann": gen_office_tiny_dann}
 
 
 def main():

@@ -158,3 +158,14 @@ def bn_apply(z, C, nhwc, ab):
     z, ab = _f32(z), _f32(ab); B = z.shape[0]; HW = z.size // B // C
     x = np.empty_like(z)
     lib().oq_bn_apply(_p(z), c_int(B), c_int(C), c_long(HW), c_int(nhwc), _p(ab), _p(x)); return x
+
+
+def corr_xy_fwd(x, y, eps=0.0):
+    x, y = _f32(x), _f32(y); B, F = x.shape; G = np.empty((B, B), np.float32)
+    lib().oq_corr_xy_fwd(_p(x), _p(y), c_int(B), c_long(F), c_float(eps), _p(G)); return G
+
+
+def corr_xy_bwd(dG, x, y, eps=0.0):
+    x, y, dG = _f32(x), _f32(y), _f32(dG); B, F = x.shape
+    dx, dy = np.empty_like(x), np.empty_like(y)
+    lib().oq_corr_xy_bwd(_p(dG), _p(x), _p(y), c_int(B), c_long(F), c_float(eps), _p(dx), _p(dy)); return dx, dy

@@ -204,9 +204,17 @@ def test_corr_vs_reference(dev, fname, eps):
         ci += 1
 
 
-@pytest.mark.parametrize("B,F", [(128, 4096), (128, 16384), (28, 1568), (64, 640), (10, 100), (33, 70), (3, 64)])
+@pytest.mark.parametrize("B,F", [(128, 4096), (128, 16384), (28, 1568), (64, 640), (10, 100), (33, 70), (3, 64), (2, 64)])
 def test_corr_vs_oracle_shapes(dev, B, F):
-    """ragged shapes: F not a multiple of the 64-feature tile or of 4, B not a multiple of 32."""
+    """ragged shapes: F not a multiple of the 64-feature tile or of 4, B not a multiple of 32; B = 2 is the smallest batch the
+    ABI advertises (include/alignq.h: 2 <= B).
+
+    The bar on dx scales with the size of the terms it is a difference of: dx_f = rho_f * (dXh - mean(dXh) - xh * proj), each
+    term of magnitude |S| |xh| rho_f / F with rho_f = 1 / std_f.  At B = 2 every standardised column is exactly +-1/sqrt(2)
+    and the analytic gradient is ZERO (the three terms cancel), while rho_f reaches 10^2 for columns whose two samples
+    nearly coincide; the kernels evaluate S * Xh on split-bf16 operands (16 mantissa bits, 2^-16 relative to the TERMS, the
+    accuracy that keeps D within 6e-7), so the residue is 2^-16 * max-term, not 1e-5 absolute.  (Round 1 saw 2.2e-5 here
+    and dropped the case; it is the conditioning of the expression, the same code passes 1e-5 wherever rho is O(1).)"""
     from alignq_amd import ops
     rng = np.random.default_rng(B * 1000 + F)
     x = (rng.standard_normal((B, F)) * 0.7 + 0.2).astype(np.float32)
@@ -216,7 +224,10 @@ def test_corr_vs_oracle_shapes(dev, B, F):
     G.backward(cu(dG, dev))
     np.testing.assert_allclose(npy(G), O.corr_fwd(x, 0.0), atol=TOL, rtol=0)
     ref = O.corr_bwd(dG, x, 0.0)
-    np.testing.assert_allclose(npy(xt.grad), ref, atol=TOL * max(1.0, np.abs(ref).max()), rtol=1e-4)
+    rho = 1.0 / x.astype(np.float64).std(0, ddof=1)
+    term = np.abs(dG).max() * 2 * np.sqrt(B) / F * rho                   # per-column magnitude of the cancelling terms
+    atol = np.maximum(TOL * max(1.0, np.abs(ref).max()), 2.0 ** -15 * term)[None, :]
+    assert (np.abs(npy(xt.grad) - ref) <= atol + 1e-4 * np.abs(ref)).all(), float(np.abs(npy(xt.grad) - ref).max())
 
 
 # ------------------------------------------------------------------------------------------- R4+R5+R6 site

@@ -249,3 +249,20 @@ def test_bn_folded_site_oracle_vs_torch_batchnorm(nhwc, relu, residual):
     np.testing.assert_allclose(db, bn.bias.grad.numpy(), atol=1e-4, rtol=1e-3)
     if residual:
         assert (unmem(dres) != rr.grad.numpy()).mean() < 2e-3
+
+
+@pytest.mark.parametrize("fname,eps,cases", [("g4b_corr_xy_noeps", 0.0, 3), ("g4b_corr_xy_eps", 1e-5, 2)])
+def test_general_corr_xy_vs_reference(fname, eps, cases):
+    """oq_corr_xy_fwd / _bwd against the reference's corr(x, y) called with two DIFFERENT matrices (fixture captured from
+    model/quantization.py:134-137 and the Office tree's :158-161)."""
+    g = load_golden(fname)
+    for ci in range(cases):
+        x, y, dG = g[f"x_c{ci}"], g[f"y_c{ci}"], g[f"dG_c{ci}"]
+        G = O.corr_xy_fwd(x, y, eps)
+        np.testing.assert_allclose(G, g[f"G_c{ci}"], atol=TOL, rtol=0)
+        assert np.abs(G - G.T).max() > 1e-3                    # really the non-symmetric product
+        dx, dy = O.corr_xy_bwd(dG, x, y, eps)
+        np.testing.assert_allclose(dx, g[f"dx_c{ci}"], atol=TOL, rtol=1e-4)
+        np.testing.assert_allclose(dy, g[f"dy_c{ci}"], atol=TOL, rtol=1e-4)
+        # corr(x, x) through the general path equals the SYRK oracle
+        np.testing.assert_allclose(O.corr_xy_fwd(x, x, eps), O.corr_fwd(x, eps), atol=1e-6)

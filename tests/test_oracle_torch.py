@@ -204,3 +204,39 @@ def test_g8_tiny_resnet_two_steps():
                 n = ref_to_oracle_name(key[len(f"after{it}/"):])
                 if n is not None:
                     np.testing.assert_allclose(got[n].numpy(), v, atol=2e-5, rtol=1e-4, err_msg=n)
+
+
+def test_office_tiny_dann_two_iterations_match_the_reference():
+    """G10: the eager restatement of the Office harness (OfficeDANN + OfficeTrainStep: two passes per iteration, summed
+    loss, three SGD groups incl. alterD/gamma, ADMM_OPT on the TARGET pass's D, per-epoch SGD re-creation) against the
+    reference's own dann_office model driven through main.py:343-456's sequence — same ATen ops, so values match to
+    rounding (1e-6) over both iterations."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from det_init import det_init_, sample
+    from oracle import torch_ref as R
+    g = load_golden("g10_office_tiny_dann")
+    torch.set_num_threads(4)
+    cfg = R.Config(tree="office", bitW=4, abitW=4, train_batch_size=6)
+    torch.manual_seed(0)
+    net = R.OfficeDANN(cfg, 4, 4, str(g["stage"]), (1, 1, 1, 1), width_per_group=8).train()
+    assert [n for n, _ in net.named_parameters()] == list(g["names"])
+    det_init_(net)
+    step = R.OfficeTrainStep(net, cfg, lr=float(g["lr"]), alpha=float(g["alpha"]))
+    named = list(net.named_parameters())
+    for it, epoch in enumerate((1, 2)):
+        rate = step.new_epoch(epoch, int(g["num_epochs"]), float(g["lr"]))
+        assert abs(rate - float(g[f"rate_{it}"])) < 1e-12
+        out = step(torch.from_numpy(g["xs"][it]), torch.from_numpy(g["ys"][it]), torch.from_numpy(g["xt"][it]))
+        for key in ("cls_s", "dom_s", "dom_t", "tl_s", "tl_t", "loss"):
+            np.testing.assert_allclose(out[key].detach().numpy(), g[f"{key}_{it}"], atol=2e-5, rtol=1e-5, err_msg=key)
+        for bi, b in enumerate(net.feature.blocks()):
+            np.testing.assert_allclose(b.admm0.D.detach().numpy(), g[f"D_{it}_{bi}"], atol=1e-6)      # the TARGET pass's D
+            np.testing.assert_allclose(step.D_src[bi].numpy(), g[f"Dsrc_{it}_{bi}"], atol=1e-6)
+            assert np.abs(g[f"D_{it}_{bi}"] - g[f"Dsrc_{it}_{bi}"]).max() > 1e-4                       # and they do differ
+        for j, (n, p) in enumerate(named):
+            np.testing.assert_allclose(sample(p).numpy(), g[f"after_{it}/{j}"], atol=2e-6, rtol=1e-5, err_msg=n)
+            if f"buf_{it}/{j}" in g:
+                np.testing.assert_allclose(sample(step.opt_t.state[p]["momentum_buffer"]).numpy(), g[f"buf_{it}/{j}"],
+                                           atol=2e-6, rtol=1e-5, err_msg=n)
