@@ -26,6 +26,10 @@ SIGNATURES = {
     "alignq_act_quant_bwd": (_i, [_vp, _vp, _vp, _i64, _f, _vp]),
     "alignq_act_quant_relu_fwd": (_i, [_vp, _vp, _i64, _i, _f, _i, _vp]),
     "alignq_act_quant_relu_bwd": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _vp]),
+    "alignq_bin_bytes": (_i, [_i, _f, _i]),
+    "alignq_act_quant_fwd_packed": (_i, [_vp, _vp, _vp, _i64, _i, _f, _i, _i, _vp]),
+    "alignq_bins_dequant": (_i, [_vp, _vp, _i64, _i, _f, _i, _i, _vp]),
+    "alignq_act_quant_bwd_packed": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _f, _i, _i, _vp]),
     "alignq_weight_ws_bytes": (_sz, [_i64]),
     "alignq_weight_stats": (_i, [_vp, _i64, _vp, _vp, _vp]),
     "alignq_weight_quant_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp]),

@@ -209,6 +209,130 @@ __global__ __launch_bounds__(kThreads) void weight_bwd_apply_kernel(const float*
   }
 }
 
+
+// ------------------------------------------------------------------ N2: integer bin storage ----
+// the quantised activation IS an integer level index; stored as int8 / int16 it costs 1-2 B instead of the
+// 4 B of the dequantised fp32 value (reference format sites: model/quantization.py:23-31 `round(x*n)/n`, :109-110).
+//   ADMM / Office formula: idx = round(t*n) in [-r*n, r*n]  -> SIGNED   int8 while r*n <= 127 (k <= 6 at r = 2), else int16
+//                          (8-bit: 1021 levels); value = idx / n
+//   CDF-tree formula     : idx = round(c*n) in [0, n]       -> UNSIGNED uint8 for k <= 8, else uint16;
+//                          value = (idx / n * 2 - 1) * r
+// value(idx) below is the SAME sequence of IEEE operations as round_bins / act_quant1, so a dequantised bin is bit-identical
+// to the fp32 x_q the fused quantiser writes.
+template <int FORMULA>
+__device__ __forceinline__ float bin_value(float b, int k, const Levels& L, float r) {
+  float q = b;
+  if (k != 1 && k != 32) q = (L.yn != 0.0f) ? div_const(b, L.n, L.yn) : __fdiv_rn(b, L.n);
+  if (FORMULA == 0) return q;
+  return __fmul_rn(__fsub_rn(__fmul_rn(q, 2.0f), 1.0f), r);
+}
+
+template <typename T> struct Vec4;
+template <> struct Vec4<int8_t> { typedef char4 type; };
+template <> struct Vec4<uint8_t> { typedef uchar4 type; };
+template <> struct Vec4<int16_t> { typedef short4 type; };
+template <> struct Vec4<uint16_t> { typedef ushort4 type; };
+
+template <int FORMULA, typename T, bool WITH_XQ>
+__global__ __launch_bounds__(kThreads) void act_quant_fwd_packed_kernel(const float* __restrict__ x, float* __restrict__ xq,
+                                                                        T* __restrict__ bins, int64_t n, int k, float r,
+                                                                        int relu) {
+  typedef typename Vec4<T>::type V4;
+  const Levels nlev = make_levels(k, fabsf(r) <= 8.0f);
+  const int64_t nvec = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += stride) {
+    const float4 v = x4[i];
+    float4 o;
+    float t, b0, b1, b2, b3;
+    o.x = act_quant1<FORMULA>(v.x, k, nlev, r, &t, &b0);
+    o.y = act_quant1<FORMULA>(v.y, k, nlev, r, &t, &b1);
+    o.z = act_quant1<FORMULA>(v.z, k, nlev, r, &t, &b2);
+    o.w = act_quant1<FORMULA>(v.w, k, nlev, r, &t, &b3);
+    V4 bi;
+    bi.x = (T)(int)b0; bi.y = (T)(int)b1; bi.z = (T)(int)b2; bi.w = (T)(int)b3;
+    reinterpret_cast<V4*>(bins)[i] = bi;
+    if (WITH_XQ) {
+      if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      reinterpret_cast<float4*>(xq)[i] = o;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = (nvec << 2) + threadIdx.x;
+    float t, b;
+    const float q = act_quant1<FORMULA>(x[i], k, nlev, r, &t, &b);
+    bins[i] = (T)(int)b;
+    if (WITH_XQ) xq[i] = relu ? fmaxf(q, 0.f) : q;
+  }
+}
+
+template <int FORMULA, typename T>
+__global__ __launch_bounds__(kThreads) void bins_dequant_kernel(const T* __restrict__ bins, float* __restrict__ y, int64_t n,
+                                                                int k, float r, int relu) {
+  typedef typename Vec4<T>::type V4;
+  const Levels nlev = make_levels(k, fabsf(r) <= 8.0f);
+  const int64_t nvec = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += stride) {
+    const V4 b = reinterpret_cast<const V4*>(bins)[i];
+    float4 o;
+    o.x = bin_value<FORMULA>((float)b.x, k, nlev, r);
+    o.y = bin_value<FORMULA>((float)b.y, k, nlev, r);
+    o.z = bin_value<FORMULA>((float)b.z, k, nlev, r);
+    o.w = bin_value<FORMULA>((float)b.w, k, nlev, r);
+    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    reinterpret_cast<float4*>(y)[i] = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = (nvec << 2) + threadIdx.x;
+    const float v = bin_value<FORMULA>((float)bins[i], k, nlev, r);
+    y[i] = relu ? fmaxf(v, 0.f) : v;
+  }
+}
+
+// STE backward with the ReLU mask taken from the stored bin (value(idx) > 0) instead of from an fp32 copy of relu(x_q):
+// reads g 4 B + x 4 B + idx 1-2 B, writes dx 4 B.  ADMM formula: value > 0 <=> idx > 0; CDF: <=> 2 idx > n (r > 0).
+template <int FORMULA, typename T>
+__global__ __launch_bounds__(kThreads) void act_quant_bwd_packed_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                                        const T* __restrict__ bins, float* __restrict__ dx,
+                                                                        int64_t n, int k, float r, int relu) {
+  typedef typename Vec4<T>::type V4;
+  const Levels nlev = make_levels(k, fabsf(r) <= 8.0f);
+  const int64_t nvec = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += stride) {
+    float4 gv = reinterpret_cast<const float4*>(g)[i];
+    const float4 xv = reinterpret_cast<const float4*>(x)[i];
+    if (relu) {
+      const V4 b = reinterpret_cast<const V4*>(bins)[i];
+      gv.x = bin_value<FORMULA>((float)b.x, k, nlev, r) > 0.f ? gv.x : 0.f;
+      gv.y = bin_value<FORMULA>((float)b.y, k, nlev, r) > 0.f ? gv.y : 0.f;
+      gv.z = bin_value<FORMULA>((float)b.z, k, nlev, r) > 0.f ? gv.z : 0.f;
+      gv.w = bin_value<FORMULA>((float)b.w, k, nlev, r) > 0.f ? gv.w : 0.f;
+    }
+    float4 o;
+    o.x = gv.x * act_jac(xv.x, r); o.y = gv.y * act_jac(xv.y, r); o.z = gv.z * act_jac(xv.z, r); o.w = gv.w * act_jac(xv.w, r);
+    reinterpret_cast<float4*>(dx)[i] = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = (nvec << 2) + threadIdx.x;
+    const bool keep = !relu || bin_value<FORMULA>((float)bins[i], k, nlev, r) > 0.f;
+    dx[i] = (keep ? g[i] : 0.f) * act_jac(x[i], r);
+  }
+}
+
+inline int bin_bytes_of(int k, float r, int formula) {
+  if (!(k >= 1 && k <= 16) || !(r > 0.0f)) return 0;
+  const double n = (double)((1 << k) - 1);
+  if (formula == ALIGNQ_FORMULA_ADMM) {
+    const double m = (k == 1) ? 1.0 : ceil((double)r * n);
+    return m <= 127.0 ? 1 : (m <= 32767.0 ? 2 : 0);
+  }
+  if (formula == ALIGNQ_FORMULA_CDF) return n <= 255.0 ? 1 : 2;
+  return 0;
+}
+
 inline int ws_blocks(int64_t n) {
   int64_t b = (n + (int64_t)kThreads * 8 - 1) / ((int64_t)kThreads * 8);
   if (b < 1) b = 1;
@@ -284,6 +408,71 @@ int alignq_act_quant_relu_bwd(const float* g, const float* x, const float* y, fl
        reinterpret_cast<uintptr_t>(y)) & 15)
     return ALIGNQ_EINVAL;
   hipLaunchKernelGGL(act_quant_bwd_kernel<true>, grid_for(n >> 2), kThreads, 0, (hipStream_t)stream, g, x, y, dx, n, act_range);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+
+int alignq_bin_bytes(int k, float act_range, int formula) { return bin_bytes_of(k, act_range, formula); }
+
+int alignq_act_quant_fwd_packed(const float* x, float* xq, void* bins, int64_t n, int k, float act_range, int formula,
+                                int relu, void* stream) {
+  if (!x || !bins || n <= 0) return ALIGNQ_EINVAL;
+  const int bb = bin_bytes_of(k, act_range, formula);
+  if (bb == 0) return ALIGNQ_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(xq) | reinterpret_cast<uintptr_t>(bins)) & 15)
+    return ALIGNQ_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = grid_for(n >> 2);
+#define FWDP(F, T)                                                                                                            \
+  do {                                                                                                                        \
+    if (xq) hipLaunchKernelGGL((act_quant_fwd_packed_kernel<F, T, true>), grid, kThreads, 0, st, x, xq, (T*)bins, n, k,        \
+                               act_range, relu);                                                                              \
+    else hipLaunchKernelGGL((act_quant_fwd_packed_kernel<F, T, false>), grid, kThreads, 0, st, x, xq, (T*)bins, n, k,          \
+                            act_range, relu);                                                                                 \
+  } while (0)
+  if (formula == ALIGNQ_FORMULA_ADMM) { if (bb == 1) FWDP(0, int8_t); else FWDP(0, int16_t); }
+  else { if (bb == 1) FWDP(1, uint8_t); else FWDP(1, uint16_t); }
+#undef FWDP
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int alignq_bins_dequant(const void* bins, float* y, int64_t n, int k, float act_range, int formula, int relu, void* stream) {
+  if (!bins || !y || n <= 0) return ALIGNQ_EINVAL;
+  const int bb = bin_bytes_of(k, act_range, formula);
+  if (bb == 0) return ALIGNQ_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(bins)) & 15) return ALIGNQ_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = grid_for(n >> 2);
+  if (formula == ALIGNQ_FORMULA_ADMM) {
+    if (bb == 1) hipLaunchKernelGGL((bins_dequant_kernel<0, int8_t>), grid, kThreads, 0, st, (const int8_t*)bins, y, n, k, act_range, relu);
+    else hipLaunchKernelGGL((bins_dequant_kernel<0, int16_t>), grid, kThreads, 0, st, (const int16_t*)bins, y, n, k, act_range, relu);
+  } else {
+    if (bb == 1) hipLaunchKernelGGL((bins_dequant_kernel<1, uint8_t>), grid, kThreads, 0, st, (const uint8_t*)bins, y, n, k, act_range, relu);
+    else hipLaunchKernelGGL((bins_dequant_kernel<1, uint16_t>), grid, kThreads, 0, st, (const uint16_t*)bins, y, n, k, act_range, relu);
+  }
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int alignq_act_quant_bwd_packed(const float* g, const float* x, const void* bins, float* dx, int64_t n, int k,
+                                float act_range, int formula, int relu, void* stream) {
+  if (!g || !x || !dx || n <= 0 || (relu && !bins)) return ALIGNQ_EINVAL;
+  const int bb = bin_bytes_of(k, act_range, formula);
+  if (bb == 0) return ALIGNQ_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(dx) |
+       reinterpret_cast<uintptr_t>(bins)) & 15)
+    return ALIGNQ_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = grid_for(n >> 2);
+  if (formula == ALIGNQ_FORMULA_ADMM) {
+    if (bb == 1) hipLaunchKernelGGL((act_quant_bwd_packed_kernel<0, int8_t>), grid, kThreads, 0, st, g, x, (const int8_t*)bins, dx, n, k, act_range, relu);
+    else hipLaunchKernelGGL((act_quant_bwd_packed_kernel<0, int16_t>), grid, kThreads, 0, st, g, x, (const int16_t*)bins, dx, n, k, act_range, relu);
+  } else {
+    if (bb == 1) hipLaunchKernelGGL((act_quant_bwd_packed_kernel<1, uint8_t>), grid, kThreads, 0, st, g, x, (const uint8_t*)bins, dx, n, k, act_range, relu);
+    else hipLaunchKernelGGL((act_quant_bwd_packed_kernel<1, uint16_t>), grid, kThreads, 0, st, g, x, (const uint16_t*)bins, dx, n, k, act_range, relu);
+  }
   LAUNCH_CHECK();
   return 0;
 }

@@ -85,6 +85,67 @@ class ActQuantReluFn(torch.autograd.Function):
         return dx, None, None, None
 
 
+# ------------------------------------------------------------------------------------------------ N2: packed bins
+_BIN_DTYPES = {(0, 1): torch.int8, (0, 2): torch.int16, (1, 1): torch.uint8, (1, 2): torch.uint16}
+
+
+def bin_dtype(k, act_range, formula):
+    """torch dtype of the stored level index (include/alignq.h, N2): int8 / int16 (ADMM, Office formulas: signed) or
+    uint8 / uint16 (CDF-tree formula); None when the arguments have no packed form (k == 32)."""
+    nb = L.load().alignq_bin_bytes(int(k), float(act_range), int(formula))
+    return _BIN_DTYPES[(int(formula), nb)] if nb else None
+
+
+def act_quant_pack(x, k, act_range, formula, want_xq=False, relu=False):
+    """x -> narrow integer bins (and optionally [relu](x_q) in fp32) in one launch (alignq_act_quant_fwd_packed)."""
+    x = L.dense_f32(x, "activation")
+    dt = bin_dtype(k, act_range, formula)
+    if dt is None:
+        raise RuntimeError(f"no packed bin format for k={k}, act_range={act_range}, formula={formula}")
+    bins = torch.empty_strided(x.shape, x.stride(), dtype=dt, device=x.device)
+    xq = torch.empty_like(x) if want_xq else None
+    L.check(L.load().alignq_act_quant_fwd_packed(L.ptr(x), L.ptr(xq), L.ptr(bins), x.numel(), int(k), float(act_range),
+                                                 int(formula), int(bool(relu)), L.stream_ptr()), "alignq_act_quant_fwd_packed")
+    return (bins, xq) if want_xq else bins
+
+
+def dequant_bins(bins, k, act_range, formula, relu=False):
+    """[relu](value(idx)) in fp32, bit-identical to the fused quantiser's x_q (alignq_bins_dequant)."""
+    if not bins.is_cuda:
+        raise RuntimeError("alignq_amd: bins must be a CUDA/ROCm tensor (no CPU fallback in the product path)")
+    if bins.dtype != bin_dtype(k, act_range, formula):
+        raise TypeError(f"bins dtype {bins.dtype} does not match the packed format {bin_dtype(k, act_range, formula)}")
+    y = torch.empty_strided(bins.shape, bins.stride(), dtype=torch.float32, device=bins.device)
+    L.check(L.load().alignq_bins_dequant(L.ptr(bins), L.ptr(y), bins.numel(), int(k), float(act_range), int(formula),
+                                         int(bool(relu)), L.stream_ptr()), "alignq_bins_dequant")
+    return y
+
+
+class ActQuantPackedFn(torch.autograd.Function):
+    """[relu](activation_quantize_fn(x)) whose autograd node keeps the 1-2 B level index instead of a 4 B fp32 copy of the
+    output for its backward: forward x -> (y fp32, bins), backward reads g, x and the bins (ReLU mask =
+    value(idx) > 0).  The second output (bins) is what a consumer that understands the format stores / reads instead of y."""
+
+    @staticmethod
+    def forward(ctx, x, k, act_range, formula, relu):
+        x = L.dense_f32(x, "activation")
+        bins, y = act_quant_pack(x, k, act_range, formula, want_xq=True, relu=relu)
+        ctx.save_for_backward(x, bins)
+        ctx.cfg = (int(k), float(act_range), int(formula), bool(relu))
+        ctx.mark_non_differentiable(bins)
+        return y, bins
+
+    @staticmethod
+    def backward(ctx, g, _gb):
+        x, bins = ctx.saved_tensors
+        k, act_range, formula, relu = ctx.cfg
+        g = L.like_layout(g, x)
+        dx = torch.empty_like(x)
+        L.check(L.load().alignq_act_quant_bwd_packed(L.ptr(g), L.ptr(x), L.ptr(bins), L.ptr(dx), x.numel(), k, act_range,
+                                                     formula, int(relu), L.stream_ptr()), "alignq_act_quant_bwd_packed")
+        return dx, None, None, None, None
+
+
 def act_quant_bins(x, k, act_range, formula):
     """Parity instrumentation: (x_q, int32 bins) of the activation quantiser."""
     x = L.dev_f32(x, "activation")

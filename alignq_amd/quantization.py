@@ -99,6 +99,8 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
         """relu(_plain_act(x)); one launch each way when the quantiser is active."""
         if (a_bit == 32) or not (x.is_cuda and x.dtype == torch.float32 and x.numel() % 4 == 0):
             return torch.relu(_plain_act(x, a_bit, stage))
+        if getattr(config.args, "pack_bins", False):     # N2: the node keeps the 1-2 B level index instead of fp32 relu(x_q)
+            return ops.ActQuantPackedFn.apply(x, a_bit, config.args.act_range, formula, True)[0]
         return ops.ActQuantReluFn.apply(x, a_bit, config.args.act_range, formula)
 
     def _site_act(mod, x):
@@ -154,6 +156,11 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
         def forward_relu(self, x):
             """relu(self(x)) in one launch each way (not part of the reference's interface: an opt-in for the caller)."""
             return _plain_act_relu(x, self.a_bit, self.stage)
+
+        def forward_packed(self, x, relu=False):
+            """([relu](self(x)), bins): the quantised activation both as fp32 and as its narrow integer level index
+            (ops.dequant_bins(bins, ...) reproduces the fp32 tensor bit for bit)."""
+            return ops.ActQuantPackedFn.apply(x, self.a_bit, config.args.act_range, formula, relu)
 
     class _act_admm(nn.Module):
         def __init__(self, a_bit, stage, admm):

@@ -65,6 +65,23 @@ int alignq_act_quant_relu_fwd(const float* x, float* y, int64_t N, int k, float 
 int alignq_act_quant_relu_bwd(const float* g, const float* x, const float* y, float* dx, int64_t N, float act_range,
                               void* stream);
 
+/* ---- N2: integer bin storage.  The quantised activation is an integer level index idx = round(t*n)
+ * (model/quantization.py:23-31 `torch.round(input * n) / n`; callers :109-110, Conv2d_Q.forward :149-154 consumes it): stored
+ * narrow it costs 1-2 B per element instead of the 4 B of the dequantised fp32 value.
+ *   ADMM / Office formula: idx in [-r*n, r*n], SIGNED: int8 while r*n <= 127 (k <= 6 at act_range 2), else int16 (8-bit:
+ *   1021 levels);  CDF-tree formula: idx in [0, n], UNSIGNED: uint8 for k <= 8, else uint16.
+ * alignq_bin_bytes: bytes per stored index (1 or 2; 0: no packed form for these arguments, e.g. k == 32).
+ * alignq_act_quant_fwd_packed: as alignq_act_quant_fwd, but writes the (pre-ReLU) index in the narrow type; xq (optional)
+ *   additionally receives [relu](x_q) in fp32.  alignq_bins_dequant: y = [relu](value(idx)), BIT-IDENTICAL to the fp32 x_q of
+ *   the fused quantiser (same IEEE operations).  alignq_act_quant_bwd_packed: dx = g * dt/dx with the ReLU mask (relu != 0)
+ *   taken from the stored index (value(idx) > 0) instead of from an fp32 copy of relu(x_q).  16-byte aligned pointers. */
+int alignq_bin_bytes(int k, float act_range, int formula);
+int alignq_act_quant_fwd_packed(const float* x, float* xq, void* bins, int64_t n, int k, float act_range, int formula,
+                                int relu, void* stream);
+int alignq_bins_dequant(const void* bins, float* y, int64_t n, int k, float act_range, int formula, int relu, void* stream);
+int alignq_act_quant_bwd_packed(const float* g, const float* x, const void* bins, float* dx, int64_t n, int k,
+                                float act_range, int formula, int relu, void* stream);
+
 /* ---- R3: weight quantisation -------------------------------------------------------------------
  * stats: torch.mean / torch.std (unbiased) over all n elements (model/quantization.py:78).
  *        ms: device float[2] = {mean, std}.  ws: alignq_weight_ws_bytes(n) bytes of scratch.        */

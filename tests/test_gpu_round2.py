@@ -321,3 +321,44 @@ def test_office_tiny_dann_two_iterations_vs_reference(dev, channels_last, fuse_r
     finally:
         config.args.bitW = config.args.abitW = 8
         config.args.train_batch_size, config.args.eval_batch_size = 128, 100
+
+
+# ------------------------------------------------------------------------------------------------ N2: integer bin storage
+@pytest.mark.parametrize("formula", [0, 1])
+@pytest.mark.parametrize("k", [1, 2, 4, 6, 7, 8])
+def test_packed_bins_bit_exact_and_dequant_identity(dev, formula, k):
+    """the narrow integer bins (int8 while r*n <= 127, else int16; CDF tree: uint8 for k <= 8) are
+    bit-exact against the oracle's bins (oq_act_quant_fwd), the dequantised value equals idx / n EXACTLY as the oracle
+    divides it (bit-identical to the fused quantiser's fp32 x_q), and the packed backward equals the fp32-masked one."""
+    from alignq_amd import ops
+    rng = np.random.default_rng(100 * formula + k)
+    x = np.concatenate([rng.standard_normal((1 << 18) + 3) * 1.7, rng.uniform(-6, 6, 1021),
+                        np.array([0.0, -0.0, 30.0, -30.0, np.inf, -np.inf])]).astype(np.float32)
+    n = 2 ** k - 1
+    want = {(0, True): torch.int8, (0, False): torch.int16, (1, True): torch.uint8}[(formula, formula == 1 or 2.0 * n <= 127 or k == 1)]
+    assert ops.bin_dtype(k, 2.0, formula) == want
+    xt = cu(x, dev)
+    bins, xq = ops.act_quant_pack(xt, k, 2.0, formula, want_xq=True)
+    oq, ot, ob = O.act_quant_fwd(x, k, 2.0, formula)
+    assert bins.dtype == want and np.array_equal(npy(bins).astype(np.int32), ob)
+    assert np.array_equal(npy(xq).view(np.uint32), oq.view(np.uint32))
+    deq = ops.dequant_bins(bins, k, 2.0, formula)
+    assert np.array_equal(npy(deq).view(np.uint32), oq.view(np.uint32)), "dequantised bins != fused quantiser's x_q"
+    if formula == 0 and k > 1:          # value == idx / n exactly (IEEE division), range as SURVEY F5
+        assert np.array_equal(npy(deq), (ob.astype(np.float32) / np.float32(n)))
+        assert ob.min() >= -2 * n and ob.max() <= 2 * n
+    deq_r = ops.dequant_bins(bins, k, 2.0, formula, relu=True)
+    assert np.array_equal(npy(deq_r), np.maximum(oq, np.float32(0)))
+    # backward: mask from the bins == mask from fp32 relu(x_q)
+    m = 1 << 16
+    g = torch.randn(m, device=dev)
+    xa = xt[:m].clone().requires_grad_(True)
+    ya = ops.ActQuantReluFn.apply(xa, k, 2.0, formula)
+    ya.backward(g)
+    xb = xt[:m].clone().requires_grad_(True)
+    yb, bb = ops.ActQuantPackedFn.apply(xb, k, 2.0, formula, True)
+    yb.backward(g)
+    assert np.array_equal(npy(ya), npy(yb)) and np.array_equal(npy(xa.grad), npy(xb.grad))
+    assert bb.dtype == want and bb.element_size() in (1, 2)
+    with pytest.raises(RuntimeError):
+        ops.act_quant_pack(xt, 32, 2.0, formula)
