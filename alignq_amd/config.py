@@ -15,6 +15,7 @@ args = SimpleNamespace(
     eval_batch_size=100,
     stage="second",
     gpus=[0],
+    global_corr=None,       # not a reference option: True / a process group -> exact-global-batch corr
     pack_bins=False,        # not a reference option: plain quantiser nodes keep int8/int16 bins for backward
 )
 

@@ -127,10 +127,285 @@ class GradAndDAllReduce:
         self.unpack()
 
 
-def attach(train_step, group=None, force=False):
-    """Wire data parallelism into a TrainStep: broadcast the initial state, install the all-reduce hook."""
+def attach(train_step, group=None, force=False, global_corr=False):
+    """Wire data parallelism into a TrainStep: broadcast the initial state, install the all-reduce hook.
+    global_corr=True (opt-in): every ADMM site computes the correlation pair of the GLOBAL batch
+    (global_corr below; the model's ADMM(dim) must have been built with the global batch size, <= 128) instead of the
+    per-rank [b,b] matrices; BN fold and deferred site launches are switched off for it (the sites run unfused)."""
+    if global_corr:
+        from . import config
+        config.args.global_corr = True if group is None else group
+        for m in train_step.model.modules():
+            if hasattr(m, "fuse_bn"):
+                m.fuse_bn = False
+        train_step._deferred = None
     broadcast_module_state(train_step.model, 0, group)
     hook = GradAndDAllReduce([p for _, p in train_step.param_t], lambda: [m.D for m in train_step.admms], group,
                              force=force)
     train_step.grad_hook = hook
     return hook
+
+
+class BucketedGradAllReduce:
+    """Data parallelism for the Office / DANN step (BASELINE config 5: ResNet-50, ~94 MB of fp32 gradients per step, ring
+    time ~1.1 ms per link-bound ring on xGMI): the gradients are all-reduced in >= `min_buckets` flat
+    buckets (<= `bucket_bytes` each), launched FROM AUTOGRAD HOOKS while the backward is still running, so the collectives of
+    the deep layers overlap the backward of the shallow ones; the stacked D matrices of the ADMM sites ride in the bucket that
+    completes last (the stem's).  Every rank runs the reference semantics at its local batch; after `finish()` every
+    p.grad and every ADMM.D holds the mean over ranks, so SGD.step / ADMM_OPT.step keep the replicas bit-identical.
+
+    Order of the buckets = reverse registration order of the parameters (the order the backward produces gradients in).  The
+    set of parameters that actually receive gradients is discovered in the first iteration (DANN never uses feature.fc), which
+    therefore reduces without overlap.  Interface: begin() before backward, finish() after it; or the phased pack() /
+    reduce() / unpack() of GradAndDAllReduce for a captured step (two HIP graphs with the collectives eager in between)."""
+
+    def __init__(self, params: List[torch.nn.Parameter], get_Ds: Callable[[], List[torch.Tensor]], group=None,
+                 force: bool = False, bucket_bytes: int = 24 << 20, min_buckets: int = 4):
+        self.params = [p for p in params if p.requires_grad]
+        self.get_Ds = get_Ds
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.force = force and dist.is_initialized()
+        self.bucket_bytes, self.min_buckets = int(bucket_bytes), int(min_buckets)
+        self._live = None            # parameters that receive gradients (discovered), in bucket order
+        self._groups = None          # list of lists of parameters
+        self._where = {}             # id(p) -> bucket index
+        self._layouts = {}           # (bucket index, D shapes) -> FlatBucket
+        self._armed = False
+        self._pending, self._works, self._buckets_now = [], [], []
+        self._comm = None
+        self.launched_from_hooks = 0          # diagnostics: buckets whose collective started inside the backward
+        for p in self.params:
+            p.register_post_accumulate_grad_hook(self._on_grad)
+
+    def active(self) -> bool:
+        return self.world > 1 or self.force
+
+    # ---- layout ---------------------------------------------------------------------------------------------------
+    def _discover(self):
+        live = [p for p in reversed(self.params) if p.grad is not None]
+        total = sum(p.numel() for p in live) * 4
+        target = max(1, min(self.bucket_bytes, -(-total // self.min_buckets)))
+        groups, cur, size = [], [], 0
+        for p in live:
+            cur.append(p)
+            size += p.numel() * 4
+            if size >= target:
+                groups.append(cur)
+                cur, size = [], 0
+        if cur:
+            groups.append(cur)
+        self._live, self._groups = live, groups
+        self._where = {id(p): bi for bi, g in enumerate(groups) for p in g}
+        self._layouts = {}
+
+    def _tensors(self, bi):
+        ts = [p.grad for p in self._groups[bi]]
+        if any(t is None for t in ts):
+            raise RuntimeError("BucketedGradAllReduce: a parameter that had a gradient in the first iteration has none now; "
+                               "call reset() when the set of trained parameters changes")
+        if bi == len(self._groups) - 1:
+            ts = ts + [d for d in self.get_Ds() if d is not None]
+        return ts
+
+    def _bucket(self, bi, tensors):
+        key = (bi, tuple(tuple(t.shape) for t in tensors[len(self._groups[bi]):]))     # D shapes: the short last batch
+        b = self._layouts.get(key)
+        if b is None or not b.matches(tensors):
+            b = self._layouts[key] = FlatBucket([t.shape for t in tensors], tensors[0].device)
+        return b
+
+    def reset(self):
+        self._live = self._groups = None
+
+    # ---- one bucket: pack on the compute stream, all-reduce on the communication stream --------------------------
+    def _launch(self, bi, overlap=True):
+        tensors = self._tensors(bi)
+        b = self._bucket(bi, tensors)
+        b.pack(tensors)
+        self._buckets_now[bi] = (b, tensors)
+        backend = dist.get_backend(self.group)
+        if b.flat.is_cuda and overlap:
+            if self._comm is None:
+                self._comm = torch.cuda.Stream()
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(self._comm):
+                self._comm.wait_event(ev)
+                self._works[bi] = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG if backend == "nccl" else dist.ReduceOp.SUM,
+                                                  group=self.group, async_op=True)
+        else:
+            self._works[bi] = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG if backend == "nccl" else dist.ReduceOp.SUM,
+                                              group=self.group, async_op=True)
+
+    def _on_grad(self, p):
+        if not self._armed:
+            return
+        bi = self._where.get(id(p))
+        if bi is None:
+            return
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0:
+            self._launch(bi)
+            self.launched_from_hooks += 1
+
+    # ---- eager interface ------------------------------------------------------------------------------------------
+    def begin(self):
+        """Call after the forward (the D matrices exist), right before backward()."""
+        if not self.active():
+            return
+        self._armed = self._groups is not None
+        if self._armed:
+            n = len(self._groups)
+            self._pending = [len(g) for g in self._groups]
+            self._works, self._buckets_now = [None] * n, [None] * n
+
+    def finish(self):
+        """Call after backward(): waits for every bucket (the current stream waits, not the host, on RCCL) and scatters the
+        means back into p.grad / ADMM.D."""
+        if not self.active():
+            return
+        was_armed, self._armed = self._armed, False
+        if self._groups is None:
+            self._discover()
+        n = len(self._groups)
+        if not was_armed:
+            self._works, self._buckets_now = [None] * n, [None] * n
+        for bi in range(n):
+            if self._works[bi] is None:          # first iteration, or a bucket whose hooks did not all fire
+                self._launch(bi, overlap=False)
+        backend = dist.get_backend(self.group)
+        for bi in range(n):
+            self._works[bi].wait()
+            b, tensors = self._buckets_now[bi]
+            if backend != "nccl":
+                b.flat.mul_(1.0 / self.world)
+            b.unpack(tensors)
+        self._works = [None] * n
+
+    def __call__(self, _step=None):
+        self.begin()
+        self._armed = False
+        self.finish()
+
+    # ---- phased interface for a captured step (no hooks inside a graph: the collectives run between two graphs) ----
+    def pack(self):
+        if not self.active():
+            return
+        if self._groups is None:
+            self._discover()
+        self._phase = []
+        for bi in range(len(self._groups)):
+            tensors = self._tensors(bi)
+            b = self._bucket(bi, tensors)
+            b.pack(tensors)
+            self._phase.append((b, tensors))
+
+    def reduce(self):
+        if not self.active():
+            return
+        backend = dist.get_backend(self.group)
+        works = [dist.all_reduce(b.flat, op=dist.ReduceOp.AVG if backend == "nccl" else dist.ReduceOp.SUM, group=self.group,
+                                 async_op=True) for b, _ in self._phase]
+        for w, (b, _) in zip(works, self._phase):
+            w.wait()
+            if backend != "nccl":
+                b.flat.mul_(1.0 / self.world)
+
+    def unpack(self):
+        if not self.active():
+            return
+        for b, tensors in self._phase:
+            b.unpack(tensors)
+
+
+def attach_office(office_step, group=None, force=False, bucket_bytes=24 << 20, min_buckets=4):
+    """Wire data parallelism into an OfficeTrainStep: broadcast the initial state, install the bucketed, overlapped
+    all-reduce over every parameter SGD steps (feature extractor incl. alterD / gamma, both heads) + the sites' D."""
+    broadcast_module_state(office_step.model, 0, group)
+    params = [p for g in office_step.optimizer_t.param_groups for p in g["params"]]
+    hook = BucketedGradAllReduce(params, lambda: [b.admm0.D for b in office_step.blocks], group, force=force,
+                                 bucket_bytes=bucket_bytes, min_buckets=min_buckets)
+    office_step.grad_hook = hook
+    return hook
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N4 (SURVEY.md §8e "exact-global alternative"): the [B_g, B_g] correlation of the GLOBAL batch instead of per-rank [b, b]
+# matrices.  corr standardises every feature over the batch, so a rank needs all B_g samples of the features it contracts:
+#   all-to-all  [b, F] (batch-sharded) -> [B_g, F / world] (feature-sharded)
+#   local SYRK  G_r = Xh_r Xh_r^T / F_r on the shard (the same split-bf16 MFMA kernels: ops.CorrFn; B_g <= 128)
+#   all-reduce  G = sum_r (F_r / F) G_r                                  (exact: features are disjoint)
+# and the mirrored backward (dG is identical on every rank; the shard's dX_r goes back through the reverse all-to-all).
+# Reference op: model/quantization.py:134-137 applied to the concatenated batch.
+class _FeatureShard(torch.autograd.Function):
+    """[b, F] on every rank -> [B_g, F / world]: all samples of this rank's feature shard, rows in rank order."""
+
+    @staticmethod
+    def forward(ctx, x, group, grad_scale):
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        b, F = x.shape
+        if F % world:
+            raise RuntimeError(f"global corr: feature count {F} is not divisible by the world size {world}")
+        Fr = F // world
+        ctx.meta = (group, world, rank, b, F, Fr, float(grad_scale))
+        if dist.get_backend(group) == "nccl":       # RCCL all-to-all over xGMI: N*4 bytes per rank each way
+            send = x.view(b, world, Fr).permute(1, 0, 2).contiguous()          # [dst rank][b][Fr]
+            recv = torch.empty_like(send)                                       # [src rank][b][Fr]
+            dist.all_to_all_single(recv, send, group=group)
+            return recv.view(world * b, Fr)
+        # gloo (CPU tests) has no all-to-all: gather every rank's rows and keep this rank's columns
+        rows = [torch.empty_like(x) for _ in range(world)]
+        dist.all_gather(rows, x.contiguous(), group=group)
+        return torch.cat(rows, 0)[:, rank * Fr:(rank + 1) * Fr].contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        group, world, rank, b, F, Fr, scale = ctx.meta
+        g = g.contiguous()
+        if dist.get_backend(group) == "nccl":
+            send = g.view(world, b, Fr)                                         # [dst rank (owner of the rows)][b][Fr]
+            recv = torch.empty_like(send)                                       # [src rank (owner of the columns)][b][Fr]
+            dist.all_to_all_single(recv, send.contiguous(), group=group)
+            dx = recv.permute(1, 0, 2).reshape(b, F)
+        else:
+            shards = [torch.empty_like(g) for _ in range(world)]
+            dist.all_gather(shards, g, group=group)
+            dx = torch.cat([s[rank * b:(rank + 1) * b] for s in shards], 1)     # my rows, every rank's columns
+        return dx * scale, None, None
+
+
+class _SumAcrossRanks(torch.autograd.Function):
+    """all-reduce(sum) whose result feeds a loss every rank evaluates identically: d(loss)/d(local term) = d(loss)/d(sum)."""
+
+    @staticmethod
+    def forward(ctx, t, group):
+        out = t.clone()
+        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def global_corr(x, eps=0.0, group=None, local_corr=None, grad_scale=None):
+    """corr(x, x) of the GLOBAL batch (rows = all ranks' samples in rank order), identical on every rank.
+
+    x: this rank's [b, ...] activations.  local_corr(X) -> [B_g, B_g]: the per-shard SYRK (default ops.CorrFn on the HIP
+    kernels, which hold at most ALIGNQ_MAX_BATCH = 128 rows).  grad_scale multiplies the gradient that returns to x;
+    default = world size, which makes the usual MEAN all-reduce of the parameter gradients reproduce the gradient of a
+    correlation loss that is counted once for the global batch (the per-rank cross-entropy means average correctly as is)."""
+    world = dist.get_world_size(group)
+    x2 = x.reshape(x.shape[0], -1)
+    Bg = x2.shape[0] * world
+    if local_corr is None:
+        from . import _lib as L
+        from . import ops
+        if Bg > L.MAX_BATCH:
+            raise RuntimeError(f"global corr: global batch {Bg} exceeds the {L.MAX_BATCH} rows the fused Gram kernels hold "
+                               "on chip; use the per-rank semantics (SURVEY.md §8e) for larger global batches")
+        local_corr = lambda X: ops.CorrFn.apply(X, float(eps))      # noqa: E731
+    Xr = _FeatureShard.apply(x2, group, world if grad_scale is None else grad_scale)
+    Gr = local_corr(Xr) * (1.0 / world)          # (F_r / F) with equal shards
+    return _SumAcrossRanks.apply(Gr, group)

@@ -107,6 +107,17 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
         a_bit = mod.a_bit
         if a_bit == 32 and mod.stage != "align":
             return x, 0
+        if config.args.method == "ours" and a_bit < 32 and getattr(config.args, "global_corr", None) is not None:
+            # opt-in exact-global-batch correlation (dp.attach(..., global_corr=True)): D is the
+            # [B_g, B_g] matrix of the concatenated batch, identical on every rank; unfused (x is read three times)
+            from . import dp
+            grp = None if config.args.global_corr is True else config.args.global_corr
+            admm = mod.opt
+            r_ = config.args.act_range
+            xq = ops.ActQuantFn.apply(x, a_bit, r_, formula)
+            t = ops.ActQuantFn.apply(x, 32, r_, formula)            # k == 32 writes the pre-round transform itself
+            D = dp.global_corr(t, eps, grp) - dp.global_corr(x, eps, grp)
+            return xq, admm(D)
         if config.args.method == "ours" and a_bit < 32:
             admm = mod.opt
             from . import fused

@@ -245,8 +245,12 @@ class OfficeTrainStep:
     ADMM_OPT.step.  Each ADMM.D holds the TARGET pass's D when ADMM_OPT runs (admm.py:25 overwrites) and alterD/gamma are
     SGD-stepped first and then overwritten by the closed form, exactly like the reference."""
 
-    def __init__(self, model, lr=0.04, momentum=0.9, weight_decay=5e-4, alpha=0.5, channels_last=False, fuse_relu=True):
-        """channels_last: activations and conv weights in torch.channels_last memory (values / names unchanged): MIOpen's NHWC
+    def __init__(self, model, lr=0.04, momentum=0.9, weight_decay=5e-4, alpha=0.5, channels_last=False, fuse_relu=True,
+                 grad_hook=None):
+        """grad_hook: the data-parallel all-reduce (alignq_amd.dp.attach_office -> BucketedGradAllReduce): begin() right
+        before backward, its buckets' collectives start from autograd hooks while the backward runs, finish() before the
+        optimizer steps.
+        channels_last: activations and conv weights in torch.channels_last memory (values / names unchanged): MIOpen's NHWC
         kernels run the ResNet-50 step in 30.9 instead of 34.7 ms on MI355X; the quantise / Gram kernels are layout-agnostic.
         fuse_relu: `relu(act_q(.))` of the stem and of each bottleneck's first two sites as one launch each way."""
         if channels_last:
@@ -275,10 +279,17 @@ class OfficeTrainStep:
                 if conv is not None:
                     self.convs.append(conv[0] if k == 3 else conv)
         self.all_convs = [m for m in model.modules() if hasattr(m, "quantize_fn")]
+        self.grad_hook = grad_hook
         self._graph: Optional[torch.cuda.CUDAGraph] = None
+        self._graph2: Optional[torch.cuda.CUDAGraph] = None
         self._static = None
 
     def _iteration(self, xs, ys, xt, set_to_none=True):
+        out = self._forward_backward(xs, ys, xt, set_to_none, overlap=True)
+        self._optimizer_steps()
+        return out
+
+    def _forward_backward(self, xs, ys, xt, set_to_none=True, overlap=False):
         m = self.model
         self.optimizer_t.zero_grad(set_to_none=set_to_none)
         self.optimizer_admm.zero_grad(set_to_none=set_to_none)
@@ -294,14 +305,21 @@ class OfficeTrainStep:
         _, dom_t, tl_t = m(xt, alpha=self.alpha)
         loss = (F.cross_entropy(cls_s, ys) + F.cross_entropy(dom_s, label_src) + F.cross_entropy(dom_t, label_tgt)
                 + tl_s + tl_t)
+        hook = self.grad_hook if overlap else None
+        if hook is not None:
+            hook.begin()              # the buckets' all-reduces start from autograd hooks during this backward
         loss.backward()
+        if hook is not None:
+            hook.finish()
+        return cls_s, loss, tl_s + tl_t
+
+    def _optimizer_steps(self):
         w_cdf = [c.quantize_fn.weight_cdf for c in self.convs]
         w_pdf = [c.quantize_fn.weight_pdf for c in self.convs]
         self.optimizer_t.step(self.idx, w_cdf, w_pdf, config.args.lam, config.args.lam2)
         a = [b.admm0 for b in self.blocks]
         self.optimizer_admm.step(self.alterD_idx, self.gamma_idx, [q.D for q in a], [q.alterD for q in a],
                                  [q.gamma for q in a], [q.mu for q in a], [q.rho for q in a])
-        return cls_s, loss, tl_s + tl_t
 
     def new_epoch(self, epoch, num_epochs, lr, momentum=0.9, weight_decay=5e-4):
         """dann_office/main.py:321-328: every epoch the reference builds a NEW SGD (so momentum buffers start from scratch)
@@ -330,6 +348,9 @@ class OfficeTrainStep:
         for dst, src in zip(self._static[:3], (xs, ys, xt)):
             dst.copy_(src, non_blocking=True)
         self._graph.replay()
+        if self._graph2 is not None:       # data parallel: the buckets' collectives run eagerly between the two graphs
+            self.grad_hook.reduce()
+            self._graph2.replay()
         return self._static[3]
 
     def _eager_fallback(self, xs, ys, xt):
@@ -354,11 +375,31 @@ class OfficeTrainStep:
                 self._iteration(sxs, sys_, sxt, set_to_none=False)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        for group in self.optimizer_t.param_groups:      # see TrainStep._assert_momentum_buffers
+            for p in group["params"]:
+                if group["momentum"] != 0 and p.grad is not None and "momentum_buffer" not in self.optimizer_t.state[p]:
+                    raise RuntimeError("OfficeTrainStep.capture: a parameter has no momentum buffer yet; run at least one "
+                                       "eager iteration (capture(..., warmup>=1)) before capturing the step")
         self.optimizer_t.zero_grad(set_to_none=True)
         self.optimizer_admm.zero_grad(set_to_none=True)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            outs = self._iteration(sxs, sys_, sxt, set_to_none=True)
+        self._graph2 = None
+        if self.grad_hook is None or not self.grad_hook.active():
+            with torch.cuda.graph(graph):
+                outs = self._iteration(sxs, sys_, sxt, set_to_none=True)
+        else:
+            # data parallel: forward + backward + bucket pack | eager all-reduces | bucket unpack + optimizer steps
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+            mode = dict(capture_error_mode="thread_local")
+            with torch.cuda.graph(graph, **mode):
+                outs = self._forward_backward(sxs, sys_, sxt, set_to_none=True, overlap=False)
+                self.grad_hook.pack()
+            graph2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph2, pool=graph.pool(), **mode):
+                self.grad_hook.unpack()
+                self._optimizer_steps()
+            self._graph2 = graph2
         self._graph = graph
         self._static = (sxs, sys_, sxt, outs)
         return self

@@ -495,8 +495,9 @@ class OfficeDANN(nn.Module):
 class OfficeTrainStep:
     """dann_office/main.py:343-456; `new_epoch` = the SGD re-creation of :321-328."""
 
-    def __init__(self, net: OfficeDANN, cfg: Config, lr=0.04, momentum=0.9, weight_decay=5e-4, alpha=0.5):
+    def __init__(self, net: OfficeDANN, cfg: Config, lr=0.04, momentum=0.9, weight_decay=5e-4, alpha=0.5, grad_hook=None):
         self.net, self.cfg, self.alpha = net, cfg, alpha
+        self.grad_hook = grad_hook      # data-parallel tests: begin() before backward, finish() after (alignq_amd.dp)
         self.momentum, self.weight_decay = momentum, weight_decay
         named = list(net.named_parameters())
         self.named = named
@@ -530,7 +531,13 @@ class OfficeTrainStep:
         _, dom_t, tl_t = net(xt, self.alpha)
         l_dt = F.cross_entropy(dom_t, torch.ones(xt.shape[0], dtype=torch.long))
         loss = l_cls + l_ds + l_dt + tl_s + tl_t
+        if self.grad_hook is not None:
+            for b in net.feature.blocks():
+                b.admm0.D = b.admm0.D.detach().clone()
+            self.grad_hook.begin()
         loss.backward()
+        if self.grad_hook is not None:
+            self.grad_hook.finish()
         convs = []
         for b in net.feature.blocks():
             for k, conv in enumerate((b.conv1, b.conv2, b.conv3, b.downsample)):

@@ -154,3 +154,121 @@ def test_flat_bucket_rejects_a_changed_layout_and_the_hook_switches_buckets():
     Ds[0] = torch.ones(4, 4)
     hook()
     assert hook.bucket is first                # layouts are cached, not re-allocated every time
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Office / DANN step (BASELINE config 5): bucketed all-reduce launched from autograd hooks (alignq_amd.dp.BucketedGradAllReduce)
+def _office_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from alignq_amd import dp
+        from oracle import torch_ref as R
+        cfg = R.Config(tree="office", bitW=4, abitW=4, train_batch_size=4)
+        torch.manual_seed(10 + rank)                   # different init per rank: the broadcast must fix it
+        net = R.OfficeDANN(cfg, 4, 4, "aligned", (1, 1, 1, 1), width_per_group=8).train()
+        dp.broadcast_module_state(net, 0)
+        step = R.OfficeTrainStep(net, cfg, lr=0.004)
+        params = [p for g in step.opt_t.param_groups for p in g["params"]]
+        blocks = net.feature.blocks()
+        hook = dp.BucketedGradAllReduce(params, lambda: [b.admm0.D for b in blocks], bucket_bytes=256 << 10, min_buckets=4)
+        step.grad_hook = hook
+        g = torch.Generator().manual_seed(100 + rank)  # different data per rank
+        rec = {}
+        for it in range(2):
+            xs, xt = torch.randn(4, 3, 32, 32, generator=g), torch.randn(4, 3, 32, 32, generator=g)
+            ys = torch.randint(0, 31, (4,), generator=g)
+            # local (pre-reduction) values of one early and one late parameter and of one D, captured through a probe that runs
+            # just before finish(): wrap finish
+            local = {}
+            orig_finish = hook.finish
+
+            def finish(local=local, orig=orig_finish):
+                local["g_stem"] = net.feature.conv1.weight.grad.clone()
+                local["g_head"] = net.class_classifier.c_fc3.weight.grad.clone()
+                local["D0"] = blocks[0].admm0.D.clone()
+                local["from_hooks"] = hook.launched_from_hooks
+                orig()
+            hook.finish = finish
+            step(xs, ys, xt)
+            hook.finish = orig_finish
+            rec[it] = dict(g_stem_local=local["g_stem"].numpy(), g_head_local=local["g_head"].numpy(), D0_local=local["D0"].numpy(),
+                           from_hooks=local["from_hooks"], g_stem=None, D0=blocks[0].admm0.D.numpy().copy(),
+                           flat=torch.cat([p.detach().reshape(-1) for p in net.parameters()]).numpy().copy())
+        out[rank] = dict(rec=rec, n_buckets=len(hook._groups), n_live=len(hook._live), n_params=len(params),
+                         last_has_D=len(hook._tensors(len(hook._groups) - 1)) == len(hook._groups[-1]) + len(blocks),
+                         last_is_stem=any(p is net.feature.conv1.weight for p in hook._groups[-1]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_office_bucketed_overlapped_allreduce_two_ranks_gloo():
+    """SURVEY §8e for config 5: >= 4 buckets in backward order, launched from autograd hooks DURING the backward (second
+    iteration; the first discovers which parameters get gradients: DANN never uses feature.fc), D matrices in the bucket that
+    completes last; the reduced values are the mean over ranks and the replicas stay bit-identical after SGD + ADMM_OPT."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_office_worker, args=(world, port, out), nprocs=world, join=True)
+    r0, r1 = out[0], out[1]
+    assert r0["n_buckets"] >= 4 and r0["n_live"] == r0["n_params"] - 2           # feature.fc.{weight,bias} never get grads
+    assert r0["last_has_D"] and r0["last_is_stem"]
+    for it in range(2):
+        a, b = r0["rec"][it], r1["rec"][it]
+        assert np.array_equal(a["flat"], b["flat"]) and np.isfinite(a["flat"]).all()      # replicas identical after the step
+        assert not np.array_equal(a["g_stem_local"], b["g_stem_local"])                   # the ranks did see different data
+        np.testing.assert_allclose(a["D0"], 0.5 * (a["D0_local"] + b["D0_local"]), atol=1e-7)
+        assert np.array_equal(a["D0"], b["D0"])
+    # iteration 0 reduced without overlap (discovery); in iteration 1 every bucket was launched from an autograd hook, i.e.
+    # before finish() ran — the probe reads the counter at the entry of finish()
+    assert r0["rec"][0]["from_hooks"] == 0 and r0["rec"][1]["from_hooks"] == r0["n_buckets"]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N4: exact-global-batch correlation (alignq_amd.dp.global_corr)
+def _gcorr_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from alignq_amd import dp
+        from oracle import torch_ref as R
+        g = torch.Generator().manual_seed(7)
+        b, C, H, W = 8, 6, 4, 4                        # F = 96, divisible by the world size
+        X = torch.randn(world * b, C, H, W, generator=g) * 0.9 + 0.2      # the global batch, identical on every rank
+        dG = torch.randn(world * b, world * b, generator=g)
+        for eps in (0.0, 1e-5):
+            x = X[rank * b:(rank + 1) * b].clone().requires_grad_(True)
+            G = dp.global_corr(x, eps, None, local_corr=lambda V: R.corr(V, V, eps), grad_scale=1.0)
+            (G * dG).sum().backward()
+            out[(rank, eps)] = dict(G=G.detach().numpy().copy(), dx=x.grad.numpy().copy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_global_corr_equals_single_process_corr_on_the_concatenated_batch():
+    """all-to-all (gloo: all-gather) to the feature-sharded layout -> per-shard SYRK -> all-reduce; result and
+    the gradient that returns to every rank's samples equal the single-process corr of the concatenated batch (<= 1e-5)."""
+    from oracle import torch_ref as R
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_gcorr_worker, args=(world, port, out), nprocs=world, join=True)
+    g = torch.Generator().manual_seed(7)
+    b = 8
+    X = torch.randn(world * b, 6, 4, 4, generator=g) * 0.9 + 0.2
+    dG = torch.randn(world * b, world * b, generator=g)
+    for eps in (0.0, 1e-5):
+        Xi = X.clone().requires_grad_(True)
+        Gref = R.corr(Xi.view(world * b, -1), Xi.view(world * b, -1), eps)
+        (Gref * dG).sum().backward()
+        for rank in range(world):
+            o = out[(rank, eps)]
+            np.testing.assert_allclose(o["G"], Gref.detach().numpy(), atol=1e-5)
+            np.testing.assert_allclose(o["dx"], Xi.grad[rank * b:(rank + 1) * b].numpy(), atol=1e-5, rtol=1e-4)
+        assert np.array_equal(out[(0, eps)]["G"], out[(1, eps)]["G"])          # identical on every rank

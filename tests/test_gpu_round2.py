@@ -362,3 +362,97 @@ def test_packed_bins_bit_exact_and_dequant_identity(dev, formula, k):
     assert bb.dtype == want and bb.element_size() in (1, 2)
     with pytest.raises(RuntimeError):
         ops.act_quant_pack(xt, 32, 2.0, formula)
+
+
+# ------------------------------------------------------------------------------------------------ RCCL paths at world size 1
+@pytest.fixture(scope="module")
+def pg(dev):
+    """A one-rank process group on RCCL (backend "nccl"): exercises the collective code paths on the real backend."""
+    import socket
+    import torch.distributed as dist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    yield dist
+    dist.destroy_process_group()
+
+
+def test_global_corr_on_rccl_matches_the_fused_site(dev, pg):
+    """N4 on the GPU path: dp.global_corr (all_to_all_single + all_reduce on RCCL, per-shard SYRK on the HIP kernels) at
+    world size 1 equals ops.CorrFn, and a site run with config.args.global_corr gives the fused site's x_q (bit for bit),
+    D, loss and dx."""
+    import alignq_amd.cdf_alignment_admm as A
+    from alignq_amd import config, dp, ops
+    torch.manual_seed(0)
+    x0 = torch.randn(64, 8, 8, 8, device=dev) * 1.2
+    xa = x0.clone().requires_grad_(True)
+    G = dp.global_corr(xa, 0.0)
+    dG = torch.randn(64, 64, device=dev)
+    G.backward(dG)
+    xb = x0.clone().requires_grad_(True)
+    Gb = ops.CorrFn.apply(xb.view(64, -1), 0.0)
+    Gb.backward(dG)
+    assert np.array_equal(npy(G), npy(Gb)) and np.array_equal(npy(xa.grad), npy(xb.grad))
+    gq = torch.randn_like(x0) * 0.01
+    res = []
+    try:
+        for glob in (False, True):
+            config.args.global_corr = True if glob else None
+            torch.manual_seed(1)
+            admm = A.ADMM(64).to(dev)
+            act = A.activation_quantize_fn(8, "second", admm)
+            x = x0.clone().requires_grad_(True)
+            xq, loss = act(x)
+            (loss + (xq * gq).sum()).backward()
+            res.append((npy(xq), npy(admm.D), float(loss.detach()), npy(x.grad), npy(admm.alterD.grad)))
+    finally:
+        config.args.global_corr = None
+    (q0, D0, l0, dx0, dA0), (q1, D1, l1, dx1, dA1) = res
+    assert np.array_equal(q0, q1)
+    np.testing.assert_allclose(D1, D0, atol=TOL)
+    np.testing.assert_allclose(l1, l0, atol=TOL)
+    np.testing.assert_allclose(dx1, dx0, atol=TOL, rtol=1e-4)
+    np.testing.assert_allclose(dA1, dA0, atol=1e-7, rtol=1e-4)
+    with pytest.raises(RuntimeError, match="exceeds"):
+        dp.global_corr(torch.randn(129, 64, device=dev), 0.0)
+
+
+def test_office_step_with_bucketed_allreduce_at_world_one(dev, pg):
+    """dp.attach_office(force=True): the Office step with its gradient buckets all-reduced on RCCL from autograd hooks
+    (eager) and between two HIP graphs (captured); at world size 1 the mean is the identity, so both must track the plain
+    step (same bars as graph-vs-eager elsewhere: MIOpen's atomics and 4-bit bin flips)."""
+    from alignq_amd import config, dp
+    from alignq_amd.resnet_office import DANN, Bottleneck, ResNet
+    from alignq_amd.train_step import OfficeTrainStep
+    config.args.bitW = config.args.abitW = 8
+    config.args.train_batch_size = config.args.eval_batch_size = 6
+    try:
+        def make():
+            torch.manual_seed(7)
+            return DANN(lambda w, a, s: ResNet(w, a, s, Bottleneck, [1, 1, 1, 1]), 8, 8, "aligned").to(dev).train()
+        g = torch.Generator().manual_seed(0)
+        xs = torch.randn(6, 3, 64, 64, generator=g).to(dev)
+        xt = torch.randn(6, 3, 64, 64, generator=g).to(dev)
+        ys = torch.randint(0, 31, (6,), generator=g).to(dev)
+        m0, m1, m2 = make(), make(), make()
+        s0 = OfficeTrainStep(m0, lr=0.004)
+        s1 = OfficeTrainStep(m1, lr=0.004)
+        h1 = dp.attach_office(s1, force=True, bucket_bytes=4 << 20)
+        s2 = OfficeTrainStep(m2, lr=0.004)
+        h2 = dp.attach_office(s2, force=True, bucket_bytes=4 << 20)
+        for _ in range(3):
+            s0(xs, ys, xt)
+            s1(xs, ys, xt)
+        torch.cuda.synchronize()
+        assert len(h1._groups) >= 4 and h1.launched_from_hooks == 2 * len(h1._groups)      # iterations 2 and 3 overlapped
+        assert sum(p.numel() for g_ in h1._groups for p in g_) == sum(p.numel() for p in m1.parameters() if p.grad is not None)
+        s2.capture(xs, ys, xt, warmup=2)
+        assert s2._graph2 is not None
+        s2(xs, ys, xt)
+        torch.cuda.synchronize()
+        for (n, p0), (_, p1), (_, p2) in zip(m0.named_parameters(), m1.named_parameters(), m2.named_parameters()):
+            for p in (p1, p2):
+                d = np.abs(npy(p0) - npy(p))
+                assert np.isfinite(d).all() and np.median(d) < 1e-3 and d.max() < 3e-2, (n, float(np.median(d)), float(d.max()))
+    finally:
+        config.args.train_batch_size, config.args.eval_batch_size = 128, 100
