@@ -72,8 +72,8 @@ int alignq_act_quant_relu_bwd(const float* g, const float* x, const float* y, fl
  *   1021 levels);  CDF-tree formula: idx in [0, n], UNSIGNED: uint8 for k <= 8, else uint16.
  * alignq_bin_bytes: bytes per stored index (1 or 2; 0: no packed form for these arguments, e.g. k == 32).
  * alignq_act_quant_fwd_packed: as alignq_act_quant_fwd, but writes the (pre-ReLU) index in the narrow type; xq (optional)
- *   additionally receives [relu](x_q) in fp32.  alignq_bins_dequant: y = [relu](value(idx)), BIT-IDENTICAL to the fp32 x_q of
- *   the fused quantiser (same IEEE operations).  alignq_act_quant_bwd_packed: dx = g * dt/dx with the ReLU mask (relu != 0)
+ *   additionally receives [relu](x_q) in fp32.  alignq_bins_dequant: y = [relu](value(idx)), the same fp32 value as the x_q of
+ *   the fused quantiser (same IEEE operations; bit-identical except that an integer 0 cannot carry the sign of x_q = -0.0).  alignq_act_quant_bwd_packed: dx = g * dt/dx with the ReLU mask (relu != 0)
  *   taken from the stored index (value(idx) > 0) instead of from an fp32 copy of relu(x_q).  16-byte aligned pointers. */
 int alignq_bin_bytes(int k, float act_range, int formula);
 int alignq_act_quant_fwd_packed(const float* x, float* xq, void* bins, int64_t n, int k, float act_range, int formula,
