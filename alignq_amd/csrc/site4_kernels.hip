@@ -47,31 +47,36 @@ __device__ unsigned long long g_blk[2][2][2048];
 #define BSTAMP(kern, which) do { } while (0)
 #endif
 
-__device__ __forceinline__ float4 ld4(const float* __restrict__ x, int64_t off, int col, int64_t F, bool row_ok,
+// Addressing of the forward kernel: kernel-argument base (SGPR pair) + ONE unsigned 32-bit element offset per (row, column
+// quad), shared by x / residual / x_q (global_load / global_store saddr + voffset form: no 64-bit address arithmetic in
+// VGPRs; the launcher guarantees B*F*4 < 2^32).
+__device__ __forceinline__ float4 ld4(const float* __restrict__ x, unsigned off, int col, int64_t F, bool row_ok,
                                       bool aligned) {
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (!row_ok) return v;
   if (aligned) {
-    if (col < F) v = *reinterpret_cast<const float4*>(x + off);
+    if (col < F) v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(x) + 4u * off);
   } else {
-    if (col + 0 < F) v.x = x[off + 0];
-    if (col + 1 < F) v.y = x[off + 1];
-    if (col + 2 < F) v.z = x[off + 2];
-    if (col + 3 < F) v.w = x[off + 3];
+    const char* xb = reinterpret_cast<const char*>(x);
+    if (col + 0 < F) v.x = *reinterpret_cast<const float*>(xb + 4u * off);
+    if (col + 1 < F) v.y = *reinterpret_cast<const float*>(xb + 4u * off + 4u);
+    if (col + 2 < F) v.z = *reinterpret_cast<const float*>(xb + 4u * off + 8u);
+    if (col + 3 < F) v.w = *reinterpret_cast<const float*>(xb + 4u * off + 12u);
   }
   return v;
 }
 
-__device__ __forceinline__ void st4(float* __restrict__ y, int64_t off, int col, int64_t F, bool row_ok, bool aligned,
+__device__ __forceinline__ void st4(float* __restrict__ y, unsigned off, int col, int64_t F, bool row_ok, bool aligned,
                                     float4 v) {
   if (!row_ok) return;
   if (aligned) {
-    if (col < F) *reinterpret_cast<float4*>(y + off) = v;
+    if (col < F) *reinterpret_cast<float4*>(reinterpret_cast<char*>(y) + 4u * off) = v;
   } else {
-    if (col + 0 < F) y[off + 0] = v.x;
-    if (col + 1 < F) y[off + 1] = v.y;
-    if (col + 2 < F) y[off + 2] = v.z;
-    if (col + 3 < F) y[off + 3] = v.w;
+    char* yb = reinterpret_cast<char*>(y);
+    if (col + 0 < F) *reinterpret_cast<float*>(yb + 4u * off) = v.x;
+    if (col + 1 < F) *reinterpret_cast<float*>(yb + 4u * off + 4u) = v.y;
+    if (col + 2 < F) *reinterpret_cast<float*>(yb + 4u * off + 8u) = v.z;
+    if (col + 3 < F) *reinterpret_cast<float*>(yb + 4u * off + 12u) = v.w;
   }
 }
 
@@ -129,7 +134,10 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
   float* colv = reinterpret_cast<float*>(lds_raw + STAGE_BYTES);   // mean_x, rho_x, mean_t, rho_t : [4][TFv]
   float* red = colv + 4 * TFv;                                     // [2 operands][16 waves][TFv]
 
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // the wave index is wave-uniform: readfirstlane puts it (and the work-item bookkeeping derived from it: tile, K-half,
+  // I/J blocks, LDS fragment bases) into SGPRs instead of long-lived VGPRs of a kernel that runs at its 128-VGPR cap
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = tid % LPR, rg = tid / LPR;
   const int h = lane >> 5, l31 = lane & 31;
   const Levels nlev = make_levels(k, fabsf(r) <= 8.0f);
@@ -160,7 +168,7 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
     for (int j = 0; j < RJ; j++) {
       const int row = rg + RG * j;
       const bool ok = row < B;
-      const int64_t off = (int64_t)row * F + col;
+      const unsigned off = (unsigned)row * (unsigned)F + (unsigned)col;
       xv[j] = ld4(x, off, col, F, ok, aligned);
     }
     // ---- folded batch-norm: x = a*z + b with (a, b) of this tile's channel (HW % 64 == 0: one channel per tile) -------
@@ -311,14 +319,14 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
 #pragma unroll
       for (int j = 0; j < RJ; j++) {
         const int row = rg + RG * j;
-        rv[j] = ld4(bn.res, (int64_t)row * F + col, col, F, row < B, aligned);
+        rv[j] = ld4(bn.res, (unsigned)row * (unsigned)F + (unsigned)col, col, F, row < B, aligned);
       }
     }
 #pragma unroll
     for (int j = 0; j < RJ; j++) {
       const int row = rg + RG * j;
       const bool ok = row < B;
-      const int64_t off = (int64_t)row * F + col;
+      const unsigned off = (unsigned)row * (unsigned)F + (unsigned)col;
       tv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (PAIR) {
         float4 q, rl = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1123,6 +1131,7 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
 
 int launch_partials4(bool pair, const Geom& g, const float* x, int B, int64_t F, int k, float r, float eps, float* xq,
                      float* stats, float* ws, hipStream_t st, BnFold bn) {
+  if ((int64_t)B * F * 4 >= ((int64_t)1 << 32)) return ALIGNQ_EUNSUPPORTED;   // 32-bit byte offsets (see ld4 / st4)
   const int aligned = ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
                       (!xq || (reinterpret_cast<uintptr_t>(xq) & 15) == 0);
   unsigned* counter = reinterpret_cast<unsigned*>(ws + (size_t)g.grid * g.slab_floats + kPartFloats);
