@@ -710,6 +710,21 @@ __global__ __launch_bounds__(1024) void slab_reduce_multi_kernel(RChunk c, int B
 // gradients dA_out = gscale*(mu*sign(A)/n - gD), dG_out = gscale*|D-A|/n  (zero outside [:B,:B]).
 //   FUSED : gD = c_con*(D-A) + gamma*sign(D-A)/n from the forward's scal = {loss, c_con, 1/n, rms}
 //   !FUSED: gD = dD (explicit upstream gradient)
+// S image for the B in (64,128] backward (site_bwd4_kernel's MFMA A operand), written next to the fp32 S at byte offset
+// kSImageOffset of the S buffer: every element split ONCE into bf16 hi / lo (the backward used to split its 64 elements per
+// lane in every workgroup: ~400 VALU instructions per lane of a kernel that issues ~1100), in fragment order
+//   img[ks][h][i][0..7] = hi(S[i][16 ks + 8 h + 0..7]),  img[ks][h][i][8..15] = lo(...)        (32 B per (ks, h, i))
+// so that the 32 lanes l31 of a half-wave read 1 KB contiguously.  Rows / columns >= B are zero.
+constexpr int kSImageOffset = 128 * 128 * 4;      // bytes; the fp32 S occupies at most the first 64 KB
+__device__ __forceinline__ void s_image_store(float* __restrict__ S, int i, int j, float v) {
+  __bf16* img = reinterpret_cast<__bf16*>(reinterpret_cast<char*>(S) + kSImageOffset);
+  const __bf16 hi = (__bf16)v;
+  const __bf16 lo = (__bf16)(v - (float)hi);
+  const int o = (((j >> 4) * 2 + ((j >> 3) & 1)) * 128 + i) * 16 + (j & 7);
+  img[o] = hi;
+  img[o + 8] = lo;
+}
+
 template <bool FUSED>
 __device__ __forceinline__ void site_prep_body(const float* __restrict__ dD, const float* __restrict__ D,
                                                         const float* __restrict__ A, const float* __restrict__ gamma,
@@ -721,6 +736,7 @@ __device__ __forceinline__ void site_prep_body(const float* __restrict__ dD, con
   const int total = FUSED ? dim * dim : B * B;
   const int side = FUSED ? dim : B;
   const float c_con = FUSED ? scal[1] : 0.f, inv_n = FUSED ? scal[2] : 0.f;
+  const bool image = B > 64;                 // only the B in (64,128] backward reads it
   for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
     const int i = e / side, j = e - i * side;
     if (i < B && j < B) {
@@ -738,10 +754,18 @@ __device__ __forceinline__ void site_prep_body(const float* __restrict__ dD, con
         gij = dD[i * B + j];
         gji = dD[j * B + i];
       }
-      S[i * B + j] = (gij + gji) * gs * invF;
+      const float sv = (gij + gji) * gs * invF;
+      S[i * B + j] = sv;
+      if (image) s_image_store(S, i, j, sv);
     } else if (FUSED) {
       if (dA_out) dA_out[e] = 0.f;
       if (dG_out) dG_out[e] = 0.f;
+    }
+  }
+  if (image && B < 128) {                    // zero padding of the image (rows / columns B..127)
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < 128 * 128; e += gridDim.x * 256) {
+      const int i = e >> 7, j = e & 127;
+      if (i >= B || j >= B) s_image_store(S, i, j, 0.0f);
     }
   }
 }
@@ -908,34 +932,17 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
       }
     }
     __builtin_amdgcn_sched_barrier(0);   // keep the 16 fragment loads below out of the register-hungry load phase
-    // S fragments (already scaled, symmetric): A[i][k], i = I*32 + l31, k = 16*ks + 8h + jj, split into bf16 hi/lo.
-    // Loaded here, after the load phase's registers are dead (a workgroup normally owns ONE tile: grid == n_tiles)
+    // S fragments (already scaled, symmetric, split into bf16 hi / lo by the prep kernel: s_image_store): A[i][k],
+    // i = I*32 + l31, k = 16*ks + 8h + jj.  Loaded here, after the load phase's registers are dead (a workgroup owns ONE
+    // tile: grid == n_tiles); two 16-byte loads per k step, the 32 lanes of a half-wave read 1 KB contiguously.
     bf16x8 sh[8], sl[8];
     {
-      const int i = I * 32 + l31;
-      const bool vec = ((B & 7) == 0) && ((reinterpret_cast<uintptr_t>(S) & 15) == 0);
+      const char* img = reinterpret_cast<const char*>(S) + kSImageOffset;
   #pragma unroll
       for (int ks = 0; ks < 8; ks++) {
-        const int kk0 = 16 * ks + 8 * h;
-        float v[8];
-        if (vec) {                              // 8 consecutive j of row i: two 16-byte loads
-          float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = a4;
-          if (i < B && kk0 < B) {
-            a4 = *reinterpret_cast<const float4*>(S + i * B + kk0);
-            b4 = *reinterpret_cast<const float4*>(S + i * B + kk0 + 4);
-          }
-          v[0] = a4.x; v[1] = a4.y; v[2] = a4.z; v[3] = a4.w; v[4] = b4.x; v[5] = b4.y; v[6] = b4.z; v[7] = b4.w;
-        } else {
-  #pragma unroll
-          for (int jj = 0; jj < 8; jj++) v[jj] = (i < B && kk0 + jj < B) ? S[i * B + kk0 + jj] : 0.0f;
-        }
-  #pragma unroll
-        for (int jj = 0; jj < 8; jj++) {
-          __bf16 a, b2;
-          split_bf16(v[jj], a, b2);
-          sh[ks][jj] = a;
-          sl[ks][jj] = b2;
-        }
+        const char* q = img + ((((ks * 2 + h) * 128) + I * 32 + l31) * 32);
+        sh[ks] = *reinterpret_cast<const bf16x8*>(q);
+        sl[ks] = *reinterpret_cast<const bf16x8*>(q + 16);
       }
     }
     __syncthreads();

@@ -494,7 +494,9 @@ size_t alignq_site_ws_bytes(int B, int64_t F) {
   return ws_floats(geom(B, F)) * sizeof(float);
 }
 
-size_t alignq_site_bwd_ws_bytes(int B) { return (size_t)(B > 0 ? B : 1) * (size_t)(B > 0 ? B : 1) * sizeof(float); }
+// the S buffer of the backward: [B,B] fp32 (sym(dD) * scale / F) in its first 64 KB, followed at byte offset 65536 by the
+// bf16 hi / lo fragment image of the same matrix that the prep kernels leave for the B in (64,128] backward (64 KB)
+size_t alignq_site_bwd_ws_bytes(int B) { (void)B; return (size_t)2 * 128 * 128 * sizeof(float); }
 
 int alignq_site_partials(const float* x, int B, int64_t F, int k, float act_range, float eps, float* xq, float* stats,
                          void* ws, void* stream) {

@@ -114,7 +114,7 @@ class LossSumFn(torch.autograd.Function):
         for (B, dim, mu, rho), recs in groups.items():
             dev = recs[0].D.device
             for r in recs:
-                r.S = torch.empty(B, B, dtype=torch.float32, device=dev)
+                r.S = torch.empty(lib.alignq_site_bwd_ws_bytes(B) // 4, dtype=torch.float32, device=dev)   # fp32 S + bf16 image
                 r.dA, r.dG = torch.empty_like(r.A), torch.empty_like(r.Gm)
             L.check(lib.alignq_site_prep_fused_multi(
                 len(recs), L.ptr_array([r.D for r in recs]), L.ptr_array([r.A for r in recs]),
@@ -384,7 +384,7 @@ class BNSiteFn(torch.autograd.Function):
             S, dA, dG = rec.S, rec.dA, rec.dG
             rec.S = rec.dA = rec.dG = None       # sole owner: AccumulateGrad takes dA/dG without a copy
         else:
-            S = torch.empty(B, B, dtype=torch.float32, device=dev)
+            S = torch.empty(lib.alignq_site_bwd_ws_bytes(B) // 4, dtype=torch.float32, device=dev)       # fp32 S + bf16 image
             dA, dG = torch.empty_like(A), torch.empty_like(Gm)
             L.check(lib.alignq_site_prep_fused(L.ptr(D), L.ptr(A), L.ptr(Gm), dim, L.ptr(scal), mu, L.ptr(g_loss), B, F,
                                                L.ptr(S), L.ptr(dA), L.ptr(dG), st), "alignq_site_prep_fused")

@@ -101,7 +101,7 @@ def measure_kernels(dev, B, k, site_F_counts, hw_of_F, folded=True, nhwc=False):
         ress = [torch.randn(B, F, device=dev) for _ in range(R)]       # the block's shortcut (added before the ReLU)
         dress = [torch.empty(B, F, device=dev) for _ in range(R)]
         D = torch.empty(B, B, device=dev)
-        S = torch.empty(B, B, device=dev)
+        S = torch.empty(lib.alignq_site_bwd_ws_bytes(B) // 4, device=dev)       # fp32 S + its bf16 fragment image (prep writes both)
         scal = torch.empty(4, device=dev)
         dA, dG = torch.empty_like(A), torch.empty_like(Gm)
         one = torch.ones((), device=dev)

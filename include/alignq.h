@@ -129,8 +129,10 @@ int alignq_site_reduce_loss(void* ws, int B, int64_t F, float* D, const float* a
  *                           alignq_site_reduce_loss); also writes the parameter gradients of the loss,
  *                           dalterD / dgamma [dim,dim] (already multiplied by dD_scale; may be NULL).          */
 size_t alignq_site_bwd_ws_bytes(int B);
-/* second launch of both forms alone: S = the prepared, scaled, symmetrised dD [B,B] that the first launch
- * (site_prep_kernel) leaves in ws.                                                                             */
+/* second launch of both forms alone: S = the buffer (alignq_site_bwd_ws_bytes(B) bytes) the first launch (site_prep_kernel:
+ * alignq_site_prep_fused[_multi], or the first half of alignq_site_bwd / _bwd_fused) leaves: the prepared, scaled,
+ * symmetrised dD [B,B] in fp32, followed at byte offset 65536 by its bf16 hi/lo split in MFMA fragment order (read by the
+ * 64 < B <= 128 kernels; the prep kernel splits each element once instead of every workgroup of the backward).        */
 int alignq_site_bwd_apply(const float* g, const float* S, const float* x, const float* stats, int B, int64_t F,
                           float act_range, float eps, float* dx, void* stream);
 int alignq_site_bwd(const float* g, const float* dD, const float* dD_scale, const float* x,

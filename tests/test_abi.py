@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.alignq_site_ws_bytes(28, 802816) == (2048 * 32 * 32 + tail) * 4
     assert lib.alignq_site_ws_bytes(28, 1024) == (8 * 32 * 32 + tail) * 4            # 32 sub-tiles of 32 features / 4 waves
     assert lib.alignq_site_ws_bytes(129, 64) == 0
-    assert lib.alignq_site_bwd_ws_bytes(128) == 128 * 128 * 4
+    assert lib.alignq_site_bwd_ws_bytes(128) == 2 * 128 * 128 * 4        # fp32 S + its bf16 hi/lo fragment image
 
 
 def test_argument_validation_without_gpu():

@@ -107,7 +107,7 @@ class _SiteRun:
         st = L.stream_ptr()
         f32 = dict(dtype=torch.float32, device=dev)
         gl = torch.tensor(g_loss, **f32)
-        self.S = torch.empty(B, B, **f32)
+        self.S = torch.empty(lib.alignq_site_bwd_ws_bytes(B) // 4, **f32)      # fp32 S + its bf16 fragment image
         self.dA, self.dG = torch.empty_like(self.A), torch.empty_like(self.Gm)
         L.check(lib.alignq_site_prep_fused(L.ptr(self.D), L.ptr(self.A), L.ptr(self.Gm), self.A.shape[0], L.ptr(self.scal),
                                            self.mu, L.ptr(gl), B, F, L.ptr(self.S), L.ptr(self.dA), L.ptr(self.dG), st),

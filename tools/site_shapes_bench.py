@@ -8,7 +8,7 @@ for B, F in [(28, 802816), (28, 401408), (28, 200704), (28, 100352), (64, 65536)
     xq, dx = torch.empty_like(x), torch.empty_like(x)
     D = torch.empty(B, B, device=dev); stats = torch.empty(4, F, device=dev)
     ws = torch.empty(lib.alignq_site_ws_bytes(B, F), dtype=torch.uint8, device=dev)
-    S = torch.rand(B, B, device=dev) * 1e-6
+    S = torch.zeros(lib.alignq_site_bwd_ws_bytes(B) // 4, device=dev)   # fp32 S + bf16 image, zero (timing only)
     A = torch.rand(B, B, device=dev); Gm = torch.rand(B, B, device=dev); scal = torch.empty(4, device=dev)
     tp = time_call(lambda: lib.alignq_site_partials(p(x), B, F, 8, 2.0, 1e-5, p(xq), p(stats), p(ws), st), 20)
     def pair():
