@@ -106,6 +106,9 @@ __device__ __forceinline__ bf16x8 neg8(bf16x8 v) {
   return __builtin_bit_cast(bf16x8, u);
 }
 
+// component e of a float4 (e is a compile-time constant after unrolling: folds to the register, no scratch array)
+__device__ __forceinline__ float f4get(const float4& v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
+
 __device__ __forceinline__ void split_bf16(float v, __bf16& hi, __bf16& lo) {
   hi = (__bf16)v;
   lo = (__bf16)(v - (float)hi);
@@ -807,7 +810,11 @@ __global__ __launch_bounds__(256) void site_prep_multi_kernel(PChunk c, int dim,
 //       batch rows (256-byte coalesced row segments per wave instruction), two 16-byte LDS stores per array.
 // TFv = 64: 512 threads, one workgroup per CU (138 KB LDS);  TFv = 32: 256 threads, 69 KB LDS, two workgroups per CU whose
 // phases interleave, and twice as many tiles for the small-F sites.
-template <int TFv, bool PAIR, bool BN>
+// VEC (F % 4 == 0, 16-byte aligned tensors): a thread owns FOUR feature columns x FOUR batch rows and moves them with 16-byte
+// global accesses (12 loads + 4-8 stores per thread instead of 48 + 16-32 dword ones: the dword form kept the texture
+// addresser busy for ~4 us per launch at F = 16384); the transposed staging is then one 8-byte LDS store per column and
+// array.  !VEC: one column x 16 rows per thread, dword accesses with clamped offsets (any F, any alignment).
+template <int TFv, bool PAIR, bool BN, bool VEC>
 __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restrict__ gup, const float* __restrict__ S,
                                                         const float* __restrict__ x, const float* __restrict__ stats,
                                                         int B, int64_t F, float r, float eps, float* __restrict__ dx,
@@ -830,11 +837,14 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
   float* Js = Os + TILE;                                               // [128][65] dt/dx (PAIR)
   float* red = Os + NF_ARR * TILE;                                     // [4 row blocks][2 operands][2][64]
 
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: I, cj and the LDS bases derived from it in SGPRs
   const int h = lane >> 5, l31 = lane & 31;
   const int I = w / CB, cj = w % CB;
   const int cc = cj * 32 + l31;            // this lane's feature column inside the tile (accumulator layout)
-  const int lcol = tid % TFv, lrow0 = (tid / TFv) * 16;   // load mapping: one feature column, 16 consecutive batch rows
+  const int lcol = tid % TFv, lrow0 = (tid / TFv) * 16;   // !VEC load mapping: one feature column, 16 consecutive batch rows
+  constexpr int NCQ = TFv / 4;                             // VEC load mapping: column quad lc4, rows lrow4 .. lrow4 + 3
+  const int lc4 = tid % NCQ, lrow4 = (tid / NCQ) * 4;
 
   const float invB = 1.0f / (float)B, invBm1 = 1.0f / (float)(B - 1);
   STAMP(10);
@@ -853,6 +863,113 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
     for (int q = 0; q < 16; q++) boff[q] = (unsigned)min(lrow0 + q, B - 1) * rowB + colc;
 #define AT(ptr, q) (*reinterpret_cast<const float*>(reinterpret_cast<const char*>(ptr) + boff[q]))
 #define ATW(ptr, q) (*reinterpret_cast<float*>(reinterpret_cast<char*>(ptr) + boff[q]))
+    // VEC addressing: one 32-bit byte offset per row for the thread's column quad (clamped like the dword form)
+    const bool q_ok = (col0 + 4 * lc4) < F;                  // F % 4 == 0: a quad lies inside or outside as a whole
+    const unsigned colq = (unsigned)(q_ok ? col0 + 4 * lc4 : (int)F - 4) * 4u;
+    const uint4 bo4 = make_uint4((unsigned)min(lrow4 + 0, B - 1) * rowB + colq, (unsigned)min(lrow4 + 1, B - 1) * rowB + colq,
+                                 (unsigned)min(lrow4 + 2, B - 1) * rowB + colq, (unsigned)min(lrow4 + 3, B - 1) * rowB + colq);
+#define BO4(q) ((q) == 0 ? bo4.x : ((q) == 1 ? bo4.y : ((q) == 2 ? bo4.z : bo4.w)))
+#define AT4(ptr, q) (*reinterpret_cast<const float4*>(reinterpret_cast<const char*>(ptr) + BO4(q)))
+#define ATW4(ptr, q) (*reinterpret_cast<float4*>(reinterpret_cast<char*>(ptr) + BO4(q)))
+    if constexpr (VEC) {
+      // ---- load x / g / y quads of 4 rows, recompute t / jac, standardise, stage transposed ---------------------------
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int fq = col0 + 4 * lc4;
+      // (clamped address + value select: `ok ? *p : zero` would be turned into a select of POINTERS with the zero on the stack)
+      const int fqc = q_ok ? fq : 0;
+      float4 mx4 = *reinterpret_cast<const float4*>(stats + fqc);
+      float4 rx4 = *reinterpret_cast<const float4*>(stats + F + fqc);
+      float4 mt4 = z4, rt4 = z4;
+      if (PAIR) {
+        mt4 = *reinterpret_cast<const float4*>(stats + 2 * F + fqc);
+        rt4 = *reinterpret_cast<const float4*>(stats + 3 * F + fqc);
+      }
+      if (!q_ok) { mx4 = z4; rx4 = z4; mt4 = z4; rt4 = z4; }
+      float4 a4 = make_float4(1.f, 1.f, 1.f, 1.f), b4 = z4;
+      if (BN && q_ok) {
+        if (bn.nhwc) {             // channels-last: the quad covers 4 consecutive channels (C % 4 == 0)
+          const int ch = fq & (bn.C - 1);
+          a4 = *reinterpret_cast<const float4*>(bn.ab + ch);
+          b4 = *reinterpret_cast<const float4*>(bn.ab + bn.C + ch);
+        } else {                   // one channel for the whole quad (HW % 4 == 0)
+          const int ch = fq / bn.HW;
+          const float av = bn.ab[ch], bv = bn.ab[bn.C + ch];
+          a4 = make_float4(av, av, av, av);
+          b4 = make_float4(bv, bv, bv, bv);
+        }
+      }
+      float4 xr[4], gr[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) xr[q] = AT4(x, q);          // all loads in flight before the first use
+      const bool has_g = PAIR && gup != nullptr;
+      if (has_g) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) gr[q] = AT4(gup, q);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) gr[q] = z4;
+      }
+      if (BN) {
+        float4 yr[4];
+        const bool masked = bn.y != nullptr;
+        if (masked) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) yr[q] = AT4(bn.y, q);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          xr[q].x = __fmaf_rn(a4.x, xr[q].x, b4.x); xr[q].y = __fmaf_rn(a4.y, xr[q].y, b4.y);
+          xr[q].z = __fmaf_rn(a4.z, xr[q].z, b4.z); xr[q].w = __fmaf_rn(a4.w, xr[q].w, b4.w);
+          if (masked) {                                          // fused ReLU backward
+            gr[q].x = yr[q].x > 0.0f ? gr[q].x : 0.0f; gr[q].y = yr[q].y > 0.0f ? gr[q].y : 0.0f;
+            gr[q].z = yr[q].z > 0.0f ? gr[q].z : 0.0f; gr[q].w = yr[q].w > 0.0f ? gr[q].w : 0.0f;
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        if (!(q_ok && (lrow4 + q) < B)) { xr[q] = z4; gr[q] = z4; }
+      }
+      if (BN && bn.dres && q_ok) {            // the masked gradient is also the residual branch's gradient
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          if (lrow4 + q < B) ATW4(bn.dres, q) = gr[q];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; e++) {            // column 4*lc4 + e: its 4 rows are 4 consecutive entries of a transposed row
+        // (scalars + one braced vector construction per array: element-wise insertion into four live bf16x4 put them on the
+        // stack in the PAIR instantiations)
+        __bf16 xh0, xh1, xh2, xh3, xl0, xl1, xl2, xl3, th0, th1, th2, th3, tl0, tl1, tl2, tl3;
+#define ALIGNQ_ROW(q, XH, XL, TH, TL)                                                              \
+        {                                                                                          \
+          const int row = lrow4 + q;                                                               \
+          const bool ok = q_ok && row < B;                                                         \
+          const float xe = f4get(xr[q], e);                                                        \
+          split_bf16(ok ? (xe - f4get(mx4, e)) * f4get(rx4, e) : 0.0f, XH, XL);                    \
+          if (PAIR) {                                                                              \
+            float t, jac;                                                                          \
+            act_transform_fast(xe, r, &t, &jac);                                                   \
+            split_bf16(ok ? (t - f4get(mt4, e)) * f4get(rt4, e) : 0.0f, TH, TL);                   \
+            Js[row * LDv + 4 * lc4 + e] = jac;                                                     \
+            Os[row * LDv + 4 * lc4 + e] = f4get(gr[q], e) * jac;                                   \
+          } else {                                                                                 \
+            TH = (__bf16)0.0f; TL = (__bf16)0.0f;                                                  \
+          }                                                                                        \
+        }
+        ALIGNQ_ROW(0, xh0, xl0, th0, tl0)
+        ALIGNQ_ROW(1, xh1, xl1, th1, tl1)
+        ALIGNQ_ROW(2, xh2, xl2, th2, tl2)
+        ALIGNQ_ROW(3, xh3, xl3, th3, tl3)
+#undef ALIGNQ_ROW
+        const int o = (4 * lc4 + e) * LDT + lrow4;       // 8-byte aligned: LDT * 2 and lrow4 * 2 are multiples of 8
+        *reinterpret_cast<bf16x4*>(XThi + o) = (bf16x4){xh0, xh1, xh2, xh3};
+        *reinterpret_cast<bf16x4*>(XTlo + o) = (bf16x4){xl0, xl1, xl2, xl3};
+        if (PAIR) {
+          *reinterpret_cast<bf16x4*>(TThi + o) = (bf16x4){th0, th1, th2, th3};
+          *reinterpret_cast<bf16x4*>(TTlo + o) = (bf16x4){tl0, tl1, tl2, tl3};
+        }
+      }
+    } else
     // ---- load x (and g) for (feature lcol, rows lrow0..+15), recompute t / jac, standardise ---------------
     {
       const float mx = lcol_ok ? stats[col0 + lcol] : 0.f;
@@ -971,13 +1088,15 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
     // folded batch-norm backward needs zhat of the elements this thread copies out below (the ones it loaded above):
     // re-issue those 16 loads now (L2 hits), while no other large register array is live, so that their latency
     // overlaps the projection / assemble phases
-    float zr[16];
+    float zr[VEC ? 1 : 16];
+    float4 zr4[VEC ? 4 : 1];
     if (BN) {
+      if constexpr (VEC) {
 #pragma unroll
-      for (int q = 0; q < 16; q++) {
-        const int row = lrow0 + q;
-        (void)row;
-        zr[q] = AT(x, q);                      // clamped offset; out-of-range elements are not used below
+        for (int q = 0; q < 4; q++) zr4[q] = AT4(x, q);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 16; q++) zr[q] = AT(x, q);   // clamped offset; out-of-range elements are not used below
       }
     }
     // ---- projections over this wave's 32 batch rows: sum dVh, sum dVh*Vh.  Vh of this lane's accumulator cells
@@ -1068,6 +1187,83 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
     }
     __syncthreads();
     STAMP(14);
+    if constexpr (VEC) {
+      // ---- copy out: one 16-byte store per (row, column quad); folded BN: per-column sums of dx and dx * zhat -----------
+      float bp0[4] = {0.f, 0.f, 0.f, 0.f}, bp1[4] = {0.f, 0.f, 0.f, 0.f};
+      if (q_ok) {
+        float bmu[4] = {0.f, 0.f, 0.f, 0.f}, bis[4] = {0.f, 0.f, 0.f, 0.f};
+        if (BN) {
+          const int fq = col0 + 4 * lc4;
+          if (bn.nhwc) {
+            const int ch = fq & (bn.C - 1);
+            const float4 m4 = *reinterpret_cast<const float4*>(bn.save + ch);
+            const float4 i4 = *reinterpret_cast<const float4*>(bn.save + bn.C + ch);
+            bmu[0] = m4.x; bmu[1] = m4.y; bmu[2] = m4.z; bmu[3] = m4.w;
+            bis[0] = i4.x; bis[1] = i4.y; bis[2] = i4.z; bis[3] = i4.w;
+          } else {
+            const int ch = fq / bn.HW;
+#pragma unroll
+            for (int e = 0; e < 4; e++) { bmu[e] = bn.save[ch]; bis[e] = bn.save[bn.C + ch]; }
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int row = lrow4 + q;
+          if (row < B) {
+            const float* op = Os + row * LDv + 4 * lc4;
+            const float oo[4] = {op[0], op[1], op[2], op[3]};
+            ATW4(dx, q) = make_float4(oo[0], oo[1], oo[2], oo[3]);
+            if (BN) {
+#pragma unroll
+              for (int e = 0; e < 4; e++) {      // x is the conv output z here
+                bp0[e] += oo[e];
+                bp1[e] += oo[e] * ((f4get(zr4[q], e) - bmu[e]) * bis[e]);
+              }
+            }
+          }
+        }
+      }
+      // red is free again (all its reads finished before the barrier above)
+      if (BN && bn.nhwc) {
+        // sum over the wave's row groups (lanes NCQ apart), then one row of `red` per wave: [2 * wave + {0,1}][column]
+#pragma unroll
+        for (int o = NCQ; o < 64; o <<= 1) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) { bp0[e] += __shfl_xor(bp0[e], o, 64); bp1[e] += __shfl_xor(bp1[e], o, 64); }
+        }
+        if (lane < NCQ) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            red[(2 * w) * TFv + 4 * lc4 + e] = bp0[e];
+            red[(2 * w + 1) * TFv + 4 * lc4 + e] = bp1[e];
+          }
+        }
+      } else if (BN) {                 // one channel per tile
+        float s0 = wave_sum(bp0[0] + bp0[1] + bp0[2] + bp0[3]);
+        float s1 = wave_sum(bp1[0] + bp1[1] + bp1[2] + bp1[3]);
+        if (lane == 0) { red[2 * w] = s0; red[2 * w + 1] = s1; }
+      }
+      __syncthreads();
+      if (BN && bn.nhwc) {
+        const int C = bn.C;
+        const int cp = C < TFv ? C : TFv;                      // distinct channels in a tile
+        if (tid < cp) {
+          float t0 = 0.f, t1 = 0.f;
+          for (int j = tid; j < TFv; j += cp) {
+#pragma unroll
+            for (int q = 0; q < NWv; q++) { t0 += red[(2 * q) * TFv + j]; t1 += red[(2 * q + 1) * TFv + j]; }
+          }
+          bn.dx_part[((int64_t)tile * cp + tid) * 2] = t0;
+          bn.dx_part[((int64_t)tile * cp + tid) * 2 + 1] = t1;
+        }
+      } else if (BN && tid == 0) {
+        float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int q = 0; q < NWv; q++) { t0 += red[2 * q]; t1 += red[2 * q + 1]; }
+        bn.dx_part[2 * tile] = t0;
+        bn.dx_part[2 * tile + 1] = t1;
+      }
+    } else {
     // ---- copy out: 256-byte row segments, one feature column per lane -----------------------------------
     float bp0 = 0.f, bp1 = 0.f;     // folded batch-norm backward: this tile's sum dx and sum dx*zhat (one channel per tile)
     if (lcol_ok) {
@@ -1121,9 +1317,13 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
       bn.dx_part[2 * tile] = t0;
       bn.dx_part[2 * tile + 1] = t1;
     }
+    }
     STAMP(15);
 #undef AT
 #undef ATW
+#undef AT4
+#undef ATW4
+#undef BO4
   }
   BSTAMP(1, 1);
 }
@@ -1224,7 +1424,17 @@ int launch_bwd4(bool pair, const Geom& g, const float* gup, const float* S, cons
   const int n_tiles = (int)((F + tf - 1) / tf);
   const int grid = n_tiles;               // one tile per workgroup
   const int aligned = 0;
-#define LB(TFV, P, N) hipLaunchKernelGGL((site_bwd4_kernel<TFV, P, N>), grid, TFV * 8, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_tiles, aligned, bn)
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  // 16-byte accesses need whole column quads and aligned rows (channels-last BN: C % 4 == 0 holds, C is a power of two >= 4)
+  const bool vec = (F % 4 == 0) && al16(gup) && al16(x) && al16(stats) && al16(dx) && al16(bn.y) && al16(bn.dres) &&
+                   al16(bn.ab) && al16(bn.save) && (!bn.ab || bn.nhwc || bn.HW % 4 == 0) && (!bn.nhwc || bn.C % 4 == 0);
+#define LB(TFV, P, N)                                                                                                        \
+  do {                                                                                                                       \
+    if (vec) hipLaunchKernelGGL((site_bwd4_kernel<TFV, P, N, true>), grid, TFV * 8, 0, st, gup, S, x, stats, B, F, r, eps,   \
+                                dx, n_tiles, aligned, bn);                                                                   \
+    else hipLaunchKernelGGL((site_bwd4_kernel<TFV, P, N, false>), grid, TFV * 8, 0, st, gup, S, x, stats, B, F, r, eps, dx,  \
+                            n_tiles, aligned, bn);                                                                           \
+  } while (0)
   if (tf == 64) {
     if (pair && bn.ab) LB(64, true, true); else if (pair) LB(64, true, false); else LB(64, false, false);
   } else {
