@@ -298,7 +298,10 @@ __global__ __launch_bounds__(kThreads) void act_quant_bwd_packed_kernel(const fl
                                                                         const T* __restrict__ bins, float* __restrict__ dx,
                                                                         int64_t n, int k, float r, int relu) {
   typedef typename Vec4<T>::type V4;
-  const Levels nlev = make_levels(k, fabsf(r) <= 8.0f);
+  // value(idx) > 0 as an INTEGER test (exact: ADMM formula value = idx / n; CDF formula value = r (2 idx / n - 1) with n odd,
+  // so 2 idx != n and the fp32 quotient cannot round across 1/2): idx > thr with thr = 0 | n / 2 (floor); k == 1: the CDF
+  // tree's sign(c) is always 1 (value +r), the ADMM tree's sign(t) is in {-1, 0, 1}
+  const int thr = (FORMULA == 0 || k == 1) ? 0 : (((1 << k) - 1) >> 1);
   const int64_t nvec = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * kThreads;
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += stride) {
@@ -306,10 +309,10 @@ __global__ __launch_bounds__(kThreads) void act_quant_bwd_packed_kernel(const fl
     const float4 xv = reinterpret_cast<const float4*>(x)[i];
     if (relu) {
       const V4 b = reinterpret_cast<const V4*>(bins)[i];
-      gv.x = bin_value<FORMULA>((float)b.x, k, nlev, r) > 0.f ? gv.x : 0.f;
-      gv.y = bin_value<FORMULA>((float)b.y, k, nlev, r) > 0.f ? gv.y : 0.f;
-      gv.z = bin_value<FORMULA>((float)b.z, k, nlev, r) > 0.f ? gv.z : 0.f;
-      gv.w = bin_value<FORMULA>((float)b.w, k, nlev, r) > 0.f ? gv.w : 0.f;
+      gv.x = (int)b.x > thr ? gv.x : 0.f;
+      gv.y = (int)b.y > thr ? gv.y : 0.f;
+      gv.z = (int)b.z > thr ? gv.z : 0.f;
+      gv.w = (int)b.w > thr ? gv.w : 0.f;
     }
     float4 o;
     o.x = gv.x * act_jac(xv.x, r); o.y = gv.y * act_jac(xv.y, r); o.z = gv.z * act_jac(xv.z, r); o.w = gv.w * act_jac(xv.w, r);
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(kThreads) void act_quant_bwd_packed_kernel(const fl
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const int64_t i = (nvec << 2) + threadIdx.x;
-    const bool keep = !relu || bin_value<FORMULA>((float)bins[i], k, nlev, r) > 0.f;
+    const bool keep = !relu || (int)bins[i] > thr;
     dx[i] = (keep ? g[i] : 0.f) * act_jac(x[i], r);
   }
 }

@@ -29,6 +29,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0 # dense bf16 matrix peak (no sparsity)
 
 
 def parse():
@@ -46,6 +47,7 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--no-fuse-bn", action="store_true", help="keep torch/MIOpen batch-norm instead of folding it into the ADMM-site kernels")
     ap.add_argument("--dp-selftest", action="store_true", help="run the DP path (RCCL all-reduce, two graphs) even at N=1")
+    ap.add_argument("--no-dp-probe", action="store_true", help="skip the short world-size-1 DP-path measurement (extra key dp_selftest)")
     ap.add_argument("--no-qconv", action="store_true", help="keep MIOpen for every convolution (default: Conv2d_Q's 3x3 "
                     "stride-1 body convolutions, forward and data gradient, run on alignq_conv3x3_nhwc)")
     ap.add_argument("--nchw", action="store_true",
@@ -82,6 +84,7 @@ def measure_kernels(dev, B, k, site_F_counts, hw_of_F, folded=True, nhwc=False):
     out = {}
     names = ("bn_partial_stats", "site_partials", "site_reduce_loss", "site_bwd_prep", "site_bwd", "bn_bwd_apply")
     per_step = {n: [0.0, 0.0] for n in names}
+    multi_sites = []
     A = torch.rand(B, B, device=dev)
     Gm = torch.rand(B, B, device=dev)
     R = 4   # buffer sets in rotation: a launch finds its operands where the training step finds them (written a few launches
@@ -120,14 +123,24 @@ def measure_kernels(dev, B, k, site_F_counts, hw_of_F, folded=True, nhwc=False):
 
         if folded:
             stats_fn = lib.alignq_bn_partial_stats_nhwc if nh else lib.alignq_bn_partial_stats
+            # channels-last: the captured step feeds the fold with the producing convolution's per-workgroup float partials
+            # (conv_parts), not with a statistics pass of its own: time THAT entry-point form
+            Wd = int(round(HW ** 0.5))
+            conv_parts = lib.alignq_conv3x3_bn_parts(B, Wd, Wd, C) if nh else 0
+            cparts = []
+            if conv_parts > 0:
+                for i in range(R):
+                    zc = xs[i].view(conv_parts, (B * HW) // conv_parts, C)          # rows of [B*HW, C] split like the conv's tiles
+                    cparts.append(torch.stack([zc.sum(1).t(), (zc * zc).sum(1).t()], 2).contiguous())   # [C][parts][2]
 
             def stats_i(i):
                 return stats_fn(p(xs[i]), B, C, HW, p(ws_bns[i]), st)
 
             def part_i(i, res=False):
-                return lib.alignq_site_partials_bn(p(xs[i]), p(ws_bns[i]), p(gam), p(bet), p(rm), p(rv), p(nbt), 0.1, 1e-5, p(ab),
-                                                   p(save), C, HW, B, F, k, 2.0, 0.0, 1, p(ress[i]) if res else None, nh, 0,
-                                                   p(xqs[i]), p(statss[i]), p(wss[i]), st)
+                return lib.alignq_site_partials_bn(p(xs[i]), p(cparts[i]) if conv_parts > 0 else p(ws_bns[i]), p(gam), p(bet), p(rm),
+                                                   p(rv), p(nbt), 0.1, 1e-5, p(ab), p(save), C, HW, B, F, k, 2.0, 0.0, 1,
+                                                   p(ress[i]) if res else None, nh, conv_parts, p(xqs[i]), p(statss[i]),
+                                                   p(wss[i]), st)
 
             def bwd_i(i, res=False):
                 return lib.alignq_site_bwd_apply_bn(p(gs[i]), p(S), p(xs[i]), p(ab), p(save), C, HW, nh, p(xqs[i]),
@@ -165,6 +178,7 @@ def measure_kernels(dev, B, k, site_F_counts, hw_of_F, folded=True, nhwc=False):
             part_i(i)
             red_i(i)
 
+        multi_sites.append((F, count, wss, D, S))
         for i in range(R):          # every set holds a finished forward (statistics, x_q, slabs) before anything is timed
             if stats_i:
                 stats_i(i)
@@ -200,6 +214,27 @@ def measure_kernels(dev, B, k, site_F_counts, hw_of_F, folded=True, nhwc=False):
                             ("bn_bwd_apply", t_bnb, 0.0)):
             per_step[name][0] += t * count
             per_step[name][1] += fl * count
+    # ---- the two deferred multi-site launches of the captured step (fused.DeferredLosses): ALL sites' slab reduction + ADMM
+    #      loss in one launch after the forward, ALL sites' S / dalterD / dgamma in one launch before the backward
+    t_red_multi = t_prep_multi = 0.0
+    if 64 < B <= 128:
+        wsl, Dl, Al, Gl, scl, Fl, Sl, dAl, dGl = [], [], [], [], [], [], [], [], []
+        for F, count, wss, _, _ in multi_sites:
+            for j in range(count):
+                wsl.append(wss[j % R]); Fl.append(F)
+                Dl.append(torch.empty(B, B, device=dev)); scl.append(torch.empty(4, device=dev))
+                Al.append(A); Gl.append(Gm)
+                Sl.append(torch.empty(lib.alignq_site_bwd_ws_bytes(B) // 4, device=dev))
+                dAl.append(torch.empty_like(A)); dGl.append(torch.empty_like(Gm))
+        nS = len(wsl)
+        one = torch.ones((), device=dev)
+        pa, i64 = L.ptr_array, L.i64_array
+        args_r = (nS, pa(wsl), pa(Dl), pa(Al), pa(Gl), pa(scl), i64(Fl), B, B, 0.2, 0.3, st)
+        args_p = (nS, pa(Dl), pa(Al), pa(Gl), pa(scl), L.ptr(one), i64(Fl), B, B, 0.2, pa(Sl), pa(dAl), pa(dGl), st)
+        t_red_multi = time_call(lambda: lib.alignq_site_reduce_loss_multi(*args_r), 30)
+        t_prep_multi = time_call(lambda: lib.alignq_site_prep_fused_multi(*args_p), 30)
+        del wsl, Dl, scl, Sl, dAl, dGl
+    del multi_sites
     # plain CDF-quantise kernels on a roofline-sized tensor (2^26 elements = 268 MB, beyond the 256 MiB L3)
     n = 1 << 26
     x = torch.randn(n, device=dev)
@@ -208,6 +243,22 @@ def measure_kernels(dev, B, k, site_F_counts, hw_of_F, folded=True, nhwc=False):
     p = L.ptr
     t_f = time_call(lambda: lib.alignq_act_quant_fwd(p(x), p(y), None, n, k, 2.0, 0, st), 20)
     t_b = time_call(lambda: lib.alignq_act_quant_bwd(p(g), p(x), p(y), n, 2.0, st), 20)
+    for kk in (2, 4):        # k in {2, 4, 8}
+        t_k = time_call(lambda: lib.alignq_act_quant_fwd(p(x), p(y), None, n, kk, 2.0, 0, st), 10)
+        out[f"act_quant_fwd_2p26_k{kk}"] = {"us": t_k * 1e6, "hbm_gbs": 8.0 * n / t_k / 1e9, "frac_of_8TBs": 8.0 * n / t_k / 1e9 / HBM_PEAK_GBS}
+    # N2: the packed-bin forms (int16 bins for the 8-bit ADMM formula): forward 4 B read + 2 B written per element instead of
+    # 4 + 4; backward 4 + 4 + 2 read and 4 written instead of 4 + 4 + 4 and 4 (ReLU mask from the bins instead of fp32 y)
+    nb = lib.alignq_bin_bytes(k, 2.0, 0)
+    if nb:
+        bins = torch.empty(n * nb, dtype=torch.uint8, device=dev)
+        t_pf = time_call(lambda: lib.alignq_act_quant_fwd_packed(p(x), None, p(bins), n, k, 2.0, 0, 0, st), 10)
+        t_pb = time_call(lambda: lib.alignq_act_quant_bwd_packed(p(g), p(x), p(bins), p(y), n, k, 2.0, 0, 1, st), 10)
+        t_mb = time_call(lambda: lib.alignq_act_quant_relu_bwd(p(g), p(x), p(x), p(y), n, 2.0, st), 10)
+        out["act_quant_packed_2p26"] = {"bin_bytes": nb, "fwd_us": t_pf * 1e6, "fwd_bytes_per_elem": 4 + nb,
+                                        "fwd_hbm_gbs": (4.0 + nb) * n / t_pf / 1e9, "bwd_masked_us": t_pb * 1e6,
+                                        "bwd_masked_bytes_per_elem": 12 + nb, "bwd_masked_hbm_gbs": (12.0 + nb) * n / t_pb / 1e9,
+                                        "bwd_masked_fp32_y_us": t_mb * 1e6, "bwd_masked_fp32_y_bytes_per_elem": 16}
+        del bins
     # on-box streaming ceilings with the same traffic shapes: a device copy (1 read + 1 write per element)
     # and an elementwise add (2 reads + 1 write), both plain PyTorch-ROCm kernels
     t_copy = time_call(lambda: y.copy_(x), 20)
@@ -219,6 +270,7 @@ def measure_kernels(dev, B, k, site_F_counts, hw_of_F, folded=True, nhwc=False):
     out["act_quant_bwd_2p26"] = {"us": t_b * 1e6, "hbm_gbs": 12.0 * n / t_b / 1e9, "frac_of_8TBs": 12.0 * n / t_b / 1e9 / HBM_PEAK_GBS,
                                  "frac_of_add_ceiling": t_add / t_b}
     del x, y, g
+    out["roofline_shapes"] = measure_roofline_shapes(dev, k)
     n_sites = sum(site_F_counts.values())
     dom = max(("site_partials", "site_bwd"), key=lambda kname: per_step[kname][0])
     t_sum, fl_sum = per_step[dom]
@@ -244,8 +296,76 @@ def measure_kernels(dev, B, k, site_F_counts, hw_of_F, folded=True, nhwc=False):
                         "launches over 4 rotating buffer sets, the step's mix of sites with and without a residual operand); "
                         "CIFAR sites are 2-8 MB per launch, i.e. launch-latency shapes (SURVEY H2); see kernels.act_quant_* "
                         "for the HBM-roofline-sized CDF-quantise kernel"}
-    out["per_step_us"] = {kname: v[0] * 1e6 for kname, v in per_step.items()}
+    # what the CAPTURED step launches (tools/count_step_kernels.sh lists the same kernels from a rocprofv3 trace of the graph):
+    # one folded site forward and one folded site backward per site, ONE slab_reduce_multi and ONE site_prep_multi per step.
+    # The per-site reduce / prep / statistics / bn_bwd_apply entry points are launched by the eager per-module API only.
+    out["per_step_us"] = {"site_partials": per_step["site_partials"][0] * 1e6, "site_bwd": per_step["site_bwd"][0] * 1e6,
+                          "slab_reduce_multi": t_red_multi * 1e6, "site_prep_multi": t_prep_multi * 1e6,
+                          "note": "kernels of the captured step (graph); forward timed in its conv_parts form"}
+    out["eager_only_per_step_us"] = {kname: per_step[kname][0] * 1e6 for kname in
+                                     ("bn_partial_stats", "site_reduce_loss", "site_bwd_prep", "bn_bwd_apply")}
+    # Gram step on the matrix cores (north_star: "MFMA utilisation for the Gram step against gfx950 peak"): the forward issues
+    # 6 v_mfma_f32_32x32x16_bf16 (3-term split, T and X Gram) per 16 features for each of the 10 upper-triangular 32x32 tiles;
+    # one such MFMA is 32768 flop and occupies a SIMD's matrix pipe for 32 cycles (2.5 PFLOP/s dense bf16 / 1024 SIMDs / 2.4 GHz)
+    n_mfma = sum(6 * 10 * (F // 16) * cnt for F, cnt in site_F_counts.items())
+    t_fwd_sum = per_step["site_partials"][0]
+    roofline["gram_mfma"] = {"bf16_mfma_per_step": n_mfma, "bf16_tflops_issued": n_mfma * 32768 / t_fwd_sum / 1e12,
+                             "frac_of_bf16_peak": n_mfma * 32768 / t_fwd_sum / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                             "mfma_pipe_busy_frac": n_mfma * 32 / (1024 * 2.4e9) / t_fwd_sum,
+                             "note": "issued bf16 MFMA flop of the site forward launches / their summed time; the Gram is 5-6 % of "
+                                     "these latency- and VALU-bound launches"}
     return roofline, out
+
+
+def measure_roofline_shapes(dev, k):
+    """SURVEY.md §8d microbench shapes beyond the CIFAR sites: the roofline-sized [128, 524288] site (2^26 elements), the
+    config-5 (Office, batch 28) sites [28, 802816] and [28, 100352] with the eps corr, and the weight quantiser on a
+    ResNet-50-sized filter [512, 512, 3, 3].  HIP events on the launch stream; GB/s from the ALGORITHMIC bytes
+    (8 B/element forward, 12 B/element backward; weights 28 B/element forward incl. cdf/pdf, 12 B backward)."""
+    from alignq_amd import _lib as L
+    lib = L.load()
+    st = L.stream_ptr()
+    p = L.ptr
+    out = {}
+    for B, F, eps in ((128, 524288, 0.0), (28, 802816, 1e-5), (28, 100352, 1e-5)):
+        x = torch.randn(B, F, device=dev)
+        g = torch.randn(B, F, device=dev) * 0.01
+        xq, dx = torch.empty_like(x), torch.empty_like(x)
+        stats = torch.empty(4, F, device=dev)
+        ws = torch.empty(lib.alignq_site_ws_bytes(B, F), dtype=torch.uint8, device=dev)
+        D, A, Gm = torch.empty(B, B, device=dev), torch.rand(B, B, device=dev), torch.rand(B, B, device=dev)
+        scal, one = torch.empty(4, device=dev), torch.ones((), device=dev)
+        S = torch.empty(lib.alignq_site_bwd_ws_bytes(B) // 4, device=dev)
+        dA, dG = torch.empty_like(A), torch.empty_like(Gm)
+        f_fwd = lambda: lib.alignq_site_partials(p(x), B, F, k, 2.0, eps, p(xq), p(stats), p(ws), st)
+        f_fwd()
+        lib.alignq_site_reduce_loss(p(ws), B, F, p(D), p(A), p(Gm), B, 0.2, 0.3, p(scal), st)
+        lib.alignq_site_prep_fused(p(D), p(A), p(Gm), B, p(scal), 0.2, p(one), B, F, p(S), p(dA), p(dG), st)
+        f_bwd = lambda: lib.alignq_site_bwd_apply(p(g), p(S), p(x), p(stats), B, F, 2.0, eps, p(dx), st)
+        t_f, t_b = time_call(f_fwd, 10), time_call(f_bwd, 10)
+        n = B * F
+        out[f"site_{B}x{F}"] = {"fwd_us": t_f * 1e6, "fwd_hbm_gbs": 8.0 * n / t_f / 1e9, "fwd_frac_of_8TBs": 8.0 * n / t_f / 1e9 / HBM_PEAK_GBS,
+                                "bwd_us": t_b * 1e6, "bwd_hbm_gbs": 12.0 * n / t_b / 1e9, "bwd_frac_of_8TBs": 12.0 * n / t_b / 1e9 / HBM_PEAK_GBS,
+                                "mbytes": 4.0 * n / 1e6, "eps": eps}
+        del x, g, xq, dx, stats, ws
+    # weights: one ResNet-50 layer4 3x3 filter
+    nw = 512 * 512 * 9
+    w = torch.randn(nw, device=dev) * 0.05
+    gq = torch.randn(nw, device=dev)
+    q, c, pdf, dw = (torch.empty_like(w) for _ in range(4))
+    ms = torch.empty(2, device=dev)
+    wsw = torch.empty(lib.alignq_weight_ws_bytes(nw), dtype=torch.uint8, device=dev)
+
+    def w_fwd():
+        lib.alignq_weight_stats(p(w), nw, p(ms), p(wsw), st)
+        lib.alignq_weight_quant_fwd(p(w), p(ms), p(q), p(c), p(pdf), None, nw, k, 0, st)
+    t_wf = time_call(w_fwd, 20)
+    t_wb = time_call(lambda: lib.alignq_weight_quant_bwd(p(gq), p(w), p(ms), p(dw), nw, p(wsw), st), 20)
+    out["weight_512x512x3x3"] = {"fwd_us": t_wf * 1e6, "fwd_hbm_gbs": 20.0 * nw / t_wf / 1e9, "fwd_note": "stats (2 launches) + "
+                                 "quantise: reads w twice (stats, apply), writes q, cdf, pdf = 20 B/element",
+                                 "bwd_us": t_wb * 1e6, "bwd_hbm_gbs": 20.0 * nw / t_wb / 1e9, "bwd_note": "two passes: reads g, w "
+                                 "twice, writes dw = 20 B/element", "mbytes": 4.0 * nw / 1e6}
+    return out
 
 
 def cpu_baseline(batch, bits, model, steps):
@@ -281,10 +401,46 @@ def cpu_baseline(batch, bits, model, steps):
         if best is None or med < best[1]:
             best = (cores, med)
     cores, med = best
-    return {"value": batch / med, "unit": "images/sec", "cores": cores, "kind": "port",
+    return {"value": batch / med, "unit": "images/sec", "cores": cores, "host_cores": os.cpu_count(), "usable_cores": avail,
+            "kind": "port",
             "sample": f"{steps} full training steps (median) of the same workload after 2 warm-ups, batch {batch}, "
                       f"oracle/torch_ref.py on torch-CPU {torch.__version__}; thread counts tried -> images/sec: {tried}",
             "s_per_step": med}
+
+
+def dp_probe(dev, a, steps=50):
+    """ms per step of the DATA-PARALLEL form of the same step at world size 1 (its own model, after the main measurement)."""
+    import torch.distributed as dist
+    from alignq_amd import dp
+    from alignq_amd.resnet import resnet20_quant, resnet56_quant
+    from alignq_amd.train_step import TrainStep
+    try:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29534")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        torch.manual_seed(0)
+        model = (resnet20_quant if a.model == "resnet20" else resnet56_quant)(a.bits, a.bits).to(dev).train()
+        step = TrainStep(model, fuse_bn=not a.no_fuse_bn, channels_last=not a.nchw, qconv=not a.no_qconv)
+        hook = dp.attach(step, force=True)
+        x = torch.randn(a.batch, 3, 32, 32, device=dev)
+        y = torch.randint(0, 10, (a.batch,), device=dev)
+        step.capture(x, y, warmup=3)
+        for _ in range(5):
+            step(x, y)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(x, y)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        out = {"ms_per_step": ms, "bucket_bytes": int(hook.bucket.flat.numel()) * 4, "world_size": 1, "backend": "nccl (RCCL)",
+               "note": "two HIP graphs (fwd+bwd+pack | unpack+optimizers) with one eager RCCL AVG all-reduce of the flat bucket"}
+    except Exception as e:           # never fail the headline line on the probe
+        out = {"error": repr(e)[:200]}
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    return out
 
 
 def main():
@@ -409,6 +565,10 @@ def main():
         if world == 1 and not a.no_cpu_baseline and not office:
             res["cpu_baseline"] = cpu_baseline(a.batch, a.bits, a.model, a.cpu_steps)
             res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
+        if world == 1 and not office and not a.dp_selftest and not a.no_dp_probe:
+            # the data-parallel path at world size 1 (RCCL all-reduce of the flat gradient + D bucket between two HIP graphs):
+            # what one rank of the N > 1 runs executes per step, minus the wire time (no 8-GPU node in this session)
+            res["dp_selftest"] = dp_probe(dev, a)
         print(json.dumps(res))
     if dist.is_initialized():
         dist.barrier()
