@@ -41,6 +41,10 @@ def parse():
     ap.add_argument("--bits", type=int, default=8)
     ap.add_argument("--model", default="resnet20", choices=["resnet20", "resnet56", "resnet50_dann"],
                     help="resnet50_dann = BASELINE config 5 (Office-31 shapes 3x224x224, use --batch 28)")
+    ap.add_argument("--lr", type=float, default=None,
+                    help="learning rate (default: the reference's 0.04 for the CIFAR nets; 0.004 for resnet50_dann, whose "
+                         "reference default 0.04 assumes ImageNet-pretrained weights (dann_office/model/resnet.py:274-288, no "
+                         "network here): from RANDOM init 0.04 diverges within ~20 steps, in the eager-torch restatement too)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true", help="skip the per-kernel roofline measurements")
@@ -479,7 +483,7 @@ def main():
         from alignq_amd.resnet_office import resnet50_dann
         from alignq_amd.train_step import OfficeTrainStep
         model = resnet50_dann(a.bits, a.bits).to(dev).train()
-        ostep = OfficeTrainStep(model, channels_last=not a.nchw)
+        ostep = OfficeTrainStep(model, lr=a.lr if a.lr is not None else 0.004, channels_last=not a.nchw)
         xs = torch.randn(a.batch, 3, 224, 224, generator=gen).to(dev)
         xt = torch.randn(a.batch, 3, 224, 224, generator=gen).to(dev)
         ys = torch.randint(0, 31, (a.batch,), generator=gen).to(dev)
@@ -495,7 +499,8 @@ def main():
         images_per_step = 2 * a.batch            # source + target images both pass through the network
     else:
         model = (resnet20_quant if a.model == "resnet20" else resnet56_quant)(a.bits, a.bits).to(dev).train()
-        step = TrainStep(model, fuse_bn=not a.no_fuse_bn, channels_last=not a.nchw, qconv=not a.no_qconv)
+        step = TrainStep(model, lr=a.lr if a.lr is not None else 0.04, fuse_bn=not a.no_fuse_bn, channels_last=not a.nchw,
+                         qconv=not a.no_qconv)
         if world > 1 or a.dp_selftest:
             dp.attach(step, force=a.dp_selftest)
         x = torch.randn(a.batch, 3, 32, 32, generator=gen).to(dev)
@@ -538,6 +543,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"{a.model} Office-31 shape 3x224x224 DANN, {a.bits}W/{a.bits}A CDF+ADMM full train step "
                                     f"(cdf_alignment_admm/dann_office: source+target pass), batch {a.batch}+{a.batch}/GPU, "
+                                    f"random init at lr {a.lr if a.lr is not None else 0.004}, "
                                     if office else
                                     f"{a.model} CIFAR-shape 3x32x32, {a.bits}W/{a.bits}A CDF+ADMM full train step "
                                     f"(cdf_alignment_admm/resnet-20-cifar-10), batch {a.batch}/GPU, ")
