@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true", help="skip the per-kernel roofline measurements")
+    ap.add_argument("--no-shapes", action="store_true", help="skip the roofline-sized microbench shapes (kernels.roofline_shapes); "
+                    "the rocprofv3 passes of tools/make_profiles.sh use it so that their per-kernel averages hold the CIFAR shapes only")
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--no-fuse-bn", action="store_true", help="keep torch/MIOpen batch-norm instead of folding it into the ADMM-site kernels")
     ap.add_argument("--dp-selftest", action="store_true", help="run the DP path (RCCL all-reduce, two graphs) even at N=1")
@@ -77,7 +79,7 @@ def time_call(fn, reps, warm=3):
     return e0.elapsed_time(e1) * 1e-3 / reps
 
 
-def measure_kernels(dev, B, k, site_F_counts, hw_of_F, folded=True, nhwc=False):
+def measure_kernels(dev, B, k, site_F_counts, hw_of_F, folded=True, nhwc=False, shapes=True):
     """Per-kernel live timings through the C ABI, HIP events on the launch stream, over R rotating buffer sets.
     site_F_counts: {F: number of ADMM sites with F features}; hw_of_F: {F: H*W} (the channel size for the BN fold).
     folded=True times the entry points the training step actually uses (batch-norm + ReLU folded into the site kernels);
@@ -274,7 +276,8 @@ def measure_kernels(dev, B, k, site_F_counts, hw_of_F, folded=True, nhwc=False):
     out["act_quant_bwd_2p26"] = {"us": t_b * 1e6, "hbm_gbs": 12.0 * n / t_b / 1e9, "frac_of_8TBs": 12.0 * n / t_b / 1e9 / HBM_PEAK_GBS,
                                  "frac_of_add_ceiling": t_add / t_b}
     del x, y, g
-    out["roofline_shapes"] = measure_roofline_shapes(dev, k)
+    if shapes:
+        out["roofline_shapes"] = measure_roofline_shapes(dev, k)
     n_sites = sum(site_F_counts.values())
     dom = max(("site_partials", "site_bwd"), key=lambda kname: per_step[kname][0])
     t_sum, fl_sum = per_step[dom]
@@ -412,6 +415,23 @@ def cpu_baseline(batch, bits, model, steps):
             "s_per_step": med}
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on STDOUT when its first communicator is created; the driver parses stdout for the one
+    JSON line, so file descriptor 1 points at stderr while process groups are set up."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def dp_probe(dev, a, steps=50):
     """ms per step of the DATA-PARALLEL form of the same step at world size 1 (its own model, after the main measurement)."""
     import torch.distributed as dist
@@ -421,7 +441,9 @@ def dp_probe(dev, a, steps=50):
     try:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29534")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        with _StdoutToStderr():
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            dist.barrier()                   # creates the communicator (and prints RCCL's banner) here
         torch.manual_seed(0)
         model = (resnet20_quant if a.model == "resnet20" else resnet56_quant)(a.bits, a.bits).to(dev).train()
         step = TrainStep(model, fuse_bn=not a.no_fuse_bn, channels_last=not a.nchw, qconv=not a.no_qconv)
@@ -462,7 +484,9 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        with _StdoutToStderr():
+            dist.init_process_group("nccl", device_id=dev)
+            dist.barrier()                   # creates the communicator (and prints RCCL's banner) here, not on stdout
     from alignq_amd import _lib, config, dp
     from alignq_amd.resnet import resnet20_quant, resnet56_quant
     from alignq_amd.train_step import TrainStep
@@ -565,7 +589,7 @@ def main():
             counts[8192] = 2 * units[1] + 1
             counts[4096] = 2 * units[2] + 1
             roof, kernels = measure_kernels(dev, a.batch, a.bits, counts, {16384: 1024, 8192: 256, 4096: 64},
-                                            folded=not a.no_fuse_bn, nhwc=not a.nchw)
+                                            folded=not a.no_fuse_bn, nhwc=not a.nchw, shapes=not a.no_shapes)
             res["roofline"] = roof
             res["kernels"] = kernels
         if world == 1 and not a.no_cpu_baseline and not office:
