@@ -212,6 +212,16 @@ def _as_bf(x):
     return B, x.numel() // B
 
 
+def _check_batch(B, what):
+    """The correlation kernels hold the whole batch of a feature tile on chip: 2 <= B <= 128 (include/alignq.h,
+    ALIGNQ_MAX_BATCH).  The reference accepts any batch; every BASELINE configuration's per-GPU batch is 128 or 28.  Raised here
+    with a clear message instead of surfacing as ALIGNQ_EUNSUPPORTED from the C ABI."""
+    if not (2 <= B <= L.MAX_BATCH):
+        raise RuntimeError(f"alignq_amd: {what} needs a batch of 2..{L.MAX_BATCH} rows (got {B}): the fused Gram kernels keep all "
+                           "rows of a feature tile on chip; split the batch (data parallel: alignq_amd.dp) or use "
+                           "config.args.method != 'ours' for the plain quantiser")
+
+
 class CorrFn(torch.autograd.Function):
     """corr(x, x) — ADMM tree model/quantization.py:134-137; Office tree :158-161 (eps=1e-5)."""
 
@@ -219,6 +229,7 @@ class CorrFn(torch.autograd.Function):
     def forward(ctx, x, eps):
         x = L.dev_f32(x, "corr input")
         B, F = _as_bf(x)
+        _check_batch(B, "corr")
         lib = L.load()
         G = torch.empty(B, B, dtype=torch.float32, device=x.device)
         stats = torch.empty(2, F, dtype=torch.float32, device=x.device)
@@ -250,6 +261,7 @@ class CorrXYFn(torch.autograd.Function):
     def forward(ctx, x, y, eps):
         x, y = L.dev_f32(x, "corr x"), L.dev_f32(y, "corr y")
         B, F = _as_bf(x)
+        _check_batch(B, "corr")
         if _as_bf(y) != (B, F):
             raise RuntimeError(f"corr(x, y): shapes {tuple(x.shape)} and {tuple(y.shape)} do not give the same [B, F]")
         lib = L.load()
@@ -321,6 +333,7 @@ class SiteFn(torch.autograd.Function):
         A = L.dev_f32(alterD, "alterD")
         Gm = L.dev_f32(gamma, "gamma")
         B, F = _as_bf(x)
+        _check_batch(B, "an ADMM activation site")
         dim = A.shape[0]
         if B > dim:
             raise RuntimeError(f"batch {B} larger than ADMM dim {dim}")

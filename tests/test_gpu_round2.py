@@ -497,3 +497,15 @@ def test_resnet50_dann_loss_trajectory_tracks_the_reference_restatement(dev):
     finally:
         config.args.bitW = config.args.abitW = 8
         config.args.train_batch_size, config.args.eval_batch_size = 128, 100
+
+
+def test_batch_contract_is_a_clear_python_error(dev):
+    """2 <= B <= 128 is a contract of the fused correlation kernels; the Python API says so instead of passing
+    ALIGNQ_EUNSUPPORTED through."""
+    from alignq_amd import ops
+    for B in (1, 129):
+        with pytest.raises(RuntimeError, match="batch of 2..128"):
+            ops.CorrFn.apply(torch.randn(B, 64, device=dev), 0.0)
+        with pytest.raises(RuntimeError, match="batch of 2..128"):
+            ops.SiteFn.apply(torch.randn(B, 64, device=dev), torch.rand(129, 129, device=dev), torch.rand(129, 129, device=dev),
+                             8, 2.0, 0.0, 0.2, 0.3)
