@@ -58,7 +58,7 @@ SIGNATURES = {
     "alignq_site_reduce_loss_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp]),
     "alignq_site_prep_fused_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "alignq_conv3x3_bn_parts": (_i, [_i, _i, _i, _i]),
-    "alignq_conv3x3_nhwc": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "alignq_conv3x3_nhwc": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "alignq_conv_gen_bn_parts": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "alignq_conv_gen_nhwc_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "alignq_conv_gen_nhwc_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -68,8 +68,9 @@ SIGNATURES = {
     "alignq_conv_gen_wgrad_ws_bytes": (_sz, [_i, _i, _i]),
     "alignq_conv_gen_nhwc_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "alignq_conv3x3_wgrad_ws_bytes": (_sz, [_i]),
-    "alignq_conv3x3_nhwc_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "alignq_conv3x3_nhwc_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "alignq_conv3x3_nhwc_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp]),
+    "alignq_conv3x3_nhwc_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                     _i, _i, _vp]),
     "alignq_bn_bwd_totals": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "alignq_conv3x3_wgrad_reduce_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
     "alignq_head_ce_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -79,12 +80,13 @@ SIGNATURES = {
     "alignq_bn_stats": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp]),
     "alignq_bn_partial_stats": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "alignq_site_partials_bn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _i, _i, _i, _i64, _i, _f, _f, _i,
-                                     _vp, _i, _i, _vp, _vp, _vp, _vp]),
+                                     _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "alignq_site_bn_part_bytes": (_sz, [_i64, _i]),
     "alignq_bn_nhwc_ws_bytes": (_sz, [_i]),
     "alignq_bn_partial_stats_nhwc": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "alignq_site_prep_fused": (_i, [_vp, _vp, _vp, _i, _vp, _f, _vp, _i, _i64, _vp, _vp, _vp, _vp]),
-    "alignq_site_bwd_apply_bn": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i64, _f, _f, _vp, _vp, _vp]),
+    "alignq_site_bwd_apply_bn": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i64, _f, _f, _vp, _vp,
+                                      _vp]),
     "alignq_bn_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "alignq_weight_multi_ws_bytes": (_sz, [_i]),
     "alignq_weight_quant_fwd_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),

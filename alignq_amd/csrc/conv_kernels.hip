@@ -40,6 +40,20 @@ __device__ __forceinline__ bf16x8 join8(s16x4 a, s16x4 b) {
 }
 
 
+// N2: the activation operand given as its integer level index instead of fp32 x_q.  xb = bytes per index (0: the
+// tensor is fp32).  Returns 4 consecutive channels at ELEMENT offset `off` as floats: the raw index for xb != 0 (the kernels
+// then divide the accumulated sum by the level count once: the products index x filter bin are exact integers).
+template <int xb>
+__device__ __forceinline__ f32x4 fetch_act4(const float* __restrict__ x, int64_t off) {
+  if constexpr (xb == 0) return *reinterpret_cast<const f32x4*>(x + off);
+  if constexpr (xb == 2) {
+    const s16x4 b = *reinterpret_cast<const s16x4*>(reinterpret_cast<const short*>(x) + off);
+    return (f32x4){(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+  }
+  const char4 b = *reinterpret_cast<const char4*>(reinterpret_cast<const signed char*>(x) + off);
+  return (f32x4){(float)b.x, (float)b.y, (float)b.z, (float)b.w};
+}
+
 // C channels, WD image width, PT pixels per workgroup (TR = PT / WD whole image rows, TR divides H so a tile never straddles
 // two images).  LDS pixel stride is C + 8 bf16: the 16 lanes of a ds_read_b128 phase then hit 16 distinct 16-byte slots.
 // The gradient w.r.t. a folded batch-norm's input, formed ON LOAD from the site backward's output g (gradient w.r.t. the BN
@@ -119,12 +133,16 @@ struct ConvLds {
   static constexpr int kBf16 = 3 * ((PT / WD) + 2) * (WD + 2) * (C + 8);      // three bf16 images of the tile with halo
 };
 
-template <int C, int WD, int PT, bool DGRAD>
+template <int C, int WD, int PT, bool DGRAD, int XB = 0>
 __device__ __forceinline__ void conv3x3_body(const float* __restrict__ x, const float* __restrict__ w,
                                              float* __restrict__ y, int H, int total_rows, float nlev, __bf16* lds,
                                              int block, const float* __restrict__ add,
                                              float* __restrict__ bn_part = nullptr, int n_wg = 0,
-                                             BnLazy lazy = BnLazy{nullptr, nullptr, nullptr, nullptr}) {
+                                             BnLazy lazy = BnLazy{nullptr, nullptr, nullptr, nullptr}, float xlev = 1.0f) {
+  // XB != 0 (forward only; a template parameter so that the fp32 form carries no trace of it): x holds int16 / int8 level
+  // indices idx (value idx / xlev): two exact bf16 terms instead of three, the result is divided by nlev * xlev
+  static_assert(XB == 0 || !DGRAD, "the data gradient reads fp32 dy");
+  constexpr int xb = XB;
   constexpr int TR = PT / WD;                 // image rows per workgroup
   constexpr int NS = (9 * C + 31) / 32;       // k steps of 32
   constexpr int NCG = C / 16;                 // 16-channel output groups
@@ -155,8 +173,8 @@ __device__ __forceinline__ void conv3x3_body(const float* __restrict__ x, const 
       const int grow = row0 + lr - 1;
       const bool ok = i < N4 && col >= 1 && col <= WD && grow >= img_lo && grow < img_hi && grow < total_rows;
       const int64_t off = ok ? ((int64_t)grow * WD + (col - 1)) * C + 4 * c4 : 0;
-      v[it] = *reinterpret_cast<const float4*>(x + off);
-      if (!ok) v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const f32x4 ld = fetch_act4<XB>(x, off);
+      v[it] = ok ? make_float4(ld[0], ld[1], ld[2], ld[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (DGRAD && lazy.z) {       // x is g: turn it into the batch-norm input gradient here (zeros stay zeros: padding)
       float4 zz[NIT];
@@ -260,15 +278,17 @@ __device__ __forceinline__ void conv3x3_body(const float* __restrict__ x, const 
 #pragma unroll
         for (int j = 0; j < 8; j++) { bh[j] = (__bf16)0.f; bm[j] = (__bf16)0.f; bl[j] = (__bf16)0.f; }
       }
-      // smallest terms first: the fp32 accumulator then loses the least
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[s], bl, acc, 0, 0, 0);
+      // smallest terms first: the fp32 accumulator then loses the least (an integer index is exact in two terms: its third
+      // term is zero and its MFMA is skipped, a wave-uniform branch)
+      if (DGRAD || xb == 0) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[s], bl, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[s], bm, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[s], bh, acc, 0, 0, 0);
     }
     const int grow = row0 + r;
     if (grow < total_rows) {
       const int64_t o = ((int64_t)grow * WD + c) * C + cog * 16 + 4 * q;
-      float4 v = make_float4(acc[0] / nlev, acc[1] / nlev, acc[2] / nlev, acc[3] / nlev);
+      const float den = (!DGRAD && xb != 0) ? nlev * xlev : nlev;        // integers <= 255 * 65535: exact in fp32 up to 2^24
+      float4 v = make_float4(acc[0] / den, acc[1] / den, acc[2] / den, acc[3] / den);
       if (add) {       // e.g. the identity shortcut's gradient joining the data gradient (saves an accumulation kernel)
         const float4 r = *reinterpret_cast<const float4*>(add + o);
         v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
@@ -313,12 +333,14 @@ __device__ __forceinline__ void conv3x3_body(const float* __restrict__ x, const 
   }
 }
 
-template <int C, int WD, int PT, bool DGRAD>
+template <int C, int WD, int PT, bool DGRAD, int XB = 0>
 __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            float* __restrict__ y, int H, int total_rows, float nlev,
-                                                           const float* __restrict__ add, float* __restrict__ bn_part) {
+                                                           const float* __restrict__ add, float* __restrict__ bn_part,
+                                                           float xlev) {
   __shared__ __attribute__((aligned(16))) __bf16 lds[ConvLds<C, WD, PT>::kBf16];
-  conv3x3_body<C, WD, PT, DGRAD>(x, w, y, H, total_rows, nlev, lds, blockIdx.x, add, bn_part, gridDim.x);
+  conv3x3_body<C, WD, PT, DGRAD, XB>(x, w, y, H, total_rows, nlev, lds, blockIdx.x, add, bn_part, gridDim.x,
+                                     BnLazy{nullptr, nullptr, nullptr, nullptr}, xlev);
 }
 
 // ---- forward of the remaining Conv2d_Q shapes of the ResNet body: stride 2 (3x3, padding 1) and the 1x1 stride-2 shortcut
@@ -837,13 +859,15 @@ int launch_gen(const float* x, const float* w, float* y, int B, int H, float nle
 
 template <int C, int WD, int PT>
 int launch(const float* x, const float* w, float* y, int B, int H, int dgrad, float nlev, const float* add, float* bn_part,
-           hipStream_t st) {
+           hipStream_t st, int xb = 0, float xlev = 1.0f) {
   constexpr int TR = PT / WD;
   const int total_rows = B * H;
   if (H % TR) return ALIGNQ_EUNSUPPORTED;
   const int grid = total_rows / TR;
-  if (dgrad) hipLaunchKernelGGL((conv3x3_nhwc_kernel<C, WD, PT, true>), grid, 256, 0, st, x, w, y, H, total_rows, nlev, add, nullptr);
-  else hipLaunchKernelGGL((conv3x3_nhwc_kernel<C, WD, PT, false>), grid, 256, 0, st, x, w, y, H, total_rows, nlev, add, bn_part);
+  if (dgrad) hipLaunchKernelGGL((conv3x3_nhwc_kernel<C, WD, PT, true, 0>), grid, 256, 0, st, x, w, y, H, total_rows, nlev, add, nullptr, 1.0f);
+  else if (xb == 2) hipLaunchKernelGGL((conv3x3_nhwc_kernel<C, WD, PT, false, 2>), grid, 256, 0, st, x, w, y, H, total_rows, nlev, add, bn_part, xlev);
+  else if (xb == 1) hipLaunchKernelGGL((conv3x3_nhwc_kernel<C, WD, PT, false, 1>), grid, 256, 0, st, x, w, y, H, total_rows, nlev, add, bn_part, xlev);
+  else hipLaunchKernelGGL((conv3x3_nhwc_kernel<C, WD, PT, false, 0>), grid, 256, 0, st, x, w, y, H, total_rows, nlev, add, bn_part, xlev);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
@@ -882,10 +906,12 @@ struct WgradLds : WgradGeo<C, C, WD, 3, 1, PT> {};
 
 // bx / gx: index and count of the pixel-range workgroups, by: (co block, ci block) index
 // H is the OUTPUT height (the input has S*H rows); x [.., S*H, WDI, CIN], dy [.., H, WDI/S, COUT].
-template <int CIN, int COUT, int WDI, int KS, int S, int PT>
+template <int CIN, int COUT, int WDI, int KS, int S, int PT, int XB = 0>
 __device__ __forceinline__ void wgrad_body(const float* __restrict__ x, const float* __restrict__ dy,
                                            float* __restrict__ slabs, int H, int n_tiles, float* lds_f, int bx, int gx,
-                                           int by, BnLazy lazy = BnLazy{nullptr, nullptr, nullptr, nullptr}) {
+                                           int by, BnLazy lazy = BnLazy{nullptr, nullptr, nullptr, nullptr}, float xlev = 1.0f) {
+  // XB != 0: x holds int16 / int8 level indices (value idx / xlev): exact in two bf16 terms; the slab is scaled by 1 / xlev
+  constexpr int xb = XB;
   using G = WgradGeo<CIN, COUT, WDI, KS, S, PT>;
   constexpr int WDO = G::WDO, TR = G::TR, NT = G::NT, CB = G::CB, LW = G::LW, XA = G::XA, DA = G::DA, XROWS = G::XROWS;
   constexpr int NBLK = CIN / CB;                 // ci blocks (by = co block * NBLK + ci block)
@@ -923,7 +949,7 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ x, const fl
       const int gcol = KS == 3 ? col - 1 : col * S;
       const bool ok = i < N4 && gcol >= 0 && gcol < WDI && grow >= img_lo_ && grow < img_hi_;
       const int64_t off = ok ? ((int64_t)grow * WDI + gcol) * CIN + bj * CB + 4 * c4 : 0;
-      rx[it] = *reinterpret_cast<const f32x4*>(x + off);
+      rx[it] = fetch_act4<XB>(x, off);
       if (!ok) rx[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
@@ -1007,7 +1033,7 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ x, const fl
         const int gcol = KS == 3 ? col - 1 : col * S;
         const bool ok = i < N4 && gcol >= 0 && gcol < WDI && grow >= img_lo_ && grow < img_hi_;
         const int64_t off = ok ? ((int64_t)grow * WDI + gcol) * CIN + bj * CB + 4 * c4 : 0;
-        rx[it] = *reinterpret_cast<const f32x4*>(x + off);
+        rx[it] = fetch_act4<XB>(x, off);
         if (!ok) rx[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
@@ -1042,7 +1068,7 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ x, const fl
         // six leading term pairs, smallest first
         f32x4 v = acc[tap];
         v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], v, 0, 0, 0);
-        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], v, 0, 0, 0);
+        if (xb == 0) v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], v, 0, 0, 0);      // (an index has no third term)
         v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], v, 0, 0, 0);
         v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], v, 0, 0, 0);
         v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], v, 0, 0, 0);
@@ -1053,6 +1079,11 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ x, const fl
   }
   // ---- results: C/D layout of the 16x16 MFMA: column (ci) = lane & 15, rows (co) = 4 (lane >> 4) + e ---------------------
   float* slab = slabs + (int64_t)bx * (NT * CIN * COUT);
+  if (xb != 0) {
+    const float inv = 1.0f / xlev;
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = acc[t] * inv;
+  }
   if (CB == 16) {      // the four waves hold partial sums over alternate steps: fixed-order sum through LDS, wave 0 writes
     float* red = lds_f;
     __syncthreads();
@@ -1084,11 +1115,11 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ x, const fl
   }
 }
 
-template <int C, int WD, int PT>
+template <int C, int WD, int PT, int XB = 0>
 __device__ __forceinline__ void wgrad3x3_body(const float* __restrict__ x, const float* __restrict__ dy,
                                               float* __restrict__ slabs, int H, int n_tiles, float* lds_f, int bx, int gx,
-                                              int by, BnLazy lazy = BnLazy{nullptr, nullptr, nullptr, nullptr}) {
-  wgrad_body<C, C, WD, 3, 1, PT>(x, dy, slabs, H, n_tiles, lds_f, bx, gx, by, lazy);
+                                              int by, BnLazy lazy = BnLazy{nullptr, nullptr, nullptr, nullptr}, float xlev = 1.0f) {
+  wgrad_body<C, C, WD, 3, 1, PT, XB>(x, dy, slabs, H, n_tiles, lds_f, bx, gx, by, lazy, xlev);
 }
 
 // stand-alone filter gradient of the transition convolutions (stride 2: 3x3 and 1x1)
@@ -1099,27 +1130,28 @@ __global__ __launch_bounds__(256) void wgradgen_kernel(const float* __restrict__
   wgrad_body<CIN, COUT, WDI, KS, S, PT>(x, dy, slabs, H, n_tiles, lds, blockIdx.x, gridDim.x, blockIdx.y, lazy);
 }
 
-template <int C, int WD, int PT>
+template <int C, int WD, int PT, int XB>
 __global__ __launch_bounds__(256) void wgrad3x3_nhwc_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                            float* __restrict__ slabs, int H, int n_tiles) {
+                                                            float* __restrict__ slabs, int H, int n_tiles, float xlev) {
   __shared__ __attribute__((aligned(16))) float lds[WgradLds<C, WD, PT>::kFloats];
-  wgrad3x3_body<C, WD, PT>(x, dy, slabs, H, n_tiles, lds, blockIdx.x, gridDim.x, blockIdx.y);
+  wgrad3x3_body<C, WD, PT, XB>(x, dy, slabs, H, n_tiles, lds, blockIdx.x, gridDim.x, blockIdx.y,
+                               BnLazy{nullptr, nullptr, nullptr, nullptr}, xlev);
 }
 
 // Backward of one convolution in ONE launch: the first n_wg workgroups take the filter-gradient role (the longer one, so
 // it starts first), the rest the data-gradient role; the two are independent and fill the chip together.
-template <int C, int WD, int PTD, int PTW>
+template <int C, int WD, int PTD, int PTW, int XB>
 __global__ __launch_bounds__(256) void conv3x3_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                           const float* __restrict__ w, float* __restrict__ dx,
                                                           float* __restrict__ slabs, int H, int total_rows, float nlev,
                                                           int n_tiles_w, int splits, int nblk2,
-                                                          const float* __restrict__ add, BnLazy lazy) {
+                                                          const float* __restrict__ add, BnLazy lazy, float xlev) {
   constexpr int kBytesD = ConvLds<C, WD, PTD>::kBf16 * 2, kBytesW = WgradLds<C, WD, PTW>::kFloats * 4;
   __shared__ __attribute__((aligned(16))) unsigned char lds[kBytesD > kBytesW ? kBytesD : kBytesW];
   const int n_wg = splits * nblk2;
   if ((int)blockIdx.x < n_wg) {
-    wgrad3x3_body<C, WD, PTW>(x, dy, slabs, H, n_tiles_w, reinterpret_cast<float*>(lds), blockIdx.x % splits, splits,
-                              blockIdx.x / splits, lazy);
+    wgrad3x3_body<C, WD, PTW, XB>(x, dy, slabs, H, n_tiles_w, reinterpret_cast<float*>(lds), blockIdx.x % splits, splits,
+                                  blockIdx.x / splits, lazy, xlev);
   } else {
     conv3x3_body<C, WD, PTD, true>(dy, w, dx, H, total_rows, nlev, reinterpret_cast<__bf16*>(lds), blockIdx.x - n_wg, add,
                                    nullptr, 0, lazy);
@@ -1197,14 +1229,17 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_multi_kernel(WgChunk c, int
 }
 
 template <int C, int WD, int PT>
-int launch_wgrad(const float* x, const float* dy, float* dw, float* ws, int B, int H, int* n_slabs_out, hipStream_t st) {
+int launch_wgrad(const float* x, const float* dy, float* dw, float* ws, int B, int H, int* n_slabs_out, hipStream_t st,
+                 int xb = 0, float xlev = 1.0f) {
   constexpr int TR = PT / WD;
   if (H % TR) return ALIGNQ_EUNSUPPORTED;
   const int n_tiles = B * H / TR;
   constexpr int NB = (C >= 32 ? C / 32 : 1);
   int splits = 256 / (NB * NB);                    // pixel ranges (= slabs): ~256 workgroups in total
   if (splits > n_tiles) splits = n_tiles;
-  hipLaunchKernelGGL((wgrad3x3_nhwc_kernel<C, WD, PT>), dim3(splits, NB * NB), 256, 0, st, x, dy, ws, H, n_tiles);
+  if (xb == 2) hipLaunchKernelGGL((wgrad3x3_nhwc_kernel<C, WD, PT, 2>), dim3(splits, NB * NB), 256, 0, st, x, dy, ws, H, n_tiles, xlev);
+  else if (xb == 1) hipLaunchKernelGGL((wgrad3x3_nhwc_kernel<C, WD, PT, 1>), dim3(splits, NB * NB), 256, 0, st, x, dy, ws, H, n_tiles, xlev);
+  else hipLaunchKernelGGL((wgrad3x3_nhwc_kernel<C, WD, PT, 0>), dim3(splits, NB * NB), 256, 0, st, x, dy, ws, H, n_tiles, xlev);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   if (n_slabs_out) { *n_slabs_out = splits; return 0; }      // deferred: the caller reduces (alignq_conv3x3_wgrad_reduce_multi)
@@ -1216,7 +1251,7 @@ int launch_wgrad(const float* x, const float* dy, float* dw, float* ws, int B, i
 
 template <int C, int WD, int PTD, int PTW>
 int launch_bwd(const float* x, const float* dy, const float* w, float* dx, float* ws, int B, int H, float nlev,
-               int* n_slabs_out, const float* add, BnLazy lazy, hipStream_t st) {
+               int* n_slabs_out, const float* add, BnLazy lazy, hipStream_t st, int xb = 0, float xlev = 1.0f) {
   constexpr int TRD = PTD / WD, TRW = PTW / WD;
   if (H % TRD || H % TRW) return ALIGNQ_EUNSUPPORTED;
   const int total_rows = B * H;
@@ -1225,8 +1260,9 @@ int launch_bwd(const float* x, const float* dy, const float* w, float* dx, float
   int splits = 256 / (NB * NB);
   if (splits > n_tiles_w) splits = n_tiles_w;
   const int grid = splits * NB * NB + total_rows / TRD;
-  hipLaunchKernelGGL((conv3x3_bwd_kernel<C, WD, PTD, PTW>), grid, 256, 0, st, x, dy, w, dx, ws, H, total_rows, nlev, n_tiles_w,
-                     splits, NB * NB, add, lazy);
+#define LBW(XBV) hipLaunchKernelGGL((conv3x3_bwd_kernel<C, WD, PTD, PTW, XBV>), grid, 256, 0, st, x, dy, w, dx, ws, H, total_rows, nlev, n_tiles_w, splits, NB * NB, add, lazy, xlev)
+  if (xb == 2) LBW(2); else if (xb == 1) LBW(1); else LBW(0);
+#undef LBW
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   *n_slabs_out = splits;
@@ -1277,13 +1313,27 @@ int alignq_conv3x3_bn_parts(int B, int H, int W, int C) {
   return B * H / (pt / W);
 }
 
+static int act_bins_ok(const void* x_bins, int x_bin_bytes, int a_bit) {
+  if (!x_bins) return 1;
+  return (x_bin_bytes == 1 || x_bin_bytes == 2) && a_bit >= 1 && a_bit <= 16 && !(reinterpret_cast<uintptr_t>(x_bins) & 15);
+}
+
 int alignq_conv3x3_nhwc(const float* x, const float* wt, float* y, int B, int H, int W, int C, int w_bit, int dgrad,
-                        const float* add, float* bn_part, void* stream) {
-  if (!x || !wt || !y || B < 1 || H < 1) return ALIGNQ_EINVAL;
+                        const float* add, float* bn_part, const void* x_bins, int x_bin_bytes, int a_bit, void* stream) {
+  if ((!x && !x_bins) || !wt || !y || B < 1 || H < 1) return ALIGNQ_EINVAL;
+  if (x_bins && (dgrad || !act_bins_ok(x_bins, x_bin_bytes, a_bit))) return ALIGNQ_EINVAL;
   if (w_bit < 1 || w_bit > 8) return ALIGNQ_EUNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(wt) | reinterpret_cast<uintptr_t>(y)) & 15) return ALIGNQ_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const float nlev = (float)((1 << w_bit) - 1);
+  if (x_bins) {        // N2: the activation operand as int8 / int16 level indices of an a_bit-bit ADMM-formula quantiser
+    const float xlev = (float)((1 << a_bit) - 1);
+    const float* xb_ = reinterpret_cast<const float*>(x_bins);
+    if (C == 16 && W == 32) return launch<16, 32, 256>(xb_, wt, y, B, H, 0, nlev, add, bn_part, st, x_bin_bytes, xlev);
+    if (C == 32 && W == 16) return launch<32, 16, 128>(xb_, wt, y, B, H, 0, nlev, add, bn_part, st, x_bin_bytes, xlev);
+    if (C == 64 && W == 8) return launch<64, 8, 32>(xb_, wt, y, B, H, 0, nlev, add, bn_part, st, x_bin_bytes, xlev);
+    return ALIGNQ_EUNSUPPORTED;
+  }
   // tile sizes measured on MI355X (forward us per layer at batch 128): C=16: 256 pixels 7.8 (128: 8.7); C=32: 128 pixels 8.0
   // (256: 11.0); C=64: 32 pixels 9.3 (64: 12.3)
   if (C == 16 && W == 32) return launch<16, 32, 256>(x, wt, y, B, H, dgrad, nlev, add, bn_part, st);
@@ -1299,13 +1349,17 @@ size_t alignq_conv3x3_wgrad_ws_bytes(int C) { return (size_t)256 * 9 * (size_t)C
 // n_slabs_out != NULL: partial sums only; *n_slabs_out receives the number of slabs left in ws for
 // alignq_conv3x3_wgrad_reduce_multi.
 int alignq_conv3x3_nhwc_wgrad(const float* x, const float* dy, float* dw, void* ws, int B, int H, int W, int C,
-                              int* n_slabs_out, void* stream) {
-  if (!x || !dy || !ws || B < 1 || H < 1 || (!dw && !n_slabs_out)) return ALIGNQ_EINVAL;
+                              int* n_slabs_out, const void* x_bins, int x_bin_bytes, int a_bit, void* stream) {
+  if ((!x && !x_bins) || !dy || !ws || B < 1 || H < 1 || (!dw && !n_slabs_out)) return ALIGNQ_EINVAL;
+  if (!act_bins_ok(x_bins, x_bin_bytes, a_bit)) return ALIGNQ_EINVAL;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dw)) & 15) return ALIGNQ_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  if (C == 16 && W == 32) return launch_wgrad<16, 32, 128>(x, dy, dw, (float*)ws, B, H, n_slabs_out, st);
-  if (C == 32 && W == 16) return launch_wgrad<32, 16, 128>(x, dy, dw, (float*)ws, B, H, n_slabs_out, st);
-  if (C == 64 && W == 8) return launch_wgrad<64, 8, 64>(x, dy, dw, (float*)ws, B, H, n_slabs_out, st);
+  const int xb = x_bins ? x_bin_bytes : 0;
+  const float xlev = x_bins ? (float)((1 << a_bit) - 1) : 1.0f;
+  const float* xp = x_bins ? reinterpret_cast<const float*>(x_bins) : x;
+  if (C == 16 && W == 32) return launch_wgrad<16, 32, 128>(xp, dy, dw, (float*)ws, B, H, n_slabs_out, st, xb, xlev);
+  if (C == 32 && W == 16) return launch_wgrad<32, 16, 128>(xp, dy, dw, (float*)ws, B, H, n_slabs_out, st, xb, xlev);
+  if (C == 64 && W == 8) return launch_wgrad<64, 8, 64>(xp, dy, dw, (float*)ws, B, H, n_slabs_out, st, xb, xlev);
   return ALIGNQ_EUNSUPPORTED;
 }
 
@@ -1337,19 +1391,23 @@ int alignq_conv3x3_wgrad_reduce_multi(int T, const void* const* ws, float* const
 int alignq_conv3x3_nhwc_bwd(const float* x, const float* dy, const float* wt, float* dx, void* ws, int B, int H, int W,
                             int C, int w_bit, int* n_slabs_out, const float* add, const float* bn_z, const float* bn_ab,
                             const float* bn_save, const float* bn_ktot, const float* bn_dx_part, float* bn_dgamma,
-                            float* bn_dbeta, void* stream) {
+                            float* bn_dbeta, const void* x_bins, int x_bin_bytes, int a_bit, void* stream) {
   if (bn_z && (!bn_ab || !bn_save || (!bn_ktot && !bn_dx_part))) return ALIGNQ_EINVAL;
   BnLazy lazy{bn_z, bn_ab, bn_save, bn_ktot};
   if (int rc = lazy_parts(lazy, bn_dx_part, bn_dgamma, bn_dbeta, B, C, H * W)) return rc;   // totals formed inside the kernel
-  if (!x || !dy || !wt || !dx || !ws || !n_slabs_out || B < 1 || H < 1) return ALIGNQ_EINVAL;
+  if ((!x && !x_bins) || !dy || !wt || !dx || !ws || !n_slabs_out || B < 1 || H < 1) return ALIGNQ_EINVAL;
+  if (!act_bins_ok(x_bins, x_bin_bytes, a_bit)) return ALIGNQ_EINVAL;
+  const int xb = x_bins ? x_bin_bytes : 0;                 // N2: the filter-gradient role reads the level indices of x
+  const float xlev = x_bins ? (float)((1 << a_bit) - 1) : 1.0f;
+  if (x_bins) x = reinterpret_cast<const float*>(x_bins);
   if (w_bit < 1 || w_bit > 8) return ALIGNQ_EUNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(wt) |
        reinterpret_cast<uintptr_t>(dx)) & 15) return ALIGNQ_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const float nlev = (float)((1 << w_bit) - 1);
-  if (C == 16 && W == 32) return launch_bwd<16, 32, 256, 128>(x, dy, wt, dx, (float*)ws, B, H, nlev, n_slabs_out, add, lazy, st);
-  if (C == 32 && W == 16) return launch_bwd<32, 16, 128, 128>(x, dy, wt, dx, (float*)ws, B, H, nlev, n_slabs_out, add, lazy, st);
-  if (C == 64 && W == 8) return launch_bwd<64, 8, 32, 64>(x, dy, wt, dx, (float*)ws, B, H, nlev, n_slabs_out, add, lazy, st);
+  if (C == 16 && W == 32) return launch_bwd<16, 32, 256, 128>(x, dy, wt, dx, (float*)ws, B, H, nlev, n_slabs_out, add, lazy, st, xb, xlev);
+  if (C == 32 && W == 16) return launch_bwd<32, 16, 128, 128>(x, dy, wt, dx, (float*)ws, B, H, nlev, n_slabs_out, add, lazy, st, xb, xlev);
+  if (C == 64 && W == 8) return launch_bwd<64, 8, 32, 64>(x, dy, wt, dx, (float*)ws, B, H, nlev, n_slabs_out, add, lazy, st, xb, xlev);
   return ALIGNQ_EUNSUPPORTED;
 }
 

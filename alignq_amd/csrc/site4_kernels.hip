@@ -334,11 +334,23 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
       if (PAIR) {
         float4 q, rl = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!kEarlyRes && bn.res) rl = ld4(bn.res, off, col, F, ok, aligned);
-        float b;
-        q.x = act_quant1<0>(xv[j].x, k, nlev, r, &tv[j].x, &b);
-        q.y = act_quant1<0>(xv[j].y, k, nlev, r, &tv[j].y, &b);
-        q.z = act_quant1<0>(xv[j].z, k, nlev, r, &tv[j].z, &b);
-        q.w = act_quant1<0>(xv[j].w, k, nlev, r, &tv[j].w, &b);
+        float b0, b1, b2, b3;
+        q.x = act_quant1<0>(xv[j].x, k, nlev, r, &tv[j].x, &b0);
+        q.y = act_quant1<0>(xv[j].y, k, nlev, r, &tv[j].y, &b1);
+        q.z = act_quant1<0>(xv[j].z, k, nlev, r, &tv[j].z, &b2);
+        q.w = act_quant1<0>(xv[j].w, k, nlev, r, &tv[j].w, &b3);
+        if (bn.bins && ok && col < F) {
+          // N2: the level index of the stored value (no residual on this path; the fused ReLU clamps the index at 0), narrow:
+          // 8 or 4 bytes per quad at the element offset (the launcher requires the aligned float4 path: F % 4 == 0)
+          if (bn.relu) { b0 = fmaxf(b0, 0.f); b1 = fmaxf(b1, 0.f); b2 = fmaxf(b2, 0.f); b3 = fmaxf(b3, 0.f); }
+          if (bn.bin_bytes == 2) {
+            short4 bi; bi.x = (short)(int)b0; bi.y = (short)(int)b1; bi.z = (short)(int)b2; bi.w = (short)(int)b3;
+            *reinterpret_cast<short4*>(reinterpret_cast<char*>(bn.bins) + 2u * off) = bi;
+          } else {
+            char4 bi; bi.x = (signed char)(int)b0; bi.y = (signed char)(int)b1; bi.z = (signed char)(int)b2; bi.w = (signed char)(int)b3;
+            *reinterpret_cast<char4*>(reinterpret_cast<char*>(bn.bins) + off) = bi;
+          }
+        }
         if (bn.res) {
           const float4 rr = kEarlyRes ? rv[j] : rl;
           q.x += rr.x; q.y += rr.y; q.z += rr.z; q.w += rr.w;
@@ -911,10 +923,21 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
       }
       if (BN) {
         float4 yr[4];
-        const bool masked = bn.y != nullptr;
-        if (masked) {
+        const bool masked = bn.y != nullptr || bn.ybins != nullptr;
+        if (bn.y) {
 #pragma unroll
           for (int q = 0; q < 4; q++) yr[q] = AT4(bn.y, q);
+        } else if (bn.ybins) {             // N2: the mask from the stored level index (idx > 0), 2 or 1 B per element
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            if (bn.bin_bytes == 2) {
+              const short4 bi = *reinterpret_cast<const short4*>(reinterpret_cast<const char*>(bn.ybins) + (BO4(q) >> 1));
+              yr[q] = make_float4((float)bi.x, (float)bi.y, (float)bi.z, (float)bi.w);
+            } else {
+              const char4 bi = *reinterpret_cast<const char4*>(reinterpret_cast<const char*>(bn.ybins) + (BO4(q) >> 2));
+              yr[q] = make_float4((float)bi.x, (float)bi.y, (float)bi.z, (float)bi.w);
+            }
+          }
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -995,10 +1018,17 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
       }
       if (BN) {      // separate loops: a use inside a load loop would serialise the loads on their latency
         float yr[16];
-        const bool masked = bn.y != nullptr;
-        if (masked) {
+        const bool masked = bn.y != nullptr || bn.ybins != nullptr;
+        if (bn.y) {
 #pragma unroll
           for (int q = 0; q < 16; q++) yr[q] = AT(bn.y, q);
+        } else if (bn.ybins) {
+#pragma unroll
+          for (int q = 0; q < 16; q++) {
+            const char* bp = reinterpret_cast<const char*>(bn.ybins);
+            yr[q] = bn.bin_bytes == 2 ? (float)*reinterpret_cast<const short*>(bp + (boff[q] >> 1))
+                                      : (float)*reinterpret_cast<const signed char*>(bp + (boff[q] >> 2));
+          }
         }
 #pragma unroll
         for (int q = 0; q < 16; q++) {
@@ -1341,6 +1371,8 @@ int launch_partials4(bool pair, const Geom& g, const float* x, int B, int64_t F,
   if ((int64_t)B * F * 4 >= ((int64_t)1 << 32)) return ALIGNQ_EUNSUPPORTED;   // 32-bit byte offsets (see ld4 / st4)
   const int aligned = ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
                       (!xq || (reinterpret_cast<uintptr_t>(xq) & 15) == 0);
+  if (bn.bins && (!aligned || bn.res || (reinterpret_cast<uintptr_t>(bn.bins) & 15) || (bn.bin_bytes != 1 && bn.bin_bytes != 2)))
+    return ALIGNQ_EINVAL;             // the index is stored per aligned column quad and only for a value that IS a level
   unsigned* counter = reinterpret_cast<unsigned*>(ws + (size_t)g.grid * g.slab_floats + kPartFloats);
 #define L4(TFV, P) hipLaunchKernelGGL((site_fwd4_kernel<TFV, P>), g.grid, NT, 0, st, x, B, F, k, r, eps, xq, ws, stats, g.n_tiles, aligned, counter, bn)
   if (pair) {
@@ -1426,7 +1458,7 @@ int launch_bwd4(bool pair, const Geom& g, const float* gup, const float* S, cons
   const int aligned = 0;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   // 16-byte accesses need whole column quads and aligned rows (channels-last BN: C % 4 == 0 holds, C is a power of two >= 4)
-  const bool vec = (F % 4 == 0) && al16(gup) && al16(x) && al16(stats) && al16(dx) && al16(bn.y) && al16(bn.dres) &&
+  const bool vec = (F % 4 == 0) && al16(gup) && al16(x) && al16(stats) && al16(dx) && al16(bn.y) && al16(bn.dres) && al16(bn.ybins) &&
                    al16(bn.ab) && al16(bn.save) && (!bn.ab || bn.nhwc || bn.HW % 4 == 0) && (!bn.nhwc || bn.C % 4 == 0);
 #define LB(TFV, P, N)                                                                                                        \
   do {                                                                                                                       \

@@ -37,10 +37,14 @@ struct BnFold {
                         // two in [4,256]): forward `part` is [C][n_parts][2]; backward dx_part is [n_tiles][min(C,TF)][2]
   int n_parts;          // channels-last forward: partials per channel (kNhwcParts doubles from alignq_bn_partial_stats_nhwc,
   int part_f32;         //   or, part_f32 = 1, the convolution epilogue's per-workgroup FLOAT partials)
+  // N2: the stored activation as its integer level index, int8 (bin_bytes 1) or int16 (2); only without a residual
+  void* bins;           // forward: optional output, [B,F] indices of the stored value (clamped at 0 when the ReLU is fused)
+  const void* ybins;    // backward: the forward's indices; the ReLU mask is idx > 0 (instead of y > 0 on an fp32 y)
+  int bin_bytes;
 };
 inline BnFold no_bn() {
   return BnFold{nullptr, nullptr, 1, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0,
-                nullptr, nullptr, 0, 0, 0};
+                nullptr, nullptr, 0, 0, 0, nullptr, nullptr, 0};
 }
 
 // Features per tile of the B in (64,128] backward kernel (also the granularity of BnFold::dx_part).

@@ -566,8 +566,8 @@ static inline bool bn_shape_ok(int B, int64_t F, int C, int HW, int nhwc) {
 int alignq_site_partials_bn(const float* z, const void* bn_part, const float* bn_gamma, const float* bn_beta,
                             float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
                             float bn_eps, float* ab, float* save, int C, int HW, int B, int64_t F, int k, float act_range,
-                            float eps, int relu, const float* residual, int nhwc, int conv_parts, float* xq, float* stats,
-                            void* ws, void* stream) {
+                            float eps, int relu, const float* residual, int nhwc, int conv_parts, float* xq, void* bins_out,
+                            float* stats, void* ws, void* stream) {
   if (!z || !ab || !save || !ws) return ALIGNQ_EINVAL;
   if (bad_k(k)) return ALIGNQ_EINVAL;
   if (!bn_shape_ok(B, F, C, HW, nhwc)) return ALIGNQ_EUNSUPPORTED;
@@ -576,6 +576,11 @@ int alignq_site_partials_bn(const float* z, const void* bn_part, const float* bn
   bn.part = (const double*)bn_part; bn.gamma = bn_gamma; bn.beta = bn_beta;
   bn.running_mean = running_mean; bn.running_var = running_var; bn.nbt = (long long*)num_batches_tracked;
   bn.momentum = momentum; bn.bn_eps = bn_eps; bn.relu = relu; bn.res = residual;
+  if (bins_out) {                  // N2: the stored activation's level index in alignq_bin_bytes(k, act_range, ADMM) bytes
+    bn.bins = bins_out;
+    bn.bin_bytes = alignq_bin_bytes(k, act_range, ALIGNQ_FORMULA_ADMM);
+    if (bn.bin_bytes == 0 || residual) return ALIGNQ_EINVAL;
+  }
   if (conv_parts > 0) {          // bn_part holds the producing convolution's per-workgroup float partials
     if (!nhwc || !bn_part) return ALIGNQ_EINVAL;
     bn.n_parts = conv_parts; bn.part_f32 = 1;
@@ -588,13 +593,15 @@ size_t alignq_site_bn_part_bytes(int64_t F, int nhwc) {
 }
 
 int alignq_site_bwd_apply_bn(const float* g, const float* S, const float* z, const float* ab, const float* save, int C,
-                             int HW, int nhwc, const float* y_relu, float* dresidual, const float* stats, int B, int64_t F,
-                             float act_range, float eps, float* dx, float* dx_part, void* stream) {
+                             int HW, int nhwc, const float* y_relu, const void* y_bins, int y_bin_bytes, float* dresidual,
+                             const float* stats, int B, int64_t F, float act_range, float eps, float* dx, float* dx_part,
+                             void* stream) {
   if (!S || !z || !ab || !save || !stats || !dx || !dx_part) return ALIGNQ_EINVAL;
+  if (y_bins && (y_relu || (y_bin_bytes != 1 && y_bin_bytes != 2))) return ALIGNQ_EINVAL;
   if (!bn_shape_ok(B, F, C, HW, nhwc)) return ALIGNQ_EUNSUPPORTED;
   BnFold bn = no_bn();
   bn.ab = ab; bn.save = save; bn.HW = HW; bn.C = C; bn.nhwc = nhwc;
-  bn.dx_part = dx_part; bn.y = y_relu; bn.dres = dresidual;
+  bn.dx_part = dx_part; bn.y = y_relu; bn.dres = dresidual; bn.ybins = y_bins; bn.bin_bytes = y_bin_bytes;
   return launch_bwd4(true, geom(B, F), g, S, z, stats, B, F, act_range, eps, dx, (hipStream_t)stream, bn);
 }
 

@@ -311,7 +311,11 @@ class BNSiteFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, bn_weight, bn_bias, running_mean, running_var, nbt, momentum, bn_eps, alterD, gamma, k, act_range,
-                eps, mu, rho, relu, rec=None, res=None, conv_part=None):
+                eps, mu, rho, relu, rec=None, res=None, conv_part=None, pack=False):
+        """pack (N2; only with relu and without a residual): the output is NOT written as fp32; the kernel stores
+        the int8 / int16 level index of relu(x_q) instead (1-2 B per element) and the first return value is a data-less HANDLE
+        (`packed_handle`) carrying it as `._alignq_bins = (bins, k)` for a consumer that reads indices (ops.QConv3x3Fn:
+        forward and filter gradient); this node's own backward takes the ReLU mask from the index as well."""
         z = L.dense_f32(z, "conv output")
         nhwc = not z.is_contiguous()             # dense_f32 only lets contiguous or channels-last 4-D tensors through
         if res is not None:
@@ -338,7 +342,16 @@ class BNSiteFn(torch.autograd.Function):
         else:
             ws_bn = torch.empty(lib.alignq_bn_ws_bytes(C), dtype=torch.uint8, device=dev)
             L.check(lib.alignq_bn_partial_stats(L.ptr(z), B, C, HW, L.ptr(ws_bn), st), "alignq_bn_partial_stats")
-        y = torch.empty_like(z)
+        bins = None
+        if pack:
+            from . import ops
+            bdt = ops.bin_dtype(k, act_range, L.FORMULA_ADMM)
+            if not relu or res is not None or bdt is None or F % 4:
+                raise RuntimeError("BNSiteFn(pack=True) needs relu, no residual, k <= 16 and F % 4 == 0")
+            bins = torch.empty_strided(z.shape, z.stride(), dtype=bdt, device=dev)
+            y = None
+        else:
+            y = torch.empty_like(z)
         D = torch.empty(B, B, dtype=torch.float32, device=dev)
         stats = torch.empty(4, F, dtype=torch.float32, device=dev)
         scal = rec.scal if rec is not None else torch.empty(4, dtype=torch.float32, device=dev)
@@ -346,7 +359,7 @@ class BNSiteFn(torch.autograd.Function):
         L.check(lib.alignq_site_partials_bn(L.ptr(z), L.ptr(ws_bn), L.ptr(bn_weight), L.ptr(bn_bias), L.ptr(running_mean),
                                             L.ptr(running_var), L.ptr(nbt), float(momentum), float(bn_eps), L.ptr(ab),
                                             L.ptr(save), C, HW, B, F, int(k), float(act_range), float(eps),
-                                            int(bool(relu)), L.ptr(res), int(nhwc), int(conv_parts), L.ptr(y), L.ptr(stats), L.ptr(ws), st),
+                                            int(bool(relu)), L.ptr(res), int(nhwc), int(conv_parts), L.ptr(y), L.ptr(bins), L.ptr(stats), L.ptr(ws), st),
                 "alignq_site_partials_bn")
         if rec is not None:      # reduced with all other sites in DeferredLosses.total()
             rec.ws, rec.D, rec.A, rec.Gm, rec.B, rec.F, rec.dim = ws, D, A, Gm, B, F, dim
@@ -358,16 +371,21 @@ class BNSiteFn(torch.autograd.Function):
         ctx.from_qconv = int(conv_part[2]) if (nhwc and conv_part is not None and len(conv_part) > 3) else 0
         ctx.link = conv_part[3] if ctx.from_qconv else None
         ctx.bn_params = (bn_weight, bn_bias)
-        ctx.save_for_backward(z, ab, save, stats, D, A, Gm, scal, y if relu else None)
+        ctx.save_for_backward(z, ab, save, stats, D, A, Gm, scal, y if (relu and not pack) else None, bins)
         ctx.set_materialize_grads(False)
         ctx.cfg = (float(act_range), float(eps), float(mu), bn_weight is not None, bn_bias is not None, res is not None,
                    int(nhwc))
         ctx.mark_non_differentiable(D)
+        if pack:
+            y = packed_handle(z.shape, dev)
+            BNSiteFn._bins_mailbox = (bins, int(k))
         return y, scal[0], D
+
+    _bins_mailbox = None
 
     @staticmethod
     def backward(ctx, g_y, g_loss, _gD):
-        z, ab, save, stats, D, A, Gm, scal, y = ctx.saved_tensors
+        z, ab, save, stats, D, A, Gm, scal, y, ybins = ctx.saved_tensors
         act_range, eps, mu, has_w, has_b, has_res, nhwc = ctx.cfg
         B, C, H, W = z.shape
         HW, F = H * W, C * H * W
@@ -395,6 +413,7 @@ class BNSiteFn(torch.autograd.Function):
         if has_res and g_y is not None:
             dres = torch.empty_like(z) if y is not None else g_y
         L.check(lib.alignq_site_bwd_apply_bn(L.ptr(g_y), L.ptr(S), L.ptr(z), L.ptr(ab), L.ptr(save), C, HW, nhwc, L.ptr(y),
+                                             L.ptr(ybins), ybins.element_size() if ybins is not None else 0,
                                              L.ptr(dres) if y is not None else None, L.ptr(stats), B, F, act_range, eps,
                                              L.ptr(dx), L.ptr(part), st), "alignq_site_bwd_apply_bn")
         dgam = torch.empty(C, dtype=torch.float32, device=dev) if has_w else None
@@ -409,7 +428,7 @@ class BNSiteFn(torch.autograd.Function):
             # copy the still unwritten buffer otherwise); the buffers themselves travel with the lazy record.
             post_lazy_dz(ctx.link, dx, z, ab, save, None, part, dgam, dbet)
             return (dx, None if dgam is None else dgam.view_as(dgam), None if dbet is None else dbet.view_as(dbet), None, None,
-                    None, None, None, dA, dG, None, None, None, None, None, None, None, dres, None)
+                    None, None, None, dA, dG, None, None, None, None, None, None, None, dres, None, None)
         if ctx.from_qconv and active_wgrads() is not None:
             # z is the output of one of ops' convolutions and a whole-model backward is running: only the per-channel totals
             # are computed here; the convolution's backward forms dz = a*(g - k0 - zhat*k1) on load (no elementwise pass)
@@ -417,11 +436,48 @@ class BNSiteFn(torch.autograd.Function):
             L.check(lib.alignq_bn_bwd_totals(L.ptr(part), B, C, HW, L.ptr(ktot), L.ptr(dgam), L.ptr(dbet), st),
                     "alignq_bn_bwd_totals")
             post_lazy_dz(ctx.link, dx, z, ab, save, ktot)
-            return (dx, dgam, dbet, None, None, None, None, None, dA, dG, None, None, None, None, None, None, None, dres, None)
+            return (dx, dgam, dbet, None, None, None, None, None, dA, dG, None, None, None, None, None, None, None, dres, None,
+                    None)
         dz = torch.empty_like(z)
         L.check(lib.alignq_bn_bwd_apply(L.ptr(dx), L.ptr(z), L.ptr(ab), L.ptr(save), L.ptr(part), B, C, HW, nhwc, L.ptr(dz),
                                         L.ptr(dgam), L.ptr(dbet), st), "alignq_bn_bwd_apply")
-        return (dz, dgam, dbet, None, None, None, None, None, dA, dG, None, None, None, None, None, None, None, dres, None)
+        return (dz, dgam, dbet, None, None, None, None, None, dA, dG, None, None, None, None, None, None, None, dres, None, None)
+
+
+def packed_handle(shape, device):
+    """A data-less fp32 tensor of the given shape (one element of storage, all strides 0): what a packed site returns in
+    place of its fp32 output.  It carries the autograd edge and the shape; the VALUES live in `._alignq_bins`.  Anything that
+    is not an index-reading consumer must go through `materialize` (Conv2d_Q does)."""
+    key = (device.type, device.index)
+    base = _handle_base.get(key)
+    if base is None:                       # one persistent element per device: creating a handle launches nothing
+        base = _handle_base[key] = torch.zeros(1, dtype=torch.float32, device=device)
+    return base.expand(shape)
+
+
+_handle_base = {}
+
+
+class MaterializeFn(torch.autograd.Function):
+    """handle + bins -> the fp32 tensor (alignq_bins_dequant; the index is already ReLU-clamped); gradient passes through."""
+
+    @staticmethod
+    def forward(ctx, handle, bins, k, act_range):
+        from . import ops
+        return ops.dequant_bins(bins, k, act_range, L.FORMULA_ADMM)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None, None, None
+
+
+def materialize(t):
+    """t itself, or — for a packed handle — the fp32 tensor its level indices stand for."""
+    info = getattr(t, "_alignq_bins", None)
+    if info is None:
+        return t
+    from . import config
+    return MaterializeFn.apply(t, info[0], info[1], config.args.act_range)
 
 
 def _is_nhwc(z) -> bool:
@@ -446,9 +502,11 @@ def bn_site_fusable(bn, act, z) -> bool:
             and config.args.method == "ours" and act.opt.alterD.shape[0] >= B)
 
 
-def bn_site(bn, act, z, eps=0.0, relu=False, residual=None):
+def bn_site(bn, act, z, eps=0.0, relu=False, residual=None, pack=False):
     """out, loss = act(bn(z)) [; out = out + residual] [; out = relu(out) when relu=True] — folded into the site kernels
-    when `bn_site_fusable`, otherwise exactly that composition.  z may be contiguous (NCHW) or channels-last."""
+    when `bn_site_fusable`, otherwise exactly that composition.  z may be contiguous (NCHW) or channels-last.
+    pack=True (N2; needs relu, no residual, channels-last, a_bit <= 8): `out` is a packed handle (see BNSiteFn.forward) whose
+    values are int8 / int16 level indices; only hand it to Conv2d_Q (which reads the indices) or through `materialize`."""
     from . import config
     if not bn_site_fusable(bn, act, z) or (residual is not None and not (
             residual.shape == z.shape and residual.stride() == z.stride() and residual.dtype == torch.float32)):
@@ -459,10 +517,15 @@ def bn_site(bn, act, z, eps=0.0, relu=False, residual=None):
     admm = act.opt
     deferred = active_deferred()
     rec = deferred.new_record(z.shape[0], z.device) if deferred is not None else None
+    pack = bool(pack and relu and residual is None and _is_nhwc(z) and act.a_bit <= 8 and (z.shape[1] * z.shape[2] * z.shape[3]) % 4 == 0)
+    BNSiteFn._bins_mailbox = None
     y, loss, D = BNSiteFn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
                                 bn.momentum, bn.eps, admm.alterD, admm.gamma, act.a_bit, config.args.act_range, eps,
                                 admm.mu, admm.rho, relu, rec, residual,
-                                getattr(z, "_alignq_bn_part", None) if _is_nhwc(z) else None)
+                                getattr(z, "_alignq_bn_part", None) if _is_nhwc(z) else None, pack)
+    if pack:
+        y._alignq_bins = BNSiteFn._bins_mailbox
+        BNSiteFn._bins_mailbox = None
     admm.D = D
     if deferred is not None:
         if rec is not None:

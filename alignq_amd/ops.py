@@ -452,20 +452,28 @@ class QConv3x3Fn(torch.autograd.Function):
     instead of by a separate accumulation kernel."""
 
     @staticmethod
-    def forward(ctx, x, w, w_bit, tap=False, bn_stats=False):
+    def forward(ctx, x, w, w_bit, tap=False, bn_stats=False, xbins=None, a_bit=0):
         """bn_stats=True: the kernel's epilogue also leaves per-workgroup per-channel {sum y, sum y^2}; they are attached to
         the output as `y._alignq_bn_part = (float tensor [C, parts, 2], parts)` for fused.bn_site, which then skips its own
-        statistics pass over y."""
+        statistics pass over y.
+        xbins (N2): x is only a HANDLE (fused.packed_handle: shape and autograd edge, no data); the activation is read from its
+        int8 / int16 level indices `xbins` (a_bit-bit ADMM-formula quantiser, ReLU already applied), forward and filter gradient."""
         B, C, H, W = x.shape
         lib = L.load()
-        y = torch.empty_like(x)
+        dev = w.device
+        y = torch.empty((B, C, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
         part, n_parts = None, 0
         if bn_stats:
             n_parts = lib.alignq_conv3x3_bn_parts(B, H, W, C)
-            part = torch.empty(C, n_parts, 2, dtype=torch.float32, device=x.device) if n_parts > 0 else None
-        L.check(lib.alignq_conv3x3_nhwc(L.ptr(x), L.ptr(w), L.ptr(y), B, H, W, C, int(w_bit), 0, None, L.ptr(part),
-                                        L.stream_ptr()), "alignq_conv3x3_nhwc")
-        ctx.save_for_backward(x, w)
+            part = torch.empty(C, n_parts, 2, dtype=torch.float32, device=dev) if n_parts > 0 else None
+        xb = xbins.element_size() if xbins is not None else 0
+        L.check(lib.alignq_conv3x3_nhwc(None if xbins is not None else L.ptr(x), L.ptr(w), L.ptr(y), B, H, W, C, int(w_bit), 0,
+                                        None, L.ptr(part), L.ptr(xbins), xb, int(a_bit), L.stream_ptr()), "alignq_conv3x3_nhwc")
+        if xbins is not None:
+            ctx.save_for_backward(xbins, w)
+        else:
+            ctx.save_for_backward(x, w)
+        ctx.packed = (xbins is not None, int(a_bit), (B, C, H, W))
         ctx.w_bit = int(w_bit)
         ctx.tap = bool(tap)
         ctx.link = None
@@ -484,11 +492,11 @@ class QConv3x3Fn(torch.autograd.Function):
         return y
 
     @staticmethod
-    def apply_with_stats(x, w, w_bit, tap=False):
+    def apply_with_stats(x, w, w_bit, tap=False, xbins=None, a_bit=0):
         """apply(...) with bn_stats=True; attaches the partial statistics to the returned y (a plain python attribute)."""
         # the partials are created inside forward; fetch them through a one-slot mailbox (autograd hides ctx from callers)
         QConv3x3Fn._mailbox = None
-        out = QConv3x3Fn.apply(x, w, w_bit, tap, True)
+        out = QConv3x3Fn.apply(x, w, w_bit, tap, True, xbins, a_bit)
         y = out[0] if tap else out
         if QConv3x3Fn._mailbox is not None:
             y._alignq_bn_part = QConv3x3Fn._mailbox
@@ -500,49 +508,60 @@ class QConv3x3Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, gtap=None):
         x, w = ctx.saved_tensors
-        B, C, H, W = x.shape
+        packed, a_bit, (B, C, H, W) = ctx.packed
+        none7 = (None,) * 5
         if gy is None:                     # only the shortcut alias was used downstream
-            return gtap, None, None, None, None
+            return (gtap, None) + none7
         lazy = fused.take_lazy_dz(ctx.link, gy)      # (g, z, ab, save, ktot): gy is the gradient w.r.t. the folded BN's OUTPUT
-        gy = L.like_layout(gy, x)
-        add = None if gtap is None else L.like_layout(gtap, x)
+        dev = w.device
+        cl = torch.channels_last
+
+        def new_x():                       # an fp32 tensor of x's shape in channels-last memory (x itself may be the index tensor)
+            return torch.empty((B, C, H, W), dtype=torch.float32, device=dev, memory_format=cl)
+        if not (gy.dim() == 4 and gy.is_contiguous(memory_format=cl)):
+            gy = gy.contiguous(memory_format=cl)
+        add = None
+        if gtap is not None:
+            add = gtap if gtap.is_contiguous(memory_format=cl) else gtap.contiguous(memory_format=cl)
+        # N2: the x operand of the filter gradient from its level indices
+        xp, xbp, xbb = (None, L.ptr(x), x.element_size()) if packed else (L.ptr(x), None, 0)
         dx = dw = None
         lib = L.load()
         pending = fused.active_wgrads()
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and pending is not None:
             # whole-model step: data gradient + filter-gradient partial sums in ONE launch; the slab reduction of all
             # convolutions follows in one launch at the end of the backward (fused.DeferredWgrads.flush)
-            dx, dw = torch.empty_like(x), torch.empty_like(w)
-            ws = _ws(lib.alignq_conv3x3_wgrad_ws_bytes(C), x.device)
+            dx, dw = new_x(), torch.empty_like(w)
+            ws = _ws(lib.alignq_conv3x3_wgrad_ws_bytes(C), dev)
             ns = ctypes.c_int(0)
             bz, bab, bsave, bk, bpart, bdg, bdb = lazy[1:8] if lazy is not None else (None,) * 7
-            L.check(lib.alignq_conv3x3_nhwc_bwd(L.ptr(x), L.ptr(gy), L.ptr(w), L.ptr(dx), L.ptr(ws), B, H, W, C, ctx.w_bit,
+            L.check(lib.alignq_conv3x3_nhwc_bwd(xp, L.ptr(gy), L.ptr(w), L.ptr(dx), L.ptr(ws), B, H, W, C, ctx.w_bit,
                                                 ctypes.byref(ns), L.ptr(add), L.ptr(bz), L.ptr(bab), L.ptr(bsave), L.ptr(bk),
-                                                L.ptr(bpart) if bk is None else None, L.ptr(bdg), L.ptr(bdb),
+                                                L.ptr(bpart) if bk is None else None, L.ptr(bdg), L.ptr(bdb), xbp, xbb, a_bit,
                                                 L.stream_ptr()), "alignq_conv3x3_nhwc_bwd")
             pending.add(ws, dw, ns.value, 9 * C * C)
-            return dx, dw, None, None, None
+            return (dx, dw) + none7
         if lazy is not None:               # not the fused path after all: finish the batch-norm input gradient here
-            bz, bab, bsave, bk = _lazy_fields(lazy, True, B, C, H * W, x.device)[:4]
+            bz, bab, bsave, bk = _lazy_fields(lazy, True, B, C, H * W, dev)[:4]
             shp = (1, C, 1, 1)
             gy = bab[0].view(shp) * (gy - bk[0].view(shp) - (bz - bsave[0].view(shp)) * bsave[1].view(shp) * bk[1].view(shp))
-            gy = L.like_layout(gy, x)
+            gy = gy.contiguous(memory_format=cl)
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            L.check(lib.alignq_conv3x3_nhwc(L.ptr(gy), L.ptr(w), L.ptr(dx), B, H, W, C, ctx.w_bit, 1, L.ptr(add), None,
+            dx = new_x()
+            L.check(lib.alignq_conv3x3_nhwc(L.ptr(gy), L.ptr(w), L.ptr(dx), B, H, W, C, ctx.w_bit, 1, L.ptr(add), None, None, 0, 0,
                                             L.stream_ptr()), "alignq_conv3x3_nhwc")
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)          # channels-last [C,3,3,C] storage like w
-            ws = _ws(lib.alignq_conv3x3_wgrad_ws_bytes(C), x.device)
+            ws = _ws(lib.alignq_conv3x3_wgrad_ws_bytes(C), dev)
             if pending is not None:           # whole-model step: all filter-gradient reductions in one launch at the end
                 ns = ctypes.c_int(0)
-                L.check(lib.alignq_conv3x3_nhwc_wgrad(L.ptr(x), L.ptr(gy), None, L.ptr(ws), B, H, W, C, ctypes.byref(ns),
+                L.check(lib.alignq_conv3x3_nhwc_wgrad(xp, L.ptr(gy), None, L.ptr(ws), B, H, W, C, ctypes.byref(ns), xbp, xbb, a_bit,
                                                       L.stream_ptr()), "alignq_conv3x3_nhwc_wgrad")
                 pending.add(ws, dw, ns.value, 9 * C * C)
             else:
-                L.check(lib.alignq_conv3x3_nhwc_wgrad(L.ptr(x), L.ptr(gy), L.ptr(dw), L.ptr(ws), B, H, W, C, None,
+                L.check(lib.alignq_conv3x3_nhwc_wgrad(xp, L.ptr(gy), L.ptr(dw), L.ptr(ws), B, H, W, C, None, xbp, xbb, a_bit,
                                                       L.stream_ptr()), "alignq_conv3x3_nhwc_wgrad")
-        return dx, dw, None, None, None
+        return (dx, dw) + none7
 
 
 def _lazy_fields(lazy, need_totals_now, B, C, HW, device):

@@ -205,6 +205,19 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
                 return self._conv(input, self.quantize_fn(self.weight))
 
             def _conv(self, input, weight_q):
+                packed = getattr(input, "_alignq_bins", None)
+                if packed is not None:
+                    # N2: the input is a packed handle (fused.bn_site(pack=True)): its values are int8 / int16 level
+                    # indices; the 3x3 body convolution reads them directly, anything else gets the dequantised tensor
+                    bins, a_bit = packed
+                    B_, C_, H_, W_ = input.shape
+                    if (getattr(self, "use_qconv", False) and self.bias is None and self.groups == 1 and weight_q.is_cuda
+                            and tuple(self.stride) == (1, 1) and tuple(self.padding) == (1, 1) and tuple(self.dilation) == (1, 1)
+                            and tuple(weight_q.shape) == (C_, C_, 3, 3) and (C_, W_) in ((16, 32), (32, 16), (64, 8)) and H_ % 8 == 0
+                            and 1 <= self.quantize_fn.w_bit <= 8 and weight_q.is_contiguous(memory_format=torch.channels_last)):
+                        return ops.QConv3x3Fn.apply_with_stats(input, weight_q, self.quantize_fn.w_bit, False, bins, a_bit)
+                    from . import fused
+                    input = fused.materialize(input)
                 # opt-in (TrainStep(channels_last=True) sets use_qconv): the convolutions on the matrix cores
                 # (with the batch-norm statistics of the output as a by-product for fused.bn_site)
                 if getattr(self, "use_qconv", False):

@@ -57,11 +57,12 @@ class PreActBlock_conv_Q(nn.Module):
             return fn(x)
         return fn(x), 0
 
-    def _bnq(self, bn, fn, z, relu=False, residual=None):
+    def _bnq(self, bn, fn, z, relu=False, residual=None, pack=False):
         """act(bn(z)) [+ residual] [-> relu]; with fuse_bn the batch-norm, the shortcut add and the ReLU are folded into
-        the site kernels (alignq_amd.fused.bn_site)."""
+        the site kernels (alignq_amd.fused.bn_site).  pack: the output may come back as a packed handle (int8 / int16 level
+        indices) - only for a tensor whose SOLE consumer is a Conv2d_Q."""
         if self.tree == "admm" and self.fuse_bn:
-            return bn_site(bn, fn, z, relu=relu, residual=residual)
+            return bn_site(bn, fn, z, relu=relu, residual=residual, pack=pack)
         out, loss = self._q(fn, bn(z))
         if residual is not None:
             out += residual
@@ -75,7 +76,9 @@ class PreActBlock_conv_Q(nn.Module):
             trans_loss += loss
         else:
             z0, shortcut = self.conv0.forward_with_shortcut(x)      # shortcut = x (its gradient joins conv0's data gradient)
-        out, loss = self._bnq(self.bn0, self.act_q0, z0, relu=True)
+        # relu(act_q0(bn0(.))) feeds conv1 and nothing else: with pack_bins it travels as its level indices (N2)
+        out, loss = self._bnq(self.bn0, self.act_q0, z0, relu=True,
+                              pack=getattr(self, "pack_bins", False) and getattr(self.conv1, "use_qconv", False))
         trans_loss += loss
         out, loss = self._bnq(self.bn1, self.act_q1, self.conv1(out), relu=True, residual=shortcut)   # out += shortcut; relu
         trans_loss += loss

@@ -19,7 +19,7 @@ from .optimizer import ADMM_OPT, SGD
 
 class TrainStep:
     def __init__(self, model, lr=0.04, momentum=0.9, weight_decay=1e-4, grad_hook=None, defer_losses=True, fuse_bn=True,
-                 channels_last=False, qconv=True):
+                 channels_last=False, qconv=True, pack_bins=True):
         """channels_last: keep activations and conv weights in torch.channels_last memory (values, parameter names and
         state_dict are unchanged).  MIOpen's NHWC convolution kernels need no layout transposes around the weight-gradient
         igemm (2.22 vs 2.50 ms per ResNet-20 step on MI355X); the quantise / Gram / ADMM kernels are layout-agnostic and the
@@ -30,6 +30,13 @@ class TrainStep:
                 for m in model.modules():
                     if hasattr(m, "quantize_fn"):
                         m.use_qconv = True
+        if channels_last and qconv and fuse_bn and pack_bins:
+            # N2: relu(act_q0(bn0(.))) of every block feeds conv1 only -> it is stored as its int8 / int16 level
+            # index (no fp32 copy): the site forward writes, the convolution forward / filter gradient and the site backward's
+            # ReLU mask read 1-2 B per element instead of 4
+            for m in model.modules():
+                if hasattr(m, "conv1") and hasattr(m, "act_q0") and hasattr(m, "bn0"):
+                    m.pack_bins = True
         self.channels_last = channels_last
         self._wgrads = DeferredWgrads(fresh_grads=True) if (channels_last and qconv and torch.cuda.is_available()) else None
         self.model = model

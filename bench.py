@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--no-dp-probe", action="store_true", help="skip the short world-size-1 DP-path measurement (extra key dp_selftest)")
     ap.add_argument("--no-qconv", action="store_true", help="keep MIOpen for every convolution (default: Conv2d_Q's 3x3 "
                     "stride-1 body convolutions, forward and data gradient, run on alignq_conv3x3_nhwc)")
+    ap.add_argument("--no-pack-bins", action="store_true", help="keep relu(act_q0(.)) of every block as an fp32 tensor instead of "
+                    "its int8 / int16 level index (SURVEY 8f-N2; default: packed)")
     ap.add_argument("--nchw", action="store_true",
                     help="contiguous NCHW activations/weights instead of torch.channels_last (the default: MIOpen's NHWC "
                          "kernels need no transposes; 2.22 vs 2.50 ms per step)")
@@ -145,11 +147,11 @@ def measure_kernels(dev, B, k, site_F_counts, hw_of_F, folded=True, nhwc=False, 
             def part_i(i, res=False):
                 return lib.alignq_site_partials_bn(p(xs[i]), p(cparts[i]) if conv_parts > 0 else p(ws_bns[i]), p(gam), p(bet), p(rm),
                                                    p(rv), p(nbt), 0.1, 1e-5, p(ab), p(save), C, HW, B, F, k, 2.0, 0.0, 1,
-                                                   p(ress[i]) if res else None, nh, conv_parts, p(xqs[i]), p(statss[i]),
+                                                   p(ress[i]) if res else None, nh, conv_parts, p(xqs[i]), None, p(statss[i]),
                                                    p(wss[i]), st)
 
             def bwd_i(i, res=False):
-                return lib.alignq_site_bwd_apply_bn(p(gs[i]), p(S), p(xs[i]), p(ab), p(save), C, HW, nh, p(xqs[i]),
+                return lib.alignq_site_bwd_apply_bn(p(gs[i]), p(S), p(xs[i]), p(ab), p(save), C, HW, nh, p(xqs[i]), None, 0,
                                                     p(dress[i]) if res else None, p(statss[i]), B, F, 2.0, 0.0, p(dxs[i]),
                                                     p(parts[i]), st)
 
@@ -524,7 +526,7 @@ def main():
     else:
         model = (resnet20_quant if a.model == "resnet20" else resnet56_quant)(a.bits, a.bits).to(dev).train()
         step = TrainStep(model, lr=a.lr if a.lr is not None else 0.04, fuse_bn=not a.no_fuse_bn, channels_last=not a.nchw,
-                         qconv=not a.no_qconv)
+                         qconv=not a.no_qconv, pack_bins=not a.no_pack_bins)
         if world > 1 or a.dp_selftest:
             dp.attach(step, force=a.dp_selftest)
         x = torch.randn(a.batch, 3, 32, 32, generator=gen).to(dev)

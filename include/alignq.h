@@ -232,7 +232,11 @@ int alignq_site_prep_fused_multi(int S, const float* const* D, const float* cons
  * batch-norm that follows (alignq_site_partials_bn, conv_parts).                                                          */
 int alignq_conv3x3_bn_parts(int B, int H, int W, int C);   /* workgroups of the forward launch (0: unsupported shape) */
 int alignq_conv3x3_nhwc(const float* x, const float* wt, float* y, int B, int H, int W, int C, int w_bit, int dgrad,
-                        const float* add, float* bn_part, void* stream);
+                        const float* add, float* bn_part, const void* x_bins, int x_bin_bytes, int a_bit, void* stream);
+/* x_bins (N2, forward only, may be NULL; x may then be NULL): the activation operand as the int8 / int16 (x_bin_bytes 1 / 2)
+ * level indices of an a_bit-bit ADMM-formula activation quantiser (alignq_site_partials_bn bins_out: value = idx / (2^a_bit - 1),
+ * idx already clamped by the fused ReLU): the index is exact in TWO bf16 terms (two instead of three MFMAs per k step, 1-2 B
+ * instead of 4 B read per activation) and the integer sum is divided by (2^w_bit - 1)(2^a_bit - 1) once.                   */
 
 /* Forward of the body's transition convolutions (stride 2: 3x3 padding 1, and the 1x1 shortcut), C_in != C_out:
  * (CIN, COUT, W_in) in {(16, 32, 32), (32, 64, 16)}; x [B,H_in,W_in,CIN], wt [COUT,KS,KS,CIN], y [B,H_in/2,W_in/2,COUT], all
@@ -266,7 +270,8 @@ int alignq_conv_stem_nhwc_wgrad(const float* x, const float* dy, float* dw, void
  * (alignq_conv3x3_wgrad_ws_bytes(C)) reduced in fixed order by a second launch: deterministic, no zero-fill, no atomics.  */
 size_t alignq_conv3x3_wgrad_ws_bytes(int C);
 int alignq_conv3x3_nhwc_wgrad(const float* x, const float* dy, float* dw, void* ws, int B, int H, int W, int C,
-                              int* n_slabs_out, void* stream);
+                              int* n_slabs_out, const void* x_bins, int x_bin_bytes, int a_bit, void* stream);
+/* (x_bins / x_bin_bytes / a_bit as in alignq_conv3x3_nhwc: the x operand of the filter gradient from its level indices)       */
 /* n_slabs_out (HOST pointer) != NULL defers the reduction: only the partial sums are launched, *n_slabs_out receives the
  * slab count, and ONE alignq_conv3x3_wgrad_reduce_multi launch later finishes T filters (HOST arrays ws / dw / n_slabs / C). */
 int alignq_conv3x3_wgrad_reduce_multi(int T, const void* const* ws, float* const* dw, const int* n_slabs, const int* n_elem,
@@ -286,7 +291,7 @@ int alignq_conv_gen_nhwc_wgrad(const float* x, const float* dy, float* dw, void*
 int alignq_conv3x3_nhwc_bwd(const float* x, const float* dy, const float* wt, float* dx, void* ws, int B, int H, int W,
                             int C, int w_bit, int* n_slabs_out, const float* add, const float* bn_z, const float* bn_ab,
                             const float* bn_save, const float* bn_ktot, const float* bn_dx_part, float* bn_dgamma,
-                            float* bn_dbeta, void* stream);
+                            float* bn_dbeta, const void* x_bins, int x_bin_bytes, int a_bit, void* stream);
 /* bn_z != NULL: `dy` is not the convolution output's gradient but g, the gradient w.r.t. the OUTPUT of the training-mode
  * batch-norm that follows the convolution (what alignq_site_bwd_apply_bn writes); both roles form
  * dy = a[c] * (g - k0[c] - (z - mean[c]) * invstd[c] * k1[c]) on load from bn_z (the convolution's forward output), bn_ab,
@@ -331,15 +336,19 @@ int alignq_bn_stats(const float* z, int B, int C, int HW, const float* gamma, co
 int alignq_site_partials_bn(const float* z, const void* bn_part, const float* bn_gamma, const float* bn_beta,
                             float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
                             float bn_eps, float* ab, float* save, int C, int HW, int B, int64_t F, int k, float act_range,
-                            float eps, int relu, const float* residual, int nhwc, int conv_parts, float* xq, float* stats,
-                            void* ws, void* stream);
+                            float eps, int relu, const float* residual, int nhwc, int conv_parts, float* xq, void* bins_out,
+                            float* stats, void* ws, void* stream);
+/* bins_out (N2, optional; residual must be NULL, F % 4 == 0): the level index of the STORED value (idx, clamped at 0 when the
+ * ReLU is fused) in alignq_bin_bytes(k, act_range, ALIGNQ_FORMULA_ADMM) bytes per element, same [B,F] order as xq; xq may then
+ * be NULL: consumers that understand the index (alignq_conv3x3_nhwc x_bins, alignq_site_bwd_apply_bn y_bins) need no fp32 copy. */
 size_t alignq_site_bn_part_bytes(int64_t F, int nhwc);
 int alignq_site_prep_fused(const float* D, const float* alterD, const float* gamma, int dim, const float* scal, float mu,
                            const float* dD_scale, int B, int64_t F, float* S, float* dalterD, float* dgamma,
                            void* stream);
 int alignq_site_bwd_apply_bn(const float* g, const float* S, const float* z, const float* ab, const float* save, int C,
-                             int HW, int nhwc, const float* y_relu, float* dresidual, const float* stats, int B, int64_t F,
-                             float act_range, float eps, float* dx, float* dx_part, void* stream);
+                             int HW, int nhwc, const float* y_relu, const void* y_bins, int y_bin_bytes, float* dresidual,
+                             const float* stats, int B, int64_t F, float act_range, float eps, float* dx, float* dx_part,
+                             void* stream);     /* y_bins (N2): the ReLU mask from the forward's level index (idx > 0) instead of y_relu */
 int alignq_bn_bwd_apply(const float* dx, const float* z, const float* ab, const float* save, const float* dx_part, int B,
                         int C, int HW, int nhwc, float* dz, float* dgamma, float* dbeta, void* stream);
 /* Channels-last (torch.channels_last, memory [B,H,W,C]) form of the fold, nhwc = 1 above: channel = f mod C with C a power

@@ -63,7 +63,9 @@ class _SiteRun:
         self.B, self.C, H, W = z.shape
         self.HW, self.F = H * W, self.C * H * W
 
-    def forward(self, mode, ab_in=None, save_in=None, conv_part=None):
+    mask_from_bins = False
+
+    def forward(self, mode, ab_in=None, save_in=None, conv_part=None, want_bins=False):
         L, lib, dev = self.L, self.lib, self.dev
         B, C, HW, F = self.B, self.C, self.HW, self.F
         st = L.stream_ptr()
@@ -83,13 +85,17 @@ class _SiteRun:
         elif mode == "conv":
             part, conv_parts = conv_part
         self.y = torch.empty_like(self.z)
+        self.bins = None
+        if want_bins:
+            nb = lib.alignq_bin_bytes(self.k, self.r, 0)
+            self.bins = torch.empty_strided(self.z.shape, self.z.stride(), dtype={1: torch.int8, 2: torch.int16}[nb], device=dev)
         self.stats = torch.empty(4, F, **f32)
         self.ws = torch.empty(lib.alignq_site_ws_bytes(B, F), dtype=torch.uint8, device=dev)
         L.check(lib.alignq_site_partials_bn(L.ptr(self.z), L.ptr(part), L.ptr(self.gamma), L.ptr(self.beta), L.ptr(self.rm),
                                             L.ptr(self.rv), L.ptr(self.nbt), self.momentum, self.bn_eps, L.ptr(self.ab),
                                             L.ptr(self.save), C, HW, B, F, self.k, self.r, self.eps, int(self.relu),
-                                            L.ptr(self.res), int(self.nhwc), int(conv_parts), L.ptr(self.y), L.ptr(self.stats),
-                                            L.ptr(self.ws), st), "alignq_site_partials_bn")
+                                            L.ptr(self.res), int(self.nhwc), int(conv_parts), L.ptr(self.y), L.ptr(self.bins),
+                                            L.ptr(self.stats), L.ptr(self.ws), st), "alignq_site_partials_bn")
         return self
 
     def reduce_loss(self, A, Gm, mu=0.2, rho=0.3):
@@ -116,7 +122,9 @@ class _SiteRun:
         self.part = torch.empty(lib.alignq_site_bn_part_bytes(F, int(self.nhwc)), dtype=torch.uint8, device=dev)
         self.dres = torch.empty_like(self.z) if (self.res is not None and self.relu) else None
         L.check(lib.alignq_site_bwd_apply_bn(L.ptr(g), L.ptr(self.S), L.ptr(self.z), L.ptr(self.ab), L.ptr(self.save), C, HW,
-                                             int(self.nhwc), L.ptr(self.y) if self.relu else None, L.ptr(self.dres),
+                                             int(self.nhwc), L.ptr(self.y) if (self.relu and not self.mask_from_bins) else None,
+                                             L.ptr(self.bins) if self.mask_from_bins else None,
+                                             self.bins.element_size() if self.mask_from_bins else 0, L.ptr(self.dres),
                                              L.ptr(self.stats), B, F, self.r, self.eps, L.ptr(self.dx), L.ptr(self.part), st),
                 "alignq_site_bwd_apply_bn")
         return self
@@ -228,7 +236,7 @@ def test_conv_parts_site_and_lazy_bn_conv_backward_vs_oracle(dev, B, C, H, k):
     n_parts = lib.alignq_conv3x3_bn_parts(B, H, H, C)
     assert n_parts > 0
     part = torch.empty(C, n_parts, 2, **f32)
-    L.check(lib.alignq_conv3x3_nhwc(L.ptr(x), L.ptr(wq), L.ptr(z), B, H, H, C, k, 0, None, L.ptr(part), st), "conv fwd")
+    L.check(lib.alignq_conv3x3_nhwc(L.ptr(x), L.ptr(wq), L.ptr(z), B, H, H, C, k, 0, None, L.ptr(part), None, 0, 0, st), "conv fwd")
     torch.cuda.synchronize()
     zm = _mem(z, 1)
     F = C * H * H
@@ -268,7 +276,7 @@ def test_conv_parts_site_and_lazy_bn_conv_backward_vs_oracle(dev, B, C, H, k):
     ns = ctypes.c_int(0)
     L.check(lib.alignq_conv3x3_nhwc_bwd(L.ptr(x), L.ptr(run.dx), L.ptr(wq), L.ptr(dxc), L.ptr(ws), B, H, H, C, k,
                                         ctypes.byref(ns), None, L.ptr(z), L.ptr(run.ab), L.ptr(run.save), None,
-                                        L.ptr(run.part), L.ptr(dgam), L.ptr(dbet), st), "alignq_conv3x3_nhwc_bwd")
+                                        L.ptr(run.part), L.ptr(dgam), L.ptr(dbet), None, 0, 0, st), "alignq_conv3x3_nhwc_bwd")
     L.check(lib.alignq_conv3x3_wgrad_reduce_multi(1, L.ptr_array([ws]), L.ptr_array([dw]), (ctypes.c_int * 1)(ns.value),
                                                   (ctypes.c_int * 1)(9 * C * C), st), "wgrad_reduce_multi")
     torch.cuda.synchronize()
@@ -322,6 +330,111 @@ def test_full_size_model_deferred_multi_equals_per_site(dev, name, units, k, S):
         for n_ in a["grads"]:
             assert np.array_equal(a["grads"][n_], b["grads"][n_]), n_
             assert np.isfinite(a["grads"][n_]).all(), n_
+    finally:
+        config.args.bitW = config.args.abitW = 8
+        config.args.train_batch_size = 128
+
+
+# ------------------------------------------------------------------------------------------------ N2 in the bench path
+@pytest.mark.parametrize("B,C,H,k", [(128, 16, 32, 8), (128, 32, 16, 4), (128, 64, 8, 8), (100, 32, 16, 2)])
+def test_site_emits_level_indices_and_consumers_read_them(dev, B, C, H, k):
+    """SURVEY 8f-N2 on the kernels of the captured step: alignq_site_partials_bn(bins_out) stores the level index of
+    relu(x_q) (int16 for 8-bit: 1021 levels, int8 for <= 4-bit) — bit-exact against the oracle's bins clamped at 0, and
+    idx / n is exactly the fp32 output of the same launch; alignq_site_bwd_apply_bn masks by the index exactly as by y;
+    alignq_conv3x3_nhwc / _wgrad / _bwd reading the indices agree with the fp32-input kernels and with an fp64 convolution."""
+    from alignq_amd import _lib as L
+    lib = L.load()
+    st = L.stream_ptr()
+    rng = np.random.default_rng(B + C + k)
+    F = C * H * H
+    shape = (B, C, H, H)
+    zm = (rng.standard_normal((B, F)) * 1.5 + 0.2).astype(np.float32)
+    gm = (rng.standard_normal((B, F)) * 0.01).astype(np.float32)
+    gamma = (rng.random(C) + 0.5).astype(np.float32)
+    beta = (rng.standard_normal(C) * 0.2).astype(np.float32)
+    A0 = (rng.standard_normal((128, 128)) * 0.05).astype(np.float32)
+    G0 = (rng.standard_normal((128, 128)) * 0.05).astype(np.float32)
+    z, g = _dev_like(zm, shape, 1, dev), _dev_like(gm, shape, 1, dev)
+    tg, tb = torch.from_numpy(gamma).to(dev), torch.from_numpy(beta).to(dev)
+    A, Gm = torch.from_numpy(A0).to(dev), torch.from_numpy(G0).to(dev)
+    n = 2 ** k - 1
+    run = _SiteRun(dev, z, tg, tb, k, True, None, 1).forward("stats", want_bins=True).reduce_loss(A, Gm)
+    torch.cuda.synchronize()
+    assert run.bins.dtype == (torch.int16 if 2 * n > 127 else torch.int8)
+    ab_k = npy(run.ab)
+    x = O.bn_apply(zm, C, 1, ab_k)
+    xq_o, _, bins_o = O.act_quant_fwd(x, k, 2.0, O.FORMULA_ADMM)
+    bins = _mem(run.bins, 1).astype(np.int32)
+    assert np.array_equal(bins, np.maximum(bins_o, 0)), "stored level index != oracle bins (clamped by the ReLU)"
+    y = _mem(run.y, 1)
+    assert bits_equal(y, np.maximum(xq_o, np.float32(0)))
+    assert np.array_equal(y, (bins.astype(np.float32) / np.float32(n)))                 # dequantised value == idx / n exactly
+    # backward: mask from the index == mask from y, bit for bit
+    tf = 64 if F >= 16384 else 32
+    n_part = (F // tf) * min(C, tf) * 2                  # floats the backward writes: [tiles][channels of a tile][2]
+    run.backward(g, 1.0)
+    dx_y, part_y = npy(run.dx).copy(), npy(run.part).view(np.float32)[:n_part].copy()
+    run.mask_from_bins = True
+    run.backward(g, 1.0)
+    torch.cuda.synchronize()
+    assert np.array_equal(npy(run.dx), dx_y) and np.array_equal(npy(run.part).view(np.float32)[:n_part], part_y)
+    # convolution consumers: forward and filter gradient from the indices vs from the fp32 tensor vs fp64
+    torch.manual_seed(k)
+    wq = (torch.round(torch.tanh(torch.randn(C, C, 3, 3)) * 255) / 255).to(dev).contiguous(memory_format=torch.channels_last)
+    f32 = dict(dtype=torch.float32, device=dev)
+    ya, yb = torch.empty_like(run.y), torch.empty_like(run.y)
+    nb = run.bins.element_size()
+    L.check(lib.alignq_conv3x3_nhwc(L.ptr(run.y), L.ptr(wq), L.ptr(ya), B, H, H, C, 8, 0, None, None, None, 0, 0, st), "conv fp32")
+    L.check(lib.alignq_conv3x3_nhwc(None, L.ptr(wq), L.ptr(yb), B, H, H, C, 8, 0, None, None, L.ptr(run.bins), nb, k, st), "conv bins")
+    yd = torch.nn.functional.conv2d(run.y.double(), wq.double(), padding=1)
+    torch.cuda.synchronize()
+    ea, eb = float((ya - yd).abs().max()), float((yb - yd).abs().max())
+    assert eb <= max(ea, 2e-6 * float(yd.abs().max())) * 1.05, (ea, eb)                 # at least as accurate as the fp32 form
+    dy = torch.randn_like(run.y)
+    ws = torch.empty(lib.alignq_conv3x3_wgrad_ws_bytes(C), dtype=torch.uint8, device=dev)
+    dwa, dwb = torch.empty_like(wq), torch.empty_like(wq)
+    L.check(lib.alignq_conv3x3_nhwc_wgrad(L.ptr(run.y), L.ptr(dy), L.ptr(dwa), L.ptr(ws), B, H, H, C, None, None, 0, 0, st), "wgrad fp32")
+    L.check(lib.alignq_conv3x3_nhwc_wgrad(None, L.ptr(dy), L.ptr(dwb), L.ptr(ws), B, H, H, C, None, L.ptr(run.bins), nb, k, st), "wgrad bins")
+    dwd = torch.nn.grad.conv2d_weight(run.y.double(), wq.shape, dy.double(), padding=1)
+    torch.cuda.synchronize()
+    sw = float(dwd.abs().max())
+    np.testing.assert_allclose(npy(dwb), npy(dwd.float()), atol=2e-5 * sw, rtol=2e-4)
+    np.testing.assert_allclose(npy(dwb), npy(dwa), atol=2e-5 * sw, rtol=2e-4)
+
+
+def test_trainstep_with_packed_activations_tracks_the_fp32_form(dev):
+    """TrainStep(pack_bins=True) (the default: site0 of every block hands conv1 its level indices, no fp32 copy exists)
+    against pack_bins=False on full-size resnet20_quant(8,8) at B=128: the same forward up to convolution rounding (the
+    index form sums exact integers), so D of every site, the losses and every gradient agree closely."""
+    from alignq_amd import config
+    from alignq_amd.resnet import resnet20_quant
+    from alignq_amd.train_step import TrainStep
+    config.args.bitW = config.args.abitW = 8
+    config.args.train_batch_size = 128
+    try:
+        outs = []
+        for pack in (False, True):
+            torch.manual_seed(0)
+            net = resnet20_quant(8, 8).to(dev).train()
+            step = TrainStep(net, channels_last=True, qconv=True, pack_bins=pack)
+            assert any(getattr(m, "pack_bins", False) for m in net.modules()) == pack
+            torch.manual_seed(1)
+            x = torch.randn(128, 3, 32, 32, device=dev)
+            y = torch.randint(0, 10, (128,), device=dev)
+            logits, ce, tl = step._forward_backward(x, y, set_to_none=True)
+            torch.cuda.synchronize()
+            outs.append(dict(logits=npy(logits), ce=float(ce.detach()), tl=float(tl.detach()), D=[npy(m.D) for m in step.admms],
+                             grads={n_: npy(p.grad) for n_, p in net.named_parameters() if p.grad is not None}))
+        a, b = outs
+        np.testing.assert_allclose(b["logits"], a["logits"], atol=2e-2)        # 8-bit bins flip on 1e-6 convolution differences
+        np.testing.assert_allclose(b["tl"], a["tl"], rtol=1e-3)
+        for i, (da, db) in enumerate(zip(a["D"], b["D"])):
+            np.testing.assert_allclose(db, da, atol=2e-3, err_msg=f"site {i}")
+        for n_ in a["grads"]:
+            ga, gb = a["grads"][n_].ravel(), b["grads"][n_].ravel()
+            if ga.size >= 64 and "alterD" not in n_ and "gamma" not in n_:
+                cos = float(np.dot(ga, gb) / (np.linalg.norm(ga) * np.linalg.norm(gb) + 1e-30))
+                assert cos > 0.97, (n_, cos)          # (the stem, 20 layers of 8-bit bin flips upstream, sits lowest: 0.989)
     finally:
         config.args.bitW = config.args.abitW = 8
         config.args.train_batch_size = 128

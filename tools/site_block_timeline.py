@@ -37,9 +37,9 @@ for (C, HW) in ((16, 1024), (32, 256), (64, 64)):
     for it in range(4):
         (lib.alignq_bn_partial_stats_nhwc if NHWC else lib.alignq_bn_partial_stats)(p(z), B, C, HW, p(ws_bn), st)
         lib.alignq_site_partials_bn(p(z), p(ws_bn), p(gam), p(bet), None, None, None, 0.1, 1e-5, p(ab), p(save), C, HW, B, F,
-                                    k, 2.0, 0.0, 1, None, NHWC, 0, p(xq), p(stats), p(ws), st)
+                                    k, 2.0, 0.0, 1, None, NHWC, 0, p(xq), None, p(stats), p(ws), st)
         torch.cuda.synchronize()
-        lib.alignq_site_bwd_apply_bn(p(g), p(S), p(z), p(ab), p(save), C, HW, NHWC, p(xq), None, p(stats), B, F, 2.0, 0.0, p(dx),
+        lib.alignq_site_bwd_apply_bn(p(g), p(S), p(z), p(ab), p(save), C, HW, NHWC, p(xq), None, 0, None, p(stats), B, F, 2.0, 0.0, p(dx),
                                      p(part), st)
         torch.cuda.synchronize()
     buf = (ctypes.c_ulonglong * 64)()

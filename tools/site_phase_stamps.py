@@ -26,8 +26,8 @@ for F, C, n_parts in ((16384, 16, 512), (8192, 32, 256), (4096, 64, 256)):
         res_f, res_b = [], []
         for it in range(6):
             L.check(lib.alignq_site_partials_bn(p(z), p(part), p(gam), p(bet), None, None, None, 0.1, 1e-5, p(ab), p(save), C, HW, B, F, k,
-                                                2.0, 0.0, 1, p(res) if with_res else None, 1, n_parts, p(y), p(stats), p(ws), st), "fwd")
-            L.check(lib.alignq_site_bwd_apply_bn(p(g), p(S), p(z), p(ab), p(save), C, HW, 1, p(y), p(dres) if with_res else None,
+                                                2.0, 0.0, 1, p(res) if with_res else None, 1, n_parts, p(y), None, p(stats), p(ws), st), "fwd")
+            L.check(lib.alignq_site_bwd_apply_bn(p(g), p(S), p(z), p(ab), p(save), C, HW, 1, p(y), None, 0, p(dres) if with_res else None,
                                                  p(stats), B, F, 2.0, 0.0, p(dx), p(bpart), st), "bwd")
             torch.cuda.synchronize()
             buf = (ctypes.c_ulonglong * 64)()
