@@ -507,8 +507,46 @@ def gen_office_tiny_dann():
     _save("g10_office_tiny_dann", **out)
 
 
+def gen_tiny_resnet_sites():
+    """G8b ("capture per-site inputs/outputs via forward hooks on 3 sites"): the tiny PreActResNet([1,1,1]) of G8
+    (same seed, same first batch) with forward hooks on three activation sites — the stem's, the first block's act_q1 (whose
+    output joins the shortcut) and the last block's act_q0 — recording, in model context, the site's input (the BN output),
+    its x_q, its trans loss, its D and its ADMM state.  The GPU test teacher-forces exactly these inputs through the HIP site,
+    which makes the whole-model comparison of G8 tight where it matters (per site) instead of bin-flip scale end to end."""
+    import torch
+    q, args = _enter("admm_cifar", ["--bitW", "4", "--abitW", "4", "--train_batch_size", "8"])
+    import model.resnet as r
+    r.device = torch.device("cpu")
+    g = torch.Generator().manual_seed(1234)
+    # replay the generator consumption of gen_admm_cifar up to G8's inputs is not needed: G8's own file holds xs / init
+    g8 = np.load(os.path.join(HERE, "g8_tiny_resnet_admm.npz"))
+    torch.manual_seed(5)
+    net = r.PreActResNet(r.PreActBlock_conv_Q, [1, 1, 1], 4, 4, "second", 10)
+    net.train()
+    sd = {k[len("init/"):]: torch.from_numpy(g8[k]) for k in g8.files if k.startswith("init/")}
+    net.load_state_dict(sd)
+    sites = {"stem": net.act_q0, "b0q1": net.layers[0].act_q1, "b2q0": net.layers[2].act_q0}
+    rec = {}
+
+    def hook(name):
+        def fn(mod, inp, out):
+            rec[name] = dict(x=_np(inp[0]), xq=_np(out[0]), loss=_np(out[1]), D=_np(mod.opt.D), alterD=_np(mod.opt.alterD),
+                             gamma=_np(mod.opt.gamma))
+        return fn
+    hs = [m.register_forward_hook(hook(n)) for n, m in sites.items()]
+    logits, tl = net(torch.from_numpy(g8["xs"][0]))
+    for h in hs:
+        h.remove()
+    out = {"k": np.array(4), "act_range": np.array(float(args.act_range), dtype=np.float32), "logits": _np(logits), "trans": _np(tl)}
+    for n, d in rec.items():
+        for k_, v in d.items():
+            out[f"{n}/{k_}"] = v
+    assert np.allclose(out["logits"], g8["logits_0"], atol=1e-6), "G8b must replay G8's first forward"
+    _save("g8b_tiny_resnet_sites", **out)
+
+
 GEN = {"admm_cifar": gen_admm_cifar, "cdf_only": gen_cdf_only, "office": gen_office, "office_keys": gen_office_keys,
-       "corr_xy_admm": gen_corr_xy_admm, "corr_xy_office": gen_corr_xy_office, "office_tiny_dann": gen_office_tiny_dann}
+       "corr_xy_admm": gen_corr_xy_admm, "corr_xy_office": gen_corr_xy_office, "office_tiny_dann": gen_office_tiny_dann, "tiny_resnet_sites": gen_tiny_resnet_sites}
 
 
 def main():

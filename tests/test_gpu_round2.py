@@ -509,3 +509,25 @@ def test_batch_contract_is_a_clear_python_error(dev):
         with pytest.raises(RuntimeError, match="batch of 2..128"):
             ops.SiteFn.apply(torch.randn(B, 64, device=dev), torch.rand(129, 129, device=dev), torch.rand(129, 129, device=dev),
                              8, 2.0, 0.0, 0.2, 0.3)
+
+
+def test_teacher_forced_sites_of_the_tiny_resnet_on_the_hip_path(dev):
+    """G8b: per-site teacher forcing.  The inputs the reference's own tiny PreActResNet fed to three of its
+    activation sites (captured by forward hooks in model context) go through the HIP site (ops.SiteFn, and the small-batch
+    kernels that B = 8 selects): x_q bins exact outside the tie zone, D / trans loss within 1e-5 of the reference — the tight
+    counterpart of the whole-model G8 comparison, which can only hold at bin-flip scale."""
+    from alignq_amd import ops
+    g = load_golden("g8b_tiny_resnet_sites")
+    k, r = int(g["k"]), float(g["act_range"])
+    n = 2 ** k - 1
+    for name in ("stem", "b0q1", "b2q0"):
+        x = cu(g[f"{name}/x"], dev)
+        A, Gm = cu(g[f"{name}/alterD"], dev), cu(g[f"{name}/gamma"], dev)
+        xq, loss, D = ops.SiteFn.apply(x, A, Gm, k, r, 0.0, 0.2, 0.3)
+        _, t, _ = O.act_quant_fwd(g[f"{name}/x"], k, r, O.FORMULA_ADMM)
+        frac = t.astype(np.float64) * n
+        tie = np.abs(frac - np.floor(frac) - 0.5) < 1e-4
+        diff = np.abs(npy(xq) - g[f"{name}/xq"]) * n
+        assert np.all(diff[~tie] == 0) and np.all(diff[tie] <= 1.0 + 1e-3), name
+        np.testing.assert_allclose(npy(D), g[f"{name}/D"], atol=TOL, err_msg=name)
+        np.testing.assert_allclose(float(loss), float(g[f"{name}/loss"]), atol=TOL, err_msg=name)

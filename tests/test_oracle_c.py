@@ -266,3 +266,20 @@ def test_general_corr_xy_vs_reference(fname, eps, cases):
         np.testing.assert_allclose(dy, g[f"dy_c{ci}"], atol=TOL, rtol=1e-4)
         # corr(x, x) through the general path equals the SYRK oracle
         np.testing.assert_allclose(O.corr_xy_fwd(x, x, eps), O.corr_fwd(x, eps), atol=1e-6)
+
+
+def test_teacher_forced_sites_of_the_tiny_resnet():
+    """G8b: three activation sites of the reference's tiny PreActResNet captured IN MODEL CONTEXT by forward hooks (input =
+    the BN output, x_q, trans loss, D, ADMM state): the C oracle on exactly those inputs (teacher forcing) — bins exact outside
+    the tie zone, D and loss within 1e-5."""
+    g = load_golden("g8b_tiny_resnet_sites")
+    k, r = int(g["k"]), float(g["act_range"])
+    n = 2 ** k - 1
+    for name in ("stem", "b0q1", "b2q0"):
+        x = g[f"{name}/x"]
+        xq, D = O.site_fwd(x, k, r, 0.0)
+        _, t, _ = O.act_quant_fwd(x, k, r, O.FORMULA_ADMM)
+        check_bins(xq, g[f"{name}/xq"], t.astype(np.float64) * n, n)
+        np.testing.assert_allclose(D, g[f"{name}/D"], atol=TOL, rtol=0)
+        loss, _, _, _ = O.admm_loss(D, g[f"{name}/alterD"], g[f"{name}/gamma"], 0.2, 0.3)
+        np.testing.assert_allclose(loss, g[f"{name}/loss"], atol=TOL)
