@@ -114,7 +114,9 @@ __device__ __forceinline__ void split_bf16(float v, __bf16& hi, __bf16& lo) {
   lo = (__bf16)(v - (float)hi);
 }
 
-template <int TFv, bool PAIR>
+// SINGLE: one tile per workgroup (n_tiles <= grid, every CIFAR-size site): no tile loop, so nothing is hoisted out of it and
+// kept alive across the phases (88 instead of 128 VGPRs), which buys the early requests of the batch-norm finalisation.
+template <int TFv, bool PAIR, bool SINGLE>
 __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__ x, int B, int64_t F, int k, float r,
                                                        float eps, float* __restrict__ xq, float* __restrict__ slabs,
                                                        float* __restrict__ stats, int n_tiles, int aligned,
@@ -166,6 +168,44 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
     const int col0 = tile * TFv;
     const int col = col0 + 4 * c;
     float4 xv[RJ], tv[RJ];
+    // ---- channels-last batch-norm finalisation, part 1 (one-tile launches): everything it reads is requested BEFORE the
+    // tile loads (memory returns in order, and no element can be transformed before (a, b) exist).  Wave w owns channel
+    // chbase + w (and + 16 on the narrow tiles); lane l of every wave fetches gamma / beta (/ the running statistics in the
+    // publishing workgroups) of channel chbase + l with one coalesced load; the convolution epilogue's float partials
+    // [C][n_parts][2] come as float4 = two partials per lane and load (16 registers in flight cover 512 partials of one
+    // channel, or 256 of two).  The multi-tile variant runs at its 128-register cap and keeps the plain order.
+    constexpr bool kPairCh = TFv < 64;
+    constexpr int PU = kPairCh ? 2 : 4;
+    const bool fin = bn.ab && bn.nhwc && bn.part;
+    const bool fin4 = SINGLE && fin && bn.part_f32 && !(bn.n_parts & 1);
+    const int nch = bn.C < TFv ? bn.C : TFv;
+    const int chbase = col0 & (bn.C - 1);
+    const bool publish = col0 < bn.C;       // the tiles of the first pixel cover every channel exactly once
+    float gam_l = 1.0f, bet_l = 0.0f, rm_l = 0.0f, rv_l = 0.0f;
+    float4 pv0[SINGLE ? PU : 1], pv1[SINGLE ? PU : 1];
+    if constexpr (SINGLE) {
+      if (fin) {
+        const int chl = chbase + (lane & (nch - 1));
+        if (bn.gamma) gam_l = bn.gamma[chl];
+        if (bn.beta) bet_l = bn.beta[chl];
+        if (publish) {
+          if (bn.running_mean) rm_l = bn.running_mean[chl];
+          if (bn.running_var) rv_l = bn.running_var[chl];
+        }
+      }
+      if (fin4 && w < nch) {
+        const int nq = bn.n_parts >> 1;
+        const bool two = kPairCh && w + 16 < nch;
+        const float4* pq0 = reinterpret_cast<const float4*>(bn.part) + (int64_t)(chbase + w) * nq;
+        const float4* pq1 = reinterpret_cast<const float4*>(bn.part) + (int64_t)(chbase + (two ? w + 16 : w)) * nq;
+#pragma unroll
+        for (int u = 0; u < PU; u++) {
+          const int pi = lane + 64 * u, pc = pi < nq ? pi : nq - 1;
+          pv0[u] = pq0[pc];
+          if (kPairCh) pv1[u] = pq1[pc];
+        }
+      }
+    }
     // ---- load + transform + quantise ----------------------------------------------------------------
 #pragma unroll
     for (int j = 0; j < RJ; j++) {
@@ -182,33 +222,57 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
       if (bn.part) {
         {
         // finalise the batch statistics of this tile's channels here (saves a launch and a grid-wide hand-off): wave w
-        // reduces the kNhwcParts partials of channel chbase + w (+16, ...) with a fixed butterfly
+        // reduces the partials of channel chbase + w (+16, ...) with a fixed butterfly
         const int C = bn.C;
-        const int nch = C < TFv ? C : TFv;
-        const int chbase = col0 & (C - 1);
-        // two channels per wave and pass (w, w+16): independent load + butterfly chains interleave
-        // (the 64-feature tile runs at its 128-VGPR budget: one channel per pass there)
-        constexpr bool kPairCh = TFv < 64;
+        const double n = (double)B * (double)bn.HW;
+        // 1/n is wave-uniform: kept in a scalar register pair
+        const double inv_nv = 1.0 / n;
+        const double inv_n = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(inv_nv)),
+                                              __builtin_amdgcn_readfirstlane(__double2loint(inv_nv)));
         for (int cl0 = w; cl0 < nch; cl0 += kPairCh ? 32 : 16) {
           const int cl1 = cl0 + 16;
-          const bool two = kPairCh && cl1 < nch;
-          const int c0 = chbase + cl0, c1 = chbase + (two ? cl1 : cl0);
+          const bool two_p = kPairCh && cl1 < nch;
+          const int c0 = chbase + cl0, c1 = chbase + (two_p ? cl1 : cl0);
           double sa0 = 0, sq0 = 0, sa1 = 0, sq1 = 0;
-          if (bn.part_f32) {       // per-workgroup float partials of the convolution that produced z: [C][n_parts][2]
-            // (up to 8 x 64 = 512 partials per channel in flight at once: one memory round trip, not n_parts / 64 of them)
-            const float2* pf0 = reinterpret_cast<const float2*>(bn.part) + (int64_t)c0 * bn.n_parts;
-            const float2* pf1 = reinterpret_cast<const float2*>(bn.part) + (int64_t)c1 * bn.n_parts;
-            constexpr int PU = kPairCh ? 4 : 8;     // 16 registers of loads either way
-            for (int p0 = lane; p0 < bn.n_parts; p0 += 64 * PU) {
-              float2 v0[PU], v1[PU];
+          if (fin4) {
+            const int nq = bn.n_parts >> 1;
+            const float4* pq0 = reinterpret_cast<const float4*>(bn.part) + (int64_t)c0 * nq;
+            const float4* pq1 = reinterpret_cast<const float4*>(bn.part) + (int64_t)c1 * nq;
+            for (int p0 = lane; p0 < nq; p0 += 64 * PU) {
+              float4 v0[PU], v1[PU];
+              if (SINGLE && cl0 == w && p0 == lane) {    // first round of the first pass: requested in front of the tile loads
+#pragma unroll
+                for (int u = 0; u < PU; u++) { v0[u] = pv0[SINGLE ? u : 0]; v1[u] = pv1[SINGLE ? u : 0]; }
+              } else {
+#pragma unroll
+                for (int u = 0; u < PU; u++) {
+                  const int pi = p0 + 64 * u, pc = pi < nq ? pi : nq - 1;
+                  v0[u] = pq0[pc];
+                  if (kPairCh) v1[u] = pq1[pc];
+                }
+              }
 #pragma unroll
               for (int u = 0; u < PU; u++) {
+                if (p0 + 64 * u < nq) {
+                  sa0 += v0[u].x; sq0 += v0[u].y; sa0 += v0[u].z; sq0 += v0[u].w;
+                  if (kPairCh) { sa1 += v1[u].x; sq1 += v1[u].y; sa1 += v1[u].z; sq1 += v1[u].w; }
+                }
+              }
+            }
+          } else if (bn.part_f32) {  // odd partial count or a multi-tile launch: one partial per lane and load
+            const float2* pf0 = reinterpret_cast<const float2*>(bn.part) + (int64_t)c0 * bn.n_parts;
+            const float2* pf1 = reinterpret_cast<const float2*>(bn.part) + (int64_t)c1 * bn.n_parts;
+            constexpr int PU2 = kPairCh ? 4 : 8;     // 16 registers of loads either way
+            for (int p0 = lane; p0 < bn.n_parts; p0 += 64 * PU2) {
+              float2 v0[PU2], v1[PU2];
+#pragma unroll
+              for (int u = 0; u < PU2; u++) {
                 const int pi = p0 + 64 * u, pc = pi < bn.n_parts ? pi : bn.n_parts - 1;
                 v0[u] = pf0[pc];
                 if (kPairCh) v1[u] = pf1[pc];
               }
 #pragma unroll
-              for (int u = 0; u < PU; u++) {
+              for (int u = 0; u < PU2; u++) {
                 if (p0 + 64 * u < bn.n_parts) {
                   sa0 += v0[u].x; sq0 += v0[u].y;
                   if (kPairCh) { sa1 += v1[u].x; sq1 += v1[u].y; }
@@ -223,34 +287,58 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
               sq1 = bn.part[((int64_t)c1 * kNhwcParts + lane) * 2 + 1];
             }
           }
-              sa0 = wave_sum_d_dpp(sa0);
+          sa0 = wave_sum_d_dpp(sa0);
           sq0 = wave_sum_d_dpp(sq0);
           if (kPairCh) { sa1 = wave_sum_d_dpp(sa1); sq1 = wave_sum_d_dpp(sq1); }
-          if (lane < 2 && (lane == 0 || two)) {            // lane 0: channel c0, lane 1: channel c1
+          // per-channel inputs of the owner lanes: fetched in front of the tile loads by lane cl of every wave (cl0, cl1 are
+          // wave-uniform: v_readlane); the multi-tile variant has no registers to hold them and loads at the point of use
+          float g0 = 1.0f, g1 = 1.0f, e0 = 0.0f, e1 = 0.0f, rm0 = 0.0f, rm1 = 0.0f, rv0 = 0.0f, rv1 = 0.0f;
+          if constexpr (SINGLE) {
+            const int cla = cl0, clb = two_p ? cl1 : cl0;
+            g0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gam_l), cla));
+            g1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gam_l), clb));
+            e0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bet_l), cla));
+            e1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bet_l), clb));
+            if (publish) {
+              rm0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rm_l), cla));
+              rm1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rm_l), clb));
+              rv0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv_l), cla));
+              rv1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv_l), clb));
+            }
+          }
+          if (lane < 2 && (lane == 0 || two_p)) {            // lane 0: channel c0, lane 1: channel c1
             const int cl = lane ? cl1 : cl0, cc = lane ? c1 : c0;
             const double sa = lane ? sa1 : sa0, sq = lane ? sq1 : sq0;
-            const double n = (double)B * (double)bn.HW;
-            const double mean = sa / n;
-            double var = sq / n - mean * mean;
+            const double mean = sa * inv_n;
+            double var = sq * inv_n - mean * mean;
             if (var < 0) var = 0;
             const float invstd = 1.0f / sqrtf((float)(var + (double)bn.bn_eps));     // fp32 like torch's batch-norm
-            const float av = (bn.gamma ? bn.gamma[cc] : 1.0f) * invstd;
-            const float bv = (bn.beta ? bn.beta[cc] : 0.0f) - (float)mean * av;
+            float gv = lane ? g1 : g0, ev = lane ? e1 : e0;
+            if constexpr (!SINGLE) {
+              gv = bn.gamma ? bn.gamma[cc] : 1.0f;
+              ev = bn.beta ? bn.beta[cc] : 0.0f;
+            }
+            const float av = gv * invstd;
+            const float bv = ev - (float)mean * av;
             colv[cl] = av;
             colv[TFv + cl] = bv;
-            if (col0 < C) {                  // the tiles of the first pixel cover every channel exactly once: they publish
+            if (publish) {
               float* abo = const_cast<float*>(bn.ab);
               float* svo = const_cast<float*>(bn.save);
               abo[cc] = av; abo[C + cc] = bv;
               svo[cc] = (float)mean; svo[C + cc] = invstd;
-              if (bn.running_mean) bn.running_mean[cc] = (1.0f - bn.momentum) * bn.running_mean[cc] + bn.momentum * (float)mean;
-              if (bn.running_var) bn.running_var[cc] = (1.0f - bn.momentum) * bn.running_var[cc] + bn.momentum * (float)(var * n / (n - 1.0));
+              float rm = lane ? rm1 : rm0, rv = lane ? rv1 : rv0;
+              if constexpr (!SINGLE) {
+                rm = bn.running_mean ? bn.running_mean[cc] : 0.0f;
+                rv = bn.running_var ? bn.running_var[cc] : 0.0f;
+              }
+              if (bn.running_mean) bn.running_mean[cc] = (1.0f - bn.momentum) * rm + bn.momentum * (float)mean;
+              if (bn.running_var) bn.running_var[cc] = (1.0f - bn.momentum) * rv + bn.momentum * (float)(var * n / (n - 1.0));
               if (cc == 0 && bn.nbt) *bn.nbt += 1;
             }
           }
         }
         }
-        const int nch = bn.C < TFv ? bn.C : TFv;
         __syncthreads();
         const int jl = (4 * c) & (nch - 1);                // this thread's columns -> local channel index
         a4 = *reinterpret_cast<const float4*>(colv + jl);
@@ -487,6 +575,10 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
     __syncthreads();
     STAMP(3);
     // ---- MFMA: upper-triangular tiles of Th Th^T and Xh Xh^T (3 bf16 MFMAs each per 16 features) ------------
+    if constexpr (SINGLE) {      // one tile per workgroup: the accumulators start their life here, not in front of the erf work
+#pragma unroll
+      for (int e = 0; e < 16; e++) { acc0[e] = 0.0f; acc1[e] = 0.0f; }
+    }
     // A operand: lane -> row I*32 + l31, 8 consecutive features k0 + 8h..; B operand: row J*32 + l31, same features
     if (item0) {
       const int ra = (I0 * 32 + l31) * LDB + 8 * h, rb = (J0 * 32 + l31) * LDB + 8 * h;
@@ -537,6 +629,7 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
       }
     }
     __syncthreads();   // LDS tiles are overwritten by the next iteration / by the combine below
+    if constexpr (SINGLE) break;
   }
 
   STAMP(4);
@@ -1374,13 +1467,19 @@ int launch_partials4(bool pair, const Geom& g, const float* x, int B, int64_t F,
   if (bn.bins && (!aligned || bn.res || (reinterpret_cast<uintptr_t>(bn.bins) & 15) || (bn.bin_bytes != 1 && bn.bin_bytes != 2)))
     return ALIGNQ_EINVAL;             // the index is stored per aligned column quad and only for a value that IS a level
   unsigned* counter = reinterpret_cast<unsigned*>(ws + (size_t)g.grid * g.slab_floats + kPartFloats);
-#define L4(TFV, P) hipLaunchKernelGGL((site_fwd4_kernel<TFV, P>), g.grid, NT, 0, st, x, B, F, k, r, eps, xq, ws, stats, g.n_tiles, aligned, counter, bn)
+  // (geom(): only the 64-feature kernel ever loops over tiles)
+#define L4(TFV, P)                                                                                                       \
+  do {                                                                                                                  \
+    if (g.n_tiles <= g.grid) L4S(TFV, P, true); else if (TFV == 64) L4S(64, P, false); else return ALIGNQ_EINVAL;        \
+  } while (0)
+#define L4S(TFV, P, SG) hipLaunchKernelGGL((site_fwd4_kernel<TFV, P, SG>), g.grid, NT, 0, st, x, B, F, k, r, eps, xq, ws, stats, g.n_tiles, aligned, counter, bn)
   if (pair) {
     if (g.tf == 64) L4(64, true); else if (g.tf == 32) L4(32, true); else L4(16, true);
   } else {
     if (g.tf == 64) L4(64, false); else if (g.tf == 32) L4(32, false); else L4(16, false);
   }
 #undef L4
+#undef L4S
   RET_ON_ERR();
   return 0;
 }

@@ -67,8 +67,9 @@ inline Geom geom(int B, int64_t F) {
   Geom g;
   g.nb = B <= 32 ? 1 : (B <= 64 ? 2 : 4);
   if (g.nb == 4) {
-    // keep >= 256 tiles (one per CU) when the site is small: 64 -> 32 -> 16 features per tile
-    g.tf = (F >= 64 * 256) ? 64 : ((F >= 32 * 256) ? 32 : 16);
+    // narrower tiles while that still fits one tile per CU: 16 features up to F = 4096, 32 up to 8192, else 64 (only the
+    // 64-feature kernel ever loops over tiles; its one-tile form and the narrow kernels are the latency-tuned ones)
+    g.tf = (F > 32 * 256) ? 64 : ((F > 16 * 256) ? 32 : 16);
     g.n_tiles = (int)((F + g.tf - 1) / g.tf);
     g.grid = g.n_tiles < 256 ? g.n_tiles : 256;
     g.slab_floats = 10 * 1024;
