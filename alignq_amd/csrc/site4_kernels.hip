@@ -109,6 +109,31 @@ __device__ __forceinline__ bf16x8 neg8(bf16x8 v) {
 // component e of a float4 (e is a compile-time constant after unrolling: folds to the register, no scratch array)
 __device__ __forceinline__ float f4get(const float4& v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
 
+// Sum per-lane values over the row groups of a wave (lanes with equal lane % LPR) on the VALU, no LDS crossbar: the two
+// cross-row levels use v_permlane32_swap / v_permlane16_swap, which exchange halves / odd-even rows of TWO registers at once, so
+// one swap + one add reduces two values and leaves each in half of the lanes (a reduce-scatter): 8 values -> 4 -> 2 registers
+// with 6 swaps + 6 adds.  Result: in DPP row r (lanes 16r..16r+15), t0 holds the total of v[kRowVal[r]] and t1 that of
+// v[4 + kRowVal[r]], kRowVal = {0, 2, 1, 3}; levels inside a row (LPR < 16) are row_ror all-reduces.
+__device__ __forceinline__ float swap_add32(float a, float b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);     // lanes < 32: a(l) + a(l+32); lanes >= 32: b(l-32) + b(l)
+}
+__device__ __forceinline__ float swap_add16(float a, float b) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);     // rows 0, 2: a(r) + a(r+1); rows 1, 3: b(r-1) + b(r)
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int LPR, bool PAIR>
+__device__ __forceinline__ void rowgroup_sums(const float (&vx)[4], const float (&vt)[4], float& t0, float& t1) {
+  t0 = swap_add16(swap_add32(vx[0], vx[1]), swap_add32(vx[2], vx[3]));
+  t1 = PAIR ? swap_add16(swap_add32(vt[0], vt[1]), swap_add32(vt[2], vt[3])) : 0.0f;
+  if (LPR <= 4) { t0 = dpp_add<0x124>(t0); if (PAIR) t1 = dpp_add<0x124>(t1); }      // row_ror:4
+  if (LPR <= 8) { t0 = dpp_add<0x128>(t0); if (PAIR) t1 = dpp_add<0x128>(t1); }      // row_ror:8
+}
+
 __device__ __forceinline__ void split_bf16(float v, __bf16& hi, __bf16& lo) {
   hi = (__bf16)v;
   lo = (__bf16)(v - (float)hi);
@@ -448,7 +473,10 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
       }
     }
     STAMP(1);
-    // ---- column means: registers -> wave shuffles over the row groups of the wave -> LDS over waves ----
+    // ---- column means: registers -> row-group sums inside the wave (VALU lane swaps) -> LDS over waves ----
+    // after rowgroup_sums, lane (row r, column quad c = lane % LPR) holds the wave's sum of column 4c + kRowVal[r]
+    const int rsel = ((lane >> 4) & 1) * 2 + (lane >> 5);     // kRowVal[lane / 16]
+    const bool rwrite = (lane & 15) < LPR;
     {
       float sx[4] = {0, 0, 0, 0}, st[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -458,29 +486,25 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
           if (PAIR) { st[0] += tv[j].x; st[1] += tv[j].y; st[2] += tv[j].z; st[3] += tv[j].w; }
         }
       }
-#pragma unroll
-      for (int o = LPR; o < 64; o <<= 1) {
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          sx[e] += __shfl_xor(sx[e], o, 64);
-          if (PAIR) st[e] += __shfl_xor(st[e], o, 64);
-        }
-      }
-      if (lane < LPR) {
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          red[w * TFv + 4 * c + e] = sx[e];
-          if (PAIR) red[16 * TFv + w * TFv + 4 * c + e] = st[e];
-        }
+      float t0, t1;
+      rowgroup_sums<LPR, PAIR>(sx, st, t0, t1);
+      if (rwrite) {
+        red[w * TFv + 4 * c + rsel] = t0;
+        if (PAIR) red[16 * TFv + w * TFv + 4 * c + rsel] = t1;
       }
     }
     __syncthreads();
     if (tid < NOP * TFv) {
       const int op = tid / TFv, cc = tid % TFv;
-      float s = 0.f;
+      float pw[16];
 #pragma unroll
-      for (int g = 0; g < 16; g++) s += red[op * 16 * TFv + g * TFv + cc];
-      colv[(2 * op) * TFv + cc] = s * invB;
+      for (int g = 0; g < 16; g++) pw[g] = red[op * 16 * TFv + g * TFv + cc];      // 16 reads in flight, then a fixed tree
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+#pragma unroll
+        for (int g = 0; g < 16; g += 2 * o) pw[g] += pw[g + o];
+      }
+      colv[(2 * op) * TFv + cc] = pw[0] * invB;
     }
     __syncthreads();
     // ---- column variances (two-pass) --------------------------------------------------------------
@@ -501,29 +525,25 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
           }
         }
       }
-#pragma unroll
-      for (int o = LPR; o < 64; o <<= 1) {
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          sx[e] += __shfl_xor(sx[e], o, 64);
-          if (PAIR) st[e] += __shfl_xor(st[e], o, 64);
-        }
-      }
-      if (lane < LPR) {
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          red[w * TFv + 4 * c + e] = sx[e];
-          if (PAIR) red[16 * TFv + w * TFv + 4 * c + e] = st[e];
-        }
+      float t0, t1;
+      rowgroup_sums<LPR, PAIR>(sx, st, t0, t1);
+      if (rwrite) {
+        red[w * TFv + 4 * c + rsel] = t0;
+        if (PAIR) red[16 * TFv + w * TFv + 4 * c + rsel] = t1;
       }
     }
     __syncthreads();
     if (tid < NOP * TFv) {
       const int op = tid / TFv, cc = tid % TFv;
-      float s = 0.f;
+      float pw[16];
 #pragma unroll
-      for (int g = 0; g < 16; g++) s += red[op * 16 * TFv + g * TFv + cc];
-      const float sd = sqrtf(s * invBm1);
+      for (int g = 0; g < 16; g++) pw[g] = red[op * 16 * TFv + g * TFv + cc];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+#pragma unroll
+        for (int g = 0; g < 16; g += 2 * o) pw[g] += pw[g + o];
+      }
+      const float sd = sqrtf(pw[0] * invBm1);
       const float rho = 1.0f / (sd + eps);
       colv[(2 * op + 1) * TFv + cc] = rho;
       if (stats && col0 + cc < F) {
