@@ -1266,16 +1266,13 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
           }
         }
       }
-      x0 += __shfl_xor(x0, 32, 64);
-      x1 += __shfl_xor(x1, 32, 64);
-      if (PAIR) { t0 += __shfl_xor(t0, 32, 64); t1 += __shfl_xor(t1, 32, 64); }
-      if (h == 0) {
-        red[((I * 2 + 0) * 2 + 0) * TFv + cc] = x0;
-        red[((I * 2 + 0) * 2 + 1) * TFv + cc] = x1;
-        if (PAIR) {
-          red[((I * 2 + 1) * 2 + 0) * TFv + cc] = t0;
-          red[((I * 2 + 1) * 2 + 1) * TFv + cc] = t1;
-        }
+      // the two half-waves hold the two 16-row halves of every column: one lane swap + add sums both quantities at once and
+      // leaves sum dVh in the lower half-wave, sum dVh*Vh in the upper one (no LDS crossbar round trips)
+      const float px = swap_add32(x0, x1);
+      red[((I * 2 + 0) * 2 + h) * TFv + cc] = px;
+      if (PAIR) {
+        const float pt = swap_add32(t0, t1);
+        red[((I * 2 + 1) * 2 + h) * TFv + cc] = pt;
       }
     }
     __syncthreads();
@@ -1368,18 +1365,14 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
       }
       // red is free again (all its reads finished before the barrier above)
       if (BN && bn.nhwc) {
-        // sum over the wave's row groups (lanes NCQ apart), then one row of `red` per wave: [2 * wave + {0,1}][column]
-#pragma unroll
-        for (int o = NCQ; o < 64; o <<= 1) {
-#pragma unroll
-          for (int e = 0; e < 4; e++) { bp0[e] += __shfl_xor(bp0[e], o, 64); bp1[e] += __shfl_xor(bp1[e], o, 64); }
-        }
-        if (lane < NCQ) {
-#pragma unroll
-          for (int e = 0; e < 4; e++) {
-            red[(2 * w) * TFv + 4 * lc4 + e] = bp0[e];
-            red[(2 * w + 1) * TFv + 4 * lc4 + e] = bp1[e];
-          }
+        // sum over the wave's row groups (lanes NCQ apart; VALU lane swaps, see rowgroup_sums), then one row of `red` per
+        // wave: [2 * wave + {0,1}][column]; lane (DPP row r, quad lc4) ends with column 4*lc4 + kRowVal[r]
+        float s0, s1;
+        rowgroup_sums<NCQ, true>(bp0, bp1, s0, s1);
+        if ((lane & 15) < NCQ) {
+          const int rsel = ((lane >> 4) & 1) * 2 + (lane >> 5);
+          red[(2 * w) * TFv + 4 * lc4 + rsel] = s0;
+          red[(2 * w + 1) * TFv + 4 * lc4 + rsel] = s1;
         }
       } else if (BN) {                 // one channel per tile
         float s0 = wave_sum(bp0[0] + bp0[1] + bp0[2] + bp0[3]);
