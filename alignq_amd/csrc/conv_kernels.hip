@@ -1167,46 +1167,71 @@ __host__ __device__ __forceinline__ int wgrad_reduce_groups(int n_slabs) {
   while (g < 16 && g * 16 < n_slabs) g <<= 1;
   return g;
 }
+// (n_elem % 4 == 0, every filter shape here: a thread owns four consecutive elements, one 16-byte load per slab)
 __host__ __device__ __forceinline__ int wgrad_reduce_blocks(int n_slabs, int n_elem) {
-  const int per = 1024 / wgrad_reduce_groups(n_slabs);
+  const int per = (1024 / wgrad_reduce_groups(n_slabs)) * ((n_elem & 3) ? 1 : 4);
   return (n_elem + per - 1) / per;
 }
-__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ slabs, int n_slabs, int n_elem,
-                                                  float* __restrict__ dw, int blk, float* __restrict__ part /* [1024] */) {
+template <int EPL>
+__device__ __forceinline__ void wgrad_reduce_body_t(const float* __restrict__ slabs, int n_slabs, int n_elem,
+                                                    float* __restrict__ dw, int blk, float* __restrict__ part /* [1024 * EPL] */) {
   const int G = wgrad_reduce_groups(n_slabs), per = 1024 / G;
   const int g = threadIdx.x / per, l = threadIdx.x - g * per;
-  const int e = blk * per + l;
-  const int ec = e < n_elem ? e : n_elem - 1;
-  float s = 0.f;
+  const int e = (blk * per + l) * EPL;
+  const int ec = e < n_elem ? e : n_elem - EPL;
+  float s[EPL];
+#pragma unroll
+  for (int q = 0; q < EPL; q++) s[q] = 0.f;
   constexpr int U = 16;
   for (int sl0 = g; sl0 < n_slabs; sl0 += G * U) {
-    float v[U];
+    float v[U][EPL];
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int sl = sl0 + G * u;
-      v[u] = slabs[(int64_t)(sl < n_slabs ? sl : n_slabs - 1) * n_elem + ec];
+      const float* p = slabs + (int64_t)(sl < n_slabs ? sl : n_slabs - 1) * n_elem + ec;
+      if constexpr (EPL == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w;
+      } else {
+        v[u][0] = *p;
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      if (sl0 + G * u < n_slabs) s += v[u];
+      if (sl0 + G * u < n_slabs) {
+#pragma unroll
+        for (int q = 0; q < EPL; q++) s[q] += v[u][q];
+      }
     }
   }
   if (G == 1) {                                    // block-uniform
-    if (e < n_elem) dw[e] = s;
+    if (e < n_elem) {
+#pragma unroll
+      for (int q = 0; q < EPL; q++) dw[e + q] = s[q];
+    }
     return;
   }
-  part[threadIdx.x] = s;
+#pragma unroll
+  for (int q = 0; q < EPL; q++) part[threadIdx.x * EPL + q] = s[q];
   __syncthreads();
   if (g == 0 && e < n_elem) {
-    float t = 0.f;
-    for (int q = 0; q < G; q++) t += part[q * per + l];
-    dw[e] = t;
+#pragma unroll
+    for (int q = 0; q < EPL; q++) {
+      float t = 0.f;
+      for (int k = 0; k < G; k++) t += part[(k * per + l) * EPL + q];
+      dw[e + q] = t;
+    }
   }
+}
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ slabs, int n_slabs, int n_elem,
+                                                  float* __restrict__ dw, int blk, float* __restrict__ part /* [4096] */) {
+  if (n_elem & 3) wgrad_reduce_body_t<1>(slabs, n_slabs, n_elem, dw, blk, part);      // block-uniform
+  else wgrad_reduce_body_t<4>(slabs, n_slabs, n_elem, dw, blk, part);
 }
 
 __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ slabs, int n_slabs, int n_elem,
                                                             float* __restrict__ dw) {
-  __shared__ float part[1024];
+  __shared__ __attribute__((aligned(16))) float part[4096];
   wgrad_reduce_body(slabs, n_slabs, n_elem, dw, blockIdx.x, part);
 }
 
@@ -1222,7 +1247,7 @@ struct WgChunk {
   int blk0[kWgMulti + 1];
 };
 __global__ __launch_bounds__(1024) void wgrad_reduce_multi_kernel(WgChunk c, int cnt) {
-  __shared__ float part[1024];
+  __shared__ __attribute__((aligned(16))) float part[4096];
   int t = 0;
   while (t + 1 < cnt && (int)blockIdx.x >= c.blk0[t + 1]) t++;          // block-uniform (scalar) search
   wgrad_reduce_body(c.slabs[t], c.n_slabs[t], c.n_elem[t], c.dw[t], (int)blockIdx.x - c.blk0[t], part);

@@ -691,68 +691,93 @@ __device__ __forceinline__ void slab_reduce_body(const float* __restrict__ slabs
                                                            const float* __restrict__ gamma, int dim, float mu,
                                                            float rho, float* __restrict__ parts,
                                                            unsigned* __restrict__ counter, float* __restrict__ scal) {
-  __shared__ float part[16][64];
+  // SYM: a lane owns FOUR consecutive stored elements (one 16-byte load per slab: the slab stream is the HBM-bound part of a
+  // step, 215 MB for ResNet-20); else one element of the full BPxBP slab.
+  constexpr int EPL = SYM ? 4 : 1;
+  __shared__ float part[16][64 * EPL];
   __shared__ double fin[48];
   __shared__ int is_last;
   const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + lane;
+  const int e = (blockIdx.x * 64 + lane) * EPL;
   // SYM: iterate over the STORED elements (10 tiles x 32 x 32, coalesced) and mirror the off-diagonal tiles;
   // else: over the output elements of the full BPxBP slab.
   int i, j, off;
-  bool ok, mirror = false;
+  bool ok[EPL], any_ok, mirror = false;
   if (SYM) {
     const int tile = e >> 10, within = e & 1023;
     int t = tile, I = 0;
     while (t >= 4 - I && I < 3) { t -= 4 - I; I++; }
     const int J = I + t;
     i = I * 32 + (within >> 5);
-    j = J * 32 + (within & 31);
-    ok = (tile < 10) && i < B && j < B;
-    mirror = ok && (I != J);
+    j = J * 32 + (within & 31);        // j .. j + 3: the same row of the same tile
+#pragma unroll
+    for (int q = 0; q < EPL; q++) ok[q] = (tile < 10) && i < B && j + q < B;
+    any_ok = (tile < 10) && i < B && j < B;
+    mirror = any_ok && (I != J);
     off = e;
   } else {
-    ok = e < B * B;
-    i = ok ? e / B : 0;
-    j = ok ? e - i * B : 0;
+    ok[0] = e < B * B;
+    any_ok = ok[0];
+    i = ok[0] ? e / B : 0;
+    j = ok[0] ? e - i * B : 0;
     off = i * BP + j;
   }
   const float* p = slabs + off;
   // the loss operands do not depend on the slab sums: issue their loads first so they fly under the reduction
-  float a_ij = 0.f, g_ij = 0.f, a_ji = 0.f, g_ji = 0.f;
+  float a_ij[EPL], g_ij[EPL], a_ji[EPL], g_ji[EPL];
+#pragma unroll
+  for (int q = 0; q < EPL; q++) { a_ij[q] = 0.f; g_ij[q] = 0.f; a_ji[q] = 0.f; g_ji[q] = 0.f; }
   if (LOSS && sg == 0) {
-    if (ok) { a_ij = A[i * dim + j]; g_ij = gamma[i * dim + j]; }
-    if (mirror) { a_ji = A[j * dim + i]; g_ji = gamma[j * dim + i]; }
+#pragma unroll
+    for (int q = 0; q < EPL; q++) {
+      if (ok[q]) { a_ij[q] = A[i * dim + j + q]; g_ij[q] = gamma[i * dim + j + q]; }
+      if (mirror && ok[q]) { a_ji[q] = A[(j + q) * dim + i]; g_ji[q] = gamma[(j + q) * dim + i]; }
+    }
   }
-  float s = 0.f;
-  if (ok) {
+  float s[EPL];
+#pragma unroll
+  for (int q = 0; q < EPL; q++) s[q] = 0.f;
+  if (any_ok) {
+    if constexpr (SYM) {
 #pragma unroll 16
-    for (int sl = sg; sl < n_slabs; sl += 16) s += p[(int64_t)sl * slab_floats];
+      for (int sl = sg; sl < n_slabs; sl += 16) {
+        const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)sl * slab_floats);
+        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+      }
+    } else {
+#pragma unroll 16
+      for (int sl = sg; sl < n_slabs; sl += 16) s[0] += p[(int64_t)sl * slab_floats];
+    }
   }
-  part[sg][lane] = s;
+#pragma unroll
+  for (int q = 0; q < EPL; q++) part[sg][lane * EPL + q] = s[q];
   __syncthreads();
   if (sg == 0) {
-    float t = 0.f;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f;
 #pragma unroll
-    for (int g = 0; g < 16; g++) t += part[g][lane];
-    const float d = t * scale;
-    if (ok) out[i * B + j] = d;
-    if (mirror) out[j * B + i] = d;
+    for (int q = 0; q < EPL; q++) {
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; g++) t += part[g][lane * EPL + q];
+      const float d = t * scale;
+      if (ok[q]) out[i * B + j + q] = d;
+      if (mirror && ok[q]) out[(j + q) * B + i] = d;
+      if (LOSS) {
+        if (ok[q]) {
+          const float dd = d - a_ij[q];
+          v0 += fabsf(a_ij[q]);
+          v1 += dd * dd;
+          v2 += g_ij[q] * fabsf(dd);
+        }
+        if (mirror && ok[q]) {
+          const float dd = d - a_ji[q];
+          v0 += fabsf(a_ji[q]);
+          v1 += dd * dd;
+          v2 += g_ji[q] * fabsf(dd);
+        }
+      }
+    }
     if (LOSS) {
-      float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-      if (ok) {
-        const float a = a_ij, gm = g_ij;
-        const float dd = d - a;
-        v0 = fabsf(a);
-        v1 = dd * dd;
-        v2 = gm * fabsf(dd);
-      }
-      if (mirror) {
-        const float a = a_ji, gm = g_ji;
-        const float dd = d - a;
-        v0 += fabsf(a);
-        v1 += dd * dd;
-        v2 += gm * fabsf(dd);
-      }
       v0 = wave_sum(v0);
       v1 = wave_sum(v1);
       v2 = wave_sum(v2);
@@ -1501,7 +1526,7 @@ int launch_reduce_any(const Geom& g, const float* ws_c, float* ws_mut, int B, in
                       const float* alterD, const float* gamma, int dim, float mu, float rho, float* scal,
                       hipStream_t st) {
   const int BP = 32 * g.nb;
-  const int blocks = (g.nb == 4) ? 160 : (B * B + 63) / 64;   // site4: one thread per STORED element (10x32x32)
+  const int blocks = (g.nb == 4) ? 40 : (B * B + 63) / 64;   // site4: four STORED elements (10x32x32 in all) per lane
   float* parts = ws_mut ? ws_mut + (size_t)g.grid * g.slab_floats : nullptr;
   unsigned* counter = ws_mut ? reinterpret_cast<unsigned*>(ws_mut + (size_t)g.grid * g.slab_floats + kPartFloats) : nullptr;
   const float scale = 1.0f / (float)F;
@@ -1538,7 +1563,7 @@ int launch_reduce_loss_multi(int S, void* const* ws, float* const* D, const floa
       c.slabs[i] = (const float*)ws[s0 + i]; c.out[i] = D[s0 + i]; c.A[i] = alterD[s0 + i]; c.gamma[i] = gamma[s0 + i];
       c.scal[i] = scal[s0 + i]; c.scale[i] = 1.0f / (float)F[s0 + i]; c.n_slabs[i] = g.grid;
     }
-    hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3(160, cnt), 1024, 0, st, c, B, dim, mu, rho);
+    hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3(40, cnt), 1024, 0, st, c, B, dim, mu, rho);
     RET_ON_ERR();
   }
   return 0;
