@@ -672,9 +672,25 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
       C[tile1 * 1024 + ((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + l31] += acc1[e];
   }
   __syncthreads();
-  float4* slab4 = reinterpret_cast<float4*>(slabs + (int64_t)blockIdx.x * 10240);
+  // packed slab (site_internal.h, kSlab4Floats): six off-diagonal tiles as they are, the four diagonal tiles' upper
+  // triangles two to a [32][33] block
+  float* slab = slabs + (int64_t)blockIdx.x * kSlab4Floats;
+  float4* slab4 = reinterpret_cast<float4*>(slab);
   const float4* C4 = reinterpret_cast<const float4*>(C);
-  for (int e = tid; e < 2560; e += NT) slab4[e] = C4[e];
+  for (int e = tid; e < kSlab4Off / 4; e += NT) {
+    const int t6 = e >> 8;                                      // C tiles 1, 2, 3, 5, 6, 8
+    const int tl = t6 < 3 ? t6 + 1 : (t6 < 5 ? t6 + 2 : 8);
+    slab4[e] = C4[tl * 256 + (e & 255)];
+  }
+  for (int idx = tid; idx < kSlab4Packed; idx += NT) {
+    const int blk = idx / 1056, rem = idx - blk * 1056;
+    const int row = rem / 33, col = rem - row * 33;
+    const bool second = col <= row;                             // tile 2*blk + 1, stored transposed
+    const int rr = second ? col : row, cc2 = second ? row : col - 1;
+    const int d = 2 * blk + (second ? 1 : 0);
+    const int tl = d == 0 ? 0 : (d == 1 ? 4 : (d == 2 ? 7 : 9));
+    slab[kSlab4Off + idx] = C[tl * 1024 + rr * 32 + cc2];
+  }
   STAMP(5);
   BSTAMP(0, 1);
 }
@@ -701,26 +717,40 @@ __device__ __forceinline__ void slab_reduce_body(const float* __restrict__ slabs
   const int e = (blockIdx.x * 64 + lane) * EPL;
   // SYM: iterate over the STORED elements (10 tiles x 32 x 32, coalesced) and mirror the off-diagonal tiles;
   // else: over the output elements of the full BPxBP slab.
-  int i, j, off;
-  bool ok[EPL], any_ok, mirror = false;
+  int iq[EPL], jq[EPL], off;
+  bool ok[EPL], mir[EPL], any_ok = false;
   if (SYM) {
-    const int tile = e >> 10, within = e & 1023;
-    int t = tile, I = 0;
-    while (t >= 4 - I && I < 3) { t -= 4 - I; I++; }
-    const int J = I + t;
-    i = I * 32 + (within >> 5);
-    j = J * 32 + (within & 31);        // j .. j + 3: the same row of the same tile
 #pragma unroll
-    for (int q = 0; q < EPL; q++) ok[q] = (tile < 10) && i < B && j + q < B;
-    any_ok = (tile < 10) && i < B && j < B;
-    mirror = any_ok && (I != J);
-    off = e;
+    for (int q = 0; q < EPL; q++) {
+      const int eq = e + q;
+      int ti, tj, r, c2;
+      if (eq < kSlab4Off) {
+        const int t6 = eq >> 10, within = eq & 1023;
+        ti = t6 < 3 ? 0 : (t6 < 5 ? 1 : 2);
+        tj = t6 < 3 ? t6 + 1 : (t6 < 5 ? t6 - 1 : 3);
+        r = within >> 5; c2 = within & 31;
+      } else {
+        const int idx = eq - kSlab4Off;
+        const int blk = idx / 1056, rem = idx - blk * 1056;
+        const int row = rem / 33, col = rem - row * 33;
+        const bool second = col <= row;
+        r = second ? col : row; c2 = second ? row : col - 1;
+        ti = tj = 2 * blk + (second ? 1 : 0);
+      }
+      iq[q] = ti * 32 + r;
+      jq[q] = tj * 32 + c2;
+      ok[q] = eq < kSlab4Floats && iq[q] < B && jq[q] < B;
+      mir[q] = ok[q] && iq[q] != jq[q];
+      any_ok = any_ok || ok[q];
+    }
+    off = e < kSlab4Floats ? e : 0;
   } else {
     ok[0] = e < B * B;
     any_ok = ok[0];
-    i = ok[0] ? e / B : 0;
-    j = ok[0] ? e - i * B : 0;
-    off = i * BP + j;
+    iq[0] = ok[0] ? e / B : 0;
+    jq[0] = ok[0] ? e - iq[0] * B : 0;
+    mir[0] = false;
+    off = iq[0] * BP + jq[0];
   }
   const float* p = slabs + off;
   // the loss operands do not depend on the slab sums: issue their loads first so they fly under the reduction
@@ -730,8 +760,8 @@ __device__ __forceinline__ void slab_reduce_body(const float* __restrict__ slabs
   if (LOSS && sg == 0) {
 #pragma unroll
     for (int q = 0; q < EPL; q++) {
-      if (ok[q]) { a_ij[q] = A[i * dim + j + q]; g_ij[q] = gamma[i * dim + j + q]; }
-      if (mirror && ok[q]) { a_ji[q] = A[(j + q) * dim + i]; g_ji[q] = gamma[(j + q) * dim + i]; }
+      if (ok[q]) { a_ij[q] = A[iq[q] * dim + jq[q]]; g_ij[q] = gamma[iq[q] * dim + jq[q]]; }
+      if (mir[q]) { a_ji[q] = A[jq[q] * dim + iq[q]]; g_ji[q] = gamma[jq[q] * dim + iq[q]]; }
     }
   }
   float s[EPL];
@@ -760,8 +790,8 @@ __device__ __forceinline__ void slab_reduce_body(const float* __restrict__ slabs
 #pragma unroll
       for (int g = 0; g < 16; g++) t += part[g][lane * EPL + q];
       const float d = t * scale;
-      if (ok[q]) out[i * B + j + q] = d;
-      if (mirror && ok[q]) out[(j + q) * B + i] = d;
+      if (ok[q]) out[iq[q] * B + jq[q]] = d;
+      if (mir[q]) out[jq[q] * B + iq[q]] = d;
       if (LOSS) {
         if (ok[q]) {
           const float dd = d - a_ij[q];
@@ -769,7 +799,7 @@ __device__ __forceinline__ void slab_reduce_body(const float* __restrict__ slabs
           v1 += dd * dd;
           v2 += g_ij[q] * fabsf(dd);
         }
-        if (mirror && ok[q]) {
+        if (mir[q]) {
           const float dd = d - a_ji[q];
           v0 += fabsf(a_ji[q]);
           v1 += dd * dd;
@@ -852,9 +882,9 @@ struct RChunk {
 __global__ __launch_bounds__(1024) void slab_reduce_multi_kernel(RChunk c, int B, int dim, float mu, float rho) {
   const int s = blockIdx.y;
   float* ws = const_cast<float*>(c.slabs[s]);
-  float* parts = ws + (size_t)c.n_slabs[s] * 10240;
+  float* parts = ws + (size_t)c.n_slabs[s] * kSlab4Floats;
   unsigned* counter = reinterpret_cast<unsigned*>(parts + kPartFloats);
-  slab_reduce_body<true, true>(c.slabs[s], c.n_slabs[s], 10240, 128, B, c.scale[s], c.out[s], c.A[s], c.gamma[s], dim, mu,
+  slab_reduce_body<true, true>(c.slabs[s], c.n_slabs[s], kSlab4Floats, 128, B, c.scale[s], c.out[s], c.A[s], c.gamma[s], dim, mu,
                                rho, parts, counter, c.scal[s]);
 }
 
@@ -1526,7 +1556,7 @@ int launch_reduce_any(const Geom& g, const float* ws_c, float* ws_mut, int B, in
                       const float* alterD, const float* gamma, int dim, float mu, float rho, float* scal,
                       hipStream_t st) {
   const int BP = 32 * g.nb;
-  const int blocks = (g.nb == 4) ? 40 : (B * B + 63) / 64;   // site4: four STORED elements (10x32x32 in all) per lane
+  const int blocks = (g.nb == 4) ? (kSlab4Floats + 255) / 256 : (B * B + 63) / 64;   // site4: four STORED elements per lane
   float* parts = ws_mut ? ws_mut + (size_t)g.grid * g.slab_floats : nullptr;
   unsigned* counter = ws_mut ? reinterpret_cast<unsigned*>(ws_mut + (size_t)g.grid * g.slab_floats + kPartFloats) : nullptr;
   const float scale = 1.0f / (float)F;
@@ -1563,7 +1593,7 @@ int launch_reduce_loss_multi(int S, void* const* ws, float* const* D, const floa
       c.slabs[i] = (const float*)ws[s0 + i]; c.out[i] = D[s0 + i]; c.A[i] = alterD[s0 + i]; c.gamma[i] = gamma[s0 + i];
       c.scal[i] = scal[s0 + i]; c.scale[i] = 1.0f / (float)F[s0 + i]; c.n_slabs[i] = g.grid;
     }
-    hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3(40, cnt), 1024, 0, st, c, B, dim, mu, rho);
+    hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3((kSlab4Floats + 255) / 256, cnt), 1024, 0, st, c, B, dim, mu, rho);
     RET_ON_ERR();
   }
   return 0;

@@ -10,6 +10,10 @@ namespace alignq_site {
 // Workspace layout (floats): [grid * slab_floats partial slabs][kPartFloats loss partials][counter, pad]
 constexpr int kPartFloats = 1024;   // up to 256 blocks x 4 floats of ADMM-loss partial sums
 constexpr int kTailFloats = kPartFloats + 16;
+// Partial-Gram slab of the B in (64,128] kernels: the 10 upper-triangular 32x32 tiles of the symmetric 128x128 partial, packed:
+// the six off-diagonal tiles (0,1)(0,2)(0,3)(1,2)(1,3)(2,3) row-major (6144 floats), then two [32][33] blocks that each hold
+// the upper triangles (r <= c) of TWO diagonal tiles: tile 2*blk at [r][c + 1], tile 2*blk + 1 transposed at [c][r].
+constexpr int kSlab4Off = 6 * 1024, kSlab4Packed = 2 * 32 * 33, kSlab4Floats = kSlab4Off + kSlab4Packed;   // 8256 (was 10240)
 
 // Optional batch-norm fold: the site kernels read the CONV output z and apply x = a[c]*z + b[c] on load
 // (c = feature / HW), a = gamma*invstd, b = beta - mean*a; ab == nullptr means the input already is x.
@@ -60,7 +64,7 @@ struct Geom {
   int tf;           // features per tile
   int n_tiles;
   int grid;         // workgroups of the partials kernel == number of slabs
-  int slab_floats;  // nb<4: BP*BP (full matrix);  nb==4: 10 upper-triangular 32x32 tiles
+  int slab_floats;  // nb<4: BP*BP (full matrix);  nb==4: kSlab4Floats (packed upper triangle)
 };
 
 inline Geom geom(int B, int64_t F) {
@@ -72,7 +76,7 @@ inline Geom geom(int B, int64_t F) {
     g.tf = (F > 32 * 256) ? 64 : ((F > 16 * 256) ? 32 : 16);
     g.n_tiles = (int)((F + g.tf - 1) / g.tf);
     g.grid = g.n_tiles < 256 ? g.n_tiles : 256;
-    g.slab_floats = 10 * 1024;
+    g.slab_floats = kSlab4Floats;
   } else {
     g.tf = 64;
     g.n_tiles = (int)((F + 63) / 64);
