@@ -12,7 +12,7 @@ SO_PATH = os.path.join(_HERE, "lib", "libalignq_hip.so")
 
 FORMULA_ADMM, FORMULA_CDF = 0, 1
 MAX_BATCH = 128
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _c = ctypes
 _vp, _i, _i64, _f, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_size_t
@@ -62,6 +62,8 @@ SIGNATURES = {
     "alignq_conv_gen_bn_parts": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "alignq_conv_gen_nhwc_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "alignq_conv_gen_nhwc_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "alignq_transition_nhwc_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "alignq_transition_nhwc_bwd": (_i, [_vp] * 8 + [_i] * 6 + [_vp] * 3 + [_vp] * 14 + [_vp]),
     "alignq_conv_stem_bn_parts": (_i, [_i, _i, _i]),
     "alignq_conv_stem_nhwc_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "alignq_conv_stem_nhwc_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -357,21 +357,21 @@ struct ConvGen {
   static constexpr int ARR = LROWS * LW * CP;
 };
 
+// block / n_wg: index and count of the workgroups of THIS convolution (a launch may carry several roles)
 template <int CIN, int COUT, int WDI, int KS, int S, int PT>
-__global__ __launch_bounds__(256) void convgen_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                          float* __restrict__ y, int H, int total_rows, float nlev,
-                                                          float* __restrict__ bn_part) {
+__device__ __forceinline__ void convgen_fwd_body(const float* __restrict__ x, const float* __restrict__ w,
+                                                 float* __restrict__ y, int H, int total_rows, float nlev,
+                                                 float* __restrict__ bn_part, __bf16* lds, int block, int n_wg) {
   using G = ConvGen<CIN, COUT, WDI, KS, S, PT>;
   constexpr int WDO = G::WDO, TR = G::TR, LROWS = G::LROWS, LW = G::LW, CP = G::CP, ARR = G::ARR;
   constexpr int NS = (KS * KS * CIN + 31) / 32;
   constexpr int NCG = COUT / 16, NPP = 4 / NCG, NG = PT / 16;
   static_assert(NCG == 1 || NCG == 2 || NCG == 4, "output channels");
-  __shared__ __attribute__((aligned(16))) __bf16 lds[3 * ARR];
   __bf16* Xhi = lds;
   __bf16* Xmi = lds + ARR;
   __bf16* Xlo = lds + 2 * ARR;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int row0 = blockIdx.x * TR;                              // first OUTPUT row (image*H + h) of the tile
+  const int row0 = block * TR;                                   // first OUTPUT row (image*H + h) of the tile
   const int Hin = H * S;
   const int img_lo = (row0 / H) * Hin, img_hi = img_lo + Hin;    // INPUT rows of the tile's image
   {
@@ -488,10 +488,34 @@ __global__ __launch_bounds__(256) void convgen_fwd_kernel(const float* __restric
         s0 += red[((ppi * NCG + cg) * 16 + cl) * 2];
         s1 += red[((ppi * NCG + cg) * 16 + cl) * 2 + 1];
       }
-      bn_part[((int64_t)tid * gridDim.x + blockIdx.x) * 2] = s0;
-      bn_part[((int64_t)tid * gridDim.x + blockIdx.x) * 2 + 1] = s1;
+      bn_part[((int64_t)tid * n_wg + block) * 2] = s0;
+      bn_part[((int64_t)tid * n_wg + block) * 2 + 1] = s1;
     }
   }
+}
+
+template <int CIN, int COUT, int WDI, int KS, int S, int PT>
+__global__ __launch_bounds__(256) void convgen_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          float* __restrict__ y, int H, int total_rows, float nlev,
+                                                          float* __restrict__ bn_part) {
+  __shared__ __attribute__((aligned(16))) __bf16 lds[3 * ConvGen<CIN, COUT, WDI, KS, S, PT>::ARR];
+  convgen_fwd_body<CIN, COUT, WDI, KS, S, PT>(x, w, y, H, total_rows, nlev, bn_part, lds, blockIdx.x, gridDim.x);
+}
+
+// Both convolutions of a transition block (3x3 and 1x1, stride 2, same input) in ONE launch: the first n3 workgroups take
+// the 3x3 role, the rest the 1x1 role (a launch boundary costs more than the 1x1 convolution itself).
+template <int CIN, int COUT, int WDI, int PT3, int PT1>
+__global__ __launch_bounds__(256) void transition_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w3,
+                                                             const float* __restrict__ w1, float* __restrict__ y3,
+                                                             float* __restrict__ y1, int H, int total_rows, float nlev,
+                                                             float* __restrict__ part3, float* __restrict__ part1, int n3) {
+  constexpr int A3 = ConvGen<CIN, COUT, WDI, 3, 2, PT3>::ARR, A1 = ConvGen<CIN, COUT, WDI, 1, 2, PT1>::ARR;
+  __shared__ __attribute__((aligned(16))) __bf16 lds[3 * (A3 > A1 ? A3 : A1)];
+  if ((int)blockIdx.x < n3)
+    convgen_fwd_body<CIN, COUT, WDI, 3, 2, PT3>(x, w3, y3, H, total_rows, nlev, part3, lds, blockIdx.x, n3);
+  else
+    convgen_fwd_body<CIN, COUT, WDI, 1, 2, PT1>(x, w1, y1, H, total_rows, nlev, part1, lds, blockIdx.x - n3,
+                                                (int)gridDim.x - n3);
 }
 
 // ---- data gradient of the stride-2 transition convolutions -----------------------------------------------------------
@@ -500,33 +524,42 @@ __global__ __launch_bounds__(256) void convgen_fwd_kernel(const float* __restric
 // bins, registers), B[k][n = input pixel] = the dy pixel that tap reaches, or a zero pixel of the LDS image when the parity
 // does not match / the position lies outside (address select, no branch).  dy may arrive in the lazy batch-norm form.
 // H is the INPUT height (rows of dx), WDI its width; dy is [.., H/2, WDI/2, COUT].  PT input pixels (an even number of rows).
-template <int CIN, int COUT, int WDI, int KS, int PT>
-__global__ __launch_bounds__(256) void dgrad_s2_kernel(const float* __restrict__ dy, const float* __restrict__ w,
-                                                       float* __restrict__ dx, int H, int total_rows, float nlev,
-                                                       const float* __restrict__ add, BnLazy lazy) {
+// WITH1 (KS == 3): the data gradient of the block's 1x1 stride-2 shortcut convolution (same input, own output gradient dy1,
+// filter w1 and lazy batch-norm record) is accumulated in the same pass as a tenth tap (it reaches input pixel (2i, 2j) only,
+// from dy1 pixel (i, j)): its output pixels sit behind the 3x3 image in the LDS arrays.
+template <int CIN, int COUT, int WDI, int KS, int PT, bool WITH1>
+__device__ __forceinline__ void dgrad_s2_body(const float* __restrict__ dy, const float* __restrict__ w,
+                                              float* __restrict__ dx, int H, int total_rows, float nlev,
+                                              const float* __restrict__ add, BnLazy lazy, __bf16* lds, int block,
+                                              const float* __restrict__ dy1 = nullptr, const float* __restrict__ w1 = nullptr,
+                                              BnLazy lazy1 = BnLazy{nullptr, nullptr, nullptr, nullptr}) {
+  static_assert(!WITH1 || KS == 3, "the second source is the 1x1 shortcut of a 3x3 transition");
   constexpr int P = KS == 3 ? 1 : 0;
   constexpr int WDO = WDI / 2, TR = PT / WDI;
   constexpr int DROWS = TR / 2 + P, DCOLS = WDO + P;       // dy rows / columns the tile's taps can reach
   constexpr int CP = COUT + 8;
-  constexpr int NPIX = DROWS * DCOLS + 1;                  // + one all-zero pixel
+  constexpr int NPIX3 = DROWS * DCOLS + 1;                 // + one all-zero pixel
+  constexpr int NPIX1 = WITH1 ? (TR / 2) * WDO : 0;        // the 1x1 convolution's dy pixels of the tile
+  constexpr int NPIX = NPIX3 + NPIX1;
   constexpr int ARR = NPIX * CP;
-  constexpr int NT = KS * KS;
+  constexpr int NT = KS * KS + (WITH1 ? 1 : 0);
   constexpr int NS = (NT * COUT + 31) / 32;
   constexpr int NCG = CIN / 16, NPP = 4 / NCG, NG = PT / 16;
-  __shared__ __attribute__((aligned(16))) __bf16 lds[3 * ARR];
   __bf16* Xhi = lds;
   __bf16* Xmi = lds + ARR;
   __bf16* Xlo = lds + 2 * ARR;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int row0 = blockIdx.x * TR;                         // first INPUT row (image*H + ih), even
+  const int row0 = block * TR;                              // first INPUT row (image*H + ih), even
   const int Ho = H / 2;
   const int orow0 = (row0 / H) * Ho + (row0 % H) / 2;       // first dy row the tile reaches (ky = P)
   const int oimg_hi = (row0 / H + 1) * Ho;                  // end of the image's dy rows
   {
     constexpr int C4 = COUT / 4;
-    constexpr int N4 = NPIX * C4;
+    constexpr int N4 = NPIX3 * C4;
     constexpr int NIT = (N4 + 255) / 256;
-    float4 v[NIT], zz[NIT];
+    constexpr int M4 = NPIX1 * C4;
+    constexpr int NI1 = WITH1 ? (M4 + 255) / 256 : 1;
+    float4 v[NIT], zz[NIT], v1[NI1], z1[NI1];
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
       const int i = tid + 256 * it;
@@ -539,15 +572,24 @@ __global__ __launch_bounds__(256) void dgrad_s2_kernel(const float* __restrict__
       if (lazy.z) zz[it] = *reinterpret_cast<const float4*>(lazy.z + off);
       if (!ok) v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    if constexpr (WITH1) {
+#pragma unroll
+      for (int it = 0; it < NI1; it++) {       // rows orow0 .. orow0 + TR/2 - 1 of dy1: always inside the image
+        const int i = tid + 256 * it;
+        const int64_t off = i < M4 ? ((int64_t)orow0 * WDO) * COUT + 4 * (int64_t)i : 0;
+        v1[it] = *reinterpret_cast<const float4*>(dy1 + off);
+        if (lazy1.z) z1[it] = *reinterpret_cast<const float4*>(lazy1.z + off);
+      }
+    }
+    const int c4t = tid % C4;
     if (lazy.z) {
-      const int c4t = tid % C4;
       const float4 a4 = *reinterpret_cast<const float4*>(lazy.ab + 4 * c4t);
       const float4 m4 = *reinterpret_cast<const float4*>(lazy.save + 4 * c4t);
       const float4 i4 = *reinterpret_cast<const float4*>(lazy.save + COUT + 4 * c4t);
       float4 k0, k1;
       if (lazy.part) {           // (workgroup-uniform) see bn_totals_lds
         __shared__ __attribute__((aligned(16))) float kt[2 * COUT];
-        bn_totals_lds<COUT>(lazy, kt, blockIdx.x == 0);
+        bn_totals_lds<COUT>(lazy, kt, block == 0);
         k0 = *reinterpret_cast<const float4*>(kt + 4 * c4t);
         k1 = *reinterpret_cast<const float4*>(kt + COUT + 4 * c4t);
       } else {
@@ -563,13 +605,36 @@ __global__ __launch_bounds__(256) void dgrad_s2_kernel(const float* __restrict__
         if (ok) v[it] = bn_lazy4(v[it], zz[it], a4, m4, i4, k0, k1);
       }
     }
+    if constexpr (WITH1) {
+      if (lazy1.z) {
+        const float4 a4 = *reinterpret_cast<const float4*>(lazy1.ab + 4 * c4t);
+        const float4 m4 = *reinterpret_cast<const float4*>(lazy1.save + 4 * c4t);
+        const float4 i4 = *reinterpret_cast<const float4*>(lazy1.save + COUT + 4 * c4t);
+        float4 k0, k1;
+        if (lazy1.part) {
+          __shared__ __attribute__((aligned(16))) float kt1[2 * COUT];
+          bn_totals_lds<COUT>(lazy1, kt1, block == 0);
+          k0 = *reinterpret_cast<const float4*>(kt1 + 4 * c4t);
+          k1 = *reinterpret_cast<const float4*>(kt1 + COUT + 4 * c4t);
+        } else {
+          k0 = *reinterpret_cast<const float4*>(lazy1.ktot + 4 * c4t);
+          k1 = *reinterpret_cast<const float4*>(lazy1.ktot + COUT + 4 * c4t);
+        }
 #pragma unroll
-    for (int it = 0; it < NIT; it++) {
-      const int i = tid + 256 * it;
-      if (i < N4) {
-        const int c4 = i % C4, pix = i / C4;
+        for (int it = 0; it < NI1; it++) {
+          if (tid + 256 * it < M4) v1[it] = bn_lazy4(v1[it], z1[it], a4, m4, i4, k0, k1);
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT + (WITH1 ? NI1 : 0); it++) {
+      const bool second = it >= NIT;
+      const int i = tid + 256 * (second ? it - NIT : it);
+      if (i < (second ? M4 : N4)) {
+        const int c4 = i % C4, pix = (second ? NPIX3 : 0) + i / C4;
         bf16x4 h4, m4, l4;
-        const float vv[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+        const float4 src = second ? v1[second ? it - NIT : 0] : v[second ? 0 : it];
+        const float vv[4] = {src.x, src.y, src.z, src.w};
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           const __bf16 hi = (__bf16)vv[e];
@@ -593,7 +658,9 @@ __global__ __launch_bounds__(256) void dgrad_s2_kernel(const float* __restrict__
     const int tap = k0 / COUT, c0 = k0 % COUT;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-      const float v = tap < NT ? w[((int64_t)(c0 + j) * NT + tap) * CIN + cig * 16 + m] : 0.f;
+      float v = 0.f;
+      if (tap < KS * KS) v = w[((int64_t)(c0 + j) * (KS * KS) + tap) * CIN + cig * 16 + m];
+      else if (WITH1 && tap == KS * KS) v = w1[(int64_t)(c0 + j) * CIN + cig * 16 + m];
       ab[s][j] = (__bf16)rintf(v * nlev);
     }
   }
@@ -607,10 +674,12 @@ __global__ __launch_bounds__(256) void dgrad_s2_kernel(const float* __restrict__
       const int k0 = 32 * s + 8 * q;
       const int tap = k0 / COUT, c0 = k0 % COUT;
       int pix = DROWS * DCOLS;                              // the zero pixel
-      if (tap < NT) {
+      if (tap < KS * KS) {
         const int ky = tap / KS, kx = tap % KS;
         const int a = r + P - ky, b = c + P - kx;           // 2 * (dy row - orow0 ... ) when even and >= 0
         if (a >= 0 && b >= 0 && !(a & 1) && !(b & 1)) pix = (a >> 1) * DCOLS + (b >> 1);
+      } else if (WITH1 && tap == KS * KS) {
+        if (!(r & 1) && !(c & 1)) pix = NPIX3 + (r >> 1) * WDO + (c >> 1);
       }
       const int o = pix * CP + c0;
       const bf16x8 bh = *reinterpret_cast<const bf16x8*>(Xhi + o);
@@ -631,6 +700,20 @@ __global__ __launch_bounds__(256) void dgrad_s2_kernel(const float* __restrict__
       *reinterpret_cast<float4*>(dx + o) = out;
     }
   }
+}
+
+template <int CIN, int COUT, int WDI, int KS, int PT, bool WITH1>
+struct DgradS2Lds {
+  static constexpr int P = KS == 3 ? 1 : 0, TR = PT / WDI;
+  static constexpr int kBf16 = 3 * (((TR / 2 + P) * (WDI / 2 + P) + 1) + (WITH1 ? (TR / 2) * (WDI / 2) : 0)) * (COUT + 8);
+};
+
+template <int CIN, int COUT, int WDI, int KS, int PT>
+__global__ __launch_bounds__(256) void dgrad_s2_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                       float* __restrict__ dx, int H, int total_rows, float nlev,
+                                                       const float* __restrict__ add, BnLazy lazy) {
+  __shared__ __attribute__((aligned(16))) __bf16 lds[DgradS2Lds<CIN, COUT, WDI, KS, PT, false>::kBf16];
+  dgrad_s2_body<CIN, COUT, WDI, KS, PT, false>(dy, w, dx, H, total_rows, nlev, add, lazy, lds, blockIdx.x);
 }
 
 template <int CIN, int COUT, int WDI, int KS, int PT>
@@ -1158,6 +1241,41 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_kernel(const float* __restric
   }
 }
 
+// Backward of a transition block's two stride-2 convolutions (3x3 `conv0` and the 1x1 shortcut, same input x) in ONE
+// launch instead of four: workgroups [0, n_d) form the data gradient of BOTH convolutions (dgrad_s2_body<.., WITH1>; the longest
+// role, so it is dispatched first), the next n_w3 the 3x3 filter gradient's partial slabs, the rest the 1x1 filter gradient's.
+// The roles are independent.
+template <int CIN, int COUT, int WDI, int PTW3, int PTW1, int PTD>
+__global__ __launch_bounds__(256) void transition_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy3,
+                                                             const float* __restrict__ dy1, const float* __restrict__ w3,
+                                                             const float* __restrict__ w1, float* __restrict__ dx,
+                                                             float* __restrict__ slabs3, float* __restrict__ slabs1, int Ho,
+                                                             int n_tiles3, int n_tiles1, int splits3, int splits1, int n_d,
+                                                             float nlev, const float* __restrict__ add, BnLazy lazy3,
+                                                             BnLazy lazy1) {
+  using G3 = WgradGeo<CIN, COUT, WDI, 3, 2, PTW3>;
+  using G1 = WgradGeo<CIN, COUT, WDI, 1, 2, PTW1>;
+  constexpr int NBY = (COUT / G3::CB) * (CIN / G3::CB);
+  static_assert(G3::CB == G1::CB, "same channel blocking");
+  constexpr int kD = DgradS2Lds<CIN, COUT, WDI, 3, PTD, true>::kBf16 * 2;
+  constexpr int kW = G3::kBytes > G1::kBytes ? G3::kBytes : G1::kBytes;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kD > kW ? kD : kW];
+  const int n_w3 = splits3 * NBY;
+  const int b = blockIdx.x;
+  if (b < n_d) {           // (this role publishes the batch-norm parameter gradients of both records)
+    dgrad_s2_body<CIN, COUT, WDI, 3, PTD, true>(dy3, w3, dx, 2 * Ho, 0x7fffffff, nlev, add, lazy3,
+                                                reinterpret_cast<__bf16*>(lds), b, dy1, w1, lazy1);
+  } else if (b < n_d + n_w3) {
+    const int c = b - n_d;
+    wgrad_body<CIN, COUT, WDI, 3, 2, PTW3>(x, dy3, slabs3, Ho, n_tiles3, reinterpret_cast<float*>(lds), c % splits3, splits3,
+                                           c / splits3, lazy3);
+  } else {
+    const int c = b - n_d - n_w3;
+    wgrad_body<CIN, COUT, WDI, 1, 2, PTW1>(x, dy1, slabs1, Ho, n_tiles1, reinterpret_cast<float*>(lds), c % splits1, splits1,
+                                           c / splits1, lazy1);
+  }
+}
+
 // dW[e] = sum over slabs in a fixed order.  1024 threads = G slab groups x (1024 / G) elements with G = n_slabs / 16 clipped to
 // [1, 16] (a power of two): every thread owns (up to) 16 slab rows sl = g, g + G, ... and has all of them in flight at once;
 // the G partial sums of an element meet in LDS and are added in group order.  Few slabs (C = 64: 16) therefore mean wide
@@ -1311,6 +1429,42 @@ int launch_wgradgen(const float* x, const float* dy, float* dw, float* ws, int B
   hipLaunchKernelGGL(wgrad_reduce_kernel, wgrad_reduce_blocks(splits, n_elem), 1024, 0, st, ws, splits, n_elem, dw);
   e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
+}
+
+template <int CIN, int COUT, int WDI, int PT3, int PT1>
+int launch_transition_fwd(const float* x, const float* w3, const float* w1, float* y3, float* y1, int B, int H, float nlev,
+                          float* part3, float* part1, hipStream_t st) {
+  constexpr int TR3 = ConvGen<CIN, COUT, WDI, 3, 2, PT3>::TR, TR1 = ConvGen<CIN, COUT, WDI, 1, 2, PT1>::TR;
+  if (H % TR3 || H % TR1) return ALIGNQ_EUNSUPPORTED;
+  const int total_rows = B * H, n3 = total_rows / TR3, n1 = total_rows / TR1;
+  hipLaunchKernelGGL((transition_fwd_kernel<CIN, COUT, WDI, PT3, PT1>), n3 + n1, 256, 0, st, x, w3, w1, y3, y1, H, total_rows,
+                     nlev, part3, part1, n3);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+template <int CIN, int COUT, int WDI, int PTW3, int PTW1, int PTD>
+int launch_transition_bwd(const float* x, const float* dy3, const float* dy1, const float* w3, const float* w1, float* dx,
+                          float* ws3, float* ws1, int B, int Ho, float nlev, int* ns3, int* ns1, const float* add,
+                          BnLazy lazy3, BnLazy lazy1, hipStream_t st) {
+  using G3 = WgradGeo<CIN, COUT, WDI, 3, 2, PTW3>;
+  using G1 = WgradGeo<CIN, COUT, WDI, 1, 2, PTW1>;
+  constexpr int TRD = PTD / WDI;
+  if (Ho % G3::TR || Ho % G1::TR || (2 * Ho) % TRD) return ALIGNQ_EUNSUPPORTED;
+  const int n_tiles3 = B * Ho / G3::TR, n_tiles1 = B * Ho / G1::TR;
+  constexpr int NBY = (COUT / G3::CB) * (CIN / G3::CB);
+  // the same pixel ranges as the stand-alone filter-gradient launches (so the slabs, hence dW, are bit-identical to theirs)
+  int splits3 = 256 / NBY, splits1 = 256 / NBY;
+  if (splits3 > n_tiles3) splits3 = n_tiles3;
+  if (splits1 > n_tiles1) splits1 = n_tiles1;
+  const int n_d = B * 2 * Ho / TRD;
+  hipLaunchKernelGGL((transition_bwd_kernel<CIN, COUT, WDI, PTW3, PTW1, PTD>), (splits3 + splits1) * NBY + n_d, 256, 0, st, x,
+                     dy3, dy1, w3, w1, dx, ws3, ws1, Ho, n_tiles3, n_tiles1, splits3, splits1, n_d, nlev, add, lazy3, lazy1);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  *ns3 = splits3;
+  *ns1 = splits1;
+  return 0;
 }
 
 }  // namespace
@@ -1505,6 +1659,62 @@ int alignq_conv_gen_nhwc_dgrad(const float* dy, const float* wt, float* dx, int 
   if (CIN == 16 && KS == 1) return launch_dgrad_s2<16, 32, 32, 1, 128>(dy, wt, dx, B, H_in, nlev, add, lazy, st);
   if (CIN == 32 && KS == 3) return launch_dgrad_s2<32, 64, 16, 3, 128>(dy, wt, dx, B, H_in, nlev, add, lazy, st);
   if (CIN == 32 && KS == 1) return launch_dgrad_s2<32, 64, 16, 1, 128>(dy, wt, dx, B, H_in, nlev, add, lazy, st);
+  return ALIGNQ_EUNSUPPORTED;
+}
+
+// Both convolutions of a transition block in one launch each way (shapes of alignq_conv_gen_nhwc_fwd; wt3 [COUT,3,3,CIN], wt1
+// [COUT,1,1,CIN], the same w_bit): y3 / y1 [B,H_in/2,W_in/2,COUT]; bn_part3 / bn_part1 as alignq_conv_gen_nhwc_fwd's for KS = 3 /
+// KS = 1.  Results are bit-identical to the two (forward) / four (backward) separate launches.
+int alignq_transition_nhwc_fwd(const float* x, const float* wt3, const float* wt1, float* y3, float* y1, int B, int H_in,
+                               int W_in, int CIN, int COUT, int w_bit, float* bn_part3, float* bn_part1, void* stream) {
+  if (!x || !wt3 || !wt1 || !y3 || !y1 || B < 1) return ALIGNQ_EINVAL;
+  if (w_bit < 1 || w_bit > 8 || !alignq_conv_gen_bn_parts(B, H_in, W_in, CIN, COUT, 3, 2) ||
+      !alignq_conv_gen_bn_parts(B, H_in, W_in, CIN, COUT, 1, 2))
+    return ALIGNQ_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(wt3) | reinterpret_cast<uintptr_t>(wt1) |
+       reinterpret_cast<uintptr_t>(y3) | reinterpret_cast<uintptr_t>(y1)) & 15)
+    return ALIGNQ_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const float nlev = (float)((1 << w_bit) - 1);
+  const int H = H_in / 2;
+  if (CIN == 16) return launch_transition_fwd<16, 32, 32, 64, 128>(x, wt3, wt1, y3, y1, B, H, nlev, bn_part3, bn_part1, st);
+  if (CIN == 32) return launch_transition_fwd<32, 64, 16, 32, 64>(x, wt3, wt1, y3, y1, B, H, nlev, bn_part3, bn_part1, st);
+  return ALIGNQ_EUNSUPPORTED;
+}
+
+// dx [B,H_in,W_in,CIN] = data gradient of BOTH convolutions (+ add), and the partial-sum slabs of both filter gradients
+// (ws3 / ws1 = alignq_conv_gen_wgrad_ws_bytes for KS = 3 / 1; *n_slabs3 / *n_slabs1 slabs are left for
+// alignq_conv3x3_wgrad_reduce_multi).  bn3_* / bn1_*: the lazy batch-norm form of dy3 / dy1 as in alignq_conv_gen_nhwc_dgrad.
+int alignq_transition_nhwc_bwd(const float* x, const float* dy3, const float* dy1, const float* wt3, const float* wt1,
+                               float* dx, void* ws3, void* ws1, int B, int H_in, int W_in, int CIN, int COUT, int w_bit,
+                               int* n_slabs3, int* n_slabs1, const float* add,
+                               const float* bn3_z, const float* bn3_ab, const float* bn3_save, const float* bn3_ktot,
+                               const float* bn3_dx_part, float* bn3_dgamma, float* bn3_dbeta,
+                               const float* bn1_z, const float* bn1_ab, const float* bn1_save, const float* bn1_ktot,
+                               const float* bn1_dx_part, float* bn1_dgamma, float* bn1_dbeta, void* stream) {
+  if (!x || !dy3 || !dy1 || !wt3 || !wt1 || !dx || !ws3 || !ws1 || !n_slabs3 || !n_slabs1 || B < 1) return ALIGNQ_EINVAL;
+  if (bn3_z && (!bn3_ab || !bn3_save || (!bn3_ktot && !bn3_dx_part))) return ALIGNQ_EINVAL;
+  if (bn1_z && (!bn1_ab || !bn1_save || (!bn1_ktot && !bn1_dx_part))) return ALIGNQ_EINVAL;
+  if (w_bit < 1 || w_bit > 8 || !alignq_conv_gen_bn_parts(B, H_in, W_in, CIN, COUT, 3, 2) ||
+      !alignq_conv_gen_bn_parts(B, H_in, W_in, CIN, COUT, 1, 2))
+    return ALIGNQ_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy3) | reinterpret_cast<uintptr_t>(dy1) |
+       reinterpret_cast<uintptr_t>(wt3) | reinterpret_cast<uintptr_t>(wt1) | reinterpret_cast<uintptr_t>(dx) |
+       reinterpret_cast<uintptr_t>(add)) & 15)
+    return ALIGNQ_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const float nlev = (float)((1 << w_bit) - 1);
+  BnLazy lazy3{bn3_z, bn3_ab, bn3_save, bn3_ktot}, lazy1{bn1_z, bn1_ab, bn1_save, bn1_ktot};
+  const int HWo = (H_in / 2) * (W_in / 2);
+  if (int rc = lazy_parts(lazy3, bn3_dx_part, bn3_dgamma, bn3_dbeta, B, COUT, HWo)) return rc;
+  if (int rc = lazy_parts(lazy1, bn1_dx_part, bn1_dgamma, bn1_dbeta, B, COUT, HWo)) return rc;
+  const int Ho = H_in / 2;
+  if (CIN == 16)
+    return launch_transition_bwd<16, 32, 32, 64, 128, 128>(x, dy3, dy1, wt3, wt1, dx, (float*)ws3, (float*)ws1, B, Ho, nlev,
+                                                          n_slabs3, n_slabs1, add, lazy3, lazy1, st);
+  if (CIN == 32)
+    return launch_transition_bwd<32, 64, 16, 64, 64, 128>(x, dy3, dy1, wt3, wt1, dx, (float*)ws3, (float*)ws1, B, Ho, nlev,
+                                                         n_slabs3, n_slabs1, add, lazy3, lazy1, st);
   return ALIGNQ_EUNSUPPORTED;
 }
 

@@ -678,6 +678,90 @@ class QConvGenFn(torch.autograd.Function):
         return out
 
 
+class QTransitionFn(torch.autograd.Function):
+    """(conv0(x), skip_conv(x)) of a transition block — the 3x3 and the 1x1 stride-2 Conv2d_Q reading the same input
+    (model/resnet.py PreActBlock_conv_Q.forward) — as ONE launch each way (alignq_transition_nhwc_fwd / _bwd) instead of two
+    forward and four backward launches.  Both outputs carry their batch-norm partial statistics and lazy-gradient links like
+    QConvGenFn's; values equal the separate launches'."""
+
+    _mailbox = None
+
+    @staticmethod
+    def forward(ctx, x, w3, w1, w_bit):
+        B, CIN, H, W = x.shape
+        COUT = w3.shape[0]
+        lib = L.load()
+        cl = torch.channels_last
+        y3 = torch.empty((B, COUT, H // 2, W // 2), dtype=torch.float32, device=x.device, memory_format=cl)
+        y1 = torch.empty((B, COUT, H // 2, W // 2), dtype=torch.float32, device=x.device, memory_format=cl)
+        n3 = lib.alignq_conv_gen_bn_parts(B, H, W, CIN, COUT, 3, 2)
+        n1 = lib.alignq_conv_gen_bn_parts(B, H, W, CIN, COUT, 1, 2)
+        part3 = torch.empty(COUT, n3, 2, dtype=torch.float32, device=x.device)
+        part1 = torch.empty(COUT, n1, 2, dtype=torch.float32, device=x.device)
+        L.check(lib.alignq_transition_nhwc_fwd(L.ptr(x), L.ptr(w3), L.ptr(w1), L.ptr(y3), L.ptr(y1), B, H, W, CIN, COUT,
+                                               int(w_bit), L.ptr(part3), L.ptr(part1), L.stream_ptr()),
+                "alignq_transition_nhwc_fwd")
+        ctx.save_for_backward(x, w3, w1)
+        ctx.w_bit = int(w_bit)
+        ctx.link3, ctx.link1 = fused.LazyLink(), fused.LazyLink()
+        # mode 2: the data-gradient role reduces the site backward's per-tile sums and publishes the BN parameter gradients
+        QTransitionFn._mailbox = ((part3, n3, 2, ctx.link3), (part1, n1, 2, ctx.link1))
+        return y3, y1
+
+    @staticmethod
+    def backward(ctx, gy3, gy1):
+        x, w3, w1 = ctx.saved_tensors
+        lazy3 = fused.take_lazy_dz(ctx.link3, gy3)
+        lazy1 = fused.take_lazy_dz(ctx.link1, gy1)
+        cl = torch.channels_last
+        gy3, gy1 = gy3.contiguous(memory_format=cl), gy1.contiguous(memory_format=cl)
+        B, CIN, H, W = x.shape
+        COUT = w3.shape[0]
+        HWo = (H // 2) * (W // 2)
+        f3 = _lazy_fields(lazy3, False, B, COUT, HWo, x.device)
+        f1 = _lazy_fields(lazy1, False, B, COUT, HWo, x.device)
+        lib = L.load()
+        dx = torch.empty_like(x)
+        dw3, dw1 = torch.empty_like(w3), torch.empty_like(w1)
+        ws3 = _ws(lib.alignq_conv_gen_wgrad_ws_bytes(CIN, COUT, 3), x.device)
+        ws1 = _ws(lib.alignq_conv_gen_wgrad_ws_bytes(CIN, COUT, 1), x.device)
+        ns3, ns1 = ctypes.c_int(0), ctypes.c_int(0)
+        L.check(lib.alignq_transition_nhwc_bwd(
+            L.ptr(x), L.ptr(gy3), L.ptr(gy1), L.ptr(w3), L.ptr(w1), L.ptr(dx), L.ptr(ws3), L.ptr(ws1), B, H, W, CIN, COUT,
+            ctx.w_bit, ctypes.byref(ns3), ctypes.byref(ns1), None, *[L.ptr(t) for t in f3], *[L.ptr(t) for t in f1],
+            L.stream_ptr()), "alignq_transition_nhwc_bwd")
+        pending = fused.active_wgrads()
+        if pending is not None:
+            pending.add(ws3, dw3, ns3.value, 9 * CIN * COUT)
+            pending.add(ws1, dw1, ns1.value, CIN * COUT)
+        else:
+            L.check(lib.alignq_conv3x3_wgrad_reduce_multi(
+                2, L.ptr_array([ws3, ws1]), L.ptr_array([dw3, dw1]), (ctypes.c_int * 2)(ns3.value, ns1.value),
+                (ctypes.c_int * 2)(9 * CIN * COUT, CIN * COUT), L.stream_ptr()), "alignq_conv3x3_wgrad_reduce_multi")
+        return dx, dw3, dw1, None
+
+    @staticmethod
+    def apply_with_stats(x, w3, w1, w_bit):
+        QTransitionFn._mailbox = None
+        y3, y1 = QTransitionFn.apply(x, w3, w1, w_bit)
+        if QTransitionFn._mailbox is not None:
+            y3._alignq_bn_part, y1._alignq_bn_part = QTransitionFn._mailbox
+            QTransitionFn._mailbox = None
+        return y3, y1
+
+
+def transition_supported(conv3, conv1, x, w3, w1) -> bool:
+    """Both convolutions of a transition block on this repository's kernels, gradients needed for x and both filters."""
+    if not (getattr(conv3, "use_qconv", False) and getattr(conv1, "use_qconv", False)):
+        return False
+    if conv3.quantize_fn.w_bit != conv1.quantize_fn.w_bit or not (x.requires_grad and w3.requires_grad and w1.requires_grad):
+        return False
+    a3 = (x, w3, conv3.stride, conv3.padding, conv3.dilation, conv3.groups, conv3.bias, conv3.quantize_fn.w_bit)
+    a1 = (x, w1, conv1.stride, conv1.padding, conv1.dilation, conv1.groups, conv1.bias, conv1.quantize_fn.w_bit)
+    return (tuple(w3.shape[2:]) == (3, 3) and tuple(w1.shape[2:]) == (1, 1) and qconv_gen_supported(*a3)
+            and qconv_gen_supported(*a1))
+
+
 def qconv_stem_supported(x, w, stride, padding, dilation, groups, bias, w_bit) -> bool:
     """The stem convolution alignq_conv_stem_nhwc_fwd implements: 3 -> 16 channels, 3x3 / stride 1 / padding 1, width 32,
     channels-last fp32 input that needs no gradient, <= 8-bit quantised filter."""

@@ -20,6 +20,20 @@ from .admm import ADMM
 from .fused import bn_site
 
 
+def _transition_pair(conv3, conv1, x):
+    """(conv3(x), conv1(x)) through ops.QTransitionFn when both stride-2 convolutions of a transition block run on this
+    repository's kernels (TrainStep(channels_last=True, qconv=True)); None otherwise (the caller takes the separate path)."""
+    if not (getattr(conv3, "use_qconv", False) and getattr(conv1, "use_qconv", False) and x.is_cuda):
+        return None
+    from . import ops
+    # (decided on the parameters: the quantised filters have their shape, layout and gradient requirement, and a quantiser
+    # call consumes the pre-quantised tensor parked for it)
+    if not ops.transition_supported(conv3, conv1, x, conv3.weight, conv1.weight):
+        return None
+    w3, w1 = conv3.quantize_fn(conv3.weight), conv1.quantize_fn(conv1.weight)
+    return ops.QTransitionFn.apply_with_stats(x, w3, w1, conv3.quantize_fn.w_bit)
+
+
 class PreActBlock_conv_Q(nn.Module):
     """Pre-activation basic block; `tree` selects the ADMM (tuple-returning) or CDF-only activation fn."""
 
@@ -71,8 +85,13 @@ class PreActBlock_conv_Q(nn.Module):
     def forward(self, x):
         trans_loss = 0.
         if self.skip_conv is not None:
-            z0, xa = self.conv0.forward_with_shortcut(x)            # xa = x (skip_conv's input gradient joins conv0's)
-            shortcut, loss = self._bnq(self.skip_bn, self.act_skip_q, self.skip_conv(xa))
+            pair = _transition_pair(self.conv0, self.skip_conv, x)   # both stride-2 convolutions in one launch each way
+            if pair is not None:
+                z0, zs = pair
+            else:
+                z0, xa = self.conv0.forward_with_shortcut(x)        # xa = x (skip_conv's input gradient joins conv0's)
+                zs = self.skip_conv(xa)
+            shortcut, loss = self._bnq(self.skip_bn, self.act_skip_q, zs)
             trans_loss += loss
         else:
             z0, shortcut = self.conv0.forward_with_shortcut(x)      # shortcut = x (its gradient joins conv0's data gradient)

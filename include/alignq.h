@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALIGNQ_ABI_VERSION 5
+#define ALIGNQ_ABI_VERSION 6
 
 #define ALIGNQ_FORMULA_ADMM 0
 #define ALIGNQ_FORMULA_CDF 1
@@ -254,6 +254,24 @@ int alignq_conv_gen_nhwc_dgrad(const float* dy, const float* wt, float* dx, int 
                                int stride, int w_bit, const float* add, const float* bn_z, const float* bn_ab,
                                const float* bn_save, const float* bn_ktot, const float* bn_dx_part, float* bn_dgamma,
                                float* bn_dbeta, void* stream);
+
+/* Both convolutions of a transition block (the 3x3 `conv0` and the 1x1 `skip_conv`, stride 2, reading the SAME input;
+ * reference: model/resnet.py PreActBlock_conv_Q.forward, `self.skip_conv(x)` and `self.conv0(x)`) in ONE launch each way: a launch
+ * boundary costs more than the 1x1 convolution.  Shapes of alignq_conv_gen_nhwc_fwd; wt3 [COUT,3,3,CIN], wt1 [COUT,1,1,CIN], one
+ * w_bit.  Forward: workgroup roles (3x3 | 1x1).  Backward: roles (data gradient of both convolutions, the 1x1 one entering as a
+ * tenth tap | 3x3 filter-gradient slabs | 1x1 filter-gradient slabs); ws3 / ws1 = alignq_conv_gen_wgrad_ws_bytes(.., 3 / 1), the
+ * slabs are left for alignq_conv3x3_wgrad_reduce_multi (*n_slabs3 / *n_slabs1); bn3_* / bn1_*: lazy batch-norm form of dy3 / dy1
+ * as in alignq_conv_gen_nhwc_dgrad; add (or NULL) joins dx.  Results equal the separate launches' (y, bn_part, dW bit for bit;
+ * dx to fp32 accumulation order).                                                                                          */
+int alignq_transition_nhwc_fwd(const float* x, const float* wt3, const float* wt1, float* y3, float* y1, int B, int H_in,
+                               int W_in, int CIN, int COUT, int w_bit, float* bn_part3, float* bn_part1, void* stream);
+int alignq_transition_nhwc_bwd(const float* x, const float* dy3, const float* dy1, const float* wt3, const float* wt1,
+                               float* dx, void* ws3, void* ws1, int B, int H_in, int W_in, int CIN, int COUT, int w_bit,
+                               int* n_slabs3, int* n_slabs1, const float* add,
+                               const float* bn3_z, const float* bn3_ab, const float* bn3_save, const float* bn3_ktot,
+                               const float* bn3_dx_part, float* bn3_dgamma, float* bn3_dbeta,
+                               const float* bn1_z, const float* bn1_ab, const float* bn1_save, const float* bn1_ktot,
+                               const float* bn1_dx_part, float* bn1_dgamma, float* bn1_dbeta, void* stream);
 
 /* The stem (3 -> 16 channels, 3x3, stride 1, padding 1, width 32; x [B,H,32,3], wt [16,3,3,3], y [B,H,32,16], channels-last):
  * forward with the optional batch-norm partials, and its filter gradient (ws: 256 * 432 floats); K = 27 is one MFMA k step

@@ -25,12 +25,12 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.alignq_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.alignq_abi_version() == _lib.ABI_VERSION == 6
     assert b"invalid" in lib.alignq_strerror(-1)
     # pure host-side queries are safe without a GPU
     tail = 1024 + 16                                     # loss partials + arrival counter
-    assert lib.alignq_site_ws_bytes(128, 16384) == (256 * 10 * 1024 + tail) * 4   # 10 upper-triangular 32x32 tiles
-    assert lib.alignq_site_ws_bytes(128, 4096) == (256 * 10 * 1024 + tail) * 4    # 16-feature tiles keep 256 CUs busy
+    assert lib.alignq_site_ws_bytes(128, 16384) == (256 * 8256 + tail) * 4   # 6 off-diagonal 32x32 tiles + 2 packed [32][33] blocks
+    assert lib.alignq_site_ws_bytes(128, 4096) == (256 * 8256 + tail) * 4    # 16-feature tiles keep 256 CUs busy
     assert lib.alignq_site_ws_bytes(28, 802816) == (2048 * 32 * 32 + tail) * 4
     assert lib.alignq_site_ws_bytes(28, 1024) == (8 * 32 * 32 + tail) * 4            # 32 sub-tiles of 32 features / 4 waves
     assert lib.alignq_site_ws_bytes(129, 64) == 0
