@@ -75,7 +75,9 @@ SIGNATURES = {
                                      _i, _i, _vp]),
     "alignq_bn_bwd_totals": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "alignq_conv3x3_wgrad_reduce_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
-    "alignq_head_ce_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "alignq_head_ce_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "alignq_head_ce_bwd_site_prep": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp,
+                                          _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "alignq_head_ce_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "alignq_bucket_copy_multi": (_i, [_i, _vp, _vp, _vp, _i, _vp]),
     "alignq_bn_ws_bytes": (_sz, [_i]),

@@ -7,21 +7,27 @@
 #include <stdint.h>
 
 #include "../../include/alignq.h"
+#include "alignq_math.h"
+#include "head_body.h"
 
 namespace {
 
-constexpr int kMaxC = 256, kMaxK = 64;
+using alignq_head::kMaxC;
+using alignq_head::kMaxK;
 
 // one workgroup per sample: pooled[c] = mean_p feat[b][p][c]; logits = W pooled + bias; log-softmax; loss_b; probs
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ W,
                                                        const float* __restrict__ bias, const int64_t* __restrict__ target,
                                                        int HW, int C, int K, float* __restrict__ pooled,
                                                        float* __restrict__ logits, float* __restrict__ probs,
-                                                       float* __restrict__ loss) {
+                                                       float* __restrict__ loss, float* __restrict__ ce_mean,
+                                                       unsigned* __restrict__ counter, const float* __restrict__ site_scal,
+                                                       int n_sites, float* __restrict__ trans_total) {
   __shared__ float sp[kMaxC];
   __shared__ float sl[kMaxK];
   const int b = blockIdx.x, tid = threadIdx.x;
   __shared__ float spart[256];
+  __shared__ int is_last;
   {   // thread -> (channel, pixel part): 256 / C parts, 8 loads in flight, then a fixed-order sum over the parts
     const int parts = 256 / C > 0 ? 256 / C : 1;
     const int c = tid % C, part = tid / C;
@@ -68,78 +74,46 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
     probs[(int64_t)b * K + tid] = expf(sl[tid] - lse);
     if (tid == 0) {
       const int64_t y = target[b];
-      loss[b] = (y >= 0 && y < K) ? lse - sl[y] : 0.f;
+      const float lb = (y >= 0 && y < K) ? lse - sl[y] : 0.f;
+      if (!ce_mean) {
+        loss[b] = lb;
+      } else {
+        // mean over the batch (and the sum of the sites' trans losses) without a launch of their own: the workgroup whose
+        // ticket is last adds the per-sample losses in index order.  Hand-off as in slab_reduce_body: write-through store,
+        // drain, one relaxed agent-scope ticket; the last workgroup reads with agent-scope loads.
+        __hip_atomic_store(&loss[b], lb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned tk = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = (tk == gridDim.x - 1);
+      }
+    }
+  }
+  if (!ce_mean) return;
+  __syncthreads();
+  if (!is_last || tid >= 64) return;
+  {
+    const int B = gridDim.x;
+    double s = 0.0;
+    for (int i = tid; i < B; i += 64) s += (double)__hip_atomic_load(&loss[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s = alignq::wave_sum_d_dpp(s);
+    double t = 0.0;
+    if (site_scal)
+      for (int i = tid; i < n_sites; i += 64) t += (double)site_scal[4 * i];   // scal = {loss, c_con, 1/n, rms} per site
+    t = alignq::wave_sum_d_dpp(t);
+    if (tid == 0) {
+      ce_mean[0] = (float)(s / (double)B);
+      if (trans_total) trans_total[0] = (float)t;
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-arm
     }
   }
 }
 
-// blocks [0, B): dfeat[b][p][c] = (1/HW) sum_j dl[b][j] W[j][c] for every pixel p;  blocks [B, B+K): dW[j][:], dbias[j]
-// with dl[b][j] = g * (probs[b][j] - [j == target_b]) / B   (mean reduction of the loss; g = upstream scalar)
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ g, const float* __restrict__ probs,
                                                        const int64_t* __restrict__ target, const float* __restrict__ pooled,
                                                        const float* __restrict__ W, int B, int HW, int C, int K,
                                                        float* __restrict__ dfeat, float* __restrict__ dW,
                                                        float* __restrict__ dbias) {
-  __shared__ float sd[kMaxK];
-  const int tid = threadIdx.x;
-  const float gs = g[0] / (float)B;
-  __shared__ float sdl[1024];
-  __shared__ float spart[256];
-  const int parts = 256 / C > 0 ? 256 / C : 1;
-  const int c = tid % C, part = tid / C;
-  if ((int)blockIdx.x < B) {
-    const int b = blockIdx.x;
-    if (tid < K) sd[tid] = gs * (probs[(int64_t)b * K + tid] - (target[b] == tid ? 1.f : 0.f));
-    __syncthreads();
-    if (part < parts) {
-      float s = 0.f;
-      for (int j = 0; j < K; j++) s = __fmaf_rn(sd[j], W[(int64_t)j * C + c], s);
-      s = s / (float)HW;
-      float* p = dfeat + (int64_t)b * HW * C + c;
-      const int per = (HW + parts - 1) / parts;
-      const int i0 = part * per, i1 = (i0 + per < HW) ? i0 + per : HW;
-      for (int i = i0; i < i1; i++) p[(int64_t)i * C] = s;
-    }
-  } else {
-    const int j = blockIdx.x - B;
-    // dl[b] for this class (B <= 1024 staged in LDS; larger batches fall back to recomputing in the loop)
-    const bool staged = B <= 1024;
-    if (staged)
-      for (int b = tid; b < B; b += 256) sdl[b] = gs * (probs[(int64_t)b * K + j] - (target[b] == j ? 1.f : 0.f));
-    __syncthreads();
-    float dw = 0.f;
-    if (part < parts) {
-      const int per = (B + parts - 1) / parts;
-      const int b0 = part * per, b1 = (b0 + per < B) ? b0 + per : B;
-      int b = b0;
-      for (; b + 8 <= b1; b += 8) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = pooled[(int64_t)(b + u) * C + c];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-          const float d = staged ? sdl[b + u] : gs * (probs[(int64_t)(b + u) * K + j] - (target[b + u] == j ? 1.f : 0.f));
-          dw = __fmaf_rn(d, v[u], dw);
-        }
-      }
-      for (; b < b1; b++) {
-        const float d = staged ? sdl[b] : gs * (probs[(int64_t)b * K + j] - (target[b] == j ? 1.f : 0.f));
-        dw = __fmaf_rn(d, pooled[(int64_t)b * C + c], dw);
-      }
-    }
-    spart[tid] = dw;
-    __syncthreads();
-    if (tid < C) {
-      float t = 0.f;
-      for (int q = 0; q < parts; q++) t += spart[q * C + tid];
-      dW[(int64_t)j * C + tid] = t;
-    }
-    if (tid == 0 && dbias) {
-      float db = 0.f;
-      for (int b = 0; b < B; b++) db += staged ? sdl[b] : gs * (probs[(int64_t)b * K + j] - (target[b] == j ? 1.f : 0.f));
-      dbias[j] = db;
-    }
-  }
+  alignq_head::head_bwd_body(g, probs, target, pooled, W, B, HW, C, K, dfeat, dW, dbias, blockIdx.x);
 }
 
 }  // namespace
@@ -147,11 +121,13 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 extern "C" {
 
 int alignq_head_ce_fwd(const float* feat, const float* W, const float* bias, const int64_t* target, int B, int HW, int C, int K,
-                       float* pooled, float* logits, float* probs, float* loss, void* stream) {
+                       float* pooled, float* logits, float* probs, float* loss, float* ce_mean, unsigned* counter,
+                       const float* site_scal, int n_sites, float* trans_total, void* stream) {
   if (!feat || !W || !target || !pooled || !logits || !probs || !loss || B < 1 || HW < 1) return ALIGNQ_EINVAL;
+  if ((ce_mean && !counter) || (site_scal && (!ce_mean || !trans_total || n_sites < 1))) return ALIGNQ_EINVAL;
   if (C < 1 || C > kMaxC || K < 1 || K > kMaxK) return ALIGNQ_EUNSUPPORTED;
   hipLaunchKernelGGL(head_fwd_kernel, B, 256, 0, (hipStream_t)stream, feat, W, bias, target, HW, C, K, pooled, logits, probs,
-                     loss);
+                     loss, ce_mean, counter, site_scal, n_sites, trans_total);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }

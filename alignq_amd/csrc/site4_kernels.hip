@@ -19,6 +19,7 @@
 #include "../../include/alignq.h"
 #include "alignq_math.h"
 #include "site_internal.h"
+#include "head_body.h"
 
 using namespace alignq;
 
@@ -914,13 +915,14 @@ __device__ __forceinline__ void site_prep_body(const float* __restrict__ dD, con
                                                         int dim, const float* __restrict__ scal, float mu,
                                                         const float* __restrict__ gscale, int B, float invF,
                                                         float* __restrict__ S, float* __restrict__ dA_out,
-                                                        float* __restrict__ dG_out) {
+                                                        float* __restrict__ dG_out, int bx, int gx) {
+  // bx / gx: index and count of the 256-thread workgroups working on THIS site (a launch may carry other roles)
   const float gs = gscale ? gscale[0] : 1.0f;
   const int total = FUSED ? dim * dim : B * B;
   const int side = FUSED ? dim : B;
   const float c_con = FUSED ? scal[1] : 0.f, inv_n = FUSED ? scal[2] : 0.f;
   const bool image = B > 64;                 // only the B in (64,128] backward reads it
-  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+  for (int e = bx * 256 + threadIdx.x; e < total; e += gx * 256) {
     const int i = e / side, j = e - i * side;
     if (i < B && j < B) {
       float gij, gji;
@@ -946,7 +948,7 @@ __device__ __forceinline__ void site_prep_body(const float* __restrict__ dD, con
     }
   }
   if (image && B < 128) {                    // zero padding of the image (rows / columns B..127)
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < 128 * 128; e += gridDim.x * 256) {
+    for (int e = bx * 256 + threadIdx.x; e < 128 * 128; e += gx * 256) {
       const int i = e >> 7, j = e & 127;
       if (i >= B || j >= B) s_image_store(S, i, j, 0.0f);
     }
@@ -960,7 +962,7 @@ __global__ __launch_bounds__(256) void site_prep_kernel(const float* __restrict_
                                                         const float* __restrict__ gscale, int B, float invF,
                                                         float* __restrict__ S, float* __restrict__ dA_out,
                                                         float* __restrict__ dG_out) {
-  site_prep_body<FUSED>(dD, D, A, gamma, dim, scal, mu, gscale, B, invF, S, dA_out, dG_out);
+  site_prep_body<FUSED>(dD, D, A, gamma, dim, scal, mu, gscale, B, invF, S, dA_out, dG_out, blockIdx.x, gridDim.x);
 }
 
 struct PChunk {
@@ -977,7 +979,26 @@ __global__ __launch_bounds__(256) void site_prep_multi_kernel(PChunk c, int dim,
                                                               int B) {
   const int s = blockIdx.y;
   site_prep_body<true>(nullptr, c.D[s], c.A[s], c.gamma[s], dim, c.scal[s], mu, gscale, B, c.invF[s], c.S[s], c.dA[s],
-                       c.dG[s]);
+                       c.dG[s], blockIdx.x, gridDim.x);
+}
+
+// The classifier head's backward and the preparation of every site's S / dalterD / dgamma in ONE launch (two independent roles:
+// the first n_head workgroups are alignq_head::head_bwd_body's B + K, the rest the sites' gx each).
+struct HeadBwdArgs {
+  const float* g; const float* probs; const int64_t* target; const float* pooled; const float* W;
+  int B, HW, C, K;
+  float* dfeat; float* dW; float* dbias;
+};
+__global__ __launch_bounds__(256) void head_bwd_prep_multi_kernel(HeadBwdArgs h, int n_head, PChunk c, int dim, float mu,
+                                                                  const float* __restrict__ gscale, int B, int gx) {
+  const int b = blockIdx.x;
+  if (b < n_head) {
+    alignq_head::head_bwd_body(h.g, h.probs, h.target, h.pooled, h.W, h.B, h.HW, h.C, h.K, h.dfeat, h.dW, h.dbias, b);
+  } else {
+    const int r = b - n_head, s = r / gx, bx = r - s * gx;
+    site_prep_body<true>(nullptr, c.D[s], c.A[s], c.gamma[s], dim, c.scal[s], mu, gscale, B, c.invF[s], c.S[s], c.dA[s],
+                         c.dG[s], bx, gx);
+  }
 }
 
 // ================================================================================================ backward
@@ -1612,6 +1633,28 @@ int launch_prep_multi(int S, const float* const* D, const float* const* alterD, 
     hipLaunchKernelGGL(site_prep_multi_kernel, dim3((dim * dim + 255) / 256, cnt), 256, 0, st, c, dim, mu, gscale, B);
     RET_ON_ERR();
   }
+  return 0;
+}
+
+int launch_head_bwd_prep_multi(const float* g_ce, const float* probs, const int64_t* target, const float* pooled, const float* W,
+                               int HB, int HW, int C, int K, float* dfeat, float* dW, float* dbias, int S, const float* const* D,
+                               const float* const* alterD, const float* const* gamma, const float* const* scal,
+                               const float* gscale, const int64_t* F, int B, int dim, float mu, float* const* Sout,
+                               float* const* dA, float* const* dG, hipStream_t st) {
+  if (C < 1 || C > alignq_head::kMaxC || K < 1 || K > alignq_head::kMaxK) return ALIGNQ_EUNSUPPORTED;
+  const int cnt = S < kMultiSites ? S : kMultiSites;          // the first chunk of sites rides with the head
+  PChunk c;
+  for (int i = 0; i < cnt; i++) {
+    c.D[i] = D[i]; c.A[i] = alterD[i]; c.gamma[i] = gamma[i]; c.scal[i] = scal[i];
+    c.S[i] = Sout[i]; c.dA[i] = dA[i]; c.dG[i] = dG[i]; c.invF[i] = 1.0f / (float)F[i];
+  }
+  const HeadBwdArgs h{g_ce, probs, target, pooled, W, HB, HW, C, K, dfeat, dW, dbias};
+  const int gx = (dim * dim + 255) / 256, n_head = HB + K;
+  hipLaunchKernelGGL(head_bwd_prep_multi_kernel, n_head + gx * cnt, 256, 0, st, h, n_head, c, dim, mu, gscale, B, gx);
+  RET_ON_ERR();
+  if (S > cnt)
+    return launch_prep_multi(S - cnt, D + cnt, alterD + cnt, gamma + cnt, scal + cnt, gscale, F + cnt, B, dim, mu, Sout + cnt,
+                             dA + cnt, dG + cnt, st);
   return 0;
 }
 

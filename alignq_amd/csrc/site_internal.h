@@ -116,6 +116,12 @@ int launch_reduce_loss_multi(int S, void* const* ws, float* const* D, const floa
 int launch_prep_multi(int S, const float* const* D, const float* const* alterD, const float* const* gamma,
                       const float* const* scal, const float* gscale, const int64_t* F, int B, int dim, float mu,
                       float* const* Sout, float* const* dA, float* const* dG, hipStream_t st);
+// the same plus the classifier head's backward (alignq_head_ce_bwd's arguments) as a second role of the launch
+int launch_head_bwd_prep_multi(const float* g_ce, const float* probs, const int64_t* target, const float* pooled, const float* W,
+                               int HB, int HW, int C, int K, float* dfeat, float* dW, float* dbias, int S, const float* const* D,
+                               const float* const* alterD, const float* const* gamma, const float* const* scal,
+                               const float* gscale, const int64_t* F, int B, int dim, float mu, float* const* Sout,
+                               float* const* dA, float* const* dG, hipStream_t st);
 // slab reduction for both geometries (+ optional ADMM-loss scalar through a last-block epilogue)
 int launch_reduce_any(const Geom& g, const float* ws_c, float* ws_mut, int B, int64_t F, float* out, bool with_loss,
                       const float* alterD, const float* gamma, int dim, float mu, float rho, float* scal,

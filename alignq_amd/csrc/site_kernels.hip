@@ -635,6 +635,20 @@ int alignq_site_prep_fused_multi(int S, const float* const* D, const float* cons
   return launch_prep_multi(S, D, alterD, gamma, scal, dD_scale, F, B, dim, mu, S_out, dalterD, dgamma, (hipStream_t)stream);
 }
 
+int alignq_head_ce_bwd_site_prep(const float* g_ce, const float* probs, const int64_t* target, const float* pooled,
+                                 const float* W, int HB, int HW, int C, int K, float* dfeat, float* dW, float* dbias, int S,
+                                 const float* const* D, const float* const* alterD, const float* const* gamma,
+                                 const float* const* scal, const float* dD_scale, const int64_t* F, int B, int dim, float mu,
+                                 float* const* S_out, float* const* dalterD, float* const* dgamma, void* stream) {
+  if (!g_ce || !probs || !target || !pooled || !W || !dfeat || !dW || HB < 1 || HW < 1) return ALIGNQ_EINVAL;
+  if (S <= 0 || !D || !alterD || !gamma || !scal || !F || !S_out || !dalterD || !dgamma || dim < B) return ALIGNQ_EINVAL;
+  for (int i = 0; i < S; i++)
+    if (!D[i] || !alterD[i] || !gamma[i] || !scal[i] || !S_out[i] || !dalterD[i] || !dgamma[i] || F[i] <= 0)
+      return ALIGNQ_EINVAL;
+  return launch_head_bwd_prep_multi(g_ce, probs, target, pooled, W, HB, HW, C, K, dfeat, dW, dbias, S, D, alterD, gamma, scal,
+                                    dD_scale, F, B, dim, mu, S_out, dalterD, dgamma, (hipStream_t)stream);
+}
+
 int alignq_site_bwd_apply(const float* g, const float* S, const float* x, const float* stats, int B, int64_t F,
                           float act_range, float eps, float* dx, void* stream) {
   if (!S || !x || !stats || !dx) return ALIGNQ_EINVAL;

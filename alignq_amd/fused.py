@@ -91,14 +91,7 @@ class LossSumFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, collector, scal_all, *losses):
-        lib = L.load()
-        st = L.stream_ptr()
-        for (B, dim, mu, rho), recs in collector.groups().items():
-            L.check(lib.alignq_site_reduce_loss_multi(
-                len(recs), L.ptr_array([r.ws for r in recs]), L.ptr_array([r.D for r in recs]),
-                L.ptr_array([r.A for r in recs]), L.ptr_array([r.Gm for r in recs]),
-                L.ptr_array([r.scal for r in recs]), L.i64_array([r.F for r in recs]), B, dim, mu, rho, st),
-                "alignq_site_reduce_loss_multi")
+        collector.reduce_all()
         ctx.collector = collector
         ctx.recs = list(collector.records)
         return scal_all[:len(losses), 0].sum()
@@ -181,6 +174,25 @@ class DeferredLosses:
         for r in self.records:
             g.setdefault((r.B, r.dim, r.mu, r.rho), []).append(r)
         return g
+
+    def reduce_all(self):
+        """Slab reduction + ADMM loss of every batched site (one launch per (B, dim, mu, rho) group)."""
+        lib = L.load()
+        st = L.stream_ptr()
+        for (B, dim, mu, rho), recs in self.groups().items():
+            L.check(lib.alignq_site_reduce_loss_multi(
+                len(recs), L.ptr_array([r.ws for r in recs]), L.ptr_array([r.D for r in recs]),
+                L.ptr_array([r.A for r in recs]), L.ptr_array([r.Gm for r in recs]),
+                L.ptr_array([r.scal for r in recs]), L.i64_array([r.F for r in recs]), B, dim, mu, rho, st),
+                "alignq_site_reduce_loss_multi")
+
+    def can_fuse_head(self):
+        """Every site's loss is a batched record (the normal whole-model step): StepLossFn can take both loss roots."""
+        return self.side is None and bool(self.records) and not self.losses and len(self._rec_losses) == len(self.records)
+
+    def total_with_head(self, feat, weight, bias, target):
+        """(logits, ce, trans_total) through StepLossFn; call instead of total() + HeadCEFn when can_fuse_head()."""
+        return StepLossFn.apply(self, self._scal_all, feat, weight, bias, target, *self._rec_losses)
 
     def total(self):
         if self.side is not None:
@@ -537,6 +549,88 @@ def bn_site(bn, act, z, eps=0.0, relu=False, residual=None, pack=False):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+_head_counters = {}
+
+
+def _head_counter(device):
+    """The arrival counter of alignq_head_ce_fwd's in-kernel mean: one zeroed word per device, re-armed by the kernel
+    (allocated on the first eager call, i.e. outside any graph capture)."""
+    key = (device.type, device.index)
+    c = _head_counters.get(key)
+    if c is None:
+        c = _head_counters[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return c
+
+
+class StepLossFn(torch.autograd.Function):
+    """The two loss roots of a whole-model training step from ONE autograd node: (logits, ce, trans_total) with
+    ce = cross_entropy(logit(avgpool(feat)), target) and trans_total = sum of the batched sites' transition losses.
+    Forward: alignq_site_reduce_loss_multi (as LossSumFn) + alignq_head_ce_fwd, whose last workgroup also forms the batch mean
+    and the sum over sites (no reduction launches).  Backward: alignq_head_ce_bwd_site_prep, the head's backward and every
+    site's S / dalterD / dgamma in one launch.  Four launches where HeadCEFn + LossSumFn take seven."""
+
+    @staticmethod
+    def forward(ctx, collector, scal_all, feat, weight, bias, target, *losses):
+        collector.reduce_all()
+        feat = L.dense_f32(feat, "features")
+        if feat.dim() != 4 or feat.is_contiguous():
+            raise RuntimeError("StepLossFn needs channels-last 4-D features")
+        B, C, H, W = feat.shape
+        K = weight.shape[0]
+        lib = L.load()
+        dev = feat.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        pooled, logits, probs = torch.empty(B, C, **f32), torch.empty(B, K, **f32), torch.empty(B, K, **f32)
+        loss, ce, trans = torch.empty(B, **f32), torch.empty((), **f32), torch.empty((), **f32)
+        w = L.dev_f32(weight, "head weight")
+        L.check(lib.alignq_head_ce_fwd(L.ptr(feat), L.ptr(w), L.ptr(bias), L.ptr(target), B, H * W, C, K, L.ptr(pooled),
+                                       L.ptr(logits), L.ptr(probs), L.ptr(loss), L.ptr(ce), L.ptr(_head_counter(dev)),
+                                       L.ptr(scal_all), len(losses), L.ptr(trans), L.stream_ptr()), "alignq_head_ce_fwd")
+        ctx.save_for_backward(feat, w, target, pooled, probs)
+        ctx.has_bias = bias is not None
+        ctx.recs = list(collector.records)
+        ctx.mark_non_differentiable(logits)
+        ctx.set_materialize_grads(False)
+        return logits, ce, trans
+
+    @staticmethod
+    def backward(ctx, _g_logits, g_ce, g_tr):
+        feat, w, target, pooled, probs = ctx.saved_tensors
+        B, C, H, W = feat.shape
+        K = w.shape[0]
+        dev = feat.device
+        lib = L.load()
+        st = L.stream_ptr()
+        zero = None
+        if g_ce is None or g_tr is None:
+            zero = torch.zeros((), dtype=torch.float32, device=dev)
+        g_ce = L.dev_f32(zero if g_ce is None else g_ce, "loss grad")
+        g_tr = L.dev_f32(zero if g_tr is None else g_tr, "loss grad")
+        dfeat, dW = torch.empty_like(feat), torch.empty_like(w)
+        db = torch.empty(K, dtype=torch.float32, device=dev) if ctx.has_bias else None
+        groups = {}
+        for r in ctx.recs:
+            groups.setdefault((r.B, r.dim, r.mu, r.rho), []).append(r)
+            r.S = torch.empty(lib.alignq_site_bwd_ws_bytes(r.B) // 4, dtype=torch.float32, device=dev)   # fp32 S + bf16 image
+            r.dA, r.dG = torch.empty_like(r.A), torch.empty_like(r.Gm)
+        head_done = False
+        for (sB, dim, mu, rho), recs in groups.items():
+            site_args = (len(recs), L.ptr_array([r.D for r in recs]), L.ptr_array([r.A for r in recs]),
+                         L.ptr_array([r.Gm for r in recs]), L.ptr_array([r.scal for r in recs]), L.ptr(g_tr),
+                         L.i64_array([r.F for r in recs]), sB, dim, mu, L.ptr_array([r.S for r in recs]),
+                         L.ptr_array([r.dA for r in recs]), L.ptr_array([r.dG for r in recs]), st)
+            if not head_done:
+                L.check(lib.alignq_head_ce_bwd_site_prep(L.ptr(g_ce), L.ptr(probs), L.ptr(target), L.ptr(pooled), L.ptr(w), B,
+                                                         H * W, C, K, L.ptr(dfeat), L.ptr(dW), L.ptr(db), *site_args),
+                        "alignq_head_ce_bwd_site_prep")
+                head_done = True
+            else:
+                L.check(lib.alignq_site_prep_fused_multi(*site_args), "alignq_site_prep_fused_multi")
+            for r in recs:
+                r.prepared = True
+        return (None, None, dfeat, dW, db, None) + (g_tr,) * len(ctx.recs)
+
+
 class HeadCEFn(torch.autograd.Function):
     """logits = logit(avgpool(feat).flatten(1)); ce = cross_entropy(logits, target) (mean) as one forward and one backward
     launch (alignq_head_ce_fwd / _bwd) for channels-last features.  Returns (logits, ce); only ce is differentiable."""
@@ -554,14 +648,16 @@ class HeadCEFn(torch.autograd.Function):
         logits = torch.empty(B, K, dtype=torch.float32, device=dev)
         probs = torch.empty(B, K, dtype=torch.float32, device=dev)
         loss = torch.empty(B, dtype=torch.float32, device=dev)
+        ce = torch.empty((), dtype=torch.float32, device=dev)
         w = L.dev_f32(weight, "head weight")
         L.check(lib.alignq_head_ce_fwd(L.ptr(feat), L.ptr(w), L.ptr(bias), L.ptr(target), B, H * W, C, K, L.ptr(pooled),
-                                       L.ptr(logits), L.ptr(probs), L.ptr(loss), L.stream_ptr()), "alignq_head_ce_fwd")
+                                       L.ptr(logits), L.ptr(probs), L.ptr(loss), L.ptr(ce), L.ptr(_head_counter(dev)), None, 0,
+                                       None, L.stream_ptr()), "alignq_head_ce_fwd")
         ctx.save_for_backward(feat, w, target, pooled, probs)
         ctx.has_bias = bias is not None
         ctx.mark_non_differentiable(logits)
         ctx.set_materialize_grads(False)
-        return logits, loss.mean()
+        return logits, ce
 
     @staticmethod
     def backward(ctx, _g_logits, g_ce):

@@ -81,12 +81,17 @@ class TrainStep:
         prequantize_weights(self.all_convs)     # all conv weights in two launches
         fused_head = self.channels_last and hasattr(model, "logit") and hasattr(model, "avgpool")
         model._features_only = fused_head
+        ce = None
         try:
             if self._deferred is not None and self.admms:
                 with self._deferred as d:
                     out = model(x)
                     logits = out[0] if isinstance(out, tuple) else out
-                    trans_loss = d.total()          # joins the side stream, one stacked sum
+                    if fused_head and d.can_fuse_head() and head_ce_supported(logits, model.logit.weight, y):
+                        # both loss roots from one node: no reduction launches, head backward + site preparation together
+                        logits, ce, trans_loss = d.total_with_head(logits, model.logit.weight, model.logit.bias, y)
+                    else:
+                        trans_loss = d.total()          # joins the side stream, one stacked sum
             else:
                 out = model(x)
                 if isinstance(out, tuple):
@@ -95,7 +100,9 @@ class TrainStep:
                     logits, trans_loss = out, None
         finally:
             model._features_only = False
-        if fused_head and head_ce_supported(logits, model.logit.weight, y):
+        if ce is not None:
+            pass
+        elif fused_head and head_ce_supported(logits, model.logit.weight, y):
             # `logits` still holds the pre-pool features: pool + linear + cross-entropy in one launch each way
             logits, ce = HeadCEFn.apply(logits, model.logit.weight, model.logit.bias, y)
         else:

@@ -320,10 +320,22 @@ int alignq_bn_bwd_totals(const float* dx_part, int B, int C, int HW, float* ktot
  * pooled = mean over HW; logits = pooled W^T + bias (W [K,C]); loss[b] = cross-entropy(logits[b], target[b]) per sample (the
  * caller averages); probs = softmax(logits) kept for the backward.  Backward for the MEAN of loss with upstream scalar *g:
  * dfeat, dW, dbias (dbias may be NULL).  C <= 256, K <= 64.  Reference: model/resnet.py:127-129 + main.py's criterion.   */
+/* ce_mean (or NULL): additionally *ce_mean = mean_b loss[b], formed in index order by the workgroup that finishes last
+ * (`counter`: one zero-initialised unsigned the kernel re-arms); site_scal / n_sites / trans_total (or NULL / 0 / NULL, need
+ * ce_mean): *trans_total = sum_i site_scal[4 i], the total of the sites' transition losses (the `scal` rows of
+ * alignq_site_reduce_loss_multi, consecutive) — neither reduction gets a launch of its own in a training step.           */
 int alignq_head_ce_fwd(const float* feat, const float* W, const float* bias, const int64_t* target, int B, int HW, int C, int K,
-                       float* pooled, float* logits, float* probs, float* loss, void* stream);
+                       float* pooled, float* logits, float* probs, float* loss, float* ce_mean, unsigned* counter,
+                       const float* site_scal, int n_sites, float* trans_total, void* stream);
 int alignq_head_ce_bwd(const float* g, const float* probs, const int64_t* target, const float* pooled, const float* W, int B,
                        int HW, int C, int K, float* dfeat, float* dW, float* dbias, void* stream);
+/* alignq_head_ce_bwd (head batch HB) and alignq_site_prep_fused_multi (S sites) as two roles of ONE launch: the two backward
+ * roots of a training step (cross-entropy and the summed transition loss) start together.                                 */
+int alignq_head_ce_bwd_site_prep(const float* g_ce, const float* probs, const int64_t* target, const float* pooled,
+                                 const float* W, int HB, int HW, int C, int K, float* dfeat, float* dW, float* dbias, int S,
+                                 const float* const* D, const float* const* alterD, const float* const* gamma,
+                                 const float* const* scal, const float* dD_scale, const int64_t* F, int B, int dim, float mu,
+                                 float* const* S_out, float* const* dalterD, float* const* dgamma, void* stream);
 
 /* ---- data-parallel flat bucket (ONE mean all-reduce per step over gradients + stacked D matrices):
  * gather T dense device tensors (HOST array of pointers, element counts n[T]) into `flat` back to back (unpack = 0) or

@@ -94,3 +94,60 @@ def test_transition_function_matches_the_two_convolution_functions():
     assert torch.equal(y3, z3) and torch.equal(y1, z1)
     assert torch.equal(w3a.grad, w3b.grad) and torch.equal(w1a.grad, w1b.grad)
     assert (xa.grad - xb.grad).abs().max().item() <= 2e-5 * max(1.0, xb.grad.abs().max().item())
+
+
+def test_head_forward_means_and_merged_head_prep_backward():
+    """alignq_head_ce_fwd's in-kernel batch mean / site-loss total against torch, twice (the ticket re-arms), and
+    alignq_head_ce_bwd_site_prep against the two launches it replaces, bit for bit."""
+    import torch.nn.functional as F
+    from alignq_amd import _lib as L
+    lib = L.load()
+    dev = torch.device("cuda:0")
+    f32 = dict(dtype=torch.float32, device=dev)
+    g = torch.Generator(device="cpu").manual_seed(11)
+    B, C, H, W, K, S, dim = 128, 64, 8, 8, 10, 21, 128
+    feat = torch.randn(B, C, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    Wt, bias = torch.randn(K, C, generator=g).to(dev) * 0.2, torch.randn(K, generator=g).to(dev) * 0.1
+    target = torch.randint(0, K, (B,), generator=g).to(dev)
+    scal_all = torch.rand(64, 4, generator=g).to(dev)
+    st, p = L.stream_ptr(), L.ptr
+    counter = torch.zeros(1, dtype=torch.int32, device=dev)
+    ref_logits = F.adaptive_avg_pool2d(feat, 1).flatten(1) @ Wt.t() + bias
+    ref_ce = F.cross_entropy(ref_logits, target)
+    for _ in range(2):
+        pooled, logits, probs = torch.empty(B, C, **f32), torch.empty(B, K, **f32), torch.empty(B, K, **f32)
+        loss, ce, tr = torch.empty(B, **f32), torch.empty((), **f32), torch.empty((), **f32)
+        L.check(lib.alignq_head_ce_fwd(p(feat), p(Wt), p(bias), p(target), B, H * W, C, K, p(pooled), p(logits), p(probs), p(loss),
+                                       p(ce), p(counter), p(scal_all), S, p(tr), st), "head fwd")
+        torch.cuda.synchronize()
+        assert abs(ce.item() - ref_ce.item()) <= 2e-6 * max(1.0, abs(ref_ce.item()))
+        assert abs(ce.item() - loss.double().mean().item()) <= 1e-6
+        assert abs(tr.item() - scal_all[:S, 0].double().sum().item()) <= 1e-5
+        assert counter.item() == 0
+    # ---- backward: merged launch == head backward + site preparation
+    gce, gtr = torch.full((), 1.0, **f32), torch.full((), 0.7, **f32)
+    D = [torch.randn(B, B, generator=g).to(dev) * 0.05 for _ in range(S)]
+    A = [torch.randn(dim, dim, generator=g).to(dev) * 0.05 for _ in range(S)]
+    Gm = [torch.rand(dim, dim, generator=g).to(dev) * 0.01 for _ in range(S)]
+    scal = [scal_all[i] for i in range(S)]
+    Fs = [16384] * 7 + [8192] * 7 + [4096] * 7
+    nS = lib.alignq_site_bwd_ws_bytes(B) // 4
+
+    def outs():
+        return ([torch.zeros(nS, **f32) for _ in range(S)], [torch.empty(dim, dim, **f32) for _ in range(S)],
+                [torch.empty(dim, dim, **f32) for _ in range(S)])
+
+    S1, dA1, dG1 = outs()
+    S2, dA2, dG2 = outs()
+    df1, dW1, db1 = torch.empty_like(feat), torch.empty_like(Wt), torch.empty(K, **f32)
+    df2, dW2, db2 = torch.empty_like(feat), torch.empty_like(Wt), torch.empty(K, **f32)
+    site = lambda So, dAo, dGo: (S, L.ptr_array(D), L.ptr_array(A), L.ptr_array(Gm), L.ptr_array(scal), p(gtr), L.i64_array(Fs),
+                                 B, dim, 0.01, L.ptr_array(So), L.ptr_array(dAo), L.ptr_array(dGo), st)
+    L.check(lib.alignq_head_ce_bwd(p(gce), p(probs), p(target), p(pooled), p(Wt), B, H * W, C, K, p(df1), p(dW1), p(db1), st), "hb")
+    L.check(lib.alignq_site_prep_fused_multi(*site(S1, dA1, dG1)), "prep")
+    L.check(lib.alignq_head_ce_bwd_site_prep(p(gce), p(probs), p(target), p(pooled), p(Wt), B, H * W, C, K, p(df2), p(dW2), p(db2),
+                                             *site(S2, dA2, dG2)), "merged")
+    torch.cuda.synchronize()
+    assert torch.equal(df1, df2) and torch.equal(dW1, dW2) and torch.equal(db1, db2)
+    for i in range(S):
+        assert torch.equal(S1[i], S2[i]) and torch.equal(dA1[i], dA2[i]) and torch.equal(dG1[i], dG2[i])
