@@ -1318,6 +1318,18 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
         for (int q = 0; q < 16; q++) zr[q] = AT(x, q);   // clamped offset; out-of-range elements are not used below
       }
     }
+    // per-column constants of the assemble / copy-out phases: requested here too, so that their round trip is over by then
+    const bool cok = (col0 + cc) < F;
+    const float rho_x = cok ? stats[F + col0 + cc] : 0.f;
+    const float rho_t = (PAIR && cok) ? stats[3 * F + col0 + cc] : 0.0f;
+    float4 sv_m = make_float4(0.f, 0.f, 0.f, 0.f), sv_i = sv_m;      // (VEC, channels-last) batch mean / invstd of the column quad
+    if constexpr (VEC && BN) {
+      if (bn.nhwc && q_ok) {
+        const int ch = (col0 + 4 * lc4) & (bn.C - 1);
+        sv_m = *reinterpret_cast<const float4*>(bn.save + ch);
+        sv_i = *reinterpret_cast<const float4*>(bn.save + bn.C + ch);
+      }
+    }
     // ---- projections over this wave's 32 batch rows: sum dVh, sum dVh*Vh.  Vh of this lane's accumulator cells
     //      (rows (e&3)+8(e>>2)+4h of block I, column cc) are 4 consecutive entries of the transposed row: 8-byte reads
     {
@@ -1365,9 +1377,6 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
           st1 += red[((rb * 2 + 1) * 2 + 1) * TFv + cc];
         }
       }
-      const bool cok = (col0 + cc) < F;
-      const float rho_x = cok ? stats[F + col0 + cc] : 0.f;
-      const float rho_t = (PAIR && cok) ? stats[3 * F + col0 + cc] : 0.0f;
       // through-std factor (sd+eps)/sd = 1/(1-eps*rho); torch's std backward is 0 where sd == 0
       float kap_x = 1.0f, kap_t = 1.0f;
       if (eps != 0.0f) {
@@ -1411,11 +1420,9 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
         if (BN) {
           const int fq = col0 + 4 * lc4;
           if (bn.nhwc) {
-            const int ch = fq & (bn.C - 1);
-            const float4 m4 = *reinterpret_cast<const float4*>(bn.save + ch);
-            const float4 i4 = *reinterpret_cast<const float4*>(bn.save + bn.C + ch);
-            bmu[0] = m4.x; bmu[1] = m4.y; bmu[2] = m4.z; bmu[3] = m4.w;
-            bis[0] = i4.x; bis[1] = i4.y; bis[2] = i4.z; bis[3] = i4.w;
+            (void)fq;
+            bmu[0] = sv_m.x; bmu[1] = sv_m.y; bmu[2] = sv_m.z; bmu[3] = sv_m.w;
+            bis[0] = sv_i.x; bis[1] = sv_i.y; bis[2] = sv_i.z; bis[3] = sv_i.w;
           } else {
             const int ch = fq / bn.HW;
 #pragma unroll
