@@ -1020,8 +1020,12 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ x, const fl
   f32x4 rx[NIX], rd[NID], rz[NID];     // plain vector registers (HIP's float4 struct here ends up in scratch)
   // (fetch / park are spelled out twice below rather than hidden in a lambda or macro: the register arrays must be indexed
   // by unrolled constants or they end up in scratch)
-  int nxt = bx;
-  if (nxt < n_tiles) {
+  // pixel range of this workgroup: `per` CONSECUTIVE tiles (the data-gradient workgroups of the same launch that read the same
+  // rows of dy are placed on this workgroup's XCD, see conv3x3_bwd_kernel: the second reader finds them in that XCD's L2)
+  const int per = (n_tiles + gx - 1) / gx;
+  const int t_begin = bx * per, t_end = (t_begin + per < n_tiles) ? t_begin + per : n_tiles;
+  int nxt = t_begin;
+  if (nxt < t_end) {
     const int row0_ = nxt * TR;
     const int img_lo_ = (row0_ / H) * (H * S), img_hi_ = img_lo_ + H * S;      // INPUT rows of the tile's image
 #pragma unroll
@@ -1060,7 +1064,7 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ x, const fl
       lk1 = *reinterpret_cast<const f32x4*>(lazy.ktot + COUT + cq);
     }
   }
-  for (int tile = bx; tile < n_tiles; tile += gx) {
+  for (int tile = t_begin; tile < t_end; tile++) {
     __syncthreads();                               // previous tile's readers are done
 #pragma unroll
     for (int it = 0; it < NIX; it++) {             // park the fetched tile in LDS as three bf16 terms
@@ -1104,8 +1108,8 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ x, const fl
       }
     }
     __syncthreads();
-    nxt = tile + gx;
-    if (nxt < n_tiles) {                           // next tile's loads fly under this tile's MFMA phase
+    nxt = tile + 1;
+    if (nxt < t_end) {                           // next tile's loads fly under this tile's MFMA phase
       const int row0_ = nxt * TR;
       const int img_lo_ = (row0_ / H) * (H * S), img_hi_ = img_lo_ + H * S;      // INPUT rows of the tile's image
 #pragma unroll
@@ -1228,7 +1232,7 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_kernel(const float* __restric
                                                           const float* __restrict__ w, float* __restrict__ dx,
                                                           float* __restrict__ slabs, int H, int total_rows, float nlev,
                                                           int n_tiles_w, int splits, int nblk2,
-                                                          const float* __restrict__ add, BnLazy lazy, float xlev) {
+                                                          const float* __restrict__ add, BnLazy lazy, float xlev, int dg_R) {
   constexpr int kBytesD = ConvLds<C, WD, PTD>::kBf16 * 2, kBytesW = WgradLds<C, WD, PTW>::kFloats * 4;
   __shared__ __attribute__((aligned(16))) unsigned char lds[kBytesD > kBytesW ? kBytesD : kBytesW];
   const int n_wg = splits * nblk2;
@@ -1236,8 +1240,15 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_kernel(const float* __restric
     wgrad3x3_body<C, WD, PTW, XB>(x, dy, slabs, H, n_tiles_w, reinterpret_cast<float*>(lds), blockIdx.x % splits, splits,
                                   blockIdx.x / splits, lazy, xlev);
   } else {
-    conv3x3_body<C, WD, PTD, true>(dy, w, dx, H, total_rows, nlev, reinterpret_cast<__bf16*>(lds), blockIdx.x - n_wg, add,
-                                   nullptr, 0, lazy);
+    // XCD placement (blocks are dealt round-robin over the 8 XCDs; for speed only): data-gradient tile t reads the dy rows
+    // that filter-gradient workgroup t / dg_R reads, so it goes to a block on that workgroup's XCD — the later of the two reads
+    // is then an L2 hit instead of a second trip over the fabric
+    int m = blockIdx.x - n_wg;
+    if (dg_R > 0) {
+      const int i = (m / (8 * dg_R)) * 8 + (m & 7), r = (m >> 3) % dg_R;
+      m = dg_R * i + r;
+    }
+    conv3x3_body<C, WD, PTD, true>(dy, w, dx, H, total_rows, nlev, reinterpret_cast<__bf16*>(lds), m, add, nullptr, 0, lazy);
   }
 }
 
@@ -1402,8 +1413,16 @@ int launch_bwd(const float* x, const float* dy, const float* w, float* dx, float
   constexpr int NB = (C >= 32 ? C / 32 : 1);
   int splits = 256 / (NB * NB);
   if (splits > n_tiles_w) splits = n_tiles_w;
-  const int grid = splits * NB * NB + total_rows / TRD;
-#define LBW(XBV) hipLaunchKernelGGL((conv3x3_bwd_kernel<C, WD, PTD, PTW, XBV>), grid, 256, 0, st, x, dy, w, dx, ws, H, total_rows, nlev, n_tiles_w, splits, NB * NB, add, lazy, xlev)
+  const int n_d = total_rows / TRD;
+  const int grid = splits * NB * NB + n_d;
+  // data-gradient tiles per filter-gradient pixel range (0: no XCD placement: the ranges do not tile the batch evenly)
+  const int per = (n_tiles_w + splits - 1) / splits;
+  int dg_R = 0;
+  if ((per * TRW) % TRD == 0 && (splits * NB * NB) % 8 == 0 && splits % 8 == 0) {
+    const int R = per * TRW / TRD;
+    if (R >= 1 && R * splits == n_d) dg_R = R;
+  }
+#define LBW(XBV) hipLaunchKernelGGL((conv3x3_bwd_kernel<C, WD, PTD, PTW, XBV>), grid, 256, 0, st, x, dy, w, dx, ws, H, total_rows, nlev, n_tiles_w, splits, NB * NB, add, lazy, xlev, dg_R)
   if (xb == 2) LBW(2); else if (xb == 1) LBW(1); else LBW(0);
 #undef LBW
   hipError_t e = hipGetLastError();
