@@ -842,6 +842,16 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
   if (lazy.z && lazy.part) bn_totals_lds<16>(lazy, kt, blockIdx.x == 0);      // (workgroup-uniform) totals by this workgroup
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int row0 = tile * 4;
+    // the dy (and z) quads of this thread are requested BEFORE the im2col gather, whose 16 loads per thread are consumed inside
+    // stem_stage: one memory round trip per tile instead of two
+    f32x4 dvr[2], zvr[2];
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+      const int i = tid + 256 * it;
+      const int64_t off = ((int64_t)row0 * 32 + i / 4) * 16 + 4 * (tid % 4);
+      dvr[it] = *reinterpret_cast<const f32x4*>(dy + off);
+      zvr[it] = lazy.z ? *reinterpret_cast<const f32x4*>(lazy.z + off) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     __syncthreads();
     stem_stage(x, H, row0, Ci[0], Ci[1], Ci[2]);
     {   // dy tile [128 pixels][16 co] as three bf16 terms (optionally the lazy batch-norm form)
@@ -858,9 +868,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
 #pragma unroll
       for (int it = 0; it < 2; it++) {
         const int i = tid + 256 * it;                  // 512 float4 slots
-        const int64_t off = ((int64_t)row0 * 32 + i / 4) * 16 + 4 * c4;
-        f32x4 dv = *reinterpret_cast<const f32x4*>(dy + off);
-        if (lazy.z) dv = la * (dv - lk0 - (*reinterpret_cast<const f32x4*>(lazy.z + off) - lm) * li * lk1);
+        f32x4 dv = dvr[it];
+        if (lazy.z) dv = la * (dv - lk0 - (zvr[it] - lm) * li * lk1);
         bf16x4 h4, m4, l4;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
@@ -1263,7 +1272,7 @@ __global__ __launch_bounds__(256) void transition_bwd_kernel(const float* __rest
                                                              float* __restrict__ slabs3, float* __restrict__ slabs1, int Ho,
                                                              int n_tiles3, int n_tiles1, int splits3, int splits1, int n_d,
                                                              float nlev, const float* __restrict__ add, BnLazy lazy3,
-                                                             BnLazy lazy1) {
+                                                             BnLazy lazy1, int dg_R) {
   using G3 = WgradGeo<CIN, COUT, WDI, 3, 2, PTW3>;
   using G1 = WgradGeo<CIN, COUT, WDI, 1, 2, PTW1>;
   constexpr int NBY = (COUT / G3::CB) * (CIN / G3::CB);
@@ -1274,8 +1283,14 @@ __global__ __launch_bounds__(256) void transition_bwd_kernel(const float* __rest
   const int n_w3 = splits3 * NBY;
   const int b = blockIdx.x;
   if (b < n_d) {           // (this role publishes the batch-norm parameter gradients of both records)
+    // XCD placement as in conv3x3_bwd_kernel: tile t reads the dy rows of filter-gradient pixel range t / dg_R
+    int m = b;
+    if (dg_R > 0) {
+      const int i = (m / (8 * dg_R)) * 8 + (m & 7), r = (m >> 3) % dg_R;
+      m = dg_R * i + r;
+    }
     dgrad_s2_body<CIN, COUT, WDI, 3, PTD, true>(dy3, w3, dx, 2 * Ho, 0x7fffffff, nlev, add, lazy3,
-                                                reinterpret_cast<__bf16*>(lds), b, dy1, w1, lazy1);
+                                                reinterpret_cast<__bf16*>(lds), m, dy1, w1, lazy1);
   } else if (b < n_d + n_w3) {
     const int c = b - n_d;
     wgrad_body<CIN, COUT, WDI, 3, 2, PTW3>(x, dy3, slabs3, Ho, n_tiles3, reinterpret_cast<float*>(lds), c % splits3, splits3,
@@ -1477,8 +1492,19 @@ int launch_transition_bwd(const float* x, const float* dy3, const float* dy1, co
   if (splits3 > n_tiles3) splits3 = n_tiles3;
   if (splits1 > n_tiles1) splits1 = n_tiles1;
   const int n_d = B * 2 * Ho / TRD;
+  // data-gradient tiles per filter-gradient pixel range (both filter roles cut the output rows the same way), 0: no placement
+  int dg_R = 0;
+  {
+    const int per3 = (n_tiles3 + splits3 - 1) / splits3, per1 = (n_tiles1 + splits1 - 1) / splits1;
+    const int rows3 = per3 * G3::TR, rows1 = per1 * G1::TR;            // output rows per pixel range
+    if (rows3 == rows1 && splits3 == splits1 && splits3 % 8 == 0 && n_d % 8 == 0 && (2 * rows3) % TRD == 0) {
+      const int R = 2 * rows3 / TRD;
+      if (R >= 1 && R * splits3 == n_d) dg_R = R;
+    }
+  }
   hipLaunchKernelGGL((transition_bwd_kernel<CIN, COUT, WDI, PTW3, PTW1, PTD>), (splits3 + splits1) * NBY + n_d, 256, 0, st, x,
-                     dy3, dy1, w3, w1, dx, ws3, ws1, Ho, n_tiles3, n_tiles1, splits3, splits1, n_d, nlev, add, lazy3, lazy1);
+                     dy3, dy1, w3, w1, dx, ws3, ws1, Ho, n_tiles3, n_tiles1, splits3, splits1, n_d, nlev, add, lazy3, lazy1,
+                     dg_R);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   *ns3 = splits3;
@@ -1729,7 +1755,7 @@ int alignq_transition_nhwc_bwd(const float* x, const float* dy3, const float* dy
   if (int rc = lazy_parts(lazy1, bn1_dx_part, bn1_dgamma, bn1_dbeta, B, COUT, HWo)) return rc;
   const int Ho = H_in / 2;
   if (CIN == 16)
-    return launch_transition_bwd<16, 32, 32, 64, 128, 128>(x, dy3, dy1, wt3, wt1, dx, (float*)ws3, (float*)ws1, B, Ho, nlev,
+    return launch_transition_bwd<16, 32, 32, 64, 128, 256>(x, dy3, dy1, wt3, wt1, dx, (float*)ws3, (float*)ws1, B, Ho, nlev,
                                                           n_slabs3, n_slabs1, add, lazy3, lazy1, st);
   if (CIN == 32)
     return launch_transition_bwd<32, 64, 16, 64, 64, 128>(x, dy3, dy1, wt3, wt1, dx, (float*)ws3, (float*)ws1, B, Ho, nlev,
