@@ -152,8 +152,12 @@ class TrainStep:
             # graph only fits its static shapes, so this one iteration runs eagerly; the graph's own gradient / D tensors
             # (which p.grad and ADMM.D name between replays) are put back afterwards
             return self._eager_fallback(x, y)
-        sx.copy_(x, non_blocking=True)
-        sy.copy_(y, non_blocking=True)
+        # a loader that writes its batches straight into `static_inputs()` (the target of its host-to-device copy) hands the
+        # same tensors back: nothing to stage
+        if x is not sx:
+            sx.copy_(x, non_blocking=True)
+        if y is not sy:
+            sy.copy_(y, non_blocking=True)
         self._graph.replay()
         if self._graph2 is not None:
             # data-parallel: only the collective runs eagerly between the two captured halves (pack / unpack of the flat
@@ -161,6 +165,12 @@ class TrainStep:
             self.grad_hook.reduce() if hasattr(self.grad_hook, "reduce") else self.grad_hook(self)
             self._graph2.replay()
         return self._static[2]
+
+    def static_inputs(self):
+        """(x, y) buffers the captured graph reads (x in the step's memory format).  Fill them in place — e.g. as the
+        destination of the loader's host-to-device copy — and call the step with these very tensors: the per-step staging
+        copies (a layout-converting one for NCHW input) are skipped.  None before `capture`."""
+        return None if self._static is None else (self._static[0], self._static[1])
 
     def _eager_fallback(self, x, y):
         params = [p for _, p in self.param_t + self.param_admm]
