@@ -306,11 +306,14 @@ def measure_kernels(dev, B, k, site_F_counts, hw_of_F, folded=True, nhwc=False, 
                         "CIFAR sites are 2-8 MB per launch, i.e. launch-latency shapes (SURVEY H2); see kernels.act_quant_* "
                         "for the HBM-roofline-sized CDF-quantise kernel"}
     # what the CAPTURED step launches (tools/count_step_kernels.sh lists the same kernels from a rocprofv3 trace of the graph):
-    # one folded site forward and one folded site backward per site, ONE slab_reduce_multi and ONE site_prep_multi per step.
+    # one folded site forward and one folded site backward per site, ONE slab_reduce_multi per step, the site preparation as a
+    # role of the head-backward launch.
     # The per-site reduce / prep / statistics / bn_bwd_apply entry points are launched by the eager per-module API only.
     out["per_step_us"] = {"site_partials": per_step["site_partials"][0] * 1e6, "site_bwd": per_step["site_bwd"][0] * 1e6,
                           "slab_reduce_multi": t_red_multi * 1e6, "site_prep_multi": t_prep_multi * 1e6,
-                          "note": "kernels of the captured step (graph); forward timed in its conv_parts form"}
+                          "note": "kernels of the captured step (graph); forward timed in its conv_parts form; in the step the "
+                                  "site preparation is one role of the launch that also runs the classifier head's backward "
+                                  "(alignq_head_ce_bwd_site_prep), timed here stand-alone"}
     out["eager_only_per_step_us"] = {kname: per_step[kname][0] * 1e6 for kname in
                                      ("bn_partial_stats", "site_reduce_loss", "site_bwd_prep", "bn_bwd_apply")}
     # Gram step on the matrix cores (north_star: "MFMA utilisation for the Gram step against gfx950 peak"): the forward issues
