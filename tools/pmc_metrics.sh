@@ -7,7 +7,7 @@ rm -rf gpurun_out/pmcm && mkdir -p gpurun_out/pmcm
 i=0
 IFS='|' read -ra GR <<< "$GROUPS_"
 for g in "${GR[@]}"; do
-  rocprofv3 --pmc $g --kernel-trace --output-format csv -d gpurun_out/pmcm/p$i -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-shapes --no-dp-probe --no-kernels > gpurun_out/pmcm/log$i 2>&1
+  rocprofv3 --pmc $g --kernel-trace --output-format csv -d gpurun_out/pmcm/p$i -o run -- python3 ${PMC_PROG:-bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-shapes --no-dp-probe --no-kernels} > gpurun_out/pmcm/log$i 2>&1
   i=$((i+1))
 done
 python3 - <<'PY'
