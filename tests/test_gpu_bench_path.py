@@ -151,11 +151,15 @@ def _expected_y(x, k, r, res, relu):
 
 
 @pytest.mark.parametrize("k", [2, 4, 8])
-@pytest.mark.parametrize("B,C,H", [(128, 16, 32), (128, 32, 16), (128, 64, 8)])
+@pytest.mark.parametrize("B,C,H", [(128, 16, 32), (128, 32, 16), (128, 64, 8), (128, 16, 48), (100, 32, 32)])
 @pytest.mark.parametrize("nhwc", [0, 1])
 def test_bn_folded_site_kernels_vs_oracle(dev, nhwc, B, C, H, k):
     """site_fwd4_kernel<TF,true> / site_bwd4_kernel<TF,true,true> / bn_bwd_apply at the ResNet-20/56 site shapes
-    128 x {16384, 8192, 4096}, both layouts, against the C oracle."""
+    128 x {16384, 8192, 4096}, both layouts, against the C oracle; F = 36864 and 32768 (a short batch) run the forward's
+    multi-tile instantiation (more tiles than workgroups: accumulators carried over the tile loop)."""
+    if F_big := (C * H * H > 16384):
+        if k == 4:
+            pytest.skip("one bit width fewer at the large shapes (oracle time)")
     rng = np.random.default_rng(1000 * nhwc + 10 * C + k)
     relu, with_res = (k != 4), (k == 8 or C == 32)
     shape = (B, C, H, H)
