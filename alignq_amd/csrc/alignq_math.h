@@ -1,4 +1,4 @@
-// Device-side ALIGNQ-EXP32 / ALIGNQ-ERF32 (spec: gen_erf32_coeffs.py docstring).
+// Device-side ALIGNQ-EXP32 / ALIGNQ-NERF32 (spec: gen_erf32_coeffs.py docstring).
 // Every step is one IEEE-754 single operation (fma / mul / add / rint / exact 2^k scaling), so the
 // result is bit-identical to the scalar C statement of the same spec used by the test oracle.
 // Translation units including this header are compiled with -ffp-contract=off.
@@ -32,84 +32,101 @@ __device__ __forceinline__ float exp32(float x) {
   return res;
 }
 
-// exp32 for arguments known to lie in [-40, 0] (the erf tail): no range guards, single 2^n scale.
-__device__ __forceinline__ float exp32_neg_small(float x) {
-  float nf = rintf(x * ALIGNQ_LOG2E);
-  float r = __fmaf_rn(nf, -ALIGNQ_LN2_HI, x);
-  r = __fmaf_rn(nf, -ALIGNQ_LN2_LO, r);
-  float p = ALIGNQ_PE5;
-  p = __fmaf_rn(p, r, ALIGNQ_PE4);
-  p = __fmaf_rn(p, r, ALIGNQ_PE3);
-  p = __fmaf_rn(p, r, ALIGNQ_PE2);
-  p = __fmaf_rn(p, r, ALIGNQ_PE1);
-  p = __fmaf_rn(p, r, ALIGNQ_PE0);
-  float r2 = r * r;
-  float e = 1.0f + __fmaf_rn(r2, p, r);
-  // one exact scaling by 2^n (v_ldexp_f32) == the spec's e*2^h*2^(n-h): no subnormals or overflow for -58 <= n <= 0
-  return __builtin_ldexpf(e, (int)nf);
+// ---- ALIGNQ-NERF32 (round 3): nerf32(y) ~ erf(y/sqrt(2)) = 2*Phi(y)-1, ONE evaluated branch per element ------------
+// Spec: gen_erf32_coeffs.py (table in include/alignq_erf32_coeffs.h), C statement oracle/alignq_oracle.c:oq_nerf32_1.
+//   a = min(|y|, 5.625) (NaN-propagating: v_minimum3_f32);  u = a + 2^20 (ulp 1/8: the low mantissa bits of u ARE the node
+//   index k = round(8a));  d = a - P[k] (exact);  res = C0[k] + d*(C1[k] + d*(C2[k] + d*(C3[k] + d*C4[k]))) as four fma.
+// 9 vector ops + 2 LDS reads (round 1-2 erf32: both polynomial regions and an exp for every lane, 34 ops).  The table
+// (46 nodes x 32 B) lives in LDS: per node a 16-byte record C1..C4 and, 736 B behind it at the same 16-byte stride,
+// (C0, P): one address register, ds_read_b128 + ds_read_b64.  Lanes reading the same node broadcast; different nodes
+// collide only 16 nodes apart (|y| differing by 2), so N(0,1) data reads almost conflict-free.  A NaN input gives a NaN
+// address (an LDS read never faults: out of range returns 0) and a NaN result.
+#define ALIGNQ_NERF_LDS_FLOATS (ALIGNQ_NERF_N * 8)
+static __device__ const float g_nerf_tab[2][ALIGNQ_NERF_N][4] = {ALIGNQ_NERF_POLY, ALIGNQ_NERF_CENTRE};   // the LDS image
+
+// every thread of the block calls it; the CALLER places a __syncthreads() before the first nerf32
+__device__ __forceinline__ void nerf_tab_load(float* tab) {
+  for (int i = threadIdx.x; i < ALIGNQ_NERF_LDS_FLOATS; i += blockDim.x) tab[i] = (&g_nerf_tab[0][0][0])[i];
+}
+// The same in two halves for the latency-bound kernels: request the image into registers first, issue the kernel's own
+// loads, THEN store it (memory returns in order, so the store waits for the image only) and pass a barrier.
+template <int NT>
+struct NerfRegs {
+  float v[(ALIGNQ_NERF_LDS_FLOATS + NT - 1) / NT];
+};
+template <int NT>
+__device__ __forceinline__ NerfRegs<NT> nerf_tab_fetch() {
+  NerfRegs<NT> r;
+#pragma unroll
+  for (int j = 0; j < (ALIGNQ_NERF_LDS_FLOATS + NT - 1) / NT; j++) {
+    const int i = threadIdx.x + j * NT;
+    r.v[j] = (&g_nerf_tab[0][0][0])[i < ALIGNQ_NERF_LDS_FLOATS ? i : ALIGNQ_NERF_LDS_FLOATS - 1];
+  }
+  return r;
+}
+template <int NT>
+__device__ __forceinline__ void nerf_tab_store(float* tab, const NerfRegs<NT>& r) {
+#pragma unroll
+  for (int j = 0; j < (ALIGNQ_NERF_LDS_FLOATS + NT - 1) / NT; j++) {
+    const int i = threadIdx.x + j * NT;
+    if (i < ALIGNQ_NERF_LDS_FLOATS) tab[i] = r.v[j];
+  }
 }
 
-// Branch-free form: both polynomial regions are evaluated and selected per lane (v_cndmask).  Issue rates measured on
-// MI355X (tools/src/valu_rate.hip): v_fma/v_mul/v_add ~2.7 cycles per wave64 instruction, v_rndne/v_min/v_cmp/v_cndmask/
-// v_ldexp/v_cvt/v_bfi 4, v_exp/v_rcp 8, v_pk_fma_f32 ~4.9 (so packed fp32 does not pay here) - hence as few selects,
-// compares and conversions as the spec allows.  On random data almost
-// every wave has lanes in both regions, so a branchy form executes both anyway and pays the exec-mask/branch traffic
-// on top (measured in the ISA of the site kernels: ~4 scalar/branch instructions per element).  Values are identical
-// to the branchy statement of the spec (same operations per lane).
-__device__ __forceinline__ float erf32(float x) {
-  const float a = fabsf(x);
-  // region A: a < 0.875
-  const float s = a * a;
-  float pa = ALIGNQ_PA6;
-  pa = __fmaf_rn(pa, s, ALIGNQ_PA5);
-  pa = __fmaf_rn(pa, s, ALIGNQ_PA4);
-  pa = __fmaf_rn(pa, s, ALIGNQ_PA3);
-  pa = __fmaf_rn(pa, s, ALIGNQ_PA2);
-  pa = __fmaf_rn(pa, s, ALIGNQ_PA1);
-  pa = __fmaf_rn(pa, s, ALIGNQ_PA0);
-  const float ra = __fmaf_rn(a, pa, a);
-  // region B: 0.875 <= a < 4 (the argument is clamped so the unselected lanes stay finite)
-  const float ab = fminf(a, ALIGNQ_ERF_HI);
-  float pb = ALIGNQ_PB7;
-  pb = __fmaf_rn(pb, ab, ALIGNQ_PB6);
-  pb = __fmaf_rn(pb, ab, ALIGNQ_PB5);
-  pb = __fmaf_rn(pb, ab, ALIGNQ_PB4);
-  pb = __fmaf_rn(pb, ab, ALIGNQ_PB3);
-  pb = __fmaf_rn(pb, ab, ALIGNQ_PB2);
-  pb = __fmaf_rn(pb, ab, ALIGNQ_PB1);
-  pb = __fmaf_rn(pb, ab, ALIGNQ_PB0);
-  const float rb = 1.0f - exp32_neg_small(-pb);
-  // One select covers the spec's three cases: for a >= ERF_HI the clamped region-B value is 1 - 1.54e-8 == 1.0f exactly
-  // (checked against the oracle by tests/test_oracle_c.py), and a NaN fails (a >= T), picking ra = fma(NaN, ., NaN).
-  const float res = (a >= ALIGNQ_ERF_T) ? rb : ra;
-  return copysignf(res, x);
+// `tab` as the kernels pass it around: the LDS byte address of the image plus 16 * -bits(2^20) (mod 2^32), wave-uniform, so
+// that ONE v_lshl_add_u32 turns the bits of u into the address of the node's first record (the second record is the
+// instruction's offset field).
+typedef float nerf_f4 __attribute__((ext_vector_type(4)));
+typedef float nerf_f2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const nerf_f4 LdsF4;
+typedef __attribute__((address_space(3))) const nerf_f2 LdsF2;
+struct NerfTab {
+  uint32_t base;
+};
+__device__ __forceinline__ NerfTab nerf_tab(const float* tab) {
+  NerfTab t;
+  t.base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float*)tab + 0x68000000u;   // -(0x49800000 << 4)
+  // opaque to the optimiser: otherwise it folds the (link-time constant) address into two different 32-bit literals and
+  // spends three vector instructions per element on the two addresses instead of one v_lshl_add_u32 + an offset field
+  asm volatile("" : "+s"(t.base));
+  return t;
 }
 
-#define ALIGNQ_SQRT2F 1.41421356237309504880f
+__device__ __forceinline__ float nerf32(float y, const NerfTab tab) {
+  const float a = __builtin_elementwise_minimum(__builtin_fabsf(y), ALIGNQ_NERF_YMAX);
+  const float u = __fadd_rn(a, ALIGNQ_NERF_MAGIC);
+  const uint32_t addr = (__float_as_uint(u) << 4) + tab.base;
+  const nerf_f4 c = *reinterpret_cast<LdsF4*>(addr);
+  const nerf_f2 p = *reinterpret_cast<LdsF2*>(addr + ALIGNQ_NERF_N * 16);
+  const float d = __fsub_rn(a, p.y);
+  float q = __fmaf_rn(c.w, d, c.z);
+  q = __fmaf_rn(q, d, c.y);
+  q = __fmaf_rn(q, d, c.x);
+  return copysignf(__fmaf_rn(q, d, p.x), y);
+}
+
 #define ALIGNQ_LOG_SQRT_2PI_F 0.91893853320467274178f
 #define ALIGNQ_TWO_OVER_SQRT_2PI 0.79788456080286535588f  // 2*phi(0)
 
-// IEEE-754 division x/d by a fixed divisor through its correctly rounded reciprocal y = RN(1/d):
-//   q0 = x*y; r = fma(-q0, d, x) (exact remainder); q = fma(r, y, q0)      (3 VALU ops instead of ~10)
+// IEEE-754 division b/n of a level index by n = 2^k-1 through the correctly rounded reciprocal y = RN(1/n):
+//   q0 = b*y; r = fma(-q0, n, b) (exact remainder); q = fma(r, y, q0)      (3 VALU ops instead of ~10)
 // The arithmetic SPEC remains "IEEE division" (the C oracle divides).  tests/native/verify_div.c proves equality
-// exhaustively for d = float(sqrt(2)) over every finite float with |x| >= 1e-30 (below that the remainder underflows;
-// such z are absorbed by 0.5*(1+erf(z)) == 0.5 exactly, so no output changes), both zeros included, and for d = 2^k-1,
-// k<=16, over every integer-valued |x| <= 8*d+2 and -0 (the bin indices).  +-inf is passed through like a division would.
-__device__ __forceinline__ float div_const(float x, float d, float y) {
-  const float q0 = __fmul_rn(x, y);
-  const float r = __fmaf_rn(-q0, d, x);
+// exhaustively for k<=16 over every integer-valued |b| <= 8*n+2 and -0.  The fma chain turns b = -0 into +0: the sign
+// bit of b is OR-ed back (q is +0 or carries b's sign already; NaN stays NaN) - one v_and_or_b32.
+__device__ __forceinline__ float div_levels(float b, float n, float y) {
+  const float q0 = __fmul_rn(b, y);
+  const float r = __fmaf_rn(-q0, n, b);
   const float q = __fmaf_rn(r, y, q0);
-  // q0 already is the answer for the two cases the correction step mangles: a signed zero (the fma chain turns -0
-  // into +0) and +-inf (inf - inf = NaN)
-  return __builtin_amdgcn_classf(q0, 0x264) ? q0 : q;     // v_cmp_class: -inf | -0 | +0 | +inf
+  return __uint_as_float(__float_as_uint(q) | (__float_as_uint(b) & 0x80000000u));
 }
-#define ALIGNQ_RCP_SQRT2F 0.707106769084930419921875f   // RN(1/float(sqrt(2)))
 
-// Normal(m,s).cdf in torch's op order (torch/distributions/normal.py; reference
-// model/quantization.py:50-51): 0.5*(1+erf((v-m)*(1/s)/sqrt(2))).  rs = 1/s.
-__device__ __forceinline__ float gauss_cdf32(float v, float m, float rs) {
-  float z = div_const(__fmul_rn(__fsub_rn(v, m), rs), ALIGNQ_SQRT2F, ALIGNQ_RCP_SQRT2F);
-  return __fmul_rn(0.5f, __fadd_rn(1.0f, erf32(z)));
+// 1 + nerf32((v-m)*rs): twice Normal(m,s).cdf (torch/distributions/normal.py; reference model/quantization.py:50-51).
+// The halving and the doubling that follow in the reference (c = 0.5*(1+erf), 2c-1) are exact, so both trees continue from u1.
+__device__ __forceinline__ float gauss_u1(float v, float m, float rs, const NerfTab tab) {
+  return __fadd_rn(1.0f, nerf32(__fmul_rn(__fsub_rn(v, m), rs), tab));
+}
+__device__ __forceinline__ float gauss_cdf32(float v, float m, float rs, const NerfTab tab) {
+  return __fmul_rn(0.5f, gauss_u1(v, m, rs, tab));
 }
 
 // Level-division context: n = 2^k-1 and, when every |bin| of the call is known to stay within the exhaustively
@@ -132,21 +149,44 @@ __device__ __forceinline__ float round_bins(float t, int k, const Levels& L, flo
   if (k == 1) { float s = (float)((t > 0.0f) - (t < 0.0f)); *bin = s; return s; }
   float b = rintf(__fmul_rn(t, L.n));
   *bin = b;
-  if (L.yn != 0.0f) return div_const(b, L.n, L.yn);
+  if (L.yn != 0.0f) return div_levels(b, L.n, L.yn);
   return __fdiv_rn(b, L.n);
 }
 
+// BOUNDED: the caller has checked L.yn != 0 (k not 1 or 32, |level index| within the verified range) for the whole launch,
+// which removes the per-element scalar branches on k from the streaming loops: `ALIGNQ_BOUNDED_SWITCH(L, body)` runs
+// `body` with a constexpr bool kBounded in both forms.
+template <bool BOUNDED>
+__device__ __forceinline__ float round_bins_t(float t, int k, const Levels& L, float* bin) {
+  if (BOUNDED) {
+    const float b = rintf(__fmul_rn(t, L.n));
+    *bin = b;
+    return div_levels(b, L.n, L.yn);
+  }
+  return round_bins(t, k, L, bin);
+}
+#define ALIGNQ_BOUNDED_SWITCH(L, ...)                          \
+  if ((L).yn != 0.0f) {                                        \
+    constexpr bool kBounded = true;                            \
+    __VA_ARGS__                                                \
+  } else {                                                     \
+    constexpr bool kBounded = false;                           \
+    __VA_ARGS__                                                \
+  }
+
 // activation transform + quantise for one element; returns x_q, *t_pre = pre-round transform
-template <int FORMULA>
-__device__ __forceinline__ float act_quant1(float x, int k, const Levels& n, float r, float* t_pre, float* bin) {
-  float c = gauss_cdf32(x, 0.0f, 1.0f);
+template <int FORMULA, bool BOUNDED = false>
+__device__ __forceinline__ float act_quant1(float x, int k, const Levels& n, float r, float* t_pre, float* bin,
+                                            const NerfTab tab) {
+  const float u1 = __fadd_rn(1.0f, nerf32(x, tab));          // (x - 0) * 1 == x
   if (FORMULA == 0) {
-    float t = __fmul_rn(__fsub_rn(__fmul_rn(c, 2.0f), 1.0f), r);
+    float t = __fmul_rn(__fsub_rn(u1, 1.0f), r);             // (2c - 1) * r with 2c == u1 exactly
     *t_pre = t;
-    return round_bins(t, k, n, bin);
+    return round_bins_t<BOUNDED>(t, k, n, bin);
   } else {
+    const float c = __fmul_rn(0.5f, u1);
     *t_pre = c;
-    float q = round_bins(c, k, n, bin);
+    float q = round_bins_t<BOUNDED>(c, k, n, bin);
     return __fmul_rn(__fsub_rn(__fmul_rn(q, 2.0f), 1.0f), r);
   }
 }
@@ -209,12 +249,14 @@ __device__ __forceinline__ WeightConsts weight_consts(float m, float s, int k) {
 
 // weight_quantize_fn.forward for one element given (m, s): returns W_q, *t = the tree's weight_cdf
 template <int FORMULA>
-__device__ __forceinline__ float weight_quant1(float v, const WeightConsts& wc, int k, float* t, float* bin) {
-  float c = gauss_cdf32(v, wc.m, wc.rs);
+__device__ __forceinline__ float weight_quant1(float v, const WeightConsts& wc, int k, float* t, float* bin,
+                                               const NerfTab tab) {
+  const float u1 = gauss_u1(v, wc.m, wc.rs, tab);
   if (FORMULA == 0) {
-    *t = __fsub_rn(__fmul_rn(c, 2.0f), 1.0f);
+    *t = __fsub_rn(u1, 1.0f);
     return round_bins(*t, k, wc.nlev, bin);
   }
+  const float c = __fmul_rn(0.5f, u1);
   *t = c;
   return __fsub_rn(__fmul_rn(round_bins(c, k, wc.nlev, bin), 2.0f), 1.0f);
 }

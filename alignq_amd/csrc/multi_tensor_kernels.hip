@@ -70,6 +70,9 @@ template <int FORMULA>
 __global__ __launch_bounds__(kThreads) void mt_weight_apply_kernel(WChunk c, const double* __restrict__ ws,
                                                                    float* __restrict__ ms_out, int t0, int k) {
   __shared__ double sm[32];
+  __shared__ __attribute__((aligned(16))) float nerf_lds[ALIGNQ_NERF_LDS_FLOATS];
+  nerf_tab_load(nerf_lds);                  // block_sum2d's barriers publish it
+  const NerfTab tab = nerf_tab(nerf_lds);
   const int t = blockIdx.y;
   const long n = c.n[t];
   double s = 0, s2 = 0;
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(kThreads) void mt_weight_apply_kernel(WChunk c, con
       const long i = MT_IDX(u);
       if (i < n) {
         float tt, b;
-        q[i] = weight_quant1<FORMULA>(v[u], wc, k, &tt, &b);
+        q[i] = weight_quant1<FORMULA>(v[u], wc, k, &tt, &b, tab);
         if (cdf) cdf[i] = tt;
         if (pdf) pdf[i] = weight_pdf2(v[u], wc);
       }

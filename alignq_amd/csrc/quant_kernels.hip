@@ -18,6 +18,7 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kMaxBlocks = 2048;      // 256 CUs x 8 blocks (guide: cap the grid, stride the rest)
 constexpr int kWsBlocks = 256;        // partials per reduction (one block per CU)
+constexpr int kU = 4;                 // independent float4 per thread and iteration in the streaming kernels
 
 inline int grid_for(int64_t n_vec) {
   int64_t b = (n_vec + kThreads - 1) / kThreads;
@@ -32,31 +33,49 @@ __global__ __launch_bounds__(kThreads) void act_quant_fwd_kernel(const float* __
                                                                  float* __restrict__ xq,
                                                                  int32_t* __restrict__ bins, int64_t n,
                                                                  int k, float r) {
+  __shared__ __attribute__((aligned(16))) float tab_lds[ALIGNQ_NERF_LDS_FLOATS];
+  nerf_tab_load(tab_lds);
+  __syncthreads();
+  const NerfTab tab = nerf_tab(tab_lds);
   const Levels nlev = make_levels(k, fabsf(r) <= 8.0f);
   const int64_t nvec = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * kThreads;
   const float4* x4 = reinterpret_cast<const float4*>(x);
   float4* q4 = reinterpret_cast<float4*>(xq);
-  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += stride) {
-    float4 v = x4[i];
-    float4 o;
-    float t, b0, b1, b2, b3;
-    o.x = act_quant1<FORMULA>(v.x, k, nlev, r, &t, &b0);
-    o.y = act_quant1<FORMULA>(v.y, k, nlev, r, &t, &b1);
-    o.z = act_quant1<FORMULA>(v.z, k, nlev, r, &t, &b2);
-    o.w = act_quant1<FORMULA>(v.w, k, nlev, r, &t, &b3);
-    if (RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-    q4[i] = o;
-    if (BINS) {
-      int4 bi = make_int4((int)b0, (int)b1, (int)b2, (int)b3);
-      reinterpret_cast<int4*>(bins)[i] = bi;
+  // kU independent 16-byte loads per thread in flight (the transform is ~19 vector instructions per element since round 3:
+  // the kernel is bound by memory, so what matters is bytes in flight: 32 waves x kU KiB per CU)
+  ALIGNQ_BOUNDED_SWITCH(nlev,
+  for (int64_t i0 = (int64_t)blockIdx.x * kThreads + threadIdx.x; i0 < nvec; i0 += kU * stride) {
+    float4 v[kU];
+_Pragma("unroll")
+    for (int u = 0; u < kU; u++) {
+      const int64_t i = i0 + u * stride;
+      v[u] = x4[i < nvec ? i : i0];
     }
-  }
+_Pragma("unroll")
+    for (int u = 0; u < kU; u++) {
+      const int64_t i = i0 + u * stride;
+      float4 o;
+      float t, b0, b1, b2, b3;
+      o.x = act_quant1<FORMULA, kBounded>(v[u].x, k, nlev, r, &t, &b0, tab);
+      o.y = act_quant1<FORMULA, kBounded>(v[u].y, k, nlev, r, &t, &b1, tab);
+      o.z = act_quant1<FORMULA, kBounded>(v[u].z, k, nlev, r, &t, &b2, tab);
+      o.w = act_quant1<FORMULA, kBounded>(v[u].w, k, nlev, r, &t, &b3, tab);
+      if (RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      if (i < nvec) {
+        q4[i] = o;
+        if (BINS) {
+          int4 bi = make_int4((int)b0, (int)b1, (int)b2, (int)b3);
+          reinterpret_cast<int4*>(bins)[i] = bi;
+        }
+      }
+    }
+  })
   // tail (n % 4) by the first threads of block 0
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     int64_t i = (nvec << 2) + threadIdx.x;
     float t, b;
-    const float q = act_quant1<FORMULA>(x[i], k, nlev, r, &t, &b);
+    const float q = act_quant1<FORMULA>(x[i], k, nlev, r, &t, &b, tab);
     xq[i] = RELU ? fmaxf(q, 0.f) : q;
     if (BINS) bins[i] = (int)b;
   }
@@ -84,18 +103,30 @@ __global__ __launch_bounds__(kThreads) void act_quant_bwd_kernel(const float* __
   const float4* g4 = reinterpret_cast<const float4*>(g);
   const float4* x4 = reinterpret_cast<const float4*>(x);
   float4* d4 = reinterpret_cast<float4*>(dx);
-  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += stride) {
-    float4 gv = g4[i], xv = x4[i], o;
-    if (MASK) {
-      const float4 yv = reinterpret_cast<const float4*>(y)[i];
-      gv.x = yv.x > 0.f ? gv.x : 0.f; gv.y = yv.y > 0.f ? gv.y : 0.f;
-      gv.z = yv.z > 0.f ? gv.z : 0.f; gv.w = yv.w > 0.f ? gv.w : 0.f;
+  constexpr int kUb = 2;     // two or three streams each
+  for (int64_t i0 = (int64_t)blockIdx.x * kThreads + threadIdx.x; i0 < nvec; i0 += kUb * stride) {
+    float4 gv[kUb], xv[kUb], yv[kUb];
+#pragma unroll
+    for (int u = 0; u < kUb; u++) {
+      const int64_t i = i0 + u * stride, ic = i < nvec ? i : i0;
+      gv[u] = g4[ic];
+      xv[u] = x4[ic];
+      if (MASK) yv[u] = reinterpret_cast<const float4*>(y)[ic];
     }
-    o.x = gv.x * act_jac(xv.x, r);
-    o.y = gv.y * act_jac(xv.y, r);
-    o.z = gv.z * act_jac(xv.z, r);
-    o.w = gv.w * act_jac(xv.w, r);
-    d4[i] = o;
+#pragma unroll
+    for (int u = 0; u < kUb; u++) {
+      const int64_t i = i0 + u * stride;
+      float4 o;
+      if (MASK) {
+        gv[u].x = yv[u].x > 0.f ? gv[u].x : 0.f; gv[u].y = yv[u].y > 0.f ? gv[u].y : 0.f;
+        gv[u].z = yv[u].z > 0.f ? gv[u].z : 0.f; gv[u].w = yv[u].w > 0.f ? gv[u].w : 0.f;
+      }
+      o.x = gv[u].x * act_jac(xv[u].x, r);
+      o.y = gv[u].y * act_jac(xv[u].y, r);
+      o.z = gv[u].z * act_jac(xv[u].z, r);
+      o.w = gv[u].w * act_jac(xv[u].w, r);
+      if (i < nvec) d4[i] = o;
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     int64_t i = (nvec << 2) + threadIdx.x;
@@ -157,12 +188,16 @@ __global__ __launch_bounds__(kThreads) void weight_quant_fwd_kernel(const float*
                                                                     float* __restrict__ q, float* __restrict__ cdf_out,
                                                                     float* __restrict__ pdf_out,
                                                                     int32_t* __restrict__ bins, int64_t n, int k) {
+  __shared__ __attribute__((aligned(16))) float tab_lds[ALIGNQ_NERF_LDS_FLOATS];
+  nerf_tab_load(tab_lds);
+  __syncthreads();
+  const NerfTab tab = nerf_tab(tab_lds);
   const WeightConsts wc = weight_consts(ms[0], ms[1], k);
   const int64_t stride = (int64_t)gridDim.x * kThreads;
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
     float v = w[i];
     float t, b;
-    q[i] = weight_quant1<FORMULA>(v, wc, k, &t, &b);
+    q[i] = weight_quant1<FORMULA>(v, wc, k, &t, &b, tab);
     if (cdf_out) cdf_out[i] = t;
     if (bins) bins[i] = (int)b;
     if (pdf_out) pdf_out[i] = weight_pdf2(v, wc);
@@ -222,7 +257,7 @@ __global__ __launch_bounds__(kThreads) void weight_bwd_apply_kernel(const float*
 template <int FORMULA>
 __device__ __forceinline__ float bin_value(float b, int k, const Levels& L, float r) {
   float q = b;
-  if (k != 1 && k != 32) q = (L.yn != 0.0f) ? div_const(b, L.n, L.yn) : __fdiv_rn(b, L.n);
+  if (k != 1 && k != 32) q = (L.yn != 0.0f) ? div_levels(b, L.n, L.yn) : __fdiv_rn(b, L.n);
   if (FORMULA == 0) return q;
   return __fmul_rn(__fsub_rn(__fmul_rn(q, 2.0f), 1.0f), r);
 }
@@ -238,18 +273,23 @@ __global__ __launch_bounds__(kThreads) void act_quant_fwd_packed_kernel(const fl
                                                                         T* __restrict__ bins, int64_t n, int k, float r,
                                                                         int relu) {
   typedef typename Vec4<T>::type V4;
+  __shared__ __attribute__((aligned(16))) float tab_lds[ALIGNQ_NERF_LDS_FLOATS];
+  nerf_tab_load(tab_lds);
+  __syncthreads();
+  const NerfTab tab = nerf_tab(tab_lds);
   const Levels nlev = make_levels(k, fabsf(r) <= 8.0f);
   const int64_t nvec = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * kThreads;
   const float4* x4 = reinterpret_cast<const float4*>(x);
+  ALIGNQ_BOUNDED_SWITCH(nlev,
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += stride) {
     const float4 v = x4[i];
     float4 o;
     float t, b0, b1, b2, b3;
-    o.x = act_quant1<FORMULA>(v.x, k, nlev, r, &t, &b0);
-    o.y = act_quant1<FORMULA>(v.y, k, nlev, r, &t, &b1);
-    o.z = act_quant1<FORMULA>(v.z, k, nlev, r, &t, &b2);
-    o.w = act_quant1<FORMULA>(v.w, k, nlev, r, &t, &b3);
+    o.x = act_quant1<FORMULA, kBounded>(v.x, k, nlev, r, &t, &b0, tab);
+    o.y = act_quant1<FORMULA, kBounded>(v.y, k, nlev, r, &t, &b1, tab);
+    o.z = act_quant1<FORMULA, kBounded>(v.z, k, nlev, r, &t, &b2, tab);
+    o.w = act_quant1<FORMULA, kBounded>(v.w, k, nlev, r, &t, &b3, tab);
     V4 bi;
     bi.x = (T)(int)b0; bi.y = (T)(int)b1; bi.z = (T)(int)b2; bi.w = (T)(int)b3;
     reinterpret_cast<V4*>(bins)[i] = bi;
@@ -257,11 +297,11 @@ __global__ __launch_bounds__(kThreads) void act_quant_fwd_packed_kernel(const fl
       if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
       reinterpret_cast<float4*>(xq)[i] = o;
     }
-  }
+  })
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const int64_t i = (nvec << 2) + threadIdx.x;
     float t, b;
-    const float q = act_quant1<FORMULA>(x[i], k, nlev, r, &t, &b);
+    const float q = act_quant1<FORMULA>(x[i], k, nlev, r, &t, &b, tab);
     bins[i] = (T)(int)b;
     if (WITH_XQ) xq[i] = relu ? fmaxf(q, 0.f) : q;
   }

@@ -102,10 +102,17 @@ __global__ __launch_bounds__(kThreads1) void site1_fwd_kernel(const float* __res
                                                               int n_sub, unsigned* __restrict__ counter,
                                                               const float* __restrict__ res, int relu) {
   __shared__ __attribute__((aligned(16))) unsigned lds[(kWaves * WBUF > 4096) ? kWaves * WBUF : 4096];
+  __shared__ __attribute__((aligned(16))) float nerf_lds[PAIR ? ALIGNQ_NERF_LDS_FLOATS : 4];
+  if (PAIR) {
+    nerf_tab_load(nerf_lds);
+    __syncthreads();
+  }
+  const NerfTab tab = nerf_tab(nerf_lds);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;      // h doubles as the row half of the load mapping
   unsigned* W = lds + w * WBUF;
   const Levels nlev = make_levels(k, fabsf(r) <= 8.0f);
+  const bool bounded = nlev.yn != 0.0f;          // launch-uniform
   const float invB = 1.0f / (float)B, invBm1 = 1.0f / (float)(B - 1);
   if (blockIdx.x == 0 && tid == 0 && counter) *counter = 0u;
 
@@ -134,7 +141,8 @@ __global__ __launch_bounds__(kThreads1) void site1_fwd_kernel(const float* __res
       if (RPL * h + q < B) {
         if (PAIR) {
           float b;
-          float qq = act_quant1<0>(xr[q], k, nlev, r, &tr[q], &b);
+          float qq = bounded ? act_quant1<0, true>(xr[q], k, nlev, r, &tr[q], &b, tab)
+                             : act_quant1<0>(xr[q], k, nlev, r, &tr[q], &b, tab);
           if (RES) qq += rr[q];
           if (relu) qq = fmaxf(qq, 0.0f);
           if (qp && cok) qp[(int64_t)q * F] = qq;

@@ -158,6 +158,11 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
   constexpr int KSPLIT = (TFv >= 32) ? 2 : 1;     // K-halves per tile (a half must hold >= 16 features)
   constexpr int KSTEPS = TFv / 16 / KSPLIT;       // 16-feature MFMA steps per item
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STAGE_BYTES + (4 * TFv + 2 * 16 * TFv) * 4];
+  __shared__ __attribute__((aligned(16))) float nerf_lds[PAIR ? ALIGNQ_NERF_LDS_FLOATS : 4];
+  // the transform's table (alignq_math.h): requested first, stored behind the tile loads of the first iteration
+  NerfRegs<NT> nerf_regs;
+  if (PAIR) nerf_regs = nerf_tab_fetch<NT>();
+  const NerfTab tab = nerf_tab(nerf_lds);
   __bf16* Xhi = reinterpret_cast<__bf16*>(lds_raw);
   __bf16* Xlo = Xhi + ARR;
   __bf16* Thi = Xhi + 2 * ARR;
@@ -239,6 +244,10 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
       const bool ok = row < B;
       const unsigned off = (unsigned)row * (unsigned)F + (unsigned)col;
       xv[j] = ld4(x, off, col, F, ok, aligned);
+    }
+    if (PAIR && tile == (int)blockIdx.x) {     // first iteration (block-uniform): publish the transform's table
+      nerf_tab_store<NT>(nerf_lds, nerf_regs);
+      __syncthreads();
     }
     // ---- folded batch-norm: x = a*z + b with (a, b) of this tile's channel (HW % 64 == 0: one channel per tile) -------
     if (bn.ab && bn.nhwc) {
@@ -449,10 +458,17 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
         float4 q, rl = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!kEarlyRes && bn.res) rl = ld4(bn.res, off, col, F, ok, aligned);
         float b0, b1, b2, b3;
-        q.x = act_quant1<0>(xv[j].x, k, nlev, r, &tv[j].x, &b0);
-        q.y = act_quant1<0>(xv[j].y, k, nlev, r, &tv[j].y, &b1);
-        q.z = act_quant1<0>(xv[j].z, k, nlev, r, &tv[j].z, &b2);
-        q.w = act_quant1<0>(xv[j].w, k, nlev, r, &tv[j].w, &b3);
+        if (nlev.yn != 0.0f) {      // launch-uniform: no per-element branches on k in the common case
+          q.x = act_quant1<0, true>(xv[j].x, k, nlev, r, &tv[j].x, &b0, tab);
+          q.y = act_quant1<0, true>(xv[j].y, k, nlev, r, &tv[j].y, &b1, tab);
+          q.z = act_quant1<0, true>(xv[j].z, k, nlev, r, &tv[j].z, &b2, tab);
+          q.w = act_quant1<0, true>(xv[j].w, k, nlev, r, &tv[j].w, &b3, tab);
+        } else {
+          q.x = act_quant1<0>(xv[j].x, k, nlev, r, &tv[j].x, &b0, tab);
+          q.y = act_quant1<0>(xv[j].y, k, nlev, r, &tv[j].y, &b1, tab);
+          q.z = act_quant1<0>(xv[j].z, k, nlev, r, &tv[j].z, &b2, tab);
+          q.w = act_quant1<0>(xv[j].w, k, nlev, r, &tv[j].w, &b3, tab);
+        }
         if (bn.bins && ok && col < F) {
           // N2: the level index of the stored value (no residual on this path; the fused ReLU clamps the index at 0), narrow:
           // 8 or 4 bytes per quad at the element offset (the launcher requires the aligned float4 path: F % 4 == 0)

@@ -78,6 +78,12 @@ __global__ __launch_bounds__(kThreads) void site_fwd_kernel(const float* __restr
   constexpr int KS = (NB == 1) ? 4 : 1;       // K-split across waves when there is a single output tile
   constexpr int LDS_FLOATS = (2 * BP * LD > 4096 ? 2 * BP * LD : 4096) + 4 * TF;
   __shared__ float lds[LDS_FLOATS];
+  __shared__ __attribute__((aligned(16))) float nerf_lds[PAIR ? ALIGNQ_NERF_LDS_FLOATS : 4];
+  if (PAIR) {
+    nerf_tab_load(nerf_lds);
+    __syncthreads();
+  }
+  const NerfTab tab = nerf_tab(nerf_lds);
   float* Xs = lds;                            // [BP][LD]
   float* Ts = lds + BP * LD;                  // [BP][LD]
   float* red = Ts;                            // [2][16][TF]   (aliased: used before Ts is written)
@@ -114,10 +120,10 @@ __global__ __launch_bounds__(kThreads) void site_fwd_kernel(const float* __restr
       if (PAIR) {
         float4 q;
         float b;
-        q.x = act_quant1<0>(xv[j].x, k, nlev, r, &tv[j].x, &b);
-        q.y = act_quant1<0>(xv[j].y, k, nlev, r, &tv[j].y, &b);
-        q.z = act_quant1<0>(xv[j].z, k, nlev, r, &tv[j].z, &b);
-        q.w = act_quant1<0>(xv[j].w, k, nlev, r, &tv[j].w, &b);
+        q.x = act_quant1<0>(xv[j].x, k, nlev, r, &tv[j].x, &b, tab);
+        q.y = act_quant1<0>(xv[j].y, k, nlev, r, &tv[j].y, &b, tab);
+        q.z = act_quant1<0>(xv[j].z, k, nlev, r, &tv[j].z, &b, tab);
+        q.w = act_quant1<0>(xv[j].w, k, nlev, r, &tv[j].w, &b, tab);
         if (xq) store4(xq, off, col, F, ok, aligned, q);
       }
     }
@@ -297,6 +303,9 @@ __global__ __launch_bounds__(kThreads) void site_bwd_kernel(const float* __restr
   constexpr int PX = (NB == 4) ? 2 : 1;
   constexpr int KSTEPS = BP / 2;
   __shared__ float lds[2 * BP * LD + 4 * TF + NB * NOP * 2 * TF];
+  __shared__ __attribute__((aligned(16))) float nerf_lds[PAIR ? ALIGNQ_NERF_LDS_FLOATS : 4];
+  if (PAIR) nerf_tab_load(nerf_lds);           // published by the tile loop's first barrier
+  const NerfTab tab = nerf_tab(nerf_lds);
   float* Xs = lds;
   float* Ts = lds + BP * LD;
   float* colv = lds + 2 * BP * LD;             // mean_x, rho_x, mean_t, rho_t  [4][TF]
@@ -352,8 +361,7 @@ __global__ __launch_bounds__(kThreads) void site_bwd_kernel(const float* __restr
           const bool okc = ok && (col + e < F);
           Xs[row * LD + 4 * c + e] = okc ? (xe[e] - mx[e]) * rx[e] : 0.0f;
           if (PAIR) {
-            const float cdfv = gauss_cdf32(xe[e], 0.0f, 1.0f);
-            const float t = (cdfv * 2.0f - 1.0f) * r;
+            const float t = __fmul_rn(__fsub_rn(gauss_u1(xe[e], 0.0f, 1.0f, tab), 1.0f), r);
             Ts[row * LD + 4 * c + e] = okc ? (t - mt[e]) * rt[e] : 0.0f;
           }
         }

@@ -8,7 +8,7 @@
  * tests/test_oracle_c.py.  Elementwise fp32 results follow the reference's op ORDER exactly; the
  * only place they can differ from torch-CPU is the last ulp of erf/exp, because torch-CPU evaluates
  * those through Intel MKL VML (closed source).  This file instead implements the repo's own
- * ALIGNQ-ERF32 / ALIGNQ-EXP32 specification (alignq_amd/csrc/gen_erf32_coeffs.py),
+ * ALIGNQ-NERF32 / ALIGNQ-EXP32 specification (alignq_amd/csrc/gen_erf32_coeffs.py),
  * which the HIP kernels implement bit-for-bit as well.  Consequence: integer
  * bins agree with torch everywhere except inside the "tie zone" |frac(t*n) - 1/2| < 1e-4, where a
  * 1-ulp erf difference may flip the rounding; tests assert exactness outside it and +-1 inside.
@@ -59,51 +59,49 @@ float oq_exp32_1(float x) {
   return e * pow2i(h) * pow2i(n - h);
 }
 
-float oq_erf32_1(float x) {
-  float a = fabsf(x);
-  float res;
-  if (a < ALIGNQ_ERF_T) {
-    float s = a * a;
-    float p = ALIGNQ_PA6;
-    p = fmaf(p, s, ALIGNQ_PA5);
-    p = fmaf(p, s, ALIGNQ_PA4);
-    p = fmaf(p, s, ALIGNQ_PA3);
-    p = fmaf(p, s, ALIGNQ_PA2);
-    p = fmaf(p, s, ALIGNQ_PA1);
-    p = fmaf(p, s, ALIGNQ_PA0);
-    res = fmaf(a, p, a);
-  } else if (a < ALIGNQ_ERF_HI) {
-    float p = ALIGNQ_PB7;
-    p = fmaf(p, a, ALIGNQ_PB6);
-    p = fmaf(p, a, ALIGNQ_PB5);
-    p = fmaf(p, a, ALIGNQ_PB4);
-    p = fmaf(p, a, ALIGNQ_PB3);
-    p = fmaf(p, a, ALIGNQ_PB2);
-    p = fmaf(p, a, ALIGNQ_PB1);
-    p = fmaf(p, a, ALIGNQ_PB0);
-    res = 1.0f - oq_exp32_1(-p);
-  } else {
-    res = (a != a) ? a : 1.0f;
-  }
-  return copysignf(res, x);
+/* ALIGNQ-NERF32 (round 3): nerf32(y) ~ erf(y/sqrt(2)) = 2*Phi(y) - 1, the function Normal(0,1).cdf needs.  ONE
+ * evaluated branch: a table node per 1/8 of |y| (found by adding 2^20, whose ulp is 1/8), a degree-4 polynomial in the
+ * exact difference to the node's centre.  Spec: alignq_amd/csrc/gen_erf32_coeffs.py; |error| <= 0.57 * 2^-24 over every
+ * fp32 (tests/native/verify_nerf.c).  It replaces "divide by sqrt(2), then erf" of torch's Normal.cdf
+ * (torch/distributions/normal.py; reference call sites model/quantization.py:50-51): the result is within 1 ulp(1) of
+ * what torch computes, the same distance the round-1/2 erf32 had (MKL's erf is not restatable). */
+static const float NERF_POLY[ALIGNQ_NERF_N][4] = ALIGNQ_NERF_POLY;
+static const float NERF_CENTRE[ALIGNQ_NERF_N][4] = ALIGNQ_NERF_CENTRE;
+
+float oq_nerf32_1(float y) {
+  float a = fabsf(y);
+  if (a != a) return y;                       /* NaN stays NaN (the device clamp is NaN-propagating) */
+  a = a < ALIGNQ_NERF_YMAX ? a : ALIGNQ_NERF_YMAX;
+  float u = a + ALIGNQ_NERF_MAGIC;            /* RN: u - 2^20 = a rounded to the nearest eighth, ties to even */
+  uint32_t ub, mb;
+  float magic = ALIGNQ_NERF_MAGIC;
+  memcpy(&ub, &u, 4);
+  memcpy(&mb, &magic, 4);
+  const uint32_t k = ub - mb;                 /* 0 .. ALIGNQ_NERF_N-1 */
+  const float* c = NERF_POLY[k];
+  float d = a - NERF_CENTRE[k][1];            /* exact */
+  float q = c[3];
+  q = fmaf(q, d, c[2]);
+  q = fmaf(q, d, c[1]);
+  q = fmaf(q, d, c[0]);
+  float res = fmaf(q, d, NERF_CENTRE[k][0]);
+  return copysignf(res, y);
 }
 
-void oq_erf32(const float* x, float* y, long n) {
-  for (long i = 0; i < n; i++) y[i] = oq_erf32_1(x[i]);
+void oq_nerf32(const float* x, float* y, long n) {
+  for (long i = 0; i < n; i++) y[i] = oq_nerf32_1(x[i]);
 }
 void oq_exp32(const float* x, float* y, long n) {
   for (long i = 0; i < n; i++) y[i] = oq_exp32_1(x[i]);
 }
 
 /* ------------------------------------------------------------------ R1/R2 elementwise ------- */
-#define SQRT2F 1.41421356237309504880f          /* float(math.sqrt(2)) */
 #define LOG_SQRT_2PI 0.91893853320467274178     /* math.log(math.sqrt(2*math.pi)) */
 
-/* Normal(m,s).cdf in torch's op order: 0.5*(1+erf((v-m)*(1/s)/sqrt(2)))
- * (torch/distributions/normal.py cdf; reference call sites model/quantization.py:50-51). */
+/* Normal(m,s).cdf: 0.5*(1+erf((v-m)*(1/s)/sqrt(2))) (torch/distributions/normal.py cdf; reference call sites
+ * model/quantization.py:50-51), with erf(./sqrt 2) taken as ONE specified function, nerf32. */
 static inline float gauss_cdf32(float v, float m, float rs) {
-  float z = ((v - m) * rs) / SQRT2F;
-  return 0.5f * (1.0f + oq_erf32_1(z));
+  return 0.5f * (1.0f + oq_nerf32_1((v - m) * rs));
 }
 
 /* uniform_quantize(k).forward on a value already transformed (model/quantization.py:23-31) */

@@ -12,8 +12,8 @@ FORMULA_ADMM, FORMULA_CDF = 0, 1
 
 
 def _build():
-    src = os.path.join(ROOT, "oracle", "alignq_oracle.c")
-    if not os.path.exists(SO) or os.path.getmtime(SO) < os.path.getmtime(src):
+    srcs = [os.path.join(ROOT, "oracle", "alignq_oracle.c"), os.path.join(ROOT, "include", "alignq_erf32_coeffs.h")]
+    if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(s) for s in srcs):
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
 
 
@@ -39,9 +39,10 @@ def _f32(a):
 c_long, c_int, c_float = ctypes.c_long, ctypes.c_int, ctypes.c_float
 
 
-def erf32(x):
+def nerf32(x):
+    """ALIGNQ-NERF32: erf(x / sqrt(2)) = 2*Phi(x) - 1 as the repo specifies it (one table node + degree-4 polynomial)."""
     x = _f32(x); y = np.empty_like(x)
-    lib().oq_erf32(_p(x), _p(y), c_long(x.size)); return y
+    lib().oq_nerf32(_p(x), _p(y), c_long(x.size)); return y
 
 
 def exp32(x):
