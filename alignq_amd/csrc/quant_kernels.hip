@@ -18,7 +18,25 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kMaxBlocks = 2048;      // 256 CUs x 8 blocks (guide: cap the grid, stride the rest)
 constexpr int kWsBlocks = 256;        // partials per reduction (one block per CU)
-constexpr int kU = 4;                 // independent float4 per thread and iteration in the streaming kernels
+constexpr int kU = 4;                 // float4 per thread and tile in the streaming kernels (forward)
+constexpr int kUb = 2;                // ... backward: two or three input streams each
+
+// Streaming structure (tools/src/stream_bw.hip on MI355X, 2^26 floats, 1 read : 1 write): a block owns TILES of kU x 256
+// float4 (thread t takes t, t+256, ...: kU independent 16-byte loads in flight), inputs that are read once come in with
+// NON-TEMPORAL loads (they do not displace the output lines the consumer is about to read), the grid covers all tiles up to
+// 64 blocks per CU: 6.7 TB/s with the NERF32 arithmetic in the loop against 5.3 TB/s for the grid-stride form this file had
+// (hipMemcpy device-to-device on the same box: 5.26 TB/s).  nt on loads AND stores is slower (6.1), nt stores alone equal.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4_stream(const float4* p) {
+  const f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+constexpr int kTileBlocks = 256 * 64;
+inline int grid_tiles(int64_t n_vec, int u) {
+  int64_t b = (n_vec + (int64_t)kThreads * u - 1) / ((int64_t)kThreads * u);
+  if (b < 1) b = 1;
+  return (int)(b > kTileBlocks ? kTileBlocks : b);
+}
 
 inline int grid_for(int64_t n_vec) {
   int64_t b = (n_vec + kThreads - 1) / kThreads;
@@ -42,19 +60,18 @@ __global__ __launch_bounds__(kThreads) void act_quant_fwd_kernel(const float* __
   const int64_t stride = (int64_t)gridDim.x * kThreads;
   const float4* x4 = reinterpret_cast<const float4*>(x);
   float4* q4 = reinterpret_cast<float4*>(xq);
-  // kU independent 16-byte loads per thread in flight (the transform is ~19 vector instructions per element since round 3:
-  // the kernel is bound by memory, so what matters is bytes in flight: 32 waves x kU KiB per CU)
+  // the transform is ~19 vector instructions per element since round 3: the kernel is bound by memory (structure: top of file)
   ALIGNQ_BOUNDED_SWITCH(nlev,
-  for (int64_t i0 = (int64_t)blockIdx.x * kThreads + threadIdx.x; i0 < nvec; i0 += kU * stride) {
+  for (int64_t i0 = (int64_t)blockIdx.x * (kThreads * kU) + threadIdx.x; i0 < nvec; i0 += kU * stride) {
     float4 v[kU];
 _Pragma("unroll")
     for (int u = 0; u < kU; u++) {
-      const int64_t i = i0 + u * stride;
-      v[u] = x4[i < nvec ? i : i0];
+      const int64_t i = i0 + u * kThreads;
+      v[u] = ld4_stream(x4 + (i < nvec ? i : i0));
     }
 _Pragma("unroll")
     for (int u = 0; u < kU; u++) {
-      const int64_t i = i0 + u * stride;
+      const int64_t i = i0 + u * kThreads;
       float4 o;
       float t, b0, b1, b2, b3;
       o.x = act_quant1<FORMULA, kBounded>(v[u].x, k, nlev, r, &t, &b0, tab);
@@ -103,19 +120,18 @@ __global__ __launch_bounds__(kThreads) void act_quant_bwd_kernel(const float* __
   const float4* g4 = reinterpret_cast<const float4*>(g);
   const float4* x4 = reinterpret_cast<const float4*>(x);
   float4* d4 = reinterpret_cast<float4*>(dx);
-  constexpr int kUb = 2;     // two or three streams each
-  for (int64_t i0 = (int64_t)blockIdx.x * kThreads + threadIdx.x; i0 < nvec; i0 += kUb * stride) {
+  for (int64_t i0 = (int64_t)blockIdx.x * (kThreads * kUb) + threadIdx.x; i0 < nvec; i0 += kUb * stride) {
     float4 gv[kUb], xv[kUb], yv[kUb];
 #pragma unroll
     for (int u = 0; u < kUb; u++) {
-      const int64_t i = i0 + u * stride, ic = i < nvec ? i : i0;
-      gv[u] = g4[ic];
-      xv[u] = x4[ic];
-      if (MASK) yv[u] = reinterpret_cast<const float4*>(y)[ic];
+      const int64_t i = i0 + u * kThreads, ic = i < nvec ? i : i0;
+      gv[u] = ld4_stream(g4 + ic);
+      xv[u] = ld4_stream(x4 + ic);
+      if (MASK) yv[u] = ld4_stream(reinterpret_cast<const float4*>(y) + ic);
     }
 #pragma unroll
     for (int u = 0; u < kUb; u++) {
-      const int64_t i = i0 + u * stride;
+      const int64_t i = i0 + u * kThreads;
       float4 o;
       if (MASK) {
         gv[u].x = yv[u].x > 0.f ? gv[u].x : 0.f; gv[u].y = yv[u].y > 0.f ? gv[u].y : 0.f;
@@ -282,20 +298,31 @@ __global__ __launch_bounds__(kThreads) void act_quant_fwd_packed_kernel(const fl
   const int64_t stride = (int64_t)gridDim.x * kThreads;
   const float4* x4 = reinterpret_cast<const float4*>(x);
   ALIGNQ_BOUNDED_SWITCH(nlev,
-  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += stride) {
-    const float4 v = x4[i];
-    float4 o;
-    float t, b0, b1, b2, b3;
-    o.x = act_quant1<FORMULA, kBounded>(v.x, k, nlev, r, &t, &b0, tab);
-    o.y = act_quant1<FORMULA, kBounded>(v.y, k, nlev, r, &t, &b1, tab);
-    o.z = act_quant1<FORMULA, kBounded>(v.z, k, nlev, r, &t, &b2, tab);
-    o.w = act_quant1<FORMULA, kBounded>(v.w, k, nlev, r, &t, &b3, tab);
-    V4 bi;
-    bi.x = (T)(int)b0; bi.y = (T)(int)b1; bi.z = (T)(int)b2; bi.w = (T)(int)b3;
-    reinterpret_cast<V4*>(bins)[i] = bi;
-    if (WITH_XQ) {
-      if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-      reinterpret_cast<float4*>(xq)[i] = o;
+  for (int64_t i0 = (int64_t)blockIdx.x * (kThreads * kU) + threadIdx.x; i0 < nvec; i0 += kU * stride) {
+    float4 v[kU];
+_Pragma("unroll")
+    for (int u = 0; u < kU; u++) {
+      const int64_t i = i0 + u * kThreads;
+      v[u] = ld4_stream(x4 + (i < nvec ? i : i0));
+    }
+_Pragma("unroll")
+    for (int u = 0; u < kU; u++) {
+      const int64_t i = i0 + u * kThreads;
+      float4 o;
+      float t, b0, b1, b2, b3;
+      o.x = act_quant1<FORMULA, kBounded>(v[u].x, k, nlev, r, &t, &b0, tab);
+      o.y = act_quant1<FORMULA, kBounded>(v[u].y, k, nlev, r, &t, &b1, tab);
+      o.z = act_quant1<FORMULA, kBounded>(v[u].z, k, nlev, r, &t, &b2, tab);
+      o.w = act_quant1<FORMULA, kBounded>(v[u].w, k, nlev, r, &t, &b3, tab);
+      if (i < nvec) {
+        V4 bi;
+        bi.x = (T)(int)b0; bi.y = (T)(int)b1; bi.z = (T)(int)b2; bi.w = (T)(int)b3;
+        reinterpret_cast<V4*>(bins)[i] = bi;
+        if (WITH_XQ) {
+          if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+          reinterpret_cast<float4*>(xq)[i] = o;
+        }
+      }
     }
   })
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
@@ -344,19 +371,30 @@ __global__ __launch_bounds__(kThreads) void act_quant_bwd_packed_kernel(const fl
   const int thr = (FORMULA == 0 || k == 1) ? 0 : (((1 << k) - 1) >> 1);
   const int64_t nvec = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * kThreads;
-  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += stride) {
-    float4 gv = reinterpret_cast<const float4*>(g)[i];
-    const float4 xv = reinterpret_cast<const float4*>(x)[i];
-    if (relu) {
-      const V4 b = reinterpret_cast<const V4*>(bins)[i];
-      gv.x = (int)b.x > thr ? gv.x : 0.f;
-      gv.y = (int)b.y > thr ? gv.y : 0.f;
-      gv.z = (int)b.z > thr ? gv.z : 0.f;
-      gv.w = (int)b.w > thr ? gv.w : 0.f;
+  for (int64_t i0 = (int64_t)blockIdx.x * (kThreads * kUb) + threadIdx.x; i0 < nvec; i0 += kUb * stride) {
+    float4 gv[kUb], xv[kUb];
+    V4 bv[kUb];
+#pragma unroll
+    for (int u = 0; u < kUb; u++) {
+      const int64_t i = i0 + u * kThreads, ic = i < nvec ? i : i0;
+      gv[u] = ld4_stream(reinterpret_cast<const float4*>(g) + ic);
+      xv[u] = ld4_stream(reinterpret_cast<const float4*>(x) + ic);
+      if (relu) bv[u] = reinterpret_cast<const V4*>(bins)[ic];
     }
-    float4 o;
-    o.x = gv.x * act_jac(xv.x, r); o.y = gv.y * act_jac(xv.y, r); o.z = gv.z * act_jac(xv.z, r); o.w = gv.w * act_jac(xv.w, r);
-    reinterpret_cast<float4*>(dx)[i] = o;
+#pragma unroll
+    for (int u = 0; u < kUb; u++) {
+      const int64_t i = i0 + u * kThreads;
+      if (relu) {
+        gv[u].x = (int)bv[u].x > thr ? gv[u].x : 0.f;
+        gv[u].y = (int)bv[u].y > thr ? gv[u].y : 0.f;
+        gv[u].z = (int)bv[u].z > thr ? gv[u].z : 0.f;
+        gv[u].w = (int)bv[u].w > thr ? gv[u].w : 0.f;
+      }
+      float4 o;
+      o.x = gv[u].x * act_jac(xv[u].x, r); o.y = gv[u].y * act_jac(xv[u].y, r);
+      o.z = gv[u].z * act_jac(xv[u].z, r); o.w = gv[u].w * act_jac(xv[u].w, r);
+      if (i < nvec) reinterpret_cast<float4*>(dx)[i] = o;
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const int64_t i = (nvec << 2) + threadIdx.x;
@@ -400,7 +438,7 @@ int alignq_act_quant_fwd(const float* x, float* xq, int32_t* bins, int64_t n, in
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(xq) | reinterpret_cast<uintptr_t>(bins)) & 15)
     return ALIGNQ_EINVAL;  // 16-byte alignment for the float4 path (torch allocations are 256-B aligned)
   hipStream_t st = (hipStream_t)stream;
-  int grid = grid_for(n >> 2);
+  int grid = grid_tiles(n >> 2, kU);
   if (formula == ALIGNQ_FORMULA_ADMM) {
     if (bins) hipLaunchKernelGGL((act_quant_fwd_kernel<0, true>), grid, kThreads, 0, st, x, xq, bins, n, k, act_range);
     else hipLaunchKernelGGL((act_quant_fwd_kernel<0, false>), grid, kThreads, 0, st, x, xq, bins, n, k, act_range);
@@ -424,7 +462,7 @@ int alignq_act_quant_bwd(const float* g, const float* x, float* dx, int64_t n, f
   if (!g || !x || !dx || n <= 0) return ALIGNQ_EINVAL;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(dx)) & 15)
     return ALIGNQ_EINVAL;
-  hipLaunchKernelGGL(act_quant_bwd_kernel<false>, grid_for(n >> 2), kThreads, 0, (hipStream_t)stream, g, x, nullptr, dx, n, act_range);
+  hipLaunchKernelGGL(act_quant_bwd_kernel<false>, grid_tiles(n >> 2, kUb), kThreads, 0, (hipStream_t)stream, g, x, nullptr, dx, n, act_range);
   LAUNCH_CHECK();
   return 0;
 }
@@ -435,7 +473,7 @@ int alignq_act_quant_relu_fwd(const float* x, float* y, int64_t n, int k, float 
   if (formula != ALIGNQ_FORMULA_ADMM && formula != ALIGNQ_FORMULA_CDF) return ALIGNQ_EINVAL;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) return ALIGNQ_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const int grid = grid_for(n >> 2);
+  const int grid = grid_tiles(n >> 2, kU);
   if (formula == ALIGNQ_FORMULA_ADMM)
     hipLaunchKernelGGL((act_quant_fwd_kernel<0, false, true>), grid, kThreads, 0, st, x, y, nullptr, n, k, act_range);
   else
@@ -450,7 +488,7 @@ int alignq_act_quant_relu_bwd(const float* g, const float* x, const float* y, fl
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(dx) |
        reinterpret_cast<uintptr_t>(y)) & 15)
     return ALIGNQ_EINVAL;
-  hipLaunchKernelGGL(act_quant_bwd_kernel<true>, grid_for(n >> 2), kThreads, 0, (hipStream_t)stream, g, x, y, dx, n, act_range);
+  hipLaunchKernelGGL(act_quant_bwd_kernel<true>, grid_tiles(n >> 2, kUb), kThreads, 0, (hipStream_t)stream, g, x, y, dx, n, act_range);
   LAUNCH_CHECK();
   return 0;
 }
@@ -466,7 +504,7 @@ int alignq_act_quant_fwd_packed(const float* x, float* xq, void* bins, int64_t n
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(xq) | reinterpret_cast<uintptr_t>(bins)) & 15)
     return ALIGNQ_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const int grid = grid_for(n >> 2);
+  const int grid = grid_tiles(n >> 2, kU);
 #define FWDP(F, T)                                                                                                            \
   do {                                                                                                                        \
     if (xq) hipLaunchKernelGGL((act_quant_fwd_packed_kernel<F, T, true>), grid, kThreads, 0, st, x, xq, (T*)bins, n, k,        \
@@ -508,7 +546,7 @@ int alignq_act_quant_bwd_packed(const float* g, const float* x, const void* bins
        reinterpret_cast<uintptr_t>(bins)) & 15)
     return ALIGNQ_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const int grid = grid_for(n >> 2);
+  const int grid = grid_tiles(n >> 2, kUb);
   if (formula == ALIGNQ_FORMULA_ADMM) {
     if (bb == 1) hipLaunchKernelGGL((act_quant_bwd_packed_kernel<0, int8_t>), grid, kThreads, 0, st, g, x, (const int8_t*)bins, dx, n, k, act_range, relu);
     else hipLaunchKernelGGL((act_quant_bwd_packed_kernel<0, int16_t>), grid, kThreads, 0, st, g, x, (const int16_t*)bins, dx, n, k, act_range, relu);

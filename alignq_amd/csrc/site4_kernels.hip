@@ -67,6 +67,20 @@ __device__ __forceinline__ float4 ld4(const float* __restrict__ x, unsigned off,
   return v;
 }
 
+// the same for an input that is read exactly once (the forward's x): non-temporal, so the stream does not displace the
+// lines written for the consumer (tools/src/stream_bw.hip: +25 % on a 1:1 read/write stream)
+typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4_stream(const float* __restrict__ x, unsigned off, int col, int64_t F, bool row_ok,
+                                             bool aligned) {
+  if (!aligned) return ld4(x, off, col, F, row_ok, aligned);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (row_ok && col < F) {
+    const f32x4_nt t = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(reinterpret_cast<const char*>(x) + 4u * off));
+    v = make_float4(t.x, t.y, t.z, t.w);
+  }
+  return v;
+}
+
 __device__ __forceinline__ void st4(float* __restrict__ y, unsigned off, int col, int64_t F, bool row_ok, bool aligned,
                                     float4 v) {
   if (!row_ok) return;
@@ -195,10 +209,11 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
   for (int e = 0; e < 16; e++) { acc0[e] = 0.0f; acc1[e] = 0.0f; }
 
   STAMP(0);
+  float4 xv[RJ];      // this tile's rows; in the multi-tile form refilled with the NEXT tile's rows once they are staged
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int col0 = tile * TFv;
     const int col = col0 + 4 * c;
-    float4 xv[RJ], tv[RJ];
+    float4 tv[RJ];
     // ---- channels-last batch-norm finalisation, part 1 (one-tile launches): everything it reads is requested BEFORE the
     // tile loads (memory returns in order, and no element can be transformed before (a, b) exist).  Wave w owns channel
     // chbase + w (and + 16 on the narrow tiles); lane l of every wave fetches gamma / beta (/ the running statistics in the
@@ -238,12 +253,15 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
       }
     }
     // ---- load + transform + quantise ----------------------------------------------------------------
+    // (multi-tile launches: every tile but the first was requested by the previous iteration, in front of its MFMA phase)
+    if (SINGLE || tile == (int)blockIdx.x) {
 #pragma unroll
-    for (int j = 0; j < RJ; j++) {
-      const int row = rg + RG * j;
-      const bool ok = row < B;
-      const unsigned off = (unsigned)row * (unsigned)F + (unsigned)col;
-      xv[j] = ld4(x, off, col, F, ok, aligned);
+      for (int j = 0; j < RJ; j++) {
+        const int row = rg + RG * j;
+        const bool ok = row < B;
+        const unsigned off = (unsigned)row * (unsigned)F + (unsigned)col;
+        xv[j] = SINGLE ? ld4(x, off, col, F, ok, aligned) : ld4_stream(x, off, col, F, ok, aligned);
+      }
     }
     if (PAIR && tile == (int)blockIdx.x) {     // first iteration (block-uniform): publish the transform's table
       nerf_tab_store<NT>(nerf_lds, nerf_regs);
@@ -611,6 +629,19 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
     }
     __syncthreads();
     STAMP(3);
+    if constexpr (!SINGLE) {
+      // software pipeline: x and t of this tile now live in LDS, so the registers take the next tile's rows; the loads fly
+      // under the MFMA phase and the loop's closing barrier instead of in front of the next transform
+      const int tn = tile + (int)gridDim.x;
+      if (tn < n_tiles) {
+        const int coln = tn * TFv + 4 * c;
+#pragma unroll
+        for (int j = 0; j < RJ; j++) {
+          const int row = rg + RG * j;
+          xv[j] = ld4_stream(x, (unsigned)row * (unsigned)F + (unsigned)coln, coln, F, row < B, aligned);
+        }
+      }
+    }
     // ---- MFMA: upper-triangular tiles of Th Th^T and Xh Xh^T (3 bf16 MFMAs each per 16 features) ------------
     if constexpr (SINGLE) {      // one tile per workgroup: the accumulators start their life here, not in front of the erf work
 #pragma unroll

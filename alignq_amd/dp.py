@@ -32,8 +32,8 @@ class FlatBucket:
         return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
 
     def matches(self, tensors) -> bool:
-        """True when `tensors` are exactly the tensors this bucket was laid out for (count and element counts)."""
-        return len(tensors) == len(self.numels) and all(int(t.numel()) == n for t, n in zip(tensors, self.numels))
+        """True when `tensors` are exactly the tensors this bucket was laid out for (count and shapes)."""
+        return len(tensors) == len(self.shapes) and all(tuple(t.shape) == tuple(s) for t, s in zip(tensors, self.shapes))
 
     def _check(self, tensors):
         # the native copy kernel takes the element counts cached at construction and cannot see the tensors' real sizes:
@@ -126,6 +126,16 @@ class GradAndDAllReduce:
         self.reduce()
         self.unpack()
 
+    # A captured TrainStep bakes the CURRENT bucket's flat buffer into its two graphs (pack at the end of the first, unpack at
+    # the start of the second) and calls reduce() eagerly in between.  An eager iteration on another layout (the short last
+    # batch) rebinds self.bucket; the step saves / restores the binding around it so that reduce() keeps all-reducing the
+    # buffer the graphs pack into.
+    def snapshot(self):
+        return self.bucket
+
+    def restore(self, state):
+        self.bucket = state
+
 
 def attach(train_step, group=None, force=False, global_corr=False):
     """Wire data parallelism into a TrainStep: broadcast the initial state, install the all-reduce hook.
@@ -133,17 +143,37 @@ def attach(train_step, group=None, force=False, global_corr=False):
     (global_corr below; the model's ADMM(dim) must have been built with the global batch size, <= 128) instead of the
     per-rank [b,b] matrices; BN fold and deferred site launches are switched off for it (the sites run unfused)."""
     if global_corr:
-        from . import config
-        config.args.global_corr = True if group is None else group
+        # scoped to THIS model's quantiser modules (not the process-global config): other models / steps in the process keep
+        # the per-rank semantics; detach() restores what is changed here
+        undo = {"fuse_bn": [], "sites": [], "deferred": train_step._deferred}
         for m in train_step.model.modules():
             if hasattr(m, "fuse_bn"):
+                undo["fuse_bn"].append((m, m.fuse_bn))
                 m.fuse_bn = False
+            if hasattr(m, "a_bit") and hasattr(m, "opt"):
+                undo["sites"].append(m)
+                m.global_corr = True if group is None else group
         train_step._deferred = None
+        train_step._global_corr_undo = undo
     broadcast_module_state(train_step.model, 0, group)
     hook = GradAndDAllReduce([p for _, p in train_step.param_t], lambda: [m.D for m in train_step.admms], group,
                              force=force)
     train_step.grad_hook = hook
     return hook
+
+
+def detach(train_step):
+    """Undo attach(): remove the hook and, after global_corr=True, give the sites back their per-rank correlation, the BN
+    fold and the deferred launches."""
+    train_step.grad_hook = None
+    undo = getattr(train_step, "_global_corr_undo", None)
+    if undo is not None:
+        for m, v in undo["fuse_bn"]:
+            m.fuse_bn = v
+        for m in undo["sites"]:
+            m.global_corr = None
+        train_step._deferred = undo["deferred"]
+        train_step._global_corr_undo = None
 
 
 class BucketedGradAllReduce:
@@ -317,6 +347,12 @@ class BucketedGradAllReduce:
             return
         for b, tensors in self._phase:
             b.unpack(tensors)
+
+    def snapshot(self):
+        return getattr(self, "_phase", None)
+
+    def restore(self, state):
+        self._phase = state
 
 
 def attach_office(office_step, group=None, force=False, bucket_bytes=24 << 20, min_buckets=4):

@@ -519,7 +519,7 @@ def bn_site(bn, act, z, eps=0.0, relu=False, residual=None, pack=False):
     when `bn_site_fusable`, otherwise exactly that composition.  z may be contiguous (NCHW) or channels-last.
     pack=True (N2; needs relu, no residual, channels-last, a_bit <= 8): `out` is a packed handle (see BNSiteFn.forward) whose
     values are int8 / int16 level indices; only hand it to Conv2d_Q (which reads the indices) or through `materialize`."""
-    from . import config
+    from . import config, ops
     if not bn_site_fusable(bn, act, z) or (residual is not None and not (
             residual.shape == z.shape and residual.stride() == z.stride() and residual.dtype == torch.float32)):
         out, loss = act(bn(z))
@@ -529,7 +529,8 @@ def bn_site(bn, act, z, eps=0.0, relu=False, residual=None, pack=False):
     admm = act.opt
     deferred = active_deferred()
     rec = deferred.new_record(z.shape[0], z.device) if deferred is not None else None
-    pack = bool(pack and relu and residual is None and _is_nhwc(z) and act.a_bit <= 8 and (z.shape[1] * z.shape[2] * z.shape[3]) % 4 == 0)
+    pack = bool(pack and relu and residual is None and _is_nhwc(z) and act.a_bit <= 8 and (z.shape[1] * z.shape[2] * z.shape[3]) % 4 == 0
+                and ops.bin_dtype(act.a_bit, config.args.act_range, L.FORMULA_ADMM) is not None)   # a large act_range has no narrow form
     BNSiteFn._bins_mailbox = None
     y, loss, D = BNSiteFn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
                                 bn.momentum, bn.eps, admm.alterD, admm.gamma, act.a_bit, config.args.act_range, eps,
@@ -552,13 +553,21 @@ def bn_site(bn, act, z, eps=0.0, relu=False, residual=None, pack=False):
 _head_counters = {}
 
 
-def _head_counter(device):
-    """The arrival counter of alignq_head_ce_fwd's in-kernel mean: one zeroed word per device, re-armed by the kernel
-    (allocated on the first eager call, i.e. outside any graph capture)."""
-    key = (device.type, device.index)
-    c = _head_counters.get(key)
+def _head_counter(device, owner=None):
+    """The arrival counter of alignq_head_ce_fwd's in-kernel mean: a zeroed word the kernel re-arms.  The last-workgroup
+    reduction assumes exclusive ownership of it for the duration of a launch, so two head launches that may be in flight
+    together must not share one: the word belongs to `owner` (a step's DeferredLosses: one TrainStep = one in-order chain)
+    or, for the stand-alone HeadCEFn, to the (device, stream) it is launched on.  Allocated on the owner's first eager call,
+    i.e. outside any graph capture (TrainStep.capture warms up eagerly first)."""
+    if owner is not None:
+        d = owner.__dict__.setdefault("_head_counters", {})
+        key = (device.type, device.index)
+    else:
+        d = _head_counters
+        key = (device.type, device.index, int(torch.cuda.current_stream(device).cuda_stream))
+    c = d.get(key)
     if c is None:
-        c = _head_counters[key] = torch.zeros(1, dtype=torch.int32, device=device)
+        c = d[key] = torch.zeros(1, dtype=torch.int32, device=device)
     return c
 
 
@@ -584,7 +593,8 @@ class StepLossFn(torch.autograd.Function):
         loss, ce, trans = torch.empty(B, **f32), torch.empty((), **f32), torch.empty((), **f32)
         w = L.dev_f32(weight, "head weight")
         L.check(lib.alignq_head_ce_fwd(L.ptr(feat), L.ptr(w), L.ptr(bias), L.ptr(target), B, H * W, C, K, L.ptr(pooled),
-                                       L.ptr(logits), L.ptr(probs), L.ptr(loss), L.ptr(ce), L.ptr(_head_counter(dev)),
+                                       L.ptr(logits), L.ptr(probs), L.ptr(loss), L.ptr(ce),
+                                       L.ptr(_head_counter(dev, collector)),
                                        L.ptr(scal_all), len(losses), L.ptr(trans), L.stream_ptr()), "alignq_head_ce_fwd")
         ctx.save_for_backward(feat, w, target, pooled, probs)
         ctx.has_bias = bias is not None

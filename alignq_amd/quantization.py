@@ -99,7 +99,9 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
         """relu(_plain_act(x)); one launch each way when the quantiser is active."""
         if (a_bit == 32) or not (x.is_cuda and x.dtype == torch.float32 and x.numel() % 4 == 0):
             return torch.relu(_plain_act(x, a_bit, stage))
-        if getattr(config.args, "pack_bins", False):     # N2: the node keeps the 1-2 B level index instead of fp32 relu(x_q)
+        if getattr(config.args, "pack_bins", False) and ops.bin_dtype(a_bit, config.args.act_range, formula) is not None:
+            # N2: the node keeps the 1-2 B level index instead of fp32 relu(x_q) (no narrow form: 16 < k < 32 or a large
+            # act_range -> the fp32 path below, like the reference)
             return ops.ActQuantPackedFn.apply(x, a_bit, config.args.act_range, formula, True)[0]
         return ops.ActQuantReluFn.apply(x, a_bit, config.args.act_range, formula)
 
@@ -107,11 +109,14 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
         a_bit = mod.a_bit
         if a_bit == 32 and mod.stage != "align":
             return x, 0
-        if config.args.method == "ours" and a_bit < 32 and getattr(config.args, "global_corr", None) is not None:
+        gc = getattr(mod, "global_corr", None)        # set per model by dp.attach(..., global_corr=True)
+        if gc is None:
+            gc = getattr(config.args, "global_corr", None)       # process-wide switch (tests)
+        if config.args.method == "ours" and a_bit < 32 and gc is not None:
             # opt-in exact-global-batch correlation (dp.attach(..., global_corr=True)): D is the
             # [B_g, B_g] matrix of the concatenated batch, identical on every rank; unfused (x is read three times)
             from . import dp
-            grp = None if config.args.global_corr is True else config.args.global_corr
+            grp = None if gc is True else gc
             admm = mod.opt
             r_ = config.args.act_range
             xq = ops.ActQuantFn.apply(x, a_bit, r_, formula)

@@ -175,6 +175,11 @@ class TrainStep:
     def _eager_fallback(self, x, y):
         params = [p for _, p in self.param_t + self.param_admm]
         keep_g, keep_D = [p.grad for p in params], [m.D for m in self.admms]
+        # a data-parallel hook rebinds its flat bucket to the off-shape layout during this iteration; the graphs keep packing
+        # into / unpacking from the bucket that was current at capture, so the eager reduce() between them must see that one
+        # again afterwards (otherwise it all-reduces the stale short-batch buffer and the replicas diverge silently)
+        hook = self.grad_hook
+        keep_hook = hook.snapshot() if hasattr(hook, "snapshot") else None
         try:
             return self._iteration(x, y)
         finally:
@@ -182,6 +187,8 @@ class TrainStep:
                 p.grad = g
             for m, D in zip(self.admms, keep_D):
                 m.D = D
+            if hasattr(hook, "restore"):
+                hook.restore(keep_hook)
 
     def _assert_momentum_buffers(self):
         """A momentum buffer created INSIDE a capture is baked into the graph with first=1 (buf = grad on every replay:
@@ -234,6 +241,11 @@ class TrainStep:
             torch.distributed.barrier()
             torch.cuda.synchronize()
         cap_mode = dict(capture_error_mode="thread_local") if dist_on else {}
+        if getattr(self, "_global_corr_undo", None) is not None or getattr(config.args, "global_corr", None) is not None:
+            # the exact-global correlation issues all_to_all / all_reduce from inside the forward: they can be captured with
+            # RCCL only (gloo collectives are host calls)
+            if not (torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl"):
+                raise RuntimeError("TrainStep.capture: global_corr needs the nccl (RCCL) backend to be captured")
         graph = torch.cuda.CUDAGraph()
         self._graph2 = None
         # inside the capture grads are re-created (set_to_none=True): no zero-fill and no accumulate-add per
@@ -381,6 +393,8 @@ class OfficeTrainStep:
         params = [p for g in self.optimizer_t.param_groups for p in g["params"]]
         admms = [b.admm0 for b in self.blocks]
         keep_g, keep_D = [p.grad for p in params], [q.D for q in admms]
+        hook = self.grad_hook
+        keep_hook = hook.snapshot() if hasattr(hook, "snapshot") else None      # see TrainStep._eager_fallback
         try:
             return self._iteration(xs, ys, xt)
         finally:
@@ -388,6 +402,8 @@ class OfficeTrainStep:
                 p.grad = g
             for q, D in zip(admms, keep_D):
                 q.D = D
+            if hasattr(hook, "restore"):
+                hook.restore(keep_hook)
 
     def capture(self, xs, ys, xt, warmup=2):
         fmt = torch.channels_last if self.channels_last else torch.contiguous_format
