@@ -11,7 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libalignq_hip.so")
 
 FORMULA_ADMM, FORMULA_CDF = 0, 1
-MAX_BATCH = 128
+MAX_BATCH = 128            # rows the FUSED site kernels hold on chip (ALIGNQ_MAX_BATCH)
+MAX_CORR_BATCH = 1024      # rows alignq_corr_fwd / _bwd take (ALIGNQ_MAX_CORR_BATCH: blocked Gram above 128)
 ABI_VERSION = 6
 
 _c = ctypes

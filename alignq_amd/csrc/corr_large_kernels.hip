@@ -1,0 +1,386 @@
+// corr_large_kernels.hip — corr(x, x) for batches ABOVE the 128 rows the fused site kernels hold on chip
+// (128 < B <= ALIGNQ_MAX_CORR_BATCH = 1024): the exact-global-batch correlation of SURVEY.md §8f-N4 at the BASELINE global
+// batches (224 / 512 / 1024) and a single GPU run at batch 256.
+//
+// Reference semantics: corr (ADMM tree model/quantization.py:134-137; Office tree :158-161 with eps = 1e-5); the reference
+// takes any batch (utils/admm.py:17-27 sizes alterD / gamma by train_batch_size).
+//
+// Blocked form (the one-pass kernels need all rows of a feature tile in ONE workgroup, which stops at 128 rows):
+//   1. corrl_stats_kernel  : per feature column mean and 1/(std + eps) over ALL B rows (one sweep, double accumulation)
+//   2. corrl_gram_kernel   : the B x B Gram in 128 x 128 output blocks, upper block triangle only; a workgroup owns one block
+//                            pair (I <= J) and a K range of 64-feature tiles: rows of block I and block J are standardised on
+//                            load into LDS, the product runs on v_mfma_f32_32x32x2_f32 (exact fp32: this path is about
+//                            reach, not speed; the bf16-split pipe of site4_kernels.hip is 5x faster per flop);
+//                            one 128 x 128 partial slab per (pair, K split)
+//   3. corrl_reduce_kernel : fixed-order sum of a pair's slabs, x 1/F, written to G[I][J] and mirrored to G[J][I]
+// Backward (dG any, G symmetric in x):  dXh = S Xh,  S = (dG + dG^T)/F  [B,B];  dx = (dXh - mean_b dXh) rho
+//                                       - xh * sum_b(dXh o xh) / ((B-1) std)          (torch's std backward: 0 where std == 0)
+//   4. corrl_sym_kernel    : S
+//   5. corrl_bwd_kernel<RB>: a workgroup owns a 32-feature tile with ALL rows: Xh tile in LDS (B x 33 floats), wave w the
+//                            32-row blocks w, w+4, ... (RB of them: B <= 128 RB); A fragments of S from L2 (S is symmetric,
+//                            so S[k][i] is read: coalesced in i), column projections over all rows through LDS, 128-byte
+//                            row-segment stores.
+// Deterministic (no atomics); HBM traffic of the forward: x once for the statistics plus (nb+1)/2 x for the Gram (nb = B/128).
+#include <hip/hip_runtime.h>
+
+#include "../../include/alignq.h"
+#include "site_internal.h"
+
+namespace alignq_site {
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kT = 256;          // threads per workgroup (4 waves)
+constexpr int kTF = 64;          // features per Gram tile
+constexpr int kLD = kTF + 1;     // LDS row stride (odd: the strided fragment reads are conflict-free)
+constexpr int kBlk = 128;        // rows per output block
+constexpr int kTFb = 32;         // features per backward tile
+constexpr int kLDb = kTFb + 1;
+
+__device__ __forceinline__ float4 ldq(const float* __restrict__ x, int64_t off, int col, int64_t F, bool row_ok, bool aligned) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!row_ok) return v;
+  if (aligned) {
+    if (col < F) v = *reinterpret_cast<const float4*>(x + off);
+  } else {
+    if (col + 0 < F) v.x = x[off + 0];
+    if (col + 1 < F) v.y = x[off + 1];
+    if (col + 2 < F) v.z = x[off + 2];
+    if (col + 3 < F) v.w = x[off + 3];
+  }
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------- 1. column statistics
+// grid = feature tiles of 64; thread = (column quad c, row group rg of 16); rows rg, rg+16, ...
+__global__ __launch_bounds__(kT) void corrl_stats_kernel(const float* __restrict__ x, int B, int64_t F, float eps,
+                                                         float* __restrict__ stats, int aligned) {
+  __shared__ double red[16][kTF][2];
+  const int tid = threadIdx.x, c = tid & 15, rg = tid >> 4;
+  const int col = blockIdx.x * kTF + 4 * c;
+  double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  for (int r0 = rg; r0 < B; r0 += 64) {       // four rows in flight
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int r = r0 + 16 * u;
+      v[u] = ldq(x, (int64_t)r * F + col, col, F, r < B, aligned);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+      for (int j = 0; j < 4; j++) { s[j] += (double)e[j]; q[j] += (double)e[j] * (double)e[j]; }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) { red[rg][4 * c + j][0] = s[j]; red[rg][4 * c + j][1] = q[j]; }
+  __syncthreads();
+  if (tid < kTF) {
+    double a = 0, b = 0;
+    for (int g = 0; g < 16; g++) { a += red[g][tid][0]; b += red[g][tid][1]; }     // fixed order
+    const int64_t f = (int64_t)blockIdx.x * kTF + tid;
+    if (f < F) {
+      const double mean = a / (double)B;
+      double var = (b - a * mean) / (double)(B - 1);
+      if (var < 0) var = 0;
+      stats[f] = (float)mean;
+      stats[F + f] = 1.0f / ((float)sqrt(var) + eps);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- 2. blocked Gram
+__device__ __forceinline__ void pair_ij(int p, int nb, int& I, int& J) {
+  int t = p;
+  I = 0;
+  while (t >= nb - I) { t -= nb - I; I++; }
+  J = I + t;
+}
+
+// grid = (ksplit, npairs).  slabs: [npairs][ksplit][128][128]
+__global__ __launch_bounds__(kT) void corrl_gram_kernel(const float* __restrict__ x, const float* __restrict__ stats, int B,
+                                                        int64_t F, float* __restrict__ slabs, int n_tiles, int nb,
+                                                        int aligned) {
+  __shared__ float As[kBlk * kLD];
+  __shared__ float Bs[kBlk * kLD];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c = tid & 15, rg = tid >> 4;
+  const int h = lane >> 5, l31 = lane & 31;
+  int I, J;
+  pair_ij(blockIdx.y, nb, I, J);
+  const bool diag = I == J;
+  const int wr = w >> 1, wc = w & 1;          // the wave's 64 x 64 quadrant
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+  const float* Bsel = diag ? As : Bs;
+
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int col = tile * kTF + 4 * c;
+    float m[4], rho[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const bool ok = col + e < F;
+      m[e] = ok ? stats[col + e] : 0.0f;
+      rho[e] = ok ? stats[F + col + e] : 0.0f;
+    }
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      if (half == 1 && diag) break;
+      const int blk = half == 0 ? I : J;
+      float* dst = half == 0 ? As : Bs;
+      float4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int grow = blk * kBlk + rg + 16 * j;
+        v[j] = ldq(x, (int64_t)grow * F + col, col, F, grow < B, aligned);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int row = rg + 16 * j;
+        const bool ok = blk * kBlk + row < B;
+        const float e4[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) dst[row * kLD + 4 * c + e] = (ok && col + e < F) ? (e4[e] - m[e]) * rho[e] : 0.0f;
+      }
+    }
+    __syncthreads();
+    const int rowA = wr * 64 + l31, rowB = wc * 64 + l31;
+#pragma unroll 4
+    for (int k0 = 0; k0 < kTF; k0 += 2) {
+      float a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        a[i] = As[(rowA + 32 * i) * kLD + k0 + h];
+        b[i] = Bsel[(rowB + 32 * i) * kLD + k0 + h];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  float* slab = slabs + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (kBlk * kBlk);
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int row = wr * 64 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+        slab[row * kBlk + wc * 64 + 32 * j + l31] = acc[i][j][e];
+      }
+}
+
+// ---------------------------------------------------------------------------------------------- 3. slab reduction
+// grid = (64, npairs): thread = one element of the pair's 128 x 128 block
+__global__ __launch_bounds__(kT) void corrl_reduce_kernel(const float* __restrict__ slabs, int ksplit, int nb, int B, float scale,
+                                                          float* __restrict__ G) {
+  int I, J;
+  pair_ij(blockIdx.y, nb, I, J);
+  const int e = blockIdx.x * kT + threadIdx.x;
+  const float* p = slabs + (int64_t)blockIdx.y * ksplit * (kBlk * kBlk) + e;
+  float s = 0.f;
+  int k = 0;
+  for (; k + 4 <= ksplit; k += 4) {
+    const float a0 = p[(int64_t)(k + 0) * (kBlk * kBlk)], a1 = p[(int64_t)(k + 1) * (kBlk * kBlk)];
+    const float a2 = p[(int64_t)(k + 2) * (kBlk * kBlk)], a3 = p[(int64_t)(k + 3) * (kBlk * kBlk)];
+    s += a0; s += a1; s += a2; s += a3;
+  }
+  for (; k < ksplit; k++) s += p[(int64_t)k * (kBlk * kBlk)];
+  const int i = I * kBlk + (e >> 7), j = J * kBlk + (e & 127);
+  if (i < B && j < B) {
+    G[(int64_t)i * B + j] = s * scale;
+    if (I != J) G[(int64_t)j * B + i] = s * scale;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- 4. S = (dG + dG^T) / F
+__global__ __launch_bounds__(kT) void corrl_sym_kernel(const float* __restrict__ dG, int B, float scale, float* __restrict__ S) {
+  const int64_t n = (int64_t)B * B;
+  for (int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x; e < n; e += (int64_t)gridDim.x * kT) {
+    const int i = (int)(e / B), j = (int)(e - (int64_t)i * B);
+    S[e] = (dG[e] + dG[(int64_t)j * B + i]) * scale;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- 5. backward
+// dynamic LDS: Xh [nblk*32][33] floats + red [4][2][32]
+template <int RB>
+__global__ __launch_bounds__(kT) void corrl_bwd_kernel(const float* __restrict__ S, const float* __restrict__ x,
+                                                       const float* __restrict__ stats, int B, int64_t F, float eps,
+                                                       float* __restrict__ dx, int n_tiles, int aligned) {
+  extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+  const int nblk = (B + 31) >> 5, BP = nblk * 32;
+  float* Xs = lds_dyn;
+  float* red = lds_dyn + BP * kLDb;            // [4 waves][2][32]
+  float* tot = red + 4 * 2 * 32;               // [2][32]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int c = tid & 7, rg = tid >> 3;        // load mapping: column quad, 32 row groups
+  const float invB = 1.0f / (float)B, invBm1 = 1.0f / (float)(B - 1);
+
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int col0 = tile * kTFb, col = col0 + 4 * c;
+    float m[4], rho[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const bool ok = col + e < F;
+      m[e] = ok ? stats[col + e] : 0.0f;
+      rho[e] = ok ? stats[F + col + e] : 0.0f;
+    }
+    for (int r0 = rg; r0 < BP; r0 += 32 * 4) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int r = r0 + 32 * u;
+        v[u] = ldq(x, (int64_t)r * F + col, col, F, r < B, aligned);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int r = r0 + 32 * u;
+        if (r < BP) {
+          const float e4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+          for (int e = 0; e < 4; e++) Xs[r * kLDb + 4 * c + e] = (r < B && col + e < F) ? (e4[e] - m[e]) * rho[e] : 0.0f;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- dXh block rows of this wave: acc[q] = S[rows of block w + 4q][:] Xh ----------------------------------------
+    f32x16 acc[RB];
+#pragma unroll
+    for (int q = 0; q < RB; q++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[q][e] = 0.0f;
+#pragma unroll 2
+    for (int k0 = 0; k0 < BP; k0 += 2) {
+      const int kk = k0 + h;
+      const float b = Xs[kk * kLDb + l31];
+      float a[RB];
+#pragma unroll
+      for (int q = 0; q < RB; q++) {
+        const int i = (w + 4 * q) * 32 + l31;
+        a[q] = (i < B && kk < B) ? S[(int64_t)kk * B + i] : 0.0f;        // S symmetric: S[i][kk], read coalesced in i
+      }
+#pragma unroll
+      for (int q = 0; q < RB; q++)
+        if (w + 4 * q < nblk) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b, acc[q], 0, 0, 0);
+    }
+    // ---- column projections over ALL rows: sum_b dXh, sum_b dXh * xh ------------------------------------------------
+    float sd = 0.f, sdx = 0.f;
+#pragma unroll
+    for (int q = 0; q < RB; q++) {
+      if (w + 4 * q < nblk) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          const int row = (w + 4 * q) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const float d = acc[q][e];            // rows >= B: S rows are zero there, so d == 0
+          sd += d;
+          sdx += d * Xs[row * kLDb + l31];
+        }
+      }
+    }
+    sd += __shfl_xor(sd, 32, 64);
+    sdx += __shfl_xor(sdx, 32, 64);
+    if (h == 0) { red[(w * 2 + 0) * 32 + l31] = sd; red[(w * 2 + 1) * 32 + l31] = sdx; }
+    __syncthreads();
+    if (tid < 64) {
+      const int which = tid >> 5, cc = tid & 31;
+      tot[which * 32 + cc] = ((red[(0 * 2 + which) * 32 + cc] + red[(1 * 2 + which) * 32 + cc]) +
+                              (red[(2 * 2 + which) * 32 + cc] + red[(3 * 2 + which) * 32 + cc]));
+    }
+    __syncthreads();
+    // ---- assemble and store (lanes l31 -> 32 consecutive features of one row: 128-byte segments) ---------------------
+    {
+      const int f = col0 + l31;
+      const bool fok = f < F;
+      const float rr = fok ? stats[F + f] : 0.0f;
+      const float sdev = fok ? (1.0f / rr - eps) : 0.0f;
+      const float mean_d = tot[l31] * invB;
+      // torch's std backward gives no gradient through a zero std (masked_fill), DESIGN.md §7
+      const float kdot = (sdev > 0.0f) ? tot[32 + l31] * invBm1 / sdev : 0.0f;
+#pragma unroll
+      for (int q = 0; q < RB; q++) {
+        if (w + 4 * q < nblk) {
+#pragma unroll
+          for (int e = 0; e < 16; e++) {
+            const int row = (w + 4 * q) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (row < B && fok) dx[(int64_t)row * F + f] = (acc[q][e] - mean_d) * rr - Xs[row * kLDb + l31] * kdot;
+          }
+        }
+      }
+    }
+    __syncthreads();      // Xs is overwritten by the next tile
+  }
+}
+
+inline int n_pairs(int nb) { return nb * (nb + 1) / 2; }
+
+}  // namespace
+
+// K splits of the Gram launch: enough workgroups for the chip, never more than there are feature tiles
+int corrl_ksplit(int B, int64_t F) {
+  const int nb = (B + kBlk - 1) / kBlk, np = n_pairs(nb);
+  const int64_t n_tiles = (F + kTF - 1) / kTF;
+  int64_t ks = (1024 + np - 1) / np;
+  if (ks > n_tiles) ks = n_tiles;
+  if (ks > 512) ks = 512;
+  return (int)(ks < 1 ? 1 : ks);
+}
+
+size_t corrl_ws_bytes(int B, int64_t F) {
+  const int nb = (B + kBlk - 1) / kBlk;
+  return (size_t)n_pairs(nb) * corrl_ksplit(B, F) * kBlk * kBlk * sizeof(float);
+}
+
+int launch_corrl_fwd(const float* x, int B, int64_t F, float eps, float* G, float* stats, float* ws, hipStream_t st) {
+  const int aligned = ((F & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) ? 1 : 0;
+  const int nb = (B + kBlk - 1) / kBlk, np = n_pairs(nb), ks = corrl_ksplit(B, F);
+  const int n_tiles = (int)((F + kTF - 1) / kTF);
+  hipLaunchKernelGGL(corrl_stats_kernel, dim3(n_tiles), dim3(kT), 0, st, x, B, F, eps, stats, aligned);
+  hipLaunchKernelGGL(corrl_gram_kernel, dim3(ks, np), dim3(kT), 0, st, x, (const float*)stats, B, F, ws, n_tiles, nb, aligned);
+  hipLaunchKernelGGL(corrl_reduce_kernel, dim3(kBlk * kBlk / kT, np), dim3(kT), 0, st, (const float*)ws, ks, nb, B,
+                     1.0f / (float)F, G);
+  return hipGetLastError() == hipSuccess ? 0 : ALIGNQ_EINVAL;
+}
+
+int launch_corrl_bwd(const float* dG, const float* x, const float* stats, int B, int64_t F, float eps, float* dx, float* S,
+                     hipStream_t st) {
+  const int aligned = ((F & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) ? 1 : 0;
+  const int64_t n = (int64_t)B * B;
+  int gs = (int)((n + kT - 1) / kT);
+  if (gs > 2048) gs = 2048;
+  hipLaunchKernelGGL(corrl_sym_kernel, dim3(gs), dim3(kT), 0, st, dG, B, 1.0f / (float)F, S);
+  const int nblk = (B + 31) / 32, rb = (nblk + 3) / 4;
+  const int n_tiles = (int)((F + kTFb - 1) / kTFb);
+  const size_t lds = ((size_t)nblk * 32 * kLDb + 4 * 2 * 32 + 2 * 32) * sizeof(float);
+  int grid = n_tiles < 2048 ? n_tiles : 2048;
+#define CORRL_BWD(RB)                                                                                                          \
+  do {                                                                                                                         \
+    static bool attr_set = false;                                                                                              \
+    if (!attr_set) {                                                                                                           \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&corrl_bwd_kernel<RB>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              160 * 1024 - 512) != hipSuccess)                                                                 \
+        return ALIGNQ_EINVAL;                                                                                                  \
+      attr_set = true;                                                                                                         \
+    }                                                                                                                          \
+    hipLaunchKernelGGL((corrl_bwd_kernel<RB>), dim3(grid), dim3(kT), lds, st, (const float*)S, x, stats, B, F, eps, dx,        \
+                       n_tiles, aligned);                                                                                      \
+  } while (0)
+  if (rb <= 2) CORRL_BWD(2);
+  else if (rb <= 4) CORRL_BWD(4);
+  else CORRL_BWD(8);
+#undef CORRL_BWD
+  return hipGetLastError() == hipSuccess ? 0 : ALIGNQ_EINVAL;
+}
+
+}  // namespace alignq_site

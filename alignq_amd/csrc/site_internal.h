@@ -127,4 +127,10 @@ int launch_reduce_any(const Geom& g, const float* ws_c, float* ws_mut, int B, in
                       const float* alterD, const float* gamma, int dim, float mu, float rho, float* scal,
                       hipStream_t st);
 
+// ---- corr_large_kernels.hip: corr(x, x) for 128 < B <= ALIGNQ_MAX_CORR_BATCH (blocked Gram, exact fp32) ------------------
+size_t corrl_ws_bytes(int B, int64_t F);
+int launch_corrl_fwd(const float* x, int B, int64_t F, float eps, float* G, float* stats, float* ws, hipStream_t st);
+int launch_corrl_bwd(const float* dG, const float* x, const float* stats, int B, int64_t F, float eps, float* dx, float* S,
+                     hipStream_t st);
+
 }  // namespace alignq_site

@@ -491,6 +491,7 @@ int launch_bwd(const Geom& g, const float* gup, const float* S, const float* x, 
 }
 
 inline bool bad_shape(int B, int64_t F) { return B < 2 || B > ALIGNQ_MAX_BATCH || F <= 0; }
+inline bool large_corr(int B, int64_t F) { return B > ALIGNQ_MAX_BATCH && B <= ALIGNQ_MAX_CORR_BATCH && F > 0; }
 inline bool bad_k(int k) { return !((k >= 1 && k <= 16) || k == 32); }
 
 }  // namespace
@@ -498,13 +499,17 @@ inline bool bad_k(int k) { return !((k >= 1 && k <= 16) || k == 32); }
 extern "C" {
 
 size_t alignq_site_ws_bytes(int B, int64_t F) {
+  if (large_corr(B, F)) return corrl_ws_bytes(B, F);      // alignq_corr_fwd only
   if (bad_shape(B, F)) return 0;
   return ws_floats(geom(B, F)) * sizeof(float);
 }
 
 // the S buffer of the backward: [B,B] fp32 (sym(dD) * scale / F) in its first 64 KB, followed at byte offset 65536 by the
 // bf16 hi / lo fragment image of the same matrix that the prep kernels leave for the B in (64,128] backward (64 KB)
-size_t alignq_site_bwd_ws_bytes(int B) { (void)B; return (size_t)2 * 128 * 128 * sizeof(float); }
+size_t alignq_site_bwd_ws_bytes(int B) {
+  if (B > ALIGNQ_MAX_BATCH) return (size_t)B * B * sizeof(float);     // alignq_corr_bwd, large batch: S only
+  return (size_t)2 * 128 * 128 * sizeof(float);
+}
 
 int alignq_site_partials(const float* x, int B, int64_t F, int k, float act_range, float eps, float* xq, float* stats,
                          void* ws, void* stream) {
@@ -678,6 +683,10 @@ int alignq_site_bwd_fused(const float* g, const float* D, const float* alterD, c
 
 int alignq_corr_fwd(const float* x, int B, int64_t F, float eps, float* G, float* stats, void* ws, void* stream) {
   if (!x || !G || !ws) return ALIGNQ_EINVAL;
+  if (large_corr(B, F)) {       // 128 < B <= 1024: blocked Gram (corr_large_kernels.hip); stats is required there
+    if (!stats) return ALIGNQ_EINVAL;
+    return launch_corrl_fwd(x, B, F, eps, G, stats, (float*)ws, (hipStream_t)stream);
+  }
   if (bad_shape(B, F)) return F <= 0 ? ALIGNQ_EINVAL : ALIGNQ_EUNSUPPORTED;
   const Geom g = geom(B, F);
   int rc = launch_partials<false>(g, x, B, F, 32, 1.0f, eps, nullptr, stats, (float*)ws, (hipStream_t)stream);
@@ -689,6 +698,7 @@ int alignq_corr_fwd(const float* x, int B, int64_t F, float eps, float* G, float
 int alignq_corr_bwd(const float* dG, const float* x, const float* stats, int B, int64_t F, float eps, float* dx,
                     void* ws, void* stream) {
   if (!dG || !x || !stats || !dx || !ws) return ALIGNQ_EINVAL;
+  if (large_corr(B, F)) return launch_corrl_bwd(dG, x, stats, B, F, eps, dx, (float*)ws, (hipStream_t)stream);
   if (bad_shape(B, F)) return F <= 0 ? ALIGNQ_EINVAL : ALIGNQ_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   int rc = launch_prep(false, dG, nullptr, nullptr, nullptr, 0, nullptr, 0.f, nullptr, B, F, (float*)ws, nullptr, nullptr,

@@ -140,7 +140,7 @@ class GradAndDAllReduce:
 def attach(train_step, group=None, force=False, global_corr=False):
     """Wire data parallelism into a TrainStep: broadcast the initial state, install the all-reduce hook.
     global_corr=True (opt-in): every ADMM site computes the correlation pair of the GLOBAL batch
-    (global_corr below; the model's ADMM(dim) must have been built with the global batch size, <= 128) instead of the
+    (global_corr below; the model's ADMM(dim) must have been built with the global batch size, <= 1024: above 128 rows the blocked Gram of corr_large_kernels.hip) instead of the
     per-rank [b,b] matrices; BN fold and deferred site launches are switched off for it (the sites run unfused)."""
     if global_corr:
         # scoped to THIS model's quantiser modules (not the process-global config): other models / steps in the process keep
@@ -429,7 +429,7 @@ def global_corr(x, eps=0.0, group=None, local_corr=None, grad_scale=None):
     """corr(x, x) of the GLOBAL batch (rows = all ranks' samples in rank order), identical on every rank.
 
     x: this rank's [b, ...] activations.  local_corr(X) -> [B_g, B_g]: the per-shard SYRK (default ops.CorrFn on the HIP
-    kernels, which hold at most ALIGNQ_MAX_BATCH = 128 rows).  grad_scale multiplies the gradient that returns to x;
+    kernels: fused split-bf16 Gram up to 128 rows, blocked exact-fp32 Gram up to ALIGNQ_MAX_CORR_BATCH = 1024).  grad_scale multiplies the gradient that returns to x;
     default = world size, which makes the usual MEAN all-reduce of the parameter gradients reproduce the gradient of a
     correlation loss that is counted once for the global batch (the per-rank cross-entropy means average correctly as is)."""
     world = dist.get_world_size(group)
@@ -438,9 +438,9 @@ def global_corr(x, eps=0.0, group=None, local_corr=None, grad_scale=None):
     if local_corr is None:
         from . import _lib as L
         from . import ops
-        if Bg > L.MAX_BATCH:
-            raise RuntimeError(f"global corr: global batch {Bg} exceeds the {L.MAX_BATCH} rows the fused Gram kernels hold "
-                               "on chip; use the per-rank semantics (SURVEY.md §8e) for larger global batches")
+        if Bg > L.MAX_CORR_BATCH:
+            raise RuntimeError(f"global corr: global batch {Bg} exceeds the {L.MAX_CORR_BATCH} rows alignq_corr_fwd takes; "
+                               "use the per-rank semantics (SURVEY.md §8e) for larger global batches")
         local_corr = lambda X: ops.CorrFn.apply(X, float(eps))      # noqa: E731
     Xr = _FeatureShard.apply(x2, group, world if grad_scale is None else grad_scale)
     Gr = local_corr(Xr) * (1.0 / world)          # (F_r / F) with equal shards

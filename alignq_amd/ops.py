@@ -212,14 +212,15 @@ def _as_bf(x):
     return B, x.numel() // B
 
 
-def _check_batch(B, what):
-    """The correlation kernels hold the whole batch of a feature tile on chip: 2 <= B <= 128 (include/alignq.h,
-    ALIGNQ_MAX_BATCH).  The reference accepts any batch; every BASELINE configuration's per-GPU batch is 128 or 28.  Raised here
-    with a clear message instead of surfacing as ALIGNQ_EUNSUPPORTED from the C ABI."""
-    if not (2 <= B <= L.MAX_BATCH):
-        raise RuntimeError(f"alignq_amd: {what} needs a batch of 2..{L.MAX_BATCH} rows (got {B}): the fused Gram kernels keep all "
-                           "rows of a feature tile on chip; split the batch (data parallel: alignq_amd.dp) or use "
-                           "config.args.method != 'ours' for the plain quantiser")
+def _check_batch(B, what, limit=None):
+    """The FUSED site kernels hold the whole batch of a feature tile on chip: 2 <= B <= 128 (include/alignq.h,
+    ALIGNQ_MAX_BATCH); corr(x, x) alone runs blocked up to ALIGNQ_MAX_CORR_BATCH = 1024 rows and the module layer composes
+    the ADMM site from it above 128 (site_unfused).  The reference accepts any batch; every BASELINE configuration's per-GPU
+    batch is 128 or 28.  Raised here with a clear message instead of surfacing as ALIGNQ_EUNSUPPORTED from the C ABI."""
+    limit = L.MAX_BATCH if limit is None else limit
+    if not (2 <= B <= limit):
+        raise RuntimeError(f"alignq_amd: {what} needs a batch of 2..{limit} rows (got {B}); split the batch (data parallel: "
+                           "alignq_amd.dp) or use config.args.method != 'ours' for the plain quantiser")
 
 
 class CorrFn(torch.autograd.Function):
@@ -229,7 +230,7 @@ class CorrFn(torch.autograd.Function):
     def forward(ctx, x, eps):
         x = L.dev_f32(x, "corr input")
         B, F = _as_bf(x)
-        _check_batch(B, "corr")
+        _check_batch(B, "corr", L.MAX_CORR_BATCH)        # above 128 rows: the blocked Gram of corr_large_kernels.hip
         lib = L.load()
         G = torch.empty(B, B, dtype=torch.float32, device=x.device)
         stats = torch.empty(2, F, dtype=torch.float32, device=x.device)
@@ -412,6 +413,18 @@ class SiteFn(torch.autograd.Function):
                                           L.ptr(g_loss), L.ptr(x), L.ptr(stats), B, F, act_range, eps, L.ptr(dx),
                                           L.ptr(dA), L.ptr(dG), L.ptr(ws), L.stream_ptr()), "alignq_site_bwd_fused")
         return dx, dA, dG, None, None, None, None, None, None, None, None, dres, None
+
+
+def site_unfused(x, admm, k, act_range, eps, formula):
+    """The ADMM activation site for 128 < B <= ALIGNQ_MAX_CORR_BATCH, composed from the stand-alone kernels (the fused site
+    kernels keep all rows of a feature tile on chip and stop at 128): x_q = quantise(x), t = the pre-round transform (the
+    quantiser at k = 32 writes it), D = corr(t, t) - corr(x, x) on the blocked Gram, loss = ADMM(D).  x is read four times
+    instead of once; same values as the reference's lines (model/quantization.py:109-123).  Returns (x_q, loss, D)."""
+    xq = ActQuantFn.apply(x, k, act_range, formula)
+    t = ActQuantFn.apply(x, 32, act_range, formula)
+    D = CorrFn.apply(t, float(eps)) - CorrFn.apply(x, float(eps))
+    loss = AdmmLossFn.apply(D, admm.alterD, admm.gamma, admm.mu, admm.rho)
+    return xq, loss, D
 
 
 def site_res_supported(x, residual) -> bool:

@@ -123,6 +123,12 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
             t = ops.ActQuantFn.apply(x, 32, r_, formula)            # k == 32 writes the pre-round transform itself
             D = dp.global_corr(t, eps, grp) - dp.global_corr(x, eps, grp)
             return xq, admm(D)
+        if config.args.method == "ours" and a_bit < 32 and x.shape[0] > L.MAX_BATCH:
+            # above the 128 rows the fused kernels hold on chip: the site composed from the blocked correlation
+            admm = mod.opt
+            xq, loss, D = ops.site_unfused(x, admm, a_bit, config.args.act_range, eps, formula)
+            admm.D = D
+            return xq, loss
         if config.args.method == "ours" and a_bit < 32:
             admm = mod.opt
             from . import fused

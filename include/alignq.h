@@ -37,7 +37,11 @@ extern "C" {
 #define ALIGNQ_EINVAL (-1)       /* bad argument (null pointer, k out of range, n <= 0 ...) */
 #define ALIGNQ_EUNSUPPORTED (-2) /* shape outside what the kernels handle (e.g. batch > ALIGNQ_MAX_BATCH) */
 
-#define ALIGNQ_MAX_BATCH 128 /* rows of a correlation site the fused kernels hold on chip */
+#define ALIGNQ_MAX_BATCH 128 /* rows of a correlation site the FUSED kernels (alignq_site_*) hold on chip */
+#define ALIGNQ_MAX_CORR_BATCH 1024 /* rows alignq_corr_fwd / _bwd take: above 128 a blocked Gram (column statistics over all
+                                      rows, 128x128 output blocks, exact fp32) - the reference takes any batch
+                                      (model/quantization.py:134-137, utils/admm.py:17-27); the module layer composes the
+                                      ADMM site from it for B > 128 */
 
 int alignq_abi_version(void);
 /* message for a return code of this library (static string) */
@@ -143,6 +147,7 @@ int alignq_site_bwd_fused(const float* g, const float* D, const float* alterD, c
                           const float* stats, int B, int64_t F, float act_range, float eps, float* dx,
                           float* dalterD, float* dgamma, void* ws, void* stream);
 /* corr(x,x) alone (module-level `corr`, model/quantization.py:134-137): G [B,B]; stats [2][F];
+ * 2 <= B <= ALIGNQ_MAX_CORR_BATCH (B > ALIGNQ_MAX_BATCH: blocked form, stats required);
  * ws: alignq_site_ws_bytes(B,F) forward, alignq_site_bwd_ws_bytes(B) backward.                               */
 int alignq_corr_fwd(const float* x, int B, int64_t F, float eps, float* G, float* stats, void* ws,
                     void* stream);

@@ -419,7 +419,55 @@ def test_global_corr_on_rccl_matches_the_fused_site(dev, pg):
     np.testing.assert_allclose(dx1, dx0, atol=TOL, rtol=1e-4)
     np.testing.assert_allclose(dA1, dA0, atol=1e-7, rtol=1e-4)
     with pytest.raises(RuntimeError, match="exceeds"):
-        dp.global_corr(torch.randn(129, 64, device=dev), 0.0)
+        dp.global_corr(torch.randn(1025, 64, device=dev), 0.0)
+    # above 128 rows the shard SYRK is the blocked Gram (round 3): same value as the stand-alone corr
+    xl = torch.randn(192, 640, device=dev)
+    np.testing.assert_allclose(npy(dp.global_corr(xl, 0.0)), npy(ops.CorrFn.apply(xl, 0.0)), atol=1e-6)
+
+
+def test_captured_dp_step_keeps_its_bucket_across_a_short_batch(dev, pg):
+    """ADVICE r2 (high).  A captured TrainStep with the data-parallel hook (world size 1 on RCCL, force=True): capture, a
+    SHORT last batch (eager fallback: the hook lays out a second bucket for the [b',b'] D matrices), then a full batch again.
+    The eager reduce() between the two graphs must all-reduce the buffer the graphs pack into and unpack from: checked by
+    turning the collective into "multiply the reduced buffer by 2" and observing the doubled gradients in the step's result."""
+    from alignq_amd import config, dp
+    from alignq_amd.resnet import PreActBlock_conv_Q, PreActResNet
+    from alignq_amd.train_step import TrainStep
+    config.args.bitW = config.args.abitW = 8
+    config.args.train_batch_size = 128
+    torch.manual_seed(5)
+    x = torch.randn(128, 3, 32, 32, device=dev)
+    y = torch.randint(0, 10, (128,), device=dev)
+    net = PreActResNet(PreActBlock_conv_Q, [1, 1, 1], 8, 8, "second", 10).to(dev).train()
+    step = TrainStep(net, lr=0.01, channels_last=True)
+    hook = dp.attach(step, force=True)
+    step.capture(x, y, warmup=2)
+    assert step._graph2 is not None
+    cap_bucket = hook.bucket
+    step(x, y)
+    step(x[:80], y[:80])                       # CIFAR's last batch: 80 of 128 (no drop_last in the reference's loaders)
+    assert hook.bucket is cap_bucket and len(hook._buckets) == 2       # the fallback used its own bucket and put this one back
+    seen = []
+    orig = hook.reduce
+
+    def doubling_reduce():
+        seen.append(hook.bucket)
+        hook.bucket.flat.mul_(2.0)             # stands in for a SUM over two identical ranks
+    hook.reduce = doubling_reduce
+    try:
+        torch.cuda.synchronize()
+        step._graph.replay()
+        torch.cuda.synchronize()
+        packed = cap_bucket.flat.clone()       # what graph 1 packed (this step's local gradients and D)
+        hook.reduce()
+        step._graph2.replay()                  # unpack + optimiser steps
+        torch.cuda.synchronize()
+    finally:
+        hook.reduce = orig
+    assert seen == [cap_bucket]
+    # graph 2 unpacked the DOUBLED buffer into the tensors the optimisers read: the first gradient tensor shows it
+    g0 = next(p.grad for p in hook.params if p.grad is not None)
+    np.testing.assert_allclose(npy(g0).ravel(), 2.0 * npy(packed[:g0.numel()]), rtol=1e-6, atol=0)
 
 
 def test_office_step_with_bucketed_allreduce_at_world_one(dev, pg):
@@ -500,12 +548,13 @@ def test_resnet50_dann_loss_trajectory_tracks_the_reference_restatement(dev):
 
 
 def test_batch_contract_is_a_clear_python_error(dev):
-    """2 <= B <= 128 is a contract of the fused correlation kernels; the Python API says so instead of passing
-    ALIGNQ_EUNSUPPORTED through."""
+    """2 <= B <= 128 is a contract of the FUSED site kernels (round 3: corr alone goes to 1024 rows, and the module
+    layer composes the site from it above 128); the Python API says so instead of passing ALIGNQ_EUNSUPPORTED through."""
     from alignq_amd import ops
-    for B in (1, 129):
-        with pytest.raises(RuntimeError, match="batch of 2..128"):
+    for B in (1, 1025):
+        with pytest.raises(RuntimeError, match="batch of 2..1024"):
             ops.CorrFn.apply(torch.randn(B, 64, device=dev), 0.0)
+    for B in (1, 129):
         with pytest.raises(RuntimeError, match="batch of 2..128"):
             ops.SiteFn.apply(torch.randn(B, 64, device=dev), torch.rand(129, 129, device=dev), torch.rand(129, 129, device=dev),
                              8, 2.0, 0.0, 0.2, 0.3)

@@ -1,0 +1,154 @@
+"""GPU tests added in round 3 (all through the C ABI via alignq_amd.ops / the Python mirror):
+value-level parity at config 5's site sizes; corr / the ADMM site above 128 rows (blocked Gram); NERF32 edge inputs."""
+import numpy as np
+import pytest
+import torch
+
+from tests import oracle_c as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X box"
+    from alignq_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def cu(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def bits_equal(a, b):
+    a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+    return np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+# ------------------------------------------------------------------------------------------------ VERDICT r2 item 2
+@pytest.mark.parametrize("F", [100352, 802816])
+def test_small_batch_site_by_value_at_config5_sizes(dev, F):
+    """The wave-autonomous B <= 32 kernels at the Office tree's own shapes (batch 28, eps 1e-5; dann_office/model/
+    quantization.py:112-161, sites of model/resnet.py:131-156): x_q bit for bit, D / loss / dx / dalterD / dgamma within 1e-5
+    of the C oracle BY VALUE (round 2 only asserted symmetry / trace / lattice at these sizes).  [28, 802816] is the stem."""
+    from alignq_amd import ops
+    rng = np.random.default_rng(F % 1000)
+    B, k, r, eps = 28, 8, 2.0, 1e-5
+    x0 = (rng.standard_normal((B, F)) * 1.1 + 0.15).astype(np.float32)
+    A0, G0 = rng.random((B, B), dtype=np.float32), rng.random((B, B), dtype=np.float32)
+    gq = (rng.standard_normal((B, F)) * 1e-3).astype(np.float32)
+    x = cu(x0, dev).requires_grad_(True)
+    A, Gm = cu(A0, dev).requires_grad_(True), cu(G0, dev).requires_grad_(True)
+    xq, loss, D = ops.SiteFn.apply(x, A, Gm, k, r, eps, 0.2, 0.3)
+    torch.autograd.backward([xq, loss], [cu(gq, dev), torch.ones((), device=dev)])
+    oq, oD = O.site_fwd(x0, k, r, eps)
+    assert bits_equal(npy(xq), oq)
+    np.testing.assert_allclose(npy(D), oD, atol=TOL, rtol=0)
+    ol, odD, odA, odG = O.admm_loss(oD, A0, G0, 0.2, 0.3)
+    np.testing.assert_allclose(float(loss), ol, atol=TOL)
+    odx = O.site_bwd(gq, odD, x0, r, eps)
+    np.testing.assert_allclose(npy(x.grad), odx, atol=TOL, rtol=1e-4)
+    np.testing.assert_allclose(npy(A.grad), odA, atol=1e-7, rtol=1e-4)
+    np.testing.assert_allclose(npy(Gm.grad), odG, atol=1e-7, rtol=1e-4)
+
+
+def test_plain_quantiser_by_value_at_the_stem_size(dev):
+    """activation_quantize_fn (no ADMM: act_q1 / act_q2 of every bottleneck) at [28, 64, 112, 112]: x_q and the packed level
+    indices bit for bit against the oracle over all 22.5 M elements, dx within 1e-5."""
+    from alignq_amd import _lib as L
+    from alignq_amd import ops
+    rng = np.random.default_rng(3)
+    n, k, r = 28 * 802816, 8, 2.0
+    x0 = (rng.standard_normal(n) * 1.3).astype(np.float32)
+    g0 = rng.standard_normal(n).astype(np.float32)
+    x = cu(x0, dev).requires_grad_(True)
+    q = ops.ActQuantFn.apply(x, k, r, L.FORMULA_ADMM)
+    q.backward(cu(g0, dev))
+    oq, _, obins = O.act_quant_fwd(x0, k, r, O.FORMULA_ADMM)
+    assert bits_equal(npy(q), oq)
+    np.testing.assert_allclose(npy(x.grad), O.act_quant_bwd(g0, x0, r), atol=TOL, rtol=1e-4)
+    bins = ops.act_quant_pack(x.detach(), k, r, L.FORMULA_ADMM)
+    bins = bins[0] if isinstance(bins, (tuple, list)) else bins
+    assert np.array_equal(npy(bins).astype(np.int32), obins)
+
+
+# ------------------------------------------------------------------------------------------------ VERDICT r2 item 3
+@pytest.mark.parametrize("B,F,eps", [(192, 1000, 0.0), (256, 4096, 0.0), (512, 2050, 1e-5), (130, 70, 1e-5), (1024, 256, 0.0)])
+def test_corr_above_128_rows_vs_oracle(dev, B, F, eps):
+    """corr(x, x) on the blocked Gram (corr_large_kernels.hip; reference model/quantization.py:134-137, Office :158-161):
+    G and dx for a non-symmetric upstream dG within 1e-5 of the C oracle, ragged F (not a multiple of 4 / 32 / 64) included."""
+    from alignq_amd import ops
+    rng = np.random.default_rng(B + F)
+    x0 = (rng.standard_normal((B, F)) * 0.8 + 0.3).astype(np.float32)
+    x0[:, 3] = 0.25 if eps > 0 else x0[:, 3]                 # a constant column: std == 0 (only meaningful with eps)
+    dG = rng.standard_normal((B, B)).astype(np.float32)
+    x = cu(x0, dev).requires_grad_(True)
+    G = ops.CorrFn.apply(x, eps)
+    G.backward(cu(dG, dev))
+    np.testing.assert_allclose(npy(G), O.corr_fwd(x0, eps), atol=TOL, rtol=0)
+    np.testing.assert_allclose(npy(x.grad), O.corr_bwd(dG, x0, eps), atol=TOL, rtol=1e-4)
+    assert np.array_equal(npy(G), npy(G).T)                  # the mirrored blocks are copies
+    G2 = ops.CorrFn.apply(x.detach(), eps)
+    assert bits_equal(npy(G), npy(G2))                       # deterministic run to run
+
+
+@pytest.mark.parametrize("tree,B", [("admm", 192), ("office", 256)])
+def test_admm_site_above_128_rows_vs_oracle(dev, tree, B):
+    """activation_quantize_fn with ADMM at a batch the fused kernels do not hold (the module composes the site from the plain
+    quantiser, the blocked correlation and the ADMM loss): x_q bit for bit, D / loss / dx / dalterD / dgamma within 1e-5 of
+    the oracle; ADMM(dim) is sized by the batch like the reference does (utils/admm.py:17-27)."""
+    import alignq_amd.cdf_alignment_admm as NA
+    import alignq_amd.office as NO
+    from alignq_amd import config
+    ns, eps = (NA, 0.0) if tree == "admm" else (NO, 1e-5)
+    old = (config.args.abitW, config.args.train_batch_size)
+    config.args.abitW, config.args.train_batch_size = 4, B
+    try:
+        rng = np.random.default_rng(B)
+        C, H = 6, 8
+        x0 = (rng.standard_normal((B, C, H, H)) * 1.2).astype(np.float32)
+        gq = (rng.standard_normal((B, C, H, H)) * 1e-2).astype(np.float32)
+        admm = ns.ADMM(B).to(dev)
+        A0, G0 = npy(admm.alterD), npy(admm.gamma)
+        act = (ns.activation_quantize_fn if tree == "admm" else ns.activation_quantize_fn2)(4, "aligned", admm).to(dev)
+        x = cu(x0, dev).requires_grad_(True)
+        xq, loss = act(x)
+        torch.autograd.backward([xq, loss], [cu(gq, dev), torch.ones((), device=dev)])
+        F = C * H * H
+        oq, oD = O.site_fwd(x0.reshape(B, F), 4, 2.0, eps)
+        assert bits_equal(npy(xq).reshape(B, F), oq)
+        np.testing.assert_allclose(npy(admm.D), oD, atol=TOL, rtol=0)
+        ol, odD, odA, odG = O.admm_loss(oD, A0, G0, 0.2, 0.3)
+        np.testing.assert_allclose(float(loss), ol, atol=TOL)
+        odx = O.site_bwd(gq.reshape(B, F), odD, x0.reshape(B, F), 2.0, eps)
+        np.testing.assert_allclose(npy(x.grad).reshape(B, F), odx, atol=TOL, rtol=1e-4)
+        np.testing.assert_allclose(npy(admm.alterD.grad), odA, atol=1e-7, rtol=1e-4)
+        np.testing.assert_allclose(npy(admm.gamma.grad), odG, atol=1e-7, rtol=1e-4)
+    finally:
+        config.args.abitW, config.args.train_batch_size = old
+
+
+# ------------------------------------------------------------------------------------------------ NERF32 on the device
+def test_nerf32_device_equals_oracle_on_edge_inputs(dev):
+    """The table-driven transform on the GPU against its C statement: every node boundary and its fp32 neighbours, the
+    clamp, signed zeros, infinities and NaN, through the plain quantiser at k = 32 (which writes the pre-round transform)."""
+    from alignq_amd import _lib as L
+    from alignq_amd import ops
+    edges = (np.arange(0, 120, dtype=np.float64) / 16.0).astype(np.float32)
+    xs = np.concatenate([edges, np.nextafter(edges, np.float32(-1)), np.nextafter(edges, np.float32(99)),
+                         np.array([0.0, -0.0, np.inf, -np.inf, 5.625, 5.6250005, 1e30, -1e30, 1e-45, -1e-45, 1e-30], np.float32)])
+    xs = np.concatenate([xs, -xs]).astype(np.float32)
+    xs = np.concatenate([xs, np.zeros((-len(xs)) % 4, np.float32)])
+    for formula, of in ((L.FORMULA_ADMM, O.FORMULA_ADMM), (L.FORMULA_CDF, O.FORMULA_CDF)):
+        for k in (32, 8, 2):
+            got = npy(ops.ActQuantFn.apply(cu(xs, dev), k, 2.0, formula))
+            want, _, _ = O.act_quant_fwd(xs, k, 2.0, of)
+            assert bits_equal(got, want), (formula, k)
+    nan_out = npy(ops.ActQuantFn.apply(cu(np.array([np.nan, 1.0, -np.nan, 0.5], np.float32), dev), 8, 2.0, L.FORMULA_ADMM))
+    assert np.isnan(nan_out[0]) and np.isnan(nan_out[2]) and np.isfinite(nan_out[1]) and np.isfinite(nan_out[3])
