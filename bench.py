@@ -50,7 +50,9 @@ def parse():
     ap.add_argument("--no-kernels", action="store_true", help="skip the per-kernel roofline measurements")
     ap.add_argument("--no-shapes", action="store_true", help="skip the roofline-sized microbench shapes (kernels.roofline_shapes); "
                     "the rocprofv3 passes of tools/make_profiles.sh use it so that their per-kernel averages hold the CIFAR shapes only")
-    ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--cpu-steps", type=int, default=10, help="timed steps per thread count of the CPU baseline (BASELINE.md: >= 10)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short captured runs of BASELINE.json's other "
+                    "configurations (extra key other_configs: ResNet-20 2W/2A, ResNet-56 4W/4A, ResNet-50-DANN batch 28)")
     ap.add_argument("--no-fuse-bn", action="store_true", help="keep torch/MIOpen batch-norm instead of folding it into the ADMM-site kernels")
     ap.add_argument("--dp-selftest", action="store_true", help="run the DP path (RCCL all-reduce, two graphs) even at N=1")
     ap.add_argument("--no-dp-probe", action="store_true", help="skip the short world-size-1 DP-path measurement (extra key dp_selftest)")
@@ -382,8 +384,9 @@ def measure_roofline_shapes(dev, k):
 
 def cpu_baseline(batch, bits, model, steps):
     """The eager-torch restatement of the reference on the host cores: same workload, bounded sample.  Oversubscribing
-    torch's intra-op pool hurts this elementwise-heavy workload (64 threads ran slower than 16 on the GPU box), so two
-    thread counts are tried and the FASTER one is reported."""
+    torch's intra-op pool hurts this elementwise-heavy workload (64 threads ran slower than 16 on the GPU box), so a sweep
+    of thread counts {8, 16, 32, 64, 128} (those the box offers) is timed, >= 10 steps each, and the FASTEST is reported
+    with the whole list."""
     from oracle import torch_ref as R
     try:
         avail = len(os.sched_getaffinity(0))
@@ -395,7 +398,7 @@ def cpu_baseline(batch, bits, model, steps):
     y = torch.randint(0, 10, (batch,), generator=gen)
     best = None
     tried = {}
-    for cores in sorted({max(1, min(avail, 16)), max(1, min(avail, 64))}):
+    for cores in sorted({max(1, min(avail, c)) for c in (8, 16, 32, 64, 128)}):
         torch.set_num_threads(cores)
         torch.manual_seed(0)
         net = (R.resnet20 if model == "resnet20" else R.resnet56)(cfg).train()
@@ -415,9 +418,9 @@ def cpu_baseline(batch, bits, model, steps):
     cores, med = best
     return {"value": batch / med, "unit": "images/sec", "cores": cores, "host_cores": os.cpu_count(), "usable_cores": avail,
             "kind": "port",
-            "sample": f"{steps} full training steps (median) of the same workload after 2 warm-ups, batch {batch}, "
-                      f"oracle/torch_ref.py on torch-CPU {torch.__version__}; thread counts tried -> images/sec: {tried}",
-            "s_per_step": med}
+            "sample": f"{steps} full training steps (median) of the same workload after 2 warm-ups per thread count, batch "
+                      f"{batch}, oracle/torch_ref.py on torch-CPU {torch.__version__}; best of the thread sweep",
+            "thread_sweep_images_per_sec": tried, "s_per_step": med}
 
 
 class _StdoutToStderr:
@@ -471,6 +474,74 @@ def dp_probe(dev, a, steps=50):
     finally:
         if dist.is_initialized():
             dist.destroy_process_group()
+    return out
+
+
+# Algorithmic HBM bytes per GPU and step of the in-scope kernels (20 B per activation element of a
+# quantiser site; weights 20-28 B each, quantised once per pass)
+_CFG_BYTES = {"resnet20": 128 * 200704 * 20 + 0.27e6 * 28, "resnet56": 128 * 544768 * 20 + 0.85e6 * 28,
+              "resnet50_dann": 2 * 28 * 9608704 * 20 + 2 * 23.5e6 * 20 + 23.5e6 * 8}
+
+
+def other_configs(dev, a, steps=30):
+    """BASELINE.json's other configurations through the same code, one GPU's share each, short captured runs (the headline
+    line above stays configs[1]): configs[2] ResNet-20 2W/2A (batch 1024 / 8 GPUs = 128 per GPU), configs[3] ResNet-56 4W/4A
+    (512 / 4 = 128), configs[4] ResNet-50-DANN Office-31 8W/8A (224 / 8 = 28, source + target pass).  Iteration order of the
+    reference: cdf_alignment_admm/resnet-20-cifar-10/main.py:288-378, dann_office/main.py:343-456."""
+    import gc
+    from alignq_amd import config
+    from alignq_amd.resnet import resnet20_quant, resnet56_quant
+    from alignq_amd.resnet_office import resnet50_dann
+    from alignq_amd.train_step import OfficeTrainStep, TrainStep
+    saved = (config.args.bitW, config.args.abitW, config.args.train_batch_size, config.args.eval_batch_size)
+    out = {}
+    gen = torch.Generator().manual_seed(1)
+    for name, kind, bits, batch in (("resnet20_2w2a_b128", "resnet20", 2, 128), ("resnet56_4w4a_b128", "resnet56", 4, 128),
+                                    ("resnet50_dann_8w8a_b28", "resnet50_dann", 8, 28)):
+        try:
+            config.args.bitW = config.args.abitW = bits
+            config.args.train_batch_size = config.args.eval_batch_size = batch
+            torch.manual_seed(0)
+            if kind == "resnet50_dann":
+                model = resnet50_dann(bits, bits).to(dev).train()
+                st = OfficeTrainStep(model, lr=0.004, channels_last=True)
+                xs = torch.randn(batch, 3, 224, 224, generator=gen).to(dev)
+                xt = torch.randn(batch, 3, 224, 224, generator=gen).to(dev)
+                ys = torch.randint(0, 31, (batch,), generator=gen).to(dev)
+                st.capture(xs, ys, xt, warmup=2)
+                run = lambda: st(xs, ys, xt)                         # noqa: E731
+                images = 2 * batch
+            else:
+                model = (resnet20_quant if kind == "resnet20" else resnet56_quant)(bits, bits).to(dev).train()
+                st = TrainStep(model, lr=0.04, channels_last=True)
+                x = torch.randn(batch, 3, 32, 32, generator=gen).to(dev)
+                y = torch.randint(0, 10, (batch,), generator=gen).to(dev)
+                st.capture(x, y, warmup=3)
+                x, y = st.static_inputs()
+                run = lambda: st(x, y)                               # noqa: E731
+                images = batch
+            n = steps if kind != "resnet50_dann" else max(20, steps // 2)
+            for _ in range(5):
+                run()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                res = run()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / n * 1e3
+            ce = float(res[1].detach())
+            out[name] = {"ms_per_step": ms, "images_per_sec": images / ms * 1e3, "steps": n, "per_gpu_batch": batch,
+                         "algorithmic_mbytes_per_step": _CFG_BYTES[kind] / 1e6,
+                         "in_scope_bytes_over_step_time_gbs": _CFG_BYTES[kind] / (ms * 1e-3) / 1e9,
+                         "final_loss": ce, "finite": bool(ce == ce and abs(ce) != float("inf"))}
+            del st, model, run
+        except Exception as e:            # never fail the headline line on the extras
+            out[name] = {"error": repr(e)[:300]}
+        gc.collect()
+        torch.cuda.empty_cache()
+    config.args.bitW, config.args.abitW, config.args.train_batch_size, config.args.eval_batch_size = saved
+    out["note"] = ("one GPU's share of BASELINE.json configs[2..4], HIP-graph replay, channels-last; config 5's convolutions "
+                   "and batch-norms are MIOpen's (out of scope), lr 0.004 from random init (DESIGN.md section 5b)")
     return out
 
 
@@ -609,6 +680,8 @@ def main():
             # the data-parallel path at world size 1 (RCCL all-reduce of the flat gradient + D bucket between two HIP graphs):
             # what one rank of the N > 1 runs executes per step, minus the wire time (no 8-GPU node in this session)
             res["dp_selftest"] = dp_probe(dev, a)
+        if world == 1 and not office and not a.no_other_configs and a.model == "resnet20" and a.bits == 8:
+            res["other_configs"] = other_configs(dev, a)
         print(json.dumps(res))
     if dist.is_initialized():
         dist.barrier()

@@ -229,7 +229,7 @@ def test_office_bucketed_overlapped_allreduce_two_ranks_gloo():
 
 # ---------------------------------------------------------------------------------------------------------------------
 # N4: exact-global-batch correlation (alignq_amd.dp.global_corr)
-def _gcorr_worker(rank, world, port, out):
+def _gcorr_worker(rank, world, port, out, b=8):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -237,7 +237,7 @@ def _gcorr_worker(rank, world, port, out):
         from alignq_amd import dp
         from oracle import torch_ref as R
         g = torch.Generator().manual_seed(7)
-        b, C, H, W = 8, 6, 4, 4                        # F = 96, divisible by the world size
+        C, H, W = 6, 4, 4                              # F = 96, divisible by the world size
         X = torch.randn(world * b, C, H, W, generator=g) * 0.9 + 0.2      # the global batch, identical on every rank
         dG = torch.randn(world * b, world * b, generator=g)
         for eps in (0.0, 1e-5):
@@ -250,17 +250,19 @@ def _gcorr_worker(rank, world, port, out):
 
 
 @pytest.mark.timeout(300)
-def test_global_corr_equals_single_process_corr_on_the_concatenated_batch():
+@pytest.mark.parametrize("b", [8, 128])
+def test_global_corr_equals_single_process_corr_on_the_concatenated_batch(b):
     """all-to-all (gloo: all-gather) to the feature-sharded layout -> per-shard SYRK -> all-reduce; result and
-    the gradient that returns to every rank's samples equal the single-process corr of the concatenated batch (<= 1e-5)."""
+    the gradient that returns to every rank's samples equal the single-process corr of the concatenated batch (<= 1e-5).
+    b = 128 per rank is a GLOBAL batch of 256 (the 128-row cap of round 2 is gone; on the GPU the shard
+    SYRK at 256 rows is the blocked Gram, tests/test_gpu_round3.py checks that one against the oracle)."""
     from oracle import torch_ref as R
     world = 2
     port = _free_port()
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_gcorr_worker, args=(world, port, out), nprocs=world, join=True)
+    mp.spawn(_gcorr_worker, args=(world, port, out, b), nprocs=world, join=True)
     g = torch.Generator().manual_seed(7)
-    b = 8
     X = torch.randn(world * b, 6, 4, 4, generator=g) * 0.9 + 0.2
     dG = torch.randn(world * b, world * b, generator=g)
     for eps in (0.0, 1e-5):
