@@ -1,0 +1,295 @@
+// bnq_kernels.hip — training-mode batch-norm folded into the PLAIN CDF quantiser (+ the ReLU behind it), any batch, for
+// channels-last tensors: the Office tree's bottleneck sites without an ADMM term,
+//     out = relu(act_q1(bn1(conv1(x))));  out = relu(act_q2(bn2(conv2(out))))      (cdf_alignment_admm/dann_office/model/
+//     resnet.py:134-143, stem :230-233; activation_quantize_fn :87-110)
+// SURVEY.md §8f-N1 on configuration 5.  The convolution is MIOpen's (out of scope) and hands over z; what is folded is
+// everything between z and the next convolution's input:
+//   forward : bnq_sums<STATS> (per-channel sum / sum of squares of z: one read of z) -> bnq_finalize (mean, invstd, running
+//             statistics, a = gamma*invstd, b = beta - mean*a) -> bnq_apply_fwd: y = relu(quantise(a*z + b)) (read z, write y)
+//             = 12 B/element instead of 20 (BatchNorm forward: two reads + one write, then the quantiser's read + write); the
+//             normalised activation is never written;
+//   backward: bnq_sums<BWD> (dx = g * [y > 0] * dt/dx(a*z + b); per-channel sum dx, sum dx*zhat: reads g, z, y) ->
+//             bnq_finalize_bwd (k0 = mean dx, k1 = mean dx*zhat, dgamma, dbeta) -> bnq_apply_bwd: dz = a*(dx - k0 - zhat*k1)
+//             (reads g, z, y, writes dz) = 28 B/element instead of 16 (quantiser + ReLU backward) + ~20 (BatchNorm backward).
+// z viewed as [P, C], P = B*H*W pixels, C channels fastest (torch.channels_last); C = 4 * 2^j <= 1024 so that a thread's
+// channel quad is fixed for the whole launch (256 threads = slots x C/4 quads).  Arithmetic: statistics in double, the
+// affine as ONE fma (the form oracle/alignq_oracle.c: oq_bn_fold_ab / oq_bn_apply pin to torch.nn.BatchNorm2d), then the
+// quantiser of alignq_math.h: y is bit-identical to quantising the oracle's BN output.  Deterministic (fixed-order sums).
+#include <hip/hip_runtime.h>
+
+#include "../../include/alignq.h"
+#include "alignq_math.h"
+
+using namespace alignq;
+
+namespace {
+
+constexpr int kT = 256;
+constexpr int kParts = 512;          // workgroups of the two reduction kernels = partials per channel
+constexpr int kUs = 4;               // pixels in flight per thread in the reductions
+constexpr int kUa = 4;               // float4 per thread and tile in the elementwise kernels
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ldnt(const float* p) {
+  const f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+
+// ---- per-channel sums over the pixels -----------------------------------------------------------------------------------
+// BWD = false: {sum z, sum z^2};  BWD = true: {sum dx, sum dx*zhat} with dx = g * [y > 0] * jac(a*z + b).
+// part: [gridDim.x][C][2] doubles.
+template <bool BWD>
+__global__ __launch_bounds__(kT) void bnq_sums_kernel(const float* __restrict__ z, const float* __restrict__ g,
+                                                      const float* __restrict__ y, const float* __restrict__ ab,
+                                                      const float* __restrict__ save, int64_t P, int C, float r, int relu,
+                                                      double* __restrict__ part) {
+  __shared__ double sm[kT][8];
+  const int tid = threadIdx.x;
+  const int C4 = C >> 2, slots = kT / C4;
+  const int cq = tid % C4, slot = tid / C4;
+  const int64_t per = (P + gridDim.x - 1) / gridDim.x;
+  const int64_t p0 = (int64_t)blockIdx.x * per, p1 = (p0 + per < P) ? p0 + per : P;
+  float4 a4, b4, m4, i4;
+  if (BWD) {
+    a4 = *reinterpret_cast<const float4*>(ab + 4 * cq);
+    b4 = *reinterpret_cast<const float4*>(ab + C + 4 * cq);
+    m4 = *reinterpret_cast<const float4*>(save + 4 * cq);
+    i4 = *reinterpret_cast<const float4*>(save + C + 4 * cq);
+  }
+  double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+  for (int64_t base = p0 + slot; base < p1; base += (int64_t)slots * kUs) {
+    float4 zv[kUs], gv[kUs], yv[kUs];
+#pragma unroll
+    for (int u = 0; u < kUs; u++) {            // clamped address, masked below
+      const int64_t px = base + (int64_t)u * slots;
+      const int64_t off = (px < p1 ? px : p1 - 1) * C + 4 * cq;
+      zv[u] = *reinterpret_cast<const float4*>(z + off);
+      if (BWD) {
+        gv[u] = *reinterpret_cast<const float4*>(g + off);
+        if (relu) yv[u] = *reinterpret_cast<const float4*>(y + off);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kUs; u++) {
+      if (base + (int64_t)u * slots < p1) {
+        const float ze[4] = {zv[u].x, zv[u].y, zv[u].z, zv[u].w};
+        if (!BWD) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) { s0[e] += (double)ze[e]; s1[e] += (double)ze[e] * (double)ze[e]; }
+        } else {
+          const float ge[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+          const float ye[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};
+          const float ae[4] = {a4.x, a4.y, a4.z, a4.w}, be[4] = {b4.x, b4.y, b4.z, b4.w};
+          const float me[4] = {m4.x, m4.y, m4.z, m4.w}, ie[4] = {i4.x, i4.y, i4.z, i4.w};
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const float x = __fmaf_rn(ae[e], ze[e], be[e]);
+            const float gm = (relu && !(ye[e] > 0.f)) ? 0.f : ge[e];
+            const float dx = gm * act_jac(x, r);
+            const float zh = (ze[e] - me[e]) * ie[e];
+            s0[e] += (double)dx;
+            s1[e] += (double)dx * (double)zh;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; e++) { sm[tid][e] = s0[e]; sm[tid][4 + e] = s1[e]; }
+  __syncthreads();
+  for (int c = tid; c < C; c += kT) {
+    const int qd = c >> 2, e = c & 3;
+    double a = 0, b = 0;
+    for (int s = 0; s < slots; s++) { a += sm[s * C4 + qd][e]; b += sm[s * C4 + qd][4 + e]; }      // fixed order
+    part[((int64_t)blockIdx.x * C + c) * 2] = a;
+    part[((int64_t)blockIdx.x * C + c) * 2 + 1] = b;
+  }
+}
+
+// one thread per channel
+__global__ __launch_bounds__(kT) void bnq_finalize_kernel(const double* __restrict__ part, int nparts, int64_t P, int C,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                          long long* __restrict__ nbt, float momentum, float eps,
+                                                          float* __restrict__ ab, float* __restrict__ save) {
+  const int c = blockIdx.x * kT + threadIdx.x;
+  if (c == 0 && nbt) *nbt += 1;
+  if (c >= C) return;
+  double a = 0, q = 0;
+  for (int s = 0; s < nparts; s++) { a += part[((int64_t)s * C + c) * 2]; q += part[((int64_t)s * C + c) * 2 + 1]; }
+  const double n = (double)P;
+  const double mean = a / n;
+  double var = q / n - mean * mean;
+  if (var < 0) var = 0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float gm = gamma ? gamma[c] : 1.0f, bt = beta ? beta[c] : 0.0f;
+  const float av = gm * invstd;
+  ab[c] = av;
+  ab[C + c] = bt - (float)mean * av;
+  save[c] = (float)mean;
+  save[C + c] = invstd;
+  if (running_mean) running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+  if (running_var) running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)(var * n / (n - 1.0));
+}
+
+__global__ __launch_bounds__(kT) void bnq_finalize_bwd_kernel(const double* __restrict__ part, int nparts, int64_t P, int C,
+                                                              float* __restrict__ ktot, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta) {
+  const int c = blockIdx.x * kT + threadIdx.x;
+  if (c >= C) return;
+  double a = 0, q = 0;
+  for (int s = 0; s < nparts; s++) { a += part[((int64_t)s * C + c) * 2]; q += part[((int64_t)s * C + c) * 2 + 1]; }
+  ktot[c] = (float)(a / (double)P);
+  ktot[C + c] = (float)(q / (double)P);
+  if (dbeta) dbeta[c] = (float)a;
+  if (dgamma) dgamma[c] = (float)q;
+}
+
+// ---- elementwise passes: tiles of kUa x 256 float4 per block; 256 % (C/4) == 0 keeps a thread on one channel quad ----------
+template <int FORMULA>
+__global__ __launch_bounds__(kT) void bnq_apply_fwd_kernel(const float* __restrict__ z, const float* __restrict__ ab, int64_t nvec,
+                                                           int C, int k, float r, int relu, float* __restrict__ y) {
+  __shared__ __attribute__((aligned(16))) float nerf_lds[ALIGNQ_NERF_LDS_FLOATS];
+  nerf_tab_load(nerf_lds);
+  __syncthreads();
+  const NerfTab tab = nerf_tab(nerf_lds);
+  const Levels nlev = make_levels(k, fabsf(r) <= 8.0f);
+  const int cq = threadIdx.x % (C >> 2);
+  const float4 a4 = *reinterpret_cast<const float4*>(ab + 4 * cq);
+  const float4 b4 = *reinterpret_cast<const float4*>(ab + C + 4 * cq);
+  const float4* z4 = reinterpret_cast<const float4*>(z);
+  float4* y4 = reinterpret_cast<float4*>(y);
+  const int64_t stride = (int64_t)gridDim.x * kT * kUa;
+  ALIGNQ_BOUNDED_SWITCH(nlev,
+  for (int64_t i0 = (int64_t)blockIdx.x * (kT * kUa) + threadIdx.x; i0 < nvec; i0 += stride) {
+    float4 v[kUa];
+_Pragma("unroll")
+    for (int u = 0; u < kUa; u++) {
+      const int64_t i = i0 + u * kT;
+      v[u] = z4[i < nvec ? i : i0];
+    }
+_Pragma("unroll")
+    for (int u = 0; u < kUa; u++) {
+      const int64_t i = i0 + u * kT;
+      float4 o;
+      float t, b;
+      o.x = act_quant1<FORMULA, kBounded>(__fmaf_rn(a4.x, v[u].x, b4.x), k, nlev, r, &t, &b, tab);
+      o.y = act_quant1<FORMULA, kBounded>(__fmaf_rn(a4.y, v[u].y, b4.y), k, nlev, r, &t, &b, tab);
+      o.z = act_quant1<FORMULA, kBounded>(__fmaf_rn(a4.z, v[u].z, b4.z), k, nlev, r, &t, &b, tab);
+      o.w = act_quant1<FORMULA, kBounded>(__fmaf_rn(a4.w, v[u].w, b4.w), k, nlev, r, &t, &b, tab);
+      if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      if (i < nvec) y4[i] = o;
+    }
+  })
+}
+
+__global__ __launch_bounds__(kT) void bnq_apply_bwd_kernel(const float* __restrict__ g, const float* __restrict__ z,
+                                                           const float* __restrict__ y, const float* __restrict__ ab,
+                                                           const float* __restrict__ save, const float* __restrict__ ktot,
+                                                           int64_t nvec, int C, float r, int relu, float* __restrict__ dz) {
+  constexpr int U = 2;
+  const int cq = threadIdx.x % (C >> 2);
+  const float4 a4 = *reinterpret_cast<const float4*>(ab + 4 * cq), b4 = *reinterpret_cast<const float4*>(ab + C + 4 * cq);
+  const float4 m4 = *reinterpret_cast<const float4*>(save + 4 * cq), i4 = *reinterpret_cast<const float4*>(save + C + 4 * cq);
+  const float4 k0 = *reinterpret_cast<const float4*>(ktot + 4 * cq), k1 = *reinterpret_cast<const float4*>(ktot + C + 4 * cq);
+  const float ae[4] = {a4.x, a4.y, a4.z, a4.w}, be[4] = {b4.x, b4.y, b4.z, b4.w};
+  const float me[4] = {m4.x, m4.y, m4.z, m4.w}, ie[4] = {i4.x, i4.y, i4.z, i4.w};
+  const float k0e[4] = {k0.x, k0.y, k0.z, k0.w}, k1e[4] = {k1.x, k1.y, k1.z, k1.w};
+  const int64_t stride = (int64_t)gridDim.x * kT * U;
+  for (int64_t i0 = (int64_t)blockIdx.x * (kT * U) + threadIdx.x; i0 < nvec; i0 += stride) {
+    float4 gv[U], zv[U], yv[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t i = i0 + u * kT, ic = i < nvec ? i : i0;
+      gv[u] = ldnt(g + 4 * ic);                      // the upstream gradient is read here for the last time
+      zv[u] = *reinterpret_cast<const float4*>(z + 4 * ic);
+      if (relu) yv[u] = *reinterpret_cast<const float4*>(y + 4 * ic);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t i = i0 + u * kT;
+      const float ge[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w}, ze[4] = {zv[u].x, zv[u].y, zv[u].z, zv[u].w};
+      const float ye[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const float x = __fmaf_rn(ae[e], ze[e], be[e]);
+        const float gm = (relu && !(ye[e] > 0.f)) ? 0.f : ge[e];
+        const float dx = gm * act_jac(x, r);
+        const float zh = (ze[e] - me[e]) * ie[e];
+        o[e] = ae[e] * (dx - k0e[e] - zh * k1e[e]);
+      }
+      if (i < nvec) *reinterpret_cast<float4*>(dz + 4 * i) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
+inline bool bad_c(int C) { return C < 4 || C > 1024 || (C & (C - 1)) != 0; }
+inline int tiles(int64_t nvec, int u) {
+  int64_t b = (nvec + (int64_t)kT * u - 1) / ((int64_t)kT * u);
+  if (b < 1) b = 1;
+  return (int)(b > 256 * 64 ? 256 * 64 : b);
+}
+inline int parts_for(int64_t P, int C) {
+  // every block should own at least a few pixel rounds: slots * kUs pixels per round
+  const int slots = kT / (C >> 2);
+  int64_t n = P / ((int64_t)slots * kUs);
+  if (n < 1) n = 1;
+  return (int)(n > kParts ? kParts : n);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t alignq_bnq_ws_bytes(int C) {
+  if (C <= 0) return 0;
+  return (size_t)kParts * C * 2 * sizeof(double) + (size_t)2 * C * sizeof(float);
+}
+
+int alignq_bnq_fwd(const float* z, int64_t P, int C, const float* gamma, const float* beta, float* running_mean,
+                   float* running_var, int64_t* num_batches_tracked, float momentum, float bn_eps, int k, float act_range,
+                   int formula, int relu, float* ab, float* save, float* y, void* ws, void* stream) {
+  if (!z || !ab || !save || !y || !ws || P < 2) return ALIGNQ_EINVAL;
+  if (!((k >= 1 && k <= 16) || k == 32)) return ALIGNQ_EINVAL;
+  if (formula != ALIGNQ_FORMULA_ADMM && formula != ALIGNQ_FORMULA_CDF) return ALIGNQ_EINVAL;
+  if (bad_c(C)) return ALIGNQ_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(y)) & 15) return ALIGNQ_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  double* part = reinterpret_cast<double*>(ws);
+  const int np = parts_for(P, C);
+  hipLaunchKernelGGL(bnq_sums_kernel<false>, dim3(np), dim3(kT), 0, st, z, nullptr, nullptr, nullptr, nullptr, P, C, act_range,
+                     0, part);
+  hipLaunchKernelGGL(bnq_finalize_kernel, dim3((C + kT - 1) / kT), dim3(kT), 0, st, (const double*)part, np, P, C, gamma, beta,
+                     running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), momentum, bn_eps, ab, save);
+  const int64_t nvec = P * (C >> 2);
+  if (formula == ALIGNQ_FORMULA_ADMM)
+    hipLaunchKernelGGL(bnq_apply_fwd_kernel<0>, dim3(tiles(nvec, kUa)), dim3(kT), 0, st, z, (const float*)ab, nvec, C, k,
+                       act_range, relu, y);
+  else
+    hipLaunchKernelGGL(bnq_apply_fwd_kernel<1>, dim3(tiles(nvec, kUa)), dim3(kT), 0, st, z, (const float*)ab, nvec, C, k,
+                       act_range, relu, y);
+  return hipGetLastError() == hipSuccess ? 0 : ALIGNQ_EINVAL;
+}
+
+int alignq_bnq_bwd(const float* g, const float* z, const float* y, const float* ab, const float* save, int64_t P, int C,
+                   float act_range, int relu, float* dz, float* dgamma, float* dbeta, void* ws, void* stream) {
+  if (!g || !z || !ab || !save || !dz || !ws || P < 2 || (relu && !y)) return ALIGNQ_EINVAL;
+  if (bad_c(C)) return ALIGNQ_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(dz) |
+       reinterpret_cast<uintptr_t>(y)) & 15)
+    return ALIGNQ_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  double* part = reinterpret_cast<double*>(ws);
+  float* ktot = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + (size_t)kParts * C * 2 * sizeof(double));
+  const int np = parts_for(P, C);
+  hipLaunchKernelGGL(bnq_sums_kernel<true>, dim3(np), dim3(kT), 0, st, z, g, y, ab, save, P, C, act_range, relu, part);
+  hipLaunchKernelGGL(bnq_finalize_bwd_kernel, dim3((C + kT - 1) / kT), dim3(kT), 0, st, (const double*)part, np, P, C, ktot,
+                     dgamma, dbeta);
+  const int64_t nvec = P * (C >> 2);
+  hipLaunchKernelGGL(bnq_apply_bwd_kernel, dim3(tiles(nvec, 2)), dim3(kT), 0, st, g, z, y, ab, save, (const float*)ktot, nvec,
+                     C, act_range, relu, dz);
+  return hipGetLastError() == hipSuccess ? 0 : ALIGNQ_EINVAL;
+}
+
+}  // extern "C"

@@ -550,6 +550,66 @@ def bn_site(bn, act, z, eps=0.0, relu=False, residual=None, pack=False):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# N1 on the Office path (configuration 5): training-mode batch-norm folded into the PLAIN quantiser + ReLU of the bottleneck
+# (`out = relu(act_q1(bn1(conv1(x))))`, dann_office/model/resnet.py:134-143; stem :230-233).  MIOpen produces z; the fold is
+# statistics (one read of z) + one elementwise pass (a*z+b -> quantise -> relu) forward and two passes backward: the
+# normalised activation never exists in memory.  Any batch; channels-last; C a power of two in [4, 1024].
+class BNQuantReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, weight, bias, running_mean, running_var, nbt, momentum, bn_eps, k, act_range, formula, relu):
+        z = L.dense_f32(z, "conv output")
+        B, C, H, W = z.shape
+        lib = L.load()
+        dev = z.device
+        P = B * H * W
+        ab = torch.empty(2, C, dtype=torch.float32, device=dev)
+        save = torch.empty(2, C, dtype=torch.float32, device=dev)
+        y = torch.empty_like(z)
+        ws = torch.empty(lib.alignq_bnq_ws_bytes(C), dtype=torch.uint8, device=dev)
+        L.check(lib.alignq_bnq_fwd(L.ptr(z), P, C, L.ptr(weight), L.ptr(bias), L.ptr(running_mean), L.ptr(running_var),
+                                   L.ptr(nbt), float(momentum), float(bn_eps), int(k), float(act_range), int(formula),
+                                   int(bool(relu)), L.ptr(ab), L.ptr(save), L.ptr(y), L.ptr(ws), L.stream_ptr()),
+                "alignq_bnq_fwd")
+        ctx.save_for_backward(z, y if relu else None, ab, save)
+        ctx.cfg = (float(act_range), bool(relu), weight is not None, bias is not None)
+        ctx.mark_non_differentiable(*[t for t in (running_mean, running_var, nbt) if t is not None])
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        z, y, ab, save = ctx.saved_tensors
+        act_range, relu, has_w, has_b = ctx.cfg
+        B, C, H, W = z.shape
+        g = L.like_layout(g, z)
+        lib = L.load()
+        dz = torch.empty_like(z)
+        dgamma = torch.empty(C, dtype=torch.float32, device=z.device) if has_w else None
+        dbeta = torch.empty(C, dtype=torch.float32, device=z.device) if has_b else None
+        ws = torch.empty(lib.alignq_bnq_ws_bytes(C), dtype=torch.uint8, device=z.device)
+        L.check(lib.alignq_bnq_bwd(L.ptr(g), L.ptr(z), L.ptr(y), L.ptr(ab), L.ptr(save), B * H * W, C, act_range, int(relu),
+                                   L.ptr(dz), L.ptr(dgamma), L.ptr(dbeta), L.ptr(ws), L.stream_ptr()), "alignq_bnq_bwd")
+        return dz, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+
+
+def bnq_fusable(bn, act, z) -> bool:
+    C = z.shape[1] if z.dim() == 4 else 0
+    return (bn.training and z.is_cuda and z.dtype == torch.float32 and z.dim() == 4 and _is_nhwc(z) and act.a_bit < 32
+            and 4 <= C <= 1024 and (C & (C - 1)) == 0 and bn.track_running_stats and bn.momentum is not None
+            and z.shape[0] * z.shape[2] * z.shape[3] >= 2)
+
+
+def bn_act_relu(bn, act, z, formula, relu=True):
+    """[relu](act(bn(z))) for a quantiser WITHOUT an ADMM term: one fused chain when `bnq_fusable` (training mode,
+    channels-last fp32 CUDA tensor, C = 4 * 2^j <= 1024), else exactly that composition."""
+    from . import config
+    if not bnq_fusable(bn, act, z):
+        out = act(bn(z))
+        return torch.nn.functional.relu(out) if relu else out
+    return BNQuantReluFn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum,
+                               bn.eps, act.a_bit, config.args.act_range, formula, relu)
+
+
+# ------------------------------------------------------------------------------------------------------------------
 _head_counters = {}
 
 

@@ -179,6 +179,12 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
             """relu(self(x)) in one launch each way (not part of the reference's interface: an opt-in for the caller)."""
             return _plain_act_relu(x, self.a_bit, self.stage)
 
+        def forward_bn_relu(self, bn, z):
+            """relu(self(bn(z))) with the training-mode batch-norm folded into the quantiser (SURVEY.md §8f-N1 on the Office
+            path; not part of the reference's interface: an opt-in for the caller, alignq_amd.fused.bn_act_relu)."""
+            from . import fused
+            return fused.bn_act_relu(bn, self, z, formula, relu=True)
+
         def forward_packed(self, x, relu=False):
             """([relu](self(x)), bins): the quantised activation both as fp32 and as its narrow integer level index
             (ops.dequant_bins(bins, ...) reproduces the fp32 tensor bit for bit)."""

@@ -47,7 +47,10 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         trans_loss = 0.
         identity = x
-        if getattr(self, "fuse_relu", False):       # opt-in (OfficeTrainStep): quantiser + ReLU in one launch each way
+        if getattr(self, "fuse_bn", False):         # opt-in (OfficeTrainStep): batch-norm + quantiser + ReLU as one chain
+            out = self.act_q1.forward_bn_relu(self.bn1, self.conv1(x))
+            out = self.act_q2.forward_bn_relu(self.bn2, self.conv2(out))
+        elif getattr(self, "fuse_relu", False):     # opt-in: quantiser + ReLU in one launch each way
             out = self.act_q1.forward_relu(self.bn1(self.conv1(x)))
             out = self.act_q2.forward_relu(self.bn2(self.conv2(out)))
         else:
@@ -105,7 +108,9 @@ class ResNet(nn.Module):
 
     def forward(self, x):
         trans_loss = 0.
-        if getattr(self, "fuse_relu", False):
+        if getattr(self, "fuse_bn", False):
+            x = self.maxpool(self.act_q0.forward_bn_relu(self.bn1, self.conv1(x)))
+        elif getattr(self, "fuse_relu", False):
             x = self.maxpool(self.act_q0.forward_relu(self.bn1(self.conv1(x))))
         else:
             x = self.maxpool(self.relu(self.act_q0(self.bn1(self.conv1(x)))))

@@ -282,19 +282,22 @@ class OfficeTrainStep:
     SGD-stepped first and then overwritten by the closed form, exactly like the reference."""
 
     def __init__(self, model, lr=0.04, momentum=0.9, weight_decay=5e-4, alpha=0.5, channels_last=False, fuse_relu=True,
-                 grad_hook=None):
+                 grad_hook=None, fuse_bn=True):
         """grad_hook: the data-parallel all-reduce (alignq_amd.dp.attach_office -> BucketedGradAllReduce): begin() right
         before backward, its buckets' collectives start from autograd hooks while the backward runs, finish() before the
         optimizer steps.
         channels_last: activations and conv weights in torch.channels_last memory (values / names unchanged): MIOpen's NHWC
         kernels run the ResNet-50 step in 30.9 instead of 34.7 ms on MI355X; the quantise / Gram kernels are layout-agnostic.
-        fuse_relu: `relu(act_q(.))` of the stem and of each bottleneck's first two sites as one launch each way."""
+        fuse_relu: `relu(act_q(.))` of the stem and of each bottleneck's first two sites as one launch each way.
+        fuse_bn (channels_last only): additionally the training-mode batch-norm in front of those quantisers is folded into
+        them (fused.bn_act_relu: statistics + one elementwise pass; SURVEY.md 8f-N1 on configuration 5)."""
         if channels_last:
             model = model.to(memory_format=torch.channels_last)
         self.channels_last = channels_last
         for mod in model.modules():
             if hasattr(mod, "act_q0") or (hasattr(mod, "act_q1") and hasattr(mod, "act_q2") and hasattr(mod, "act_q3")):
                 mod.fuse_relu = bool(fuse_relu)
+                mod.fuse_bn = bool(fuse_bn and fuse_relu and channels_last)
         self.model, self.alpha = model, alpha
         named = list(model.named_parameters())
         self.param_admm = [(n, p) for n, p in named if "alterD" in n or "gamma" in n]

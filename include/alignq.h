@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALIGNQ_ABI_VERSION 6
+#define ALIGNQ_ABI_VERSION 7
 
 #define ALIGNQ_FORMULA_ADMM 0
 #define ALIGNQ_FORMULA_CDF 1
@@ -396,6 +396,25 @@ int alignq_bn_bwd_apply(const float* dx, const float* z, const float* ab, const 
  * alignq_conv3x3_bn_parts(B,H,W,C)): the batch-norm then needs no statistics pass of its own over z.                      */
 size_t alignq_bn_nhwc_ws_bytes(int C);
 int alignq_bn_partial_stats_nhwc(const float* z, int B, int C, int HW, void* ws, void* stream);
+
+/* ---- batch-norm folded into the PLAIN quantiser (+ ReLU), channels-last, any batch (SURVEY.md §8f-N1 on configuration 5;
+ * caller: out = relu(act_q1(bn1(conv1(x)))) of the Office bottleneck, cdf_alignment_admm/dann_office/model/resnet.py:134-143,
+ * stem :230-233; quantiser model/quantization.py:87-110) ----
+ * z: the convolution's output viewed as [P, C], P = B*H*W pixels, channels fastest (torch.channels_last); C = 4 * 2^j <= 1024
+ * (ALIGNQ_EUNSUPPORTED otherwise).  Training-mode nn.BatchNorm2d semantics (biased batch variance for the normalisation,
+ * running statistics updated with momentum and the unbiased variance, *num_batches_tracked += 1; any of the three NULL).
+ * alignq_bnq_fwd (3 launches): per-channel statistics of z -> ab = {a[C], b[C]} (a = gamma*invstd, b = beta - mean*a),
+ *   save = {mean[C], invstd[C]} -> y = [relu](quantise(a*z + b)) with alignq_act_quant_fwd's arithmetic; the normalised
+ *   activation is never written (12 B/element instead of 20).
+ * alignq_bnq_bwd (3 launches): dx = g * [y > 0] * dt/dx (y = the forward's output, required when relu), then the batch-norm
+ *   backward dz = a*(dx - mean dx - zhat*mean(dx*zhat)), dgamma = sum dx*zhat, dbeta = sum dx (28 B/element instead of ~36).
+ * ws: alignq_bnq_ws_bytes(C).                                                                                               */
+size_t alignq_bnq_ws_bytes(int C);
+int alignq_bnq_fwd(const float* z, int64_t P, int C, const float* gamma, const float* beta, float* running_mean,
+                   float* running_var, int64_t* num_batches_tracked, float momentum, float bn_eps, int k, float act_range,
+                   int formula, int relu, float* ab, float* save, float* y, void* ws, void* stream);
+int alignq_bnq_bwd(const float* g, const float* z, const float* y, const float* ab, const float* save, int64_t P, int C,
+                   float act_range, int relu, float* dz, float* dgamma, float* dbeta, void* ws, void* stream);
 
 #ifdef __cplusplus
 }

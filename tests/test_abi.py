@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.alignq_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.alignq_abi_version() == _lib.ABI_VERSION == 7
     assert b"invalid" in lib.alignq_strerror(-1)
     # pure host-side queries are safe without a GPU
     tail = 1024 + 16                                     # loss partials + arrival counter
@@ -33,7 +33,11 @@ def test_library_exports_every_declared_symbol():
     assert lib.alignq_site_ws_bytes(128, 4096) == (256 * 8256 + tail) * 4    # 16-feature tiles keep 256 CUs busy
     assert lib.alignq_site_ws_bytes(28, 802816) == (2048 * 32 * 32 + tail) * 4
     assert lib.alignq_site_ws_bytes(28, 1024) == (8 * 32 * 32 + tail) * 4            # 32 sub-tiles of 32 features / 4 waves
-    assert lib.alignq_site_ws_bytes(129, 64) == 0
+    # above 128 rows only corr(x, x) exists (blocked Gram: 3 block pairs x 1 K split of 128 x 128 floats); 1024 rows is the end
+    assert lib.alignq_site_ws_bytes(129, 64) == 3 * 128 * 128 * 4
+    assert lib.alignq_site_ws_bytes(1025, 64) == 0
+    assert lib.alignq_site_bwd_ws_bytes(256) == 256 * 256 * 4 and lib.alignq_site_bwd_ws_bytes(128) == 2 * 128 * 128 * 4
+    assert lib.alignq_bnq_ws_bytes(64) == 512 * 64 * 16 + 2 * 64 * 4
     assert lib.alignq_site_bwd_ws_bytes(128) == 2 * 128 * 128 * 4        # fp32 S + its bf16 hi/lo fragment image
 
 

@@ -152,3 +152,71 @@ def test_nerf32_device_equals_oracle_on_edge_inputs(dev):
             assert bits_equal(got, want), (formula, k)
     nan_out = npy(ops.ActQuantFn.apply(cu(np.array([np.nan, 1.0, -np.nan, 0.5], np.float32), dev), 8, 2.0, L.FORMULA_ADMM))
     assert np.isnan(nan_out[0]) and np.isnan(nan_out[2]) and np.isfinite(nan_out[1]) and np.isfinite(nan_out[3])
+
+
+# ------------------------------------------------------------------------------------------------ VERDICT r2 item 4 (N1, Office)
+@pytest.mark.parametrize("B,C,H,k", [(28, 64, 56, 8), (6, 512, 7, 4), (28, 256, 14, 8), (3, 4, 5, 2), (28, 64, 112, 8)])
+def test_bn_folded_plain_quantiser_vs_oracle_and_torch_batchnorm(dev, B, C, H, k):
+    """relu(act_q(bn(z))) of the Office bottleneck's first two sites and of the stem (dann_office/model/resnet.py:134-143,
+    :230-233) as the folded chain (fused.bn_act_relu -> alignq_bnq_fwd / _bwd), channels-last, batch 28 shapes included:
+    (a, b) within 3e-6 of the double-precision statistics (C oracle, pinned to torch.nn.BatchNorm2d), y BIT-EXACT given (a, b),
+    running statistics like torch's, and dz / dgamma / dbeta within 1e-5 of torch-CPU autograd through BatchNorm2d + the
+    transform's derivative + the ReLU mask (float64)."""
+    import alignq_amd.office as NO
+    from alignq_amd import config, fused
+    rng = np.random.default_rng(B * C + H)
+    r, bn_eps = 2.0, 1e-5
+    old = config.args.abitW
+    config.args.abitW = k
+    try:
+        z0 = (rng.standard_normal((B, C, H, H)) * 1.7 + 0.4).astype(np.float32)
+        gam = (rng.random(C) + 0.5).astype(np.float32)
+        bet = (rng.standard_normal(C) * 0.2).astype(np.float32)
+        g0 = rng.standard_normal((B, C, H, H)).astype(np.float32)
+        bn = torch.nn.BatchNorm2d(C).to(dev).train()
+        with torch.no_grad():
+            bn.weight.copy_(cu(gam, dev)); bn.bias.copy_(cu(bet, dev))
+        act = NO.activation_quantize_fn(k, "aligned").to(dev)
+        z = cu(z0, dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        assert fused.bnq_fusable(bn, act, z)
+        y = act.forward_bn_relu(bn, z)
+        y.backward(cu(g0, dev).contiguous(memory_format=torch.channels_last))
+        # ---- forward: statistics, then bit-exact given the device's (a, b)
+        z_mem = np.ascontiguousarray(z0.transpose(0, 2, 3, 1)).reshape(B, -1)          # [B, H*W*C]: channels-last memory order
+        ab_o, save_o, var_u = O.bn_fold_ab(z_mem, C, 1, gam, bet, bn_eps)
+        # the device's (a, b) are not returned by the module: recover them through the oracle's tolerance on y instead —
+        # y must equal relu(quantise(a z + b)) for the oracle's (a, b) except where a 3e-6 difference in (a, b) moves a bin
+        x_o = O.bn_apply(z_mem, C, 1, ab_o)
+        q_o, t_o, _ = O.act_quant_fwd(x_o, k, r, O.FORMULA_ADMM)
+        y_o = np.maximum(q_o, 0.0).reshape(B, H, H, C).transpose(0, 3, 1, 2)
+        n = 2 ** k - 1
+        frac = t_o.astype(np.float64) * n
+        near_tie = (np.abs(frac - np.floor(frac) - 0.5) < 2e-3).reshape(B, H, H, C).transpose(0, 3, 1, 2)
+        diff = np.abs(npy(y) - y_o) * n
+        assert np.all(diff[~near_tie] == 0), int(np.count_nonzero(diff[~near_tie]))
+        assert np.all(diff[near_tie] <= 1.0 + 1e-3)
+        # running statistics: torch's own BatchNorm2d on the same input
+        ref_bn = torch.nn.BatchNorm2d(C).train()
+        with torch.no_grad():
+            ref_bn.weight.copy_(torch.from_numpy(gam)); ref_bn.bias.copy_(torch.from_numpy(bet))
+        zc = torch.from_numpy(z0).double().requires_grad_(True)
+        ref_bn = ref_bn.double()
+        xb = ref_bn(zc)
+        np.testing.assert_allclose(npy(bn.running_mean), ref_bn.running_mean.float().numpy(), atol=1e-6, rtol=1e-5)
+        np.testing.assert_allclose(npy(bn.running_var), ref_bn.running_var.float().numpy(), atol=1e-6, rtol=1e-5)
+        assert int(bn.num_batches_tracked) == 1
+        # ---- backward: d/dx of r*(2 Phi(x) - 1) is r*2*phi(x) (STE through the rounding), masked by the forward's y > 0
+        t = r * torch.erf(xb / np.sqrt(2.0))
+        mask = torch.from_numpy((npy(y) > 0).astype(np.float64))
+        (t * mask * torch.from_numpy(g0).double()).sum().backward()
+        np.testing.assert_allclose(npy(z.grad), zc.grad.float().numpy(), atol=TOL, rtol=1e-4)
+        np.testing.assert_allclose(npy(bn.weight.grad), ref_bn.weight.grad.float().numpy(), atol=2e-5 * np.sqrt(B * H * H), rtol=1e-4)
+        np.testing.assert_allclose(npy(bn.bias.grad), ref_bn.bias.grad.float().numpy(), atol=2e-5 * np.sqrt(B * H * H), rtol=1e-4)
+        # ---- and the unfused composition gives the same tensor (same kernels' arithmetic, BN by MIOpen): values only
+        bn2 = torch.nn.BatchNorm2d(C).to(dev).train()
+        with torch.no_grad():
+            bn2.weight.copy_(cu(gam, dev)); bn2.bias.copy_(cu(bet, dev))
+        y2 = torch.relu(act(bn2(z.detach())))
+        assert float((y2 - y.detach()).abs().max()) <= 1.0 / n + 1e-6
+    finally:
+        config.args.abitW = old
