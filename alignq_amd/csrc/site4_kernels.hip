@@ -156,33 +156,39 @@ __device__ __forceinline__ void split_bf16(float v, __bf16& hi, __bf16& lo) {
 
 // SINGLE: one tile per workgroup (n_tiles <= grid, every CIFAR-size site): no tile loop, so nothing is hoisted out of it and
 // kept alive across the phases (88 instead of 128 VGPRs), which buys the early requests of the batch-norm finalisation.
-template <int TFv, bool PAIR, bool SINGLE>
-__global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__ x, int B, int64_t F, int k, float r,
+// NTv: 1024 threads (16 waves: one workgroup per CU, the latency-tuned CIFAR form) or 512 (8 waves, 32-feature tiles, 45 KB of
+// LDS: TWO workgroups per CU whose phases interleave - the multi-tile form for large F, where a tile's load -> transform ->
+// statistics -> stage -> MFMA chain with its six barriers is otherwise exposed in full; plain sites only, no batch-norm fold).
+template <int TFv, bool PAIR, bool SINGLE, int NTv = NT>
+__global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restrict__ x, int B, int64_t F, int k, float r,
                                                        float eps, float* __restrict__ xq, float* __restrict__ slabs,
                                                        float* __restrict__ stats, int n_tiles, int aligned,
                                                        unsigned* __restrict__ counter, BnFold bn) {
   BSTAMP(0, 0);
   constexpr int LDB = TFv + 8;                    // bf16 elements per LDS row (row bytes multiple of 16, see bank note)
   constexpr int LPR = TFv / 4;                    // lanes per row (float4 each)
-  constexpr int RG = NT / LPR;                    // row groups: 64 / 128 / 256
+  constexpr int NW = NTv / 64;                    // waves
+  constexpr bool kBnCode = NTv == NT;             // the batch-norm fold's wave assignment is written for 16 waves
+  constexpr int RG = NTv / LPR;                   // row groups: 64 / 128 / 256
   constexpr int RJ = (128 + RG - 1) / RG;         // rows per thread: 2 / 1 / 1
   constexpr int NOP = PAIR ? 2 : 1;
   constexpr int ARR = 128 * LDB;                  // bf16 elements per array
   constexpr int STAGE_BYTES = (4 * ARR * 2 > 40960) ? 4 * ARR * 2 : 40960;
-  constexpr int KSPLIT = (TFv >= 32) ? 2 : 1;     // K-halves per tile (a half must hold >= 16 features)
+  constexpr int KSPLIT = (TFv >= 32 && NTv == NT) ? 2 : 1;   // K-halves per tile (a half must hold >= 16 features); the
+                                                             // 8-wave form keeps 10 whole-K items (2 accumulators per wave)
   constexpr int KSTEPS = TFv / 16 / KSPLIT;       // 16-feature MFMA steps per item
-  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STAGE_BYTES + (4 * TFv + 2 * 16 * TFv) * 4];
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STAGE_BYTES + (4 * TFv + 2 * NW * TFv) * 4];
   __shared__ __attribute__((aligned(16))) float nerf_lds[PAIR ? ALIGNQ_NERF_LDS_FLOATS : 4];
   // the transform's table (alignq_math.h): requested first, stored behind the tile loads of the first iteration
-  NerfRegs<NT> nerf_regs;
-  if (PAIR) nerf_regs = nerf_tab_fetch<NT>();
+  NerfRegs<NTv> nerf_regs;
+  if (PAIR) nerf_regs = nerf_tab_fetch<NTv>();
   const NerfTab tab = nerf_tab(nerf_lds);
   __bf16* Xhi = reinterpret_cast<__bf16*>(lds_raw);
   __bf16* Xlo = Xhi + ARR;
   __bf16* Thi = Xhi + 2 * ARR;
   __bf16* Tlo = Xhi + 3 * ARR;
   float* colv = reinterpret_cast<float*>(lds_raw + STAGE_BYTES);   // mean_x, rho_x, mean_t, rho_t : [4][TFv]
-  float* red = colv + 4 * TFv;                                     // [2 operands][16 waves][TFv]
+  float* red = colv + 4 * TFv;                                     // [2 operands][NW waves][TFv]
 
   const int tid = threadIdx.x, lane = tid & 63;
   // the wave index is wave-uniform: readfirstlane puts it (and the work-item bookkeeping derived from it: tile, K-half,
@@ -195,18 +201,23 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
 
   if (blockIdx.x == 0 && tid == 0 && counter) *counter = 0u;   // arrival counter of the reduce kernel's epilogue
 
-  // work items: KSPLIT==2: q = w (all waves) and q = 16 + w (waves 0..3), item q = (tile q%10, K-half q/10);
-  //             KSPLIT==1: waves 0..9 own tile w with the whole K.
-  const int tile0 = w % 10, kh0 = (KSPLIT == 2) ? w / 10 : 0;
-  const bool item0 = (KSPLIT == 2) || (w < 10);
-  const bool item1 = (KSPLIT == 2) && (w < 4);
-  const int tile1 = 6 + w;                        // K-half 1
-  int I0, J0, I1 = 0, J1 = 0;
-  tile_ij(tile0, I0, J0);
-  if (item1) tile_ij(tile1, I1, J1);
-  f32x16 acc0, acc1;    // PAIR: T-Gram minus X-Gram (the x A-operand enters negated); else the X-Gram
+  // work items: 10 upper-triangular output tiles x KSPLIT K-halves, item q = (tile q % 10, K-half q / 10); wave w takes
+  // q = w, w + NW, ...: 16 waves: 20 items -> q = w and (waves 0..3) 16 + w; 10 items -> waves 0..9;  8 waves: 3 / 3 / 2.
+  constexpr int NITEMS = 10 * KSPLIT;
+  constexpr int NI = (NITEMS + NW - 1) / NW;
+  int it_tile[NI], it_kh[NI], it_I[NI], it_J[NI];
+  bool it_on[NI];
+  f32x16 acc[NI];       // PAIR: T-Gram minus X-Gram (the x A-operand enters negated); else the X-Gram
 #pragma unroll
-  for (int e = 0; e < 16; e++) { acc0[e] = 0.0f; acc1[e] = 0.0f; }
+  for (int i = 0; i < NI; i++) {
+    const int q = w + NW * i;
+    it_on[i] = q < NITEMS;
+    it_tile[i] = it_on[i] ? q % 10 : 0;
+    it_kh[i] = it_on[i] ? q / 10 : 0;
+    tile_ij(it_tile[i], it_I[i], it_J[i]);
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[i][e] = 0.0f;
+  }
 
   STAMP(0);
   float4 xv[RJ];      // this tile's rows; in the multi-tile form refilled with the NEXT tile's rows once they are staged
@@ -222,7 +233,7 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
     // channel, or 256 of two).  The multi-tile variant runs at its 128-register cap and keeps the plain order.
     constexpr bool kPairCh = TFv < 64;
     constexpr int PU = kPairCh ? 2 : 4;
-    const bool fin = bn.ab && bn.nhwc && bn.part;
+    const bool fin = kBnCode && bn.ab && bn.nhwc && bn.part;
     const bool fin4 = SINGLE && fin && bn.part_f32 && !(bn.n_parts & 1);
     const int nch = bn.C < TFv ? bn.C : TFv;
     const int chbase = col0 & (bn.C - 1);
@@ -264,11 +275,11 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
       }
     }
     if (PAIR && tile == (int)blockIdx.x) {     // first iteration (block-uniform): publish the transform's table
-      nerf_tab_store<NT>(nerf_lds, nerf_regs);
+      nerf_tab_store<NTv>(nerf_lds, nerf_regs);
       __syncthreads();
     }
     // ---- folded batch-norm: x = a*z + b with (a, b) of this tile's channel (HW % 64 == 0: one channel per tile) -------
-    if (bn.ab && bn.nhwc) {
+    if (kBnCode && bn.ab && bn.nhwc) {
       // channels-last: the float4 at column `col` covers channels (col mod C) .. +3 (C % 4 == 0); a, b are inputs
       const int ch = col & (bn.C - 1);
       float4 a4, b4;
@@ -409,7 +420,7 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
           xv[j].z = __fmaf_rn(a4.z, xv[j].z, b4.z); xv[j].w = __fmaf_rn(a4.w, xv[j].w, b4.w);
         }
       }
-    } else if (bn.ab) {
+    } else if (kBnCode && bn.ab) {
       const int ch = col0 / bn.HW;
       float bn_a, bn_b;
       if (bn.part) {
@@ -525,19 +536,19 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
       rowgroup_sums<LPR, PAIR>(sx, st, t0, t1);
       if (rwrite) {
         red[w * TFv + 4 * c + rsel] = t0;
-        if (PAIR) red[16 * TFv + w * TFv + 4 * c + rsel] = t1;
+        if (PAIR) red[NW * TFv + w * TFv + 4 * c + rsel] = t1;
       }
     }
     __syncthreads();
     if (tid < NOP * TFv) {
       const int op = tid / TFv, cc = tid % TFv;
-      float pw[16];
+      float pw[NW];
 #pragma unroll
-      for (int g = 0; g < 16; g++) pw[g] = red[op * 16 * TFv + g * TFv + cc];      // 16 reads in flight, then a fixed tree
+      for (int g = 0; g < NW; g++) pw[g] = red[op * NW * TFv + g * TFv + cc];      // NW reads in flight, then a fixed tree
 #pragma unroll
-      for (int o = 1; o < 16; o <<= 1) {
+      for (int o = 1; o < NW; o <<= 1) {
 #pragma unroll
-        for (int g = 0; g < 16; g += 2 * o) pw[g] += pw[g + o];
+        for (int g = 0; g < NW; g += 2 * o) pw[g] += pw[g + o];
       }
       colv[(2 * op) * TFv + cc] = pw[0] * invB;
     }
@@ -564,19 +575,19 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
       rowgroup_sums<LPR, PAIR>(sx, st, t0, t1);
       if (rwrite) {
         red[w * TFv + 4 * c + rsel] = t0;
-        if (PAIR) red[16 * TFv + w * TFv + 4 * c + rsel] = t1;
+        if (PAIR) red[NW * TFv + w * TFv + 4 * c + rsel] = t1;
       }
     }
     __syncthreads();
     if (tid < NOP * TFv) {
       const int op = tid / TFv, cc = tid % TFv;
-      float pw[16];
+      float pw[NW];
 #pragma unroll
-      for (int g = 0; g < 16; g++) pw[g] = red[op * 16 * TFv + g * TFv + cc];
+      for (int g = 0; g < NW; g++) pw[g] = red[op * NW * TFv + g * TFv + cc];
 #pragma unroll
-      for (int o = 1; o < 16; o <<= 1) {
+      for (int o = 1; o < NW; o <<= 1) {
 #pragma unroll
-        for (int g = 0; g < 16; g += 2 * o) pw[g] += pw[g + o];
+        for (int g = 0; g < NW; g += 2 * o) pw[g] += pw[g + o];
       }
       const float sd = sqrtf(pw[0] * invBm1);
       const float rho = 1.0f / (sd + eps);
@@ -645,54 +656,35 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
     // ---- MFMA: upper-triangular tiles of Th Th^T and Xh Xh^T (3 bf16 MFMAs each per 16 features) ------------
     if constexpr (SINGLE) {      // one tile per workgroup: the accumulators start their life here, not in front of the erf work
 #pragma unroll
-      for (int e = 0; e < 16; e++) { acc0[e] = 0.0f; acc1[e] = 0.0f; }
+      for (int i = 0; i < NI; i++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[i][e] = 0.0f;
     }
     // A operand: lane -> row I*32 + l31, 8 consecutive features k0 + 8h..; B operand: row J*32 + l31, same features
-    if (item0) {
-      const int ra = (I0 * 32 + l31) * LDB + 8 * h, rb = (J0 * 32 + l31) * LDB + 8 * h;
 #pragma unroll
-      for (int s = 0; s < KSTEPS; s++) {
-        const int k0 = (kh0 * KSTEPS + s) * 16;
-        bf16x8 axh = *reinterpret_cast<const bf16x8*>(Xhi + ra + k0);
-        bf16x8 axl = *reinterpret_cast<const bf16x8*>(Xlo + ra + k0);
-        const bf16x8 bxh = *reinterpret_cast<const bf16x8*>(Xhi + rb + k0);
-        const bf16x8 bxl = *reinterpret_cast<const bf16x8*>(Xlo + rb + k0);
-        if (PAIR) { axh = neg8(axh); axl = neg8(axl); }
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(axh, bxh, acc0, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(axh, bxl, acc0, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(axl, bxh, acc0, 0, 0, 0);
-        if (PAIR) {
-          const bf16x8 ath = *reinterpret_cast<const bf16x8*>(Thi + ra + k0);
-          const bf16x8 atl = *reinterpret_cast<const bf16x8*>(Tlo + ra + k0);
-          const bf16x8 bth = *reinterpret_cast<const bf16x8*>(Thi + rb + k0);
-          const bf16x8 btl = *reinterpret_cast<const bf16x8*>(Tlo + rb + k0);
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ath, bth, acc0, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ath, btl, acc0, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(atl, bth, acc0, 0, 0, 0);
-        }
-      }
-    }
-    if (item1) {
-      const int ra = (I1 * 32 + l31) * LDB + 8 * h, rb = (J1 * 32 + l31) * LDB + 8 * h;
-#pragma unroll
-      for (int s = 0; s < KSTEPS; s++) {
-        const int k0 = (KSTEPS + s) * 16;
-        bf16x8 axh = *reinterpret_cast<const bf16x8*>(Xhi + ra + k0);
-        bf16x8 axl = *reinterpret_cast<const bf16x8*>(Xlo + ra + k0);
-        const bf16x8 bxh = *reinterpret_cast<const bf16x8*>(Xhi + rb + k0);
-        const bf16x8 bxl = *reinterpret_cast<const bf16x8*>(Xlo + rb + k0);
-        if (PAIR) { axh = neg8(axh); axl = neg8(axl); }
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(axh, bxh, acc1, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(axh, bxl, acc1, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(axl, bxh, acc1, 0, 0, 0);
-        if (PAIR) {
-          const bf16x8 ath = *reinterpret_cast<const bf16x8*>(Thi + ra + k0);
-          const bf16x8 atl = *reinterpret_cast<const bf16x8*>(Tlo + ra + k0);
-          const bf16x8 bth = *reinterpret_cast<const bf16x8*>(Thi + rb + k0);
-          const bf16x8 btl = *reinterpret_cast<const bf16x8*>(Tlo + rb + k0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ath, bth, acc1, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ath, btl, acc1, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(atl, bth, acc1, 0, 0, 0);
+    for (int i = 0; i < NI; i++) {
+      if (it_on[i]) {
+        const int ra = (it_I[i] * 32 + l31) * LDB + 8 * h, rb = (it_J[i] * 32 + l31) * LDB + 8 * h;
+#pragma unroll(NTv == NT ? KSTEPS : 1)       // (the 8-wave form runs at its 128-register cap: no fragment loads hoisted across K steps)
+        for (int s = 0; s < KSTEPS; s++) {
+          const int k0 = (it_kh[i] * KSTEPS + s) * 16;
+          bf16x8 axh = *reinterpret_cast<const bf16x8*>(Xhi + ra + k0);
+          bf16x8 axl = *reinterpret_cast<const bf16x8*>(Xlo + ra + k0);
+          const bf16x8 bxh = *reinterpret_cast<const bf16x8*>(Xhi + rb + k0);
+          const bf16x8 bxl = *reinterpret_cast<const bf16x8*>(Xlo + rb + k0);
+          if (PAIR) { axh = neg8(axh); axl = neg8(axl); }
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(axh, bxh, acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(axh, bxl, acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(axl, bxh, acc[i], 0, 0, 0);
+          if (PAIR) {
+            const bf16x8 ath = *reinterpret_cast<const bf16x8*>(Thi + ra + k0);
+            const bf16x8 atl = *reinterpret_cast<const bf16x8*>(Tlo + ra + k0);
+            const bf16x8 bth = *reinterpret_cast<const bf16x8*>(Thi + rb + k0);
+            const bf16x8 btl = *reinterpret_cast<const bf16x8*>(Tlo + rb + k0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ath, bth, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ath, btl, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(atl, bth, acc[i], 0, 0, 0);
+          }
         }
       }
     }
@@ -703,21 +695,22 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
   STAMP(4);
   // ---- combine the K-halves of every tile in LDS in a fixed order (deterministic); write the slab ---------------
   float* C = reinterpret_cast<float*>(lds_raw);   // [10][32][32]
-  if (item0 && kh0 == 0) {
 #pragma unroll
-    for (int e = 0; e < 16; e++)
-      C[tile0 * 1024 + ((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + l31] = acc0[e];
+  for (int i = 0; i < NI; i++) {
+    if (it_on[i] && it_kh[i] == 0) {
+#pragma unroll
+      for (int e = 0; e < 16; e++)
+        C[it_tile[i] * 1024 + ((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + l31] = acc[i][e];
+    }
   }
   __syncthreads();
-  if (item0 && kh0 == 1) {
 #pragma unroll
-    for (int e = 0; e < 16; e++)
-      C[tile0 * 1024 + ((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + l31] += acc0[e];
-  }
-  if (item1) {
+  for (int i = 0; i < NI; i++) {
+    if (it_on[i] && it_kh[i] == 1) {
 #pragma unroll
-    for (int e = 0; e < 16; e++)
-      C[tile1 * 1024 + ((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + l31] += acc1[e];
+      for (int e = 0; e < 16; e++)
+        C[it_tile[i] * 1024 + ((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + l31] += acc[i][e];
+    }
   }
   __syncthreads();
   // packed slab (site_internal.h, kSlab4Floats): six off-diagonal tiles as they are, the four diagonal tiles' upper
@@ -725,12 +718,12 @@ __global__ __launch_bounds__(NT) void site_fwd4_kernel(const float* __restrict__
   float* slab = slabs + (int64_t)blockIdx.x * kSlab4Floats;
   float4* slab4 = reinterpret_cast<float4*>(slab);
   const float4* C4 = reinterpret_cast<const float4*>(C);
-  for (int e = tid; e < kSlab4Off / 4; e += NT) {
+  for (int e = tid; e < kSlab4Off / 4; e += NTv) {
     const int t6 = e >> 8;                                      // C tiles 1, 2, 3, 5, 6, 8
     const int tl = t6 < 3 ? t6 + 1 : (t6 < 5 ? t6 + 2 : 8);
     slab4[e] = C4[tl * 256 + (e & 255)];
   }
-  for (int idx = tid; idx < kSlab4Packed; idx += NT) {
+  for (int idx = tid; idx < kSlab4Packed; idx += NTv) {
     const int blk = idx / 1056, rem = idx - blk * 1056;
     const int row = rem / 33, col = rem - row * 33;
     const bool second = col <= row;                             // tile 2*blk + 1, stored transposed
@@ -1610,12 +1603,16 @@ int launch_partials4(bool pair, const Geom& g, const float* x, int B, int64_t F,
   if (bn.bins && (!aligned || bn.res || (reinterpret_cast<uintptr_t>(bn.bins) & 15) || (bn.bin_bytes != 1 && bn.bin_bytes != 2)))
     return ALIGNQ_EINVAL;             // the index is stored per aligned column quad and only for a value that IS a level
   unsigned* counter = reinterpret_cast<unsigned*>(ws + (size_t)g.grid * g.slab_floats + kPartFloats);
-  // (geom(): only the 64-feature kernel ever loops over tiles)
+  // geom(): one tile per workgroup up to F = 16384 (64-feature tiles at most); beyond that the tile loop runs on 32-feature
+  // tiles with up to 512 workgroups - 512-thread workgroups, two per CU, for the plain site; with the batch-norm fold
+  // (no configuration has one at such F) the 1024-thread form of the same tile
+#define L4S(TFV, P, SG, NTV) hipLaunchKernelGGL((site_fwd4_kernel<TFV, P, SG, NTV>), g.grid, NTV, 0, st, x, B, F, k, r, eps, xq, ws, stats, g.n_tiles, aligned, counter, bn)
 #define L4(TFV, P)                                                                                                       \
   do {                                                                                                                  \
-    if (g.n_tiles <= g.grid) L4S(TFV, P, true); else if (TFV == 64) L4S(64, P, false); else return ALIGNQ_EINVAL;        \
+    if (g.n_tiles <= g.grid) L4S(TFV, P, true, NT);                                                                     \
+    else if (TFV == 32) { if (bn.ab || bn.res || bn.relu || bn.bins) L4S(32, P, false, NT); else L4S(32, P, false, 512); } \
+    else return ALIGNQ_EINVAL;                                                                                          \
   } while (0)
-#define L4S(TFV, P, SG) hipLaunchKernelGGL((site_fwd4_kernel<TFV, P, SG>), g.grid, NT, 0, st, x, B, F, k, r, eps, xq, ws, stats, g.n_tiles, aligned, counter, bn)
   if (pair) {
     if (g.tf == 64) L4(64, true); else if (g.tf == 32) L4(32, true); else L4(16, true);
   } else {
