@@ -1055,7 +1055,9 @@ __global__ __launch_bounds__(256) void head_bwd_prep_multi_kernel(HeadBwdArgs h,
 // global accesses (12 loads + 4-8 stores per thread instead of 48 + 16-32 dword ones: the dword form kept the texture
 // addresser busy for ~4 us per launch at F = 16384); the transposed staging is then one 8-byte LDS store per column and
 // array.  !VEC: one column x 16 rows per thread, dword accesses with clamped offsets (any F, any alignment).
-template <int TFv, bool PAIR, bool BN, bool VEC>
+// LOOP (plain site, VEC, 64-feature tiles, many tiles per CU): a workgroup walks over tiles and requests the next tile's x / g
+// rows as soon as this tile's are staged, so they fly under the MFMA, projection, assembly and copy-out phases.
+template <int TFv, bool PAIR, bool BN, bool VEC, bool LOOP = false>
 __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restrict__ gup, const float* __restrict__ S,
                                                         const float* __restrict__ x, const float* __restrict__ stats,
                                                         int B, int64_t F, float r, float eps, float* __restrict__ dx,
@@ -1090,8 +1092,10 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
   const float invB = 1.0f / (float)B, invBm1 = 1.0f / (float)(B - 1);
   STAMP(10);
 
-  const int tile = blockIdx.x;            // one tile per workgroup (grid == n_tiles): no tile loop, nothing to hoist
-  if (tile < n_tiles) {
+  float4 xr[4], gr[4];                    // VEC: this thread's x / g quads (LOOP: refilled one tile ahead)
+  bf16x8 sh[8], sl[8];                    // S fragments
+  // !LOOP: one tile per workgroup (grid == n_tiles): no tile loop, nothing to hoist
+  for (int tile = blockIdx.x; tile < n_tiles; tile += (int)gridDim.x) {
     const int col0 = tile * TFv;
     const bool lcol_ok = (col0 + lcol) < F;
     // Addressing: kernel-argument base (SGPR pair) + one 32-bit byte offset per element, shared by x / g / y / dx /
@@ -1139,16 +1143,17 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
           b4 = make_float4(bv, bv, bv, bv);
         }
       }
-      float4 xr[4], gr[4];
-#pragma unroll
-      for (int q = 0; q < 4; q++) xr[q] = AT4(x, q);          // all loads in flight before the first use
       const bool has_g = PAIR && gup != nullptr;
-      if (has_g) {
+      if (!LOOP || tile == (int)blockIdx.x) {     // (LOOP: every later tile was requested by the previous iteration)
 #pragma unroll
-        for (int q = 0; q < 4; q++) gr[q] = AT4(gup, q);
-      } else {
+        for (int q = 0; q < 4; q++) xr[q] = AT4(x, q);          // all loads in flight before the first use
+        if (has_g) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) gr[q] = z4;
+          for (int q = 0; q < 4; q++) gr[q] = AT4(gup, q);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; q++) gr[q] = z4;
+        }
       }
       if (BN) {
         float4 yr[4];
@@ -1219,6 +1224,25 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
         if (PAIR) {
           *reinterpret_cast<bf16x4*>(TThi + o) = (bf16x4){th0, th1, th2, th3};
           *reinterpret_cast<bf16x4*>(TTlo + o) = (bf16x4){tl0, tl1, tl2, tl3};
+        }
+      }
+      if constexpr (LOOP) {     // software pipeline: the registers take the next tile's rows (read once: non-temporal)
+        const int tn = tile + (int)gridDim.x;
+        if (tn < n_tiles) {
+          const bool q_okn = (tn * TFv + 4 * lc4) < F;
+          const unsigned colqn = (unsigned)(q_okn ? tn * TFv + 4 * lc4 : (int)F - 4) * 4u;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const unsigned off = (unsigned)min(lrow4 + q, B - 1) * rowB + colqn;
+            const f32x4_nt xv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(reinterpret_cast<const char*>(x) + off));
+            xr[q] = make_float4(xv.x, xv.y, xv.z, xv.w);
+            if (has_g) {
+              const f32x4_nt gv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(reinterpret_cast<const char*>(gup) + off));
+              gr[q] = make_float4(gv.x, gv.y, gv.z, gv.w);
+            } else {
+              gr[q] = z4;
+            }
+          }
         }
       }
     } else
@@ -1311,8 +1335,8 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
     // S fragments (already scaled, symmetric, split into bf16 hi / lo by the prep kernel: s_image_store): A[i][k],
     // i = I*32 + l31, k = 16*ks + 8h + jj.  Loaded here, after the load phase's registers are dead (a workgroup owns ONE
     // tile: grid == n_tiles); two 16-byte loads per k step, the 32 lanes of a half-wave read 1 KB contiguously.
-    bf16x8 sh[8], sl[8];
-    {
+    {     // (LOOP: fetched again for every tile - keeping the 64 registers alive across the load phase next to the prefetched
+          //  rows overflowed the 256-register budget of the 8-wave workgroup: 36 B of scratch)
       const char* img = reinterpret_cast<const char*>(S) + kSImageOffset;
   #pragma unroll
       for (int ks = 0; ks < 8; ks++) {
@@ -1578,6 +1602,8 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
     }
     }
     STAMP(15);
+    if constexpr (!LOOP) break;                // no back edge: the one-tile form keeps the register allocation of a plain `if`
+    __syncthreads();                           // the staging arrays are rewritten by the next tile
 #undef AT
 #undef ATW
 #undef AT4
@@ -1603,14 +1629,13 @@ int launch_partials4(bool pair, const Geom& g, const float* x, int B, int64_t F,
   if (bn.bins && (!aligned || bn.res || (reinterpret_cast<uintptr_t>(bn.bins) & 15) || (bn.bin_bytes != 1 && bn.bin_bytes != 2)))
     return ALIGNQ_EINVAL;             // the index is stored per aligned column quad and only for a value that IS a level
   unsigned* counter = reinterpret_cast<unsigned*>(ws + (size_t)g.grid * g.slab_floats + kPartFloats);
-  // geom(): one tile per workgroup up to F = 16384 (64-feature tiles at most); beyond that the tile loop runs on 32-feature
-  // tiles with up to 512 workgroups - 512-thread workgroups, two per CU, for the plain site; with the batch-norm fold
-  // (no configuration has one at such F) the 1024-thread form of the same tile
+  // geom(): one tile per workgroup up to F = 16384; beyond that the 64-feature tile loop runs in up to 512 workgroups of 512
+  // threads, two per CU, for the plain site; with the batch-norm fold (no configuration has one at such F) in 1024-thread ones
 #define L4S(TFV, P, SG, NTV) hipLaunchKernelGGL((site_fwd4_kernel<TFV, P, SG, NTV>), g.grid, NTV, 0, st, x, B, F, k, r, eps, xq, ws, stats, g.n_tiles, aligned, counter, bn)
 #define L4(TFV, P)                                                                                                       \
   do {                                                                                                                  \
     if (g.n_tiles <= g.grid) L4S(TFV, P, true, NT);                                                                     \
-    else if (TFV == 32) { if (bn.ab || bn.res || bn.relu || bn.bins) L4S(32, P, false, NT); else L4S(32, P, false, 512); } \
+    else if (TFV == 64) { if (bn.ab || bn.res || bn.relu || bn.bins) L4S(64, P, false, NT); else L4S(64, P, false, 512); } \
     else return ALIGNQ_EINVAL;                                                                                          \
   } while (0)
   if (pair) {
@@ -1715,7 +1740,7 @@ int launch_bwd4(bool pair, const Geom& g, const float* gup, const float* S, cons
   if ((int64_t)B * F * 4 >= ((int64_t)1 << 32)) return ALIGNQ_EUNSUPPORTED;   // 32-bit byte offsets inside a tile column
   const int tf = bwd_tile_features(B, F);
   const int n_tiles = (int)((F + tf - 1) / tf);
-  const int grid = n_tiles;               // one tile per workgroup
+  int grid = n_tiles;                     // one tile per workgroup (the looped form below: one workgroup per CU)
   const int aligned = 0;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   // 16-byte accesses need whole column quads and aligned rows (channels-last BN: C % 4 == 0 holds, C is a power of two >= 4)
@@ -1728,7 +1753,12 @@ int launch_bwd4(bool pair, const Geom& g, const float* gup, const float* S, cons
     else hipLaunchKernelGGL((site_bwd4_kernel<TFV, P, N, false>), grid, TFV * 8, 0, st, gup, S, x, stats, B, F, r, eps, dx,  \
                             n_tiles, aligned, bn);                                                                           \
   } while (0)
-  if (tf == 64) {
+  if (tf == 64 && vec && !bn.ab && !bn.y && !bn.ybins && !bn.dres && n_tiles > 2 * 256) {
+    // plain site with many tiles per CU (F > 32768): the looped, software-pipelined form (138 KB of LDS: one workgroup per CU)
+    grid = 256;
+    if (pair) hipLaunchKernelGGL((site_bwd4_kernel<64, true, false, true, true>), grid, 512, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_tiles, aligned, bn);
+    else hipLaunchKernelGGL((site_bwd4_kernel<64, false, false, true, true>), grid, 512, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_tiles, aligned, bn);
+  } else if (tf == 64) {
     if (pair && bn.ab) LB(64, true, true); else if (pair) LB(64, true, false); else LB(64, false, false);
   } else {
     if (pair && bn.ab) LB(32, true, true); else if (pair) LB(32, true, false); else LB(32, false, false);

@@ -74,9 +74,10 @@ inline Geom geom(int B, int64_t F) {
     // narrower tiles while that still fits one tile per CU: 16 features up to F = 4096, 32 up to 8192, else 64 (only the
     // 64-feature kernel ever loops over tiles; its one-tile form and the narrow kernels are the latency-tuned ones)
     g.tf = (F > 32 * 256) ? 64 : ((F > 16 * 256) ? 32 : 16);
-    // beyond one 64-feature tile per CU the kernel loops over tiles: 32-feature tiles, two 512-thread workgroups per CU
+    // beyond one 64-feature tile per CU the kernel loops over tiles: two 512-thread workgroups per CU (80 KB of LDS each)
+    // (32-feature tiles were tried for this form: 128-byte row segments copy at 4.7-5.3 TB/s against 5.9-6.3 for 256-byte
+    // ones, tools/src/stream_bw.hip, and the kernel ran 203 us against 186 at [128, 524288])
     const bool looped = F > 64 * 256;
-    if (looped) g.tf = 32;
     g.n_tiles = (int)((F + g.tf - 1) / g.tf);
     const int cap = looped ? 512 : 256;
     g.grid = g.n_tiles < cap ? g.n_tiles : cap;

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <vector>
 #include <algorithm>
+#include <cstdlib>
 #include "alignq_math.h"
 using namespace alignq;
 
@@ -57,7 +58,57 @@ __global__ __launch_bounds__(NT) void k(const float4* __restrict__ x, float4* __
   }
 }
 
-static float *dx, *dy;
+// The fused site kernels' access pattern as a pure copy: x is [128, F] row-major, a workgroup owns column tiles of TF features
+// (each of the 128 rows contributes TF*4 contiguous bytes), thread = (column quad, row group).  Shows what that pattern alone
+// can reach before any arithmetic, statistics or MFMA.
+template <int NT, int TF, bool NTL>
+__global__ __launch_bounds__(NT) void k_site(const float* __restrict__ x, float* __restrict__ y, long F, int n_tiles) {
+  constexpr int LPR = TF / 4, RG = NT / LPR, RJ = (128 + RG - 1) / RG;
+  const int c = threadIdx.x % LPR, rg = threadIdx.x / LPR;
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const long col = (long)tile * TF + 4 * c;
+    float4 v[RJ];
+#pragma unroll
+    for (int j = 0; j < RJ; j++) {
+      const int row = rg + RG * j;
+      const float* p = x + (long)row * F + col;
+      if (row < 128) {
+        if (NTL) { v[j].x = __builtin_nontemporal_load(p); v[j].y = __builtin_nontemporal_load(p + 1); v[j].z = __builtin_nontemporal_load(p + 2); v[j].w = __builtin_nontemporal_load(p + 3); }
+        else v[j] = *reinterpret_cast<const float4*>(p);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < RJ; j++) {
+      const int row = rg + RG * j;
+      if (row < 128) *reinterpret_cast<float4*>(y + (long)row * F + col) = v[j];
+    }
+  }
+}
+
+template <int NT, int TF, bool NTL>
+void run_site(int grid) {
+  const long F = (1L << 26) / 128;
+  const int n_tiles = (int)(F / TF);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  std::vector<float> ms;
+  extern float *dx, *dy;
+  for (int it = 0; it < 12; it++) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((k_site<NT, TF, NTL>), grid < n_tiles ? grid : n_tiles, NT, 0, 0, (const float*)dx, dy, F, n_tiles);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float t; hipEventElapsedTime(&t, e0, e1);
+    if (it >= 2) ms.push_back(t);
+  }
+  std::sort(ms.begin(), ms.end());
+  const float med = ms[ms.size() / 2];
+  printf("site pattern [128, %ld]: NT=%4d TF=%3d ntl=%d grid=%5d : %7.1f us  %6.0f GB/s\n", F, NT, TF, (int)NTL, grid, med * 1e3,
+         8.0 * (1L << 26) / (med * 1e-3) / 1e9);
+  fflush(stdout);
+}
+
+float *dx, *dy;
 static const long N = 1L << 26;
 
 template <int NT, int U, int MODE, bool NTL, bool NTS, bool MATH>
@@ -114,6 +165,12 @@ int main() {
       if (it == 4) printf("hipMemcpy D2D: %.1f us %.0f GB/s\n", t * 1e3, 8.0 * N / (t * 1e-3) / 1e9);
     }
   }
+  printf("---- the site kernels' [128, F] column-tile pattern as a pure copy\n");
+  for (int grid : {256, 512, 1024, 8192}) {
+    run_site<1024, 64, false>(grid); run_site<1024, 64, true>(grid); run_site<1024, 128, true>(grid);
+    run_site<512, 32, true>(grid); run_site<512, 64, true>(grid); run_site<256, 64, true>(grid); run_site<1024, 32, true>(grid);
+  }
+  if (getenv("STREAM_BW_SITE_ONLY")) return 0;
   printf("---- pure copy\n");
   sweep<false>();
   printf("---- copy + NERF32 quantiser (k=8, r=2)\n");
