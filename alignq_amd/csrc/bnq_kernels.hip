@@ -11,8 +11,8 @@
 //   backward: bnq_sums<BWD> (dx = g * [y > 0] * dt/dx(a*z + b); per-channel sum dx, sum dx*zhat: reads g, z, y) ->
 //             bnq_finalize_bwd (k0 = mean dx, k1 = mean dx*zhat, dgamma, dbeta) -> bnq_apply_bwd: dz = a*(dx - k0 - zhat*k1)
 //             (reads g, z, y, writes dz) = 28 B/element instead of 16 (quantiser + ReLU backward) + ~20 (BatchNorm backward).
-// z viewed as [P, C], P = B*H*W pixels, C channels fastest (torch.channels_last); C = 4 * 2^j <= 1024 so that a thread's
-// channel quad is fixed for the whole launch (256 threads = slots x C/4 quads).  Arithmetic: statistics in double, the
+// z viewed as [P, C], P = B*H*W pixels, C channels fastest (torch.channels_last); C = 4 * 2^j <= 2048 so that a thread's
+// channel quad is fixed for the whole launch (256 threads = slots x C/4 quads; 512 at C = 2048).  Arithmetic: statistics in double, the
 // affine as ONE fma (the form oracle/alignq_oracle.c: oq_bn_fold_ab / oq_bn_apply pin to torch.nn.BatchNorm2d), then the
 // quantiser of alignq_math.h: y is bit-identical to quantising the oracle's BN output.  Deterministic (fixed-order sums).
 #include <hip/hip_runtime.h>
@@ -36,19 +36,21 @@ __device__ __forceinline__ float4 ldnt(const float* p) {
 }
 
 // ---- per-channel sums over the pixels -----------------------------------------------------------------------------------
-// BWD = false: {sum z, sum z^2};  BWD = true: {sum dx, sum dx*zhat} with dx = g * [y > 0] * jac(a*z + b).
-// part: [gridDim.x][C][2] doubles.
-template <bool BWD>
-__global__ __launch_bounds__(kT) void bnq_sums_kernel(const float* __restrict__ z, const float* __restrict__ g,
+// MODE 0: {sum z, sum z^2};  MODE 1: {sum dx, sum dx*zhat} with dx = g * [y > 0] * jac(a*z + b) (the quantiser's backward in
+// front of the batch-norm's);  MODE 2: the same sums for a GIVEN dx = g (plain batch-norm backward: the ADMM sites' bn3 and the
+// downsample branch's batch-norm).  part: [gridDim.x][C][2] doubles.
+template <int MODE, int NT>
+__global__ __launch_bounds__(NT) void bnq_sums_kernel(const float* __restrict__ z, const float* __restrict__ g,
                                                       const float* __restrict__ y, const float* __restrict__ ab,
                                                       const float* __restrict__ save, int64_t P, int C, float r, int relu,
                                                       double* __restrict__ part) {
-  __shared__ double sm[kT][8];
+  __shared__ double sm[NT][8];
   const int tid = threadIdx.x;
-  const int C4 = C >> 2, slots = kT / C4;
+  const int C4 = C >> 2, slots = NT / C4;
   const int cq = tid % C4, slot = tid / C4;
   const int64_t per = (P + gridDim.x - 1) / gridDim.x;
   const int64_t p0 = (int64_t)blockIdx.x * per, p1 = (p0 + per < P) ? p0 + per : P;
+  constexpr bool BWD = MODE != 0;
   float4 a4, b4, m4, i4;
   if (BWD) {
     a4 = *reinterpret_cast<const float4*>(ab + 4 * cq);
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(kT) void bnq_sums_kernel(const float* __restrict__ 
       zv[u] = *reinterpret_cast<const float4*>(z + off);
       if (BWD) {
         gv[u] = *reinterpret_cast<const float4*>(g + off);
-        if (relu) yv[u] = *reinterpret_cast<const float4*>(y + off);
+        if (MODE == 1 && relu) yv[u] = *reinterpret_cast<const float4*>(y + off);
       }
     }
 #pragma unroll
@@ -83,9 +85,12 @@ __global__ __launch_bounds__(kT) void bnq_sums_kernel(const float* __restrict__ 
           const float me[4] = {m4.x, m4.y, m4.z, m4.w}, ie[4] = {i4.x, i4.y, i4.z, i4.w};
 #pragma unroll
           for (int e = 0; e < 4; e++) {
-            const float x = __fmaf_rn(ae[e], ze[e], be[e]);
-            const float gm = (relu && !(ye[e] > 0.f)) ? 0.f : ge[e];
-            const float dx = gm * act_jac(x, r);
+            float dx = ge[e];
+            if (MODE == 1) {
+              const float x = __fmaf_rn(ae[e], ze[e], be[e]);
+              const float gm = (relu && !(ye[e] > 0.f)) ? 0.f : ge[e];
+              dx = gm * act_jac(x, r);
+            }
             const float zh = (ze[e] - me[e]) * ie[e];
             s0[e] += (double)dx;
             s1[e] += (double)dx * (double)zh;
@@ -97,7 +102,7 @@ __global__ __launch_bounds__(kT) void bnq_sums_kernel(const float* __restrict__ 
 #pragma unroll
   for (int e = 0; e < 4; e++) { sm[tid][e] = s0[e]; sm[tid][4 + e] = s1[e]; }
   __syncthreads();
-  for (int c = tid; c < C; c += kT) {
+  for (int c = tid; c < C; c += NT) {
     const int qd = c >> 2, e = c & 3;
     double a = 0, b = 0;
     for (int s = 0; s < slots; s++) { a += sm[s * C4 + qd][e]; b += sm[s * C4 + qd][4 + e]; }      // fixed order
@@ -170,8 +175,8 @@ __global__ __launch_bounds__(kT) void bnq_finalize_bwd_kernel(const double* __re
 }
 
 // ---- elementwise passes: tiles of kUa x 256 float4 per block; 256 % (C/4) == 0 keeps a thread on one channel quad ----------
-template <int FORMULA>
-__global__ __launch_bounds__(kT) void bnq_apply_fwd_kernel(const float* __restrict__ z, const float* __restrict__ ab, int64_t nvec,
+template <int FORMULA, int NT>
+__global__ __launch_bounds__(NT) void bnq_apply_fwd_kernel(const float* __restrict__ z, const float* __restrict__ ab, int64_t nvec,
                                                            int C, int k, float r, int relu, float* __restrict__ y) {
   __shared__ __attribute__((aligned(16))) float nerf_lds[ALIGNQ_NERF_LDS_FLOATS];
   nerf_tab_load(nerf_lds);
@@ -183,34 +188,42 @@ __global__ __launch_bounds__(kT) void bnq_apply_fwd_kernel(const float* __restri
   const float4 b4 = *reinterpret_cast<const float4*>(ab + C + 4 * cq);
   const float4* z4 = reinterpret_cast<const float4*>(z);
   float4* y4 = reinterpret_cast<float4*>(y);
-  const int64_t stride = (int64_t)gridDim.x * kT * kUa;
+  const int64_t stride = (int64_t)gridDim.x * NT * kUa;
   ALIGNQ_BOUNDED_SWITCH(nlev,
-  for (int64_t i0 = (int64_t)blockIdx.x * (kT * kUa) + threadIdx.x; i0 < nvec; i0 += stride) {
+  for (int64_t i0 = (int64_t)blockIdx.x * (NT * kUa) + threadIdx.x; i0 < nvec; i0 += stride) {
     float4 v[kUa];
 _Pragma("unroll")
     for (int u = 0; u < kUa; u++) {
-      const int64_t i = i0 + u * kT;
+      const int64_t i = i0 + u * NT;
       v[u] = z4[i < nvec ? i : i0];
     }
 _Pragma("unroll")
     for (int u = 0; u < kUa; u++) {
-      const int64_t i = i0 + u * kT;
+      const int64_t i = i0 + u * NT;
       float4 o;
       float t, b;
-      o.x = act_quant1<FORMULA, kBounded>(__fmaf_rn(a4.x, v[u].x, b4.x), k, nlev, r, &t, &b, tab);
-      o.y = act_quant1<FORMULA, kBounded>(__fmaf_rn(a4.y, v[u].y, b4.y), k, nlev, r, &t, &b, tab);
-      o.z = act_quant1<FORMULA, kBounded>(__fmaf_rn(a4.z, v[u].z, b4.z), k, nlev, r, &t, &b, tab);
-      o.w = act_quant1<FORMULA, kBounded>(__fmaf_rn(a4.w, v[u].w, b4.w), k, nlev, r, &t, &b, tab);
+      if (FORMULA == 2) {          // no quantiser: the batch-norm output itself (downsample branch)
+        o = make_float4(__fmaf_rn(a4.x, v[u].x, b4.x), __fmaf_rn(a4.y, v[u].y, b4.y), __fmaf_rn(a4.z, v[u].z, b4.z),
+                        __fmaf_rn(a4.w, v[u].w, b4.w));
+      } else {
+        constexpr int FQ = FORMULA == 2 ? 0 : FORMULA;
+        o.x = act_quant1<FQ, kBounded>(__fmaf_rn(a4.x, v[u].x, b4.x), k, nlev, r, &t, &b, tab);
+        o.y = act_quant1<FQ, kBounded>(__fmaf_rn(a4.y, v[u].y, b4.y), k, nlev, r, &t, &b, tab);
+        o.z = act_quant1<FQ, kBounded>(__fmaf_rn(a4.z, v[u].z, b4.z), k, nlev, r, &t, &b, tab);
+        o.w = act_quant1<FQ, kBounded>(__fmaf_rn(a4.w, v[u].w, b4.w), k, nlev, r, &t, &b, tab);
+      }
       if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
       if (i < nvec) y4[i] = o;
     }
   })
 }
 
-__global__ __launch_bounds__(kT) void bnq_apply_bwd_kernel(const float* __restrict__ g, const float* __restrict__ z,
+template <int NT>
+__global__ __launch_bounds__(NT) void bnq_apply_bwd_kernel(const float* __restrict__ g, const float* __restrict__ z,
                                                            const float* __restrict__ y, const float* __restrict__ ab,
                                                            const float* __restrict__ save, const float* __restrict__ ktot,
-                                                           int64_t nvec, int C, float r, int relu, float* __restrict__ dz) {
+                                                           int64_t nvec, int C, float r, int relu, int from_dx,
+                                                           float* __restrict__ dz) {
   constexpr int U = 2;
   const int cq = threadIdx.x % (C >> 2);
   const float4 a4 = *reinterpret_cast<const float4*>(ab + 4 * cq), b4 = *reinterpret_cast<const float4*>(ab + C + 4 * cq);
@@ -219,27 +232,30 @@ __global__ __launch_bounds__(kT) void bnq_apply_bwd_kernel(const float* __restri
   const float ae[4] = {a4.x, a4.y, a4.z, a4.w}, be[4] = {b4.x, b4.y, b4.z, b4.w};
   const float me[4] = {m4.x, m4.y, m4.z, m4.w}, ie[4] = {i4.x, i4.y, i4.z, i4.w};
   const float k0e[4] = {k0.x, k0.y, k0.z, k0.w}, k1e[4] = {k1.x, k1.y, k1.z, k1.w};
-  const int64_t stride = (int64_t)gridDim.x * kT * U;
-  for (int64_t i0 = (int64_t)blockIdx.x * (kT * U) + threadIdx.x; i0 < nvec; i0 += stride) {
+  const int64_t stride = (int64_t)gridDim.x * NT * U;
+  for (int64_t i0 = (int64_t)blockIdx.x * (NT * U) + threadIdx.x; i0 < nvec; i0 += stride) {
     float4 gv[U], zv[U], yv[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      const int64_t i = i0 + u * kT, ic = i < nvec ? i : i0;
+      const int64_t i = i0 + u * NT, ic = i < nvec ? i : i0;
       gv[u] = ldnt(g + 4 * ic);                      // the upstream gradient is read here for the last time
       zv[u] = *reinterpret_cast<const float4*>(z + 4 * ic);
       if (relu) yv[u] = *reinterpret_cast<const float4*>(y + 4 * ic);
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      const int64_t i = i0 + u * kT;
+      const int64_t i = i0 + u * NT;
       const float ge[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w}, ze[4] = {zv[u].x, zv[u].y, zv[u].z, zv[u].w};
       const float ye[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};
       float o[4];
 #pragma unroll
       for (int e = 0; e < 4; e++) {
-        const float x = __fmaf_rn(ae[e], ze[e], be[e]);
-        const float gm = (relu && !(ye[e] > 0.f)) ? 0.f : ge[e];
-        const float dx = gm * act_jac(x, r);
+        float dx = ge[e];
+        if (!from_dx) {            // launch-uniform
+          const float x = __fmaf_rn(ae[e], ze[e], be[e]);
+          const float gm = (relu && !(ye[e] > 0.f)) ? 0.f : ge[e];
+          dx = gm * act_jac(x, r);
+        }
         const float zh = (ze[e] - me[e]) * ie[e];
         o[e] = ae[e] * (dx - k0e[e] - zh * k1e[e]);
       }
@@ -248,19 +264,32 @@ __global__ __launch_bounds__(kT) void bnq_apply_bwd_kernel(const float* __restri
   }
 }
 
-inline bool bad_c(int C) { return C < 4 || C > 1024 || (C & (C - 1)) != 0; }
-inline int tiles(int64_t nvec, int u) {
-  int64_t b = (nvec + (int64_t)kT * u - 1) / ((int64_t)kT * u);
+inline bool bad_c(int C) { return C < 4 || C > 2048 || (C & (C - 1)) != 0; }   // threads = slots x C/4 quads (512 at C = 2048)
+inline int threads_for(int C) { return (C >> 2) > kT ? 512 : kT; }
+inline int tiles(int64_t nvec, int u, int nt = kT) {
+  int64_t b = (nvec + (int64_t)nt * u - 1) / ((int64_t)nt * u);
   if (b < 1) b = 1;
   return (int)(b > 256 * 64 ? 256 * 64 : b);
 }
 inline int parts_for(int64_t P, int C) {
   // every block should own at least a few pixel rounds: slots * kUs pixels per round
-  const int slots = kT / (C >> 2);
+  const int slots = threads_for(C) / (C >> 2);
   int64_t n = P / ((int64_t)slots * kUs);
   if (n < 1) n = 1;
   return (int)(n > kParts ? kParts : n);
 }
+
+// launch with 256 threads, or 512 where a pixel has more than 256 channel quads (C = 2048: ResNet-50's last stage)
+#define BNQ_NT(C, ...)                                   \
+  do {                                                   \
+    if (threads_for(C) == 512) {                         \
+      constexpr int NTV = 512;                           \
+      __VA_ARGS__;                                       \
+    } else {                                             \
+      constexpr int NTV = kT;                            \
+      __VA_ARGS__;                                       \
+    }                                                    \
+  } while (0)
 
 }  // namespace
 
@@ -282,17 +311,17 @@ int alignq_bnq_fwd(const float* z, int64_t P, int C, const float* gamma, const f
   hipStream_t st = (hipStream_t)stream;
   double* part = reinterpret_cast<double*>(ws);
   const int np = parts_for(P, C);
-  hipLaunchKernelGGL(bnq_sums_kernel<false>, dim3(np), dim3(kT), 0, st, z, nullptr, nullptr, nullptr, nullptr, P, C, act_range,
-                     0, part);
+  BNQ_NT(C, hipLaunchKernelGGL((bnq_sums_kernel<0, NTV>), dim3(np), dim3(NTV), 0, st, z, nullptr, nullptr, nullptr, nullptr, P, C, act_range,
+                     0, part));
   hipLaunchKernelGGL(bnq_finalize_kernel, dim3((C + 15) / 16), dim3(kT), 0, st, (const double*)part, np, P, C, gamma, beta,
                      running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), momentum, bn_eps, ab, save);
   const int64_t nvec = P * (C >> 2);
   if (formula == ALIGNQ_FORMULA_ADMM)
-    hipLaunchKernelGGL(bnq_apply_fwd_kernel<0>, dim3(tiles(nvec, kUa)), dim3(kT), 0, st, z, (const float*)ab, nvec, C, k,
-                       act_range, relu, y);
+    BNQ_NT(C, hipLaunchKernelGGL((bnq_apply_fwd_kernel<0, NTV>), dim3(tiles(nvec, kUa, NTV)), dim3(NTV), 0, st, z, (const float*)ab, nvec, C, k,
+                       act_range, relu, y));
   else
-    hipLaunchKernelGGL(bnq_apply_fwd_kernel<1>, dim3(tiles(nvec, kUa)), dim3(kT), 0, st, z, (const float*)ab, nvec, C, k,
-                       act_range, relu, y);
+    BNQ_NT(C, hipLaunchKernelGGL((bnq_apply_fwd_kernel<1, NTV>), dim3(tiles(nvec, kUa, NTV)), dim3(NTV), 0, st, z, (const float*)ab, nvec, C, k,
+                       act_range, relu, y));
   return hipGetLastError() == hipSuccess ? 0 : ALIGNQ_EINVAL;
 }
 
@@ -307,12 +336,56 @@ int alignq_bnq_bwd(const float* g, const float* z, const float* y, const float* 
   double* part = reinterpret_cast<double*>(ws);
   float* ktot = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + (size_t)kParts * C * 2 * sizeof(double));
   const int np = parts_for(P, C);
-  hipLaunchKernelGGL(bnq_sums_kernel<true>, dim3(np), dim3(kT), 0, st, z, g, y, ab, save, P, C, act_range, relu, part);
+  BNQ_NT(C, hipLaunchKernelGGL((bnq_sums_kernel<1, NTV>), dim3(np), dim3(NTV), 0, st, z, g, y, ab, save, P, C, act_range, relu, part));
   hipLaunchKernelGGL(bnq_finalize_bwd_kernel, dim3((C + 15) / 16), dim3(kT), 0, st, (const double*)part, np, P, C, ktot,
                      dgamma, dbeta);
   const int64_t nvec = P * (C >> 2);
-  hipLaunchKernelGGL(bnq_apply_bwd_kernel, dim3(tiles(nvec, 2)), dim3(kT), 0, st, g, z, y, ab, save, (const float*)ktot, nvec,
-                     C, act_range, relu, dz);
+  BNQ_NT(C, hipLaunchKernelGGL((bnq_apply_bwd_kernel<NTV>), dim3(tiles(nvec, 2, NTV)), dim3(NTV), 0, st, g, z, y, ab, save, (const float*)ktot, nvec,
+                     C, act_range, relu, 0, dz));
+  return hipGetLastError() == hipSuccess ? 0 : ALIGNQ_EINVAL;
+}
+
+// The batch-norm alone (no quantiser behind it in the same chain): statistics -> (a, b); y = a*z + b; backward from a given dx.
+int alignq_bnq_stats(const float* z, int64_t P, int C, const float* gamma, const float* beta, float* running_mean,
+                     float* running_var, int64_t* num_batches_tracked, float momentum, float bn_eps, float* ab, float* save,
+                     void* ws, void* stream) {
+  if (!z || !ab || !save || !ws || P < 2) return ALIGNQ_EINVAL;
+  if (bad_c(C)) return ALIGNQ_EUNSUPPORTED;
+  if (reinterpret_cast<uintptr_t>(z) & 15) return ALIGNQ_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  double* part = reinterpret_cast<double*>(ws);
+  const int np = parts_for(P, C);
+  BNQ_NT(C, hipLaunchKernelGGL((bnq_sums_kernel<0, NTV>), dim3(np), dim3(NTV), 0, st, z, nullptr, nullptr, nullptr, nullptr, P, C, 0.f, 0, part));
+  hipLaunchKernelGGL(bnq_finalize_kernel, dim3((C + 15) / 16), dim3(kT), 0, st, (const double*)part, np, P, C, gamma, beta,
+                     running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), momentum, bn_eps, ab, save);
+  return hipGetLastError() == hipSuccess ? 0 : ALIGNQ_EINVAL;
+}
+
+int alignq_bnq_affine(const float* z, const float* ab, int64_t P, int C, float* y, void* stream) {
+  if (!z || !ab || !y || P < 1) return ALIGNQ_EINVAL;
+  if (bad_c(C)) return ALIGNQ_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(y)) & 15) return ALIGNQ_EINVAL;
+  const int64_t nvec = P * (C >> 2);
+  BNQ_NT(C, hipLaunchKernelGGL((bnq_apply_fwd_kernel<2, NTV>), dim3(tiles(nvec, kUa, NTV)), dim3(NTV), 0, (hipStream_t)stream, z, ab, nvec, C, 32, 1.0f,
+                     0, y));
+  return hipGetLastError() == hipSuccess ? 0 : ALIGNQ_EINVAL;
+}
+
+int alignq_bnq_bwd_dx(const float* dx, const float* z, const float* ab, const float* save, int64_t P, int C, float* dz,
+                      float* dgamma, float* dbeta, void* ws, void* stream) {
+  if (!dx || !z || !ab || !save || !dz || !ws || P < 2) return ALIGNQ_EINVAL;
+  if (bad_c(C)) return ALIGNQ_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(dz)) & 15) return ALIGNQ_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  double* part = reinterpret_cast<double*>(ws);
+  float* ktot = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + (size_t)kParts * C * 2 * sizeof(double));
+  const int np = parts_for(P, C);
+  BNQ_NT(C, hipLaunchKernelGGL((bnq_sums_kernel<2, NTV>), dim3(np), dim3(NTV), 0, st, z, dx, nullptr, ab, save, P, C, 0.f, 0, part));
+  hipLaunchKernelGGL(bnq_finalize_bwd_kernel, dim3((C + 15) / 16), dim3(kT), 0, st, (const double*)part, np, P, C, ktot,
+                     dgamma, dbeta);
+  const int64_t nvec = P * (C >> 2);
+  BNQ_NT(C, hipLaunchKernelGGL((bnq_apply_bwd_kernel<NTV>), dim3(tiles(nvec, 2, NTV)), dim3(NTV), 0, st, dx, z, nullptr, ab, save, (const float*)ktot,
+                     nvec, C, 0.f, 0, 1, dz));
   return hipGetLastError() == hipSuccess ? 0 : ALIGNQ_EINVAL;
 }
 

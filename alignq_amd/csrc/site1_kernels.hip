@@ -100,7 +100,8 @@ __global__ __launch_bounds__(kThreads1) void site1_fwd_kernel(const float* __res
                                                               float r, float eps, float* __restrict__ xq,
                                                               float* __restrict__ slabs, float* __restrict__ stats,
                                                               int n_sub, unsigned* __restrict__ counter,
-                                                              const float* __restrict__ res, int relu) {
+                                                              const float* __restrict__ res, int relu,
+                                                              const float* __restrict__ ab, int nch) {
   __shared__ __attribute__((aligned(16))) unsigned lds[(kWaves * WBUF > 4096) ? kWaves * WBUF : 4096];
   __shared__ __attribute__((aligned(16))) float nerf_lds[PAIR ? ALIGNQ_NERF_LDS_FLOATS : 4];
   if (PAIR) {
@@ -129,6 +130,13 @@ __global__ __launch_bounds__(kThreads1) void site1_fwd_kernel(const float* __res
 #pragma unroll
     for (int q = 0; q < RPL; q++)       // (non-temporal dword loads measured slower here: 72.6 vs 63.8 us at [28, 802816])
       xr[q] = (cok && RPL * h + q < B) ? xp[(int64_t)q * F] : 0.0f;
+    if (ab) {      // folded batch-norm (channels-last: channel = column mod nch, nch a power of two): x = a*z + b on load
+      const int ch = (int)(col & (int64_t)(nch - 1));
+      const float av = cok ? ab[ch] : 0.0f, bv = cok ? ab[nch + ch] : 0.0f;
+#pragma unroll
+      for (int q = 0; q < RPL; q++)
+        if (cok && RPL * h + q < B) xr[q] = __fmaf_rn(av, xr[q], bv);
+    }
     if (PAIR && RES) {        // the shortcut rows: in flight under the transform below
       const float* __restrict__ rp = res + (int64_t)(RPL * h) * F + col;
 #pragma unroll
@@ -242,7 +250,8 @@ template <bool PAIR>
 __global__ __launch_bounds__(kThreads1) void site1_bwd_kernel(const float* __restrict__ gup, const float* __restrict__ S,
                                                               const float* __restrict__ x,
                                                               const float* __restrict__ stats, int B, int64_t F, float r,
-                                                              float eps, float* __restrict__ dx, int n_sub) {
+                                                              float eps, float* __restrict__ dx, int n_sub,
+                                                              const float* __restrict__ ab, int C) {
   __shared__ __attribute__((aligned(16))) unsigned lds[kWaves * WBUF];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
@@ -273,6 +282,13 @@ __global__ __launch_bounds__(kThreads1) void site1_bwd_kernel(const float* __res
       const bool ok = cok && RPL * h + q < B;
       xr[q] = ok ? x[base + (int64_t)q * F] : 0.0f;
       gr[q] = (PAIR && gup && ok) ? gup[base + (int64_t)q * F] : 0.0f;
+    }
+    if (ab) {      // folded batch-norm: x = a*z + b on load (dx is the gradient w.r.t. x; alignq_bnq_bwd_dx takes it to z)
+      const int ch = (int)(col & (int64_t)(C - 1));
+      const float av = cok ? ab[ch] : 0.0f, bv = cok ? ab[C + ch] : 0.0f;
+#pragma unroll
+      for (int q = 0; q < RPL; q++)
+        if (cok && RPL * h + q < B) xr[q] = __fmaf_rn(av, xr[q], bv);
     }
     const float mx = cok ? stats[col] : 0.f, rx = cok ? stats[F + col] : 0.f;
     const float mt = (PAIR && cok) ? stats[2 * F + col] : 0.f, rt = (PAIR && cok) ? stats[3 * F + col] : 0.f;
@@ -365,23 +381,23 @@ __global__ __launch_bounds__(kThreads1) void site1_bwd_kernel(const float* __res
 }  // namespace
 
 int launch_partials1(bool pair, const Geom& g, const float* x, int B, int64_t F, int k, float r, float eps, float* xq,
-                     float* stats, float* ws, hipStream_t st, const float* res, int relu) {
+                     float* stats, float* ws, hipStream_t st, const float* res, int relu, const float* ab, int C) {
   unsigned* counter = reinterpret_cast<unsigned*>(ws + (size_t)g.grid * g.slab_floats + kPartFloats);
   const int n_sub = (int)((F + SUBF - 1) / SUBF);
-  if (pair && res) hipLaunchKernelGGL((site1_fwd_kernel<true, true>), g.grid, kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter, res, relu);
-  else if (pair) hipLaunchKernelGGL((site1_fwd_kernel<true, false>), g.grid, kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter, nullptr, relu);
-  else hipLaunchKernelGGL((site1_fwd_kernel<false, false>), g.grid, kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter, nullptr, 0);
+  if (pair && res) hipLaunchKernelGGL((site1_fwd_kernel<true, true>), g.grid, kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter, res, relu, ab, C);
+  else if (pair) hipLaunchKernelGGL((site1_fwd_kernel<true, false>), g.grid, kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter, nullptr, relu, ab, C);
+  else hipLaunchKernelGGL((site1_fwd_kernel<false, false>), g.grid, kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter, nullptr, 0, ab, C);
   RET_ON_ERR1();
   return 0;
 }
 
 int launch_bwd1(bool pair, const float* gup, const float* S, const float* x, const float* stats, int B, int64_t F,
-                float r, float eps, float* dx, hipStream_t st) {
+                float r, float eps, float* dx, hipStream_t st, const float* ab, int C) {
   const int n_sub = (int)((F + SUBF - 1) / SUBF);
   int grid = (n_sub + kWaves - 1) / kWaves;
   if (grid > 2048) grid = 2048;
-  if (pair) hipLaunchKernelGGL((site1_bwd_kernel<true>), grid, kThreads1, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_sub);
-  else hipLaunchKernelGGL((site1_bwd_kernel<false>), grid, kThreads1, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_sub);
+  if (pair) hipLaunchKernelGGL((site1_bwd_kernel<true>), grid, kThreads1, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_sub, ab, C);
+  else hipLaunchKernelGGL((site1_bwd_kernel<false>), grid, kThreads1, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_sub, ab, C);
   RET_ON_ERR1();
   return 0;
 }

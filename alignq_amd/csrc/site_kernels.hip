@@ -531,6 +531,18 @@ int alignq_site_partials_res(const float* x, int B, int64_t F, int k, float act_
   return launch_partials1(true, g, x, B, F, k, act_range, eps, y, stats, (float*)ws, (hipStream_t)stream, residual, relu);
 }
 
+// The same with the training-mode batch-norm in front of the quantiser folded in (channels-last: channel = f mod C, C a power
+// of two): the kernel reads the convolution's output z and applies x = a*z + b on load (ab from alignq_bnq_stats).
+int alignq_site_partials_res_ab(const float* z, const float* ab, int C, int B, int64_t F, int k, float act_range, float eps,
+                                const float* residual, int relu, float* y, float* stats, void* ws, void* stream) {
+  if (!z || !ab || !ws || !y || C < 1 || (C & (C - 1)) != 0 || F % C != 0) return ALIGNQ_EINVAL;
+  if (bad_shape(B, F)) return F <= 0 ? ALIGNQ_EINVAL : ALIGNQ_EUNSUPPORTED;
+  if (bad_k(k)) return ALIGNQ_EINVAL;
+  const Geom g = geom(B, F);
+  if (g.nb != 1) return ALIGNQ_EUNSUPPORTED;
+  return launch_partials1(true, g, z, B, F, k, act_range, eps, y, stats, (float*)ws, (hipStream_t)stream, residual, relu, ab, C);
+}
+
 int alignq_site_reduce(const void* ws, int B, int64_t F, float* D, void* stream) {
   if (!ws || !D) return ALIGNQ_EINVAL;
   if (bad_shape(B, F)) return F <= 0 ? ALIGNQ_EINVAL : ALIGNQ_EUNSUPPORTED;
@@ -667,6 +679,16 @@ int alignq_site_bwd_apply(const float* g, const float* S, const float* x, const 
   if (!S || !x || !stats || !dx) return ALIGNQ_EINVAL;
   if (bad_shape(B, F)) return F <= 0 ? ALIGNQ_EINVAL : ALIGNQ_EUNSUPPORTED;
   return launch_bwd<true>(geom(B, F), g, S, x, stats, B, F, act_range, eps, dx, (hipStream_t)stream);
+}
+
+// backward of alignq_site_partials_res_ab: dx w.r.t. the batch-norm OUTPUT x = a*z + b (B <= 32); alignq_bnq_bwd_dx turns it
+// into dz, dgamma, dbeta
+int alignq_site_bwd_apply_ab(const float* g, const float* S, const float* z, const float* ab, int C, const float* stats, int B,
+                             int64_t F, float act_range, float eps, float* dx, void* stream) {
+  if (!S || !z || !ab || !stats || !dx || C < 1 || (C & (C - 1)) != 0 || F % C != 0) return ALIGNQ_EINVAL;
+  if (bad_shape(B, F)) return F <= 0 ? ALIGNQ_EINVAL : ALIGNQ_EUNSUPPORTED;
+  if (geom(B, F).nb != 1) return ALIGNQ_EUNSUPPORTED;
+  return launch_bwd1(true, g, S, z, stats, B, F, act_range, eps, dx, (hipStream_t)stream, ab, C);
 }
 
 int alignq_site_bwd_fused(const float* g, const float* D, const float* alterD, const float* gamma, int dim,

@@ -591,11 +591,149 @@ class BNQuantReluFn(torch.autograd.Function):
         return dz, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
-def bnq_fusable(bn, act, z) -> bool:
+def _bn_nhwc_ok(bn, z) -> bool:
     C = z.shape[1] if z.dim() == 4 else 0
-    return (bn.training and z.is_cuda and z.dtype == torch.float32 and z.dim() == 4 and _is_nhwc(z) and act.a_bit < 32
-            and 4 <= C <= 1024 and (C & (C - 1)) == 0 and bn.track_running_stats and bn.momentum is not None
+    return (bn.training and z.is_cuda and z.dtype == torch.float32 and z.dim() == 4 and _is_nhwc(z)
+            and 4 <= C <= 2048 and (C & (C - 1)) == 0 and bn.track_running_stats and bn.momentum is not None
             and z.shape[0] * z.shape[2] * z.shape[3] >= 2)
+
+
+def bnq_fusable(bn, act, z) -> bool:
+    return _bn_nhwc_ok(bn, z) and act.a_bit < 32
+
+
+class BNAffineFn(torch.autograd.Function):
+    """Training-mode nn.BatchNorm2d alone on a channels-last tensor (the Office bottleneck's downsample branch,
+    dann_office/model/resnet.py:122-126): alignq_bnq_stats + alignq_bnq_affine forward, alignq_bnq_bwd_dx backward."""
+
+    @staticmethod
+    def forward(ctx, z, weight, bias, running_mean, running_var, nbt, momentum, bn_eps):
+        z = L.dense_f32(z, "conv output")
+        B, C, H, W = z.shape
+        lib, dev, P = L.load(), z.device, B * H * W
+        ab = torch.empty(2, C, dtype=torch.float32, device=dev)
+        save = torch.empty(2, C, dtype=torch.float32, device=dev)
+        y = torch.empty_like(z)
+        ws = torch.empty(lib.alignq_bnq_ws_bytes(C), dtype=torch.uint8, device=dev)
+        st = L.stream_ptr()
+        L.check(lib.alignq_bnq_stats(L.ptr(z), P, C, L.ptr(weight), L.ptr(bias), L.ptr(running_mean), L.ptr(running_var),
+                                     L.ptr(nbt), float(momentum), float(bn_eps), L.ptr(ab), L.ptr(save), L.ptr(ws), st),
+                "alignq_bnq_stats")
+        L.check(lib.alignq_bnq_affine(L.ptr(z), L.ptr(ab), P, C, L.ptr(y), st), "alignq_bnq_affine")
+        ctx.save_for_backward(z, ab, save)
+        ctx.has = (weight is not None, bias is not None)
+        ctx.mark_non_differentiable(*[t for t in (running_mean, running_var, nbt) if t is not None])
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        z, ab, save = ctx.saved_tensors
+        B, C, H, W = z.shape
+        g = L.like_layout(g, z)
+        lib = L.load()
+        dz = torch.empty_like(z)
+        dgamma = torch.empty(C, dtype=torch.float32, device=z.device) if ctx.has[0] else None
+        dbeta = torch.empty(C, dtype=torch.float32, device=z.device) if ctx.has[1] else None
+        ws = torch.empty(lib.alignq_bnq_ws_bytes(C), dtype=torch.uint8, device=z.device)
+        L.check(lib.alignq_bnq_bwd_dx(L.ptr(g), L.ptr(z), L.ptr(ab), L.ptr(save), B * H * W, C, L.ptr(dz), L.ptr(dgamma),
+                                      L.ptr(dbeta), L.ptr(ws), L.stream_ptr()), "alignq_bnq_bwd_dx")
+        return dz, dgamma, dbeta, None, None, None, None, None
+
+
+def bn_only(bn, z):
+    """bn(z): the folded-family kernels when the tensor is channels-last fp32 in training mode, else the module itself."""
+    if not _bn_nhwc_ok(bn, z):
+        return bn(z)
+    return BNAffineFn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum, bn.eps)
+
+
+class BNSite1Fn(torch.autograd.Function):
+    """The Office bottleneck's tail with its batch-norm folded in (batches <= 32, channels-last):
+        out, loss = act_q3(bn3(z)); out += identity; out = relu(out)          (dann_office/model/resnet.py:146-154)
+    forward : alignq_bnq_stats (one read of z) -> alignq_site_partials_res_ab (x = a*z + b on load: quantise, both Grams,
+              + residual, ReLU) -> alignq_site_reduce_loss; bn3's output is never written;
+    backward: ReLU mask -> alignq_site_prep_fused -> alignq_site_bwd_apply_ab (dx w.r.t. the batch-norm output) ->
+              alignq_bnq_bwd_dx in place (dz, dgamma, dbeta)."""
+
+    @staticmethod
+    def forward(ctx, z, weight, bias, running_mean, running_var, nbt, momentum, bn_eps, residual, alterD, gamma, k,
+                act_range, eps, mu, rho):
+        z = L.dense_f32(z, "conv output")
+        A, Gm = L.dev_f32(alterD, "alterD"), L.dev_f32(gamma, "gamma")
+        B, C, H, W = z.shape
+        F, P = C * H * W, B * H * W
+        lib, dev = L.load(), z.device
+        if B > A.shape[0]:
+            raise RuntimeError(f"batch {B} larger than ADMM dim {A.shape[0]}")
+        ab = torch.empty(2, C, dtype=torch.float32, device=dev)
+        save = torch.empty(2, C, dtype=torch.float32, device=dev)
+        ws_bn = torch.empty(lib.alignq_bnq_ws_bytes(C), dtype=torch.uint8, device=dev)
+        st = L.stream_ptr()
+        L.check(lib.alignq_bnq_stats(L.ptr(z), P, C, L.ptr(weight), L.ptr(bias), L.ptr(running_mean), L.ptr(running_var),
+                                     L.ptr(nbt), float(momentum), float(bn_eps), L.ptr(ab), L.ptr(save), L.ptr(ws_bn), st),
+                "alignq_bnq_stats")
+        if residual is not None:
+            residual = L.like_layout(L.dense_f32(residual, "residual"), z)
+        y = torch.empty_like(z)
+        stats = torch.empty(4, F, dtype=torch.float32, device=dev)
+        D = torch.empty(B, B, dtype=torch.float32, device=dev)
+        scal = torch.empty(4, dtype=torch.float32, device=dev)
+        from .ops import _ws
+        ws = _ws(lib.alignq_site_ws_bytes(B, F), dev)
+        L.check(lib.alignq_site_partials_res_ab(L.ptr(z), L.ptr(ab), C, B, F, int(k), float(act_range), float(eps),
+                                                L.ptr(residual), 1, L.ptr(y), L.ptr(stats), L.ptr(ws), st),
+                "alignq_site_partials_res_ab")
+        L.check(lib.alignq_site_reduce_loss(L.ptr(ws), B, F, L.ptr(D), L.ptr(A), L.ptr(Gm), A.shape[0], float(mu), float(rho),
+                                            L.ptr(scal), st), "alignq_site_reduce_loss")
+        ctx.save_for_backward(z, y, ab, save, stats, D, A, Gm, scal)
+        ctx.cfg = (float(act_range), float(eps), float(mu), weight is not None, bias is not None, residual is not None)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(D, *[t for t in (running_mean, running_var, nbt) if t is not None])
+        return y, scal[0], D
+
+    @staticmethod
+    def backward(ctx, g_y, g_loss, _gD):
+        z, y, ab, save, stats, D, A, Gm, scal = ctx.saved_tensors
+        act_range, eps, mu, has_w, has_b, has_res = ctx.cfg
+        B, C, H, W = z.shape
+        F, P = C * H * W, B * H * W
+        lib, dev = L.load(), z.device
+        st = L.stream_ptr()
+        g_m = None
+        if g_y is not None:
+            g_m = torch.ops.aten.threshold_backward(L.like_layout(g_y, z), y, 0.0)      # the fused ReLU's mask
+        if g_loss is None:
+            g_loss = torch.zeros((), dtype=torch.float32, device=dev)
+        g_loss = L.dev_f32(g_loss, "loss grad")
+        dA, dG = torch.empty_like(A), torch.empty_like(Gm)
+        from .ops import _ws
+        S = _ws(lib.alignq_site_bwd_ws_bytes(B), dev)
+        L.check(lib.alignq_site_prep_fused(L.ptr(D), L.ptr(A), L.ptr(Gm), A.shape[0], L.ptr(scal), mu, L.ptr(g_loss), B, F,
+                                           L.ptr(S), L.ptr(dA), L.ptr(dG), st), "alignq_site_prep_fused")
+        dx = torch.empty_like(z)
+        L.check(lib.alignq_site_bwd_apply_ab(L.ptr(g_m), L.ptr(S), L.ptr(z), L.ptr(ab), C, L.ptr(stats), B, F, act_range, eps,
+                                             L.ptr(dx), st), "alignq_site_bwd_apply_ab")
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev) if has_w else None
+        dbeta = torch.empty(C, dtype=torch.float32, device=dev) if has_b else None
+        ws_bn = torch.empty(lib.alignq_bnq_ws_bytes(C), dtype=torch.uint8, device=dev)
+        L.check(lib.alignq_bnq_bwd_dx(L.ptr(dx), L.ptr(z), L.ptr(ab), L.ptr(save), P, C, L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta),
+                                      L.ptr(ws_bn), st), "alignq_bnq_bwd_dx")
+        return (dx, dgamma, dbeta, None, None, None, None, None, g_m if has_res else None, dA, dG, None, None, None, None, None)
+
+
+def bn_site_res_relu(bn, act, z, residual, eps):
+    """(relu(act(bn(z))[0] + residual), loss) for an ADMM site at a batch of at most 32 rows: the folded chain when the tensor
+    is channels-last fp32 in training mode (and no deferred-loss context is active), else None (the caller composes it)."""
+    from . import config
+    if not (_bn_nhwc_ok(bn, z) and 2 <= z.shape[0] <= 32 and act.a_bit < 32 and config.args.method == "ours"
+            and active_deferred() is None and residual is not None and residual.shape == z.shape and residual.is_cuda
+            and residual.dtype == torch.float32 and z.shape[0] <= act.opt.alterD.shape[0]):
+        return None
+    admm = act.opt
+    y, loss, D = BNSite1Fn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum,
+                                 bn.eps, residual, admm.alterD, admm.gamma, act.a_bit, config.args.act_range, eps, admm.mu, admm.rho)
+    admm.D = D
+    return y, loss
 
 
 def bn_act_relu(bn, act, z, formula, relu=True):

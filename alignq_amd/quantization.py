@@ -204,6 +204,13 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
             """(relu(self(x)[0] + residual), loss) (not part of the reference's interface: an opt-in for the caller)."""
             return _site_act_res_relu(self, x, residual)
 
+        def forward_bn_res_relu(self, bn, z, residual):
+            """(relu(self(bn(z))[0] + residual), loss) with the training-mode batch-norm folded into the small-batch site
+            kernels where that applies (SURVEY.md §8f-N1 on the Office path), else the composition."""
+            from . import fused
+            out = fused.bn_site_res_relu(bn, self, z, residual, eps)
+            return out if out is not None else _site_act_res_relu(self, bn(z), residual)
+
     def corr(x, y):
         """corr(x, y) -> [B,B] (ADMM tree :134-137; Office :158-161).  The reference only ever calls it with y is x: that
         is the SYRK served by the fused MFMA kernels; any other y takes the general exact-fp32 kernels."""

@@ -56,6 +56,12 @@ class Bottleneck(nn.Module):
         else:
             out = self.relu(self.act_q1(self.bn1(self.conv1(x))))
             out = self.relu(self.act_q2(self.bn2(self.conv2(out))))
+        if getattr(self, "fuse_bn", False):         # bn3 folded into the site kernels, the downsample batch-norm on the same family
+            if self.downsample is not None:
+                from . import fused
+                identity = fused.bn_only(self.downsample[1], self.downsample[0](x))
+            out, loss = self.act_q3.forward_bn_res_relu(self.bn3, self.conv3(out), identity)
+            return out, trans_loss + loss
         if getattr(self, "fuse_relu", False):       # `out += identity; relu` inside the site kernels
             z = self.bn3(self.conv3(out))
             if self.downsample is not None:

@@ -400,7 +400,7 @@ int alignq_bn_partial_stats_nhwc(const float* z, int B, int C, int HW, void* ws,
 /* ---- batch-norm folded into the PLAIN quantiser (+ ReLU), channels-last, any batch (SURVEY.md §8f-N1 on configuration 5;
  * caller: out = relu(act_q1(bn1(conv1(x)))) of the Office bottleneck, cdf_alignment_admm/dann_office/model/resnet.py:134-143,
  * stem :230-233; quantiser model/quantization.py:87-110) ----
- * z: the convolution's output viewed as [P, C], P = B*H*W pixels, channels fastest (torch.channels_last); C = 4 * 2^j <= 1024
+ * z: the convolution's output viewed as [P, C], P = B*H*W pixels, channels fastest (torch.channels_last); C = 4 * 2^j <= 2048
  * (ALIGNQ_EUNSUPPORTED otherwise).  Training-mode nn.BatchNorm2d semantics (biased batch variance for the normalisation,
  * running statistics updated with momentum and the unbiased variance, *num_batches_tracked += 1; any of the three NULL).
  * alignq_bnq_fwd (3 launches): per-channel statistics of z -> ab = {a[C], b[C]} (a = gamma*invstd, b = beta - mean*a),
@@ -409,6 +409,24 @@ int alignq_bn_partial_stats_nhwc(const float* z, int B, int C, int HW, void* ws,
  * alignq_bnq_bwd (3 launches): dx = g * [y > 0] * dt/dx (y = the forward's output, required when relu), then the batch-norm
  *   backward dz = a*(dx - mean dx - zhat*mean(dx*zhat)), dgamma = sum dx*zhat, dbeta = sum dx (28 B/element instead of ~36).
  * ws: alignq_bnq_ws_bytes(C).                                                                                               */
+/* The batch-norm of that family WITHOUT a quantiser behind it in the same chain (C <= 2048):
+ * alignq_bnq_stats: statistics + finalisation only -> ab, save (+ running statistics): what a consumer that applies
+ *   x = a*z + b itself needs (alignq_site_partials_res_ab below: bn3 in front of the bottleneck's ADMM site, resnet.py:146-150);
+ * alignq_bnq_affine: y = a*z + b (the downsample branch's batch-norm, resnet.py:122-126 / :151-152);
+ * alignq_bnq_bwd_dx: batch-norm backward for a GIVEN dx (gradient w.r.t. the batch-norm output): dz, dgamma, dbeta; dz may
+ *   alias dx.
+ * alignq_site_partials_res_ab / alignq_site_bwd_apply_ab (B <= 32): alignq_site_partials_res / alignq_site_bwd_apply reading
+ *   z and applying the affine on load (channel = f mod C); the backward's dx is w.r.t. x = a*z + b.                          */
+int alignq_bnq_stats(const float* z, int64_t P, int C, const float* gamma, const float* beta, float* running_mean,
+                     float* running_var, int64_t* num_batches_tracked, float momentum, float bn_eps, float* ab, float* save,
+                     void* ws, void* stream);
+int alignq_bnq_affine(const float* z, const float* ab, int64_t P, int C, float* y, void* stream);
+int alignq_bnq_bwd_dx(const float* dx, const float* z, const float* ab, const float* save, int64_t P, int C, float* dz,
+                      float* dgamma, float* dbeta, void* ws, void* stream);
+int alignq_site_partials_res_ab(const float* z, const float* ab, int C, int B, int64_t F, int k, float act_range, float eps,
+                                const float* residual, int relu, float* y, float* stats, void* ws, void* stream);
+int alignq_site_bwd_apply_ab(const float* g, const float* S, const float* z, const float* ab, int C, const float* stats, int B,
+                             int64_t F, float act_range, float eps, float* dx, void* stream);
 size_t alignq_bnq_ws_bytes(int C);
 int alignq_bnq_fwd(const float* z, int64_t P, int C, const float* gamma, const float* beta, float* running_mean,
                    float* running_var, int64_t* num_batches_tracked, float momentum, float bn_eps, int k, float act_range,

@@ -220,3 +220,89 @@ def test_bn_folded_plain_quantiser_vs_oracle_and_torch_batchnorm(dev, B, C, H, k
         assert float((y2 - y.detach()).abs().max()) <= 1.0 / n + 1e-6
     finally:
         config.args.abitW = old
+
+
+@pytest.mark.parametrize("B,C,H,k", [(28, 256, 14, 8), (28, 2048, 7, 8), (6, 64, 8, 4), (28, 256, 56, 8)])
+def test_bn_folded_small_batch_admm_site_vs_oracle(dev, B, C, H, k):
+    """The Office bottleneck's tail with bn3 folded into the small-batch site kernels (fused.BNSite1Fn: alignq_bnq_stats ->
+    alignq_site_partials_res_ab -> alignq_site_reduce_loss; backward alignq_site_bwd_apply_ab -> alignq_bnq_bwd_dx) against
+    the C oracle's oq_bn_site_fwd / _bwd (pinned to torch.nn.BatchNorm2d + the golden-pinned site on the CPU), channels-last,
+    eps 1e-5, batch 28 at the network's own shapes: y exact outside a near-tie band ((a, b) differ by ~1e-6 from the oracle's),
+    D / loss / dz / dgamma / dbeta / dresidual / dalterD / dgamma_admm within 1e-5."""
+    import alignq_amd.office as NO
+    from alignq_amd import config
+    rng = np.random.default_rng(B + C + H)
+    r, eps = 2.0, 1e-5
+    old = (config.args.abitW, config.args.train_batch_size)
+    config.args.abitW, config.args.train_batch_size = k, B
+    try:
+        z0 = (rng.standard_normal((B, C, H, H)) * 1.4 + 0.3).astype(np.float32)
+        res0 = np.maximum(rng.standard_normal((B, C, H, H)), 0).astype(np.float32)
+        gy0 = (rng.standard_normal((B, C, H, H)) * 1e-2).astype(np.float32)
+        gam = (rng.random(C) + 0.5).astype(np.float32)
+        bet = (rng.standard_normal(C) * 0.2).astype(np.float32)
+        bn = torch.nn.BatchNorm2d(C).to(dev).train()
+        with torch.no_grad():
+            bn.weight.copy_(cu(gam, dev)); bn.bias.copy_(cu(bet, dev))
+        admm = NO.ADMM(B).to(dev)
+        A0, G0 = npy(admm.alterD), npy(admm.gamma)
+        act = NO.activation_quantize_fn2(k, "aligned", admm).to(dev)
+        cl = lambda a: cu(a, dev).contiguous(memory_format=torch.channels_last)      # noqa: E731
+        z, res = cl(z0).requires_grad_(True), cl(res0).requires_grad_(True)
+        from alignq_amd import fused
+        assert fused.bn_site_res_relu.__name__ and fused._bn_nhwc_ok(bn, z)
+        y, loss = act.forward_bn_res_relu(bn, z, res)
+        torch.autograd.backward([y, loss], [cl(gy0), torch.ones((), device=dev)])
+        mem = lambda a: np.ascontiguousarray(a.transpose(0, 2, 3, 1)).reshape(B, -1)     # noqa: E731
+        unmem = lambda a: a.reshape(B, H, H, C).transpose(0, 3, 1, 2)                     # noqa: E731
+        zm, rm_, gm = mem(z0), mem(res0), mem(gy0)
+        ab_o, save_o, _ = O.bn_fold_ab(zm, C, 1, gam, bet, 1e-5)
+        y_o, D_o, x_o = O.bn_site_fwd(zm, C, 1, ab_o, k, r, eps, residual=rm_, relu=True)
+        n = 2 ** k - 1
+        _, t_o, _ = O.act_quant_fwd(x_o, k, r, O.FORMULA_ADMM)
+        frac = t_o.astype(np.float64) * n
+        near_tie = np.abs(frac - np.floor(frac) - 0.5) < 2e-3
+        diff = np.abs(mem(npy(y)) - y_o) * n
+        assert np.all(diff[~near_tie] < 1e-3), int(np.count_nonzero(diff[~near_tie] >= 1e-3))
+        assert np.all(diff[near_tie] <= 1.0 + 1e-3)
+        np.testing.assert_allclose(npy(admm.D), D_o, atol=TOL, rtol=0)
+        ol, odD, odA, odG = O.admm_loss(D_o, A0, G0, 0.2, 0.3)
+        np.testing.assert_allclose(float(loss.detach()), ol, atol=TOL)
+        dz_o, dg_o, db_o, dres_o, _ = O.bn_site_bwd(gm, odD, zm, C, 1, ab_o, save_o, mem(npy(y)), r, eps)
+        np.testing.assert_allclose(mem(npy(z.grad)), dz_o, atol=TOL, rtol=1e-4)
+        np.testing.assert_allclose(mem(npy(res.grad)), dres_o, atol=1e-7, rtol=0)
+        scale = np.sqrt(B * H * H)
+        np.testing.assert_allclose(npy(bn.weight.grad), dg_o, atol=2e-6 * scale, rtol=1e-4)
+        np.testing.assert_allclose(npy(bn.bias.grad), db_o, atol=2e-6 * scale, rtol=1e-4)
+        np.testing.assert_allclose(npy(admm.alterD.grad), odA, atol=1e-7, rtol=1e-4)
+        np.testing.assert_allclose(npy(admm.gamma.grad), odG, atol=1e-7, rtol=1e-4)
+        assert int(bn.num_batches_tracked) == 1
+    finally:
+        config.args.abitW, config.args.train_batch_size = old
+
+
+def test_bn_alone_on_the_folded_family_vs_torch(dev):
+    """fused.bn_only (the downsample branch's batch-norm: alignq_bnq_stats + _affine, backward alignq_bnq_bwd_dx) against
+    torch.nn.BatchNorm2d in float64 on the CPU, C = 2048 (the 512-thread instantiation) and C = 256."""
+    from alignq_amd import fused
+    for B, C, H in ((28, 2048, 7), (28, 256, 56)):
+        rng = np.random.default_rng(C)
+        z0 = (rng.standard_normal((B, C, H, H)) * 2.0 - 0.7).astype(np.float32)
+        g0 = rng.standard_normal((B, C, H, H)).astype(np.float32)
+        bn = torch.nn.BatchNorm2d(C).to(dev).train()
+        ref = torch.nn.BatchNorm2d(C).double().train()
+        with torch.no_grad():
+            w = torch.rand(C) + 0.5; b_ = torch.randn(C) * 0.1
+            bn.weight.copy_(w.to(dev)); bn.bias.copy_(b_.to(dev)); ref.weight.copy_(w.double()); ref.bias.copy_(b_.double())
+        z = cu(z0, dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        y = fused.bn_only(bn, z)
+        y.backward(cu(g0, dev).contiguous(memory_format=torch.channels_last))
+        zc = torch.from_numpy(z0).double().requires_grad_(True)
+        yr = ref(zc)
+        yr.backward(torch.from_numpy(g0).double())
+        np.testing.assert_allclose(npy(y), yr.detach().float().numpy(), atol=2e-5, rtol=1e-5)
+        np.testing.assert_allclose(npy(z.grad), zc.grad.float().numpy(), atol=2e-5, rtol=1e-4)
+        s = np.sqrt(B * H * H)
+        np.testing.assert_allclose(npy(bn.weight.grad), ref.weight.grad.float().numpy(), atol=2e-5 * s, rtol=1e-4)
+        np.testing.assert_allclose(npy(bn.bias.grad), ref.bias.grad.float().numpy(), atol=2e-5 * s, rtol=1e-4)
+        np.testing.assert_allclose(npy(bn.running_var), ref.running_var.float().numpy(), atol=1e-6, rtol=1e-5)
