@@ -545,8 +545,63 @@ def gen_tiny_resnet_sites():
     _save("g8b_tiny_resnet_sites", **out)
 
 
+def gen_office_bottleneck_sites():
+    """G13: the Office tree's counterpart of G8b.  The tiny DANN of G10 (same det_init, same first source
+    batch) with forward hooks on ONE Bottleneck (feature.layer4[0]: downsample branch, 2048 output channels) recording, in
+    model context (dann_office/model/resnet.py:131-156): the inputs of bn1 / bn2 / bn3 (the convolutions' outputs), the
+    batch-norm parameters, the inputs and outputs of act_q1 / act_q2 (plain quantisers) and of act_q3 (the ADMM site: x_q,
+    trans loss, D, alterD, gamma), the downsample branch's output and the block's output.  The GPU tests teacher-force these
+    inputs through the HIP paths (plain, ReLU-fused and batch-norm-folded)."""
+    import importlib
+    import torch
+    sys.path.insert(0, HERE)
+    from det_init import det_init_
+    q, args = _enter("office", ["--bitW", "4", "--abitW", "4", "--train_batch_size", "6"])
+    r = importlib.import_module("model.resnet")
+    r.device = torch.device("cpu")
+    torch.manual_seed(0)
+    net = r.DANN(lambda w, a, s: r.ResNet(w, a, s, r.Bottleneck, [1, 1, 1, 1], width_per_group=8), 4, 4, args.stage)
+    net.train()
+    det_init_(net)
+    g = torch.Generator().manual_seed(31)
+    xs = torch.randn(2, 6, 3, 64, 64, generator=g)          # G10's generator stream: xs[0] is its first source batch
+    blk = net.feature.layer4[0]
+    rec = {}
+
+    def bn_hook(name):
+        def fn(mod, inp, out):
+            rec[name + "/z"] = _np(inp[0])
+            rec[name + "/out"] = _np(out)
+            rec[name + "/weight"], rec[name + "/bias"] = _np(mod.weight), _np(mod.bias)
+            rec[name + "/running_mean"], rec[name + "/running_var"] = _np(mod.running_mean), _np(mod.running_var)
+            rec[name + "/eps"], rec[name + "/momentum"] = np.array(mod.eps), np.array(mod.momentum)
+        return fn
+
+    def act_hook(name):
+        def fn(mod, inp, out):
+            rec[name + "/x"] = _np(inp[0])
+            if isinstance(out, tuple):
+                rec[name + "/xq"], rec[name + "/loss"] = _np(out[0]), _np(out[1])
+                rec[name + "/D"], rec[name + "/alterD"], rec[name + "/gamma"] = _np(mod.opt.D), _np(mod.opt.alterD), _np(mod.opt.gamma)
+            else:
+                rec[name + "/xq"] = _np(out)          # (before the in-place ReLU that follows)
+        return fn
+    hs = [blk.bn1.register_forward_hook(bn_hook("bn1")), blk.bn2.register_forward_hook(bn_hook("bn2")),
+          blk.bn3.register_forward_hook(bn_hook("bn3")), blk.downsample[1].register_forward_hook(bn_hook("bnd")),
+          blk.act_q1.register_forward_hook(act_hook("q1")), blk.act_q2.register_forward_hook(act_hook("q2")),
+          blk.act_q3.register_forward_hook(act_hook("q3")),
+          blk.register_forward_hook(lambda m, i, o: rec.__setitem__("block/out", _np(o[0])))]
+    net(xs[0], alpha=0.5)
+    for h in hs:
+        h.remove()
+    out = {"k": np.array(4), "act_range": np.array(float(args.act_range), dtype=np.float32), "stage": np.array(str(args.stage))}
+    out.update(rec)
+    _save("g13_office_bottleneck_sites", **out)
+
+
 GEN = {"admm_cifar": gen_admm_cifar, "cdf_only": gen_cdf_only, "office": gen_office, "office_keys": gen_office_keys,
-       "corr_xy_admm": gen_corr_xy_admm, "corr_xy_office": gen_corr_xy_office, "office_tiny_dann": gen_office_tiny_dann, "tiny_resnet_sites": gen_tiny_resnet_sites}
+       "corr_xy_admm": gen_corr_xy_admm, "corr_xy_office": gen_corr_xy_office, "office_tiny_dann": gen_office_tiny_dann, "tiny_resnet_sites": gen_tiny_resnet_sites,
+       "office_bottleneck_sites": gen_office_bottleneck_sites}
 
 
 def main():

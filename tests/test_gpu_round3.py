@@ -306,3 +306,72 @@ def test_bn_alone_on_the_folded_family_vs_torch(dev):
         np.testing.assert_allclose(npy(bn.weight.grad), ref.weight.grad.float().numpy(), atol=2e-5 * s, rtol=1e-4)
         np.testing.assert_allclose(npy(bn.bias.grad), ref.bias.grad.float().numpy(), atol=2e-5 * s, rtol=1e-4)
         np.testing.assert_allclose(npy(bn.running_var), ref.running_var.float().numpy(), atol=1e-6, rtol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ VERDICT r2 item 2b (G13)
+def test_teacher_forced_office_bottleneck_on_the_hip_paths(dev):
+    """G13: what the reference's own Bottleneck (inside the tiny DANN of G10; dann_office/model/resnet.py:131-156) fed to and
+    got from its three quantiser sites, its batch-norms and its downsample branch.  Teacher-forced through the HIP paths:
+    plain quantiser (bins exact outside the tie zone), quantiser + ReLU, the ADMM site with the eps corr (x_q, D, trans
+    loss to 1e-5), and the batch-norm-FOLDED forms of all three plus the downsample batch-norm, which must reproduce the
+    reference's tensors from the convolutions' outputs (exact outside a near-tie band; the block's output within one level)."""
+    from tests.conftest import load_golden
+    import alignq_amd.office as NO
+    from alignq_amd import config, fused
+    g = load_golden("g13_office_bottleneck_sites")
+    k, r = int(g["k"]), float(g["act_range"])
+    n = 2 ** k - 1
+    B = g["q3/x"].shape[0]
+    old = (config.args.abitW, config.args.train_batch_size)
+    config.args.abitW, config.args.train_batch_size = k, B
+    try:
+        def tie_mask(x, band):
+            _, t, _ = O.act_quant_fwd(np.ascontiguousarray(x).reshape(-1), k, r, O.FORMULA_ADMM)
+            frac = t.astype(np.float64) * n
+            return (np.abs(frac - np.floor(frac) - 0.5) < band).reshape(x.shape)
+
+        def check_levels(got, want, tie, what):
+            diff = np.abs(got - want) * n
+            assert np.all(diff[~tie] < 1e-3), (what, int(np.count_nonzero(diff[~tie] >= 1e-3)))
+            assert np.all(diff[tie] <= 1.0 + 1e-3), what
+        cl = lambda a: cu(a, dev).contiguous(memory_format=torch.channels_last)      # noqa: E731
+
+        def make_bn(name):
+            C = g[f"{name}/weight"].shape[0]
+            bn = torch.nn.BatchNorm2d(C, eps=float(g[f"{name}/eps"]), momentum=float(g[f"{name}/momentum"])).to(dev).train()
+            with torch.no_grad():
+                bn.weight.copy_(cu(g[f"{name}/weight"], dev)); bn.bias.copy_(cu(g[f"{name}/bias"], dev))
+            return bn
+        # ---- the two plain sites
+        for q, bnn in (("q1", "bn1"), ("q2", "bn2")):
+            act = NO.activation_quantize_fn(k, str(g["stage"])).to(dev)
+            x = g[f"{q}/x"]
+            check_levels(npy(act(cu(x, dev))), g[f"{q}/xq"], tie_mask(x, 1e-4), q)
+            check_levels(npy(act.forward_relu(cl(x))), np.maximum(g[f"{q}/xq"], 0), tie_mask(x, 1e-4), q + " relu")
+            bn = make_bn(bnn)
+            y = act.forward_bn_relu(bn, cl(g[f"{bnn}/z"]))          # folded: from the convolution's output
+            check_levels(npy(y), np.maximum(g[f"{q}/xq"], 0), tie_mask(x, 2e-3), q + " folded")
+            np.testing.assert_allclose(npy(bn.running_mean), g[f"{bnn}/running_mean"], atol=1e-6)
+            np.testing.assert_allclose(npy(bn.running_var), g[f"{bnn}/running_var"], atol=1e-5, rtol=1e-5)
+        # ---- the ADMM site
+        admm = NO.ADMM(B).to(dev)
+        with torch.no_grad():
+            admm.alterD.copy_(cu(g["q3/alterD"], dev)); admm.gamma.copy_(cu(g["q3/gamma"], dev))
+        act3 = NO.activation_quantize_fn2(k, str(g["stage"]), admm).to(dev)
+        xq, loss = act3(cu(g["q3/x"], dev))
+        check_levels(npy(xq), g["q3/xq"], tie_mask(g["q3/x"], 1e-4), "q3")
+        np.testing.assert_allclose(npy(admm.D), g["q3/D"], atol=TOL)
+        np.testing.assert_allclose(float(loss), float(g["q3/loss"]), atol=TOL)
+        # ---- downsample batch-norm alone, then the folded tail: relu(act_q3(bn3(z))[0] + identity)
+        bnd = make_bn("bnd")
+        idn = fused.bn_only(bnd, cl(g["bnd/z"]))
+        np.testing.assert_allclose(npy(idn), g["bnd/out"], atol=3e-5, rtol=1e-5)
+        bn3 = make_bn("bn3")
+        out, loss2 = act3.forward_bn_res_relu(bn3, cl(g["bn3/z"]), cl(g["bnd/out"]))
+        tie3 = tie_mask(g["q3/x"], 2e-3)
+        diff = np.abs(npy(out) - g["block/out"]) * n
+        assert np.all(diff[~tie3] < 2e-3) and np.all(diff[tie3] <= 1.0 + 2e-3)
+        np.testing.assert_allclose(npy(admm.D), g["q3/D"], atol=TOL)
+        np.testing.assert_allclose(float(loss2), float(g["q3/loss"]), atol=TOL)
+    finally:
+        config.args.abitW, config.args.train_batch_size = old

@@ -311,3 +311,35 @@ def test_teacher_forced_sites_of_the_tiny_resnet():
         np.testing.assert_allclose(D, g[f"{name}/D"], atol=TOL, rtol=0)
         loss, _, _, _ = O.admm_loss(D, g[f"{name}/alterD"], g[f"{name}/gamma"], 0.2, 0.3)
         np.testing.assert_allclose(loss, g[f"{name}/loss"], atol=TOL)
+
+
+def test_office_bottleneck_sites_fixture_vs_oracle():
+    """G13 (captured from the reference's own Bottleneck inside the tiny DANN, dann_office/model/resnet.py:131-156): the C
+    oracle on the recorded site inputs — plain quantisers act_q1 / act_q2 (bins exact outside the tie zone), the ADMM site
+    act_q3 with the Office tree's eps corr (x_q, D, trans loss), and the batch-norm fold's (a, b) / affine against the
+    reference's own BatchNorm2d output."""
+    g = load_golden("g13_office_bottleneck_sites")
+    k, r = int(g["k"]), float(g["act_range"])
+    n = 2 ** k - 1
+    for name in ("q1", "q2", "q3"):
+        x = g[f"{name}/x"]
+        xq, t, _ = O.act_quant_fwd(x.reshape(-1), k, r, O.FORMULA_ADMM)
+        frac = t.astype(np.float64) * n
+        tie = np.abs(frac - np.floor(frac) - 0.5) < 1e-4
+        diff = np.abs(xq - g[f"{name}/xq"].reshape(-1)) * n
+        assert np.all(diff[~tie] == 0) and np.all(diff[tie] <= 1.0 + 1e-3), name
+    B = g["q3/x"].shape[0]
+    _, D = O.site_fwd(g["q3/x"].reshape(B, -1), k, r, 1e-5)
+    np.testing.assert_allclose(D, g["q3/D"], atol=1e-5)
+    loss, _, _, _ = O.admm_loss(D, g["q3/alterD"], g["q3/gamma"], 0.2, 0.3)
+    np.testing.assert_allclose(loss, float(g["q3/loss"]), atol=1e-5)
+    for bn in ("bn1", "bn3", "bnd"):
+        z = g[f"{bn}/z"]
+        C = z.shape[1]
+        zm = np.ascontiguousarray(z.transpose(0, 2, 3, 1)).reshape(z.shape[0], -1)          # channels-last memory order
+        ab, save, vu = O.bn_fold_ab(zm, C, 1, g[f"{bn}/weight"], g[f"{bn}/bias"], float(g[f"{bn}/eps"]))
+        x = O.bn_apply(zm, C, 1, ab).reshape(z.shape[0], z.shape[2], z.shape[3], C).transpose(0, 3, 1, 2)
+        np.testing.assert_allclose(x, g[f"{bn}/out"], atol=3e-5, rtol=1e-5)
+        m = float(g[f"{bn}/momentum"])
+        np.testing.assert_allclose(m * save[0], g[f"{bn}/running_mean"], atol=1e-6)           # running_mean started at 0
+        np.testing.assert_allclose((1 - m) * 1.0 + m * vu, g[f"{bn}/running_var"], atol=1e-5, rtol=1e-5)

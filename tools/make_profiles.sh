@@ -4,9 +4,9 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/prof && mkdir -p gpurun_out/prof
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/stats -o run -- python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-shapes --no-dp-probe > gpurun_out/prof/stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/prof/fetch -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-shapes --no-dp-probe > gpurun_out/prof/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/prof/write -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-shapes --no-dp-probe > gpurun_out/prof/write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/stats -o run -- python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-shapes --no-dp-probe --no-other-configs > gpurun_out/prof/stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/prof/fetch -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-shapes --no-dp-probe --no-other-configs > gpurun_out/prof/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/prof/write -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-shapes --no-dp-probe --no-other-configs > gpurun_out/prof/write.log 2>&1
 find gpurun_out/prof -name "*.csv" | head -20
 # keep the merge-back under the 64 MiB cap: drop the per-dispatch traces of the PMC runs except the counter tables
 find gpurun_out/prof/fetch gpurun_out/prof/write -name "*kernel_trace.csv" -delete

@@ -20,7 +20,7 @@ def one(pattern):
 
 
 # ---- kernel stats -------------------------------------------------------------------------------------------------
-OURS = ("alignq_site", "site_fwd", "site_bwd", "slab_reduce", "site_prep", "bn_stats", "bn_bwd_apply", "bn_finalize", "conv3x3",
+OURS = ("alignq_site", "site_fwd", "site_bwd", "slab_reduce", "site_prep", "bn_stats", "bn_bwd_apply", "bn_finalize", "bnq_", "corrl_", "conv3x3",
         "wgrad", "mt_", "admm_update", "act_quant", "weight_quant", "weight_stats", "uniform_quantize", "sgd_", "admm_loss")
 
 
