@@ -8,7 +8,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "lib", "libalignq_hip.so")
+SO_PATH = os.environ.get("ALIGNQ_SO") or os.path.join(_HERE, "lib", "libalignq_hip.so")   # ALIGNQ_SO: A/B builds of tools/
 
 FORMULA_ADMM, FORMULA_CDF = 0, 1
 MAX_BATCH = 128            # rows the FUSED site kernels hold on chip (ALIGNQ_MAX_BATCH)

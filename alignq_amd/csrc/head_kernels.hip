@@ -83,7 +83,11 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
         // drain, one relaxed agent-scope ticket; the last workgroup reads with agent-scope loads.
         __hip_atomic_store(&loss[b], lb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef ALIGNQ_TICKET_ACQREL
+        const unsigned tk = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+#else
         const unsigned tk = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         is_last = (tk == gridDim.x - 1);
       }
     }

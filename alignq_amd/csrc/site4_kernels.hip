@@ -29,6 +29,18 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int NT = 1024;
 
+// Memory order of the arrival ticket of the last-workgroup epilogues (slab reduction + ADMM loss here, the head's batch mean
+// in head_kernels.hip).  Product: relaxed - the partials are write-through (sc1) stores drained with s_waitcnt vmcnt(0) by the
+// ONE lane that also takes the ticket, the last workgroup reads them with sc1 loads behind a workgroup barrier: the form
+// MI355X_MICROARCH.md lists as measured-valid (its hand-off table, row 1).  -DALIGNQ_TICKET_ACQREL builds the formally
+// ordered variant (release fence = write-back of the XCD's dirty L2 lines before the ticket, acquire after it) for the A/B
+// measurement in DESIGN.md.
+#ifdef ALIGNQ_TICKET_ACQREL
+#define ALIGNQ_TICKET_ORDER __ATOMIC_ACQ_REL
+#else
+#define ALIGNQ_TICKET_ORDER __ATOMIC_RELAXED
+#endif
+
 // Diagnostic build only (-DALIGNQ_STAMPS, never shipped): wall-clock stamps (100 MHz) of workgroup 0 at phase
 // boundaries, written to a buffer no kernel reads.
 #ifdef ALIGNQ_STAMPS
@@ -864,7 +876,7 @@ __device__ __forceinline__ void slab_reduce_body(const float* __restrict__ slabs
         __hip_atomic_store(&parts[blockIdx.x * 4 + 1], v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&parts[blockIdx.x * 4 + 2], v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned tk = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned tk = __hip_atomic_fetch_add(counter, 1u, ALIGNQ_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT);
         is_last = (tk == gridDim.x - 1);
       }
     }

@@ -375,3 +375,34 @@ def test_teacher_forced_office_bottleneck_on_the_hip_paths(dev):
         np.testing.assert_allclose(float(loss2), float(g["q3/loss"]), atol=TOL)
     finally:
         config.args.abitW, config.args.train_batch_size = old
+
+
+# ------------------------------------------------------------------------------------------------ VERDICT r2 item 9
+def test_head_ticket_is_idempotent(dev):
+    """The classifier head's in-kernel batch mean (fused.HeadCEFn: the workgroup whose arrival ticket is last adds the
+    per-sample losses and re-arms the counter): 20 launches on the same inputs, on two different streams' counters, give the
+    same bits every time and the PyTorch mean cross-entropy."""
+    from alignq_amd.fused import HeadCEFn, _head_counter
+    torch.manual_seed(2)
+    B, C, H, K = 128, 64, 8, 10
+    feat = torch.randn(B, C, H, H, device=dev).contiguous(memory_format=torch.channels_last)
+    lin = torch.nn.Linear(C, K).to(dev)
+    y = torch.randint(0, K, (B,), device=dev)
+    want = torch.nn.functional.cross_entropy(lin(feat.mean((2, 3))), y)
+    outs = []
+    side = torch.cuda.Stream()
+    for it in range(20):
+        if it % 2:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                _, ce = HeadCEFn.apply(feat, lin.weight, lin.bias, y)
+            torch.cuda.current_stream().wait_stream(side)
+        else:
+            _, ce = HeadCEFn.apply(feat, lin.weight, lin.bias, y)
+        outs.append(float(ce))
+    torch.cuda.synchronize()
+    assert all(o == outs[0] for o in outs), outs
+    np.testing.assert_allclose(outs[0], float(want), rtol=1e-5)
+    with torch.cuda.stream(side):
+        c_side = _head_counter(dev)
+    assert int(_head_counter(dev)) == 0 and int(c_side) == 0 and c_side.data_ptr() != _head_counter(dev).data_ptr()
