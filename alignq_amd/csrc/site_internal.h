@@ -71,12 +71,12 @@ inline Geom geom(int B, int64_t F) {
   Geom g;
   g.nb = B <= 32 ? 1 : (B <= 64 ? 2 : 4);
   if (g.nb == 4) {
-    // narrower tiles while that still fits one tile per CU: 16 features up to F = 4096, 32 up to 8192, else 64 (only the
-    // 64-feature kernel ever loops over tiles; its one-tile form and the narrow kernels are the latency-tuned ones)
+    // tile width by F (only the 64-feature kernel ever loops over tiles; the one-tile forms are the latency-tuned ones)
     g.tf = (F > 32 * 256) ? 64 : ((F > 16 * 256) ? 32 : 16);
-    // tuning aid (A/B measurements of DESIGN.md): ALIGNQ_FWD_WIDE=1 takes twice as wide tiles for F <= 8192 (128 workgroups:
-    // half the partial-Gram slabs to write and reduce, longer per-tile chains)
-    static const int wide = [] { const char* e = getenv("ALIGNQ_FWD_WIDE"); return e ? atoi(e) : 0; }();
+    // F <= 8192: twice as wide tiles (128 workgroups instead of 256): the step is 0.3 % FASTER (1.172 vs 1.177 ms, A/B on one
+    // box) because half as many partial-Gram slabs are written and reduced (118 instead of 173 MB per ResNet-20 step), which
+    // outweighs the longer per-tile chain of the forward launches; ALIGNQ_FWD_WIDE=0 restores the 256-workgroup rule
+    static const int wide = [] { const char* e = getenv("ALIGNQ_FWD_WIDE"); return e ? atoi(e) : 1; }();
     if (wide && F <= 32 * 256) g.tf = (F > 16 * 256) ? 64 : 32;
     // beyond one 64-feature tile per CU the kernel loops over tiles: two 512-thread workgroups per CU (80 KB of LDS each)
     // (32-feature tiles were tried for this form: 128-byte row segments copy at 4.7-5.3 TB/s against 5.9-6.3 for 256-byte

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     # pure host-side queries are safe without a GPU
     tail = 1024 + 16                                     # loss partials + arrival counter
     assert lib.alignq_site_ws_bytes(128, 16384) == (256 * 8256 + tail) * 4   # 6 off-diagonal 32x32 tiles + 2 packed [32][33] blocks
-    assert lib.alignq_site_ws_bytes(128, 4096) == (256 * 8256 + tail) * 4    # 16-feature tiles keep 256 CUs busy
+    assert lib.alignq_site_ws_bytes(128, 4096) == (128 * 8256 + tail) * 4    # 32-feature tiles: half the slabs (round 3)
     assert lib.alignq_site_ws_bytes(28, 802816) == (2048 * 32 * 32 + tail) * 4
     assert lib.alignq_site_ws_bytes(28, 1024) == (8 * 32 * 32 + tail) * 4            # 32 sub-tiles of 32 features / 4 waves
     # above 128 rows only corr(x, x) exists (blocked Gram: 3 block pairs x 1 K split of 128 x 128 floats); 1024 rows is the end
