@@ -395,7 +395,10 @@ int launch_bwd1(bool pair, const float* gup, const float* S, const float* x, con
                 float r, float eps, float* dx, hipStream_t st, const float* ab, int C) {
   const int n_sub = (int)((F + SUBF - 1) / SUBF);
   int grid = (n_sub + kWaves - 1) / kWaves;
-  if (grid > 2048) grid = 2048;
+  // 141 VGPRs: three 4-wave workgroups per CU = 768 resident; a grid of exactly that (every wave loops over ~8 sub-tiles at
+  // [28, 802816]) ran 82-84 us against 86-87 for 2048 and 17.2 against 19.6 at [28, 100352] (tools/s1_grid_sweep.sh)
+  static const int capb = [] { const char* e = getenv("ALIGNQ_S1_GRID_B"); return e ? atoi(e) : 768; }();      // tuning aid
+  if (grid > capb) grid = capb;
   if (pair) hipLaunchKernelGGL((site1_bwd_kernel<true>), grid, kThreads1, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_sub, ab, C);
   else hipLaunchKernelGGL((site1_bwd_kernel<false>), grid, kThreads1, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_sub, ab, C);
   RET_ON_ERR1();

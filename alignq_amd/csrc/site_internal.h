@@ -94,7 +94,8 @@ inline Geom geom(int B, int64_t F) {
     g.grid = g.n_tiles < 2048 ? g.n_tiles : 2048;
     if (g.nb == 1) {                 // site1 kernels: four wave-autonomous 32-feature sub-tiles per workgroup
       g.grid = (int)((F + 127) / 128);
-      if (g.grid > 2048) g.grid = 2048;
+      static const int cap1 = [] { const char* e = getenv("ALIGNQ_S1_GRID_F"); return e ? atoi(e) : 2048; }();   // tuning aid
+      if (g.grid > cap1) g.grid = cap1;
     }
     g.slab_floats = (32 * g.nb) * (32 * g.nb);
   }
