@@ -121,15 +121,30 @@ __global__ __launch_bounds__(kThreads1) void site1_fwd_kernel(const float* __res
 #pragma unroll
   for (int e = 0; e < 16; e++) acc[e] = 0.0f;
 
+  // software pipeline: the rows of the NEXT sub-tile are requested before this one is transformed (a wave's 16 loads used to
+  // be waited for in full before its ~500 vector instructions: ~10 us per sub-tile at four waves per SIMD)
+  float xn[RPL];
+  {
+    const int sub0 = blockIdx.x * kWaves + w;
+    const int64_t col = (int64_t)sub0 * SUBF + l31;
+    const float* __restrict__ xp = x + (int64_t)(RPL * h) * F + col;
+#pragma unroll
+    for (int q = 0; q < RPL; q++) xn[q] = (sub0 < n_sub && col < F && RPL * h + q < B) ? xp[(int64_t)q * F] : 0.0f;
+  }
   for (int sub = blockIdx.x * kWaves + w; sub < n_sub; sub += gridDim.x * kWaves) {
     const int64_t col = (int64_t)sub * SUBF + l31;
     const bool cok = col < F;
-    const float* __restrict__ xp = x + (int64_t)(RPL * h) * F + col;
     float* __restrict__ qp = xq ? xq + (int64_t)(RPL * h) * F + col : nullptr;
     float xr[RPL], tr[RPL], rr[RES ? RPL : 1];
 #pragma unroll
-    for (int q = 0; q < RPL; q++)       // (non-temporal dword loads measured slower here: 72.6 vs 63.8 us at [28, 802816])
-      xr[q] = (cok && RPL * h + q < B) ? xp[(int64_t)q * F] : 0.0f;
+    for (int q = 0; q < RPL; q++) xr[q] = xn[q];       // (non-temporal dword loads measured slower here: 72.6 vs 63.8 us)
+    {
+      const int subn = sub + gridDim.x * kWaves;
+      const int64_t coln = (int64_t)subn * SUBF + l31;
+      const float* __restrict__ xpn = x + (int64_t)(RPL * h) * F + coln;
+#pragma unroll
+      for (int q = 0; q < RPL; q++) xn[q] = (subn < n_sub && coln < F && RPL * h + q < B) ? xpn[(int64_t)q * F] : 0.0f;
+    }
     if (ab) {      // folded batch-norm (channels-last: channel = column mod nch, nch a power of two): x = a*z + b on load
       const int ch = (int)(col & (int64_t)(nch - 1));
       const float av = cok ? ab[ch] : 0.0f, bv = cok ? ab[nch + ch] : 0.0f;
@@ -272,6 +287,10 @@ __global__ __launch_bounds__(kThreads1) void site1_bwd_kernel(const float* __res
     unpack8(wd, sh[ks], sl[ks]);
   }
 
+  // software pipeline on x only (g is consumed late: its loads, issued at the top, land under the transform and the MFMAs;
+  // prefetching both took the kernel to 256 VGPRs in round 2): the next sub-tile's x rows are requested before this one is used
+  // (round 3: requesting the next sub-tile's x rows one iteration ahead, as the forward does, takes this kernel from 141 to 160
+  //  VGPRs = two waves per SIMD instead of three: 102.9 us against 83.8 at [28, 802816]; not kept)
   for (int sub = blockIdx.x * kWaves + w; sub < n_sub; sub += gridDim.x * kWaves) {
     const int64_t col = (int64_t)sub * SUBF + l31;
     const bool cok = col < F;
