@@ -654,7 +654,9 @@ __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restri
     STAMP(3);
     if constexpr (!SINGLE) {
       // software pipeline: x and t of this tile now live in LDS, so the registers take the next tile's rows; the loads fly
-      // under the MFMA phase and the loop's closing barrier instead of in front of the next transform
+      // under the MFMA phase and the loop's closing barrier instead of in front of the next transform.  (The 8-wave form
+      // reports 12 B of scratch per lane: ONE 8-byte prologue value stored before the tile loop and reloaded after it -
+      // no scratch traffic inside the loop; requesting half of the rows behind the MFMA phase did not change that.)
       const int tn = tile + (int)gridDim.x;
       if (tn < n_tiles) {
         const int coln = tn * TFv + 4 * c;
@@ -677,7 +679,8 @@ __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restri
     for (int i = 0; i < NI; i++) {
       if (it_on[i]) {
         const int ra = (it_I[i] * 32 + l31) * LDB + 8 * h, rb = (it_J[i] * 32 + l31) * LDB + 8 * h;
-#pragma unroll(NTv == NT ? KSTEPS : 1)       // (the 8-wave form runs at its 128-register cap: no fragment loads hoisted across K steps)
+        constexpr int kUnrollK = (NTv == NT) ? KSTEPS : 1;   // (the 8-wave form runs at its 128-register cap: no fragment
+#pragma unroll kUnrollK                                     //  loads hoisted across K steps)
         for (int s = 0; s < KSTEPS; s++) {
           const int k0 = (it_kh[i] * KSTEPS + s) * 16;
           bf16x8 axh = *reinterpret_cast<const bf16x8*>(Xhi + ra + k0);
@@ -1106,6 +1109,8 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
 
   float4 xr[4], gr[4];                    // VEC: this thread's x / g quads (LOOP: refilled one tile ahead)
   bf16x8 sh[8], sl[8];                    // S fragments
+  // (round 3: requesting the 64-feature form's S fragments FIRST, under the tile loads - it has the registers: one workgroup
+  //  per CU, 256-register budget - changed nothing: 1.172 / 1.176 / 1.173 against 1.173 / 1.168 / 1.174 ms per step)
   // !LOOP: one tile per workgroup (grid == n_tiles): no tile loop, nothing to hoist
   for (int tile = blockIdx.x; tile < n_tiles; tile += (int)gridDim.x) {
     const int col0 = tile * TFv;
