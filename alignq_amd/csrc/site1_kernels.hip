@@ -158,6 +158,10 @@ __global__ __launch_bounds__(kThreads1) void site1_fwd_kernel(const float* __res
       for (int q = 0; q < RPL; q++) rr[q] = (cok && RPL * h + q < B) ? rp[(int64_t)q * F] : 0.0f;
     }
     // ---- transform + quantise; batch statistics: registers + one cross-half shuffle ---------------------------
+    // (round 3: the same as ONE straight-line block over the 16 rows - selects instead of the per-row exec-mask branches, so
+    //  that the rows' table reads and dependent chains overlap - takes 141 instead of 88 VGPRs, three waves per SIMD instead
+    //  of four: 64.6-65.6 us against 61.6-62.4 at [28, 802816].  The kernel is bound by neither bytes nor issue slots: without
+    //  the x_q store it runs 59-61 us, the x-only correlation 26 us; what it lives on is waves per SIMD.)
     float sx = 0.f, st = 0.f;
 #pragma unroll
     for (int q = 0; q < RPL; q++) {
