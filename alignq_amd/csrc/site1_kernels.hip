@@ -152,53 +152,32 @@ __global__ __launch_bounds__(kThreads1) void site1_fwd_kernel(const float* __res
       for (int q = 0; q < RPL; q++)
         if (cok && RPL * h + q < B) xr[q] = __fmaf_rn(av, xr[q], bv);
     }
-    if (PAIR && RES) {        // the shortcut rows: in flight under the transform below
-      const float* __restrict__ rp = res + (int64_t)(RPL * h) * F + col;
-#pragma unroll
-      for (int q = 0; q < RPL; q++) rr[q] = (cok && RPL * h + q < B) ? rp[(int64_t)q * F] : 0.0f;
-    }
     // ---- transform + quantise; batch statistics: registers + one cross-half shuffle ---------------------------
     // (round 3: the same as ONE straight-line block over the 16 rows - selects instead of the per-row exec-mask branches, so
     //  that the rows' table reads and dependent chains overlap - takes 141 instead of 88 VGPRs, three waves per SIMD instead
     //  of four: 64.6-65.6 us against 61.6-62.4 at [28, 802816].  The kernel is bound by neither bytes nor issue slots: without
     //  the x_q store it runs 59-61 us, the x-only correlation 26 us; what it lives on is waves per SIMD.)
-    float sx = 0.f, st = 0.f;
+    // Order (round 3): x statistics -> stage x -> x Gram, THEN the transform in place (the row registers take t as soon as
+    // x_q is stored), t statistics -> stage t -> t Gram: one 16-row array is live instead of two.
+    float sx = 0.f;
 #pragma unroll
-    for (int q = 0; q < RPL; q++) {
-      tr[q] = 0.f;
-      if (RPL * h + q < B) {
-        if (PAIR) {
-          float b;
-          float qq = bounded ? act_quant1<0, true>(xr[q], k, nlev, r, &tr[q], &b, tab)
-                             : act_quant1<0>(xr[q], k, nlev, r, &tr[q], &b, tab);
-          if (RES) qq += rr[q];
-          if (relu) qq = fmaxf(qq, 0.0f);
-          if (qp && cok) qp[(int64_t)q * F] = qq;
-          st += tr[q];
-        }
-        sx += xr[q];
-      }
-    }
+    for (int q = 0; q < RPL; q++)
+      if (RPL * h + q < B) sx += xr[q];
     sx += __shfl_xor(sx, 32, 64);
-    if (PAIR) st += __shfl_xor(st, 32, 64);
-    const float mx = sx * invB, mt = st * invB;
-    float vx = 0.f, vt = 0.f;
+    const float mx = sx * invB;
+    float vx = 0.f;
 #pragma unroll
     for (int q = 0; q < RPL; q++) {
       if (RPL * h + q < B) {
         const float d = xr[q] - mx;
         vx += d * d;
-        if (PAIR) { const float d2 = tr[q] - mt; vt += d2 * d2; }
       }
     }
     vx += __shfl_xor(vx, 32, 64);
-    if (PAIR) vt += __shfl_xor(vt, 32, 64);
     const float rx = 1.0f / (sqrtf(vx * invBm1) + eps);
-    const float rt = PAIR ? 1.0f / (sqrtf(vt * invBm1) + eps) : 0.f;
     if (stats && cok && h == 0) {
       stats[col] = mx;
       stats[F + col] = rx;
-      if (PAIR) { stats[2 * F + col] = mt; stats[3 * F + col] = rt; }
     }
     // ---- x operand: stage, Gram (negated when it is subtracted from the t Gram) --------------------------------
     {
@@ -208,9 +187,39 @@ __global__ __launch_bounds__(kThreads1) void site1_fwd_kernel(const float* __res
       stage_rows(W, l31, h, wd);
     }
     wave_lds_sync();
+    if (PAIR && RES) {        // the shortcut rows: requested here, in flight under the x Gram
+      const float* __restrict__ rp = res + (int64_t)(RPL * h) * F + col;
+#pragma unroll
+      for (int q = 0; q < RPL; q++) rr[q] = (cok && RPL * h + q < B) ? rp[(int64_t)q * F] : 0.0f;
+    }
     gram32<PAIR>(W, l31, h, acc);
     wave_lds_sync();
     if (PAIR) {
+      // ---- transform + quantise (x_q stored, the row register takes t), t statistics, stage, Gram ------------------
+      float st = 0.f;
+#pragma unroll
+      for (int q = 0; q < RPL; q++) {
+        tr[q] = 0.f;
+        if (RPL * h + q < B) {
+          float b;
+          float qq = bounded ? act_quant1<0, true>(xr[q], k, nlev, r, &tr[q], &b, tab)
+                             : act_quant1<0>(xr[q], k, nlev, r, &tr[q], &b, tab);
+          if (RES) qq += rr[q];
+          if (relu) qq = fmaxf(qq, 0.0f);
+          if (qp && cok) qp[(int64_t)q * F] = qq;
+          st += tr[q];
+        }
+      }
+      st += __shfl_xor(st, 32, 64);
+      const float mt = st * invB;
+      float vt = 0.f;
+#pragma unroll
+      for (int q = 0; q < RPL; q++) {
+        if (RPL * h + q < B) { const float d2 = tr[q] - mt; vt += d2 * d2; }
+      }
+      vt += __shfl_xor(vt, 32, 64);
+      const float rt = 1.0f / (sqrtf(vt * invBm1) + eps);
+      if (stats && cok && h == 0) { stats[2 * F + col] = mt; stats[3 * F + col] = rt; }
       unsigned wd[RPL];
 #pragma unroll
       for (int q = 0; q < RPL; q++) wd[q] = (cok && RPL * h + q < B) ? pack_hi_lo((tr[q] - mt) * rt) : 0u;
