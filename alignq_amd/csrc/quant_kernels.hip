@@ -171,10 +171,27 @@ __global__ __launch_bounds__(kThreads) void weight_partial_sums_kernel(const flo
   __shared__ double sm[16];
   double s = 0, s2 = 0;
   const int64_t stride = (int64_t)gridDim.x * kThreads;
-  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
-    double v = w[i];
-    s += v;
-    s2 += v * v;
+  if ((reinterpret_cast<uintptr_t>(w) & 15) == 0) {       // 16-byte loads, two in flight per thread; the tail by block 0
+    const int64_t nvec = n >> 2;
+    const float4* w4 = reinterpret_cast<const float4*>(w);
+    for (int64_t i0 = (int64_t)blockIdx.x * kThreads + threadIdx.x; i0 < nvec; i0 += 2 * stride) {
+      const float4 a = w4[i0];
+      const bool two = i0 + stride < nvec;
+      const float4 b = w4[two ? i0 + stride : i0];
+      s += (double)a.x + (double)a.y + (double)a.z + (double)a.w;
+      s2 += (double)a.x * a.x + (double)a.y * a.y + (double)a.z * a.z + (double)a.w * a.w;
+      if (two) {
+        s += (double)b.x + (double)b.y + (double)b.z + (double)b.w;
+        s2 += (double)b.x * b.x + (double)b.y * b.y + (double)b.z * b.z + (double)b.w * b.w;
+      }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const double v = w[(nvec << 2) + threadIdx.x]; s += v; s2 += v * v; }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+      double v = w[i];
+      s += v;
+      s2 += v * v;
+    }
   }
   block_sum2(s, s2, sm);
   if (threadIdx.x == 0) { ws[2 * blockIdx.x] = s; ws[2 * blockIdx.x + 1] = s2; }
@@ -210,7 +227,28 @@ __global__ __launch_bounds__(kThreads) void weight_quant_fwd_kernel(const float*
   const NerfTab tab = nerf_tab(tab_lds);
   const WeightConsts wc = weight_consts(ms[0], ms[1], k);
   const int64_t stride = (int64_t)gridDim.x * kThreads;
-  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+  const bool vec = ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(cdf_out) |
+                     reinterpret_cast<uintptr_t>(pdf_out) | reinterpret_cast<uintptr_t>(bins)) & 15) == 0;
+  int64_t done = 0;
+  if (vec) {          // 16-byte accesses (ResNet-50's filters are up to 2.4 M elements: the dword form was issue-bound)
+    const int64_t nvec = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += stride) {
+      const float4 v = reinterpret_cast<const float4*>(w)[i];
+      const float ve[4] = {v.x, v.y, v.z, v.w};
+      float qe[4], te[4], be[4], pe[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        qe[e] = weight_quant1<FORMULA>(ve[e], wc, k, &te[e], &be[e], tab);
+        if (pdf_out) pe[e] = weight_pdf2(ve[e], wc);
+      }
+      reinterpret_cast<float4*>(q)[i] = make_float4(qe[0], qe[1], qe[2], qe[3]);
+      if (cdf_out) reinterpret_cast<float4*>(cdf_out)[i] = make_float4(te[0], te[1], te[2], te[3]);
+      if (bins) reinterpret_cast<int4*>(bins)[i] = make_int4((int)be[0], (int)be[1], (int)be[2], (int)be[3]);
+      if (pdf_out) reinterpret_cast<float4*>(pdf_out)[i] = make_float4(pe[0], pe[1], pe[2], pe[3]);
+    }
+    done = nvec << 2;
+  }
+  for (int64_t i = done + (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
     float v = w[i];
     float t, b;
     q[i] = weight_quant1<FORMULA>(v, wc, k, &t, &b, tab);
@@ -229,7 +267,24 @@ __global__ __launch_bounds__(kThreads) void weight_bwd_partial_kernel(const floa
   const float m = ms[0], s = ms[1], rs = 1.0f / s, cs = ALIGNQ_TWO_OVER_SQRT_2PI * rs;
   double s1 = 0, s2 = 0;
   const int64_t stride = (int64_t)gridDim.x * kThreads;
-  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+  int64_t done = 0;
+  if (((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(g)) & 15) == 0) {
+    const int64_t nvec = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += stride) {
+      const float4 wv = reinterpret_cast<const float4*>(w)[i], gv = reinterpret_cast<const float4*>(g)[i];
+      const float we[4] = {wv.x, wv.y, wv.z, wv.w}, ge[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        float P, z;
+        weight_PZ(we[e], m, rs, cs, &P, &z);
+        const double gp = (double)ge[e] * (double)P;
+        s1 += gp;
+        s2 += gp * (double)z;
+      }
+    }
+    done = nvec << 2;
+  }
+  for (int64_t i = done + (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
     float P, z;
     weight_PZ(w[i], m, rs, cs, &P, &z);
     double gp = (double)g[i] * (double)P;
@@ -253,7 +308,24 @@ __global__ __launch_bounds__(kThreads) void weight_bwd_apply_kernel(const float*
   const float mean_gp = (float)(s1 / (double)n);
   const float dotn = (float)(s2 / (double)(n - 1));
   const int64_t stride = (int64_t)gridDim.x * kThreads;
-  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+  int64_t done = 0;
+  if (((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(dw)) & 15) == 0) {
+    const int64_t nvec = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += stride) {
+      const float4 wv = reinterpret_cast<const float4*>(w)[i], gv = reinterpret_cast<const float4*>(g)[i];
+      const float we[4] = {wv.x, wv.y, wv.z, wv.w}, ge[4] = {gv.x, gv.y, gv.z, gv.w};
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        float P, z;
+        weight_PZ(we[e], m, rs, cs, &P, &z);
+        o[e] = ge[e] * P - mean_gp - z * dotn;
+      }
+      reinterpret_cast<float4*>(dw)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    done = nvec << 2;
+  }
+  for (int64_t i = done + (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
     float P, z;
     weight_PZ(w[i], m, rs, cs, &P, &z);
     dw[i] = g[i] * P - mean_gp - z * dotn;
@@ -579,7 +651,7 @@ int alignq_weight_quant_fwd(const float* w, const float* ms, float* q, float* cd
   if (!w || !ms || !q || n <= 0) return ALIGNQ_EINVAL;
   if (!((k >= 1 && k <= 16) || k == 32)) return ALIGNQ_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  int grid = grid_for(n);
+  int grid = grid_for((n + 3) >> 2);
   if (formula == ALIGNQ_FORMULA_ADMM)
     hipLaunchKernelGGL((weight_quant_fwd_kernel<0>), grid, kThreads, 0, st, w, ms, q, cdf_out, pdf_out, bins, n, k);
   else if (formula == ALIGNQ_FORMULA_CDF)
@@ -597,7 +669,7 @@ int alignq_weight_quant_bwd(const float* g, const float* w, const float* ms, flo
   int nb = ws_blocks(n);
   hipLaunchKernelGGL(weight_bwd_partial_kernel, nb, kThreads, 0, st, g, w, ms, n, (double*)ws);
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(weight_bwd_apply_kernel, grid_for(n), kThreads, 0, st, g, w, ms, (const double*)ws, nb, dw, n);
+  hipLaunchKernelGGL(weight_bwd_apply_kernel, grid_for((n + 3) >> 2), kThreads, 0, st, g, w, ms, (const double*)ws, nb, dw, n);
   LAUNCH_CHECK();
   return 0;
 }
