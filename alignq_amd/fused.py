@@ -555,40 +555,59 @@ def bn_site(bn, act, z, eps=0.0, relu=False, residual=None, pack=False):
 # statistics (one read of z) + one elementwise pass (a*z+b -> quantise -> relu) forward and two passes backward: the
 # normalised activation never exists in memory.  Any batch; channels-last; C a power of two in [4, 1024].
 class BNQuantReluFn(torch.autograd.Function):
+    """groups > 1 (the Office step's merged source + target pass, train_step.OfficeTrainStep(dual=True)): z holds `groups`
+    equal batch slices that the reference pushes through the module one after the other (dann_office/main.py:351-372): every
+    slice gets its own batch statistics, the running statistics are updated slice after slice, and dgamma / dbeta are the sums
+    over the slices - one autograd node, so no gradient accumulation kernels."""
+
     @staticmethod
-    def forward(ctx, z, weight, bias, running_mean, running_var, nbt, momentum, bn_eps, k, act_range, formula, relu):
+    def forward(ctx, z, weight, bias, running_mean, running_var, nbt, momentum, bn_eps, k, act_range, formula, relu, groups=1):
         z = L.dense_f32(z, "conv output")
         B, C, H, W = z.shape
         lib = L.load()
         dev = z.device
-        P = B * H * W
-        ab = torch.empty(2, C, dtype=torch.float32, device=dev)
-        save = torch.empty(2, C, dtype=torch.float32, device=dev)
+        Bg = B // groups
+        P = Bg * H * W
+        ab = torch.empty(groups, 2, C, dtype=torch.float32, device=dev)
+        save = torch.empty(groups, 2, C, dtype=torch.float32, device=dev)
         y = torch.empty_like(z)
         ws = torch.empty(lib.alignq_bnq_ws_bytes(C), dtype=torch.uint8, device=dev)
-        L.check(lib.alignq_bnq_fwd(L.ptr(z), P, C, L.ptr(weight), L.ptr(bias), L.ptr(running_mean), L.ptr(running_var),
-                                   L.ptr(nbt), float(momentum), float(bn_eps), int(k), float(act_range), int(formula),
-                                   int(bool(relu)), L.ptr(ab), L.ptr(save), L.ptr(y), L.ptr(ws), L.stream_ptr()),
-                "alignq_bnq_fwd")
+        for gi in range(groups):
+            zg, yg = z[gi * Bg:(gi + 1) * Bg], y[gi * Bg:(gi + 1) * Bg]
+            L.check(lib.alignq_bnq_fwd(L.ptr(zg), P, C, L.ptr(weight), L.ptr(bias), L.ptr(running_mean), L.ptr(running_var),
+                                       L.ptr(nbt), float(momentum), float(bn_eps), int(k), float(act_range), int(formula),
+                                       int(bool(relu)), L.ptr(ab[gi]), L.ptr(save[gi]), L.ptr(yg), L.ptr(ws), L.stream_ptr()),
+                    "alignq_bnq_fwd")
         ctx.save_for_backward(z, y if relu else None, ab, save)
-        ctx.cfg = (float(act_range), bool(relu), weight is not None, bias is not None)
+        ctx.cfg = (float(act_range), bool(relu), weight is not None, bias is not None, int(groups))
         ctx.mark_non_differentiable(*[t for t in (running_mean, running_var, nbt) if t is not None])
         return y
 
     @staticmethod
     def backward(ctx, g):
         z, y, ab, save = ctx.saved_tensors
-        act_range, relu, has_w, has_b = ctx.cfg
+        act_range, relu, has_w, has_b, groups = ctx.cfg
         B, C, H, W = z.shape
+        Bg = B // groups
         g = L.like_layout(g, z)
         lib = L.load()
         dz = torch.empty_like(z)
-        dgamma = torch.empty(C, dtype=torch.float32, device=z.device) if has_w else None
-        dbeta = torch.empty(C, dtype=torch.float32, device=z.device) if has_b else None
+        dgamma = torch.empty(groups, C, dtype=torch.float32, device=z.device) if has_w else None
+        dbeta = torch.empty(groups, C, dtype=torch.float32, device=z.device) if has_b else None
         ws = torch.empty(lib.alignq_bnq_ws_bytes(C), dtype=torch.uint8, device=z.device)
-        L.check(lib.alignq_bnq_bwd(L.ptr(g), L.ptr(z), L.ptr(y), L.ptr(ab), L.ptr(save), B * H * W, C, act_range, int(relu),
-                                   L.ptr(dz), L.ptr(dgamma), L.ptr(dbeta), L.ptr(ws), L.stream_ptr()), "alignq_bnq_bwd")
-        return dz, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+        for gi in range(groups):
+            sl = slice(gi * Bg, (gi + 1) * Bg)
+            L.check(lib.alignq_bnq_bwd(L.ptr(g[sl]), L.ptr(z[sl]), L.ptr(None if y is None else y[sl]), L.ptr(ab[gi]),
+                                       L.ptr(save[gi]), Bg * H * W, C, act_range, int(relu), L.ptr(dz[sl]),
+                                       L.ptr(None if dgamma is None else dgamma[gi]), L.ptr(None if dbeta is None else dbeta[gi]),
+                                       L.ptr(ws), L.stream_ptr()), "alignq_bnq_bwd")
+        if groups > 1:
+            dgamma = None if dgamma is None else dgamma.sum(0)
+            dbeta = None if dbeta is None else dbeta.sum(0)
+        else:
+            dgamma = None if dgamma is None else dgamma[0]
+            dbeta = None if dbeta is None else dbeta[0]
+        return dz, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
 def _bn_nhwc_ok(bn, z) -> bool:
@@ -604,47 +623,64 @@ def bnq_fusable(bn, act, z) -> bool:
 
 class BNAffineFn(torch.autograd.Function):
     """Training-mode nn.BatchNorm2d alone on a channels-last tensor (the Office bottleneck's downsample branch,
-    dann_office/model/resnet.py:122-126): alignq_bnq_stats + alignq_bnq_affine forward, alignq_bnq_bwd_dx backward."""
+    dann_office/model/resnet.py:122-126): alignq_bnq_stats + alignq_bnq_affine forward, alignq_bnq_bwd_dx backward.
+    groups: as in BNQuantReluFn."""
 
     @staticmethod
-    def forward(ctx, z, weight, bias, running_mean, running_var, nbt, momentum, bn_eps):
+    def forward(ctx, z, weight, bias, running_mean, running_var, nbt, momentum, bn_eps, groups=1):
         z = L.dense_f32(z, "conv output")
         B, C, H, W = z.shape
-        lib, dev, P = L.load(), z.device, B * H * W
-        ab = torch.empty(2, C, dtype=torch.float32, device=dev)
-        save = torch.empty(2, C, dtype=torch.float32, device=dev)
+        Bg = B // groups
+        lib, dev, P = L.load(), z.device, Bg * H * W
+        ab = torch.empty(groups, 2, C, dtype=torch.float32, device=dev)
+        save = torch.empty(groups, 2, C, dtype=torch.float32, device=dev)
         y = torch.empty_like(z)
         ws = torch.empty(lib.alignq_bnq_ws_bytes(C), dtype=torch.uint8, device=dev)
         st = L.stream_ptr()
-        L.check(lib.alignq_bnq_stats(L.ptr(z), P, C, L.ptr(weight), L.ptr(bias), L.ptr(running_mean), L.ptr(running_var),
-                                     L.ptr(nbt), float(momentum), float(bn_eps), L.ptr(ab), L.ptr(save), L.ptr(ws), st),
-                "alignq_bnq_stats")
-        L.check(lib.alignq_bnq_affine(L.ptr(z), L.ptr(ab), P, C, L.ptr(y), st), "alignq_bnq_affine")
+        for gi in range(groups):
+            sl = slice(gi * Bg, (gi + 1) * Bg)
+            L.check(lib.alignq_bnq_stats(L.ptr(z[sl]), P, C, L.ptr(weight), L.ptr(bias), L.ptr(running_mean), L.ptr(running_var),
+                                         L.ptr(nbt), float(momentum), float(bn_eps), L.ptr(ab[gi]), L.ptr(save[gi]), L.ptr(ws), st),
+                    "alignq_bnq_stats")
+            L.check(lib.alignq_bnq_affine(L.ptr(z[sl]), L.ptr(ab[gi]), P, C, L.ptr(y[sl]), st), "alignq_bnq_affine")
         ctx.save_for_backward(z, ab, save)
-        ctx.has = (weight is not None, bias is not None)
+        ctx.has = (weight is not None, bias is not None, int(groups))
         ctx.mark_non_differentiable(*[t for t in (running_mean, running_var, nbt) if t is not None])
         return y
 
     @staticmethod
     def backward(ctx, g):
         z, ab, save = ctx.saved_tensors
+        has_w, has_b, groups = ctx.has
         B, C, H, W = z.shape
+        Bg = B // groups
         g = L.like_layout(g, z)
         lib = L.load()
         dz = torch.empty_like(z)
-        dgamma = torch.empty(C, dtype=torch.float32, device=z.device) if ctx.has[0] else None
-        dbeta = torch.empty(C, dtype=torch.float32, device=z.device) if ctx.has[1] else None
+        dgamma = torch.empty(groups, C, dtype=torch.float32, device=z.device) if has_w else None
+        dbeta = torch.empty(groups, C, dtype=torch.float32, device=z.device) if has_b else None
         ws = torch.empty(lib.alignq_bnq_ws_bytes(C), dtype=torch.uint8, device=z.device)
-        L.check(lib.alignq_bnq_bwd_dx(L.ptr(g), L.ptr(z), L.ptr(ab), L.ptr(save), B * H * W, C, L.ptr(dz), L.ptr(dgamma),
-                                      L.ptr(dbeta), L.ptr(ws), L.stream_ptr()), "alignq_bnq_bwd_dx")
-        return dz, dgamma, dbeta, None, None, None, None, None
+        for gi in range(groups):
+            sl = slice(gi * Bg, (gi + 1) * Bg)
+            L.check(lib.alignq_bnq_bwd_dx(L.ptr(g[sl]), L.ptr(z[sl]), L.ptr(ab[gi]), L.ptr(save[gi]), Bg * H * W, C, L.ptr(dz[sl]),
+                                          L.ptr(None if dgamma is None else dgamma[gi]),
+                                          L.ptr(None if dbeta is None else dbeta[gi]), L.ptr(ws), L.stream_ptr()),
+                    "alignq_bnq_bwd_dx")
+        dgamma = None if dgamma is None else (dgamma.sum(0) if groups > 1 else dgamma[0])
+        dbeta = None if dbeta is None else (dbeta.sum(0) if groups > 1 else dbeta[0])
+        return dz, dgamma, dbeta, None, None, None, None, None, None
 
 
-def bn_only(bn, z):
-    """bn(z): the folded-family kernels when the tensor is channels-last fp32 in training mode, else the module itself."""
+def bn_only(bn, z, groups=1):
+    """bn(z): the folded-family kernels when the tensor is channels-last fp32 in training mode, else the module itself
+    (groups > 1: applied to the batch slices one after the other, as the reference's successive passes do)."""
     if not _bn_nhwc_ok(bn, z):
-        return bn(z)
-    return BNAffineFn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum, bn.eps)
+        if groups == 1:
+            return bn(z)
+        Bg = z.shape[0] // groups
+        return torch.cat([bn(z[i * Bg:(i + 1) * Bg]) for i in range(groups)], 0)
+    return BNAffineFn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum, bn.eps,
+                            groups)
 
 
 class BNSite1Fn(torch.autograd.Function):
@@ -653,49 +689,60 @@ class BNSite1Fn(torch.autograd.Function):
     forward : alignq_bnq_stats (one read of z) -> alignq_site_partials_res_ab (x = a*z + b on load: quantise, both Grams,
               + residual, ReLU) -> alignq_site_reduce_loss; bn3's output is never written;
     backward: ReLU mask -> alignq_site_prep_fused -> alignq_site_bwd_apply_ab (dx w.r.t. the batch-norm output) ->
-              alignq_bnq_bwd_dx in place (dz, dgamma, dbeta)."""
+              alignq_bnq_bwd_dx in place (dz, dgamma, dbeta).
+    groups > 1: z / residual hold `groups` batch slices of <= 32 rows each that the reference sends through the module one
+    after the other (source pass, target pass): per-slice statistics and correlation matrices, running statistics updated in
+    slice order, the loss is the SUM over the slices, D is the LAST slice's (ADMM.forward overwrites self.D, utils/admm.py:25),
+    parameter gradients summed inside the node."""
 
     @staticmethod
     def forward(ctx, z, weight, bias, running_mean, running_var, nbt, momentum, bn_eps, residual, alterD, gamma, k,
-                act_range, eps, mu, rho):
+                act_range, eps, mu, rho, groups=1):
         z = L.dense_f32(z, "conv output")
         A, Gm = L.dev_f32(alterD, "alterD"), L.dev_f32(gamma, "gamma")
-        B, C, H, W = z.shape
+        Bt, C, H, W = z.shape
+        B = Bt // groups
         F, P = C * H * W, B * H * W
         lib, dev = L.load(), z.device
         if B > A.shape[0]:
             raise RuntimeError(f"batch {B} larger than ADMM dim {A.shape[0]}")
-        ab = torch.empty(2, C, dtype=torch.float32, device=dev)
-        save = torch.empty(2, C, dtype=torch.float32, device=dev)
+        ab = torch.empty(groups, 2, C, dtype=torch.float32, device=dev)
+        save = torch.empty(groups, 2, C, dtype=torch.float32, device=dev)
         ws_bn = torch.empty(lib.alignq_bnq_ws_bytes(C), dtype=torch.uint8, device=dev)
         st = L.stream_ptr()
-        L.check(lib.alignq_bnq_stats(L.ptr(z), P, C, L.ptr(weight), L.ptr(bias), L.ptr(running_mean), L.ptr(running_var),
-                                     L.ptr(nbt), float(momentum), float(bn_eps), L.ptr(ab), L.ptr(save), L.ptr(ws_bn), st),
-                "alignq_bnq_stats")
         if residual is not None:
             residual = L.like_layout(L.dense_f32(residual, "residual"), z)
         y = torch.empty_like(z)
-        stats = torch.empty(4, F, dtype=torch.float32, device=dev)
-        D = torch.empty(B, B, dtype=torch.float32, device=dev)
-        scal = torch.empty(4, dtype=torch.float32, device=dev)
+        stats = torch.empty(groups, 4, F, dtype=torch.float32, device=dev)
+        D = torch.empty(groups, B, B, dtype=torch.float32, device=dev)
+        scal = torch.empty(groups, 4, dtype=torch.float32, device=dev)
         from .ops import _ws
         ws = _ws(lib.alignq_site_ws_bytes(B, F), dev)
-        L.check(lib.alignq_site_partials_res_ab(L.ptr(z), L.ptr(ab), C, B, F, int(k), float(act_range), float(eps),
-                                                L.ptr(residual), 1, L.ptr(y), L.ptr(stats), L.ptr(ws), st),
-                "alignq_site_partials_res_ab")
-        L.check(lib.alignq_site_reduce_loss(L.ptr(ws), B, F, L.ptr(D), L.ptr(A), L.ptr(Gm), A.shape[0], float(mu), float(rho),
-                                            L.ptr(scal), st), "alignq_site_reduce_loss")
+        for gi in range(groups):
+            sl = slice(gi * B, (gi + 1) * B)
+            L.check(lib.alignq_bnq_stats(L.ptr(z[sl]), P, C, L.ptr(weight), L.ptr(bias), L.ptr(running_mean), L.ptr(running_var),
+                                         L.ptr(nbt), float(momentum), float(bn_eps), L.ptr(ab[gi]), L.ptr(save[gi]), L.ptr(ws_bn),
+                                         st), "alignq_bnq_stats")
+            L.check(lib.alignq_site_partials_res_ab(L.ptr(z[sl]), L.ptr(ab[gi]), C, B, F, int(k), float(act_range), float(eps),
+                                                    L.ptr(None if residual is None else residual[sl]), 1, L.ptr(y[sl]),
+                                                    L.ptr(stats[gi]), L.ptr(ws), st), "alignq_site_partials_res_ab")
+            L.check(lib.alignq_site_reduce_loss(L.ptr(ws), B, F, L.ptr(D[gi]), L.ptr(A), L.ptr(Gm), A.shape[0], float(mu),
+                                                float(rho), L.ptr(scal[gi]), st), "alignq_site_reduce_loss")
         ctx.save_for_backward(z, y, ab, save, stats, D, A, Gm, scal)
-        ctx.cfg = (float(act_range), float(eps), float(mu), weight is not None, bias is not None, residual is not None)
+        ctx.cfg = (float(act_range), float(eps), float(mu), weight is not None, bias is not None, residual is not None,
+                   int(groups))
         ctx.set_materialize_grads(False)
-        ctx.mark_non_differentiable(D, *[t for t in (running_mean, running_var, nbt) if t is not None])
-        return y, scal[0], D
+        Dlast = D[groups - 1]
+        loss = scal[0, 0] if groups == 1 else scal[:, 0].sum()
+        ctx.mark_non_differentiable(Dlast, *[t for t in (running_mean, running_var, nbt) if t is not None])
+        return y, loss, Dlast
 
     @staticmethod
     def backward(ctx, g_y, g_loss, _gD):
         z, y, ab, save, stats, D, A, Gm, scal = ctx.saved_tensors
-        act_range, eps, mu, has_w, has_b, has_res = ctx.cfg
-        B, C, H, W = z.shape
+        act_range, eps, mu, has_w, has_b, has_res, groups = ctx.cfg
+        Bt, C, H, W = z.shape
+        B = Bt // groups
         F, P = C * H * W, B * H * W
         lib, dev = L.load(), z.device
         st = L.stream_ptr()
@@ -705,46 +752,61 @@ class BNSite1Fn(torch.autograd.Function):
         if g_loss is None:
             g_loss = torch.zeros((), dtype=torch.float32, device=dev)
         g_loss = L.dev_f32(g_loss, "loss grad")
-        dA, dG = torch.empty_like(A), torch.empty_like(Gm)
+        dA = torch.empty(groups, *A.shape, dtype=torch.float32, device=dev)
+        dG = torch.empty(groups, *Gm.shape, dtype=torch.float32, device=dev)
         from .ops import _ws
         S = _ws(lib.alignq_site_bwd_ws_bytes(B), dev)
-        L.check(lib.alignq_site_prep_fused(L.ptr(D), L.ptr(A), L.ptr(Gm), A.shape[0], L.ptr(scal), mu, L.ptr(g_loss), B, F,
-                                           L.ptr(S), L.ptr(dA), L.ptr(dG), st), "alignq_site_prep_fused")
         dx = torch.empty_like(z)
-        L.check(lib.alignq_site_bwd_apply_ab(L.ptr(g_m), L.ptr(S), L.ptr(z), L.ptr(ab), C, L.ptr(stats), B, F, act_range, eps,
-                                             L.ptr(dx), st), "alignq_site_bwd_apply_ab")
-        dgamma = torch.empty(C, dtype=torch.float32, device=dev) if has_w else None
-        dbeta = torch.empty(C, dtype=torch.float32, device=dev) if has_b else None
+        dgamma = torch.empty(groups, C, dtype=torch.float32, device=dev) if has_w else None
+        dbeta = torch.empty(groups, C, dtype=torch.float32, device=dev) if has_b else None
         ws_bn = torch.empty(lib.alignq_bnq_ws_bytes(C), dtype=torch.uint8, device=dev)
-        L.check(lib.alignq_bnq_bwd_dx(L.ptr(dx), L.ptr(z), L.ptr(ab), L.ptr(save), P, C, L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta),
-                                      L.ptr(ws_bn), st), "alignq_bnq_bwd_dx")
-        return (dx, dgamma, dbeta, None, None, None, None, None, g_m if has_res else None, dA, dG, None, None, None, None, None)
+        for gi in range(groups):
+            sl = slice(gi * B, (gi + 1) * B)
+            L.check(lib.alignq_site_prep_fused(L.ptr(D[gi]), L.ptr(A), L.ptr(Gm), A.shape[0], L.ptr(scal[gi]), mu, L.ptr(g_loss), B,
+                                               F, L.ptr(S), L.ptr(dA[gi]), L.ptr(dG[gi]), st), "alignq_site_prep_fused")
+            L.check(lib.alignq_site_bwd_apply_ab(L.ptr(None if g_m is None else g_m[sl]), L.ptr(S), L.ptr(z[sl]), L.ptr(ab[gi]), C,
+                                                 L.ptr(stats[gi]), B, F, act_range, eps, L.ptr(dx[sl]), st),
+                    "alignq_site_bwd_apply_ab")
+            L.check(lib.alignq_bnq_bwd_dx(L.ptr(dx[sl]), L.ptr(z[sl]), L.ptr(ab[gi]), L.ptr(save[gi]), P, C, L.ptr(dx[sl]),
+                                          L.ptr(None if dgamma is None else dgamma[gi]),
+                                          L.ptr(None if dbeta is None else dbeta[gi]), L.ptr(ws_bn), st), "alignq_bnq_bwd_dx")
+        red = (lambda t: None if t is None else (t.sum(0) if groups > 1 else t[0]))
+        return (dx, red(dgamma), red(dbeta), None, None, None, None, None, g_m if has_res else None, red(dA), red(dG), None, None,
+                None, None, None, None)
 
 
-def bn_site_res_relu(bn, act, z, residual, eps):
-    """(relu(act(bn(z))[0] + residual), loss) for an ADMM site at a batch of at most 32 rows: the folded chain when the tensor
-    is channels-last fp32 in training mode (and no deferred-loss context is active), else None (the caller composes it)."""
+def bn_site_res_relu(bn, act, z, residual, eps, groups=1):
+    """(relu(act(bn(z))[0] + residual), loss) for an ADMM site at a batch of at most 32 rows (per group): the folded chain when
+    the tensor is channels-last fp32 in training mode (and no deferred-loss context is active), else None (the caller composes
+    it)."""
     from . import config
-    if not (_bn_nhwc_ok(bn, z) and 2 <= z.shape[0] <= 32 and act.a_bit < 32 and config.args.method == "ours"
+    if not (_bn_nhwc_ok(bn, z) and z.shape[0] % groups == 0 and 2 <= z.shape[0] // groups <= 32 and act.a_bit < 32
+            and config.args.method == "ours"
             and active_deferred() is None and residual is not None and residual.shape == z.shape and residual.is_cuda
-            and residual.dtype == torch.float32 and z.shape[0] <= act.opt.alterD.shape[0]):
+            and residual.dtype == torch.float32 and z.shape[0] // groups <= act.opt.alterD.shape[0]):
         return None
     admm = act.opt
     y, loss, D = BNSite1Fn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum,
-                                 bn.eps, residual, admm.alterD, admm.gamma, act.a_bit, config.args.act_range, eps, admm.mu, admm.rho)
+                                 bn.eps, residual, admm.alterD, admm.gamma, act.a_bit, config.args.act_range, eps, admm.mu, admm.rho,
+                                 groups)
     admm.D = D
     return y, loss
 
 
-def bn_act_relu(bn, act, z, formula, relu=True):
+def bn_act_relu(bn, act, z, formula, relu=True, groups=1):
     """[relu](act(bn(z))) for a quantiser WITHOUT an ADMM term: one fused chain when `bnq_fusable` (training mode,
-    channels-last fp32 CUDA tensor, C = 4 * 2^j <= 1024), else exactly that composition."""
+    channels-last fp32 CUDA tensor, C = 4 * 2^j <= 2048), else exactly that composition (groups: see BNQuantReluFn)."""
     from . import config
     if not bnq_fusable(bn, act, z):
-        out = act(bn(z))
-        return torch.nn.functional.relu(out) if relu else out
+        def one(zz):
+            out = act(bn(zz))
+            return torch.nn.functional.relu(out) if relu else out
+        if groups == 1:
+            return one(z)
+        Bg = z.shape[0] // groups
+        return torch.cat([one(z[i * Bg:(i + 1) * Bg]) for i in range(groups)], 0)
     return BNQuantReluFn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum,
-                               bn.eps, act.a_bit, config.args.act_range, formula, relu)
+                               bn.eps, act.a_bit, config.args.act_range, formula, relu, groups)
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -179,11 +179,12 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
             """relu(self(x)) in one launch each way (not part of the reference's interface: an opt-in for the caller)."""
             return _plain_act_relu(x, self.a_bit, self.stage)
 
-        def forward_bn_relu(self, bn, z):
+        def forward_bn_relu(self, bn, z, groups=1):
             """relu(self(bn(z))) with the training-mode batch-norm folded into the quantiser (SURVEY.md §8f-N1 on the Office
-            path; not part of the reference's interface: an opt-in for the caller, alignq_amd.fused.bn_act_relu)."""
+            path; not part of the reference's interface: an opt-in for the caller, alignq_amd.fused.bn_act_relu).  groups:
+            z holds that many batch slices which the reference sends through the module one after the other."""
             from . import fused
-            return fused.bn_act_relu(bn, self, z, formula, relu=True)
+            return fused.bn_act_relu(bn, self, z, formula, relu=True, groups=groups)
 
         def forward_packed(self, x, relu=False):
             """([relu](self(x)), bins): the quantised activation both as fp32 and as its narrow integer level index
@@ -204,12 +205,23 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
             """(relu(self(x)[0] + residual), loss) (not part of the reference's interface: an opt-in for the caller)."""
             return _site_act_res_relu(self, x, residual)
 
-        def forward_bn_res_relu(self, bn, z, residual):
+        def forward_bn_res_relu(self, bn, z, residual, groups=1):
             """(relu(self(bn(z))[0] + residual), loss) with the training-mode batch-norm folded into the small-batch site
-            kernels where that applies (SURVEY.md §8f-N1 on the Office path), else the composition."""
+            kernels where that applies (SURVEY.md §8f-N1 on the Office path), else the composition.  groups > 1: the batch
+            slices go through one after the other (loss = their sum, ADMM.D = the last slice's, like successive passes)."""
             from . import fused
-            out = fused.bn_site_res_relu(bn, self, z, residual, eps)
-            return out if out is not None else _site_act_res_relu(self, bn(z), residual)
+            out = fused.bn_site_res_relu(bn, self, z, residual, eps, groups)
+            if out is not None:
+                return out
+            if groups == 1:
+                return _site_act_res_relu(self, bn(z), residual)
+            Bg = z.shape[0] // groups
+            outs, loss = [], 0.
+            for i in range(groups):
+                o, l_ = _site_act_res_relu(self, bn(z[i * Bg:(i + 1) * Bg]), residual[i * Bg:(i + 1) * Bg])
+                outs.append(o)
+                loss = loss + l_
+            return torch.cat(outs, 0), loss
 
     def corr(x, y):
         """corr(x, y) -> [B,B] (ADMM tree :134-137; Office :158-161).  The reference only ever calls it with y is x: that

@@ -44,9 +44,19 @@ class Bottleneck(nn.Module):
         self.act_q2 = Q.activation_quantize_fn(a_bit=abit, stage=stage)
         self.act_q3 = Q.activation_quantize_fn2(a_bit=abit, stage=stage, admm=self.admm0)
 
-    def forward(self, x):
+    def forward(self, x, groups=1):
+        """groups > 1 (OfficeTrainStep(dual=True)): x holds the source and the target batch back to back; the convolutions
+        (per sample) run once on both, every batch statistic / quantiser site / correlation per slice in pass order."""
         trans_loss = 0.
         identity = x
+        if groups > 1:
+            out = self.act_q1.forward_bn_relu(self.bn1, self.conv1(x), groups)
+            out = self.act_q2.forward_bn_relu(self.bn2, self.conv2(out), groups)
+            if self.downsample is not None:
+                from . import fused
+                identity = fused.bn_only(self.downsample[1], self.downsample[0](x), groups)
+            out, loss = self.act_q3.forward_bn_res_relu(self.bn3, self.conv3(out), identity, groups)
+            return out, trans_loss + loss
         if getattr(self, "fuse_bn", False):         # opt-in (OfficeTrainStep): batch-norm + quantiser + ReLU as one chain
             out = self.act_q1.forward_bn_relu(self.bn1, self.conv1(x))
             out = self.act_q2.forward_bn_relu(self.bn2, self.conv2(out))
@@ -112,8 +122,15 @@ class ResNet(nn.Module):
             layers.append(block(self.wbit, self.abit, self.stage, self.inplanes, planes, base_width=self.base_width))
         return nn.Sequential(*layers)
 
-    def forward(self, x):
+    def forward(self, x, groups=1):
         trans_loss = 0.
+        if groups > 1:
+            x = self.maxpool(self.act_q0.forward_bn_relu(self.bn1, self.conv1(x), groups))
+            for layers in (self.layer1, self.layer2, self.layer3, self.layer4):
+                for layer in layers:
+                    x, loss = layer(x, groups)
+                    trans_loss += loss
+            return torch.flatten(self.avgpool(x), 1), trans_loss
         if getattr(self, "fuse_bn", False):
             x = self.maxpool(self.act_q0.forward_bn_relu(self.bn1, self.conv1(x)))
         elif getattr(self, "fuse_relu", False):
@@ -157,6 +174,21 @@ class DANN(nn.Module):
         feature = feature.view(-1, 2048)
         reverse_feature = ReverseLayerF.apply(feature, alpha)
         return self.class_classifier(feature), self.domain_classifier(reverse_feature), trans_loss
+
+    def forward_dual(self, x_src, x_tgt, alpha):
+        """The source and the target pass of one DANN iteration (dann_office/main.py:351-372) in ONE traversal: both batches
+        back to back through the per-sample convolutions, every batch statistic / quantiser site / correlation per domain in
+        pass order (running statistics: source then target; ADMM.D: the target's), so every parameter has ONE incoming
+        gradient.  Returns (class logits of the source batch, domain logits source, domain logits target, trans loss of both
+        passes) - the target pass's class logits, which main.py never uses, are not computed."""
+        B = x_src.shape[0]
+        x = torch.cat([x_src, x_tgt], 0)
+        if x_src.dim() == 4 and x_src.is_contiguous(memory_format=torch.channels_last):
+            x = x.contiguous(memory_format=torch.channels_last)
+        feature, trans_loss = self.feature(x, groups=2)
+        feature = feature.view(-1, 2048)
+        dom = self.domain_classifier(ReverseLayerF.apply(feature, alpha))
+        return self.class_classifier(feature[:B]), dom[:B], dom[B:], trans_loss
 
 
 def resnet50_dann(wbit, abit, stage="aligned", **kwargs):

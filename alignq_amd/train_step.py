@@ -282,7 +282,7 @@ class OfficeTrainStep:
     SGD-stepped first and then overwritten by the closed form, exactly like the reference."""
 
     def __init__(self, model, lr=0.04, momentum=0.9, weight_decay=5e-4, alpha=0.5, channels_last=False, fuse_relu=True,
-                 grad_hook=None, fuse_bn=True):
+                 grad_hook=None, fuse_bn=True, dual=None):
         """grad_hook: the data-parallel all-reduce (alignq_amd.dp.attach_office -> BucketedGradAllReduce): begin() right
         before backward, its buckets' collectives start from autograd hooks while the backward runs, finish() before the
         optimizer steps.
@@ -290,7 +290,10 @@ class OfficeTrainStep:
         kernels run the ResNet-50 step in 30.9 instead of 34.7 ms on MI355X; the quantise / Gram kernels are layout-agnostic.
         fuse_relu: `relu(act_q(.))` of the stem and of each bottleneck's first two sites as one launch each way.
         fuse_bn (channels_last only): additionally the training-mode batch-norm in front of those quantisers is folded into
-        them (fused.bn_act_relu: statistics + one elementwise pass; SURVEY.md 8f-N1 on configuration 5)."""
+        them (fused.bn_act_relu: statistics + one elementwise pass; SURVEY.md 8f-N1 on configuration 5).
+        dual (default: on with fuse_bn and channels_last): the source and the target pass as ONE traversal (DANN.forward_dual):
+        the per-sample convolutions see both batches at once, batch statistics / sites / correlations stay per domain in pass
+        order; every parameter then has one incoming gradient (no accumulation kernels) and the weights are quantised once."""
         if channels_last:
             model = model.to(memory_format=torch.channels_last)
         self.channels_last = channels_last
@@ -298,6 +301,7 @@ class OfficeTrainStep:
             if hasattr(mod, "act_q0") or (hasattr(mod, "act_q1") and hasattr(mod, "act_q2") and hasattr(mod, "act_q3")):
                 mod.fuse_relu = bool(fuse_relu)
                 mod.fuse_bn = bool(fuse_bn and fuse_relu and channels_last)
+        self.dual = bool(fuse_bn and fuse_relu and channels_last) if dual is None else bool(dual)
         self.model, self.alpha = model, alpha
         named = list(model.named_parameters())
         self.param_admm = [(n, p) for n, p in named if "alterD" in n or "gamma" in n]
@@ -339,9 +343,13 @@ class OfficeTrainStep:
         label_src = torch.zeros(xs.shape[0], dtype=torch.long, device=dev)
         label_tgt = torch.ones(xt.shape[0], dtype=torch.long, device=dev)
         prequantize_weights(self.all_convs)
-        cls_s, dom_s, tl_s = m(xs, alpha=self.alpha)
-        prequantize_weights(self.all_convs)          # the reference quantises every weight once per pass
-        _, dom_t, tl_t = m(xt, alpha=self.alpha)
+        if self.dual and xs.shape == xt.shape:
+            cls_s, dom_s, dom_t, tl_both = m.forward_dual(xs, xt, alpha=self.alpha)      # (same weights, hence the same W_q,
+            tl_s, tl_t = tl_both, 0.0                                                    #  in both of the reference's passes)
+        else:
+            cls_s, dom_s, tl_s = m(xs, alpha=self.alpha)
+            prequantize_weights(self.all_convs)          # the reference quantises every weight once per pass
+            _, dom_t, tl_t = m(xt, alpha=self.alpha)
         loss = (F.cross_entropy(cls_s, ys) + F.cross_entropy(dom_s, label_src) + F.cross_entropy(dom_t, label_tgt)
                 + tl_s + tl_t)
         hook = self.grad_hook if overlap else None

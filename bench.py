@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--no-shapes", action="store_true", help="skip the roofline-sized microbench shapes (kernels.roofline_shapes); "
                     "the rocprofv3 passes of tools/make_profiles.sh use it so that their per-kernel averages hold the CIFAR shapes only")
     ap.add_argument("--cpu-steps", type=int, default=10, help="timed steps per thread count of the CPU baseline (BASELINE.md: >= 10)")
+    ap.add_argument("--no-dual", action="store_true", help="resnet50_dann: source and target pass as two traversals (the "
+                    "default merges them: one convolution launch per layer for both batches)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short captured runs of BASELINE.json's other "
                     "configurations (extra key other_configs: ResNet-20 2W/2A, ResNet-56 4W/4A, ResNet-50-DANN batch 28)")
     ap.add_argument("--no-fuse-bn", action="store_true", help="keep torch/MIOpen batch-norm instead of folding it into the ADMM-site kernels")
@@ -584,7 +586,7 @@ def main():
         from alignq_amd.train_step import OfficeTrainStep
         model = resnet50_dann(a.bits, a.bits).to(dev).train()
         ostep = OfficeTrainStep(model, lr=a.lr if a.lr is not None else 0.004, channels_last=not a.nchw,
-                                fuse_bn=not a.no_fuse_bn)
+                                fuse_bn=not a.no_fuse_bn, dual=(False if a.no_dual else None))
         if world > 1 or a.dp_selftest:       # >= 4 gradient buckets all-reduced from autograd hooks during the backward
             office_hook = dp.attach_office(ostep, force=a.dp_selftest)
         xs = torch.randn(a.batch, 3, 224, 224, generator=gen).to(dev)

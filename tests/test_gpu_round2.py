@@ -246,8 +246,8 @@ def test_captured_step_runs_an_off_shape_batch_eagerly_and_keeps_its_graph(dev):
 
 
 # ------------------------------------------------------------------------------------------------ Office / DANN (N3)
-@pytest.mark.parametrize("channels_last,fuse_relu", [(False, False), (True, True)])
-def test_office_tiny_dann_two_iterations_vs_reference(dev, channels_last, fuse_relu):
+@pytest.mark.parametrize("channels_last,fuse_relu,dual", [(False, False, False), (True, True, False), (True, True, True)])
+def test_office_tiny_dann_two_iterations_vs_reference(dev, channels_last, fuse_relu, dual):
     """SURVEY §8f-N3 at value level: OfficeTrainStep on the tiny DANN of fixture G10 (captured from the reference's own
     dann_office model through main.py:343-456's sequence; the eager restatement reproduces it to 1e-6 on CPU,
     tests/test_oracle_torch.py) — two iterations with the per-epoch SGD re-creation (new_epoch) between them.
@@ -268,8 +268,10 @@ def test_office_tiny_dann_two_iterations_vs_reference(dev, channels_last, fuse_r
         assert [n for n, _ in net.named_parameters()] == list(g["names"])
         det_init_(net)
         net = net.to(dev).train()
+        # (True, True, *): every batch-norm on the folded kernels (round 3); dual: source + target pass as ONE traversal
         step = OfficeTrainStep(net, lr=float(g["lr"]), alpha=float(g["alpha"]), channels_last=channels_last,
-                               fuse_relu=fuse_relu)
+                               fuse_relu=fuse_relu, dual=dual)
+        assert step.dual == dual
         named = list(net.named_parameters())
         blocks = step.blocks
         init_state = {n: p.detach().clone() for n, p in named}
