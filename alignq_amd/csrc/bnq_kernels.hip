@@ -45,6 +45,17 @@ __global__ __launch_bounds__(NT) void bnq_sums_kernel(const float* __restrict__ 
                                                       const float* __restrict__ save, int64_t P, int C, float r, int relu,
                                                       double* __restrict__ part) {
   __shared__ double sm[NT][8];
+  // blockIdx.y = group: the batch slices of a merged multi-pass tensor ([groups][P][C] back to back), each with its own
+  // statistics (ab / save: [groups][2][C]; part: [groups][gridDim.x][C][2])
+  {
+    const int64_t go = (int64_t)blockIdx.y * P * C;
+    z += go;
+    if (g) g += go;
+    if (y) y += go;
+    if (ab) ab += (int64_t)blockIdx.y * 2 * C;
+    if (save) save += (int64_t)blockIdx.y * 2 * C;
+    part += (int64_t)blockIdx.y * gridDim.x * C * 2;
+  }
   const int tid = threadIdx.x;
   const int C4 = C >> 2, slots = NT / C4;
   const int cq = tid % C4, slot = tid / C4;
@@ -135,43 +146,62 @@ __device__ __forceinline__ void bnq_channel_totals(const double* __restrict__ pa
   for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
 }
 
-// grid = ceil(C / 16); thread = (channel c = 16*block + tid/16, lane sub = tid % 16)
+// grid = ceil(C / 16); thread = (channel c = 16*block + tid/16, lane sub = tid % 16).  groups: the slices' statistics one after
+// the other (running statistics updated in slice order, like successive forward passes of the module).
 __global__ __launch_bounds__(kT) void bnq_finalize_kernel(const double* __restrict__ part, int nparts, int64_t P, int C,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
                                                           long long* __restrict__ nbt, float momentum, float eps,
-                                                          float* __restrict__ ab, float* __restrict__ save) {
+                                                          float* __restrict__ ab, float* __restrict__ save, int groups) {
   const int c = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
-  double a, q;
-  bnq_channel_totals(part, nparts, C, c, sub, a, q);
-  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
-  if (c >= C || sub != 0) return;
-  const double n = (double)P;
-  const double mean = a / n;
-  double var = q / n - mean * mean;
-  if (var < 0) var = 0;
-  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-  const float gm = gamma ? gamma[c] : 1.0f, bt = beta ? beta[c] : 0.0f;
-  const float av = gm * invstd;
-  ab[c] = av;
-  ab[C + c] = bt - (float)mean * av;
-  save[c] = (float)mean;
-  save[C + c] = invstd;
-  if (running_mean) running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
-  if (running_var) running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)(var * n / (n - 1.0));
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += groups;
+  float rm = 0.f, rv = 0.f;
+  const bool owner = c < C && sub == 0;
+  if (owner) { rm = running_mean ? running_mean[c] : 0.f; rv = running_var ? running_var[c] : 0.f; }
+  for (int gi = 0; gi < groups; gi++) {
+    double a, q;
+    bnq_channel_totals(part + (int64_t)gi * nparts * C * 2, nparts, C, c, sub, a, q);
+    if (!owner) continue;
+    const double n = (double)P;
+    const double mean = a / n;
+    double var = q / n - mean * mean;
+    if (var < 0) var = 0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float gm = gamma ? gamma[c] : 1.0f, bt = beta ? beta[c] : 0.0f;
+    const float av = gm * invstd;
+    float* abg = ab + (int64_t)gi * 2 * C;
+    float* svg = save + (int64_t)gi * 2 * C;
+    abg[c] = av;
+    abg[C + c] = bt - (float)mean * av;
+    svg[c] = (float)mean;
+    svg[C + c] = invstd;
+    rm = (1.0f - momentum) * rm + momentum * (float)mean;
+    rv = (1.0f - momentum) * rv + momentum * (float)(var * n / (n - 1.0));
+  }
+  if (owner) {
+    if (running_mean) running_mean[c] = rm;
+    if (running_var) running_var[c] = rv;
+  }
 }
 
+// dgamma / dbeta: the SUM over the groups (one parameter, several slices); ktot: [groups][2][C]
 __global__ __launch_bounds__(kT) void bnq_finalize_bwd_kernel(const double* __restrict__ part, int nparts, int64_t P, int C,
                                                               float* __restrict__ ktot, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta) {
+                                                              float* __restrict__ dbeta, int groups) {
   const int c = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
-  double a, q;
-  bnq_channel_totals(part, nparts, C, c, sub, a, q);
+  double ta = 0, tq = 0;
+  for (int gi = 0; gi < groups; gi++) {
+    double a, q;
+    bnq_channel_totals(part + (int64_t)gi * nparts * C * 2, nparts, C, c, sub, a, q);
+    if (c >= C || sub != 0) continue;
+    ktot[(int64_t)gi * 2 * C + c] = (float)(a / (double)P);
+    ktot[(int64_t)gi * 2 * C + C + c] = (float)(q / (double)P);
+    ta += a;
+    tq += q;
+  }
   if (c >= C || sub != 0) return;
-  ktot[c] = (float)(a / (double)P);
-  ktot[C + c] = (float)(q / (double)P);
-  if (dbeta) dbeta[c] = (float)a;
-  if (dgamma) dgamma[c] = (float)q;
+  if (dbeta) dbeta[c] = (float)ta;
+  if (dgamma) dgamma[c] = (float)tq;
 }
 
 // ---- elementwise passes: tiles of kUa x 256 float4 per block; 256 % (C/4) == 0 keeps a thread on one channel quad ----------
@@ -183,6 +213,9 @@ __global__ __launch_bounds__(NT) void bnq_apply_fwd_kernel(const float* __restri
   __syncthreads();
   const NerfTab tab = nerf_tab(nerf_lds);
   const Levels nlev = make_levels(k, fabsf(r) <= 8.0f);
+  z += (int64_t)blockIdx.y * nvec * 4;           // blockIdx.y = group (see bnq_sums_kernel)
+  y += (int64_t)blockIdx.y * nvec * 4;
+  ab += (int64_t)blockIdx.y * 2 * C;
   const int cq = threadIdx.x % (C >> 2);
   const float4 a4 = *reinterpret_cast<const float4*>(ab + 4 * cq);
   const float4 b4 = *reinterpret_cast<const float4*>(ab + C + 4 * cq);
@@ -225,6 +258,12 @@ __global__ __launch_bounds__(NT) void bnq_apply_bwd_kernel(const float* __restri
                                                            int64_t nvec, int C, float r, int relu, int from_dx,
                                                            float* __restrict__ dz) {
   constexpr int U = 2;
+  {
+    const int64_t go = (int64_t)blockIdx.y * nvec * 4;       // blockIdx.y = group
+    g += go; z += go; dz += go;
+    if (y) y += go;
+    ab += (int64_t)blockIdx.y * 2 * C; save += (int64_t)blockIdx.y * 2 * C; ktot += (int64_t)blockIdx.y * 2 * C;
+  }
   const int cq = threadIdx.x % (C >> 2);
   const float4 a4 = *reinterpret_cast<const float4*>(ab + 4 * cq), b4 = *reinterpret_cast<const float4*>(ab + C + 4 * cq);
   const float4 m4 = *reinterpret_cast<const float4*>(save + 4 * cq), i4 = *reinterpret_cast<const float4*>(save + C + 4 * cq);
@@ -295,15 +334,24 @@ inline int parts_for(int64_t P, int C) {
 
 extern "C" {
 
-size_t alignq_bnq_ws_bytes(int C) {
-  if (C <= 0) return 0;
-  return (size_t)kParts * C * 2 * sizeof(double) + (size_t)2 * C * sizeof(float);
+// groups: the tensor is [groups][P][C] -- batch slices of a merged multi-pass traversal, each normalised with its own batch
+// statistics (ab / save are [groups][2][C]); one launch per kernel covers all of them (blockIdx.y = group)
+size_t alignq_bnq_ws_bytes(int C, int groups) {
+  if (C <= 0 || groups < 1 || groups > ALIGNQ_BNQ_MAX_GROUPS) return 0;
+  return (size_t)groups * ((size_t)kParts * C * 2 * sizeof(double) + (size_t)2 * C * sizeof(float));
 }
 
-int alignq_bnq_fwd(const float* z, int64_t P, int C, const float* gamma, const float* beta, float* running_mean,
+namespace {
+inline bool bad_groups(int groups) { return groups < 1 || groups > ALIGNQ_BNQ_MAX_GROUPS; }
+inline float* ktot_of(void* ws, int C, int groups) {
+  return reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + (size_t)groups * kParts * C * 2 * sizeof(double));
+}
+}  // namespace
+
+int alignq_bnq_fwd(const float* z, int64_t P, int C, int groups, const float* gamma, const float* beta, float* running_mean,
                    float* running_var, int64_t* num_batches_tracked, float momentum, float bn_eps, int k, float act_range,
                    int formula, int relu, float* ab, float* save, float* y, void* ws, void* stream) {
-  if (!z || !ab || !save || !y || !ws || P < 2) return ALIGNQ_EINVAL;
+  if (!z || !ab || !save || !y || !ws || P < 2 || bad_groups(groups)) return ALIGNQ_EINVAL;
   if (!((k >= 1 && k <= 16) || k == 32)) return ALIGNQ_EINVAL;
   if (formula != ALIGNQ_FORMULA_ADMM && formula != ALIGNQ_FORMULA_CDF) return ALIGNQ_EINVAL;
   if (bad_c(C)) return ALIGNQ_EUNSUPPORTED;
@@ -311,80 +359,82 @@ int alignq_bnq_fwd(const float* z, int64_t P, int C, const float* gamma, const f
   hipStream_t st = (hipStream_t)stream;
   double* part = reinterpret_cast<double*>(ws);
   const int np = parts_for(P, C);
-  BNQ_NT(C, hipLaunchKernelGGL((bnq_sums_kernel<0, NTV>), dim3(np), dim3(NTV), 0, st, z, nullptr, nullptr, nullptr, nullptr, P, C, act_range,
-                     0, part));
+  BNQ_NT(C, hipLaunchKernelGGL((bnq_sums_kernel<0, NTV>), dim3(np, groups), dim3(NTV), 0, st, z, nullptr, nullptr, nullptr, nullptr, P, C,
+                     act_range, 0, part));
   hipLaunchKernelGGL(bnq_finalize_kernel, dim3((C + 15) / 16), dim3(kT), 0, st, (const double*)part, np, P, C, gamma, beta,
-                     running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), momentum, bn_eps, ab, save);
+                     running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), momentum, bn_eps, ab, save,
+                     groups);
   const int64_t nvec = P * (C >> 2);
   if (formula == ALIGNQ_FORMULA_ADMM)
-    BNQ_NT(C, hipLaunchKernelGGL((bnq_apply_fwd_kernel<0, NTV>), dim3(tiles(nvec, kUa, NTV)), dim3(NTV), 0, st, z, (const float*)ab, nvec, C, k,
+    BNQ_NT(C, hipLaunchKernelGGL((bnq_apply_fwd_kernel<0, NTV>), dim3(tiles(nvec, kUa, NTV), groups), dim3(NTV), 0, st, z, (const float*)ab, nvec, C, k,
                        act_range, relu, y));
   else
-    BNQ_NT(C, hipLaunchKernelGGL((bnq_apply_fwd_kernel<1, NTV>), dim3(tiles(nvec, kUa, NTV)), dim3(NTV), 0, st, z, (const float*)ab, nvec, C, k,
+    BNQ_NT(C, hipLaunchKernelGGL((bnq_apply_fwd_kernel<1, NTV>), dim3(tiles(nvec, kUa, NTV), groups), dim3(NTV), 0, st, z, (const float*)ab, nvec, C, k,
                        act_range, relu, y));
   return hipGetLastError() == hipSuccess ? 0 : ALIGNQ_EINVAL;
 }
 
 int alignq_bnq_bwd(const float* g, const float* z, const float* y, const float* ab, const float* save, int64_t P, int C,
-                   float act_range, int relu, float* dz, float* dgamma, float* dbeta, void* ws, void* stream) {
-  if (!g || !z || !ab || !save || !dz || !ws || P < 2 || (relu && !y)) return ALIGNQ_EINVAL;
+                   int groups, float act_range, int relu, float* dz, float* dgamma, float* dbeta, void* ws, void* stream) {
+  if (!g || !z || !ab || !save || !dz || !ws || P < 2 || (relu && !y) || bad_groups(groups)) return ALIGNQ_EINVAL;
   if (bad_c(C)) return ALIGNQ_EUNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(dz) |
        reinterpret_cast<uintptr_t>(y)) & 15)
     return ALIGNQ_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   double* part = reinterpret_cast<double*>(ws);
-  float* ktot = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + (size_t)kParts * C * 2 * sizeof(double));
+  float* ktot = ktot_of(ws, C, groups);
   const int np = parts_for(P, C);
-  BNQ_NT(C, hipLaunchKernelGGL((bnq_sums_kernel<1, NTV>), dim3(np), dim3(NTV), 0, st, z, g, y, ab, save, P, C, act_range, relu, part));
+  BNQ_NT(C, hipLaunchKernelGGL((bnq_sums_kernel<1, NTV>), dim3(np, groups), dim3(NTV), 0, st, z, g, y, ab, save, P, C, act_range, relu, part));
   hipLaunchKernelGGL(bnq_finalize_bwd_kernel, dim3((C + 15) / 16), dim3(kT), 0, st, (const double*)part, np, P, C, ktot,
-                     dgamma, dbeta);
+                     dgamma, dbeta, groups);
   const int64_t nvec = P * (C >> 2);
-  BNQ_NT(C, hipLaunchKernelGGL((bnq_apply_bwd_kernel<NTV>), dim3(tiles(nvec, 2, NTV)), dim3(NTV), 0, st, g, z, y, ab, save, (const float*)ktot, nvec,
+  BNQ_NT(C, hipLaunchKernelGGL((bnq_apply_bwd_kernel<NTV>), dim3(tiles(nvec, 2, NTV), groups), dim3(NTV), 0, st, g, z, y, ab, save, (const float*)ktot, nvec,
                      C, act_range, relu, 0, dz));
   return hipGetLastError() == hipSuccess ? 0 : ALIGNQ_EINVAL;
 }
 
 // The batch-norm alone (no quantiser behind it in the same chain): statistics -> (a, b); y = a*z + b; backward from a given dx.
-int alignq_bnq_stats(const float* z, int64_t P, int C, const float* gamma, const float* beta, float* running_mean,
+int alignq_bnq_stats(const float* z, int64_t P, int C, int groups, const float* gamma, const float* beta, float* running_mean,
                      float* running_var, int64_t* num_batches_tracked, float momentum, float bn_eps, float* ab, float* save,
                      void* ws, void* stream) {
-  if (!z || !ab || !save || !ws || P < 2) return ALIGNQ_EINVAL;
+  if (!z || !ab || !save || !ws || P < 2 || bad_groups(groups)) return ALIGNQ_EINVAL;
   if (bad_c(C)) return ALIGNQ_EUNSUPPORTED;
   if (reinterpret_cast<uintptr_t>(z) & 15) return ALIGNQ_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   double* part = reinterpret_cast<double*>(ws);
   const int np = parts_for(P, C);
-  BNQ_NT(C, hipLaunchKernelGGL((bnq_sums_kernel<0, NTV>), dim3(np), dim3(NTV), 0, st, z, nullptr, nullptr, nullptr, nullptr, P, C, 0.f, 0, part));
+  BNQ_NT(C, hipLaunchKernelGGL((bnq_sums_kernel<0, NTV>), dim3(np, groups), dim3(NTV), 0, st, z, nullptr, nullptr, nullptr, nullptr, P, C, 0.f, 0, part));
   hipLaunchKernelGGL(bnq_finalize_kernel, dim3((C + 15) / 16), dim3(kT), 0, st, (const double*)part, np, P, C, gamma, beta,
-                     running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), momentum, bn_eps, ab, save);
+                     running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), momentum, bn_eps, ab, save,
+                     groups);
   return hipGetLastError() == hipSuccess ? 0 : ALIGNQ_EINVAL;
 }
 
-int alignq_bnq_affine(const float* z, const float* ab, int64_t P, int C, float* y, void* stream) {
-  if (!z || !ab || !y || P < 1) return ALIGNQ_EINVAL;
+int alignq_bnq_affine(const float* z, const float* ab, int64_t P, int C, int groups, float* y, void* stream) {
+  if (!z || !ab || !y || P < 1 || bad_groups(groups)) return ALIGNQ_EINVAL;
   if (bad_c(C)) return ALIGNQ_EUNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(y)) & 15) return ALIGNQ_EINVAL;
   const int64_t nvec = P * (C >> 2);
-  BNQ_NT(C, hipLaunchKernelGGL((bnq_apply_fwd_kernel<2, NTV>), dim3(tiles(nvec, kUa, NTV)), dim3(NTV), 0, (hipStream_t)stream, z, ab, nvec, C, 32, 1.0f,
+  BNQ_NT(C, hipLaunchKernelGGL((bnq_apply_fwd_kernel<2, NTV>), dim3(tiles(nvec, kUa, NTV), groups), dim3(NTV), 0, (hipStream_t)stream, z, ab, nvec, C, 32, 1.0f,
                      0, y));
   return hipGetLastError() == hipSuccess ? 0 : ALIGNQ_EINVAL;
 }
 
-int alignq_bnq_bwd_dx(const float* dx, const float* z, const float* ab, const float* save, int64_t P, int C, float* dz,
-                      float* dgamma, float* dbeta, void* ws, void* stream) {
-  if (!dx || !z || !ab || !save || !dz || !ws || P < 2) return ALIGNQ_EINVAL;
+int alignq_bnq_bwd_dx(const float* dx, const float* z, const float* ab, const float* save, int64_t P, int C, int groups,
+                      float* dz, float* dgamma, float* dbeta, void* ws, void* stream) {
+  if (!dx || !z || !ab || !save || !dz || !ws || P < 2 || bad_groups(groups)) return ALIGNQ_EINVAL;
   if (bad_c(C)) return ALIGNQ_EUNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(dz)) & 15) return ALIGNQ_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   double* part = reinterpret_cast<double*>(ws);
-  float* ktot = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + (size_t)kParts * C * 2 * sizeof(double));
+  float* ktot = ktot_of(ws, C, groups);
   const int np = parts_for(P, C);
-  BNQ_NT(C, hipLaunchKernelGGL((bnq_sums_kernel<2, NTV>), dim3(np), dim3(NTV), 0, st, z, dx, nullptr, ab, save, P, C, 0.f, 0, part));
+  BNQ_NT(C, hipLaunchKernelGGL((bnq_sums_kernel<2, NTV>), dim3(np, groups), dim3(NTV), 0, st, z, dx, nullptr, ab, save, P, C, 0.f, 0, part));
   hipLaunchKernelGGL(bnq_finalize_bwd_kernel, dim3((C + 15) / 16), dim3(kT), 0, st, (const double*)part, np, P, C, ktot,
-                     dgamma, dbeta);
+                     dgamma, dbeta, groups);
   const int64_t nvec = P * (C >> 2);
-  BNQ_NT(C, hipLaunchKernelGGL((bnq_apply_bwd_kernel<NTV>), dim3(tiles(nvec, 2, NTV)), dim3(NTV), 0, st, dx, z, nullptr, ab, save, (const float*)ktot,
+  BNQ_NT(C, hipLaunchKernelGGL((bnq_apply_bwd_kernel<NTV>), dim3(tiles(nvec, 2, NTV), groups), dim3(NTV), 0, st, dx, z, nullptr, ab, save, (const float*)ktot,
                      nvec, C, 0.f, 0, 1, dz));
   return hipGetLastError() == hipSuccess ? 0 : ALIGNQ_EINVAL;
 }

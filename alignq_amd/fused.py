@@ -571,13 +571,11 @@ class BNQuantReluFn(torch.autograd.Function):
         ab = torch.empty(groups, 2, C, dtype=torch.float32, device=dev)
         save = torch.empty(groups, 2, C, dtype=torch.float32, device=dev)
         y = torch.empty_like(z)
-        ws = torch.empty(lib.alignq_bnq_ws_bytes(C), dtype=torch.uint8, device=dev)
-        for gi in range(groups):
-            zg, yg = z[gi * Bg:(gi + 1) * Bg], y[gi * Bg:(gi + 1) * Bg]
-            L.check(lib.alignq_bnq_fwd(L.ptr(zg), P, C, L.ptr(weight), L.ptr(bias), L.ptr(running_mean), L.ptr(running_var),
-                                       L.ptr(nbt), float(momentum), float(bn_eps), int(k), float(act_range), int(formula),
-                                       int(bool(relu)), L.ptr(ab[gi]), L.ptr(save[gi]), L.ptr(yg), L.ptr(ws), L.stream_ptr()),
-                    "alignq_bnq_fwd")
+        ws = torch.empty(lib.alignq_bnq_ws_bytes(C, groups), dtype=torch.uint8, device=dev)
+        L.check(lib.alignq_bnq_fwd(L.ptr(z), P, C, groups, L.ptr(weight), L.ptr(bias), L.ptr(running_mean), L.ptr(running_var),
+                                   L.ptr(nbt), float(momentum), float(bn_eps), int(k), float(act_range), int(formula),
+                                   int(bool(relu)), L.ptr(ab), L.ptr(save), L.ptr(y), L.ptr(ws), L.stream_ptr()),
+                "alignq_bnq_fwd")
         ctx.save_for_backward(z, y if relu else None, ab, save)
         ctx.cfg = (float(act_range), bool(relu), weight is not None, bias is not None, int(groups))
         ctx.mark_non_differentiable(*[t for t in (running_mean, running_var, nbt) if t is not None])
@@ -592,21 +590,12 @@ class BNQuantReluFn(torch.autograd.Function):
         g = L.like_layout(g, z)
         lib = L.load()
         dz = torch.empty_like(z)
-        dgamma = torch.empty(groups, C, dtype=torch.float32, device=z.device) if has_w else None
-        dbeta = torch.empty(groups, C, dtype=torch.float32, device=z.device) if has_b else None
-        ws = torch.empty(lib.alignq_bnq_ws_bytes(C), dtype=torch.uint8, device=z.device)
-        for gi in range(groups):
-            sl = slice(gi * Bg, (gi + 1) * Bg)
-            L.check(lib.alignq_bnq_bwd(L.ptr(g[sl]), L.ptr(z[sl]), L.ptr(None if y is None else y[sl]), L.ptr(ab[gi]),
-                                       L.ptr(save[gi]), Bg * H * W, C, act_range, int(relu), L.ptr(dz[sl]),
-                                       L.ptr(None if dgamma is None else dgamma[gi]), L.ptr(None if dbeta is None else dbeta[gi]),
-                                       L.ptr(ws), L.stream_ptr()), "alignq_bnq_bwd")
-        if groups > 1:
-            dgamma = None if dgamma is None else dgamma.sum(0)
-            dbeta = None if dbeta is None else dbeta.sum(0)
-        else:
-            dgamma = None if dgamma is None else dgamma[0]
-            dbeta = None if dbeta is None else dbeta[0]
+        dgamma = torch.empty(C, dtype=torch.float32, device=z.device) if has_w else None
+        dbeta = torch.empty(C, dtype=torch.float32, device=z.device) if has_b else None
+        ws = torch.empty(lib.alignq_bnq_ws_bytes(C, groups), dtype=torch.uint8, device=z.device)
+        L.check(lib.alignq_bnq_bwd(L.ptr(g), L.ptr(z), L.ptr(y), L.ptr(ab), L.ptr(save), Bg * H * W, C, groups, act_range,
+                                   int(relu), L.ptr(dz), L.ptr(dgamma), L.ptr(dbeta), L.ptr(ws), L.stream_ptr()),
+                "alignq_bnq_bwd")
         return dz, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
@@ -635,14 +624,12 @@ class BNAffineFn(torch.autograd.Function):
         ab = torch.empty(groups, 2, C, dtype=torch.float32, device=dev)
         save = torch.empty(groups, 2, C, dtype=torch.float32, device=dev)
         y = torch.empty_like(z)
-        ws = torch.empty(lib.alignq_bnq_ws_bytes(C), dtype=torch.uint8, device=dev)
+        ws = torch.empty(lib.alignq_bnq_ws_bytes(C, groups), dtype=torch.uint8, device=dev)
         st = L.stream_ptr()
-        for gi in range(groups):
-            sl = slice(gi * Bg, (gi + 1) * Bg)
-            L.check(lib.alignq_bnq_stats(L.ptr(z[sl]), P, C, L.ptr(weight), L.ptr(bias), L.ptr(running_mean), L.ptr(running_var),
-                                         L.ptr(nbt), float(momentum), float(bn_eps), L.ptr(ab[gi]), L.ptr(save[gi]), L.ptr(ws), st),
-                    "alignq_bnq_stats")
-            L.check(lib.alignq_bnq_affine(L.ptr(z[sl]), L.ptr(ab[gi]), P, C, L.ptr(y[sl]), st), "alignq_bnq_affine")
+        L.check(lib.alignq_bnq_stats(L.ptr(z), P, C, groups, L.ptr(weight), L.ptr(bias), L.ptr(running_mean), L.ptr(running_var),
+                                     L.ptr(nbt), float(momentum), float(bn_eps), L.ptr(ab), L.ptr(save), L.ptr(ws), st),
+                "alignq_bnq_stats")
+        L.check(lib.alignq_bnq_affine(L.ptr(z), L.ptr(ab), P, C, groups, L.ptr(y), st), "alignq_bnq_affine")
         ctx.save_for_backward(z, ab, save)
         ctx.has = (weight is not None, bias is not None, int(groups))
         ctx.mark_non_differentiable(*[t for t in (running_mean, running_var, nbt) if t is not None])
@@ -657,17 +644,11 @@ class BNAffineFn(torch.autograd.Function):
         g = L.like_layout(g, z)
         lib = L.load()
         dz = torch.empty_like(z)
-        dgamma = torch.empty(groups, C, dtype=torch.float32, device=z.device) if has_w else None
-        dbeta = torch.empty(groups, C, dtype=torch.float32, device=z.device) if has_b else None
-        ws = torch.empty(lib.alignq_bnq_ws_bytes(C), dtype=torch.uint8, device=z.device)
-        for gi in range(groups):
-            sl = slice(gi * Bg, (gi + 1) * Bg)
-            L.check(lib.alignq_bnq_bwd_dx(L.ptr(g[sl]), L.ptr(z[sl]), L.ptr(ab[gi]), L.ptr(save[gi]), Bg * H * W, C, L.ptr(dz[sl]),
-                                          L.ptr(None if dgamma is None else dgamma[gi]),
-                                          L.ptr(None if dbeta is None else dbeta[gi]), L.ptr(ws), L.stream_ptr()),
-                    "alignq_bnq_bwd_dx")
-        dgamma = None if dgamma is None else (dgamma.sum(0) if groups > 1 else dgamma[0])
-        dbeta = None if dbeta is None else (dbeta.sum(0) if groups > 1 else dbeta[0])
+        dgamma = torch.empty(C, dtype=torch.float32, device=z.device) if has_w else None
+        dbeta = torch.empty(C, dtype=torch.float32, device=z.device) if has_b else None
+        ws = torch.empty(lib.alignq_bnq_ws_bytes(C, groups), dtype=torch.uint8, device=z.device)
+        L.check(lib.alignq_bnq_bwd_dx(L.ptr(g), L.ptr(z), L.ptr(ab), L.ptr(save), Bg * H * W, C, groups, L.ptr(dz), L.ptr(dgamma),
+                                      L.ptr(dbeta), L.ptr(ws), L.stream_ptr()), "alignq_bnq_bwd_dx")
         return dz, dgamma, dbeta, None, None, None, None, None, None
 
 
@@ -708,7 +689,7 @@ class BNSite1Fn(torch.autograd.Function):
             raise RuntimeError(f"batch {B} larger than ADMM dim {A.shape[0]}")
         ab = torch.empty(groups, 2, C, dtype=torch.float32, device=dev)
         save = torch.empty(groups, 2, C, dtype=torch.float32, device=dev)
-        ws_bn = torch.empty(lib.alignq_bnq_ws_bytes(C), dtype=torch.uint8, device=dev)
+        ws_bn = torch.empty(lib.alignq_bnq_ws_bytes(C, groups), dtype=torch.uint8, device=dev)
         st = L.stream_ptr()
         if residual is not None:
             residual = L.like_layout(L.dense_f32(residual, "residual"), z)
@@ -718,11 +699,11 @@ class BNSite1Fn(torch.autograd.Function):
         scal = torch.empty(groups, 4, dtype=torch.float32, device=dev)
         from .ops import _ws
         ws = _ws(lib.alignq_site_ws_bytes(B, F), dev)
+        L.check(lib.alignq_bnq_stats(L.ptr(z), P, C, groups, L.ptr(weight), L.ptr(bias), L.ptr(running_mean), L.ptr(running_var),
+                                     L.ptr(nbt), float(momentum), float(bn_eps), L.ptr(ab), L.ptr(save), L.ptr(ws_bn), st),
+                "alignq_bnq_stats")
         for gi in range(groups):
             sl = slice(gi * B, (gi + 1) * B)
-            L.check(lib.alignq_bnq_stats(L.ptr(z[sl]), P, C, L.ptr(weight), L.ptr(bias), L.ptr(running_mean), L.ptr(running_var),
-                                         L.ptr(nbt), float(momentum), float(bn_eps), L.ptr(ab[gi]), L.ptr(save[gi]), L.ptr(ws_bn),
-                                         st), "alignq_bnq_stats")
             L.check(lib.alignq_site_partials_res_ab(L.ptr(z[sl]), L.ptr(ab[gi]), C, B, F, int(k), float(act_range), float(eps),
                                                     L.ptr(None if residual is None else residual[sl]), 1, L.ptr(y[sl]),
                                                     L.ptr(stats[gi]), L.ptr(ws), st), "alignq_site_partials_res_ab")
@@ -733,7 +714,9 @@ class BNSite1Fn(torch.autograd.Function):
                    int(groups))
         ctx.set_materialize_grads(False)
         Dlast = D[groups - 1]
-        loss = scal[0, 0] if groups == 1 else scal[:, 0].sum()
+        loss = scal[0, 0]
+        for gi in range(1, groups):
+            loss = loss + scal[gi, 0]
         ctx.mark_non_differentiable(Dlast, *[t for t in (running_mean, running_var, nbt) if t is not None])
         return y, loss, Dlast
 
@@ -757,9 +740,9 @@ class BNSite1Fn(torch.autograd.Function):
         from .ops import _ws
         S = _ws(lib.alignq_site_bwd_ws_bytes(B), dev)
         dx = torch.empty_like(z)
-        dgamma = torch.empty(groups, C, dtype=torch.float32, device=dev) if has_w else None
-        dbeta = torch.empty(groups, C, dtype=torch.float32, device=dev) if has_b else None
-        ws_bn = torch.empty(lib.alignq_bnq_ws_bytes(C), dtype=torch.uint8, device=dev)
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev) if has_w else None
+        dbeta = torch.empty(C, dtype=torch.float32, device=dev) if has_b else None
+        ws_bn = torch.empty(lib.alignq_bnq_ws_bytes(C, groups), dtype=torch.uint8, device=dev)
         for gi in range(groups):
             sl = slice(gi * B, (gi + 1) * B)
             L.check(lib.alignq_site_prep_fused(L.ptr(D[gi]), L.ptr(A), L.ptr(Gm), A.shape[0], L.ptr(scal[gi]), mu, L.ptr(g_loss), B,
@@ -767,11 +750,15 @@ class BNSite1Fn(torch.autograd.Function):
             L.check(lib.alignq_site_bwd_apply_ab(L.ptr(None if g_m is None else g_m[sl]), L.ptr(S), L.ptr(z[sl]), L.ptr(ab[gi]), C,
                                                  L.ptr(stats[gi]), B, F, act_range, eps, L.ptr(dx[sl]), st),
                     "alignq_site_bwd_apply_ab")
-            L.check(lib.alignq_bnq_bwd_dx(L.ptr(dx[sl]), L.ptr(z[sl]), L.ptr(ab[gi]), L.ptr(save[gi]), P, C, L.ptr(dx[sl]),
-                                          L.ptr(None if dgamma is None else dgamma[gi]),
-                                          L.ptr(None if dbeta is None else dbeta[gi]), L.ptr(ws_bn), st), "alignq_bnq_bwd_dx")
-        red = (lambda t: None if t is None else (t.sum(0) if groups > 1 else t[0]))
-        return (dx, red(dgamma), red(dbeta), None, None, None, None, None, g_m if has_res else None, red(dA), red(dG), None, None,
+        L.check(lib.alignq_bnq_bwd_dx(L.ptr(dx), L.ptr(z), L.ptr(ab), L.ptr(save), P, C, groups, L.ptr(dx), L.ptr(dgamma),
+                                      L.ptr(dbeta), L.ptr(ws_bn), st), "alignq_bnq_bwd_dx")
+
+        def red(t):                                  # the slices' alterD / gamma gradients: one elementwise add, not a reduce
+            out = t[0]
+            for gi in range(1, groups):
+                out = out + t[gi]
+            return out
+        return (dx, dgamma, dbeta, None, None, None, None, None, g_m if has_res else None, red(dA), red(dG), None, None,
                 None, None, None, None)
 
 

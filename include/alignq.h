@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALIGNQ_ABI_VERSION 7
+#define ALIGNQ_ABI_VERSION 8
 
 #define ALIGNQ_FORMULA_ADMM 0
 #define ALIGNQ_FORMULA_CDF 1
@@ -408,7 +408,7 @@ int alignq_bn_partial_stats_nhwc(const float* z, int B, int C, int HW, void* ws,
  *   activation is never written (12 B/element instead of 20).
  * alignq_bnq_bwd (3 launches): dx = g * [y > 0] * dt/dx (y = the forward's output, required when relu), then the batch-norm
  *   backward dz = a*(dx - mean dx - zhat*mean(dx*zhat)), dgamma = sum dx*zhat, dbeta = sum dx (28 B/element instead of ~36).
- * ws: alignq_bnq_ws_bytes(C).                                                                                               */
+ * ws: alignq_bnq_ws_bytes(C, groups).                                                                                             */
 /* The batch-norm of that family WITHOUT a quantiser behind it in the same chain (C <= 2048):
  * alignq_bnq_stats: statistics + finalisation only -> ab, save (+ running statistics): what a consumer that applies
  *   x = a*z + b itself needs (alignq_site_partials_res_ab below: bn3 in front of the bottleneck's ADMM site, resnet.py:146-150);
@@ -417,22 +417,28 @@ int alignq_bn_partial_stats_nhwc(const float* z, int B, int C, int HW, void* ws,
  *   alias dx.
  * alignq_site_partials_res_ab / alignq_site_bwd_apply_ab (B <= 32): alignq_site_partials_res / alignq_site_bwd_apply reading
  *   z and applying the affine on load (channel = f mod C); the backward's dx is w.r.t. x = a*z + b.                          */
-int alignq_bnq_stats(const float* z, int64_t P, int C, const float* gamma, const float* beta, float* running_mean,
+/* groups (1..ALIGNQ_BNQ_MAX_GROUPS): z / g / y / dz are [groups][P][C] -- the batch slices of a merged multi-pass traversal
+ * (source and target passes of the Office step, dann_office/main.py:296-330, stacked along the batch) -- each slice normalised
+ * with ITS OWN batch statistics, as separate forward calls of the module would: ab and save are [groups][2][C], the running
+ * statistics are updated slice after slice and *num_batches_tracked += groups; dgamma / dbeta are the sums over the slices.
+ * One launch per kernel covers every slice.  P = pixels per slice.                                                          */
+#define ALIGNQ_BNQ_MAX_GROUPS 8
+int alignq_bnq_stats(const float* z, int64_t P, int C, int groups, const float* gamma, const float* beta, float* running_mean,
                      float* running_var, int64_t* num_batches_tracked, float momentum, float bn_eps, float* ab, float* save,
                      void* ws, void* stream);
-int alignq_bnq_affine(const float* z, const float* ab, int64_t P, int C, float* y, void* stream);
-int alignq_bnq_bwd_dx(const float* dx, const float* z, const float* ab, const float* save, int64_t P, int C, float* dz,
-                      float* dgamma, float* dbeta, void* ws, void* stream);
+int alignq_bnq_affine(const float* z, const float* ab, int64_t P, int C, int groups, float* y, void* stream);
+int alignq_bnq_bwd_dx(const float* dx, const float* z, const float* ab, const float* save, int64_t P, int C, int groups,
+                      float* dz, float* dgamma, float* dbeta, void* ws, void* stream);
 int alignq_site_partials_res_ab(const float* z, const float* ab, int C, int B, int64_t F, int k, float act_range, float eps,
                                 const float* residual, int relu, float* y, float* stats, void* ws, void* stream);
 int alignq_site_bwd_apply_ab(const float* g, const float* S, const float* z, const float* ab, int C, const float* stats, int B,
                              int64_t F, float act_range, float eps, float* dx, void* stream);
-size_t alignq_bnq_ws_bytes(int C);
-int alignq_bnq_fwd(const float* z, int64_t P, int C, const float* gamma, const float* beta, float* running_mean,
+size_t alignq_bnq_ws_bytes(int C, int groups);
+int alignq_bnq_fwd(const float* z, int64_t P, int C, int groups, const float* gamma, const float* beta, float* running_mean,
                    float* running_var, int64_t* num_batches_tracked, float momentum, float bn_eps, int k, float act_range,
                    int formula, int relu, float* ab, float* save, float* y, void* ws, void* stream);
 int alignq_bnq_bwd(const float* g, const float* z, const float* y, const float* ab, const float* save, int64_t P, int C,
-                   float act_range, int relu, float* dz, float* dgamma, float* dbeta, void* ws, void* stream);
+                   int groups, float act_range, int relu, float* dz, float* dgamma, float* dbeta, void* ws, void* stream);
 
 #ifdef __cplusplus
 }

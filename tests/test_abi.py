@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.alignq_abi_version() == _lib.ABI_VERSION == 7
+    assert lib.alignq_abi_version() == _lib.ABI_VERSION == 8
     assert b"invalid" in lib.alignq_strerror(-1)
     # pure host-side queries are safe without a GPU
     tail = 1024 + 16                                     # loss partials + arrival counter
@@ -37,7 +37,8 @@ def test_library_exports_every_declared_symbol():
     assert lib.alignq_site_ws_bytes(129, 64) == 3 * 128 * 128 * 4
     assert lib.alignq_site_ws_bytes(1025, 64) == 0
     assert lib.alignq_site_bwd_ws_bytes(256) == 256 * 256 * 4 and lib.alignq_site_bwd_ws_bytes(128) == 2 * 128 * 128 * 4
-    assert lib.alignq_bnq_ws_bytes(64) == 512 * 64 * 16 + 2 * 64 * 4
+    assert lib.alignq_bnq_ws_bytes(64, 1) == 512 * 64 * 16 + 2 * 64 * 4
+    assert lib.alignq_bnq_ws_bytes(64, 2) == 2 * (512 * 64 * 16 + 2 * 64 * 4) and lib.alignq_bnq_ws_bytes(64, 9) == 0
     assert lib.alignq_site_bwd_ws_bytes(128) == 2 * 128 * 128 * 4        # fp32 S + its bf16 hi/lo fragment image
 
 
