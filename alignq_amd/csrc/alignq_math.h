@@ -322,4 +322,20 @@ __device__ __forceinline__ void act_transform_fast(float x, float r, float* t, f
   *jac = r * ALIGNQ_TWO_OVER_SQRT_2PI * e;
 }
 
+// The same pair without the IEEE reciprocal (v_rcp_f32: 1 ulp; the rational form's own error is 1.5e-7) and with ONE exp2 shared
+// by the erf tail and the Gaussian (rjac = r * 2*phi(0)): 13 full-rate + 2 quarter-rate instructions, no table (the backward
+// kernels are as much LDS- as VALU-bound: the 24 B per element of nerf32's table reads cost more than the extra arithmetic).
+__device__ __forceinline__ void act_transform_rcp(float x, float r, float rjac, float* t, float* jac) {
+  const float a = fabsf(x) * 0.70710678118654752440f;
+  const float tt = __builtin_amdgcn_rcpf(__fmaf_rn(0.3275911f, a, 1.0f));
+  float p = 1.061405429f;
+  p = __fmaf_rn(p, tt, -1.453152027f);
+  p = __fmaf_rn(p, tt, 1.421413741f);
+  p = __fmaf_rn(p, tt, -0.284496736f);
+  p = __fmaf_rn(p, tt, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);     // exp(-x^2/2) = 2^(-x^2 * log2(e)/2)
+  *t = r * copysignf(__fmaf_rn(-p * tt, e, 1.0f), x);
+  *jac = rjac * e;
+}
+
 }  // namespace alignq

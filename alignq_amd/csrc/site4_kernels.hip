@@ -161,6 +161,24 @@ __device__ __forceinline__ void rowgroup_sums(const float (&vx)[4], const float 
   if (LPR <= 8) { t0 = dpp_add<0x128>(t0); if (PAIR) t1 = dpp_add<0x128>(t1); }      // row_ror:8
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// LDS byte address of a __shared__ object as a VECTOR register the optimiser cannot see through: accesses at base + constant
+// then use the instruction's 16-bit offset field.  (Left to itself the compiler folds the region's own offset - beyond 64 KB for
+// the backward's fp32 tiles - into every constant, materialises one address register per access and hoists them all out of the
+// tile loop: 64 registers, spilled.)
+__device__ __forceinline__ uint32_t lds_base(const void* p) {
+  uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+  asm volatile("" : "+v"(a));
+  return a;
+}
+#define XSWZ(col) ((((col) >> 4) & 1) << 4)      // site_bwd4's transposed staging: batch-row XOR of feature column `col`
+#define LDS_F32(addr) (*reinterpret_cast<__attribute__((address_space(3))) float*>(addr))
+#define LDS_F32X4(addr) (*reinterpret_cast<__attribute__((address_space(3))) f32x4_nt*>(addr))
+// the two bf16 of one dword as floats (element 0 in the low half)
+__device__ __forceinline__ f32x2 bf16_pair(uint32_t d) {
+  return f32x2{__uint_as_float(d << 16), __uint_as_float(d & 0xffff0000u)};
+}
+
 __device__ __forceinline__ void split_bf16(float v, __bf16& hi, __bf16& lo) {
   hi = (__bf16)v;
   lo = (__bf16)(v - (float)hi);
@@ -1079,7 +1097,7 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
                                                         int n_tiles, int aligned, BnFold bn) {
   BSTAMP(1, 0);
   (void)aligned;
-  constexpr int LDv = TFv + 1, TILE = 128 * LDv;
+  constexpr int LDv = TFv + 4, TILE = 128 * LDv;    // fp32 tiles: 16-byte aligned rows (copied out with 16-byte LDS reads)
   constexpr int NWv = TFv / 8;                       // waves per workgroup
   constexpr int CB = TFv / 32;                       // 32-column blocks per tile
   constexpr int LDT = 128 + 8;                       // bf16 elements per transposed row (272 B: 16-B aligned, 4-bank skew)
@@ -1091,8 +1109,11 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
   __bf16* XTlo = XThi + TARR;
   __bf16* TThi = XThi + 2 * TARR;                    // (PAIR)
   __bf16* TTlo = XThi + 3 * TARR;                    // (PAIR)
-  float* Os = reinterpret_cast<float*>(lds_raw + NT_ARR * TARR * 2);   // [128][65] output staging (PAIR: starts as g*jac)
-  float* Js = Os + TILE;                                               // [128][65] dt/dx (PAIR)
+  // dt/dx goes to the accumulator layout through Js (16-byte stores), jac*ct - cx comes back through Os (16-byte reads); g * dt/dx
+  // stays in the registers of the thread that loaded the element (round 3: the tiles used to carry g*jac too, with dword
+  // stores that collided 4-way, and the sum was formed by a read-modify-write in LDS)
+  float* Os = reinterpret_cast<float*>(lds_raw + NT_ARR * TARR * 2);   // [128][LDv] jac*ct - cx (PAIR) | cx
+  // Js = Os + TILE: [128][LDv] dt/dx (PAIR), addressed as os_acc / os_ld + kJs below
   float* red = Os + NF_ARR * TILE;                                     // [4 row blocks][2 operands][2][64]
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1105,16 +1126,40 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
   const int lc4 = tid % NCQ, lrow4 = (tid / NCQ) * 4;
 
   const float invB = 1.0f / (float)B, invBm1 = 1.0f / (float)(B - 1);
+  const float rjac = r * ALIGNQ_TWO_OVER_SQRT_2PI;
+  // Os / Js as this thread sees them: accumulator layout (rows (I*32 + 4h) + {0..3} + 8 g4, column cc) and load layout
+  const uint32_t os_acc = lds_base(Os + (I * 32 + 4 * h) * LDv + cc);
+  const uint32_t os_ld = lds_base(VEC ? Os + lrow4 * LDv + 4 * lc4 : Os + lrow0 * LDv + lcol);
+  constexpr uint32_t kJs = TILE * 4, kRow = LDv * 4;       // byte offsets: Os -> Js, row -> row + 1
   STAMP(10);
 
   float4 xr[4], gr[4];                    // VEC: this thread's x / g quads (LOOP: refilled one tile ahead)
   bf16x8 sh[8], sl[8];                    // S fragments
   // (round 3: requesting the 64-feature form's S fragments FIRST, under the tile loads - it has the registers: one workgroup
   //  per CU, 256-register budget - changed nothing: 1.172 / 1.176 / 1.173 against 1.173 / 1.168 / 1.174 ms per step)
+  if constexpr (LOOP) {     // the first tile's rows (grid <= n_tiles)
+    const bool has_g = PAIR && gup != nullptr;
+    const char* gsrc = reinterpret_cast<const char*>(has_g ? gup : x);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const unsigned off = (unsigned)(lrow4 + q) * ((unsigned)F * 4u) + (unsigned)((int)blockIdx.x * TFv + 4 * lc4) * 4u;
+      xr[q] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(x) + off);
+      gr[q] = *reinterpret_cast<const float4*>(gsrc + off);
+      if (!has_g) gr[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
   // !LOOP: one tile per workgroup (grid == n_tiles): no tile loop, nothing to hoist
   for (int tile = blockIdx.x; tile < n_tiles; tile += (int)gridDim.x) {
     const int col0 = tile * TFv;
     const bool lcol_ok = (col0 + lcol) < F;
+    float gj[PAIR ? 16 : 1];   // g * dt/dx of this thread's 16 elements (VEC: [4*row + column])
+    float4 xn[LOOP ? 4 : 1], gn[LOOP ? 4 : 1];       // (LOOP) the next tile's rows, in flight for the whole of this tile
+    float rho_x = 0.f, rho_t = 0.f;                  // 1/std of this lane's accumulator column
+    if constexpr (LOOP) {      // requested BEFORE the next tile's rows: a wait for a younger load would wait for those too
+      rho_x = stats[F + col0 + cc];
+      if (PAIR) rho_t = stats[3 * F + col0 + cc];
+    }
+
     // Addressing: kernel-argument base (SGPR pair) + one 32-bit byte offset per element, shared by x / g / y / dx /
     // dres (global_load saddr+voffset form; the launcher guarantees B*F*4 < 2^32).  Loads use offsets CLAMPED into the
     // tensor and are unconditional (a conditional load costs a branch each); out-of-range lanes are zeroed afterwards.
@@ -1126,7 +1171,10 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
 #define AT(ptr, q) (*reinterpret_cast<const float*>(reinterpret_cast<const char*>(ptr) + boff[q]))
 #define ATW(ptr, q) (*reinterpret_cast<float*>(reinterpret_cast<char*>(ptr) + boff[q]))
     // VEC addressing: one 32-bit byte offset per row for the thread's column quad (clamped like the dword form)
-    const bool q_ok = (col0 + 4 * lc4) < F;                  // F % 4 == 0: a quad lies inside or outside as a whole
+    // LOOP: only complete tiles (B == 128, F % TFv == 0 - the launcher's condition): no masks, no branches around memory
+    // operations (a conditional load or store makes the compiler wait for EVERYTHING in flight at the next use of a register
+    // that was loaded before it: the counters are in order, and it must assume the younger operation was not issued)
+    const bool q_ok = LOOP || (col0 + 4 * lc4) < F;          // F % 4 == 0: a quad lies inside or outside as a whole
     const unsigned colq = (unsigned)(q_ok ? col0 + 4 * lc4 : (int)F - 4) * 4u;
     const uint4 bo4 = make_uint4((unsigned)min(lrow4 + 0, B - 1) * rowB + colq, (unsigned)min(lrow4 + 1, B - 1) * rowB + colq,
                                  (unsigned)min(lrow4 + 2, B - 1) * rowB + colq, (unsigned)min(lrow4 + 3, B - 1) * rowB + colq);
@@ -1161,7 +1209,7 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
         }
       }
       const bool has_g = PAIR && gup != nullptr;
-      if (!LOOP || tile == (int)blockIdx.x) {     // (LOOP: every later tile was requested by the previous iteration)
+      if constexpr (!LOOP) {                      // (LOOP: requested before the loop / by the previous iteration)
 #pragma unroll
         for (int q = 0; q < 4; q++) xr[q] = AT4(x, q);          // all loads in flight before the first use
         if (has_g) {
@@ -1170,6 +1218,23 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
         } else {
 #pragma unroll
           for (int q = 0; q < 4; q++) gr[q] = z4;
+        }
+      }
+      // LOOP, software pipeline: the NEXT tile's rows are requested before this tile's are touched (read once: non-temporal),
+      // into registers of their own - a whole tile period in flight, so a CU always has 64 KB on request (requested after
+      // the staging, into the same registers, they had only the MFMA .. copy-out phases to arrive: the staging waited ~3 us)
+      if constexpr (LOOP) {
+        // always issued (the last iteration re-reads its own tile; without an upstream gradient the x rows stand in for g's)
+        const int tn = min(tile + (int)gridDim.x, n_tiles - 1);
+        const unsigned colqn = (unsigned)(tn * TFv + 4 * lc4) * 4u;
+        const char* gsrc = reinterpret_cast<const char*>(has_g ? gup : x);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const unsigned off = (unsigned)(lrow4 + q) * rowB + colqn;
+          const f32x4_nt xv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(reinterpret_cast<const char*>(x) + off));
+          const f32x4_nt gv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(gsrc + off));
+          xn[q] = make_float4(xv.x, xv.y, xv.z, xv.w);
+          gn[q] = make_float4(gv.x, gv.y, gv.z, gv.w);
         }
       }
       if (BN) {
@@ -1202,13 +1267,14 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
       }
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        if (!(q_ok && (lrow4 + q) < B)) { xr[q] = z4; gr[q] = z4; }
+        if (!LOOP && !(q_ok && (lrow4 + q) < B)) { xr[q] = z4; gr[q] = z4; }
       }
       if (BN && bn.dres && q_ok) {            // the masked gradient is also the residual branch's gradient
 #pragma unroll
         for (int q = 0; q < 4; q++)
           if (lrow4 + q < B) ATW4(bn.dres, q) = gr[q];
       }
+      float jt[PAIR ? 16 : 1];                 // dt/dx, on its way to Js
 #pragma unroll
       for (int e = 0; e < 4; e++) {            // column 4*lc4 + e: its 4 rows are 4 consecutive entries of a transposed row
         // (scalars + one braced vector construction per array: element-wise insertion into four live bf16x4 put them on the
@@ -1217,15 +1283,15 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
 #define ALIGNQ_ROW(q, XH, XL, TH, TL)                                                              \
         {                                                                                          \
           const int row = lrow4 + q;                                                               \
-          const bool ok = q_ok && row < B;                                                         \
+          const bool ok = LOOP || (q_ok && row < B);                                               \
           const float xe = f4get(xr[q], e);                                                        \
           split_bf16(ok ? (xe - f4get(mx4, e)) * f4get(rx4, e) : 0.0f, XH, XL);                    \
           if (PAIR) {                                                                              \
             float t, jac;                                                                          \
-            act_transform_fast(xe, r, &t, &jac);                                                   \
+            act_transform_rcp(xe, r, rjac, &t, &jac);                                         \
             split_bf16(ok ? (t - f4get(mt4, e)) * f4get(rt4, e) : 0.0f, TH, TL);                   \
-            Js[row * LDv + 4 * lc4 + e] = jac;                                                     \
-            Os[row * LDv + 4 * lc4 + e] = f4get(gr[q], e) * jac;                                   \
+            jt[PAIR ? 4 * q + e : 0] = jac;                                                        \
+            gj[(PAIR ? 4 * q + e : 0)] = f4get(gr[q], e) * jac;                                    \
           } else {                                                                                 \
             TH = (__bf16)0.0f; TL = (__bf16)0.0f;                                                  \
           }                                                                                        \
@@ -1235,7 +1301,9 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
         ALIGNQ_ROW(2, xh2, xl2, th2, tl2)
         ALIGNQ_ROW(3, xh3, xl3, th3, tl3)
 #undef ALIGNQ_ROW
-        const int o = (4 * lc4 + e) * LDT + lrow4;       // 8-byte aligned: LDT * 2 and lrow4 * 2 are multiples of 8
+        // 8-byte aligned: LDT * 2 and lrow4 * 2 are multiples of 8.  Rows are stored with bit 4 flipped in every second group
+        // of 16 columns (XSWZ): the 16 column quads of a wave's store would otherwise fall on 4 bank groups (4-way conflict)
+        const int o = (4 * lc4 + e) * LDT + (lrow4 ^ XSWZ(4 * lc4 + e));
         *reinterpret_cast<bf16x4*>(XThi + o) = (bf16x4){xh0, xh1, xh2, xh3};
         *reinterpret_cast<bf16x4*>(XTlo + o) = (bf16x4){xl0, xl1, xl2, xl3};
         if (PAIR) {
@@ -1243,24 +1311,11 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
           *reinterpret_cast<bf16x4*>(TTlo + o) = (bf16x4){tl0, tl1, tl2, tl3};
         }
       }
-      if constexpr (LOOP) {     // software pipeline: the registers take the next tile's rows (read once: non-temporal)
-        const int tn = tile + (int)gridDim.x;
-        if (tn < n_tiles) {
-          const bool q_okn = (tn * TFv + 4 * lc4) < F;
-          const unsigned colqn = (unsigned)(q_okn ? tn * TFv + 4 * lc4 : (int)F - 4) * 4u;
+      if (PAIR) {
 #pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const unsigned off = (unsigned)min(lrow4 + q, B - 1) * rowB + colqn;
-            const f32x4_nt xv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(reinterpret_cast<const char*>(x) + off));
-            xr[q] = make_float4(xv.x, xv.y, xv.z, xv.w);
-            if (has_g) {
-              const f32x4_nt gv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(reinterpret_cast<const char*>(gup) + off));
-              gr[q] = make_float4(gv.x, gv.y, gv.z, gv.w);
-            } else {
-              gr[q] = z4;
-            }
-          }
-        }
+        for (int q = 0; q < 4; q++)
+          LDS_F32X4(os_ld + kJs + q * kRow) =
+              f32x4_nt{jt[PAIR ? 4 * q : 0], jt[PAIR ? 4 * q + 1 : 0], jt[PAIR ? 4 * q + 2 : 0], jt[PAIR ? 4 * q + 3 : 0]};
       }
     } else
     // ---- load x (and g) for (feature lcol, rows lrow0..+15), recompute t / jac, standardise ---------------
@@ -1332,14 +1387,14 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
           xh[q] = a; xl[q] = b2;
           if (PAIR) {
             float t, jac;
-            act_transform_fast(xe, r, &t, &jac);
+            act_transform_rcp(xe, r, rjac, &t, &jac);
             split_bf16(ok ? (t - mt) * rt : 0.0f, a, b2);
             th[q] = a; tl[q] = b2;
-            Js[row * LDv + lcol] = jac;
-            Os[row * LDv + lcol] = gr[8 * half + q] * jac;
+            LDS_F32(os_ld + kJs + (8 * half + q) * kRow) = jac;
+            gj[PAIR ? 8 * half + q : 0] = gr[8 * half + q] * jac;
           }
         }
-        const int o = lcol * LDT + lrow0 + 8 * half;
+        const int o = lcol * LDT + ((lrow0 + 8 * half) ^ XSWZ(lcol));
         *reinterpret_cast<bf16x8*>(XThi + o) = xh;
         *reinterpret_cast<bf16x8*>(XTlo + o) = xl;
         if (PAIR) {
@@ -1370,7 +1425,7 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
     for (int e = 0; e < 16; e++) { accX[e] = 0.0f; accT[e] = 0.0f; }
 #pragma unroll
     for (int ks = 0; ks < 8; ks++) {
-      const int o = cc * LDT + 16 * ks + 8 * h;
+      const int o = cc * LDT + ((16 * ks + 8 * h) ^ XSWZ(cc));
       const bf16x8 bxh = *reinterpret_cast<const bf16x8*>(XThi + o);
       const bf16x8 bxl = *reinterpret_cast<const bf16x8*>(XTlo + o);
       accX = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sh[ks], bxh, accX, 0, 0, 0);
@@ -1383,6 +1438,8 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
         accT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sh[ks], btl, accT, 0, 0, 0);
         accT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sl[ks], bth, accT, 0, 0, 0);
       }
+      // (LOOP: next to the prefetched rows and the per-element factors there is no room for every k step's B operands at once)
+      if constexpr (LOOP && PAIR) { if (ks & 1) __builtin_amdgcn_sched_barrier(0); }
     }
     STAMP(12);
     // folded batch-norm backward needs zhat of the elements this thread copies out below (the ones it loaded above):
@@ -1400,9 +1457,11 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
       }
     }
     // per-column constants of the assemble / copy-out phases: requested here too, so that their round trip is over by then
-    const bool cok = (col0 + cc) < F;
-    const float rho_x = cok ? stats[F + col0 + cc] : 0.f;
-    const float rho_t = (PAIR && cok) ? stats[3 * F + col0 + cc] : 0.0f;
+    if constexpr (!LOOP) {
+      const bool cok = (col0 + cc) < F;
+      rho_x = cok ? stats[F + col0 + cc] : 0.f;
+      rho_t = (PAIR && cok) ? stats[3 * F + col0 + cc] : 0.0f;
+    }
     float4 sv_m = make_float4(0.f, 0.f, 0.f, 0.f), sv_i = sv_m;      // (VEC, channels-last) batch mean / invstd of the column quad
     if constexpr (VEC && BN) {
       if (bn.nhwc && q_ok) {
@@ -1412,41 +1471,49 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
       }
     }
     // ---- projections over this wave's 32 batch rows: sum dVh, sum dVh*Vh.  Vh of this lane's accumulator cells
-    //      (rows (e&3)+8(e>>2)+4h of block I, column cc) are 4 consecutive entries of the transposed row: 8-byte reads
+    //      (rows (e&3)+8(e>>2)+4h of block I, column cc) are 4 consecutive entries of the transposed row: 8-byte reads.
+    //      Two rows per instruction (v_pk_add/fma_f32); the reassembled Vh stay in registers for the assembly below.
+    f32x2 xv[8], tv[PAIR ? 8 : 1];
     {
-      float x0 = 0.f, x1 = 0.f, t0 = 0.f, t1 = 0.f;
+      f32x2 x0 = {0.f, 0.f}, x1 = {0.f, 0.f}, t0 = {0.f, 0.f}, t1 = {0.f, 0.f};
 #pragma unroll
       for (int g4 = 0; g4 < 4; g4++) {
-        const int o = cc * LDT + I * 32 + 8 * g4 + 4 * h;
-        const bf16x4 a = *reinterpret_cast<const bf16x4*>(XThi + o);
-        const bf16x4 b2 = *reinterpret_cast<const bf16x4*>(XTlo + o);
+        const int o = cc * LDT + ((I * 32 + 8 * g4 + 4 * h) ^ XSWZ(cc));
+        const uint2 a = *reinterpret_cast<const uint2*>(XThi + o);
+        const uint2 b2 = *reinterpret_cast<const uint2*>(XTlo + o);
+        xv[2 * g4] = bf16_pair(a.x) + bf16_pair(b2.x);
+        xv[2 * g4 + 1] = bf16_pair(a.y) + bf16_pair(b2.y);
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          x0 += accX[4 * g4 + q];
-          x1 += accX[4 * g4 + q] * ((float)a[q] + (float)b2[q]);
+        for (int q = 0; q < 2; q++) {
+          const f32x2 av = {accX[4 * g4 + 2 * q], accX[4 * g4 + 2 * q + 1]};
+          x0 += av;
+          x1 = __builtin_elementwise_fma(av, xv[2 * g4 + q], x1);
         }
         if (PAIR) {
-          const bf16x4 c2 = *reinterpret_cast<const bf16x4*>(TThi + o);
-          const bf16x4 d2 = *reinterpret_cast<const bf16x4*>(TTlo + o);
+          const uint2 c2 = *reinterpret_cast<const uint2*>(TThi + o);
+          const uint2 d2 = *reinterpret_cast<const uint2*>(TTlo + o);
+          tv[PAIR ? 2 * g4 : 0] = bf16_pair(c2.x) + bf16_pair(d2.x);
+          tv[PAIR ? 2 * g4 + 1 : 0] = bf16_pair(c2.y) + bf16_pair(d2.y);
 #pragma unroll
-          for (int q = 0; q < 4; q++) {
-            t0 += accT[4 * g4 + q];
-            t1 += accT[4 * g4 + q] * ((float)c2[q] + (float)d2[q]);
+          for (int q = 0; q < 2; q++) {
+            const f32x2 av = {accT[4 * g4 + 2 * q], accT[4 * g4 + 2 * q + 1]};
+            t0 += av;
+            t1 = __builtin_elementwise_fma(av, tv[PAIR ? 2 * g4 + q : 0], t1);
           }
         }
       }
       // the two half-waves hold the two 16-row halves of every column: one lane swap + add sums both quantities at once and
       // leaves sum dVh in the lower half-wave, sum dVh*Vh in the upper one (no LDS crossbar round trips)
-      const float px = swap_add32(x0, x1);
+      const float px = swap_add32(x0.x + x0.y, x1.x + x1.y);
       red[((I * 2 + 0) * 2 + h) * TFv + cc] = px;
       if (PAIR) {
-        const float pt = swap_add32(t0, t1);
+        const float pt = swap_add32(t0.x + t0.y, t1.x + t1.y);
         red[((I * 2 + 1) * 2 + h) * TFv + cc] = pt;
       }
     }
     __syncthreads();
     STAMP(13);
-    // ---- assemble in LDS: out = g*jac + jac*ct - cx   (PAIR)   |   out = cx   (!PAIR) -------------------
+    // ---- in accumulator layout: cx = rho_x (dVh - mean - Vh proj), ct likewise; jac * ct - cx (PAIR) | cx  ->  Os ----
     {
       float sx0 = 0.f, sx1 = 0.f, st0 = 0.f, st1 = 0.f;
 #pragma unroll
@@ -1467,27 +1534,24 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
       }
       const float mean_x = sx0 * invB, proj_x = sx1 * invBm1 * kap_x;
       const float mean_t = st0 * invB, proj_t = st1 * invBm1 * kap_t;
+      const f32x2 mx2 = {mean_x, mean_x}, px2 = {proj_x, proj_x}, rx2 = {rho_x, rho_x};
+      const f32x2 mt2 = {mean_t, mean_t}, pt2 = {proj_t, proj_t}, rt2 = {rho_t, rho_t};
 #pragma unroll
       for (int g4 = 0; g4 < 4; g4++) {
-        const int o = cc * LDT + I * 32 + 8 * g4 + 4 * h;
-        const bf16x4 xa = *reinterpret_cast<const bf16x4*>(XThi + o);
-        const bf16x4 xb = *reinterpret_cast<const bf16x4*>(XTlo + o);
-        bf16x4 ta, tb;
-        if (PAIR) {
-          ta = *reinterpret_cast<const bf16x4*>(TThi + o);
-          tb = *reinterpret_cast<const bf16x4*>(TTlo + o);
-        }
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int e = 4 * g4 + q;
-          const int a = (I * 32 + 8 * g4 + 4 * h + q) * LDv + cc;
-          const float cx = rho_x * (accX[e] - mean_x - ((float)xa[q] + (float)xb[q]) * proj_x);
+        for (int q = 0; q < 2; q++) {
+          const int e = 4 * g4 + 2 * q;
+          const uint32_t a = os_acc + (8 * g4 + 2 * q) * kRow;
+          const f32x2 ax = {accX[e], accX[e + 1]};
+          f32x2 o2 = rx2 * (ax - mx2 - xv[2 * g4 + q] * px2);             // cx
           if (PAIR) {
-            const float ct = rho_t * (accT[e] - mean_t - ((float)ta[q] + (float)tb[q]) * proj_t);
-            Os[a] = Os[a] + ct * Js[a] - cx;     // corr(x,x) enters D with a minus sign
-          } else {
-            Os[a] = cx;
+            const f32x2 at = {accT[e], accT[e + 1]};
+            const f32x2 ct = rt2 * (at - mt2 - tv[PAIR ? 2 * g4 + q : 0] * pt2);
+            const f32x2 jp = {LDS_F32(a + kJs), LDS_F32(a + kJs + kRow)};
+            o2 = jp * ct - o2;                                              // corr(x,x) enters D with a minus sign
           }
+          LDS_F32(a) = o2.x;
+          LDS_F32(a + kRow) = o2.y;
         }
       }
     }
@@ -1513,9 +1577,14 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           const int row = lrow4 + q;
-          if (row < B) {
-            const float* op = Os + row * LDv + 4 * lc4;
-            const float oo[4] = {op[0], op[1], op[2], op[3]};
+          if (LOOP || row < B) {
+            // out = g*jac + (jac*ct - cx)  (PAIR)   |   out = cx  (!PAIR)
+            const f32x4_nt c4 = LDS_F32X4(os_ld + q * kRow);
+            float oo[4] = {c4.x, c4.y, c4.z, c4.w};
+            if (PAIR) {
+#pragma unroll
+              for (int e = 0; e < 4; e++) oo[e] += gj[PAIR ? 4 * q + e : 0];
+            }
             ATW4(dx, q) = make_float4(oo[0], oo[1], oo[2], oo[3]);
             if (BN) {
 #pragma unroll
@@ -1577,7 +1646,8 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
       for (int q = 0; q < 16; q++) {
         const int row = lrow0 + q;
         if (row < B) {
-          const float o = Os[row * LDv + lcol];
+          float o = LDS_F32(os_ld + q * kRow);
+          if (PAIR) o += gj[PAIR ? q : 0];
           ATW(dx, q) = o;
           if (BN) {
             const float zh = (zr[q] - bmu) * bis;      // x is the conv output z here
@@ -1620,7 +1690,13 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
     }
     STAMP(15);
     if constexpr (!LOOP) break;                // no back edge: the one-tile form keeps the register allocation of a plain `if`
-    __syncthreads();                           // the staging arrays are rewritten by the next tile
+    if constexpr (LOOP) {
+      const bool has_g = PAIR && gup != nullptr;
+#pragma unroll
+      for (int q = 0; q < 4; q++) { xr[q] = xn[q]; gr[q] = has_g ? gn[q] : make_float4(0.f, 0.f, 0.f, 0.f); }
+    }
+    // (no barrier here: the next tile's staging writes XT / TT / Js, whose last reads - projection, assembly - lie before this
+    //  tile's second and third barrier; Os and red are rewritten only behind the next tile's first barrier)
 #undef AT
 #undef ATW
 #undef AT4
@@ -1770,7 +1846,14 @@ int launch_bwd4(bool pair, const Geom& g, const float* gup, const float* S, cons
     else hipLaunchKernelGGL((site_bwd4_kernel<TFV, P, N, false>), grid, TFV * 8, 0, st, gup, S, x, stats, B, F, r, eps, dx,  \
                             n_tiles, aligned, bn);                                                                           \
   } while (0)
-  if (tf == 64 && vec && !bn.ab && !bn.y && !bn.ybins && !bn.dres && n_tiles > 2 * 256) {
+  static const int loop32 = [] { const char* e = getenv("ALIGNQ_BWD_LOOP32"); return e ? atoi(e) : 0; }();   // tuning aid
+  if (loop32 && vec && !bn.ab && !bn.y && !bn.ybins && !bn.dres && F > 32768 && B == 128 && F % 32 == 0) {
+    // experiment: 32-feature tiles, 256 threads, 70 KB of LDS: two (or loop32 / 256) looped workgroups per CU
+    const int nt32 = (int)((F + 31) / 32);
+    grid = loop32 >= 256 ? loop32 : 512;
+    if (pair) hipLaunchKernelGGL((site_bwd4_kernel<32, true, false, true, true>), grid, 256, 0, st, gup, S, x, stats, B, F, r, eps, dx, nt32, aligned, bn);
+    else hipLaunchKernelGGL((site_bwd4_kernel<32, false, false, true, true>), grid, 256, 0, st, gup, S, x, stats, B, F, r, eps, dx, nt32, aligned, bn);
+  } else if (tf == 64 && vec && !bn.ab && !bn.y && !bn.ybins && !bn.dres && n_tiles > 2 * 256 && B == 128 && F % 64 == 0) {
     // plain site with many tiles per CU (F > 32768): the looped, software-pipelined form (138 KB of LDS: one workgroup per CU)
     grid = 256;
     if (pair) hipLaunchKernelGGL((site_bwd4_kernel<64, true, false, true, true>), grid, 512, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_tiles, aligned, bn);
