@@ -1137,7 +1137,15 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
   bf16x8 sh[8], sl[8];                    // S fragments
   // (round 3: requesting the 64-feature form's S fragments FIRST, under the tile loads - it has the registers: one workgroup
   //  per CU, 256-register budget - changed nothing: 1.172 / 1.176 / 1.173 against 1.173 / 1.168 / 1.174 ms per step)
-  if constexpr (LOOP) {     // the first tile's rows (grid <= n_tiles)
+  // LOOP: the per-column statistics (mean x, 1/std x, mean t, 1/std t) of a tile travel one tile ahead too, through a small
+  // double-buffered LDS image [2][4][TFv]: loaded at the top of a tile they would expose a full memory latency per tile
+  __shared__ __attribute__((aligned(16))) float stt[LOOP ? 2 * 4 * TFv : 4];
+  const int st_arr = (tid / NCQ) & 3, st_q = tid % NCQ;       // the float4 of the image this thread fetches (waves 1.. repeat wave 0)
+  if constexpr (LOOP) {     // the first tile's rows (grid <= n_tiles) and statistics
+    if (tid < 4 * NCQ)
+      *reinterpret_cast<float4*>(stt + st_arr * TFv + 4 * st_q) =
+          *reinterpret_cast<const float4*>(stats + (int64_t)st_arr * F + (int)blockIdx.x * TFv + 4 * st_q);
+    __syncthreads();
     const bool has_g = PAIR && gup != nullptr;
     const char* gsrc = reinterpret_cast<const char*>(has_g ? gup : x);
 #pragma unroll
@@ -1149,15 +1157,19 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
     }
   }
   // !LOOP: one tile per workgroup (grid == n_tiles): no tile loop, nothing to hoist
+  int st_buf = 0;
   for (int tile = blockIdx.x; tile < n_tiles; tile += (int)gridDim.x) {
     const int col0 = tile * TFv;
     const bool lcol_ok = (col0 + lcol) < F;
     float gj[PAIR ? 16 : 1];   // g * dt/dx of this thread's 16 elements (VEC: [4*row + column])
     float4 xn[LOOP ? 4 : 1], gn[LOOP ? 4 : 1];       // (LOOP) the next tile's rows, in flight for the whole of this tile
     float rho_x = 0.f, rho_t = 0.f;                  // 1/std of this lane's accumulator column
-    if constexpr (LOOP) {      // requested BEFORE the next tile's rows: a wait for a younger load would wait for those too
-      rho_x = stats[F + col0 + cc];
-      if (PAIR) rho_t = stats[3 * F + col0 + cc];
+    float4 st_next = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (LOOP) {      // requested BEFORE the next tile's rows: the wait for it (vmcnt is in order) leaves those in flight
+      const int tn = min(tile + (int)gridDim.x, n_tiles - 1);
+      st_next = *reinterpret_cast<const float4*>(stats + (int64_t)st_arr * F + tn * TFv + 4 * st_q);
+      rho_x = stt[(st_buf * 4 + 1) * TFv + cc];
+      if (PAIR) rho_t = stt[(st_buf * 4 + 3) * TFv + cc];
     }
 
     // Addressing: kernel-argument base (SGPR pair) + one 32-bit byte offset per element, shared by x / g / y / dx /
@@ -1187,12 +1199,21 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
       const int fq = col0 + 4 * lc4;
       // (clamped address + value select: `ok ? *p : zero` would be turned into a select of POINTERS with the zero on the stack)
       const int fqc = q_ok ? fq : 0;
-      float4 mx4 = *reinterpret_cast<const float4*>(stats + fqc);
-      float4 rx4 = *reinterpret_cast<const float4*>(stats + F + fqc);
-      float4 mt4 = z4, rt4 = z4;
-      if (PAIR) {
-        mt4 = *reinterpret_cast<const float4*>(stats + 2 * F + fqc);
-        rt4 = *reinterpret_cast<const float4*>(stats + 3 * F + fqc);
+      float4 mx4, rx4, mt4 = z4, rt4 = z4;
+      if constexpr (LOOP) {
+        mx4 = *reinterpret_cast<const float4*>(stt + (st_buf * 4 + 0) * TFv + 4 * lc4);
+        rx4 = *reinterpret_cast<const float4*>(stt + (st_buf * 4 + 1) * TFv + 4 * lc4);
+        if (PAIR) {
+          mt4 = *reinterpret_cast<const float4*>(stt + (st_buf * 4 + 2) * TFv + 4 * lc4);
+          rt4 = *reinterpret_cast<const float4*>(stt + (st_buf * 4 + 3) * TFv + 4 * lc4);
+        }
+      } else {
+        mx4 = *reinterpret_cast<const float4*>(stats + fqc);
+        rx4 = *reinterpret_cast<const float4*>(stats + F + fqc);
+        if (PAIR) {
+          mt4 = *reinterpret_cast<const float4*>(stats + 2 * F + fqc);
+          rt4 = *reinterpret_cast<const float4*>(stats + 3 * F + fqc);
+        }
       }
       if (!q_ok) { mx4 = z4; rx4 = z4; mt4 = z4; rt4 = z4; }
       float4 a4 = make_float4(1.f, 1.f, 1.f, 1.f), b4 = z4;
@@ -1513,6 +1534,9 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
     }
     __syncthreads();
     STAMP(13);
+    if constexpr (LOOP) {      // the next tile's statistics -> the other half of the image (read behind the third barrier)
+      if (tid < 4 * NCQ) *reinterpret_cast<float4*>(stt + ((st_buf ^ 1) * 4 + st_arr) * TFv + 4 * st_q) = st_next;
+    }
     // ---- in accumulator layout: cx = rho_x (dVh - mean - Vh proj), ct likewise; jac * ct - cx (PAIR) | cx  ->  Os ----
     {
       float sx0 = 0.f, sx1 = 0.f, st0 = 0.f, st1 = 0.f;
@@ -1694,6 +1718,7 @@ __global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restr
       const bool has_g = PAIR && gup != nullptr;
 #pragma unroll
       for (int q = 0; q < 4; q++) { xr[q] = xn[q]; gr[q] = has_g ? gn[q] : make_float4(0.f, 0.f, 0.f, 0.f); }
+      st_buf ^= 1;
     }
     // (no barrier here: the next tile's staging writes XT / TT / Js, whose last reads - projection, assembly - lie before this
     //  tile's second and third barrier; Os and red are rewritten only behind the next tile's first barrier)
