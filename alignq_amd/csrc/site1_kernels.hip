@@ -275,7 +275,7 @@ __device__ __forceinline__ void acc_to_rows(float* __restrict__ R, int l31, int 
 }
 
 template <bool PAIR>
-__global__ __launch_bounds__(kThreads1) void site1_bwd_kernel(const float* __restrict__ gup, const float* __restrict__ S,
+__global__ __launch_bounds__(kThreads1, 3) void site1_bwd_kernel(const float* __restrict__ gup, const float* __restrict__ S,
                                                               const float* __restrict__ x,
                                                               const float* __restrict__ stats, int B, int64_t F, float r,
                                                               float eps, float* __restrict__ dx, int n_sub,
@@ -287,17 +287,27 @@ __global__ __launch_bounds__(kThreads1) void site1_bwd_kernel(const float* __res
   float* R = reinterpret_cast<float*>(W);
   const float invB = 1.0f / (float)B, invBm1 = 1.0f / (float)(B - 1);
 
+  const float rjac = r * ALIGNQ_TWO_OVER_SQRT_2PI;
   // S fragments (already scaled, symmetric): A[i][k], i = l31, k = 16ks + 8h + jj
   bf16x8 sh[2], sl[2];
+  {
+    // clamped addresses, all 16 requests first, values selected afterwards: a conditional load is a branch and a full wait
+    // EACH (16 serial round trips at kernel start); the empty asm keeps the optimiser from sinking a load back under its condition
+    float sv[2][8];
 #pragma unroll
-  for (int ks = 0; ks < 2; ks++) {
-    unsigned wd[8];
+    for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-    for (int jj = 0; jj < 8; jj++) {
-      const int kk = 16 * ks + 8 * h + jj;
-      wd[jj] = (l31 < B && kk < B) ? pack_hi_lo(S[l31 * B + kk]) : 0u;
+      for (int jj = 0; jj < 8; jj++) sv[ks][jj] = S[min(l31, B - 1) * B + min(16 * ks + 8 * h + jj, B - 1)];
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      unsigned wd[8];
+#pragma unroll
+      for (int jj = 0; jj < 8; jj++) {
+        asm volatile("" : "+v"(sv[ks][jj]));
+        wd[jj] = (l31 < B && 16 * ks + 8 * h + jj < B) ? pack_hi_lo(sv[ks][jj]) : 0u;
+      }
+      unpack8(wd, sh[ks], sl[ks]);
     }
-    unpack8(wd, sh[ks], sl[ks]);
   }
 
   // software pipeline on x only (g is consumed late: its loads, issued at the top, land under the transform and the MFMAs;
@@ -307,23 +317,35 @@ __global__ __launch_bounds__(kThreads1) void site1_bwd_kernel(const float* __res
   for (int sub = blockIdx.x * kWaves + w; sub < n_sub; sub += gridDim.x * kWaves) {
     const int64_t col = (int64_t)sub * SUBF + l31;
     const bool cok = col < F;
-    const int64_t base = (int64_t)(RPL * h) * F + col;
+    const int64_t colc = cok ? col : F - 1;            // loads: clamped addresses, unconditional, values selected afterwards
     float xr[RPL], gr[RPL], out[RPL];
+    const char* gsrc = reinterpret_cast<const char*>((PAIR && gup) ? gup : x);   // (no upstream gradient: x stands in, values dropped)
+    // kernel-argument base + one 32-bit byte offset per row (the launcher guarantees B*F*4 < 2^32)
+    const unsigned rowB = (unsigned)F * 4u, colB = (unsigned)colc * 4u;
+    // (the clamped offsets die with the loads; the stores below address rows through the scalar base instead)
+#pragma unroll
+    for (int q = 0; q < RPL; q++) {
+      const unsigned bo = (unsigned)min(RPL * h + q, B - 1) * rowB + colB;
+      xr[q] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(x) + bo);
+      gr[q] = *reinterpret_cast<const float*>(gsrc + bo);
+    }
+    const float mx_l = stats[colc], rx_l = stats[F + colc];
+    const float mt_l = PAIR ? stats[2 * F + colc] : 0.f, rt_l = PAIR ? stats[3 * F + colc] : 0.f;
+    float av = 1.0f, bv = 0.0f;
+    if (ab) {      // folded batch-norm: x = a*z + b on load (dx is the gradient w.r.t. x; alignq_bnq_bwd_dx takes it to z)
+      const int ch = (int)(colc & (int64_t)(C - 1));
+      av = ab[ch];
+      bv = ab[C + ch];
+    }
+    const bool has_g = PAIR && gup;
 #pragma unroll
     for (int q = 0; q < RPL; q++) {
       const bool ok = cok && RPL * h + q < B;
-      xr[q] = ok ? x[base + (int64_t)q * F] : 0.0f;
-      gr[q] = (PAIR && gup && ok) ? gup[base + (int64_t)q * F] : 0.0f;
+      xr[q] = ok ? (ab ? __fmaf_rn(av, xr[q], bv) : xr[q]) : 0.0f;
+      gr[q] = (has_g && ok) ? gr[q] : 0.0f;
     }
-    if (ab) {      // folded batch-norm: x = a*z + b on load (dx is the gradient w.r.t. x; alignq_bnq_bwd_dx takes it to z)
-      const int ch = (int)(col & (int64_t)(C - 1));
-      const float av = cok ? ab[ch] : 0.0f, bv = cok ? ab[C + ch] : 0.0f;
-#pragma unroll
-      for (int q = 0; q < RPL; q++)
-        if (cok && RPL * h + q < B) xr[q] = __fmaf_rn(av, xr[q], bv);
-    }
-    const float mx = cok ? stats[col] : 0.f, rx = cok ? stats[F + col] : 0.f;
-    const float mt = (PAIR && cok) ? stats[2 * F + col] : 0.f, rt = (PAIR && cok) ? stats[3 * F + col] : 0.f;
+    const float mx = cok ? mx_l : 0.f, rx = cok ? rx_l : 0.f;
+    const float mt = cok ? mt_l : 0.f, rt = cok ? rt_l : 0.f;
     float kap_x = 1.0f, kap_t = 1.0f;       // (sd+eps)/sd = 1/(1-eps*rho); torch's std backward is 0 where sd == 0
     if (eps != 0.0f) {
       const float dxn = 1.0f - eps * rx, dtn = 1.0f - eps * rt;
@@ -368,7 +390,7 @@ __global__ __launch_bounds__(kThreads1) void site1_bwd_kernel(const float* __res
 #pragma unroll
         for (int q = 0; q < RPL; q++) {
           float t, jac;
-          act_transform_fast(xr[q], r, &t, &jac);
+          act_transform_rcp(xr[q], r, rjac, &t, &jac);        // (jac is recomputed below: 16 registers for ~5 instructions)
           th[q] = (t - mt) * rt;
           wd[q] = (cok && RPL * h + q < B) ? pack_hi_lo(th[q]) : 0u;
         }
@@ -393,13 +415,14 @@ __global__ __launch_bounds__(kThreads1) void site1_bwd_kernel(const float* __res
 #pragma unroll
       for (int q = 0; q < RPL; q++) {
         const float ct = rt * (d[q] - mean_d - th[q] * proj);
-        out[q] += (gr[q] + ct) * act_jac(xr[q], r);
+        out[q] += (gr[q] + ct) * (rjac * __builtin_amdgcn_exp2f(xr[q] * xr[q] * -0.72134752044448170368f));
       }
     }
     if (cok) {
 #pragma unroll
       for (int q = 0; q < RPL; q++)
-        if (RPL * h + q < B) dx[base + (int64_t)q * F] = out[q];
+        if (RPL * h + q < B)       // uniform row base + this lane's (row half, column) offset
+          *reinterpret_cast<float*>(reinterpret_cast<char*>(dx) + (size_t)q * rowB + ((unsigned)(RPL * h) * rowB + colB)) = out[q];
     }
   }
 }
@@ -425,6 +448,7 @@ int launch_partials1(bool pair, const Geom& g, const float* x, int B, int64_t F,
 
 int launch_bwd1(bool pair, const float* gup, const float* S, const float* x, const float* stats, int B, int64_t F,
                 float r, float eps, float* dx, hipStream_t st, const float* ab, int C) {
+  if ((int64_t)B * F * 4 >= ((int64_t)1 << 32)) return ALIGNQ_EUNSUPPORTED;   // 32-bit byte offsets
   const int n_sub = (int)((F + SUBF - 1) / SUBF);
   int grid = (n_sub + kWaves - 1) / kWaves;
   // 141 VGPRs: three 4-wave workgroups per CU = 768 resident; a grid of exactly that (every wave loops over ~8 sub-tiles at
