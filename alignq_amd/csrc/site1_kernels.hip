@@ -96,7 +96,7 @@ __device__ __forceinline__ void gram32(const unsigned* __restrict__ W, int l31, 
 // res (or nullptr): a [B,F] tensor added to x_q before it is stored (the bottleneck's `out += identity`); relu: store relu(.)
 // (`out = self.relu(out)`): dann_office/model/resnet.py:153-154 — the stored tensor is what the next layer reads.
 template <bool PAIR, bool RES>
-__global__ __launch_bounds__(kThreads1) void site1_fwd_kernel(const float* __restrict__ x, int B, int64_t F, int k,
+__global__ __launch_bounds__(kThreads1, PAIR ? 4 : 5) void site1_fwd_kernel(const float* __restrict__ x, int B, int64_t F, int k,
                                                               float r, float eps, float* __restrict__ xq,
                                                               float* __restrict__ slabs, float* __restrict__ stats,
                                                               int n_sub, unsigned* __restrict__ counter,
@@ -123,34 +123,39 @@ __global__ __launch_bounds__(kThreads1) void site1_fwd_kernel(const float* __res
 
   // software pipeline: the rows of the NEXT sub-tile are requested before this one is transformed (a wave's 16 loads used to
   // be waited for in full before its ~500 vector instructions: ~10 us per sub-tile at four waves per SIMD)
+  // Loads: clamped addresses (kernel-argument base + one 32-bit byte offset; the launcher guarantees B*F*4 < 2^32), issued
+  // unconditionally - a conditional load is a branch each, and whatever waits for a register loaded before it waits for
+  // everything in flight (the counters are in order); rows >= B and columns >= F are masked where the values are used.
+  const unsigned rowB = (unsigned)F * 4u;
   float xn[RPL];
   {
-    const int sub0 = blockIdx.x * kWaves + w;
-    const int64_t col = (int64_t)sub0 * SUBF + l31;
-    const float* __restrict__ xp = x + (int64_t)(RPL * h) * F + col;
+    const int sub0 = min(blockIdx.x * kWaves + w, n_sub - 1);
+    const unsigned colB = (unsigned)min((int64_t)sub0 * SUBF + l31, F - 1) * 4u;
 #pragma unroll
-    for (int q = 0; q < RPL; q++) xn[q] = (sub0 < n_sub && col < F && RPL * h + q < B) ? xp[(int64_t)q * F] : 0.0f;
+    for (int q = 0; q < RPL; q++)
+      xn[q] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(x) + ((unsigned)min(RPL * h + q, B - 1) * rowB + colB));
   }
   for (int sub = blockIdx.x * kWaves + w; sub < n_sub; sub += gridDim.x * kWaves) {
     const int64_t col = (int64_t)sub * SUBF + l31;
     const bool cok = col < F;
-    float* __restrict__ qp = xq ? xq + (int64_t)(RPL * h) * F + col : nullptr;
-    float xr[RPL], tr[RPL], rr[RES ? RPL : 1];
+    // this sub-tile's clamped (row, column) byte offsets are recomputed where they are used (2 instructions each)
+    const unsigned colBc = (unsigned)min(col, F - 1) * 4u;
+#define S1_OFF(q) ((unsigned)min(RPL * h + (q), B - 1) * rowB + colBc)
+    float xr[RPL], tr[RPL], rr[RES ? 4 : 1];
 #pragma unroll
     for (int q = 0; q < RPL; q++) xr[q] = xn[q];       // (non-temporal dword loads measured slower here: 72.6 vs 63.8 us)
     {
-      const int subn = sub + gridDim.x * kWaves;
-      const int64_t coln = (int64_t)subn * SUBF + l31;
-      const float* __restrict__ xpn = x + (int64_t)(RPL * h) * F + coln;
+      const int subn = min(sub + (int)(gridDim.x * kWaves), n_sub - 1);       // (the last round re-reads its own sub-tile)
+      const unsigned colB = (unsigned)min((int64_t)subn * SUBF + l31, F - 1) * 4u;
 #pragma unroll
-      for (int q = 0; q < RPL; q++) xn[q] = (subn < n_sub && coln < F && RPL * h + q < B) ? xpn[(int64_t)q * F] : 0.0f;
+      for (int q = 0; q < RPL; q++)
+        xn[q] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(x) + ((unsigned)min(RPL * h + q, B - 1) * rowB + colB));
     }
     if (ab) {      // folded batch-norm (channels-last: channel = column mod nch, nch a power of two): x = a*z + b on load
       const int ch = (int)(col & (int64_t)(nch - 1));
-      const float av = cok ? ab[ch] : 0.0f, bv = cok ? ab[nch + ch] : 0.0f;
+      const float av = ab[ch], bv = ab[nch + ch];      // (col beyond F: some channel's values, never used)
 #pragma unroll
-      for (int q = 0; q < RPL; q++)
-        if (cok && RPL * h + q < B) xr[q] = __fmaf_rn(av, xr[q], bv);
+      for (int q = 0; q < RPL; q++) xr[q] = __fmaf_rn(av, xr[q], bv);
     }
     // ---- transform + quantise; batch statistics: registers + one cross-half shuffle ---------------------------
     // (round 3: the same as ONE straight-line block over the 16 rows - selects instead of the per-row exec-mask branches, so
@@ -187,28 +192,45 @@ __global__ __launch_bounds__(kThreads1) void site1_fwd_kernel(const float* __res
       stage_rows(W, l31, h, wd);
     }
     wave_lds_sync();
-    if (PAIR && RES) {        // the shortcut rows: requested here, in flight under the x Gram
-      const float* __restrict__ rp = res + (int64_t)(RPL * h) * F + col;
+    if (PAIR && RES) {        // the first four shortcut rows: requested here, in flight under the x Gram; the rest one group ahead
 #pragma unroll
-      for (int q = 0; q < RPL; q++) rr[q] = (cok && RPL * h + q < B) ? rp[(int64_t)q * F] : 0.0f;
+      for (int q = 0; q < 4; q++) rr[q] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(res) + S1_OFF(q));
     }
     gram32<PAIR>(W, l31, h, acc);
     wave_lds_sync();
     if (PAIR) {
       // ---- transform + quantise (x_q stored, the row register takes t), t statistics, stage, Gram ------------------
+      // Straight-line, four rows at a time (their table reads and dependent chains overlap; all sixteen at once cost 141
+      // registers, a branch per row serialises them).  Rows >= B and columns >= F carry the clamped row's / column's values:
+      // they are stored too - the same value to the same address as the lane that owns it - and masked out of the sums.
       float st = 0.f;
 #pragma unroll
-      for (int q = 0; q < RPL; q++) {
-        tr[q] = 0.f;
-        if (RPL * h + q < B) {
+      for (int q4 = 0; q4 < RPL; q4 += 4) {
+        float qq[4], rn[RES ? 4 : 1];
+        if (RES && q4 + 4 < RPL) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) rn[RES ? j : 0] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(res) + S1_OFF(q4 + 4 + j));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int q = q4 + j;
           float b;
-          float qq = bounded ? act_quant1<0, true>(xr[q], k, nlev, r, &tr[q], &b, tab)
-                             : act_quant1<0>(xr[q], k, nlev, r, &tr[q], &b, tab);
-          if (RES) qq += rr[q];
-          if (relu) qq = fmaxf(qq, 0.0f);
-          if (qp && cok) qp[(int64_t)q * F] = qq;
+          qq[j] = bounded ? act_quant1<0, true>(xr[q], k, nlev, r, &tr[q], &b, tab)
+                          : act_quant1<0>(xr[q], k, nlev, r, &tr[q], &b, tab);
+          if (RES) qq[j] += rr[RES ? j : 0];
+          if (relu) qq[j] = fmaxf(qq[j], 0.0f);
+          if (RPL * h + q >= B) tr[q] = 0.f;
           st += tr[q];
         }
+        if (xq) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) *reinterpret_cast<float*>(reinterpret_cast<char*>(xq) + S1_OFF(q4 + j)) = qq[j];
+        }
+        if (RES && q4 + 4 < RPL) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) rr[RES ? j : 0] = rn[RES ? j : 0];
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
       st += __shfl_xor(st, 32, 64);
       const float mt = st * invB;
@@ -229,6 +251,7 @@ __global__ __launch_bounds__(kThreads1) void site1_fwd_kernel(const float* __res
       wave_lds_sync();
     }
   }
+#undef S1_OFF
   // ---- the only workgroup-wide step: add the four wave accumulators, write the [32][32] slab -------------------
   __syncthreads();
   float* Cw = reinterpret_cast<float*>(lds) + w * 1024;
@@ -438,6 +461,7 @@ __global__ __launch_bounds__(kThreads1, 3) void site1_bwd_kernel(const float* __
 int launch_partials1(bool pair, const Geom& g, const float* x, int B, int64_t F, int k, float r, float eps, float* xq,
                      float* stats, float* ws, hipStream_t st, const float* res, int relu, const float* ab, int C) {
   unsigned* counter = reinterpret_cast<unsigned*>(ws + (size_t)g.grid * g.slab_floats + kPartFloats);
+  if ((int64_t)B * F * 4 >= ((int64_t)1 << 32)) return ALIGNQ_EUNSUPPORTED;   // 32-bit byte offsets
   const int n_sub = (int)((F + SUBF - 1) / SUBF);
   if (pair && res) hipLaunchKernelGGL((site1_fwd_kernel<true, true>), g.grid, kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter, res, relu, ab, C);
   else if (pair) hipLaunchKernelGGL((site1_fwd_kernel<true, false>), g.grid, kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter, nullptr, relu, ab, C);
