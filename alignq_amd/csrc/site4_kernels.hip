@@ -63,18 +63,25 @@ __device__ unsigned long long g_blk[2][2][2048];
 // Addressing of the forward kernel: kernel-argument base (SGPR pair) + ONE unsigned 32-bit element offset per (row, column
 // quad), shared by x / residual / x_q (global_load / global_store saddr + voffset form: no 64-bit address arithmetic in
 // VGPRs; the launcher guarantees B*F*4 < 2^32).
+// Loads are UNCONDITIONAL on clamped addresses (offset 0 stands in for anything outside the tensor) and the values are selected
+// afterwards: a conditional load is a branch, and the compiler must assume it was not issued - so the next use of a register
+// loaded BEFORE it waits for everything in flight (vmcnt counts in order).  Both paths of the launch-uniform `aligned` branch
+// issue a fixed number of loads, so that the waits stay exact behind it.
 __device__ __forceinline__ float4 ld4(const float* __restrict__ x, unsigned off, int col, int64_t F, bool row_ok,
                                       bool aligned) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (!row_ok) return v;
+  const char* xb = reinterpret_cast<const char*>(x);
+  float4 v;
   if (aligned) {
-    if (col < F) v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(x) + 4u * off);
+    const bool ok = row_ok && col < F;
+    v = *reinterpret_cast<const float4*>(xb + (ok ? 4u * off : 0u));
+    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
   } else {
-    const char* xb = reinterpret_cast<const char*>(x);
-    if (col + 0 < F) v.x = *reinterpret_cast<const float*>(xb + 4u * off);
-    if (col + 1 < F) v.y = *reinterpret_cast<const float*>(xb + 4u * off + 4u);
-    if (col + 2 < F) v.z = *reinterpret_cast<const float*>(xb + 4u * off + 8u);
-    if (col + 3 < F) v.w = *reinterpret_cast<const float*>(xb + 4u * off + 12u);
+    const bool o0 = row_ok && col + 0 < F, o1 = row_ok && col + 1 < F, o2 = row_ok && col + 2 < F, o3 = row_ok && col + 3 < F;
+    v.x = *reinterpret_cast<const float*>(xb + (o0 ? 4u * off : 0u));
+    v.y = *reinterpret_cast<const float*>(xb + (o1 ? 4u * off + 4u : 0u));
+    v.z = *reinterpret_cast<const float*>(xb + (o2 ? 4u * off + 8u : 0u));
+    v.w = *reinterpret_cast<const float*>(xb + (o3 ? 4u * off + 12u : 0u));
+    v.x = o0 ? v.x : 0.f; v.y = o1 ? v.y : 0.f; v.z = o2 ? v.z : 0.f; v.w = o3 ? v.w : 0.f;
   }
   return v;
 }
@@ -85,12 +92,9 @@ typedef float f32x4_nt __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 ld4_stream(const float* __restrict__ x, unsigned off, int col, int64_t F, bool row_ok,
                                              bool aligned) {
   if (!aligned) return ld4(x, off, col, F, row_ok, aligned);
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (row_ok && col < F) {
-    const f32x4_nt t = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(reinterpret_cast<const char*>(x) + 4u * off));
-    v = make_float4(t.x, t.y, t.z, t.w);
-  }
-  return v;
+  const bool ok = row_ok && col < F;
+  const f32x4_nt t = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(reinterpret_cast<const char*>(x) + (ok ? 4u * off : 0u)));
+  return ok ? make_float4(t.x, t.y, t.z, t.w) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 __device__ __forceinline__ void st4(float* __restrict__ y, unsigned off, int col, int64_t F, bool row_ok, bool aligned,
