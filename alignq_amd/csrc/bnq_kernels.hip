@@ -122,63 +122,72 @@ __global__ __launch_bounds__(NT) void bnq_sums_kernel(const float* __restrict__ 
   }
 }
 
-// Sum of the `nparts` partials of 16 channels per workgroup: 16 lanes per channel, each adds every 16th partial (all loads
-// independent and in flight together: a one-thread-per-channel loop over 512 partials is a 512-deep chain of L2 round trips,
-// measured ~100 us per launch), then a fixed butterfly over the 16 lanes.  Returns the totals in the channel's lane 0.
-__device__ __forceinline__ void bnq_channel_totals(const double* __restrict__ part, int nparts, int C, int c, int sub,
-                                                   double& a, double& q) {
-  a = 0; q = 0;
-  if (c < C) {
-    for (int s0 = sub; s0 < nparts; s0 += 16 * 8) {
-      double va[8], vq[8];
+// ---- finalisation: ONE WAVE per channel (4 channels per 256-thread block, grid = C / 4) ------------------------------------------
+// Every lane takes every 64th partial of its channel - of TWO groups at a time, all loads in flight together: the kernel is a
+// chain of memory round trips (a one-thread-per-channel loop over 512 partials measured ~100 us, 16 lanes per channel and one
+// group after the other ~9 us: 4 + 4 dependent batches) - then a fixed butterfly over the 64 lanes.  Totals valid in every lane.
+__device__ __forceinline__ void bnq_wave_totals2(const double* __restrict__ p0, const double* __restrict__ p1, int nparts, int C,
+                                                 int c, int lane, double& a0, double& q0, double& a1, double& q1) {
+  constexpr int U = kParts / 64;
+  double va0[U], vq0[U], va1[U], vq1[U];
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int s = s0 + 16 * u, sc = s < nparts ? s : sub;
-        va[u] = part[((int64_t)sc * C + c) * 2];
-        vq[u] = part[((int64_t)sc * C + c) * 2 + 1];
-      }
+  for (int u = 0; u < U; u++) {
+    const int s = lane + 64 * u, sc = s < nparts ? s : nparts - 1;
+    const double2 v0 = *reinterpret_cast<const double2*>(p0 + ((int64_t)sc * C + c) * 2);
+    const double2 v1 = *reinterpret_cast<const double2*>(p1 + ((int64_t)sc * C + c) * 2);
+    va0[u] = v0.x; vq0[u] = v0.y; va1[u] = v1.x; vq1[u] = v1.y;
+  }
+  a0 = 0; q0 = 0; a1 = 0; q1 = 0;
 #pragma unroll
-      for (int u = 0; u < 8; u++)
-        if (s0 + 16 * u < nparts) { a += va[u]; q += vq[u]; }
-    }
+  for (int u = 0; u < U; u++) {
+    if (lane + 64 * u < nparts) { a0 += va0[u]; q0 += vq0[u]; a1 += va1[u]; q1 += vq1[u]; }
   }
 #pragma unroll
-  for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
+  for (int o = 32; o > 0; o >>= 1) {
+    a0 += __shfl_xor(a0, o, 64); q0 += __shfl_xor(q0, o, 64);
+    a1 += __shfl_xor(a1, o, 64); q1 += __shfl_xor(q1, o, 64);
+  }
 }
 
-// grid = ceil(C / 16); thread = (channel c = 16*block + tid/16, lane sub = tid % 16).  groups: the slices' statistics one after
-// the other (running statistics updated in slice order, like successive forward passes of the module).
+// groups: the slices' statistics one after the other (running statistics updated in slice order, like successive forward
+// passes of the module).
 __global__ __launch_bounds__(kT) void bnq_finalize_kernel(const double* __restrict__ part, int nparts, int64_t P, int C,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
                                                           long long* __restrict__ nbt, float momentum, float eps,
                                                           float* __restrict__ ab, float* __restrict__ save, int groups) {
-  const int c = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += groups;
-  float rm = 0.f, rv = 0.f;
-  const bool owner = c < C && sub == 0;
-  if (owner) { rm = running_mean ? running_mean[c] : 0.f; rv = running_var ? running_var[c] : 0.f; }
-  for (int gi = 0; gi < groups; gi++) {
-    double a, q;
-    bnq_channel_totals(part + (int64_t)gi * nparts * C * 2, nparts, C, c, sub, a, q);
-    if (!owner) continue;
-    const double n = (double)P;
-    const double mean = a / n;
-    double var = q / n - mean * mean;
-    if (var < 0) var = 0;
-    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float gm = gamma ? gamma[c] : 1.0f, bt = beta ? beta[c] : 0.0f;
-    const float av = gm * invstd;
-    float* abg = ab + (int64_t)gi * 2 * C;
-    float* svg = save + (int64_t)gi * 2 * C;
-    abg[c] = av;
-    abg[C + c] = bt - (float)mean * av;
-    svg[c] = (float)mean;
-    svg[C + c] = invstd;
-    rm = (1.0f - momentum) * rm + momentum * (float)mean;
-    rv = (1.0f - momentum) * rv + momentum * (float)(var * n / (n - 1.0));
+  if (c >= C) return;
+  float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
+  const float gm = gamma ? gamma[c] : 1.0f, bt = beta ? beta[c] : 0.0f;
+  const int64_t gstride = (int64_t)nparts * C * 2;
+  for (int g0 = 0; g0 < groups; g0 += 2) {
+    const bool two = g0 + 1 < groups;
+    double a[2], q[2];
+    bnq_wave_totals2(part + g0 * gstride, part + (two ? g0 + 1 : g0) * gstride, nparts, C, c, lane, a[0], q[0], a[1], q[1]);
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      if (j == 1 && !two) break;
+      const double n = (double)P;
+      const double mean = a[j] / n;
+      double var = q[j] / n - mean * mean;
+      if (var < 0) var = 0;
+      const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+      const float av = gm * invstd;
+      if (lane == 0) {
+        float* abg = ab + (int64_t)(g0 + j) * 2 * C;
+        float* svg = save + (int64_t)(g0 + j) * 2 * C;
+        abg[c] = av;
+        abg[C + c] = bt - (float)mean * av;
+        svg[c] = (float)mean;
+        svg[C + c] = invstd;
+      }
+      rm = (1.0f - momentum) * rm + momentum * (float)mean;
+      rv = (1.0f - momentum) * rv + momentum * (float)(var * n / (n - 1.0));
+    }
   }
-  if (owner) {
+  if (lane == 0) {
     if (running_mean) running_mean[c] = rm;
     if (running_var) running_var[c] = rv;
   }
@@ -188,18 +197,26 @@ __global__ __launch_bounds__(kT) void bnq_finalize_kernel(const double* __restri
 __global__ __launch_bounds__(kT) void bnq_finalize_bwd_kernel(const double* __restrict__ part, int nparts, int64_t P, int C,
                                                               float* __restrict__ ktot, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, int groups) {
-  const int c = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= C) return;
   double ta = 0, tq = 0;
-  for (int gi = 0; gi < groups; gi++) {
-    double a, q;
-    bnq_channel_totals(part + (int64_t)gi * nparts * C * 2, nparts, C, c, sub, a, q);
-    if (c >= C || sub != 0) continue;
-    ktot[(int64_t)gi * 2 * C + c] = (float)(a / (double)P);
-    ktot[(int64_t)gi * 2 * C + C + c] = (float)(q / (double)P);
-    ta += a;
-    tq += q;
+  const int64_t gstride = (int64_t)nparts * C * 2;
+  for (int g0 = 0; g0 < groups; g0 += 2) {
+    const bool two = g0 + 1 < groups;
+    double a[2], q[2];
+    bnq_wave_totals2(part + g0 * gstride, part + (two ? g0 + 1 : g0) * gstride, nparts, C, c, lane, a[0], q[0], a[1], q[1]);
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      if (j == 1 && !two) break;
+      if (lane == 0) {
+        ktot[(int64_t)(g0 + j) * 2 * C + c] = (float)(a[j] / (double)P);
+        ktot[(int64_t)(g0 + j) * 2 * C + C + c] = (float)(q[j] / (double)P);
+      }
+      ta += a[j];
+      tq += q[j];
+    }
   }
-  if (c >= C || sub != 0) return;
+  if (lane != 0) return;
   if (dbeta) dbeta[c] = (float)ta;
   if (dgamma) dgamma[c] = (float)tq;
 }
@@ -315,6 +332,10 @@ inline int parts_for(int64_t P, int C) {
   const int slots = threads_for(C) / (C >> 2);
   int64_t n = P / ((int64_t)slots * kUs);
   if (n < 1) n = 1;
+  // ... and the partial image [parts][C][2] doubles is written once and read once: at most 4 MB of it per group (wide layers:
+  // 512 partials of 2048 channels are 16.8 MB for a 22 MB tensor)
+  const int64_t cap = ((int64_t)4 << 20) / ((int64_t)C * 16);
+  if (n > cap) n = cap < 64 ? 64 : cap;
   return (int)(n > kParts ? kParts : n);
 }
 
@@ -361,7 +382,7 @@ int alignq_bnq_fwd(const float* z, int64_t P, int C, int groups, const float* ga
   const int np = parts_for(P, C);
   BNQ_NT(C, hipLaunchKernelGGL((bnq_sums_kernel<0, NTV>), dim3(np, groups), dim3(NTV), 0, st, z, nullptr, nullptr, nullptr, nullptr, P, C,
                      act_range, 0, part));
-  hipLaunchKernelGGL(bnq_finalize_kernel, dim3((C + 15) / 16), dim3(kT), 0, st, (const double*)part, np, P, C, gamma, beta,
+  hipLaunchKernelGGL(bnq_finalize_kernel, dim3((C + 3) / 4), dim3(kT), 0, st, (const double*)part, np, P, C, gamma, beta,
                      running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), momentum, bn_eps, ab, save,
                      groups);
   const int64_t nvec = P * (C >> 2);
@@ -386,7 +407,7 @@ int alignq_bnq_bwd(const float* g, const float* z, const float* y, const float* 
   float* ktot = ktot_of(ws, C, groups);
   const int np = parts_for(P, C);
   BNQ_NT(C, hipLaunchKernelGGL((bnq_sums_kernel<1, NTV>), dim3(np, groups), dim3(NTV), 0, st, z, g, y, ab, save, P, C, act_range, relu, part));
-  hipLaunchKernelGGL(bnq_finalize_bwd_kernel, dim3((C + 15) / 16), dim3(kT), 0, st, (const double*)part, np, P, C, ktot,
+  hipLaunchKernelGGL(bnq_finalize_bwd_kernel, dim3((C + 3) / 4), dim3(kT), 0, st, (const double*)part, np, P, C, ktot,
                      dgamma, dbeta, groups);
   const int64_t nvec = P * (C >> 2);
   BNQ_NT(C, hipLaunchKernelGGL((bnq_apply_bwd_kernel<NTV>), dim3(tiles(nvec, 2, NTV), groups), dim3(NTV), 0, st, g, z, y, ab, save, (const float*)ktot, nvec,
@@ -405,7 +426,7 @@ int alignq_bnq_stats(const float* z, int64_t P, int C, int groups, const float* 
   double* part = reinterpret_cast<double*>(ws);
   const int np = parts_for(P, C);
   BNQ_NT(C, hipLaunchKernelGGL((bnq_sums_kernel<0, NTV>), dim3(np, groups), dim3(NTV), 0, st, z, nullptr, nullptr, nullptr, nullptr, P, C, 0.f, 0, part));
-  hipLaunchKernelGGL(bnq_finalize_kernel, dim3((C + 15) / 16), dim3(kT), 0, st, (const double*)part, np, P, C, gamma, beta,
+  hipLaunchKernelGGL(bnq_finalize_kernel, dim3((C + 3) / 4), dim3(kT), 0, st, (const double*)part, np, P, C, gamma, beta,
                      running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), momentum, bn_eps, ab, save,
                      groups);
   return hipGetLastError() == hipSuccess ? 0 : ALIGNQ_EINVAL;
@@ -431,7 +452,7 @@ int alignq_bnq_bwd_dx(const float* dx, const float* z, const float* ab, const fl
   float* ktot = ktot_of(ws, C, groups);
   const int np = parts_for(P, C);
   BNQ_NT(C, hipLaunchKernelGGL((bnq_sums_kernel<2, NTV>), dim3(np, groups), dim3(NTV), 0, st, z, dx, nullptr, ab, save, P, C, 0.f, 0, part));
-  hipLaunchKernelGGL(bnq_finalize_bwd_kernel, dim3((C + 15) / 16), dim3(kT), 0, st, (const double*)part, np, P, C, ktot,
+  hipLaunchKernelGGL(bnq_finalize_bwd_kernel, dim3((C + 3) / 4), dim3(kT), 0, st, (const double*)part, np, P, C, ktot,
                      dgamma, dbeta, groups);
   const int64_t nvec = P * (C >> 2);
   BNQ_NT(C, hipLaunchKernelGGL((bnq_apply_bwd_kernel<NTV>), dim3(tiles(nvec, 2, NTV), groups), dim3(NTV), 0, st, dx, z, nullptr, ab, save, (const float*)ktot,

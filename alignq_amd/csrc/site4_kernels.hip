@@ -1095,7 +1095,7 @@ __global__ __launch_bounds__(256) void head_bwd_prep_multi_kernel(HeadBwdArgs h,
 // LOOP (plain site, VEC, 64-feature tiles, many tiles per CU): a workgroup walks over tiles and requests the next tile's x / g
 // rows as soon as this tile's are staged, so they fly under the MFMA, projection, assembly and copy-out phases.
 template <int TFv, bool PAIR, bool BN, bool VEC, bool LOOP = false>
-__global__ __launch_bounds__(TFv * 8) void site_bwd4_kernel(const float* __restrict__ gup, const float* __restrict__ S,
+__global__ __launch_bounds__(TFv * 8, 2) void site_bwd4_kernel(const float* __restrict__ gup, const float* __restrict__ S,
                                                         const float* __restrict__ x, const float* __restrict__ stats,
                                                         int B, int64_t F, float r, float eps, float* __restrict__ dx,
                                                         int n_tiles, int aligned, BnFold bn) {
