@@ -58,6 +58,38 @@ def test_small_batch_site_by_value_at_config5_sizes(dev, F):
     np.testing.assert_allclose(npy(Gm.grad), odG, atol=1e-7, rtol=1e-4)
 
 
+@pytest.mark.parametrize("F,k", [(40960, 8), (36864 + 64, 4)])
+def test_plain_site_multi_tile_forward_and_looped_backward_vs_oracle(dev, F, k):
+    """The plain (no batch-norm fold) B = 128 site above 32768 features: site_fwd4_kernel's multi-tile form (512 threads, two
+    workgroups per CU) and site_bwd4_kernel's LOOPED form (full tiles, a whole tile of prefetch distance, statistics through
+    LDS; 640 / 577 tiles over 256 workgroups: uneven trip counts) by value against the C oracle - the shapes the roofline
+    numbers of `kernels.roofline_shapes.site_128x524288` are measured on are otherwise only timed."""
+    from alignq_amd import ops
+    rng = np.random.default_rng(F + k)
+    B, r, eps = 128, 2.0, 0.0
+    x0 = (rng.standard_normal((B, F)) * 1.2 - 0.1).astype(np.float32)
+    A0, G0 = (rng.random((B, B), dtype=np.float32) - 0.5) * 0.1, (rng.random((B, B), dtype=np.float32) - 0.5) * 0.1
+    gq = (rng.standard_normal((B, F)) * 1e-3).astype(np.float32)
+    x = cu(x0, dev).requires_grad_(True)
+    A, Gm = cu(A0, dev).requires_grad_(True), cu(G0, dev).requires_grad_(True)
+    xq, loss, D = ops.SiteFn.apply(x, A, Gm, k, r, eps, 0.2, 0.3)
+    torch.autograd.backward([xq, loss], [cu(gq, dev), torch.ones((), device=dev)])
+    oq, oD = O.site_fwd(x0, k, r, eps)
+    assert bits_equal(npy(xq), oq)
+    np.testing.assert_allclose(npy(D), oD, atol=TOL, rtol=0)
+    ol, odD, odA, odG = O.admm_loss(oD, A0, G0, 0.2, 0.3)
+    np.testing.assert_allclose(float(loss), ol, atol=TOL)
+    odx = O.site_bwd(gq, odD, x0, r, eps)
+    np.testing.assert_allclose(npy(x.grad), odx, atol=TOL, rtol=1e-4)
+    np.testing.assert_allclose(npy(A.grad), odA, atol=1e-7, rtol=1e-4)
+    np.testing.assert_allclose(npy(Gm.grad), odG, atol=1e-7, rtol=1e-4)
+    # the gradient of the loss alone (no upstream gradient: the looped kernel reads x in g's place and drops it)
+    x2 = cu(x0, dev).requires_grad_(True)
+    _, loss2, _ = ops.SiteFn.apply(x2, A.detach(), Gm.detach(), k, r, eps, 0.2, 0.3)
+    loss2.backward()
+    np.testing.assert_allclose(npy(x2.grad), O.site_bwd(np.zeros_like(gq), odD, x0, r, eps), atol=TOL, rtol=1e-4)
+
+
 def test_plain_quantiser_by_value_at_the_stem_size(dev):
     """activation_quantize_fn (no ADMM: act_q1 / act_q2 of every bottleneck) at [28, 64, 112, 112]: x_q and the packed level
     indices bit for bit against the oracle over all 22.5 M elements, dx within 1e-5."""
