@@ -302,7 +302,8 @@ __global__ __launch_bounds__(kThreads1, 3) void site1_bwd_kernel(const float* __
                                                               const float* __restrict__ x,
                                                               const float* __restrict__ stats, int B, int64_t F, float r,
                                                               float eps, float* __restrict__ dx, int n_sub,
-                                                              const float* __restrict__ ab, int C) {
+                                                              const float* __restrict__ ab, int C,
+                                                              const float* __restrict__ ymask, float* __restrict__ dres) {
   __shared__ __attribute__((aligned(16))) unsigned lds[kWaves * WBUF];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
@@ -361,6 +362,21 @@ __global__ __launch_bounds__(kThreads1, 3) void site1_bwd_kernel(const float* __
       bv = ab[C + ch];
     }
     const bool has_g = PAIR && gup;
+    if (PAIR && ymask) {
+      // fused ReLU backward (the bottleneck's `out = relu(out)` behind the site, dann_office/model/resnet.py:153-154): the mask
+      // from the forward's output; the masked gradient is also the shortcut branch's gradient (dres).  Rows >= B / columns >= F
+      // carry the clamped element's values and store them to its address: the same value as the lane that owns it.
+      float yr[RPL];
+#pragma unroll
+      for (int q = 0; q < RPL; q++)
+        yr[q] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ymask) + ((unsigned)min(RPL * h + q, B - 1) * rowB + colB));
+#pragma unroll
+      for (int q = 0; q < RPL; q++) {
+        gr[q] = yr[q] > 0.0f ? gr[q] : 0.0f;
+        if (dres)
+          *reinterpret_cast<float*>(reinterpret_cast<char*>(dres) + ((unsigned)min(RPL * h + q, B - 1) * rowB + colB)) = has_g ? gr[q] : 0.0f;
+      }
+    }
 #pragma unroll
     for (int q = 0; q < RPL; q++) {
       const bool ok = cok && RPL * h + q < B;
@@ -471,7 +487,7 @@ int launch_partials1(bool pair, const Geom& g, const float* x, int B, int64_t F,
 }
 
 int launch_bwd1(bool pair, const float* gup, const float* S, const float* x, const float* stats, int B, int64_t F,
-                float r, float eps, float* dx, hipStream_t st, const float* ab, int C) {
+                float r, float eps, float* dx, hipStream_t st, const float* ab, int C, const float* ymask, float* dres) {
   if ((int64_t)B * F * 4 >= ((int64_t)1 << 32)) return ALIGNQ_EUNSUPPORTED;   // 32-bit byte offsets
   const int n_sub = (int)((F + SUBF - 1) / SUBF);
   int grid = (n_sub + kWaves - 1) / kWaves;
@@ -479,8 +495,8 @@ int launch_bwd1(bool pair, const float* gup, const float* S, const float* x, con
   // [28, 802816]) ran 82-84 us against 86-87 for 2048 and 17.2 against 19.6 at [28, 100352] (tools/s1_grid_sweep.sh)
   static const int capb = [] { const char* e = getenv("ALIGNQ_S1_GRID_B"); return e ? atoi(e) : 768; }();      // tuning aid
   if (grid > capb) grid = capb;
-  if (pair) hipLaunchKernelGGL((site1_bwd_kernel<true>), grid, kThreads1, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_sub, ab, C);
-  else hipLaunchKernelGGL((site1_bwd_kernel<false>), grid, kThreads1, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_sub, ab, C);
+  if (pair) hipLaunchKernelGGL((site1_bwd_kernel<true>), grid, kThreads1, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_sub, ab, C, ymask, dres);
+  else hipLaunchKernelGGL((site1_bwd_kernel<false>), grid, kThreads1, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_sub, ab, C, nullptr, nullptr);
   RET_ON_ERR1();
   return 0;
 }

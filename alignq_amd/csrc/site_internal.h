@@ -109,7 +109,8 @@ int launch_partials1(bool pair, const Geom& g, const float* x, int B, int64_t F,
                      float* stats, float* ws, hipStream_t st, const float* res = nullptr, int relu = 0,
                      const float* ab = nullptr, int C = 1);      // ab: folded batch-norm (channels-last, C a power of two)
 int launch_bwd1(bool pair, const float* gup, const float* S, const float* x, const float* stats, int B, int64_t F,
-                float r, float eps, float* dx, hipStream_t st, const float* ab = nullptr, int C = 1);
+                float r, float eps, float* dx, hipStream_t st, const float* ab = nullptr, int C = 1,
+                const float* ymask = nullptr, float* dres = nullptr);
 
 // ---- launchers defined in site4_kernels.hip ----------------------------------------------------------------
 int launch_partials4(bool pair, const Geom& g, const float* x, int B, int64_t F, int k, float r, float eps, float* xq,

@@ -691,6 +691,17 @@ int alignq_site_bwd_apply_ab(const float* g, const float* S, const float* z, con
   return launch_bwd1(true, g, S, z, stats, B, F, act_range, eps, dx, (hipStream_t)stream, ab, C);
 }
 
+// the same with the ReLU behind the site folded in: g is the gradient w.r.t. relu(x_q + residual), y that output (mask y > 0);
+// dres (optional) receives the masked gradient = the gradient of the residual operand
+int alignq_site_bwd_apply_ab_relu(const float* g, const float* y, const float* S, const float* z, const float* ab, int C,
+                                  const float* stats, int B, int64_t F, float act_range, float eps, float* dx, float* dres,
+                                  void* stream) {
+  if (!g || !y || !S || !z || !ab || !stats || !dx || C < 1 || (C & (C - 1)) != 0 || F % C != 0) return ALIGNQ_EINVAL;
+  if (bad_shape(B, F)) return F <= 0 ? ALIGNQ_EINVAL : ALIGNQ_EUNSUPPORTED;
+  if (geom(B, F).nb != 1) return ALIGNQ_EUNSUPPORTED;
+  return launch_bwd1(true, g, S, z, stats, B, F, act_range, eps, dx, (hipStream_t)stream, ab, C, y, dres);
+}
+
 int alignq_site_bwd_fused(const float* g, const float* D, const float* alterD, const float* gamma, int dim,
                           const float* scal, float mu, const float* dD_scale, const float* x, const float* stats,
                           int B, int64_t F, float act_range, float eps, float* dx, float* dalterD, float* dgamma,

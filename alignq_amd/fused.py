@@ -12,6 +12,8 @@
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -664,6 +666,9 @@ def bn_only(bn, z, groups=1):
                             groups)
 
 
+_S1_MASK_IN_KERNEL = os.environ.get("ALIGNQ_S1_MASK", "1") != "0"
+
+
 class BNSite1Fn(torch.autograd.Function):
     """The Office bottleneck's tail with its batch-norm folded in (batches <= 32, channels-last):
         out, loss = act_q3(bn3(z)); out += identity; out = relu(out)          (dann_office/model/resnet.py:146-154)
@@ -730,8 +735,12 @@ class BNSite1Fn(torch.autograd.Function):
         lib, dev = L.load(), z.device
         st = L.stream_ptr()
         g_m = None
-        if g_y is not None:
-            g_m = torch.ops.aten.threshold_backward(L.like_layout(g_y, z), y, 0.0)      # the fused ReLU's mask
+        if g_y is not None:      # the fused ReLU's mask is applied by the site kernel, which also leaves the masked gradient in g_m
+            g_y = L.like_layout(g_y, z)
+            if _S1_MASK_IN_KERNEL:
+                g_m = torch.empty_like(z) if has_res else None
+            else:                # (A/B aid, ALIGNQ_S1_MASK=0: the mask as its own elementwise pass)
+                g_y = g_m = torch.ops.aten.threshold_backward(g_y, y, 0.0)
         if g_loss is None:
             g_loss = torch.zeros((), dtype=torch.float32, device=dev)
         g_loss = L.dev_f32(g_loss, "loss grad")
@@ -747,9 +756,14 @@ class BNSite1Fn(torch.autograd.Function):
             sl = slice(gi * B, (gi + 1) * B)
             L.check(lib.alignq_site_prep_fused(L.ptr(D[gi]), L.ptr(A), L.ptr(Gm), A.shape[0], L.ptr(scal[gi]), mu, L.ptr(g_loss), B,
                                                F, L.ptr(S), L.ptr(dA[gi]), L.ptr(dG[gi]), st), "alignq_site_prep_fused")
-            L.check(lib.alignq_site_bwd_apply_ab(L.ptr(None if g_m is None else g_m[sl]), L.ptr(S), L.ptr(z[sl]), L.ptr(ab[gi]), C,
-                                                 L.ptr(stats[gi]), B, F, act_range, eps, L.ptr(dx[sl]), st),
-                    "alignq_site_bwd_apply_ab")
+            if g_y is None or not _S1_MASK_IN_KERNEL:
+                L.check(lib.alignq_site_bwd_apply_ab(L.ptr(None if g_y is None else g_y[sl]), L.ptr(S), L.ptr(z[sl]), L.ptr(ab[gi]), C, L.ptr(stats[gi]), B, F, act_range,
+                                                     eps, L.ptr(dx[sl]), st), "alignq_site_bwd_apply_ab")
+            else:
+                L.check(lib.alignq_site_bwd_apply_ab_relu(L.ptr(g_y[sl]), L.ptr(y[sl]), L.ptr(S), L.ptr(z[sl]), L.ptr(ab[gi]), C,
+                                                          L.ptr(stats[gi]), B, F, act_range, eps, L.ptr(dx[sl]),
+                                                          L.ptr(None if g_m is None else g_m[sl]), st),
+                        "alignq_site_bwd_apply_ab_relu")
         L.check(lib.alignq_bnq_bwd_dx(L.ptr(dx), L.ptr(z), L.ptr(ab), L.ptr(save), P, C, groups, L.ptr(dx), L.ptr(dgamma),
                                       L.ptr(dbeta), L.ptr(ws_bn), st), "alignq_bnq_bwd_dx")
 

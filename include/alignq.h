@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALIGNQ_ABI_VERSION 8
+#define ALIGNQ_ABI_VERSION 9
 
 #define ALIGNQ_FORMULA_ADMM 0
 #define ALIGNQ_FORMULA_CDF 1
@@ -433,6 +433,11 @@ int alignq_site_partials_res_ab(const float* z, const float* ab, int C, int B, i
                                 const float* residual, int relu, float* y, float* stats, void* ws, void* stream);
 int alignq_site_bwd_apply_ab(const float* g, const float* S, const float* z, const float* ab, int C, const float* stats, int B,
                              int64_t F, float act_range, float eps, float* dx, void* stream);
+/* alignq_site_bwd_apply_ab with the bottleneck's closing ReLU (resnet.py:153-154) folded in: g = gradient w.r.t.
+ * relu(x_q + residual), y = that tensor (mask y > 0); dres (or NULL) receives the masked gradient (the residual's gradient).  */
+int alignq_site_bwd_apply_ab_relu(const float* g, const float* y, const float* S, const float* z, const float* ab, int C,
+                                  const float* stats, int B, int64_t F, float act_range, float eps, float* dx, float* dres,
+                                  void* stream);
 size_t alignq_bnq_ws_bytes(int C, int groups);
 int alignq_bnq_fwd(const float* z, int64_t P, int C, int groups, const float* gamma, const float* beta, float* running_mean,
                    float* running_var, int64_t* num_batches_tracked, float momentum, float bn_eps, int k, float act_range,
