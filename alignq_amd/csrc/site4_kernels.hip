@@ -1203,6 +1203,21 @@ __global__ __launch_bounds__(TFv * 8, 2) void site_bwd4_kernel(const float* __re
       const int fq = col0 + 4 * lc4;
       // (clamped address + value select: `ok ? *p : zero` would be turned into a select of POINTERS with the zero on the stack)
       const int fqc = q_ok ? fq : 0;
+      const bool has_g = PAIR && gup != nullptr;
+      // Request order of the one-tile form: the tile's rows first (x, g: unconditional - without an upstream gradient the x
+      // rows stand in and are dropped), then the per-column statistics and (a, b), the ReLU mask's source last, as RAW words
+      // (fp32 y, or the 2- / 1-byte level indices: one launch-uniform branch, all four requests of a kind together - the
+      // compiler turns them into predicates on the spot, which waits for everything older, so nothing may follow them).
+      float4 yraw[(!LOOP && BN) ? 4 : 1];
+      uint2 ybraw[(!LOOP && BN) ? 4 : 1];
+      int ykind = 0;                       // 0 none, 1 fp32 y, 2 int16 indices, 3 int8 indices
+      if constexpr (!LOOP) {
+        const char* gsrc = reinterpret_cast<const char*>(has_g ? gup : x);
+#pragma unroll
+        for (int q = 0; q < 4; q++) xr[q] = AT4(x, q);
+#pragma unroll
+        for (int q = 0; q < 4; q++) gr[q] = *reinterpret_cast<const float4*>(gsrc + BO4(q));
+      }
       float4 mx4, rx4, mt4 = z4, rt4 = z4;
       if constexpr (LOOP) {
         mx4 = *reinterpret_cast<const float4*>(stt + (st_buf * 4 + 0) * TFv + 4 * lc4);
@@ -1219,7 +1234,6 @@ __global__ __launch_bounds__(TFv * 8, 2) void site_bwd4_kernel(const float* __re
           rt4 = *reinterpret_cast<const float4*>(stats + 3 * F + fqc);
         }
       }
-      if (!q_ok) { mx4 = z4; rx4 = z4; mt4 = z4; rt4 = z4; }
       float4 a4 = make_float4(1.f, 1.f, 1.f, 1.f), b4 = z4;
       if (BN && q_ok) {
         if (bn.nhwc) {             // channels-last: the quad covers 4 consecutive channels (C % 4 == 0)
@@ -1233,14 +1247,21 @@ __global__ __launch_bounds__(TFv * 8, 2) void site_bwd4_kernel(const float* __re
           b4 = make_float4(bv, bv, bv, bv);
         }
       }
-      const bool has_g = PAIR && gup != nullptr;
-      if constexpr (!LOOP) {                      // (LOOP: requested before the loop / by the previous iteration)
+      if constexpr (!LOOP) {
+        if constexpr (BN) {
+          ykind = bn.y ? 1 : (bn.ybins ? (bn.bin_bytes == 2 ? 2 : 3) : 0);
+          if (ykind == 1) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) xr[q] = AT4(x, q);          // all loads in flight before the first use
-        if (has_g) {
+            for (int q = 0; q < 4; q++) yraw[q] = AT4(bn.y, q);
+          } else if (ykind == 2) {
 #pragma unroll
-          for (int q = 0; q < 4; q++) gr[q] = AT4(gup, q);
-        } else {
+            for (int q = 0; q < 4; q++) ybraw[q] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(bn.ybins) + (BO4(q) >> 1));
+          } else if (ykind == 3) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) ybraw[q].x = *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(bn.ybins) + (BO4(q) >> 2));
+          }
+        }
+        if (!has_g) {
 #pragma unroll
           for (int q = 0; q < 4; q++) gr[q] = z4;
         }
@@ -1262,31 +1283,28 @@ __global__ __launch_bounds__(TFv * 8, 2) void site_bwd4_kernel(const float* __re
           gn[q] = make_float4(gv.x, gv.y, gv.z, gv.w);
         }
       }
-      if (BN) {
-        float4 yr[4];
-        const bool masked = bn.y != nullptr || bn.ybins != nullptr;
-        if (bn.y) {
-#pragma unroll
-          for (int q = 0; q < 4; q++) yr[q] = AT4(bn.y, q);
-        } else if (bn.ybins) {             // N2: the mask from the stored level index (idx > 0), 2 or 1 B per element
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            if (bn.bin_bytes == 2) {
-              const short4 bi = *reinterpret_cast<const short4*>(reinterpret_cast<const char*>(bn.ybins) + (BO4(q) >> 1));
-              yr[q] = make_float4((float)bi.x, (float)bi.y, (float)bi.z, (float)bi.w);
-            } else {
-              const char4 bi = *reinterpret_cast<const char4*>(reinterpret_cast<const char*>(bn.ybins) + (BO4(q) >> 2));
-              yr[q] = make_float4((float)bi.x, (float)bi.y, (float)bi.z, (float)bi.w);
-            }
-          }
-        }
+      if (!q_ok) { mx4 = z4; rx4 = z4; mt4 = z4; rt4 = z4; }      // (a use: behind every request)
+      if constexpr (BN && !LOOP) {
+        // the mask as four booleans per row (N2: the stored level index is positive exactly where y is: sign tests on the
+        // packed words, no conversion)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           xr[q].x = __fmaf_rn(a4.x, xr[q].x, b4.x); xr[q].y = __fmaf_rn(a4.y, xr[q].y, b4.y);
           xr[q].z = __fmaf_rn(a4.z, xr[q].z, b4.z); xr[q].w = __fmaf_rn(a4.w, xr[q].w, b4.w);
-          if (masked) {                                          // fused ReLU backward
-            gr[q].x = yr[q].x > 0.0f ? gr[q].x : 0.0f; gr[q].y = yr[q].y > 0.0f ? gr[q].y : 0.0f;
-            gr[q].z = yr[q].z > 0.0f ? gr[q].z : 0.0f; gr[q].w = yr[q].w > 0.0f ? gr[q].w : 0.0f;
+          if (ykind != 0) {                                          // fused ReLU backward
+            bool p0, p1, p2, p3;
+            if (ykind == 1) {
+              p0 = yraw[q].x > 0.0f; p1 = yraw[q].y > 0.0f; p2 = yraw[q].z > 0.0f; p3 = yraw[q].w > 0.0f;
+            } else if (ykind == 2) {
+              p0 = (short)(ybraw[q].x & 0xffffu) > 0; p1 = (short)(ybraw[q].x >> 16) > 0;
+              p2 = (short)(ybraw[q].y & 0xffffu) > 0; p3 = (short)(ybraw[q].y >> 16) > 0;
+            } else {
+              const unsigned wv = ybraw[q].x;
+              p0 = (signed char)(wv & 0xffu) > 0; p1 = (signed char)((wv >> 8) & 0xffu) > 0;
+              p2 = (signed char)((wv >> 16) & 0xffu) > 0; p3 = (signed char)(wv >> 24) > 0;
+            }
+            gr[q].x = p0 ? gr[q].x : 0.0f; gr[q].y = p1 ? gr[q].y : 0.0f;
+            gr[q].z = p2 ? gr[q].z : 0.0f; gr[q].w = p3 ? gr[q].w : 0.0f;
           }
         }
       }
