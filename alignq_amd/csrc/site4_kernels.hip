@@ -232,6 +232,10 @@ __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restri
   constexpr int KSPLIT = (TFv >= 32 && NTv == NT) ? 2 : 1;   // K-halves per tile (a half must hold >= 16 features); the
                                                              // 8-wave form keeps 10 whole-K items (2 accumulators per wave)
   constexpr int KSTEPS = TFv / 16 / KSPLIT;       // 16-feature MFMA steps per item
+  // the 512-thread multi-tile form is launched for COMPLETE tiles only (B == 128, F % 64 == 0, 16-byte aligned tensors): no
+  // row / column masks, no selects behind the loads (54 -> vector instructions per element counted in the masks' favour: the
+  // kernel runs at 62 % VALUBusy at [128, 524288])
+  constexpr bool kFull = !SINGLE && NTv == 512;
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STAGE_BYTES + (4 * TFv + 2 * NW * TFv) * 4];
   __shared__ __attribute__((aligned(16))) float nerf_lds[PAIR ? ALIGNQ_NERF_LDS_FLOATS : 4];
   // the transform's table (alignq_math.h): requested first, stored behind the tile loads of the first iteration
@@ -324,9 +328,14 @@ __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restri
 #pragma unroll
       for (int j = 0; j < RJ; j++) {
         const int row = rg + RG * j;
-        const bool ok = row < B;
+        const bool ok = kFull || row < B;
         const unsigned off = (unsigned)row * (unsigned)F + (unsigned)col;
-        xv[j] = SINGLE ? ld4(x, off, col, F, ok, aligned) : ld4_stream(x, off, col, F, ok, aligned);
+        if constexpr (kFull) {
+          const f32x4_nt t4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(reinterpret_cast<const char*>(x) + 4u * off));
+          xv[j] = make_float4(t4.x, t4.y, t4.z, t4.w);
+        } else {
+          xv[j] = SINGLE ? ld4(x, off, col, F, ok, aligned) : ld4_stream(x, off, col, F, ok, aligned);
+        }
       }
     }
     if (PAIR && tile == (int)blockIdx.x) {     // first iteration (block-uniform): publish the transform's table
@@ -535,7 +544,7 @@ __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restri
 #pragma unroll
     for (int j = 0; j < RJ; j++) {
       const int row = rg + RG * j;
-      const bool ok = row < B;
+      const bool ok = kFull || row < B;
       const unsigned off = (unsigned)row * (unsigned)F + (unsigned)col;
       tv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (PAIR) {
@@ -570,7 +579,11 @@ __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restri
           q.x += rr.x; q.y += rr.y; q.z += rr.z; q.w += rr.w;
         }
         if (bn.relu) { q.x = fmaxf(q.x, 0.f); q.y = fmaxf(q.y, 0.f); q.z = fmaxf(q.z, 0.f); q.w = fmaxf(q.w, 0.f); }
-        if (xq) st4(xq, off, col, F, ok, aligned, q);
+        if constexpr (kFull) {
+          if (xq) *reinterpret_cast<float4*>(reinterpret_cast<char*>(xq) + 4u * off) = q;
+        } else {
+          if (xq) st4(xq, off, col, F, ok, aligned, q);
+        }
       }
     }
     STAMP(1);
@@ -582,7 +595,7 @@ __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restri
       float sx[4] = {0, 0, 0, 0}, st[4] = {0, 0, 0, 0};
 #pragma unroll
       for (int j = 0; j < RJ; j++) {
-        if (rg + RG * j < B) {
+        if (kFull || rg + RG * j < B) {
           sx[0] += xv[j].x; sx[1] += xv[j].y; sx[2] += xv[j].z; sx[3] += xv[j].w;
           if (PAIR) { st[0] += tv[j].x; st[1] += tv[j].y; st[2] += tv[j].z; st[3] += tv[j].w; }
         }
@@ -615,7 +628,7 @@ __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restri
       for (int e = 0; e < 4; e++) { mx[e] = colv[4 * c + e]; mt[e] = PAIR ? colv[2 * TFv + 4 * c + e] : 0.f; }
 #pragma unroll
       for (int j = 0; j < RJ; j++) {
-        if (rg + RG * j < B) {
+        if (kFull || rg + RG * j < B) {
           const float xe[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
           const float te[4] = {tv[j].x, tv[j].y, tv[j].z, tv[j].w};
 #pragma unroll
@@ -647,7 +660,7 @@ __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restri
       const float sd = sqrtf(pw[0] * invBm1);
       const float rho = 1.0f / (sd + eps);
       colv[(2 * op + 1) * TFv + cc] = rho;
-      if (stats && col0 + cc < F) {
+      if (stats && (kFull || col0 + cc < F)) {
         stats[(int64_t)(2 * op) * F + col0 + cc] = colv[(2 * op) * TFv + cc];
         stats[(int64_t)(2 * op + 1) * F + col0 + cc] = rho;
       }
@@ -668,13 +681,13 @@ __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restri
       for (int j = 0; j < RJ; j++) {
         const int row = rg + RG * j;
         if (row < 128) {
-          const bool ok = row < B;
+          const bool ok = kFull || row < B;
           const float xe[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
           const float te[4] = {tv[j].x, tv[j].y, tv[j].z, tv[j].w};
           bf16x4 xh, xl, th, tl;
 #pragma unroll
           for (int e = 0; e < 4; e++) {
-            const bool okc = ok && (col + e < F);
+            const bool okc = kFull || (ok && (col + e < F));
             __bf16 a, b2;
             split_bf16(okc ? (xe[e] - mx[e]) * rx[e] : 0.0f, a, b2);
             xh[e] = a; xl[e] = b2;
@@ -700,13 +713,25 @@ __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restri
       // under the MFMA phase and the loop's closing barrier instead of in front of the next transform.  (The 8-wave form
       // reports 12 B of scratch per lane: ONE 8-byte prologue value stored before the tile loop and reloaded after it -
       // no scratch traffic inside the loop; requesting half of the rows behind the MFMA phase did not change that.)
-      const int tn = tile + (int)gridDim.x;
-      if (tn < n_tiles) {
+      if constexpr (kFull) {      // always issued (the last iteration re-reads its own tile): no branch around the loads
+        const int tn = min(tile + (int)gridDim.x, n_tiles - 1);
         const int coln = tn * TFv + 4 * c;
 #pragma unroll
         for (int j = 0; j < RJ; j++) {
           const int row = rg + RG * j;
-          xv[j] = ld4_stream(x, (unsigned)row * (unsigned)F + (unsigned)coln, coln, F, row < B, aligned);
+          const f32x4_nt t4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(
+              reinterpret_cast<const char*>(x) + 4u * ((unsigned)row * (unsigned)F + (unsigned)coln)));
+          xv[j] = make_float4(t4.x, t4.y, t4.z, t4.w);
+        }
+      } else {
+        const int tn = tile + (int)gridDim.x;
+        if (tn < n_tiles) {
+          const int coln = tn * TFv + 4 * c;
+#pragma unroll
+          for (int j = 0; j < RJ; j++) {
+            const int row = rg + RG * j;
+            xv[j] = ld4_stream(x, (unsigned)row * (unsigned)F + (unsigned)coln, coln, F, row < B, aligned);
+          }
         }
       }
     }
@@ -1792,11 +1817,12 @@ int launch_partials4(bool pair, const Geom& g, const float* x, int B, int64_t F,
   unsigned* counter = reinterpret_cast<unsigned*>(ws + (size_t)g.grid * g.slab_floats + kPartFloats);
   // geom(): one tile per workgroup up to F = 16384; beyond that the 64-feature tile loop runs in up to 512 workgroups of 512
   // threads, two per CU, for the plain site; with the batch-norm fold (no configuration has one at such F) in 1024-thread ones
+  const bool full64 = B == 128 && F % 64 == 0 && aligned;     // the 512-thread multi-tile form takes complete tiles only
 #define L4S(TFV, P, SG, NTV) hipLaunchKernelGGL((site_fwd4_kernel<TFV, P, SG, NTV>), g.grid, NTV, 0, st, x, B, F, k, r, eps, xq, ws, stats, g.n_tiles, aligned, counter, bn)
 #define L4(TFV, P)                                                                                                       \
   do {                                                                                                                  \
     if (g.n_tiles <= g.grid) L4S(TFV, P, true, NT);                                                                     \
-    else if (TFV == 64) { if (bn.ab || bn.res || bn.relu || bn.bins) L4S(64, P, false, NT); else L4S(64, P, false, 512); } \
+    else if (TFV == 64) { if (bn.ab || bn.res || bn.relu || bn.bins || !full64) L4S(64, P, false, NT); else L4S(64, P, false, 512); } \
     else return ALIGNQ_EINVAL;                                                                                          \
   } while (0)
   if (pair) {
