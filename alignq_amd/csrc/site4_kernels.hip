@@ -534,7 +534,7 @@ __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restri
     // to spare (128-VGPR budget at 1024 threads) and loads row by row inside the loop instead
     constexpr bool kEarlyRes = TFv < 64;
     float4 rv[RJ];
-    if (PAIR && kEarlyRes && bn.res) {
+    if (!kFull && PAIR && kEarlyRes && bn.res) {
 #pragma unroll
       for (int j = 0; j < RJ; j++) {
         const int row = rg + RG * j;
@@ -549,7 +549,8 @@ __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restri
       tv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (PAIR) {
         float4 q, rl = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!kEarlyRes && bn.res) rl = ld4(bn.res, off, col, F, ok, aligned);
+        if (!kFull && !kEarlyRes && bn.res) rl = ld4(bn.res, off, col, F, ok, aligned);       // (kFull: the plain site - no
+                                                                                                 //  shortcut, ReLU, indices)
         float b0, b1, b2, b3;
         if (nlev.yn != 0.0f) {      // launch-uniform: no per-element branches on k in the common case
           q.x = act_quant1<0, true>(xv[j].x, k, nlev, r, &tv[j].x, &b0, tab);
@@ -562,7 +563,7 @@ __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restri
           q.z = act_quant1<0>(xv[j].z, k, nlev, r, &tv[j].z, &b2, tab);
           q.w = act_quant1<0>(xv[j].w, k, nlev, r, &tv[j].w, &b3, tab);
         }
-        if (bn.bins && ok && col < F) {
+        if (!kFull && bn.bins && ok && col < F) {
           // N2: the level index of the stored value (no residual on this path; the fused ReLU clamps the index at 0), narrow:
           // 8 or 4 bytes per quad at the element offset (the launcher requires the aligned float4 path: F % 4 == 0)
           if (bn.relu) { b0 = fmaxf(b0, 0.f); b1 = fmaxf(b1, 0.f); b2 = fmaxf(b2, 0.f); b3 = fmaxf(b3, 0.f); }
@@ -574,11 +575,11 @@ __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restri
             *reinterpret_cast<char4*>(reinterpret_cast<char*>(bn.bins) + off) = bi;
           }
         }
-        if (bn.res) {
+        if (!kFull && bn.res) {
           const float4 rr = kEarlyRes ? rv[j] : rl;
           q.x += rr.x; q.y += rr.y; q.z += rr.z; q.w += rr.w;
         }
-        if (bn.relu) { q.x = fmaxf(q.x, 0.f); q.y = fmaxf(q.y, 0.f); q.z = fmaxf(q.z, 0.f); q.w = fmaxf(q.w, 0.f); }
+        if (!kFull && bn.relu) { q.x = fmaxf(q.x, 0.f); q.y = fmaxf(q.y, 0.f); q.z = fmaxf(q.z, 0.f); q.w = fmaxf(q.w, 0.f); }
         if constexpr (kFull) {
           if (xq) *reinterpret_cast<float4*>(reinterpret_cast<char*>(xq) + 4u * off) = q;
         } else {
