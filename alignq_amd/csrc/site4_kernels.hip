@@ -214,7 +214,7 @@ __device__ __forceinline__ void split_bf16(float v, __bf16& hi, __bf16& lo) {
 // NTv: 1024 threads (16 waves: one workgroup per CU, the latency-tuned CIFAR form) or 512 (8 waves, 32-feature tiles, 45 KB of
 // LDS: TWO workgroups per CU whose phases interleave - the multi-tile form for large F, where a tile's load -> transform ->
 // statistics -> stage -> MFMA chain with its six barriers is otherwise exposed in full; plain sites only, no batch-norm fold).
-template <int TFv, bool PAIR, bool SINGLE, int NTv = NT>
+template <int TFv, bool PAIR, bool SINGLE, int NTv = NT, bool FULLP = false>
 __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restrict__ x, int B, int64_t F, int k, float r,
                                                        float eps, float* __restrict__ xq, float* __restrict__ slabs,
                                                        float* __restrict__ stats, int n_tiles, int aligned,
@@ -235,7 +235,8 @@ __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restri
   // the 512-thread multi-tile form is launched for COMPLETE tiles only (B == 128, F % 64 == 0, 16-byte aligned tensors): no
   // row / column masks, no selects behind the loads (54 -> vector instructions per element counted in the masks' favour: the
   // kernel runs at 62 % VALUBusy at [128, 524288])
-  constexpr bool kFull = !SINGLE && NTv == 512;
+  constexpr bool kPlain = !SINGLE && NTv == 512;     // no shortcut / ReLU / index / batch-norm paths at all
+  constexpr bool kFull = FULLP || kPlain;            // complete tiles: no masks (FULLP: the launcher's promise for the one-tile forms)
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STAGE_BYTES + (4 * TFv + 2 * NW * TFv) * 4];
   __shared__ __attribute__((aligned(16))) float nerf_lds[PAIR ? ALIGNQ_NERF_LDS_FLOATS : 4];
   // the transform's table (alignq_math.h): requested first, stored behind the tile loads of the first iteration
@@ -330,7 +331,9 @@ __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restri
         const int row = rg + RG * j;
         const bool ok = kFull || row < B;
         const unsigned off = (unsigned)row * (unsigned)F + (unsigned)col;
-        if constexpr (kFull) {
+        if constexpr (kFull && SINGLE) {
+          xv[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(x) + 4u * off);
+        } else if constexpr (kFull) {
           const f32x4_nt t4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(reinterpret_cast<const char*>(x) + 4u * off));
           xv[j] = make_float4(t4.x, t4.y, t4.z, t4.w);
         } else {
@@ -479,7 +482,7 @@ __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restri
       }
 #pragma unroll
       for (int j = 0; j < RJ; j++) {
-        if (rg + RG * j < B && col < F) {
+        if (kFull || (rg + RG * j < B && col < F)) {
           xv[j].x = __fmaf_rn(a4.x, xv[j].x, b4.x); xv[j].y = __fmaf_rn(a4.y, xv[j].y, b4.y);
           xv[j].z = __fmaf_rn(a4.z, xv[j].z, b4.z); xv[j].w = __fmaf_rn(a4.w, xv[j].w, b4.w);
         }
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restri
       }
 #pragma unroll
       for (int j = 0; j < RJ; j++) {
-        if (rg + RG * j < B && col < F) {
+        if (kFull || (rg + RG * j < B && col < F)) {
           xv[j].x = __fmaf_rn(bn_a, xv[j].x, bn_b); xv[j].y = __fmaf_rn(bn_a, xv[j].y, bn_b);
           xv[j].z = __fmaf_rn(bn_a, xv[j].z, bn_b); xv[j].w = __fmaf_rn(bn_a, xv[j].w, bn_b);
         }
@@ -534,11 +537,12 @@ __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restri
     // to spare (128-VGPR budget at 1024 threads) and loads row by row inside the loop instead
     constexpr bool kEarlyRes = TFv < 64;
     float4 rv[RJ];
-    if (!kFull && PAIR && kEarlyRes && bn.res) {
+    if (!kPlain && PAIR && kEarlyRes && bn.res) {
 #pragma unroll
       for (int j = 0; j < RJ; j++) {
         const int row = rg + RG * j;
-        rv[j] = ld4(bn.res, (unsigned)row * (unsigned)F + (unsigned)col, col, F, row < B, aligned);
+        if constexpr (kFull) rv[j] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(bn.res) + 4u * ((unsigned)row * (unsigned)F + (unsigned)col));
+        else rv[j] = ld4(bn.res, (unsigned)row * (unsigned)F + (unsigned)col, col, F, row < B, aligned);
       }
     }
 #pragma unroll
@@ -549,8 +553,10 @@ __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restri
       tv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (PAIR) {
         float4 q, rl = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!kFull && !kEarlyRes && bn.res) rl = ld4(bn.res, off, col, F, ok, aligned);       // (kFull: the plain site - no
-                                                                                                 //  shortcut, ReLU, indices)
+        if (!kPlain && !kEarlyRes && bn.res) {                 // (kPlain: the plain site - no shortcut, ReLU, indices)
+          if constexpr (kFull) rl = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(bn.res) + 4u * off);
+          else rl = ld4(bn.res, off, col, F, ok, aligned);
+        }
         float b0, b1, b2, b3;
         if (nlev.yn != 0.0f) {      // launch-uniform: no per-element branches on k in the common case
           q.x = act_quant1<0, true>(xv[j].x, k, nlev, r, &tv[j].x, &b0, tab);
@@ -563,7 +569,7 @@ __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restri
           q.z = act_quant1<0>(xv[j].z, k, nlev, r, &tv[j].z, &b2, tab);
           q.w = act_quant1<0>(xv[j].w, k, nlev, r, &tv[j].w, &b3, tab);
         }
-        if (!kFull && bn.bins && ok && col < F) {
+        if (!kPlain && bn.bins && (kFull || (ok && col < F))) {
           // N2: the level index of the stored value (no residual on this path; the fused ReLU clamps the index at 0), narrow:
           // 8 or 4 bytes per quad at the element offset (the launcher requires the aligned float4 path: F % 4 == 0)
           if (bn.relu) { b0 = fmaxf(b0, 0.f); b1 = fmaxf(b1, 0.f); b2 = fmaxf(b2, 0.f); b3 = fmaxf(b3, 0.f); }
@@ -575,11 +581,11 @@ __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restri
             *reinterpret_cast<char4*>(reinterpret_cast<char*>(bn.bins) + off) = bi;
           }
         }
-        if (!kFull && bn.res) {
+        if (!kPlain && bn.res) {
           const float4 rr = kEarlyRes ? rv[j] : rl;
           q.x += rr.x; q.y += rr.y; q.z += rr.z; q.w += rr.w;
         }
-        if (!kFull && bn.relu) { q.x = fmaxf(q.x, 0.f); q.y = fmaxf(q.y, 0.f); q.z = fmaxf(q.z, 0.f); q.w = fmaxf(q.w, 0.f); }
+        if (!kPlain && bn.relu) { q.x = fmaxf(q.x, 0.f); q.y = fmaxf(q.y, 0.f); q.z = fmaxf(q.z, 0.f); q.w = fmaxf(q.w, 0.f); }
         if constexpr (kFull) {
           if (xq) *reinterpret_cast<float4*>(reinterpret_cast<char*>(xq) + 4u * off) = q;
         } else {
@@ -714,7 +720,7 @@ __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restri
       // under the MFMA phase and the loop's closing barrier instead of in front of the next transform.  (The 8-wave form
       // reports 12 B of scratch per lane: ONE 8-byte prologue value stored before the tile loop and reloaded after it -
       // no scratch traffic inside the loop; requesting half of the rows behind the MFMA phase did not change that.)
-      if constexpr (kFull) {      // always issued (the last iteration re-reads its own tile): no branch around the loads
+      if constexpr (kPlain) {     // always issued (the last iteration re-reads its own tile): no branch around the loads
         const int tn = min(tile + (int)gridDim.x, n_tiles - 1);
         const int coln = tn * TFv + 4 * c;
 #pragma unroll
@@ -1820,9 +1826,10 @@ int launch_partials4(bool pair, const Geom& g, const float* x, int B, int64_t F,
   // threads, two per CU, for the plain site; with the batch-norm fold (no configuration has one at such F) in 1024-thread ones
   const bool full64 = B == 128 && F % 64 == 0 && aligned;     // the 512-thread multi-tile form takes complete tiles only
 #define L4S(TFV, P, SG, NTV) hipLaunchKernelGGL((site_fwd4_kernel<TFV, P, SG, NTV>), g.grid, NTV, 0, st, x, B, F, k, r, eps, xq, ws, stats, g.n_tiles, aligned, counter, bn)
+#define L4F(TFV, P) hipLaunchKernelGGL((site_fwd4_kernel<TFV, P, true, NT, true>), g.grid, NT, 0, st, x, B, F, k, r, eps, xq, ws, stats, g.n_tiles, aligned, counter, bn)
 #define L4(TFV, P)                                                                                                       \
   do {                                                                                                                  \
-    if (g.n_tiles <= g.grid) L4S(TFV, P, true, NT);                                                                     \
+    if (g.n_tiles <= g.grid) { if (B == 128 && F % TFV == 0 && aligned) L4F(TFV, P); else L4S(TFV, P, true, NT); }      \
     else if (TFV == 64) { if (bn.ab || bn.res || bn.relu || bn.bins || !full64) L4S(64, P, false, NT); else L4S(64, P, false, 512); } \
     else return ALIGNQ_EINVAL;                                                                                          \
   } while (0)
@@ -1833,6 +1840,7 @@ int launch_partials4(bool pair, const Geom& g, const float* x, int B, int64_t F,
   }
 #undef L4
 #undef L4S
+#undef L4F
   RET_ON_ERR();
   return 0;
 }
