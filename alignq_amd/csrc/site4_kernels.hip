@@ -1147,7 +1147,7 @@ __global__ __launch_bounds__(256) void head_bwd_prep_multi_kernel(HeadBwdArgs h,
 // array.  !VEC: one column x 16 rows per thread, dword accesses with clamped offsets (any F, any alignment).
 // LOOP (plain site, VEC, 64-feature tiles, many tiles per CU): a workgroup walks over tiles and requests the next tile's x / g
 // rows as soon as this tile's are staged, so they fly under the MFMA, projection, assembly and copy-out phases.
-template <int TFv, bool PAIR, bool BN, bool VEC, bool LOOP = false>
+template <int TFv, bool PAIR, bool BN, bool VEC, bool LOOP = false, bool FULLP = false>
 __global__ __launch_bounds__(TFv * 8, 2) void site_bwd4_kernel(const float* __restrict__ gup, const float* __restrict__ S,
                                                         const float* __restrict__ x, const float* __restrict__ stats,
                                                         int B, int64_t F, float r, float eps, float* __restrict__ dx,
@@ -1243,7 +1243,9 @@ __global__ __launch_bounds__(TFv * 8, 2) void site_bwd4_kernel(const float* __re
     // LOOP: only complete tiles (B == 128, F % TFv == 0 - the launcher's condition): no masks, no branches around memory
     // operations (a conditional load or store makes the compiler wait for EVERYTHING in flight at the next use of a register
     // that was loaded before it: the counters are in order, and it must assume the younger operation was not issued)
-    const bool q_ok = LOOP || (col0 + 4 * lc4) < F;          // F % 4 == 0: a quad lies inside or outside as a whole
+    // FULLP: the launcher's promise of complete tiles for the one-tile VEC form (B == 128, F % TFv == 0): the masks fold away
+    constexpr bool kFullB = LOOP || (FULLP && VEC);
+    const bool q_ok = kFullB || (col0 + 4 * lc4) < F;          // F % 4 == 0: a quad lies inside or outside as a whole
     const unsigned colq = (unsigned)(q_ok ? col0 + 4 * lc4 : (int)F - 4) * 4u;
     const uint4 bo4 = make_uint4((unsigned)min(lrow4 + 0, B - 1) * rowB + colq, (unsigned)min(lrow4 + 1, B - 1) * rowB + colq,
                                  (unsigned)min(lrow4 + 2, B - 1) * rowB + colq, (unsigned)min(lrow4 + 3, B - 1) * rowB + colq);
@@ -1363,12 +1365,12 @@ __global__ __launch_bounds__(TFv * 8, 2) void site_bwd4_kernel(const float* __re
       }
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        if (!LOOP && !(q_ok && (lrow4 + q) < B)) { xr[q] = z4; gr[q] = z4; }
+        if (!kFullB && !(q_ok && (lrow4 + q) < B)) { xr[q] = z4; gr[q] = z4; }
       }
       if (BN && bn.dres && q_ok) {            // the masked gradient is also the residual branch's gradient
 #pragma unroll
         for (int q = 0; q < 4; q++)
-          if (lrow4 + q < B) ATW4(bn.dres, q) = gr[q];
+          if (kFullB || lrow4 + q < B) ATW4(bn.dres, q) = gr[q];
       }
       float jt[PAIR ? 16 : 1];                 // dt/dx, on its way to Js
 #pragma unroll
@@ -1379,7 +1381,7 @@ __global__ __launch_bounds__(TFv * 8, 2) void site_bwd4_kernel(const float* __re
 #define ALIGNQ_ROW(q, XH, XL, TH, TL)                                                              \
         {                                                                                          \
           const int row = lrow4 + q;                                                               \
-          const bool ok = LOOP || (q_ok && row < B);                                               \
+          const bool ok = kFullB || (q_ok && row < B);                                             \
           const float xe = f4get(xr[q], e);                                                        \
           split_bf16(ok ? (xe - f4get(mx4, e)) * f4get(rx4, e) : 0.0f, XH, XL);                    \
           if (PAIR) {                                                                              \
@@ -1554,7 +1556,7 @@ __global__ __launch_bounds__(TFv * 8, 2) void site_bwd4_kernel(const float* __re
     }
     // per-column constants of the assemble / copy-out phases: requested here too, so that their round trip is over by then
     if constexpr (!LOOP) {
-      const bool cok = (col0 + cc) < F;
+      const bool cok = kFullB || (col0 + cc) < F;
       rho_x = cok ? stats[F + col0 + cc] : 0.f;
       rho_t = (PAIR && cok) ? stats[3 * F + col0 + cc] : 0.0f;
     }
@@ -1676,7 +1678,7 @@ __global__ __launch_bounds__(TFv * 8, 2) void site_bwd4_kernel(const float* __re
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           const int row = lrow4 + q;
-          if (LOOP || row < B) {
+          if (kFullB || row < B) {
             // out = g*jac + (jac*ct - cx)  (PAIR)   |   out = cx  (!PAIR)
             const f32x4_nt c4 = LDS_F32X4(os_ld + q * kRow);
             float oo[4] = {c4.x, c4.y, c4.z, c4.w};
@@ -1944,7 +1946,10 @@ int launch_bwd4(bool pair, const Geom& g, const float* gup, const float* S, cons
                    al16(bn.ab) && al16(bn.save) && (!bn.ab || bn.nhwc || bn.HW % 4 == 0) && (!bn.nhwc || bn.C % 4 == 0);
 #define LB(TFV, P, N)                                                                                                        \
   do {                                                                                                                       \
-    if (vec) hipLaunchKernelGGL((site_bwd4_kernel<TFV, P, N, true>), grid, TFV * 8, 0, st, gup, S, x, stats, B, F, r, eps,   \
+    if (vec && B == 128 && F % TFV == 0)                                                                                     \
+      hipLaunchKernelGGL((site_bwd4_kernel<TFV, P, N, true, false, true>), grid, TFV * 8, 0, st, gup, S, x, stats, B, F, r,  \
+                         eps, dx, n_tiles, aligned, bn);                                                                     \
+    else if (vec) hipLaunchKernelGGL((site_bwd4_kernel<TFV, P, N, true>), grid, TFV * 8, 0, st, gup, S, x, stats, B, F, r, eps,   \
                                 dx, n_tiles, aligned, bn);                                                                   \
     else hipLaunchKernelGGL((site_bwd4_kernel<TFV, P, N, false>), grid, TFV * 8, 0, st, gup, S, x, stats, B, F, r, eps, dx,  \
                             n_tiles, aligned, bn);                                                                           \
