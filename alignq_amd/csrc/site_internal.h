@@ -94,7 +94,9 @@ inline Geom geom(int B, int64_t F) {
     g.grid = g.n_tiles < 2048 ? g.n_tiles : 2048;
     if (g.nb == 1) {                 // site1 kernels: four wave-autonomous 32-feature sub-tiles per workgroup
       g.grid = (int)((F + 127) / 128);
-      static const int cap1 = [] { const char* e = getenv("ALIGNQ_S1_GRID_F"); return e ? atoi(e) : 2048; }();   // tuning aid
+      // 1024 workgroups = one resident round at four waves per SIMD (round 3: 2048 ran the kernel no faster - 57.6 vs 58.2 us at
+      // [28, 802816] - and doubled the slabs the reduction reads: config 5 22.36 -> 22.24 ms)
+      static const int cap1 = [] { const char* e = getenv("ALIGNQ_S1_GRID_F"); return e ? atoi(e) : 1024; }();   // tuning aid
       if (g.grid > cap1) g.grid = cap1;
     }
     g.slab_floats = (32 * g.nb) * (32 * g.nb);

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     tail = 1024 + 16                                     # loss partials + arrival counter
     assert lib.alignq_site_ws_bytes(128, 16384) == (256 * 8256 + tail) * 4   # 6 off-diagonal 32x32 tiles + 2 packed [32][33] blocks
     assert lib.alignq_site_ws_bytes(128, 4096) == (128 * 8256 + tail) * 4    # 32-feature tiles: half the slabs (round 3)
-    assert lib.alignq_site_ws_bytes(28, 802816) == (2048 * 32 * 32 + tail) * 4
+    assert lib.alignq_site_ws_bytes(28, 802816) == (1024 * 32 * 32 + tail) * 4        # one resident round of site1 workgroups
     assert lib.alignq_site_ws_bytes(28, 1024) == (8 * 32 * 32 + tail) * 4            # 32 sub-tiles of 32 features / 4 waves
     # above 128 rows only corr(x, x) exists (blocked Gram: 3 block pairs x 1 K split of 128 x 128 floats); 1024 rows is the end
     assert lib.alignq_site_ws_bytes(129, 64) == 3 * 128 * 128 * 4
