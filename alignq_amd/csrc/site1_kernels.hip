@@ -101,7 +101,19 @@ __global__ __launch_bounds__(kThreads1, PAIR ? 4 : 5) void site1_fwd_kernel(cons
                                                               float* __restrict__ slabs, float* __restrict__ stats,
                                                               int n_sub, unsigned* __restrict__ counter,
                                                               const float* __restrict__ res, int relu,
-                                                              const float* __restrict__ ab, int nch) {
+                                                              const float* __restrict__ ab, int nch, int64_t ws_gstride) {
+  // blockIdx.y = group: batch slices of a merged multi-pass tensor ([groups][B][F]), each with its own statistics, slabs
+  // (workspace regions ws_gstride floats apart) and (a, b)
+  {
+    const int64_t gi = blockIdx.y, go = gi * (int64_t)B * F;
+    x += go;
+    if (xq) xq += go;
+    if (res) res += go;
+    if (stats) stats += gi * 4 * F;
+    slabs += gi * ws_gstride;
+    if (counter) counter += gi * ws_gstride;
+    if (ab) ab += gi * 2 * nch;
+  }
   __shared__ __attribute__((aligned(16))) unsigned lds[(kWaves * WBUF > 4096) ? kWaves * WBUF : 4096];
   __shared__ __attribute__((aligned(16))) float nerf_lds[PAIR ? ALIGNQ_NERF_LDS_FLOATS : 4];
   if (PAIR) {
@@ -303,7 +315,18 @@ __global__ __launch_bounds__(kThreads1, 3) void site1_bwd_kernel(const float* __
                                                               const float* __restrict__ stats, int B, int64_t F, float r,
                                                               float eps, float* __restrict__ dx, int n_sub,
                                                               const float* __restrict__ ab, int C,
-                                                              const float* __restrict__ ymask, float* __restrict__ dres) {
+                                                              const float* __restrict__ ymask, float* __restrict__ dres,
+                                                              int64_t s_gstride) {
+  {        // blockIdx.y = group (see site1_fwd_kernel); S matrices s_gstride floats apart
+    const int64_t gi = blockIdx.y, go = gi * (int64_t)B * F;
+    x += go; dx += go;
+    if (gup) gup += go;
+    if (ymask) ymask += go;
+    if (dres) dres += go;
+    S += gi * s_gstride;
+    stats += gi * 4 * F;
+    if (ab) ab += gi * 2 * C;
+  }
   __shared__ __attribute__((aligned(16))) unsigned lds[kWaves * WBUF];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
@@ -475,19 +498,21 @@ __global__ __launch_bounds__(kThreads1, 3) void site1_bwd_kernel(const float* __
 }  // namespace
 
 int launch_partials1(bool pair, const Geom& g, const float* x, int B, int64_t F, int k, float r, float eps, float* xq,
-                     float* stats, float* ws, hipStream_t st, const float* res, int relu, const float* ab, int C) {
+                     float* stats, float* ws, hipStream_t st, const float* res, int relu, const float* ab, int C, int groups,
+                     int64_t ws_gstride) {
   unsigned* counter = reinterpret_cast<unsigned*>(ws + (size_t)g.grid * g.slab_floats + kPartFloats);
   if ((int64_t)B * F * 4 >= ((int64_t)1 << 32)) return ALIGNQ_EUNSUPPORTED;   // 32-bit byte offsets
   const int n_sub = (int)((F + SUBF - 1) / SUBF);
-  if (pair && res) hipLaunchKernelGGL((site1_fwd_kernel<true, true>), g.grid, kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter, res, relu, ab, C);
-  else if (pair) hipLaunchKernelGGL((site1_fwd_kernel<true, false>), g.grid, kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter, nullptr, relu, ab, C);
-  else hipLaunchKernelGGL((site1_fwd_kernel<false, false>), g.grid, kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter, nullptr, 0, ab, C);
+  if (pair && res) hipLaunchKernelGGL((site1_fwd_kernel<true, true>), dim3(g.grid, groups), kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter, res, relu, ab, C, ws_gstride);
+  else if (pair) hipLaunchKernelGGL((site1_fwd_kernel<true, false>), dim3(g.grid, groups), kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter, nullptr, relu, ab, C, ws_gstride);
+  else hipLaunchKernelGGL((site1_fwd_kernel<false, false>), dim3(g.grid, groups), kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter, nullptr, 0, ab, C, ws_gstride);
   RET_ON_ERR1();
   return 0;
 }
 
 int launch_bwd1(bool pair, const float* gup, const float* S, const float* x, const float* stats, int B, int64_t F,
-                float r, float eps, float* dx, hipStream_t st, const float* ab, int C, const float* ymask, float* dres) {
+                float r, float eps, float* dx, hipStream_t st, const float* ab, int C, const float* ymask, float* dres, int groups,
+                int64_t s_gstride) {
   if ((int64_t)B * F * 4 >= ((int64_t)1 << 32)) return ALIGNQ_EUNSUPPORTED;   // 32-bit byte offsets
   const int n_sub = (int)((F + SUBF - 1) / SUBF);
   int grid = (n_sub + kWaves - 1) / kWaves;
@@ -495,8 +520,9 @@ int launch_bwd1(bool pair, const float* gup, const float* S, const float* x, con
   // [28, 802816]) ran 82-84 us against 86-87 for 2048 and 17.2 against 19.6 at [28, 100352] (tools/s1_grid_sweep.sh)
   static const int capb = [] { const char* e = getenv("ALIGNQ_S1_GRID_B"); return e ? atoi(e) : 768; }();      // tuning aid
   if (grid > capb) grid = capb;
-  if (pair) hipLaunchKernelGGL((site1_bwd_kernel<true>), grid, kThreads1, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_sub, ab, C, ymask, dres);
-  else hipLaunchKernelGGL((site1_bwd_kernel<false>), grid, kThreads1, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_sub, ab, C, nullptr, nullptr);
+  if (groups > 1 && grid * groups > capb) grid = (capb + groups - 1) / groups;      // the groups share the resident round
+  if (pair) hipLaunchKernelGGL((site1_bwd_kernel<true>), dim3(grid, groups), kThreads1, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_sub, ab, C, ymask, dres, s_gstride);
+  else hipLaunchKernelGGL((site1_bwd_kernel<false>), dim3(grid, groups), kThreads1, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_sub, ab, C, nullptr, nullptr, s_gstride);
   RET_ON_ERR1();
   return 0;
 }

@@ -1019,6 +1019,22 @@ __global__ __launch_bounds__(1024) void slab_reduce_multi_kernel(RChunk c, int B
                                rho, parts, counter, c.scal[s]);
 }
 
+// The B <= 64 geometries (full [BP][BP] slabs) for several batch slices of one site in ONE launch (blockIdx.y = group; the
+// slices' workspace regions lie ws_gstride floats apart, D and scal are [groups][B][B] / [groups][4]): the merged source +
+// target pass of the Office step.
+__global__ __launch_bounds__(1024) void slab_reduce_groups_kernel(float* __restrict__ ws0, int n_slabs, int slab_floats, int BP,
+                                                                  int B, float scale, float* __restrict__ out,
+                                                                  const float* __restrict__ A, const float* __restrict__ gamma,
+                                                                  int dim, float mu, float rho, float* __restrict__ scal,
+                                                                  int64_t ws_gstride) {
+  const int64_t gi = blockIdx.y;
+  float* ws = ws0 + gi * ws_gstride;
+  float* parts = ws + (size_t)n_slabs * slab_floats;
+  unsigned* counter = reinterpret_cast<unsigned*>(parts + kPartFloats);
+  slab_reduce_body<false, true>(ws, n_slabs, slab_floats, BP, B, scale, out + gi * B * B, A, gamma, dim, mu, rho, parts, counter,
+                                scal + gi * 4);
+}
+
 // ================================================================================================ backward prep
 // S = (gD + gD^T) * gscale / F  [B,B]   (MFMA A operand of the backward), and (FUSED) the scaled parameter
 // gradients dA_out = gscale*(mu*sign(A)/n - gD), dG_out = gscale*|D-A|/n  (zero outside [:B,:B]).
@@ -1859,6 +1875,16 @@ int launch_reduce_any(const Geom& g, const float* ws_c, float* ws_mut, int B, in
   if (g.nb == 4) { if (with_loss) LR(true, true); else LR(true, false); }
   else { if (with_loss) LR(false, true); else LR(false, false); }
 #undef LR
+  RET_ON_ERR();
+  return 0;
+}
+
+int launch_reduce_loss_groups(const Geom& g, float* ws, int B, int64_t F, int groups, float* D, const float* alterD,
+                              const float* gamma, int dim, float mu, float rho, float* scal, int64_t ws_gstride, hipStream_t st) {
+  if (g.nb == 4) return ALIGNQ_EUNSUPPORTED;
+  const int BP = 32 * g.nb, blocks = (B * B + 63) / 64;
+  hipLaunchKernelGGL(slab_reduce_groups_kernel, dim3(blocks, groups), 1024, 0, st, ws, g.grid, g.slab_floats, BP, B,
+                     1.0f / (float)F, D, alterD, gamma, dim, mu, rho, scal, ws_gstride);
   RET_ON_ERR();
   return 0;
 }

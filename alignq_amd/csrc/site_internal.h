@@ -109,10 +109,12 @@ inline size_t ws_floats(const Geom& g) { return (size_t)g.grid * g.slab_floats +
 // ---- launchers defined in site1_kernels.hip (2 <= B <= 32) ---------------------------------------------------
 int launch_partials1(bool pair, const Geom& g, const float* x, int B, int64_t F, int k, float r, float eps, float* xq,
                      float* stats, float* ws, hipStream_t st, const float* res = nullptr, int relu = 0,
-                     const float* ab = nullptr, int C = 1);      // ab: folded batch-norm (channels-last, C a power of two)
+                     const float* ab = nullptr, int C = 1, int groups = 1, int64_t ws_gstride = 0);      // ab: folded batch-norm (channels-last, C a power of two)
+int launch_reduce_loss_groups(const Geom& g, float* ws, int B, int64_t F, int groups, float* D, const float* alterD,
+                              const float* gamma, int dim, float mu, float rho, float* scal, int64_t ws_gstride, hipStream_t st);
 int launch_bwd1(bool pair, const float* gup, const float* S, const float* x, const float* stats, int B, int64_t F,
                 float r, float eps, float* dx, hipStream_t st, const float* ab = nullptr, int C = 1,
-                const float* ymask = nullptr, float* dres = nullptr);
+                const float* ymask = nullptr, float* dres = nullptr, int groups = 1, int64_t s_gstride = 0);
 
 // ---- launchers defined in site4_kernels.hip ----------------------------------------------------------------
 int launch_partials4(bool pair, const Geom& g, const float* x, int B, int64_t F, int k, float r, float eps, float* xq,

@@ -702,6 +702,42 @@ int alignq_site_bwd_apply_ab_relu(const float* g, const float* y, const float* S
   return launch_bwd1(true, g, S, z, stats, B, F, act_range, eps, dx, (hipStream_t)stream, ab, C, y, dres);
 }
 
+// ---- the B <= 32 site for `groups` batch slices stacked along the batch (the Office step's merged source + target pass):
+// ONE launch per kernel, blockIdx.y = slice.  z / residual / y / g / dx / dres: [groups][B][F]; ab: [groups][2][C]; stats:
+// [groups][4][F]; D: [groups][B][B]; scal: [groups][4]; ws: groups regions of alignq_site_ws_bytes(B, F); S: groups regions of
+// alignq_site_bwd_ws_bytes(B) (alignq_site_prep_fused_multi fills them, one "site" per slice).
+int alignq_site1_groups_fwd(const float* z, const float* ab, int C, int B, int64_t F, int groups, int k, float act_range,
+                            float eps, const float* residual, int relu, float* y, float* stats, void* ws, void* stream) {
+  if (!z || !ab || !ws || !y || groups < 1 || C < 1 || (C & (C - 1)) != 0 || F % C != 0) return ALIGNQ_EINVAL;
+  if (bad_shape(B, F)) return F <= 0 ? ALIGNQ_EINVAL : ALIGNQ_EUNSUPPORTED;
+  if (bad_k(k)) return ALIGNQ_EINVAL;
+  const Geom g = geom(B, F);
+  if (g.nb != 1) return ALIGNQ_EUNSUPPORTED;
+  return launch_partials1(true, g, z, B, F, k, act_range, eps, y, stats, (float*)ws, (hipStream_t)stream, residual, relu, ab, C,
+                          groups, (int64_t)(alignq_site_ws_bytes(B, F) / 4));
+}
+
+int alignq_site1_groups_reduce_loss(void* ws, int B, int64_t F, int groups, float* D, const float* alterD, const float* gamma,
+                                    int dim, float mu, float rho, float* scal, void* stream) {
+  if (!ws || !D || !alterD || !gamma || !scal || groups < 1 || dim < B) return ALIGNQ_EINVAL;
+  if (bad_shape(B, F)) return F <= 0 ? ALIGNQ_EINVAL : ALIGNQ_EUNSUPPORTED;
+  const Geom g = geom(B, F);
+  if (g.nb != 1) return ALIGNQ_EUNSUPPORTED;
+  return launch_reduce_loss_groups(g, (float*)ws, B, F, groups, D, alterD, gamma, dim, mu, rho, scal,
+                                   (int64_t)(alignq_site_ws_bytes(B, F) / 4), (hipStream_t)stream);
+}
+
+int alignq_site1_groups_bwd(const float* g, const float* y, const float* S, const float* z, const float* ab, int C,
+                            const float* stats, int B, int64_t F, int groups, float act_range, float eps, float* dx,
+                            float* dres, void* stream) {
+  if (!S || !z || !ab || !stats || !dx || groups < 1 || (g && !y) || C < 1 || (C & (C - 1)) != 0 || F % C != 0)
+    return ALIGNQ_EINVAL;
+  if (bad_shape(B, F)) return F <= 0 ? ALIGNQ_EINVAL : ALIGNQ_EUNSUPPORTED;
+  if (geom(B, F).nb != 1) return ALIGNQ_EUNSUPPORTED;
+  return launch_bwd1(true, g, S, z, stats, B, F, act_range, eps, dx, (hipStream_t)stream, ab, C, g ? y : nullptr, g ? dres : nullptr,
+                     groups, (int64_t)(alignq_site_bwd_ws_bytes(B) / 4));
+}
+
 int alignq_site_bwd_fused(const float* g, const float* D, const float* alterD, const float* gamma, int dim,
                           const float* scal, float mu, const float* dD_scale, const float* x, const float* stats,
                           int B, int64_t F, float act_range, float eps, float* dx, float* dalterD, float* dgamma,

@@ -703,17 +703,15 @@ class BNSite1Fn(torch.autograd.Function):
         D = torch.empty(groups, B, B, dtype=torch.float32, device=dev)
         scal = torch.empty(groups, 4, dtype=torch.float32, device=dev)
         from .ops import _ws
-        ws = _ws(lib.alignq_site_ws_bytes(B, F), dev)
+        ws = _ws(lib.alignq_site_ws_bytes(B, F) * groups, dev)
         L.check(lib.alignq_bnq_stats(L.ptr(z), P, C, groups, L.ptr(weight), L.ptr(bias), L.ptr(running_mean), L.ptr(running_var),
                                      L.ptr(nbt), float(momentum), float(bn_eps), L.ptr(ab), L.ptr(save), L.ptr(ws_bn), st),
                 "alignq_bnq_stats")
-        for gi in range(groups):
-            sl = slice(gi * B, (gi + 1) * B)
-            L.check(lib.alignq_site_partials_res_ab(L.ptr(z[sl]), L.ptr(ab[gi]), C, B, F, int(k), float(act_range), float(eps),
-                                                    L.ptr(None if residual is None else residual[sl]), 1, L.ptr(y[sl]),
-                                                    L.ptr(stats[gi]), L.ptr(ws), st), "alignq_site_partials_res_ab")
-            L.check(lib.alignq_site_reduce_loss(L.ptr(ws), B, F, L.ptr(D[gi]), L.ptr(A), L.ptr(Gm), A.shape[0], float(mu),
-                                                float(rho), L.ptr(scal[gi]), st), "alignq_site_reduce_loss")
+        # every slice in ONE launch per kernel (blockIdx.y = slice; the slices' workspace regions lie back to back)
+        L.check(lib.alignq_site1_groups_fwd(L.ptr(z), L.ptr(ab), C, B, F, groups, int(k), float(act_range), float(eps),
+                                            L.ptr(residual), 1, L.ptr(y), L.ptr(stats), L.ptr(ws), st), "alignq_site1_groups_fwd")
+        L.check(lib.alignq_site1_groups_reduce_loss(L.ptr(ws), B, F, groups, L.ptr(D), L.ptr(A), L.ptr(Gm), A.shape[0], float(mu),
+                                                    float(rho), L.ptr(scal), st), "alignq_site1_groups_reduce_loss")
         ctx.save_for_backward(z, y, ab, save, stats, D, A, Gm, scal)
         ctx.cfg = (float(act_range), float(eps), float(mu), weight is not None, bias is not None, residual is not None,
                    int(groups))
@@ -747,23 +745,31 @@ class BNSite1Fn(torch.autograd.Function):
         dA = torch.empty(groups, *A.shape, dtype=torch.float32, device=dev)
         dG = torch.empty(groups, *Gm.shape, dtype=torch.float32, device=dev)
         from .ops import _ws
-        S = _ws(lib.alignq_site_bwd_ws_bytes(B), dev)
+        s_bytes = lib.alignq_site_bwd_ws_bytes(B)
+        S = _ws(s_bytes * groups, dev)
         dx = torch.empty_like(z)
         dgamma = torch.empty(C, dtype=torch.float32, device=dev) if has_w else None
         dbeta = torch.empty(C, dtype=torch.float32, device=dev) if has_b else None
         ws_bn = torch.empty(lib.alignq_bnq_ws_bytes(C, groups), dtype=torch.uint8, device=dev)
-        for gi in range(groups):
-            sl = slice(gi * B, (gi + 1) * B)
-            L.check(lib.alignq_site_prep_fused(L.ptr(D[gi]), L.ptr(A), L.ptr(Gm), A.shape[0], L.ptr(scal[gi]), mu, L.ptr(g_loss), B,
-                                               F, L.ptr(S), L.ptr(dA[gi]), L.ptr(dG[gi]), st), "alignq_site_prep_fused")
-            if g_y is None or not _S1_MASK_IN_KERNEL:
-                L.check(lib.alignq_site_bwd_apply_ab(L.ptr(None if g_y is None else g_y[sl]), L.ptr(S), L.ptr(z[sl]), L.ptr(ab[gi]), C, L.ptr(stats[gi]), B, F, act_range,
-                                                     eps, L.ptr(dx[sl]), st), "alignq_site_bwd_apply_ab")
-            else:
-                L.check(lib.alignq_site_bwd_apply_ab_relu(L.ptr(g_y[sl]), L.ptr(y[sl]), L.ptr(S), L.ptr(z[sl]), L.ptr(ab[gi]), C,
-                                                          L.ptr(stats[gi]), B, F, act_range, eps, L.ptr(dx[sl]),
-                                                          L.ptr(None if g_m is None else g_m[sl]), st),
-                        "alignq_site_bwd_apply_ab_relu")
+        if _S1_MASK_IN_KERNEL:
+            # one preparation launch (a "site" per slice: S, dalterD, dgamma) and one backward launch for all slices
+            Sg = [S[gi * s_bytes:(gi + 1) * s_bytes] for gi in range(groups)]
+            L.check(lib.alignq_site_prep_fused_multi(
+                groups, L.ptr_array([D[gi] for gi in range(groups)]), L.ptr_array([A] * groups), L.ptr_array([Gm] * groups),
+                L.ptr_array([scal[gi] for gi in range(groups)]), L.ptr(g_loss), L.i64_array([F] * groups), B, A.shape[0], mu,
+                L.ptr_array(Sg), L.ptr_array([dA[gi] for gi in range(groups)]), L.ptr_array([dG[gi] for gi in range(groups)]), st),
+                "alignq_site_prep_fused_multi")
+            L.check(lib.alignq_site1_groups_bwd(L.ptr(g_y), L.ptr(None if g_y is None else y), L.ptr(S), L.ptr(z), L.ptr(ab), C,
+                                                L.ptr(stats), B, F, groups, act_range, eps, L.ptr(dx), L.ptr(g_m), st),
+                    "alignq_site1_groups_bwd")
+        else:
+            for gi in range(groups):
+                sl = slice(gi * B, (gi + 1) * B)
+                L.check(lib.alignq_site_prep_fused(L.ptr(D[gi]), L.ptr(A), L.ptr(Gm), A.shape[0], L.ptr(scal[gi]), mu, L.ptr(g_loss),
+                                                   B, F, L.ptr(S), L.ptr(dA[gi]), L.ptr(dG[gi]), st), "alignq_site_prep_fused")
+                L.check(lib.alignq_site_bwd_apply_ab(L.ptr(None if g_y is None else g_y[sl]), L.ptr(S), L.ptr(z[sl]), L.ptr(ab[gi]), C,
+                                                     L.ptr(stats[gi]), B, F, act_range, eps, L.ptr(dx[sl]), st),
+                        "alignq_site_bwd_apply_ab")
         L.check(lib.alignq_bnq_bwd_dx(L.ptr(dx), L.ptr(z), L.ptr(ab), L.ptr(save), P, C, groups, L.ptr(dx), L.ptr(dgamma),
                                       L.ptr(dbeta), L.ptr(ws_bn), st), "alignq_bnq_bwd_dx")
 

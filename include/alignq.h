@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALIGNQ_ABI_VERSION 9
+#define ALIGNQ_ABI_VERSION 10
 
 #define ALIGNQ_FORMULA_ADMM 0
 #define ALIGNQ_FORMULA_CDF 1
@@ -438,6 +438,18 @@ int alignq_site_bwd_apply_ab(const float* g, const float* S, const float* z, con
 int alignq_site_bwd_apply_ab_relu(const float* g, const float* y, const float* S, const float* z, const float* ab, int C,
                                   const float* stats, int B, int64_t F, float act_range, float eps, float* dx, float* dres,
                                   void* stream);
+/* The B <= 32 site (alignq_site_partials_res_ab / alignq_site_reduce_loss / alignq_site_bwd_apply_ab_relu) for `groups` batch
+ * slices stacked along the batch - the Office step's merged source + target pass (dann_office/main.py:296-330) - in ONE launch
+ * per kernel: z / residual / y / g / dx / dres [groups][B][F]; ab [groups][2][C]; stats [groups][4][F]; D [groups][B][B];
+ * scal [groups][4]; ws = groups regions of alignq_site_ws_bytes(B, F) each; S = groups regions of alignq_site_bwd_ws_bytes(B)
+ * each (filled by alignq_site_prep_fused_multi with one entry per slice).  g == NULL: no upstream gradient (no mask, no dres). */
+int alignq_site1_groups_fwd(const float* z, const float* ab, int C, int B, int64_t F, int groups, int k, float act_range,
+                            float eps, const float* residual, int relu, float* y, float* stats, void* ws, void* stream);
+int alignq_site1_groups_reduce_loss(void* ws, int B, int64_t F, int groups, float* D, const float* alterD, const float* gamma,
+                                    int dim, float mu, float rho, float* scal, void* stream);
+int alignq_site1_groups_bwd(const float* g, const float* y, const float* S, const float* z, const float* ab, int C,
+                            const float* stats, int B, int64_t F, int groups, float act_range, float eps, float* dx,
+                            float* dres, void* stream);
 size_t alignq_bnq_ws_bytes(int C, int groups);
 int alignq_bnq_fwd(const float* z, int64_t P, int C, int groups, const float* gamma, const float* beta, float* running_mean,
                    float* running_var, int64_t* num_batches_tracked, float momentum, float bn_eps, int k, float act_range,
