@@ -313,6 +313,53 @@ def test_bn_folded_small_batch_admm_site_vs_oracle(dev, B, C, H, k):
         config.args.abitW, config.args.train_batch_size = old
 
 
+@pytest.mark.parametrize("B,C,H", [(28, 256, 14), (6, 64, 8), (28, 2048, 7)])
+def test_two_batch_slices_in_one_launch_equal_two_passes(dev, B, C, H):
+    """The merged source + target traversal of the Office step (groups = 2: alignq_bnq_stats, alignq_site1_groups_fwd /
+    _reduce_loss / _bwd, alignq_site_prep_fused_multi, alignq_bnq_bwd_dx with blockIdx.y = batch slice) against the module called
+    twice, slice after slice, as dann_office/main.py:296-330 does: outputs, the summed loss, D (the LAST pass's), running
+    statistics and every gradient bit for bit - the grouped launches run the same arithmetic on the same data."""
+    import alignq_amd.office as NO
+    from alignq_amd import config
+    rng = np.random.default_rng(B * C + H)
+    k = 8
+    old = (config.args.abitW, config.args.train_batch_size)
+    config.args.abitW, config.args.train_batch_size = k, B
+    try:
+        cl = lambda a: cu(a, dev).contiguous(memory_format=torch.channels_last)      # noqa: E731
+        z0 = (rng.standard_normal((2 * B, C, H, H)) * 1.3 + 0.2).astype(np.float32)
+        r0 = np.maximum(rng.standard_normal((2 * B, C, H, H)), 0).astype(np.float32)
+        g0 = (rng.standard_normal((2 * B, C, H, H)) * 1e-2).astype(np.float32)
+        outs = []
+        for merged in (True, False):
+            torch.manual_seed(5)
+            bn = torch.nn.BatchNorm2d(C).to(dev).train()
+            with torch.no_grad():
+                bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.2)
+            admm = NO.ADMM(B).to(dev)
+            act = NO.activation_quantize_fn2(k, "aligned", admm).to(dev)
+            z, res = cl(z0).requires_grad_(True), cl(r0).requires_grad_(True)
+            if merged:
+                y, loss = act.forward_bn_res_relu(bn, z, res, groups=2)
+            else:
+                ya, la = act.forward_bn_res_relu(bn, z[:B], res[:B])
+                yb, lb = act.forward_bn_res_relu(bn, z[B:], res[B:])
+                y, loss = torch.cat([ya, yb], 0), la + lb
+            torch.autograd.backward([y, loss], [cl(g0), torch.ones((), device=dev)])
+            outs.append([npy(t) for t in (y, loss.detach(), admm.D, bn.running_mean, bn.running_var, z.grad, res.grad, bn.weight.grad,
+                                          bn.bias.grad, admm.alterD.grad, admm.gamma.grad)] + [int(bn.num_batches_tracked)])
+        names = "y loss D running_mean running_var dz dres dgamma_bn dbeta_bn dalterD dgamma nbt".split()
+        for nm, a, b in zip(names, outs[0], outs[1]):
+            if nm in ("loss", "dgamma_bn", "dbeta_bn", "dalterD", "dgamma"):      # sums over the two slices: one rounding apart
+                np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-7, err_msg=nm)      # (float + float vs one rounding of the double sum)
+            elif nm == "nbt":
+                assert a == b == 2
+            else:
+                assert bits_equal(a, b), nm
+    finally:
+        config.args.abitW, config.args.train_batch_size = old
+
+
 def test_bn_alone_on_the_folded_family_vs_torch(dev):
     """fused.bn_only (the downsample branch's batch-norm: alignq_bnq_stats + _affine, backward alignq_bnq_bwd_dx) against
     torch.nn.BatchNorm2d in float64 on the CPU, C = 2048 (the 512-thread instantiation) and C = 256."""
