@@ -543,7 +543,8 @@ def other_configs(dev, a, steps=30):
         torch.cuda.empty_cache()
     config.args.bitW, config.args.abitW, config.args.train_batch_size, config.args.eval_batch_size = saved
     out["note"] = ("one GPU's share of BASELINE.json configs[2..4], HIP-graph replay, channels-last; config 5's convolutions "
-                   "and batch-norms are MIOpen's (out of scope), lr 0.004 from random init (DESIGN.md section 5b)")
+                   "are MIOpen's (out of scope), its batch-norms run folded into the quantiser / site kernels, source and target "
+                   "batch in one traversal; lr 0.004 from random init (DESIGN.md section 5b)")
     return out
 
 
