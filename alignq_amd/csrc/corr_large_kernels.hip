@@ -213,19 +213,21 @@ __global__ __launch_bounds__(kT) void corrl_sym_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------- 5. backward
-// dynamic LDS: Xh [nblk*32][33] floats + red [4][2][32]
-template <int RB>
-__global__ __launch_bounds__(kT) void corrl_bwd_kernel(const float* __restrict__ S, const float* __restrict__ x,
+// dynamic LDS: Xh [nblk*32][33] floats + red [NW][2][32] + tot [2][32].  NW waves share the row blocks (wave w: blocks w + NW q,
+// q < RB); B <= 512: 4 waves x RB <= 4; above: 8 waves x 4 (8 accumulators per wave spilled 54 registers at 256 + 256)
+template <int RB, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void corrl_bwd_kernel(const float* __restrict__ S, const float* __restrict__ x,
                                                        const float* __restrict__ stats, int B, int64_t F, float eps,
                                                        float* __restrict__ dx, int n_tiles, int aligned) {
   extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
   const int nblk = (B + 31) >> 5, BP = nblk * 32;
   float* Xs = lds_dyn;
-  float* red = lds_dyn + BP * kLDb;            // [4 waves][2][32]
-  float* tot = red + 4 * 2 * 32;               // [2][32]
+  float* red = lds_dyn + BP * kLDb;            // [NW waves][2][32]
+  float* tot = red + NW * 2 * 32;              // [2][32]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
-  const int c = tid & 7, rg = tid >> 3;        // load mapping: column quad, 32 row groups
+  const int c = tid & 7, rg = tid >> 3;        // load mapping: column quad, 8 NW row groups
+  constexpr int RG = 8 * NW;
   const float invB = 1.0f / (float)B, invBm1 = 1.0f / (float)(B - 1);
 
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -237,16 +239,16 @@ __global__ __launch_bounds__(kT) void corrl_bwd_kernel(const float* __restrict__
       m[e] = ok ? stats[col + e] : 0.0f;
       rho[e] = ok ? stats[F + col + e] : 0.0f;
     }
-    for (int r0 = rg; r0 < BP; r0 += 32 * 4) {
+    for (int r0 = rg; r0 < BP; r0 += RG * 4) {
       float4 v[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const int r = r0 + 32 * u;
+        const int r = r0 + RG * u;
         v[u] = ldq(x, (int64_t)r * F + col, col, F, r < B, aligned);
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const int r = r0 + 32 * u;
+        const int r = r0 + RG * u;
         if (r < BP) {
           const float e4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
@@ -268,21 +270,21 @@ __global__ __launch_bounds__(kT) void corrl_bwd_kernel(const float* __restrict__
       float a[RB];
 #pragma unroll
       for (int q = 0; q < RB; q++) {
-        const int i = (w + 4 * q) * 32 + l31;
+        const int i = (w + NW * q) * 32 + l31;
         a[q] = (i < B && kk < B) ? S[(int64_t)kk * B + i] : 0.0f;        // S symmetric: S[i][kk], read coalesced in i
       }
 #pragma unroll
       for (int q = 0; q < RB; q++)
-        if (w + 4 * q < nblk) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b, acc[q], 0, 0, 0);
+        if (w + NW * q < nblk) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b, acc[q], 0, 0, 0);
     }
     // ---- column projections over ALL rows: sum_b dXh, sum_b dXh * xh ------------------------------------------------
     float sd = 0.f, sdx = 0.f;
 #pragma unroll
     for (int q = 0; q < RB; q++) {
-      if (w + 4 * q < nblk) {
+      if (w + NW * q < nblk) {
 #pragma unroll
         for (int e = 0; e < 16; e++) {
-          const int row = (w + 4 * q) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const int row = (w + NW * q) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
           const float d = acc[q][e];            // rows >= B: S rows are zero there, so d == 0
           sd += d;
           sdx += d * Xs[row * kLDb + l31];
@@ -295,8 +297,12 @@ __global__ __launch_bounds__(kT) void corrl_bwd_kernel(const float* __restrict__
     __syncthreads();
     if (tid < 64) {
       const int which = tid >> 5, cc = tid & 31;
-      tot[which * 32 + cc] = ((red[(0 * 2 + which) * 32 + cc] + red[(1 * 2 + which) * 32 + cc]) +
-                              (red[(2 * 2 + which) * 32 + cc] + red[(3 * 2 + which) * 32 + cc]));
+      float t4 = (red[(0 * 2 + which) * 32 + cc] + red[(1 * 2 + which) * 32 + cc]) +
+                 (red[(2 * 2 + which) * 32 + cc] + red[(3 * 2 + which) * 32 + cc]);
+      if (NW == 8)
+        t4 += (red[(4 * 2 + which) * 32 + cc] + red[(5 * 2 + which) * 32 + cc]) +
+              (red[(6 * 2 + which) * 32 + cc] + red[(7 * 2 + which) * 32 + cc]);
+      tot[which * 32 + cc] = t4;
     }
     __syncthreads();
     // ---- assemble and store (lanes l31 -> 32 consecutive features of one row: 128-byte segments) ---------------------
@@ -310,10 +316,10 @@ __global__ __launch_bounds__(kT) void corrl_bwd_kernel(const float* __restrict__
       const float kdot = (sdev > 0.0f) ? tot[32 + l31] * invBm1 / sdev : 0.0f;
 #pragma unroll
       for (int q = 0; q < RB; q++) {
-        if (w + 4 * q < nblk) {
+        if (w + NW * q < nblk) {
 #pragma unroll
           for (int e = 0; e < 16; e++) {
-            const int row = (w + 4 * q) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const int row = (w + NW * q) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
             if (row < B && fok) dx[(int64_t)row * F + f] = (acc[q][e] - mean_d) * rr - Xs[row * kLDb + l31] * kdot;
           }
         }
@@ -362,23 +368,23 @@ int launch_corrl_bwd(const float* dG, const float* x, const float* stats, int B,
   hipLaunchKernelGGL(corrl_sym_kernel, dim3(gs), dim3(kT), 0, st, dG, B, 1.0f / (float)F, S);
   const int nblk = (B + 31) / 32, rb = (nblk + 3) / 4;
   const int n_tiles = (int)((F + kTFb - 1) / kTFb);
-  const size_t lds = ((size_t)nblk * 32 * kLDb + 4 * 2 * 32 + 2 * 32) * sizeof(float);
+  const size_t lds = ((size_t)nblk * 32 * kLDb + 8 * 2 * 32 + 2 * 32) * sizeof(float);
   int grid = n_tiles < 2048 ? n_tiles : 2048;
-#define CORRL_BWD(RB)                                                                                                          \
+#define CORRL_BWD(RB, NWV)                                                                                                     \
   do {                                                                                                                         \
     static bool attr_set = false;                                                                                              \
     if (!attr_set) {                                                                                                           \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&corrl_bwd_kernel<RB>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              160 * 1024 - 512) != hipSuccess)                                                                 \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&corrl_bwd_kernel<RB, NWV>),                                       \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess)                     \
         return ALIGNQ_EINVAL;                                                                                                  \
       attr_set = true;                                                                                                         \
     }                                                                                                                          \
-    hipLaunchKernelGGL((corrl_bwd_kernel<RB>), dim3(grid), dim3(kT), lds, st, (const float*)S, x, stats, B, F, eps, dx,        \
-                       n_tiles, aligned);                                                                                      \
+    hipLaunchKernelGGL((corrl_bwd_kernel<RB, NWV>), dim3(grid), dim3(64 * NWV), lds, st, (const float*)S, x, stats, B, F, eps, \
+                       dx, n_tiles, aligned);                                                                                  \
   } while (0)
-  if (rb <= 2) CORRL_BWD(2);
-  else if (rb <= 4) CORRL_BWD(4);
-  else CORRL_BWD(8);
+  if (rb <= 2) CORRL_BWD(2, 4);
+  else if (rb <= 4) CORRL_BWD(4, 4);
+  else CORRL_BWD(4, 8);                   // 512 < B <= 1024: eight waves, four row blocks each
 #undef CORRL_BWD
   return hipGetLastError() == hipSuccess ? 0 : ALIGNQ_EINVAL;
 }
