@@ -158,8 +158,8 @@ def test_bn_folded_site_kernels_vs_oracle(dev, nhwc, B, C, H, k):
     128 x {16384, 8192, 4096}, both layouts, against the C oracle; F = 36864 and 32768 (a short batch) run the forward's
     multi-tile instantiation (more tiles than workgroups: accumulators carried over the tile loop)."""
     if F_big := (C * H * H > 16384):
-        if k == 4:
-            pytest.skip("one bit width fewer at the large shapes (oracle time)")
+        if k == 4 and not nhwc:
+            pytest.skip("k = 4 at the large shapes runs in the channels-last layout only (oracle time)")
     rng = np.random.default_rng(1000 * nhwc + 10 * C + k)
     relu, with_res = (k != 4), (k == 8 or C == 32)
     shape = (B, C, H, H)
