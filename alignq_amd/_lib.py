@@ -13,7 +13,7 @@ SO_PATH = os.environ.get("ALIGNQ_SO") or os.path.join(_HERE, "lib", "libalignq_h
 FORMULA_ADMM, FORMULA_CDF = 0, 1
 MAX_BATCH = 128            # rows the FUSED site kernels hold on chip (ALIGNQ_MAX_BATCH)
 MAX_CORR_BATCH = 1024      # rows alignq_corr_fwd / _bwd take (ALIGNQ_MAX_CORR_BATCH: blocked Gram above 128)
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _c = ctypes
 _vp, _i, _i64, _f, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_size_t
@@ -109,6 +109,8 @@ SIGNATURES = {
     "alignq_weight_quant_fwd_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "alignq_weight_quant_bwd_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "alignq_sgd_step_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i, _i, _f, _f, _vp]),
+    "alignq_sgd_admm_step_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i, _i, _f, _f,
+                                        _i, _vp, _vp, _vp, _i, _i, _f, _f, _vp]),
 }
 
 _lib = None

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/alignq.h"
+#include "admm_body.h"
 #include "alignq_math.h"
 
 using namespace alignq;
@@ -24,9 +25,10 @@ constexpr int kMaxBlk = 256;    // blocks per tensor (partials per tensor in the
 constexpr int kU = 8;           // loads in flight per thread and pass (= elements per thread at 2048 elements per block)
 
 // element index of pass slot u, clamped for the (unconditional) load; `ok` tells whether the slot is real
-#define MT_FOR_ELEMENTS(n)                                                                   \
-  const long stride__ = (long)gridDim.x * kThreads;                                          \
-  for (long i0 = (long)blockIdx.x * kThreads + threadIdx.x; i0 < (n); i0 += stride__ * kU)
+#define MT_FOR_ELEMENTS_NT(n, NT)                                                            \
+  const long stride__ = (long)gridDim.x * (NT);                                              \
+  for (long i0 = (long)blockIdx.x * (NT) + threadIdx.x; i0 < (n); i0 += stride__ * kU)
+#define MT_FOR_ELEMENTS(n) MT_FOR_ELEMENTS_NT(n, kThreads)
 #define MT_IDX(u) (i0 + (long)(u) * stride__)
 #define MT_CLAMP(i, n) ((i) < (n) ? (i) : (n) - 1)
 
@@ -195,18 +197,14 @@ struct SChunk {
   unsigned char first[kSgdChunk];   // 1 => momentum buffer is being created this step
 };
 
-__global__ __launch_bounds__(kThreads) void mt_sgd_kernel(SChunk c, float lr, float mom, float damp, float wd,
-                                                          int nesterov, float nlev, float lam, float lam2) {
-  const int t = blockIdx.y;
-  float* __restrict__ p = c.p[t];
-  float* __restrict__ g = c.g[t];
-  float* __restrict__ buf = c.buf[t];
-  const float* __restrict__ cdf = c.cdf[t];
-  const float* __restrict__ pdf = c.pdf[t];
-  const long n = c.n[t];
-  const bool first = c.first[t] != 0;
+// one parameter tensor's SGD step by the workgroups (blockIdx.x, NT threads each) of its grid row
+template <int NT>
+__device__ __forceinline__ void sgd_tensor(float* __restrict__ p, float* __restrict__ g, float* __restrict__ buf,
+                                           const float* __restrict__ cdf, const float* __restrict__ pdf, long n, bool first,
+                                           float lr, float mom, float damp, float wd, int nesterov, float nlev, float lam,
+                                           float lam2) {
   const bool use_buf = mom != 0.0f && !first;
-  MT_FOR_ELEMENTS(n) {
+  MT_FOR_ELEMENTS_NT(n, NT) {
     float pv[kU], gv[kU], bv[kU], cv[kU], fv[kU];
 #pragma unroll
     for (int u = 0; u < kU; u++) {
@@ -241,6 +239,43 @@ __global__ __launch_bounds__(kThreads) void mt_sgd_kernel(SChunk c, float lr, fl
         g[i] = gout;
       }
     }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void mt_sgd_kernel(SChunk c, float lr, float mom, float damp, float wd,
+                                                          int nesterov, float nlev, float lam, float lam2) {
+  const int t = blockIdx.y;
+  sgd_tensor<kThreads>(c.p[t], c.g[t], c.buf[t], c.cdf[t], c.pdf[t], c.n[t], c.first[t] != 0, lr, mom, damp, wd, nesterov, nlev,
+                       lam, lam2);
+}
+
+// The SGD step and the ADMM primal / dual update of one iteration as ROLES of one launch (they touch disjoint tensors: the
+// alterD / gamma parameters are not in the SGD list, main.py:256-260): grid rows [0, T) take the parameters, rows [T, T + S) one
+// site each (workgroup 0 of the row; 1024 threads, the site in registers).  66 parameters + 22 sites = 3.8 KB of arguments.
+constexpr int kSgdA = 66, kSiteA = 22;
+struct SAChunk {
+  float* p[kSgdA];
+  float* g[kSgdA];
+  float* buf[kSgdA];
+  const float* cdf[kSgdA];
+  const float* pdf[kSgdA];
+  long n[kSgdA];
+  const float* D[kSiteA];
+  float* A[kSiteA];
+  float* G[kSiteA];
+  unsigned char first[kSgdA];
+};
+__global__ __launch_bounds__(kAdmmThreads) void mt_sgd_admm_kernel(SAChunk c, int T, float lr, float mom, float damp, float wd,
+                                                                   int nesterov, float nlev, float lam, float lam2, int b,
+                                                                   int dim, float mu, float rho) {
+  __shared__ double sm[48];
+  const int t = blockIdx.y;
+  if (t < T) {
+    sgd_tensor<kAdmmThreads>(c.p[t], c.g[t], c.buf[t], c.cdf[t], c.pdf[t], c.n[t], c.first[t] != 0, lr, mom, damp, wd, nesterov,
+                             nlev, lam, lam2);
+  } else if (blockIdx.x == 0) {
+    const int s = t - T;
+    admm_update_site(c.D[s], c.A[s], c.G[s], b, dim, mu, rho, sm);
   }
 }
 
@@ -370,6 +405,46 @@ int alignq_sgd_step_multi(int T, float* const* p, float* const* g, float* const*
     hipLaunchKernelGGL(mt_sgd_kernel, grid, kThreads, 0, st, c, lr, mom, damp, wd, nesterov, nlev, lam, lam2);
     LAUNCH_CHECK();
   }
+  return 0;
+}
+
+int alignq_sgd_admm_step_multi(int T, float* const* p, float* const* g, float* const* buf, const int64_t* n,
+                               const float* const* w_cdf, const float* const* w_pdf, const int32_t* first, float lr, float mom,
+                               float damp, float wd, int nesterov, int bitW, float lam, float lam2, int S,
+                               const float* const* D_tab, float* const* alterD_tab, float* const* gamma_tab, int b, int dim,
+                               float mu, float rho, void* stream) {
+  if (T <= 0 || !p || !g || !n || S <= 0 || !D_tab || !alterD_tab || !gamma_tab || b <= 0 || dim < b) return ALIGNQ_EINVAL;
+  if (mom != 0.0f && !buf) return ALIGNQ_EINVAL;
+  if (dim > 4096) return ALIGNQ_EUNSUPPORTED;
+  if (T > kSgdA || S > kSiteA) {       // more tensors than one argument block holds: the two launches of the separate entry points
+    if (int rc = alignq_sgd_step_multi(T, p, g, buf, n, w_cdf, w_pdf, first, lr, mom, damp, wd, nesterov, bitW, lam, lam2, stream))
+      return rc;
+    return alignq_admm_update(D_tab, alterD_tab, gamma_tab, S, b, dim, mu, rho, stream);
+  }
+  if (bitW < 1 || bitW > 30) bitW = 1;
+  const float nlev = (float)((1 << bitW) - 1);
+  SAChunk c;
+  long max_n = 0;
+  for (int i = 0; i < T; i++) {
+    if (!p[i] || !g[i] || n[i] <= 0) return ALIGNQ_EINVAL;
+    if (mom != 0.0f && !buf[i]) return ALIGNQ_EINVAL;
+    c.p[i] = p[i]; c.g[i] = g[i]; c.buf[i] = buf ? buf[i] : nullptr;
+    c.cdf[i] = (w_cdf && w_pdf && w_cdf[i] && w_pdf[i]) ? w_cdf[i] : nullptr;
+    c.pdf[i] = c.cdf[i] ? w_pdf[i] : nullptr;
+    c.n[i] = (long)n[i];
+    c.first[i] = (first && first[i]) ? 1 : 0;
+    if (c.n[i] > max_n) max_n = c.n[i];
+  }
+  for (int i = 0; i < S; i++) {
+    if (!D_tab[i] || !alterD_tab[i] || !gamma_tab[i]) return ALIGNQ_EINVAL;
+    c.D[i] = D_tab[i]; c.A[i] = alterD_tab[i]; c.G[i] = gamma_tab[i];
+  }
+  long bx = (max_n + (long)kAdmmThreads * kU - 1) / ((long)kAdmmThreads * kU);
+  if (bx < 1) bx = 1;
+  if (bx > kMaxBlk) bx = kMaxBlk;
+  hipLaunchKernelGGL(mt_sgd_admm_kernel, dim3((unsigned)bx, T + S), kAdmmThreads, 0, (hipStream_t)stream, c, T, lr, mom, damp, wd,
+                     nesterov, nlev, lam, lam2, b, dim, mu, rho);
+  LAUNCH_CHECK();
   return 0;
 }
 

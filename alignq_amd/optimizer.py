@@ -37,15 +37,10 @@ class SGD(Optimizer):
         for group in self.param_groups:
             group.setdefault("nesterov", False)
 
-    @torch.no_grad()
-    def step(self, idx, w_cdf, w_pdf, lam, lam2, closure=None):
-        loss = None
-        if closure is not None:
-            with torch.enable_grad():
-                loss = closure()
-        lib = L.load()
-        st = L.stream_ptr()
+    def _gather(self, idx, w_cdf, w_pdf):
+        """Per parameter group: (hyper-parameters, tensors of the multi-tensor launch); creates missing momentum buffers."""
         bitW = int(config.args.bitW)
+        out = []
         for group in self.param_groups:
             wd, mom, damp, nest, lr = (group["weight_decay"], group["momentum"], group["dampening"],
                                        group["nesterov"], group["lr"])
@@ -70,15 +65,29 @@ class SGD(Optimizer):
                     j = idx.index(i)
                     c, pdf = L.like_layout(w_cdf[j].detach(), p, "w_cdf"), L.like_layout(w_pdf[j].detach(), p, "w_pdf")
                 ps.append(p); gs.append(g); bufs.append(buf); firsts.append(first); cdfs.append(c); pdfs.append(pdf)
-            if not ps:
-                continue
+            if ps:
+                out.append(((float(lr), float(mom), float(damp), float(wd), int(bool(nest))), ps, gs, bufs, firsts, cdfs, pdfs))
+        return out
+
+    @staticmethod
+    def _c_args(item):
+        """The argument prefix alignq_sgd_step_multi and alignq_sgd_admm_step_multi share."""
+        (lr, mom, damp, wd, nest), ps, gs, bufs, firsts, cdfs, pdfs = item
+        return (len(ps), L.ptr_array(ps), L.ptr_array(gs), L.ptr_array(bufs) if mom != 0 else None,
+                L.i64_array([p.numel() for p in ps]), L.ptr_array(cdfs), L.ptr_array(pdfs), L.i32_array(firsts), lr, mom, damp,
+                wd, nest, min(int(config.args.bitW), 30))
+
+    @torch.no_grad()
+    def step(self, idx, w_cdf, w_pdf, lam, lam2, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = L.load()
+        st = L.stream_ptr()
+        for item in self._gather(idx, w_cdf, w_pdf):
             # one multi-tensor launch (per <=72 tensors) for the whole group: step + p.grad rewrite for idx members
-            L.check(lib.alignq_sgd_step_multi(len(ps), L.ptr_array(ps), L.ptr_array(gs),
-                                              L.ptr_array(bufs) if mom != 0 else None,
-                                              L.i64_array([p.numel() for p in ps]), L.ptr_array(cdfs),
-                                              L.ptr_array(pdfs), L.i32_array(firsts), float(lr), float(mom),
-                                              float(damp), float(wd), int(bool(nest)), min(bitW, 30), float(lam),
-                                              float(lam2), st), "alignq_sgd_step_multi")
+            L.check(lib.alignq_sgd_step_multi(*self._c_args(item), float(lam), float(lam2), st), "alignq_sgd_step_multi")
         return loss
 
 
@@ -94,8 +103,14 @@ class ADMM_OPT(Optimizer):
                 loss = closure()
         if int(config.args.bitW) >= 32:
             raise KeyError("lr")   # the reference's non-quantised branch reads group['lr'], which ADMM_OPT never defines
-        lib = L.load()
-        # walk the parameter list like utils/optimizer.py:76-124 and collect (site j, alterD param, gamma param)
+        for (mu, rho, b, dim), sites in self._gather(alterD_idx, gamma_idx, Ds, gammas, mus, rhos).items():
+            L.check(L.load().alignq_admm_update(L.ptr_array([s_[0] for s_ in sites]), L.ptr_array([s_[1] for s_ in sites]),
+                                                L.ptr_array([s_[2] for s_ in sites]), len(sites), b, dim, mu, rho,
+                                                L.stream_ptr()), "alignq_admm_update")
+        return loss
+
+    def _gather(self, alterD_idx, gamma_idx, Ds, gammas, mus, rhos):
+        """{(mu, rho, b, dim): [(D, alterD, gamma)]}: walks the parameter list like utils/optimizer.py:76-124."""
         groups = {}
         for group in self.param_groups:
             params = group["params"]
@@ -124,9 +139,27 @@ class ADMM_OPT(Optimizer):
             if pending is not None:
                 # alterD updated, dual skipped: do the primal only by pairing with a scratch dual
                 raise NotImplementedError("alterD parameter without a following gamma parameter")
-        st = L.stream_ptr()
-        for (mu, rho, b, dim), sites in groups.items():
-            L.check(lib.alignq_admm_update(L.ptr_array([s_[0] for s_ in sites]), L.ptr_array([s_[1] for s_ in sites]),
-                                           L.ptr_array([s_[2] for s_ in sites]), len(sites), b, dim, mu, rho, st),
-                    "alignq_admm_update")
-        return loss
+        return groups
+
+
+@torch.no_grad()
+def sgd_admm_step(sgd, sgd_args, admm, admm_args):
+    """`sgd.step(*sgd_args)` then `admm.step(*admm_args)` (main.py:330-340) with ONE kernel launch when the two optimizers
+    hold disjoint parameters (the CIFAR drivers split alterD / gamma off by name), there is one SGD group and all sites share
+    (mu, rho, b, dim); anything else runs the two steps as they are.  Same results either way."""
+    idx, w_cdf, w_pdf, lam, lam2 = sgd_args
+    alterD_idx, gamma_idx, Ds, alterDs, gammas, mus, rhos = admm_args
+    if int(config.args.bitW) < 32:
+        mine = {id(p) for g in sgd.param_groups for p in g["params"]}
+        disjoint = not any(id(p) in mine for g in admm.param_groups for p in g["params"])
+        items = sgd._gather(idx, w_cdf, w_pdf) if disjoint else None
+        groups = admm._gather(alterD_idx, gamma_idx, Ds, gammas, mus, rhos) if disjoint else None
+        if disjoint and len(items) == 1 and len(groups) == 1:
+            ((mu, rho, b, dim), sites), = groups.items()
+            L.check(L.load().alignq_sgd_admm_step_multi(
+                *SGD._c_args(items[0]), float(lam), float(lam2), len(sites), L.ptr_array([s_[0] for s_ in sites]),
+                L.ptr_array([s_[1] for s_ in sites]), L.ptr_array([s_[2] for s_ in sites]), b, dim, mu, rho, L.stream_ptr()),
+                "alignq_sgd_admm_step_multi")
+            return
+    sgd.step(idx, w_cdf, w_pdf, lam, lam2)
+    admm.step(alterD_idx, gamma_idx, Ds, alterDs, gammas, mus, rhos)

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 
 from . import config
 from .fused import DeferredLosses, DeferredWgrads, HeadCEFn, head_ce_supported, prequantize_weights
-from .optimizer import ADMM_OPT, SGD
+from .optimizer import ADMM_OPT, SGD, sgd_admm_step
 
 
 class TrainStep:
@@ -128,10 +128,11 @@ class TrainStep:
         if config.args.bitW < 32 and self.admms:
             w_cdf = [c.quantize_fn.weight_cdf for c in self.convs]
             w_pdf = [c.quantize_fn.weight_pdf for c in self.convs]
-            self.optimizer_t.step(self.idx, w_cdf, w_pdf, config.args.lam, config.args.lam2)
             a = self.admms
-            self.optimizer_admm.step(self.alterD_idx, self.gamma_idx, [m.D for m in a], [m.alterD for m in a],
-                                     [m.gamma for m in a], [m.mu for m in a], [m.rho for m in a])
+            # the two steps of main.py:330-340 as roles of one launch (disjoint parameters: see optimizer.sgd_admm_step)
+            sgd_admm_step(self.optimizer_t, (self.idx, w_cdf, w_pdf, config.args.lam, config.args.lam2), self.optimizer_admm,
+                          (self.alterD_idx, self.gamma_idx, [m.D for m in a], [m.alterD for m in a], [m.gamma for m in a],
+                           [m.mu for m in a], [m.rho for m in a]))
         else:
             # CDF-only tree (main.py:308 crashes as shipped): plain momentum SGD, no grad rewrite
             self.optimizer_t.step([], [], [], config.args.lam, config.args.lam2)

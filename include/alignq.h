@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALIGNQ_ABI_VERSION 10
+#define ALIGNQ_ABI_VERSION 11
 
 #define ALIGNQ_FORMULA_ADMM 0
 #define ALIGNQ_FORMULA_CDF 1
@@ -210,6 +210,16 @@ int alignq_sgd_step_multi(int T, float* const* p, float* const* g, float* const*
                           const float* const* w_cdf, const float* const* w_pdf, const int32_t* first, float lr,
                           float mom, float damp, float wd, int nesterov, int bitW, float lam, float lam2,
                           void* stream);
+
+/* The SGD step (alignq_sgd_step_multi) and the ADMM update (alignq_admm_update) of one iteration in ONE launch: the two touch
+ * disjoint tensors when alterD / gamma are not SGD parameters (the CIFAR drivers: main.py:256-260 split them by name), so the
+ * order utils' main.py:330-340 calls them in does not matter.  Same arguments and results as the two calls; more than 66
+ * parameters or 22 sites fall back to exactly those two calls.                                                                */
+int alignq_sgd_admm_step_multi(int T, float* const* p, float* const* g, float* const* buf, const int64_t* n,
+                               const float* const* w_cdf, const float* const* w_pdf, const int32_t* first, float lr,
+                               float mom, float damp, float wd, int nesterov, int bitW, float lam, float lam2, int S,
+                               const float* const* D_tab, float* const* alterD_tab, float* const* gamma_tab, int b,
+                               int dim, float mu, float rho, void* stream);
 
 /* ---- all ADMM sites of a model in one launch each (64 < B <= 128): the slab reduction + loss of every site is off the
  * network's critical path (only x_q feeds the next layer), so a whole-model step can defer them to the end of the forward;

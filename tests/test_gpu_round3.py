@@ -485,3 +485,65 @@ def test_head_ticket_is_idempotent(dev):
     with torch.cuda.stream(side):
         c_side = _head_counter(dev)
     assert int(_head_counter(dev)) == 0 and int(c_side) == 0 and c_side.data_ptr() != _head_counter(dev).data_ptr()
+
+
+# ------------------------------------------------------------------------------------------------ VERDICT r2 item 6
+@pytest.mark.parametrize("b,n_par,n_sites", [(128, 65, 21), (80, 9, 3), (128, 70, 21), (128, 12, 23)])
+def test_sgd_and_admm_update_in_one_launch_equal_the_two_steps(dev, b, n_par, n_sites):
+    """optimizer.sgd_admm_step (alignq_sgd_admm_step_multi: the SGD step and the ADMM update as roles of one launch) leaves the
+    bits of SGD.step followed by ADMM_OPT.step in every parameter, momentum buffer, rewritten p.grad, alterD and gamma; b = 80 is
+    a short batch in dim 128 (the padded form, utils/optimizer.py:95-103); 70 parameters / 23 sites exceed one argument block
+    (the entry point then issues the two launches itself)."""
+    from alignq_amd import config
+    from alignq_amd.admm import ADMM
+    from alignq_amd.optimizer import ADMM_OPT, SGD, sgd_admm_step
+    old = config.args.bitW
+    config.args.bitW = 4
+    try:
+        def world():
+            g = torch.Generator(device="cpu").manual_seed(5)
+            sizes = [432, 36864, 16, 640, 2304, 9216, 10, 18432, 64][:n_par] + [int(s) for s in
+                                                                              torch.randint(1, 5000, (max(0, n_par - 9),), generator=g)]
+            ps = [torch.nn.Parameter(torch.randn(s, generator=g).to(dev)) for s in sizes]
+            for p in ps:
+                p.grad = torch.randn(p.shape, generator=g).to(dev)
+            idx = [0, 1, 4]
+            cdfs = [torch.rand(ps[i].shape, generator=g).to(dev) - 0.5 for i in idx]
+            pdfs = [torch.rand(ps[i].shape, generator=g).to(dev) for i in idx]
+            admms = []
+            for _ in range(n_sites):
+                m = ADMM(128).to(dev)
+                with torch.no_grad():
+                    m.alterD.copy_(torch.rand(128, 128, generator=g))
+                    m.gamma.copy_(torch.rand(128, 128, generator=g))
+                m.alterD.grad = torch.zeros_like(m.alterD)
+                m.gamma.grad = torch.zeros_like(m.gamma)
+                m.D = (torch.randn(b, b, generator=g) * 0.05).to(dev)
+                admms.append(m)
+            sgd = SGD(ps, lr=0.1, momentum=0.9, weight_decay=5e-4)
+            aps = [p for m in admms for p in (m.alterD, m.gamma)]
+            opt = ADMM_OPT(aps)
+            sargs = (idx, cdfs, pdfs, 0.7, 1.3)
+            aargs = (list(range(0, 2 * n_sites, 2)), list(range(1, 2 * n_sites, 2)), [m.D for m in admms],
+                     [m.alterD for m in admms], [m.gamma for m in admms], [m.mu for m in admms], [m.rho for m in admms])
+            return ps, admms, sgd, opt, sargs, aargs
+
+        def state(ps, admms, sgd):
+            return ([p.detach().clone() for p in ps] + [p.grad.clone() for p in ps] +
+                    [sgd.state[p]["momentum_buffer"].clone() for p in ps] +
+                    [t.detach().clone() for m in admms for t in (m.alterD, m.gamma)])
+
+        ps, admms, sgd, opt, sargs, aargs = world()
+        for it in range(2):                                  # second round: existing momentum buffers
+            sgd.step(*sargs)
+            opt.step(*aargs)
+        want = state(ps, admms, sgd)
+        ps, admms, sgd, opt, sargs, aargs = world()
+        for it in range(2):
+            sgd_admm_step(sgd, sargs, opt, aargs)
+        got = state(ps, admms, sgd)
+        assert len(want) == len(got)
+        for w, g_ in zip(want, got):
+            assert torch.equal(w, g_)
+    finally:
+        config.args.bitW = old

@@ -1,0 +1,39 @@
+# node-by-node timeline of the captured step: for each of its kernels the duration and the idle gap to the next one
+# (rocprofv3 --kernel-trace timestamps, median over the replays).   bash tools/step_timeline.sh   -> gpurun_out/step_timeline.txt
+set -e
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+rm -rf gpurun_out/tl && mkdir -p gpurun_out/tl
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl/tr -o run -- python3 bench.py --steps ${STEPS:-60} --warmup 5 --no-cpu-baseline --no-kernels --no-shapes --no-dp-probe --no-other-configs $EXTRA > gpurun_out/tl/log 2>&1
+python3 - <<'PY'
+import csv, glob, re, statistics as st
+f = glob.glob('gpurun_out/tl/tr/**/*kernel_trace.csv', recursive=True)[0]
+rows = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in csv.DictReader(open(f))]
+rows.sort()
+# the replays are the tail of the trace: find the period p such that names repeat with lag p over the last 20 periods
+names = [r[2] for r in rows]
+best = None
+for p in range(60, 140):
+    if len(names) > 21 * p and all(names[-1 - i] == names[-1 - i - p] for i in range(20 * p)):
+        best = p; break
+assert best, 'no period found'
+p = best
+reps = 40
+tail = rows[-reps * p:]
+# rotate so that a period starts after the largest gap (the step boundary)
+gaps0 = [tail[i + 1][0] - tail[i][1] for i in range(p)]
+rot = max(range(p), key=lambda i: gaps0[i]) + 1
+tail = rows[-reps * p - (p - rot):][: (reps - 1) * p + 1]
+out = []
+tot_d = tot_g = 0.0
+for j in range(p):
+    d = st.median((tail[i * p + j][1] - tail[i * p + j][0]) / 1e3 for i in range(reps - 1))
+    g = st.median((tail[i * p + j + 1][0] - tail[i * p + j][1]) / 1e3 for i in range(reps - 1))
+    nm = re.sub(r'\(anonymous namespace\)::|alignq_site::|void ', '', tail[j][2])[:70]
+    out.append(f"{j:3d} {d:8.2f} {g:7.2f}  {nm}")
+    tot_d += d; tot_g += g
+per = st.median((tail[(i + 1) * p][0] - tail[i * p][0]) / 1e3 for i in range(reps - 2))
+hdr = f"# nodes per step {p}; step period {per:.1f} us; sum of kernel durations {tot_d:.1f} us; sum of gaps {tot_g:.1f} us (incl. the step boundary)\n# idx  dur_us  gap_us  kernel\n"
+open('gpurun_out/step_timeline.txt', 'w').write(hdr + "\n".join(out) + "\n")
+print(hdr)
+PY
+rm -rf gpurun_out/tl/tr
