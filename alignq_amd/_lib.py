@@ -86,6 +86,8 @@ SIGNATURES = {
     "alignq_conv3x3_nhwc_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp]),
     "alignq_conv3x3_nhwc_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                      _i, _i, _vp]),
+    "alignq_conv3x3_nhwc_bwd_fill": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                          _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "alignq_bn_bwd_totals": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "alignq_conv3x3_wgrad_reduce_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
     "alignq_head_ce_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),

@@ -1234,6 +1234,91 @@ __global__ __launch_bounds__(256) void wgrad3x3_nhwc_kernel(const float* __restr
                                BnLazy{nullptr, nullptr, nullptr, nullptr}, xlev);
 }
 
+// dW[e] = sum over slabs in a fixed order.  1024 threads = G slab groups x (1024 / G) elements with G = n_slabs / 16 clipped to
+// [1, 16] (a power of two): every thread owns (up to) 16 slab rows sl = g, g + G, ... and has all of them in flight at once;
+// the G partial sums of an element meet in LDS and are added in group order.  Few slabs (C = 64: 16) therefore mean wide
+// workgroups (1024 elements, 64 KB) instead of sixteen times as many workgroups of one load per thread.
+__host__ __device__ __forceinline__ int wgrad_reduce_groups(int n_slabs) {
+  int g = 1;
+  while (g < 16 && g * 16 < n_slabs) g <<= 1;
+  return g;
+}
+// (n_elem % 4 == 0, every filter shape here: a thread owns four consecutive elements, one 16-byte load per slab)
+__host__ __device__ __forceinline__ int wgrad_reduce_blocks(int n_slabs, int n_elem, int nt = 1024) {
+  const int per = (nt / wgrad_reduce_groups(n_slabs)) * ((n_elem & 3) ? 1 : 4);
+  return (n_elem + per - 1) / per;
+}
+template <int EPL, int NT = 1024>
+__device__ __forceinline__ void wgrad_reduce_body_t(const float* __restrict__ slabs, int n_slabs, int n_elem,
+                                                    float* __restrict__ dw, int blk, float* __restrict__ part /* [NT * EPL] */) {
+  const int G = wgrad_reduce_groups(n_slabs), per = NT / G;
+  const int g = threadIdx.x / per, l = threadIdx.x - g * per;
+  const int e = (blk * per + l) * EPL;
+  const int ec = e < n_elem ? e : n_elem - EPL;
+  float s[EPL];
+#pragma unroll
+  for (int q = 0; q < EPL; q++) s[q] = 0.f;
+  constexpr int U = 16;
+  for (int sl0 = g; sl0 < n_slabs; sl0 += G * U) {
+    float v[U][EPL];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int sl = sl0 + G * u;
+      const float* p = slabs + (int64_t)(sl < n_slabs ? sl : n_slabs - 1) * n_elem + ec;
+      if constexpr (EPL == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w;
+      } else {
+        v[u][0] = *p;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (sl0 + G * u < n_slabs) {
+#pragma unroll
+        for (int q = 0; q < EPL; q++) s[q] += v[u][q];
+      }
+    }
+  }
+  if (G == 1) {                                    // block-uniform
+    if (e < n_elem) {
+#pragma unroll
+      for (int q = 0; q < EPL; q++) dw[e + q] = s[q];
+    }
+    return;
+  }
+#pragma unroll
+  for (int q = 0; q < EPL; q++) part[threadIdx.x * EPL + q] = s[q];
+  __syncthreads();
+  if (g == 0 && e < n_elem) {
+#pragma unroll
+    for (int q = 0; q < EPL; q++) {
+      float t = 0.f;
+      for (int k = 0; k < G; k++) t += part[(k * per + l) * EPL + q];
+      dw[e + q] = t;
+    }
+  }
+}
+template <int NT = 1024>
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ slabs, int n_slabs, int n_elem,
+                                                  float* __restrict__ dw, int blk, float* __restrict__ part /* [4 * NT] */) {
+  if (n_elem & 3) wgrad_reduce_body_t<1, NT>(slabs, n_slabs, n_elem, dw, blk, part);      // block-uniform
+  else wgrad_reduce_body_t<4, NT>(slabs, n_slabs, n_elem, dw, blk, part);
+}
+
+// Filler role of a convolution's backward launch: the slab reduction of up to four EARLIER convolutions' filter gradients (their
+// partial sums were written by earlier launches; nothing reads the finished gradient before the weight quantiser's backward), by
+// workgroups of 256 threads placed behind the filter-gradient role.  Same groups, same summation order, same bits as
+// wgrad_reduce[_multi]_kernel: only the elements per workgroup differ.
+constexpr int kFill = 4;
+struct RedFill {
+  const float* slabs[kFill];
+  float* dw[kFill];
+  int n_slabs[kFill];
+  int n_elem[kFill];
+  int blk0[kFill + 1];    // first filler workgroup of every item, total
+};
+
 // Backward of one convolution in ONE launch: the first n_wg workgroups take the filter-gradient role (the longer one, so
 // it starts first), the rest the data-gradient role; the two are independent and fill the chip together.
 template <int C, int WD, int PTD, int PTW, int XB>
@@ -1241,13 +1326,22 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_kernel(const float* __restric
                                                           const float* __restrict__ w, float* __restrict__ dx,
                                                           float* __restrict__ slabs, int H, int total_rows, float nlev,
                                                           int n_tiles_w, int splits, int nblk2,
-                                                          const float* __restrict__ add, BnLazy lazy, float xlev, int dg_R) {
+                                                          const float* __restrict__ add, BnLazy lazy, float xlev, int dg_R,
+                                                          RedFill fill, int n_dg) {
   constexpr int kBytesD = ConvLds<C, WD, PTD>::kBf16 * 2, kBytesW = WgradLds<C, WD, PTW>::kFloats * 4;
+  static_assert(kBytesD >= 4096 || kBytesW >= 4096, "the filler role's 4 KB");
   __shared__ __attribute__((aligned(16))) unsigned char lds[kBytesD > kBytesW ? kBytesD : kBytesW];
   const int n_wg = splits * nblk2;
   if ((int)blockIdx.x < n_wg) {
     wgrad3x3_body<C, WD, PTW, XB>(x, dy, slabs, H, n_tiles_w, reinterpret_cast<float*>(lds), blockIdx.x % splits, splits,
                                   blockIdx.x / splits, lazy, xlev);
+  } else if ((int)blockIdx.x >= n_wg + n_dg) {
+    // dispatched last: the data-gradient tiles finish before the (one per CU, longer) filter-gradient workgroups do
+    const int fb = blockIdx.x - n_wg - n_dg;
+    int it = 0;
+    while (it + 1 < kFill && fb >= fill.blk0[it + 1]) it++;          // block-uniform (scalar) search
+    wgrad_reduce_body<256>(fill.slabs[it], fill.n_slabs[it], fill.n_elem[it], fill.dw[it], fb - fill.blk0[it],
+                           reinterpret_cast<float*>(lds));
   } else {
     // XCD placement (blocks are dealt round-robin over the 8 XCDs; for speed only): data-gradient tile t reads the dy rows
     // that filter-gradient workgroup t / dg_R reads, so it goes to a block on that workgroup's XCD — the later of the two reads
@@ -1302,77 +1396,6 @@ __global__ __launch_bounds__(256) void transition_bwd_kernel(const float* __rest
   }
 }
 
-// dW[e] = sum over slabs in a fixed order.  1024 threads = G slab groups x (1024 / G) elements with G = n_slabs / 16 clipped to
-// [1, 16] (a power of two): every thread owns (up to) 16 slab rows sl = g, g + G, ... and has all of them in flight at once;
-// the G partial sums of an element meet in LDS and are added in group order.  Few slabs (C = 64: 16) therefore mean wide
-// workgroups (1024 elements, 64 KB) instead of sixteen times as many workgroups of one load per thread.
-__host__ __device__ __forceinline__ int wgrad_reduce_groups(int n_slabs) {
-  int g = 1;
-  while (g < 16 && g * 16 < n_slabs) g <<= 1;
-  return g;
-}
-// (n_elem % 4 == 0, every filter shape here: a thread owns four consecutive elements, one 16-byte load per slab)
-__host__ __device__ __forceinline__ int wgrad_reduce_blocks(int n_slabs, int n_elem) {
-  const int per = (1024 / wgrad_reduce_groups(n_slabs)) * ((n_elem & 3) ? 1 : 4);
-  return (n_elem + per - 1) / per;
-}
-template <int EPL>
-__device__ __forceinline__ void wgrad_reduce_body_t(const float* __restrict__ slabs, int n_slabs, int n_elem,
-                                                    float* __restrict__ dw, int blk, float* __restrict__ part /* [1024 * EPL] */) {
-  const int G = wgrad_reduce_groups(n_slabs), per = 1024 / G;
-  const int g = threadIdx.x / per, l = threadIdx.x - g * per;
-  const int e = (blk * per + l) * EPL;
-  const int ec = e < n_elem ? e : n_elem - EPL;
-  float s[EPL];
-#pragma unroll
-  for (int q = 0; q < EPL; q++) s[q] = 0.f;
-  constexpr int U = 16;
-  for (int sl0 = g; sl0 < n_slabs; sl0 += G * U) {
-    float v[U][EPL];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int sl = sl0 + G * u;
-      const float* p = slabs + (int64_t)(sl < n_slabs ? sl : n_slabs - 1) * n_elem + ec;
-      if constexpr (EPL == 4) {
-        const float4 t = *reinterpret_cast<const float4*>(p);
-        v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w;
-      } else {
-        v[u][0] = *p;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      if (sl0 + G * u < n_slabs) {
-#pragma unroll
-        for (int q = 0; q < EPL; q++) s[q] += v[u][q];
-      }
-    }
-  }
-  if (G == 1) {                                    // block-uniform
-    if (e < n_elem) {
-#pragma unroll
-      for (int q = 0; q < EPL; q++) dw[e + q] = s[q];
-    }
-    return;
-  }
-#pragma unroll
-  for (int q = 0; q < EPL; q++) part[threadIdx.x * EPL + q] = s[q];
-  __syncthreads();
-  if (g == 0 && e < n_elem) {
-#pragma unroll
-    for (int q = 0; q < EPL; q++) {
-      float t = 0.f;
-      for (int k = 0; k < G; k++) t += part[(k * per + l) * EPL + q];
-      dw[e + q] = t;
-    }
-  }
-}
-__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ slabs, int n_slabs, int n_elem,
-                                                  float* __restrict__ dw, int blk, float* __restrict__ part /* [4096] */) {
-  if (n_elem & 3) wgrad_reduce_body_t<1>(slabs, n_slabs, n_elem, dw, blk, part);      // block-uniform
-  else wgrad_reduce_body_t<4>(slabs, n_slabs, n_elem, dw, blk, part);
-}
-
 __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ slabs, int n_slabs, int n_elem,
                                                             float* __restrict__ dw) {
   __shared__ __attribute__((aligned(16))) float part[4096];
@@ -1420,7 +1443,7 @@ int launch_wgrad(const float* x, const float* dy, float* dw, float* ws, int B, i
 
 template <int C, int WD, int PTD, int PTW>
 int launch_bwd(const float* x, const float* dy, const float* w, float* dx, float* ws, int B, int H, float nlev,
-               int* n_slabs_out, const float* add, BnLazy lazy, hipStream_t st, int xb = 0, float xlev = 1.0f) {
+               int* n_slabs_out, const float* add, BnLazy lazy, hipStream_t st, int xb, float xlev, const RedFill& fill) {
   constexpr int TRD = PTD / WD, TRW = PTW / WD;
   if (H % TRD || H % TRW) return ALIGNQ_EUNSUPPORTED;
   const int total_rows = B * H;
@@ -1429,7 +1452,7 @@ int launch_bwd(const float* x, const float* dy, const float* w, float* dx, float
   int splits = 256 / (NB * NB);
   if (splits > n_tiles_w) splits = n_tiles_w;
   const int n_d = total_rows / TRD;
-  const int grid = splits * NB * NB + n_d;
+  const int grid = splits * NB * NB + n_d + fill.blk0[kFill];
   // data-gradient tiles per filter-gradient pixel range (0: no XCD placement: the ranges do not tile the batch evenly)
   const int per = (n_tiles_w + splits - 1) / splits;
   int dg_R = 0;
@@ -1437,7 +1460,7 @@ int launch_bwd(const float* x, const float* dy, const float* w, float* dx, float
     const int R = per * TRW / TRD;
     if (R >= 1 && R * splits == n_d) dg_R = R;
   }
-#define LBW(XBV) hipLaunchKernelGGL((conv3x3_bwd_kernel<C, WD, PTD, PTW, XBV>), grid, 256, 0, st, x, dy, w, dx, ws, H, total_rows, nlev, n_tiles_w, splits, NB * NB, add, lazy, xlev, dg_R)
+#define LBW(XBV) hipLaunchKernelGGL((conv3x3_bwd_kernel<C, WD, PTD, PTW, XBV>), grid, 256, 0, st, x, dy, w, dx, ws, H, total_rows, nlev, n_tiles_w, splits, NB * NB, add, lazy, xlev, dg_R, fill, n_d)
   if (xb == 2) LBW(2); else if (xb == 1) LBW(1); else LBW(0);
 #undef LBW
   hipError_t e = hipGetLastError();
@@ -1612,10 +1635,12 @@ int alignq_conv3x3_wgrad_reduce_multi(int T, const void* const* ws, float* const
 
 // Both gradients of one convolution in a single launch (data gradient as alignq_conv3x3_nhwc(dgrad = 1), filter-gradient
 // partial sums as alignq_conv3x3_nhwc_wgrad with a deferred reduction: *n_slabs_out slabs are left in ws).
-int alignq_conv3x3_nhwc_bwd(const float* x, const float* dy, const float* wt, float* dx, void* ws, int B, int H, int W,
-                            int C, int w_bit, int* n_slabs_out, const float* add, const float* bn_z, const float* bn_ab,
+int alignq_conv3x3_nhwc_bwd_fill(const float* x, const float* dy, const float* wt, float* dx, void* ws, int B, int H, int W,
+                                 int C, int w_bit, int* n_slabs_out, const float* add, const float* bn_z, const float* bn_ab,
                             const float* bn_save, const float* bn_ktot, const float* bn_dx_part, float* bn_dgamma,
-                            float* bn_dbeta, const void* x_bins, int x_bin_bytes, int a_bit, void* stream) {
+                            float* bn_dbeta, const void* x_bins, int x_bin_bytes, int a_bit, int n_fill,
+                                 const void* const* fill_ws, float* const* fill_dw, const int* fill_n_slabs,
+                                 const int* fill_n_elem, void* stream) {
   if (bn_z && (!bn_ab || !bn_save || (!bn_ktot && !bn_dx_part))) return ALIGNQ_EINVAL;
   BnLazy lazy{bn_z, bn_ab, bn_save, bn_ktot};
   if (int rc = lazy_parts(lazy, bn_dx_part, bn_dgamma, bn_dbeta, B, C, H * W)) return rc;   // totals formed inside the kernel
@@ -1629,10 +1654,28 @@ int alignq_conv3x3_nhwc_bwd(const float* x, const float* dy, const float* wt, fl
        reinterpret_cast<uintptr_t>(dx)) & 15) return ALIGNQ_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const float nlev = (float)((1 << w_bit) - 1);
-  if (C == 16 && W == 32) return launch_bwd<16, 32, 256, 128>(x, dy, wt, dx, (float*)ws, B, H, nlev, n_slabs_out, add, lazy, st, xb, xlev);
-  if (C == 32 && W == 16) return launch_bwd<32, 16, 128, 128>(x, dy, wt, dx, (float*)ws, B, H, nlev, n_slabs_out, add, lazy, st, xb, xlev);
-  if (C == 64 && W == 8) return launch_bwd<64, 8, 32, 64>(x, dy, wt, dx, (float*)ws, B, H, nlev, n_slabs_out, add, lazy, st, xb, xlev);
+  RedFill fill{};
+  if (n_fill < 0 || n_fill > kFill || (n_fill && (!fill_ws || !fill_dw || !fill_n_slabs || !fill_n_elem))) return ALIGNQ_EINVAL;
+  for (int i = 0; i < n_fill; i++) {
+    if (!fill_ws[i] || !fill_dw[i] || fill_n_slabs[i] < 1 || fill_n_elem[i] < 1) return ALIGNQ_EINVAL;
+    fill.slabs[i] = (const float*)fill_ws[i]; fill.dw[i] = fill_dw[i]; fill.n_slabs[i] = fill_n_slabs[i];
+    fill.n_elem[i] = fill_n_elem[i];
+    fill.blk0[i + 1] = fill.blk0[i] + wgrad_reduce_blocks(fill_n_slabs[i], fill_n_elem[i], 256);
+  }
+  for (int i = n_fill; i < kFill; i++) fill.blk0[i + 1] = fill.blk0[i];
+  if (C == 16 && W == 32) return launch_bwd<16, 32, 256, 128>(x, dy, wt, dx, (float*)ws, B, H, nlev, n_slabs_out, add, lazy, st, xb, xlev, fill);
+  if (C == 32 && W == 16) return launch_bwd<32, 16, 128, 128>(x, dy, wt, dx, (float*)ws, B, H, nlev, n_slabs_out, add, lazy, st, xb, xlev, fill);
+  if (C == 64 && W == 8) return launch_bwd<64, 8, 32, 64>(x, dy, wt, dx, (float*)ws, B, H, nlev, n_slabs_out, add, lazy, st, xb, xlev, fill);
   return ALIGNQ_EUNSUPPORTED;
+}
+
+int alignq_conv3x3_nhwc_bwd(const float* x, const float* dy, const float* wt, float* dx, void* ws, int B, int H, int W,
+                            int C, int w_bit, int* n_slabs_out, const float* add, const float* bn_z, const float* bn_ab,
+                            const float* bn_save, const float* bn_ktot, const float* bn_dx_part, float* bn_dgamma,
+                            float* bn_dbeta, const void* x_bins, int x_bin_bytes, int a_bit, void* stream) {
+  return alignq_conv3x3_nhwc_bwd_fill(x, dy, wt, dx, ws, B, H, W, C, w_bit, n_slabs_out, add, bn_z, bn_ab, bn_save, bn_ktot,
+                                      bn_dx_part, bn_dgamma, bn_dbeta, x_bins, x_bin_bytes, a_bit, 0, nullptr, nullptr, nullptr,
+                                      nullptr, stream);
 }
 
 // Forward of the ResNet body's transition convolutions (see convgen_fwd_kernel): (KS, stride) = (3, 2) padding 1 or (1, 2)

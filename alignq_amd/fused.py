@@ -249,6 +249,16 @@ class DeferredWgrads:
     def add(self, ws, dw, n_slabs, n_elem):
         self.items.append((ws, dw, int(n_slabs), int(n_elem)))
 
+    def take(self, C):
+        """Hands the oldest pending reductions to a caller that finishes them inside its own launch (the filler role of
+        alignq_conv3x3_nhwc_bwd_fill; C: its channel count); they leave the list.  Measured: the 16-channel
+        launches absorb ~5 MB of slabs for nothing (their one-per-CU filter-gradient role outlasts the data-gradient tiles), the
+        32- / 64-channel ones grow by about what the closing reduction saves.  ALIGNQ_WGRAD_FILL="a,b,c": items per launch at
+        16 / 32 / 64 channels ("0,0,0": everything is left to `flush`)."""
+        most = _WGRAD_FILL.get(C, 0)
+        out, self.items = self.items[:most], self.items[most:]
+        return out
+
     def flush(self):
         if not self.items:
             return
@@ -262,6 +272,7 @@ class DeferredWgrads:
 
 
 _active_wgrads = None
+_WGRAD_FILL = dict(zip((16, 32, 64), (min(4, max(0, int(v))) for v in os.environ.get("ALIGNQ_WGRAD_FILL", "2,2,0").split(","))))
 
 
 def active_wgrads():

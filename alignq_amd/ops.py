@@ -548,10 +548,15 @@ class QConv3x3Fn(torch.autograd.Function):
             ws = _ws(lib.alignq_conv3x3_wgrad_ws_bytes(C), dev)
             ns = ctypes.c_int(0)
             bz, bab, bsave, bk, bpart, bdg, bdb = lazy[1:8] if lazy is not None else (None,) * 7
-            L.check(lib.alignq_conv3x3_nhwc_bwd(xp, L.ptr(gy), L.ptr(w), L.ptr(dx), L.ptr(ws), B, H, W, C, ctx.w_bit,
-                                                ctypes.byref(ns), L.ptr(add), L.ptr(bz), L.ptr(bab), L.ptr(bsave), L.ptr(bk),
-                                                L.ptr(bpart) if bk is None else None, L.ptr(bdg), L.ptr(bdb), xbp, xbb, a_bit,
-                                                L.stream_ptr()), "alignq_conv3x3_nhwc_bwd")
+            # filler role: this launch also finishes slab reductions of convolutions whose backward already ran
+            fill = pending.take(C)
+            nf = len(fill)
+            L.check(lib.alignq_conv3x3_nhwc_bwd_fill(
+                xp, L.ptr(gy), L.ptr(w), L.ptr(dx), L.ptr(ws), B, H, W, C, ctx.w_bit, ctypes.byref(ns), L.ptr(add), L.ptr(bz),
+                L.ptr(bab), L.ptr(bsave), L.ptr(bk), L.ptr(bpart) if bk is None else None, L.ptr(bdg), L.ptr(bdb), xbp, xbb, a_bit,
+                nf, L.ptr_array([f[0] for f in fill]) if nf else None, L.ptr_array([f[1] for f in fill]) if nf else None,
+                (ctypes.c_int * nf)(*[f[2] for f in fill]) if nf else None,
+                (ctypes.c_int * nf)(*[f[3] for f in fill]) if nf else None, L.stream_ptr()), "alignq_conv3x3_nhwc_bwd_fill")
             pending.add(ws, dw, ns.value, 9 * C * C)
             return (dx, dw) + none7
         if lazy is not None:               # not the fused path after all: finish the batch-norm input gradient here

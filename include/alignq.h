@@ -325,6 +325,17 @@ int alignq_conv3x3_nhwc_bwd(const float* x, const float* dy, const float* wt, fl
                             int C, int w_bit, int* n_slabs_out, const float* add, const float* bn_z, const float* bn_ab,
                             const float* bn_save, const float* bn_ktot, const float* bn_dx_part, float* bn_dgamma,
                             float* bn_dbeta, const void* x_bins, int x_bin_bytes, int a_bit, void* stream);
+/* The same launch with a FILLER role: workgroups behind the filter-gradient role finish the slab reduction of up to four EARLIER
+ * convolutions (fill_ws[i]: their slab workspace, fill_n_slabs[i] / fill_n_elem[i] as alignq_conv3x3_wgrad_reduce_multi takes
+ * them, fill_dw[i]: the finished gradient; HOST arrays of n_fill <= 4 entries).  Independent work inside a launch that is on the
+ * backward's critical path anyway: the closing alignq_conv3x3_wgrad_reduce_multi is left with the last convolutions only.
+ * Bit-identical to that reduction.                                                                                          */
+int alignq_conv3x3_nhwc_bwd_fill(const float* x, const float* dy, const float* wt, float* dx, void* ws, int B, int H, int W,
+                            int C, int w_bit, int* n_slabs_out, const float* add, const float* bn_z, const float* bn_ab,
+                            const float* bn_save, const float* bn_ktot, const float* bn_dx_part, float* bn_dgamma,
+                            float* bn_dbeta, const void* x_bins, int x_bin_bytes, int a_bit, int n_fill,
+                                 const void* const* fill_ws, float* const* fill_dw, const int* fill_n_slabs,
+                                 const int* fill_n_elem, void* stream);
 /* bn_z != NULL: `dy` is not the convolution output's gradient but g, the gradient w.r.t. the OUTPUT of the training-mode
  * batch-norm that follows the convolution (what alignq_site_bwd_apply_bn writes); both roles form
  * dy = a[c] * (g - k0[c] - (z - mean[c]) * invstd[c] * k1[c]) on load from bn_z (the convolution's forward output), bn_ab,
