@@ -100,6 +100,9 @@ SIGNATURES = {
     "alignq_bn_partial_stats": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "alignq_site_partials_bn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _i, _i, _i, _i64, _i, _f, _f, _i,
                                      _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "alignq_site_fill_slots": (_i, [_i, _i64]),
+    "alignq_site_partials_bn_fill": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _i, _i, _i, _i64, _i, _f, _f, _i,
+                                          _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _vp]),
     "alignq_site_bn_part_bytes": (_sz, [_i64, _i]),
     "alignq_bn_nhwc_ws_bytes": (_sz, [_i]),
     "alignq_bn_partial_stats_nhwc": (_i, [_vp, _i, _i, _i, _vp, _vp]),

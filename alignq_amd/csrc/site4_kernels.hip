@@ -209,6 +209,34 @@ __device__ __forceinline__ void split_bf16(float v, __bf16& hi, __bf16& lo) {
   lo = (__bf16)(v - (float)hi);
 }
 
+template <bool SYM>
+constexpr int kSlabReduceLds = 16 * 64 * (SYM ? 4 : 1) * 4 + 48 * 8 + 16;
+template <bool SYM, bool LOSS>
+__device__ __forceinline__ void slab_reduce_body(const float* __restrict__ slabs, int n_slabs, int slab_floats, int BP, int B,
+                                                 float scale, float* __restrict__ out, const float* __restrict__ A,
+                                                 const float* __restrict__ gamma, int dim, float mu, float rho,
+                                                 float* __restrict__ parts, unsigned* __restrict__ counter,
+                                                 float* __restrict__ scal, const int blk, const int nblk,
+                                                 unsigned char* __restrict__ lds);
+
+// Filler role of a one-tile forward launch that leaves CUs idle (F <= 8192: 128 workgroups): the slab reduction + ADMM loss of
+// up to three EARLIER sites of the same step (same B, dim, mu, rho), kSlabRedBlocks workgroups each behind the site's own tiles.
+// Nothing reads those sites' D or loss before the end of the forward, and the reduction is the same code with the same workgroup
+// partition as slab_reduce_multi_kernel: same bits.
+constexpr int kSiteFill = 3;
+constexpr int kSlabRedBlocks = (kSlab4Floats + 255) / 256;
+struct SFill {
+  const float* slabs[kSiteFill];
+  float* out[kSiteFill];
+  const float* A[kSiteFill];
+  const float* gamma[kSiteFill];
+  float* scal[kSiteFill];
+  float scale[kSiteFill];
+  int n_slabs[kSiteFill];
+  int n, dim;
+  float mu, rho;
+};
+
 // SINGLE: one tile per workgroup (n_tiles <= grid, every CIFAR-size site): no tile loop, so nothing is hoisted out of it and
 // kept alive across the phases (88 instead of 128 VGPRs), which buys the early requests of the batch-norm finalisation.
 // NTv: 1024 threads (16 waves: one workgroup per CU, the latency-tuned CIFAR form) or 512 (8 waves, 32-feature tiles, 45 KB of
@@ -218,7 +246,7 @@ template <int TFv, bool PAIR, bool SINGLE, int NTv = NT, bool FULLP = false>
 __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restrict__ x, int B, int64_t F, int k, float r,
                                                        float eps, float* __restrict__ xq, float* __restrict__ slabs,
                                                        float* __restrict__ stats, int n_tiles, int aligned,
-                                                       unsigned* __restrict__ counter, BnFold bn) {
+                                                       unsigned* __restrict__ counter, BnFold bn, SFill fill) {
   BSTAMP(0, 0);
   constexpr int LDB = TFv + 8;                    // bf16 elements per LDS row (row bytes multiple of 16, see bank note)
   constexpr int LPR = TFv / 4;                    // lanes per row (float4 each)
@@ -239,6 +267,19 @@ __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restri
   constexpr bool kFull = FULLP || kPlain;            // complete tiles: no masks (FULLP: the launcher's promise for the one-tile forms)
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STAGE_BYTES + (4 * TFv + 2 * NW * TFv) * 4];
   __shared__ __attribute__((aligned(16))) float nerf_lds[PAIR ? ALIGNQ_NERF_LDS_FLOATS : 4];
+  if constexpr (SINGLE && NTv == 1024) {
+    if ((int)blockIdx.x >= n_tiles) {          // filler workgroups (block-uniform): see SFill
+      static_assert(STAGE_BYTES >= kSlabReduceLds<true>, "the reduction's LDS lies in the staging area");
+      const int fb = blockIdx.x - n_tiles, it = fb / kSlabRedBlocks;
+      float* wsf = const_cast<float*>(fill.slabs[it]);
+      float* parts = wsf + (size_t)fill.n_slabs[it] * kSlab4Floats;
+      slab_reduce_body<true, true>(fill.slabs[it], fill.n_slabs[it], kSlab4Floats, 128, B, fill.scale[it], fill.out[it], fill.A[it],
+                                   fill.gamma[it], fill.dim, fill.mu, fill.rho, parts,
+                                   reinterpret_cast<unsigned*>(parts + kPartFloats), fill.scal[it], fb - it * kSlabRedBlocks,
+                                   kSlabRedBlocks, lds_raw);
+      return;
+    }
+  }
   // the transform's table (alignq_math.h): requested first, stored behind the tile loads of the first iteration
   NerfRegs<NTv> nerf_regs;
   if (PAIR) nerf_regs = nerf_tab_fetch<NTv>();
@@ -837,15 +878,18 @@ __device__ __forceinline__ void slab_reduce_body(const float* __restrict__ slabs
                                                            float* __restrict__ out, const float* __restrict__ A,
                                                            const float* __restrict__ gamma, int dim, float mu,
                                                            float rho, float* __restrict__ parts,
-                                                           unsigned* __restrict__ counter, float* __restrict__ scal) {
+                                                           unsigned* __restrict__ counter, float* __restrict__ scal,
+                                                           const int blk, const int nblk, unsigned char* __restrict__ lds) {
   // SYM: a lane owns FOUR consecutive stored elements (one 16-byte load per slab: the slab stream is the HBM-bound part of a
   // step, 215 MB for ResNet-20); else one element of the full BPxBP slab.
+  // blk / nblk: this workgroup's index among the workgroups of THIS reduction (a launch of its own: blockIdx.x / gridDim.x; a
+  // filler role of another launch: see SFill);  lds: kSlabReduceLds<SYM> bytes, 16-byte aligned
   constexpr int EPL = SYM ? 4 : 1;
-  __shared__ float part[16][64 * EPL];
-  __shared__ double fin[48];
-  __shared__ int is_last;
+  float (*part)[64 * EPL] = reinterpret_cast<float (*)[64 * EPL]>(lds);
+  double* fin = reinterpret_cast<double*>(lds + 16 * 64 * EPL * 4);
+  int& is_last = *reinterpret_cast<int*>(lds + 16 * 64 * EPL * 4 + 48 * 8);
   const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6;
-  const int e = (blockIdx.x * 64 + lane) * EPL;
+  const int e = (blk * 64 + lane) * EPL;
   // SYM: iterate over the STORED elements (10 tiles x 32 x 32, coalesced) and mirror the off-diagonal tiles;
   // else: over the output elements of the full BPxBP slab.
   int iq[EPL], jq[EPL], off;
@@ -950,12 +994,12 @@ __device__ __forceinline__ void slab_reduce_body(const float* __restrict__ slabs
         // bypass the non-coherent per-XCD L2 for these addresses; s_waitcnt vmcnt(0) orders this wave's three stores
         // before its ticket.  Formally this is a relaxed hand-off; tests/test_gpu_bench_path.py::
         // test_reduce_loss_is_idempotent_and_matches_the_oracle runs it 20x against the oracle's loss.
-        __hip_atomic_store(&parts[blockIdx.x * 4 + 0], v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&parts[blockIdx.x * 4 + 1], v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&parts[blockIdx.x * 4 + 2], v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&parts[blk * 4 + 0], v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&parts[blk * 4 + 1], v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&parts[blk * 4 + 2], v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned tk = __hip_atomic_fetch_add(counter, 1u, ALIGNQ_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT);
-        is_last = (tk == gridDim.x - 1);
+        is_last = (tk == (unsigned)nblk - 1);
       }
     }
   }
@@ -963,7 +1007,7 @@ __device__ __forceinline__ void slab_reduce_body(const float* __restrict__ slabs
   __syncthreads();
   if (!is_last) return;
   double s0 = 0, s1 = 0, s2 = 0;
-  if ((int)threadIdx.x < (int)gridDim.x) {
+  if ((int)threadIdx.x < nblk) {
     s0 = __hip_atomic_load(&parts[threadIdx.x * 4 + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s1 = __hip_atomic_load(&parts[threadIdx.x * 4 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s2 = __hip_atomic_load(&parts[threadIdx.x * 4 + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -995,7 +1039,9 @@ __global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restri
                                                            const float* __restrict__ gamma, int dim, float mu,
                                                            float rho, float* __restrict__ parts,
                                                            unsigned* __restrict__ counter, float* __restrict__ scal) {
-  slab_reduce_body<SYM, LOSS>(slabs, n_slabs, slab_floats, BP, B, scale, out, A, gamma, dim, mu, rho, parts, counter, scal);
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kSlabReduceLds<SYM>];
+  slab_reduce_body<SYM, LOSS>(slabs, n_slabs, slab_floats, BP, B, scale, out, A, gamma, dim, mu, rho, parts, counter, scal,
+                              blockIdx.x, gridDim.x, lds);
 }
 
 // All sites of a model in ONE launch (blockIdx.y = site): the per-site reductions are off the critical path of the
@@ -1015,8 +1061,9 @@ __global__ __launch_bounds__(1024) void slab_reduce_multi_kernel(RChunk c, int B
   float* ws = const_cast<float*>(c.slabs[s]);
   float* parts = ws + (size_t)c.n_slabs[s] * kSlab4Floats;
   unsigned* counter = reinterpret_cast<unsigned*>(parts + kPartFloats);
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kSlabReduceLds<true>];
   slab_reduce_body<true, true>(c.slabs[s], c.n_slabs[s], kSlab4Floats, 128, B, c.scale[s], c.out[s], c.A[s], c.gamma[s], dim, mu,
-                               rho, parts, counter, c.scal[s]);
+                               rho, parts, counter, c.scal[s], blockIdx.x, gridDim.x, lds);
 }
 
 // The B <= 64 geometries (full [BP][BP] slabs) for several batch slices of one site in ONE launch (blockIdx.y = group; the
@@ -1031,8 +1078,9 @@ __global__ __launch_bounds__(1024) void slab_reduce_groups_kernel(float* __restr
   float* ws = ws0 + gi * ws_gstride;
   float* parts = ws + (size_t)n_slabs * slab_floats;
   unsigned* counter = reinterpret_cast<unsigned*>(parts + kPartFloats);
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kSlabReduceLds<false>];
   slab_reduce_body<false, true>(ws, n_slabs, slab_floats, BP, B, scale, out + gi * B * B, A, gamma, dim, mu, rho, parts, counter,
-                                scal + gi * 4);
+                                scal + gi * 4, blockIdx.x, gridDim.x, lds);
 }
 
 // ================================================================================================ backward prep
@@ -1833,7 +1881,21 @@ __global__ __launch_bounds__(TFv * 8, 2) void site_bwd4_kernel(const float* __re
 }  // namespace
 
 int launch_partials4(bool pair, const Geom& g, const float* x, int B, int64_t F, int k, float r, float eps, float* xq,
-                     float* stats, float* ws, hipStream_t st, BnFold bn) {
+                     float* stats, float* ws, hipStream_t st, BnFold bn, const SiteFillArgs* fa) {
+  SFill fill{};
+  if (fa && fa->n > 0) {
+    // only the one-tile launches that leave half the chip idle take fillers; the caller asked alignq_site_fill_slots first
+    if (fa->n > kSiteFill || g.nb != 4 || g.n_tiles > g.grid || g.grid > 128) return ALIGNQ_EINVAL;
+    for (int i = 0; i < fa->n; i++) {
+      if (!fa->ws[i] || !fa->D[i] || !fa->A[i] || !fa->G[i] || !fa->scal[i] || fa->F[i] < 1) return ALIGNQ_EINVAL;
+      const Geom gi = geom(B, fa->F[i]);
+      if (gi.nb != 4) return ALIGNQ_EINVAL;
+      fill.slabs[i] = (const float*)fa->ws[i]; fill.out[i] = fa->D[i]; fill.A[i] = fa->A[i]; fill.gamma[i] = fa->G[i];
+      fill.scal[i] = fa->scal[i]; fill.scale[i] = 1.0f / (float)fa->F[i]; fill.n_slabs[i] = gi.grid;
+    }
+    fill.n = fa->n; fill.dim = fa->dim; fill.mu = fa->mu; fill.rho = fa->rho;
+  }
+  const int fgrid = g.grid + fill.n * kSlabRedBlocks;
   if ((int64_t)B * F * 4 >= ((int64_t)1 << 32)) return ALIGNQ_EUNSUPPORTED;   // 32-bit byte offsets (see ld4 / st4)
   const int aligned = ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
                       (!xq || (reinterpret_cast<uintptr_t>(xq) & 15) == 0);
@@ -1843,8 +1905,8 @@ int launch_partials4(bool pair, const Geom& g, const float* x, int B, int64_t F,
   // geom(): one tile per workgroup up to F = 16384; beyond that the 64-feature tile loop runs in up to 512 workgroups of 512
   // threads, two per CU, for the plain site; with the batch-norm fold (no configuration has one at such F) in 1024-thread ones
   const bool full64 = B == 128 && F % 64 == 0 && aligned;     // the 512-thread multi-tile form takes complete tiles only
-#define L4S(TFV, P, SG, NTV) hipLaunchKernelGGL((site_fwd4_kernel<TFV, P, SG, NTV>), g.grid, NTV, 0, st, x, B, F, k, r, eps, xq, ws, stats, g.n_tiles, aligned, counter, bn)
-#define L4F(TFV, P) hipLaunchKernelGGL((site_fwd4_kernel<TFV, P, true, NT, true>), g.grid, NT, 0, st, x, B, F, k, r, eps, xq, ws, stats, g.n_tiles, aligned, counter, bn)
+#define L4S(TFV, P, SG, NTV) hipLaunchKernelGGL((site_fwd4_kernel<TFV, P, SG, NTV>), (SG && NTV == NT) ? fgrid : g.grid, NTV, 0, st, x, B, F, k, r, eps, xq, ws, stats, g.n_tiles, aligned, counter, bn, fill)
+#define L4F(TFV, P) hipLaunchKernelGGL((site_fwd4_kernel<TFV, P, true, NT, true>), fgrid, NT, 0, st, x, B, F, k, r, eps, xq, ws, stats, g.n_tiles, aligned, counter, bn, fill)
 #define L4(TFV, P)                                                                                                       \
   do {                                                                                                                  \
     if (g.n_tiles <= g.grid) { if (B == 128 && F % TFV == 0 && aligned) L4F(TFV, P); else L4S(TFV, P, true, NT); }      \

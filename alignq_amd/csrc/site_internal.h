@@ -117,8 +117,25 @@ int launch_bwd1(bool pair, const float* gup, const float* S, const float* x, con
                 const float* ymask = nullptr, float* dres = nullptr, int groups = 1, int64_t s_gstride = 0);
 
 // ---- launchers defined in site4_kernels.hip ----------------------------------------------------------------
+// earlier sites whose slab reduction + ADMM loss ride in this forward launch as a filler role (site4_kernels.hip: SFill)
+struct SiteFillArgs {
+  int n;
+  void* const* ws;
+  float* const* D;
+  const float* const* A;
+  const float* const* G;
+  float* const* scal;
+  const int64_t* F;
+  int dim;
+  float mu, rho;
+};
+inline int site_fill_slots(int B, int64_t F) {       // fillers a forward launch at (B, F) takes: the launches that leave CUs idle
+  if (B <= 64 || B > 128 || F < 1) return 0;
+  const Geom g = geom(B, F);
+  return (g.nb == 4 && g.n_tiles <= g.grid && g.grid <= 128) ? 3 : 0;
+}
 int launch_partials4(bool pair, const Geom& g, const float* x, int B, int64_t F, int k, float r, float eps, float* xq,
-                     float* stats, float* ws, hipStream_t st, BnFold bn = no_bn());
+                     float* stats, float* ws, hipStream_t st, BnFold bn = no_bn(), const SiteFillArgs* fa = nullptr);
 int launch_bwd4(bool pair, const Geom& g, const float* gup, const float* S, const float* x, const float* stats, int B,
                 int64_t F, float r, float eps, float* dx, hipStream_t st, BnFold bn = no_bn());
 // S = sym(gD) * gscale / F (and, fused, the scaled ADMM parameter gradients) — first launch of every backward

@@ -593,7 +593,26 @@ int alignq_site_partials_bn(const float* z, const void* bn_part, const float* bn
                             float bn_eps, float* ab, float* save, int C, int HW, int B, int64_t F, int k, float act_range,
                             float eps, int relu, const float* residual, int nhwc, int conv_parts, float* xq, void* bins_out,
                             float* stats, void* ws, void* stream) {
+  return alignq_site_partials_bn_fill(z, bn_part, bn_gamma, bn_beta, running_mean, running_var, num_batches_tracked, momentum,
+                                      bn_eps, ab, save, C, HW, B, F, k, act_range, eps, relu, residual, nhwc, conv_parts, xq,
+                                      bins_out, stats, ws, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, 0.f,
+                                      stream);
+}
+
+int alignq_site_fill_slots(int B, int64_t F) { return site_fill_slots(B, F); }
+
+int alignq_site_partials_bn_fill(const float* z, const void* bn_part, const float* bn_gamma, const float* bn_beta,
+                                 float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                                 float bn_eps, float* ab, float* save, int C, int HW, int B, int64_t F, int k,
+                                 float act_range, float eps, int relu, const float* residual, int nhwc, int conv_parts,
+                                 float* xq, void* bins_out, float* stats, void* ws, int n_fill, void* const* fill_ws,
+                                 float* const* fill_D, const float* const* fill_alterD, const float* const* fill_gamma,
+                                 float* const* fill_scal, const int64_t* fill_F, int fill_dim, float fill_mu, float fill_rho,
+                                 void* stream) {
   if (!z || !ab || !save || !ws) return ALIGNQ_EINVAL;
+  if (n_fill < 0 || n_fill > site_fill_slots(B, F)) return ALIGNQ_EINVAL;
+  if (n_fill && (!fill_ws || !fill_D || !fill_alterD || !fill_gamma || !fill_scal || !fill_F || fill_dim < B)) return ALIGNQ_EINVAL;
+  const SiteFillArgs fa{n_fill, fill_ws, fill_D, fill_alterD, fill_gamma, fill_scal, fill_F, fill_dim, fill_mu, fill_rho};
   if (bad_k(k)) return ALIGNQ_EINVAL;
   if (!bn_shape_ok(B, F, C, HW, nhwc)) return ALIGNQ_EUNSUPPORTED;
   BnFold bn = no_bn();
@@ -610,7 +629,8 @@ int alignq_site_partials_bn(const float* z, const void* bn_part, const float* bn
     if (!nhwc || !bn_part) return ALIGNQ_EINVAL;
     bn.n_parts = conv_parts; bn.part_f32 = 1;
   }
-  return launch_partials4(true, geom(B, F), z, B, F, k, act_range, eps, xq, stats, (float*)ws, (hipStream_t)stream, bn);
+  return launch_partials4(true, geom(B, F), z, B, F, k, act_range, eps, xq, stats, (float*)ws, (hipStream_t)stream, bn,
+                          n_fill ? &fa : nullptr);
 }
 
 size_t alignq_site_bn_part_bytes(int64_t F, int nhwc) {

@@ -80,10 +80,11 @@ class SiteRecord:
     """Per-site bookkeeping of a batched (deferred) step: the site's forward only launches the partial-slab kernel and
     parks its buffers here; `DeferredLosses.total()` reduces all sites' slabs (+ ADMM loss) in one launch and its backward
     prepares all sites' S / dalterD / dgamma in one launch."""
-    __slots__ = ("ws", "D", "A", "Gm", "scal", "B", "F", "dim", "mu", "rho", "S", "dA", "dG", "prepared")
+    __slots__ = ("ws", "D", "A", "Gm", "scal", "B", "F", "dim", "mu", "rho", "S", "dA", "dG", "prepared", "reduced")
 
     def __init__(self):
         self.prepared = False
+        self.reduced = False        # True: a later site's forward launch took this site's reduction along (take_fill)
 
 
 class LossSumFn(torch.autograd.Function):
@@ -177,11 +178,33 @@ class DeferredLosses:
             g.setdefault((r.B, r.dim, r.mu, r.rho), []).append(r)
         return g
 
+    def take_fill(self, rec, B, F, dim, mu, rho):
+        """Earlier sites (same B, dim, mu, rho, not reduced yet) whose slab reduction + ADMM loss the forward launch of the site
+        `rec` at (B, F) takes along as its filler role (alignq_site_partials_bn_fill): only the one-tile launches that leave half
+        the chip idle have slots (alignq_site_fill_slots).  ALIGNQ_SITE_FILL=<n> caps the items per launch (0: none)."""
+        slots = min(_SITE_FILL, L.load().alignq_site_fill_slots(int(B), int(F)))
+        out = []
+        if slots > 0:
+            for r in self.records:
+                if r is rec or r.reduced or getattr(r, "ws", None) is None:
+                    continue
+                if (r.B, r.dim, r.mu, r.rho) != (B, dim, float(mu), float(rho)):
+                    continue
+                out.append(r)
+                if len(out) == slots:
+                    break
+        for r in out:
+            r.reduced = True
+        return out
+
     def reduce_all(self):
-        """Slab reduction + ADMM loss of every batched site (one launch per (B, dim, mu, rho) group)."""
+        """Slab reduction + ADMM loss of every batched site still open (one launch per (B, dim, mu, rho) group)."""
         lib = L.load()
         st = L.stream_ptr()
         for (B, dim, mu, rho), recs in self.groups().items():
+            recs = [r for r in recs if not r.reduced]
+            if not recs:
+                continue
             L.check(lib.alignq_site_reduce_loss_multi(
                 len(recs), L.ptr_array([r.ws for r in recs]), L.ptr_array([r.D for r in recs]),
                 L.ptr_array([r.A for r in recs]), L.ptr_array([r.Gm for r in recs]),
@@ -272,6 +295,7 @@ class DeferredWgrads:
 
 
 _active_wgrads = None
+_SITE_FILL = max(0, int(os.environ.get("ALIGNQ_SITE_FILL", "3")))
 _WGRAD_FILL = dict(zip((16, 32, 64), (min(4, max(0, int(v))) for v in os.environ.get("ALIGNQ_WGRAD_FILL", "2,2,0").split(","))))
 
 
@@ -381,11 +405,17 @@ class BNSiteFn(torch.autograd.Function):
         stats = torch.empty(4, F, dtype=torch.float32, device=dev)
         scal = rec.scal if rec is not None else torch.empty(4, dtype=torch.float32, device=dev)
         ws = torch.empty(lib.alignq_site_ws_bytes(B, F), dtype=torch.uint8, device=dev)
-        L.check(lib.alignq_site_partials_bn(L.ptr(z), L.ptr(ws_bn), L.ptr(bn_weight), L.ptr(bn_bias), L.ptr(running_mean),
-                                            L.ptr(running_var), L.ptr(nbt), float(momentum), float(bn_eps), L.ptr(ab),
-                                            L.ptr(save), C, HW, B, F, int(k), float(act_range), float(eps),
-                                            int(bool(relu)), L.ptr(res), int(nhwc), int(conv_parts), L.ptr(y), L.ptr(bins), L.ptr(stats), L.ptr(ws), st),
-                "alignq_site_partials_bn")
+        # filler role: earlier sites' slab reductions ride in this launch when it leaves CUs idle (DeferredLosses.take_fill)
+        fill = _active.take_fill(rec, B, F, dim, mu, rho) if (rec is not None and _active is not None) else []
+        nf = len(fill)
+        L.check(lib.alignq_site_partials_bn_fill(
+            L.ptr(z), L.ptr(ws_bn), L.ptr(bn_weight), L.ptr(bn_bias), L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt),
+            float(momentum), float(bn_eps), L.ptr(ab), L.ptr(save), C, HW, B, F, int(k), float(act_range), float(eps),
+            int(bool(relu)), L.ptr(res), int(nhwc), int(conv_parts), L.ptr(y), L.ptr(bins), L.ptr(stats), L.ptr(ws), nf,
+            L.ptr_array([r.ws for r in fill]) if nf else None, L.ptr_array([r.D for r in fill]) if nf else None,
+            L.ptr_array([r.A for r in fill]) if nf else None, L.ptr_array([r.Gm for r in fill]) if nf else None,
+            L.ptr_array([r.scal for r in fill]) if nf else None, L.i64_array([r.F for r in fill]) if nf else None,
+            dim, float(mu), float(rho), st), "alignq_site_partials_bn_fill")
         if rec is not None:      # reduced with all other sites in DeferredLosses.total()
             rec.ws, rec.D, rec.A, rec.Gm, rec.B, rec.F, rec.dim = ws, D, A, Gm, B, F, dim
             rec.mu, rec.rho = float(mu), float(rho)

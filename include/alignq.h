@@ -394,6 +394,20 @@ int alignq_site_partials_bn(const float* z, const void* bn_part, const float* bn
                             float bn_eps, float* ab, float* save, int C, int HW, int B, int64_t F, int k, float act_range,
                             float eps, int relu, const float* residual, int nhwc, int conv_parts, float* xq, void* bins_out,
                             float* stats, void* ws, void* stream);
+/* The same launch with a FILLER role (one-tile launches that leave CUs idle; alignq_site_fill_slots(B, F) says how many items
+ * this shape takes, 0 = none): workgroups behind the site's own tiles finish the slab reduction + ADMM loss of n_fill EARLIER
+ * sites of the step (arguments per item as alignq_site_reduce_loss_multi takes them; all items share this site's B and
+ * fill_dim / fill_mu / fill_rho).  Nothing reads a site's D or loss before the end of the forward; same code, same workgroup
+ * partition, same bits as alignq_site_reduce_loss[_multi].                                                              */
+int alignq_site_fill_slots(int B, int64_t F);
+int alignq_site_partials_bn_fill(const float* z, const void* bn_part, const float* bn_gamma, const float* bn_beta,
+                                 float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                                 float bn_eps, float* ab, float* save, int C, int HW, int B, int64_t F, int k,
+                                 float act_range, float eps, int relu, const float* residual, int nhwc, int conv_parts,
+                                 float* xq, void* bins_out, float* stats, void* ws, int n_fill, void* const* fill_ws,
+                                 float* const* fill_D, const float* const* fill_alterD, const float* const* fill_gamma,
+                                 float* const* fill_scal, const int64_t* fill_F, int fill_dim, float fill_mu, float fill_rho,
+                                 void* stream);
 /* bins_out (N2, optional; residual must be NULL, F % 4 == 0): the level index of the STORED value (idx, clamped at 0 when the
  * ReLU is fused) in alignq_bin_bytes(k, act_range, ALIGNQ_FORMULA_ADMM) bytes per element, same [B,F] order as xq; xq may then
  * be NULL: consumers that understand the index (alignq_conv3x3_nhwc x_bins, alignq_site_bwd_apply_bn y_bins) need no fp32 copy. */

@@ -581,3 +581,30 @@ def test_filter_gradient_reduction_as_a_filler_role_leaves_the_same_bits(dev, un
         fused._WGRAD_FILL = old
         config.args.bitW = config.args.abitW = 8
         config.args.train_batch_size = 128
+
+
+@pytest.mark.parametrize("units,k", [([3, 3, 3], 8), ([1, 2, 1], 4)])
+def test_site_slab_reduction_as_a_filler_role_leaves_the_same_bits(dev, units, k):
+    """alignq_site_partials_bn_fill: the slab reduction + ADMM loss of earlier sites ride in the forward launches of the later,
+    narrower sites (fused.DeferredLosses.take_fill).  D of every site, the loss total, the logits and every gradient of a
+    full-batch ResNet step must equal, bit for bit, the step that leaves all reductions to alignq_site_reduce_loss_multi."""
+    from alignq_amd import config, fused
+    from tests.test_gpu_bench_path import _run_model_step
+    old = fused._SITE_FILL
+    try:
+        fused._SITE_FILL = 0
+        a, _ = _run_model_step(dev, units, k, 128, deferred=True)
+        fused._SITE_FILL = 3
+        b, step_b = _run_model_step(dev, units, k, 128, deferred=True)
+        n_filled = sum(1 for r in step_b._deferred.records if r.reduced)
+        assert n_filled >= len(step_b._deferred.records) - 2 - units[0] * 2       # all but the last site(s) rode along
+        assert np.array_equal(a["logits"], b["logits"]) and a["ce"] == b["ce"] and a["tl"] == b["tl"]
+        for i, (da, db) in enumerate(zip(a["D"], b["D"])):
+            assert np.array_equal(da, db), f"site {i} D"
+        assert a["grads"].keys() == b["grads"].keys()
+        for n_ in a["grads"]:
+            assert np.array_equal(a["grads"][n_], b["grads"][n_]), n_
+    finally:
+        fused._SITE_FILL = old
+        config.args.bitW = config.args.abitW = 8
+        config.args.train_batch_size = 128
