@@ -109,6 +109,9 @@ SIGNATURES = {
     "alignq_site_prep_fused": (_i, [_vp, _vp, _vp, _i, _vp, _f, _vp, _i, _i64, _vp, _vp, _vp, _vp]),
     "alignq_site_bwd_apply_bn": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i64, _f, _f, _vp, _vp,
                                       _vp]),
+    "alignq_site_bwd_fill_slots": (_i, [_i, _i64]),
+    "alignq_site_bwd_apply_bn_fill": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i64, _f, _f, _vp,
+                                           _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "alignq_bn_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "alignq_weight_multi_ws_bytes": (_sz, [_i]),
     "alignq_weight_quant_fwd_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),

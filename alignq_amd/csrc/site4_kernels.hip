@@ -945,8 +945,8 @@ __device__ __forceinline__ void slab_reduce_body(const float* __restrict__ slabs
   if (any_ok) {
     if constexpr (SYM) {
 #pragma unroll 16
-      for (int sl = sg; sl < n_slabs; sl += 16) {
-        const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)sl * slab_floats);
+      for (int sl = sg; sl < n_slabs; sl += 16) {     // non-temporal: read once, and not to evict the host launch's operands
+        const f32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(p + (int64_t)sl * slab_floats));
         s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
       }
     } else {
@@ -1215,7 +1215,7 @@ template <int TFv, bool PAIR, bool BN, bool VEC, bool LOOP = false, bool FULLP =
 __global__ __launch_bounds__(TFv * 8, 2) void site_bwd4_kernel(const float* __restrict__ gup, const float* __restrict__ S,
                                                         const float* __restrict__ x, const float* __restrict__ stats,
                                                         int B, int64_t F, float r, float eps, float* __restrict__ dx,
-                                                        int n_tiles, int aligned, BnFold bn) {
+                                                        int n_tiles, int aligned, BnFold bn, alignq_wgr::RedFill fill) {
   BSTAMP(1, 0);
   (void)aligned;
   constexpr int LDv = TFv + 4, TILE = 128 * LDv;    // fp32 tiles: 16-byte aligned rows (copied out with 16-byte LDS reads)
@@ -1226,6 +1226,18 @@ __global__ __launch_bounds__(TFv * 8, 2) void site_bwd4_kernel(const float* __re
   constexpr int NT_ARR = PAIR ? 4 : 2;
   constexpr int NF_ARR = PAIR ? 2 : 1;
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[NT_ARR * TARR * 2 + NF_ARR * TILE * 4 + 4 * 2 * 2 * TFv * 4];
+  if constexpr (!LOOP && TFv == 32) {
+    // filler workgroups (block-uniform; the narrow sites' launches leave half the chip idle): filter-gradient slab reductions
+    // of convolutions whose backward already ran, see wgrad_reduce_body.h
+    if ((int)blockIdx.x >= n_tiles) {
+      const int fb = blockIdx.x - n_tiles;
+      int it = 0;
+      while (it + 1 < alignq_wgr::kFill && fb >= fill.blk0[it + 1]) it++;
+      alignq_wgr::wgrad_reduce_body<256>(fill.slabs[it], fill.n_slabs[it], fill.n_elem[it], fill.dw[it], fb - fill.blk0[it],
+                                         reinterpret_cast<float*>(lds_raw));
+      return;
+    }
+  }
   __bf16* XThi = reinterpret_cast<__bf16*>(lds_raw);
   __bf16* XTlo = XThi + TARR;
   __bf16* TThi = XThi + 2 * TARR;                    // (PAIR)
@@ -2021,12 +2033,18 @@ int launch_head_bwd_prep_multi(const float* g_ce, const float* probs, const int6
 }
 
 int launch_bwd4(bool pair, const Geom& g, const float* gup, const float* S, const float* x, const float* stats, int B,
-                int64_t F, float r, float eps, float* dx, hipStream_t st, BnFold bn) {
+                int64_t F, float r, float eps, float* dx, hipStream_t st, BnFold bn, const alignq_wgr::RedFill* fa) {
   (void)g;
+  alignq_wgr::RedFill fill{};
+  if (fa) fill = *fa;
   if ((int64_t)B * F * 4 >= ((int64_t)1 << 32)) return ALIGNQ_EUNSUPPORTED;   // 32-bit byte offsets inside a tile column
   const int tf = bwd_tile_features(B, F);
   const int n_tiles = (int)((F + tf - 1) / tf);
   int grid = n_tiles;                     // one tile per workgroup (the looped form below: one workgroup per CU)
+  if (fill.blk0[alignq_wgr::kFill] > 0) {
+    if (!bwd_fill_ok(B, F)) return ALIGNQ_EINVAL;      // only the 32-feature one-tile launches carry the filler role
+    grid += fill.blk0[alignq_wgr::kFill];
+  }
   const int aligned = 0;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   // 16-byte accesses need whole column quads and aligned rows (channels-last BN: C % 4 == 0 holds, C is a power of two >= 4)
@@ -2036,24 +2054,24 @@ int launch_bwd4(bool pair, const Geom& g, const float* gup, const float* S, cons
   do {                                                                                                                       \
     if (vec && B == 128 && F % TFV == 0)                                                                                     \
       hipLaunchKernelGGL((site_bwd4_kernel<TFV, P, N, true, false, true>), grid, TFV * 8, 0, st, gup, S, x, stats, B, F, r,  \
-                         eps, dx, n_tiles, aligned, bn);                                                                     \
+                         eps, dx, n_tiles, aligned, bn, fill);                                                                     \
     else if (vec) hipLaunchKernelGGL((site_bwd4_kernel<TFV, P, N, true>), grid, TFV * 8, 0, st, gup, S, x, stats, B, F, r, eps,   \
-                                dx, n_tiles, aligned, bn);                                                                   \
+                                dx, n_tiles, aligned, bn, fill);                                                                   \
     else hipLaunchKernelGGL((site_bwd4_kernel<TFV, P, N, false>), grid, TFV * 8, 0, st, gup, S, x, stats, B, F, r, eps, dx,  \
-                            n_tiles, aligned, bn);                                                                           \
+                            n_tiles, aligned, bn, fill);                                                                           \
   } while (0)
   static const int loop32 = [] { const char* e = getenv("ALIGNQ_BWD_LOOP32"); return e ? atoi(e) : 0; }();   // tuning aid
   if (loop32 && vec && !bn.ab && !bn.y && !bn.ybins && !bn.dres && F > 32768 && B == 128 && F % 32 == 0) {
     // experiment: 32-feature tiles, 256 threads, 70 KB of LDS: two (or loop32 / 256) looped workgroups per CU
     const int nt32 = (int)((F + 31) / 32);
     grid = loop32 >= 256 ? loop32 : 512;
-    if (pair) hipLaunchKernelGGL((site_bwd4_kernel<32, true, false, true, true>), grid, 256, 0, st, gup, S, x, stats, B, F, r, eps, dx, nt32, aligned, bn);
-    else hipLaunchKernelGGL((site_bwd4_kernel<32, false, false, true, true>), grid, 256, 0, st, gup, S, x, stats, B, F, r, eps, dx, nt32, aligned, bn);
+    if (pair) hipLaunchKernelGGL((site_bwd4_kernel<32, true, false, true, true>), grid, 256, 0, st, gup, S, x, stats, B, F, r, eps, dx, nt32, aligned, bn, fill);
+    else hipLaunchKernelGGL((site_bwd4_kernel<32, false, false, true, true>), grid, 256, 0, st, gup, S, x, stats, B, F, r, eps, dx, nt32, aligned, bn, fill);
   } else if (tf == 64 && vec && !bn.ab && !bn.y && !bn.ybins && !bn.dres && n_tiles > 2 * 256 && B == 128 && F % 64 == 0) {
     // plain site with many tiles per CU (F > 32768): the looped, software-pipelined form (138 KB of LDS: one workgroup per CU)
     grid = 256;
-    if (pair) hipLaunchKernelGGL((site_bwd4_kernel<64, true, false, true, true>), grid, 512, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_tiles, aligned, bn);
-    else hipLaunchKernelGGL((site_bwd4_kernel<64, false, false, true, true>), grid, 512, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_tiles, aligned, bn);
+    if (pair) hipLaunchKernelGGL((site_bwd4_kernel<64, true, false, true, true>), grid, 512, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_tiles, aligned, bn, fill);
+    else hipLaunchKernelGGL((site_bwd4_kernel<64, false, false, true, true>), grid, 512, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_tiles, aligned, bn, fill);
   } else if (tf == 64) {
     if (pair && bn.ab) LB(64, true, true); else if (pair) LB(64, true, false); else LB(64, false, false);
   } else {

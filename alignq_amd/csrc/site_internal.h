@@ -1,6 +1,7 @@
 // site_internal.h — geometry and launcher declarations shared by site_kernels.hip (generic B<=64 kernels,
 // C ABI) and site4_kernels.hip (the B in (64,128] kernels: 1024-thread workgroups, symmetric tiles).
 #pragma once
+#include "wgrad_reduce_body.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -58,6 +59,10 @@ inline int bwd_tile_features(int B, int64_t F) {
   if (forced == 32 || forced == 64) return forced;
   return F >= 16384 ? 64 : 32;
 }
+
+// the backward launches that carry a filler role (site4_kernels.hip: site_bwd4_kernel<32, ..>, one tile per workgroup, at most
+// 256 workgroups of 256 threads: half the chip's wave slots stay free)
+inline bool bwd_fill_ok(int B, int64_t F) { return B > 64 && B <= 128 && F >= 32 && bwd_tile_features(B, F) == 32 && F <= 8192; }
 
 struct Geom {
   int nb;           // 32-row blocks: 1, 2 (generic kernels) or 4 (site4 kernels)
@@ -137,7 +142,7 @@ inline int site_fill_slots(int B, int64_t F) {       // fillers a forward launch
 int launch_partials4(bool pair, const Geom& g, const float* x, int B, int64_t F, int k, float r, float eps, float* xq,
                      float* stats, float* ws, hipStream_t st, BnFold bn = no_bn(), const SiteFillArgs* fa = nullptr);
 int launch_bwd4(bool pair, const Geom& g, const float* gup, const float* S, const float* x, const float* stats, int B,
-                int64_t F, float r, float eps, float* dx, hipStream_t st, BnFold bn = no_bn());
+                int64_t F, float r, float eps, float* dx, hipStream_t st, BnFold bn = no_bn(), const alignq_wgr::RedFill* fill = nullptr);
 // S = sym(gD) * gscale / F (and, fused, the scaled ADMM parameter gradients) — first launch of every backward
 int launch_prep(bool fused, const float* dD, const float* D, const float* alterD, const float* gamma, int dim,
                 const float* scal, float mu, const float* gscale, int B, int64_t F, float* S, float* dA_out,

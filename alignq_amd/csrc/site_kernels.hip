@@ -641,13 +641,34 @@ int alignq_site_bwd_apply_bn(const float* g, const float* S, const float* z, con
                              int HW, int nhwc, const float* y_relu, const void* y_bins, int y_bin_bytes, float* dresidual,
                              const float* stats, int B, int64_t F, float act_range, float eps, float* dx, float* dx_part,
                              void* stream) {
+  return alignq_site_bwd_apply_bn_fill(g, S, z, ab, save, C, HW, nhwc, y_relu, y_bins, y_bin_bytes, dresidual, stats, B, F,
+                                       act_range, eps, dx, dx_part, 0, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+int alignq_site_bwd_fill_slots(int B, int64_t F) { return bwd_fill_ok(B, F) ? alignq_wgr::kFill : 0; }
+
+int alignq_site_bwd_apply_bn_fill(const float* g, const float* S, const float* z, const float* ab, const float* save, int C,
+                                  int HW, int nhwc, const float* y_relu, const void* y_bins, int y_bin_bytes,
+                                  float* dresidual, const float* stats, int B, int64_t F, float act_range, float eps,
+                                  float* dx, float* dx_part, int n_fill, const void* const* fill_ws, float* const* fill_dw,
+                                  const int* fill_n_slabs, const int* fill_n_elem, void* stream) {
   if (!S || !z || !ab || !save || !stats || !dx || !dx_part) return ALIGNQ_EINVAL;
+  if (n_fill < 0 || n_fill > alignq_site_bwd_fill_slots(B, F)) return ALIGNQ_EINVAL;
+  if (n_fill && (!fill_ws || !fill_dw || !fill_n_slabs || !fill_n_elem)) return ALIGNQ_EINVAL;
+  alignq_wgr::RedFill fill{};
+  for (int i = 0; i < n_fill; i++) {
+    if (!fill_ws[i] || !fill_dw[i] || fill_n_slabs[i] < 1 || fill_n_elem[i] < 1) return ALIGNQ_EINVAL;
+    fill.slabs[i] = (const float*)fill_ws[i]; fill.dw[i] = fill_dw[i]; fill.n_slabs[i] = fill_n_slabs[i];
+    fill.n_elem[i] = fill_n_elem[i];
+    fill.blk0[i + 1] = fill.blk0[i] + alignq_wgr::wgrad_reduce_blocks(fill_n_slabs[i], fill_n_elem[i], 256);
+  }
+  for (int i = n_fill; i < alignq_wgr::kFill; i++) fill.blk0[i + 1] = fill.blk0[i];
   if (y_bins && (y_relu || (y_bin_bytes != 1 && y_bin_bytes != 2))) return ALIGNQ_EINVAL;
   if (!bn_shape_ok(B, F, C, HW, nhwc)) return ALIGNQ_EUNSUPPORTED;
   BnFold bn = no_bn();
   bn.ab = ab; bn.save = save; bn.HW = HW; bn.C = C; bn.nhwc = nhwc;
   bn.dx_part = dx_part; bn.y = y_relu; bn.dres = dresidual; bn.ybins = y_bins; bn.bin_bytes = y_bin_bytes;
-  return launch_bwd4(true, geom(B, F), g, S, z, stats, B, F, act_range, eps, dx, (hipStream_t)stream, bn);
+  return launch_bwd4(true, geom(B, F), g, S, z, stats, B, F, act_range, eps, dx, (hipStream_t)stream, bn, n_fill ? &fill : nullptr);
 }
 
 int alignq_site_prep_fused(const float* D, const float* alterD, const float* gamma, int dim, const float* scal, float mu,

@@ -12,6 +12,7 @@
 """
 from __future__ import annotations
 
+import ctypes
 import os
 
 import torch
@@ -282,10 +283,16 @@ class DeferredWgrads:
         out, self.items = self.items[:most], self.items[most:]
         return out
 
+    def take_site(self, B, F):
+        """The same for a site's backward launch (alignq_site_bwd_apply_bn_fill): the narrow sites (F <= 8192) fill half the
+        chip, the reductions run beside them for nothing.  ALIGNQ_WGRAD_FILL_SITE=<n>: items per launch (0: none)."""
+        most = min(_WGRAD_FILL_SITE, L.load().alignq_site_bwd_fill_slots(int(B), int(F)))
+        out, self.items = self.items[:most], self.items[most:]
+        return out
+
     def flush(self):
         if not self.items:
             return
-        import ctypes
         T = len(self.items)
         L.check(L.load().alignq_conv3x3_wgrad_reduce_multi(
             T, L.ptr_array([i[0] for i in self.items]), L.ptr_array([i[1] for i in self.items]),
@@ -296,7 +303,8 @@ class DeferredWgrads:
 
 _active_wgrads = None
 _SITE_FILL = max(0, int(os.environ.get("ALIGNQ_SITE_FILL", "3")))
-_WGRAD_FILL = dict(zip((16, 32, 64), (min(4, max(0, int(v))) for v in os.environ.get("ALIGNQ_WGRAD_FILL", "2,2,0").split(","))))
+_WGRAD_FILL_SITE = max(0, int(os.environ.get("ALIGNQ_WGRAD_FILL_SITE", "2")))
+_WGRAD_FILL = dict(zip((16, 32, 64), (min(4, max(0, int(v))) for v in os.environ.get("ALIGNQ_WGRAD_FILL", "2,0,0").split(","))))
 
 
 def active_wgrads():
@@ -467,10 +475,15 @@ class BNSiteFn(torch.autograd.Function):
         dres = None
         if has_res and g_y is not None:
             dres = torch.empty_like(z) if y is not None else g_y
-        L.check(lib.alignq_site_bwd_apply_bn(L.ptr(g_y), L.ptr(S), L.ptr(z), L.ptr(ab), L.ptr(save), C, HW, nhwc, L.ptr(y),
-                                             L.ptr(ybins), ybins.element_size() if ybins is not None else 0,
-                                             L.ptr(dres) if y is not None else None, L.ptr(stats), B, F, act_range, eps,
-                                             L.ptr(dx), L.ptr(part), st), "alignq_site_bwd_apply_bn")
+        # filler role: the narrow sites' launches take pending filter-gradient slab reductions along (DeferredWgrads.take_site)
+        fill = active_wgrads().take_site(B, F) if active_wgrads() is not None else []
+        nf = len(fill)
+        L.check(lib.alignq_site_bwd_apply_bn_fill(
+            L.ptr(g_y), L.ptr(S), L.ptr(z), L.ptr(ab), L.ptr(save), C, HW, nhwc, L.ptr(y), L.ptr(ybins),
+            ybins.element_size() if ybins is not None else 0, L.ptr(dres) if y is not None else None, L.ptr(stats), B, F,
+            act_range, eps, L.ptr(dx), L.ptr(part), nf, L.ptr_array([f[0] for f in fill]) if nf else None,
+            L.ptr_array([f[1] for f in fill]) if nf else None, (ctypes.c_int * nf)(*[f[2] for f in fill]) if nf else None,
+            (ctypes.c_int * nf)(*[f[3] for f in fill]) if nf else None, st), "alignq_site_bwd_apply_bn_fill")
         dgam = torch.empty(C, dtype=torch.float32, device=dev) if has_w else None
         dbet = torch.empty(C, dtype=torch.float32, device=dev) if has_b else None
         # the in-kernel form fills dgam / dbet AFTER autograd has adopted them as .grad: only valid while both .grad are

@@ -419,6 +419,15 @@ int alignq_site_bwd_apply_bn(const float* g, const float* S, const float* z, con
                              int HW, int nhwc, const float* y_relu, const void* y_bins, int y_bin_bytes, float* dresidual,
                              const float* stats, int B, int64_t F, float act_range, float eps, float* dx, float* dx_part,
                              void* stream);     /* y_bins (N2): the ReLU mask from the forward's level index (idx > 0) instead of y_relu */
+/* alignq_site_bwd_apply_bn with a FILLER role (the narrow sites' launches, F <= 8192, fill half the chip; alignq_site_bwd_fill_slots
+ * says how many items a shape takes, 0 = none): filter-gradient slab reductions of convolutions whose backward already ran, items
+ * as in alignq_conv3x3_nhwc_bwd_fill.  Bit-identical to alignq_conv3x3_wgrad_reduce_multi.                                  */
+int alignq_site_bwd_fill_slots(int B, int64_t F);
+int alignq_site_bwd_apply_bn_fill(const float* g, const float* S, const float* z, const float* ab, const float* save, int C,
+                                  int HW, int nhwc, const float* y_relu, const void* y_bins, int y_bin_bytes,
+                                  float* dresidual, const float* stats, int B, int64_t F, float act_range, float eps,
+                                  float* dx, float* dx_part, int n_fill, const void* const* fill_ws, float* const* fill_dw,
+                                  const int* fill_n_slabs, const int* fill_n_elem, void* stream);
 int alignq_bn_bwd_apply(const float* dx, const float* z, const float* ab, const float* save, const float* dx_part, int B,
                         int C, int HW, int nhwc, float* dz, float* dgamma, float* dbeta, void* stream);
 /* Channels-last (torch.channels_last, memory [B,H,W,C]) form of the fold, nhwc = 1 above: channel = f mod C with C a power

@@ -551,34 +551,41 @@ def test_sgd_and_admm_update_in_one_launch_equal_the_two_steps(dev, b, n_par, n_
 
 @pytest.mark.parametrize("units,k", [([3, 3, 3], 8), ([2, 1, 2], 4)])
 def test_filter_gradient_reduction_as_a_filler_role_leaves_the_same_bits(dev, units, k):
-    """alignq_conv3x3_nhwc_bwd_fill: the slab reductions of earlier convolutions ride in the following convolutions' backward
-    launches (fused.DeferredWgrads.take); every parameter gradient of a full-batch ResNet step must equal, bit for bit, the step
-    that leaves all reductions to the closing alignq_conv3x3_wgrad_reduce_multi."""
+    """alignq_conv3x3_nhwc_bwd_fill / alignq_site_bwd_apply_bn_fill: the slab reductions of earlier convolutions ride in the
+    following convolutions' and narrow sites' backward launches (fused.DeferredWgrads.take / take_site); every parameter
+    gradient of a full-batch ResNet step must equal, bit for bit, the step that leaves all reductions to the closing
+    alignq_conv3x3_wgrad_reduce_multi."""
     from alignq_amd import config, fused
     from tests.test_gpu_bench_path import _run_model_step
-    old = fused._WGRAD_FILL
+    old = fused._WGRAD_FILL, fused._WGRAD_FILL_SITE
     try:
-        fused._WGRAD_FILL = {}
+        fused._WGRAD_FILL, fused._WGRAD_FILL_SITE = {}, 0
         a, _ = _run_model_step(dev, units, k, 128, deferred=True)
-        fused._WGRAD_FILL = {16: 4, 32: 1, 64: 2}
-        taken = []
-        orig = fused.DeferredWgrads.take
+        for conv_fill, site_fill in (({16: 4, 32: 1, 64: 2}, 0), ({16: 2}, 2), ({}, 4)):
+            fused._WGRAD_FILL, fused._WGRAD_FILL_SITE = conv_fill, site_fill
+            taken = []
+            orig, orig_s = fused.DeferredWgrads.take, fused.DeferredWgrads.take_site
 
-        def spy(self, C):
-            out = orig(self, C)
-            taken.append(len(out))
-            return out
-        fused.DeferredWgrads.take = spy
-        try:
-            b, _ = _run_model_step(dev, units, k, 128, deferred=True)
-        finally:
-            fused.DeferredWgrads.take = orig
-        assert sum(taken) >= sum(units) and max(taken) == 4        # the filler role really ran, with four items at least once
-        assert a["grads"].keys() == b["grads"].keys()
-        for n_ in a["grads"]:
-            assert np.array_equal(a["grads"][n_], b["grads"][n_]), n_
+            def spy(self, C):
+                out = orig(self, C)
+                taken.append(len(out))
+                return out
+
+            def spy_s(self, B, F):
+                out = orig_s(self, B, F)
+                taken.append(len(out))
+                return out
+            fused.DeferredWgrads.take, fused.DeferredWgrads.take_site = spy, spy_s
+            try:
+                b, _ = _run_model_step(dev, units, k, 128, deferred=True)
+            finally:
+                fused.DeferredWgrads.take, fused.DeferredWgrads.take_site = orig, orig_s
+            assert sum(taken) >= sum(units[1:]) and max(taken) >= 2     # the filler roles really ran, several items at once
+            assert a["grads"].keys() == b["grads"].keys()
+            for n_ in a["grads"]:
+                assert np.array_equal(a["grads"][n_], b["grads"][n_]), (n_, conv_fill, site_fill)
     finally:
-        fused._WGRAD_FILL = old
+        fused._WGRAD_FILL, fused._WGRAD_FILL_SITE = old
         config.args.bitW = config.args.abitW = 8
         config.args.train_batch_size = 128
 
