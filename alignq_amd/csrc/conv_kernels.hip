@@ -1201,7 +1201,8 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ x, const fl
           float v = acc[t][e];
 #pragma unroll
           for (int w2 = 0; w2 < 3; w2++) v += red[((w2 * NT + t) * 4 + e) * 64 + lane];
-          slab[((int64_t)(bi * CB + 4 * (lane >> 4) + e) * NT + t) * CIN + bj * CB + (lane & 15)] = v;
+          // non-temporal: the slab is read once, launches later; it must not displace dx (the next launch's operand) from the caches
+          __builtin_nontemporal_store(v, &slab[((int64_t)(bi * CB + 4 * (lane >> 4) + e) * NT + t) * CIN + bj * CB + (lane & 15)]);
         }
       }
     }
@@ -1210,7 +1211,7 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ x, const fl
     for (int t = 0; t < NT; t++)
 #pragma unroll
       for (int e = 0; e < 4; e++)
-        slab[((int64_t)(bi * CB + cob * 16 + 4 * (lane >> 4) + e) * NT + t) * CIN + bj * CB + cib * 16 + (lane & 15)] = acc[t][e];
+        __builtin_nontemporal_store(acc[t][e], &slab[((int64_t)(bi * CB + cob * 16 + 4 * (lane >> 4) + e) * NT + t) * CIN + bj * CB + cib * 16 + (lane & 15)]);
   }
 }
 
