@@ -264,7 +264,10 @@ __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restri
   // row / column masks, no selects behind the loads (54 -> vector instructions per element counted in the masks' favour: the
   // kernel runs at 62 % VALUBusy at [128, 524288])
   constexpr bool kPlain = !SINGLE && NTv == 512;     // no shortcut / ReLU / index / batch-norm paths at all
-  constexpr bool kFull = FULLP || kPlain;            // complete tiles: no masks (FULLP: the launcher's promise for the one-tile forms)
+  // complete tiles: no masks (FULLP: the launcher's promise for the one-tile forms).  A complete tile has 128 rows: with 16-feature
+  // tiles the 1024 threads form 256 row groups, half of them beyond the batch, so that geometry (ALIGNQ_FWD_WIDE=0 reaches it) keeps
+  // the row mask whatever the launcher promised
+  constexpr bool kFull = (FULLP && RG <= 128) || kPlain;
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STAGE_BYTES + (4 * TFv + 2 * NW * TFv) * 4];
   __shared__ __attribute__((aligned(16))) float nerf_lds[PAIR ? ALIGNQ_NERF_LDS_FLOATS : 4];
   if constexpr (SINGLE && NTv == 1024) {
@@ -1921,7 +1924,7 @@ int launch_partials4(bool pair, const Geom& g, const float* x, int B, int64_t F,
 #define L4F(TFV, P) hipLaunchKernelGGL((site_fwd4_kernel<TFV, P, true, NT, true>), fgrid, NT, 0, st, x, B, F, k, r, eps, xq, ws, stats, g.n_tiles, aligned, counter, bn, fill)
 #define L4(TFV, P)                                                                                                       \
   do {                                                                                                                  \
-    if (g.n_tiles <= g.grid) { if (B == 128 && F % TFV == 0 && aligned) L4F(TFV, P); else L4S(TFV, P, true, NT); }      \
+    if (g.n_tiles <= g.grid) { if (TFV >= 32 && B == 128 && F % TFV == 0 && aligned) L4F(TFV, P); else L4S(TFV, P, true, NT); } \
     else if (TFV == 64) { if (bn.ab || bn.res || bn.relu || bn.bins || !full64) L4S(64, P, false, NT); else L4S(64, P, false, 512); } \
     else return ALIGNQ_EINVAL;                                                                                          \
   } while (0)

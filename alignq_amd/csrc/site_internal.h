@@ -82,7 +82,10 @@ inline Geom geom(int B, int64_t F) {
     // box) because half as many partial-Gram slabs are written and reduced (118 instead of 173 MB per ResNet-20 step), which
     // outweighs the longer per-tile chain of the forward launches; ALIGNQ_FWD_WIDE=0 restores the 256-workgroup rule
     static const int wide = [] { const char* e = getenv("ALIGNQ_FWD_WIDE"); return e ? atoi(e) : 1; }();
-    if (wide && F <= 32 * 256) g.tf = (F > 16 * 256) ? 64 : 32;
+    if (wide == 1 && F <= 32 * 256) g.tf = (F > 16 * 256) ? 64 : 32;
+    // (=2: wide tiles at F <= 4096 only, i.e. 256 workgroups at F = 8192 and the fillers left to the seven F = 4096 launches:
+    //  1.056 / 1.057 ms against 1.040 with =1 once the reductions ride in the narrow launches)
+    if (wide == 2 && F <= 16 * 256) g.tf = 32;
     // beyond one 64-feature tile per CU the kernel loops over tiles: two 512-thread workgroups per CU (80 KB of LDS each)
     // (32-feature tiles were tried for this form: 128-byte row segments copy at 4.7-5.3 TB/s against 5.9-6.3 for 256-byte
     // ones, tools/src/stream_bw.hip, and the kernel ran 203 us against 186 at [128, 524288])
