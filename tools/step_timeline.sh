@@ -12,10 +12,11 @@ rows.sort()
 # the replays are the tail of the trace: find the period p such that names repeat with lag p over the last 20 periods
 names = [r[2] for r in rows]
 best = off = None
-for p_ in range(60, 140):                      # the trace ends with a few kernels of bench.py's epilogue: try small offsets
+import os
+for p_ in range(int(os.environ.get('PMIN', '60')), int(os.environ.get('PMAX', '140'))):                      # the trace ends with a few kernels of bench.py's epilogue: try small offsets
     for o in range(0, 40):
         end = len(names) - o
-        if end > 21 * p_ and all(names[end - 1 - i] == names[end - 1 - i - p_] for i in range(10 * p_)):
+        if end > (int(os.environ.get('REPS', '40')) + 1) * p_ and all(names[end - 1 - i] == names[end - 1 - i - p_] for i in range(3 * p_)):
             best, off = p_, o
             break
     if best:
@@ -23,7 +24,7 @@ for p_ in range(60, 140):                      # the trace ends with a few kerne
 assert best, 'no period found'
 rows = rows[:len(rows) - off]
 p = best
-reps = 40
+reps = int(os.environ.get('REPS', '40'))
 tail = rows[-reps * p:]
 # rotate so that a period starts after the largest gap (the step boundary)
 gaps0 = [tail[i + 1][0] - tail[i][1] for i in range(p)]
