@@ -7,6 +7,7 @@
 // consumer kernel re-reduces the <= ALIGNQ_WS_BLOCKS partials), so results do not depend on
 // scheduling and need no atomics.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "../../include/alignq.h"
 #include "alignq_math.h"
@@ -27,6 +28,18 @@ constexpr int kUb = 2;                // ... backward: two or three input stream
 // 64 blocks per CU: 6.7 TB/s with the NERF32 arithmetic in the loop against 5.3 TB/s for the grid-stride form this file had
 // (hipMemcpy device-to-device on the same box: 5.26 TB/s).  nt on loads AND stores is slower (6.1), nt stores alone equal.
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+// output store: plain (the consumer may find the lines in the caches) or, for tensors far beyond the caches (`nts`: the launcher's
+// choice, >= 2^25 elements), non-temporal - on cold operands loads AND stores marked as streams copy at 6.0 TB/s against 5.7-5.8
+// for either alone (tools/src/stream_bw.hip with STREAM_BW_SETS=4)
+__device__ __forceinline__ void st4_out(float4* p, const float4 v, const int nts) {
+  if (nts) {
+    typedef float f32x4_s __attribute__((ext_vector_type(4)));
+    f32x4_s t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x4_s*>(p));
+  } else {
+    *p = v;
+  }
+}
 __device__ __forceinline__ float4 ld4_stream(const float4* p) {
   const f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p));
   return make_float4(v.x, v.y, v.z, v.w);
@@ -50,7 +63,7 @@ template <int FORMULA, bool BINS, bool RELU = false>
 __global__ __launch_bounds__(kThreads) void act_quant_fwd_kernel(const float* __restrict__ x,
                                                                  float* __restrict__ xq,
                                                                  int32_t* __restrict__ bins, int64_t n,
-                                                                 int k, float r) {
+                                                                 int k, float r, int nts) {
   __shared__ __attribute__((aligned(16))) float tab_lds[ALIGNQ_NERF_LDS_FLOATS];
   nerf_tab_load(tab_lds);
   __syncthreads();
@@ -80,7 +93,7 @@ _Pragma("unroll")
       o.w = act_quant1<FORMULA, kBounded>(v[u].w, k, nlev, r, &t, &b3, tab);
       if (RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
       if (i < nvec) {
-        q4[i] = o;
+        st4_out(q4 + i, o, nts);
         if (BINS) {
           int4 bi = make_int4((int)b0, (int)b1, (int)b2, (int)b3);
           reinterpret_cast<int4*>(bins)[i] = bi;
@@ -114,7 +127,7 @@ template <bool MASK>
 __global__ __launch_bounds__(kThreads) void act_quant_bwd_kernel(const float* __restrict__ g,
                                                                  const float* __restrict__ x,
                                                                  const float* __restrict__ y,
-                                                                 float* __restrict__ dx, int64_t n, float r) {
+                                                                 float* __restrict__ dx, int64_t n, float r, int nts) {
   const int64_t nvec = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * kThreads;
   const float4* g4 = reinterpret_cast<const float4*>(g);
@@ -141,7 +154,7 @@ __global__ __launch_bounds__(kThreads) void act_quant_bwd_kernel(const float* __
       o.y = gv[u].y * act_jac(xv[u].y, r);
       o.z = gv[u].z * act_jac(xv[u].z, r);
       o.w = gv[u].w * act_jac(xv[u].w, r);
-      if (i < nvec) d4[i] = o;
+      if (i < nvec) st4_out(d4 + i, o, nts);
     }
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
@@ -500,6 +513,13 @@ inline int ws_blocks(int64_t n) {
     if (e__ != hipSuccess) return (int)e__;     \
   } while (0)
 
+// tensors of 2^25 elements (128 MB) and more are beyond the caches whatever comes next: their outputs are stored as streams
+// (ALIGNQ_AQ_NTS=0 / 1 forces the choice: tuning aid)
+static inline int stream_out(int64_t n) {
+  static const int forced = [] { const char* e = getenv("ALIGNQ_AQ_NTS"); return e ? atoi(e) : -1; }();
+  return forced >= 0 ? forced : (n >= ((int64_t)1 << 25) ? 1 : 0);
+}
+
 extern "C" {
 
 int alignq_act_quant_fwd(const float* x, float* xq, int32_t* bins, int64_t n, int k, float act_range,
@@ -512,11 +532,11 @@ int alignq_act_quant_fwd(const float* x, float* xq, int32_t* bins, int64_t n, in
   hipStream_t st = (hipStream_t)stream;
   int grid = grid_tiles(n >> 2, kU);
   if (formula == ALIGNQ_FORMULA_ADMM) {
-    if (bins) hipLaunchKernelGGL((act_quant_fwd_kernel<0, true>), grid, kThreads, 0, st, x, xq, bins, n, k, act_range);
-    else hipLaunchKernelGGL((act_quant_fwd_kernel<0, false>), grid, kThreads, 0, st, x, xq, bins, n, k, act_range);
+    if (bins) hipLaunchKernelGGL((act_quant_fwd_kernel<0, true>), grid, kThreads, 0, st, x, xq, bins, n, k, act_range, stream_out(n));
+    else hipLaunchKernelGGL((act_quant_fwd_kernel<0, false>), grid, kThreads, 0, st, x, xq, bins, n, k, act_range, stream_out(n));
   } else {
-    if (bins) hipLaunchKernelGGL((act_quant_fwd_kernel<1, true>), grid, kThreads, 0, st, x, xq, bins, n, k, act_range);
-    else hipLaunchKernelGGL((act_quant_fwd_kernel<1, false>), grid, kThreads, 0, st, x, xq, bins, n, k, act_range);
+    if (bins) hipLaunchKernelGGL((act_quant_fwd_kernel<1, true>), grid, kThreads, 0, st, x, xq, bins, n, k, act_range, stream_out(n));
+    else hipLaunchKernelGGL((act_quant_fwd_kernel<1, false>), grid, kThreads, 0, st, x, xq, bins, n, k, act_range, stream_out(n));
   }
   LAUNCH_CHECK();
   return 0;
@@ -534,7 +554,7 @@ int alignq_act_quant_bwd(const float* g, const float* x, float* dx, int64_t n, f
   if (!g || !x || !dx || n <= 0) return ALIGNQ_EINVAL;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(dx)) & 15)
     return ALIGNQ_EINVAL;
-  hipLaunchKernelGGL(act_quant_bwd_kernel<false>, grid_tiles(n >> 2, kUb), kThreads, 0, (hipStream_t)stream, g, x, nullptr, dx, n, act_range);
+  hipLaunchKernelGGL(act_quant_bwd_kernel<false>, grid_tiles(n >> 2, kUb), kThreads, 0, (hipStream_t)stream, g, x, nullptr, dx, n, act_range, stream_out(n));
   LAUNCH_CHECK();
   return 0;
 }
@@ -547,9 +567,9 @@ int alignq_act_quant_relu_fwd(const float* x, float* y, int64_t n, int k, float 
   hipStream_t st = (hipStream_t)stream;
   const int grid = grid_tiles(n >> 2, kU);
   if (formula == ALIGNQ_FORMULA_ADMM)
-    hipLaunchKernelGGL((act_quant_fwd_kernel<0, false, true>), grid, kThreads, 0, st, x, y, nullptr, n, k, act_range);
+    hipLaunchKernelGGL((act_quant_fwd_kernel<0, false, true>), grid, kThreads, 0, st, x, y, nullptr, n, k, act_range, stream_out(n));
   else
-    hipLaunchKernelGGL((act_quant_fwd_kernel<1, false, true>), grid, kThreads, 0, st, x, y, nullptr, n, k, act_range);
+    hipLaunchKernelGGL((act_quant_fwd_kernel<1, false, true>), grid, kThreads, 0, st, x, y, nullptr, n, k, act_range, stream_out(n));
   LAUNCH_CHECK();
   return 0;
 }
@@ -560,7 +580,7 @@ int alignq_act_quant_relu_bwd(const float* g, const float* x, const float* y, fl
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(dx) |
        reinterpret_cast<uintptr_t>(y)) & 15)
     return ALIGNQ_EINVAL;
-  hipLaunchKernelGGL(act_quant_bwd_kernel<true>, grid_tiles(n >> 2, kUb), kThreads, 0, (hipStream_t)stream, g, x, y, dx, n, act_range);
+  hipLaunchKernelGGL(act_quant_bwd_kernel<true>, grid_tiles(n >> 2, kUb), kThreads, 0, (hipStream_t)stream, g, x, y, dx, n, act_range, stream_out(n));
   LAUNCH_CHECK();
   return 0;
 }

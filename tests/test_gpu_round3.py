@@ -631,3 +631,19 @@ def test_narrow_tile_geometry_switch_runs_the_masked_kernels(dev):
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+def test_plain_quantiser_with_streamed_outputs_vs_oracle(dev):
+    """From 2^25 elements on the plain quantiser stores its outputs non-temporally (quant_kernels.hip: stream_out); the whole
+    33.5 M-element result, ragged tail included, against the C oracle: forward bit for bit, backward to 1e-5."""
+    from alignq_amd import ops
+    n = (1 << 25) + 5
+    rng = np.random.default_rng(77)
+    x = (rng.standard_normal(n) * 1.3).astype(np.float32)
+    g = rng.standard_normal(n).astype(np.float32)
+    xt = cu(x, dev).requires_grad_(True)
+    y = ops.ActQuantFn.apply(xt, 8, 2.0, 0)
+    y.backward(cu(g, dev))
+    oq, _, _ = O.act_quant_fwd(x, 8, 2.0, 0)
+    assert bits_equal(npy(y), oq)
+    np.testing.assert_allclose(npy(xt.grad), O.act_quant_bwd(g, x, 2.0), rtol=1e-5, atol=1e-6)

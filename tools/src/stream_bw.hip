@@ -110,6 +110,11 @@ void run_site(int grid) {
 
 float *dx, *dy;
 static const long N = 1L << 26;
+// STREAM_BW_SETS=<n>: rotate inputs and outputs over n buffer pairs (cold operands: with one pair, part of the re-read input is
+// served by the 256 MB memory-side cache for non-temporal readers)
+static int g_sets = 1;
+static float* g_xs[8];
+static float* g_ys[8];
 
 template <int NT, int U, int MODE, bool NTL, bool NTS, bool MATH>
 void run(int blocks_per_cu) {
@@ -121,7 +126,7 @@ void run(int blocks_per_cu) {
   std::vector<float> ms;
   for (int it = 0; it < 12; it++) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL((k<NT, U, MODE, NTL, NTS, MATH>), grid, NT, 0, 0, (const float4*)dx, (float4*)dy, nvec, 8, 2.0f);
+    hipLaunchKernelGGL((k<NT, U, MODE, NTL, NTS, MATH>), grid, NT, 0, 0, (const float4*)g_xs[it % g_sets], (float4*)g_ys[it % g_sets], nvec, 8, 2.0f);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float t; hipEventElapsedTime(&t, e0, e1);
@@ -156,6 +161,12 @@ int main() {
   }
   hipMemcpy(dx, h.data(), N * 4, hipMemcpyHostToDevice);
   hipMemcpy(dy, dx, N * 4, hipMemcpyDeviceToDevice);
+  if (const char* e = getenv("STREAM_BW_SETS")) g_sets = std::max(1, std::min(8, atoi(e)));
+  g_xs[0] = dx; g_ys[0] = dy;
+  for (int i = 1; i < g_sets; i++) {
+    hipMalloc(&g_xs[i], N * 4); hipMalloc(&g_ys[i], N * 4);
+    hipMemcpy(g_xs[i], dx, N * 4, hipMemcpyDeviceToDevice);
+  }
   hipDeviceSynchronize();
   {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -166,11 +177,12 @@ int main() {
     }
   }
   printf("---- the site kernels' [128, F] column-tile pattern as a pure copy\n");
-  for (int grid : {256, 512, 1024, 8192}) {
+  if (!getenv("STREAM_BW_NO_SITE")) for (int grid : {256, 512, 1024, 8192}) {
     run_site<1024, 64, false>(grid); run_site<1024, 64, true>(grid); run_site<1024, 128, true>(grid);
     run_site<512, 32, true>(grid); run_site<512, 64, true>(grid); run_site<256, 64, true>(grid); run_site<1024, 32, true>(grid);
   }
   if (getenv("STREAM_BW_SITE_ONLY")) return 0;
+  printf("---- operand sets: %d\n", g_sets);
   printf("---- pure copy\n");
   sweep<false>();
   printf("---- copy + NERF32 quantiser (k=8, r=2)\n");
