@@ -85,6 +85,24 @@ def time_call(fn, reps, warm=3):
     return e0.elapsed_time(e1) * 1e-3 / reps
 
 
+def time_call_serial(fn, reps, warm=2):
+    """Median duration (s) of fn() with every launch bracketed by its own event pair and a synchronisation: the conditions of a
+    rocprofv3 --kernel-trace run (no launch follows another back to back)."""
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e-3)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
 def time_call_rot(fn, reps, sets, warm=3):
     """time_call for fn(i) with i cycling over `sets` operand sets (cold operands: see measure_roofline_shapes)."""
     it = [0]
@@ -399,6 +417,10 @@ def measure_roofline_shapes(dev, k):
         gs = [g] + [torch.randn(B, F, device=dev) * 0.01 for _ in range(sets - 1)]
         t_fc = time_call_rot(lambda i: lib.alignq_site_partials(p(xs[i]), B, F, k, 2.0, eps, p(xq), p(stats), p(ws), st), 12, sets)
         t_bc = time_call_rot(lambda i: lib.alignq_site_bwd_apply(p(gs[i]), p(S), p(xs[i]), p(stats), B, F, 2.0, eps, p(dx), st), 12, sets)
+        t_fs, t_bs = time_call_serial(f_fwd, 8), time_call_serial(f_bwd, 8)
+        out[f"site_{B}x{F}"].update({"fwd_us_serial": t_fs * 1e6, "bwd_us_serial": t_bs * 1e6,
+                                     "serial_note": "each launch alone between two synchronisations (what a rocprofv3 kernel trace "
+                                                    "sees); *_us: 10 launches back to back"})
         out[f"site_{B}x{F}"].update({"operand_sets_cold": sets, "fwd_us_cold": t_fc * 1e6, "fwd_frac_of_8TBs_cold": 8.0 * n / t_fc / 1e9 / HBM_PEAK_GBS,
                                      "bwd_us_cold": t_bc * 1e6, "bwd_frac_of_8TBs_cold": 12.0 * n / t_bc / 1e9 / HBM_PEAK_GBS})
         del x, g, xq, dx, stats, ws, xs, gs
