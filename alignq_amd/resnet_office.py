@@ -56,7 +56,7 @@ class Bottleneck(nn.Module):
                 from . import fused
                 identity = fused.bn_only(self.downsample[1], self.downsample[0](x), groups)
             out, loss = self.act_q3.forward_bn_res_relu(self.bn3, self.conv3(out), identity, groups)
-            return out, trans_loss + loss
+            return out, loss              # (= 0. + loss without the launch that forms it)
         if getattr(self, "fuse_bn", False):         # opt-in (OfficeTrainStep): batch-norm + quantiser + ReLU as one chain
             out = self.act_q1.forward_bn_relu(self.bn1, self.conv1(x))
             out = self.act_q2.forward_bn_relu(self.bn2, self.conv2(out))
@@ -71,7 +71,7 @@ class Bottleneck(nn.Module):
                 from . import fused
                 identity = fused.bn_only(self.downsample[1], self.downsample[0](x))
             out, loss = self.act_q3.forward_bn_res_relu(self.bn3, self.conv3(out), identity)
-            return out, trans_loss + loss
+            return out, loss              # (= 0. + loss without the launch that forms it)
         if getattr(self, "fuse_relu", False):       # `out += identity; relu` inside the site kernels
             z = self.bn3(self.conv3(out))
             if self.downsample is not None:
@@ -126,11 +126,14 @@ class ResNet(nn.Module):
         trans_loss = 0.
         if groups > 1:
             x = self.maxpool(self.act_q0.forward_bn_relu(self.bn1, self.conv1(x), groups))
+            losses = []
             for layers in (self.layer1, self.layer2, self.layer3, self.layer4):
                 for layer in layers:
                     x, loss = layer(x, groups)
-                    trans_loss += loss
-            return torch.flatten(self.avgpool(x), 1), trans_loss
+                    losses.append(loss)
+            # one stack + one sum instead of 16 scalar additions on the in-order chain (the fast path only: the value may differ
+            # from main.py's running sum in the last bit, the gradients - ones - do not)
+            return torch.flatten(self.avgpool(x), 1), torch.stack(losses).sum()
         if getattr(self, "fuse_bn", False):
             x = self.maxpool(self.act_q0.forward_bn_relu(self.bn1, self.conv1(x)))
         elif getattr(self, "fuse_relu", False):
