@@ -796,8 +796,10 @@ class BNSite1Fn(torch.autograd.Function):
         if g_loss is None:
             g_loss = torch.zeros((), dtype=torch.float32, device=dev)
         g_loss = L.dev_f32(g_loss, "loss grad")
-        dA = torch.empty(groups, *A.shape, dtype=torch.float32, device=dev)
-        dG = torch.empty(groups, *Gm.shape, dtype=torch.float32, device=dev)
+        # alterD and gamma have one shape: both gradients of all slices in ONE buffer, so that the slices are added by one launch
+        dAG = torch.empty(2, groups, *A.shape, dtype=torch.float32, device=dev) if A.shape == Gm.shape else None
+        dA = dAG[0] if dAG is not None else torch.empty(groups, *A.shape, dtype=torch.float32, device=dev)
+        dG = dAG[1] if dAG is not None else torch.empty(groups, *Gm.shape, dtype=torch.float32, device=dev)
         from .ops import _ws
         s_bytes = lib.alignq_site_bwd_ws_bytes(B)
         S = _ws(s_bytes * groups, dev)
@@ -832,7 +834,12 @@ class BNSite1Fn(torch.autograd.Function):
             for gi in range(1, groups):
                 out = out + t[gi]
             return out
-        return (dx, dgamma, dbeta, None, None, None, None, None, g_m if has_res else None, red(dA), red(dG), None, None,
+        if dAG is not None and groups == 2:          # a + b either way: the same bits, one launch instead of two
+            both = dAG[:, 0] + dAG[:, 1]
+            rA, rG = both[0], both[1]
+        else:
+            rA, rG = red(dA), red(dG)
+        return (dx, dgamma, dbeta, None, None, None, None, None, g_m if has_res else None, rA, rG, None, None,
                 None, None, None, None)
 
 
