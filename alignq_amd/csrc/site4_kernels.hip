@@ -267,7 +267,10 @@ __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restri
   // complete tiles: no masks (FULLP: the launcher's promise for the one-tile forms).  A complete tile has 128 rows: with 16-feature
   // tiles the 1024 threads form 256 row groups, half of them beyond the batch, so that geometry (ALIGNQ_FWD_WIDE=0 reaches it) keeps
   // the row mask whatever the launcher promised
-  constexpr bool kFull = (FULLP && RG <= 128) || kPlain;
+  static_assert(!FULLP || (SINGLE && NTv == NT && RG <= 128),
+                "FULLP is the one-tile 1024-thread form over complete 128-row tiles: 16-feature tiles have 256 row groups");
+  static_assert(!kPlain || TFv == 64, "the 512-thread multi-tile form is written for 64-feature tiles");
+  constexpr bool kFull = FULLP || kPlain;
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STAGE_BYTES + (4 * TFv + 2 * NW * TFv) * 4];
   __shared__ __attribute__((aligned(16))) float nerf_lds[PAIR ? ALIGNQ_NERF_LDS_FLOATS : 4];
   if constexpr (SINGLE && NTv == 1024) {
@@ -1323,7 +1326,9 @@ __global__ __launch_bounds__(TFv * 8, 2) void site_bwd4_kernel(const float* __re
     // operations (a conditional load or store makes the compiler wait for EVERYTHING in flight at the next use of a register
     // that was loaded before it: the counters are in order, and it must assume the younger operation was not issued)
     // FULLP: the launcher's promise of complete tiles for the one-tile VEC form (B == 128, F % TFv == 0): the masks fold away
-    constexpr bool kFullB = LOOP || (FULLP && VEC);
+    static_assert(!FULLP || (VEC && !LOOP), "FULLP names the one-tile VEC form over complete tiles");
+    static_assert(!LOOP || (VEC && !BN), "the looped form is the plain site's: 16-byte accesses, no batch-norm fold");
+    constexpr bool kFullB = LOOP || FULLP;
     const bool q_ok = kFullB || (col0 + 4 * lc4) < F;          // F % 4 == 0: a quad lies inside or outside as a whole
     const unsigned colq = (unsigned)(q_ok ? col0 + 4 * lc4 : (int)F - 4) * 4u;
     const uint4 bo4 = make_uint4((unsigned)min(lrow4 + 0, B - 1) * rowB + colq, (unsigned)min(lrow4 + 1, B - 1) * rowB + colq,
@@ -1893,6 +1898,64 @@ __global__ __launch_bounds__(TFv * 8, 2) void site_bwd4_kernel(const float* __re
     if (e__ != hipSuccess) return (int)e__;           \
   } while (0)
 
+
+// One forward launch.  Which instantiation runs is decided HERE, next to the conditions it was written for, so a promise of
+// complete tiles (FULLP, the 512-thread multi-tile form) cannot be made for a geometry the kernel masks differently: the
+// unmasked one-tile form exists for 32- and 64-feature tiles only (static_assert in the kernel), and is chosen only when
+// B == 128, F % TFV == 0 and the tensors are 16-byte aligned.
+struct FwdLaunch {
+  const float* x; int B; int64_t F; int k; float r, eps; float* xq; float* ws; float* stats; int n_tiles, aligned;
+  unsigned* counter; BnFold bn; SFill fill; int grid, fgrid; bool full64; hipStream_t st;
+};
+template <int TFV, bool P, bool SG, int NTV, bool FULLP>
+inline void launch_fwd4_inst(const FwdLaunch& a) {
+  hipLaunchKernelGGL((site_fwd4_kernel<TFV, P, SG, NTV, FULLP>), (SG && NTV == NT) ? a.fgrid : a.grid, NTV, 0, a.st, a.x, a.B, a.F,
+                     a.k, a.r, a.eps, a.xq, a.ws, a.stats, a.n_tiles, a.aligned, a.counter, a.bn, a.fill);
+}
+template <int TFV, bool P>
+inline int launch_fwd4_tf(const FwdLaunch& a) {
+  if (a.n_tiles <= a.grid) {                                  // one tile per workgroup
+    const bool complete = a.B == 128 && a.F % TFV == 0 && a.aligned;
+    if constexpr (TFV >= 32) {
+      if (complete) { launch_fwd4_inst<TFV, P, true, NT, true>(a); return 0; }
+    }
+    launch_fwd4_inst<TFV, P, true, NT, false>(a);
+    return 0;
+  }
+  if constexpr (TFV == 64) {                                  // the tile loop
+    const BnFold& bn = a.bn;
+    if (bn.ab || bn.res || bn.relu || bn.bins || !a.full64) launch_fwd4_inst<64, P, false, NT, false>(a);
+    else launch_fwd4_inst<64, P, false, 512, false>(a);
+    return 0;
+  }
+  return ALIGNQ_EINVAL;
+}
+
+// One backward launch, same rule as the forward's: the unmasked instantiations (FULLP one-tile, LOOP) are chosen only by the
+// functions that check what they assume.
+struct BwdLaunch {
+  const float* gup; const float* S; const float* x; const float* stats; int B; int64_t F; float r, eps; float* dx;
+  int n_tiles, aligned; BnFold bn; alignq_wgr::RedFill fill; int grid; bool vec; hipStream_t st;
+};
+template <int TFV, bool P, bool N, bool VEC, bool LOOP, bool FULLP>
+inline void launch_bwd4_inst(const BwdLaunch& a) {
+  hipLaunchKernelGGL((site_bwd4_kernel<TFV, P, N, VEC, LOOP, FULLP>), a.grid, TFV * 8, 0, a.st, a.gup, a.S, a.x, a.stats, a.B, a.F,
+                     a.r, a.eps, a.dx, a.n_tiles, a.aligned, a.bn, a.fill);
+}
+template <int TFV, bool P, bool N>
+inline void launch_bwd4_tile(const BwdLaunch& a) {             // one tile per workgroup
+  if (a.vec && a.B == 128 && a.F % TFV == 0) launch_bwd4_inst<TFV, P, N, true, false, true>(a);
+  else if (a.vec) launch_bwd4_inst<TFV, P, N, true, false, false>(a);
+  else launch_bwd4_inst<TFV, P, N, false, false, false>(a);
+}
+template <int TFV, bool P>
+inline int launch_bwd4_loop(const BwdLaunch& a) {              // complete tiles only, no fold
+  const BnFold& bn = a.bn;
+  if (!a.vec || a.B != 128 || a.F % TFV != 0 || bn.ab || bn.y || bn.ybins || bn.dres) return ALIGNQ_EINVAL;
+  if (a.grid < 1 || a.n_tiles != (int)(a.F / TFV)) return ALIGNQ_EINVAL;
+  launch_bwd4_inst<TFV, P, false, true, true, false>(a);
+  return 0;
+}
 }  // namespace
 
 int launch_partials4(bool pair, const Geom& g, const float* x, int B, int64_t F, int k, float r, float eps, float* xq,
@@ -1920,22 +1983,11 @@ int launch_partials4(bool pair, const Geom& g, const float* x, int B, int64_t F,
   // geom(): one tile per workgroup up to F = 16384; beyond that the 64-feature tile loop runs in up to 512 workgroups of 512
   // threads, two per CU, for the plain site; with the batch-norm fold (no configuration has one at such F) in 1024-thread ones
   const bool full64 = B == 128 && F % 64 == 0 && aligned;     // the 512-thread multi-tile form takes complete tiles only
-#define L4S(TFV, P, SG, NTV) hipLaunchKernelGGL((site_fwd4_kernel<TFV, P, SG, NTV>), (SG && NTV == NT) ? fgrid : g.grid, NTV, 0, st, x, B, F, k, r, eps, xq, ws, stats, g.n_tiles, aligned, counter, bn, fill)
-#define L4F(TFV, P) hipLaunchKernelGGL((site_fwd4_kernel<TFV, P, true, NT, true>), fgrid, NT, 0, st, x, B, F, k, r, eps, xq, ws, stats, g.n_tiles, aligned, counter, bn, fill)
-#define L4(TFV, P)                                                                                                       \
-  do {                                                                                                                  \
-    if (g.n_tiles <= g.grid) { if (TFV >= 32 && B == 128 && F % TFV == 0 && aligned) L4F(TFV, P); else L4S(TFV, P, true, NT); } \
-    else if (TFV == 64) { if (bn.ab || bn.res || bn.relu || bn.bins || !full64) L4S(64, P, false, NT); else L4S(64, P, false, 512); } \
-    else return ALIGNQ_EINVAL;                                                                                          \
-  } while (0)
-  if (pair) {
-    if (g.tf == 64) L4(64, true); else if (g.tf == 32) L4(32, true); else L4(16, true);
-  } else {
-    if (g.tf == 64) L4(64, false); else if (g.tf == 32) L4(32, false); else L4(16, false);
-  }
-#undef L4
-#undef L4S
-#undef L4F
+  const FwdLaunch fl{x, B, F, k, r, eps, xq, ws, stats, g.n_tiles, aligned, counter, bn, fill, g.grid, fgrid, full64, st};
+  int rc;
+  if (pair) rc = g.tf == 64 ? launch_fwd4_tf<64, true>(fl) : (g.tf == 32 ? launch_fwd4_tf<32, true>(fl) : launch_fwd4_tf<16, true>(fl));
+  else rc = g.tf == 64 ? launch_fwd4_tf<64, false>(fl) : (g.tf == 32 ? launch_fwd4_tf<32, false>(fl) : launch_fwd4_tf<16, false>(fl));
+  if (rc) return rc;
   RET_ON_ERR();
   return 0;
 }
@@ -2053,34 +2105,27 @@ int launch_bwd4(bool pair, const Geom& g, const float* gup, const float* S, cons
   // 16-byte accesses need whole column quads and aligned rows (channels-last BN: C % 4 == 0 holds, C is a power of two >= 4)
   const bool vec = (F % 4 == 0) && al16(gup) && al16(x) && al16(stats) && al16(dx) && al16(bn.y) && al16(bn.dres) && al16(bn.ybins) &&
                    al16(bn.ab) && al16(bn.save) && (!bn.ab || bn.nhwc || bn.HW % 4 == 0) && (!bn.nhwc || bn.C % 4 == 0);
-#define LB(TFV, P, N)                                                                                                        \
-  do {                                                                                                                       \
-    if (vec && B == 128 && F % TFV == 0)                                                                                     \
-      hipLaunchKernelGGL((site_bwd4_kernel<TFV, P, N, true, false, true>), grid, TFV * 8, 0, st, gup, S, x, stats, B, F, r,  \
-                         eps, dx, n_tiles, aligned, bn, fill);                                                                     \
-    else if (vec) hipLaunchKernelGGL((site_bwd4_kernel<TFV, P, N, true>), grid, TFV * 8, 0, st, gup, S, x, stats, B, F, r, eps,   \
-                                dx, n_tiles, aligned, bn, fill);                                                                   \
-    else hipLaunchKernelGGL((site_bwd4_kernel<TFV, P, N, false>), grid, TFV * 8, 0, st, gup, S, x, stats, B, F, r, eps, dx,  \
-                            n_tiles, aligned, bn, fill);                                                                           \
-  } while (0)
-  static const int loop32 = [] { const char* e = getenv("ALIGNQ_BWD_LOOP32"); return e ? atoi(e) : 0; }();   // tuning aid
-  if (loop32 && vec && !bn.ab && !bn.y && !bn.ybins && !bn.dres && F > 32768 && B == 128 && F % 32 == 0) {
+  const BwdLaunch bl{gup, S, x, stats, B, F, r, eps, dx, n_tiles, aligned, bn, fill, grid, vec, st};
+  static const int loop32 = alignq_env::env_int("ALIGNQ_BWD_LOOP32", 0, 0, 4096);   // tuning aid
+  const bool plain = !bn.ab && !bn.y && !bn.ybins && !bn.dres;
+  if (loop32 && plain && F > 32768) {
     // experiment: 32-feature tiles, 256 threads, 70 KB of LDS: two (or loop32 / 256) looped workgroups per CU
-    const int nt32 = (int)((F + 31) / 32);
-    grid = loop32 >= 256 ? loop32 : 512;
-    if (pair) hipLaunchKernelGGL((site_bwd4_kernel<32, true, false, true, true>), grid, 256, 0, st, gup, S, x, stats, B, F, r, eps, dx, nt32, aligned, bn, fill);
-    else hipLaunchKernelGGL((site_bwd4_kernel<32, false, false, true, true>), grid, 256, 0, st, gup, S, x, stats, B, F, r, eps, dx, nt32, aligned, bn, fill);
-  } else if (tf == 64 && vec && !bn.ab && !bn.y && !bn.ybins && !bn.dres && n_tiles > 2 * 256 && B == 128 && F % 64 == 0) {
+    BwdLaunch b2 = bl;
+    b2.n_tiles = (int)((F + 31) / 32);
+    b2.grid = loop32 >= 256 ? loop32 : 512;
+    const int rc = pair ? launch_bwd4_loop<32, true>(b2) : launch_bwd4_loop<32, false>(b2);
+    if (rc) return rc;
+  } else if (tf == 64 && plain && n_tiles > 2 * 256 && vec && B == 128 && F % 64 == 0) {
     // plain site with many tiles per CU (F > 32768): the looped, software-pipelined form (138 KB of LDS: one workgroup per CU)
-    grid = 256;
-    if (pair) hipLaunchKernelGGL((site_bwd4_kernel<64, true, false, true, true>), grid, 512, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_tiles, aligned, bn, fill);
-    else hipLaunchKernelGGL((site_bwd4_kernel<64, false, false, true, true>), grid, 512, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_tiles, aligned, bn, fill);
+    BwdLaunch b2 = bl;
+    b2.grid = 256;
+    const int rc = pair ? launch_bwd4_loop<64, true>(b2) : launch_bwd4_loop<64, false>(b2);
+    if (rc) return rc;
   } else if (tf == 64) {
-    if (pair && bn.ab) LB(64, true, true); else if (pair) LB(64, true, false); else LB(64, false, false);
+    if (pair && bn.ab) launch_bwd4_tile<64, true, true>(bl); else if (pair) launch_bwd4_tile<64, true, false>(bl); else launch_bwd4_tile<64, false, false>(bl);
   } else {
-    if (pair && bn.ab) LB(32, true, true); else if (pair) LB(32, true, false); else LB(32, false, false);
+    if (pair && bn.ab) launch_bwd4_tile<32, true, true>(bl); else if (pair) launch_bwd4_tile<32, true, false>(bl); else launch_bwd4_tile<32, false, false>(bl);
   }
-#undef LB
   RET_ON_ERR();
   return 0;
 }
