@@ -164,8 +164,10 @@ __global__ __launch_bounds__(kThreads1, PAIR ? 4 : 5) void site1_fwd_kernel(cons
         xn[q] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(x) + ((unsigned)min(RPL * h + q, B - 1) * rowB + colB));
     }
     if (ab) {      // folded batch-norm (channels-last: channel = column mod nch, nch a power of two): x = a*z + b on load
-      const int ch = (int)(col & (int64_t)(nch - 1));
-      const float av = ab[ch], bv = ab[nch + ch];      // (col beyond F: some channel's values, never used)
+      // lanes beyond F work on the CLAMPED column F - 1 (loads above, the x_q store below): they take ITS channel, so what they
+      // store is the owning lane's value (round-3 advisor finding: F % 32 != 0 stored a wrong-channel value there)
+      const int ch = (int)(min(col, F - 1) & (int64_t)(nch - 1));
+      const float av = ab[ch], bv = ab[nch + ch];
 #pragma unroll
       for (int q = 0; q < RPL; q++) xr[q] = __fmaf_rn(av, xr[q], bv);
     }

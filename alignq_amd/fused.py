@@ -655,15 +655,24 @@ class BNQuantReluFn(torch.autograd.Function):
         return dz, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
-def _bn_nhwc_ok(bn, z) -> bool:
+def _bn_nhwc_ok(bn, z, groups=1) -> bool:
+    """groups: the batch slices that are normalised separately (the Office step's source + target halves): the batch must
+    divide into them and EACH slice needs its >= 2 values per channel (alignq_bnq_* compute var * n / (n - 1) per slice)."""
     C = z.shape[1] if z.dim() == 4 else 0
     return (bn.training and z.is_cuda and z.dtype == torch.float32 and z.dim() == 4 and _is_nhwc(z)
             and 4 <= C <= 2048 and (C & (C - 1)) == 0 and bn.track_running_stats and bn.momentum is not None
-            and z.shape[0] * z.shape[2] * z.shape[3] >= 2)
+            and groups >= 1 and z.shape[0] % groups == 0 and (z.shape[0] // groups) * z.shape[2] * z.shape[3] >= 2)
 
 
-def bnq_fusable(bn, act, z) -> bool:
-    return _bn_nhwc_ok(bn, z) and act.a_bit < 32
+def _slices(z, groups):
+    if z.shape[0] % groups:
+        raise ValueError(f"a batch of {z.shape[0]} rows does not split into {groups} equal slices")
+    Bg = z.shape[0] // groups
+    return [z[i * Bg:(i + 1) * Bg] for i in range(groups)]
+
+
+def bnq_fusable(bn, act, z, groups=1) -> bool:
+    return _bn_nhwc_ok(bn, z, groups) and act.a_bit < 32
 
 
 class BNAffineFn(torch.autograd.Function):
@@ -711,11 +720,10 @@ class BNAffineFn(torch.autograd.Function):
 def bn_only(bn, z, groups=1):
     """bn(z): the folded-family kernels when the tensor is channels-last fp32 in training mode, else the module itself
     (groups > 1: applied to the batch slices one after the other, as the reference's successive passes do)."""
-    if not _bn_nhwc_ok(bn, z):
+    if not _bn_nhwc_ok(bn, z, groups):
         if groups == 1:
             return bn(z)
-        Bg = z.shape[0] // groups
-        return torch.cat([bn(z[i * Bg:(i + 1) * Bg]) for i in range(groups)], 0)
+        return torch.cat([bn(zz) for zz in _slices(z, groups)], 0)
     return BNAffineFn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum, bn.eps,
                             groups)
 
@@ -848,7 +856,7 @@ def bn_site_res_relu(bn, act, z, residual, eps, groups=1):
     the tensor is channels-last fp32 in training mode (and no deferred-loss context is active), else None (the caller composes
     it)."""
     from . import config
-    if not (_bn_nhwc_ok(bn, z) and z.shape[0] % groups == 0 and 2 <= z.shape[0] // groups <= 32 and act.a_bit < 32
+    if not (_bn_nhwc_ok(bn, z, groups) and 2 <= z.shape[0] // groups <= 32 and act.a_bit < 32
             and config.args.method == "ours"
             and active_deferred() is None and residual is not None and residual.shape == z.shape and residual.is_cuda
             and residual.dtype == torch.float32 and z.shape[0] // groups <= act.opt.alterD.shape[0]):
@@ -865,14 +873,13 @@ def bn_act_relu(bn, act, z, formula, relu=True, groups=1):
     """[relu](act(bn(z))) for a quantiser WITHOUT an ADMM term: one fused chain when `bnq_fusable` (training mode,
     channels-last fp32 CUDA tensor, C = 4 * 2^j <= 2048), else exactly that composition (groups: see BNQuantReluFn)."""
     from . import config
-    if not bnq_fusable(bn, act, z):
+    if not bnq_fusable(bn, act, z, groups):
         def one(zz):
             out = act(bn(zz))
             return torch.nn.functional.relu(out) if relu else out
         if groups == 1:
             return one(z)
-        Bg = z.shape[0] // groups
-        return torch.cat([one(z[i * Bg:(i + 1) * Bg]) for i in range(groups)], 0)
+        return torch.cat([one(zz) for zz in _slices(z, groups)], 0)
     return BNQuantReluFn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum,
                                bn.eps, act.a_bit, config.args.act_range, formula, relu, groups)
 

@@ -83,12 +83,17 @@ class SGD(Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        self._launch(self._gather(idx, w_cdf, w_pdf), lam, lam2)
+        return loss
+
+    def _launch(self, items, lam, lam2):
+        """Run gathered groups.  `items` carries the `first` flags of momentum buffers `_gather` has just created (uninitialised
+        memory the kernel must overwrite, not read): whoever gathers must launch THESE items, never gather again."""
         lib = L.load()
         st = L.stream_ptr()
-        for item in self._gather(idx, w_cdf, w_pdf):
+        for item in items:
             # one multi-tensor launch (per <=72 tensors) for the whole group: step + p.grad rewrite for idx members
             L.check(lib.alignq_sgd_step_multi(*self._c_args(item), float(lam), float(lam2), st), "alignq_sgd_step_multi")
-        return loss
 
 
 class ADMM_OPT(Optimizer):
@@ -152,9 +157,14 @@ def sgd_admm_step(sgd, sgd_args, admm, admm_args):
     if int(config.args.bitW) < 32:
         mine = {id(p) for g in sgd.param_groups for p in g["params"]}
         disjoint = not any(id(p) in mine for g in admm.param_groups for p in g["params"])
-        items = sgd._gather(idx, w_cdf, w_pdf) if disjoint else None
-        groups = admm._gather(alterD_idx, gamma_idx, Ds, gammas, mus, rhos) if disjoint else None
-        if disjoint and len(items) == 1 and len(groups) == 1:
+        # eligibility is decided BEFORE any optimizer state is created: _gather makes the missing momentum buffers and reports
+        # them only in the items it returns (round-3 advisor finding: items gathered here and dropped left buffers that a second
+        # gather took for initialised ones)
+        one_group = sum(1 for g in sgd.param_groups if any(p.grad is not None for p in g["params"])) == 1
+        groups = admm._gather(alterD_idx, gamma_idx, Ds, gammas, mus, rhos) if disjoint and one_group else None
+        if groups is not None and len(groups) == 1:
+            items = sgd._gather(idx, w_cdf, w_pdf)
+            assert len(items) == 1
             ((mu, rho, b, dim), sites), = groups.items()
             L.check(L.load().alignq_sgd_admm_step_multi(
                 *SGD._c_args(items[0]), float(lam), float(lam2), len(sites), L.ptr_array([s_[0] for s_ in sites]),

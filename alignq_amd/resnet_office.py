@@ -133,7 +133,12 @@ class ResNet(nn.Module):
                     losses.append(loss)
             # one stack + one sum instead of 16 scalar additions on the in-order chain (the fast path only: the value may differ
             # from main.py's running sum in the last bit, the gradients - ones - do not)
-            return torch.flatten(self.avgpool(x), 1), torch.stack(losses).sum()
+            # (a site without an ADMM term - abitW == 32, method != 'ours', a deferred-loss context - returns the number 0: those
+            # are summed as numbers, as the running sum of the one-pass form does)
+            tens = [l for l in losses if torch.is_tensor(l)]
+            rest = sum(l for l in losses if not torch.is_tensor(l))
+            total = torch.stack(tens).sum() + rest if tens else rest
+            return torch.flatten(self.avgpool(x), 1), total
         if getattr(self, "fuse_bn", False):
             x = self.maxpool(self.act_q0.forward_bn_relu(self.bn1, self.conv1(x)))
         elif getattr(self, "fuse_relu", False):

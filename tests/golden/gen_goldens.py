@@ -62,6 +62,45 @@ def _enter(variant, extra_argv):
 
 
 # ----------------------------------------------------------------------------------------------
+G3L_SEED, G3L_SHAPE, G3L_TIE = 20261004, (128, 8192), 1e-4
+
+
+def _g3l(q, args, tree):
+    """G3L: the reference's activation quantiser on 2^20 N(0,1) elements (post-batch-norm statistics), k in {2,4,8}: the
+    INTEGER BINS behind its output as int16, plus - for the documented erf tie zone (|frac(pre-round value in bin units) - 1/2|
+    < 1e-4) - the indices of the elements inside it and the reference's own fp32 pre-round value there.
+    The same seeded x in both trees (stored once, in the ADMM-tree file; the CDF-only file carries its SHA-256).
+    A generator of its own and called LAST in each variant, so the older fixtures' random streams are unchanged."""
+    import hashlib
+    import torch
+    g = torch.Generator().manual_seed(G3L_SEED)
+    x = torch.randn(G3L_SHAPE, generator=g)
+    r = float(args.act_range)
+    out = {"act_range": np.array(r, dtype=np.float32), "tie": np.array(G3L_TIE),
+           "x_sha256": np.array(hashlib.sha256(_np(x).tobytes()).hexdigest())}
+    pre, _ = q.cdf(torch.zeros(1), torch.ones(1), "a")(x)      # ADMM tree: t = r (2 Phi - 1); CDF-only tree: c = Phi
+    pre = _np(pre).astype(np.float32).ravel()
+    for k in (2, 4, 8):
+        n = 2 ** k - 1
+        if tree == "admm":
+            xq, tl = q.activation_quantize_fn(k, "second", None)(x)
+            assert tl == 0
+            b = np.rint(_np(xq).astype(np.float64) * n)
+        else:
+            xq = q.activation_quantize_fn(k, "second")(x)
+            b = np.rint((_np(xq).astype(np.float64) / r + 1.0) * 0.5 * n)
+        assert np.abs(b).max() < 32768
+        out[f"bins_k{k}"] = b.astype(np.int16).ravel()
+        y = pre * np.float32(n)                                  # what torch.round saw (fp32, as the reference forms it)
+        tie = np.flatnonzero(np.abs((y - np.floor(y)) - 0.5) < G3L_TIE)
+        out[f"tie_idx_k{k}"] = tie.astype(np.int32)
+        out[f"tie_pre_k{k}"] = pre[tie]
+    if tree == "admm":
+        out["x"] = _np(x).ravel()
+    _save("g3l_act_bins_" + ("admm" if tree == "admm" else "cdfonly"), **out)
+
+
+# ----------------------------------------------------------------------------------------------
 def gen_admm_cifar():
     import torch
     q, args = _enter("admm_cifar", ["--bitW", "8", "--abitW", "8", "--train_batch_size", "8"])
@@ -599,7 +638,18 @@ def gen_office_bottleneck_sites():
     _save("g13_office_bottleneck_sites", **out)
 
 
-GEN = {"admm_cifar": gen_admm_cifar, "cdf_only": gen_cdf_only, "office": gen_office, "office_keys": gen_office_keys,
+def gen_g3l_admm():
+    q, args = _enter("admm_cifar", ["--bitW", "8", "--abitW", "8", "--train_batch_size", "8"])
+    args.method = "plain"          # model/quantization.py:112: the quantiser alone, no corr / ADMM branch
+    _g3l(q, args, "admm")
+
+
+def gen_g3l_cdfonly():
+    q, args = _enter("cdf_only", ["--bitW", "8", "--abitW", "8"])
+    _g3l(q, args, "cdf")
+
+
+GEN = {"g3l_admm": gen_g3l_admm, "g3l_cdfonly": gen_g3l_cdfonly, "admm_cifar": gen_admm_cifar, "cdf_only": gen_cdf_only, "office": gen_office, "office_keys": gen_office_keys,
        "corr_xy_admm": gen_corr_xy_admm, "corr_xy_office": gen_corr_xy_office, "office_tiny_dann": gen_office_tiny_dann, "tiny_resnet_sites": gen_tiny_resnet_sites,
        "office_bottleneck_sites": gen_office_bottleneck_sites}
 

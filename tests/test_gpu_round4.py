@@ -1,0 +1,159 @@
+"""GPU tests added in round 4 (all through the C ABI via alignq_amd.ops / the Python mirror)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import oracle_c as O  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X box"
+    from alignq_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def cu(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------ ADVICE r3 (medium 2)
+@pytest.mark.parametrize("n_groups", [2, 3])
+def test_sgd_admm_step_with_several_sgd_groups_on_the_first_step(dev, n_groups):
+    """optimizer.sgd_admm_step with MORE than one SGD parameter group (the Office step has three) falls back to SGD.step +
+    ADMM_OPT.step.  Round 3 gathered the SGD items first - creating the momentum buffers with torch.empty_like - dropped them
+    and gathered again: the second gather saw existing buffers (first = 0) and the kernel read uninitialised memory
+    (utils/optimizer.py:231-243: the first step SETS buf = d_p).  The caching allocator is primed with NaN-filled blocks of the
+    buffers' sizes so that such a read cannot pass by luck."""
+    from alignq_amd import config
+    from alignq_amd.admm import ADMM
+    from alignq_amd.optimizer import ADMM_OPT, SGD, sgd_admm_step
+    old = config.args.bitW
+    config.args.bitW = 4
+    try:
+        sizes = [432, 36864, 16, 640, 2304, 9216][: 2 * n_groups]
+
+        def world():
+            g = torch.Generator(device="cpu").manual_seed(11)
+            ps = [torch.nn.Parameter(torch.randn(s, generator=g).to(dev)) for s in sizes]
+            for p in ps:
+                p.grad = torch.randn(p.shape, generator=g).to(dev)
+            m = ADMM(16).to(dev)
+            with torch.no_grad():
+                m.alterD.copy_(torch.rand(16, 16, generator=g))
+                m.gamma.copy_(torch.rand(16, 16, generator=g))
+            m.alterD.grad, m.gamma.grad = torch.zeros_like(m.alterD), torch.zeros_like(m.gamma)
+            m.D = (torch.randn(16, 16, generator=g) * 0.05).to(dev)
+            groups = [dict(params=ps[2 * i:2 * i + 2], lr=0.1 / (i + 1)) for i in range(n_groups)]
+            sgd = SGD(groups, lr=0.1, momentum=0.9, weight_decay=5e-4)
+            opt = ADMM_OPT([m.alterD, m.gamma])
+            sargs = ([], [], [], 1.0, 4.0)
+            aargs = ([0], [1], [m.D], [m.alterD], [m.gamma], [m.mu], [m.rho])
+            return ps, m, sgd, opt, sargs, aargs
+
+        def poison():
+            junk = [torch.full((s,), float("nan"), device=dev) for s in sizes for _ in range(2)]
+            del junk
+
+        ps, m, sgd, opt, sargs, aargs = world()
+        sgd.step(*sargs)
+        opt.step(*aargs)
+        want = [npy(p) for p in ps] + [npy(sgd.state[p]["momentum_buffer"]) for p in ps] + [npy(m.alterD), npy(m.gamma)]
+        ps, m, sgd, opt, sargs, aargs = world()
+        poison()
+        sgd_admm_step(sgd, sargs, opt, aargs)
+        got = [npy(p) for p in ps] + [npy(sgd.state[p]["momentum_buffer"]) for p in ps] + [npy(m.alterD), npy(m.gamma)]
+        for w, g_ in zip(want, got):
+            assert np.isfinite(g_).all()
+            assert np.array_equal(w, g_)
+        # the first step's buffer IS the decayed gradient
+        np.testing.assert_allclose(got[len(ps)], npy(ps[0].grad) + 5e-4 * (got[0] + 0.1 * got[len(ps)]), rtol=1e-5, atol=1e-6)
+    finally:
+        config.args.bitW = old
+
+
+# ------------------------------------------------------------------------------------------------ ADVICE r3 (low)
+def test_folded_batchnorm_eligibility_is_per_batch_slice(dev):
+    """fused._bn_nhwc_ok with groups: every slice needs >= 2 values per channel and the batch must divide (alignq_bnq_* take
+    P = (B / groups) * H * W and return ALIGNQ_EINVAL below 2); bn_only / bn_act_relu then fall back to the per-slice modules."""
+    import alignq_amd.office as NO
+    from alignq_amd import config, fused
+    bn = torch.nn.BatchNorm2d(8).to(dev).train()
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)      # noqa: E731
+    z = cl(torch.randn(2, 8, 1, 1, device=dev))
+    assert fused._bn_nhwc_ok(bn, z) and not fused._bn_nhwc_ok(bn, z, 2)
+    z3 = cl(torch.randn(3, 8, 4, 4, device=dev))
+    assert fused._bn_nhwc_ok(bn, z3) and not fused._bn_nhwc_ok(bn, z3, 2)
+    with pytest.raises(ValueError):
+        fused.bn_only(bn, z3, groups=2)
+    z4 = cl(torch.randn(4, 8, 4, 4, device=dev))
+    old = config.args.abitW
+    config.args.abitW = 8
+    try:
+        act = NO.activation_quantize_fn(8, "aligned").to(dev)
+        bn2 = torch.nn.BatchNorm2d(8).to(dev).train()
+        y = fused.bn_act_relu(bn, act, z4, 0, relu=True, groups=2)
+        want = torch.cat([torch.relu(act(bn2(z4[:2]))), torch.relu(act(bn2(z4[2:])))], 0)
+        assert float((y - want).abs().max()) <= 2.0 / 255 + 1e-6          # tie-zone flips between the folded and MIOpen's BN
+        np.testing.assert_allclose(npy(bn.running_mean), npy(bn2.running_mean), atol=1e-6)
+    finally:
+        config.args.abitW = old
+
+
+def test_office_dual_traversal_without_admm_terms(dev):
+    """ResNet.forward(groups=2) with sites that return the number 0 as their loss (abitW == 32: W-only quantisation,
+    dann_office/model/quantization.py:121-123) - torch.stack on floats raised a TypeError in round 3."""
+    from alignq_amd import config
+    from alignq_amd.resnet_office import DANN, Bottleneck, ResNet
+    old = (config.args.bitW, config.args.abitW, config.args.train_batch_size)
+    config.args.bitW, config.args.abitW, config.args.train_batch_size = 8, 32, 4
+    try:
+        torch.manual_seed(3)
+        m = DANN(lambda w, a, s: ResNet(w, a, s, Bottleneck, [1, 1, 1, 1]), 8, 32, "aligned").to(dev).train()
+        x = torch.randn(8, 3, 64, 64, device=dev)
+        feat, tl = m.feature(x, groups=2)
+        assert feat.shape[0] == 8 and float(tl) == 0.0
+    finally:
+        config.args.bitW, config.args.abitW, config.args.train_batch_size = old
+
+
+# ------------------------------------------------------------------------------------------------ VERDICT r3 item 2
+@pytest.mark.parametrize("tree,formula", [("admm", 0), ("cdf", 1)])
+def test_hip_bins_vs_reference_at_scale(dev, tree, formula, record_property):
+    """G3L on the HIP path: alignq_act_quant_fwd's int32 bins, the packed (int8 / int16 / uint8) indices of
+    alignq_act_quant_fwd_packed and the ADMM site's x_q against the REFERENCE's integer bins on 2^20 captured elements per bit
+    width: equal outside the reference's own tie zone, at most one off inside, flips <= 16 per 2^20 and reported; and the HIP
+    bins equal the C oracle's on every element (shared NERF32 specification)."""
+    from alignq_amd import _lib as L, ops
+    from tests.test_oracle_c import g3l_check, load_g3l
+    assert (O.FORMULA_ADMM, O.FORMULA_CDF) == (0, 1)
+    x, g = load_g3l(tree)
+    r = float(g["act_range"])
+    xd = cu(x, dev)
+    for k in (2, 4, 8):
+        n = 2 ** k - 1
+        xq = torch.empty_like(xd)
+        bins = torch.empty(xd.shape, dtype=torch.int32, device=dev)
+        L.check(L.load().alignq_act_quant_fwd(L.ptr(xd), L.ptr(xq), L.ptr(bins), xd.numel(), k, r, formula, L.stream_ptr()),
+                "alignq_act_quant_fwd")
+        n_tie, flips = g3l_check(npy(bins), g, k)
+        record_property(f"g3l_hip_{tree}_k{k}", {"tie_zone": n_tie, "flips": flips})
+        print(f"G3L HIP {tree} k={k}: {n_tie} in the tie zone, {flips} bins differ from the reference")
+        assert flips <= 16
+        oq, _, obins = O.act_quant_fwd(x, k, r, formula)
+        assert np.array_equal(npy(bins), obins) and np.array_equal(npy(xq).view(np.uint32), oq.view(np.uint32))
+        packed = ops.act_quant_pack(xd, k, r, formula)
+        assert np.array_equal(npy(packed).astype(np.int32), obins)
+        if tree == "admm":          # the fused ADMM site quantises with the same arithmetic: [128, 8192] as one site
+            xs = xd.view(128, -1)
+            A = torch.rand(128, 128, device=dev)
+            xq_s, _, _ = ops.SiteFn.apply(xs, A, A.clone(), k, r, 0.0, 0.2, 0.3)
+            assert np.array_equal(np.rint(npy(xq_s).astype(np.float64).ravel() * n).astype(np.int32), obins)

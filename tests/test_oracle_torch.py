@@ -240,3 +240,19 @@ def test_office_tiny_dann_two_iterations_match_the_reference():
             if f"buf_{it}/{j}" in g:
                 np.testing.assert_allclose(sample(step.opt_t.state[p]["momentum_buffer"]).numpy(), g[f"buf_{it}/{j}"],
                                            atol=2e-6, rtol=1e-5, err_msg=n)
+
+
+@pytest.mark.parametrize("tree", ["admm", "cdf"])
+def test_g3l_bins_at_scale(tree):
+    """The torch restatement (the cpu_baseline leg of bench.py) reproduces the reference's integer bins on all 2^20 G3L
+    elements with NO flips - it runs the reference's own op sequence on the same torch build."""
+    from tests.test_oracle_c import load_g3l
+    x, g = load_g3l(tree)
+    r = float(g["act_range"])
+    cfg = R.Config(tree=tree, act_range=r, method="plain")
+    for k in (2, 4, 8):
+        n = 2 ** k - 1
+        xq, _ = R.act_quant(T(x.reshape(128, -1)), k, "second", cfg, None)
+        xq = xq.numpy().astype(np.float64).ravel()
+        bins = np.rint(xq * n) if tree == "admm" else np.rint((xq / r + 1.0) * 0.5 * n)
+        assert np.array_equal(bins.astype(np.int16), g[f"bins_k{k}"])
