@@ -19,6 +19,8 @@
 
 #include "../../include/alignq.h"
 #include "alignq_math.h"
+#include "env_switch.h"
+#include "site_internal.h"
 
 using namespace alignq;
 
@@ -26,7 +28,7 @@ namespace {
 
 constexpr int kT = 256;
 constexpr int kParts = 512;          // workgroups of the two reduction kernels = partials per channel
-constexpr int kUs = 4;               // pixels in flight per thread in the reductions
+constexpr int kUs = 4;               // pixels per thread and round the partial-count rule assumes (parts_for)
 constexpr int kUa = 4;               // float4 per thread and tile in the elementwise kernels
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -39,11 +41,28 @@ __device__ __forceinline__ float4 ldnt(const float* p) {
 // MODE 0: {sum z, sum z^2};  MODE 1: {sum dx, sum dx*zhat} with dx = g * [y > 0] * jac(a*z + b) (the quantiser's backward in
 // front of the batch-norm's);  MODE 2: the same sums for a GIVEN dx = g (plain batch-norm backward: the ADMM sites' bn3 and the
 // downsample branch's batch-norm).  part: [gridDim.x][C][2] doubles.
+// ReLU mask (round 4): `mask` != nullptr replaces the fp32 y (4 B/element in each backward pass) by ONE BIT per element, written by
+// the forward's apply pass (bnq_apply_fwd_kernel).  Layout per group: for every chunk of 64 consecutive float4 (vec index i,
+// chunk i >> 6) four 64-bit words, one per float4 component, bit (i & 63) = [y > 0] of that component: the wave-wide compare
+// results of the forward, stored as they come.  mask_gstride: 64-bit words per group.
+__device__ __forceinline__ void mask_bits4(const unsigned long long* __restrict__ mask, int64_t i, bool (&m)[4]) {
+  const ulonglong2* p2 = reinterpret_cast<const ulonglong2*>(mask + (i >> 6) * 4);
+  const ulonglong2 a = p2[0], b = p2[1];
+  const int sh = (int)(i & 63);
+  m[0] = (a.x >> sh) & 1ull; m[1] = (a.y >> sh) & 1ull; m[2] = (b.x >> sh) & 1ull; m[3] = (b.y >> sh) & 1ull;
+}
+__host__ __device__ __forceinline__ int64_t mask_words(int64_t nvec) { return ((nvec + 63) >> 6) * 4; }
+
+template <int MODE>
+struct SumsDepth { static constexpr int U = MODE == 0 ? 8 : (MODE == 2 ? 6 : 4); };   // float4 per thread and array in flight
+
 template <int MODE, int NT>
 __global__ __launch_bounds__(NT) void bnq_sums_kernel(const float* __restrict__ z, const float* __restrict__ g,
                                                       const float* __restrict__ y, const float* __restrict__ ab,
                                                       const float* __restrict__ save, int64_t P, int C, float r, int relu,
-                                                      double* __restrict__ part) {
+                                                      double* __restrict__ part,
+                                                      const unsigned long long* __restrict__ mask = nullptr) {
+  constexpr int kUs = SumsDepth<MODE>::U;        // (round 4: one array of 64 B per thread kept 8 MB in flight on the chip: 4.9 TB/s)
   __shared__ double sm[NT][8];
   // blockIdx.y = group: the batch slices of a merged multi-pass tensor ([groups][P][C] back to back), each with its own
   // statistics (ab / save: [groups][2][C]; part: [groups][gridDim.x][C][2])
@@ -52,6 +71,7 @@ __global__ __launch_bounds__(NT) void bnq_sums_kernel(const float* __restrict__ 
     z += go;
     if (g) g += go;
     if (y) y += go;
+    if (mask) mask += (int64_t)blockIdx.y * mask_words(P * (C >> 2));
     if (ab) ab += (int64_t)blockIdx.y * 2 * C;
     if (save) save += (int64_t)blockIdx.y * 2 * C;
     part += (int64_t)blockIdx.y * gridDim.x * C * 2;
@@ -72,6 +92,7 @@ __global__ __launch_bounds__(NT) void bnq_sums_kernel(const float* __restrict__ 
   double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
   for (int64_t base = p0 + slot; base < p1; base += (int64_t)slots * kUs) {
     float4 zv[kUs], gv[kUs], yv[kUs];
+    bool mk[kUs][4];
 #pragma unroll
     for (int u = 0; u < kUs; u++) {            // clamped address, masked below
       const int64_t px = base + (int64_t)u * slots;
@@ -79,7 +100,10 @@ __global__ __launch_bounds__(NT) void bnq_sums_kernel(const float* __restrict__ 
       zv[u] = *reinterpret_cast<const float4*>(z + off);
       if (BWD) {
         gv[u] = *reinterpret_cast<const float4*>(g + off);
-        if (MODE == 1 && relu) yv[u] = *reinterpret_cast<const float4*>(y + off);
+        if (MODE == 1 && relu) {
+          if (mask) mask_bits4(mask, off >> 2, mk[u]);
+          else yv[u] = *reinterpret_cast<const float4*>(y + off);
+        }
       }
     }
 #pragma unroll
@@ -99,7 +123,8 @@ __global__ __launch_bounds__(NT) void bnq_sums_kernel(const float* __restrict__ 
             float dx = ge[e];
             if (MODE == 1) {
               const float x = __fmaf_rn(ae[e], ze[e], be[e]);
-              const float gm = (relu && !(ye[e] > 0.f)) ? 0.f : ge[e];
+              const bool pos = mask ? mk[u][e] : (ye[e] > 0.f);
+              const float gm = (relu && !pos) ? 0.f : ge[e];
               dx = gm * act_jac(x, r);
             }
             const float zh = (ze[e] - me[e]) * ie[e];
@@ -224,7 +249,8 @@ __global__ __launch_bounds__(kT) void bnq_finalize_bwd_kernel(const double* __re
 // ---- elementwise passes: tiles of kUa x 256 float4 per block; 256 % (C/4) == 0 keeps a thread on one channel quad ----------
 template <int FORMULA, int NT>
 __global__ __launch_bounds__(NT) void bnq_apply_fwd_kernel(const float* __restrict__ z, const float* __restrict__ ab, int64_t nvec,
-                                                           int C, int k, float r, int relu, float* __restrict__ y) {
+                                                           int C, int k, float r, int relu, float* __restrict__ y,
+                                                           unsigned long long* __restrict__ mask = nullptr) {
   __shared__ __attribute__((aligned(16))) float nerf_lds[ALIGNQ_NERF_LDS_FLOATS];
   nerf_tab_load(nerf_lds);
   __syncthreads();
@@ -232,6 +258,7 @@ __global__ __launch_bounds__(NT) void bnq_apply_fwd_kernel(const float* __restri
   const Levels nlev = make_levels(k, fabsf(r) <= 8.0f);
   z += (int64_t)blockIdx.y * nvec * 4;           // blockIdx.y = group (see bnq_sums_kernel)
   y += (int64_t)blockIdx.y * nvec * 4;
+  if (mask) mask += (int64_t)blockIdx.y * mask_words(nvec);
   ab += (int64_t)blockIdx.y * 2 * C;
   const int cq = threadIdx.x % (C >> 2);
   const float4 a4 = *reinterpret_cast<const float4*>(ab + 4 * cq);
@@ -264,21 +291,38 @@ _Pragma("unroll")
       }
       if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
       if (i < nvec) y4[i] = o;
+      if (mask) {
+        // the wave's 64 float4 are the consecutive vec indices of ONE chunk (tile bases and NT are multiples of 64): four
+        // wave-wide compares = the chunk's four words, stored by lane 0 (a chunk is written whole or - beyond nvec - not at all)
+        const bool in = i < nvec;
+        const unsigned long long bx = __ballot(in && o.x > 0.f), by = __ballot(in && o.y > 0.f);
+        const unsigned long long bz = __ballot(in && o.z > 0.f), bw = __ballot(in && o.w > 0.f);
+        const int lane = threadIdx.x & 63;
+        const int64_t i_w = i - lane;                 // the wave's first vec index
+        if (lane == 0 && i_w < nvec) {                // (lane 0 is in the loop whenever any lane of its wave is)
+          ulonglong2* mw = reinterpret_cast<ulonglong2*>(mask + (i_w >> 6) * 4);
+          mw[0] = make_ulonglong2(bx, by);
+          mw[1] = make_ulonglong2(bz, bw);
+        }
+      }
     }
   })
 }
 
 template <int NT>
-__global__ __launch_bounds__(NT) void bnq_apply_bwd_kernel(const float* __restrict__ g, const float* __restrict__ z,
+// g and dz may be the SAME buffer (alignq_bnq_bwd_dx in place: every thread reads its own elements before it writes them),
+// hence no __restrict__ on the two.
+__global__ __launch_bounds__(NT) void bnq_apply_bwd_kernel(const float* g, const float* __restrict__ z,
                                                            const float* __restrict__ y, const float* __restrict__ ab,
                                                            const float* __restrict__ save, const float* __restrict__ ktot,
                                                            int64_t nvec, int C, float r, int relu, int from_dx,
-                                                           float* __restrict__ dz) {
+                                                           float* dz, const unsigned long long* __restrict__ mask = nullptr) {
   constexpr int U = 2;
   {
     const int64_t go = (int64_t)blockIdx.y * nvec * 4;       // blockIdx.y = group
     g += go; z += go; dz += go;
     if (y) y += go;
+    if (mask) mask += (int64_t)blockIdx.y * mask_words(nvec);
     ab += (int64_t)blockIdx.y * 2 * C; save += (int64_t)blockIdx.y * 2 * C; ktot += (int64_t)blockIdx.y * 2 * C;
   }
   const int cq = threadIdx.x % (C >> 2);
@@ -291,12 +335,16 @@ __global__ __launch_bounds__(NT) void bnq_apply_bwd_kernel(const float* __restri
   const int64_t stride = (int64_t)gridDim.x * NT * U;
   for (int64_t i0 = (int64_t)blockIdx.x * (NT * U) + threadIdx.x; i0 < nvec; i0 += stride) {
     float4 gv[U], zv[U], yv[U];
+    bool mk[U][4];
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int64_t i = i0 + u * NT, ic = i < nvec ? i : i0;
       gv[u] = ldnt(g + 4 * ic);                      // the upstream gradient is read here for the last time
       zv[u] = *reinterpret_cast<const float4*>(z + 4 * ic);
-      if (relu) yv[u] = *reinterpret_cast<const float4*>(y + 4 * ic);
+      if (relu) {
+        if (mask) mask_bits4(mask, ic, mk[u]);
+        else yv[u] = *reinterpret_cast<const float4*>(y + 4 * ic);
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -309,7 +357,8 @@ __global__ __launch_bounds__(NT) void bnq_apply_bwd_kernel(const float* __restri
         float dx = ge[e];
         if (!from_dx) {            // launch-uniform
           const float x = __fmaf_rn(ae[e], ze[e], be[e]);
-          const float gm = (relu && !(ye[e] > 0.f)) ? 0.f : ge[e];
+          const bool pos = mask ? mk[u][e] : (ye[e] > 0.f);
+          const float gm = (relu && !pos) ? 0.f : ge[e];
           dx = gm * act_jac(x, r);
         }
         const float zh = (ze[e] - me[e]) * ie[e];
@@ -327,9 +376,15 @@ inline int tiles(int64_t nvec, int u, int nt = kT) {
   if (b < 1) b = 1;
   return (int)(b > 256 * 64 ? 256 * 64 : b);
 }
+// the reductions run 512-thread workgroups (round 4): at most 512 of them exist (kParts), i.e. two per CU - with 256 threads
+// that is two waves per SIMD for a kernel that is one long chain of load rounds (ALIGNQ_BNQ_SUMS_NT=256: round 3's form)
+inline int sums_threads(int C) {
+  static const int nt = alignq_env::env_choice("ALIGNQ_BNQ_SUMS_NT", 512, {256, 512});
+  return (C >> 2) > kT ? 512 : nt;
+}
 inline int parts_for(int64_t P, int C) {
   // every block should own at least a few pixel rounds: slots * kUs pixels per round
-  const int slots = threads_for(C) / (C >> 2);
+  const int slots = sums_threads(C) / (C >> 2);
   int64_t n = P / ((int64_t)slots * kUs);
   if (n < 1) n = 1;
   // ... and the partial image [parts][C][2] doubles is written once and read once: at most 4 MB of it per group (wide layers:
@@ -343,6 +398,17 @@ inline int parts_for(int64_t P, int C) {
 #define BNQ_NT(C, ...)                                   \
   do {                                                   \
     if (threads_for(C) == 512) {                         \
+      constexpr int NTV = 512;                           \
+      __VA_ARGS__;                                       \
+    } else {                                             \
+      constexpr int NTV = kT;                            \
+      __VA_ARGS__;                                       \
+    }                                                    \
+  } while (0)
+
+#define BNQ_SUMS_NT(C, ...)                              \
+  do {                                                   \
+    if (sums_threads(C) == 512) {                        \
       constexpr int NTV = 512;                           \
       __VA_ARGS__;                                       \
     } else {                                             \
@@ -369,10 +435,17 @@ inline float* ktot_of(void* ws, int C, int groups) {
 }
 }  // namespace
 
+size_t alignq_bnq_mask_bytes(int64_t P, int C, int groups) {
+  if (P < 1 || C < 4 || groups < 1 || groups > ALIGNQ_BNQ_MAX_GROUPS) return 0;
+  return (size_t)groups * (size_t)mask_words(P * (C >> 2)) * sizeof(unsigned long long);
+}
+
 int alignq_bnq_fwd(const float* z, int64_t P, int C, int groups, const float* gamma, const float* beta, float* running_mean,
                    float* running_var, int64_t* num_batches_tracked, float momentum, float bn_eps, int k, float act_range,
-                   int formula, int relu, float* ab, float* save, float* y, void* ws, void* stream) {
+                   int formula, int relu, float* ab, float* save, float* y, void* mask, void* ws, void* stream) {
   if (!z || !ab || !save || !y || !ws || P < 2 || bad_groups(groups)) return ALIGNQ_EINVAL;
+  if (reinterpret_cast<uintptr_t>(mask) & 15) return ALIGNQ_EINVAL;
+  unsigned long long* mk = reinterpret_cast<unsigned long long*>(mask);
   if (!((k >= 1 && k <= 16) || k == 32)) return ALIGNQ_EINVAL;
   if (formula != ALIGNQ_FORMULA_ADMM && formula != ALIGNQ_FORMULA_CDF) return ALIGNQ_EINVAL;
   if (bad_c(C)) return ALIGNQ_EUNSUPPORTED;
@@ -380,7 +453,7 @@ int alignq_bnq_fwd(const float* z, int64_t P, int C, int groups, const float* ga
   hipStream_t st = (hipStream_t)stream;
   double* part = reinterpret_cast<double*>(ws);
   const int np = parts_for(P, C);
-  BNQ_NT(C, hipLaunchKernelGGL((bnq_sums_kernel<0, NTV>), dim3(np, groups), dim3(NTV), 0, st, z, nullptr, nullptr, nullptr, nullptr, P, C,
+  BNQ_SUMS_NT(C, hipLaunchKernelGGL((bnq_sums_kernel<0, NTV>), dim3(np, groups), dim3(NTV), 0, st, z, nullptr, nullptr, nullptr, nullptr, P, C,
                      act_range, 0, part));
   hipLaunchKernelGGL(bnq_finalize_kernel, dim3((C + 3) / 4), dim3(kT), 0, st, (const double*)part, np, P, C, gamma, beta,
                      running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), momentum, bn_eps, ab, save,
@@ -388,16 +461,19 @@ int alignq_bnq_fwd(const float* z, int64_t P, int C, int groups, const float* ga
   const int64_t nvec = P * (C >> 2);
   if (formula == ALIGNQ_FORMULA_ADMM)
     BNQ_NT(C, hipLaunchKernelGGL((bnq_apply_fwd_kernel<0, NTV>), dim3(tiles(nvec, kUa, NTV), groups), dim3(NTV), 0, st, z, (const float*)ab, nvec, C, k,
-                       act_range, relu, y));
+                       act_range, relu, y, mk));
   else
     BNQ_NT(C, hipLaunchKernelGGL((bnq_apply_fwd_kernel<1, NTV>), dim3(tiles(nvec, kUa, NTV), groups), dim3(NTV), 0, st, z, (const float*)ab, nvec, C, k,
-                       act_range, relu, y));
+                       act_range, relu, y, mk));
   return hipGetLastError() == hipSuccess ? 0 : ALIGNQ_EINVAL;
 }
 
-int alignq_bnq_bwd(const float* g, const float* z, const float* y, const float* ab, const float* save, int64_t P, int C,
-                   int groups, float act_range, int relu, float* dz, float* dgamma, float* dbeta, void* ws, void* stream) {
-  if (!g || !z || !ab || !save || !dz || !ws || P < 2 || (relu && !y) || bad_groups(groups)) return ALIGNQ_EINVAL;
+int alignq_bnq_bwd(const float* g, const float* z, const float* y, const void* mask, const float* ab, const float* save, int64_t P,
+                   int C, int groups, float act_range, int relu, float* dz, float* dgamma, float* dbeta, void* ws, void* stream) {
+  if (!g || !z || !ab || !save || !dz || !ws || P < 2 || (relu && !y && !mask) || bad_groups(groups)) return ALIGNQ_EINVAL;
+  if (reinterpret_cast<uintptr_t>(mask) & 15) return ALIGNQ_EINVAL;
+  const unsigned long long* mk = reinterpret_cast<const unsigned long long*>(mask);
+  if (mk) y = nullptr;          // one source for the ReLU mask: the bits when they are given
   if (bad_c(C)) return ALIGNQ_EUNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(dz) |
        reinterpret_cast<uintptr_t>(y)) & 15)
@@ -406,12 +482,12 @@ int alignq_bnq_bwd(const float* g, const float* z, const float* y, const float* 
   double* part = reinterpret_cast<double*>(ws);
   float* ktot = ktot_of(ws, C, groups);
   const int np = parts_for(P, C);
-  BNQ_NT(C, hipLaunchKernelGGL((bnq_sums_kernel<1, NTV>), dim3(np, groups), dim3(NTV), 0, st, z, g, y, ab, save, P, C, act_range, relu, part));
+  BNQ_SUMS_NT(C, hipLaunchKernelGGL((bnq_sums_kernel<1, NTV>), dim3(np, groups), dim3(NTV), 0, st, z, g, y, ab, save, P, C, act_range, relu, part, mk));
   hipLaunchKernelGGL(bnq_finalize_bwd_kernel, dim3((C + 3) / 4), dim3(kT), 0, st, (const double*)part, np, P, C, ktot,
                      dgamma, dbeta, groups);
   const int64_t nvec = P * (C >> 2);
   BNQ_NT(C, hipLaunchKernelGGL((bnq_apply_bwd_kernel<NTV>), dim3(tiles(nvec, 2, NTV), groups), dim3(NTV), 0, st, g, z, y, ab, save, (const float*)ktot, nvec,
-                     C, act_range, relu, 0, dz));
+                     C, act_range, relu, 0, dz, mk));
   return hipGetLastError() == hipSuccess ? 0 : ALIGNQ_EINVAL;
 }
 
@@ -425,7 +501,7 @@ int alignq_bnq_stats(const float* z, int64_t P, int C, int groups, const float* 
   hipStream_t st = (hipStream_t)stream;
   double* part = reinterpret_cast<double*>(ws);
   const int np = parts_for(P, C);
-  BNQ_NT(C, hipLaunchKernelGGL((bnq_sums_kernel<0, NTV>), dim3(np, groups), dim3(NTV), 0, st, z, nullptr, nullptr, nullptr, nullptr, P, C, 0.f, 0, part));
+  BNQ_SUMS_NT(C, hipLaunchKernelGGL((bnq_sums_kernel<0, NTV>), dim3(np, groups), dim3(NTV), 0, st, z, nullptr, nullptr, nullptr, nullptr, P, C, 0.f, 0, part));
   hipLaunchKernelGGL(bnq_finalize_kernel, dim3((C + 3) / 4), dim3(kT), 0, st, (const double*)part, np, P, C, gamma, beta,
                      running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), momentum, bn_eps, ab, save,
                      groups);
@@ -451,7 +527,7 @@ int alignq_bnq_bwd_dx(const float* dx, const float* z, const float* ab, const fl
   double* part = reinterpret_cast<double*>(ws);
   float* ktot = ktot_of(ws, C, groups);
   const int np = parts_for(P, C);
-  BNQ_NT(C, hipLaunchKernelGGL((bnq_sums_kernel<2, NTV>), dim3(np, groups), dim3(NTV), 0, st, z, dx, nullptr, ab, save, P, C, 0.f, 0, part));
+  BNQ_SUMS_NT(C, hipLaunchKernelGGL((bnq_sums_kernel<2, NTV>), dim3(np, groups), dim3(NTV), 0, st, z, dx, nullptr, ab, save, P, C, 0.f, 0, part));
   hipLaunchKernelGGL(bnq_finalize_bwd_kernel, dim3((C + 3) / 4), dim3(kT), 0, st, (const double*)part, np, P, C, ktot,
                      dgamma, dbeta, groups);
   const int64_t nvec = P * (C >> 2);
@@ -461,3 +537,20 @@ int alignq_bnq_bwd_dx(const float* dx, const float* z, const float* ab, const fl
 }
 
 }  // extern "C"
+
+// The batch-norm backward when the per-channel sums already lie in ws (site1_bwd_kernel<true, true> leaves them there)
+namespace alignq_site {
+int launch_bnq_bwd_from_parts(const float* dx, const float* z, const float* ab, const float* save, int64_t P, int C, int groups,
+                              int nparts, float* dz, float* dgamma, float* dbeta, void* ws, hipStream_t st) {
+  if (!dx || !z || !ab || !save || !dz || !ws || P < 2 || bad_groups(groups) || nparts < 1 || nparts > kParts) return ALIGNQ_EINVAL;
+  if (bad_c(C)) return ALIGNQ_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(dz)) & 15) return ALIGNQ_EINVAL;
+  float* ktot = ktot_of(ws, C, groups);
+  hipLaunchKernelGGL(bnq_finalize_bwd_kernel, dim3((C + 3) / 4), dim3(kT), 0, st, (const double*)ws, nparts, P, C, ktot, dgamma, dbeta,
+                     groups);
+  const int64_t nvec = P * (C >> 2);
+  BNQ_NT(C, hipLaunchKernelGGL((bnq_apply_bwd_kernel<NTV>), dim3(tiles(nvec, 2, NTV), groups), dim3(NTV), 0, st, dx, z, nullptr, ab, save,
+                     (const float*)ktot, nvec, C, 0.f, 0, 1, dz));
+  return hipGetLastError() == hipSuccess ? 0 : ALIGNQ_EINVAL;
+}
+}  // namespace alignq_site

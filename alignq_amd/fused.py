@@ -628,11 +628,15 @@ class BNQuantReluFn(torch.autograd.Function):
         save = torch.empty(groups, 2, C, dtype=torch.float32, device=dev)
         y = torch.empty_like(z)
         ws = torch.empty(lib.alignq_bnq_ws_bytes(C, groups), dtype=torch.uint8, device=dev)
+        # the ReLU mask the backward needs, one bit per element (round 4): the node keeps 1/32 of a tensor instead of reading the
+        # fp32 y twice; y itself belongs to whoever consumes it
+        mask = torch.empty(lib.alignq_bnq_mask_bytes(P, C, groups), dtype=torch.uint8, device=dev) if (relu and _BNQ_BITMASK) else None
         L.check(lib.alignq_bnq_fwd(L.ptr(z), P, C, groups, L.ptr(weight), L.ptr(bias), L.ptr(running_mean), L.ptr(running_var),
                                    L.ptr(nbt), float(momentum), float(bn_eps), int(k), float(act_range), int(formula),
-                                   int(bool(relu)), L.ptr(ab), L.ptr(save), L.ptr(y), L.ptr(ws), L.stream_ptr()),
+                                   int(bool(relu)), L.ptr(ab), L.ptr(save), L.ptr(y), L.ptr(mask), L.ptr(ws), L.stream_ptr()),
                 "alignq_bnq_fwd")
-        ctx.save_for_backward(z, y if relu else None, ab, save)
+        ctx.save_for_backward(z, (mask if mask is not None else y) if relu else None, ab, save)
+        ctx.bitmask = mask is not None
         ctx.cfg = (float(act_range), bool(relu), weight is not None, bias is not None, int(groups))
         ctx.mark_non_differentiable(*[t for t in (running_mean, running_var, nbt) if t is not None])
         return y
@@ -649,7 +653,8 @@ class BNQuantReluFn(torch.autograd.Function):
         dgamma = torch.empty(C, dtype=torch.float32, device=z.device) if has_w else None
         dbeta = torch.empty(C, dtype=torch.float32, device=z.device) if has_b else None
         ws = torch.empty(lib.alignq_bnq_ws_bytes(C, groups), dtype=torch.uint8, device=z.device)
-        L.check(lib.alignq_bnq_bwd(L.ptr(g), L.ptr(z), L.ptr(y), L.ptr(ab), L.ptr(save), Bg * H * W, C, groups, act_range,
+        ym, mk = (None, y) if ctx.bitmask else (y, None)
+        L.check(lib.alignq_bnq_bwd(L.ptr(g), L.ptr(z), L.ptr(ym), L.ptr(mk), L.ptr(ab), L.ptr(save), Bg * H * W, C, groups, act_range,
                                    int(relu), L.ptr(dz), L.ptr(dgamma), L.ptr(dbeta), L.ptr(ws), L.stream_ptr()),
                 "alignq_bnq_bwd")
         return dz, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
@@ -729,6 +734,8 @@ def bn_only(bn, z, groups=1):
 
 
 _S1_MASK_IN_KERNEL = os.environ.get("ALIGNQ_S1_MASK", "1") != "0"
+_BNQ_BITMASK = os.environ.get("ALIGNQ_BNQ_BITMASK", "1") != "0"     # A/B aid: 0 = the backward reads the fp32 y for the ReLU mask
+_S1_BN_SUMS = os.environ.get("ALIGNQ_S1_BN_SUMS", "1") != "0"      # A/B aid: 0 = alignq_site1_groups_bwd + alignq_bnq_bwd_dx
 
 
 class BNSite1Fn(torch.autograd.Function):
@@ -745,7 +752,8 @@ class BNSite1Fn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, weight, bias, running_mean, running_var, nbt, momentum, bn_eps, residual, alterD, gamma, k,
-                act_range, eps, mu, rho, groups=1):
+                act_range, eps, mu, rho, groups=1, tok=None):
+        ctx.tok = tok             # GradFork's mailbox (see there): a dict shared with whoever forks this node's output
         z = L.dense_f32(z, "conv output")
         A, Gm = L.dev_f32(alterD, "alterD"), L.dev_f32(gamma, "gamma")
         Bt, C, H, W = z.shape
@@ -795,6 +803,13 @@ class BNSite1Fn(torch.autograd.Function):
         lib, dev = L.load(), z.device
         st = L.stream_ptr()
         g_m = None
+        g_y2 = ctx.tok.pop("extra", None) if ctx.tok is not None else None      # the shortcut's addend, left by GradFork.backward
+        if g_y2 is not None:
+            if g_y is None or not (_S1_MASK_IN_KERNEL and _S1_BN_SUMS) or g_y2.shape != z.shape:
+                g_y = g_y2 if g_y is None else g_y + g_y2                        # (forms without the second pointer: add here)
+                g_y2 = None
+            else:
+                g_y2 = L.like_layout(g_y2, z)
         if g_y is not None:      # the fused ReLU's mask is applied by the site kernel, which also leaves the masked gradient in g_m
             g_y = L.like_layout(g_y, z)
             if _S1_MASK_IN_KERNEL:
@@ -823,9 +838,17 @@ class BNSite1Fn(torch.autograd.Function):
                 L.ptr_array([scal[gi] for gi in range(groups)]), L.ptr(g_loss), L.i64_array([F] * groups), B, A.shape[0], mu,
                 L.ptr_array(Sg), L.ptr_array([dA[gi] for gi in range(groups)]), L.ptr_array([dG[gi] for gi in range(groups)]), st),
                 "alignq_site_prep_fused_multi")
-            L.check(lib.alignq_site1_groups_bwd(L.ptr(g_y), L.ptr(None if g_y is None else y), L.ptr(S), L.ptr(z), L.ptr(ab), C,
-                                                L.ptr(stats), B, F, groups, act_range, eps, L.ptr(dx), L.ptr(g_m), st),
-                    "alignq_site1_groups_bwd")
+            if _S1_BN_SUMS:
+                # round 4: the site backward leaves the batch-norm backward's per-channel sums (C % 32 == 0), the finalisation and
+                # dz (in place) follow in the same entry: no separate pass over dx and z
+                L.check(lib.alignq_site1_groups_bwd_bn(L.ptr(g_y), L.ptr(g_y2), L.ptr(None if g_y is None else y), L.ptr(S), L.ptr(z), L.ptr(ab),
+                                                       L.ptr(save), C, L.ptr(stats), B, F, groups, act_range, eps, L.ptr(dx),
+                                                       L.ptr(g_m), L.ptr(dgamma), L.ptr(dbeta), L.ptr(ws_bn), st),
+                        "alignq_site1_groups_bwd_bn")
+            else:
+                L.check(lib.alignq_site1_groups_bwd(L.ptr(g_y), L.ptr(None if g_y is None else y), L.ptr(S), L.ptr(z), L.ptr(ab), C,
+                                                    L.ptr(stats), B, F, groups, act_range, eps, L.ptr(dx), L.ptr(g_m), st),
+                        "alignq_site1_groups_bwd")
         else:
             for gi in range(groups):
                 sl = slice(gi * B, (gi + 1) * B)
@@ -834,8 +857,9 @@ class BNSite1Fn(torch.autograd.Function):
                 L.check(lib.alignq_site_bwd_apply_ab(L.ptr(None if g_y is None else g_y[sl]), L.ptr(S), L.ptr(z[sl]), L.ptr(ab[gi]), C,
                                                      L.ptr(stats[gi]), B, F, act_range, eps, L.ptr(dx[sl]), st),
                         "alignq_site_bwd_apply_ab")
-        L.check(lib.alignq_bnq_bwd_dx(L.ptr(dx), L.ptr(z), L.ptr(ab), L.ptr(save), P, C, groups, L.ptr(dx), L.ptr(dgamma),
-                                      L.ptr(dbeta), L.ptr(ws_bn), st), "alignq_bnq_bwd_dx")
+        if not (_S1_MASK_IN_KERNEL and _S1_BN_SUMS):
+            L.check(lib.alignq_bnq_bwd_dx(L.ptr(dx), L.ptr(z), L.ptr(ab), L.ptr(save), P, C, groups, L.ptr(dx), L.ptr(dgamma),
+                                          L.ptr(dbeta), L.ptr(ws_bn), st), "alignq_bnq_bwd_dx")
 
         def red(t):                                  # the slices' alterD / gamma gradients: one elementwise add, not a reduce
             out = t[0]
@@ -848,7 +872,7 @@ class BNSite1Fn(torch.autograd.Function):
         else:
             rA, rG = red(dA), red(dG)
         return (dx, dgamma, dbeta, None, None, None, None, None, g_m if has_res else None, rA, rG, None, None,
-                None, None, None, None)
+                None, None, None, None, None)
 
 
 def bn_site_res_relu(bn, act, z, residual, eps, groups=1):
@@ -862,11 +886,48 @@ def bn_site_res_relu(bn, act, z, residual, eps, groups=1):
             and residual.dtype == torch.float32 and z.shape[0] // groups <= act.opt.alterD.shape[0]):
         return None
     admm = act.opt
+    tok = {} if _GRAD_FORK else None
     y, loss, D = BNSite1Fn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum,
                                  bn.eps, residual, admm.alterD, admm.gamma, act.a_bit, config.args.act_range, eps, admm.mu, admm.rho,
-                                 groups)
+                                 groups, tok)
+    if tok is not None:
+        y._alignq_site_tok = tok          # read by fork_block_input (the next bottleneck)
     admm.D = D
     return y, loss
+
+
+_GRAD_FORK = os.environ.get("ALIGNQ_GRAD_FORK", "1") != "0"      # A/B aid: 0 = autograd adds the two gradients itself
+
+
+class GradFork(torch.autograd.Function):
+    """x -> (x, x) for a block input that feeds BOTH the block's first convolution and its shortcut (dann_office/model/
+    resnet.py:131-154 without a downsample branch) when x is the output of a folded small-batch site (BNSite1Fn).  Autograd
+    would form grad x = g_conv + g_shortcut in an elementwise pass of its own (12 B/element at every such block input); here
+    the backward hands g_conv on as "the" gradient and leaves g_shortcut in the producing node's mailbox `tok`; BNSite1Fn.backward
+    takes it out and gives both pointers to the site kernel, which reads g + g2 (the same fp32 sum).  The mailbox is a dict
+    created by bn_site_res_relu and shared by exactly these two nodes, so nothing can pick up a stale or foreign addend; it is
+    only used when x carries that token, i.e. when its producer is known to honour it."""
+
+    @staticmethod
+    def forward(ctx, x, tok):
+        ctx.tok = tok
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g_a, g_b):
+        if g_a is None or g_b is None:
+            return (g_b if g_a is None else g_a), None
+        assert "extra" not in ctx.tok, "GradFork: the producing site has not consumed the previous addend"
+        ctx.tok["extra"] = g_b
+        return g_a, None
+
+
+def fork_block_input(x):
+    """(x for the convolution branch, x for the shortcut): the forked pair when x comes from a folded small-batch site."""
+    tok = getattr(x, "_alignq_site_tok", None)
+    if tok is None or not x.requires_grad or not torch.is_grad_enabled():
+        return x, x
+    return GradFork.apply(x, tok)
 
 
 def bn_act_relu(bn, act, z, formula, relu=True, groups=1):

@@ -50,6 +50,9 @@ class Bottleneck(nn.Module):
         trans_loss = 0.
         identity = x
         if groups > 1:
+            if self.downsample is None:       # x feeds conv1 AND the shortcut: their gradients meet in the producing site's kernel
+                from . import fused
+                x, identity = fused.fork_block_input(x)
             out = self.act_q1.forward_bn_relu(self.bn1, self.conv1(x), groups)
             out = self.act_q2.forward_bn_relu(self.bn2, self.conv2(out), groups)
             if self.downsample is not None:
@@ -58,6 +61,9 @@ class Bottleneck(nn.Module):
             out, loss = self.act_q3.forward_bn_res_relu(self.bn3, self.conv3(out), identity, groups)
             return out, loss              # (= 0. + loss without the launch that forms it)
         if getattr(self, "fuse_bn", False):         # opt-in (OfficeTrainStep): batch-norm + quantiser + ReLU as one chain
+            if self.downsample is None:
+                from . import fused
+                x, identity = fused.fork_block_input(x)
             out = self.act_q1.forward_bn_relu(self.bn1, self.conv1(x))
             out = self.act_q2.forward_bn_relu(self.bn2, self.conv2(out))
         elif getattr(self, "fuse_relu", False):     # opt-in: quantiser + ReLU in one launch each way

@@ -331,6 +331,7 @@ def measure_kernels(dev, B, k, site_F_counts, hw_of_F, folded=True, nhwc=False, 
     del x, y, g, xs, gs, ys
     if shapes:
         out["roofline_shapes"] = measure_roofline_shapes(dev, k)
+        out["office_shapes"] = measure_office_shapes(dev, k)
     n_sites = sum(site_F_counts.values())
     dom = max(("site_partials", "site_bwd"), key=lambda kname: per_step[kname][0])
     t_sum, fl_sum = per_step[dom]
@@ -441,6 +442,139 @@ def measure_roofline_shapes(dev, k):
                                  "quantise: reads w twice (stats, apply), writes q, cdf, pdf = 20 B/element",
                                  "bwd_us": t_wb * 1e6, "bwd_hbm_gbs": 20.0 * nw / t_wb / 1e9, "bwd_note": "two passes: reads g, w "
                                  "twice, writes dw = 20 B/element", "mbytes": 4.0 * nw / 1e6}
+    return out
+
+
+def measure_office_shapes(dev, k):
+    """Configuration 5's in-scope chains at the network's own shapes, as OfficeTrainStep(dual=True) launches
+    them: channels-last tensors holding the source and the target batch back to back (groups = 2 x 28 samples).
+      bnq_*    : `relu(act_q(bn(z)))` of the plain sites (dann_office/model/resnet.py:134-143, stem :230-233) folded:
+                 alignq_bnq_fwd (statistics pass + apply pass: 4 + 8 = 12 B/element, + 1 bit of ReLU mask) and alignq_bnq_bwd (sums pass
+                 g, z, mask + apply pass g, z, mask -> dz: 8 + 12 + 2 bits = 20.25 B/element; with the mask read from the fp32 y: 28); `stats_us` is the statistics pass alone (alignq_bnq_stats), apply = chain - stats.
+      site_*   : the bottleneck tail `relu(act_q3(bn3(z))[0] + identity)` (resnet.py:146-154) at layer4's [28, 100352] and layer1's
+                 [28, 802816]: forward alignq_bnq_stats + alignq_site1_groups_fwd + alignq_site1_groups_reduce_loss (reads z twice and the
+                 residual, writes y: 16 B/element), backward alignq_site_prep_fused_multi + alignq_site1_groups_bwd + alignq_bnq_bwd_dx
+                 (alignq_site1_groups_bwd_bn: g, y, z -> dx, dres and the batch-norm sums; then dx, z -> dz: 32 B/element;
+                 `bwd_us_with_sums_pass` is round 3's form with alignq_bnq_bwd_dx's own pass over dx and z, 40 B/element).
+    HIP events on the launch stream, 4 rotating operand sets (a launch finds its operands where the step finds them)."""
+    from alignq_amd import _lib as L
+    lib = L.load()
+    st = L.stream_ptr()
+    p = L.ptr
+    out = {}
+    R, G = 4, 2
+    for C, H in ((256, 56), (64, 112)):
+        Bt = 28 * G
+        P = 28 * H * H
+        n = Bt * C * H * H
+        zs = [torch.randn(Bt, H, H, C, device=dev) * 1.3 + 0.2 for _ in range(R)]
+        gs = [torch.randn(Bt, H, H, C, device=dev) * 0.01 for _ in range(R)]
+        ys, dzs = ([torch.empty(Bt, H, H, C, device=dev) for _ in range(R)] for _ in range(2))
+        gam, bet = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev) * 0.1
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        nbt = torch.zeros((), dtype=torch.int64, device=dev)
+        ab, save = torch.empty(G, 2, C, device=dev), torch.empty(G, 2, C, device=dev)
+        dgam, dbet = torch.empty(C, device=dev), torch.empty(C, device=dev)
+        ws = torch.empty(lib.alignq_bnq_ws_bytes(C, G), dtype=torch.uint8, device=dev)
+        masks = [torch.empty(lib.alignq_bnq_mask_bytes(P, C, G), dtype=torch.uint8, device=dev) for _ in range(R)]
+
+        def f_fwd(i):
+            L.check(lib.alignq_bnq_fwd(p(zs[i]), P, C, G, p(gam), p(bet), p(rm), p(rv), p(nbt), 0.1, 1e-5, k, 2.0, 0, 1, p(ab), p(save),
+                                       p(ys[i]), p(masks[i]), p(ws), st), "alignq_bnq_fwd")
+
+        def f_stats(i):
+            L.check(lib.alignq_bnq_stats(p(zs[i]), P, C, G, p(gam), p(bet), p(rm), p(rv), p(nbt), 0.1, 1e-5, p(ab), p(save), p(ws), st),
+                    "alignq_bnq_stats")
+
+        def f_bwd(i):
+            L.check(lib.alignq_bnq_bwd(p(gs[i]), p(zs[i]), None, p(masks[i]), p(ab), p(save), P, C, G, 2.0, 1, p(dzs[i]), p(dgam), p(dbet),
+                                       p(ws), st), "alignq_bnq_bwd")
+
+        def f_bwd_y(i):           # round 3's form: the ReLU mask from the fp32 y (28 B/element)
+            L.check(lib.alignq_bnq_bwd(p(gs[i]), p(zs[i]), p(ys[i]), None, p(ab), p(save), P, C, G, 2.0, 1, p(dzs[i]), p(dgam), p(dbet),
+                                       p(ws), st), "alignq_bnq_bwd")
+        for i in range(R):
+            f_fwd(i)
+        t_f, t_s, t_b = time_call_rot(f_fwd, 20, R), time_call_rot(f_stats, 20, R), time_call_rot(f_bwd, 20, R)
+        t_by = time_call_rot(f_bwd_y, 20, R)
+        t_a = max(t_f - t_s, 1e-9)
+        out[f"bnq_{Bt}x{C}x{H}x{H}"] = {
+            "elements": n, "fwd_us": t_f * 1e6, "fwd_hbm_gbs": 12.0 * n / t_f / 1e9, "fwd_frac_of_8TBs": 12.0 * n / t_f / 1e9 / HBM_PEAK_GBS,
+            "stats_us": t_s * 1e6, "stats_frac_of_8TBs": 4.0 * n / t_s / 1e9 / HBM_PEAK_GBS,
+            "apply_fwd_us": t_a * 1e6, "apply_fwd_frac_of_8TBs": 8.0 * n / t_a / 1e9 / HBM_PEAK_GBS,
+            "bwd_us": t_b * 1e6, "bwd_hbm_gbs": 20.25 * n / t_b / 1e9, "bwd_frac_of_8TBs": 20.25 * n / t_b / 1e9 / HBM_PEAK_GBS,
+            "bwd_us_mask_from_fp32_y": t_by * 1e6, "fwd_bytes_per_elem": 12.125, "bwd_bytes_per_elem": 20.25}
+        del zs, gs, ys, dzs
+    for C, H in ((2048, 7), (256, 56)):
+        B, Bt = 28, 28 * G
+        F, P = C * H * H, 28 * H * H
+        n = Bt * F
+        zs = [torch.randn(Bt, H, H, C, device=dev) * 1.1 + 0.15 for _ in range(R)]
+        rs = [torch.relu(torch.randn(Bt, H, H, C, device=dev)) for _ in range(R)]
+        gs = [torch.randn(Bt, H, H, C, device=dev) * 0.01 for _ in range(R)]
+        ys, dxs, dress = ([torch.empty(Bt, H, H, C, device=dev) for _ in range(R)] for _ in range(3))
+        gam, bet = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev) * 0.1
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        nbt = torch.zeros((), dtype=torch.int64, device=dev)
+        ab, save = torch.empty(G, 2, C, device=dev), torch.empty(G, 2, C, device=dev)
+        dgam, dbet = torch.empty(C, device=dev), torch.empty(C, device=dev)
+        ws_bn = torch.empty(lib.alignq_bnq_ws_bytes(C, G), dtype=torch.uint8, device=dev)
+        stats = torch.empty(G, 4, F, device=dev)
+        D, scal = torch.empty(G, B, B, device=dev), torch.empty(G, 4, device=dev)
+        A, Gm = torch.rand(B, B, device=dev), torch.rand(B, B, device=dev)
+        dA, dG = torch.empty(G, B, B, device=dev), torch.empty(G, B, B, device=dev)
+        one = torch.ones((), device=dev)
+        wsb = lib.alignq_site_ws_bytes(B, F)
+        ws = torch.empty(wsb * G, dtype=torch.uint8, device=dev)
+        sb = lib.alignq_site_bwd_ws_bytes(B)
+        S = torch.empty(sb * G, dtype=torch.uint8, device=dev)
+        Sg = [S[i * sb:(i + 1) * sb] for i in range(G)]
+        prep_args = (G, L.ptr_array([D[i] for i in range(G)]), L.ptr_array([A] * G), L.ptr_array([Gm] * G),
+                     L.ptr_array([scal[i] for i in range(G)]), p(one), L.i64_array([F] * G), B, B, 0.2, L.ptr_array(Sg),
+                     L.ptr_array([dA[i] for i in range(G)]), L.ptr_array([dG[i] for i in range(G)]), st)
+
+        def s_fwd(i):
+            L.check(lib.alignq_bnq_stats(p(zs[i]), P, C, G, p(gam), p(bet), p(rm), p(rv), p(nbt), 0.1, 1e-5, p(ab), p(save), p(ws_bn), st),
+                    "alignq_bnq_stats")
+            L.check(lib.alignq_site1_groups_fwd(p(zs[i]), p(ab), C, B, F, G, k, 2.0, 1e-5, p(rs[i]), 1, p(ys[i]), p(stats), p(ws), st),
+                    "alignq_site1_groups_fwd")
+            L.check(lib.alignq_site1_groups_reduce_loss(p(ws), B, F, G, p(D), p(A), p(Gm), B, 0.2, 0.3, p(scal), st),
+                    "alignq_site1_groups_reduce_loss")
+
+        def s_fwd_site(i):
+            L.check(lib.alignq_site1_groups_fwd(p(zs[i]), p(ab), C, B, F, G, k, 2.0, 1e-5, p(rs[i]), 1, p(ys[i]), p(stats), p(ws), st),
+                    "alignq_site1_groups_fwd")
+
+        def s_bwd(i):
+            L.check(lib.alignq_site_prep_fused_multi(*prep_args), "alignq_site_prep_fused_multi")
+            L.check(lib.alignq_site1_groups_bwd(p(gs[i]), p(ys[i]), p(S), p(zs[i]), p(ab), C, p(stats), B, F, G, 2.0, 1e-5, p(dxs[i]),
+                                                p(dress[i]), st), "alignq_site1_groups_bwd")
+            L.check(lib.alignq_bnq_bwd_dx(p(dxs[i]), p(zs[i]), p(ab), p(save), P, C, G, p(dxs[i]), p(dgam), p(dbet), p(ws_bn), st),
+                    "alignq_bnq_bwd_dx")
+
+        def s_bwd_bn(i):          # round 4 (the step's path): the site backward leaves the batch-norm sums; finalisation + dz follow
+            L.check(lib.alignq_site_prep_fused_multi(*prep_args), "alignq_site_prep_fused_multi")
+            L.check(lib.alignq_site1_groups_bwd_bn(p(gs[i]), None, p(ys[i]), p(S), p(zs[i]), p(ab), p(save), C, p(stats), B, F, G, 2.0, 1e-5,
+                                                   p(dxs[i]), p(dress[i]), p(dgam), p(dbet), p(ws_bn), st), "alignq_site1_groups_bwd_bn")
+
+        def s_bwd_site(i):
+            L.check(lib.alignq_site1_groups_bwd(p(gs[i]), p(ys[i]), p(S), p(zs[i]), p(ab), C, p(stats), B, F, G, 2.0, 1e-5, p(dxs[i]),
+                                                p(dress[i]), st), "alignq_site1_groups_bwd")
+        for i in range(R):
+            s_fwd(i)       # (the statistics of the LAST set stay in `stats` for the backward launches: timing only)
+        t_f, t_fs = time_call_rot(s_fwd, 20, R), time_call_rot(s_fwd_site, 20, R)
+        t_b5, t_bs = time_call_rot(s_bwd, 20, R), time_call_rot(s_bwd_site, 20, R)
+        t_b = time_call_rot(s_bwd_bn, 20, R)
+        out[f"bn_site_2x{B}x{F}"] = {
+            "elements": n, "fwd_us": t_f * 1e6, "fwd_hbm_gbs": 16.0 * n / t_f / 1e9, "fwd_frac_of_8TBs": 16.0 * n / t_f / 1e9 / HBM_PEAK_GBS,
+            "site_fwd_kernel_us": t_fs * 1e6, "site_fwd_kernel_frac_of_8TBs": 12.0 * n / t_fs / 1e9 / HBM_PEAK_GBS,
+            "bwd_us": t_b * 1e6, "bwd_hbm_gbs": 32.0 * n / t_b / 1e9, "bwd_frac_of_8TBs": 32.0 * n / t_b / 1e9 / HBM_PEAK_GBS,
+            "bwd_us_with_sums_pass": t_b5 * 1e6,
+            "site_bwd_kernel_us": t_bs * 1e6, "site_bwd_kernel_frac_of_8TBs": 20.0 * n / t_bs / 1e9 / HBM_PEAK_GBS,
+            "fwd_bytes_per_elem": 16, "bwd_bytes_per_elem": 32,
+            "note": "site_*_kernel: alignq_site1_groups_fwd (z, residual -> y: 12 B/element) / alignq_site1_groups_bwd (g, y, z -> dx, "
+                    "dres: 20 B/element) alone"}
+        del zs, rs, gs, ys, dxs, dress
     return out
 
 

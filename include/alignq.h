@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALIGNQ_ABI_VERSION 11
+#define ALIGNQ_ABI_VERSION 12
 
 #define ALIGNQ_FORMULA_ADMM 0
 #define ALIGNQ_FORMULA_CDF 1
@@ -494,12 +494,28 @@ int alignq_site1_groups_reduce_loss(void* ws, int B, int64_t F, int groups, floa
 int alignq_site1_groups_bwd(const float* g, const float* y, const float* S, const float* z, const float* ab, int C,
                             const float* stats, int B, int64_t F, int groups, float act_range, float eps, float* dx,
                             float* dres, void* stream);
+/* alignq_site1_groups_bwd + alignq_bnq_bwd_dx as ONE entry (round 4): the backward of `relu(act_q3(bn3(z))[0] + identity)`
+ * (dann_office/model/resnet.py:146-154) from the gradient g of that output to dz, dgamma, dbeta, dres.  When C % 32 == 0 (a
+ * 32-feature sub-tile = 32 channels of one pixel) the site kernel leaves the batch-norm backward's per-channel sums of its own
+ * output in ws_bn, so the separate pass over dx and z is not launched (3 launches: site backward, finalisation, dz in place);
+ * otherwise exactly the two calls it replaces.  save: [groups][2][C] (mean, invstd) of alignq_bnq_stats; dz: [groups][B][F]
+ * (receives dx first, then dz in place); ws_bn: alignq_bnq_ws_bytes(C, groups).  g == NULL: no upstream gradient.
+ * g2 (or NULL): a second addend of the upstream gradient, same layout as g; the kernel reads g + g2 (the sum autograd would
+ * form in a pass of its own where the block's output feeds the next block's convolution AND its shortcut).                  */
+int alignq_site1_groups_bwd_bn(const float* g, const float* g2, const float* y, const float* S, const float* z, const float* ab,
+                               const float* save, int C, const float* stats, int B, int64_t F, int groups, float act_range, float eps,
+                               float* dz, float* dres, float* dgamma, float* dbeta, void* ws_bn, void* stream);
 size_t alignq_bnq_ws_bytes(int C, int groups);
+/* ReLU mask as ONE BIT per element (round 4): alignq_bnq_fwd with mask != NULL also writes [y > 0] for every element
+ * (alignq_bnq_mask_bytes(P, C, groups) bytes, 16-byte aligned; per group and per 64 consecutive channel quads four 64-bit words,
+ * one per quad component: the forward's wave-wide compare results); alignq_bnq_bwd with mask != NULL takes the ReLU mask from
+ * those bits and does not read y (y may be NULL): 20.25 instead of 28 B/element.  Same values either way.                   */
+size_t alignq_bnq_mask_bytes(int64_t P, int C, int groups);
 int alignq_bnq_fwd(const float* z, int64_t P, int C, int groups, const float* gamma, const float* beta, float* running_mean,
                    float* running_var, int64_t* num_batches_tracked, float momentum, float bn_eps, int k, float act_range,
-                   int formula, int relu, float* ab, float* save, float* y, void* ws, void* stream);
-int alignq_bnq_bwd(const float* g, const float* z, const float* y, const float* ab, const float* save, int64_t P, int C,
-                   int groups, float act_range, int relu, float* dz, float* dgamma, float* dbeta, void* ws, void* stream);
+                   int formula, int relu, float* ab, float* save, float* y, void* mask, void* ws, void* stream);
+int alignq_bnq_bwd(const float* g, const float* z, const float* y, const void* mask, const float* ab, const float* save, int64_t P,
+                   int C, int groups, float act_range, int relu, float* dz, float* dgamma, float* dbeta, void* ws, void* stream);
 
 #ifdef __cplusplus
 }
