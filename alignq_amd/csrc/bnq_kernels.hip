@@ -537,20 +537,3 @@ int alignq_bnq_bwd_dx(const float* dx, const float* z, const float* ab, const fl
 }
 
 }  // extern "C"
-
-// The batch-norm backward when the per-channel sums already lie in ws (site1_bwd_kernel<true, true> leaves them there)
-namespace alignq_site {
-int launch_bnq_bwd_from_parts(const float* dx, const float* z, const float* ab, const float* save, int64_t P, int C, int groups,
-                              int nparts, float* dz, float* dgamma, float* dbeta, void* ws, hipStream_t st) {
-  if (!dx || !z || !ab || !save || !dz || !ws || P < 2 || bad_groups(groups) || nparts < 1 || nparts > kParts) return ALIGNQ_EINVAL;
-  if (bad_c(C)) return ALIGNQ_EUNSUPPORTED;
-  if ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(dz)) & 15) return ALIGNQ_EINVAL;
-  float* ktot = ktot_of(ws, C, groups);
-  hipLaunchKernelGGL(bnq_finalize_bwd_kernel, dim3((C + 3) / 4), dim3(kT), 0, st, (const double*)ws, nparts, P, C, ktot, dgamma, dbeta,
-                     groups);
-  const int64_t nvec = P * (C >> 2);
-  BNQ_NT(C, hipLaunchKernelGGL((bnq_apply_bwd_kernel<NTV>), dim3(tiles(nvec, 2, NTV), groups), dim3(NTV), 0, st, dx, z, nullptr, ab, save,
-                     (const float*)ktot, nvec, C, 0.f, 0, 1, dz));
-  return hipGetLastError() == hipSuccess ? 0 : ALIGNQ_EINVAL;
-}
-}  // namespace alignq_site

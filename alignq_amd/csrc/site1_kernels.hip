@@ -311,22 +311,14 @@ __device__ __forceinline__ void acc_to_rows(float* __restrict__ R, int l31, int 
   wave_lds_sync();
 }
 
-// BNS (round 4; folded batch-norm with C % 32 == 0, i.e. a sub-tile = 32 channels of ONE pixel): the kernel also leaves the
-// batch-norm backward's per-channel sums of its own output - sum dx, sum dx * zhat (zhat = (z - mean) * invstd) - so that
-// alignq_bnq_bwd_dx's first pass over dx and z (8 B/element) is not needed.  The sub-tiles are then dealt so that a workgroup
-// stays on ONE 32-channel block (blockIdx.x % (C / 32)) and walks over pixels: a lane's channel is fixed for the launch, its
-// two sums live in registers (double, as in bnq_sums_kernel), the four waves are added in a fixed order at the end:
-// bn_part [groups][gridDim.x / (C / 32)][C][2] doubles, the layout bnq_finalize_bwd_kernel reads.
-template <bool PAIR, bool BNS = false>
+template <bool PAIR>
 __global__ __launch_bounds__(kThreads1, 3) void site1_bwd_kernel(const float* __restrict__ gup, const float* __restrict__ S,
                                                               const float* __restrict__ x,
                                                               const float* __restrict__ stats, int B, int64_t F, float r,
                                                               float eps, float* __restrict__ dx, int n_sub,
                                                               const float* __restrict__ ab, int C,
                                                               const float* __restrict__ ymask, float* __restrict__ dres,
-                                                              int64_t s_gstride, const float* __restrict__ save = nullptr,
-                                                              double* __restrict__ bn_part = nullptr,
-                                                              const float* __restrict__ gup2 = nullptr) {
+                                                              int64_t s_gstride, const float* __restrict__ gup2 = nullptr) {
   {        // blockIdx.y = group (see site1_fwd_kernel); S matrices s_gstride floats apart
     const int64_t gi = blockIdx.y, go = gi * (int64_t)B * F;
     x += go; dx += go;
@@ -337,7 +329,6 @@ __global__ __launch_bounds__(kThreads1, 3) void site1_bwd_kernel(const float* __
     S += gi * s_gstride;
     stats += gi * 4 * F;
     if (ab) ab += gi * 2 * C;
-    if (BNS) { save += gi * 2 * C; bn_part += gi * (int64_t)(gridDim.x / (C >> 5)) * C * 2; }
   }
   __shared__ __attribute__((aligned(16))) unsigned lds[kWaves * WBUF];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -373,15 +364,11 @@ __global__ __launch_bounds__(kThreads1, 3) void site1_bwd_kernel(const float* __
   // prefetching both took the kernel to 256 VGPRs in round 2): the next sub-tile's x rows are requested before this one is used
   // (round 3: requesting the next sub-tile's x rows one iteration ahead, as the forward does, takes this kernel from 141 to 160
   //  VGPRs = two waves per SIMD instead of three: 102.9 us against 83.8 at [28, 802816]; not kept)
-  // BNS: workgroup = (32-channel block cb, pixel lane pb); its waves take pixels pb * 4 + w, + 4 * (workgroups per channel block), ...
-  const int CB = BNS ? (C >> 5) : 1;
-  const int cb = BNS ? (int)(blockIdx.x % CB) : 0, pb = BNS ? (int)(blockIdx.x / CB) : (int)blockIdx.x;
-  const int it_step = (BNS ? (int)(gridDim.x / CB) : (int)gridDim.x) * kWaves, it_lim = BNS ? n_sub / CB : n_sub;
-  // the lane's two running sums live in LDS between sub-tiles (a slot of its own: no synchronisation), not in registers
-  __shared__ double bn_acc[BNS ? 2 * kThreads1 : 2];
-  if (BNS) { bn_acc[2 * tid] = 0.0; bn_acc[2 * tid + 1] = 0.0; }
-  for (int it = pb * kWaves + w; it < it_lim; it += it_step) {
-    const int sub = BNS ? it * CB + cb : it;
+  // the upstream gradient is needed at the very end of a sub-tile only: each lane parks its 16 rows in LDS meanwhile ([4][thread]
+  // quads: conflict-free 16-byte accesses, a slot of its own) - 16 registers fewer across both operand phases of a kernel that
+  // sits at its 168-register cap (three waves per SIMD)
+  __shared__ __attribute__((aligned(16))) float4 g_park[PAIR ? 4 * kThreads1 : 1];
+  for (int sub = blockIdx.x * kWaves + w; sub < n_sub; sub += gridDim.x * kWaves) {
     const int64_t col = (int64_t)sub * SUBF + l31;
     const bool cok = col < F;
     const int64_t colc = cok ? col : F - 1;            // loads: clamped addresses, unconditional, values selected afterwards
@@ -430,18 +417,16 @@ __global__ __launch_bounds__(kThreads1, 3) void site1_bwd_kernel(const float* __
           *reinterpret_cast<float*>(reinterpret_cast<char*>(dres) + ((unsigned)min(RPL * h + q, B - 1) * rowB + colB)) = has_g ? gr[q] : 0.0f;
       }
     }
-    // BNS: the row registers KEEP z (the batch-norm sums at the end need zhat = (z - mean) * invstd) and x = a*z + b is formed
-    // where it is used (XV: one fma per use instead of 16 more live registers: the kernel sits at its 168-register cap).  The
-    // clamped loads hold real elements everywhere, so the zeroing of rows >= B / columns >= F is not needed for that form:
-    // everything they feed (staged words, batch sums, stores) is masked where it is formed.
-#define XV(q) (BNS ? __fmaf_rn(av_p, xr[q], bv) : xr[q])
-    float av_p = av;              // a phase-local copy of `a`, hidden from common-subexpression elimination ACROSS the phases
-    asm volatile("" : "+v"(av_p));
 #pragma unroll
     for (int q = 0; q < RPL; q++) {
       const bool ok = cok && RPL * h + q < B;
-      if (!BNS) xr[q] = ok ? (ab ? __fmaf_rn(av, xr[q], bv) : xr[q]) : 0.0f;
+      xr[q] = ok ? (ab ? __fmaf_rn(av, xr[q], bv) : xr[q]) : 0.0f;
       gr[q] = (has_g && ok) ? gr[q] : 0.0f;
+    }
+    if (PAIR) {
+#pragma unroll
+      for (int q4 = 0; q4 < RPL / 4; q4++)
+        g_park[q4 * kThreads1 + tid] = make_float4(gr[4 * q4], gr[4 * q4 + 1], gr[4 * q4 + 2], gr[4 * q4 + 3]);
     }
     const float mx = cok ? mx_l : 0.f, rx = cok ? rx_l : 0.f;
     const float mt = cok ? mt_l : 0.f, rt = cok ? rt_l : 0.f;
@@ -455,7 +440,7 @@ __global__ __launch_bounds__(kThreads1, 3) void site1_bwd_kernel(const float* __
     {
       unsigned wd[RPL];
 #pragma unroll
-      for (int q = 0; q < RPL; q++) wd[q] = (cok && RPL * h + q < B) ? pack_hi_lo((XV(q) - mx) * rx) : 0u;
+      for (int q = 0; q < RPL; q++) wd[q] = (cok && RPL * h + q < B) ? pack_hi_lo((xr[q] - mx) * rx) : 0u;
       stage_rows(W, l31, h, wd);
     }
     wave_lds_sync();
@@ -470,27 +455,26 @@ __global__ __launch_bounds__(kThreads1, 3) void site1_bwd_kernel(const float* __
       float s0 = 0.f, s1 = 0.f;
 #pragma unroll
       for (int q = 0; q < RPL; q++) {
-        if (RPL * h + q < B) { s0 += d[q]; s1 += d[q] * ((XV(q) - mx) * rx); }
+        if (RPL * h + q < B) { s0 += d[q]; s1 += d[q] * ((xr[q] - mx) * rx); }
       }
       s0 += __shfl_xor(s0, 32, 64);
       s1 += __shfl_xor(s1, 32, 64);
       const float mean_d = s0 * invB, proj = s1 * invBm1 * kap_x;
 #pragma unroll
       for (int q = 0; q < RPL; q++) {
-        const float cx = rx * (d[q] - mean_d - ((XV(q) - mx) * rx) * proj);
+        const float cx = rx * (d[q] - mean_d - ((xr[q] - mx) * rx) * proj);
         out[q] = PAIR ? -cx : cx;          // corr(x,x) enters D with a minus sign
       }
     }
     // ---- t operand (PAIR) -------------------------------------------------------------------------------------
     if (PAIR) {
-      if (BNS) { av_p = av; asm volatile("" : "+v"(av_p)); }
       float th[RPL];
       {
         unsigned wd[RPL];
 #pragma unroll
         for (int q = 0; q < RPL; q++) {
           float t, jac;
-          act_transform_rcp(XV(q), r, rjac, &t, &jac);        // (jac is recomputed below: 16 registers for ~5 instructions)
+          act_transform_rcp(xr[q], r, rjac, &t, &jac);        // (jac is recomputed below: 16 registers for ~5 instructions)
           th[q] = (t - mt) * rt;
           wd[q] = (cok && RPL * h + q < B) ? pack_hi_lo(th[q]) : 0u;
         }
@@ -512,12 +496,17 @@ __global__ __launch_bounds__(kThreads1, 3) void site1_bwd_kernel(const float* __
       s0 += __shfl_xor(s0, 32, 64);
       s1 += __shfl_xor(s1, 32, 64);
       const float mean_d = s0 * invB, proj = s1 * invBm1 * kap_t;
-      if (BNS) { av_p = av; asm volatile("" : "+v"(av_p)); }
 #pragma unroll
-      for (int q = 0; q < RPL; q++) {
-        const float ct = rt * (d[q] - mean_d - th[q] * proj);
-        const float xv = XV(q);
-        out[q] += (gr[q] + ct) * (rjac * __builtin_amdgcn_exp2f(xv * xv * -0.72134752044448170368f));
+      for (int q4 = 0; q4 < RPL / 4; q4++) {
+        const float4 g4 = g_park[q4 * kThreads1 + tid];
+        const float ge[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int q = 4 * q4 + j;
+          const float ct = rt * (d[q] - mean_d - th[q] * proj);
+          const float xv = xr[q];
+          out[q] += (ge[j] + ct) * (rjac * __builtin_amdgcn_exp2f(xv * xv * -0.72134752044448170368f));
+        }
       }
     }
     if (cok) {
@@ -525,36 +514,6 @@ __global__ __launch_bounds__(kThreads1, 3) void site1_bwd_kernel(const float* __
       for (int q = 0; q < RPL; q++)
         if (RPL * h + q < B)       // uniform row base + this lane's (row half, column) offset
           *reinterpret_cast<float*>(reinterpret_cast<char*>(dx) + (size_t)q * rowB + ((unsigned)(RPL * h) * rowB + colB)) = out[q];
-    }
-    if (BNS && cok) {
-      const float bn_m = save[cb * 32 + l31], bn_i = save[C + cb * 32 + l31];
-      double bs0 = bn_acc[2 * tid], bs1 = bn_acc[2 * tid + 1];
-#pragma unroll
-      for (int q = 0; q < RPL; q++) {
-        if (RPL * h + q < B) {
-          bs0 += (double)out[q];
-          bs1 += (double)out[q] * (double)((xr[q] - bn_m) * bn_i);      // zhat in bnq_sums_kernel's form
-        }
-      }
-      bn_acc[2 * tid] = bs0;
-      bn_acc[2 * tid + 1] = bs1;
-    }
-  }
-#undef XV
-  if (BNS) {
-    // the two row halves of a column, then the four waves in a fixed order (each wave parks its sums in its own LDS buffer)
-    double bs0 = bn_acc[2 * tid], bs1 = bn_acc[2 * tid + 1];
-    bs0 += __shfl_xor(bs0, 32, 64);
-    bs1 += __shfl_xor(bs1, 32, 64);
-    double* Wd = reinterpret_cast<double*>(W);
-    if (h == 0) { Wd[2 * l31] = bs0; Wd[2 * l31 + 1] = bs1; }
-    __syncthreads();
-    if (tid < 64) {
-      const int l = tid >> 1, e = tid & 1;
-      double a = 0.0;
-#pragma unroll
-      for (int ww = 0; ww < kWaves; ww++) a += reinterpret_cast<const double*>(lds + ww * WBUF)[2 * l + e];
-      bn_part[((int64_t)pb * C + cb * 32 + l) * 2 + e] = a;
     }
   }
 }
@@ -582,7 +541,7 @@ int launch_partials1(bool pair, const Geom& g, const float* x, int B, int64_t F,
 
 int launch_bwd1(bool pair, const float* gup, const float* S, const float* x, const float* stats, int B, int64_t F,
                 float r, float eps, float* dx, hipStream_t st, const float* ab, int C, const float* ymask, float* dres, int groups,
-                int64_t s_gstride, const float* save, double* bn_part, int* bn_nparts, const float* gup2) {
+                int64_t s_gstride, const float* gup2) {
   if (gup2 && (!gup || !pair)) return ALIGNQ_EINVAL;
   if ((int64_t)B * F * 4 >= ((int64_t)1 << 32)) return ALIGNQ_EUNSUPPORTED;   // 32-bit byte offsets
   const int n_sub = (int)((F + SUBF - 1) / SUBF);
@@ -592,22 +551,8 @@ int launch_bwd1(bool pair, const float* gup, const float* S, const float* x, con
   static const int capb = alignq_env::env_int("ALIGNQ_S1_GRID_B", 768, 1, 65535);      // tuning aid
   if (grid > capb) grid = capb;
   if (groups > 1 && grid * groups > capb) grid = (capb + groups - 1) / groups;      // the groups share the resident round
-  if (bn_part) {
-    // batch-norm sums in the epilogue (BNS): a workgroup stays on one 32-channel block; grid = channel blocks x pixel lanes
-    if (!pair || !ab || !save || !bn_nparts || C < 32 || (C & 31) || F % C != 0) return ALIGNQ_EINVAL;
-    const int CB = C >> 5, HW = (int)(F / C);
-    int npb = (capb / groups) / CB;
-    const int want = (HW + kWaves - 1) / kWaves;
-    if (npb > want) npb = want;
-    if (npb < 1) npb = 1;
-    *bn_nparts = npb;
-    hipLaunchKernelGGL((site1_bwd_kernel<true, true>), dim3(CB * npb, groups), kThreads1, 0, st, gup, S, x, stats, B, F, r, eps, dx,
-                       n_sub, ab, C, ymask, dres, s_gstride, save, bn_part, gup2);
-    RET_ON_ERR1();
-    return 0;
-  }
-  if (pair) hipLaunchKernelGGL((site1_bwd_kernel<true>), dim3(grid, groups), kThreads1, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_sub, ab, C, ymask, dres, s_gstride, nullptr, nullptr, gup2);
-  else hipLaunchKernelGGL((site1_bwd_kernel<false>), dim3(grid, groups), kThreads1, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_sub, ab, C, nullptr, nullptr, s_gstride, nullptr, nullptr);
+  if (pair) hipLaunchKernelGGL((site1_bwd_kernel<true>), dim3(grid, groups), kThreads1, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_sub, ab, C, ymask, dres, s_gstride, gup2);
+  else hipLaunchKernelGGL((site1_bwd_kernel<false>), dim3(grid, groups), kThreads1, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_sub, ab, C, nullptr, nullptr, s_gstride, nullptr);
   RET_ON_ERR1();
   return 0;
 }

@@ -124,9 +124,6 @@ int launch_reduce_loss_groups(const Geom& g, float* ws, int B, int64_t F, int gr
 int launch_bwd1(bool pair, const float* gup, const float* S, const float* x, const float* stats, int B, int64_t F,
                 float r, float eps, float* dx, hipStream_t st, const float* ab = nullptr, int C = 1,
                 const float* ymask = nullptr, float* dres = nullptr, int groups = 1, int64_t s_gstride = 0,
-                // round 4: the folded batch-norm's backward sums in the kernel's epilogue (C % 32 == 0): save = [groups][2][C]
-                // (mean, invstd), bn_part = [groups][*bn_nparts][C][2] doubles (written), *bn_nparts = partials per channel
-                const float* save = nullptr, double* bn_part = nullptr, int* bn_nparts = nullptr,
                 const float* gup2 = nullptr);      // a second addend of the upstream gradient (fused.GradFork), or nullptr
 
 // ---- launchers defined in site4_kernels.hip ----------------------------------------------------------------
@@ -172,11 +169,6 @@ int launch_head_bwd_prep_multi(const float* g_ce, const float* probs, const int6
 int launch_reduce_any(const Geom& g, const float* ws_c, float* ws_mut, int B, int64_t F, float* out, bool with_loss,
                       const float* alterD, const float* gamma, int dim, float mu, float rho, float* scal,
                       hipStream_t st);
-
-// ---- bnq_kernels.hip: the batch-norm backward from per-channel partial sums that are already in `ws` (nparts x C x 2 doubles
-// per group, bnq_sums_kernel's layout): finalisation + dz = a * (dx - mean dx - zhat * mean(dx * zhat)) (in place when dz == dx)
-int launch_bnq_bwd_from_parts(const float* dx, const float* z, const float* ab, const float* save, int64_t P, int C, int groups,
-                              int nparts, float* dz, float* dgamma, float* dbeta, void* ws, hipStream_t st);
 
 // ---- corr_large_kernels.hip: corr(x, x) for 128 < B <= ALIGNQ_MAX_CORR_BATCH (blocked Gram, exact fp32) ------------------
 size_t corrl_ws_bytes(int B, int64_t F);

@@ -768,40 +768,15 @@ int alignq_site1_groups_reduce_loss(void* ws, int B, int64_t F, int groups, floa
                                    (int64_t)(alignq_site_ws_bytes(B, F) / 4), (hipStream_t)stream);
 }
 
-int alignq_site1_groups_bwd(const float* g, const float* y, const float* S, const float* z, const float* ab, int C,
+int alignq_site1_groups_bwd(const float* g, const float* g2, const float* y, const float* S, const float* z, const float* ab, int C,
                             const float* stats, int B, int64_t F, int groups, float act_range, float eps, float* dx,
                             float* dres, void* stream) {
-  if (!S || !z || !ab || !stats || !dx || groups < 1 || (g && !y) || C < 1 || (C & (C - 1)) != 0 || F % C != 0)
+  if (!S || !z || !ab || !stats || !dx || groups < 1 || (g && !y) || (g2 && !g) || C < 1 || (C & (C - 1)) != 0 || F % C != 0)
     return ALIGNQ_EINVAL;
   if (bad_shape(B, F)) return F <= 0 ? ALIGNQ_EINVAL : ALIGNQ_EUNSUPPORTED;
   if (geom(B, F).nb != 1) return ALIGNQ_EUNSUPPORTED;
   return launch_bwd1(true, g, S, z, stats, B, F, act_range, eps, dx, (hipStream_t)stream, ab, C, g ? y : nullptr, g ? dres : nullptr,
-                     groups, (int64_t)(alignq_site_bwd_ws_bytes(B) / 4));
-}
-
-int alignq_site1_groups_bwd_bn(const float* g, const float* g2, const float* y, const float* S, const float* z, const float* ab,
-                               const float* save, int C, const float* stats, int B, int64_t F, int groups, float act_range, float eps,
-                               float* dz, float* dres, float* dgamma, float* dbeta, void* ws_bn, void* stream) {
-  if (!S || !z || !ab || !save || !stats || !dz || !ws_bn || groups < 1 || groups > ALIGNQ_BNQ_MAX_GROUPS || (g && !y) ||
-      (g2 && !g) || C < 1 || (C & (C - 1)) != 0 || F % C != 0)
-    return ALIGNQ_EINVAL;
-  if (bad_shape(B, F)) return F <= 0 ? ALIGNQ_EINVAL : ALIGNQ_EUNSUPPORTED;
-  if (geom(B, F).nb != 1) return ALIGNQ_EUNSUPPORTED;
-  const int64_t P = (int64_t)B * (F / C);
-  if (P < 2) return ALIGNQ_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
-  const int64_t sg = (int64_t)(alignq_site_bwd_ws_bytes(B) / 4);
-  if (C % 32 != 0) {          // a sub-tile spans several pixels: the sums stay a pass of their own
-    const int rc = launch_bwd1(true, g, S, z, stats, B, F, act_range, eps, dz, st, ab, C, g ? y : nullptr, g ? dres : nullptr, groups, sg,
-                               nullptr, nullptr, nullptr, g2);
-    if (rc) return rc;
-    return alignq_bnq_bwd_dx(dz, z, ab, save, P, C, groups, dz, dgamma, dbeta, ws_bn, stream);
-  }
-  int nparts = 0;
-  const int rc = launch_bwd1(true, g, S, z, stats, B, F, act_range, eps, dz, st, ab, C, g ? y : nullptr, g ? dres : nullptr, groups, sg,
-                             save, reinterpret_cast<double*>(ws_bn), &nparts, g2);
-  if (rc) return rc;
-  return launch_bnq_bwd_from_parts(dz, z, ab, save, P, C, groups, nparts, dz, dgamma, dbeta, ws_bn, st);
+                     groups, (int64_t)(alignq_site_bwd_ws_bytes(B) / 4), g2);
 }
 
 int alignq_site_bwd_fused(const float* g, const float* D, const float* alterD, const float* gamma, int dim,

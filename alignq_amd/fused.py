@@ -735,7 +735,6 @@ def bn_only(bn, z, groups=1):
 
 _S1_MASK_IN_KERNEL = os.environ.get("ALIGNQ_S1_MASK", "1") != "0"
 _BNQ_BITMASK = os.environ.get("ALIGNQ_BNQ_BITMASK", "1") != "0"     # A/B aid: 0 = the backward reads the fp32 y for the ReLU mask
-_S1_BN_SUMS = os.environ.get("ALIGNQ_S1_BN_SUMS", "1") != "0"      # A/B aid: 0 = alignq_site1_groups_bwd + alignq_bnq_bwd_dx
 
 
 class BNSite1Fn(torch.autograd.Function):
@@ -805,7 +804,7 @@ class BNSite1Fn(torch.autograd.Function):
         g_m = None
         g_y2 = ctx.tok.pop("extra", None) if ctx.tok is not None else None      # the shortcut's addend, left by GradFork.backward
         if g_y2 is not None:
-            if g_y is None or not (_S1_MASK_IN_KERNEL and _S1_BN_SUMS) or g_y2.shape != z.shape:
+            if g_y is None or not _S1_MASK_IN_KERNEL or g_y2.shape != z.shape:
                 g_y = g_y2 if g_y is None else g_y + g_y2                        # (forms without the second pointer: add here)
                 g_y2 = None
             else:
@@ -838,17 +837,9 @@ class BNSite1Fn(torch.autograd.Function):
                 L.ptr_array([scal[gi] for gi in range(groups)]), L.ptr(g_loss), L.i64_array([F] * groups), B, A.shape[0], mu,
                 L.ptr_array(Sg), L.ptr_array([dA[gi] for gi in range(groups)]), L.ptr_array([dG[gi] for gi in range(groups)]), st),
                 "alignq_site_prep_fused_multi")
-            if _S1_BN_SUMS:
-                # round 4: the site backward leaves the batch-norm backward's per-channel sums (C % 32 == 0), the finalisation and
-                # dz (in place) follow in the same entry: no separate pass over dx and z
-                L.check(lib.alignq_site1_groups_bwd_bn(L.ptr(g_y), L.ptr(g_y2), L.ptr(None if g_y is None else y), L.ptr(S), L.ptr(z), L.ptr(ab),
-                                                       L.ptr(save), C, L.ptr(stats), B, F, groups, act_range, eps, L.ptr(dx),
-                                                       L.ptr(g_m), L.ptr(dgamma), L.ptr(dbeta), L.ptr(ws_bn), st),
-                        "alignq_site1_groups_bwd_bn")
-            else:
-                L.check(lib.alignq_site1_groups_bwd(L.ptr(g_y), L.ptr(None if g_y is None else y), L.ptr(S), L.ptr(z), L.ptr(ab), C,
-                                                    L.ptr(stats), B, F, groups, act_range, eps, L.ptr(dx), L.ptr(g_m), st),
-                        "alignq_site1_groups_bwd")
+            L.check(lib.alignq_site1_groups_bwd(L.ptr(g_y), L.ptr(g_y2), L.ptr(None if g_y is None else y), L.ptr(S), L.ptr(z),
+                                                L.ptr(ab), C, L.ptr(stats), B, F, groups, act_range, eps, L.ptr(dx), L.ptr(g_m), st),
+                    "alignq_site1_groups_bwd")
         else:
             for gi in range(groups):
                 sl = slice(gi * B, (gi + 1) * B)
@@ -857,9 +848,8 @@ class BNSite1Fn(torch.autograd.Function):
                 L.check(lib.alignq_site_bwd_apply_ab(L.ptr(None if g_y is None else g_y[sl]), L.ptr(S), L.ptr(z[sl]), L.ptr(ab[gi]), C,
                                                      L.ptr(stats[gi]), B, F, act_range, eps, L.ptr(dx[sl]), st),
                         "alignq_site_bwd_apply_ab")
-        if not (_S1_MASK_IN_KERNEL and _S1_BN_SUMS):
-            L.check(lib.alignq_bnq_bwd_dx(L.ptr(dx), L.ptr(z), L.ptr(ab), L.ptr(save), P, C, groups, L.ptr(dx), L.ptr(dgamma),
-                                          L.ptr(dbeta), L.ptr(ws_bn), st), "alignq_bnq_bwd_dx")
+        L.check(lib.alignq_bnq_bwd_dx(L.ptr(dx), L.ptr(z), L.ptr(ab), L.ptr(save), P, C, groups, L.ptr(dx), L.ptr(dgamma),
+                                      L.ptr(dbeta), L.ptr(ws_bn), st), "alignq_bnq_bwd_dx")
 
         def red(t):                                  # the slices' alterD / gamma gradients: one elementwise add, not a reduce
             out = t[0]

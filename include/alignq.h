@@ -486,25 +486,16 @@ int alignq_site_bwd_apply_ab_relu(const float* g, const float* y, const float* S
  * slices stacked along the batch - the Office step's merged source + target pass (dann_office/main.py:296-330) - in ONE launch
  * per kernel: z / residual / y / g / dx / dres [groups][B][F]; ab [groups][2][C]; stats [groups][4][F]; D [groups][B][B];
  * scal [groups][4]; ws = groups regions of alignq_site_ws_bytes(B, F) each; S = groups regions of alignq_site_bwd_ws_bytes(B)
- * each (filled by alignq_site_prep_fused_multi with one entry per slice).  g == NULL: no upstream gradient (no mask, no dres). */
+ * each (filled by alignq_site_prep_fused_multi with one entry per slice).  g == NULL: no upstream gradient (no mask, no dres).
+ * g2 (round 4; or NULL): a second addend of the upstream gradient, same layout as g; the kernel reads g + g2 - the sum autograd
+ * would form in an elementwise pass of its own where the block's output feeds the next block's convolution AND its shortcut. */
 int alignq_site1_groups_fwd(const float* z, const float* ab, int C, int B, int64_t F, int groups, int k, float act_range,
                             float eps, const float* residual, int relu, float* y, float* stats, void* ws, void* stream);
 int alignq_site1_groups_reduce_loss(void* ws, int B, int64_t F, int groups, float* D, const float* alterD, const float* gamma,
                                     int dim, float mu, float rho, float* scal, void* stream);
-int alignq_site1_groups_bwd(const float* g, const float* y, const float* S, const float* z, const float* ab, int C,
+int alignq_site1_groups_bwd(const float* g, const float* g2, const float* y, const float* S, const float* z, const float* ab, int C,
                             const float* stats, int B, int64_t F, int groups, float act_range, float eps, float* dx,
                             float* dres, void* stream);
-/* alignq_site1_groups_bwd + alignq_bnq_bwd_dx as ONE entry (round 4): the backward of `relu(act_q3(bn3(z))[0] + identity)`
- * (dann_office/model/resnet.py:146-154) from the gradient g of that output to dz, dgamma, dbeta, dres.  When C % 32 == 0 (a
- * 32-feature sub-tile = 32 channels of one pixel) the site kernel leaves the batch-norm backward's per-channel sums of its own
- * output in ws_bn, so the separate pass over dx and z is not launched (3 launches: site backward, finalisation, dz in place);
- * otherwise exactly the two calls it replaces.  save: [groups][2][C] (mean, invstd) of alignq_bnq_stats; dz: [groups][B][F]
- * (receives dx first, then dz in place); ws_bn: alignq_bnq_ws_bytes(C, groups).  g == NULL: no upstream gradient.
- * g2 (or NULL): a second addend of the upstream gradient, same layout as g; the kernel reads g + g2 (the sum autograd would
- * form in a pass of its own where the block's output feeds the next block's convolution AND its shortcut).                  */
-int alignq_site1_groups_bwd_bn(const float* g, const float* g2, const float* y, const float* S, const float* z, const float* ab,
-                               const float* save, int C, const float* stats, int B, int64_t F, int groups, float act_range, float eps,
-                               float* dz, float* dres, float* dgamma, float* dbeta, void* ws_bn, void* stream);
 size_t alignq_bnq_ws_bytes(int C, int groups);
 /* ReLU mask as ONE BIT per element (round 4): alignq_bnq_fwd with mask != NULL also writes [y > 0] for every element
  * (alignq_bnq_mask_bytes(P, C, groups) bytes, 16-byte aligned; per group and per 64 consecutive channel quads four 64-bit words,
