@@ -17,7 +17,7 @@ from . import cdf_alignment as _cdf
 from . import cdf_alignment_admm as _admm
 from . import config
 from .admm import ADMM
-from .fused import bn_site
+from .fused import bn_act_relu, bn_site
 
 
 def _transition_pair(conv3, conv1, x):
@@ -77,6 +77,16 @@ class PreActBlock_conv_Q(nn.Module):
         indices) - only for a tensor whose SOLE consumer is a Conv2d_Q."""
         if self.tree == "admm" and self.fuse_bn:
             return bn_site(bn, fn, z, relu=relu, residual=residual, pack=pack)
+        if self.tree == "cdf" and self.fuse_bn:
+            # configuration 1 (cdf_alignment/resnet-20-cifar-10/model/resnet.py:63-79): no correlation term, so the fold is the
+            # plain-quantiser family (alignq_bnq_fwd / _bwd, formula 1); it falls back to exactly the composition below when
+            # the tensor is not channels-last fp32 in training mode
+            out = bn_act_relu(bn, fn, z, 1, relu=relu and residual is None)
+            if residual is not None:
+                out = out + residual
+                if relu:
+                    out = F.relu(out)
+            return out, 0
         out, loss = self._q(fn, bn(z))
         if residual is not None:
             out += residual
@@ -139,6 +149,8 @@ class PreActResNet(nn.Module):
             out, loss = self.act_q0(self.bn(self.conv0(x)))
             trans_loss = 0. + loss
             out = F.relu(out)
+        elif self.fuse_bn:
+            out = bn_act_relu(self.bn, self.act_q0, self.conv0(x), 1, relu=True)
         else:
             out = F.relu(self.act_q0(self.bn(self.conv0(x))))
         for layer in self.layers:

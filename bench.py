@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--bits", type=int, default=8)
     ap.add_argument("--model", default="resnet20", choices=["resnet20", "resnet56", "resnet50_dann"],
                     help="resnet50_dann = BASELINE config 5 (Office-31 shapes 3x224x224, use --batch 28)")
+    ap.add_argument("--tree", default="admm", choices=["admm", "cdf"], help="resnet20 / resnet56: the CDF+ADMM tree (BASELINE "
+                    "configs[1..3]) or the CDF-only tree of configs[0] (cdf_alignment/resnet-20-cifar-10); the headline line is the "
+                    "default; the metric string names the tree")
     ap.add_argument("--lr", type=float, default=None,
                     help="learning rate (default: the reference's 0.04 for the CIFAR nets; 0.004 for resnet50_dann, whose "
                          "reference default 0.04 assumes ImageNet-pretrained weights (dann_office/model/resnet.py:274-288, no "
@@ -570,7 +573,7 @@ def measure_office_shapes(dev, k):
     return out
 
 
-def cpu_baseline(batch, bits, model, steps):
+def cpu_baseline(batch, bits, model, steps, tree="admm", thread_counts=(8, 16, 32, 64, 128)):
     """The eager-torch restatement of the reference on the host cores: same workload, bounded sample.  Oversubscribing
     torch's intra-op pool hurts this elementwise-heavy workload (64 threads ran slower than 16 on the GPU box), so a sweep
     of thread counts {8, 16, 32, 64, 128} (those the box offers) is timed, >= 10 steps each, and the FASTEST is reported
@@ -580,13 +583,13 @@ def cpu_baseline(batch, bits, model, steps):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cfg = R.Config(tree="admm", bitW=bits, abitW=bits, train_batch_size=batch)
+    cfg = R.Config(tree=tree, bitW=bits, abitW=bits, train_batch_size=batch)
     gen = torch.Generator().manual_seed(0)
     x = torch.randn(batch, 3, 32, 32, generator=gen)
     y = torch.randint(0, 10, (batch,), generator=gen)
     best = None
     tried = {}
-    for cores in sorted({max(1, min(avail, c)) for c in (8, 16, 32, 64, 128)}):
+    for cores in sorted({max(1, min(avail, c)) for c in thread_counts}):
         torch.set_num_threads(cores)
         torch.manual_seed(0)
         net = (R.resnet20 if model == "resnet20" else R.resnet56)(cfg).train()
@@ -628,6 +631,44 @@ class _StdoutToStderr:
         return False
 
 
+def office_dp_probe(dev, steps=12):
+    """Configuration 5's data-parallel form (dp.attach_office: >= 4 gradient buckets all-reduced from backward hooks, D in the
+    last) at world size 1, inside the process group dp_probe has open: what one of the 8 ranks executes per step
+    minus the wire time."""
+    import gc
+    from alignq_amd import config, dp
+    from alignq_amd.resnet_office import resnet50_dann
+    from alignq_amd.train_step import OfficeTrainStep
+    saved = (config.args.bitW, config.args.abitW, config.args.train_batch_size, config.args.eval_batch_size)
+    try:
+        config.args.bitW = config.args.abitW = 8
+        config.args.train_batch_size = config.args.eval_batch_size = 28
+        torch.manual_seed(0)
+        model = resnet50_dann(8, 8).to(dev).train()
+        step = OfficeTrainStep(model, lr=0.004, channels_last=True)
+        hook = dp.attach_office(step, force=True)
+        xs, xt = torch.randn(28, 3, 224, 224, device=dev), torch.randn(28, 3, 224, 224, device=dev)
+        ys = torch.randint(0, 31, (28,), device=dev)
+        step.capture(xs, ys, xt, warmup=2)
+        for _ in range(3):
+            step(xs, ys, xt)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(xs, ys, xt)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        out = {"ms_per_step": ms, "buckets_mib": [int(b.flat.numel()) * 4 // 2 ** 20 for b, _ in hook._phase], "world_size": 1}
+        del step, model, hook
+    except Exception as e:
+        out = {"error": repr(e)[:200]}
+    finally:
+        config.args.bitW, config.args.abitW, config.args.train_batch_size, config.args.eval_batch_size = saved
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
+
+
 def dp_probe(dev, a, steps=50):
     """ms per step of the DATA-PARALLEL form of the same step at world size 1 (its own model, after the main measurement)."""
     import torch.distributed as dist
@@ -657,6 +698,9 @@ def dp_probe(dev, a, steps=50):
         ms = (time.perf_counter() - t0) / steps * 1e3
         out = {"ms_per_step": ms, "bucket_bytes": int(hook.bucket.flat.numel()) * 4, "world_size": 1, "backend": "nccl (RCCL)",
                "note": "two HIP graphs (fwd+bwd+pack | unpack+optimizers) with one eager RCCL AVG all-reduce of the flat bucket"}
+        del step, model, hook
+        if a.model == "resnet20" and a.bits == 8 and not a.no_other_configs:
+            out["office"] = office_dp_probe(dev)
     except Exception as e:           # never fail the headline line on the probe
         out = {"error": repr(e)[:200]}
     finally:
@@ -667,7 +711,7 @@ def dp_probe(dev, a, steps=50):
 
 # Algorithmic HBM bytes per GPU and step of the in-scope kernels (20 B per activation element of a
 # quantiser site; weights 20-28 B each, quantised once per pass)
-_CFG_BYTES = {"resnet20": 128 * 200704 * 20 + 0.27e6 * 28, "resnet56": 128 * 544768 * 20 + 0.85e6 * 28,
+_CFG_BYTES = {"resnet20": 128 * 200704 * 20 + 0.27e6 * 28, "resnet20_cdf": 128 * 200704 * 20 + 0.27e6 * 20, "resnet56": 128 * 544768 * 20 + 0.85e6 * 28,
               "resnet50_dann": 2 * 28 * 9608704 * 20 + 2 * 23.5e6 * 20 + 23.5e6 * 8}
 
 
@@ -684,8 +728,8 @@ def other_configs(dev, a, steps=30):
     saved = (config.args.bitW, config.args.abitW, config.args.train_batch_size, config.args.eval_batch_size)
     out = {}
     gen = torch.Generator().manual_seed(1)
-    for name, kind, bits, batch in (("resnet20_2w2a_b128", "resnet20", 2, 128), ("resnet56_4w4a_b128", "resnet56", 4, 128),
-                                    ("resnet50_dann_8w8a_b28", "resnet50_dann", 8, 28)):
+    for name, kind, bits, batch in (("resnet20_cdf_only_8w8a_b128", "resnet20_cdf", 8, 128), ("resnet20_2w2a_b128", "resnet20", 2, 128),
+                                    ("resnet56_4w4a_b128", "resnet56", 4, 128), ("resnet50_dann_8w8a_b28", "resnet50_dann", 8, 28)):
         try:
             config.args.bitW = config.args.abitW = bits
             config.args.train_batch_size = config.args.eval_batch_size = batch
@@ -700,7 +744,10 @@ def other_configs(dev, a, steps=30):
                 run = lambda: st(xs, ys, xt)                         # noqa: E731
                 images = 2 * batch
             else:
-                model = (resnet20_quant if kind == "resnet20" else resnet56_quant)(bits, bits).to(dev).train()
+                if kind == "resnet20_cdf":      # configs[0]: the CDF-only tree (no correlation / ADMM term), batch-norm folded too
+                    model = resnet20_quant(bits, bits, tree="cdf").to(dev).train()
+                else:
+                    model = (resnet20_quant if kind == "resnet20" else resnet56_quant)(bits, bits).to(dev).train()
                 st = TrainStep(model, lr=0.04, channels_last=True)
                 x = torch.randn(batch, 3, 32, 32, generator=gen).to(dev)
                 y = torch.randint(0, 10, (batch,), generator=gen).to(dev)
@@ -790,7 +837,7 @@ def main():
         x = y = None
         images_per_step = 2 * a.batch            # source + target images both pass through the network
     else:
-        model = (resnet20_quant if a.model == "resnet20" else resnet56_quant)(a.bits, a.bits).to(dev).train()
+        model = (resnet20_quant if a.model == "resnet20" else resnet56_quant)(a.bits, a.bits, tree=a.tree).to(dev).train()
         step = TrainStep(model, lr=a.lr if a.lr is not None else 0.04, fuse_bn=not a.no_fuse_bn, channels_last=not a.nchw,
                          qconv=not a.no_qconv, pack_bins=not a.no_pack_bins)
         if world > 1 or a.dp_selftest:
@@ -831,8 +878,9 @@ def main():
     if rank == 0:
         images = a.steps * images_per_step * world
         res = {
-            "metric": "images/sec (train step, CDF+ADMM) ResNet-20 8-bit" if (a.model == "resnet20" and a.bits == 8) else
-                      f"images/sec (train step, CDF+ADMM) {a.model} {a.bits}-bit",
+            "metric": (f"images/sec (train step, CDF-only tree) {a.model} {a.bits}-bit" if (a.tree == "cdf" and not office) else
+                       "images/sec (train step, CDF+ADMM) ResNet-20 8-bit" if (a.model == "resnet20" and a.bits == 8) else
+                       f"images/sec (train step, CDF+ADMM) {a.model} {a.bits}-bit"),
             "value": images / elapsed, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -840,6 +888,9 @@ def main():
                                     f"(cdf_alignment_admm/dann_office: source+target pass), batch {a.batch}+{a.batch}/GPU, "
                                     f"random init at lr {a.lr if a.lr is not None else 0.004}, "
                                     if office else
+                                    f"{a.model} CIFAR-shape 3x32x32, {a.bits}W/{a.bits}A CDF-only full train step "
+                                    f"(cdf_alignment/resnet-20-cifar-10), batch {a.batch}/GPU, "
+                                    if a.tree == "cdf" else
                                     f"{a.model} CIFAR-shape 3x32x32, {a.bits}W/{a.bits}A CDF+ADMM full train step "
                                     f"(cdf_alignment_admm/resnet-20-cifar-10), batch {a.batch}/GPU, ")
                                    + f"{'HIP-graph replay' if not a.no_graph else 'eager launches'}"
@@ -866,12 +917,26 @@ def main():
         if world == 1 and not a.no_cpu_baseline and not office:
             res["cpu_baseline"] = cpu_baseline(a.batch, a.bits, a.model, a.cpu_steps)
             res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
+            if a.model == "resnet20" and not a.no_other_configs:
+                # BASELINE.json configs[0] (the reference's own CPU-runnable case: CDF-only tree, cdf_alignment/resnet-20-cifar-10/
+                # main.py:269-315) on the same host cores: the three thread counts around the ADMM workload's best
+                best = res["cpu_baseline"]["cores"]
+                res["cpu_baseline_cdf_only"] = cpu_baseline(a.batch, a.bits, a.model, a.cpu_steps, tree="cdf",
+                                                            thread_counts=(max(8, best // 2), best, best * 2))
+
         if world == 1 and not office and not a.dp_selftest and not a.no_dp_probe:
             # the data-parallel path at world size 1 (RCCL all-reduce of the flat gradient + D bucket between two HIP graphs):
             # what one rank of the N > 1 runs executes per step, minus the wire time (no 8-GPU node in this session)
             res["dp_selftest"] = dp_probe(dev, a)
         if world == 1 and not office and not a.no_other_configs and a.model == "resnet20" and a.bits == 8:
             res["other_configs"] = other_configs(dev, a)
+            off_dp = res.get("dp_selftest", {}).get("office", {})
+            if "ms_per_step" in off_dp and "resnet50_dann_8w8a_b28" in res["other_configs"]:
+                res["other_configs"]["resnet50_dann_8w8a_b28"]["dp_selftest_ms"] = off_dp["ms_per_step"]
+            gpu1 = res["other_configs"].get("resnet20_cdf_only_8w8a_b128", {}).get("images_per_sec")
+            if gpu1 and "cpu_baseline_cdf_only" in res:
+                res["cpu_baseline_cdf_only"]["gpu_images_per_sec"] = gpu1
+                res["cpu_baseline_cdf_only"]["gpu_speedup"] = gpu1 / res["cpu_baseline_cdf_only"]["value"]
         print(json.dumps(res))
     if dist.is_initialized():
         dist.barrier()

@@ -241,3 +241,77 @@ def test_forked_block_input_gives_the_bits_of_autograds_own_sum(dev, B, C, H, gr
             assert np.array_equal(u.view(np.uint32), v.view(np.uint32))
     finally:
         config.args.abitW, config.args.train_batch_size = old
+
+
+# ------------------------------------------------------------------------------------------------ VERDICT r3 item 3
+def test_cdf_only_resnet20_full_size_step_on_the_fast_path(dev, monkeypatch):
+    """Configuration 1 (cdf_alignment/resnet-20-cifar-10: model/resnet.py:63-79,134, main.py:269-315) at FULL size - ResNet-20,
+    batch 128, 8W/8A - on the HIP fast path: channels-last, Conv2d_Q's body convolutions on alignq_conv3x3_nhwc, every
+    `act_q(bn(.))` folded (fused.bn_act_relu -> alignq_bnq_fwd / _bwd, formula 1).  Three sites (stem; a block's bn0 with the
+    ReLU; the last block's bn1 without) are checked teacher-forced against the C oracle on the tensors the step itself produced:
+    x_q bit-exact outside a near-tie band (the device's (a, b) differ by ~1e-6 from the oracle's), at most one level inside;
+    the loss is finite, every site really took the folded path, and the captured HIP graph reproduces eager iterations."""
+    import alignq_amd.resnet as RN
+    from alignq_amd import config, fused
+    from alignq_amd.train_step import TrainStep
+    old = (config.args.bitW, config.args.abitW, config.args.train_batch_size)
+    config.args.bitW = config.args.abitW = 8
+    config.args.train_batch_size = 128
+    try:
+        k, r, n = 8, float(config.args.act_range), 255
+        calls = []
+        real = fused.bn_act_relu
+
+        def spy(bn, act, z, formula, relu=True, groups=1):
+            assert formula == 1 and fused.bnq_fusable(bn, act, z, groups)
+            out = real(bn, act, z, formula, relu=relu, groups=groups)
+            calls.append((bn, z.detach(), out.detach(), relu))
+            return out
+        monkeypatch.setattr(RN, "bn_act_relu", spy)
+
+        def make():
+            torch.manual_seed(3)
+            return RN.resnet20_quant(8, 8, tree="cdf").to(dev).train()
+        g = torch.Generator().manual_seed(9)
+        x = torch.randn(128, 3, 32, 32, generator=g).to(dev)
+        y = torch.randint(0, 10, (128,), generator=g).to(dev)
+        net = make()
+        step = TrainStep(net, channels_last=True)
+        assert not step.admms
+        # the batch-norm parameters / statistics the recorded calls saw (the optimizer step changes them afterwards)
+        before = {id(m): (npy(m.weight), npy(m.bias)) for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d)}
+        logits, ce, tl = step(x, y)
+        torch.cuda.synchronize()
+        assert torch.isfinite(logits).all() and torch.isfinite(ce) and (tl is None or float(tl) == 0.0)
+        assert len(calls) == 21                                  # 1 stem + 9 blocks x 2 + 2 shortcut sites
+        for idx in (0, 1, len(calls) - 1):
+            bn, z, out, relu = calls[idx]
+            B, C, H, W = z.shape
+            gam, bet = before[id(bn)]
+            zm = np.ascontiguousarray(npy(z).transpose(0, 2, 3, 1)).reshape(B, -1)
+            ab_o, _, _ = O.bn_fold_ab(zm, C, 1, gam, bet, bn.eps)
+            x_o = O.bn_apply(zm, C, 1, ab_o)
+            q_o, c_o, _ = O.act_quant_fwd(x_o, k, r, O.FORMULA_CDF)
+            y_o = np.maximum(q_o, 0.0) if relu else q_o
+            frac = c_o.astype(np.float64) * n
+            near = np.abs(frac - np.floor(frac) - 0.5) < 2e-3
+            got = np.ascontiguousarray(npy(out).transpose(0, 2, 3, 1)).reshape(B, -1)
+            diff = np.abs(got - y_o) * n / (2.0 * r)             # in levels: x_q = r * (2 * bin / n - 1)
+            assert np.all(diff[~near] == 0), (idx, int(np.count_nonzero(diff[~near])))
+            assert np.all(diff[near] <= 1.0 + 1e-3)
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+        # ---- graph == eager over three iterations from the same initial state
+        monkeypatch.setattr(RN, "bn_act_relu", real)
+        n1, n2 = make(), make()
+        s1, s2 = TrainStep(n1, channels_last=True), TrainStep(n2, channels_last=True)
+        for _ in range(3):
+            l1, c1, _ = s1(x, y)
+        s2.capture(x, y, warmup=2)          # two real iterations, then the captured third
+        l2, c2, _ = s2(x, y)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(float(c1), float(c2), atol=2e-2)
+        for (nm, p1), (_, p2) in zip(n1.named_parameters(), n2.named_parameters()):
+            d = np.abs(npy(p1) - npy(p2))
+            assert np.median(d) < 1e-4 and d.max() < 2e-2, (nm, float(np.median(d)), float(d.max()))
+    finally:
+        config.args.bitW, config.args.abitW, config.args.train_batch_size = old
