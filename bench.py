@@ -335,6 +335,7 @@ def measure_kernels(dev, B, k, site_F_counts, hw_of_F, folded=True, nhwc=False, 
     if shapes:
         out["roofline_shapes"] = measure_roofline_shapes(dev, k)
         out["office_shapes"] = measure_office_shapes(dev, k)
+        out["corr_large"] = measure_corr_large(dev, k)
     n_sites = sum(site_F_counts.values())
     dom = max(("site_partials", "site_bwd"), key=lambda kname: per_step[kname][0])
     t_sum, fl_sum = per_step[dom]
@@ -573,6 +574,64 @@ def measure_office_shapes(dev, k):
     return out
 
 
+def measure_corr_large(dev, k):
+    """what the rows above 128 cost.  corr(x, x) on the blocked exact-fp32 Gram (corr_large_kernels.hip,
+    v_mfma_f32_32x32x2_f32) at B in {256, 1024}, F = 16384: forward / backward time, fp32-MFMA TFLOP/s against the 157 TFLOP/s
+    dense fp32-matrix peak (2 B^2 F flop forward, 4 B^2 F backward: dX = (S + S^T) Xh), HBM fraction on the algorithmic bytes
+    (forward 4 B/element, backward 8); and the ADMM site COMPOSED for B = 256 (ops.site_unfused: plain quantiser twice + corr
+    twice + ADMM loss, autograd backward) against the FUSED site at B = 128 run twice on the same 256 rows."""
+    from alignq_amd import _lib as L, ops
+    from alignq_amd.admm import ADMM
+    lib = L.load()
+    st = L.stream_ptr()
+    p = L.ptr
+    out = {}
+    F = 16384
+    for B in (256, 1024):
+        x = torch.randn(B, F, device=dev)
+        dG = torch.randn(B, B, device=dev) * 1e-3
+        G, stats, dx = torch.empty(B, B, device=dev), torch.empty(2, F, device=dev), torch.empty(B, F, device=dev)
+        ws = torch.empty(lib.alignq_site_ws_bytes(B, F), dtype=torch.uint8, device=dev)
+        wsb = torch.empty(lib.alignq_site_bwd_ws_bytes(B), dtype=torch.uint8, device=dev)
+        f_fwd = lambda: L.check(lib.alignq_corr_fwd(p(x), B, F, 0.0, p(G), p(stats), p(ws), st), "alignq_corr_fwd")      # noqa: E731
+        f_bwd = lambda: L.check(lib.alignq_corr_bwd(p(dG), p(x), p(stats), B, F, 0.0, p(dx), p(wsb), st), "alignq_corr_bwd")  # noqa: E731
+        f_fwd()
+        t_f, t_b = time_call(f_fwd, 20), time_call(f_bwd, 20)
+        n = B * F
+        out[f"corr_{B}x{F}"] = {
+            "fwd_us": t_f * 1e6, "fwd_tflops_fp32": 2.0 * B * B * F / t_f / 1e12, "fwd_frac_of_157_tflops": 2.0 * B * B * F / t_f / 1e12 / 157.0,
+            "fwd_frac_of_8TBs": 4.0 * n / t_f / 1e9 / HBM_PEAK_GBS,
+            "bwd_us": t_b * 1e6, "bwd_tflops_fp32": 4.0 * B * B * F / t_b / 1e12, "bwd_frac_of_157_tflops": 4.0 * B * B * F / t_b / 1e12 / 157.0,
+            "bwd_frac_of_8TBs": 8.0 * n / t_b / 1e9 / HBM_PEAK_GBS}
+        del x, dx, ws
+    # the ADMM site at 256 rows: composed (the only form above 128 rows) vs two fused 128-row sites
+    B = 256
+    x = torch.randn(B, F, device=dev)
+    gq = torch.randn(B, F, device=dev) * 0.01
+    admm = ADMM(B).to(dev)
+    one = torch.ones((), device=dev)
+
+    def composed():
+        xi = x.detach().requires_grad_(True)
+        xq, loss, _ = ops.site_unfused(xi, admm, k, 2.0, 0.0, 0)
+        torch.autograd.backward([xq, loss], [gq, one])
+        admm.alterD.grad = admm.gamma.grad = None
+    admm1 = ADMM(128).to(dev)
+
+    def fused_twice():
+        for h in range(2):
+            xi = x[h * 128:(h + 1) * 128].detach().requires_grad_(True)
+            xq, loss, _ = ops.SiteFn.apply(xi, admm1.alterD, admm1.gamma, k, 2.0, 0.0, admm1.mu, admm1.rho)
+            torch.autograd.backward([xq, loss], [gq[h * 128:(h + 1) * 128], one])
+        admm1.alterD.grad = admm1.gamma.grad = None
+    t_c, t_f2 = time_call(composed, 10), time_call(fused_twice, 10)
+    out["site_256x16384"] = {"composed_fwd_bwd_us": t_c * 1e6, "fused_128_rows_twice_fwd_bwd_us": t_f2 * 1e6, "ratio": t_c / t_f2,
+                             "note": "eager launches through the autograd functions (host overhead included on both sides); the "
+                                     "two halves are NOT the same computation as the 256-row site (their correlation matrices are "
+                                     "128 x 128): a cost yardstick per element only"}
+    return out
+
+
 def cpu_baseline(batch, bits, model, steps, tree="admm", thread_counts=(8, 16, 32, 64, 128)):
     """The eager-torch restatement of the reference on the host cores: same workload, bounded sample.  Oversubscribing
     torch's intra-op pool hurts this elementwise-heavy workload (64 threads ran slower than 16 on the GPU box), so a sweep
@@ -781,6 +840,64 @@ def other_configs(dev, a, steps=30):
     return out
 
 
+def timed_steps(step, x, y, steps, world, dist, dev, sync=None):
+    """The timed region of the driver contract: EXACTLY `steps` steps bracketed by a barrier + device synchronisation on both
+    sides; the elapsed time is the MAX over the ranks (an all-reduce, so every rank holds it).  `sync` / `dist` are parameters
+    so that tests/test_bench_assembly.py can drive this bookkeeping without a GPU or a real process group."""
+    sync = sync or torch.cuda.synchronize
+
+    def fence():
+        sync()
+        if world > 1:
+            dist.barrier()
+        sync()
+
+    fence()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(steps):
+        out = step(x, y)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, out
+
+
+def headline(a, elapsed, images_per_step, world, office, final_ce, final_tl):
+    """The driver's JSON line (before the roofline / cpu_baseline / extras are attached): `value` is the WHOLE-JOB aggregate -
+    every rank processed steps x images_per_step images in the max-over-ranks time - `scaling` weak (fixed per-GPU batch)."""
+    images = a.steps * images_per_step * world
+    return {
+        "metric": (f"images/sec (train step, CDF-only tree) {a.model} {a.bits}-bit" if (a.tree == "cdf" and not office) else
+                   "images/sec (train step, CDF+ADMM) ResNet-20 8-bit" if (a.model == "resnet20" and a.bits == 8) else
+                   f"images/sec (train step, CDF+ADMM) {a.model} {a.bits}-bit"),
+        "value": images / elapsed, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": (f"{a.model} Office-31 shape 3x224x224 DANN, {a.bits}W/{a.bits}A CDF+ADMM full train step "
+                                f"(cdf_alignment_admm/dann_office: source+target pass), batch {a.batch}+{a.batch}/GPU, "
+                                f"random init at lr {a.lr if a.lr is not None else 0.004}, "
+                                if office else
+                                f"{a.model} CIFAR-shape 3x32x32, {a.bits}W/{a.bits}A CDF-only full train step "
+                                f"(cdf_alignment/resnet-20-cifar-10), batch {a.batch}/GPU, "
+                                if a.tree == "cdf" else
+                                f"{a.model} CIFAR-shape 3x32x32, {a.bits}W/{a.bits}A CDF+ADMM full train step "
+                                f"(cdf_alignment_admm/resnet-20-cifar-10), batch {a.batch}/GPU, ")
+                               + f"{'HIP-graph replay' if not a.no_graph else 'eager launches'}"
+                               + ("" if (office or a.no_fuse_bn) else ", batch-norm folded into the site kernels")
+                               + ("" if (a.no_miopen_find or not (office or a.nchw or a.no_qconv)) else
+                                  ", MIOpen find mode for the convolutions")
+                               + ("" if a.nchw else ", channels-last tensors")
+                               + ("" if (office or a.nchw or a.no_qconv) else
+                                  ", all Conv2d_Q convolutions on alignq_conv*_nhwc (exact-product bf16 MFMA)"),
+                   "global_batch": a.batch * world, "parallelism": f"dp{world}",
+                   "final_ce": final_ce, "final_trans_loss": final_tl},
+    }
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -856,53 +973,13 @@ def main():
     for _ in range(a.warmup):
         step(x, y)
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = step(x, y)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, out = timed_steps(step, x, y, a.steps, world, dist, dev)
     logits, ce, tl = out
     assert torch.isfinite(ce).item(), "training step produced a non-finite loss"
 
     if rank == 0:
-        images = a.steps * images_per_step * world
-        res = {
-            "metric": (f"images/sec (train step, CDF-only tree) {a.model} {a.bits}-bit" if (a.tree == "cdf" and not office) else
-                       "images/sec (train step, CDF+ADMM) ResNet-20 8-bit" if (a.model == "resnet20" and a.bits == 8) else
-                       f"images/sec (train step, CDF+ADMM) {a.model} {a.bits}-bit"),
-            "value": images / elapsed, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (f"{a.model} Office-31 shape 3x224x224 DANN, {a.bits}W/{a.bits}A CDF+ADMM full train step "
-                                    f"(cdf_alignment_admm/dann_office: source+target pass), batch {a.batch}+{a.batch}/GPU, "
-                                    f"random init at lr {a.lr if a.lr is not None else 0.004}, "
-                                    if office else
-                                    f"{a.model} CIFAR-shape 3x32x32, {a.bits}W/{a.bits}A CDF-only full train step "
-                                    f"(cdf_alignment/resnet-20-cifar-10), batch {a.batch}/GPU, "
-                                    if a.tree == "cdf" else
-                                    f"{a.model} CIFAR-shape 3x32x32, {a.bits}W/{a.bits}A CDF+ADMM full train step "
-                                    f"(cdf_alignment_admm/resnet-20-cifar-10), batch {a.batch}/GPU, ")
-                                   + f"{'HIP-graph replay' if not a.no_graph else 'eager launches'}"
-                                   + ("" if (office or a.no_fuse_bn) else ", batch-norm folded into the site kernels")
-                                   + ("" if (a.no_miopen_find or not (office or a.nchw or a.no_qconv)) else
-                                      ", MIOpen find mode for the convolutions")
-                                   + ("" if a.nchw else ", channels-last tensors")
-                                   + ("" if (office or a.nchw or a.no_qconv) else
-                                      ", all Conv2d_Q convolutions on alignq_conv*_nhwc (exact-product bf16 MFMA)"),
-                       "global_batch": a.batch * world, "parallelism": f"dp{world}",
-                       "final_ce": float(ce.detach()), "final_trans_loss": float(tl.detach()) if tl is not None else None},
-        }
+        res = headline(a, elapsed, images_per_step, world, office, float(ce.detach()),
+                       float(tl.detach()) if tl is not None else None)
         if not a.no_kernels and not office:
             counts = {}
             units = [3, 3, 3] if a.model == "resnet20" else [9, 9, 9]
