@@ -246,33 +246,105 @@ __global__ __launch_bounds__(kT) void bnq_finalize_bwd_kernel(const double* __re
   if (dgamma) dgamma[c] = (float)tq;
 }
 
+// ---- in-kernel finalisation (round 4, "small" sites: one group, C <= kFinC, a few MB - configuration 1's CIFAR-size tensors) ----
+// At these sizes bnq_finalize* are launches at the ~5 us node floor between two 5-10 us kernels.  With at most kFinParts partials
+// per channel every workgroup of the APPLY pass can afford to finalise for itself (C x partials x 16 B <= 64 KB of L2 reads per
+// workgroup, all of them the same lines, read by all its threads at once): the statistics kernel is followed by the apply kernel directly; workgroup 0 also writes
+// what the module keeps (a, b, mean, invstd, running statistics / dgamma, dbeta).  Same arithmetic and summation order as the
+// finalisation kernels (partials in index order, double).
+constexpr int kFinC = 64, kFinParts = 128;      // C x partials x 16 B <= 64 KB per workgroup (fin_parts)
+
+struct FinFwd {                 // bnq_finalize_kernel's arguments
+  const double* part; int nparts; int64_t P;
+  const float* gamma; const float* beta; float* running_mean; float* running_var; long long* nbt; float momentum, eps;
+  float* ab_out; float* save_out;
+};
+struct FinBwd {                 // bnq_finalize_bwd_kernel's arguments
+  const double* part; int nparts; int64_t P; float* dgamma; float* dbeta;
+};
+
+// Totals of channel c = tid % C over the partials, by ALL threads of the workgroup: thread (c, slice = tid / C) adds every
+// (NT / C)-th partial (all its loads in flight together, rounds of 8), the slices are then added in slice order by the threads of
+// slice 0: one or two memory round trips per workgroup instead of nparts / 8.  Valid in threads tid < C after the call.
+template <int NT>
+__device__ __forceinline__ void fin_totals(const double* __restrict__ part, int nparts, int C, double* __restrict__ sm, double& a,
+                                           double& q) {
+  const int tid = threadIdx.x, c = tid % C, sl = tid / C, slices = NT / C;
+  double pa = 0, pq = 0;
+  for (int s0 = sl; s0 < nparts; s0 += 8 * slices) {
+    double2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const double2*>(part + ((int64_t)min(s0 + u * slices, nparts - 1) * C + c) * 2);
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (s0 + u * slices < nparts) { pa += v[u].x; pq += v[u].y; }
+  }
+  sm[2 * tid] = pa;
+  sm[2 * tid + 1] = pq;
+  __syncthreads();
+  a = 0; q = 0;
+  if (tid < C)
+    for (int j = 0; j < slices; j++) { a += sm[2 * (j * C + tid)]; q += sm[2 * (j * C + tid) + 1]; }
+}
+
 // ---- elementwise passes: tiles of kUa x 256 float4 per block; 256 % (C/4) == 0 keeps a thread on one channel quad ----------
-template <int FORMULA, int NT>
+// res (or nullptr): a tensor of z's shape added to the quantised value before the ReLU (the CDF-only block's `out += shortcut;
+// out = F.relu(out)`, cdf_alignment/resnet-20-cifar-10/model/resnet.py:76-78); the mask bits are those of the stored value.
+template <int FORMULA, int NT, bool FIN = false>
 __global__ __launch_bounds__(NT) void bnq_apply_fwd_kernel(const float* __restrict__ z, const float* __restrict__ ab, int64_t nvec,
                                                            int C, int k, float r, int relu, float* __restrict__ y,
-                                                           unsigned long long* __restrict__ mask = nullptr) {
+                                                           unsigned long long* __restrict__ mask = nullptr,
+                                                           const float* __restrict__ res = nullptr, FinFwd fin = FinFwd{}) {
   __shared__ __attribute__((aligned(16))) float nerf_lds[ALIGNQ_NERF_LDS_FLOATS];
+  __shared__ __attribute__((aligned(16))) float ab_s[FIN ? 2 * kFinC : 4];
   nerf_tab_load(nerf_lds);
+  __shared__ double fin_sm[FIN ? 2 * NT : 2];
+  if (FIN) {
+    double a, q;
+    fin_totals<NT>(fin.part, fin.nparts, C, fin_sm, a, q);
+    if ((int)threadIdx.x < C) {
+      const int c = threadIdx.x;
+      const double n = (double)fin.P;
+      const double mean = a / n;
+      double var = q / n - mean * mean;
+      if (var < 0) var = 0;
+      const float invstd = (float)(1.0 / sqrt(var + (double)fin.eps));
+      const float av = (fin.gamma ? fin.gamma[c] : 1.0f) * invstd;
+      const float bv = (fin.beta ? fin.beta[c] : 0.0f) - (float)mean * av;
+      ab_s[c] = av;
+      ab_s[C + c] = bv;
+      if (blockIdx.x == 0) {
+        fin.ab_out[c] = av; fin.ab_out[C + c] = bv;
+        fin.save_out[c] = (float)mean; fin.save_out[C + c] = invstd;
+        if (fin.running_mean) fin.running_mean[c] = (1.0f - fin.momentum) * fin.running_mean[c] + fin.momentum * (float)mean;
+        if (fin.running_var) fin.running_var[c] = (1.0f - fin.momentum) * fin.running_var[c] + fin.momentum * (float)(var * n / (n - 1.0));
+      }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && fin.nbt) *fin.nbt += 1;
+  }
   __syncthreads();
   const NerfTab tab = nerf_tab(nerf_lds);
   const Levels nlev = make_levels(k, fabsf(r) <= 8.0f);
   z += (int64_t)blockIdx.y * nvec * 4;           // blockIdx.y = group (see bnq_sums_kernel)
   y += (int64_t)blockIdx.y * nvec * 4;
+  if (res) res += (int64_t)blockIdx.y * nvec * 4;
   if (mask) mask += (int64_t)blockIdx.y * mask_words(nvec);
-  ab += (int64_t)blockIdx.y * 2 * C;
+  if (!FIN) ab += (int64_t)blockIdx.y * 2 * C;
+  const float* abp = FIN ? ab_s : ab;
   const int cq = threadIdx.x % (C >> 2);
-  const float4 a4 = *reinterpret_cast<const float4*>(ab + 4 * cq);
-  const float4 b4 = *reinterpret_cast<const float4*>(ab + C + 4 * cq);
+  const float4 a4 = *reinterpret_cast<const float4*>(abp + 4 * cq);
+  const float4 b4 = *reinterpret_cast<const float4*>(abp + C + 4 * cq);
   const float4* z4 = reinterpret_cast<const float4*>(z);
   float4* y4 = reinterpret_cast<float4*>(y);
   const int64_t stride = (int64_t)gridDim.x * NT * kUa;
   ALIGNQ_BOUNDED_SWITCH(nlev,
   for (int64_t i0 = (int64_t)blockIdx.x * (NT * kUa) + threadIdx.x; i0 < nvec; i0 += stride) {
-    float4 v[kUa];
+    float4 v[kUa], rv[kUa];
 _Pragma("unroll")
     for (int u = 0; u < kUa; u++) {
       const int64_t i = i0 + u * NT;
       v[u] = z4[i < nvec ? i : i0];
+      if (res) rv[u] = reinterpret_cast<const float4*>(res)[i < nvec ? i : i0];
     }
 _Pragma("unroll")
     for (int u = 0; u < kUa; u++) {
@@ -289,6 +361,7 @@ _Pragma("unroll")
         o.z = act_quant1<FQ, kBounded>(__fmaf_rn(a4.z, v[u].z, b4.z), k, nlev, r, &t, &b, tab);
         o.w = act_quant1<FQ, kBounded>(__fmaf_rn(a4.w, v[u].w, b4.w), k, nlev, r, &t, &b, tab);
       }
+      if (res) { o.x += rv[u].x; o.y += rv[u].y; o.z += rv[u].z; o.w += rv[u].w; }
       if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
       if (i < nvec) y4[i] = o;
       if (mask) {
@@ -309,21 +382,42 @@ _Pragma("unroll")
   })
 }
 
-template <int NT>
 // g and dz may be the SAME buffer (alignq_bnq_bwd_dx in place: every thread reads its own elements before it writes them),
-// hence no __restrict__ on the two.
+// hence no __restrict__ on the two.  dres (or nullptr): receives the masked upstream gradient g * [y > 0] = the gradient of the
+// forward's residual operand.  FIN: see above (ktot is then formed here from the sums kernel's partials).
+template <int NT, bool FIN = false>
 __global__ __launch_bounds__(NT) void bnq_apply_bwd_kernel(const float* g, const float* __restrict__ z,
                                                            const float* __restrict__ y, const float* __restrict__ ab,
                                                            const float* __restrict__ save, const float* __restrict__ ktot,
                                                            int64_t nvec, int C, float r, int relu, int from_dx,
-                                                           float* dz, const unsigned long long* __restrict__ mask = nullptr) {
+                                                           float* dz, const unsigned long long* __restrict__ mask = nullptr,
+                                                           float* __restrict__ dres = nullptr, FinBwd fin = FinBwd{}) {
   constexpr int U = 2;
+  __shared__ __attribute__((aligned(16))) float k_s[FIN ? 2 * kFinC : 4];
+  __shared__ double fin_sm[FIN ? 2 * NT : 2];
+  if (FIN) {
+    double a, q;
+    fin_totals<NT>(fin.part, fin.nparts, C, fin_sm, a, q);
+    if ((int)threadIdx.x < C) {
+      const int c = threadIdx.x;
+      k_s[c] = (float)(a / (double)fin.P);
+      k_s[C + c] = (float)(q / (double)fin.P);
+      if (blockIdx.x == 0) {
+        if (fin.dbeta) fin.dbeta[c] = (float)a;
+        if (fin.dgamma) fin.dgamma[c] = (float)q;
+      }
+    }
+    __syncthreads();
+    ktot = k_s;
+  }
   {
     const int64_t go = (int64_t)blockIdx.y * nvec * 4;       // blockIdx.y = group
     g += go; z += go; dz += go;
     if (y) y += go;
+    if (dres) dres += go;
     if (mask) mask += (int64_t)blockIdx.y * mask_words(nvec);
-    ab += (int64_t)blockIdx.y * 2 * C; save += (int64_t)blockIdx.y * 2 * C; ktot += (int64_t)blockIdx.y * 2 * C;
+    ab += (int64_t)blockIdx.y * 2 * C; save += (int64_t)blockIdx.y * 2 * C;
+    if (!FIN) ktot += (int64_t)blockIdx.y * 2 * C;
   }
   const int cq = threadIdx.x % (C >> 2);
   const float4 a4 = *reinterpret_cast<const float4*>(ab + 4 * cq), b4 = *reinterpret_cast<const float4*>(ab + C + 4 * cq);
@@ -351,20 +445,23 @@ __global__ __launch_bounds__(NT) void bnq_apply_bwd_kernel(const float* g, const
       const int64_t i = i0 + u * NT;
       const float ge[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w}, ze[4] = {zv[u].x, zv[u].y, zv[u].z, zv[u].w};
       const float ye[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};
-      float o[4];
+      float o[4], gmv[4];
 #pragma unroll
       for (int e = 0; e < 4; e++) {
         float dx = ge[e];
+        gmv[e] = ge[e];
         if (!from_dx) {            // launch-uniform
           const float x = __fmaf_rn(ae[e], ze[e], be[e]);
           const bool pos = mask ? mk[u][e] : (ye[e] > 0.f);
           const float gm = (relu && !pos) ? 0.f : ge[e];
+          gmv[e] = gm;
           dx = gm * act_jac(x, r);
         }
         const float zh = (ze[e] - me[e]) * ie[e];
         o[e] = ae[e] * (dx - k0e[e] - zh * k1e[e]);
       }
       if (i < nvec) *reinterpret_cast<float4*>(dz + 4 * i) = make_float4(o[0], o[1], o[2], o[3]);
+      if (dres && i < nvec) *reinterpret_cast<float4*>(dres + 4 * i) = make_float4(gmv[0], gmv[1], gmv[2], gmv[3]);
     }
   }
 }
@@ -440,11 +537,25 @@ size_t alignq_bnq_mask_bytes(int64_t P, int C, int groups) {
   return (size_t)groups * (size_t)mask_words(P * (C >> 2)) * sizeof(unsigned long long);
 }
 
+namespace {
+// "small" sites finalise inside the apply kernels (see kFinC): one group, few channels, a tensor of a few MB
+inline bool fin_small(int64_t P, int C, int groups) {
+  static const int on = alignq_env::env_choice("ALIGNQ_BNQ_FIN", 1, {0, 1});      // A/B aid: 0 = always the finalisation launches
+  return on && groups == 1 && C <= kFinC && P * C <= ((int64_t)4 << 20);
+}
+inline int fin_parts(int64_t P, int C) {
+  const int n = parts_for(P, C), cap = (64 * 1024) / (C * 16) < kFinParts ? (64 * 1024) / (C * 16) : kFinParts;
+  return n < cap ? n : cap;
+}
+inline int fin_grid(int64_t nvec, int u) { const int t = tiles(nvec, u); return t < 512 ? t : 512; }
+}  // namespace
+
 int alignq_bnq_fwd(const float* z, int64_t P, int C, int groups, const float* gamma, const float* beta, float* running_mean,
                    float* running_var, int64_t* num_batches_tracked, float momentum, float bn_eps, int k, float act_range,
-                   int formula, int relu, float* ab, float* save, float* y, void* mask, void* ws, void* stream) {
+                   int formula, int relu, const float* residual, float* ab, float* save, float* y, void* mask, void* ws,
+                   void* stream) {
   if (!z || !ab || !save || !y || !ws || P < 2 || bad_groups(groups)) return ALIGNQ_EINVAL;
-  if (reinterpret_cast<uintptr_t>(mask) & 15) return ALIGNQ_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(mask) | reinterpret_cast<uintptr_t>(residual)) & 15) return ALIGNQ_EINVAL;
   unsigned long long* mk = reinterpret_cast<unsigned long long*>(mask);
   if (!((k >= 1 && k <= 16) || k == 32)) return ALIGNQ_EINVAL;
   if (formula != ALIGNQ_FORMULA_ADMM && formula != ALIGNQ_FORMULA_CDF) return ALIGNQ_EINVAL;
@@ -452,26 +563,42 @@ int alignq_bnq_fwd(const float* z, int64_t P, int C, int groups, const float* ga
   if ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(y)) & 15) return ALIGNQ_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   double* part = reinterpret_cast<double*>(ws);
+  const int64_t nvec = P * (C >> 2);
+  if (fin_small(P, C, groups)) {
+    const int np = fin_parts(P, C);
+    BNQ_SUMS_NT(C, hipLaunchKernelGGL((bnq_sums_kernel<0, NTV>), dim3(np, 1), dim3(NTV), 0, st, z, nullptr, nullptr, nullptr, nullptr, P, C,
+                       act_range, 0, part));
+    const FinFwd fin{part, np, P, gamma, beta, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), momentum,
+                     bn_eps, ab, save};
+    const dim3 grid(fin_grid(nvec, kUa), 1);
+    if (formula == ALIGNQ_FORMULA_ADMM)
+      hipLaunchKernelGGL((bnq_apply_fwd_kernel<0, kT, true>), grid, dim3(kT), 0, st, z, (const float*)ab, nvec, C, k, act_range, relu, y, mk,
+                         residual, fin);
+    else
+      hipLaunchKernelGGL((bnq_apply_fwd_kernel<1, kT, true>), grid, dim3(kT), 0, st, z, (const float*)ab, nvec, C, k, act_range, relu, y, mk,
+                         residual, fin);
+    return hipGetLastError() == hipSuccess ? 0 : ALIGNQ_EINVAL;
+  }
   const int np = parts_for(P, C);
   BNQ_SUMS_NT(C, hipLaunchKernelGGL((bnq_sums_kernel<0, NTV>), dim3(np, groups), dim3(NTV), 0, st, z, nullptr, nullptr, nullptr, nullptr, P, C,
                      act_range, 0, part));
   hipLaunchKernelGGL(bnq_finalize_kernel, dim3((C + 3) / 4), dim3(kT), 0, st, (const double*)part, np, P, C, gamma, beta,
                      running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), momentum, bn_eps, ab, save,
                      groups);
-  const int64_t nvec = P * (C >> 2);
   if (formula == ALIGNQ_FORMULA_ADMM)
     BNQ_NT(C, hipLaunchKernelGGL((bnq_apply_fwd_kernel<0, NTV>), dim3(tiles(nvec, kUa, NTV), groups), dim3(NTV), 0, st, z, (const float*)ab, nvec, C, k,
-                       act_range, relu, y, mk));
+                       act_range, relu, y, mk, residual));
   else
     BNQ_NT(C, hipLaunchKernelGGL((bnq_apply_fwd_kernel<1, NTV>), dim3(tiles(nvec, kUa, NTV), groups), dim3(NTV), 0, st, z, (const float*)ab, nvec, C, k,
-                       act_range, relu, y, mk));
+                       act_range, relu, y, mk, residual));
   return hipGetLastError() == hipSuccess ? 0 : ALIGNQ_EINVAL;
 }
 
 int alignq_bnq_bwd(const float* g, const float* z, const float* y, const void* mask, const float* ab, const float* save, int64_t P,
-                   int C, int groups, float act_range, int relu, float* dz, float* dgamma, float* dbeta, void* ws, void* stream) {
+                   int C, int groups, float act_range, int relu, float* dz, float* dres, float* dgamma, float* dbeta, void* ws,
+                   void* stream) {
   if (!g || !z || !ab || !save || !dz || !ws || P < 2 || (relu && !y && !mask) || bad_groups(groups)) return ALIGNQ_EINVAL;
-  if (reinterpret_cast<uintptr_t>(mask) & 15) return ALIGNQ_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(mask) | reinterpret_cast<uintptr_t>(dres)) & 15) return ALIGNQ_EINVAL;
   const unsigned long long* mk = reinterpret_cast<const unsigned long long*>(mask);
   if (mk) y = nullptr;          // one source for the ReLU mask: the bits when they are given
   if (bad_c(C)) return ALIGNQ_EUNSUPPORTED;
@@ -481,13 +608,21 @@ int alignq_bnq_bwd(const float* g, const float* z, const float* y, const void* m
   hipStream_t st = (hipStream_t)stream;
   double* part = reinterpret_cast<double*>(ws);
   float* ktot = ktot_of(ws, C, groups);
+  const int64_t nvec = P * (C >> 2);
+  if (fin_small(P, C, groups)) {
+    const int np = fin_parts(P, C);
+    BNQ_SUMS_NT(C, hipLaunchKernelGGL((bnq_sums_kernel<1, NTV>), dim3(np, 1), dim3(NTV), 0, st, z, g, y, ab, save, P, C, act_range, relu, part, mk));
+    const FinBwd fin{part, np, P, dgamma, dbeta};
+    hipLaunchKernelGGL((bnq_apply_bwd_kernel<kT, true>), dim3(fin_grid(nvec, 2), 1), dim3(kT), 0, st, g, z, y, ab, save, (const float*)ktot, nvec,
+                       C, act_range, relu, 0, dz, mk, dres, fin);
+    return hipGetLastError() == hipSuccess ? 0 : ALIGNQ_EINVAL;
+  }
   const int np = parts_for(P, C);
   BNQ_SUMS_NT(C, hipLaunchKernelGGL((bnq_sums_kernel<1, NTV>), dim3(np, groups), dim3(NTV), 0, st, z, g, y, ab, save, P, C, act_range, relu, part, mk));
   hipLaunchKernelGGL(bnq_finalize_bwd_kernel, dim3((C + 3) / 4), dim3(kT), 0, st, (const double*)part, np, P, C, ktot,
                      dgamma, dbeta, groups);
-  const int64_t nvec = P * (C >> 2);
   BNQ_NT(C, hipLaunchKernelGGL((bnq_apply_bwd_kernel<NTV>), dim3(tiles(nvec, 2, NTV), groups), dim3(NTV), 0, st, g, z, y, ab, save, (const float*)ktot, nvec,
-                     C, act_range, relu, 0, dz, mk));
+                     C, act_range, relu, 0, dz, mk, dres));
   return hipGetLastError() == hipSuccess ? 0 : ALIGNQ_EINVAL;
 }
 

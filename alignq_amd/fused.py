@@ -617,8 +617,13 @@ class BNQuantReluFn(torch.autograd.Function):
     over the slices - one autograd node, so no gradient accumulation kernels."""
 
     @staticmethod
-    def forward(ctx, z, weight, bias, running_mean, running_var, nbt, momentum, bn_eps, k, act_range, formula, relu, groups=1):
+    def forward(ctx, z, weight, bias, running_mean, running_var, nbt, momentum, bn_eps, k, act_range, formula, relu, groups=1,
+                residual=None):
+        """residual: added to the quantised value before the ReLU in the same pass (the CDF-only block's `out += shortcut;
+        relu`); its gradient - the masked upstream gradient - is a second output of the backward's apply pass."""
         z = L.dense_f32(z, "conv output")
+        if residual is not None:
+            residual = L.like_layout(L.dense_f32(residual, "residual"), z)
         B, C, H, W = z.shape
         lib = L.load()
         dev = z.device
@@ -633,10 +638,12 @@ class BNQuantReluFn(torch.autograd.Function):
         mask = torch.empty(lib.alignq_bnq_mask_bytes(P, C, groups), dtype=torch.uint8, device=dev) if (relu and _BNQ_BITMASK) else None
         L.check(lib.alignq_bnq_fwd(L.ptr(z), P, C, groups, L.ptr(weight), L.ptr(bias), L.ptr(running_mean), L.ptr(running_var),
                                    L.ptr(nbt), float(momentum), float(bn_eps), int(k), float(act_range), int(formula),
-                                   int(bool(relu)), L.ptr(ab), L.ptr(save), L.ptr(y), L.ptr(mask), L.ptr(ws), L.stream_ptr()),
+                                   int(bool(relu)), L.ptr(residual), L.ptr(ab), L.ptr(save), L.ptr(y), L.ptr(mask), L.ptr(ws),
+                                   L.stream_ptr()),
                 "alignq_bnq_fwd")
         ctx.save_for_backward(z, (mask if mask is not None else y) if relu else None, ab, save)
         ctx.bitmask = mask is not None
+        ctx.has_res = residual is not None
         ctx.cfg = (float(act_range), bool(relu), weight is not None, bias is not None, int(groups))
         ctx.mark_non_differentiable(*[t for t in (running_mean, running_var, nbt) if t is not None])
         return y
@@ -654,10 +661,14 @@ class BNQuantReluFn(torch.autograd.Function):
         dbeta = torch.empty(C, dtype=torch.float32, device=z.device) if has_b else None
         ws = torch.empty(lib.alignq_bnq_ws_bytes(C, groups), dtype=torch.uint8, device=z.device)
         ym, mk = (None, y) if ctx.bitmask else (y, None)
+        # the residual's gradient: g itself without a ReLU behind the sum, else the masked g (written by the apply pass)
+        dres = torch.empty_like(z) if (ctx.has_res and relu and ctx.needs_input_grad[13]) else None
         L.check(lib.alignq_bnq_bwd(L.ptr(g), L.ptr(z), L.ptr(ym), L.ptr(mk), L.ptr(ab), L.ptr(save), Bg * H * W, C, groups, act_range,
-                                   int(relu), L.ptr(dz), L.ptr(dgamma), L.ptr(dbeta), L.ptr(ws), L.stream_ptr()),
+                                   int(relu), L.ptr(dz), L.ptr(dres), L.ptr(dgamma), L.ptr(dbeta), L.ptr(ws), L.stream_ptr()),
                 "alignq_bnq_bwd")
-        return dz, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
+        if ctx.has_res and not relu and ctx.needs_input_grad[13]:
+            dres = g
+        return dz, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, dres
 
 
 def _bn_nhwc_ok(bn, z, groups=1) -> bool:
@@ -920,19 +931,23 @@ def fork_block_input(x):
     return GradFork.apply(x, tok)
 
 
-def bn_act_relu(bn, act, z, formula, relu=True, groups=1):
-    """[relu](act(bn(z))) for a quantiser WITHOUT an ADMM term: one fused chain when `bnq_fusable` (training mode,
+def bn_act_relu(bn, act, z, formula, relu=True, groups=1, residual=None):
+    """[relu](act(bn(z)) [+ residual]) for a quantiser WITHOUT an ADMM term: one fused chain when `bnq_fusable` (training mode,
     channels-last fp32 CUDA tensor, C = 4 * 2^j <= 2048), else exactly that composition (groups: see BNQuantReluFn)."""
     from . import config
-    if not bnq_fusable(bn, act, z, groups):
-        def one(zz):
+    res_ok = residual is None or (residual.shape == z.shape and residual.is_cuda and residual.dtype == torch.float32)
+    if not (bnq_fusable(bn, act, z, groups) and res_ok):
+        def one(zz, rr):
             out = act(bn(zz))
+            if rr is not None:
+                out = out + rr
             return torch.nn.functional.relu(out) if relu else out
         if groups == 1:
-            return one(z)
-        return torch.cat([one(zz) for zz in _slices(z, groups)], 0)
+            return one(z, residual)
+        rs = _slices(residual, groups) if residual is not None else [None] * groups
+        return torch.cat([one(zz, rr) for zz, rr in zip(_slices(z, groups), rs)], 0)
     return BNQuantReluFn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum,
-                               bn.eps, act.a_bit, config.args.act_range, formula, relu, groups)
+                               bn.eps, act.a_bit, config.args.act_range, formula, relu, groups, residual)
 
 
 # ------------------------------------------------------------------------------------------------------------------

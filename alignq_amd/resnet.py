@@ -81,12 +81,7 @@ class PreActBlock_conv_Q(nn.Module):
             # configuration 1 (cdf_alignment/resnet-20-cifar-10/model/resnet.py:63-79): no correlation term, so the fold is the
             # plain-quantiser family (alignq_bnq_fwd / _bwd, formula 1); it falls back to exactly the composition below when
             # the tensor is not channels-last fp32 in training mode
-            out = bn_act_relu(bn, fn, z, 1, relu=relu and residual is None)
-            if residual is not None:
-                out = out + residual
-                if relu:
-                    out = F.relu(out)
-            return out, 0
+            return bn_act_relu(bn, fn, z, 1, relu=relu, residual=residual), 0
         out, loss = self._q(fn, bn(z))
         if residual is not None:
             out += residual

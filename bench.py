@@ -482,7 +482,7 @@ def measure_office_shapes(dev, k):
         masks = [torch.empty(lib.alignq_bnq_mask_bytes(P, C, G), dtype=torch.uint8, device=dev) for _ in range(R)]
 
         def f_fwd(i):
-            L.check(lib.alignq_bnq_fwd(p(zs[i]), P, C, G, p(gam), p(bet), p(rm), p(rv), p(nbt), 0.1, 1e-5, k, 2.0, 0, 1, p(ab), p(save),
+            L.check(lib.alignq_bnq_fwd(p(zs[i]), P, C, G, p(gam), p(bet), p(rm), p(rv), p(nbt), 0.1, 1e-5, k, 2.0, 0, 1, None, p(ab), p(save),
                                        p(ys[i]), p(masks[i]), p(ws), st), "alignq_bnq_fwd")
 
         def f_stats(i):
@@ -490,11 +490,11 @@ def measure_office_shapes(dev, k):
                     "alignq_bnq_stats")
 
         def f_bwd(i):
-            L.check(lib.alignq_bnq_bwd(p(gs[i]), p(zs[i]), None, p(masks[i]), p(ab), p(save), P, C, G, 2.0, 1, p(dzs[i]), p(dgam), p(dbet),
+            L.check(lib.alignq_bnq_bwd(p(gs[i]), p(zs[i]), None, p(masks[i]), p(ab), p(save), P, C, G, 2.0, 1, p(dzs[i]), None, p(dgam), p(dbet),
                                        p(ws), st), "alignq_bnq_bwd")
 
         def f_bwd_y(i):           # round 3's form: the ReLU mask from the fp32 y (28 B/element)
-            L.check(lib.alignq_bnq_bwd(p(gs[i]), p(zs[i]), p(ys[i]), None, p(ab), p(save), P, C, G, 2.0, 1, p(dzs[i]), p(dgam), p(dbet),
+            L.check(lib.alignq_bnq_bwd(p(gs[i]), p(zs[i]), p(ys[i]), None, p(ab), p(save), P, C, G, 2.0, 1, p(dzs[i]), None, p(dgam), p(dbet),
                                        p(ws), st), "alignq_bnq_bwd")
         for i in range(R):
             f_fwd(i)

@@ -502,11 +502,17 @@ size_t alignq_bnq_ws_bytes(int C, int groups);
  * one per quad component: the forward's wave-wide compare results); alignq_bnq_bwd with mask != NULL takes the ReLU mask from
  * those bits and does not read y (y may be NULL): 20.25 instead of 28 B/element.  Same values either way.                   */
 size_t alignq_bnq_mask_bytes(int64_t P, int C, int groups);
+/* residual (round 4; or NULL): a tensor of z's shape added to the quantised value before the ReLU - `out = act_q1(bn1(.)); out +=
+ * shortcut; out = F.relu(out)` of the CDF-only block (cdf_alignment/resnet-20-cifar-10/model/resnet.py:73-78) in the one apply
+ * pass; dres (or NULL) then receives its gradient, the masked upstream gradient g * [y > 0].  Small single-group sites (C <= 64, a
+ * few MB: configuration 1) skip the two finalisation launches: the apply kernels finalise the <= 32 partials per channel themselves.*/
 int alignq_bnq_fwd(const float* z, int64_t P, int C, int groups, const float* gamma, const float* beta, float* running_mean,
                    float* running_var, int64_t* num_batches_tracked, float momentum, float bn_eps, int k, float act_range,
-                   int formula, int relu, float* ab, float* save, float* y, void* mask, void* ws, void* stream);
+                   int formula, int relu, const float* residual, float* ab, float* save, float* y, void* mask, void* ws,
+                   void* stream);
 int alignq_bnq_bwd(const float* g, const float* z, const float* y, const void* mask, const float* ab, const float* save, int64_t P,
-                   int C, int groups, float act_range, int relu, float* dz, float* dgamma, float* dbeta, void* ws, void* stream);
+                   int C, int groups, float act_range, int relu, float* dz, float* dres, float* dgamma, float* dbeta, void* ws,
+                   void* stream);
 
 #ifdef __cplusplus
 }

@@ -187,7 +187,9 @@ def test_nerf32_device_equals_oracle_on_edge_inputs(dev):
 
 
 # ------------------------------------------------------------------------------------------------ VERDICT r2 item 4 (N1, Office)
-@pytest.mark.parametrize("B,C,H,k", [(28, 64, 56, 8), (6, 512, 7, 4), (28, 256, 14, 8), (3, 4, 5, 2), (28, 64, 112, 8)])
+# (128, 16, 32) / (100, 32, 16) / (3, 4, 5): "small" sites (round 4: the apply kernels finalise the statistics themselves)
+@pytest.mark.parametrize("B,C,H,k", [(28, 64, 56, 8), (6, 512, 7, 4), (28, 256, 14, 8), (3, 4, 5, 2), (28, 64, 112, 8), (128, 16, 32, 8),
+                                     (100, 32, 16, 4)])
 def test_bn_folded_plain_quantiser_vs_oracle_and_torch_batchnorm(dev, B, C, H, k):
     """relu(act_q(bn(z))) of the Office bottleneck's first two sites and of the stem (dann_office/model/resnet.py:134-143,
     :230-233) as the folded chain (fused.bn_act_relu -> alignq_bnq_fwd / _bwd), channels-last, batch 28 shapes included:

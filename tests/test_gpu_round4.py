@@ -182,7 +182,7 @@ def test_bnq_backward_with_the_relu_mask_as_bits_equals_the_fp32_y_form(dev, Bt,
     nvec = P * C // 4
     assert nbytes == groups * ((nvec + 63) // 64) * 32
     mask = torch.full((nbytes,), 0xAA, dtype=torch.uint8, device=dev)
-    L.check(lib.alignq_bnq_fwd(p(z), P, C, groups, p(gam), p(bet), p(rm), p(rv), p(nbt), 0.1, 1e-5, 8, 2.0, 0, 1, p(ab), p(save), p(y),
+    L.check(lib.alignq_bnq_fwd(p(z), P, C, groups, p(gam), p(bet), p(rm), p(rv), p(nbt), 0.1, 1e-5, 8, 2.0, 0, 1, None, p(ab), p(save), p(y),
                                p(mask), p(ws), st), "alignq_bnq_fwd")
     # the bits: per group and chunk of 64 quads four little-endian 64-bit words, word = quad component, bit = quad within the chunk
     yq = npy(y).reshape(groups, nvec, 4) > 0
@@ -193,7 +193,7 @@ def test_bnq_backward_with_the_relu_mask_as_bits_equals_the_fp32_y_form(dev, Bt,
     for use_bits in (False, True):
         dz, dg, db = torch.empty_like(z), torch.empty(C, device=dev), torch.empty(C, device=dev)
         L.check(lib.alignq_bnq_bwd(p(g), p(z), None if use_bits else p(y), p(mask) if use_bits else None, p(ab), p(save), P, C, groups,
-                                   2.0, 1, p(dz), p(dg), p(db), p(ws), st), "alignq_bnq_bwd")
+                                   2.0, 1, p(dz), None, p(dg), p(db), p(ws), st), "alignq_bnq_bwd")
         outs.append((npy(dz), npy(dg), npy(db)))
     for a, b in zip(*outs):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
@@ -248,7 +248,7 @@ def test_cdf_only_resnet20_full_size_step_on_the_fast_path(dev, monkeypatch):
     """Configuration 1 (cdf_alignment/resnet-20-cifar-10: model/resnet.py:63-79,134, main.py:269-315) at FULL size - ResNet-20,
     batch 128, 8W/8A - on the HIP fast path: channels-last, Conv2d_Q's body convolutions on alignq_conv3x3_nhwc, every
     `act_q(bn(.))` folded (fused.bn_act_relu -> alignq_bnq_fwd / _bwd, formula 1).  Three sites (stem; a block's bn0 with the
-    ReLU; the last block's bn1 without) are checked teacher-forced against the C oracle on the tensors the step itself produced:
+    ReLU; the last block's bn1 with the shortcut and the ReLU in the same pass) are checked teacher-forced against the C oracle on the tensors the step itself produced:
     x_q bit-exact outside a near-tie band (the device's (a, b) differ by ~1e-6 from the oracle's), at most one level inside;
     the loss is finite, every site really took the folded path, and the captured HIP graph reproduces eager iterations."""
     import alignq_amd.resnet as RN
@@ -262,10 +262,10 @@ def test_cdf_only_resnet20_full_size_step_on_the_fast_path(dev, monkeypatch):
         calls = []
         real = fused.bn_act_relu
 
-        def spy(bn, act, z, formula, relu=True, groups=1):
+        def spy(bn, act, z, formula, relu=True, groups=1, residual=None):
             assert formula == 1 and fused.bnq_fusable(bn, act, z, groups)
-            out = real(bn, act, z, formula, relu=relu, groups=groups)
-            calls.append((bn, z.detach(), out.detach(), relu))
+            out = real(bn, act, z, formula, relu=relu, groups=groups, residual=residual)
+            calls.append((bn, z.detach(), out.detach(), relu, None if residual is None else residual.detach()))
             return out
         monkeypatch.setattr(RN, "bn_act_relu", spy)
 
@@ -285,13 +285,15 @@ def test_cdf_only_resnet20_full_size_step_on_the_fast_path(dev, monkeypatch):
         assert torch.isfinite(logits).all() and torch.isfinite(ce) and (tl is None or float(tl) == 0.0)
         assert len(calls) == 21                                  # 1 stem + 9 blocks x 2 + 2 shortcut sites
         for idx in (0, 1, len(calls) - 1):
-            bn, z, out, relu = calls[idx]
+            bn, z, out, relu, resid = calls[idx]
             B, C, H, W = z.shape
             gam, bet = before[id(bn)]
             zm = np.ascontiguousarray(npy(z).transpose(0, 2, 3, 1)).reshape(B, -1)
             ab_o, _, _ = O.bn_fold_ab(zm, C, 1, gam, bet, bn.eps)
             x_o = O.bn_apply(zm, C, 1, ab_o)
             q_o, c_o, _ = O.act_quant_fwd(x_o, k, r, O.FORMULA_CDF)
+            if resid is not None:         # `out += shortcut` rides in the same pass (resnet.py:76-78)
+                q_o = q_o + np.ascontiguousarray(npy(resid).transpose(0, 2, 3, 1)).reshape(B, -1)
             y_o = np.maximum(q_o, 0.0) if relu else q_o
             frac = c_o.astype(np.float64) * n
             near = np.abs(frac - np.floor(frac) - 0.5) < 2e-3
@@ -315,3 +317,99 @@ def test_cdf_only_resnet20_full_size_step_on_the_fast_path(dev, monkeypatch):
             assert np.median(d) < 1e-4 and d.max() < 2e-2, (nm, float(np.median(d)), float(d.max()))
     finally:
         config.args.bitW, config.args.abitW, config.args.train_batch_size = old
+
+
+# ------------------------------------------------------------------------------------------------ round 4: residual in the fold
+@pytest.mark.parametrize("B,C,H,relu", [(128, 16, 32, True), (100, 64, 8, True), (28, 128, 28, True), (9, 8, 5, False)])
+def test_bn_folded_plain_quantiser_with_residual_equals_the_composition(dev, B, C, H, relu):
+    """`out = act_q1(bn1(z)); out += shortcut; out = F.relu(out)` of the CDF-only block (cdf_alignment/resnet-20-cifar-10/model/
+    resnet.py:73-78) as ONE folded chain (fused.bn_act_relu(residual=): the shortcut joins in the apply pass, its gradient is the
+    apply pass's second output) against the fold WITHOUT the residual followed by torch's add and ReLU: the same bits forward and
+    backward (same kernels' arithmetic on the same data, fp32 add and max are exact operations), small (in-kernel finalisation) and
+    large sites alike."""
+    import alignq_amd.cdf_alignment as NC
+    from alignq_amd import config, fused
+    old = config.args.abitW
+    config.args.abitW = 8
+    try:
+        torch.manual_seed(B + C + H)
+        cl = lambda t: t.contiguous(memory_format=torch.channels_last)      # noqa: E731
+        z0 = cl(torch.randn(B, C, H, H, device=dev) * 1.3 + 0.2)
+        r0 = cl(torch.randn(B, C, H, H, device=dev))
+        g0 = cl(torch.randn(B, C, H, H, device=dev) * 0.01)
+        outs = []
+        for folded in (False, True):
+            torch.manual_seed(5)
+            bn = torch.nn.BatchNorm2d(C).to(dev).train()
+            with torch.no_grad():
+                bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.2)
+            act = NC.activation_quantize_fn(8, "second").to(dev)
+            z, res = z0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+            if folded:
+                y = fused.bn_act_relu(bn, act, z, 1, relu=relu, residual=res)
+            else:
+                y = fused.bn_act_relu(bn, act, z, 1, relu=False) + res
+                if relu:
+                    y = torch.relu(y)
+            y.backward(g0)
+            outs.append([npy(t) for t in (y, z.grad, res.grad, bn.weight.grad, bn.bias.grad, bn.running_mean, bn.running_var)])
+        for u, v in zip(*outs):
+            assert np.array_equal(u, v)            # by value: a ReLU may return either zero for a negative zero
+    finally:
+        config.args.abitW = old
+
+
+def test_small_site_finalisation_inside_the_apply_kernels_equals_the_launches(dev):
+    """ALIGNQ_BNQ_FIN=0 (the finalisation launches everywhere) against the default (small single-group sites finalise inside the
+    apply kernels) in child processes on one seeded problem: y, the mask bits, (a, b), the saved statistics, the running statistics,
+    dz, dgamma, dbeta - the partial counts differ (<= 32 instead of up to 512 per channel), so the sums agree to double rounding and
+    the fp32 results to 1 ulp of the statistics: compared at 1e-6 relative, y at bin-flip scale."""
+    import os
+    import subprocess
+    import sys
+    prog = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, ".")
+from alignq_amd import _lib as L
+lib = L.load(); st, p = L.stream_ptr(), L.ptr
+dev = torch.device("cuda:0"); torch.manual_seed(0)
+B, C, H = 128, 16, 32
+P = B * H * H
+z = torch.randn(B, H, H, C, device=dev) * 1.3 + 0.1
+g = torch.randn(B, H, H, C, device=dev) * 0.01
+res = torch.randn(B, H, H, C, device=dev)
+gam, bet = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev) * 0.3
+rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+nbt = torch.zeros((), dtype=torch.int64, device=dev)
+ab, save = torch.empty(1, 2, C, device=dev), torch.empty(1, 2, C, device=dev)
+y, dz, dres = torch.empty_like(z), torch.empty_like(z), torch.empty_like(z)
+dg, db = torch.empty(C, device=dev), torch.empty(C, device=dev)
+ws = torch.empty(lib.alignq_bnq_ws_bytes(C, 1), dtype=torch.uint8, device=dev)
+mask = torch.zeros(lib.alignq_bnq_mask_bytes(P, C, 1), dtype=torch.uint8, device=dev)
+L.check(lib.alignq_bnq_fwd(p(z), P, C, 1, p(gam), p(bet), p(rm), p(rv), p(nbt), 0.1, 1e-5, 8, 2.0, 1, 1, p(res), p(ab), p(save), p(y),
+                           p(mask), p(ws), st), "fwd")
+L.check(lib.alignq_bnq_bwd(p(g), p(z), None, p(mask), p(ab), p(save), P, C, 1, 2.0, 1, p(dz), p(dres), p(dg), p(db), p(ws), st), "bwd")
+torch.cuda.synchronize()
+np.savez(sys.argv[1], y=y.cpu().numpy(), mask=mask.cpu().numpy(), ab=ab.cpu().numpy(), save=save.cpu().numpy(), rm=rm.cpu().numpy(),
+         rv=rv.cpu().numpy(), nbt=nbt.cpu().numpy(), dz=dz.cpu().numpy(), dres=dres.cpu().numpy(), dg=dg.cpu().numpy(), db=db.cpu().numpy())
+'''
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for fin in ("0", "1"):
+            out = os.path.join(td, f"r{fin}.npz")
+            env = dict(os.environ, ALIGNQ_BNQ_FIN=fin)
+            subprocess.run([sys.executable, "-c", prog, out], cwd=root, env=env, check=True, timeout=300)
+            with np.load(out) as f:
+                res[fin] = {k: f[k] for k in f.files}
+    a, b = res["0"], res["1"]
+    assert int(a["nbt"]) == int(b["nbt"]) == 1
+    for key in ("ab", "save", "rm", "rv", "dg", "db"):
+        np.testing.assert_allclose(b[key], a[key], rtol=2e-6, atol=1e-7, err_msg=key)
+    np.testing.assert_allclose(b["dz"], a["dz"], rtol=1e-4, atol=1e-7)
+    lev = 4.0 / 255                                               # one level of x_q = r * (2 bin / n - 1)
+    dy = np.abs(b["y"] - a["y"])
+    assert dy.max() <= lev * 1.001 and np.count_nonzero(dy) < 1e-4 * dy.size      # a 1-ulp (a, b) moves a few near-tie elements
+    same = dy == 0
+    assert np.array_equal(b["dres"][same], a["dres"][same])
