@@ -91,7 +91,7 @@ latest = {"site_bwd": {"hbm_bytes_per_launch_avg": avg_bytes("site_bwd4_kernel")
           "site_partials": {"hbm_bytes_per_launch_avg": avg_bytes("site_fwd4_kernel")},
           "act_quant_fwd": {"hbm_bytes_per_launch_avg": avg_bytes("act_quant_fwd_kernel")},
           "act_quant_bwd": {"hbm_bytes_per_launch_avg": avg_bytes("act_quant_bwd_kernel")},
-          "source": "profiles/r03_pmc_hbm_bytes.csv (2 x FETCH_SIZE + WRITE_SIZE per dispatch, mean over all dispatches of the "
+          "source": "profiles/r04_pmc_hbm_bytes.csv (2 x FETCH_SIZE + WRITE_SIZE per dispatch, mean over all dispatches of the "
                     "kernel in `bench.py --steps 2`: the three site shapes of ResNet-20 for the site kernels, 2^26 elements for act_quant)"}
 json.dump(latest, open(os.path.join(out, "pmc_latest.json"), "w"), indent=1)
 print(json.dumps(latest, indent=1))
