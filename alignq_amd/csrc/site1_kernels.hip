@@ -10,9 +10,9 @@
 //     [feature][row] with 16-byte stores; the same wave reads it back in MFMA fragment order (lane = row, 8 consecutive
 //     features: conflict-free 4-byte reads, hi and lo in one word) and runs the 3-term split-bf16 Gram
 //     (v_mfma_f32_32x32x16_bf16) into ONE 32x32 accumulator per wave, D = T-Gram - X-Gram (x A-operand sign-flipped);
-//   * backward: the same staging feeds S*Xh / S*Th (S = 32x32, two K-steps, register-resident hi/lo A fragments);
-//     the 32x32 results go back through the wave's LDS buffer into lane = column layout, where the standardisation
-//     backward (batch projections) is again pure register arithmetic and dx leaves as 256-byte row segments.
+//   * backward (rewritten in round 4): S*Xh / S*Th on the FP32 matrix instruction with operands and results in registers only - a
+//     lane owns exactly the rows the accumulator hands it, so nothing is split into bf16 halves, staged or transposed (see
+//     site1_bwd_kernel); the standardisation backward (batch projections) is register arithmetic, dx leaves as row segments.
 //   * the four waves of a workgroup only meet at the very end of the forward to add their accumulators into the slab.
 #include <hip/hip_runtime.h>
 
@@ -278,47 +278,30 @@ __global__ __launch_bounds__(kThreads1, PAIR ? 4 : 5) void site1_fwd_kernel(cons
 }
 
 // ================================================================================================ backward
-// dVh = S Vh for the staged 32 features: [32 batch rows][32 features] in accumulator layout
-// (lane -> feature l31, rows (e&3)+8(e>>2)+4h)
-__device__ __forceinline__ void s_times_staged(const unsigned* __restrict__ W, const bf16x8 (&sh)[2],
-                                               const bf16x8 (&sl)[2], int l31, int h, f32x16& acc) {
-#pragma unroll
-  for (int ks = 0; ks < 2; ks++) {
-    // B operand: feature l31, 8 consecutive batch rows 16ks + 8h .. : contiguous words of W
-    const u32x4* src = reinterpret_cast<const u32x4*>(W + l31 * LDW + 16 * ks + 8 * h);
-    const u32x4 a = src[0], b = src[1];
-    const unsigned wd[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-    bf16x8 hi, lo;
-    unpack8(wd, hi, lo);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sh[ks], hi, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sh[ks], lo, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sl[ks], hi, acc, 0, 0, 0);
-  }
-}
-
-// accumulator layout -> (feature l31, row half hh) layout through the wave buffer (as fp32): R[feature][row]
-__device__ __forceinline__ void acc_to_rows(float* __restrict__ R, int l31, int h, const f32x16& acc,
-                                            float (&out)[RPL]) {
-#pragma unroll
-  for (int e = 0; e < 16; e++) R[l31 * LDW + (e & 3) + 8 * (e >> 2) + 4 * h] = acc[e];
-  wave_lds_sync();
-  const float4* src = reinterpret_cast<const float4*>(R + l31 * LDW + RPL * h);
-#pragma unroll
-  for (int q = 0; q < RPL / 4; q++) {
-    const float4 v = src[q];
-    out[4 * q] = v.x; out[4 * q + 1] = v.y; out[4 * q + 2] = v.z; out[4 * q + 3] = v.w;
-  }
-  wave_lds_sync();
-}
+// site1_bwd_kernel (rewritten in round 4): S * Vh on the FP32 matrix instruction v_mfma_f32_32x32x2_f32, operands and results in
+// registers only.  Round 3's kernel is vector-ALU bound (~1500 vector instructions per 32-feature sub-tile and wave: 61 of its
+// 68 us at [28, 802816] are issue slots); a fifth of them split every standardised value into bf16 hi / lo halves, staged the
+// packed words through LDS into MFMA fragment order, unpacked them, and carried the 32x32 result back through LDS into the
+// lanes' row layout.  None of that is needed when a lane owns the ROWS the accumulator hands it:
+//   * lane (feature f = l & 31, half h = l >> 5) owns rows R(q, h) = (q & 3) + 8 (q >> 2) + 4 h, q = 0..15 - exactly the rows of
+//     accumulator element q of v_mfma_f32_32x32x* in that lane (loads and stores address these rows; a wave instruction still
+//     reads two 128-byte row segments);
+//   * D[i][f] = sum_k S[i][k] Vh[k][f]: step m of 16 contracts k = R(m, half): the B operand of lane (f, h) is ITS OWN register
+//     Vh[R(m, h)][f], the A operand is S[i = l & 31][R(m, l >> 5)] - sixteen registers loaded once per launch (fp32: no split);
+//     rows >= B contribute nothing because S is zero there (the clamped loads keep every operand finite);
+//   * the result element q of lane (f, h) is D[R(q, h)][f]: the lane's own rows - no transposition.
+// 32 fp32 MFMAs per sub-tile (2048 matrix-pipe cycles per SIMD and sub-tile against ~4600 vector cycles): the matrix pipe is
+// not the limit, and exact fp32 products replace the 3-term split.  No LDS at all.
+__device__ __forceinline__ int row_of(int q, int h) { return (q & 3) + 8 * (q >> 2) + 4 * h; }
 
 template <bool PAIR>
-__global__ __launch_bounds__(kThreads1, 3) void site1_bwd_kernel(const float* __restrict__ gup, const float* __restrict__ S,
-                                                              const float* __restrict__ x,
-                                                              const float* __restrict__ stats, int B, int64_t F, float r,
-                                                              float eps, float* __restrict__ dx, int n_sub,
-                                                              const float* __restrict__ ab, int C,
-                                                              const float* __restrict__ ymask, float* __restrict__ dres,
-                                                              int64_t s_gstride, const float* __restrict__ gup2 = nullptr) {
+__global__ __launch_bounds__(kThreads1, PAIR ? 3 : 5) void site1_bwd_kernel(const float* __restrict__ gup, const float* __restrict__ S,
+                                                               const float* __restrict__ x,
+                                                               const float* __restrict__ stats, int B, int64_t F, float r,
+                                                               float eps, float* __restrict__ dx, int n_sub,
+                                                               const float* __restrict__ ab, int C,
+                                                               const float* __restrict__ ymask, float* __restrict__ dres,
+                                                               int64_t s_gstride, const float* __restrict__ gup2) {
   {        // blockIdx.y = group (see site1_fwd_kernel); S matrices s_gstride floats apart
     const int64_t gi = blockIdx.y, go = gi * (int64_t)B * F;
     x += go; dx += go;
@@ -330,66 +313,42 @@ __global__ __launch_bounds__(kThreads1, 3) void site1_bwd_kernel(const float* __
     stats += gi * 4 * F;
     if (ab) ab += gi * 2 * C;
   }
-  __shared__ __attribute__((aligned(16))) unsigned lds[kWaves * WBUF];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
-  unsigned* W = lds + w * WBUF;
-  float* R = reinterpret_cast<float*>(W);
   const float invB = 1.0f / (float)B, invBm1 = 1.0f / (float)(B - 1);
-
   const float rjac = r * ALIGNQ_TWO_OVER_SQRT_2PI;
-  // S fragments (already scaled, symmetric): A[i][k], i = l31, k = 16ks + 8h + jj
-  bf16x8 sh[2], sl[2];
-  {
-    // clamped addresses, all 16 requests first, values selected afterwards: a conditional load is a branch and a full wait
-    // EACH (16 serial round trips at kernel start); the empty asm keeps the optimiser from sinking a load back under its condition
-    float sv[2][8];
+  // A operands: S[i = l31][k = R(m, h)], zero outside the batch (clamped addresses, all requests first)
+  float sA[RPL];
 #pragma unroll
-    for (int ks = 0; ks < 2; ks++)
+  for (int m = 0; m < RPL; m++) sA[m] = S[min(l31, B - 1) * B + min(row_of(m, h), B - 1)];
 #pragma unroll
-      for (int jj = 0; jj < 8; jj++) sv[ks][jj] = S[min(l31, B - 1) * B + min(16 * ks + 8 * h + jj, B - 1)];
-#pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
-      unsigned wd[8];
-#pragma unroll
-      for (int jj = 0; jj < 8; jj++) {
-        asm volatile("" : "+v"(sv[ks][jj]));
-        wd[jj] = (l31 < B && 16 * ks + 8 * h + jj < B) ? pack_hi_lo(sv[ks][jj]) : 0u;
-      }
-      unpack8(wd, sh[ks], sl[ks]);
-    }
+  for (int m = 0; m < RPL; m++) {
+    asm volatile("" : "+v"(sA[m]));
+    sA[m] = (l31 < B && row_of(m, h) < B) ? sA[m] : 0.0f;
   }
-
-  // software pipeline on x only (g is consumed late: its loads, issued at the top, land under the transform and the MFMAs;
-  // prefetching both took the kernel to 256 VGPRs in round 2): the next sub-tile's x rows are requested before this one is used
-  // (round 3: requesting the next sub-tile's x rows one iteration ahead, as the forward does, takes this kernel from 141 to 160
-  //  VGPRs = two waves per SIMD instead of three: 102.9 us against 83.8 at [28, 802816]; not kept)
-  // the upstream gradient is needed at the very end of a sub-tile only: each lane parks its 16 rows in LDS meanwhile ([4][thread]
-  // quads: conflict-free 16-byte accesses, a slot of its own) - 16 registers fewer across both operand phases of a kernel that
-  // sits at its 168-register cap (three waves per SIMD)
+  const unsigned rowB = (unsigned)F * 4u;
+  const bool has_g = PAIR && gup;
+  // the upstream gradient is needed in the last loop of a sub-tile only: each lane parks its 16 rows in LDS meanwhile ([4][thread]
+  // quads: conflict-free 16-byte accesses, a slot of its own, no synchronisation) - with it the kernel fits 128 registers = four
+  // waves per SIMD
   __shared__ __attribute__((aligned(16))) float4 g_park[PAIR ? 4 * kThreads1 : 1];
   for (int sub = blockIdx.x * kWaves + w; sub < n_sub; sub += gridDim.x * kWaves) {
     const int64_t col = (int64_t)sub * SUBF + l31;
     const bool cok = col < F;
     const int64_t colc = cok ? col : F - 1;            // loads: clamped addresses, unconditional, values selected afterwards
+    const unsigned colB = (unsigned)colc * 4u;
+#define S2_OFF(q) ((unsigned)min(row_of(q, h), B - 1) * rowB + colB)
     float xr[RPL], gr[RPL], out[RPL];
-    const char* gsrc = reinterpret_cast<const char*>((PAIR && gup) ? gup : x);   // (no upstream gradient: x stands in, values dropped)
-    // kernel-argument base + one 32-bit byte offset per row (the launcher guarantees B*F*4 < 2^32)
-    const unsigned rowB = (unsigned)F * 4u, colB = (unsigned)colc * 4u;
-    // (the clamped offsets die with the loads; the stores below address rows through the scalar base instead)
+    const char* gsrc = reinterpret_cast<const char*>(has_g ? gup : x);   // (no upstream gradient: x stands in, values dropped)
 #pragma unroll
     for (int q = 0; q < RPL; q++) {
-      const unsigned bo = (unsigned)min(RPL * h + q, B - 1) * rowB + colB;
-      xr[q] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(x) + bo);
-      gr[q] = *reinterpret_cast<const float*>(gsrc + bo);
+      xr[q] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(x) + S2_OFF(q));
+      gr[q] = *reinterpret_cast<const float*>(gsrc + S2_OFF(q));
     }
-    if (PAIR && gup2) {
-      // the upstream gradient arrives as TWO addends (the next block's convolution branch and its shortcut, which autograd
-      // would add in a pass of its own: fused.GradFork): summed here, g + g2 = the same fp32 value as that pass
+    if (PAIR && gup2) {      // the upstream gradient as two addends (fused.GradFork): g + g2, the sum autograd would have formed
       float g2[RPL];
 #pragma unroll
-      for (int q = 0; q < RPL; q++)
-        g2[q] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(gup2) + ((unsigned)min(RPL * h + q, B - 1) * rowB + colB));
+      for (int q = 0; q < RPL; q++) g2[q] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(gup2) + S2_OFF(q));
 #pragma unroll
       for (int q = 0; q < RPL; q++) gr[q] += g2[q];
     }
@@ -401,97 +360,76 @@ __global__ __launch_bounds__(kThreads1, 3) void site1_bwd_kernel(const float* __
       av = ab[ch];
       bv = ab[C + ch];
     }
-    const bool has_g = PAIR && gup;
     if (PAIR && ymask) {
-      // fused ReLU backward (the bottleneck's `out = relu(out)` behind the site, dann_office/model/resnet.py:153-154): the mask
-      // from the forward's output; the masked gradient is also the shortcut branch's gradient (dres).  Rows >= B / columns >= F
-      // carry the clamped element's values and store them to its address: the same value as the lane that owns it.
+      // fused ReLU backward: the mask from the forward's output; the masked gradient is also the shortcut's gradient (dres).
+      // Rows >= B / columns >= F carry the clamped element's values and store them to its address (the owning lane's value).
       float yr[RPL];
 #pragma unroll
-      for (int q = 0; q < RPL; q++)
-        yr[q] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ymask) + ((unsigned)min(RPL * h + q, B - 1) * rowB + colB));
+      for (int q = 0; q < RPL; q++) yr[q] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ymask) + S2_OFF(q));
 #pragma unroll
       for (int q = 0; q < RPL; q++) {
         gr[q] = yr[q] > 0.0f ? gr[q] : 0.0f;
-        if (dres)
-          *reinterpret_cast<float*>(reinterpret_cast<char*>(dres) + ((unsigned)min(RPL * h + q, B - 1) * rowB + colB)) = has_g ? gr[q] : 0.0f;
+        if (dres) *reinterpret_cast<float*>(reinterpret_cast<char*>(dres) + S2_OFF(q)) = has_g ? gr[q] : 0.0f;
       }
     }
 #pragma unroll
     for (int q = 0; q < RPL; q++) {
-      const bool ok = cok && RPL * h + q < B;
-      xr[q] = ok ? (ab ? __fmaf_rn(av, xr[q], bv) : xr[q]) : 0.0f;
-      gr[q] = (has_g && ok) ? gr[q] : 0.0f;
+      if (ab) xr[q] = __fmaf_rn(av, xr[q], bv);
+      gr[q] = has_g ? gr[q] : 0.0f;
     }
     if (PAIR) {
 #pragma unroll
       for (int q4 = 0; q4 < RPL / 4; q4++)
         g_park[q4 * kThreads1 + tid] = make_float4(gr[4 * q4], gr[4 * q4 + 1], gr[4 * q4 + 2], gr[4 * q4 + 3]);
     }
-    const float mx = cok ? mx_l : 0.f, rx = cok ? rx_l : 0.f;
-    const float mt = cok ? mt_l : 0.f, rt = cok ? rt_l : 0.f;
+    const float mx = mx_l, rx = rx_l, mt = mt_l, rt = rt_l;        // (columns >= F: the clamped column's, results never stored)
     float kap_x = 1.0f, kap_t = 1.0f;       // (sd+eps)/sd = 1/(1-eps*rho); torch's std backward is 0 where sd == 0
     if (eps != 0.0f) {
       const float dxn = 1.0f - eps * rx, dtn = 1.0f - eps * rt;
       kap_x = (dxn > 1e-12f) ? 1.0f / dxn : 0.0f;
       kap_t = (dtn > 1e-12f) ? 1.0f / dtn : 0.0f;
     }
-    // ---- x operand -------------------------------------------------------------------------------------------
-    {
-      unsigned wd[RPL];
+    // ---- x operand: S * Xh, operands and result in registers ----------------------------------------------------
+    f32x16 ax;
 #pragma unroll
-      for (int q = 0; q < RPL; q++) wd[q] = (cok && RPL * h + q < B) ? pack_hi_lo((xr[q] - mx) * rx) : 0u;
-      stage_rows(W, l31, h, wd);
+    for (int e = 0; e < 16; e++) ax[e] = 0.f;
+#pragma unroll
+    for (int m = 0; m < RPL; m++) ax = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[m], (xr[m] - mx) * rx, ax, 0, 0, 0);
+    // ---- t operand's transform: vector-ALU work while the matrix pipe contracts the x operand ---------------------------
+    float th[PAIR ? RPL : 1];
+    if (PAIR) {
+#pragma unroll
+      for (int q = 0; q < RPL; q++) {
+        float t, jac;
+        act_transform_rcp(xr[q], r, rjac, &t, &jac);        // (jac is recomputed below: 16 registers for ~5 instructions)
+        th[q] = (t - mt) * rt;
+      }
     }
-    wave_lds_sync();
     {
-      f32x16 acc;
-#pragma unroll
-      for (int e = 0; e < 16; e++) acc[e] = 0.f;
-      s_times_staged(W, sh, sl, l31, h, acc);
-      wave_lds_sync();
-      float d[RPL];
-      acc_to_rows(R, l31, h, acc, d);
       float s0 = 0.f, s1 = 0.f;
 #pragma unroll
       for (int q = 0; q < RPL; q++) {
-        if (RPL * h + q < B) { s0 += d[q]; s1 += d[q] * ((xr[q] - mx) * rx); }
+        if (row_of(q, h) < B) { s0 += ax[q]; s1 += ax[q] * ((xr[q] - mx) * rx); }
       }
       s0 += __shfl_xor(s0, 32, 64);
       s1 += __shfl_xor(s1, 32, 64);
       const float mean_d = s0 * invB, proj = s1 * invBm1 * kap_x;
 #pragma unroll
       for (int q = 0; q < RPL; q++) {
-        const float cx = rx * (d[q] - mean_d - ((xr[q] - mx) * rx) * proj);
+        const float cx = rx * (ax[q] - mean_d - ((xr[q] - mx) * rx) * proj);
         out[q] = PAIR ? -cx : cx;          // corr(x,x) enters D with a minus sign
       }
     }
-    // ---- t operand (PAIR) -------------------------------------------------------------------------------------
     if (PAIR) {
-      float th[RPL];
-      {
-        unsigned wd[RPL];
+      f32x16 at;                            // (the x operand's accumulator is dead: the same registers)
 #pragma unroll
-        for (int q = 0; q < RPL; q++) {
-          float t, jac;
-          act_transform_rcp(xr[q], r, rjac, &t, &jac);        // (jac is recomputed below: 16 registers for ~5 instructions)
-          th[q] = (t - mt) * rt;
-          wd[q] = (cok && RPL * h + q < B) ? pack_hi_lo(th[q]) : 0u;
-        }
-        stage_rows(W, l31, h, wd);
-      }
-      wave_lds_sync();
-      f32x16 acc;
+      for (int e = 0; e < 16; e++) at[e] = 0.f;
 #pragma unroll
-      for (int e = 0; e < 16; e++) acc[e] = 0.f;
-      s_times_staged(W, sh, sl, l31, h, acc);
-      wave_lds_sync();
-      float d[RPL];
-      acc_to_rows(R, l31, h, acc, d);
+      for (int m = 0; m < RPL; m++) at = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[m], th[PAIR ? m : 0], at, 0, 0, 0);
       float s0 = 0.f, s1 = 0.f;
 #pragma unroll
       for (int q = 0; q < RPL; q++) {
-        if (RPL * h + q < B) { s0 += d[q]; s1 += d[q] * th[q]; }
+        if (row_of(q, h) < B) { s0 += at[q]; s1 += at[q] * th[q]; }
       }
       s0 += __shfl_xor(s0, 32, 64);
       s1 += __shfl_xor(s1, 32, 64);
@@ -503,7 +441,7 @@ __global__ __launch_bounds__(kThreads1, 3) void site1_bwd_kernel(const float* __
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           const int q = 4 * q4 + j;
-          const float ct = rt * (d[q] - mean_d - th[q] * proj);
+          const float ct = rt * (at[q] - mean_d - th[q] * proj);
           const float xv = xr[q];
           out[q] += (ge[j] + ct) * (rjac * __builtin_amdgcn_exp2f(xv * xv * -0.72134752044448170368f));
         }
@@ -512,9 +450,10 @@ __global__ __launch_bounds__(kThreads1, 3) void site1_bwd_kernel(const float* __
     if (cok) {
 #pragma unroll
       for (int q = 0; q < RPL; q++)
-        if (RPL * h + q < B)       // uniform row base + this lane's (row half, column) offset
-          *reinterpret_cast<float*>(reinterpret_cast<char*>(dx) + (size_t)q * rowB + ((unsigned)(RPL * h) * rowB + colB)) = out[q];
+        if (row_of(q, h) < B)
+          *reinterpret_cast<float*>(reinterpret_cast<char*>(dx) + ((unsigned)row_of(q, h) * rowB + colB)) = out[q];
     }
+#undef S2_OFF
   }
 }
 
@@ -546,7 +485,7 @@ int launch_bwd1(bool pair, const float* gup, const float* S, const float* x, con
   if ((int64_t)B * F * 4 >= ((int64_t)1 << 32)) return ALIGNQ_EUNSUPPORTED;   // 32-bit byte offsets
   const int n_sub = (int)((F + SUBF - 1) / SUBF);
   int grid = (n_sub + kWaves - 1) / kWaves;
-  // 141 VGPRs: three 4-wave workgroups per CU = 768 resident; a grid of exactly that (every wave loops over ~8 sub-tiles at
+  // three 4-wave workgroups per CU (167 VGPRs) = 768 resident; a grid of exactly that (every wave loops over ~8 sub-tiles at
   // [28, 802816]) ran 82-84 us against 86-87 for 2048 and 17.2 against 19.6 at [28, 100352] (tools/s1_grid_sweep.sh)
   static const int capb = alignq_env::env_int("ALIGNQ_S1_GRID_B", 768, 1, 65535);      // tuning aid
   if (grid > capb) grid = capb;
