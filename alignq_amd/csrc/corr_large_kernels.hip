@@ -21,10 +21,21 @@
 //                            so S[k][i] is read: coalesced in i), column projections over all rows through LDS, 128-byte
 //                            row-segment stores.
 // Deterministic (no atomics); HBM traffic of the forward: x once for the statistics plus (nb+1)/2 x for the Gram (nb = B/128).
+//
+// Round 4: the ADMM SITE above 128 rows on the same blocked form (the module layer composed it from four stand-alone passes before:
+// 5x the fused site's cost per element): PAIR instantiations of the kernels above -
+//   1'. sitel_stats_kernel : one sweep over x leaves the statistics of x AND of t = r (2 Phi(x) - 1) (stats [4][F]) and x_q;
+//   2'. corrl_gram_kernel<true> : a tile's rows are staged twice - Xh, contracted with a NEGATED A operand, then Th (the transform
+//       re-formed from the registers that hold x) - into ONE accumulator: the slabs hold D = corr(t,t) - corr(x,x) directly;
+//   5'. corrl_bwd_kernel<RB, NW, true> : both operands in one launch: dx = -dcorr_x + (g + dcorr_t) dt/dx.
+// Forward = x read (nb+1)/2 + 1 times and written once (was 4 reads + 2 writes + two Gram passes), backward one kernel (was five).
 #include <hip/hip_runtime.h>
 
 #include "../../include/alignq.h"
+#include "alignq_math.h"
 #include "site_internal.h"
+
+using namespace alignq;
 
 namespace alignq_site {
 
@@ -92,6 +103,74 @@ __global__ __launch_bounds__(kT) void corrl_stats_kernel(const float* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------- 1'. pair statistics + x_q
+// As corrl_stats_kernel, for the ADMM site: every element also goes through the quantiser (alignq_math.h: x_q bit-identical to
+// alignq_act_quant_fwd) whose pre-round transform t is accumulated like x.  stats: [4][F] = mean_x, 1/(std_x+eps), mean_t, 1/(std_t+eps).
+__global__ __launch_bounds__(kT) void sitel_stats_kernel(const float* __restrict__ x, int B, int64_t F, int k, float r, float eps,
+                                                         float* __restrict__ xq, float* __restrict__ stats, int aligned) {
+  __shared__ double red[16][kTF][4];
+  __shared__ __attribute__((aligned(16))) float nerf_lds[ALIGNQ_NERF_LDS_FLOATS];
+  nerf_tab_load(nerf_lds);
+  __syncthreads();
+  const NerfTab tab = nerf_tab(nerf_lds);
+  const Levels nlev = make_levels(k, fabsf(r) <= 8.0f);
+  const int tid = threadIdx.x, c = tid & 15, rg = tid >> 4;
+  const int col = blockIdx.x * kTF + 4 * c;
+  double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0}, st[4] = {0, 0, 0, 0}, qt[4] = {0, 0, 0, 0};
+  for (int r0 = rg; r0 < B; r0 += 64) {       // four rows in flight
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int rr = r0 + 16 * u;
+      v[u] = ldq(x, (int64_t)rr * F + col, col, F, rr < B, aligned);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int rr = r0 + 16 * u;
+      const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+      float o[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        float t, b;
+        o[j] = act_quant1<0>(e[j], k, nlev, r, &t, &b, tab);
+        if (rr < B) {
+          s[j] += (double)e[j]; q[j] += (double)e[j] * (double)e[j];
+          st[j] += (double)t; qt[j] += (double)t * (double)t;
+        }
+      }
+      if (xq && rr < B) {
+        const int64_t off = (int64_t)rr * F + col;
+        if (aligned) {
+          if (col < F) *reinterpret_cast<float4*>(xq + off) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if (col + j < F) xq[off + j] = o[j];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    red[rg][4 * c + j][0] = s[j]; red[rg][4 * c + j][1] = q[j];
+    red[rg][4 * c + j][2] = st[j]; red[rg][4 * c + j][3] = qt[j];
+  }
+  __syncthreads();
+  if (tid < 2 * kTF) {
+    const int cc = tid & (kTF - 1), which = tid >> 6;          // which: 0 = x, 1 = t
+    double a = 0, b = 0;
+    for (int g = 0; g < 16; g++) { a += red[g][cc][2 * which]; b += red[g][cc][2 * which + 1]; }     // fixed order
+    const int64_t f = (int64_t)blockIdx.x * kTF + cc;
+    if (f < F) {
+      const double mean = a / (double)B;
+      double var = (b - a * mean) / (double)(B - 1);
+      if (var < 0) var = 0;
+      stats[(2 * which) * F + f] = (float)mean;
+      stats[(2 * which + 1) * F + f] = 1.0f / ((float)sqrt(var) + eps);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- 2. blocked Gram
 __device__ __forceinline__ void pair_ij(int p, int nb, int& I, int& J) {
   int t = p;
@@ -100,10 +179,11 @@ __device__ __forceinline__ void pair_ij(int p, int nb, int& I, int& J) {
   J = I + t;
 }
 
-// grid = (ksplit, npairs).  slabs: [npairs][ksplit][128][128]
+// grid = (ksplit, npairs).  slabs: [npairs][ksplit][128][128].  PAIR: see the file header (stats is then [4][F], r the act_range)
+template <bool PAIR>
 __global__ __launch_bounds__(kT) void corrl_gram_kernel(const float* __restrict__ x, const float* __restrict__ stats, int B,
                                                         int64_t F, float* __restrict__ slabs, int n_tiles, int nb,
-                                                        int aligned) {
+                                                        int aligned, float r) {
   __shared__ float As[kBlk * kLD];
   __shared__ float Bs[kBlk * kLD];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -122,51 +202,74 @@ __global__ __launch_bounds__(kT) void corrl_gram_kernel(const float* __restrict_
       for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
   const float* Bsel = diag ? As : Bs;
 
+  const float rjac = r * ALIGNQ_TWO_OVER_SQRT_2PI;
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int col = tile * kTF + 4 * c;
-    float m[4], rho[4];
+    float m[4], rho[4], mt[4], rhot[4];
 #pragma unroll
     for (int e = 0; e < 4; e++) {
       const bool ok = col + e < F;
       m[e] = ok ? stats[col + e] : 0.0f;
       rho[e] = ok ? stats[F + col + e] : 0.0f;
+      mt[e] = (PAIR && ok) ? stats[2 * F + col + e] : 0.0f;
+      rhot[e] = (PAIR && ok) ? stats[3 * F + col + e] : 0.0f;
     }
+    // the rows of both blocks stay in registers: staged as Xh first and (PAIR) as Th afterwards
+    float4 v[2][8];
 #pragma unroll
     for (int half = 0; half < 2; half++) {
       if (half == 1 && diag) break;
       const int blk = half == 0 ? I : J;
-      float* dst = half == 0 ? As : Bs;
-      float4 v[8];
 #pragma unroll
       for (int j = 0; j < 8; j++) {
         const int grow = blk * kBlk + rg + 16 * j;
-        v[j] = ldq(x, (int64_t)grow * F + col, col, F, grow < B, aligned);
-      }
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const int row = rg + 16 * j;
-        const bool ok = blk * kBlk + row < B;
-        const float e4[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
-#pragma unroll
-        for (int e = 0; e < 4; e++) dst[row * kLD + 4 * c + e] = (ok && col + e < F) ? (e4[e] - m[e]) * rho[e] : 0.0f;
+        v[half][j] = ldq(x, (int64_t)grow * F + col, col, F, grow < B, aligned);
       }
     }
-    __syncthreads();
     const int rowA = wr * 64 + l31, rowB = wc * 64 + l31;
-#pragma unroll 4
-    for (int k0 = 0; k0 < kTF; k0 += 2) {
-      float a[2], b[2];
 #pragma unroll
-      for (int i = 0; i < 2; i++) {
-        a[i] = As[(rowA + 32 * i) * kLD + k0 + h];
-        b[i] = Bsel[(rowB + 32 * i) * kLD + k0 + h];
+    for (int op = 0; op < (PAIR ? 2 : 1); op++) {
+#pragma unroll
+      for (int half = 0; half < 2; half++) {
+        if (half == 1 && diag) break;
+        const int blk = half == 0 ? I : J;
+        float* dst = half == 0 ? As : Bs;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const int row = rg + 16 * j;
+          const bool ok = blk * kBlk + row < B;
+          const float e4[4] = {v[half][j].x, v[half][j].y, v[half][j].z, v[half][j].w};
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            float val;
+            if (op == 0) val = (e4[e] - m[e]) * rho[e];
+            else {
+              float t, jac;
+              act_transform_rcp(e4[e], r, rjac, &t, &jac);
+              val = (t - mt[e]) * rhot[e];
+            }
+            dst[row * kLD + 4 * c + e] = (ok && col + e < F) ? val : 0.0f;
+          }
+        }
       }
+      __syncthreads();
+      const bool neg = PAIR && op == 0;            // D = corr(t,t) - corr(x,x): the x operand enters with a minus sign
+#pragma unroll 4
+      for (int k0 = 0; k0 < kTF; k0 += 2) {
+        float a[2], b[2];
 #pragma unroll
-      for (int i = 0; i < 2; i++)
+        for (int i = 0; i < 2; i++) {
+          const float av = As[(rowA + 32 * i) * kLD + k0 + h];
+          a[i] = neg ? -av : av;
+          b[i] = Bsel[(rowB + 32 * i) * kLD + k0 + h];
+        }
 #pragma unroll
-        for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
   float* slab = slabs + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (kBlk * kBlk);
 #pragma unroll
@@ -204,7 +307,9 @@ __global__ __launch_bounds__(kT) void corrl_reduce_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------- 4. S = (dG + dG^T) / F
-__global__ __launch_bounds__(kT) void corrl_sym_kernel(const float* __restrict__ dG, int B, float scale, float* __restrict__ S) {
+__global__ __launch_bounds__(kT) void corrl_sym_kernel(const float* __restrict__ dG, int B, float scale, float* __restrict__ S,
+                                                       const float* __restrict__ dscale = nullptr) {
+  if (dscale) scale *= *dscale;                 // optional DEVICE scalar (the upstream gradient of a scalar loss)
   const int64_t n = (int64_t)B * B;
   for (int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x; e < n; e += (int64_t)gridDim.x * kT) {
     const int i = (int)(e / B), j = (int)(e - (int64_t)i * B);
@@ -215,10 +320,14 @@ __global__ __launch_bounds__(kT) void corrl_sym_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------------------------- 5. backward
 // dynamic LDS: Xh [nblk*32][33] floats + red [NW][2][32] + tot [2][32].  NW waves share the row blocks (wave w: blocks w + NW q,
 // q < RB); B <= 512: 4 waves x RB <= 4; above: 8 waves x 4 (8 accumulators per wave spilled 54 registers at 256 + 256)
-template <int RB, int NW = 4>
+// PAIR (round 4, the ADMM site above 128 rows): both operands in one launch.  Pass 0 is the corr(x,x) part (it enters D with a minus
+// sign): dx = -dcorr_x is stored; pass 1 stages Th (the transform re-formed from x, read again from L2), contracts, projects with the
+// t statistics (stats [4][F]) and finishes dx = -dcorr_x + (g + dcorr_t) * dt/dx, g = the upstream gradient of x_q (or nullptr).
+template <int RB, int NW = 4, bool PAIR = false>
 __global__ __launch_bounds__(64 * NW) void corrl_bwd_kernel(const float* __restrict__ S, const float* __restrict__ x,
                                                        const float* __restrict__ stats, int B, int64_t F, float eps,
-                                                       float* __restrict__ dx, int n_tiles, int aligned) {
+                                                       float* __restrict__ dx, int n_tiles, int aligned,
+                                                       const float* __restrict__ gup = nullptr, float r = 1.0f) {
   extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
   const int nblk = (B + 31) >> 5, BP = nblk * 32;
   float* Xs = lds_dyn;
@@ -229,103 +338,139 @@ __global__ __launch_bounds__(64 * NW) void corrl_bwd_kernel(const float* __restr
   const int c = tid & 7, rg = tid >> 3;        // load mapping: column quad, 8 NW row groups
   constexpr int RG = 8 * NW;
   const float invB = 1.0f / (float)B, invBm1 = 1.0f / (float)(B - 1);
+  const float rjac = r * ALIGNQ_TWO_OVER_SQRT_2PI;
 
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int col0 = tile * kTFb, col = col0 + 4 * c;
-    float m[4], rho[4];
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
-      const bool ok = col + e < F;
-      m[e] = ok ? stats[col + e] : 0.0f;
-      rho[e] = ok ? stats[F + col + e] : 0.0f;
-    }
-    for (int r0 = rg; r0 < BP; r0 += RG * 4) {
-      float4 v[4];
+    for (int op = 0; op < (PAIR ? 2 : 1); op++) {
+      const int so = 2 * op;                     // statistics rows of this operand: (mean, rho) at [so], [so + 1]
+      float m[4], rho[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int r = r0 + RG * u;
-        v[u] = ldq(x, (int64_t)r * F + col, col, F, r < B, aligned);
+      for (int e = 0; e < 4; e++) {
+        const bool ok = col + e < F;
+        m[e] = ok ? stats[so * F + col + e] : 0.0f;
+        rho[e] = ok ? stats[(so + 1) * F + col + e] : 0.0f;
       }
+      for (int r0 = rg; r0 < BP; r0 += RG * 4) {
+        float4 v[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int r = r0 + RG * u;
-        if (r < BP) {
-          const float e4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+        for (int u = 0; u < 4; u++) {
+          const int rr = r0 + RG * u;
+          v[u] = ldq(x, (int64_t)rr * F + col, col, F, rr < B, aligned);
+        }
 #pragma unroll
-          for (int e = 0; e < 4; e++) Xs[r * kLDb + 4 * c + e] = (r < B && col + e < F) ? (e4[e] - m[e]) * rho[e] : 0.0f;
+        for (int u = 0; u < 4; u++) {
+          const int rr = r0 + RG * u;
+          if (rr < BP) {
+            const float e4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              float val = e4[e];
+              if (PAIR && op == 1) {
+                float t, jac;
+                act_transform_rcp(e4[e], r, rjac, &t, &jac);
+                val = t;
+              }
+              Xs[rr * kLDb + 4 * c + e] = (rr < B && col + e < F) ? (val - m[e]) * rho[e] : 0.0f;
+            }
+          }
         }
       }
-    }
-    __syncthreads();
-    // ---- dXh block rows of this wave: acc[q] = S[rows of block w + 4q][:] Xh ----------------------------------------
-    f32x16 acc[RB];
-#pragma unroll
-    for (int q = 0; q < RB; q++)
-#pragma unroll
-      for (int e = 0; e < 16; e++) acc[q][e] = 0.0f;
-#pragma unroll 2
-    for (int k0 = 0; k0 < BP; k0 += 2) {
-      const int kk = k0 + h;
-      const float b = Xs[kk * kLDb + l31];
-      float a[RB];
-#pragma unroll
-      for (int q = 0; q < RB; q++) {
-        const int i = (w + NW * q) * 32 + l31;
-        a[q] = (i < B && kk < B) ? S[(int64_t)kk * B + i] : 0.0f;        // S symmetric: S[i][kk], read coalesced in i
-      }
+      __syncthreads();
+      // ---- dVh block rows of this wave: acc[q] = S[rows of block w + NW q][:] Vh ------------------------------------
+      f32x16 acc[RB];
 #pragma unroll
       for (int q = 0; q < RB; q++)
-        if (w + NW * q < nblk) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b, acc[q], 0, 0, 0);
-    }
-    // ---- column projections over ALL rows: sum_b dXh, sum_b dXh * xh ------------------------------------------------
-    float sd = 0.f, sdx = 0.f;
 #pragma unroll
-    for (int q = 0; q < RB; q++) {
-      if (w + NW * q < nblk) {
+        for (int e = 0; e < 16; e++) acc[q][e] = 0.0f;
+#pragma unroll 2
+      for (int k0 = 0; k0 < BP; k0 += 2) {
+        const int kk = k0 + h;
+        const float b = Xs[kk * kLDb + l31];
+        float a[RB];
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-          const int row = (w + NW * q) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          const float d = acc[q][e];            // rows >= B: S rows are zero there, so d == 0
-          sd += d;
-          sdx += d * Xs[row * kLDb + l31];
+        for (int q = 0; q < RB; q++) {
+          const int i = (w + NW * q) * 32 + l31;
+          a[q] = (i < B && kk < B) ? S[(int64_t)kk * B + i] : 0.0f;        // S symmetric: S[i][kk], read coalesced in i
         }
+#pragma unroll
+        for (int q = 0; q < RB; q++)
+          if (w + NW * q < nblk) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b, acc[q], 0, 0, 0);
       }
-    }
-    sd += __shfl_xor(sd, 32, 64);
-    sdx += __shfl_xor(sdx, 32, 64);
-    if (h == 0) { red[(w * 2 + 0) * 32 + l31] = sd; red[(w * 2 + 1) * 32 + l31] = sdx; }
-    __syncthreads();
-    if (tid < 64) {
-      const int which = tid >> 5, cc = tid & 31;
-      float t4 = (red[(0 * 2 + which) * 32 + cc] + red[(1 * 2 + which) * 32 + cc]) +
-                 (red[(2 * 2 + which) * 32 + cc] + red[(3 * 2 + which) * 32 + cc]);
-      if (NW == 8)
-        t4 += (red[(4 * 2 + which) * 32 + cc] + red[(5 * 2 + which) * 32 + cc]) +
-              (red[(6 * 2 + which) * 32 + cc] + red[(7 * 2 + which) * 32 + cc]);
-      tot[which * 32 + cc] = t4;
-    }
-    __syncthreads();
-    // ---- assemble and store (lanes l31 -> 32 consecutive features of one row: 128-byte segments) ---------------------
-    {
-      const int f = col0 + l31;
-      const bool fok = f < F;
-      const float rr = fok ? stats[F + f] : 0.0f;
-      const float sdev = fok ? (1.0f / rr - eps) : 0.0f;
-      const float mean_d = tot[l31] * invB;
-      // torch's std backward gives no gradient through a zero std (masked_fill), DESIGN.md §7
-      const float kdot = (sdev > 0.0f) ? tot[32 + l31] * invBm1 / sdev : 0.0f;
+      // ---- column projections over ALL rows: sum_b dVh, sum_b dVh * vh ----------------------------------------------
+      float sd = 0.f, sdx = 0.f;
 #pragma unroll
       for (int q = 0; q < RB; q++) {
         if (w + NW * q < nblk) {
 #pragma unroll
           for (int e = 0; e < 16; e++) {
             const int row = (w + NW * q) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (row < B && fok) dx[(int64_t)row * F + f] = (acc[q][e] - mean_d) * rr - Xs[row * kLDb + l31] * kdot;
+            const float d = acc[q][e];            // rows >= B: S rows are zero there, so d == 0
+            sd += d;
+            sdx += d * Xs[row * kLDb + l31];
           }
         }
       }
+      sd += __shfl_xor(sd, 32, 64);
+      sdx += __shfl_xor(sdx, 32, 64);
+      if (h == 0) { red[(w * 2 + 0) * 32 + l31] = sd; red[(w * 2 + 1) * 32 + l31] = sdx; }
+      __syncthreads();
+      if (tid < 64) {
+        const int which = tid >> 5, cc = tid & 31;
+        float t4 = (red[(0 * 2 + which) * 32 + cc] + red[(1 * 2 + which) * 32 + cc]) +
+                   (red[(2 * 2 + which) * 32 + cc] + red[(3 * 2 + which) * 32 + cc]);
+        if (NW == 8)
+          t4 += (red[(4 * 2 + which) * 32 + cc] + red[(5 * 2 + which) * 32 + cc]) +
+                (red[(6 * 2 + which) * 32 + cc] + red[(7 * 2 + which) * 32 + cc]);
+        tot[which * 32 + cc] = t4;
+      }
+      __syncthreads();
+      // ---- assemble and store (lanes l31 -> 32 consecutive features of one row: 128-byte segments) -------------------
+      {
+        const int f = col0 + l31;
+        const bool fok = f < F;
+        const float rr = fok ? stats[(so + 1) * F + f] : 0.0f;
+        const float sdev = fok ? (1.0f / rr - eps) : 0.0f;
+        const float mean_d = tot[l31] * invB;
+        // torch's std backward gives no gradient through a zero std (masked_fill), DESIGN.md §7
+        const float kdot = (sdev > 0.0f) ? tot[32 + l31] * invBm1 / sdev : 0.0f;
+#pragma unroll
+        for (int q = 0; q < RB; q++) {
+          if (w + NW * q < nblk) {
+#pragma unroll
+            for (int e4 = 0; e4 < 4; e4++) {
+              // four rows at a time (their x / g loads in flight together, then the stores): all sixty-four at once, as the
+              // optimiser would have it, needs more registers than the kernel has
+              __builtin_amdgcn_sched_barrier(0);
+              const int row0 = (w + NW * q) * 32 + 8 * e4 + 4 * h;
+              float xv[4], gv[4], cx[4];
+              if (PAIR && op == 1) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                  const int64_t o = (int64_t)min(row0 + j, B - 1) * F + (fok ? f : 0);
+                  xv[j] = x[o];
+                  gv[j] = gup ? gup[o] : 0.0f;
+                  cx[j] = dx[o];                                  // pass 0 left -dcorr_x here
+                }
+              }
+#pragma unroll
+              for (int j = 0; j < 4; j++) {
+                const int e = 4 * e4 + j, row = row0 + j;
+                const float cv = (acc[q][e] - mean_d) * rr - Xs[row * kLDb + l31] * kdot;
+                if (row < B && fok) {
+                  float* o = dx + (int64_t)row * F + f;
+                  if (!PAIR) *o = cv;
+                  else if (op == 0) *o = -cv;                    // corr(x,x) enters D with a minus sign
+                  else *o = cx[j] + (gv[j] + cv) * (rjac * __builtin_amdgcn_exp2f(xv[j] * xv[j] * -0.72134752044448170368f));
+                }
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();      // Xs is overwritten by the next operand / tile
     }
-    __syncthreads();      // Xs is overwritten by the next tile
   }
 }
 
@@ -353,19 +498,32 @@ int launch_corrl_fwd(const float* x, int B, int64_t F, float eps, float* G, floa
   const int nb = (B + kBlk - 1) / kBlk, np = n_pairs(nb), ks = corrl_ksplit(B, F);
   const int n_tiles = (int)((F + kTF - 1) / kTF);
   hipLaunchKernelGGL(corrl_stats_kernel, dim3(n_tiles), dim3(kT), 0, st, x, B, F, eps, stats, aligned);
-  hipLaunchKernelGGL(corrl_gram_kernel, dim3(ks, np), dim3(kT), 0, st, x, (const float*)stats, B, F, ws, n_tiles, nb, aligned);
+  hipLaunchKernelGGL((corrl_gram_kernel<false>), dim3(ks, np), dim3(kT), 0, st, x, (const float*)stats, B, F, ws, n_tiles, nb, aligned, 1.0f);
   hipLaunchKernelGGL(corrl_reduce_kernel, dim3(kBlk * kBlk / kT, np), dim3(kT), 0, st, (const float*)ws, ks, nb, B,
                      1.0f / (float)F, G);
   return hipGetLastError() == hipSuccess ? 0 : ALIGNQ_EINVAL;
 }
 
-int launch_corrl_bwd(const float* dG, const float* x, const float* stats, int B, int64_t F, float eps, float* dx, float* S,
+// The ADMM site above 128 rows (round 4): x_q, stats [4][F] and D = corr(t,t) - corr(x,x) in three launches
+int launch_sitel_fwd(const float* x, int B, int64_t F, int k, float r, float eps, float* xq, float* D, float* stats, float* ws,
                      hipStream_t st) {
+  const int aligned = ((F & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(xq) & 15) == 0) ? 1 : 0;
+  const int nb = (B + kBlk - 1) / kBlk, np = n_pairs(nb), ks = corrl_ksplit(B, F);
+  const int n_tiles = (int)((F + kTF - 1) / kTF);
+  hipLaunchKernelGGL(sitel_stats_kernel, dim3(n_tiles), dim3(kT), 0, st, x, B, F, k, r, eps, xq, stats, aligned);
+  hipLaunchKernelGGL((corrl_gram_kernel<true>), dim3(ks, np), dim3(kT), 0, st, x, (const float*)stats, B, F, ws, n_tiles, nb, aligned, r);
+  hipLaunchKernelGGL(corrl_reduce_kernel, dim3(kBlk * kBlk / kT, np), dim3(kT), 0, st, (const float*)ws, ks, nb, B,
+                     1.0f / (float)F, D);
+  return hipGetLastError() == hipSuccess ? 0 : ALIGNQ_EINVAL;
+}
+
+int launch_corrl_bwd(const float* dG, const float* x, const float* stats, int B, int64_t F, float eps, float* dx, float* S,
+                     hipStream_t st, bool pair, const float* gup, float r, const float* dG_scale) {
   const int aligned = ((F & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) ? 1 : 0;
   const int64_t n = (int64_t)B * B;
   int gs = (int)((n + kT - 1) / kT);
   if (gs > 2048) gs = 2048;
-  hipLaunchKernelGGL(corrl_sym_kernel, dim3(gs), dim3(kT), 0, st, dG, B, 1.0f / (float)F, S);
+  hipLaunchKernelGGL(corrl_sym_kernel, dim3(gs), dim3(kT), 0, st, dG, B, 1.0f / (float)F, S, dG_scale);
   const int nblk = (B + 31) / 32, rb = (nblk + 3) / 4;
   const int n_tiles = (int)((F + kTFb - 1) / kTFb);
   const size_t lds = ((size_t)nblk * 32 * kLDb + 8 * 2 * 32 + 2 * 32) * sizeof(float);
@@ -380,12 +538,31 @@ int launch_corrl_bwd(const float* dG, const float* x, const float* stats, int B,
       attr_set = true;                                                                                                         \
     }                                                                                                                          \
     hipLaunchKernelGGL((corrl_bwd_kernel<RB, NWV>), dim3(grid), dim3(64 * NWV), lds, st, (const float*)S, x, stats, B, F, eps, \
-                       dx, n_tiles, aligned);                                                                                  \
+                       dx, n_tiles, aligned, nullptr, 1.0f);                                                                   \
   } while (0)
+#define SITEL_BWD(RB, NWV)                                                                                                     \
+  do {                                                                                                                         \
+    static bool attr_set = false;                                                                                              \
+    if (!attr_set) {                                                                                                           \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&corrl_bwd_kernel<RB, NWV, true>),                                 \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess)                     \
+        return ALIGNQ_EINVAL;                                                                                                  \
+      attr_set = true;                                                                                                         \
+    }                                                                                                                          \
+    hipLaunchKernelGGL((corrl_bwd_kernel<RB, NWV, true>), dim3(grid), dim3(64 * NWV), lds, st, (const float*)S, x, stats, B, F, \
+                       eps, dx, n_tiles, aligned, gup, r);                                                                     \
+  } while (0)
+  if (pair) {
+    if (rb <= 2) SITEL_BWD(2, 4);
+    else if (rb <= 4) SITEL_BWD(4, 4);
+    else SITEL_BWD(4, 8);
+    return hipGetLastError() == hipSuccess ? 0 : ALIGNQ_EINVAL;
+  }
   if (rb <= 2) CORRL_BWD(2, 4);
   else if (rb <= 4) CORRL_BWD(4, 4);
   else CORRL_BWD(4, 8);                   // 512 < B <= 1024: eight waves, four row blocks each
 #undef CORRL_BWD
+#undef SITEL_BWD
   return hipGetLastError() == hipSuccess ? 0 : ALIGNQ_EINVAL;
 }
 

@@ -561,6 +561,10 @@ int alignq_site_reduce_loss(void* ws, int B, int64_t F, float* D, const float* a
 int alignq_site_fwd(const float* x, int B, int64_t F, int k, float act_range, float eps, float* xq, float* D,
                     float* stats, void* ws, void* stream) {
   if (!x || !D || !ws) return ALIGNQ_EINVAL;
+  if (large_corr(B, F)) {       // 128 < B <= 1024: the pair kernels on the blocked Gram (corr_large_kernels.hip); stats required
+    if (!stats || bad_k(k)) return ALIGNQ_EINVAL;
+    return launch_sitel_fwd(x, B, F, k, act_range, eps, xq, D, stats, (float*)ws, (hipStream_t)stream);
+  }
   if (bad_shape(B, F)) return F <= 0 ? ALIGNQ_EINVAL : ALIGNQ_EUNSUPPORTED;
   if (bad_k(k)) return ALIGNQ_EINVAL;
   const Geom g = geom(B, F);
@@ -573,6 +577,8 @@ int alignq_site_fwd(const float* x, int B, int64_t F, int k, float act_range, fl
 int alignq_site_bwd(const float* g, const float* dD, const float* dD_scale, const float* x, const float* stats,
                     int B, int64_t F, float act_range, float eps, float* dx, void* ws, void* stream) {
   if (!dD || !x || !stats || !dx || !ws) return ALIGNQ_EINVAL;
+  if (large_corr(B, F))         // ws: alignq_site_bwd_ws_bytes(B) = B*B floats (S)
+    return launch_corrl_bwd(dD, x, stats, B, F, eps, dx, (float*)ws, (hipStream_t)stream, true, g, act_range, dD_scale);
   if (bad_shape(B, F)) return F <= 0 ? ALIGNQ_EINVAL : ALIGNQ_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   int rc = launch_prep(false, dD, nullptr, nullptr, nullptr, 0, nullptr, 0.f, dD_scale, B, F, (float*)ws, nullptr,

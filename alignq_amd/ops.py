@@ -415,11 +415,56 @@ class SiteFn(torch.autograd.Function):
         return dx, dA, dG, None, None, None, None, None, None, None, None, dres, None
 
 
+class SiteLargeFn(torch.autograd.Function):
+    """(x_q, D) of the ADMM site for 128 < B <= ALIGNQ_MAX_CORR_BATCH rows on the blocked Gram (round 4: alignq_site_fwd / _bwd take
+    these batches through the PAIR kernels of corr_large_kernels.hip): one sweep leaves x_q and the statistics of x and of the
+    pre-round transform t, one Gram launch accumulates D = corr(t, t) - corr(x, x), one backward launch returns
+    dx = dD-path + STE-path (model/quantization.py:109-122, corr :134-137; Office :158-161 with eps)."""
+
+    @staticmethod
+    def forward(ctx, x, k, act_range, eps):
+        x = L.dense_f32(x, "activation")
+        B, F = _as_bf(x)
+        _check_batch(B, "site", L.MAX_CORR_BATCH)
+        lib = L.load()
+        xq = torch.empty_like(x)
+        D = torch.empty(B, B, dtype=torch.float32, device=x.device)
+        stats = torch.empty(4, F, dtype=torch.float32, device=x.device)
+        ws = _ws(lib.alignq_site_ws_bytes(B, F), x.device)
+        L.check(lib.alignq_site_fwd(L.ptr(x), B, F, int(k), float(act_range), float(eps), L.ptr(xq), L.ptr(D), L.ptr(stats), L.ptr(ws),
+                                    L.stream_ptr()), "alignq_site_fwd")
+        ctx.save_for_backward(x, stats)
+        ctx.cfg = (float(act_range), float(eps))
+        ctx.set_materialize_grads(False)
+        return xq, D
+
+    @staticmethod
+    def backward(ctx, g_xq, g_D):
+        x, stats = ctx.saved_tensors
+        act_range, eps = ctx.cfg
+        B, F = _as_bf(x)
+        lib = L.load()
+        if g_D is None:
+            g_D = torch.zeros(B, B, dtype=torch.float32, device=x.device)
+        g_D = L.dev_f32(g_D, "grad of D")
+        if g_xq is not None:
+            g_xq = L.like_layout(g_xq, x)
+        dx = torch.empty_like(x)
+        ws = _ws(lib.alignq_site_bwd_ws_bytes(B), x.device)
+        L.check(lib.alignq_site_bwd(L.ptr(g_xq), L.ptr(g_D), None, L.ptr(x), L.ptr(stats), B, F, act_range, eps, L.ptr(dx), L.ptr(ws),
+                                    L.stream_ptr()), "alignq_site_bwd")
+        return dx, None, None, None
+
+
 def site_unfused(x, admm, k, act_range, eps, formula):
-    """The ADMM activation site for 128 < B <= ALIGNQ_MAX_CORR_BATCH, composed from the stand-alone kernels (the fused site
-    kernels keep all rows of a feature tile on chip and stop at 128): x_q = quantise(x), t = the pre-round transform (the
-    quantiser at k = 32 writes it), D = corr(t, t) - corr(x, x) on the blocked Gram, loss = ADMM(D).  x is read four times
-    instead of once; same values as the reference's lines (model/quantization.py:109-123).  Returns (x_q, loss, D)."""
+    """The ADMM activation site for 128 < B <= ALIGNQ_MAX_CORR_BATCH (the fused site kernels keep all rows of a feature tile on
+    chip and stop at 128): (x_q, D) from SiteLargeFn - the pair kernels on the blocked Gram - and loss = ADMM(D); the CDF-only
+    formula (no BASELINE site uses it) keeps round 3's composition from the stand-alone kernels.  Same values as the reference's
+    lines (model/quantization.py:109-123).  Returns (x_q, loss, D)."""
+    if formula == L.FORMULA_ADMM and k < 32 and x.dim() >= 2:
+        xq, D = SiteLargeFn.apply(x, k, act_range, float(eps))
+        loss = AdmmLossFn.apply(D, admm.alterD, admm.gamma, admm.mu, admm.rho)
+        return xq, loss, D
     xq = ActQuantFn.apply(x, k, act_range, formula)
     t = ActQuantFn.apply(x, 32, act_range, formula)
     D = CorrFn.apply(t, float(eps)) - CorrFn.apply(x, float(eps))

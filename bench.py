@@ -578,8 +578,8 @@ def measure_corr_large(dev, k):
     """what the rows above 128 cost.  corr(x, x) on the blocked exact-fp32 Gram (corr_large_kernels.hip,
     v_mfma_f32_32x32x2_f32) at B in {256, 1024}, F = 16384: forward / backward time, fp32-MFMA TFLOP/s against the 157 TFLOP/s
     dense fp32-matrix peak (2 B^2 F flop forward, 4 B^2 F backward: dX = (S + S^T) Xh), HBM fraction on the algorithmic bytes
-    (forward 4 B/element, backward 8); and the ADMM site COMPOSED for B = 256 (ops.site_unfused: plain quantiser twice + corr
-    twice + ADMM loss, autograd backward) against the FUSED site at B = 128 run twice on the same 256 rows."""
+    (forward 4 B/element, backward 8); and the ADMM site at B = 256 (ops.site_unfused: round 4's pair kernels on the blocked Gram -
+    ops.SiteLargeFn - plus the ADMM loss, autograd backward) against the FUSED site at B = 128 run twice on the same 256 rows."""
     from alignq_amd import _lib as L, ops
     from alignq_amd.admm import ADMM
     lib = L.load()

@@ -130,11 +130,13 @@ def test_corr_above_128_rows_vs_oracle(dev, B, F, eps):
     assert bits_equal(npy(G), npy(G2))                       # deterministic run to run
 
 
-@pytest.mark.parametrize("tree,B", [("admm", 192), ("office", 256)])
-def test_admm_site_above_128_rows_vs_oracle(dev, tree, B):
-    """activation_quantize_fn with ADMM at a batch the fused kernels do not hold (the module composes the site from the plain
-    quantiser, the blocked correlation and the ADMM loss): x_q bit for bit, D / loss / dx / dalterD / dgamma within 1e-5 of
-    the oracle; ADMM(dim) is sized by the batch like the reference does (utils/admm.py:17-27)."""
+@pytest.mark.parametrize("tree,B,C,H", [("admm", 192, 6, 8), ("office", 256, 6, 8), ("admm", 130, 3, 5), ("office", 1000, 4, 4),
+                                        ("admm", 513, 2, 6)])
+def test_admm_site_above_128_rows_vs_oracle(dev, tree, B, C, H):
+    """activation_quantize_fn with ADMM at a batch the fused kernels do not hold (round 4: ops.SiteLargeFn - alignq_site_fwd /
+    alignq_site_bwd on the pair kernels of the blocked Gram - plus the ADMM loss; round 3 composed it from four stand-alone
+    passes): x_q bit for bit, D / loss / dx / dalterD / dgamma within 1e-5 of the oracle; ADMM(dim) is sized by the batch like the
+    reference does (utils/admm.py:17-27); F not a multiple of 4 (the unaligned loads), 5 and 8 row blocks of 128."""
     import alignq_amd.cdf_alignment_admm as NA
     import alignq_amd.office as NO
     from alignq_amd import config
@@ -143,7 +145,6 @@ def test_admm_site_above_128_rows_vs_oracle(dev, tree, B):
     config.args.abitW, config.args.train_batch_size = 4, B
     try:
         rng = np.random.default_rng(B)
-        C, H = 6, 8
         x0 = (rng.standard_normal((B, C, H, H)) * 1.2).astype(np.float32)
         gq = (rng.standard_normal((B, C, H, H)) * 1e-2).astype(np.float32)
         admm = ns.ADMM(B).to(dev)
