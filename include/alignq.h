@@ -111,7 +111,10 @@ int alignq_weight_quant_bwd(const float* g, const float* w, const float* ms, flo
  * alignq_site_fwd = alignq_site_partials (per-tile quantise + Gram partial slabs -> ws) followed by
  * alignq_site_reduce (deterministic slab reduction ws -> D, scaled by 1/F).
  * alignq_site_reduce_loss = the same reduction plus the ADMM loss of utils/admm.py:24-33 in the same launch
- * (alterD, gamma: [dim,dim] sliced [:B,:B]): scal = device float[4] {loss, rho/2/(n*rms), 1/n, rms}, n = B*B.   */
+ * (alterD, gamma: [dim,dim] sliced [:B,:B]): scal = device float[4] {loss, rho/2/(n*rms), 1/n, rms}, n = B*B.
+ * Round 4: alignq_site_fwd and alignq_site_bwd (below) also take ALIGNQ_MAX_BATCH < B <= ALIGNQ_MAX_CORR_BATCH (the reference
+ * takes any batch): pair kernels on the blocked exact-fp32 Gram of corr_large_kernels.hip (stats required; ws sizes from the
+ * same two query functions); the split entry points (_partials / _reduce / _bwd_apply / _bwd_fused) stay at B <= 128.       */
 size_t alignq_site_ws_bytes(int B, int64_t F);
 int alignq_site_fwd(const float* x, int B, int64_t F, int k, float act_range, float eps, float* xq,
                     float* D, float* stats, void* ws, void* stream);
