@@ -59,6 +59,64 @@ __global__ __launch_bounds__(kBig) void admm_loss_kernel(const float* __restrict
   }
 }
 
+// The same above 128 rows (round 4: b up to ALIGNQ_MAX_CORR_BATCH = 1024 is a million elements - the one-workgroup kernel took 69 us at
+// b = 256): kLossBlocks workgroups leave partial sums (double, fixed order), then every workgroup of the gradient pass adds them
+// up for itself (3 x kLossBlocks doubles), workgroup 0 writes the loss.
+constexpr int kLossBlocks = 128, kLossThreads = 256;
+
+__global__ __launch_bounds__(kLossThreads) void admm_loss_partial_kernel(const float* __restrict__ D, int b,
+                                                                         const float* __restrict__ A,
+                                                                         const float* __restrict__ gamma, int dim,
+                                                                         double* __restrict__ part) {
+  __shared__ double sm[48];
+  const int nn = b * b;
+  double sabs = 0, ssq = 0, srel = 0;
+  for (int e = blockIdx.x * kLossThreads + threadIdx.x; e < nn; e += kLossBlocks * kLossThreads) {
+    const int i = e / b, j = e - i * b;
+    const float a = A[i * dim + j];
+    const float d = D[e] - a;
+    sabs += fabsf(a);
+    ssq += (double)d * (double)d;
+    srel += (double)gamma[i * dim + j] * fabsf(d);
+  }
+  block_sum3(sabs, ssq, srel, sm);
+  if (threadIdx.x == 0) { part[3 * blockIdx.x] = sabs; part[3 * blockIdx.x + 1] = ssq; part[3 * blockIdx.x + 2] = srel; }
+}
+
+__global__ __launch_bounds__(kLossThreads) void admm_loss_grad_kernel(const float* __restrict__ D, int b,
+                                                                      const float* __restrict__ A,
+                                                                      const float* __restrict__ gamma, int dim, float mu,
+                                                                      float rho, const double* __restrict__ part,
+                                                                      float* __restrict__ loss, float* __restrict__ dD,
+                                                                      float* __restrict__ dA, float* __restrict__ dgamma) {
+  __shared__ double sm[48];
+  double sabs = 0, ssq = 0, srel = 0;
+  if (threadIdx.x < kLossBlocks) { sabs = part[3 * threadIdx.x]; ssq = part[3 * threadIdx.x + 1]; srel = part[3 * threadIdx.x + 2]; }
+  block_sum3(sabs, ssq, srel, sm);              // (the same order in every workgroup)
+  const double n = (double)b * (double)b;
+  const double rms = sqrt(ssq / n);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *loss = (float)(mu * sabs / n + 0.5 * rho * rms + srel / n);
+  const float c_con = (float)(0.5 * rho / (n * rms));
+  const float inv_n = (float)(1.0 / n);
+  const int full = dim * dim;
+  for (int e = blockIdx.x * kLossThreads + threadIdx.x; e < full; e += gridDim.x * kLossThreads) {
+    const int i = e / dim, j = e - i * dim;
+    float ga = 0.0f, gg = 0.0f;
+    if (i < b && j < b) {
+      const float a = A[e], gm = gamma[e];
+      const float d = D[i * b + j] - a;
+      const float sg = (float)((d > 0.0f) - (d < 0.0f));
+      const float sa = (float)((a > 0.0f) - (a < 0.0f));
+      const float gD = c_con * d + gm * sg * inv_n;
+      if (dD) dD[i * b + j] = gD;
+      ga = mu * sa * inv_n - gD;
+      gg = fabsf(d) * inv_n;
+    }
+    if (dA) dA[e] = ga;
+    if (dgamma) dgamma[e] = gg;
+  }
+}
+
 // utils/optimizer.py:97-124, one workgroup per site; the per-site pointers travel by value in the arguments.
 constexpr int kSiteChunk = 64;
 struct AChunk {
@@ -127,15 +185,23 @@ inline int grid_for(int64_t n) {
 extern "C" {
 
 size_t alignq_admm_ws_bytes(int dim) {
-  (void)dim;
-  return 16;
+  return dim > 128 ? (size_t)kLossBlocks * 3 * sizeof(double) : 16;     // the partial sums of the many-workgroup form
 }
 
 int alignq_admm_loss(const float* D, int b, const float* alterD, const float* gamma, int dim, float mu, float rho,
                      float* loss, float* dD, float* dalterD, float* dgamma, void* ws, void* stream) {
-  (void)ws;
   if (!D || !alterD || !gamma || !loss || b <= 0 || dim < b) return ALIGNQ_EINVAL;
   if (dim > 4096) return ALIGNQ_EUNSUPPORTED;
+  if (ws && dim > 128) {        // many workgroups (ws: alignq_admm_ws_bytes(dim)); without a workspace the one-workgroup kernel
+    double* part = reinterpret_cast<double*>(ws);
+    hipLaunchKernelGGL(admm_loss_partial_kernel, kLossBlocks, kLossThreads, 0, (hipStream_t)stream, D, b, alterD, gamma, dim, part);
+    int gb = (dim * dim + kLossThreads * 4 - 1) / (kLossThreads * 4);
+    if (gb > 1024) gb = 1024;
+    hipLaunchKernelGGL(admm_loss_grad_kernel, gb, kLossThreads, 0, (hipStream_t)stream, D, b, alterD, gamma, dim, mu, rho,
+                       (const double*)part, loss, dD, dalterD, dgamma);
+    LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(admm_loss_kernel, 1, kBig, 0, (hipStream_t)stream, D, b, alterD, gamma, dim, mu, rho, loss, dD,
                      dalterD, dgamma);
   LAUNCH_CHECK();

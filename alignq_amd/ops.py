@@ -299,8 +299,11 @@ class AdmmLossFn(torch.autograd.Function):
         b, dim = D.shape[0], A.shape[0]
         loss = torch.empty((), dtype=torch.float32, device=D.device)
         dD, dA, dG = torch.empty_like(D), torch.empty_like(A), torch.empty_like(Gm)
-        L.check(L.load().alignq_admm_loss(L.ptr(D), b, L.ptr(A), L.ptr(Gm), dim, float(mu), float(rho), L.ptr(loss),
-                                          L.ptr(dD), L.ptr(dA), L.ptr(dG), None, L.stream_ptr()), "alignq_admm_loss")
+        lib = L.load()
+        # above 128 rows the loss runs on many workgroups (partial sums in ws) instead of one
+        ws = torch.empty(lib.alignq_admm_ws_bytes(dim), dtype=torch.uint8, device=D.device) if dim > 128 else None
+        L.check(lib.alignq_admm_loss(L.ptr(D), b, L.ptr(A), L.ptr(Gm), dim, float(mu), float(rho), L.ptr(loss),
+                                     L.ptr(dD), L.ptr(dA), L.ptr(dG), L.ptr(ws), L.stream_ptr()), "alignq_admm_loss")
         ctx.save_for_backward(dD, dA, dG)
         return loss
 
