@@ -53,8 +53,10 @@ __device__ __forceinline__ void mask_bits4(const unsigned long long* __restrict_
 }
 __host__ __device__ __forceinline__ int64_t mask_words(int64_t nvec) { return ((nvec + 63) >> 6) * 4; }
 
+// MODE 3 (round 4): the plain per-channel sums of TWO arrays {sum z, sum g} - the second stage over the per-column sums the small-batch
+// site backward leaves (site1_bwd_kernel: P is then the number of columns per channel).
 template <int MODE>
-struct SumsDepth { static constexpr int U = MODE == 0 ? 8 : (MODE == 2 ? 6 : 4); };   // float4 per thread and array in flight
+struct SumsDepth { static constexpr int U = MODE == 0 ? 8 : (MODE == 1 ? 4 : 6); };   // float4 per thread and array in flight
 
 template <int MODE, int NT>
 __global__ __launch_bounds__(NT) void bnq_sums_kernel(const float* __restrict__ z, const float* __restrict__ g,
@@ -82,8 +84,9 @@ __global__ __launch_bounds__(NT) void bnq_sums_kernel(const float* __restrict__ 
   const int64_t per = (P + gridDim.x - 1) / gridDim.x;
   const int64_t p0 = (int64_t)blockIdx.x * per, p1 = (p0 + per < P) ? p0 + per : P;
   constexpr bool BWD = MODE != 0;
+  constexpr bool STAT = MODE == 1 || MODE == 2;      // forms using (a, b, mean, invstd)
   float4 a4, b4, m4, i4;
-  if (BWD) {
+  if (STAT) {
     a4 = *reinterpret_cast<const float4*>(ab + 4 * cq);
     b4 = *reinterpret_cast<const float4*>(ab + C + 4 * cq);
     m4 = *reinterpret_cast<const float4*>(save + 4 * cq);
@@ -113,6 +116,10 @@ __global__ __launch_bounds__(NT) void bnq_sums_kernel(const float* __restrict__ 
         if (!BWD) {
 #pragma unroll
           for (int e = 0; e < 4; e++) { s0[e] += (double)ze[e]; s1[e] += (double)ze[e] * (double)ze[e]; }
+        } else if (MODE == 3) {
+          const float ge[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+#pragma unroll
+          for (int e = 0; e < 4; e++) { s0[e] += (double)ze[e]; s1[e] += (double)ge[e]; }
         } else {
           const float ge[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
           const float ye[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};
@@ -219,11 +226,19 @@ __global__ __launch_bounds__(kT) void bnq_finalize_kernel(const double* __restri
 }
 
 // dgamma / dbeta: the SUM over the groups (one parameter, several slices); ktot: [groups][2][C]
+// fix (or nullptr; round 4): the second sums came from x = a*z + b as sum dx * (x - beta) / gamma (the small-batch site backward's
+// per-column sums); a channel with gamma == 0 (a == 0) carries no trace of z there, so the wave forms its sum dx * zhat from dx and z
+// directly (P strided reads: slow, and only for such channels - e.g. a zero-initialised last batch-norm of a residual branch).
+struct ZeroGammaFix {
+  const float* dx; const float* z; const float* ab; const float* save;
+};
 __global__ __launch_bounds__(kT) void bnq_finalize_bwd_kernel(const double* __restrict__ part, int nparts, int64_t P, int C,
                                                               float* __restrict__ ktot, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, int groups) {
+                                                              float* __restrict__ dbeta, int groups, int64_t Pfull = 0,
+                                                              ZeroGammaFix fix = ZeroGammaFix{nullptr, nullptr, nullptr, nullptr}) {
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= C) return;
+  if (Pfull == 0) Pfull = P;                    // (P: what the partials were summed over; Pfull: elements per channel and group)
   double ta = 0, tq = 0;
   const int64_t gstride = (int64_t)nparts * C * 2;
   for (int g0 = 0; g0 < groups; g0 += 2) {
@@ -233,9 +248,19 @@ __global__ __launch_bounds__(kT) void bnq_finalize_bwd_kernel(const double* __re
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       if (j == 1 && !two) break;
+      if (fix.dx && fix.ab[(int64_t)(g0 + j) * 2 * C + c] == 0.0f) {
+        const float* dxg = fix.dx + (int64_t)(g0 + j) * Pfull * C;
+        const float* zg = fix.z + (int64_t)(g0 + j) * Pfull * C;
+        const float mm = fix.save[(int64_t)(g0 + j) * 2 * C + c], ii = fix.save[(int64_t)(g0 + j) * 2 * C + C + c];
+        double qq = 0;
+        for (int64_t px = lane; px < Pfull; px += 64) qq += (double)dxg[px * C + c] * (double)((zg[px * C + c] - mm) * ii);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) qq += __shfl_xor(qq, o, 64);
+        q[j] = qq;
+      }
       if (lane == 0) {
-        ktot[(int64_t)(g0 + j) * 2 * C + c] = (float)(a[j] / (double)P);
-        ktot[(int64_t)(g0 + j) * 2 * C + C + c] = (float)(q[j] / (double)P);
+        ktot[(int64_t)(g0 + j) * 2 * C + c] = (float)(a[j] / (double)Pfull);
+        ktot[(int64_t)(g0 + j) * 2 * C + C + c] = (float)(q[j] / (double)Pfull);
       }
       ta += a[j];
       tq += q[j];
@@ -672,3 +697,28 @@ int alignq_bnq_bwd_dx(const float* dx, const float* z, const float* ab, const fl
 }
 
 }  // extern "C"
+
+// The batch-norm backward when the small-batch site backward has left per-column sums (site1_bwd_kernel): [2][groups][HW * C] floats
+namespace alignq_site {
+int launch_bnq_bwd_from_cols(const float* cols, const float* dx, const float* z, const float* ab, const float* save, int64_t P,
+                             int64_t HW, int C, int groups, float* dz, float* dgamma, float* dbeta, void* ws, hipStream_t st) {
+  if (!cols || !dx || !z || !ab || !save || !dz || !ws || P < 2 || HW < 1 || bad_groups(groups)) return ALIGNQ_EINVAL;
+  if (bad_c(C)) return ALIGNQ_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(dz) |
+       reinterpret_cast<uintptr_t>(cols)) & 15)
+    return ALIGNQ_EINVAL;
+  double* part = reinterpret_cast<double*>(ws);
+  float* ktot = ktot_of(ws, C, groups);
+  const int np = parts_for(HW, C);
+  const float* cols1 = cols + (int64_t)groups * HW * C;
+  BNQ_SUMS_NT(C, hipLaunchKernelGGL((bnq_sums_kernel<3, NTV>), dim3(np, groups), dim3(NTV), 0, st, cols, cols1, nullptr, nullptr, nullptr, HW, C,
+                     0.f, 0, part));
+  const ZeroGammaFix fix{dx, z, ab, save};
+  hipLaunchKernelGGL(bnq_finalize_bwd_kernel, dim3((C + 3) / 4), dim3(kT), 0, st, (const double*)part, np, HW, C, ktot, dgamma, dbeta,
+                     groups, P, fix);
+  const int64_t nvec = P * (C >> 2);
+  BNQ_NT(C, hipLaunchKernelGGL((bnq_apply_bwd_kernel<NTV>), dim3(tiles(nvec, 2, NTV), groups), dim3(NTV), 0, st, dx, z, nullptr, ab, save,
+                     (const float*)ktot, nvec, C, 0.f, 0, 1, dz));
+  return hipGetLastError() == hipSuccess ? 0 : ALIGNQ_EINVAL;
+}
+}  // namespace alignq_site

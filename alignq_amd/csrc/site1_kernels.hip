@@ -301,7 +301,8 @@ __global__ __launch_bounds__(kThreads1, PAIR ? 3 : 5) void site1_bwd_kernel(cons
                                                                float eps, float* __restrict__ dx, int n_sub,
                                                                const float* __restrict__ ab, int C,
                                                                const float* __restrict__ ymask, float* __restrict__ dres,
-                                                               int64_t s_gstride, const float* __restrict__ gup2) {
+                                                               int64_t s_gstride, const float* __restrict__ gup2,
+                                                               const float* __restrict__ save = nullptr, float* __restrict__ colsum = nullptr) {
   {        // blockIdx.y = group (see site1_fwd_kernel); S matrices s_gstride floats apart
     const int64_t gi = blockIdx.y, go = gi * (int64_t)B * F;
     x += go; dx += go;
@@ -312,7 +313,10 @@ __global__ __launch_bounds__(kThreads1, PAIR ? 3 : 5) void site1_bwd_kernel(cons
     S += gi * s_gstride;
     stats += gi * 4 * F;
     if (ab) ab += gi * 2 * C;
+    if (save) save += gi * 2 * C;
+    if (colsum) colsum += gi * F;               // [2][groups][F]: the second array starts gridDim.y * F floats further
   }
+  const int64_t cs2 = (int64_t)gridDim.y * F;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
   const float invB = 1.0f / (float)B, invBm1 = 1.0f / (float)(B - 1);
@@ -453,6 +457,33 @@ __global__ __launch_bounds__(kThreads1, PAIR ? 3 : 5) void site1_bwd_kernel(cons
         if (row_of(q, h) < B)
           *reinterpret_cast<float*>(reinterpret_cast<char*>(dx) + ((unsigned)row_of(q, h) * rowB + colB)) = out[q];
     }
+    if (PAIR && colsum) {
+      // The folded batch-norm's backward needs sum dx and sum dx * zhat per channel over batch AND pixels: the batch part is formed
+      // here, per feature column, from the registers that still hold this sub-tile's dx and x (zhat = (z - mean) * invstd =
+      // (x - beta) / gamma up to the rounding of x = a*z + b; gamma == 0 leaves 0 and bnq_finalize_bwd_kernel forms that channel
+      // from dx and z itself): 8 bytes per column instead of alignq_bnq_bwd_dx's own pass over dx and z (8 B per ELEMENT).  A pass
+      // of its own behind the stores and scheduling barriers, a and the statistics re-read through pointers the optimiser cannot
+      // match with the earlier ones: inside the loop above (the kernel's register peak) every form of it spilled.
+      __builtin_amdgcn_sched_barrier(0);
+      const float* ab2 = ab;
+      const float* sv2 = save;
+      asm volatile("" : "+s"(ab2), "+s"(sv2));
+      const int ch = (int)(colc & (int64_t)(C - 1));
+      const float a2 = ab2[ch];
+      const float bt = __fmaf_rn(sv2[ch], a2, ab2[C + ch]);
+      const float rg = a2 != 0.0f ? sv2[C + ch] / a2 : 0.0f;
+      float f0 = 0.f, f1 = 0.f;
+#pragma unroll
+      for (int q = 0; q < RPL; q++) {
+        const float o = row_of(q, h) < B ? out[q] : 0.0f;
+        f0 += o;
+        f1 = __fmaf_rn(o, (xr[q] - bt) * rg, f1);
+      }
+      f0 += __shfl_xor(f0, 32, 64);
+      f1 += __shfl_xor(f1, 32, 64);
+      if (h == 0 && cok) { colsum[col] = f0; colsum[cs2 + col] = f1; }
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #undef S2_OFF
   }
 }
@@ -480,8 +511,9 @@ int launch_partials1(bool pair, const Geom& g, const float* x, int B, int64_t F,
 
 int launch_bwd1(bool pair, const float* gup, const float* S, const float* x, const float* stats, int B, int64_t F,
                 float r, float eps, float* dx, hipStream_t st, const float* ab, int C, const float* ymask, float* dres, int groups,
-                int64_t s_gstride, const float* gup2) {
+                int64_t s_gstride, const float* gup2, const float* save, float* colsum) {
   if (gup2 && (!gup || !pair)) return ALIGNQ_EINVAL;
+  if (colsum && (!pair || !ab || !save)) return ALIGNQ_EINVAL;
   if ((int64_t)B * F * 4 >= ((int64_t)1 << 32)) return ALIGNQ_EUNSUPPORTED;   // 32-bit byte offsets
   const int n_sub = (int)((F + SUBF - 1) / SUBF);
   int grid = (n_sub + kWaves - 1) / kWaves;
@@ -490,8 +522,8 @@ int launch_bwd1(bool pair, const float* gup, const float* S, const float* x, con
   static const int capb = alignq_env::env_int("ALIGNQ_S1_GRID_B", 768, 1, 65535);      // tuning aid
   if (grid > capb) grid = capb;
   if (groups > 1 && grid * groups > capb) grid = (capb + groups - 1) / groups;      // the groups share the resident round
-  if (pair) hipLaunchKernelGGL((site1_bwd_kernel<true>), dim3(grid, groups), kThreads1, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_sub, ab, C, ymask, dres, s_gstride, gup2);
-  else hipLaunchKernelGGL((site1_bwd_kernel<false>), dim3(grid, groups), kThreads1, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_sub, ab, C, nullptr, nullptr, s_gstride, nullptr);
+  if (pair) hipLaunchKernelGGL((site1_bwd_kernel<true>), dim3(grid, groups), kThreads1, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_sub, ab, C, ymask, dres, s_gstride, gup2, save, colsum);
+  else hipLaunchKernelGGL((site1_bwd_kernel<false>), dim3(grid, groups), kThreads1, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_sub, ab, C, nullptr, nullptr, s_gstride, nullptr, nullptr, nullptr);
   RET_ON_ERR1();
   return 0;
 }

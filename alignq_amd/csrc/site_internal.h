@@ -124,7 +124,14 @@ int launch_reduce_loss_groups(const Geom& g, float* ws, int B, int64_t F, int gr
 int launch_bwd1(bool pair, const float* gup, const float* S, const float* x, const float* stats, int B, int64_t F,
                 float r, float eps, float* dx, hipStream_t st, const float* ab = nullptr, int C = 1,
                 const float* ymask = nullptr, float* dres = nullptr, int groups = 1, int64_t s_gstride = 0,
-                const float* gup2 = nullptr);      // a second addend of the upstream gradient (fused.GradFork), or nullptr
+                const float* gup2 = nullptr,       // a second addend of the upstream gradient (fused.GradFork), or nullptr
+                // round 4: per feature column sum_b dx and sum_b dx * zhat for the folded batch-norm's backward: save = [groups][2][C]
+                // (mean, invstd), colsum = [2][groups][F] floats (written)
+                const float* save = nullptr, float* colsum = nullptr);
+// bnq_kernels.hip: the batch-norm backward from those per-column sums (HW columns per channel and group): a small reduction over
+// the columns, the finalisation (channels with gamma == 0 are summed from dx and z directly) and dz = a (dx - k0 - zhat k1)
+int launch_bnq_bwd_from_cols(const float* cols, const float* dx, const float* z, const float* ab, const float* save, int64_t P,
+                             int64_t HW, int C, int groups, float* dz, float* dgamma, float* dbeta, void* ws, hipStream_t st);
 
 // ---- launchers defined in site4_kernels.hip ----------------------------------------------------------------
 // earlier sites whose slab reduction + ADMM loss ride in this forward launch as a filler role (site4_kernels.hip: SFill)

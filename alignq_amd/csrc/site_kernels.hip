@@ -785,6 +785,30 @@ int alignq_site1_groups_bwd(const float* g, const float* g2, const float* y, con
                      groups, (int64_t)(alignq_site_bwd_ws_bytes(B) / 4), g2);
 }
 
+// alignq_site1_groups_bwd + alignq_bnq_bwd_dx with the batch-norm backward's first pass replaced by per-column sums the site
+// kernel leaves (round 4): cols = alignq_site1_cols_bytes(F, groups) bytes of scratch
+size_t alignq_site1_cols_bytes(int64_t F, int groups) {
+  if (F <= 0 || groups < 1 || groups > ALIGNQ_BNQ_MAX_GROUPS) return 0;
+  return (size_t)2 * groups * F * sizeof(float);
+}
+
+int alignq_site1_groups_bwd_bn(const float* g, const float* g2, const float* y, const float* S, const float* z, const float* ab,
+                               const float* save, int C, const float* stats, int B, int64_t F, int groups, float act_range, float eps,
+                               float* dz, float* dres, float* dgamma, float* dbeta, void* cols, void* ws_bn, void* stream) {
+  if (!S || !z || !ab || !save || !stats || !dz || !cols || !ws_bn || groups < 1 || groups > ALIGNQ_BNQ_MAX_GROUPS || (g && !y) ||
+      (g2 && !g) || C < 1 || (C & (C - 1)) != 0 || F % C != 0)
+    return ALIGNQ_EINVAL;
+  if (bad_shape(B, F)) return F <= 0 ? ALIGNQ_EINVAL : ALIGNQ_EUNSUPPORTED;
+  if (geom(B, F).nb != 1) return ALIGNQ_EUNSUPPORTED;
+  const int64_t HW = F / C, P = (int64_t)B * HW;
+  if (P < 2) return ALIGNQ_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int rc = launch_bwd1(true, g, S, z, stats, B, F, act_range, eps, dz, st, ab, C, g ? y : nullptr, g ? dres : nullptr, groups,
+                             (int64_t)(alignq_site_bwd_ws_bytes(B) / 4), g2, save, (float*)cols);
+  if (rc) return rc;
+  return launch_bnq_bwd_from_cols((const float*)cols, dz, z, ab, save, P, HW, C, groups, dz, dgamma, dbeta, ws_bn, st);
+}
+
 int alignq_site_bwd_fused(const float* g, const float* D, const float* alterD, const float* gamma, int dim,
                           const float* scal, float mu, const float* dD_scale, const float* x, const float* stats,
                           int B, int64_t F, float act_range, float eps, float* dx, float* dalterD, float* dgamma,

@@ -745,6 +745,7 @@ def bn_only(bn, z, groups=1):
 
 
 _S1_MASK_IN_KERNEL = os.environ.get("ALIGNQ_S1_MASK", "1") != "0"
+_S1_BN_COLS = os.environ.get("ALIGNQ_S1_BN_COLS", "1") != "0"       # A/B aid: 0 = alignq_site1_groups_bwd + alignq_bnq_bwd_dx
 _BNQ_BITMASK = os.environ.get("ALIGNQ_BNQ_BITMASK", "1") != "0"     # A/B aid: 0 = the backward reads the fp32 y for the ReLU mask
 
 
@@ -848,9 +849,18 @@ class BNSite1Fn(torch.autograd.Function):
                 L.ptr_array([scal[gi] for gi in range(groups)]), L.ptr(g_loss), L.i64_array([F] * groups), B, A.shape[0], mu,
                 L.ptr_array(Sg), L.ptr_array([dA[gi] for gi in range(groups)]), L.ptr_array([dG[gi] for gi in range(groups)]), st),
                 "alignq_site_prep_fused_multi")
-            L.check(lib.alignq_site1_groups_bwd(L.ptr(g_y), L.ptr(g_y2), L.ptr(None if g_y is None else y), L.ptr(S), L.ptr(z),
-                                                L.ptr(ab), C, L.ptr(stats), B, F, groups, act_range, eps, L.ptr(dx), L.ptr(g_m), st),
-                    "alignq_site1_groups_bwd")
+            if _S1_BN_COLS:
+                # round 4: the site kernel leaves the batch-norm backward's sums per feature column; a small reduction, the
+                # finalisation and dz (in place) follow in the same entry: no pass of its own over dx and z
+                cols = torch.empty(lib.alignq_site1_cols_bytes(F, groups), dtype=torch.uint8, device=dev)
+                L.check(lib.alignq_site1_groups_bwd_bn(L.ptr(g_y), L.ptr(g_y2), L.ptr(None if g_y is None else y), L.ptr(S), L.ptr(z),
+                                                       L.ptr(ab), L.ptr(save), C, L.ptr(stats), B, F, groups, act_range, eps, L.ptr(dx),
+                                                       L.ptr(g_m), L.ptr(dgamma), L.ptr(dbeta), L.ptr(cols), L.ptr(ws_bn), st),
+                        "alignq_site1_groups_bwd_bn")
+            else:
+                L.check(lib.alignq_site1_groups_bwd(L.ptr(g_y), L.ptr(g_y2), L.ptr(None if g_y is None else y), L.ptr(S), L.ptr(z),
+                                                    L.ptr(ab), C, L.ptr(stats), B, F, groups, act_range, eps, L.ptr(dx), L.ptr(g_m), st),
+                        "alignq_site1_groups_bwd")
         else:
             for gi in range(groups):
                 sl = slice(gi * B, (gi + 1) * B)
@@ -859,8 +869,9 @@ class BNSite1Fn(torch.autograd.Function):
                 L.check(lib.alignq_site_bwd_apply_ab(L.ptr(None if g_y is None else g_y[sl]), L.ptr(S), L.ptr(z[sl]), L.ptr(ab[gi]), C,
                                                      L.ptr(stats[gi]), B, F, act_range, eps, L.ptr(dx[sl]), st),
                         "alignq_site_bwd_apply_ab")
-        L.check(lib.alignq_bnq_bwd_dx(L.ptr(dx), L.ptr(z), L.ptr(ab), L.ptr(save), P, C, groups, L.ptr(dx), L.ptr(dgamma),
-                                      L.ptr(dbeta), L.ptr(ws_bn), st), "alignq_bnq_bwd_dx")
+        if not (_S1_MASK_IN_KERNEL and _S1_BN_COLS):
+            L.check(lib.alignq_bnq_bwd_dx(L.ptr(dx), L.ptr(z), L.ptr(ab), L.ptr(save), P, C, groups, L.ptr(dx), L.ptr(dgamma),
+                                          L.ptr(dbeta), L.ptr(ws_bn), st), "alignq_bnq_bwd_dx")
 
         def red(t):                                  # the slices' alterD / gamma gradients: one elementwise add, not a reduce
             out = t[0]

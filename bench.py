@@ -458,7 +458,8 @@ def measure_office_shapes(dev, k):
       site_*   : the bottleneck tail `relu(act_q3(bn3(z))[0] + identity)` (resnet.py:146-154) at layer4's [28, 100352] and layer1's
                  [28, 802816]: forward alignq_bnq_stats + alignq_site1_groups_fwd + alignq_site1_groups_reduce_loss (reads z twice and the
                  residual, writes y: 16 B/element), backward alignq_site_prep_fused_multi + alignq_site1_groups_bwd + alignq_bnq_bwd_dx
-                 (g, y, z -> dx, dres; then dx, z twice -> dz: 40 B/element).
+                 (alignq_site1_groups_bwd_bn: g, y, z -> dx, dres and per-column batch-norm sums; then dx, z -> dz: 32 B/element;
+                 `bwd_us_with_sums_pass`: alignq_site1_groups_bwd + alignq_bnq_bwd_dx with its own pass over dx and z, 40 B/element).
     HIP events on the launch stream, 4 rotating operand sets (a launch finds its operands where the step finds them)."""
     from alignq_amd import _lib as L
     lib = L.load()
@@ -529,6 +530,7 @@ def measure_office_shapes(dev, k):
         one = torch.ones((), device=dev)
         wsb = lib.alignq_site_ws_bytes(B, F)
         ws = torch.empty(wsb * G, dtype=torch.uint8, device=dev)
+        cols = torch.empty(lib.alignq_site1_cols_bytes(F, G), dtype=torch.uint8, device=dev)
         sb = lib.alignq_site_bwd_ws_bytes(B)
         S = torch.empty(sb * G, dtype=torch.uint8, device=dev)
         Sg = [S[i * sb:(i + 1) * sb] for i in range(G)]
@@ -555,19 +557,27 @@ def measure_office_shapes(dev, k):
             L.check(lib.alignq_bnq_bwd_dx(p(dxs[i]), p(zs[i]), p(ab), p(save), P, C, G, p(dxs[i]), p(dgam), p(dbet), p(ws_bn), st),
                     "alignq_bnq_bwd_dx")
 
+        def s_bwd_cols(i):        # round 4 (the step's path): the site backward leaves per-column sums for the batch-norm backward
+            L.check(lib.alignq_site_prep_fused_multi(*prep_args), "alignq_site_prep_fused_multi")
+            L.check(lib.alignq_site1_groups_bwd_bn(p(gs[i]), None, p(ys[i]), p(S), p(zs[i]), p(ab), p(save), C, p(stats), B, F, G, 2.0, 1e-5,
+                                                   p(dxs[i]), p(dress[i]), p(dgam), p(dbet), p(cols), p(ws_bn), st),
+                    "alignq_site1_groups_bwd_bn")
+
         def s_bwd_site(i):
             L.check(lib.alignq_site1_groups_bwd(p(gs[i]), None, p(ys[i]), p(S), p(zs[i]), p(ab), C, p(stats), B, F, G, 2.0, 1e-5, p(dxs[i]),
                                                 p(dress[i]), st), "alignq_site1_groups_bwd")
         for i in range(R):
             s_fwd(i)       # (the statistics of the LAST set stay in `stats` for the backward launches: timing only)
         t_f, t_fs = time_call_rot(s_fwd, 20, R), time_call_rot(s_fwd_site, 20, R)
-        t_b, t_bs = time_call_rot(s_bwd, 20, R), time_call_rot(s_bwd_site, 20, R)
+        t_b5, t_bs = time_call_rot(s_bwd, 20, R), time_call_rot(s_bwd_site, 20, R)
+        t_b = time_call_rot(s_bwd_cols, 20, R)
         out[f"bn_site_2x{B}x{F}"] = {
             "elements": n, "fwd_us": t_f * 1e6, "fwd_hbm_gbs": 16.0 * n / t_f / 1e9, "fwd_frac_of_8TBs": 16.0 * n / t_f / 1e9 / HBM_PEAK_GBS,
             "site_fwd_kernel_us": t_fs * 1e6, "site_fwd_kernel_frac_of_8TBs": 12.0 * n / t_fs / 1e9 / HBM_PEAK_GBS,
-            "bwd_us": t_b * 1e6, "bwd_hbm_gbs": 40.0 * n / t_b / 1e9, "bwd_frac_of_8TBs": 40.0 * n / t_b / 1e9 / HBM_PEAK_GBS,
+            "bwd_us": t_b * 1e6, "bwd_hbm_gbs": 32.0 * n / t_b / 1e9, "bwd_frac_of_8TBs": 32.0 * n / t_b / 1e9 / HBM_PEAK_GBS,
+            "bwd_us_with_sums_pass": t_b5 * 1e6,
             "site_bwd_kernel_us": t_bs * 1e6, "site_bwd_kernel_frac_of_8TBs": 20.0 * n / t_bs / 1e9 / HBM_PEAK_GBS,
-            "fwd_bytes_per_elem": 16, "bwd_bytes_per_elem": 40,
+            "fwd_bytes_per_elem": 16, "bwd_bytes_per_elem": 32,
             "note": "site_*_kernel: alignq_site1_groups_fwd (z, residual -> y: 12 B/element) / alignq_site1_groups_bwd (g, y, z -> dx, "
                     "dres: 20 B/element) alone"}
         del zs, rs, gs, ys, dxs, dress

@@ -499,6 +499,16 @@ int alignq_site1_groups_reduce_loss(void* ws, int B, int64_t F, int groups, floa
 int alignq_site1_groups_bwd(const float* g, const float* g2, const float* y, const float* S, const float* z, const float* ab, int C,
                             const float* stats, int B, int64_t F, int groups, float act_range, float eps, float* dx,
                             float* dres, void* stream);
+/* alignq_site1_groups_bwd + alignq_bnq_bwd_dx as ONE entry (round 4): the backward of `relu(act_q3(bn3(z))[0] + identity)`
+ * (dann_office/model/resnet.py:146-154) from the gradient of that output to dz, dgamma, dbeta, dres.  The site kernel also leaves,
+ * per feature column, sum_b dx and sum_b dx * zhat (8 bytes per column, taken from the registers that hold the sub-tile); the
+ * batch-norm backward's first pass over dx and z (8 B per ELEMENT) becomes a reduction over those columns.  save: [groups][2][C]
+ * (mean, invstd) of alignq_bnq_stats; dz: [groups][B][F] (receives dx, then dz in place); cols: alignq_site1_cols_bytes(F, groups)
+ * bytes of scratch; ws_bn: alignq_bnq_ws_bytes(C, groups).  Channels whose gamma is exactly 0 are summed from dx and z directly.  */
+size_t alignq_site1_cols_bytes(int64_t F, int groups);
+int alignq_site1_groups_bwd_bn(const float* g, const float* g2, const float* y, const float* S, const float* z, const float* ab,
+                               const float* save, int C, const float* stats, int B, int64_t F, int groups, float act_range, float eps,
+                               float* dz, float* dres, float* dgamma, float* dbeta, void* cols, void* ws_bn, void* stream);
 size_t alignq_bnq_ws_bytes(int C, int groups);
 /* ReLU mask as ONE BIT per element (round 4): alignq_bnq_fwd with mask != NULL also writes [y > 0] for every element
  * (alignq_bnq_mask_bytes(P, C, groups) bytes, 16-byte aligned; per group and per 64 consecutive channel quads four 64-bit words,

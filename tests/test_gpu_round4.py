@@ -413,3 +413,49 @@ np.savez(sys.argv[1], y=y.cpu().numpy(), mask=mask.cpu().numpy(), ab=ab.cpu().nu
     assert dy.max() <= lev * 1.001 and np.count_nonzero(dy) < 1e-4 * dy.size      # a 1-ulp (a, b) moves a few near-tie elements
     same = dy == 0
     assert np.array_equal(b["dres"][same], a["dres"][same])
+
+
+# ------------------------------------------------------------------------------------------------ round 4: per-column BN sums
+@pytest.mark.parametrize("B,C,H,groups", [(6, 64, 8, 1), (28, 256, 14, 2), (5, 16, 3, 1), (28, 2048, 7, 2)])
+def test_small_batch_site_backward_with_per_column_bn_sums_equals_the_sums_pass(dev, B, C, H, groups):
+    """alignq_site1_groups_bwd_bn (the site kernel leaves sum_b dx and sum_b dx * zhat per feature column, zhat formed from
+    x = gamma * zhat + beta; a small reduction over the columns replaces alignq_bnq_bwd_dx's pass over dx and z) against
+    alignq_site1_groups_bwd + alignq_bnq_bwd_dx on the same inputs: dx is the same kernel's (bit-identical), so dz / dgamma / dbeta
+    may differ by the summation order and by the one rounding of x = a*z + b only.  Two channels have gamma == 0: x carries no
+    trace of z there and the finalisation must sum them from dx and z directly (their dgamma is NOT zero).  The oracle comparison
+    of the default path is test_bn_folded_small_batch_admm_site_vs_oracle."""
+    import alignq_amd.office as NO
+    from alignq_amd import config, fused
+    Bt = B * groups
+    old = (config.args.abitW, config.args.train_batch_size, fused._S1_BN_COLS)
+    config.args.abitW, config.args.train_batch_size = 8, B
+    try:
+        torch.manual_seed(B + C)
+        cl = lambda t: t.contiguous(memory_format=torch.channels_last)      # noqa: E731
+        z0 = cl(torch.randn(Bt, C, H, H, device=dev) * 1.2 + 0.2)
+        r0 = cl(torch.relu(torch.randn(Bt, C, H, H, device=dev)))
+        g0 = cl(torch.randn(Bt, C, H, H, device=dev) * 0.01)
+        outs = []
+        for cols in (False, True):
+            fused._S1_BN_COLS = cols
+            torch.manual_seed(1)
+            bn = torch.nn.BatchNorm2d(C).to(dev).train()
+            with torch.no_grad():
+                bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.2)
+                bn.weight[1] = 0.0
+                bn.weight[C - 3] = 0.0
+            admm = NO.ADMM(B).to(dev)
+            act = NO.activation_quantize_fn2(8, "aligned", admm).to(dev)
+            z, res = z0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+            y, loss = fused.bn_site_res_relu(bn, act, z, res, 1e-5, groups)
+            torch.autograd.backward([y, loss], [g0, torch.ones((), device=dev)])
+            outs.append([npy(t) for t in (z.grad, res.grad, bn.weight.grad, bn.bias.grad)])
+        (dz_a, dr_a, dg_a, db_a), (dz_b, dr_b, dg_b, db_b) = outs
+        assert np.array_equal(dr_a, dr_b)
+        assert abs(dg_a[1]) > 0 and abs(dg_a[C - 3]) > 0
+        scale = float(np.abs(dg_a).max())
+        np.testing.assert_allclose(dg_b, dg_a, rtol=2e-5, atol=2e-6 * scale)
+        np.testing.assert_allclose(db_b, db_a, rtol=2e-5, atol=2e-6 * float(np.abs(db_a).max()))
+        np.testing.assert_allclose(dz_b, dz_a, rtol=1e-4, atol=1e-6 * float(np.abs(dz_a).max()) + 1e-9)
+    finally:
+        config.args.abitW, config.args.train_batch_size, fused._S1_BN_COLS = old
