@@ -50,20 +50,22 @@ class Bottleneck(nn.Module):
         trans_loss = 0.
         identity = x
         if groups > 1:
-            if self.downsample is None:       # x feeds conv1 AND the shortcut: their gradients meet in the producing site's kernel
-                from . import fused
-                x, identity = fused.fork_block_input(x)
+            # x feeds conv1 AND the shortcut (directly, or through the downsample convolution): the two gradients meet in the
+            # producing site's kernel instead of in an elementwise add (fused.GradFork; a no-op unless x comes from a folded site)
+            from . import fused
+            x, x_short = fused.fork_block_input(x)
+            identity = x_short
             out = self.act_q1.forward_bn_relu(self.bn1, self.conv1(x), groups)
             out = self.act_q2.forward_bn_relu(self.bn2, self.conv2(out), groups)
             if self.downsample is not None:
-                from . import fused
-                identity = fused.bn_only(self.downsample[1], self.downsample[0](x), groups)
+                identity = fused.bn_only(self.downsample[1], self.downsample[0](x_short), groups)
             out, loss = self.act_q3.forward_bn_res_relu(self.bn3, self.conv3(out), identity, groups)
             return out, loss              # (= 0. + loss without the launch that forms it)
+        x_short = x
         if getattr(self, "fuse_bn", False):         # opt-in (OfficeTrainStep): batch-norm + quantiser + ReLU as one chain
-            if self.downsample is None:
-                from . import fused
-                x, identity = fused.fork_block_input(x)
+            from . import fused
+            x, x_short = fused.fork_block_input(x)
+            identity = x_short
             out = self.act_q1.forward_bn_relu(self.bn1, self.conv1(x))
             out = self.act_q2.forward_bn_relu(self.bn2, self.conv2(out))
         elif getattr(self, "fuse_relu", False):     # opt-in: quantiser + ReLU in one launch each way
@@ -75,7 +77,7 @@ class Bottleneck(nn.Module):
         if getattr(self, "fuse_bn", False):         # bn3 folded into the site kernels, the downsample batch-norm on the same family
             if self.downsample is not None:
                 from . import fused
-                identity = fused.bn_only(self.downsample[1], self.downsample[0](x))
+                identity = fused.bn_only(self.downsample[1], self.downsample[0](x_short))
             out, loss = self.act_q3.forward_bn_res_relu(self.bn3, self.conv3(out), identity)
             return out, loss              # (= 0. + loss without the launch that forms it)
         if getattr(self, "fuse_relu", False):       # `out += identity; relu` inside the site kernels
