@@ -57,6 +57,7 @@ SIGNATURES = {
     "alignq_site1_groups_fwd": (_i, [_vp, _vp, _i, _i, _i64, _i, _i, _f, _f, _vp, _i, _vp, _vp, _vp, _vp]),
     "alignq_site1_groups_reduce_loss": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _i, _f, _f, _vp, _vp]),
     "alignq_site1_groups_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i64, _i, _f, _f, _vp, _vp, _vp]),
+    "alignq_site1_groups_prep": (_i, [_vp, _vp, _vp, _i, _vp, _f, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp]),
     "alignq_site1_cols_bytes": (_sz, [_i64, _i]),
     "alignq_site1_groups_bwd_bn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i64, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "alignq_site_bwd_apply_ab_relu": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i64, _f, _f, _vp, _vp, _vp]),

@@ -1182,6 +1182,42 @@ __global__ __launch_bounds__(256) void site_prep_multi_kernel(PChunk c, int dim,
                        c.dG[s], blockIdx.x, gridDim.x);
 }
 
+// The B <= 32 site's preparation for `groups` batch slices that share ONE ADMM module (the Office step's merged source + target
+// pass): S of every slice (blockIdx.y = slice) and - by the workgroups of slice 0 - the parameter gradients of ALL slices added
+// in slice order (dalterD = sum_g dalterD_g: the sum autograd forms when the module is called once per pass; round 4: it was an
+// elementwise launch of its own behind the per-slice gradients).  D: [groups][B][B], scal: [groups][4], S regions s_gstride floats apart.
+__global__ __launch_bounds__(256) void site_prep_groups_kernel(const float* __restrict__ D, const float* __restrict__ A,
+                                                               const float* __restrict__ gamma, int dim,
+                                                               const float* __restrict__ scal, float mu,
+                                                               const float* __restrict__ gscale, int B, float invF,
+                                                               float* __restrict__ S, int64_t s_gstride,
+                                                               float* __restrict__ dA_out, float* __restrict__ dG_out, int groups) {
+  const int gi = blockIdx.y;
+  // S of this slice (no parameter gradients from here: dA_out / dG_out nullptr)
+  site_prep_body<true>(nullptr, D + (int64_t)gi * B * B, A, gamma, dim, scal + 4 * gi, mu, gscale, B, invF, S + gi * s_gstride, nullptr,
+                       nullptr, blockIdx.x, gridDim.x);
+  if (gi != 0 || (!dA_out && !dG_out)) return;
+  const float gs = gscale ? gscale[0] : 1.0f;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < dim * dim; e += gridDim.x * 256) {
+    const int i = e / dim, j = e - i * dim;
+    float da = 0.f, dg = 0.f;
+    if (i < B && j < B) {
+      const float a = A[e], gm = gamma[e];
+      const float sa = (float)((a > 0.f) - (a < 0.f));
+      for (int g = 0; g < groups; g++) {                      // slice order: the same sum as pass after pass
+        const float c_con = scal[4 * g + 1], inv_n = scal[4 * g + 2];
+        const float d = D[(int64_t)g * B * B + i * B + j] - a;
+        const float gij = c_con * d + gm * (float)((d > 0.f) - (d < 0.f)) * inv_n;
+        const float va = gs * (mu * sa * inv_n - gij), vg = gs * fabsf(d) * inv_n;
+        da = g == 0 ? va : da + va;
+        dg = g == 0 ? vg : dg + vg;
+      }
+    }
+    if (dA_out) dA_out[e] = da;
+    if (dG_out) dG_out[e] = dg;
+  }
+}
+
 // The classifier head's backward and the preparation of every site's S / dalterD / dgamma in ONE launch (two independent roles:
 // the first n_head workgroups are alignq_head::head_bwd_body's B + K, the rest the sites' gx each).
 struct HeadBwdArgs {
@@ -2046,6 +2082,16 @@ int launch_reduce_loss_multi(int S, void* const* ws, float* const* D, const floa
     hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3((kSlab4Floats + 255) / 256, cnt), 1024, 0, st, c, B, dim, mu, rho);
     RET_ON_ERR();
   }
+  return 0;
+}
+
+int launch_prep_groups(const float* D, const float* alterD, const float* gamma, int dim, const float* scal, float mu,
+                       const float* gscale, int B, int64_t F, int groups, float* S, int64_t s_gstride, float* dA, float* dG,
+                       hipStream_t st) {
+  const int gx = (dim * dim + 255) / 256;
+  hipLaunchKernelGGL(site_prep_groups_kernel, dim3(gx, groups), 256, 0, st, D, alterD, gamma, dim, scal, mu, gscale, B, 1.0f / (float)F,
+                     S, s_gstride, dA, dG, groups);
+  RET_ON_ERR();
   return 0;
 }
 

@@ -830,10 +830,15 @@ class BNSite1Fn(torch.autograd.Function):
         if g_loss is None:
             g_loss = torch.zeros((), dtype=torch.float32, device=dev)
         g_loss = L.dev_f32(g_loss, "loss grad")
-        # alterD and gamma have one shape: both gradients of all slices in ONE buffer, so that the slices are added by one launch
-        dAG = torch.empty(2, groups, *A.shape, dtype=torch.float32, device=dev) if A.shape == Gm.shape else None
-        dA = dAG[0] if dAG is not None else torch.empty(groups, *A.shape, dtype=torch.float32, device=dev)
-        dG = dAG[1] if dAG is not None else torch.empty(groups, *Gm.shape, dtype=torch.float32, device=dev)
+        # _S1_MASK_IN_KERNEL (the default): alignq_site1_groups_prep writes dalterD / dgamma already summed over the slices
+        summed = _S1_MASK_IN_KERNEL
+        dAG = None
+        if summed:
+            rA, rG = torch.empty_like(A), torch.empty_like(Gm)
+            dA = dG = None
+        else:
+            dA = torch.empty(groups, *A.shape, dtype=torch.float32, device=dev)
+            dG = torch.empty(groups, *Gm.shape, dtype=torch.float32, device=dev)
         from .ops import _ws
         s_bytes = lib.alignq_site_bwd_ws_bytes(B)
         S = _ws(s_bytes * groups, dev)
@@ -842,13 +847,9 @@ class BNSite1Fn(torch.autograd.Function):
         dbeta = torch.empty(C, dtype=torch.float32, device=dev) if has_b else None
         ws_bn = torch.empty(lib.alignq_bnq_ws_bytes(C, groups), dtype=torch.uint8, device=dev)
         if _S1_MASK_IN_KERNEL:
-            # one preparation launch (a "site" per slice: S, dalterD, dgamma) and one backward launch for all slices
-            Sg = [S[gi * s_bytes:(gi + 1) * s_bytes] for gi in range(groups)]
-            L.check(lib.alignq_site_prep_fused_multi(
-                groups, L.ptr_array([D[gi] for gi in range(groups)]), L.ptr_array([A] * groups), L.ptr_array([Gm] * groups),
-                L.ptr_array([scal[gi] for gi in range(groups)]), L.ptr(g_loss), L.i64_array([F] * groups), B, A.shape[0], mu,
-                L.ptr_array(Sg), L.ptr_array([dA[gi] for gi in range(groups)]), L.ptr_array([dG[gi] for gi in range(groups)]), st),
-                "alignq_site_prep_fused_multi")
+            # one preparation launch (S per slice; dalterD / dgamma summed over the slices in slice order) and one backward launch
+            L.check(lib.alignq_site1_groups_prep(L.ptr(D), L.ptr(A), L.ptr(Gm), A.shape[0], L.ptr(scal), mu, L.ptr(g_loss), B, F, groups,
+                                                 L.ptr(S), L.ptr(rA), L.ptr(rG), st), "alignq_site1_groups_prep")
             if _S1_BN_COLS:
                 # round 4: the site kernel leaves the batch-norm backward's sums per feature column; a small reduction, the
                 # finalisation and dz (in place) follow in the same entry: no pass of its own over dx and z
@@ -873,15 +874,12 @@ class BNSite1Fn(torch.autograd.Function):
             L.check(lib.alignq_bnq_bwd_dx(L.ptr(dx), L.ptr(z), L.ptr(ab), L.ptr(save), P, C, groups, L.ptr(dx), L.ptr(dgamma),
                                           L.ptr(dbeta), L.ptr(ws_bn), st), "alignq_bnq_bwd_dx")
 
-        def red(t):                                  # the slices' alterD / gamma gradients: one elementwise add, not a reduce
-            out = t[0]
-            for gi in range(1, groups):
-                out = out + t[gi]
-            return out
-        if dAG is not None and groups == 2:          # a + b either way: the same bits, one launch instead of two
-            both = dAG[:, 0] + dAG[:, 1]
-            rA, rG = both[0], both[1]
-        else:
+        if not summed:
+            def red(t):                              # the slices' alterD / gamma gradients added in slice order
+                out = t[0]
+                for gi in range(1, groups):
+                    out = out + t[gi]
+                return out
             rA, rG = red(dA), red(dG)
         return (dx, dgamma, dbeta, None, None, None, None, None, g_m if has_res else None, rA, rG, None, None,
                 None, None, None, None, None)

@@ -496,6 +496,12 @@ int alignq_site1_groups_fwd(const float* z, const float* ab, int C, int B, int64
                             float eps, const float* residual, int relu, float* y, float* stats, void* ws, void* stream);
 int alignq_site1_groups_reduce_loss(void* ws, int B, int64_t F, int groups, float* D, const float* alterD, const float* gamma,
                                     int dim, float mu, float rho, float* scal, void* stream);
+/* (round 4) the backward's preparation for all slices of ONE site in one launch: S regions as alignq_site_prep_fused_multi leaves
+ * them, and dalterD / dgamma [dim,dim] = the SUM over the slices in slice order - what autograd accumulates when the reference
+ * calls the module once per pass (dann_office/main.py:372,377), without the per-slice buffers and the launch that added them.   */
+int alignq_site1_groups_prep(const float* D, const float* alterD, const float* gamma, int dim, const float* scal, float mu,
+                             const float* dD_scale, int B, int64_t F, int groups, float* S, float* dalterD, float* dgamma,
+                             void* stream);
 int alignq_site1_groups_bwd(const float* g, const float* g2, const float* y, const float* S, const float* z, const float* ab, int C,
                             const float* stats, int B, int64_t F, int groups, float act_range, float eps, float* dx,
                             float* dres, void* stream);
