@@ -307,13 +307,15 @@ __global__ __launch_bounds__(kT) void corrl_reduce_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------- 4. S = (dG + dG^T) / F
+// S is stored PADDED: [BP = 32 ceil(B/32)][WP = the 32 NW RB columns the backward's waves cover], zero outside [B][B], so the backward's
+// K loop reads it without a condition (corrl_s_width)
 __global__ __launch_bounds__(kT) void corrl_sym_kernel(const float* __restrict__ dG, int B, float scale, float* __restrict__ S,
-                                                       const float* __restrict__ dscale = nullptr) {
+                                                       const float* __restrict__ dscale, int BP, int WP) {
   if (dscale) scale *= *dscale;                 // optional DEVICE scalar (the upstream gradient of a scalar loss)
-  const int64_t n = (int64_t)B * B;
-  for (int64_t e = (int64_t)blockIdx.x * kT + threadIdx.x; e < n; e += (int64_t)gridDim.x * kT) {
-    const int i = (int)(e / B), j = (int)(e - (int64_t)i * B);
-    S[e] = (dG[e] + dG[(int64_t)j * B + i]) * scale;
+  const int n = BP * WP;
+  for (int e = (int)blockIdx.x * kT + threadIdx.x; e < n; e += (int)gridDim.x * kT) {
+    const int i = e / WP, j = e - i * WP;
+    S[e] = (i < B && j < B) ? (dG[(int64_t)i * B + j] + dG[(int64_t)j * B + i]) * scale : 0.0f;
   }
 }
 
@@ -323,6 +325,10 @@ __global__ __launch_bounds__(kT) void corrl_sym_kernel(const float* __restrict__
 // PAIR (round 4, the ADMM site above 128 rows): both operands in one launch.  Pass 0 is the corr(x,x) part (it enters D with a minus
 // sign): dx = -dcorr_x is stored; pass 1 stages Th (the transform re-formed from x, read again from L2), contracts, projects with the
 // t statistics (stats [4][F]) and finishes dx = -dcorr_x + (g + dcorr_t) * dt/dx, g = the upstream gradient of x_q (or nullptr).
+// assemble: rows written per group of requests (x / g / -dcorr_x in flight together); measured 4 / 8 / 16 at 256, 512, 1024 rows x 16384
+#ifndef CORRL_AG
+#define CORRL_AG 16
+#endif
 template <int RB, int NW = 4, bool PAIR = false>
 __global__ __launch_bounds__(64 * NW) void corrl_bwd_kernel(const float* __restrict__ S, const float* __restrict__ x,
                                                        const float* __restrict__ stats, int B, int64_t F, float eps,
@@ -384,19 +390,40 @@ __global__ __launch_bounds__(64 * NW) void corrl_bwd_kernel(const float* __restr
       for (int q = 0; q < RB; q++)
 #pragma unroll
         for (int e = 0; e < 16; e++) acc[q][e] = 0.0f;
-#pragma unroll 2
-      for (int k0 = 0; k0 < BP; k0 += 2) {
-        const int kk = k0 + h;
-        const float b = Xs[kk * kLDb + l31];
-        float a[RB];
+      // software pipeline, two register sets: the S fragments and Vh values of the NEXT KD K steps are requested before this
+      // chunk's matrix instructions are issued (always: the last chunk re-reads the one before it), so an L2 round trip hides
+      // under 64 KD RB cycles of the matrix pipe.  No branch around the matrix instruction (a row block past the last one
+      // reads zero padding): under `if (block < nblk)` the accumulators travelled VGPR -> AGPR -> VGPR around EVERY instruction
+      {
+        constexpr int KD = RB <= 2 ? 2 : 1;      // K steps per request: four S loads in flight per wave and register set either way
+        static_assert(32 % (4 * KD) == 0, "two chunks of K steps must divide the 32-row blocks");
+        float a0[KD][RB], b0[KD], a1[KD][RB], b1[KD];
+        const float* Sw = S + (unsigned)(w * 32 + l31);
+        const float* Xw = Xs + h * kLDb + l31;
+        auto request = [&](int kb, float (&a)[KD][RB], float (&b)[KD]) {
 #pragma unroll
-        for (int q = 0; q < RB; q++) {
-          const int i = (w + NW * q) * 32 + l31;
-          a[q] = (i < B && kk < B) ? S[(int64_t)kk * B + i] : 0.0f;        // S symmetric: S[i][kk], read coalesced in i
+          for (int s2 = 0; s2 < KD; s2++) {
+            b[s2] = Xw[(kb + 2 * s2) * kLDb];
+#pragma unroll
+            for (int q = 0; q < RB; q++)
+              a[s2][q] = Sw[(unsigned)(kb + 2 * s2 + h) * (unsigned)(32 * NW * RB) + (unsigned)(NW * q * 32)];
+          }
+        };
+        auto contract = [&](const float (&a)[KD][RB], const float (&b)[KD]) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int s2 = 0; s2 < KD; s2++)
+#pragma unroll
+            for (int q = 0; q < RB; q++) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2][q], b[s2], acc[q], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        request(0, a0, b0);
+        for (int k0 = 0; k0 < BP; k0 += 4 * KD) {
+          request(k0 + 2 * KD, a1, b1);
+          contract(a0, b0);
+          request(min(k0 + 4 * KD, BP - 2 * KD), a0, b0);
+          contract(a1, b1);
         }
-#pragma unroll
-        for (int q = 0; q < RB; q++)
-          if (w + NW * q < nblk) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b, acc[q], 0, 0, 0);
       }
       // ---- column projections over ALL rows: sum_b dVh, sum_b dVh * vh ----------------------------------------------
       float sd = 0.f, sdx = 0.f;
@@ -439,24 +466,27 @@ __global__ __launch_bounds__(64 * NW) void corrl_bwd_kernel(const float* __restr
         for (int q = 0; q < RB; q++) {
           if (w + NW * q < nblk) {
 #pragma unroll
-            for (int e4 = 0; e4 < 4; e4++) {
-              // four rows at a time (their x / g loads in flight together, then the stores): all sixty-four at once, as the
-              // optimiser would have it, needs more registers than the kernel has
+            for (int grp = 0; grp < 16 / CORRL_AG; grp++) {
+              // CORRL_AG rows at a time (their x / g / -dcorr_x loads in flight together, then the stores)
               __builtin_amdgcn_sched_barrier(0);
-              const int row0 = (w + NW * q) * 32 + 8 * e4 + 4 * h;
-              float xv[4], gv[4], cx[4];
+              int rowb = (w + NW * q) * 32 + 4 * h;
+              // opaque: row * F is the same for every tile, and the optimiser otherwise keeps all 16 RB (x 2 for the pair) 64-bit
+              // row offsets in registers across the tile loop (256 + 246 of them at RB = 4; 134 spilled with 8 waves)
+              asm volatile("" : "+v"(rowb));
+              float xv[CORRL_AG], gv[CORRL_AG], cx[CORRL_AG];
               if (PAIR && op == 1) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                  const int64_t o = (int64_t)min(row0 + j, B - 1) * F + (fok ? f : 0);
+                for (int j = 0; j < CORRL_AG; j++) {
+                  const int e = CORRL_AG * grp + j, row = rowb + (e & 3) + 8 * (e >> 2);
+                  const int64_t o = (int64_t)min(row, B - 1) * F + (fok ? f : 0);
                   xv[j] = x[o];
                   gv[j] = gup ? gup[o] : 0.0f;
                   cx[j] = dx[o];                                  // pass 0 left -dcorr_x here
                 }
               }
 #pragma unroll
-              for (int j = 0; j < 4; j++) {
-                const int e = 4 * e4 + j, row = row0 + j;
+              for (int j = 0; j < CORRL_AG; j++) {
+                const int e = CORRL_AG * grp + j, row = rowb + (e & 3) + 8 * (e >> 2);
                 const float cv = (acc[q][e] - mean_d) * rr - Xs[row * kLDb + l31] * kdot;
                 if (row < B && fok) {
                   float* o = dx + (int64_t)row * F + f;
@@ -478,14 +508,31 @@ inline int n_pairs(int nb) { return nb * (nb + 1) / 2; }
 
 }  // namespace
 
-// K splits of the Gram launch: enough workgroups for the chip, never more than there are feature tiles
+// columns of the padded S image = 32 x the row blocks the backward's workgroup covers (launch_corrl_bwd's choice of <RB, NW>)
+int corrl_s_width(int B) {
+  const int nblk = (B + 31) / 32, rb = (nblk + 3) / 4;
+  return rb <= 2 ? 32 * 4 * 2 : (rb <= 4 ? 32 * 4 * 4 : 32 * 8 * 4);
+}
+size_t corrl_s_bytes(int B) { return (size_t)((B + 31) / 32 * 32) * corrl_s_width(B) * sizeof(float); }
+
+// K splits of the Gram launch.  512 workgroups are resident at once (two per CU: 66 KB of LDS each), a workgroup costs its
+// ceil(n_tiles / ks) tiles, the launch ceil(np ks / 512) rounds of them; every slab (64 KB written, read once by the reduction)
+// costs about 0.0064 of a tile round.  Rounds 3 took ceil(1024 / np) splits: 1044 workgroups of 9 tiles at 1024 x 16384, i.e. three
+// rounds of 9 where 14 splits make ONE round of 19.  ALIGNQ_CORRL_KS overrides (tuning aid).
 int corrl_ksplit(int B, int64_t F) {
   const int nb = (B + kBlk - 1) / kBlk, np = n_pairs(nb);
   const int64_t n_tiles = (F + kTF - 1) / kTF;
-  int64_t ks = (1024 + np - 1) / np;
-  if (ks > n_tiles) ks = n_tiles;
-  if (ks > 512) ks = 512;
-  return (int)(ks < 1 ? 1 : ks);
+  static const int forced = alignq_env::env_int("ALIGNQ_CORRL_KS", 0, 0, 512);
+  const int kmax = (int)(n_tiles < 512 ? n_tiles : 512);
+  if (forced > 0) return forced < kmax ? forced : kmax;
+  int best = 1;
+  double best_cost = 1e30;
+  for (int ks = 1; ks <= kmax; ks++) {
+    const int64_t rounds = ((int64_t)np * ks + 511) / 512, per_wg = (n_tiles + ks - 1) / ks;
+    const double cost = (double)(rounds * per_wg) + 0.0064 * np * ks;
+    if (cost < best_cost) { best_cost = cost; best = ks; }
+  }
+  return best;
 }
 
 size_t corrl_ws_bytes(int B, int64_t F) {
@@ -520,11 +567,11 @@ int launch_sitel_fwd(const float* x, int B, int64_t F, int k, float r, float eps
 int launch_corrl_bwd(const float* dG, const float* x, const float* stats, int B, int64_t F, float eps, float* dx, float* S,
                      hipStream_t st, bool pair, const float* gup, float r, const float* dG_scale) {
   const int aligned = ((F & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) ? 1 : 0;
-  const int64_t n = (int64_t)B * B;
-  int gs = (int)((n + kT - 1) / kT);
-  if (gs > 2048) gs = 2048;
-  hipLaunchKernelGGL(corrl_sym_kernel, dim3(gs), dim3(kT), 0, st, dG, B, 1.0f / (float)F, S, dG_scale);
   const int nblk = (B + 31) / 32, rb = (nblk + 3) / 4;
+  const int BP = nblk * 32, WP = corrl_s_width(B);
+  int gs = (BP * WP + kT - 1) / kT;
+  if (gs > 2048) gs = 2048;
+  hipLaunchKernelGGL(corrl_sym_kernel, dim3(gs), dim3(kT), 0, st, dG, B, 1.0f / (float)F, S, dG_scale, BP, WP);
   const int n_tiles = (int)((F + kTFb - 1) / kTFb);
   const size_t lds = ((size_t)nblk * 32 * kLDb + 8 * 2 * 32 + 2 * 32) * sizeof(float);
   int grid = n_tiles < 2048 ? n_tiles : 2048;

@@ -184,6 +184,8 @@ int launch_reduce_any(const Geom& g, const float* ws_c, float* ws_mut, int B, in
 // ---- corr_large_kernels.hip: corr(x, x) for 128 < B <= ALIGNQ_MAX_CORR_BATCH (blocked Gram, exact fp32) ------------------
 size_t corrl_ws_bytes(int B, int64_t F);
 int launch_corrl_fwd(const float* x, int B, int64_t F, float eps, float* G, float* stats, float* ws, hipStream_t st);
+int corrl_s_width(int B);
+size_t corrl_s_bytes(int B);      // the backward's zero-padded S image
 int launch_corrl_bwd(const float* dG, const float* x, const float* stats, int B, int64_t F, float eps, float* dx, float* S,
                      hipStream_t st, bool pair = false, const float* gup = nullptr, float r = 1.0f, const float* dG_scale = nullptr);
 // the ADMM site for 128 < B <= ALIGNQ_MAX_CORR_BATCH on the blocked Gram (stats [4][F]; ws: corrl_ws_bytes)

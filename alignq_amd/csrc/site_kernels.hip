@@ -507,7 +507,7 @@ size_t alignq_site_ws_bytes(int B, int64_t F) {
 // the S buffer of the backward: [B,B] fp32 (sym(dD) * scale / F) in its first 64 KB, followed at byte offset 65536 by the
 // bf16 hi / lo fragment image of the same matrix that the prep kernels leave for the B in (64,128] backward (64 KB)
 size_t alignq_site_bwd_ws_bytes(int B) {
-  if (B > ALIGNQ_MAX_BATCH) return (size_t)B * B * sizeof(float);     // alignq_corr_bwd, large batch: S only
+  if (B > ALIGNQ_MAX_BATCH) return corrl_s_bytes(B);     // large batch: S only, zero-padded to the backward's tiling (<= 4 MB)
   return (size_t)2 * 128 * 128 * sizeof(float);
 }
 
@@ -577,7 +577,7 @@ int alignq_site_fwd(const float* x, int B, int64_t F, int k, float act_range, fl
 int alignq_site_bwd(const float* g, const float* dD, const float* dD_scale, const float* x, const float* stats,
                     int B, int64_t F, float act_range, float eps, float* dx, void* ws, void* stream) {
   if (!dD || !x || !stats || !dx || !ws) return ALIGNQ_EINVAL;
-  if (large_corr(B, F))         // ws: alignq_site_bwd_ws_bytes(B) = B*B floats (S)
+  if (large_corr(B, F))         // ws: alignq_site_bwd_ws_bytes(B) (the padded S)
     return launch_corrl_bwd(dD, x, stats, B, F, eps, dx, (float*)ws, (hipStream_t)stream, true, g, act_range, dD_scale);
   if (bad_shape(B, F)) return F <= 0 ? ALIGNQ_EINVAL : ALIGNQ_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;

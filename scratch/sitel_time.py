@@ -4,7 +4,7 @@ import bench
 from alignq_amd import _lib as L
 lib = L.load(); st = L.stream_ptr(); p = L.ptr
 dev = torch.device('cuda:0')
-for B, F in ((256, 16384),):
+for B, F in ((256, 16384), (512, 16384), (1024, 16384)):
     x = torch.randn(B, F, device=dev); g = torch.randn(B, F, device=dev) * 0.01
     xq, dx = torch.empty_like(x), torch.empty_like(x)
     D = torch.empty(B, B, device=dev); stats = torch.empty(4, F, device=dev)

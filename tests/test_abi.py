@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
     # above 128 rows only corr(x, x) exists (blocked Gram: 3 block pairs x 1 K split of 128 x 128 floats); 1024 rows is the end
     assert lib.alignq_site_ws_bytes(129, 64) == 3 * 128 * 128 * 4
     assert lib.alignq_site_ws_bytes(1025, 64) == 0
-    assert lib.alignq_site_bwd_ws_bytes(256) == 256 * 256 * 4 and lib.alignq_site_bwd_ws_bytes(128) == 2 * 128 * 128 * 4
+    assert lib.alignq_site_bwd_ws_bytes(256) == 256 * 256 * 4 and lib.alignq_site_bwd_ws_bytes(300) == 320 * 512 * 4 and lib.alignq_site_bwd_ws_bytes(128) == 2 * 128 * 128 * 4
     assert lib.alignq_bnq_ws_bytes(64, 1) == 512 * 64 * 16 + 2 * 64 * 4
     assert lib.alignq_bnq_ws_bytes(64, 2) == 2 * (512 * 64 * 16 + 2 * 64 * 4) and lib.alignq_bnq_ws_bytes(64, 9) == 0
     assert lib.alignq_site_bwd_ws_bytes(128) == 2 * 128 * 128 * 4        # fp32 S + its bf16 hi/lo fragment image
