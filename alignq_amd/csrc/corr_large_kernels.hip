@@ -65,22 +65,27 @@ __device__ __forceinline__ float4 ldq(const float* __restrict__ x, int64_t off, 
 }
 
 // ---------------------------------------------------------------------------------------------- 1. column statistics
-// grid = feature tiles of 64; thread = (column quad c, row group rg of 16); rows rg, rg+16, ...
+// grid = feature tiles of kTFs = 32 (two workgroups per CU at F = 16384; 64-feature tiles with four rows in flight had 16 KB per CU on
+// request: 19 us for 2 x 16 MB at 256 rows); thread = (column quad c, row group rg of 32); rows rg, rg + 32, ...: eight in flight
+constexpr int kTFs = 32;
+constexpr int kRGs = kT / (kTFs / 4);      // 32 row groups
+constexpr int kRows = 8;                   // rows in flight per thread
+
 __global__ __launch_bounds__(kT) void corrl_stats_kernel(const float* __restrict__ x, int B, int64_t F, float eps,
                                                          float* __restrict__ stats, int aligned) {
-  __shared__ double red[16][kTF][2];
-  const int tid = threadIdx.x, c = tid & 15, rg = tid >> 4;
-  const int col = blockIdx.x * kTF + 4 * c;
+  __shared__ double red[kRGs][kTFs][2];
+  const int tid = threadIdx.x, c = tid & (kTFs / 4 - 1), rg = tid / (kTFs / 4);
+  const int col = blockIdx.x * kTFs + 4 * c;
   double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
-  for (int r0 = rg; r0 < B; r0 += 64) {       // four rows in flight
-    float4 v[4];
+  for (int r0 = rg; r0 < B; r0 += kRGs * kRows) {
+    float4 v[kRows];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int r = r0 + 16 * u;
+    for (int u = 0; u < kRows; u++) {
+      const int r = r0 + kRGs * u;
       v[u] = ldq(x, (int64_t)r * F + col, col, F, r < B, aligned);
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < kRows; u++) {
       const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
       for (int j = 0; j < 4; j++) { s[j] += (double)e[j]; q[j] += (double)e[j] * (double)e[j]; }
@@ -89,10 +94,10 @@ __global__ __launch_bounds__(kT) void corrl_stats_kernel(const float* __restrict
 #pragma unroll
   for (int j = 0; j < 4; j++) { red[rg][4 * c + j][0] = s[j]; red[rg][4 * c + j][1] = q[j]; }
   __syncthreads();
-  if (tid < kTF) {
+  if (tid < kTFs) {
     double a = 0, b = 0;
-    for (int g = 0; g < 16; g++) { a += red[g][tid][0]; b += red[g][tid][1]; }     // fixed order
-    const int64_t f = (int64_t)blockIdx.x * kTF + tid;
+    for (int g = 0; g < kRGs; g++) { a += red[g][tid][0]; b += red[g][tid][1]; }     // fixed order
+    const int64_t f = (int64_t)blockIdx.x * kTFs + tid;
     if (f < F) {
       const double mean = a / (double)B;
       double var = (b - a * mean) / (double)(B - 1);
@@ -108,25 +113,25 @@ __global__ __launch_bounds__(kT) void corrl_stats_kernel(const float* __restrict
 // alignq_act_quant_fwd) whose pre-round transform t is accumulated like x.  stats: [4][F] = mean_x, 1/(std_x+eps), mean_t, 1/(std_t+eps).
 __global__ __launch_bounds__(kT) void sitel_stats_kernel(const float* __restrict__ x, int B, int64_t F, int k, float r, float eps,
                                                          float* __restrict__ xq, float* __restrict__ stats, int aligned) {
-  __shared__ double red[16][kTF][4];
+  __shared__ double red[kRGs][kTFs][4];
   __shared__ __attribute__((aligned(16))) float nerf_lds[ALIGNQ_NERF_LDS_FLOATS];
   nerf_tab_load(nerf_lds);
   __syncthreads();
   const NerfTab tab = nerf_tab(nerf_lds);
   const Levels nlev = make_levels(k, fabsf(r) <= 8.0f);
-  const int tid = threadIdx.x, c = tid & 15, rg = tid >> 4;
-  const int col = blockIdx.x * kTF + 4 * c;
+  const int tid = threadIdx.x, c = tid & (kTFs / 4 - 1), rg = tid / (kTFs / 4);
+  const int col = blockIdx.x * kTFs + 4 * c;
   double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0}, st[4] = {0, 0, 0, 0}, qt[4] = {0, 0, 0, 0};
-  for (int r0 = rg; r0 < B; r0 += 64) {       // four rows in flight
-    float4 v[4];
+  for (int r0 = rg; r0 < B; r0 += kRGs * kRows) {
+    float4 v[kRows];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int rr = r0 + 16 * u;
+    for (int u = 0; u < kRows; u++) {
+      const int rr = r0 + kRGs * u;
       v[u] = ldq(x, (int64_t)rr * F + col, col, F, rr < B, aligned);
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int rr = r0 + 16 * u;
+    for (int u = 0; u < kRows; u++) {
+      const int rr = r0 + kRGs * u;
       const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
       float o[4];
 #pragma unroll
@@ -156,11 +161,11 @@ __global__ __launch_bounds__(kT) void sitel_stats_kernel(const float* __restrict
     red[rg][4 * c + j][2] = st[j]; red[rg][4 * c + j][3] = qt[j];
   }
   __syncthreads();
-  if (tid < 2 * kTF) {
-    const int cc = tid & (kTF - 1), which = tid >> 6;          // which: 0 = x, 1 = t
+  if (tid < 2 * kTFs) {
+    const int cc = tid & (kTFs - 1), which = tid / kTFs;          // which: 0 = x, 1 = t
     double a = 0, b = 0;
-    for (int g = 0; g < 16; g++) { a += red[g][cc][2 * which]; b += red[g][cc][2 * which + 1]; }     // fixed order
-    const int64_t f = (int64_t)blockIdx.x * kTF + cc;
+    for (int g = 0; g < kRGs; g++) { a += red[g][cc][2 * which]; b += red[g][cc][2 * which + 1]; }     // fixed order
+    const int64_t f = (int64_t)blockIdx.x * kTFs + cc;
     if (f < F) {
       const double mean = a / (double)B;
       double var = (b - a * mean) / (double)(B - 1);
@@ -293,6 +298,13 @@ __global__ __launch_bounds__(kT) void corrl_reduce_kernel(const float* __restric
   const float* p = slabs + (int64_t)blockIdx.y * ksplit * (kBlk * kBlk) + e;
   float s = 0.f;
   int k = 0;
+  for (; k + 16 <= ksplit; k += 16) {        // sixteen slabs in flight per thread (192 workgroups per launch at two row blocks); the
+    float a[16];                              // additions stay in slab order
+#pragma unroll
+    for (int u = 0; u < 16; u++) a[u] = p[(int64_t)(k + u) * (kBlk * kBlk)];
+#pragma unroll
+    for (int u = 0; u < 16; u++) s += a[u];
+  }
   for (; k + 4 <= ksplit; k += 4) {
     const float a0 = p[(int64_t)(k + 0) * (kBlk * kBlk)], a1 = p[(int64_t)(k + 1) * (kBlk * kBlk)];
     const float a2 = p[(int64_t)(k + 2) * (kBlk * kBlk)], a3 = p[(int64_t)(k + 3) * (kBlk * kBlk)];
@@ -544,7 +556,7 @@ int launch_corrl_fwd(const float* x, int B, int64_t F, float eps, float* G, floa
   const int aligned = ((F & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) ? 1 : 0;
   const int nb = (B + kBlk - 1) / kBlk, np = n_pairs(nb), ks = corrl_ksplit(B, F);
   const int n_tiles = (int)((F + kTF - 1) / kTF);
-  hipLaunchKernelGGL(corrl_stats_kernel, dim3(n_tiles), dim3(kT), 0, st, x, B, F, eps, stats, aligned);
+  hipLaunchKernelGGL(corrl_stats_kernel, dim3((unsigned)((F + kTFs - 1) / kTFs)), dim3(kT), 0, st, x, B, F, eps, stats, aligned);
   hipLaunchKernelGGL((corrl_gram_kernel<false>), dim3(ks, np), dim3(kT), 0, st, x, (const float*)stats, B, F, ws, n_tiles, nb, aligned, 1.0f);
   hipLaunchKernelGGL(corrl_reduce_kernel, dim3(kBlk * kBlk / kT, np), dim3(kT), 0, st, (const float*)ws, ks, nb, B,
                      1.0f / (float)F, G);
@@ -557,7 +569,7 @@ int launch_sitel_fwd(const float* x, int B, int64_t F, int k, float r, float eps
   const int aligned = ((F & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(xq) & 15) == 0) ? 1 : 0;
   const int nb = (B + kBlk - 1) / kBlk, np = n_pairs(nb), ks = corrl_ksplit(B, F);
   const int n_tiles = (int)((F + kTF - 1) / kTF);
-  hipLaunchKernelGGL(sitel_stats_kernel, dim3(n_tiles), dim3(kT), 0, st, x, B, F, k, r, eps, xq, stats, aligned);
+  hipLaunchKernelGGL(sitel_stats_kernel, dim3((unsigned)((F + kTFs - 1) / kTFs)), dim3(kT), 0, st, x, B, F, k, r, eps, xq, stats, aligned);
   hipLaunchKernelGGL((corrl_gram_kernel<true>), dim3(ks, np), dim3(kT), 0, st, x, (const float*)stats, B, F, ws, n_tiles, nb, aligned, r);
   hipLaunchKernelGGL(corrl_reduce_kernel, dim3(kBlk * kBlk / kT, np), dim3(kT), 0, st, (const float*)ws, ks, nb, B,
                      1.0f / (float)F, D);
