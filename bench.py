@@ -802,7 +802,7 @@ _CFG_BYTES = {"resnet20": 128 * 200704 * 20 + 0.27e6 * 28, "resnet20_cdf": 128 *
               "resnet50_dann": 2 * 28 * 9608704 * 20 + 2 * 23.5e6 * 20 + 23.5e6 * 8}
 
 
-def other_configs(dev, a, steps=30):
+def other_configs(dev, a, steps=30, only=None):
     """BASELINE.json's other configurations through the same code, one GPU's share each, short captured runs (the headline
     line above stays configs[1]): configs[2] ResNet-20 2W/2A (batch 1024 / 8 GPUs = 128 per GPU), configs[3] ResNet-56 4W/4A
     (512 / 4 = 128), configs[4] ResNet-50-DANN Office-31 8W/8A (224 / 8 = 28, source + target pass).  Iteration order of the
@@ -817,6 +817,8 @@ def other_configs(dev, a, steps=30):
     gen = torch.Generator().manual_seed(1)
     for name, kind, bits, batch in (("resnet20_cdf_only_8w8a_b128", "resnet20_cdf", 8, 128), ("resnet20_2w2a_b128", "resnet20", 2, 128),
                                     ("resnet56_4w4a_b128", "resnet56", 4, 128), ("resnet50_dann_8w8a_b28", "resnet50_dann", 8, 28)):
+        if only is not None and name not in only:
+            continue
         try:
             config.args.bitW = config.args.abitW = bits
             config.args.train_batch_size = config.args.eval_batch_size = batch
