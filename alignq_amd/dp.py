@@ -445,3 +445,26 @@ def global_corr(x, eps=0.0, group=None, local_corr=None, grad_scale=None):
     Xr = _FeatureShard.apply(x2, group, world if grad_scale is None else grad_scale)
     Gr = local_corr(Xr) * (1.0 / world)          # (F_r / F) with equal shards
     return _SumAcrossRanks.apply(Gr, group)
+
+
+def global_site_D(x, k, act_range, eps=0.0, group=None, local_site=None, grad_scale=None):
+    """D = corr(t, t) - corr(x, x) of the GLOBAL batch from ONE exchange of x (round 4; global_corr(t) - global_corr(x) moved
+    both tensors: two all-to-alls and two all-reduces each way).  The transform t = r (2 Phi(x) - 1) is elementwise, so the
+    feature shard re-forms it from the exchanged x; local_site(X) -> [B_g, B_g] is the shard's pair correlation (default
+    ops.SiteDFn: the fused site kernels up to 128 rows, the pair kernels of the blocked Gram up to ALIGNQ_MAX_CORR_BATCH), the
+    all-reduce sums the shards' (F_r / F) D_r.  grad_scale as in global_corr.  Reference: model/quantization.py:109-123 applied to
+    the concatenated batch."""
+    world = dist.get_world_size(group)
+    x2 = x.reshape(x.shape[0], -1)
+    Bg = x2.shape[0] * world
+    if local_site is None:
+        from . import _lib as L
+        from . import ops
+        if Bg > L.MAX_CORR_BATCH:
+            raise RuntimeError(f"global corr: global batch {Bg} exceeds the {L.MAX_CORR_BATCH} rows alignq_site_fwd takes; "
+                               "use the per-rank semantics (SURVEY.md §8e) for larger global batches")
+        local_site = lambda X: ops.SiteDFn.apply(X, int(k), float(act_range), float(eps))      # noqa: E731
+    Xr = _FeatureShard.apply(x2, group, world if grad_scale is None else grad_scale)
+    Dr = local_site(Xr) * (1.0 / world)          # (F_r / F) with equal shards
+    return _SumAcrossRanks.apply(Dr, group)
+

@@ -459,6 +459,40 @@ class SiteLargeFn(torch.autograd.Function):
         return dx, None, None, None
 
 
+class SiteDFn(torch.autograd.Function):
+    """D = corr(t, t) - corr(x, x) alone (t = the pre-round transform of x; model/quantization.py:109-122 without the x_q
+    output): alignq_site_fwd with xq = NULL, alignq_site_bwd with no upstream x_q gradient, any 2 <= B <= ALIGNQ_MAX_CORR_BATCH.
+    The shard kernel of dp.global_site_D (round 4): the exact-global correlation pair from ONE exchange of x."""
+
+    @staticmethod
+    def forward(ctx, x, k, act_range, eps):
+        x = L.dense_f32(x, "activation")
+        B, F = _as_bf(x)
+        _check_batch(B, "site", L.MAX_CORR_BATCH)
+        lib = L.load()
+        D = torch.empty(B, B, dtype=torch.float32, device=x.device)
+        stats = torch.empty(4, F, dtype=torch.float32, device=x.device)
+        ws = _ws(lib.alignq_site_ws_bytes(B, F), x.device)
+        L.check(lib.alignq_site_fwd(L.ptr(x), B, F, int(k), float(act_range), float(eps), None, L.ptr(D), L.ptr(stats), L.ptr(ws),
+                                    L.stream_ptr()), "alignq_site_fwd")
+        ctx.save_for_backward(x, stats)
+        ctx.cfg = (float(act_range), float(eps))
+        return D
+
+    @staticmethod
+    def backward(ctx, g_D):
+        x, stats = ctx.saved_tensors
+        act_range, eps = ctx.cfg
+        B, F = _as_bf(x)
+        lib = L.load()
+        g_D = L.dev_f32(g_D, "grad of D")
+        dx = torch.empty_like(x)
+        ws = _ws(lib.alignq_site_bwd_ws_bytes(B), x.device)
+        L.check(lib.alignq_site_bwd(None, L.ptr(g_D), None, L.ptr(x), L.ptr(stats), B, F, act_range, eps, L.ptr(dx), L.ptr(ws),
+                                    L.stream_ptr()), "alignq_site_bwd")
+        return dx, None, None, None
+
+
 def site_unfused(x, admm, k, act_range, eps, formula):
     """The ADMM activation site for 128 < B <= ALIGNQ_MAX_CORR_BATCH (the fused site kernels keep all rows of a feature tile on
     chip and stop at 128): (x_q, D) from SiteLargeFn - the pair kernels on the blocked Gram - and loss = ADMM(D); the CDF-only

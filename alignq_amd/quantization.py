@@ -114,14 +114,19 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
             gc = getattr(config.args, "global_corr", None)       # process-wide switch (tests)
         if config.args.method == "ours" and a_bit < 32 and gc is not None:
             # opt-in exact-global-batch correlation (dp.attach(..., global_corr=True)): D is the
-            # [B_g, B_g] matrix of the concatenated batch, identical on every rank; unfused (x is read three times)
+            # [B_g, B_g] matrix of the concatenated batch, identical on every rank.  ADMM tree (round 4): x is exchanged ONCE, the
+            # feature shard re-forms the transform and leaves D_r from the pair kernels (dp.global_site_D); the CDF-only formula
+            # keeps the two-correlation composition
             from . import dp
             grp = None if gc is True else gc
             admm = mod.opt
             r_ = config.args.act_range
             xq = ops.ActQuantFn.apply(x, a_bit, r_, formula)
-            t = ops.ActQuantFn.apply(x, 32, r_, formula)            # k == 32 writes the pre-round transform itself
-            D = dp.global_corr(t, eps, grp) - dp.global_corr(x, eps, grp)
+            if formula == L.FORMULA_ADMM and x.is_cuda:
+                D = dp.global_site_D(x, a_bit, r_, eps, grp)
+            else:
+                t = ops.ActQuantFn.apply(x, 32, r_, formula)        # k == 32 writes the pre-round transform itself
+                D = dp.global_corr(t, eps, grp) - dp.global_corr(x, eps, grp)
             return xq, admm(D)
         if config.args.method == "ours" and a_bit < 32 and x.shape[0] > L.MAX_BATCH:
             # above the 128 rows the fused kernels hold on chip: the site composed from the blocked correlation

@@ -276,6 +276,55 @@ def test_global_corr_equals_single_process_corr_on_the_concatenated_batch(b):
         assert np.array_equal(out[(0, eps)]["G"], out[(1, eps)]["G"])          # identical on every rank
 
 
+def _torch_site_D(V, r, eps):
+    """the shard's pair correlation in plain torch (oracle/torch_ref.py: the reference's lines restated)"""
+    from oracle import torch_ref as R
+    t = r * (2.0 * 0.5 * (1.0 + torch.erf(V / 2.0 ** 0.5)) - 1.0)          # model/quantization.py:49-59 with m = 0, s = 1
+    return R.corr(t, t, eps) - R.corr(V, V, eps)
+
+
+def _gsite_worker(rank, world, port, out, b=8):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from alignq_amd import dp
+        g = torch.Generator().manual_seed(11)
+        X = torch.randn(world * b, 6, 4, 4, generator=g) * 0.9 + 0.2
+        dD = torch.randn(world * b, world * b, generator=g)
+        for eps in (0.0, 1e-5):
+            x = X[rank * b:(rank + 1) * b].clone().requires_grad_(True)
+            D = dp.global_site_D(x, 4, 2.0, eps, None, local_site=lambda V: _torch_site_D(V, 2.0, eps), grad_scale=1.0)
+            (D * dD).sum().backward()
+            out[(rank, eps)] = dict(D=D.detach().numpy().copy(), dx=x.grad.numpy().copy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_global_site_D_from_one_exchange_equals_the_single_process_pair(tmp_path):
+    """Round 4: D = corr(t, t) - corr(x, x) of the global batch from ONE exchange of x (dp.global_site_D: the feature shard
+    re-forms the elementwise transform): value and the gradient returning to every rank's rows equal the single-process pair on
+    the concatenated batch (model/quantization.py:109-123; <= 1e-5), identical on every rank."""
+    world, b = 2, 8
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_gsite_worker, args=(world, port, out, b), nprocs=world, join=True)
+    g = torch.Generator().manual_seed(11)
+    X = torch.randn(world * b, 6, 4, 4, generator=g) * 0.9 + 0.2
+    dD = torch.randn(world * b, world * b, generator=g)
+    for eps in (0.0, 1e-5):
+        Xi = X.clone().requires_grad_(True)
+        Dref = _torch_site_D(Xi.view(world * b, -1), 2.0, eps)
+        (Dref * dD).sum().backward()
+        for rank in range(world):
+            o = out[(rank, eps)]
+            np.testing.assert_allclose(o["D"], Dref.detach().numpy(), atol=1e-5)
+            np.testing.assert_allclose(o["dx"], Xi.grad[rank * b:(rank + 1) * b].numpy(), atol=1e-5, rtol=1e-4)
+        assert np.array_equal(out[(0, eps)]["D"], out[(1, eps)]["D"])
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # The phased pack | reduce | unpack interface as a CAPTURED TrainStep drives it (alignq_amd/train_step.py: capture() bakes
 # pack() into the first graph and unpack() into the second, __call__ replays them around an eager reduce(), and an off-shape

@@ -393,6 +393,7 @@ def test_global_corr_on_rccl_matches_the_fused_site(dev, pg):
     world size 1 equals ops.CorrFn, and a site run with config.args.global_corr gives the fused site's x_q (bit for bit),
     D, loss and dx."""
     import alignq_amd.cdf_alignment_admm as A
+    from alignq_amd import _lib as L
     from alignq_amd import config, dp, ops
     torch.manual_seed(0)
     x0 = torch.randn(64, 8, 8, 8, device=dev) * 1.2
@@ -429,6 +430,22 @@ def test_global_corr_on_rccl_matches_the_fused_site(dev, pg):
     # above 128 rows the shard SYRK is the blocked Gram (round 3): same value as the stand-alone corr
     xl = torch.randn(192, 640, device=dev)
     np.testing.assert_allclose(npy(dp.global_corr(xl, 0.0)), npy(ops.CorrFn.apply(xl, 0.0)), atol=1e-6)
+    # round 4: the pair from ONE exchange of x (dp.global_site_D on ops.SiteDFn) against the two-correlation composition and
+    # the oracle, in every batch regime of the site kernels (<= 32, <= 64, <= 128 rows, blocked Gram above), x_q not written
+    for Bq, Fq, eps in ((28, 512, 1e-5), (48, 320, 0.0), (128, 1024, 0.0), (192, 640, 1e-5)):
+        x1 = (torch.randn(Bq, Fq, device=dev) * 1.1).requires_grad_(True)
+        dD = torch.randn(Bq, Bq, device=dev) * 0.1
+        D1 = dp.global_site_D(x1, 4, 2.0, eps)
+        D1.backward(dD)
+        x2 = x1.detach().clone().requires_grad_(True)
+        t2 = ops.ActQuantFn.apply(x2, 32, 2.0, L.FORMULA_ADMM)
+        D2 = dp.global_corr(t2, eps) - dp.global_corr(x2, eps)
+        D2.backward(dD)
+        np.testing.assert_allclose(npy(D1), npy(D2), atol=TOL)
+        np.testing.assert_allclose(npy(x1.grad), npy(x2.grad), atol=TOL, rtol=1e-4)
+        oD = O.site_fwd(npy(x1), 4, 2.0, eps)[1]
+        np.testing.assert_allclose(npy(D1), oD, atol=TOL)
+        np.testing.assert_allclose(npy(x1.grad), O.site_bwd(np.zeros((Bq, Fq), np.float32), npy(dD), npy(x1), 2.0, eps), atol=TOL, rtol=1e-4)
 
 
 def test_captured_dp_step_keeps_its_bucket_across_a_short_batch(dev, pg):
