@@ -134,7 +134,9 @@ int alignq_site_reduce_loss(void* ws, int B, int64_t F, float* D, const float* a
  *   alignq_site_bwd       : explicit upstream gradient dD [B,B] w.r.t. D;
  *   alignq_site_bwd_fused : dD is the ADMM-loss gradient, rebuilt from (D, alterD, gamma, scal of
  *                           alignq_site_reduce_loss); also writes the parameter gradients of the loss,
- *                           dalterD / dgamma [dim,dim] (already multiplied by dD_scale; may be NULL).          */
+ *                           dalterD / dgamma [dim,dim] (already multiplied by dD_scale; may be NULL).
+ * alignq_site_bwd_ws_bytes: B <= ALIGNQ_MAX_BATCH: 128 KB (fp32 S + its bf16 image); above (alignq_site_bwd / alignq_corr_bwd on the
+ * blocked form): S zero-padded to the backward's tiling, [32 ceil(B/32)][256 | 512 | 1024] floats (<= 4 MB), always ask.       */
 size_t alignq_site_bwd_ws_bytes(int B);
 /* second launch of both forms alone: S = the buffer (alignq_site_bwd_ws_bytes(B) bytes) the first launch (site_prep_kernel:
  * alignq_site_prep_fused[_multi], or the first half of alignq_site_bwd / _bwd_fused) leaves: the prepared, scaled,
