@@ -13,7 +13,7 @@ SO_PATH = os.environ.get("ALIGNQ_SO") or os.path.join(_HERE, "lib", "libalignq_h
 FORMULA_ADMM, FORMULA_CDF = 0, 1
 MAX_BATCH = 128            # rows the FUSED site kernels hold on chip (ALIGNQ_MAX_BATCH)
 MAX_CORR_BATCH = 1024      # rows alignq_corr_fwd / _bwd take (ALIGNQ_MAX_CORR_BATCH: blocked Gram above 128)
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _c = ctypes
 _vp, _i, _i64, _f, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_size_t
@@ -70,6 +70,8 @@ SIGNATURES = {
     "alignq_admm_ws_bytes": (_sz, [_i]),
     "alignq_admm_loss": (_i, [_vp, _i, _vp, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "alignq_admm_update": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _vp]),
+    "alignq_admm_update_ws_bytes": (_sz, [_i, _i]),
+    "alignq_admm_update_ws": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp]),
     "alignq_sgd_step": (_i, [_vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _i, _vp]),
     "alignq_sgd_grad_approx": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _f, _f, _vp]),
     "alignq_site_reduce_loss_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp]),

@@ -130,6 +130,93 @@ __global__ __launch_bounds__(kBig) void admm_update_kernel(AChunk c, int b, int 
   admm_update_site(c.D[blockIdx.x], c.A[blockIdx.x], c.G[blockIdx.x], b, dim, mu, rho, sm);
 }
 
+// dim > 128 (the exact-global correlation's ADMM(dim = B_g)): one workgroup per site walks dim^2 elements with
+// one load in flight per thread - 210 us at dim = 512, 1.0 ms at 1024 for 21 sites (as long as a whole ResNet-20 step).  Two
+// launches over kUpdBlocks workgroups per site instead: partial sums of |V|_F^2, then every workgroup adds the site's partials
+// in a fixed order and updates its slice.
+constexpr int kUpdBlocks = 64;
+constexpr int kUpdThreads = 256;
+constexpr int kUpdIn = 8;                  // elements in flight per thread
+
+__global__ __launch_bounds__(kUpdThreads) void admm_update_partial_kernel(AChunk c, int b, int dim, float rho, double* __restrict__ parts) {
+  __shared__ double sm[kUpdThreads / 64];
+  const float* __restrict__ D = c.D[blockIdx.y];
+  const float* __restrict__ G = c.G[blockIdx.y];
+  const int full = dim * dim;
+  const float inv_rho = 1.0f / rho;
+  double ss = 0;
+  for (int e0 = (int)blockIdx.x * kUpdThreads + threadIdx.x; e0 < full; e0 += kUpdBlocks * kUpdThreads * kUpdIn) {
+    float dv[kUpdIn], gv[kUpdIn];
+#pragma unroll
+    for (int u = 0; u < kUpdIn; u++) {       // clamped, unconditional loads: all in flight together
+      const int e = e0 + u * kUpdBlocks * kUpdThreads;
+      const int ec = e < full ? e : full - 1;
+      const int i = ec / dim, j = ec - i * dim;
+      const bool in = i < b && j < b;
+      const float d = D[in ? i * b + j : 0];
+      dv[u] = in ? d : 0.0f;
+      gv[u] = G[ec];
+    }
+#pragma unroll
+    for (int u = 0; u < kUpdIn; u++) {
+      if (e0 + u * kUpdBlocks * kUpdThreads < full) {
+        const float v = dv[u] + inv_rho * gv[u];
+        ss += (double)v * (double)v;
+      }
+    }
+  }
+  ss = wave_sum_d(ss);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0;
+    for (int w = 0; w < kUpdThreads / 64; w++) t += sm[w];
+    parts[(size_t)blockIdx.y * kUpdBlocks + blockIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(kUpdThreads) void admm_update_apply_kernel(AChunk c, int b, int dim, float mu, float rho,
+                                                                      const double* __restrict__ parts) {
+  __shared__ double sm[kUpdBlocks];
+  __shared__ float shrink_s;
+  const float* __restrict__ D = c.D[blockIdx.y];
+  float* __restrict__ A = c.A[blockIdx.y];
+  float* __restrict__ G = c.G[blockIdx.y];
+  if (threadIdx.x < kUpdBlocks) sm[threadIdx.x] = parts[(size_t)blockIdx.y * kUpdBlocks + threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ss = 0;
+    for (int k = 0; k < kUpdBlocks; k++) ss += sm[k];          // fixed order: every workgroup of the site forms the same bits
+    const float nv = (float)sqrt(ss), thr = mu / rho;
+    shrink_s = (nv > thr) ? (1.0f - thr / nv) : 0.0f;
+  }
+  __syncthreads();
+  const float shrink = shrink_s, inv_rho = 1.0f / rho;
+  const int full = dim * dim;
+  for (int e0 = (int)blockIdx.x * kUpdThreads + threadIdx.x; e0 < full; e0 += kUpdBlocks * kUpdThreads * kUpdIn) {
+    float dv[kUpdIn], gv[kUpdIn];
+#pragma unroll
+    for (int u = 0; u < kUpdIn; u++) {
+      const int e = e0 + u * kUpdBlocks * kUpdThreads;
+      const int ec = e < full ? e : full - 1;
+      const int i = ec / dim, j = ec - i * dim;
+      const bool in = i < b && j < b;
+      const float d = D[in ? i * b + j : 0];
+      dv[u] = in ? d : 0.0f;
+      gv[u] = G[ec];
+    }
+#pragma unroll
+    for (int u = 0; u < kUpdIn; u++) {
+      const int e = e0 + u * kUpdBlocks * kUpdThreads;
+      if (e < full) {
+        const float a = shrink * (dv[u] + inv_rho * gv[u]);
+        A[e] = a;
+        G[e] = gv[u] + rho * (dv[u] - a);
+      }
+    }
+  }
+}
+
 constexpr int kThreads = 256;
 
 __global__ __launch_bounds__(kThreads) void sgd_step_kernel(float* __restrict__ p, float* __restrict__ g,
@@ -220,6 +307,33 @@ int alignq_admm_update(const float* const* D_tab, float* const* alterD_tab, floa
       c.D[i] = D_tab[s0 + i]; c.A[i] = alterD_tab[s0 + i]; c.G[i] = gamma_tab[s0 + i];
     }
     hipLaunchKernelGGL(admm_update_kernel, cnt, kBig, 0, (hipStream_t)stream, c, b, dim, mu, rho);
+    LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+size_t alignq_admm_update_ws_bytes(int S, int dim) {
+  return (S > 0 && dim > 128) ? (size_t)S * kUpdBlocks * sizeof(double) : 16;
+}
+
+int alignq_admm_update_ws(const float* const* D_tab, float* const* alterD_tab, float* const* gamma_tab, int S, int b, int dim,
+                          float mu, float rho, void* ws, void* stream) {
+  if (!ws || dim <= 128) return alignq_admm_update(D_tab, alterD_tab, gamma_tab, S, b, dim, mu, rho, stream);
+  if (!D_tab || !alterD_tab || !gamma_tab || S <= 0 || b <= 0 || dim < b) return ALIGNQ_EINVAL;
+  if (dim > 4096) return ALIGNQ_EUNSUPPORTED;
+  double* parts = (double*)ws;
+  for (int s0 = 0; s0 < S; s0 += kSiteChunk) {
+    const int cnt = (S - s0 < kSiteChunk) ? S - s0 : kSiteChunk;
+    AChunk c;
+    for (int i = 0; i < cnt; i++) {
+      if (!D_tab[s0 + i] || !alterD_tab[s0 + i] || !gamma_tab[s0 + i]) return ALIGNQ_EINVAL;
+      c.D[i] = D_tab[s0 + i]; c.A[i] = alterD_tab[s0 + i]; c.G[i] = gamma_tab[s0 + i];
+    }
+    hipLaunchKernelGGL(admm_update_partial_kernel, dim3(kUpdBlocks, cnt), kUpdThreads, 0, (hipStream_t)stream, c, b, dim, rho,
+                       parts + (size_t)s0 * kUpdBlocks);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(admm_update_apply_kernel, dim3(kUpdBlocks, cnt), kUpdThreads, 0, (hipStream_t)stream, c, b, dim, mu, rho,
+                       (const double*)(parts + (size_t)s0 * kUpdBlocks));
     LAUNCH_CHECK();
   }
   return 0;

@@ -109,9 +109,13 @@ class ADMM_OPT(Optimizer):
         if int(config.args.bitW) >= 32:
             raise KeyError("lr")   # the reference's non-quantised branch reads group['lr'], which ADMM_OPT never defines
         for (mu, rho, b, dim), sites in self._gather(alterD_idx, gamma_idx, Ds, gammas, mus, rhos).items():
-            L.check(L.load().alignq_admm_update(L.ptr_array([s_[0] for s_ in sites]), L.ptr_array([s_[1] for s_ in sites]),
-                                                L.ptr_array([s_[2] for s_ in sites]), len(sites), b, dim, mu, rho,
-                                                L.stream_ptr()), "alignq_admm_update")
+            lib = L.load()
+            # above dim = 128 (the exact-global correlation's ADMM(dim = B_g)): 64 workgroups per site through a workspace
+            ws = (torch.empty(lib.alignq_admm_update_ws_bytes(len(sites), dim), dtype=torch.uint8, device=sites[0][1].device)
+                  if dim > 128 else None)
+            L.check(lib.alignq_admm_update_ws(L.ptr_array([s_[0] for s_ in sites]), L.ptr_array([s_[1] for s_ in sites]),
+                                              L.ptr_array([s_[2] for s_ in sites]), len(sites), b, dim, mu, rho, L.ptr(ws),
+                                              L.stream_ptr()), "alignq_admm_update_ws")
         return loss
 
     def _gather(self, alterD_idx, gamma_idx, Ds, gammas, mus, rhos):
@@ -162,7 +166,9 @@ def sgd_admm_step(sgd, sgd_args, admm, admm_args):
         # gather took for initialised ones)
         one_group = sum(1 for g in sgd.param_groups if any(p.grad is not None for p in g["params"])) == 1
         groups = admm._gather(alterD_idx, gamma_idx, Ds, gammas, mus, rhos) if disjoint and one_group else None
-        if groups is not None and len(groups) == 1:
+        # (above dim = 128 the ADMM role of the one-launch form would walk dim^2 elements with one workgroup per site: 1 ms at
+        #  dim = 1024; the separate steps take the many-workgroup update)
+        if groups is not None and len(groups) == 1 and next(iter(groups))[3] <= 128:
             items = sgd._gather(idx, w_cdf, w_pdf)
             assert len(items) == 1
             ((mu, rho, b, dim), sites), = groups.items()

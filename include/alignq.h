@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALIGNQ_ABI_VERSION 12
+#define ALIGNQ_ABI_VERSION 13
 
 #define ALIGNQ_FORMULA_ADMM 0
 #define ALIGNQ_FORMULA_CDF 1
@@ -185,6 +185,12 @@ int alignq_admm_loss(const float* D, int b, const float* alterD, const float* ga
  *   V = pad(D)+gamma/rho; A = (1-(mu/rho)/|V|_F) V if |V|_F > mu/rho else 0; gamma += rho (pad(D)-A). */
 int alignq_admm_update(const float* const* D_tab, float* const* alterD_tab, float* const* gamma_tab,
                        int S, int b, int dim, float mu, float rho, void* stream);
+/* the same with a workspace (alignq_admm_update_ws_bytes(S, dim)): above dim = 128 (ADMM(dim = B_g) of the exact-global correlation)
+ * 64 workgroups per site in two launches (partial |V|_F^2, then update) instead of one workgroup walking dim^2 elements; at
+ * dim <= 128 or ws == NULL it IS alignq_admm_update.  The norm is summed in another order than there (last-bit differences).   */
+size_t alignq_admm_update_ws_bytes(int S, int dim);
+int alignq_admm_update_ws(const float* const* D_tab, float* const* alterD_tab, float* const* gamma_tab,
+                          int S, int b, int dim, float mu, float rho, void* ws, void* stream);
 
 /* ---- R8: SGD step (utils/optimizer.py:212-229,251,255) and the grad rewrite (:6-13,233-249) ------
  * d = g + wd*p; buf = first ? d : mom*buf + (1-damp)*d; dir = nesterov ? d + mom*buf : buf;

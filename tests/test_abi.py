@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.alignq_abi_version() == _lib.ABI_VERSION == 12
+    assert lib.alignq_abi_version() == _lib.ABI_VERSION == 13
     assert b"invalid" in lib.alignq_strerror(-1)
     # pure host-side queries are safe without a GPU
     tail = 1024 + 16                                     # loss partials + arrival counter
@@ -48,6 +48,7 @@ def test_argument_validation_without_gpu():
     assert lib.alignq_act_quant_fwd(None, None, None, 16, 8, 2.0, 0, None) == -1
     assert lib.alignq_site_fwd(None, 128, 64, 8, 2.0, 0.0, None, None, None, None, None) == -1
     assert lib.alignq_admm_update(None, None, None, 1, 8, 8, 0.2, 0.3, None) == -1
+    assert lib.alignq_admm_update_ws_bytes(21, 128) == 16 and lib.alignq_admm_update_ws_bytes(21, 1024) == 21 * 64 * 8
 
 
 def test_python_mirror_names_and_signatures():

@@ -459,3 +459,37 @@ def test_small_batch_site_backward_with_per_column_bn_sums_equals_the_sums_pass(
         np.testing.assert_allclose(dz_b, dz_a, rtol=1e-4, atol=1e-6 * float(np.abs(dz_a).max()) + 1e-9)
     finally:
         config.args.abitW, config.args.train_batch_size, fused._S1_BN_COLS = old
+
+
+# ------------------------------------------------------------------------------------------------ ADMM update above dim = 128
+@pytest.mark.parametrize("dim,b,S,scale", [(256, 256, 3, 0.05), (520, 300, 2, 0.05), (1024, 1024, 2, 0.02), (200, 200, 2, 1e-6)])
+def test_admm_update_above_128_rows_on_many_workgroups_vs_oracle(dev, dim, b, S, scale):
+    """ADMM_OPT.step for ADMM(dim > 128) - the exact-global correlation builds ADMM(dim = B_g) - runs 64 workgroups per site in two
+    launches (alignq_admm_update_ws) instead of one workgroup per site (1 ms at dim = 1024): alterD / gamma against the C oracle's
+    statement of utils/optimizer.py:97-124, a short batch (b < dim: D zero-padded), S sites in one call, and the branch
+    |V|_F <= mu / rho (scale 1e-6 with gamma = 0: alterD becomes 0); in place."""
+    from alignq_amd import _lib as L
+    lib = L.load()
+    rng = np.random.default_rng(dim + b)
+    mu, rho = 0.2, 0.3
+    Ds = [(rng.standard_normal((b, b)) * scale).astype(np.float32) for _ in range(S)]
+    As = [rng.random((dim, dim)).astype(np.float32) for _ in range(S)]
+    Gs = [(rng.random((dim, dim)) * (0.0 if scale < 1e-5 else 1.0)).astype(np.float32) for _ in range(S)]
+    want = [O.admm_update(D.copy(), A.copy(), G.copy(), mu, rho) for D, A, G in zip(Ds, As, Gs)]
+    dD, dA, dG = [cu(v, dev) for v in Ds], [cu(v, dev) for v in As], [cu(v, dev) for v in Gs]
+    ws = torch.empty(lib.alignq_admm_update_ws_bytes(S, dim), dtype=torch.uint8, device=dev)
+    ptrs = [t.data_ptr() for t in dA + dG]
+    L.check(lib.alignq_admm_update_ws(L.ptr_array(dD), L.ptr_array(dA), L.ptr_array(dG), S, b, dim, mu, rho, L.ptr(ws), L.stream_ptr()),
+            "alignq_admm_update_ws")
+    assert ptrs == [t.data_ptr() for t in dA + dG]
+    for s in range(S):
+        np.testing.assert_allclose(npy(dA[s]), want[s][0], atol=TOL, rtol=1e-5)
+        np.testing.assert_allclose(npy(dG[s]), want[s][1], atol=TOL, rtol=1e-5)
+    if scale < 1e-5:
+        assert all(not npy(a).any() for a in dA)
+    # the one-workgroup entry on the same inputs: same values up to the summation order of the norm
+    eA, eG = [cu(v, dev) for v in As], [cu(v, dev) for v in Gs]
+    L.check(lib.alignq_admm_update(L.ptr_array(dD), L.ptr_array(eA), L.ptr_array(eG), S, b, dim, mu, rho, L.stream_ptr()), "alignq_admm_update")
+    for s in range(S):
+        np.testing.assert_allclose(npy(dA[s]), npy(eA[s]), atol=1e-6, rtol=1e-5)
+        np.testing.assert_allclose(npy(dG[s]), npy(eG[s]), atol=1e-6, rtol=1e-5)
