@@ -17,7 +17,7 @@ from . import cdf_alignment as _cdf
 from . import cdf_alignment_admm as _admm
 from . import config
 from .admm import ADMM
-from .fused import bn_act_relu, bn_site
+from .fused import bn_act_relu, bn_only, bn_site
 
 
 def _transition_pair(conv3, conv1, x):
@@ -82,7 +82,9 @@ class PreActBlock_conv_Q(nn.Module):
             # plain-quantiser family (alignq_bnq_fwd / _bwd, formula 1); it falls back to exactly the composition below when
             # the tensor is not channels-last fp32 in training mode
             return bn_act_relu(bn, fn, z, 1, relu=relu, residual=residual), 0
-        out, loss = self._q(fn, bn(z))
+        # no fold (fuse_bn off: the exact-global correlation, a caller's choice): the batch-norm alone still runs on the folded
+        # family's kernels when the tensor is channels-last fp32 in training mode (fused.bn_only), else the module itself
+        out, loss = self._q(fn, bn_only(bn, z))
         if residual is not None:
             out += residual
         return (F.relu(out) if relu else out), loss
@@ -141,7 +143,7 @@ class PreActResNet(nn.Module):
             out, loss = bn_site(self.bn, self.act_q0, self.conv0(x), relu=True)
             trans_loss = 0. + loss
         elif self.tree == "admm":
-            out, loss = self.act_q0(self.bn(self.conv0(x)))
+            out, loss = self.act_q0(bn_only(self.bn, self.conv0(x)))
             trans_loss = 0. + loss
             out = F.relu(out)
         elif self.fuse_bn:
