@@ -492,12 +492,14 @@ def test_head_ticket_is_idempotent(dev):
 
 
 # ------------------------------------------------------------------------------------------------ VERDICT r2 item 6
-@pytest.mark.parametrize("b,n_par,n_sites", [(128, 65, 21), (80, 9, 3), (128, 70, 21), (128, 12, 23)])
-def test_sgd_and_admm_update_in_one_launch_equal_the_two_steps(dev, b, n_par, n_sites):
+@pytest.mark.parametrize("b,n_par,n_sites,dim", [(128, 65, 21, 128), (80, 9, 3, 128), (128, 70, 21, 128), (128, 12, 23, 128),
+                                                 (200, 9, 3, 256)])
+def test_sgd_and_admm_update_in_one_launch_equal_the_two_steps(dev, b, n_par, n_sites, dim):
     """optimizer.sgd_admm_step (alignq_sgd_admm_step_multi: the SGD step and the ADMM update as roles of one launch) leaves the
     bits of SGD.step followed by ADMM_OPT.step in every parameter, momentum buffer, rewritten p.grad, alterD and gamma; b = 80 is
     a short batch in dim 128 (the padded form, utils/optimizer.py:95-103); 70 parameters / 23 sites exceed one argument block
-    (the entry point then issues the two launches itself)."""
+    (the entry point then issues the two launches itself); dim = 256 (round 4): above 128 the call runs the two steps as they
+    are (the many-workgroup ADMM update, alignq_admm_update_ws)."""
     from alignq_amd import config
     from alignq_amd.admm import ADMM
     from alignq_amd.optimizer import ADMM_OPT, SGD, sgd_admm_step
@@ -516,10 +518,10 @@ def test_sgd_and_admm_update_in_one_launch_equal_the_two_steps(dev, b, n_par, n_
             pdfs = [torch.rand(ps[i].shape, generator=g).to(dev) for i in idx]
             admms = []
             for _ in range(n_sites):
-                m = ADMM(128).to(dev)
+                m = ADMM(dim).to(dev)
                 with torch.no_grad():
-                    m.alterD.copy_(torch.rand(128, 128, generator=g))
-                    m.gamma.copy_(torch.rand(128, 128, generator=g))
+                    m.alterD.copy_(torch.rand(dim, dim, generator=g))
+                    m.gamma.copy_(torch.rand(dim, dim, generator=g))
                 m.alterD.grad = torch.zeros_like(m.alterD)
                 m.gamma.grad = torch.zeros_like(m.gamma)
                 m.D = (torch.randn(b, b, generator=g) * 0.05).to(dev)
