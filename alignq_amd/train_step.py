@@ -243,10 +243,12 @@ class TrainStep:
             torch.cuda.synchronize()
         cap_mode = dict(capture_error_mode="thread_local") if dist_on else {}
         if getattr(self, "_global_corr_undo", None) is not None or getattr(config.args, "global_corr", None) is not None:
-            # the exact-global correlation issues all_to_all / all_reduce from inside the forward: they can be captured with
-            # RCCL only (gloo collectives are host calls)
-            if not (torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl"):
-                raise RuntimeError("TrainStep.capture: global_corr needs the nccl (RCCL) backend to be captured")
+            # the exact-global correlation issues all_to_all / all_reduce from INSIDE the forward.  Rounds 2-3 let RCCL capture them;
+            # round 4 ran it for the first time (ResNet-20, B_g = 256, world size 1, ROCm 7.2): the capture / first replay never
+            # returned (the box was killed after 7 silent minutes).  Until that is understood the step runs eagerly in this mode -
+            # a refusal instead of a hang; the per-rank semantics (the default) capture as before.
+            raise RuntimeError("TrainStep.capture: the exact-global correlation (global_corr) is not captured into a HIP graph - "
+                               "call the step eagerly (collectives inside the captured forward hung on ROCm 7.2; DESIGN.md section 6)")
         graph = torch.cuda.CUDAGraph()
         self._graph2 = None
         # inside the capture grads are re-created (set_to_none=True): no zero-fill and no accumulate-add per

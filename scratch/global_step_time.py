@@ -16,6 +16,9 @@ model = resnet20_quant(8, 8).to(dev).train()
 st = TrainStep(model, lr=0.04, channels_last=True)
 dp.attach(st, force=True, global_corr=True)
 x = torch.randn(B, 3, 32, 32, device=dev); y = torch.randint(0, 10, (B,), device=dev)
+if len(sys.argv) > 3 and sys.argv[3] == "graph":
+    st.capture(x, y, warmup=3)
+    x, y = st.static_inputs()
 for _ in range(3):
     out = st(x, y)
 torch.cuda.synchronize()
@@ -24,5 +27,5 @@ t0 = time.perf_counter()
 for _ in range(n):
     out = st(x, y)
 torch.cuda.synchronize()
-print("B", B, "eager global-corr step %.2f ms" % ((time.perf_counter() - t0) / n * 1e3), "ce", float(out[1]))
+print("B", B, sys.argv[3:] , "global-corr step %.2f ms" % ((time.perf_counter() - t0) / n * 1e3), "ce", float(out[1]))
 dist.destroy_process_group()
