@@ -155,6 +155,7 @@ def attach(train_step, group=None, force=False, global_corr=False):
                 m.global_corr = True if group is None else group
         train_step._deferred = None
         train_step._global_corr_undo = undo
+        train_step._had_global_corr = True          # TrainStep.capture refuses such a step, also after detach (see there)
     broadcast_module_state(train_step.model, 0, group)
     hook = GradAndDAllReduce([p for _, p in train_step.param_t], lambda: [m.D for m in train_step.admms], group,
                              force=force)

@@ -231,7 +231,10 @@ class TrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._assert_momentum_buffers()
-        dist_on = (self.grad_hook is not None and torch.distributed.is_available() and torch.distributed.is_initialized())
+        # an initialised process group matters even WITHOUT a hook (round 4: after dp.detach the one-graph capture ran in the
+        # global capture mode while the group's watchdog thread was still polling the events of earlier collectives: a
+        # segmentation fault inside hipStreamEndCapture)
+        dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
         if dist_on:
             # The warm-up iterations issued collectives.  Quiesce explicitly instead of sleeping: a barrier orders every rank
             # behind its peers' warm-up collectives and the device synchronise retires them, so no collective is in flight
@@ -242,6 +245,12 @@ class TrainStep:
             torch.distributed.barrier()
             torch.cuda.synchronize()
         cap_mode = dict(capture_error_mode="thread_local") if dist_on else {}
+        if getattr(self, "_had_global_corr", False) and getattr(self, "_global_corr_undo", None) is None:
+            # ... and a capture AFTER an eager exact-global phase of the same step object (dp.attach(global_corr=True), steps,
+            # dp.detach) ended in a segmentation fault inside hipStreamEndCapture (round 4, both capture modes): refused as well
+            raise RuntimeError("TrainStep.capture: this step ran the exact-global correlation (global_corr) earlier in this process; "
+                               "capturing it afterwards crashed inside hipStreamEndCapture on ROCm 7.2 - build a fresh TrainStep "
+                               "for captured per-rank steps (a new step object captures fine in the same process; DESIGN.md section 6)")
         if getattr(self, "_global_corr_undo", None) is not None or getattr(config.args, "global_corr", None) is not None:
             # the exact-global correlation issues all_to_all / all_reduce from INSIDE the forward.  Rounds 2-3 let RCCL capture them;
             # round 4 ran it for the first time (ResNet-20, B_g = 256, world size 1, ROCm 7.2): the capture / first replay never
@@ -258,7 +267,7 @@ class TrainStep:
         if self.optimizer_admm is not None:
             self.optimizer_admm.zero_grad(set_to_none=True)
         if self.grad_hook is None:
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, **cap_mode):
                 outs = self._iteration(sx, sy, set_to_none=True)
         else:
             phased = hasattr(self.grad_hook, "reduce")
@@ -439,7 +448,9 @@ class OfficeTrainStep:
         graph = torch.cuda.CUDAGraph()
         self._graph2 = None
         if self.grad_hook is None or not self.grad_hook.active():
-            with torch.cuda.graph(graph):
+            # (an initialised process group's watchdog thread issues HIP calls of its own: thread-local capture mode, see TrainStep.capture)
+            pg_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+            with torch.cuda.graph(graph, **(dict(capture_error_mode="thread_local") if pg_on else {})):
                 outs = self._iteration(sxs, sys_, sxt, set_to_none=True)
         else:
             # data parallel: forward + backward + bucket pack | eager all-reduces | bucket unpack + optimizer steps

@@ -448,6 +448,33 @@ def test_global_corr_on_rccl_matches_the_fused_site(dev, pg):
         np.testing.assert_allclose(npy(x1.grad), O.site_bwd(np.zeros((Bq, Fq), np.float32), npy(dD), npy(x1), 2.0, eps), atol=TOL, rtol=1e-4)
 
 
+def test_capture_refuses_the_exact_global_mode_and_the_eager_step_still_runs(dev, pg):
+    """Round 4: collectives issued from inside a captured forward hung on ROCm 7.2: TrainStep.capture refuses
+    the exact-global correlation mode with an error instead; the same step runs eagerly (world size 1: D_global == the fused
+    site's D up to the summation order), dp.detach gives the per-rank sites back (eagerly), and a capture of that step object
+    afterwards - it ended in a segmentation fault inside hipStreamEndCapture - is refused too."""
+    from alignq_amd import config, dp
+    from alignq_amd.resnet import PreActBlock_conv_Q, PreActResNet
+    from alignq_amd.train_step import TrainStep
+    config.args.bitW = config.args.abitW = 8
+    config.args.train_batch_size = 128
+    torch.manual_seed(5)
+    x = torch.randn(128, 3, 32, 32, device=dev)
+    y = torch.randint(0, 10, (128,), device=dev)
+    net = PreActResNet(PreActBlock_conv_Q, [1, 1, 1], 8, 8, "second", 10).to(dev).train()
+    step = TrainStep(net, lr=0.01, channels_last=True)
+    dp.attach(step, force=True, global_corr=True)
+    with pytest.raises(RuntimeError, match="global_corr"):
+        step.capture(x, y, warmup=1)
+    out = step(x, y)
+    assert torch.isfinite(out[1]).item() and torch.isfinite(out[2]).item()
+    dp.detach(step)
+    out = step(x, y)                                   # per-rank sites again, eagerly
+    assert torch.isfinite(out[1]).item()
+    with pytest.raises(RuntimeError, match="earlier in this process"):      # (that capture crashed in hipStreamEndCapture)
+        step.capture(x, y, warmup=1)
+
+
 def test_captured_dp_step_keeps_its_bucket_across_a_short_batch(dev, pg):
     """ADVICE r2 (high).  A captured TrainStep with the data-parallel hook (world size 1 on RCCL, force=True): capture, a
     SHORT last batch (eager fallback: the hook lays out a second bucket for the [b',b'] D matrices), then a full batch again.
