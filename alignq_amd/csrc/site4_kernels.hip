@@ -1191,13 +1191,14 @@ __global__ __launch_bounds__(256) void site_prep_groups_kernel(const float* __re
                                                                const float* __restrict__ scal, float mu,
                                                                const float* __restrict__ gscale, int B, float invF,
                                                                float* __restrict__ S, int64_t s_gstride,
-                                                               float* __restrict__ dA_out, float* __restrict__ dG_out, int groups) {
+                                                               float* __restrict__ dA_out, float* __restrict__ dG_out, int groups,
+                                                               int gs_stride) {
+  // gs_stride: elements between the slices' upstream loss gradients (0: one scalar for all of them)
   const int gi = blockIdx.y;
   // S of this slice (no parameter gradients from here: dA_out / dG_out nullptr)
-  site_prep_body<true>(nullptr, D + (int64_t)gi * B * B, A, gamma, dim, scal + 4 * gi, mu, gscale, B, invF, S + gi * s_gstride, nullptr,
-                       nullptr, blockIdx.x, gridDim.x);
+  site_prep_body<true>(nullptr, D + (int64_t)gi * B * B, A, gamma, dim, scal + 4 * gi, mu, gscale ? gscale + (int64_t)gi * gs_stride : nullptr,
+                       B, invF, S + gi * s_gstride, nullptr, nullptr, blockIdx.x, gridDim.x);
   if (gi != 0 || (!dA_out && !dG_out)) return;
-  const float gs = gscale ? gscale[0] : 1.0f;
   for (int e = blockIdx.x * 256 + threadIdx.x; e < dim * dim; e += gridDim.x * 256) {
     const int i = e / dim, j = e - i * dim;
     float da = 0.f, dg = 0.f;
@@ -1208,6 +1209,7 @@ __global__ __launch_bounds__(256) void site_prep_groups_kernel(const float* __re
         const float c_con = scal[4 * g + 1], inv_n = scal[4 * g + 2];
         const float d = D[(int64_t)g * B * B + i * B + j] - a;
         const float gij = c_con * d + gm * (float)((d > 0.f) - (d < 0.f)) * inv_n;
+        const float gs = gscale ? gscale[(int64_t)g * gs_stride] : 1.0f;
         const float va = gs * (mu * sa * inv_n - gij), vg = gs * fabsf(d) * inv_n;
         da = g == 0 ? va : da + va;
         dg = g == 0 ? vg : dg + vg;
@@ -2087,10 +2089,10 @@ int launch_reduce_loss_multi(int S, void* const* ws, float* const* D, const floa
 
 int launch_prep_groups(const float* D, const float* alterD, const float* gamma, int dim, const float* scal, float mu,
                        const float* gscale, int B, int64_t F, int groups, float* S, int64_t s_gstride, float* dA, float* dG,
-                       hipStream_t st) {
+                       hipStream_t st, int gs_stride) {
   const int gx = (dim * dim + 255) / 256;
   hipLaunchKernelGGL(site_prep_groups_kernel, dim3(gx, groups), 256, 0, st, D, alterD, gamma, dim, scal, mu, gscale, B, 1.0f / (float)F,
-                     S, s_gstride, dA, dG, groups);
+                     S, s_gstride, dA, dG, groups, gs_stride);
   RET_ON_ERR();
   return 0;
 }

@@ -162,7 +162,7 @@ int launch_prep(bool fused, const float* dD, const float* D, const float* alterD
 // `groups` batch slices of ONE small-batch site: S per slice, the shared module's parameter gradients summed over the slices
 int launch_prep_groups(const float* D, const float* alterD, const float* gamma, int dim, const float* scal, float mu,
                        const float* gscale, int B, int64_t F, int groups, float* S, int64_t s_gstride, float* dA, float* dG,
-                       hipStream_t st);
+                       hipStream_t st, int gs_stride = 0);     // gs_stride: elements between the slices' loss gradients (0: one for all)
 // all sites of a model in one launch each (64 < B <= 128 only)
 int launch_reduce_loss_multi(int S, void* const* ws, float* const* D, const float* const* alterD,
                              const float* const* gamma, float* const* scal, const int64_t* F, int B, int dim, float mu,

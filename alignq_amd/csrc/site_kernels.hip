@@ -776,13 +776,14 @@ int alignq_site1_groups_reduce_loss(void* ws, int B, int64_t F, int groups, floa
 
 // the backward's preparation for all slices in one launch: S per slice + dalterD / dgamma SUMMED over the slices (slice order)
 int alignq_site1_groups_prep(const float* D, const float* alterD, const float* gamma, int dim, const float* scal, float mu,
-                             const float* dD_scale, int B, int64_t F, int groups, float* S, float* dalterD, float* dgamma,
-                             void* stream) {
-  if (!D || !alterD || !gamma || !scal || !S || groups < 1 || groups > ALIGNQ_BNQ_MAX_GROUPS || dim < B) return ALIGNQ_EINVAL;
+                             const float* dD_scale, int dD_scale_stride, int B, int64_t F, int groups, float* S, float* dalterD,
+                             float* dgamma, void* stream) {
+  if (!D || !alterD || !gamma || !scal || !S || groups < 1 || groups > ALIGNQ_BNQ_MAX_GROUPS || dim < B || dD_scale_stride < 0)
+    return ALIGNQ_EINVAL;
   if (bad_shape(B, F)) return F <= 0 ? ALIGNQ_EINVAL : ALIGNQ_EUNSUPPORTED;
   if (geom(B, F).nb != 1) return ALIGNQ_EUNSUPPORTED;
   return launch_prep_groups(D, alterD, gamma, dim, scal, mu, dD_scale, B, F, groups, S, (int64_t)(alignq_site_bwd_ws_bytes(B) / 4),
-                            dalterD, dgamma, (hipStream_t)stream);
+                            dalterD, dgamma, (hipStream_t)stream, dD_scale_stride);
 }
 
 int alignq_site1_groups_bwd(const float* g, const float* g2, const float* y, const float* S, const float* z, const float* ab, int C,

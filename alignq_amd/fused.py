@@ -766,7 +766,7 @@ class BNSite1Fn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, weight, bias, running_mean, running_var, nbt, momentum, bn_eps, residual, alterD, gamma, k,
-                act_range, eps, mu, rho, groups=1, tok=None):
+                act_range, eps, mu, rho, groups=1, tok=None, loss_vec=False):
         ctx.tok = tok             # GradFork's mailbox (see there): a dict shared with whoever forks this node's output
         z = L.dense_f32(z, "conv output")
         A, Gm = L.dev_f32(alterD, "alterD"), L.dev_f32(gamma, "gamma")
@@ -801,9 +801,14 @@ class BNSite1Fn(torch.autograd.Function):
                    int(groups))
         ctx.set_materialize_grads(False)
         Dlast = D[groups - 1]
-        loss = scal[0, 0]
-        for gi in range(1, groups):
-            loss = loss + scal[gi, 0]
+        if loss_vec:
+            # the slices' losses as a VECTOR (a view: no kernel); the caller sums all sites' vectors at once.  One elementwise
+            # addition per site fewer on the in-order chain (16 per Office step); the backward takes a gradient per slice.
+            loss = scal[:, 0]
+        else:
+            loss = scal[0, 0]
+            for gi in range(1, groups):
+                loss = loss + scal[gi, 0]
         ctx.mark_non_differentiable(Dlast, *[t for t in (running_mean, running_var, nbt) if t is not None])
         return y, loss, Dlast
 
@@ -832,7 +837,12 @@ class BNSite1Fn(torch.autograd.Function):
                 g_y = g_m = torch.ops.aten.threshold_backward(g_y, y, 0.0)
         if g_loss is None:
             g_loss = torch.zeros((), dtype=torch.float32, device=dev)
-        g_loss = L.dev_f32(g_loss, "loss grad")
+        if g_loss.dim() == 0:
+            g_loss, gs_stride = L.dev_f32(g_loss, "loss grad"), 0
+        else:       # loss_vec: one upstream gradient per slice, read where autograd left it (an expanded tensor has stride 0)
+            if not (g_loss.is_cuda and g_loss.dtype == torch.float32 and tuple(g_loss.shape) == (groups,)):
+                raise RuntimeError("BNSite1Fn: the gradient of the loss vector must be a float32 device tensor of shape [groups]")
+            gs_stride = int(g_loss.stride(0))
         # _S1_MASK_IN_KERNEL (the default): alignq_site1_groups_prep writes dalterD / dgamma already summed over the slices
         summed = _S1_MASK_IN_KERNEL
         dAG = None
@@ -851,8 +861,8 @@ class BNSite1Fn(torch.autograd.Function):
         ws_bn = torch.empty(lib.alignq_bnq_ws_bytes(C, groups), dtype=torch.uint8, device=dev)
         if _S1_MASK_IN_KERNEL:
             # one preparation launch (S per slice; dalterD / dgamma summed over the slices in slice order) and one backward launch
-            L.check(lib.alignq_site1_groups_prep(L.ptr(D), L.ptr(A), L.ptr(Gm), A.shape[0], L.ptr(scal), mu, L.ptr(g_loss), B, F, groups,
-                                                 L.ptr(S), L.ptr(rA), L.ptr(rG), st), "alignq_site1_groups_prep")
+            L.check(lib.alignq_site1_groups_prep(L.ptr(D), L.ptr(A), L.ptr(Gm), A.shape[0], L.ptr(scal), mu, L.ptr(g_loss), gs_stride, B, F,
+                                                 groups, L.ptr(S), L.ptr(rA), L.ptr(rG), st), "alignq_site1_groups_prep")
             if _S1_BN_COLS:
                 # round 4: the site kernel leaves the batch-norm backward's sums per feature column; a small reduction, the
                 # finalisation and dz (in place) follow in the same entry: no pass of its own over dx and z
@@ -868,8 +878,9 @@ class BNSite1Fn(torch.autograd.Function):
         else:
             for gi in range(groups):
                 sl = slice(gi * B, (gi + 1) * B)
-                L.check(lib.alignq_site_prep_fused(L.ptr(D[gi]), L.ptr(A), L.ptr(Gm), A.shape[0], L.ptr(scal[gi]), mu, L.ptr(g_loss),
-                                                   B, F, L.ptr(S), L.ptr(dA[gi]), L.ptr(dG[gi]), st), "alignq_site_prep_fused")
+                L.check(lib.alignq_site_prep_fused(L.ptr(D[gi]), L.ptr(A), L.ptr(Gm), A.shape[0], L.ptr(scal[gi]), mu,
+                                                   L.ptr(g_loss if g_loss.dim() == 0 else g_loss[gi]), B, F, L.ptr(S), L.ptr(dA[gi]),
+                                                   L.ptr(dG[gi]), st), "alignq_site_prep_fused")
                 L.check(lib.alignq_site_bwd_apply_ab(L.ptr(None if g_y is None else g_y[sl]), L.ptr(S), L.ptr(z[sl]), L.ptr(ab[gi]), C,
                                                      L.ptr(stats[gi]), B, F, act_range, eps, L.ptr(dx[sl]), st),
                         "alignq_site_bwd_apply_ab")
@@ -885,13 +896,14 @@ class BNSite1Fn(torch.autograd.Function):
                 return out
             rA, rG = red(dA), red(dG)
         return (dx, dgamma, dbeta, None, None, None, None, None, g_m if has_res else None, rA, rG, None, None,
-                None, None, None, None, None)
+                None, None, None, None, None, None)
 
 
-def bn_site_res_relu(bn, act, z, residual, eps, groups=1):
+def bn_site_res_relu(bn, act, z, residual, eps, groups=1, loss_vec=False):
     """(relu(act(bn(z))[0] + residual), loss) for an ADMM site at a batch of at most 32 rows (per group): the folded chain when
     the tensor is channels-last fp32 in training mode (and no deferred-loss context is active), else None (the caller composes
-    it)."""
+    it).  loss_vec (groups > 1): the loss comes back as the VECTOR of the slices' losses (a view, no kernel) for a caller that sums
+    all its sites at once (resnet_office.ResNet.forward), instead of their sum."""
     from . import config
     if not (_bn_nhwc_ok(bn, z, groups) and 2 <= z.shape[0] // groups <= 32 and act.a_bit < 32
             and config.args.method == "ours"
@@ -902,7 +914,7 @@ def bn_site_res_relu(bn, act, z, residual, eps, groups=1):
     tok = {} if _GRAD_FORK else None
     y, loss, D = BNSite1Fn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum,
                                  bn.eps, residual, admm.alterD, admm.gamma, act.a_bit, config.args.act_range, eps, admm.mu, admm.rho,
-                                 groups, tok)
+                                 groups, tok, bool(loss_vec and groups > 1))
     if tok is not None:
         y._alignq_site_tok = tok          # read by fork_block_input (the next bottleneck)
     admm.D = D

@@ -210,12 +210,12 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
             """(relu(self(x)[0] + residual), loss) (not part of the reference's interface: an opt-in for the caller)."""
             return _site_act_res_relu(self, x, residual)
 
-        def forward_bn_res_relu(self, bn, z, residual, groups=1):
+        def forward_bn_res_relu(self, bn, z, residual, groups=1, loss_vec=False):
             """(relu(self(bn(z))[0] + residual), loss) with the training-mode batch-norm folded into the small-batch site
             kernels where that applies (SURVEY.md §8f-N1 on the Office path), else the composition.  groups > 1: the batch
             slices go through one after the other (loss = their sum, ADMM.D = the last slice's, like successive passes)."""
             from . import fused
-            out = fused.bn_site_res_relu(bn, self, z, residual, eps, groups)
+            out = fused.bn_site_res_relu(bn, self, z, residual, eps, groups, loss_vec)      # (loss_vec: see there)
             if out is not None:
                 return out
             if groups == 1:

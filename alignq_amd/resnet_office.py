@@ -7,6 +7,8 @@ downsample.1}, class_classifier.c_fc3, domain_classifier.d_fc2) so its checkpoin
 (the reference's `pretrained=True` default needs the network)."""
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -22,6 +24,8 @@ def conv3x3(wbit, stage, cin, cout, stride=1):
 def conv1x1(wbit, stage, cin, cout, stride=1):
     return Q.conv2d_Q_fn(w_bit=wbit, stage=stage)(cin, cout, kernel_size=1, stride=stride, bias=False)
 
+
+_LOSS_VEC = os.environ.get("ALIGNQ_S1_LOSS_VEC", "1") != "0"      # A/B aid: 0 = every folded site adds its slices' losses itself
 
 class Bottleneck(nn.Module):
     expansion = 4
@@ -59,7 +63,7 @@ class Bottleneck(nn.Module):
             out = self.act_q2.forward_bn_relu(self.bn2, self.conv2(out), groups)
             if self.downsample is not None:
                 identity = fused.bn_only(self.downsample[1], self.downsample[0](x_short), groups)
-            out, loss = self.act_q3.forward_bn_res_relu(self.bn3, self.conv3(out), identity, groups)
+            out, loss = self.act_q3.forward_bn_res_relu(self.bn3, self.conv3(out), identity, groups, loss_vec=_LOSS_VEC)
             return out, loss              # (= 0. + loss without the launch that forms it)
         x_short = x
         if getattr(self, "fuse_bn", False):         # opt-in (OfficeTrainStep): batch-norm + quantiser + ReLU as one chain
@@ -145,7 +149,8 @@ class ResNet(nn.Module):
             # are summed as numbers, as the running sum of the one-pass form does)
             tens = [l for l in losses if torch.is_tensor(l)]
             rest = sum(l for l in losses if not torch.is_tensor(l))
-            total = torch.stack(tens).sum() + rest if tens else rest
+            # (the folded sites return the VECTOR of their slices' losses - a view, no kernel: one concatenation + one sum)
+            total = torch.cat([t.reshape(-1) for t in tens]).sum() + rest if tens else rest
             return torch.flatten(self.avgpool(x), 1), total
         if getattr(self, "fuse_bn", False):
             x = self.maxpool(self.act_q0.forward_bn_relu(self.bn1, self.conv1(x)))

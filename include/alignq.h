@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALIGNQ_ABI_VERSION 13
+#define ALIGNQ_ABI_VERSION 14
 
 #define ALIGNQ_FORMULA_ADMM 0
 #define ALIGNQ_FORMULA_CDF 1
@@ -507,9 +507,11 @@ int alignq_site1_groups_reduce_loss(void* ws, int B, int64_t F, int groups, floa
 /* (round 4) the backward's preparation for all slices of ONE site in one launch: S regions as alignq_site_prep_fused_multi leaves
  * them, and dalterD / dgamma [dim,dim] = the SUM over the slices in slice order - what autograd accumulates when the reference
  * calls the module once per pass (dann_office/main.py:372,377), without the per-slice buffers and the launch that added them.   */
+/* dD_scale (or NULL): the upstream gradient(s) of the slices' losses, slice g's at dD_scale[g * dD_scale_stride] (stride 0: one
+ * device scalar for all slices - the gradient of their SUM; stride >= 1: the loss left as a vector over the slices).              */
 int alignq_site1_groups_prep(const float* D, const float* alterD, const float* gamma, int dim, const float* scal, float mu,
-                             const float* dD_scale, int B, int64_t F, int groups, float* S, float* dalterD, float* dgamma,
-                             void* stream);
+                             const float* dD_scale, int dD_scale_stride, int B, int64_t F, int groups, float* S, float* dalterD,
+                             float* dgamma, void* stream);
 int alignq_site1_groups_bwd(const float* g, const float* g2, const float* y, const float* S, const float* z, const float* ab, int C,
                             const float* stats, int B, int64_t F, int groups, float act_range, float eps, float* dx,
                             float* dres, void* stream);
