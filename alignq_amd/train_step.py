@@ -9,6 +9,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -352,8 +354,13 @@ class OfficeTrainStep:
         if self.channels_last:
             xs = xs.contiguous(memory_format=torch.channels_last)
             xt = xt.contiguous(memory_format=torch.channels_last)
-        label_src = torch.zeros(xs.shape[0], dtype=torch.long, device=dev)
-        label_tgt = torch.ones(xt.shape[0], dtype=torch.long, device=dev)
+        # the domain labels (main.py:360-361 builds them every iteration) are constants of the batch sizes: kept, not re-filled
+        key = (int(xs.shape[0]), int(xt.shape[0]), dev)
+        if getattr(self, "_dom_labels_key", None) != key:
+            self._dom_labels = (torch.zeros(xs.shape[0], dtype=torch.long, device=dev),
+                                torch.ones(xt.shape[0], dtype=torch.long, device=dev))
+            self._dom_labels_key = key
+        label_src, label_tgt = self._dom_labels
         prequantize_weights(self.all_convs)
         if self.dual and xs.shape == xt.shape:
             cls_s, dom_s, dom_t, tl_both = m.forward_dual(xs, xt, alpha=self.alpha)      # (same weights, hence the same W_q,
@@ -362,15 +369,16 @@ class OfficeTrainStep:
             cls_s, dom_s, tl_s = m(xs, alpha=self.alpha)
             prequantize_weights(self.all_convs)          # the reference quantises every weight once per pass
             _, dom_t, tl_t = m(xt, alpha=self.alpha)
-        loss = (F.cross_entropy(cls_s, ys) + F.cross_entropy(dom_s, label_src) + F.cross_entropy(dom_t, label_tgt)
-                + tl_s + tl_t)
+        # (a pass without a loss tensor contributes the NUMBER 0: adding it would be an elementwise launch of its own)
+        tl = tl_s if not torch.is_tensor(tl_t) and tl_t == 0 else (tl_t if not torch.is_tensor(tl_s) and tl_s == 0 else tl_s + tl_t)
+        loss = F.cross_entropy(cls_s, ys) + F.cross_entropy(dom_s, label_src) + F.cross_entropy(dom_t, label_tgt) + tl
         hook = self.grad_hook if overlap else None
         if hook is not None:
             hook.begin()              # the buckets' all-reduces start from autograd hooks during this backward
         loss.backward()
         if hook is not None:
             hook.finish()
-        return cls_s, loss, tl_s + tl_t
+        return cls_s, loss, tl
 
     def _optimizer_steps(self):
         w_cdf = [c.quantize_fn.weight_cdf for c in self.convs]
