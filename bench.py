@@ -4,8 +4,10 @@
 8W/8A, CDF alignment + ADMM, batch 128 per GPU (BASELINE.json configs[1]), synthetic 3x32x32 inputs
 resident in HBM, random-init weights.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1 without a launcher: starts the N ranks itself as a child
+                                                          `python -m torch.distributed.run --nproc-per-node N bench.py ...`)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+Every rank exits with code 2 when WORLD_SIZE differs from --gpus.
 
 Prints ONE JSON line on rank 0.  Besides the contract fields it carries
   roofline      : the dominant hand-written kernel of the step (by summed time over its launches in one step),
@@ -68,6 +70,10 @@ def parse():
     ap.add_argument("--nchw", action="store_true",
                     help="contiguous NCHW activations/weights instead of torch.channels_last (the default: MIOpen's NHWC "
                          "kernels need no transposes; 2.22 vs 2.50 ms per step)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch rehearsal without a GPU: the ranks form a gloo group on the CPU, run the timed region's "
+                         "bookkeeping over a stub step and rank 0 prints a line whose metric says 'dry run' (tests/"
+                         "test_bench_assembly.py drives `bench.py --gpus 2 --dry-run` through the self-launch)")
     ap.add_argument("--no-miopen-find", action="store_true",
                     help="torch.backends.cudnn.benchmark=False: MIOpen's immediate-mode solver choice instead of its find "
                          "step for the (not ours) convolutions; find is on by default, it is worth ~2%% of a step")
@@ -928,11 +934,67 @@ def headline(a, elapsed, images_per_step, world, office, final_ce, final_tl):
     }
 
 
+def launcher_command(a, argv, port=None):
+    """The command line `python bench.py --gpus N ...` (N > 1, not already a rank of a launch) starts as a CHILD process:
+    one rank per GPU of this node under torch.distributed.run, same arguments.  127.0.0.1 rendezvous (the host name of a
+    GPU box may not resolve)."""
+    port = port or int(os.environ.get("MASTER_PORT", 29533))
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(a, argv):
+    """`--gpus N` without a launcher around it: this process has touched no GPU yet (importing torch does not), so it starts
+    the N ranks as a child process, relays rank 0's stdout (the one JSON line) and stderr untouched, and returns the child's
+    exit code.  Never os.exec* here: a process image replaced after HIP initialisation takes the machine down."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(launcher_command(a, argv), env=env)
+
+
+def check_world(a, world):
+    """Every rank: the number of ranks the launcher gave must be the --gpus the line will report."""
+    if world != a.gpus:
+        sys.stderr.write(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus} "
+                         f"(or run `python bench.py --gpus {a.gpus}` alone, which starts the ranks itself)\n")
+        sys.exit(2)
+
+
+def dry_run(a, rank, world):
+    """No GPU, no kernels: the launch chain (self_launch -> torch.distributed.run -> ranks), the fences and the max-over-ranks
+    clock of timed_steps, and the line assembly, on a gloo group.  The line cannot be mistaken for a measurement."""
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo")
+
+    def stub(_x, _y):
+        time.sleep(0.001 * (1 + rank))           # the last rank is the slowest: the line must carry ITS time
+        return None, torch.tensor(0.0), None
+    elapsed, _ = timed_steps(stub, None, None, a.steps, world, dist, torch.device("cpu"), sync=lambda: None)
+    if rank == 0:
+        res = headline(a, elapsed, a.batch, world, a.model == "resnet50_dann", 0.0, None)
+        res["metric"] = "dry run (launch rehearsal on CPU/gloo, no GPU work): " + res["metric"]
+        res["data"] = "none (dry run)"
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a, sys.argv[1:]))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    check_world(a, world)
+    if a.dry_run:
+        return dry_run(a, rank, world)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback in the product path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)

@@ -85,3 +85,66 @@ def test_office_headline_counts_both_passes():
     a = _args(model="resnet50_dann", batch=28, steps=5, gpus=8)
     res = bench.headline(a, 1.0, 2 * 28, 8, True, 3.0, 1.0)
     assert res["value"] == 5 * 56 * 8 and "Office-31" in res["config"]["workload"] and res["config"]["global_batch"] == 224
+
+
+# ---- round 5: `python bench.py --gpus N` must start N ranks by itself, and a rank count that differs
+#      from --gpus must stop every rank with a non-zero exit instead of printing n_gpus from somewhere else
+def test_launcher_command_line_for_8_gpus():
+    import bench
+    argv = ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    a = _args(gpus=8, steps=20, warmup=5)
+    cmd = bench.launcher_command(a, argv, port=29999)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == argv                                      # the ranks get the same arguments, --gpus 8 included
+
+
+def test_self_launch_is_a_child_process_and_relays_its_exit_code(monkeypatch):
+    import subprocess
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(os, "execv", lambda *a, **k: (_ for _ in ()).throw(AssertionError("never exec from bench.py")))
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    try:
+        bench.main()
+        raise AssertionError("main() must exit with the child's code")
+    except SystemExit as e:
+        assert e.code == 7
+    assert "--nproc-per-node=4" in seen["cmd"] and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_world_size_mismatch_exits_non_zero():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "--gpus 8 but WORLD_SIZE=2" in r.stderr and r.stdout.strip() == ""
+
+
+def test_gpus_2_dry_run_through_the_self_launch():
+    """The whole chain on the CPU: parent -> torch.distributed.run child -> 2 gloo ranks -> fences, MAX over ranks -> one JSON
+    line on the parent's stdout with n_gpus 2."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["MASTER_PORT"] = str(port)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--dry-run"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 5 and res["config"]["parallelism"] == "dp2" and res["metric"].startswith("dry run")
+    assert res["ms_per_step"] >= 2.0                                # rank 1 sleeps 2 ms per step: the slowest rank's clock
+    assert res["value"] == 5 * 128 * 2 / (res["ms_per_step"] * 5e-3) or abs(res["value"] * res["ms_per_step"] * 5e-3 - 1280) < 1e-6
