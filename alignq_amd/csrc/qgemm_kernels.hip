@@ -1,0 +1,636 @@
+// qgemm_kernels.hip — Conv2d_Q's convolution (reference: cdf_alignment_admm/dann_office/model/quantization.py:164-181,
+// F.conv2d(input, weight_q, ...); callers model/resnet.py:31-41 conv3x3 / conv1x1, Bottleneck :104-110, :131-156) at the
+// ResNet-50 shapes of BASELINE config 5: channels-last fp32 tensors, C_in / C_out multiples of 64, 1x1 (stride 1 or 2) and 3x3
+// (padding 1).  Forward, data gradient and filter gradient as GEMMs on the bf16 / f16 matrix cores with EXACT products:
+//   * the filter is weight_quantize_fn's output W_q = b / n, integer bins |b| <= n = 2^k - 1 <= 255: the operand is b itself
+//     (exact in bf16's 8 and f16's 11 significant bits), recovered as rint(W_q * n) while the tile is staged;
+//   * a general fp32 activation / gradient is split exactly into THREE bf16 terms hi + mid + lo while its tile is staged
+//     (three v_mfma_f32_16x16x32_bf16 per step): every product bin x term is exact in fp32, accumulation is fp32;
+//   * an activation known to be a quantiser output x_q = idx / n_a (the `relu(act_q(bn(.)))` tensors that feed conv2 / conv3
+//     of a bottleneck; idx <= r * n_a <= 2048) enters as ONE f16 term idx = rint(x_q * n_a) (v_mfma_f32_16x16x32_f16): the sum is
+//     an integer, divided by n * n_a once in the epilogue;
+//   * filter gradient: dy in three bf16 terms, x in three (the six leading pairs: everything above 2^-24 relative) or, for a
+//     level tensor, its index in two exact bf16 terms (all six pairs): fp32-grade sums, deterministic split-K slabs reduced in
+//     fixed order by alignq_conv3x3_wgrad_reduce_multi (no atomics, no zero-fill).
+// MFMA roles: A operand = filter side (rows of D = output channels, 4 consecutive per lane -> one float4 store per lane),
+// B operand = pixel side (columns of D).  One workgroup = 256 threads = 4 waves; a wave owns 64 channels x 16*TM pixels.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/alignq.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+constexpr int BK = 64;            // k per step of the forward / data-gradient GEMM (two MFMA k-substeps)
+constexpr int LDK = BK + 8;       // halfwords per row of a direct image: 144 B rows, 16 lanes of a ds_read_b128 on 16 slots
+
+// 4 rows x 16 columns block at `p` (this lane's row (lane & 15) >> 2, columns 4 * (lane & 3)), transposed by the LDS hardware:
+// the lane receives column (lane & 15) of the 4 rows.  EXEC all ones at every call.
+__device__ __forceinline__ s16x4 tr_read(const u16* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+__device__ __forceinline__ s16x8 join8(s16x4 a, s16x4 b) { return (s16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
+
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma16(s16x8 a, s16x8 b, f32x4 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// exact three-way split of four floats: v == hi + mid + lo
+__device__ __forceinline__ void split3(const f32x4 v, s16x4& h, s16x4& m, s16x4& l) {
+  bf16x4 h4, m4, l4;
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const __bf16 hi = (__bf16)v[e];
+    const float r1 = v[e] - (float)hi;
+    const __bf16 mi = (__bf16)r1;
+    h4[e] = hi; m4[e] = mi; l4[e] = (__bf16)(r1 - (float)mi);
+  }
+  h = __builtin_bit_cast(s16x4, h4); m = __builtin_bit_cast(s16x4, m4); l = __builtin_bit_cast(s16x4, l4);
+}
+// integer-valued floats |v| < 2^16 in two exact bf16 terms
+__device__ __forceinline__ void split2(const f32x4 v, s16x4& h, s16x4& l) {
+  bf16x4 h4, l4;
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const __bf16 hi = (__bf16)v[e];
+    h4[e] = hi; l4[e] = (__bf16)(v[e] - (float)hi);
+  }
+  h = __builtin_bit_cast(s16x4, h4); l = __builtin_bit_cast(s16x4, l4);
+}
+template <bool F16>
+__device__ __forceinline__ s16x4 to_half4(const f32x4 v) {      // exact for the integers this file feeds it
+  if constexpr (F16) {
+    const f16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    return __builtin_bit_cast(s16x4, h);
+  } else {
+    const bf16x4 h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    return __builtin_bit_cast(s16x4, h);
+  }
+}
+__device__ __forceinline__ f32x4 rint4(const f32x4 v, float s) {
+  return (f32x4){rintf(v[0] * s), rintf(v[1] * s), rintf(v[2] * s), rintf(v[3] * s)};
+}
+
+// Workgroups that share operand rows on one XCD (blockIdx round-robins over the 8 XCDs, each with its own L2): bijective for any n.
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+  const int q = n >> 3, r = n & 7, x = id & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Forward and data gradient:  out[row m][col n] = (1 / den) * sum_k  A[m][k] * Wb[n][k]
+//   rows m  : pixels of the ROW grid [img][Hr][Wr] (forward: output pixels; data gradient: input pixels, or - SCATTER, the 1x1
+//             stride-2 data gradient - dy's own pixels whose result goes to input pixel (2h, 2w) with zeros around it);
+//   A[m][k] : k = (tap, channel) of the activation-side tensor xa ([img][Ha][Wa][CA], forward x, data gradient dy) at pixel
+//             (hr * S + sgn * (ky - PAD), wr * S + sgn * (kx - PAD)), zero outside the image;
+//   Wb[n][k]: forward (WTR = false) w[n][tap][c] - rows k-contiguous; data gradient (WTR = true) w[c][tap][n]: the staged image is
+//             [k][n] and the fragments come through ds_read_b64_tr_b16.
+struct QG {
+  const float* xa; const float* w; float* out;
+  int Mg, groups, tiles_per_group, n_tiles;       // rows per group (a tile never straddles two groups), row tiles, column tiles
+  int N, CA, KC;                                   // output columns, channels of xa, KC = CA / BK k-steps per tap
+  int Hr, Wr, Ha, Wa, S, sgn;                      // row grid, xa grid, stride from row grid to xa grid, tap direction
+  int wrow, wtap;                                  // filter strides (elements): between rows of the staged filter image, per tap
+  int Ho, Wo;                                      // SCATTER: the output grid (H_in, W_in of the convolution)
+  float nlev, xlev;                                // filter bins = rint(w * nlev); MODE 1: index = rint(x * xlev)
+  double* bn_part;                                 // forward: [groups][tiles_per_group][N][2] {sum y, sum y^2} or nullptr
+};
+
+template <int WN, int TM, int MODE, bool WTR, bool KS3, bool SCATTER>
+__global__ __launch_bounds__(256, 2) void qgemm_kernel(const QG a) {
+  constexpr int WM = 4 / WN, BM = WM * 16 * TM, BN = 64 * WN;
+  constexpr int TA = MODE == 0 ? 3 : 1;
+  constexpr bool F16 = MODE == 1;
+  constexpr int NA = BM / 16;                      // float4 per thread of the pixel-side tile (16 float4 per row of BK)
+  constexpr int NB = BN / 16;                      // float4 per thread of the filter tile
+  constexpr int LDN = BN + 16;                     // halfwords per row of the transposed filter image
+  constexpr int XPL = BM * LDK;                    // halfwords per pixel-side plane
+  constexpr int WSZ = WTR ? BK * LDN : BN * LDK;
+  constexpr int RED_HW = BN * WM * 16 * 4;      // halfwords of the epilogue's statistics buffer [BN][WM * 16][2] floats
+  constexpr int LDS_HW = (TA * XPL + WSZ) > RED_HW ? (TA * XPL + WSZ) : RED_HW;
+  __shared__ __attribute__((aligned(16))) u16 lds[LDS_HW];
+  u16* const Xs = lds;
+  u16* const Ws = lds + TA * XPL;
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wn = wv % WN, wm = wv / WN;
+  const int pid = xcd_remap(blockIdx.x, gridDim.x);
+  const int nt = pid % a.n_tiles, mt_all = pid / a.n_tiles;
+  const int grp = mt_all / a.tiles_per_group, mt = mt_all % a.tiles_per_group;
+  const int m_lo = grp * a.Mg + mt * BM, m_end = (grp + 1) * a.Mg;
+  const int n0 = nt * BN;
+
+  // ---- this thread's rows of the pixel-side tile: row r = (tid >> 4) + 16 i, float4 column c4 = tid & 15 ------------------------
+  const int c4 = tid & 15, rr = tid >> 4;
+  int pix[NA];             // pixel index of xa at the centre tap, -1: row beyond the group
+  int hw[NA];              // KS3: (h << 16) | w of that pixel in the xa grid
+#pragma unroll
+  for (int i = 0; i < NA; i++) {
+    const int m = m_lo + rr + 16 * i;
+    if (m < m_end) {
+      const int wr = m % a.Wr, t = m / a.Wr, hr = t % a.Hr, img = t / a.Hr;
+      pix[i] = (img * a.Ha + hr * a.S) * a.Wa + wr * a.S;
+      hw[i] = ((hr * a.S) << 16) | (wr * a.S);
+    } else {
+      pix[i] = -1;
+      hw[i] = 0;
+    }
+  }
+  const int nk = (KS3 ? 9 : 1) * a.KC;
+  f32x4 ra[NA], rw[NB];
+
+  auto fetch = [&](int kt) {
+    const int tap = KS3 ? kt / a.KC : 0, c0 = (KS3 ? kt % a.KC : kt) * BK;
+    const int dy = KS3 ? a.sgn * (tap / 3 - 1) : 0, dx = KS3 ? a.sgn * (tap % 3 - 1) : 0;
+#pragma unroll
+    for (int i = 0; i < NA; i++) {
+      bool ok = pix[i] >= 0;
+      if (KS3) ok = ok && (unsigned)((hw[i] >> 16) + dy) < (unsigned)a.Ha && (unsigned)((hw[i] & 0xffff) + dx) < (unsigned)a.Wa;
+      const int64_t off = ok ? ((int64_t)(pix[i] + dy * a.Wa + dx) * a.CA + c0 + 4 * c4) : 0;
+      ra[i] = *reinterpret_cast<const f32x4*>(a.xa + off);
+      if (!ok) ra[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    if (!WTR) {           // rows n of the tile, 16 float4 of k each
+#pragma unroll
+      for (int i = 0; i < NB; i++)
+        rw[i] = *reinterpret_cast<const f32x4*>(a.w + (int64_t)(n0 + rr + 16 * i) * a.wrow + (int64_t)kt * BK + 4 * c4);
+    } else {              // rows k (channels of xa), BN / 4 float4 of n each
+#pragma unroll
+      for (int i = 0; i < NB; i++) {
+        const int idx = tid + 256 * i, kr = idx / (BN / 4), n4 = idx % (BN / 4);
+        rw[i] = *reinterpret_cast<const f32x4*>(a.w + (int64_t)(c0 + kr) * a.wrow + (int64_t)tap * a.wtap + n0 + 4 * n4);
+      }
+    }
+  };
+  auto park = [&]() {
+#pragma unroll
+    for (int i = 0; i < NA; i++) {
+      const int o = (rr + 16 * i) * LDK + 4 * c4;
+      if constexpr (MODE == 0) {
+        s16x4 h, m, l;
+        split3(ra[i], h, m, l);
+        *reinterpret_cast<s16x4*>(Xs + o) = h;
+        *reinterpret_cast<s16x4*>(Xs + XPL + o) = m;
+        *reinterpret_cast<s16x4*>(Xs + 2 * XPL + o) = l;
+      } else {
+        *reinterpret_cast<s16x4*>(Xs + o) = to_half4<true>(rint4(ra[i], a.xlev));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+      const s16x4 b = to_half4<F16>(rint4(rw[i], a.nlev));
+      if (!WTR) {
+        *reinterpret_cast<s16x4*>(Ws + (rr + 16 * i) * LDK + 4 * c4) = b;
+      } else {
+        const int idx = tid + 256 * i, kr = idx / (BN / 4), n4 = idx % (BN / 4);
+        *reinterpret_cast<s16x4*>(Ws + kr * LDN + 4 * n4) = b;
+      }
+    }
+  };
+
+  f32x4 acc[4][TM];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < TM; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fg = lane >> 4, fq = (lane & 15) >> 2, fc = 4 * (lane & 3);
+  fetch(0);
+  for (int kt = 0; kt < nk; kt++) {
+    __syncthreads();                         // the previous step's fragment reads are done
+    park();
+    __syncthreads();
+    if (kt + 1 < nk) fetch(kt + 1);          // in flight under this step's MFMAs
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      s16x8 wf[4];
+#pragma unroll
+      for (int tn = 0; tn < 4; tn++) {
+        if (!WTR) {
+          wf[tn] = *reinterpret_cast<const s16x8*>(Ws + (wn * 64 + tn * 16 + fr) * LDK + ks * 32 + 8 * fg);
+        } else {
+          const u16* p = Ws + (ks * 32 + 8 * fg + fq) * LDN + wn * 64 + tn * 16 + fc;
+          wf[tn] = join8(tr_read(p), tr_read(p + 4 * LDN));
+        }
+      }
+#pragma unroll
+      for (int tm = 0; tm < TM; tm++) {
+        const u16* p = Xs + ((wm * TM + tm) * 16 + fr) * LDK + ks * 32 + 8 * fg;
+#pragma unroll
+        for (int t = TA - 1; t >= 0; t--) {           // smallest term first
+          const s16x8 xf = *reinterpret_cast<const s16x8*>(p + t * XPL);
+#pragma unroll
+          for (int tn = 0; tn < 4; tn++) acc[tn][tm] = mfma16<F16>(wf[tn], xf, acc[tn][tm]);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: lane = pixel (lane & 15) of the 16-pixel tile, 4 consecutive channels 4 * (lane >> 4) + e ----------------------
+  const float den = MODE == 1 ? a.nlev * a.xlev : a.nlev;
+  float bs[4][4], bq[4][4];                           // [tn][e]: this lane's sums over its TM pixels (forward statistics)
+#pragma unroll
+  for (int tn = 0; tn < 4; tn++)
+#pragma unroll
+    for (int e = 0; e < 4; e++) { bs[tn][e] = 0.f; bq[tn][e] = 0.f; }
+#pragma unroll
+  for (int tm = 0; tm < TM; tm++) {
+    const int m = m_lo + (wm * TM + tm) * 16 + fr;
+    const bool ok = m < m_end;
+    int64_t orow = (int64_t)m * a.N;
+    bool z01 = false, z10 = false;
+    if (SCATTER) {
+      const int mm = ok ? m : m_lo;
+      const int wr = mm % a.Wr, t = mm / a.Wr, hr = t % a.Hr, img = t / a.Hr;
+      orow = ((int64_t)(img * a.Ho + 2 * hr) * a.Wo + 2 * wr) * a.N;
+      z01 = 2 * wr + 1 < a.Wo;
+      z10 = 2 * hr + 1 < a.Ho;
+    }
+#pragma unroll
+    for (int tn = 0; tn < 4; tn++) {
+      const int n = n0 + wn * 64 + tn * 16 + 4 * fg;
+      f32x4 v = acc[tn][tm];
+      v = (f32x4){v[0] / den, v[1] / den, v[2] / den, v[3] / den};
+      if (ok) {
+        *reinterpret_cast<f32x4*>(a.out + orow + n) = v;
+        if (SCATTER) {
+          const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          if (z01) *reinterpret_cast<f32x4*>(a.out + orow + a.N + n) = z;
+          if (z10) *reinterpret_cast<f32x4*>(a.out + orow + (int64_t)a.Wo * a.N + n) = z;
+          if (z01 && z10) *reinterpret_cast<f32x4*>(a.out + orow + (int64_t)(a.Wo + 1) * a.N + n) = z;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) { bs[tn][e] += v[e]; bq[tn][e] += v[e] * v[e]; }
+      }
+    }
+  }
+  if (a.bn_part) {
+    // per-channel {sum y, sum y^2} of the tile for the batch-norm that follows: the floats of every lane (TM values each) meet in
+    // LDS and one thread per channel adds them in double, in a fixed order
+    float* red = reinterpret_cast<float*>(lds);       // [BN channels][WM * 16 slots][2]
+    constexpr int SL = WM * 16;
+    static_assert(BN * SL * 4 == RED_HW, "reduction buffer size");
+    __syncthreads();
+#pragma unroll
+    for (int tn = 0; tn < 4; tn++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int ch = wn * 64 + tn * 16 + 4 * fg + e;
+        red[(ch * SL + wm * 16 + fr) * 2] = bs[tn][e];
+        red[(ch * SL + wm * 16 + fr) * 2 + 1] = bq[tn][e];
+      }
+    __syncthreads();
+    if (tid < BN) {
+      double s0 = 0, s1 = 0;
+#pragma unroll 8
+      for (int s = 0; s < SL; s++) { s0 += (double)red[(tid * SL + s) * 2]; s1 += (double)red[(tid * SL + s) * 2 + 1]; }
+      double* p = a.bn_part + (((int64_t)grp * a.tiles_per_group + mt) * a.N + n0 + tid) * 2;
+      p[0] = s0;
+      p[1] = s1;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Filter gradient:  slab[split][n][tap][c] = sum over the split's pixels m of  dy[m][n] * x[pixel(m, tap)][c]
+// Both tiles are staged [k = pixel][channel] (32 pixels per step) and read through ds_read_b64_tr_b16; lane group g takes pixels
+// {4g .. 4g+3} and {16 + 4g .. 16 + 4g + 3} of the step (the contraction index is a dummy: both operands use the same order), so
+// that the 32 lanes of one LDS cycle touch 8 different rows = all 64 banks.  D rows = c (4 consecutive per lane -> float4 store).
+constexpr int WK = 32;
+struct QW {
+  const float* x; const float* dy; float* slabs;
+  int M, per;                      // dy pixels in all, pixels per split (multiple of WK)
+  int CIN, COUT, c_tiles, n_tiles, taps;
+  int Hr, Wr, Ha, Wa, S;           // dy grid, x grid, stride
+  float xlev;                      // TX == 2: x index = rint(x * xlev), the slab is divided by xlev
+};
+
+template <int TC, int TN, int TX, bool GATHER>
+__global__ __launch_bounds__(256, 2) void qgemm_wgrad_kernel(const QW a) {
+  constexpr int BC = 32 * TC, BNO = 32 * TN;       // tile: BC input channels x BNO output channels; wave = (16 TC) x (16 TN)
+  constexpr int LDC = BC + 16, LDO = BNO + 16;
+  constexpr int XPL = WK * LDC, DPL = WK * LDO;
+  constexpr int NX = (WK * BC / 4) / 256, ND = (WK * BNO / 4) / 256;
+  __shared__ __attribute__((aligned(16))) u16 lds[TX * XPL + 3 * DPL];
+  u16* const Xs = lds;
+  u16* const Ds = lds + TX * XPL;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wc = wv & 1, wo = wv >> 1;
+  const int tiles = a.c_tiles * a.n_tiles * a.taps;
+  const int pid = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = pid / tiles, tile = pid % tiles;
+  const int tap = tile % a.taps, ct = (tile / a.taps) % a.c_tiles, ot = tile / (a.taps * a.c_tiles);
+  const int c0 = ct * BC, o0 = ot * BNO;
+  const int m_begin = split * a.per, m_end = (m_begin + a.per < a.M) ? m_begin + a.per : a.M;
+  const int dyy = GATHER ? tap / 3 - (a.taps == 9 ? 1 : 0) : 0, dxx = GATHER ? tap % 3 - (a.taps == 9 ? 1 : 0) : 0;
+
+  f32x4 rx[NX], rd[ND];
+  auto fetch = [&](int m0) {
+#pragma unroll
+    for (int i = 0; i < NX; i++) {
+      const int idx = tid + 256 * i, kr = idx / (BC / 4), q4 = idx % (BC / 4);
+      const int m = m0 + kr;
+      bool ok = m < m_end;
+      int64_t p = m;
+      if (GATHER) {
+        const int mm = ok ? m : 0;
+        const int wr = mm % a.Wr, t = mm / a.Wr, hr = t % a.Hr, img = t / a.Hr;
+        const int h = hr * a.S + dyy, w = wr * a.S + dxx;
+        ok = ok && (unsigned)h < (unsigned)a.Ha && (unsigned)w < (unsigned)a.Wa;
+        p = (int64_t)(img * a.Ha + h) * a.Wa + w;
+      }
+      rx[i] = *reinterpret_cast<const f32x4*>(a.x + (ok ? p * a.CIN + c0 + 4 * q4 : 0));
+      if (!ok) rx[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < ND; i++) {
+      const int idx = tid + 256 * i, kr = idx / (BNO / 4), q4 = idx % (BNO / 4);
+      const int m = m0 + kr;
+      const bool ok = m < m_end;
+      rd[i] = *reinterpret_cast<const f32x4*>(a.dy + (ok ? (int64_t)m * a.COUT + o0 + 4 * q4 : 0));
+      if (!ok) rd[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto park = [&]() {
+#pragma unroll
+    for (int i = 0; i < NX; i++) {
+      const int idx = tid + 256 * i, kr = idx / (BC / 4), q4 = idx % (BC / 4);
+      const int o = kr * LDC + 4 * q4;
+      if constexpr (TX == 3) {
+        s16x4 h, m, l;
+        split3(rx[i], h, m, l);
+        *reinterpret_cast<s16x4*>(Xs + o) = h;
+        *reinterpret_cast<s16x4*>(Xs + XPL + o) = m;
+        *reinterpret_cast<s16x4*>(Xs + 2 * XPL + o) = l;
+      } else {
+        s16x4 h, l;
+        split2(rint4(rx[i], a.xlev), h, l);
+        *reinterpret_cast<s16x4*>(Xs + o) = h;
+        *reinterpret_cast<s16x4*>(Xs + XPL + o) = l;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < ND; i++) {
+      const int idx = tid + 256 * i, kr = idx / (BNO / 4), q4 = idx % (BNO / 4);
+      const int o = kr * LDO + 4 * q4;
+      s16x4 h, m, l;
+      split3(rd[i], h, m, l);
+      *reinterpret_cast<s16x4*>(Ds + o) = h;
+      *reinterpret_cast<s16x4*>(Ds + DPL + o) = m;
+      *reinterpret_cast<s16x4*>(Ds + 2 * DPL + o) = l;
+    }
+  };
+
+  f32x4 acc[TC][TN];
+#pragma unroll
+  for (int i = 0; i < TC; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int fg = lane >> 4, fq = (lane & 15) >> 2, fc = 4 * (lane & 3);
+  const int krow = 4 * fg + fq;                       // first pixel row of this lane's block (second: + 16)
+  if (m_begin < m_end) fetch(m_begin);
+  for (int m0 = m_begin; m0 < m_end; m0 += WK) {
+    __syncthreads();
+    park();
+    __syncthreads();
+    if (m0 + WK < m_end) fetch(m0 + WK);
+    s16x8 xf[TC][TX];
+#pragma unroll
+    for (int tc = 0; tc < TC; tc++)
+#pragma unroll
+      for (int t = 0; t < TX; t++) {
+        const u16* p = Xs + t * XPL + krow * LDC + (wc * TC + tc) * 16 + fc;
+        xf[tc][t] = join8(tr_read(p), tr_read(p + 16 * LDC));
+      }
+#pragma unroll
+    for (int tn = 0; tn < TN; tn++) {
+      s16x8 df[3];
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        const u16* p = Ds + t * DPL + krow * LDO + (wo * TN + tn) * 16 + fc;
+        df[t] = join8(tr_read(p), tr_read(p + 16 * LDO));
+      }
+#pragma unroll
+      for (int tc = 0; tc < TC; tc++) {
+        f32x4 v = acc[tc][tn];
+        if constexpr (TX == 3) {          // the six leading pairs, smallest first
+          v = mfma16<false>(xf[tc][1], df[1], v);
+          v = mfma16<false>(xf[tc][0], df[2], v);
+          v = mfma16<false>(xf[tc][2], df[0], v);
+          v = mfma16<false>(xf[tc][0], df[1], v);
+          v = mfma16<false>(xf[tc][1], df[0], v);
+          v = mfma16<false>(xf[tc][0], df[0], v);
+        } else {                          // index = hi + lo exactly: all six pairs
+          v = mfma16<false>(xf[tc][1], df[2], v);
+          v = mfma16<false>(xf[tc][1], df[1], v);
+          v = mfma16<false>(xf[tc][0], df[2], v);
+          v = mfma16<false>(xf[tc][1], df[0], v);
+          v = mfma16<false>(xf[tc][0], df[1], v);
+          v = mfma16<false>(xf[tc][0], df[0], v);
+        }
+        acc[tc][tn] = v;
+      }
+    }
+  }
+  // D: column = output channel (lane & 15), rows = input channels 4 * (lane >> 4) + e
+  float* slab = a.slabs + (int64_t)split * a.COUT * a.taps * a.CIN;
+#pragma unroll
+  for (int tn = 0; tn < TN; tn++) {
+    const int o = o0 + (wo * TN + tn) * 16 + (lane & 15);
+#pragma unroll
+    for (int tc = 0; tc < TC; tc++) {
+      const int c = c0 + (wc * TC + tc) * 16 + 4 * fg;
+      f32x4 v = acc[tc][tn];
+      if constexpr (TX == 2) v = (f32x4){v[0] / a.xlev, v[1] / a.xlev, v[2] / a.xlev, v[3] / a.xlev};
+      __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(slab + ((int64_t)o * a.taps + tap) * a.CIN + c));
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void qgemm_slab_sum_kernel(const float* __restrict__ slabs, int n_slabs, int64_t n_elem,
+                                                             float* __restrict__ dw) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n_elem) return;
+  f32x4 s = *reinterpret_cast<const f32x4*>(slabs + i);
+  for (int k = 1; k < n_slabs; k++) s = s + *reinterpret_cast<const f32x4*>(slabs + (int64_t)k * n_elem + i);      // fixed order
+  *reinterpret_cast<f32x4*>(dw + i) = s;
+}
+
+bool shape_ok(int B, int H, int W, int CIN, int COUT, int KS, int stride) {
+  if (B < 1 || H < 1 || W < 1 || CIN < 64 || COUT < 64 || CIN % 64 || COUT % 64) return false;
+  if (!((KS == 1 && (stride == 1 || stride == 2)) || (KS == 3 && (stride == 1 || stride == 2)))) return false;
+  if (H > 32767 || W > 32767) return false;
+  const int64_t Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  if ((int64_t)B * H * W * (CIN > COUT ? CIN : COUT) >= (int64_t)1 << 40) return false;
+  if ((int64_t)B * H * W >= (int64_t)1 << 30 || (int64_t)B * Ho * Wo < 1) return false;
+  return true;
+}
+
+template <int WN, int TM, int MODE, bool WTR, bool KS3, bool SCATTER>
+int launch_g(const QG& a, hipStream_t st) {
+  const int grid = a.groups * a.tiles_per_group * a.n_tiles;
+  hipLaunchKernelGGL((qgemm_kernel<WN, TM, MODE, WTR, KS3, SCATTER>), dim3(grid), dim3(256), 0, st, a);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+// tile choice: 64 columns -> 128 rows x 64 (WN = 1, TM = 2), else 128 x 128 (WN = 2, TM = 4)
+template <int MODE, bool WTR, bool KS3, bool SCATTER>
+int launch_g_tiles(QG a, hipStream_t st) {
+  if (a.N % 128 == 0) {
+    constexpr int BM = 128;
+    a.tiles_per_group = (a.Mg + BM - 1) / BM;
+    a.n_tiles = a.N / 128;
+    return launch_g<2, 4, MODE, WTR, KS3, SCATTER>(a, st);
+  }
+  constexpr int BM = 128;
+  a.tiles_per_group = (a.Mg + BM - 1) / BM;
+  a.n_tiles = a.N / 64;
+  return launch_g<1, 2, MODE, WTR, KS3, SCATTER>(a, st);
+}
+
+int wgrad_splits(int64_t M, int tiles) {
+  int s = (512 + tiles - 1) / tiles;
+  const int64_t max_s = (M + 2 * WK - 1) / (2 * WK);       // at least two steps per split
+  if (s > max_s) s = (int)max_s;
+  if (s < 1) s = 1;
+  if (s > 1024) s = 1024;
+  return s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int alignq_qconv_supported(int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride) {
+  return shape_ok(B, H_in, W_in, CIN, COUT, KS, stride) ? 1 : 0;
+}
+
+int alignq_qconv_bn_parts(int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride, int groups) {
+  if (!shape_ok(B, H_in, W_in, CIN, COUT, KS, stride) || groups < 1 || B % groups) return 0;
+  const int Ho = (H_in - 1) / stride + 1, Wo = (W_in - 1) / stride + 1;
+  return (int)(((int64_t)(B / groups) * Ho * Wo + 127) / 128);
+}
+
+int alignq_qconv_fwd(const float* x, const float* wt, float* y, int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride,
+                     int w_bit, float x_levels, int groups, double* bn_part, void* stream) {
+  if (!x || !wt || !y || w_bit < 1 || w_bit > 8 || groups < 1) return ALIGNQ_EINVAL;
+  if (!shape_ok(B, H_in, W_in, CIN, COUT, KS, stride) || B % groups) return ALIGNQ_EUNSUPPORTED;
+  if (x_levels != 0.0f && !(x_levels >= 1.0f)) return ALIGNQ_EINVAL;
+  const int Ho = (H_in - 1) / stride + 1, Wo = (W_in - 1) / stride + 1;
+  QG a{};
+  a.xa = x; a.w = wt; a.out = y;
+  a.Mg = (B / groups) * Ho * Wo; a.groups = groups;
+  a.N = COUT; a.CA = CIN; a.KC = CIN / BK;
+  a.Hr = Ho; a.Wr = Wo; a.Ha = H_in; a.Wa = W_in; a.S = stride; a.sgn = 1;
+  a.wrow = KS * KS * CIN; a.wtap = CIN;
+  a.Ho = Ho; a.Wo = Wo;
+  a.nlev = (float)((1 << w_bit) - 1); a.xlev = x_levels;
+  a.bn_part = bn_part;
+  hipStream_t st = (hipStream_t)stream;
+  if (KS == 3) return x_levels != 0.0f ? launch_g_tiles<1, false, true, false>(a, st) : launch_g_tiles<0, false, true, false>(a, st);
+  return x_levels != 0.0f ? launch_g_tiles<1, false, false, false>(a, st) : launch_g_tiles<0, false, false, false>(a, st);
+}
+
+int alignq_qconv_dgrad(const float* dy, const float* wt, float* dx, int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride,
+                       int w_bit, void* stream) {
+  if (!dy || !wt || !dx || w_bit < 1 || w_bit > 8) return ALIGNQ_EINVAL;
+  if (!shape_ok(B, H_in, W_in, CIN, COUT, KS, stride)) return ALIGNQ_EUNSUPPORTED;
+  if (KS == 3 && stride != 1) return ALIGNQ_EUNSUPPORTED;
+  const int Ho = (H_in - 1) / stride + 1, Wo = (W_in - 1) / stride + 1;
+  QG a{};
+  a.xa = dy; a.w = wt; a.out = dx;
+  a.groups = 1;
+  a.N = CIN; a.CA = COUT; a.KC = COUT / BK;
+  a.Ha = Ho; a.Wa = Wo; a.S = 1; a.sgn = -1;
+  a.wrow = KS * KS * CIN; a.wtap = CIN;
+  a.Ho = H_in; a.Wo = W_in;
+  a.nlev = (float)((1 << w_bit) - 1); a.xlev = 0.f;
+  a.bn_part = nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  if (stride == 2) {         // 1x1: rows = dy's pixels, scattered to (2h, 2w) with zeros at the other three pixels of the 2x2 cell
+    a.Mg = B * Ho * Wo; a.Hr = Ho; a.Wr = Wo;
+    return launch_g_tiles<0, true, false, true>(a, st);
+  }
+  a.Mg = B * H_in * W_in; a.Hr = H_in; a.Wr = W_in;
+  if (KS == 3) return launch_g_tiles<0, true, true, false>(a, st);
+  return launch_g_tiles<0, true, false, false>(a, st);
+}
+
+static int wgrad_geometry(int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride, int* tc, int* tn, int* tiles, int* splits,
+                          int64_t* M) {
+  const int Ho = (H_in - 1) / stride + 1, Wo = (W_in - 1) / stride + 1;
+  *M = (int64_t)B * Ho * Wo;
+  *tc = CIN % 128 == 0 ? 4 : 2;
+  *tn = COUT % 128 == 0 ? 4 : 2;
+  *tiles = (CIN / (32 * *tc)) * (COUT / (32 * *tn)) * KS * KS;
+  *splits = wgrad_splits(*M, *tiles);
+  return 0;
+}
+
+size_t alignq_qconv_wgrad_ws_bytes(int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride) {
+  if (!shape_ok(B, H_in, W_in, CIN, COUT, KS, stride)) return 0;
+  int tc, tn, tiles, splits;
+  int64_t M;
+  wgrad_geometry(B, H_in, W_in, CIN, COUT, KS, stride, &tc, &tn, &tiles, &splits, &M);
+  return (size_t)splits * (size_t)COUT * KS * KS * CIN * sizeof(float);
+}
+
+int alignq_qconv_wgrad(const float* x, const float* dy, float* dw, void* ws, int B, int H_in, int W_in, int CIN, int COUT, int KS,
+                       int stride, float x_levels, int* n_slabs_out, void* stream) {
+  if (!x || !dy || !ws || (!dw && !n_slabs_out)) return ALIGNQ_EINVAL;
+  if (!shape_ok(B, H_in, W_in, CIN, COUT, KS, stride)) return ALIGNQ_EUNSUPPORTED;
+  if (x_levels != 0.0f && !(x_levels >= 1.0f)) return ALIGNQ_EINVAL;
+  int tc, tn, tiles, splits;
+  int64_t M;
+  wgrad_geometry(B, H_in, W_in, CIN, COUT, KS, stride, &tc, &tn, &tiles, &splits, &M);
+  QW a{};
+  a.x = x; a.dy = dy; a.slabs = (float*)ws;
+  a.M = (int)M;
+  int64_t per = (M + splits - 1) / splits;
+  per = (per + WK - 1) / WK * WK;
+  a.per = (int)per;
+  a.CIN = CIN; a.COUT = COUT; a.c_tiles = CIN / (32 * tc); a.n_tiles = COUT / (32 * tn); a.taps = KS * KS;
+  a.Hr = (H_in - 1) / stride + 1; a.Wr = (W_in - 1) / stride + 1; a.Ha = H_in; a.Wa = W_in; a.S = stride;
+  a.xlev = x_levels;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(tiles * splits), blk(256);
+  const bool gather = KS == 3 || stride != 1;
+  const bool lev = x_levels != 0.0f;
+#define QW_LAUNCH(TC_, TN_)                                                                                              \
+  do {                                                                                                                   \
+    if (lev) {                                                                                                           \
+      if (gather) hipLaunchKernelGGL((qgemm_wgrad_kernel<TC_, TN_, 2, true>), grid, blk, 0, st, a);                       \
+      else hipLaunchKernelGGL((qgemm_wgrad_kernel<TC_, TN_, 2, false>), grid, blk, 0, st, a);                             \
+    } else {                                                                                                             \
+      if (gather) hipLaunchKernelGGL((qgemm_wgrad_kernel<TC_, TN_, 3, true>), grid, blk, 0, st, a);                       \
+      else hipLaunchKernelGGL((qgemm_wgrad_kernel<TC_, TN_, 3, false>), grid, blk, 0, st, a);                             \
+    }                                                                                                                    \
+  } while (0)
+  if (tc == 4 && tn == 4) QW_LAUNCH(4, 4);
+  else if (tc == 2 && tn == 4) QW_LAUNCH(2, 4);
+  else if (tc == 4 && tn == 2) QW_LAUNCH(4, 2);
+  else QW_LAUNCH(2, 2);
+#undef QW_LAUNCH
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  if (n_slabs_out) { *n_slabs_out = splits; return 0; }      // deferred: the caller reduces (alignq_conv3x3_wgrad_reduce_multi)
+  const int64_t n_elem = (int64_t)COUT * KS * KS * CIN;
+  hipLaunchKernelGGL(qgemm_slab_sum_kernel, dim3((unsigned)((n_elem / 4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, splits,
+                     n_elem, dw);
+  e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+}  // extern "C"

@@ -862,6 +862,103 @@ def transition_supported(conv3, conv1, x, w3, w1) -> bool:
             and qconv_gen_supported(*a1))
 
 
+def qconv_gemm_supported(x, w, stride, padding, dilation, groups, bias, w_bit) -> bool:
+    """The Conv2d_Q convolutions alignq_qconv_* take (the ResNet-50 / Office-31 shapes of BASELINE config 5): channels-last fp32,
+    C_in and C_out multiples of 64, 1x1 (padding 0) or 3x3 (padding 1), stride 1 or 2, <= 8-bit quantised filter."""
+    if bias is not None or groups != 1 or not (1 <= w_bit <= 8) or tuple(dilation) != (1, 1):
+        return False
+    if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and w.dtype == torch.float32 and w.is_cuda):
+        return False
+    B, CIN, H, W = x.shape
+    COUT, ks = w.shape[0], w.shape[2]
+    if w.shape[1] != CIN or w.shape[3] != ks or ks not in (1, 3) or tuple(padding) != ((ks - 1) // 2,) * 2:
+        return False
+    if stride[0] != stride[1] or stride[0] not in (1, 2):
+        return False
+    cl = torch.channels_last
+    if not (x.is_contiguous(memory_format=cl) and (ks == 1 or w.is_contiguous(memory_format=cl))):
+        return False
+    return bool(L.load().alignq_qconv_supported(B, H, W, CIN, COUT, ks, int(stride[0])))
+
+
+def level_count(t):
+    """n_a if `t` is known to hold quantiser outputs idx / n_a with integer |idx| <= 2048 (the tag the folded quantiser chains
+    put on their outputs, fused.tag_levels), else 0.0."""
+    return float(getattr(t, "_alignq_levels", 0.0) or 0.0)
+
+
+class QConvGemmFn(torch.autograd.Function):
+    """F.conv2d(input, weight_q, None, stride, padding) of Conv2d_Q.forward (cdf_alignment_admm/dann_office/model/quantization.py:
+    164-181) at the ResNet-50 shapes on alignq_qconv_fwd / _dgrad / _wgrad (csrc/qgemm_kernels.hip): exact products on the bf16 /
+    f16 matrix cores.  x_levels: see level_count (0.0: a general fp32 input).  The filter gradient's slab reduction is deferred to
+    fused.DeferredWgrads when such a context is active."""
+
+    @staticmethod
+    def forward(ctx, x, w, w_bit, stride, x_levels=0.0, groups=1, bn_stats=False):
+        B, CIN, H, W = x.shape
+        COUT, ks = w.shape[0], w.shape[2]
+        s = int(stride)
+        Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+        lib = L.load()
+        y = torch.empty((B, COUT, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        part = None
+        if bn_stats:
+            n_parts = lib.alignq_qconv_bn_parts(B, H, W, CIN, COUT, ks, s, int(groups))
+            part = torch.empty(int(groups), n_parts, COUT, 2, dtype=torch.float64, device=x.device)
+            QConvGemmFn._mailbox = (part, n_parts)
+        L.check(lib.alignq_qconv_fwd(L.ptr(x), L.ptr(w), L.ptr(y), B, H, W, CIN, COUT, ks, s, int(w_bit), float(x_levels),
+                                     int(groups if bn_stats else 1), L.ptr(part), L.stream_ptr()), "alignq_qconv_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (int(w_bit), s, float(x_levels), ks)
+        return y
+
+    _mailbox = None
+
+    @staticmethod
+    def apply_with_stats(x, w, w_bit, stride, x_levels=0.0, groups=1):
+        """apply(...) that also leaves the batch-norm partial statistics of the output on it: y._alignq_bnq_part =
+        (double tensor [groups, parts, C_out, 2], parts) for fused.bn_act_relu / bn_only / bn_site_res_relu."""
+        QConvGemmFn._mailbox = None
+        y = QConvGemmFn.apply(x, w, w_bit, stride, x_levels, groups, True)
+        if QConvGemmFn._mailbox is not None:
+            y._alignq_bnq_part = QConvGemmFn._mailbox + (int(groups),)
+            QConvGemmFn._mailbox = None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        w_bit, s, x_levels, ks = ctx.cfg
+        B, CIN, H, W = x.shape
+        COUT = w.shape[0]
+        lib = L.load()
+        cl = torch.channels_last
+        if not gy.is_contiguous(memory_format=cl):
+            gy = gy.contiguous(memory_format=cl)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            if ks == 3 and s != 1:      # the three stride-2 3x3 layers: MIOpen's data gradient (not among alignq_qconv_dgrad's shapes)
+                dx = torch.ops.aten.convolution_backward(gy, x, w, None, (s, s), (1, 1), (1, 1), False, (0, 0), 1,
+                                                         (True, False, False))[0]
+            else:
+                dx = torch.empty((B, CIN, H, W), dtype=torch.float32, device=x.device, memory_format=cl)
+                L.check(lib.alignq_qconv_dgrad(L.ptr(gy), L.ptr(w), L.ptr(dx), B, H, W, CIN, COUT, ks, s, w_bit, L.stream_ptr()),
+                        "alignq_qconv_dgrad")
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            ws = _ws(lib.alignq_qconv_wgrad_ws_bytes(B, H, W, CIN, COUT, ks, s), x.device)
+            pending = fused.active_wgrads()
+            if pending is not None:
+                ns = ctypes.c_int(0)
+                L.check(lib.alignq_qconv_wgrad(L.ptr(x), L.ptr(gy), None, L.ptr(ws), B, H, W, CIN, COUT, ks, s, x_levels,
+                                               ctypes.byref(ns), L.stream_ptr()), "alignq_qconv_wgrad")
+                pending.add(ws, dw, ns.value, COUT * ks * ks * CIN)
+            else:
+                L.check(lib.alignq_qconv_wgrad(L.ptr(x), L.ptr(gy), L.ptr(dw), L.ptr(ws), B, H, W, CIN, COUT, ks, s, x_levels, None,
+                                               L.stream_ptr()), "alignq_qconv_wgrad")
+        return dx, dw, None, None, None, None, None
+
+
 def qconv_stem_supported(x, w, stride, padding, dilation, groups, bias, w_bit) -> bool:
     """The stem convolution alignq_conv_stem_nhwc_fwd implements: 3 -> 16 channels, 3x3 / stride 1 / padding 1, width 32,
     channels-last fp32 input that needs no gradient, <= 8-bit quantised filter."""

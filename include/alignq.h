@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALIGNQ_ABI_VERSION 14
+#define ALIGNQ_ABI_VERSION 15
 
 #define ALIGNQ_FORMULA_ADMM 0
 #define ALIGNQ_FORMULA_CDF 1
@@ -325,6 +325,36 @@ size_t alignq_conv_gen_wgrad_ws_bytes(int CIN, int COUT, int KS);
 int alignq_conv_gen_nhwc_wgrad(const float* x, const float* dy, float* dw, void* ws, int B, int H_in, int W_in, int CIN,
                                int COUT, int KS, int stride, int* n_slabs_out, const float* bn_z, const float* bn_ab,
                                const float* bn_save, const float* bn_ktot, const float* bn_dx_part, void* stream);
+
+/* ---- Conv2d_Q's convolution at the ResNet-50 / Office-31 shapes (BASELINE config 5) as an exact-product GEMM -----------------
+ * Reference: cdf_alignment_admm/dann_office/model/quantization.py:164-181 (Conv2d_Q.forward: F.conv2d(input, weight_q, bias,
+ * stride, padding, dilation, groups)), built by model/resnet.py:31-41 (conv3x3 / conv1x1) and called from Bottleneck.forward
+ * :131-156 and the downsample branch :122-126; the gradients are what autograd derives from that call.
+ * Shapes: x [B, H_in, W_in, CIN] channels-last fp32; wt = weight_q [COUT, KS, KS, CIN] (channels-last storage of [COUT,CIN,KS,KS]),
+ * w_bit <= 8; y [B, H_out, W_out, COUT] with H_out = (H_in - 1) / stride + 1; CIN, COUT multiples of 64; KS = 1 (padding 0) or
+ * KS = 3 (padding 1), stride 1 or 2; no bias, no groups, no dilation.  alignq_qconv_supported says whether a shape is taken.
+ * Arithmetic: integer filter bins rint(wt * (2^w_bit - 1)) times either the three exact bf16 terms of a general fp32 operand
+ * (x_levels == 0) or - x_levels = n_a > 0: x is a quantiser output idx / n_a with integer |idx| <= 2048, e.g. relu(act_q(.)) of
+ * activation_quantize_fn - the index itself as one f16 term; fp32 accumulation on v_mfma_f32_16x16x32_{bf16,f16}; see
+ * csrc/qgemm_kernels.hip.  A wrong x_levels (a tensor that is not on that grid) silently rounds the operand: callers pass it only
+ * for tensors they produced with the quantiser.
+ * groups / bn_part (forward, optional): per-row-tile per-channel {sum y, sum y^2} in double,
+ * [groups][alignq_qconv_bn_parts][COUT][2], the layout alignq_bnq_* finalise (the batch is `groups` equal slices with separate
+ * batch-norm statistics; a tile never straddles two slices).                                                                    */
+int alignq_qconv_supported(int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride);
+int alignq_qconv_bn_parts(int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride, int groups);
+int alignq_qconv_fwd(const float* x, const float* wt, float* y, int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride,
+                     int w_bit, float x_levels, int groups, double* bn_part, void* stream);
+/* data gradient dx [B, H_in, W_in, CIN] from dy [B, H_out, W_out, COUT] (every element of dx is written; the 3x3 stride-2 form
+ * is ALIGNQ_EUNSUPPORTED: the caller keeps its own path for those three layers)                                                */
+int alignq_qconv_dgrad(const float* dy, const float* wt, float* dx, int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride,
+                       int w_bit, void* stream);
+/* filter gradient dW [COUT, KS, KS, CIN] (the layout of wt): deterministic split-K slabs in ws (alignq_qconv_wgrad_ws_bytes),
+ * summed in slab order - by this call (dw != NULL, n_slabs_out == NULL) or later by alignq_conv3x3_wgrad_reduce_multi
+ * (n_slabs_out receives the slab count; n_elem = COUT * KS * KS * CIN).  x_levels as in alignq_qconv_fwd.                       */
+size_t alignq_qconv_wgrad_ws_bytes(int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride);
+int alignq_qconv_wgrad(const float* x, const float* dy, float* dw, void* ws, int B, int H_in, int W_in, int CIN, int COUT, int KS,
+                       int stride, float x_levels, int* n_slabs_out, void* stream);
 
 /* Data gradient AND filter-gradient partial sums of one convolution in a single launch (workgroup roles by block index; the
  * two are independent and fill the chip together).  The slabs left in ws are finished by alignq_conv3x3_wgrad_reduce_multi.

@@ -1,0 +1,124 @@
+"""Round 5: Conv2d_Q's convolution at the ResNet-50 / Office-31 shapes on the exact-product GEMM kernels
+(csrc/qgemm_kernels.hip, alignq_qconv_fwd / _dgrad / _wgrad) against an fp64 convolution of the same fp32 inputs.
+Reference op: cdf_alignment_admm/dann_office/model/quantization.py:164-181 (F.conv2d(input, weight_q, ...)), shapes of
+model/resnet.py:31-41,104-110,131-156 (Bottleneck) and :122-126 (downsample)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CL = torch.channels_last
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _wq(cout, cin, ks, k, dev, seed):
+    g = torch.Generator().manual_seed(seed)
+    n = 2 ** k - 1
+    w = torch.round(torch.tanh(torch.randn(cout, cin, ks, ks, generator=g)) * n) / n
+    return w.to(dev).contiguous(memory_format=CL)
+
+
+def _levels(shape, n_a, r, dev, seed):
+    """relu(act_q(.)) of the ADMM / Office formula: idx / n_a with integer idx in [0, r * n_a]"""
+    g = torch.Generator().manual_seed(seed)
+    idx = torch.clamp(torch.round(torch.randn(shape, generator=g) * 0.6 * n_a), 0, r * n_a)
+    return (idx / n_a).to(dev).contiguous(memory_format=CL)
+
+
+# every 1x1 convolution of ResNet-50's bottlenecks (C_in, C_out, H_in, stride): conv1 / conv3 of each layer, conv1 of the first
+# block of a layer (reads the previous layer's resolution), the downsample convolutions
+R50_1X1 = [(64, 64, 56, 1), (64, 256, 56, 1), (256, 64, 56, 1), (256, 128, 56, 1), (128, 512, 28, 1), (512, 128, 28, 1),
+           (256, 512, 56, 2), (512, 256, 28, 1), (256, 1024, 14, 1), (1024, 256, 14, 1), (512, 1024, 28, 2), (1024, 512, 14, 1),
+           (512, 2048, 7, 1), (2048, 512, 7, 1), (1024, 2048, 14, 2)]
+R50_3X3 = [(64, 56, 1), (128, 56, 2), (128, 28, 1), (256, 28, 2), (256, 14, 1), (512, 14, 2), (512, 7, 1)]
+
+
+def _check(dev, B, cin, cout, H, ks, stride, k, level, seed):
+    from alignq_amd import ops
+    pad = (ks - 1) // 2
+    wq = _wq(cout, cin, ks, k, dev, seed).requires_grad_(True)
+    if level:
+        x = _levels((B, cin, H, H), 255.0, 2, dev, seed + 1)
+    else:
+        x = (torch.randn(B, cin, H, H, generator=torch.Generator().manual_seed(seed + 1)) * 1.3).to(dev).contiguous(memory_format=CL)
+    x.requires_grad_(True)
+    assert ops.qconv_gemm_supported(x, wq, (stride, stride), (pad, pad), (1, 1), 1, None, k)
+    y = ops.QConvGemmFn.apply(x, wq, k, stride, 255.0 if level else 0.0)
+    assert y.is_contiguous(memory_format=CL)
+    gy = (torch.randn(y.shape, generator=torch.Generator().manual_seed(seed + 2)) * 1e-3).to(dev).contiguous(memory_format=CL)
+    y.backward(gy)
+    xd, wd = x.detach().double().requires_grad_(True), wq.detach().double().requires_grad_(True)
+    yd = torch.nn.functional.conv2d(xd, wd, stride=stride, padding=pad)
+    yd.backward(gy.double())
+    y32 = torch.nn.functional.conv2d(x.detach(), wq.detach(), stride=stride, padding=pad)
+    floor = 2e-6 * float(yd.abs().max())
+    err = float((y.detach() - yd).abs().max())
+    assert err <= max(float((y32 - yd).abs().max()), floor), ("fwd", err, floor)
+    if level:       # integer operands: the sum is an exact integer below 2^24, one correctly rounded division
+        n_w = 2 ** k - 1
+        acc = torch.nn.functional.conv2d(torch.round(xd.detach() * 255.0), torch.round(wd.detach() * n_w), stride=stride, padding=pad)
+        if float(acc.abs().max()) < 2 ** 24:
+            want = (acc / (255.0 * n_w)).float()
+            assert torch.equal(y.detach(), want), "level operands: bit-exact quotient of the integer sum"
+    dx32, dw32 = torch.ops.aten.convolution_backward(gy, x.detach(), wq.detach(), None, (stride, stride), (pad, pad), (1, 1), False,
+                                                      (0, 0), 1, (True, True, False))[:2]
+    floor = 2e-6 * float(xd.grad.abs().max())
+    err = float((x.grad - xd.grad).abs().max())
+    assert err <= max(float((dx32 - xd.grad).abs().max()), floor), ("dgrad", err, floor)
+    floor = 2e-6 * float(wd.grad.abs().max())
+    err = float((wq.grad - wd.grad).abs().max())
+    assert err <= max(float((dw32 - wd.grad).abs().max()), floor), ("wgrad", err, floor, float((dw32 - wd.grad).abs().max()))
+
+
+@pytest.mark.parametrize("cin,cout,H,stride", R50_1X1)
+@pytest.mark.parametrize("level", [False, True])
+def test_qconv1x1_matches_fp64_at_every_resnet50_shape(dev, cin, cout, H, stride, level):
+    """B = 3 (rows not a multiple of the 128-row tile at 14x14 / 7x7; odd batch): forward, data gradient, filter gradient."""
+    _check(dev, 3, cin, cout, H, 1, stride, 8, level, seed=cin + cout + H)
+
+
+@pytest.mark.parametrize("c,H,stride", R50_3X3)
+@pytest.mark.parametrize("level", [False, True])
+def test_qconv3x3_matches_fp64_at_every_resnet50_shape(dev, c, H, stride, level):
+    _check(dev, 3, c, c, H, 3, stride, 8, level, seed=c + H)
+
+
+@pytest.mark.parametrize("cin,cout,H,ks,stride,k", [(256, 64, 56, 1, 1, 8), (512, 1024, 28, 1, 2, 4), (256, 256, 14, 3, 1, 2),
+                                                    (2048, 512, 7, 1, 1, 8)])
+def test_qconv_full_batch_of_config5(dev, cin, cout, H, ks, stride, k):
+    """the merged source + target batch of the Office step (2 x 28 images)"""
+    _check(dev, 56, cin, cout, H, ks, stride, k, level=(ks == 3), seed=7)
+
+
+def test_qconv_bn_partials_are_the_column_sums(dev):
+    """forward epilogue: per-tile per-channel {sum y, sum y^2} (double), two groups that must not share a tile"""
+    from alignq_amd import ops
+    B, cin, cout, H = 6, 128, 256, 14
+    wq = _wq(cout, cin, 1, 8, dev, 3)
+    x = (torch.randn(B, cin, H, H, generator=torch.Generator().manual_seed(4)) * 1.3).to(dev).contiguous(memory_format=CL)
+    y = ops.QConvGemmFn.apply_with_stats(x, wq, 8, 1, 0.0, 2)
+    part, n_parts, groups = y._alignq_bnq_part
+    assert groups == 2 and tuple(part.shape) == (2, n_parts, cout, 2) and n_parts == (3 * H * H + 127) // 128
+    yg = y.detach().permute(0, 2, 3, 1).reshape(2, 3 * H * H, cout).double()
+    tot = part.sum(1)
+    np.testing.assert_allclose(tot[..., 0].cpu().numpy(), yg.sum(1).cpu().numpy(), rtol=1e-6, atol=1e-4)
+    np.testing.assert_allclose(tot[..., 1].cpu().numpy(), (yg * yg).sum(1).cpu().numpy(), rtol=1e-6, atol=1e-4)
+    y2 = ops.QConvGemmFn.apply(x, wq, 8, 1, 0.0)
+    assert torch.equal(y2, y)
+
+
+def test_qconv_rejects_what_it_does_not_take(dev):
+    from alignq_amd import _lib as L
+    lib = L.load()
+    assert lib.alignq_qconv_supported(2, 8, 8, 48, 64, 1, 1) == 0
+    assert lib.alignq_qconv_supported(2, 8, 8, 64, 64, 5, 1) == 0
+    assert lib.alignq_qconv_supported(2, 8, 8, 64, 64, 3, 3) == 0
+    x = torch.zeros(2, 8, 8, 64, device=dev)
+    assert lib.alignq_qconv_dgrad(L.ptr(x), L.ptr(x), L.ptr(x), 2, 8, 8, 64, 64, 3, 2, 8, None) == -2       # ALIGNQ_EUNSUPPORTED
+    assert lib.alignq_qconv_fwd(L.ptr(x), L.ptr(x), L.ptr(x), 2, 8, 8, 64, 64, 1, 1, 9, 0.0, 1, None, None) == -1    # w_bit
