@@ -18,6 +18,7 @@
 #include <stdint.h>
 
 #include "../../include/alignq.h"
+#include "wgrad_reduce_body.h"
 
 namespace {
 
@@ -458,13 +459,11 @@ __global__ __launch_bounds__(256, 2) void qgemm_wgrad_kernel(const QW a) {
   }
 }
 
-__global__ __launch_bounds__(256) void qgemm_slab_sum_kernel(const float* __restrict__ slabs, int n_slabs, int64_t n_elem,
-                                                             float* __restrict__ dw) {
-  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (i >= n_elem) return;
-  f32x4 s = *reinterpret_cast<const f32x4*>(slabs + i);
-  for (int k = 1; k < n_slabs; k++) s = s + *reinterpret_cast<const f32x4*>(slabs + (int64_t)k * n_elem + i);      // fixed order
-  *reinterpret_cast<f32x4*>(dw + i) = s;
+// stand-alone reduction of the split-K slabs (a whole-model step defers it to alignq_conv3x3_wgrad_reduce_multi: same body, same order)
+__global__ __launch_bounds__(1024) void qgemm_slab_reduce_kernel(const float* __restrict__ slabs, int n_slabs, int n_elem,
+                                                                 float* __restrict__ dw) {
+  __shared__ __attribute__((aligned(16))) float part[4096];
+  alignq_wgr::wgrad_reduce_body(slabs, n_slabs, n_elem, dw, blockIdx.x, part);
 }
 
 bool shape_ok(int B, int H, int W, int CIN, int COUT, int KS, int stride) {
@@ -626,9 +625,9 @@ int alignq_qconv_wgrad(const float* x, const float* dy, float* dw, void* ws, int
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   if (n_slabs_out) { *n_slabs_out = splits; return 0; }      // deferred: the caller reduces (alignq_conv3x3_wgrad_reduce_multi)
-  const int64_t n_elem = (int64_t)COUT * KS * KS * CIN;
-  hipLaunchKernelGGL(qgemm_slab_sum_kernel, dim3((unsigned)((n_elem / 4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, splits,
-                     n_elem, dw);
+  const int n_elem = COUT * KS * KS * CIN;
+  hipLaunchKernelGGL(qgemm_slab_reduce_kernel, dim3(alignq_wgr::wgrad_reduce_blocks(splits, n_elem)), dim3(1024), 0, st,
+                     (const float*)ws, splits, n_elem, dw);
   e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }

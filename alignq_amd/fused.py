@@ -970,8 +970,20 @@ def bn_act_relu(bn, act, z, formula, relu=True, groups=1, residual=None):
             return one(z, residual)
         rs = _slices(residual, groups) if residual is not None else [None] * groups
         return torch.cat([one(zz, rr) for zz, rr in zip(_slices(z, groups), rs)], 0)
-    return BNQuantReluFn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum,
-                               bn.eps, act.a_bit, config.args.act_range, formula, relu, groups, residual)
+    y = BNQuantReluFn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum,
+                            bn.eps, act.a_bit, config.args.act_range, formula, relu, groups, residual)
+    if residual is None:
+        tag_levels(y, act.a_bit, config.args.act_range, formula)
+    return y
+
+
+def tag_levels(y, a_bit, act_range, formula):
+    """Marks y as a tensor of quantiser outputs idx / n with integer |idx| <= 2048 (ADMM / Office formula: x_q = round(t n) / n,
+    |t| <= act_range; model/quantization.py:103-104 Office, :109-110 ADMM tree): Conv2d_Q's GEMM kernels then take the index itself
+    as ONE exact f16 operand term (ops.level_count reads the tag; ops.QConvGemmFn).  Only the producing kernels' callers set it."""
+    n = float(2 ** int(a_bit) - 1) if 1 <= int(a_bit) <= 16 else 0.0
+    if formula == L.FORMULA_ADMM and n > 0 and float(act_range) * n <= 2048.0 and float(act_range) == int(act_range):
+        y._alignq_levels = n
 
 
 # ------------------------------------------------------------------------------------------------------------------

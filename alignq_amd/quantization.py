@@ -270,6 +270,9 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
                         return ops.QConvGenFn.apply_with_stats(input, weight_q, self.quantize_fn.w_bit, self.padding[0])
                     if ops.qconv_stem_supported(*args):
                         return ops.QConvStemFn.apply_with_stats(input, weight_q, self.quantize_fn.w_bit)
+                    if ops.qconv_gemm_supported(*args):      # the ResNet-50 shapes: exact-product GEMMs (csrc/qgemm_kernels.hip)
+                        return ops.QConvGemmFn.apply(input, weight_q, self.quantize_fn.w_bit, self.stride[0],
+                                                     ops.level_count(input))
                 return F.conv2d(input, weight_q, self.bias, self.stride, self.padding, self.dilation, self.groups)
 
             def forward_with_shortcut(self, input):

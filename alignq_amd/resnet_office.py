@@ -137,7 +137,10 @@ class ResNet(nn.Module):
     def forward(self, x, groups=1):
         trans_loss = 0.
         if groups > 1:
-            x = self.maxpool(self.act_q0.forward_bn_relu(self.bn1, self.conv1(x), groups))
+            q0 = self.act_q0.forward_bn_relu(self.bn1, self.conv1(x), groups)
+            x = self.maxpool(q0)
+            if hasattr(q0, "_alignq_levels"):        # the maximum of quantiser levels is one of them (fused.tag_levels)
+                x._alignq_levels = q0._alignq_levels
             losses = []
             for layers in (self.layer1, self.layer2, self.layer3, self.layer4):
                 for layer in layers:
@@ -153,7 +156,10 @@ class ResNet(nn.Module):
             total = torch.cat([t.reshape(-1) for t in tens]).sum() + rest if tens else rest
             return torch.flatten(self.avgpool(x), 1), total
         if getattr(self, "fuse_bn", False):
-            x = self.maxpool(self.act_q0.forward_bn_relu(self.bn1, self.conv1(x)))
+            q0 = self.act_q0.forward_bn_relu(self.bn1, self.conv1(x))
+            x = self.maxpool(q0)
+            if hasattr(q0, "_alignq_levels"):
+                x._alignq_levels = q0._alignq_levels
         elif getattr(self, "fuse_relu", False):
             x = self.maxpool(self.act_q0.forward_relu(self.bn1(self.conv1(x))))
         else:

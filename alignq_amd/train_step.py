@@ -296,7 +296,7 @@ class OfficeTrainStep:
     SGD-stepped first and then overwritten by the closed form, exactly like the reference."""
 
     def __init__(self, model, lr=0.04, momentum=0.9, weight_decay=5e-4, alpha=0.5, channels_last=False, fuse_relu=True,
-                 grad_hook=None, fuse_bn=True, dual=None):
+                 grad_hook=None, fuse_bn=True, dual=None, qconv=True):
         """grad_hook: the data-parallel all-reduce (alignq_amd.dp.attach_office -> BucketedGradAllReduce): begin() right
         before backward, its buckets' collectives start from autograd hooks while the backward runs, finish() before the
         optimizer steps.
@@ -311,6 +311,14 @@ class OfficeTrainStep:
         if channels_last:
             model = model.to(memory_format=torch.channels_last)
         self.channels_last = channels_last
+        # qconv (channels_last only): Conv2d_Q's 1x1 / 3x3 convolutions on alignq_qconv_* (exact-product GEMMs on the bf16 / f16
+        # matrix cores, csrc/qgemm_kernels.hip) instead of MIOpen's fp32 kernels; the 7x7 stem stays with MIOpen.  Their filter
+        # gradients leave split-K slabs that one reduction launch per 32 filters finishes (fused.DeferredWgrads).
+        self.qconv = bool(qconv and channels_last and torch.cuda.is_available())
+        for mod in model.modules():
+            if hasattr(mod, "quantize_fn"):
+                mod.use_qconv = self.qconv
+        self._wgrads = DeferredWgrads() if self.qconv else None
         for mod in model.modules():
             if hasattr(mod, "act_q0") or (hasattr(mod, "act_q1") and hasattr(mod, "act_q2") and hasattr(mod, "act_q3")):
                 mod.fuse_relu = bool(fuse_relu)
@@ -375,7 +383,12 @@ class OfficeTrainStep:
         hook = self.grad_hook if overlap else None
         if hook is not None:
             hook.begin()              # the buckets' all-reduces start from autograd hooks during this backward
-        loss.backward()
+        if self._wgrads is not None:
+            with self._wgrads as wg:  # (the weight quantiser's backward finishes the slab reductions before it reads them)
+                loss.backward()
+                wg.flush()
+        else:
+            loss.backward()
         if hook is not None:
             hook.finish()
         return cls_s, loss, tl

@@ -1029,7 +1029,7 @@ def main():
         from alignq_amd.train_step import OfficeTrainStep
         model = resnet50_dann(a.bits, a.bits).to(dev).train()
         ostep = OfficeTrainStep(model, lr=a.lr if a.lr is not None else 0.004, channels_last=not a.nchw,
-                                fuse_bn=not a.no_fuse_bn, dual=(False if a.no_dual else None))
+                                fuse_bn=not a.no_fuse_bn, dual=(False if a.no_dual else None), qconv=not a.no_qconv)
         if world > 1 or a.dp_selftest:       # >= 4 gradient buckets all-reduced from autograd hooks during the backward
             office_hook = dp.attach_office(ostep, force=a.dp_selftest)
         xs = torch.randn(a.batch, 3, 224, 224, generator=gen).to(dev)
