@@ -96,6 +96,7 @@ SIGNATURES = {
                                           _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "alignq_qconv_supported": (_i, [_i] * 7),
     "alignq_qconv_bn_parts": (_i, [_i] * 8),
+    "alignq_qconv_pack_weights": (_i, [_i, _vp, _vp, _i, _vp, _vp, _vp]),
     "alignq_qconv_fwd": (_i, [_vp, _vp, _vp] + [_i] * 8 + [_f, _i, _vp, _vp]),
     "alignq_qconv_dgrad": (_i, [_vp, _vp, _vp] + [_i] * 8 + [_vp]),
     "alignq_qconv_wgrad_ws_bytes": (_sz, [_i] * 7),

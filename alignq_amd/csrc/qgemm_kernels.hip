@@ -98,23 +98,25 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 //   Wb[n][k]: forward (WTR = false) w[n][tap][c] - rows k-contiguous; data gradient (WTR = true) w[c][tap][n]: the staged image is
 //             [k][n] and the fragments come through ds_read_b64_tr_b16.
 struct QG {
-  const float* xa; const float* w; float* out;
+  const float* xa; const u16* w; float* out;       // w: the filter's integer bins as bf16 (MODE 0) / f16 (MODE 1) bit patterns
   int Mg, groups, tiles_per_group, n_tiles;       // rows per group (a tile never straddles two groups), row tiles, column tiles
   int N, CA, KC;                                   // output columns, channels of xa, KC = CA / BK k-steps per tap
   int Hr, Wr, Ha, Wa, S, sgn;                      // row grid, xa grid, stride from row grid to xa grid, tap direction
   int wrow, wtap;                                  // filter strides (elements): between rows of the staged filter image, per tap
   int Ho, Wo;                                      // SCATTER: the output grid (H_in, W_in of the convolution)
-  float nlev, xlev;                                // filter bins = rint(w * nlev); MODE 1: index = rint(x * xlev)
+  float nlev, xlev;                                // the filter is bins / nlev; MODE 1: index = rint(x * xlev)
   double* bn_part;                                 // forward: [groups][tiles_per_group][N][2] {sum y, sum y^2} or nullptr
 };
 
-template <int WN, int TM, int MODE, bool WTR, bool KS3, bool SCATTER>
-__global__ __launch_bounds__(256, 2) void qgemm_kernel(const QG a) {
+// OCC: workgroups per CU the register / LDS budget is sized for (a small tile runs 3-4 of them: latency hiding comes from the
+// other workgroups' waves, the staging of one overlaps the MFMAs of another)
+template <int WN, int TM, int MODE, bool WTR, bool KS3, bool SCATTER, int OCC>
+__global__ __launch_bounds__(256, OCC) void qgemm_kernel(const QG a) {
   constexpr int WM = 4 / WN, BM = WM * 16 * TM, BN = 64 * WN;
   constexpr int TA = MODE == 0 ? 3 : 1;
   constexpr bool F16 = MODE == 1;
   constexpr int NA = BM / 16;                      // float4 per thread of the pixel-side tile (16 float4 per row of BK)
-  constexpr int NB = BN / 16;                      // float4 per thread of the filter tile
+  constexpr int NB = BN / 32;                      // 16-byte pieces (8 bins) per thread of the filter tile
   constexpr int LDN = BN + 16;                     // halfwords per row of the transposed filter image
   constexpr int XPL = BM * LDK;                    // halfwords per pixel-side plane
   constexpr int WSZ = WTR ? BK * LDN : BN * LDK;
@@ -149,7 +151,8 @@ __global__ __launch_bounds__(256, 2) void qgemm_kernel(const QG a) {
     }
   }
   const int nk = (KS3 ? 9 : 1) * a.KC;
-  f32x4 ra[NA], rw[NB];
+  f32x4 ra[NA];
+  s16x8 rw[NB];
 
   auto fetch = [&](int kt) {
     const int tap = KS3 ? kt / a.KC : 0, c0 = (KS3 ? kt % a.KC : kt) * BK;
@@ -162,15 +165,15 @@ __global__ __launch_bounds__(256, 2) void qgemm_kernel(const QG a) {
       ra[i] = *reinterpret_cast<const f32x4*>(a.xa + off);
       if (!ok) ra[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    if (!WTR) {           // rows n of the tile, 16 float4 of k each
+    if (!WTR) {           // rows n of the tile, 8 pieces of 8 k each: row = (tid >> 3) + 32 i, piece = tid & 7
 #pragma unroll
       for (int i = 0; i < NB; i++)
-        rw[i] = *reinterpret_cast<const f32x4*>(a.w + (int64_t)(n0 + rr + 16 * i) * a.wrow + (int64_t)kt * BK + 4 * c4);
-    } else {              // rows k (channels of xa), BN / 4 float4 of n each
+        rw[i] = *reinterpret_cast<const s16x8*>(a.w + (int64_t)(n0 + (tid >> 3) + 32 * i) * a.wrow + (int64_t)kt * BK + 8 * (tid & 7));
+    } else {              // rows k (channels of xa), BN / 8 pieces of 8 n each
 #pragma unroll
       for (int i = 0; i < NB; i++) {
-        const int idx = tid + 256 * i, kr = idx / (BN / 4), n4 = idx % (BN / 4);
-        rw[i] = *reinterpret_cast<const f32x4*>(a.w + (int64_t)(c0 + kr) * a.wrow + (int64_t)tap * a.wtap + n0 + 4 * n4);
+        const int idx = tid + 256 * i, kr = idx / (BN / 8), n8 = idx % (BN / 8);
+        rw[i] = *reinterpret_cast<const s16x8*>(a.w + (int64_t)(c0 + kr) * a.wrow + (int64_t)tap * a.wtap + n0 + 8 * n8);
       }
     }
   };
@@ -190,12 +193,11 @@ __global__ __launch_bounds__(256, 2) void qgemm_kernel(const QG a) {
     }
 #pragma unroll
     for (int i = 0; i < NB; i++) {
-      const s16x4 b = to_half4<F16>(rint4(rw[i], a.nlev));
       if (!WTR) {
-        *reinterpret_cast<s16x4*>(Ws + (rr + 16 * i) * LDK + 4 * c4) = b;
+        *reinterpret_cast<s16x8*>(Ws + ((tid >> 3) + 32 * i) * LDK + 8 * (tid & 7)) = rw[i];
       } else {
-        const int idx = tid + 256 * i, kr = idx / (BN / 4), n4 = idx % (BN / 4);
-        *reinterpret_cast<s16x4*>(Ws + kr * LDN + 4 * n4) = b;
+        const int idx = tid + 256 * i, kr = idx / (BN / 8), n8 = idx % (BN / 8);
+        *reinterpret_cast<s16x8*>(Ws + kr * LDN + 8 * n8) = rw[i];
       }
     }
   };
@@ -466,6 +468,28 @@ __global__ __launch_bounds__(1024) void qgemm_slab_reduce_kernel(const float* __
   alignq_wgr::wgrad_reduce_body(slabs, n_slabs, n_elem, dw, blockIdx.x, part);
 }
 
+// The integer bins of quantised filters, b = rint(W_q * n), as bf16 and as f16 bit patterns (both exact for |b| <= 255): the
+// operands of the GEMMs above.  Multi-tensor: blockIdx.y = filter.
+constexpr int kPackMax = 64;
+struct PackChunk {
+  const float* w[kPackMax];
+  u16* bf[kPackMax];
+  u16* hf[kPackMax];
+  int64_t n[kPackMax];
+};
+__global__ __launch_bounds__(256) void qgemm_pack_kernel(const PackChunk c, float nlev) {
+  const int t = blockIdx.y;
+  const float* __restrict__ w = c.w[t];
+  u16* __restrict__ bf = c.bf[t];
+  u16* __restrict__ hf = c.hf[t];
+  const int64_t n4 = c.n[t] >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const f32x4 b = rint4(*reinterpret_cast<const f32x4*>(w + 4 * i), nlev);
+    *reinterpret_cast<s16x4*>(bf + 4 * i) = to_half4<false>(b);
+    *reinterpret_cast<s16x4*>(hf + 4 * i) = to_half4<true>(b);
+  }
+}
+
 bool shape_ok(int B, int H, int W, int CIN, int COUT, int KS, int stride) {
   if (B < 1 || H < 1 || W < 1 || CIN < 64 || COUT < 64 || CIN % 64 || COUT % 64) return false;
   if (!((KS == 1 && (stride == 1 || stride == 2)) || (KS == 3 && (stride == 1 || stride == 2)))) return false;
@@ -476,27 +500,33 @@ bool shape_ok(int B, int H, int W, int CIN, int COUT, int KS, int stride) {
   return true;
 }
 
-template <int WN, int TM, int MODE, bool WTR, bool KS3, bool SCATTER>
-int launch_g(const QG& a, hipStream_t st) {
+template <int WN, int TM, int MODE, bool WTR, bool KS3, bool SCATTER, int OCC>
+int launch_g(QG a, hipStream_t st) {
+  constexpr int BM = (4 / WN) * 16 * TM, BN = 64 * WN;
+  a.tiles_per_group = (a.Mg + BM - 1) / BM;
+  a.n_tiles = a.N / BN;
   const int grid = a.groups * a.tiles_per_group * a.n_tiles;
-  hipLaunchKernelGGL((qgemm_kernel<WN, TM, MODE, WTR, KS3, SCATTER>), dim3(grid), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((qgemm_kernel<WN, TM, MODE, WTR, KS3, SCATTER, OCC>), dim3(grid), dim3(256), 0, st, a);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
 
-// tile choice: 64 columns -> 128 rows x 64 (WN = 1, TM = 2), else 128 x 128 (WN = 2, TM = 4)
+// Tile choice: the largest of 128x128, 64x128, 64x64 (pixels x channels) that still gives the chip >= kWantBlocks workgroups; the
+// batch-norm partials (bn_part) are laid out for 128-row tiles, so a forward that writes them keeps 128 rows per tile.
+constexpr int kWantBlocks = 1024;
 template <int MODE, bool WTR, bool KS3, bool SCATTER>
-int launch_g_tiles(QG a, hipStream_t st) {
-  if (a.N % 128 == 0) {
-    constexpr int BM = 128;
-    a.tiles_per_group = (a.Mg + BM - 1) / BM;
-    a.n_tiles = a.N / 128;
-    return launch_g<2, 4, MODE, WTR, KS3, SCATTER>(a, st);
+int launch_g_tiles(const QG& a, hipStream_t st) {
+  const int64_t rows = (int64_t)a.Mg * a.groups;
+  const bool n128 = a.N % 128 == 0;
+  auto blocks = [&](int bm, int bn) { return ((rows + bm - 1) / bm) * (a.N / bn); };
+  if (a.bn_part) {
+    if (n128 && blocks(128, 128) >= kWantBlocks) return launch_g<2, 4, MODE, WTR, KS3, SCATTER, 2>(a, st);
+    return launch_g<1, 2, MODE, WTR, KS3, SCATTER, 2>(a, st);
   }
-  constexpr int BM = 128;
-  a.tiles_per_group = (a.Mg + BM - 1) / BM;
-  a.n_tiles = a.N / 64;
-  return launch_g<1, 2, MODE, WTR, KS3, SCATTER>(a, st);
+  if (n128 && blocks(128, 128) >= kWantBlocks) return launch_g<2, 4, MODE, WTR, KS3, SCATTER, 2>(a, st);
+  if (n128 && blocks(64, 128) >= kWantBlocks) return launch_g<2, 2, MODE, WTR, KS3, SCATTER, 3>(a, st);
+  if (blocks(128, 64) >= 2 * kWantBlocks) return launch_g<1, 2, MODE, WTR, KS3, SCATTER, 2>(a, st);
+  return launch_g<1, 1, MODE, WTR, KS3, SCATTER, 4>(a, st);
 }
 
 int wgrad_splits(int64_t M, int tiles) {
@@ -522,14 +552,37 @@ int alignq_qconv_bn_parts(int B, int H_in, int W_in, int CIN, int COUT, int KS, 
   return (int)(((int64_t)(B / groups) * Ho * Wo + 127) / 128);
 }
 
-int alignq_qconv_fwd(const float* x, const float* wt, float* y, int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride,
+int alignq_qconv_pack_weights(int T, const float* const* wt, const int64_t* n, int w_bit, void* const* bins_bf16, void* const* bins_f16,
+                              void* stream) {
+  if (T <= 0 || !wt || !n || !bins_bf16 || !bins_f16 || w_bit < 1 || w_bit > 8) return ALIGNQ_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  for (int t0 = 0; t0 < T; t0 += kPackMax) {
+    const int cnt = T - t0 < kPackMax ? T - t0 : kPackMax;
+    PackChunk c;
+    int64_t max_n = 0;
+    for (int i = 0; i < cnt; i++) {
+      if (!wt[t0 + i] || !bins_bf16[t0 + i] || !bins_f16[t0 + i] || n[t0 + i] < 4 || (n[t0 + i] & 3)) return ALIGNQ_EINVAL;
+      c.w[i] = wt[t0 + i]; c.bf[i] = (u16*)bins_bf16[t0 + i]; c.hf[i] = (u16*)bins_f16[t0 + i]; c.n[i] = n[t0 + i];
+      if (n[t0 + i] > max_n) max_n = n[t0 + i];
+    }
+    int gx = (int)((max_n / 4 + 1023) / 1024);
+    if (gx < 1) gx = 1;
+    if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(qgemm_pack_kernel, dim3(gx, cnt), dim3(256), 0, st, c, (float)((1 << w_bit) - 1));
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+  }
+  return 0;
+}
+
+int alignq_qconv_fwd(const float* x, const void* w_bins, float* y, int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride,
                      int w_bit, float x_levels, int groups, double* bn_part, void* stream) {
-  if (!x || !wt || !y || w_bit < 1 || w_bit > 8 || groups < 1) return ALIGNQ_EINVAL;
+  if (!x || !w_bins || !y || w_bit < 1 || w_bit > 8 || groups < 1) return ALIGNQ_EINVAL;
   if (!shape_ok(B, H_in, W_in, CIN, COUT, KS, stride) || B % groups) return ALIGNQ_EUNSUPPORTED;
   if (x_levels != 0.0f && !(x_levels >= 1.0f)) return ALIGNQ_EINVAL;
   const int Ho = (H_in - 1) / stride + 1, Wo = (W_in - 1) / stride + 1;
   QG a{};
-  a.xa = x; a.w = wt; a.out = y;
+  a.xa = x; a.w = (const u16*)w_bins; a.out = y;
   a.Mg = (B / groups) * Ho * Wo; a.groups = groups;
   a.N = COUT; a.CA = CIN; a.KC = CIN / BK;
   a.Hr = Ho; a.Wr = Wo; a.Ha = H_in; a.Wa = W_in; a.S = stride; a.sgn = 1;
@@ -542,14 +595,14 @@ int alignq_qconv_fwd(const float* x, const float* wt, float* y, int B, int H_in,
   return x_levels != 0.0f ? launch_g_tiles<1, false, false, false>(a, st) : launch_g_tiles<0, false, false, false>(a, st);
 }
 
-int alignq_qconv_dgrad(const float* dy, const float* wt, float* dx, int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride,
+int alignq_qconv_dgrad(const float* dy, const void* w_bins, float* dx, int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride,
                        int w_bit, void* stream) {
-  if (!dy || !wt || !dx || w_bit < 1 || w_bit > 8) return ALIGNQ_EINVAL;
+  if (!dy || !w_bins || !dx || w_bit < 1 || w_bit > 8) return ALIGNQ_EINVAL;
   if (!shape_ok(B, H_in, W_in, CIN, COUT, KS, stride)) return ALIGNQ_EUNSUPPORTED;
   if (KS == 3 && stride != 1) return ALIGNQ_EUNSUPPORTED;
   const int Ho = (H_in - 1) / stride + 1, Wo = (W_in - 1) / stride + 1;
   QG a{};
-  a.xa = dy; a.w = wt; a.out = dx;
+  a.xa = dy; a.w = (const u16*)w_bins; a.out = dx;
   a.groups = 1;
   a.N = CIN; a.CA = COUT; a.KC = COUT / BK;
   a.Ha = Ho; a.Wa = Wo; a.S = 1; a.sgn = -1;

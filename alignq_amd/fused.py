@@ -61,8 +61,10 @@ class WeightQuantAllFn(torch.autograd.Function):
         return (None, None) + tuple(dws)
 
 
-def prequantize_weights(convs):
-    """convs: modules with `.weight` and `.quantize_fn` (Conv2d_Q).  All must share w_bit (< 32) and tree."""
+def prequantize_weights(convs, pack=False):
+    """convs: modules with `.weight` and `.quantize_fn` (Conv2d_Q).  All must share w_bit (< 32) and tree.
+    pack: also leave every (<= 8-bit) filter's integer bins as bf16 / f16 bit patterns (ops.pack_filter_bins, one launch per 64
+    filters) for the GEMM convolutions of ops.QConvGemmFn."""
     convs = [c for c in convs if c.quantize_fn.w_bit != 32]
     if not convs:
         return
@@ -72,8 +74,15 @@ def prequantize_weights(convs):
     for (k, formula), cs in groups.items():
         outs = WeightQuantAllFn.apply(k, formula, *[c.weight for c in cs])
         T = len(cs)
+        bins = None
+        if pack and 1 <= k <= 8:
+            from . import ops
+            sel = [i for i in range(T) if outs[i].numel() % 4 == 0]
+            packed = ops.pack_filter_bins([outs[i].detach() for i in sel], k)
+            bins = dict(zip(sel, packed))
         for i, c in enumerate(cs):
-            c.quantize_fn._pre = (c.weight, outs[i], outs[T + i], outs[2 * T + i])
+            pre = (c.weight, outs[i], outs[T + i], outs[2 * T + i])
+            c.quantize_fn._pre = pre + ((bins[i],) if bins is not None and i in bins else ())
 
 
 # ------------------------------------------------------------------------------------------------------------------

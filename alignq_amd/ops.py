@@ -887,39 +887,53 @@ def level_count(t):
     return float(getattr(t, "_alignq_levels", 0.0) or 0.0)
 
 
+def pack_filter_bins(weights, w_bit):
+    """[(bf16 bins, f16 bins)] of quantised filters (int16 tensors of the filters' shapes and layouts holding the bit patterns):
+    alignq_qconv_pack_weights, one launch per 64 filters.  The operands of alignq_qconv_fwd / _dgrad."""
+    ws_ = [L.dense_f32(w, "quantised filter") for w in weights]
+    bf = [torch.empty_like(w, dtype=torch.int16) for w in ws_]
+    hf = [torch.empty_like(w, dtype=torch.int16) for w in ws_]
+    L.check(L.load().alignq_qconv_pack_weights(len(ws_), L.ptr_array(ws_), L.i64_array([w.numel() for w in ws_]), int(w_bit),
+                                               L.ptr_array(bf), L.ptr_array(hf), L.stream_ptr()), "alignq_qconv_pack_weights")
+    return list(zip(bf, hf))
+
+
 class QConvGemmFn(torch.autograd.Function):
     """F.conv2d(input, weight_q, None, stride, padding) of Conv2d_Q.forward (cdf_alignment_admm/dann_office/model/quantization.py:
     164-181) at the ResNet-50 shapes on alignq_qconv_fwd / _dgrad / _wgrad (csrc/qgemm_kernels.hip): exact products on the bf16 /
-    f16 matrix cores.  x_levels: see level_count (0.0: a general fp32 input).  The filter gradient's slab reduction is deferred to
+    f16 matrix cores.  x_levels: see level_count (0.0: a general fp32 input).  bins: (bf16, f16) bit patterns of the filter's
+    integer bins from pack_filter_bins (None: packed here, one small launch).  The filter gradient's slab reduction is deferred to
     fused.DeferredWgrads when such a context is active."""
 
     @staticmethod
-    def forward(ctx, x, w, w_bit, stride, x_levels=0.0, groups=1, bn_stats=False):
+    def forward(ctx, x, w, w_bit, stride, x_levels=0.0, groups=1, bn_stats=False, bins=None):
         B, CIN, H, W = x.shape
         COUT, ks = w.shape[0], w.shape[2]
         s = int(stride)
         Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
         lib = L.load()
+        if bins is None:
+            bins = pack_filter_bins([w], w_bit)[0]
         y = torch.empty((B, COUT, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
         part = None
         if bn_stats:
             n_parts = lib.alignq_qconv_bn_parts(B, H, W, CIN, COUT, ks, s, int(groups))
             part = torch.empty(int(groups), n_parts, COUT, 2, dtype=torch.float64, device=x.device)
             QConvGemmFn._mailbox = (part, n_parts)
-        L.check(lib.alignq_qconv_fwd(L.ptr(x), L.ptr(w), L.ptr(y), B, H, W, CIN, COUT, ks, s, int(w_bit), float(x_levels),
-                                     int(groups if bn_stats else 1), L.ptr(part), L.stream_ptr()), "alignq_qconv_fwd")
-        ctx.save_for_backward(x, w)
+        L.check(lib.alignq_qconv_fwd(L.ptr(x), L.ptr(bins[1] if x_levels else bins[0]), L.ptr(y), B, H, W, CIN, COUT, ks, s, int(w_bit),
+                                     float(x_levels), int(groups if bn_stats else 1), L.ptr(part), L.stream_ptr()), "alignq_qconv_fwd")
+        ctx.save_for_backward(x, w, bins[0])
         ctx.cfg = (int(w_bit), s, float(x_levels), ks)
         return y
 
     _mailbox = None
 
     @staticmethod
-    def apply_with_stats(x, w, w_bit, stride, x_levels=0.0, groups=1):
+    def apply_with_stats(x, w, w_bit, stride, x_levels=0.0, groups=1, bins=None):
         """apply(...) that also leaves the batch-norm partial statistics of the output on it: y._alignq_bnq_part =
-        (double tensor [groups, parts, C_out, 2], parts) for fused.bn_act_relu / bn_only / bn_site_res_relu."""
+        (double tensor [groups, parts, C_out, 2], parts, groups) for fused.bn_act_relu / bn_only / bn_site_res_relu."""
         QConvGemmFn._mailbox = None
-        y = QConvGemmFn.apply(x, w, w_bit, stride, x_levels, groups, True)
+        y = QConvGemmFn.apply(x, w, w_bit, stride, x_levels, groups, True, bins)
         if QConvGemmFn._mailbox is not None:
             y._alignq_bnq_part = QConvGemmFn._mailbox + (int(groups),)
             QConvGemmFn._mailbox = None
@@ -927,7 +941,7 @@ class QConvGemmFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        x, w = ctx.saved_tensors
+        x, w, wb = ctx.saved_tensors
         w_bit, s, x_levels, ks = ctx.cfg
         B, CIN, H, W = x.shape
         COUT = w.shape[0]
@@ -942,7 +956,7 @@ class QConvGemmFn(torch.autograd.Function):
                                                          (True, False, False))[0]
             else:
                 dx = torch.empty((B, CIN, H, W), dtype=torch.float32, device=x.device, memory_format=cl)
-                L.check(lib.alignq_qconv_dgrad(L.ptr(gy), L.ptr(w), L.ptr(dx), B, H, W, CIN, COUT, ks, s, w_bit, L.stream_ptr()),
+                L.check(lib.alignq_qconv_dgrad(L.ptr(gy), L.ptr(wb), L.ptr(dx), B, H, W, CIN, COUT, ks, s, w_bit, L.stream_ptr()),
                         "alignq_qconv_dgrad")
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
@@ -956,7 +970,7 @@ class QConvGemmFn(torch.autograd.Function):
             else:
                 L.check(lib.alignq_qconv_wgrad(L.ptr(x), L.ptr(gy), L.ptr(dw), L.ptr(ws), B, H, W, CIN, COUT, ks, s, x_levels, None,
                                                L.stream_ptr()), "alignq_qconv_wgrad")
-        return dx, dw, None, None, None, None, None
+        return dx, dw, None, None, None, None, None, None
 
 
 def qconv_stem_supported(x, w, stride, padding, dilation, groups, bias, w_bit) -> bool:

@@ -74,8 +74,11 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
                     self.weight_q = x
                 return x
             pre, self._pre = self._pre, None
+            self._bins = None
             if pre is not None and pre[0] is x:
                 q, c, pdf = pre[1], pre[2], pre[3]
+                if len(pre) > 4:
+                    self._bins = (q, pre[4])          # the filter's packed integer bins (fused.prequantize_weights(pack=True))
             else:
                 q, c, pdf = ops.WeightQuantFn.apply(x, self.w_bit, formula)
             if tree != "cdf":   # the CDF tree keeps these as locals (quantization.py:70-72)
@@ -83,6 +86,11 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
             else:
                 self._weight_cdf, self._weight_pdf = c, pdf
             return q
+
+        def take_bins(self, weight_q):
+            """(bf16, f16) bins of `weight_q` if the last forward left them (else None: the convolution packs them itself)."""
+            held = getattr(self, "_bins", None)
+            return held[1] if held is not None and held[0] is weight_q else None
 
     def _plain_act(x, a_bit, stage):
         if a_bit == 32 and stage != "align":
@@ -272,7 +280,7 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
                         return ops.QConvStemFn.apply_with_stats(input, weight_q, self.quantize_fn.w_bit)
                     if ops.qconv_gemm_supported(*args):      # the ResNet-50 shapes: exact-product GEMMs (csrc/qgemm_kernels.hip)
                         return ops.QConvGemmFn.apply(input, weight_q, self.quantize_fn.w_bit, self.stride[0],
-                                                     ops.level_count(input))
+                                                     ops.level_count(input), 1, False, self.quantize_fn.take_bins(weight_q))
                 return F.conv2d(input, weight_q, self.bias, self.stride, self.padding, self.dilation, self.groups)
 
             def forward_with_shortcut(self, input):

@@ -369,13 +369,13 @@ class OfficeTrainStep:
                                 torch.ones(xt.shape[0], dtype=torch.long, device=dev))
             self._dom_labels_key = key
         label_src, label_tgt = self._dom_labels
-        prequantize_weights(self.all_convs)
+        prequantize_weights(self.all_convs, pack=self.qconv)
         if self.dual and xs.shape == xt.shape:
             cls_s, dom_s, dom_t, tl_both = m.forward_dual(xs, xt, alpha=self.alpha)      # (same weights, hence the same W_q,
             tl_s, tl_t = tl_both, 0.0                                                    #  in both of the reference's passes)
         else:
             cls_s, dom_s, tl_s = m(xs, alpha=self.alpha)
-            prequantize_weights(self.all_convs)          # the reference quantises every weight once per pass
+            prequantize_weights(self.all_convs, pack=self.qconv)          # the reference quantises every weight once per pass
             _, dom_t, tl_t = m(xt, alpha=self.alpha)
         # (a pass without a loss tensor contributes the NUMBER 0: adding it would be an elementwise launch of its own)
         tl = tl_s if not torch.is_tensor(tl_t) and tl_t == 0 else (tl_t if not torch.is_tensor(tl_s) and tl_s == 0 else tl_s + tl_t)

@@ -343,11 +343,18 @@ int alignq_conv_gen_nhwc_wgrad(const float* x, const float* dy, float* dw, void*
  * batch-norm statistics; a tile never straddles two slices).                                                                    */
 int alignq_qconv_supported(int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride);
 int alignq_qconv_bn_parts(int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride, int groups);
-int alignq_qconv_fwd(const float* x, const float* wt, float* y, int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride,
+/* The filter operand of the forward and the data gradient: the integer bins b = rint(W_q * (2^w_bit - 1)) of T quantised filters
+ * (wt[i]: n[i] floats, n[i] % 4 == 0, any layout - the bins keep it) as 16-bit patterns, bf16 in bins_bf16[i] and f16 in
+ * bins_f16[i] (n[i] halfwords each; both exact for |b| <= 255).  One launch per 64 filters; HOST arrays of DEVICE pointers.       */
+int alignq_qconv_pack_weights(int T, const float* const* wt, const int64_t* n, int w_bit, void* const* bins_bf16, void* const* bins_f16,
+                              void* stream);
+/* w_bins: the filter's bins [COUT, KS, KS, CIN] from alignq_qconv_pack_weights - the bf16 patterns when x_levels == 0, the f16
+ * patterns when x_levels > 0.                                                                                                    */
+int alignq_qconv_fwd(const float* x, const void* w_bins, float* y, int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride,
                      int w_bit, float x_levels, int groups, double* bn_part, void* stream);
-/* data gradient dx [B, H_in, W_in, CIN] from dy [B, H_out, W_out, COUT] (every element of dx is written; the 3x3 stride-2 form
- * is ALIGNQ_EUNSUPPORTED: the caller keeps its own path for those three layers)                                                */
-int alignq_qconv_dgrad(const float* dy, const float* wt, float* dx, int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride,
+/* data gradient dx [B, H_in, W_in, CIN] from dy [B, H_out, W_out, COUT] and the filter's bf16 bins (every element of dx is written;
+ * the 3x3 stride-2 form is ALIGNQ_EUNSUPPORTED: the caller keeps its own path for those three layers)                            */
+int alignq_qconv_dgrad(const float* dy, const void* w_bins, float* dx, int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride,
                        int w_bit, void* stream);
 /* filter gradient dW [COUT, KS, KS, CIN] (the layout of wt): deterministic split-K slabs in ws (alignq_qconv_wgrad_ws_bytes),
  * summed in slab order - by this call (dw != NULL, n_slabs_out == NULL) or later by alignq_conv3x3_wgrad_reduce_multi

@@ -122,3 +122,16 @@ def test_qconv_rejects_what_it_does_not_take(dev):
     x = torch.zeros(2, 8, 8, 64, device=dev)
     assert lib.alignq_qconv_dgrad(L.ptr(x), L.ptr(x), L.ptr(x), 2, 8, 8, 64, 64, 3, 2, 8, None) == -2       # ALIGNQ_EUNSUPPORTED
     assert lib.alignq_qconv_fwd(L.ptr(x), L.ptr(x), L.ptr(x), 2, 8, 8, 64, 64, 1, 1, 9, 0.0, 1, None, None) == -1    # w_bit
+
+
+def test_filter_bins_pack_is_exact(dev):
+    """alignq_qconv_pack_weights: bf16 and f16 bit patterns of rint(W_q * n), multi-tensor, any layout"""
+    from alignq_amd import ops
+    ws = [_wq(64, 64, 3, 8, dev, 1), _wq(128, 64, 1, 4, dev, 2).contiguous(), _wq(64, 256, 1, 8, dev, 3)]
+    for k, w in ((8, ws[0]), (4, ws[1]), (8, ws[2])):
+        (bf, hf), = ops.pack_filter_bins([w], k)
+        want = torch.round(w * (2 ** k - 1))
+        assert bf.stride() == w.stride() and hf.stride() == w.stride()
+        assert torch.equal(bf.view(torch.bfloat16).float(), want) and torch.equal(hf.view(torch.float16).float(), want)
+    many = ops.pack_filter_bins([ws[0]] * 70, 8)          # more filters than one launch takes
+    assert all(torch.equal(b.view(torch.bfloat16).float(), torch.round(ws[0] * 255)) for b, _ in many)

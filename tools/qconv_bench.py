@@ -73,12 +73,15 @@ def main():
         dw = torch.empty_like(w)
         ws = torch.empty(max(16, lib.alignq_qconv_wgrad_ws_bytes(B, H, H, cin, cout, ks, s)), dtype=torch.uint8, device=dev)
         xl = 255.0 if lev else 0.0
-        f = lambda i: L.check(lib.alignq_qconv_fwd(p(xs[i]), p(w), p(ys[i]), B, H, H, cin, cout, ks, s, 8, xl, 1, None, st), "fwd")
+        wbf, whf = torch.empty_like(w, dtype=torch.int16), torch.empty_like(w, dtype=torch.int16)
+        L.check(lib.alignq_qconv_pack_weights(1, L.ptr_array([w]), L.i64_array([w.numel()]), 8, L.ptr_array([wbf]), L.ptr_array([whf]), st), "pack")
+        wfw = whf if lev else wbf
+        f = lambda i: L.check(lib.alignq_qconv_fwd(p(xs[i]), p(wfw), p(ys[i]), B, H, H, cin, cout, ks, s, 8, xl, 1, None, st), "fwd")
         t_f = time_rot(f, R)
         if ks == 3 and s == 2:
             t_d = float("nan")
         else:
-            d = lambda i: L.check(lib.alignq_qconv_dgrad(p(gys[i]), p(w), p(dxs[i]), B, H, H, cin, cout, ks, s, 8, st), "dgrad")
+            d = lambda i: L.check(lib.alignq_qconv_dgrad(p(gys[i]), p(wbf), p(dxs[i]), B, H, H, cin, cout, ks, s, 8, st), "dgrad")
             t_d = time_rot(d, R)
         import ctypes
         ns = ctypes.c_int(0)
