@@ -50,6 +50,9 @@ SIGNATURES = {
     "alignq_corr_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _f, _vp, _vp, _vp]),
     "alignq_bnq_ws_bytes": (_sz, [_i, _i]),
     "alignq_bnq_stats": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp]),
+    "alignq_bnq_stats_parts": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _i, _vp]),
+    "alignq_bnq_fwd_parts": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i,
+                                  _vp]),
     "alignq_bnq_affine": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     "alignq_bnq_bwd_dx": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "alignq_site_partials_res_ab": (_i, [_vp, _vp, _i, _i, _i64, _i, _f, _f, _vp, _i, _vp, _vp, _vp, _vp]),

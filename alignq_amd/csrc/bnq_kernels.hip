@@ -161,18 +161,21 @@ __global__ __launch_bounds__(NT) void bnq_sums_kernel(const float* __restrict__ 
 __device__ __forceinline__ void bnq_wave_totals2(const double* __restrict__ p0, const double* __restrict__ p1, int nparts, int C,
                                                  int c, int lane, double& a0, double& q0, double& a1, double& q1) {
   constexpr int U = kParts / 64;
-  double va0[U], vq0[U], va1[U], vq1[U];
-#pragma unroll
-  for (int u = 0; u < U; u++) {
-    const int s = lane + 64 * u, sc = s < nparts ? s : nparts - 1;
-    const double2 v0 = *reinterpret_cast<const double2*>(p0 + ((int64_t)sc * C + c) * 2);
-    const double2 v1 = *reinterpret_cast<const double2*>(p1 + ((int64_t)sc * C + c) * 2);
-    va0[u] = v0.x; vq0[u] = v0.y; va1[u] = v1.x; vq1[u] = v1.y;
-  }
   a0 = 0; q0 = 0; a1 = 0; q1 = 0;
+  // (one round for the <= kParts partials of bnq_sums_kernel; more when a convolution's epilogue left one partial per row tile)
+  for (int base = 0; base < nparts; base += 64 * U) {
+    double va0[U], vq0[U], va1[U], vq1[U];
 #pragma unroll
-  for (int u = 0; u < U; u++) {
-    if (lane + 64 * u < nparts) { a0 += va0[u]; q0 += vq0[u]; a1 += va1[u]; q1 += vq1[u]; }
+    for (int u = 0; u < U; u++) {
+      const int s = base + lane + 64 * u, sc = s < nparts ? s : nparts - 1;
+      const double2 v0 = *reinterpret_cast<const double2*>(p0 + ((int64_t)sc * C + c) * 2);
+      const double2 v1 = *reinterpret_cast<const double2*>(p1 + ((int64_t)sc * C + c) * 2);
+      va0[u] = v0.x; vq0[u] = v0.y; va1[u] = v1.x; vq1[u] = v1.y;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (base + lane + 64 * u < nparts) { a0 += va0[u]; q0 += vq0[u]; a1 += va1[u]; q1 += vq1[u]; }
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -579,7 +582,15 @@ int alignq_bnq_fwd(const float* z, int64_t P, int C, int groups, const float* ga
                    float* running_var, int64_t* num_batches_tracked, float momentum, float bn_eps, int k, float act_range,
                    int formula, int relu, const float* residual, float* ab, float* save, float* y, void* mask, void* ws,
                    void* stream) {
-  if (!z || !ab || !save || !y || !ws || P < 2 || bad_groups(groups)) return ALIGNQ_EINVAL;
+  return alignq_bnq_fwd_parts(z, P, C, groups, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, bn_eps, k,
+                              act_range, formula, relu, residual, ab, save, y, mask, ws, nullptr, 0, stream);
+}
+
+int alignq_bnq_fwd_parts(const float* z, int64_t P, int C, int groups, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, int64_t* num_batches_tracked, float momentum, float bn_eps, int k, float act_range,
+                         int formula, int relu, const float* residual, float* ab, float* save, float* y, void* mask, void* ws,
+                         const double* conv_part, int conv_parts, void* stream) {
+  if (!z || !ab || !save || !y || (!ws && !conv_part) || P < 2 || bad_groups(groups) || (conv_part && conv_parts < 1)) return ALIGNQ_EINVAL;
   if ((reinterpret_cast<uintptr_t>(mask) | reinterpret_cast<uintptr_t>(residual)) & 15) return ALIGNQ_EINVAL;
   unsigned long long* mk = reinterpret_cast<unsigned long long*>(mask);
   if (!((k >= 1 && k <= 16) || k == 32)) return ALIGNQ_EINVAL;
@@ -589,7 +600,7 @@ int alignq_bnq_fwd(const float* z, int64_t P, int C, int groups, const float* ga
   hipStream_t st = (hipStream_t)stream;
   double* part = reinterpret_cast<double*>(ws);
   const int64_t nvec = P * (C >> 2);
-  if (fin_small(P, C, groups)) {
+  if (!conv_part && fin_small(P, C, groups)) {
     const int np = fin_parts(P, C);
     BNQ_SUMS_NT(C, hipLaunchKernelGGL((bnq_sums_kernel<0, NTV>), dim3(np, 1), dim3(NTV), 0, st, z, nullptr, nullptr, nullptr, nullptr, P, C,
                        act_range, 0, part));
@@ -604,9 +615,14 @@ int alignq_bnq_fwd(const float* z, int64_t P, int C, int groups, const float* ga
                          residual, fin);
     return hipGetLastError() == hipSuccess ? 0 : ALIGNQ_EINVAL;
   }
-  const int np = parts_for(P, C);
-  BNQ_SUMS_NT(C, hipLaunchKernelGGL((bnq_sums_kernel<0, NTV>), dim3(np, groups), dim3(NTV), 0, st, z, nullptr, nullptr, nullptr, nullptr, P, C,
-                     act_range, 0, part));
+  int np = parts_for(P, C);
+  if (conv_part) {      // the producing convolution's epilogue already summed z and z^2 per row tile (alignq_qconv_fwd bn_part)
+    part = const_cast<double*>(conv_part);
+    np = conv_parts;
+  } else {
+    BNQ_SUMS_NT(C, hipLaunchKernelGGL((bnq_sums_kernel<0, NTV>), dim3(np, groups), dim3(NTV), 0, st, z, nullptr, nullptr, nullptr, nullptr, P, C,
+                       act_range, 0, part));
+  }
   hipLaunchKernelGGL(bnq_finalize_kernel, dim3((C + 3) / 4), dim3(kT), 0, st, (const double*)part, np, P, C, gamma, beta,
                      running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), momentum, bn_eps, ab, save,
                      groups);
@@ -655,13 +671,26 @@ int alignq_bnq_bwd(const float* g, const float* z, const float* y, const void* m
 int alignq_bnq_stats(const float* z, int64_t P, int C, int groups, const float* gamma, const float* beta, float* running_mean,
                      float* running_var, int64_t* num_batches_tracked, float momentum, float bn_eps, float* ab, float* save,
                      void* ws, void* stream) {
-  if (!z || !ab || !save || !ws || P < 2 || bad_groups(groups)) return ALIGNQ_EINVAL;
+  return alignq_bnq_stats_parts(z, P, C, groups, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, bn_eps, ab,
+                                save, ws, nullptr, 0, stream);
+}
+
+int alignq_bnq_stats_parts(const float* z, int64_t P, int C, int groups, const float* gamma, const float* beta, float* running_mean,
+                           float* running_var, int64_t* num_batches_tracked, float momentum, float bn_eps, float* ab, float* save,
+                           void* ws, const double* conv_part, int conv_parts, void* stream) {
+  if (!ab || !save || P < 2 || bad_groups(groups)) return ALIGNQ_EINVAL;
+  if (conv_part ? conv_parts < 1 : (!z || !ws)) return ALIGNQ_EINVAL;
   if (bad_c(C)) return ALIGNQ_EUNSUPPORTED;
   if (reinterpret_cast<uintptr_t>(z) & 15) return ALIGNQ_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   double* part = reinterpret_cast<double*>(ws);
-  const int np = parts_for(P, C);
-  BNQ_SUMS_NT(C, hipLaunchKernelGGL((bnq_sums_kernel<0, NTV>), dim3(np, groups), dim3(NTV), 0, st, z, nullptr, nullptr, nullptr, nullptr, P, C, 0.f, 0, part));
+  int np = parts_for(P, C);
+  if (conv_part) {
+    part = const_cast<double*>(conv_part);
+    np = conv_parts;
+  } else {
+    BNQ_SUMS_NT(C, hipLaunchKernelGGL((bnq_sums_kernel<0, NTV>), dim3(np, groups), dim3(NTV), 0, st, z, nullptr, nullptr, nullptr, nullptr, P, C, 0.f, 0, part));
+  }
   hipLaunchKernelGGL(bnq_finalize_kernel, dim3((C + 3) / 4), dim3(kT), 0, st, (const double*)part, np, P, C, gamma, beta,
                      running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), momentum, bn_eps, ab, save,
                      groups);

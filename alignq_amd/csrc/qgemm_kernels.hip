@@ -511,22 +511,27 @@ int launch_g(QG a, hipStream_t st) {
   return e == hipSuccess ? 0 : (int)e;
 }
 
-// Tile choice: the largest of 128x128, 64x128, 64x64 (pixels x channels) that still gives the chip >= kWantBlocks workgroups; the
-// batch-norm partials (bn_part) are laid out for 128-row tiles, so a forward that writes them keeps 128 rows per tile.
+// Tile choice: the largest of 128x128, 64x128, 64x64 (pixels x channels) that still gives the chip >= kWantBlocks workgroups
+// (rows = all groups' rows; alignq_qconv_bn_parts reports the row tiles per group of the same choice).
 constexpr int kWantBlocks = 1024;
+inline int pick_tile(int64_t rows, int N) {        // 0: 128x128, 1: 64x128, 2: 128x64, 3: 64x64
+  const bool n128 = N % 128 == 0;
+  auto blocks = [&](int bm, int bn) { return ((rows + bm - 1) / bm) * (N / bn); };
+  if (n128 && blocks(128, 128) >= kWantBlocks) return 0;
+  if (n128 && blocks(64, 128) >= kWantBlocks) return 1;
+  if (blocks(128, 64) >= 2 * kWantBlocks) return 2;
+  return 3;
+}
+inline int tile_rows(int cfg) { return (cfg == 0 || cfg == 2) ? 128 : 64; }
+
 template <int MODE, bool WTR, bool KS3, bool SCATTER>
 int launch_g_tiles(const QG& a, hipStream_t st) {
-  const int64_t rows = (int64_t)a.Mg * a.groups;
-  const bool n128 = a.N % 128 == 0;
-  auto blocks = [&](int bm, int bn) { return ((rows + bm - 1) / bm) * (a.N / bn); };
-  if (a.bn_part) {
-    if (n128 && blocks(128, 128) >= kWantBlocks) return launch_g<2, 4, MODE, WTR, KS3, SCATTER, 2>(a, st);
-    return launch_g<1, 2, MODE, WTR, KS3, SCATTER, 2>(a, st);
+  switch (pick_tile((int64_t)a.Mg * a.groups, a.N)) {
+    case 0: return launch_g<2, 4, MODE, WTR, KS3, SCATTER, 2>(a, st);
+    case 1: return launch_g<2, 2, MODE, WTR, KS3, SCATTER, 3>(a, st);
+    case 2: return launch_g<1, 2, MODE, WTR, KS3, SCATTER, 2>(a, st);
+    default: return launch_g<1, 1, MODE, WTR, KS3, SCATTER, 4>(a, st);
   }
-  if (n128 && blocks(128, 128) >= kWantBlocks) return launch_g<2, 4, MODE, WTR, KS3, SCATTER, 2>(a, st);
-  if (n128 && blocks(64, 128) >= kWantBlocks) return launch_g<2, 2, MODE, WTR, KS3, SCATTER, 3>(a, st);
-  if (blocks(128, 64) >= 2 * kWantBlocks) return launch_g<1, 2, MODE, WTR, KS3, SCATTER, 2>(a, st);
-  return launch_g<1, 1, MODE, WTR, KS3, SCATTER, 4>(a, st);
 }
 
 int wgrad_splits(int64_t M, int tiles) {
@@ -549,7 +554,8 @@ int alignq_qconv_supported(int B, int H_in, int W_in, int CIN, int COUT, int KS,
 int alignq_qconv_bn_parts(int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride, int groups) {
   if (!shape_ok(B, H_in, W_in, CIN, COUT, KS, stride) || groups < 1 || B % groups) return 0;
   const int Ho = (H_in - 1) / stride + 1, Wo = (W_in - 1) / stride + 1;
-  return (int)(((int64_t)(B / groups) * Ho * Wo + 127) / 128);
+  const int bm = tile_rows(pick_tile((int64_t)B * Ho * Wo, COUT));
+  return (int)(((int64_t)(B / groups) * Ho * Wo + bm - 1) / bm);
 }
 
 int alignq_qconv_pack_weights(int T, const float* const* wt, const int64_t* n, int w_bit, void* const* bins_bf16, void* const* bins_f16,

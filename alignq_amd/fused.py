@@ -630,7 +630,7 @@ class BNQuantReluFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, weight, bias, running_mean, running_var, nbt, momentum, bn_eps, k, act_range, formula, relu, groups=1,
-                residual=None):
+                residual=None, conv_part=None):
         """residual: added to the quantised value before the ReLU in the same pass (the CDF-only block's `out += shortcut;
         relu`); its gradient - the masked upstream gradient - is a second output of the backward's apply pass."""
         z = L.dense_f32(z, "conv output")
@@ -648,11 +648,14 @@ class BNQuantReluFn(torch.autograd.Function):
         # the ReLU mask the backward needs, one bit per element (round 4): the node keeps 1/32 of a tensor instead of reading the
         # fp32 y twice; y itself belongs to whoever consumes it
         mask = torch.empty(lib.alignq_bnq_mask_bytes(P, C, groups), dtype=torch.uint8, device=dev) if (relu and _BNQ_BITMASK) else None
-        L.check(lib.alignq_bnq_fwd(L.ptr(z), P, C, groups, L.ptr(weight), L.ptr(bias), L.ptr(running_mean), L.ptr(running_var),
-                                   L.ptr(nbt), float(momentum), float(bn_eps), int(k), float(act_range), int(formula),
-                                   int(bool(relu)), L.ptr(residual), L.ptr(ab), L.ptr(save), L.ptr(y), L.ptr(mask), L.ptr(ws),
-                                   L.stream_ptr()),
-                "alignq_bnq_fwd")
+        # conv_part: (double [groups, parts, C, 2], parts) left by the producing convolution's epilogue (ops.QConvGemmFn): the
+        # statistics pass over z is skipped
+        cp, cn = (conv_part[0], int(conv_part[1])) if conv_part is not None else (None, 0)
+        L.check(lib.alignq_bnq_fwd_parts(L.ptr(z), P, C, groups, L.ptr(weight), L.ptr(bias), L.ptr(running_mean), L.ptr(running_var),
+                                         L.ptr(nbt), float(momentum), float(bn_eps), int(k), float(act_range), int(formula),
+                                         int(bool(relu)), L.ptr(residual), L.ptr(ab), L.ptr(save), L.ptr(y), L.ptr(mask), L.ptr(ws),
+                                         L.ptr(cp), cn, L.stream_ptr()),
+                "alignq_bnq_fwd_parts")
         ctx.save_for_backward(z, (mask if mask is not None else y) if relu else None, ab, save)
         ctx.bitmask = mask is not None
         ctx.has_res = residual is not None
@@ -680,7 +683,7 @@ class BNQuantReluFn(torch.autograd.Function):
                 "alignq_bnq_bwd")
         if ctx.has_res and not relu and ctx.needs_input_grad[13]:
             dres = g
-        return dz, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, dres
+        return dz, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, dres, None
 
 
 def _bn_nhwc_ok(bn, z, groups=1) -> bool:
@@ -709,19 +712,20 @@ class BNAffineFn(torch.autograd.Function):
     groups: as in BNQuantReluFn."""
 
     @staticmethod
-    def forward(ctx, z, weight, bias, running_mean, running_var, nbt, momentum, bn_eps, groups=1):
+    def forward(ctx, z, weight, bias, running_mean, running_var, nbt, momentum, bn_eps, groups=1, conv_part=None):
         z = L.dense_f32(z, "conv output")
         B, C, H, W = z.shape
         Bg = B // groups
         lib, dev, P = L.load(), z.device, Bg * H * W
+        cp, cn = (conv_part[0], int(conv_part[1])) if conv_part is not None else (None, 0)
         ab = torch.empty(groups, 2, C, dtype=torch.float32, device=dev)
         save = torch.empty(groups, 2, C, dtype=torch.float32, device=dev)
         y = torch.empty_like(z)
         ws = torch.empty(lib.alignq_bnq_ws_bytes(C, groups), dtype=torch.uint8, device=dev)
         st = L.stream_ptr()
-        L.check(lib.alignq_bnq_stats(L.ptr(z), P, C, groups, L.ptr(weight), L.ptr(bias), L.ptr(running_mean), L.ptr(running_var),
-                                     L.ptr(nbt), float(momentum), float(bn_eps), L.ptr(ab), L.ptr(save), L.ptr(ws), st),
-                "alignq_bnq_stats")
+        L.check(lib.alignq_bnq_stats_parts(L.ptr(z), P, C, groups, L.ptr(weight), L.ptr(bias), L.ptr(running_mean),
+                                           L.ptr(running_var), L.ptr(nbt), float(momentum), float(bn_eps), L.ptr(ab), L.ptr(save),
+                                           L.ptr(ws), L.ptr(cp), cn, st), "alignq_bnq_stats_parts")
         L.check(lib.alignq_bnq_affine(L.ptr(z), L.ptr(ab), P, C, groups, L.ptr(y), st), "alignq_bnq_affine")
         ctx.save_for_backward(z, ab, save)
         ctx.has = (weight is not None, bias is not None, int(groups))
@@ -742,7 +746,29 @@ class BNAffineFn(torch.autograd.Function):
         ws = torch.empty(lib.alignq_bnq_ws_bytes(C, groups), dtype=torch.uint8, device=z.device)
         L.check(lib.alignq_bnq_bwd_dx(L.ptr(g), L.ptr(z), L.ptr(ab), L.ptr(save), Bg * H * W, C, groups, L.ptr(dz), L.ptr(dgamma),
                                       L.ptr(dbeta), L.ptr(ws), L.stream_ptr()), "alignq_bnq_bwd_dx")
-        return dz, dgamma, dbeta, None, None, None, None, None, None
+        return dz, dgamma, dbeta, None, None, None, None, None, None, None
+
+
+_conv_groups = 1
+
+
+def set_conv_groups(groups):
+    """How many equal batch slices the tensors of the current traversal hold (resnet_office.ResNet.forward(groups)): a convolution
+    that leaves batch-norm partial statistics (Conv2d_Q.emit_bn_stats) sums them per slice."""
+    global _conv_groups
+    _conv_groups = int(groups)
+
+
+def conv_groups():
+    return _conv_groups
+
+
+def conv_partials(z, groups):
+    """(partials, parts) a GEMM convolution left on its output for `groups` batch slices (ops.QConvGemmFn.apply_with_stats), or None"""
+    rec = getattr(z, "_alignq_bnq_part", None)
+    if rec is None or rec[2] != int(groups):
+        return None
+    return rec[0], rec[1]
 
 
 def bn_only(bn, z, groups=1):
@@ -753,7 +779,7 @@ def bn_only(bn, z, groups=1):
             return bn(z)
         return torch.cat([bn(zz) for zz in _slices(z, groups)], 0)
     return BNAffineFn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum, bn.eps,
-                            groups)
+                            groups, conv_partials(z, groups))
 
 
 _S1_MASK_IN_KERNEL = os.environ.get("ALIGNQ_S1_MASK", "1") != "0"
@@ -775,7 +801,7 @@ class BNSite1Fn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, weight, bias, running_mean, running_var, nbt, momentum, bn_eps, residual, alterD, gamma, k,
-                act_range, eps, mu, rho, groups=1, tok=None, loss_vec=False):
+                act_range, eps, mu, rho, groups=1, tok=None, loss_vec=False, conv_part=None):
         ctx.tok = tok             # GradFork's mailbox (see there): a dict shared with whoever forks this node's output
         z = L.dense_f32(z, "conv output")
         A, Gm = L.dev_f32(alterD, "alterD"), L.dev_f32(gamma, "gamma")
@@ -797,9 +823,10 @@ class BNSite1Fn(torch.autograd.Function):
         scal = torch.empty(groups, 4, dtype=torch.float32, device=dev)
         from .ops import _ws
         ws = _ws(lib.alignq_site_ws_bytes(B, F) * groups, dev)
-        L.check(lib.alignq_bnq_stats(L.ptr(z), P, C, groups, L.ptr(weight), L.ptr(bias), L.ptr(running_mean), L.ptr(running_var),
-                                     L.ptr(nbt), float(momentum), float(bn_eps), L.ptr(ab), L.ptr(save), L.ptr(ws_bn), st),
-                "alignq_bnq_stats")
+        cp, cn = (conv_part[0], int(conv_part[1])) if conv_part is not None else (None, 0)
+        L.check(lib.alignq_bnq_stats_parts(L.ptr(z), P, C, groups, L.ptr(weight), L.ptr(bias), L.ptr(running_mean),
+                                           L.ptr(running_var), L.ptr(nbt), float(momentum), float(bn_eps), L.ptr(ab), L.ptr(save),
+                                           L.ptr(ws_bn), L.ptr(cp), cn, st), "alignq_bnq_stats_parts")
         # every slice in ONE launch per kernel (blockIdx.y = slice; the slices' workspace regions lie back to back)
         L.check(lib.alignq_site1_groups_fwd(L.ptr(z), L.ptr(ab), C, B, F, groups, int(k), float(act_range), float(eps),
                                             L.ptr(residual), 1, L.ptr(y), L.ptr(stats), L.ptr(ws), st), "alignq_site1_groups_fwd")
@@ -905,7 +932,7 @@ class BNSite1Fn(torch.autograd.Function):
                 return out
             rA, rG = red(dA), red(dG)
         return (dx, dgamma, dbeta, None, None, None, None, None, g_m if has_res else None, rA, rG, None, None,
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, None)
 
 
 def bn_site_res_relu(bn, act, z, residual, eps, groups=1, loss_vec=False):
@@ -923,7 +950,7 @@ def bn_site_res_relu(bn, act, z, residual, eps, groups=1, loss_vec=False):
     tok = {} if _GRAD_FORK else None
     y, loss, D = BNSite1Fn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum,
                                  bn.eps, residual, admm.alterD, admm.gamma, act.a_bit, config.args.act_range, eps, admm.mu, admm.rho,
-                                 groups, tok, bool(loss_vec and groups > 1))
+                                 groups, tok, bool(loss_vec and groups > 1), conv_partials(z, groups))
     if tok is not None:
         y._alignq_site_tok = tok          # read by fork_block_input (the next bottleneck)
     admm.D = D
@@ -980,7 +1007,7 @@ def bn_act_relu(bn, act, z, formula, relu=True, groups=1, residual=None):
         rs = _slices(residual, groups) if residual is not None else [None] * groups
         return torch.cat([one(zz, rr) for zz, rr in zip(_slices(z, groups), rs)], 0)
     y = BNQuantReluFn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum,
-                            bn.eps, act.a_bit, config.args.act_range, formula, relu, groups, residual)
+                            bn.eps, act.a_bit, config.args.act_range, formula, relu, groups, residual, conv_partials(z, groups))
     if residual is None:
         tag_levels(y, act.a_bit, config.args.act_range, formula)
     return y

@@ -279,8 +279,13 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
                     if ops.qconv_stem_supported(*args):
                         return ops.QConvStemFn.apply_with_stats(input, weight_q, self.quantize_fn.w_bit)
                     if ops.qconv_gemm_supported(*args):      # the ResNet-50 shapes: exact-product GEMMs (csrc/qgemm_kernels.hip)
+                        bins = self.quantize_fn.take_bins(weight_q)
+                        if getattr(self, "emit_bn_stats", False):     # the batch-norm behind this convolution takes its statistics
+                            from . import fused                        # from the epilogue (fused.conv_partials)
+                            return ops.QConvGemmFn.apply_with_stats(input, weight_q, self.quantize_fn.w_bit, self.stride[0],
+                                                                    ops.level_count(input), fused.conv_groups(), bins)
                         return ops.QConvGemmFn.apply(input, weight_q, self.quantize_fn.w_bit, self.stride[0],
-                                                     ops.level_count(input), 1, False, self.quantize_fn.take_bins(weight_q))
+                                                     ops.level_count(input), 1, False, bins)
                 return F.conv2d(input, weight_q, self.bias, self.stride, self.padding, self.dilation, self.groups)
 
             def forward_with_shortcut(self, input):

@@ -136,6 +136,8 @@ class ResNet(nn.Module):
 
     def forward(self, x, groups=1):
         trans_loss = 0.
+        from . import fused
+        fused.set_conv_groups(groups)        # (the GEMM convolutions' batch-norm statistics epilogue sums per batch slice)
         if groups > 1:
             q0 = self.act_q0.forward_bn_relu(self.bn1, self.conv1(x), groups)
             x = self.maxpool(q0)

@@ -318,6 +318,9 @@ class OfficeTrainStep:
         for mod in model.modules():
             if hasattr(mod, "quantize_fn"):
                 mod.use_qconv = self.qconv
+                # every Conv2d_Q of this network is followed by a batch-norm; folded (fuse_bn) it reads the convolution's
+                # per-tile statistics instead of making a pass of its own over the output
+                mod.emit_bn_stats = bool(self.qconv and fuse_bn and fuse_relu)
         self._wgrads = DeferredWgrads() if self.qconv else None
         for mod in model.modules():
             if hasattr(mod, "act_q0") or (hasattr(mod, "act_q1") and hasattr(mod, "act_q2") and hasattr(mod, "act_q3")):

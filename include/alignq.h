@@ -518,6 +518,12 @@ int alignq_bn_partial_stats_nhwc(const float* z, int B, int C, int HW, void* ws,
 int alignq_bnq_stats(const float* z, int64_t P, int C, int groups, const float* gamma, const float* beta, float* running_mean,
                      float* running_var, int64_t* num_batches_tracked, float momentum, float bn_eps, float* ab, float* save,
                      void* ws, void* stream);
+/* The same with the statistics pass replaced by partial sums the producing convolution left in its epilogue (alignq_qconv_fwd
+ * bn_part: conv_part [groups][conv_parts][C][2] doubles, {sum z, sum z^2} per row tile): no read of z here.  conv_part == NULL: as
+ * alignq_bnq_stats.                                                                                                          */
+int alignq_bnq_stats_parts(const float* z, int64_t P, int C, int groups, const float* gamma, const float* beta, float* running_mean,
+                           float* running_var, int64_t* num_batches_tracked, float momentum, float bn_eps, float* ab, float* save,
+                           void* ws, const double* conv_part, int conv_parts, void* stream);
 int alignq_bnq_affine(const float* z, const float* ab, int64_t P, int C, int groups, float* y, void* stream);
 int alignq_bnq_bwd_dx(const float* dx, const float* z, const float* ab, const float* save, int64_t P, int C, int groups,
                       float* dz, float* dgamma, float* dbeta, void* ws, void* stream);
@@ -576,6 +582,11 @@ int alignq_bnq_fwd(const float* z, int64_t P, int C, int groups, const float* ga
                    float* running_var, int64_t* num_batches_tracked, float momentum, float bn_eps, int k, float act_range,
                    int formula, int relu, const float* residual, float* ab, float* save, float* y, void* mask, void* ws,
                    void* stream);
+/* alignq_bnq_fwd with the statistics pass replaced by a convolution's partial sums (see alignq_bnq_stats_parts)                  */
+int alignq_bnq_fwd_parts(const float* z, int64_t P, int C, int groups, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, int64_t* num_batches_tracked, float momentum, float bn_eps, int k, float act_range,
+                         int formula, int relu, const float* residual, float* ab, float* save, float* y, void* mask, void* ws,
+                         const double* conv_part, int conv_parts, void* stream);
 int alignq_bnq_bwd(const float* g, const float* z, const float* y, const void* mask, const float* ab, const float* save, int64_t P,
                    int C, int groups, float act_range, int relu, float* dz, float* dres, float* dgamma, float* dbeta, void* ws,
                    void* stream);
