@@ -98,7 +98,7 @@ SIGNATURES = {
     "alignq_conv3x3_nhwc_bwd_fill": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                           _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "alignq_qconv_supported": (_i, [_i] * 7),
-    "alignq_qconv_bn_parts": (_i, [_i] * 8),
+    "alignq_qconv_bn_parts": (_i, [_i] * 8 + [_f]),
     "alignq_qconv_pack_weights": (_i, [_i, _vp, _vp, _i, _vp, _vp, _vp]),
     "alignq_qconv_fwd": (_i, [_vp, _vp, _vp] + [_i] * 8 + [_f, _i, _vp, _vp]),
     "alignq_qconv_dgrad": (_i, [_vp, _vp, _vp] + [_i] * 8 + [_vp]),

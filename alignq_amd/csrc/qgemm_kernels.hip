@@ -32,7 +32,6 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 
 constexpr int BK = 64;            // k per step of the forward / data-gradient GEMM (two MFMA k-substeps)
-constexpr int LDK = BK + 8;       // halfwords per row of a direct image: 144 B rows, 16 lanes of a ds_read_b128 on 16 slots
 
 // 4 rows x 16 columns block at `p` (this lane's row (lane & 15) >> 2, columns 4 * (lane & 3)), transposed by the LDS hardware:
 // the lane receives column (lane & 15) of the 4 rows.  EXEC all ones at every call.
@@ -110,16 +109,26 @@ struct QG {
 
 // OCC: workgroups per CU the register / LDS budget is sized for (a small tile runs 3-4 of them: latency hiding comes from the
 // other workgroups' waves, the staging of one overlaps the MFMAs of another)
-template <int WN, int TM, int MODE, bool WTR, bool KS3, bool SCATTER, int OCC>
+// KM: 0 = 1x1 (one tap); 1 = 3x3, the pixel-side tile gathered per tap (any stride); 2 = 3x3 stride 1 with a HALO image: the
+// workgroup's BM consecutive pixels plus W + 1 pixels on either side are staged ONCE per channel chunk (rows = flattened pixel
+// index) and the nine taps read them at row offsets dy * W + dx; a lane whose tap falls outside its image reads an all-zero row
+// instead (address select, no branch).  The pixel-side global loads, splits and LDS writes drop by ~9 BM / (BM + 2 W + 2).
+constexpr int kHaloW = 56;        // widest image the halo form takes (LDS is sized for it)
+template <int WN, int TM, int MODE, bool WTR, int KM, bool SCATTER, int OCC>
 __global__ __launch_bounds__(256, OCC) void qgemm_kernel(const QG a) {
   constexpr int WM = 4 / WN, BM = WM * 16 * TM, BN = 64 * WN;
   constexpr int TA = MODE == 0 ? 3 : 1;
   constexpr bool F16 = MODE == 1;
-  constexpr int NA = BM / 16;                      // float4 per thread of the pixel-side tile (16 float4 per row of BK)
-  constexpr int NB = BN / 32;                      // 16-byte pieces (8 bins) per thread of the filter tile
-  constexpr int LDN = BN + 16;                     // halfwords per row of the transposed filter image
-  constexpr int XPL = BM * LDK;                    // halfwords per pixel-side plane
-  constexpr int WSZ = WTR ? BK * LDN : BN * LDK;
+  constexpr bool KS3 = KM != 0, HALO = KM == 2;
+  constexpr int KB = (HALO && MODE == 0) ? 32 : BK;      // k per step (the three-plane halo image would not fit at 64)
+  constexpr int LDX = KB + 8;                            // halfwords per row of a direct image (80- / 144-byte rows: conflict-free b128)
+  constexpr int XR = HALO ? BM + 2 * kHaloW + 3 : BM;    // rows of the pixel-side image (+ the zero row)
+  constexpr int NA = (XR * (KB / 4) + 255) / 256;        // float4 per thread of the pixel-side tile
+  constexpr int NB = (BN * KB / 8) / 256;                // 16-byte pieces (8 bins) per thread of the filter tile
+  static_assert(NB >= 1, "filter tile");
+  constexpr int LDN = BN + 16;                           // halfwords per row of the transposed filter image
+  constexpr int XPL = XR * LDX;                          // halfwords per pixel-side plane
+  constexpr int WSZ = WTR ? KB * LDN : BN * LDX;
   constexpr int RED_HW = BN * WM * 16 * 4;      // halfwords of the epilogue's statistics buffer [BN][WM * 16][2] floats
   constexpr int LDS_HW = (TA * XPL + WSZ) > RED_HW ? (TA * XPL + WSZ) : RED_HW;
   __shared__ __attribute__((aligned(16))) u16 lds[LDS_HW];
@@ -133,42 +142,75 @@ __global__ __launch_bounds__(256, OCC) void qgemm_kernel(const QG a) {
   const int grp = mt_all / a.tiles_per_group, mt = mt_all % a.tiles_per_group;
   const int m_lo = grp * a.Mg + mt * BM, m_end = (grp + 1) * a.Mg;
   const int n0 = nt * BN;
+  const int fr = lane & 15, fg = lane >> 4, fq = (lane & 15) >> 2, fc = 4 * (lane & 3);
 
-  // ---- this thread's rows of the pixel-side tile: row r = (tid >> 4) + 16 i, float4 column c4 = tid & 15 ------------------------
-  const int c4 = tid & 15, rr = tid >> 4;
-  int pix[NA];             // pixel index of xa at the centre tap, -1: row beyond the group
-  int hw[NA];              // KS3: (h << 16) | w of that pixel in the xa grid
+  // ---- this thread's share of the pixel-side tile -----------------------------------------------------------------------------
+  constexpr int C4 = KB / 4;                       // float4 per row
+  const int c4 = tid % C4, rr = tid / C4;          // row rr + (256 / C4) i, float4 column c4
+  constexpr int RP = 256 / C4;                     // rows per pass
+  int pix[HALO ? 1 : NA];      // gather forms: pixel index of xa at the centre tap, -1: row beyond the group
+  int hw[HALO ? 1 : NA];       // KM == 1: (h << 16) | w of that pixel in the xa grid
+  const int total_px = a.Mg * a.groups;            // HALO: pixels of xa (row grid == xa grid)
+  const int halo_rows = BM + 2 * a.Wa + 2;         // HALO: staged rows; row halo_rows is the zero row
+  if constexpr (!HALO) {
 #pragma unroll
-  for (int i = 0; i < NA; i++) {
-    const int m = m_lo + rr + 16 * i;
-    if (m < m_end) {
-      const int wr = m % a.Wr, t = m / a.Wr, hr = t % a.Hr, img = t / a.Hr;
-      pix[i] = (img * a.Ha + hr * a.S) * a.Wa + wr * a.S;
-      hw[i] = ((hr * a.S) << 16) | (wr * a.S);
-    } else {
-      pix[i] = -1;
-      hw[i] = 0;
+    for (int i = 0; i < NA; i++) {
+      const int m = m_lo + rr + RP * i;
+      if (m < m_end) {
+        const int wr = m % a.Wr, t = m / a.Wr, hr = t % a.Hr, img = t / a.Hr;
+        pix[i] = (img * a.Ha + hr * a.S) * a.Wa + wr * a.S;
+        hw[i] = ((hr * a.S) << 16) | (wr * a.S);
+      } else {
+        pix[i] = -1;
+        hw[i] = 0;
+      }
+    }
+  } else {
+    pix[0] = hw[0] = 0;
+    // the zero row (and the never-staged rows behind it) of every plane
+    for (int i = tid; i < TA * (XR - halo_rows) * (LDX / 4); i += 256) {
+      const int pl = i / ((XR - halo_rows) * (LDX / 4)), j = i % ((XR - halo_rows) * (LDX / 4));
+      *reinterpret_cast<s16x4*>(Xs + pl * XPL + halo_rows * LDX + 4 * j) = (s16x4){0, 0, 0, 0};
     }
   }
-  const int nk = (KS3 ? 9 : 1) * a.KC;
+  // k steps: KM 0: channel chunks; KM 1: (tap, chunk) tap-major; KM 2: (chunk, tap) chunk-major (the halo image serves 9 taps)
+  const int KC = a.CA / KB;
+  const int nk = (KS3 ? 9 : 1) * KC;
   f32x4 ra[NA];
   s16x8 rw[NB];
 
-  auto fetch = [&](int kt) {
-    const int tap = KS3 ? kt / a.KC : 0, c0 = (KS3 ? kt % a.KC : kt) * BK;
-    const int dy = KS3 ? a.sgn * (tap / 3 - 1) : 0, dx = KS3 ? a.sgn * (tap % 3 - 1) : 0;
+  auto fetch_x = [&](int kt) {          // KM 0 / 1: the step's tile; KM 2: chunk kt's halo image
+    if constexpr (HALO) {
+      const int c0 = kt * KB;
 #pragma unroll
-    for (int i = 0; i < NA; i++) {
-      bool ok = pix[i] >= 0;
-      if (KS3) ok = ok && (unsigned)((hw[i] >> 16) + dy) < (unsigned)a.Ha && (unsigned)((hw[i] & 0xffff) + dx) < (unsigned)a.Wa;
-      const int64_t off = ok ? ((int64_t)(pix[i] + dy * a.Wa + dx) * a.CA + c0 + 4 * c4) : 0;
-      ra[i] = *reinterpret_cast<const f32x4*>(a.xa + off);
-      if (!ok) ra[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < NA; i++) {
+        const int r = rr + RP * i;
+        const int f = m_lo - a.Wa - 1 + r;
+        const bool ok = r < halo_rows && f >= 0 && f < total_px;
+        ra[i] = *reinterpret_cast<const f32x4*>(a.xa + (ok ? (int64_t)f * a.CA + c0 + 4 * c4 : 0));
+        if (!ok) ra[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    } else {
+      const int tap = KS3 ? kt / KC : 0, c0 = (KS3 ? kt % KC : kt) * KB;
+      const int dy = KS3 ? a.sgn * (tap / 3 - 1) : 0, dx = KS3 ? a.sgn * (tap % 3 - 1) : 0;
+#pragma unroll
+      for (int i = 0; i < NA; i++) {
+        bool ok = pix[i] >= 0;
+        if (KS3) ok = ok && (unsigned)((hw[i] >> 16) + dy) < (unsigned)a.Ha && (unsigned)((hw[i] & 0xffff) + dx) < (unsigned)a.Wa;
+        const int64_t off = ok ? ((int64_t)(pix[i] + dy * a.Wa + dx) * a.CA + c0 + 4 * c4) : 0;
+        ra[i] = *reinterpret_cast<const f32x4*>(a.xa + off);
+        if (!ok) ra[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
     }
-    if (!WTR) {           // rows n of the tile, 8 pieces of 8 k each: row = (tid >> 3) + 32 i, piece = tid & 7
+  };
+  auto fetch_w = [&](int kt) {
+    const int tap = !KS3 ? 0 : (HALO ? kt % 9 : kt / KC), c0 = (!KS3 ? kt : (HALO ? kt / 9 : kt % KC)) * KB;
+    if (!WTR) {           // rows n of the tile, KB / 8 pieces of 8 k each
+      constexpr int PPR = KB / 8, RPW = 256 / PPR;
 #pragma unroll
       for (int i = 0; i < NB; i++)
-        rw[i] = *reinterpret_cast<const s16x8*>(a.w + (int64_t)(n0 + (tid >> 3) + 32 * i) * a.wrow + (int64_t)kt * BK + 8 * (tid & 7));
+        rw[i] = *reinterpret_cast<const s16x8*>(a.w + (int64_t)(n0 + tid / PPR + RPW * i) * a.wrow + (int64_t)tap * a.CA + c0 +
+                                                8 * (tid % PPR));
     } else {              // rows k (channels of xa), BN / 8 pieces of 8 n each
 #pragma unroll
       for (int i = 0; i < NB; i++) {
@@ -177,10 +219,13 @@ __global__ __launch_bounds__(256, OCC) void qgemm_kernel(const QG a) {
       }
     }
   };
-  auto park = [&]() {
+  auto park_x = [&]() {
 #pragma unroll
     for (int i = 0; i < NA; i++) {
-      const int o = (rr + 16 * i) * LDK + 4 * c4;
+      const int r = rr + RP * i;
+      if (HALO && r >= halo_rows) continue;
+      if (!HALO && NA * RP > BM && r >= BM) continue;
+      const int o = r * LDX + 4 * c4;
       if constexpr (MODE == 0) {
         s16x4 h, m, l;
         split3(ra[i], h, m, l);
@@ -191,10 +236,13 @@ __global__ __launch_bounds__(256, OCC) void qgemm_kernel(const QG a) {
         *reinterpret_cast<s16x4*>(Xs + o) = to_half4<true>(rint4(ra[i], a.xlev));
       }
     }
+  };
+  auto park_w = [&]() {
 #pragma unroll
     for (int i = 0; i < NB; i++) {
       if (!WTR) {
-        *reinterpret_cast<s16x8*>(Ws + ((tid >> 3) + 32 * i) * LDK + 8 * (tid & 7)) = rw[i];
+        constexpr int PPR = KB / 8, RPW = 256 / PPR;
+        *reinterpret_cast<s16x8*>(Ws + (tid / PPR + RPW * i) * LDX + 8 * (tid % PPR)) = rw[i];
       } else {
         const int idx = tid + 256 * i, kr = idx / (BN / 8), n8 = idx % (BN / 8);
         *reinterpret_cast<s16x8*>(Ws + kr * LDN + 8 * n8) = rw[i];
@@ -202,26 +250,58 @@ __global__ __launch_bounds__(256, OCC) void qgemm_kernel(const QG a) {
     }
   };
 
+  // HALO: this lane's pixel of every 16-pixel tile: its row in the halo image and (h << 16) | w (-1: beyond the group: zero row)
+  int hrow[HALO ? TM : 1], hhw[HALO ? TM : 1];
+  if constexpr (HALO) {
+#pragma unroll
+    for (int tm = 0; tm < TM; tm++) {
+      const int m = m_lo + (wm * TM + tm) * 16 + fr;
+      hrow[tm] = (m - m_lo) + a.Wa + 1;
+      hhw[tm] = m < m_end ? ((((m / a.Wa) % a.Ha) << 16) | (m % a.Wa)) : -1;
+    }
+  } else {
+    hrow[0] = hhw[0] = 0;
+  }
+
   f32x4 acc[4][TM];
 #pragma unroll
   for (int i = 0; i < 4; i++)
 #pragma unroll
     for (int j = 0; j < TM; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int fr = lane & 15, fg = lane >> 4, fq = (lane & 15) >> 2, fc = 4 * (lane & 3);
-  fetch(0);
+  fetch_x(0);
+  fetch_w(0);
   for (int kt = 0; kt < nk; kt++) {
+    const int tap = HALO ? kt % 9 : 0;
     __syncthreads();                         // the previous step's fragment reads are done
-    park();
+    if (!HALO || tap == 0) park_x();
+    park_w();
     __syncthreads();
-    if (kt + 1 < nk) fetch(kt + 1);          // in flight under this step's MFMAs
+    if (kt + 1 < nk) {                       // in flight under this step's MFMAs
+      fetch_w(kt + 1);
+      if (!HALO) fetch_x(kt + 1);
+    }
+    if (HALO && tap == 6 && kt + 3 < nk) fetch_x(kt / 9 + 1);      // the next chunk's halo image: three taps of MFMAs ahead
+    int xrow[TM];
+    if constexpr (HALO) {
+      const int dy = a.sgn * (tap / 3 - 1), dx = a.sgn * (tap % 3 - 1);
 #pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
+      for (int tm = 0; tm < TM; tm++) {
+        const bool ok = hhw[tm] >= 0 && (unsigned)((hhw[tm] >> 16) + dy) < (unsigned)a.Ha &&
+                        (unsigned)((hhw[tm] & 0xffff) + dx) < (unsigned)a.Wa;
+        xrow[tm] = ok ? hrow[tm] + dy * a.Wa + dx : halo_rows;
+      }
+    } else {
+#pragma unroll
+      for (int tm = 0; tm < TM; tm++) xrow[tm] = (wm * TM + tm) * 16 + fr;
+    }
+#pragma unroll
+    for (int ks = 0; ks < KB / 32; ks++) {
       s16x8 wf[4];
 #pragma unroll
       for (int tn = 0; tn < 4; tn++) {
         if (!WTR) {
-          wf[tn] = *reinterpret_cast<const s16x8*>(Ws + (wn * 64 + tn * 16 + fr) * LDK + ks * 32 + 8 * fg);
+          wf[tn] = *reinterpret_cast<const s16x8*>(Ws + (wn * 64 + tn * 16 + fr) * LDX + ks * 32 + 8 * fg);
         } else {
           const u16* p = Ws + (ks * 32 + 8 * fg + fq) * LDN + wn * 64 + tn * 16 + fc;
           wf[tn] = join8(tr_read(p), tr_read(p + 4 * LDN));
@@ -229,7 +309,7 @@ __global__ __launch_bounds__(256, OCC) void qgemm_kernel(const QG a) {
       }
 #pragma unroll
       for (int tm = 0; tm < TM; tm++) {
-        const u16* p = Xs + ((wm * TM + tm) * 16 + fr) * LDK + ks * 32 + 8 * fg;
+        const u16* p = Xs + xrow[tm] * LDX + ks * 32 + 8 * fg;
 #pragma unroll
         for (int t = TA - 1; t >= 0; t--) {           // smallest term first
           const s16x8 xf = *reinterpret_cast<const s16x8*>(p + t * XPL);
@@ -461,6 +541,166 @@ __global__ __launch_bounds__(256, 2) void qgemm_wgrad_kernel(const QW a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Filter gradient of the 3x3 stride-1 convolutions with a HALO image: a workgroup owns a 64 x 64 (c, n) tile for ALL nine taps.
+// Per step of 32 pixels dy's rows are staged once and x's rows [m0 - W - 1, m0 + 32 + W + 1) once (rows = flattened pixel index);
+// tap (dy, dx) reads x at row offset dy * W + dx, a pixel whose tap leaves its image reads the all-zero row (the lane's row
+// address is selected, no branch: ds_read_b64_tr_b16 takes one row address per lane).  Nine accumulator sets per wave (32 x 32 of
+// the tile each).  Against the per-tap form above: the staging (global loads, splits, LDS writes) of x and dy is shared by the
+// nine taps instead of repeated for each.
+template <int TX>
+__global__ __launch_bounds__(256, TX == 2 ? 2 : 1) void qgemm_wgrad3_kernel(const QW a) {
+  constexpr int BC = 64, BNO = 64, LDC = BC + 16;
+  constexpr int XR = WK + 2 * kHaloW + 3;            // rows of the x image (+ the zero row)
+  constexpr int XPL = XR * LDC, DPL = WK * LDC;
+  constexpr int NX = (XR * (BC / 4) + 255) / 256, ND = (WK * BNO / 4) / 256;
+  __shared__ __attribute__((aligned(16))) u16 lds[TX * XPL + 3 * DPL];
+  u16* const Xs = lds;
+  u16* const Ds = lds + TX * XPL;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wc = wv & 1, wo = wv >> 1;
+  const int tiles = a.c_tiles * a.n_tiles;
+  const int pid = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = pid / tiles, tile = pid % tiles;
+  const int ct = tile % a.c_tiles, ot = tile / a.c_tiles;
+  const int c0 = ct * BC, o0 = ot * BNO;
+  const int m_begin = split * a.per, m_end = (m_begin + a.per < a.M) ? m_begin + a.per : a.M;
+  const int W = a.Wa, H = a.Ha;
+  const int halo_rows = WK + 2 * W + 2;              // staged rows; row halo_rows is the zero row
+  for (int i = tid; i < TX * (XR - halo_rows) * (LDC / 4); i += 256) {
+    const int pl = i / ((XR - halo_rows) * (LDC / 4)), j = i % ((XR - halo_rows) * (LDC / 4));
+    *reinterpret_cast<s16x4*>(Xs + pl * XPL + halo_rows * LDC + 4 * j) = (s16x4){0, 0, 0, 0};
+  }
+  f32x4 rx[NX], rd[ND];
+  auto fetch = [&](int m0) {
+#pragma unroll
+    for (int i = 0; i < NX; i++) {
+      const int idx = tid + 256 * i, r = idx / (BC / 4), q4 = idx % (BC / 4);
+      const int f = m0 - W - 1 + r;
+      const bool ok = r < halo_rows && f >= 0 && f < a.M;
+      rx[i] = *reinterpret_cast<const f32x4*>(a.x + (ok ? (int64_t)f * a.CIN + c0 + 4 * q4 : 0));
+      if (!ok) rx[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < ND; i++) {
+      const int idx = tid + 256 * i, kr = idx / (BNO / 4), q4 = idx % (BNO / 4);
+      const int m = m0 + kr;
+      const bool ok = m < m_end;
+      rd[i] = *reinterpret_cast<const f32x4*>(a.dy + (ok ? (int64_t)m * a.COUT + o0 + 4 * q4 : 0));
+      if (!ok) rd[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto park = [&]() {
+#pragma unroll
+    for (int i = 0; i < NX; i++) {
+      const int idx = tid + 256 * i, r = idx / (BC / 4), q4 = idx % (BC / 4);
+      if (r >= halo_rows) continue;
+      const int o = r * LDC + 4 * q4;
+      if constexpr (TX == 3) {
+        s16x4 h, m, l;
+        split3(rx[i], h, m, l);
+        *reinterpret_cast<s16x4*>(Xs + o) = h;
+        *reinterpret_cast<s16x4*>(Xs + XPL + o) = m;
+        *reinterpret_cast<s16x4*>(Xs + 2 * XPL + o) = l;
+      } else {
+        s16x4 h, l;
+        split2(rint4(rx[i], a.xlev), h, l);
+        *reinterpret_cast<s16x4*>(Xs + o) = h;
+        *reinterpret_cast<s16x4*>(Xs + XPL + o) = l;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < ND; i++) {
+      const int idx = tid + 256 * i, kr = idx / (BNO / 4), q4 = idx % (BNO / 4);
+      const int o = kr * LDC + 4 * q4;
+      s16x4 h, m, l;
+      split3(rd[i], h, m, l);
+      *reinterpret_cast<s16x4*>(Ds + o) = h;
+      *reinterpret_cast<s16x4*>(Ds + DPL + o) = m;
+      *reinterpret_cast<s16x4*>(Ds + 2 * DPL + o) = l;
+    }
+  };
+
+  f32x4 acc[9][2][2];
+#pragma unroll
+  for (int t = 0; t < 9; t++)
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int fg = lane >> 4, fq = (lane & 15) >> 2, fc = 4 * (lane & 3);
+  const int kp = 4 * fg + fq;                         // this lane's pixel of the step (second block: + 16)
+  if (m_begin < m_end) fetch(m_begin);
+  for (int m0 = m_begin; m0 < m_end; m0 += WK) {
+    __syncthreads();
+    park();
+    __syncthreads();
+    if (m0 + WK < m_end) fetch(m0 + WK);
+    // (h, w) of this lane's two pixels
+    const int ma = m0 + kp, mb = ma + 16;
+    const int wa = ma % W, ha = (ma / W) % H, wb = mb % W, hb = (mb / W) % H;
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++) {
+      const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+      const bool oka = (unsigned)(ha + dy) < (unsigned)H && (unsigned)(wa + dx) < (unsigned)W;
+      const bool okb = (unsigned)(hb + dy) < (unsigned)H && (unsigned)(wb + dx) < (unsigned)W;
+      const int ra = oka ? kp + W + 1 + dy * W + dx : halo_rows;
+      const int rb = okb ? kp + 16 + W + 1 + dy * W + dx : halo_rows;
+      s16x8 xf[2][TX];
+#pragma unroll
+      for (int tc = 0; tc < 2; tc++)
+#pragma unroll
+        for (int t = 0; t < TX; t++) {
+          const u16* p = Xs + t * XPL + (wc * 2 + tc) * 16 + fc;
+          xf[tc][t] = join8(tr_read(p + ra * LDC), tr_read(p + rb * LDC));
+        }
+#pragma unroll
+      for (int tn = 0; tn < 2; tn++) {
+        s16x8 df[3];
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+          const u16* p = Ds + t * DPL + kp * LDC + (wo * 2 + tn) * 16 + fc;
+          df[t] = join8(tr_read(p), tr_read(p + 16 * LDC));
+        }
+#pragma unroll
+        for (int tc = 0; tc < 2; tc++) {
+          f32x4 v = acc[tap][tc][tn];
+          if constexpr (TX == 3) {
+            v = mfma16<false>(xf[tc][1], df[1], v);
+            v = mfma16<false>(xf[tc][0], df[2], v);
+            v = mfma16<false>(xf[tc][2], df[0], v);
+            v = mfma16<false>(xf[tc][0], df[1], v);
+            v = mfma16<false>(xf[tc][1], df[0], v);
+            v = mfma16<false>(xf[tc][0], df[0], v);
+          } else {
+            v = mfma16<false>(xf[tc][1], df[2], v);
+            v = mfma16<false>(xf[tc][1], df[1], v);
+            v = mfma16<false>(xf[tc][0], df[2], v);
+            v = mfma16<false>(xf[tc][1], df[0], v);
+            v = mfma16<false>(xf[tc][0], df[1], v);
+            v = mfma16<false>(xf[tc][0], df[0], v);
+          }
+          acc[tap][tc][tn] = v;
+        }
+      }
+    }
+  }
+  float* slab = a.slabs + (int64_t)split * a.COUT * 9 * a.CIN;
+#pragma unroll
+  for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+    for (int tn = 0; tn < 2; tn++) {
+      const int o = o0 + (wo * 2 + tn) * 16 + (lane & 15);
+#pragma unroll
+      for (int tc = 0; tc < 2; tc++) {
+        const int c = c0 + (wc * 2 + tc) * 16 + 4 * fg;
+        f32x4 v = acc[tap][tc][tn];
+        if constexpr (TX == 2) v = (f32x4){v[0] / a.xlev, v[1] / a.xlev, v[2] / a.xlev, v[3] / a.xlev};
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(slab + ((int64_t)o * 9 + tap) * a.CIN + c));
+      }
+    }
+}
+
 // stand-alone reduction of the split-K slabs (a whole-model step defers it to alignq_conv3x3_wgrad_reduce_multi: same body, same order)
 __global__ __launch_bounds__(1024) void qgemm_slab_reduce_kernel(const float* __restrict__ slabs, int n_slabs, int n_elem,
                                                                  float* __restrict__ dw) {
@@ -500,42 +740,48 @@ bool shape_ok(int B, int H, int W, int CIN, int COUT, int KS, int stride) {
   return true;
 }
 
-template <int WN, int TM, int MODE, bool WTR, bool KS3, bool SCATTER, int OCC>
+template <int WN, int TM, int MODE, bool WTR, int KM, bool SCATTER, int OCC>
 int launch_g(QG a, hipStream_t st) {
   constexpr int BM = (4 / WN) * 16 * TM, BN = 64 * WN;
   a.tiles_per_group = (a.Mg + BM - 1) / BM;
   a.n_tiles = a.N / BN;
   const int grid = a.groups * a.tiles_per_group * a.n_tiles;
-  hipLaunchKernelGGL((qgemm_kernel<WN, TM, MODE, WTR, KS3, SCATTER, OCC>), dim3(grid), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((qgemm_kernel<WN, TM, MODE, WTR, KM, SCATTER, OCC>), dim3(grid), dim3(256), 0, st, a);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
 
-// Tile choice: the largest of 128x128, 64x128, 64x64 (pixels x channels) that still gives the chip >= kWantBlocks workgroups
-// (rows = all groups' rows; alignq_qconv_bn_parts reports the row tiles per group of the same choice).
+// Tile choice: the largest of 128x128, 64x128, 64x64 (pixels x channels) that still gives the chip >= `want` workgroups
+// (rows = all groups' rows; alignq_qconv_bn_parts reports the row tiles per group of the same choice).  The halo form of a level
+// operand (64 channels per step) keeps to 64-row tiles: its image of 128 + 2 W + 2 rows would not fit the prefetch registers.
 constexpr int kWantBlocks = 1024;
-inline int pick_tile(int64_t rows, int N) {        // 0: 128x128, 1: 64x128, 2: 128x64, 3: 64x64
+inline int pick_tile(int64_t rows, int N, bool rows64_only = false, int want = kWantBlocks) {        // 0: 128x128, 1: 64x128, 2: 128x64, 3: 64x64
   const bool n128 = N % 128 == 0;
   auto blocks = [&](int bm, int bn) { return ((rows + bm - 1) / bm) * (N / bn); };
-  if (n128 && blocks(128, 128) >= kWantBlocks) return 0;
-  if (n128 && blocks(64, 128) >= kWantBlocks) return 1;
-  if (blocks(128, 64) >= 2 * kWantBlocks) return 2;
+  if (!rows64_only && n128 && blocks(128, 128) >= want) return 0;
+  if (n128 && (blocks(64, 128) >= want || rows64_only)) return (blocks(64, 128) >= want) ? 1 : 3;
+  if (!rows64_only && blocks(128, 64) >= 2 * want) return 2;
   return 3;
 }
 inline int tile_rows(int cfg) { return (cfg == 0 || cfg == 2) ? 128 : 64; }
+// (KM, MODE) -> whether the halo form runs and what pick_tile gets for it
+inline bool halo_ok(int KS, int stride, int W) { return KS == 3 && stride == 1 && W <= kHaloW; }
+inline int pick_tile_conv(int64_t rows, int N, bool halo, bool level) {
+  return halo ? pick_tile(rows, N, level, kWantBlocks / 2) : pick_tile(rows, N);
+}
 
-template <int MODE, bool WTR, bool KS3, bool SCATTER>
+template <int MODE, bool WTR, int KM, bool SCATTER>
 int launch_g_tiles(const QG& a, hipStream_t st) {
-  switch (pick_tile((int64_t)a.Mg * a.groups, a.N)) {
-    case 0: return launch_g<2, 4, MODE, WTR, KS3, SCATTER, 2>(a, st);
-    case 1: return launch_g<2, 2, MODE, WTR, KS3, SCATTER, 3>(a, st);
-    case 2: return launch_g<1, 2, MODE, WTR, KS3, SCATTER, 2>(a, st);
-    default: return launch_g<1, 1, MODE, WTR, KS3, SCATTER, 4>(a, st);
+  switch (pick_tile_conv((int64_t)a.Mg * a.groups, a.N, KM == 2, MODE == 1)) {
+    case 0: return launch_g<2, 4, MODE, WTR, KM, SCATTER, 2>(a, st);
+    case 1: return launch_g<2, 2, MODE, WTR, KM, SCATTER, (KM == 2 ? 2 : 3)>(a, st);
+    case 2: return launch_g<1, 2, MODE, WTR, KM, SCATTER, 2>(a, st);
+    default: return launch_g<1, 1, MODE, WTR, KM, SCATTER, (KM == 2 ? 3 : 4)>(a, st);
   }
 }
 
-int wgrad_splits(int64_t M, int tiles) {
-  int s = (512 + tiles - 1) / tiles;
+int wgrad_splits(int64_t M, int tiles, int want = 512) {
+  int s = (want + tiles - 1) / tiles;
   const int64_t max_s = (M + 2 * WK - 1) / (2 * WK);       // at least two steps per split
   if (s > max_s) s = (int)max_s;
   if (s < 1) s = 1;
@@ -551,10 +797,11 @@ int alignq_qconv_supported(int B, int H_in, int W_in, int CIN, int COUT, int KS,
   return shape_ok(B, H_in, W_in, CIN, COUT, KS, stride) ? 1 : 0;
 }
 
-int alignq_qconv_bn_parts(int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride, int groups) {
+int alignq_qconv_bn_parts(int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride, int groups, float x_levels) {
   if (!shape_ok(B, H_in, W_in, CIN, COUT, KS, stride) || groups < 1 || B % groups) return 0;
   const int Ho = (H_in - 1) / stride + 1, Wo = (W_in - 1) / stride + 1;
-  const int bm = tile_rows(pick_tile((int64_t)B * Ho * Wo, COUT));
+  // (the row tiles of alignq_qconv_fwd's tile choice for the same arguments)
+  const int bm = tile_rows(pick_tile_conv((int64_t)B * Ho * Wo, COUT, halo_ok(KS, stride, W_in), x_levels != 0.0f));
   return (int)(((int64_t)(B / groups) * Ho * Wo + bm - 1) / bm);
 }
 
@@ -597,8 +844,10 @@ int alignq_qconv_fwd(const float* x, const void* w_bins, float* y, int B, int H_
   a.nlev = (float)((1 << w_bit) - 1); a.xlev = x_levels;
   a.bn_part = bn_part;
   hipStream_t st = (hipStream_t)stream;
-  if (KS == 3) return x_levels != 0.0f ? launch_g_tiles<1, false, true, false>(a, st) : launch_g_tiles<0, false, true, false>(a, st);
-  return x_levels != 0.0f ? launch_g_tiles<1, false, false, false>(a, st) : launch_g_tiles<0, false, false, false>(a, st);
+  if (KS == 3 && halo_ok(KS, stride, W_in))
+    return x_levels != 0.0f ? launch_g_tiles<1, false, 2, false>(a, st) : launch_g_tiles<0, false, 2, false>(a, st);
+  if (KS == 3) return x_levels != 0.0f ? launch_g_tiles<1, false, 1, false>(a, st) : launch_g_tiles<0, false, 1, false>(a, st);
+  return x_levels != 0.0f ? launch_g_tiles<1, false, 0, false>(a, st) : launch_g_tiles<0, false, 0, false>(a, st);
 }
 
 int alignq_qconv_dgrad(const float* dy, const void* w_bins, float* dx, int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride,
@@ -619,11 +868,11 @@ int alignq_qconv_dgrad(const float* dy, const void* w_bins, float* dx, int B, in
   hipStream_t st = (hipStream_t)stream;
   if (stride == 2) {         // 1x1: rows = dy's pixels, scattered to (2h, 2w) with zeros at the other three pixels of the 2x2 cell
     a.Mg = B * Ho * Wo; a.Hr = Ho; a.Wr = Wo;
-    return launch_g_tiles<0, true, false, true>(a, st);
+    return launch_g_tiles<0, true, 0, true>(a, st);
   }
   a.Mg = B * H_in * W_in; a.Hr = H_in; a.Wr = W_in;
-  if (KS == 3) return launch_g_tiles<0, true, true, false>(a, st);
-  return launch_g_tiles<0, true, false, false>(a, st);
+  if (KS == 3) return halo_ok(KS, stride, W_in) ? launch_g_tiles<0, true, 2, false>(a, st) : launch_g_tiles<0, true, 1, false>(a, st);
+  return launch_g_tiles<0, true, 0, false>(a, st);
 }
 
 static int wgrad_geometry(int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride, int* tc, int* tn, int* tiles, int* splits,
@@ -632,8 +881,14 @@ static int wgrad_geometry(int B, int H_in, int W_in, int CIN, int COUT, int KS, 
   *M = (int64_t)B * Ho * Wo;
   *tc = CIN % 128 == 0 ? 4 : 2;
   *tn = COUT % 128 == 0 ? 4 : 2;
+  if (halo_ok(KS, stride, W_in)) {        // qgemm_wgrad3_kernel: 64 x 64 tiles, nine taps per workgroup
+    *tc = *tn = 2;
+    *tiles = (CIN / 64) * (COUT / 64);
+    *splits = wgrad_splits(*M, *tiles, 512);
+    return 1;
+  }
   *tiles = (CIN / (32 * *tc)) * (COUT / (32 * *tn)) * KS * KS;
-  *splits = wgrad_splits(*M, *tiles);
+  *splits = wgrad_splits(*M, *tiles, KS == 3 ? 1024 : 512);
   return 0;
 }
 
@@ -652,7 +907,7 @@ int alignq_qconv_wgrad(const float* x, const float* dy, float* dw, void* ws, int
   if (x_levels != 0.0f && !(x_levels >= 1.0f)) return ALIGNQ_EINVAL;
   int tc, tn, tiles, splits;
   int64_t M;
-  wgrad_geometry(B, H_in, W_in, CIN, COUT, KS, stride, &tc, &tn, &tiles, &splits, &M);
+  const int halo = wgrad_geometry(B, H_in, W_in, CIN, COUT, KS, stride, &tc, &tn, &tiles, &splits, &M);
   QW a{};
   a.x = x; a.dy = dy; a.slabs = (float*)ws;
   a.M = (int)M;
@@ -676,7 +931,10 @@ int alignq_qconv_wgrad(const float* x, const float* dy, float* dw, void* ws, int
       else hipLaunchKernelGGL((qgemm_wgrad_kernel<TC_, TN_, 3, false>), grid, blk, 0, st, a);                             \
     }                                                                                                                    \
   } while (0)
-  if (tc == 4 && tn == 4) QW_LAUNCH(4, 4);
+  if (halo) {
+    if (lev) hipLaunchKernelGGL((qgemm_wgrad3_kernel<2>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((qgemm_wgrad3_kernel<3>), grid, blk, 0, st, a);
+  } else if (tc == 4 && tn == 4) QW_LAUNCH(4, 4);
   else if (tc == 2 && tn == 4) QW_LAUNCH(2, 4);
   else if (tc == 4 && tn == 2) QW_LAUNCH(4, 2);
   else QW_LAUNCH(2, 2);

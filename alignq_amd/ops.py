@@ -917,7 +917,7 @@ class QConvGemmFn(torch.autograd.Function):
         y = torch.empty((B, COUT, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
         part = None
         if bn_stats:
-            n_parts = lib.alignq_qconv_bn_parts(B, H, W, CIN, COUT, ks, s, int(groups))
+            n_parts = lib.alignq_qconv_bn_parts(B, H, W, CIN, COUT, ks, s, int(groups), float(x_levels))
             part = torch.empty(int(groups), n_parts, COUT, 2, dtype=torch.float64, device=x.device)
             QConvGemmFn._mailbox = (part, n_parts)
         L.check(lib.alignq_qconv_fwd(L.ptr(x), L.ptr(bins[1] if x_levels else bins[0]), L.ptr(y), B, H, W, CIN, COUT, ks, s, int(w_bit),

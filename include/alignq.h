@@ -342,7 +342,7 @@ int alignq_conv_gen_nhwc_wgrad(const float* x, const float* dy, float* dw, void*
  * [groups][alignq_qconv_bn_parts][COUT][2], the layout alignq_bnq_* finalise (the batch is `groups` equal slices with separate
  * batch-norm statistics; a tile never straddles two slices).                                                                    */
 int alignq_qconv_supported(int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride);
-int alignq_qconv_bn_parts(int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride, int groups);
+int alignq_qconv_bn_parts(int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride, int groups, float x_levels);
 /* The filter operand of the forward and the data gradient: the integer bins b = rint(W_q * (2^w_bit - 1)) of T quantised filters
  * (wt[i]: n[i] floats, n[i] % 4 == 0, any layout - the bins keep it) as 16-bit patterns, bf16 in bins_bf16[i] and f16 in
  * bins_f16[i] (n[i] halfwords each; both exact for |b| <= 255).  One launch per 64 filters; HOST arrays of DEVICE pointers.       */
