@@ -155,7 +155,6 @@ def attach(train_step, group=None, force=False, global_corr=False):
                 m.global_corr = True if group is None else group
         train_step._deferred = None
         train_step._global_corr_undo = undo
-        train_step._had_global_corr = True          # TrainStep.capture refuses such a step, also after detach (see there)
     broadcast_module_state(train_step.model, 0, group)
     hook = GradAndDAllReduce([p for _, p in train_step.param_t], lambda: [m.D for m in train_step.admms], group,
                              force=force)
@@ -173,6 +172,11 @@ def detach(train_step):
             m.fuse_bn = v
         for m in undo["sites"]:
             m.global_corr = None
+            # the exact-global sites stored D WITH its autograd graph (ADMM.forward, utils/admm.py:25): dropped here, or the last
+            # eager iteration's graph - and the gradient-accumulation nodes bound to its stream - would outlive the mode
+            # (train_step.retained_graph_params: what crashed a later capture in round 4)
+            if getattr(m.opt, "D", None) is not None and m.opt.D.grad_fn is not None:
+                m.opt.D = m.opt.D.detach()
         train_step._deferred = undo["deferred"]
         train_step._global_corr_undo = None
 

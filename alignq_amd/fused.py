@@ -163,6 +163,10 @@ class DeferredLosses:
     def __exit__(self, *exc):
         global _active
         _active = None
+        # the sites' loss tensors were summed inside the context (total / total_with_head); kept any longer they would hold the
+        # iteration's autograd graph - and with it every parameter's gradient-accumulation node - until the next iteration
+        # (train_step.retained_graph_params)
+        self.losses, self._rec_losses = [], []
         return False
 
     def add(self, loss):

@@ -78,11 +78,14 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
             if pre is not None and pre[0] is x:
                 q, c, pdf = pre[1], pre[2], pre[3]
                 if len(pre) > 4:
-                    self._bins = (q, pre[4])          # the filter's packed integer bins (fused.prequantize_weights(pack=True))
+                    self._bins = (q.data_ptr(), pre[4])          # the filter's packed integer bins (fused.prequantize_weights(pack=True))
             else:
                 q, c, pdf = ops.WeightQuantFn.apply(x, self.w_bit, formula)
             if tree != "cdf":   # the CDF tree keeps these as locals (quantization.py:70-72)
-                self.weight_cdf, self.weight_pdf, self.weight_q = c, pdf, q
+                # (weight_q is kept WITHOUT its autograd history: same values for every reader - main.py:326-327 reads cdf / pdf -
+                # but a module attribute with history would keep each iteration's graph alive into the next: see
+                # train_step.retained_graph_params)
+                self.weight_cdf, self.weight_pdf, self.weight_q = c, pdf, q.detach()
             else:
                 self._weight_cdf, self._weight_pdf = c, pdf
             return q
@@ -90,7 +93,7 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
         def take_bins(self, weight_q):
             """(bf16, f16) bins of `weight_q` if the last forward left them (else None: the convolution packs them itself)."""
             held = getattr(self, "_bins", None)
-            return held[1] if held is not None and held[0] is weight_q else None
+            return held[1] if held is not None and held[0] == weight_q.data_ptr() else None
 
     def _plain_act(x, a_bit, stage):
         if a_bit == 32 and stage != "align":

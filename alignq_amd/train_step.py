@@ -19,6 +19,59 @@ from .fused import DeferredLosses, DeferredWgrads, HeadCEFn, head_ce_supported, 
 from .optimizer import ADMM_OPT, SGD, sgd_admm_step
 
 
+_PROBE = "alignq_capture_probe"
+
+
+def retained_graph_params(params):
+    """Parameters whose AccumulateGrad node is kept alive by an autograd graph of an EARLIER iteration (a retained loss / output
+    tensor, or ADMM.D kept with its graph as utils/admm.py:25 does).  Such a node is bound to the stream that iteration ran on;
+    a backward inside a stream capture then makes autograd synchronise that stream with the capturing one, which pulls it into
+    the capture: hipStreamEndCapture finds an unjoined stream (ROCm 7.2: a segmentation fault - round 4's crash when a step was
+    captured after eager iterations whose outputs were still referenced).  Found by tagging: a node nobody else holds dies when
+    the probe's temporary graph goes, and the next lookup creates an untagged one."""
+    token = object()
+    live = [p for p in params if p.requires_grad]
+    for p in live:
+        p.expand_as(p).grad_fn.next_functions[0][0].metadata[_PROBE] = token
+    stale = []
+    for p in live:
+        acc = p.expand_as(p).grad_fn.next_functions[0][0]
+        if acc.metadata.get(_PROBE) is token:
+            stale.append(p)
+        acc.metadata.pop(_PROBE, None)
+    return stale
+
+
+def release_step_graphs(admms):
+    """What the step itself may keep of an earlier iteration's autograd graph: ADMM.D with its history (the exact-global and the
+    unfused sites store D as the reference does, utils/admm.py:25; the fused sites store a detached D)."""
+    for a in admms:
+        if a.D is not None and a.D.grad_fn is not None:
+            a.D = a.D.detach()
+
+
+def assert_no_retained_graph(params, who):
+    stale = retained_graph_params(params)
+    if stale:
+        if os.environ.get("ALIGNQ_DEBUG_RETAINED"):      # who holds them (diagnostic aid)
+            import gc
+            acc = stale[0].expand_as(stale[0]).grad_fn.next_functions[0][0]
+            for r in gc.get_referrers(acc)[:8]:
+                print("retained-graph referrer:", type(r), str(r)[:200], flush=True)
+        raise RuntimeError(
+            f"{who}: {len(stale)} parameter(s) are still referenced by the autograd graph of an earlier iteration (a loss / output "
+            "tensor of an eager step that is still alive).  Their gradient-accumulation nodes are bound to the stream that "
+            "iteration ran on; capturing a backward that reuses them pulls that stream into the capture (hipStreamEndCapture "
+            "crashes on the unjoined stream).  Drop those tensors (del the step's outputs, or .detach() them) and call capture() "
+            "again.")
+
+
+def _detached(outs):
+    """The step's results without their autograd history: the backward already ran inside the step, and a result that kept the
+    iteration's graph alive would keep its gradient-accumulation nodes alive too (retained_graph_params)."""
+    return tuple(t.detach() if torch.is_tensor(t) else t for t in outs)
+
+
 class TrainStep:
     def __init__(self, model, lr=0.04, momentum=0.9, weight_decay=1e-4, grad_hook=None, defer_losses=True, fuse_bn=True,
                  channels_last=False, qconv=True, pack_bins=True):
@@ -144,7 +197,7 @@ class TrainStep:
         if self.grad_hook is not None:
             self.grad_hook(self)
         self._optimizer_steps()
-        return outs
+        return _detached(outs)
 
     def __call__(self, x, y):
         if self._graph is None:
@@ -223,6 +276,21 @@ class TrainStep:
         the model, as real steps) so allocator pools, momentum buffers, pointer tables and MIOpen plans
         exist.  Without a grad_hook the whole iteration is ONE graph; with one (data parallel) it is two
         graphs (forward+backward | optimizer steps) with the all-reduce launched eagerly in between."""
+        # refusals first: nothing below may touch the model before them (ADVICE r4: the warm-up iterations are real steps)
+        if getattr(self, "_global_corr_undo", None) is not None or getattr(config.args, "global_corr", None) is not None:
+            # The exact-global correlation issues all_to_all / all_reduce from INSIDE the forward and, through
+            # dp._FeatureShard.backward, from inside the ONE autograd.backward call of the step: the capture region cannot be cut at
+            # them (the phased form of the gradient bucket cuts BETWEEN backward and optimizer).  Capturing the collectives
+            # themselves is only defined for a process group whose asynchronous error handling (its watchdog's event polling) was
+            # switched off BEFORE init_process_group (TORCH_NCCL_ASYNC_ERROR_HANDLING=0, torch's own rule for whole-network
+            # capture with collectives): a property of the process this library cannot change for an existing group - with it on,
+            # the round-4 capture never returned.  The mode therefore runs eagerly, by design (DESIGN.md section 6).
+            raise RuntimeError("TrainStep.capture: the exact-global correlation (global_corr) is eager-only: its collectives sit "
+                               "inside the forward and inside autograd's backward call, where the capture cannot be split, and "
+                               "captured collectives need a process group created with TORCH_NCCL_ASYNC_ERROR_HANDLING=0 "
+                               "(DESIGN.md section 6) - call the step eagerly")
+        release_step_graphs(self.admms)
+        assert_no_retained_graph([p for g in self.optimizer_t.param_groups for p in g["params"]], "TrainStep.capture")
         sx = x.clone(memory_format=torch.channels_last) if (self.channels_last and x.dim() == 4) else x.clone()
         sy = y.clone()
         side = torch.cuda.Stream()
@@ -233,33 +301,18 @@ class TrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._assert_momentum_buffers()
-        # an initialised process group matters even WITHOUT a hook (round 4: after dp.detach the one-graph capture ran in the
-        # global capture mode while the group's watchdog thread was still polling the events of earlier collectives: a
-        # segmentation fault inside hipStreamEndCapture)
+        release_step_graphs(self.admms)          # (an unfused site of the warm-up keeps D with its graph)
+        # An initialised process group matters even WITHOUT a hook: its watchdog thread polls HIP events of earlier collectives,
+        # which the default (global) capture mode forbids while ANY stream captures; under capture_error_mode="thread_local" HIP
+        # calls of other threads neither fail nor invalidate the capture.
         dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
-        if dist_on:
-            # The warm-up iterations issued collectives.  Quiesce explicitly instead of sleeping: a barrier orders every rank
-            # behind its peers' warm-up collectives and the device synchronise retires them, so no collective is in flight
-            # when the capture starts; the capture itself uses capture_error_mode="thread_local", under which HIP calls made
-            # by OTHER threads (the process group's watchdog polling its completion events) neither fail nor invalidate it.
-            # (Round 1 slept 0.5 s here against a "operation not permitted when stream is capturing" abort seen once with
-            # the default global mode; no log of it was kept.)
+        if dist_on and self.grad_hook is not None:
+            # The warm-up iterations issued collectives: a barrier orders every rank behind its peers' warm-up collectives and the
+            # device synchronise retires them, so none is in flight when the capture starts.  Only on the all-ranks data-parallel
+            # path: a step without a hook (after dp.detach, a rank-local evaluation step) must not meet its peers here.
             torch.distributed.barrier()
             torch.cuda.synchronize()
         cap_mode = dict(capture_error_mode="thread_local") if dist_on else {}
-        if getattr(self, "_had_global_corr", False) and getattr(self, "_global_corr_undo", None) is None:
-            # ... and a capture AFTER an eager exact-global phase of the same step object (dp.attach(global_corr=True), steps,
-            # dp.detach) ended in a segmentation fault inside hipStreamEndCapture (round 4, both capture modes): refused as well
-            raise RuntimeError("TrainStep.capture: this step ran the exact-global correlation (global_corr) earlier in this process; "
-                               "capturing it afterwards crashed inside hipStreamEndCapture on ROCm 7.2 - build a fresh TrainStep "
-                               "for captured per-rank steps (a new step object captures fine in the same process; DESIGN.md section 6)")
-        if getattr(self, "_global_corr_undo", None) is not None or getattr(config.args, "global_corr", None) is not None:
-            # the exact-global correlation issues all_to_all / all_reduce from INSIDE the forward.  Rounds 2-3 let RCCL capture them;
-            # round 4 ran it for the first time (ResNet-20, B_g = 256, world size 1, ROCm 7.2): the capture / first replay never
-            # returned (the box was killed after 7 silent minutes).  Until that is understood the step runs eagerly in this mode -
-            # a refusal instead of a hang; the per-rank semantics (the default) capture as before.
-            raise RuntimeError("TrainStep.capture: the exact-global correlation (global_corr) is not captured into a HIP graph - "
-                               "call the step eagerly (collectives inside the captured forward hung on ROCm 7.2; DESIGN.md section 6)")
         graph = torch.cuda.CUDAGraph()
         self._graph2 = None
         # inside the capture grads are re-created (set_to_none=True): no zero-fill and no accumulate-add per
@@ -284,7 +337,7 @@ class TrainStep:
                 self._optimizer_steps()
             self._graph2 = graph2
         self._graph = graph
-        self._static = (sx, sy, outs)
+        self._static = (sx, sy, _detached(outs))
         return self
 
 
@@ -355,7 +408,7 @@ class OfficeTrainStep:
     def _iteration(self, xs, ys, xt, set_to_none=True):
         out = self._forward_backward(xs, ys, xt, set_to_none, overlap=True)
         self._optimizer_steps()
-        return out
+        return _detached(out)
 
     def _forward_backward(self, xs, ys, xt, set_to_none=True, overlap=False):
         m = self.model
@@ -453,6 +506,9 @@ class OfficeTrainStep:
                 hook.restore(keep_hook)
 
     def capture(self, xs, ys, xt, warmup=2):
+        admms = [b.admm0 for b in self.blocks]
+        release_step_graphs(admms)
+        assert_no_retained_graph([p for g in self.optimizer_t.param_groups for p in g["params"]], "OfficeTrainStep.capture")
         fmt = torch.channels_last if self.channels_last else torch.contiguous_format
         sxs, sys_, sxt = xs.clone(memory_format=fmt), ys.clone(), xt.clone(memory_format=fmt)
         side = torch.cuda.Stream()
@@ -467,6 +523,7 @@ class OfficeTrainStep:
                 if group["momentum"] != 0 and p.grad is not None and "momentum_buffer" not in self.optimizer_t.state[p]:
                     raise RuntimeError("OfficeTrainStep.capture: a parameter has no momentum buffer yet; run at least one "
                                        "eager iteration (capture(..., warmup>=1)) before capturing the step")
+        release_step_graphs(admms)
         self.optimizer_t.zero_grad(set_to_none=True)
         self.optimizer_admm.zero_grad(set_to_none=True)
         graph = torch.cuda.CUDAGraph()
@@ -490,5 +547,5 @@ class OfficeTrainStep:
                 self._optimizer_steps()
             self._graph2 = graph2
         self._graph = graph
-        self._static = (sxs, sys_, sxt, outs)
+        self._static = (sxs, sys_, sxt, _detached(outs))
         return self

@@ -411,3 +411,95 @@ def test_flat_bucket_matches_compares_shapes_not_only_element_counts():
     b = FlatBucket([(4, 4), (3,)], "cpu")
     assert b.matches([torch.zeros(4, 4), torch.zeros(3)])
     assert not b.matches([torch.zeros(2, 8), torch.zeros(3)])       # same element counts, other tensors
+
+
+# ---- round 5 (VERDICT r4 item 3 / ADVICE r4): what round 4's crash in hipStreamEndCapture came from, on the CPU -----------------
+def test_retained_graph_params_sees_a_graph_kept_alive_by_an_output():
+    """train_step.retained_graph_params: an iteration whose loss tensor is still referenced keeps every parameter's
+    gradient-accumulation node alive (bound to the stream it ran on); once the tensor is gone the nodes are gone."""
+    from alignq_amd.train_step import retained_graph_params
+    lin = torch.nn.Linear(4, 3)
+    frozen = torch.nn.Parameter(torch.zeros(2), requires_grad=False)
+    params = list(lin.parameters()) + [frozen]
+    assert retained_graph_params(params) == []
+    loss = lin(torch.randn(5, 4)).sum()
+    loss.backward()
+    stale = retained_graph_params(params)
+    assert len(stale) == 2 and all(any(s is p for p in lin.parameters()) for s in stale)
+    kept = loss.detach()
+    del loss
+    assert retained_graph_params(params) == [] and float(kept) == float(kept)
+    # idempotent, and no probe tag is left behind on a surviving node
+    out = lin(torch.randn(2, 4))
+    assert len(retained_graph_params(params)) == 2 and len(retained_graph_params(params)) == 2
+    acc = lin.weight.expand_as(lin.weight).grad_fn.next_functions[0][0]
+    assert "alignq_capture_probe" not in acc.metadata
+    del out
+
+
+def _attach_detach_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from alignq_amd import config, dp
+        from alignq_amd.resnet import PreActBlock_conv_Q, PreActResNet
+        from alignq_amd.train_step import TrainStep, release_step_graphs, retained_graph_params
+        config.args.bitW = config.args.abitW = 4
+        config.args.train_batch_size = 4
+        torch.manual_seed(0)
+        net = PreActResNet(PreActBlock_conv_Q, [1, 1, 1], 4, 4, "second", 10).train()
+        step = TrainStep(net, lr=0.01)
+
+        def snapshot():
+            snap = {"step": {k: (id(v) if not isinstance(v, (bool, int, float, str, type(None))) else v)
+                             for k, v in vars(step).items() if k not in ("_global_corr_undo",)}}
+            for name, m in net.named_modules():
+                snap[name] = {k: v for k, v in vars(m).items()
+                              if isinstance(v, (bool, int, float, str, type(None))) and not k.startswith("_") and k != "D"}
+            return snap
+        before = snapshot()
+        dp.attach(step, force=True, global_corr=True)
+        during = snapshot()
+        changed = sorted(n for n in before if before[n] != during.get(n))
+        # the eager exact-global iterations leave D WITH its autograd graph on every ADMM module (ADMM.forward, utils/admm.py:25):
+        # emulated here (no HIP kernels on the CPU) with a D that hangs on the model's parameters
+        for a in step.admms:
+            a.D = (a.alterD * 2.0 + net.logit.weight.sum())
+        assert len(retained_graph_params(list(net.parameters()))) > 0
+        dp.detach(step)
+        after = snapshot()
+        for a in step.admms:
+            assert a.D.grad_fn is None                                  # detach() dropped the graphs with the mode
+        assert retained_graph_params(list(net.parameters())) == []
+        # everything attach(global_corr=True) changed is back; a site module now carries global_corr = None (getattr default)
+        diff = {n: (before[n], after[n]) for n in before if before[n] != after[n]}
+        for n, (b, a_) in list(diff.items()):
+            extra = {k: v for k, v in a_.items() if k not in b}
+            same = all(a_[k] == b[k] for k in b)
+            if same and all(k == "global_corr" and v is None for k, v in extra.items()):
+                del diff[n]
+        # release_step_graphs: what capture() does for a step that was never attached
+        step.admms[0].D = step.admms[0].gamma * 3.0
+        release_step_graphs(step.admms)
+        ok_release = step.admms[0].D.grad_fn is None
+        out.put((rank, changed[:6], len(changed), diff, ok_release, getattr(step, "_had_global_corr", None)))
+    except BaseException as e:       # the parent must not wait for its queue timeout
+        out.put((rank, [], 0, {"worker failed": repr(e)}, False, None))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_attach_global_corr_then_detach_restores_the_step_and_drops_its_graphs():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_attach_detach_worker, args=(0, 1, _free_port(), q))
+    p.start()
+    res = q.get(timeout=300)
+    p.join(60)
+    assert p.exitcode == 0
+    _, changed, n_changed, diff, ok_release, had = res
+    assert n_changed > 0 and "step" in changed or n_changed > 0          # attach did change state (fuse_bn flags, deferred, hook)
+    assert diff == {}, diff                                             # ... and detach restored all of it
+    assert ok_release and had is None                                   # no sticky "was global once" flag any more
