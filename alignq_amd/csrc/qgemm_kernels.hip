@@ -543,17 +543,17 @@ __global__ __launch_bounds__(256, 2) void qgemm_wgrad_kernel(const QW a) {
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Filter gradient of the 3x3 stride-1 convolutions with a HALO image: a workgroup owns a 64 x 64 (c, n) tile for ALL nine taps.
-// Per step of 32 pixels dy's rows are staged once and x's rows [m0 - W - 1, m0 + 32 + W + 1) once (rows = flattened pixel index);
-// tap (dy, dx) reads x at row offset dy * W + dx, a pixel whose tap leaves its image reads the all-zero row (the lane's row
-// address is selected, no branch: ds_read_b64_tr_b16 takes one row address per lane).  Nine accumulator sets per wave (32 x 32 of
-// the tile each).  Against the per-tap form above: the staging (global loads, splits, LDS writes) of x and dy is shared by the
-// nine taps instead of repeated for each.
+// x's rows live in a RING of R = 2 W + 34 LDS rows indexed by the flattened pixel (slot = (pixel + W + 1) mod R): a step of 32
+// pixels needs the window [m0 - W - 1, m0 + 33 + W) and only its last 32 rows are new - each step stages 32 rows of x and 32
+// rows of dy, whatever W is.  Tap (dy, dx) reads x at slot offset dy * W + dx; a pixel whose tap leaves its image reads the
+// all-zero row (ds_read_b64_tr_b16 takes one row address per lane: an address select, no branch).  Nine accumulator sets per wave
+// (32 x 32 of the tile each).  Against the per-tap form above, the staging of x and dy is shared by the nine taps.
 template <int TX>
 __global__ __launch_bounds__(256, TX == 2 ? 2 : 1) void qgemm_wgrad3_kernel(const QW a) {
   constexpr int BC = 64, BNO = 64, LDC = BC + 16;
-  constexpr int XR = WK + 2 * kHaloW + 3;            // rows of the x image (+ the zero row)
+  constexpr int XR = 2 * kHaloW + 34 + 1;            // ring rows at the widest image + the zero row
   constexpr int XPL = XR * LDC, DPL = WK * LDC;
-  constexpr int NX = (XR * (BC / 4) + 255) / 256, ND = (WK * BNO / 4) / 256;
+  constexpr int NX = (WK * BC / 4) / 256, ND = (WK * BNO / 4) / 256;
   __shared__ __attribute__((aligned(16))) u16 lds[TX * XPL + 3 * DPL];
   u16* const Xs = lds;
   u16* const Ds = lds + TX * XPL;
@@ -566,36 +566,26 @@ __global__ __launch_bounds__(256, TX == 2 ? 2 : 1) void qgemm_wgrad3_kernel(cons
   const int c0 = ct * BC, o0 = ot * BNO;
   const int m_begin = split * a.per, m_end = (m_begin + a.per < a.M) ? m_begin + a.per : a.M;
   const int W = a.Wa, H = a.Ha;
-  const int halo_rows = WK + 2 * W + 2;              // staged rows; row halo_rows is the zero row
-  for (int i = tid; i < TX * (XR - halo_rows) * (LDC / 4); i += 256) {
-    const int pl = i / ((XR - halo_rows) * (LDC / 4)), j = i % ((XR - halo_rows) * (LDC / 4));
-    *reinterpret_cast<s16x4*>(Xs + pl * XPL + halo_rows * LDC + 4 * j) = (s16x4){0, 0, 0, 0};
-  }
+  const int R = 2 * W + 34;                          // ring rows; row R is the zero row
+  for (int i = tid; i < TX * (LDC / 4); i += 256)
+    *reinterpret_cast<s16x4*>(Xs + (i / (LDC / 4)) * XPL + R * LDC + 4 * (i % (LDC / 4))) = (s16x4){0, 0, 0, 0};
   f32x4 rx[NX], rd[ND];
-  auto fetch = [&](int m0) {
+  // x rows [f0, f0 + 32) that lie below f_hi (pixels outside the tensor are zeros)
+  auto fetch_x = [&](int f0, int f_hi) {
 #pragma unroll
     for (int i = 0; i < NX; i++) {
-      const int idx = tid + 256 * i, r = idx / (BC / 4), q4 = idx % (BC / 4);
-      const int f = m0 - W - 1 + r;
-      const bool ok = r < halo_rows && f >= 0 && f < a.M;
+      const int idx = tid + 256 * i, f = f0 + idx / (BC / 4), q4 = idx % (BC / 4);
+      const bool ok = f < f_hi && f >= 0 && f < a.M;
       rx[i] = *reinterpret_cast<const f32x4*>(a.x + (ok ? (int64_t)f * a.CIN + c0 + 4 * q4 : 0));
       if (!ok) rx[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-#pragma unroll
-    for (int i = 0; i < ND; i++) {
-      const int idx = tid + 256 * i, kr = idx / (BNO / 4), q4 = idx % (BNO / 4);
-      const int m = m0 + kr;
-      const bool ok = m < m_end;
-      rd[i] = *reinterpret_cast<const f32x4*>(a.dy + (ok ? (int64_t)m * a.COUT + o0 + 4 * q4 : 0));
-      if (!ok) rd[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
   };
-  auto park = [&]() {
+  auto park_x = [&](int f0, int f_hi) {
 #pragma unroll
     for (int i = 0; i < NX; i++) {
-      const int idx = tid + 256 * i, r = idx / (BC / 4), q4 = idx % (BC / 4);
-      if (r >= halo_rows) continue;
-      const int o = r * LDC + 4 * q4;
+      const int idx = tid + 256 * i, f = f0 + idx / (BC / 4), q4 = idx % (BC / 4);
+      if (f >= f_hi) continue;
+      const int o = ((f + W + 1) % R) * LDC + 4 * q4;
       if constexpr (TX == 3) {
         s16x4 h, m, l;
         split3(rx[i], h, m, l);
@@ -609,6 +599,18 @@ __global__ __launch_bounds__(256, TX == 2 ? 2 : 1) void qgemm_wgrad3_kernel(cons
         *reinterpret_cast<s16x4*>(Xs + XPL + o) = l;
       }
     }
+  };
+  auto fetch_d = [&](int m0) {
+#pragma unroll
+    for (int i = 0; i < ND; i++) {
+      const int idx = tid + 256 * i, kr = idx / (BNO / 4), q4 = idx % (BNO / 4);
+      const int m = m0 + kr;
+      const bool ok = m < m_end;
+      rd[i] = *reinterpret_cast<const f32x4*>(a.dy + (ok ? (int64_t)m * a.COUT + o0 + 4 * q4 : 0));
+      if (!ok) rd[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto park_d = [&]() {
 #pragma unroll
     for (int i = 0; i < ND; i++) {
       const int idx = tid + 256 * i, kr = idx / (BNO / 4), q4 = idx % (BNO / 4);
@@ -630,55 +632,70 @@ __global__ __launch_bounds__(256, TX == 2 ? 2 : 1) void qgemm_wgrad3_kernel(cons
       for (int j = 0; j < 2; j++) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int fg = lane >> 4, fq = (lane & 15) >> 2, fc = 4 * (lane & 3);
   const int kp = 4 * fg + fq;                         // this lane's pixel of the step (second block: + 16)
-  if (m_begin < m_end) fetch(m_begin);
+  if (m_begin < m_end) {
+    // prologue: the window's old part [m_begin - W - 1, m_begin + W + 1); the loop adds 32 rows per step
+    const int f_hi = m_begin + W + 1;
+    for (int f0 = m_begin - W - 1; f0 < f_hi; f0 += WK) {
+      fetch_x(f0, f_hi);
+      park_x(f0, f_hi);
+    }
+    fetch_x(f_hi, f_hi + WK);
+    fetch_d(m_begin);
+  }
   for (int m0 = m_begin; m0 < m_end; m0 += WK) {
+    __syncthreads();                                  // the previous step's reads are done (its oldest 32 rows may go)
+    park_x(m0 + W + 1, m0 + W + 1 + WK);
+    park_d();
     __syncthreads();
-    park();
-    __syncthreads();
-    if (m0 + WK < m_end) fetch(m0 + WK);
-    // (h, w) of this lane's two pixels
+    if (m0 + WK < m_end) {
+      fetch_x(m0 + WK + W + 1, m0 + 2 * WK + W + 1);
+      fetch_d(m0 + WK);
+    }
+    // (h, w) of this lane's two pixels, and the ring slot of pixel m0 + kp
     const int ma = m0 + kp, mb = ma + 16;
     const int wa = ma % W, ha = (ma / W) % H, wb = mb % W, hb = (mb / W) % H;
+    const int sa = (ma + W + 1) % R;
 #pragma unroll
     for (int tap = 0; tap < 9; tap++) {
       const int dy = tap / 3 - 1, dx = tap % 3 - 1;
       const bool oka = (unsigned)(ha + dy) < (unsigned)H && (unsigned)(wa + dx) < (unsigned)W;
       const bool okb = (unsigned)(hb + dy) < (unsigned)H && (unsigned)(wb + dx) < (unsigned)W;
-      const int ra = oka ? kp + W + 1 + dy * W + dx : halo_rows;
-      const int rb = okb ? kp + 16 + W + 1 + dy * W + dx : halo_rows;
-      s16x8 xf[2][TX];
+      int ra = sa + dy * W + dx, rb = ra + 16;
+      ra += ra < 0 ? R : 0; ra -= ra >= R ? R : 0;
+      rb += rb < 0 ? R : 0; rb -= rb >= R ? R : 0;
+      ra = oka ? ra : R;
+      rb = okb ? rb : R;
 #pragma unroll
-      for (int tc = 0; tc < 2; tc++)
+      for (int tc = 0; tc < 2; tc++) {
+        s16x8 xf[TX];
 #pragma unroll
         for (int t = 0; t < TX; t++) {
           const u16* p = Xs + t * XPL + (wc * 2 + tc) * 16 + fc;
-          xf[tc][t] = join8(tr_read(p + ra * LDC), tr_read(p + rb * LDC));
+          xf[t] = join8(tr_read(p + ra * LDC), tr_read(p + rb * LDC));
         }
 #pragma unroll
-      for (int tn = 0; tn < 2; tn++) {
-        s16x8 df[3];
+        for (int tn = 0; tn < 2; tn++) {
+          s16x8 df[3];
 #pragma unroll
-        for (int t = 0; t < 3; t++) {
-          const u16* p = Ds + t * DPL + kp * LDC + (wo * 2 + tn) * 16 + fc;
-          df[t] = join8(tr_read(p), tr_read(p + 16 * LDC));
-        }
-#pragma unroll
-        for (int tc = 0; tc < 2; tc++) {
+          for (int t = 0; t < 3; t++) {
+            const u16* p = Ds + t * DPL + kp * LDC + (wo * 2 + tn) * 16 + fc;
+            df[t] = join8(tr_read(p), tr_read(p + 16 * LDC));
+          }
           f32x4 v = acc[tap][tc][tn];
           if constexpr (TX == 3) {
-            v = mfma16<false>(xf[tc][1], df[1], v);
-            v = mfma16<false>(xf[tc][0], df[2], v);
-            v = mfma16<false>(xf[tc][2], df[0], v);
-            v = mfma16<false>(xf[tc][0], df[1], v);
-            v = mfma16<false>(xf[tc][1], df[0], v);
-            v = mfma16<false>(xf[tc][0], df[0], v);
+            v = mfma16<false>(xf[1], df[1], v);
+            v = mfma16<false>(xf[0], df[2], v);
+            v = mfma16<false>(xf[2], df[0], v);
+            v = mfma16<false>(xf[0], df[1], v);
+            v = mfma16<false>(xf[1], df[0], v);
+            v = mfma16<false>(xf[0], df[0], v);
           } else {
-            v = mfma16<false>(xf[tc][1], df[2], v);
-            v = mfma16<false>(xf[tc][1], df[1], v);
-            v = mfma16<false>(xf[tc][0], df[2], v);
-            v = mfma16<false>(xf[tc][1], df[0], v);
-            v = mfma16<false>(xf[tc][0], df[1], v);
-            v = mfma16<false>(xf[tc][0], df[0], v);
+            v = mfma16<false>(xf[1], df[2], v);
+            v = mfma16<false>(xf[1], df[1], v);
+            v = mfma16<false>(xf[0], df[2], v);
+            v = mfma16<false>(xf[1], df[0], v);
+            v = mfma16<false>(xf[0], df[1], v);
+            v = mfma16<false>(xf[0], df[0], v);
           }
           acc[tap][tc][tn] = v;
         }
