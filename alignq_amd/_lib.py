@@ -35,6 +35,7 @@ SIGNATURES = {
     "alignq_weight_stats": (_i, [_vp, _i64, _vp, _vp, _vp]),
     "alignq_weight_quant_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp]),
     "alignq_weight_quant_bwd": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "alignq_cdf_bwd": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _i64, _vp, _vp]),
     "alignq_site_ws_bytes": (_sz, [_i, _i64]),
     "alignq_site_fwd": (_i, [_vp, _i, _i64, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "alignq_site_partials": (_i, [_vp, _i, _i64, _i, _f, _f, _vp, _vp, _vp, _vp]),

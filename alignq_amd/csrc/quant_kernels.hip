@@ -500,6 +500,38 @@ inline int bin_bytes_of(int k, float r, int formula) {
   return 0;
 }
 
+// ------------------------------------------------------------------ stand-alone cdf(m, s, src): backward with LIVE (m, s) --------
+// cdf.forward (ADMM tree model/quantization.py:49-59, CDF tree :45-50) returns c = kc * Phi(z) [+ const] and pdf = 2 * phi_s with
+// z = (x - m) / s, phi_s = N(x; m, s); all three of x, m, s sit in the autograd graph there.  With upstream gradients gc (of c) and gp (of pdf):
+//   dx_j = gc_j kc phi_s - gp_j 2 phi_s z / s,   dm = -sum_j dx_j,   ds = sum_j (-gc_j kc phi_s z + gp_j 2 phi_s (z^2 - 1) / s).
+// One pass writes dx and per-block partial sums (double), a one-block pass adds them in block order.
+__global__ __launch_bounds__(kThreads) void cdf_bwd_kernel(const float* __restrict__ gc, const float* __restrict__ gp,
+                                                           const float* __restrict__ x, const float* __restrict__ ms, float kc,
+                                                           float* __restrict__ dx, int64_t n, double* __restrict__ ws) {
+  __shared__ double sm[16];
+  const float m = ms[0], s = ms[1], rs = 1.0f / s, cs = ALIGNQ_TWO_OVER_SQRT_2PI * rs;      // P = 2 phi_s
+  double s1 = 0, s2 = 0;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+    float P, z;
+    weight_PZ(x[i], m, rs, cs, &P, &z);
+    const float a = gc ? gc[i] * (0.5f * kc) * P : 0.f;       // gc kc phi_s
+    const float b = gp ? gp[i] * P * rs : 0.f;                // gp 2 phi_s / s
+    const float d = a - b * z;
+    if (dx) dx[i] = d;
+    s1 -= (double)d;
+    s2 += (double)b * ((double)z * (double)z - 1.0) - (double)a * (double)z;
+  }
+  block_sum2(s1, s2, sm);
+  if (threadIdx.x == 0) { ws[2 * blockIdx.x] = s1; ws[2 * blockIdx.x + 1] = s2; }
+}
+__global__ __launch_bounds__(kThreads) void cdf_bwd_finalize_kernel(const double* __restrict__ ws, int nblk, float* __restrict__ dms) {
+  __shared__ double sm[16];
+  double s1 = 0, s2 = 0;
+  for (int i = threadIdx.x; i < nblk; i += kThreads) { s1 += ws[2 * i]; s2 += ws[2 * i + 1]; }
+  block_sum2(s1, s2, sm);
+  if (threadIdx.x == 0) { dms[0] = (float)s1; dms[1] = (float)s2; }
+}
+
 inline int ws_blocks(int64_t n) {
   int64_t b = (n + (int64_t)kThreads * 8 - 1) / ((int64_t)kThreads * 8);
   if (b < 1) b = 1;
@@ -691,6 +723,18 @@ int alignq_weight_quant_bwd(const float* g, const float* w, const float* ms, flo
   hipLaunchKernelGGL(weight_bwd_partial_kernel, nb, kThreads, 0, st, g, w, ms, n, (double*)ws);
   LAUNCH_CHECK();
   hipLaunchKernelGGL(weight_bwd_apply_kernel, grid_for((n + 3) >> 2), kThreads, 0, st, g, w, ms, (const double*)ws, nb, dw, n);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int alignq_cdf_bwd(const float* gc, const float* gp, const float* x, const float* ms, float kc, float* dx, float* dms, int64_t n,
+                   void* ws, void* stream) {
+  if ((!gc && !gp) || !x || !ms || !dms || !ws || n < 1) return ALIGNQ_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = ws_blocks(n);
+  hipLaunchKernelGGL(cdf_bwd_kernel, nb, kThreads, 0, st, gc, gp, x, ms, kc, dx, n, (double*)ws);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(cdf_bwd_finalize_kernel, 1, kThreads, 0, st, (const double*)ws, nb, dms);
   LAUNCH_CHECK();
   return 0;
 }

@@ -178,6 +178,38 @@ def weight_quant_given_stats(w, ms, k, formula, want_aux=True, want_bins=False):
     return q, c, pdf, bins
 
 
+class CdfFn(torch.autograd.Function):
+    """cdf(m, s, quant_src).forward (ADMM tree model/quantization.py:49-59; CDF tree :45-50): (c, pdf) from the weight kernel at the
+    given statistics; backward of both outputs w.r.t. the tensor, m and s (alignq_cdf_bwd).  kc = d c / d Phi, scale = what the
+    'a' source multiplies the transform by (the kernel writes the 'w' form)."""
+
+    @staticmethod
+    def forward(ctx, x, m, s, formula, kc, scale):
+        ms = torch.stack([m.detach(), s.detach()])
+        _, c, pdf, _ = weight_quant_given_stats(x.detach(), ms, 32, formula, True)
+        if scale != 1.0:
+            c = c * scale
+        ctx.save_for_backward(x, ms)
+        ctx.kc = float(kc)
+        return c, pdf
+
+    @staticmethod
+    def backward(ctx, gc, gp):
+        x, ms = ctx.saved_tensors
+        lib = L.load()
+        need_x = ctx.needs_input_grad[0]
+        gc = None if gc is None else L.like_layout(gc, x)
+        gp = None if gp is None else L.like_layout(gp, x)
+        if gc is None and gp is None:
+            return None, None, None, None, None, None
+        dx = torch.empty_like(x) if need_x else None
+        dms = torch.empty(2, dtype=torch.float32, device=x.device)
+        ws = _ws(lib.alignq_weight_ws_bytes(x.numel()), x.device)
+        L.check(lib.alignq_cdf_bwd(L.ptr(gc), L.ptr(gp), L.ptr(x), L.ptr(ms), ctx.kc, L.ptr(dx), L.ptr(dms), x.numel(), L.ptr(ws),
+                                   L.stream_ptr()), "alignq_cdf_bwd")
+        return (dx, dms[0] if ctx.needs_input_grad[1] else None, dms[1] if ctx.needs_input_grad[2] else None, None, None, None)
+
+
 class WeightQuantFn(torch.autograd.Function):
     """weight_quantize_fn.forward (ADMM tree :71-85; CDF tree :62-78) with the backward through
     mean(W) and std(W).  Returns (W_q, weight_cdf, weight_pdf); only W_q is differentiable."""

@@ -38,9 +38,9 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
     formula, eps = _FORMULA[tree], _EPS[tree]
 
     class cdf(nn.Module):
-        """cdf(m, s, quant_src).forward(tensor) -> (cdf, pdf)  (ADMM tree :41-59; CDF tree :37-50).
-        Standalone use: values come from the HIP weight kernel with the given (m, s); the gradient is
-        propagated to `tensor` only through the first output (m, s are treated as constants)."""
+        """cdf(m, s, quant_src).forward(tensor) -> (cdf, pdf)  (ADMM tree :41-59; CDF tree :37-50).  Values from the HIP weight
+        kernel with the given (m, s); gradients of BOTH outputs w.r.t. `tensor` and - when they are tensors of the autograd graph,
+        as in the reference's own use cdf(torch.mean(x), torch.std(x), 'w') (:78) - w.r.t. m and s (ops.CdfFn)."""
 
         def __init__(self, m, s, quant_src):
             super().__init__()
@@ -48,15 +48,11 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
 
         def forward(self, tensor):
             x = L.dev_f32(tensor, "tensor")
-            ms = torch.stack([torch.as_tensor(self.m, dtype=torch.float32, device=x.device).reshape(()),
-                              torch.as_tensor(self.s, dtype=torch.float32, device=x.device).reshape(())])
-            _, c, pdf, _ = ops.weight_quant_given_stats(x.detach(), ms, 32, formula, True)
-            if tree != "cdf" and self.quant_src == "a":
-                c = c * config.args.act_range
-            if tensor.requires_grad:
-                scale = (config.args.act_range if self.quant_src == "a" else 1.0) if tree != "cdf" else 0.5
-                c = _AttachGrad.apply(tensor, c, pdf * scale)
-            return c, pdf
+            m = torch.as_tensor(self.m, dtype=torch.float32, device=x.device).reshape(())
+            s_ = torch.as_tensor(self.s, dtype=torch.float32, device=x.device).reshape(())
+            kc = 1.0 if tree == "cdf" else (2.0 * config.args.act_range if self.quant_src == "a" else 2.0)
+            scale = config.args.act_range if (tree != "cdf" and self.quant_src == "a") else 1.0
+            return ops.CdfFn.apply(x, m, s_, formula, float(kc), float(scale))
 
     class weight_quantize_fn(nn.Module):
         def __init__(self, w_bit, stage):

@@ -99,6 +99,13 @@ int alignq_weight_quant_fwd(const float* w, const float* ms, float* q, float* cd
  * dw_i = g_i P_i - mean(g P) - z_i/(n-1) * sum(g P z).  ws as above.                               */
 int alignq_weight_quant_bwd(const float* g, const float* w, const float* ms, float* dw, int64_t n,
                             void* ws, void* stream);
+/* Backward of the stand-alone cdf(m, s, quant_src).forward (ADMM tree model/quantization.py:41-59, CDF tree :37-50) when m and s
+ * are tensors of the autograd graph (the reference builds cdf(torch.mean(w), torch.std(w), 'w'), :78): c = kc * Phi(z) (+ const),
+ * pdf = 2 N(x; m, s), z = (x - m) / s.  gc / gp: upstream gradients of c / pdf (either may be NULL); ms = {m, s} on the device;
+ * kc = 2 (ADMM / Office trees; x act_range for quant_src == 'a') or 1 (CDF tree).  dx [n] (may be NULL), dms[2] = {d/dm, d/ds};
+ * ws: alignq_weight_ws_bytes(n).                                                                                               */
+int alignq_cdf_bwd(const float* gc, const float* gp, const float* x, const float* ms, float kc, float* dx, float* dms, int64_t n,
+                   void* ws, void* stream);
 
 /* ---- R4+R5(+R6): fused ADMM site: quantise + both sample-correlation matrices (+ ADMM loss) ---------
  * x: [B,F] (the [B,C,H,W] activation viewed as [B,-1]); 2 <= B <= ALIGNQ_MAX_BATCH.

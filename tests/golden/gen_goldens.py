@@ -649,7 +649,43 @@ def gen_g3l_cdfonly():
     _g3l(q, args, "cdf")
 
 
-GEN = {"g3l_admm": gen_g3l_admm, "g3l_cdfonly": gen_g3l_cdfonly, "admm_cifar": gen_admm_cifar, "cdf_only": gen_cdf_only, "office": gen_office, "office_keys": gen_office_keys,
+def _g11b(q, args, tree):
+    """G11b (round 5): the `cdf` module with LIVE statistics - m and s are tensors of the autograd graph, as in the reference's own
+    use cdf(torch.mean(x), torch.std(x), 'w')(x) (ADMM tree model/quantization.py:78, CDF tree :70): the gradients of BOTH
+    outputs w.r.t. the tensor, m and s (free m, s), and dW of the composed form through mean / std."""
+    import torch
+    g = torch.Generator().manual_seed(20261005)
+    out = {"act_range": np.array(float(getattr(args, "act_range", 2)), dtype=np.float32)}
+    v = torch.randn(6, 4, 3, 3, generator=g) * 0.7 + 0.05
+    gc, gp = torch.randn(v.shape, generator=g), torch.randn(v.shape, generator=g) * 0.3
+    out["v"], out["gc"], out["gp"] = _np(v), _np(gc), _np(gp)
+    for src, m0, s0 in (("w", 0.07, 0.6), ("a", -0.2, 1.3)):
+        vi = v.clone().requires_grad_(True)
+        m, s = torch.tensor(m0, requires_grad=True), torch.tensor(s0, requires_grad=True)
+        c, pdf = q.cdf(m, s, src)(vi)
+        torch.autograd.backward([c, pdf], [gc, gp])
+        out[f"m_{src}"], out[f"s_{src}"] = np.array(m0, np.float32), np.array(s0, np.float32)
+        out[f"cdf_{src}"], out[f"pdf_{src}"] = _np(c), _np(pdf)
+        out[f"dv_{src}"], out[f"dm_{src}"], out[f"ds_{src}"] = _np(vi.grad), _np(m.grad), _np(s.grad)
+    # the composed form the reference's weight quantiser builds: gradient of the first output only, through mean and std
+    wi = v.clone().requires_grad_(True)
+    c, pdf = q.cdf(torch.mean(wi), torch.std(wi), "w")(wi)
+    c.backward(gc)
+    out["cdf_ms"], out["pdf_ms"], out["dW_ms"] = _np(c), _np(pdf), _np(wi.grad)
+    _save("g11b_cdf_live_stats_" + tree, **out)
+
+
+def gen_g11b_admm():
+    q, args = _enter("admm_cifar", ["--bitW", "8", "--abitW", "8", "--train_batch_size", "8"])
+    _g11b(q, args, "admm")
+
+
+def gen_g11b_cdfonly():
+    q, args = _enter("cdf_only", ["--bitW", "8", "--abitW", "8"])
+    _g11b(q, args, "cdfonly")
+
+
+GEN = {"g11b_admm": gen_g11b_admm, "g11b_cdfonly": gen_g11b_cdfonly, "g3l_admm": gen_g3l_admm, "g3l_cdfonly": gen_g3l_cdfonly, "admm_cifar": gen_admm_cifar, "cdf_only": gen_cdf_only, "office": gen_office, "office_keys": gen_office_keys,
        "corr_xy_admm": gen_corr_xy_admm, "corr_xy_office": gen_corr_xy_office, "office_tiny_dann": gen_office_tiny_dann, "tiny_resnet_sites": gen_tiny_resnet_sites,
        "office_bottleneck_sites": gen_office_bottleneck_sites}
 

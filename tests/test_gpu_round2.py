@@ -83,6 +83,38 @@ def test_cdf_module_vs_reference(dev):
         np.testing.assert_allclose(npy(v.grad), g[f"dv_{src}"], atol=1e-6, rtol=1e-5)
 
 
+@pytest.mark.parametrize("tree,fname", [("admm", "g11b_cdf_live_stats_admm"), ("cdf", "g11b_cdf_live_stats_cdfonly")])
+def test_cdf_module_with_live_statistics_vs_reference(dev, tree, fname):
+    """Round 5: `cdf(m, s, src)` with m and s as tensors of the autograd graph - the reference's own use is
+    cdf(torch.mean(x), torch.std(x), 'w')(x) (ADMM tree model/quantization.py:78, CDF tree :70).  Gradients of BOTH outputs w.r.t.
+    the tensor, m and s (alignq_cdf_bwd) vs fixture G11b, and dW of the composed form through mean / std."""
+    import importlib
+    A = importlib.import_module("alignq_amd.cdf_alignment_admm" if tree == "admm" else "alignq_amd.cdf_alignment")
+    g = load_golden(fname)
+    gc, gp = cu(g["gc"], dev), cu(g["gp"], dev)
+    for src in ("w", "a"):
+        v = cu(g["v"], dev).requires_grad_(True)
+        m = torch.tensor(float(g[f"m_{src}"]), device=dev, requires_grad=True)
+        s = torch.tensor(float(g[f"s_{src}"]), device=dev, requires_grad=True)
+        c, pdf = A.cdf(m, s, src)(v)
+        torch.autograd.backward([c, pdf], [gc, gp])
+        np.testing.assert_allclose(npy(c), g[f"cdf_{src}"], atol=1e-6)
+        np.testing.assert_allclose(npy(pdf), g[f"pdf_{src}"], atol=1e-6, rtol=1e-5)
+        np.testing.assert_allclose(npy(v.grad), g[f"dv_{src}"], atol=2e-6, rtol=1e-5)
+        np.testing.assert_allclose(float(m.grad), float(g[f"dm_{src}"]), rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(float(s.grad), float(g[f"ds_{src}"]), rtol=2e-5, atol=2e-5)
+    w = cu(g["v"], dev).requires_grad_(True)
+    c, pdf = A.cdf(torch.mean(w), torch.std(w), "w")(w)
+    c.backward(gc)
+    np.testing.assert_allclose(npy(c), g["cdf_ms"], atol=1e-6)
+    np.testing.assert_allclose(npy(w.grad), g["dW_ms"], atol=2e-6, rtol=1e-5)
+    # constants still work (python floats / tensors without a graph): the gradient reaches the tensor only
+    v = cu(g["v"], dev).requires_grad_(True)
+    c, pdf = A.cdf(0.07, 0.6, "w")(v)
+    c.backward(gc)
+    np.testing.assert_allclose(npy(v.grad), npy(gc * pdf.detach()) * (1.0 if tree == "admm" else 0.5), atol=1e-6, rtol=1e-5)
+
+
 # ------------------------------------------------------------------------------------------------ reduce + loss hand-off
 @pytest.mark.parametrize("B,F", [(128, 16384), (100, 4096), (28, 6272)])
 def test_reduce_loss_is_idempotent_and_matches_the_oracle(dev, B, F):

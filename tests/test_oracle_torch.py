@@ -256,3 +256,28 @@ def test_g3l_bins_at_scale(tree):
         xq = xq.numpy().astype(np.float64).ravel()
         bins = np.rint(xq * n) if tree == "admm" else np.rint((xq / r + 1.0) * 0.5 * n)
         assert np.array_equal(bins.astype(np.int16), g[f"bins_k{k}"])
+
+
+@pytest.mark.parametrize("tree,fname", [("admm", "g11b_cdf_live_stats_admm"), ("cdf", "g11b_cdf_live_stats_cdfonly")])
+def test_g11b_cdf_with_live_statistics(tree, fname):
+    """Round 5: the oracle's cdf_transform with m and s IN the autograd graph against the reference's
+    cdf(m, s, src) module - both outputs' gradients w.r.t. tensor, m, s, and dW through mean / std (model/quantization.py:49-59,78)."""
+    g = load_golden(fname)
+    cfg = R.Config(tree=tree, act_range=float(g["act_range"]))
+    v0, gc, gp = torch.tensor(g["v"]), torch.tensor(g["gc"]), torch.tensor(g["gp"])
+    for src in ("w", "a"):
+        v = v0.clone().requires_grad_(True)
+        m = torch.tensor(float(g[f"m_{src}"]), requires_grad=True)
+        s = torch.tensor(float(g[f"s_{src}"]), requires_grad=True)
+        c, pdf = R.cdf_transform(v, m, s, src, cfg)
+        torch.autograd.backward([c, pdf], [gc, gp])
+        np.testing.assert_allclose(c.detach().numpy(), g[f"cdf_{src}"], atol=1e-6)
+        np.testing.assert_allclose(pdf.detach().numpy(), g[f"pdf_{src}"], atol=1e-6, rtol=1e-5)
+        np.testing.assert_allclose(v.grad.numpy(), g[f"dv_{src}"], atol=1e-6, rtol=1e-5)
+        np.testing.assert_allclose(float(m.grad), float(g[f"dm_{src}"]), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(float(s.grad), float(g[f"ds_{src}"]), rtol=1e-5, atol=1e-5)
+    w = v0.clone().requires_grad_(True)
+    c, pdf = R.cdf_transform(w, torch.mean(w), torch.std(w), "w", cfg)
+    c.backward(gc)
+    np.testing.assert_allclose(c.detach().numpy(), g["cdf_ms"], atol=1e-6)
+    np.testing.assert_allclose(w.grad.numpy(), g["dW_ms"], atol=2e-6, rtol=1e-5)
