@@ -230,8 +230,10 @@ __global__ __launch_bounds__(kT) void bnq_finalize_kernel(const double* __restri
 
 // dgamma / dbeta: the SUM over the groups (one parameter, several slices); ktot: [groups][2][C]
 // fix (or nullptr; round 4): the second sums came from x = a*z + b as sum dx * (x - beta) / gamma (the small-batch site backward's
-// per-column sums); a channel with gamma == 0 (a == 0) carries no trace of z there, so the wave forms its sum dx * zhat from dx and z
-// directly (P strided reads: slow, and only for such channels - e.g. a zero-initialised last batch-norm of a residual branch).
+// per-column sums); a channel with gamma == 0 carries no trace of z there and one with |gamma| << |beta| only noise (round 5,
+// alignq_bn_col_ill in site_internal.h), so the wave forms its sum dx * zhat from dx and z directly (P strided reads: slow, and
+// only for such channels - e.g. a zero-initialised last batch-norm of a residual branch and the step after it, dead channels of a
+// pretrained network).
 struct ZeroGammaFix {
   const float* dx; const float* z; const float* ab; const float* save;
 };
@@ -251,7 +253,8 @@ __global__ __launch_bounds__(kT) void bnq_finalize_bwd_kernel(const double* __re
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       if (j == 1 && !two) break;
-      if (fix.dx && fix.ab[(int64_t)(g0 + j) * 2 * C + c] == 0.0f) {
+      if (fix.dx && alignq_bn_col_ill(fix.ab[(int64_t)(g0 + j) * 2 * C + c], fix.ab[(int64_t)(g0 + j) * 2 * C + C + c],
+                                      fix.save[(int64_t)(g0 + j) * 2 * C + c], fix.save[(int64_t)(g0 + j) * 2 * C + C + c])) {
         const float* dxg = fix.dx + (int64_t)(g0 + j) * Pfull * C;
         const float* zg = fix.z + (int64_t)(g0 + j) * Pfull * C;
         const float mm = fix.save[(int64_t)(g0 + j) * 2 * C + c], ii = fix.save[(int64_t)(g0 + j) * 2 * C + C + c];

@@ -460,8 +460,8 @@ __global__ __launch_bounds__(kThreads1, PAIR ? 3 : 5) void site1_bwd_kernel(cons
     if (PAIR && colsum) {
       // The folded batch-norm's backward needs sum dx and sum dx * zhat per channel over batch AND pixels: the batch part is formed
       // here, per feature column, from the registers that still hold this sub-tile's dx and x (zhat = (z - mean) * invstd =
-      // (x - beta) / gamma up to the rounding of x = a*z + b; gamma == 0 leaves 0 and bnq_finalize_bwd_kernel forms that channel
-      // from dx and z itself): 8 bytes per column instead of alignq_bnq_bwd_dx's own pass over dx and z (8 B per ELEMENT).  A pass
+      // (x - beta) / gamma up to the rounding of x = a*z + b; an ill-conditioned channel (alignq_bn_col_ill: gamma == 0 or
+      // |gamma| < 1e-2 |beta|) leaves 0 and bnq_finalize_bwd_kernel forms it from dx and z itself): 8 bytes per column instead of alignq_bnq_bwd_dx's own pass over dx and z (8 B per ELEMENT).  A pass
       // of its own behind the stores and scheduling barriers, a and the statistics re-read through pointers the optimiser cannot
       // match with the earlier ones: inside the loop above (the kernel's register peak) every form of it spilled.
       __builtin_amdgcn_sched_barrier(0);
@@ -471,7 +471,8 @@ __global__ __launch_bounds__(kThreads1, PAIR ? 3 : 5) void site1_bwd_kernel(cons
       const int ch = (int)(colc & (int64_t)(C - 1));
       const float a2 = ab2[ch];
       const float bt = __fmaf_rn(sv2[ch], a2, ab2[C + ch]);
-      const float rg = a2 != 0.0f ? sv2[C + ch] / a2 : 0.0f;
+      // (an ill-conditioned channel - gamma == 0 or |gamma| << |beta| - contributes 0 here: bnq_finalize_bwd_kernel sums it itself)
+      const float rg = alignq_bn_col_ill(a2, ab2[C + ch], sv2[ch], sv2[C + ch]) ? 0.0f : sv2[C + ch] / a2;
       float f0 = 0.f, f1 = 0.f;
 #pragma unroll
       for (int q = 0; q < RPL; q++) {

@@ -193,3 +193,13 @@ int launch_sitel_fwd(const float* x, int B, int64_t F, int k, float r, float eps
                      hipStream_t st);
 
 }  // namespace alignq_site
+
+// The small-batch site backward leaves sum dx * zhat per feature column with zhat rebuilt from x = a*z + b as (x - beta) / gamma
+// (site1_kernels.hip); x carries z only to about eps_f32 * |beta + gamma zhat|, so for |gamma| << |beta| the rebuilt zhat is
+// noise (gamma = 1e-8, beta = 0.1: steps of ~0.7).  Such channels - gamma == 0 included - are summed from dx and z directly by
+// bnq_finalize_bwd_kernel instead (at 1e-2 the column form keeps zhat to 6e-6); BOTH kernels decide with this predicate on the same (a, b, mean, invstd) floats:
+// |gamma| < 1e-2 |beta|  <=>  |a| < 1e-2 |beta| invstd  (a = gamma * invstd, beta = mean * a + b as the forward formed b).
+__host__ __device__ __forceinline__ bool alignq_bn_col_ill(float a, float b, float mean, float invstd) {
+  const float beta = fmaf(mean, a, b);
+  return a == 0.0f || fabsf(a) < 1e-2f * fabsf(beta) * invstd;
+}

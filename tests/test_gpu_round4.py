@@ -444,6 +444,12 @@ def test_small_batch_site_backward_with_per_column_bn_sums_equals_the_sums_pass(
                 bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.2)
                 bn.weight[1] = 0.0
                 bn.weight[C - 3] = 0.0
+                # round 5: tiny NON-zero gamma beside a beta of ordinary size - x = gamma * zhat + beta keeps zhat only to
+                # eps * |beta| / |gamma| (1e-8: nothing of it, 1e-5: 3e-3): such channels must take the direct sum as well
+                # (alignq_bn_col_ill: |gamma| < 1e-2 |beta|)
+                for ch, gv in ((2, 1e-8), (3, 1e-5), (4, 1e-3), (5, -1e-6)):
+                    bn.weight[ch] = gv
+                    bn.bias[ch] = 0.5
             admm = NO.ADMM(B).to(dev)
             act = NO.activation_quantize_fn2(8, "aligned", admm).to(dev)
             z, res = z0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
@@ -452,7 +458,7 @@ def test_small_batch_site_backward_with_per_column_bn_sums_equals_the_sums_pass(
             outs.append([npy(t) for t in (z.grad, res.grad, bn.weight.grad, bn.bias.grad)])
         (dz_a, dr_a, dg_a, db_a), (dz_b, dr_b, dg_b, db_b) = outs
         assert np.array_equal(dr_a, dr_b)
-        assert abs(dg_a[1]) > 0 and abs(dg_a[C - 3]) > 0
+        assert abs(dg_a[1]) > 0 and abs(dg_a[C - 3]) > 0 and all(abs(dg_a[ch]) > 0 for ch in (2, 3, 4, 5))
         scale = float(np.abs(dg_a).max())
         np.testing.assert_allclose(dg_b, dg_a, rtol=2e-5, atol=2e-6 * scale)
         np.testing.assert_allclose(db_b, db_a, rtol=2e-5, atol=2e-6 * float(np.abs(db_a).max()))
