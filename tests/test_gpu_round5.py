@@ -1,0 +1,148 @@
+"""Round 5: BASELINE config 5 at its REAL size through the whole step.
+Reference iteration: cdf_alignment_admm/dann_office/main.py:343-456 (source pass + target pass of DANN(ResNet-50), 28 + 28 images
+of 3 x 224 x 224); here as train_step.OfficeTrainStep(channels_last=True) with its defaults: merged (`dual`) traversal, folded
+batch-norms, Conv2d_Q on the GEMM kernels (alignq_qconv_*)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from tests import oracle_c as O
+from tests.golden.det_init import det_init_
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def npy(t):
+    return t.detach().float().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def test_config5_full_size_step(dev, monkeypatch):
+    """resnet50_dann(8, 8), B = 28 + 28 at 224 x 224, det_init_:
+      (a) three ADMM sites - layer1[0] (stem-adjacent, with downsample), layer2[0] (stride-2 block with downsample), layer4[2] (the
+          last) - teacher-forced against the C oracle on the tensors the step itself produced, per batch slice: y = relu(act_q3(
+          bn3(z)) + identity) exact outside a near-tie band (the device's (a, b) differ by ~1e-6 from the oracle's), at most one
+          level inside; D and the slice's loss within 1e-5;
+      (b) every one of the 16 ADMM modules holds the TARGET slice's D afterwards (utils/admm.py:25 overwrites; main.py:372,377):
+          the same chain run on the target slice alone gives it to rounding (2e-6), the source slice's is far from it;
+      (c) the captured HIP graph reproduces eager iterations from the same initial state at the bin-flip bars of the small
+          harness test (median 1e-3 / max 2e-2 on every parameter after three steps);
+      (d) with Conv2d_Q on the GEMM kernels and on MIOpen the first iteration's class logits agree at bin-flip scale - the scale
+          measured beside it: MIOpen against MIOpen with the inputs perturbed by 1e-6 relative."""
+    import alignq_amd.quantization  # noqa: F401
+    from alignq_amd import config, fused
+    from alignq_amd.resnet_office import resnet50_dann
+    from alignq_amd.train_step import OfficeTrainStep
+    old = (config.args.bitW, config.args.abitW, config.args.train_batch_size, config.args.eval_batch_size)
+    config.args.bitW = config.args.abitW = 8
+    config.args.train_batch_size = config.args.eval_batch_size = 28
+    k, r, eps, B = 8, float(config.args.act_range), 1e-5, 28
+    n = 2 ** k - 1
+    try:
+        g = torch.Generator().manual_seed(11)
+        xs = torch.randn(B, 3, 224, 224, generator=g).to(dev)
+        xt = torch.randn(B, 3, 224, 224, generator=g).to(dev)
+        ys = torch.randint(0, 31, (B,), generator=g).to(dev)
+
+        def make():
+            return det_init_(resnet50_dann(8, 8)).to(dev).train()
+
+        # ---- (a) + (b): one eager iteration with a spy on the folded bottleneck tail
+        rec = []
+        real = fused.bn_site_res_relu
+
+        def spy(bn, act, z, residual, eps_, groups=1, loss_vec=False):
+            assert groups == 2 and z.shape[0] == 2 * B
+            bn_t, bn_s = copy.deepcopy(bn), copy.deepcopy(bn)       # parameters and running statistics BEFORE this call
+            out = real(bn, act, z, residual, eps_, groups, loss_vec)
+            assert out is not None                                  # the folded chain, not the composition
+            y, loss = out
+            with torch.no_grad():                                   # the same chain on each slice alone (b)
+                d_alone = []
+                for sl, bnc in ((slice(0, B), bn_s), (slice(B, 2 * B), bn_t)):
+                    a2 = type(act)(act.a_bit, act.stage, copy.deepcopy(act.opt))
+                    real(bnc, a2, z[sl].detach(), residual[sl].detach(), eps_, 1, False)
+                    d_alone.append(a2.opt.D.clone())
+            rec.append(dict(bn=bn, gam=npy(bn_s.weight), bet=npy(bn_s.bias), z=z.detach(), res=residual.detach(), y=y.detach(),
+                            loss=loss.detach().reshape(-1).clone(), admm=act.opt, d_alone=d_alone))
+            return out
+        monkeypatch.setattr(fused, "bn_site_res_relu", spy)
+        net = make()
+        step = OfficeTrainStep(net, lr=0.004, channels_last=True)
+        assert step.dual and step.qconv
+        A0 = [npy(b.admm0.alterD) for b in step.blocks]
+        G0 = [npy(b.admm0.gamma) for b in step.blocks]
+        cls0, loss0, tl0 = step(xs, ys, xt)
+        torch.cuda.synchronize()
+        monkeypatch.setattr(fused, "bn_site_res_relu", real)
+        assert torch.isfinite(cls0).all() and torch.isfinite(loss0) and torch.isfinite(tl0)
+        assert len(rec) == 16
+        for i, rr_ in enumerate(rec):                               # (b)
+            D_now = rr_["admm"].D
+            assert D_now.shape == (B, B) and rr_["admm"] is step.blocks[i].admm0
+            # (the merged call takes its batch-norm statistics from the convolution's epilogue, the slice alone makes its own pass:
+            # same sums in another order, so (a, b) - and D - agree to rounding, not bit for bit)
+            to_t = float((D_now - rr_["d_alone"][1]).abs().max()), float((D_now - rr_["d_alone"][0]).abs().max())
+            assert to_t[0] < 2e-6 and to_t[1] > 50 * to_t[0] + 1e-5, f"site {i}: D is not the target slice's {to_t}"
+        for i in (0, 3, 15):                                        # (a)
+            rr_ = rec[i]
+            Bt, C, H, W = rr_["z"].shape
+            mem = lambda t, sl: np.ascontiguousarray(npy(t[sl]).transpose(0, 2, 3, 1)).reshape(B, -1)     # noqa: E731
+            for gi, sl in enumerate((slice(0, B), slice(B, 2 * B))):
+                zm, rm_ = mem(rr_["z"], sl), mem(rr_["res"], sl)
+                ab_o, _, _ = O.bn_fold_ab(zm, C, 1, rr_["gam"], rr_["bet"], 1e-5)
+                y_o, D_o, x_o = O.bn_site_fwd(zm, C, 1, ab_o, k, r, eps, residual=rm_, relu=True)
+                _, t_o, _ = O.act_quant_fwd(x_o, k, r, O.FORMULA_ADMM)
+                frac = t_o.astype(np.float64) * n
+                near = np.abs(frac - np.floor(frac) - 0.5) < 2e-3
+                diff = np.abs(mem(rr_["y"], sl) - y_o) * n
+                assert np.all(diff[~near] < 1e-3), (i, gi, int(np.count_nonzero(diff[~near] >= 1e-3)))
+                assert np.all(diff[near] <= 1.0 + 1e-3)
+                np.testing.assert_allclose(npy(rr_["d_alone"][gi]), D_o, atol=TOL, rtol=0)
+                assert rr_["loss"].numel() == 2                                # the slices' losses as a vector (fast path)
+                np.testing.assert_allclose(float(rr_["loss"][gi]), O.admm_loss(D_o, A0[i], G0[i], 0.2, 0.3)[0], atol=TOL)
+        del rec, step, net
+
+        # ---- (d): the first iteration's logits, GEMM convolutions vs MIOpen.  Both convolutions are fp32-exact to ~1e-7 relative
+        # (tests/test_gpu_qconv.py: each against fp64), so their outputs differ in the last bits, 8-bit bins flip at 49 quantiser sites
+        # and the flips travel to the logits.  The yardstick for that "bin-flip scale" is measured beside it on MIOpen alone: the
+        # same network with its inputs perturbed by 1e-6 relative (what tools/office_sensitivity.py does to the reference itself)
+        outs = {}
+        gp = torch.Generator().manual_seed(5)
+        noise = [(1.0 + 1e-6 * torch.randn(xs.shape, generator=gp)).to(dev) for _ in range(2)]
+        for name, kw, pert in (("gemm", dict(qconv=True), False), ("miopen", dict(qconv=False), False),
+                               ("miopen_perturbed", dict(qconv=False), True)):
+            m = make()
+            s = OfficeTrainStep(m, lr=0.004, channels_last=True, **kw)
+            assert s.qconv is kw["qconv"]
+            outs[name] = npy(s(xs * noise[0] if pert else xs, ys, xt * noise[1] if pert else xt)[0])
+            del s, m
+        d = np.abs(outs["gemm"] - outs["miopen"])
+        d_ref = np.abs(outs["miopen_perturbed"] - outs["miopen"])
+        scale = float(np.abs(outs["miopen"]).max())
+        print("config5 first-iteration logits: GEMM vs MIOpen median |d|", float(np.median(d)), "max", float(d.max()),
+              "| MIOpen vs MIOpen on 1e-6-perturbed inputs median", float(np.median(d_ref)), "max", float(d_ref.max()), "| scale", scale)
+        assert np.median(d) <= 3.0 * np.median(d_ref) + 1e-3 * scale and d.max() <= 3.0 * d_ref.max() + 1e-2 * scale
+
+        # ---- (c): graph == eager over three iterations from the same initial state
+        m1, m2 = make(), make()
+        s1, s2 = OfficeTrainStep(m1, lr=0.004, channels_last=True), OfficeTrainStep(m2, lr=0.004, channels_last=True)
+        for _ in range(3):
+            c1 = s1(xs, ys, xt)
+        s2.capture(xs, ys, xt, warmup=2)          # two real iterations, then the captured third
+        c2 = s2(xs, ys, xt)
+        torch.cuda.synchronize()
+        assert torch.isfinite(c1[1]) and torch.isfinite(c2[1]) and c2[1].grad_fn is None
+        for (nm, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+            dd = np.abs(npy(p1) - npy(p2))
+            assert np.median(dd) < 1e-3 and dd.max() < 2e-2, (nm, float(np.median(dd)), float(dd.max()))
+    finally:
+        config.args.bitW, config.args.abitW, config.args.train_batch_size, config.args.eval_batch_size = old
