@@ -19,7 +19,6 @@
 
 #include "../../include/alignq.h"
 #include "alignq_math.h"
-#include "env_switch.h"
 #include "site_internal.h"
 
 using namespace alignq;
@@ -505,10 +504,10 @@ inline int tiles(int64_t nvec, int u, int nt = kT) {
   return (int)(b > 256 * 64 ? 256 * 64 : b);
 }
 // the reductions run 512-thread workgroups (round 4): at most 512 of them exist (kParts), i.e. two per CU - with 256 threads
-// that is two waves per SIMD for a kernel that is one long chain of load rounds (ALIGNQ_BNQ_SUMS_NT=256: round 3's form)
+// that is two waves per SIMD for a kernel that is one long chain of load rounds
 inline int sums_threads(int C) {
-  static const int nt = alignq_env::env_choice("ALIGNQ_BNQ_SUMS_NT", 512, {256, 512});
-  return (C >> 2) > kT ? 512 : nt;
+  (void)C;
+  return 512;
 }
 inline int parts_for(int64_t P, int C) {
   // every block should own at least a few pixel rounds: slots * kUs pixels per round
@@ -571,8 +570,7 @@ size_t alignq_bnq_mask_bytes(int64_t P, int C, int groups) {
 namespace {
 // "small" sites finalise inside the apply kernels (see kFinC): one group, few channels, a tensor of a few MB
 inline bool fin_small(int64_t P, int C, int groups) {
-  static const int on = alignq_env::env_choice("ALIGNQ_BNQ_FIN", 1, {0, 1});      // A/B aid: 0 = always the finalisation launches
-  return on && groups == 1 && C <= kFinC && P * C <= ((int64_t)4 << 20);
+  return groups == 1 && C <= kFinC && P * C <= ((int64_t)4 << 20);
 }
 inline int fin_parts(int64_t P, int C) {
   const int n = parts_for(P, C), cap = (64 * 1024) / (C * 16) < kFinParts ? (64 * 1024) / (C * 16) : kFinParts;

@@ -530,13 +530,11 @@ size_t corrl_s_bytes(int B) { return (size_t)((B + 31) / 32 * 32) * corrl_s_widt
 // K splits of the Gram launch.  512 workgroups are resident at once (two per CU: 66 KB of LDS each), a workgroup costs its
 // ceil(n_tiles / ks) tiles, the launch ceil(np ks / 512) rounds of them; every slab (64 KB written, read once by the reduction)
 // costs about 0.0064 of a tile round.  Rounds 3 took ceil(1024 / np) splits: 1044 workgroups of 9 tiles at 1024 x 16384, i.e. three
-// rounds of 9 where 14 splits make ONE round of 19.  ALIGNQ_CORRL_KS overrides (tuning aid).
+// rounds of 9 where 14 splits make ONE round of 19.
 int corrl_ksplit(int B, int64_t F) {
   const int nb = (B + kBlk - 1) / kBlk, np = n_pairs(nb);
   const int64_t n_tiles = (F + kTF - 1) / kTF;
-  static const int forced = alignq_env::env_int("ALIGNQ_CORRL_KS", 0, 0, 512);
   const int kmax = (int)(n_tiles < 512 ? n_tiles : 512);
-  if (forced > 0) return forced < kmax ? forced : kmax;
   int best = 1;
   double best_cost = 1e30;
   for (int ks = 1; ks <= kmax; ks++) {

@@ -11,7 +11,6 @@
 
 #include "../../include/alignq.h"
 #include "alignq_math.h"
-#include "env_switch.h"
 
 using namespace alignq;
 
@@ -547,11 +546,7 @@ inline int ws_blocks(int64_t n) {
   } while (0)
 
 // tensors of 2^25 elements (128 MB) and more are beyond the caches whatever comes next: their outputs are stored as streams
-// (ALIGNQ_AQ_NTS=0 / 1 forces the choice: tuning aid)
-static inline int stream_out(int64_t n) {
-  static const int forced = alignq_env::env_choice("ALIGNQ_AQ_NTS", -1, {-1, 0, 1});
-  return forced >= 0 ? forced : (n >= ((int64_t)1 << 25) ? 1 : 0);
-}
+static inline int stream_out(int64_t n) { return n >= ((int64_t)1 << 25) ? 1 : 0; }
 
 extern "C" {
 

@@ -520,7 +520,7 @@ int launch_bwd1(bool pair, const float* gup, const float* S, const float* x, con
   int grid = (n_sub + kWaves - 1) / kWaves;
   // three 4-wave workgroups per CU (167 VGPRs) = 768 resident; a grid of exactly that (every wave loops over ~8 sub-tiles at
   // [28, 802816]) ran 82-84 us against 86-87 for 2048 and 17.2 against 19.6 at [28, 100352] (tools/s1_grid_sweep.sh)
-  static const int capb = alignq_env::env_int("ALIGNQ_S1_GRID_B", 768, 1, 65535);      // tuning aid
+  constexpr int capb = 768;
   if (grid > capb) grid = capb;
   if (groups > 1 && grid * groups > capb) grid = (capb + groups - 1) / groups;      // the groups share the resident round
   if (pair) hipLaunchKernelGGL((site1_bwd_kernel<true>), dim3(grid, groups), kThreads1, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_sub, ab, C, ymask, dres, s_gstride, gup2, save, colsum);

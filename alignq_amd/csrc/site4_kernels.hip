@@ -2023,8 +2023,8 @@ int launch_partials4(bool pair, const Geom& g, const float* x, int B, int64_t F,
   const bool full64 = B == 128 && F % 64 == 0 && aligned;     // the 512-thread multi-tile form takes complete tiles only
   const FwdLaunch fl{x, B, F, k, r, eps, xq, ws, stats, g.n_tiles, aligned, counter, bn, fill, g.grid, fgrid, full64, st};
   int rc;
-  if (pair) rc = g.tf == 64 ? launch_fwd4_tf<64, true>(fl) : (g.tf == 32 ? launch_fwd4_tf<32, true>(fl) : launch_fwd4_tf<16, true>(fl));
-  else rc = g.tf == 64 ? launch_fwd4_tf<64, false>(fl) : (g.tf == 32 ? launch_fwd4_tf<32, false>(fl) : launch_fwd4_tf<16, false>(fl));
+  if (pair) rc = g.tf == 64 ? launch_fwd4_tf<64, true>(fl) : launch_fwd4_tf<32, true>(fl);
+  else rc = g.tf == 64 ? launch_fwd4_tf<64, false>(fl) : launch_fwd4_tf<32, false>(fl);
   if (rc) return rc;
   RET_ON_ERR();
   return 0;
@@ -2154,16 +2154,8 @@ int launch_bwd4(bool pair, const Geom& g, const float* gup, const float* S, cons
   const bool vec = (F % 4 == 0) && al16(gup) && al16(x) && al16(stats) && al16(dx) && al16(bn.y) && al16(bn.dres) && al16(bn.ybins) &&
                    al16(bn.ab) && al16(bn.save) && (!bn.ab || bn.nhwc || bn.HW % 4 == 0) && (!bn.nhwc || bn.C % 4 == 0);
   const BwdLaunch bl{gup, S, x, stats, B, F, r, eps, dx, n_tiles, aligned, bn, fill, grid, vec, st};
-  static const int loop32 = alignq_env::env_int("ALIGNQ_BWD_LOOP32", 0, 0, 4096);   // tuning aid
   const bool plain = !bn.ab && !bn.y && !bn.ybins && !bn.dres;
-  if (loop32 && plain && F > 32768) {
-    // experiment: 32-feature tiles, 256 threads, 70 KB of LDS: two (or loop32 / 256) looped workgroups per CU
-    BwdLaunch b2 = bl;
-    b2.n_tiles = (int)((F + 31) / 32);
-    b2.grid = loop32 >= 256 ? loop32 : 512;
-    const int rc = pair ? launch_bwd4_loop<32, true>(b2) : launch_bwd4_loop<32, false>(b2);
-    if (rc) return rc;
-  } else if (tf == 64 && plain && n_tiles > 2 * 256 && vec && B == 128 && F % 64 == 0) {
+  if (tf == 64 && plain && n_tiles > 2 * 256 && vec && B == 128 && F % 64 == 0) {
     // plain site with many tiles per CU (F > 32768): the looped, software-pipelined form (138 KB of LDS: one workgroup per CU)
     BwdLaunch b2 = bl;
     b2.grid = 256;

@@ -1,7 +1,6 @@
 // site_internal.h — geometry and launcher declarations shared by site_kernels.hip (generic B<=64 kernels,
 // C ABI) and site4_kernels.hip (the B in (64,128] kernels: 1024-thread workgroups, symmetric tiles).
 #pragma once
-#include "env_switch.h"
 #include "wgrad_reduce_body.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -56,8 +55,6 @@ inline BnFold no_bn() {
 // Features per tile of the B in (64,128] backward kernel (also the granularity of BnFold::dx_part).
 inline int bwd_tile_features(int B, int64_t F) {
   (void)B;
-  static const int forced = alignq_env::env_choice("ALIGNQ_BWD_TF", 0, {0, 32, 64});   // tuning aid
-  if (forced == 32 || forced == 64) return forced;
   return F >= 16384 ? 64 : 32;
 }
 
@@ -78,15 +75,9 @@ inline Geom geom(int B, int64_t F) {
   g.nb = B <= 32 ? 1 : (B <= 64 ? 2 : 4);
   if (g.nb == 4) {
     // tile width by F (only the 64-feature kernel ever loops over tiles; the one-tile forms are the latency-tuned ones)
-    g.tf = (F > 32 * 256) ? 64 : ((F > 16 * 256) ? 32 : 16);
-    // F <= 8192: twice as wide tiles (128 workgroups instead of 256): the step is 0.3 % FASTER (1.172 vs 1.177 ms, A/B on one
-    // box) because half as many partial-Gram slabs are written and reduced (118 instead of 173 MB per ResNet-20 step), which
-    // outweighs the longer per-tile chain of the forward launches; ALIGNQ_FWD_WIDE=0 restores the 256-workgroup rule
-    static const int wide = alignq_env::env_choice("ALIGNQ_FWD_WIDE", 1, {0, 1, 2});
-    if (wide == 1 && F <= 32 * 256) g.tf = (F > 16 * 256) ? 64 : 32;
-    // (=2: wide tiles at F <= 4096 only, i.e. 256 workgroups at F = 8192 and the fillers left to the seven F = 4096 launches:
-    //  1.056 / 1.057 ms against 1.040 with =1 once the reductions ride in the narrow launches)
-    if (wide == 2 && F <= 16 * 256) g.tf = 32;
+    // F <= 8192 takes tiles twice as wide as "one tile per CU" would (128 workgroups instead of 256): half as many partial-Gram
+    // slabs are written and reduced (118 instead of 173 MB per ResNet-20 step), which outweighs the longer per-tile chain
+    g.tf = (F > 16 * 256) ? 64 : 32;
     // beyond one 64-feature tile per CU the kernel loops over tiles: two 512-thread workgroups per CU (80 KB of LDS each)
     // (32-feature tiles were tried for this form: 128-byte row segments copy at 4.7-5.3 TB/s against 5.9-6.3 for 256-byte
     // ones, tools/src/stream_bw.hip, and the kernel ran 203 us against 186 at [128, 524288])
@@ -105,7 +96,7 @@ inline Geom geom(int B, int64_t F) {
       g.grid = (int)((F + 127) / 128);
       // 1024 workgroups = one resident round at four waves per SIMD (round 3: 2048 ran the kernel no faster - 57.6 vs 58.2 us at
       // [28, 802816] - and doubled the slabs the reduction reads: config 5 22.36 -> 22.24 ms)
-      static const int cap1 = alignq_env::env_int("ALIGNQ_S1_GRID_F", 1024, 1, 65535);   // tuning aid
+      constexpr int cap1 = 1024;
       if (g.grid > cap1) g.grid = cap1;
     }
     g.slab_floats = (32 * g.nb) * (32 * g.nb);

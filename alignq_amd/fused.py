@@ -195,7 +195,7 @@ class DeferredLosses:
     def take_fill(self, rec, B, F, dim, mu, rho):
         """Earlier sites (same B, dim, mu, rho, not reduced yet) whose slab reduction + ADMM loss the forward launch of the site
         `rec` at (B, F) takes along as its filler role (alignq_site_partials_bn_fill): only the one-tile launches that leave half
-        the chip idle have slots (alignq_site_fill_slots).  ALIGNQ_SITE_FILL=<n> caps the items per launch (0: none)."""
+        the chip idle have slots (alignq_site_fill_slots); _SITE_FILL caps the items per launch."""
         slots = min(_SITE_FILL, L.load().alignq_site_fill_slots(int(B), int(F)))
         out = []
         if slots > 0:
@@ -290,15 +290,14 @@ class DeferredWgrads:
         """Hands the oldest pending reductions to a caller that finishes them inside its own launch (the filler role of
         alignq_conv3x3_nhwc_bwd_fill; C: its channel count); they leave the list.  Measured: the 16-channel
         launches absorb ~5 MB of slabs for nothing (their one-per-CU filter-gradient role outlasts the data-gradient tiles), the
-        32- / 64-channel ones grow by about what the closing reduction saves.  ALIGNQ_WGRAD_FILL="a,b,c": items per launch at
-        16 / 32 / 64 channels ("0,0,0": everything is left to `flush`)."""
+        32- / 64-channel ones grow by about what the closing reduction saves (_WGRAD_FILL: items per launch by channel count)."""
         most = _WGRAD_FILL.get(C, 0)
         out, self.items = self.items[:most], self.items[most:]
         return out
 
     def take_site(self, B, F):
         """The same for a site's backward launch (alignq_site_bwd_apply_bn_fill): the narrow sites (F <= 8192) fill half the
-        chip, the reductions run beside them for nothing.  ALIGNQ_WGRAD_FILL_SITE=<n>: items per launch (0: none)."""
+        chip, the reductions run beside them for nothing (_WGRAD_FILL_SITE items per launch)."""
         most = min(_WGRAD_FILL_SITE, L.load().alignq_site_bwd_fill_slots(int(B), int(F)))
         out, self.items = self.items[:most], self.items[most:]
         return out
@@ -315,9 +314,13 @@ class DeferredWgrads:
 
 
 _active_wgrads = None
-_SITE_FILL = max(0, int(os.environ.get("ALIGNQ_SITE_FILL", "3")))
-_WGRAD_FILL_SITE = max(0, int(os.environ.get("ALIGNQ_WGRAD_FILL_SITE", "2")))
-_WGRAD_FILL = dict(zip((16, 32, 64), (min(4, max(0, int(v))) for v in os.environ.get("ALIGNQ_WGRAD_FILL", "2,0,0").split(","))))
+# Filler roles: reductions of EARLIER launches ride in launches that leave part of the chip idle (values by measurement, NOTES.md).
+# ALIGNQ_FILL=0 switches all of them off - the one runtime switch of the product path: the PMC passes (tools/make_profiles*.sh)
+# need every launch to move its own role's bytes only.
+_FILL_ON = os.environ.get("ALIGNQ_FILL", "1") != "0"
+_SITE_FILL = 3 if _FILL_ON else 0                        # items per one-tile site forward launch
+_WGRAD_FILL_SITE = 2 if _FILL_ON else 0                  # items per narrow site backward launch
+_WGRAD_FILL = {16: 2, 32: 0, 64: 0} if _FILL_ON else {}  # items per convolution backward launch, by channel count
 
 
 def active_wgrads():
@@ -651,7 +654,7 @@ class BNQuantReluFn(torch.autograd.Function):
         ws = torch.empty(lib.alignq_bnq_ws_bytes(C, groups), dtype=torch.uint8, device=dev)
         # the ReLU mask the backward needs, one bit per element (round 4): the node keeps 1/32 of a tensor instead of reading the
         # fp32 y twice; y itself belongs to whoever consumes it
-        mask = torch.empty(lib.alignq_bnq_mask_bytes(P, C, groups), dtype=torch.uint8, device=dev) if (relu and _BNQ_BITMASK) else None
+        mask = torch.empty(lib.alignq_bnq_mask_bytes(P, C, groups), dtype=torch.uint8, device=dev) if relu else None
         # conv_part: (double [groups, parts, C, 2], parts) left by the producing convolution's epilogue (ops.QConvGemmFn): the
         # statistics pass over z is skipped
         cp, cn = (conv_part[0], int(conv_part[1])) if conv_part is not None else (None, 0)
@@ -786,9 +789,7 @@ def bn_only(bn, z, groups=1):
                             groups, conv_partials(z, groups))
 
 
-_S1_MASK_IN_KERNEL = os.environ.get("ALIGNQ_S1_MASK", "1") != "0"
-_S1_BN_COLS = os.environ.get("ALIGNQ_S1_BN_COLS", "1") != "0"       # A/B aid: 0 = alignq_site1_groups_bwd + alignq_bnq_bwd_dx
-_BNQ_BITMASK = os.environ.get("ALIGNQ_BNQ_BITMASK", "1") != "0"     # A/B aid: 0 = the backward reads the fp32 y for the ReLU mask
+_S1_BN_COLS = True        # False: alignq_site1_groups_bwd + alignq_bnq_bwd_dx (a test's comparison arm; not an environment switch)
 
 
 class BNSite1Fn(torch.autograd.Function):
@@ -864,17 +865,14 @@ class BNSite1Fn(torch.autograd.Function):
         g_m = None
         g_y2 = ctx.tok.pop("extra", None) if ctx.tok is not None else None      # the shortcut's addend, left by GradFork.backward
         if g_y2 is not None:
-            if g_y is None or not _S1_MASK_IN_KERNEL or g_y2.shape != z.shape:
+            if g_y is None or g_y2.shape != z.shape:
                 g_y = g_y2 if g_y is None else g_y + g_y2                        # (forms without the second pointer: add here)
                 g_y2 = None
             else:
                 g_y2 = L.like_layout(g_y2, z)
         if g_y is not None:      # the fused ReLU's mask is applied by the site kernel, which also leaves the masked gradient in g_m
             g_y = L.like_layout(g_y, z)
-            if _S1_MASK_IN_KERNEL:
-                g_m = torch.empty_like(z) if has_res else None
-            else:                # (A/B aid, ALIGNQ_S1_MASK=0: the mask as its own elementwise pass)
-                g_y = g_m = torch.ops.aten.threshold_backward(g_y, y, 0.0)
+            g_m = torch.empty_like(z) if has_res else None
         if g_loss is None:
             g_loss = torch.zeros((), dtype=torch.float32, device=dev)
         if g_loss.dim() == 0:
@@ -883,15 +881,8 @@ class BNSite1Fn(torch.autograd.Function):
             if not (g_loss.is_cuda and g_loss.dtype == torch.float32 and tuple(g_loss.shape) == (groups,)):
                 raise RuntimeError("BNSite1Fn: the gradient of the loss vector must be a float32 device tensor of shape [groups]")
             gs_stride = int(g_loss.stride(0))
-        # _S1_MASK_IN_KERNEL (the default): alignq_site1_groups_prep writes dalterD / dgamma already summed over the slices
-        summed = _S1_MASK_IN_KERNEL
-        dAG = None
-        if summed:
-            rA, rG = torch.empty_like(A), torch.empty_like(Gm)
-            dA = dG = None
-        else:
-            dA = torch.empty(groups, *A.shape, dtype=torch.float32, device=dev)
-            dG = torch.empty(groups, *Gm.shape, dtype=torch.float32, device=dev)
+        # alignq_site1_groups_prep writes dalterD / dgamma already summed over the slices
+        rA, rG = torch.empty_like(A), torch.empty_like(Gm)
         from .ops import _ws
         s_bytes = lib.alignq_site_bwd_ws_bytes(B)
         S = _ws(s_bytes * groups, dev)
@@ -899,42 +890,23 @@ class BNSite1Fn(torch.autograd.Function):
         dgamma = torch.empty(C, dtype=torch.float32, device=dev) if has_w else None
         dbeta = torch.empty(C, dtype=torch.float32, device=dev) if has_b else None
         ws_bn = torch.empty(lib.alignq_bnq_ws_bytes(C, groups), dtype=torch.uint8, device=dev)
-        if _S1_MASK_IN_KERNEL:
-            # one preparation launch (S per slice; dalterD / dgamma summed over the slices in slice order) and one backward launch
-            L.check(lib.alignq_site1_groups_prep(L.ptr(D), L.ptr(A), L.ptr(Gm), A.shape[0], L.ptr(scal), mu, L.ptr(g_loss), gs_stride, B, F,
-                                                 groups, L.ptr(S), L.ptr(rA), L.ptr(rG), st), "alignq_site1_groups_prep")
-            if _S1_BN_COLS:
-                # round 4: the site kernel leaves the batch-norm backward's sums per feature column; a small reduction, the
-                # finalisation and dz (in place) follow in the same entry: no pass of its own over dx and z
-                cols = torch.empty(lib.alignq_site1_cols_bytes(F, groups), dtype=torch.uint8, device=dev)
-                L.check(lib.alignq_site1_groups_bwd_bn(L.ptr(g_y), L.ptr(g_y2), L.ptr(None if g_y is None else y), L.ptr(S), L.ptr(z),
-                                                       L.ptr(ab), L.ptr(save), C, L.ptr(stats), B, F, groups, act_range, eps, L.ptr(dx),
-                                                       L.ptr(g_m), L.ptr(dgamma), L.ptr(dbeta), L.ptr(cols), L.ptr(ws_bn), st),
-                        "alignq_site1_groups_bwd_bn")
-            else:
-                L.check(lib.alignq_site1_groups_bwd(L.ptr(g_y), L.ptr(g_y2), L.ptr(None if g_y is None else y), L.ptr(S), L.ptr(z),
-                                                    L.ptr(ab), C, L.ptr(stats), B, F, groups, act_range, eps, L.ptr(dx), L.ptr(g_m), st),
-                        "alignq_site1_groups_bwd")
-        else:
-            for gi in range(groups):
-                sl = slice(gi * B, (gi + 1) * B)
-                L.check(lib.alignq_site_prep_fused(L.ptr(D[gi]), L.ptr(A), L.ptr(Gm), A.shape[0], L.ptr(scal[gi]), mu,
-                                                   L.ptr(g_loss if g_loss.dim() == 0 else g_loss[gi]), B, F, L.ptr(S), L.ptr(dA[gi]),
-                                                   L.ptr(dG[gi]), st), "alignq_site_prep_fused")
-                L.check(lib.alignq_site_bwd_apply_ab(L.ptr(None if g_y is None else g_y[sl]), L.ptr(S), L.ptr(z[sl]), L.ptr(ab[gi]), C,
-                                                     L.ptr(stats[gi]), B, F, act_range, eps, L.ptr(dx[sl]), st),
-                        "alignq_site_bwd_apply_ab")
-        if not (_S1_MASK_IN_KERNEL and _S1_BN_COLS):
+        # one preparation launch (S per slice; dalterD / dgamma summed over the slices in slice order) and one backward launch
+        L.check(lib.alignq_site1_groups_prep(L.ptr(D), L.ptr(A), L.ptr(Gm), A.shape[0], L.ptr(scal), mu, L.ptr(g_loss), gs_stride, B, F,
+                                             groups, L.ptr(S), L.ptr(rA), L.ptr(rG), st), "alignq_site1_groups_prep")
+        if _S1_BN_COLS:
+            # the site kernel leaves the batch-norm backward's sums per feature column; a small reduction, the finalisation and dz
+            # (in place) follow in the same entry: no pass of its own over dx and z
+            cols = torch.empty(lib.alignq_site1_cols_bytes(F, groups), dtype=torch.uint8, device=dev)
+            L.check(lib.alignq_site1_groups_bwd_bn(L.ptr(g_y), L.ptr(g_y2), L.ptr(None if g_y is None else y), L.ptr(S), L.ptr(z),
+                                                   L.ptr(ab), L.ptr(save), C, L.ptr(stats), B, F, groups, act_range, eps, L.ptr(dx),
+                                                   L.ptr(g_m), L.ptr(dgamma), L.ptr(dbeta), L.ptr(cols), L.ptr(ws_bn), st),
+                    "alignq_site1_groups_bwd_bn")
+        else:       # (the two-launch form, kept as the comparison arm of tests/test_gpu_round4.py: the sums from a pass over dx and z)
+            L.check(lib.alignq_site1_groups_bwd(L.ptr(g_y), L.ptr(g_y2), L.ptr(None if g_y is None else y), L.ptr(S), L.ptr(z),
+                                                L.ptr(ab), C, L.ptr(stats), B, F, groups, act_range, eps, L.ptr(dx), L.ptr(g_m), st),
+                    "alignq_site1_groups_bwd")
             L.check(lib.alignq_bnq_bwd_dx(L.ptr(dx), L.ptr(z), L.ptr(ab), L.ptr(save), P, C, groups, L.ptr(dx), L.ptr(dgamma),
                                           L.ptr(dbeta), L.ptr(ws_bn), st), "alignq_bnq_bwd_dx")
-
-        if not summed:
-            def red(t):                              # the slices' alterD / gamma gradients added in slice order
-                out = t[0]
-                for gi in range(1, groups):
-                    out = out + t[gi]
-                return out
-            rA, rG = red(dA), red(dG)
         return (dx, dgamma, dbeta, None, None, None, None, None, g_m if has_res else None, rA, rG, None, None,
                 None, None, None, None, None, None, None)
 
@@ -951,7 +923,7 @@ def bn_site_res_relu(bn, act, z, residual, eps, groups=1, loss_vec=False):
             and residual.dtype == torch.float32 and z.shape[0] // groups <= act.opt.alterD.shape[0]):
         return None
     admm = act.opt
-    tok = {} if _GRAD_FORK else None
+    tok = {}
     y, loss, D = BNSite1Fn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum,
                                  bn.eps, residual, admm.alterD, admm.gamma, act.a_bit, config.args.act_range, eps, admm.mu, admm.rho,
                                  groups, tok, bool(loss_vec and groups > 1), conv_partials(z, groups))
@@ -959,9 +931,6 @@ def bn_site_res_relu(bn, act, z, residual, eps, groups=1, loss_vec=False):
         y._alignq_site_tok = tok          # read by fork_block_input (the next bottleneck)
     admm.D = D
     return y, loss
-
-
-_GRAD_FORK = os.environ.get("ALIGNQ_GRAD_FORK", "1") != "0"      # A/B aid: 0 = autograd adds the two gradients itself
 
 
 class GradFork(torch.autograd.Function):
@@ -982,7 +951,11 @@ class GradFork(torch.autograd.Function):
     def backward(ctx, g_a, g_b):
         if g_a is None or g_b is None:
             return (g_b if g_a is None else g_a), None
-        assert "extra" not in ctx.tok, "GradFork: the producing site has not consumed the previous addend"
+        if "extra" in ctx.tok:
+            # a pruned / partial backward on a retained graph left the previous addend behind (its producer never ran): it belongs
+            # to that backward, not to this one
+            raise RuntimeError("GradFork: the producing site has not consumed the previous shortcut gradient (a partial backward "
+                               "through a retained graph?); run whole backwards through the folded bottleneck")
         ctx.tok["extra"] = g_b
         return g_a, None
 

@@ -7,7 +7,6 @@ downsample.1}, class_classifier.c_fc3, domain_classifier.d_fc2) so its checkpoin
 (the reference's `pretrained=True` default needs the network)."""
 from __future__ import annotations
 
-import os
 
 import torch
 import torch.nn as nn
@@ -24,8 +23,6 @@ def conv3x3(wbit, stage, cin, cout, stride=1):
 def conv1x1(wbit, stage, cin, cout, stride=1):
     return Q.conv2d_Q_fn(w_bit=wbit, stage=stage)(cin, cout, kernel_size=1, stride=stride, bias=False)
 
-
-_LOSS_VEC = os.environ.get("ALIGNQ_S1_LOSS_VEC", "1") != "0"      # A/B aid: 0 = every folded site adds its slices' losses itself
 
 class Bottleneck(nn.Module):
     expansion = 4
@@ -48,9 +45,11 @@ class Bottleneck(nn.Module):
         self.act_q2 = Q.activation_quantize_fn(a_bit=abit, stage=stage)
         self.act_q3 = Q.activation_quantize_fn2(a_bit=abit, stage=stage, admm=self.admm0)
 
-    def forward(self, x, groups=1):
+    def forward(self, x, groups=1, loss_vec=False):
         """groups > 1 (OfficeTrainStep(dual=True)): x holds the source and the target batch back to back; the convolutions
-        (per sample) run once on both, every batch statistic / quantiser site / correlation per slice in pass order."""
+        (per sample) run once on both, every batch statistic / quantiser site / correlation per slice in pass order.
+        loss_vec (groups > 1; ResNet.forward passes it): the trans loss comes back as the VECTOR of the slices' losses (a view, no
+        kernel) for a caller that sums all its sites at once; the default is the scalar, like the reference's block."""
         trans_loss = 0.
         identity = x
         if groups > 1:
@@ -63,7 +62,7 @@ class Bottleneck(nn.Module):
             out = self.act_q2.forward_bn_relu(self.bn2, self.conv2(out), groups)
             if self.downsample is not None:
                 identity = fused.bn_only(self.downsample[1], self.downsample[0](x_short), groups)
-            out, loss = self.act_q3.forward_bn_res_relu(self.bn3, self.conv3(out), identity, groups, loss_vec=_LOSS_VEC)
+            out, loss = self.act_q3.forward_bn_res_relu(self.bn3, self.conv3(out), identity, groups, loss_vec=loss_vec)
             return out, loss              # (= 0. + loss without the launch that forms it)
         x_short = x
         if getattr(self, "fuse_bn", False):         # opt-in (OfficeTrainStep): batch-norm + quantiser + ReLU as one chain
@@ -146,7 +145,7 @@ class ResNet(nn.Module):
             losses = []
             for layers in (self.layer1, self.layer2, self.layer3, self.layer4):
                 for layer in layers:
-                    x, loss = layer(x, groups)
+                    x, loss = layer(x, groups, loss_vec=True)
                     losses.append(loss)
             # one stack + one sum instead of 16 scalar additions on the in-order chain (the fast path only: the value may differ
             # from main.py's running sum in the last bit, the gradients - ones - do not)

@@ -9,8 +9,6 @@ from __future__ import annotations
 
 from typing import Optional
 
-import os
-
 import torch
 import torch.nn.functional as F
 
@@ -53,11 +51,6 @@ def release_step_graphs(admms):
 def assert_no_retained_graph(params, who):
     stale = retained_graph_params(params)
     if stale:
-        if os.environ.get("ALIGNQ_DEBUG_RETAINED"):      # who holds them (diagnostic aid)
-            import gc
-            acc = stale[0].expand_as(stale[0]).grad_fn.next_functions[0][0]
-            for r in gc.get_referrers(acc)[:8]:
-                print("retained-graph referrer:", type(r), str(r)[:200], flush=True)
         raise RuntimeError(
             f"{who}: {len(stale)} parameter(s) are still referenced by the autograd graph of an earlier iteration (a loss / output "
             "tensor of an eager step that is still alive).  Their gradient-accumulation nodes are bound to the stream that "

@@ -623,22 +623,6 @@ def test_site_slab_reduction_as_a_filler_role_leaves_the_same_bits(dev, units, k
         config.args.train_batch_size = 128
 
 
-def test_narrow_tile_geometry_switch_runs_the_masked_kernels(dev):
-    """ALIGNQ_FWD_WIDE=0 (256 slabs per site: 16-feature forward tiles at F = 4096, whose 1024 threads form 256 row groups for 128
-    rows) once launched the unmasked full-tile instantiation and faulted; the environment switch is read once per process, so the
-    folded-site parity cases at the CIFAR shapes run here in ONE child process with the switch set."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, ALIGNQ_FWD_WIDE="0")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_bench_path.py", "-q", "-x", "-m", "gpu", "-k",
-                        "bn_folded_site_kernels_vs_oracle and 128-64-8 or bn_folded_site_kernels_vs_oracle and 128-32-16"],
-                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout
-
-
 def test_plain_quantiser_with_streamed_outputs_vs_oracle(dev):
     """From 2^25 elements on the plain quantiser stores its outputs non-temporally (quant_kernels.hip: stream_out); the whole
     33.5 M-element result, ragged tail included, against the C oracle: forward bit for bit, backward to 1e-5."""

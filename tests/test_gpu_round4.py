@@ -360,52 +360,41 @@ def test_bn_folded_plain_quantiser_with_residual_equals_the_composition(dev, B, 
 
 
 def test_small_site_finalisation_inside_the_apply_kernels_equals_the_launches(dev):
-    """ALIGNQ_BNQ_FIN=0 (the finalisation launches everywhere) against the default (small single-group sites finalise inside the
-    apply kernels) in child processes on one seeded problem: y, the mask bits, (a, b), the saved statistics, the running statistics,
-    dz, dgamma, dbeta - the partial counts differ (<= 32 instead of up to 512 per channel), so the sums agree to double rounding and
-    the fp32 results to 1 ulp of the statistics: compared at 1e-6 relative, y at bin-flip scale."""
-    import os
-    import subprocess
-    import sys
-    prog = r'''
-import sys, numpy as np, torch
-sys.path.insert(0, ".")
-from alignq_amd import _lib as L
-lib = L.load(); st, p = L.stream_ptr(), L.ptr
-dev = torch.device("cuda:0"); torch.manual_seed(0)
-B, C, H = 128, 16, 32
-P = B * H * H
-z = torch.randn(B, H, H, C, device=dev) * 1.3 + 0.1
-g = torch.randn(B, H, H, C, device=dev) * 0.01
-res = torch.randn(B, H, H, C, device=dev)
-gam, bet = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev) * 0.3
-rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
-nbt = torch.zeros((), dtype=torch.int64, device=dev)
-ab, save = torch.empty(1, 2, C, device=dev), torch.empty(1, 2, C, device=dev)
-y, dz, dres = torch.empty_like(z), torch.empty_like(z), torch.empty_like(z)
-dg, db = torch.empty(C, device=dev), torch.empty(C, device=dev)
-ws = torch.empty(lib.alignq_bnq_ws_bytes(C, 1), dtype=torch.uint8, device=dev)
-mask = torch.zeros(lib.alignq_bnq_mask_bytes(P, C, 1), dtype=torch.uint8, device=dev)
-L.check(lib.alignq_bnq_fwd(p(z), P, C, 1, p(gam), p(bet), p(rm), p(rv), p(nbt), 0.1, 1e-5, 8, 2.0, 1, 1, p(res), p(ab), p(save), p(y),
-                           p(mask), p(ws), st), "fwd")
-L.check(lib.alignq_bnq_bwd(p(g), p(z), None, p(mask), p(ab), p(save), P, C, 1, 2.0, 1, p(dz), p(dres), p(dg), p(db), p(ws), st), "bwd")
-torch.cuda.synchronize()
-np.savez(sys.argv[1], y=y.cpu().numpy(), mask=mask.cpu().numpy(), ab=ab.cpu().numpy(), save=save.cpu().numpy(), rm=rm.cpu().numpy(),
-         rv=rv.cpu().numpy(), nbt=nbt.cpu().numpy(), dz=dz.cpu().numpy(), dres=dres.cpu().numpy(), dg=dg.cpu().numpy(), db=db.cpu().numpy())
-'''
-    import tempfile
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    """Small single-group sites finalise their batch-norm statistics inside the apply kernels (bnq_kernels.hip: fin_small); sites
+    with several batch slices run the finalisation launches.  One seeded problem through both forms in one process (round 5: no
+    environment switch any more): the slice alone (in-kernel finalisation) against the same slice twice as two groups (launches):
+    y, (a, b), the saved statistics, dz of group 0, dgamma / dbeta (twice the single slice's) - the partial counts differ, so the
+    sums agree to double rounding and the fp32 results to 1 ulp of the statistics: 1e-6 relative, y at bin-flip scale."""
+    from alignq_amd import _lib as L
+    lib = L.load()
+    st, p = L.stream_ptr(), L.ptr
+    torch.manual_seed(0)
+    B, C, H = 128, 16, 32
+    P = B * H * H
+    z1 = torch.randn(B, H, H, C, device=dev) * 1.3 + 0.1
+    g1 = torch.randn(B, H, H, C, device=dev) * 0.01
+    r1 = torch.randn(B, H, H, C, device=dev)
+    gam, bet = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev) * 0.3
     res = {}
-    with tempfile.TemporaryDirectory() as td:
-        for fin in ("0", "1"):
-            out = os.path.join(td, f"r{fin}.npz")
-            env = dict(os.environ, ALIGNQ_BNQ_FIN=fin)
-            subprocess.run([sys.executable, "-c", prog, out], cwd=root, env=env, check=True, timeout=300)
-            with np.load(out) as f:
-                res[fin] = {k: f[k] for k in f.files}
-    a, b = res["0"], res["1"]
-    assert int(a["nbt"]) == int(b["nbt"]) == 1
-    for key in ("ab", "save", "rm", "rv", "dg", "db"):
+    for G in (1, 2):
+        z, g, rs = (torch.cat([t] * G, 0).contiguous() for t in (z1, g1, r1))
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        nbt = torch.zeros((), dtype=torch.int64, device=dev)
+        ab, save = torch.empty(G, 2, C, device=dev), torch.empty(G, 2, C, device=dev)
+        y, dz, dres = torch.empty_like(z), torch.empty_like(z), torch.empty_like(z)
+        dg, db = torch.empty(C, device=dev), torch.empty(C, device=dev)
+        ws = torch.empty(lib.alignq_bnq_ws_bytes(C, G), dtype=torch.uint8, device=dev)
+        mask = torch.zeros(lib.alignq_bnq_mask_bytes(P, C, G), dtype=torch.uint8, device=dev)
+        L.check(lib.alignq_bnq_fwd(p(z), P, C, G, p(gam), p(bet), p(rm), p(rv), p(nbt), 0.1, 1e-5, 8, 2.0, 1, 1, p(rs), p(ab), p(save),
+                                   p(y), p(mask), p(ws), st), "fwd")
+        L.check(lib.alignq_bnq_bwd(p(g), p(z), None, p(mask), p(ab), p(save), P, C, G, 2.0, 1, p(dz), p(dres), p(dg), p(db), p(ws), st),
+                "bwd")
+        torch.cuda.synchronize()
+        res[G] = dict(y=npy(y[:B]), ab=npy(ab[0]), save=npy(save[0]), nbt=int(nbt), dz=npy(dz[:B]), dres=npy(dres[:B]),
+                      dg=npy(dg) / G, db=npy(db) / G)
+    a, b = res[2], res[1]
+    assert a["nbt"] == 2 and b["nbt"] == 1
+    for key in ("ab", "save", "dg", "db"):
         np.testing.assert_allclose(b[key], a[key], rtol=2e-6, atol=1e-7, err_msg=key)
     np.testing.assert_allclose(b["dz"], a["dz"], rtol=1e-4, atol=1e-7)
     lev = 4.0 / 255                                               # one level of x_q = r * (2 bin / n - 1)

@@ -7,7 +7,7 @@ rm -rf gpurun_out/prof && mkdir -p gpurun_out/prof
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/stats -o run -- python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-shapes --no-dp-probe --no-other-configs > gpurun_out/prof/stats.log 2>&1
 # the two counter passes run with the filler roles off (a launch's bytes are then its own role's: with them on, the narrow sites'
 # launches also read the slabs of earlier sites / convolutions, bytes that the closing reductions read otherwise)
-export ALIGNQ_SITE_FILL=0 ALIGNQ_WGRAD_FILL=0,0,0 ALIGNQ_WGRAD_FILL_SITE=0
+export ALIGNQ_FILL=0
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/prof/fetch -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-shapes --no-dp-probe --no-other-configs > gpurun_out/prof/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/prof/write -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-shapes --no-dp-probe --no-other-configs > gpurun_out/prof/write.log 2>&1
 unset ALIGNQ_SITE_FILL ALIGNQ_WGRAD_FILL ALIGNQ_WGRAD_FILL_SITE

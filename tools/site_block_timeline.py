@@ -55,7 +55,7 @@ for (C, HW) in ((16, 1024), (32, 256), (64, 64)):
     print(f"F={F} block 0 bwd: entry->tile loop {(a[10] - e0[1, 0, 0]) * 0.01:.2f} | load+erf+LDS(+S frags) {bb[0]:.2f} | MFMA {bb[1]:.2f} | "
           f"proj {bb[2]:.2f} | assemble {bb[3]:.2f} | copy-out {bb[4]:.2f} | last stamp->exit {(e0[1, 1, 0] - a[15]) * 0.01:.2f}")
     nf = min((F + (64 if F >= 16384 else 32 if F >= 8192 else 16) - 1) // (64 if F >= 16384 else 32 if F >= 8192 else 16), 256)
-    tfb = int(os.environ.get('ALIGNQ_BWD_TF', 64 if F >= 16384 else 32))
+    tfb = 64 if F >= 16384 else 32
     nb = (F + tfb - 1) // tfb
     for name, kern, n in (("fwd", 0, nf), ("bwd", 1, nb)):
         ent, ext = blocks(kern, n)

@@ -74,7 +74,7 @@ for k in sorted(set(fetch) | set(write)):
 rows.sort(key=lambda r: -r[7] * r[2])
 with open(os.path.join(out, "pmc_hbm_bytes.csv"), "w") as fo:
     fo.write("# rocprofv3 --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) --kernel-trace --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-shapes --no-dp-probe\n")
-    fo.write("# filler roles off in these two passes (ALIGNQ_SITE_FILL=0 ALIGNQ_WGRAD_FILL=0,0,0 ALIGNQ_WGRAD_FILL_SITE=0): every launch moves its own role's bytes only\n")
+    fo.write("# filler roles off in these two passes (ALIGNQ_FILL=0): every launch moves its own role's bytes only\n")
     fo.write("# Units: KB per dispatch (mean over dispatches). gfx950: FETCH_SIZE reports 1/2 of wide coalesced reads (MI355X_MICROARCH.md, HBM) -> fetch_corrected = 2*FETCH\n")
     fo.write("kernel,grid_threads,dispatches,FETCH_SIZE_KB,fetch_corrected_MB,WRITE_SIZE_KB,write_MB,total_corrected_MB\n")
     for r in rows[:60]:
