@@ -35,3 +35,56 @@ def test_no_kernel_spills_or_uses_scratch():
     assert len(kernels) > 100, len(kernels)          # the remarks were produced (every kernel reports both quantities)
     bad = [r for r in rows if r[3] != 0]
     assert not bad, bad
+
+
+def _isa(src):
+    """gfx950 assembly of one .hip file (device side only): {kernel symbol: [instruction lines]}"""
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", f"-I{ROOT}/include",
+           f"-I{ROOT}/alignq_amd/csrc", "--cuda-device-only", "-S", src, "-o", "-"]
+    text = subprocess.run(cmd, capture_output=True, text=True).stdout
+    out, name = {}, None
+    for line in text.split("\n"):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            name = m.group(1)
+            out[name] = []
+        elif name is not None:
+            if line.startswith(".Lfunc_end"):
+                name = None
+            else:
+                out[name].append(line.strip())
+    return out
+
+
+def test_ticket_hand_off_stores_and_loads_are_write_through():
+    """the last-arriver epilogues (slab reduction + ADMM loss in site4_kernels.hip, the batch mean in
+    head_kernels.hip) publish their partials with RELAXED agent-scope atomic stores, drain them, take a relaxed ticket, and the
+    last workgroup reads them with relaxed agent-scope atomic loads.  That is a valid hand-off on gfx950 only because the compiler
+    emits those stores and loads with the sc1 bit (write-through to / read from memory past the non-coherent per-XCD L2) and the
+    ticket as a device-scope atomic - an ISA property, not one of the C++ memory model: a compiler update that dropped the bit
+    would break the hand-off without any numerical test noticing on a quiet machine.  Asserted on the generated code."""
+    head = _isa(os.path.join(ROOT, "alignq_amd", "csrc", "head_kernels.hip"))
+    fwd = [v for k, v in head.items() if "head_fwd_kernel" in k]
+    assert len(fwd) == 1
+    st = [ln for ln in fwd[0] if ln.startswith("global_store_dword ")]
+    ld_sc1 = [ln for ln in fwd[0] if ln.startswith("global_load_dword ") and ln.endswith(" sc1")]
+    assert any(ln.endswith(" sc1") for ln in st) and ld_sc1, (st, ld_sc1)            # loss[b] published / read write-through
+    assert any(ln.startswith("global_atomic_add ") for ln in fwd[0])                # the ticket
+    site = _isa(os.path.join(ROOT, "alignq_amd", "csrc", "site4_kernels.hip"))
+    red = {k: v for k, v in site.items() if "slab_reduce" in k}
+    assert red, list(site)[:5]
+    checked = 0
+    for k, body in red.items():
+        tick = [i for i, ln in enumerate(body) if ln.startswith("global_atomic_add ")]
+        if not tick:
+            continue                                                                  # (a form without the loss epilogue)
+        checked += 1
+        first = tick[0]
+        # the three partial stores right in front of the ticket, write-through, with the drain between them and the ticket
+        before = [ln for ln in body[max(0, first - 40):first]]
+        sc1_st = [ln for ln in before if ln.startswith("global_store_dword ") and ln.endswith(" sc1")]
+        assert len(sc1_st) >= 3, (k, before[-12:])
+        assert any(ln.startswith("s_waitcnt vmcnt(0)") for ln in before), k
+        sc1_ld = [ln for ln in body[first:] if ln.startswith("global_load_dword ") and ln.endswith(" sc1")]
+        assert len(sc1_ld) >= 3, (k, len(sc1_ld))
+    assert checked >= 1
