@@ -463,7 +463,7 @@ __global__ __launch_bounds__(kThreads1, PAIR ? 3 : 5) void site1_bwd_kernel(cons
       // (x - beta) / gamma up to the rounding of x = a*z + b; an ill-conditioned channel (alignq_bn_col_ill: gamma == 0 or
       // |gamma| < 1e-2 |beta|) leaves 0 and bnq_finalize_bwd_kernel forms it from dx and z itself): 8 bytes per column instead of alignq_bnq_bwd_dx's own pass over dx and z (8 B per ELEMENT).  A pass
       // of its own behind the stores and scheduling barriers, a and the statistics re-read through pointers the optimiser cannot
-      // match with the earlier ones: inside the loop above (the kernel's register peak) every form of it spilled.
+      // match with the earlier ones: inside the loop above (the kernel's register peak) every form of it spilled (NOTES.md 5g).
       __builtin_amdgcn_sched_barrier(0);
       const float* ab2 = ab;
       const float* sv2 = save;

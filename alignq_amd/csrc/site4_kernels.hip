@@ -34,7 +34,7 @@ constexpr int NT = 1024;
 // ONE lane that also takes the ticket, the last workgroup reads them with sc1 loads behind a workgroup barrier: the form
 // MI355X_MICROARCH.md lists as measured-valid (its hand-off table, row 1).  -DALIGNQ_TICKET_ACQREL builds the formally
 // ordered variant (release fence = write-back of the XCD's dirty L2 lines before the ticket, acquire after it) for the A/B
-// measurement in DESIGN.md.
+// measurement in NOTES.md.
 #ifdef ALIGNQ_TICKET_ACQREL
 #define ALIGNQ_TICKET_ORDER __ATOMIC_ACQ_REL
 #else

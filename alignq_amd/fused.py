@@ -288,7 +288,7 @@ class DeferredWgrads:
 
     def take(self, C):
         """Hands the oldest pending reductions to a caller that finishes them inside its own launch (the filler role of
-        alignq_conv3x3_nhwc_bwd_fill; C: its channel count); they leave the list.  Measured: the 16-channel
+        alignq_conv3x3_nhwc_bwd_fill; C: its channel count); they leave the list.  Measured (NOTES.md 5f): the 16-channel
         launches absorb ~5 MB of slabs for nothing (their one-per-CU filter-gradient role outlasts the data-gradient tiles), the
         32- / 64-channel ones grow by about what the closing reduction saves (_WGRAD_FILL: items per launch by channel count)."""
         most = _WGRAD_FILL.get(C, 0)

@@ -359,6 +359,8 @@ def measure_kernels(dev, B, k, site_F_counts, hw_of_F, folded=True, nhwc=False, 
     # 10-15 us launch) the matrix pipe no longer bounds these kernels: the irreducible work is the HBM traffic.
     roofline = {"kernel": kernel_sym, "bound": "hbm", "achieved": by_sum / t_sum / 1e9, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": by_sum / t_sum / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": "profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+                                  "2 x FETCH_SIZE + WRITE_SIZE per launch; a stored figure, not measured in this run)",
                 "launches_per_step": n_sites, "avg_launch_us": t_sum / n_sites * 1e6,
                 "bytes_per_launch_avg": by_sum / n_sites,
                 "gram_tflops_fp32_equiv": fl_sum / t_sum / 1e12,
@@ -870,9 +872,10 @@ def other_configs(dev, a, steps=30, only=None):
         gc.collect()
         torch.cuda.empty_cache()
     config.args.bitW, config.args.abitW, config.args.train_batch_size, config.args.eval_batch_size = saved
-    out["note"] = ("one GPU's share of BASELINE.json configs[2..4], HIP-graph replay, channels-last; config 5's convolutions "
-                   "are MIOpen's (out of scope), its batch-norms run folded into the quantiser / site kernels, source and target "
-                   "batch in one traversal; lr 0.004 from random init (DESIGN.md section 5b)")
+    out["note"] = ("one GPU's share of BASELINE.json configs[2..4], HIP-graph replay, channels-last; config 5: Conv2d_Q's 1x1 / 3x3 "
+                   "convolutions on alignq_qconv_* (round 5), batch-norms folded into the quantiser / site kernels with their "
+                   "statistics from the convolutions' epilogues, source and target batch in one traversal; lr 0.004 from random "
+                   "init; CPU numbers of configs 4 and 5 on the same kind of box: profiles/r05_cpu_baseline_configs.json")
     return out
 
 
@@ -928,7 +931,10 @@ def headline(a, elapsed, images_per_step, world, office, final_ce, final_tl):
                                   ", MIOpen find mode for the convolutions")
                                + ("" if a.nchw else ", channels-last tensors")
                                + ("" if (office or a.nchw or a.no_qconv) else
-                                  ", all Conv2d_Q convolutions on alignq_conv*_nhwc (exact-product bf16 MFMA)"),
+                                  ", all Conv2d_Q convolutions on alignq_conv*_nhwc (exact-product bf16 MFMA)")
+                               + ("" if (not office or a.nchw or a.no_qconv) else
+                                  ", Conv2d_Q's 1x1 / 3x3 convolutions on alignq_qconv_* (exact-product bf16 / f16 MFMA GEMMs; the 7x7 "
+                                  "stem and three stride-2 data gradients on MIOpen)"),
                    "global_batch": a.batch * world, "parallelism": f"dp{world}",
                    "final_ce": final_ce, "final_trans_loss": final_tl},
     }

@@ -1,6 +1,6 @@
 """No kernel of the library spills registers or uses scratch memory (hipcc -Rpass-analysis=kernel-resource-usage over every
 .hip file, cross-compiled for gfx950: no GPU needed).  A spill in a streaming kernel is scratch traffic in its inner loop; the
-site kernels are sized against the 128 / 168 / 256 register steps on purpose."""
+site kernels are sized against the 128 / 168 / 256 register steps on purpose (NOTES.md section 5e)."""
 import concurrent.futures
 import glob
 import os

@@ -4,7 +4,7 @@
     python tools/isa_kernel.py <file.s> <substring of the mangled kernel name> [--count]
 
 --count prints, per basic block, the number of vector-ALU, LDS, vector-memory and scalar instructions, so the
-instructions per element of a streaming loop can be read off (DESIGN.md quotes these numbers)."""
+instructions per element of a streaming loop can be read off (NOTES.md quotes these numbers)."""
 import re
 import sys
 

@@ -111,7 +111,7 @@ void run_site(int grid) {
 float *dx, *dy;
 static const long N = 1L << 26;
 // STREAM_BW_SETS=<n>: rotate inputs and outputs over n buffer pairs (cold operands: with one pair, part of the re-read input is
-// served by the 256 MB memory-side cache for non-temporal readers)
+// served by the 256 MB memory-side cache for non-temporal readers, see NOTES.md 5f)
 static int g_sets = 1;
 static float* g_xs[8];
 static float* g_ys[8];
