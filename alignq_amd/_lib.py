@@ -53,7 +53,7 @@ SIGNATURES = {
     "alignq_bnq_stats": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp]),
     "alignq_bnq_stats_parts": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _i, _vp]),
     "alignq_bnq_fwd_parts": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i,
-                                  _vp]),
+                                  _vp, _vp]),
     "alignq_bnq_affine": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     "alignq_bnq_bwd_dx": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "alignq_site_partials_res_ab": (_i, [_vp, _vp, _i, _i, _i64, _i, _f, _f, _vp, _i, _vp, _vp, _vp, _vp]),
@@ -101,10 +101,10 @@ SIGNATURES = {
     "alignq_qconv_supported": (_i, [_i] * 7),
     "alignq_qconv_bn_parts": (_i, [_i] * 8 + [_f]),
     "alignq_qconv_pack_weights": (_i, [_i, _vp, _vp, _i, _vp, _vp, _vp]),
-    "alignq_qconv_fwd": (_i, [_vp, _vp, _vp] + [_i] * 8 + [_f, _i, _vp, _vp]),
+    "alignq_qconv_fwd": (_i, [_vp, _vp, _vp] + [_i] * 8 + [_f, _i, _i, _vp, _vp]),
     "alignq_qconv_dgrad": (_i, [_vp, _vp, _vp] + [_i] * 8 + [_vp]),
     "alignq_qconv_wgrad_ws_bytes": (_sz, [_i] * 7),
-    "alignq_qconv_wgrad": (_i, [_vp, _vp, _vp, _vp] + [_i] * 7 + [_f, _vp, _vp]),
+    "alignq_qconv_wgrad": (_i, [_vp, _vp, _vp, _vp] + [_i] * 7 + [_f, _i, _vp, _vp]),
     "alignq_bn_bwd_totals": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "alignq_conv3x3_wgrad_reduce_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
     "alignq_head_ce_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),

@@ -324,7 +324,8 @@ template <int FORMULA, int NT, bool FIN = false>
 __global__ __launch_bounds__(NT) void bnq_apply_fwd_kernel(const float* __restrict__ z, const float* __restrict__ ab, int64_t nvec,
                                                            int C, int k, float r, int relu, float* __restrict__ y,
                                                            unsigned long long* __restrict__ mask = nullptr,
-                                                           const float* __restrict__ res = nullptr, FinFwd fin = FinFwd{}) {
+                                                           const float* __restrict__ res = nullptr, FinFwd fin = FinFwd{},
+                                                           short* __restrict__ ybins = nullptr) {
   __shared__ __attribute__((aligned(16))) float nerf_lds[ALIGNQ_NERF_LDS_FLOATS];
   __shared__ __attribute__((aligned(16))) float ab_s[FIN ? 2 * kFinC : 4];
   nerf_tab_load(nerf_lds);
@@ -356,7 +357,8 @@ __global__ __launch_bounds__(NT) void bnq_apply_fwd_kernel(const float* __restri
   const NerfTab tab = nerf_tab(nerf_lds);
   const Levels nlev = make_levels(k, fabsf(r) <= 8.0f);
   z += (int64_t)blockIdx.y * nvec * 4;           // blockIdx.y = group (see bnq_sums_kernel)
-  y += (int64_t)blockIdx.y * nvec * 4;
+  if (y) y += (int64_t)blockIdx.y * nvec * 4;
+  if (ybins) ybins += (int64_t)blockIdx.y * nvec * 4;   // N2 on the Office path: the (ReLU-clamped) level index as int16
   if (res) res += (int64_t)blockIdx.y * nvec * 4;
   if (mask) mask += (int64_t)blockIdx.y * mask_words(nvec);
   if (!FIN) ab += (int64_t)blockIdx.y * 2 * C;
@@ -380,20 +382,25 @@ _Pragma("unroll")
     for (int u = 0; u < kUa; u++) {
       const int64_t i = i0 + u * NT;
       float4 o;
-      float t, b;
+      float t;
       if (FORMULA == 2) {          // no quantiser: the batch-norm output itself (downsample branch)
         o = make_float4(__fmaf_rn(a4.x, v[u].x, b4.x), __fmaf_rn(a4.y, v[u].y, b4.y), __fmaf_rn(a4.z, v[u].z, b4.z),
                         __fmaf_rn(a4.w, v[u].w, b4.w));
       } else {
         constexpr int FQ = FORMULA == 2 ? 0 : FORMULA;
-        o.x = act_quant1<FQ, kBounded>(__fmaf_rn(a4.x, v[u].x, b4.x), k, nlev, r, &t, &b, tab);
-        o.y = act_quant1<FQ, kBounded>(__fmaf_rn(a4.y, v[u].y, b4.y), k, nlev, r, &t, &b, tab);
-        o.z = act_quant1<FQ, kBounded>(__fmaf_rn(a4.z, v[u].z, b4.z), k, nlev, r, &t, &b, tab);
-        o.w = act_quant1<FQ, kBounded>(__fmaf_rn(a4.w, v[u].w, b4.w), k, nlev, r, &t, &b, tab);
+        float bx, by, bz, bw;
+        o.x = act_quant1<FQ, kBounded>(__fmaf_rn(a4.x, v[u].x, b4.x), k, nlev, r, &t, &bx, tab);
+        o.y = act_quant1<FQ, kBounded>(__fmaf_rn(a4.y, v[u].y, b4.y), k, nlev, r, &t, &by, tab);
+        o.z = act_quant1<FQ, kBounded>(__fmaf_rn(a4.z, v[u].z, b4.z), k, nlev, r, &t, &bz, tab);
+        o.w = act_quant1<FQ, kBounded>(__fmaf_rn(a4.w, v[u].w, b4.w), k, nlev, r, &t, &bw, tab);
+        if (ybins && i < nvec) {       // (host: only without a residual, ADMM formula, index range within int16)
+          if (relu) { bx = fmaxf(bx, 0.f); by = fmaxf(by, 0.f); bz = fmaxf(bz, 0.f); bw = fmaxf(bw, 0.f); }
+          reinterpret_cast<short4*>(ybins)[i] = make_short4((short)bx, (short)by, (short)bz, (short)bw);
+        }
       }
       if (res) { o.x += rv[u].x; o.y += rv[u].y; o.z += rv[u].z; o.w += rv[u].w; }
       if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-      if (i < nvec) y4[i] = o;
+      if (y && i < nvec) y4[i] = o;
       if (mask) {
         // the wave's 64 float4 are the consecutive vec indices of ONE chunk (tile bases and NT are multiples of 64): four
         // wave-wide compares = the chunk's four words, stored by lane 0 (a chunk is written whole or - beyond nvec - not at all)
@@ -584,14 +591,21 @@ int alignq_bnq_fwd(const float* z, int64_t P, int C, int groups, const float* ga
                    int formula, int relu, const float* residual, float* ab, float* save, float* y, void* mask, void* ws,
                    void* stream) {
   return alignq_bnq_fwd_parts(z, P, C, groups, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, bn_eps, k,
-                              act_range, formula, relu, residual, ab, save, y, mask, ws, nullptr, 0, stream);
+                              act_range, formula, relu, residual, ab, save, y, mask, ws, nullptr, 0, nullptr, stream);
 }
 
 int alignq_bnq_fwd_parts(const float* z, int64_t P, int C, int groups, const float* gamma, const float* beta, float* running_mean,
                          float* running_var, int64_t* num_batches_tracked, float momentum, float bn_eps, int k, float act_range,
                          int formula, int relu, const float* residual, float* ab, float* save, float* y, void* mask, void* ws,
-                         const double* conv_part, int conv_parts, void* stream) {
-  if (!z || !ab || !save || !y || (!ws && !conv_part) || P < 2 || bad_groups(groups) || (conv_part && conv_parts < 1)) return ALIGNQ_EINVAL;
+                         const double* conv_part, int conv_parts, void* bins_out, void* stream) {
+  if (!z || !ab || !save || (!y && !bins_out) || (!ws && !conv_part) || P < 2 || bad_groups(groups) || (conv_part && conv_parts < 1))
+    return ALIGNQ_EINVAL;
+  if (bins_out) {      // the int16 level index: ADMM / Office formula, no residual, |index| <= act_range * (2^k - 1) within int16
+    if (formula != ALIGNQ_FORMULA_ADMM || residual || k < 1 || k > 14 || !(fabsf(act_range) * (float)((1 << k) - 1) <= 32767.0f) ||
+        (reinterpret_cast<uintptr_t>(bins_out) & 7))
+      return ALIGNQ_EINVAL;
+  }
+  short* yb = reinterpret_cast<short*>(bins_out);
   if ((reinterpret_cast<uintptr_t>(mask) | reinterpret_cast<uintptr_t>(residual)) & 15) return ALIGNQ_EINVAL;
   unsigned long long* mk = reinterpret_cast<unsigned long long*>(mask);
   if (!((k >= 1 && k <= 16) || k == 32)) return ALIGNQ_EINVAL;
@@ -610,7 +624,7 @@ int alignq_bnq_fwd_parts(const float* z, int64_t P, int C, int groups, const flo
     const dim3 grid(fin_grid(nvec, kUa), 1);
     if (formula == ALIGNQ_FORMULA_ADMM)
       hipLaunchKernelGGL((bnq_apply_fwd_kernel<0, kT, true>), grid, dim3(kT), 0, st, z, (const float*)ab, nvec, C, k, act_range, relu, y, mk,
-                         residual, fin);
+                         residual, fin, yb);
     else
       hipLaunchKernelGGL((bnq_apply_fwd_kernel<1, kT, true>), grid, dim3(kT), 0, st, z, (const float*)ab, nvec, C, k, act_range, relu, y, mk,
                          residual, fin);
@@ -629,7 +643,7 @@ int alignq_bnq_fwd_parts(const float* z, int64_t P, int C, int groups, const flo
                      groups);
   if (formula == ALIGNQ_FORMULA_ADMM)
     BNQ_NT(C, hipLaunchKernelGGL((bnq_apply_fwd_kernel<0, NTV>), dim3(tiles(nvec, kUa, NTV), groups), dim3(NTV), 0, st, z, (const float*)ab, nvec, C, k,
-                       act_range, relu, y, mk, residual));
+                       act_range, relu, y, mk, residual, FinFwd{}, yb));
   else
     BNQ_NT(C, hipLaunchKernelGGL((bnq_apply_fwd_kernel<1, NTV>), dim3(tiles(nvec, kUa, NTV), groups), dim3(NTV), 0, st, z, (const float*)ab, nvec, C, k,
                        act_range, relu, y, mk, residual));

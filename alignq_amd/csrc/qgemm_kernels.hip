@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/alignq.h"
 #include "wgrad_reduce_body.h"
 
@@ -114,8 +116,12 @@ struct QG {
 // index) and the nine taps read them at row offsets dy * W + dx; a lane whose tap falls outside its image reads an all-zero row
 // instead (address select, no branch).  The pixel-side global loads, splits and LDS writes drop by ~9 BM / (BM + 2 W + 2).
 constexpr int kHaloW = 56;        // widest image the halo form takes (LDS is sized for it)
-template <int WN, int TM, int MODE, bool WTR, int KM, bool SCATTER, int OCC>
+// XI (MODE 1 only): the level operand arrives as its int16 index (N2 on the Office path: 2 B per element through the CU's load path
+// instead of 4, no rint on the way to the f16 term).
+template <int WN, int TM, int MODE, bool WTR, int KM, bool SCATTER, int OCC, bool XI = false>
 __global__ __launch_bounds__(256, OCC) void qgemm_kernel(const QG a) {
+  static_assert(!XI || MODE == 1, "only a level operand has an index form");
+  using RA = typename std::conditional<XI, s16x4, f32x4>::type;
   constexpr int WM = 4 / WN, BM = WM * 16 * TM, BN = 64 * WN;
   constexpr int TA = MODE == 0 ? 3 : 1;
   constexpr bool F16 = MODE == 1;
@@ -176,8 +182,19 @@ __global__ __launch_bounds__(256, OCC) void qgemm_kernel(const QG a) {
   // k steps: KM 0: channel chunks; KM 1: (tap, chunk) tap-major; KM 2: (chunk, tap) chunk-major (the halo image serves 9 taps)
   const int KC = a.CA / KB;
   const int nk = (KS3 ? 9 : 1) * KC;
-  f32x4 ra[NA];
+  RA ra[NA];
   s16x8 rw[NB];
+  auto load_a = [&](int64_t off, bool ok) -> RA {
+    RA v;
+    if constexpr (XI) {
+      v = *reinterpret_cast<const s16x4*>(reinterpret_cast<const short*>(a.xa) + (ok ? off : 0));
+      if (!ok) v = (s16x4){0, 0, 0, 0};
+    } else {
+      v = *reinterpret_cast<const f32x4*>(a.xa + (ok ? off : 0));
+      if (!ok) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    return v;
+  };
 
   auto fetch_x = [&](int kt) {          // KM 0 / 1: the step's tile; KM 2: chunk kt's halo image
     if constexpr (HALO) {
@@ -187,8 +204,7 @@ __global__ __launch_bounds__(256, OCC) void qgemm_kernel(const QG a) {
         const int r = rr + RP * i;
         const int f = m_lo - a.Wa - 1 + r;
         const bool ok = r < halo_rows && f >= 0 && f < total_px;
-        ra[i] = *reinterpret_cast<const f32x4*>(a.xa + (ok ? (int64_t)f * a.CA + c0 + 4 * c4 : 0));
-        if (!ok) ra[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        ra[i] = load_a((int64_t)f * a.CA + c0 + 4 * c4, ok);
       }
     } else {
       const int tap = KS3 ? kt / KC : 0, c0 = (KS3 ? kt % KC : kt) * KB;
@@ -197,9 +213,7 @@ __global__ __launch_bounds__(256, OCC) void qgemm_kernel(const QG a) {
       for (int i = 0; i < NA; i++) {
         bool ok = pix[i] >= 0;
         if (KS3) ok = ok && (unsigned)((hw[i] >> 16) + dy) < (unsigned)a.Ha && (unsigned)((hw[i] & 0xffff) + dx) < (unsigned)a.Wa;
-        const int64_t off = ok ? ((int64_t)(pix[i] + dy * a.Wa + dx) * a.CA + c0 + 4 * c4) : 0;
-        ra[i] = *reinterpret_cast<const f32x4*>(a.xa + off);
-        if (!ok) ra[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        ra[i] = load_a((int64_t)(pix[i] + dy * a.Wa + dx) * a.CA + c0 + 4 * c4, ok);
       }
     }
   };
@@ -232,6 +246,9 @@ __global__ __launch_bounds__(256, OCC) void qgemm_kernel(const QG a) {
         *reinterpret_cast<s16x4*>(Xs + o) = h;
         *reinterpret_cast<s16x4*>(Xs + XPL + o) = m;
         *reinterpret_cast<s16x4*>(Xs + 2 * XPL + o) = l;
+      } else if constexpr (XI) {
+        const f16x4 h = {(_Float16)ra[i][0], (_Float16)ra[i][1], (_Float16)ra[i][2], (_Float16)ra[i][3]};      // exact: |index| <= 2048
+        *reinterpret_cast<s16x4*>(Xs + o) = __builtin_bit_cast(s16x4, h);
       } else {
         *reinterpret_cast<s16x4*>(Xs + o) = to_half4<true>(rint4(ra[i], a.xlev));
       }
@@ -399,8 +416,10 @@ struct QW {
   float xlev;                      // TX == 2: x index = rint(x * xlev), the slab is divided by xlev
 };
 
-template <int TC, int TN, int TX, bool GATHER>
+template <int TC, int TN, int TX, bool GATHER, bool XI = false>
 __global__ __launch_bounds__(256, 2) void qgemm_wgrad_kernel(const QW a) {
+  static_assert(!XI || TX == 2, "only a level operand has an index form");
+  using RX = typename std::conditional<XI, s16x4, f32x4>::type;
   constexpr int BC = 32 * TC, BNO = 32 * TN;       // tile: BC input channels x BNO output channels; wave = (16 TC) x (16 TN)
   constexpr int LDC = BC + 16, LDO = BNO + 16;
   constexpr int XPL = WK * LDC, DPL = WK * LDO;
@@ -418,7 +437,8 @@ __global__ __launch_bounds__(256, 2) void qgemm_wgrad_kernel(const QW a) {
   const int m_begin = split * a.per, m_end = (m_begin + a.per < a.M) ? m_begin + a.per : a.M;
   const int dyy = GATHER ? tap / 3 - (a.taps == 9 ? 1 : 0) : 0, dxx = GATHER ? tap % 3 - (a.taps == 9 ? 1 : 0) : 0;
 
-  f32x4 rx[NX], rd[ND];
+  RX rx[NX];
+  f32x4 rd[ND];
   auto fetch = [&](int m0) {
 #pragma unroll
     for (int i = 0; i < NX; i++) {
@@ -433,8 +453,13 @@ __global__ __launch_bounds__(256, 2) void qgemm_wgrad_kernel(const QW a) {
         ok = ok && (unsigned)h < (unsigned)a.Ha && (unsigned)w < (unsigned)a.Wa;
         p = (int64_t)(img * a.Ha + h) * a.Wa + w;
       }
-      rx[i] = *reinterpret_cast<const f32x4*>(a.x + (ok ? p * a.CIN + c0 + 4 * q4 : 0));
-      if (!ok) rx[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if constexpr (XI) {
+        rx[i] = *reinterpret_cast<const s16x4*>(reinterpret_cast<const short*>(a.x) + (ok ? p * a.CIN + c0 + 4 * q4 : 0));
+        if (!ok) rx[i] = (s16x4){0, 0, 0, 0};
+      } else {
+        rx[i] = *reinterpret_cast<const f32x4*>(a.x + (ok ? p * a.CIN + c0 + 4 * q4 : 0));
+        if (!ok) rx[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
     }
 #pragma unroll
     for (int i = 0; i < ND; i++) {
@@ -458,7 +483,8 @@ __global__ __launch_bounds__(256, 2) void qgemm_wgrad_kernel(const QW a) {
         *reinterpret_cast<s16x4*>(Xs + 2 * XPL + o) = l;
       } else {
         s16x4 h, l;
-        split2(rint4(rx[i], a.xlev), h, l);
+        if constexpr (XI) split2((f32x4){(float)rx[i][0], (float)rx[i][1], (float)rx[i][2], (float)rx[i][3]}, h, l);
+        else split2(rint4(rx[i], a.xlev), h, l);
         *reinterpret_cast<s16x4*>(Xs + o) = h;
         *reinterpret_cast<s16x4*>(Xs + XPL + o) = l;
       }
@@ -548,8 +574,10 @@ __global__ __launch_bounds__(256, 2) void qgemm_wgrad_kernel(const QW a) {
 // rows of dy, whatever W is.  Tap (dy, dx) reads x at slot offset dy * W + dx; a pixel whose tap leaves its image reads the
 // all-zero row (ds_read_b64_tr_b16 takes one row address per lane: an address select, no branch).  Nine accumulator sets per wave
 // (32 x 32 of the tile each).  Against the per-tap form above, the staging of x and dy is shared by the nine taps.
-template <int TX>
+template <int TX, bool XI = false>
 __global__ __launch_bounds__(256, TX == 2 ? 2 : 1) void qgemm_wgrad3_kernel(const QW a) {
+  static_assert(!XI || TX == 2, "only a level operand has an index form");
+  using RX = typename std::conditional<XI, s16x4, f32x4>::type;
   constexpr int BC = 64, BNO = 64, LDC = BC + 16;
   constexpr int XR = 2 * kHaloW + 34 + 1;            // ring rows at the widest image + the zero row
   constexpr int XPL = XR * LDC, DPL = WK * LDC;
@@ -569,15 +597,21 @@ __global__ __launch_bounds__(256, TX == 2 ? 2 : 1) void qgemm_wgrad3_kernel(cons
   const int R = 2 * W + 34;                          // ring rows; row R is the zero row
   for (int i = tid; i < TX * (LDC / 4); i += 256)
     *reinterpret_cast<s16x4*>(Xs + (i / (LDC / 4)) * XPL + R * LDC + 4 * (i % (LDC / 4))) = (s16x4){0, 0, 0, 0};
-  f32x4 rx[NX], rd[ND];
+  RX rx[NX];
+  f32x4 rd[ND];
   // x rows [f0, f0 + 32) that lie below f_hi (pixels outside the tensor are zeros)
   auto fetch_x = [&](int f0, int f_hi) {
 #pragma unroll
     for (int i = 0; i < NX; i++) {
       const int idx = tid + 256 * i, f = f0 + idx / (BC / 4), q4 = idx % (BC / 4);
       const bool ok = f < f_hi && f >= 0 && f < a.M;
-      rx[i] = *reinterpret_cast<const f32x4*>(a.x + (ok ? (int64_t)f * a.CIN + c0 + 4 * q4 : 0));
-      if (!ok) rx[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if constexpr (XI) {
+        rx[i] = *reinterpret_cast<const s16x4*>(reinterpret_cast<const short*>(a.x) + (ok ? (int64_t)f * a.CIN + c0 + 4 * q4 : 0));
+        if (!ok) rx[i] = (s16x4){0, 0, 0, 0};
+      } else {
+        rx[i] = *reinterpret_cast<const f32x4*>(a.x + (ok ? (int64_t)f * a.CIN + c0 + 4 * q4 : 0));
+        if (!ok) rx[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
     }
   };
   auto park_x = [&](int f0, int f_hi) {
@@ -594,7 +628,8 @@ __global__ __launch_bounds__(256, TX == 2 ? 2 : 1) void qgemm_wgrad3_kernel(cons
         *reinterpret_cast<s16x4*>(Xs + 2 * XPL + o) = l;
       } else {
         s16x4 h, l;
-        split2(rint4(rx[i], a.xlev), h, l);
+        if constexpr (XI) split2((f32x4){(float)rx[i][0], (float)rx[i][1], (float)rx[i][2], (float)rx[i][3]}, h, l);
+        else split2(rint4(rx[i], a.xlev), h, l);
         *reinterpret_cast<s16x4*>(Xs + o) = h;
         *reinterpret_cast<s16x4*>(Xs + XPL + o) = l;
       }
@@ -757,13 +792,13 @@ bool shape_ok(int B, int H, int W, int CIN, int COUT, int KS, int stride) {
   return true;
 }
 
-template <int WN, int TM, int MODE, bool WTR, int KM, bool SCATTER, int OCC>
+template <int WN, int TM, int MODE, bool WTR, int KM, bool SCATTER, int OCC, bool XI = false>
 int launch_g(QG a, hipStream_t st) {
   constexpr int BM = (4 / WN) * 16 * TM, BN = 64 * WN;
   a.tiles_per_group = (a.Mg + BM - 1) / BM;
   a.n_tiles = a.N / BN;
   const int grid = a.groups * a.tiles_per_group * a.n_tiles;
-  hipLaunchKernelGGL((qgemm_kernel<WN, TM, MODE, WTR, KM, SCATTER, OCC>), dim3(grid), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((qgemm_kernel<WN, TM, MODE, WTR, KM, SCATTER, OCC, XI>), dim3(grid), dim3(256), 0, st, a);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
@@ -787,13 +822,13 @@ inline int pick_tile_conv(int64_t rows, int N, bool halo, bool level) {
   return halo ? pick_tile(rows, N, level, kWantBlocks / 2) : pick_tile(rows, N);
 }
 
-template <int MODE, bool WTR, int KM, bool SCATTER>
+template <int MODE, bool WTR, int KM, bool SCATTER, bool XI = false>
 int launch_g_tiles(const QG& a, hipStream_t st) {
   switch (pick_tile_conv((int64_t)a.Mg * a.groups, a.N, KM == 2, MODE == 1)) {
-    case 0: return launch_g<2, 4, MODE, WTR, KM, SCATTER, 2>(a, st);
-    case 1: return launch_g<2, 2, MODE, WTR, KM, SCATTER, (KM == 2 ? 2 : 3)>(a, st);
-    case 2: return launch_g<1, 2, MODE, WTR, KM, SCATTER, 2>(a, st);
-    default: return launch_g<1, 1, MODE, WTR, KM, SCATTER, (KM == 2 ? 3 : 4)>(a, st);
+    case 0: return launch_g<2, 4, MODE, WTR, KM, SCATTER, 2, XI>(a, st);
+    case 1: return launch_g<2, 2, MODE, WTR, KM, SCATTER, (KM == 2 ? 2 : 3), XI>(a, st);
+    case 2: return launch_g<1, 2, MODE, WTR, KM, SCATTER, 2, XI>(a, st);
+    default: return launch_g<1, 1, MODE, WTR, KM, SCATTER, (KM == 2 ? 3 : 4), XI>(a, st);
   }
 }
 
@@ -845,14 +880,15 @@ int alignq_qconv_pack_weights(int T, const float* const* wt, const int64_t* n, i
   return 0;
 }
 
-int alignq_qconv_fwd(const float* x, const void* w_bins, float* y, int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride,
-                     int w_bit, float x_levels, int groups, double* bn_part, void* stream) {
+int alignq_qconv_fwd(const void* x, const void* w_bins, float* y, int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride,
+                     int w_bit, float x_levels, int x_bin_bytes, int groups, double* bn_part, void* stream) {
   if (!x || !w_bins || !y || w_bit < 1 || w_bit > 8 || groups < 1) return ALIGNQ_EINVAL;
+  if (x_bin_bytes != 0 && (x_bin_bytes != 2 || x_levels == 0.0f)) return ALIGNQ_EINVAL;      // int16 indices of a level tensor, or fp32
   if (!shape_ok(B, H_in, W_in, CIN, COUT, KS, stride) || B % groups) return ALIGNQ_EUNSUPPORTED;
   if (x_levels != 0.0f && !(x_levels >= 1.0f)) return ALIGNQ_EINVAL;
   const int Ho = (H_in - 1) / stride + 1, Wo = (W_in - 1) / stride + 1;
   QG a{};
-  a.xa = x; a.w = (const u16*)w_bins; a.out = y;
+  a.xa = (const float*)x; a.w = (const u16*)w_bins; a.out = y;
   a.Mg = (B / groups) * Ho * Wo; a.groups = groups;
   a.N = COUT; a.CA = CIN; a.KC = CIN / BK;
   a.Hr = Ho; a.Wr = Wo; a.Ha = H_in; a.Wa = W_in; a.S = stride; a.sgn = 1;
@@ -861,6 +897,11 @@ int alignq_qconv_fwd(const float* x, const void* w_bins, float* y, int B, int H_
   a.nlev = (float)((1 << w_bit) - 1); a.xlev = x_levels;
   a.bn_part = bn_part;
   hipStream_t st = (hipStream_t)stream;
+  if (x_bin_bytes == 2) {
+    if (KS == 3 && halo_ok(KS, stride, W_in)) return launch_g_tiles<1, false, 2, false, true>(a, st);
+    if (KS == 3) return launch_g_tiles<1, false, 1, false, true>(a, st);
+    return launch_g_tiles<1, false, 0, false, true>(a, st);
+  }
   if (KS == 3 && halo_ok(KS, stride, W_in))
     return x_levels != 0.0f ? launch_g_tiles<1, false, 2, false>(a, st) : launch_g_tiles<0, false, 2, false>(a, st);
   if (KS == 3) return x_levels != 0.0f ? launch_g_tiles<1, false, 1, false>(a, st) : launch_g_tiles<0, false, 1, false>(a, st);
@@ -917,16 +958,17 @@ size_t alignq_qconv_wgrad_ws_bytes(int B, int H_in, int W_in, int CIN, int COUT,
   return (size_t)splits * (size_t)COUT * KS * KS * CIN * sizeof(float);
 }
 
-int alignq_qconv_wgrad(const float* x, const float* dy, float* dw, void* ws, int B, int H_in, int W_in, int CIN, int COUT, int KS,
-                       int stride, float x_levels, int* n_slabs_out, void* stream) {
+int alignq_qconv_wgrad(const void* x, const float* dy, float* dw, void* ws, int B, int H_in, int W_in, int CIN, int COUT, int KS,
+                       int stride, float x_levels, int x_bin_bytes, int* n_slabs_out, void* stream) {
   if (!x || !dy || !ws || (!dw && !n_slabs_out)) return ALIGNQ_EINVAL;
+  if (x_bin_bytes != 0 && (x_bin_bytes != 2 || x_levels == 0.0f)) return ALIGNQ_EINVAL;
   if (!shape_ok(B, H_in, W_in, CIN, COUT, KS, stride)) return ALIGNQ_EUNSUPPORTED;
   if (x_levels != 0.0f && !(x_levels >= 1.0f)) return ALIGNQ_EINVAL;
   int tc, tn, tiles, splits;
   int64_t M;
   const int halo = wgrad_geometry(B, H_in, W_in, CIN, COUT, KS, stride, &tc, &tn, &tiles, &splits, &M);
   QW a{};
-  a.x = x; a.dy = dy; a.slabs = (float*)ws;
+  a.x = (const float*)x; a.dy = dy; a.slabs = (float*)ws;
   a.M = (int)M;
   int64_t per = (M + splits - 1) / splits;
   per = (per + WK - 1) / WK * WK;
@@ -937,10 +979,13 @@ int alignq_qconv_wgrad(const float* x, const float* dy, float* dw, void* ws, int
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(tiles * splits), blk(256);
   const bool gather = KS == 3 || stride != 1;
-  const bool lev = x_levels != 0.0f;
+  const bool lev = x_levels != 0.0f, xi = x_bin_bytes == 2;
 #define QW_LAUNCH(TC_, TN_)                                                                                              \
   do {                                                                                                                   \
-    if (lev) {                                                                                                           \
+    if (xi) {                                                                                                            \
+      if (gather) hipLaunchKernelGGL((qgemm_wgrad_kernel<TC_, TN_, 2, true, true>), grid, blk, 0, st, a);                 \
+      else hipLaunchKernelGGL((qgemm_wgrad_kernel<TC_, TN_, 2, false, true>), grid, blk, 0, st, a);                       \
+    } else if (lev) {                                                                                                    \
       if (gather) hipLaunchKernelGGL((qgemm_wgrad_kernel<TC_, TN_, 2, true>), grid, blk, 0, st, a);                       \
       else hipLaunchKernelGGL((qgemm_wgrad_kernel<TC_, TN_, 2, false>), grid, blk, 0, st, a);                             \
     } else {                                                                                                             \
@@ -949,7 +994,8 @@ int alignq_qconv_wgrad(const float* x, const float* dy, float* dw, void* ws, int
     }                                                                                                                    \
   } while (0)
   if (halo) {
-    if (lev) hipLaunchKernelGGL((qgemm_wgrad3_kernel<2>), grid, blk, 0, st, a);
+    if (xi) hipLaunchKernelGGL((qgemm_wgrad3_kernel<2, true>), grid, blk, 0, st, a);
+    else if (lev) hipLaunchKernelGGL((qgemm_wgrad3_kernel<2>), grid, blk, 0, st, a);
     else hipLaunchKernelGGL((qgemm_wgrad3_kernel<3>), grid, blk, 0, st, a);
   } else if (tc == 4 && tn == 4) QW_LAUNCH(4, 4);
   else if (tc == 2 && tn == 4) QW_LAUNCH(2, 4);

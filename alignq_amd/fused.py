@@ -637,7 +637,7 @@ class BNQuantReluFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, weight, bias, running_mean, running_var, nbt, momentum, bn_eps, k, act_range, formula, relu, groups=1,
-                residual=None, conv_part=None):
+                residual=None, conv_part=None, pack=False):
         """residual: added to the quantised value before the ReLU in the same pass (the CDF-only block's `out += shortcut;
         relu`); its gradient - the masked upstream gradient - is a second output of the backward's apply pass."""
         z = L.dense_f32(z, "conv output")
@@ -650,7 +650,11 @@ class BNQuantReluFn(torch.autograd.Function):
         P = Bg * H * W
         ab = torch.empty(groups, 2, C, dtype=torch.float32, device=dev)
         save = torch.empty(groups, 2, C, dtype=torch.float32, device=dev)
-        y = torch.empty_like(z)
+        # pack (N2 on the Office path; the caller checked: ADMM formula, no residual, int16 index, f16-exact range): the output is NOT
+        # written as fp32; the kernel stores the ReLU-clamped level index as int16 and the function returns a data-less handle
+        # (packed_handle) that carries it as `._alignq_bins` for consumers that read indices (ops.QConvGemmFn)
+        bins = torch.empty(z.shape, dtype=torch.int16, device=dev, memory_format=torch.channels_last) if pack else None
+        y = None if pack else torch.empty_like(z)
         ws = torch.empty(lib.alignq_bnq_ws_bytes(C, groups), dtype=torch.uint8, device=dev)
         # the ReLU mask the backward needs, one bit per element (round 4): the node keeps 1/32 of a tensor instead of reading the
         # fp32 y twice; y itself belongs to whoever consumes it
@@ -661,8 +665,11 @@ class BNQuantReluFn(torch.autograd.Function):
         L.check(lib.alignq_bnq_fwd_parts(L.ptr(z), P, C, groups, L.ptr(weight), L.ptr(bias), L.ptr(running_mean), L.ptr(running_var),
                                          L.ptr(nbt), float(momentum), float(bn_eps), int(k), float(act_range), int(formula),
                                          int(bool(relu)), L.ptr(residual), L.ptr(ab), L.ptr(save), L.ptr(y), L.ptr(mask), L.ptr(ws),
-                                         L.ptr(cp), cn, L.stream_ptr()),
+                                         L.ptr(cp), cn, L.ptr(bins), L.stream_ptr()),
                 "alignq_bnq_fwd_parts")
+        if pack:
+            y = packed_handle(z.shape, dev)
+            BNQuantReluFn._bins_mailbox = (bins, int(k))
         ctx.save_for_backward(z, (mask if mask is not None else y) if relu else None, ab, save)
         ctx.bitmask = mask is not None
         ctx.has_res = residual is not None
@@ -690,7 +697,9 @@ class BNQuantReluFn(torch.autograd.Function):
                 "alignq_bnq_bwd")
         if ctx.has_res and not relu and ctx.needs_input_grad[13]:
             dres = g
-        return dz, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, dres, None
+        return dz, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, dres, None, None
+
+    _bins_mailbox = None
 
 
 def _bn_nhwc_ok(bn, z, groups=1) -> bool:
@@ -968,9 +977,12 @@ def fork_block_input(x):
     return GradFork.apply(x, tok)
 
 
-def bn_act_relu(bn, act, z, formula, relu=True, groups=1, residual=None):
+def bn_act_relu(bn, act, z, formula, relu=True, groups=1, residual=None, pack=False):
     """[relu](act(bn(z)) [+ residual]) for a quantiser WITHOUT an ADMM term: one fused chain when `bnq_fusable` (training mode,
-    channels-last fp32 CUDA tensor, C = 4 * 2^j <= 2048), else exactly that composition (groups: see BNQuantReluFn)."""
+    channels-last fp32 CUDA tensor, C = 4 * 2^j <= 2048), else exactly that composition (groups: see BNQuantReluFn).
+    pack (N2; folded chain with relu, no residual, ADMM / Office formula, an int16 index that one f16 term holds
+    exactly): `out` is a packed handle (BNQuantReluFn.forward) whose values live in `out._alignq_bins = (int16 indices, a_bit)` -
+    hand it to a Conv2d_Q only (anything else: fused.materialize)."""
     from . import config
     res_ok = residual is None or (residual.shape == z.shape and residual.is_cuda and residual.dtype == torch.float32)
     if not (bnq_fusable(bn, act, z, groups) and res_ok):
@@ -983,8 +995,16 @@ def bn_act_relu(bn, act, z, formula, relu=True, groups=1, residual=None):
             return one(z, residual)
         rs = _slices(residual, groups) if residual is not None else [None] * groups
         return torch.cat([one(zz, rr) for zz, rr in zip(_slices(z, groups), rs)], 0)
+    pack = bool(pack and relu and residual is None and formula == L.FORMULA_ADMM and 1 <= act.a_bit <= 14
+                and L.load().alignq_bin_bytes(int(act.a_bit), float(config.args.act_range), int(formula)) == 2
+                and float(config.args.act_range) * (2 ** int(act.a_bit) - 1) <= 2048.0
+                and float(config.args.act_range) == int(config.args.act_range))
+    BNQuantReluFn._bins_mailbox = None
     y = BNQuantReluFn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum,
-                            bn.eps, act.a_bit, config.args.act_range, formula, relu, groups, residual, conv_partials(z, groups))
+                            bn.eps, act.a_bit, config.args.act_range, formula, relu, groups, residual, conv_partials(z, groups), pack)
+    if pack:
+        y._alignq_bins = BNQuantReluFn._bins_mailbox
+        BNQuantReluFn._bins_mailbox = None
     if residual is None:
         tag_levels(y, act.a_bit, config.args.act_range, formula)
     return y

@@ -930,15 +930,34 @@ def pack_filter_bins(weights, w_bit):
     return list(zip(bf, hf))
 
 
+def qconv_gemm_shape_supported(shape, w, stride, padding, dilation, groups, bias, w_bit) -> bool:
+    """qconv_gemm_supported for an input given by its SHAPE only (a packed handle, fused.packed_handle: the values live in int16
+    level indices laid out channels-last)."""
+    if bias is not None or groups != 1 or not (1 <= w_bit <= 8) or tuple(dilation) != (1, 1) or len(shape) != 4:
+        return False
+    if not (w.dtype == torch.float32 and w.is_cuda):
+        return False
+    B, CIN, H, W = shape
+    COUT, ks = w.shape[0], w.shape[2]
+    if w.shape[1] != CIN or w.shape[3] != ks or ks not in (1, 3) or tuple(padding) != ((ks - 1) // 2,) * 2:
+        return False
+    if stride[0] != stride[1] or stride[0] not in (1, 2):
+        return False
+    if not (ks == 1 or w.is_contiguous(memory_format=torch.channels_last)):
+        return False
+    return bool(L.load().alignq_qconv_supported(B, H, W, CIN, COUT, ks, int(stride[0])))
+
+
 class QConvGemmFn(torch.autograd.Function):
     """F.conv2d(input, weight_q, None, stride, padding) of Conv2d_Q.forward (cdf_alignment_admm/dann_office/model/quantization.py:
     164-181) at the ResNet-50 shapes on alignq_qconv_fwd / _dgrad / _wgrad (csrc/qgemm_kernels.hip): exact products on the bf16 /
     f16 matrix cores.  x_levels: see level_count (0.0: a general fp32 input).  bins: (bf16, f16) bit patterns of the filter's
-    integer bins from pack_filter_bins (None: packed here, one small launch).  The filter gradient's slab reduction is deferred to
-    fused.DeferredWgrads when such a context is active."""
+    integer bins from pack_filter_bins (None: packed here, one small launch).  xbins (N2): x is only a HANDLE (fused.packed_handle:
+    shape and autograd edge); the activation is read from its int16 level indices `xbins`, forward and filter gradient.  The filter
+    gradient's slab reduction is deferred to fused.DeferredWgrads when such a context is active."""
 
     @staticmethod
-    def forward(ctx, x, w, w_bit, stride, x_levels=0.0, groups=1, bn_stats=False, bins=None):
+    def forward(ctx, x, w, w_bit, stride, x_levels=0.0, groups=1, bn_stats=False, bins=None, xbins=None):
         B, CIN, H, W = x.shape
         COUT, ks = w.shape[0], w.shape[2]
         s = int(stride)
@@ -946,26 +965,30 @@ class QConvGemmFn(torch.autograd.Function):
         lib = L.load()
         if bins is None:
             bins = pack_filter_bins([w], w_bit)[0]
-        y = torch.empty((B, COUT, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        if xbins is not None and not (x_levels and xbins.dtype == torch.int16 and tuple(xbins.shape) == tuple(x.shape)
+                                      and xbins.is_contiguous(memory_format=torch.channels_last)):
+            raise RuntimeError("QConvGemmFn: xbins must be the channels-last int16 level indices of a level tensor of x's shape")
+        y = torch.empty((B, COUT, Ho, Wo), dtype=torch.float32, device=w.device, memory_format=torch.channels_last)
         part = None
         if bn_stats:
             n_parts = lib.alignq_qconv_bn_parts(B, H, W, CIN, COUT, ks, s, int(groups), float(x_levels))
-            part = torch.empty(int(groups), n_parts, COUT, 2, dtype=torch.float64, device=x.device)
+            part = torch.empty(int(groups), n_parts, COUT, 2, dtype=torch.float64, device=w.device)
             QConvGemmFn._mailbox = (part, n_parts)
-        L.check(lib.alignq_qconv_fwd(L.ptr(x), L.ptr(bins[1] if x_levels else bins[0]), L.ptr(y), B, H, W, CIN, COUT, ks, s, int(w_bit),
-                                     float(x_levels), int(groups if bn_stats else 1), L.ptr(part), L.stream_ptr()), "alignq_qconv_fwd")
-        ctx.save_for_backward(x, w, bins[0])
-        ctx.cfg = (int(w_bit), s, float(x_levels), ks)
+        L.check(lib.alignq_qconv_fwd(L.ptr(xbins if xbins is not None else x), L.ptr(bins[1] if x_levels else bins[0]), L.ptr(y), B, H, W,
+                                     CIN, COUT, ks, s, int(w_bit), float(x_levels), 2 if xbins is not None else 0,
+                                     int(groups if bn_stats else 1), L.ptr(part), L.stream_ptr()), "alignq_qconv_fwd")
+        ctx.save_for_backward(xbins if xbins is not None else x, w, bins[0])
+        ctx.cfg = (int(w_bit), s, float(x_levels), ks, xbins is not None, (B, CIN, H, W))
         return y
 
     _mailbox = None
 
     @staticmethod
-    def apply_with_stats(x, w, w_bit, stride, x_levels=0.0, groups=1, bins=None):
+    def apply_with_stats(x, w, w_bit, stride, x_levels=0.0, groups=1, bins=None, xbins=None):
         """apply(...) that also leaves the batch-norm partial statistics of the output on it: y._alignq_bnq_part =
         (double tensor [groups, parts, C_out, 2], parts, groups) for fused.bn_act_relu / bn_only / bn_site_res_relu."""
         QConvGemmFn._mailbox = None
-        y = QConvGemmFn.apply(x, w, w_bit, stride, x_levels, groups, True, bins)
+        y = QConvGemmFn.apply(x, w, w_bit, stride, x_levels, groups, True, bins, xbins)
         if QConvGemmFn._mailbox is not None:
             y._alignq_bnq_part = QConvGemmFn._mailbox + (int(groups),)
             QConvGemmFn._mailbox = None
@@ -974,8 +997,7 @@ class QConvGemmFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, w, wb = ctx.saved_tensors
-        w_bit, s, x_levels, ks = ctx.cfg
-        B, CIN, H, W = x.shape
+        w_bit, s, x_levels, ks, packed, (B, CIN, H, W) = ctx.cfg
         COUT = w.shape[0]
         lib = L.load()
         cl = torch.channels_last
@@ -984,25 +1006,25 @@ class QConvGemmFn(torch.autograd.Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             if ks == 3 and s != 1:      # the three stride-2 3x3 layers: MIOpen's data gradient (not among alignq_qconv_dgrad's shapes)
-                dx = torch.ops.aten.convolution_backward(gy, x, w, None, (s, s), (1, 1), (1, 1), False, (0, 0), 1,
-                                                         (True, False, False))[0]
+                dx = torch.nn.grad.conv2d_input((B, CIN, H, W), w, gy, stride=s, padding=1)
             else:
-                dx = torch.empty((B, CIN, H, W), dtype=torch.float32, device=x.device, memory_format=cl)
+                dx = torch.empty((B, CIN, H, W), dtype=torch.float32, device=w.device, memory_format=cl)
                 L.check(lib.alignq_qconv_dgrad(L.ptr(gy), L.ptr(wb), L.ptr(dx), B, H, W, CIN, COUT, ks, s, w_bit, L.stream_ptr()),
                         "alignq_qconv_dgrad")
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
-            ws = _ws(lib.alignq_qconv_wgrad_ws_bytes(B, H, W, CIN, COUT, ks, s), x.device)
+            ws = _ws(lib.alignq_qconv_wgrad_ws_bytes(B, H, W, CIN, COUT, ks, s), w.device)
+            xb = 2 if packed else 0
             pending = fused.active_wgrads()
             if pending is not None:
                 ns = ctypes.c_int(0)
-                L.check(lib.alignq_qconv_wgrad(L.ptr(x), L.ptr(gy), None, L.ptr(ws), B, H, W, CIN, COUT, ks, s, x_levels,
+                L.check(lib.alignq_qconv_wgrad(L.ptr(x), L.ptr(gy), None, L.ptr(ws), B, H, W, CIN, COUT, ks, s, x_levels, xb,
                                                ctypes.byref(ns), L.stream_ptr()), "alignq_qconv_wgrad")
                 pending.add(ws, dw, ns.value, COUT * ks * ks * CIN)
             else:
-                L.check(lib.alignq_qconv_wgrad(L.ptr(x), L.ptr(gy), L.ptr(dw), L.ptr(ws), B, H, W, CIN, COUT, ks, s, x_levels, None,
+                L.check(lib.alignq_qconv_wgrad(L.ptr(x), L.ptr(gy), L.ptr(dw), L.ptr(ws), B, H, W, CIN, COUT, ks, s, x_levels, xb, None,
                                                L.stream_ptr()), "alignq_qconv_wgrad")
-        return dx, dw, None, None, None, None, None, None
+        return dx, dw, None, None, None, None, None, None, None
 
 
 def qconv_stem_supported(x, w, stride, padding, dilation, groups, bias, w_bit) -> bool:

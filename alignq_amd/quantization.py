@@ -191,12 +191,12 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
             """relu(self(x)) in one launch each way (not part of the reference's interface: an opt-in for the caller)."""
             return _plain_act_relu(x, self.a_bit, self.stage)
 
-        def forward_bn_relu(self, bn, z, groups=1):
+        def forward_bn_relu(self, bn, z, groups=1, pack=False):
             """relu(self(bn(z))) with the training-mode batch-norm folded into the quantiser (SURVEY.md §8f-N1 on the Office
             path; not part of the reference's interface: an opt-in for the caller, alignq_amd.fused.bn_act_relu).  groups:
             z holds that many batch slices which the reference sends through the module one after the other."""
             from . import fused
-            return fused.bn_act_relu(bn, self, z, formula, relu=True, groups=groups)
+            return fused.bn_act_relu(bn, self, z, formula, relu=True, groups=groups, pack=pack)
 
         def forward_packed(self, x, relu=False):
             """([relu](self(x)), bins): the quantised activation both as fp32 and as its narrow integer level index
@@ -264,6 +264,17 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
                             and tuple(weight_q.shape) == (C_, C_, 3, 3) and (C_, W_) in ((16, 32), (32, 16), (64, 8)) and H_ % 8 == 0
                             and 1 <= self.quantize_fn.w_bit <= 8 and weight_q.is_contiguous(memory_format=torch.channels_last)):
                         return ops.QConv3x3Fn.apply_with_stats(input, weight_q, self.quantize_fn.w_bit, False, bins, a_bit)
+                    if (getattr(self, "use_qconv", False) and bins.dtype == torch.int16 and ops.level_count(input)
+                            and ops.qconv_gemm_shape_supported(tuple(input.shape), weight_q, self.stride, self.padding, self.dilation,
+                                                               self.groups, self.bias, self.quantize_fn.w_bit)):
+                        # the ResNet-50 shapes: the GEMM kernels read the int16 indices directly (forward and filter gradient)
+                        fb = self.quantize_fn.take_bins(weight_q)
+                        if getattr(self, "emit_bn_stats", False):
+                            from . import fused
+                            return ops.QConvGemmFn.apply_with_stats(input, weight_q, self.quantize_fn.w_bit, self.stride[0],
+                                                                    ops.level_count(input), fused.conv_groups(), fb, bins)
+                        return ops.QConvGemmFn.apply(input, weight_q, self.quantize_fn.w_bit, self.stride[0], ops.level_count(input),
+                                                     1, False, fb, bins)
                     from . import fused
                     input = fused.materialize(input)
                 # opt-in (TrainStep(channels_last=True) sets use_qconv): the convolutions on the matrix cores

@@ -58,8 +58,9 @@ class Bottleneck(nn.Module):
             from . import fused
             x, x_short = fused.fork_block_input(x)
             identity = x_short
-            out = self.act_q1.forward_bn_relu(self.bn1, self.conv1(x), groups)
-            out = self.act_q2.forward_bn_relu(self.bn2, self.conv2(out), groups)
+            pack = getattr(self, "pack_bins", False)        # N2: conv2 / conv3 read int16 level indices instead of fp32 values
+            out = self.act_q1.forward_bn_relu(self.bn1, self.conv1(x), groups, pack)
+            out = self.act_q2.forward_bn_relu(self.bn2, self.conv2(out), groups, pack)
             if self.downsample is not None:
                 identity = fused.bn_only(self.downsample[1], self.downsample[0](x_short), groups)
             out, loss = self.act_q3.forward_bn_res_relu(self.bn3, self.conv3(out), identity, groups, loss_vec=loss_vec)
@@ -69,8 +70,9 @@ class Bottleneck(nn.Module):
             from . import fused
             x, x_short = fused.fork_block_input(x)
             identity = x_short
-            out = self.act_q1.forward_bn_relu(self.bn1, self.conv1(x))
-            out = self.act_q2.forward_bn_relu(self.bn2, self.conv2(out))
+            pack = getattr(self, "pack_bins", False)
+            out = self.act_q1.forward_bn_relu(self.bn1, self.conv1(x), 1, pack)
+            out = self.act_q2.forward_bn_relu(self.bn2, self.conv2(out), 1, pack)
         elif getattr(self, "fuse_relu", False):     # opt-in: quantiser + ReLU in one launch each way
             out = self.act_q1.forward_relu(self.bn1(self.conv1(x)))
             out = self.act_q2.forward_relu(self.bn2(self.conv2(out)))

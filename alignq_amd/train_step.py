@@ -342,7 +342,7 @@ class OfficeTrainStep:
     SGD-stepped first and then overwritten by the closed form, exactly like the reference."""
 
     def __init__(self, model, lr=0.04, momentum=0.9, weight_decay=5e-4, alpha=0.5, channels_last=False, fuse_relu=True,
-                 grad_hook=None, fuse_bn=True, dual=None, qconv=True):
+                 grad_hook=None, fuse_bn=True, dual=None, qconv=True, pack_bins=True):
         """grad_hook: the data-parallel all-reduce (alignq_amd.dp.attach_office -> BucketedGradAllReduce): begin() right
         before backward, its buckets' collectives start from autograd hooks while the backward runs, finish() before the
         optimizer steps.
@@ -368,6 +368,12 @@ class OfficeTrainStep:
                 # per-tile statistics instead of making a pass of its own over the output
                 mod.emit_bn_stats = bool(self.qconv and fuse_bn and fuse_relu)
         self._wgrads = DeferredWgrads() if self.qconv else None
+        # pack_bins (N2; with qconv and fuse_bn): relu(act_q1(bn1(.))) and relu(act_q2(bn2(.))) of every bottleneck feed
+        # conv2 / conv3 only - they are stored as int16 level indices (no fp32 copy): the quantiser writes, the convolution's
+        # forward and filter gradient read 2 B per element instead of 4
+        for mod in model.modules():
+            if hasattr(mod, "act_q1") and hasattr(mod, "act_q2") and hasattr(mod, "act_q3"):
+                mod.pack_bins = bool(pack_bins and self.qconv and fuse_bn and fuse_relu)
         for mod in model.modules():
             if hasattr(mod, "act_q0") or (hasattr(mod, "act_q1") and hasattr(mod, "act_q2") and hasattr(mod, "act_q3")):
                 mod.fuse_relu = bool(fuse_relu)

@@ -357,8 +357,10 @@ int alignq_qconv_pack_weights(int T, const float* const* wt, const int64_t* n, i
                               void* stream);
 /* w_bins: the filter's bins [COUT, KS, KS, CIN] from alignq_qconv_pack_weights - the bf16 patterns when x_levels == 0, the f16
  * patterns when x_levels > 0.                                                                                                    */
-int alignq_qconv_fwd(const float* x, const void* w_bins, float* y, int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride,
-                     int w_bit, float x_levels, int groups, double* bn_part, void* stream);
+int alignq_qconv_fwd(const void* x, const void* w_bins, float* y, int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride,
+                     int w_bit, float x_levels, int x_bin_bytes, int groups, double* bn_part, void* stream);
+/* x_bin_bytes = 2 (N2; needs x_levels > 0): x holds the level tensor's int16 indices (alignq_bnq_fwd_parts bins_out)
+ * instead of fp32 values; 0: fp32.                                                                                              */
 /* data gradient dx [B, H_in, W_in, CIN] from dy [B, H_out, W_out, COUT] and the filter's bf16 bins (every element of dx is written;
  * the 3x3 stride-2 form is ALIGNQ_EUNSUPPORTED: the caller keeps its own path for those three layers)                            */
 int alignq_qconv_dgrad(const float* dy, const void* w_bins, float* dx, int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride,
@@ -367,8 +369,8 @@ int alignq_qconv_dgrad(const float* dy, const void* w_bins, float* dx, int B, in
  * summed in slab order - by this call (dw != NULL, n_slabs_out == NULL) or later by alignq_conv3x3_wgrad_reduce_multi
  * (n_slabs_out receives the slab count; n_elem = COUT * KS * KS * CIN).  x_levels as in alignq_qconv_fwd.                       */
 size_t alignq_qconv_wgrad_ws_bytes(int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride);
-int alignq_qconv_wgrad(const float* x, const float* dy, float* dw, void* ws, int B, int H_in, int W_in, int CIN, int COUT, int KS,
-                       int stride, float x_levels, int* n_slabs_out, void* stream);
+int alignq_qconv_wgrad(const void* x, const float* dy, float* dw, void* ws, int B, int H_in, int W_in, int CIN, int COUT, int KS,
+                       int stride, float x_levels, int x_bin_bytes, int* n_slabs_out, void* stream);
 
 /* Data gradient AND filter-gradient partial sums of one convolution in a single launch (workgroup roles by block index; the
  * two are independent and fill the chip together).  The slabs left in ws are finished by alignq_conv3x3_wgrad_reduce_multi.
@@ -589,11 +591,14 @@ int alignq_bnq_fwd(const float* z, int64_t P, int C, int groups, const float* ga
                    float* running_var, int64_t* num_batches_tracked, float momentum, float bn_eps, int k, float act_range,
                    int formula, int relu, const float* residual, float* ab, float* save, float* y, void* mask, void* ws,
                    void* stream);
-/* alignq_bnq_fwd with the statistics pass replaced by a convolution's partial sums (see alignq_bnq_stats_parts)                  */
+/* alignq_bnq_fwd with the statistics pass replaced by a convolution's partial sums (see alignq_bnq_stats_parts), and - N2 on the
+ * Office path - bins_out (or NULL): the quantised value's integer level index round(t n), ReLU-clamped when relu, as
+ * int16 in z's layout (ADMM / Office formula, no residual, act_range * (2^k - 1) <= 32767); y may then be NULL: a consumer that
+ * reads indices (alignq_qconv_fwd / _wgrad with x_bin_bytes = 2) needs no fp32 copy.  value = index / (2^k - 1) exactly as y.   */
 int alignq_bnq_fwd_parts(const float* z, int64_t P, int C, int groups, const float* gamma, const float* beta, float* running_mean,
                          float* running_var, int64_t* num_batches_tracked, float momentum, float bn_eps, int k, float act_range,
                          int formula, int relu, const float* residual, float* ab, float* save, float* y, void* mask, void* ws,
-                         const double* conv_part, int conv_parts, void* stream);
+                         const double* conv_part, int conv_parts, void* bins_out, void* stream);
 int alignq_bnq_bwd(const float* g, const float* z, const float* y, const void* mask, const float* ab, const float* save, int64_t P,
                    int C, int groups, float act_range, int relu, float* dz, float* dres, float* dgamma, float* dbeta, void* ws,
                    void* stream);

@@ -162,7 +162,77 @@ def test_qconv_rejects_what_it_does_not_take(dev):
     assert lib.alignq_qconv_supported(2, 8, 8, 64, 64, 3, 3) == 0
     x = torch.zeros(2, 8, 8, 64, device=dev)
     assert lib.alignq_qconv_dgrad(L.ptr(x), L.ptr(x), L.ptr(x), 2, 8, 8, 64, 64, 3, 2, 8, None) == -2       # ALIGNQ_EUNSUPPORTED
-    assert lib.alignq_qconv_fwd(L.ptr(x), L.ptr(x), L.ptr(x), 2, 8, 8, 64, 64, 1, 1, 9, 0.0, 1, None, None) == -1    # w_bit
+    assert lib.alignq_qconv_fwd(L.ptr(x), L.ptr(x), L.ptr(x), 2, 8, 8, 64, 64, 1, 1, 9, 0.0, 0, 1, None, None) == -1    # w_bit
+    assert lib.alignq_qconv_fwd(L.ptr(x), L.ptr(x), L.ptr(x), 2, 8, 8, 64, 64, 1, 1, 8, 0.0, 2, 1, None, None) == -1    # indices need x_levels
+
+
+@pytest.mark.parametrize("cin,cout,H,ks,stride", [(64, 256, 56, 1, 1), (128, 128, 28, 3, 1), (128, 128, 56, 3, 2), (512, 2048, 7, 1, 1),
+                                                  (256, 256, 14, 3, 1)])
+def test_qconv_reads_int16_level_indices_bit_for_bit(dev, cin, cout, H, ks, stride):
+    """N2 on the Office path: the level operand as int16 indices (x_bin_bytes = 2) gives the SAME bits as the fp32 level tensor
+    (the f16 operand terms are the same integers) - forward, filter gradient - and the data gradient does not depend on it."""
+    from alignq_amd import fused, ops
+    B = 5
+    wq = _wq(cout, cin, ks, 8, dev, 21)
+    x = _levels((B, cin, H, H), 255.0, 2, dev, 22)
+    xb = torch.round(x * 255.0).to(torch.int16).contiguous(memory_format=CL)
+    gy = None
+    res = []
+    for packed in (False, True):
+        w = wq.clone(memory_format=CL).requires_grad_(True)
+        if packed:
+            xin = fused.packed_handle(x.shape, dev).requires_grad_(True)
+            y = ops.QConvGemmFn.apply(xin, w, 8, stride, 255.0, 1, False, None, xb)
+        else:
+            xin = x.clone(memory_format=CL).requires_grad_(True)
+            y = ops.QConvGemmFn.apply(xin, w, 8, stride, 255.0)
+        if gy is None:
+            gy = (torch.randn(y.shape, generator=torch.Generator().manual_seed(23)) * 1e-3).to(dev).contiguous(memory_format=CL)
+        y.backward(gy)
+        res.append((y.detach(), w.grad.clone(), xin.grad.clone()))
+    for u, v in zip(*res):
+        assert torch.equal(u, v)
+
+
+def test_folded_quantiser_emits_int16_indices_and_a_handle(dev):
+    """fused.bn_act_relu(pack=True): the int16 indices are round(y * n) of the fp32 form bit for bit, the handle carries them and the
+    level tag, fused.materialize gives the fp32 tensor back, and the backward (through the one-bit mask) is unchanged."""
+    from alignq_amd import config, fused, office as Q
+    saved = config.args.abitW
+    config.args.abitW = 8
+    try:
+        B, C, H = 6, 128, 14
+        z0 = (torch.randn(B, C, H, H, generator=torch.Generator().manual_seed(31)) * 1.3 + 0.2).to(dev).contiguous(memory_format=CL)
+        g0 = torch.randn(B, C, H, H, generator=torch.Generator().manual_seed(32)).to(dev).contiguous(memory_format=CL)
+        outs = []
+        for pack in (False, True):
+            torch.manual_seed(0)
+            bn = torch.nn.BatchNorm2d(C).to(dev).train()
+            with torch.no_grad():
+                bn.weight.uniform_(0.5, 1.5)
+                bn.bias.normal_(0, 0.2)
+            act = Q.activation_quantize_fn(a_bit=8, stage="aligned")
+            z = z0.clone(memory_format=CL).requires_grad_(True)
+            y = fused.bn_act_relu(bn, act, z, 0, True, 2, None, pack)
+            assert ops_level(y) == 255.0
+            if pack:
+                bins, a_bit = y._alignq_bins
+                assert bins.dtype == torch.int16 and a_bit == 8 and y.stride() == (0, 0, 0, 0)
+                val = fused.materialize(y)
+            else:
+                bins, val = None, y
+            val.backward(g0)
+            outs.append((val.detach(), bins, z.grad.clone(), bn.weight.grad.clone()))
+        (y0, _, dz0, dg0), (y1, b1, dz1, dg1) = outs
+        assert torch.equal(y0, y1) and torch.equal(dz0, dz1) and torch.equal(dg0, dg1)
+        assert torch.equal(b1.float(), torch.round(y0 * 255.0)) and int(b1.min()) >= 0
+    finally:
+        config.args.abitW = saved
+
+
+def ops_level(t):
+    from alignq_amd import ops
+    return ops.level_count(t)
 
 
 def test_filter_bins_pack_is_exact(dev):

@@ -125,6 +125,13 @@ def test_config5_full_size_step(dev, monkeypatch):
             assert s.qconv is kw["qconv"]
             outs[name] = npy(s(xs * noise[0] if pert else xs, ys, xt * noise[1] if pert else xt)[0])
             del s, m
+        # N2: with the int16 level indices between the quantisers and conv2 / conv3 (the default) and with fp32 values there, the
+        # forward is the same computation on the same integers: identical logits
+        m = make()
+        s_ = OfficeTrainStep(m, lr=0.004, channels_last=True, pack_bins=False)
+        assert not any(getattr(b, "pack_bins", False) for b in s_.blocks)
+        assert np.array_equal(npy(s_(xs, ys, xt)[0]), outs["gemm"])
+        del s_, m
         d = np.abs(outs["gemm"] - outs["miopen"])
         d_ref = np.abs(outs["miopen_perturbed"] - outs["miopen"])
         scale = float(np.abs(outs["miopen"]).max())

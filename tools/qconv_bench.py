@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--B", type=int, default=56)
     ap.add_argument("--only", default="")
     ap.add_argument("--no-ref", action="store_true")
+    ap.add_argument("--i16", action="store_true", help="level inputs as int16 indices (N2) instead of fp32 values")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.backends.cudnn.benchmark = True
@@ -76,7 +77,9 @@ def main():
         wbf, whf = torch.empty_like(w, dtype=torch.int16), torch.empty_like(w, dtype=torch.int16)
         L.check(lib.alignq_qconv_pack_weights(1, L.ptr_array([w]), L.i64_array([w.numel()]), 8, L.ptr_array([wbf]), L.ptr_array([whf]), st), "pack")
         wfw = whf if lev else wbf
-        f = lambda i: L.check(lib.alignq_qconv_fwd(p(xs[i]), p(wfw), p(ys[i]), B, H, H, cin, cout, ks, s, 8, xl, 1, None, st), "fwd")
+        xb = 2 if (lev and a.i16) else 0
+        xin = [torch.round(x * 255.0).to(torch.int16).contiguous(memory_format=CL) for x in xs] if xb else xs
+        f = lambda i: L.check(lib.alignq_qconv_fwd(p(xin[i]), p(wfw), p(ys[i]), B, H, H, cin, cout, ks, s, 8, xl, xb, 1, None, st), "fwd")
         t_f = time_rot(f, R)
         if ks == 3 and s == 2:
             t_d = float("nan")
@@ -85,9 +88,9 @@ def main():
             t_d = time_rot(d, R)
         import ctypes
         ns = ctypes.c_int(0)
-        g = lambda i: L.check(lib.alignq_qconv_wgrad(p(xs[i]), p(gys[i]), None, p(ws), B, H, H, cin, cout, ks, s, xl, ctypes.byref(ns), st), "wgrad")
+        g = lambda i: L.check(lib.alignq_qconv_wgrad(p(xin[i]), p(gys[i]), None, p(ws), B, H, H, cin, cout, ks, s, xl, xb, ctypes.byref(ns), st), "wgrad")
         t_w = time_rot(g, R)
-        g2 = lambda i: L.check(lib.alignq_qconv_wgrad(p(xs[i]), p(gys[i]), p(dw), p(ws), B, H, H, cin, cout, ks, s, xl, None, st), "wgrad")
+        g2 = lambda i: L.check(lib.alignq_qconv_wgrad(p(xin[i]), p(gys[i]), p(dw), p(ws), B, H, H, cin, cout, ks, s, xl, xb, None, st), "wgrad")
         t_w2 = time_rot(g2, R)
         r_f = r_d = r_w = float("nan")
         if not a.no_ref:
