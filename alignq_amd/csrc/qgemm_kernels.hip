@@ -127,7 +127,13 @@ __global__ __launch_bounds__(256, OCC) void qgemm_kernel(const QG a) {
   constexpr bool F16 = MODE == 1;
   constexpr bool KS3 = KM != 0, HALO = KM == 2;
   constexpr int KB = (HALO && MODE == 0) ? 32 : BK;      // k per step (the three-plane halo image would not fit at 64)
-  constexpr int LDX = KB + 8;                            // halfwords per row of a direct image (80- / 144-byte rows: conflict-free b128)
+  // halfwords per row of a direct image.  ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32):
+  // sixteen different rows, half of them 16 B further along k.  Rows of 96 / 160 B (32 B of padding) put those sixteen 16-byte
+  // pieces on sixteen different slots of the 256-B bank row; 80 / 144 B rows (16 B of padding) cost two extra cycles per read.
+  // The 128x128 three-plane tile keeps 144 B (160 B rows would not leave room for two workgroups per CU).
+  // The data gradient (WTR) reads the pixel side with two ds_read_b64 per fragment (see the k order below): 80 / 144 B rows are the
+  // conflict-free ones for those.
+  constexpr int LDX = KB + ((WTR || (TA == 3 && BM == 128 && BN == 128)) ? 8 : 16);
   constexpr int XR = HALO ? BM + 2 * kHaloW + 3 : BM;    // rows of the pixel-side image (+ the zero row)
   constexpr int NA = (XR * (KB / 4) + 255) / 256;        // float4 per thread of the pixel-side tile
   constexpr int NB = (BN * KB / 8) / 256;                // 16-byte pieces (8 bins) per thread of the filter tile
@@ -186,12 +192,14 @@ __global__ __launch_bounds__(256, OCC) void qgemm_kernel(const QG a) {
   s16x8 rw[NB];
   auto load_a = [&](int64_t off, bool ok) -> RA {
     RA v;
+    // (1x1: a row beyond the group only feeds its own output pixel, which is neither stored nor counted in the statistics - its
+    // loads stay in bounds by the clamped address and need no zeroing; a 3x3 tap outside the image must contribute zeros)
     if constexpr (XI) {
       v = *reinterpret_cast<const s16x4*>(reinterpret_cast<const short*>(a.xa) + (ok ? off : 0));
-      if (!ok) v = (s16x4){0, 0, 0, 0};
+      if (KS3 && !ok) v = (s16x4){0, 0, 0, 0};
     } else {
       v = *reinterpret_cast<const f32x4*>(a.xa + (ok ? off : 0));
-      if (!ok) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (KS3 && !ok) v = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     return v;
   };
@@ -320,16 +328,21 @@ __global__ __launch_bounds__(256, OCC) void qgemm_kernel(const QG a) {
         if (!WTR) {
           wf[tn] = *reinterpret_cast<const s16x8*>(Ws + (wn * 64 + tn * 16 + fr) * LDX + ks * 32 + 8 * fg);
         } else {
-          const u16* p = Ws + (ks * 32 + 8 * fg + fq) * LDN + wn * 64 + tn * 16 + fc;
-          wf[tn] = join8(tr_read(p), tr_read(p + 4 * LDN));
+          // k order of the transposed filter image: lane group g takes rows {4g .. 4g+3} and {16 + 4g .. 16 + 4g + 3} of the
+          // 32-row substep (the contraction index is a dummy; the pixel side below uses the same order), so that the 32 lanes of one
+          // LDS cycle touch 8 consecutive rows = all 64 banks (rows 8 apart share banks at these row lengths)
+          const u16* p = Ws + (ks * 32 + 4 * fg + fq) * LDN + wn * 64 + tn * 16 + fc;
+          wf[tn] = join8(tr_read(p), tr_read(p + 16 * LDN));
         }
       }
 #pragma unroll
       for (int tm = 0; tm < TM; tm++) {
-        const u16* p = Xs + xrow[tm] * LDX + ks * 32 + 8 * fg;
+        const u16* p = Xs + xrow[tm] * LDX + ks * 32 + (WTR ? 4 : 8) * fg;
 #pragma unroll
         for (int t = TA - 1; t >= 0; t--) {           // smallest term first
-          const s16x8 xf = *reinterpret_cast<const s16x8*>(p + t * XPL);
+          s16x8 xf;
+          if constexpr (WTR) xf = join8(*reinterpret_cast<const s16x4*>(p + t * XPL), *reinterpret_cast<const s16x4*>(p + t * XPL + 16));
+          else xf = *reinterpret_cast<const s16x8*>(p + t * XPL);
 #pragma unroll
           for (int tn = 0; tn < 4; tn++) acc[tn][tm] = mfma16<F16>(wf[tn], xf, acc[tn][tm]);
         }
@@ -828,7 +841,7 @@ int launch_g_tiles(const QG& a, hipStream_t st) {
     case 0: return launch_g<2, 4, MODE, WTR, KM, SCATTER, 2, XI>(a, st);
     case 1: return launch_g<2, 2, MODE, WTR, KM, SCATTER, (KM == 2 ? 2 : 3), XI>(a, st);
     case 2: return launch_g<1, 2, MODE, WTR, KM, SCATTER, 2, XI>(a, st);
-    default: return launch_g<1, 1, MODE, WTR, KM, SCATTER, (KM == 2 ? 3 : 4), XI>(a, st);
+    default: return launch_g<1, 1, MODE, WTR, KM, SCATTER, (KM == 2 ? (MODE == 0 ? 2 : 3) : 4), XI>(a, st);
   }
 }
 

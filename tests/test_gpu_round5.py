@@ -139,17 +139,35 @@ def test_config5_full_size_step(dev, monkeypatch):
               "| MIOpen vs MIOpen on 1e-6-perturbed inputs median", float(np.median(d_ref)), "max", float(d_ref.max()), "| scale", scale)
         assert np.median(d) <= 3.0 * np.median(d_ref) + 1e-3 * scale and d.max() <= 3.0 * d_ref.max() + 1e-2 * scale
 
-        # ---- (c): graph == eager over three iterations from the same initial state
+        # ---- (c): graph == eager over three iterations from the same initial state.  At this depth and lr = 0.004 from a random
+        # init the iteration is explosive (the stem's gradients are of order 10: rounding-level differences - MIOpen's stem filter
+        # gradient accumulates with atomics - grow to the size of the weights within three steps), so the comparison runs at a
+        # learning rate where three steps stay a perturbation, and its bars are RELATIVE to what the three steps changed: a captured
+        # step that lost or doubled an update would differ by ~100 % of it.
+        lr_c = 4e-5
+        m0 = make()
+        p_init = {n_: npy(p_) for n_, p_ in m0.named_parameters()}
+        del m0
         m1, m2 = make(), make()
-        s1, s2 = OfficeTrainStep(m1, lr=0.004, channels_last=True), OfficeTrainStep(m2, lr=0.004, channels_last=True)
+        s1, s2 = OfficeTrainStep(m1, lr=lr_c, channels_last=True), OfficeTrainStep(m2, lr=lr_c, channels_last=True)
         for _ in range(3):
             c1 = s1(xs, ys, xt)
         s2.capture(xs, ys, xt, warmup=2)          # two real iterations, then the captured third
         c2 = s2(xs, ys, xt)
         torch.cuda.synchronize()
         assert torch.isfinite(c1[1]) and torch.isfinite(c2[1]) and c2[1].grad_fn is None
+        np.testing.assert_allclose(float(c1[1]), float(c2[1]), rtol=2e-2)
+        worst = 0.0
         for (nm, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+            if "alterD" in nm or "gamma" in nm:       # (ADMM_OPT overwrites them with the closed form of D: compared through D below)
+                continue
+            moved = np.abs(npy(p1) - p_init[nm])
             dd = np.abs(npy(p1) - npy(p2))
-            assert np.median(dd) < 1e-3 and dd.max() < 2e-2, (nm, float(np.median(dd)), float(dd.max()))
+            ratio = float(np.median(dd)) / (float(np.median(moved)) + 1e-12)
+            worst = max(worst, ratio)
+            assert ratio < 0.25, (nm, float(np.median(dd)), float(np.median(moved)))
+        print("config5 graph vs eager after 3 steps: worst median |p1 - p2| / median |p1 - p_init| =", worst)
+        for b1, b2 in zip(s1.blocks, s2.blocks):
+            np.testing.assert_allclose(npy(b1.admm0.D), npy(b2.admm0.D), atol=5e-3)
     finally:
         config.args.bitW, config.args.abitW, config.args.train_batch_size, config.args.eval_batch_size = old
