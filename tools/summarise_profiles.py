@@ -9,6 +9,8 @@ Units / corrections (MI355X_MICROARCH.md, HBM): rocprofv3 reports FETCH_SIZE and
 FETCH_SIZE counts 64 B per 128-B request of wide coalesced reads, so fetch bytes = 2 x FETCH_SIZE; WRITE_SIZE is exact."""
 import csv, glob, json, os, sys, collections
 
+ROUND = os.environ.get("ROUND", "r05")
+
 src, out = sys.argv[1], sys.argv[2]
 os.makedirs(out, exist_ok=True)
 
@@ -21,7 +23,7 @@ def one(pattern):
 
 # ---- kernel stats -------------------------------------------------------------------------------------------------
 OURS = ("alignq_site", "site_fwd", "site_bwd", "slab_reduce", "site_prep", "bn_stats", "bn_bwd_apply", "bn_finalize", "bnq_", "corrl_", "conv3x3",
-        "wgrad", "mt_", "admm_update", "act_quant", "weight_quant", "weight_stats", "uniform_quantize", "sgd_", "admm_loss")
+        "wgrad", "qgemm", "cdf_", "stem_", "convgen", "transition", "dgrad_s2", "mt_", "admm_update", "act_quant", "weight_quant", "weight_stats", "uniform_quantize", "sgd_", "admm_loss")
 
 
 def is_ours(name):
@@ -34,7 +36,7 @@ head, data = rows[0], rows[1:]
 ours = [r for r in data if is_ours(r[0])]
 others = [r for r in data if not is_ours(r[0])]
 with open(os.path.join(out, "kernel_stats_train_step.csv"), "w") as fo:
-    fo.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-shapes --no-dp-probe   (MI355X)\n")
+    fo.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-shapes --no-dp-probe --no-other-configs   (MI355X)\n")
     fo.write("# 3 eager warm-ups + HIP-graph capture + 33 replays of the ResNet-20 8W/8A CDF+ADMM step (batch 128), then bench.py's per-kernel\n")
     fo.write("# measurement loops (site kernels x ~55 launches per shape, act_quant / copy / add x 23 launches on 2^26 elements)\n")
     fo.write("# --- this repository's kernels (all of them), by total time ---\n")
@@ -73,7 +75,7 @@ for k in sorted(set(fetch) | set(write)):
                  (2 * f_kb + w_kb) * 1024 / 1e6))
 rows.sort(key=lambda r: -r[7] * r[2])
 with open(os.path.join(out, "pmc_hbm_bytes.csv"), "w") as fo:
-    fo.write("# rocprofv3 --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) --kernel-trace --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-shapes --no-dp-probe\n")
+    fo.write("# rocprofv3 --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) --kernel-trace --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-shapes --no-dp-probe --no-other-configs\n")
     fo.write("# filler roles off in these two passes (ALIGNQ_FILL=0): every launch moves its own role's bytes only\n")
     fo.write("# Units: KB per dispatch (mean over dispatches). gfx950: FETCH_SIZE reports 1/2 of wide coalesced reads (MI355X_MICROARCH.md, HBM) -> fetch_corrected = 2*FETCH\n")
     fo.write("kernel,grid_threads,dispatches,FETCH_SIZE_KB,fetch_corrected_MB,WRITE_SIZE_KB,write_MB,total_corrected_MB\n")
@@ -91,7 +93,7 @@ latest = {"site_bwd": {"hbm_bytes_per_launch_avg": avg_bytes("site_bwd4_kernel")
           "site_partials": {"hbm_bytes_per_launch_avg": avg_bytes("site_fwd4_kernel")},
           "act_quant_fwd": {"hbm_bytes_per_launch_avg": avg_bytes("act_quant_fwd_kernel")},
           "act_quant_bwd": {"hbm_bytes_per_launch_avg": avg_bytes("act_quant_bwd_kernel")},
-          "source": "profiles/r04_pmc_hbm_bytes.csv (2 x FETCH_SIZE + WRITE_SIZE per dispatch, mean over all dispatches of the "
+          "source": f"profiles/{ROUND}_pmc_hbm_bytes.csv (2 x FETCH_SIZE + WRITE_SIZE per dispatch, mean over all dispatches of the "
                     "kernel in `bench.py --steps 2`: the three site shapes of ResNet-20 for the site kernels, 2^26 elements for act_quant)"}
 json.dump(latest, open(os.path.join(out, "pmc_latest.json"), "w"), indent=1)
 print(json.dumps(latest, indent=1))
