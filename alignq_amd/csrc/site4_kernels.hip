@@ -1089,6 +1089,31 @@ __global__ __launch_bounds__(1024) void slab_reduce_groups_kernel(float* __restr
                                 scal + gi * 4, blockIdx.x, gridDim.x, lds);
 }
 
+// The same for SEVERAL sites in one launch (round 5: the Office step's 16 bottleneck tails leave their reductions to the end of the
+// forward, as the CIFAR step's sites do): blockIdx.y = site * groups + slice.  Same body, same workgroup partition and
+// summation order as slab_reduce_groups_kernel => same bits.
+struct GRChunk {
+  float* ws[kMultiSites];
+  float* D[kMultiSites];
+  const float* A[kMultiSites];
+  const float* gamma[kMultiSites];
+  float* scal[kMultiSites];
+  int64_t ws_gstride[kMultiSites];
+  float scale[kMultiSites];
+  int n_slabs[kMultiSites];
+};
+__global__ __launch_bounds__(1024) void slab_reduce_groups_multi_kernel(GRChunk c, int groups, int slab_floats, int BP, int B, int dim,
+                                                                        float mu, float rho) {
+  const int s = blockIdx.y / groups;
+  const int64_t gi = blockIdx.y - s * groups;
+  float* ws = c.ws[s] + gi * c.ws_gstride[s];
+  float* parts = ws + (size_t)c.n_slabs[s] * slab_floats;
+  unsigned* counter = reinterpret_cast<unsigned*>(parts + kPartFloats);
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kSlabReduceLds<false>];
+  slab_reduce_body<false, true>(ws, c.n_slabs[s], slab_floats, BP, B, c.scale[s], c.D[s] + gi * B * B, c.A[s], c.gamma[s], dim, mu, rho,
+                                parts, counter, c.scal[s] + gi * 4, blockIdx.x, gridDim.x, lds);
+}
+
 // ================================================================================================ backward prep
 // S = (gD + gD^T) * gscale / F  [B,B]   (MFMA A operand of the backward), and (FUSED) the scaled parameter
 // gradients dA_out = gscale*(mu*sign(A)/n - gD), dG_out = gscale*|D-A|/n  (zero outside [:B,:B]).
@@ -1186,15 +1211,14 @@ __global__ __launch_bounds__(256) void site_prep_multi_kernel(PChunk c, int dim,
 // pass): S of every slice (blockIdx.y = slice) and - by the workgroups of slice 0 - the parameter gradients of ALL slices added
 // in slice order (dalterD = sum_g dalterD_g: the sum autograd forms when the module is called once per pass; round 4: it was an
 // elementwise launch of its own behind the per-slice gradients).  D: [groups][B][B], scal: [groups][4], S regions s_gstride floats apart.
-__global__ __launch_bounds__(256) void site_prep_groups_kernel(const float* __restrict__ D, const float* __restrict__ A,
-                                                               const float* __restrict__ gamma, int dim,
-                                                               const float* __restrict__ scal, float mu,
-                                                               const float* __restrict__ gscale, int B, float invF,
-                                                               float* __restrict__ S, int64_t s_gstride,
-                                                               float* __restrict__ dA_out, float* __restrict__ dG_out, int groups,
-                                                               int gs_stride) {
+__device__ __forceinline__ void site_prep_groups_body(const float* __restrict__ D, const float* __restrict__ A,
+                                                      const float* __restrict__ gamma, int dim,
+                                                      const float* __restrict__ scal, float mu,
+                                                      const float* __restrict__ gscale, int B, float invF,
+                                                      float* __restrict__ S, int64_t s_gstride,
+                                                      float* __restrict__ dA_out, float* __restrict__ dG_out, int groups,
+                                                      int gs_stride, int gi) {
   // gs_stride: elements between the slices' upstream loss gradients (0: one scalar for all of them)
-  const int gi = blockIdx.y;
   // S of this slice (no parameter gradients from here: dA_out / dG_out nullptr)
   site_prep_body<true>(nullptr, D + (int64_t)gi * B * B, A, gamma, dim, scal + 4 * gi, mu, gscale ? gscale + (int64_t)gi * gs_stride : nullptr,
                        B, invF, S + gi * s_gstride, nullptr, nullptr, blockIdx.x, gridDim.x);
@@ -1218,6 +1242,23 @@ __global__ __launch_bounds__(256) void site_prep_groups_kernel(const float* __re
     if (dA_out) dA_out[e] = da;
     if (dG_out) dG_out[e] = dg;
   }
+}
+__global__ __launch_bounds__(256) void site_prep_groups_kernel(const float* __restrict__ D, const float* __restrict__ A,
+                                                               const float* __restrict__ gamma, int dim,
+                                                               const float* __restrict__ scal, float mu,
+                                                               const float* __restrict__ gscale, int B, float invF,
+                                                               float* __restrict__ S, int64_t s_gstride,
+                                                               float* __restrict__ dA_out, float* __restrict__ dG_out, int groups,
+                                                               int gs_stride) {
+  site_prep_groups_body(D, A, gamma, dim, scal, mu, gscale, B, invF, S, s_gstride, dA_out, dG_out, groups, gs_stride, blockIdx.y);
+}
+// ... of SEVERAL sites in one launch (blockIdx.y = site * groups + slice; one upstream scalar for every site and slice: the
+// gradient of the sum of all their losses)
+__global__ __launch_bounds__(256) void site_prep_groups_multi_kernel(PChunk c, int groups, int dim, float mu,
+                                                                     const float* __restrict__ gscale, int B, int64_t s_gstride) {
+  const int s = blockIdx.y / groups, gi = blockIdx.y - s * groups;
+  site_prep_groups_body(c.D[s], c.A[s], c.gamma[s], dim, c.scal[s], mu, gscale, B, c.invF[s], c.S[s], s_gstride, c.dA[s], c.dG[s],
+                        groups, 0, gi);
 }
 
 // The classifier head's backward and the preparation of every site's S / dalterD / dgamma in ONE launch (two independent roles:
@@ -2094,6 +2135,48 @@ int launch_prep_groups(const float* D, const float* alterD, const float* gamma, 
   hipLaunchKernelGGL(site_prep_groups_kernel, dim3(gx, groups), 256, 0, st, D, alterD, gamma, dim, scal, mu, gscale, B, 1.0f / (float)F,
                      S, s_gstride, dA, dG, groups, gs_stride);
   RET_ON_ERR();
+  return 0;
+}
+
+int launch_reduce_loss_groups_multi(int T, float* const* ws, const int64_t* F, int B, int groups, float* const* D,
+                                    const float* const* alterD, const float* const* gamma, int dim, float mu, float rho,
+                                    float* const* scal, hipStream_t st) {
+  const int blocks = (B * B + 63) / 64;
+  for (int s0 = 0; s0 < T; s0 += kMultiSites) {
+    const int cnt = (T - s0 < kMultiSites) ? T - s0 : kMultiSites;
+    GRChunk c;
+    int slab_floats = 0, BP = 0;
+    for (int i = 0; i < cnt; i++) {
+      const Geom g = geom(B, F[s0 + i]);
+      if (g.nb == 4) return ALIGNQ_EUNSUPPORTED;
+      if (i == 0) { slab_floats = g.slab_floats; BP = 32 * g.nb; }
+      else if (slab_floats != g.slab_floats || BP != 32 * g.nb) return ALIGNQ_EUNSUPPORTED;       // (one B: one slab geometry)
+      c.ws[i] = ws[s0 + i]; c.D[i] = D[s0 + i]; c.A[i] = alterD[s0 + i]; c.gamma[i] = gamma[s0 + i]; c.scal[i] = scal[s0 + i];
+      c.ws_gstride[i] = (int64_t)(alignq_site_ws_bytes(B, F[s0 + i]) / 4);
+      c.scale[i] = 1.0f / (float)F[s0 + i]; c.n_slabs[i] = g.grid;
+    }
+    hipLaunchKernelGGL(slab_reduce_groups_multi_kernel, dim3(blocks, cnt * groups), 1024, 0, st, c, groups, slab_floats, BP, B, dim,
+                       mu, rho);
+    RET_ON_ERR();
+  }
+  return 0;
+}
+
+int launch_prep_groups_multi(int T, const float* const* D, const float* const* alterD, const float* const* gamma, int dim,
+                             const float* const* scal, float mu, const float* gscale, int B, const int64_t* F, int groups,
+                             float* const* S, int64_t s_gstride, float* const* dA, float* const* dG, hipStream_t st) {
+  const int gx = (dim * dim + 255) / 256;
+  for (int s0 = 0; s0 < T; s0 += kMultiSites) {
+    const int cnt = (T - s0 < kMultiSites) ? T - s0 : kMultiSites;
+    PChunk c;
+    for (int i = 0; i < cnt; i++) {
+      c.D[i] = D[s0 + i]; c.A[i] = alterD[s0 + i]; c.gamma[i] = gamma[s0 + i]; c.scal[i] = scal[s0 + i];
+      c.S[i] = S[s0 + i]; c.dA[i] = dA ? dA[s0 + i] : nullptr; c.dG[i] = dG ? dG[s0 + i] : nullptr;
+      c.invF[i] = 1.0f / (float)F[s0 + i];
+    }
+    hipLaunchKernelGGL(site_prep_groups_multi_kernel, dim3(gx, cnt * groups), 256, 0, st, c, groups, dim, mu, gscale, B, s_gstride);
+    RET_ON_ERR();
+  }
   return 0;
 }
 

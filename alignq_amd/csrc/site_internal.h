@@ -151,6 +151,12 @@ int launch_prep(bool fused, const float* dD, const float* D, const float* alterD
                 const float* scal, float mu, const float* gscale, int B, int64_t F, float* S, float* dA_out,
                 float* dG_out, hipStream_t st);
 // `groups` batch slices of ONE small-batch site: S per slice, the shared module's parameter gradients summed over the slices
+int launch_reduce_loss_groups_multi(int T, float* const* ws, const int64_t* F, int B, int groups, float* const* D,
+                                    const float* const* alterD, const float* const* gamma, int dim, float mu, float rho,
+                                    float* const* scal, hipStream_t st);
+int launch_prep_groups_multi(int T, const float* const* D, const float* const* alterD, const float* const* gamma, int dim,
+                             const float* const* scal, float mu, const float* gscale, int B, const int64_t* F, int groups,
+                             float* const* S, int64_t s_gstride, float* const* dA, float* const* dG, hipStream_t st);
 int launch_prep_groups(const float* D, const float* alterD, const float* gamma, int dim, const float* scal, float mu,
                        const float* gscale, int B, int64_t F, int groups, float* S, int64_t s_gstride, float* dA, float* dG,
                        hipStream_t st, int gs_stride = 0);     // gs_stride: elements between the slices' loss gradients (0: one for all)

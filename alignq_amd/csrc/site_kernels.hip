@@ -786,6 +786,34 @@ int alignq_site1_groups_prep(const float* D, const float* alterD, const float* g
                             dalterD, dgamma, (hipStream_t)stream, dD_scale_stride);
 }
 
+// (round 5) the two launches above for SEVERAL sites at once: the Office step's bottleneck tails defer them to the end of the
+// forward / the start of the backward (one launch each instead of 16); bit-identical to the per-site calls
+int alignq_site1_groups_reduce_loss_multi(int T, void* const* ws, const int64_t* F, int B, int groups, float* const* D,
+                                          const float* const* alterD, const float* const* gamma, int dim, float mu, float rho,
+                                          float* const* scal, void* stream) {
+  if (T < 1 || !ws || !F || !D || !alterD || !gamma || !scal || groups < 1 || dim < B) return ALIGNQ_EINVAL;
+  for (int i = 0; i < T; i++) {
+    if (!ws[i] || !D[i] || !alterD[i] || !gamma[i] || !scal[i]) return ALIGNQ_EINVAL;
+    if (bad_shape(B, F[i])) return F[i] <= 0 ? ALIGNQ_EINVAL : ALIGNQ_EUNSUPPORTED;
+    if (geom(B, F[i]).nb != 1) return ALIGNQ_EUNSUPPORTED;
+  }
+  return launch_reduce_loss_groups_multi(T, (float* const*)ws, F, B, groups, D, alterD, gamma, dim, mu, rho, scal, (hipStream_t)stream);
+}
+
+int alignq_site1_groups_prep_multi(int T, const float* const* D, const float* const* alterD, const float* const* gamma, int dim,
+                                   const float* const* scal, float mu, const float* dD_scale, int B, const int64_t* F, int groups,
+                                   float* const* S, float* const* dalterD, float* const* dgamma, void* stream) {
+  if (T < 1 || !D || !alterD || !gamma || !scal || !S || !F || groups < 1 || groups > ALIGNQ_BNQ_MAX_GROUPS || dim < B)
+    return ALIGNQ_EINVAL;
+  for (int i = 0; i < T; i++) {
+    if (!D[i] || !alterD[i] || !gamma[i] || !scal[i] || !S[i]) return ALIGNQ_EINVAL;
+    if (bad_shape(B, F[i])) return F[i] <= 0 ? ALIGNQ_EINVAL : ALIGNQ_EUNSUPPORTED;
+    if (geom(B, F[i]).nb != 1) return ALIGNQ_EUNSUPPORTED;
+  }
+  return launch_prep_groups_multi(T, D, alterD, gamma, dim, scal, mu, dD_scale, B, F, groups, S,
+                                  (int64_t)(alignq_site_bwd_ws_bytes(B) / 4), dalterD, dgamma, (hipStream_t)stream);
+}
+
 int alignq_site1_groups_bwd(const float* g, const float* g2, const float* y, const float* S, const float* z, const float* ab, int C,
                             const float* stats, int B, int64_t F, int groups, float act_range, float eps, float* dx,
                             float* dres, void* stream) {

@@ -798,6 +798,101 @@ def bn_only(bn, z, groups=1):
                             groups, conv_partials(z, groups))
 
 
+class Site1Record:
+    """One folded small-batch site of a Site1Batch: its buffers between the forward launch and the deferred reduction / preparation."""
+    __slots__ = ("ws", "D", "A", "Gm", "scal", "B", "F", "groups", "dim", "mu", "rho", "S", "rA", "rG", "prepared")
+
+
+_site1_batch = None
+
+
+def active_site1():
+    return _site1_batch
+
+
+class Site1LossSumFn(torch.autograd.Function):
+    """total = the sum of the sites' loss vectors.  Forward: alignq_site1_groups_reduce_loss_multi (D and the loss scalars of every
+    site and slice in one launch), then one concatenation + sum.  Backward: alignq_site1_groups_prep_multi with the upstream
+    scalar - the loss vectors are inputs, so autograd runs this node before any site's backward (as LossSumFn for the CIFAR sites)."""
+
+    @staticmethod
+    def forward(ctx, batch, *loss_vecs):
+        batch.reduce_all()
+        ctx.recs = list(batch.records)
+        ctx.shapes = [tuple(v.shape) for v in loss_vecs]
+        return torch.cat([v.reshape(-1) for v in loss_vecs]).sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        lib, st = L.load(), L.stream_ptr()
+        g = L.dev_f32(g, "loss grad")
+        by_key = {}
+        for r in ctx.recs:
+            by_key.setdefault((r.B, r.groups, r.dim, r.mu, r.rho), []).append(r)
+        for (B, groups, dim, mu, rho), recs in by_key.items():
+            dev = recs[0].D.device
+            n_s = lib.alignq_site_bwd_ws_bytes(B) // 4 * groups
+            for r in recs:
+                r.S = torch.empty(n_s, dtype=torch.float32, device=dev)
+                r.rA, r.rG = torch.empty_like(r.A), torch.empty_like(r.Gm)
+            L.check(lib.alignq_site1_groups_prep_multi(
+                len(recs), L.ptr_array([r.D for r in recs]), L.ptr_array([r.A for r in recs]), L.ptr_array([r.Gm for r in recs]), dim,
+                L.ptr_array([r.scal for r in recs]), mu, L.ptr(g), B, L.i64_array([r.F for r in recs]), groups,
+                L.ptr_array([r.S for r in recs]), L.ptr_array([r.rA for r in recs]), L.ptr_array([r.rG for r in recs]), st),
+                "alignq_site1_groups_prep_multi")
+            for r in recs:
+                r.prepared = True
+        return (None,) + tuple(g.expand(sh) for sh in ctx.shapes)
+
+
+class Site1Batch:
+    """The Office step's merged traversal (resnet_office.ResNet.forward, groups > 1): while active, the folded bottleneck tails
+    (BNSite1Fn with a loss vector) launch only their site kernel; `total()` reduces every site's slabs to D + loss in ONE launch
+    (off the forward's critical path: only y feeds the next layer) and its backward prepares every site's S / dalterD / dgamma in
+    ONE launch - 2 launches per iteration instead of 32.  Bit-identical to the per-site launches."""
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        global _site1_batch
+        self.records = []
+        self._outer = _site1_batch
+        _site1_batch = self
+        return self
+
+    def __exit__(self, *exc):
+        global _site1_batch
+        _site1_batch = self._outer
+        self.records = []         # (the loss node holds its own list until the backward has run)
+        return False
+
+    def add(self, **kw):
+        rec = Site1Record()
+        for k_, v in kw.items():
+            setattr(rec, k_, v)
+        rec.prepared = False
+        self.records.append(rec)
+        return rec
+
+    def reduce_all(self):
+        lib, st = L.load(), L.stream_ptr()
+        by_key = {}
+        for r in self.records:
+            by_key.setdefault((r.B, r.groups, r.dim, r.mu, r.rho), []).append(r)
+        for (B, groups, dim, mu, rho), recs in by_key.items():
+            L.check(lib.alignq_site1_groups_reduce_loss_multi(
+                len(recs), L.ptr_array([r.ws for r in recs]), L.i64_array([r.F for r in recs]), B, groups,
+                L.ptr_array([r.D for r in recs]), L.ptr_array([r.A for r in recs]), L.ptr_array([r.Gm for r in recs]), dim, mu, rho,
+                L.ptr_array([r.scal for r in recs]), st), "alignq_site1_groups_reduce_loss_multi")
+
+    def total(self, loss_vecs):
+        """Sum of the tensors in loss_vecs (the sites' loss vectors and whatever else the caller collected)."""
+        if not self.records:
+            return torch.cat([t.reshape(-1) for t in loss_vecs]).sum()
+        return Site1LossSumFn.apply(self, *loss_vecs)
+
+
 _S1_BN_COLS = True        # False: alignq_site1_groups_bwd + alignq_bnq_bwd_dx (a test's comparison arm; not an environment switch)
 
 
@@ -836,7 +931,11 @@ class BNSite1Fn(torch.autograd.Function):
         D = torch.empty(groups, B, B, dtype=torch.float32, device=dev)
         scal = torch.empty(groups, 4, dtype=torch.float32, device=dev)
         from .ops import _ws
-        ws = _ws(lib.alignq_site_ws_bytes(B, F) * groups, dev)
+        batch = active_site1() if loss_vec else None
+        if batch is not None:      # the slabs wait for the batch's reduction launch: a buffer of this site's own
+            ws = torch.empty(lib.alignq_site_ws_bytes(B, F) * groups, dtype=torch.uint8, device=dev)
+        else:
+            ws = _ws(lib.alignq_site_ws_bytes(B, F) * groups, dev)
         cp, cn = (conv_part[0], int(conv_part[1])) if conv_part is not None else (None, 0)
         L.check(lib.alignq_bnq_stats_parts(L.ptr(z), P, C, groups, L.ptr(weight), L.ptr(bias), L.ptr(running_mean),
                                            L.ptr(running_var), L.ptr(nbt), float(momentum), float(bn_eps), L.ptr(ab), L.ptr(save),
@@ -844,8 +943,13 @@ class BNSite1Fn(torch.autograd.Function):
         # every slice in ONE launch per kernel (blockIdx.y = slice; the slices' workspace regions lie back to back)
         L.check(lib.alignq_site1_groups_fwd(L.ptr(z), L.ptr(ab), C, B, F, groups, int(k), float(act_range), float(eps),
                                             L.ptr(residual), 1, L.ptr(y), L.ptr(stats), L.ptr(ws), st), "alignq_site1_groups_fwd")
-        L.check(lib.alignq_site1_groups_reduce_loss(L.ptr(ws), B, F, groups, L.ptr(D), L.ptr(A), L.ptr(Gm), A.shape[0], float(mu),
-                                                    float(rho), L.ptr(scal), st), "alignq_site1_groups_reduce_loss")
+        ctx.rec = None
+        if batch is not None:
+            ctx.rec = batch.add(ws=ws, D=D, A=A, Gm=Gm, scal=scal, B=B, F=F, groups=int(groups), dim=int(A.shape[0]), mu=float(mu),
+                                rho=float(rho))
+        else:
+            L.check(lib.alignq_site1_groups_reduce_loss(L.ptr(ws), B, F, groups, L.ptr(D), L.ptr(A), L.ptr(Gm), A.shape[0], float(mu),
+                                                        float(rho), L.ptr(scal), st), "alignq_site1_groups_reduce_loss")
         ctx.save_for_backward(z, y, ab, save, stats, D, A, Gm, scal)
         ctx.cfg = (float(act_range), float(eps), float(mu), weight is not None, bias is not None, residual is not None,
                    int(groups))
@@ -882,26 +986,31 @@ class BNSite1Fn(torch.autograd.Function):
         if g_y is not None:      # the fused ReLU's mask is applied by the site kernel, which also leaves the masked gradient in g_m
             g_y = L.like_layout(g_y, z)
             g_m = torch.empty_like(z) if has_res else None
-        if g_loss is None:
-            g_loss = torch.zeros((), dtype=torch.float32, device=dev)
-        if g_loss.dim() == 0:
-            g_loss, gs_stride = L.dev_f32(g_loss, "loss grad"), 0
-        else:       # loss_vec: one upstream gradient per slice, read where autograd left it (an expanded tensor has stride 0)
-            if not (g_loss.is_cuda and g_loss.dtype == torch.float32 and tuple(g_loss.shape) == (groups,)):
-                raise RuntimeError("BNSite1Fn: the gradient of the loss vector must be a float32 device tensor of shape [groups]")
-            gs_stride = int(g_loss.stride(0))
-        # alignq_site1_groups_prep writes dalterD / dgamma already summed over the slices
-        rA, rG = torch.empty_like(A), torch.empty_like(Gm)
-        from .ops import _ws
-        s_bytes = lib.alignq_site_bwd_ws_bytes(B)
-        S = _ws(s_bytes * groups, dev)
+        rec = ctx.rec
+        prepared = rec is not None and rec.prepared        # Site1LossSumFn.backward has prepared every site of the batch
+        if prepared:
+            S, rA, rG = rec.S, rec.rA, rec.rG
+        else:
+            if g_loss is None:
+                g_loss = torch.zeros((), dtype=torch.float32, device=dev)
+            if g_loss.dim() == 0:
+                g_loss, gs_stride = L.dev_f32(g_loss, "loss grad"), 0
+            else:       # loss_vec: one upstream gradient per slice, read where autograd left it (an expanded tensor has stride 0)
+                if not (g_loss.is_cuda and g_loss.dtype == torch.float32 and tuple(g_loss.shape) == (groups,)):
+                    raise RuntimeError("BNSite1Fn: the gradient of the loss vector must be a float32 device tensor of shape [groups]")
+                gs_stride = int(g_loss.stride(0))
+            # alignq_site1_groups_prep writes dalterD / dgamma already summed over the slices
+            rA, rG = torch.empty_like(A), torch.empty_like(Gm)
+            from .ops import _ws
+            S = _ws(lib.alignq_site_bwd_ws_bytes(B) * groups, dev)
         dx = torch.empty_like(z)
         dgamma = torch.empty(C, dtype=torch.float32, device=dev) if has_w else None
         dbeta = torch.empty(C, dtype=torch.float32, device=dev) if has_b else None
         ws_bn = torch.empty(lib.alignq_bnq_ws_bytes(C, groups), dtype=torch.uint8, device=dev)
         # one preparation launch (S per slice; dalterD / dgamma summed over the slices in slice order) and one backward launch
-        L.check(lib.alignq_site1_groups_prep(L.ptr(D), L.ptr(A), L.ptr(Gm), A.shape[0], L.ptr(scal), mu, L.ptr(g_loss), gs_stride, B, F,
-                                             groups, L.ptr(S), L.ptr(rA), L.ptr(rG), st), "alignq_site1_groups_prep")
+        if not prepared:
+            L.check(lib.alignq_site1_groups_prep(L.ptr(D), L.ptr(A), L.ptr(Gm), A.shape[0], L.ptr(scal), mu, L.ptr(g_loss), gs_stride, B,
+                                                 F, groups, L.ptr(S), L.ptr(rA), L.ptr(rG), st), "alignq_site1_groups_prep")
         if _S1_BN_COLS:
             # the site kernel leaves the batch-norm backward's sums per feature column; a small reduction, the finalisation and dz
             # (in place) follow in the same entry: no pass of its own over dx and z

@@ -145,18 +145,20 @@ class ResNet(nn.Module):
             if hasattr(q0, "_alignq_levels"):        # the maximum of quantiser levels is one of them (fused.tag_levels)
                 x._alignq_levels = q0._alignq_levels
             losses = []
-            for layers in (self.layer1, self.layer2, self.layer3, self.layer4):
-                for layer in layers:
-                    x, loss = layer(x, groups, loss_vec=True)
-                    losses.append(loss)
+            with fused.Site1Batch() as s1:      # the folded tails' reductions / preparations: one launch each for all 16 sites
+                for layers in (self.layer1, self.layer2, self.layer3, self.layer4):
+                    for layer in layers:
+                        x, loss = layer(x, groups, loss_vec=True)
+                        losses.append(loss)
+                tens = [l for l in losses if torch.is_tensor(l)]
+                total_t = s1.total(tens) if tens else None
             # one stack + one sum instead of 16 scalar additions on the in-order chain (the fast path only: the value may differ
             # from main.py's running sum in the last bit, the gradients - ones - do not)
             # (a site without an ADMM term - abitW == 32, method != 'ours', a deferred-loss context - returns the number 0: those
             # are summed as numbers, as the running sum of the one-pass form does)
-            tens = [l for l in losses if torch.is_tensor(l)]
             rest = sum(l for l in losses if not torch.is_tensor(l))
             # (the folded sites return the VECTOR of their slices' losses - a view, no kernel: one concatenation + one sum)
-            total = torch.cat([t.reshape(-1) for t in tens]).sum() + rest if tens else rest
+            total = total_t + rest if tens else rest
             return torch.flatten(self.avgpool(x), 1), total
         if getattr(self, "fuse_bn", False):
             q0 = self.act_q0.forward_bn_relu(self.bn1, self.conv1(x))

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALIGNQ_ABI_VERSION 15
+#define ALIGNQ_ABI_VERSION 16
 
 #define ALIGNQ_FORMULA_ADMM 0
 #define ALIGNQ_FORMULA_CDF 1
@@ -564,6 +564,17 @@ int alignq_site1_groups_reduce_loss(void* ws, int B, int64_t F, int groups, floa
 int alignq_site1_groups_prep(const float* D, const float* alterD, const float* gamma, int dim, const float* scal, float mu,
                              const float* dD_scale, int dD_scale_stride, int B, int64_t F, int groups, float* S, float* dalterD,
                              float* dgamma, void* stream);
+/* (round 5, ABI 16) alignq_site1_groups_reduce_loss / _prep for T sites in ONE launch each (HOST arrays of device pointers, F[i]
+ * per site; one B, groups, dim, mu, rho for all; dD_scale: ONE device scalar - the gradient of the sum of every site's and slice's
+ * loss - or NULL = 1).  The Office iteration's 16 bottleneck tails (dann_office/model/resnet.py:145-154 called from main.py:372,377)
+ * leave their reductions to the end of the forward and their preparations to the start of the backward; results are bit-identical
+ * to the per-site calls.  Each site needs its OWN ws (alignq_site_ws_bytes(B, F) * groups) until the reduction has run.            */
+int alignq_site1_groups_reduce_loss_multi(int T, void* const* ws, const int64_t* F, int B, int groups, float* const* D,
+                                          const float* const* alterD, const float* const* gamma, int dim, float mu, float rho,
+                                          float* const* scal, void* stream);
+int alignq_site1_groups_prep_multi(int T, const float* const* D, const float* const* alterD, const float* const* gamma, int dim,
+                                   const float* const* scal, float mu, const float* dD_scale, int B, const int64_t* F, int groups,
+                                   float* const* S, float* const* dalterD, float* const* dgamma, void* stream);
 int alignq_site1_groups_bwd(const float* g, const float* g2, const float* y, const float* S, const float* z, const float* ab, int C,
                             const float* stats, int B, int64_t F, int groups, float act_range, float eps, float* dx,
                             float* dres, void* stream);
