@@ -115,6 +115,10 @@ struct QG {
 // workgroup's BM consecutive pixels plus W + 1 pixels on either side are staged ONCE per channel chunk (rows = flattened pixel
 // index) and the nine taps read them at row offsets dy * W + dx; a lane whose tap falls outside its image reads an all-zero row
 // instead (address select, no branch).  The pixel-side global loads, splits and LDS writes drop by ~9 BM / (BM + 2 W + 2).
+// KM 3 = the DATA GRADIENT of a 3x3 stride-2 convolution (padding 1, even H_in and W_in) by parity class: the input pixels
+// (2i + py, 2j + px) of one class (py, px) = one "group" of rows; dx[2i + py, 2j + px] = sum over the taps (ky, kx) with
+// ky = py + 1 (mod 2), kx = px + 1 (mod 2) of dy[i + (py + 1 - ky) / 2, j + (px + 1 - kx) / 2] * W[ky][kx] - 1, 2, 2 or 4 taps instead of
+// the 9 a gather over every tap would run with 5 to 8 of them multiplying zeros; rows = the half grid, gathered per tap like KM 1.
 constexpr int kHaloW = 56;        // widest image the halo form takes (LDS is sized for it)
 // XI (MODE 1 only): the level operand arrives as its int16 index (N2 on the Office path: 2 B per element through the CU's load path
 // instead of 4, no rint on the way to the f16 term).
@@ -125,7 +129,8 @@ __global__ __launch_bounds__(256, OCC) void qgemm_kernel(const QG a) {
   constexpr int WM = 4 / WN, BM = WM * 16 * TM, BN = 64 * WN;
   constexpr int TA = MODE == 0 ? 3 : 1;
   constexpr bool F16 = MODE == 1;
-  constexpr bool KS3 = KM != 0, HALO = KM == 2;
+  constexpr bool KS3 = KM != 0, HALO = KM == 2, S2D = KM == 3;
+  static_assert(!S2D || (WTR && !SCATTER && MODE == 0), "the parity-class form is a data gradient");
   constexpr int KB = (HALO && MODE == 0) ? 32 : BK;      // k per step (the three-plane halo image would not fit at 64)
   // halfwords per row of a direct image.  ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32):
   // sixteen different rows, half of them 16 B further along k.  Rows of 96 / 160 B (32 B of padding) put those sixteen 16-byte
@@ -169,7 +174,8 @@ __global__ __launch_bounds__(256, OCC) void qgemm_kernel(const QG a) {
     for (int i = 0; i < NA; i++) {
       const int m = m_lo + rr + RP * i;
       if (m < m_end) {
-        const int wr = m % a.Wr, t = m / a.Wr, hr = t % a.Hr, img = t / a.Hr;
+        const int ml = S2D ? m - grp * a.Mg : m;         // (parity classes: every group covers all images)
+        const int wr = ml % a.Wr, t = ml / a.Wr, hr = t % a.Hr, img = t / a.Hr;
         pix[i] = (img * a.Ha + hr * a.S) * a.Wa + wr * a.S;
         hw[i] = ((hr * a.S) << 16) | (wr * a.S);
       } else {
@@ -187,7 +193,8 @@ __global__ __launch_bounds__(256, OCC) void qgemm_kernel(const QG a) {
   }
   // k steps: KM 0: channel chunks; KM 1: (tap, chunk) tap-major; KM 2: (chunk, tap) chunk-major (the halo image serves 9 taps)
   const int KC = a.CA / KB;
-  const int nk = (KS3 ? 9 : 1) * KC;
+  const int py = S2D ? (grp >> 1) : 0, px = S2D ? (grp & 1) : 0, ntx = 1 + px;          // S2D: this class's taps: (1 + py) x (1 + px)
+  const int nk = (S2D ? (1 + py) * ntx : (KS3 ? 9 : 1)) * KC;
   RA ra[NA];
   s16x8 rw[NB];
   auto load_a = [&](int64_t off, bool ok) -> RA {
@@ -216,7 +223,9 @@ __global__ __launch_bounds__(256, OCC) void qgemm_kernel(const QG a) {
       }
     } else {
       const int tap = KS3 ? kt / KC : 0, c0 = (KS3 ? kt % KC : kt) * KB;
-      const int dy = KS3 ? a.sgn * (tap / 3 - 1) : 0, dx = KS3 ? a.sgn * (tap % 3 - 1) : 0;
+      // S2D: tap (ty, tx) of the class: the dy pixel one further down / right for ky = 0 / kx = 0 (py = 1 / px = 1, ty = 0 / tx = 0)
+      const int dy = S2D ? (py ? 1 - tap / ntx : 0) : (KS3 ? a.sgn * (tap / 3 - 1) : 0);
+      const int dx = S2D ? (px ? 1 - tap % ntx : 0) : (KS3 ? a.sgn * (tap % 3 - 1) : 0);
 #pragma unroll
       for (int i = 0; i < NA; i++) {
         bool ok = pix[i] >= 0;
@@ -226,7 +235,9 @@ __global__ __launch_bounds__(256, OCC) void qgemm_kernel(const QG a) {
     }
   };
   auto fetch_w = [&](int kt) {
-    const int tap = !KS3 ? 0 : (HALO ? kt % 9 : kt / KC), c0 = (!KS3 ? kt : (HALO ? kt / 9 : kt % KC)) * KB;
+    int tap = !KS3 ? 0 : (HALO ? kt % 9 : kt / KC);
+    const int c0 = (!KS3 ? kt : (HALO ? kt / 9 : kt % KC)) * KB;
+    if (S2D) tap = (py ? 2 * (tap / ntx) : 1) * 3 + (px ? 2 * (tap % ntx) : 1);         // (ky, kx) of the class's tap (ty, tx)
     if (!WTR) {           // rows n of the tile, KB / 8 pieces of 8 k each
       constexpr int PPR = KB / 8, RPW = 256 / PPR;
 #pragma unroll
@@ -363,6 +374,11 @@ __global__ __launch_bounds__(256, OCC) void qgemm_kernel(const QG a) {
     const bool ok = m < m_end;
     int64_t orow = (int64_t)m * a.N;
     bool z01 = false, z10 = false;
+    if (S2D) {
+      const int ml = (ok ? m : m_lo) - grp * a.Mg;
+      const int wr = ml % a.Wr, t = ml / a.Wr, hr = t % a.Hr, img = t / a.Hr;
+      orow = ((int64_t)(img * a.Ho + 2 * hr + py) * a.Wo + 2 * wr + px) * a.N;
+    }
     if (SCATTER) {
       const int mm = ok ? m : m_lo;
       const int wr = mm % a.Wr, t = mm / a.Wr, hr = t % a.Hr, img = t / a.Hr;
@@ -925,7 +941,7 @@ int alignq_qconv_dgrad(const float* dy, const void* w_bins, float* dx, int B, in
                        int w_bit, void* stream) {
   if (!dy || !w_bins || !dx || w_bit < 1 || w_bit > 8) return ALIGNQ_EINVAL;
   if (!shape_ok(B, H_in, W_in, CIN, COUT, KS, stride)) return ALIGNQ_EUNSUPPORTED;
-  if (KS == 3 && stride != 1) return ALIGNQ_EUNSUPPORTED;
+  if (KS == 3 && stride != 1 && ((H_in | W_in) & 1)) return ALIGNQ_EUNSUPPORTED;       // (the parity classes need even H_in, W_in)
   const int Ho = (H_in - 1) / stride + 1, Wo = (W_in - 1) / stride + 1;
   QG a{};
   a.xa = dy; a.w = (const u16*)w_bins; a.out = dx;
@@ -937,6 +953,11 @@ int alignq_qconv_dgrad(const float* dy, const void* w_bins, float* dx, int B, in
   a.nlev = (float)((1 << w_bit) - 1); a.xlev = 0.f;
   a.bn_part = nullptr;
   hipStream_t st = (hipStream_t)stream;
+  if (stride == 2 && KS == 3) {      // rows = the half grid, once per parity class of the input pixels (see KM 3)
+    a.groups = 4;
+    a.Mg = B * Ho * Wo; a.Hr = Ho; a.Wr = Wo;
+    return launch_g_tiles<0, true, 3, false>(a, st);
+  }
   if (stride == 2) {         // 1x1: rows = dy's pixels, scattered to (2h, 2w) with zeros at the other three pixels of the 2x2 cell
     a.Mg = B * Ho * Wo; a.Hr = Ho; a.Wr = Wo;
     return launch_g_tiles<0, true, 0, true>(a, st);

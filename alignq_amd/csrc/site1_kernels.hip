@@ -95,7 +95,10 @@ __device__ __forceinline__ void gram32(const unsigned* __restrict__ W, int l31, 
 // ================================================================================================ forward
 // res (or nullptr): a [B,F] tensor added to x_q before it is stored (the bottleneck's `out += identity`); relu: store relu(.)
 // (`out = self.relu(out)`): dann_office/model/resnet.py:153-154 — the stored tensor is what the next layer reads.
-template <bool PAIR, bool RES>
+// BND (PAIR only): the launch's (k, act_range) keep every level index in the verified range (Levels.yn != 0, alignq_math.h): the
+// quantiser is the straight-line form.  Without it every ROW carried the scalar switch on k (k == 32 / k == 1 / bounded) that the
+// generic form needs - five scalar branches per row, 80 per sub-tile, in a kernel that lives on issue slots.
+template <bool PAIR, bool RES, bool BND = false>
 __global__ __launch_bounds__(kThreads1, PAIR ? 4 : 5) void site1_fwd_kernel(const float* __restrict__ x, int B, int64_t F, int k,
                                                               float r, float eps, float* __restrict__ xq,
                                                               float* __restrict__ slabs, float* __restrict__ stats,
@@ -125,7 +128,6 @@ __global__ __launch_bounds__(kThreads1, PAIR ? 4 : 5) void site1_fwd_kernel(cons
   const int h = lane >> 5, l31 = lane & 31;      // h doubles as the row half of the load mapping
   unsigned* W = lds + w * WBUF;
   const Levels nlev = make_levels(k, fabsf(r) <= 8.0f);
-  const bool bounded = nlev.yn != 0.0f;          // launch-uniform
   const float invB = 1.0f / (float)B, invBm1 = 1.0f / (float)(B - 1);
   if (blockIdx.x == 0 && tid == 0 && counter) *counter = 0u;
 
@@ -229,8 +231,7 @@ __global__ __launch_bounds__(kThreads1, PAIR ? 4 : 5) void site1_fwd_kernel(cons
         for (int j = 0; j < 4; j++) {
           const int q = q4 + j;
           float b;
-          qq[j] = bounded ? act_quant1<0, true>(xr[q], k, nlev, r, &tr[q], &b, tab)
-                          : act_quant1<0>(xr[q], k, nlev, r, &tr[q], &b, tab);
+          qq[j] = act_quant1<0, BND>(xr[q], k, nlev, r, &tr[q], &b, tab);
           if (RES) qq[j] += rr[RES ? j : 0];
           if (relu) qq[j] = fmaxf(qq[j], 0.0f);
           if (RPL * h + q >= B) tr[q] = 0.f;
@@ -503,7 +504,10 @@ int launch_partials1(bool pair, const Geom& g, const float* x, int B, int64_t F,
   unsigned* counter = reinterpret_cast<unsigned*>(ws + (size_t)g.grid * g.slab_floats + kPartFloats);
   if ((int64_t)B * F * 4 >= ((int64_t)1 << 32)) return ALIGNQ_EUNSUPPORTED;   // 32-bit byte offsets
   const int n_sub = (int)((F + SUBF - 1) / SUBF);
-  if (pair && res) hipLaunchKernelGGL((site1_fwd_kernel<true, true>), dim3(g.grid, groups), kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter, res, relu, ab, C, ws_gstride);
+  const bool bnd = make_levels(k, fabsf(r) <= 8.0f).yn != 0.0f;       // as the kernel forms its Levels
+  if (pair && res && bnd) hipLaunchKernelGGL((site1_fwd_kernel<true, true, true>), dim3(g.grid, groups), kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter, res, relu, ab, C, ws_gstride);
+  else if (pair && res) hipLaunchKernelGGL((site1_fwd_kernel<true, true>), dim3(g.grid, groups), kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter, res, relu, ab, C, ws_gstride);
+  else if (pair && bnd) hipLaunchKernelGGL((site1_fwd_kernel<true, false, true>), dim3(g.grid, groups), kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter, nullptr, relu, ab, C, ws_gstride);
   else if (pair) hipLaunchKernelGGL((site1_fwd_kernel<true, false>), dim3(g.grid, groups), kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter, nullptr, relu, ab, C, ws_gstride);
   else hipLaunchKernelGGL((site1_fwd_kernel<false, false>), dim3(g.grid, groups), kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter, nullptr, 0, ab, C, ws_gstride);
   RET_ON_ERR1();

@@ -96,7 +96,10 @@ inline Geom geom(int B, int64_t F) {
       g.grid = (int)((F + 127) / 128);
       // 1024 workgroups = one resident round at four waves per SIMD (round 3: 2048 ran the kernel no faster - 57.6 vs 58.2 us at
       // [28, 802816] - and doubled the slabs the reduction reads: config 5 22.36 -> 22.24 ms)
-      constexpr int cap1 = 1024;
+#ifndef ALIGNQ_S1_CAP
+#define ALIGNQ_S1_CAP 1024
+#endif
+      constexpr int cap1 = ALIGNQ_S1_CAP;
       if (g.grid > cap1) g.grid = cap1;
     }
     g.slab_floats = (32 * g.nb) * (32 * g.nb);

@@ -1005,7 +1005,7 @@ class QConvGemmFn(torch.autograd.Function):
             gy = gy.contiguous(memory_format=cl)
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            if ks == 3 and s != 1:      # the three stride-2 3x3 layers: MIOpen's data gradient (not among alignq_qconv_dgrad's shapes)
+            if ks == 3 and s != 1 and (H % 2 or W % 2):      # (an odd grid has no parity classes: torch's data gradient for that layer)
                 dx = torch.nn.grad.conv2d_input((B, CIN, H, W), w, gy, stride=s, padding=1)
             else:
                 dx = torch.empty((B, CIN, H, W), dtype=torch.float32, device=w.device, memory_format=cl)

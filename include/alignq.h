@@ -362,7 +362,7 @@ int alignq_qconv_fwd(const void* x, const void* w_bins, float* y, int B, int H_i
 /* x_bin_bytes = 2 (N2; needs x_levels > 0): x holds the level tensor's int16 indices (alignq_bnq_fwd_parts bins_out)
  * instead of fp32 values; 0: fp32.                                                                                              */
 /* data gradient dx [B, H_in, W_in, CIN] from dy [B, H_out, W_out, COUT] and the filter's bf16 bins (every element of dx is written;
- * the 3x3 stride-2 form is ALIGNQ_EUNSUPPORTED: the caller keeps its own path for those three layers)                            */
+ * the 3x3 stride-2 form runs per parity class of the input pixel and needs even H_in and W_in, else ALIGNQ_EUNSUPPORTED)          */
 int alignq_qconv_dgrad(const float* dy, const void* w_bins, float* dx, int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride,
                        int w_bit, void* stream);
 /* filter gradient dW [COUT, KS, KS, CIN] (the layout of wt): deterministic split-K slabs in ws (alignq_qconv_wgrad_ws_bytes),

@@ -89,6 +89,21 @@ def test_qconv3x3_matches_fp64_at_every_resnet50_shape(dev, c, H, stride, level)
     _check(dev, 3, c, c, H, 3, stride, 8, level, seed=c + H)
 
 
+def test_qconv3x3_stride2_data_gradient_runs_on_the_parity_class_kernel(dev, monkeypatch):
+    """round 5: the three 3x3 stride-2 layers' data gradients (even grids) are alignq_qconv_dgrad's (KM 3: one group of rows per
+    parity class of the input pixel, 1 / 2 / 2 / 4 taps each) - torch's conv2d_input is not called; an odd grid (no ResNet-50 layer
+    has one at 224 x 224) keeps torch's.  Values: _check against fp64, every class's border (last row / column: the tap that
+    reaches dy row H/2 contributes nothing), a batch whose class size is not a multiple of the row tile."""
+    def boom(*a, **k):
+        raise AssertionError("torch.nn.grad.conv2d_input called for an even grid")
+    monkeypatch.setattr(torch.nn.grad, "conv2d_input", boom)
+    for B, c, H in ((3, 128, 56), (5, 64, 6), (2, 256, 10), (56, 256, 14)):
+        _check(dev, B, c, c, H, 3, 2, 8, False, seed=B + c + H)
+    _check(dev, 3, 64, 128, 12, 3, 2, 4, True, seed=11)
+    monkeypatch.undo()
+    _check(dev, 3, 64, 64, 9, 3, 2, 8, False, seed=5)          # odd grid: torch's data gradient, same bars
+
+
 @pytest.mark.parametrize("cin,cout,H,ks,stride,k", [(256, 64, 56, 1, 1, 8), (512, 1024, 28, 1, 2, 4), (256, 256, 14, 3, 1, 2),
                                                     (2048, 512, 7, 1, 1, 8)])
 def test_qconv_full_batch_of_config5(dev, cin, cout, H, ks, stride, k):
@@ -161,7 +176,7 @@ def test_qconv_rejects_what_it_does_not_take(dev):
     assert lib.alignq_qconv_supported(2, 8, 8, 64, 64, 5, 1) == 0
     assert lib.alignq_qconv_supported(2, 8, 8, 64, 64, 3, 3) == 0
     x = torch.zeros(2, 8, 8, 64, device=dev)
-    assert lib.alignq_qconv_dgrad(L.ptr(x), L.ptr(x), L.ptr(x), 2, 8, 8, 64, 64, 3, 2, 8, None) == -2       # ALIGNQ_EUNSUPPORTED
+    assert lib.alignq_qconv_dgrad(L.ptr(x), L.ptr(x), L.ptr(x), 2, 7, 8, 64, 64, 3, 2, 8, None) == -2       # ALIGNQ_EUNSUPPORTED: odd grid
     assert lib.alignq_qconv_fwd(L.ptr(x), L.ptr(x), L.ptr(x), 2, 8, 8, 64, 64, 1, 1, 9, 0.0, 0, 1, None, None) == -1    # w_bit
     assert lib.alignq_qconv_fwd(L.ptr(x), L.ptr(x), L.ptr(x), 2, 8, 8, 64, 64, 1, 1, 8, 0.0, 2, 1, None, None) == -1    # indices need x_levels
 

@@ -1,6 +1,12 @@
-for f in 1024 2048 3072 4096; do for b in 768 1536 2048 2304 3072; do
-  echo -n "F=$f B=$b: "; ALIGNQ_S1_GRID_F=$f ALIGNQ_S1_GRID_B=$b python tools/roofline_shapes.py 2>/dev/null | tail -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.read())
-print({k:(round(v['fwd_us'],1),round(v['bwd_us'],1)) for k,v in d.items() if k.startswith('site_28')})"
-done; done
+#!/bin/bash
+# Runs ON THE GPU BOX: the small-batch site kernels at config 5's two extreme shapes (2 x [28, 100352], 2 x [28, 802816]) for several
+# builds of the library (tools/build_variant.sh; e.g. -DALIGNQ_S1_CAP=n: workgroups of the forward per batch slice).
+cd "$GRAFT_REPO_ROOT"
+for so in "" $@; do
+  echo "== ${so:-product}"
+  ALIGNQ_SO=$so python3 tools/office_shapes.py 2>/dev/null | grep "^bn_site" | python3 -c "
+import sys, json
+for l in sys.stdin:
+    n, j = l.split(' ', 1); d = json.loads(j)
+    print(n, 'site_fwd_kernel_us', d['site_fwd_kernel_us'], 'frac', d['site_fwd_kernel_frac_of_8TBs'], '| fwd_us', d['fwd_us'], '| site_bwd_kernel_us', d['site_bwd_kernel_us'])"
+done
