@@ -35,6 +35,8 @@ def test_config5_full_size_step(dev, monkeypatch):
           the same chain run on the target slice alone gives it to rounding (2e-6), the source slice's is far from it;
       (c) the captured HIP graph reproduces eager iterations from the same initial state at the bin-flip bars of the small
           harness test (median 1e-3 / max 2e-2 on every parameter after three steps);
+      (b') the reported trans loss (one concatenation + sum over the 32 per-slice losses) against main.py's running sums: within the
+          bound of 32 fp32 additions;
       (d) with Conv2d_Q on the GEMM kernels and on MIOpen the first iteration's class logits agree at bin-flip scale - the scale
           measured beside it: MIOpen against MIOpen with the inputs perturbed by 1e-6 relative."""
     import alignq_amd.quantization  # noqa: F401
@@ -93,6 +95,17 @@ def test_config5_full_size_step(dev, monkeypatch):
             # same sums in another order, so (a, b) - and D - agree to rounding, not bit for bit)
             to_t = float((D_now - rr_["d_alone"][1]).abs().max()), float((D_now - rr_["d_alone"][0]).abs().max())
             assert to_t[0] < 2e-6 and to_t[1] > 50 * to_t[0] + 1e-5, f"site {i}: D is not the target slice's {to_t}"
+        # the fast path sums the 32 per-slice losses in one concatenation + sum instead of main.py's running sums (model/resnet.py
+        # `trans_loss += loss` per block and pass, main.py:380 src_trans_loss + tgt_trans_loss): same numbers in another order,
+        # within the worst-case bound of 32 fp32 additions (the bound, tested)
+        lv = np.stack([npy(rr_["loss"]) for rr_ in rec]).astype(np.float32)           # [16 sites][2 slices]
+        run = [np.float32(0), np.float32(0)]
+        for i in range(16):
+            for gi in range(2):
+                run[gi] = np.float32(run[gi] + lv[i, gi])
+        ref_total = np.float32(run[0] + run[1])
+        assert abs(float(tl0) - float(ref_total)) <= 32 * 2.0 ** -24 * float(np.abs(lv).sum()), (float(tl0), float(ref_total))
+        print("config5 trans loss: fast path", float(tl0), "running sums", float(ref_total))
         for i in (0, 3, 15):                                        # (a)
             rr_ = rec[i]
             Bt, C, H, W = rr_["z"].shape
