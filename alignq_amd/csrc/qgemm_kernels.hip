@@ -107,6 +107,9 @@ struct QG {
   int Ho, Wo;                                      // SCATTER: the output grid (H_in, W_in of the convolution)
   float nlev, xlev;                                // the filter is bins / nlev; MODE 1: index = rint(x * xlev)
   double* bn_part;                                 // forward: [groups][tiles_per_group][N][2] {sum y, sum y^2} or nullptr
+  // split-K (data gradient of the small-M, long-K layers): workgroup (tile, split) runs its share of the k steps and leaves RAW sums
+  // in part[split][out_elems] at the output's own addresses; qgemm_ksplit_reduce_kernel adds the splits in order and divides
+  int ksplit; float* part; int64_t out_elems;
 };
 
 // OCC: workgroups per CU the register / LDS budget is sized for (a small tile runs 3-4 of them: latency hiding comes from the
@@ -154,7 +157,9 @@ __global__ __launch_bounds__(256, OCC) void qgemm_kernel(const QG a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wn = wv % WN, wm = wv / WN;
-  const int pid = xcd_remap(blockIdx.x, gridDim.x);
+  int pid = xcd_remap(blockIdx.x, gridDim.x);
+  const int ksp = pid % a.ksplit;                  // (the splits of one tile sit next to each other: same XCD, same operand rows)
+  pid /= a.ksplit;
   const int nt = pid % a.n_tiles, mt_all = pid / a.n_tiles;
   const int grp = mt_all / a.tiles_per_group, mt = mt_all % a.tiles_per_group;
   const int m_lo = grp * a.Mg + mt * BM, m_end = (grp + 1) * a.Mg;
@@ -305,19 +310,23 @@ __global__ __launch_bounds__(256, OCC) void qgemm_kernel(const QG a) {
 #pragma unroll
     for (int j = 0; j < TM; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  fetch_x(0);
-  fetch_w(0);
-  for (int kt = 0; kt < nk; kt++) {
+  // this workgroup's share of the k steps (split-K: whole channel chunks for the halo form, whose image serves nine steps)
+  const int units = HALO ? KC : nk;
+  const int kt0 = (HALO ? 9 : 1) * (int)((int64_t)units * ksp / a.ksplit);
+  const int kt1 = (HALO ? 9 : 1) * (int)((int64_t)units * (ksp + 1) / a.ksplit);
+  fetch_x(HALO ? kt0 / 9 : kt0);
+  fetch_w(kt0);
+  for (int kt = kt0; kt < kt1; kt++) {
     const int tap = HALO ? kt % 9 : 0;
     __syncthreads();                         // the previous step's fragment reads are done
     if (!HALO || tap == 0) park_x();
     park_w();
     __syncthreads();
-    if (kt + 1 < nk) {                       // in flight under this step's MFMAs
+    if (kt + 1 < kt1) {                      // in flight under this step's MFMAs
       fetch_w(kt + 1);
       if (!HALO) fetch_x(kt + 1);
     }
-    if (HALO && tap == 6 && kt + 3 < nk) fetch_x(kt / 9 + 1);      // the next chunk's halo image: three taps of MFMAs ahead
+    if (HALO && tap == 6 && kt + 3 < kt1) fetch_x(kt / 9 + 1);     // the next chunk's halo image: three taps of MFMAs ahead
     int xrow[TM];
     if constexpr (HALO) {
       const int dy = a.sgn * (tap / 3 - 1), dx = a.sgn * (tap % 3 - 1);
@@ -362,7 +371,9 @@ __global__ __launch_bounds__(256, OCC) void qgemm_kernel(const QG a) {
   }
 
   // ---- epilogue: lane = pixel (lane & 15) of the 16-pixel tile, 4 consecutive channels 4 * (lane >> 4) + e ----------------------
-  const float den = MODE == 1 ? a.nlev * a.xlev : a.nlev;
+  const bool raw = a.ksplit > 1;                      // split-K: raw sums into this split's image
+  const float den = raw ? 1.0f : (MODE == 1 ? a.nlev * a.xlev : a.nlev);
+  float* const outp = raw ? a.part + (int64_t)ksp * a.out_elems : a.out;
   float bs[4][4], bq[4][4];                           // [tn][e]: this lane's sums over its TM pixels (forward statistics)
 #pragma unroll
   for (int tn = 0; tn < 4; tn++)
@@ -392,12 +403,12 @@ __global__ __launch_bounds__(256, OCC) void qgemm_kernel(const QG a) {
       f32x4 v = acc[tn][tm];
       v = (f32x4){v[0] / den, v[1] / den, v[2] / den, v[3] / den};
       if (ok) {
-        *reinterpret_cast<f32x4*>(a.out + orow + n) = v;
+        *reinterpret_cast<f32x4*>(outp + orow + n) = v;
         if (SCATTER) {
           const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-          if (z01) *reinterpret_cast<f32x4*>(a.out + orow + a.N + n) = z;
-          if (z10) *reinterpret_cast<f32x4*>(a.out + orow + (int64_t)a.Wo * a.N + n) = z;
-          if (z01 && z10) *reinterpret_cast<f32x4*>(a.out + orow + (int64_t)(a.Wo + 1) * a.N + n) = z;
+          if (z01) *reinterpret_cast<f32x4*>(outp + orow + a.N + n) = z;
+          if (z10) *reinterpret_cast<f32x4*>(outp + orow + (int64_t)a.Wo * a.N + n) = z;
+          if (z01 && z10) *reinterpret_cast<f32x4*>(outp + orow + (int64_t)(a.Wo + 1) * a.N + n) = z;
         }
 #pragma unroll
         for (int e = 0; e < 4; e++) { bs[tn][e] += v[e]; bq[tn][e] += v[e] * v[e]; }
@@ -811,6 +822,28 @@ __global__ __launch_bounds__(256) void qgemm_pack_kernel(const PackChunk c, floa
   }
 }
 
+// out = (part[0] + part[1] + ... in split order) / den, elementwise (float4): the closing pass of a split-K data gradient
+__global__ __launch_bounds__(256) void qgemm_ksplit_reduce_kernel(const float* __restrict__ part, int S, int64_t n4, int64_t stride,
+                                                                  float den, float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(part) + i);
+    for (int s2 = 1; s2 < S; s2++) v += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(part + s2 * stride) + i);
+    *(reinterpret_cast<f32x4*>(out) + i) = (f32x4){v[0] / den, v[1] / den, v[2] / den, v[3] / den};
+  }
+}
+
+// Split-K choice: `blocks` workgroups of `units` sequential k units each on `slots` resident workgroup slots.  Modelled time =
+// rounds x (units per split + 2 for a workgroup's prologue / epilogue); a split is taken when it saves a quarter (it costs a
+// closing pass over S + 1 images of the output).  The layers this finds: M = B H W of layer4 / layer3 with K = 9 C or 2048.
+constexpr int kMaxKSplit = 4;
+inline int pick_ksplit(int64_t blocks, int slots, int units) {
+  auto cost = [&](int S) { return (double)((blocks * S + slots - 1) / slots) * ((double)((units + S - 1) / S) + 2.0); };
+  int best = 1;
+  for (int S = 2; S <= kMaxKSplit && units / S >= 2; S++)
+    if (cost(S) < cost(best)) best = S;
+  return cost(best) <= 0.75 * cost(1) ? best : 1;
+}
+
 bool shape_ok(int B, int H, int W, int CIN, int COUT, int KS, int stride) {
   if (B < 1 || H < 1 || W < 1 || CIN < 64 || COUT < 64 || CIN % 64 || COUT % 64) return false;
   if (!((KS == 1 && (stride == 1 || stride == 2)) || (KS == 3 && (stride == 1 || stride == 2)))) return false;
@@ -826,9 +859,22 @@ int launch_g(QG a, hipStream_t st) {
   constexpr int BM = (4 / WN) * 16 * TM, BN = 64 * WN;
   a.tiles_per_group = (a.Mg + BM - 1) / BM;
   a.n_tiles = a.N / BN;
-  const int grid = a.groups * a.tiles_per_group * a.n_tiles;
-  hipLaunchKernelGGL((qgemm_kernel<WN, TM, MODE, WTR, KM, SCATTER, OCC, XI>), dim3(grid), dim3(256), 0, st, a);
-  const hipError_t e = hipGetLastError();
+  const int blocks = a.groups * a.tiles_per_group * a.n_tiles;
+  constexpr int KBh = (KM == 2 && MODE == 0) ? 32 : BK;
+  // k units per workgroup (the parity-class form: 1 to 4 taps, 2.25 on average)
+  const int units = KM == 2 ? a.CA / KBh : (KM == 1 ? 9 : (KM == 3 ? 2 : 1)) * (a.CA / BK);
+  a.ksplit = (a.part && !a.bn_part) ? pick_ksplit(blocks, 256 * OCC, units) : 1;
+  if (KM == 3 && a.ksplit > a.CA / BK) a.ksplit = 1;          // (a one-tap class must have a k unit for every split)
+  hipLaunchKernelGGL((qgemm_kernel<WN, TM, MODE, WTR, KM, SCATTER, OCC, XI>), dim3(blocks * a.ksplit), dim3(256), 0, st, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  if (a.ksplit > 1) {
+    const int64_t n4 = a.out_elems / 4;
+    const int gx = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(qgemm_ksplit_reduce_kernel, dim3(gx), dim3(256), 0, st, a.part, a.ksplit, n4, a.out_elems,
+                       MODE == 1 ? a.nlev * a.xlev : a.nlev, a.out);
+    e = hipGetLastError();
+  }
   return e == hipSuccess ? 0 : (int)e;
 }
 
@@ -937,8 +983,15 @@ int alignq_qconv_fwd(const void* x, const void* w_bins, float* y, int B, int H_i
   return x_levels != 0.0f ? launch_g_tiles<1, false, 0, false>(a, st) : launch_g_tiles<0, false, 0, false>(a, st);
 }
 
+size_t alignq_qconv_dgrad_ws_bytes(int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride) {
+  if (!shape_ok(B, H_in, W_in, CIN, COUT, KS, stride)) return 0;
+  // split-K is for the layers with few row tiles: their dx is small (layer3 / layer4 of ResNet-50 at B = 56: 2.8 - 11 MB)
+  const size_t out = (size_t)B * H_in * W_in * CIN * sizeof(float);
+  return out <= ((size_t)32 << 20) ? kMaxKSplit * out : 0;
+}
+
 int alignq_qconv_dgrad(const float* dy, const void* w_bins, float* dx, int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride,
-                       int w_bit, void* stream) {
+                       int w_bit, void* ws, void* stream) {
   if (!dy || !w_bins || !dx || w_bit < 1 || w_bit > 8) return ALIGNQ_EINVAL;
   if (!shape_ok(B, H_in, W_in, CIN, COUT, KS, stride)) return ALIGNQ_EUNSUPPORTED;
   if (KS == 3 && stride != 1 && ((H_in | W_in) & 1)) return ALIGNQ_EUNSUPPORTED;       // (the parity classes need even H_in, W_in)
@@ -952,6 +1005,8 @@ int alignq_qconv_dgrad(const float* dy, const void* w_bins, float* dx, int B, in
   a.Ho = H_in; a.Wo = W_in;
   a.nlev = (float)((1 << w_bit) - 1); a.xlev = 0.f;
   a.bn_part = nullptr;
+  a.out_elems = (int64_t)B * H_in * W_in * CIN;
+  a.part = (ws && alignq_qconv_dgrad_ws_bytes(B, H_in, W_in, CIN, COUT, KS, stride)) ? (float*)ws : nullptr;
   hipStream_t st = (hipStream_t)stream;
   if (stride == 2 && KS == 3) {      // rows = the half grid, once per parity class of the input pixels (see KM 3)
     a.groups = 4;

@@ -1009,8 +1009,10 @@ class QConvGemmFn(torch.autograd.Function):
                 dx = torch.nn.grad.conv2d_input((B, CIN, H, W), w, gy, stride=s, padding=1)
             else:
                 dx = torch.empty((B, CIN, H, W), dtype=torch.float32, device=w.device, memory_format=cl)
-                L.check(lib.alignq_qconv_dgrad(L.ptr(gy), L.ptr(wb), L.ptr(dx), B, H, W, CIN, COUT, ks, s, w_bit, L.stream_ptr()),
-                        "alignq_qconv_dgrad")
+                nws = lib.alignq_qconv_dgrad_ws_bytes(B, H, W, CIN, COUT, ks, s)        # split-K scratch of the small-M layers
+                wsd = _ws(nws, w.device) if nws else None
+                L.check(lib.alignq_qconv_dgrad(L.ptr(gy), L.ptr(wb), L.ptr(dx), B, H, W, CIN, COUT, ks, s, w_bit, L.ptr(wsd),
+                                               L.stream_ptr()), "alignq_qconv_dgrad")
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
             ws = _ws(lib.alignq_qconv_wgrad_ws_bytes(B, H, W, CIN, COUT, ks, s), w.device)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALIGNQ_ABI_VERSION 16
+#define ALIGNQ_ABI_VERSION 17
 
 #define ALIGNQ_FORMULA_ADMM 0
 #define ALIGNQ_FORMULA_CDF 1
@@ -363,8 +363,12 @@ int alignq_qconv_fwd(const void* x, const void* w_bins, float* y, int B, int H_i
  * instead of fp32 values; 0: fp32.                                                                                              */
 /* data gradient dx [B, H_in, W_in, CIN] from dy [B, H_out, W_out, COUT] and the filter's bf16 bins (every element of dx is written;
  * the 3x3 stride-2 form runs per parity class of the input pixel and needs even H_in and W_in, else ALIGNQ_EUNSUPPORTED)          */
+/* ws (or NULL; alignq_qconv_dgrad_ws_bytes, 0 = none needed): scratch for split-K - layers with few row tiles and a long
+ * contraction (layer3 / layer4 at B = 56) run 2 to 4 workgroups per tile over disjoint k ranges and a closing pass adds their raw
+ * sums in split order (deterministic); without ws every tile is one workgroup.                                                     */
+size_t alignq_qconv_dgrad_ws_bytes(int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride);
 int alignq_qconv_dgrad(const float* dy, const void* w_bins, float* dx, int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride,
-                       int w_bit, void* stream);
+                       int w_bit, void* ws, void* stream);
 /* filter gradient dW [COUT, KS, KS, CIN] (the layout of wt): deterministic split-K slabs in ws (alignq_qconv_wgrad_ws_bytes),
  * summed in slab order - by this call (dw != NULL, n_slabs_out == NULL) or later by alignq_conv3x3_wgrad_reduce_multi
  * (n_slabs_out receives the slab count; n_elem = COUT * KS * KS * CIN).  x_levels as in alignq_qconv_fwd.                       */

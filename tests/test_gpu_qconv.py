@@ -104,6 +104,36 @@ def test_qconv3x3_stride2_data_gradient_runs_on_the_parity_class_kernel(dev, mon
     _check(dev, 3, 64, 64, 9, 3, 2, 8, False, seed=5)          # odd grid: torch's data gradient, same bars
 
 
+@pytest.mark.parametrize("cin,cout,H,ks,stride", [(512, 2048, 7, 1, 1), (512, 512, 7, 3, 1), (512, 1024, 14, 1, 2), (256, 256, 14, 3, 1),
+                                                  (512, 512, 14, 3, 2), (64, 64, 56, 3, 1)])
+def test_qconv_data_gradient_split_k_matches_one_workgroup_per_tile(dev, cin, cout, H, ks, stride):
+    """alignq_qconv_dgrad with its scratch (layers with few row tiles and a long contraction: 2-4 workgroups per tile over disjoint
+    k ranges + a closing pass that adds the raw sums in split order and divides) against the same call without it, B = 56: every
+    form (1x1, scattering 1x1 stride 2, halo 3x3, parity-class 3x3 stride 2).  Same products, another grouping of the fp32 sums:
+    equal to 4e-6 of the largest element (each is within 2e-6 of fp64, _check); the last shape takes no split and is bit-equal.
+    Deterministic: a second call reproduces the first bit for bit."""
+    from alignq_amd import _lib as L, ops
+    lib = L.load()
+    B, Ho = 56, (H - 1) // stride + 1
+    w = _wq(cout, cin, ks, 8, dev, 3)
+    wb = ops.pack_filter_bins([w], 8)[0][0]
+    gy = (torch.randn(B, cout, Ho, Ho, generator=torch.Generator().manual_seed(4)) * 1e-3).to(dev).contiguous(memory_format=CL)
+    nws = lib.alignq_qconv_dgrad_ws_bytes(B, H, H, cin, cout, ks, stride)
+    assert (nws > 0) == ((cin, H, ks) != (64, 56, 3))          # (layer1's 45 MB data gradient has 3136 row tiles: no scratch offered)
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev) if nws else None
+    outs = []
+    for scratch in (ws, None, ws):
+        dx = torch.full((B, cin, H, H), float("nan"), device=dev).contiguous(memory_format=CL)
+        L.check(lib.alignq_qconv_dgrad(L.ptr(gy), L.ptr(wb), L.ptr(dx), B, H, H, cin, cout, ks, stride, 8, L.ptr(scratch), None), "dgrad")
+        outs.append(dx)
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[2])
+    scale = float(outs[1].abs().max())
+    assert float((outs[0] - outs[1]).abs().max()) <= 4e-6 * scale
+    if (cin, H, ks) == (64, 56, 3):
+        assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("cin,cout,H,ks,stride,k", [(256, 64, 56, 1, 1, 8), (512, 1024, 28, 1, 2, 4), (256, 256, 14, 3, 1, 2),
                                                     (2048, 512, 7, 1, 1, 8)])
 def test_qconv_full_batch_of_config5(dev, cin, cout, H, ks, stride, k):
@@ -176,7 +206,7 @@ def test_qconv_rejects_what_it_does_not_take(dev):
     assert lib.alignq_qconv_supported(2, 8, 8, 64, 64, 5, 1) == 0
     assert lib.alignq_qconv_supported(2, 8, 8, 64, 64, 3, 3) == 0
     x = torch.zeros(2, 8, 8, 64, device=dev)
-    assert lib.alignq_qconv_dgrad(L.ptr(x), L.ptr(x), L.ptr(x), 2, 7, 8, 64, 64, 3, 2, 8, None) == -2       # ALIGNQ_EUNSUPPORTED: odd grid
+    assert lib.alignq_qconv_dgrad(L.ptr(x), L.ptr(x), L.ptr(x), 2, 7, 8, 64, 64, 3, 2, 8, None, None) == -2       # ALIGNQ_EUNSUPPORTED: odd grid
     assert lib.alignq_qconv_fwd(L.ptr(x), L.ptr(x), L.ptr(x), 2, 8, 8, 64, 64, 1, 1, 9, 0.0, 0, 1, None, None) == -1    # w_bit
     assert lib.alignq_qconv_fwd(L.ptr(x), L.ptr(x), L.ptr(x), 2, 8, 8, 64, 64, 1, 1, 8, 0.0, 2, 1, None, None) == -1    # indices need x_levels
 

@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--no-ref", action="store_true")
     ap.add_argument("--i16", action="store_true", help="level inputs as int16 indices (N2) instead of fp32 values")
+    ap.add_argument("--no-ksplit", action="store_true", help="data gradient without the split-K scratch (one workgroup per tile)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.backends.cudnn.benchmark = True
@@ -81,11 +82,10 @@ def main():
         xin = [torch.round(x * 255.0).to(torch.int16).contiguous(memory_format=CL) for x in xs] if xb else xs
         f = lambda i: L.check(lib.alignq_qconv_fwd(p(xin[i]), p(wfw), p(ys[i]), B, H, H, cin, cout, ks, s, 8, xl, xb, 1, None, st), "fwd")
         t_f = time_rot(f, R)
-        if ks == 3 and s == 2:
-            t_d = float("nan")
-        else:
-            d = lambda i: L.check(lib.alignq_qconv_dgrad(p(gys[i]), p(wbf), p(dxs[i]), B, H, H, cin, cout, ks, s, 8, st), "dgrad")
-            t_d = time_rot(d, R)
+        nwd = 0 if a.no_ksplit else lib.alignq_qconv_dgrad_ws_bytes(B, H, H, cin, cout, ks, s)
+        wsd = torch.empty(nwd, dtype=torch.uint8, device=dev) if nwd else None
+        d = lambda i: L.check(lib.alignq_qconv_dgrad(p(gys[i]), p(wbf), p(dxs[i]), B, H, H, cin, cout, ks, s, 8, p(wsd), st), "dgrad")
+        t_d = time_rot(d, R)
         import ctypes
         ns = ctypes.c_int(0)
         g = lambda i: L.check(lib.alignq_qconv_wgrad(p(xin[i]), p(gys[i]), None, p(ws), B, H, H, cin, cout, ks, s, xl, xb, ctypes.byref(ns), st), "wgrad")
