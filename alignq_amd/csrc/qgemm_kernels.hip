@@ -844,6 +844,190 @@ inline int pick_ksplit(int64_t blocks, int slots, int units) {
   return cost(best) <= 0.75 * cost(1) ? best : 1;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The stem of the Office ResNet-50 (dann_office/model/resnet.py:193-195: Conv2d_Q(3, 64, kernel_size = 7, stride = 2, padding = 3)):
+// y[m][co] = (1 / n) sum_{ky, j} bins[co][ky][j] * x(m; ky, j),  j = kx * 3 + c < 21.  Channels-last x makes the 21 values of one
+// filter row CONTIGUOUS in memory ((2 ow - 3) * 3 + j of input row 2 oh - 3 + ky), so the contraction index is laid out as
+// k = ky * 24 + j (three zero-bin pads per filter row, 168 -> 192 = six MFMA k steps): a lane's B fragment - 8 consecutive k of ONE
+// pixel - is then ONE 32-byte piece of one input row, fetched straight from global memory as two dword-aligned 16-byte loads (the
+// 16 pixels of a wave's tile sit 24 B apart; the input is 34 MB and lives in L2); no im2col image, no LDS for the pixel side.  The
+// three values behind j = 20 belong to the pixel's right neighbours and meet zero bins.  Each value is split into three exact bf16
+// terms in registers; the filter's bins [64][192] stay in LDS for the whole workgroup.  A wave owns 16-pixel tiles (all 64
+// channels, 4 accumulators) and walks over them; four workgroups per CU cover the gather's latency.  Measured (B = 56, 224 x 224):
+// 112 us against MIOpen's 159-207; the counters say vector issue (753 instructions per tile at 4 cycles each = 54 us of it, 290 of
+// them the split) + 21 us of MFMA, not memory.  Epilogue: y = sum / n, float4
+// stores; per-workgroup per-channel {sum y, sum y^2} in double for the batch-norm that follows ([groups][workgroups per group][64][2]).
+struct QS {
+  const float* x; const u16* w; float* y;
+  int H, W, Ho, Wo;            // input / output grids
+  int tiles_pg, wg_pg;         // 16-pixel tiles per group, workgroups per group (grid = groups * wg_pg)
+  int Mg;                      // output pixels per group
+  float nlev;
+  double* bn_part;
+  uint64_t magic_w, magic_h;   // ceil(2^40 / Wo), ceil(2^40 / Ho)
+};
+constexpr int kStemK = 147, kStemLDW = 208;      // (192 k per filter) 416-byte rows (= 32 mod 64): conflict-free ds_read_b128 (see LDX above)
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));      // a dword-aligned 16-byte global load
+
+// the 8 values of k group g of a BORDER pixel, every element's bounds checked.  Not inlined: the compiler otherwise turns the rare
+// path into straight-line predicated code that every tile executes (80 of 149 vector instructions per step).
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+__device__ __attribute__((noinline)) f32x8 stem_border8(const char* xbytes, int org, int oh, int ow, int H, int W, int g) {
+  const int ky = g / 3, jb = 8 * (g - 3 * ky);
+  f32x8 v;
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    const int j = jb + e, ih = 2 * oh - 3 + ky, iw = 2 * ow - 3 + j / 3;
+    const bool in = g < 21 && j < 21 && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+    const float ld = *reinterpret_cast<const float*>(xbytes + (in ? (unsigned)(org + ky * W * 3 + j) * 4u : 0u));
+    v[e] = in ? ld : 0.f;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(256, 4) void qstem7_fwd_kernel(const QS a) {
+  __shared__ __attribute__((aligned(16))) u16 Ws[64 * kStemLDW];
+  __shared__ float red[64][16][2];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int grp = blockIdx.x / a.wg_pg, wg = blockIdx.x % a.wg_pg;
+  // the filter's 64 x 147 bins into the padded [64][192] image: 19 dword loads per thread, ALL in flight before the first is used (a
+  // loop of single 2-byte loads waited for each one: ~48 L2 round trips = 70 us per workgroup, more than the rest of the kernel)
+  {
+    constexpr int ND = 64 * kStemK / 2, NL = (ND + 255) / 256;          // 4704 dwords
+    unsigned wd[NL];
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const int d = tid + 256 * i;
+      wd[i] = reinterpret_cast<const unsigned*>(a.w)[d < ND ? d : 0];
+    }
+    for (int i = tid; i < 64 * kStemLDW / 2; i += 256) reinterpret_cast<unsigned*>(Ws)[i] = 0u;       // pads (and everything else) zero
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const int d = tid + 256 * i;
+      if (d < ND) {
+#pragma unroll
+        for (int hlf = 0; hlf < 2; hlf++) {
+          const int f = 2 * d + hlf, co = f / kStemK, kk = f - co * kStemK, ky = kk / 21, j = kk - 21 * ky;
+          Ws[co * kStemLDW + ky * 24 + j] = (u16)(hlf ? wd[i] >> 16 : wd[i] & 0xffffu);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int rs = a.W * 3;
+  const int m_base = grp * a.Mg;
+  const char* const xbytes = reinterpret_cast<const char*>(a.x);
+  const float rn = 1.0f / a.nlev;
+  float bs[4][4], bq[4][4];
+#pragma unroll
+  for (int tn = 0; tn < 4; tn++)
+#pragma unroll
+    for (int e = 0; e < 4; e++) { bs[tn][e] = 0.f; bq[tn][e] = 0.f; }
+  for (int t = wg * 4 + wv; t < a.tiles_pg; t += a.wg_pg * 4) {
+    const int ml = t * 16 + fr;
+    const int m = m_base + (ml < a.Mg ? ml : a.Mg - 1);       // (stem7_ok: every index below 2^30)
+    // m = (img * Ho + oh) * Wo + ow by multiplication (q = m * ceil(2^40 / d) >> 40 is exact while m * d < 2^40: stem7_ok)
+    const int r = (int)(((uint64_t)(unsigned)m * a.magic_w) >> 40), ow = m - r * a.Wo;
+    const int img = (int)(((uint64_t)(unsigned)r * a.magic_h) >> 40), oh = r - img * a.Ho;
+    // interior: the patch and the three elements read behind each of its rows lie inside the image's rows
+    const bool inner = oh >= 2 && 2 * oh + 3 < a.H && ow >= 2 && 2 * ow + 4 < a.W;
+    const int org = ((img * a.H + 2 * oh - 3) * a.W + (2 * ow - 3)) * 3;
+    const bool plain = __builtin_amdgcn_ballot_w64(!inner) == 0;
+    int fgv = fg;
+    asm volatile("" : "+v"(fgv));      // (the per-step tap coordinates are re-derived per tile: hoisted out of the tile loop they spill)
+    // the 8 values of step ks: k = 32 ks + 8 fg + e = 24 ky + jb + e
+#define STEM_LOAD(KS, V)                                                                                                          \
+    {                                                                                                                             \
+      const int g = 4 * (KS) + fgv, ky = g / 3, jb = 8 * (g - 3 * ky);                                                           \
+      if (plain) {                                                                                                                \
+        const unsigned o = g < 21 ? (unsigned)(org + ky * rs + jb) * 4u : 0u;      /* (groups 21..23: zero bins) */               \
+        const f32x4 v0 = *reinterpret_cast<const f32x4u*>(xbytes + o), v1 = *reinterpret_cast<const f32x4u*>(xbytes + o + 16);   \
+        V[0] = v0[0]; V[1] = v0[1]; V[2] = v0[2]; V[3] = v0[3]; V[4] = v1[0]; V[5] = v1[1]; V[6] = v1[2]; V[7] = v1[3];           \
+      } else {      /* a border tile (3 of 112 rows, the first and last tile of a row) */                                         \
+        const f32x8 b8 = stem_border8(xbytes, org, oh, ow, a.H, a.W, g);                                                          \
+        _Pragma("unroll") for (int e = 0; e < 8; e++) V[e] = b8[e];                                                               \
+      }                                                                                                                           \
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int tn = 0; tn < 4; tn++) acc[tn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float cur[8], nxt[8];
+    STEM_LOAD(0, cur)
+#pragma unroll
+    for (int ks = 0; ks < 6; ks++) {
+      if (ks < 5) STEM_LOAD(ks + 1, nxt)              // in flight under this step's splits and MFMAs
+      s16x4 h0, m0, l0, h1, m1, l1;
+      split3((f32x4){cur[0], cur[1], cur[2], cur[3]}, h0, m0, l0);
+      split3((f32x4){cur[4], cur[5], cur[6], cur[7]}, h1, m1, l1);
+      const s16x8 xh = join8(h0, h1), xm = join8(m0, m1), xl = join8(l0, l1);
+#pragma unroll
+      for (int tn = 0; tn < 4; tn++) {
+        const s16x8 wf = *reinterpret_cast<const s16x8*>(Ws + (tn * 16 + fr) * kStemLDW + 32 * ks + 8 * fg);
+        acc[tn] = mfma16<false>(wf, xl, acc[tn]);       // smallest term first
+        acc[tn] = mfma16<false>(wf, xm, acc[tn]);
+        acc[tn] = mfma16<false>(wf, xh, acc[tn]);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; e++) cur[e] = nxt[e];
+      __builtin_amdgcn_sched_barrier(0);      // (else every step's fragments and split terms are formed up front: 250+ registers)
+    }
+#undef STEM_LOAD
+    if (ml < a.Mg) {
+      float* yo = a.y + (int64_t)(m_base + ml) * 64 + 4 * fg;
+#pragma unroll
+      for (int tn = 0; tn < 4; tn++) {
+        // sum / n as q = s * (1/n) with one residual correction (within an ulp of the quotient; a full division is ten vector
+        // instructions per value, 160 per tile in a kernel that is short of issue slots)
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const float q = acc[tn][e] * rn;
+          v[e] = __fmaf_rn(__fmaf_rn(-q, a.nlev, acc[tn][e]), rn, q);
+        }
+        *reinterpret_cast<f32x4*>(yo + tn * 16) = v;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { bs[tn][e] += v[e]; bq[tn][e] += v[e] * v[e]; }
+      }
+    }
+  }
+  if (a.bn_part) {      // channel ch = tn * 16 + 4 fg + e: this lane's sums over its pixels; 16 lanes (fr) x 4 waves per channel
+#pragma unroll
+    for (int w2 = 0; w2 < 4; w2++) {
+      __syncthreads();
+      if (wv == w2) {
+#pragma unroll
+        for (int tn = 0; tn < 4; tn++)
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const int ch = tn * 16 + 4 * fg + e;
+            if (w2 == 0) { red[ch][fr][0] = bs[tn][e]; red[ch][fr][1] = bq[tn][e]; }
+            else { red[ch][fr][0] += bs[tn][e]; red[ch][fr][1] += bq[tn][e]; }
+          }
+      }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      double s0 = 0, s1 = 0;
+#pragma unroll
+      for (int j = 0; j < 16; j++) { s0 += (double)red[tid][j][0]; s1 += (double)red[tid][j][1]; }
+      double* p = a.bn_part + ((int64_t)blockIdx.x * 64 + tid) * 2;
+      p[0] = s0;
+      p[1] = s1;
+    }
+  }
+}
+
+inline bool stem7_ok(int B, int H, int W, int groups) {
+  return B >= 1 && groups >= 1 && B % groups == 0 && H >= 8 && W >= 8 && H <= 4096 && W <= 4096 && (int64_t)B * H * W * 3 < ((int64_t)1 << 30);
+}
+inline int stem7_wgs(int64_t Mg) {          // workgroups per group: <= 512, every wave at least one tile
+  const int64_t tiles = (Mg + 15) / 16;
+  const int64_t w = (tiles + 3) / 4;
+  return (int)(w < 512 ? w : 512);
+}
+
 bool shape_ok(int B, int H, int W, int CIN, int COUT, int KS, int stride) {
   if (B < 1 || H < 1 || W < 1 || CIN < 64 || COUT < 64 || CIN % 64 || COUT % 64) return false;
   if (!((KS == 1 && (stride == 1 || stride == 2)) || (KS == 3 && (stride == 1 || stride == 2)))) return false;
@@ -981,6 +1165,31 @@ int alignq_qconv_fwd(const void* x, const void* w_bins, float* y, int B, int H_i
     return x_levels != 0.0f ? launch_g_tiles<1, false, 2, false>(a, st) : launch_g_tiles<0, false, 2, false>(a, st);
   if (KS == 3) return x_levels != 0.0f ? launch_g_tiles<1, false, 1, false>(a, st) : launch_g_tiles<0, false, 1, false>(a, st);
   return x_levels != 0.0f ? launch_g_tiles<1, false, 0, false>(a, st) : launch_g_tiles<0, false, 0, false>(a, st);
+}
+
+int alignq_qconv_stem7_bn_parts(int B, int H_in, int W_in, int groups) {
+  if (!stem7_ok(B, H_in, W_in, groups)) return 0;
+  const int Ho = (H_in - 1) / 2 + 1, Wo = (W_in - 1) / 2 + 1;
+  return stem7_wgs((int64_t)(B / groups) * Ho * Wo);
+}
+
+int alignq_qconv_stem7_fwd(const float* x, const void* w_bins, float* y, int B, int H_in, int W_in, int w_bit, int groups,
+                           double* bn_part, void* stream) {
+  if (!x || !w_bins || !y || w_bit < 1 || w_bit > 8) return ALIGNQ_EINVAL;
+  if (!stem7_ok(B, H_in, W_in, groups)) return ALIGNQ_EUNSUPPORTED;
+  QS a{};
+  a.x = x; a.w = (const u16*)w_bins; a.y = y;
+  a.H = H_in; a.W = W_in; a.Ho = (H_in - 1) / 2 + 1; a.Wo = (W_in - 1) / 2 + 1;
+  a.Mg = (B / groups) * a.Ho * a.Wo;
+  a.tiles_pg = (a.Mg + 15) / 16;
+  a.wg_pg = stem7_wgs(a.Mg);
+  a.nlev = (float)((1 << w_bit) - 1);
+  a.bn_part = bn_part;
+  a.magic_w = (((uint64_t)1 << 40) + a.Wo - 1) / a.Wo;
+  a.magic_h = (((uint64_t)1 << 40) + a.Ho - 1) / a.Ho;
+  hipLaunchKernelGGL(qstem7_fwd_kernel, dim3(groups * a.wg_pg), dim3(256), 0, (hipStream_t)stream, a);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
 }
 
 size_t alignq_qconv_dgrad_ws_bytes(int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride) {

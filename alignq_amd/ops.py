@@ -1029,6 +1029,65 @@ class QConvGemmFn(torch.autograd.Function):
         return dx, dw, None, None, None, None, None, None, None
 
 
+def qconv_stem7_supported(x, w, stride, padding, dilation, groups, bias, w_bit) -> bool:
+    """The Office ResNet-50's stem (dann_office/model/resnet.py:193-195: Conv2d_Q(3, 64, kernel_size=7, stride=2, padding=3)) as
+    alignq_qconv_stem7_fwd takes it: channels-last fp32 image that needs no gradient, <= 8-bit quantised filter."""
+    if bias is not None or groups != 1 or not (1 <= w_bit <= 8) or x.requires_grad:
+        return False
+    if tuple(stride) != (2, 2) or tuple(padding) != (3, 3) or tuple(dilation) != (1, 1):
+        return False
+    if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and w.dtype == torch.float32 and w.is_cuda):
+        return False
+    B, C, H, W = x.shape
+    cl = torch.channels_last
+    return (C == 3 and tuple(w.shape) == (64, 3, 7, 7) and H >= 8 and W >= 8 and x.is_contiguous(memory_format=cl)
+            and w.is_contiguous(memory_format=cl) and bool(L.load().alignq_qconv_stem7_bn_parts(B, H, W, 1)))
+
+
+class QConvStem7Fn(torch.autograd.Function):
+    """F.conv2d(image, weight_q, None, 2, 3) of the Office stem on alignq_qconv_stem7_fwd (csrc/qgemm_kernels.hip: the filter's integer
+    bins times three exact bf16 terms of the image, gathered straight from global memory); batch-norm statistics of the output in
+    the epilogue (bn_stats).  The image needs no gradient; the filter gradient is alignq_qconv_stem7_wgrad's."""
+
+    @staticmethod
+    def forward(ctx, x, w, w_bit, groups=1, bn_stats=False, bins=None):
+        B, _, H, W = x.shape
+        lib = L.load()
+        if bins is None:
+            bins = pack_filter_bins([w], w_bit)[0]
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty((B, 64, Ho, Wo), dtype=torch.float32, device=w.device, memory_format=torch.channels_last)
+        part = None
+        if bn_stats:
+            n_parts = lib.alignq_qconv_stem7_bn_parts(B, H, W, int(groups))
+            part = torch.empty(int(groups), n_parts, 64, 2, dtype=torch.float64, device=w.device)
+            QConvGemmFn._mailbox = (part, n_parts)
+        L.check(lib.alignq_qconv_stem7_fwd(L.ptr(x), L.ptr(bins[0]), L.ptr(y), B, H, W, int(w_bit), int(groups if bn_stats else 1),
+                                           L.ptr(part), L.stream_ptr()), "alignq_qconv_stem7_fwd")
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def apply_with_stats(x, w, w_bit, groups=1, bins=None):
+        """apply(...) that also leaves y._alignq_bnq_part (see QConvGemmFn.apply_with_stats)"""
+        QConvGemmFn._mailbox = None
+        y = QConvStem7Fn.apply(x, w, w_bit, groups, True, bins)
+        if QConvGemmFn._mailbox is not None:
+            y._alignq_bnq_part = QConvGemmFn._mailbox + (int(groups),)
+            QConvGemmFn._mailbox = None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        dw = None
+        if ctx.needs_input_grad[1]:
+            if not gy.is_contiguous(memory_format=torch.channels_last):
+                gy = gy.contiguous(memory_format=torch.channels_last)
+            dw = torch.ops.aten.convolution_backward(gy, x, w, None, (2, 2), (3, 3), (1, 1), False, (0, 0), 1, (False, True, False))[1]
+        return None, dw, None, None, None, None
+
+
 def qconv_stem_supported(x, w, stride, padding, dilation, groups, bias, w_bit) -> bool:
     """The stem convolution alignq_conv_stem_nhwc_fwd implements: 3 -> 16 channels, 3x3 / stride 1 / padding 1, width 32,
     channels-last fp32 input that needs no gradient, <= 8-bit quantised filter."""

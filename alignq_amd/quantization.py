@@ -288,6 +288,12 @@ def make_namespace(tree: str) -> types.SimpleNamespace:
                         return ops.QConvGenFn.apply_with_stats(input, weight_q, self.quantize_fn.w_bit, self.padding[0])
                     if ops.qconv_stem_supported(*args):
                         return ops.QConvStemFn.apply_with_stats(input, weight_q, self.quantize_fn.w_bit)
+                    if ops.qconv_stem7_supported(*args):     # the Office stem (7x7, stride 2, 3 -> 64 channels)
+                        bins = self.quantize_fn.take_bins(weight_q)
+                        if getattr(self, "emit_bn_stats", False):
+                            from . import fused
+                            return ops.QConvStem7Fn.apply_with_stats(input, weight_q, self.quantize_fn.w_bit, fused.conv_groups(), bins)
+                        return ops.QConvStem7Fn.apply(input, weight_q, self.quantize_fn.w_bit, 1, False, bins)
                     if ops.qconv_gemm_supported(*args):      # the ResNet-50 shapes: exact-product GEMMs (csrc/qgemm_kernels.hip)
                         bins = self.quantize_fn.take_bins(weight_q)
                         if getattr(self, "emit_bn_stats", False):     # the batch-norm behind this convolution takes its statistics

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALIGNQ_ABI_VERSION 17
+#define ALIGNQ_ABI_VERSION 18
 
 #define ALIGNQ_FORMULA_ADMM 0
 #define ALIGNQ_FORMULA_CDF 1
@@ -363,6 +363,13 @@ int alignq_qconv_fwd(const void* x, const void* w_bins, float* y, int B, int H_i
  * instead of fp32 values; 0: fp32.                                                                                              */
 /* data gradient dx [B, H_in, W_in, CIN] from dy [B, H_out, W_out, COUT] and the filter's bf16 bins (every element of dx is written;
  * the 3x3 stride-2 form runs per parity class of the input pixel and needs even H_in and W_in, else ALIGNQ_EUNSUPPORTED)          */
+/* The Office ResNet-50's stem, Conv2d_Q(3, 64, kernel_size = 7, stride = 2, padding = 3, bias = False) (dann_office/model/resnet.py:193-195):
+ * x [B, H_in, W_in, 3] channels-last fp32 (the image: no data gradient), w_bins = the filter's bf16 bins [64][7][7][3] from
+ * alignq_qconv_pack_weights, y [B, H_out, W_out, 64]; three exact bf16 terms of x, fp32 accumulation (as alignq_qconv_fwd).
+ * bn_part (or NULL): [groups][alignq_qconv_stem7_bn_parts][64][2] doubles {sum y, sum y^2} for alignq_bnq_fwd_parts.              */
+int alignq_qconv_stem7_bn_parts(int B, int H_in, int W_in, int groups);
+int alignq_qconv_stem7_fwd(const float* x, const void* w_bins, float* y, int B, int H_in, int W_in, int w_bit, int groups,
+                           double* bn_part, void* stream);
 /* ws (or NULL; alignq_qconv_dgrad_ws_bytes, 0 = none needed): scratch for split-K - layers with few row tiles and a long
  * contraction (layer3 / layer4 at B = 56) run 2 to 4 workgroups per tile over disjoint k ranges and a closing pass adds their raw
  * sums in split order (deterministic); without ws every tile is one workgroup.                                                     */

@@ -291,3 +291,37 @@ def test_filter_bins_pack_is_exact(dev):
         assert torch.equal(bf.view(torch.bfloat16).float(), want) and torch.equal(hf.view(torch.float16).float(), want)
     many = ops.pack_filter_bins([ws[0]] * 70, 8)          # more filters than one launch takes
     assert all(torch.equal(b.view(torch.bfloat16).float(), torch.round(ws[0] * 255)) for b, _ in many)
+
+
+@pytest.mark.parametrize("B,H,W,k", [(3, 224, 224, 8), (2, 64, 48, 8), (4, 37, 41, 4), (2, 8, 8, 2), (56, 32, 32, 8)])
+def test_qconv_stem7_matches_fp64_and_leaves_the_batch_norm_sums(dev, B, H, W, k):
+    """The Office stem Conv2d_Q(3, 64, 7, stride 2, padding 3) (dann_office/model/resnet.py:193-195) on alignq_qconv_stem7_fwd:
+    against fp64 (bar: MIOpen's own fp32 error or 2e-6 of the largest output), borders (odd sizes, an 8 x 8 image whose every
+    pixel is a border pixel), the epilogue's per-workgroup {sum y, sum y^2} for 1 and 2 batch slices against the column sums of y,
+    and the filter gradient through the Function against fp64."""
+    from alignq_amd import _lib as L, ops
+    lib = L.load()
+    g = torch.Generator().manual_seed(B + H + W)
+    x = (torch.randn(B, 3, H, W, generator=g) * 1.7).to(dev).contiguous(memory_format=CL)
+    wq = _wq(64, 3, 7, k, dev, 9).requires_grad_(True)
+    assert ops.qconv_stem7_supported(x, wq, (2, 2), (3, 3), (1, 1), 1, None, k)
+    yd = torch.nn.functional.conv2d(x.double(), wq.detach().double(), stride=2, padding=3)
+    y32 = torch.nn.functional.conv2d(x, wq.detach(), stride=2, padding=3)
+    for groups in ((1, 2) if B % 2 == 0 else (1,)):
+        y = ops.QConvStem7Fn.apply_with_stats(x, wq, k, groups)
+        assert y.shape == yd.shape and y.is_contiguous(memory_format=CL)
+        err, floor = float((y.detach() - yd).abs().max()), 2e-6 * float(yd.abs().max())
+        assert err <= max(float((y32 - yd).abs().max()), floor), ("fwd", err, floor)
+        part, n_parts, gr = y._alignq_bnq_part
+        assert gr == groups and tuple(part.shape) == (groups, n_parts, 64, 2)
+        ys = y.detach().double().reshape(groups, B // groups, 64, -1)
+        want = torch.stack([ys.sum(dim=(1, 3)), (ys * ys).sum(dim=(1, 3))], dim=-1)          # [groups][64][2]
+        got = part.sum(dim=1)
+        assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max()) + 1e-9
+    gy = (torch.randn(y.shape, generator=g) * 1e-3).to(dev).contiguous(memory_format=CL)
+    y.backward(gy)
+    wd = wq.detach().double().requires_grad_(True)
+    torch.nn.functional.conv2d(x.double(), wd, stride=2, padding=3).backward(gy.double())
+    dw32 = torch.ops.aten.convolution_backward(gy, x, wq.detach(), None, (2, 2), (3, 3), (1, 1), False, (0, 0), 1, (False, True, False))[1]
+    err, floor = float((wq.grad - wd.grad).abs().max()), 2e-6 * float(wd.grad.abs().max())
+    assert err <= max(float((dw32 - wd.grad).abs().max()), floor), ("wgrad", err, floor)
