@@ -48,27 +48,32 @@ __device__ __forceinline__ f32x4 mfma16(s16x8 a, s16x8 b, f32x4 c) {
   else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// exact three-way split of four floats: v == hi + mid + lo
+// exact three-way split of four floats: v == hi + mid + lo.  Two values per v_cvt_pk_bf16_f32 and per v_pk_add_f32 (round 5: the
+// element-wise form compiled to 26 vector instructions per four values, this one to 20 - the same bits; these kernels are
+// bound by vector issue, a wave64 instruction holding its SIMD for four cycles)
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_bf16x2(f32x2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); }
+__device__ __forceinline__ f32x2 bf16x2_as_f32(unsigned b) {
+  return (f32x2){__builtin_bit_cast(float, b << 16), __builtin_bit_cast(float, b & 0xffff0000u)};
+}
 __device__ __forceinline__ void split3(const f32x4 v, s16x4& h, s16x4& m, s16x4& l) {
-  bf16x4 h4, m4, l4;
-#pragma unroll
-  for (int e = 0; e < 4; e++) {
-    const __bf16 hi = (__bf16)v[e];
-    const float r1 = v[e] - (float)hi;
-    const __bf16 mi = (__bf16)r1;
-    h4[e] = hi; m4[e] = mi; l4[e] = (__bf16)(r1 - (float)mi);
-  }
-  h = __builtin_bit_cast(s16x4, h4); m = __builtin_bit_cast(s16x4, m4); l = __builtin_bit_cast(s16x4, l4);
+  const f32x2 a = {v[0], v[1]}, b = {v[2], v[3]};
+  const unsigned ha = cvt_bf16x2(a), hb = cvt_bf16x2(b);
+  const f32x2 ra = a - bf16x2_as_f32(ha), rb = b - bf16x2_as_f32(hb);
+  const unsigned ma = cvt_bf16x2(ra), mb = cvt_bf16x2(rb);
+  const f32x2 sa = ra - bf16x2_as_f32(ma), sb = rb - bf16x2_as_f32(mb);
+  h = __builtin_bit_cast(s16x4, (u32x2){ha, hb});
+  m = __builtin_bit_cast(s16x4, (u32x2){ma, mb});
+  l = __builtin_bit_cast(s16x4, (u32x2){cvt_bf16x2(sa), cvt_bf16x2(sb)});
 }
 // integer-valued floats |v| < 2^16 in two exact bf16 terms
 __device__ __forceinline__ void split2(const f32x4 v, s16x4& h, s16x4& l) {
-  bf16x4 h4, l4;
-#pragma unroll
-  for (int e = 0; e < 4; e++) {
-    const __bf16 hi = (__bf16)v[e];
-    h4[e] = hi; l4[e] = (__bf16)(v[e] - (float)hi);
-  }
-  h = __builtin_bit_cast(s16x4, h4); l = __builtin_bit_cast(s16x4, l4);
+  const f32x2 a = {v[0], v[1]}, b = {v[2], v[3]};
+  const unsigned ha = cvt_bf16x2(a), hb = cvt_bf16x2(b);
+  h = __builtin_bit_cast(s16x4, (u32x2){ha, hb});
+  l = __builtin_bit_cast(s16x4, (u32x2){cvt_bf16x2(a - bf16x2_as_f32(ha)), cvt_bf16x2(b - bf16x2_as_f32(hb))});
 }
 template <bool F16>
 __device__ __forceinline__ s16x4 to_half4(const f32x4 v) {      // exact for the integers this file feeds it
