@@ -41,18 +41,6 @@ __device__ __forceinline__ unsigned pack_hi_lo(float v) {
   const __bf16 lo = (__bf16)(v - (float)hi);
   return ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16) | (unsigned)__builtin_bit_cast(unsigned short, lo);
 }
-// the same for two values at once: one v_cvt_pk_bf16_f32 per pair and term, one v_pk_add_f32 for the residuals, one v_perm_b32 per
-// packed word (7 vector instructions per two values instead of 11: the forward is bound by vector issue); same bits
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void pack_hi_lo2(float v0, float v1, unsigned& w0, unsigned& w1) {
-  const f32x2 v = {v0, v1};
-  const unsigned hp = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));          // [hi1 : hi0]
-  const f32x2 hf = {__builtin_bit_cast(float, hp << 16), __builtin_bit_cast(float, hp & 0xffff0000u)};
-  const unsigned lp = __builtin_bit_cast(unsigned, __builtin_convertvector(v - hf, bf16x2));     // [lo1 : lo0]
-  w0 = __builtin_amdgcn_perm(hp, lp, 0x05040100u);       // hi0 << 16 | lo0
-  w1 = __builtin_amdgcn_perm(hp, lp, 0x07060302u);       // hi1 << 16 | lo1
-}
 
 // 8 packed words -> bf16x8 of the high halves / of the low halves (element j from word j)
 __device__ __forceinline__ void unpack8(const unsigned (&wd)[8], bf16x8& hi, bf16x8& lo) {
@@ -139,19 +127,8 @@ __global__ __launch_bounds__(kThreads1, PAIR ? 4 : 5) void site1_fwd_kernel(cons
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;      // h doubles as the row half of the load mapping
   unsigned* W = lds + w * WBUF;
-  // launch-uniform floats: into scalar registers (computed on the vector unit they would each hold a vector register of a kernel
-  // that sits at the 128 four waves per SIMD allow)
-  auto uni = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
-  Levels nlev = make_levels(k, fabsf(r) <= 8.0f);
-  nlev.n = uni(nlev.n);
-  nlev.yn = uni(nlev.yn);
-  const float invB = uni(1.0f / (float)B), invBm1 = uni(1.0f / (float)(B - 1));
-  // rows of this lane at or beyond B (re-derived from the lane index where it is used: held, it is one register too many)
-  auto rows_beyond = [&]() {
-    int hv = h;
-    asm volatile("" : "+v"(hv));
-    return (float)min(max(RPL * hv + RPL - B, 0), RPL);
-  };
+  const Levels nlev = make_levels(k, fabsf(r) <= 8.0f);
+  const float invB = 1.0f / (float)B, invBm1 = 1.0f / (float)(B - 1);
   if (blockIdx.x == 0 && tid == 0 && counter) *counter = 0u;
 
   f32x16 acc;
@@ -205,22 +182,17 @@ __global__ __launch_bounds__(kThreads1, PAIR ? 4 : 5) void site1_fwd_kernel(cons
     // x_q is stored), t statistics -> stage t -> t Gram: one 16-row array is live instead of two.
     float sx = 0.f;
 #pragma unroll
-    for (int q = 0; q < RPL; q++) sx += xr[q];
-    // rows >= B hold the clamped row B - 1 (the loads clamp), which is this lane's LAST register whenever the lane has such rows: the
-    // sum over the valid rows is the plain sum minus rows_beyond() copies of it (one multiply-subtract instead of a select per row; the
-    // kernel is bound by vector issue)
-    sx = __fmaf_rn(-rows_beyond(), xr[RPL - 1], sx);
+    for (int q = 0; q < RPL; q++)
+      if (RPL * h + q < B) sx += xr[q];
     sx += __shfl_xor(sx, 32, 64);
     const float mx = sx * invB;
     float vx = 0.f;
 #pragma unroll
     for (int q = 0; q < RPL; q++) {
-      const float d = xr[q] - mx;
-      vx += d * d;
-    }
-    {
-      const float dl = xr[RPL - 1] - mx;
-      vx = __fmaf_rn(-rows_beyond() * dl, dl, vx);
+      if (RPL * h + q < B) {
+        const float d = xr[q] - mx;
+        vx += d * d;
+      }
     }
     vx += __shfl_xor(vx, 32, 64);
     const float rx = 1.0f / (sqrtf(vx * invBm1) + eps);
@@ -229,15 +201,10 @@ __global__ __launch_bounds__(kThreads1, PAIR ? 4 : 5) void site1_fwd_kernel(cons
       stats[F + col] = rx;
     }
     // ---- x operand: stage, Gram (negated when it is subtracted from the t Gram) --------------------------------
-    __builtin_amdgcn_sched_barrier(0);        // (keeps the statistics' temporaries from living into the packing: 5 spills without)
     {
       unsigned wd[RPL];
 #pragma unroll
-      for (int q = 0; q < RPL; q += 2) {
-        pack_hi_lo2((xr[q] - mx) * rx, (xr[q + 1] - mx) * rx, wd[q], wd[q + 1]);
-        if (!(cok && RPL * h + q < B)) wd[q] = 0u;
-        if (!(cok && RPL * h + q + 1 < B)) wd[q + 1] = 0u;
-      }
+      for (int q = 0; q < RPL; q++) wd[q] = (cok && RPL * h + q < B) ? pack_hi_lo((xr[q] - mx) * rx) : 0u;
       stage_rows(W, l31, h, wd);
     }
     wave_lds_sync();
@@ -267,6 +234,7 @@ __global__ __launch_bounds__(kThreads1, PAIR ? 4 : 5) void site1_fwd_kernel(cons
           qq[j] = act_quant1<0, BND>(xr[q], k, nlev, r, &tr[q], &b, tab);
           if (RES) qq[j] += rr[RES ? j : 0];
           if (relu) qq[j] = fmaxf(qq[j], 0.0f);
+          if (RPL * h + q >= B) tr[q] = 0.f;
           st += tr[q];
         }
         if (xq) {
@@ -279,22 +247,18 @@ __global__ __launch_bounds__(kThreads1, PAIR ? 4 : 5) void site1_fwd_kernel(cons
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      st = __fmaf_rn(-rows_beyond(), tr[RPL - 1], st);         // (rows >= B: copies of the last register, as for x above)
       st += __shfl_xor(st, 32, 64);
       const float mt = st * invB;
       float vt = 0.f;
 #pragma unroll
-      for (int q = 0; q < RPL; q++) { const float d2 = tr[q] - mt; vt += d2 * d2; }
-      {
-        const float dl = tr[RPL - 1] - mt;
-        vt = __fmaf_rn(-rows_beyond() * dl, dl, vt);
+      for (int q = 0; q < RPL; q++) {
+        if (RPL * h + q < B) { const float d2 = tr[q] - mt; vt += d2 * d2; }
       }
       vt += __shfl_xor(vt, 32, 64);
       const float rt = 1.0f / (sqrtf(vt * invBm1) + eps);
       if (stats && cok && h == 0) { stats[2 * F + col] = mt; stats[3 * F + col] = rt; }
       unsigned wd[RPL];
 #pragma unroll
-      // (element by element here: the paired form of the x operand above costs this block 5 spills at 128 registers)
       for (int q = 0; q < RPL; q++) wd[q] = (cok && RPL * h + q < B) ? pack_hi_lo((tr[q] - mt) * rt) : 0u;
       stage_rows(W, l31, h, wd);
       wave_lds_sync();
