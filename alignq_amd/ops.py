@@ -1047,7 +1047,7 @@ def qconv_stem7_supported(x, w, stride, padding, dilation, groups, bias, w_bit) 
 class QConvStem7Fn(torch.autograd.Function):
     """F.conv2d(image, weight_q, None, 2, 3) of the Office stem on alignq_qconv_stem7_fwd (csrc/qgemm_kernels.hip: the filter's integer
     bins times three exact bf16 terms of the image, gathered straight from global memory); batch-norm statistics of the output in
-    the epilogue (bn_stats).  The image needs no gradient; the filter gradient is alignq_qconv_stem7_wgrad's."""
+    the epilogue (bn_stats).  The image needs no gradient; the filter gradient is still MIOpen's (aten.convolution_backward)."""
 
     @staticmethod
     def forward(ctx, x, w, w_bit, groups=1, bn_stats=False, bins=None):
