@@ -13,7 +13,7 @@ SO_PATH = os.environ.get("ALIGNQ_SO") or os.path.join(_HERE, "lib", "libalignq_h
 FORMULA_ADMM, FORMULA_CDF = 0, 1
 MAX_BATCH = 128            # rows the FUSED site kernels hold on chip (ALIGNQ_MAX_BATCH)
 MAX_CORR_BATCH = 1024      # rows alignq_corr_fwd / _bwd take (ALIGNQ_MAX_CORR_BATCH: blocked Gram above 128)
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 _c = ctypes
 _vp, _i, _i64, _f, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_size_t
@@ -106,6 +106,8 @@ SIGNATURES = {
     "alignq_qconv_fwd": (_i, [_vp, _vp, _vp] + [_i] * 8 + [_f, _i, _i, _vp, _vp]),
     "alignq_qconv_stem7_bn_parts": (_i, [_i] * 4),
     "alignq_qconv_stem7_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "alignq_qconv_stem7_wgrad_ws_bytes": (_sz, [_i] * 3),
+    "alignq_qconv_stem7_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "alignq_qconv_dgrad_ws_bytes": (_sz, [_i] * 7),
     "alignq_qconv_dgrad": (_i, [_vp, _vp, _vp] + [_i] * 8 + [_vp, _vp]),
     "alignq_qconv_wgrad_ws_bytes": (_sz, [_i] * 7),

@@ -1024,6 +1024,148 @@ __global__ __launch_bounds__(256, 4) void qstem7_fwd_kernel(const QS a) {
   }
 }
 
+// Filter gradient of the stem: slab[split][co][ky * 21 + j] = sum over the split's output pixels m of dy[m][co] * x(m; ky, j).  The
+// contraction runs over PIXELS (32 per step), so both tiles are staged [pixel][column] and read through ds_read_b64_tr_b16 as in
+// qgemm_wgrad_kernel: the dy tile [32][64] (three bf16 terms) and the gathered patch tile [32][192] (k' = ky * 24 + j, the 32-byte
+// pieces of the forward; three bf16 terms; the pad columns j = 21..23 and k' >= 168 hold whatever lies there - every output column
+// depends on its own k' only and the pads are never stored).  Wave (wc, wo) owns 6 of the 12 k' tiles x 2 of the 4 channel tiles:
+// 12 accumulators; six leading term pairs per product.  Deterministic split slabs, reduced by the caller's closing reduction.
+struct QSW {
+  const float* x; const float* dy; float* slabs;
+  int H, W, Ho, Wo;
+  int M, per;                  // output pixels in all, per split (a multiple of 32)
+  uint64_t magic_w, magic_h;
+};
+__global__ __launch_bounds__(256, 2) void qstem7_wgrad_kernel(const QSW a) {
+  constexpr int LDC = 192 + 16, LDO = 64 + 16, XPL = WK * LDC, DPL = WK * LDO;
+  __shared__ __attribute__((aligned(16))) u16 lds[3 * XPL + 3 * DPL];
+  u16* const Xs = lds;
+  u16* const Ds = lds + 3 * XPL;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wc = wv & 1, wo = wv >> 1;
+  const int m_begin = blockIdx.x * a.per, m_end = (m_begin + a.per < a.M) ? m_begin + a.per : a.M;
+  const char* const xbytes = reinterpret_cast<const char*>(a.x);
+  const int rs = a.W * 3;
+  float rx[3][8];
+  f32x4 rd[2];
+  auto fetch = [&](int m0) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {          // (pixel, 8-column group) items of the patch tile: 32 x 24
+      const int idx = tid + 256 * i, p = idx / 24, g = idx - 24 * p;
+      const int m = m0 + p;
+      const bool ok = m < m_end;
+      const int mm = ok ? m : m_end - 1;
+      const int r = (int)(((uint64_t)(unsigned)mm * a.magic_w) >> 40), ow = mm - r * a.Wo;
+      const int img = (int)(((uint64_t)(unsigned)r * a.magic_h) >> 40), oh = r - img * a.Ho;
+      const bool inner = oh >= 2 && 2 * oh + 3 < a.H && ow >= 2 && 2 * ow + 4 < a.W;
+      const int org = ((img * a.H + 2 * oh - 3) * a.W + (2 * ow - 3)) * 3;
+      const int ky = g / 3, jb = 8 * (g - 3 * ky);
+      if (inner) {
+        const unsigned o = g < 21 ? (unsigned)(org + ky * rs + jb) * 4u : 0u;
+        const f32x4 v0 = *reinterpret_cast<const f32x4u*>(xbytes + o), v1 = *reinterpret_cast<const f32x4u*>(xbytes + o + 16);
+        rx[i][0] = v0[0]; rx[i][1] = v0[1]; rx[i][2] = v0[2]; rx[i][3] = v0[3];
+        rx[i][4] = v1[0]; rx[i][5] = v1[1]; rx[i][6] = v1[2]; rx[i][7] = v1[3];
+      } else {
+        const f32x8 b8 = stem_border8(xbytes, org, oh, ow, a.H, a.W, g);
+#pragma unroll
+        for (int e = 0; e < 8; e++) rx[i][e] = b8[e];
+      }
+      if (!ok) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) rx[i][e] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int idx = tid + 256 * i, kr = idx >> 4, q4 = idx & 15;
+      const int m = m0 + kr;
+      const bool ok = m < m_end;
+      rd[i] = *reinterpret_cast<const f32x4*>(a.dy + (ok ? (int64_t)m * 64 + 4 * q4 : 0));
+      if (!ok) rd[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto park = [&]() {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const int idx = tid + 256 * i, p = idx / 24, g = idx - 24 * p;
+      const int o = p * LDC + 8 * g;
+      s16x4 h0, m0, l0, h1, m1, l1;
+      split3((f32x4){rx[i][0], rx[i][1], rx[i][2], rx[i][3]}, h0, m0, l0);
+      split3((f32x4){rx[i][4], rx[i][5], rx[i][6], rx[i][7]}, h1, m1, l1);
+      *reinterpret_cast<s16x8*>(Xs + o) = join8(h0, h1);
+      *reinterpret_cast<s16x8*>(Xs + XPL + o) = join8(m0, m1);
+      *reinterpret_cast<s16x8*>(Xs + 2 * XPL + o) = join8(l0, l1);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int idx = tid + 256 * i, kr = idx >> 4, q4 = idx & 15;
+      const int o = kr * LDO + 4 * q4;
+      s16x4 h, m, l;
+      split3(rd[i], h, m, l);
+      *reinterpret_cast<s16x4*>(Ds + o) = h;
+      *reinterpret_cast<s16x4*>(Ds + DPL + o) = m;
+      *reinterpret_cast<s16x4*>(Ds + 2 * DPL + o) = l;
+    }
+  };
+  f32x4 acc[6][2];
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int fg = lane >> 4, fq = (lane & 15) >> 2, fc = 4 * (lane & 3);
+  const int krow = 4 * fg + fq;                       // first pixel row of this lane's block (second: + 16), as qgemm_wgrad_kernel
+  if (m_begin < m_end) fetch(m_begin);
+  for (int m0 = m_begin; m0 < m_end; m0 += WK) {
+    __syncthreads();
+    park();
+    __syncthreads();
+    if (m0 + WK < m_end) fetch(m0 + WK);
+    s16x8 df[2][3];
+#pragma unroll
+    for (int tn = 0; tn < 2; tn++)
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        const u16* p = Ds + t * DPL + krow * LDO + (wo * 2 + tn) * 16 + fc;
+        df[tn][t] = join8(tr_read(p), tr_read(p + 16 * LDO));
+      }
+#pragma unroll
+    for (int tc = 0; tc < 6; tc++) {
+      s16x8 xf[3];
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        const u16* p = Xs + t * XPL + krow * LDC + (wc * 6 + tc) * 16 + fc;
+        xf[t] = join8(tr_read(p), tr_read(p + 16 * LDC));
+      }
+#pragma unroll
+      for (int tn = 0; tn < 2; tn++) {
+        f32x4 v = acc[tc][tn];            // the six leading pairs, smallest first
+        v = mfma16<false>(xf[1], df[tn][1], v);
+        v = mfma16<false>(xf[0], df[tn][2], v);
+        v = mfma16<false>(xf[2], df[tn][0], v);
+        v = mfma16<false>(xf[0], df[tn][1], v);
+        v = mfma16<false>(xf[1], df[tn][0], v);
+        v = mfma16<false>(xf[0], df[tn][0], v);
+        acc[tc][tn] = v;
+      }
+    }
+  }
+  // D: column = output channel (lane & 15), rows = k' = 16 tile + 4 * (lane >> 4) + e -> (ky, j); j < 21 are the filter's elements
+  float* slab = a.slabs + (int64_t)blockIdx.x * (64 * kStemK);
+#pragma unroll
+  for (int tn = 0; tn < 2; tn++) {
+    const int co = (wo * 2 + tn) * 16 + (lane & 15);
+#pragma unroll
+    for (int tc = 0; tc < 6; tc++) {
+      const int kp = (wc * 6 + tc) * 16 + 4 * fg, ky = kp / 24, j = kp - 24 * ky;
+      if (ky < 7) {
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+          if (j + e < 21) slab[co * kStemK + ky * 21 + j + e] = acc[tc][tn][e];
+      }
+    }
+  }
+}
+
 inline bool stem7_ok(int B, int H, int W, int groups) {
   return B >= 1 && groups >= 1 && B % groups == 0 && H >= 8 && W >= 8 && H <= 4096 && W <= 4096 && (int64_t)B * H * W * 3 < ((int64_t)1 << 30);
 }
@@ -1194,6 +1336,42 @@ int alignq_qconv_stem7_fwd(const float* x, const void* w_bins, float* y, int B, 
   a.magic_h = (((uint64_t)1 << 40) + a.Ho - 1) / a.Ho;
   hipLaunchKernelGGL(qstem7_fwd_kernel, dim3(groups * a.wg_pg), dim3(256), 0, (hipStream_t)stream, a);
   const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+static int stem7_wgrad_splits(int64_t M) {
+  const int64_t steps = (M + WK - 1) / WK;
+  return (int)(steps < 512 ? steps : 512);
+}
+
+size_t alignq_qconv_stem7_wgrad_ws_bytes(int B, int H_in, int W_in) {
+  if (!stem7_ok(B, H_in, W_in, 1)) return 0;
+  const int Ho = (H_in - 1) / 2 + 1, Wo = (W_in - 1) / 2 + 1;
+  return (size_t)stem7_wgrad_splits((int64_t)B * Ho * Wo) * 64 * kStemK * sizeof(float);
+}
+
+int alignq_qconv_stem7_wgrad(const float* x, const float* dy, float* dw, void* ws, int B, int H_in, int W_in, int* n_slabs_out,
+                             void* stream) {
+  if (!x || !dy || !ws || (!dw && !n_slabs_out)) return ALIGNQ_EINVAL;
+  if (!stem7_ok(B, H_in, W_in, 1)) return ALIGNQ_EUNSUPPORTED;
+  QSW a{};
+  a.x = x; a.dy = dy; a.slabs = (float*)ws;
+  a.H = H_in; a.W = W_in; a.Ho = (H_in - 1) / 2 + 1; a.Wo = (W_in - 1) / 2 + 1;
+  a.M = B * a.Ho * a.Wo;
+  const int splits = stem7_wgrad_splits(a.M);
+  const int64_t steps = ((int64_t)a.M + WK - 1) / WK;
+  a.per = (int)((steps + splits - 1) / splits) * WK;
+  a.magic_w = (((uint64_t)1 << 40) + a.Wo - 1) / a.Wo;
+  a.magic_h = (((uint64_t)1 << 40) + a.Ho - 1) / a.Ho;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(qstem7_wgrad_kernel, dim3(splits), dim3(256), 0, st, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  if (n_slabs_out) { *n_slabs_out = splits; return 0; }      // deferred: the caller reduces (alignq_conv3x3_wgrad_reduce_multi)
+  const int n_elem = 64 * kStemK;
+  hipLaunchKernelGGL(qgemm_slab_reduce_kernel, dim3(alignq_wgr::wgrad_reduce_blocks(splits, n_elem)), dim3(1024), 0, st,
+                     (const float*)ws, splits, n_elem, dw);
+  e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
 

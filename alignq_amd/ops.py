@@ -1047,7 +1047,8 @@ def qconv_stem7_supported(x, w, stride, padding, dilation, groups, bias, w_bit) 
 class QConvStem7Fn(torch.autograd.Function):
     """F.conv2d(image, weight_q, None, 2, 3) of the Office stem on alignq_qconv_stem7_fwd (csrc/qgemm_kernels.hip: the filter's integer
     bins times three exact bf16 terms of the image, gathered straight from global memory); batch-norm statistics of the output in
-    the epilogue (bn_stats).  The image needs no gradient; the filter gradient is still MIOpen's (aten.convolution_backward)."""
+    the epilogue (bn_stats).  The image needs no gradient; the filter gradient is alignq_qconv_stem7_wgrad's (six leading term pairs,
+    deterministic slabs; their reduction is deferred to fused.DeferredWgrads when such a context is active)."""
 
     @staticmethod
     def forward(ctx, x, w, w_bit, groups=1, bn_stats=False, bins=None):
@@ -1084,7 +1085,19 @@ class QConvStem7Fn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             if not gy.is_contiguous(memory_format=torch.channels_last):
                 gy = gy.contiguous(memory_format=torch.channels_last)
-            dw = torch.ops.aten.convolution_backward(gy, x, w, None, (2, 2), (3, 3), (1, 1), False, (0, 0), 1, (False, True, False))[1]
+            B, _, H, W = x.shape
+            lib = L.load()
+            dw = torch.empty_like(w)
+            ws = _ws(lib.alignq_qconv_stem7_wgrad_ws_bytes(B, H, W), w.device)
+            pending = fused.active_wgrads()
+            if pending is not None:         # the slab reduction rides in the step's closing reduction launch
+                ns = ctypes.c_int(0)
+                L.check(lib.alignq_qconv_stem7_wgrad(L.ptr(x), L.ptr(gy), None, L.ptr(ws), B, H, W, ctypes.byref(ns), L.stream_ptr()),
+                        "alignq_qconv_stem7_wgrad")
+                pending.add(ws, dw, ns.value, 64 * 147)
+            else:
+                L.check(lib.alignq_qconv_stem7_wgrad(L.ptr(x), L.ptr(gy), L.ptr(dw), L.ptr(ws), B, H, W, None, L.stream_ptr()),
+                        "alignq_qconv_stem7_wgrad")
         return None, dw, None, None, None, None
 
 

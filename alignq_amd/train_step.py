@@ -358,7 +358,7 @@ class OfficeTrainStep:
             model = model.to(memory_format=torch.channels_last)
         self.channels_last = channels_last
         # qconv (channels_last only): Conv2d_Q's 1x1 / 3x3 convolutions on alignq_qconv_* (exact-product GEMMs on the bf16 / f16
-        # matrix cores, csrc/qgemm_kernels.hip) instead of MIOpen's fp32 kernels (of the 7x7 stem only the filter gradient stays with MIOpen).  Their filter
+        # matrix cores, csrc/qgemm_kernels.hip) instead of MIOpen's fp32 kernels (the 7x7 stem included: alignq_qconv_stem7_*).  Their filter
         # gradients leave split-K slabs that one reduction launch per 32 filters finishes (fused.DeferredWgrads).
         self.qconv = bool(qconv and channels_last and torch.cuda.is_available())
         for mod in model.modules():

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALIGNQ_ABI_VERSION 18
+#define ALIGNQ_ABI_VERSION 19
 
 #define ALIGNQ_FORMULA_ADMM 0
 #define ALIGNQ_FORMULA_CDF 1
@@ -370,6 +370,12 @@ int alignq_qconv_fwd(const void* x, const void* w_bins, float* y, int B, int H_i
 int alignq_qconv_stem7_bn_parts(int B, int H_in, int W_in, int groups);
 int alignq_qconv_stem7_fwd(const float* x, const void* w_bins, float* y, int B, int H_in, int W_in, int w_bit, int groups,
                            double* bn_part, void* stream);
+/* its filter gradient dw [64][7][7][3] (the layout of the filter) from the image and dy [B, H_out, W_out, 64]: six leading bf16 term
+ * pairs, deterministic split slabs in ws (alignq_qconv_stem7_wgrad_ws_bytes), summed in slab order by this call (dw != NULL,
+ * n_slabs_out == NULL) or later by alignq_conv3x3_wgrad_reduce_multi (n_slabs_out receives the slab count; n_elem = 64 * 147). */
+size_t alignq_qconv_stem7_wgrad_ws_bytes(int B, int H_in, int W_in);
+int alignq_qconv_stem7_wgrad(const float* x, const float* dy, float* dw, void* ws, int B, int H_in, int W_in, int* n_slabs_out,
+                             void* stream);
 /* ws (or NULL; alignq_qconv_dgrad_ws_bytes, 0 = none needed): scratch for split-K - layers with few row tiles and a long
  * contraction (layer3 / layer4 at B = 56) run 2 to 4 workgroups per tile over disjoint k ranges and a closing pass adds their raw
  * sums in split order (deterministic); without ws every tile is one workgroup.                                                     */

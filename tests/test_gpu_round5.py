@@ -250,3 +250,50 @@ def test_site1_batch_matches_per_site_launches(dev, monkeypatch):
                                            err_msg=n_)
     finally:
         config.args.bitW, config.args.abitW, config.args.train_batch_size, config.args.eval_batch_size = old
+
+
+def test_office_step_calls_no_library_convolution(dev, monkeypatch):
+    """With qconv (the default of OfficeTrainStep(channels_last=True)) EVERY Conv2d_Q of the DANN ResNet-50 - the 7 x 7 stem, the
+    1 x 1 and 3 x 3 convolutions at stride 1 and 2, the downsample convolutions - runs forward, data gradient and filter gradient on
+    this repository's kernels (alignq_qconv_*): torch's convolution entry points are never reached during an iteration (even
+    grids: 64 x 64 images here, 224 x 224 in configuration 5)."""
+    import alignq_amd.quantization  # noqa: F401
+    from alignq_amd import config
+    from alignq_amd.resnet_office import resnet50_dann
+    from alignq_amd.train_step import OfficeTrainStep
+    old = (config.args.bitW, config.args.abitW, config.args.train_batch_size, config.args.eval_batch_size)
+    config.args.bitW = config.args.abitW = 8
+    config.args.train_batch_size = config.args.eval_batch_size = 4
+    try:
+        g = torch.Generator().manual_seed(1)
+        xs = torch.randn(4, 3, 64, 64, generator=g).to(dev)
+        xt = torch.randn(4, 3, 64, 64, generator=g).to(dev)
+        ys = torch.randint(0, 31, (4,), generator=g).to(dev)
+        net = det_init_(resnet50_dann(8, 8)).to(dev).train()
+        step = OfficeTrainStep(net, lr=0.004, channels_last=True)
+        assert step.qconv
+
+        def boom(*a, **k):
+            raise AssertionError("a library convolution was called")
+        for name in ("conv2d", "conv_transpose2d"):
+            monkeypatch.setattr(torch.nn.functional, name, boom)
+        monkeypatch.setattr(torch, "conv2d", boom)
+        monkeypatch.setattr(torch.nn.grad, "conv2d_input", boom)
+        monkeypatch.setattr(torch.nn.grad, "conv2d_weight", boom)
+        real_cb = torch.ops.aten.convolution_backward
+        calls = []
+
+        class Spy:
+            def __call__(self, *a, **k):
+                calls.append(1)
+                return real_cb(*a, **k)
+
+            def __getattr__(self, n):
+                return getattr(real_cb, n)
+        monkeypatch.setattr(torch.ops.aten, "convolution_backward", Spy(), raising=False)
+        cls, loss, tl = step(xs, ys, xt)
+        torch.cuda.synchronize()
+        assert torch.isfinite(loss) and torch.isfinite(tl) and not calls
+        assert all(p.grad is not None for n_, p in net.named_parameters() if "conv" in n_ and n_.endswith("weight"))
+    finally:
+        config.args.bitW, config.args.abitW, config.args.train_batch_size, config.args.eval_batch_size = old

@@ -30,5 +30,5 @@ print("stem7 fwd (no stats)  %.1f us" % timeit(lambda: ops.QConvStem7Fn.apply(x,
 print("stem7 fwd (+ stats)   %.1f us" % timeit(lambda: ops.QConvStem7Fn.apply_with_stats(x, w, 8, 2, bins)))
 print("MIOpen fwd            %.1f us" % timeit(lambda: torch.nn.functional.conv2d(x, w.detach(), stride=2, padding=3)))
 y = ops.QConvStem7Fn.apply(x, w, 8, 1, False, bins)
-print("stem backward (Fn)    %.1f us" % timeit(lambda: torch.autograd.grad(y, w, gy, retain_graph=True)))
+print("stem7 wgrad (+reduce) %.1f us" % timeit(lambda: torch.autograd.grad(y, w, gy, retain_graph=True)))
 print("MIOpen wrw            %.1f us" % timeit(lambda: torch.ops.aten.convolution_backward(gy, x, w.detach(), None, (2, 2), (3, 3), (1, 1), False, (0, 0), 1, (False, True, False))))
