@@ -872,8 +872,8 @@ def other_configs(dev, a, steps=30, only=None):
         gc.collect()
         torch.cuda.empty_cache()
     config.args.bitW, config.args.abitW, config.args.train_batch_size, config.args.eval_batch_size = saved
-    out["note"] = ("one GPU's share of BASELINE.json configs[2..4], HIP-graph replay, channels-last; config 5: Conv2d_Q's 1x1 / 3x3 "
-                   "convolutions on alignq_qconv_* (round 5), batch-norms folded into the quantiser / site kernels with their "
+    out["note"] = ("one GPU's share of BASELINE.json configs[2..4], HIP-graph replay, channels-last; config 5: every Conv2d_Q "
+                   "convolution (stem included) on alignq_qconv_* (round 5), batch-norms folded into the quantiser / site kernels with their "
                    "statistics from the convolutions' epilogues, source and target batch in one traversal; lr 0.004 from random "
                    "init; CPU numbers of configs 4 and 5 on the same kind of box: profiles/r05_cpu_baseline_configs.json")
     return out
@@ -933,8 +933,8 @@ def headline(a, elapsed, images_per_step, world, office, final_ce, final_tl):
                                + ("" if (office or a.nchw or a.no_qconv) else
                                   ", all Conv2d_Q convolutions on alignq_conv*_nhwc (exact-product bf16 MFMA)")
                                + ("" if (not office or a.nchw or a.no_qconv) else
-                                  ", Conv2d_Q's 1x1 / 3x3 convolutions on alignq_qconv_* (exact-product bf16 / f16 MFMA GEMMs; the 7x7 "
-                                  "stem and three stride-2 data gradients on MIOpen)"),
+                                  ", every Conv2d_Q convolution (7x7 stem, 1x1, 3x3, stride 1 and 2) on alignq_qconv_* "
+                                  "(exact-product bf16 / f16 MFMA GEMMs)"),
                    "global_batch": a.batch * world, "parallelism": f"dp{world}",
                    "final_ce": final_ce, "final_trans_loss": final_tl},
     }
