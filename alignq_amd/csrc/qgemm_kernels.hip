@@ -1212,7 +1212,7 @@ int launch_g(QG a, hipStream_t st) {
 // Tile choice: the largest of 128x128, 64x128, 64x64 (pixels x channels) that still gives the chip >= `want` workgroups
 // (rows = all groups' rows; alignq_qconv_bn_parts reports the row tiles per group of the same choice).  The halo form of a level
 // operand (64 channels per step) keeps to 64-row tiles: its image of 128 + 2 W + 2 rows would not fit the prefetch registers.
-constexpr int kWantBlocks = 1024;
+constexpr int kWantBlocks = 1024;        // (round 5 sweep 512 / 768 / 1024 / 1536: forward + data gradient 4717 / 4651 / 4656 / 4733 us per iteration)
 inline int pick_tile(int64_t rows, int N, bool rows64_only = false, int want = kWantBlocks) {        // 0: 128x128, 1: 64x128, 2: 128x64, 3: 64x64
   const bool n128 = N % 128 == 0;
   auto blocks = [&](int bm, int bn) { return ((rows + bm - 1) / bm) * (N / bn); };
