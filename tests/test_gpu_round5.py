@@ -297,3 +297,40 @@ def test_office_step_calls_no_library_convolution(dev, monkeypatch):
         assert all(p.grad is not None for n_, p in net.named_parameters() if "conv" in n_ and n_.endswith("weight"))
     finally:
         config.args.bitW, config.args.abitW, config.args.train_batch_size, config.args.eval_batch_size = old
+
+
+def test_office_iteration_is_reproducible_run_to_run(dev):
+    """Two fresh models from the same initial state, three eager iterations each on the same inputs: every parameter behind this
+    repository's kernels comes out bit for bit the same (deterministic split-K slabs, fixed-order reductions, last-arriver tickets
+    that fix the summation order, no float atomics anywhere).  The stem's two layers sit behind torch's max-pool backward, which
+    adds with atomics: compared to rounding (they were bit-equal too whenever measured, tools/diag_determinism.py at full size)."""
+    import alignq_amd.quantization  # noqa: F401
+    from alignq_amd import config
+    from alignq_amd.resnet_office import resnet50_dann
+    from alignq_amd.train_step import OfficeTrainStep
+    old = (config.args.bitW, config.args.abitW, config.args.train_batch_size, config.args.eval_batch_size)
+    config.args.bitW = config.args.abitW = 8
+    config.args.train_batch_size = config.args.eval_batch_size = 6
+    try:
+        g = torch.Generator().manual_seed(2)
+        xs = torch.randn(6, 3, 96, 96, generator=g).to(dev)
+        xt = torch.randn(6, 3, 96, 96, generator=g).to(dev)
+        ys = torch.randint(0, 31, (6,), generator=g).to(dev)
+        res = []
+        for _ in range(2):
+            net = det_init_(resnet50_dann(8, 8)).to(dev).train()
+            step = OfficeTrainStep(net, lr=4e-5, channels_last=True)
+            for _i in range(3):
+                out = step(xs, ys, xt)
+            torch.cuda.synchronize()
+            res.append(({n_: npy(p_) for n_, p_ in net.named_parameters()}, npy(out[1]), npy(out[2])))
+            del step, net
+        (p1, l1, t1), (p2, l2, t2) = res
+        assert np.isfinite(l1) and np.array_equal(t1, t2)
+        for n_ in p1:
+            if n_.startswith(("feature.conv1.", "feature.bn1.")):
+                np.testing.assert_allclose(p1[n_], p2[n_], rtol=1e-5, atol=1e-7 * float(np.abs(p1[n_]).max()), err_msg=n_)
+            else:
+                assert np.array_equal(p1[n_], p2[n_]), n_
+    finally:
+        config.args.bitW, config.args.abitW, config.args.train_batch_size, config.args.eval_batch_size = old
