@@ -987,7 +987,9 @@ class BNSite1Fn(torch.autograd.Function):
             g_y = L.like_layout(g_y, z)
             g_m = torch.empty_like(z) if has_res else None
         rec = ctx.rec
-        prepared = rec is not None and rec.prepared        # Site1LossSumFn.backward has prepared every site of the batch
+        # Site1LossSumFn.backward has prepared every site of the batch (a second backward over a retained graph finds the record
+        # emptied and prepares this site by itself)
+        prepared = rec is not None and rec.prepared and rec.S is not None
         if prepared:
             # (the record lets go of them: a gradient tensor somebody else still references is CLONED by autograd's accumulation
             # node instead of taken over - 2 copies of 5 us per site)
