@@ -13,7 +13,7 @@ SO_PATH = os.environ.get("ALIGNQ_SO") or os.path.join(_HERE, "lib", "libalignq_h
 FORMULA_ADMM, FORMULA_CDF = 0, 1
 MAX_BATCH = 128            # rows the FUSED site kernels hold on chip (ALIGNQ_MAX_BATCH)
 MAX_CORR_BATCH = 1024      # rows alignq_corr_fwd / _bwd take (ALIGNQ_MAX_CORR_BATCH: blocked Gram above 128)
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 _c = ctypes
 _vp, _i, _i64, _f, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_size_t
@@ -59,6 +59,8 @@ SIGNATURES = {
     "alignq_site_partials_res_ab": (_i, [_vp, _vp, _i, _i, _i64, _i, _f, _f, _vp, _i, _vp, _vp, _vp, _vp]),
     "alignq_site_bwd_apply_ab": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i64, _f, _f, _vp, _vp]),
     "alignq_site1_groups_fwd": (_i, [_vp, _vp, _i, _i, _i64, _i, _i, _f, _f, _vp, _i, _vp, _vp, _vp, _vp]),
+    "alignq_site1_mask_bytes": (_sz, [_i, _i64, _i]),
+    "alignq_site1_groups_fwd_m": (_i, [_vp, _vp, _i, _i, _i64, _i, _i, _f, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "alignq_site1_groups_reduce_loss": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _i, _f, _f, _vp, _vp]),
     "alignq_site1_groups_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i64, _i, _f, _f, _vp, _vp, _vp]),
     "alignq_site1_groups_prep": (_i, [_vp, _vp, _vp, _i, _vp, _f, _vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp]),
@@ -66,6 +68,7 @@ SIGNATURES = {
     "alignq_site1_groups_prep_multi": (_i, [_i, _vp, _vp, _vp, _i, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "alignq_site1_cols_bytes": (_sz, [_i64, _i]),
     "alignq_site1_groups_bwd_bn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i64, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "alignq_site1_groups_bwd_bn_m": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i64, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "alignq_site_bwd_apply_ab_relu": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i64, _f, _f, _vp, _vp, _vp]),
     "alignq_bnq_mask_bytes": (_sz, [_i64, _i, _i]),
     "alignq_bnq_fwd": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

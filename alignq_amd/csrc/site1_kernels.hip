@@ -104,7 +104,8 @@ __global__ __launch_bounds__(kThreads1, PAIR ? 4 : 5) void site1_fwd_kernel(cons
                                                               float* __restrict__ slabs, float* __restrict__ stats,
                                                               int n_sub, unsigned* __restrict__ counter,
                                                               const float* __restrict__ res, int relu,
-                                                              const float* __restrict__ ab, int nch, int64_t ws_gstride) {
+                                                              const float* __restrict__ ab, int nch, int64_t ws_gstride,
+                                                              unsigned* __restrict__ rmask = nullptr) {
   // blockIdx.y = group: batch slices of a merged multi-pass tensor ([groups][B][F]), each with its own statistics, slabs
   // (workspace regions ws_gstride floats apart) and (a, b)
   {
@@ -116,6 +117,7 @@ __global__ __launch_bounds__(kThreads1, PAIR ? 4 : 5) void site1_fwd_kernel(cons
     slabs += gi * ws_gstride;
     if (counter) counter += gi * ws_gstride;
     if (ab) ab += gi * 2 * nch;
+    if (rmask) rmask += gi * (int64_t)n_sub * 32;
   }
   __shared__ __attribute__((aligned(16))) unsigned lds[(kWaves * WBUF > 4096) ? kWaves * WBUF : 4096];
   __shared__ __attribute__((aligned(16))) float nerf_lds[PAIR ? ALIGNQ_NERF_LDS_FLOATS : 4];
@@ -127,8 +129,13 @@ __global__ __launch_bounds__(kThreads1, PAIR ? 4 : 5) void site1_fwd_kernel(cons
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;      // h doubles as the row half of the load mapping
   unsigned* W = lds + w * WBUF;
-  const Levels nlev = make_levels(k, fabsf(r) <= 8.0f);
-  const float invB = 1.0f / (float)B, invBm1 = 1.0f / (float)(B - 1);
+  // launch-uniform floats: into scalar registers (computed on the vector unit they would each hold a vector register of a kernel
+  // that sits at the 128 four waves per SIMD allow)
+  auto uni = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+  Levels nlev = make_levels(k, fabsf(r) <= 8.0f);
+  nlev.n = uni(nlev.n);
+  nlev.yn = uni(nlev.yn);
+  const float invB = uni(1.0f / (float)B), invBm1 = uni(1.0f / (float)(B - 1));
   if (blockIdx.x == 0 && tid == 0 && counter) *counter = 0u;
 
   f32x16 acc;
@@ -220,6 +227,7 @@ __global__ __launch_bounds__(kThreads1, PAIR ? 4 : 5) void site1_fwd_kernel(cons
       // registers, a branch per row serialises them).  Rows >= B and columns >= F carry the clamped row's / column's values:
       // they are stored too - the same value to the same address as the lane that owns it - and masked out of the sums.
       float st = 0.f;
+      unsigned mword = 0u;         // lane i < 16 of each half collects the stored-output sign bits of row 16 h + i (rmask)
 #pragma unroll
       for (int q4 = 0; q4 < RPL; q4 += 4) {
         float qq[4], rn[RES ? 4 : 1];
@@ -241,12 +249,24 @@ __global__ __launch_bounds__(kThreads1, PAIR ? 4 : 5) void site1_fwd_kernel(cons
 #pragma unroll
           for (int j = 0; j < 4; j++) *reinterpret_cast<float*>(reinterpret_cast<char*>(xq) + S1_OFF(q4 + j)) = qq[j];
         }
+        if (BND && rmask) {  // (launch-uniform; the bounded-quantiser form only: the generic one has no register left for it)
+                             // one bit per stored element: [sub-tile][row][32 features], the backward's ReLU mask
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const unsigned long long bal = __ballot(qq[j] > 0.0f);
+            // row q's word into lane q of the half that owns the row (selects: this compiler has no v_writelane builtin, and an
+            // inline-asm one sits outside its hazard handling - it produced wrong words)
+            const unsigned wq = h ? (unsigned)(bal >> 32) : (unsigned)bal;
+            mword = l31 == q4 + j ? wq : mword;
+          }
+        }
         if (RES && q4 + 4 < RPL) {
 #pragma unroll
           for (int j = 0; j < 4; j++) rr[RES ? j : 0] = rn[RES ? j : 0];
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (BND && rmask && l31 < RPL) rmask[(int64_t)sub * 32 + RPL * h + l31] = mword;
       st += __shfl_xor(st, 32, 64);
       const float mt = st * invB;
       float vt = 0.f;
@@ -303,7 +323,8 @@ __global__ __launch_bounds__(kThreads1, PAIR ? 3 : 5) void site1_bwd_kernel(cons
                                                                const float* __restrict__ ab, int C,
                                                                const float* __restrict__ ymask, float* __restrict__ dres,
                                                                int64_t s_gstride, const float* __restrict__ gup2,
-                                                               const float* __restrict__ save = nullptr, float* __restrict__ colsum = nullptr) {
+                                                               const float* __restrict__ save = nullptr, float* __restrict__ colsum = nullptr,
+                                                               const unsigned* __restrict__ rmask = nullptr) {
   {        // blockIdx.y = group (see site1_fwd_kernel); S matrices s_gstride floats apart
     const int64_t gi = blockIdx.y, go = gi * (int64_t)B * F;
     x += go; dx += go;
@@ -316,6 +337,7 @@ __global__ __launch_bounds__(kThreads1, PAIR ? 3 : 5) void site1_bwd_kernel(cons
     if (ab) ab += gi * 2 * C;
     if (save) save += gi * 2 * C;
     if (colsum) colsum += gi * F;               // [2][groups][F]: the second array starts gridDim.y * F floats further
+    if (rmask) rmask += gi * (int64_t)n_sub * 32;
   }
   const int64_t cs2 = (int64_t)gridDim.y * F;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -365,7 +387,20 @@ __global__ __launch_bounds__(kThreads1, PAIR ? 3 : 5) void site1_bwd_kernel(cons
       av = ab[ch];
       bv = ab[C + ch];
     }
-    if (PAIR && ymask) {
+    if (PAIR && rmask) {
+      // fused ReLU backward from the forward's ONE-BIT mask (round 5: 4 bytes per element of y were read for its sign): lane i holds
+      // the word of row i of this sub-tile (one 128-byte load per wave), row R(q, h)'s word comes over by v_readlane, this
+      // lane's feature is bit l31.  Rows >= B carry row B - 1's bits (the forward's clamped rows hold its values).
+      const unsigned mw = rmask[(int64_t)sub * 32 + l31];
+#pragma unroll
+      for (int q = 0; q < RPL; q++) {
+        const unsigned w0 = (unsigned)__builtin_amdgcn_readlane((int)mw, row_of(q, 0));
+        const unsigned w1 = (unsigned)__builtin_amdgcn_readlane((int)mw, row_of(q, 1));
+        const bool pos = (((h ? w1 : w0) >> l31) & 1u) != 0u;
+        gr[q] = pos ? gr[q] : 0.0f;
+        if (dres) *reinterpret_cast<float*>(reinterpret_cast<char*>(dres) + S2_OFF(q)) = has_g ? gr[q] : 0.0f;
+      }
+    } else if (PAIR && ymask) {
       // fused ReLU backward: the mask from the forward's output; the masked gradient is also the shortcut's gradient (dres).
       // Rows >= B / columns >= F carry the clamped element's values and store them to its address (the owning lane's value).
       float yr[RPL];
@@ -500,15 +535,16 @@ __global__ __launch_bounds__(kThreads1, PAIR ? 3 : 5) void site1_bwd_kernel(cons
 
 int launch_partials1(bool pair, const Geom& g, const float* x, int B, int64_t F, int k, float r, float eps, float* xq,
                      float* stats, float* ws, hipStream_t st, const float* res, int relu, const float* ab, int C, int groups,
-                     int64_t ws_gstride) {
+                     int64_t ws_gstride, unsigned* rmask) {
   unsigned* counter = reinterpret_cast<unsigned*>(ws + (size_t)g.grid * g.slab_floats + kPartFloats);
   if ((int64_t)B * F * 4 >= ((int64_t)1 << 32)) return ALIGNQ_EUNSUPPORTED;   // 32-bit byte offsets
   const int n_sub = (int)((F + SUBF - 1) / SUBF);
   const bool bnd = make_levels(k, fabsf(r) <= 8.0f).yn != 0.0f;       // as the kernel forms its Levels
-  if (pair && res && bnd) hipLaunchKernelGGL((site1_fwd_kernel<true, true, true>), dim3(g.grid, groups), kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter, res, relu, ab, C, ws_gstride);
-  else if (pair && res) hipLaunchKernelGGL((site1_fwd_kernel<true, true>), dim3(g.grid, groups), kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter, res, relu, ab, C, ws_gstride);
-  else if (pair && bnd) hipLaunchKernelGGL((site1_fwd_kernel<true, false, true>), dim3(g.grid, groups), kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter, nullptr, relu, ab, C, ws_gstride);
-  else if (pair) hipLaunchKernelGGL((site1_fwd_kernel<true, false>), dim3(g.grid, groups), kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter, nullptr, relu, ab, C, ws_gstride);
+  if (rmask && !(pair && bnd)) return ALIGNQ_EUNSUPPORTED;            // (k == 1 / k == 32 / a huge act_range: the caller keeps y for the mask)
+  if (pair && res && bnd) hipLaunchKernelGGL((site1_fwd_kernel<true, true, true>), dim3(g.grid, groups), kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter, res, relu, ab, C, ws_gstride, rmask);
+  else if (pair && res) hipLaunchKernelGGL((site1_fwd_kernel<true, true>), dim3(g.grid, groups), kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter, res, relu, ab, C, ws_gstride, rmask);
+  else if (pair && bnd) hipLaunchKernelGGL((site1_fwd_kernel<true, false, true>), dim3(g.grid, groups), kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter, nullptr, relu, ab, C, ws_gstride, rmask);
+  else if (pair) hipLaunchKernelGGL((site1_fwd_kernel<true, false>), dim3(g.grid, groups), kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter, nullptr, relu, ab, C, ws_gstride, rmask);
   else hipLaunchKernelGGL((site1_fwd_kernel<false, false>), dim3(g.grid, groups), kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter, nullptr, 0, ab, C, ws_gstride);
   RET_ON_ERR1();
   return 0;
@@ -516,7 +552,7 @@ int launch_partials1(bool pair, const Geom& g, const float* x, int B, int64_t F,
 
 int launch_bwd1(bool pair, const float* gup, const float* S, const float* x, const float* stats, int B, int64_t F,
                 float r, float eps, float* dx, hipStream_t st, const float* ab, int C, const float* ymask, float* dres, int groups,
-                int64_t s_gstride, const float* gup2, const float* save, float* colsum) {
+                int64_t s_gstride, const float* gup2, const float* save, float* colsum, const unsigned* rmask) {
   if (gup2 && (!gup || !pair)) return ALIGNQ_EINVAL;
   if (colsum && (!pair || !ab || !save)) return ALIGNQ_EINVAL;
   if ((int64_t)B * F * 4 >= ((int64_t)1 << 32)) return ALIGNQ_EUNSUPPORTED;   // 32-bit byte offsets
@@ -527,7 +563,7 @@ int launch_bwd1(bool pair, const float* gup, const float* S, const float* x, con
   constexpr int capb = 768;
   if (grid > capb) grid = capb;
   if (groups > 1 && grid * groups > capb) grid = (capb + groups - 1) / groups;      // the groups share the resident round
-  if (pair) hipLaunchKernelGGL((site1_bwd_kernel<true>), dim3(grid, groups), kThreads1, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_sub, ab, C, ymask, dres, s_gstride, gup2, save, colsum);
+  if (pair) hipLaunchKernelGGL((site1_bwd_kernel<true>), dim3(grid, groups), kThreads1, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_sub, ab, C, ymask, dres, s_gstride, gup2, save, colsum, rmask);
   else hipLaunchKernelGGL((site1_bwd_kernel<false>), dim3(grid, groups), kThreads1, 0, st, gup, S, x, stats, B, F, r, eps, dx, n_sub, ab, C, nullptr, nullptr, s_gstride, nullptr, nullptr, nullptr);
   RET_ON_ERR1();
   return 0;

@@ -112,7 +112,8 @@ inline size_t ws_floats(const Geom& g) { return (size_t)g.grid * g.slab_floats +
 // ---- launchers defined in site1_kernels.hip (2 <= B <= 32) ---------------------------------------------------
 int launch_partials1(bool pair, const Geom& g, const float* x, int B, int64_t F, int k, float r, float eps, float* xq,
                      float* stats, float* ws, hipStream_t st, const float* res = nullptr, int relu = 0,
-                     const float* ab = nullptr, int C = 1, int groups = 1, int64_t ws_gstride = 0);      // ab: folded batch-norm (channels-last, C a power of two)
+                     const float* ab = nullptr, int C = 1, int groups = 1, int64_t ws_gstride = 0,       // ab: folded batch-norm (channels-last, C a power of two)
+                     unsigned* rmask = nullptr);      // (round 5) one sign bit per stored element [groups][sub-tiles][32 rows]: the backward's ReLU mask
 int launch_reduce_loss_groups(const Geom& g, float* ws, int B, int64_t F, int groups, float* D, const float* alterD,
                               const float* gamma, int dim, float mu, float rho, float* scal, int64_t ws_gstride, hipStream_t st);
 int launch_bwd1(bool pair, const float* gup, const float* S, const float* x, const float* stats, int B, int64_t F,
@@ -121,7 +122,8 @@ int launch_bwd1(bool pair, const float* gup, const float* S, const float* x, con
                 const float* gup2 = nullptr,       // a second addend of the upstream gradient (fused.GradFork), or nullptr
                 // round 4: per feature column sum_b dx and sum_b dx * zhat for the folded batch-norm's backward: save = [groups][2][C]
                 // (mean, invstd), colsum = [2][groups][F] floats (written)
-                const float* save = nullptr, float* colsum = nullptr);
+                const float* save = nullptr, float* colsum = nullptr,
+                const unsigned* rmask = nullptr);      // the forward's one-bit ReLU mask instead of ymask (4 B per element)
 // bnq_kernels.hip: the batch-norm backward from those per-column sums (HW columns per channel and group): a small reduction over
 // the columns, the finalisation (channels with gamma == 0 are summed from dx and z directly) and dz = a (dx - k0 - zhat k1)
 int launch_bnq_bwd_from_cols(const float* cols, const float* dx, const float* z, const float* ab, const float* save, int64_t P,

@@ -764,6 +764,25 @@ int alignq_site1_groups_fwd(const float* z, const float* ab, int C, int B, int64
                           groups, (int64_t)(alignq_site_ws_bytes(B, F) / 4));
 }
 
+// (round 5) the same with the stored output's sign bits for the backward (alignq_site1_groups_bwd_bn_m): one bit per element,
+// [groups][ceil(F / 32)][32 rows] words - the backward then reads 0.14 B per element for its ReLU mask instead of 4 B of y
+size_t alignq_site1_mask_bytes(int B, int64_t F, int groups) {
+  if (bad_shape(B, F) || groups < 1) return 0;
+  return (size_t)groups * (size_t)((F + 31) / 32) * 32 * sizeof(unsigned);
+}
+
+int alignq_site1_groups_fwd_m(const float* z, const float* ab, int C, int B, int64_t F, int groups, int k, float act_range,
+                              float eps, const float* residual, int relu, float* y, float* stats, void* ws, void* relu_mask,
+                              void* stream) {
+  if (!z || !ab || !ws || !y || !relu_mask || groups < 1 || C < 1 || (C & (C - 1)) != 0 || F % C != 0) return ALIGNQ_EINVAL;
+  if (bad_shape(B, F)) return F <= 0 ? ALIGNQ_EINVAL : ALIGNQ_EUNSUPPORTED;
+  if (bad_k(k)) return ALIGNQ_EINVAL;
+  const Geom g = geom(B, F);
+  if (g.nb != 1) return ALIGNQ_EUNSUPPORTED;
+  return launch_partials1(true, g, z, B, F, k, act_range, eps, y, stats, (float*)ws, (hipStream_t)stream, residual, relu, ab, C,
+                          groups, (int64_t)(alignq_site_ws_bytes(B, F) / 4), (unsigned*)relu_mask);
+}
+
 int alignq_site1_groups_reduce_loss(void* ws, int B, int64_t F, int groups, float* D, const float* alterD, const float* gamma,
                                     int dim, float mu, float rho, float* scal, void* stream) {
   if (!ws || !D || !alterD || !gamma || !scal || groups < 1 || dim < B) return ALIGNQ_EINVAL;
@@ -845,6 +864,24 @@ int alignq_site1_groups_bwd_bn(const float* g, const float* g2, const float* y, 
   hipStream_t st = (hipStream_t)stream;
   const int rc = launch_bwd1(true, g, S, z, stats, B, F, act_range, eps, dz, st, ab, C, g ? y : nullptr, g ? dres : nullptr, groups,
                              (int64_t)(alignq_site_bwd_ws_bytes(B) / 4), g2, save, (float*)cols);
+  if (rc) return rc;
+  return launch_bnq_bwd_from_cols((const float*)cols, dz, z, ab, save, P, HW, C, groups, dz, dgamma, dbeta, ws_bn, st);
+}
+
+int alignq_site1_groups_bwd_bn_m(const float* g, const float* g2, const void* relu_mask, const float* S, const float* z,
+                                 const float* ab, const float* save, int C, const float* stats, int B, int64_t F, int groups,
+                                 float act_range, float eps, float* dz, float* dres, float* dgamma, float* dbeta, void* cols,
+                                 void* ws_bn, void* stream) {
+  if (!S || !z || !ab || !save || !stats || !dz || !cols || !ws_bn || groups < 1 || groups > ALIGNQ_BNQ_MAX_GROUPS ||
+      (g && !relu_mask) || (g2 && !g) || C < 1 || (C & (C - 1)) != 0 || F % C != 0)
+    return ALIGNQ_EINVAL;
+  if (bad_shape(B, F)) return F <= 0 ? ALIGNQ_EINVAL : ALIGNQ_EUNSUPPORTED;
+  if (geom(B, F).nb != 1) return ALIGNQ_EUNSUPPORTED;
+  const int64_t HW = F / C, P = (int64_t)B * HW;
+  if (P < 2) return ALIGNQ_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int rc = launch_bwd1(true, g, S, z, stats, B, F, act_range, eps, dz, st, ab, C, nullptr, g ? dres : nullptr, groups,
+                             (int64_t)(alignq_site_bwd_ws_bytes(B) / 4), g2, save, (float*)cols, g ? (const unsigned*)relu_mask : nullptr);
   if (rc) return rc;
   return launch_bnq_bwd_from_cols((const float*)cols, dz, z, ab, save, P, HW, C, groups, dz, dgamma, dbeta, ws_bn, st);
 }

@@ -894,6 +894,7 @@ class Site1Batch:
 
 
 _S1_BN_COLS = True        # False: alignq_site1_groups_bwd + alignq_bnq_bwd_dx (a test's comparison arm; not an environment switch)
+_S1_RMASK = True          # False: the bottleneck tail's backward re-reads y for its ReLU mask (tools/ab_office.py's comparison arm)
 
 
 class BNSite1Fn(torch.autograd.Function):
@@ -941,8 +942,18 @@ class BNSite1Fn(torch.autograd.Function):
                                            L.ptr(running_var), L.ptr(nbt), float(momentum), float(bn_eps), L.ptr(ab), L.ptr(save),
                                            L.ptr(ws_bn), L.ptr(cp), cn, st), "alignq_bnq_stats_parts")
         # every slice in ONE launch per kernel (blockIdx.y = slice; the slices' workspace regions lie back to back)
-        L.check(lib.alignq_site1_groups_fwd(L.ptr(z), L.ptr(ab), C, B, F, groups, int(k), float(act_range), float(eps),
-                                            L.ptr(residual), 1, L.ptr(y), L.ptr(stats), L.ptr(ws), st), "alignq_site1_groups_fwd")
+        # (round 5) the stored output's sign bits for the backward's ReLU mask: 1 bit per element instead of re-reading y (the plain
+        # sites have had that since round 4); only with the bounded quantiser form the kernel takes the mask in (2 <= k <= 8 here)
+        rmask = None
+        if _S1_RMASK and _S1_BN_COLS and residual is not None and 2 <= int(k) <= 8 and abs(float(act_range)) <= 8.0:
+            rmask = torch.empty(lib.alignq_site1_mask_bytes(B, F, groups), dtype=torch.uint8, device=dev)
+            L.check(lib.alignq_site1_groups_fwd_m(L.ptr(z), L.ptr(ab), C, B, F, groups, int(k), float(act_range), float(eps),
+                                                  L.ptr(residual), 1, L.ptr(y), L.ptr(stats), L.ptr(ws), L.ptr(rmask), st),
+                    "alignq_site1_groups_fwd_m")
+        else:
+            L.check(lib.alignq_site1_groups_fwd(L.ptr(z), L.ptr(ab), C, B, F, groups, int(k), float(act_range), float(eps),
+                                                L.ptr(residual), 1, L.ptr(y), L.ptr(stats), L.ptr(ws), st), "alignq_site1_groups_fwd")
+        ctx.rmask = rmask
         ctx.rec = None
         if batch is not None:
             ctx.rec = batch.add(ws=ws, D=D, A=A, Gm=Gm, scal=scal, B=B, F=F, groups=int(groups), dim=int(A.shape[0]), mu=float(mu),
@@ -1020,10 +1031,16 @@ class BNSite1Fn(torch.autograd.Function):
             # the site kernel leaves the batch-norm backward's sums per feature column; a small reduction, the finalisation and dz
             # (in place) follow in the same entry: no pass of its own over dx and z
             cols = torch.empty(lib.alignq_site1_cols_bytes(F, groups), dtype=torch.uint8, device=dev)
-            L.check(lib.alignq_site1_groups_bwd_bn(L.ptr(g_y), L.ptr(g_y2), L.ptr(None if g_y is None else y), L.ptr(S), L.ptr(z),
-                                                   L.ptr(ab), L.ptr(save), C, L.ptr(stats), B, F, groups, act_range, eps, L.ptr(dx),
-                                                   L.ptr(g_m), L.ptr(dgamma), L.ptr(dbeta), L.ptr(cols), L.ptr(ws_bn), st),
-                    "alignq_site1_groups_bwd_bn")
+            if ctx.rmask is not None:
+                L.check(lib.alignq_site1_groups_bwd_bn_m(L.ptr(g_y), L.ptr(g_y2), L.ptr(None if g_y is None else ctx.rmask), L.ptr(S),
+                                                         L.ptr(z), L.ptr(ab), L.ptr(save), C, L.ptr(stats), B, F, groups, act_range, eps,
+                                                         L.ptr(dx), L.ptr(g_m), L.ptr(dgamma), L.ptr(dbeta), L.ptr(cols), L.ptr(ws_bn),
+                                                         st), "alignq_site1_groups_bwd_bn_m")
+            else:
+                L.check(lib.alignq_site1_groups_bwd_bn(L.ptr(g_y), L.ptr(g_y2), L.ptr(None if g_y is None else y), L.ptr(S), L.ptr(z),
+                                                       L.ptr(ab), L.ptr(save), C, L.ptr(stats), B, F, groups, act_range, eps, L.ptr(dx),
+                                                       L.ptr(g_m), L.ptr(dgamma), L.ptr(dbeta), L.ptr(cols), L.ptr(ws_bn), st),
+                        "alignq_site1_groups_bwd_bn")
         else:       # (the two-launch form, kept as the comparison arm of tests/test_gpu_round4.py: the sums from a pass over dx and z)
             L.check(lib.alignq_site1_groups_bwd(L.ptr(g_y), L.ptr(g_y2), L.ptr(None if g_y is None else y), L.ptr(S), L.ptr(z),
                                                 L.ptr(ab), C, L.ptr(stats), B, F, groups, act_range, eps, L.ptr(dx), L.ptr(g_m), st),

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALIGNQ_ABI_VERSION 19
+#define ALIGNQ_ABI_VERSION 20
 
 #define ALIGNQ_FORMULA_ADMM 0
 #define ALIGNQ_FORMULA_CDF 1
@@ -581,6 +581,18 @@ int alignq_site1_groups_reduce_loss(void* ws, int B, int64_t F, int groups, floa
 int alignq_site1_groups_prep(const float* D, const float* alterD, const float* gamma, int dim, const float* scal, float mu,
                              const float* dD_scale, int dD_scale_stride, int B, int64_t F, int groups, float* S, float* dalterD,
                              float* dgamma, void* stream);
+/* (round 5, ABI 20) the bottleneck tail with a ONE-BIT ReLU mask: alignq_site1_groups_fwd_m also leaves, per stored element of
+ * y = relu(x_q + identity), its sign bit in relu_mask (alignq_site1_mask_bytes; [groups][ceil(F / 32)][32] words: bit f of word
+ * (s, row) = y[row][32 s + f] > 0); alignq_site1_groups_bwd_bn_m takes that mask where alignq_site1_groups_bwd_bn takes y - the
+ * backward of `out = self.relu(out)` (dann_office/model/resnet.py:154) then reads 0.14 B per element instead of 4.  Same results. */
+size_t alignq_site1_mask_bytes(int B, int64_t F, int groups);
+int alignq_site1_groups_fwd_m(const float* z, const float* ab, int C, int B, int64_t F, int groups, int k, float act_range,
+                              float eps, const float* residual, int relu, float* y, float* stats, void* ws, void* relu_mask,
+                              void* stream);
+int alignq_site1_groups_bwd_bn_m(const float* g, const float* g2, const void* relu_mask, const float* S, const float* z,
+                                 const float* ab, const float* save, int C, const float* stats, int B, int64_t F, int groups,
+                                 float act_range, float eps, float* dz, float* dres, float* dgamma, float* dbeta, void* cols,
+                                 void* ws_bn, void* stream);
 /* (round 5, ABI 16) alignq_site1_groups_reduce_loss / _prep for T sites in ONE launch each (HOST arrays of device pointers, F[i]
  * per site; one B, groups, dim, mu, rho for all; dD_scale: ONE device scalar - the gradient of the sum of every site's and slice's
  * loss - or NULL = 1).  The Office iteration's 16 bottleneck tails (dann_office/model/resnet.py:145-154 called from main.py:372,377)

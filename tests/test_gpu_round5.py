@@ -334,3 +334,55 @@ def test_office_iteration_is_reproducible_run_to_run(dev):
                 assert np.array_equal(p1[n_], p2[n_]), n_
     finally:
         config.args.bitW, config.args.abitW, config.args.train_batch_size, config.args.eval_batch_size = old
+
+
+@pytest.mark.parametrize("B,C,H", [(28, 256, 8), (6, 64, 4), (17, 128, 3), (32, 64, 2)])
+def test_site1_one_bit_relu_mask_gives_the_same_backward(dev, B, C, H):
+    """alignq_site1_groups_fwd_m leaves the sign bit of every stored element of y = relu(x_q + identity); alignq_site1_groups_bwd_bn_m
+    takes those bits where alignq_site1_groups_bwd_bn reads y: dz, dres, dgamma, dbeta bit for bit the same; the bits themselves
+    against y > 0 (two batch slices; batches that leave clamped rows in the last row group; F not reaching a full sub-tile row)."""
+    from alignq_amd import _lib as L
+    lib = L.load()
+    G, k, r, eps = 2, 8, 2.0, 1e-5
+    F, P = C * H * H, B * H * H
+    g = torch.Generator().manual_seed(B + C + H)
+    z = (torch.randn(G * B, H, H, C, generator=g) * 1.2 + 0.1).to(dev)
+    res = torch.relu(torch.randn(G * B, H, H, C, generator=g)).to(dev) - 0.3
+    gy = (torch.randn(G * B, H, H, C, generator=g) * 1e-2).to(dev)
+    gam, bet = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.1).to(dev)
+    ab, save = torch.empty(G, 2, C, device=dev), torch.empty(G, 2, C, device=dev)
+    ws_bn = torch.empty(lib.alignq_bnq_ws_bytes(C, G), dtype=torch.uint8, device=dev)
+    L.check(lib.alignq_bnq_stats(L.ptr(z), P, C, G, L.ptr(gam), L.ptr(bet), None, None, None, 0.1, 1e-5, L.ptr(ab), L.ptr(save), L.ptr(ws_bn),
+                                 None), "stats")
+    stats = torch.empty(G, 4, F, device=dev)
+    ws = torch.empty(lib.alignq_site_ws_bytes(B, F) * G, dtype=torch.uint8, device=dev)
+    y1, y2 = torch.empty_like(z), torch.empty_like(z)
+    mask = torch.zeros(lib.alignq_site1_mask_bytes(B, F, G), dtype=torch.uint8, device=dev)
+    L.check(lib.alignq_site1_groups_fwd(L.ptr(z), L.ptr(ab), C, B, F, G, k, r, eps, L.ptr(res), 1, L.ptr(y1), L.ptr(stats), L.ptr(ws), None), "fwd")
+    L.check(lib.alignq_site1_groups_fwd_m(L.ptr(z), L.ptr(ab), C, B, F, G, k, r, eps, L.ptr(res), 1, L.ptr(y2), L.ptr(stats), L.ptr(ws),
+                                          L.ptr(mask), None), "fwd_m")
+    assert torch.equal(y1, y2)
+    n_sub = (F + 31) // 32
+    words = mask.view(torch.int32).reshape(G, n_sub, 32).cpu().numpy().astype(np.uint32)
+    yn = npy(y1).reshape(G, B, F)
+    for gi in range(G):
+        for row in (0, B // 2, B - 1):
+            bits = ((words[gi, :, row][:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1).reshape(-1)[:F]
+            assert np.array_equal(bits.astype(bool), yn[gi, row] > 0), (gi, row)
+    S = torch.randn(G, B, B, generator=g).to(dev) * 1e-3
+    sb = lib.alignq_site_bwd_ws_bytes(B)
+    Sbuf = torch.zeros(sb * G, dtype=torch.uint8, device=dev)
+    for gi in range(G):
+        Sbuf[gi * sb: gi * sb + B * B * 4] = S[gi].contiguous().view(torch.uint8).reshape(-1)
+    outs = []
+    for use_mask in (False, True):
+        dz, dres = torch.empty_like(z), torch.empty_like(z)
+        dg, db = torch.empty(C, device=dev), torch.empty(C, device=dev)
+        cols = torch.empty(lib.alignq_site1_cols_bytes(F, G), dtype=torch.uint8, device=dev)
+        fn = lib.alignq_site1_groups_bwd_bn_m if use_mask else lib.alignq_site1_groups_bwd_bn
+        L.check(fn(L.ptr(gy), None, L.ptr(mask if use_mask else y1), L.ptr(Sbuf), L.ptr(z), L.ptr(ab), L.ptr(save), C, L.ptr(stats), B, F, G,
+                   r, eps, L.ptr(dz), L.ptr(dres), L.ptr(dg), L.ptr(db), L.ptr(cols), L.ptr(ws_bn), None), "bwd")
+        outs.append((dz, dres, dg, db))
+    torch.cuda.synchronize()
+    for a_, b_ in zip(*outs):
+        assert torch.isfinite(a_).all() and torch.equal(a_, b_)

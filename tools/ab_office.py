@@ -9,6 +9,7 @@ import torch
 ARMS = {
     "base": lambda: None,
     "no_site1_batch": lambda: setattr(__import__("alignq_amd.fused", fromlist=["x"]), "active_site1", lambda: None),
+    "no_rmask": lambda: setattr(__import__("alignq_amd.fused", fromlist=["x"]), "_S1_RMASK", False),
 }
 
 
@@ -48,7 +49,7 @@ def run(arm, steps=20, reps=5):
 
 if __name__ == "__main__":
     from alignq_amd import fused
-    saved = {k: getattr(fused, k) for k in ("active_site1",)}
+    saved = {k: getattr(fused, k) for k in ("active_site1", "_S1_RMASK")}
     for arm in sys.argv[1:] or list(ARMS):
         for k, v in saved.items():
             setattr(fused, k, v)
