@@ -1423,7 +1423,7 @@ static int wgrad_geometry(int B, int H_in, int W_in, int CIN, int COUT, int KS, 
   if (halo_ok(KS, stride, W_in)) {        // qgemm_wgrad3_kernel: 64 x 64 tiles, nine taps per workgroup
     *tc = *tn = 2;
     *tiles = (CIN / 64) * (COUT / 64);
-    *splits = wgrad_splits(*M, *tiles, 512);
+    *splits = wgrad_splits(*M, *tiles, 512);       // (256 / 384: the kernel +6 / +9 us, its slab reduction -9 / -2 us per convolution: a wash)
     return 1;
   }
   *tiles = (CIN / (32 * *tc)) * (COUT / (32 * *tn)) * KS * KS;
