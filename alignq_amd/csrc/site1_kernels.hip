@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kThreads1, PAIR ? 4 : 5) void site1_fwd_kernel(cons
       // registers, a branch per row serialises them).  Rows >= B and columns >= F carry the clamped row's / column's values:
       // they are stored too - the same value to the same address as the lane that owns it - and masked out of the sums.
       float st = 0.f;
-      unsigned mword = 0u;         // lane i < 16 of each half collects the stored-output sign bits of row 16 h + i (rmask)
+      unsigned mbits = 0u;         // rmask: this lane's 16 stored-output sign bits, row 16 h + q at bit 15 - q while they are collected
 #pragma unroll
       for (int q4 = 0; q4 < RPL; q4 += 4) {
         float qq[4], rn[RES ? 4 : 1];
@@ -250,15 +250,8 @@ __global__ __launch_bounds__(kThreads1, PAIR ? 4 : 5) void site1_fwd_kernel(cons
           for (int j = 0; j < 4; j++) *reinterpret_cast<float*>(reinterpret_cast<char*>(xq) + S1_OFF(q4 + j)) = qq[j];
         }
         if (BND && rmask) {  // (launch-uniform; the bounded-quantiser form only: the generic one has no register left for it)
-                             // one bit per stored element: [sub-tile][row][32 features], the backward's ReLU mask
 #pragma unroll
-          for (int j = 0; j < 4; j++) {
-            const unsigned long long bal = __ballot(qq[j] > 0.0f);
-            // row q's word into lane q of the half that owns the row (selects: this compiler has no v_writelane builtin, and an
-            // inline-asm one sits outside its hazard handling - it produced wrong words)
-            const unsigned wq = h ? (unsigned)(bal >> 32) : (unsigned)bal;
-            mword = l31 == q4 + j ? wq : mword;
-          }
+          for (int j = 0; j < 4; j++) mbits = mbits + mbits + (qq[j] > 0.0f ? 1u : 0u);      // (a compare and an add-with-carry per row)
         }
         if (RES && q4 + 4 < RPL) {
 #pragma unroll
@@ -266,7 +259,13 @@ __global__ __launch_bounds__(kThreads1, PAIR ? 4 : 5) void site1_fwd_kernel(cons
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (BND && rmask && l31 < RPL) rmask[(int64_t)sub * 32 + RPL * h + l31] = mword;
+      if (BND && rmask) {
+        // one bit per stored element for the backward's ReLU mask: word [sub-tile][feature], bit R = sign of row R (both row halves
+        // of a feature in one word: the backward's lanes own rows of both)
+        const unsigned mine = __builtin_bitreverse32(mbits) >> 16;                 // row 16 h + q at bit q
+        const unsigned other = (unsigned)__shfl_xor((int)mine, 32, 64);
+        if (h == 0) rmask[(int64_t)sub * 32 + l31] = mine | (other << 16);
+      }
       st += __shfl_xor(st, 32, 64);
       const float mt = st * invB;
       float vt = 0.f;
@@ -388,15 +387,12 @@ __global__ __launch_bounds__(kThreads1, PAIR ? 3 : 5) void site1_bwd_kernel(cons
       bv = ab[C + ch];
     }
     if (PAIR && rmask) {
-      // fused ReLU backward from the forward's ONE-BIT mask (round 5: 4 bytes per element of y were read for its sign): lane i holds
-      // the word of row i of this sub-tile (one 128-byte load per wave), row R(q, h)'s word comes over by v_readlane, this
-      // lane's feature is bit l31.  Rows >= B carry row B - 1's bits (the forward's clamped rows hold its values).
-      const unsigned mw = rmask[(int64_t)sub * 32 + l31];
+      // fused ReLU backward from the forward's ONE-BIT mask (round 5: 4 bytes per element of y were read for its sign): one word
+      // per feature of the sub-tile, bit R = row R.  Rows >= B carry row B - 1's bits (the forward's clamped rows hold its values).
+      const unsigned mw = rmask[(int64_t)sub * 32 + l31] >> (4 * h);       // bit R(q, 0) of it = row R(q, h) of this lane's feature
 #pragma unroll
       for (int q = 0; q < RPL; q++) {
-        const unsigned w0 = (unsigned)__builtin_amdgcn_readlane((int)mw, row_of(q, 0));
-        const unsigned w1 = (unsigned)__builtin_amdgcn_readlane((int)mw, row_of(q, 1));
-        const bool pos = (((h ? w1 : w0) >> l31) & 1u) != 0u;
+        const bool pos = (mw & (1u << row_of(q, 0))) != 0u;
         gr[q] = pos ? gr[q] : 0.0f;
         if (dres) *reinterpret_cast<float*>(reinterpret_cast<char*>(dres) + S2_OFF(q)) = has_g ? gr[q] : 0.0f;
       }

@@ -765,7 +765,7 @@ int alignq_site1_groups_fwd(const float* z, const float* ab, int C, int B, int64
 }
 
 // (round 5) the same with the stored output's sign bits for the backward (alignq_site1_groups_bwd_bn_m): one bit per element,
-// [groups][ceil(F / 32)][32 rows] words - the backward then reads 0.14 B per element for its ReLU mask instead of 4 B of y
+// [groups][ceil(F / 32)][32 features] words, bit = row - the backward then reads 0.14 B per element for its ReLU mask instead of 4 B of y
 size_t alignq_site1_mask_bytes(int B, int64_t F, int groups) {
   if (bad_shape(B, F) || groups < 1) return 0;
   return (size_t)groups * (size_t)((F + 31) / 32) * 32 * sizeof(unsigned);

@@ -539,6 +539,7 @@ def measure_office_shapes(dev, k):
         wsb = lib.alignq_site_ws_bytes(B, F)
         ws = torch.empty(wsb * G, dtype=torch.uint8, device=dev)
         cols = torch.empty(lib.alignq_site1_cols_bytes(F, G), dtype=torch.uint8, device=dev)
+        rmask = torch.empty(lib.alignq_site1_mask_bytes(B, F, G), dtype=torch.uint8, device=dev)       # the forward's one-bit ReLU mask
         sb = lib.alignq_site_bwd_ws_bytes(B)
         S = torch.empty(sb * G, dtype=torch.uint8, device=dev)
         Sg = [S[i * sb:(i + 1) * sb] for i in range(G)]
@@ -549,14 +550,14 @@ def measure_office_shapes(dev, k):
         def s_fwd(i):
             L.check(lib.alignq_bnq_stats(p(zs[i]), P, C, G, p(gam), p(bet), p(rm), p(rv), p(nbt), 0.1, 1e-5, p(ab), p(save), p(ws_bn), st),
                     "alignq_bnq_stats")
-            L.check(lib.alignq_site1_groups_fwd(p(zs[i]), p(ab), C, B, F, G, k, 2.0, 1e-5, p(rs[i]), 1, p(ys[i]), p(stats), p(ws), st),
-                    "alignq_site1_groups_fwd")
+            L.check(lib.alignq_site1_groups_fwd_m(p(zs[i]), p(ab), C, B, F, G, k, 2.0, 1e-5, p(rs[i]), 1, p(ys[i]), p(stats), p(ws), p(rmask), st),
+                    "alignq_site1_groups_fwd_m")
             L.check(lib.alignq_site1_groups_reduce_loss(p(ws), B, F, G, p(D), p(A), p(Gm), B, 0.2, 0.3, p(scal), st),
                     "alignq_site1_groups_reduce_loss")
 
         def s_fwd_site(i):
-            L.check(lib.alignq_site1_groups_fwd(p(zs[i]), p(ab), C, B, F, G, k, 2.0, 1e-5, p(rs[i]), 1, p(ys[i]), p(stats), p(ws), st),
-                    "alignq_site1_groups_fwd")
+            L.check(lib.alignq_site1_groups_fwd_m(p(zs[i]), p(ab), C, B, F, G, k, 2.0, 1e-5, p(rs[i]), 1, p(ys[i]), p(stats), p(ws), p(rmask), st),
+                    "alignq_site1_groups_fwd_m")
 
         def s_bwd(i):
             L.check(lib.alignq_site_prep_fused_multi(*prep_args), "alignq_site_prep_fused_multi")
@@ -567,9 +568,9 @@ def measure_office_shapes(dev, k):
 
         def s_bwd_cols(i):        # round 4 (the step's path): the site backward leaves per-column sums for the batch-norm backward
             L.check(lib.alignq_site_prep_fused_multi(*prep_args), "alignq_site_prep_fused_multi")
-            L.check(lib.alignq_site1_groups_bwd_bn(p(gs[i]), None, p(ys[i]), p(S), p(zs[i]), p(ab), p(save), C, p(stats), B, F, G, 2.0, 1e-5,
-                                                   p(dxs[i]), p(dress[i]), p(dgam), p(dbet), p(cols), p(ws_bn), st),
-                    "alignq_site1_groups_bwd_bn")
+            L.check(lib.alignq_site1_groups_bwd_bn_m(p(gs[i]), None, p(rmask), p(S), p(zs[i]), p(ab), p(save), C, p(stats), B, F, G, 2.0, 1e-5,
+                                                     p(dxs[i]), p(dress[i]), p(dgam), p(dbet), p(cols), p(ws_bn), st),
+                    "alignq_site1_groups_bwd_bn_m")
 
         def s_bwd_site(i):
             L.check(lib.alignq_site1_groups_bwd(p(gs[i]), None, p(ys[i]), p(S), p(zs[i]), p(ab), C, p(stats), B, F, G, 2.0, 1e-5, p(dxs[i]),
@@ -582,11 +583,11 @@ def measure_office_shapes(dev, k):
         out[f"bn_site_2x{B}x{F}"] = {
             "elements": n, "fwd_us": t_f * 1e6, "fwd_hbm_gbs": 16.0 * n / t_f / 1e9, "fwd_frac_of_8TBs": 16.0 * n / t_f / 1e9 / HBM_PEAK_GBS,
             "site_fwd_kernel_us": t_fs * 1e6, "site_fwd_kernel_frac_of_8TBs": 12.0 * n / t_fs / 1e9 / HBM_PEAK_GBS,
-            "bwd_us": t_b * 1e6, "bwd_hbm_gbs": 32.0 * n / t_b / 1e9, "bwd_frac_of_8TBs": 32.0 * n / t_b / 1e9 / HBM_PEAK_GBS,
+            "bwd_us": t_b * 1e6, "bwd_hbm_gbs": 28.125 * n / t_b / 1e9, "bwd_frac_of_8TBs": 28.125 * n / t_b / 1e9 / HBM_PEAK_GBS,
             "bwd_us_with_sums_pass": t_b5 * 1e6,
             "site_bwd_kernel_us": t_bs * 1e6, "site_bwd_kernel_frac_of_8TBs": 20.0 * n / t_bs / 1e9 / HBM_PEAK_GBS,
-            "fwd_bytes_per_elem": 16, "bwd_bytes_per_elem": 32,
-            "note": "site_*_kernel: alignq_site1_groups_fwd (z, residual -> y: 12 B/element) / alignq_site1_groups_bwd (g, y, z -> dx, "
+            "fwd_bytes_per_elem": 16.125, "bwd_bytes_per_elem": 28.125,
+            "note": "bwd (round 5): the ReLU mask from the forward's one-bit mask instead of y; site_*_kernel: alignq_site1_groups_fwd (z, residual -> y: 12 B/element) / alignq_site1_groups_bwd (g, y, z -> dx, "
                     "dres: 20 B/element) alone"}
         del zs, rs, gs, ys, dxs, dress
     return out

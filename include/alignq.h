@@ -582,8 +582,8 @@ int alignq_site1_groups_prep(const float* D, const float* alterD, const float* g
                              const float* dD_scale, int dD_scale_stride, int B, int64_t F, int groups, float* S, float* dalterD,
                              float* dgamma, void* stream);
 /* (round 5, ABI 20) the bottleneck tail with a ONE-BIT ReLU mask: alignq_site1_groups_fwd_m also leaves, per stored element of
- * y = relu(x_q + identity), its sign bit in relu_mask (alignq_site1_mask_bytes; [groups][ceil(F / 32)][32] words: bit f of word
- * (s, row) = y[row][32 s + f] > 0); alignq_site1_groups_bwd_bn_m takes that mask where alignq_site1_groups_bwd_bn takes y - the
+ * y = relu(x_q + identity), its sign bit in relu_mask (alignq_site1_mask_bytes; [groups][ceil(F / 32)][32] words: bit `row` of word
+ * (s, f) = y[row][32 s + f] > 0; rows >= B repeat row B - 1); alignq_site1_groups_bwd_bn_m takes that mask where alignq_site1_groups_bwd_bn takes y - the
  * backward of `out = self.relu(out)` (dann_office/model/resnet.py:154) then reads 0.14 B per element instead of 4.  Same results. */
 size_t alignq_site1_mask_bytes(int B, int64_t F, int groups);
 int alignq_site1_groups_fwd_m(const float* z, const float* ab, int C, int B, int64_t F, int groups, int k, float act_range,

@@ -367,7 +367,7 @@ def test_site1_one_bit_relu_mask_gives_the_same_backward(dev, B, C, H):
     yn = npy(y1).reshape(G, B, F)
     for gi in range(G):
         for row in (0, B // 2, B - 1):
-            bits = ((words[gi, :, row][:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1).reshape(-1)[:F]
+            bits = ((words[gi] >> np.uint32(row)) & 1).reshape(-1)[:F]            # word (sub-tile, feature), bit = row
             assert np.array_equal(bits.astype(bool), yn[gi, row] > 0), (gi, row)
     S = torch.randn(G, B, B, generator=g).to(dev) * 1e-3
     sb = lib.alignq_site_bwd_ws_bytes(B)
