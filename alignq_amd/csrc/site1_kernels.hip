@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kThreads1, PAIR ? 4 : 5) void site1_fwd_kernel(cons
         // one bit per stored element for the backward's ReLU mask: word [sub-tile][feature], bit R = sign of row R (both row halves
         // of a feature in one word: the backward's lanes own rows of both)
         const unsigned mine = __builtin_bitreverse32(mbits) >> 16;                 // row 16 h + q at bit q
-        const unsigned other = (unsigned)__shfl_xor((int)mine, 32, 64);
+        const unsigned other = __builtin_amdgcn_permlane32_swap(mine, mine, false, false)[1];      // lanes < 32: the other half's (no LDS)
         if (h == 0) rmask[(int64_t)sub * 32 + l31] = mine | (other << 16);
       }
       st += __shfl_xor(st, 32, 64);

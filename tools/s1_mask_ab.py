@@ -10,7 +10,7 @@ p = L.ptr
 G, B, k, R = 2, 28, 8, 4
 
 
-def t(fn, n=20):
+def t(fn, n=200):
     for i in range(R):
         fn(i)
     torch.cuda.synchronize()
