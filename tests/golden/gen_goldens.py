@@ -684,10 +684,60 @@ def gen_g11b_cdfonly():
     q, args = _enter("cdf_only", ["--bitW", "8", "--abitW", "8"])
     _g11b(q, args, "cdfonly")
 
+def gen_g14_constant_column():
+    """G14: the CIFAR trees' `corr` divides by an unguarded std (model/quantization.py:134-137), so a feature
+    that is constant over the batch gives 0/0 = NaN in the standardised matrix, and through x_hat x_hat^T / F every entry of the
+    correlation becomes NaN.  `corr` alone with a finite upstream dG: dx is NaN in the constant columns only (column j of the
+    gradient only sees column j of x_hat).  The whole ADMM site: D, the loss and EVERY gradient (dx, dalterD, dgamma) are NaN, while
+    x_q (elementwise) is untouched.  Recorded: the reference's own outputs at [128, 4096] and [28, 1568] with two constant columns
+    (value 0 and value 0.75).  Kept small: x is generated fp16-representable and stored as fp16; x_q as its int16 level index
+    (x_q = idx / n exactly) and corr's dx by value for the first 64 columns (both constant ones among them); everything else as
+    NaN masks (the site's upstream gradient is any finite tensor: not stored)."""
+    import torch
+    q, args = _enter("admm_cifar", ["--bitW", "8", "--abitW", "8", "--train_batch_size", "8"])
+    from utils.admm import ADMM
+    g = torch.Generator().manual_seed(1414)
+    k, n = 8, 255
+    out = {"const_cols": np.array([5, 17]), "const_vals": np.array([0.0, 0.75], dtype=np.float32), "k": np.array(k), "head": np.array(64)}
+    for name, B, C, H, W in (("a", 128, 16, 16, 16), ("b", 28, 8, 14, 14)):
+        x = (torch.randn(B, C * H * W, generator=g) * 0.8 + 0.1).half().float()
+        x[:, 5] = 0.0
+        x[:, 17] = 0.75
+        out[f"x_{name}"] = _np(x).astype(np.float16)
+        assert np.array_equal(out[f"x_{name}"].astype(np.float32), _np(x))
+        out[f"shape_{name}"] = np.array([B, C, H, W])
+        # corr alone
+        dG = torch.randn(B, B, generator=g)
+        xi = x.clone().requires_grad_(True)
+        G = q.corr(xi, xi)
+        G.backward(dG)
+        cdx = _np(xi.grad)
+        out[f"dG_{name}"] = _np(dG)
+        out[f"G_isnan_{name}"] = np.packbits(np.isnan(_np(G)))
+        out[f"corr_dx_isnan_{name}"] = np.packbits(np.isnan(cdx))
+        out[f"corr_dx_head_{name}"] = cdx[:, :64].copy()
+        # the whole ADMM site (model/quantization.py:102-132, utils/admm.py:24-33)
+        torch.manual_seed(141)
+        admm = ADMM(B)
+        fn = q.activation_quantize_fn(k, "second", admm)
+        gq = (torch.randn(B, C, H, W, generator=g) * 0.01).half().float()
+        xi = x.clone().view(B, C, H, W).requires_grad_(True)
+        out[f"alterD0_{name}"], out[f"gamma0_{name}"] = _np(admm.alterD), _np(admm.gamma)
+        xq, tl = fn(xi)
+        (tl + (xq * gq).sum()).backward()
+        bins = np.rint(_np(xq).astype(np.float64) * n).reshape(B, -1)
+        assert np.array_equal((bins / n).astype(np.float32), _np(xq).reshape(B, -1))
+        out[f"bins_head_{name}"] = bins[:, :64].astype(np.int16)       # (the upstream gradient is not stored: any finite one gives NaN)
+        out[f"loss_{name}"] = _np(tl)
+        for key, t in (("D", admm.D), ("dx", xi.grad), ("dalterD", admm.alterD.grad), ("dgamma", admm.gamma.grad)):
+            out[f"{key}_isnan_{name}"] = np.packbits(np.isnan(_np(t)))
+    _save("g14_constant_column", **out)
+
 
 GEN = {"g11b_admm": gen_g11b_admm, "g11b_cdfonly": gen_g11b_cdfonly, "g3l_admm": gen_g3l_admm, "g3l_cdfonly": gen_g3l_cdfonly, "admm_cifar": gen_admm_cifar, "cdf_only": gen_cdf_only, "office": gen_office, "office_keys": gen_office_keys,
        "corr_xy_admm": gen_corr_xy_admm, "corr_xy_office": gen_corr_xy_office, "office_tiny_dann": gen_office_tiny_dann, "tiny_resnet_sites": gen_tiny_resnet_sites,
-       "office_bottleneck_sites": gen_office_bottleneck_sites}
+       "office_bottleneck_sites": gen_office_bottleneck_sites,
+       "g14_constant_column": gen_g14_constant_column}
 
 
 def main():

@@ -381,3 +381,52 @@ def test_act_quant_bins_vs_reference_at_scale(tree, formula, record_property):
         print(f"G3L {tree} k={k}: {n_tie} of 2^20 elements in the tie zone, {flips} bins differ from the reference")
         assert flips <= 16
         assert 100 < n_tie < 400            # 2 * TIE of the unit interval per bin: ~210 expected
+
+
+def _unpack_nan(g, key, shape):
+    return np.unpackbits(g[key])[: int(np.prod(shape))].astype(bool).reshape(shape)
+
+
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_constant_column_gives_the_reference_nan_pattern(name):
+    """SURVEY H5 / F9 (fixture G14): the CIFAR trees' corr has no epsilon (cdf_alignment_admm/resnet-20-cifar-10/model/
+    quantization.py:134-137).  With two columns constant over the batch the reference gives: corr all NaN; corr's dx for a finite
+    dG NaN in exactly those columns and the usual values elsewhere; the ADMM site: D, loss, dx, dalterD, dgamma all NaN, x_q
+    untouched.  The C oracle reproduces each of them (IEEE arithmetic, no clamping); with eps = 1e-5 everything is finite."""
+    g = load_golden("g14_constant_column")
+    x = g[f"x_{name}"].astype(np.float32)
+    B, F = x.shape
+    k, head = int(g["k"]), int(g["head"])
+    n = 2 ** k - 1
+    cols = [int(c) for c in g["const_cols"]]
+    assert all(np.all(x[:, c] == v) for c, v in zip(cols, g["const_vals"]))
+    # corr alone
+    G = O.corr_fwd(x, 0.0)
+    assert np.array_equal(np.isnan(G), _unpack_nan(g, f"G_isnan_{name}", (B, B))) and np.isnan(G).all()
+    dx = O.corr_bwd(g[f"dG_{name}"], x, 0.0)
+    want_nan = _unpack_nan(g, f"corr_dx_isnan_{name}", (B, F))
+    assert np.array_equal(np.isnan(dx), want_nan)
+    assert want_nan[:, cols].all() and want_nan.sum() == B * len(cols)
+    ref = g[f"corr_dx_head_{name}"]
+    ok = ~np.isnan(ref)
+    np.testing.assert_allclose(dx[:, :head][ok], ref[ok], atol=TOL * max(1.0, float(np.abs(ref[ok]).max())), rtol=1e-4)
+    # the whole site
+    xq, D = O.site_fwd(x, k, 2.0, 0.0)
+    assert np.isnan(D).all() and _unpack_nan(g, f"D_isnan_{name}", (B, B)).all()
+    _, t, _ = O.act_quant_fwd(x, k, 2.0, O.FORMULA_ADMM)
+    bins_ref = g[f"bins_head_{name}"].astype(np.float32) / n
+    check_bins(xq[:, :head], bins_ref, t[:, :head].astype(np.float64) * n, n)
+    assert np.isfinite(xq).all()
+    loss, dD, dA, dg = O.admm_loss(D, g[f"alterD0_{name}"], g[f"gamma0_{name}"], 0.2, 0.3)
+    assert np.isnan(loss) and np.isnan(g[f"loss_{name}"])
+    for got, key, shape in ((dD, None, None), (dA, "dalterD", (B, B)), (dg, "dgamma", (B, B))):
+        assert np.isnan(got).all()
+        if key:
+            assert _unpack_nan(g, f"{key}_isnan_{name}", shape).all()
+    gq = (np.random.default_rng(3).standard_normal((B, F)) * 0.01).astype(np.float32)
+    sdx = O.site_bwd(gq, dD, x, 2.0, 0.0)
+    assert np.isnan(sdx).all() and _unpack_nan(g, f"dx_isnan_{name}", (B, F)).all()
+    # Office form (dann_office/model/quantization.py:158-161): the guarded std keeps everything finite
+    xq_e, D_e = O.site_fwd(x, k, 2.0, 1e-5)
+    assert np.isfinite(D_e).all() and np.array_equal(xq_e, xq)
+    assert np.isfinite(O.corr_bwd(g[f"dG_{name}"], x, 1e-5)).all()

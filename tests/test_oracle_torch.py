@@ -281,3 +281,39 @@ def test_g11b_cdf_with_live_statistics(tree, fname):
     c.backward(gc)
     np.testing.assert_allclose(c.detach().numpy(), g["cdf_ms"], atol=1e-6)
     np.testing.assert_allclose(w.grad.numpy(), g["dW_ms"], atol=2e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_g14_constant_column_nan_pattern(name):
+    """corr without epsilon (cdf_alignment_admm/resnet-20-cifar-10/model/quantization.py:134-137) on a batch with
+    constant columns - the restatement gives the reference's NaN pattern: corr all NaN, its dx NaN in those columns only, the ADMM
+    site's D / loss / every gradient NaN, x_q bit-identical to the recorded level indices."""
+    g = load_golden("g14_constant_column")
+    x0 = T(g[f"x_{name}"].astype(np.float32))
+    B, F = x0.shape
+    k, head = int(g["k"]), int(g["head"])
+    n = 2 ** k - 1
+    unpack = lambda key, shape: np.unpackbits(g[key])[: int(np.prod(shape))].astype(bool).reshape(shape)     # noqa: E731
+    x = x0.clone().requires_grad_(True)
+    G = R.corr(x, x, 0.0)
+    G.backward(T(g[f"dG_{name}"]))
+    assert np.array_equal(np.isnan(G.detach().numpy()), unpack(f"G_isnan_{name}", (B, B)))
+    dx = x.grad.numpy()
+    assert np.array_equal(np.isnan(dx), unpack(f"corr_dx_isnan_{name}", (B, F)))
+    ref = g[f"corr_dx_head_{name}"]
+    ok = ~np.isnan(ref)
+    np.testing.assert_allclose(dx[:, :head][ok], ref[ok], rtol=1e-5, atol=1e-6)
+    cfg = R.Config(tree="admm")
+    admm = R.ADMM(B)
+    with torch.no_grad():
+        admm.alterD.copy_(T(g[f"alterD0_{name}"]))
+        admm.gamma.copy_(T(g[f"gamma0_{name}"]))
+    shape = tuple(int(v) for v in g[f"shape_{name}"])
+    x = x0.clone().view(shape).requires_grad_(True)
+    xq, tl = R.act_quant(x, k, "second", cfg, admm)
+    (tl + (xq * 0.01).sum()).backward()
+    # (by value: the fixture keeps integer level indices, which cannot tell -0 from +0)
+    assert np.array_equal(xq.detach().view(B, F)[:, :head].numpy(), (g[f"bins_head_{name}"].astype(np.float64) / n).astype(np.float32))
+    assert torch.isnan(tl) and np.isnan(g[f"loss_{name}"])
+    for t, key, shp in ((admm.D, "D", (B, B)), (x.grad, "dx", (B, F)), (admm.alterD.grad, "dalterD", (B, B)), (admm.gamma.grad, "dgamma", (B, B))):
+        assert np.array_equal(np.isnan(t.detach().numpy().reshape(shp)), unpack(f"{key}_isnan_{name}", shp)), key
