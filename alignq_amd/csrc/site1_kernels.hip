@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kThreads1, PAIR ? 4 : 5) void site1_fwd_kernel(cons
   Levels nlev = make_levels(k, fabsf(r) <= 8.0f);
   nlev.n = uni(nlev.n);
   nlev.yn = uni(nlev.yn);
-  const float invB = uni(1.0f / (float)B), invBm1 = uni(1.0f / (float)(B - 1));
+  const float invBm1 = uni(1.0f / (float)(B - 1));
   if (blockIdx.x == 0 && tid == 0 && counter) *counter = 0u;
 
   f32x16 acc;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(kThreads1, PAIR ? 4 : 5) void site1_fwd_kernel(cons
     for (int q = 0; q < RPL; q++)
       if (RPL * h + q < B) sx += xr[q];
     sx += __shfl_xor(sx, 32, 64);
-    const float mx = sx * invB;
+    const float mx = sx / (float)B;          // true division, like torch.mean: a constant column gives EXACTLY its value
     float vx = 0.f;
 #pragma unroll
     for (int q = 0; q < RPL; q++) {
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(kThreads1, PAIR ? 4 : 5) void site1_fwd_kernel(cons
         if (h == 0) rmask[(int64_t)sub * 32 + l31] = mine | (other << 16);
       }
       st += __shfl_xor(st, 32, 64);
-      const float mt = st * invB;
+      const float mt = st / (float)B;
       float vt = 0.f;
 #pragma unroll
       for (int q = 0; q < RPL; q++) {

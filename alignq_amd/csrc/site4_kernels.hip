@@ -304,7 +304,7 @@ __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restri
   const int c = tid % LPR, rg = tid / LPR;
   const int h = lane >> 5, l31 = lane & 31;
   const Levels nlev = make_levels(k, fabsf(r) <= 8.0f);
-  const float invB = 1.0f / (float)B, invBm1 = 1.0f / (float)(B - 1);
+  const float invBm1 = 1.0f / (float)(B - 1);
 
   if (blockIdx.x == 0 && tid == 0 && counter) *counter = 0u;   // arrival counter of the reduce kernel's epilogue
 
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restri
 #pragma unroll
         for (int g = 0; g < NW; g += 2 * o) pw[g] += pw[g + o];
       }
-      colv[(2 * op) * TFv + cc] = pw[0] * invB;
+      colv[(2 * op) * TFv + cc] = pw[0] / (float)B;      // true division, like torch.mean (a constant column: exactly its value)
     }
     __syncthreads();
     // ---- column variances (two-pass) --------------------------------------------------------------

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(kThreads) void site_fwd_kernel(const float* __restr
   const int c = tid & 15, rg = tid >> 4;
   const int h = lane >> 5, l31 = lane & 31;
   const Levels nlev = make_levels(k, fabsf(r) <= 8.0f);
-  const float invB = 1.0f / (float)B, invBm1 = 1.0f / (float)(B - 1);
+  const float invBm1 = 1.0f / (float)(B - 1);
   if (blockIdx.x == 0 && tid == 0 && counter) *counter = 0u;   // arrival counter of the reduce epilogue
 
   // wave -> output tiles
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(kThreads) void site_fwd_kernel(const float* __restr
       float s = 0.f;
 #pragma unroll
       for (int g = 0; g < 16; g++) s += red[op * 16 * TF + g * TF + cc];
-      colv[(2 * op) * TF + cc] = s * invB;
+      colv[(2 * op) * TF + cc] = s / (float)B;      // true division, like torch.mean (a constant column: exactly its value)
     }
     __syncthreads();
     // ---- column variances (two-pass) ----------------------------------------------------------

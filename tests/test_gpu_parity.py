@@ -513,9 +513,17 @@ def test_graph_capture_matches_eager(dev):
             eager(x, y)
             graphed(x, y)
         torch.cuda.synchronize()
-        # eager did 5 iterations; graphed did 3 warm-up + 1 capture pass (not executed) + 2 replays = 5
-        for (n1, p1), (_, p2) in zip(nets[0].named_parameters(), nets[1].named_parameters()):
-            np.testing.assert_allclose(npy(p1), npy(p2), atol=2e-4, rtol=1e-3, err_msg=n1)
+        # eager did 5 iterations; graphed did 3 warm-up + 1 capture pass (not executed) + 2 replays = 5.
+        # NAMED, BOUNDED EXCEPTION to round 6's bit-for-bit rule (tests/test_gpu_round6.py asserts equality on every benchmarked
+        # configuration, whose convolutions are this repository's kernels): this small NCHW step runs F.conv2d on MIOpen, which
+        # picks its filter-gradient algorithm per call context (measured on MI355X: conv weights differ by 1-3e-8 = one ulp after five
+        # steps, nothing else does) - library code outside this repository.  Bound: 1e-6 absolute / 1e-5 relative.
+        from tests.test_gpu_round6 import differing, full_state
+        sa, sb = full_state(nets[0], eager, eager.admms), full_state(nets[1], graphed, graphed.admms)
+        bad = differing(sa, sb)
+        print("MIOpen-path graph vs eager: tensors differing bitwise:", [(b_[0], b_[3]) for b_ in bad])
+        for key in sa:
+            np.testing.assert_allclose(sa[key], sb[key], atol=1e-6, rtol=1e-5, err_msg=key)
     finally:
         config.args.bitW = config.args.abitW = 8
         config.args.train_batch_size = 128

@@ -149,3 +149,161 @@ def test_graph_replay_equals_eager_bit_for_bit_office(dev):
         assert not bad, "graph replay differs from eager in %d tensors, first: %s" % (len(bad), bad[:6])
     finally:
         config.args.bitW, config.args.abitW, config.args.train_batch_size, config.args.eval_batch_size = old
+
+
+# ------------------------------------------------------------------------------------------------ SURVEY H5 / F9
+from tests import oracle_c as O                      # noqa: E402
+from tests.conftest import load_golden               # noqa: E402
+
+
+def cu(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _unpack_nan(g, key, shape):
+    return np.unpackbits(g[key])[: int(np.prod(shape))].astype(bool).reshape(shape)
+
+
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_constant_column_without_epsilon_gives_the_reference_nan_pattern(dev, name):
+    """The CIFAR trees' corr divides by an unguarded std (cdf_alignment_admm/resnet-20-cifar-10/model/quantization.py:134-137): a
+    feature that is constant over the batch makes the whole correlation NaN.  Fixture G14 holds the reference's own outputs at
+    [128, 4096] ("a": the split-bf16 MFMA site kernels) and [28, 1568] ("b": the wave-autonomous small-batch kernels) with two
+    constant columns.  Through the drop-in modules (activation_quantize_fn + ADMM, corr): x_q unaffected and bit-exact, D / loss /
+    dx / dalterD / dgamma NaN exactly where the reference's are (everywhere); corr's dx for a finite dG NaN in the constant columns
+    only and within 1e-5 of the reference elsewhere; with the Office tree's eps = 1e-5 everything is finite."""
+    import alignq_amd.cdf_alignment_admm as NA
+    import alignq_amd.office as NO
+    from alignq_amd import config, ops
+    g = load_golden("g14_constant_column")
+    x0 = g[f"x_{name}"].astype(np.float32)
+    B, F = x0.shape
+    shape = tuple(int(v) for v in g[f"shape_{name}"])
+    k, head = int(g["k"]), int(g["head"])
+    n = 2 ** k - 1
+    cols = [int(c) for c in g["const_cols"]]
+    old = (config.args.abitW, config.args.train_batch_size)
+    config.args.abitW, config.args.train_batch_size = k, B
+    try:
+        # ---- corr alone (ops.CorrFn through the namespace's corr)
+        x = cu(x0, dev).requires_grad_(True)
+        G = NA.corr(x, x)
+        G.backward(cu(g[f"dG_{name}"], dev))
+        assert np.isnan(npy(G)).all() and _unpack_nan(g, f"G_isnan_{name}", (B, B)).all()
+        dx = npy(x.grad)
+        want_nan = _unpack_nan(g, f"corr_dx_isnan_{name}", (B, F))
+        assert np.array_equal(np.isnan(dx), want_nan), (int(np.isnan(dx).sum()), int(want_nan.sum()))
+        ref = g[f"corr_dx_head_{name}"]
+        ok = ~np.isnan(ref)
+        np.testing.assert_allclose(dx[:, :head][ok], ref[ok], atol=1e-5 * max(1.0, float(np.abs(ref[ok]).max())), rtol=1e-4)
+        o_dx = O.corr_bwd(g[f"dG_{name}"], x0, 0.0)
+        fin = ~want_nan
+        np.testing.assert_allclose(dx[fin], o_dx[fin], atol=1e-5 * max(1.0, float(np.abs(o_dx[fin]).max())), rtol=1e-4)
+        # ---- the whole ADMM site
+        admm = NA.ADMM(B).to(dev)
+        with torch.no_grad():
+            admm.alterD.copy_(cu(g[f"alterD0_{name}"], dev))
+            admm.gamma.copy_(cu(g[f"gamma0_{name}"], dev))
+        act = NA.activation_quantize_fn(k, "second", admm).to(dev)
+        xs = cu(x0.reshape(shape), dev).requires_grad_(True)
+        gq = (torch.randn(shape, generator=torch.Generator().manual_seed(1)) * 0.01).to(dev)
+        xq, loss = act(xs)
+        torch.autograd.backward([xq, loss], [gq, torch.ones((), device=dev)])
+        oq, oD = O.site_fwd(x0, k, 2.0, 0.0)
+        assert np.array_equal(npy(xq).reshape(B, F).view(np.uint32), oq.view(np.uint32))               # x_q: bit for bit
+        assert np.array_equal(npy(xq).reshape(B, F)[:, :head], (g[f"bins_head_{name}"].astype(np.float64) / n).astype(np.float32))
+        for t, key, shp in ((admm.D, "D", (B, B)), (xs.grad, "dx", (B, F)), (admm.alterD.grad, "dalterD", (B, B)),
+                            (admm.gamma.grad, "dgamma", (B, B))):
+            got = np.isnan(npy(t).reshape(shp))
+            assert np.array_equal(got, _unpack_nan(g, f"{key}_isnan_{name}", shp)), (key, int(got.sum()), got.size)
+        assert np.isnan(float(loss.detach())) and np.isnan(g[f"loss_{name}"]) and np.isnan(oD).all()
+        # ---- Office tree: std + 1e-5 (dann_office/model/quantization.py:158-161): finite, and equal to the oracle
+        xe = cu(x0, dev).requires_grad_(True)
+        Ge = NO.corr(xe, xe)
+        Ge.backward(cu(g[f"dG_{name}"], dev))
+        np.testing.assert_allclose(npy(Ge), O.corr_fwd(x0, 1e-5), atol=1e-5, rtol=0)
+        o_dxe = O.corr_bwd(g[f"dG_{name}"], x0, 1e-5)
+        np.testing.assert_allclose(npy(xe.grad), o_dxe, atol=1e-5 * max(1.0, float(np.abs(o_dxe).max())), rtol=1e-4)
+    finally:
+        config.args.abitW, config.args.train_batch_size = old
+
+
+@pytest.mark.parametrize("B,F", [(192, 1000), (300, 4096)])
+def test_constant_column_without_epsilon_above_128_rows(dev, B, F):
+    """The same on the blocked Gram (corr_large_kernels.hip, B > 128): G all NaN, dx NaN in the constant columns only, the other
+    columns within 1e-5 of the C oracle (which the G14 fixture pins to the reference's pattern at [128, 4096] / [28, 1568])."""
+    from alignq_amd import ops
+    rng = np.random.default_rng(B)
+    x0 = (rng.standard_normal((B, F)) * 0.8 + 0.1).astype(np.float32)
+    x0[:, 5], x0[:, 17] = 0.0, 0.75
+    dG = rng.standard_normal((B, B)).astype(np.float32)
+    x = cu(x0, dev).requires_grad_(True)
+    G = ops.CorrFn.apply(x, 0.0)
+    G.backward(cu(dG, dev))
+    oG, odx = O.corr_fwd(x0, 0.0), O.corr_bwd(dG, x0, 0.0)
+    assert np.isnan(oG).all() and np.isnan(npy(G)).all()
+    dx = npy(x.grad)
+    assert np.array_equal(np.isnan(dx), np.isnan(odx)) and np.isnan(odx).sum() == 2 * B and np.isnan(odx[:, [5, 17]]).all()
+    fin = ~np.isnan(odx)
+    np.testing.assert_allclose(dx[fin], odx[fin], atol=1e-5 * max(1.0, float(np.abs(odx[fin]).max())), rtol=1e-4)
+
+
+@pytest.mark.parametrize("nhwc", [False, True])
+def test_constant_column_through_the_bn_folded_site(dev, nhwc):
+    """The bench path's site (fused.bn_site: batch-norm folded into site_fwd4 / site_bwd4, slab_reduce_multi, ADMM loss; CIFAR tree,
+    eps = 0) with a feature position that is constant over the batch in z (hence in x = a z + b): y = relu(x_q + residual) is the
+    oracle's up to tie-zone flips (the device's (a, b) differ from the oracle's in the last bit); D, the loss, dz, dgamma, dbeta,
+    dalterD, dgamma_admm are NaN like the oracle's (all of them), the residual's gradient (a ReLU mask of the upstream) stays
+    finite and bit-exact."""
+    import alignq_amd.cdf_alignment_admm as NA
+    from alignq_amd import config
+    from alignq_amd.fused import bn_site, bn_site_fusable
+    g = load_golden("g14_constant_column")
+    B, C, H, W = (int(v) for v in g["shape_a"])
+    k, r = 8, 2.0
+    n = 2 ** k - 1
+    old = (config.args.bitW, config.args.abitW, config.args.train_batch_size)
+    config.args.bitW = config.args.abitW = k
+    config.args.train_batch_size = B
+    try:
+        zl = g["x_a"].astype(np.float32) * 1.7 + 0.3                  # [B, F] in MEMORY order (columns 5 and 17 constant)
+        rng = np.random.default_rng(8)
+        rl = (rng.standard_normal(zl.shape) * 0.7).astype(np.float32)
+        gl = (rng.standard_normal(zl.shape) * 0.01).astype(np.float32)
+        gam, bet = (rng.random(C) + 0.5).astype(np.float32), (rng.standard_normal(C) * 0.2).astype(np.float32)
+
+        def to_dev(m):
+            if nhwc:
+                return cu(m.reshape(B, H, W, C), dev).permute(0, 3, 1, 2)       # channels-last strides, logical NCHW
+            return cu(m.reshape(B, C, H, W), dev)
+
+        def mem(t):
+            t = t.detach()
+            return npy(t.permute(0, 2, 3, 1).contiguous() if nhwc else t.contiguous()).reshape(B, -1)
+        bn = torch.nn.BatchNorm2d(C).to(dev).train()
+        with torch.no_grad():
+            bn.weight.copy_(cu(gam, dev))
+            bn.bias.copy_(cu(bet, dev))
+        admm = NA.ADMM(B).to(dev)
+        A0, G0 = npy(admm.alterD), npy(admm.gamma)
+        act = NA.activation_quantize_fn(k, "second", admm)
+        z = to_dev(zl).requires_grad_(True)
+        res = to_dev(rl).requires_grad_(True)
+        assert bn_site_fusable(bn, act, z)
+        y, loss = bn_site(bn, act, z, relu=True, residual=res)
+        torch.autograd.backward([y, loss], [to_dev(gl), torch.ones((), device=dev)])
+        ab_o, save_o, _ = O.bn_fold_ab(zl, C, int(nhwc), gam, bet, 1e-5)
+        y_o, D_o, x_o = O.bn_site_fwd(zl, C, int(nhwc), ab_o, k, r, 0.0, rl, True)
+        loss_o, dD_o, dA_o, dG_o = O.admm_loss(D_o, A0, G0, 0.2, 0.3)
+        dz_o, dgam_o, dbet_o, dres_o, _ = O.bn_site_bwd(gl, dD_o, zl, C, int(nhwc), ab_o, save_o, y_o, r, 0.0)
+        assert np.isnan(D_o).all() and np.isnan(loss_o) and np.isnan(dz_o).all() and np.isfinite(dres_o).all()
+        flips = np.abs(mem(y) - y_o) * n
+        assert np.isfinite(mem(y)).all() and flips.max() <= 1.0 + 1e-3 and (flips > 0.5).mean() < 1e-4
+        assert np.isnan(npy(admm.D)).all() and np.isnan(float(loss.detach()))
+        for got, want, what in ((mem(z.grad), dz_o, "dz"), (npy(bn.weight.grad), dgam_o, "dgamma"), (npy(bn.bias.grad), dbet_o, "dbeta"),
+                                (npy(admm.alterD.grad), dA_o, "dalterD"), (npy(admm.gamma.grad), dG_o, "dgamma_admm")):
+            assert np.array_equal(np.isnan(got), np.isnan(want)) and np.isnan(want).all(), what
+        same_mask = (mem(y) > 0) == (y_o > 0)
+        assert np.array_equal(mem(res.grad)[same_mask], dres_o[same_mask]) and same_mask.mean() > 1 - 1e-4
+    finally:
+        config.args.bitW, config.args.abitW, config.args.train_batch_size = old
