@@ -297,6 +297,276 @@ __global__ __launch_bounds__(kThreads1, PAIR ? 4 : 5) void site1_fwd_kernel(cons
   for (int e = tid; e < 1024; e += kThreads1) slab[e] = C[e] + C[1024 + e] + C[2048 + e] + C[3072 + e];
 }
 
+// ================================================================================================ forward, 64-feature form (round 6)
+// VERDICT r5 item 2a asked for >= 256-byte row segments without the registers that two feature columns per lane cost.  This form
+// gets them by turning the wave's tile around: ONE LANE PER FEATURE COLUMN (64 features = 256-byte row segments for every load
+// and store of the kernel), the lane holding ALL B rows of its column:
+//   * no row is padded: 28 rows cost 28 rows (the 32-feature form computes 16 rows in both half-waves: 4 of 32 wasted at B = 28),
+//     the batch statistics are plain register sums - no cross-half shuffle, no per-row "row < B" selects, no clamped addresses;
+//   * the standardised columns go to a wave-private fp32 image [row][feature] with ONE ds_write_b32 per element; the Gram reads it
+//     back in MFMA fragment order (lane = row, 8 consecutive features = two ds_read_b128) and only THERE splits into bf16 hi / lo -
+//     on pairs (v_cvt_pk_bf16_f32), 3 vector instructions per value instead of ~10 for the packed (hi << 16 | lo) words plus their
+//     unpacking;
+//   * image layout: [32 rows][68 floats] (272-byte rows): the lane = feature accesses of one row touch 64 consecutive dwords
+//     (conflict-free b32, the row a compile-time offset of the instruction), the lane = row b128 reads of one 16-byte feature
+//     granule start (17 r + g) granules in: 16 distinct bank quads within each of the instruction's 16-lane groups
+//     (MI355X_MICROARCH.md, LDS table);
+//   * every row address is a scalar base (x + q * rowB) plus ONE vector offset (the lane's column): no vector add per access;
+//   * nothing is prefetched: measured on one box (NOTES.md, round 6) a second register set for the next tile's x rows (3 waves per SIMD,
+//     or 4 with spills), all 28 shortcut rows requested with the x rows (one wait per tile instead of seven) and both together are
+//     equal or slower - the kernel sits at 82-86 % of what a LINEAR copy of the same 2 reads + 1 write reaches on this chip
+//     (tools/src/rows_bw.hip: 5.2-5.4 TB/s), and a compute-free build of it is only 8 us faster.  An LDS-DMA landing pad for the next
+//     tile (global_load_lds_dwordx4) was priced, not built: with the staging image it is 15 KiB per wave = 10 waves per CU.
+// Preconditions (launcher): PAIR, bounded quantiser, B = 28 or 32 (straight-line code over the rows: a template parameter; with the
+// row count a run-time value the register allocation degenerated); everything else runs the 32-feature form above.
+constexpr int TF1 = 64;
+constexpr int kRowB = 272;                 // bytes per image row: 64 floats + 16 B (17 granules: b128 reads down a column spread over all banks)
+constexpr int kStageB = 32 * kRowB;        // bytes of one wave's image (rows >= B stay zero)
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x4_t1 __attribute__((ext_vector_type(4)));
+
+// 8 fp32 values -> their bf16 high parts and the bf16 of the remainders (element j of the vectors = value j)
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+  u32x4 h, l;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const f32x2_t two = {v[2 * q], v[2 * q + 1]};
+    const unsigned pw = __builtin_bit_cast(unsigned, __builtin_convertvector(two, bf16x2_t));
+    const float h0 = __uint_as_float(pw << 16), h1 = __uint_as_float(pw & 0xffff0000u);
+    const f32x2_t rem = {v[2 * q] - h0, v[2 * q + 1] - h1};
+    h[q] = pw;
+    l[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(rem, bf16x2_t));
+  }
+  hi = __builtin_bit_cast(bf16x8, h);
+  lo = __builtin_bit_cast(bf16x8, l);
+}
+
+
+// Gram of the staged 64 features: acc (+/-)= V V^T; lane = (row l & 31, feature group l >> 5), 4 K-steps of 16 features
+template <bool NEG>
+__device__ __forceinline__ void gram64(const char* __restrict__ Wr, f32x16& acc) {       // Wr: this lane's row, at its K-half
+#pragma unroll
+  for (int ks = 0; ks < TF1 / 16; ks++) {
+    const f32x4_t1 a = *reinterpret_cast<const f32x4_t1*>(Wr + 64 * ks);
+    const f32x4_t1 b = *reinterpret_cast<const f32x4_t1*>(Wr + 64 * ks + 16);
+    const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    bf16x8 hi, lo;
+    split8(v, hi, lo);
+    if (NEG) {          // - V V^T in three terms from hi, lo and ONE negated vector: (-hi) hi + (-hi) lo + lo (-hi)
+      const bf16x8 nhi = neg8(hi);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nhi, hi, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nhi, lo, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lo, nhi, acc, 0, 0, 0);
+    } else {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hi, hi, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hi, lo, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lo, hi, acc, 0, 0, 0);
+    }
+  }
+}
+
+template <bool RES, int NG>
+__global__ __launch_bounds__(kThreads1, 4) void site1_fwd64_kernel(const float* __restrict__ x, int B, int64_t F, int k, float r,
+                                                                   float eps, float* __restrict__ xq, float* __restrict__ slabs,
+                                                                   float* __restrict__ stats, int n_sub32,
+                                                                   unsigned* __restrict__ counter, const float* __restrict__ res,
+                                                                   int relu, const float* __restrict__ ab, int nch,
+                                                                   int64_t ws_gstride, unsigned* __restrict__ rmask) {
+  {      // blockIdx.y = group, as in site1_fwd_kernel
+    const int64_t gi = blockIdx.y, go = gi * (int64_t)B * F;
+    x += go;
+    if (xq) xq += go;
+    if (res) res += go;
+    if (stats) stats += gi * 4 * F;
+    slabs += gi * ws_gstride;
+    if (counter) counter += gi * ws_gstride;
+    if (ab) ab += gi * 2 * nch;
+    if (rmask) rmask += gi * (int64_t)n_sub32 * 32;
+  }
+  __shared__ __attribute__((aligned(16))) char img[kWaves * kStageB];
+  __shared__ __attribute__((aligned(16))) float nerf_lds[ALIGNQ_NERF_LDS_FLOATS];
+  nerf_tab_load(nerf_lds);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  char* Wb = img + w * kStageB;
+  {      // rows >= B of the image stay zero for the whole launch (never written again)
+    for (int j = lane * 16; j < kStageB; j += 1024) *reinterpret_cast<u32x4*>(Wb + j) = (u32x4){0u, 0u, 0u, 0u};
+  }
+  __syncthreads();
+  const NerfTab tab = nerf_tab(nerf_lds);
+  auto uni = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+  Levels nlev = make_levels(k, fabsf(r) <= 8.0f);
+  nlev.n = uni(nlev.n);
+  nlev.yn = uni(nlev.yn);
+  const float fB = uni((float)B), invBm1 = uni(1.0f / (float)(B - 1));
+  constexpr int ng = NG;                      // 4-row groups: B = 4 NG (a template parameter: straight-line code over the rows)
+  if (blockIdx.x == 0 && tid == 0 && counter) *counter = 0u;
+  char* Wl = Wb + lane * 4;                   // lane = feature: this lane's column (row q at q * kRowB)
+  // Gram layout: row l & 31, features 8 h .. 8 h + 7 of every 16-feature K-step
+  const int r31 = lane & 31, hh = lane >> 5;
+  const char* Wr = Wb + r31 * kRowB + hh * 32;
+  const unsigned rowB = (unsigned)F * 4u;
+  const int n_tile = (int)((F + TF1 - 1) / TF1);
+
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; e++) acc[e] = 0.0f;
+
+  for (int tile = blockIdx.x * kWaves + w; tile < n_tile; tile += gridDim.x * kWaves) {
+    const int64_t col = (int64_t)tile * TF1 + lane;
+    const bool cok = col < F;
+    const unsigned colB = (unsigned)min(col, F - 1) * 4u;       // lanes beyond F work on the clamped column (masked below)
+    // rows: a scalar base per row (x + q * rowB in scalar registers) + ONE vector offset for the lane's column - no vector add per access
+#define S64_ROW(base, q) (reinterpret_cast<const char*>(base) + (size_t)(q) * rowB + colB)
+    float xr[32];
+#pragma unroll
+    for (int g = 0; g < 8; g++) {
+      if (g < ng) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) xr[4 * g + j] = *reinterpret_cast<const float*>(S64_ROW(x, 4 * g + j));
+      }
+    }
+    float rr[RES ? 4 : 1];
+    if (RES) {        // the first four shortcut rows: in flight under the x statistics and the x Gram
+#pragma unroll
+      for (int j = 0; j < 4; j++) rr[RES ? j : 0] = *reinterpret_cast<const float*>(S64_ROW(res, j));
+    }
+    if (ab) {         // folded batch-norm (channels-last: channel = column mod nch): x = a*z + b on load
+      const int ch = (int)(min(col, F - 1) & (int64_t)(nch - 1));
+      const float av = ab[ch], bv = ab[nch + ch];
+#pragma unroll
+      for (int g = 0; g < 8; g++) {
+        if (g < ng) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) xr[4 * g + j] = __fmaf_rn(av, xr[4 * g + j], bv);
+        }
+      }
+    }
+    // ---- x statistics: register sums over the lane's own column -------------------------------------------------------------
+    float sx = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; g++) {
+      if (g < ng) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) sx += xr[4 * g + j];
+      }
+    }
+    const float mx = sx / fB;                 // true division, like torch.mean
+    float vx = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; g++) {
+      if (g < ng) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const float d = xr[4 * g + j] - mx;
+          vx += d * d;
+        }
+      }
+    }
+    const float rx = 1.0f / (sqrtf(vx * invBm1) + eps);
+    if (stats && cok) {
+      stats[col] = mx;
+      stats[F + col] = rx;
+    }
+    {
+      // xhat = x * r - m * r as ONE fma per element (|error| ~ 6e-8 |x r|: far below the 1e-5 bar on D); columns beyond F contribute zeros
+      const float rxm = cok ? rx : 0.0f, nmx = -mx * rxm;
+#pragma unroll
+      for (int g = 0; g < 8; g++) {
+        if (g < ng) {
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            *reinterpret_cast<float*>(Wl + (4 * g + j) * kRowB) = __fmaf_rn(xr[4 * g + j], rxm, nmx);
+        }
+      }
+    }
+    wave_lds_sync();
+    gram64<true>(Wr, acc);
+    wave_lds_sync();
+    // ---- transform + quantise, four rows at a time; the row register takes t; x_q (+ shortcut, ReLU) leaves as 256-byte segments --
+    float st = 0.f;
+    unsigned mbits = 0u;
+#pragma unroll
+    for (int g = 0; g < 8; g++) {
+      if (g < ng) {
+        float qq[4], rn[RES ? 4 : 1];
+        if (RES && g + 1 < ng) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) rn[RES ? j : 0] = *reinterpret_cast<const float*>(S64_ROW(res, 4 * g + 4 + j));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int q = 4 * g + j;
+          float b, t;
+          qq[j] = act_quant1<0, true>(xr[q], k, nlev, r, &t, &b, tab);
+          xr[q] = t;
+          if (RES) qq[j] += rr[RES ? j : 0];
+          if (relu) qq[j] = fmaxf(qq[j], 0.0f);
+          st += t;
+        }
+        if (xq) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) *reinterpret_cast<float*>(const_cast<char*>(S64_ROW(xq, 4 * g + j))) = qq[j];
+        }
+        if (rmask) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) mbits = mbits + mbits + (qq[j] > 0.0f ? 1u : 0u);
+        }
+        if (RES && g + 1 < ng) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) rr[RES ? j : 0] = rn[RES ? j : 0];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // bit R = [stored row R > 0]; bits B..31 repeat row B - 1 (arithmetic shift): the backward's lanes that own rows >= B work on the
+    // clamped row B - 1 and must see ITS bit (they store its dres value to its address)
+    if (rmask && cok) rmask[col] = (unsigned)((int)__builtin_bitreverse32(mbits) >> (32 - B));
+    const float mt = st / fB;
+    float vt = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; g++) {
+      if (g < ng) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const float d2 = xr[4 * g + j] - mt;
+          vt += d2 * d2;
+        }
+      }
+    }
+    const float rt = 1.0f / (sqrtf(vt * invBm1) + eps);
+    if (stats && cok) {
+      stats[2 * F + col] = mt;
+      stats[3 * F + col] = rt;
+    }
+    {
+      const float rtm = cok ? rt : 0.0f, nmt = -mt * rtm;
+#pragma unroll
+      for (int g = 0; g < 8; g++) {
+        if (g < ng) {
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            *reinterpret_cast<float*>(Wl + (4 * g + j) * kRowB) = __fmaf_rn(xr[4 * g + j], rtm, nmt);
+        }
+      }
+    }
+    wave_lds_sync();
+    gram64<false>(Wr, acc);
+    wave_lds_sync();
+#undef S64_ROW
+  }
+  // ---- the only workgroup-wide step: add the four wave accumulators, write the [32][32] slab (as site1_fwd_kernel) -----------
+  __syncthreads();
+  float* Cw = reinterpret_cast<float*>(img) + w * 1024;
+#pragma unroll
+  for (int e = 0; e < 16; e++) Cw[((e & 3) + 8 * (e >> 2) + 4 * hh) * 32 + r31] = acc[e];
+  __syncthreads();
+  const float* C = reinterpret_cast<const float*>(img);
+  float* slab = slabs + (int64_t)blockIdx.x * 1024;
+  for (int e = tid; e < 1024; e += kThreads1) slab[e] = C[e] + C[1024 + e] + C[2048 + e] + C[3072 + e];
+}
+
 // ================================================================================================ backward
 // site1_bwd_kernel (rewritten in round 4): S * Vh on the FP32 matrix instruction v_mfma_f32_32x32x2_f32, operands and results in
 // registers only.  Round 3's kernel is vector-ALU bound (~1500 vector instructions per 32-feature sub-tile and wave: 61 of its
@@ -537,6 +807,18 @@ int launch_partials1(bool pair, const Geom& g, const float* x, int B, int64_t F,
   const int n_sub = (int)((F + SUBF - 1) / SUBF);
   const bool bnd = make_levels(k, fabsf(r) <= 8.0f).yn != 0.0f;       // as the kernel forms its Levels
   if (rmask && !(pair && bnd)) return ALIGNQ_EUNSUPPORTED;            // (k == 1 / k == 32 / a huge act_range: the caller keeps y for the mask)
+#ifndef ALIGNQ_S1_FWD32_ONLY
+  if (pair && bnd && (B == 28 || B == 32)) {       // round 6: one lane per feature column, 256-byte row segments (Office batch 28; 32)
+#define S1_L64(RESV, NGV) hipLaunchKernelGGL((site1_fwd64_kernel<RESV, NGV>), dim3(g.grid, groups), kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter, res, relu, ab, C, ws_gstride, rmask)
+    if (res && B == 28) S1_L64(true, 7);
+    else if (res) S1_L64(true, 8);
+    else if (B == 28) S1_L64(false, 7);
+    else S1_L64(false, 8);
+#undef S1_L64
+    RET_ON_ERR1();
+    return 0;
+  }
+#endif
   if (pair && res && bnd) hipLaunchKernelGGL((site1_fwd_kernel<true, true, true>), dim3(g.grid, groups), kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter, res, relu, ab, C, ws_gstride, rmask);
   else if (pair && res) hipLaunchKernelGGL((site1_fwd_kernel<true, true>), dim3(g.grid, groups), kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter, res, relu, ab, C, ws_gstride, rmask);
   else if (pair && bnd) hipLaunchKernelGGL((site1_fwd_kernel<true, false, true>), dim3(g.grid, groups), kThreads1, 0, st, x, B, F, k, r, eps, xq, ws, stats, n_sub, counter, nullptr, relu, ab, C, ws_gstride, rmask);
