@@ -13,7 +13,7 @@ SO_PATH = os.environ.get("ALIGNQ_SO") or os.path.join(_HERE, "lib", "libalignq_h
 FORMULA_ADMM, FORMULA_CDF = 0, 1
 MAX_BATCH = 128            # rows the FUSED site kernels hold on chip (ALIGNQ_MAX_BATCH)
 MAX_CORR_BATCH = 1024      # rows alignq_corr_fwd / _bwd take (ALIGNQ_MAX_CORR_BATCH: blocked Gram above 128)
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 _c = ctypes
 _vp, _i, _i64, _f, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_size_t
@@ -122,6 +122,9 @@ SIGNATURES = {
                                           _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "alignq_head_ce_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "alignq_bucket_copy_multi": (_i, [_i, _vp, _vp, _vp, _i, _vp]),
+    "alignq_dp_counter_bump": (_i, [_vp, _vp]),
+    "alignq_dp_flag_publish": (_i, [_vp, _vp, _vp]),
+    "alignq_dp_stream_wait_ge": (_i, [_vp, _vp, _c.c_uint32]),
     "alignq_bn_ws_bytes": (_sz, [_i]),
     "alignq_bn_stats": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp]),
     "alignq_bn_partial_stats": (_i, [_vp, _i, _i, _i, _vp, _vp]),

@@ -157,11 +157,14 @@ __global__ __launch_bounds__(NT) void bnq_sums_kernel(const float* __restrict__ 
 // Every lane takes every 64th partial of its channel - of TWO groups at a time, all loads in flight together: the kernel is a
 // chain of memory round trips (a one-thread-per-channel loop over 512 partials measured ~100 us, 16 lanes per channel and one
 // group after the other ~9 us: 4 + 4 dependent batches) - then a fixed butterfly over the 64 lanes.  Totals valid in every lane.
+// U: partials per lane and round.  8 covers the <= kParts partials of bnq_sums_kernel in ONE round of loads; a convolution's epilogue
+// leaves one partial per row tile (686 per batch slice at layer1 of configuration 5): U = 12 keeps those in one round too (round 6:
+// with two rounds - two dependent trips to memory the previous kernel has only just written - the layer1 nodes took 11-14 us
+// against 6-7 for the others)
+template <int U = kParts / 64>
 __device__ __forceinline__ void bnq_wave_totals2(const double* __restrict__ p0, const double* __restrict__ p1, int nparts, int C,
                                                  int c, int lane, double& a0, double& q0, double& a1, double& q1) {
-  constexpr int U = kParts / 64;
   a0 = 0; q0 = 0; a1 = 0; q1 = 0;
-  // (one round for the <= kParts partials of bnq_sums_kernel; more when a convolution's epilogue left one partial per row tile)
   for (int base = 0; base < nparts; base += 64 * U) {
     double va0[U], vq0[U], va1[U], vq1[U];
 #pragma unroll
@@ -185,6 +188,7 @@ __device__ __forceinline__ void bnq_wave_totals2(const double* __restrict__ p0, 
 
 // groups: the slices' statistics one after the other (running statistics updated in slice order, like successive forward
 // passes of the module).
+template <int U>
 __global__ __launch_bounds__(kT) void bnq_finalize_kernel(const double* __restrict__ part, int nparts, int64_t P, int C,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(kT) void bnq_finalize_kernel(const double* __restri
   for (int g0 = 0; g0 < groups; g0 += 2) {
     const bool two = g0 + 1 < groups;
     double a[2], q[2];
-    bnq_wave_totals2(part + g0 * gstride, part + (two ? g0 + 1 : g0) * gstride, nparts, C, c, lane, a[0], q[0], a[1], q[1]);
+    bnq_wave_totals2<U>(part + g0 * gstride, part + (two ? g0 + 1 : g0) * gstride, nparts, C, c, lane, a[0], q[0], a[1], q[1]);
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       if (j == 1 && !two) break;
@@ -551,6 +555,19 @@ inline int parts_for(int64_t P, int C) {
     }                                                    \
   } while (0)
 
+// the finalisation with every partial of a channel in flight at once whenever they fit one round (see bnq_wave_totals2)
+inline void launch_finalize(int np, int C, hipStream_t st, const double* part, int64_t P, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, long long* nbt, float momentum, float bn_eps, float* ab,
+                            float* save, int groups) {
+  const dim3 grid((C + 3) / 4), blk(kT);
+  if (np > 64 * 8 && np <= 64 * 12)
+    hipLaunchKernelGGL((bnq_finalize_kernel<12>), grid, blk, 0, st, part, np, P, C, gamma, beta, running_mean, running_var, nbt, momentum,
+                       bn_eps, ab, save, groups);
+  else
+    hipLaunchKernelGGL((bnq_finalize_kernel<8>), grid, blk, 0, st, part, np, P, C, gamma, beta, running_mean, running_var, nbt, momentum,
+                       bn_eps, ab, save, groups);
+}
+
 }  // namespace
 
 extern "C" {
@@ -638,9 +655,8 @@ int alignq_bnq_fwd_parts(const float* z, int64_t P, int C, int groups, const flo
     BNQ_SUMS_NT(C, hipLaunchKernelGGL((bnq_sums_kernel<0, NTV>), dim3(np, groups), dim3(NTV), 0, st, z, nullptr, nullptr, nullptr, nullptr, P, C,
                        act_range, 0, part));
   }
-  hipLaunchKernelGGL(bnq_finalize_kernel, dim3((C + 3) / 4), dim3(kT), 0, st, (const double*)part, np, P, C, gamma, beta,
-                     running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), momentum, bn_eps, ab, save,
-                     groups);
+  launch_finalize(np, C, st, (const double*)part, P, gamma, beta, running_mean, running_var,
+                  reinterpret_cast<long long*>(num_batches_tracked), momentum, bn_eps, ab, save, groups);
   if (formula == ALIGNQ_FORMULA_ADMM)
     BNQ_NT(C, hipLaunchKernelGGL((bnq_apply_fwd_kernel<0, NTV>), dim3(tiles(nvec, kUa, NTV), groups), dim3(NTV), 0, st, z, (const float*)ab, nvec, C, k,
                        act_range, relu, y, mk, residual, FinFwd{}, yb));
@@ -706,9 +722,8 @@ int alignq_bnq_stats_parts(const float* z, int64_t P, int C, int groups, const f
   } else {
     BNQ_SUMS_NT(C, hipLaunchKernelGGL((bnq_sums_kernel<0, NTV>), dim3(np, groups), dim3(NTV), 0, st, z, nullptr, nullptr, nullptr, nullptr, P, C, 0.f, 0, part));
   }
-  hipLaunchKernelGGL(bnq_finalize_kernel, dim3((C + 3) / 4), dim3(kT), 0, st, (const double*)part, np, P, C, gamma, beta,
-                     running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), momentum, bn_eps, ab, save,
-                     groups);
+  launch_finalize(np, C, st, (const double*)part, P, gamma, beta, running_mean, running_var,
+                  reinterpret_cast<long long*>(num_batches_tracked), momentum, bn_eps, ab, save, groups);
   return hipGetLastError() == hipSuccess ? 0 : ALIGNQ_EINVAL;
 }
 

@@ -469,4 +469,36 @@ int alignq_bucket_copy_multi(int T, float* const* tensors, const int64_t* n, flo
   return 0;
 }
 
+// ---- ordering an eagerly enqueued collective behind a node INSIDE a replayed HIP graph (round 6, include/alignq.h) ----------------
+namespace {
+__global__ void dp_bump_kernel(unsigned* counter) { *counter += 1u; }
+__global__ void dp_publish_kernel(unsigned* flag, const unsigned* counter) {
+  __threadfence_system();
+  *flag = *counter;
+}
+}  // namespace
+
+int alignq_dp_counter_bump(uint32_t* counter, void* stream) {
+  if (!counter) return ALIGNQ_EINVAL;
+  hipLaunchKernelGGL(dp_bump_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int alignq_dp_flag_publish(uint32_t* flag, const uint32_t* counter, void* stream) {
+  if (!flag || !counter) return ALIGNQ_EINVAL;
+  hipLaunchKernelGGL(dp_publish_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, flag, counter);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int alignq_dp_stream_wait_ge(void* stream, uint32_t* flag, uint32_t value) {
+  if (!flag) return ALIGNQ_EINVAL;
+  int can = 0, dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, dev) != hipSuccess || !can)
+    return ALIGNQ_EUNSUPPORTED;
+  const hipError_t e = hipStreamWaitValue32((hipStream_t)stream, flag, value, hipStreamWaitValueGte, 0xFFFFFFFFu);
+  return e == hipSuccess ? 0 : (int)e;
+}
+
 }  // extern "C"

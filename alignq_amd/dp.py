@@ -184,7 +184,7 @@ def detach(train_step):
 class BucketedGradAllReduce:
     """Data parallelism for the Office / DANN step (BASELINE config 5: ResNet-50, ~94 MB of fp32 gradients per step, ring
     time ~1.1 ms per link-bound ring on xGMI): the gradients are all-reduced in >= `min_buckets` flat
-    buckets (<= `bucket_bytes` each), launched FROM AUTOGRAD HOOKS while the backward is still running, so the collectives of
+    buckets (<= `bucket_bytes` each; a single larger tensor is a bucket of its own), launched FROM AUTOGRAD HOOKS while the backward is still running, so the collectives of
     the deep layers overlap the backward of the shallow ones; the stacked D matrices of the ADMM sites ride in the bucket that
     completes last (the stem's).  Every rank runs the reference semantics at its local batch; after `finish()` every
     p.grad and every ADMM.D holds the mean over ranks, so SGD.step / ADMM_OPT.step keep the replicas bit-identical.
@@ -192,7 +192,14 @@ class BucketedGradAllReduce:
     Order of the buckets = reverse registration order of the parameters (the order the backward produces gradients in).  The
     set of parameters that actually receive gradients is discovered in the first iteration (DANN never uses feature.fc), which
     therefore reduces without overlap.  Interface: begin() before backward, finish() after it; or the phased pack() /
-    reduce() / unpack() of GradAndDAllReduce for a captured step (two HIP graphs with the collectives eager in between)."""
+    reduce() / unpack() of GradAndDAllReduce for a captured step (two HIP graphs with the collectives eager in between).
+
+    Captured step WITH overlap (round 6): capture_begin() / capture_end() bracket the captured forward + backward.  The autograd
+    hooks then only PACK a completed bucket into its flat buffer and publish a flag behind it (alignq_dp_flag_publish: nodes of
+    the graph); after launching that graph, reduce() enqueues on the communication stream, per bucket in completion order,
+    alignq_dp_stream_wait_ge(flag_i >= replay number) + the eager all-reduce - bucket i's collective starts when the replayed
+    backward has packed it and runs beside the rest of the backward.  (A collective cannot be captured here, DESIGN.md section 6;
+    torch refuses external events on ROCm; tools/src/probe_waitvalue.hip is the stand-alone probe of the mechanism.)"""
 
     def __init__(self, params: List[torch.nn.Parameter], get_Ds: Callable[[], List[torch.Tensor]], group=None,
                  force: bool = False, bucket_bytes: int = 24 << 20, min_buckets: int = 4):
@@ -210,6 +217,10 @@ class BucketedGradAllReduce:
         self._pending, self._works, self._buckets_now = [], [], []
         self._comm = None
         self.launched_from_hooks = 0          # diagnostics: buckets whose collective started inside the backward
+        self._cap = False                     # inside capture_begin() .. capture_end(): hooks pack + publish, no collective
+        self._sync = None                     # device words: [0] replay counter, [1 + i] flag of bucket i
+        self._replays = 0                     # host mirror of the replay counter
+        self._overlap_ready = False           # the current `_phase` was laid out by a captured backward (flags exist)
         for p in self.params:
             p.register_post_accumulate_grad_hook(self._on_grad)
 
@@ -221,18 +232,26 @@ class BucketedGradAllReduce:
         live = [p for p in reversed(self.params) if p.grad is not None]
         total = sum(p.numel() for p in live) * 4
         target = max(1, min(self.bucket_bytes, -(-total // self.min_buckets)))
+        # a bucket is closed BEFORE the tensor that would take it past the target (round 6: closing after it let a 9.4 MB filter
+        # push a bucket to 30 MiB against bucket_bytes = 24 MiB); only a single tensor larger than the target exceeds it, alone
         groups, cur, size = [], [], 0
         for p in live:
-            cur.append(p)
-            size += p.numel() * 4
-            if size >= target:
+            sz = p.numel() * 4
+            if cur and size + sz > target:
                 groups.append(cur)
                 cur, size = [], 0
+            cur.append(p)
+            size += sz
         if cur:
             groups.append(cur)
         self._live, self._groups = live, groups
         self._where = {id(p): bi for bi, g in enumerate(groups) for p in g}
         self._layouts = {}
+        # the replay counter and the buckets' flags of the captured form: allocated HERE, in an eager iteration - inside the capture
+        # the allocation would come from the graph's pool and its zero-fill would be a node that resets them on every replay
+        dev = live[0].device if live else None
+        self._sync = torch.zeros(1 + len(groups), dtype=torch.int32, device=dev) if dev is not None and dev.type == "cuda" else None
+        self._replays = 0
 
     def _tensors(self, bi):
         ts = [p.grad for p in self._groups[bi]]
@@ -281,8 +300,55 @@ class BucketedGradAllReduce:
             return
         self._pending[bi] -= 1
         if self._pending[bi] == 0:
-            self._launch(bi)
+            if self._cap:
+                self._pack_publish(bi)
+            else:
+                self._launch(bi)
             self.launched_from_hooks += 1
+
+    # ---- captured step with overlap ---------------------------------------------------------------------------------------
+    def _pack_publish(self, bi):
+        tensors = self._tensors(bi)
+        b = self._bucket(bi, tensors)
+        b.pack(tensors)
+        self._phase.append((b, tensors))
+        self._cap_order.append(bi)
+        self._cap_done[bi] = True
+        if self._sync is not None:
+            from . import _lib as L
+            base = self._sync.data_ptr()
+            L.check(L.load().alignq_dp_flag_publish(base + 4 * (1 + bi), base, L.stream_ptr()), "alignq_dp_flag_publish")
+
+    def capture_begin(self):
+        """Inside the capture region, before the forward: the graph's first node bumps the replay counter; the hooks are armed in
+        pack-and-publish mode.  Needs the bucket layout of an earlier (warm-up) iteration."""
+        if not self.active():
+            return
+        if self._groups is None:
+            raise RuntimeError("BucketedGradAllReduce.capture_begin: no bucket layout yet - run one eager iteration first")
+        n = len(self._groups)
+        dev = next(p.device for p in self._live)
+        self._phase, self._cap_order, self._cap_done = [], [], [False] * n
+        self._pending = [len(g) for g in self._groups]
+        if dev.type == "cuda":
+            from . import _lib as L
+            if self._sync is None or self._sync.numel() != 1 + n:
+                raise RuntimeError("BucketedGradAllReduce.capture_begin: the flag words must exist before the capture (_discover)")
+            # (the counter keeps counting across re-captures; `_replays` mirrors it on the host)
+            L.check(L.load().alignq_dp_counter_bump(self._sync.data_ptr(), L.stream_ptr()), "alignq_dp_counter_bump")
+        self._cap = self._armed = True
+
+    def capture_end(self):
+        """Inside the capture region, after the backward: buckets whose hooks did not all fire are packed here."""
+        if not self.active():
+            return
+        self._armed = self._cap = False
+        for bi in range(len(self._groups)):
+            if not self._cap_done[bi]:
+                self._cap = True
+                self._pack_publish(bi)
+                self._cap = False
+        self._overlap_ready = True
 
     # ---- eager interface ------------------------------------------------------------------------------------------
     def begin(self):
@@ -330,6 +396,7 @@ class BucketedGradAllReduce:
         if self._groups is None:
             self._discover()
         self._phase = []
+        self._overlap_ready = False
         for bi in range(len(self._groups)):
             tensors = self._tensors(bi)
             b = self._bucket(bi, tensors)
@@ -340,8 +407,26 @@ class BucketedGradAllReduce:
         if not self.active():
             return
         backend = dist.get_backend(self.group)
-        works = [dist.all_reduce(b.flat, op=dist.ReduceOp.AVG if backend == "nccl" else dist.ReduceOp.SUM, group=self.group,
-                                 async_op=True) for b, _ in self._phase]
+        op = dist.ReduceOp.AVG if backend == "nccl" else dist.ReduceOp.SUM
+        if self._overlap_ready and self._sync is not None and self._phase and self._phase[0][0].flat.is_cuda:
+            # the graph that packs the buckets has just been LAUNCHED (not finished): each collective waits, on the communication
+            # stream, for its bucket's flag of THIS replay and then runs beside the rest of the replayed backward
+            from . import _lib as L
+            lib = L.load()
+            if self._comm is None:
+                self._comm = torch.cuda.Stream()
+            self._replays += 1
+            base = self._sync.data_ptr()
+            works = []
+            with torch.cuda.stream(self._comm):
+                for (b, _), bi in zip(self._phase, self._cap_order):
+                    L.check(lib.alignq_dp_stream_wait_ge(self._comm.cuda_stream, base + 4 * (1 + bi), self._replays),
+                            "alignq_dp_stream_wait_ge")
+                    works.append(dist.all_reduce(b.flat, op=op, group=self.group, async_op=True))
+            for w in works:
+                w.wait()                  # the CURRENT stream waits (behind the graph it has just been given)
+            return
+        works = [dist.all_reduce(b.flat, op=op, group=self.group, async_op=True) for b, _ in self._phase]
         for w, (b, _) in zip(works, self._phase):
             w.wait()
             if backend != "nccl":
@@ -354,10 +439,10 @@ class BucketedGradAllReduce:
             b.unpack(tensors)
 
     def snapshot(self):
-        return getattr(self, "_phase", None)
+        return (getattr(self, "_phase", None), getattr(self, "_cap_order", None), self._overlap_ready)
 
     def restore(self, state):
-        self._phase = state
+        self._phase, self._cap_order, self._overlap_ready = state
 
 
 def attach_office(office_step, group=None, force=False, bucket_bytes=24 << 20, min_buckets=4):
@@ -368,6 +453,11 @@ def attach_office(office_step, group=None, force=False, bucket_bytes=24 << 20, m
     hook = BucketedGradAllReduce(params, lambda: [b.admm0.D for b in office_step.blocks], group, force=force,
                                  bucket_bytes=bucket_bytes, min_buckets=min_buckets)
     office_step.grad_hook = hook
+    # the conv weights' gradients leave the weight quantiser's backward: ONE multi-tensor node for the whole model would hand all
+    # 94 MB over at the very end of the backward (nothing left to overlap with); per ResNet stage, each created right before the
+    # stage's forward, they leave as the backward passes the stage boundaries
+    if hasattr(office_step, "stage_weights"):
+        office_step.stage_weights(True)
     return hook
 
 

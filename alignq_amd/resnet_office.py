@@ -139,6 +139,9 @@ class ResNet(nn.Module):
         trans_loss = 0.
         from . import fused
         fused.set_conv_groups(groups)        # (the GEMM convolutions' batch-norm statistics epilogue sums per batch slice)
+        # staged weight quantisation (OfficeTrainStep.stage_weights, data parallelism): stage i's filters right before stage i
+        wq = getattr(self, "_wq_stage", None) or (lambda i: None)
+        wq(0)
         if groups > 1:
             q0 = self.act_q0.forward_bn_relu(self.bn1, self.conv1(x), groups)
             x = self.maxpool(q0)
@@ -146,7 +149,8 @@ class ResNet(nn.Module):
                 x._alignq_levels = q0._alignq_levels
             losses = []
             with fused.Site1Batch() as s1:      # the folded tails' reductions / preparations: one launch each for all 16 sites
-                for layers in (self.layer1, self.layer2, self.layer3, self.layer4):
+                for li, layers in enumerate((self.layer1, self.layer2, self.layer3, self.layer4)):
+                    wq(li + 1)
                     for layer in layers:
                         x, loss = layer(x, groups, loss_vec=True)
                         losses.append(loss)
@@ -169,7 +173,8 @@ class ResNet(nn.Module):
             x = self.maxpool(self.act_q0.forward_relu(self.bn1(self.conv1(x))))
         else:
             x = self.maxpool(self.relu(self.act_q0(self.bn1(self.conv1(x)))))
-        for layers in (self.layer1, self.layer2, self.layer3, self.layer4):
+        for li, layers in enumerate((self.layer1, self.layer2, self.layer3, self.layer4)):
+            wq(li + 1)
             for layer in layers:
                 x, loss = layer(x)
                 trans_loss += loss

@@ -400,9 +400,27 @@ class OfficeTrainStep:
                     self.convs.append(conv[0] if k == 3 else conv)
         self.all_convs = [m for m in model.modules() if hasattr(m, "quantize_fn")]
         self.grad_hook = grad_hook
+        self._staged = False
         self._graph: Optional[torch.cuda.CUDAGraph] = None
         self._graph2: Optional[torch.cuda.CUDAGraph] = None
         self._static = None
+
+    def stage_weights(self, on=True):
+        """Quantise the conv weights per ResNet stage, each stage right before its forward (ResNet.forward calls back), instead of
+        all of them before the first layer.  Same per-tensor arithmetic (the multi-tensor kernels treat every filter alone), 5 x 2
+        launches each way instead of 2.  For data parallelism: a stage's weight gradients then leave the weight quantiser's
+        backward when the backward passes that stage, so their buckets' all-reduces overlap the earlier stages' backward
+        (dp.attach_office switches it on)."""
+        f = self.model.feature
+        if on:
+            layers = (f.layer1, f.layer2, f.layer3, f.layer4)
+            owner = {id(m): i + 1 for i, layer in enumerate(layers) for m in layer.modules() if hasattr(m, "quantize_fn")}
+            stages = [[c for c in self.all_convs if owner.get(id(c), 0) == i] for i in range(len(layers) + 1)]
+            f._wq_stage = lambda i: prequantize_weights(stages[i], pack=self.qconv)
+        else:
+            f._wq_stage = None
+        self._staged = bool(on)
+        return self
 
     def _iteration(self, xs, ys, xt, set_to_none=True):
         out = self._forward_backward(xs, ys, xt, set_to_none, overlap=True)
@@ -424,13 +442,15 @@ class OfficeTrainStep:
                                 torch.ones(xt.shape[0], dtype=torch.long, device=dev))
             self._dom_labels_key = key
         label_src, label_tgt = self._dom_labels
-        prequantize_weights(self.all_convs, pack=self.qconv)
+        if not self._staged:               # (staged: ResNet.forward quantises each stage's weights right before the stage)
+            prequantize_weights(self.all_convs, pack=self.qconv)
         if self.dual and xs.shape == xt.shape:
             cls_s, dom_s, dom_t, tl_both = m.forward_dual(xs, xt, alpha=self.alpha)      # (same weights, hence the same W_q,
             tl_s, tl_t = tl_both, 0.0                                                    #  in both of the reference's passes)
         else:
             cls_s, dom_s, tl_s = m(xs, alpha=self.alpha)
-            prequantize_weights(self.all_convs, pack=self.qconv)          # the reference quantises every weight once per pass
+            if not self._staged:
+                prequantize_weights(self.all_convs, pack=self.qconv)      # the reference quantises every weight once per pass
             _, dom_t, tl_t = m(xt, alpha=self.alpha)
         # (a pass without a loss tensor contributes the NUMBER 0: adding it would be an elementwise launch of its own)
         tl = tl_s if not torch.is_tensor(tl_t) and tl_t == 0 else (tl_t if not torch.is_tensor(tl_s) and tl_s == 0 else tl_s + tl_t)
@@ -533,13 +553,22 @@ class OfficeTrainStep:
             with torch.cuda.graph(graph, **(dict(capture_error_mode="thread_local") if pg_on else {})):
                 outs = self._iteration(sxs, sys_, sxt, set_to_none=True)
         else:
-            # data parallel: forward + backward + bucket pack | eager all-reduces | bucket unpack + optimizer steps
+            # data parallel: forward + backward (+ each bucket packed where its last gradient lands) | eager all-reduces, started
+            # per bucket by a flag the replayed graph publishes | bucket unpack + optimizer steps
             torch.distributed.barrier()
             torch.cuda.synchronize()
             mode = dict(capture_error_mode="thread_local")
+            overlapped = hasattr(self.grad_hook, "capture_begin")
             with torch.cuda.graph(graph, **mode):
-                outs = self._forward_backward(sxs, sys_, sxt, set_to_none=True, overlap=False)
-                self.grad_hook.pack()
+                if overlapped:
+                    # the hooks pack each bucket and publish its flag where the captured backward completes it; reduce() then
+                    # starts bucket i's all-reduce beside the rest of the replayed backward (dp.BucketedGradAllReduce)
+                    self.grad_hook.capture_begin()
+                    outs = self._forward_backward(sxs, sys_, sxt, set_to_none=True, overlap=False)
+                    self.grad_hook.capture_end()
+                else:
+                    outs = self._forward_backward(sxs, sys_, sxt, set_to_none=True, overlap=False)
+                    self.grad_hook.pack()
             graph2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph2, pool=graph.pool(), **mode):
                 self.grad_hook.unpack()

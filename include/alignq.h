@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALIGNQ_ABI_VERSION 20
+#define ALIGNQ_ABI_VERSION 21
 
 #define ALIGNQ_FORMULA_ADMM 0
 #define ALIGNQ_FORMULA_CDF 1
@@ -441,6 +441,17 @@ int alignq_head_ce_bwd_site_prep(const float* g_ce, const float* probs, const in
  * gather T dense device tensors (HOST array of pointers, element counts n[T]) into `flat` back to back (unpack = 0) or
  * scatter them back (unpack = 1); one launch per 128 tensors instead of one copy kernel per tensor.                      */
 int alignq_bucket_copy_multi(int T, float* const* tensors, const int64_t* n, float* flat, int unpack, void* stream);
+/* Overlapping the buckets' all-reduces with a CAPTURED backward (round 6; SURVEY.md §5 "bucket + overlap with backward", §8e; the
+ * reference has no distributed code, cdf_alignment_admm/dann_office/main.py:28).  A collective cannot be captured into the step's HIP
+ * graph and torch refuses external events on ROCm, so the order "bucket i packed -> all-reduce of bucket i"
+ * goes through a flag in device memory: the graph holds  alignq_dp_counter_bump(counter)  once at its start and, behind the pack of
+ * bucket i,  alignq_dp_flag_publish(flag_i, counter)  (flag_i = the replay's number, system-scope release); after launching the
+ * graph the host enqueues  alignq_dp_stream_wait_ge(comm_stream, flag_i, replay number)  (hipStreamWaitValue32, >=) followed by the
+ * eager all-reduce on the communication stream.  counter / flag: 4-byte aligned device words (any device allocation).  The wait
+ * returns ALIGNQ_EUNSUPPORTED where the device has no stream memory operations (hipDeviceAttributeCanUseStreamWaitValue).        */
+int alignq_dp_counter_bump(uint32_t* counter, void* stream);
+int alignq_dp_flag_publish(uint32_t* flag, const uint32_t* counter, void* stream);
+int alignq_dp_stream_wait_ge(void* stream, uint32_t* flag, uint32_t value);
 
 /* ---- batch-norm (and the ReLU that follows) folded into the ADMM site (caller:
  * out, loss = act_q(bn(conv(x))); out = relu(out), cdf_alignment_admm/resnet-56-cifar-10/model/resnet.py:87-94) ----

@@ -227,6 +227,95 @@ def test_office_bucketed_overlapped_allreduce_two_ranks_gloo():
     assert r0["rec"][0]["from_hooks"] == 0 and r0["rec"][1]["from_hooks"] == r0["n_buckets"]
 
 
+def _office_captured_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from alignq_amd import dp
+        from oracle import torch_ref as R
+        cfg = R.Config(tree="office", bitW=4, abitW=4, train_batch_size=4)
+        torch.manual_seed(10 + rank)
+        net = R.OfficeDANN(cfg, 4, 4, "aligned", (1, 1, 1, 1), width_per_group=8).train()
+        dp.broadcast_module_state(net, 0)
+        step = R.OfficeTrainStep(net, cfg, lr=0.004)
+        params = [p for g in step.opt_t.param_groups for p in g["params"]]
+        blocks = net.feature.blocks()
+        cap = 96 << 10
+        hook = dp.BucketedGradAllReduce(params, lambda: [b.admm0.D for b in blocks], bucket_bytes=cap, min_buckets=4)
+
+        class CapturedForm:
+            """What OfficeTrainStep.capture() + __call__ do around the backward on the data-parallel path: capture_begin() before
+            the (captured) forward + backward, capture_end() behind it, then reduce() and unpack() (graph 2)."""
+            def __init__(self):
+                self.log = {}
+
+            def begin(self):
+                hook.capture_begin()
+
+            def finish(self):
+                self.log["from_hooks"] = hook.launched_from_hooks
+                hook.capture_end()
+                self.log["order"] = list(hook._cap_order)
+                self.log["local"] = [b.flat.clone() for b, _ in hook._phase]
+                self.log["D0_local"] = blocks[0].admm0.D.clone()
+                hook.reduce()
+                hook.unpack()
+        g = torch.Generator().manual_seed(100 + rank)
+        data = lambda: (torch.randn(4, 3, 32, 32, generator=g), torch.randint(0, 31, (4,), generator=g),      # noqa: E731
+                        torch.randn(4, 3, 32, 32, generator=g))
+        step.grad_hook = hook                         # iteration 0: eager, discovers the layout
+        xs, ys, xt = data()
+        step(xs, ys, xt)
+        sizes = [sum(p.numel() * 4 for p in grp) for grp in hook._groups]
+        biggest = max(p.numel() * 4 for p in hook._live)
+        form = CapturedForm()
+        step.grad_hook = form
+        rec = []
+        for it in range(2):
+            before = hook.launched_from_hooks
+            xs, ys, xt = data()
+            step(xs, ys, xt)
+            rec.append(dict(packed_from_hooks=form.log["from_hooks"] - before, order=form.log["order"],
+                            local=[t.numpy() for t in form.log["local"]],
+                            reduced=[b.flat.numpy().copy() for b, _ in hook._phase],
+                            D0_local=form.log["D0_local"].numpy(), D0=blocks[0].admm0.D.numpy().copy(),
+                            flat=torch.cat([p.detach().reshape(-1) for p in net.parameters()]).numpy().copy()))
+        out[rank] = dict(rec=rec, sizes=sizes, cap=cap, biggest=biggest, n_buckets=len(hook._groups))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_office_captured_form_packs_buckets_from_hooks_and_reduces_them_in_order_two_ranks_gloo():
+    """the captured data-parallel Office step's protocol (capture_begin -> hooks pack every bucket where the
+    backward completes it -> capture_end -> reduce -> unpack; on the GPU reduce() additionally orders each collective behind its
+    bucket's flag of the running replay), world 2 on gloo: every bucket is packed from an autograd hook, in the same completion order on both ranks; the
+    reduced buffers are the mean of the two ranks' local ones; replicas stay bit-identical; D = mean.  And the layout honours
+    bucket_bytes: no bucket exceeds it unless it is a single larger tensor."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_office_captured_worker, args=(world, port, out), nprocs=world, join=True)
+    r0, r1 = out[0], out[1]
+    assert r0["n_buckets"] >= 4
+    for sz in r0["sizes"]:
+        assert sz <= r0["cap"] or sz <= r0["biggest"], (sz, r0["cap"], r0["biggest"])
+    for it in range(2):
+        a, b = r0["rec"][it], r1["rec"][it]
+        # every bucket from a hook; completion order = the order autograd finishes them in (a permutation of the layout order: a
+        # downsample branch finishes out of registration order), the SAME on both ranks - the collectives are issued in it
+        assert a["packed_from_hooks"] == r0["n_buckets"] and sorted(a["order"]) == list(range(r0["n_buckets"]))
+        assert a["order"] == b["order"]
+        for la, lb, ra, rb in zip(a["local"], b["local"], a["reduced"], b["reduced"]):
+            np.testing.assert_allclose(ra, 0.5 * (la + lb), rtol=0, atol=1e-7)
+            assert np.array_equal(ra, rb)
+        assert np.array_equal(a["flat"], b["flat"]) and np.isfinite(a["flat"]).all()
+        np.testing.assert_allclose(a["D0"], 0.5 * (a["D0_local"] + b["D0_local"]), atol=1e-7)
+        assert np.array_equal(a["D0"], b["D0"])
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # N4: exact-global-batch correlation (alignq_amd.dp.global_corr)
 def _gcorr_worker(rank, world, port, out, b=8):

@@ -307,3 +307,78 @@ def test_constant_column_through_the_bn_folded_site(dev, nhwc):
         assert np.array_equal(mem(res.grad)[same_mask], dres_o[same_mask]) and same_mask.mean() > 1 - 1e-4
     finally:
         config.args.bitW, config.args.abitW, config.args.train_batch_size = old
+
+
+# ------------------------------------------------------------------------------------------------ captured DP with overlap
+@pytest.fixture()
+def pg_world_one(dev):
+    """A one-rank process group on RCCL (backend "nccl"): the collective code paths on the real backend."""
+    import os
+    import socket
+    import torch.distributed as dist
+    if dist.is_initialized():
+        yield None
+        return
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        yield None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_captured_office_step_with_overlapped_allreduce_equals_the_plain_step_at_world_one(dev, pg_world_one):
+    """dp.attach_office(force=True) + capture(): forward + backward are ONE graph in which the autograd hooks pack every gradient
+    bucket where the backward completes it and publish its flag (alignq_dp_flag_publish); each replay's reduce() puts, per bucket,
+    alignq_dp_stream_wait_ge + the RCCL all-reduce on the communication stream, so bucket i's collective runs beside the rest of the
+    replayed backward; the conv weights are quantised per ResNet stage so that their gradients leave the weight quantiser's backward
+    stage by stage.  At world size 1 the mean is the identity and the staged quantiser does the same per-tensor arithmetic: every
+    parameter, momentum buffer and ADMM.D is BIT-identical to the plain single-graph step (the stem's two layers, behind torch's
+    max-pool backward, to rounding)."""
+    import alignq_amd.quantization  # noqa: F401
+    from alignq_amd import config, dp
+    from alignq_amd.resnet_office import resnet50_dann
+    from alignq_amd.train_step import OfficeTrainStep
+    old = (config.args.bitW, config.args.abitW, config.args.train_batch_size, config.args.eval_batch_size)
+    config.args.bitW = config.args.abitW = 8
+    config.args.train_batch_size = config.args.eval_batch_size = 6
+    try:
+        g = torch.Generator().manual_seed(4)
+        xs = torch.randn(6, 3, 64, 64, generator=g).to(dev)
+        xt = torch.randn(6, 3, 64, 64, generator=g).to(dev)
+        ys = torch.randint(0, 31, (6,), generator=g).to(dev)
+
+        def make():
+            return det_init_(resnet50_dann(8, 8)).to(dev).train()
+        m0, m1 = make(), make()
+        s0 = OfficeTrainStep(m0, lr=4e-5, channels_last=True)
+        s1 = OfficeTrainStep(m1, lr=4e-5, channels_last=True)
+        hook = dp.attach_office(s1, force=True, bucket_bytes=24 << 20)
+        assert s1._staged and m1.feature._wq_stage is not None
+        s0.capture(xs, ys, xt, warmup=2)
+        s1.capture(xs, ys, xt, warmup=2)
+        assert s0._graph2 is None and s1._graph2 is not None and hook._overlap_ready
+        n_b = len(hook._groups)
+        assert n_b >= 4 and sorted(hook._cap_order) == list(range(n_b)) and len(hook._phase) == n_b
+        cap = 24 << 20
+        biggest = max(p.numel() * 4 for p in hook._live)
+        assert all(sum(p.numel() * 4 for p in grp) <= max(cap, biggest) for grp in hook._groups)
+        for _ in range(3):
+            o0 = s0(xs, ys, xt)
+            o1 = s1(xs, ys, xt)
+        torch.cuda.synchronize()
+        assert hook._replays == 3 and int(hook._sync[0]) == 3 and all(int(v) == 3 for v in hook._sync[1:])
+        assert torch.isfinite(o0[1]) and same_bits(npy(o0[1]), npy(o1[1])) and same_bits(npy(o0[2]), npy(o1[2]))
+        st0 = full_state(m0, s0, [b.admm0 for b in s0.blocks])
+        st1 = full_state(m1, s1, [b.admm0 for b in s1.blocks])
+        for key in [k_ for k_ in st0 if k_.split(":", 1)[1].startswith(("feature.conv1.", "feature.bn1."))]:
+            np.testing.assert_allclose(st0[key], st1[key], rtol=1e-5, atol=1e-7 * float(np.abs(st0[key]).max()) + 1e-12, err_msg=key)
+            st0.pop(key), st1.pop(key)
+        bad = differing(st0, st1)
+        assert not bad, bad[:6]
+    finally:
+        config.args.bitW, config.args.abitW, config.args.train_batch_size, config.args.eval_batch_size = old
