@@ -4,6 +4,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -16,6 +17,17 @@ MAX_CORR_BATCH = 1024      # rows alignq_corr_fwd / _bwd take (ALIGNQ_MAX_CORR_B
 ABI_VERSION = 21
 
 _c = ctypes
+
+
+class Mailboxes(threading.local):
+    """One-slot hand-overs from an autograd Function's forward to the wrapper that called it (autograd hides ctx from callers): a
+    convolution's batch-norm partial statistics, a quantiser's integer bins.  Per THREAD (as class attributes two models
+    or threads interleaving forwards could pick up each other's tensors); a slot is written inside `forward` and emptied by the
+    wrapper right behind the `apply` call, in the same thread."""
+    conv3x3 = transition = gemm = site_bins = bnq_bins = None
+
+
+MB = Mailboxes()
 _vp, _i, _i64, _f, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_size_t
 
 # name -> (restype, argtypes)   — mirrors include/alignq.h one to one

@@ -115,6 +115,7 @@ struct QG {
   // split-K (data gradient of the small-M, long-K layers): workgroup (tile, split) runs its share of the k steps and leaves RAW sums
   // in part[split][out_elems] at the output's own addresses; qgemm_ksplit_reduce_kernel adds the splits in order and divides
   int ksplit; float* part; int64_t out_elems;
+  int part_splits;                                 // host only: images of the output the caller's workspace holds (the planned split)
 };
 
 // OCC: workgroups per CU the register / LDS budget is sized for (a small tile runs 3-4 of them: latency hiding comes from the
@@ -1196,6 +1197,7 @@ int launch_g(QG a, hipStream_t st) {
   const int units = KM == 2 ? a.CA / KBh : (KM == 1 ? 9 : (KM == 3 ? 2 : 1)) * (a.CA / BK);
   a.ksplit = (a.part && !a.bn_part) ? pick_ksplit(blocks, 256 * OCC, units) : 1;
   if (KM == 3 && a.ksplit > a.CA / BK) a.ksplit = 1;          // (a one-tap class must have a k unit for every split)
+  if (a.part && a.ksplit > a.part_splits) return ALIGNQ_EINVAL;   // (the workspace query and this launch disagree on the plan: never write past it)
   hipLaunchKernelGGL((qgemm_kernel<WN, TM, MODE, WTR, KM, SCATTER, OCC, XI>), dim3(blocks * a.ksplit), dim3(256), 0, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
@@ -1375,11 +1377,40 @@ int alignq_qconv_stem7_wgrad(const float* x, const float* dy, float* dw, void* w
   return e == hipSuccess ? 0 : (int)e;
 }
 
+// The split-K factor alignq_qconv_dgrad will choose for this layer: the SAME tile choice (pick_tile_conv) and cost model (pick_ksplit)
+// as launch_g_tiles / launch_g take for the data gradient (MODE 0).  Round 6: the workspace query used to answer
+// kMaxKSplit images of dx for every layer with dx <= 32 MB, although most of them never split - up to 128 MB allocated and dropped
+// per convolution backward and reserved in the captured graph's pool.
+static int dgrad_ksplit(int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride) {
+  const int Ho = (H_in - 1) / stride + 1, Wo = (W_in - 1) / stride + 1;
+  int km, groups = 1;
+  int64_t Mg;
+  if (stride == 2 && KS == 3) { km = 3; groups = 4; Mg = (int64_t)B * Ho * Wo; }
+  else if (stride == 2) { km = 0; Mg = (int64_t)B * Ho * Wo; }
+  else { Mg = (int64_t)B * H_in * W_in; km = KS == 3 ? (halo_ok(KS, stride, W_in) ? 2 : 1) : 0; }
+  const int N = CIN, CA = COUT;
+  int bm, bn, occ;
+  switch (pick_tile_conv(Mg * groups, N, km == 2, false)) {
+    case 0: bm = 128; bn = 128; occ = 2; break;
+    case 1: bm = 64; bn = 128; occ = km == 2 ? 2 : 3; break;
+    case 2: bm = 128; bn = 64; occ = 2; break;
+    default: bm = 64; bn = 64; occ = km == 2 ? 2 : 4; break;
+  }
+  const int64_t blocks = (int64_t)groups * ((Mg + bm - 1) / bm) * (N / bn);
+  const int kbh = km == 2 ? 32 : BK;
+  const int units = km == 2 ? CA / kbh : (km == 1 ? 9 : (km == 3 ? 2 : 1)) * (CA / BK);
+  int ks = pick_ksplit(blocks, 256 * occ, units);
+  if (km == 3 && ks > CA / BK) ks = 1;
+  return ks;
+}
+
 size_t alignq_qconv_dgrad_ws_bytes(int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride) {
   if (!shape_ok(B, H_in, W_in, CIN, COUT, KS, stride)) return 0;
   // split-K is for the layers with few row tiles: their dx is small (layer3 / layer4 of ResNet-50 at B = 56: 2.8 - 11 MB)
   const size_t out = (size_t)B * H_in * W_in * CIN * sizeof(float);
-  return out <= ((size_t)32 << 20) ? kMaxKSplit * out : 0;
+  if (out > ((size_t)32 << 20)) return 0;
+  const int ks = dgrad_ksplit(B, H_in, W_in, CIN, COUT, KS, stride);
+  return ks > 1 ? (size_t)ks * out : 0;
 }
 
 int alignq_qconv_dgrad(const float* dy, const void* w_bins, float* dx, int B, int H_in, int W_in, int CIN, int COUT, int KS, int stride,
@@ -1398,7 +1429,11 @@ int alignq_qconv_dgrad(const float* dy, const void* w_bins, float* dx, int B, in
   a.nlev = (float)((1 << w_bit) - 1); a.xlev = 0.f;
   a.bn_part = nullptr;
   a.out_elems = (int64_t)B * H_in * W_in * CIN;
-  a.part = (ws && alignq_qconv_dgrad_ws_bytes(B, H_in, W_in, CIN, COUT, KS, stride)) ? (float*)ws : nullptr;
+  {
+    const size_t wsb = alignq_qconv_dgrad_ws_bytes(B, H_in, W_in, CIN, COUT, KS, stride);
+    a.part = (ws && wsb) ? (float*)ws : nullptr;
+    a.part_splits = a.part ? (int)(wsb / ((size_t)a.out_elems * sizeof(float))) : 1;
+  }
   hipStream_t st = (hipStream_t)stream;
   if (stride == 2 && KS == 3) {      // rows = the half grid, once per parity class of the input pixels (see KM 3)
     a.groups = 4;

@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -457,10 +458,9 @@ class BNSiteFn(torch.autograd.Function):
         ctx.mark_non_differentiable(D)
         if pack:
             y = packed_handle(z.shape, dev)
-            BNSiteFn._bins_mailbox = (bins, int(k))
+            L.MB.site_bins = (bins, int(k))
         return y, scal[0], D
 
-    _bins_mailbox = None
 
     @staticmethod
     def backward(ctx, g_y, g_loss, _gD):
@@ -606,14 +606,14 @@ def bn_site(bn, act, z, eps=0.0, relu=False, residual=None, pack=False):
     rec = deferred.new_record(z.shape[0], z.device) if deferred is not None else None
     pack = bool(pack and relu and residual is None and _is_nhwc(z) and act.a_bit <= 8 and (z.shape[1] * z.shape[2] * z.shape[3]) % 4 == 0
                 and ops.bin_dtype(act.a_bit, config.args.act_range, L.FORMULA_ADMM) is not None)   # a large act_range has no narrow form
-    BNSiteFn._bins_mailbox = None
+    L.MB.site_bins = None
     y, loss, D = BNSiteFn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
                                 bn.momentum, bn.eps, admm.alterD, admm.gamma, act.a_bit, config.args.act_range, eps,
                                 admm.mu, admm.rho, relu, rec, residual,
                                 getattr(z, "_alignq_bn_part", None) if _is_nhwc(z) else None, pack)
     if pack:
-        y._alignq_bins = BNSiteFn._bins_mailbox
-        BNSiteFn._bins_mailbox = None
+        y._alignq_bins = L.MB.site_bins
+        L.MB.site_bins = None
     admm.D = D
     if deferred is not None:
         if rec is not None:
@@ -669,7 +669,7 @@ class BNQuantReluFn(torch.autograd.Function):
                 "alignq_bnq_fwd_parts")
         if pack:
             y = packed_handle(z.shape, dev)
-            BNQuantReluFn._bins_mailbox = (bins, int(k))
+            L.MB.bnq_bins = (bins, int(k))
         ctx.save_for_backward(z, (mask if mask is not None else y) if relu else None, ab, save)
         ctx.bitmask = mask is not None
         ctx.has_res = residual is not None
@@ -699,7 +699,6 @@ class BNQuantReluFn(torch.autograd.Function):
             dres = g
         return dz, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, dres, None, None
 
-    _bins_mailbox = None
 
 
 def _bn_nhwc_ok(bn, z, groups=1) -> bool:
@@ -765,18 +764,33 @@ class BNAffineFn(torch.autograd.Function):
         return dz, dgamma, dbeta, None, None, None, None, None, None, None
 
 
-_conv_groups = 1
+class _ConvGroups(threading.local):
+    n = 1
 
 
-def set_conv_groups(groups):
+_conv_groups = _ConvGroups()
+
+
+class conv_groups_scope:
     """How many equal batch slices the tensors of the current traversal hold (resnet_office.ResNet.forward(groups)): a convolution
-    that leaves batch-norm partial statistics (Conv2d_Q.emit_bn_stats) sums them per slice."""
-    global _conv_groups
-    _conv_groups = int(groups)
+    that leaves batch-norm partial statistics (Conv2d_Q.emit_bn_stats) sums them per slice.  A scope, per thread (as a
+    module global that ResNet.forward only ever set, a Conv2d_Q called OUTSIDE a traversal after a merged one inherited groups = 2
+    and alignq_qconv_fwd refused its batch): the count is back to what it was when the traversal ends."""
+
+    def __init__(self, groups):
+        self.groups = int(groups)
+
+    def __enter__(self):
+        self.prev, _conv_groups.n = _conv_groups.n, self.groups
+        return self
+
+    def __exit__(self, *exc):
+        _conv_groups.n = self.prev
+        return False
 
 
 def conv_groups():
-    return _conv_groups
+    return _conv_groups.n
 
 
 def conv_partials(z, groups):
@@ -800,7 +814,7 @@ def bn_only(bn, z, groups=1):
 
 class Site1Record:
     """One folded small-batch site of a Site1Batch: its buffers between the forward launch and the deferred reduction / preparation."""
-    __slots__ = ("ws", "D", "A", "Gm", "scal", "B", "F", "groups", "dim", "mu", "rho", "S", "rA", "rG", "prepared")
+    __slots__ = ("ws", "D", "A", "Gm", "scal", "B", "F", "groups", "dim", "mu", "rho", "S", "rA", "rG", "prepared", "g_ptr")
 
 
 _site1_batch = None
@@ -842,6 +856,7 @@ class Site1LossSumFn(torch.autograd.Function):
                 "alignq_site1_groups_prep_multi")
             for r in recs:
                 r.prepared = True
+                r.g_ptr = g.data_ptr()        # BNSite1Fn.backward checks that what reaches it IS this scalar, expanded (see there)
         return (None,) + tuple(g.expand(sh) for sh in ctx.shapes)
 
 
@@ -1001,6 +1016,15 @@ class BNSite1Fn(torch.autograd.Function):
         # Site1LossSumFn.backward has prepared every site of the batch (a second backward over a retained graph finds the record
         # emptied and prepares this site by itself)
         prepared = rec is not None and rec.prepared and rec.S is not None
+        if prepared and not (g_loss is not None and g_loss.dim() == 1 and g_loss.stride(0) == 0
+                             and g_loss.data_ptr() == getattr(rec, "g_ptr", None)):
+            # The record was prepared with the ONE upstream scalar of the summed loss.  That is this site's gradient only if its loss
+            # vector reached the total unscaled and through no other path (resnet_office.ResNet.forward); a caller that weights the
+            # vector after total(), feeds it to total() twice or through another path as well hands over something else - autograd then
+            # delivers a tensor that is not the expanded scalar: prepare this site by itself from the gradient that arrived
+            # (a vector left OUT of total() never gets its values at all: they exist only once total() has launched the reduction)
+            prepared = False
+            rec.S = rec.rA = rec.rG = None
         if prepared:
             # (the record lets go of them: a gradient tensor somebody else still references is CLONED by autograd's accumulation
             # node instead of taken over - 2 copies of 5 us per site)
@@ -1130,12 +1154,12 @@ def bn_act_relu(bn, act, z, formula, relu=True, groups=1, residual=None, pack=Fa
                 and L.load().alignq_bin_bytes(int(act.a_bit), float(config.args.act_range), int(formula)) == 2
                 and float(config.args.act_range) * (2 ** int(act.a_bit) - 1) <= 2048.0
                 and float(config.args.act_range) == int(config.args.act_range))
-    BNQuantReluFn._bins_mailbox = None
+    L.MB.bnq_bins = None
     y = BNQuantReluFn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum,
                             bn.eps, act.a_bit, config.args.act_range, formula, relu, groups, residual, conv_partials(z, groups), pack)
     if pack:
-        y._alignq_bins = BNQuantReluFn._bins_mailbox
-        BNQuantReluFn._bins_mailbox = None
+        y._alignq_bins = L.MB.bnq_bins
+        L.MB.bnq_bins = None
     if residual is None:
         tag_levels(y, act.a_bit, config.args.act_range, formula)
     return y

@@ -610,9 +610,9 @@ class QConv3x3Fn(torch.autograd.Function):
             # through which the BN site's backward hands that gradient's record to THIS node's backward
             if x.requires_grad or w.requires_grad:
                 ctx.link = fused.LazyLink()
-                QConv3x3Fn._mailbox = (part, n_parts, 2 if (x.requires_grad and w.requires_grad) else 1, ctx.link)
+                L.MB.conv3x3 = (part, n_parts, 2 if (x.requires_grad and w.requires_grad) else 1, ctx.link)
             else:       # this node's backward never runs: the BN site must finish its own input gradient
-                QConv3x3Fn._mailbox = (part, n_parts)
+                L.MB.conv3x3 = (part, n_parts)
         if tap:
             ctx.set_materialize_grads(False)
             return y, x.view_as(x)
@@ -622,15 +622,14 @@ class QConv3x3Fn(torch.autograd.Function):
     def apply_with_stats(x, w, w_bit, tap=False, xbins=None, a_bit=0):
         """apply(...) with bn_stats=True; attaches the partial statistics to the returned y (a plain python attribute)."""
         # the partials are created inside forward; fetch them through a one-slot mailbox (autograd hides ctx from callers)
-        QConv3x3Fn._mailbox = None
+        L.MB.conv3x3 = None
         out = QConv3x3Fn.apply(x, w, w_bit, tap, True, xbins, a_bit)
         y = out[0] if tap else out
-        if QConv3x3Fn._mailbox is not None:
-            y._alignq_bn_part = QConv3x3Fn._mailbox
-            QConv3x3Fn._mailbox = None
+        if L.MB.conv3x3 is not None:
+            y._alignq_bn_part = L.MB.conv3x3
+            L.MB.conv3x3 = None
         return out
 
-    _mailbox = None
 
     @staticmethod
     def backward(ctx, gy, gtap=None):
@@ -754,9 +753,9 @@ class QConvGenFn(torch.autograd.Function):
         ctx.link = None
         if x.requires_grad or w.requires_grad:
             ctx.link = fused.LazyLink()
-            QConv3x3Fn._mailbox = (part, n_parts, 2 if x.requires_grad else 1, ctx.link)
+            L.MB.conv3x3 = (part, n_parts, 2 if x.requires_grad else 1, ctx.link)
         else:
-            QConv3x3Fn._mailbox = (part, n_parts)
+            L.MB.conv3x3 = (part, n_parts)
         if tap:
             ctx.set_materialize_grads(False)
             return y, x.view_as(x)
@@ -801,12 +800,12 @@ class QConvGenFn(torch.autograd.Function):
 
     @staticmethod
     def apply_with_stats(x, w, w_bit, padding, tap=False):
-        QConv3x3Fn._mailbox = None
+        L.MB.conv3x3 = None
         out = QConvGenFn.apply(x, w, w_bit, padding, tap)
         y = out[0] if tap else out
-        if QConv3x3Fn._mailbox is not None:
-            y._alignq_bn_part = QConv3x3Fn._mailbox
-            QConv3x3Fn._mailbox = None
+        if L.MB.conv3x3 is not None:
+            y._alignq_bn_part = L.MB.conv3x3
+            L.MB.conv3x3 = None
         return out
 
 
@@ -816,7 +815,6 @@ class QTransitionFn(torch.autograd.Function):
     forward and four backward launches.  Both outputs carry their batch-norm partial statistics and lazy-gradient links like
     QConvGenFn's; values equal the separate launches'."""
 
-    _mailbox = None
 
     @staticmethod
     def forward(ctx, x, w3, w1, w_bit):
@@ -837,7 +835,7 @@ class QTransitionFn(torch.autograd.Function):
         ctx.w_bit = int(w_bit)
         ctx.link3, ctx.link1 = fused.LazyLink(), fused.LazyLink()
         # mode 2: the data-gradient role reduces the site backward's per-tile sums and publishes the BN parameter gradients
-        QTransitionFn._mailbox = ((part3, n3, 2, ctx.link3), (part1, n1, 2, ctx.link1))
+        L.MB.transition = ((part3, n3, 2, ctx.link3), (part1, n1, 2, ctx.link1))
         return y3, y1
 
     @staticmethod
@@ -874,11 +872,11 @@ class QTransitionFn(torch.autograd.Function):
 
     @staticmethod
     def apply_with_stats(x, w3, w1, w_bit):
-        QTransitionFn._mailbox = None
+        L.MB.transition = None
         y3, y1 = QTransitionFn.apply(x, w3, w1, w_bit)
-        if QTransitionFn._mailbox is not None:
-            y3._alignq_bn_part, y1._alignq_bn_part = QTransitionFn._mailbox
-            QTransitionFn._mailbox = None
+        if L.MB.transition is not None:
+            y3._alignq_bn_part, y1._alignq_bn_part = L.MB.transition
+            L.MB.transition = None
         return y3, y1
 
 
@@ -973,7 +971,7 @@ class QConvGemmFn(torch.autograd.Function):
         if bn_stats:
             n_parts = lib.alignq_qconv_bn_parts(B, H, W, CIN, COUT, ks, s, int(groups), float(x_levels))
             part = torch.empty(int(groups), n_parts, COUT, 2, dtype=torch.float64, device=w.device)
-            QConvGemmFn._mailbox = (part, n_parts)
+            L.MB.gemm = (part, n_parts)
         L.check(lib.alignq_qconv_fwd(L.ptr(xbins if xbins is not None else x), L.ptr(bins[1] if x_levels else bins[0]), L.ptr(y), B, H, W,
                                      CIN, COUT, ks, s, int(w_bit), float(x_levels), 2 if xbins is not None else 0,
                                      int(groups if bn_stats else 1), L.ptr(part), L.stream_ptr()), "alignq_qconv_fwd")
@@ -981,17 +979,16 @@ class QConvGemmFn(torch.autograd.Function):
         ctx.cfg = (int(w_bit), s, float(x_levels), ks, xbins is not None, (B, CIN, H, W))
         return y
 
-    _mailbox = None
 
     @staticmethod
     def apply_with_stats(x, w, w_bit, stride, x_levels=0.0, groups=1, bins=None, xbins=None):
         """apply(...) that also leaves the batch-norm partial statistics of the output on it: y._alignq_bnq_part =
         (double tensor [groups, parts, C_out, 2], parts, groups) for fused.bn_act_relu / bn_only / bn_site_res_relu."""
-        QConvGemmFn._mailbox = None
+        L.MB.gemm = None
         y = QConvGemmFn.apply(x, w, w_bit, stride, x_levels, groups, True, bins, xbins)
-        if QConvGemmFn._mailbox is not None:
-            y._alignq_bnq_part = QConvGemmFn._mailbox + (int(groups),)
-            QConvGemmFn._mailbox = None
+        if L.MB.gemm is not None:
+            y._alignq_bnq_part = L.MB.gemm + (int(groups),)
+            L.MB.gemm = None
         return y
 
     @staticmethod
@@ -1062,7 +1059,7 @@ class QConvStem7Fn(torch.autograd.Function):
         if bn_stats:
             n_parts = lib.alignq_qconv_stem7_bn_parts(B, H, W, int(groups))
             part = torch.empty(int(groups), n_parts, 64, 2, dtype=torch.float64, device=w.device)
-            QConvGemmFn._mailbox = (part, n_parts)
+            L.MB.gemm = (part, n_parts)
         L.check(lib.alignq_qconv_stem7_fwd(L.ptr(x), L.ptr(bins[0]), L.ptr(y), B, H, W, int(w_bit), int(groups if bn_stats else 1),
                                            L.ptr(part), L.stream_ptr()), "alignq_qconv_stem7_fwd")
         ctx.save_for_backward(x, w)
@@ -1071,11 +1068,11 @@ class QConvStem7Fn(torch.autograd.Function):
     @staticmethod
     def apply_with_stats(x, w, w_bit, groups=1, bins=None):
         """apply(...) that also leaves y._alignq_bnq_part (see QConvGemmFn.apply_with_stats)"""
-        QConvGemmFn._mailbox = None
+        L.MB.gemm = None
         y = QConvStem7Fn.apply(x, w, w_bit, groups, True, bins)
-        if QConvGemmFn._mailbox is not None:
-            y._alignq_bnq_part = QConvGemmFn._mailbox + (int(groups),)
-            QConvGemmFn._mailbox = None
+        if L.MB.gemm is not None:
+            y._alignq_bnq_part = L.MB.gemm + (int(groups),)
+            L.MB.gemm = None
         return y
 
     @staticmethod
@@ -1133,9 +1130,9 @@ class QConvStemFn(torch.autograd.Function):
         ctx.link = None
         if w.requires_grad:
             ctx.link = fused.LazyLink()
-            QConv3x3Fn._mailbox = (part, n_parts, 2, ctx.link)
+            L.MB.conv3x3 = (part, n_parts, 2, ctx.link)
         else:
-            QConv3x3Fn._mailbox = (part, n_parts)
+            L.MB.conv3x3 = (part, n_parts)
         return y
 
     @staticmethod
@@ -1165,9 +1162,9 @@ class QConvStemFn(torch.autograd.Function):
 
     @staticmethod
     def apply_with_stats(x, w, w_bit):
-        QConv3x3Fn._mailbox = None
+        L.MB.conv3x3 = None
         y = QConvStemFn.apply(x, w, w_bit)
-        if QConv3x3Fn._mailbox is not None:
-            y._alignq_bn_part = QConv3x3Fn._mailbox
-            QConv3x3Fn._mailbox = None
+        if L.MB.conv3x3 is not None:
+            y._alignq_bn_part = L.MB.conv3x3
+            L.MB.conv3x3 = None
         return y

@@ -136,9 +136,13 @@ class ResNet(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x, groups=1):
+        from . import fused
+        with fused.conv_groups_scope(groups):        # (the GEMM convolutions' batch-norm statistics epilogue sums per batch slice)
+            return self._forward(x, groups)
+
+    def _forward(self, x, groups):
         trans_loss = 0.
         from . import fused
-        fused.set_conv_groups(groups)        # (the GEMM convolutions' batch-norm statistics epilogue sums per batch slice)
         # staged weight quantisation (OfficeTrainStep.stage_weights, data parallelism): stage i's filters right before stage i
         wq = getattr(self, "_wq_stage", None) or (lambda i: None)
         wq(0)

@@ -29,14 +29,23 @@ def retained_graph_params(params):
     the probe's temporary graph goes, and the next lookup creates an untagged one."""
     token = object()
     live = [p for p in params if p.requires_grad]
-    for p in live:
+    # self-check (ADVICE r5): a parameter created HERE cannot be part of any earlier graph.  If its node survives the probe's
+    # temporary graph too, something pins accumulation nodes (hooks registered on the node itself, a torch that caches it): the
+    # probe would then call EVERY parameter stale and capture() would blame the caller's tensors for it
+    fresh = torch.nn.Parameter(torch.zeros(1))
+    for p in live + [fresh]:
         p.expand_as(p).grad_fn.next_functions[0][0].metadata[_PROBE] = token
     stale = []
-    for p in live:
+    for p in live + [fresh]:
         acc = p.expand_as(p).grad_fn.next_functions[0][0]
         if acc.metadata.get(_PROBE) is token:
             stale.append(p)
         acc.metadata.pop(_PROBE, None)
+    if any(p is fresh for p in stale):
+        raise RuntimeError("retained_graph_params: the probe is unusable in this process - the gradient-accumulation node of a "
+                           "parameter created inside the probe outlived its temporary graph (this torch build, or a component "
+                           "that registers hooks on the accumulation nodes themselves, keeps them alive), so a retained autograd "
+                           "graph cannot be told from a pinned node here; capture() cannot verify its precondition")
     return stale
 
 

@@ -941,11 +941,20 @@ def headline(a, elapsed, images_per_step, world, office, final_ce, final_tl):
     }
 
 
+def free_port():
+    """A port nobody listens on right now (bound to port 0 and released): two `bench.py --gpus N` on one box, or a stale rank of a
+    killed run, would collide on a fixed rendezvous port and the caller would get no JSON line."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def launcher_command(a, argv, port=None):
     """The command line `python bench.py --gpus N ...` (N > 1, not already a rank of a launch) starts as a CHILD process:
     one rank per GPU of this node under torch.distributed.run, same arguments.  127.0.0.1 rendezvous (the host name of a
     GPU box may not resolve)."""
-    port = port or int(os.environ.get("MASTER_PORT", 29533))
+    port = port or (int(os.environ["MASTER_PORT"]) if os.environ.get("MASTER_PORT") else free_port())
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
             "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 

@@ -526,6 +526,30 @@ def test_retained_graph_params_sees_a_graph_kept_alive_by_an_output():
     del out
 
 
+def test_retained_graph_probe_says_so_when_accumulation_nodes_are_pinned(monkeypatch):
+    """the probe tells a retained graph from a fresh parameter by whether the tagged gradient-accumulation node dies with
+    the probe's temporary graph.  If nodes are kept alive by something else (here: a cache that pins every node it hands out, as a
+    component registering hooks on the nodes themselves would), every parameter would look stale and capture() would blame the
+    caller's tensors; the probe's own fresh parameter detects that and the error says what is wrong."""
+    from alignq_amd import train_step
+    lin = torch.nn.Linear(4, 3)
+    assert train_step.retained_graph_params(list(lin.parameters())) == []          # healthy: fresh parameters are not stale
+    pinned = []
+    real = torch.Tensor.expand_as
+
+    def pinning_expand_as(self, other):
+        out = real(self, other)
+        if out.grad_fn is not None:
+            pinned.append(out.grad_fn.next_functions[0][0])       # somebody keeps the accumulation node alive
+        return out
+    monkeypatch.setattr(torch.Tensor, "expand_as", pinning_expand_as)
+    with pytest.raises(RuntimeError, match="probe is unusable"):
+        train_step.retained_graph_params(list(lin.parameters()))
+    monkeypatch.undo()
+    del pinned[:]
+    assert train_step.retained_graph_params(list(lin.parameters())) == []
+
+
 def _attach_detach_worker(rank, world, port, out):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     torch.set_num_threads(1)

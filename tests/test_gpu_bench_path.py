@@ -308,7 +308,7 @@ def _run_model_step(dev, depth_units, k, batch, deferred, seed=0):
     y = torch.randint(0, 10, (batch,), device=dev)
     logits, ce, tl = step._forward_backward(x, y, set_to_none=True)
     torch.cuda.synchronize()
-    out = dict(logits=npy(logits), ce=float(ce), tl=float(tl), D=[npy(m.D) for m in step.admms],
+    out = dict(logits=npy(logits), ce=float(ce.detach()), tl=float(tl.detach()), D=[npy(m.D) for m in step.admms],
                grads={n_: npy(p.grad) for n_, p in net.named_parameters() if p.grad is not None})
     return out, step
 

@@ -31,6 +31,8 @@ def test_config5_full_size_step(dev, monkeypatch):
           last) - teacher-forced against the C oracle on the tensors the step itself produced, per batch slice: y = relu(act_q3(
           bn3(z)) + identity) exact outside a near-tie band (the device's (a, b) differ by ~1e-6 from the oracle's), at most one
           level inside; D and the slice's loss within 1e-5;
+      (a') the same three sites' backward inside the step (round 6): dz, dresidual, dgamma / dbeta, dalterD / dgamma_admm against
+          oq_bn_site_bwd + oq_admm_loss on the upstream gradient the step itself delivered, per slice;
       (b) every one of the 16 ADMM modules holds the TARGET slice's D afterwards (utils/admm.py:25 overwrites; main.py:372,377):
           the same chain run on the target slice alone gives it to rounding (2e-6), the source slice's is far from it;
       (c) the captured HIP graph reproduces eager iterations from the same initial state BIT FOR BIT (every parameter, momentum
@@ -78,6 +80,22 @@ def test_config5_full_size_step(dev, monkeypatch):
                             loss=loss.detach().reshape(-1), admm=act.opt, d_alone=d_alone))
             return out
         monkeypatch.setattr(fused, "bn_site_res_relu", spy)
+        # round 6: the BACKWARD of the same sites inside the step - what reaches BNSite1Fn.backward (the upstream
+        # gradient: the convolution branch's plus, through fused.GradFork's mailbox, the shortcut's) and what leaves it
+        bw = []
+        real_bwd = fused.BNSite1Fn.backward
+
+        def spy_bwd(ctx, g_y, g_loss, g_d):
+            extra = ctx.tok.get("extra") if ctx.tok is not None else None
+            g_tot = g_y if extra is None else g_y + extra              # the fp32 sum the kernel forms on load
+            keep = len(bw) in (0, 12, 15)                               # backward order: site 15 first ... site 0 last
+            g_keep = g_tot.detach().clone() if keep else None
+            out = real_bwd(ctx, g_y, g_loss, g_d)
+            bw.append(dict(z_ptr=ctx.saved_tensors[0].data_ptr(), g=g_keep, dz=out[0].clone() if keep else None,
+                           dgam=out[1].clone(), dbet=out[2].clone(), dres=out[8].clone() if keep else None, dA=out[9].clone(),
+                           dG=out[10].clone()))
+            return out
+        monkeypatch.setattr(fused.BNSite1Fn, "backward", staticmethod(spy_bwd))
         net = make()
         step = OfficeTrainStep(net, lr=0.004, channels_last=True)
         assert step.dual and step.qconv
@@ -86,8 +104,9 @@ def test_config5_full_size_step(dev, monkeypatch):
         cls0, loss0, tl0 = step(xs, ys, xt)
         torch.cuda.synchronize()
         monkeypatch.setattr(fused, "bn_site_res_relu", real)
+        monkeypatch.setattr(fused.BNSite1Fn, "backward", staticmethod(real_bwd))
         assert torch.isfinite(cls0).all() and torch.isfinite(loss0) and torch.isfinite(tl0)
-        assert len(rec) == 16
+        assert len(rec) == 16 and len(bw) == 16
         for i, rr_ in enumerate(rec):                               # (b)
             D_now = rr_["admm"].D
             assert D_now.shape == (B, B) and rr_["admm"] is step.blocks[i].admm0
@@ -123,7 +142,35 @@ def test_config5_full_size_step(dev, monkeypatch):
                 np.testing.assert_allclose(npy(rr_["d_alone"][gi]), D_o, atol=TOL, rtol=0)
                 assert rr_["loss"].numel() == 2                                # the slices' losses as a vector (fast path)
                 np.testing.assert_allclose(float(rr_["loss"][gi]), O.admm_loss(D_o, A0[i], G0[i], 0.2, 0.3)[0], atol=TOL)
-        del rec, step, net
+        # ---- (a', round 6): the same three sites' BACKWARD inside the step against the C oracle, per batch slice, on the tensors the
+        # step itself produced: dz, dresidual within 1e-5 (relative to the gradient's scale), dgamma / dbeta (both slices summed),
+        # dalterD / dgamma_admm (both slices summed, upstream loss gradient 1) - with the one-bit ReLU mask and the column-sum
+        # batch-norm backward on, as the step runs them.  Reference: dann_office/model/resnet.py:131-156 under autograd.
+        by_ptr = {b_["z_ptr"]: b_ for b_ in bw}
+        for i in (0, 3, 15):
+            rr_, bb = rec[i], by_ptr[rec[i]["z"].data_ptr()]
+            assert bb["g"] is not None, i
+            Bt, C, H, W = rr_["z"].shape
+            mem = lambda t, sl: np.ascontiguousarray(npy(t[sl]).transpose(0, 2, 3, 1)).reshape(B, -1)     # noqa: E731
+            dgam_o, dbet_o = np.zeros(C, np.float64), np.zeros(C, np.float64)
+            dA_o, dG_o = np.zeros((B, B), np.float64), np.zeros((B, B), np.float64)
+            for gi, sl in enumerate((slice(0, B), slice(B, 2 * B))):
+                zm, rm_ = mem(rr_["z"], sl), mem(rr_["res"], sl)
+                ab_o, save_o, _ = O.bn_fold_ab(zm, C, 1, rr_["gam"], rr_["bet"], 1e-5)
+                _, D_o, _ = O.bn_site_fwd(zm, C, 1, ab_o, k, r, eps, residual=rm_, relu=True)
+                _, dD_o, dA_s, dG_s = O.admm_loss(D_o, A0[i], G0[i], 0.2, 0.3)
+                gm = mem(bb["g"], sl)
+                dz_o, dg_s, db_s, dres_o, _ = O.bn_site_bwd(gm, dD_o, zm, C, 1, ab_o, save_o, mem(rr_["y"], sl), r, eps)
+                sc = max(1.0, float(np.abs(dz_o).max()))
+                np.testing.assert_allclose(mem(bb["dz"], sl), dz_o, atol=TOL * sc, rtol=1e-4, err_msg=f"dz site {i} slice {gi}")
+                assert np.array_equal(mem(bb["dres"], sl), dres_o), (i, gi)                  # the masked upstream: bit for bit
+                dgam_o += dg_s; dbet_o += db_s; dA_o += dA_s; dG_o += dG_s
+            scale = np.sqrt(B * H * W) * max(1.0, float(np.abs(npy(bb["g"])).max()))
+            np.testing.assert_allclose(npy(bb["dgam"]), dgam_o, atol=2e-6 * scale, rtol=1e-4, err_msg=f"dgamma site {i}")
+            np.testing.assert_allclose(npy(bb["dbet"]), dbet_o, atol=2e-6 * scale, rtol=1e-4, err_msg=f"dbeta site {i}")
+            np.testing.assert_allclose(npy(bb["dA"]), dA_o, atol=1e-7, rtol=1e-4, err_msg=f"dalterD site {i}")
+            np.testing.assert_allclose(npy(bb["dG"]), dG_o, atol=1e-7, rtol=1e-4, err_msg=f"dgamma_admm site {i}")
+        del rec, bw, by_ptr, step, net
 
         # ---- (d): the first iteration's logits, GEMM convolutions vs MIOpen.  Both convolutions are fp32-exact to ~1e-7 relative
         # (tests/test_gpu_qconv.py: each against fp64), so their outputs differ in the last bits, 8-bit bins flip at 49 quantiser sites

@@ -382,3 +382,49 @@ def test_captured_office_step_with_overlapped_allreduce_equals_the_plain_step_at
         assert not bad, bad[:6]
     finally:
         config.args.bitW, config.args.abitW, config.args.train_batch_size, config.args.eval_batch_size = old
+
+
+def test_prepared_site_backward_is_only_used_for_the_gradient_it_was_prepared_with(dev):
+    """Site1LossSumFn.backward prepares every site of a Site1Batch with the ONE upstream scalar of the summed
+    loss.  That is a site's gradient only if its loss vector enters the total exactly once: a vector that enters it TWICE reaches
+    BNSite1Fn.backward with twice the scalar (autograd adds the two), and the site must then prepare itself from what actually
+    arrived (before the fix it silently used the scalar: gradients of z, alterD, gamma too small by the factor).  (A vector
+    weighted BEFORE total() is not a valid use at all: its values only exist once total() has launched the batch's reduction.)
+    Reference semantics: plain autograd through trans_loss (cdf_alignment_admm/dann_office/model/resnet.py:146-156)."""
+    import alignq_amd.office as NO
+    from alignq_amd import config, fused
+    old = (config.args.abitW, config.args.train_batch_size)
+    config.args.abitW, config.args.train_batch_size = 8, 6
+    try:
+        B, C, H, G = 6, 64, 8, 2
+        g = torch.Generator().manual_seed(21)
+        z0 = (torch.randn(G * B, C, H, H, generator=g) * 1.3).to(dev).contiguous(memory_format=torch.channels_last)
+        r0 = torch.relu(torch.randn(G * B, C, H, H, generator=g)).to(dev).contiguous(memory_format=torch.channels_last)
+        gy = (torch.randn(G * B, C, H, H, generator=g) * 1e-2).to(dev).contiguous(memory_format=torch.channels_last)
+        res = {}
+        for arm in ("batched_twice", "per_site_twice", "batched_once"):
+            torch.manual_seed(5)
+            bn = torch.nn.BatchNorm2d(C).to(dev).train()
+            admm = NO.ADMM(B).to(dev)
+            act = NO.activation_quantize_fn2(8, "aligned", admm).to(dev)
+            z, r_ = z0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+            if arm.startswith("batched"):
+                with fused.Site1Batch() as s1:
+                    y, lv = fused.bn_site_res_relu(bn, act, z, r_, 1e-5, groups=G, loss_vec=True)
+                    total = s1.total([lv, lv] if arm == "batched_twice" else [lv])
+            else:
+                y, lv = fused.bn_site_res_relu(bn, act, z, r_, 1e-5, groups=G, loss_vec=True)
+                total = (lv * 2.0).sum()
+            (total + (y * gy).sum()).backward()
+            torch.cuda.synchronize()
+            res[arm] = dict(total=npy(total), dz=npy(z.grad), dr=npy(r_.grad), dA=npy(admm.alterD.grad), dG=npy(admm.gamma.grad),
+                            dw=npy(bn.weight.grad), db=npy(bn.bias.grad))
+        a, b, c = res["batched_twice"], res["per_site_twice"], res["batched_once"]
+        np.testing.assert_allclose(a["total"], b["total"], rtol=1e-6)
+        for key in ("dz", "dr", "dA", "dG", "dw", "db"):
+            assert np.isfinite(a[key]).all() and np.array_equal(a[key], b[key]), key
+        # and it does matter: the ADMM parameter gradients of the doubled loss are twice those of the single one
+        np.testing.assert_allclose(a["dA"], 2.0 * c["dA"], rtol=1e-5, atol=1e-9)
+        assert np.abs(c["dA"]).max() > 0
+    finally:
+        config.args.abitW, config.args.train_batch_size = old
