@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (via gpurun): the three rocprofv3 passes behind profiles/ (kernel trace + stats; PMC FETCH_SIZE; PMC
 # WRITE_SIZE in separate runs, as MI355X_MICROARCH.md prescribes).  Outputs land in gpurun_out/prof/{stats,fetch,write}.
 set -e
-export ROUND=${ROUND:-r05}
+export ROUND=${ROUND:-r06}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/prof && mkdir -p gpurun_out/prof
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/stats -o run -- python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-shapes --no-dp-probe --no-other-configs > gpurun_out/prof/stats.log 2>&1

@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (via gpurun): tools/corr_large_bench.py (bench.py's kernels.corr_large) plain and under rocprofv3 kernel stats
 # -> gpurun_out/profiles/${ROUND}_corr_large.txt (the bench's own lines, then the kernel table of the rows above 128)
 set -e
-export ROUND=${ROUND:-r05}
+export ROUND=${ROUND:-r06}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/prof_c && mkdir -p gpurun_out/prof_c gpurun_out/profiles
 python3 tools/corr_large_bench.py 2>/dev/null > gpurun_out/profiles/${ROUND}_corr_large.txt

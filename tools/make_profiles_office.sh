@@ -5,7 +5,7 @@
 #   3. the eager step kernel by kernel (tools/profile_office.sh) and the captured step's timeline (tools/step_timeline.sh).
 # -> gpurun_out/profiles/${ROUND}_office_*
 set -e
-export ROUND=${ROUND:-r05}
+export ROUND=${ROUND:-r06}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/prof_o && mkdir -p gpurun_out/prof_o gpurun_out/profiles
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_o/stats -o run -- python3 tools/office_shapes.py > gpurun_out/prof_o/stats.log 2>&1

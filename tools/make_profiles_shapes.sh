@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (via gpurun): rocprofv3 kernel stats + the two PMC passes (FETCH_SIZE, WRITE_SIZE in separate runs,
 # MI355X_MICROARCH.md) of tools/roofline_shapes.py; condensed into gpurun_out/profiles/${ROUND}_shapes_*.
 set -e
-export ROUND=${ROUND:-r05}
+export ROUND=${ROUND:-r06}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/prof_s && mkdir -p gpurun_out/prof_s gpurun_out/profiles
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_s/stats -o run -- python3 tools/roofline_shapes.py > gpurun_out/prof_s/stats.log 2>&1

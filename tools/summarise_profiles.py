@@ -9,7 +9,7 @@ Units / corrections (MI355X_MICROARCH.md, HBM): rocprofv3 reports FETCH_SIZE and
 FETCH_SIZE counts 64 B per 128-B request of wide coalesced reads, so fetch bytes = 2 x FETCH_SIZE; WRITE_SIZE is exact."""
 import csv, glob, json, os, sys, collections
 
-ROUND = os.environ.get("ROUND", "r05")
+ROUND = os.environ.get("ROUND", "r06")
 
 src, out = sys.argv[1], sys.argv[2]
 os.makedirs(out, exist_ok=True)
