@@ -28,6 +28,8 @@ class UniformQuantizeFn(torch.autograd.Function):
             return x
         x = L.dev_f32(x, "input")
         y = torch.empty_like(x)
+        if x.numel() == 0:           # (an empty tensor: the reference's elementwise ops return an empty tensor; nothing to launch)
+            return y
         L.check(L.load().alignq_uniform_quantize(L.ptr(x), L.ptr(y), x.numel(), int(k), L.stream_ptr()),
                 "alignq_uniform_quantize")
         return y
@@ -45,6 +47,9 @@ class ActQuantFn(torch.autograd.Function):
     def forward(ctx, x, k, act_range, formula):
         x = L.dense_f32(x, "activation")
         xq = torch.empty_like(x)
+        ctx.empty = x.numel() == 0
+        if ctx.empty:                # (as the reference's elementwise chain: empty in, empty out, nothing to launch)
+            return xq
         L.check(L.load().alignq_act_quant_fwd(L.ptr(x), L.ptr(xq), None, x.numel(), int(k), float(act_range),
                                               int(formula), L.stream_ptr()), "alignq_act_quant_fwd")
         ctx.save_for_backward(x)
@@ -53,6 +58,8 @@ class ActQuantFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.empty:
+            return torch.empty_like(g), None, None, None
         (x,) = ctx.saved_tensors
         g = L.like_layout(g, x)
         dx = torch.empty_like(x)

@@ -428,3 +428,29 @@ def test_prepared_site_backward_is_only_used_for_the_gradient_it_was_prepared_wi
         assert np.abs(c["dA"]).max() > 0
     finally:
         config.args.abitW, config.args.train_batch_size = old
+
+
+def test_empty_inputs_follow_the_reference_elementwise_ops(dev):
+    """Edge case: an empty tensor.  The reference's uniform_quantize (model/quantization.py:19-38) and its plain activation quantiser
+    (cdf_alignment/resnet-20-cifar-10/model/quantization.py:81-103: `method != 'ours'` or no ADMM module) are chains of elementwise
+    ATen ops - empty in, empty out, gradients empty; the C ABI itself refuses n <= 0 (ALIGNQ_EINVAL), the Python mirror does not launch."""
+    import alignq_amd.cdf_alignment as NC
+    from alignq_amd import _lib as L
+    from alignq_amd import config
+    x = torch.empty(0, 16, 4, 4, device=dev, requires_grad=True)
+    for k in (1, 2, 8, 32):
+        y = NC.uniform_quantize(k)(x)
+        assert y.shape == x.shape and y.device == x.device
+    old = config.args.abitW
+    config.args.abitW = 8
+    try:
+        act = NC.activation_quantize_fn(8, "second").to(dev)
+        y = act(x)
+        assert y.shape == x.shape
+        y.sum().backward()
+        assert x.grad is not None and x.grad.shape == x.shape
+    finally:
+        config.args.abitW = old
+    lib = L.load()
+    z = torch.zeros(4, device=dev)
+    assert lib.alignq_act_quant_fwd(L.ptr(z), L.ptr(z), None, 0, 8, 2.0, 0, None) < 0          # ALIGNQ_EINVAL: n <= 0
