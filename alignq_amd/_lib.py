@@ -14,7 +14,8 @@ SO_PATH = os.environ.get("ALIGNQ_SO") or os.path.join(_HERE, "lib", "libalignq_h
 FORMULA_ADMM, FORMULA_CDF = 0, 1
 MAX_BATCH = 128            # rows the FUSED site kernels hold on chip (ALIGNQ_MAX_BATCH)
 MAX_CORR_BATCH = 1024      # rows alignq_corr_fwd / _bwd take (ALIGNQ_MAX_CORR_BATCH: blocked Gram above 128)
-ABI_VERSION = 21
+ABI_VERSION = 22
+EINVAL, EUNSUPPORTED = -1, -2          # include/alignq.h: ALIGNQ_EINVAL, ALIGNQ_EUNSUPPORTED
 
 _c = ctypes
 
@@ -28,7 +29,25 @@ class Mailboxes(threading.local):
 
 
 MB = Mailboxes()
+
+
 _vp, _i, _i64, _f, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_size_t
+
+
+class SiteBnArgs(ctypes.Structure):
+    """include/alignq.h: alignq_site_bn_args (one site of alignq_site_partials_bn_twin; the arguments of alignq_site_partials_bn)"""
+    _fields_ = [("z", _vp), ("bn_part", _vp), ("bn_gamma", _vp), ("bn_beta", _vp), ("running_mean", _vp), ("running_var", _vp),
+                ("num_batches_tracked", _vp), ("momentum", _f), ("bn_eps", _f), ("ab", _vp), ("save", _vp), ("C", _i), ("HW", _i),
+                ("B", _i), ("F", _i64), ("k", _i), ("act_range", _f), ("eps", _f), ("relu", _i), ("residual", _vp), ("nhwc", _i),
+                ("conv_parts", _i), ("xq", _vp), ("bins_out", _vp), ("stats", _vp), ("ws", _vp)]
+
+
+class SiteBwdBnArgs(ctypes.Structure):
+    """include/alignq.h: alignq_site_bwd_bn_args (one site of alignq_site_bwd_apply_bn_twin; alignq_site_bwd_apply_bn's arguments)"""
+    _fields_ = [("g", _vp), ("S", _vp), ("z", _vp), ("ab", _vp), ("save", _vp), ("C", _i), ("HW", _i), ("nhwc", _i), ("y_relu", _vp),
+                ("y_bins", _vp), ("y_bin_bytes", _i), ("dresidual", _vp), ("stats", _vp), ("B", _i), ("F", _i64), ("act_range", _f),
+                ("eps", _f), ("dx", _vp), ("dx_part", _vp)]
+
 
 # name -> (restype, argtypes)   — mirrors include/alignq.h one to one
 SIGNATURES = {
@@ -134,6 +153,8 @@ SIGNATURES = {
                                           _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "alignq_head_ce_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "alignq_bucket_copy_multi": (_i, [_i, _vp, _vp, _vp, _i, _vp]),
+    "alignq_site_partials_bn_twin": (_i, [_vp, _vp, _vp]),
+    "alignq_site_bwd_apply_bn_twin": (_i, [_vp, _vp, _vp]),
     "alignq_dp_counter_bump": (_i, [_vp, _vp]),
     "alignq_dp_flag_publish": (_i, [_vp, _vp, _vp]),
     "alignq_dp_stream_wait_ge": (_i, [_vp, _vp, _c.c_uint32]),

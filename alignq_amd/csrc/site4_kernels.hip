@@ -237,6 +237,14 @@ struct SFill {
   float mu, rho;
 };
 
+// Twin launch (round 6): TWO sites of the same shape (B, F, k, act_range, eps) in one launch of the one-tile form - the workgroups from
+// `split` on work on the second site's tensors.  For the two sites behind a transition block's convolutions (conv0's and skip_conv's
+// outputs, model/resnet.py PreActBlock_conv_Q.forward): each of them is a 128-workgroup launch that leaves half the chip idle, and
+// they do not depend on each other - one launch saves a node of the step's chain.  Same code per workgroup: bit-identical results.
+struct Twin {
+  const float* x; float* xq; float* slabs; float* stats; unsigned* counter; BnFold bn; int split;
+};
+
 // SINGLE: one tile per workgroup (n_tiles <= grid, every CIFAR-size site): no tile loop, so nothing is hoisted out of it and
 // kept alive across the phases (88 instead of 128 VGPRs), which buys the early requests of the batch-norm finalisation.
 // NTv: 1024 threads (16 waves: one workgroup per CU, the latency-tuned CIFAR form) or 512 (8 waves, 32-feature tiles, 45 KB of
@@ -246,8 +254,15 @@ template <int TFv, bool PAIR, bool SINGLE, int NTv = NT, bool FULLP = false>
 __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restrict__ x, int B, int64_t F, int k, float r,
                                                        float eps, float* __restrict__ xq, float* __restrict__ slabs,
                                                        float* __restrict__ stats, int n_tiles, int aligned,
-                                                       unsigned* __restrict__ counter, BnFold bn, SFill fill) {
+                                                       unsigned* __restrict__ counter, BnFold bn, SFill fill, Twin twin) {
   BSTAMP(0, 0);
+  int bid = blockIdx.x;
+  if constexpr (SINGLE && NTv == 1024) {
+    if (twin.split && bid >= twin.split) {        // block-uniform: the second site of a twin launch
+      bid -= twin.split;
+      x = twin.x; xq = twin.xq; slabs = twin.slabs; stats = twin.stats; counter = twin.counter; bn = twin.bn;
+    }
+  }
   constexpr int LDB = TFv + 8;                    // bf16 elements per LDS row (row bytes multiple of 16, see bank note)
   constexpr int LPR = TFv / 4;                    // lanes per row (float4 each)
   constexpr int NW = NTv / 64;                    // waves
@@ -274,9 +289,9 @@ __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restri
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[STAGE_BYTES + (4 * TFv + 2 * NW * TFv) * 4];
   __shared__ __attribute__((aligned(16))) float nerf_lds[PAIR ? ALIGNQ_NERF_LDS_FLOATS : 4];
   if constexpr (SINGLE && NTv == 1024) {
-    if ((int)blockIdx.x >= n_tiles) {          // filler workgroups (block-uniform): see SFill
+    if (bid >= n_tiles) {          // filler workgroups (block-uniform): see SFill (a twin launch has none)
       static_assert(STAGE_BYTES >= kSlabReduceLds<true>, "the reduction's LDS lies in the staging area");
-      const int fb = blockIdx.x - n_tiles, it = fb / kSlabRedBlocks;
+      const int fb = bid - n_tiles, it = fb / kSlabRedBlocks;
       float* wsf = const_cast<float*>(fill.slabs[it]);
       float* parts = wsf + (size_t)fill.n_slabs[it] * kSlab4Floats;
       slab_reduce_body<true, true>(fill.slabs[it], fill.n_slabs[it], kSlab4Floats, 128, B, fill.scale[it], fill.out[it], fill.A[it],
@@ -306,7 +321,7 @@ __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restri
   const Levels nlev = make_levels(k, fabsf(r) <= 8.0f);
   const float invBm1 = 1.0f / (float)(B - 1);
 
-  if (blockIdx.x == 0 && tid == 0 && counter) *counter = 0u;   // arrival counter of the reduce kernel's epilogue
+  if (bid == 0 && tid == 0 && counter) *counter = 0u;   // arrival counter of the reduce kernel's epilogue
 
   // work items: 10 upper-triangular output tiles x KSPLIT K-halves, item q = (tile q % 10, K-half q / 10); wave w takes
   // q = w, w + NW, ...: 16 waves: 20 items -> q = w and (waves 0..3) 16 + w; 10 items -> waves 0..9;  8 waves: 3 / 3 / 2.
@@ -328,7 +343,7 @@ __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restri
 
   STAMP(0);
   float4 xv[RJ];      // this tile's rows; in the multi-tile form refilled with the NEXT tile's rows once they are staged
-  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  for (int tile = bid; tile < n_tiles; tile += gridDim.x) {
     const int col0 = tile * TFv;
     const int col = col0 + 4 * c;
     float4 tv[RJ];
@@ -372,7 +387,7 @@ __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restri
     }
     // ---- load + transform + quantise ----------------------------------------------------------------
     // (multi-tile launches: every tile but the first was requested by the previous iteration, in front of its MFMA phase)
-    if (SINGLE || tile == (int)blockIdx.x) {
+    if (SINGLE || tile == bid) {
 #pragma unroll
       for (int j = 0; j < RJ; j++) {
         const int row = rg + RG * j;
@@ -388,7 +403,7 @@ __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restri
         }
       }
     }
-    if (PAIR && tile == (int)blockIdx.x) {     // first iteration (block-uniform): publish the transform's table
+    if (PAIR && tile == bid) {     // first iteration (block-uniform): publish the transform's table
       nerf_tab_store<NTv>(nerf_lds, nerf_regs);
       __syncthreads();
     }
@@ -852,7 +867,7 @@ __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restri
   __syncthreads();
   // packed slab (site_internal.h, kSlab4Floats): six off-diagonal tiles as they are, the four diagonal tiles' upper
   // triangles two to a [32][33] block
-  float* slab = slabs + (int64_t)blockIdx.x * kSlab4Floats;
+  float* slab = slabs + (int64_t)bid * kSlab4Floats;
   float4* slab4 = reinterpret_cast<float4*>(slab);
   const float4* C4 = reinterpret_cast<const float4*>(C);
   for (int e = tid; e < kSlab4Off / 4; e += NTv) {
@@ -1288,21 +1303,33 @@ __global__ __launch_bounds__(256) void head_bwd_prep_multi_kernel(HeadBwdArgs h,
 //   B = Vh[j][c] needs 8 CONSECUTIVE j per lane, so the standardised tiles are staged TRANSPOSED in LDS
 //       ([feature][batch], bf16 hi/lo): the load mapping gives each thread one feature column and 16 consecutive
 //       batch rows (256-byte coalesced row segments per wave instruction), two 16-byte LDS stores per array.
-// TFv = 64: 512 threads, one workgroup per CU (138 KB LDS);  TFv = 32: 256 threads, 69 KB LDS, two workgroups per CU whose
-// phases interleave, and twice as many tiles for the small-F sites.
+// TFv = 64: 512 threads, one workgroup per CU (138 KB LDS);  TFv = 32: 256 threads, 69 KB LDS, twice as many tiles for the small-F
+// sites; launched ONE workgroup per CU (kBwd32OnePerCuLds at the launcher: two co-resident ones were not reproducible to the bit).
 // VEC (F % 4 == 0, 16-byte aligned tensors): a thread owns FOUR feature columns x FOUR batch rows and moves them with 16-byte
 // global accesses (12 loads + 4-8 stores per thread instead of 48 + 16-32 dword ones: the dword form kept the texture
 // addresser busy for ~4 us per launch at F = 16384); the transposed staging is then one 8-byte LDS store per column and
 // array.  !VEC: one column x 16 rows per thread, dword accesses with clamped offsets (any F, any alignment).
 // LOOP (plain site, VEC, 64-feature tiles, many tiles per CU): a workgroup walks over tiles and requests the next tile's x / g
 // rows as soon as this tile's are staged, so they fly under the MFMA, projection, assembly and copy-out phases.
+// Twin launch (round 6; 32-feature one-tile form only): the backward of TWO sites of one shape - the workgroups from `split` on work on
+// the second site's tensors (see Twin at the forward kernel).  No filler role in such a launch.
+struct BwdTwin {
+  const float* gup; const float* S; const float* x; const float* stats; float* dx; BnFold bn; int split;
+};
 template <int TFv, bool PAIR, bool BN, bool VEC, bool LOOP = false, bool FULLP = false>
 __global__ __launch_bounds__(TFv * 8, 2) void site_bwd4_kernel(const float* __restrict__ gup, const float* __restrict__ S,
                                                         const float* __restrict__ x, const float* __restrict__ stats,
                                                         int B, int64_t F, float r, float eps, float* __restrict__ dx,
-                                                        int n_tiles, int aligned, BnFold bn, alignq_wgr::RedFill fill) {
+                                                        int n_tiles, int aligned, BnFold bn, alignq_wgr::RedFill fill, BwdTwin twin) {
   BSTAMP(1, 0);
   (void)aligned;
+  int bid = blockIdx.x;
+  if constexpr (!LOOP && TFv == 32) {
+    if (twin.split && bid >= twin.split) {        // block-uniform: the second site of a twin launch
+      bid -= twin.split;
+      gup = twin.gup; S = twin.S; x = twin.x; stats = twin.stats; dx = twin.dx; bn = twin.bn;
+    }
+  }
   constexpr int LDv = TFv + 4, TILE = 128 * LDv;    // fp32 tiles: 16-byte aligned rows (copied out with 16-byte LDS reads)
   constexpr int NWv = TFv / 8;                       // waves per workgroup
   constexpr int CB = TFv / 32;                       // 32-column blocks per tile
@@ -1314,8 +1341,8 @@ __global__ __launch_bounds__(TFv * 8, 2) void site_bwd4_kernel(const float* __re
   if constexpr (!LOOP && TFv == 32) {
     // filler workgroups (block-uniform; the narrow sites' launches leave half the chip idle): filter-gradient slab reductions
     // of convolutions whose backward already ran, see wgrad_reduce_body.h
-    if ((int)blockIdx.x >= n_tiles) {
-      const int fb = blockIdx.x - n_tiles;
+    if (bid >= n_tiles) {
+      const int fb = bid - n_tiles;
       int it = 0;
       while (it + 1 < alignq_wgr::kFill && fb >= fill.blk0[it + 1]) it++;
       alignq_wgr::wgrad_reduce_body<256>(fill.slabs[it], fill.n_slabs[it], fill.n_elem[it], fill.dw[it], fb - fill.blk0[it],
@@ -1376,7 +1403,7 @@ __global__ __launch_bounds__(TFv * 8, 2) void site_bwd4_kernel(const float* __re
   }
   // !LOOP: one tile per workgroup (grid == n_tiles): no tile loop, nothing to hoist
   int st_buf = 0;
-  for (int tile = blockIdx.x; tile < n_tiles; tile += (int)gridDim.x) {
+  for (int tile = LOOP ? (int)blockIdx.x : bid; tile < n_tiles; tile += (int)gridDim.x) {
     const int col0 = tile * TFv;
     const bool lcol_ok = (col0 + lcol) < F;
     float gj[PAIR ? 16 : 1];   // g * dt/dx of this thread's 16 elements (VEC: [4*row + column])
@@ -1984,12 +2011,12 @@ __global__ __launch_bounds__(TFv * 8, 2) void site_bwd4_kernel(const float* __re
 // B == 128, F % TFV == 0 and the tensors are 16-byte aligned.
 struct FwdLaunch {
   const float* x; int B; int64_t F; int k; float r, eps; float* xq; float* ws; float* stats; int n_tiles, aligned;
-  unsigned* counter; BnFold bn; SFill fill; int grid, fgrid; bool full64; hipStream_t st;
+  unsigned* counter; BnFold bn; SFill fill; int grid, fgrid; bool full64; hipStream_t st; Twin twin;
 };
 template <int TFV, bool P, bool SG, int NTV, bool FULLP>
 inline void launch_fwd4_inst(const FwdLaunch& a) {
   hipLaunchKernelGGL((site_fwd4_kernel<TFV, P, SG, NTV, FULLP>), (SG && NTV == NT) ? a.fgrid : a.grid, NTV, 0, a.st, a.x, a.B, a.F,
-                     a.k, a.r, a.eps, a.xq, a.ws, a.stats, a.n_tiles, a.aligned, a.counter, a.bn, a.fill);
+                     a.k, a.r, a.eps, a.xq, a.ws, a.stats, a.n_tiles, a.aligned, a.counter, a.bn, a.fill, a.twin);
 }
 template <int TFV, bool P>
 inline int launch_fwd4_tf(const FwdLaunch& a) {
@@ -2012,14 +2039,21 @@ inline int launch_fwd4_tf(const FwdLaunch& a) {
 
 // One backward launch, same rule as the forward's: the unmasked instantiations (FULLP one-tile, LOOP) are chosen only by the
 // functions that check what they assume.
+// site_bwd4_kernel<32, ..> with more than 256 workgroups: 16 KB of unused dynamic LDS per workgroup keep the workgroups ONE per CU.
+// Two co-resident site workgroups of that kernel (69 KB of LDS, 196 VGPRs: they fit) gave results that differed by one ulp in scattered
+// elements of a few tiles from launch to launch - 8 of 20 launches behind a large GEMM, 2 of 8 training steps, found by the
+// graph-replay-equals-eager test (tools/diag_cold_determinism.py; NOTES.md round 6: never with one workgroup per CU, never in a build
+// of this file without SLP vectorisation; cause not established).  The twin launch's step time is the same within the spread
+// (1.017 / 1.018 ms per step), so nothing is given up.
+constexpr int kBwd32OnePerCuLds = 16384;
 struct BwdLaunch {
   const float* gup; const float* S; const float* x; const float* stats; int B; int64_t F; float r, eps; float* dx;
-  int n_tiles, aligned; BnFold bn; alignq_wgr::RedFill fill; int grid; bool vec; hipStream_t st;
+  int n_tiles, aligned; BnFold bn; alignq_wgr::RedFill fill; int grid; bool vec; hipStream_t st; BwdTwin twin; int dyn_lds = 0;
 };
 template <int TFV, bool P, bool N, bool VEC, bool LOOP, bool FULLP>
 inline void launch_bwd4_inst(const BwdLaunch& a) {
-  hipLaunchKernelGGL((site_bwd4_kernel<TFV, P, N, VEC, LOOP, FULLP>), a.grid, TFV * 8, 0, a.st, a.gup, a.S, a.x, a.stats, a.B, a.F,
-                     a.r, a.eps, a.dx, a.n_tiles, a.aligned, a.bn, a.fill);
+  hipLaunchKernelGGL((site_bwd4_kernel<TFV, P, N, VEC, LOOP, FULLP>), a.grid, TFV * 8, a.dyn_lds, a.st, a.gup, a.S, a.x, a.stats, a.B, a.F,
+                     a.r, a.eps, a.dx, a.n_tiles, a.aligned, a.bn, a.fill, a.twin);
 }
 template <int TFV, bool P, bool N>
 inline void launch_bwd4_tile(const BwdLaunch& a) {             // one tile per workgroup
@@ -2062,10 +2096,33 @@ int launch_partials4(bool pair, const Geom& g, const float* x, int B, int64_t F,
   // geom(): one tile per workgroup up to F = 16384; beyond that the 64-feature tile loop runs in up to 512 workgroups of 512
   // threads, two per CU, for the plain site; with the batch-norm fold (no configuration has one at such F) in 1024-thread ones
   const bool full64 = B == 128 && F % 64 == 0 && aligned;     // the 512-thread multi-tile form takes complete tiles only
-  const FwdLaunch fl{x, B, F, k, r, eps, xq, ws, stats, g.n_tiles, aligned, counter, bn, fill, g.grid, fgrid, full64, st};
+  const FwdLaunch fl{x, B, F, k, r, eps, xq, ws, stats, g.n_tiles, aligned, counter, bn, fill, g.grid, fgrid, full64, st, Twin{}};
   int rc;
   if (pair) rc = g.tf == 64 ? launch_fwd4_tf<64, true>(fl) : launch_fwd4_tf<32, true>(fl);
   else rc = g.tf == 64 ? launch_fwd4_tf<64, false>(fl) : launch_fwd4_tf<32, false>(fl);
+  if (rc) return rc;
+  RET_ON_ERR();
+  return 0;
+}
+
+// Two sites of one shape in ONE launch of the one-tile form (see Twin): only where a single site's launch leaves half the chip
+// idle (at most 128 workgroups), complete or masked tiles alike; no filler roles.  ALIGNQ_EUNSUPPORTED otherwise (the caller then
+// launches the sites one after the other).
+int launch_partials4_twin(const Geom& g, int B, int64_t F, int k, float r, float eps, const float* xa, float* xqa, float* statsa,
+                          float* wsa, BnFold bna, const float* xb, float* xqb, float* statsb, float* wsb, BnFold bnb, hipStream_t st) {
+  if (g.nb != 4 || g.n_tiles > g.grid || g.grid > 128) return ALIGNQ_EUNSUPPORTED;
+  if ((int64_t)B * F * 4 >= ((int64_t)1 << 32)) return ALIGNQ_EUNSUPPORTED;
+  auto al = [&](const float* x, float* xq) {
+    return ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && (!xq || (reinterpret_cast<uintptr_t>(xq) & 15) == 0);
+  };
+  const int aligned = al(xa, xqa) && al(xb, xqb);
+  for (const BnFold* bn : {&bna, &bnb})
+    if (bn->bins && (!aligned || bn->res || (reinterpret_cast<uintptr_t>(bn->bins) & 15) || (bn->bin_bytes != 1 && bn->bin_bytes != 2)))
+      return ALIGNQ_EINVAL;
+  auto ctr = [&](float* ws) { return reinterpret_cast<unsigned*>(ws + (size_t)g.grid * g.slab_floats + kPartFloats); };
+  const Twin tw{xb, xqb, wsb, statsb, ctr(wsb), bnb, g.grid};
+  const FwdLaunch fl{xa, B, F, k, r, eps, xqa, wsa, statsa, g.n_tiles, aligned, ctr(wsa), bna, SFill{}, 2 * g.grid, 2 * g.grid, false, st, tw};
+  const int rc = g.tf == 64 ? launch_fwd4_tf<64, true>(fl) : launch_fwd4_tf<32, true>(fl);
   if (rc) return rc;
   RET_ON_ERR();
   return 0;
@@ -2236,7 +2293,8 @@ int launch_bwd4(bool pair, const Geom& g, const float* gup, const float* S, cons
   // 16-byte accesses need whole column quads and aligned rows (channels-last BN: C % 4 == 0 holds, C is a power of two >= 4)
   const bool vec = (F % 4 == 0) && al16(gup) && al16(x) && al16(stats) && al16(dx) && al16(bn.y) && al16(bn.dres) && al16(bn.ybins) &&
                    al16(bn.ab) && al16(bn.save) && (!bn.ab || bn.nhwc || bn.HW % 4 == 0) && (!bn.nhwc || bn.C % 4 == 0);
-  const BwdLaunch bl{gup, S, x, stats, B, F, r, eps, dx, n_tiles, aligned, bn, fill, grid, vec, st};
+  BwdLaunch bl{gup, S, x, stats, B, F, r, eps, dx, n_tiles, aligned, bn, fill, grid, vec, st, BwdTwin{}};
+  if (tf == 32 && n_tiles > 256) bl.dyn_lds = kBwd32OnePerCuLds;      // (8192 < F < 16384: no configuration has such a site)
   const bool plain = !bn.ab && !bn.y && !bn.ybins && !bn.dres;
   if (tf == 64 && plain && n_tiles > 2 * 256 && vec && B == 128 && F % 64 == 0) {
     // plain site with many tiles per CU (F > 32768): the looped, software-pipelined form (138 KB of LDS: one workgroup per CU)
@@ -2249,6 +2307,30 @@ int launch_bwd4(bool pair, const Geom& g, const float* gup, const float* S, cons
   } else {
     if (pair && bn.ab) launch_bwd4_tile<32, true, true>(bl); else if (pair) launch_bwd4_tile<32, true, false>(bl); else launch_bwd4_tile<32, false, false>(bl);
   }
+  RET_ON_ERR();
+  return 0;
+}
+
+// The backward of two sites of one shape in ONE launch (see BwdTwin): only the 32-feature one-tile form whose single launch leaves
+// half of the chip's workgroup slots free (bwd_fill_ok); both sites with the folded batch-norm and the same access form.
+int launch_bwd4_twin(int B, int64_t F, float r, float eps, const float* ga, const float* Sa, const float* xa, const float* statsa,
+                     float* dxa, BnFold bna, const float* gb, const float* Sb, const float* xb, const float* statsb, float* dxb,
+                     BnFold bnb, hipStream_t st) {
+  if (!bwd_fill_ok(B, F) || !bna.ab || !bnb.ab) return ALIGNQ_EUNSUPPORTED;
+  if ((int64_t)B * F * 4 >= ((int64_t)1 << 32)) return ALIGNQ_EUNSUPPORTED;
+  const int n_tiles = (int)((F + 31) / 32);
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  auto vec_of = [&](const float* g, const float* x, const float* stats, const float* dx, const BnFold& bn) {
+    return (F % 4 == 0) && al16(g) && al16(x) && al16(stats) && al16(dx) && al16(bn.y) && al16(bn.dres) && al16(bn.ybins) &&
+           al16(bn.ab) && al16(bn.save) && (bn.nhwc || bn.HW % 4 == 0) && (!bn.nhwc || bn.C % 4 == 0);
+  };
+  const bool va = vec_of(ga, xa, statsa, dxa, bna), vb = vec_of(gb, xb, statsb, dxb, bnb);
+  if (va != vb) return ALIGNQ_EUNSUPPORTED;
+  alignq_wgr::RedFill fill{};
+  const BwdTwin tw{gb, Sb, xb, statsb, dxb, bnb, n_tiles};
+  BwdLaunch bl{ga, Sa, xa, statsa, B, F, r, eps, dxa, n_tiles, 0, bna, fill, 2 * n_tiles, va, st, tw};
+  if (2 * n_tiles > 256) bl.dyn_lds = kBwd32OnePerCuLds;      // the F = 8192 pair: 512 workgroups, two rounds of 256
+  launch_bwd4_tile<32, true, true>(bl);
   RET_ON_ERR();
   return 0;
 }

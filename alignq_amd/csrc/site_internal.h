@@ -149,8 +149,14 @@ inline int site_fill_slots(int B, int64_t F) {       // fillers a forward launch
 }
 int launch_partials4(bool pair, const Geom& g, const float* x, int B, int64_t F, int k, float r, float eps, float* xq,
                      float* stats, float* ws, hipStream_t st, BnFold bn = no_bn(), const SiteFillArgs* fa = nullptr);
+// two sites of one shape in one launch of the one-tile form (ALIGNQ_EUNSUPPORTED unless a single site leaves half the chip idle)
+int launch_partials4_twin(const Geom& g, int B, int64_t F, int k, float r, float eps, const float* xa, float* xqa, float* statsa,
+                          float* wsa, BnFold bna, const float* xb, float* xqb, float* statsb, float* wsb, BnFold bnb, hipStream_t st);
 int launch_bwd4(bool pair, const Geom& g, const float* gup, const float* S, const float* x, const float* stats, int B,
                 int64_t F, float r, float eps, float* dx, hipStream_t st, BnFold bn = no_bn(), const alignq_wgr::RedFill* fill = nullptr);
+int launch_bwd4_twin(int B, int64_t F, float r, float eps, const float* ga, const float* Sa, const float* xa, const float* statsa,
+                     float* dxa, BnFold bna, const float* gb, const float* Sb, const float* xb, const float* statsb, float* dxb,
+                     BnFold bnb, hipStream_t st);
 // S = sym(gD) * gscale / F (and, fused, the scaled ADMM parameter gradients) — first launch of every backward
 int launch_prep(bool fused, const float* dD, const float* D, const float* alterD, const float* gamma, int dim,
                 const float* scal, float mu, const float* gscale, int B, int64_t F, float* S, float* dA_out,

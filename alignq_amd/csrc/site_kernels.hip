@@ -639,6 +639,42 @@ int alignq_site_partials_bn_fill(const float* z, const void* bn_part, const floa
                           n_fill ? &fa : nullptr);
 }
 
+// Two sites of one shape in one launch (include/alignq.h): each described as alignq_site_partials_bn's arguments.
+static int site_bn_fold(const alignq_site_bn_args& a, BnFold* out) {
+  if (!a.z || !a.ab || !a.save || !a.ws || !a.stats) return ALIGNQ_EINVAL;
+  if (bad_k(a.k)) return ALIGNQ_EINVAL;
+  if (!bn_shape_ok(a.B, a.F, a.C, a.HW, a.nhwc)) return ALIGNQ_EUNSUPPORTED;
+  BnFold bn = no_bn();
+  bn.ab = a.ab; bn.save = a.save; bn.HW = a.HW; bn.C = a.C; bn.nhwc = a.nhwc;
+  bn.part = (const double*)a.bn_part; bn.gamma = a.bn_gamma; bn.beta = a.bn_beta;
+  bn.running_mean = a.running_mean; bn.running_var = a.running_var; bn.nbt = (long long*)a.num_batches_tracked;
+  bn.momentum = a.momentum; bn.bn_eps = a.bn_eps; bn.relu = a.relu; bn.res = a.residual;
+  if (a.bins_out) {
+    bn.bins = a.bins_out;
+    bn.bin_bytes = alignq_bin_bytes(a.k, a.act_range, ALIGNQ_FORMULA_ADMM);
+    if (bn.bin_bytes == 0 || a.residual) return ALIGNQ_EINVAL;
+  }
+  if (a.conv_parts > 0) {
+    if (!a.nhwc || !a.bn_part) return ALIGNQ_EINVAL;
+    bn.n_parts = a.conv_parts; bn.part_f32 = 1;
+  }
+  *out = bn;
+  return 0;
+}
+
+int alignq_site_partials_bn_twin(const alignq_site_bn_args* a, const alignq_site_bn_args* b, void* stream) {
+  if (!a || !b) return ALIGNQ_EINVAL;
+  if (a->B != b->B || a->F != b->F || a->k != b->k || a->act_range != b->act_range || a->eps != b->eps) return ALIGNQ_EUNSUPPORTED;
+  if (a->ws == b->ws || a->stats == b->stats || (a->xq && a->xq == b->xq) || a->ab == b->ab) return ALIGNQ_EINVAL;   // two sites, two sets of buffers
+  BnFold bna, bnb;
+  int rc = site_bn_fold(*a, &bna);
+  if (rc) return rc;
+  rc = site_bn_fold(*b, &bnb);
+  if (rc) return rc;
+  return launch_partials4_twin(geom(a->B, a->F), a->B, a->F, a->k, a->act_range, a->eps, a->z, a->xq, a->stats, (float*)a->ws, bna,
+                               b->z, b->xq, b->stats, (float*)b->ws, bnb, (hipStream_t)stream);
+}
+
 size_t alignq_site_bn_part_bytes(int64_t F, int nhwc) {
   return (nhwc ? (size_t)F : (size_t)((F + 31) / 32)) * 2 * sizeof(float);   // <= per column | per smallest backward tile
 }
@@ -675,6 +711,26 @@ int alignq_site_bwd_apply_bn_fill(const float* g, const float* S, const float* z
   bn.ab = ab; bn.save = save; bn.HW = HW; bn.C = C; bn.nhwc = nhwc;
   bn.dx_part = dx_part; bn.y = y_relu; bn.dres = dresidual; bn.ybins = y_bins; bn.bin_bytes = y_bin_bytes;
   return launch_bwd4(true, geom(B, F), g, S, z, stats, B, F, act_range, eps, dx, (hipStream_t)stream, bn, n_fill ? &fill : nullptr);
+}
+
+// The backward of two sites of one shape in one launch (include/alignq.h): each described as alignq_site_bwd_apply_bn's arguments.
+int alignq_site_bwd_apply_bn_twin(const alignq_site_bwd_bn_args* a, const alignq_site_bwd_bn_args* b, void* stream) {
+  if (!a || !b) return ALIGNQ_EINVAL;
+  if (a->B != b->B || a->F != b->F || a->act_range != b->act_range || a->eps != b->eps) return ALIGNQ_EUNSUPPORTED;
+  BnFold bn[2];
+  const alignq_site_bwd_bn_args* two[2] = {a, b};
+  for (int i = 0; i < 2; i++) {
+    const alignq_site_bwd_bn_args& q = *two[i];
+    if (!q.S || !q.z || !q.ab || !q.save || !q.stats || !q.dx || !q.dx_part) return ALIGNQ_EINVAL;
+    if (q.y_bins && (q.y_relu || (q.y_bin_bytes != 1 && q.y_bin_bytes != 2))) return ALIGNQ_EINVAL;
+    if (!bn_shape_ok(q.B, q.F, q.C, q.HW, q.nhwc)) return ALIGNQ_EUNSUPPORTED;
+    bn[i] = no_bn();
+    bn[i].ab = q.ab; bn[i].save = q.save; bn[i].HW = q.HW; bn[i].C = q.C; bn[i].nhwc = q.nhwc;
+    bn[i].dx_part = q.dx_part; bn[i].y = q.y_relu; bn[i].dres = q.dresidual; bn[i].ybins = q.y_bins; bn[i].bin_bytes = q.y_bin_bytes;
+  }
+  if (a->dx == b->dx || a->dx_part == b->dx_part) return ALIGNQ_EINVAL;
+  return launch_bwd4_twin(a->B, a->F, a->act_range, a->eps, a->g, a->S, a->z, a->stats, a->dx, bn[0], b->g, b->S, b->z, b->stats, b->dx,
+                          bn[1], (hipStream_t)stream);
 }
 
 int alignq_site_prep_fused(const float* D, const float* alterD, const float* gamma, int dim, const float* scal, float mu,

@@ -273,6 +273,10 @@ class DeferredWgrads:
     def __exit__(self, exc_type, *exc):
         global _active_wgrads
         _active_wgrads = None
+        if exc_type is None:
+            flush_bwd_twins()
+        else:
+            del _bwd_twins.open[:]
         stale = [l for l in _posted_links if l.record is not None]
         del _posted_links[:]
         for l in stale:
@@ -304,6 +308,7 @@ class DeferredWgrads:
         return out
 
     def flush(self):
+        flush_bwd_twins()
         if not self.items:
             return
         T = len(self.items)
@@ -355,6 +360,7 @@ def post_lazy_dz(link, g, z, ab, save, ktot, part=None, dgamma=None, dbeta=None)
 def take_lazy_dz(link, g):
     """The record posted for this convolution's output gradient, or None.  Raises if a record exists but the incoming
     gradient is not the posted tensor (it was altered or summed with another gradient on the way)."""
+    flush_bwd_twins()            # (a parked site backward writes what the record below points at)
     if link is None or link.record is None:
         return None
     rec, link.record = link.record, None
@@ -374,6 +380,128 @@ def active_deferred():
     return _active
 
 
+class _TwinState(threading.local):
+    ctx = None
+
+
+_twin = _TwinState()
+
+
+class twin_sites:
+    """Inside this context two BN-folded ADMM sites of ONE shape whose single launches leave half the chip idle (F <= 8192 at batch
+    128) are launched TOGETHER (alignq_site_partials_bn_twin): the sites behind a transition block's two convolutions, model/
+    resnet.py PreActBlock_conv_Q.forward - one node of the step's chain instead of two, bit-identical results.  The first site's
+    forward parks its arguments, the second launches both; a site without a partner (or of another shape) is launched on its own,
+    at the latest when the context ends.  Only the whole-model deferred step (fused.DeferredLosses) uses it."""
+
+    def __init__(self):
+        self.pending = None
+        self.bwd = _BwdTwin()
+
+    def __enter__(self):
+        self.prev, _twin.ctx = _twin.ctx, self
+        return self
+
+    def __exit__(self, *exc):
+        _twin.ctx = self.prev
+        if exc[0] is None:
+            self.flush()
+        self.pending = None
+        return False
+
+    @staticmethod
+    def _single(args, st):
+        a = args
+        L.check(L.load().alignq_site_partials_bn(a.z, a.bn_part, a.bn_gamma, a.bn_beta, a.running_mean, a.running_var,
+                                                 a.num_batches_tracked, a.momentum, a.bn_eps, a.ab, a.save, a.C, a.HW, a.B, a.F, a.k,
+                                                 a.act_range, a.eps, a.relu, a.residual, a.nhwc, a.conv_parts, a.xq, a.bins_out,
+                                                 a.stats, a.ws, st), "alignq_site_partials_bn")
+
+    def flush(self):
+        if self.pending is not None:
+            args, _keep, st = self.pending
+            self.pending = None
+            self._single(args, st)
+
+    def add(self, args, keep, st):
+        if self.pending is None:
+            self.pending = (args, keep, st)
+            return
+        pa, _pk, pst = self.pending
+        self.pending = None
+        rc = L.load().alignq_site_partials_bn_twin(ctypes.byref(pa), ctypes.byref(args), st) if pst == st else L.EUNSUPPORTED
+        if rc == L.EUNSUPPORTED:           # another shape, or a site that fills the chip alone: one after the other
+            self._single(pa, pst)
+            self._single(args, st)
+        else:
+            L.check(rc, "alignq_site_partials_bn_twin")
+
+
+def _site_bwd_launch(lib, g_y, S, z, ab, save, C, HW, nhwc, y, ybins, dres, stats, B, F, act_range, eps, dx, part, fill, st):
+    nf = len(fill)
+    L.check(lib.alignq_site_bwd_apply_bn_fill(
+        L.ptr(g_y), L.ptr(S), L.ptr(z), L.ptr(ab), L.ptr(save), C, HW, nhwc, L.ptr(y), L.ptr(ybins),
+        ybins.element_size() if ybins is not None else 0, L.ptr(dres) if y is not None else None, L.ptr(stats), B, F,
+        act_range, eps, L.ptr(dx), L.ptr(part), nf, L.ptr_array([f[0] for f in fill]) if nf else None,
+        L.ptr_array([f[1] for f in fill]) if nf else None, (ctypes.c_int * nf)(*[f[2] for f in fill]) if nf else None,
+        (ctypes.c_int * nf)(*[f[3] for f in fill]) if nf else None, st), "alignq_site_bwd_apply_bn_fill")
+
+
+class _BwdTwin:
+    """Where the backward launches of a twin pair meet (created by `twin_sites`, carried by both sites' autograd contexts): the first
+    site's backward parks its arguments, the second launches both (alignq_site_bwd_apply_bn_twin).  The only reader of what the
+    launch writes - the producing convolution's backward - calls flush_bwd_twins() before it takes the lazy records, so a site whose
+    partner never ran is launched on its own there; DeferredWgrads flushes as well when the backward ends."""
+
+    def __init__(self):
+        self.pending = None
+
+    @staticmethod
+    def _single(a, st):
+        L.check(L.load().alignq_site_bwd_apply_bn(a.g, a.S, a.z, a.ab, a.save, a.C, a.HW, a.nhwc, a.y_relu, a.y_bins, a.y_bin_bytes,
+                                                  a.dresidual, a.stats, a.B, a.F, a.act_range, a.eps, a.dx, a.dx_part, st),
+                "alignq_site_bwd_apply_bn")
+
+    def flush(self):
+        if self.pending is not None:
+            args, _keep, st = self.pending
+            self.pending = None
+            if self in _bwd_twins.open:
+                _bwd_twins.open.remove(self)
+            self._single(args, st)
+
+    def add(self, args, keep, st):
+        if self.pending is None:
+            self.pending = (args, keep, st)
+            _bwd_twins.open.append(self)
+            return
+        pa, _pk, pst = self.pending
+        self.pending = None
+        if self in _bwd_twins.open:
+            _bwd_twins.open.remove(self)
+        rc = L.load().alignq_site_bwd_apply_bn_twin(ctypes.byref(pa), ctypes.byref(args), st) if pst == st else L.EUNSUPPORTED
+        if rc == L.EUNSUPPORTED:
+            self._single(pa, pst)
+            self._single(args, st)
+        else:
+            L.check(rc, "alignq_site_bwd_apply_bn_twin")
+
+
+class _BwdTwins(threading.local):
+    def __init__(self):
+        self.open = []
+
+
+_bwd_twins = _BwdTwins()
+
+
+def flush_bwd_twins():
+    """Launch every parked site backward of this thread (see _BwdTwin) - called by whoever is about to read or to launch a reader of
+    a site backward's outputs."""
+    for t in list(_bwd_twins.open):
+        t.flush()
+
+
 # ------------------------------------------------------------------------------------------------------------------
 class BNSiteFn(torch.autograd.Function):
     """act_q(bn(z)) with the batch-norm folded into the ADMM-site kernels (training mode).
@@ -391,6 +519,7 @@ class BNSiteFn(torch.autograd.Function):
         (`packed_handle`) carrying it as `._alignq_bins = (bins, k)` for a consumer that reads indices (ops.QConv3x3Fn:
         forward and filter gradient); this node's own backward takes the ReLU mask from the index as well."""
         z = L.dense_f32(z, "conv output")
+        ctx.twin_bwd = None
         nhwc = not z.is_contiguous()             # dense_f32 only lets contiguous or channels-last 4-D tensors through
         if res is not None:
             res = L.dense_f32(res, "residual")
@@ -430,17 +559,31 @@ class BNSiteFn(torch.autograd.Function):
         stats = torch.empty(4, F, dtype=torch.float32, device=dev)
         scal = rec.scal if rec is not None else torch.empty(4, dtype=torch.float32, device=dev)
         ws = torch.empty(lib.alignq_site_ws_bytes(B, F), dtype=torch.uint8, device=dev)
-        # filler role: earlier sites' slab reductions ride in this launch when it leaves CUs idle (DeferredLosses.take_fill)
-        fill = _active.take_fill(rec, B, F, dim, mu, rho) if (rec is not None and _active is not None) else []
-        nf = len(fill)
-        L.check(lib.alignq_site_partials_bn_fill(
-            L.ptr(z), L.ptr(ws_bn), L.ptr(bn_weight), L.ptr(bn_bias), L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt),
-            float(momentum), float(bn_eps), L.ptr(ab), L.ptr(save), C, HW, B, F, int(k), float(act_range), float(eps),
-            int(bool(relu)), L.ptr(res), int(nhwc), int(conv_parts), L.ptr(y), L.ptr(bins), L.ptr(stats), L.ptr(ws), nf,
-            L.ptr_array([r.ws for r in fill]) if nf else None, L.ptr_array([r.D for r in fill]) if nf else None,
-            L.ptr_array([r.A for r in fill]) if nf else None, L.ptr_array([r.Gm for r in fill]) if nf else None,
-            L.ptr_array([r.scal for r in fill]) if nf else None, L.i64_array([r.F for r in fill]) if nf else None,
-            dim, float(mu), float(rho), st), "alignq_site_partials_bn_fill")
+        tw = _twin.ctx
+        if (tw is not None and rec is not None and _active is not None and nhwc and res is None
+                and lib.alignq_site_fill_slots(B, F) > 0):
+            # twin launch (round 6): inside `twin_sites()` two half-chip sites of one shape share ONE launch - the first only parks its
+            # arguments (its outputs are allocated; nobody reads them before the partner's forward launches both), no filler role
+            args = L.SiteBnArgs(L.ptr(z), L.ptr(ws_bn), L.ptr(bn_weight), L.ptr(bn_bias), L.ptr(running_mean), L.ptr(running_var),
+                                L.ptr(nbt), float(momentum), float(bn_eps), L.ptr(ab), L.ptr(save), C, HW, B, F, int(k),
+                                float(act_range), float(eps), int(bool(relu)), None, int(nhwc), int(conv_parts), L.ptr(y), L.ptr(bins),
+                                L.ptr(stats), L.ptr(ws))
+            tw.add(args, (z, ws_bn, bn_weight, bn_bias, running_mean, running_var, nbt, ab, save, y, bins, stats, ws), st)
+            ctx.twin_bwd = tw.bwd           # the pair's backward launches meet there again (BNSiteFn.backward)
+        else:
+            if tw is not None:
+                tw.flush()         # (keep the launches in program order: a parked site goes first)
+            # filler role: earlier sites' slab reductions ride in this launch when it leaves CUs idle (DeferredLosses.take_fill)
+            fill = _active.take_fill(rec, B, F, dim, mu, rho) if (rec is not None and _active is not None) else []
+            nf = len(fill)
+            L.check(lib.alignq_site_partials_bn_fill(
+                L.ptr(z), L.ptr(ws_bn), L.ptr(bn_weight), L.ptr(bn_bias), L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt),
+                float(momentum), float(bn_eps), L.ptr(ab), L.ptr(save), C, HW, B, F, int(k), float(act_range), float(eps),
+                int(bool(relu)), L.ptr(res), int(nhwc), int(conv_parts), L.ptr(y), L.ptr(bins), L.ptr(stats), L.ptr(ws), nf,
+                L.ptr_array([r.ws for r in fill]) if nf else None, L.ptr_array([r.D for r in fill]) if nf else None,
+                L.ptr_array([r.A for r in fill]) if nf else None, L.ptr_array([r.Gm for r in fill]) if nf else None,
+                L.ptr_array([r.scal for r in fill]) if nf else None, L.i64_array([r.F for r in fill]) if nf else None,
+                dim, float(mu), float(rho), st), "alignq_site_partials_bn_fill")
         if rec is not None:      # reduced with all other sites in DeferredLosses.total()
             rec.ws, rec.D, rec.A, rec.Gm, rec.B, rec.F, rec.dim = ws, D, A, Gm, B, F, dim
             rec.mu, rec.rho = float(mu), float(rho)
@@ -491,21 +634,25 @@ class BNSiteFn(torch.autograd.Function):
         dres = None
         if has_res and g_y is not None:
             dres = torch.empty_like(z) if y is not None else g_y
-        # filler role: the narrow sites' launches take pending filter-gradient slab reductions along (DeferredWgrads.take_site)
-        fill = active_wgrads().take_site(B, F) if active_wgrads() is not None else []
-        nf = len(fill)
-        L.check(lib.alignq_site_bwd_apply_bn_fill(
-            L.ptr(g_y), L.ptr(S), L.ptr(z), L.ptr(ab), L.ptr(save), C, HW, nhwc, L.ptr(y), L.ptr(ybins),
-            ybins.element_size() if ybins is not None else 0, L.ptr(dres) if y is not None else None, L.ptr(stats), B, F,
-            act_range, eps, L.ptr(dx), L.ptr(part), nf, L.ptr_array([f[0] for f in fill]) if nf else None,
-            L.ptr_array([f[1] for f in fill]) if nf else None, (ctypes.c_int * nf)(*[f[2] for f in fill]) if nf else None,
-            (ctypes.c_int * nf)(*[f[3] for f in fill]) if nf else None, st), "alignq_site_bwd_apply_bn_fill")
+        fresh = all(p is None or p.grad is None for p in ctx.bn_params)
+        lazy2 = ctx.from_qconv == 2 and active_wgrads() is not None and active_wgrads().fresh_grads and fresh
+        if ctx.twin_bwd is not None and lazy2 and g_y is not None:
+            # the backward of a twin pair (round 6): nothing else is launched by this node on the lazy path, and the one consumer of dx
+            # and of the per-tile sums - the producing convolution's backward - flushes the pair before it reads them (take_lazy_dz)
+            args = L.SiteBwdBnArgs(L.ptr(g_y), L.ptr(S), L.ptr(z), L.ptr(ab), L.ptr(save), C, HW, nhwc, L.ptr(y), L.ptr(ybins),
+                                   ybins.element_size() if ybins is not None else 0, L.ptr(dres) if y is not None else None,
+                                   L.ptr(stats), B, F, act_range, eps, L.ptr(dx), L.ptr(part))
+            ctx.twin_bwd.add(args, (g_y, S, z, ab, save, y, ybins, dres, stats, dx, part), st)
+        else:
+            flush_bwd_twins()
+            # filler role: the narrow sites' launches take pending filter-gradient slab reductions along (DeferredWgrads.take_site)
+            fill = active_wgrads().take_site(B, F) if active_wgrads() is not None else []
+            _site_bwd_launch(lib, g_y, S, z, ab, save, C, HW, nhwc, y, ybins, dres, stats, B, F, act_range, eps, dx, part, fill, st)
         dgam = torch.empty(C, dtype=torch.float32, device=dev) if has_w else None
         dbet = torch.empty(C, dtype=torch.float32, device=dev) if has_b else None
         # the in-kernel form fills dgam / dbet AFTER autograd has adopted them as .grad: only valid while both .grad are
-        # really None (the DeferredWgrads(fresh_grads=True) promise, checked here rather than trusted)
-        fresh = all(p is None or p.grad is None for p in ctx.bn_params)
-        if ctx.from_qconv == 2 and active_wgrads() is not None and active_wgrads().fresh_grads and fresh:
+        # really None (the DeferredWgrads(fresh_grads=True) promise, checked here rather than trusted: `fresh` above)
+        if lazy2:
             # z is the output of a 3x3 body convolution whose fused backward reduces the per-tile sums itself: nothing is
             # launched here; dgam / dbet are filled by that kernel (later in this backward, before anything reads them).
             # Autograd receives VIEWS: it adopts a gradient as .grad only while nobody else holds the tensor object (it would

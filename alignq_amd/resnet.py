@@ -17,7 +17,7 @@ from . import cdf_alignment as _cdf
 from . import cdf_alignment_admm as _admm
 from . import config
 from .admm import ADMM
-from .fused import bn_act_relu, bn_only, bn_site
+from .fused import bn_act_relu, bn_only, bn_site, twin_sites
 
 
 def _transition_pair(conv3, conv1, x):
@@ -98,14 +98,20 @@ class PreActBlock_conv_Q(nn.Module):
             else:
                 z0, xa = self.conv0.forward_with_shortcut(x)        # xa = x (skip_conv's input gradient joins conv0's)
                 zs = self.skip_conv(xa)
-            shortcut, loss = self._bnq(self.skip_bn, self.act_skip_q, zs)
-            trans_loss += loss
+            # the two sites behind the transition's convolutions do not depend on each other: with the fold they share ONE launch
+            # (fused.twin_sites: each alone leaves half the chip idle)
+            with twin_sites():
+                shortcut, loss = self._bnq(self.skip_bn, self.act_skip_q, zs)
+                trans_loss += loss
+                out, loss = self._bnq(self.bn0, self.act_q0, z0, relu=True,
+                                      pack=getattr(self, "pack_bins", False) and getattr(self.conv1, "use_qconv", False))
+                trans_loss += loss
         else:
             z0, shortcut = self.conv0.forward_with_shortcut(x)      # shortcut = x (its gradient joins conv0's data gradient)
-        # relu(act_q0(bn0(.))) feeds conv1 and nothing else: with pack_bins it travels as its level indices (N2)
-        out, loss = self._bnq(self.bn0, self.act_q0, z0, relu=True,
-                              pack=getattr(self, "pack_bins", False) and getattr(self.conv1, "use_qconv", False))
-        trans_loss += loss
+            # relu(act_q0(bn0(.))) feeds conv1 and nothing else: with pack_bins it travels as its level indices (N2)
+            out, loss = self._bnq(self.bn0, self.act_q0, z0, relu=True,
+                                  pack=getattr(self, "pack_bins", False) and getattr(self.conv1, "use_qconv", False))
+            trans_loss += loss
         out, loss = self._bnq(self.bn1, self.act_q1, self.conv1(out), relu=True, residual=shortcut)   # out += shortcut; relu
         trans_loss += loss
         if self.tree == "admm":

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALIGNQ_ABI_VERSION 21
+#define ALIGNQ_ABI_VERSION 22
 
 #define ALIGNQ_FORMULA_ADMM 0
 #define ALIGNQ_FORMULA_CDF 1
@@ -485,6 +485,27 @@ int alignq_site_partials_bn(const float* z, const void* bn_part, const float* bn
  * fill_dim / fill_mu / fill_rho).  Nothing reads a site's D or loss before the end of the forward; same code, same workgroup
  * partition, same bits as alignq_site_reduce_loss[_multi].                                                              */
 int alignq_site_fill_slots(int B, int64_t F);
+/* TWO sites of one shape in ONE launch (round 6): the sites behind a transition block's two convolutions - `out = act_q0(bn0(conv0(x)))`
+ * and `shortcut = act_skip_q(skip_bn(skip_conv(x)))`, cdf_alignment_admm/resnet-56-cifar-10/model/resnet.py:81-90 - do not depend on each
+ * other and each is a 128-workgroup launch that leaves half of the chip idle; together they are one node of the step's chain instead of
+ * two.  Each site is described by alignq_site_partials_bn's arguments (same meaning); both must share B, F, k, act_range, eps and have
+ * their own buffers.  Same code per workgroup as two alignq_site_partials_bn launches: bit-identical outputs.  No filler role.
+ * ALIGNQ_EUNSUPPORTED where a single site's launch already fills the chip (more than 128 tiles) or loops over tiles: launch them one
+ * after the other then.                                                                                                          */
+typedef struct alignq_site_bn_args {
+  const float* z; const void* bn_part; const float* bn_gamma; const float* bn_beta; float* running_mean; float* running_var;
+  int64_t* num_batches_tracked; float momentum, bn_eps; float* ab; float* save; int C, HW, B; int64_t F; int k; float act_range, eps;
+  int relu; const float* residual; int nhwc, conv_parts; float* xq; void* bins_out; float* stats; void* ws;
+} alignq_site_bn_args;
+int alignq_site_partials_bn_twin(const alignq_site_bn_args* a, const alignq_site_bn_args* b, void* stream);
+/* ... and their backward (alignq_site_bwd_apply_bn's arguments per site; both need the folded batch-norm): the two launches of 256
+ * workgroups of 256 threads each leave half of the chip's workgroup slots free.  ALIGNQ_EUNSUPPORTED for other shapes.        */
+typedef struct alignq_site_bwd_bn_args {
+  const float* g; const float* S; const float* z; const float* ab; const float* save; int C, HW, nhwc; const float* y_relu;
+  const void* y_bins; int y_bin_bytes; float* dresidual; const float* stats; int B; int64_t F; float act_range, eps; float* dx;
+  float* dx_part;
+} alignq_site_bwd_bn_args;
+int alignq_site_bwd_apply_bn_twin(const alignq_site_bwd_bn_args* a, const alignq_site_bwd_bn_args* b, void* stream);
 int alignq_site_partials_bn_fill(const float* z, const void* bn_part, const float* bn_gamma, const float* bn_beta,
                                  float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
                                  float bn_eps, float* ab, float* save, int C, int HW, int B, int64_t F, int k,

@@ -454,3 +454,139 @@ def test_empty_inputs_follow_the_reference_elementwise_ops(dev):
     lib = L.load()
     z = torch.zeros(4, device=dev)
     assert lib.alignq_act_quant_fwd(L.ptr(z), L.ptr(z), None, 0, 8, 2.0, 0, None) < 0          # ALIGNQ_EINVAL: n <= 0
+
+
+# ------------------------------------------------------------------------------------------------ round 6: twin site launch (headline)
+def _site_bn_args(L, lib, dev, z, gamma, beta, k, relu, want_bins, C, HW, B, F):
+    f32 = dict(dtype=torch.float32, device=dev)
+    part = torch.empty(lib.alignq_bn_nhwc_ws_bytes(C), dtype=torch.uint8, device=dev)
+    L.check(lib.alignq_bn_partial_stats_nhwc(L.ptr(z), B, C, HW, L.ptr(part), None), "bn_partial_stats_nhwc")
+    t = dict(part=part, ab=torch.empty(2, C, **f32), save=torch.empty(2, C, **f32), rm=torch.zeros(C, **f32), rv=torch.ones(C, **f32),
+             nbt=torch.zeros((), dtype=torch.int64, device=dev), stats=torch.empty(4, F, **f32),
+             ws=torch.zeros(lib.alignq_site_ws_bytes(B, F), dtype=torch.uint8, device=dev),
+             y=None if want_bins else torch.empty_like(z),
+             bins=torch.empty_strided(z.shape, z.stride(), dtype=torch.int16, device=dev) if want_bins else None)
+    a = L.SiteBnArgs(L.ptr(z), L.ptr(part), L.ptr(gamma), L.ptr(beta), L.ptr(t["rm"]), L.ptr(t["rv"]), L.ptr(t["nbt"]), 0.1, 1e-5,
+                     L.ptr(t["ab"]), L.ptr(t["save"]), C, HW, B, F, k, 2.0, 0.0, int(relu), None, 1, 0, L.ptr(t["y"]), L.ptr(t["bins"]),
+                     L.ptr(t["stats"]), L.ptr(t["ws"]))
+    return a, t
+
+
+@pytest.mark.parametrize("B,C,H", [(128, 32, 16), (128, 64, 8), (100, 64, 8)])
+def test_twin_site_launch_equals_two_launches_bit_for_bit(dev, B, C, H):
+    """alignq_site_partials_bn_twin: the two sites behind a transition block's convolutions (cdf_alignment_admm/resnet-56-cifar-10/
+    model/resnet.py:81-90: act_skip_q(skip_bn(skip_conv(x))) without ReLU, relu(act_q0(bn0(conv0(x)))) stored as level indices) in ONE
+    launch against the two alignq_site_partials_bn launches it replaces: outputs, level indices, column statistics, (a, b), running
+    statistics and - after the slab reduction - D and the ADMM loss are bit-identical (same code per workgroup).  And a shape whose
+    single launch already fills the chip is refused (ALIGNQ_EUNSUPPORTED = -2): the caller launches the sites one after the other."""
+    import ctypes
+    from alignq_amd import _lib as L
+    lib = L.load()
+    k, HW, F = 8, H * H, C * H * H
+    g = torch.Generator().manual_seed(B + C)
+    mk = lambda: (torch.randn(B, H, H, C, generator=g) * 1.5 + 0.2).to(dev).permute(0, 3, 1, 2)       # channels-last      # noqa: E731
+    za, zb = mk(), mk()
+    gam = [(torch.rand(C, generator=g) + 0.5).to(dev) for _ in range(2)]
+    bet = [(torch.randn(C, generator=g) * 0.2).to(dev) for _ in range(2)]
+    A, Gm = (torch.randn(128, 128, generator=g) * 0.05).to(dev), (torch.randn(128, 128, generator=g) * 0.05).to(dev)
+    res = {}
+    for arm in ("twin", "separate"):
+        a, ta = _site_bn_args(L, lib, dev, za, gam[0], bet[0], k, False, False, C, HW, B, F)
+        b, tb = _site_bn_args(L, lib, dev, zb, gam[1], bet[1], k, True, True, C, HW, B, F)
+        if arm == "twin":
+            L.check(lib.alignq_site_partials_bn_twin(ctypes.byref(a), ctypes.byref(b), None), "twin")
+        else:
+            for s_, t in ((a, ta), (b, tb)):
+                L.check(lib.alignq_site_partials_bn(s_.z, s_.bn_part, s_.bn_gamma, s_.bn_beta, s_.running_mean, s_.running_var,
+                                                    s_.num_batches_tracked, s_.momentum, s_.bn_eps, s_.ab, s_.save, C, HW, B, F, k, 2.0, 0.0,
+                                                    s_.relu, None, 1, 0, s_.xq, s_.bins_out, s_.stats, s_.ws, None), "single")
+        out = []
+        for t in (ta, tb):
+            D, scal = torch.empty(B, B, device=dev), torch.empty(4, device=dev)
+            L.check(lib.alignq_site_reduce_loss(L.ptr(t["ws"]), B, F, L.ptr(D), L.ptr(A), L.ptr(Gm), 128, 0.2, 0.3, L.ptr(scal), None), "reduce")
+            out.append(dict(D=npy(D), loss=npy(scal[:1]), stats=npy(t["stats"]), ab=npy(t["ab"]), save=npy(t["save"]), rm=npy(t["rm"]),
+                            rv=npy(t["rv"]), nbt=int(t["nbt"]), y=None if t["y"] is None else npy(t["y"]),
+                            bins=None if t["bins"] is None else t["bins"].cpu().numpy()))
+        torch.cuda.synchronize()
+        res[arm] = out
+    for sa, sb in zip(res["twin"], res["separate"]):
+        for key in sa:
+            if sa[key] is None:
+                assert sb[key] is None
+            elif isinstance(sa[key], int):
+                assert sa[key] == sb[key] == 1
+            else:
+                assert np.isfinite(sa[key].astype(np.float64)).all() and np.array_equal(sa[key], sb[key]), key
+    assert np.abs(res["twin"][0]["D"]).max() > 0 and res["twin"][1]["bins"].min() >= 0            # (the second site's ReLU clamps its indices)
+    # a 256-tile site fills the chip on its own: refused
+    Bf, Cf, Hf = 128, 16, 32
+    zf = (torch.randn(Bf, Hf, Hf, Cf, generator=g)).to(dev).permute(0, 3, 1, 2)
+    gf, bf = torch.ones(Cf, device=dev), torch.zeros(Cf, device=dev)
+    a, _ta = _site_bn_args(L, lib, dev, zf, gf, bf, k, False, False, Cf, Hf * Hf, Bf, Cf * Hf * Hf)
+    b, _tb = _site_bn_args(L, lib, dev, zf.clone(memory_format=torch.preserve_format), gf, bf, k, False, False, Cf, Hf * Hf, Bf, Cf * Hf * Hf)
+    assert lib.alignq_site_partials_bn_twin(ctypes.byref(a), ctypes.byref(b), None) == -2
+
+
+@pytest.mark.parametrize("B,C,H", [(128, 32, 16), (128, 64, 8), (100, 64, 8)])
+def test_twin_site_backward_equals_two_launches_bit_for_bit(dev, B, C, H):
+    """alignq_site_bwd_apply_bn_twin against the two alignq_site_bwd_apply_bn launches it replaces (the backward of the pair of
+    test_twin_site_launch_equals_two_launches_bit_for_bit: one site with an fp32 output and no ReLU, one stored as level indices with
+    the ReLU mask taken from them): dx and the per-tile batch-norm sums bit for bit."""
+    import ctypes
+    from alignq_amd import _lib as L
+    lib = L.load()
+    k, HW, F = 8, H * H, C * H * H
+    g = torch.Generator().manual_seed(B + C + 1)
+    mk = lambda sc=1.5: (torch.randn(B, H, H, C, generator=g) * sc + 0.2).to(dev).permute(0, 3, 1, 2)      # noqa: E731
+    za, zb = mk(), mk()
+    ga, gb = mk(1e-2), mk(1e-2)
+    gam = [(torch.rand(C, generator=g) + 0.5).to(dev) for _ in range(2)]
+    bet = [(torch.randn(C, generator=g) * 0.2).to(dev) for _ in range(2)]
+    a, ta = _site_bn_args(L, lib, dev, za, gam[0], bet[0], k, False, False, C, HW, B, F)
+    b, tb = _site_bn_args(L, lib, dev, zb, gam[1], bet[1], k, True, True, C, HW, B, F)
+    L.check(lib.alignq_site_partials_bn_twin(ctypes.byref(a), ctypes.byref(b), None), "fwd twin")
+    S = [(torch.randn(lib.alignq_site_bwd_ws_bytes(B) // 4, generator=g) * 1e-3).to(dev) for _ in range(2)]
+    Dm, A, Gm, scal = torch.empty(B, B, device=dev), torch.zeros(128, 128, device=dev), torch.zeros(128, 128, device=dev), torch.empty(4, device=dev)
+    for t, s_ in ((ta, S[0]), (tb, S[1])):       # a consistent S (fp32 + its bf16 image) from the preparation entry point
+        L.check(lib.alignq_site_reduce_loss(L.ptr(t["ws"]), B, F, L.ptr(Dm), L.ptr(A), L.ptr(Gm), 128, 0.2, 0.3, L.ptr(scal), None), "reduce")
+        one = torch.ones((), device=dev)
+        dA, dG = torch.empty_like(A), torch.empty_like(Gm)
+        L.check(lib.alignq_site_prep_fused(L.ptr(Dm), L.ptr(A), L.ptr(Gm), 128, L.ptr(scal), 0.2, L.ptr(one), B, F, L.ptr(s_), L.ptr(dA),
+                                           L.ptr(dG), None), "prep")
+    res = {}
+    for arm in ("twin", "separate"):
+        outs = []
+        structs = []
+        for (t, z, gy, s_, bins) in ((ta, za, ga, S[0], None), (tb, zb, gb, S[1], tb["bins"])):
+            dx = torch.full_like(z, float("nan"))
+            part = torch.zeros(lib.alignq_site_bn_part_bytes(F, 1), dtype=torch.uint8, device=dev)
+            structs.append(L.SiteBwdBnArgs(L.ptr(gy), L.ptr(s_), L.ptr(z), L.ptr(t["ab"]), L.ptr(t["save"]), C, HW, 1, None, L.ptr(bins),
+                                           2 if bins is not None else 0, None, L.ptr(t["stats"]), B, F, 2.0, 0.0, L.ptr(dx), L.ptr(part)))
+            outs.append((dx, part))
+        if arm == "twin":
+            L.check(lib.alignq_site_bwd_apply_bn_twin(ctypes.byref(structs[0]), ctypes.byref(structs[1]), None), "bwd twin")
+        else:
+            for q in structs:
+                L.check(lib.alignq_site_bwd_apply_bn(q.g, q.S, q.z, q.ab, q.save, q.C, q.HW, q.nhwc, q.y_relu, q.y_bins, q.y_bin_bytes,
+                                                     q.dresidual, q.stats, q.B, q.F, q.act_range, q.eps, q.dx, q.dx_part, None), "bwd single")
+        torch.cuda.synchronize()
+        res[arm] = [(npy(dx), part.cpu().numpy()) for dx, part in outs]
+    for (dx1, p1), (dx2, p2) in zip(res["twin"], res["separate"]):
+        assert np.isfinite(dx1).all() and np.array_equal(dx1, dx2) and np.array_equal(p1, p2)
+    assert np.abs(res["twin"][0][0]).max() > 0 and np.abs(res["twin"][1][0]).max() > 0
+    # and the same bits behind foreign work (a large GEMM: cold L2, skewed workgroup starts) - two co-resident workgroups of the 512-
+    # workgroup F = 8192 launch differed by one ulp in 8 of 20 such launches (round 6; the launcher now keeps them one per CU)
+    m = torch.randn(4096, 4096, device=dev)
+    for _ in range(12):
+        outs = []
+        for q in structs:
+            dx = torch.full((B, C, H, H), float("nan"), device=dev).contiguous(memory_format=torch.channels_last)
+            part = torch.zeros(lib.alignq_site_bn_part_bytes(F, 1), dtype=torch.uint8, device=dev)
+            q.dx, q.dx_part = L.ptr(dx), L.ptr(part)
+            outs.append((dx, part))
+        torch.cuda.synchronize()
+        torch.mm(m, m)
+        L.check(lib.alignq_site_bwd_apply_bn_twin(ctypes.byref(structs[0]), ctypes.byref(structs[1]), None), "bwd twin")
+        torch.cuda.synchronize()
+        for (dx, part), (dx2, p2) in zip(outs, res["separate"]):
+            assert np.array_equal(npy(dx), dx2) and np.array_equal(part.cpu().numpy(), p2)
