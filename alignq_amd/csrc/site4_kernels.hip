@@ -2329,7 +2329,9 @@ int launch_bwd4_twin(int B, int64_t F, float r, float eps, const float* ga, cons
   alignq_wgr::RedFill fill{};
   const BwdTwin tw{gb, Sb, xb, statsb, dxb, bnb, n_tiles};
   BwdLaunch bl{ga, Sa, xa, statsa, B, F, r, eps, dxa, n_tiles, 0, bna, fill, 2 * n_tiles, va, st, tw};
+#ifndef ALIGNQ_DIAG_CORESIDENT
   if (2 * n_tiles > 256) bl.dyn_lds = kBwd32OnePerCuLds;      // the F = 8192 pair: 512 workgroups, two rounds of 256
+#endif
   launch_bwd4_tile<32, true, true>(bl);
   RET_ON_ERR();
   return 0;

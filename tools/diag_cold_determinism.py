@@ -79,5 +79,5 @@ def audit(B, C, H):
             bad += any(not (x.tobytes() == y.tobytes()) for x, y in zip(v, rf))
         print(f"B={B} C={C} H={H} F={F}: {name}: {bad} of {REPS} repetitions differ", flush=True)
 
-for shape in ((128, 16, 32), (128, 32, 16), (128, 64, 8), (100, 32, 16)):
+for shape in ((128, 16, 32), (128, 32, 16), (128, 64, 8), (100, 32, 16))[slice(1, 2) if os.environ.get("ONLY_F8192") else slice(None)]:
     audit(*shape)
