@@ -590,3 +590,56 @@ def test_twin_site_backward_equals_two_launches_bit_for_bit(dev, B, C, H):
         torch.cuda.synchronize()
         for (dx, part), (dx2, p2) in zip(outs, res["separate"]):
             assert np.array_equal(npy(dx), dx2) and np.array_equal(part.cpu().numpy(), p2)
+
+
+def test_eager_iteration_is_bit_identical_with_foreign_work_in_front_of_every_launch(dev):
+    """The headline configuration's eager iteration with a 4096^3 GEMM launched in front of EVERY call into the library (cold L2,
+    skewed workgroup starts) against the plain eager iteration: the whole state bit for bit (tools/diag_cold_step.py runs the same audit
+    for every configuration, profiles/r06_cold_determinism.txt).  Round 6: the backward twin launch with two workgroups per CU failed
+    exactly this and nothing else did."""
+    from alignq_amd import config, _lib as L
+    from alignq_amd.resnet import resnet20_quant
+    from alignq_amd.train_step import TrainStep
+    old = (config.args.bitW, config.args.abitW, config.args.train_batch_size)
+    config.args.bitW = config.args.abitW = 8
+    config.args.train_batch_size = 128
+    real = L.load()
+    operand = torch.randn(4096, 4096, device=dev)
+    count = [0]
+
+    class Cold:
+        def __getattr__(self, name):
+            fn = getattr(real, name)
+            sig = L.SIGNATURES.get(name)
+            if sig is None or not sig[1] or name.endswith(("_bytes", "_slots", "_supported", "_version", "strerror")):
+                return fn
+
+            def wrapped(*a):
+                count[0] += 1
+                torch.mm(operand, operand)
+                return fn(*a)
+            return wrapped
+    try:
+        g = torch.Generator().manual_seed(13)
+        x = torch.randn(128, 3, 32, 32, generator=g).to(dev)
+        y = torch.randint(0, 10, (128,), generator=g).to(dev)
+
+        def run(cold):
+            torch.manual_seed(7)
+            m = resnet20_quant(8, 8).to(dev).train()
+            s = TrainStep(m, channels_last=True, qconv=True, fuse_bn=True)
+            L._lib = Cold() if cold else real
+            try:
+                for _ in range(2):
+                    s(x, y)
+                torch.cuda.synchronize()
+            finally:
+                L._lib = real
+            return full_state(m, s, s.admms)
+        ref, got = run(False), run(True)
+        assert count[0] > 150                                     # (every launch of two iterations went through the wrapper)
+        bad = differing(ref, got)
+        assert not bad, "cold iteration differs in %d tensors, first: %s" % (len(bad), bad[:6])
+    finally:
+        L._lib = real
+        config.args.bitW, config.args.abitW, config.args.train_batch_size = old
