@@ -14,7 +14,7 @@ SO_PATH = os.environ.get("ALIGNQ_SO") or os.path.join(_HERE, "lib", "libalignq_h
 FORMULA_ADMM, FORMULA_CDF = 0, 1
 MAX_BATCH = 128            # rows the FUSED site kernels hold on chip (ALIGNQ_MAX_BATCH)
 MAX_CORR_BATCH = 1024      # rows alignq_corr_fwd / _bwd take (ALIGNQ_MAX_CORR_BATCH: blocked Gram above 128)
-ABI_VERSION = 22
+ABI_VERSION = 23
 EINVAL, EUNSUPPORTED = -1, -2          # include/alignq.h: ALIGNQ_EINVAL, ALIGNQ_EUNSUPPORTED
 
 _c = ctypes
@@ -115,6 +115,8 @@ SIGNATURES = {
     "alignq_sgd_step": (_i, [_vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _i, _vp]),
     "alignq_sgd_grad_approx": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _f, _f, _vp]),
     "alignq_site_reduce_loss_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp]),
+    "alignq_site_reduce_loss_multi_head": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i,
+                                                _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "alignq_site_prep_fused_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "alignq_conv3x3_bn_parts": (_i, [_i, _i, _i, _i]),
     "alignq_conv3x3_nhwc": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),

@@ -112,6 +112,69 @@ __global__ __launch_bounds__(kThreads) void mt_weight_apply_kernel(WChunk c, con
   }
 }
 
+// Statistics + quantisation in ONE launch for filters of at most kFusedMaxN elements (every CIFAR filter: 432 .. 36864; round 6: the
+// two launches above were 12.6 us of the ResNet-20 step's chain, this one 7-8): a workgroup of 1024 threads owns kFusedPerBlk
+// consecutive elements of its tensor and computes the WHOLE tensor's sums itself - nine 16-byte loads per thread at most, all in
+// flight at once, the same order in every workgroup of the tensor, hence the same mean / std bits in all of them - instead of
+// meeting the other workgroups' partial sums in a second launch.  Needs n % 4 == 0 and 16-byte aligned filters (the launcher checks).
+constexpr int kFusedThreads = 1024, kFusedPerBlk = 2048, kFusedQuads = 9, kFusedMaxN = kFusedQuads * 4 * kFusedThreads;
+template <int FORMULA>
+__global__ __launch_bounds__(kFusedThreads) void mt_weight_fused_kernel(WChunk c, float* __restrict__ ms_out, int t0, int k) {
+  __shared__ double sm[32];
+  __shared__ __attribute__((aligned(16))) float nerf_lds[ALIGNQ_NERF_LDS_FLOATS];
+  const int t = blockIdx.y;
+  const long n = c.n[t];
+  if ((long)blockIdx.x * kFusedPerBlk >= n) return;           // block-uniform: this tensor has fewer workgroups
+  nerf_tab_load(nerf_lds);                  // block_sum2d's barriers publish it
+  const NerfTab tab = nerf_tab(nerf_lds);
+  const float* __restrict__ w = c.w[t];
+  const int n4 = (int)(n >> 2);
+  float4 v4[kFusedQuads];
+#pragma unroll
+  for (int u = 0; u < kFusedQuads; u++) {
+    const int i = threadIdx.x + u * kFusedThreads;
+    v4[u] = reinterpret_cast<const float4*>(w)[i < n4 ? i : n4 - 1];
+  }
+  double s = 0, s2 = 0;
+#pragma unroll
+  for (int u = 0; u < kFusedQuads; u++) {
+    if (threadIdx.x + u * kFusedThreads < n4) {
+      const double d0 = v4[u].x, d1 = v4[u].y, d2 = v4[u].z, d3 = v4[u].w;
+      s += d0; s2 += d0 * d0;
+      s += d1; s2 += d1 * d1;
+      s += d2; s2 += d2 * d2;
+      s += d3; s2 += d3 * d3;
+    }
+  }
+  block_sum2d(s, s2, sm);
+  const double dn = (double)n;
+  const double mean = s / dn;
+  double var = (s2 - s * s / dn) / (dn - 1.0);
+  if (var < 0) var = 0;
+  const float m = (float)mean, sd = (float)sqrt(var);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { ms_out[2 * (t0 + t)] = m; ms_out[2 * (t0 + t) + 1] = sd; }
+  const WeightConsts wc = weight_consts(m, sd, k);
+  float* __restrict__ q = c.q[t];
+  float* __restrict__ cdf = c.cdf[t];
+  float* __restrict__ pdf = c.pdf[t];
+  float v[kFusedPerBlk / kFusedThreads];
+#pragma unroll
+  for (int u = 0; u < kFusedPerBlk / kFusedThreads; u++) {
+    const long i = (long)blockIdx.x * kFusedPerBlk + threadIdx.x + u * kFusedThreads;
+    v[u] = w[MT_CLAMP(i, n)];
+  }
+#pragma unroll
+  for (int u = 0; u < kFusedPerBlk / kFusedThreads; u++) {
+    const long i = (long)blockIdx.x * kFusedPerBlk + threadIdx.x + u * kFusedThreads;
+    if (i < n) {
+      float tt, b;
+      q[i] = weight_quant1<FORMULA>(v[u], wc, k, &tt, &b, tab);
+      if (cdf) cdf[i] = tt;
+      if (pdf) pdf[i] = weight_pdf2(v[u], wc);
+    }
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void mt_weight_bwd_partial_kernel(WChunk c, const float* __restrict__ ms,
                                                                          double* __restrict__ ws, int t0) {
   __shared__ double sm[32];
@@ -342,6 +405,17 @@ int alignq_weight_quant_fwd_multi(int T, const float* const* w, float* const* q,
       c.pdf[i] = pdf_out ? pdf_out[t0 + i] : nullptr;
       c.n[i] = (long)n[t0 + i];
       if (c.n[i] > max_n) max_n = c.n[i];
+    }
+    bool fused = max_n <= kFusedMaxN;
+    for (int i = 0; i < cnt && fused; i++) fused = (c.n[i] & 3) == 0 && (reinterpret_cast<uintptr_t>(c.w[i]) & 15) == 0;
+    if (fused) {            // small filters: statistics and quantisation in one launch (mt_weight_fused_kernel)
+      dim3 fgrid((unsigned)((max_n + kFusedPerBlk - 1) / kFusedPerBlk), cnt);
+      if (formula == ALIGNQ_FORMULA_ADMM)
+        hipLaunchKernelGGL((mt_weight_fused_kernel<0>), fgrid, kFusedThreads, 0, st, c, ms, t0, k);
+      else
+        hipLaunchKernelGGL((mt_weight_fused_kernel<1>), fgrid, kFusedThreads, 0, st, c, ms, t0, k);
+      LAUNCH_CHECK();
+      continue;
     }
     dim3 grid(blocks_for(max_n), cnt);
     hipLaunchKernelGGL(mt_weight_partial_kernel, grid, kThreads, 0, st, c, (double*)ws, t0);

@@ -212,7 +212,7 @@ __device__ __forceinline__ void split_bf16(float v, __bf16& hi, __bf16& lo) {
 template <bool SYM>
 constexpr int kSlabReduceLds = 16 * 64 * (SYM ? 4 : 1) * 4 + 48 * 8 + 16;
 template <bool SYM, bool LOSS>
-__device__ __forceinline__ void slab_reduce_body(const float* __restrict__ slabs, int n_slabs, int slab_floats, int BP, int B,
+__device__ __forceinline__ bool slab_reduce_body(const float* __restrict__ slabs, int n_slabs, int slab_floats, int BP, int B,
                                                  float scale, float* __restrict__ out, const float* __restrict__ A,
                                                  const float* __restrict__ gamma, int dim, float mu, float rho,
                                                  float* __restrict__ parts, unsigned* __restrict__ counter,
@@ -894,7 +894,7 @@ __global__ __launch_bounds__(NTv, 4) void site_fwd4_kernel(const float* __restri
 // LOSS: additionally the ADMM loss scalar (utils/admm.py:24-33) through a last-block epilogue:
 //       scal = {loss, c_con = rho/2/(n*rms), 1/n, rms}.
 template <bool SYM, bool LOSS>
-__device__ __forceinline__ void slab_reduce_body(const float* __restrict__ slabs, int n_slabs,
+__device__ __forceinline__ bool slab_reduce_body(const float* __restrict__ slabs, int n_slabs,
                                                            int slab_floats, int BP, int B, float scale,
                                                            float* __restrict__ out, const float* __restrict__ A,
                                                            const float* __restrict__ gamma, int dim, float mu,
@@ -1024,9 +1024,9 @@ __device__ __forceinline__ void slab_reduce_body(const float* __restrict__ slabs
       }
     }
   }
-  if (!LOSS) return;
+  if (!LOSS) return false;
   __syncthreads();
-  if (!is_last) return;
+  if (!is_last) return false;
   double s0 = 0, s1 = 0, s2 = 0;
   if ((int)threadIdx.x < nblk) {
     s0 = __hip_atomic_load(&parts[threadIdx.x * 4 + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1043,7 +1043,8 @@ __device__ __forceinline__ void slab_reduce_body(const float* __restrict__ slabs
     for (int g = 0; g < 16; g++) { a0 += fin[g]; a1 += fin[16 + g]; a2 += fin[32 + g]; }
     const double n = (double)B * (double)B;
     const double rms = sqrt(a1 / n);
-    scal[0] = (float)(mu * a0 / n + 0.5 * rho * rms + a2 / n);
+    // (the loss itself write-through: slab_reduce_multi_head_kernel's last site reads every site's loss inside the launch)
+    __hip_atomic_store(&scal[0], (float)(mu * a0 / n + 0.5 * rho * rms + a2 / n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     scal[1] = (float)(0.5 * rho / (n * rms));
     scal[2] = (float)(1.0 / n);
     scal[3] = (float)rms;
@@ -1051,6 +1052,7 @@ __device__ __forceinline__ void slab_reduce_body(const float* __restrict__ slabs
     // the partials kernel also zeroes it, which covers the very first use of an uninitialised workspace)
     __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  return true;       // (block-uniform) this workgroup closed the reduction: its thread 0 has written scal
 }
 
 template <bool SYM, bool LOSS>
@@ -1085,6 +1087,55 @@ __global__ __launch_bounds__(1024) void slab_reduce_multi_kernel(RChunk c, int B
   __shared__ __attribute__((aligned(16))) unsigned char lds[kSlabReduceLds<true>];
   slab_reduce_body<true, true>(c.slabs[s], c.n_slabs[s], kSlab4Floats, 128, B, c.scale[s], c.out[s], c.A[s], c.gamma[s], dim, mu,
                                rho, parts, counter, c.scal[s], blockIdx.x, gridDim.x, lds);
+}
+
+// The same launch with the classifier head's forward as a second ROLE (round 6: the head reads the last site's x_q, the reductions
+// read the sites' slabs - neither needs the other, and each alone is a 9-10 us node of the step's chain).  Workgroups [0, cnt *
+// kSlabRedBlocks): slab_reduce_body of site blk / kSlabRedBlocks, same partition as slab_reduce_multi_kernel (same bits); the rest:
+// head_fwd_body, one workgroup per sample, first four waves.  The sum of ALL sites' losses (trans_total; the head's last workgroup
+// formed it when the reductions were a launch of their own) is formed by the workgroup that closes the LAST of this launch's sites:
+// second-level ticket over the cnt sites, hand-off as in slab_reduce_body (write-through loss, drain, relaxed agent-scope ticket,
+// agent-scope loads by the last arriver); the sites reduced by earlier launches are visible by launch order.
+struct HeadFwd {
+  const float* feat; const float* W; const float* bias; const int64_t* target; int HW, C, K, B;
+  float* pooled; float* logits; float* probs; float* loss; float* ce_mean; unsigned* counter;
+};
+struct TransTail {
+  const float* scal_all; int n_sites; float* trans_total; unsigned* counter;
+};
+__global__ __launch_bounds__(1024) void slab_reduce_multi_head_kernel(RChunk c, int B, int dim, float mu, float rho, int cnt, HeadFwd h,
+                                                                      TransTail tt) {
+  const int nred = cnt * kSlabRedBlocks;
+  if ((int)blockIdx.x >= nred) {          // block-uniform: the head role
+    if (threadIdx.x >= 256) return;
+    alignq_head::head_fwd_body(h.feat, h.W, h.bias, h.target, h.HW, h.C, h.K, h.pooled, h.logits, h.probs, h.loss, h.ce_mean, h.counter,
+                               nullptr, 0, nullptr, (int)blockIdx.x - nred, h.B);
+    return;
+  }
+  const int s = blockIdx.x / kSlabRedBlocks, blk = blockIdx.x - s * kSlabRedBlocks;
+  float* ws = const_cast<float*>(c.slabs[s]);
+  float* parts = ws + (size_t)c.n_slabs[s] * kSlab4Floats;
+  unsigned* counter = reinterpret_cast<unsigned*>(parts + kPartFloats);
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kSlabReduceLds<true>];
+  __shared__ int all_sites;
+  const bool closed = slab_reduce_body<true, true>(c.slabs[s], c.n_slabs[s], kSlab4Floats, 128, B, c.scale[s], c.out[s], c.A[s], c.gamma[s],
+                                                   dim, mu, rho, parts, counter, c.scal[s], blk, kSlabRedBlocks, lds);
+  if (!closed) return;
+  if (threadIdx.x == 0) {                 // (the thread that stored this site's loss)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned tk = __hip_atomic_fetch_add(tt.counter, 1u, ALIGNQ_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT);
+    all_sites = (tk == (unsigned)cnt - 1);
+  }
+  __syncthreads();
+  if (!all_sites || threadIdx.x >= 64) return;
+  double t = 0.0;
+  for (int i = threadIdx.x; i < tt.n_sites; i += 64)       // scal = {loss, c_con, 1/n, rms} per site
+    t += (double)__hip_atomic_load(&tt.scal_all[4 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  t = alignq::wave_sum_d_dpp(t);
+  if (threadIdx.x == 0) {
+    tt.trans_total[0] = (float)t;
+    __hip_atomic_store(tt.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-arm
+  }
 }
 
 // The B <= 64 geometries (full [BP][BP] slabs) for several batch slices of one site in ONE launch (blockIdx.y = group; the
@@ -2182,6 +2233,29 @@ int launch_reduce_loss_multi(int S, void* const* ws, float* const* D, const floa
     hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3((kSlab4Floats + 255) / 256, cnt), 1024, 0, st, c, B, dim, mu, rho);
     RET_ON_ERR();
   }
+  return 0;
+}
+
+int launch_reduce_loss_multi_head(int S, void* const* ws, float* const* D, const float* const* alterD, const float* const* gamma,
+                                  float* const* scal, const int64_t* F, int B, int dim, float mu, float rho, const float* feat,
+                                  const float* W, const float* bias, const int64_t* target, int HB, int HW, int C, int K, float* pooled,
+                                  float* logits, float* probs, float* loss, float* ce_mean, unsigned* head_counter,
+                                  const float* scal_all, int n_sites, float* trans_total, unsigned* site_counter, hipStream_t st) {
+  // all but the last chunk of sites as plain launches; the last chunk takes the head along
+  const int s_last = ((S - 1) / kMultiSites) * kMultiSites;
+  if (s_last > 0)
+    if (int rc = launch_reduce_loss_multi(s_last, ws, D, alterD, gamma, scal, F, B, dim, mu, rho, st)) return rc;
+  const int cnt = S - s_last;
+  RChunk c;
+  for (int i = 0; i < cnt; i++) {
+    const Geom g = geom(B, F[s_last + i]);
+    c.slabs[i] = (const float*)ws[s_last + i]; c.out[i] = D[s_last + i]; c.A[i] = alterD[s_last + i]; c.gamma[i] = gamma[s_last + i];
+    c.scal[i] = scal[s_last + i]; c.scale[i] = 1.0f / (float)F[s_last + i]; c.n_slabs[i] = g.grid;
+  }
+  const HeadFwd h{feat, W, bias, target, HW, C, K, HB, pooled, logits, probs, loss, ce_mean, head_counter};
+  const TransTail tt{scal_all, n_sites, trans_total, site_counter};
+  hipLaunchKernelGGL(slab_reduce_multi_head_kernel, cnt * kSlabRedBlocks + HB, 1024, 0, st, c, B, dim, mu, rho, cnt, h, tt);
+  RET_ON_ERR();
   return 0;
 }
 

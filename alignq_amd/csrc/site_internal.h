@@ -175,6 +175,12 @@ int launch_prep_groups(const float* D, const float* alterD, const float* gamma, 
 int launch_reduce_loss_multi(int S, void* const* ws, float* const* D, const float* const* alterD,
                              const float* const* gamma, float* const* scal, const int64_t* F, int B, int dim, float mu,
                              float rho, hipStream_t st);
+// the same with the classifier head's forward as a second role of the (last) launch: see slab_reduce_multi_head_kernel
+int launch_reduce_loss_multi_head(int S, void* const* ws, float* const* D, const float* const* alterD, const float* const* gamma,
+                                  float* const* scal, const int64_t* F, int B, int dim, float mu, float rho, const float* feat,
+                                  const float* W, const float* bias, const int64_t* target, int HB, int HW, int C, int K, float* pooled,
+                                  float* logits, float* probs, float* loss, float* ce_mean, unsigned* head_counter,
+                                  const float* scal_all, int n_sites, float* trans_total, unsigned* site_counter, hipStream_t st);
 int launch_prep_multi(int S, const float* const* D, const float* const* alterD, const float* const* gamma,
                       const float* const* scal, const float* gscale, const int64_t* F, int B, int dim, float mu,
                       float* const* Sout, float* const* dA, float* const* dG, hipStream_t st);

@@ -752,6 +752,24 @@ int alignq_site_reduce_loss_multi(int S, void* const* ws, float* const* D, const
   return launch_reduce_loss_multi(S, ws, D, alterD, gamma, scal, F, B, dim, mu, rho, (hipStream_t)stream);
 }
 
+int alignq_site_reduce_loss_multi_head(int S, void* const* ws, float* const* D, const float* const* alterD,
+                                       const float* const* gamma, float* const* scal, const int64_t* F, int B, int dim, float mu,
+                                       float rho, const float* feat, const float* W, const float* bias, const int64_t* target, int HB,
+                                       int HW, int C, int K, float* pooled, float* logits, float* probs, float* loss, float* ce_mean,
+                                       unsigned* head_counter, const float* scal_all, int n_sites, float* trans_total,
+                                       unsigned* site_counter, void* stream) {
+  if (S <= 0 || !ws || !D || !alterD || !gamma || !scal || !F || dim < B) return ALIGNQ_EINVAL;
+  if (B <= 64 || B > ALIGNQ_MAX_BATCH) return ALIGNQ_EUNSUPPORTED;
+  for (int i = 0; i < S; i++)
+    if (!ws[i] || !D[i] || !alterD[i] || !gamma[i] || !scal[i] || F[i] <= 0) return ALIGNQ_EINVAL;
+  if (!feat || !W || !target || !pooled || !logits || !probs || !loss || !ce_mean || !head_counter || HB < 1 || HW < 1) return ALIGNQ_EINVAL;
+  if (!scal_all || n_sites < S || !trans_total || !site_counter) return ALIGNQ_EINVAL;
+  if (C < 1 || C > 256 || K < 1 || K > 64) return ALIGNQ_EUNSUPPORTED;      // (alignq_head::kMaxC / kMaxK, as alignq_head_ce_fwd)
+  return launch_reduce_loss_multi_head(S, ws, D, alterD, gamma, scal, F, B, dim, mu, rho, feat, W, bias, target, HB, HW, C, K, pooled,
+                                       logits, probs, loss, ce_mean, head_counter, scal_all, n_sites, trans_total, site_counter,
+                                       (hipStream_t)stream);
+}
+
 int alignq_site_prep_fused_multi(int S, const float* const* D, const float* const* alterD, const float* const* gamma,
                                  const float* const* scal, const float* dD_scale, const int64_t* F, int B, int dim,
                                  float mu, float* const* S_out, float* const* dalterD, float* const* dgamma,

@@ -212,14 +212,20 @@ class DeferredLosses:
             r.reduced = True
         return out
 
+    def open_groups(self):
+        """The batched sites whose slab reduction no forward launch has taken along yet, by (B, dim, mu, rho)."""
+        out = {}
+        for key, recs in self.groups().items():
+            recs = [r for r in recs if not r.reduced]
+            if recs:
+                out[key] = recs
+        return out
+
     def reduce_all(self):
         """Slab reduction + ADMM loss of every batched site still open (one launch per (B, dim, mu, rho) group)."""
         lib = L.load()
         st = L.stream_ptr()
-        for (B, dim, mu, rho), recs in self.groups().items():
-            recs = [r for r in recs if not r.reduced]
-            if not recs:
-                continue
+        for (B, dim, mu, rho), recs in self.open_groups().items():
             L.check(lib.alignq_site_reduce_loss_multi(
                 len(recs), L.ptr_array([r.ws for r in recs]), L.ptr_array([r.D for r in recs]),
                 L.ptr_array([r.A for r in recs]), L.ptr_array([r.Gm for r in recs]),
@@ -1339,20 +1345,23 @@ def _head_counter(device, owner=None):
         key = (device.type, device.index, int(torch.cuda.current_stream(device).cuda_stream))
     c = d.get(key)
     if c is None:
-        c = d[key] = torch.zeros(1, dtype=torch.int32, device=device)
+        # word 0: the head's workgroups; word 1: the sites closed inside alignq_site_reduce_loss_multi_head's launch
+        c = d[key] = torch.zeros(2, dtype=torch.int32, device=device)
     return c
+
+
+_HEAD_ROLE = True        # (tests switch it off to compare with the two launches it replaces)
 
 
 class StepLossFn(torch.autograd.Function):
     """The two loss roots of a whole-model training step from ONE autograd node: (logits, ce, trans_total) with
     ce = cross_entropy(logit(avgpool(feat)), target) and trans_total = sum of the batched sites' transition losses.
-    Forward: alignq_site_reduce_loss_multi (as LossSumFn) + alignq_head_ce_fwd, whose last workgroup also forms the batch mean
-    and the sum over sites (no reduction launches).  Backward: alignq_head_ce_bwd_site_prep, the head's backward and every
+    Forward: alignq_site_reduce_loss_multi_head - the sites' closing slab reductions (as LossSumFn) and the head as two roles of ONE
+    launch (round 6), the batch mean and the sum over sites formed by last-arriving workgroups (no reduction launches).  Backward: alignq_head_ce_bwd_site_prep, the head's backward and every
     site's S / dalterD / dgamma in one launch.  Four launches where HeadCEFn + LossSumFn take seven."""
 
     @staticmethod
     def forward(ctx, collector, scal_all, feat, weight, bias, target, *losses):
-        collector.reduce_all()
         feat = L.dense_f32(feat, "features")
         if feat.dim() != 4 or feat.is_contiguous():
             raise RuntimeError("StepLossFn needs channels-last 4-D features")
@@ -1364,10 +1373,22 @@ class StepLossFn(torch.autograd.Function):
         pooled, logits, probs = torch.empty(B, C, **f32), torch.empty(B, K, **f32), torch.empty(B, K, **f32)
         loss, ce, trans = torch.empty(B, **f32), torch.empty((), **f32), torch.empty((), **f32)
         w = L.dev_f32(weight, "head weight")
-        L.check(lib.alignq_head_ce_fwd(L.ptr(feat), L.ptr(w), L.ptr(bias), L.ptr(target), B, H * W, C, K, L.ptr(pooled),
-                                       L.ptr(logits), L.ptr(probs), L.ptr(loss), L.ptr(ce),
-                                       L.ptr(_head_counter(dev, collector)),
-                                       L.ptr(scal_all), len(losses), L.ptr(trans), L.stream_ptr()), "alignq_head_ce_fwd")
+        counters = _head_counter(dev, collector)
+        open_groups = [(key, recs) for key, recs in collector.open_groups().items()]
+        if len(open_groups) == 1 and _HEAD_ROLE:
+            # the sites still open and the head in ONE launch (round 6): neither role reads what the other writes
+            (sB, dim, mu, rho), recs = open_groups[0]
+            L.check(lib.alignq_site_reduce_loss_multi_head(
+                len(recs), L.ptr_array([r.ws for r in recs]), L.ptr_array([r.D for r in recs]), L.ptr_array([r.A for r in recs]),
+                L.ptr_array([r.Gm for r in recs]), L.ptr_array([r.scal for r in recs]), L.i64_array([r.F for r in recs]), sB, dim, mu,
+                rho, L.ptr(feat), L.ptr(w), L.ptr(bias), L.ptr(target), B, H * W, C, K, L.ptr(pooled), L.ptr(logits), L.ptr(probs),
+                L.ptr(loss), L.ptr(ce), L.ptr(counters), L.ptr(scal_all), len(losses), L.ptr(trans), L.ptr(counters[1:]),
+                L.stream_ptr()), "alignq_site_reduce_loss_multi_head")
+        else:
+            collector.reduce_all()
+            L.check(lib.alignq_head_ce_fwd(L.ptr(feat), L.ptr(w), L.ptr(bias), L.ptr(target), B, H * W, C, K, L.ptr(pooled),
+                                           L.ptr(logits), L.ptr(probs), L.ptr(loss), L.ptr(ce), L.ptr(counters),
+                                           L.ptr(scal_all), len(losses), L.ptr(trans), L.stream_ptr()), "alignq_head_ce_fwd")
         ctx.save_for_backward(feat, w, target, pooled, probs)
         ctx.has_bias = bias is not None
         ctx.recs = list(collector.records)

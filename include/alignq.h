@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ALIGNQ_ABI_VERSION 22
+#define ALIGNQ_ABI_VERSION 23
 
 #define ALIGNQ_FORMULA_ADMM 0
 #define ALIGNQ_FORMULA_CDF 1
@@ -250,6 +250,18 @@ int alignq_site_prep_fused_multi(int S, const float* const* D, const float* cons
                                  const float* const* scal, const float* dD_scale, const int64_t* F, int B, int dim,
                                  float mu, float* const* S_out, float* const* dalterD, float* const* dgamma,
                                  void* stream);
+/* alignq_site_reduce_loss_multi (the S sites still open at the end of the forward) and alignq_head_ce_fwd (head batch HB, with
+ * ce_mean) as two roles of ONE launch (round 6, ABI 23): the head reads the last site's x_q, the reductions the sites' slabs -
+ * neither needs the other (main.py:300-312: `outputs, trans_loss = net(inputs)`; `loss = criterion(outputs, targets)`).  Same
+ * code and workgroup partition per role: same bits as the two calls.  *trans_total = sum_i scal_all[4 i] over ALL n_sites sites
+ * of the step (scal_all: the consecutive `scal` rows, these S sites' among them), formed by the workgroup that closes the last of
+ * the S reductions (`site_counter`: one zero-initialised unsigned the kernel re-arms, like `head_counter`).                  */
+int alignq_site_reduce_loss_multi_head(int S, void* const* ws, float* const* D, const float* const* alterD,
+                                       const float* const* gamma, float* const* scal, const int64_t* F, int B, int dim, float mu,
+                                       float rho, const float* feat, const float* W, const float* bias, const int64_t* target, int HB,
+                                       int HW, int C, int K, float* pooled, float* logits, float* probs, float* loss, float* ce_mean,
+                                       unsigned* head_counter, const float* scal_all, int n_sites, float* trans_total,
+                                       unsigned* site_counter, void* stream);
 
 /* ---- Conv2d_Q's convolution on the matrix cores (model/quantization.py:149-154: F.conv2d(input, weight_q, bias, stride,
  * padding, dilation, groups)) for the ResNet-20/56 body: 3x3, stride 1, padding 1, groups 1, no bias, C_in == C_out == C,

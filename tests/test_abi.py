@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.alignq_abi_version() == _lib.ABI_VERSION == 22
+    assert lib.alignq_abi_version() == _lib.ABI_VERSION == 23
     assert b"invalid" in lib.alignq_strerror(-1)
     # pure host-side queries are safe without a GPU
     tail = 1024 + 16                                     # loss partials + arrival counter

@@ -643,3 +643,67 @@ def test_eager_iteration_is_bit_identical_with_foreign_work_in_front_of_every_la
     finally:
         L._lib = real
         config.args.bitW, config.args.abitW, config.args.train_batch_size = old
+
+
+@pytest.mark.parametrize("depth,bits", [(20, 8), (56, 4)])
+def test_head_as_a_role_of_the_closing_reduction_launch_equals_the_two_launches(dev, depth, bits):
+    """alignq_site_reduce_loss_multi_head (the sites still open at the end of the forward + the classifier head's forward in ONE launch;
+    main.py:300-312) against alignq_site_reduce_loss_multi + alignq_head_ce_fwd: two eager iterations from the same state, everything
+    the iterations leave behind and both loss values bit for bit (ResNet-56: 55 sites, more than one argument chunk)."""
+    from alignq_amd import config, fused
+    from alignq_amd.resnet import resnet20_quant, resnet56_quant
+    from alignq_amd.train_step import TrainStep
+    old = (config.args.bitW, config.args.abitW, config.args.train_batch_size)
+    config.args.bitW = config.args.abitW = bits
+    config.args.train_batch_size = 128
+    try:
+        g = torch.Generator().manual_seed(13)
+        x = torch.randn(128, 3, 32, 32, generator=g).to(dev)
+        y = torch.randint(0, 10, (128,), generator=g).to(dev)
+
+        def run(role):
+            torch.manual_seed(7)
+            m = (resnet20_quant if depth == 20 else resnet56_quant)(bits, bits).to(dev).train()
+            s = TrainStep(m, channels_last=True, qconv=True, fuse_bn=True)
+            fused._HEAD_ROLE = role
+            try:
+                for _ in range(2):
+                    o = s(x, y)
+                torch.cuda.synchronize()
+            finally:
+                fused._HEAD_ROLE = True
+            return full_state(m, s, s.admms), [npy(t) for t in o if torch.is_tensor(t)]
+        (sa, oa), (sb, ob) = run(True), run(False)
+        assert not differing(sa, sb)
+        assert len(oa) == len(ob) >= 2 and all(same_bits(a, b) and np.isfinite(a).all() for a, b in zip(oa, ob))
+    finally:
+        config.args.bitW, config.args.abitW, config.args.train_batch_size = old
+
+
+@pytest.mark.parametrize("shapes", [[(64, 64, 3, 3)], [(65, 64, 3, 3)], [(16, 3, 3, 3), (64, 64, 3, 3), (32, 16, 1, 1)], [(16, 3, 3, 3), (10, 9, 1, 1)]],
+                         ids=["one_launch_max", "two_launches_above_max", "one_launch_mixed", "two_launches_odd_count"])
+def test_weight_quantiser_for_small_filters_in_one_launch_equals_the_per_tensor_path(dev, shapes):
+    """alignq_weight_quant_fwd_multi quantises filters of at most 36864 elements (n % 4 == 0) with statistics and quantisation in ONE
+    launch (mt_weight_fused_kernel, round 6) and keeps its two launches otherwise: both against the per-tensor entry point
+    (model/quantization.py weight_quantize_fn.forward: mean / std of the tensor, CDF transform, uniform bins) - W_q and the CDF
+    image bit for bit, the saved density to rounding - on either side of the limits."""
+    from alignq_amd import ops
+    from alignq_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(sum(s[0] for s in shapes))
+    ws = [(torch.randn(*s, generator=g) * 0.1 + 0.01).to(dev) for s in shapes]
+    T = len(ws)
+    q = [torch.empty_like(w) for w in ws]
+    cdf = [torch.empty_like(w) for w in ws]
+    pdf = [torch.empty_like(w) for w in ws]
+    ms = torch.empty(T, 2, device=dev)
+    scratch = torch.empty(lib.alignq_weight_multi_ws_bytes(T), dtype=torch.uint8, device=dev)
+    L.check(lib.alignq_weight_quant_fwd_multi(T, L.ptr_array(ws), L.ptr_array(q), L.ptr_array(cdf), L.ptr_array(pdf),
+                                              L.i64_array([w.numel() for w in ws]), L.ptr(ms), 4, L.FORMULA_ADMM, L.ptr(scratch), None),
+            "alignq_weight_quant_fwd_multi")
+    torch.cuda.synchronize()
+    for i, w in enumerate(ws):
+        q2, c2, p2 = ops.WeightQuantFn.apply(w, 4, 0)
+        assert np.array_equal(npy(q[i]), npy(q2)) and np.array_equal(npy(cdf[i]), npy(c2))
+        np.testing.assert_allclose(npy(pdf[i]), npy(p2), rtol=1e-6)
+        np.testing.assert_allclose(npy(ms[i]), [float(w.double().mean()), float(w.double().std())], rtol=1e-6)
