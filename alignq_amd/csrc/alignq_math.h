@@ -327,13 +327,19 @@ __device__ __forceinline__ void act_transform_fast(float x, float r, float* t, f
 // kernels are as much LDS- as VALU-bound: the 24 B per element of nerf32's table reads cost more than the extra arithmetic).
 __device__ __forceinline__ void act_transform_rcp(float x, float r, float rjac, float* t, float* jac) {
   const float a = fabsf(x) * 0.70710678118654752440f;
-  const float tt = __builtin_amdgcn_rcpf(__fmaf_rn(0.3275911f, a, 1.0f));
+  float tt = __builtin_amdgcn_rcpf(__fmaf_rn(0.3275911f, a, 1.0f));
+#ifdef ALIGNQ_DIAG_TRANS_NOP      /* diagnostic build: N wait states behind the transcendental (NOTES.md round 6) */
+  asm volatile("s_nop %1" : "+v"(tt) : "n"(ALIGNQ_DIAG_TRANS_NOP));
+#endif
   float p = 1.061405429f;
   p = __fmaf_rn(p, tt, -1.453152027f);
   p = __fmaf_rn(p, tt, 1.421413741f);
   p = __fmaf_rn(p, tt, -0.284496736f);
   p = __fmaf_rn(p, tt, 0.254829592f);
-  const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);     // exp(-x^2/2) = 2^(-x^2 * log2(e)/2)
+  float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);     // exp(-x^2/2) = 2^(-x^2 * log2(e)/2)
+#ifdef ALIGNQ_DIAG_TRANS_NOP      /* diagnostic build: N wait states behind the transcendental (NOTES.md round 6) */
+  asm volatile("s_nop %1" : "+v"(e) : "n"(ALIGNQ_DIAG_TRANS_NOP));
+#endif
   *t = r * copysignf(__fmaf_rn(-p * tt, e, 1.0f), x);
   *jac = rjac * e;
 }
