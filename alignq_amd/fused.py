@@ -1357,8 +1357,9 @@ class StepLossFn(torch.autograd.Function):
     """The two loss roots of a whole-model training step from ONE autograd node: (logits, ce, trans_total) with
     ce = cross_entropy(logit(avgpool(feat)), target) and trans_total = sum of the batched sites' transition losses.
     Forward: alignq_site_reduce_loss_multi_head - the sites' closing slab reductions (as LossSumFn) and the head as two roles of ONE
-    launch (round 6), the batch mean and the sum over sites formed by last-arriving workgroups (no reduction launches).  Backward: alignq_head_ce_bwd_site_prep, the head's backward and every
-    site's S / dalterD / dgamma in one launch.  Four launches where HeadCEFn + LossSumFn take seven."""
+    launch (round 6), the batch mean and the sum over sites formed by last-arriving workgroups (no reduction launches).
+    Backward: alignq_head_ce_bwd_site_prep, the head's backward and every site's S / dalterD / dgamma in one launch.  Two
+    launches where HeadCEFn + LossSumFn take seven."""
 
     @staticmethod
     def forward(ctx, collector, scal_all, feat, weight, bias, target, *losses):
