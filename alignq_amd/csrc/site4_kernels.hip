@@ -59,6 +59,22 @@ __device__ unsigned long long g_blk[2][2][2048];
 #define STAMP(i) do { } while (0)
 #define BSTAMP(kern, which) do { } while (0)
 #endif
+#ifdef ALIGNQ_DIAG_DUMP
+#define ALIGNQ_DIAG_DUMP_BITS (ALIGNQ_DIAG_DUMP)
+// diagnostic build (round 6, tools/diag_twin_dump.py): intermediates of the 32-feature backward twin launch, by stage
+__device__ float* g_dump = nullptr;       // [4 stages][2 sites][256 tiles][128 rows][32 columns][2]
+#define DUMP2(stage, site, tile, row, col, v0, v1)                                                                        \
+  do {                                                                                                                    \
+    if (((((ALIGNQ_DIAG_DUMP) >> (stage)) & 1) || ((stage) == 0 && ((ALIGNQ_DIAG_DUMP) & 16)) || ((stage) == 2 && ((ALIGNQ_DIAG_DUMP) & 32))) && g_dump) { \
+      float* p__ = g_dump + ((((((size_t)(stage) * 2 + (site)) * 256 + (tile)) * 128 + (row)) * 32 + (col)) * 2);         \
+      p__[0] = (v0); p__[1] = (v1);                                                                                       \
+    }                                                                                                                     \
+  } while (0)
+#else
+#define ALIGNQ_DIAG_DUMP_BITS 0
+#define DUMP2(stage, site, tile, row, col, v0, v1) do { } while (0)
+#endif
+
 
 // Addressing of the forward kernel: kernel-argument base (SGPR pair) + ONE unsigned 32-bit element offset per (row, column
 // quad), shared by x / residual / x_q (global_load / global_store saddr + voffset form: no 64-bit address arithmetic in
@@ -1375,8 +1391,10 @@ __global__ __launch_bounds__(TFv * 8, 2) void site_bwd4_kernel(const float* __re
   BSTAMP(1, 0);
   (void)aligned;
   int bid = blockIdx.x;
+  [[maybe_unused]] int dsite = 0;
   if constexpr (!LOOP && TFv == 32) {
     if (twin.split && bid >= twin.split) {        // block-uniform: the second site of a twin launch
+      dsite = 1;
       bid -= twin.split;
       gup = twin.gup; S = twin.S; x = twin.x; stats = twin.stats; dx = twin.dx; bn = twin.bn;
     }
@@ -1631,6 +1649,10 @@ __global__ __launch_bounds__(TFv * 8, 2) void site_bwd4_kernel(const float* __re
             split_bf16(ok ? (t - f4get(mt4, e)) * f4get(rt4, e) : 0.0f, TH, TL);                   \
             jt[PAIR ? 4 * q + e : 0] = jac;                                                        \
             gj[(PAIR ? 4 * q + e : 0)] = f4get(gr[q], e) * jac;                                    \
+            if constexpr (TFv == 32 && !LOOP && ((ALIGNQ_DIAG_DUMP_BITS) & 1)) DUMP2(0, dsite, tile, row, 4 * lc4 + e, t, jac); \
+            if constexpr (TFv == 32 && !LOOP && ((ALIGNQ_DIAG_DUMP_BITS) & 32)) {                  \
+              if (q == 2 && e == 1) DUMP2(2, dsite, tile, 64 + row / 2, 4 * lc4 + e, t, (t - f4get(mt4, e)) * f4get(rt4, e)); \
+            }                                                                                      \
           } else {                                                                                 \
             TH = (__bf16)0.0f; TL = (__bf16)0.0f;                                                  \
           }                                                                                        \
@@ -1781,6 +1803,10 @@ __global__ __launch_bounds__(TFv * 8, 2) void site_bwd4_kernel(const float* __re
       if constexpr (LOOP && PAIR) { if (ks & 1) __builtin_amdgcn_sched_barrier(0); }
     }
     STAMP(12);
+    if constexpr (TFv == 32 && !LOOP) {
+#pragma unroll
+      for (int e = 0; e < 16; e++) DUMP2(1, dsite, tile, I * 32 + 4 * h + (e & 3) + 8 * (e >> 2), cc, accX[e], PAIR ? accT[e] : 0.f);
+    }
     // folded batch-norm backward needs zhat of the elements this thread copies out below (the ones it loaded above):
     // re-issue those 16 loads now (L2 hits), while no other large register array is live, so that their latency
     // overlaps the projection / assemble phases
@@ -1833,6 +1859,17 @@ __global__ __launch_bounds__(TFv * 8, 2) void site_bwd4_kernel(const float* __re
           const uint2 d2 = *reinterpret_cast<const uint2*>(TTlo + o);
           tv[PAIR ? 2 * g4 : 0] = bf16_pair(c2.x) + bf16_pair(d2.x);
           tv[PAIR ? 2 * g4 + 1 : 0] = bf16_pair(c2.y) + bf16_pair(d2.y);
+#ifdef ALIGNQ_DIAG_DUMP
+          if constexpr (TFv == 32 && !LOOP && PAIR) {           // stage 4 (stored in slot 0): the standardised operands as the MFMAs read them
+            if ((ALIGNQ_DIAG_DUMP) & 16) {
+              const int r0 = I * 32 + 8 * g4 + 4 * h;
+              DUMP2(0, dsite, tile, r0 + 0, cc, xv[2 * g4].x, tv[2 * g4].x);
+              DUMP2(0, dsite, tile, r0 + 1, cc, xv[2 * g4].y, tv[2 * g4].y);
+              DUMP2(0, dsite, tile, r0 + 2, cc, xv[2 * g4 + 1].x, tv[2 * g4 + 1].x);
+              DUMP2(0, dsite, tile, r0 + 3, cc, xv[2 * g4 + 1].y, tv[2 * g4 + 1].y);
+            }
+          }
+#endif
 #pragma unroll
           for (int q = 0; q < 2; q++) {
             const f32x2 av = {accT[4 * g4 + 2 * q], accT[4 * g4 + 2 * q + 1]};
@@ -1876,6 +1913,9 @@ __global__ __launch_bounds__(TFv * 8, 2) void site_bwd4_kernel(const float* __re
       }
       const float mean_x = sx0 * invB, proj_x = sx1 * invBm1 * kap_x;
       const float mean_t = st0 * invB, proj_t = st1 * invBm1 * kap_t;
+      if constexpr (TFv == 32 && !LOOP) {
+        if (h == 0) { DUMP2(2, dsite, tile, 2 * I, cc, sx0, sx1); DUMP2(2, dsite, tile, 2 * I + 1, cc, st0, st1); }
+      }
       const f32x2 mx2 = {mean_x, mean_x}, px2 = {proj_x, proj_x}, rx2 = {rho_x, rho_x};
       const f32x2 mt2 = {mean_t, mean_t}, pt2 = {proj_t, proj_t}, rt2 = {rho_t, rho_t};
 #pragma unroll
@@ -1894,6 +1934,7 @@ __global__ __launch_bounds__(TFv * 8, 2) void site_bwd4_kernel(const float* __re
           }
           LDS_F32(a) = o2.x;
           LDS_F32(a + kRow) = o2.y;
+          if constexpr (TFv == 32 && !LOOP) DUMP2(3, dsite, tile, I * 32 + 4 * h + 8 * g4 + 2 * q, cc, o2.x, o2.y);
         }
       }
     }
@@ -2405,12 +2446,19 @@ int launch_bwd4_twin(int B, int64_t F, float r, float eps, const float* ga, cons
   BwdLaunch bl{ga, Sa, xa, statsa, B, F, r, eps, dxa, n_tiles, 0, bna, fill, 2 * n_tiles, va, st, tw};
 #ifndef ALIGNQ_DIAG_CORESIDENT
   if (2 * n_tiles > 256) bl.dyn_lds = kBwd32OnePerCuLds;      // the F = 8192 pair: 512 workgroups, two rounds of 256
+#else
+  if (2 * n_tiles > 256 && getenv("ALIGNQ_DIAG_ONE_PER_CU")) bl.dyn_lds = kBwd32OnePerCuLds;
 #endif
   launch_bwd4_tile<32, true, true>(bl);
   RET_ON_ERR();
   return 0;
 }
 
+#ifdef ALIGNQ_DIAG_DUMP
+extern "C" int alignq_debug_set_dump(float* device_buffer) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dump), &device_buffer, sizeof(float*));
+}
+#endif
 #ifdef ALIGNQ_STAMPS
 extern "C" int alignq_debug_read_stamps(unsigned long long* host_out) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64);
