@@ -2138,6 +2138,9 @@ inline int launch_fwd4_tf(const FwdLaunch& a) {
 // of this file without SLP vectorisation; cause not established).  The twin launch's step time is the same within the spread
 // (1.017 / 1.018 ms per step), so nothing is given up.
 constexpr int kBwd32OnePerCuLds = 16384;
+#ifdef ALIGNQ_DIAG_CORESIDENT
+static int g_diag_one_per_cu = 0;
+#endif
 struct BwdLaunch {
   const float* gup; const float* S; const float* x; const float* stats; int B; int64_t F; float r, eps; float* dx;
   int n_tiles, aligned; BnFold bn; alignq_wgr::RedFill fill; int grid; bool vec; hipStream_t st; BwdTwin twin; int dyn_lds = 0;
@@ -2447,13 +2450,16 @@ int launch_bwd4_twin(int B, int64_t F, float r, float eps, const float* ga, cons
 #ifndef ALIGNQ_DIAG_CORESIDENT
   if (2 * n_tiles > 256) bl.dyn_lds = kBwd32OnePerCuLds;      // the F = 8192 pair: 512 workgroups, two rounds of 256
 #else
-  if (2 * n_tiles > 256 && getenv("ALIGNQ_DIAG_ONE_PER_CU")) bl.dyn_lds = kBwd32OnePerCuLds;
+  if (2 * n_tiles > 256 && g_diag_one_per_cu) bl.dyn_lds = kBwd32OnePerCuLds;      // (diagnostic build: alignq_debug_one_per_cu)
 #endif
   launch_bwd4_tile<32, true, true>(bl);
   RET_ON_ERR();
   return 0;
 }
 
+#ifdef ALIGNQ_DIAG_CORESIDENT
+extern "C" void alignq_debug_one_per_cu(int on) { g_diag_one_per_cu = on; }
+#endif
 #ifdef ALIGNQ_DIAG_DUMP
 extern "C" int alignq_debug_set_dump(float* device_buffer) {
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dump), &device_buffer, sizeof(float*));

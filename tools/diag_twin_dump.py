@@ -7,6 +7,7 @@ spec = importlib.util.spec_from_file_location("r6", "tests/test_gpu_round6.py");
 from alignq_amd import _lib as L
 lib = L.load(); dev = torch.device('cuda:0')
 lib.alignq_debug_set_dump.argtypes = [ctypes.c_void_p]; lib.alignq_debug_set_dump.restype = ctypes.c_int
+lib.alignq_debug_one_per_cu.argtypes = [ctypes.c_int]; lib.alignq_debug_one_per_cu.restype = None
 B, C, H = 128, 32, 16
 k, HW, F = 8, H * H, C * H * H
 g = torch.Generator().manual_seed(B + C + H)
@@ -31,10 +32,7 @@ assert lib.alignq_debug_set_dump(dump.data_ptr()) == 0
 
 
 def launch(one_per_cu):
-    if one_per_cu:
-        os.environ["ALIGNQ_DIAG_ONE_PER_CU"] = "1"
-    else:
-        os.environ.pop("ALIGNQ_DIAG_ONE_PER_CU", None)
+    lib.alignq_debug_one_per_cu(int(one_per_cu))
     outs, structs = [], []
     for i, t in enumerate((ta, tb)):
         dx = torch.full_like(z[i], float("nan")); part = torch.zeros(lib.alignq_site_bn_part_bytes(F, 1), dtype=torch.uint8, device=dev)
