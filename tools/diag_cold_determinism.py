@@ -70,7 +70,32 @@ def audit(B, C, H):
         torch.cuda.synchronize()
         return [o.cpu().numpy() for o in outs], rc != L.EUNSUPPORTED
 
+    # the single launches with their filler role (F <= 8192: two pending filter-gradient slab reductions ride along, as in the step)
+    slabs = [torch.randn(64, 36864, generator=g).to(dev) * 1e-3 for _ in range(2)]
+
+    def bwd_fill(cold):
+        outs = []
+        calls = []
+        for i, t in enumerate((ta, tb)):
+            dx = torch.full_like(z[i], float("nan")); part = torch.zeros(lib.alignq_site_bn_part_bytes(F, 1), dtype=torch.uint8, device=dev)
+            dws = [torch.full((36864,), float("nan"), device=dev) for _ in range(2)]
+            bins = t["bins"]
+            calls.append((L.ptr(gy[i]), L.ptr(S[i]), L.ptr(z[i]), L.ptr(t["ab"]), L.ptr(t["save"]), C, HW, 1, None, L.ptr(bins),
+                          2 if bins is not None else 0, None, L.ptr(t["stats"]), B, F, 2.0, 0.0, L.ptr(dx), L.ptr(part), 2,
+                          L.ptr_array(slabs), L.ptr_array(dws), (ctypes.c_int * 2)(64, 64), (ctypes.c_int * 2)(36864, 36864), None))
+            outs += [dx, part] + dws
+        torch.cuda.synchronize()
+        for c in calls:
+            if cold: torch.mm(m1, m1)
+            L.check(lib.alignq_site_bwd_apply_bn_fill(*c), "bwd fill")
+        torch.cuda.synchronize()
+        return [o.cpu().numpy() for o in outs]
+
     bref, _ = bwd(False, False)
+    if lib.alignq_site_bwd_fill_slots(B, F) >= 2:
+        fref = bwd_fill(False)
+        bad = sum(any(x.tobytes() != y.tobytes() for x, y in zip(bwd_fill(True), fref)) for _ in range(REPS))
+        print(f"B={B} C={C} H={H} F={F}: bwd single + 2 fillers: {bad} of {REPS} repetitions differ", flush=True)
     for name, fn, rf in (("fwd single", lambda: fwd(False, True)[0], ref), ("fwd twin", lambda: fwd(True, True)[0], ref),
                          ("bwd single", lambda: bwd(False, True)[0], bref), ("bwd twin", lambda: bwd(True, True)[0], bref)):
         bad = 0
