@@ -65,7 +65,7 @@ __device__ unsigned long long g_blk[2][2][2048];
 __device__ float* g_dump = nullptr;       // [4 stages][2 sites][256 tiles][128 rows][32 columns][2]
 #define DUMP2(stage, site, tile, row, col, v0, v1)                                                                        \
   do {                                                                                                                    \
-    if (((((ALIGNQ_DIAG_DUMP) >> (stage)) & 1) || ((stage) == 0 && ((ALIGNQ_DIAG_DUMP) & 16)) || ((stage) == 2 && ((ALIGNQ_DIAG_DUMP) & 32))) && g_dump) { \
+    if (((((ALIGNQ_DIAG_DUMP) >> (stage)) & 1) || ((stage) == 0 && ((ALIGNQ_DIAG_DUMP) & 16)) || ((stage) == 2 && ((ALIGNQ_DIAG_DUMP) & 32)) || ((stage) == 3 && ((ALIGNQ_DIAG_DUMP) & 64))) && g_dump) { \
       float* p__ = g_dump + ((((((size_t)(stage) * 2 + (site)) * 256 + (tile)) * 128 + (row)) * 32 + (col)) * 2);         \
       p__[0] = (v0); p__[1] = (v1);                                                                                       \
     }                                                                                                                     \
@@ -1672,6 +1672,21 @@ __global__ __launch_bounds__(TFv * 8, 2) void site_bwd4_kernel(const float* __re
           *reinterpret_cast<bf16x4*>(TTlo + o) = (bf16x4){tl0, tl1, tl2, tl3};
         }
       }
+#ifdef ALIGNQ_DIAG_DUMP
+      if constexpr (TFv == 32 && !LOOP && PAIR) {      // stage 6 (slot 3): the thread's own staged t operands, read back right behind its stores
+        if ((ALIGNQ_DIAG_DUMP) & 64) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const int o = (4 * lc4 + e) * LDT + (lrow4 ^ XSWZ(4 * lc4 + e));
+            const uint2 hh = *reinterpret_cast<const uint2*>(TThi + o), ll = *reinterpret_cast<const uint2*>(TTlo + o);
+            DUMP2(3, dsite, tile, lrow4 + 0, 4 * lc4 + e, bf16_pair(hh.x).x, bf16_pair(ll.x).x);
+            DUMP2(3, dsite, tile, lrow4 + 1, 4 * lc4 + e, bf16_pair(hh.x).y, bf16_pair(ll.x).y);
+            DUMP2(3, dsite, tile, lrow4 + 2, 4 * lc4 + e, bf16_pair(hh.y).x, bf16_pair(ll.y).x);
+            DUMP2(3, dsite, tile, lrow4 + 3, 4 * lc4 + e, bf16_pair(hh.y).y, bf16_pair(ll.y).y);
+          }
+        }
+      }
+#endif
       if (PAIR) {
 #pragma unroll
         for (int q = 0; q < 4; q++)

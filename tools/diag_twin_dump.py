@@ -51,7 +51,7 @@ def launch(one_per_cu):
 ref, dref = launch(True)
 ref2, dref2 = launch(True)
 print("one-per-CU launches agree:", all(x.tobytes() == y.tobytes() for x, y in zip(ref, ref2)), "dumps agree:", dref.tobytes() == dref2.tobytes(), flush=True)
-names = ["t / jac (phase A) | with mask bit 16: the standardised x / t operands as the projection reads them from LDS", "accX / accT (after the MFMAs)", "projection sums", "assembled tile (Os)"]
+names = ["t / jac (phase A) | with mask bit 16: the standardised x / t operands as the projection reads them from LDS", "accX / accT (after the MFMAs)", "projection sums", "assembled tile (Os) | with mask bit 64: the staged t operands (hi, lo) read back by the staging thread right behind its stores"]
 found = 0
 for rep in range(60):
     got, dgot = launch(False)
